@@ -1,0 +1,316 @@
+/*
+ * theia_hip.h -- C-ABI of the MI355X (gfx950) bundle-adjustment + RANSAC engine.
+ *
+ * This is the drop-in boundary: plain C structs of pointers and sizes, no
+ * Eigen / STL / torch types.  Every entry point names the reference interface
+ * (pyTheiaSfM, paths relative to the reference root) that it replaces.  The
+ * reference-side shim (flatten Reconstruction -> call -> scatter back) is shown
+ * in INTEGRATION.md.
+ *
+ * All floating point data is IEEE FP64.  All index data is int32 unless noted.
+ * Return value of every function: 0 = THEIA_HIP_OK, negative = error code;
+ * the library never throws and never aborts.  theia_hip_last_error() returns a
+ * thread-local human-readable message for the last failing call.
+ */
+#ifndef THEIA_HIP_H_
+#define THEIA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+enum {
+  THEIA_HIP_OK = 0,
+  THEIA_HIP_ERR_INVALID_ARGUMENT = -1, /* reference: glog CHECK -> abort        */
+  THEIA_HIP_ERR_NO_DEVICE = -2,        /* no gfx950 device / HIP runtime error  */
+  THEIA_HIP_ERR_UNSUPPORTED = -3,      /* option combination not built yet      */
+  THEIA_HIP_ERR_OUT_OF_MEMORY = -4,
+  THEIA_HIP_ERR_INTERNAL = -5
+};
+
+int theia_hip_init(int device_ordinal);
+int theia_hip_shutdown(void);
+int theia_hip_device_count(int* count);
+const char* theia_hip_last_error(void);
+const char* theia_hip_version(void);
+
+/* ------------------------------------------------------- camera model enums */
+/* src/theia/sfm/camera/camera_intrinsics_model_type.h:46-56 */
+enum {
+  THEIA_CAM_PINHOLE = 0,
+  THEIA_CAM_PINHOLE_RADIAL_TANGENTIAL = 1,
+  THEIA_CAM_FISHEYE = 2,
+  THEIA_CAM_FOV = 3,
+  THEIA_CAM_DIVISION_UNDISTORTION = 4,
+  THEIA_CAM_DOUBLE_SPHERE = 5,
+  THEIA_CAM_EXTENDED_UNIFIED = 6,
+  THEIA_CAM_ORTHOGRAPHIC = 7
+};
+#define THEIA_MAX_INTRINSICS 10 /* largest kIntrinsicsSize (radial-tangential) */
+
+/* src/theia/sfm/bundle_adjustment/create_loss_function.h:52-60 */
+enum {
+  THEIA_LOSS_TRIVIAL = 0,
+  THEIA_LOSS_HUBER = 1,
+  THEIA_LOSS_SOFTLONE = 2,
+  THEIA_LOSS_CAUCHY = 3,
+  THEIA_LOSS_ARCTAN = 4,
+  THEIA_LOSS_TUKEY = 5,
+  THEIA_LOSS_TRUNCATED = 6
+};
+
+/* src/theia/sfm/bundle_adjustment/bundle_adjustment.h:71-85 (bitmask) */
+enum {
+  THEIA_INTR_NONE = 0x00,
+  THEIA_INTR_FOCAL_LENGTH = 0x01,
+  THEIA_INTR_ASPECT_RATIO = 0x02,
+  THEIA_INTR_SKEW = 0x04,
+  THEIA_INTR_PRINCIPAL_POINTS = 0x08,
+  THEIA_INTR_RADIAL_DISTORTION = 0x10,
+  THEIA_INTR_TANGENTIAL_DISTORTION = 0x20,
+  THEIA_INTR_ALL = 0x3f
+};
+
+/* per-camera constant mask bits (what BundleAdjuster freezes):
+ *   bundle_adjuster.cc:477-518 SetCameraExtrinsicsConstant / PositionConstant /
+ *   OrientationConstant / SetTzConstant. */
+enum {
+  THEIA_CAM_CONST_POSITION = 0x1,
+  THEIA_CAM_CONST_ORIENTATION = 0x2,
+  THEIA_CAM_CONST_ALL = 0x3,
+  THEIA_CAM_CONST_TZ = 0x4
+};
+
+/* ------------------------------------------------------------ BA problem IR */
+/*
+ * Flattened form of what BundleAdjuster::AddView/AddTrack build inside Ceres
+ * (bundle_adjuster.cc:116-221): one 2-residual block per (estimated view,
+ * estimated track) observation; raw parameter blocks
+ *   camera extrinsics  [position(3) | angle-axis(3)]   camera.h:202-204,251
+ *   shared intrinsics  [K doubles per intrinsics group] camera_intrinsics_model.h
+ *   homogeneous point  [x y z w]                        track.h:66,110
+ * Parameters are updated IN PLACE (as Ceres writes through the borrowed
+ * double* of the Reconstruction, bundle_adjuster.cc:585-591).
+ * Caller owns every buffer; nothing is retained after a call returns unless a
+ * handle was created, and a handle owns device copies only.
+ */
+/* problem flags: a track shard of a multi-GPU solve keeps every non-constant
+ * camera in the reduced system (also those it does not observe) so that all
+ * ranks index the reduced camera system identically. */
+enum { THEIA_BA_FLAG_KEEP_UNOBSERVED_CAMERAS = 0x1 };
+
+typedef struct theia_ba_problem {
+  int32_t num_cameras;
+  int32_t num_groups;
+  int32_t num_points;
+  int32_t flags;               /* THEIA_BA_FLAG_* */
+  int64_t num_obs;
+
+  double* cam_ext;             /* [num_cameras][6]  in/out */
+  double* intrinsics;          /* [num_groups][THEIA_MAX_INTRINSICS] in/out */
+  const int32_t* group_model;  /* [num_groups] THEIA_CAM_*                 */
+  const int32_t* cam_group;    /* [num_cameras] intrinsics group of camera */
+  const uint8_t* cam_const;    /* [num_cameras] THEIA_CAM_CONST_* bits, or NULL */
+  const uint8_t* group_const;  /* [num_groups] 1 = whole block constant, or NULL
+                                  (bundle_adjuster.cc:444-459)             */
+  double* points;              /* [num_points][4]  in/out */
+  const uint8_t* point_const;  /* [num_points] 1 = SetTrackConstant, or NULL */
+
+  const double* obs_uv;        /* [num_obs][2] Feature::point_             */
+  const double* obs_sqrt_info; /* [num_obs][2] 1/sqrt(cov_xx), 1/sqrt(cov_yy)
+                                  (reprojection_error.h:94-99) or NULL = 1 */
+  const int32_t* obs_cam;      /* [num_obs] camera index                   */
+  const int32_t* obs_pt;       /* [num_obs] point index                    */
+} theia_ba_problem;
+
+/* Mirrors BundleAdjustmentOptions (bundle_adjustment.h:87-167), the fields the
+ * HIP backend honours.  The linear-algebra selector fields of the reference
+ * struct have no counterpart: this backend IS the linear solver. */
+typedef struct theia_ba_options {
+  int32_t loss_function_type;    /* THEIA_LOSS_*                  (:90) */
+  int32_t intrinsics_to_optimize;/* THEIA_INTR_* bitmask          (:135) */
+  int32_t max_num_iterations;    /*                               (:138) */
+  int32_t use_homogeneous_point_parametrization; /* SphereManifold<4> (:127) */
+  int32_t constant_camera_orientation;           /* (:122) */
+  int32_t constant_camera_position;              /* (:123) */
+  int32_t orthographic_camera;                   /* (:163) tz constant */
+  int32_t use_inner_iterations;  /* (:144) accepted, see DESIGN.md deviation */
+  int32_t verbose;               /* (:118) per-iteration table on stderr */
+  int32_t reserved0;
+  double robust_loss_width;      /* (:91) */
+  double function_tolerance;     /* (:148) */
+  double gradient_tolerance;     /* (:149) */
+  double parameter_tolerance;    /* (:150) */
+  double max_trust_region_radius;/* (:151) */
+  double max_solver_time_in_seconds; /* (:141) */
+} theia_ba_options;
+
+void theia_ba_options_default(theia_ba_options* o);
+
+/* termination_type values (ceres::TerminationType order) */
+enum {
+  THEIA_TERM_CONVERGENCE = 0,
+  THEIA_TERM_NO_CONVERGENCE = 1,
+  THEIA_TERM_FAILURE = 2
+};
+
+/* Mirrors BundleAdjustmentSummary (bundle_adjustment.h:170-178) plus the
+ * per-iteration trace used for parity checking against the oracle. */
+typedef struct theia_ba_summary {
+  int32_t success;               /* IsSolutionUsable() (bundle_adjuster.cc:352) */
+  int32_t termination_type;
+  int32_t num_iterations;        /* LM iterations run (successful + rejected)   */
+  int32_t num_successful_steps;
+  double initial_cost;
+  double final_cost;
+  double setup_time_in_seconds;
+  double solve_time_in_seconds;
+  /* optional trace, caller-allocated arrays of trace_capacity entries each
+   * (entry 0 = iteration 0), NULL to skip */
+  int32_t trace_capacity;
+  int32_t trace_size;
+  double* trace_cost;
+  double* trace_gradient_max_norm;
+  double* trace_step_norm;
+  double* trace_radius;
+  int32_t* trace_accepted;
+  /* time spent per phase (seconds, device-side events): linearize+Schur,
+   * reduced solve, back-substitution+trial cost */
+  double time_linearize;
+  double time_solve_reduced;
+  double time_backsub;
+} theia_ba_summary;
+
+/* One-shot solve: replaces BundleAdjuster::Optimize -> ceres::Solve
+ * (bundle_adjuster.cc:315-355) for the problem built by
+ * BundleAdjustReconstruction / BundleAdjustPartialReconstruction /
+ * BundleAdjustPartialViewsConstant (bundle_adjustment.cc:111-217). */
+int theia_hip_ba_solve(const theia_ba_problem* problem,
+                       const theia_ba_options* options,
+                       theia_ba_summary* summary);
+
+/* Handle API: problem resident in HBM across calls (bench, repeated solves). */
+typedef struct theia_ba_handle_s* theia_ba_handle;
+int theia_hip_ba_create(const theia_ba_problem* problem,
+                        const theia_ba_options* options, theia_ba_handle* out);
+int theia_hip_ba_reset_parameters(theia_ba_handle h,
+                                  const theia_ba_problem* problem);
+int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* summary);
+int theia_hip_ba_download(theia_ba_handle h, theia_ba_problem* problem);
+int theia_hip_ba_destroy(theia_ba_handle h);
+
+/* Introspection used by parity tests (device results copied to host):
+ *  - per-observation residual r[2] and Jacobian blocks J_cam[2][6],
+ *    J_pt[2][pt_dof] (tangent space, loss-corrected, NOT Jacobi-scaled) of
+ *    ReprojectionError<Model> (reprojection_error.h:54-110); valid[i] = functor
+ *    return value.
+ *  - the dense reduced camera system  S (n x n, row-major, both triangles) and
+ *    rhs (n) for trust-region radius `radius`, n = 6 * (#variable cameras),
+ *    in Jacobi-scaled space exactly as handed to the Cholesky kernel. */
+int theia_hip_ba_evaluate(theia_ba_handle h, double* cost, double* residuals,
+                          double* jac_cam, double* jac_pt, uint8_t* valid);
+int theia_hip_ba_reduced_system(theia_ba_handle h, double radius, int32_t* n,
+                                double* S, double* rhs, int64_t capacity);
+
+/* Multi-GPU (one process per GPU): tracks are sharded by the caller; each
+ * rank's handle holds its shard plus ALL cameras.  The reduced camera system
+ * (and the scalar reductions) are summed across ranks through this callback,
+ * which the host implements with RCCL (ncclAllReduce(sum, fp64)) -- see
+ * pytheiasfm_amd/distributed.py and INTEGRATION.md.  The buffer is device
+ * memory; `stream` is the hipStream_t the library enqueued its producers on. */
+enum { THEIA_REDUCE_SUM = 0, THEIA_REDUCE_MAX = 1 };
+typedef int (*theia_allreduce_fn)(void* ctx, void* device_buffer,
+                                  size_t count_f64, int op, void* stream);
+int theia_hip_ba_set_allreduce(theia_ba_handle h, theia_allreduce_fn fn,
+                               void* ctx);
+
+/* ------------------------------------------------------------------ RANSAC */
+/* src/theia/solvers/sample_consensus_estimator.h:58-126 */
+typedef struct theia_ransac_params {
+  double error_thresh;
+  double failure_probability;
+  double min_inlier_ratio;
+  int32_t min_iterations;
+  int32_t max_iterations;
+  int32_t use_mle;
+  int32_t use_lo;              /* accepted; LO refinement is a "next" row */
+  int32_t lo_start_iterations;
+  int32_t use_Tdd_test;        /* reference: "Not currently implemented"  */
+  uint32_t seed;               /* seeds the mt19937 stream (util/random.cc:60-66),
+                                  i.e. RandomNumberGenerator(seed)        */
+  int32_t reserved0;
+} theia_ransac_params;
+
+void theia_ransac_params_default(theia_ransac_params* p);
+
+/* estimator ids: which Estimate* front-end is replaced */
+enum {
+  /* EstimateRelativePose, estimators/estimate_relative_pose.cc:159-172 */
+  THEIA_EST_RELATIVE_POSE = 0,
+  /* EstimateEssentialMatrix, estimators/estimate_essential_matrix.cc:90-106 */
+  THEIA_EST_ESSENTIAL_MATRIX = 1,
+  /* EstimateCalibratedAbsolutePose, estimate_calibrated_absolute_pose.cc:176-190 */
+  THEIA_EST_ABSOLUTE_POSE_KNEIP = 2,
+  THEIA_EST_ABSOLUTE_POSE_DLS = 3,
+  THEIA_EST_ABSOLUTE_POSE_SQPNP = 4
+};
+
+/* A batch of independent estimation problems ("pairs").  Datum layout:
+ *   relative pose / essential: FeatureCorrespondence = [x1 y1 x2 y2]
+ *     (matching/feature_correspondence.h; only Feature::point_ is used)
+ *   absolute pose: FeatureCorrespondence2D3D = [u v X Y Z]
+ *     (sfm/feature_correspondence_2d_3d.h:42-49)                           */
+typedef struct theia_ransac_batch {
+  int32_t estimator;           /* THEIA_EST_*                              */
+  int32_t num_problems;
+  const int64_t* offsets;      /* [num_problems+1] datum offsets           */
+  const double* data;          /* [offsets[num_problems]][datum_size]      */
+} theia_ransac_batch;
+
+/* Result per problem.  model layout:
+ *   RELATIVE_POSE:    E(9, row-major) R(9, row-major) position(3)  = 21
+ *   ESSENTIAL_MATRIX: E(9)                                          = 9
+ *   ABSOLUTE_POSE_*:  R(9, row-major) position(3)                   = 12 */
+#define THEIA_RANSAC_MODEL_STRIDE 21
+typedef struct theia_ransac_result {
+  int32_t* success;            /* [num_problems] Estimate() return value   */
+  double* models;              /* [num_problems][THEIA_RANSAC_MODEL_STRIDE]*/
+  int32_t* num_inliers;        /* [num_problems]                           */
+  uint8_t* inlier_mask;        /* [offsets[num_problems]] 1 = inlier       */
+  int32_t* num_iterations;     /* [num_problems] RansacSummary             */
+  double* confidence;          /* [num_problems]                           */
+  /* totals over the batch, for hypotheses/s accounting */
+  int64_t hypotheses_evaluated;/* minimal samples fitted + fully scored    */
+  int64_t models_scored;       /* models scored against all data           */
+  double time_fit_score_seconds; /* device time in the fit+score kernels   */
+} theia_ransac_result;
+
+/* Replaces SampleConsensusEstimator<E>::Estimate
+ * (solvers/sample_consensus_estimator.h:300-415) with Ransac<E> +
+ * RandomSampler (ransac.h:57-61, random_sampler.cc:53-72), for every problem
+ * of the batch.  Problem i uses RandomNumberGenerator(seed + i). */
+int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch,
+                                    const theia_ransac_params* params,
+                                    theia_ransac_result* result);
+
+/* Directly bound minimal solvers (src/pytheia/sfm/sfm.cc:573-592,
+ * pose_wrapper.cc:166-173).  Batched: `num` independent minimal problems.
+ *  five point: in = [num][5][4] (x1 y1 x2 y2), out E = [num][10][9],
+ *              num_solutions[num]  (five_point_relative_pose.cc:212-293)
+ *  p3p:        in = [num][3][5] (u v X Y Z), out R=[num][4][9], t=[num][4][3]
+ *              (perspective_three_point.cc PoseFromThreePoints)            */
+int theia_hip_five_point_relative_pose(int32_t num, const double* corr,
+                                       double* essential_matrices,
+                                       int32_t* num_solutions);
+int theia_hip_pose_from_three_points(int32_t num, const double* corr2d3d,
+                                     double* rotations, double* translations,
+                                     int32_t* num_solutions);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THEIA_HIP_H_ */

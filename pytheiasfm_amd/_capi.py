@@ -1,0 +1,232 @@
+"""ctypes binding of the C-ABI in include/theia_hip.h (libtheia_hip.so).
+
+The product path has NO CPU fallback: if the HIP extension is missing, or no
+gfx950 device is visible, every compute entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtheia_hip.so")
+
+THEIA_MAX_INTRINSICS = 10
+THEIA_RANSAC_MODEL_STRIDE = 21
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class TheiaHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"theia_hip error {code}: {message}")
+        self.code = code
+
+
+class BaProblem(C.Structure):
+    """theia_ba_problem (include/theia_hip.h)."""
+    _fields_ = [
+        ("num_cameras", C.c_int32), ("num_groups", C.c_int32), ("num_points", C.c_int32),
+        ("flags", C.c_int32), ("num_obs", C.c_int64),
+        ("cam_ext", c_double_p), ("intrinsics", c_double_p), ("group_model", c_int32_p),
+        ("cam_group", c_int32_p), ("cam_const", c_uint8_p), ("group_const", c_uint8_p),
+        ("points", c_double_p), ("point_const", c_uint8_p),
+        ("obs_uv", c_double_p), ("obs_sqrt_info", c_double_p), ("obs_cam", c_int32_p),
+        ("obs_pt", c_int32_p),
+    ]
+
+
+class BaOptions(C.Structure):
+    """theia_ba_options."""
+    _fields_ = [
+        ("loss_function_type", C.c_int32), ("intrinsics_to_optimize", C.c_int32),
+        ("max_num_iterations", C.c_int32), ("use_homogeneous_point_parametrization", C.c_int32),
+        ("constant_camera_orientation", C.c_int32), ("constant_camera_position", C.c_int32),
+        ("orthographic_camera", C.c_int32), ("use_inner_iterations", C.c_int32),
+        ("verbose", C.c_int32), ("reserved0", C.c_int32),
+        ("robust_loss_width", C.c_double), ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+        ("max_trust_region_radius", C.c_double), ("max_solver_time_in_seconds", C.c_double),
+    ]
+
+
+class BaSummary(C.Structure):
+    """theia_ba_summary."""
+    _fields_ = [
+        ("success", C.c_int32), ("termination_type", C.c_int32), ("num_iterations", C.c_int32),
+        ("num_successful_steps", C.c_int32),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double),
+        ("setup_time_in_seconds", C.c_double), ("solve_time_in_seconds", C.c_double),
+        ("trace_capacity", C.c_int32), ("trace_size", C.c_int32),
+        ("trace_cost", c_double_p), ("trace_gradient_max_norm", c_double_p),
+        ("trace_step_norm", c_double_p), ("trace_radius", c_double_p),
+        ("trace_accepted", c_int32_p),
+        ("time_linearize", C.c_double), ("time_solve_reduced", C.c_double),
+        ("time_backsub", C.c_double),
+    ]
+
+
+class RansacParams(C.Structure):
+    """theia_ransac_params."""
+    _fields_ = [
+        ("error_thresh", C.c_double), ("failure_probability", C.c_double),
+        ("min_inlier_ratio", C.c_double),
+        ("min_iterations", C.c_int32), ("max_iterations", C.c_int32), ("use_mle", C.c_int32),
+        ("use_lo", C.c_int32), ("lo_start_iterations", C.c_int32), ("use_Tdd_test", C.c_int32),
+        ("seed", C.c_uint32), ("reserved0", C.c_int32),
+    ]
+
+
+class RansacBatch(C.Structure):
+    _fields_ = [("estimator", C.c_int32), ("num_problems", C.c_int32),
+                ("offsets", c_int64_p), ("data", c_double_p)]
+
+
+class RansacResult(C.Structure):
+    _fields_ = [("success", c_int32_p), ("models", c_double_p), ("num_inliers", c_int32_p),
+                ("inlier_mask", c_uint8_p), ("num_iterations", c_int32_p),
+                ("confidence", c_double_p),
+                ("hypotheses_evaluated", C.c_int64), ("models_scored", C.c_int64),
+                ("time_fit_score_seconds", C.c_double)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+
+# every symbol include/theia_hip.h declares (checked by tests/test_capi_symbols.py)
+EXPORTED_SYMBOLS = [
+    "theia_hip_init", "theia_hip_shutdown", "theia_hip_device_count", "theia_hip_last_error",
+    "theia_hip_version", "theia_ba_options_default", "theia_hip_ba_solve", "theia_hip_ba_create",
+    "theia_hip_ba_reset_parameters", "theia_hip_ba_run", "theia_hip_ba_download",
+    "theia_hip_ba_destroy", "theia_hip_ba_evaluate", "theia_hip_ba_reduced_system",
+    "theia_hip_ba_set_allreduce", "theia_ransac_params_default",
+    "theia_hip_ransac_estimate_batch", "theia_hip_five_point_relative_pose",
+    "theia_hip_pose_from_three_points",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libtheia_hip.so; raises loudly if the extension was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+            "(pytheiasfm_amd has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    L.theia_hip_last_error.restype = C.c_char_p
+    L.theia_hip_version.restype = C.c_char_p
+    L.theia_hip_ba_create.argtypes = [C.POINTER(BaProblem), C.POINTER(BaOptions), C.POINTER(C.c_void_p)]
+    L.theia_hip_ba_run.argtypes = [C.c_void_p, C.POINTER(BaSummary)]
+    L.theia_hip_ba_download.argtypes = [C.c_void_p, C.POINTER(BaProblem)]
+    L.theia_hip_ba_reset_parameters.argtypes = [C.c_void_p, C.POINTER(BaProblem)]
+    L.theia_hip_ba_destroy.argtypes = [C.c_void_p]
+    L.theia_hip_ba_solve.argtypes = [C.POINTER(BaProblem), C.POINTER(BaOptions), C.POINTER(BaSummary)]
+    L.theia_hip_ba_evaluate.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_uint8_p]
+    L.theia_hip_ba_reduced_system.argtypes = [C.c_void_p, C.c_double, c_int32_p, c_double_p, c_double_p, C.c_int64]
+    L.theia_hip_ba_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
+    L.theia_ba_options_default.argtypes = [C.POINTER(BaOptions)]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise TheiaHipError(rc, lib().theia_hip_last_error().decode())
+
+
+def ptr(a, ctype):
+    """Pointer to a C-contiguous numpy array (or NULL for None)."""
+    if a is None:
+        return C.cast(None, C.POINTER(ctype))
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+class FlatProblem:
+    """Owns the numpy arrays behind a theia_ba_problem (keeps them alive)."""
+
+    def __init__(self, cam_ext, intrinsics, group_model, cam_group, points, obs_uv, obs_cam, obs_pt,
+                 cam_const=None, group_const=None, point_const=None, obs_sqrt_info=None, flags=0):
+        self.flags = int(flags)
+        f8 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        i4 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        u1 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+        self.cam_ext = f8(cam_ext).reshape(-1, 6)
+        self.points = f8(points).reshape(-1, 4)
+        intr = f8(intrinsics)
+        if intr.ndim == 1:
+            intr = intr.reshape(1, -1)
+        full = np.zeros((intr.shape[0], THEIA_MAX_INTRINSICS))
+        full[:, :intr.shape[1]] = intr
+        self.intrinsics = full
+        self.group_model = i4(group_model).reshape(-1)
+        self.cam_group = i4(cam_group).reshape(-1)
+        self.obs_uv = f8(obs_uv).reshape(-1, 2)
+        self.obs_cam = i4(obs_cam).reshape(-1)
+        self.obs_pt = i4(obs_pt).reshape(-1)
+        self.cam_const = u1(cam_const)
+        self.group_const = u1(group_const)
+        self.point_const = u1(point_const)
+        self.obs_sqrt_info = None if obs_sqrt_info is None else f8(obs_sqrt_info).reshape(-1, 2)
+        assert self.cam_group.shape[0] == self.cam_ext.shape[0]
+        assert self.group_model.shape[0] == self.intrinsics.shape[0]
+        assert self.obs_cam.shape[0] == self.obs_uv.shape[0] == self.obs_pt.shape[0]
+
+    def copy(self):
+        return FlatProblem(self.cam_ext.copy(), self.intrinsics.copy(), self.group_model, self.cam_group,
+                           self.points.copy(), self.obs_uv, self.obs_cam, self.obs_pt,
+                           self.cam_const, self.group_const, self.point_const, self.obs_sqrt_info, self.flags)
+
+    def as_struct(self):
+        p = BaProblem()
+        p.num_cameras = self.cam_ext.shape[0]
+        p.num_groups = self.intrinsics.shape[0]
+        p.num_points = self.points.shape[0]
+        p.num_obs = self.obs_uv.shape[0]
+        p.flags = self.flags
+        p.cam_ext = ptr(self.cam_ext, C.c_double)
+        p.intrinsics = ptr(self.intrinsics, C.c_double)
+        p.group_model = ptr(self.group_model, C.c_int32)
+        p.cam_group = ptr(self.cam_group, C.c_int32)
+        p.cam_const = ptr(self.cam_const, C.c_uint8)
+        p.group_const = ptr(self.group_const, C.c_uint8)
+        p.points = ptr(self.points, C.c_double)
+        p.point_const = ptr(self.point_const, C.c_uint8)
+        p.obs_uv = ptr(self.obs_uv, C.c_double)
+        p.obs_sqrt_info = ptr(self.obs_sqrt_info, C.c_double)
+        p.obs_cam = ptr(self.obs_cam, C.c_int32)
+        p.obs_pt = ptr(self.obs_pt, C.c_int32)
+        return p
+
+
+class Trace:
+    """Caller-allocated per-iteration trace arrays of a theia_ba_summary."""
+
+    def __init__(self, capacity=256):
+        self.cost = np.zeros(capacity)
+        self.gradient_max_norm = np.zeros(capacity)
+        self.step_norm = np.zeros(capacity)
+        self.radius = np.zeros(capacity)
+        self.accepted = np.zeros(capacity, dtype=np.int32)
+        self.capacity = capacity
+        self.size = 0
+
+    def attach(self, s):
+        s.trace_capacity = self.capacity
+        s.trace_size = 0
+        s.trace_cost = ptr(self.cost, C.c_double)
+        s.trace_gradient_max_norm = ptr(self.gradient_max_norm, C.c_double)
+        s.trace_step_norm = ptr(self.step_norm, C.c_double)
+        s.trace_radius = ptr(self.radius, C.c_double)
+        s.trace_accepted = ptr(self.accepted, C.c_int32)
+
+    def finish(self, s):
+        self.size = s.trace_size
+        for name in ("cost", "gradient_max_norm", "step_norm", "radius", "accepted"):
+            setattr(self, name, getattr(self, name)[: self.size])

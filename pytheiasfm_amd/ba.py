@@ -1,0 +1,104 @@
+"""Thin Python wrapper over the BA C-ABI (theia_hip_ba_*): device-resident
+handle, one-shot solve, and the introspection calls the parity tests use."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+
+
+def default_options():
+    o = capi.BaOptions()
+    capi.lib().theia_ba_options_default(C.byref(o))
+    return o
+
+
+class BaHandle:
+    """Problem resident in HBM (theia_hip_ba_create ... destroy)."""
+
+    def __init__(self, problem, options):
+        self.problem = problem
+        self.options = options
+        self._st = problem.as_struct()
+        self._h = C.c_void_p()
+        self._cb = None
+        capi.check(capi.lib().theia_hip_ba_create(C.byref(self._st), C.byref(options), C.byref(self._h)))
+        self.pd = 3 if options.use_homogeneous_point_parametrization else 4
+
+    def close(self):
+        if self._h:
+            capi.lib().theia_hip_ba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, trace_capacity=256):
+        s = capi.BaSummary()
+        tr = capi.Trace(trace_capacity)
+        tr.attach(s)
+        capi.check(capi.lib().theia_hip_ba_run(self._h, C.byref(s)))
+        tr.finish(s)
+        return s, tr
+
+    def reset(self, problem=None):
+        """Re-upload parameters (of `problem`, default: the creating problem)."""
+        st = (problem or self.problem).as_struct()
+        capi.check(capi.lib().theia_hip_ba_reset_parameters(self._h, C.byref(st)))
+
+    def download(self, problem=None):
+        p = problem or self.problem
+        st = p.as_struct()
+        capi.check(capi.lib().theia_hip_ba_download(self._h, C.byref(st)))
+        return p
+
+    def evaluate(self):
+        n = self.problem.obs_uv.shape[0]
+        cost = C.c_double(0)
+        r = np.zeros((n, 2)); jc = np.zeros((n, 2, 6)); jp = np.zeros((n, 2, self.pd))
+        valid = np.zeros(n, dtype=np.uint8)
+        capi.check(capi.lib().theia_hip_ba_evaluate(
+            self._h, C.byref(cost), capi.ptr(r, C.c_double), capi.ptr(jc, C.c_double),
+            capi.ptr(jp, C.c_double), capi.ptr(valid, C.c_uint8)))
+        return cost.value, r, jc, jp, valid
+
+    def reduced_system(self, radius):
+        ncam = self.problem.cam_ext.shape[0]
+        cap = (6 * ncam) ** 2
+        S = np.zeros(max(cap, 1)); rhs = np.zeros(max(6 * ncam, 1)); n = C.c_int32(0)
+        capi.check(capi.lib().theia_hip_ba_reduced_system(
+            self._h, radius, C.byref(n), capi.ptr(S, C.c_double), capi.ptr(rhs, C.c_double), cap))
+        n = n.value
+        return S[: n * n].reshape(n, n).copy(), rhs[:n].copy()
+
+    def set_allreduce(self, fn):
+        """fn(device_ptr:int, count:int, op:int, stream:int) -> int (0 = ok)."""
+        def tramp(ctx, buf, count, op, stream):
+            try:
+                return int(fn(buf, count, op, stream) or 0)
+            except Exception as e:  # never propagate through the C frame
+                import sys
+                print(f"[pytheiasfm_amd] allreduce callback raised: {e!r}", file=sys.stderr)
+                return -1
+        self._cb = capi.ALLREDUCE_FN(tramp)
+        capi.check(capi.lib().theia_hip_ba_set_allreduce(self._h, self._cb, None))
+
+
+def solve(problem, options, trace_capacity=256):
+    """theia_hip_ba_solve: parameters of `problem` are updated in place."""
+    s = capi.BaSummary()
+    tr = capi.Trace(trace_capacity)
+    tr.attach(s)
+    st = problem.as_struct()
+    capi.check(capi.lib().theia_hip_ba_solve(C.byref(st), C.byref(options), C.byref(s)))
+    tr.finish(s)
+    return s, tr

@@ -1,0 +1,287 @@
+// ba_device.h -- per-observation device math of the BA path (gfx950, FP64).
+//
+// Hand-derived analytic derivatives of the reference's residual functor
+//   ReprojectionError<Model>::operator()   src/theia/sfm/camera/reprojection_error.h:54-110
+// (the reference differentiates the same code path with Ceres Jets; the oracle
+// restates that, this file is the closed form).  Branches are differentiated
+// on the branch taken, exactly like autodiff does.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+
+#include "theia_hip.h"
+
+namespace thip {
+
+#define THIP_DEV __device__ __forceinline__
+
+struct ObsLin {        // linearisation of one observation (unscaled, uncorrected)
+  double r[2];         // residual
+  double Jc[12];       // 2x6 wrt [position | angle-axis]
+  double Jx[8];        // 2x4 wrt homogeneous point (ambient)
+  bool valid;          // functor return value
+};
+
+// Rotation terms of one camera: R and the scalars the d/d(omega) needs.
+struct RotTerms {
+  double R[9];
+  double A, B, cA, cB;  // A=sin/th, B=(1-cos)/th^2, cA=(cos-A)/th^2, cB=(A-2B)/th^2
+  bool small;
+};
+
+// ceres/rotation.h AngleAxisRotatePoint: Rodrigues if theta^2 > DBL_EPSILON,
+// else first order p + w x p.
+THIP_DEV void rotation_terms(const double w[3], RotTerms& t) {
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  if (th2 > DBL_EPSILON) {
+    const double th = sqrt(th2);
+    double s, c;
+    sincos(th, &s, &c);
+    const double A = s / th;
+    const double B = (1.0 - c) / th2;
+    t.A = A; t.B = B; t.cA = (c - A) / th2; t.cB = (A - 2.0 * B) / th2; t.small = false;
+    t.R[0] = c + B * w[0] * w[0];        t.R[1] = B * w[0] * w[1] - A * w[2]; t.R[2] = B * w[0] * w[2] + A * w[1];
+    t.R[3] = B * w[0] * w[1] + A * w[2]; t.R[4] = c + B * w[1] * w[1];        t.R[5] = B * w[1] * w[2] - A * w[0];
+    t.R[6] = B * w[0] * w[2] - A * w[1]; t.R[7] = B * w[1] * w[2] + A * w[0]; t.R[8] = c + B * w[2] * w[2];
+  } else {
+    t.A = 1.0; t.B = 0.0; t.cA = 0.0; t.cB = 0.0; t.small = true;
+    t.R[0] = 1.0;   t.R[1] = -w[2]; t.R[2] = w[1];
+    t.R[3] = w[2];  t.R[4] = 1.0;   t.R[5] = -w[0];
+    t.R[6] = -w[1]; t.R[7] = w[0];  t.R[8] = 1.0;
+  }
+}
+
+// d(R(w) p)/dw, 3x3 row-major.
+THIP_DEV void rotation_dq_dw(const double w[3], const double p[3], const RotTerms& t, double M[9]) {
+  // column k = A (e_k x p) + B (p_k w + (w.p) e_k) + w_k h
+  const double c0 = w[1] * p[2] - w[2] * p[1];
+  const double c1 = w[2] * p[0] - w[0] * p[2];
+  const double c2 = w[0] * p[1] - w[1] * p[0];
+  const double d = w[0] * p[0] + w[1] * p[1] + w[2] * p[2];
+  double h0 = 0.0, h1 = 0.0, h2 = 0.0;
+  if (!t.small) {
+    h0 = -t.A * p[0] + t.cA * c0 + t.cB * d * w[0];
+    h1 = -t.A * p[1] + t.cA * c1 + t.cB * d * w[1];
+    h2 = -t.A * p[2] + t.cA * c2 + t.cB * d * w[2];
+  }
+  const double A = t.A, B = t.B, Bd = t.B * d;
+  // k = 0: e0 x p = (0, -p2, p1)
+  M[0] = B * p[0] * w[0] + Bd + w[0] * h0;
+  M[3] = -A * p[2] + B * p[0] * w[1] + w[0] * h1;
+  M[6] = A * p[1] + B * p[0] * w[2] + w[0] * h2;
+  // k = 1: e1 x p = (p2, 0, -p0)
+  M[1] = A * p[2] + B * p[1] * w[0] + w[1] * h0;
+  M[4] = B * p[1] * w[1] + Bd + w[1] * h1;
+  M[7] = -A * p[0] + B * p[1] * w[2] + w[1] * h2;
+  // k = 2: e2 x p = (-p1, p0, 0)
+  M[2] = -A * p[1] + B * p[2] * w[0] + w[2] * h0;
+  M[5] = A * p[0] + B * p[2] * w[1] + w[2] * h1;
+  M[8] = B * p[2] * w[2] + Bd + w[2] * h2;
+}
+
+// Projection pi(k, q) and its 2x3 Jacobian wrt q for the supported models.
+// Returns the model's validity boolean.
+template <bool WANT_JAC>
+THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2], double Jq[6]) {
+  double dx, dy;          // distorted normalised point
+  double ddx[3], ddy[3];  // d(dx)/dq, d(dy)/dq
+  bool ok = true;
+  if (model == THEIA_CAM_PINHOLE) {
+    // pinhole_camera_model.h:181-211,243-260
+    const double iz = 1.0 / q[2];
+    const double x = q[0] / q[2], y = q[1] / q[2];
+    const double r2 = x * x + y * y;
+    const double d = 1.0 + r2 * (k[5] + k[6] * r2);
+    dx = x * d; dy = y * d;
+    if (WANT_JAC) {
+      const double e = 2.0 * (k[5] + 2.0 * k[6] * r2);
+      const double dxx = d + x * x * e, dxy = x * y * e, dyy = d + y * y * e;
+      // chain through x = q0/q2, y = q1/q2
+      ddx[0] = dxx * iz; ddx[1] = dxy * iz; ddx[2] = -(dxx * x + dxy * y) * iz;
+      ddy[0] = dxy * iz; ddy[1] = dyy * iz; ddy[2] = -(dxy * x + dyy * y) * iz;
+    }
+  } else if (model == THEIA_CAM_DOUBLE_SPHERE) {
+    // double_sphere_camera_model.h:160-249
+    const double alpha = k[6], xi = k[5];
+    const double r2 = q[0] * q[0] + q[1] * q[1];
+    const double d1 = sqrt(r2 + q[2] * q[2]);
+    const double w1 = alpha > 0.5 ? (1.0 - alpha) / alpha : alpha / (1.0 - alpha);
+    const double w2 = (w1 + xi) / sqrt(2.0 * w1 * xi + xi * xi + 1.0);
+    if (q[2] <= -w2 * d1) ok = false;
+    const double kk = xi * d1 + q[2];
+    const double d2 = sqrt(r2 + kk * kk);
+    const double n = alpha * d2 + (1.0 - alpha) * kk;
+    dx = q[0] / n; dy = q[1] / n;
+    if (WANT_JAC) {
+      const double id1 = 1.0 / d1, id2 = 1.0 / d2, in = 1.0 / n;
+      const double dk[3] = {xi * q[0] * id1, xi * q[1] * id1, xi * q[2] * id1 + 1.0};
+      const double dd2[3] = {(q[0] + kk * dk[0]) * id2, (q[1] + kk * dk[1]) * id2, (kk * dk[2]) * id2};
+      for (int i = 0; i < 3; ++i) {
+        const double dn = alpha * dd2[i] + (1.0 - alpha) * dk[i];
+        ddx[i] = -dx * dn * in;
+        ddy[i] = -dy * dn * in;
+      }
+      ddx[0] += in; ddy[1] += in;
+    }
+  } else {
+    uv[0] = 0.0; uv[1] = 0.0;
+    if (WANT_JAC) for (int i = 0; i < 6; ++i) Jq[i] = 0.0;
+    return false;
+  }
+  // affine stage (pinhole_camera_model.h:205-208): u = f dx + s dy + cx, v = f a dy + cy
+  uv[0] = k[0] * dx + k[2] * dy + k[3];
+  uv[1] = k[0] * k[1] * dy + k[4];
+  if (WANT_JAC) {
+    const double fa = k[0] * k[1];
+    for (int i = 0; i < 3; ++i) {
+      Jq[i] = k[0] * ddx[i] + k[2] * ddy[i];
+      Jq[3 + i] = fa * ddy[i];
+    }
+  }
+  return ok;
+}
+
+// Residual (and optionally Jacobians) of one observation.
+template <bool WANT_JAC>
+THIP_DEV void observe(int model, const double* ext, const double* intr, const double X[4],
+                      double u0, double v0, double six, double siy, ObsLin& o) {
+  const double p[3] = {X[0] - X[3] * ext[0], X[1] - X[3] * ext[1], X[2] - X[3] * ext[2]};
+  const double sq = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+  if (sq < 1e-8) {  // reprojection_error.h:78-80 -> functor returns false
+    o.valid = false; o.r[0] = 0.0; o.r[1] = 0.0;
+    if (WANT_JAC) { for (int i = 0; i < 12; ++i) o.Jc[i] = 0.0; for (int i = 0; i < 8; ++i) o.Jx[i] = 0.0; }
+    return;
+  }
+  RotTerms t;
+  rotation_terms(ext + 3, t);
+  const double q[3] = {t.R[0] * p[0] + t.R[1] * p[1] + t.R[2] * p[2],
+                       t.R[3] * p[0] + t.R[4] * p[1] + t.R[5] * p[2],
+                       t.R[6] * p[0] + t.R[7] * p[1] + t.R[8] * p[2]};
+  double uv[2], Jq[6];
+  o.valid = project<WANT_JAC>(model, intr, q, uv, Jq);
+  o.r[0] = six * (uv[0] - u0);
+  o.r[1] = siy * (uv[1] - v0);
+  if (WANT_JAC) {
+    double M[9];
+    rotation_dq_dw(ext + 3, p, t, M);
+    const double s[2] = {six, siy};
+    for (int a = 0; a < 2; ++a) {
+      const double* jq = Jq + 3 * a;
+      // A = Jq R  (1x3)
+      const double A0 = jq[0] * t.R[0] + jq[1] * t.R[3] + jq[2] * t.R[6];
+      const double A1 = jq[0] * t.R[1] + jq[1] * t.R[4] + jq[2] * t.R[7];
+      const double A2 = jq[0] * t.R[2] + jq[1] * t.R[5] + jq[2] * t.R[8];
+      // dq/dC = -w R
+      o.Jc[6 * a + 0] = -s[a] * X[3] * A0;
+      o.Jc[6 * a + 1] = -s[a] * X[3] * A1;
+      o.Jc[6 * a + 2] = -s[a] * X[3] * A2;
+      o.Jc[6 * a + 3] = s[a] * (jq[0] * M[0] + jq[1] * M[3] + jq[2] * M[6]);
+      o.Jc[6 * a + 4] = s[a] * (jq[0] * M[1] + jq[1] * M[4] + jq[2] * M[7]);
+      o.Jc[6 * a + 5] = s[a] * (jq[0] * M[2] + jq[1] * M[5] + jq[2] * M[8]);
+      // dq/dX = [R | -R C]
+      o.Jx[4 * a + 0] = s[a] * A0;
+      o.Jx[4 * a + 1] = s[a] * A1;
+      o.Jx[4 * a + 2] = s[a] * A2;
+      o.Jx[4 * a + 3] = -s[a] * (A0 * ext[0] + A1 * ext[1] + A2 * ext[2]);
+    }
+  }
+}
+
+// ceres/loss_function.cc + theia TruncatedLoss (loss_functions.cc:40-44).
+// Returns rho(s); *rho1 = rho'(s).  Every loss here has rho'' <= 0, so the
+// Triggs corrector (ceres/corrector.cc) reduces to scaling by sqrt(rho').
+THIP_DEV double loss_eval(int type, double a, double s, double* rho1) {
+  switch (type) {
+    case THEIA_LOSS_HUBER: {
+      const double b = a * a;
+      if (s > b) { const double r = sqrt(s); *rho1 = fmax(DBL_MIN, a / r); return 2.0 * a * r - b; }
+      *rho1 = 1.0; return s; }
+    case THEIA_LOSS_SOFTLONE: {
+      const double b = a * a; const double sum = 1.0 + s / b; const double tmp = sqrt(sum);
+      *rho1 = fmax(DBL_MIN, 1.0 / tmp); return 2.0 * b * (tmp - 1.0); }
+    case THEIA_LOSS_CAUCHY: {
+      const double b = a * a; const double sum = 1.0 + s / b;
+      *rho1 = fmax(DBL_MIN, 1.0 / sum); return b * log(sum); }
+    case THEIA_LOSS_ARCTAN: {
+      const double sum = 1.0 + s * s / (a * a);
+      *rho1 = fmax(DBL_MIN, 1.0 / sum); return a * atan2(s, a); }
+    case THEIA_LOSS_TUKEY: {
+      const double a2 = a * a;
+      if (s <= a2) { const double v = 1.0 - s / a2; const double v2 = v * v; *rho1 = v2;
+        return a2 / 3.0 * (1.0 - v2 * v); }
+      *rho1 = 0.0; return a2 / 3.0; }
+    case THEIA_LOSS_TRUNCATED: {
+      const double se = a * a; *rho1 = s < se ? 1.0 : 0.0; return fmin(s, se); }
+    default: *rho1 = 1.0; return s;
+  }
+}
+
+// ceres SphereManifold<4> (bundle_adjuster.cc:538-545): Householder vector.
+THIP_DEV void householder4(const double x[4], double v[4], double& beta) {
+  const double sigma = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+  v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = 1.0;
+  beta = 0.0;
+  if (sigma <= DBL_EPSILON) { if (x[3] < 0.0) beta = 2.0; return; }
+  const double mu = sqrt(x[3] * x[3] + sigma);
+  const double vp = (x[3] <= 0.0) ? x[3] - mu : -sigma / (x[3] + mu);
+  beta = 2.0 * vp * vp / (sigma + vp * vp);
+  v[0] /= vp; v[1] /= vp; v[2] /= vp;
+}
+
+// Tangent-space point Jacobian: Jt(2x3) = Jx(2x4) * |x| (I - beta v v^T)[:,0:3]
+THIP_DEV void to_tangent(const double X[4], const double Jx[8], double Jt[6]) {
+  double v[4], beta;
+  householder4(X, v, beta);
+  const double nx = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2] + X[3] * X[3]);
+  for (int a = 0; a < 2; ++a) {
+    const double* j = Jx + 4 * a;
+    const double jv = j[0] * v[0] + j[1] * v[1] + j[2] * v[2] + j[3] * v[3];
+    for (int c = 0; c < 3; ++c) Jt[3 * a + c] = nx * (j[c] - beta * v[c] * jv);
+  }
+}
+
+THIP_DEV void sphere_plus(const double x[4], const double d[3], double out[4]) {
+  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (nd == 0.0) { out[0] = x[0]; out[1] = x[1]; out[2] = x[2]; out[3] = x[3]; return; }
+  double v[4], beta;
+  householder4(x, v, beta);
+  const double nx = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+  double s, c;
+  sincos(nd, &s, &c);
+  const double sbd = s / nd;
+  const double y[4] = {sbd * d[0], sbd * d[1], sbd * d[2], c};
+  const double vty = v[0] * y[0] + v[1] * y[1] + v[2] * y[2] + v[3] * y[3];
+  for (int i = 0; i < 4; ++i) out[i] = nx * (y[i] - v[i] * (beta * vty));
+}
+
+// 3x3 SPD inverse through Cholesky (ceres InvertPSDMatrix, full-rank branch).
+// V = [v00 v10 v11 v20 v21 v22] lower; returns false if not positive definite.
+THIP_DEV bool invert_spd3(const double V[6], double Vi[6]) {
+  if (!(V[0] > 0.0)) return false;
+  const double l00 = sqrt(V[0]);
+  const double l10 = V[1] / l00;
+  const double d11 = V[2] - l10 * l10;
+  if (!(d11 > 0.0)) return false;
+  const double l11 = sqrt(d11);
+  const double l20 = V[3] / l00;
+  const double l21 = (V[4] - l20 * l10) / l11;
+  const double d22 = V[5] - l20 * l20 - l21 * l21;
+  if (!(d22 > 0.0)) return false;
+  const double l22 = sqrt(d22);
+  // inverse of L (lower)
+  const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+  const double i10 = -l10 * i00 * i11;
+  const double i21 = -l21 * i11 * i22;
+  const double i20 = -(l20 * i00 + l21 * i10) * i22;
+  // Vi = Li^T Li
+  Vi[0] = i00 * i00 + i10 * i10 + i20 * i20;
+  Vi[1] = i10 * i11 + i20 * i21;
+  Vi[2] = i11 * i11 + i21 * i21;
+  Vi[3] = i20 * i22;
+  Vi[4] = i21 * i22;
+  Vi[5] = i22 * i22;
+  return true;
+}
+
+}  // namespace thip

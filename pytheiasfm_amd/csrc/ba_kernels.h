@@ -1,0 +1,74 @@
+// ba_kernels.h -- launch interface of the BA device kernels (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace thip {
+
+// Device-resident problem (SoA, observations sorted by point and packed into
+// wave tiles of <= 64 observations that never split a point).
+struct DevProblem {
+  int nc, np, ncv, ntiles;
+  int64_t nobs;
+  int n;                       // reduced system size = 6 * ncv
+  int pd;                      // point tangent dofs: 3 (SphereManifold<4>) or 4
+  int loss_type;
+  double loss_width;
+  const double* intr;          // [ng][10]
+  const int* group_model;      // [ng]
+  const int* cam_group;        // [nc]
+  const int* cam_red;          // [nc] reduced index or -1
+  const uint8_t* cam_mask;     // [nc] bit q = extrinsics column q frozen
+  const uint8_t* pt_const;     // [np]
+  const double2* obs_uv;       // [nobs]
+  const double2* obs_si;       // [nobs] or nullptr
+  const int* obs_cam;          // [nobs]
+  const int* obs_pt;           // [nobs]
+  const int* tile_start;       // [ntiles]
+  const int* tile_count;       // [ntiles]
+  const double* scale_c;       // [nc][6] Jacobi scaling
+  const double* scale_p;       // [np][pd]
+};
+
+// Per-iteration reduced-system workspace: one contiguous buffer so that a
+// single memset clears it and a single all-reduce sums it across ranks.
+//   [ S (n*n) | rhs (n) | colsq (n) | gc (n) | scalars (16) ]
+struct ReduceBuf {
+  double* base;
+  size_t count;     // doubles
+  double* S; double* rhs; double* colsq; double* gc; double* scal;
+};
+enum {  // indices into ReduceBuf::scal: [0,8) are SUM-reduced, [8,16) MAX-reduced
+  SC_COST = 0,      // sum 1/2 rho at x
+  SC_INVALID = 1,   // > 0 if any functor returned false
+  SC_NOTPD = 2,     // > 0 if a point block / the reduced matrix was not PD
+  SC_GMAX = 8,      // max |gradient| (points part; cameras folded in by finalize)
+  SC_COUNT = 16
+};
+
+void launch_colnorm(const DevProblem& P, const double* cam, const double* pts, double* colsq_c,
+                    double* colsq_p, hipStream_t st);
+void launch_make_scale(int count, const double* colsq, double* scale, hipStream_t st);
+void launch_linearize(const DevProblem& P, const double* cam, const double* pts, double radius,
+                      const ReduceBuf& rb, double* Vinv, double* gp, double* tile_part,
+                      hipStream_t st);
+void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,
+                         const int* field_is_max, double* scal, hipStream_t st);
+void launch_finalize_rcs(const DevProblem& P, double radius, const ReduceBuf& rb, hipStream_t st);
+void launch_cam_update(const DevProblem& P, const double* cam, const double* yc, double* cand_cam,
+                       double* out_stepsq, double* out_xnormsq, hipStream_t st);
+void launch_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,
+                    double* cand_pts, const double* yc, const double* Vinv, double* tile_part,
+                    double* scal, hipStream_t st);
+void launch_evaluate(const DevProblem& P, const double* cam, const double* pts, double* residuals,
+                     double* jac_cam, double* jac_pt, uint8_t* valid, double* tile_part,
+                     hipStream_t st);
+void launch_cost_only(const DevProblem& P, const double* cam, const double* pts, double* tile_part,
+                      double* scal, hipStream_t st);
+
+// dense SPD solve  A x = b  (lower triangle of row-major A, leading dim lda;
+// A is overwritten by its Cholesky factor, b by x).  fail_flag (device) is
+// incremented if a pivot is not positive.
+void dense_cholesky_solve(int n, double* A, int lda, double* b, double* fail_flag, hipStream_t st);
+
+}  // namespace thip

@@ -1,0 +1,704 @@
+// ba_kernels.hip -- BA hot-path kernels for gfx950 (CDNA4), FP64.
+//
+// Layout / mapping (DESIGN.md "BA kernels"):
+//  * observations are sorted by track and packed into WAVE TILES: one 64-lane
+//    wavefront owns <= 64 consecutive observations that never split a track;
+//    lane = observation.  All per-track sums (V_p = sum Jp^T Jp, g_p, the
+//    back-substitution sum) are wave-level segmented reductions done with
+//    cross-lane shuffles in a FIXED order (bitwise reproducible);
+//  * the per-track Schur products  S_ij -= W_i V^-1 W_j^T  stage the W blocks of
+//    the tile in LDS (64 x 6 x pd doubles per wave) and every lane walks its own
+//    track's segment;
+//  * Jacobians are never written to HBM: the linearize/Schur kernel and the
+//    back-substitution kernel both recompute them from the 24 B/observation
+//    SoA stream (FP64 flops are free relative to HBM/atomic traffic here).
+//
+// Reference arithmetic restated: src/theia/sfm/camera/reprojection_error.h:54-110
+// (+ camera models), Ceres SchurEliminator semantics for the 3-group ordering of
+// bundle_adjuster.cc:547-577, Ceres LM diagonal (levenberg_marquardt_strategy.cc).
+#include "ba_kernels.h"
+
+#include "ba_device.h"
+
+namespace thip {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = kWave * kWavesPerBlock;
+
+THIP_DEV double shfl_d(double v, int src) { return __shfl(v, src, kWave); }
+
+THIP_DEV double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+  return v;
+}
+THIP_DEV double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+
+THIP_DEV void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+template <int PD>
+struct LaneLin {
+  double r[2];
+  double Jc[12];
+  double Jt[2 * PD];
+  double X[4];
+  double cost;
+  int c, p, rc;
+  bool active, valid, pconst;
+};
+
+// Load one observation and linearise it: loss-corrected, column-masked,
+// Jacobi-scaled, tangent-space blocks.  WANT_JAC=false: residual/cost only.
+template <int PD, bool WANT_JAC>
+THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam,
+                             const double* __restrict__ pts, int o, bool active, int lane,
+                             LaneLin<PD>& L) {
+  L.active = active;
+  L.valid = true;
+  L.cost = 0.0;
+  L.r[0] = L.r[1] = 0.0;
+  L.rc = -1;
+  L.c = 0;
+  L.p = -1 - lane;  // unique sentinel: inactive lanes are their own segment
+  L.pconst = true;
+  if (WANT_JAC) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) L.Jc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 2 * PD; ++i) L.Jt[i] = 0.0;
+  }
+  L.X[0] = L.X[1] = L.X[2] = 0.0; L.X[3] = 1.0;
+  if (!active) return;
+  const int c = P.obs_cam[o];
+  const int p = P.obs_pt[o];
+  L.c = c; L.p = p;
+  L.rc = P.cam_red[c];
+  L.pconst = P.pt_const[p] != 0;
+  const double2 uv = P.obs_uv[o];
+  double six = 1.0, siy = 1.0;
+  if (P.obs_si) { const double2 s = P.obs_si[o]; six = s.x; siy = s.y; }
+  const double4 Xv = reinterpret_cast<const double4*>(pts)[p];
+  L.X[0] = Xv.x; L.X[1] = Xv.y; L.X[2] = Xv.z; L.X[3] = Xv.w;
+  double ext[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) ext[i] = cam[6 * c + i];
+  const int g = P.cam_group[c];
+  const int model = P.group_model[g];
+  const double* intr = P.intr + (size_t)g * THEIA_MAX_INTRINSICS;
+  ObsLin ol;
+  observe<WANT_JAC>(model, ext, intr, L.X, uv.x, uv.y, six, siy, ol);
+  L.valid = ol.valid;
+  const double s = ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1];
+  double rho1;
+  const double rho = loss_eval(P.loss_type, P.loss_width, s, &rho1);
+  L.cost = 0.5 * rho;
+  const double sr = sqrt(rho1);
+  L.r[0] = sr * ol.r[0];
+  L.r[1] = sr * ol.r[1];
+  if (WANT_JAC) {
+    const unsigned mask = P.cam_mask[c];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const double sc = ((mask >> q) & 1u) ? 0.0 : sr * P.scale_c[6 * c + q];
+      L.Jc[q] = ol.Jc[q] * sc;
+      L.Jc[6 + q] = ol.Jc[6 + q] * sc;
+    }
+    if (!L.pconst) {
+      if (PD == 3) {
+        double Jt[6];
+        to_tangent(L.X, ol.Jx, Jt);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const double sp = sr * P.scale_p[(size_t)3 * p + q];
+          L.Jt[q] = Jt[q] * sp;
+          L.Jt[PD + q] = Jt[3 + q] * sp;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < PD; ++q) {
+          const double sp = sr * P.scale_p[(size_t)PD * p + q];
+          L.Jt[q] = ol.Jx[q] * sp;
+          L.Jt[PD + q] = ol.Jx[4 + q] * sp;
+        }
+      }
+    }
+  }
+}
+
+struct Segment {
+  int start, len, maxlen;
+  bool head;
+};
+
+// Segment (= track) geometry of a lane inside its wave tile.
+THIP_DEV Segment lane_segment(int p, int lane) {
+  const int prev = __shfl_up(p, 1, kWave);
+  const bool head = (lane == 0) || (p != prev);
+  const unsigned long long H = __ballot(head);
+  const unsigned long long low = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+  Segment s;
+  s.head = head;
+  s.start = 63 - __clzll((long long)(H & low));
+  const unsigned long long Hn = H & ~low;
+  const int end = Hn ? (__ffsll((long long)Hn) - 1) : 64;
+  s.len = end - s.start;
+  int m = s.len;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, kWave));
+  s.maxlen = m;
+  return s;
+}
+
+// Sum `N` per-lane values over the lanes of the segment, in lane order; every
+// lane of the segment receives the (bitwise identical) total.
+template <int N>
+THIP_DEV void segment_allsum(const Segment& s, const double (&in)[N], double (&out)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) out[k] = 0.0;
+  for (int j = 0; j < s.maxlen; ++j) {
+    const int src = (s.start + j) & 63;
+    const bool take = j < s.len;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const double v = shfl_d(in[k], src);
+      if (take) out[k] += v;
+    }
+  }
+}
+
+template <int PD> constexpr int tri() { return PD * (PD + 1) / 2; }
+THIP_DEV constexpr int lidx(int a, int b) { return a * (a + 1) / 2 + b; }  // a >= b
+
+// SPD inverse (packed lower) through Cholesky; false if not positive definite.
+template <int PD>
+THIP_DEV bool invert_spd(const double (&V)[PD * (PD + 1) / 2], double (&Vi)[PD * (PD + 1) / 2]) {
+  double Lm[PD][PD];
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < PD; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double s = V[lidx(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= Lm[i][k] * Lm[j][k];
+      if (i == j) { if (!(s > 0.0)) ok = false; Lm[i][i] = sqrt(s); }
+      else Lm[i][j] = s / Lm[j][j];
+    }
+  }
+  // inverse of L (lower triangular)
+  double Li[PD][PD];
+#pragma unroll
+  for (int i = 0; i < PD; ++i) {
+    Li[i][i] = 1.0 / Lm[i][i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = j; k < i; ++k) s -= Lm[i][k] * Li[k][j];
+      Li[i][j] = s / Lm[i][i];
+    }
+  }
+  // Vi = Li^T Li
+#pragma unroll
+  for (int a = 0; a < PD; ++a)
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = a; k < PD; ++k) s += Li[k][a] * Li[k][b];
+      Vi[lidx(a, b)] = s;
+    }
+  return ok;
+}
+
+template <int PD>
+THIP_DEV double sym_get(const double (&V)[PD * (PD + 1) / 2], int a, int b) {
+  return a >= b ? V[lidx(a, b)] : V[lidx(b, a)];
+}
+
+// ---------------------------------------------------------------- colnorm
+// Squared column norms of the unscaled Jacobian at the initial point: the
+// Jacobi scaling 1/(1+sqrt(.)) is computed once from them
+// (ceres trust_region_minimizer.cc, jacobi_scaling = true).
+template <int PD>
+__global__ __launch_bounds__(kBlock) void k_colnorm(DevProblem P, const double* __restrict__ cam,
+                                                    const double* __restrict__ pts,
+                                                    double* __restrict__ colsq_c,
+                                                    double* __restrict__ colsq_p) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (tile >= P.ntiles) return;
+  const int cnt = P.tile_count[tile];
+  const int start = P.tile_start[tile];
+  LaneLin<PD> L;
+  lane_linearize<PD, true>(P, cam, pts, start + lane, lane < cnt, lane, L);
+  const Segment sg = lane_segment(L.p, lane);
+  double in[PD], out[PD];
+#pragma unroll
+  for (int q = 0; q < PD; ++q) in[q] = L.Jt[q] * L.Jt[q] + L.Jt[PD + q] * L.Jt[PD + q];
+  segment_allsum<PD>(sg, in, out);
+  if (L.active && sg.head) {
+#pragma unroll
+    for (int q = 0; q < PD; ++q) colsq_p[(size_t)PD * L.p + q] = out[q];
+  }
+  if (L.active && L.rc >= 0) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) atomic_add(&colsq_c[6 * L.c + q], L.Jc[q] * L.Jc[q] + L.Jc[6 + q] * L.Jc[6 + q]);
+  }
+}
+
+__global__ void k_make_scale(int count, const double* __restrict__ colsq, double* __restrict__ scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) scale[i] = 1.0 / (1.0 + sqrt(colsq[i]));
+}
+
+// -------------------------------------------------- linearize + Schur (K1+K2)
+// tile_part layout: [ntiles][4] = {cost, gmax_points, invalid, notpd}
+template <int PD>
+__global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double* __restrict__ cam,
+                                                      const double* __restrict__ pts, double radius,
+                                                      double* __restrict__ S, double* __restrict__ rhs,
+                                                      double* __restrict__ colsq, double* __restrict__ gc,
+                                                      double* __restrict__ Vinv, double* __restrict__ gp,
+                                                      double* __restrict__ tile_part) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  constexpr int NW = 6 * PD;
+  __shared__ double sW[kWavesPerBlock][kWave][NW + 1];
+  __shared__ int sRc[kWavesPerBlock][kWave];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int tile = blockIdx.x * kWavesPerBlock + wv;
+  const bool tile_ok = tile < P.ntiles;
+  const int cnt = tile_ok ? P.tile_count[tile] : 0;
+  const int start = tile_ok ? P.tile_start[tile] : 0;
+  LaneLin<PD> L;
+  lane_linearize<PD, true>(P, cam, pts, start + lane, lane < cnt, lane, L);
+  const Segment sg = lane_segment(L.p, lane);
+
+  // V_p (packed lower) and g_p = E^T r : segmented all-reduce
+  double in[NT + PD], tot[NT + PD];
+#pragma unroll
+  for (int a = 0; a < PD; ++a) {
+#pragma unroll
+    for (int b = 0; b <= a; ++b) in[lidx(a, b)] = L.Jt[a] * L.Jt[b] + L.Jt[PD + a] * L.Jt[PD + b];
+    in[NT + a] = L.Jt[a] * L.r[0] + L.Jt[PD + a] * L.r[1];
+  }
+  segment_allsum<NT + PD>(sg, in, tot);
+
+  double V[NT], Vi[NT], g[PD];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) V[k] = tot[k];
+#pragma unroll
+  for (int a = 0; a < PD; ++a) g[a] = tot[NT + a];
+  // LM diagonal of the point block: clamp(colnorm^2, 1e-6, 1e32) / radius
+#pragma unroll
+  for (int a = 0; a < PD; ++a) V[lidx(a, a)] += fmin(fmax(V[lidx(a, a)], 1e-6), 1e32) / radius;
+  bool pd_ok = true;
+  if (L.active && !L.pconst) pd_ok = invert_spd<PD>(V, Vi);
+  if (!L.active || L.pconst || !pd_ok) {
+#pragma unroll
+    for (int k = 0; k < NT; ++k) Vi[k] = 0.0;
+  }
+  double gmax = 0.0;
+  if (L.active && sg.head && !L.pconst) {
+#pragma unroll
+    for (int k = 0; k < NT; ++k) Vinv[(size_t)NT * L.p + k] = Vi[k];
+#pragma unroll
+    for (int a = 0; a < PD; ++a) {
+      gp[(size_t)PD * L.p + a] = g[a];
+      gmax = fmax(gmax, fabs(g[a] / P.scale_p[(size_t)PD * L.p + a]));
+    }
+  }
+
+  // W = F^T E (6 x PD), T = W Vinv, y = Vinv g
+  double W[NW], T[NW], y[PD];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < PD; ++b) W[a * PD + b] = L.Jc[a] * L.Jt[b] + L.Jc[6 + a] * L.Jt[PD + b];
+#pragma unroll
+  for (int a = 0; a < PD; ++a) {
+    double s = 0.0;
+#pragma unroll
+    for (int b = 0; b < PD; ++b) s += sym_get<PD>(Vi, a, b) * g[b];
+    y[a] = s;
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < PD; ++b) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < PD; ++k) s += W[a * PD + k] * sym_get<PD>(Vi, k, b);
+      T[a * PD + b] = s;
+    }
+
+  const int n = P.n;
+  const int rc = L.rc;
+  if (L.active && rc >= 0) {
+    double* Sd = S + (size_t)(6 * rc) * n + 6 * rc;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double jr = L.Jc[a] * L.r[0] + L.Jc[6 + a] * L.r[1];
+      double wy = 0.0;
+#pragma unroll
+      for (int b = 0; b < PD; ++b) wy += W[a * PD + b] * y[b];
+      atomic_add(&rhs[6 * rc + a], jr - wy);
+      atomic_add(&gc[6 * rc + a], jr);
+      atomic_add(&colsq[6 * rc + a], L.Jc[a] * L.Jc[a] + L.Jc[6 + a] * L.Jc[6 + a]);
+#pragma unroll
+      for (int b = 0; b <= a; ++b)
+        atomic_add(&Sd[(size_t)a * n + b], L.Jc[a] * L.Jc[b] + L.Jc[6 + a] * L.Jc[6 + b]);
+    }
+  }
+
+  // stage W of the tile in LDS, then every lane walks its track's segment
+#pragma unroll
+  for (int k = 0; k < NW; ++k) sW[wv][lane][k] = W[k];
+  sRc[wv][lane] = (L.active && !L.pconst) ? rc : -1;
+  __syncthreads();
+  const bool me = L.active && !L.pconst && rc >= 0;
+  for (int j = 0; j < sg.maxlen; ++j) {
+    const int src = (sg.start + j) & 63;
+    const int rcs = sRc[wv][src];
+    const bool take = me && (j < sg.len) && rcs >= 0 && rc >= rcs;
+    if (!take) continue;
+    double Ws[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) Ws[k] = sW[wv][src][k];
+    double* Sb = S + (size_t)(6 * rc) * n + 6 * rcs;
+    if (rc == rcs) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+          double s = 0.0;
+#pragma unroll
+          for (int k = 0; k < PD; ++k) s += T[a * PD + k] * Ws[b * PD + k];
+          atomic_add(&Sb[(size_t)a * n + b], -s);
+        }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          double s = 0.0;
+#pragma unroll
+          for (int k = 0; k < PD; ++k) s += T[a * PD + k] * Ws[b * PD + k];
+          atomic_add(&Sb[(size_t)a * n + b], -s);
+        }
+    }
+  }
+
+  // per-tile partials (reduced in fixed order by k_reduce_tiles)
+  const double cost = wave_sum(L.cost);
+  gmax = wave_max(gmax);
+  const double inval = wave_sum((L.active && !L.valid) ? 1.0 : 0.0);
+  const double npd = wave_sum((L.active && !pd_ok) ? 1.0 : 0.0);
+  if (tile_ok && lane == 0) {
+    tile_part[4 * (size_t)tile + 0] = cost;
+    tile_part[4 * (size_t)tile + 1] = gmax;
+    tile_part[4 * (size_t)tile + 2] = inval;
+    tile_part[4 * (size_t)tile + 3] = npd;
+  }
+}
+
+// Deterministic reduction of per-tile partials into the scalar block.
+// field f of tile t at tile_part[t*nfields + f]; result -> scal[field_to_scal[f]]
+// (sum, or max if field_is_max[f]).
+__global__ __launch_bounds__(1024) void k_reduce_tiles(int ntiles, const double* __restrict__ part,
+                                                       int nfields, const int* __restrict__ f2s,
+                                                       const int* __restrict__ fmaxflag,
+                                                       double* __restrict__ scal) {
+  __shared__ double sm[1024];
+  for (int f = 0; f < nfields; ++f) {
+    const bool ismax = fmaxflag[f] != 0;
+    double acc = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += 1024) {
+      const double v = part[(size_t)t * nfields + f];
+      acc = ismax ? fmax(acc, v) : acc + v;
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) {
+        const double o = sm[threadIdx.x + s];
+        sm[threadIdx.x] = ismax ? fmax(sm[threadIdx.x], o) : sm[threadIdx.x] + o;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      if (ismax) scal[f2s[f]] = fmax(scal[f2s[f]], sm[0]);
+      else scal[f2s[f]] += sm[0];
+    }
+    __syncthreads();
+  }
+}
+
+// Add the LM diagonal to the camera blocks and fold the camera gradient into
+// the gradient max-norm: S_dd += clamp(colsq_d) / radius.
+__global__ void k_finalize_rcs(DevProblem P, double radius, double* __restrict__ S,
+                               const double* __restrict__ colsq, const double* __restrict__ gc,
+                               double* __restrict__ scal) {
+  __shared__ double sm[256];
+  double gmax = 0.0;
+  for (int c = threadIdx.x; c < P.nc; c += blockDim.x) {
+    const int rc = P.cam_red[c];
+    if (rc < 0) continue;
+    for (int q = 0; q < 6; ++q) {
+      const int d = 6 * rc + q;
+      S[(size_t)d * P.n + d] += fmin(fmax(colsq[d], 1e-6), 1e32) / radius;
+      gmax = fmax(gmax, fabs(gc[d] / P.scale_c[6 * c + q]));
+    }
+  }
+  sm[threadIdx.x] = gmax;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scal[SC_GMAX] = fmax(scal[SC_GMAX], sm[0]);
+}
+
+// candidate cameras: x + (-y_c) * scale_c ; adds their |step|^2 and |x+|^2.
+__global__ void k_cam_update(DevProblem P, const double* __restrict__ cam, const double* __restrict__ yc,
+                             double* __restrict__ cand, double* __restrict__ out_stepsq,
+                             double* __restrict__ out_xnormsq) {
+  __shared__ double s1[256], s2[256];
+  double st = 0.0, xn = 0.0;
+  for (int c = threadIdx.x; c < P.nc; c += blockDim.x) {
+    const int rc = P.cam_red[c];
+    for (int q = 0; q < 6; ++q) {
+      const double x = cam[6 * c + q];
+      double xp = x;
+      if (rc >= 0) {
+        const unsigned mask = P.cam_mask[c];
+        if (!((mask >> q) & 1u)) xp = x + (-yc[6 * rc + q]) * P.scale_c[6 * c + q];
+        st += (x - xp) * (x - xp);
+        xn += xp * xp;
+      }
+      cand[6 * c + q] = xp;
+    }
+  }
+  s1[threadIdx.x] = st; s2[threadIdx.x] = xn;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { s1[threadIdx.x] += s1[threadIdx.x + s]; s2[threadIdx.x] += s2[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { *out_stepsq = s1[0]; *out_xnormsq = s2[0]; }
+}
+
+// ------------------------------- back-substitution + candidate + trial cost
+// tile_part: [ntiles][5] = {cand_cost, mcc, stepsq, xnormsq, invalid}
+template <int PD>
+__global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* __restrict__ cam,
+                                                    const double* __restrict__ pts,
+                                                    const double* __restrict__ cand_cam,
+                                                    double* __restrict__ cand_pts,
+                                                    const double* __restrict__ yc,
+                                                    const double* __restrict__ Vinv,
+                                                    double* __restrict__ tile_part) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (tile >= P.ntiles) return;
+  const int cnt = P.tile_count[tile];
+  const int start = P.tile_start[tile];
+  LaneLin<PD> L;
+  lane_linearize<PD, true>(P, cam, pts, start + lane, lane < cnt, lane, L);
+  const Segment sg = lane_segment(L.p, lane);
+  // m_c = F y_c
+  double mc[2] = {0.0, 0.0};
+  if (L.active && L.rc >= 0) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const double yv = yc[6 * L.rc + q];
+      mc[0] += L.Jc[q] * yv;
+      mc[1] += L.Jc[6 + q] * yv;
+    }
+  }
+  // t = E^T (r - F y_c), summed over the track
+  double in[PD], tsum[PD];
+#pragma unroll
+  for (int q = 0; q < PD; ++q) in[q] = L.Jt[q] * (L.r[0] - mc[0]) + L.Jt[PD + q] * (L.r[1] - mc[1]);
+  segment_allsum<PD>(sg, in, tsum);
+  double Vi[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) Vi[k] = (L.active && !L.pconst) ? Vinv[(size_t)NT * L.p + k] : 0.0;
+  double yp[PD];
+#pragma unroll
+  for (int a = 0; a < PD; ++a) {
+    double s = 0.0;
+#pragma unroll
+    for (int b = 0; b < PD; ++b) s += sym_get<PD>(Vi, a, b) * tsum[b];
+    yp[a] = s;
+  }
+  // step = -y ; model residual m = Js * step ; mcc = -m . (r + m/2)
+  double mcc = 0.0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    double m = -mc[a];
+#pragma unroll
+    for (int q = 0; q < PD; ++q) m -= L.Jt[a * PD + q] * yp[q];
+    mcc -= m * (L.r[a] + m / 2.0);
+  }
+  if (!L.active) mcc = 0.0;
+  // candidate point (every lane of the track computes the same value)
+  double Xp[4] = {L.X[0], L.X[1], L.X[2], L.X[3]};
+  double stepsq = 0.0, xnormsq = 0.0;
+  if (L.active && !L.pconst) {
+    double d[PD];
+#pragma unroll
+    for (int q = 0; q < PD; ++q) d[q] = -yp[q] * P.scale_p[(size_t)PD * L.p + q];
+    if (PD == 3) {
+      const double d3[3] = {d[0], d[1], d[2]};
+      sphere_plus(L.X, d3, Xp);
+    } else {
+#pragma unroll
+      for (int q = 0; q < PD; ++q) Xp[q] = L.X[q] + d[q];
+    }
+    if (sg.head) {
+      reinterpret_cast<double4*>(cand_pts)[L.p] = make_double4(Xp[0], Xp[1], Xp[2], Xp[3]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { stepsq += (L.X[q] - Xp[q]) * (L.X[q] - Xp[q]); xnormsq += Xp[q] * Xp[q]; }
+    }
+  }
+  // trial cost at the candidate
+  double ccost = 0.0;
+  bool cvalid = true;
+  if (L.active) {
+    double ext[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ext[i] = cand_cam[6 * L.c + i];
+    const int g = P.cam_group[L.c];
+    const double2 uv = P.obs_uv[start + lane];
+    double six = 1.0, siy = 1.0;
+    if (P.obs_si) { const double2 s = P.obs_si[start + lane]; six = s.x; siy = s.y; }
+    ObsLin ol;
+    observe<false>(P.group_model[g], ext, P.intr + (size_t)g * THEIA_MAX_INTRINSICS, Xp, uv.x, uv.y, six, siy, ol);
+    cvalid = ol.valid;
+    double rho1;
+    ccost = 0.5 * loss_eval(P.loss_type, P.loss_width, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
+  }
+  ccost = wave_sum(ccost);
+  mcc = wave_sum(mcc);
+  stepsq = wave_sum(stepsq);
+  xnormsq = wave_sum(xnormsq);
+  const double inval = wave_sum(cvalid ? 0.0 : 1.0);
+  if (lane == 0) {
+    double* tp = tile_part + 5 * (size_t)tile;
+    tp[0] = ccost; tp[1] = mcc; tp[2] = stepsq; tp[3] = xnormsq; tp[4] = inval;
+  }
+}
+
+// ------------------------------------------------ introspection / cost only
+// residuals/Jacobians in SORTED observation order (host un-permutes).
+// tile_part: [ntiles][2] = {cost, invalid}
+template <int PD, bool WANT_JAC>
+__global__ __launch_bounds__(kBlock) void k_evaluate(DevProblem P, const double* __restrict__ cam,
+                                                     const double* __restrict__ pts,
+                                                     double* __restrict__ residuals,
+                                                     double* __restrict__ jac_cam,
+                                                     double* __restrict__ jac_pt,
+                                                     uint8_t* __restrict__ valid,
+                                                     double* __restrict__ tile_part) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (tile >= P.ntiles) return;
+  const int cnt = P.tile_count[tile];
+  const int start = P.tile_start[tile];
+  LaneLin<PD> L;
+  lane_linearize<PD, WANT_JAC>(P, cam, pts, start + lane, lane < cnt, lane, L);
+  if (L.active) {
+    const size_t o = (size_t)start + lane;
+    if (residuals) { residuals[2 * o] = L.r[0]; residuals[2 * o + 1] = L.r[1]; }
+    if (WANT_JAC) {
+      if (jac_cam) for (int i = 0; i < 12; ++i) jac_cam[12 * o + i] = L.Jc[i];
+      if (jac_pt) for (int i = 0; i < 2 * PD; ++i) jac_pt[2 * PD * o + i] = L.Jt[i];
+    }
+    if (valid) valid[o] = L.valid ? 1 : 0;
+  }
+  const double cost = wave_sum(L.cost);
+  const double inval = wave_sum((L.active && !L.valid) ? 1.0 : 0.0);
+  if (lane == 0) { tile_part[2 * (size_t)tile] = cost; tile_part[2 * (size_t)tile + 1] = inval; }
+}
+
+inline int tile_blocks(int ntiles) { return (ntiles + kWavesPerBlock - 1) / kWavesPerBlock; }
+
+}  // namespace
+
+// ------------------------------------------------------------------ launchers
+void launch_colnorm(const DevProblem& P, const double* cam, const double* pts, double* colsq_c,
+                    double* colsq_p, hipStream_t st) {
+  if (P.ntiles == 0) return;
+  if (P.pd == 3) k_colnorm<3><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_p);
+  else k_colnorm<4><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_p);
+}
+
+void launch_make_scale(int count, const double* colsq, double* scale, hipStream_t st) {
+  if (count == 0) return;
+  k_make_scale<<<(count + 255) / 256, 256, 0, st>>>(count, colsq, scale);
+}
+
+void launch_linearize(const DevProblem& P, const double* cam, const double* pts, double radius,
+                      const ReduceBuf& rb, double* Vinv, double* gp, double* tile_part, hipStream_t st) {
+  if (P.ntiles == 0) return;
+  if (P.pd == 3)
+    k_linearize<3><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, radius, rb.S, rb.rhs, rb.colsq, rb.gc, Vinv, gp, tile_part);
+  else
+    k_linearize<4><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, radius, rb.S, rb.rhs, rb.colsq, rb.gc, Vinv, gp, tile_part);
+}
+
+void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,
+                         const int* field_is_max, double* scal, hipStream_t st) {
+  k_reduce_tiles<<<1, 1024, 0, st>>>(ntiles, tile_part, nfields, field_to_scal, field_is_max, scal);
+}
+
+void launch_finalize_rcs(const DevProblem& P, double radius, const ReduceBuf& rb, hipStream_t st) {
+  k_finalize_rcs<<<1, 256, 0, st>>>(P, radius, rb.S, rb.colsq, rb.gc, rb.scal);
+}
+
+void launch_cam_update(const DevProblem& P, const double* cam, const double* yc, double* cand_cam,
+                       double* out_stepsq, double* out_xnormsq, hipStream_t st) {
+  k_cam_update<<<1, 256, 0, st>>>(P, cam, yc, cand_cam, out_stepsq, out_xnormsq);
+}
+
+void launch_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,
+                    double* cand_pts, const double* yc, const double* Vinv, double* tile_part,
+                    double* scal, hipStream_t st) {
+  (void)scal;
+  if (P.ntiles == 0) return;
+  if (P.pd == 3)
+    k_backsub<3><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, yc, Vinv, tile_part);
+  else
+    k_backsub<4><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, yc, Vinv, tile_part);
+}
+
+void launch_evaluate(const DevProblem& P, const double* cam, const double* pts, double* residuals,
+                     double* jac_cam, double* jac_pt, uint8_t* valid, double* tile_part, hipStream_t st) {
+  if (P.ntiles == 0) return;
+  if (P.pd == 3)
+    k_evaluate<3, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, residuals, jac_cam, jac_pt, valid, tile_part);
+  else
+    k_evaluate<4, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, residuals, jac_cam, jac_pt, valid, tile_part);
+}
+
+void launch_cost_only(const DevProblem& P, const double* cam, const double* pts, double* tile_part,
+                      double* scal, hipStream_t st) {
+  (void)scal;
+  if (P.ntiles == 0) return;
+  if (P.pd == 3)
+    k_evaluate<3, false><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, nullptr, nullptr, nullptr, nullptr, tile_part);
+  else
+    k_evaluate<4, false><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, nullptr, nullptr, nullptr, nullptr, tile_part);
+}
+
+}  // namespace thip

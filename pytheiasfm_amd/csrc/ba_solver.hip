@@ -1,0 +1,613 @@
+// ba_solver.hip -- host side of the BA C-ABI (include/theia_hip.h): problem
+// flattening into wave tiles, device residency, and the Levenberg-Marquardt
+// control loop that replaces ceres::Solve as configured by
+//   BundleAdjuster::SetSolverOptions / Optimize
+//   (src/theia/sfm/bundle_adjustment/bundle_adjuster.cc:63-89,315-355).
+// LM rules restated from Ceres 2.2 (trust_region_minimizer.cc,
+// levenberg_marquardt_strategy.cc): see DESIGN.md "LM control".
+// All state stays in HBM; per LM iteration the host reads back one 32-double
+// scalar block (one stream sync).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ba_kernels.h"
+#include "theia_hip.h"
+#include "theia_hip_internal.h"
+
+namespace thip {
+
+thread_local std::string g_last_error;
+
+int set_error(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return set_error(e_ == hipErrorOutOfMemory ? THEIA_HIP_ERR_OUT_OF_MEMORY         \
+                                                 : THEIA_HIP_ERR_NO_DEVICE,            \
+                       "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t count) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    n = count;
+    if (count == 0) return 0;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e != hipSuccess) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    return 0;
+  }
+  int upload(const std::vector<T>& h, hipStream_t st) {
+    int rc = alloc(h.size());
+    if (rc) return rc;
+    if (!h.empty()) HIP_TRY(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    return 0;
+  }
+};
+
+}  // namespace thip
+
+using namespace thip;
+
+struct theia_ba_handle_s {
+  theia_ba_options opt;
+  int nc = 0, ng = 0, np = 0, ncv = 0, n = 0, pd = 3;
+  int64_t nobs = 0, nobs_main = 0;
+  int ntiles_main = 0, ntiles_all = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // host-side bookkeeping
+  std::vector<int64_t> perm;       // sorted obs index -> original obs index
+  std::vector<int> cam_red;
+  std::vector<uint8_t> cam_mask, pt_const;
+  // device buffers
+  DevBuf<double> cam[2], pts[2], intr, scale_c, scale_p, ones_c, ones_p, colsq_c0, colsq_p0;
+  DevBuf<int> group_model, cam_group, d_cam_red, obs_cam, obs_pt, tile_start, tile_count, f2s, fmaxflag;
+  DevBuf<uint8_t> d_cam_mask, d_pt_const;
+  DevBuf<double2> obs_uv, obs_si;
+  DevBuf<double> reduce, Vinv, gp, tile_part, scalB;
+  double* h_scal = nullptr;  // pinned: [scalA(16) | scalB(16)]
+  int cur = 0;
+  bool have_scale = false;
+  double fixed_cost = 0.0;
+  theia_allreduce_fn allreduce = nullptr;
+  void* allreduce_ctx = nullptr;
+  ReduceBuf rb;
+  DevProblem P;
+
+  ~theia_ba_handle_s() {
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    if (h_scal) (void)hipHostFree(h_scal);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+enum { SB_COST = 0, SB_MCC = 1, SB_STEPSQ = 2, SB_XNORMSQ = 3, SB_INVALID = 4, SB_STEPSQ_CAM = 8, SB_XNORMSQ_CAM = 9 };
+
+int supported_model(int m) { return m == THEIA_CAM_PINHOLE || m == THEIA_CAM_DOUBLE_SPHERE; }
+
+int validate(const theia_ba_problem* p, const theia_ba_options* o) {
+  if (!p || !o) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null problem/options");
+  if (p->num_cameras < 0 || p->num_points < 0 || p->num_obs < 0 || p->num_groups < 0)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "negative sizes");
+  if (p->num_obs >= (int64_t)1 << 31) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "num_obs >= 2^31");
+  if (p->num_obs > 0 && (!p->cam_ext || !p->intrinsics || !p->group_model || !p->cam_group || !p->points ||
+                         !p->obs_uv || !p->obs_cam || !p->obs_pt))
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null array in problem");
+  for (int c = 0; c < p->num_cameras; ++c)
+    if (p->cam_group[c] < 0 || p->cam_group[c] >= p->num_groups)
+      return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "cam_group[%d] out of range", c);
+  for (int g = 0; g < p->num_groups; ++g)
+    if (!supported_model(p->group_model[g]))
+      return set_error(THEIA_HIP_ERR_UNSUPPORTED, "camera model %d of group %d has no HIP kernel yet", p->group_model[g], g);
+  for (int64_t i = 0; i < p->num_obs; ++i) {
+    if (p->obs_cam[i] < 0 || p->obs_cam[i] >= p->num_cameras || p->obs_pt[i] < 0 || p->obs_pt[i] >= p->num_points)
+      return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "observation %lld indexes out of range", (long long)i);
+  }
+  if (o->intrinsics_to_optimize != THEIA_INTR_NONE)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "intrinsics_to_optimize != NONE is not built yet (DESIGN.md scope)");
+  if (o->loss_function_type < 0 || o->loss_function_type > THEIA_LOSS_TRUNCATED)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "invalid loss function type");  // reference: LOG(FATAL)
+  return 0;
+}
+
+void fill_devproblem(theia_ba_handle_s* h) {
+  DevProblem& P = h->P;
+  P.nc = h->nc; P.np = h->np; P.ncv = h->ncv; P.ntiles = h->ntiles_main; P.nobs = h->nobs_main;
+  P.n = h->n; P.pd = h->pd; P.loss_type = h->opt.loss_function_type; P.loss_width = h->opt.robust_loss_width;
+  P.intr = h->intr.p; P.group_model = h->group_model.p; P.cam_group = h->cam_group.p;
+  P.cam_red = h->d_cam_red.p; P.cam_mask = h->d_cam_mask.p; P.pt_const = h->d_pt_const.p;
+  P.obs_uv = h->obs_uv.p; P.obs_si = h->obs_si.p; P.obs_cam = h->obs_cam.p; P.obs_pt = h->obs_pt.p;
+  P.tile_start = h->tile_start.p; P.tile_count = h->tile_count.p;
+  P.scale_c = h->scale_c.p; P.scale_p = h->scale_p.p;
+}
+
+int upload_parameters(theia_ba_handle_s* h, const theia_ba_problem* p) {
+  for (int k = 0; k < 2; ++k) {
+    if (h->nc) HIP_TRY(hipMemcpyAsync(h->cam[k].p, p->cam_ext, sizeof(double) * 6 * h->nc, hipMemcpyHostToDevice, h->stream));
+    if (h->np) HIP_TRY(hipMemcpyAsync(h->pts[k].p, p->points, sizeof(double) * 4 * h->np, hipMemcpyHostToDevice, h->stream));
+  }
+  if (h->ng) HIP_TRY(hipMemcpyAsync(h->intr.p, p->intrinsics, sizeof(double) * THEIA_MAX_INTRINSICS * h->ng, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->cur = 0;
+  h->have_scale = false;
+  return 0;
+}
+
+// reduce_tiles configurations, uploaded once at create():
+//   cfg 0 (linearize): {cost, gmax(max), invalid, notpd} -> rb.scal
+//   cfg 1 (backsub)  : {cost, mcc, stepsq, xnormsq, invalid} -> scalB
+//   cfg 2 (cost only): {cost, invalid} -> scalB
+const int kCfgF2S[3][8] = {{SC_COST, SC_GMAX, SC_INVALID, SC_NOTPD, 0, 0, 0, 0},
+                           {SB_COST, SB_MCC, SB_STEPSQ, SB_XNORMSQ, SB_INVALID, 0, 0, 0},
+                           {SB_COST, SB_INVALID, 0, 0, 0, 0, 0, 0}};
+const int kCfgMax[3][8] = {{0, 1, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+
+int do_allreduce(theia_ba_handle_s* h, double* buf, size_t count, int op) {
+  if (!h->allreduce || count == 0) return 0;
+  const int rc = h->allreduce(h->allreduce_ctx, buf, count, op, (void*)h->stream);
+  if (rc) return set_error(THEIA_HIP_ERR_INTERNAL, "allreduce callback failed (%d)", rc);
+  return 0;
+}
+
+// cost of a tile range at given parameters (deterministic reduction)
+int cost_of_tiles(theia_ba_handle_s* h, int tile0, int ntiles, const double* cam, const double* pts, double* cost, double* invalid) {
+  *cost = 0.0; *invalid = 0.0;
+  if (ntiles == 0) return 0;
+  DevProblem Q = h->P;
+  Q.tile_start = h->tile_start.p + tile0; Q.tile_count = h->tile_count.p + tile0; Q.ntiles = ntiles;
+  HIP_TRY(hipMemsetAsync(h->scalB.p, 0, sizeof(double) * 16, h->stream));
+  launch_cost_only(Q, cam, pts, h->tile_part.p, h->scalB.p, h->stream);
+  launch_reduce_tiles(ntiles, h->tile_part.p, 2, h->f2s.p + 16, h->fmaxflag.p + 16, h->scalB.p, h->stream);
+  HIP_TRY(hipMemcpyAsync(h->h_scal + 16, h->scalB.p, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *cost = h->h_scal[16 + SB_COST]; *invalid = h->h_scal[16 + SB_INVALID];
+  return 0;
+}
+
+// Jacobi scaling 1/(1+sqrt(colnorm^2)) from the unscaled Jacobian at the
+// current point (ceres trust_region_minimizer.cc, computed once per solve).
+// With several ranks the camera column norms are summed first: cameras are
+// shared by all track shards.
+int compute_scale(theia_ba_handle_s* h) {
+  DevProblem Q = h->P;
+  Q.scale_c = h->ones_c.p; Q.scale_p = h->ones_p.p;
+  if (h->colsq_c0.n) HIP_TRY(hipMemsetAsync(h->colsq_c0.p, 0, sizeof(double) * h->colsq_c0.n, h->stream));
+  if (h->colsq_p0.n) HIP_TRY(hipMemsetAsync(h->colsq_p0.p, 0, sizeof(double) * h->colsq_p0.n, h->stream));
+  launch_colnorm(Q, h->cam[h->cur].p, h->pts[h->cur].p, h->colsq_c0.p, h->colsq_p0.p, h->stream);
+  int rc = do_allreduce(h, h->colsq_c0.p, h->colsq_c0.n, THEIA_REDUCE_SUM);
+  if (rc) return rc;
+  launch_make_scale((int)h->colsq_c0.n, h->colsq_c0.p, h->scale_c.p, h->stream);
+  launch_make_scale((int)h->colsq_p0.n, h->colsq_p0.p, h->scale_p.p, h->stream);
+  h->have_scale = true;
+  return 0;
+}
+
+// enqueue: clear, linearize + Schur, tile reduction, (all-reduce), LM diagonal.
+int enqueue_linearize(theia_ba_handle_s* h, double radius) {
+  HIP_TRY(hipMemsetAsync(h->reduce.p, 0, sizeof(double) * h->reduce.n, h->stream));
+  launch_linearize(h->P, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->tile_part.p, h->stream);
+  if (h->ntiles_main) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 4, h->f2s.p, h->fmaxflag.p, h->rb.scal, h->stream);
+  // one SUM all-reduce of [S | rhs | colsq | gc | scal[0,8)], one MAX of scal[8,16)
+  int rc = do_allreduce(h, h->reduce.p, (size_t)h->n * h->n + 3 * (size_t)h->n + 8, THEIA_REDUCE_SUM);
+  if (!rc) rc = do_allreduce(h, h->rb.scal + 8, 8, THEIA_REDUCE_MAX);
+  if (rc) return rc;
+  launch_finalize_rcs(h->P, radius, h->rb, h->stream);
+  return 0;
+}
+
+// enqueue: dense solve, candidate cameras, back-substitution + trial cost.
+int enqueue_solve_and_backsub(theia_ba_handle_s* h) {
+  double* yc = h->rb.rhs;  // the solution overwrites the rhs row
+  dense_cholesky_solve(h->n, h->rb.S, h->n, h->rb.rhs, h->rb.scal + SC_NOTPD, h->stream);
+  HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+  HIP_TRY(hipMemsetAsync(h->scalB.p, 0, sizeof(double) * 16, h->stream));
+  const int nxt = 1 - h->cur;
+  launch_cam_update(h->P, h->cam[h->cur].p, yc, h->cam[nxt].p, h->scalB.p + SB_STEPSQ_CAM, h->scalB.p + SB_XNORMSQ_CAM, h->stream);
+  launch_backsub(h->P, h->cam[h->cur].p, h->pts[h->cur].p, h->cam[nxt].p, h->pts[nxt].p, yc, h->Vinv.p, h->tile_part.p, h->scalB.p, h->stream);
+  if (h->ntiles_main) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 5, h->f2s.p + 8, h->fmaxflag.p + 8, h->scalB.p, h->stream);
+  return do_allreduce(h, h->scalB.p, 8, THEIA_REDUCE_SUM);
+}
+
+void trace_push(theia_ba_summary* S, double cost, double g, double step, double radius, int acc) {
+  if (!S->trace_cost || S->trace_size >= S->trace_capacity) return;
+  const int k = S->trace_size++;
+  S->trace_cost[k] = cost;
+  if (S->trace_gradient_max_norm) S->trace_gradient_max_norm[k] = g;
+  if (S->trace_step_norm) S->trace_step_norm[k] = step;
+  if (S->trace_radius) S->trace_radius[k] = radius;
+  if (S->trace_accepted) S->trace_accepted[k] = acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+void theia_ba_options_default(theia_ba_options* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->loss_function_type = THEIA_LOSS_TRIVIAL;
+  o->robust_loss_width = 2.0;
+  o->intrinsics_to_optimize = THEIA_INTR_NONE;
+  o->max_num_iterations = 100;
+  o->use_homogeneous_point_parametrization = 1;
+  o->use_inner_iterations = 1;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->max_trust_region_radius = 1e12;
+  o->max_solver_time_in_seconds = 3600.0;
+}
+
+int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_handle* out) {
+  if (!out) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle pointer");
+  *out = nullptr;
+  int rc = validate(p, o);
+  if (rc) return rc;
+  rc = thip::ensure_device();
+  if (rc) return rc;
+  theia_ba_handle_s* h = new theia_ba_handle_s();
+  std::unique_ptr<theia_ba_handle_s> guard(h);
+  h->opt = *o;
+  h->nc = p->num_cameras; h->ng = p->num_groups; h->np = p->num_points; h->nobs = p->num_obs;
+  h->pd = o->use_homogeneous_point_parametrization ? 3 : 4;
+  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
+  HIP_TRY(hipHostMalloc((void**)&h->h_scal, sizeof(double) * 32, hipHostMallocDefault));
+
+  // --- problem structure (bundle_adjuster.cc:116-221,357-380,477-527) ---
+  std::vector<uint8_t> cam_used(h->nc, 0), pt_used(h->np, 0);
+  for (int64_t i = 0; i < h->nobs; ++i) { cam_used[p->obs_cam[i]] = 1; pt_used[p->obs_pt[i]] = 1; }
+  h->cam_red.assign(h->nc, -1); h->cam_mask.assign(h->nc, 0x3f); h->pt_const.assign(h->np, 1);
+  h->ncv = 0;
+  for (int c = 0; c < h->nc; ++c) {
+    unsigned m = p->cam_const ? p->cam_const[c] : 0;
+    if (o->constant_camera_orientation) m |= THEIA_CAM_CONST_ORIENTATION;
+    if (o->constant_camera_position) m |= THEIA_CAM_CONST_POSITION;
+    if (o->orthographic_camera) m |= THEIA_CAM_CONST_TZ;
+    unsigned cols = 0;
+    if (m & THEIA_CAM_CONST_POSITION) cols |= 0x07;
+    if (m & THEIA_CAM_CONST_ORIENTATION) cols |= 0x38;
+    if (m & THEIA_CAM_CONST_TZ) cols |= 0x04;
+    if (cols != 0x3f && (cam_used[c] || (p->flags & THEIA_BA_FLAG_KEEP_UNOBSERVED_CAMERAS))) { h->cam_red[c] = h->ncv++; h->cam_mask[c] = (uint8_t)cols; }
+  }
+  h->n = 6 * h->ncv;
+  for (int q = 0; q < h->np; ++q) h->pt_const[q] = ((p->point_const && p->point_const[q]) || !pt_used[q]) ? 1 : 0;
+
+  // observations sorted by track; residual blocks whose blocks are all
+  // constant are evaluated once ("fixed cost", ceres reduced program).
+  std::vector<uint8_t> fixed(h->nobs, 0);
+  std::vector<int64_t> cnt_main(h->np + 1, 0), cnt_fix(h->np + 1, 0);
+  for (int64_t i = 0; i < h->nobs; ++i) {
+    fixed[i] = (h->cam_red[p->obs_cam[i]] < 0 && h->pt_const[p->obs_pt[i]]) ? 1 : 0;
+    (fixed[i] ? cnt_fix : cnt_main)[p->obs_pt[i] + 1]++;
+  }
+  for (int q = 0; q < h->np; ++q) { cnt_main[q + 1] += cnt_main[q]; cnt_fix[q + 1] += cnt_fix[q]; }
+  h->nobs_main = cnt_main[h->np];
+  h->perm.assign(h->nobs, 0);
+  {
+    std::vector<int64_t> fm(cnt_main.begin(), cnt_main.end() - 1), ff(cnt_fix.begin(), cnt_fix.end() - 1);
+    for (int64_t i = 0; i < h->nobs; ++i) {
+      const int q = p->obs_pt[i];
+      if (fixed[i]) h->perm[h->nobs_main + ff[q]++] = i; else h->perm[fm[q]++] = i;
+    }
+  }
+  // wave tiles: <= 64 observations, never splitting a track
+  std::vector<int> tstart, tcount;
+  auto build_tiles = [&](const std::vector<int64_t>& off, int64_t base) -> int {
+    int64_t cur0 = 0, curlen = 0;
+    for (int q = 0; q < h->np; ++q) {
+      const int64_t L = off[q + 1] - off[q];
+      if (L == 0) continue;
+      if (L > 64) return -1;
+      if (curlen + L > 64) { tstart.push_back((int)(base + cur0)); tcount.push_back((int)curlen); cur0 = off[q]; curlen = 0; }
+      if (curlen == 0) cur0 = off[q];
+      curlen += L;
+    }
+    if (curlen) { tstart.push_back((int)(base + cur0)); tcount.push_back((int)curlen); }
+    return 0;
+  };
+  if (build_tiles(cnt_main, 0))
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "a track has more than 64 observations (long-track kernel not built yet)");
+  h->ntiles_main = (int)tstart.size();
+  if (build_tiles(cnt_fix, h->nobs_main))
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "a track has more than 64 observations (long-track kernel not built yet)");
+  h->ntiles_all = (int)tstart.size();
+
+  std::vector<double2> uv(h->nobs), si;
+  std::vector<int> ocam(h->nobs), opt(h->nobs);
+  if (p->obs_sqrt_info) si.resize(h->nobs);
+  for (int64_t s = 0; s < h->nobs; ++s) {
+    const int64_t i = h->perm[s];
+    uv[s] = make_double2(p->obs_uv[2 * i], p->obs_uv[2 * i + 1]);
+    if (p->obs_sqrt_info) si[s] = make_double2(p->obs_sqrt_info[2 * i], p->obs_sqrt_info[2 * i + 1]);
+    ocam[s] = p->obs_cam[i]; opt[s] = p->obs_pt[i];
+  }
+  hipStream_t st = h->stream;
+#define UP(buf, vec) do { rc = h->buf.upload(vec, st); if (rc) return rc; } while (0)
+#define AL(buf, cnt) do { rc = h->buf.alloc(cnt); if (rc) return rc; } while (0)
+  UP(obs_uv, uv); UP(obs_si, si); UP(obs_cam, ocam); UP(obs_pt, opt);
+  UP(tile_start, tstart); UP(tile_count, tcount);
+  UP(d_cam_red, h->cam_red); UP(d_cam_mask, h->cam_mask); UP(d_pt_const, h->pt_const);
+  std::vector<int> gm(p->group_model, p->group_model + h->ng), cg(p->cam_group, p->cam_group + h->nc);
+  UP(group_model, gm); UP(cam_group, cg);
+  for (int k = 0; k < 2; ++k) { AL(cam[k], (size_t)6 * h->nc); AL(pts[k], (size_t)4 * h->np); }
+  AL(intr, (size_t)THEIA_MAX_INTRINSICS * h->ng);
+  std::vector<double> ones_c((size_t)6 * h->nc, 1.0), ones_p((size_t)h->pd * h->np, 1.0);
+  UP(ones_c, ones_c); UP(ones_p, ones_p); UP(scale_c, ones_c); UP(scale_p, ones_p);
+  AL(colsq_c0, (size_t)6 * h->nc); AL(colsq_p0, (size_t)h->pd * h->np);
+  {
+    std::vector<int> a(&kCfgF2S[0][0], &kCfgF2S[0][0] + 24), b(&kCfgMax[0][0], &kCfgMax[0][0] + 24);
+    UP(f2s, a); UP(fmaxflag, b);
+  }
+  const size_t nn = (size_t)h->n * h->n;
+  AL(reduce, nn + 3 * (size_t)h->n + SC_COUNT);
+  h->rb.base = h->reduce.p; h->rb.count = h->reduce.n;
+  h->rb.S = h->reduce.p; h->rb.rhs = h->rb.S + nn; h->rb.colsq = h->rb.rhs + h->n; h->rb.gc = h->rb.colsq + h->n;
+  h->rb.scal = h->rb.gc + h->n;
+  AL(Vinv, (size_t)(h->pd * (h->pd + 1) / 2) * h->np); AL(gp, (size_t)h->pd * h->np);
+  AL(tile_part, (size_t)5 * std::max(1, h->ntiles_all)); AL(scalB, 16);
+#undef UP
+#undef AL
+  fill_devproblem(h);
+  rc = upload_parameters(h, p);
+  if (rc) return rc;
+  // fixed cost
+  double fc = 0.0, inv = 0.0;
+  rc = cost_of_tiles(h, h->ntiles_main, h->ntiles_all - h->ntiles_main, h->cam[0].p, h->pts[0].p, &fc, &inv);
+  if (rc) return rc;
+  h->fixed_cost = fc;
+  *out = guard.release();
+  return 0;
+}
+
+int theia_hip_ba_reset_parameters(theia_ba_handle h, const theia_ba_problem* p) {
+  if (!h || !p) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (p->num_cameras != h->nc || p->num_points != h->np || p->num_groups != h->ng)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "problem shape differs from the handle's");
+  return upload_parameters(h, p);
+}
+
+int theia_hip_ba_set_allreduce(theia_ba_handle h, theia_allreduce_fn fn, void* ctx) {
+  if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
+  h->allreduce = fn; h->allreduce_ctx = ctx;
+  return 0;
+}
+
+int theia_hip_ba_download(theia_ba_handle h, theia_ba_problem* p) {
+  if (!h || !p) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (h->nc) HIP_TRY(hipMemcpyAsync(p->cam_ext, h->cam[h->cur].p, sizeof(double) * 6 * h->nc, hipMemcpyDeviceToHost, h->stream));
+  if (h->np) HIP_TRY(hipMemcpyAsync(p->points, h->pts[h->cur].p, sizeof(double) * 4 * h->np, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int theia_hip_ba_destroy(theia_ba_handle h) {
+  delete h;
+  return 0;
+}
+
+int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
+  if (!h || !S) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const theia_ba_options& O = h->opt;
+  const double t_start = now_s();
+  S->trace_size = 0; S->success = 0; S->num_iterations = 0; S->num_successful_steps = 0;
+  S->time_linearize = S->time_solve_reduced = S->time_backsub = 0.0;
+  S->setup_time_in_seconds = 0.0;
+  int rc = compute_scale(h);
+  if (rc) return rc;
+  double radius = 1e4, decrease_factor = 2.0;
+  bool step_successful = true;
+  int iter = 0, invalid_steps = 0, term = THEIA_TERM_NO_CONVERGENCE;
+  double x_cost = 0.0, x_norm = 0.0, gmax = 0.0, minimum_cost = 0.0;
+  bool first = true;
+  // |x| of the variable blocks at the start: cameras on the host side are
+  // cheap, but keep everything on device: a zero-step back-substitution is
+  // not available before the first solve, so compute it from a download.
+  {
+    std::vector<double> hc((size_t)6 * h->nc), hp((size_t)4 * h->np);
+    if (h->nc) HIP_TRY(hipMemcpyAsync(hc.data(), h->cam[h->cur].p, sizeof(double) * hc.size(), hipMemcpyDeviceToHost, h->stream));
+    if (h->np) HIP_TRY(hipMemcpyAsync(hp.data(), h->pts[h->cur].p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    double s = 0.0;
+    for (int c = 0; c < h->nc; ++c) if (h->cam_red[c] >= 0) for (int q = 0; q < 6; ++q) s += hc[6 * c + q] * hc[6 * c + q];
+    double sp = 0.0;
+    for (int p = 0; p < h->np; ++p) if (!h->pt_const[p]) for (int q = 0; q < 4; ++q) sp += hp[4 * (size_t)p + q] * hp[4 * (size_t)p + q];
+    if (h->allreduce) {  // the point part is per shard: sum it over ranks
+      HIP_TRY(hipMemcpyAsync(h->scalB.p, &sp, sizeof(double), hipMemcpyHostToDevice, h->stream));
+      int rc2 = do_allreduce(h, h->scalB.p, 1, THEIA_REDUCE_SUM);
+      if (rc2) return rc2;
+      HIP_TRY(hipMemcpyAsync(&sp, h->scalB.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    x_norm = std::sqrt(s + sp);
+  }
+  int pending_grad = -1;  // trace entry of the last accepted step (gradient known one read-back later)
+  while (true) {
+    // one LM iteration is enqueued speculatively; the host reads back scalars once
+    HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    rc = enqueue_linearize(h, radius); if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    rc = enqueue_solve_and_backsub(h); if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->h_scal, h->rb.scal, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->h_scal + 16, h->scalB.p, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) S->time_linearize += ms * 1e-3;
+      if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) S->time_solve_reduced += ms * 1e-3;
+      if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) S->time_backsub += ms * 1e-3;
+    }
+    const double* sa = h->h_scal;
+    const double* sb = h->h_scal + 16;
+    x_cost = sa[SC_COST];
+    gmax = sa[SC_GMAX];
+    if (pending_grad >= 0 && S->trace_gradient_max_norm) S->trace_gradient_max_norm[pending_grad] = gmax;
+    pending_grad = -1;
+    if (first) {
+      first = false;
+      S->initial_cost = x_cost + h->fixed_cost;
+      minimum_cost = x_cost;
+      if (sa[SC_INVALID] > 0.0 || !std::isfinite(x_cost)) {
+        // "Initial residual and Jacobian evaluation failed." -> FAILURE
+        term = THEIA_TERM_FAILURE; S->final_cost = S->initial_cost; break;
+      }
+      trace_push(S, x_cost + h->fixed_cost, gmax, 0.0, radius, 1);
+    }
+    // FinalizeIterationAndCheckIfMinimizerCanContinue
+    if (now_s() - t_start >= O.max_solver_time_in_seconds) { term = THEIA_TERM_NO_CONVERGENCE; break; }
+    if (iter >= O.max_num_iterations) { term = THEIA_TERM_NO_CONVERGENCE; break; }
+    if (step_successful && gmax <= O.gradient_tolerance) { term = THEIA_TERM_CONVERGENCE; break; }
+    if (radius <= 1e-32) { term = THEIA_TERM_CONVERGENCE; break; }
+    ++iter;
+    const double mcc = sb[SB_MCC];
+    const bool solved = sa[SC_NOTPD] == 0.0 && std::isfinite(mcc) && std::isfinite(sb[SB_STEPSQ] + sb[SB_STEPSQ_CAM]);
+    const bool step_valid = solved && mcc > 0.0;
+    if (!step_valid) {
+      if (++invalid_steps >= 5) { term = THEIA_TERM_FAILURE; break; }
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+      trace_push(S, x_cost + h->fixed_cost, gmax, 0.0, radius, 0);
+      if (O.verbose) std::fprintf(stderr, "[theia_hip] %3d invalid step, radius %.3e\n", iter, radius);
+      continue;
+    }
+    invalid_steps = 0;
+    double cand_cost = sb[SB_COST];
+    if (sb[SB_INVALID] > 0.0 || !std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+    const double step_norm = std::sqrt(sb[SB_STEPSQ] + sb[SB_STEPSQ_CAM]);
+    if (step_norm <= O.parameter_tolerance * (x_norm + O.parameter_tolerance)) {
+      trace_push(S, cand_cost + h->fixed_cost, gmax, step_norm, radius, 0);
+      term = THEIA_TERM_CONVERGENCE; break;
+    }
+    const double cost_change = x_cost - cand_cost;
+    if (std::fabs(cost_change) <= O.function_tolerance * x_cost) {
+      trace_push(S, cand_cost + h->fixed_cost, gmax, step_norm, radius, 0);
+      term = THEIA_TERM_CONVERGENCE; break;
+    }
+    const double relative_decrease = cost_change / mcc;
+    if (relative_decrease > 1e-3) {
+      h->cur = 1 - h->cur;  // candidate buffers become the state
+      x_norm = std::sqrt(sb[SB_XNORMSQ] + sb[SB_XNORMSQ_CAM]);
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3));
+      radius = std::min(O.max_trust_region_radius, radius);
+      decrease_factor = 2.0; step_successful = true;
+      S->num_successful_steps++;
+      if (cand_cost < minimum_cost) minimum_cost = cand_cost;
+      // gradient at the new point is produced by the next linearize; the
+      // trace entry is completed there (gmax of the NEXT read-back).
+      if (S->trace_cost && S->trace_size < S->trace_capacity) pending_grad = S->trace_size;
+      trace_push(S, cand_cost + h->fixed_cost, -1.0, step_norm, radius, 1);
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+      trace_push(S, cand_cost + h->fixed_cost, gmax, step_norm, radius, 0);
+    }
+    if (O.verbose)
+      std::fprintf(stderr, "[theia_hip] %3d cost %.6e cand %.6e rho %.3e |g| %.3e |step| %.3e radius %.3e %s\n", iter,
+                   x_cost, cand_cost, relative_decrease, gmax, step_norm, radius, step_successful ? "ok" : "rej");
+  }
+  // patch the gradient entries of accepted steps (known one read-back later)
+  S->num_iterations = iter;
+  S->termination_type = term;
+  S->success = term != THEIA_TERM_FAILURE;
+  if (term != THEIA_TERM_FAILURE || S->final_cost == 0.0) S->final_cost = minimum_cost + h->fixed_cost;
+  S->solve_time_in_seconds = now_s() - t_start;
+  return 0;
+}
+
+int theia_hip_ba_solve(const theia_ba_problem* problem, const theia_ba_options* options, theia_ba_summary* summary) {
+  if (!summary) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null summary");
+  const double t0 = now_s();
+  theia_ba_handle h = nullptr;
+  int rc = theia_hip_ba_create(problem, options, &h);
+  if (rc) return rc;
+  const double t1 = now_s();
+  rc = theia_hip_ba_run(h, summary);
+  if (!rc) rc = theia_hip_ba_download(h, const_cast<theia_ba_problem*>(problem));
+  summary->setup_time_in_seconds = t1 - t0;
+  theia_hip_ba_destroy(h);
+  return rc;
+}
+
+int theia_hip_ba_evaluate(theia_ba_handle h, double* cost, double* residuals, double* jac_cam, double* jac_pt, uint8_t* valid) {
+  if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
+  const int pd = h->pd;
+  DevBuf<double> dr, djc, djp; DevBuf<uint8_t> dv;
+  int rc;
+  const size_t nm = (size_t)h->nobs_main;
+  if ((rc = dr.alloc(2 * nm)) || (rc = djc.alloc(12 * nm)) || (rc = djp.alloc(2 * pd * nm)) || (rc = dv.alloc(nm))) return rc;
+  DevProblem Q = h->P;
+  Q.scale_c = h->ones_c.p; Q.scale_p = h->ones_p.p;
+  HIP_TRY(hipMemsetAsync(h->scalB.p, 0, sizeof(double) * 16, h->stream));
+  launch_evaluate(Q, h->cam[h->cur].p, h->pts[h->cur].p, dr.p, djc.p, djp.p, dv.p, h->tile_part.p, h->stream);
+  if (h->ntiles_main) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 2, h->f2s.p + 16, h->fmaxflag.p + 16, h->scalB.p, h->stream);
+  std::vector<double> hr(2 * nm), hjc(12 * nm), hjp(2 * pd * nm); std::vector<uint8_t> hv(nm);
+  if (nm) {
+    HIP_TRY(hipMemcpyAsync(hr.data(), dr.p, sizeof(double) * hr.size(), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(hjc.data(), djc.p, sizeof(double) * hjc.size(), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(hjp.data(), djp.p, sizeof(double) * hjp.size(), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(hv.data(), dv.p, hv.size(), hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(h->h_scal + 16, h->scalB.p, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (cost) *cost = h->h_scal[16 + SB_COST] + h->fixed_cost;
+  if (residuals) std::fill(residuals, residuals + 2 * h->nobs, 0.0);
+  if (jac_cam) std::fill(jac_cam, jac_cam + 12 * h->nobs, 0.0);
+  if (jac_pt) std::fill(jac_pt, jac_pt + 2 * pd * h->nobs, 0.0);
+  if (valid) std::fill(valid, valid + h->nobs, (uint8_t)1);
+  for (size_t s = 0; s < nm; ++s) {
+    const int64_t i = h->perm[s];
+    if (residuals) { residuals[2 * i] = hr[2 * s]; residuals[2 * i + 1] = hr[2 * s + 1]; }
+    if (jac_cam) std::copy(&hjc[12 * s], &hjc[12 * s] + 12, jac_cam + 12 * i);
+    if (jac_pt) std::copy(&hjp[2 * pd * s], &hjp[2 * pd * s] + 2 * pd, jac_pt + 2 * pd * i);
+    if (valid) valid[i] = hv[s];
+  }
+  return 0;
+}
+
+int theia_hip_ba_reduced_system(theia_ba_handle h, double radius, int32_t* n_out, double* S, double* rhs, int64_t capacity) {
+  if (!h || !n_out) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  int rc = compute_scale(h);
+  if (rc) return rc;
+  rc = enqueue_linearize(h, radius);
+  if (rc) return rc;
+  const int n = h->n;
+  *n_out = n;
+  if ((int64_t)n * n > capacity) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "capacity too small for %d x %d", n, n);
+  if (n) {
+    HIP_TRY(hipMemcpyAsync(S, h->rb.S, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(rhs, h->rb.rhs, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) S[(size_t)i * n + j] = S[(size_t)j * n + i];
+  return 0;
+}
+
+}  // extern "C"

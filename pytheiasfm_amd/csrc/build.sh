@@ -1,0 +1,20 @@
+#!/bin/bash
+# Builds libtheia_hip.so (gfx950) in-tree.  -ffp-contract=off keeps FP64
+# arithmetic free of FMA contraction so RANSAC results are bit-reproducible
+# against the CPU oracle (built with the same flag).
+set -e
+cd "$(dirname "$0")"
+SRCS=$(ls *.hip)
+mkdir -p _obj
+OBJS=""
+for f in $SRCS; do
+  o=_obj/${f%.hip}.o
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find . ../../include -maxdepth 1 -name '*.h' -newer "$o")" ]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics \
+      -I../../include -I. -c "$f" -o "$o" &
+  fi
+  OBJS="$OBJS $o"
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libtheia_hip.so $OBJS
+echo "built $(realpath ../libtheia_hip.so)"

@@ -1,0 +1,268 @@
+"""Deterministic synthetic workloads of BASELINE.json.
+
+synth_ba_v1      ring-of-cameras reconstruction (configs C1/C2/C4)
+synth_ransac_v1  batch of two-view / 2D-3D correspondence problems (config C5)
+
+Randomness is a counter-based splitmix64 stream written here (identical on
+every platform; no std:: / numpy distributions), so the same seed gives the
+same scene in this container and on the GPU box.
+"""
+import numpy as np
+
+from ._capi import FlatProblem
+
+MASK = (1 << 64) - 1
+CAM_PINHOLE = 0
+CAM_DOUBLE_SPHERE = 5
+
+
+def splitmix64(x):
+    """Vectorised splitmix64 finaliser on uint64 arrays."""
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        z = x
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+class Stream:
+    """Counter-based random stream: value k of stream (seed, tag) is a pure function."""
+
+    def __init__(self, seed, tag):
+        self.base = splitmix64(np.uint64((seed * 0x100000001B3 + tag) & MASK))
+
+    def bits(self, idx):
+        idx = np.asarray(idx, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            return splitmix64(self.base + idx * np.uint64(0xD1342543DE82EF95))
+
+    def uniform(self, idx):
+        return (self.bits(idx) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+    def normal(self, idx):
+        idx = np.asarray(idx, dtype=np.uint64)
+        u1 = self.uniform(2 * idx)
+        u2 = self.uniform(2 * idx + 1)
+        return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
+
+    def integers(self, idx, n):
+        return (self.bits(idx) % np.uint64(n)).astype(np.int64)
+
+
+# ------------------------------------------------------------------ rotations
+def angle_axis_to_matrix(w):
+    """Rodrigues, batched: w (...,3) -> R (...,3,3)."""
+    w = np.asarray(w, dtype=np.float64)
+    th = np.linalg.norm(w, axis=-1)
+    small = th < 1e-12
+    ths = np.where(small, 1.0, th)
+    k = w / ths[..., None]
+    K = np.zeros(w.shape[:-1] + (3, 3))
+    K[..., 0, 1] = -k[..., 2]; K[..., 0, 2] = k[..., 1]
+    K[..., 1, 0] = k[..., 2]; K[..., 1, 2] = -k[..., 0]
+    K[..., 2, 0] = -k[..., 1]; K[..., 2, 1] = k[..., 0]
+    s = np.sin(th)[..., None, None]
+    c = np.cos(th)[..., None, None]
+    R = np.eye(3) + s * K + (1.0 - c) * (K @ K)
+    if np.any(small):
+        R = np.where(small[..., None, None], np.eye(3), R)
+    return R
+
+
+def matrix_to_angle_axis(R):
+    """Batched log map through the quaternion (robust near pi)."""
+    R = np.asarray(R, dtype=np.float64)
+    out = np.zeros(R.shape[:-2] + (3,))
+    Rf = R.reshape(-1, 3, 3)
+    of = out.reshape(-1, 3)
+    for i, M in enumerate(Rf):
+        tr = M[0, 0] + M[1, 1] + M[2, 2]
+        if tr > 0:
+            s = np.sqrt(tr + 1.0) * 2
+            q = np.array([0.25 * s, (M[2, 1] - M[1, 2]) / s, (M[0, 2] - M[2, 0]) / s, (M[1, 0] - M[0, 1]) / s])
+        elif M[0, 0] > M[1, 1] and M[0, 0] > M[2, 2]:
+            s = np.sqrt(1.0 + M[0, 0] - M[1, 1] - M[2, 2]) * 2
+            q = np.array([(M[2, 1] - M[1, 2]) / s, 0.25 * s, (M[0, 1] + M[1, 0]) / s, (M[0, 2] + M[2, 0]) / s])
+        elif M[1, 1] > M[2, 2]:
+            s = np.sqrt(1.0 + M[1, 1] - M[0, 0] - M[2, 2]) * 2
+            q = np.array([(M[0, 2] - M[2, 0]) / s, (M[0, 1] + M[1, 0]) / s, 0.25 * s, (M[1, 2] + M[2, 1]) / s])
+        else:
+            s = np.sqrt(1.0 + M[2, 2] - M[0, 0] - M[1, 1]) * 2
+            q = np.array([(M[1, 0] - M[0, 1]) / s, (M[0, 2] + M[2, 0]) / s, (M[1, 2] + M[2, 1]) / s, 0.25 * s])
+        if q[0] < 0:
+            q = -q
+        sn = np.linalg.norm(q[1:])
+        if sn < 1e-15:
+            of[i] = 2.0 * q[1:]
+        else:
+            of[i] = q[1:] / sn * (2.0 * np.arctan2(sn, q[0]))
+    return out
+
+
+# ----------------------------------------------------------------- projection
+def project(model, intr, cam_ext, X):
+    """Reference projection (reprojection_error.h:54-110) for arrays of
+    observations: cam_ext (M,6), intr (M,>=7), X (M,4). Returns uv (M,2), ok (M,)."""
+    C = cam_ext[:, :3]
+    R = angle_axis_to_matrix(cam_ext[:, 3:6])
+    p = X[:, :3] - X[:, 3:4] * C
+    q = np.einsum("nij,nj->ni", R, p)
+    f, a, s, cx, cy = intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], intr[:, 4]
+    ok = np.ones(len(X), dtype=bool)
+    if model == CAM_PINHOLE:
+        x = q[:, 0] / q[:, 2]; y = q[:, 1] / q[:, 2]
+        r2 = x * x + y * y
+        d = 1.0 + r2 * (intr[:, 5] + intr[:, 6] * r2)
+        dx, dy = x * d, y * d
+        ok &= q[:, 2] > 0
+    elif model == CAM_DOUBLE_SPHERE:
+        xi, al = intr[:, 5], intr[:, 6]
+        r2 = q[:, 0] ** 2 + q[:, 1] ** 2
+        d1 = np.sqrt(r2 + q[:, 2] ** 2)
+        w1 = np.where(al > 0.5, (1 - al) / al, al / (1 - al))
+        w2 = (w1 + xi) / np.sqrt(2 * w1 * xi + xi * xi + 1)
+        ok &= q[:, 2] > -w2 * d1
+        k = xi * d1 + q[:, 2]
+        d2 = np.sqrt(r2 + k * k)
+        n = al * d2 + (1 - al) * k
+        dx, dy = q[:, 0] / n, q[:, 1] / n
+        ok &= q[:, 2] > 0
+    else:
+        raise ValueError("model")
+    u = f * dx + s * dy + cx
+    v = f * a * dy + cy
+    return np.stack([u, v], axis=1), ok
+
+
+PINHOLE_INTR = np.array([1000.0, 1.0, 0.0, 960.0, 540.0, -0.05, 0.01])
+DOUBLE_SPHERE_INTR = np.array([600.0, 1.0, 0.0, 960.0, 540.0, -0.2, 0.55])
+
+
+def synth_ba_v1(num_views, num_tracks, seed=0xBA5E0000, num_groups=8, mixed_models=False,
+                pixel_noise=0.5, sigma_pos=0.05, sigma_rot_deg=0.5, sigma_pt=0.02,
+                fix_gauge=False, return_truth=False):
+    """SURVEY.md 8(d) "synth_ba_v1": ring of cameras looking at the origin,
+    tracks over contiguous windows of the ring (banded reduced system)."""
+    nv, nt = int(num_views), int(num_tracks)
+    num_groups = min(num_groups, nv)
+    # --- cameras
+    sc = Stream(seed, 1)
+    ci = np.arange(nv)
+    ang = 2.0 * np.pi * ci / nv
+    pos = np.stack([10.0 * np.cos(ang), 10.0 * np.sin(ang), 2.0 * sc.uniform(ci) - 1.0], axis=1)
+    z = -pos / np.linalg.norm(pos, axis=1, keepdims=True)
+    up = np.array([0.0, 0.0, 1.0])
+    x = np.cross(up[None, :], z); x /= np.linalg.norm(x, axis=1, keepdims=True)
+    y = np.cross(z, x)
+    Rlook = np.stack([x, y, z], axis=1)  # rows = camera axes in world
+    jit = np.deg2rad(0.5) * np.stack([sc.normal(3 * ci + 100000), sc.normal(3 * ci + 100001), sc.normal(3 * ci + 100002)], axis=1)
+    R = angle_axis_to_matrix(jit) @ Rlook
+    aa = matrix_to_angle_axis(R)
+    cam_gt = np.concatenate([pos, aa], axis=1)
+    cam_group = (ci % num_groups).astype(np.int32)
+    group_model = np.full(num_groups, CAM_PINHOLE, dtype=np.int32)
+    intr = np.tile(PINHOLE_INTR, (num_groups, 1))
+    if mixed_models:
+        odd = np.arange(num_groups) % 2 == 1
+        group_model[odd] = CAM_DOUBLE_SPHERE
+        intr[odd] = DOUBLE_SPHERE_INTR
+    # --- tracks: length 2 + (hash mod 9), contiguous window start hash2 mod nv
+    st = Stream(seed, 2)
+    ti = np.arange(nt)
+    L = 2 + st.integers(ti, 9)
+    L = np.minimum(L, nv)
+    w0 = st.integers(ti + (1 << 40), nv)
+    obs_pt = np.repeat(ti, L)
+    within = np.arange(len(obs_pt)) - np.repeat(np.cumsum(L) - L, L)
+    obs_cam = ((np.repeat(w0, L) + within) % nv).astype(np.int32)
+    # --- points U[-3,3]^3, re-drawn until every observation is in the image
+    sp = Stream(seed, 3)
+    pts = np.zeros((nt, 4)); pts[:, 3] = 1.0
+    todo = np.ones(nt, dtype=bool)
+    rnd = 0
+    while todo.any() and rnd < 64:
+        idx = np.nonzero(todo)[0]
+        for k in range(3):
+            pts[idx, k] = 6.0 * sp.uniform(idx * 256 + rnd * 4 + k) - 3.0
+        sel = todo[obs_pt]
+        oc, op = obs_cam[sel], obs_pt[sel]
+        bad_pt = np.zeros(nt, dtype=bool)
+        for m in np.unique(group_model):
+            mm = group_model[cam_group[oc]] == m
+            if not mm.any():
+                continue
+            uv, ok = project(m, intr[cam_group[oc[mm]]], cam_gt[oc[mm]], pts[op[mm]])
+            ok &= (uv[:, 0] >= 0) & (uv[:, 0] < 1920) & (uv[:, 1] >= 0) & (uv[:, 1] < 1080)
+            bad_pt[op[mm][~ok]] = True
+        todo = bad_pt
+        rnd += 1
+    if todo.any():
+        raise RuntimeError("synth_ba_v1: could not place all points")
+    # --- observations = exact projection + N(0, pixel_noise)
+    nobs = len(obs_pt)
+    obs_uv = np.zeros((nobs, 2))
+    for m in np.unique(group_model):
+        mm = group_model[cam_group[obs_cam]] == m
+        uv, _ = project(m, intr[cam_group[obs_cam[mm]]], cam_gt[obs_cam[mm]], pts[obs_pt[mm]])
+        obs_uv[mm] = uv
+    sn = Stream(seed, 4)
+    oi = np.arange(nobs)
+    obs_uv[:, 0] += pixel_noise * sn.normal(2 * oi)
+    obs_uv[:, 1] += pixel_noise * sn.normal(2 * oi + 1)
+    # --- initial state = ground truth perturbed
+    spert = Stream(seed, 5)
+    cam0 = cam_gt.copy()
+    for k in range(3):
+        cam0[:, k] += sigma_pos * spert.normal(6 * ci + k)
+        cam0[:, 3 + k] += np.deg2rad(sigma_rot_deg) * spert.normal(6 * ci + 3 + k)
+    pts0 = pts.copy()
+    for k in range(3):
+        pts0[:, k] += sigma_pt * spert.normal((1 << 32) + 3 * ti + k)
+    cam_const = None
+    if fix_gauge:
+        cam_const = np.zeros(nv, dtype=np.uint8)
+        cam_const[0] = 3; cam_const[nv // 2] = 3
+        cam0[0] = cam_gt[0]; cam0[nv // 2] = cam_gt[nv // 2]
+    prob = FlatProblem(cam0, intr, group_model, cam_group, pts0, obs_uv, obs_cam, obs_pt.astype(np.int32),
+                       cam_const=cam_const)
+    if return_truth:
+        return prob, cam_gt, pts
+    return prob
+
+
+BA_CONFIGS = {
+    # name: (views, tracks, seed, mixed pinhole + double-sphere)
+    "C1": (20, 2000, 0xBA5E0001, False),
+    "C2": (200, 50000, 0xBA5E0002, False),
+    "C4": (1000, 500000, 0xBA5E0004, True),
+}
+
+
+def ba_config(name, **kw):
+    nv, nt, seed, mixed = BA_CONFIGS[name]
+    return synth_ba_v1(nv, nt, seed=seed, mixed_models=mixed, **kw)
+
+
+def shard_tracks(problem, rank, world_size):
+    """Multi-GPU partition: tracks (with their observations) are
+    dealt to ranks in contiguous blocks balanced by sum L^2 (Schur work);
+    cameras and intrinsics are replicated.  Returns the rank's FlatProblem and
+    the global indices of its tracks."""
+    npts = problem.points.shape[0]
+    L = np.bincount(problem.obs_pt, minlength=npts).astype(np.float64)
+    w = np.cumsum(L * L)
+    total = w[-1] if npts else 0.0
+    bounds = np.searchsorted(w, total * np.arange(1, world_size) / world_size, side="left")
+    edges = np.concatenate([[0], bounds, [npts]]).astype(np.int64)
+    lo, hi = edges[rank], edges[rank + 1]
+    sel = (problem.obs_pt >= lo) & (problem.obs_pt < hi)
+    pc = None if problem.point_const is None else problem.point_const[lo:hi]
+    si = None if problem.obs_sqrt_info is None else problem.obs_sqrt_info[sel]
+    shard = FlatProblem(problem.cam_ext.copy(), problem.intrinsics.copy(), problem.group_model,
+                        problem.cam_group, problem.points[lo:hi].copy(), problem.obs_uv[sel],
+                        problem.obs_cam[sel], problem.obs_pt[sel] - lo, cam_const=problem.cam_const,
+                        group_const=problem.group_const, point_const=pc, obs_sqrt_info=si, flags=problem.flags | 1)
+    return shard, np.arange(lo, hi)
