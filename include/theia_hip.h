@@ -183,6 +183,10 @@ typedef struct theia_ba_summary {
   double time_linearize;
   double time_solve_reduced;
   double time_backsub;
+  /* the dominant kernel alone (ba_linearize_schur), HIP events on its stream */
+  double time_kernel_linearize;
+  int32_t num_linearize_launches;
+  int32_t reserved1;
 } theia_ba_summary;
 
 /* One-shot solve: replaces BundleAdjuster::Optimize -> ceres::Solve
@@ -199,6 +203,11 @@ int theia_hip_ba_create(const theia_ba_problem* problem,
                         const theia_ba_options* options, theia_ba_handle* out);
 int theia_hip_ba_reset_parameters(theia_ba_handle h,
                                   const theia_ba_problem* problem);
+/* Replace the solver-control options of a handle (iteration cap, tolerances,
+ * loss, radius cap, verbosity).  Options that shape the problem
+ * (parametrisation, constant-camera switches, intrinsics mask) must equal the
+ * ones given to create(), else THEIA_HIP_ERR_INVALID_ARGUMENT. */
+int theia_hip_ba_set_options(theia_ba_handle h, const theia_ba_options* options);
 int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* summary);
 int theia_hip_ba_download(theia_ba_handle h, theia_ba_problem* problem);
 int theia_hip_ba_destroy(theia_ba_handle h);

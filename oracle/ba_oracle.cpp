@@ -390,6 +390,7 @@ struct oba_summary {
   double* trace_cost; double* trace_gradient_max_norm; double* trace_step_norm;
   double* trace_radius; int32_t* trace_accepted;
   double time_linearize, time_solve_reduced, time_backsub;
+  double time_kernel_linearize; int32_t num_linearize_launches, reserved1;
 };
 
 // Single observation: residual + ambient Jacobians (what Ceres' autodiff

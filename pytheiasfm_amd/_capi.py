@@ -66,6 +66,8 @@ class BaSummary(C.Structure):
         ("trace_accepted", c_int32_p),
         ("time_linearize", C.c_double), ("time_solve_reduced", C.c_double),
         ("time_backsub", C.c_double),
+        ("time_kernel_linearize", C.c_double), ("num_linearize_launches", C.c_int32),
+        ("reserved1", C.c_int32),
     ]
 
 
@@ -99,7 +101,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
 EXPORTED_SYMBOLS = [
     "theia_hip_init", "theia_hip_shutdown", "theia_hip_device_count", "theia_hip_last_error",
     "theia_hip_version", "theia_ba_options_default", "theia_hip_ba_solve", "theia_hip_ba_create",
-    "theia_hip_ba_reset_parameters", "theia_hip_ba_run", "theia_hip_ba_download",
+    "theia_hip_ba_reset_parameters", "theia_hip_ba_set_options", "theia_hip_ba_run", "theia_hip_ba_download",
     "theia_hip_ba_destroy", "theia_hip_ba_evaluate", "theia_hip_ba_reduced_system",
     "theia_hip_ba_set_allreduce", "theia_ransac_params_default",
     "theia_hip_ransac_estimate_batch", "theia_hip_five_point_relative_pose",
@@ -125,6 +127,7 @@ def lib():
     L.theia_hip_ba_run.argtypes = [C.c_void_p, C.POINTER(BaSummary)]
     L.theia_hip_ba_download.argtypes = [C.c_void_p, C.POINTER(BaProblem)]
     L.theia_hip_ba_reset_parameters.argtypes = [C.c_void_p, C.POINTER(BaProblem)]
+    L.theia_hip_ba_set_options.argtypes = [C.c_void_p, C.POINTER(BaOptions)]
     L.theia_hip_ba_destroy.argtypes = [C.c_void_p]
     L.theia_hip_ba_solve.argtypes = [C.POINTER(BaProblem), C.POINTER(BaOptions), C.POINTER(BaSummary)]
     L.theia_hip_ba_evaluate.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_uint8_p]

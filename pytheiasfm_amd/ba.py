@@ -55,6 +55,10 @@ class BaHandle:
         st = (problem or self.problem).as_struct()
         capi.check(capi.lib().theia_hip_ba_reset_parameters(self._h, C.byref(st)))
 
+    def set_options(self, options):
+        capi.check(capi.lib().theia_hip_ba_set_options(self._h, C.byref(options)))
+        self.options = options
+
     def download(self, problem=None):
         p = problem or self.problem
         st = p.as_struct()

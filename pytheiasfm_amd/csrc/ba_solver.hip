@@ -82,7 +82,7 @@ struct theia_ba_handle_s {
   int64_t nobs = 0, nobs_main = 0;
   int ntiles_main = 0, ntiles_all = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // host-side bookkeeping
   std::vector<int64_t> perm;       // sorted obs index -> original obs index
   std::vector<int> cam_red;
@@ -215,7 +215,9 @@ int compute_scale(theia_ba_handle_s* h) {
 // enqueue: clear, linearize + Schur, tile reduction, (all-reduce), LM diagonal.
 int enqueue_linearize(theia_ba_handle_s* h, double radius) {
   HIP_TRY(hipMemsetAsync(h->reduce.p, 0, sizeof(double) * h->reduce.n, h->stream));
+  HIP_TRY(hipEventRecord(h->ev[4], h->stream));
   launch_linearize(h->P, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->tile_part.p, h->stream);
+  HIP_TRY(hipEventRecord(h->ev[5], h->stream));
   if (h->ntiles_main) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 4, h->f2s.p, h->fmaxflag.p, h->rb.scal, h->stream);
   // one SUM all-reduce of [S | rhs | colsq | gc | scal[0,8)], one MAX of scal[8,16)
   int rc = do_allreduce(h, h->reduce.p, (size_t)h->n * h->n + 3 * (size_t)h->n + 8, THEIA_REDUCE_SUM);
@@ -396,6 +398,22 @@ int theia_hip_ba_reset_parameters(theia_ba_handle h, const theia_ba_problem* p) 
   return upload_parameters(h, p);
 }
 
+int theia_hip_ba_set_options(theia_ba_handle h, const theia_ba_options* o) {
+  if (!h || !o) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const theia_ba_options& c = h->opt;
+  if (o->use_homogeneous_point_parametrization != c.use_homogeneous_point_parametrization ||
+      o->constant_camera_orientation != c.constant_camera_orientation ||
+      o->constant_camera_position != c.constant_camera_position || o->orthographic_camera != c.orthographic_camera ||
+      o->intrinsics_to_optimize != c.intrinsics_to_optimize)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "structural options differ from the ones the handle was created with");
+  if (o->loss_function_type < 0 || o->loss_function_type > THEIA_LOSS_TRUNCATED)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "invalid loss function type");
+  h->opt = *o;
+  h->P.loss_type = o->loss_function_type;
+  h->P.loss_width = o->robust_loss_width;
+  return 0;
+}
+
 int theia_hip_ba_set_allreduce(theia_ba_handle h, theia_allreduce_fn fn, void* ctx) {
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
   h->allreduce = fn; h->allreduce_ctx = ctx;
@@ -421,6 +439,7 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   const double t_start = now_s();
   S->trace_size = 0; S->success = 0; S->num_iterations = 0; S->num_successful_steps = 0;
   S->time_linearize = S->time_solve_reduced = S->time_backsub = 0.0;
+  S->time_kernel_linearize = 0.0; S->num_linearize_launches = 0;
   S->setup_time_in_seconds = 0.0;
   int rc = compute_scale(h);
   if (rc) return rc;
@@ -452,6 +471,9 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   }
   int pending_grad = -1;  // trace entry of the last accepted step (gradient known one read-back later)
   while (true) {
+    // the two host-only stop rules are checked before any work is enqueued
+    if (!first && now_s() - t_start >= O.max_solver_time_in_seconds) { term = THEIA_TERM_NO_CONVERGENCE; break; }
+    if (!first && iter >= O.max_num_iterations) { term = THEIA_TERM_NO_CONVERGENCE; break; }
     // one LM iteration is enqueued speculatively; the host reads back scalars once
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     rc = enqueue_linearize(h, radius); if (rc) return rc;
@@ -466,6 +488,8 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
       if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) S->time_linearize += ms * 1e-3;
       if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) S->time_solve_reduced += ms * 1e-3;
       if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) S->time_backsub += ms * 1e-3;
+      if (hipEventElapsedTime(&ms, h->ev[4], h->ev[5]) == hipSuccess) S->time_kernel_linearize += ms * 1e-3;
+      S->num_linearize_launches++;
     }
     const double* sa = h->h_scal;
     const double* sb = h->h_scal + 16;

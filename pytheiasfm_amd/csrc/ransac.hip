@@ -1,0 +1,555 @@
+// ransac.hip -- many-hypothesis RANSAC on gfx950: K5 (minimal-solver fit) and
+// K6 (score every correspondence under every model) plus the host driver that
+// replaces SampleConsensusEstimator<E>::Estimate
+//   (src/theia/solvers/sample_consensus_estimator.h:300-415)
+// for Ransac<E> + RandomSampler (ransac.h:57-61, random_sampler.cc:53-72).
+//
+// Split of work (DESIGN.md "RANSAC"):
+//  host   : the std::mt19937 sample stream (bit-exact restatement, util/random.cc)
+//           for a ROUND of iterations up front; sequential replay of the
+//           accept / adaptive-termination rules in sample order.
+//  device : k_fit   -- one thread per hypothesis: minimal solver -> <= 10 models
+//           k_score -- one thread per (hypothesis, model): walks all N
+//                      correspondences (staged in LDS, broadcast reads) in data
+//                      order, so the MLE sum keeps the reference's
+//                      left-to-right FP64 order.
+//  Hypotheses of a round are independent given the pre-generated samples, so a
+//  batch of problems x iterations fills the chip; results are identical to the
+//  sequential loop because acceptance is replayed in order.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "ransac_device.h"
+#include "theia_hip.h"
+#include "theia_hip_internal.h"
+
+namespace thip {
+namespace {
+
+constexpr int kMaxModels = 10;
+constexpr int kStride = THEIA_RANSAC_MODEL_STRIDE;
+
+__host__ __device__ inline int sample_size(int est) {
+  return (est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_ESSENTIAL_MATRIX) ? 5 : 3;
+}
+__host__ __device__ inline int datum_size(int est) {
+  return (est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_ESSENTIAL_MATRIX) ? 4 : 5;
+}
+
+// EstimateModel of the three estimators (estimate_relative_pose.cc:75-109,
+// estimate_essential_matrix.cc:62-73, estimate_calibrated_absolute_pose.cc:76-118).
+__device__ int estimate_models(int est, const double* subset, double* models) {
+  if (est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_ESSENTIAL_MATRIX) {
+    double E[90];
+    const int ne = rsc::five_point(subset, E);
+    if (ne == 0) return 0;
+    int nm = 0;
+    for (int i = 0; i < ne; ++i) {
+      double* m = models + kStride * nm;
+      for (int k = 0; k < 9; ++k) m[k] = E[9 * i + k];
+      if (est == THEIA_EST_ESSENTIAL_MATRIX) { for (int k = 9; k < kStride; ++k) m[k] = 0.0; nm++; continue; }
+      const int nfront = rsc::best_pose_from_E(E + 9 * i, subset, 5, m + 9, m + 18);
+      if (nfront >= 4) nm++;
+    }
+    return nm;
+  }
+  if (est == THEIA_EST_ABSOLUTE_POSE_KNEIP) {
+    double Rs[36], ts[12];
+    const int n = rsc::p3p(subset, Rs, ts);
+    for (int i = 0; i < n; ++i) {
+      double* m = models + kStride * i;
+      const double* R = Rs + 9 * i;
+      const double* t = ts + 3 * i;
+      for (int k = 0; k < 9; ++k) m[k] = R[k];
+      for (int c = 0; c < 3; ++c) m[9 + c] = -((R[c] * t[0] + R[3 + c] * t[1]) + R[6 + c] * t[2]);
+      for (int k = 12; k < kStride; ++k) m[k] = 0.0;
+    }
+    return n;
+  }
+  return 0;
+}
+
+// Estimator::Error (estimate_relative_pose.cc:142-151, estimate_essential_matrix.cc:77-83,
+// estimate_calibrated_absolute_pose.cc:158-167)
+__device__ inline double model_error(int est, const double* m, const double* d) {
+  if (est == THEIA_EST_RELATIVE_POSE) {
+    if (rsc::in_front(d, m + 9, m + 18)) return rsc::sampson(m, d);
+    return DBL_MAX;
+  }
+  if (est == THEIA_EST_ESSENTIAL_MATRIX) return rsc::sampson(m, d);
+  const double dx = d[2] - m[9], dy = d[3] - m[10], dz = d[4] - m[11];
+  const double px = (m[0] * dx + m[1] * dy) + m[2] * dz;
+  const double py = (m[3] * dx + m[4] * dy) + m[5] * dz;
+  const double pz = (m[6] * dx + m[7] * dy) + m[8] * dz;
+  const double ex = px / pz - d[0], ey = py / pz - d[1];
+  return ex * ex + ey * ey;
+}
+
+// K5: one thread per (problem, iteration of the round).
+//   samples : [nprob][B][m] indices into the problem's data
+//   models  : [nprob][B][kMaxModels][kStride]
+//   counts  : [nprob][B]
+__global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int64_t* __restrict__ offsets,
+                                            const double* __restrict__ data, const int* __restrict__ samples,
+                                            const int* __restrict__ active_iters, double* __restrict__ models,
+                                            int* __restrict__ counts) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.y;
+  if (b >= B || p >= nprob) return;
+  const size_t hyp = (size_t)p * B + b;
+  if (b >= active_iters[p]) { counts[hyp] = 0; return; }
+  const int m = sample_size(est), ds = datum_size(est);
+  const double* pd = data + (size_t)offsets[p] * ds;
+  double subset[25];
+  for (int i = 0; i < m; ++i) {
+    const int idx = samples[hyp * m + i];
+    for (int k = 0; k < ds; ++k) subset[i * ds + k] = pd[(size_t)idx * ds + k];
+  }
+  double mloc[kMaxModels * kStride];
+  const int nm = estimate_models(est, subset, mloc);
+  counts[hyp] = nm;
+  double* mo = models + hyp * (size_t)(kMaxModels * kStride);
+  for (int j = 0; j < nm; ++j)
+    for (int k = 0; k < kStride; ++k) mo[j * kStride + k] = mloc[j * kStride + k];
+}
+
+// K6: one thread per (problem, iteration, model slot); block = 256 slots of ONE
+// problem, whose correspondences are staged in LDS when they fit.
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void k_score(int est, int nprob, int B, const int64_t* __restrict__ offsets,
+                                               const double* __restrict__ data, const double* __restrict__ models,
+                                               const int* __restrict__ counts, double thresh, int use_mle,
+                                               double* __restrict__ cost, int* __restrict__ ninl) {
+  extern __shared__ __attribute__((aligned(16))) double sdata[];
+  const int p = blockIdx.y;
+  const int ds = datum_size(est);
+  const int64_t n64 = offsets[p + 1] - offsets[p];
+  const int n = (int)n64;
+  const double* pd = data + (size_t)offsets[p] * ds;
+  if (USE_LDS) {
+    for (int i = threadIdx.x; i < n * ds; i += blockDim.x) sdata[i] = pd[i];
+    __syncthreads();
+    pd = sdata;
+  }
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= B * kMaxModels) return;
+  const int b = slot / kMaxModels, j = slot % kMaxModels;
+  const size_t hyp = (size_t)p * B + b;
+  if (j >= counts[hyp]) return;
+  double m[kStride];
+  const double* mo = models + (hyp * kMaxModels + j) * (size_t)kStride;
+#pragma unroll
+  for (int k = 0; k < kStride; ++k) m[k] = mo[k];
+  int cnt = 0;
+  double mle = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double r = model_error(est, m, pd + (size_t)i * ds);
+    if (r < thresh) { cnt++; mle += r; }
+    else mle += thresh;
+  }
+  cost[hyp * kMaxModels + j] = use_mle ? mle : (double)(n - cnt);
+  ninl[hyp * kMaxModels + j] = cnt;
+}
+
+// final pass: refit the winning hypothesis (deterministic -> identical model)
+// and mark the inliers of every datum (sample_consensus_estimator.h:396-399).
+__global__ void k_refit(int est, int nprob, const int64_t* __restrict__ offsets, const double* __restrict__ data,
+                        const int* __restrict__ best_samples, const int* __restrict__ best_slot,
+                        double* __restrict__ out_models) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nprob) return;
+  double* mo = out_models + (size_t)p * kStride;
+  for (int k = 0; k < kStride; ++k) mo[k] = 0.0;
+  if (best_slot[p] < 0) return;
+  const int m = sample_size(est), ds = datum_size(est);
+  const double* pd = data + (size_t)offsets[p] * ds;
+  double subset[25];
+  for (int i = 0; i < m; ++i) {
+    const int idx = best_samples[p * 5 + i];
+    for (int k = 0; k < ds; ++k) subset[i * ds + k] = pd[(size_t)idx * ds + k];
+  }
+  double mloc[kMaxModels * kStride];
+  const int nm = estimate_models(est, subset, mloc);
+  const int j = best_slot[p];
+  if (j < nm) for (int k = 0; k < kStride; ++k) mo[k] = mloc[j * kStride + k];
+}
+
+__global__ void k_inlier_mask(int est, int nprob, const int64_t* __restrict__ offsets, const double* __restrict__ data,
+                              const double* __restrict__ best_models, double thresh, uint8_t* __restrict__ mask) {
+  const int p = blockIdx.y;
+  const int ds = datum_size(est);
+  const int n = (int)(offsets[p + 1] - offsets[p]);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double m[kStride];
+  for (int k = 0; k < kStride; ++k) m[k] = best_models[(size_t)p * kStride + k];
+  const double r = model_error(est, m, data + ((size_t)offsets[p] + i) * ds);
+  mask[offsets[p] + i] = (r < thresh) ? 1 : 0;
+}
+
+// batched minimal solvers (directly bound entry points)
+__global__ void k_five_point(int num, const double* __restrict__ corr, double* __restrict__ E, int* __restrict__ nsol) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= num) return;
+  double c[20], e[90];
+  for (int k = 0; k < 20; ++k) c[k] = corr[(size_t)i * 20 + k];
+  const int n = rsc::five_point(c, e);
+  nsol[i] = n;
+  for (int k = 0; k < 90; ++k) E[(size_t)i * 90 + k] = (k < 9 * n) ? e[k] : 0.0;
+}
+
+__global__ void k_p3p(int num, const double* __restrict__ corr, double* __restrict__ R, double* __restrict__ t, int* __restrict__ nsol) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= num) return;
+  double c[15], r[36], tt[12];
+  for (int k = 0; k < 15; ++k) c[k] = corr[(size_t)i * 15 + k];
+  const int n = rsc::p3p(c, r, tt);
+  nsol[i] = n;
+  for (int k = 0; k < 36; ++k) R[(size_t)i * 36 + k] = (k < 9 * n) ? r[k] : 0.0;
+  for (int k = 0; k < 12; ++k) t[(size_t)i * 12 + k] = (k < 3 * n) ? tt[k] : 0.0;
+}
+
+// ------------------------------------------------------------------ host side
+// std::mt19937 + libstdc++ uniform_int_distribution<int> (Lemire), i.e. the
+// stream RandomNumberGenerator::RandInt draws (util/random.cc:46-84).
+struct Mt19937 {
+  uint32_t mt[624];
+  int idx;
+  void seed(uint32_t s) {
+    mt[0] = s;
+    for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    idx = 624;
+  }
+  uint32_t next() {
+    if (idx >= 624) {
+      for (int i = 0; i < 624; ++i) {
+        const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+        mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      idx = 0;
+    }
+    uint32_t y = mt[idx++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+  }
+  int rand_int(int lo, int hi) {
+    const uint32_t urange = (uint32_t)hi - (uint32_t)lo;
+    uint32_t ret;
+    if (urange == 0xffffffffu) ret = next();
+    else {
+      const uint32_t range = urange + 1u;
+      uint64_t product = (uint64_t)next() * (uint64_t)range;
+      uint32_t low = (uint32_t)product;
+      if (low < range) {
+        const uint32_t threshold = (uint32_t)(-range) % range;
+        while (low < threshold) { product = (uint64_t)next() * (uint64_t)range; low = (uint32_t)product; }
+      }
+      ret = (uint32_t)(product >> 32);
+    }
+    return (int)(ret + (uint32_t)lo);
+  }
+};
+
+// sample_consensus_estimator.h:252-297
+int compute_max_iterations(const theia_ransac_params& P, double min_sample_size, double inlier_ratio,
+                           double log_failure_prob, int total) {
+  if (inlier_ratio == 1.0) return P.min_iterations;
+  const int ninl = (int)(inlier_ratio * total);
+  const double num_samples = P.use_Tdd_test ? min_sample_size + 1 : min_sample_size;
+  double a = 1.0, b = 1.0;
+  for (int i = 0; i < num_samples; ++i) { a *= ninl - i; b *= total - i; }
+  const double prob_all_inliers = a / b;
+  if (prob_all_inliers < std::numeric_limits<double>::epsilon()) return P.max_iterations;
+  if (prob_all_inliers >= 1.0 - std::numeric_limits<double>::epsilon()) return P.min_iterations;
+  const double num_iterations = log_failure_prob / std::log(1.0 - prob_all_inliers);
+  return (int)std::max((double)P.min_iterations, std::min(num_iterations, (double)P.max_iterations));
+}
+
+struct ProblemState {
+  Mt19937 rng;
+  std::vector<int> idx;
+  double best_cost;
+  int max_iterations, it, n;
+  bool done;
+  int best_slot;
+  int best_samples[5];
+  int round_iters;
+};
+
+#define HIP_TRYR(expr)                                                                               \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess)                                                                            \
+      return set_error(e_ == hipErrorOutOfMemory ? THEIA_HIP_ERR_OUT_OF_MEMORY : THEIA_HIP_ERR_NO_DEVICE, \
+                       "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);   \
+  } while (0)
+
+template <typename T>
+struct DBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  ~DBuf() { if (p) (void)hipFree(p); }
+  int ensure(size_t count) {
+    if (count <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e != hipSuccess) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    cap = count;
+    return 0;
+  }
+};
+
+}  // namespace
+}  // namespace thip
+
+using namespace thip;
+
+extern "C" {
+
+void theia_ransac_params_default(theia_ransac_params* p) {
+  // sample_consensus_estimator.h:59-68
+  std::memset(p, 0, sizeof(*p));
+  p->error_thresh = -1;
+  p->failure_probability = 0.01;
+  p->min_inlier_ratio = 0;
+  p->min_iterations = 100;
+  p->max_iterations = std::numeric_limits<int>::max();
+  p->use_mle = 0; p->use_Tdd_test = 0; p->use_lo = 0; p->lo_start_iterations = 50;
+  p->seed = 0;
+}
+
+int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia_ransac_params* params,
+                                    theia_ransac_result* result) {
+  if (!batch || !params || !result) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const theia_ransac_params& P = *params;
+  // SampleConsensusEstimator ctor CHECKs (sample_consensus_estimator.h:217-223)
+  if (!(P.error_thresh > 0)) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "Error threshold must be set to greater than zero");
+  if (!(P.min_inlier_ratio <= 1.0) || !(P.min_inlier_ratio >= 0.0)) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "min_inlier_ratio must be in [0, 1]");
+  if (!(P.failure_probability < 1.0) || !(P.failure_probability > 0.0)) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "failure_probability must be in (0, 1)");
+  if (P.max_iterations < P.min_iterations) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "max_iterations < min_iterations");
+  const int est = batch->estimator;
+  if (est == THEIA_EST_ABSOLUTE_POSE_DLS || est == THEIA_EST_ABSOLUTE_POSE_SQPNP)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "DLS / SQPnP minimal solvers have no HIP kernel yet");
+  if (est < 0 || est > THEIA_EST_ABSOLUTE_POSE_SQPNP) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
+  if (P.use_lo) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: LO-RANSAC refinement is not built yet (DESIGN.md scope)");
+  const int nprob = batch->num_problems;
+  if (nprob < 0 || (nprob > 0 && (!batch->offsets || !batch->data))) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad batch");
+  if (nprob > 0 && (!result->success || !result->models || !result->num_inliers || !result->inlier_mask ||
+                    !result->num_iterations || !result->confidence))
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null result array");
+  result->hypotheses_evaluated = 0; result->models_scored = 0; result->time_fit_score_seconds = 0.0;
+  if (nprob == 0) return 0;
+  int rc = ensure_device();
+  if (rc) return rc;
+  const int m = sample_size(est), ds = datum_size(est);
+  const int64_t total = batch->offsets[nprob];
+  int nmax = 0;
+  for (int p = 0; p < nprob; ++p) {
+    const int64_t n = batch->offsets[p + 1] - batch->offsets[p];
+    if (n <= 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "Cannot perform estimation with 0 data measurements!");
+    if (n < m) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "problem %d has fewer data than the sample size", p);
+    if (n > (1 << 30)) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "problem too large");
+    nmax = std::max(nmax, (int)n);
+  }
+  hipStream_t st;
+  HIP_TRYR(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sguard{st};
+  hipEvent_t ev0, ev1;
+  HIP_TRYR(hipEventCreate(&ev0)); HIP_TRYR(hipEventCreate(&ev1));
+  struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } eguard{ev0, ev1};
+
+  DBuf<double> d_data; DBuf<int64_t> d_off;
+  if ((rc = d_data.ensure((size_t)total * ds)) || (rc = d_off.ensure(nprob + 1))) return rc;
+  HIP_TRYR(hipMemcpyAsync(d_data.p, batch->data, sizeof(double) * total * ds, hipMemcpyHostToDevice, st));
+  HIP_TRYR(hipMemcpyAsync(d_off.p, batch->offsets, sizeof(int64_t) * (nprob + 1), hipMemcpyHostToDevice, st));
+
+  const double log_failure_prob = std::log(P.failure_probability);
+  // round size: everything at once when the iteration count is fixed/small,
+  // otherwise chunks that the adaptive bound usually ends within
+  int first_round = std::max(128, std::min(P.max_iterations, std::max(P.min_iterations, 512)));
+  first_round = std::min(first_round, 4096);
+  const int next_round = 1024;
+  // problems per chunk: bound the model workspace to ~1.5 GiB
+  const size_t per_hyp = (size_t)kMaxModels * kStride * sizeof(double);
+  int chunk = (int)std::max<size_t>(1, ((size_t)3 << 29) / (per_hyp * (size_t)first_round));
+  chunk = std::min(chunk, nprob);
+
+  DBuf<int> d_samples, d_counts, d_ninl, d_active, d_best_samples, d_best_slot;
+  DBuf<double> d_models, d_cost, d_best_models;
+  DBuf<uint8_t> d_mask;
+  std::vector<int> h_samples, h_counts, h_ninl, h_active;
+  std::vector<double> h_cost;
+  const bool use_lds = (size_t)nmax * ds * sizeof(double) <= 96 * 1024;
+  const size_t lds_bytes = use_lds ? (size_t)nmax * ds * sizeof(double) : 0;
+  if (use_lds && lds_bytes > 48 * 1024) {
+    HIP_TRYR(hipFuncSetAttribute((const void*)k_score<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  }
+
+  std::vector<int> best_samples_all((size_t)nprob * 5, 0), best_slot_all(nprob, -1);
+  std::vector<ProblemState> S(nprob);
+  for (int p = 0; p < nprob; ++p) {
+    ProblemState& s = S[p];
+    s.n = (int)(batch->offsets[p + 1] - batch->offsets[p]);
+    s.rng.seed(P.seed + (uint32_t)p);
+    s.idx.resize(s.n);
+    for (int i = 0; i < s.n; ++i) s.idx[i] = i;
+    s.best_cost = std::numeric_limits<double>::max();
+    s.max_iterations = P.max_iterations;
+    if (P.min_inlier_ratio > 0)
+      s.max_iterations = std::min(compute_max_iterations(P, m, P.min_inlier_ratio, log_failure_prob, s.n), P.max_iterations);
+    s.it = 0; s.done = s.max_iterations <= 0; s.best_slot = -1;
+    for (int k = 0; k < 5; ++k) s.best_samples[k] = 0;
+  }
+  double fit_score_ms = 0.0;
+  for (int c0 = 0; c0 < nprob; c0 += chunk) {
+    const int cn = std::min(chunk, nprob - c0);
+    bool first = true;
+    while (true) {
+      // iterations of this round per problem
+      int B = 0;
+      h_active.assign(cn, 0);
+      for (int q = 0; q < cn; ++q) {
+        ProblemState& s = S[c0 + q];
+        s.round_iters = 0;
+        if (s.done) continue;
+        const int cap = first ? first_round : next_round;
+        s.round_iters = std::min(cap, s.max_iterations - s.it);
+        h_active[q] = s.round_iters;
+        B = std::max(B, s.round_iters);
+      }
+      if (B == 0) break;
+      first = false;
+      // the sample stream of the round (RandomSampler::Sample, persistent permutation)
+      h_samples.assign((size_t)cn * B * m, 0);
+      for (int q = 0; q < cn; ++q) {
+        ProblemState& s = S[c0 + q];
+        int* out = h_samples.data() + (size_t)q * B * m;
+        for (int b = 0; b < s.round_iters; ++b)
+          for (int i = 0; i < m; ++i) {
+            std::swap(s.idx[i], s.idx[s.rng.rand_int(i, s.n - 1)]);
+            out[(size_t)b * m + i] = s.idx[i];
+          }
+      }
+      const size_t nh = (size_t)cn * B;
+      if ((rc = d_samples.ensure(nh * m)) || (rc = d_counts.ensure(nh)) || (rc = d_models.ensure(nh * kMaxModels * kStride)) ||
+          (rc = d_cost.ensure(nh * kMaxModels)) || (rc = d_ninl.ensure(nh * kMaxModels)) || (rc = d_active.ensure(cn)))
+        return rc;
+      HIP_TRYR(hipMemcpyAsync(d_samples.p, h_samples.data(), sizeof(int) * nh * m, hipMemcpyHostToDevice, st));
+      HIP_TRYR(hipMemcpyAsync(d_active.p, h_active.data(), sizeof(int) * cn, hipMemcpyHostToDevice, st));
+      HIP_TRYR(hipEventRecord(ev0, st));
+      {
+        dim3 grid((B + 63) / 64, cn);
+        k_fit<<<grid, 64, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_models.p, d_counts.p);
+      }
+      {
+        dim3 grid((B * kMaxModels + 255) / 256, cn);
+        if (use_lds)
+          k_score<true><<<grid, 256, lds_bytes, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_models.p, d_counts.p, P.error_thresh, P.use_mle, d_cost.p, d_ninl.p);
+        else
+          k_score<false><<<grid, 256, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_models.p, d_counts.p, P.error_thresh, P.use_mle, d_cost.p, d_ninl.p);
+      }
+      HIP_TRYR(hipEventRecord(ev1, st));
+      h_counts.resize(nh); h_cost.resize(nh * kMaxModels); h_ninl.resize(nh * kMaxModels);
+      HIP_TRYR(hipMemcpyAsync(h_counts.data(), d_counts.p, sizeof(int) * nh, hipMemcpyDeviceToHost, st));
+      HIP_TRYR(hipMemcpyAsync(h_cost.data(), d_cost.p, sizeof(double) * nh * kMaxModels, hipMemcpyDeviceToHost, st));
+      HIP_TRYR(hipMemcpyAsync(h_ninl.data(), d_ninl.p, sizeof(int) * nh * kMaxModels, hipMemcpyDeviceToHost, st));
+      HIP_TRYR(hipStreamSynchronize(st));
+      { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) fit_score_ms += ms; }
+      // sequential replay of the acceptance rules (sample_consensus_estimator.h:330-394)
+      for (int q = 0; q < cn; ++q) {
+        ProblemState& s = S[c0 + q];
+        if (s.done) continue;
+        const int base_it = s.it;
+        int b = 0;
+        for (; b < s.round_iters && base_it + b < s.max_iterations; ++b) {
+          const size_t hyp = (size_t)q * B + b;
+          const int nm = h_counts[hyp];
+          result->hypotheses_evaluated++;
+          for (int j = 0; j < nm; ++j) {
+            const double cost = h_cost[hyp * kMaxModels + j];
+            const int ninl = h_ninl[hyp * kMaxModels + j];
+            result->models_scored++;
+            const double inlier_ratio = (double)ninl / (double)s.n;
+            if (cost < s.best_cost) {
+              s.best_cost = cost;
+              s.best_slot = j;
+              for (int i = 0; i < m; ++i) s.best_samples[i] = h_samples[hyp * m + i];
+              if (inlier_ratio < m / (double)s.n) continue;
+              s.max_iterations = std::min(compute_max_iterations(P, m, inlier_ratio, log_failure_prob, s.n), s.max_iterations);
+            }
+          }
+        }
+        s.it = base_it + b;
+        if (s.it >= s.max_iterations) s.done = true;
+      }
+    }
+  }
+  // final models + inlier masks
+  for (int p = 0; p < nprob; ++p) {
+    best_slot_all[p] = S[p].best_slot;
+    for (int k = 0; k < 5; ++k) best_samples_all[(size_t)p * 5 + k] = S[p].best_samples[k];
+  }
+  if ((rc = d_best_samples.ensure((size_t)nprob * 5)) || (rc = d_best_slot.ensure(nprob)) ||
+      (rc = d_best_models.ensure((size_t)nprob * kStride)) || (rc = d_mask.ensure((size_t)total)))
+    return rc;
+  HIP_TRYR(hipMemcpyAsync(d_best_samples.p, best_samples_all.data(), sizeof(int) * nprob * 5, hipMemcpyHostToDevice, st));
+  HIP_TRYR(hipMemcpyAsync(d_best_slot.p, best_slot_all.data(), sizeof(int) * nprob, hipMemcpyHostToDevice, st));
+  k_refit<<<(nprob + 63) / 64, 64, 0, st>>>(est, nprob, d_off.p, d_data.p, d_best_samples.p, d_best_slot.p, d_best_models.p);
+  {
+    dim3 grid((nmax + 255) / 256, nprob);
+    k_inlier_mask<<<grid, 256, 0, st>>>(est, nprob, d_off.p, d_data.p, d_best_models.p, P.error_thresh, d_mask.p);
+  }
+  HIP_TRYR(hipMemcpyAsync(result->models, d_best_models.p, sizeof(double) * nprob * kStride, hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipMemcpyAsync(result->inlier_mask, d_mask.p, (size_t)total, hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipStreamSynchronize(st));
+  for (int p = 0; p < nprob; ++p) {
+    const ProblemState& s = S[p];
+    int cnt = 0;
+    for (int64_t i = batch->offsets[p]; i < batch->offsets[p + 1]; ++i) cnt += result->inlier_mask[i];
+    result->num_inliers[p] = cnt;
+    result->num_iterations[p] = s.it;
+    result->success[p] = 1;
+    const double inlier_ratio = (double)cnt / s.n;
+    result->confidence[p] = 1.0 - std::pow(1.0 - std::pow(inlier_ratio, (double)m), (double)s.it);
+  }
+  result->time_fit_score_seconds = fit_score_ms * 1e-3;
+  return 0;
+}
+
+int theia_hip_five_point_relative_pose(int32_t num, const double* corr, double* essential_matrices, int32_t* num_solutions) {
+  if (num < 0 || (num > 0 && (!corr || !essential_matrices || !num_solutions))) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+  if (num == 0) return 0;
+  int rc = ensure_device();
+  if (rc) return rc;
+  DBuf<double> dc, de; DBuf<int> dn;
+  if ((rc = dc.ensure((size_t)num * 20)) || (rc = de.ensure((size_t)num * 90)) || (rc = dn.ensure(num))) return rc;
+  HIP_TRYR(hipMemcpy(dc.p, corr, sizeof(double) * num * 20, hipMemcpyHostToDevice));
+  k_five_point<<<(num + 63) / 64, 64>>>(num, dc.p, de.p, dn.p);
+  HIP_TRYR(hipMemcpy(essential_matrices, de.p, sizeof(double) * num * 90, hipMemcpyDeviceToHost));
+  HIP_TRYR(hipMemcpy(num_solutions, dn.p, sizeof(int) * num, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int theia_hip_pose_from_three_points(int32_t num, const double* corr2d3d, double* rotations, double* translations, int32_t* num_solutions) {
+  if (num < 0 || (num > 0 && (!corr2d3d || !rotations || !translations || !num_solutions))) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+  if (num == 0) return 0;
+  int rc = ensure_device();
+  if (rc) return rc;
+  DBuf<double> dc, dr, dt; DBuf<int> dn;
+  if ((rc = dc.ensure((size_t)num * 15)) || (rc = dr.ensure((size_t)num * 36)) || (rc = dt.ensure((size_t)num * 12)) || (rc = dn.ensure(num))) return rc;
+  HIP_TRYR(hipMemcpy(dc.p, corr2d3d, sizeof(double) * num * 15, hipMemcpyHostToDevice));
+  k_p3p<<<(num + 63) / 64, 64>>>(num, dc.p, dr.p, dt.p, dn.p);
+  HIP_TRYR(hipMemcpy(rotations, dr.p, sizeof(double) * num * 36, hipMemcpyDeviceToHost));
+  HIP_TRYR(hipMemcpy(translations, dt.p, sizeof(double) * num * 12, hipMemcpyDeviceToHost));
+  HIP_TRYR(hipMemcpy(num_solutions, dn.p, sizeof(int) * num, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,737 @@
+// ransac_device.h -- device numerics of the RANSAC minimal solvers (gfx950, FP64).
+//
+// One thread runs one minimal problem.  The linear algebra restates the
+// published algorithms behind the Eigen calls of the reference:
+//   Eigen::FullPivLU   (five_point_relative_pose.cc:242-247,261-263)
+//   Eigen::EigenSolver (five_point_relative_pose.cc:275; companion-matrix
+//                       roots, math/find_polynomial_roots_companion_matrix.cc)
+//                      = EISPACK orthes + hqr2
+//   Eigen::JacobiSVD   (essential_matrix_utils.cc:66-67) = two-sided Jacobi
+// Built with -ffp-contract=off: the operation order below is kept identical to
+// the CPU oracle's transcription of the same algorithms, which is what makes
+// RANSAC inlier sets bit-identical between the two (DESIGN.md "RANSAC parity").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+
+namespace thip {
+namespace rsc {
+
+#define RDEV __device__ inline
+
+template <typename T>
+RDEV void dswap(T& a, T& b) { T t = a; a = b; b = t; }
+
+// ------------------------------------------------------- small linear algebra
+// Full-pivot LU of a rows x cols row-major matrix (Eigen::FullPivLU::compute).
+// The pivot search scans the remaining corner column by column and keeps the
+// first strict maximum.
+struct FullPivLU {
+  int rows, cols, size, nonzero_pivots;
+  double maxpivot;
+  int rowt[10], colt[20];
+};
+
+RDEV void fullpiv_lu(double* A, int rows, int cols, FullPivLU& f) {
+  f.rows = rows; f.cols = cols; f.size = rows < cols ? rows : cols;
+  f.nonzero_pivots = f.size; f.maxpivot = 0.0;
+  for (int k = 0; k < f.size; ++k) {
+    double best = -1.0; int br = k, bc = k;
+    for (int j = k; j < cols; ++j)
+      for (int i = k; i < rows; ++i) {
+        const double a = fabs(A[i * cols + j]);
+        if (a > best) { best = a; br = i; bc = j; }
+      }
+    if (best == 0.0) {
+      f.nonzero_pivots = k;
+      for (int i = k; i < f.size; ++i) { f.rowt[i] = i; f.colt[i] = i; }
+      break;
+    }
+    if (best > f.maxpivot) f.maxpivot = best;
+    f.rowt[k] = br; f.colt[k] = bc;
+    if (br != k) for (int j = 0; j < cols; ++j) dswap(A[k * cols + j], A[br * cols + j]);
+    if (bc != k) for (int i = 0; i < rows; ++i) dswap(A[i * cols + k], A[i * cols + bc]);
+    if (k < rows - 1) for (int i = k + 1; i < rows; ++i) A[i * cols + k] /= A[k * cols + k];
+    if (k < f.size - 1)
+      for (int i = k + 1; i < rows; ++i)
+        for (int j = k + 1; j < cols; ++j) A[i * cols + j] -= A[i * cols + k] * A[k * cols + j];
+  }
+}
+
+// Real general eigen-decomposition (EISPACK orthes + hqr2, as in JAMA) of an
+// n x n row-major matrix, n <= 10.  H is destroyed.  wr/wi: eigenvalues; if V
+// is non-null it receives the (un-normalised) eigenvectors of the REAL
+// eigenvalues in the corresponding columns (row-major n x n).
+const int EIG_MAXN = 10;
+RDEV bool eig_real_general(int nn, double* H, double* wr, double* wi, double* V) {
+#define HH(i, j) H[(i) * nn + (j)]
+#define VV(i, j) V[(i) * nn + (j)]
+  const int low = 0, high = nn - 1;
+  double ort[EIG_MAXN];
+  // ---- orthes: reduce to Hessenberg form
+  for (int m = low + 1; m <= high - 1; ++m) {
+    double scale = 0.0;
+    for (int i = m; i <= high; ++i) scale += fabs(HH(i, m - 1));
+    if (scale != 0.0) {
+      double h = 0.0;
+      for (int i = high; i >= m; --i) { ort[i] = HH(i, m - 1) / scale; h += ort[i] * ort[i]; }
+      double g = sqrt(h);
+      if (ort[m] > 0) g = -g;
+      h = h - ort[m] * g;
+      ort[m] = ort[m] - g;
+      for (int j = m; j < nn; ++j) {
+        double f = 0.0;
+        for (int i = high; i >= m; --i) f += ort[i] * HH(i, j);
+        f = f / h;
+        for (int i = m; i <= high; ++i) HH(i, j) -= f * ort[i];
+      }
+      for (int i = 0; i <= high; ++i) {
+        double f = 0.0;
+        for (int j = high; j >= m; --j) f += ort[j] * HH(i, j);
+        f = f / h;
+        for (int j = m; j <= high; ++j) HH(i, j) -= f * ort[j];
+      }
+      ort[m] = scale * ort[m];
+      HH(m, m - 1) = scale * g;
+    } else {
+      ort[m] = 0.0;
+    }
+  }
+  if (V) {
+    for (int i = 0; i < nn; ++i) for (int j = 0; j < nn; ++j) VV(i, j) = (i == j) ? 1.0 : 0.0;
+    for (int m = high - 1; m >= low + 1; --m) {
+      if (HH(m, m - 1) != 0.0) {
+        for (int i = m + 1; i <= high; ++i) ort[i] = HH(i, m - 1);
+        for (int j = m; j <= high; ++j) {
+          double g = 0.0;
+          for (int i = m; i <= high; ++i) g += ort[i] * VV(i, j);
+          g = (g / ort[m]) / HH(m, m - 1);
+          for (int i = m; i <= high; ++i) VV(i, j) += g * ort[i];
+        }
+      }
+    }
+  }
+  // ---- hqr2
+  int n = nn - 1;
+  const double eps = 2.220446049250313e-16;
+  double exshift = 0.0;
+  double p = 0, q = 0, r = 0, s = 0, z = 0, t, w, x, y;
+  double norm = 0.0;
+  for (int i = 0; i < nn; ++i)
+    for (int j = (i - 1 > 0 ? i - 1 : 0); j < nn; ++j) norm += fabs(HH(i, j));
+  int iter = 0, total_iter = 0;
+  while (n >= low) {
+    int l = n;
+    while (l > low) {
+      s = fabs(HH(l - 1, l - 1)) + fabs(HH(l, l));
+      if (s == 0.0) s = norm;
+      if (fabs(HH(l, l - 1)) < eps * s) break;
+      l--;
+    }
+    if (l == n) {  // one root
+      HH(n, n) = HH(n, n) + exshift;
+      wr[n] = HH(n, n); wi[n] = 0.0;
+      n--; iter = 0;
+    } else if (l == n - 1) {  // two roots
+      w = HH(n, n - 1) * HH(n - 1, n);
+      p = (HH(n - 1, n - 1) - HH(n, n)) / 2.0;
+      q = p * p + w;
+      z = sqrt(fabs(q));
+      HH(n, n) = HH(n, n) + exshift;
+      HH(n - 1, n - 1) = HH(n - 1, n - 1) + exshift;
+      x = HH(n, n);
+      if (q >= 0) {  // real pair
+        z = (p >= 0) ? p + z : p - z;
+        wr[n - 1] = x + z;
+        wr[n] = wr[n - 1];
+        if (z != 0.0) wr[n] = x - w / z;
+        wi[n - 1] = 0.0; wi[n] = 0.0;
+        x = HH(n, n - 1);
+        s = fabs(x) + fabs(z);
+        p = x / s; q = z / s;
+        r = sqrt(p * p + q * q);
+        p = p / r; q = q / r;
+        for (int j = n - 1; j < nn; ++j) { z = HH(n - 1, j); HH(n - 1, j) = q * z + p * HH(n, j); HH(n, j) = q * HH(n, j) - p * z; }
+        for (int i = 0; i <= n; ++i) { z = HH(i, n - 1); HH(i, n - 1) = q * z + p * HH(i, n); HH(i, n) = q * HH(i, n) - p * z; }
+        if (V) for (int i = low; i <= high; ++i) { z = VV(i, n - 1); VV(i, n - 1) = q * z + p * VV(i, n); VV(i, n) = q * VV(i, n) - p * z; }
+      } else {  // complex pair
+        wr[n - 1] = x + p; wr[n] = x + p; wi[n - 1] = z; wi[n] = -z;
+      }
+      n = n - 2; iter = 0;
+    } else {
+      x = HH(n, n); y = 0.0; w = 0.0;
+      if (l < n) { y = HH(n - 1, n - 1); w = HH(n, n - 1) * HH(n - 1, n); }
+      if (iter == 10) {  // Wilkinson's original ad hoc shift
+        exshift += x;
+        for (int i = low; i <= n; ++i) HH(i, i) -= x;
+        s = fabs(HH(n, n - 1)) + fabs(HH(n - 1, n - 2));
+        x = y = 0.75 * s;
+        w = -0.4375 * s * s;
+      }
+      if (iter == 30) {  // MATLAB's new ad hoc shift
+        s = (y - x) / 2.0;
+        s = s * s + w;
+        if (s > 0) {
+          s = sqrt(s);
+          if (y < x) s = -s;
+          s = x - w / ((y - x) / 2.0 + s);
+          for (int i = low; i <= n; ++i) HH(i, i) -= s;
+          exshift += s;
+          x = y = w = 0.964;
+        }
+      }
+      iter = iter + 1;
+      if (++total_iter > 40 * nn) return false;  // Eigen: m_maxIterationsPerRow * size
+      int m = n - 2;
+      while (m >= l) {
+        z = HH(m, m);
+        r = x - z; s = y - z;
+        p = (r * s - w) / HH(m + 1, m) + HH(m, m + 1);
+        q = HH(m + 1, m + 1) - z - r - s;
+        r = HH(m + 2, m + 1);
+        s = fabs(p) + fabs(q) + fabs(r);
+        p = p / s; q = q / s; r = r / s;
+        if (m == l) break;
+        if (fabs(HH(m, m - 1)) * (fabs(q) + fabs(r)) <
+            eps * (fabs(p) * (fabs(HH(m - 1, m - 1)) + fabs(z) + fabs(HH(m + 1, m + 1))))) break;
+        m--;
+      }
+      for (int i = m + 2; i <= n; ++i) { HH(i, i - 2) = 0.0; if (i > m + 2) HH(i, i - 3) = 0.0; }
+      for (int k = m; k <= n - 1; ++k) {
+        const bool notlast = (k != n - 1);
+        if (k != m) {
+          p = HH(k, k - 1); q = HH(k + 1, k - 1);
+          r = notlast ? HH(k + 2, k - 1) : 0.0;
+          x = fabs(p) + fabs(q) + fabs(r);
+          if (x == 0.0) continue;
+          p = p / x; q = q / x; r = r / x;
+        }
+        s = sqrt(p * p + q * q + r * r);
+        if (p < 0) s = -s;
+        if (s != 0) {
+          if (k != m) HH(k, k - 1) = -s * x;
+          else if (l != m) HH(k, k - 1) = -HH(k, k - 1);
+          p = p + s; x = p / s; y = q / s; z = r / s; q = q / p; r = r / p;
+          for (int j = k; j < nn; ++j) {
+            p = HH(k, j) + q * HH(k + 1, j);
+            if (notlast) { p = p + r * HH(k + 2, j); HH(k + 2, j) = HH(k + 2, j) - p * z; }
+            HH(k, j) = HH(k, j) - p * x;
+            HH(k + 1, j) = HH(k + 1, j) - p * y;
+          }
+          const int imax = (n < k + 3) ? n : k + 3;
+          for (int i = 0; i <= imax; ++i) {
+            p = x * HH(i, k) + y * HH(i, k + 1);
+            if (notlast) { p = p + z * HH(i, k + 2); HH(i, k + 2) = HH(i, k + 2) - p * r; }
+            HH(i, k) = HH(i, k) - p;
+            HH(i, k + 1) = HH(i, k + 1) - p * q;
+          }
+          if (V) for (int i = low; i <= high; ++i) {
+            p = x * VV(i, k) + y * VV(i, k + 1);
+            if (notlast) { p = p + z * VV(i, k + 2); VV(i, k + 2) = VV(i, k + 2) - p * r; }
+            VV(i, k) = VV(i, k) - p;
+            VV(i, k + 1) = VV(i, k + 1) - p * q;
+          }
+        }
+      }
+    }
+  }
+  if (!V) return true;
+  if (norm == 0.0) return true;
+  // back-substitution for the REAL eigenvectors of the quasi-triangular form
+  for (n = nn - 1; n >= 0; --n) {
+    p = wr[n]; q = wi[n];
+    if (q != 0) continue;
+    int l = n;
+    HH(n, n) = 1.0;
+    for (int i = n - 1; i >= 0; --i) {
+      w = HH(i, i) - p;
+      r = 0.0;
+      for (int j = l; j <= n; ++j) r = r + HH(i, j) * HH(j, n);
+      if (wi[i] < 0.0) { z = w; s = r; }
+      else {
+        l = i;
+        if (wi[i] == 0.0) {
+          if (w != 0.0) HH(i, n) = -r / w;
+          else HH(i, n) = -r / (eps * norm);
+        } else {
+          x = HH(i, i + 1); y = HH(i + 1, i);
+          q = (wr[i] - p) * (wr[i] - p) + wi[i] * wi[i];
+          t = (x * s - z * r) / q;
+          HH(i, n) = t;
+          if (fabs(x) > fabs(z)) HH(i + 1, n) = (-r - w * t) / x;
+          else HH(i + 1, n) = (-s - y * t) / z;
+        }
+        t = fabs(HH(i, n));
+        if ((eps * t) * t > 1) for (int j = i; j <= n; ++j) HH(j, n) = HH(j, n) / t;
+      }
+    }
+  }
+  // back transformation (only the real-eigenvalue columns are meaningful)
+  for (int j = nn - 1; j >= low; --j) {
+    if (wi[j] != 0) continue;
+    for (int i = low; i <= high; ++i) {
+      z = 0.0;
+      for (int k = low; k <= j; ++k) z = z + VV(i, k) * HH(k, j);
+      VV(i, j) = z;
+    }
+  }
+  return true;
+#undef HH
+#undef VV
+}
+
+// Two-sided Jacobi SVD of a 3x3 row-major matrix (the algorithm of
+// Eigen::JacobiSVD for square real matrices): A = U diag(s) V^T, s sorted
+// descending, s >= 0.
+RDEV void jacobi_rot_sym(double x, double y, double z, double* c, double* s) {
+  // JacobiRotation::makeJacobi for the symmetric 2x2 [[x, y], [y, z]]
+  const double deno = 2.0 * fabs(y);
+  if (deno < DBL_MIN) { *c = 1.0; *s = 0.0; return; }
+  const double tau = (x - z) / deno;
+  const double w = sqrt(tau * tau + 1.0);
+  const double t = (tau > 0) ? 1.0 / (tau + w) : 1.0 / (tau - w);
+  const double sign_t = t > 0 ? 1.0 : -1.0;
+  const double n = 1.0 / sqrt(t * t + 1.0);
+  *s = -sign_t * (y / fabs(y)) * fabs(t) * n;
+  *c = n;
+}
+
+RDEV void svd3(const double* Ain, double* U, double* S, double* V) {
+  double W[9];
+  double scale = 0.0;
+  for (int i = 0; i < 9; ++i) scale = fmax(scale, fabs(Ain[i]));
+  if (scale == 0.0) scale = 1.0;
+  for (int i = 0; i < 9; ++i) W[i] = Ain[i] / scale;
+  for (int i = 0; i < 9; ++i) { U[i] = (i % 4 == 0) ? 1.0 : 0.0; V[i] = U[i]; }
+  const double precision = 2.0 * DBL_EPSILON;
+  double maxdiag = fmax(fabs(W[0]), fmax(fabs(W[4]), fabs(W[8])));
+  bool finished = false;
+  int sweeps = 0;
+  while (!finished && sweeps++ < 64) {
+    finished = true;
+    for (int p = 1; p < 3; ++p)
+      for (int q = 0; q < p; ++q) {
+        const double threshold = fmax(DBL_MIN, precision * maxdiag);
+        if (fabs(W[p * 3 + q]) > threshold || fabs(W[q * 3 + p]) > threshold) {
+          finished = false;
+          // real_2x2_jacobi_svd on [[W_pp, W_pq], [W_qp, W_qq]]
+          double m00 = W[p * 3 + p], m01 = W[p * 3 + q], m10 = W[q * 3 + p], m11 = W[q * 3 + q];
+          double r1c, r1s;
+          const double tt = m00 + m11, dd = m10 - m01;
+          if (fabs(dd) < DBL_MIN) { r1c = 1.0; r1s = 0.0; }
+          else { const double u = tt / dd; const double tmp = sqrt(1.0 + u * u); r1s = 1.0 / tmp; r1c = u / tmp; }
+          // m <- rot1 * m  (rows: r0' = c r0 + s r1 ; r1' = -s r0 + c r1)
+          const double n00 = r1c * m00 + r1s * m10, n01 = r1c * m01 + r1s * m11;
+          const double n11 = -r1s * m01 + r1c * m11;
+          double jc, js;
+          jacobi_rot_sym(n00, n01, n11, &jc, &js);
+          // left rotation L = rot1 * jr^T   (jr = [[jc, js], [-js, jc]])
+          const double lc = r1c * jc + r1s * js, ls = r1s * jc - r1c * js;
+          // W <- L on rows (p, q): row_p' = lc row_p + ls row_q ; row_q' = -ls row_p + lc row_q
+          for (int k = 0; k < 3; ++k) {
+            const double a = W[p * 3 + k], b = W[q * 3 + k];
+            W[p * 3 + k] = lc * a + ls * b; W[q * 3 + k] = -ls * a + lc * b;
+          }
+          // U <- U L^T on columns (p, q)
+          for (int k = 0; k < 3; ++k) {
+            const double a = U[k * 3 + p], b = U[k * 3 + q];
+            U[k * 3 + p] = lc * a + ls * b; U[k * 3 + q] = -ls * a + lc * b;
+          }
+          // W <- W jr on columns (p, q): col_p' = jc col_p - js col_q ; col_q' = js col_p + jc col_q
+          for (int k = 0; k < 3; ++k) {
+            const double a = W[k * 3 + p], b = W[k * 3 + q];
+            W[k * 3 + p] = jc * a - js * b; W[k * 3 + q] = js * a + jc * b;
+          }
+          for (int k = 0; k < 3; ++k) {
+            const double a = V[k * 3 + p], b = V[k * 3 + q];
+            V[k * 3 + p] = jc * a - js * b; V[k * 3 + q] = js * a + jc * b;
+          }
+          maxdiag = fmax(maxdiag, fmax(fabs(W[p * 3 + p]), fabs(W[q * 3 + q])));
+        }
+      }
+  }
+  for (int i = 0; i < 3; ++i) {
+    const double a = W[i * 3 + i];
+    S[i] = fabs(a);
+    if (a < 0) for (int k = 0; k < 3; ++k) U[k * 3 + i] = -U[k * 3 + i];
+  }
+  for (int i = 0; i < 3; ++i) {  // selection sort, descending
+    int best = i;
+    for (int j = i + 1; j < 3; ++j) if (S[j] > S[best]) best = j;
+    if (best != i) {
+      dswap(S[i], S[best]);
+      for (int k = 0; k < 3; ++k) { dswap(U[k * 3 + i], U[k * 3 + best]); dswap(V[k * 3 + i], V[k * 3 + best]); }
+    }
+  }
+  for (int i = 0; i < 3; ++i) S[i] *= scale;
+}
+
+RDEV double det3(const double* M) {
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// ------------------------------------------------------------ five point
+RDEV void mul_deg1(const double* a, const double* b, double* o) {  // five_point_relative_pose.cc:68-92
+  o[0] = a[0] * b[0];
+  o[1] = a[0] * b[1] + a[1] * b[0];
+  o[2] = a[1] * b[1];
+  o[3] = a[0] * b[2] + a[2] * b[0];
+  o[4] = a[1] * b[2] + a[2] * b[1];
+  o[5] = a[2] * b[2];
+  o[6] = a[0] * b[3] + a[3] * b[0];
+  o[7] = a[1] * b[3] + a[3] * b[1];
+  o[8] = a[2] * b[3] + a[3] * b[2];
+  o[9] = a[3] * b[3];
+}
+RDEV void mul_deg2_deg1(const double* a, const double* b, double* o) {  // :96-140
+  o[0] = a[0] * b[0];
+  o[1] = a[0] * b[1] + a[1] * b[0];
+  o[2] = a[1] * b[1] + a[2] * b[0];
+  o[3] = a[2] * b[1];
+  o[4] = a[0] * b[2] + a[3] * b[0];
+  o[5] = a[1] * b[2] + a[3] * b[1] + a[4] * b[0];
+  o[6] = a[2] * b[2] + a[4] * b[1];
+  o[7] = a[3] * b[2] + a[5] * b[0];
+  o[8] = a[4] * b[2] + a[5] * b[1];
+  o[9] = a[5] * b[2];
+  o[10] = a[0] * b[3] + a[6] * b[0];
+  o[11] = a[1] * b[3] + a[6] * b[1] + a[7] * b[0];
+  o[12] = a[2] * b[3] + a[7] * b[1];
+  o[13] = a[3] * b[3] + a[6] * b[2] + a[8] * b[0];
+  o[14] = a[4] * b[3] + a[7] * b[2] + a[8] * b[1];
+  o[15] = a[5] * b[3] + a[8] * b[2];
+  o[16] = a[6] * b[3] + a[9] * b[0];
+  o[17] = a[7] * b[3] + a[9] * b[1];
+  o[18] = a[8] * b[3] + a[9] * b[2];
+  o[19] = a[9] * b[3];
+}
+
+// corr: 5 x [x1 y1 x2 y2]; E: up to 10 row-major 3x3.  Returns #solutions.
+RDEV int five_point(const double* corr, double* E) {
+  // Step 1: 5x9 epipolar constraint rows (:228-236)
+  double A[45];
+  for (int i = 0; i < 5; ++i) {
+    const double x1 = corr[4 * i], y1 = corr[4 * i + 1], x2 = corr[4 * i + 2], y2 = corr[4 * i + 3];
+    double* r = A + 9 * i;
+    r[0] = x2 * x1; r[1] = y2 * x1; r[2] = x1; r[3] = x2 * y1; r[4] = y2 * y1; r[5] = y1; r[6] = x2; r[7] = y2; r[8] = 1.0;
+  }
+  // null space via full-pivot LU (Eigen FullPivLU::kernel, :242-247)
+  FullPivLU f;
+  fullpiv_lu(A, 5, 9, f);
+  const double premult = fabs(f.maxpivot) * (DBL_EPSILON * 5.0);
+  int rank = 0;
+  for (int i = 0; i < f.nonzero_pivots; ++i) rank += fabs(A[i * 9 + i]) > premult;
+  if (9 - rank != 4) return 0;
+  int cidx[9];
+  for (int j = 0; j < 9; ++j) cidx[j] = j;
+  for (int k = 0; k < f.size; ++k) dswap(cidx[k], cidx[f.colt[k]]);
+  // solve U1 X = U2 (5x5 upper, 4 right-hand sides)
+  double X[20];
+  for (int c = 0; c < 4; ++c)
+    for (int i = 4; i >= 0; --i) {
+      double s = A[i * 9 + 5 + c];
+      for (int j = i + 1; j < 5; ++j) s -= A[i * 9 + j] * X[j * 4 + c];
+      X[i * 4 + c] = s / A[i * 9 + i];
+    }
+  double N[36];  // null_space 9 x 4
+  for (int i = 0; i < 36; ++i) N[i] = 0.0;
+  for (int i = 0; i < 5; ++i) for (int c = 0; c < 4; ++c) N[cidx[i] * 4 + c] = -X[i * 4 + c];
+  for (int c = 0; c < 4; ++c) N[cidx[5 + c] * 4 + c] = 1.0;
+  // null_space_matrix[i][j] = row (3*j + i) of N  (:254-257)
+  const double* ns[3][3];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) ns[i][j] = N + 4 * (3 * j + i);
+  // Step 2: constraint matrix 10 x 20 (:142-206)
+  double C[200];
+  {
+    double eet[3][3][10];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+      double t0[10], t1[10], t2[10];
+      mul_deg1(ns[i][0], ns[j][0], t0); mul_deg1(ns[i][1], ns[j][1], t1); mul_deg1(ns[i][2], ns[j][2], t2);
+      for (int k = 0; k < 10; ++k) eet[i][j][k] = 2 * ((t0[k] + t1[k]) + t2[k]);
+    }
+    double trace[10];
+    for (int k = 0; k < 10; ++k) trace[k] = (eet[0][0][k] + eet[1][1][k]) + eet[2][2][k];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+      double a[20], b[20], c[20], d[20];
+      mul_deg2_deg1(eet[i][0], ns[0][j], a); mul_deg2_deg1(eet[i][1], ns[1][j], b);
+      mul_deg2_deg1(eet[i][2], ns[2][j], c); mul_deg2_deg1(trace, ns[i][j], d);
+      double* row = C + 20 * (3 * i + j);
+      for (int k = 0; k < 20; ++k) row[k] = ((a[k] + b[k]) + c[k]) - 0.5 * d[k];
+    }
+    double p0[10], p1[10], q[10], d0[20], d1[20], d2[20];
+    mul_deg1(ns[0][1], ns[1][2], p0); mul_deg1(ns[0][2], ns[1][1], p1);
+    for (int k = 0; k < 10; ++k) q[k] = p0[k] - p1[k];
+    mul_deg2_deg1(q, ns[2][0], d0);
+    mul_deg1(ns[0][2], ns[1][0], p0); mul_deg1(ns[0][0], ns[1][2], p1);
+    for (int k = 0; k < 10; ++k) q[k] = p0[k] - p1[k];
+    mul_deg2_deg1(q, ns[2][1], d1);
+    mul_deg1(ns[0][0], ns[1][1], p0); mul_deg1(ns[0][1], ns[1][0], p1);
+    for (int k = 0; k < 10; ++k) q[k] = p0[k] - p1[k];
+    mul_deg2_deg1(q, ns[2][2], d2);
+    for (int k = 0; k < 20; ++k) C[180 + k] = (d0[k] + d1[k]) + d2[k];
+  }
+  // Step 3: eliminated = lu(C[:, :10]).solve(C[:, 10:])  (:260-263)
+  double L[100], B[100];
+  for (int i = 0; i < 10; ++i) for (int j = 0; j < 10; ++j) { L[i * 10 + j] = C[i * 20 + j]; B[i * 10 + j] = C[i * 20 + 10 + j]; }
+  FullPivLU g;
+  fullpiv_lu(L, 10, 10, g);
+  for (int k = 0; k < 10; ++k) if (g.rowt[k] != k) for (int j = 0; j < 10; ++j) dswap(B[k * 10 + j], B[g.rowt[k] * 10 + j]);
+  for (int c = 0; c < 10; ++c) {
+    for (int i = 0; i < 10; ++i) { double s = B[i * 10 + c]; for (int j = 0; j < i; ++j) s -= L[i * 10 + j] * B[j * 10 + c]; B[i * 10 + c] = s; }
+    for (int i = 9; i >= 0; --i) { double s = B[i * 10 + c]; for (int j = i + 1; j < 10; ++j) s -= L[i * 10 + j] * B[j * 10 + c]; B[i * 10 + c] = s / L[i * 10 + i]; }
+  }
+  int gidx[10];
+  for (int j = 0; j < 10; ++j) gidx[j] = j;
+  for (int k = 0; k < 10; ++k) dswap(gidx[k], gidx[g.colt[k]]);
+  double El[100];  // eliminated matrix: row gidx[i] = B row i
+  for (int i = 0; i < 10; ++i) for (int j = 0; j < 10; ++j) El[gidx[i] * 10 + j] = B[i * 10 + j];
+  // action matrix (:265-273)
+  double M[100];
+  for (int i = 0; i < 100; ++i) M[i] = 0.0;
+  const int src[6] = {0, 1, 2, 4, 5, 7};
+  for (int r = 0; r < 6; ++r) for (int j = 0; j < 10; ++j) M[r * 10 + j] = El[src[r] * 10 + j];
+  M[6 * 10 + 0] = -1.0; M[7 * 10 + 1] = -1.0; M[8 * 10 + 3] = -1.0; M[9 * 10 + 6] = -1.0;
+  double wr[10], wi[10], Vv[100];
+  if (!eig_real_general(10, M, wr, wi, Vv)) return 0;
+  int ns_out = 0;
+  for (int i = 0; i < 10; ++i) {
+    if (wi[i] != 0) continue;  // only real solutions (:281-284)
+    double nrm = 0.0;
+    for (int k = 0; k < 10; ++k) nrm += Vv[k * 10 + i] * Vv[k * 10 + i];
+    nrm = sqrt(nrm);  // Eigen normalises eigenvectors
+    double v4[4];
+    for (int k = 0; k < 4; ++k) v4[k] = Vv[(6 + k) * 10 + i] / nrm;
+    // Map<Matrix<9,1>>(ematrix.data()) = null_space * v  (column-major 3x3)
+    double e9[9];
+    for (int rI = 0; rI < 9; ++rI) e9[rI] = ((N[rI * 4] * v4[0] + N[rI * 4 + 1] * v4[1]) + N[rI * 4 + 2] * v4[2]) + N[rI * 4 + 3] * v4[3];
+    double* Eo = E + 9 * ns_out;
+    for (int c = 0; c < 3; ++c) for (int rr = 0; rr < 3; ++rr) Eo[rr * 3 + c] = e9[c * 3 + rr];
+    ns_out++;
+  }
+  return ns_out;
+}
+
+// triangulation.cc:216-232
+RDEV bool in_front(const double* c, const double* R, const double* pos) {
+  const double d1[3] = {c[0], c[1], 1.0};
+  const double h2[3] = {c[2], c[3], 1.0};
+  const double d2[3] = {(R[0] * h2[0] + R[3] * h2[1]) + R[6] * h2[2], (R[1] * h2[0] + R[4] * h2[1]) + R[7] * h2[2],
+                        (R[2] * h2[0] + R[5] * h2[1]) + R[8] * h2[2]};
+  const double d1sq = (d1[0] * d1[0] + d1[1] * d1[1]) + d1[2] * d1[2];
+  const double d2sq = (d2[0] * d2[0] + d2[1] * d2[1]) + d2[2] * d2[2];
+  const double d1d2 = (d1[0] * d2[0] + d1[1] * d2[1]) + d1[2] * d2[2];
+  const double d1p = (d1[0] * pos[0] + d1[1] * pos[1]) + d1[2] * pos[2];
+  const double d2p = (d2[0] * pos[0] + d2[1] * pos[1]) + d2[2] * pos[2];
+  return (d2sq * d1p - d1d2 * d2p > 0) && (d1d2 * d1p - d1sq * d2p > 0);
+}
+
+// pose/util.cc:56-68, y^T F x with x = feature1, y = feature2
+RDEV double sampson(const double* F, const double* c) {
+  const double x0 = c[0], x1 = c[1], y0 = c[2], y1 = c[3];
+  const double ex0 = (F[0] * x0 + F[1] * x1) + F[2];
+  const double ex1 = (F[3] * x0 + F[4] * x1) + F[5];
+  const double ex2 = (F[6] * x0 + F[7] * x1) + F[8];
+  const double num = (y0 * ex0 + y1 * ex1) + ex2;
+  const double dn0 = (y0 * F[0] + y1 * F[3]) + F[6];
+  const double dn1 = (y0 * F[1] + y1 * F[4]) + F[7];
+  const double den = ((dn0 * dn0 + dn1 * dn1) + ex0 * ex0) + ex1 * ex1;
+  return num * num / den;
+}
+
+// essential_matrix_utils.cc:57-80,109-149.  Returns #points in front.
+RDEV int best_pose_from_E(const double* E, const double* corr, int ncorr, double* Rout, double* posout) {
+  double U[9], S[3], V[9];
+  svd3(E, U, S, V);
+  if (det3(U) < 0) for (int k = 0; k < 3; ++k) U[k * 3 + 2] = -U[k * 3 + 2];
+  if (det3(V) < 0) for (int k = 0; k < 3; ++k) V[k * 3 + 2] = -V[k * 3 + 2];
+  // R1 = U d V^T, R2 = U d^T V^T, d = [0 1 0; -1 0 0; 0 0 1]
+  double Ud[9], Udt[9];
+  for (int i = 0; i < 3; ++i) {
+    Ud[i * 3 + 0] = -U[i * 3 + 1]; Ud[i * 3 + 1] = U[i * 3 + 0]; Ud[i * 3 + 2] = U[i * 3 + 2];
+    Udt[i * 3 + 0] = U[i * 3 + 1]; Udt[i * 3 + 1] = -U[i * 3 + 0]; Udt[i * 3 + 2] = U[i * 3 + 2];
+  }
+  double R[2][9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    R[0][i * 3 + j] = (Ud[i * 3] * V[j * 3] + Ud[i * 3 + 1] * V[j * 3 + 1]) + Ud[i * 3 + 2] * V[j * 3 + 2];
+    R[1][i * 3 + j] = (Udt[i * 3] * V[j * 3] + Udt[i * 3 + 1] * V[j * 3 + 1]) + Udt[i * 3 + 2] * V[j * 3 + 2];
+  }
+  double t[3] = {U[2], U[5], U[8]};
+  const double tn = sqrt((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+  t[0] /= tn; t[1] /= tn; t[2] /= tn;
+  int best = -1, bestcount = -1;
+  double bestpos[3] = {0, 0, 0};
+  for (int k = 0; k < 4; ++k) {
+    const double* Rk = R[k >> 1];
+    const double sg = (k & 1) ? -1.0 : 1.0;
+    const double tk[3] = {sg * t[0], sg * t[1], sg * t[2]};
+    // position = -R^T * translation
+    const double pos[3] = {-((Rk[0] * tk[0] + Rk[3] * tk[1]) + Rk[6] * tk[2]), -((Rk[1] * tk[0] + Rk[4] * tk[1]) + Rk[7] * tk[2]),
+                           -((Rk[2] * tk[0] + Rk[5] * tk[1]) + Rk[8] * tk[2])};
+    int cnt = 0;
+    for (int i = 0; i < ncorr; ++i) cnt += in_front(corr + 4 * i, Rk, pos) ? 1 : 0;
+    if (cnt > bestcount) { bestcount = cnt; best = k; bestpos[0] = pos[0]; bestpos[1] = pos[1]; bestpos[2] = pos[2]; }
+  }
+  for (int i = 0; i < 9; ++i) Rout[i] = R[best >> 1][i];
+  posout[0] = bestpos[0]; posout[1] = bestpos[1]; posout[2] = bestpos[2];
+  return bestcount;
+}
+
+// ----------------------------------------------------------------- P3P
+// math/find_polynomial_roots_companion_matrix.cc for degree >= 3 (the quartic
+// of P3P): normalise, companion matrix, power-of-two balancing (gamma = 0.9),
+// eigenvalues; REAL PARTS of all roots are returned (reference quirk).
+RDEV int poly_roots_real_parts(const double* poly_in, int size, double* real_out) {
+  int lead = 0;
+  while (lead < size - 1 && poly_in[lead] == 0) ++lead;  // RemoveLeadingZeros
+  const double* poly = poly_in + lead;
+  const int degree = size - lead - 1;
+  if (degree == 0) return 0;
+  if (degree == 1) { real_out[0] = -poly[1] / poly[0]; return 1; }
+  if (degree == 2) {  // FindQuadraticPolynomialRoots (math/polynomial.cc)
+    const double a = poly[0], b = poly[1], c = poly[2];
+    const double D = b * b - 4 * a * c;
+    const double sqrt_D = sqrt(fabs(D));
+    if (D >= 0) {
+      if (b >= 0) { real_out[0] = (-b - sqrt_D) / (2.0 * a); real_out[1] = (2.0 * c) / (-b - sqrt_D); }
+      else { real_out[0] = (2.0 * c) / (-b + sqrt_D); real_out[1] = (-b + sqrt_D) / (2.0 * a); }
+    } else { real_out[0] = -b / (2.0 * a); real_out[1] = -b / (2.0 * a); }
+    return 2;
+  }
+  double p[EIG_MAXN + 1];
+  for (int i = 0; i <= degree; ++i) p[i] = poly[i] / poly[0];
+  double Cm[EIG_MAXN * EIG_MAXN];
+  for (int i = 0; i < degree * degree; ++i) Cm[i] = 0.0;
+  for (int i = 1; i < degree; ++i) Cm[i * degree + i - 1] = 1.0;
+  for (int i = 0; i < degree; ++i) Cm[i * degree + degree - 1] = -p[degree - i];
+  // BalanceCompanionMatrix
+  {
+    double Off[EIG_MAXN * EIG_MAXN];
+    for (int i = 0; i < degree * degree; ++i) Off[i] = Cm[i];
+    for (int i = 0; i < degree; ++i) Off[i * degree + i] = 0.0;
+    const double gamma = 0.9;
+    bool changed;
+    do {
+      changed = false;
+      for (int i = 0; i < degree; ++i) {
+        double row_norm = 0.0, col_norm = 0.0;
+        for (int j = 0; j < degree; ++j) { row_norm += fabs(Off[i * degree + j]); col_norm += fabs(Off[j * degree + i]); }
+        int exponent = 0;
+        frexp(row_norm / col_norm, &exponent);
+        exponent /= 2;
+        if (exponent != 0) {
+          const double scaled_col = ldexp(col_norm, exponent);
+          const double scaled_row = ldexp(row_norm, -exponent);
+          if (scaled_col + scaled_row < gamma * (col_norm + row_norm)) {
+            changed = true;
+            const double rs = ldexp(1.0, -exponent), cs = ldexp(1.0, exponent);
+            for (int j = 0; j < degree; ++j) Off[i * degree + j] *= rs;
+            for (int j = 0; j < degree; ++j) Off[j * degree + i] *= cs;
+          }
+        }
+      }
+    } while (changed);
+    for (int i = 0; i < degree; ++i) Off[i * degree + i] = Cm[i * degree + i];
+    for (int i = 0; i < degree * degree; ++i) Cm[i] = Off[i];
+  }
+  double wr[EIG_MAXN], wi[EIG_MAXN];
+  if (!eig_real_general(degree, Cm, wr, wi, nullptr)) return 0;
+  for (int i = 0; i < degree; ++i) real_out[i] = wr[i];
+  return degree;
+}
+
+RDEV void cross3(const double* a, const double* b, double* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+RDEV double dot3(const double* a, const double* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+RDEV void normalize3(double* a) { const double n = sqrt(dot3(a, a)); a[0] /= n; a[1] /= n; a[2] /= n; }
+
+// perspective_three_point.cc:187-291.  corr: 3 x [u v X Y Z].
+// R: up to 4 row-major 3x3 (world -> camera), t: up to 4 translations.
+RDEV int p3p(const double* corr, double* Rs, double* ts) {
+  double f[3][3], wp[3][3];
+  for (int i = 0; i < 3; ++i) {
+    f[i][0] = corr[5 * i]; f[i][1] = corr[5 * i + 1]; f[i][2] = 1.0;
+    normalize3(f[i]);
+    wp[i][0] = corr[5 * i + 2]; wp[i][1] = corr[5 * i + 3]; wp[i][2] = corr[5 * i + 4];
+  }
+  double w10[3], w20[3], cr[3];
+  for (int k = 0; k < 3; ++k) { w10[k] = wp[1][k] - wp[0][k]; w20[k] = wp[2][k] - wp[0][k]; }
+  cross3(w10, w20, cr);
+  if (dot3(cr, cr) < 1e-6) return 0;
+  double T[9];  // intermediate camera frame, rows
+  auto build_T = [&]() {
+    for (int k = 0; k < 3; ++k) T[k] = f[0][k];
+    cross3(f[0], f[1], T + 6); normalize3(T + 6);
+    cross3(T + 6, T, T + 3);
+  };
+  build_T();
+  double ip[3] = {dot3(T, f[2]), dot3(T + 3, f[2]), dot3(T + 6, f[2])};
+  if (ip[2] > 0) {
+    for (int k = 0; k < 3; ++k) { dswap(f[0][k], f[1][k]); }
+    build_T();
+    ip[0] = dot3(T, f[2]); ip[1] = dot3(T + 3, f[2]); ip[2] = dot3(T + 6, f[2]);
+    for (int k = 0; k < 3; ++k) dswap(wp[0][k], wp[1][k]);
+    for (int k = 0; k < 3; ++k) { w10[k] = wp[1][k] - wp[0][k]; w20[k] = wp[2][k] - wp[0][k]; }
+  }
+  double Nw[9];  // intermediate world frame, rows
+  for (int k = 0; k < 3; ++k) Nw[k] = w10[k];
+  normalize3(Nw);
+  cross3(Nw, w20, Nw + 6); normalize3(Nw + 6);
+  cross3(Nw + 6, Nw, Nw + 3);
+  const double iw[3] = {dot3(Nw, w20), dot3(Nw + 3, w20), dot3(Nw + 6, w20)};
+  const double d_12 = sqrt(dot3(w10, w10));
+  // SolvePlaneRotation (:56-137)
+  const double f_1 = ip[0] / ip[2], f_2 = ip[1] / ip[2];
+  const double p_1 = iw[0], p_2 = iw[1];
+  const double cos_beta = dot3(f[0], f[1]);
+  double b = 1.0 / (1.0 - cos_beta * cos_beta) - 1.0;
+  b = (cos_beta < 0) ? -sqrt(b) : sqrt(b);
+  const double f_1_pw2 = f_1 * f_1, f_2_pw2 = f_2 * f_2;
+  const double p_1_pw2 = p_1 * p_1, p_1_pw3 = p_1_pw2 * p_1, p_1_pw4 = p_1_pw3 * p_1;
+  const double p_2_pw2 = p_2 * p_2, p_2_pw3 = p_2_pw2 * p_2, p_2_pw4 = p_2_pw3 * p_2;
+  const double d_12_pw2 = d_12 * d_12, b_pw2 = b * b;
+  double co[5];
+  co[0] = -f_2_pw2 * p_2_pw4 - p_2_pw4 * f_1_pw2 - p_2_pw4;
+  co[1] = 2.0 * p_2_pw3 * d_12 * b + 2.0 * f_2_pw2 * p_2_pw3 * d_12 * b - 2.0 * f_2 * p_2_pw3 * f_1 * d_12;
+  co[2] = -f_2_pw2 * p_2_pw2 * p_1_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 +
+          f_2_pw2 * p_2_pw4 + p_2_pw4 * f_1_pw2 + 2.0 * p_1 * p_2_pw2 * d_12 +
+          2.0 * f_1 * f_2 * p_1 * p_2_pw2 * d_12 * b - p_2_pw2 * p_1_pw2 * f_1_pw2 +
+          2.0 * p_1 * p_2_pw2 * f_2_pw2 * d_12 - p_2_pw2 * d_12_pw2 * b_pw2 - 2.0 * p_1_pw2 * p_2_pw2;
+  co[3] = 2.0 * p_1_pw2 * p_2 * d_12 * b + 2.0 * f_2 * p_2_pw3 * f_1 * d_12 - 2.0 * f_2_pw2 * p_2_pw3 * d_12 * b -
+          2.0 * p_1 * p_2 * d_12_pw2 * b;
+  co[4] = -2 * f_2 * p_2_pw2 * f_1 * p_1 * d_12 * b + f_2_pw2 * p_2_pw2 * d_12_pw2 + 2.0 * p_1_pw3 * d_12 -
+          p_1_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw2 * p_1_pw2 - p_1_pw4 - 2.0 * f_2_pw2 * p_2_pw2 * p_1 * d_12 +
+          p_2_pw2 * f_1_pw2 * p_1_pw2 + f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
+  double roots[4];
+  const int nroots = poly_roots_real_parts(co, 5, roots);
+  for (int i = 0; i < nroots; ++i) {
+    const double cos_theta = roots[i];
+    const double cot_alpha = (-f_1 * p_1 / f_2 - cos_theta * p_2 + d_12 * b) / (-f_1 * cos_theta * p_2 / f_2 + p_1 - d_12);
+    // Backsubstitute (:142-183)
+    const double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+    const double sin_alpha = sqrt(1.0 / (cot_alpha * cot_alpha + 1.0));
+    double cos_alpha = sqrt(1.0 - sin_alpha * sin_alpha);
+    if (cot_alpha < 0) cos_alpha = -cos_alpha;
+    const double c_nu[3] = {d_12 * cos_alpha * (sin_alpha * b + cos_alpha),
+                            cos_theta * d_12 * sin_alpha * (sin_alpha * b + cos_alpha),
+                            sin_theta * d_12 * sin_alpha * (sin_alpha * b + cos_alpha)};
+    double tr[3];
+    for (int k = 0; k < 3; ++k) tr[k] = wp[0][k] + ((Nw[k] * c_nu[0] + Nw[3 + k] * c_nu[1]) + Nw[6 + k] * c_nu[2]);
+    const double Q[9] = {-cos_alpha, -sin_alpha * cos_theta, -sin_alpha * sin_theta,
+                         sin_alpha, -cos_alpha * cos_theta, -cos_alpha * sin_theta,
+                         0, -sin_theta, cos_theta};
+    // rotation = (N^T Q^T T)^T = T^T Q N
+    double QN[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) QN[r * 3 + c] = (Q[r * 3] * Nw[c] + Q[r * 3 + 1] * Nw[3 + c]) + Q[r * 3 + 2] * Nw[6 + c];
+    double* R = Rs + 9 * i;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[r * 3 + c] = (T[r] * QN[c] + T[3 + r] * QN[3 + c]) + T[6 + r] * QN[6 + c];
+    double* t = ts + 3 * i;
+    for (int r = 0; r < 3; ++r) t[r] = -((R[r * 3] * tr[0] + R[r * 3 + 1] * tr[1]) + R[r * 3 + 2] * tr[2]);
+  }
+  return nroots;
+}
+
+
+}  // namespace rsc
+}  // namespace thip

@@ -1,0 +1,236 @@
+"""Host-side mirror of pyTheia's RANSAC estimators (pytheia.sfm.Estimate*,
+src/pytheia/sfm/sfm.cc:812-850, solvers/solvers.cc:68-102) over the C-ABI
+batch entry point theia_hip_ransac_estimate_batch.
+
+Same names / argument order as the pybind wrappers
+(estimators_wrapper.cc:41-57,130-142): Estimate*(ransac_params, ransac_type,
+..., correspondences) -> (success, model, RansacSummary).
+"""
+import ctypes as C
+import enum
+import time
+
+import numpy as np
+
+from . import _capi as capi
+
+
+class RansacType(enum.IntEnum):  # create_and_initialize_ransac_variant.h:52
+    RANSAC = 0
+    PROSAC = 1
+    LMED = 2
+    EXHAUSTIVE = 3
+
+
+class PnPType(enum.IntEnum):  # estimate_calibrated_absolute_pose.h:54
+    KNEIP = 0
+    SQPnP = 1
+    DLS = 2
+
+
+EST_RELATIVE_POSE, EST_ESSENTIAL_MATRIX, EST_ABS_KNEIP, EST_ABS_DLS, EST_ABS_SQPNP = range(5)
+
+
+class RansacParameters:
+    """solvers/sample_consensus_estimator.h:58-126, same fields and defaults.
+    `rng` is not bound to Python in the reference either (solvers.cc:89-102);
+    `seed` is this backend's handle on RandomNumberGenerator(seed)."""
+
+    def __init__(self):
+        self.error_thresh = -1.0
+        self.failure_probability = 0.01
+        self.min_inlier_ratio = 0.0
+        self.min_iterations = 100
+        self.max_iterations = 2 ** 31 - 1
+        self.use_mle = False
+        self.use_Tdd_test = False
+        self.use_lo = False
+        self.lo_start_iterations = 50
+        self.seed = 0
+
+    def to_c(self):
+        p = capi.RansacParams()
+        p.error_thresh = float(self.error_thresh)
+        p.failure_probability = float(self.failure_probability)
+        p.min_inlier_ratio = float(self.min_inlier_ratio)
+        p.min_iterations = int(self.min_iterations)
+        p.max_iterations = int(self.max_iterations)
+        p.use_mle = int(bool(self.use_mle))
+        p.use_lo = int(bool(self.use_lo))
+        p.lo_start_iterations = int(self.lo_start_iterations)
+        p.use_Tdd_test = int(bool(self.use_Tdd_test))
+        p.seed = int(self.seed) & 0xFFFFFFFF
+        return p
+
+
+class RansacSummary:
+    """solvers/sample_consensus_estimator.h:129-144."""
+
+    def __init__(self):
+        self.inliers = []
+        self.num_input_data_points = 0
+        self.num_iterations = 0
+        self.confidence = 0.0
+        self.num_lo_iterations = 0
+
+
+class RelativePose:  # estimate_relative_pose.h:49-53
+    def __init__(self, m):
+        self.essential_matrix = m[0:9].reshape(3, 3).copy()
+        self.rotation = m[9:18].reshape(3, 3).copy()
+        self.position = m[18:21].copy()
+
+
+class CalibratedAbsolutePose:  # estimate_calibrated_absolute_pose.h:49-52
+    def __init__(self, m):
+        self.rotation = m[0:9].reshape(3, 3).copy()
+        self.position = m[9:12].copy()
+
+
+def _sig():
+    L = capi.lib()
+    if not getattr(L, "_ransac_ready", False):
+        L.theia_hip_ransac_estimate_batch.argtypes = [C.POINTER(capi.RansacBatch), C.POINTER(capi.RansacParams),
+                                                      C.POINTER(capi.RansacResult)]
+        L.theia_hip_five_point_relative_pose.argtypes = [C.c_int32, capi.c_double_p, capi.c_double_p, capi.c_int32_p]
+        L.theia_hip_pose_from_three_points.argtypes = [C.c_int32, capi.c_double_p, capi.c_double_p, capi.c_double_p,
+                                                       capi.c_int32_p]
+        L.theia_ransac_params_default.argtypes = [C.POINTER(capi.RansacParams)]
+        L._ransac_ready = True
+    return L
+
+
+def estimate_batch(estimator, data, offsets, params):
+    """theia_hip_ransac_estimate_batch.  data [total][datum], offsets [P+1].
+    Returns dict of per-problem arrays."""
+    L = _sig()
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    P = len(offsets) - 1
+    total = int(offsets[-1]) if P > 0 else 0
+    b = capi.RansacBatch()
+    b.estimator = int(estimator); b.num_problems = P
+    b.offsets = capi.ptr(offsets, C.c_int64); b.data = capi.ptr(data, C.c_double)
+    success = np.zeros(max(P, 1), dtype=np.int32); models = np.zeros((max(P, 1), capi.THEIA_RANSAC_MODEL_STRIDE))
+    ninl = np.zeros(max(P, 1), dtype=np.int32); mask = np.zeros(max(total, 1), dtype=np.uint8)
+    nit = np.zeros(max(P, 1), dtype=np.int32); conf = np.zeros(max(P, 1))
+    r = capi.RansacResult()
+    r.success = capi.ptr(success, C.c_int32); r.models = capi.ptr(models, C.c_double)
+    r.num_inliers = capi.ptr(ninl, C.c_int32); r.inlier_mask = capi.ptr(mask, C.c_uint8)
+    r.num_iterations = capi.ptr(nit, C.c_int32); r.confidence = capi.ptr(conf, C.c_double)
+    pc = params.to_c() if isinstance(params, RansacParameters) else params
+    capi.check(L.theia_hip_ransac_estimate_batch(C.byref(b), C.byref(pc), C.byref(r)))
+    return {"success": success[:P], "models": models[:P], "num_inliers": ninl[:P], "inlier_mask": mask[:total],
+            "num_iterations": nit[:P], "confidence": conf[:P], "hypotheses_evaluated": r.hypotheses_evaluated,
+            "models_scored": r.models_scored, "time_fit_score_seconds": r.time_fit_score_seconds}
+
+
+def _single(estimator, ransac_params, ransac_type, data):
+    if RansacType(ransac_type) != RansacType.RANSAC:
+        raise capi.TheiaHipError(-3, f"RansacType {RansacType(ransac_type).name} is not built in the HIP backend yet")
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    res = estimate_batch(estimator, data, np.array([0, data.shape[0]], dtype=np.int64), ransac_params)
+    s = RansacSummary()
+    s.inliers = np.nonzero(res["inlier_mask"])[0].tolist()
+    s.num_input_data_points = data.shape[0]
+    s.num_iterations = int(res["num_iterations"][0])
+    s.confidence = float(res["confidence"][0])
+    return bool(res["success"][0]), res["models"][0], s
+
+
+def EstimateRelativePose(ransac_params, ransac_type, normalized_correspondences):
+    """estimate_relative_pose.cc:159-172.  correspondences: (N,4) x1 y1 x2 y2."""
+    ok, m, s = _single(EST_RELATIVE_POSE, ransac_params, ransac_type, normalized_correspondences)
+    return ok, RelativePose(m), s
+
+
+def EstimateEssentialMatrix(ransac_params, ransac_type, normalized_correspondences):
+    """estimate_essential_matrix.cc:90-106."""
+    ok, m, s = _single(EST_ESSENTIAL_MATRIX, ransac_params, ransac_type, normalized_correspondences)
+    return ok, m[0:9].reshape(3, 3).copy(), s
+
+
+def EstimateCalibratedAbsolutePose(ransac_params, ransac_type, pnp_type, normalized_correspondences):
+    """estimate_calibrated_absolute_pose.cc:176-190.  correspondences: (N,5) u v X Y Z."""
+    est = {PnPType.KNEIP: EST_ABS_KNEIP, PnPType.DLS: EST_ABS_DLS, PnPType.SQPnP: EST_ABS_SQPNP}[PnPType(pnp_type)]
+    ok, m, s = _single(est, ransac_params, ransac_type, normalized_correspondences)
+    return ok, CalibratedAbsolutePose(m), s
+
+
+def FivePointRelativePose(image1_points, image2_points):
+    """pose_wrapper.cc:166-173 (minimal, 5 correspondences per problem; batched
+    when the inputs carry a leading batch dimension)."""
+    a = np.asarray(image1_points, dtype=np.float64); b = np.asarray(image2_points, dtype=np.float64)
+    single = a.ndim == 2
+    if single:
+        a, b = a[None], b[None]
+    corr = np.ascontiguousarray(np.concatenate([a, b], axis=2))
+    num = corr.shape[0]
+    E = np.zeros((num, 10, 3, 3)); ns = np.zeros(num, dtype=np.int32)
+    capi.check(_sig().theia_hip_five_point_relative_pose(num, capi.ptr(corr, C.c_double), capi.ptr(E, C.c_double),
+                                                          capi.ptr(ns, C.c_int32)))
+    if single:
+        return bool(ns[0] > 0), [E[0, k] for k in range(ns[0])]
+    return ns, E
+
+
+def PoseFromThreePoints(feature_points, points_3d):
+    """sfm.cc:573 / perspective_three_point.cc (Kneip P3P)."""
+    a = np.asarray(feature_points, dtype=np.float64); b = np.asarray(points_3d, dtype=np.float64)
+    single = a.ndim == 2
+    if single:
+        a, b = a[None], b[None]
+    corr = np.ascontiguousarray(np.concatenate([a, b], axis=2))
+    num = corr.shape[0]
+    R = np.zeros((num, 4, 3, 3)); t = np.zeros((num, 4, 3)); ns = np.zeros(num, dtype=np.int32)
+    capi.check(_sig().theia_hip_pose_from_three_points(num, capi.ptr(corr, C.c_double), capi.ptr(R, C.c_double),
+                                                        capi.ptr(t, C.c_double), capi.ptr(ns, C.c_int32)))
+    if single:
+        return bool(ns[0] > 0), [R[0, k] for k in range(ns[0])], [t[0, k] for k in range(ns[0])]
+    return ns, R, t
+
+
+def smoke_check():
+    """Small batch through the C-ABI, checked against the oracle (inlier sets
+    bit-identical under the same seed)."""
+    from . import synth
+    from tests import oracle_lib as ol
+    data, offsets, _ = synth.synth_ransac_v1(4, 200, "relative", seed=0x5AC50001)
+    p = RansacParameters(); p.error_thresh = (2.0 / 1000.0) ** 2; p.min_iterations = 64; p.max_iterations = 64; p.seed = 65
+    res = estimate_batch(EST_RELATIVE_POSE, data, offsets, p)
+    for i in range(4):
+        pc = p.to_c(); pc.seed = p.seed + i
+        o = ol.ransac_estimate(EST_RELATIVE_POSE, data[offsets[i]:offsets[i + 1]], pc)
+        assert np.array_equal(o["inlier_mask"], res["inlier_mask"][offsets[i]:offsets[i + 1]]), f"inlier set differs on problem {i}"
+        assert o["num_iterations"] == res["num_iterations"][i]
+    print(f"smoke RANSAC ok: 4 problems x 64 hypotheses, inlier sets identical to the oracle ({res['num_inliers']})")
+
+
+def bench(cpu_baseline=True, problems=256, corr=2000, hyps=4096):
+    """RANSAC hypotheses/s on a bounded slice of BASELINE.json configs[4]
+    (2k correspondences / pair, 4096 hypotheses, FivePointRelativePose)."""
+    from . import synth
+    data, offsets, _ = synth.synth_ransac_v1(problems, corr, "relative", seed=0x5AC50005)
+    p = RansacParameters(); p.error_thresh = (2.0 / 1000.0) ** 2; p.min_iterations = hyps; p.max_iterations = hyps; p.seed = 1
+    estimate_batch(EST_RELATIVE_POSE, data[: offsets[8]], offsets[:9], p)  # warm-up
+    t0 = time.perf_counter()
+    res = estimate_batch(EST_RELATIVE_POSE, data, offsets, p)
+    dt = time.perf_counter() - t0
+    out = {"workload": f"synth_ransac_v1: {problems} pairs x {corr} correspondences x {hyps} hypotheses, five-point relative pose, InlierSupport",
+           "hypotheses_per_sec": res["hypotheses_evaluated"] / dt,
+           "hypotheses_per_sec_kernels_only": res["hypotheses_evaluated"] / max(res["time_fit_score_seconds"], 1e-12),
+           "models_scored": int(res["models_scored"]), "wall_s": dt, "kernel_s": res["time_fit_score_seconds"],
+           "note": "wall time includes the PCIe upload of correspondences, host sample generation and host replay"}
+    if cpu_baseline:
+        from tests import oracle_lib as ol
+        pc = p.to_c(); pc.min_iterations = 256; pc.max_iterations = 256
+        t0 = time.perf_counter()
+        nprob = 4
+        for i in range(nprob):
+            pc.seed = p.seed + i
+            ol.ransac_estimate(EST_RELATIVE_POSE, data[offsets[i]:offsets[i + 1]], pc)
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": nprob * 256 / dtc, "unit": "hypotheses/s", "cores": 1, "kind": "port",
+                               "sample": f"{nprob} pairs x 256 hypotheses x {corr} correspondences (oracle/ransac_oracle.cpp), {dtc:.1f} s"}
+        out["speedup_vs_cpu_baseline"] = out["hypotheses_per_sec"] / out["cpu_baseline"]["value"]
+    return out

@@ -1,0 +1,302 @@
+"""Host-side mirror of pyTheia's BA interface (pytheia.sfm.BundleAdjust*).
+
+Same names, argument order and error behaviour as the pybind surface
+(src/pytheia/sfm/sfm.cc:1605-1626 -> bundle_adjustment_wrapper.cc:98-114):
+the functions flatten a reconstruction into the C-ABI problem exactly the way
+BundleAdjuster::AddView / AddTrack build the Ceres problem
+(bundle_adjuster.cc:116-221), call libtheia_hip.so, scatter the parameters
+back and run the reference's post-step (UpdateInverseDepth,
+bundle_adjustment.cc:69-83).
+
+The data model (Reconstruction/View/Track) is OUT OF SCOPE of this engine --
+in the real integration it stays theia's C++ types.  The
+`Reconstruction` below is a compact array-backed stand-in with the accessors
+the BA entry points need, so that the parity tests read like the reference's.
+"""
+import enum
+
+import numpy as np
+
+from . import _capi as capi
+from . import ba as _ba
+from .synth import angle_axis_to_matrix
+
+kInvalidViewId = 0xFFFFFFFF
+
+
+class LossFunctionType(enum.IntEnum):  # create_loss_function.h:52-60
+    TRIVIAL = 0
+    HUBER = 1
+    SOFTLONE = 2
+    CAUCHY = 3
+    ARCTAN = 4
+    TUKEY = 5
+    TRUNCATED = 6  # C++ only in the reference (not in the Python enum, sfm.cc:1566-1572)
+
+
+class OptimizeIntrinsicsType(enum.IntFlag):  # bundle_adjustment.h:71-85
+    NONE = 0x00
+    FOCAL_LENGTH = 0x01
+    ASPECT_RATIO = 0x02
+    SKEW = 0x04
+    PRINCIPAL_POINTS = 0x08
+    RADIAL_DISTORTION = 0x10
+    TANGENTIAL_DISTORTION = 0x20
+    ALL = 0x3F
+
+
+class CameraIntrinsicsModelType(enum.IntEnum):  # camera_intrinsics_model_type.h:46-56
+    PINHOLE = 0
+    PINHOLE_RADIAL_TANGENTIAL = 1
+    FISHEYE = 2
+    FOV = 3
+    DIVISION_UNDISTORTION = 4
+    DOUBLE_SPHERE = 5
+    EXTENDED_UNIFIED = 6
+    ORTHOGRAPHIC = 7
+
+
+class BundleAdjustmentOptions:
+    """bundle_adjustment.h:87-167, same field names and defaults.  The
+    linear-algebra selectors are accepted and ignored: the HIP backend is the
+    linear solver (Schur complement + dense FP64-MFMA Cholesky)."""
+
+    def __init__(self):
+        self.loss_function_type = LossFunctionType.TRIVIAL
+        self.robust_loss_width = 2.0
+        self.robust_loss_width_depth_prior = 0.01
+        self.linear_solver_type = "SPARSE_SCHUR"
+        self.preconditioner_type = "SCHUR_JACOBI"
+        self.visibility_clustering_type = "CANONICAL_VIEWS"
+        self.dense_linear_algebra_library_type = "EIGEN"
+        self.sparse_linear_algebra_library_type = "EIGEN_SPARSE"
+        self.optimize_for_forward_facing_trajectory = False
+        self.use_mixed_precision_solves = False
+        self.max_num_refinement_iterations = 2
+        self.verbose = False
+        self.constant_camera_orientation = False
+        self.constant_camera_position = False
+        self.use_homogeneous_point_parametrization = True
+        self.use_inverse_depth_parametrization = False
+        self.intrinsics_to_optimize = OptimizeIntrinsicsType.NONE
+        self.num_threads = 1
+        self.max_num_iterations = 100
+        self.max_solver_time_in_seconds = 3600.0
+        self.use_inner_iterations = True
+        self.function_tolerance = 1e-6
+        self.gradient_tolerance = 1e-10
+        self.parameter_tolerance = 1e-8
+        self.max_trust_region_radius = 1e12
+        self.use_position_priors = False
+        self.use_orientation_priors = False
+        self.use_depth_priors = False
+        self.orthographic_camera = False
+        self.use_gravity_priors = False
+
+    def to_c(self):
+        unsupported = [n for n in ("use_inverse_depth_parametrization", "use_position_priors",
+                                   "use_orientation_priors", "use_depth_priors", "use_gravity_priors",
+                                   "optimize_for_forward_facing_trajectory") if getattr(self, n)]
+        if unsupported:
+            raise capi.TheiaHipError(-3, "options not built in the HIP backend yet: " + ", ".join(unsupported))
+        o = _ba.default_options()
+        o.loss_function_type = int(self.loss_function_type)
+        o.robust_loss_width = float(self.robust_loss_width)
+        o.intrinsics_to_optimize = int(self.intrinsics_to_optimize)
+        o.max_num_iterations = int(self.max_num_iterations)
+        o.use_homogeneous_point_parametrization = int(bool(self.use_homogeneous_point_parametrization))
+        o.constant_camera_orientation = int(bool(self.constant_camera_orientation))
+        o.constant_camera_position = int(bool(self.constant_camera_position))
+        o.orthographic_camera = int(bool(self.orthographic_camera))
+        o.use_inner_iterations = int(bool(self.use_inner_iterations))
+        o.verbose = int(bool(self.verbose))
+        o.function_tolerance = float(self.function_tolerance)
+        o.gradient_tolerance = float(self.gradient_tolerance)
+        o.parameter_tolerance = float(self.parameter_tolerance)
+        o.max_trust_region_radius = float(self.max_trust_region_radius)
+        o.max_solver_time_in_seconds = float(self.max_solver_time_in_seconds)
+        return o
+
+
+class BundleAdjustmentSummary:
+    """bundle_adjustment.h:170-178."""
+
+    def __init__(self, c=None):
+        self.success = bool(c.success) if c is not None else False
+        self.initial_cost = c.initial_cost if c is not None else 0.0
+        self.final_cost = c.final_cost if c is not None else 0.0
+        self.setup_time_in_seconds = c.setup_time_in_seconds if c is not None else 0.0
+        self.solve_time_in_seconds = c.solve_time_in_seconds if c is not None else 0.0
+        # extras of the HIP backend (not in the reference struct)
+        self.num_iterations = c.num_iterations if c is not None else 0
+        self.termination_type = c.termination_type if c is not None else 2
+
+
+class Reconstruction:
+    """Array-backed stand-in for theia::Reconstruction: ids are dense indices."""
+
+    def __init__(self):
+        self.cam_ext = np.zeros((0, 6))
+        self.view_estimated = np.zeros(0, dtype=bool)
+        self.view_group = np.zeros(0, dtype=np.int32)
+        self.group_model = np.zeros(0, dtype=np.int32)
+        self.group_intrinsics = np.zeros((0, capi.THEIA_MAX_INTRINSICS))
+        self.points = np.zeros((0, 4))
+        self.track_estimated = np.zeros(0, dtype=bool)
+        self.track_reference_view = np.zeros(0, dtype=np.int64)
+        self.inverse_depth = np.zeros(0)
+        self.obs_view = np.zeros(0, dtype=np.int32)
+        self.obs_track = np.zeros(0, dtype=np.int32)
+        self.obs_uv = np.zeros((0, 2))
+        self.obs_cov = np.zeros((0, 2))  # diagonal of Feature::covariance_
+
+    @classmethod
+    def from_flat(cls, p):
+        r = cls()
+        r.cam_ext = p.cam_ext.copy()
+        nv, nt = p.cam_ext.shape[0], p.points.shape[0]
+        r.view_estimated = np.ones(nv, dtype=bool)
+        r.view_group = p.cam_group.copy()
+        r.group_model = p.group_model.copy()
+        r.group_intrinsics = p.intrinsics.copy()
+        r.points = p.points.copy()
+        r.track_estimated = np.ones(nt, dtype=bool)
+        r.obs_view = p.obs_cam.copy(); r.obs_track = p.obs_pt.copy(); r.obs_uv = p.obs_uv.copy()
+        r.obs_cov = np.ones((len(r.obs_view), 2)) if p.obs_sqrt_info is None else 1.0 / p.obs_sqrt_info ** 2
+        first = np.full(nt, kInvalidViewId, dtype=np.int64)
+        order = np.argsort(r.obs_track, kind="stable")
+        tr, idx = np.unique(r.obs_track[order], return_index=True)
+        first[tr] = r.obs_view[order][idx]
+        r.track_reference_view = first
+        r.inverse_depth = np.zeros(nt)
+        return r
+
+    def NumViews(self):
+        return self.cam_ext.shape[0]
+
+    def NumTracks(self):
+        return self.points.shape[0]
+
+    def ViewIds(self):
+        return list(range(self.NumViews()))
+
+    def TrackIds(self):
+        return list(range(self.NumTracks()))
+
+
+def _flatten(recon, view_ids, track_ids, const_view_ids=()):
+    """BundleAdjuster::AddView (:116-173) for `view_ids` (+ const views), then
+    AddTrack (:175-221) for `track_ids`."""
+    nv, nt = recon.NumViews(), recon.NumTracks()
+    view_added = np.zeros(nv, dtype=bool)
+    vi = np.asarray(list(view_ids) + list(const_view_ids), dtype=np.int64)
+    if len(vi):
+        if vi.min() < 0 or vi.max() >= nv:
+            raise capi.TheiaHipError(-1, "view id out of range (reference: CHECK_NOTNULL aborts)")
+        view_added[vi] = True
+    view_added &= recon.view_estimated
+    track_added = np.zeros(nt, dtype=bool)
+    ti = np.asarray(list(track_ids), dtype=np.int64)
+    if len(ti):
+        if ti.min() < 0 or ti.max() >= nt:
+            raise capi.TheiaHipError(-1, "track id out of range (reference: CHECK_NOTNULL aborts)")
+        track_added[ti] = True
+    track_added &= recon.track_estimated
+    ov, ot = recon.obs_view, recon.obs_track
+    est = recon.view_estimated[ov] & recon.track_estimated[ot]
+    keep = est & (view_added[ov] | track_added[ot])
+    cam_const = np.zeros(nv, dtype=np.uint8)
+    # cameras reached only through AddTrack are frozen (:204)
+    cam_const[~view_added] = capi_const_all()
+    if len(const_view_ids):
+        cam_const[np.asarray(list(const_view_ids), dtype=np.int64)] = capi_const_all()
+    point_const = (~track_added).astype(np.uint8)  # SetTrackConstant (:149) unless AddTrack'ed
+    sqrt_info = None
+    cov = recon.obs_cov[keep]
+    if len(cov) and not np.all(cov == 1.0):
+        sqrt_info = 1.0 / np.sqrt(cov)
+    return capi.FlatProblem(recon.cam_ext.copy(), recon.group_intrinsics.copy(), recon.group_model,
+                            recon.view_group, recon.points.copy(), recon.obs_uv[keep], ov[keep], ot[keep],
+                            cam_const=cam_const, point_const=point_const, obs_sqrt_info=sqrt_info)
+
+
+def capi_const_all():
+    return 0x3
+
+
+def _update_inverse_depth(recon, track_ids):
+    """UpdateInverseDepth (bundle_adjustment.cc:69-83): inverse depth of the
+    track in its reference view, Camera::ProjectPoint depth (camera.cc:206-216)."""
+    ti = np.asarray(list(track_ids), dtype=np.int64)
+    if not len(ti):
+        return
+    ti = ti[recon.track_estimated[ti]]
+    ref = recon.track_reference_view[ti]
+    ok = ref != kInvalidViewId
+    ti, ref = ti[ok], ref[ok]
+    if not len(ti):
+        return
+    X = recon.points[ti]
+    ce = recon.cam_ext[ref]
+    R = angle_axis_to_matrix(ce[:, 3:6])
+    p = X[:, :3] - X[:, 3:4] * ce[:, :3]
+    depth = np.einsum("nj,nj->n", R[:, 2, :], p) / X[:, 3]
+    recon.inverse_depth[ti] = 1.0 / depth
+
+
+def _run(options, recon, flat):
+    s, _ = _ba.solve(flat, options.to_c())
+    recon.cam_ext[:] = flat.cam_ext
+    recon.points[:] = flat.points
+    return BundleAdjustmentSummary(s)
+
+
+def BundleAdjustReconstruction(options, reconstruction):
+    """bundle_adjustment.cc:188-217 (argument order of the pybind wrapper)."""
+    flat = _flatten(reconstruction, reconstruction.ViewIds(), reconstruction.TrackIds())
+    summary = _run(options, reconstruction, flat)
+    _update_inverse_depth(reconstruction, reconstruction.TrackIds())
+    return summary
+
+
+def BundleAdjustPartialReconstruction(options, view_ids, track_ids, reconstruction):
+    """bundle_adjustment.cc:111-143."""
+    flat = _flatten(reconstruction, view_ids, track_ids)
+    summary = _run(options, reconstruction, flat)
+    # reference quirk (:134-135): the post-update list carries len(track_ids)
+    # leading zeros, i.e. track 0 is also "updated" -- harmless, reproduced.
+    post = ([0] if len(list(track_ids)) and reconstruction.NumTracks() else []) + list(track_ids)
+    _update_inverse_depth(reconstruction, post)
+    return summary
+
+
+def BundleAdjustPartialViewsConstant(options, var_view_ids, const_view_ids, reconstruction):
+    """bundle_adjustment.cc:146-185."""
+    flat = _flatten(reconstruction, var_view_ids, reconstruction.TrackIds(), const_view_ids=const_view_ids)
+    summary = _run(options, reconstruction, flat)
+    _update_inverse_depth(reconstruction, reconstruction.TrackIds())
+    return summary
+
+
+def BundleAdjustViews(reconstruction, options, view_ids):
+    """bundle_adjustment.cc:240-258 (wrapper argument order :14-17)."""
+    flat = _flatten(reconstruction, view_ids, [])
+    return _run(options, reconstruction, flat)
+
+
+def BundleAdjustView(reconstruction, options, view_id):
+    """bundle_adjustment.cc:220-237."""
+    return BundleAdjustViews(reconstruction, options, [view_id])
+
+
+def BundleAdjustTracks(reconstruction, options, track_ids):
+    """bundle_adjustment.cc:389-418."""
+    flat = _flatten(reconstruction, [], track_ids)
+    summary = _run(options, reconstruction, flat)
+    _update_inverse_depth(reconstruction, track_ids)
+    return summary
+
+
+def BundleAdjustTrack(reconstruction, options, track_id):
+    """bundle_adjustment.cc:261-285."""
+    return BundleAdjustTracks(reconstruction, options, [track_id])

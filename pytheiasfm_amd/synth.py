@@ -266,3 +266,58 @@ def shard_tracks(problem, rank, world_size):
                         problem.obs_cam[sel], problem.obs_pt[sel] - lo, cam_const=problem.cam_const,
                         group_const=problem.group_const, point_const=pc, obs_sqrt_info=si, flags=problem.flags | 1)
     return shard, np.arange(lo, hi)
+
+
+# --------------------------------------------------------------------- RANSAC
+def _random_rotations(stream, idx, max_angle_rad):
+    ax = np.stack([stream.normal(4 * idx), stream.normal(4 * idx + 1), stream.normal(4 * idx + 2)], axis=1)
+    ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    ang = max_angle_rad * stream.uniform(4 * idx + 3)
+    return angle_axis_to_matrix(ax * ang[:, None])
+
+
+def synth_ransac_v1(num_problems, num_corr, kind="relative", seed=0x5AC50000, focal=1000.0,
+                    noise_px=1.0, inlier_lo=0.3, inlier_hi=0.8):
+    """SURVEY.md 8(d) "synth_ransac_v1" (config C5): per problem a random pose
+    (rotation <= 30 deg, unit baseline), 3-D points in a frustum of depth
+    [4, 10], inlier ratio U[0.3, 0.8], inliers + N(0, 1 px / f) noise, outliers
+    uniform in the normalised image.
+      kind = "relative": data [P*N][4] = (x1 y1 x2 y2), FeatureCorrespondence
+      kind = "absolute": data [P*N][5] = (u v X Y Z),   FeatureCorrespondence2D3D
+    Returns data, offsets, truth dict."""
+    P, N = int(num_problems), int(num_corr)
+    sp = Stream(seed, 11)
+    pi = np.arange(P)
+    R = _random_rotations(sp, pi, np.deg2rad(30.0))                       # (P,3,3)
+    t = np.stack([sp.normal(8 * pi + (1 << 33)), sp.normal(8 * pi + 1 + (1 << 33)), sp.normal(8 * pi + 2 + (1 << 33))], axis=1)
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    ratio = inlier_lo + (inlier_hi - inlier_lo) * sp.uniform(pi + (1 << 34))
+    sd = Stream(seed, 12)
+    gi = np.arange(P * N).reshape(P, N)
+    depth = 4.0 + 6.0 * sd.uniform(6 * gi)
+    x1 = 0.5 * (2.0 * sd.uniform(6 * gi + 1) - 1.0)
+    y1 = 0.5 * (2.0 * sd.uniform(6 * gi + 2) - 1.0)
+    X = np.stack([x1 * depth, y1 * depth, depth], axis=2)                 # (P,N,3) in camera-1 / world frame
+    X2 = np.einsum("pij,pnj->pni", R, X) + t[:, None, :]
+    x2 = X2[:, :, :2] / X2[:, :, 2:3]
+    sig = noise_px / focal
+    is_in = (np.arange(N)[None, :] < np.floor(ratio * N)[:, None])
+    nz = np.stack([sd.normal(4 * gi + (1 << 40)), sd.normal(4 * gi + 1 + (1 << 40)),
+                   sd.normal(4 * gi + 2 + (1 << 40)), sd.normal(4 * gi + 3 + (1 << 40))], axis=2) * sig
+    out2 = np.stack([2.0 * sd.uniform(6 * gi + 3) - 1.0, 2.0 * sd.uniform(6 * gi + 4) - 1.0], axis=2) * 0.6
+    if kind == "relative":
+        a = np.stack([x1, y1], axis=2) + nz[:, :, :2]
+        b = np.where(is_in[:, :, None], x2 + nz[:, :, 2:], out2)
+        data = np.concatenate([a, b], axis=2).reshape(P * N, 4)
+    elif kind == "absolute":
+        uv = np.where(is_in[:, :, None], x2 + nz[:, :, 2:], out2)
+        data = np.concatenate([uv, X], axis=2).reshape(P * N, 5)
+    else:
+        raise ValueError(kind)
+    # shuffle within each problem so inliers are not a prefix
+    perm = np.argsort(sd.uniform(gi + (1 << 44)), axis=1)
+    data = data.reshape(P, N, -1)[np.arange(P)[:, None], perm].reshape(P * N, -1)
+    is_in = is_in[np.arange(P)[:, None], perm]
+    offsets = (np.arange(P + 1) * N).astype(np.int64)
+    truth = {"R": R, "t": t, "position": -np.einsum("pji,pj->pi", R, t), "inlier": is_in, "ratio": ratio}
+    return np.ascontiguousarray(data), offsets, truth

@@ -99,3 +99,111 @@ def solve(problem, options, trace_capacity=256):
     assert rc == 0, rc
     tr.finish(s)
     return s, tr
+
+
+# ------------------------------------------------------------------ RANSAC
+def _ransac_sigs(L):
+    if getattr(L, "_ransac_ready", False):
+        return
+    dp, ip = capi.c_double_p, capi.c_int32_p
+    L.oracle_mt_randint_stream.argtypes = [C.c_uint32, C.c_int, ip, ip, ip]
+    L.oracle_sampler_stream.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int, ip]
+    L.oracle_five_point.argtypes = [dp, dp]
+    L.oracle_p3p.argtypes = [dp, dp, dp]
+    L.oracle_estimate_models.argtypes = [C.c_int, dp, dp]
+    L.oracle_model_error.argtypes = [C.c_int, dp, dp]
+    L.oracle_model_error.restype = C.c_double
+    L.oracle_svd3.argtypes = [dp, dp, dp, dp]
+    L.oracle_eig.argtypes = [C.c_int, dp, dp, dp, dp]
+    L.oracle_poly_roots.argtypes = [dp, C.c_int, dp]
+    L.oracle_ransac_estimate.argtypes = [C.c_int, dp, C.c_int, C.POINTER(capi.RansacParams), dp, capi.c_uint8_p, ip, ip, dp,
+                                         capi.c_int64_p, C.c_int32, ip, dp, ip, ip]
+    L._ransac_ready = True
+
+
+def rlib():
+    L = load()
+    _ransac_sigs(L)
+    return L
+
+
+def randint_stream(seed, lo, hi):
+    lo = np.ascontiguousarray(lo, dtype=np.int32); hi = np.ascontiguousarray(hi, dtype=np.int32)
+    out = np.zeros(len(lo), dtype=np.int32)
+    rlib().oracle_mt_randint_stream(seed, len(lo), capi.ptr(lo, C.c_int32), capi.ptr(hi, C.c_int32), capi.ptr(out, C.c_int32))
+    return out
+
+
+def sampler_stream(seed, N, m, iters):
+    out = np.zeros((iters, m), dtype=np.int32)
+    rlib().oracle_sampler_stream(seed, N, m, iters, capi.ptr(out, C.c_int32))
+    return out
+
+
+def five_point(corr):
+    corr = np.ascontiguousarray(corr, dtype=np.float64).reshape(5, 4)
+    E = np.zeros((10, 3, 3))
+    n = rlib().oracle_five_point(capi.ptr(corr, C.c_double), capi.ptr(E, C.c_double))
+    return E[:n]
+
+
+def p3p(corr):
+    corr = np.ascontiguousarray(corr, dtype=np.float64).reshape(3, 5)
+    R = np.zeros((4, 3, 3)); t = np.zeros((4, 3))
+    n = rlib().oracle_p3p(capi.ptr(corr, C.c_double), capi.ptr(R, C.c_double), capi.ptr(t, C.c_double))
+    return R[:n], t[:n]
+
+
+def estimate_models(est, subset):
+    subset = np.ascontiguousarray(subset, dtype=np.float64)
+    m = np.zeros((10, 21))
+    n = rlib().oracle_estimate_models(est, capi.ptr(subset, C.c_double), capi.ptr(m, C.c_double))
+    return m[:n]
+
+
+def svd3(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    U = np.zeros((3, 3)); S = np.zeros(3); V = np.zeros((3, 3))
+    rlib().oracle_svd3(capi.ptr(A, C.c_double), capi.ptr(U, C.c_double), capi.ptr(S, C.c_double), capi.ptr(V, C.c_double))
+    return U, S, V
+
+
+def eig(A, vectors=True):
+    A = np.ascontiguousarray(A, dtype=np.float64).copy()
+    n = A.shape[0]
+    wr = np.zeros(n); wi = np.zeros(n); V = np.zeros((n, n))
+    ok = rlib().oracle_eig(n, capi.ptr(A, C.c_double), capi.ptr(wr, C.c_double), capi.ptr(wi, C.c_double),
+                           capi.ptr(V, C.c_double) if vectors else None)
+    return ok, wr, wi, V
+
+
+def poly_roots(poly):
+    poly = np.ascontiguousarray(poly, dtype=np.float64)
+    out = np.zeros(max(1, len(poly)))
+    n = rlib().oracle_poly_roots(capi.ptr(poly, C.c_double), len(poly), capi.ptr(out, C.c_double))
+    return out[:n]
+
+
+def default_ransac_params(error_thresh, seed=0):
+    p = capi.RansacParams()
+    p.error_thresh = error_thresh; p.failure_probability = 0.01; p.min_inlier_ratio = 0.0
+    p.min_iterations = 100; p.max_iterations = 2 ** 31 - 1; p.use_mle = 0; p.use_lo = 0
+    p.lo_start_iterations = 50; p.use_Tdd_test = 0; p.seed = seed
+    return p
+
+
+def ransac_estimate(est, data, params, trace_capacity=0):
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    n = data.shape[0]
+    model = np.zeros(21); mask = np.zeros(n, dtype=np.uint8)
+    ninl = C.c_int32(0); nit = C.c_int32(0); conf = C.c_double(0); scored = C.c_int64(0)
+    cap = max(1, trace_capacity)
+    ti = np.zeros(cap, dtype=np.int32); tc = np.zeros(cap); tn = np.zeros(cap, dtype=np.int32); ts = C.c_int32(0)
+    ok = rlib().oracle_ransac_estimate(est, capi.ptr(data, C.c_double), n, C.byref(params), capi.ptr(model, C.c_double),
+                                       capi.ptr(mask, C.c_uint8), C.byref(ninl), C.byref(nit), C.byref(conf), C.byref(scored),
+                                       trace_capacity, capi.ptr(ti, C.c_int32), capi.ptr(tc, C.c_double),
+                                       capi.ptr(tn, C.c_int32), C.byref(ts))
+    k = ts.value
+    return {"success": ok, "model": model, "inlier_mask": mask, "num_inliers": ninl.value, "num_iterations": nit.value,
+            "confidence": conf.value, "models_scored": scored.value,
+            "trace": (ti[:k].copy(), tc[:k].copy(), tn[:k].copy())}
