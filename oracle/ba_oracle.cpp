@@ -213,9 +213,10 @@ inline bool eucm_project(const T* k, const T* p, T* pixel) {
   T dp[2];
   bool zero = false;
   if (norm < 1e-3) zero = true;
-  if (alpha > 0.5) {
+  if (!zero && alpha > 0.5) {
+    const T zn = p[2] / norm;
     const T c = (alpha - 1.0) / (alpha + alpha - 1.0);
-    if (p[2] < c * rho) zero = true;  // reference: zero output, returns true
+    if (zn < c) zero = true;  // reference: zero output, returns true
   }
   if (zero) { dp[0] = T(0.0); dp[1] = T(0.0); }
   else { dp[0] = p[0] / norm; dp[1] = p[1] / norm; }
@@ -605,7 +606,7 @@ bool dense_cholesky_solve(int n, std::vector<double>& A, std::vector<double>& b)
 // following ceres SchurEliminator: per point chunk
 //   ete = sum E^T E + D_p^2 ; lhs -= (F^T E) ete^-1 (E^T F) ; rhs -= (F^T E) ete^-1 (E^T b)
 // with lhs initialised to block-diag(F^T F + D_c^2).
-bool build_reduced(Oracle& o, double radius) {
+bool build_reduced(Oracle& o, double radius, bool add_cam_diag = true) {
   const oba_problem& P = *o.P; const int pd = o.pd;
   const int n = 6 * o.ncv;
   o.S.assign((size_t)n * n, 0.0); o.rhs.assign(n, 0.0);
@@ -622,8 +623,9 @@ bool build_reduced(Oracle& o, double radius) {
       o.rhs[6 * rc + a] += J[a] * o.r[2 * i] + J[6 + a] * o.r[2 * i + 1];
     }
   }
-  for (int c = 0; c < o.nc; ++c) { const int rc = o.cam_red[c]; if (rc < 0) continue;
-    for (int a = 0; a < 6; ++a) o.S[(size_t)(6 * rc + a) * n + 6 * rc + a] += o.diag_c[6 * c + a] / radius; }
+  if (add_cam_diag)
+    for (int c = 0; c < o.nc; ++c) { const int rc = o.cam_red[c]; if (rc < 0) continue;
+      for (int a = 0; a < 6; ++a) o.S[(size_t)(6 * rc + a) * n + 6 * rc + a] += o.diag_c[6 * c + a] / radius; }
   // eliminate points
   std::vector<double> W;  // per obs of the point: F^T E (6 x pd)
   for (int p = 0; p < o.np; ++p) {
@@ -795,6 +797,39 @@ int oracle_ba_reduced_system(const oba_problem* P, const oba_options* O, double 
   const int n = 6 * o.ncv; *n_out = n;
   if ((int64_t)n * n > capacity) return -1;
   std::copy(o.S.begin(), o.S.end(), S); std::copy(o.rhs.begin(), o.rhs.end(), rhs);
+  return 0;
+}
+
+// Multi-rank protocol pieces (what each rank computes before / after the
+// all-reduce of the sharded path; used by the world_size-2 gloo test):
+//  1. unscaled squared camera column norms of this shard        [6 * nc]
+//  2. with the GLOBAL (summed) norms -> Jacobi scale, this shard's partial
+//     reduced system WITHOUT the camera LM diagonal, and this shard's scaled
+//     squared camera column norms (summed over ranks, they give that diagonal).
+int oracle_ba_colnorms(const oba_problem* P, const oba_options* O, double* colsq_c) {
+  Oracle o; int rc = setup(o, P, O); if (rc) return rc;
+  double c; if (!evaluate(o, o.cam, o.pts, true, &c)) return -5;
+  column_norms(o, o.diag_c, o.diag_p);
+  std::copy(o.diag_c.begin(), o.diag_c.end(), colsq_c);
+  return 0;
+}
+
+int oracle_ba_reduced_partial(const oba_problem* P, const oba_options* O, double radius, const double* colsq_c_global,
+                              int32_t* n_out, double* S, double* rhs, double* colsq_scaled, int64_t capacity) {
+  Oracle o; int rc = setup(o, P, O); if (rc) return rc;
+  double c; if (!evaluate(o, o.cam, o.pts, true, &c)) return -5;
+  column_norms(o, o.diag_c, o.diag_p);
+  for (size_t i = 0; i < o.scale_c.size(); ++i) o.scale_c[i] = 1.0 / (1.0 + std::sqrt(colsq_c_global[i]));
+  for (size_t i = 0; i < o.scale_p.size(); ++i) o.scale_p[i] = 1.0 / (1.0 + std::sqrt(o.diag_p[i]));
+  apply_scaling(o);
+  column_norms(o, o.diag_c, o.diag_p);
+  for (auto& d : o.diag_p) d = std::min(std::max(d, 1e-6), 1e32);
+  if (!build_reduced(o, radius, false)) return -5;
+  const int n = 6 * o.ncv; *n_out = n;
+  if ((int64_t)n * n > capacity) return -1;
+  std::copy(o.S.begin(), o.S.end(), S); std::copy(o.rhs.begin(), o.rhs.end(), rhs);
+  for (int cidx = 0; cidx < o.nc; ++cidx) { const int r = o.cam_red[cidx]; if (r < 0) continue;
+    for (int a = 0; a < 6; ++a) colsq_scaled[6 * r + a] = o.diag_c[6 * cidx + a]; }
   return 0;
 }
 

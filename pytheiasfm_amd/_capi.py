@@ -120,6 +120,15 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
             "(pytheiasfm_amd has no CPU fallback)")
+    # Processes that also use torch (bench.py, the RCCL all-reduce callback) must
+    # map torch's bundled HIP runtime BEFORE this library binds libamdhip64.so.7:
+    # the reverse order leaves torch with "No HIP GPUs are available" (two HIP
+    # runtimes in one process; measured on the MI355X box).
+    if os.environ.get("THEIA_HIP_NO_TORCH_PRELOAD", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     L.theia_hip_last_error.restype = C.c_char_p
     L.theia_hip_version.restype = C.c_char_p

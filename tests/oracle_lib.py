@@ -88,6 +88,35 @@ def reduced_system(problem, options, radius):
     return S[: n * n].reshape(n, n).copy(), rhs[:n].copy()
 
 
+def reduced_system_partial(shard, options, radius, colsq_c_global):
+    """One rank's partial reduced system (no camera LM diagonal) + its scaled
+    camera column norms, given the globally summed unscaled column norms."""
+    L = load()
+    dp = capi.c_double_p
+    L.oracle_ba_reduced_partial.argtypes = [C.POINTER(capi.BaProblem), C.POINTER(capi.BaOptions), C.c_double, dp,
+                                            capi.c_int32_p, dp, dp, dp, C.c_int64]
+    ncam = shard.cam_ext.shape[0]
+    cap = (6 * ncam) ** 2
+    S = np.zeros(cap); rhs = np.zeros(6 * ncam); cs = np.zeros(6 * ncam); n = C.c_int32(0)
+    st = shard.as_struct()
+    g = np.ascontiguousarray(colsq_c_global, dtype=np.float64)
+    rc = L.oracle_ba_reduced_partial(C.byref(st), C.byref(options), radius, capi.ptr(g, C.c_double), C.byref(n),
+                                     capi.ptr(S, C.c_double), capi.ptr(rhs, C.c_double), capi.ptr(cs, C.c_double), cap)
+    assert rc == 0, rc
+    n = n.value
+    return S[: n * n].reshape(n, n).copy(), rhs[:n].copy(), cs[:n].copy()
+
+
+def colnorms(problem, options):
+    L = load()
+    L.oracle_ba_colnorms.argtypes = [C.POINTER(capi.BaProblem), C.POINTER(capi.BaOptions), capi.c_double_p]
+    out = np.zeros(6 * problem.cam_ext.shape[0])
+    st = problem.as_struct()
+    rc = L.oracle_ba_colnorms(C.byref(st), C.byref(options), capi.ptr(out, C.c_double))
+    assert rc == 0, rc
+    return out
+
+
 def solve(problem, options, trace_capacity=256):
     """Runs the oracle LM loop; problem parameters are updated in place."""
     L = load()

@@ -1,0 +1,43 @@
+"""GPU: the all-reduce callback path of the sharded BA solve with a
+world_size-1 RCCL group (one GPU box): device-pointer wrapping, the library's
+own stream, and the SUM / MAX protocol -- results must equal the plain solve."""
+import os
+
+import numpy as np
+import pytest
+
+from pytheiasfm_amd import ba, distributed as tdist, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_allreduce_callback_path_world_size_1():
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 1000))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        p = synth.synth_ba_v1(16, 800, seed=81)
+        shard, ids = synth.shard_tracks(p, 0, 1)
+        o = ba.default_options()
+        calls = []
+        cb = tdist.make_torch_allreduce(0)
+
+        def counting(ptr, count, op, stream):
+            calls.append((count, op))
+            return cb(ptr, count, op, stream)
+
+        with ba.BaHandle(shard, o) as h:
+            h.set_allreduce(counting)
+            s, tr = h.run()
+            out = h.download(shard.copy())
+        ref = p.copy()
+        s0, tr0 = ba.solve(ref, o)
+        assert s.num_iterations == s0.num_iterations and abs(s.final_cost - s0.final_cost) <= 1e-9 * s0.final_cost
+        assert np.abs(out.cam_ext - ref.cam_ext).max() <= 1e-8 and np.abs(out.points - ref.points).max() <= 1e-8
+        n = 6 * 16
+        assert (n * n + 3 * n + 8, tdist.REDUCE_SUM) in calls and (8, tdist.REDUCE_MAX) in calls
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,124 @@
+"""CPU: host-side logic -- synthetic generators, the AddView/AddTrack
+flattening of the Python mirror, track sharding, and the world_size-2 (gloo)
+reduction algebra of the multi-GPU path."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from pytheiasfm_amd import _capi as capi, sfm, synth
+from tests import oracle_lib as ol
+
+
+def digest(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()[:16]
+
+
+def test_synth_ba_is_deterministic_and_well_formed():
+    a = synth.ba_config("C1"); b = synth.ba_config("C1")
+    assert digest(a.cam_ext, a.points, a.obs_uv, a.obs_cam, a.obs_pt) == digest(b.cam_ext, b.points, b.obs_uv, b.obs_cam, b.obs_pt)
+    assert a.cam_ext.shape == (20, 6) and a.points.shape == (2000, 4)
+    L = np.bincount(a.obs_pt, minlength=2000)
+    assert L.min() >= 2 and L.max() <= 10 and 5.0 < L.mean() < 7.0
+    assert (a.obs_uv[:, 0] > -5).all() and (a.obs_uv[:, 0] < 1925).all()
+    # every track observes distinct cameras
+    key = a.obs_pt.astype(np.int64) * 1000 + a.obs_cam
+    assert len(np.unique(key)) == len(key)
+
+
+def test_synth_mixed_models_and_gauge():
+    p = synth.synth_ba_v1(16, 200, seed=3, mixed_models=True, fix_gauge=True)
+    assert set(p.group_model.tolist()) == {0, 5}
+    assert p.cam_const[0] == 3 and p.cam_const[8] == 3 and p.cam_const.sum() == 6
+
+
+def test_flatten_matches_add_view_add_track_semantics():
+    p = synth.synth_ba_v1(6, 40, seed=5, num_groups=2)
+    rec = sfm.Reconstruction.from_flat(p)
+    rec.view_estimated[5] = False
+    rec.track_estimated[7] = False
+    # BundleAdjustPartialReconstruction(views {0,1}, tracks {0..9})
+    flat = sfm._flatten(rec, [0, 1], list(range(10)))
+    ov, ot = flat.obs_cam, flat.obs_pt
+    assert not np.any(ov == 5) and not np.any(ot == 7)          # unestimated blocks add nothing
+    in_view = np.isin(ov, [0, 1]); in_track = np.isin(ot, np.arange(10))
+    assert np.all(in_view | in_track)                           # only AddView or AddTrack residuals
+    full = (p.obs_cam != 5) & (p.obs_pt != 7) & (np.isin(p.obs_cam, [0, 1]) | np.isin(p.obs_pt, np.arange(10)))
+    assert len(ov) == full.sum()
+    assert list(flat.cam_const[:2]) == [0, 0] and np.all(flat.cam_const[2:] == 3)  # AddTrack freezes other cameras (:204)
+    assert np.all(flat.point_const[:10][rec.track_estimated[:10]] == 0) and np.all(flat.point_const[10:] == 1)
+    with pytest.raises(capi.TheiaHipError):
+        sfm._flatten(rec, [99], [])
+
+
+def test_options_mirror_defaults_and_unsupported():
+    o = sfm.BundleAdjustmentOptions()
+    assert o.loss_function_type == sfm.LossFunctionType.TRIVIAL and o.use_inner_iterations and o.max_num_iterations == 100
+    assert o.intrinsics_to_optimize == sfm.OptimizeIntrinsicsType.NONE and o.use_homogeneous_point_parametrization
+    o.use_position_priors = True
+    with pytest.raises(capi.TheiaHipError):
+        o.to_c()
+
+
+def test_shard_tracks_partitions_every_track_once():
+    p = synth.ba_config("C1")
+    seen = np.zeros(2000, dtype=int); work = []
+    for r in range(4):
+        sh, ids = synth.shard_tracks(p, r, 4)
+        seen[ids] += 1
+        assert sh.flags & 1 and sh.cam_ext.shape == p.cam_ext.shape
+        assert np.array_equal(sh.points, p.points[ids])
+        L = np.bincount(sh.obs_pt, minlength=len(ids))
+        work.append(float((L * L).sum()))
+        assert sh.obs_uv.shape[0] == np.isin(p.obs_pt, ids).sum()
+    assert np.all(seen == 1)
+    assert max(work) / min(work) < 1.2
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pytheiasfm_amd import distributed as tdist
+    p = synth.synth_ba_v1(8, 120, seed=0xBA5E0300, num_groups=2)
+    o = ol.default_options()
+    sh, ids = synth.shard_tracks(p, rank, world)
+    # the protocol of the sharded GPU path: all-reduce the unscaled camera column
+    # norms (Jacobi scaling), then all-reduce [S | rhs | scaled column norms]
+    allreduce = tdist.make_host_allreduce()
+    colsq = ol.colnorms(sh, o)
+    allreduce(colsq)
+    S, rhs, cs = ol.reduced_system_partial(sh, o, 1e4, colsq)
+    n = S.shape[0]
+    buf = np.concatenate([S.ravel(), rhs, cs])
+    allreduce(buf)
+    S = buf[: n * n].reshape(n, n) + np.diag(np.clip(buf[n * n + n:], 1e-6, 1e32) / 1e4)  # finalize step
+    buf = np.concatenate([S.ravel(), buf[n * n: n * n + n]])
+    pts = tdist.gather_points(sh.points, ids, p.points.shape[0])
+    if rank == 0:
+        Sf, rf = ol.reduced_system(p, o, 1e4)
+        n = Sf.shape[0]
+        q.put((float(np.abs(buf[: n * n].reshape(n, n) - Sf).max() / np.abs(Sf).max()),
+               float(np.abs(buf[n * n:] - rf).max() / np.abs(rf).max()), bool(np.array_equal(pts, p.points))))
+    dist.destroy_process_group()
+
+
+def test_world_size_2_reduction_of_the_reduced_camera_system():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = q.get(timeout=180)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    s_err, r_err, pts_ok = res
+    assert s_err < 1e-12 and r_err < 1e-10 and pts_ok

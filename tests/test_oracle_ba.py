@@ -1,0 +1,239 @@
+"""CPU: pins the BA oracle (oracle/ba_oracle.cpp): Jet Jacobians against
+finite differences, manifold / loss identities, Schur step against the dense
+normal equations, the LM loop against scipy, and the reference's threshold
+tests (bundle_adjustment_test.cc:76-115,117-207)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from pytheiasfm_amd import _capi as capi, synth
+from tests import oracle_lib as ol
+
+MODELS = {
+    0: np.array([900.0, 1.02, 0.3, 640.0, 480.0, -0.05, 0.01]),                      # pinhole
+    5: np.array([600.0, 0.98, 0.1, 640.0, 480.0, -0.2, 0.55]),                       # double sphere
+    6: np.array([600.0, 1.0, 0.0, 640.0, 480.0, 0.6, 1.1]),                          # EUCM
+    2: np.array([500.0, 1.0, 0.0, 640.0, 480.0, 0.01, -0.002, 0.001, 0.0005, 0.0]),  # fisheye (9 used)
+    1: np.array([800.0, 1.0, 0.0, 640.0, 480.0, -0.1, 0.02, 0.001, 0.001, -0.002]),  # radial-tangential
+}
+
+
+def numeric_jac(f, x, eps=1e-6):
+    x = np.asarray(x, dtype=np.float64)
+    cols = []
+    for k in range(len(x)):
+        d = np.zeros_like(x); d[k] = eps
+        cols.append((f(x + d) - f(x - d)) / (2 * eps))
+    return np.stack(cols, axis=1)
+
+
+@pytest.mark.parametrize("model", sorted(MODELS))
+@pytest.mark.parametrize("case", ["generic", "small_angle", "w_not_one"])
+def test_jet_jacobian_matches_finite_differences(model, case):
+    intr = MODELS[model][: {0: 7, 5: 7, 6: 7, 2: 9, 1: 10}[model]]
+    ext = np.array([0.3, -0.2, 0.1, 0.21, -0.13, 0.32])
+    X = np.array([0.4, -0.3, 5.0, 1.0])
+    if case == "small_angle":
+        ext[3:] = [1e-9, -2e-9, 5e-10]  # first-order branch of AngleAxisRotatePoint
+    if case == "w_not_one":
+        X = np.array([0.8, -0.6, 10.0, 2.0])
+    uv = np.array([700.0, 400.0])
+    ok, res, Je, Ji, Jp = ol.reprojection_error(model, ext, intr, X, uv, sqrt_info=[0.5, 2.0])
+    assert ok == 1
+    fe = lambda e: ol.reprojection_error(model, e, intr, X, uv, [0.5, 2.0])[1]
+    fx = lambda x: ol.reprojection_error(model, ext, intr, x, uv, [0.5, 2.0])[1]
+    fi = lambda k: ol.reprojection_error(model, ext, k, X, uv, [0.5, 2.0])[1]
+    scale = max(1.0, np.abs(Je).max())
+    if case != "small_angle":  # central differences straddle the branch point there
+        assert np.abs(numeric_jac(fe, ext) - Je).max() < 2e-6 * scale
+    else:
+        assert np.abs(numeric_jac(fe, ext)[:, :3] - Je[:, :3]).max() < 2e-6 * scale
+    assert np.abs(numeric_jac(fx, X) - Jp).max() < 2e-6 * max(1.0, np.abs(Jp).max())
+    assert np.abs(numeric_jac(fi, intr, eps=1e-7) - Ji).max() < 1e-5 * max(1.0, np.abs(Ji).max())
+
+
+def test_functor_rejects_point_at_camera_centre_and_double_sphere_cone():
+    ext = np.array([1.0, 2.0, 3.0, 0.1, 0.2, 0.3])
+    ok, *_ = ol.reprojection_error(0, ext, MODELS[0], np.array([1.0, 2.0, 3.0 + 1e-5, 1.0]), np.zeros(2))
+    assert ok == 0  # reprojection_error.h:78-80
+    ok, *_ = ol.reprojection_error(5, np.zeros(6), MODELS[5], np.array([0.0, 0.1, -5.0, 1.0]), np.zeros(2))
+    assert ok == 0  # double_sphere_camera_model.h:233-235
+    ok, *_ = ol.reprojection_error(0, np.zeros(6), MODELS[0], np.array([0.1, 0.1, -5.0, 1.0]), np.zeros(2))
+    assert ok == 1  # pinhole never reports invalid (pinhole_camera_model.h:210)
+
+
+def test_sphere_manifold_identities():
+    L = ol.load()
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        x = rng.standard_normal(4) * 3
+        out = np.zeros(4); z = np.zeros(3)
+        L.oracle_sphere_plus(capi.ptr(x, C.c_double), capi.ptr(z, C.c_double), capi.ptr(out, C.c_double))
+        assert np.array_equal(out, x)
+        d = rng.standard_normal(3) * 0.3
+        L.oracle_sphere_plus(capi.ptr(x, C.c_double), capi.ptr(d, C.c_double), capi.ptr(out, C.c_double))
+        assert abs(np.linalg.norm(out) - np.linalg.norm(x)) < 1e-12 * np.linalg.norm(x)
+        J = np.zeros((4, 3))
+        L.oracle_sphere_plus_jacobian(capi.ptr(x, C.c_double), capi.ptr(J, C.c_double))
+        def plus(dd):
+            o = np.zeros(4)
+            dd = np.ascontiguousarray(dd)
+            L.oracle_sphere_plus(capi.ptr(x, C.c_double), capi.ptr(dd, C.c_double), capi.ptr(o, C.c_double))
+            return o
+        Jn = numeric_jac(plus, np.zeros(3) + 1e-12, eps=1e-6)
+        assert np.abs(Jn - J).max() < 1e-6 * np.linalg.norm(x)
+        assert np.abs(J.T @ x).max() < 1e-12 * np.linalg.norm(x) ** 2  # tangent to the sphere
+
+
+@pytest.mark.parametrize("loss", range(7))
+def test_loss_derivative_consistency(loss):
+    L = ol.load()
+    for s in [0.1, 1.0, 3.9, 4.1, 25.0]:
+        rho = np.zeros(3)
+        L.oracle_loss_evaluate(loss, 2.0, s, capi.ptr(rho, C.c_double))
+        e = 1e-6 * max(1.0, s)
+        r1 = np.zeros(3); r0 = np.zeros(3)
+        L.oracle_loss_evaluate(loss, 2.0, s + e, capi.ptr(r1, C.c_double))
+        L.oracle_loss_evaluate(loss, 2.0, s - e, capi.ptr(r0, C.c_double))
+        if loss == 6 and abs(s - 4.0) < 0.2:
+            continue
+        assert abs((r1[0] - r0[0]) / (2 * e) - rho[1]) < 1e-5
+        assert rho[2] <= 0.0  # corrector reduces to sqrt(rho') scaling (ceres corrector.cc)
+    rho = np.zeros(3)
+    L.oracle_loss_evaluate(0, 2.0, 7.0, capi.ptr(rho, C.c_double))
+    assert list(rho) == [7.0, 1.0, 0.0]
+
+
+def small_problem(nv=6, nt=60, **kw):
+    return synth.synth_ba_v1(nv, nt, seed=0xBA5E0100, num_groups=2, **kw)
+
+
+def dense_system(p, o, radius):
+    """Full (cameras + points) damped normal equations from the oracle's blocks."""
+    ok, cost, r, jc, jp = ol.evaluate(p, o)
+    nobs, nc, npt, pd = len(r), p.cam_ext.shape[0], p.points.shape[0], jp.shape[2]
+    J = np.zeros((2 * nobs, 6 * nc + pd * npt))
+    for i in range(nobs):
+        c, q = p.obs_cam[i], p.obs_pt[i]
+        J[2 * i:2 * i + 2, 6 * c:6 * c + 6] = jc[i]
+        J[2 * i:2 * i + 2, 6 * nc + pd * q:6 * nc + pd * q + pd] = jp[i]
+    cn = np.sqrt((J * J).sum(0))
+    s = 1.0 / (1.0 + cn)
+    Js = J * s
+    diag = np.clip((Js * Js).sum(0), 1e-6, 1e32)
+    A = Js.T @ Js + np.diag(diag / radius)
+    g = Js.T @ r.reshape(-1)
+    return A, g, 6 * nc
+
+
+@pytest.mark.parametrize("manifold", [1, 0])
+def test_schur_step_equals_dense_normal_equations(manifold):
+    p = small_problem()
+    o = ol.default_options(); o.use_homogeneous_point_parametrization = manifold
+    S, rhs = ol.reduced_system(p, o, 1e4)
+    A, g, ncam = dense_system(p, o, 1e4)
+    y = np.linalg.solve(A, g)
+    yc = np.linalg.solve(S, rhs)
+    assert np.abs(yc - y[:ncam]).max() < 1e-8 * np.abs(y[:ncam]).max()
+    assert np.abs(S - S.T).max() < 1e-9 * np.abs(S).max()
+
+
+def test_lm_matches_scipy_on_gauge_fixed_problem():
+    from scipy.optimize import least_squares
+    p = small_problem(nv=4, nt=30, fix_gauge=True)
+    o = ol.default_options()
+    o.function_tolerance = 1e-14; o.gradient_tolerance = 1e-12; o.parameter_tolerance = 1e-14; o.max_num_iterations = 60
+    po = p.copy()
+    s, tr = ol.solve(po, o)
+    assert s.success
+    var_c = np.nonzero(p.cam_const == 0)[0]
+
+    def residuals(x):
+        q = p.copy()
+        q.cam_ext[var_c] = x[: 6 * len(var_c)].reshape(-1, 6)
+        q.points[:, :3] = x[6 * len(var_c):].reshape(-1, 3)
+        return ol.evaluate(q, o)[2].reshape(-1)
+
+    x0 = np.concatenate([p.cam_ext[var_c].ravel(), p.points[:, :3].ravel()])
+    ref = least_squares(residuals, x0, method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    assert abs(0.5 * np.sum(ref.fun ** 2) - s.final_cost) < 1e-9 * s.final_cost
+    cam_ref = ref.x[: 6 * len(var_c)].reshape(-1, 6)
+    assert np.abs(cam_ref - po.cam_ext[var_c]).max() < 1e-6 * np.abs(cam_ref).max()
+    pts = po.points[:, :3] / po.points[:, 3:4]
+    assert np.abs(ref.x[6 * len(var_c):].reshape(-1, 3) - pts).max() < 1e-6 * np.abs(pts).max()
+
+
+def _view_scene(noise, seed):
+    """bundle_adjustment_test.cc TestOptimizeView: 1 camera, 100 points, BundleAdjustView."""
+    st = synth.Stream(seed, 1)
+    i = np.arange(100)
+    pts = np.stack([10 * st.uniform(3 * i) - 5, 10 * st.uniform(3 * i + 1) - 5, 4 + 6 * st.uniform(3 * i + 2), np.ones(100)], 1)
+    cam = np.concatenate([2 * st.uniform(np.arange(3) + 1000) - 1, 0.2 * (2 * st.uniform(np.arange(3) + 2000) - 1)])[None]
+    intr = np.array([[500.0, 1.0, 0.0, 500.0, 500.0, 0.0, 0.0]])
+    uv, ok = synth.project(0, np.repeat(intr, 100, 0), np.repeat(cam, 100, 0), pts)
+    uv = uv + noise * np.stack([st.normal(2 * i + 5000), st.normal(2 * i + 5001)], 1)
+    keep = ok
+    return capi.FlatProblem(cam, intr, [0], [0], pts, uv[keep], np.zeros(keep.sum(), np.int32), i[keep].astype(np.int32),
+                            point_const=np.ones(100, np.uint8))
+
+
+@pytest.mark.parametrize("noise", [0.0, 0.1])
+def test_reference_threshold_optimize_view(noise):
+    p = _view_scene(noise, 52)
+    s, _ = ol.solve(p, ol.default_options())
+    assert s.success
+    n = p.obs_uv.shape[0]
+    assert 2.0 * s.final_cost / n < (1e-15 if noise == 0.0 else noise)
+
+
+@pytest.mark.parametrize("noise", [0.0, 0.5])
+@pytest.mark.parametrize("manifold", [1, 0])
+def test_reference_threshold_optimize_tracks(noise, manifold):
+    """TestOptimizeTracks: 3 fixed cameras, 100 points, BundleAdjustTracks."""
+    st = synth.Stream(53, 2)
+    i = np.arange(100)
+    pts = np.stack([10 * st.uniform(3 * i) - 5, 10 * st.uniform(3 * i + 1) - 5, 4 + 6 * st.uniform(3 * i + 2), np.ones(100)], 1)
+    cams = np.zeros((3, 6)); cams[1, 0] = 1.0; cams[2, 0] = -1.0
+    cams[:, 3:] = 0.001 * (2 * st.uniform(np.arange(9) + 900).reshape(3, 3) - 1)
+    intr = np.array([[500.0, 1.0, 0.0, 500.0, 500.0, 0.0, 0.0]])
+    oc = np.tile(np.arange(3), 100).astype(np.int32); op = np.repeat(i, 3).astype(np.int32)
+    uv, _ = synth.project(0, np.repeat(intr, 300, 0), cams[oc], pts[op])
+    uv = uv + noise * np.stack([st.normal(2 * np.arange(300) + 7000), st.normal(2 * np.arange(300) + 7001)], 1)
+    p = capi.FlatProblem(cams, intr, [0], [0, 0, 0], pts, uv, oc, op, cam_const=np.full(3, 3, np.uint8))
+    o = ol.default_options(); o.use_homogeneous_point_parametrization = manifold
+    s, _ = ol.solve(p, o)
+    assert s.success
+    assert 2.0 * s.final_cost / 300 < (1e-15 if noise == 0.0 else noise)
+
+
+def test_fixed_cost_and_constant_blocks():
+    p = small_problem(nv=5, nt=40)
+    p.cam_const = np.array([3, 0, 0, 3, 0], np.uint8)
+    pc = np.zeros(40, np.uint8); pc[::3] = 1
+    p.point_const = pc
+    o = ol.default_options()
+    ok, cost, r, jc, jp = ol.evaluate(p, o)
+    fixed = (p.cam_const[p.obs_cam] == 3) & (pc[p.obs_pt] == 1)
+    assert fixed.any()
+    assert np.all(jc[p.cam_const[p.obs_cam] == 3] == 0) and np.all(jp[pc[p.obs_pt] == 1] == 0)
+    before = p.copy()
+    s, _ = ol.solve(p, o)
+    assert s.success and s.final_cost < s.initial_cost
+    assert np.array_equal(p.cam_ext[[0, 3]], before.cam_ext[[0, 3]])
+    assert np.array_equal(p.points[pc == 1], before.points[pc == 1])
+    assert not np.array_equal(p.points[pc == 0], before.points[pc == 0])
+
+
+def test_golden_ba_fixture():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ba_small.npz"))
+    p = capi.FlatProblem(g["cam_ext"], g["intrinsics"], g["group_model"], g["cam_group"], g["points"], g["obs_uv"],
+                         g["obs_cam"], g["obs_pt"])
+    o = ol.default_options()
+    S, rhs = ol.reduced_system(p, o, 1e4)
+    assert np.abs(S - g["S"]).max() <= 1e-10 * np.abs(g["S"]).max()
+    s, tr = ol.solve(p, o)
+    assert s.num_iterations == int(g["num_iterations"])
+    assert np.abs(tr.cost - g["trace_cost"]).max() <= 1e-9 * g["trace_cost"].max()
+    assert np.abs(p.cam_ext - g["cam_ext_final"]).max() < 1e-9 and np.abs(p.points - g["points_final"]).max() < 1e-9
