@@ -26,6 +26,8 @@ struct DevProblem {
   const int* obs_pt;           // [nobs]
   const int* tile_start;       // [ntiles]
   const int* tile_count;       // [ntiles]
+  int tiles_per_wg, nwg;       // linearize: workgroup b owns tiles [b*tiles_per_wg, ...)
+  const int* wg_base;          // [nwg] first reduced camera of the workgroup's LDS window
   const double* scale_c;       // [nc][6] Jacobi scaling
   const double* scale_p;       // [np][pd]
 };

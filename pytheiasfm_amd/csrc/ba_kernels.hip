@@ -260,7 +260,19 @@ __global__ void k_make_scale(int count, const double* __restrict__ colsq, double
 }
 
 // -------------------------------------------------- linearize + Schur (K1+K2)
+// One workgroup walks a contiguous range of wave tiles (tracks are sorted by
+// their first camera at create()), so the cameras it touches form a short
+// window [base, base + kWin) of the reduced camera ordering.  All Schur blocks
+// S_ij, the camera diagonal blocks and the per-camera vectors of that window
+// are accumulated in LDS (ds_add_f64) and flushed to HBM ONCE per workgroup;
+// only contributions that leave the window (ring wrap-around, very long
+// tracks) go straight to global FP64 atomics.
 // tile_part layout: [ntiles][4] = {cost, gmax_points, invalid, notpd}
+constexpr int kWin = 16;                       // cameras per LDS window
+constexpr int kWinBlocks = kWin * (kWin + 1) / 2;
+
+THIP_DEV void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
 template <int PD>
 __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double* __restrict__ cam,
                                                       const double* __restrict__ pts, double radius,
@@ -272,141 +284,175 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
   constexpr int NW = 6 * PD;
   __shared__ double sW[kWavesPerBlock][kWave][NW + 1];
   __shared__ int sRc[kWavesPerBlock][kWave];
+  __shared__ double accS[kWinBlocks][36];       // lower block triangle of the window
+  __shared__ double accC[kWin][18];             // per camera: rhs(6) | g_c(6) | colsq(6)
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  const int tile = blockIdx.x * kWavesPerBlock + wv;
-  const bool tile_ok = tile < P.ntiles;
-  const int cnt = tile_ok ? P.tile_count[tile] : 0;
-  const int start = tile_ok ? P.tile_start[tile] : 0;
-  LaneLin<PD> L;
-  lane_linearize<PD, true>(P, cam, pts, start + lane, lane < cnt, lane, L);
-  const Segment sg = lane_segment(L.p, lane);
+  const int n = P.n;
+  const int base = P.wg_base[blockIdx.x];
+  for (int i = threadIdx.x; i < kWinBlocks * 36; i += kBlock) (&accS[0][0])[i] = 0.0;
+  for (int i = threadIdx.x; i < kWin * 18; i += kBlock) (&accC[0][0])[i] = 0.0;
+  __syncthreads();
 
-  // V_p (packed lower) and g_p = E^T r : segmented all-reduce
-  double in[NT + PD], tot[NT + PD];
-#pragma unroll
-  for (int a = 0; a < PD; ++a) {
-#pragma unroll
-    for (int b = 0; b <= a; ++b) in[lidx(a, b)] = L.Jt[a] * L.Jt[b] + L.Jt[PD + a] * L.Jt[PD + b];
-    in[NT + a] = L.Jt[a] * L.r[0] + L.Jt[PD + a] * L.r[1];
-  }
-  segment_allsum<NT + PD>(sg, in, tot);
+  const int tile0 = blockIdx.x * P.tiles_per_wg;
+  for (int rnd = 0; rnd < P.tiles_per_wg; rnd += kWavesPerBlock) {
+    const int tile = tile0 + rnd + wv;
+    const bool tile_ok = (rnd + wv < P.tiles_per_wg) && tile < P.ntiles;
+    const int cnt = tile_ok ? P.tile_count[tile] : 0;
+    const int start = tile_ok ? P.tile_start[tile] : 0;
+    LaneLin<PD> L;
+    lane_linearize<PD, true>(P, cam, pts, start + lane, lane < cnt, lane, L);
+    const Segment sg = lane_segment(L.p, lane);
 
-  double V[NT], Vi[NT], g[PD];
-#pragma unroll
-  for (int k = 0; k < NT; ++k) V[k] = tot[k];
-#pragma unroll
-  for (int a = 0; a < PD; ++a) g[a] = tot[NT + a];
-  // LM diagonal of the point block: clamp(colnorm^2, 1e-6, 1e32) / radius
-#pragma unroll
-  for (int a = 0; a < PD; ++a) V[lidx(a, a)] += fmin(fmax(V[lidx(a, a)], 1e-6), 1e32) / radius;
-  bool pd_ok = true;
-  if (L.active && !L.pconst) pd_ok = invert_spd<PD>(V, Vi);
-  if (!L.active || L.pconst || !pd_ok) {
-#pragma unroll
-    for (int k = 0; k < NT; ++k) Vi[k] = 0.0;
-  }
-  double gmax = 0.0;
-  if (L.active && sg.head && !L.pconst) {
-#pragma unroll
-    for (int k = 0; k < NT; ++k) Vinv[(size_t)NT * L.p + k] = Vi[k];
+    // V_p (packed lower) and g_p = E^T r : segmented all-reduce
+    double in[NT + PD], tot[NT + PD];
 #pragma unroll
     for (int a = 0; a < PD; ++a) {
-      gp[(size_t)PD * L.p + a] = g[a];
-      gmax = fmax(gmax, fabs(g[a] / P.scale_p[(size_t)PD * L.p + a]));
+#pragma unroll
+      for (int b = 0; b <= a; ++b) in[lidx(a, b)] = L.Jt[a] * L.Jt[b] + L.Jt[PD + a] * L.Jt[PD + b];
+      in[NT + a] = L.Jt[a] * L.r[0] + L.Jt[PD + a] * L.r[1];
     }
-  }
+    segment_allsum<NT + PD>(sg, in, tot);
 
-  // W = F^T E (6 x PD), T = W Vinv, y = Vinv g
-  double W[NW], T[NW], y[PD];
+    double V[NT], Vi[NT], g[PD];
 #pragma unroll
-  for (int a = 0; a < 6; ++a)
+    for (int k = 0; k < NT; ++k) V[k] = tot[k];
 #pragma unroll
-    for (int b = 0; b < PD; ++b) W[a * PD + b] = L.Jc[a] * L.Jt[b] + L.Jc[6 + a] * L.Jt[PD + b];
+    for (int a = 0; a < PD; ++a) g[a] = tot[NT + a];
+    // LM diagonal of the point block: clamp(colnorm^2, 1e-6, 1e32) / radius
 #pragma unroll
-  for (int a = 0; a < PD; ++a) {
-    double s = 0.0;
+    for (int a = 0; a < PD; ++a) V[lidx(a, a)] += fmin(fmax(V[lidx(a, a)], 1e-6), 1e32) / radius;
+    bool pd_ok = true;
+    if (L.active && !L.pconst) pd_ok = invert_spd<PD>(V, Vi);
+    if (!L.active || L.pconst || !pd_ok) {
 #pragma unroll
-    for (int b = 0; b < PD; ++b) s += sym_get<PD>(Vi, a, b) * g[b];
-    y[a] = s;
-  }
+      for (int k = 0; k < NT; ++k) Vi[k] = 0.0;
+    }
+    double gmax = 0.0;
+    if (L.active && sg.head && !L.pconst) {
 #pragma unroll
-  for (int a = 0; a < 6; ++a)
+      for (int k = 0; k < NT; ++k) Vinv[(size_t)NT * L.p + k] = Vi[k];
 #pragma unroll
-    for (int b = 0; b < PD; ++b) {
+      for (int a = 0; a < PD; ++a) {
+        gp[(size_t)PD * L.p + a] = g[a];
+        gmax = fmax(gmax, fabs(g[a] / P.scale_p[(size_t)PD * L.p + a]));
+      }
+    }
+
+    // W = F^T E (6 x PD), T = W Vinv, y = Vinv g
+    double W[NW], T[NW], y[PD];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < PD; ++b) W[a * PD + b] = L.Jc[a] * L.Jt[b] + L.Jc[6 + a] * L.Jt[PD + b];
+#pragma unroll
+    for (int a = 0; a < PD; ++a) {
       double s = 0.0;
 #pragma unroll
-      for (int k = 0; k < PD; ++k) s += W[a * PD + k] * sym_get<PD>(Vi, k, b);
-      T[a * PD + b] = s;
+      for (int b = 0; b < PD; ++b) s += sym_get<PD>(Vi, a, b) * g[b];
+      y[a] = s;
     }
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < PD; ++b) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < PD; ++k) s += W[a * PD + k] * sym_get<PD>(Vi, k, b);
+        T[a * PD + b] = s;
+      }
 
-  const int n = P.n;
-  const int rc = L.rc;
-  if (L.active && rc >= 0) {
-    double* Sd = S + (size_t)(6 * rc) * n + 6 * rc;
+    const int rc = L.rc;
+    const int li = rc - base;
+    const bool in_win = li >= 0 && li < kWin;
+    if (L.active && rc >= 0) {
+      double* Sd = in_win ? &accS[lidx(li, li)][0] : S + (size_t)(6 * rc) * n + 6 * rc;
+      const int ldS = in_win ? 6 : n;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      const double jr = L.Jc[a] * L.r[0] + L.Jc[6 + a] * L.r[1];
-      double wy = 0.0;
+      for (int a = 0; a < 6; ++a) {
+        const double jr = L.Jc[a] * L.r[0] + L.Jc[6 + a] * L.r[1];
+        double wy = 0.0;
 #pragma unroll
-      for (int b = 0; b < PD; ++b) wy += W[a * PD + b] * y[b];
-      atomic_add(&rhs[6 * rc + a], jr - wy);
-      atomic_add(&gc[6 * rc + a], jr);
-      atomic_add(&colsq[6 * rc + a], L.Jc[a] * L.Jc[a] + L.Jc[6 + a] * L.Jc[6 + a]);
-#pragma unroll
-      for (int b = 0; b <= a; ++b)
-        atomic_add(&Sd[(size_t)a * n + b], L.Jc[a] * L.Jc[b] + L.Jc[6 + a] * L.Jc[6 + b]);
-    }
-  }
-
-  // stage W of the tile in LDS, then every lane walks its track's segment
-#pragma unroll
-  for (int k = 0; k < NW; ++k) sW[wv][lane][k] = W[k];
-  sRc[wv][lane] = (L.active && !L.pconst) ? rc : -1;
-  __syncthreads();
-  const bool me = L.active && !L.pconst && rc >= 0;
-  for (int j = 0; j < sg.maxlen; ++j) {
-    const int src = (sg.start + j) & 63;
-    const int rcs = sRc[wv][src];
-    const bool take = me && (j < sg.len) && rcs >= 0 && rc >= rcs;
-    if (!take) continue;
-    double Ws[NW];
-#pragma unroll
-    for (int k = 0; k < NW; ++k) Ws[k] = sW[wv][src][k];
-    double* Sb = S + (size_t)(6 * rc) * n + 6 * rcs;
-    if (rc == rcs) {
-#pragma unroll
-      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < PD; ++b) wy += W[a * PD + b] * y[b];
+        const double cs = L.Jc[a] * L.Jc[a] + L.Jc[6 + a] * L.Jc[6 + a];
+        if (in_win) {
+          lds_add(&accC[li][a], jr - wy); lds_add(&accC[li][6 + a], jr); lds_add(&accC[li][12 + a], cs);
+        } else {
+          atomic_add(&rhs[6 * rc + a], jr - wy); atomic_add(&gc[6 * rc + a], jr); atomic_add(&colsq[6 * rc + a], cs);
+        }
 #pragma unroll
         for (int b = 0; b <= a; ++b) {
-          double s = 0.0;
-#pragma unroll
-          for (int k = 0; k < PD; ++k) s += T[a * PD + k] * Ws[b * PD + k];
-          atomic_add(&Sb[(size_t)a * n + b], -s);
+          const double v = L.Jc[a] * L.Jc[b] + L.Jc[6 + a] * L.Jc[6 + b];
+          if (in_win) lds_add(&Sd[a * ldS + b], v); else atomic_add(&Sd[(size_t)a * ldS + b], v);
         }
-    } else {
+      }
+    }
+
+    // stage W of the tile in LDS, then every lane walks its track's segment
+#pragma unroll
+    for (int k = 0; k < NW; ++k) sW[wv][lane][k] = W[k];
+    sRc[wv][lane] = (L.active && !L.pconst) ? rc : -1;
+    __syncthreads();
+    const bool me = L.active && !L.pconst && rc >= 0;
+    for (int j = 0; j < sg.maxlen; ++j) {
+      const int src = (sg.start + j) & 63;
+      const int rcs = sRc[wv][src];
+      const bool take = me && (j < sg.len) && rcs >= 0 && rc >= rcs;
+      if (!take) continue;
+      double Ws[NW];
+#pragma unroll
+      for (int k = 0; k < NW; ++k) Ws[k] = sW[wv][src][k];
+      const int lj = rcs - base;
+      const bool blk_in = in_win && lj >= 0;   // lj <= li < kWin
+      double* Sb = blk_in ? &accS[lidx(li, lj)][0] : S + (size_t)(6 * rc) * n + 6 * rcs;
+      const int ldS = blk_in ? 6 : n;
+      const bool diag = rc == rcs;
 #pragma unroll
       for (int a = 0; a < 6; ++a)
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
+          if (diag && b > a) continue;
           double s = 0.0;
 #pragma unroll
           for (int k = 0; k < PD; ++k) s += T[a * PD + k] * Ws[b * PD + k];
-          atomic_add(&Sb[(size_t)a * n + b], -s);
+          if (blk_in) lds_add(&Sb[a * ldS + b], -s); else atomic_add(&Sb[(size_t)a * ldS + b], -s);
         }
+    }
+    __syncthreads();  // sW / sRc are reused by the next round
+
+    // per-tile partials (reduced in fixed order by k_reduce_tiles)
+    const double cost = wave_sum(L.cost);
+    gmax = wave_max(gmax);
+    const double inval = wave_sum((L.active && !L.valid) ? 1.0 : 0.0);
+    const double npd = wave_sum((L.active && !pd_ok) ? 1.0 : 0.0);
+    if (tile_ok && lane == 0) {
+      tile_part[4 * (size_t)tile + 0] = cost;
+      tile_part[4 * (size_t)tile + 1] = gmax;
+      tile_part[4 * (size_t)tile + 2] = inval;
+      tile_part[4 * (size_t)tile + 3] = npd;
     }
   }
 
-  // per-tile partials (reduced in fixed order by k_reduce_tiles)
-  const double cost = wave_sum(L.cost);
-  gmax = wave_max(gmax);
-  const double inval = wave_sum((L.active && !L.valid) ? 1.0 : 0.0);
-  const double npd = wave_sum((L.active && !pd_ok) ? 1.0 : 0.0);
-  if (tile_ok && lane == 0) {
-    tile_part[4 * (size_t)tile + 0] = cost;
-    tile_part[4 * (size_t)tile + 1] = gmax;
-    tile_part[4 * (size_t)tile + 2] = inval;
-    tile_part[4 * (size_t)tile + 3] = npd;
+  // flush the window to HBM: one FP64 atomic per non-zero accumulator entry
+  __syncthreads();
+  const int ncv = P.ncv;
+  for (int e = threadIdx.x; e < kWinBlocks * 36; e += kBlock) {
+    const double v = (&accS[0][0])[e];
+    if (v == 0.0) continue;
+    const int blk = e / 36, ab = e % 36;
+    int bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;   // blk = bi (bi+1)/2 + bj
+    const int bj = blk - bi * (bi + 1) / 2;
+    if (base + bi >= ncv) continue;
+    atomic_add(&S[(size_t)(6 * (base + bi) + ab / 6) * n + 6 * (base + bj) + ab % 6], v);
+  }
+  for (int e = threadIdx.x; e < kWin * 18; e += kBlock) {
+    const double v = (&accC[0][0])[e];
+    if (v == 0.0) continue;
+    const int c = e / 18, q = e % 18;
+    if (base + c >= ncv) continue;
+    double* dst = q < 6 ? rhs : (q < 12 ? gc : colsq);
+    atomic_add(&dst[6 * (base + c) + q % 6], v);
   }
 }
 
@@ -652,9 +698,9 @@ void launch_linearize(const DevProblem& P, const double* cam, const double* pts,
                       const ReduceBuf& rb, double* Vinv, double* gp, double* tile_part, hipStream_t st) {
   if (P.ntiles == 0) return;
   if (P.pd == 3)
-    k_linearize<3><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, radius, rb.S, rb.rhs, rb.colsq, rb.gc, Vinv, gp, tile_part);
+    k_linearize<3><<<P.nwg, kBlock, 0, st>>>(P, cam, pts, radius, rb.S, rb.rhs, rb.colsq, rb.gc, Vinv, gp, tile_part);
   else
-    k_linearize<4><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, radius, rb.S, rb.rhs, rb.colsq, rb.gc, Vinv, gp, tile_part);
+    k_linearize<4><<<P.nwg, kBlock, 0, st>>>(P, cam, pts, radius, rb.S, rb.rhs, rb.colsq, rb.gc, Vinv, gp, tile_part);
 }
 
 void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,

@@ -89,7 +89,8 @@ struct theia_ba_handle_s {
   std::vector<uint8_t> cam_mask, pt_const;
   // device buffers
   DevBuf<double> cam[2], pts[2], intr, scale_c, scale_p, ones_c, ones_p, colsq_c0, colsq_p0;
-  DevBuf<int> group_model, cam_group, d_cam_red, obs_cam, obs_pt, tile_start, tile_count, f2s, fmaxflag;
+  DevBuf<int> group_model, cam_group, d_cam_red, obs_cam, obs_pt, tile_start, tile_count, f2s, fmaxflag, wg_base;
+  int tiles_per_wg = 4, nwg = 0;
   DevBuf<uint8_t> d_cam_mask, d_pt_const;
   DevBuf<double2> obs_uv, obs_si;
   DevBuf<double> reduce, Vinv, gp, tile_part, scalB;
@@ -148,6 +149,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.cam_red = h->d_cam_red.p; P.cam_mask = h->d_cam_mask.p; P.pt_const = h->d_pt_const.p;
   P.obs_uv = h->obs_uv.p; P.obs_si = h->obs_si.p; P.obs_cam = h->obs_cam.p; P.obs_pt = h->obs_pt.p;
   P.tile_start = h->tile_start.p; P.tile_count = h->tile_count.p;
+  P.tiles_per_wg = h->tiles_per_wg; P.nwg = h->nwg; P.wg_base = h->wg_base.p;
   P.scale_c = h->scale_c.p; P.scale_p = h->scale_p.p;
 }
 
@@ -304,37 +306,49 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   h->n = 6 * h->ncv;
   for (int q = 0; q < h->np; ++q) h->pt_const[q] = ((p->point_const && p->point_const[q]) || !pt_used[q]) ? 1 : 0;
 
-  // observations sorted by track; residual blocks whose blocks are all
-  // constant are evaluated once ("fixed cost", ceres reduced program).
+  // Tracks are visited in the order of their first (lowest) variable camera of
+  // the reduced ordering, so that a workgroup's tile range touches a short
+  // window of cameras (LDS accumulation in k_linearize).  Observations are
+  // sorted by that track order; residual blocks whose blocks are all constant
+  // are evaluated once ("fixed cost", ceres reduced program).
   std::vector<uint8_t> fixed(h->nobs, 0);
-  std::vector<int64_t> cnt_main(h->np + 1, 0), cnt_fix(h->np + 1, 0);
+  std::vector<int> pkey(h->np, std::numeric_limits<int>::max());
   for (int64_t i = 0; i < h->nobs; ++i) {
-    fixed[i] = (h->cam_red[p->obs_cam[i]] < 0 && h->pt_const[p->obs_pt[i]]) ? 1 : 0;
-    (fixed[i] ? cnt_fix : cnt_main)[p->obs_pt[i] + 1]++;
+    const int rc = h->cam_red[p->obs_cam[i]];
+    fixed[i] = (rc < 0 && h->pt_const[p->obs_pt[i]]) ? 1 : 0;
+    if (rc >= 0 && rc < pkey[p->obs_pt[i]]) pkey[p->obs_pt[i]] = rc;
   }
+  std::vector<int> porder(h->np), prank(h->np);
+  for (int q = 0; q < h->np; ++q) porder[q] = q;
+  std::stable_sort(porder.begin(), porder.end(), [&](int x, int y) { return pkey[x] < pkey[y]; });
+  for (int r = 0; r < h->np; ++r) prank[porder[r]] = r;
+  // offsets indexed by track RANK
+  std::vector<int64_t> cnt_main(h->np + 1, 0), cnt_fix(h->np + 1, 0);
+  for (int64_t i = 0; i < h->nobs; ++i) (fixed[i] ? cnt_fix : cnt_main)[prank[p->obs_pt[i]] + 1]++;
   for (int q = 0; q < h->np; ++q) { cnt_main[q + 1] += cnt_main[q]; cnt_fix[q + 1] += cnt_fix[q]; }
   h->nobs_main = cnt_main[h->np];
   h->perm.assign(h->nobs, 0);
   {
     std::vector<int64_t> fm(cnt_main.begin(), cnt_main.end() - 1), ff(cnt_fix.begin(), cnt_fix.end() - 1);
     for (int64_t i = 0; i < h->nobs; ++i) {
-      const int q = p->obs_pt[i];
+      const int q = prank[p->obs_pt[i]];
       if (fixed[i]) h->perm[h->nobs_main + ff[q]++] = i; else h->perm[fm[q]++] = i;
     }
   }
   // wave tiles: <= 64 observations, never splitting a track
-  std::vector<int> tstart, tcount;
+  std::vector<int> tstart, tcount, tkey;
   auto build_tiles = [&](const std::vector<int64_t>& off, int64_t base) -> int {
     int64_t cur0 = 0, curlen = 0;
+    int curkey = 0;
     for (int q = 0; q < h->np; ++q) {
       const int64_t L = off[q + 1] - off[q];
       if (L == 0) continue;
       if (L > 64) return -1;
-      if (curlen + L > 64) { tstart.push_back((int)(base + cur0)); tcount.push_back((int)curlen); cur0 = off[q]; curlen = 0; }
-      if (curlen == 0) cur0 = off[q];
+      if (curlen + L > 64) { tstart.push_back((int)(base + cur0)); tcount.push_back((int)curlen); tkey.push_back(curkey); curlen = 0; }
+      if (curlen == 0) { cur0 = off[q]; curkey = pkey[porder[q]]; }
       curlen += L;
     }
-    if (curlen) { tstart.push_back((int)(base + cur0)); tcount.push_back((int)curlen); }
+    if (curlen) { tstart.push_back((int)(base + cur0)); tcount.push_back((int)curlen); tkey.push_back(curkey); }
     return 0;
   };
   if (build_tiles(cnt_main, 0))
@@ -343,6 +357,22 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   if (build_tiles(cnt_fix, h->nobs_main))
     return set_error(THEIA_HIP_ERR_UNSUPPORTED, "a track has more than 64 observations (long-track kernel not built yet)");
   h->ntiles_all = (int)tstart.size();
+  // linearize workgroups: ~2 per CU, each owning a contiguous run of tiles; the
+  // LDS window starts at the first camera of the run's first track
+  {
+    const int target_wg = 512;
+    int tpw = (h->ntiles_main + target_wg - 1) / target_wg;
+    tpw = std::max(4, ((tpw + 3) / 4) * 4);
+    h->tiles_per_wg = tpw;
+    h->nwg = (h->ntiles_main + tpw - 1) / tpw;
+    std::vector<int> wgb(std::max(1, h->nwg), 0);
+    for (int b2 = 0; b2 < h->nwg; ++b2) {
+      const int k = tkey[(size_t)b2 * tpw];
+      wgb[b2] = (k == std::numeric_limits<int>::max()) ? 0 : k;
+    }
+    rc = h->wg_base.upload(wgb, h->stream);
+    if (rc) return rc;
+  }
 
   std::vector<double2> uv(h->nobs), si;
   std::vector<int> ocam(h->nobs), opt(h->nobs);
