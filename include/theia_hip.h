@@ -225,6 +225,12 @@ int theia_hip_ba_evaluate(theia_ba_handle h, double* cost, double* residuals,
 int theia_hip_ba_reduced_system(theia_ba_handle h, double radius, int32_t* n,
                                 double* S, double* rhs, int64_t capacity);
 
+/* K3 alone (introspection for the parity tests): solve the dense SPD system
+ * A x = b with the reduced-camera Cholesky kernels.  A: n x n row-major, only
+ * the lower triangle is read; x: n.  Returns THEIA_HIP_ERR_INTERNAL when a
+ * pivot is not positive (what makes an LM step "invalid"). */
+int theia_hip_dense_spd_solve(int32_t n, const double* A, const double* b, double* x);
+
 /* Multi-GPU (one process per GPU): tracks are sharded by the caller; each
  * rank's handle holds its shard plus ALL cameras.  The reduced camera system
  * (and the scalar reductions) are summed across ranks through this callback,

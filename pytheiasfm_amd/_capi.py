@@ -103,7 +103,7 @@ EXPORTED_SYMBOLS = [
     "theia_hip_version", "theia_ba_options_default", "theia_hip_ba_solve", "theia_hip_ba_create",
     "theia_hip_ba_reset_parameters", "theia_hip_ba_set_options", "theia_hip_ba_run", "theia_hip_ba_download",
     "theia_hip_ba_destroy", "theia_hip_ba_evaluate", "theia_hip_ba_reduced_system",
-    "theia_hip_ba_set_allreduce", "theia_ransac_params_default",
+    "theia_hip_ba_set_allreduce", "theia_hip_dense_spd_solve", "theia_ransac_params_default",
     "theia_hip_ransac_estimate_batch", "theia_hip_five_point_relative_pose",
     "theia_hip_pose_from_three_points",
 ]
@@ -143,6 +143,7 @@ def lib():
     L.theia_hip_ba_reduced_system.argtypes = [C.c_void_p, C.c_double, c_int32_p, c_double_p, c_double_p, C.c_int64]
     L.theia_hip_ba_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p]
     L.theia_ba_options_default.argtypes = [C.POINTER(BaOptions)]
+    L.theia_hip_dense_spd_solve.argtypes = [C.c_int32, c_double_p, c_double_p, c_double_p]
     _lib = L
     return L
 

@@ -97,6 +97,15 @@ class BaHandle:
         capi.check(capi.lib().theia_hip_ba_set_allreduce(self._h, self._cb, None))
 
 
+def dense_spd_solve(A, b):
+    """K3 alone: x = A^-1 b through the reduced-camera Cholesky kernels."""
+    A = np.ascontiguousarray(A, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros_like(b)
+    capi.check(capi.lib().theia_hip_dense_spd_solve(A.shape[0], capi.ptr(A, C.c_double), capi.ptr(b, C.c_double),
+                                                    capi.ptr(x, C.c_double)))
+    return x
+
+
 def solve(problem, options, trace_capacity=256):
     """theia_hip_ba_solve: parameters of `problem` are updated in place."""
     s = capi.BaSummary()

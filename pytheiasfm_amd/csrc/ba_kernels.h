@@ -71,6 +71,7 @@ void launch_cost_only(const DevProblem& P, const double* cam, const double* pts,
 // dense SPD solve  A x = b  (lower triangle of row-major A, leading dim lda;
 // A is overwritten by its Cholesky factor, b by x).  fail_flag (device) is
 // incremented if a pivot is not positive.
-void dense_cholesky_solve(int n, double* A, int lda, double* b, double* fail_flag, hipStream_t st);
+size_t dense_cholesky_workspace(int n);  // doubles
+void dense_cholesky_solve(int n, double* A, int lda, double* b, double* work, double* fail_flag, hipStream_t st);
 
 }  // namespace thip

@@ -93,7 +93,7 @@ struct theia_ba_handle_s {
   int tiles_per_wg = 4, nwg = 0;
   DevBuf<uint8_t> d_cam_mask, d_pt_const;
   DevBuf<double2> obs_uv, obs_si;
-  DevBuf<double> reduce, Vinv, gp, tile_part, scalB;
+  DevBuf<double> reduce, Vinv, gp, tile_part, scalB, chol_work;
   double* h_scal = nullptr;  // pinned: [scalA(16) | scalB(16)]
   int cur = 0;
   bool have_scale = false;
@@ -232,7 +232,7 @@ int enqueue_linearize(theia_ba_handle_s* h, double radius) {
 // enqueue: dense solve, candidate cameras, back-substitution + trial cost.
 int enqueue_solve_and_backsub(theia_ba_handle_s* h) {
   double* yc = h->rb.rhs;  // the solution overwrites the rhs row
-  dense_cholesky_solve(h->n, h->rb.S, h->n, h->rb.rhs, h->rb.scal + SC_NOTPD, h->stream);
+  dense_cholesky_solve(h->n, h->rb.S, h->n, h->rb.rhs, h->chol_work.p, h->rb.scal + SC_NOTPD, h->stream);
   HIP_TRY(hipEventRecord(h->ev[2], h->stream));
   HIP_TRY(hipMemsetAsync(h->scalB.p, 0, sizeof(double) * 16, h->stream));
   const int nxt = 1 - h->cur;
@@ -407,6 +407,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   h->rb.scal = h->rb.gc + h->n;
   AL(Vinv, (size_t)(h->pd * (h->pd + 1) / 2) * h->np); AL(gp, (size_t)h->pd * h->np);
   AL(tile_part, (size_t)5 * std::max(1, h->ntiles_all)); AL(scalB, 16);
+  AL(chol_work, dense_cholesky_workspace(h->n));
 #undef UP
 #undef AL
   fill_devproblem(h);
@@ -643,6 +644,27 @@ int theia_hip_ba_evaluate(theia_ba_handle h, double* cost, double* residuals, do
     if (jac_pt) std::copy(&hjp[2 * pd * s], &hjp[2 * pd * s] + 2 * pd, jac_pt + 2 * pd * i);
     if (valid) valid[i] = hv[s];
   }
+  return 0;
+}
+
+int theia_hip_dense_spd_solve(int32_t n, const double* A, const double* b, double* x) {
+  if (n < 0 || (n > 0 && (!A || !b || !x))) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+  if (n == 0) return 0;
+  int rc = thip::ensure_device();
+  if (rc) return rc;
+  DevBuf<double> dA, dw, dflag;
+  if ((rc = dA.alloc((size_t)n * n + n)) || (rc = dw.alloc(dense_cholesky_workspace(n))) || (rc = dflag.alloc(1))) return rc;
+  HIP_TRY(hipMemcpy(dA.p, A, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dA.p + (size_t)n * n, b, sizeof(double) * n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(dflag.p, 0, sizeof(double)));
+  dense_cholesky_solve(n, dA.p, n, dA.p + (size_t)n * n, dw.p, dflag.p, nullptr);
+  double flag = 0.0;
+  if (getenv("THEIA_HIP_DEBUG_FACTOR")) {  // development aid: hand back the factor in place of A
+    HIP_TRY(hipMemcpy(const_cast<double*>(A), dA.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost));
+  }
+  HIP_TRY(hipMemcpy(x, dA.p + (size_t)n * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&flag, dflag.p, sizeof(double), hipMemcpyDeviceToHost));
+  if (flag != 0.0) return set_error(THEIA_HIP_ERR_INTERNAL, "matrix is not positive definite");
   return 0;
 }
 

@@ -5,85 +5,137 @@
 // Blocked right-looking Cholesky on the lower triangle of a row-major matrix.
 // The right-hand side is stored as row n of the same (n+1) x lda array, so the
 // forward substitution  y = L^-1 b  falls out of the panel solves for free;
-// only the backward substitution  x = L^-T y  is a separate kernel.
+// only the backward substitution  x = L^-T y  is separate.
 //
-//   per panel (NB = 32 columns):
-//     k_panel : every workgroup re-factors the 32x32 diagonal block in LDS
-//               (11 kflop, cheaper than a launch boundary) and solves
-//               X L11^T = A21 for its own 256 rows;
-//     k_syrk  : trailing update A22 -= L21 L21^T on 64x64 tiles with the FP64
-//               matrix core  v_mfma_f64_16x16x4_f64  (4x4 MFMA tiles per
-//               wave-quadrant), lower tiles only.
+// Everything at this size (n = 6 x #cameras ~ 10^3) is LATENCY bound: measured
+// on MI355X a dependent FP64 op costs ~22 cycles and sqrt/div several hundred,
+// with one wave per SIMD nothing hides it.  Hence:
+//   k_potrf : ONE wavefront factors the 64x64 diagonal block in registers
+//             (lane = row, pivot row broadcast by v_readlane, 8 partial sums,
+//             one rsqrt per column) and also forms its inverse L11^-1;
+//   k_trsm  : A21 <- A21 L11^-T as a GEMM with that inverse on the FP64 matrix
+//             core (v_mfma_f64_16x16x4_f64): no dependent chains;
+//   k_syrk  : trailing update A22 -= L21 L21^T, 64x64 tiles, FP64 MFMA;
+//   backward substitution in 64-wide steps with the same block inverses.
 #include "ba_kernels.h"
+
+#include <algorithm>
 
 namespace thip {
 namespace {
 
-constexpr int NB = 32;
-
-// Factor the NB x NB diagonal block held in LDS (lower, in place). 256 threads.
-__device__ void factor_diag_lds(double (*D)[NB + 1], int nb, int tid, int nthreads, int* bad) {
-  for (int j = 0; j < nb; ++j) {
-    __syncthreads();
-    if (tid == 0) {
-      const double d = D[j][j];
-      if (!(d > 0.0)) { *bad = 1; D[j][j] = 1.0; }
-      else D[j][j] = sqrt(d);
-    }
-    __syncthreads();
-    const double inv = 1.0 / D[j][j];
-    for (int i = j + 1 + tid; i < nb; i += nthreads) D[i][j] *= inv;
-    __syncthreads();
-    // trailing update of the block: D[i][k] -= D[i][j] * D[k][j], j < k <= i
-    const int m = nb - j - 1;
-    for (int t = tid; t < m * m; t += nthreads) {
-      const int i = j + 1 + t / m, k = j + 1 + t % m;
-      if (k <= i) D[i][k] -= D[i][j] * D[k][j];
-    }
-  }
-  __syncthreads();
-}
-
-// Panel step at column block k0: rows [k0, nrows). Workgroup b handles rows
-// k0 + nb + b*256 + tid; workgroup 0 also writes back the factored diagonal.
-__global__ __launch_bounds__(256) void k_panel(double* __restrict__ A, int lda, int nrows, int k0, int nb,
-                                               double* __restrict__ fail_flag) {
-  __shared__ double D[NB][NB + 1];
-  __shared__ int bad;
-  const int tid = threadIdx.x;
-  if (tid == 0) bad = 0;
-  for (int t = tid; t < nb * nb; t += 256) {
-    const int i = t / nb, j = t % nb;
-    D[i][j] = (j <= i) ? A[(size_t)(k0 + i) * lda + k0 + j] : 0.0;
-  }
-  factor_diag_lds(D, nb, tid, 256, &bad);
-  if (blockIdx.x == 0) {
-    for (int t = tid; t < nb * nb; t += 256) {
-      const int i = t / nb, j = t % nb;
-      if (j <= i) A[(size_t)(k0 + i) * lda + k0 + j] = D[i][j];
-    }
-    if (tid == 0 && bad) unsafeAtomicAdd(fail_flag, 1.0);
-  }
-  const int r = k0 + nb + blockIdx.x * 256 + tid;
-  if (r >= nrows) return;
-  double* row = A + (size_t)r * lda + k0;
-  double x[NB];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) x[j] = (j < nb) ? row[j] : 0.0;
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    if (j < nb) {
-      double s = x[j];
-#pragma unroll
-      for (int i = 0; i < j; ++i) s -= x[i] * D[j][i];
-      x[j] = s / D[j][j];
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < NB; ++j) if (j < nb) row[j] = x[j];
-}
+constexpr int NB = 64;
+constexpr int LDP = NB + 1;  // LDS row pitch (doubles)
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+
+// One wavefront: factor the diagonal block at k0 (nb <= 64 valid rows; the rest
+// is padded with the identity), write L11 back, and write L11^-1 (64 x 64,
+// row-major, zero upper part) to Linv.
+__global__ __launch_bounds__(64) void k_potrf(double* __restrict__ A, int lda, int k0, int nb,
+                                              double* __restrict__ Linv, double* __restrict__ fail_flag) {
+  __shared__ double Ls[NB][LDP];
+  const int i = threadIdx.x;
+  double row[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+    row[j] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * lda + k0 + j] : ((i == j) ? 1.0 : 0.0);
+  int bad = 0;
+  double rdiag[NB];  // 1 / L[j][j] (wave-uniform), reused by the inverse below
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    double s[8];
+    s[0] = row[j];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) s[q] = 0.0;
+#pragma unroll
+    for (int k = 0; k < j; ++k) s[k & 7] -= row[k] * readlane_d(row[k], j);
+    const double sj = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    double d = readlane_d(sj, j);
+    if (!(d > 0.0)) { bad = 1; d = 1.0; }
+    // hardware v_rsq_f64 seed + two Newton steps (full FP64), no sqrt / divide
+    double rinv = __builtin_amdgcn_rsq(d);
+    rinv = rinv * (1.5 - (0.5 * d) * (rinv * rinv));
+    rinv = rinv * (1.5 - (0.5 * d) * (rinv * rinv));
+    rdiag[j] = rinv;
+    row[j] = (i == j) ? d * rinv : (i > j ? sj * rinv : 0.0);
+  }
+  if (i < nb) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) if (j <= i) A[(size_t)(k0 + i) * lda + k0 + j] = row[j];
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) Ls[i][j] = row[j];
+  if (bad && i == 0) unsafeAtomicAdd(fail_flag, 1.0);
+  __syncthreads();
+  // lane c computes column c of Z = L^-1:  z[r] = (delta_rc - sum_{k<r} L[r][k] z[k]) / L[r][r]
+  const int c = i;
+  double z[NB];
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    double s[8];
+    s[0] = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) s[q] = 0.0;
+#pragma unroll
+    for (int k = 0; k < r; ++k) s[k & 7] -= Ls[r][k] * z[k];
+    const double sr = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    z[r] = sr * rdiag[r];
+  }
+#pragma unroll
+  for (int r = 0; r < NB; ++r) Linv[r * NB + c] = z[r];
+}
+
+// A21 <- A21 * L11^-T for rows [k0 + nb, nrows): X[r][j] = sum_i P[r][i] Z[j][i].
+// 128 rows per workgroup; wave w owns rows [32w, 32w + 32).
+__global__ __launch_bounds__(256) void k_trsm(double* __restrict__ A, int lda, int nrows, int k0, int nb,
+                                              const double* __restrict__ Linv) {
+  __shared__ double P[128][LDP];
+  __shared__ double Z[NB][LDP];
+  const int tid = threadIdx.x;
+  const int r0 = k0 + nb + blockIdx.x * 128;
+  for (int t = tid; t < NB * NB; t += 256) Z[t / NB][t % NB] = Linv[t];
+  for (int t = tid; t < 128 * NB; t += 256) {
+    const int rr = t / NB, j = t % NB;
+    P[rr][j] = (r0 + rr < nrows && j < nb) ? A[(size_t)(r0 + rr) * lda + k0 + j] : 0.0;
+  }
+  __syncthreads();
+  const int wv = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  double4_t acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[a][q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < NB; kk += 4) {
+    const double a0 = P[32 * wv + li][kk + lk];
+    const double a1 = P[32 * wv + 16 + li][kk + lk];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double b = Z[16 * q + li][kk + lk];
+      acc[0][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][q], 0, 0, 0);
+      acc[1][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][q], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = r0 + 32 * wv + 16 * a + lk + 4 * reg;
+        const int col = 16 * q + li;
+        if (row < nrows && col < nb) A[(size_t)row * lda + k0 + col] = acc[a][q][reg];
+      }
+}
 
 // Trailing update with FP64 MFMA.  Tile = 64 x 64 outputs per workgroup of 256
 // threads (4 waves); wave w owns output rows [16w, 16w+16) x 64 columns = four
@@ -95,9 +147,22 @@ __global__ __launch_bounds__(256) void k_syrk(double* __restrict__ A, int lda, i
   const int ti = blockIdx.y, tj = blockIdx.x;
   if (tj > ti) return;  // lower tiles only
   const int r0 = base + ti * 64, c0 = base + tj * 64;
-  __shared__ double Pr[64][NB + 1];  // rows of the panel for this tile's rows
-  __shared__ double Pc[64][NB + 1];  // rows of the panel for this tile's cols
+  __shared__ double Pr[64][LDP];  // rows of the panel for this tile's rows
+  __shared__ double Pc[64][LDP];  // rows of the panel for this tile's cols
   const int tid = threadIdx.x;
+  const int wv = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  // prefetch the C tile (independent of the panel loads) to overlap one memory round trip
+  double4_t cold[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = r0 + 16 * wv + lk + 4 * reg;
+      const int col = c0 + 16 * q + li;
+      const bool ok = row < nrows && col <= row && col < nrows - 1;
+      cold[q][reg] = ok ? A[(size_t)row * lda + col] : 0.0;
+    }
   for (int t = tid; t < 64 * NB; t += 256) {
     const int i = t / NB, k = t % NB;
     const int rr = r0 + i, cc = c0 + i;
@@ -105,8 +170,6 @@ __global__ __launch_bounds__(256) void k_syrk(double* __restrict__ A, int lda, i
     Pc[i][k] = (cc < nrows && k < nb) ? A[(size_t)cc * lda + k0 + k] : 0.0;
   }
   __syncthreads();
-  const int wv = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, lk = lane >> 4;
   double4_t acc[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -120,84 +183,94 @@ __global__ __launch_bounds__(256) void k_syrk(double* __restrict__ A, int lda, i
     }
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < 4; ++q)
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int row = r0 + 16 * wv + lk + 4 * reg;
       const int col = c0 + 16 * q + li;
-      if (row < nrows && col <= row && col < nrows - 0) {
-        // the rhs row (row == nrows-1) only has columns < nrows-1
-        if (!(row == nrows - 1 && col >= nrows - 1))
-          A[(size_t)row * lda + col] -= acc[q][reg];
-      }
+      // the rhs row (row == nrows-1) has columns < nrows-1 only
+      if (row < nrows && col <= row && col < nrows - 1) A[(size_t)row * lda + col] = cold[q][reg] - acc[q][reg];
     }
-  }
 }
 
-// Backward substitution x = L^-T y, y in row n of A (A[n*lda + j]); result in b.
-// Single workgroup; block-column sweep from the last panel to the first.
-__global__ __launch_bounds__(1024) void k_backward(const double* __restrict__ A, int lda, int n,
-                                                   double* __restrict__ b) {
-  extern __shared__ double sh[];  // y[n] | xk[NB] | D[NB][NB+1]
-  double* y = sh;
-  double* xk = sh + n;
-  double* D = xk + NB;
+// Backward substitution x = L^-T y in 64-wide block steps with the block
+// inverses saved by k_potrf: x_k = Linv_k^T y_k, then y_j -= L[k-rows][j]^T x_k
+// spread over one workgroup per 256 columns.
+__global__ __launch_bounds__(256) void k_back_step(const double* __restrict__ A, int lda, int n, int kb,
+                                                   const double* __restrict__ Linv, double* __restrict__ y,
+                                                   double* __restrict__ x) {
+  __shared__ double yk[NB], xk[NB], part[4][NB];
+  const int k0 = kb * NB;
+  const int nb = min(NB, n - k0);
   const int tid = threadIdx.x;
-  for (int j = tid; j < n; j += 1024) y[j] = A[(size_t)n * lda + j];
+  if (tid < NB) yk[tid] = (tid < nb) ? y[k0 + tid] : 0.0;
   __syncthreads();
-  const int nblk = (n + NB - 1) / NB;
-  for (int kb = nblk - 1; kb >= 0; --kb) {
-    const int k0 = kb * NB;
-    const int nb = min(NB, n - k0);
-    for (int t = tid; t < nb * nb; t += 1024) {
-      const int i = t / nb, j = t % nb;
-      D[i * (NB + 1) + j] = (j <= i) ? A[(size_t)(k0 + i) * lda + k0 + j] : 0.0;
-    }
-    __syncthreads();
-    if (tid < 64) {
-      // solve L11^T x = y_k : x_i = (y_i - sum_{r>i} L[r][i] x_r) / L[i][i]
-      for (int i = nb - 1; i >= 0; --i) {
-        double part = 0.0;
-        for (int r = i + 1 + tid; r < nb; r += 64) part += D[r * (NB + 1) + i] * xk[r];
+  {
+    // x_k[i] = sum_r Linv[r][i] y_k[r] : 4 row chunks of 16 per column i
+    const int i = tid & 63, ch = tid >> 6;
+    const double* Z = Linv + (size_t)kb * NB * NB;
+    double s = 0.0;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-        if (tid == 0) xk[i] = (y[k0 + i] - part) / D[i * (NB + 1) + i];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+    for (int q = 0; q < 16; ++q) { const int r = ch * 16 + q; s += Z[r * NB + i] * yk[r]; }
+    part[ch][i] = s;
+  }
+  __syncthreads();
+  if (tid < NB) {
+    const double s = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    xk[tid] = s;
+    if (blockIdx.x == 0 && tid < nb) x[k0 + tid] = s;
+  }
+  __syncthreads();
+  const int j = blockIdx.x * 256 + tid;
+  if (j < k0) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const double* col = A + (size_t)k0 * lda + j;
+    if (nb == NB) {
+#pragma unroll
+      for (int r = 0; r < NB; r += 4) {
+        s0 += col[(size_t)r * lda] * xk[r]; s1 += col[(size_t)(r + 1) * lda] * xk[r + 1];
+        s2 += col[(size_t)(r + 2) * lda] * xk[r + 2]; s3 += col[(size_t)(r + 3) * lda] * xk[r + 3];
       }
+    } else {
+      for (int r = 0; r < nb; ++r) s0 += col[(size_t)r * lda] * xk[r];
     }
-    __syncthreads();
-    for (int i = tid; i < nb; i += 1024) b[k0 + i] = xk[i];
-    // y_j -= sum_r L[k0+r][j] x_r  for j < k0
-    for (int j = tid; j < k0; j += 1024) {
-      double s = 0.0;
-#pragma unroll 8
-      for (int r = 0; r < nb; ++r) s += A[(size_t)(k0 + r) * lda + j] * xk[r];
-      y[j] -= s;
-    }
-    __syncthreads();
+    y[j] -= (s0 + s1) + (s2 + s3);
   }
 }
 
 }  // namespace
 
-void dense_cholesky_solve(int n, double* A, int lda, double* b, double* fail_flag, hipStream_t st) {
+size_t dense_cholesky_workspace(int n) {
+  const int nblk = (n + NB - 1) / NB;
+  return (size_t)std::max(1, nblk) * NB * NB + (size_t)n + 8;
+}
+
+void dense_cholesky_solve(int n, double* A, int lda, double* b, double* work, double* fail_flag, hipStream_t st) {
   if (n <= 0) return;
   const int nrows = n + 1;  // row n = right-hand side (b must alias A + n*lda)
-  (void)b;
-  for (int k0 = 0; k0 < n; k0 += NB) {
+  const int nblk = (n + NB - 1) / NB;
+  double* Linv = work;
+  double* x = work + (size_t)nblk * NB * NB;
+  for (int kb = 0; kb < nblk; ++kb) {
+    const int k0 = kb * NB;
     const int nb = (n - k0 < NB) ? (n - k0) : NB;
     const int below = nrows - (k0 + nb);
-    const int pblocks = below > 0 ? (below + 255) / 256 : 1;
-    k_panel<<<pblocks, 256, 0, st>>>(A, lda, nrows, k0, nb, fail_flag);
+    double* Zk = Linv + (size_t)kb * NB * NB;
+    k_potrf<<<1, 64, 0, st>>>(A, lda, k0, nb, Zk, fail_flag);
     if (below > 0) {
+      k_trsm<<<(below + 127) / 128, 256, 0, st>>>(A, lda, nrows, k0, nb, Zk);
       const int tiles = (below + 63) / 64;
       dim3 grid(tiles, tiles);
       k_syrk<<<grid, 256, 0, st>>>(A, lda, nrows, k0, nb);
     }
   }
-  const size_t shmem = (size_t)(n + NB + NB * (NB + 1)) * sizeof(double);
-  k_backward<<<1, 1024, shmem, st>>>(A, lda, n, A + (size_t)n * lda);
+  double* y = A + (size_t)n * lda;
+  for (int kb = nblk - 1; kb >= 0; --kb) {
+    const int k0 = kb * NB;
+    const int grid = k0 > 0 ? (k0 + 255) / 256 : 1;
+    k_back_step<<<grid, 256, 0, st>>>(A, lda, n, kb, Linv, y, x);
+  }
+  (void)hipMemcpyAsync(b, x, sizeof(double) * n, hipMemcpyDeviceToDevice, st);
 }
 
 }  // namespace thip

@@ -191,3 +191,18 @@ def test_full_size_c2_properties():
     # mean squared residual at the optimum ~ pixel noise variance (0.5 px)
     n = p.obs_uv.shape[0]
     assert 0.15 < 2.0 * s.final_cost / (2 * n) < 0.30
+
+
+@pytest.mark.parametrize("n", [1, 6, 24, 32, 33, 120, 121, 300, 1200])
+def test_dense_cholesky_kernel_against_numpy(n):
+    """K3 alone (FP64-MFMA blocked Cholesky + substitutions) vs numpy."""
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n + 8))
+    A = M @ M.T + 1e-3 * np.eye(n)
+    b = rng.standard_normal(n)
+    x = ba.dense_spd_solve(np.tril(A), b)   # only the lower triangle is read
+    xr = np.linalg.solve(A, b)
+    assert np.abs(x - xr).max() <= 1e-9 * np.abs(xr).max() * max(1.0, np.linalg.cond(A) * 1e-6)
+    with pytest.raises(capi.TheiaHipError):
+        Abad = A.copy(); Abad[n // 2, n // 2] = -1.0
+        ba.dense_spd_solve(np.tril(Abad), b)
