@@ -28,6 +28,7 @@ struct DevProblem {
   const int* tile_count;       // [ntiles]
   int tiles_per_wg, nwg;       // linearize: workgroup b owns tiles [b*tiles_per_wg, ...)
   const int* wg_base;          // [nwg] first reduced camera of the workgroup's LDS window
+  long long* stamps;           // development: per-phase cycle counts of workgroup 0 (or nullptr)
   const double* scale_c;       // [nc][6] Jacobi scaling
   const double* scale_p;       // [np][pd]
 };

@@ -295,6 +295,9 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
   __syncthreads();
 
   const int tile0 = blockIdx.x * P.tiles_per_wg;
+  long long st_[6] = {0, 0, 0, 0, 0, 0};
+  long long tprev = clock64();
+#define STAMP(k_) do { const long long tn_ = clock64(); st_[k_] += tn_ - tprev; tprev = tn_; } while (0)
   for (int rnd = 0; rnd < P.tiles_per_wg; rnd += kWavesPerBlock) {
     const int tile = tile0 + rnd + wv;
     const bool tile_ok = (rnd + wv < P.tiles_per_wg) && tile < P.ntiles;
@@ -303,6 +306,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
     LaneLin<PD> L;
     lane_linearize<PD, true>(P, cam, pts, start + lane, lane < cnt, lane, L);
     const Segment sg = lane_segment(L.p, lane);
+    STAMP(0);
 
     // V_p (packed lower) and g_p = E^T r : segmented all-reduce
     double in[NT + PD], tot[NT + PD];
@@ -313,6 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
       in[NT + a] = L.Jt[a] * L.r[0] + L.Jt[PD + a] * L.r[1];
     }
     segment_allsum<NT + PD>(sg, in, tot);
+    STAMP(1);
 
     double V[NT], Vi[NT], g[PD];
 #pragma unroll
@@ -362,6 +367,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
         T[a * PD + b] = s;
       }
 
+    STAMP(2);
     const int rc = L.rc;
     const int li = rc - base;
     const bool in_win = li >= 0 && li < kWin;
@@ -388,6 +394,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
       }
     }
 
+    STAMP(3);
     // stage W of the tile in LDS, then every lane walks its track's segment
 #pragma unroll
     for (int k = 0; k < NW; ++k) sW[wv][lane][k] = W[k];
@@ -419,6 +426,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
         }
     }
     __syncthreads();  // sW / sRc are reused by the next round
+    STAMP(4);
 
     // per-tile partials (reduced in fixed order by k_reduce_tiles)
     const double cost = wave_sum(L.cost);
@@ -454,6 +462,10 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
     double* dst = q < 6 ? rhs : (q < 12 ? gc : colsq);
     atomic_add(&dst[6 * (base + c) + q % 6], v);
   }
+  STAMP(5);
+#undef STAMP
+  if (P.stamps && blockIdx.x == (unsigned)(P.nwg / 2) && threadIdx.x == 0)
+    for (int k = 0; k < 6; ++k) P.stamps[k] = st_[k];
 }
 
 // Deterministic reduction of per-tile partials into the scalar block.

@@ -94,6 +94,7 @@ struct theia_ba_handle_s {
   DevBuf<uint8_t> d_cam_mask, d_pt_const;
   DevBuf<double2> obs_uv, obs_si;
   DevBuf<double> reduce, Vinv, gp, tile_part, scalB, chol_work;
+  DevBuf<long long> stamps;
   double* h_scal = nullptr;  // pinned: [scalA(16) | scalB(16)]
   int cur = 0;
   bool have_scale = false;
@@ -151,6 +152,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.tile_start = h->tile_start.p; P.tile_count = h->tile_count.p;
   P.tiles_per_wg = h->tiles_per_wg; P.nwg = h->nwg; P.wg_base = h->wg_base.p;
   P.scale_c = h->scale_c.p; P.scale_p = h->scale_p.p;
+  P.stamps = h->stamps.p;
 }
 
 int upload_parameters(theia_ba_handle_s* h, const theia_ba_problem* p) {
@@ -408,6 +410,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   AL(Vinv, (size_t)(h->pd * (h->pd + 1) / 2) * h->np); AL(gp, (size_t)h->pd * h->np);
   AL(tile_part, (size_t)5 * std::max(1, h->ntiles_all)); AL(scalB, 16);
   AL(chol_work, dense_cholesky_workspace(h->n));
+  if (getenv("THEIA_HIP_STAMPS")) AL(stamps, 16);
 #undef UP
 #undef AL
   fill_devproblem(h);
@@ -589,6 +592,12 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
                    x_cost, cand_cost, relative_decrease, gmax, step_norm, radius, step_successful ? "ok" : "rej");
   }
   // patch the gradient entries of accepted steps (known one read-back later)
+  if (h->stamps.p) {  // development aid: cycle breakdown of one k_linearize workgroup
+    long long st[6];
+    if (hipMemcpy(st, h->stamps.p, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
+      std::fprintf(stderr, "[theia_hip] k_linearize WG cycles: load+jac %lld | seg-reduce %lld | invert+W/T %lld | camera LDS adds %lld | "
+                   "pair blocks %lld | flush %lld (tiles/WG %d, nwg %d)\n", st[0], st[1], st[2], st[3], st[4], st[5], h->tiles_per_wg, h->nwg);
+  }
   S->num_iterations = iter;
   S->termination_type = term;
   S->success = term != THEIA_TERM_FAILURE;
