@@ -133,7 +133,7 @@ THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam
 }
 
 struct Segment {
-  int start, len, maxlen;
+  int start, len, maxlen, rank;  // rank = index of the track inside its tile
   bool head;
 };
 
@@ -146,6 +146,7 @@ THIP_DEV Segment lane_segment(int p, int lane) {
   Segment s;
   s.head = head;
   s.start = 63 - __clzll((long long)(H & low));
+  s.rank = __popcll(H & low) - 1;
   const unsigned long long Hn = H & ~low;
   const int end = Hn ? (__ffsll((long long)Hn) - 1) : 64;
   s.len = end - s.start;
@@ -402,7 +403,12 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
     __syncthreads();
     const bool me = L.active && !L.pconst && rc >= 0;
     for (int j = 0; j < sg.maxlen; ++j) {
-      const int src = (sg.start + j) & 63;
+      // walk the partners in an order rotated by the track's rank in the tile:
+      // tracks that share a camera window then hit DIFFERENT accumulator blocks
+      // in the same ds_add_f64 instruction (no same-address serialisation)
+      int jj = j + sg.rank;
+      jj = (j < sg.len) ? jj % sg.len : 0;
+      const int src = (sg.start + jj) & 63;
       const int rcs = sRc[wv][src];
       const bool take = me && (j < sg.len) && rcs >= 0 && rc >= rcs;
       if (!take) continue;
