@@ -257,6 +257,55 @@ inline bool radtan_project(const T* k, const T* p, T* pixel) {
   return true;
 }
 
+// fov_camera_model.h:156-258 ([f, a, cx, cy, omega]; no skew)
+template <typename T>
+inline bool fov_project(const T* k, const T* p, T* pixel) {
+  const T x = p[0] / p[2], y = p[1] / p[2];
+  const T& omega = k[4];
+  const T r_u_sq = x * x + y * y;
+  T r_d;
+  if (omega < 1e-3) {
+    r_d = (omega * omega * r_u_sq) / 3.0 - omega * omega / 12.0 + 1.0;
+  } else if (r_u_sq < 1e-3) {
+    const T th = jtan(omega / 2.0);
+    r_d = (-2.0 * th * (4.0 * r_u_sq * th * th - 3.0)) / (3.0 * omega);
+  } else {
+    const T r_u = jsqrt(r_u_sq);
+    r_d = jatan(2.0 * r_u * jtan(omega / 2.0)) / (r_u * omega);
+  }
+  pixel[0] = k[0] * (r_d * x) + k[2];
+  pixel[1] = k[0] * k[1] * (r_d * y) + k[3];
+  return true;
+}
+
+// division_undistortion_camera_model.h:173-231,263-297 ([f, a, cx, cy, k]):
+// the distortion acts on focal-scaled coordinates.
+template <typename T>
+inline bool division_project(const T* k, const T* p, T* pixel) {
+  const T ux = k[0] * (p[0] / p[2]);
+  const T uy = k[0] * k[1] * (p[1] / p[2]);
+  const T r_u_sq = ux * ux + uy * uy;
+  const T denom = 2.0 * k[4] * r_u_sq;
+  const T inner_sqrt = 1.0 - 4.0 * k[4] * r_u_sq;
+  if (scalar_of(jabs(denom)) < std::numeric_limits<double>::epsilon() || inner_sqrt < 0.0) {
+    pixel[0] = ux + k[2]; pixel[1] = uy + k[3];
+  } else {
+    const T scale = (1.0 - jsqrt(inner_sqrt)) / denom;
+    pixel[0] = ux * scale + k[2]; pixel[1] = uy * scale + k[3];
+  }
+  return true;
+}
+
+// orthographic_camera_model.h:162-240 ([f, a, s, cx, cy, k1, k2]): no depth division
+template <typename T>
+inline bool ortho_project(const T* k, const T* p, T* pixel) {
+  const T r_sq = p[0] * p[0] + p[1] * p[1];
+  const T d = 1.0 + r_sq * (k[5] + k[6] * r_sq);
+  const T dp[2] = {p[0] * d, p[1] * d};
+  affine_stage(k, dp, pixel);
+  return true;
+}
+
 template <typename T>
 inline bool project(int model, const T* k, const T* p, T* pixel) {
   switch (model) {
@@ -265,6 +314,9 @@ inline bool project(int model, const T* k, const T* p, T* pixel) {
     case CAM_EXTENDED_UNIFIED: return eucm_project(k, p, pixel);
     case CAM_FISHEYE: return fisheye_project(k, p, pixel);
     case CAM_PINHOLE_RADIAL_TANGENTIAL: return radtan_project(k, p, pixel);
+    case CAM_FOV: return fov_project(k, p, pixel);
+    case CAM_DIVISION_UNDISTORTION: return division_project(k, p, pixel);
+    case CAM_ORTHOGRAPHIC: return ortho_project(k, p, pixel);
     default: pixel[0] = T(0.0); pixel[1] = T(0.0); return false;
   }
 }

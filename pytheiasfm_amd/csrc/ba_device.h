@@ -80,62 +80,198 @@ THIP_DEV void rotation_dq_dw(const double w[3], const double p[3], const RotTerm
   M[8] = B * p[2] * w[2] + Bd + w[2] * h2;
 }
 
-// Projection pi(k, q) and its 2x3 Jacobian wrt q for the supported models.
-// Returns the model's validity boolean.
+// Projection pi(k, q) and its 2x3 Jacobian wrt q for the eight camera models of
+// create_reprojection_error_cost_function.h:61-135.  Returns the model's
+// validity boolean.  Derivatives are those of the branch taken.
 template <bool WANT_JAC>
 THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2], double Jq[6]) {
-  double dx, dy;          // distorted normalised point
-  double ddx[3], ddy[3];  // d(dx)/dq, d(dy)/dq
+  double dx = 0.0, dy = 0.0;                                  // distorted normalised point
+  double ddx[3] = {0.0, 0.0, 0.0}, ddy[3] = {0.0, 0.0, 0.0};  // d(dx)/dq, d(dy)/dq
   bool ok = true;
-  if (model == THEIA_CAM_PINHOLE) {
-    // pinhole_camera_model.h:181-211,243-260
-    const double iz = 1.0 / q[2];
-    const double x = q[0] / q[2], y = q[1] / q[2];
-    const double r2 = x * x + y * y;
-    const double d = 1.0 + r2 * (k[5] + k[6] * r2);
-    dx = x * d; dy = y * d;
-    if (WANT_JAC) {
-      const double e = 2.0 * (k[5] + 2.0 * k[6] * r2);
-      const double dxx = d + x * x * e, dxy = x * y * e, dyy = d + y * y * e;
-      // chain through x = q0/q2, y = q1/q2
-      ddx[0] = dxx * iz; ddx[1] = dxy * iz; ddx[2] = -(dxx * x + dxy * y) * iz;
-      ddy[0] = dxy * iz; ddy[1] = dyy * iz; ddy[2] = -(dxy * x + dyy * y) * iz;
-    }
-  } else if (model == THEIA_CAM_DOUBLE_SPHERE) {
-    // double_sphere_camera_model.h:160-249
-    const double alpha = k[6], xi = k[5];
-    const double r2 = q[0] * q[0] + q[1] * q[1];
-    const double d1 = sqrt(r2 + q[2] * q[2]);
-    const double w1 = alpha > 0.5 ? (1.0 - alpha) / alpha : alpha / (1.0 - alpha);
-    const double w2 = (w1 + xi) / sqrt(2.0 * w1 * xi + xi * xi + 1.0);
-    if (q[2] <= -w2 * d1) ok = false;
-    const double kk = xi * d1 + q[2];
-    const double d2 = sqrt(r2 + kk * kk);
-    const double n = alpha * d2 + (1.0 - alpha) * kk;
-    dx = q[0] / n; dy = q[1] / n;
-    if (WANT_JAC) {
-      const double id1 = 1.0 / d1, id2 = 1.0 / d2, in = 1.0 / n;
-      const double dk[3] = {xi * q[0] * id1, xi * q[1] * id1, xi * q[2] * id1 + 1.0};
-      const double dd2[3] = {(q[0] + kk * dk[0]) * id2, (q[1] + kk * dk[1]) * id2, (kk * dk[2]) * id2};
-      for (int i = 0; i < 3; ++i) {
-        const double dn = alpha * dd2[i] + (1.0 - alpha) * dk[i];
-        ddx[i] = -dx * dn * in;
-        ddy[i] = -dy * dn * in;
+  // models whose distortion acts on (x, y) = (q0/q2, q1/q2): fill dxx.. then chain
+  bool planar = false;
+  double x = 0.0, y = 0.0, dxx = 0.0, dxy = 0.0, dyx = 0.0, dyy = 0.0;
+  switch (model) {
+    case THEIA_CAM_PINHOLE: {
+      // pinhole_camera_model.h:181-211,243-260
+      planar = true;
+      x = q[0] / q[2]; y = q[1] / q[2];
+      const double r2 = x * x + y * y;
+      const double d = 1.0 + r2 * (k[5] + k[6] * r2);
+      dx = x * d; dy = y * d;
+      if (WANT_JAC) {
+        const double e = 2.0 * (k[5] + 2.0 * k[6] * r2);
+        dxx = d + x * x * e; dxy = x * y * e; dyx = dxy; dyy = d + y * y * e;
       }
-      ddx[0] += in; ddy[1] += in;
-    }
-  } else {
-    uv[0] = 0.0; uv[1] = 0.0;
-    if (WANT_JAC) for (int i = 0; i < 6; ++i) Jq[i] = 0.0;
-    return false;
+      break; }
+    case THEIA_CAM_PINHOLE_RADIAL_TANGENTIAL: {
+      // pinhole_radial_tangential_camera_model.h:191-296  [.., k1 k2 k3 t1 t2]
+      planar = true;
+      x = q[0] / q[2]; y = q[1] / q[2];
+      const double r2 = x * x + y * y;
+      const double rd = 1.0 + k[5] * r2 + k[6] * r2 * r2 + k[7] * r2 * r2 * r2;
+      const double t1 = k[8], t2 = k[9];
+      dx = x * rd + (t2 * (r2 + 2.0 * x * x) + 2.0 * t1 * x * y);
+      dy = y * rd + (t1 * (r2 + 2.0 * y * y) + 2.0 * t2 * x * y);
+      if (WANT_JAC) {
+        const double e = 2.0 * (k[5] + 2.0 * k[6] * r2 + 3.0 * k[7] * r2 * r2);
+        dxx = rd + x * x * e + 6.0 * t2 * x + 2.0 * t1 * y;
+        dxy = x * y * e + 2.0 * t2 * y + 2.0 * t1 * x;
+        dyx = x * y * e + 2.0 * t1 * x + 2.0 * t2 * y;
+        dyy = rd + y * y * e + 6.0 * t1 * y + 2.0 * t2 * x;
+      }
+      break; }
+    case THEIA_CAM_FOV: {
+      // fov_camera_model.h:156-258  [f a cx cy omega]
+      planar = true;
+      x = q[0] / q[2]; y = q[1] / q[2];
+      const double omega = k[4];
+      const double ru2 = x * x + y * y;
+      double rd, g;  // g = d rd / d(ru2)
+      if (omega < 1e-3) {
+        rd = (omega * omega * ru2) / 3.0 - omega * omega / 12.0 + 1.0;
+        g = omega * omega / 3.0;
+      } else if (ru2 < 1e-3) {
+        const double th = tan(omega / 2.0);
+        rd = (-2.0 * th * (4.0 * ru2 * th * th - 3.0)) / (3.0 * omega);
+        g = -8.0 * th * th * th / (3.0 * omega);
+      } else {
+        const double ru = sqrt(ru2);
+        const double th = tan(omega / 2.0);
+        const double at = atan(2.0 * ru * th);
+        rd = at / (ru * omega);
+        const double drd_dru = ((2.0 * th / (1.0 + 4.0 * ru2 * th * th)) * ru - at) / (ru2 * omega);
+        g = drd_dru / (2.0 * ru);
+      }
+      dx = rd * x; dy = rd * y;
+      if (WANT_JAC) { dxx = rd + 2.0 * x * x * g; dxy = 2.0 * x * y * g; dyx = dxy; dyy = rd + 2.0 * y * y * g; }
+      break; }
+    case THEIA_CAM_ORTHOGRAPHIC: {
+      // orthographic_camera_model.h:162-240: distortion on (q0, q1), no depth division
+      const double r2 = q[0] * q[0] + q[1] * q[1];
+      const double d = 1.0 + r2 * (k[5] + k[6] * r2);
+      dx = q[0] * d; dy = q[1] * d;
+      if (WANT_JAC) {
+        const double e = 2.0 * (k[5] + 2.0 * k[6] * r2);
+        ddx[0] = d + q[0] * q[0] * e; ddx[1] = q[0] * q[1] * e;
+        ddy[0] = ddx[1]; ddy[1] = d + q[1] * q[1] * e;
+      }
+      break; }
+    case THEIA_CAM_FISHEYE: {
+      // fisheye_camera_model.h:163-272  [.., k1 k2 k3 k4]
+      const double r2 = q[0] * q[0] + q[1] * q[1];
+      if (r2 < 1e-8) {
+        dx = q[0]; dy = q[1];
+        if (WANT_JAC) { ddx[0] = 1.0; ddy[1] = 1.0; }
+      } else {
+        const double r = sqrt(r2);
+        const double az = fabs(q[2]);
+        const double th = atan2(r, az);
+        const double t2 = th * th;
+        const double thd = th * (1.0 + k[5] * t2 + k[6] * t2 * t2 + k[7] * t2 * t2 * t2 + k[8] * t2 * t2 * t2 * t2);
+        const double sgn = (q[2] < 0.0) ? -1.0 : 1.0;
+        const double s = thd / r;
+        dx = sgn * s * q[0]; dy = sgn * s * q[1];
+        if (WANT_JAC) {
+          const double P = 1.0 + 3.0 * k[5] * t2 + 5.0 * k[6] * t2 * t2 + 7.0 * k[7] * t2 * t2 * t2 + 9.0 * k[8] * t2 * t2 * t2 * t2;
+          const double den = r2 + q[2] * q[2];
+          const double dth_dr = az / den;
+          const double dth_dz = -r * ((q[2] < 0.0) ? -1.0 : 1.0) / den;
+          const double ds_dr = (P * dth_dr * r - thd) / r2;
+          const double ds0 = ds_dr * q[0] / r, ds1 = ds_dr * q[1] / r, ds2 = P * dth_dz / r;
+          ddx[0] = sgn * (s + q[0] * ds0); ddx[1] = sgn * (q[0] * ds1); ddx[2] = sgn * (q[0] * ds2);
+          ddy[0] = sgn * (q[1] * ds0); ddy[1] = sgn * (s + q[1] * ds1); ddy[2] = sgn * (q[1] * ds2);
+        }
+      }
+      break; }
+    case THEIA_CAM_DOUBLE_SPHERE: {
+      // double_sphere_camera_model.h:160-249
+      const double alpha = k[6], xi = k[5];
+      const double r2 = q[0] * q[0] + q[1] * q[1];
+      const double d1 = sqrt(r2 + q[2] * q[2]);
+      const double w1 = alpha > 0.5 ? (1.0 - alpha) / alpha : alpha / (1.0 - alpha);
+      const double w2 = (w1 + xi) / sqrt(2.0 * w1 * xi + xi * xi + 1.0);
+      if (q[2] <= -w2 * d1) ok = false;
+      const double kk = xi * d1 + q[2];
+      const double d2 = sqrt(r2 + kk * kk);
+      const double n = alpha * d2 + (1.0 - alpha) * kk;
+      dx = q[0] / n; dy = q[1] / n;
+      if (WANT_JAC) {
+        const double id1 = 1.0 / d1, id2 = 1.0 / d2, in = 1.0 / n;
+        const double dk[3] = {xi * q[0] * id1, xi * q[1] * id1, xi * q[2] * id1 + 1.0};
+        const double dd2[3] = {(q[0] + kk * dk[0]) * id2, (q[1] + kk * dk[1]) * id2, (kk * dk[2]) * id2};
+        for (int i = 0; i < 3; ++i) {
+          const double dn = alpha * dd2[i] + (1.0 - alpha) * dk[i];
+          ddx[i] = -dx * dn * in;
+          ddy[i] = -dy * dn * in;
+        }
+        ddx[0] += in; ddy[1] += in;
+      }
+      break; }
+    case THEIA_CAM_EXTENDED_UNIFIED: {
+      // extended_unified_camera_model.h:161-249  [.., alpha, beta]
+      const double alpha = k[5], beta = k[6];
+      const double r2 = q[0] * q[0] + q[1] * q[1];
+      const double rho = sqrt(beta * r2 + q[2] * q[2]);
+      const double n = alpha * rho + (1.0 - alpha) * q[2];
+      bool zero = n < 1e-3;
+      if (!zero && alpha > 0.5) zero = (q[2] / n) < (alpha - 1.0) / (alpha + alpha - 1.0);
+      if (!zero) {
+        dx = q[0] / n; dy = q[1] / n;
+        if (WANT_JAC) {
+          const double in = 1.0 / n, ir = 1.0 / rho;
+          const double dn[3] = {alpha * beta * q[0] * ir, alpha * beta * q[1] * ir, alpha * q[2] * ir + (1.0 - alpha)};
+          for (int i = 0; i < 3; ++i) { ddx[i] = -dx * dn[i] * in; ddy[i] = -dy * dn[i] * in; }
+          ddx[0] += in; ddy[1] += in;
+        }
+      }
+      break; }
+    case THEIA_CAM_DIVISION_UNDISTORTION: {
+      // division_undistortion_camera_model.h:173-231,263-297  [f a cx cy k]:
+      // distortion AFTER focal scaling, no skew -> own affine stage
+      const double iz = 1.0 / q[2];
+      const double fx = k[0], fy = k[0] * k[1];
+      const double ux = fx * (q[0] / q[2]), uy = fy * (q[1] / q[2]);
+      const double ru2 = ux * ux + uy * uy;
+      const double denom = 2.0 * k[4] * ru2;
+      const double inner = 1.0 - 4.0 * k[4] * ru2;
+      double scale = 1.0, g = 0.0;  // g = d scale / d(ru2)
+      if (!(fabs(denom) < DBL_EPSILON || inner < 0.0)) {
+        const double sq = sqrt(inner);
+        scale = (1.0 - sq) / denom;
+        g = ((2.0 * k[4] / sq) * denom - (1.0 - sq) * (2.0 * k[4])) / (denom * denom);
+      }
+      uv[0] = ux * scale + k[2];
+      uv[1] = uy * scale + k[3];
+      if (WANT_JAC) {
+        const double pxx = scale + 2.0 * ux * ux * g, pxy = 2.0 * ux * uy * g, pyy = scale + 2.0 * uy * uy * g;
+        // d(ux)/dq = fx (1/z, 0, -x/z), d(uy)/dq = fy (0, 1/z, -y/z)
+        const double xx = q[0] * iz, yy = q[1] * iz;
+        Jq[0] = pxx * fx * iz; Jq[1] = pxy * fy * iz; Jq[2] = -(pxx * fx * xx + pxy * fy * yy) * iz;
+        Jq[3] = pxy * fx * iz; Jq[4] = pyy * fy * iz; Jq[5] = -(pxy * fx * xx + pyy * fy * yy) * iz;
+      }
+      return true; }
+    default:
+      uv[0] = 0.0; uv[1] = 0.0;
+      if (WANT_JAC) for (int i = 0; i < 6; ++i) Jq[i] = 0.0;
+      return false;
   }
-  // affine stage (pinhole_camera_model.h:205-208): u = f dx + s dy + cx, v = f a dy + cy
-  uv[0] = k[0] * dx + k[2] * dy + k[3];
-  uv[1] = k[0] * k[1] * dy + k[4];
+  if (planar && WANT_JAC) {
+    // chain through x = q0/q2, y = q1/q2
+    const double iz = 1.0 / q[2];
+    ddx[0] = dxx * iz; ddx[1] = dxy * iz; ddx[2] = -(dxx * x + dxy * y) * iz;
+    ddy[0] = dyx * iz; ddy[1] = dyy * iz; ddy[2] = -(dyx * x + dyy * y) * iz;
+  }
+  // affine stage: u = f dx + s dy + cx, v = f a dy + cy; FOV has no skew slot
+  const bool noskew = (model == THEIA_CAM_FOV);
+  const double f = k[0], fa = k[0] * k[1];
+  const double sk = noskew ? 0.0 : k[2];
+  const double cx = noskew ? k[2] : k[3], cy = noskew ? k[3] : k[4];
+  uv[0] = f * dx + sk * dy + cx;
+  uv[1] = fa * dy + cy;
   if (WANT_JAC) {
-    const double fa = k[0] * k[1];
     for (int i = 0; i < 3; ++i) {
-      Jq[i] = k[0] * ddx[i] + k[2] * ddy[i];
+      Jq[i] = f * ddx[i] + sk * ddy[i];
       Jq[3 + i] = fa * ddy[i];
     }
   }

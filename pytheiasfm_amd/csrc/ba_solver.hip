@@ -115,7 +115,7 @@ namespace {
 
 enum { SB_COST = 0, SB_MCC = 1, SB_STEPSQ = 2, SB_XNORMSQ = 3, SB_INVALID = 4, SB_STEPSQ_CAM = 8, SB_XNORMSQ_CAM = 9 };
 
-int supported_model(int m) { return m == THEIA_CAM_PINHOLE || m == THEIA_CAM_DOUBLE_SPHERE; }
+int supported_model(int m) { return m >= THEIA_CAM_PINHOLE && m <= THEIA_CAM_ORTHOGRAPHIC; }
 
 int validate(const theia_ba_problem* p, const theia_ba_options* o) {
   if (!p || !o) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null problem/options");

@@ -165,9 +165,9 @@ def test_edge_cases_empty_invalid_and_errors():
     o2 = ba.default_options(); o2.intrinsics_to_optimize = 1
     with pytest.raises(capi.TheiaHipError):
         ba.solve(synth.synth_ba_v1(4, 20, seed=73), o2)
-    fish = synth.synth_ba_v1(4, 20, seed=74); fish.group_model[:] = 2
+    unknown = synth.synth_ba_v1(4, 20, seed=74); unknown.group_model[:] = 9
     with pytest.raises(capi.TheiaHipError):
-        ba.solve(fish, o)
+        ba.solve(unknown, o)
 
 
 def test_full_size_c2_properties():
@@ -206,3 +206,43 @@ def test_dense_cholesky_kernel_against_numpy(n):
     with pytest.raises(capi.TheiaHipError):
         Abad = A.copy(); Abad[n // 2, n // 2] = -1.0
         ba.dense_spd_solve(np.tril(Abad), b)
+
+
+CAMERA_MODEL_INTRINSICS = {
+    0: [1000.0, 1.0, 0.0, 960.0, 540.0, -0.05, 0.01],
+    1: [1000.0, 1.02, 0.2, 960.0, 540.0, -0.1, 0.02, 0.001, 0.001, -0.002],
+    2: [600.0, 1.0, 0.1, 960.0, 540.0, 0.01, -0.002, 0.001, 0.0005],
+    3: [800.0, 1.01, 960.0, 540.0, 0.9],
+    4: [1000.0, 0.99, 960.0, 540.0, -1e-7],
+    5: [600.0, 1.0, 0.0, 960.0, 540.0, -0.2, 0.55],
+    6: [600.0, 1.0, 0.0, 960.0, 540.0, 0.6, 1.1],
+    7: [80.0, 1.0, 0.1, 960.0, 540.0, 0.001, -0.0001],
+}
+
+
+@pytest.mark.parametrize("model", sorted(CAMERA_MODEL_INTRINSICS))
+def test_every_camera_model_matches_jet_oracle(model):
+    """A7: closed-form derivatives of all eight camera models vs the Jet oracle,
+    plus one LM solve (trajectory parity)."""
+    p = synth.synth_ba_v1(12, 500, seed=200 + model, num_groups=3)
+    k = CAMERA_MODEL_INTRINSICS[model]
+    p.group_model[:] = model
+    p.intrinsics[:] = 0.0
+    p.intrinsics[:, : len(k)] = k
+    if model == 3:
+        p.intrinsics[1, 4] = 5e-4      # small-omega Taylor branch of the FOV model
+    o, oo = both_options()
+    with ba.BaHandle(p.copy(), o) as h:
+        cost, r, jc, jp, valid = h.evaluate()
+    ok, ocost, orr, ojc, ojp = ol.evaluate(p, oo)
+    assert valid.all() == bool(ok)
+    assert abs(cost - ocost) <= 1e-12 * ocost
+    assert np.abs(r - orr).max() <= 1e-9 * max(1.0, np.abs(orr).max())
+    assert rel(jc, ojc) <= 1e-11 and rel(jp, ojp) <= 1e-11
+    o.max_num_iterations = oo.max_num_iterations = 6
+    pg, po = p.copy(), p.copy()
+    s, tr = ba.solve(pg, o)
+    so, tro = ol.solve(po, oo)
+    assert s.num_iterations == so.num_iterations and np.array_equal(tr.accepted, tro.accepted)
+    fin = tro.cost < 1e300
+    assert rel(tr.cost[fin], tro.cost[fin]) <= 1e-8
