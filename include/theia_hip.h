@@ -257,8 +257,14 @@ typedef struct theia_ransac_params {
   int32_t use_Tdd_test;        /* reference: "Not currently implemented"  */
   uint32_t seed;               /* seeds the mt19937 stream (util/random.cc:60-66),
                                   i.e. RandomNumberGenerator(seed)        */
-  int32_t reserved0;
+  int32_t ransac_type;         /* THEIA_RANSAC_* (create_and_initialize_ransac_variant.h:52) */
 } theia_ransac_params;
+
+/* RansacType: RANSAC = RandomSampler + InlierSupport/MLE; PROSAC = ProsacSampler
+ * (prosac_sampler.cc:53-128, data sorted by quality, best first); LMED and
+ * EXHAUSTIVE are rejected (EXHAUSTIVE CHECK-fails in the reference for every
+ * estimator here: its sampler requires a sample size of 2). */
+enum { THEIA_RANSAC_RANSAC = 0, THEIA_RANSAC_PROSAC = 1, THEIA_RANSAC_LMED = 2, THEIA_RANSAC_EXHAUSTIVE = 3 };
 
 void theia_ransac_params_default(theia_ransac_params* p);
 

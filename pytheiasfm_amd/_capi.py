@@ -78,7 +78,7 @@ class RansacParams(C.Structure):
         ("min_inlier_ratio", C.c_double),
         ("min_iterations", C.c_int32), ("max_iterations", C.c_int32), ("use_mle", C.c_int32),
         ("use_lo", C.c_int32), ("lo_start_iterations", C.c_int32), ("use_Tdd_test", C.c_int32),
-        ("seed", C.c_uint32), ("reserved0", C.c_int32),
+        ("seed", C.c_uint32), ("ransac_type", C.c_int32),
     ]
 
 

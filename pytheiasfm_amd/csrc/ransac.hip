@@ -271,6 +271,40 @@ int compute_max_iterations(const theia_ransac_params& P, double min_sample_size,
   return (int)std::max((double)P.min_iterations, std::min(num_iterations, (double)P.max_iterations));
 }
 
+// ProsacSampler::Sample (solvers/prosac_sampler.cc:62-128): data sorted by
+// quality; the k-th sample draws m-1 points from the top n-1 and the n-th point
+// (or m from the top n once T'_n < k).  The reference pushes index `n` itself,
+// which is one past the end once n reaches N; that single case is clamped to N-1
+// here (the reference reads out of bounds there).
+void prosac_sample(Mt19937& rng, int N, int m, int kth, int* out) {
+  double t_n = 20000.0;  // ransac_convergence_iterations_
+  int n = m;
+  for (int i = 0; i < m; ++i) t_n *= (double)(n - i) / (N - i);
+  double t_n_prime = 1.0;
+  for (int t = 1; t <= kth; ++t) {
+    if (t > t_n_prime && n < N) {
+      const double t_n_plus1 = (t_n * (n + 1.0)) / (n + 1.0 - m);
+      t_n_prime += std::ceil(t_n_plus1 - t_n);
+      t_n = t_n_plus1;
+      n++;
+    }
+  }
+  auto draw_unique = [&](int count, int hi) {
+    for (int i = 0; i < count; ++i) {
+      int r;
+      bool dup;
+      do {
+        r = rng.rand_int(0, hi);
+        dup = false;
+        for (int q = 0; q < i; ++q) dup |= (out[q] == r);
+      } while (dup);
+      out[i] = r;
+    }
+  };
+  if (t_n_prime < kth) draw_unique(m, n - 1);
+  else { draw_unique(m - 1, n - 2); out[m - 1] = std::min(n, N - 1); }
+}
+
 struct ProblemState {
   Mt19937 rng;
   std::vector<int> idx;
@@ -280,6 +314,7 @@ struct ProblemState {
   int best_slot;
   int best_samples[5];
   int round_iters;
+  int kth;  // PROSAC sample counter
 };
 
 #define HIP_TRYR(expr)                                                                               \
@@ -339,6 +374,12 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     return set_error(THEIA_HIP_ERR_UNSUPPORTED, "DLS / SQPnP minimal solvers have no HIP kernel yet");
   if (est < 0 || est > THEIA_EST_ABSOLUTE_POSE_SQPNP) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
   if (P.use_lo) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: LO-RANSAC refinement is not built yet (DESIGN.md scope)");
+  if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "ExhaustiveSampler makes a hard assumption that the number of samples needed is 2.");
+  if (P.ransac_type == THEIA_RANSAC_LMED)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "LMED (median quality measurement) has no HIP kernel yet");
+  if (P.ransac_type != THEIA_RANSAC_RANSAC && P.ransac_type != THEIA_RANSAC_PROSAC)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown ransac_type");
   const int nprob = batch->num_problems;
   if (nprob < 0 || (nprob > 0 && (!batch->offsets || !batch->data))) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad batch");
   if (nprob > 0 && (!result->success || !result->models || !result->num_inliers || !result->inlier_mask ||
@@ -404,7 +445,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     s.max_iterations = P.max_iterations;
     if (P.min_inlier_ratio > 0)
       s.max_iterations = std::min(compute_max_iterations(P, m, P.min_inlier_ratio, log_failure_prob, s.n), P.max_iterations);
-    s.it = 0; s.done = s.max_iterations <= 0; s.best_slot = -1;
+    s.it = 0; s.done = s.max_iterations <= 0; s.best_slot = -1; s.kth = 1;
     for (int k = 0; k < 5; ++k) s.best_samples[k] = 0;
   }
   double fit_score_ms = 0.0;
@@ -431,11 +472,13 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       for (int q = 0; q < cn; ++q) {
         ProblemState& s = S[c0 + q];
         int* out = h_samples.data() + (size_t)q * B * m;
-        for (int b = 0; b < s.round_iters; ++b)
+        for (int b = 0; b < s.round_iters; ++b) {
+          if (P.ransac_type == THEIA_RANSAC_PROSAC) { prosac_sample(s.rng, s.n, m, s.kth++, out + (size_t)b * m); continue; }
           for (int i = 0; i < m; ++i) {
             std::swap(s.idx[i], s.idx[s.rng.rand_int(i, s.n - 1)]);
             out[(size_t)b * m + i] = s.idx[i];
           }
+        }
       }
       const size_t nh = (size_t)cn * B;
       if ((rc = d_samples.ensure(nh * m)) || (rc = d_counts.ensure(nh)) || (rc = d_models.ensure(nh * kMaxModels * kStride)) ||

@@ -47,6 +47,7 @@ class RansacParameters:
         self.use_lo = False
         self.lo_start_iterations = 50
         self.seed = 0
+        self.ransac_type = RansacType.RANSAC  # set by the Estimate* wrappers from their ransac_type argument
 
     def to_c(self):
         p = capi.RansacParams()
@@ -60,6 +61,7 @@ class RansacParameters:
         p.lo_start_iterations = int(self.lo_start_iterations)
         p.use_Tdd_test = int(bool(self.use_Tdd_test))
         p.seed = int(self.seed) & 0xFFFFFFFF
+        p.ransac_type = int(self.ransac_type)
         return p
 
 
@@ -126,10 +128,10 @@ def estimate_batch(estimator, data, offsets, params):
 
 
 def _single(estimator, ransac_params, ransac_type, data):
-    if RansacType(ransac_type) != RansacType.RANSAC:
-        raise capi.TheiaHipError(-3, f"RansacType {RansacType(ransac_type).name} is not built in the HIP backend yet")
     data = np.ascontiguousarray(data, dtype=np.float64)
-    res = estimate_batch(estimator, data, np.array([0, data.shape[0]], dtype=np.int64), ransac_params)
+    pc = ransac_params.to_c()
+    pc.ransac_type = int(RansacType(ransac_type))
+    res = estimate_batch(estimator, data, np.array([0, data.shape[0]], dtype=np.int64), pc)
     s = RansacSummary()
     s.inliers = np.nonzero(res["inlier_mask"])[0].tolist()
     s.num_input_data_points = data.shape[0]

@@ -217,7 +217,7 @@ def default_ransac_params(error_thresh, seed=0):
     p = capi.RansacParams()
     p.error_thresh = error_thresh; p.failure_probability = 0.01; p.min_inlier_ratio = 0.0
     p.min_iterations = 100; p.max_iterations = 2 ** 31 - 1; p.use_mle = 0; p.use_lo = 0
-    p.lo_start_iterations = 50; p.use_Tdd_test = 0; p.seed = seed
+    p.lo_start_iterations = 50; p.use_Tdd_test = 0; p.seed = seed; p.ransac_type = 0
     return p
 
 

@@ -54,3 +54,4 @@ def test_defaults_match_reference_structs():
     # sample_consensus_estimator.h:59-68
     assert p.error_thresh == -1 and p.failure_probability == 0.01 and p.min_iterations == 100
     assert p.max_iterations == 2 ** 31 - 1 and p.use_mle == 0 and p.use_lo == 0 and p.lo_start_iterations == 50
+    assert p.ransac_type == 0

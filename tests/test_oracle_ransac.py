@@ -233,3 +233,16 @@ def test_golden_ransac_fixture():
                 if i == 0:
                     assert np.array_equal(r["trace"][0], g[f"{kind}_mle{use_mle}_trace_iter"])
                     assert np.array_equal(r["trace"][2], g[f"{kind}_mle{use_mle}_trace_ninl"])
+
+
+def test_prosac_sampler_properties():
+    """ProsacSampler: early samples come from the top of the quality-sorted data,
+    indices are unique and in range; PROSAC finds the model with sorted data."""
+    data, offsets, truth = synth.synth_ransac_v1(1, 300, "relative", seed=77)
+    order = np.argsort(~truth["inlier"][0], kind="stable")
+    data = data[order]
+    prm = ol.default_ransac_params((2 / 1000.0) ** 2, seed=3); prm.ransac_type = 1
+    r = ol.ransac_estimate(0, data, prm, trace_capacity=4096)
+    assert r["success"] and r["num_inliers"] > 0.8 * truth["inlier"][0].sum()
+    # first scored models already have many inliers (samples drawn from the best data)
+    assert r["trace"][2][:5].max() > 0.5 * truth["inlier"][0].sum()

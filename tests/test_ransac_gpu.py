@@ -112,7 +112,9 @@ def test_mirror_api_and_error_conventions():
     with pytest.raises(capi.TheiaHipError):
         ransac.EstimateRelativePose(bad, ransac.RansacType.RANSAC, data)
     with pytest.raises(capi.TheiaHipError):
-        ransac.EstimateRelativePose(p, ransac.RansacType.PROSAC, data)
+        ransac.EstimateRelativePose(p, ransac.RansacType.EXHAUSTIVE, data)   # reference CHECK: sample size must be 2
+    with pytest.raises(capi.TheiaHipError):
+        ransac.EstimateRelativePose(p, ransac.RansacType.LMED, data)
     with pytest.raises(capi.TheiaHipError):
         ransac.EstimateCalibratedAbsolutePose(p, ransac.RansacType.RANSAC, ransac.PnPType.DLS, da)
     with pytest.raises(capi.TheiaHipError):
@@ -130,3 +132,23 @@ def test_c5_slice_properties():
     assert np.all(a["num_iterations"] == 4096) and a["hypotheses_evaluated"] == 16 * 4096
     ratio = a["num_inliers"] / 2000.0
     assert np.all(ratio > 0.8 * truth["ratio"] - 0.05) and np.all(ratio <= 1.0)
+
+
+@pytest.mark.parametrize("est,kind", [(0, "relative"), (2, "absolute")])
+def test_prosac_inlier_sets_bit_identical_to_oracle(est, kind):
+    """R4: PROSAC sampler (prosac_sampler.cc:62-128); data sorted best-first
+    (inliers first is a valid quality order for the synthetic data)."""
+    data, offsets, truth = synth.synth_ransac_v1(6, 300, kind, seed=0x5AC50400 + est)
+    for i in range(6):  # quality order: true inliers first
+        sl = slice(offsets[i], offsets[i + 1])
+        order = np.argsort(~truth["inlier"][i], kind="stable")
+        data[sl] = data[sl][order]
+    p = ransac.RansacParameters(); p.error_thresh = THR[est]; p.seed = 11; p.ransac_type = ransac.RansacType.PROSAC
+    res = ransac.estimate_batch(est, data, offsets, p)
+    for i in range(6):
+        pc = p.to_c(); pc.seed = 11 + i
+        o = ol.ransac_estimate(est, data[offsets[i]:offsets[i + 1]], pc)
+        sl = slice(offsets[i], offsets[i + 1])
+        assert np.array_equal(o["inlier_mask"], res["inlier_mask"][sl]) and o["num_iterations"] == res["num_iterations"][i]
+        assert np.array_equal(o["model"][: MLEN[est]], res["models"][i][: MLEN[est]], equal_nan=True)
+        assert res["num_inliers"][i] > 0.8 * truth["inlier"][i].sum()
