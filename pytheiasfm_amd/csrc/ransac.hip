@@ -98,7 +98,8 @@ __device__ inline double model_error(int est, const double* m, const double* d) 
 __global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int64_t* __restrict__ offsets,
                                             const double* __restrict__ data, const int* __restrict__ samples,
                                             const int* __restrict__ active_iters, double* __restrict__ models,
-                                            int* __restrict__ counts) {
+                                            int* __restrict__ counts, int* __restrict__ dense_count,
+                                            int* __restrict__ tags) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int p = blockIdx.y;
   if (b >= B || p >= nprob) return;
@@ -114,9 +115,17 @@ __global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int
   double mloc[kMaxModels * kStride];
   const int nm = estimate_models(est, subset, mloc);
   counts[hyp] = nm;
-  double* mo = models + hyp * (size_t)(kMaxModels * kStride);
-  for (int j = 0; j < nm; ++j)
+  if (nm == 0) return;
+  // append to the problem's DENSE model list (most of the 10 slots per hypothesis
+  // are empty: scoring a dense list keeps every lane of k_score busy); the tag
+  // remembers (iteration, slot) so the host replays in sample order.
+  const int base = atomicAdd(&dense_count[p], nm);
+  double* mo = models + ((size_t)p * B * kMaxModels + base) * (size_t)kStride;
+  int* tg = tags + (size_t)p * B * kMaxModels + base;
+  for (int j = 0; j < nm; ++j) {
     for (int k = 0; k < kStride; ++k) mo[j * kStride + k] = mloc[j * kStride + k];
+    tg[j] = b * kMaxModels + j;
+  }
 }
 
 // K6: one thread per (problem, iteration, model slot); block = 256 slots of ONE
@@ -124,10 +133,13 @@ __global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int
 template <bool USE_LDS>
 __global__ __launch_bounds__(256) void k_score(int est, int nprob, int B, const int64_t* __restrict__ offsets,
                                                const double* __restrict__ data, const double* __restrict__ models,
-                                               const int* __restrict__ counts, double thresh, int use_mle,
-                                               double* __restrict__ cost, int* __restrict__ ninl) {
+                                               const int* __restrict__ dense_count, const int* __restrict__ tags,
+                                               double thresh, int use_mle, double* __restrict__ cost,
+                                               int* __restrict__ ninl) {
   extern __shared__ __attribute__((aligned(16))) double sdata[];
   const int p = blockIdx.y;
+  const int nmodels = dense_count[p];
+  if ((int)(blockIdx.x * blockDim.x) >= nmodels) return;  // whole block beyond the dense list
   const int ds = datum_size(est);
   const int64_t n64 = offsets[p + 1] - offsets[p];
   const int n = (int)n64;
@@ -138,12 +150,11 @@ __global__ __launch_bounds__(256) void k_score(int est, int nprob, int B, const 
     pd = sdata;
   }
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= B * kMaxModels) return;
-  const int b = slot / kMaxModels, j = slot % kMaxModels;
-  const size_t hyp = (size_t)p * B + b;
-  if (j >= counts[hyp]) return;
+  if (slot >= nmodels) return;
+  const size_t dense = (size_t)p * B * kMaxModels + slot;
+  const size_t out = (size_t)p * B * kMaxModels + tags[dense];  // [hyp][slot] position
   double m[kStride];
-  const double* mo = models + (hyp * kMaxModels + j) * (size_t)kStride;
+  const double* mo = models + dense * (size_t)kStride;
 #pragma unroll
   for (int k = 0; k < kStride; ++k) m[k] = mo[k];
   int cnt = 0;
@@ -153,8 +164,8 @@ __global__ __launch_bounds__(256) void k_score(int est, int nprob, int B, const 
     if (r < thresh) { cnt++; mle += r; }
     else mle += thresh;
   }
-  cost[hyp * kMaxModels + j] = use_mle ? mle : (double)(n - cnt);
-  ninl[hyp * kMaxModels + j] = cnt;
+  cost[out] = use_mle ? mle : (double)(n - cnt);
+  ninl[out] = cnt;
 }
 
 // final pass: refit the winning hypothesis (deterministic -> identical model)
@@ -422,7 +433,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   int chunk = (int)std::max<size_t>(1, ((size_t)3 << 29) / (per_hyp * (size_t)first_round));
   chunk = std::min(chunk, nprob);
 
-  DBuf<int> d_samples, d_counts, d_ninl, d_active, d_best_samples, d_best_slot;
+  DBuf<int> d_samples, d_counts, d_ninl, d_active, d_best_samples, d_best_slot, d_dense, d_tags;
   DBuf<double> d_models, d_cost, d_best_models;
   DBuf<uint8_t> d_mask;
   std::vector<int> h_samples, h_counts, h_ninl, h_active;
@@ -482,21 +493,23 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       }
       const size_t nh = (size_t)cn * B;
       if ((rc = d_samples.ensure(nh * m)) || (rc = d_counts.ensure(nh)) || (rc = d_models.ensure(nh * kMaxModels * kStride)) ||
-          (rc = d_cost.ensure(nh * kMaxModels)) || (rc = d_ninl.ensure(nh * kMaxModels)) || (rc = d_active.ensure(cn)))
+          (rc = d_cost.ensure(nh * kMaxModels)) || (rc = d_ninl.ensure(nh * kMaxModels)) || (rc = d_active.ensure(cn)) ||
+          (rc = d_dense.ensure(cn)) || (rc = d_tags.ensure(nh * kMaxModels)))
         return rc;
+      HIP_TRYR(hipMemsetAsync(d_dense.p, 0, sizeof(int) * cn, st));
       HIP_TRYR(hipMemcpyAsync(d_samples.p, h_samples.data(), sizeof(int) * nh * m, hipMemcpyHostToDevice, st));
       HIP_TRYR(hipMemcpyAsync(d_active.p, h_active.data(), sizeof(int) * cn, hipMemcpyHostToDevice, st));
       HIP_TRYR(hipEventRecord(ev0, st));
       {
         dim3 grid((B + 63) / 64, cn);
-        k_fit<<<grid, 64, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_models.p, d_counts.p);
+        k_fit<<<grid, 64, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_models.p, d_counts.p, d_dense.p, d_tags.p);
       }
       {
         dim3 grid((B * kMaxModels + 255) / 256, cn);
         if (use_lds)
-          k_score<true><<<grid, 256, lds_bytes, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_models.p, d_counts.p, P.error_thresh, P.use_mle, d_cost.p, d_ninl.p);
+          k_score<true><<<grid, 256, lds_bytes, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_models.p, d_dense.p, d_tags.p, P.error_thresh, P.use_mle, d_cost.p, d_ninl.p);
         else
-          k_score<false><<<grid, 256, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_models.p, d_counts.p, P.error_thresh, P.use_mle, d_cost.p, d_ninl.p);
+          k_score<false><<<grid, 256, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_models.p, d_dense.p, d_tags.p, P.error_thresh, P.use_mle, d_cost.p, d_ninl.p);
       }
       HIP_TRYR(hipEventRecord(ev1, st));
       h_counts.resize(nh); h_cost.resize(nh * kMaxModels); h_ninl.resize(nh * kMaxModels);
