@@ -29,6 +29,12 @@ struct DevProblem {
   int tiles_per_wg, nwg;       // linearize: workgroup b owns tiles [b*tiles_per_wg, ...)
   const int* wg_base;          // [nwg] first reduced camera of the workgroup's LDS window
   long long* stamps;           // development: per-phase cycle counts of workgroup 0 (or nullptr)
+  // tracks with > 64 observations (slow path, ba_kernels.hip "long tracks")
+  int long_nobs, long_ntracks;
+  const int* long_obs_index;   // [long_nobs] index into the sorted observation arrays
+  const int* long_obs_slot;    // [long_nobs]
+  const int* long_track_start; // [long_ntracks + 1]
+  const int* long_track_pt;    // [long_ntracks]
   const double* scale_c;       // [nc][6] Jacobi scaling
   const double* scale_p;       // [np][pd]
 };
@@ -68,6 +74,14 @@ void launch_evaluate(const DevProblem& P, const double* cam, const double* pts, 
                      hipStream_t st);
 void launch_cost_only(const DevProblem& P, const double* cam, const double* pts, double* tile_part,
                       double* scal, hipStream_t st);
+
+void launch_long_colnorm(const DevProblem& P, const double* cam, const double* pts, double* colsq_c, double* colsq_p,
+                         double* scratch, hipStream_t st);
+void launch_long_linearize(const DevProblem& P, const double* cam, const double* pts, double radius, const ReduceBuf& rb,
+                           double* Vinv, double* gp, double* scratch, hipStream_t st);
+void launch_long_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,
+                         double* cand_pts, const double* yc, const double* Vinv, double* scratch, double* scalB,
+                         hipStream_t st);
 
 // dense SPD solve  A x = b  (lower triangle of row-major A, leading dim lda;
 // A is overwritten by its Cholesky factor, b by x).  fail_flag (device) is

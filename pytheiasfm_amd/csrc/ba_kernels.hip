@@ -695,6 +695,210 @@ __global__ __launch_bounds__(kBlock) void k_evaluate(DevProblem P, const double*
   if (lane == 0) { tile_part[2 * (size_t)tile] = cost; tile_part[2 * (size_t)tile + 1] = inval; }
 }
 
+// ------------------------------------------------------------- long tracks
+// Tracks with more than 64 observations do not fit a wave tile.  They are rare
+// (a few percent of real reconstructions) and take this slower path: one thread
+// per observation, per-track sums through global FP64 atomics into a small
+// scratch [track][NT + PD], pair products by re-linearising the partner.
+// Results are the same quantities the tiled kernels produce.
+struct LongView {
+  int nobs;                    // observations of long tracks
+  int ntracks;
+  const int* obs_index;        // [nobs] index into the sorted observation arrays
+  const int* obs_slot;         // [nobs] long-track slot of the observation
+  const int* track_start;      // [ntracks + 1] offsets into obs_index
+  const int* track_pt;         // [ntracks] point id
+};
+
+THIP_DEV void atomic_max_nonneg(double* p, double v) {
+  atomicMax(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v));
+}
+
+// pass A: per-observation linearisation -> per-track V/g (scratch), camera terms.
+//   MODE 0: column norms only (Jacobi scaling pass); MODE 1: linearize.
+template <int PD, int MODE>
+__global__ void k_long_accum(DevProblem P, LongView Lv, const double* __restrict__ cam, const double* __restrict__ pts,
+                             double* __restrict__ scratch, double* __restrict__ S, double* __restrict__ rhs,
+                             double* __restrict__ colsq, double* __restrict__ gc, double* __restrict__ scal,
+                             double* __restrict__ colsq_c0) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Lv.nobs) return;
+  LaneLin<PD> L;
+  lane_linearize<PD, true>(P, cam, pts, Lv.obs_index[t], true, 0, L);
+  double* sc = scratch + (size_t)Lv.obs_slot[t] * (NT + PD);
+#pragma unroll
+  for (int a = 0; a < PD; ++a) {
+#pragma unroll
+    for (int b = 0; b <= a; ++b) atomic_add(&sc[lidx(a, b)], L.Jt[a] * L.Jt[b] + L.Jt[PD + a] * L.Jt[PD + b]);
+    if (MODE == 1) atomic_add(&sc[NT + a], L.Jt[a] * L.r[0] + L.Jt[PD + a] * L.r[1]);
+  }
+  if (MODE == 0) {
+    if (L.rc >= 0)
+      for (int q = 0; q < 6; ++q) atomic_add(&colsq_c0[6 * L.c + q], L.Jc[q] * L.Jc[q] + L.Jc[6 + q] * L.Jc[6 + q]);
+    return;
+  }
+  atomic_add(&scal[SC_COST], L.cost);
+  if (!L.valid) atomic_add(&scal[SC_INVALID], 1.0);
+  if (L.rc >= 0) {
+    const int n = P.n, rc = L.rc;
+    double* Sd = S + (size_t)(6 * rc) * n + 6 * rc;
+    for (int a = 0; a < 6; ++a) {
+      const double jr = L.Jc[a] * L.r[0] + L.Jc[6 + a] * L.r[1];
+      atomic_add(&rhs[6 * rc + a], jr);
+      atomic_add(&gc[6 * rc + a], jr);
+      atomic_add(&colsq[6 * rc + a], L.Jc[a] * L.Jc[a] + L.Jc[6 + a] * L.Jc[6 + a]);
+      for (int b = 0; b <= a; ++b) atomic_add(&Sd[(size_t)a * n + b], L.Jc[a] * L.Jc[b] + L.Jc[6 + a] * L.Jc[6 + b]);
+    }
+  }
+}
+
+// pass B: per long track: colsq_p (MODE 0) or damped inverse, g_p, gradient max (MODE 1)
+template <int PD, int MODE>
+__global__ void k_long_track(DevProblem P, LongView Lv, double radius, const double* __restrict__ scratch,
+                             double* __restrict__ colsq_p, double* __restrict__ Vinv, double* __restrict__ gp,
+                             double* __restrict__ scal) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Lv.ntracks) return;
+  const int p = Lv.track_pt[t];
+  const double* sc = scratch + (size_t)t * (NT + PD);
+  if (MODE == 0) {
+    for (int a = 0; a < PD; ++a) colsq_p[(size_t)PD * p + a] = sc[lidx(a, a)];
+    return;
+  }
+  if (P.pt_const[p]) return;
+  double V[NT], Vi[NT];
+  for (int k = 0; k < NT; ++k) V[k] = sc[k];
+  for (int a = 0; a < PD; ++a) V[lidx(a, a)] += fmin(fmax(V[lidx(a, a)], 1e-6), 1e32) / radius;
+  const bool ok = invert_spd<PD>(V, Vi);
+  if (!ok) { atomic_add(&scal[SC_NOTPD], 1.0); for (int k = 0; k < NT; ++k) Vi[k] = 0.0; }
+  for (int k = 0; k < NT; ++k) Vinv[(size_t)NT * p + k] = Vi[k];
+  double gmax = 0.0;
+  for (int a = 0; a < PD; ++a) {
+    gp[(size_t)PD * p + a] = sc[NT + a];
+    gmax = fmax(gmax, fabs(sc[NT + a] / P.scale_p[(size_t)PD * p + a]));
+  }
+  atomic_max_nonneg(&scal[SC_GMAX], gmax);
+}
+
+// pass C: Schur products of long tracks: thread = observation i, walks the
+// track's observations j (re-linearised), S_ij -= W_i V^-1 W_j^T, rhs -= W_i V^-1 g.
+template <int PD>
+__global__ void k_long_schur(DevProblem P, LongView Lv, const double* __restrict__ cam, const double* __restrict__ pts,
+                             const double* __restrict__ Vinv, const double* __restrict__ gp, double* __restrict__ S,
+                             double* __restrict__ rhs) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  constexpr int NW = 6 * PD;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Lv.nobs) return;
+  LaneLin<PD> L;
+  lane_linearize<PD, true>(P, cam, pts, Lv.obs_index[t], true, 0, L);
+  if (L.rc < 0 || L.pconst) return;
+  double Vi[NT], T[NW];
+  for (int k = 0; k < NT; ++k) Vi[k] = Vinv[(size_t)NT * L.p + k];
+  for (int a = 0; a < 6; ++a) {
+    double W[PD];
+    for (int b = 0; b < PD; ++b) W[b] = L.Jc[a] * L.Jt[b] + L.Jc[6 + a] * L.Jt[PD + b];
+    double wy = 0.0;
+    for (int b = 0; b < PD; ++b) {
+      double s = 0.0;
+      for (int k = 0; k < PD; ++k) s += W[k] * sym_get<PD>(Vi, k, b);
+      T[a * PD + b] = s;
+      wy += s * gp[(size_t)PD * L.p + b];   // (W Vinv) g = W (Vinv g)
+    }
+    atomic_add(&rhs[6 * L.rc + a], -wy);
+  }
+  const int n = P.n, slot = Lv.obs_slot[t];
+  for (int u = Lv.track_start[slot]; u < Lv.track_start[slot + 1]; ++u) {
+    LaneLin<PD> M;
+    lane_linearize<PD, true>(P, cam, pts, Lv.obs_index[u], true, 0, M);
+    if (M.rc < 0 || L.rc < M.rc) continue;
+    double* Sb = S + (size_t)(6 * L.rc) * n + 6 * M.rc;
+    const bool diag = L.rc == M.rc;
+    for (int a = 0; a < 6; ++a)
+      for (int b = 0; b < 6; ++b) {
+        if (diag && b > a) continue;
+        double s = 0.0;
+        for (int k = 0; k < PD; ++k) s += T[a * PD + k] * (M.Jc[b] * M.Jt[k] + M.Jc[6 + b] * M.Jt[PD + k]);
+        atomic_add(&Sb[(size_t)a * n + b], -s);
+      }
+  }
+}
+
+// back-substitution, pass 1: t_p = sum E^T (r - F y_c) into the scratch
+template <int PD>
+__global__ void k_long_back1(DevProblem P, LongView Lv, const double* __restrict__ cam, const double* __restrict__ pts,
+                             const double* __restrict__ yc, double* __restrict__ scratch) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Lv.nobs) return;
+  LaneLin<PD> L;
+  lane_linearize<PD, true>(P, cam, pts, Lv.obs_index[t], true, 0, L);
+  double mc[2] = {0.0, 0.0};
+  if (L.rc >= 0)
+    for (int q = 0; q < 6; ++q) { mc[0] += L.Jc[q] * yc[6 * L.rc + q]; mc[1] += L.Jc[6 + q] * yc[6 * L.rc + q]; }
+  double* sc = scratch + (size_t)Lv.obs_slot[t] * (NT + PD);
+  for (int q = 0; q < PD; ++q) atomic_add(&sc[q], L.Jt[q] * (L.r[0] - mc[0]) + L.Jt[PD + q] * (L.r[1] - mc[1]));
+}
+
+// back-substitution, pass 2: y_p, model cost change, candidate point + trial cost
+template <int PD>
+__global__ void k_long_back2(DevProblem P, LongView Lv, const double* __restrict__ cam, const double* __restrict__ pts,
+                             const double* __restrict__ cand_cam, double* __restrict__ cand_pts,
+                             const double* __restrict__ yc, const double* __restrict__ Vinv,
+                             const double* __restrict__ scratch, double* __restrict__ scalB) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Lv.nobs) return;
+  const int o = Lv.obs_index[t];
+  LaneLin<PD> L;
+  lane_linearize<PD, true>(P, cam, pts, o, true, 0, L);
+  const int slot = Lv.obs_slot[t];
+  const double* sc = scratch + (size_t)slot * (NT + PD);
+  double yp[PD];
+  for (int a = 0; a < PD; ++a) {
+    double s = 0.0;
+    if (!L.pconst) for (int b = 0; b < PD; ++b) {
+      const double v = (a >= b) ? Vinv[(size_t)NT * L.p + lidx(a, b)] : Vinv[(size_t)NT * L.p + lidx(b, a)];
+      s += v * sc[b];
+    }
+    yp[a] = s;
+  }
+  double mcc = 0.0;
+  for (int a = 0; a < 2; ++a) {
+    double m = 0.0;
+    if (L.rc >= 0) for (int q = 0; q < 6; ++q) m -= L.Jc[6 * a + q] * yc[6 * L.rc + q];
+    for (int q = 0; q < PD; ++q) m -= L.Jt[a * PD + q] * yp[q];
+    mcc -= m * (L.r[a] + m / 2.0);
+  }
+  double Xp[4] = {L.X[0], L.X[1], L.X[2], L.X[3]};
+  if (!L.pconst) {
+    double d[PD];
+    for (int q = 0; q < PD; ++q) d[q] = -yp[q] * P.scale_p[(size_t)PD * L.p + q];
+    if (PD == 3) { const double d3[3] = {d[0], d[1], d[2]}; sphere_plus(L.X, d3, Xp); }
+    else for (int q = 0; q < PD; ++q) Xp[q] = L.X[q] + d[q];
+    if (t == Lv.track_start[slot]) {  // first observation of the track writes the point
+      reinterpret_cast<double4*>(cand_pts)[L.p] = make_double4(Xp[0], Xp[1], Xp[2], Xp[3]);
+      double st = 0.0, xn = 0.0;
+      for (int q = 0; q < 4; ++q) { st += (L.X[q] - Xp[q]) * (L.X[q] - Xp[q]); xn += Xp[q] * Xp[q]; }
+      atomic_add(&scalB[2], st); atomic_add(&scalB[3], xn);
+    }
+  }
+  double ext[6];
+  for (int i = 0; i < 6; ++i) ext[i] = cand_cam[6 * L.c + i];
+  const int g = P.cam_group[L.c];
+  const double2 uv = P.obs_uv[o];
+  double six = 1.0, siy = 1.0;
+  if (P.obs_si) { const double2 s = P.obs_si[o]; six = s.x; siy = s.y; }
+  ObsLin ol;
+  observe<false>(P.group_model[g], ext, P.intr + (size_t)g * THEIA_MAX_INTRINSICS, Xp, uv.x, uv.y, six, siy, ol);
+  double rho1;
+  const double cc = 0.5 * loss_eval(P.loss_type, P.loss_width, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
+  atomic_add(&scalB[0], cc); atomic_add(&scalB[1], mcc);
+  if (!ol.valid) atomic_add(&scalB[4], 1.0);
+}
+
 inline int tile_blocks(int ntiles) { return (ntiles + kWavesPerBlock - 1) / kWavesPerBlock; }
 
 }  // namespace
@@ -763,6 +967,72 @@ void launch_cost_only(const DevProblem& P, const double* cam, const double* pts,
     k_evaluate<3, false><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, nullptr, nullptr, nullptr, nullptr, tile_part);
   else
     k_evaluate<4, false><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, nullptr, nullptr, nullptr, nullptr, tile_part);
+}
+
+}  // namespace thip
+
+namespace thip {
+
+// ------------------------------------------------------------ long-track path
+namespace {
+LongView long_view(const DevProblem& P) {
+  LongView v;
+  v.nobs = P.long_nobs; v.ntracks = P.long_ntracks; v.obs_index = P.long_obs_index; v.obs_slot = P.long_obs_slot;
+  v.track_start = P.long_track_start; v.track_pt = P.long_track_pt;
+  return v;
+}
+template <int PD> constexpr int long_stride() { return PD * (PD + 1) / 2 + PD; }
+}  // namespace
+
+void launch_long_colnorm(const DevProblem& P, const double* cam, const double* pts, double* colsq_c, double* colsq_p,
+                         double* scratch, hipStream_t st) {
+  if (P.long_nobs == 0) return;
+  const LongView v = long_view(P);
+  const int gb = (v.nobs + 127) / 128, tb = (v.ntracks + 127) / 128;
+  if (P.pd == 3) {
+    (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<3>() * v.ntracks, st);
+    k_long_accum<3, 0><<<gb, 128, 0, st>>>(P, v, cam, pts, scratch, nullptr, nullptr, nullptr, nullptr, nullptr, colsq_c);
+    k_long_track<3, 0><<<tb, 128, 0, st>>>(P, v, 1.0, scratch, colsq_p, nullptr, nullptr, nullptr);
+  } else {
+    (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<4>() * v.ntracks, st);
+    k_long_accum<4, 0><<<gb, 128, 0, st>>>(P, v, cam, pts, scratch, nullptr, nullptr, nullptr, nullptr, nullptr, colsq_c);
+    k_long_track<4, 0><<<tb, 128, 0, st>>>(P, v, 1.0, scratch, colsq_p, nullptr, nullptr, nullptr);
+  }
+}
+
+void launch_long_linearize(const DevProblem& P, const double* cam, const double* pts, double radius, const ReduceBuf& rb,
+                           double* Vinv, double* gp, double* scratch, hipStream_t st) {
+  if (P.long_nobs == 0) return;
+  const LongView v = long_view(P);
+  const int gb = (v.nobs + 127) / 128, tb = (v.ntracks + 127) / 128;
+  if (P.pd == 3) {
+    (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<3>() * v.ntracks, st);
+    k_long_accum<3, 1><<<gb, 128, 0, st>>>(P, v, cam, pts, scratch, rb.S, rb.rhs, rb.colsq, rb.gc, rb.scal, nullptr);
+    k_long_track<3, 1><<<tb, 128, 0, st>>>(P, v, radius, scratch, nullptr, Vinv, gp, rb.scal);
+    k_long_schur<3><<<gb, 128, 0, st>>>(P, v, cam, pts, Vinv, gp, rb.S, rb.rhs);
+  } else {
+    (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<4>() * v.ntracks, st);
+    k_long_accum<4, 1><<<gb, 128, 0, st>>>(P, v, cam, pts, scratch, rb.S, rb.rhs, rb.colsq, rb.gc, rb.scal, nullptr);
+    k_long_track<4, 1><<<tb, 128, 0, st>>>(P, v, radius, scratch, nullptr, Vinv, gp, rb.scal);
+    k_long_schur<4><<<gb, 128, 0, st>>>(P, v, cam, pts, Vinv, gp, rb.S, rb.rhs);
+  }
+}
+
+void launch_long_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,
+                         double* cand_pts, const double* yc, const double* Vinv, double* scratch, double* scalB,
+                         hipStream_t st) {
+  if (P.long_nobs == 0) return;
+  const LongView v = long_view(P);
+  const int gb = (v.nobs + 127) / 128;
+  if (P.pd == 3) {
+    (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<3>() * v.ntracks, st);
+    k_long_back1<3><<<gb, 128, 0, st>>>(P, v, cam, pts, yc, scratch);
+    k_long_back2<3><<<gb, 128, 0, st>>>(P, v, cam, pts, cand_cam, cand_pts, yc, Vinv, scratch, scalB);
+  } else {
+    (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<4>() * v.ntracks, st);
+    k_long_back1<4><<<gb, 128, 0, st>>>(P, v, cam, pts, yc, scratch);
+    k_long_back2<4><<<gb, 128, 0, st>>>(P, v, cam, pts, cand_cam, cand_pts, yc, Vinv, scratch, scalB);
+  }
 }
 
 }  // namespace thip

@@ -80,7 +80,10 @@ struct theia_ba_handle_s {
   theia_ba_options opt;
   int nc = 0, ng = 0, np = 0, ncv = 0, n = 0, pd = 3;
   int64_t nobs = 0, nobs_main = 0;
-  int ntiles_main = 0, ntiles_all = 0;
+  int ntiles_main = 0, ntiles_eval = 0, ntiles_all = 0;  // linearize tiles < + long-track eval tiles < + fixed tiles
+  int long_nobs = 0, long_ntracks = 0;
+  DevBuf<int> long_obs_index, long_obs_slot, long_track_start, long_track_pt;
+  DevBuf<double> long_scratch;
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // host-side bookkeeping
@@ -153,6 +156,9 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.tiles_per_wg = h->tiles_per_wg; P.nwg = h->nwg; P.wg_base = h->wg_base.p;
   P.scale_c = h->scale_c.p; P.scale_p = h->scale_p.p;
   P.stamps = h->stamps.p;
+  P.long_nobs = h->long_nobs; P.long_ntracks = h->long_ntracks;
+  P.long_obs_index = h->long_obs_index.p; P.long_obs_slot = h->long_obs_slot.p;
+  P.long_track_start = h->long_track_start.p; P.long_track_pt = h->long_track_pt.p;
 }
 
 int upload_parameters(theia_ba_handle_s* h, const theia_ba_problem* p) {
@@ -208,6 +214,7 @@ int compute_scale(theia_ba_handle_s* h) {
   if (h->colsq_c0.n) HIP_TRY(hipMemsetAsync(h->colsq_c0.p, 0, sizeof(double) * h->colsq_c0.n, h->stream));
   if (h->colsq_p0.n) HIP_TRY(hipMemsetAsync(h->colsq_p0.p, 0, sizeof(double) * h->colsq_p0.n, h->stream));
   launch_colnorm(Q, h->cam[h->cur].p, h->pts[h->cur].p, h->colsq_c0.p, h->colsq_p0.p, h->stream);
+  launch_long_colnorm(Q, h->cam[h->cur].p, h->pts[h->cur].p, h->colsq_c0.p, h->colsq_p0.p, h->long_scratch.p, h->stream);
   int rc = do_allreduce(h, h->colsq_c0.p, h->colsq_c0.n, THEIA_REDUCE_SUM);
   if (rc) return rc;
   launch_make_scale((int)h->colsq_c0.n, h->colsq_c0.p, h->scale_c.p, h->stream);
@@ -223,6 +230,7 @@ int enqueue_linearize(theia_ba_handle_s* h, double radius) {
   launch_linearize(h->P, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->tile_part.p, h->stream);
   HIP_TRY(hipEventRecord(h->ev[5], h->stream));
   if (h->ntiles_main) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 4, h->f2s.p, h->fmaxflag.p, h->rb.scal, h->stream);
+  launch_long_linearize(h->P, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->long_scratch.p, h->stream);
   // one SUM all-reduce of [S | rhs | colsq | gc | scal[0,8)], one MAX of scal[8,16)
   int rc = do_allreduce(h, h->reduce.p, (size_t)h->n * h->n + 3 * (size_t)h->n + 8, THEIA_REDUCE_SUM);
   if (!rc) rc = do_allreduce(h, h->rb.scal + 8, 8, THEIA_REDUCE_MAX);
@@ -241,6 +249,7 @@ int enqueue_solve_and_backsub(theia_ba_handle_s* h) {
   launch_cam_update(h->P, h->cam[h->cur].p, yc, h->cam[nxt].p, h->scalB.p + SB_STEPSQ_CAM, h->scalB.p + SB_XNORMSQ_CAM, h->stream);
   launch_backsub(h->P, h->cam[h->cur].p, h->pts[h->cur].p, h->cam[nxt].p, h->pts[nxt].p, yc, h->Vinv.p, h->tile_part.p, h->scalB.p, h->stream);
   if (h->ntiles_main) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 5, h->f2s.p + 8, h->fmaxflag.p + 8, h->scalB.p, h->stream);
+  launch_long_backsub(h->P, h->cam[h->cur].p, h->pts[h->cur].p, h->cam[nxt].p, h->pts[nxt].p, yc, h->Vinv.p, h->long_scratch.p, h->scalB.p, h->stream);
   return do_allreduce(h, h->scalB.p, 8, THEIA_REDUCE_SUM);
 }
 
@@ -339,13 +348,27 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   }
   // wave tiles: <= 64 observations, never splitting a track
   std::vector<int> tstart, tcount, tkey;
-  auto build_tiles = [&](const std::vector<int64_t>& off, int64_t base) -> int {
+  std::vector<int> l_obs, l_slot, l_start(1, 0), l_pt;  // long tracks (> 64 observations): slow path
+  auto build_tiles = [&](const std::vector<int64_t>& off, int64_t base, bool allow_long) -> int {
     int64_t cur0 = 0, curlen = 0;
     int curkey = 0;
     for (int q = 0; q < h->np; ++q) {
       const int64_t L = off[q + 1] - off[q];
       if (L == 0) continue;
-      if (L > 64) return -1;
+      if (L > 64) {
+        if (!allow_long) {  // fixed (all-constant) blocks: any split is fine, no per-track sums needed
+          if (curlen) { tstart.push_back((int)(base + cur0)); tcount.push_back((int)curlen); tkey.push_back(curkey); curlen = 0; }
+          for (int64_t c = 0; c < L; c += 64) { tstart.push_back((int)(base + off[q] + c)); tcount.push_back((int)std::min<int64_t>(64, L - c)); tkey.push_back(0); }
+          continue;
+        }
+        // tiles are contiguous observation ranges: close the open tile before skipping this track
+        if (curlen) { tstart.push_back((int)(base + cur0)); tcount.push_back((int)curlen); tkey.push_back(curkey); curlen = 0; }
+        const int slot = (int)l_pt.size();
+        l_pt.push_back(porder[q]);
+        for (int64_t c = 0; c < L; ++c) { l_obs.push_back((int)(base + off[q] + c)); l_slot.push_back(slot); }
+        l_start.push_back((int)l_obs.size());
+        continue;
+      }
       if (curlen + L > 64) { tstart.push_back((int)(base + cur0)); tcount.push_back((int)curlen); tkey.push_back(curkey); curlen = 0; }
       if (curlen == 0) { cur0 = off[q]; curkey = pkey[porder[q]]; }
       curlen += L;
@@ -353,11 +376,16 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     if (curlen) { tstart.push_back((int)(base + cur0)); tcount.push_back((int)curlen); tkey.push_back(curkey); }
     return 0;
   };
-  if (build_tiles(cnt_main, 0))
-    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "a track has more than 64 observations (long-track kernel not built yet)");
+  build_tiles(cnt_main, 0, true);
   h->ntiles_main = (int)tstart.size();
-  if (build_tiles(cnt_fix, h->nobs_main))
-    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "a track has more than 64 observations (long-track kernel not built yet)");
+  // evaluation-only tiles over the long tracks' observations (no per-track sums there)
+  h->long_nobs = (int)l_obs.size(); h->long_ntracks = (int)l_pt.size();
+  for (int s2 = 0; s2 < h->long_ntracks; ++s2)
+    for (int c = l_start[s2]; c < l_start[s2 + 1]; c += 64) {
+      tstart.push_back(l_obs[c]); tcount.push_back(std::min(64, l_start[s2 + 1] - c)); tkey.push_back(0);
+    }
+  h->ntiles_eval = (int)tstart.size();
+  build_tiles(cnt_fix, h->nobs_main, false);
   h->ntiles_all = (int)tstart.size();
   // linearize workgroups: ~2 per CU, each owning a contiguous run of tiles; the
   // LDS window starts at the first camera of the run's first track
@@ -390,6 +418,8 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
 #define AL(buf, cnt) do { rc = h->buf.alloc(cnt); if (rc) return rc; } while (0)
   UP(obs_uv, uv); UP(obs_si, si); UP(obs_cam, ocam); UP(obs_pt, opt);
   UP(tile_start, tstart); UP(tile_count, tcount);
+  UP(long_obs_index, l_obs); UP(long_obs_slot, l_slot); UP(long_track_start, l_start); UP(long_track_pt, l_pt);
+  AL(long_scratch, (size_t)14 * std::max(1, h->long_ntracks));
   UP(d_cam_red, h->cam_red); UP(d_cam_mask, h->cam_mask); UP(d_pt_const, h->pt_const);
   std::vector<int> gm(p->group_model, p->group_model + h->ng), cg(p->cam_group, p->cam_group + h->nc);
   UP(group_model, gm); UP(cam_group, cg);
@@ -418,7 +448,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   if (rc) return rc;
   // fixed cost
   double fc = 0.0, inv = 0.0;
-  rc = cost_of_tiles(h, h->ntiles_main, h->ntiles_all - h->ntiles_main, h->cam[0].p, h->pts[0].p, &fc, &inv);
+  rc = cost_of_tiles(h, h->ntiles_eval, h->ntiles_all - h->ntiles_eval, h->cam[0].p, h->pts[0].p, &fc, &inv);
   if (rc) return rc;
   h->fixed_cost = fc;
   *out = guard.release();
@@ -629,9 +659,10 @@ int theia_hip_ba_evaluate(theia_ba_handle h, double* cost, double* residuals, do
   if ((rc = dr.alloc(2 * nm)) || (rc = djc.alloc(12 * nm)) || (rc = djp.alloc(2 * pd * nm)) || (rc = dv.alloc(nm))) return rc;
   DevProblem Q = h->P;
   Q.scale_c = h->ones_c.p; Q.scale_p = h->ones_p.p;
+  Q.ntiles = h->ntiles_eval;
   HIP_TRY(hipMemsetAsync(h->scalB.p, 0, sizeof(double) * 16, h->stream));
   launch_evaluate(Q, h->cam[h->cur].p, h->pts[h->cur].p, dr.p, djc.p, djp.p, dv.p, h->tile_part.p, h->stream);
-  if (h->ntiles_main) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 2, h->f2s.p + 16, h->fmaxflag.p + 16, h->scalB.p, h->stream);
+  if (h->ntiles_eval) launch_reduce_tiles(h->ntiles_eval, h->tile_part.p, 2, h->f2s.p + 16, h->fmaxflag.p + 16, h->scalB.p, h->stream);
   std::vector<double> hr(2 * nm), hjc(12 * nm), hjp(2 * pd * nm); std::vector<uint8_t> hv(nm);
   if (nm) {
     HIP_TRY(hipMemcpyAsync(hr.data(), dr.p, sizeof(double) * hr.size(), hipMemcpyDeviceToHost, h->stream));

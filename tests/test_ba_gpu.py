@@ -246,3 +246,41 @@ def test_every_camera_model_matches_jet_oracle(model):
     assert s.num_iterations == so.num_iterations and np.array_equal(tr.accepted, tro.accepted)
     fin = tro.cost < 1e300
     assert rel(tr.cost[fin], tro.cost[fin]) <= 1e-8
+
+
+def _with_long_tracks(nv=80, nt=400, nlong=5, seed=301):
+    """synth scene plus `nlong` tracks seen by EVERY camera (> 64 observations)."""
+    p, cam_gt, pts_gt = synth.synth_ba_v1(nv, nt, seed=seed, return_truth=True)
+    st = synth.Stream(seed, 99)
+    i = np.arange(nlong)
+    X = np.stack([st.uniform(3 * i) - 0.5, st.uniform(3 * i + 1) - 0.5, 0.4 * st.uniform(3 * i + 2) - 0.2, np.ones(nlong)], 1)
+    oc = np.tile(np.arange(nv), nlong).astype(np.int32)
+    op = (nt + np.repeat(i, nv)).astype(np.int32)
+    uv, ok = synth.project(0, p.intrinsics[p.cam_group[oc]], cam_gt[oc], X[np.repeat(i, nv)])
+    assert ok.all()
+    uv = uv + 0.5 * np.stack([st.normal(2 * np.arange(len(oc)) + 1000), st.normal(2 * np.arange(len(oc)) + 1001)], 1)
+    X0 = X.copy(); X0[:, :3] += 0.02 * np.stack([st.normal(3 * i + 500), st.normal(3 * i + 501), st.normal(3 * i + 502)], 1)
+    return capi.FlatProblem(p.cam_ext, p.intrinsics, p.group_model, p.cam_group, np.vstack([p.points, X0]),
+                            np.vstack([p.obs_uv, uv]), np.concatenate([p.obs_cam, oc]), np.concatenate([p.obs_pt, op]))
+
+
+@pytest.mark.parametrize("manifold", [1, 0])
+def test_long_tracks_slow_path_matches_oracle(manifold):
+    """Tracks with more than 64 observations take the per-observation path."""
+    p = _with_long_tracks()
+    assert np.bincount(p.obs_pt).max() == 80
+    o, oo = both_options(use_homogeneous_point_parametrization=manifold)
+    with ba.BaHandle(p.copy(), o) as h:
+        cost, r, jc, jp, valid = h.evaluate()
+        S, rhs = h.reduced_system(1e4)
+    ok, ocost, orr, ojc, ojp = ol.evaluate(p, oo)
+    assert abs(cost - ocost) <= 1e-12 * ocost and np.abs(r - orr).max() <= 1e-10
+    assert rel(jc, ojc) <= 1e-12 and rel(jp, ojp) <= 1e-12
+    So, ro = ol.reduced_system(p, oo, 1e4)
+    assert rel(S, So) <= 1e-10 and rel(rhs, ro) <= 1e-10
+    pg, po = p.copy(), p.copy()
+    s, tr = ba.solve(pg, o)
+    so, tro = ol.solve(po, oo)
+    assert s.success and s.num_iterations == so.num_iterations and np.array_equal(tr.accepted, tro.accepted)
+    assert rel(tr.cost, tro.cost) <= 1e-9
+    assert np.abs(pg.cam_ext - po.cam_ext).max() <= 1e-7 and np.abs(pg.points - po.points).max() <= 1e-7
