@@ -218,10 +218,17 @@ int theia_hip_ba_destroy(theia_ba_handle h);
  *    ReprojectionError<Model> (reprojection_error.h:54-110); valid[i] = functor
  *    return value.
  *  - the dense reduced camera system  S (n x n, row-major, both triangles) and
- *    rhs (n) for trust-region radius `radius`, n = 6 * (#variable cameras),
- *    in Jacobi-scaled space exactly as handed to the Cholesky kernel. */
+ *    rhs (n) for trust-region radius `radius`,
+ *    n = 10 * (#variable intrinsics groups) + 6 * (#variable cameras) with the
+ *    intrinsics slots first, in Jacobi-scaled space exactly as handed to the
+ *    Cholesky kernel. */
 int theia_hip_ba_evaluate(theia_ba_handle h, double* cost, double* residuals,
                           double* jac_cam, double* jac_pt, uint8_t* valid);
+/* as theia_hip_ba_evaluate plus J_intr[2][THEIA_MAX_INTRINSICS] per observation
+ * (zero for constant groups / frozen parameters). */
+int theia_hip_ba_evaluate_ex(theia_ba_handle h, double* cost, double* residuals,
+                             double* jac_cam, double* jac_pt, double* jac_intr,
+                             uint8_t* valid);
 int theia_hip_ba_reduced_system(theia_ba_handle h, double radius, int32_t* n,
                                 double* S, double* rhs, int64_t capacity);
 

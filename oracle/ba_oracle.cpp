@@ -480,34 +480,76 @@ void oracle_sphere_plus_jacobian(const double* x, double* J) { sphere_plus_jacob
 // ============================================================ BA solver state
 namespace {
 
+// Which intrinsics are FREE for a model under an OptimizeIntrinsicsType mask:
+// GetSubsetFromOptimizeIntrinsicsType of every *_camera_model.cc (e.g.
+// pinhole_camera_model.cc:132-162).  Returns a bit mask over the K parameters.
+inline unsigned intrinsics_free_mask(int model, int opt) {
+  const bool noskew = (model == CAM_FOV || model == CAM_DIVISION_UNDISTORTION);
+  unsigned m = 0;
+  if (opt & 0x01) m |= 1u << 0;                                   // FOCAL_LENGTH
+  if (opt & 0x02) m |= 1u << 1;                                   // ASPECT_RATIO
+  if ((opt & 0x04) && !noskew) m |= 1u << 2;                      // SKEW
+  if (opt & 0x08) m |= noskew ? (3u << 2) : (3u << 3);            // PRINCIPAL_POINTS
+  if (opt & 0x10) {                                               // RADIAL_DISTORTION
+    switch (model) {
+      case CAM_PINHOLE: case CAM_DOUBLE_SPHERE: case CAM_EXTENDED_UNIFIED: case CAM_ORTHOGRAPHIC: m |= 3u << 5; break;
+      case CAM_PINHOLE_RADIAL_TANGENTIAL: m |= 7u << 5; break;
+      case CAM_FISHEYE: m |= 15u << 5; break;
+      case CAM_FOV: case CAM_DIVISION_UNDISTORTION: m |= 1u << 4; break;
+    }
+  }
+  if ((opt & 0x20) && model == CAM_PINHOLE_RADIAL_TANGENTIAL) m |= 3u << 8;  // TANGENTIAL_DISTORTION
+  return m;
+}
+
+// bundle_adjuster.cc:406-427: focal >= 1; double sphere xi in [-1,1], alpha in
+// [0,1]; EUCM alpha in [0,1], beta >= 0.1.  (Ceres: constrained problem; this
+// restatement projects the LM step onto the box, see DESIGN.md deviations.)
+inline void project_intrinsics_to_bounds(int model, double* k) {
+  if (k[0] < 1.0) k[0] = 1.0;
+  if (model == CAM_DOUBLE_SPHERE) { k[5] = std::min(1.0, std::max(-1.0, k[5])); k[6] = std::min(1.0, std::max(0.0, k[6])); }
+  if (model == CAM_EXTENDED_UNIFIED) { k[5] = std::min(1.0, std::max(0.0, k[5])); k[6] = std::max(0.1, k[6]); }
+}
+
+const int FW = kMaxIntr + 6;  // camera-side columns of one observation: [intrinsics(10) | extrinsics(6)]
+
 struct Oracle {
   const oba_problem* P;
   oba_options O;
-  int nc, np; int64_t nobs;
+  int nc, np, ng; int64_t nobs;
   int pd;                        // point tangent dofs (3 manifold / 4 plain)
   std::vector<int> cam_red;      // camera -> reduced index or -1 (whole block const)
-  int ncv;                       // variable cameras
+  std::vector<int> grp_red;      // intrinsics group -> reduced index or -1
+  int ncv, ngv, ni;              // ni = 10 * ngv: intrinsics come first in the reduced system
   std::vector<uint8_t> cam_mask; // per camera: 6 bits, 1 = column frozen
+  std::vector<unsigned> grp_free;// per group: bit q = parameter q free
   std::vector<uint8_t> pt_const;
   std::vector<uint8_t> obs_fixed;// residual blocks with only constant blocks
   double fixed_cost;
   // state
-  std::vector<double> cam, pts;      // current x
-  std::vector<double> ccam, cpts;    // candidate
+  std::vector<double> cam, pts, intr;      // current x
+  std::vector<double> ccam, cpts, cintr;   // candidate
   // linearisation at x (Jacobi-scaled, loss-corrected, tangent space)
   std::vector<double> r;             // 2*nobs
-  std::vector<double> Jc;            // nobs*12
+  std::vector<double> F;             // nobs * 2 * FW   camera-side Jacobian [Jk | Jc]
   std::vector<double> Jp;            // nobs*2*pd
-  std::vector<double> scale_c, scale_p;  // jacobi scaling
-  std::vector<double> diag_c, diag_p;    // clamped squared column norms
-  std::vector<double> g_c, g_p;          // gradient (unscaled)
+  std::vector<double> scale_f, scale_p;  // jacobi scaling of the reduced camera-side columns / points
+  std::vector<double> diag_f, diag_p;    // clamped squared column norms
   // CSR by point
   std::vector<int64_t> pt_off; std::vector<int64_t> pt_obs;
   // reduced system
   std::vector<double> S, rhs, Vinv, yp, yc;
+  int n() const { return ni + 6 * ncv; }
 };
 
-bool evaluate(Oracle& o, const std::vector<double>& cam, const std::vector<double>& pts,
+// reduced index of camera-side column q (0..9 intrinsics, 10..15 extrinsics) of an observation, or -1
+inline int fcol(const Oracle& o, int c, int g, int q) {
+  if (q < kMaxIntr) { const int gr = o.grp_red[g]; return (gr >= 0 && ((o.grp_free[g] >> q) & 1u)) ? 10 * gr + q : -1; }
+  const int rc = o.cam_red[c]; const int e = q - kMaxIntr;
+  return (rc >= 0 && !((o.cam_mask[c] >> e) & 1)) ? o.ni + 6 * rc + e : -1;
+}
+
+bool evaluate(Oracle& o, const std::vector<double>& cam, const std::vector<double>& pts, const std::vector<double>& intrv,
               bool want_jac, double* cost_out) {
   const oba_problem& P = *o.P;
   double cost = 0.0;
@@ -519,7 +561,7 @@ bool evaluate(Oracle& o, const std::vector<double>& cam, const std::vector<doubl
     const int c = P.obs_cam[i], p = P.obs_pt[i];
     const int g = P.cam_group[c];
     const int model = P.group_model[g];
-    const double* intr = P.intrinsics + (size_t)g * kMaxIntr;
+    const double* intr = &intrv[(size_t)g * kMaxIntr];
     const double* si = P.obs_sqrt_info ? P.obs_sqrt_info + 2 * i : one;
     double res[2];
     if (!want_jac) {
@@ -530,11 +572,11 @@ bool evaluate(Oracle& o, const std::vector<double>& cam, const std::vector<doubl
       cost += 0.5 * rho[0];
       continue;
     }
-    typedef Jet<10> J;  // 6 extrinsics + 4 point (intrinsics constant in this path)
+    typedef Jet<20> J;  // 6 extrinsics + 10 intrinsics + 4 point, as AutoDiffCostFunction<.., 2, 6, K, 4>
     J e[6], k[kMaxIntr], x[4], rr[2];
     for (int q = 0; q < 6; ++q) e[q] = J(cam[6 * c + q], q);
-    for (int q = 0; q < kMaxIntr; ++q) k[q] = J(intr[q]);
-    for (int q = 0; q < 4; ++q) x[q] = J(pts[4 * p + q], 6 + q);
+    for (int q = 0; q < kMaxIntr; ++q) k[q] = J(intr[q], 6 + q);
+    for (int q = 0; q < 4; ++q) x[q] = J(pts[4 * p + q], 16 + q);
     if (!reprojection_error<J>(model, e, k, x, P.obs_uv + 2 * i, si, rr)) ok = false;
     res[0] = rr[0].a; res[1] = rr[1].a;
     const double s = res[0] * res[0] + res[1] * res[1];
@@ -548,14 +590,13 @@ bool evaluate(Oracle& o, const std::vector<double>& cam, const std::vector<doubl
     if (pd == 3) sphere_plus_jacobian(&pts[4 * p], PJ);
     for (int a = 0; a < 2; ++a) {
       o.r[2 * i + a] = sr * res[a];
-      for (int q = 0; q < 6; ++q) {
-        const bool frozen = (o.cam_mask[c] >> q) & 1;
-        o.Jc[12 * i + 6 * a + q] = frozen ? 0.0 : sr * rr[a].v[q];
-      }
+      double* Fr = &o.F[((size_t)i * 2 + a) * FW];
+      for (int q = 0; q < kMaxIntr; ++q) Fr[q] = (fcol(o, c, g, q) >= 0) ? sr * rr[a].v[6 + q] : 0.0;
+      for (int q = 0; q < 6; ++q) Fr[kMaxIntr + q] = (fcol(o, c, g, kMaxIntr + q) >= 0) ? sr * rr[a].v[q] : 0.0;
       for (int q = 0; q < pd; ++q) {
         double v;
-        if (pd == 3) { v = 0.0; for (int t = 0; t < 4; ++t) v += rr[a].v[6 + t] * PJ[t * 3 + q]; }
-        else v = rr[a].v[6 + q];
+        if (pd == 3) { v = 0.0; for (int t = 0; t < 4; ++t) v += rr[a].v[16 + t] * PJ[t * 3 + q]; }
+        else v = rr[a].v[16 + q];
         o.Jp[(size_t)i * 2 * pd + a * pd + q] = o.pt_const[p] ? 0.0 : sr * v;
       }
     }
@@ -565,14 +606,15 @@ bool evaluate(Oracle& o, const std::vector<double>& cam, const std::vector<doubl
 }
 
 // squared column norms of the current (scaled or not) Jacobian
-void column_norms(Oracle& o, std::vector<double>& nc_, std::vector<double>& np_) {
+void column_norms(Oracle& o, std::vector<double>& nf_, std::vector<double>& np_) {
   const oba_problem& P = *o.P; const int pd = o.pd;
-  std::fill(nc_.begin(), nc_.end(), 0.0); std::fill(np_.begin(), np_.end(), 0.0);
+  std::fill(nf_.begin(), nf_.end(), 0.0); std::fill(np_.begin(), np_.end(), 0.0);
   for (int64_t i = 0; i < o.nobs; ++i) {
     if (o.obs_fixed[i]) continue;
-    const int c = P.obs_cam[i], p = P.obs_pt[i];
+    const int c = P.obs_cam[i], p = P.obs_pt[i], g = P.cam_group[c];
     for (int a = 0; a < 2; ++a) {
-      for (int q = 0; q < 6; ++q) { const double v = o.Jc[12 * i + 6 * a + q]; nc_[6 * c + q] += v * v; }
+      const double* Fr = &o.F[((size_t)i * 2 + a) * FW];
+      for (int q = 0; q < FW; ++q) { const int col = fcol(o, c, g, q); if (col >= 0) nf_[col] += Fr[q] * Fr[q]; }
       for (int q = 0; q < pd; ++q) { const double v = o.Jp[(size_t)i * 2 * pd + a * pd + q]; np_[(size_t)pd * p + q] += v * v; }
     }
   }
@@ -582,32 +624,33 @@ void apply_scaling(Oracle& o) {
   const oba_problem& P = *o.P; const int pd = o.pd;
   for (int64_t i = 0; i < o.nobs; ++i) {
     if (o.obs_fixed[i]) continue;
-    const int c = P.obs_cam[i], p = P.obs_pt[i];
+    const int c = P.obs_cam[i], p = P.obs_pt[i], g = P.cam_group[c];
     for (int a = 0; a < 2; ++a) {
-      for (int q = 0; q < 6; ++q) o.Jc[12 * i + 6 * a + q] *= o.scale_c[6 * c + q];
+      double* Fr = &o.F[((size_t)i * 2 + a) * FW];
+      for (int q = 0; q < FW; ++q) { const int col = fcol(o, c, g, q); if (col >= 0) Fr[q] *= o.scale_f[col]; }
       for (int q = 0; q < pd; ++q) o.Jp[(size_t)i * 2 * pd + a * pd + q] *= o.scale_p[(size_t)pd * p + q];
     }
   }
 }
 
-// gradient in tangent space (unscaled): g = J^T r = (Js^T r) / scale
+// gradient in tangent space (unscaled): g = J^T r = (Js^T r) / scale ; returns max |g|
 double compute_gradient(Oracle& o) {
   const oba_problem& P = *o.P; const int pd = o.pd;
-  std::fill(o.g_c.begin(), o.g_c.end(), 0.0); std::fill(o.g_p.begin(), o.g_p.end(), 0.0);
+  std::vector<double> gf(o.n(), 0.0), gp((size_t)pd * o.np, 0.0);
   for (int64_t i = 0; i < o.nobs; ++i) {
     if (o.obs_fixed[i]) continue;
-    const int c = P.obs_cam[i], p = P.obs_pt[i];
+    const int c = P.obs_cam[i], p = P.obs_pt[i], g = P.cam_group[c];
     for (int a = 0; a < 2; ++a) {
       const double ra = o.r[2 * i + a];
-      for (int q = 0; q < 6; ++q) o.g_c[6 * c + q] += o.Jc[12 * i + 6 * a + q] * ra;
-      for (int q = 0; q < pd; ++q) o.g_p[(size_t)pd * p + q] += o.Jp[(size_t)i * 2 * pd + a * pd + q] * ra;
+      const double* Fr = &o.F[((size_t)i * 2 + a) * FW];
+      for (int q = 0; q < FW; ++q) { const int col = fcol(o, c, g, q); if (col >= 0) gf[col] += Fr[q] * ra; }
+      for (int q = 0; q < pd; ++q) gp[(size_t)pd * p + q] += o.Jp[(size_t)i * 2 * pd + a * pd + q] * ra;
     }
   }
   double gmax = 0.0;
-  for (int c = 0; c < o.nc; ++c) if (o.cam_red[c] >= 0)
-    for (int q = 0; q < 6; ++q) gmax = std::max(gmax, std::fabs(o.g_c[6 * c + q] / o.scale_c[6 * c + q]));
+  for (int d = 0; d < o.n(); ++d) gmax = std::max(gmax, std::fabs(gf[d] / o.scale_f[d]));
   for (int p = 0; p < o.np; ++p) if (!o.pt_const[p])
-    for (int q = 0; q < pd; ++q) gmax = std::max(gmax, std::fabs(o.g_p[(size_t)pd * p + q] / o.scale_p[(size_t)pd * p + q]));
+    for (int q = 0; q < pd; ++q) gmax = std::max(gmax, std::fabs(gp[(size_t)pd * p + q] / o.scale_p[(size_t)pd * p + q]));
   return gmax;
 }
 
@@ -657,29 +700,28 @@ bool dense_cholesky_solve(int n, std::vector<double>& A, std::vector<double>& b)
 // Build the reduced camera system for LM radius `radius` (Jacobi-scaled space)
 // following ceres SchurEliminator: per point chunk
 //   ete = sum E^T E + D_p^2 ; lhs -= (F^T E) ete^-1 (E^T F) ; rhs -= (F^T E) ete^-1 (E^T b)
-// with lhs initialised to block-diag(F^T F + D_c^2).
+// with lhs initialised to F^T F + D_c^2 (groups 1 and 2 = intrinsics and
+// extrinsics blocks, bundle_adjuster.cc:547-563, are NOT eliminated).
 bool build_reduced(Oracle& o, double radius, bool add_cam_diag = true) {
   const oba_problem& P = *o.P; const int pd = o.pd;
-  const int n = 6 * o.ncv;
+  const int n = o.n();
   o.S.assign((size_t)n * n, 0.0); o.rhs.assign(n, 0.0);
   o.Vinv.assign((size_t)o.np * pd * pd, 0.0);
-  // camera diagonal blocks + rhs
+  int cols[FW];
   for (int64_t i = 0; i < o.nobs; ++i) {
     if (o.obs_fixed[i]) continue;
-    const int c = P.obs_cam[i]; const int rc = o.cam_red[c];
-    if (rc < 0) continue;
-    const double* J = &o.Jc[12 * i];
-    for (int a = 0; a < 6; ++a) {
-      for (int b = 0; b < 6; ++b)
-        o.S[(size_t)(6 * rc + a) * n + 6 * rc + b] += J[a] * J[b] + J[6 + a] * J[6 + b];
-      o.rhs[6 * rc + a] += J[a] * o.r[2 * i] + J[6 + a] * o.r[2 * i + 1];
-    }
+    const int c = P.obs_cam[i], g = P.cam_group[c];
+    for (int q = 0; q < FW; ++q) cols[q] = fcol(o, c, g, q);
+    const double* F0 = &o.F[((size_t)i * 2) * FW]; const double* F1 = F0 + FW;
+    for (int a = 0; a < FW; ++a) { if (cols[a] < 0) continue;
+      for (int b = 0; b < FW; ++b) if (cols[b] >= 0)
+        o.S[(size_t)cols[a] * n + cols[b]] += F0[a] * F0[b] + F1[a] * F1[b];
+      o.rhs[cols[a]] += F0[a] * o.r[2 * i] + F1[a] * o.r[2 * i + 1]; }
   }
-  if (add_cam_diag)
-    for (int c = 0; c < o.nc; ++c) { const int rc = o.cam_red[c]; if (rc < 0) continue;
-      for (int a = 0; a < 6; ++a) o.S[(size_t)(6 * rc + a) * n + 6 * rc + a] += o.diag_c[6 * c + a] / radius; }
+  if (add_cam_diag) for (int d = 0; d < n; ++d) o.S[(size_t)d * n + d] += o.diag_f[d] / radius;
   // eliminate points
-  std::vector<double> W;  // per obs of the point: F^T E (6 x pd)
+  std::vector<double> W;  // per obs of the point: F^T E (FW x pd)
+  std::vector<int> wc;
   for (int p = 0; p < o.np; ++p) {
     if (o.pt_const[p]) continue;
     const int64_t b0 = o.pt_off[p], b1 = o.pt_off[p + 1];
@@ -693,27 +735,25 @@ bool build_reduced(Oracle& o, double radius, bool add_cam_diag = true) {
     double* Vi = &o.Vinv[(size_t)p * pd * pd];
     if (!invert_spd(pd, V, Vi)) return false;
     const int L = (int)(b1 - b0);
-    W.assign((size_t)L * 6 * pd, 0.0);
+    W.assign((size_t)L * FW * pd, 0.0); wc.assign((size_t)L * FW, -1);
     for (int t = 0; t < L; ++t) { const int64_t i = o.pt_obs[b0 + t];
-      const double* F = &o.Jc[12 * i]; const double* E = &o.Jp[(size_t)i * 2 * pd];
-      for (int a = 0; a < 6; ++a) for (int b = 0; b < pd; ++b)
-        W[(size_t)t * 6 * pd + a * pd + b] = F[a] * E[b] + F[6 + a] * E[pd + b]; }
+      const int c = P.obs_cam[i], g = P.cam_group[c];
+      const double* F0 = &o.F[((size_t)i * 2) * FW]; const double* F1 = F0 + FW; const double* E = &o.Jp[(size_t)i * 2 * pd];
+      for (int a = 0; a < FW; ++a) { wc[(size_t)t * FW + a] = fcol(o, c, g, a);
+        for (int b = 0; b < pd; ++b) W[((size_t)t * FW + a) * pd + b] = F0[a] * E[b] + F1[a] * E[pd + b]; } }
     double Vig[4];
     for (int a = 0; a < pd; ++a) { double s = 0; for (int b = 0; b < pd; ++b) s += Vi[a * pd + b] * gp[b]; Vig[a] = s; }
     for (int t = 0; t < L; ++t) {
-      const int ct = o.cam_red[P.obs_cam[o.pt_obs[b0 + t]]]; if (ct < 0) continue;
-      const double* Wt = &W[(size_t)t * 6 * pd];
-      double WV[24];  // W_t * Vinv (6 x pd)
-      for (int a = 0; a < 6; ++a) for (int b = 0; b < pd; ++b) { double s = 0;
-        for (int k = 0; k < pd; ++k) s += Wt[a * pd + k] * Vi[k * pd + b]; WV[a * pd + b] = s; }
-      for (int a = 0; a < 6; ++a) { double s = 0; for (int b = 0; b < pd; ++b) s += Wt[a * pd + b] * Vig[b];
-        o.rhs[6 * ct + a] -= s; }
-      for (int u = 0; u < L; ++u) {
-        const int cu = o.cam_red[P.obs_cam[o.pt_obs[b0 + u]]]; if (cu < 0) continue;
-        const double* Wu = &W[(size_t)u * 6 * pd];
-        for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) { double s = 0;
-          for (int k = 0; k < pd; ++k) s += WV[a * pd + k] * Wu[b * pd + k];
-          o.S[(size_t)(6 * ct + a) * n + 6 * cu + b] -= s; }
+      for (int a = 0; a < FW; ++a) { const int ca = wc[(size_t)t * FW + a]; if (ca < 0) continue;
+        const double* Wt = &W[((size_t)t * FW + a) * pd];
+        double WV[4];
+        for (int b = 0; b < pd; ++b) { double s = 0; for (int k = 0; k < pd; ++k) s += Wt[k] * Vi[k * pd + b]; WV[b] = s; }
+        double s0 = 0; for (int b = 0; b < pd; ++b) s0 += Wt[b] * Vig[b];
+        o.rhs[ca] -= s0;
+        for (int u = 0; u < L; ++u) for (int b = 0; b < FW; ++b) { const int cb = wc[(size_t)u * FW + b]; if (cb < 0) continue;
+          const double* Wu = &W[((size_t)u * FW + b) * pd];
+          double s = 0; for (int k = 0; k < pd; ++k) s += WV[k] * Wu[k];
+          o.S[(size_t)ca * n + cb] -= s; }
       }
     }
   }
@@ -728,10 +768,11 @@ void back_substitute(Oracle& o) {
     if (o.pt_const[p]) continue;
     double t[4] = {0};
     for (int64_t k = o.pt_off[p]; k < o.pt_off[p + 1]; ++k) { const int64_t i = o.pt_obs[k];
-      const int rc = o.cam_red[P.obs_cam[i]];
-      const double* F = &o.Jc[12 * i]; const double* E = &o.Jp[(size_t)i * 2 * pd];
+      const int c = P.obs_cam[i], g = P.cam_group[c];
+      const double* E = &o.Jp[(size_t)i * 2 * pd];
       for (int a = 0; a < 2; ++a) { double m = o.r[2 * i + a];
-        if (rc >= 0) for (int q = 0; q < 6; ++q) m -= F[6 * a + q] * o.yc[6 * rc + q];
+        const double* Fr = &o.F[((size_t)i * 2 + a) * FW];
+        for (int q = 0; q < FW; ++q) { const int col = fcol(o, c, g, q); if (col >= 0) m -= Fr[q] * o.yc[col]; }
         for (int q = 0; q < pd; ++q) t[q] += E[a * pd + q] * m; } }
     const double* Vi = &o.Vinv[(size_t)p * pd * pd];
     for (int a = 0; a < pd; ++a) { double s = 0; for (int b = 0; b < pd; ++b) s += Vi[a * pd + b] * t[b];
@@ -742,12 +783,21 @@ void back_substitute(Oracle& o) {
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int setup(Oracle& o, const oba_problem* P, const oba_options* O) {
-  o.P = P; o.O = *O; o.nc = P->num_cameras; o.np = P->num_points; o.nobs = P->num_obs;
+  o.P = P; o.O = *O; o.nc = P->num_cameras; o.np = P->num_points; o.ng = P->num_groups; o.nobs = P->num_obs;
   o.pd = O->use_homogeneous_point_parametrization ? 3 : 4;
-  if (O->intrinsics_to_optimize != 0) return -3;  // oracle restates the default (NONE) path
   o.cam_red.assign(o.nc, -1); o.cam_mask.assign(o.nc, 0); o.pt_const.assign(o.np, 0);
-  std::vector<uint8_t> cam_used(o.nc, 0), pt_used(o.np, 0);
-  for (int64_t i = 0; i < o.nobs; ++i) { cam_used[P->obs_cam[i]] = 1; pt_used[P->obs_pt[i]] = 1; }
+  o.grp_red.assign(o.ng, -1); o.grp_free.assign(o.ng, 0u);
+  std::vector<uint8_t> cam_used(o.nc, 0), pt_used(o.np, 0), grp_used(o.ng, 0);
+  for (int64_t i = 0; i < o.nobs; ++i) { cam_used[P->obs_cam[i]] = 1; pt_used[P->obs_pt[i]] = 1; grp_used[P->cam_group[P->obs_cam[i]]] = 1; }
+  // intrinsics blocks (bundle_adjuster.cc:382-460): constant when nothing is
+  // optimised or when the caller marked the group constant, else a subset manifold
+  o.ngv = 0;
+  for (int g = 0; g < o.ng; ++g) {
+    const unsigned fm = intrinsics_free_mask(P->group_model[g], O->intrinsics_to_optimize);
+    const bool gconst = (P->group_const && P->group_const[g]) || fm == 0 || (!grp_used[g] && !(P->flags & 1));
+    if (!gconst) { o.grp_red[g] = o.ngv++; o.grp_free[g] = fm; }
+  }
+  o.ni = kMaxIntr * o.ngv;
   o.ncv = 0;
   for (int c = 0; c < o.nc; ++c) {
     uint8_t m = P->cam_const ? P->cam_const[c] : 0;
@@ -764,7 +814,7 @@ int setup(Oracle& o, const oba_problem* P, const oba_options* O) {
   for (int p = 0; p < o.np; ++p) o.pt_const[p] = (P->point_const && P->point_const[p]) || !pt_used[p];
   o.obs_fixed.assign(o.nobs, 0);
   for (int64_t i = 0; i < o.nobs; ++i)
-    if (o.cam_red[P->obs_cam[i]] < 0 && o.pt_const[P->obs_pt[i]]) o.obs_fixed[i] = 1;
+    if (o.cam_red[P->obs_cam[i]] < 0 && o.grp_red[P->cam_group[P->obs_cam[i]]] < 0 && o.pt_const[P->obs_pt[i]]) o.obs_fixed[i] = 1;
   // CSR by point
   o.pt_off.assign(o.np + 1, 0);
   for (int64_t i = 0; i < o.nobs; ++i) if (!o.obs_fixed[i]) o.pt_off[P->obs_pt[i] + 1]++;
@@ -774,17 +824,18 @@ int setup(Oracle& o, const oba_problem* P, const oba_options* O) {
     for (int64_t i = 0; i < o.nobs; ++i) if (!o.obs_fixed[i]) o.pt_obs[fill[P->obs_pt[i]]++] = i; }
   o.cam.assign(P->cam_ext, P->cam_ext + 6 * (size_t)o.nc);
   o.pts.assign(P->points, P->points + 4 * (size_t)o.np);
-  o.r.assign(2 * o.nobs, 0.0); o.Jc.assign(12 * o.nobs, 0.0); o.Jp.assign((size_t)2 * o.pd * o.nobs, 0.0);
-  o.scale_c.assign(6 * (size_t)o.nc, 1.0); o.scale_p.assign((size_t)o.pd * o.np, 1.0);
-  o.diag_c.assign(6 * (size_t)o.nc, 0.0); o.diag_p.assign((size_t)o.pd * o.np, 0.0);
-  o.g_c.assign(6 * (size_t)o.nc, 0.0); o.g_p.assign((size_t)o.pd * o.np, 0.0);
+  o.intr.assign(P->intrinsics, P->intrinsics + (size_t)kMaxIntr * o.ng);
+  for (int g = 0; g < o.ng; ++g) if (o.grp_red[g] >= 0) project_intrinsics_to_bounds(P->group_model[g], &o.intr[(size_t)g * kMaxIntr]);
+  o.r.assign(2 * o.nobs, 0.0); o.F.assign((size_t)2 * FW * o.nobs, 0.0); o.Jp.assign((size_t)2 * o.pd * o.nobs, 0.0);
+  o.scale_f.assign(o.n(), 1.0); o.scale_p.assign((size_t)o.pd * o.np, 1.0);
+  o.diag_f.assign(o.n(), 0.0); o.diag_p.assign((size_t)o.pd * o.np, 0.0);
   // fixed cost: residual blocks whose parameter blocks are all constant
   o.fixed_cost = 0.0;
   const double one[2] = {1.0, 1.0};
   for (int64_t i = 0; i < o.nobs; ++i) if (o.obs_fixed[i]) {
     const int c = P->obs_cam[i], p = P->obs_pt[i], g = P->cam_group[c];
     double res[2] = {0, 0};
-    reprojection_error<double>(P->group_model[g], &o.cam[6 * c], P->intrinsics + (size_t)g * kMaxIntr,
+    reprojection_error<double>(P->group_model[g], &o.cam[6 * c], &o.intr[(size_t)g * kMaxIntr],
                                &o.pts[4 * p], P->obs_uv + 2 * i, P->obs_sqrt_info ? P->obs_sqrt_info + 2 * i : one, res);
     double rho[3]; loss_evaluate(O->loss_function_type, O->robust_loss_width, res[0] * res[0] + res[1] * res[1], rho);
     o.fixed_cost += 0.5 * rho[0];
@@ -792,8 +843,11 @@ int setup(Oracle& o, const oba_problem* P, const oba_options* O) {
   return 0;
 }
 
-double state_norm(const Oracle& o, const std::vector<double>& cam, const std::vector<double>& pts) {
+double state_norm(const Oracle& o, const std::vector<double>& cam, const std::vector<double>& pts, const std::vector<double>& intr) {
   double s = 0;
+  for (int g = 0; g < o.ng; ++g) if (o.grp_red[g] >= 0) {
+    const int K = intrinsics_size(o.P->group_model[g]);
+    for (int q = 0; q < K; ++q) s += intr[(size_t)g * kMaxIntr + q] * intr[(size_t)g * kMaxIntr + q]; }
   for (int c = 0; c < o.nc; ++c) if (o.cam_red[c] >= 0) for (int q = 0; q < 6; ++q) s += cam[6 * c + q] * cam[6 * c + q];
   for (int p = 0; p < o.np; ++p) if (!o.pt_const[p]) for (int q = 0; q < 4; ++q) s += pts[4 * p + q] * pts[4 * p + q];
   return std::sqrt(s);
@@ -804,6 +858,18 @@ void trace_push(oba_summary* S, double cost, double g, double step, double radiu
   const int k = S->trace_size++;
   S->trace_cost[k] = cost; S->trace_gradient_max_norm[k] = g; S->trace_step_norm[k] = step;
   S->trace_radius[k] = radius; S->trace_accepted[k] = acc;
+}
+
+void init_scaling(Oracle& o) {
+  column_norms(o, o.diag_f, o.diag_p);  // jacobi scaling, computed once (trust_region_minimizer.cc)
+  for (size_t i = 0; i < o.scale_f.size(); ++i) o.scale_f[i] = 1.0 / (1.0 + std::sqrt(o.diag_f[i]));
+  for (size_t i = 0; i < o.scale_p.size(); ++i) o.scale_p[i] = 1.0 / (1.0 + std::sqrt(o.diag_p[i]));
+  apply_scaling(o);
+}
+void lm_diagonal(Oracle& o) {
+  column_norms(o, o.diag_f, o.diag_p);
+  for (auto& d : o.diag_f) d = std::min(std::max(d, 1e-6), 1e32);
+  for (auto& d : o.diag_p) d = std::min(std::max(d, 1e-6), 1e32);
 }
 
 }  // namespace
@@ -819,34 +885,39 @@ void oracle_ba_options_default(oba_options* o) {
 }
 
 // Evaluate residuals / Jacobian blocks at the problem's current parameters:
-// residuals[nobs][2], jac_cam[nobs][2][6], jac_pt[nobs][2][pd] (loss-corrected,
-// tangent space, unscaled), valid = all functors returned true.
-int oracle_ba_evaluate(const oba_problem* P, const oba_options* O, double* cost, double* residuals,
-                       double* jac_cam, double* jac_pt) {
+// residuals[nobs][2], jac_cam[nobs][2][6], jac_pt[nobs][2][pd], optional
+// jac_intr[nobs][2][10] (loss-corrected, tangent space, unscaled; frozen
+// columns are zero), returns 1 iff all functors returned true.
+int oracle_ba_evaluate_ex(const oba_problem* P, const oba_options* O, double* cost, double* residuals,
+                          double* jac_cam, double* jac_pt, double* jac_intr) {
   Oracle o; int rc = setup(o, P, O); if (rc) return rc;
-  double c; const bool ok = evaluate(o, o.cam, o.pts, true, &c);
+  double c; const bool ok = evaluate(o, o.cam, o.pts, o.intr, true, &c);
   *cost = c + o.fixed_cost;
   if (residuals) std::copy(o.r.begin(), o.r.end(), residuals);
-  if (jac_cam) std::copy(o.Jc.begin(), o.Jc.end(), jac_cam);
+  for (int64_t i = 0; i < o.nobs; ++i) for (int a = 0; a < 2; ++a) {
+    const double* Fr = &o.F[((size_t)i * 2 + a) * FW];
+    if (jac_cam) for (int q = 0; q < 6; ++q) jac_cam[12 * i + 6 * a + q] = Fr[kMaxIntr + q];
+    if (jac_intr) for (int q = 0; q < kMaxIntr; ++q) jac_intr[20 * i + 10 * a + q] = Fr[q];
+  }
   if (jac_pt) std::copy(o.Jp.begin(), o.Jp.end(), jac_pt);
   return ok ? 1 : 0;
 }
+int oracle_ba_evaluate(const oba_problem* P, const oba_options* O, double* cost, double* residuals,
+                       double* jac_cam, double* jac_pt) {
+  return oracle_ba_evaluate_ex(P, O, cost, residuals, jac_cam, jac_pt, nullptr);
+}
 
 // Dense reduced camera system at the current parameters for a given radius
-// (Jacobi-scaled, as the LM step solves it). S: n*n row-major, rhs: n.
+// (Jacobi-scaled, as the LM step solves it). S: n*n row-major, rhs: n;
+// n = 10 * (#variable intrinsics groups) + 6 * (#variable cameras).
 int oracle_ba_reduced_system(const oba_problem* P, const oba_options* O, double radius, int32_t* n_out,
                              double* S, double* rhs, int64_t capacity) {
   Oracle o; int rc = setup(o, P, O); if (rc) return rc;
-  double c; if (!evaluate(o, o.cam, o.pts, true, &c)) return -5;
-  column_norms(o, o.diag_c, o.diag_p);
-  for (size_t i = 0; i < o.scale_c.size(); ++i) o.scale_c[i] = 1.0 / (1.0 + std::sqrt(o.diag_c[i]));
-  for (size_t i = 0; i < o.scale_p.size(); ++i) o.scale_p[i] = 1.0 / (1.0 + std::sqrt(o.diag_p[i]));
-  apply_scaling(o);
-  column_norms(o, o.diag_c, o.diag_p);
-  for (auto& d : o.diag_c) d = std::min(std::max(d, 1e-6), 1e32);
-  for (auto& d : o.diag_p) d = std::min(std::max(d, 1e-6), 1e32);
+  double c; if (!evaluate(o, o.cam, o.pts, o.intr, true, &c)) return -5;
+  init_scaling(o);
+  lm_diagonal(o);
   if (!build_reduced(o, radius)) return -5;
-  const int n = 6 * o.ncv; *n_out = n;
+  const int n = o.n(); *n_out = n;
   if ((int64_t)n * n > capacity) return -1;
   std::copy(o.S.begin(), o.S.end(), S); std::copy(o.rhs.begin(), o.rhs.end(), rhs);
   return 0;
@@ -854,34 +925,37 @@ int oracle_ba_reduced_system(const oba_problem* P, const oba_options* O, double 
 
 // Multi-rank protocol pieces (what each rank computes before / after the
 // all-reduce of the sharded path; used by the world_size-2 gloo test):
-//  1. unscaled squared camera column norms of this shard        [6 * nc]
+//  1. unscaled squared camera-side column norms of this shard        [n]
 //  2. with the GLOBAL (summed) norms -> Jacobi scale, this shard's partial
-//     reduced system WITHOUT the camera LM diagonal, and this shard's scaled
-//     squared camera column norms (summed over ranks, they give that diagonal).
+//     reduced system WITHOUT the camera-side LM diagonal, and this shard's scaled
+//     squared column norms (summed over ranks, they give that diagonal).
 int oracle_ba_colnorms(const oba_problem* P, const oba_options* O, double* colsq_c) {
   Oracle o; int rc = setup(o, P, O); if (rc) return rc;
-  double c; if (!evaluate(o, o.cam, o.pts, true, &c)) return -5;
-  column_norms(o, o.diag_c, o.diag_p);
-  std::copy(o.diag_c.begin(), o.diag_c.end(), colsq_c);
+  double c; if (!evaluate(o, o.cam, o.pts, o.intr, true, &c)) return -5;
+  column_norms(o, o.diag_f, o.diag_p);
+  std::fill(colsq_c, colsq_c + 6 * (size_t)o.nc, 0.0);
+  for (int cc = 0; cc < o.nc; ++cc) { const int r = o.cam_red[cc]; if (r < 0) continue;
+    for (int a = 0; a < 6; ++a) colsq_c[6 * cc + a] = o.diag_f[o.ni + 6 * r + a]; }
   return 0;
 }
 
 int oracle_ba_reduced_partial(const oba_problem* P, const oba_options* O, double radius, const double* colsq_c_global,
                               int32_t* n_out, double* S, double* rhs, double* colsq_scaled, int64_t capacity) {
   Oracle o; int rc = setup(o, P, O); if (rc) return rc;
-  double c; if (!evaluate(o, o.cam, o.pts, true, &c)) return -5;
-  column_norms(o, o.diag_c, o.diag_p);
-  for (size_t i = 0; i < o.scale_c.size(); ++i) o.scale_c[i] = 1.0 / (1.0 + std::sqrt(colsq_c_global[i]));
+  if (o.ni != 0) return -3;  // protocol test covers the default (intrinsics NONE) path
+  double c; if (!evaluate(o, o.cam, o.pts, o.intr, true, &c)) return -5;
+  column_norms(o, o.diag_f, o.diag_p);
+  for (int cc = 0; cc < o.nc; ++cc) { const int r = o.cam_red[cc]; if (r < 0) continue;
+    for (int a = 0; a < 6; ++a) o.scale_f[6 * r + a] = 1.0 / (1.0 + std::sqrt(colsq_c_global[6 * cc + a])); }
   for (size_t i = 0; i < o.scale_p.size(); ++i) o.scale_p[i] = 1.0 / (1.0 + std::sqrt(o.diag_p[i]));
   apply_scaling(o);
-  column_norms(o, o.diag_c, o.diag_p);
+  column_norms(o, o.diag_f, o.diag_p);
   for (auto& d : o.diag_p) d = std::min(std::max(d, 1e-6), 1e32);
   if (!build_reduced(o, radius, false)) return -5;
-  const int n = 6 * o.ncv; *n_out = n;
+  const int n = o.n(); *n_out = n;
   if ((int64_t)n * n > capacity) return -1;
   std::copy(o.S.begin(), o.S.end(), S); std::copy(o.rhs.begin(), o.rhs.end(), rhs);
-  for (int cidx = 0; cidx < o.nc; ++cidx) { const int r = o.cam_red[cidx]; if (r < 0) continue;
-    for (int a = 0; a < 6; ++a) colsq_scaled[6 * r + a] = o.diag_c[6 * cidx + a]; }
+  for (int d = 0; d < n; ++d) colsq_scaled[d] = o.diag_f[d];
   return 0;
 }
 
@@ -897,17 +971,14 @@ int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
   // iteration zero
   double x_cost;
   double tl = now_s();
-  if (!evaluate(o, o.cam, o.pts, true, &x_cost)) {
+  if (!evaluate(o, o.cam, o.pts, o.intr, true, &x_cost)) {
     S->termination_type = 2; S->initial_cost = S->final_cost = x_cost + o.fixed_cost;
     S->solve_time_in_seconds = now_s() - t1; return 0;
   }
-  column_norms(o, o.diag_c, o.diag_p);  // jacobi scaling, computed once (trust_region_minimizer.cc)
-  for (size_t i = 0; i < o.scale_c.size(); ++i) o.scale_c[i] = 1.0 / (1.0 + std::sqrt(o.diag_c[i]));
-  for (size_t i = 0; i < o.scale_p.size(); ++i) o.scale_p[i] = 1.0 / (1.0 + std::sqrt(o.diag_p[i]));
-  apply_scaling(o);
+  init_scaling(o);
   double gmax = compute_gradient(o);
   S->time_linearize += now_s() - tl;
-  double x_norm = state_norm(o, o.cam, o.pts);
+  double x_norm = state_norm(o, o.cam, o.pts, o.intr);
   S->initial_cost = x_cost + o.fixed_cost;
   double radius = 1e4, decrease_factor = 2.0;
   bool reuse_diagonal = false, step_successful = true;
@@ -915,7 +986,7 @@ int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
   double minimum_cost = x_cost;
   trace_push(S, x_cost + o.fixed_cost, gmax, 0.0, radius, 1);
   int term = 1;
-  const int n = 6 * o.ncv;
+  const int n = o.n();
   while (true) {
     // FinalizeIterationAndCheckIfMinimizerCanContinue
     if (now_s() - t1 >= O->max_solver_time_in_seconds) { term = 1; break; }
@@ -925,11 +996,7 @@ int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
     ++iter;
     // LevenbergMarquardtStrategy::ComputeStep
     double ts = now_s();
-    if (!reuse_diagonal) {
-      column_norms(o, o.diag_c, o.diag_p);
-      for (auto& d : o.diag_c) d = std::min(std::max(d, 1e-6), 1e32);
-      for (auto& d : o.diag_p) d = std::min(std::max(d, 1e-6), 1e32);
-    }
+    if (!reuse_diagonal) lm_diagonal(o);
     reuse_diagonal = true;
     bool solved = build_reduced(o, radius);
     S->time_linearize += now_s() - ts; ts = now_s();
@@ -942,9 +1009,10 @@ int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
       back_substitute(o);
       // step = -y ; model_residuals = Js * step ; mcc = -m.(r + m/2)
       for (int64_t i = 0; i < o.nobs; ++i) { if (o.obs_fixed[i]) continue;
-        const int rc2 = o.cam_red[P->obs_cam[i]]; const int p = P->obs_pt[i];
+        const int c = P->obs_cam[i], p = P->obs_pt[i], g = P->cam_group[c];
         for (int a = 0; a < 2; ++a) { double m = 0;
-          if (rc2 >= 0) for (int q = 0; q < 6; ++q) m -= o.Jc[12 * i + 6 * a + q] * o.yc[6 * rc2 + q];
+          const double* Fr = &o.F[((size_t)i * 2 + a) * FW];
+          for (int q = 0; q < FW; ++q) { const int col = fcol(o, c, g, q); if (col >= 0) m -= Fr[q] * o.yc[col]; }
           for (int q = 0; q < pd; ++q) m -= o.Jp[(size_t)i * 2 * pd + a * pd + q] * o.yp[(size_t)pd * p + q];
           model_cost_change -= m * (o.r[2 * i + a] + m / 2.0); } }
       step_valid = model_cost_change > 0.0;
@@ -957,19 +1025,25 @@ int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
       continue;
     }
     invalid_steps = 0;
-    // candidate = Plus(x, delta), delta = step .* scale
-    o.ccam = o.cam; o.cpts = o.pts;
+    // candidate = Plus(x, delta), delta = step .* scale (intrinsics: projected onto their bounds)
+    o.ccam = o.cam; o.cpts = o.pts; o.cintr = o.intr;
+    for (int g = 0; g < o.ng; ++g) { const int gr = o.grp_red[g]; if (gr < 0) continue;
+      for (int q = 0; q < kMaxIntr; ++q) if ((o.grp_free[g] >> q) & 1u)
+        o.cintr[(size_t)g * kMaxIntr + q] = o.intr[(size_t)g * kMaxIntr + q] + (-o.yc[10 * gr + q]) * o.scale_f[10 * gr + q];
+      project_intrinsics_to_bounds(P->group_model[g], &o.cintr[(size_t)g * kMaxIntr]); }
     for (int c = 0; c < o.nc; ++c) { const int rc2 = o.cam_red[c]; if (rc2 < 0) continue;
-      for (int q = 0; q < 6; ++q) o.ccam[6 * c + q] = o.cam[6 * c + q] + (-o.yc[6 * rc2 + q]) * o.scale_c[6 * c + q]; }
+      for (int q = 0; q < 6; ++q) if (!((o.cam_mask[c] >> q) & 1))
+        o.ccam[6 * c + q] = o.cam[6 * c + q] + (-o.yc[o.ni + 6 * rc2 + q]) * o.scale_f[o.ni + 6 * rc2 + q]; }
     for (int p = 0; p < o.np; ++p) { if (o.pt_const[p]) continue;
       double d[4]; for (int q = 0; q < pd; ++q) d[q] = -o.yp[(size_t)pd * p + q] * o.scale_p[(size_t)pd * p + q];
       if (pd == 3) sphere_plus(&o.pts[4 * p], d, &o.cpts[4 * p]);
       else for (int q = 0; q < 4; ++q) o.cpts[4 * p + q] = o.pts[4 * p + q] + d[q]; }
     double cand_cost;
-    if (!evaluate(o, o.ccam, o.cpts, false, &cand_cost)) cand_cost = std::numeric_limits<double>::max();
+    if (!evaluate(o, o.ccam, o.cpts, o.cintr, false, &cand_cost)) cand_cost = std::numeric_limits<double>::max();
     S->time_backsub += now_s() - ts;
     // ParameterToleranceReached
     double sn = 0;
+    for (int g = 0; g < o.ng; ++g) if (o.grp_red[g] >= 0) for (int q = 0; q < kMaxIntr; ++q) { const double d = o.intr[(size_t)g * kMaxIntr + q] - o.cintr[(size_t)g * kMaxIntr + q]; sn += d * d; }
     for (int c = 0; c < o.nc; ++c) if (o.cam_red[c] >= 0) for (int q = 0; q < 6; ++q) { const double d = o.cam[6 * c + q] - o.ccam[6 * c + q]; sn += d * d; }
     for (int p = 0; p < o.np; ++p) if (!o.pt_const[p]) for (int q = 0; q < 4; ++q) { const double d = o.pts[4 * p + q] - o.cpts[4 * p + q]; sn += d * d; }
     const double step_norm = std::sqrt(sn);
@@ -981,10 +1055,10 @@ int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
       trace_push(S, cand_cost + o.fixed_cost, gmax, step_norm, radius, 0); term = 0; break; }
     const double relative_decrease = cost_change / model_cost_change;
     if (relative_decrease > 1e-3) {
-      o.cam.swap(o.ccam); o.pts.swap(o.cpts);
-      x_norm = state_norm(o, o.cam, o.pts);
+      o.cam.swap(o.ccam); o.pts.swap(o.cpts); o.intr.swap(o.cintr);
+      x_norm = state_norm(o, o.cam, o.pts, o.intr);
       double tl2 = now_s();
-      evaluate(o, o.cam, o.pts, true, &x_cost);
+      evaluate(o, o.cam, o.pts, o.intr, true, &x_cost);
       apply_scaling(o);
       gmax = compute_gradient(o);
       S->time_linearize += now_s() - tl2;
@@ -1003,6 +1077,7 @@ int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
   S->final_cost = minimum_cost + o.fixed_cost;
   std::copy(o.cam.begin(), o.cam.end(), P->cam_ext);
   std::copy(o.pts.begin(), o.pts.end(), P->points);
+  std::copy(o.intr.begin(), o.intr.end(), P->intrinsics);
   S->solve_time_in_seconds = now_s() - t1;
   if (O->verbose) std::fprintf(stderr, "[oracle] iters=%d term=%d cost %.6e -> %.6e\n", iter, term, S->initial_cost, S->final_cost);
   return 0;

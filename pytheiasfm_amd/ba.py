@@ -75,10 +75,22 @@ class BaHandle:
             capi.ptr(jp, C.c_double), capi.ptr(valid, C.c_uint8)))
         return cost.value, r, jc, jp, valid
 
+    def evaluate_ex(self):
+        """evaluate() plus the intrinsics Jacobian J_intr[nobs][2][10]."""
+        n = self.problem.obs_uv.shape[0]
+        cost = C.c_double(0)
+        r = np.zeros((n, 2)); jc = np.zeros((n, 2, 6)); jp = np.zeros((n, 2, self.pd)); ji = np.zeros((n, 2, 10))
+        valid = np.zeros(n, dtype=np.uint8)
+        capi.check(capi.lib().theia_hip_ba_evaluate_ex(
+            self._h, C.byref(cost), capi.ptr(r, C.c_double), capi.ptr(jc, C.c_double),
+            capi.ptr(jp, C.c_double), capi.ptr(ji, C.c_double), capi.ptr(valid, C.c_uint8)))
+        return cost.value, r, jc, jp, ji, valid
+
     def reduced_system(self, radius):
         ncam = self.problem.cam_ext.shape[0]
-        cap = (6 * ncam) ** 2
-        S = np.zeros(max(cap, 1)); rhs = np.zeros(max(6 * ncam, 1)); n = C.c_int32(0)
+        nmax = 6 * ncam + 10 * self.problem.intrinsics.shape[0]
+        cap = nmax ** 2
+        S = np.zeros(max(cap, 1)); rhs = np.zeros(max(nmax, 1)); n = C.c_int32(0)
         capi.check(capi.lib().theia_hip_ba_reduced_system(
             self._h, radius, C.byref(n), capi.ptr(S, C.c_double), capi.ptr(rhs, C.c_double), cap))
         n = n.value

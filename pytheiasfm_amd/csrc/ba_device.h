@@ -22,6 +22,9 @@ struct ObsLin {        // linearisation of one observation (unscaled, uncorrecte
   double Jx[8];        // 2x4 wrt homogeneous point (ambient)
   bool valid;          // functor return value
 };
+struct ObsLinK : ObsLin {
+  double Jk[2 * THEIA_MAX_INTRINSICS];  // 2xK wrt the intrinsics block (already sqrt-information weighted)
+};
 
 // Rotation terms of one camera: R and the scalars the d/d(omega) needs.
 struct RotTerms {
@@ -83,10 +86,20 @@ THIP_DEV void rotation_dq_dw(const double w[3], const double p[3], const RotTerm
 // Projection pi(k, q) and its 2x3 Jacobian wrt q for the eight camera models of
 // create_reprojection_error_cost_function.h:61-135.  Returns the model's
 // validity boolean.  Derivatives are those of the branch taken.
-template <bool WANT_JAC>
-THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2], double Jq[6]) {
+// WANT_KJAC additionally returns Jk (2 x THEIA_MAX_INTRINSICS, row-major): the
+// derivatives wrt the intrinsics block (zero beyond the model's K parameters).
+template <bool WANT_JAC, bool WANT_KJAC = false>
+THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2], double Jq[6], double* Jk = nullptr) {
   double dx = 0.0, dy = 0.0;                                  // distorted normalised point
   double ddx[3] = {0.0, 0.0, 0.0}, ddy[3] = {0.0, 0.0, 0.0};  // d(dx)/dq, d(dy)/dq
+  // d(dx)/d(distortion parameter p), d(dy)/d(p) for p >= 5 (or 4 for the no-skew layouts)
+  double pdx[THEIA_MAX_INTRINSICS], pdy[THEIA_MAX_INTRINSICS];
+  if (WANT_KJAC) {
+#pragma unroll
+    for (int i = 0; i < THEIA_MAX_INTRINSICS; ++i) { pdx[i] = 0.0; pdy[i] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < 2 * THEIA_MAX_INTRINSICS; ++i) Jk[i] = 0.0;
+  }
   bool ok = true;
   // models whose distortion acts on (x, y) = (q0/q2, q1/q2): fill dxx.. then chain
   bool planar = false;
@@ -103,6 +116,7 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
         const double e = 2.0 * (k[5] + 2.0 * k[6] * r2);
         dxx = d + x * x * e; dxy = x * y * e; dyx = dxy; dyy = d + y * y * e;
       }
+      if (WANT_KJAC) { pdx[5] = x * r2; pdy[5] = y * r2; pdx[6] = x * r2 * r2; pdy[6] = y * r2 * r2; }
       break; }
     case THEIA_CAM_PINHOLE_RADIAL_TANGENTIAL: {
       // pinhole_radial_tangential_camera_model.h:191-296  [.., k1 k2 k3 t1 t2]
@@ -120,6 +134,12 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
         dyx = x * y * e + 2.0 * t1 * x + 2.0 * t2 * y;
         dyy = rd + y * y * e + 6.0 * t1 * y + 2.0 * t2 * x;
       }
+      if (WANT_KJAC) {
+        pdx[5] = x * r2; pdy[5] = y * r2; pdx[6] = x * r2 * r2; pdy[6] = y * r2 * r2;
+        pdx[7] = x * r2 * r2 * r2; pdy[7] = y * r2 * r2 * r2;
+        pdx[8] = 2.0 * x * y; pdy[8] = r2 + 2.0 * y * y;
+        pdx[9] = r2 + 2.0 * x * x; pdy[9] = 2.0 * x * y;
+      }
       break; }
     case THEIA_CAM_FOV: {
       // fov_camera_model.h:156-258  [f a cx cy omega]
@@ -127,23 +147,29 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
       x = q[0] / q[2]; y = q[1] / q[2];
       const double omega = k[4];
       const double ru2 = x * x + y * y;
-      double rd, g;  // g = d rd / d(ru2)
+      double rd, g, gw;  // g = d rd / d(ru2), gw = d rd / d(omega)
       if (omega < 1e-3) {
         rd = (omega * omega * ru2) / 3.0 - omega * omega / 12.0 + 1.0;
         g = omega * omega / 3.0;
+        gw = 2.0 * omega * ru2 / 3.0 - omega / 6.0;
       } else if (ru2 < 1e-3) {
         const double th = tan(omega / 2.0);
+        const double dth = 0.5 * (1.0 + th * th);
         rd = (-2.0 * th * (4.0 * ru2 * th * th - 3.0)) / (3.0 * omega);
         g = -8.0 * th * th * th / (3.0 * omega);
+        gw = (-2.0 * dth * (4.0 * ru2 * th * th - 3.0) - 2.0 * th * (8.0 * ru2 * th * dth)) / (3.0 * omega) - rd / omega;
       } else {
         const double ru = sqrt(ru2);
         const double th = tan(omega / 2.0);
+        const double dth = 0.5 * (1.0 + th * th);
         const double at = atan(2.0 * ru * th);
         rd = at / (ru * omega);
         const double drd_dru = ((2.0 * th / (1.0 + 4.0 * ru2 * th * th)) * ru - at) / (ru2 * omega);
         g = drd_dru / (2.0 * ru);
+        gw = (2.0 * ru * dth / (1.0 + 4.0 * ru2 * th * th)) / (ru * omega) - rd / omega;
       }
       dx = rd * x; dy = rd * y;
+      if (WANT_KJAC) { pdx[4] = gw * x; pdy[4] = gw * y; }
       if (WANT_JAC) { dxx = rd + 2.0 * x * x * g; dxy = 2.0 * x * y * g; dyx = dxy; dyy = rd + 2.0 * y * y * g; }
       break; }
     case THEIA_CAM_ORTHOGRAPHIC: {
@@ -156,6 +182,7 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
         ddx[0] = d + q[0] * q[0] * e; ddx[1] = q[0] * q[1] * e;
         ddy[0] = ddx[1]; ddy[1] = d + q[1] * q[1] * e;
       }
+      if (WANT_KJAC) { pdx[5] = q[0] * r2; pdy[5] = q[1] * r2; pdx[6] = q[0] * r2 * r2; pdy[6] = q[1] * r2 * r2; }
       break; }
     case THEIA_CAM_FISHEYE: {
       // fisheye_camera_model.h:163-272  [.., k1 k2 k3 k4]
@@ -182,6 +209,11 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
           ddx[0] = sgn * (s + q[0] * ds0); ddx[1] = sgn * (q[0] * ds1); ddx[2] = sgn * (q[0] * ds2);
           ddy[0] = sgn * (q[1] * ds0); ddy[1] = sgn * (s + q[1] * ds1); ddy[2] = sgn * (q[1] * ds2);
         }
+        if (WANT_KJAC) {
+          double tp = th * t2;  // theta^3, ^5, ^7, ^9
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { pdx[5 + i] = sgn * tp * q[0] / r; pdy[5 + i] = sgn * tp * q[1] / r; tp *= t2; }
+        }
       }
       break; }
     case THEIA_CAM_DOUBLE_SPHERE: {
@@ -207,6 +239,13 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
         }
         ddx[0] += in; ddy[1] += in;
       }
+      if (WANT_KJAC) {
+        // n = alpha d2 + (1 - alpha) kk, kk = xi d1 + z, d2 = sqrt(r2 + kk^2)
+        const double dn_dxi = alpha * kk * d1 / d2 + (1.0 - alpha) * d1;
+        const double dn_dal = d2 - kk;
+        pdx[5] = -dx * dn_dxi / n; pdy[5] = -dy * dn_dxi / n;
+        pdx[6] = -dx * dn_dal / n; pdy[6] = -dy * dn_dal / n;
+      }
       break; }
     case THEIA_CAM_EXTENDED_UNIFIED: {
       // extended_unified_camera_model.h:161-249  [.., alpha, beta]
@@ -223,6 +262,11 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
           const double dn[3] = {alpha * beta * q[0] * ir, alpha * beta * q[1] * ir, alpha * q[2] * ir + (1.0 - alpha)};
           for (int i = 0; i < 3; ++i) { ddx[i] = -dx * dn[i] * in; ddy[i] = -dy * dn[i] * in; }
           ddx[0] += in; ddy[1] += in;
+        }
+        if (WANT_KJAC) {
+          const double dn_dal = rho - q[2], dn_dbe = alpha * r2 / (2.0 * rho);
+          pdx[5] = -dx * dn_dal / n; pdy[5] = -dy * dn_dal / n;
+          pdx[6] = -dx * dn_dbe / n; pdy[6] = -dy * dn_dbe / n;
         }
       }
       break; }
@@ -250,6 +294,20 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
         Jq[0] = pxx * fx * iz; Jq[1] = pxy * fy * iz; Jq[2] = -(pxx * fx * xx + pxy * fy * yy) * iz;
         Jq[3] = pxy * fx * iz; Jq[4] = pyy * fy * iz; Jq[5] = -(pxy * fx * xx + pyy * fy * yy) * iz;
       }
+      if (WANT_KJAC) {
+        const double xn = q[0] * iz, yn = q[1] * iz;
+        const double pxx = scale + 2.0 * ux * ux * g, pxy = 2.0 * ux * uy * g, pyy = scale + 2.0 * uy * uy * g;
+        // f: ux = f xn, uy = f a yn ; a: uy = f a yn
+        Jk[0] = pxx * xn + pxy * k[1] * yn;                         Jk[THEIA_MAX_INTRINSICS + 0] = pxy * xn + pyy * k[1] * yn;
+        Jk[1] = pxy * k[0] * yn;                                    Jk[THEIA_MAX_INTRINSICS + 1] = pyy * k[0] * yn;
+        Jk[2] = 1.0;                                                Jk[THEIA_MAX_INTRINSICS + 3] = 1.0;
+        double gk = 0.0;  // d scale / d k  at fixed ru2
+        if (!(fabs(denom) < DBL_EPSILON || inner < 0.0)) {
+          const double sq = sqrt(inner);
+          gk = ((2.0 * ru2 / sq) * denom - (1.0 - sq) * (2.0 * ru2)) / (denom * denom);
+        }
+        Jk[4] = ux * gk;                                            Jk[THEIA_MAX_INTRINSICS + 4] = uy * gk;
+      }
       return true; }
     default:
       uv[0] = 0.0; uv[1] = 0.0;
@@ -275,18 +333,31 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
       Jq[3 + i] = fa * ddy[i];
     }
   }
+  if (WANT_KJAC) {
+    double* Ju = Jk;
+    double* Jv = Jk + THEIA_MAX_INTRINSICS;
+    Ju[0] = dx;            Jv[0] = k[1] * dy;   // focal
+    Jv[1] = k[0] * dy;                          // aspect ratio
+    if (noskew) { Ju[2] = 1.0; Jv[3] = 1.0; }
+    else { Ju[2] = dy; Ju[3] = 1.0; Jv[4] = 1.0; }
+    const int p0 = noskew ? 4 : 5;
+#pragma unroll
+    for (int i = 4; i < THEIA_MAX_INTRINSICS; ++i)
+      if (i >= p0) { Ju[i] = f * pdx[i] + sk * pdy[i]; Jv[i] = fa * pdy[i]; }
+  }
   return ok;
 }
 
 // Residual (and optionally Jacobians) of one observation.
-template <bool WANT_JAC>
+template <bool WANT_JAC, bool WANT_KJAC = false, typename OL = ObsLin>
 THIP_DEV void observe(int model, const double* ext, const double* intr, const double X[4],
-                      double u0, double v0, double six, double siy, ObsLin& o) {
+                      double u0, double v0, double six, double siy, OL& o) {
   const double p[3] = {X[0] - X[3] * ext[0], X[1] - X[3] * ext[1], X[2] - X[3] * ext[2]};
   const double sq = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
   if (sq < 1e-8) {  // reprojection_error.h:78-80 -> functor returns false
     o.valid = false; o.r[0] = 0.0; o.r[1] = 0.0;
     if (WANT_JAC) { for (int i = 0; i < 12; ++i) o.Jc[i] = 0.0; for (int i = 0; i < 8; ++i) o.Jx[i] = 0.0; }
+    if constexpr (WANT_KJAC) { for (int i = 0; i < 2 * THEIA_MAX_INTRINSICS; ++i) o.Jk[i] = 0.0; }
     return;
   }
   RotTerms t;
@@ -295,7 +366,12 @@ THIP_DEV void observe(int model, const double* ext, const double* intr, const do
                        t.R[3] * p[0] + t.R[4] * p[1] + t.R[5] * p[2],
                        t.R[6] * p[0] + t.R[7] * p[1] + t.R[8] * p[2]};
   double uv[2], Jq[6];
-  o.valid = project<WANT_JAC>(model, intr, q, uv, Jq);
+  if constexpr (WANT_KJAC) {
+    o.valid = project<WANT_JAC, true>(model, intr, q, uv, Jq, o.Jk);
+    for (int i = 0; i < THEIA_MAX_INTRINSICS; ++i) { o.Jk[i] *= six; o.Jk[THEIA_MAX_INTRINSICS + i] *= siy; }
+  } else {
+    o.valid = project<WANT_JAC, false>(model, intr, q, uv, Jq);
+  }
   o.r[0] = six * (uv[0] - u0);
   o.r[1] = siy * (uv[1] - v0);
   if (WANT_JAC) {

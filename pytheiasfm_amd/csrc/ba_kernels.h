@@ -37,6 +37,16 @@ struct DevProblem {
   const int* long_track_pt;    // [long_ntracks]
   const double* scale_c;       // [nc][6] Jacobi scaling
   const double* scale_p;       // [np][pd]
+  // intrinsics blocks (intrinsics_to_optimize != NONE): they come FIRST in the
+  // reduced system, 10 slots per variable group; cameras follow at ni + 6 * rc
+  int ni;                      // 10 * (#variable intrinsics groups), 0 = all intrinsics constant
+  int ng_total;                // number of intrinsics groups
+  const int* grp_k;            // [ng] number of parameters K of the group's model
+  const int* grp_red;          // [ng] reduced group index or -1
+  const unsigned* grp_free;    // [ng] bit q = parameter q is free
+  const double* scale_i;       // [ng][10] Jacobi scaling of the intrinsics columns
+  const double* intr_cand;     // [ng][10] candidate intrinsics (back-substitution / trial cost)
+  const double* scale_red;     // [n] Jacobi scaling by reduced index (finalize)
 };
 
 // Per-iteration reduced-system workspace: one contiguous buffer so that a
@@ -56,7 +66,8 @@ enum {  // indices into ReduceBuf::scal: [0,8) are SUM-reduced, [8,16) MAX-reduc
 };
 
 void launch_colnorm(const DevProblem& P, const double* cam, const double* pts, double* colsq_c,
-                    double* colsq_p, hipStream_t st);
+                    double* colsq_p, double* colsq_i, hipStream_t st);
+void launch_build_scale_red(const DevProblem& P, double* scale_red, hipStream_t st);
 void launch_make_scale(int count, const double* colsq, double* scale, hipStream_t st);
 void launch_linearize(const DevProblem& P, const double* cam, const double* pts, double radius,
                       const ReduceBuf& rb, double* Vinv, double* gp, double* tile_part,
@@ -64,14 +75,14 @@ void launch_linearize(const DevProblem& P, const double* cam, const double* pts,
 void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,
                          const int* field_is_max, double* scal, hipStream_t st);
 void launch_finalize_rcs(const DevProblem& P, double radius, const ReduceBuf& rb, hipStream_t st);
-void launch_cam_update(const DevProblem& P, const double* cam, const double* yc, double* cand_cam,
-                       double* out_stepsq, double* out_xnormsq, hipStream_t st);
+void launch_cam_update(const DevProblem& P, const double* cam, const double* y, double* cand_cam,
+                       double* cand_intr, double* out_stepsq, double* out_xnormsq, hipStream_t st);
 void launch_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,
                     double* cand_pts, const double* yc, const double* Vinv, double* tile_part,
                     double* scal, hipStream_t st);
 void launch_evaluate(const DevProblem& P, const double* cam, const double* pts, double* residuals,
                      double* jac_cam, double* jac_pt, uint8_t* valid, double* tile_part,
-                     hipStream_t st);
+                     hipStream_t st, double* jac_intr = nullptr);
 void launch_cost_only(const DevProblem& P, const double* cam, const double* pts, double* tile_part,
                       double* scal, hipStream_t st);
 

@@ -20,6 +20,8 @@
 
 #include "ba_device.h"
 
+#include <type_traits>
+
 namespace thip {
 
 namespace {
@@ -43,24 +45,31 @@ THIP_DEV double wave_max(double v) {
 
 THIP_DEV void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
-template <int PD>
+template <int PD, bool INTR = false>
 struct LaneLin {
   double r[2];
   double Jc[12];
   double Jt[2 * PD];
+  double Jk[INTR ? 2 * THEIA_MAX_INTRINSICS : 1];  // 2 x 10 wrt the intrinsics block (INTR only)
   double X[4];
   double cost;
   int c, p, rc;
+  int g, gr;   // intrinsics group and its reduced index (-1 = constant)
   bool active, valid, pconst;
 };
 
 // Load one observation and linearise it: loss-corrected, column-masked,
 // Jacobi-scaled, tangent-space blocks.  WANT_JAC=false: residual/cost only.
-template <int PD, bool WANT_JAC>
+template <int PD, bool WANT_JAC, bool INTR = false>
 THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam,
                              const double* __restrict__ pts, int o, bool active, int lane,
-                             LaneLin<PD>& L) {
+                             LaneLin<PD, INTR>& L) {
   L.active = active;
+  L.g = 0; L.gr = -1;
+  if (INTR) {
+#pragma unroll
+    for (int i = 0; i < (INTR ? 2 * THEIA_MAX_INTRINSICS : 1); ++i) L.Jk[i] = 0.0;
+  }
   L.valid = true;
   L.cost = 0.0;
   L.r[0] = L.r[1] = 0.0;
@@ -92,8 +101,9 @@ THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam
   const int g = P.cam_group[c];
   const int model = P.group_model[g];
   const double* intr = P.intr + (size_t)g * THEIA_MAX_INTRINSICS;
-  ObsLin ol;
-  observe<WANT_JAC>(model, ext, intr, L.X, uv.x, uv.y, six, siy, ol);
+  L.g = g;
+  typename std::conditional<INTR, ObsLinK, ObsLin>::type ol;
+  observe<WANT_JAC, INTR && WANT_JAC>(model, ext, intr, L.X, uv.x, uv.y, six, siy, ol);
   L.valid = ol.valid;
   const double s = ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1];
   double rho1;
@@ -109,6 +119,18 @@ THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam
       const double sc = ((mask >> q) & 1u) ? 0.0 : sr * P.scale_c[6 * c + q];
       L.Jc[q] = ol.Jc[q] * sc;
       L.Jc[6 + q] = ol.Jc[6 + q] * sc;
+    }
+    if constexpr (INTR) {
+      L.gr = P.grp_red[g];
+      if (L.gr >= 0) {
+        const unsigned fm = P.grp_free[g];
+#pragma unroll
+        for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) {
+          const double sc = ((fm >> q) & 1u) ? sr * P.scale_i[(size_t)g * THEIA_MAX_INTRINSICS + q] : 0.0;
+          L.Jk[q] = ol.Jk[q] * sc;
+          L.Jk[THEIA_MAX_INTRINSICS + q] = ol.Jk[THEIA_MAX_INTRINSICS + q] * sc;
+        }
+      }
     }
     if (!L.pconst) {
       if (PD == 3) {
@@ -228,19 +250,29 @@ THIP_DEV double sym_get(const double (&V)[PD * (PD + 1) / 2], int a, int b) {
 // Squared column norms of the unscaled Jacobian at the initial point: the
 // Jacobi scaling 1/(1+sqrt(.)) is computed once from them
 // (ceres trust_region_minimizer.cc, jacobi_scaling = true).
-template <int PD>
+template <int PD, bool INTR>
 __global__ __launch_bounds__(kBlock) void k_colnorm(DevProblem P, const double* __restrict__ cam,
                                                     const double* __restrict__ pts,
                                                     double* __restrict__ colsq_c,
-                                                    double* __restrict__ colsq_p) {
+                                                    double* __restrict__ colsq_p,
+                                                    double* __restrict__ colsq_i) {
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (tile >= P.ntiles) return;
   const int cnt = P.tile_count[tile];
   const int start = P.tile_start[tile];
-  LaneLin<PD> L;
-  lane_linearize<PD, true>(P, cam, pts, start + lane, lane < cnt, lane, L);
+  LaneLin<PD, INTR> L;
+  lane_linearize<PD, true, INTR>(P, cam, pts, start + lane, lane < cnt, lane, L);
   const Segment sg = lane_segment(L.p, lane);
+  if constexpr (INTR) {
+    if (L.active && L.gr >= 0) {
+#pragma unroll
+      for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) {
+        const double v = L.Jk[q] * L.Jk[q] + L.Jk[THEIA_MAX_INTRINSICS + q] * L.Jk[THEIA_MAX_INTRINSICS + q];
+        if (v != 0.0) atomic_add(&colsq_i[(size_t)L.g * THEIA_MAX_INTRINSICS + q], v);
+      }
+    }
+  }
   double in[PD], out[PD];
 #pragma unroll
   for (int q = 0; q < PD; ++q) in[q] = L.Jt[q] * L.Jt[q] + L.Jt[PD + q] * L.Jt[PD + q];
@@ -274,38 +306,48 @@ constexpr int kWinBlocks = kWin * (kWin + 1) / 2;
 
 THIP_DEV void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
-template <int PD>
+// INTR (intrinsics_to_optimize != NONE): S/rhs/colsq/gc point at the CAMERA part of
+// the reduced system (shifted by ni), SI/rhsI/colsqI/gcI at its origin.  The
+// intrinsics blocks are shared by many cameras; their contributions go through
+// global FP64 atomics (first version of this path: correct, not yet tuned).
+template <int PD, bool INTR>
 __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double* __restrict__ cam,
                                                       const double* __restrict__ pts, double radius,
                                                       double* __restrict__ S, double* __restrict__ rhs,
                                                       double* __restrict__ colsq, double* __restrict__ gc,
                                                       double* __restrict__ Vinv, double* __restrict__ gp,
-                                                      double* __restrict__ tile_part) {
+                                                      double* __restrict__ tile_part,
+                                                      double* __restrict__ SI, double* __restrict__ rhsI,
+                                                      double* __restrict__ colsqI, double* __restrict__ gcI) {
   constexpr int NT = PD * (PD + 1) / 2;
   constexpr int NW = 6 * PD;
-  __shared__ double sW[kWavesPerBlock][kWave][NW + 1];
-  __shared__ int sRc[kWavesPerBlock][kWave];
+  constexpr int NWI = INTR ? THEIA_MAX_INTRINSICS * PD : 1;
+  constexpr int WPB = INTR ? 2 : kWavesPerBlock;   // waves per workgroup (LDS budget)
+  __shared__ double sW[WPB][kWave][NW + 1];
+  __shared__ int sRc[WPB][kWave];
+  __shared__ double sWI[INTR ? WPB : 1][INTR ? kWave : 1][NWI + 1];
+  __shared__ int sGr[INTR ? WPB : 1][INTR ? kWave : 1];
   __shared__ double accS[kWinBlocks][36];       // lower block triangle of the window
   __shared__ double accC[kWin][18];             // per camera: rhs(6) | g_c(6) | colsq(6)
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   const int n = P.n;
   const int base = P.wg_base[blockIdx.x];
-  for (int i = threadIdx.x; i < kWinBlocks * 36; i += kBlock) (&accS[0][0])[i] = 0.0;
-  for (int i = threadIdx.x; i < kWin * 18; i += kBlock) (&accC[0][0])[i] = 0.0;
+  for (int i = threadIdx.x; i < kWinBlocks * 36; i += blockDim.x) (&accS[0][0])[i] = 0.0;
+  for (int i = threadIdx.x; i < kWin * 18; i += blockDim.x) (&accC[0][0])[i] = 0.0;
   __syncthreads();
 
   const int tile0 = blockIdx.x * P.tiles_per_wg;
   long long st_[6] = {0, 0, 0, 0, 0, 0};
   long long tprev = clock64();
 #define STAMP(k_) do { const long long tn_ = clock64(); st_[k_] += tn_ - tprev; tprev = tn_; } while (0)
-  for (int rnd = 0; rnd < P.tiles_per_wg; rnd += kWavesPerBlock) {
+  for (int rnd = 0; rnd < P.tiles_per_wg; rnd += WPB) {
     const int tile = tile0 + rnd + wv;
     const bool tile_ok = (rnd + wv < P.tiles_per_wg) && tile < P.ntiles;
     const int cnt = tile_ok ? P.tile_count[tile] : 0;
     const int start = tile_ok ? P.tile_start[tile] : 0;
-    LaneLin<PD> L;
-    lane_linearize<PD, true>(P, cam, pts, start + lane, lane < cnt, lane, L);
+    LaneLin<PD, INTR> L;
+    lane_linearize<PD, true, INTR>(P, cam, pts, start + lane, lane < cnt, lane, L);
     const Segment sg = lane_segment(L.p, lane);
     STAMP(0);
 
@@ -395,6 +437,48 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
       }
     }
 
+    // ---- intrinsics block of this observation (global atomics)
+    double TI[NWI];
+    const int gr = L.gr;
+    if constexpr (INTR) {
+      const int nfull = P.n;
+      double WI[NWI];
+#pragma unroll
+      for (int a = 0; a < THEIA_MAX_INTRINSICS; ++a)
+#pragma unroll
+        for (int b = 0; b < PD; ++b) WI[a * PD + b] = L.Jk[a] * L.Jt[b] + L.Jk[THEIA_MAX_INTRINSICS + a] * L.Jt[PD + b];
+#pragma unroll
+      for (int a = 0; a < THEIA_MAX_INTRINSICS; ++a)
+#pragma unroll
+        for (int b = 0; b < PD; ++b) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int k = 0; k < PD; ++k) sacc += WI[a * PD + k] * sym_get<PD>(Vi, k, b);
+          TI[a * PD + b] = sacc;
+        }
+      if (L.active && gr >= 0) {
+        const unsigned fm = P.grp_free[L.g];
+        double* Sg = SI + (size_t)(10 * gr) * nfull + 10 * gr;
+        for (int a = 0; a < THEIA_MAX_INTRINSICS; ++a) {
+          if (!((fm >> a) & 1u)) continue;
+          const double jr = L.Jk[a] * L.r[0] + L.Jk[THEIA_MAX_INTRINSICS + a] * L.r[1];
+          double wy = 0.0;
+          for (int b = 0; b < PD; ++b) wy += WI[a * PD + b] * y[b];
+          atomic_add(&rhsI[10 * gr + a], jr - wy);
+          atomic_add(&gcI[10 * gr + a], jr);
+          atomic_add(&colsqI[10 * gr + a], L.Jk[a] * L.Jk[a] + L.Jk[THEIA_MAX_INTRINSICS + a] * L.Jk[THEIA_MAX_INTRINSICS + a]);
+          for (int b = 0; b <= a; ++b)
+            if ((fm >> b) & 1u)
+              atomic_add(&Sg[(size_t)a * nfull + b], L.Jk[a] * L.Jk[b] + L.Jk[THEIA_MAX_INTRINSICS + a] * L.Jk[THEIA_MAX_INTRINSICS + b]);
+          if (L.rc >= 0)   // camera rows x intrinsics columns: F_c^T F_k
+            for (int e = 0; e < 6; ++e)
+              atomic_add(&SI[(size_t)(P.ni + 6 * L.rc + e) * nfull + 10 * gr + a], L.Jc[e] * L.Jk[a] + L.Jc[6 + e] * L.Jk[THEIA_MAX_INTRINSICS + a]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NWI; ++k) sWI[wv][lane][k] = WI[k];
+      sGr[wv][lane] = (L.active && !L.pconst) ? gr : -1;
+    }
     STAMP(3);
     // stage W of the tile in LDS, then every lane walks its track's segment
 #pragma unroll
@@ -411,6 +495,37 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
       const int src = (sg.start + jj) & 63;
       const int rcs = sRc[wv][src];
       const bool take = me && (j < sg.len) && rcs >= 0 && rc >= rcs;
+      if constexpr (INTR) {
+        // every ORDERED pair (lane, src) of the track: intrinsics x intrinsics and camera x intrinsics
+        const int grs = sGr[wv][src];
+        if (L.active && !L.pconst && (j < sg.len) && grs >= 0) {
+          const int nfull = P.n;
+          double WIs[NWI];
+#pragma unroll
+          for (int k = 0; k < NWI; ++k) WIs[k] = sWI[wv][src][k];
+          if (gr >= 0 && gr >= grs) {
+            double* Sb2 = SI + (size_t)(10 * gr) * nfull + 10 * grs;
+            for (int a = 0; a < THEIA_MAX_INTRINSICS; ++a)
+              for (int b = 0; b < THEIA_MAX_INTRINSICS; ++b) {
+                if (gr == grs && b > a) continue;
+                double sacc = 0.0;
+#pragma unroll
+                for (int k = 0; k < PD; ++k) sacc += TI[a * PD + k] * WIs[b * PD + k];
+                if (sacc != 0.0) atomic_add(&Sb2[(size_t)a * nfull + b], -sacc);
+              }
+          }
+          if (rc >= 0) {
+            double* Sb3 = SI + (size_t)(P.ni + 6 * rc) * nfull + 10 * grs;
+            for (int a = 0; a < 6; ++a)
+              for (int b = 0; b < THEIA_MAX_INTRINSICS; ++b) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int k = 0; k < PD; ++k) sacc += T[a * PD + k] * WIs[b * PD + k];
+                if (sacc != 0.0) atomic_add(&Sb3[(size_t)a * nfull + b], -sacc);
+              }
+          }
+        }
+      }
       if (!take) continue;
       double Ws[NW];
 #pragma unroll
@@ -450,7 +565,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
   // flush the window to HBM: one FP64 atomic per non-zero accumulator entry
   __syncthreads();
   const int ncv = P.ncv;
-  for (int e = threadIdx.x; e < kWinBlocks * 36; e += kBlock) {
+  for (int e = threadIdx.x; e < kWinBlocks * 36; e += blockDim.x) {
     const double v = (&accS[0][0])[e];
     if (v == 0.0) continue;
     const int blk = e / 36, ab = e % 36;
@@ -460,7 +575,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
     if (base + bi >= ncv) continue;
     atomic_add(&S[(size_t)(6 * (base + bi) + ab / 6) * n + 6 * (base + bj) + ab % 6], v);
   }
-  for (int e = threadIdx.x; e < kWin * 18; e += kBlock) {
+  for (int e = threadIdx.x; e < kWin * 18; e += blockDim.x) {
     const double v = (&accC[0][0])[e];
     if (v == 0.0) continue;
     const int c = e / 18, q = e % 18;
@@ -506,21 +621,16 @@ __global__ __launch_bounds__(1024) void k_reduce_tiles(int ntiles, const double*
   }
 }
 
-// Add the LM diagonal to the camera blocks and fold the camera gradient into
-// the gradient max-norm: S_dd += clamp(colsq_d) / radius.
+// Add the LM diagonal to the camera-side blocks (intrinsics + extrinsics) and
+// fold their gradient into the gradient max-norm: S_dd += clamp(colsq_d) / radius.
 __global__ void k_finalize_rcs(DevProblem P, double radius, double* __restrict__ S,
                                const double* __restrict__ colsq, const double* __restrict__ gc,
                                double* __restrict__ scal) {
   __shared__ double sm[256];
   double gmax = 0.0;
-  for (int c = threadIdx.x; c < P.nc; c += blockDim.x) {
-    const int rc = P.cam_red[c];
-    if (rc < 0) continue;
-    for (int q = 0; q < 6; ++q) {
-      const int d = 6 * rc + q;
-      S[(size_t)d * P.n + d] += fmin(fmax(colsq[d], 1e-6), 1e32) / radius;
-      gmax = fmax(gmax, fabs(gc[d] / P.scale_c[6 * c + q]));
-    }
+  for (int d = threadIdx.x; d < P.n; d += blockDim.x) {
+    S[(size_t)d * P.n + d] += fmin(fmax(colsq[d], 1e-6), 1e32) / radius;
+    gmax = fmax(gmax, fabs(gc[d] / P.scale_red[d]));
   }
   sm[threadIdx.x] = gmax;
   __syncthreads();
@@ -531,12 +641,31 @@ __global__ void k_finalize_rcs(DevProblem P, double radius, double* __restrict__
   if (threadIdx.x == 0) scal[SC_GMAX] = fmax(scal[SC_GMAX], sm[0]);
 }
 
-// candidate cameras: x + (-y_c) * scale_c ; adds their |step|^2 and |x+|^2.
-__global__ void k_cam_update(DevProblem P, const double* __restrict__ cam, const double* __restrict__ yc,
-                             double* __restrict__ cand, double* __restrict__ out_stepsq,
-                             double* __restrict__ out_xnormsq) {
+// Jacobi scaling by reduced index (frozen columns: 1).  One workgroup.
+__global__ void k_build_scale_red(DevProblem P, double* __restrict__ scale_red) {
+  for (int d = threadIdx.x; d < P.n; d += blockDim.x) scale_red[d] = 1.0;
+  __syncthreads();
+  if (P.ni)
+    for (int i = threadIdx.x; i < THEIA_MAX_INTRINSICS * P.ng_total; i += blockDim.x) {
+      const int g = i / THEIA_MAX_INTRINSICS, q = i % THEIA_MAX_INTRINSICS;
+      const int gr = P.grp_red[g];
+      if (gr >= 0 && ((P.grp_free[g] >> q) & 1u)) scale_red[10 * gr + q] = P.scale_i[i];
+    }
+  for (int i = threadIdx.x; i < 6 * P.nc; i += blockDim.x) {
+    const int c = i / 6, q = i % 6;
+    const int rc = P.cam_red[c];
+    if (rc >= 0 && !((P.cam_mask[c] >> q) & 1u)) scale_red[P.ni + 6 * rc + q] = P.scale_c[i];
+  }
+}
+
+// candidate cameras and intrinsics: x + (-y) * scale (intrinsics projected onto
+// their bounds, bundle_adjuster.cc:406-427); their |step|^2 and |x+|^2.
+__global__ void k_cam_update(DevProblem P, const double* __restrict__ cam, const double* __restrict__ y,
+                             double* __restrict__ cand, double* __restrict__ cand_intr,
+                             double* __restrict__ out_stepsq, double* __restrict__ out_xnormsq) {
   __shared__ double s1[256], s2[256];
   double st = 0.0, xn = 0.0;
+  const double* yc = y + P.ni;
   for (int c = threadIdx.x; c < P.nc; c += blockDim.x) {
     const int rc = P.cam_red[c];
     for (int q = 0; q < 6; ++q) {
@@ -551,6 +680,27 @@ __global__ void k_cam_update(DevProblem P, const double* __restrict__ cam, const
       cand[6 * c + q] = xp;
     }
   }
+  if (cand_intr) {
+    for (int g = threadIdx.x; g < P.ng_total; g += blockDim.x) {
+      const int gr = P.grp_red ? P.grp_red[g] : -1;
+      double kk[THEIA_MAX_INTRINSICS];
+      for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) {
+        kk[q] = P.intr[(size_t)g * THEIA_MAX_INTRINSICS + q];
+        if (gr >= 0 && ((P.grp_free[g] >> q) & 1u)) kk[q] += (-y[10 * gr + q]) * P.scale_i[(size_t)g * THEIA_MAX_INTRINSICS + q];
+      }
+      if (gr >= 0) {
+        const int model = P.group_model[g];
+        if (kk[0] < 1.0) kk[0] = 1.0;
+        if (model == THEIA_CAM_DOUBLE_SPHERE) { kk[5] = fmin(1.0, fmax(-1.0, kk[5])); kk[6] = fmin(1.0, fmax(0.0, kk[6])); }
+        if (model == THEIA_CAM_EXTENDED_UNIFIED) { kk[5] = fmin(1.0, fmax(0.0, kk[5])); kk[6] = fmax(0.1, kk[6]); }
+      }
+      for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) {
+        const double x = P.intr[(size_t)g * THEIA_MAX_INTRINSICS + q];
+        cand_intr[(size_t)g * THEIA_MAX_INTRINSICS + q] = kk[q];
+        if (gr >= 0 && q < P.grp_k[g]) { st += (x - kk[q]) * (x - kk[q]); xn += kk[q] * kk[q]; }
+      }
+    }
+  }
   s1[threadIdx.x] = st; s2[threadIdx.x] = xn;
   __syncthreads();
   for (int s = blockDim.x / 2; s > 0; s >>= 1) {
@@ -562,7 +712,7 @@ __global__ void k_cam_update(DevProblem P, const double* __restrict__ cam, const
 
 // ------------------------------- back-substitution + candidate + trial cost
 // tile_part: [ntiles][5] = {cand_cost, mcc, stepsq, xnormsq, invalid}
-template <int PD>
+template <int PD, bool INTR>
 __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* __restrict__ cam,
                                                     const double* __restrict__ pts,
                                                     const double* __restrict__ cand_cam,
@@ -576,10 +726,10 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
   if (tile >= P.ntiles) return;
   const int cnt = P.tile_count[tile];
   const int start = P.tile_start[tile];
-  LaneLin<PD> L;
-  lane_linearize<PD, true>(P, cam, pts, start + lane, lane < cnt, lane, L);
+  LaneLin<PD, INTR> L;
+  lane_linearize<PD, true, INTR>(P, cam, pts, start + lane, lane < cnt, lane, L);
   const Segment sg = lane_segment(L.p, lane);
-  // m_c = F y_c
+  // m_c = F y_c   (yc points at the camera part; the intrinsics part sits ni before it)
   double mc[2] = {0.0, 0.0};
   if (L.active && L.rc >= 0) {
 #pragma unroll
@@ -587,6 +737,16 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
       const double yv = yc[6 * L.rc + q];
       mc[0] += L.Jc[q] * yv;
       mc[1] += L.Jc[6 + q] * yv;
+    }
+  }
+  if constexpr (INTR) {
+    if (L.active && L.gr >= 0) {
+      const double* yi = yc - P.ni + 10 * L.gr;
+#pragma unroll
+      for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) {
+        mc[0] += L.Jk[q] * yi[q];
+        mc[1] += L.Jk[THEIA_MAX_INTRINSICS + q] * yi[q];
+      }
     }
   }
   // t = E^T (r - F y_c), summed over the track
@@ -647,7 +807,8 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
     double six = 1.0, siy = 1.0;
     if (P.obs_si) { const double2 s = P.obs_si[start + lane]; six = s.x; siy = s.y; }
     ObsLin ol;
-    observe<false>(P.group_model[g], ext, P.intr + (size_t)g * THEIA_MAX_INTRINSICS, Xp, uv.x, uv.y, six, siy, ol);
+    const double* kc = (INTR ? P.intr_cand : P.intr) + (size_t)g * THEIA_MAX_INTRINSICS;
+    observe<false>(P.group_model[g], ext, kc, Xp, uv.x, uv.y, six, siy, ol);
     cvalid = ol.valid;
     double rho1;
     ccost = 0.5 * loss_eval(P.loss_type, P.loss_width, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
@@ -666,23 +827,27 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
 // ------------------------------------------------ introspection / cost only
 // residuals/Jacobians in SORTED observation order (host un-permutes).
 // tile_part: [ntiles][2] = {cost, invalid}
-template <int PD, bool WANT_JAC>
+template <int PD, bool WANT_JAC, bool INTR = false>
 __global__ __launch_bounds__(kBlock) void k_evaluate(DevProblem P, const double* __restrict__ cam,
                                                      const double* __restrict__ pts,
                                                      double* __restrict__ residuals,
                                                      double* __restrict__ jac_cam,
                                                      double* __restrict__ jac_pt,
                                                      uint8_t* __restrict__ valid,
-                                                     double* __restrict__ tile_part) {
+                                                     double* __restrict__ tile_part,
+                                                     double* __restrict__ jac_intr = nullptr) {
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (tile >= P.ntiles) return;
   const int cnt = P.tile_count[tile];
   const int start = P.tile_start[tile];
-  LaneLin<PD> L;
-  lane_linearize<PD, WANT_JAC>(P, cam, pts, start + lane, lane < cnt, lane, L);
+  LaneLin<PD, INTR> L;
+  lane_linearize<PD, WANT_JAC, INTR>(P, cam, pts, start + lane, lane < cnt, lane, L);
   if (L.active) {
     const size_t o = (size_t)start + lane;
+    if constexpr (INTR) {
+      if (jac_intr) for (int i = 0; i < 2 * THEIA_MAX_INTRINSICS; ++i) jac_intr[2 * THEIA_MAX_INTRINSICS * o + i] = L.Jk[i];
+    }
     if (residuals) { residuals[2 * o] = L.r[0]; residuals[2 * o + 1] = L.r[1]; }
     if (WANT_JAC) {
       if (jac_cam) for (int i = 0; i < 12; ++i) jac_cam[12 * o + i] = L.Jc[i];
@@ -905,10 +1070,21 @@ inline int tile_blocks(int ntiles) { return (ntiles + kWavesPerBlock - 1) / kWav
 
 // ------------------------------------------------------------------ launchers
 void launch_colnorm(const DevProblem& P, const double* cam, const double* pts, double* colsq_c,
-                    double* colsq_p, hipStream_t st) {
+                    double* colsq_p, double* colsq_i, hipStream_t st) {
   if (P.ntiles == 0) return;
-  if (P.pd == 3) k_colnorm<3><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_p);
-  else k_colnorm<4><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_p);
+  const int nb = tile_blocks(P.ntiles);
+  if (P.ni) {
+    if (P.pd == 3) k_colnorm<3, true><<<nb, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_p, colsq_i);
+    else k_colnorm<4, true><<<nb, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_p, colsq_i);
+  } else {
+    if (P.pd == 3) k_colnorm<3, false><<<nb, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_p, colsq_i);
+    else k_colnorm<4, false><<<nb, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_p, colsq_i);
+  }
+}
+
+void launch_build_scale_red(const DevProblem& P, double* scale_red, hipStream_t st) {
+  if (P.n == 0) return;
+  k_build_scale_red<<<1, 1024, 0, st>>>(P, scale_red);
 }
 
 void launch_make_scale(int count, const double* colsq, double* scale, hipStream_t st) {
@@ -919,10 +1095,20 @@ void launch_make_scale(int count, const double* colsq, double* scale, hipStream_
 void launch_linearize(const DevProblem& P, const double* cam, const double* pts, double radius,
                       const ReduceBuf& rb, double* Vinv, double* gp, double* tile_part, hipStream_t st) {
   if (P.ntiles == 0) return;
-  if (P.pd == 3)
-    k_linearize<3><<<P.nwg, kBlock, 0, st>>>(P, cam, pts, radius, rb.S, rb.rhs, rb.colsq, rb.gc, Vinv, gp, tile_part);
-  else
-    k_linearize<4><<<P.nwg, kBlock, 0, st>>>(P, cam, pts, radius, rb.S, rb.rhs, rb.colsq, rb.gc, Vinv, gp, tile_part);
+  // camera part of the reduced system: shifted by the intrinsics slots
+  double* Sc = rb.S + (size_t)P.ni * P.n + P.ni;
+  double* rhs_c = rb.rhs + P.ni; double* colsq_c = rb.colsq + P.ni; double* gc_c = rb.gc + P.ni;
+  if (P.ni) {
+    if (P.pd == 3)
+      k_linearize<3, true><<<P.nwg, 128, 0, st>>>(P, cam, pts, radius, Sc, rhs_c, colsq_c, gc_c, Vinv, gp, tile_part, rb.S, rb.rhs, rb.colsq, rb.gc);
+    else
+      k_linearize<4, true><<<P.nwg, 128, 0, st>>>(P, cam, pts, radius, Sc, rhs_c, colsq_c, gc_c, Vinv, gp, tile_part, rb.S, rb.rhs, rb.colsq, rb.gc);
+  } else {
+    if (P.pd == 3)
+      k_linearize<3, false><<<P.nwg, kBlock, 0, st>>>(P, cam, pts, radius, Sc, rhs_c, colsq_c, gc_c, Vinv, gp, tile_part, rb.S, rb.rhs, rb.colsq, rb.gc);
+    else
+      k_linearize<4, false><<<P.nwg, kBlock, 0, st>>>(P, cam, pts, radius, Sc, rhs_c, colsq_c, gc_c, Vinv, gp, tile_part, rb.S, rb.rhs, rb.colsq, rb.gc);
+  }
 }
 
 void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,
@@ -934,9 +1120,9 @@ void launch_finalize_rcs(const DevProblem& P, double radius, const ReduceBuf& rb
   k_finalize_rcs<<<1, 256, 0, st>>>(P, radius, rb.S, rb.colsq, rb.gc, rb.scal);
 }
 
-void launch_cam_update(const DevProblem& P, const double* cam, const double* yc, double* cand_cam,
-                       double* out_stepsq, double* out_xnormsq, hipStream_t st) {
-  k_cam_update<<<1, 256, 0, st>>>(P, cam, yc, cand_cam, out_stepsq, out_xnormsq);
+void launch_cam_update(const DevProblem& P, const double* cam, const double* y, double* cand_cam,
+                       double* cand_intr, double* out_stepsq, double* out_xnormsq, hipStream_t st) {
+  k_cam_update<<<1, 256, 0, st>>>(P, cam, y, cand_cam, cand_intr, out_stepsq, out_xnormsq);
 }
 
 void launch_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,
@@ -944,15 +1130,24 @@ void launch_backsub(const DevProblem& P, const double* cam, const double* pts, c
                     double* scal, hipStream_t st) {
   (void)scal;
   if (P.ntiles == 0) return;
-  if (P.pd == 3)
-    k_backsub<3><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, yc, Vinv, tile_part);
-  else
-    k_backsub<4><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, yc, Vinv, tile_part);
+  const double* ycc = yc + P.ni;  // camera part of the solution
+  if (P.ni) {
+    if (P.pd == 3) k_backsub<3, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
+    else k_backsub<4, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
+  } else {
+    if (P.pd == 3) k_backsub<3, false><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
+    else k_backsub<4, false><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
+  }
 }
 
 void launch_evaluate(const DevProblem& P, const double* cam, const double* pts, double* residuals,
-                     double* jac_cam, double* jac_pt, uint8_t* valid, double* tile_part, hipStream_t st) {
+                     double* jac_cam, double* jac_pt, uint8_t* valid, double* tile_part, hipStream_t st, double* jac_intr) {
   if (P.ntiles == 0) return;
+  if (P.ni) {
+    if (P.pd == 3) k_evaluate<3, true, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, residuals, jac_cam, jac_pt, valid, tile_part, jac_intr);
+    else k_evaluate<4, true, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, residuals, jac_cam, jac_pt, valid, tile_part, jac_intr);
+    return;
+  }
   if (P.pd == 3)
     k_evaluate<3, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, residuals, jac_cam, jac_pt, valid, tile_part);
   else

@@ -88,10 +88,15 @@ struct theia_ba_handle_s {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   // host-side bookkeeping
   std::vector<int64_t> perm;       // sorted obs index -> original obs index
-  std::vector<int> cam_red;
+  std::vector<int> cam_red, grp_red, grp_k;
+  std::vector<unsigned> grp_free;
   std::vector<uint8_t> cam_mask, pt_const;
+  int ni = 0, ngv = 0;
   // device buffers
-  DevBuf<double> cam[2], pts[2], intr, scale_c, scale_p, ones_c, ones_p, colsq_c0, colsq_p0;
+  DevBuf<double> cam[2], pts[2], intr[2], scale_c, scale_p, ones_c, ones_p, colsq_c0, colsq_p0;
+  DevBuf<double> scale_i, ones_i, colsq_i0, scale_red;
+  DevBuf<int> d_grp_red, d_grp_k;
+  DevBuf<unsigned> d_grp_free;
   DevBuf<int> group_model, cam_group, d_cam_red, obs_cam, obs_pt, tile_start, tile_count, f2s, fmaxflag, wg_base;
   int tiles_per_wg = 4, nwg = 0;
   DevBuf<uint8_t> d_cam_mask, d_pt_const;
@@ -116,6 +121,38 @@ struct theia_ba_handle_s {
 
 namespace {
 
+// Free intrinsics of a model under an OptimizeIntrinsicsType mask
+// (GetSubsetFromOptimizeIntrinsicsType of every *_camera_model.cc, e.g.
+// pinhole_camera_model.cc:132-162): bit q = parameter q is optimised.
+unsigned intrinsics_free_mask(int model, int opt) {
+  const bool noskew = (model == THEIA_CAM_FOV || model == THEIA_CAM_DIVISION_UNDISTORTION);
+  unsigned m = 0;
+  if (opt & THEIA_INTR_FOCAL_LENGTH) m |= 1u << 0;
+  if (opt & THEIA_INTR_ASPECT_RATIO) m |= 1u << 1;
+  if ((opt & THEIA_INTR_SKEW) && !noskew) m |= 1u << 2;
+  if (opt & THEIA_INTR_PRINCIPAL_POINTS) m |= noskew ? (3u << 2) : (3u << 3);
+  if (opt & THEIA_INTR_RADIAL_DISTORTION) {
+    switch (model) {
+      case THEIA_CAM_PINHOLE: case THEIA_CAM_DOUBLE_SPHERE: case THEIA_CAM_EXTENDED_UNIFIED: case THEIA_CAM_ORTHOGRAPHIC: m |= 3u << 5; break;
+      case THEIA_CAM_PINHOLE_RADIAL_TANGENTIAL: m |= 7u << 5; break;
+      case THEIA_CAM_FISHEYE: m |= 15u << 5; break;
+      case THEIA_CAM_FOV: case THEIA_CAM_DIVISION_UNDISTORTION: m |= 1u << 4; break;
+    }
+  }
+  if ((opt & THEIA_INTR_TANGENTIAL_DISTORTION) && model == THEIA_CAM_PINHOLE_RADIAL_TANGENTIAL) m |= 3u << 8;
+  return m;
+}
+int intrinsics_size(int model) {
+  static const int K[8] = {7, 10, 9, 5, 5, 7, 7, 7};  // kIntrinsicsSize of the eight models
+  return (model >= 0 && model < 8) ? K[model] : 0;
+}
+// bundle_adjuster.cc:406-427 parameter bounds (applied to the initial point as Ceres does)
+void project_intrinsics_to_bounds(int model, double* k) {
+  if (k[0] < 1.0) k[0] = 1.0;
+  if (model == THEIA_CAM_DOUBLE_SPHERE) { k[5] = std::min(1.0, std::max(-1.0, k[5])); k[6] = std::min(1.0, std::max(0.0, k[6])); }
+  if (model == THEIA_CAM_EXTENDED_UNIFIED) { k[5] = std::min(1.0, std::max(0.0, k[5])); k[6] = std::max(0.1, k[6]); }
+}
+
 enum { SB_COST = 0, SB_MCC = 1, SB_STEPSQ = 2, SB_XNORMSQ = 3, SB_INVALID = 4, SB_STEPSQ_CAM = 8, SB_XNORMSQ_CAM = 9 };
 
 int supported_model(int m) { return m >= THEIA_CAM_PINHOLE && m <= THEIA_CAM_ORTHOGRAPHIC; }
@@ -138,8 +175,8 @@ int validate(const theia_ba_problem* p, const theia_ba_options* o) {
     if (p->obs_cam[i] < 0 || p->obs_cam[i] >= p->num_cameras || p->obs_pt[i] < 0 || p->obs_pt[i] >= p->num_points)
       return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "observation %lld indexes out of range", (long long)i);
   }
-  if (o->intrinsics_to_optimize != THEIA_INTR_NONE)
-    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "intrinsics_to_optimize != NONE is not built yet (DESIGN.md scope)");
+  if (o->intrinsics_to_optimize < 0 || o->intrinsics_to_optimize > THEIA_INTR_ALL)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "invalid intrinsics_to_optimize bit mask");
   if (o->loss_function_type < 0 || o->loss_function_type > THEIA_LOSS_TRUNCATED)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "invalid loss function type");  // reference: LOG(FATAL)
   return 0;
@@ -149,7 +186,10 @@ void fill_devproblem(theia_ba_handle_s* h) {
   DevProblem& P = h->P;
   P.nc = h->nc; P.np = h->np; P.ncv = h->ncv; P.ntiles = h->ntiles_main; P.nobs = h->nobs_main;
   P.n = h->n; P.pd = h->pd; P.loss_type = h->opt.loss_function_type; P.loss_width = h->opt.robust_loss_width;
-  P.intr = h->intr.p; P.group_model = h->group_model.p; P.cam_group = h->cam_group.p;
+  P.intr = h->intr[h->cur].p; P.intr_cand = h->intr[1 - h->cur].p;
+  P.group_model = h->group_model.p; P.cam_group = h->cam_group.p;
+  P.ni = h->ni; P.ng_total = h->ng; P.grp_red = h->d_grp_red.p; P.grp_free = h->d_grp_free.p; P.grp_k = h->d_grp_k.p;
+  P.scale_i = h->scale_i.p; P.scale_red = h->scale_red.p;
   P.cam_red = h->d_cam_red.p; P.cam_mask = h->d_cam_mask.p; P.pt_const = h->d_pt_const.p;
   P.obs_uv = h->obs_uv.p; P.obs_si = h->obs_si.p; P.obs_cam = h->obs_cam.p; P.obs_pt = h->obs_pt.p;
   P.tile_start = h->tile_start.p; P.tile_count = h->tile_count.p;
@@ -166,9 +206,15 @@ int upload_parameters(theia_ba_handle_s* h, const theia_ba_problem* p) {
     if (h->nc) HIP_TRY(hipMemcpyAsync(h->cam[k].p, p->cam_ext, sizeof(double) * 6 * h->nc, hipMemcpyHostToDevice, h->stream));
     if (h->np) HIP_TRY(hipMemcpyAsync(h->pts[k].p, p->points, sizeof(double) * 4 * h->np, hipMemcpyHostToDevice, h->stream));
   }
-  if (h->ng) HIP_TRY(hipMemcpyAsync(h->intr.p, p->intrinsics, sizeof(double) * THEIA_MAX_INTRINSICS * h->ng, hipMemcpyHostToDevice, h->stream));
+  if (h->ng) {
+    std::vector<double> hk(p->intrinsics, p->intrinsics + (size_t)THEIA_MAX_INTRINSICS * h->ng);
+    for (int g = 0; g < h->ng; ++g) if (h->grp_red[g] >= 0) project_intrinsics_to_bounds(p->group_model[g], &hk[(size_t)g * THEIA_MAX_INTRINSICS]);
+    for (int k = 0; k < 2; ++k)
+      HIP_TRY(hipMemcpy(h->intr[k].p, hk.data(), sizeof(double) * hk.size(), hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->cur = 0;
+  h->P.intr = h->intr[0].p; h->P.intr_cand = h->intr[1].p;
   h->have_scale = false;
   return 0;
 }
@@ -213,18 +259,25 @@ int compute_scale(theia_ba_handle_s* h) {
   Q.scale_c = h->ones_c.p; Q.scale_p = h->ones_p.p;
   if (h->colsq_c0.n) HIP_TRY(hipMemsetAsync(h->colsq_c0.p, 0, sizeof(double) * h->colsq_c0.n, h->stream));
   if (h->colsq_p0.n) HIP_TRY(hipMemsetAsync(h->colsq_p0.p, 0, sizeof(double) * h->colsq_p0.n, h->stream));
-  launch_colnorm(Q, h->cam[h->cur].p, h->pts[h->cur].p, h->colsq_c0.p, h->colsq_p0.p, h->stream);
+  if (h->colsq_i0.n) HIP_TRY(hipMemsetAsync(h->colsq_i0.p, 0, sizeof(double) * h->colsq_i0.n, h->stream));
+  Q.scale_i = h->ones_i.p;
+  Q.intr = h->intr[h->cur].p;
+  launch_colnorm(Q, h->cam[h->cur].p, h->pts[h->cur].p, h->colsq_c0.p, h->colsq_p0.p, h->colsq_i0.p, h->stream);
   launch_long_colnorm(Q, h->cam[h->cur].p, h->pts[h->cur].p, h->colsq_c0.p, h->colsq_p0.p, h->long_scratch.p, h->stream);
   int rc = do_allreduce(h, h->colsq_c0.p, h->colsq_c0.n, THEIA_REDUCE_SUM);
+  if (!rc && h->ni) rc = do_allreduce(h, h->colsq_i0.p, h->colsq_i0.n, THEIA_REDUCE_SUM);
   if (rc) return rc;
   launch_make_scale((int)h->colsq_c0.n, h->colsq_c0.p, h->scale_c.p, h->stream);
   launch_make_scale((int)h->colsq_p0.n, h->colsq_p0.p, h->scale_p.p, h->stream);
+  launch_make_scale((int)h->colsq_i0.n, h->colsq_i0.p, h->scale_i.p, h->stream);
+  launch_build_scale_red(h->P, h->scale_red.p, h->stream);
   h->have_scale = true;
   return 0;
 }
 
 // enqueue: clear, linearize + Schur, tile reduction, (all-reduce), LM diagonal.
 int enqueue_linearize(theia_ba_handle_s* h, double radius) {
+  h->P.intr = h->intr[h->cur].p; h->P.intr_cand = h->intr[1 - h->cur].p;
   HIP_TRY(hipMemsetAsync(h->reduce.p, 0, sizeof(double) * h->reduce.n, h->stream));
   HIP_TRY(hipEventRecord(h->ev[4], h->stream));
   launch_linearize(h->P, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->tile_part.p, h->stream);
@@ -246,7 +299,8 @@ int enqueue_solve_and_backsub(theia_ba_handle_s* h) {
   HIP_TRY(hipEventRecord(h->ev[2], h->stream));
   HIP_TRY(hipMemsetAsync(h->scalB.p, 0, sizeof(double) * 16, h->stream));
   const int nxt = 1 - h->cur;
-  launch_cam_update(h->P, h->cam[h->cur].p, yc, h->cam[nxt].p, h->scalB.p + SB_STEPSQ_CAM, h->scalB.p + SB_XNORMSQ_CAM, h->stream);
+  launch_cam_update(h->P, h->cam[h->cur].p, yc, h->cam[nxt].p, h->ni ? h->intr[nxt].p : nullptr,
+                    h->scalB.p + SB_STEPSQ_CAM, h->scalB.p + SB_XNORMSQ_CAM, h->stream);
   launch_backsub(h->P, h->cam[h->cur].p, h->pts[h->cur].p, h->cam[nxt].p, h->pts[nxt].p, yc, h->Vinv.p, h->tile_part.p, h->scalB.p, h->stream);
   if (h->ntiles_main) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 5, h->f2s.p + 8, h->fmaxflag.p + 8, h->scalB.p, h->stream);
   launch_long_backsub(h->P, h->cam[h->cur].p, h->pts[h->cur].p, h->cam[nxt].p, h->pts[nxt].p, yc, h->Vinv.p, h->long_scratch.p, h->scalB.p, h->stream);
@@ -314,7 +368,21 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     if (m & THEIA_CAM_CONST_TZ) cols |= 0x04;
     if (cols != 0x3f && (cam_used[c] || (p->flags & THEIA_BA_FLAG_KEEP_UNOBSERVED_CAMERAS))) { h->cam_red[c] = h->ncv++; h->cam_mask[c] = (uint8_t)cols; }
   }
-  h->n = 6 * h->ncv;
+  // intrinsics blocks (bundle_adjuster.cc:382-460): constant when nothing is optimised
+  // or the caller marked the group constant, otherwise a subset manifold
+  std::vector<uint8_t> grp_used(h->ng, 0);
+  for (int64_t i = 0; i < h->nobs; ++i) grp_used[p->cam_group[p->obs_cam[i]]] = 1;
+  h->grp_red.assign(h->ng, -1); h->grp_free.assign(h->ng, 0u); h->grp_k.assign(h->ng, 0);
+  h->ngv = 0;
+  for (int g = 0; g < h->ng; ++g) {
+    h->grp_k[g] = intrinsics_size(p->group_model[g]);
+    const unsigned fm = intrinsics_free_mask(p->group_model[g], o->intrinsics_to_optimize);
+    const bool gconst = (p->group_const && p->group_const[g]) || fm == 0 ||
+                        (!grp_used[g] && !(p->flags & THEIA_BA_FLAG_KEEP_UNOBSERVED_CAMERAS));
+    if (!gconst) { h->grp_red[g] = h->ngv++; h->grp_free[g] = fm; }
+  }
+  h->ni = THEIA_MAX_INTRINSICS * h->ngv;
+  h->n = h->ni + 6 * h->ncv;
   for (int q = 0; q < h->np; ++q) h->pt_const[q] = ((p->point_const && p->point_const[q]) || !pt_used[q]) ? 1 : 0;
 
   // Tracks are visited in the order of their first (lowest) variable camera of
@@ -326,7 +394,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   std::vector<int> pkey(h->np, std::numeric_limits<int>::max());
   for (int64_t i = 0; i < h->nobs; ++i) {
     const int rc = h->cam_red[p->obs_cam[i]];
-    fixed[i] = (rc < 0 && h->pt_const[p->obs_pt[i]]) ? 1 : 0;
+    fixed[i] = (rc < 0 && h->grp_red[p->cam_group[p->obs_cam[i]]] < 0 && h->pt_const[p->obs_pt[i]]) ? 1 : 0;
     if (rc >= 0 && rc < pkey[p->obs_pt[i]]) pkey[p->obs_pt[i]] = rc;
   }
   std::vector<int> porder(h->np), prank(h->np);
@@ -423,8 +491,15 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   UP(d_cam_red, h->cam_red); UP(d_cam_mask, h->cam_mask); UP(d_pt_const, h->pt_const);
   std::vector<int> gm(p->group_model, p->group_model + h->ng), cg(p->cam_group, p->cam_group + h->nc);
   UP(group_model, gm); UP(cam_group, cg);
-  for (int k = 0; k < 2; ++k) { AL(cam[k], (size_t)6 * h->nc); AL(pts[k], (size_t)4 * h->np); }
-  AL(intr, (size_t)THEIA_MAX_INTRINSICS * h->ng);
+  for (int k = 0; k < 2; ++k) { AL(cam[k], (size_t)6 * h->nc); AL(pts[k], (size_t)4 * h->np); AL(intr[k], (size_t)THEIA_MAX_INTRINSICS * h->ng); }
+  UP(d_grp_red, h->grp_red); UP(d_grp_free, h->grp_free); UP(d_grp_k, h->grp_k);
+  {
+    std::vector<double> ones_i((size_t)THEIA_MAX_INTRINSICS * h->ng, 1.0);
+    UP(ones_i, ones_i); UP(scale_i, ones_i);
+  }
+  AL(colsq_i0, (size_t)THEIA_MAX_INTRINSICS * h->ng); AL(scale_red, (size_t)std::max(1, h->n));
+  if (h->ni && h->long_ntracks)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "intrinsics optimisation together with tracks of more than 64 observations is not built yet");
   std::vector<double> ones_c((size_t)6 * h->nc, 1.0), ones_p((size_t)h->pd * h->np, 1.0);
   UP(ones_c, ones_c); UP(ones_p, ones_p); UP(scale_c, ones_c); UP(scale_p, ones_p);
   AL(colsq_c0, (size_t)6 * h->nc); AL(colsq_p0, (size_t)h->pd * h->np);
@@ -488,6 +563,7 @@ int theia_hip_ba_download(theia_ba_handle h, theia_ba_problem* p) {
   if (!h || !p) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (h->nc) HIP_TRY(hipMemcpyAsync(p->cam_ext, h->cam[h->cur].p, sizeof(double) * 6 * h->nc, hipMemcpyDeviceToHost, h->stream));
   if (h->np) HIP_TRY(hipMemcpyAsync(p->points, h->pts[h->cur].p, sizeof(double) * 4 * h->np, hipMemcpyDeviceToHost, h->stream));
+  if (h->ng && h->ni) HIP_TRY(hipMemcpyAsync(p->intrinsics, h->intr[h->cur].p, sizeof(double) * THEIA_MAX_INTRINSICS * h->ng, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -521,6 +597,12 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
     if (h->np) HIP_TRY(hipMemcpyAsync(hp.data(), h->pts[h->cur].p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     double s = 0.0;
+    if (h->ni) {
+      std::vector<double> hk((size_t)THEIA_MAX_INTRINSICS * h->ng);
+      HIP_TRY(hipMemcpy(hk.data(), h->intr[h->cur].p, sizeof(double) * hk.size(), hipMemcpyDeviceToHost));
+      for (int g = 0; g < h->ng; ++g) if (h->grp_red[g] >= 0)
+        for (int q = 0; q < h->grp_k[g]; ++q) s += hk[(size_t)g * THEIA_MAX_INTRINSICS + q] * hk[(size_t)g * THEIA_MAX_INTRINSICS + q];
+    }
     for (int c = 0; c < h->nc; ++c) if (h->cam_red[c] >= 0) for (int q = 0; q < 6; ++q) s += hc[6 * c + q] * hc[6 * c + q];
     double sp = 0.0;
     for (int p = 0; p < h->np; ++p) if (!h->pt_const[p]) for (int q = 0; q < 4; ++q) sp += hp[4 * (size_t)p + q] * hp[4 * (size_t)p + q];
@@ -651,17 +733,25 @@ int theia_hip_ba_solve(const theia_ba_problem* problem, const theia_ba_options* 
 }
 
 int theia_hip_ba_evaluate(theia_ba_handle h, double* cost, double* residuals, double* jac_cam, double* jac_pt, uint8_t* valid) {
+  return theia_hip_ba_evaluate_ex(h, cost, residuals, jac_cam, jac_pt, nullptr, valid);
+}
+
+int theia_hip_ba_evaluate_ex(theia_ba_handle h, double* cost, double* residuals, double* jac_cam, double* jac_pt,
+                             double* jac_intr, uint8_t* valid) {
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
   const int pd = h->pd;
-  DevBuf<double> dr, djc, djp; DevBuf<uint8_t> dv;
+  DevBuf<double> dr, djc, djp, dji; DevBuf<uint8_t> dv;
   int rc;
   const size_t nm = (size_t)h->nobs_main;
   if ((rc = dr.alloc(2 * nm)) || (rc = djc.alloc(12 * nm)) || (rc = djp.alloc(2 * pd * nm)) || (rc = dv.alloc(nm))) return rc;
+  const bool want_ji = jac_intr && h->ni;
+  if (want_ji && (rc = dji.alloc(20 * nm))) return rc;
   DevProblem Q = h->P;
   Q.scale_c = h->ones_c.p; Q.scale_p = h->ones_p.p;
   Q.ntiles = h->ntiles_eval;
+  Q.scale_i = h->ones_i.p; Q.intr = h->intr[h->cur].p;
   HIP_TRY(hipMemsetAsync(h->scalB.p, 0, sizeof(double) * 16, h->stream));
-  launch_evaluate(Q, h->cam[h->cur].p, h->pts[h->cur].p, dr.p, djc.p, djp.p, dv.p, h->tile_part.p, h->stream);
+  launch_evaluate(Q, h->cam[h->cur].p, h->pts[h->cur].p, dr.p, djc.p, djp.p, dv.p, h->tile_part.p, h->stream, want_ji ? dji.p : nullptr);
   if (h->ntiles_eval) launch_reduce_tiles(h->ntiles_eval, h->tile_part.p, 2, h->f2s.p + 16, h->fmaxflag.p + 16, h->scalB.p, h->stream);
   std::vector<double> hr(2 * nm), hjc(12 * nm), hjp(2 * pd * nm); std::vector<uint8_t> hv(nm);
   if (nm) {
@@ -670,9 +760,13 @@ int theia_hip_ba_evaluate(theia_ba_handle h, double* cost, double* residuals, do
     HIP_TRY(hipMemcpyAsync(hjp.data(), djp.p, sizeof(double) * hjp.size(), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(hv.data(), dv.p, hv.size(), hipMemcpyDeviceToHost, h->stream));
   }
+  std::vector<double> hji;
+  if (want_ji && nm) { hji.resize(20 * nm); HIP_TRY(hipMemcpyAsync(hji.data(), dji.p, sizeof(double) * hji.size(), hipMemcpyDeviceToHost, h->stream)); }
   HIP_TRY(hipMemcpyAsync(h->h_scal + 16, h->scalB.p, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (cost) *cost = h->h_scal[16 + SB_COST] + h->fixed_cost;
+  if (jac_intr) std::fill(jac_intr, jac_intr + 20 * h->nobs, 0.0);
+  if (want_ji) for (size_t s2 = 0; s2 < nm; ++s2) std::copy(&hji[20 * s2], &hji[20 * s2] + 20, jac_intr + 20 * h->perm[s2]);
   if (residuals) std::fill(residuals, residuals + 2 * h->nobs, 0.0);
   if (jac_cam) std::fill(jac_cam, jac_cam + 12 * h->nobs, 0.0);
   if (jac_pt) std::fill(jac_pt, jac_pt + 2 * pd * h->nobs, 0.0);

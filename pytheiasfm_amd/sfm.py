@@ -211,13 +211,18 @@ def _flatten(recon, view_ids, track_ids, const_view_ids=()):
     if len(const_view_ids):
         cam_const[np.asarray(list(const_view_ids), dtype=np.int64)] = capi_const_all()
     point_const = (~track_added).astype(np.uint8)  # SetTrackConstant (:149) unless AddTrack'ed
+    # an intrinsics group is optimised iff one of its views went through AddView
+    # (:130-133); groups reached only through AddTrack stay constant (:442-455)
+    group_const = np.ones(recon.group_intrinsics.shape[0], dtype=np.uint8)
+    group_const[recon.view_group[view_added]] = 0
     sqrt_info = None
     cov = recon.obs_cov[keep]
     if len(cov) and not np.all(cov == 1.0):
         sqrt_info = 1.0 / np.sqrt(cov)
     return capi.FlatProblem(recon.cam_ext.copy(), recon.group_intrinsics.copy(), recon.group_model,
                             recon.view_group, recon.points.copy(), recon.obs_uv[keep], ov[keep], ot[keep],
-                            cam_const=cam_const, point_const=point_const, obs_sqrt_info=sqrt_info)
+                            cam_const=cam_const, group_const=group_const, point_const=point_const,
+                            obs_sqrt_info=sqrt_info)
 
 
 def capi_const_all():
@@ -248,6 +253,7 @@ def _run(options, recon, flat):
     s, _ = _ba.solve(flat, options.to_c())
     recon.cam_ext[:] = flat.cam_ext
     recon.points[:] = flat.points
+    recon.group_intrinsics[:] = flat.intrinsics   # shared CameraIntrinsicsModel parameters (:388-389)
     return BundleAdjustmentSummary(s)
 
 

@@ -75,11 +75,27 @@ def evaluate(problem, options):
     return ok, cost.value, r, jc, jp
 
 
+def evaluate_ex(problem, options):
+    """evaluate() plus the Jet intrinsics Jacobian J_intr[nobs][2][10]."""
+    L = load()
+    dp = capi.c_double_p
+    L.oracle_ba_evaluate_ex.argtypes = [C.POINTER(capi.BaProblem), C.POINTER(capi.BaOptions), dp, dp, dp, dp, dp]
+    pd = 3 if options.use_homogeneous_point_parametrization else 4
+    n = problem.obs_uv.shape[0]
+    cost = C.c_double(0)
+    r = np.zeros((n, 2)); jc = np.zeros((n, 2, 6)); jp = np.zeros((n, 2, pd)); ji = np.zeros((n, 2, 10))
+    st = problem.as_struct()
+    ok = L.oracle_ba_evaluate_ex(C.byref(st), C.byref(options), C.byref(cost), capi.ptr(r, C.c_double),
+                                 capi.ptr(jc, C.c_double), capi.ptr(jp, C.c_double), capi.ptr(ji, C.c_double))
+    return ok, cost.value, r, jc, jp, ji
+
+
 def reduced_system(problem, options, radius):
     L = load()
     ncam = problem.cam_ext.shape[0]
-    cap = (6 * ncam) ** 2
-    S = np.zeros(cap); rhs = np.zeros(6 * ncam); n = C.c_int32(0)
+    nmax = 6 * ncam + 10 * problem.intrinsics.shape[0]
+    cap = nmax ** 2
+    S = np.zeros(cap); rhs = np.zeros(nmax); n = C.c_int32(0)
     st = problem.as_struct()
     rc = L.oracle_ba_reduced_system(C.byref(st), C.byref(options), radius, C.byref(n), capi.ptr(S, C.c_double),
                                     capi.ptr(rhs, C.c_double), cap)

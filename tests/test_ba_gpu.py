@@ -146,6 +146,22 @@ def test_mirror_entry_points_partial_reconstruction():
     assert s3.success
 
 
+def test_mirror_partial_reconstruction_optimises_only_added_groups():
+    """AddView marks the view's intrinsics group optimised (bundle_adjuster.cc:130-133);
+    groups reached only through AddTrack stay constant (:442-455)."""
+    p = synth.synth_ba_v1(12, 400, seed=62, num_groups=4)
+    rec = sfm.Reconstruction.from_flat(p)
+    k0 = rec.group_intrinsics.copy()
+    opts = sfm.BundleAdjustmentOptions()
+    opts.intrinsics_to_optimize = sfm.OptimizeIntrinsicsType.FOCAL_LENGTH | sfm.OptimizeIntrinsicsType.RADIAL_DISTORTION
+    views = [v for v in range(12) if rec.view_group[v] in (0, 2)]
+    summ = sfm.BundleAdjustPartialReconstruction(opts, views, list(range(400)), rec)
+    assert summ.success and summ.final_cost < summ.initial_cost
+    assert np.array_equal(rec.group_intrinsics[[1, 3]], k0[[1, 3]])
+    assert not np.array_equal(rec.group_intrinsics[[0, 2], 0], k0[[0, 2], 0])
+    assert np.array_equal(rec.group_intrinsics[:, 1:5], k0[:, 1:5])
+
+
 def test_edge_cases_empty_invalid_and_errors():
     o = ba.default_options()
     empty = capi.FlatProblem(np.zeros((0, 6)), np.zeros((1, 7)), [0], np.zeros(0, np.int32), np.zeros((0, 4)),
@@ -162,7 +178,7 @@ def test_edge_cases_empty_invalid_and_errors():
     bad = synth.synth_ba_v1(4, 20, seed=72); bad.obs_cam[0] = 99
     with pytest.raises(capi.TheiaHipError):
         ba.solve(bad, o)
-    o2 = ba.default_options(); o2.intrinsics_to_optimize = 1
+    o2 = ba.default_options(); o2.intrinsics_to_optimize = 0x40   # not an OptimizeIntrinsicsType bit
     with pytest.raises(capi.TheiaHipError):
         ba.solve(synth.synth_ba_v1(4, 20, seed=73), o2)
     unknown = synth.synth_ba_v1(4, 20, seed=74); unknown.group_model[:] = 9
@@ -284,3 +300,71 @@ def test_long_tracks_slow_path_matches_oracle(manifold):
     assert s.success and s.num_iterations == so.num_iterations and np.array_equal(tr.accepted, tro.accepted)
     assert rel(tr.cost, tro.cost) <= 1e-9
     assert np.abs(pg.cam_ext - po.cam_ext).max() <= 1e-7 and np.abs(pg.points - po.points).max() <= 1e-7
+
+
+INTR_ALL = 0x3f
+INTR_FOCAL_RADIAL = 0x11   # pipeline default (reconstruction_estimator_options.h:281-283)
+
+
+@pytest.mark.parametrize("model", sorted(CAMERA_MODEL_INTRINSICS))
+def test_intrinsics_jacobian_matches_jet_oracle(model):
+    """A10: d residual / d intrinsics (all K parameters free) of every camera
+    model, closed form vs Jets, and the reduced system with intrinsics blocks."""
+    p = synth.synth_ba_v1(10, 300, seed=400 + model, num_groups=3)
+    k = CAMERA_MODEL_INTRINSICS[model]
+    p.group_model[:] = model
+    p.intrinsics[:] = 0.0
+    p.intrinsics[:, : len(k)] = k
+    if model == 3:
+        p.intrinsics[1, 4] = 5e-4
+    o, oo = both_options(intrinsics_to_optimize=INTR_ALL)
+    with ba.BaHandle(p.copy(), o) as h:
+        cost, r, jc, jp, ji, valid = h.evaluate_ex()
+        S, rhs = h.reduced_system(1e4)
+    ok, ocost, orr, ojc, ojp, oji = ol.evaluate_ex(p, oo)
+    assert abs(cost - ocost) <= 1e-12 * ocost
+    assert rel(jc, ojc) <= 1e-11 and rel(jp, ojp) <= 1e-11
+    assert np.abs(oji).max() > 0
+    for q in range(10):   # per parameter: columns have very different magnitudes
+        sc = np.abs(oji[:, :, q]).max()
+        assert np.abs(ji[:, :, q] - oji[:, :, q]).max() <= 1e-10 * max(sc, 1e-300), (model, q)
+    So, ro = ol.reduced_system(p, oo, 1e4)
+    assert S.shape == So.shape == (30 + 60, 30 + 60)
+    assert rel(S, So) <= 1e-9 and rel(rhs, ro) <= 1e-9
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_intrinsics_optimisation_lm_parity_and_recovery(mixed):
+    """LM with FOCAL_LENGTH | RADIAL_DISTORTION free (shared intrinsics groups):
+    same trajectory as the oracle, and the perturbed focal lengths move back
+    towards the truth on a gauge-fixed scene."""
+    p = synth.synth_ba_v1(24, 1500, seed=431, num_groups=4, mixed_models=mixed, fix_gauge=True, pixel_noise=0.2)
+    truth = p.intrinsics.copy()
+    p.intrinsics[:, 0] *= 1.02
+    o, oo = both_options(intrinsics_to_optimize=INTR_FOCAL_RADIAL, max_num_iterations=30)
+    pg, po = p.copy(), p.copy()
+    s, tr = ba.solve(pg, o)
+    so, tro = ol.solve(po, oo)
+    assert s.success and so.success and s.num_iterations == so.num_iterations
+    assert np.array_equal(tr.accepted, tro.accepted)
+    fin = tro.cost < 1e300
+    assert rel(tr.cost[fin], tro.cost[fin]) <= 1e-8
+    assert rel(pg.intrinsics, po.intrinsics) <= 1e-7 and np.abs(pg.cam_ext - po.cam_ext).max() <= 1e-6
+    if not mixed:   # with fisheye-type models focal trades against the distortion terms
+        assert np.abs(pg.intrinsics[:, 0] / truth[:, 0] - 1.0).max() < 2e-3  # focal recovered (was 2 % off)
+    assert s.final_cost < 0.05 * s.initial_cost
+    assert np.array_equal(pg.intrinsics[:, 1:5], p.intrinsics[:, 1:5])        # aspect, skew, principal point frozen
+    assert not np.array_equal(pg.intrinsics[:, 5:7], p.intrinsics[:, 5:7])    # distortion optimised
+
+
+def test_intrinsics_group_constant_and_bounds():
+    p = synth.synth_ba_v1(12, 400, seed=441, num_groups=3, mixed_models=True)
+    p.group_const = np.array([0, 1, 0], np.uint8)
+    p.intrinsics[1, 6] = 1.7     # double-sphere alpha outside [0, 1]; group constant -> untouched
+    o, oo = both_options(intrinsics_to_optimize=INTR_ALL, max_num_iterations=8)
+    pg, po = p.copy(), p.copy()
+    s, _ = ba.solve(pg, o)
+    so, _ = ol.solve(po, oo)
+    assert s.num_iterations == so.num_iterations and abs(s.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    assert np.array_equal(pg.intrinsics[1], p.intrinsics[1])
+    assert pg.intrinsics[0, 0] >= 1.0 and rel(pg.intrinsics, po.intrinsics) <= 1e-7

@@ -44,6 +44,8 @@ def test_flatten_matches_add_view_add_track_semantics():
     rec.track_estimated[7] = False
     # BundleAdjustPartialReconstruction(views {0,1}, tracks {0..9})
     flat = sfm._flatten(rec, [0, 1], list(range(10)))
+    gc = np.ones(rec.group_intrinsics.shape[0], np.uint8); gc[rec.view_group[[0, 1]]] = 0
+    assert np.array_equal(flat.group_const, gc)      # groups of AddView'ed views are optimised, others constant
     ov, ot = flat.obs_cam, flat.obs_pt
     assert not np.any(ov == 5) and not np.any(ot == 7)          # unestimated blocks add nothing
     in_view = np.isin(ov, [0, 1]); in_track = np.isin(ot, np.arange(10))
