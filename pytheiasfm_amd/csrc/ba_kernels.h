@@ -100,4 +100,14 @@ void launch_long_backsub(const DevProblem& P, const double* cam, const double* p
 size_t dense_cholesky_workspace(int n);  // doubles
 void dense_cholesky_solve(int n, double* A, int lda, double* b, double* work, double* fail_flag, hipStream_t st);
 
+// Tile-sparse, nested-dissection ordered, level-scheduled variant of the same
+// solve (sparse_cholesky.hip).  adj = symmetric nt x nt (nt = ceil(n/64)) tile
+// co-visibility matrix, or nullptr for "dense".  Same workspace as the dense
+// solve; falls back to the dense schedule when the structure offers nothing.
+struct CholPlan;
+CholPlan* chol_plan_create(int n, const uint8_t* adj);
+void chol_plan_destroy(CholPlan* plan);
+int chol_plan_levels(const CholPlan* plan);
+void chol_plan_solve(const CholPlan* plan, double* A, int lda, double* b, double* work, double* fail_flag, hipStream_t st);
+
 }  // namespace thip

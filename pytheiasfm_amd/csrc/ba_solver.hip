@@ -111,8 +111,14 @@ struct theia_ba_handle_s {
   void* allreduce_ctx = nullptr;
   ReduceBuf rb;
   DevProblem P;
+  // K3 schedule: tile co-visibility of the reduced system (this rank's tracks;
+  // OR-ed over the ranks before the first distributed solve) and its plan
+  std::vector<uint8_t> tile_adj;
+  CholPlan* plan = nullptr;
+  bool plan_is_global = true;
 
   ~theia_ba_handle_s() {
+    if (plan) chol_plan_destroy(plan);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (h_scal) (void)hipHostFree(h_scal);
     if (stream) (void)hipStreamDestroy(stream);
@@ -295,7 +301,7 @@ int enqueue_linearize(theia_ba_handle_s* h, double radius) {
 // enqueue: dense solve, candidate cameras, back-substitution + trial cost.
 int enqueue_solve_and_backsub(theia_ba_handle_s* h) {
   double* yc = h->rb.rhs;  // the solution overwrites the rhs row
-  dense_cholesky_solve(h->n, h->rb.S, h->n, h->rb.rhs, h->chol_work.p, h->rb.scal + SC_NOTPD, h->stream);
+  chol_plan_solve(h->plan, h->rb.S, h->n, h->rb.rhs, h->chol_work.p, h->rb.scal + SC_NOTPD, h->stream);
   HIP_TRY(hipEventRecord(h->ev[2], h->stream));
   HIP_TRY(hipMemsetAsync(h->scalB.p, 0, sizeof(double) * 16, h->stream));
   const int nxt = 1 - h->cur;
@@ -305,6 +311,26 @@ int enqueue_solve_and_backsub(theia_ba_handle_s* h) {
   if (h->ntiles_main) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 5, h->f2s.p + 8, h->fmaxflag.p + 8, h->scalB.p, h->stream);
   launch_long_backsub(h->P, h->cam[h->cur].p, h->pts[h->cur].p, h->cam[nxt].p, h->pts[nxt].p, yc, h->Vinv.p, h->long_scratch.p, h->scalB.p, h->stream);
   return do_allreduce(h, h->scalB.p, 8, THEIA_REDUCE_SUM);
+}
+
+// The all-reduced S has the union of the ranks' tile structures: OR the tile
+// co-visibility over the ranks (MAX all-reduce) and rebuild the K3 schedule.
+int sync_plan(theia_ba_handle_s* h) {
+  const int nt = (h->n + 63) / 64;
+  const size_t cnt = (size_t)nt * nt;
+  if (cnt == 0 || !h->allreduce) { h->plan_is_global = true; return 0; }
+  std::vector<double> a(cnt);
+  for (size_t i = 0; i < cnt; ++i) a[i] = h->tile_adj[i];
+  HIP_TRY(hipMemcpyAsync(h->reduce.p, a.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+  int rc = do_allreduce(h, h->reduce.p, cnt, THEIA_REDUCE_MAX);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(a.data(), h->reduce.p, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i < cnt; ++i) h->tile_adj[i] = a[i] != 0.0 ? 1 : 0;
+  if (h->plan) chol_plan_destroy(h->plan);
+  h->plan = chol_plan_create(h->n, h->tile_adj.data());
+  h->plan_is_global = true;
+  return 0;
 }
 
 void trace_push(theia_ba_summary* S, double cost, double g, double step, double radius, int acc) {
@@ -515,6 +541,40 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   AL(Vinv, (size_t)(h->pd * (h->pd + 1) / 2) * h->np); AL(gp, (size_t)h->pd * h->np);
   AL(tile_part, (size_t)5 * std::max(1, h->ntiles_all)); AL(scalB, 16);
   AL(chol_work, dense_cholesky_workspace(h->n));
+  {
+    // tile co-visibility: two 64-wide tiles of S couple iff a variable track is
+    // seen by cameras of both (the Schur complement's block structure)
+    const int nt = (h->n + 63) / 64;
+    h->tile_adj.assign((size_t)nt * nt, 0);
+    std::vector<int64_t> off(h->np + 1, 0);
+    for (int64_t i = 0; i < h->nobs; ++i)
+      if (h->cam_red[p->obs_cam[i]] >= 0 && !h->pt_const[p->obs_pt[i]]) off[p->obs_pt[i] + 1]++;
+    for (int q = 0; q < h->np; ++q) off[q + 1] += off[q];
+    std::vector<int> rcs(off[h->np]);
+    {
+      std::vector<int64_t> fill(off.begin(), off.end() - 1);
+      for (int64_t i = 0; i < h->nobs; ++i) {
+        const int rcam = h->cam_red[p->obs_cam[i]];
+        if (rcam >= 0 && !h->pt_const[p->obs_pt[i]]) rcs[fill[p->obs_pt[i]]++] = rcam;
+      }
+    }
+    std::vector<int> tl;
+    for (int q = 0; q < h->np; ++q) {
+      tl.clear();
+      for (int64_t k = off[q]; k < off[q + 1]; ++k) {
+        const int s0 = h->ni + 6 * rcs[k];
+        tl.push_back(s0 / 64);
+        if ((s0 + 5) / 64 != s0 / 64) tl.push_back((s0 + 5) / 64);
+      }
+      std::sort(tl.begin(), tl.end());
+      tl.erase(std::unique(tl.begin(), tl.end()), tl.end());
+      for (int a : tl) for (int b : tl) h->tile_adj[(size_t)a * nt + b] = 1;
+    }
+    // shared intrinsics couple with every camera of their group: treat as dense
+    for (int a = 0; a < (h->ni + 63) / 64; ++a)
+      for (int b = 0; b < nt; ++b) h->tile_adj[(size_t)a * nt + b] = h->tile_adj[(size_t)b * nt + a] = 1;
+    h->plan = chol_plan_create(h->n, h->tile_adj.data());
+  }
   if (getenv("THEIA_HIP_STAMPS")) AL(stamps, 16);
 #undef UP
 #undef AL
@@ -556,6 +616,7 @@ int theia_hip_ba_set_options(theia_ba_handle h, const theia_ba_options* o) {
 int theia_hip_ba_set_allreduce(theia_ba_handle h, theia_allreduce_fn fn, void* ctx) {
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
   h->allreduce = fn; h->allreduce_ctx = ctx;
+  h->plan_is_global = (fn == nullptr);   // the K3 schedule must cover every rank's tracks
   return 0;
 }
 
@@ -581,7 +642,9 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   S->time_linearize = S->time_solve_reduced = S->time_backsub = 0.0;
   S->time_kernel_linearize = 0.0; S->num_linearize_launches = 0;
   S->setup_time_in_seconds = 0.0;
-  int rc = compute_scale(h);
+  int rc = h->plan_is_global ? 0 : sync_plan(h);
+  if (rc) return rc;
+  rc = compute_scale(h);
   if (rc) return rc;
   double radius = 1e4, decrease_factor = 2.0;
   bool step_successful = true;

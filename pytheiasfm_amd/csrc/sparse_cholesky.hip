@@ -1,0 +1,412 @@
+// sparse_cholesky.hip -- K3 for structured reduced camera systems: a tile-sparse
+// (64 x 64 tiles), nested-dissection ordered, LEVEL-SCHEDULED Cholesky.
+//
+// The reference hands the reduced camera matrix to Ceres' SPARSE_SCHUR with a
+// fill-reducing ordering (bundle_adjustment.h:98-104, bundle_adjuster.cc:63-89),
+// i.e. it exploits the camera co-visibility sparsity.  A dense right-looking
+// factorisation is a chain of n/64 dependent panel steps and on MI355X every
+// step is latency bound (dense_cholesky.hip).  Here the 64-wide tiles of S are
+// reordered by nested dissection of the tile co-visibility graph (host, once
+// per problem), the tile elimination tree is cut into levels, and ALL tiles of
+// a level are factored by one launch: the dependent chain is the tree height
+// (5-8 for ring / band like camera graphs), not the tile count.
+//
+// Storage is unchanged: S row-major n x lda with the rhs as row n; the
+// permutation is applied by tile indirection only (tile (I,J) of P S P^T lives
+// at physical tile (perm[I], perm[J]); tiles that land in the physical upper
+// triangle are first mirrored from the lower one).
+#include "ba_kernels.h"
+#include "cholesky_device.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <vector>
+
+namespace thip {
+namespace {
+
+using namespace chol;
+
+// ---- per-level work lists (int32 records in one device array) ----
+// potrf : {k0, nb, slot}
+// trsm  : {row0, h, k0, nb, slot}
+// upd   : {row0, h, col0, w, sbeg, send, diag}   sources: {k0, nb}
+// back  : {k0, nb, slot, sbeg, send}             sources: {row0, h}
+// symm  : {r0, h, c0, w}   dst tile (r0, c0) <- transpose of tile (c0, r0)
+
+__global__ __launch_bounds__(64) void k_sp_potrf(double* __restrict__ A, int lda, const int* __restrict__ items,
+                                                 double* __restrict__ Linv, double* __restrict__ fail_flag) {
+  const int* it = items + 3 * blockIdx.x;
+  potrf64_wave(A, lda, it[0], it[1], Linv + (size_t)it[2] * NB * NB, fail_flag);
+}
+
+// stage a 64 x 64 tile (h valid rows, w valid columns, zero padded) in LDS; 16
+// independent loads per thread are in flight before the first LDS store
+__device__ __forceinline__ void load_tile(double (*T)[LDP], const double* __restrict__ A, int lda, int row0, int h,
+                                          int col0, int w, int tid) {
+  double v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int t = tid + 256 * q, r = t >> 6, c = t & 63;
+    v[q] = (r < h && c < w) ? A[(size_t)(row0 + r) * lda + col0 + c] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int t = tid + 256 * q;
+    T[t >> 6][t & 63] = v[q];
+  }
+}
+
+// X = P * Linv^T for one tile: X[r][j] = sum_i P[r][i] Z[j][i]
+__global__ __launch_bounds__(256) void k_sp_trsm(double* __restrict__ A, int lda, const int* __restrict__ items,
+                                                 const double* __restrict__ Linv) {
+  __shared__ double P[NB][LDP];
+  __shared__ double Z[NB][LDP];
+  const int* it = items + 5 * blockIdx.x;
+  const int row0 = it[0], h = it[1], k0 = it[2], nb = it[3];
+  const int tid = threadIdx.x;
+  load_tile(Z, Linv + (size_t)it[4] * NB * NB, NB, 0, NB, 0, NB, tid);
+  load_tile(P, A, lda, row0, h, k0, nb, tid);
+  __syncthreads();
+  const int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  if (16 * wv >= h) return;
+  double4_t acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < NB; kk += 4) {
+    const double a = P[16 * wv + li][kk + lk];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Z[16 * q + li][kk + lk], acc[q], 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int r = 16 * wv + lk + 4 * reg, c = 16 * q + li;
+      if (r < h && c < nb) A[(size_t)(row0 + r) * lda + k0 + c] = acc[q][reg];
+    }
+}
+
+// C(I,J) -= sum over the level's sources K of L(I,K) L(J,K)^T, fixed order
+__global__ __launch_bounds__(256) void k_sp_update(double* __restrict__ A, int lda, const int* __restrict__ items,
+                                                   const int* __restrict__ srcs) {
+  __shared__ double Pr[NB][LDP];
+  __shared__ double Pc[NB][LDP];
+  const int* it = items + 7 * blockIdx.x;
+  const int row0 = it[0], h = it[1], col0 = it[2], w = it[3], sbeg = it[4], send = it[5], diag = it[6];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  double4_t cold[4], acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int r = 16 * wv + lk + 4 * reg, c = 16 * q + li;
+      const bool ok = r < h && c < w && (!diag || c <= r);
+      cold[q][reg] = ok ? A[(size_t)(row0 + r) * lda + col0 + c] : 0.0;
+    }
+  }
+  for (int s = sbeg; s < send; ++s) {
+    const int k0 = srcs[2 * s], nb = srcs[2 * s + 1];
+    if (s > sbeg) __syncthreads();
+    load_tile(Pr, A, lda, row0, h, k0, nb, tid);
+    load_tile(Pc, A, lda, col0, w, k0, nb, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < NB; kk += 4) {
+      const double a = Pr[16 * wv + li][kk + lk];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Pc[16 * q + li][kk + lk], acc[q], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int r = 16 * wv + lk + 4 * reg, c = 16 * q + li;
+      if (r < h && c < w && (!diag || c <= r)) A[(size_t)(row0 + r) * lda + col0 + c] = cold[q][reg] - acc[q][reg];
+    }
+}
+
+// x_K = Linv_K^T (y_K - sum_I L(I,K)^T x_I), I over the (already solved) ancestors
+__global__ __launch_bounds__(256) void k_sp_back(const double* __restrict__ A, int lda, const int* __restrict__ items,
+                                                 const int* __restrict__ srcs, const double* __restrict__ Linv,
+                                                 const double* __restrict__ y, double* __restrict__ x) {
+  __shared__ double xs[NB], yk[NB], part[4][NB];
+  const int* it = items + 5 * blockIdx.x;
+  const int k0 = it[0], nb = it[1], sbeg = it[3], send = it[4];
+  const double* Z = Linv + (size_t)it[2] * NB * NB;
+  const int tid = threadIdx.x, j = tid & 63, ch = tid >> 6;
+  double s = 0.0;
+  for (int q = sbeg; q < send; ++q) {
+    const int row0 = srcs[2 * q], h = srcs[2 * q + 1];
+    __syncthreads();
+    if (tid < NB) xs[tid] = (tid < h) ? x[row0 + tid] : 0.0;
+    __syncthreads();
+    if (j < nb) {
+      const double* col = A + (size_t)row0 * lda + k0 + j;
+#pragma unroll 4
+      for (int r = ch * 16; r < ch * 16 + 16; ++r)
+        if (r < h) s += col[(size_t)r * lda] * xs[r];
+    }
+  }
+  part[ch][j] = s;
+  __syncthreads();
+  if (tid < NB) yk[tid] = (tid < nb) ? y[k0 + tid] - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) : 0.0;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { const int r = ch * 16 + q; t += Z[r * NB + j] * yk[r]; }
+  __syncthreads();
+  part[ch][j] = t;
+  __syncthreads();
+  if (tid < nb) x[k0 + tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+}
+
+__global__ __launch_bounds__(256) void k_sp_symm(double* __restrict__ A, int lda, const int* __restrict__ items) {
+  __shared__ double T[NB][LDP];
+  const int* it = items + 4 * blockIdx.x;
+  const int r0 = it[0], h = it[1], c0 = it[2], w = it[3];
+  load_tile(T, A, lda, c0, w, r0, h, threadIdx.x);   // source tile (c0, r0): w rows, h columns
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int t = threadIdx.x + 256 * q, r = t >> 6, c = t & 63;
+    if (r < h && c < w) A[(size_t)(r0 + r) * lda + c0 + c] = T[c][r];
+  }
+}
+
+// ------------------------------------------------------------------ host
+struct Level {
+  int potrf_off = 0, npotrf = 0, trsm_off = 0, ntrsm = 0, upd_off = 0, nupd = 0, upd_src_off = 0;
+  int back_off = 0, nback = 0, back_src_off = 0;
+};
+
+// nested dissection by BFS level-set separators on the tile graph
+struct Orderer {
+  const std::vector<std::vector<int>>& nbr;
+  std::vector<int> mark, dist, out;
+  int stamp = 0;
+  explicit Orderer(const std::vector<std::vector<int>>& g) : nbr(g), mark(g.size(), 0), dist(g.size(), 0) {}
+
+  // BFS inside the node set marked with `tag`; returns visit order, fills dist
+  std::vector<int> bfs(int src, int tag) {
+    std::vector<int> q{src};
+    const int seen = ++stamp;
+    std::vector<int>& d = dist;
+    d[src] = 0;
+    vis.resize(nbr.size());
+    vis[src] = seen;
+    for (size_t i = 0; i < q.size(); ++i)
+      for (int v : nbr[q[i]])
+        if (mark[v] == tag && vis[v] != seen) { vis[v] = seen; d[v] = d[q[i]] + 1; q.push_back(v); }
+    return q;
+  }
+  std::vector<int> vis;
+
+  void order(std::vector<int> nodes) {
+    if (nodes.size() <= 2) { for (int v : nodes) out.push_back(v); return; }
+    const int tag = ++stamp;
+    for (int v : nodes) mark[v] = tag;
+    std::vector<int> comp = bfs(nodes[0], tag);
+    if (comp.size() < nodes.size()) {   // disconnected: independent subtrees
+      std::vector<std::vector<int>> comps;
+      std::vector<char> done(nbr.size(), 0);
+      for (int v : nodes) {
+        if (done[v]) continue;
+        std::vector<int> c = bfs(v, tag);
+        for (int u : c) done[u] = 1;
+        std::sort(c.begin(), c.end());
+        comps.push_back(c);
+      }
+      for (auto& c : comps) order(c);
+      return;
+    }
+    const int far = comp.back();
+    std::vector<int> lv = bfs(far, tag);
+    const int d = dist[lv.back()];
+    if (d < 2) { for (int v : nodes) out.push_back(v); return; }
+    std::vector<int> cnt(d + 1, 0);
+    for (int v : lv) cnt[dist[v]]++;
+    int best = -1;
+    const int lo = std::max(1, d / 3), hi = std::min(d - 1, (2 * d + 2) / 3);
+    for (int m = lo; m <= hi; ++m) {
+      if (best < 0 || cnt[m] < cnt[best] || (cnt[m] == cnt[best] && std::abs(2 * m - d) < std::abs(2 * best - d))) best = m;
+    }
+    std::vector<int> sep, rest;
+    for (int v : nodes) (dist[v] == best ? sep : rest).push_back(v);
+    // components of the rest (recursion re-marks; collect them first)
+    const int tag2 = ++stamp;
+    for (int v : rest) mark[v] = tag2;
+    std::vector<std::vector<int>> comps;
+    std::vector<char> done(nbr.size(), 0);
+    for (int v : rest) {
+      if (done[v]) continue;
+      std::vector<int> c = bfs(v, tag2);
+      for (int u : c) done[u] = 1;
+      std::sort(c.begin(), c.end());
+      comps.push_back(c);
+    }
+    for (auto& c : comps) order(c);
+    for (int v : sep) out.push_back(v);
+  }
+};
+
+struct Symbolic {
+  std::vector<std::vector<int>> below;   // struct(K): I > K with L(I,K) != 0 (permuted indices)
+  std::vector<int> level;
+  int nlev = 0;
+  long long ntiles = 0;
+};
+
+Symbolic symbolic(int nt, const uint8_t* adj, const std::vector<int>& perm) {
+  Symbolic sy;
+  std::vector<uint8_t> L((size_t)nt * nt, 0);
+  for (int I = 0; I < nt; ++I)
+    for (int J = 0; J < I; ++J) L[(size_t)I * nt + J] = adj ? adj[(size_t)perm[I] * nt + perm[J]] : 1;
+  sy.below.resize(nt);
+  sy.level.assign(nt, 0);
+  for (int K = 0; K < nt; ++K) {
+    std::vector<int>& s = sy.below[K];
+    for (int I = K + 1; I < nt; ++I) if (L[(size_t)I * nt + K]) s.push_back(I);
+    for (size_t a = 0; a < s.size(); ++a)
+      for (size_t b = 0; b < a; ++b) L[(size_t)s[a] * nt + s[b]] = 1;
+    if (!s.empty()) sy.level[s[0]] = std::max(sy.level[s[0]], sy.level[K] + 1);   // etree parent = min(struct)
+    sy.ntiles += 1 + (long long)s.size();
+  }
+  for (int K = 0; K < nt; ++K) sy.nlev = std::max(sy.nlev, sy.level[K] + 1);
+  return sy;
+}
+
+}  // namespace
+
+struct CholPlan {
+  int n = 0, nt = 0, nlev = 0;
+  bool dense = true;
+  std::vector<Level> lev;
+  int symm_off = 0, nsymm = 0;
+  int* prog = nullptr;   // device
+  ~CholPlan() { if (prog) (void)hipFree(prog); }
+};
+
+CholPlan* chol_plan_create(int n, const uint8_t* adj) {
+  CholPlan* pl = new CholPlan();
+  pl->n = n;
+  const int nt = (n + NB - 1) / NB;
+  pl->nt = nt;
+  if (n <= 0 || nt <= 2 || !adj || getenv("THEIA_HIP_DENSE_CHOLESKY")) return pl;
+  // tile graph without the (near) dense nodes, which are ordered last
+  std::vector<int> deg(nt, 0);
+  for (int i = 0; i < nt; ++i) for (int j = 0; j < nt; ++j) if (i != j && adj[(size_t)i * nt + j]) deg[i]++;
+  std::vector<char> is_dense(nt, 0);
+  for (int i = 0; i < nt; ++i) is_dense[i] = (deg[i] >= std::max(8, nt / 2)) ? 1 : 0;
+  std::vector<std::vector<int>> nbr(nt);
+  std::vector<int> sparse_nodes, dense_nodes;
+  for (int i = 0; i < nt; ++i) {
+    (is_dense[i] ? dense_nodes : sparse_nodes).push_back(i);
+    if (is_dense[i]) continue;
+    for (int j = 0; j < nt; ++j) if (i != j && !is_dense[j] && adj[(size_t)i * nt + j]) nbr[i].push_back(j);
+  }
+  std::vector<int> natural(nt);
+  for (int i = 0; i < nt; ++i) natural[i] = i;
+  std::vector<int> perm = natural;
+  Symbolic best = symbolic(nt, adj, natural);
+  if (!sparse_nodes.empty()) {
+    Orderer od(nbr);
+    od.order(sparse_nodes);
+    std::vector<int> cand = od.out;
+    for (int v : dense_nodes) cand.push_back(v);
+    if ((int)cand.size() == nt) {
+      Symbolic sc = symbolic(nt, adj, cand);
+      if (sc.nlev < best.nlev) { best = sc; perm = cand; }
+    }
+  }
+  if (best.ntiles >= (long long)nt * (nt + 1) / 2 || best.nlev >= nt) return pl;   // nothing to gain: dense path
+  pl->dense = false;
+  pl->nlev = best.nlev;
+
+  auto r0 = [&](int I) { return I == nt ? n : perm[I] * NB; };                 // I == nt: the rhs row
+  auto hh = [&](int I) { return I == nt ? 1 : std::min(NB, n - perm[I] * NB); };
+  std::vector<int> prog;
+  pl->lev.resize(best.nlev);
+  for (int l = 0; l < best.nlev; ++l) {
+    Level& lv = pl->lev[l];
+    std::vector<int> ks;
+    for (int K = 0; K < nt; ++K) if (best.level[K] == l) ks.push_back(K);
+    lv.potrf_off = (int)prog.size(); lv.npotrf = (int)ks.size();
+    for (int K : ks) { prog.push_back(r0(K)); prog.push_back(hh(K)); prog.push_back(K); }
+    lv.trsm_off = (int)prog.size();
+    std::map<std::pair<int, int>, std::vector<int>> targets;
+    for (int K : ks) {
+      std::vector<int> s = best.below[K];
+      s.push_back(nt);
+      for (int I : s) { prog.push_back(r0(I)); prog.push_back(hh(I)); prog.push_back(r0(K)); prog.push_back(hh(K)); prog.push_back(K); lv.ntrsm++; }
+      for (size_t a = 0; a < s.size(); ++a)
+        for (size_t b = 0; b <= a; ++b)
+          if (s[b] != nt) targets[{s[a], s[b]}].push_back(K);
+    }
+    lv.upd_off = (int)prog.size(); lv.nupd = (int)targets.size();
+    std::vector<int> srcs;
+    for (auto& kv : targets) {
+      const int I = kv.first.first, J = kv.first.second;
+      prog.push_back(r0(I)); prog.push_back(hh(I)); prog.push_back(r0(J)); prog.push_back(hh(J));
+      prog.push_back((int)srcs.size() / 2);
+      for (int K : kv.second) { srcs.push_back(r0(K)); srcs.push_back(hh(K)); }
+      prog.push_back((int)srcs.size() / 2);
+      prog.push_back(I == J ? 1 : 0);
+    }
+    lv.upd_src_off = (int)prog.size();
+    prog.insert(prog.end(), srcs.begin(), srcs.end());
+    // backward substitution of this level's tiles
+    lv.back_off = (int)prog.size(); lv.nback = (int)ks.size();
+    std::vector<int> bsrc;
+    for (int K : ks) {
+      prog.push_back(r0(K)); prog.push_back(hh(K)); prog.push_back(K);
+      prog.push_back((int)bsrc.size() / 2);
+      for (int I : best.below[K]) { bsrc.push_back(r0(I)); bsrc.push_back(hh(I)); }
+      prog.push_back((int)bsrc.size() / 2);
+    }
+    lv.back_src_off = (int)prog.size();
+    prog.insert(prog.end(), bsrc.begin(), bsrc.end());
+  }
+  // tiles of the factor structure that sit in the physical upper triangle
+  pl->symm_off = (int)prog.size();
+  for (int K = 0; K < nt; ++K)
+    for (int I : best.below[K])
+      if (perm[I] < perm[K]) { prog.push_back(r0(I)); prog.push_back(hh(I)); prog.push_back(r0(K)); prog.push_back(hh(K)); pl->nsymm++; }
+  if (prog.empty()) prog.push_back(0);
+  if (hipMalloc((void**)&pl->prog, sizeof(int) * prog.size()) != hipSuccess ||
+      hipMemcpy(pl->prog, prog.data(), sizeof(int) * prog.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    pl->dense = true;   // dense schedule instead (same solution)
+    pl->lev.clear();
+  }
+  return pl;
+}
+
+void chol_plan_destroy(CholPlan* pl) { delete pl; }
+int chol_plan_levels(const CholPlan* pl) { return pl && !pl->dense ? pl->nlev : (pl ? pl->nt : 0); }
+
+void chol_plan_solve(const CholPlan* pl, double* A, int lda, double* b, double* work, double* fail_flag, hipStream_t st) {
+  const int n = pl->n;
+  if (n <= 0) return;
+  if (pl->dense) { dense_cholesky_solve(n, A, lda, b, work, fail_flag, st); return; }
+  double* Linv = work;
+  double* x = work + (size_t)pl->nt * NB * NB;
+  const int* pg = pl->prog;
+  if (pl->nsymm) k_sp_symm<<<pl->nsymm, 256, 0, st>>>(A, lda, pg + pl->symm_off);
+  for (const Level& lv : pl->lev) {
+    k_sp_potrf<<<lv.npotrf, 64, 0, st>>>(A, lda, pg + lv.potrf_off, Linv, fail_flag);
+    if (lv.ntrsm) k_sp_trsm<<<lv.ntrsm, 256, 0, st>>>(A, lda, pg + lv.trsm_off, Linv);
+    if (lv.nupd) k_sp_update<<<lv.nupd, 256, 0, st>>>(A, lda, pg + lv.upd_off, pg + lv.upd_src_off);
+  }
+  const double* y = A + (size_t)n * lda;
+  for (int l = (int)pl->lev.size() - 1; l >= 0; --l) {
+    const Level& lv = pl->lev[l];
+    k_sp_back<<<lv.nback, 256, 0, st>>>(A, lda, pg + lv.back_off, pg + lv.back_src_off, Linv, y, x);
+  }
+  (void)hipMemcpyAsync(b, x, sizeof(double) * n, hipMemcpyDeviceToDevice, st);
+}
+
+}  // namespace thip

@@ -368,3 +368,22 @@ def test_intrinsics_group_constant_and_bounds():
     assert s.num_iterations == so.num_iterations and abs(s.final_cost - so.final_cost) <= 1e-8 * so.final_cost
     assert np.array_equal(pg.intrinsics[1], p.intrinsics[1])
     assert pg.intrinsics[0, 0] >= 1.0 and rel(pg.intrinsics, po.intrinsics) <= 1e-7
+
+
+def test_level_scheduled_sparse_cholesky_matches_dense_schedule(monkeypatch):
+    """K3: the nested-dissection / level-scheduled tile-sparse factorisation and
+    the dense panel chain solve the same reduced systems (C2 size: 19 tiles on a
+    ring; and a 4-dof-point problem with a long-track wrap-around)."""
+    p = synth.ba_config("C2")
+    o = ba.default_options(); o.max_num_iterations = 6
+    runs = []
+    for dense in (False, True):
+        if dense:
+            monkeypatch.setenv("THEIA_HIP_DENSE_CHOLESKY", "1")
+        q = p.copy()
+        s, tr = ba.solve(q, o)
+        runs.append((s, tr, q))
+    (s0, t0, q0), (s1, t1, q1) = runs
+    assert s0.num_iterations == s1.num_iterations and np.array_equal(t0.accepted, t1.accepted)
+    assert rel(t0.cost, t1.cost) <= 1e-11
+    assert np.abs(q0.cam_ext - q1.cam_ext).max() <= 1e-9 and np.abs(q0.points - q1.points).max() <= 1e-9
