@@ -47,6 +47,14 @@ struct DevProblem {
   const double* scale_i;       // [ng][10] Jacobi scaling of the intrinsics columns
   const double* intr_cand;     // [ng][10] candidate intrinsics (back-substitution / trial cost)
   const double* scale_red;     // [n] Jacobi scaling by reduced index (finalize)
+  // gather-based Schur assembly (k_lin_obs + k_schur_diag + k_schur_blocks), ni == 0:
+  // static lists built at create(); null = LDS-window / atomic k_linearize
+  double* rec;                 // [nobs_main][6*pd + 14] per-observation record {W | Jc | r}
+  int n_diag_items, n_blk_items;
+  const int* diag_items;       // [n_diag_items][4] {rc, beg, end, atomic}
+  const int* cam_obs;          // observation (sorted index) lists per reduced camera
+  const int* blk_items;        // [n_blk_items][5] {ri, rj, beg, end, atomic}
+  const int2* blk_pairs;       // (obs a of camera ri, obs b of camera rj) of a common track
 };
 
 // Per-iteration reduced-system workspace: one contiguous buffer so that a

@@ -589,6 +589,243 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
     for (int k = 0; k < 6; ++k) P.stamps[k] = st_[k];
 }
 
+// ------------------------------------------ gather-based Schur assembly (v3)
+// The LDS-window kernel above spends most of its time in ds_add_f64 (measured
+// ~200 cycles per wave instruction) and runs one workgroup per CU.  The
+// problem topology is static, so the scatter is turned into a gather:
+//   k_lin_obs     : per wave tile: linearise, V_p / g_p by segmented sums,
+//                   V_p^-1; writes per-point Vinv, g_p and a per-observation
+//                   record {W = F^T E (6 x PD) | F (2 x 6) | r (2)}.  No LDS
+//                   accumulators -> full occupancy.
+//   k_schur_diag  : one wave per reduced camera walks the camera's observation
+//                   list: U_c - sum T W^T, rhs, g_c, column norms.
+//   k_schur_blocks: one wave per off-diagonal block (i, j) walks the host-built
+//                   list of (obs of i, obs of j) pairs of common tracks:
+//                   S_ij = - sum T_a W_b^T, T_a = W_a V^-1.
+// Lanes accumulate in registers and a shuffle reduce-scatter leaves element e
+// of the block in lane(e): no atomics (except for lists split into chunks),
+// fixed summation order, each S entry written once.
+template <int PD> constexpr int rec_stride() { return 6 * PD + 14; }
+
+template <int PD>
+__global__ __launch_bounds__(kBlock) void k_lin_obs(DevProblem P, const double* __restrict__ cam,
+                                                    const double* __restrict__ pts, double radius,
+                                                    double* __restrict__ Vinv, double* __restrict__ gp,
+                                                    double* __restrict__ tile_part) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  constexpr int NW = 6 * PD;
+  constexpr int RS = rec_stride<PD>();
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (tile >= P.ntiles) return;
+  const int cnt = P.tile_count[tile];
+  const int start = P.tile_start[tile];
+  LaneLin<PD> L;
+  lane_linearize<PD, true>(P, cam, pts, start + lane, lane < cnt, lane, L);
+  const Segment sg = lane_segment(L.p, lane);
+  double in[NT + PD], tot[NT + PD];
+#pragma unroll
+  for (int a = 0; a < PD; ++a) {
+#pragma unroll
+    for (int b = 0; b <= a; ++b) in[lidx(a, b)] = L.Jt[a] * L.Jt[b] + L.Jt[PD + a] * L.Jt[PD + b];
+    in[NT + a] = L.Jt[a] * L.r[0] + L.Jt[PD + a] * L.r[1];
+  }
+  segment_allsum<NT + PD>(sg, in, tot);
+  double gmax = 0.0;
+  bool pd_ok = true;
+  if (L.active && sg.head && !L.pconst) {
+    double V[NT], Vi[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) V[k] = tot[k];
+#pragma unroll
+    for (int a = 0; a < PD; ++a) V[lidx(a, a)] += fmin(fmax(V[lidx(a, a)], 1e-6), 1e32) / radius;
+    pd_ok = invert_spd<PD>(V, Vi);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) Vinv[(size_t)NT * L.p + k] = pd_ok ? Vi[k] : 0.0;
+#pragma unroll
+    for (int a = 0; a < PD; ++a) {
+      gp[(size_t)PD * L.p + a] = tot[NT + a];
+      gmax = fmax(gmax, fabs(tot[NT + a] / P.scale_p[(size_t)PD * L.p + a]));
+    }
+  }
+  if (L.active && L.rc >= 0) {
+    double2* R = reinterpret_cast<double2*>(P.rec + (size_t)(start + lane) * RS);
+    double w[NW];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < PD; ++b) w[a * PD + b] = L.Jc[a] * L.Jt[b] + L.Jc[6 + a] * L.Jt[PD + b];
+#pragma unroll
+    for (int k = 0; k < NW / 2; ++k) R[k] = make_double2(w[2 * k], w[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) R[NW / 2 + k] = make_double2(L.Jc[2 * k], L.Jc[2 * k + 1]);
+    R[NW / 2 + 6] = make_double2(L.r[0], L.r[1]);
+  }
+  const double cost = wave_sum(L.cost);
+  gmax = wave_max(gmax);
+  const double inval = wave_sum((L.active && !L.valid) ? 1.0 : 0.0);
+  const double npd = wave_sum((L.active && !pd_ok) ? 1.0 : 0.0);
+  if (lane == 0) {
+    tile_part[4 * (size_t)tile + 0] = cost;
+    tile_part[4 * (size_t)tile + 1] = gmax;
+    tile_part[4 * (size_t)tile + 2] = inval;
+    tile_part[4 * (size_t)tile + 3] = npd;
+  }
+}
+
+// Sum v[0..N) over the 64 lanes and scatter the totals: after the call the
+// lane with cnt > 0 holds the total of element `lo` in the return value.
+// Each stage halves the values a lane carries (xor-shuffle exchange).
+template <int N, int OFF>
+THIP_DEV double wave_reduce_scatter(double (&v)[N], int lane, int& lo, int& cnt) {
+  if constexpr (OFF == 0) {
+    return v[0];
+  } else {
+    constexpr int H = (N + 1) / 2;
+    const bool up = (lane & OFF) != 0;
+    double w[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      const double a = v[k];
+      const double b = (k + H < N) ? v[(k + H < N) ? k + H : 0] : 0.0;
+      const double send = up ? a : b;
+      const double keep = up ? b : a;
+      w[k] = keep + __shfl_xor(send, OFF, kWave);
+    }
+    lo += up ? H : 0;
+    cnt = up ? cnt - H : min(cnt, H);
+    return wave_reduce_scatter<H, OFF / 2>(w, lane, lo, cnt);
+  }
+}
+
+template <int PD>
+THIP_DEV void load_w(const double* __restrict__ rec, int o, double (&w)[6 * PD]) {
+  const double2* R = reinterpret_cast<const double2*>(rec + (size_t)o * rec_stride<PD>());
+#pragma unroll
+  for (int k = 0; k < 3 * PD; ++k) { const double2 t = R[k]; w[2 * k] = t.x; w[2 * k + 1] = t.y; }
+}
+
+template <int PD>
+__global__ __launch_bounds__(kBlock) void k_schur_diag(DevProblem P, const double* __restrict__ Vinv,
+                                                       const double* __restrict__ gp, double* __restrict__ S,
+                                                       double* __restrict__ rhs, double* __restrict__ colsq,
+                                                       double* __restrict__ gc) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  constexpr int NW = 6 * PD;
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (item >= P.n_diag_items) return;
+  const int* it = P.diag_items + 4 * item;
+  const int rc = it[0], beg = it[1], end = it[2], atomic = it[3];
+  double acc[39];
+#pragma unroll
+  for (int k = 0; k < 39; ++k) acc[k] = 0.0;
+  for (int q = beg + lane; q < end; q += 64) {
+    const int o = P.cam_obs[q];
+    const int p = P.obs_pt[o];
+    double W[NW], T[NW], Vi[NT], g[PD], Jc[12];
+    load_w<PD>(P.rec, o, W);
+    const double2* R = reinterpret_cast<const double2*>(P.rec + (size_t)o * rec_stride<PD>()) + NW / 2;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { const double2 t = R[k]; Jc[2 * k] = t.x; Jc[2 * k + 1] = t.y; }
+    const double2 r = R[6];
+    const bool pc = P.pt_const[p] != 0;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) Vi[k] = pc ? 0.0 : Vinv[(size_t)NT * p + k];
+#pragma unroll
+    for (int k = 0; k < PD; ++k) g[k] = pc ? 0.0 : gp[(size_t)PD * p + k];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < PD; ++b) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < PD; ++k) s += W[a * PD + k] * sym_get<PD>(Vi, k, b);
+        T[a * PD + b] = s;
+      }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int b = 0; b <= a; ++b) {
+        double s = Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
+#pragma unroll
+        for (int k = 0; k < PD; ++k) s -= T[a * PD + k] * W[b * PD + k];
+        acc[lidx(a, b)] += s;
+      }
+      const double jr = Jc[a] * r.x + Jc[6 + a] * r.y;
+      double tg = 0.0;
+#pragma unroll
+      for (int k = 0; k < PD; ++k) tg += T[a * PD + k] * g[k];
+      acc[21 + a] += jr - tg;
+      acc[27 + a] += jr;
+      acc[33 + a] += Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a];
+    }
+  }
+  int lo = 0, cnt = 39;
+  const double tot = wave_reduce_scatter<39, 32>(acc, lane, lo, cnt);
+  if (cnt <= 0) return;
+  double* dst;
+  if (lo < 21) {
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= lo) ++a;
+    const int b = lo - a * (a + 1) / 2;
+    dst = S + (size_t)(6 * rc + a) * P.n + 6 * rc + b;
+  } else {
+    const int q = (lo - 21) % 6;
+    dst = (lo < 27 ? rhs : (lo < 33 ? gc : colsq)) + 6 * rc + q;
+  }
+  if (atomic) atomic_add(dst, tot); else *dst = tot;
+}
+
+template <int PD>
+__global__ __launch_bounds__(kBlock) void k_schur_blocks(DevProblem P, const double* __restrict__ Vinv,
+                                                         double* __restrict__ S) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  constexpr int NW = 6 * PD;
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  if (item >= P.n_blk_items) return;
+  const int* it = P.blk_items + 5 * item;
+  const int ri = it[0], rj = it[1], beg = it[2], end = it[3], atomic = it[4];
+  double acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+  for (int q = beg + lane; q < end; q += 64) {
+    const int2 ab = P.blk_pairs[q];
+    const int p = P.obs_pt[ab.x];
+    double Wa[NW], Wb[NW], T[NW], Vi[NT];
+    load_w<PD>(P.rec, ab.x, Wa);
+    load_w<PD>(P.rec, ab.y, Wb);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) Vi[k] = Vinv[(size_t)NT * p + k];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < PD; ++b) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < PD; ++k) s += Wa[a * PD + k] * sym_get<PD>(Vi, k, b);
+        T[a * PD + b] = s;
+      }
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < PD; ++k) s += T[a * PD + k] * Wb[b * PD + k];
+        acc[a * 6 + b] += s;
+      }
+  }
+  int lo = 0, cnt = 36;
+  const double tot = wave_reduce_scatter<36, 32>(acc, lane, lo, cnt);
+  if (cnt <= 0) return;
+  const int a = lo / 6, b = lo % 6;
+  if (ri == rj && b > a) return;   // two observations of one camera in a track: lower part of the diagonal block
+  double* dst = S + (size_t)(6 * ri + a) * P.n + 6 * rj + b;
+  if (atomic) atomic_add(dst, -tot); else *dst = -tot;
+}
+
 // Deterministic reduction of per-tile partials into the scalar block.
 // field f of tile t at tile_part[t*nfields + f]; result -> scal[field_to_scal[f]]
 // (sum, or max if field_is_max[f]).
@@ -1095,6 +1332,22 @@ void launch_make_scale(int count, const double* colsq, double* scale, hipStream_
 void launch_linearize(const DevProblem& P, const double* cam, const double* pts, double radius,
                       const ReduceBuf& rb, double* Vinv, double* gp, double* tile_part, hipStream_t st) {
   if (P.ntiles == 0) return;
+  if (P.rec && P.ni == 0) {
+    const int g = tile_blocks(P.ntiles);
+    if (P.pd == 3) k_lin_obs<3><<<g, kBlock, 0, st>>>(P, cam, pts, radius, Vinv, gp, tile_part);
+    else k_lin_obs<4><<<g, kBlock, 0, st>>>(P, cam, pts, radius, Vinv, gp, tile_part);
+    if (P.n_diag_items) {
+      const int gd = tile_blocks(P.n_diag_items);
+      if (P.pd == 3) k_schur_diag<3><<<gd, kBlock, 0, st>>>(P, Vinv, gp, rb.S, rb.rhs, rb.colsq, rb.gc);
+      else k_schur_diag<4><<<gd, kBlock, 0, st>>>(P, Vinv, gp, rb.S, rb.rhs, rb.colsq, rb.gc);
+    }
+    if (P.n_blk_items) {
+      const int gb = tile_blocks(P.n_blk_items);
+      if (P.pd == 3) k_schur_blocks<3><<<gb, kBlock, 0, st>>>(P, Vinv, rb.S);
+      else k_schur_blocks<4><<<gb, kBlock, 0, st>>>(P, Vinv, rb.S);
+    }
+    return;
+  }
   // camera part of the reduced system: shifted by the intrinsics slots
   double* Sc = rb.S + (size_t)P.ni * P.n + P.ni;
   double* rhs_c = rb.rhs + P.ni; double* colsq_c = rb.colsq + P.ni; double* gc_c = rb.gc + P.ni;

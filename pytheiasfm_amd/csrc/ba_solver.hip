@@ -103,6 +103,10 @@ struct theia_ba_handle_s {
   DevBuf<double2> obs_uv, obs_si;
   DevBuf<double> reduce, Vinv, gp, tile_part, scalB, chol_work;
   DevBuf<long long> stamps;
+  DevBuf<double> rec;                       // per-observation records of the gather-based Schur assembly
+  DevBuf<int> diag_items, cam_obs, blk_items;
+  DevBuf<int2> blk_pairs;
+  int n_diag_items = 0, n_blk_items = 0;
   double* h_scal = nullptr;  // pinned: [scalA(16) | scalB(16)]
   int cur = 0;
   bool have_scale = false;
@@ -205,6 +209,8 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.long_nobs = h->long_nobs; P.long_ntracks = h->long_ntracks;
   P.long_obs_index = h->long_obs_index.p; P.long_obs_slot = h->long_obs_slot.p;
   P.long_track_start = h->long_track_start.p; P.long_track_pt = h->long_track_pt.p;
+  P.rec = h->rec.p; P.n_diag_items = h->n_diag_items; P.n_blk_items = h->n_blk_items;
+  P.diag_items = h->diag_items.p; P.cam_obs = h->cam_obs.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
 }
 
 int upload_parameters(theia_ba_handle_s* h, const theia_ba_problem* p) {
@@ -576,6 +582,80 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     h->plan = chol_plan_create(h->n, h->tile_adj.data());
   }
   if (getenv("THEIA_HIP_STAMPS")) AL(stamps, 16);
+  if (h->ni == 0 && h->ncv > 0 && h->ntiles_main > 0 && !getenv("THEIA_HIP_LINEARIZE_ATOMIC")) {
+    // Static gather lists of the Schur assembly (k_schur_diag / k_schur_blocks):
+    // per reduced camera its observations, per camera pair (ri > rj) the
+    // (observation of ri, observation of rj) pairs of their common variable
+    // tracks.  Tracks of the slow path (> 64 observations) assemble themselves.
+    const int64_t nm = h->nobs_main;
+    std::vector<char> is_long(nm, 0);
+    for (int s2 : l_obs) is_long[s2] = 1;
+    std::vector<int> red(nm);
+    for (int64_t s = 0; s < nm; ++s) red[s] = is_long[s] ? -1 : h->cam_red[ocam[s]];
+    constexpr int kChunk = 1024;
+    std::vector<int> dbeg(h->ncv + 1, 0);
+    for (int64_t s = 0; s < nm; ++s) if (red[s] >= 0) dbeg[red[s] + 1]++;
+    for (int c = 0; c < h->ncv; ++c) dbeg[c + 1] += dbeg[c];
+    std::vector<int> cam_obs(dbeg[h->ncv]);
+    {
+      std::vector<int> f(dbeg.begin(), dbeg.end() - 1);
+      for (int64_t s = 0; s < nm; ++s) if (red[s] >= 0) cam_obs[f[red[s]]++] = (int)s;
+    }
+    std::vector<int> ditems;
+    for (int c = 0; c < h->ncv; ++c) {
+      const int nchunk = (dbeg[c + 1] - dbeg[c] + kChunk - 1) / kChunk;
+      for (int k = 0; k < nchunk; ++k) {
+        ditems.push_back(c); ditems.push_back(dbeg[c] + k * kChunk);
+        ditems.push_back(std::min(dbeg[c + 1], dbeg[c] + (k + 1) * kChunk)); ditems.push_back(nchunk > 1 ? 1 : 0);
+      }
+    }
+    // pairs, bucketed by row camera then sorted by column camera
+    std::vector<int64_t> rbeg(h->ncv + 1, 0);
+    auto for_each_pair = [&](auto&& fn) {
+      for (int64_t s0 = 0; s0 < nm;) {
+        int64_t s1 = s0 + 1;
+        while (s1 < nm && opt[s1] == opt[s0]) ++s1;
+        if (!is_long[s0] && !h->pt_const[opt[s0]])
+          for (int64_t a = s0; a < s1; ++a) {
+            if (red[a] < 0) continue;
+            for (int64_t b = s0; b < s1; ++b)
+              if (red[b] >= 0 && (red[a] > red[b] || (red[a] == red[b] && a != b))) fn((int)a, (int)b);
+          }
+        s0 = s1;
+      }
+    };
+    for_each_pair([&](int a, int) { rbeg[red[a] + 1]++; });
+    for (int c = 0; c < h->ncv; ++c) rbeg[c + 1] += rbeg[c];
+    if (rbeg[h->ncv] > (int64_t)std::numeric_limits<int>::max() - 64)
+      return set_error(THEIA_HIP_ERR_UNSUPPORTED, "too many camera pairs for 32-bit pair lists");
+    std::vector<int2> pairs(rbeg[h->ncv]);
+    {
+      std::vector<int64_t> f(rbeg.begin(), rbeg.end() - 1);
+      for_each_pair([&](int a, int b) { pairs[f[red[a]]++] = make_int2(a, b); });
+    }
+    std::vector<int> bitems;
+    for (int c = 0; c < h->ncv; ++c) {
+      std::sort(pairs.begin() + rbeg[c], pairs.begin() + rbeg[c + 1], [&](const int2& x, const int2& y) {
+        if (red[x.y] != red[y.y]) return red[x.y] < red[y.y];
+        return x.x != y.x ? x.x < y.x : x.y < y.y;
+      });
+      for (int64_t q = rbeg[c]; q < rbeg[c + 1];) {
+        int64_t e = q + 1;
+        const int rj = red[pairs[q].y];
+        while (e < rbeg[c + 1] && red[pairs[e].y] == rj) ++e;
+        const int nchunk = (int)((e - q + kChunk - 1) / kChunk);
+        for (int k = 0; k < nchunk; ++k) {
+          bitems.push_back(c); bitems.push_back(rj); bitems.push_back((int)(q + (int64_t)k * kChunk));
+          bitems.push_back((int)std::min<int64_t>(e, q + (int64_t)(k + 1) * kChunk));
+          bitems.push_back((nchunk > 1 || rj == c) ? 1 : 0);
+        }
+        q = e;
+      }
+    }
+    h->n_diag_items = (int)ditems.size() / 4; h->n_blk_items = (int)bitems.size() / 5;
+    UP(diag_items, ditems); UP(cam_obs, cam_obs); UP(blk_items, bitems); UP(blk_pairs, pairs);
+    AL(rec, (size_t)nm * (6 * h->pd + 14));
+  }
 #undef UP
 #undef AL
   fill_devproblem(h);
