@@ -49,12 +49,12 @@ struct DevProblem {
   const double* scale_red;     // [n] Jacobi scaling by reduced index (finalize)
   // gather-based Schur assembly (k_lin_obs + k_schur_diag + k_schur_blocks), ni == 0:
   // static lists built at create(); null = LDS-window / atomic k_linearize
-  double* rec;                 // [nobs_main][6*pd + 14] per-observation record {W | Jc | r}
+  double* rec;                 // [#records][12*pd + 20] per-observation record {W | T | F | r | T g}, camera-major
+  const int* rec_slot;         // [nobs_main] record slot of a (sorted) observation, -1 = none
   int n_diag_items, n_blk_items;
-  const int* diag_items;       // [n_diag_items][4] {rc, beg, end, atomic}
-  const int* cam_obs;          // observation (sorted index) lists per reduced camera
+  const int* diag_items;       // [n_diag_items][4] {rc, first slot, end slot, atomic}
   const int* blk_items;        // [n_blk_items][5] {ri, rj, beg, end, atomic}
-  const int2* blk_pairs;       // (obs a of camera ri, obs b of camera rj) of a common track
+  const int2* blk_pairs;       // (slot of the obs of camera ri, slot of the obs of camera rj) of a common track
 };
 
 // Per-iteration reduced-system workspace: one contiguous buffer so that a

@@ -605,7 +605,8 @@ __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double
 // Lanes accumulate in registers and a shuffle reduce-scatter leaves element e
 // of the block in lane(e): no atomics (except for lists split into chunks),
 // fixed summation order, each S entry written once.
-template <int PD> constexpr int rec_stride() { return 6 * PD + 14; }
+// record of one observation: {W (6 x PD) | T = W V^-1 (6 x PD) | F (2 x 6) | r (2) | T g_p (6)}
+template <int PD> constexpr int rec_stride() { return 12 * PD + 20; }
 
 template <int PD>
 __global__ __launch_bounds__(kBlock) void k_lin_obs(DevProblem P, const double* __restrict__ cam,
@@ -622,6 +623,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_obs(DevProblem P, const double* 
   const int start = P.tile_start[tile];
   LaneLin<PD> L;
   lane_linearize<PD, true>(P, cam, pts, start + lane, lane < cnt, lane, L);
+  const int slot = (lane < cnt) ? P.rec_slot[start + lane] : -1;
   const Segment sg = lane_segment(L.p, lane);
   double in[NT + PD], tot[NT + PD];
 #pragma unroll
@@ -631,40 +633,63 @@ __global__ __launch_bounds__(kBlock) void k_lin_obs(DevProblem P, const double* 
     in[NT + a] = L.Jt[a] * L.r[0] + L.Jt[PD + a] * L.r[1];
   }
   segment_allsum<NT + PD>(sg, in, tot);
-  double gmax = 0.0;
+  // every lane of the track inverts the same V (lock-step anyway), no broadcast needed
+  double V[NT], Vi[NT], g[PD];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) V[k] = tot[k];
+#pragma unroll
+  for (int a = 0; a < PD; ++a) { g[a] = tot[NT + a]; V[lidx(a, a)] += fmin(fmax(V[lidx(a, a)], 1e-6), 1e32) / radius; }
   bool pd_ok = true;
+  if (L.active && !L.pconst) pd_ok = invert_spd<PD>(V, Vi);
+  if (!L.active || L.pconst || !pd_ok) {
+#pragma unroll
+    for (int k = 0; k < NT; ++k) Vi[k] = 0.0;
+  }
+  double gmax = 0.0;
   if (L.active && sg.head && !L.pconst) {
-    double V[NT], Vi[NT];
 #pragma unroll
-    for (int k = 0; k < NT; ++k) V[k] = tot[k];
-#pragma unroll
-    for (int a = 0; a < PD; ++a) V[lidx(a, a)] += fmin(fmax(V[lidx(a, a)], 1e-6), 1e32) / radius;
-    pd_ok = invert_spd<PD>(V, Vi);
-#pragma unroll
-    for (int k = 0; k < NT; ++k) Vinv[(size_t)NT * L.p + k] = pd_ok ? Vi[k] : 0.0;
+    for (int k = 0; k < NT; ++k) Vinv[(size_t)NT * L.p + k] = Vi[k];
 #pragma unroll
     for (int a = 0; a < PD; ++a) {
-      gp[(size_t)PD * L.p + a] = tot[NT + a];
-      gmax = fmax(gmax, fabs(tot[NT + a] / P.scale_p[(size_t)PD * L.p + a]));
+      gp[(size_t)PD * L.p + a] = g[a];
+      gmax = fmax(gmax, fabs(g[a] / P.scale_p[(size_t)PD * L.p + a]));
     }
   }
-  if (L.active && L.rc >= 0) {
-    double2* R = reinterpret_cast<double2*>(P.rec + (size_t)(start + lane) * RS);
-    double w[NW];
+  if (slot >= 0) {
+    double2* R = reinterpret_cast<double2*>(P.rec + (size_t)slot * RS);
+    double w[NW], t[NW], tg[6];
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
       for (int b = 0; b < PD; ++b) w[a * PD + b] = L.Jc[a] * L.Jt[b] + L.Jc[6 + a] * L.Jt[PD + b];
 #pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int b = 0; b < PD; ++b) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < PD; ++k) s += w[a * PD + k] * sym_get<PD>(Vi, k, b);
+        t[a * PD + b] = s;
+      }
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < PD; ++k) s += t[a * PD + k] * g[k];
+      tg[a] = s;
+    }
+#pragma unroll
     for (int k = 0; k < NW / 2; ++k) R[k] = make_double2(w[2 * k], w[2 * k + 1]);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) R[NW / 2 + k] = make_double2(L.Jc[2 * k], L.Jc[2 * k + 1]);
-    R[NW / 2 + 6] = make_double2(L.r[0], L.r[1]);
+    for (int k = 0; k < NW / 2; ++k) R[NW / 2 + k] = make_double2(t[2 * k], t[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) R[NW + k] = make_double2(L.Jc[2 * k], L.Jc[2 * k + 1]);
+    R[NW + 6] = make_double2(L.r[0], L.r[1]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) R[NW + 7 + k] = make_double2(tg[2 * k], tg[2 * k + 1]);
   }
   const double cost = wave_sum(L.cost);
   gmax = wave_max(gmax);
   const double inval = wave_sum((L.active && !L.valid) ? 1.0 : 0.0);
-  const double npd = wave_sum((L.active && !pd_ok) ? 1.0 : 0.0);
+  const double npd = wave_sum((L.active && !pd_ok && sg.head) ? 1.0 : 0.0);
   if (lane == 0) {
     tile_part[4 * (size_t)tile + 0] = cost;
     tile_part[4 * (size_t)tile + 1] = gmax;
@@ -698,51 +723,40 @@ THIP_DEV double wave_reduce_scatter(double (&v)[N], int lane, int& lo, int& cnt)
   }
 }
 
-template <int PD>
-THIP_DEV void load_w(const double* __restrict__ rec, int o, double (&w)[6 * PD]) {
-  const double2* R = reinterpret_cast<const double2*>(rec + (size_t)o * rec_stride<PD>());
-#pragma unroll
-  for (int k = 0; k < 3 * PD; ++k) { const double2 t = R[k]; w[2 * k] = t.x; w[2 * k + 1] = t.y; }
+// the four waves of a workgroup share one list; combine their totals in wave order
+template <int N>
+THIP_DEV double block_combine(double (*part)[N + 1], double tot, int lo, int cnt, int wv, int tid) {
+  if (cnt > 0) part[wv][lo] = tot;
+  __syncthreads();
+  return (tid < N) ? ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) : 0.0;
 }
 
+template <int PD, int K>
+THIP_DEV void load_rec(const double* __restrict__ rec, int slot, int off2, double (&w)[K]) {
+  const double2* R = reinterpret_cast<const double2*>(rec + (size_t)slot * rec_stride<PD>()) + off2;
+#pragma unroll
+  for (int k = 0; k < K / 2; ++k) { const double2 t = R[k]; w[2 * k] = t.x; w[2 * k + 1] = t.y; }
+}
+
+// one workgroup per (camera, chunk of its contiguous records)
 template <int PD>
-__global__ __launch_bounds__(kBlock) void k_schur_diag(DevProblem P, const double* __restrict__ Vinv,
-                                                       const double* __restrict__ gp, double* __restrict__ S,
+__global__ __launch_bounds__(kBlock) void k_schur_diag(DevProblem P, double* __restrict__ S,
                                                        double* __restrict__ rhs, double* __restrict__ colsq,
                                                        double* __restrict__ gc) {
-  constexpr int NT = PD * (PD + 1) / 2;
   constexpr int NW = 6 * PD;
-  const int lane = threadIdx.x & 63;
-  const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  if (item >= P.n_diag_items) return;
-  const int* it = P.diag_items + 4 * item;
+  __shared__ double part[kWavesPerBlock][40];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int* it = P.diag_items + 4 * blockIdx.x;
   const int rc = it[0], beg = it[1], end = it[2], atomic = it[3];
   double acc[39];
 #pragma unroll
   for (int k = 0; k < 39; ++k) acc[k] = 0.0;
-  for (int q = beg + lane; q < end; q += 64) {
-    const int o = P.cam_obs[q];
-    const int p = P.obs_pt[o];
-    double W[NW], T[NW], Vi[NT], g[PD], Jc[12];
-    load_w<PD>(P.rec, o, W);
-    const double2* R = reinterpret_cast<const double2*>(P.rec + (size_t)o * rec_stride<PD>()) + NW / 2;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { const double2 t = R[k]; Jc[2 * k] = t.x; Jc[2 * k + 1] = t.y; }
-    const double2 r = R[6];
-    const bool pc = P.pt_const[p] != 0;
-#pragma unroll
-    for (int k = 0; k < NT; ++k) Vi[k] = pc ? 0.0 : Vinv[(size_t)NT * p + k];
-#pragma unroll
-    for (int k = 0; k < PD; ++k) g[k] = pc ? 0.0 : gp[(size_t)PD * p + k];
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int b = 0; b < PD; ++b) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < PD; ++k) s += W[a * PD + k] * sym_get<PD>(Vi, k, b);
-        T[a * PD + b] = s;
-      }
+  for (int q = beg + tid; q < end; q += kBlock) {
+    double W[NW], T[NW], Jc[12], rt[8];
+    load_rec<PD>(P.rec, q, 0, W);
+    load_rec<PD>(P.rec, q, NW / 2, T);
+    load_rec<PD>(P.rec, q, NW, Jc);
+    load_rec<PD>(P.rec, q, NW + 6, rt);   // r (2) | T g (6)
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
 #pragma unroll
@@ -752,61 +766,44 @@ __global__ __launch_bounds__(kBlock) void k_schur_diag(DevProblem P, const doubl
         for (int k = 0; k < PD; ++k) s -= T[a * PD + k] * W[b * PD + k];
         acc[lidx(a, b)] += s;
       }
-      const double jr = Jc[a] * r.x + Jc[6 + a] * r.y;
-      double tg = 0.0;
-#pragma unroll
-      for (int k = 0; k < PD; ++k) tg += T[a * PD + k] * g[k];
-      acc[21 + a] += jr - tg;
+      const double jr = Jc[a] * rt[0] + Jc[6 + a] * rt[1];
+      acc[21 + a] += jr - rt[2 + a];
       acc[27 + a] += jr;
       acc[33 + a] += Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a];
     }
   }
   int lo = 0, cnt = 39;
-  const double tot = wave_reduce_scatter<39, 32>(acc, lane, lo, cnt);
-  if (cnt <= 0) return;
+  double tot = wave_reduce_scatter<39, 32>(acc, lane, lo, cnt);
+  tot = block_combine<39>(part, tot, lo, cnt, wv, tid);
+  if (tid >= 39) return;
   double* dst;
-  if (lo < 21) {
+  if (tid < 21) {
     int a = 0;
-    while ((a + 1) * (a + 2) / 2 <= lo) ++a;
-    const int b = lo - a * (a + 1) / 2;
+    while ((a + 1) * (a + 2) / 2 <= tid) ++a;
+    const int b = tid - a * (a + 1) / 2;
     dst = S + (size_t)(6 * rc + a) * P.n + 6 * rc + b;
   } else {
-    const int q = (lo - 21) % 6;
-    dst = (lo < 27 ? rhs : (lo < 33 ? gc : colsq)) + 6 * rc + q;
+    dst = (tid < 27 ? rhs : (tid < 33 ? gc : colsq)) + 6 * rc + (tid - 21) % 6;
   }
   if (atomic) atomic_add(dst, tot); else *dst = tot;
 }
 
+// one workgroup per (block (ri, rj), chunk of its pair list)
 template <int PD>
-__global__ __launch_bounds__(kBlock) void k_schur_blocks(DevProblem P, const double* __restrict__ Vinv,
-                                                         double* __restrict__ S) {
-  constexpr int NT = PD * (PD + 1) / 2;
+__global__ __launch_bounds__(kBlock) void k_schur_blocks(DevProblem P, double* __restrict__ S) {
   constexpr int NW = 6 * PD;
-  const int lane = threadIdx.x & 63;
-  const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  if (item >= P.n_blk_items) return;
-  const int* it = P.blk_items + 5 * item;
+  __shared__ double part[kWavesPerBlock][37];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int* it = P.blk_items + 5 * blockIdx.x;
   const int ri = it[0], rj = it[1], beg = it[2], end = it[3], atomic = it[4];
   double acc[36];
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-  for (int q = beg + lane; q < end; q += 64) {
+  for (int q = beg + tid; q < end; q += kBlock) {
     const int2 ab = P.blk_pairs[q];
-    const int p = P.obs_pt[ab.x];
-    double Wa[NW], Wb[NW], T[NW], Vi[NT];
-    load_w<PD>(P.rec, ab.x, Wa);
-    load_w<PD>(P.rec, ab.y, Wb);
-#pragma unroll
-    for (int k = 0; k < NT; ++k) Vi[k] = Vinv[(size_t)NT * p + k];
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int b = 0; b < PD; ++b) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < PD; ++k) s += Wa[a * PD + k] * sym_get<PD>(Vi, k, b);
-        T[a * PD + b] = s;
-      }
+    double T[NW], Wb[NW];
+    load_rec<PD>(P.rec, ab.x, NW / 2, T);
+    load_rec<PD>(P.rec, ab.y, 0, Wb);
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -818,9 +815,10 @@ __global__ __launch_bounds__(kBlock) void k_schur_blocks(DevProblem P, const dou
       }
   }
   int lo = 0, cnt = 36;
-  const double tot = wave_reduce_scatter<36, 32>(acc, lane, lo, cnt);
-  if (cnt <= 0) return;
-  const int a = lo / 6, b = lo % 6;
+  double tot = wave_reduce_scatter<36, 32>(acc, lane, lo, cnt);
+  tot = block_combine<36>(part, tot, lo, cnt, wv, tid);
+  if (tid >= 36) return;
+  const int a = tid / 6, b = tid % 6;
   if (ri == rj && b > a) return;   // two observations of one camera in a track: lower part of the diagonal block
   double* dst = S + (size_t)(6 * ri + a) * P.n + 6 * rj + b;
   if (atomic) atomic_add(dst, -tot); else *dst = -tot;
@@ -1337,14 +1335,12 @@ void launch_linearize(const DevProblem& P, const double* cam, const double* pts,
     if (P.pd == 3) k_lin_obs<3><<<g, kBlock, 0, st>>>(P, cam, pts, radius, Vinv, gp, tile_part);
     else k_lin_obs<4><<<g, kBlock, 0, st>>>(P, cam, pts, radius, Vinv, gp, tile_part);
     if (P.n_diag_items) {
-      const int gd = tile_blocks(P.n_diag_items);
-      if (P.pd == 3) k_schur_diag<3><<<gd, kBlock, 0, st>>>(P, Vinv, gp, rb.S, rb.rhs, rb.colsq, rb.gc);
-      else k_schur_diag<4><<<gd, kBlock, 0, st>>>(P, Vinv, gp, rb.S, rb.rhs, rb.colsq, rb.gc);
+      if (P.pd == 3) k_schur_diag<3><<<P.n_diag_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc);
+      else k_schur_diag<4><<<P.n_diag_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc);
     }
     if (P.n_blk_items) {
-      const int gb = tile_blocks(P.n_blk_items);
-      if (P.pd == 3) k_schur_blocks<3><<<gb, kBlock, 0, st>>>(P, Vinv, rb.S);
-      else k_schur_blocks<4><<<gb, kBlock, 0, st>>>(P, Vinv, rb.S);
+      if (P.pd == 3) k_schur_blocks<3><<<P.n_blk_items, kBlock, 0, st>>>(P, rb.S);
+      else k_schur_blocks<4><<<P.n_blk_items, kBlock, 0, st>>>(P, rb.S);
     }
     return;
   }

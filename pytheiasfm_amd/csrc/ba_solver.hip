@@ -210,7 +210,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.long_obs_index = h->long_obs_index.p; P.long_obs_slot = h->long_obs_slot.p;
   P.long_track_start = h->long_track_start.p; P.long_track_pt = h->long_track_pt.p;
   P.rec = h->rec.p; P.n_diag_items = h->n_diag_items; P.n_blk_items = h->n_blk_items;
-  P.diag_items = h->diag_items.p; P.cam_obs = h->cam_obs.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
+  P.diag_items = h->diag_items.p; P.rec_slot = h->cam_obs.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
 }
 
 int upload_parameters(theia_ba_handle_s* h, const theia_ba_problem* p) {
@@ -592,14 +592,15 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     for (int s2 : l_obs) is_long[s2] = 1;
     std::vector<int> red(nm);
     for (int64_t s = 0; s < nm; ++s) red[s] = is_long[s] ? -1 : h->cam_red[ocam[s]];
-    constexpr int kChunk = 1024;
+    constexpr int kChunk = 2048;
     std::vector<int> dbeg(h->ncv + 1, 0);
     for (int64_t s = 0; s < nm; ++s) if (red[s] >= 0) dbeg[red[s] + 1]++;
     for (int c = 0; c < h->ncv; ++c) dbeg[c + 1] += dbeg[c];
-    std::vector<int> cam_obs(dbeg[h->ncv]);
+    // records are stored camera-major: slot of observation s = its rank in its camera's list
+    std::vector<int> cam_obs(nm, -1);   // = rec_slot
     {
       std::vector<int> f(dbeg.begin(), dbeg.end() - 1);
-      for (int64_t s = 0; s < nm; ++s) if (red[s] >= 0) cam_obs[f[red[s]]++] = (int)s;
+      for (int64_t s = 0; s < nm; ++s) if (red[s] >= 0) cam_obs[s] = f[red[s]]++;
     }
     std::vector<int> ditems;
     for (int c = 0; c < h->ncv; ++c) {
@@ -653,8 +654,9 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
       }
     }
     h->n_diag_items = (int)ditems.size() / 4; h->n_blk_items = (int)bitems.size() / 5;
+    for (auto& pr : pairs) { pr.x = cam_obs[pr.x]; pr.y = cam_obs[pr.y]; }
     UP(diag_items, ditems); UP(cam_obs, cam_obs); UP(blk_items, bitems); UP(blk_pairs, pairs);
-    AL(rec, (size_t)nm * (6 * h->pd + 14));
+    AL(rec, (size_t)std::max(1, dbeg[h->ncv]) * (12 * h->pd + 20));
   }
 #undef UP
 #undef AL

@@ -41,115 +41,188 @@ __device__ __forceinline__ void wave_gemm32(FA Aop, FB Bop, double4_t (&acc)[2][
   }
 }
 
-// column-Crout over columns [J0, J0 + 32) of the rows held one per lane; the dot
-// products run over k in [K0, j).  rdiag[j] = 1 / L[j][j].
-template <int J0, int K0>
-__device__ __forceinline__ void crout32(double (&row)[NB], double (&rdiag)[NB], int i, int* bad) {
+// 16 x 16 x 16 product on the matrix core (4 MFMAs), accumulated onto c.
+template <typename FA, typename FB>
+__device__ __forceinline__ double4_t wave_gemm16(FA Aop, FB Bop, double4_t c, int lane) {
+  const int li = lane & 15, lk = lane >> 4;
 #pragma unroll
-  for (int j = J0; j < J0 + 32; ++j) {
-    double s[8];
-    s[0] = row[j];
-#pragma unroll
-    for (int q = 1; q < 8; ++q) s[q] = 0.0;
-#pragma unroll
-    for (int k = K0; k < j; ++k) s[(k - K0) & 7] -= row[k] * readlane_d(row[k], j);
-    const double sj = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-    double d = readlane_d(sj, j);
-    if (!(d > 0.0)) { *bad = 1; d = 1.0; }
-    // hardware v_rsq_f64 seed + two Newton steps (full FP64), no sqrt / divide
-    double rinv = __builtin_amdgcn_rsq(d);
-    rinv = rinv * (1.5 - (0.5 * d) * (rinv * rinv));
-    rinv = rinv * (1.5 - (0.5 * d) * (rinv * rinv));
-    rdiag[j] = rinv;
-    row[j] = (i == j) ? d * rinv : (i > j ? sj * rinv : 0.0);
-  }
+  for (int kk = 0; kk < 16; kk += 4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(Aop(li, kk + lk), Bop(kk + lk, li), c, 0, 0, 0);
+  return c;
 }
 
 // One wavefront: factor the diagonal block at k0 (nb <= 64 valid rows; the rest
 // is padded with the identity), write L11 back, and write L11^-1 (64 x 64,
-// row-major, zero upper part) to Linv.  Two-level recursion on 32-blocks
-//   L = [A 0; B C]:  Crout on columns 0..31 (all 64 lanes: A and B = A21 A^-T),
-//   C -= B B^T on the matrix core, Crout on columns 32..63 (dot products over
-//   32..j only);  L^-1 = [A^-1 0; -C^-1 B A^-1  C^-1] with the two 32x32
-//   triangular inverses formed by the two half-waves at once.
+// row-major, zero upper part) to Linv.
+//
+// The block lives in LDS; lane i owns row i.  Right-looking over four 16-wide
+// panels: the lane loads its 16 panel entries into registers, a rank-1 sweep
+// (pivot row broadcast with v_readlane, one rsqrt per column) produces the
+// diagonal 16x16 factor AND the rows below it at once, and the trailing
+// 16x16 tiles are updated on the FP64 matrix core.  L^-1 is built bottom-up:
+// the four 16x16 triangular inverses by quarter-waves, then
+//   [A 0; B C]^-1 = [A^-1 0; -C^-1 B A^-1  C^-1]
+// at 32 and at 64 with MFMA products.  The code is small (16-wide unrolling
+// only): a single wave executes it once per launch, so instruction fetch and
+// register spills, not arithmetic, were what the older 32-wide version paid for.
 __device__ __forceinline__ void potrf64_wave(double* __restrict__ A, int lda, int k0, int nb,
                                              double* __restrict__ Linv, double* __restrict__ fail_flag) {
   __shared__ double Ls[NB][LDP];
   __shared__ double Zs[NB][LDP];
+  __shared__ double rdiag[NB];
   const int i = threadIdx.x;
-  // coalesced load: one 512-B row per instruction, then lane i picks up row i
+  const int li = i & 15, lk = i >> 4;
+#ifdef THIP_POTRF_STAMPS
+  long long tq_ = clock64();
+#define PSTAMP(k_) do { const long long tn_ = clock64(); if (i == 0) THIP_POTRF_STAMPS[k_] = tn_ - tq_; tq_ = tn_; } while (0)
+  long long tsub_[3] = {0, 0, 0}, tp_ = 0;
+#define PSUB(k_) do { const long long tn_ = clock64(); tsub_[k_] += tn_ - tp_; tp_ = tn_; } while (0)
+#define PSUB0() do { tp_ = clock64(); } while (0)
+#else
+#define PSTAMP(k_) do {} while (0)
+#define PSUB(k_) do {} while (0)
+#define PSUB0() do {} while (0)
+#endif
+  // coalesced load: one 512-B row per instruction.  The loads are UNCONDITIONAL
+  // (clamped address, value selected afterwards): a predicated load compiles to
+  // branch + load + s_waitcnt per row, i.e. 64 serialised memory round trips.
+  {
+    const int ic = min(i, nb - 1);
+#pragma unroll
+    for (int rb = 0; rb < NB; rb += 16) {
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = A[(size_t)(k0 + min(rb + q, nb - 1)) * lda + k0 + ic];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int r = rb + q;
+        Ls[r][i] = (r < nb && i <= r) ? v[q] : ((r == i) ? 1.0 : 0.0);
+        Zs[r][i] = 0.0;
+      }
+    }
+  }
+  __syncthreads();
+  PSTAMP(0);
+  int bad = 0;
+  for (int p = 0; p < 4; ++p) {
+    const int c0 = 16 * p;
+    PSUB0();
+    double r16[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) r16[j] = Ls[i][c0 + j];
+    PSUB(0);
+    // right-looking inside the panel with the scaling deferred: the rank-1
+    // update of column j uses s_ij s_kj / d_j, so the per-column dependent chain
+    // is pivot -> 1/d -> one multiply -> one FMA; the rsqrt needed for
+    // L = s / sqrt(d) is computed off that chain and applied at the end.
+    double rs[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      double d = readlane_d(r16[j], c0 + j);
+      if (!(d > 0.0)) { bad = 1; d = 1.0; }
+      double w = __builtin_amdgcn_rcp(d);
+      w = __builtin_fma(w, __builtin_fma(-d, w, 1.0), w);
+      w = __builtin_fma(w, __builtin_fma(-d, w, 1.0), w);
+      const double t = r16[j] * w;
+#pragma unroll
+      for (int k = j + 1; k < 16; ++k) r16[k] = __builtin_fma(-t, readlane_d(r16[j], c0 + k), r16[k]);
+      rs[j] = d;
+    }
+    // 16 independent rsqrt refinements (v_rsq_f64 seed + two Newton steps, full
+    // FP64, no sqrt / divide): kept out of the in-order sweep above
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const double d = rs[j];
+      double rinv = __builtin_amdgcn_rsq(d);
+      rinv = rinv * (1.5 - (0.5 * d) * (rinv * rinv));
+      rinv = rinv * (1.5 - (0.5 * d) * (rinv * rinv));
+      rs[j] = rinv;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (i == 0) rdiag[c0 + j] = rs[j];
+      r16[j] = (i >= c0 + j) ? r16[j] * rs[j] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Ls[i][c0 + j] = r16[j];
+    __syncthreads();
+    PSUB(1);
+    // trailing tiles (ti >= tj > p):  C -= L[ti][p] L[tj][p]^T
+    for (int ti = p + 1; ti < 4; ++ti)
+      for (int tj = p + 1; tj <= ti; ++tj) {
+        double4_t c;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) c[reg] = Ls[16 * ti + lk + 4 * reg][16 * tj + li];
+        c = wave_gemm16([&](int r, int k) { return -Ls[16 * ti + r][c0 + k]; },
+                        [&](int k, int cc) { return Ls[16 * tj + cc][c0 + k]; }, c, i);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) Ls[16 * ti + lk + 4 * reg][16 * tj + li] = c[reg];
+      }
+    __syncthreads();
+    PSUB(2);
+  }
+  PSTAMP(1);
+#ifdef THIP_POTRF_STAMPS
+  if (i == 0) { THIP_POTRF_STAMPS[8] = tsub_[0]; THIP_POTRF_STAMPS[9] = tsub_[1]; THIP_POTRF_STAMPS[10] = tsub_[2]; }
+#endif
 #pragma unroll 16
   for (int r = 0; r < NB; ++r)
-    Ls[r][i] = (r < nb && i <= r) ? A[(size_t)(k0 + r) * lda + k0 + i] : ((r == i) ? 1.0 : 0.0);
-  __syncthreads();
-  double row[NB], rdiag[NB];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) row[j] = Ls[i][j];
-  int bad = 0;
-  crout32<0, 0>(row, rdiag, i, &bad);
-  // B = rows 32..63, columns 0..31 -> LDS;  C -= B B^T
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 32; ++j) Ls[i][j] = row[j];
-  __syncthreads();
-  {
-    double4_t acc[2][2];
-    wave_gemm32([&](int r, int k) { return Ls[32 + r][k]; }, [&](int k, int c) { return Ls[32 + c][k]; }, acc, i);
-    const int li = i & 15, lk = i >> 4;
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-      for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) Zs[16 * ti + lk + 4 * reg][16 * tj + li] = acc[ti][tj][reg];
-  }
-  __syncthreads();
-  if (i >= 32) {
-#pragma unroll
-    for (int j = 32; j < NB; ++j) row[j] -= Zs[i - 32][j - 32];
-  }
-  crout32<32, 32>(row, rdiag, i, &bad);
-  if (i < nb) {
-#pragma unroll
-    for (int j = 0; j < NB; ++j) if (j <= i) A[(size_t)(k0 + i) * lda + k0 + j] = row[j];
-  }
+    if (r < nb && i <= r) A[(size_t)(k0 + r) * lda + k0 + i] = Ls[r][i];
   if (bad && i == 0) unsafeAtomicAdd(fail_flag, 1.0);
-  __syncthreads();
-#pragma unroll
-  for (int j = 32; j < NB; ++j) Ls[i][j] = row[j];
-  __syncthreads();
-  // triangular inverses of A (lanes 0..31) and C (lanes 32..63): lane owns a column
-  const int h = i >> 5, c = i & 31;
-  double z[32];
-#pragma unroll
-  for (int r = 0; r < 32; ++r) {
-    double s[4];
-    s[0] = (r == c) ? 1.0 : 0.0;
-    s[1] = s[2] = s[3] = 0.0;
-#pragma unroll
-    for (int k = 0; k < r; ++k) s[k & 3] -= Ls[32 * h + r][32 * h + k] * z[k];
-    const double sr = (s[0] + s[1]) + (s[2] + s[3]);
-    z[r] = sr * (h ? rdiag[32 + r] : rdiag[r]);
-  }
-  // Zs <- [A^-1 0; 0 C^-1]
-#pragma unroll
-  for (int r = 0; r < 32; ++r) { Zs[32 * h + r][32 * h + c] = z[r]; Zs[32 * h + r][32 * (1 - h) + c] = 0.0; }
-  __syncthreads();
+  PSTAMP(2);
+  // ---- inverse: four 16 x 16 triangular inverses, lane (q, c) owns column c of block q
   {
-    // T = B A^-1  (B in Ls[32+r][k]),  Z21 = -C^-1 T
+    const int q = i >> 4, c = i & 15;
+    double z[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < r; ++k) {
+        const double t = Ls[16 * q + r][16 * q + k] * z[k];
+        if (k & 1) s1 -= t; else s0 -= t;
+      }
+      z[r] = (s0 + s1) * rdiag[16 * q + r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Zs[16 * q + r][16 * q + c] = z[r];
+  }
+  __syncthreads();
+  PSTAMP(3);
+  // ---- 32-level: Z[q1][q0] = -Z[q1][q1] (L[q1][q0] Z[q0][q0]) for (q0, q1) = (0, 1), (2, 3);
+  // the product T is parked in the (zero, unused) upper part of Ls
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int q0 = 2 * h, q1 = 2 * h + 1;
+    double4_t t = (double4_t){0.0, 0.0, 0.0, 0.0};
+    t = wave_gemm16([&](int r, int k) { return Ls[16 * q1 + r][16 * q0 + k]; },
+                    [&](int k, int cc) { return Zs[16 * q0 + k][16 * q0 + cc]; }, t, i);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) Ls[16 * q0 + lk + 4 * reg][16 * q1 + li] = t[reg];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int q0 = 2 * h, q1 = 2 * h + 1;
+    double4_t t = (double4_t){0.0, 0.0, 0.0, 0.0};
+    t = wave_gemm16([&](int r, int k) { return Zs[16 * q1 + r][16 * q1 + k]; },
+                    [&](int k, int cc) { return Ls[16 * q0 + k][16 * q1 + cc]; }, t, i);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) Zs[16 * q1 + lk + 4 * reg][16 * q0 + li] = -t[reg];
+  }
+  __syncthreads();
+  PSTAMP(4);
+  // ---- 64-level: Z21 = -Z22 (L21 Z11), 32 x 32 blocks; T parked in Ls[0..31][32..63]
+  {
     double4_t acc[2][2];
     wave_gemm32([&](int r, int k) { return Ls[32 + r][k]; }, [&](int k, int cc) { return Zs[k][cc]; }, acc, i);
-    const int li = i & 15, lk = i >> 4;
-    __syncthreads();
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) Ls[16 * ti + lk + 4 * reg][16 * tj + li] = acc[ti][tj][reg];  // T over the dead A
+        for (int reg = 0; reg < 4; ++reg) Ls[16 * ti + lk + 4 * reg][32 + 16 * tj + li] = acc[ti][tj][reg];
     __syncthreads();
-    wave_gemm32([&](int r, int k) { return Zs[32 + r][32 + k]; }, [&](int k, int cc) { return Ls[k][cc]; }, acc, i);
-    __syncthreads();
+    wave_gemm32([&](int r, int k) { return Zs[32 + r][32 + k]; }, [&](int k, int cc) { return Ls[k][32 + cc]; }, acc, i);
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -158,8 +231,13 @@ __device__ __forceinline__ void potrf64_wave(double* __restrict__ A, int lda, in
         for (int reg = 0; reg < 4; ++reg) Zs[32 + 16 * ti + lk + 4 * reg][16 * tj + li] = -acc[ti][tj][reg];
   }
   __syncthreads();
+  PSTAMP(5);
 #pragma unroll 16
   for (int r = 0; r < NB; ++r) Linv[r * NB + i] = Zs[r][i];
+  PSTAMP(6);
+#undef PSTAMP
+#undef PSUB
+#undef PSUB0
 }
 
 }  // namespace chol

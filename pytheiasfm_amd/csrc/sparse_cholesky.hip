@@ -49,12 +49,12 @@ __device__ __forceinline__ void load_tile(double (*T)[LDP], const double* __rest
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int t = tid + 256 * q, r = t >> 6, c = t & 63;
-    v[q] = (r < h && c < w) ? A[(size_t)(row0 + r) * lda + col0 + c] : 0.0;
+    v[q] = A[(size_t)(row0 + min(r, h - 1)) * lda + col0 + min(c, w - 1)];   // unconditional: no branch + wait per load
   }
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
-    const int t = tid + 256 * q;
-    T[t >> 6][t & 63] = v[q];
+    const int t = tid + 256 * q, r = t >> 6, c = t & 63;
+    T[r][c] = (r < h && c < w) ? v[q] : 0.0;
   }
 }
 
@@ -104,8 +104,7 @@ __global__ __launch_bounds__(256) void k_sp_update(double* __restrict__ A, int l
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int r = 16 * wv + lk + 4 * reg, c = 16 * q + li;
-      const bool ok = r < h && c < w && (!diag || c <= r);
-      cold[q][reg] = ok ? A[(size_t)(row0 + r) * lda + col0 + c] : 0.0;
+      cold[q][reg] = A[(size_t)(row0 + min(r, h - 1)) * lda + col0 + min(c, w - 1)];
     }
   }
   for (int s = sbeg; s < send; ++s) {
@@ -145,11 +144,14 @@ __global__ __launch_bounds__(256) void k_sp_back(const double* __restrict__ A, i
     __syncthreads();
     if (tid < NB) xs[tid] = (tid < h) ? x[row0 + tid] : 0.0;
     __syncthreads();
-    if (j < nb) {
-      const double* col = A + (size_t)row0 * lda + k0 + j;
-#pragma unroll 4
-      for (int r = ch * 16; r < ch * 16 + 16; ++r)
-        if (r < h) s += col[(size_t)r * lda] * xs[r];
+    {
+      // unconditional (clamped) loads; xs is zero beyond h and columns >= nb are dropped below
+      const double* col = A + (size_t)row0 * lda + k0 + min(j, nb - 1);
+      double v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = col[(size_t)min(ch * 16 + r, h - 1) * lda];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += v[r] * xs[ch * 16 + r];
     }
   }
   part[ch][j] = s;
