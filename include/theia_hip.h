@@ -337,6 +337,14 @@ int theia_hip_five_point_relative_pose(int32_t num, const double* corr,
 int theia_hip_pose_from_three_points(int32_t num, const double* corr2d3d,
                                      double* rotations, double* translations,
                                      int32_t* num_solutions);
+/* SQPnP (sfm/pose/sqpnp.h:58-77, bound in src/pytheia/sfm/sfm.cc:592), batched:
+ * problem i uses points [offsets[i], offsets[i+1]) of features[.][2] (normalised
+ * image coordinates) and world_points[.][3] (>= 3 points, else 0 solutions).
+ * Outputs per problem up to 18 solutions: quaternions[num][18][4] = [w x y z]
+ * (world -> camera rotation), translations[num][18][3], zero padded. */
+int theia_hip_sqpnp(int32_t num, const int64_t* offsets, const double* features,
+                    const double* world_points, double* quaternions,
+                    double* translations, int32_t* num_solutions);
 
 #ifdef __cplusplus
 }

@@ -105,7 +105,7 @@ EXPORTED_SYMBOLS = [
     "theia_hip_ba_destroy", "theia_hip_ba_evaluate", "theia_hip_ba_evaluate_ex", "theia_hip_ba_reduced_system",
     "theia_hip_ba_set_allreduce", "theia_hip_dense_spd_solve", "theia_ransac_params_default",
     "theia_hip_ransac_estimate_batch", "theia_hip_five_point_relative_pose",
-    "theia_hip_pose_from_three_points",
+    "theia_hip_pose_from_three_points", "theia_hip_sqpnp",
 ]
 
 _lib = None

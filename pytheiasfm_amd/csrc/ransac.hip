@@ -32,7 +32,11 @@
 namespace thip {
 namespace {
 
-constexpr int kMaxModels = 10;
+constexpr int kMaxCap = 18;   // largest EstimateModel output of any estimator (SQPnP: 18 solutions)
+// models per sample an estimator can return = slot stride of the per-hypothesis arrays
+__host__ __device__ inline int max_models(int est) {
+  return est == THEIA_EST_ABSOLUTE_POSE_SQPNP ? 18 : (est == THEIA_EST_ABSOLUTE_POSE_KNEIP ? 4 : 10);
+}
 constexpr int kStride = THEIA_RANSAC_MODEL_STRIDE;
 
 __host__ __device__ inline int sample_size(int est) {
@@ -72,6 +76,26 @@ __device__ int estimate_models(int est, const double* subset, double* models) {
     }
     return n;
   }
+  if (est == THEIA_EST_ABSOLUTE_POSE_SQPNP) {
+    // SQPnP on the 3 sampled correspondences; quaternion -> matrix as the estimator does
+    // (estimate_calibrated_absolute_pose.cc:99-106)
+    double feat[6], world[9], quats[72], ts[54];
+    for (int i = 0; i < 3; ++i) {
+      feat[2 * i] = subset[5 * i]; feat[2 * i + 1] = subset[5 * i + 1];
+      for (int k = 0; k < 3; ++k) world[3 * i + k] = subset[5 * i + 2 + k];
+    }
+    const int n = rsc::sqpnp(3, feat, world, quats, ts);
+    for (int i = 0; i < n; ++i) {
+      double* m = models + kStride * i;
+      double R[9];
+      rsc::quat_to_rot(quats + 4 * i, R);
+      const double* t = ts + 3 * i;
+      for (int k = 0; k < 9; ++k) m[k] = R[k];
+      for (int c = 0; c < 3; ++c) m[9 + c] = -((R[c] * t[0] + R[3 + c] * t[1]) + R[6 + c] * t[2]);
+      for (int k = 12; k < kStride; ++k) m[k] = 0.0;
+    }
+    return n;
+  }
   return 0;
 }
 
@@ -93,7 +117,7 @@ __device__ inline double model_error(int est, const double* m, const double* d) 
 
 // K5: one thread per (problem, iteration of the round).
 //   samples : [nprob][B][m] indices into the problem's data
-//   models  : [nprob][B][kMaxModels][kStride]
+//   models  : [nprob][B][mm][kStride], mm = max_models(est)
 //   counts  : [nprob][B]
 __global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int64_t* __restrict__ offsets,
                                             const double* __restrict__ data, const int* __restrict__ samples,
@@ -104,6 +128,7 @@ __global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int
   const int p = blockIdx.y;
   if (b >= B || p >= nprob) return;
   const size_t hyp = (size_t)p * B + b;
+  const int mm = max_models(est);
   if (b >= active_iters[p]) { counts[hyp] = 0; return; }
   const int m = sample_size(est), ds = datum_size(est);
   const double* pd = data + (size_t)offsets[p] * ds;
@@ -112,7 +137,7 @@ __global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int
     const int idx = samples[hyp * m + i];
     for (int k = 0; k < ds; ++k) subset[i * ds + k] = pd[(size_t)idx * ds + k];
   }
-  double mloc[kMaxModels * kStride];
+  double mloc[kMaxCap * kStride];
   const int nm = estimate_models(est, subset, mloc);
   counts[hyp] = nm;
   if (nm == 0) return;
@@ -120,11 +145,11 @@ __global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int
   // are empty: scoring a dense list keeps every lane of k_score busy); the tag
   // remembers (iteration, slot) so the host replays in sample order.
   const int base = atomicAdd(&dense_count[p], nm);
-  double* mo = models + ((size_t)p * B * kMaxModels + base) * (size_t)kStride;
-  int* tg = tags + (size_t)p * B * kMaxModels + base;
+  double* mo = models + ((size_t)p * B * mm + base) * (size_t)kStride;
+  int* tg = tags + (size_t)p * B * mm + base;
   for (int j = 0; j < nm; ++j) {
     for (int k = 0; k < kStride; ++k) mo[j * kStride + k] = mloc[j * kStride + k];
-    tg[j] = b * kMaxModels + j;
+    tg[j] = b * mm + j;
   }
 }
 
@@ -151,8 +176,9 @@ __global__ __launch_bounds__(256) void k_score(int est, int nprob, int B, const 
   }
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= nmodels) return;
-  const size_t dense = (size_t)p * B * kMaxModels + slot;
-  const size_t out = (size_t)p * B * kMaxModels + tags[dense];  // [hyp][slot] position
+  const int mm = max_models(est);
+  const size_t dense = (size_t)p * B * mm + slot;
+  const size_t out = (size_t)p * B * mm + tags[dense];  // [hyp][slot] position
   double m[kStride];
   const double* mo = models + dense * (size_t)kStride;
 #pragma unroll
@@ -185,7 +211,7 @@ __global__ void k_refit(int est, int nprob, const int64_t* __restrict__ offsets,
     const int idx = best_samples[p * 5 + i];
     for (int k = 0; k < ds; ++k) subset[i * ds + k] = pd[(size_t)idx * ds + k];
   }
-  double mloc[kMaxModels * kStride];
+  double mloc[kMaxCap * kStride];
   const int nm = estimate_models(est, subset, mloc);
   const int j = best_slot[p];
   if (j < nm) for (int k = 0; k < kStride; ++k) mo[k] = mloc[j * kStride + k];
@@ -224,6 +250,20 @@ __global__ void k_p3p(int num, const double* __restrict__ corr, double* __restri
   nsol[i] = n;
   for (int k = 0; k < 36; ++k) R[(size_t)i * 36 + k] = (k < 9 * n) ? r[k] : 0.0;
   for (int k = 0; k < 12; ++k) t[(size_t)i * 12 + k] = (k < 3 * n) ? tt[k] : 0.0;
+}
+
+// SQPnP on problems of any size (the directly bound solver, sfm.cc:592): one thread per problem
+__global__ void k_sqpnp(int num, const int64_t* __restrict__ offsets, const double* __restrict__ feat,
+                        const double* __restrict__ world, double* __restrict__ quats, double* __restrict__ ts,
+                        int* __restrict__ nsol) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= num) return;
+  double q[72], t[54];
+  const int64_t o = offsets[i];
+  const int n = rsc::sqpnp((int)(offsets[i + 1] - o), feat + 2 * o, world + 3 * o, q, t);
+  nsol[i] = n;
+  for (int k = 0; k < 72; ++k) quats[(size_t)i * 72 + k] = (k < 4 * n) ? q[k] : 0.0;
+  for (int k = 0; k < 54; ++k) ts[(size_t)i * 54 + k] = (k < 3 * n) ? t[k] : 0.0;
 }
 
 // ------------------------------------------------------------------ host side
@@ -381,8 +421,8 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   if (!(P.failure_probability < 1.0) || !(P.failure_probability > 0.0)) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "failure_probability must be in (0, 1)");
   if (P.max_iterations < P.min_iterations) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "max_iterations < min_iterations");
   const int est = batch->estimator;
-  if (est == THEIA_EST_ABSOLUTE_POSE_DLS || est == THEIA_EST_ABSOLUTE_POSE_SQPNP)
-    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "DLS / SQPnP minimal solvers have no HIP kernel yet");
+  if (est == THEIA_EST_ABSOLUTE_POSE_DLS)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "the DLS minimal solver has no HIP kernel yet");
   if (est < 0 || est > THEIA_EST_ABSOLUTE_POSE_SQPNP) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
   if (P.use_lo) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: LO-RANSAC refinement is not built yet (DESIGN.md scope)");
   if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE)
@@ -429,6 +469,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   first_round = std::min(first_round, 4096);
   const int next_round = 1024;
   // problems per chunk: bound the model workspace to ~1.5 GiB
+  const int kMaxModels = max_models(est);   // slot stride of this estimator
   const size_t per_hyp = (size_t)kMaxModels * kStride * sizeof(double);
   int chunk = (int)std::max<size_t>(1, ((size_t)3 << 29) / (per_hyp * (size_t)first_round));
   chunk = std::min(chunk, nprob);
@@ -604,6 +645,33 @@ int theia_hip_pose_from_three_points(int32_t num, const double* corr2d3d, double
   k_p3p<<<(num + 63) / 64, 64>>>(num, dc.p, dr.p, dt.p, dn.p);
   HIP_TRYR(hipMemcpy(rotations, dr.p, sizeof(double) * num * 36, hipMemcpyDeviceToHost));
   HIP_TRYR(hipMemcpy(translations, dt.p, sizeof(double) * num * 12, hipMemcpyDeviceToHost));
+  HIP_TRYR(hipMemcpy(num_solutions, dn.p, sizeof(int) * num, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int theia_hip_sqpnp(int32_t num, const int64_t* offsets, const double* features, const double* world_points,
+                    double* quaternions, double* translations, int32_t* num_solutions) {
+  if (num < 0 || (num > 0 && (!offsets || !features || !world_points || !quaternions || !translations || !num_solutions)))
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+  if (num == 0) return 0;
+  int rc = thip::ensure_device();
+  if (rc) return rc;
+  for (int i = 0; i < num; ++i)
+    if (offsets[i + 1] < offsets[i]) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
+  const int64_t total = offsets[num] - offsets[0];
+  if (offsets[0] != 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "offsets[0] must be 0");
+  DBuf<double> df, dw, dq, dt; DBuf<int> dn; DBuf<int64_t> dof;
+  if ((rc = df.ensure((size_t)std::max<int64_t>(1, total) * 2)) || (rc = dw.ensure((size_t)std::max<int64_t>(1, total) * 3)) ||
+      (rc = dq.ensure((size_t)num * 72)) || (rc = dt.ensure((size_t)num * 54)) || (rc = dn.ensure(num)) || (rc = dof.ensure(num + 1)))
+    return rc;
+  if (total) {
+    HIP_TRYR(hipMemcpy(df.p, features, sizeof(double) * total * 2, hipMemcpyHostToDevice));
+    HIP_TRYR(hipMemcpy(dw.p, world_points, sizeof(double) * total * 3, hipMemcpyHostToDevice));
+  }
+  HIP_TRYR(hipMemcpy(dof.p, offsets, sizeof(int64_t) * (num + 1), hipMemcpyHostToDevice));
+  k_sqpnp<<<(num + 63) / 64, 64>>>(num, dof.p, df.p, dw.p, dq.p, dt.p, dn.p);
+  HIP_TRYR(hipMemcpy(quaternions, dq.p, sizeof(double) * num * 72, hipMemcpyDeviceToHost));
+  HIP_TRYR(hipMemcpy(translations, dt.p, sizeof(double) * num * 54, hipMemcpyDeviceToHost));
   HIP_TRYR(hipMemcpy(num_solutions, dn.p, sizeof(int) * num, hipMemcpyDeviceToHost));
   return 0;
 }

@@ -6,7 +6,7 @@
 //   Eigen::EigenSolver (five_point_relative_pose.cc:275; companion-matrix
 //                       roots, math/find_polynomial_roots_companion_matrix.cc)
 //                      = EISPACK orthes + hqr2
-//   Eigen::JacobiSVD   (essential_matrix_utils.cc:66-67) = two-sided Jacobi
+//   Eigen::JacobiSVD   (essential_matrix_utils.cc:66-67; 9x9 in sqpnp.cc:234) = two-sided Jacobi
 // Built with -ffp-contract=off: the operation order below is kept identical to
 // the CPU oracle's transcription of the same algorithms, which is what makes
 // RANSAC inlier sets bit-identical between the two (DESIGN.md "RANSAC parity").
@@ -369,6 +369,516 @@ RDEV void svd3(const double* Ain, double* U, double* S, double* V) {
 
 RDEV double det3(const double* M) {
   return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// ------------------------------------------------------------------ SQPnP
+// sfm/pose/sqpnp.cc:23-353 + sqpnp_helper.{h,cc}.  All 3x3 matrices stored as
+// 9-vectors are ROW-MAJOR (as in the reference).
+//
+// Two-sided Jacobi SVD of an N x N row-major matrix (Eigen::JacobiSVD for square
+// real input: no QR preconditioner), generalisation of svd3 above.
+template <int N>
+RDEV void svd_sq(const double* Ain, double* U, double* S, double* V) {
+  double W[N * N];
+  double scale = 0.0;
+  for (int i = 0; i < N * N; ++i) scale = fmax(scale, fabs(Ain[i]));
+  if (scale == 0.0) scale = 1.0;
+  for (int i = 0; i < N * N; ++i) W[i] = Ain[i] / scale;
+  for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) { U[i * N + j] = (i == j) ? 1.0 : 0.0; V[i * N + j] = U[i * N + j]; }
+  const double precision = 2.0 * DBL_EPSILON;
+  double maxdiag = 0.0;
+  for (int i = 0; i < N; ++i) maxdiag = fmax(maxdiag, fabs(W[i * N + i]));
+  bool finished = false;
+  int sweeps = 0;
+  while (!finished && sweeps++ < 64) {
+    finished = true;
+    for (int p = 1; p < N; ++p)
+      for (int q = 0; q < p; ++q) {
+        const double threshold = fmax(DBL_MIN, precision * maxdiag);
+        if (fabs(W[p * N + q]) > threshold || fabs(W[q * N + p]) > threshold) {
+          finished = false;
+          const double m00 = W[p * N + p], m01 = W[p * N + q], m10 = W[q * N + p], m11 = W[q * N + q];
+          double r1c, r1s;
+          const double tt = m00 + m11, dd = m10 - m01;
+          if (fabs(dd) < DBL_MIN) { r1c = 1.0; r1s = 0.0; }
+          else { const double u = tt / dd; const double tmp = sqrt(1.0 + u * u); r1s = 1.0 / tmp; r1c = u / tmp; }
+          const double n00 = r1c * m00 + r1s * m10, n01 = r1c * m01 + r1s * m11;
+          const double n11 = -r1s * m01 + r1c * m11;
+          double jc, js;
+          jacobi_rot_sym(n00, n01, n11, &jc, &js);
+          const double lc = r1c * jc + r1s * js, ls = r1s * jc - r1c * js;
+          for (int k = 0; k < N; ++k) {
+            const double a = W[p * N + k], b = W[q * N + k];
+            W[p * N + k] = lc * a + ls * b; W[q * N + k] = -ls * a + lc * b;
+          }
+          for (int k = 0; k < N; ++k) {
+            const double a = U[k * N + p], b = U[k * N + q];
+            U[k * N + p] = lc * a + ls * b; U[k * N + q] = -ls * a + lc * b;
+          }
+          for (int k = 0; k < N; ++k) {
+            const double a = W[k * N + p], b = W[k * N + q];
+            W[k * N + p] = jc * a - js * b; W[k * N + q] = js * a + jc * b;
+          }
+          for (int k = 0; k < N; ++k) {
+            const double a = V[k * N + p], b = V[k * N + q];
+            V[k * N + p] = jc * a - js * b; V[k * N + q] = js * a + jc * b;
+          }
+          maxdiag = fmax(maxdiag, fmax(fabs(W[p * N + p]), fabs(W[q * N + q])));
+        }
+      }
+  }
+  for (int i = 0; i < N; ++i) {
+    const double a = W[i * N + i];
+    S[i] = fabs(a);
+    if (a < 0) for (int k = 0; k < N; ++k) U[k * N + i] = -U[k * N + i];
+  }
+  for (int i = 0; i < N; ++i) {  // selection sort, descending
+    int best = i;
+    for (int j = i + 1; j < N; ++j) if (S[j] > S[best]) best = j;
+    if (best != i) {
+      dswap(S[i], S[best]);
+      for (int k = 0; k < N; ++k) { dswap(U[k * N + i], U[k * N + best]); dswap(V[k * N + i], V[k * N + best]); }
+    }
+  }
+  for (int i = 0; i < N; ++i) S[i] *= scale;
+}
+
+// Eigen::Quaternion(Matrix3) and Quaternion::toRotationMatrix (Geometry/Quaternion.h).
+// M row-major; q = [w, x, y, z].
+RDEV void rot_to_quat(const double* M, double* q) {
+  double t = (M[0] + M[4]) + M[8];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0);
+    q[0] = 0.5 * t;
+    t = 0.5 / t;
+    q[1] = (M[7] - M[5]) * t; q[2] = (M[2] - M[6]) * t; q[3] = (M[3] - M[1]) * t;
+  } else {
+    int i = 0;
+    if (M[4] > M[0]) i = 1;
+    if (M[8] > M[i * 3 + i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(M[i * 3 + i] - M[j * 3 + j] - M[k * 3 + k] + 1.0);
+    q[1 + i] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (M[k * 3 + j] - M[j * 3 + k]) * t;
+    q[1 + j] = (M[j * 3 + i] + M[i * 3 + j]) * t;
+    q[1 + k] = (M[k * 3 + i] + M[i * 3 + k]) * t;
+  }
+}
+RDEV void quat_to_rot(const double* q, double* R) {
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1.0 - (txx + tyy);
+}
+
+namespace sqp {
+#define SQP_RANK_TOL 1e-7
+#define SQP_DET_THRESHOLD 1.001
+#define SQP_ORTH_SQ_ERR 1e-8
+#define SQP_EQUAL_VEC_SQ 1e-10
+#define SQP_EQUAL_SQ_ERR 1e-6
+
+struct Sol { double r[9], r_hat[9], t[3], sq_error; };
+
+RDEV double det9(const double* r) {  // sqpnp_helper.h:58-62
+  return r[0] * r[4] * r[8] + r[1] * r[5] * r[6] + r[2] * r[3] * r[7] - r[6] * r[4] * r[2] - r[7] * r[5] * r[0] - r[8] * r[3] * r[1];
+}
+RDEV double orthogonality_error(const double* a) {  // sqpnp_helper.cc:43-56
+  const double n1 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], n2 = a[3] * a[3] + a[4] * a[4] + a[5] * a[5],
+               n3 = a[6] * a[6] + a[7] * a[7] + a[8] * a[8];
+  const double d12 = a[0] * a[3] + a[1] * a[4] + a[2] * a[5], d13 = a[0] * a[6] + a[1] * a[7] + a[2] * a[8],
+               d23 = a[3] * a[6] + a[4] * a[7] + a[5] * a[8];
+  return (n1 - 1) * (n1 - 1) + (n2 - 1) * (n2 - 1) + (n3 - 1) * (n3 - 1) + 2 * (d12 * d12 + d13 * d13 + d23 * d23);
+}
+// sqpnp_helper.cc:204-238 (uses the lower triangle of the row-major Q)
+RDEV bool invert_symmetric3(const double* Q, double* Qi) {
+  const double a = Q[0], b = Q[3], d = Q[4], c = Q[6], e = Q[7], f = Q[8];
+  const double t2 = e * e, t4 = a * d, t7 = b * b, t9 = b * c, t12 = c * c;
+  const double det = -t4 * f + a * t2 + t7 * f - 2.0 * t9 * e + t12 * d;
+  if (fabs(det) < 1e-8) return false;
+  const double t15 = 1.0 / det;
+  const double t20 = (-b * f + c * e) * t15, t24 = (b * e - c * d) * t15, t30 = (a * e - t9) * t15;
+  Qi[0] = (-d * f + t2) * t15;
+  Qi[1] = Qi[3] = -t20;
+  Qi[2] = Qi[6] = -t24;
+  Qi[4] = -(a * f - t12) * t15;
+  Qi[5] = Qi[7] = t30;
+  Qi[8] = -(t4 - t7) * t15;
+  return true;
+}
+// sqpnp_helper.cc:191-202: nearest rotation of the row-major 9-vector e
+RDEV void nearest_rotation_svd(const double* e, double* r) {
+  double E[9], U[9], S[3], V[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) E[i * 3 + j] = e[i + 3 * j];  // column-major Map
+  svd3(E, U, S, V);
+  const double duv = det3(U) * det3(V);
+  const double dd[3] = {1.0, 1.0, duv};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; ++k) acc += (U[i * 3 + k] * dd[k]) * V[j * 3 + k];
+      r[i + 3 * j] = acc;
+    }
+}
+RDEV double norm9(const double* v) { double s2 = 0.0; for (int i = 0; i < 9; ++i) s2 += v[i] * v[i]; return sqrt(s2); }
+RDEV double dot9(const double* a, const double* b) { double s2 = 0.0; for (int i = 0; i < 9; ++i) s2 += a[i] * b[i]; return s2; }
+
+// sqpnp_helper.cc:317-493.  H: 9x6, N: 9x3, K: 6x6 (row-major)
+RDEV void row_and_null_space(const double* r, double* H, double* Nn, double* K) {
+  const double norm_threshold = 0.1;
+#define HH(i, j) H[(i) * 6 + (j)]
+#define KK(i, j) K[(i) * 6 + (j)]
+#define NN(i, j) Nn[(i) * 3 + (j)]
+  for (int i = 0; i < 54; ++i) H[i] = 0.0;
+  for (int i = 0; i < 36; ++i) K[i] = 0.0;
+  const double norm_r1 = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  const double inv_norm_r1 = norm_r1 > 1e-5 ? 1.0 / norm_r1 : 0.0;
+  HH(0, 0) = r[0] * inv_norm_r1; HH(1, 0) = r[1] * inv_norm_r1; HH(2, 0) = r[2] * inv_norm_r1;
+  KK(0, 0) = 2 * norm_r1;
+  const double norm_r2 = sqrt(r[3] * r[3] + r[4] * r[4] + r[5] * r[5]);
+  const double inv_norm_r2 = 1.0 / norm_r2;
+  HH(3, 1) = r[3] * inv_norm_r2; HH(4, 1) = r[4] * inv_norm_r2; HH(5, 1) = r[5] * inv_norm_r2;
+  KK(1, 1) = 2 * norm_r2;
+  const double norm_r3 = sqrt(r[6] * r[6] + r[7] * r[7] + r[8] * r[8]);
+  const double inv_norm_r3 = 1.0 / norm_r3;
+  HH(6, 2) = r[6] * inv_norm_r3; HH(7, 2) = r[7] * inv_norm_r3; HH(8, 2) = r[8] * inv_norm_r3;
+  KK(2, 2) = 2 * norm_r3;
+  // q4
+  const double dot_j4q1 = r[3] * HH(0, 0) + r[4] * HH(1, 0) + r[5] * HH(2, 0),
+               dot_j4q2 = r[0] * HH(3, 1) + r[1] * HH(4, 1) + r[2] * HH(5, 1);
+  HH(0, 3) = r[3] - dot_j4q1 * HH(0, 0); HH(1, 3) = r[4] - dot_j4q1 * HH(1, 0); HH(2, 3) = r[5] - dot_j4q1 * HH(2, 0);
+  HH(3, 3) = r[0] - dot_j4q2 * HH(3, 1); HH(4, 3) = r[1] - dot_j4q2 * HH(4, 1); HH(5, 3) = r[2] - dot_j4q2 * HH(5, 1);
+  const double inv_norm_j4 = 1.0 / sqrt(HH(0, 3) * HH(0, 3) + HH(1, 3) * HH(1, 3) + HH(2, 3) * HH(2, 3) +
+                                        HH(3, 3) * HH(3, 3) + HH(4, 3) * HH(4, 3) + HH(5, 3) * HH(5, 3));
+  for (int i = 0; i < 6; ++i) HH(i, 3) *= inv_norm_j4;
+  KK(3, 0) = r[3] * HH(0, 0) + r[4] * HH(1, 0) + r[5] * HH(2, 0);
+  KK(3, 1) = r[0] * HH(3, 1) + r[1] * HH(4, 1) + r[2] * HH(5, 1);
+  KK(3, 3) = r[3] * HH(0, 3) + r[4] * HH(1, 3) + r[5] * HH(2, 3) + r[0] * HH(3, 3) + r[1] * HH(4, 3) + r[2] * HH(5, 3);
+  // q5
+  const double dot_j5q2 = r[6] * HH(3, 1) + r[7] * HH(4, 1) + r[8] * HH(5, 1),
+               dot_j5q3 = r[3] * HH(6, 2) + r[4] * HH(7, 2) + r[5] * HH(8, 2),
+               dot_j5q4 = r[6] * HH(3, 3) + r[7] * HH(4, 3) + r[8] * HH(5, 3);
+  HH(0, 4) = -dot_j5q4 * HH(0, 3); HH(1, 4) = -dot_j5q4 * HH(1, 3); HH(2, 4) = -dot_j5q4 * HH(2, 3);
+  HH(3, 4) = r[6] - dot_j5q2 * HH(3, 1) - dot_j5q4 * HH(3, 3);
+  HH(4, 4) = r[7] - dot_j5q2 * HH(4, 1) - dot_j5q4 * HH(4, 3);
+  HH(5, 4) = r[8] - dot_j5q2 * HH(5, 1) - dot_j5q4 * HH(5, 3);
+  HH(6, 4) = r[3] - dot_j5q3 * HH(6, 2); HH(7, 4) = r[4] - dot_j5q3 * HH(7, 2); HH(8, 4) = r[5] - dot_j5q3 * HH(8, 2);
+  {
+    double s2 = 0.0;
+    for (int i = 0; i < 9; ++i) s2 += HH(i, 4) * HH(i, 4);
+    const double nrm = sqrt(s2);
+    for (int i = 0; i < 9; ++i) HH(i, 4) /= nrm;
+  }
+  KK(4, 1) = r[6] * HH(3, 1) + r[7] * HH(4, 1) + r[8] * HH(5, 1);
+  KK(4, 2) = r[3] * HH(6, 2) + r[4] * HH(7, 2) + r[5] * HH(8, 2);
+  KK(4, 3) = r[6] * HH(3, 3) + r[7] * HH(4, 3) + r[8] * HH(5, 3);
+  KK(4, 4) = r[6] * HH(3, 4) + r[7] * HH(4, 4) + r[8] * HH(5, 4) + r[3] * HH(6, 4) + r[4] * HH(7, 4) + r[5] * HH(8, 4);
+  // q6
+  const double dot_j6q1 = r[6] * HH(0, 0) + r[7] * HH(1, 0) + r[8] * HH(2, 0),
+               dot_j6q3 = r[0] * HH(6, 2) + r[1] * HH(7, 2) + r[2] * HH(8, 2),
+               dot_j6q4 = r[6] * HH(0, 3) + r[7] * HH(1, 3) + r[8] * HH(2, 3),
+               dot_j6q5 = r[0] * HH(6, 4) + r[1] * HH(7, 4) + r[2] * HH(8, 4) + r[6] * HH(0, 4) + r[7] * HH(1, 4) + r[8] * HH(2, 4);
+  HH(0, 5) = r[6] - dot_j6q1 * HH(0, 0) - dot_j6q4 * HH(0, 3) - dot_j6q5 * HH(0, 4);
+  HH(1, 5) = r[7] - dot_j6q1 * HH(1, 0) - dot_j6q4 * HH(1, 3) - dot_j6q5 * HH(1, 4);
+  HH(2, 5) = r[8] - dot_j6q1 * HH(2, 0) - dot_j6q4 * HH(2, 3) - dot_j6q5 * HH(2, 4);
+  HH(3, 5) = -dot_j6q5 * HH(3, 4) - dot_j6q4 * HH(3, 3);
+  HH(4, 5) = -dot_j6q5 * HH(4, 4) - dot_j6q4 * HH(4, 3);
+  HH(5, 5) = -dot_j6q5 * HH(5, 4) - dot_j6q4 * HH(5, 3);
+  HH(6, 5) = r[0] - dot_j6q3 * HH(6, 2) - dot_j6q5 * HH(6, 4);
+  HH(7, 5) = r[1] - dot_j6q3 * HH(7, 2) - dot_j6q5 * HH(7, 4);
+  HH(8, 5) = r[2] - dot_j6q3 * HH(8, 2) - dot_j6q5 * HH(8, 4);
+  {
+    double s2 = 0.0;
+    for (int i = 0; i < 9; ++i) s2 += HH(i, 5) * HH(i, 5);
+    const double nrm = sqrt(s2);
+    for (int i = 0; i < 9; ++i) HH(i, 5) /= nrm;
+  }
+  KK(5, 0) = r[6] * HH(0, 0) + r[7] * HH(1, 0) + r[8] * HH(2, 0);
+  KK(5, 2) = r[0] * HH(6, 2) + r[1] * HH(7, 2) + r[2] * HH(8, 2);
+  KK(5, 3) = r[6] * HH(0, 3) + r[7] * HH(1, 3) + r[8] * HH(2, 3);
+  KK(5, 4) = r[6] * HH(0, 4) + r[7] * HH(1, 4) + r[8] * HH(2, 4) + r[0] * HH(6, 4) + r[1] * HH(7, 4) + r[2] * HH(8, 4);
+  KK(5, 5) = r[6] * HH(0, 5) + r[7] * HH(1, 5) + r[8] * HH(2, 5) + r[0] * HH(6, 5) + r[1] * HH(7, 5) + r[2] * HH(8, 5);
+  // projector onto the null space of H; Pn is symmetric, columns stored as Pc[col][row]
+  double Pc[9][9];
+  for (int i = 0; i < 9; ++i)
+    for (int j = 0; j < 9; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 6; ++k) acc += HH(i, k) * HH(j, k);
+      Pc[j][i] = ((i == j) ? 1.0 : 0.0) - acc;
+    }
+  int index1 = -1, index2 = -1, index3 = -1;
+  double max_norm1 = DBL_MIN, min_dot12 = DBL_MAX, min_dot1323 = DBL_MAX;
+  double col_norms[9];
+  for (int i = 0; i < 9; ++i) {
+    col_norms[i] = norm9(Pc[i]);
+    if (col_norms[i] >= norm_threshold && max_norm1 < col_norms[i]) { max_norm1 = col_norms[i]; index1 = i; }
+  }
+  if (index1 < 0) index1 = 0;   // the reference indexes with -1 here (undefined); never seen on rank-3 input
+  const double* v1 = Pc[index1];
+  for (int i = 0; i < 9; ++i) NN(i, 0) = v1[i] * (1.0 / max_norm1);
+  for (int i = 0; i < 9; ++i) {
+    if (i == index1) continue;
+    if (col_norms[i] >= norm_threshold) {
+      const double c1 = fabs(dot9(Pc[i], v1) / col_norms[i]);
+      if (c1 <= min_dot12) { index2 = i; min_dot12 = c1; }
+    }
+  }
+  if (index2 < 0) index2 = (index1 + 1) % 9;
+  const double* v2 = Pc[index2];
+  {
+    double n0[9];
+    for (int i = 0; i < 9; ++i) n0[i] = NN(i, 0);
+    const double d = dot9(v2, n0);
+    double t[9];
+    for (int i = 0; i < 9; ++i) t[i] = v2[i] - d * n0[i];
+    const double nrm = norm9(t);
+    for (int i = 0; i < 9; ++i) NN(i, 1) = t[i] / nrm;
+  }
+  for (int i = 0; i < 9; ++i) {
+    if (i == index2 || i == index1) continue;
+    if (col_norms[i] >= norm_threshold) {
+      const double c1 = fabs(dot9(Pc[i], v1) / col_norms[i]);
+      const double c2 = fabs(dot9(Pc[i], v2) / col_norms[i]);
+      if (c1 + c2 <= min_dot1323) { index3 = i; min_dot1323 = c2 + c2; }   // sic (sqpnp_helper.cc:480)
+    }
+  }
+  if (index3 < 0) index3 = (index2 + 1) % 9;
+  const double* v3 = Pc[index3];
+  {
+    double n0[9], n1[9];
+    for (int i = 0; i < 9; ++i) { n0[i] = NN(i, 0); n1[i] = NN(i, 1); }
+    const double d1 = dot9(v3, n1), d0 = dot9(v3, n0);
+    double t[9];
+    for (int i = 0; i < 9; ++i) t[i] = v3[i] - (d1 * n1[i]) - (d0 * n0[i]);
+    const double nrm = norm9(t);
+    for (int i = 0; i < 9; ++i) NN(i, 2) = t[i] / nrm;
+  }
+#undef HH
+#undef KK
+#undef NN
+}
+
+// sqpnp_helper.cc:241-310
+RDEV void solve_sqp_system(const double* r, const double* Omega, double* delta) {
+  const double sq1 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2], sq2 = r[3] * r[3] + r[4] * r[4] + r[5] * r[5],
+               sq3 = r[6] * r[6] + r[7] * r[7] + r[8] * r[8];
+  const double d12 = r[0] * r[3] + r[1] * r[4] + r[2] * r[5], d13 = r[0] * r[6] + r[1] * r[7] + r[2] * r[8],
+               d23 = r[3] * r[6] + r[4] * r[7] + r[5] * r[8];
+  double H[54], Nn[27], JH[36];
+  row_and_null_space(r, H, Nn, JH);
+  const double g[6] = {1 - sq1, 1 - sq2, 1 - sq3, -d12, -d23, -d13};
+  double x[6];
+#define J(i, j) JH[(i) * 6 + (j)]
+  x[0] = g[0] / J(0, 0);
+  x[1] = g[1] / J(1, 1);
+  x[2] = g[2] / J(2, 2);
+  x[3] = (g[3] - J(3, 0) * x[0] - J(3, 1) * x[1]) / J(3, 3);
+  x[4] = (g[4] - J(4, 1) * x[1] - J(4, 2) * x[2] - J(4, 3) * x[3]) / J(4, 4);
+  x[5] = (g[5] - J(5, 0) * x[0] - J(5, 2) * x[2] - J(5, 3) * x[3] - J(5, 4) * x[4]) / J(5, 5);
+#undef J
+  for (int i = 0; i < 9; ++i) {
+    double acc = 0.0;
+    for (int k = 0; k < 6; ++k) acc += H[i * 6 + k] * x[k];
+    delta[i] = acc;
+  }
+  double NtO[27];   // 3 x 9
+  for (int a = 0; a < 3; ++a)
+    for (int j = 0; j < 9; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 9; ++k) acc += Nn[k * 3 + a] * Omega[k * 9 + j];
+      NtO[a * 9 + j] = acc;
+    }
+  double W[9], Winv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      double acc = 0.0;
+      for (int k = 0; k < 9; ++k) acc += NtO[a * 9 + k] * Nn[k * 3 + b];
+      W[a * 3 + b] = acc;
+    }
+  invert_symmetric3(W, Winv);
+  double M[27];   // (-Winv) * NtOmega
+  for (int a = 0; a < 3; ++a)
+    for (int j = 0; j < 9; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; ++k) acc += (-Winv[a * 3 + k]) * NtO[k * 9 + j];
+      M[a * 9 + j] = acc;
+    }
+  double y[3];
+  for (int a = 0; a < 3; ++a) {
+    double acc = 0.0;
+    for (int j = 0; j < 9; ++j) acc += M[a * 9 + j] * (delta[j] + r[j]);
+    y[a] = acc;
+  }
+  for (int i = 0; i < 9; ++i) {
+    double acc = 0.0;
+    for (int a = 0; a < 3; ++a) acc += Nn[i * 3 + a] * y[a];
+    delta[i] += acc;
+  }
+}
+
+// sqpnp.cc:23-55.  `step++ < DEFAULT_SQP_SQUARED_TOLERANCE` (an int compared with
+// 1e-10) lets exactly ONE iteration run: reference behaviour, kept.
+RDEV void run_sqp(const double* r0, const double* Omega, Sol* sol) {
+  double r[9], delta[9];
+  for (int i = 0; i < 9; ++i) r[i] = r0[i];
+  solve_sqp_system(r, Omega, delta);
+  for (int i = 0; i < 9; ++i) r[i] += delta[i];
+  for (int i = 0; i < 9; ++i) sol->r[i] = r[i];
+  double det_r = det9(sol->r);
+  if (det_r < 0) { for (int i = 0; i < 9; ++i) sol->r[i] = -r[i]; det_r = -det_r; }
+  if (det_r > SQP_DET_THRESHOLD) nearest_rotation_svd(sol->r, sol->r_hat);
+  else for (int i = 0; i < 9; ++i) sol->r_hat[i] = sol->r[i];
+}
+
+// sqpnp_helper.cc:58-101
+RDEV void handle_solution(const double* Omega, const double* mean, Sol& s, Sol* sols, double& min_sq_error, int& nsol) {
+  const double* r = s.r_hat;
+  if (!(r[6] * mean[0] + r[7] * mean[1] + r[8] * mean[2] + s.t[2] > 0)) return;
+  double acc = 0.0;
+  for (int i = 0; i < 9; ++i) {
+    double row = 0.0;
+    for (int j = 0; j < 9; ++j) row += Omega[i * 9 + j] * r[j];
+    acc += row * r[i];
+  }
+  s.sq_error = acc;
+  if (fabs(min_sq_error - s.sq_error) > SQP_EQUAL_SQ_ERR) {
+    if (min_sq_error > s.sq_error) { min_sq_error = s.sq_error; sols[0] = s; nsol = 1; }
+  } else {
+    bool found = false;
+    for (int i = 0; i < nsol; ++i) {
+      double d2 = 0.0;
+      for (int k = 0; k < 9; ++k) d2 += (sols[i].r_hat[k] - s.r_hat[k]) * (sols[i].r_hat[k] - s.r_hat[k]);
+      if (d2 < SQP_EQUAL_VEC_SQ) {
+        if (sols[i].sq_error > s.sq_error) sols[i] = s;
+        found = true;
+        break;
+      }
+    }
+    if (!found && nsol < 18) sols[nsol++] = s;   // the reference's array holds 18 and is not bounds-checked
+    if (min_sq_error > s.sq_error) min_sq_error = s.sq_error;
+  }
+}
+
+RDEV void apply_P(const double* P, const double* rh, double* t) {
+  for (int a = 0; a < 3; ++a) {
+    double acc = 0.0;
+    for (int j = 0; j < 9; ++j) acc += P[a * 9 + j] * rh[j];
+    t[a] = acc;
+  }
+}
+}  // namespace sqp
+
+// SQPnP (sqpnp.cc:58-353).  feat: n x [x y], world: n x [X Y Z].  Writes up to 18
+// solutions: quaternions [w x y z] (of the row-major rotation r_hat) and translations.
+RDEV int sqpnp(int n, const double* feat, const double* world, double* quats, double* ts) {
+  using namespace sqp;
+  if (n < 3) return 0;
+  double Om[81], QA[27];
+  for (int i = 0; i < 81; ++i) Om[i] = 0.0;
+  for (int i = 0; i < 27; ++i) QA[i] = 0.0;
+#define OM(i, j) Om[(i) * 9 + (j)]
+#define QAA(i, j) QA[(i) * 9 + (j)]
+  double sum_wx = 0, sum_wy = 0, sum_wx2y2 = 0, sum_w = 0, sum_X = 0, sum_Y = 0, sum_Z = 0;
+  for (int i = 0; i < n; ++i) {
+    const double w = 1.0;
+    const double wx = feat[2 * i] * w, wy = feat[2 * i + 1] * w;
+    const double wsq = w * (feat[2 * i] * feat[2 * i] + feat[2 * i + 1] * feat[2 * i + 1]);
+    sum_wx += wx; sum_wy += wy; sum_wx2y2 += wsq; sum_w += w;
+    const double X = world[3 * i], Y = world[3 * i + 1], Z = world[3 * i + 2];
+    sum_X += X; sum_Y += Y; sum_Z += Z;
+    const double X2 = X * X, XY = X * Y, XZ = X * Z, Y2 = Y * Y, YZ = Y * Z, Z2 = Z * Z;
+    OM(0, 0) += w * X2; OM(0, 1) += w * XY; OM(0, 2) += w * XZ; OM(1, 1) += w * Y2; OM(1, 2) += w * YZ; OM(2, 2) += w * Z2;
+    OM(0, 6) += -wx * X2; OM(0, 7) += -wx * XY; OM(0, 8) += -wx * XZ; OM(1, 7) += -wx * Y2; OM(1, 8) += -wx * YZ; OM(2, 8) += -wx * Z2;
+    OM(3, 6) += -wy * X2; OM(3, 7) += -wy * XY; OM(3, 8) += -wy * XZ; OM(4, 7) += -wy * Y2; OM(4, 8) += -wy * YZ; OM(5, 8) += -wy * Z2;
+    OM(6, 6) += wsq * X2; OM(6, 7) += wsq * XY; OM(6, 8) += wsq * XZ; OM(7, 7) += wsq * Y2; OM(7, 8) += wsq * YZ; OM(8, 8) += wsq * Z2;
+    const double wX = w * X, wY = w * Y, wZ = w * Z;
+    QAA(0, 0) += wX; QAA(0, 1) += wY; QAA(0, 2) += wZ; QAA(0, 6) += -wx * X; QAA(0, 7) += -wx * Y; QAA(0, 8) += -wx * Z;
+    QAA(1, 3) += wX; QAA(1, 4) += wY; QAA(1, 5) += wZ; QAA(1, 6) += -wy * X; QAA(1, 7) += -wy * Y; QAA(1, 8) += -wy * Z;
+    QAA(2, 0) += -wx * X; QAA(2, 1) += -wx * Y; QAA(2, 2) += -wx * Z; QAA(2, 3) += -wy * X; QAA(2, 4) += -wy * Y; QAA(2, 5) += -wy * Z;
+    QAA(2, 6) += wsq * X; QAA(2, 7) += wsq * Y; QAA(2, 8) += wsq * Z;
+  }
+  OM(1, 6) = OM(0, 7); OM(2, 6) = OM(0, 8); OM(2, 7) = OM(1, 8);
+  OM(4, 6) = OM(3, 7); OM(5, 6) = OM(3, 8); OM(5, 7) = OM(4, 8);
+  OM(7, 6) = OM(6, 7); OM(8, 6) = OM(6, 8); OM(8, 7) = OM(7, 8);
+  OM(3, 3) = OM(0, 0); OM(3, 4) = OM(0, 1); OM(3, 5) = OM(0, 2); OM(4, 4) = OM(1, 1); OM(4, 5) = OM(1, 2); OM(5, 5) = OM(2, 2);
+  for (int i = 1; i < 9; ++i) for (int j = 0; j < i; ++j) OM(i, j) = OM(j, i);   // lower triangle (sqpnp.cc:178-214)
+  const double Q[9] = {sum_w, 0, -sum_wx, 0, sum_w, -sum_wy, -sum_wx, -sum_wy, sum_wx2y2};
+  double Qinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  invert_symmetric3(Q, Qinv);
+  double P[27];
+  for (int a = 0; a < 3; ++a)
+    for (int j = 0; j < 9; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; ++k) acc += (-Qinv[a * 3 + k]) * QAA(k, j);
+      P[a * 9 + j] = acc;
+    }
+  for (int i = 0; i < 9; ++i)
+    for (int j = 0; j < 9; ++j) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; ++k) acc += QAA(k, i) * P[k * 9 + j];
+      OM(i, j) += acc;
+    }
+#undef OM
+#undef QAA
+  double U[81], S[9], V[81];
+  svd_sq<9>(Om, U, S, V);
+  int num_null = 0;
+  while (num_null <= 7 && S[7 - num_null] < SQP_RANK_TOL) num_null++;
+  if (++num_null > 6) return 0;
+  const double inv_n = 1.0 / n;
+  const double mean[3] = {sum_X * inv_n, sum_Y * inv_n, sum_Z * inv_n};
+  double min_sq_error = DBL_MAX;
+  const int nep = num_null > 0 ? num_null : 1;
+  Sol sols[18];
+  int nsol = 0;
+  const double sqrt3 = sqrt(3.0);
+  for (int i = 9 - nep; i < 9; ++i) {
+    double e[9], me[9];
+    for (int k = 0; k < 9; ++k) { e[k] = sqrt3 * U[k * 9 + i]; me[k] = -e[k]; }
+    Sol s0, s1;
+    if (orthogonality_error(e) < SQP_ORTH_SQ_ERR) {
+      const double de = det9(e);
+      for (int k = 0; k < 9; ++k) { s0.r_hat[k] = de * e[k]; s0.r[k] = s0.r_hat[k]; }
+      apply_P(P, s0.r_hat, s0.t);
+      handle_solution(Om, mean, s0, sols, min_sq_error, nsol);
+    } else {
+      double r0[9];
+      nearest_rotation_svd(e, r0);
+      run_sqp(r0, Om, &s0);
+      apply_P(P, s0.r_hat, s0.t);
+      handle_solution(Om, mean, s0, sols, min_sq_error, nsol);
+      nearest_rotation_svd(me, r0);
+      run_sqp(r0, Om, &s1);
+      apply_P(P, s1.r_hat, s1.t);
+      handle_solution(Om, mean, s1, sols, min_sq_error, nsol);
+    }
+  }
+  int c = 1;
+  while (min_sq_error > 3 * S[9 - nep - c] && 9 - nep - c > 0) {
+    const int index = 9 - nep - c;
+    double e[9], me[9], r0[9];
+    for (int k = 0; k < 9; ++k) { e[k] = U[k * 9 + index]; me[k] = -e[k]; }
+    Sol s0, s1;
+    nearest_rotation_svd(e, r0);
+    run_sqp(r0, Om, &s0);
+    apply_P(P, s0.r_hat, s0.t);
+    handle_solution(Om, mean, s0, sols, min_sq_error, nsol);
+    nearest_rotation_svd(me, r0);
+    run_sqp(r0, Om, &s1);
+    apply_P(P, s1.r_hat, s1.t);
+    handle_solution(Om, mean, s1, sols, min_sq_error, nsol);
+    c++;
+  }
+  for (int i = 0; i < nsol; ++i) {
+    rot_to_quat(sols[i].r_hat, quats + 4 * i);
+    for (int k = 0; k < 3; ++k) ts[3 * i + k] = sols[i].t[k];
+  }
+  return nsol;
 }
 
 // ------------------------------------------------------------ five point

@@ -97,6 +97,8 @@ def _sig():
         L.theia_hip_five_point_relative_pose.argtypes = [C.c_int32, capi.c_double_p, capi.c_double_p, capi.c_int32_p]
         L.theia_hip_pose_from_three_points.argtypes = [C.c_int32, capi.c_double_p, capi.c_double_p, capi.c_double_p,
                                                        capi.c_int32_p]
+        L.theia_hip_sqpnp.argtypes = [C.c_int32, C.POINTER(C.c_int64), capi.c_double_p, capi.c_double_p, capi.c_double_p,
+                                      capi.c_double_p, capi.c_int32_p]
         L.theia_ransac_params_default.argtypes = [C.POINTER(capi.RansacParams)]
         L._ransac_ready = True
     return L
@@ -190,6 +192,29 @@ def PoseFromThreePoints(feature_points, points_3d):
     if single:
         return bool(ns[0] > 0), [R[0, k] for k in range(ns[0])], [t[0, k] for k in range(ns[0])]
     return ns, R, t
+
+
+def SQPnP(feature_positions, world_points):
+    """sfm.cc:592 / sqpnp.cc:58-353.  One problem: (N, 2) and (N, 3) arrays ->
+    (success, [quaternion wxyz], [translation]).  A list of problems is solved as one
+    batch and returns (num_solutions, quaternions[num][18][4], translations[num][18][3])."""
+    single = isinstance(feature_positions, np.ndarray) and feature_positions.ndim == 2
+    fl = [np.asarray(feature_positions, dtype=np.float64)] if single else [np.asarray(f, dtype=np.float64) for f in feature_positions]
+    wl = [np.asarray(world_points, dtype=np.float64)] if single else [np.asarray(w, dtype=np.float64) for w in world_points]
+    if len(fl) != len(wl) or any(f.shape[0] != w.shape[0] for f, w in zip(fl, wl)):
+        raise capi.TheiaHipError(-1, "feature_positions / world_points size mismatch")
+    num = len(fl)
+    offsets = np.zeros(num + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([f.shape[0] for f in fl])
+    feat = np.ascontiguousarray(np.concatenate(fl, axis=0).reshape(-1, 2)) if num else np.zeros((0, 2))
+    world = np.ascontiguousarray(np.concatenate(wl, axis=0).reshape(-1, 3)) if num else np.zeros((0, 3))
+    q = np.zeros((num, 18, 4)); t = np.zeros((num, 18, 3)); ns = np.zeros(num, dtype=np.int32)
+    capi.check(_sig().theia_hip_sqpnp(num, offsets.ctypes.data_as(C.POINTER(C.c_int64)), capi.ptr(feat, C.c_double),
+                                      capi.ptr(world, C.c_double), capi.ptr(q, C.c_double), capi.ptr(t, C.c_double),
+                                      capi.ptr(ns, C.c_int32)))
+    if single:
+        return bool(ns[0] > 0), [q[0, k] for k in range(ns[0])], [t[0, k] for k in range(ns[0])]
+    return ns, q, t
 
 
 def smoke_check():

@@ -199,9 +199,33 @@ def p3p(corr):
     return R[:n], t[:n]
 
 
+def sqpnp(feat, world):
+    """SQPnP (sqpnp.cc:58-353): quaternions [w x y z] and translations of the solutions."""
+    feat = np.ascontiguousarray(feat, dtype=np.float64).reshape(-1, 2)
+    world = np.ascontiguousarray(world, dtype=np.float64).reshape(-1, 3)
+    q = np.zeros((18, 4)); t = np.zeros((18, 3))
+    n = rlib().oracle_sqpnp(feat.shape[0], capi.ptr(feat, C.c_double), capi.ptr(world, C.c_double),
+                            capi.ptr(q, C.c_double), capi.ptr(t, C.c_double))
+    return q[:n], t[:n]
+
+
+def svd9(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    U = np.zeros((9, 9)); S = np.zeros(9); V = np.zeros((9, 9))
+    rlib().oracle_svd9(capi.ptr(A, C.c_double), capi.ptr(U, C.c_double), capi.ptr(S, C.c_double), capi.ptr(V, C.c_double))
+    return U, S, V
+
+
+def rot_quat_roundtrip(R):
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    q = np.zeros(4); R2 = np.zeros((3, 3))
+    rlib().oracle_rot_quat_roundtrip(capi.ptr(R, C.c_double), capi.ptr(q, C.c_double), capi.ptr(R2, C.c_double))
+    return q, R2
+
+
 def estimate_models(est, subset):
     subset = np.ascontiguousarray(subset, dtype=np.float64)
-    m = np.zeros((10, 21))
+    m = np.zeros((18, 21))
     n = rlib().oracle_estimate_models(est, capi.ptr(subset, C.c_double), capi.ptr(m, C.c_double))
     return m[:n]
 

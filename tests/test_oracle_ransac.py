@@ -246,3 +246,114 @@ def test_prosac_sampler_properties():
     assert r["success"] and r["num_inliers"] > 0.8 * truth["inlier"][0].sum()
     # first scored models already have many inliers (samples drawn from the best data)
     assert r["trace"][2][:5].max() > 0.5 * truth["inlier"][0].sum()
+
+
+# ------------------------------------------------------------------ SQPnP
+def quat_to_matrix(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def test_svd9_and_quaternion_round_trip_against_numpy():
+    st = synth.Stream(91, 0)
+    B = (2 * st.uniform(np.arange(81)) - 1).reshape(9, 9)
+    for A in (B, B @ B.T, (B[:, :6] @ B[:, :6].T)):       # general, SPD, rank-6 PSD (the SQPnP Omega shape)
+        U, S, V = ol.svd9(A)
+        assert np.all(np.diff(S) <= 1e-12) and np.all(S >= 0)
+        assert np.abs(U @ np.diag(S) @ V.T - A).max() <= 1e-12 * max(1.0, np.abs(A).max())
+        assert np.abs(U.T @ U - np.eye(9)).max() <= 1e-13 and np.abs(V.T @ V - np.eye(9)).max() <= 1e-13
+        assert np.abs(S - np.linalg.svd(A, compute_uv=False)).max() <= 1e-12 * S[0]
+    for axis, deg in (((0, 0, 1), 13.0), ((1, 1, 1), 170.0), ((1, 0, 0), 180.0), ((0.2, -1, 0.3), -95.0)):
+        R = rot(axis, deg)
+        q, R2 = ol.rot_quat_roundtrip(R)
+        assert abs(np.linalg.norm(q) - 1) <= 1e-14 and np.abs(R2 - R).max() <= 1e-14
+
+
+SQP_POINTS = np.array([[-1.0, 3.0, 3.0], [1.0, -1.0, 2.0], [-1.0, 1.0, 2.0], [2.0, 1.0, 3.0],
+                       [-1.0, -3.0, 2.0], [1.0, -2.0, 1.0], [-1.0, 4.0, 2.0], [-2.0, 2.0, 3.0]])
+
+
+def _check_sqpnp(X, R, t, noise, max_reproj, max_rot_deg, max_trans_sq, seed=59):
+    pc = X @ R.T + t
+    uv = pc[:, :2] / pc[:, 2:]
+    if noise:
+        st = synth.Stream(seed, 1)
+        i = np.arange(len(X))
+        uv = uv + noise * np.stack([st.normal(2 * i), st.normal(2 * i + 1)], 1)
+    q, ts = ol.sqpnp(uv, X)
+    assert len(q) > 0
+    matched = False
+    for qi, ti in zip(q, ts):
+        Rs = quat_to_matrix(qi)
+        pr = X @ Rs.T + ti
+        assert np.all(np.sum((pr[:, :2] / pr[:, 2:] - uv) ** 2, axis=1) <= max_reproj)
+        ang = np.degrees(np.arccos(np.clip((np.trace(R.T @ Rs) - 1) / 2, -1, 1)))
+        if ang < max_rot_deg and np.sum((t - ti) ** 2) < max_trans_sq:
+            matched = True
+    assert matched
+
+
+def test_sqpnp_known_answers():
+    """sqpnp_test.cc: Basic (:130-152), NoiseTest (:156-181), ManyPoints-style sweeps (:183-260)."""
+    R = rot((0, 0, 1), 13.0); t = np.array([1.0, 1.0, 1.0])
+    _check_sqpnp(SQP_POINTS[:4], R, t, 0.0, 1e-4, 1.0, 1e-2)
+    _check_sqpnp(SQP_POINTS, R, t, 1.0 / 512.0, 5e-3, 0.25, 1e-2)
+    axes = [(0, 0, 1), (0, 1, 0), (1, 0, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1)]
+    angles = [7.0, 12.0, 15.0, 20.0, 11.0, 0.0]
+    trans = [(1, 1, 1), (3, 2, 13), (4, 5, 11), (1, 2, 15), (3, 1.5, 18), (0, 0, 0)]
+    st = synth.Stream(59, 7)
+    for k, (ax, an, tr) in enumerate(zip(axes, angles, trans)):
+        for npts in (100, 1000):
+            i = np.arange(npts)
+            X = np.stack([10 * st.uniform(3 * i + 7 * k) - 5, 10 * st.uniform(3 * i + 1 + 7 * k) - 5, 2 + 8 * st.uniform(3 * i + 2 + 7 * k)], 1)
+            _check_sqpnp(X, rot(ax, an), np.array(tr, float), 1.0 / 512.0, 1.0, 0.3, 5e-2)
+
+
+def test_sqpnp_minimal_three_points_models():
+    """What the RANSAC estimator feeds it (SampleSize() = 3).  With three points Omega has a
+    3-dimensional null space and RunSQP performs ONE iteration (sqpnp.cc:33-34), so the
+    solutions only approximately reproject the sample: reference behaviour, kept.  The
+    estimator's models are the quaternion round trip of those solutions."""
+    st = synth.Stream(93, 0)
+    for trial in range(40):
+        i = np.arange(3)
+        X = np.stack([4 * st.uniform(9 * trial + 3 * i) - 2, 4 * st.uniform(9 * trial + 3 * i + 1) - 2, 6 + 4 * st.uniform(9 * trial + 3 * i + 2)], 1)
+        R = rot((0.3, 1.0, -0.2), 10.0 + trial); t = np.array([0.2, -0.1, 0.5])
+        pc = X @ R.T + t
+        uv = pc[:, :2] / pc[:, 2:]
+        q, ts = ol.sqpnp(uv, X)
+        m = ol.estimate_models(4, np.hstack([uv, X]))
+        assert len(m) == len(q)
+        for qi, ti, mi in zip(q, ts, m):
+            Rs = quat_to_matrix(qi)
+            pr = X @ Rs.T + ti
+            assert np.abs(pr[:, :2] / pr[:, 2:] - uv).max() <= 5e-2
+            assert abs(np.linalg.det(Rs) - 1) <= 1e-9 and np.abs(Rs @ Rs.T - np.eye(3)).max() <= 1e-9
+            assert np.abs(mi[:9].reshape(3, 3) - Rs).max() <= 1e-14 and np.abs(mi[9:12] + Rs.T @ ti).max() <= 1e-12
+
+
+@pytest.mark.parametrize("mode", ["clean", "noise", "outliers"])
+def test_estimate_calibrated_absolute_pose_sqpnp(mode):
+    """estimate_calibrated_absolute_pose_test.cc ExecuteRandomTest with PnPType::SQPnP."""
+    R, position = ABS_ROT[1], ABS_POS[0]
+    st = synth.Stream(66, 77)
+    i = np.arange(100)
+    X = np.stack([4 * st.uniform(3 * i) - 2, 4 * st.uniform(3 * i + 1) - 2, 6 + 4 * st.uniform(3 * i + 2)], 1)
+    pc = (X - position) @ R.T
+    uv = pc[:, :2] / pc[:, 2:]
+    if mode == "outliers":
+        out = i >= 70
+        uv[out] = 2 * np.stack([st.uniform(2 * i + 900), st.uniform(2 * i + 901)], 1)[out] - 1
+    if mode == "noise":
+        uv = uv + 1e-3 * np.stack([st.normal(2 * i + 700), st.normal(2 * i + 701)], 1)
+    prm = ol.default_ransac_params((4.0 / 1000.0) ** 2, seed=66)
+    prm.use_mle = 1; prm.failure_probability = 0.001; prm.min_iterations = 50
+    r = ol.ransac_estimate(4, np.hstack([uv, X]), prm)
+    assert r["success"] and r["num_inliers"] > 3
+    Rm = r["model"][0:9].reshape(3, 3); pos = r["model"][9:12]
+    tol = 1e-2   # kPoseTolerance of the SQPnP cases (:217-248, :340-368); the minimal SQPnP models are approximate
+    cos_r = abs(np.sum(R * Rm)) / (np.linalg.norm(R) * np.linalg.norm(Rm))
+    cos_p = abs(position @ pos) / (np.linalg.norm(position) * np.linalg.norm(pos))
+    assert cos_r >= 1 - tol and cos_p >= 1 - tol

@@ -10,8 +10,8 @@ from tests import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-THR = {0: (2 / 1000.0) ** 2, 1: (2 / 1000.0) ** 2, 2: (4 / 1000.0) ** 2}
-MLEN = {0: 21, 1: 9, 2: 12}
+THR = {0: (2 / 1000.0) ** 2, 1: (2 / 1000.0) ** 2, 2: (4 / 1000.0) ** 2, 4: (4 / 1000.0) ** 2}
+MLEN = {0: 21, 1: 9, 2: 12, 4: 12}
 
 
 def test_five_point_and_p3p_bitwise_equal_oracle():
@@ -42,7 +42,30 @@ def test_single_problem_entry_points_known_answer():
     assert max(abs(np.sum(e * Egt)) / (np.linalg.norm(e) * np.linalg.norm(Egt)) for e in Es) >= 1 - 1e-4
 
 
-@pytest.mark.parametrize("est,kind", [(0, "relative"), (1, "relative"), (2, "absolute")])
+def test_sqpnp_bitwise_equal_oracle():
+    """Directly bound SQPnP (sfm.cc:592): minimal (3) and over-determined problems, ragged batch."""
+    st = synth.Stream(0x5017, 0)
+    feats, worlds = [], []
+    for k, n in enumerate([3, 3, 3, 4, 8, 50, 3, 200, 5, 3]):
+        i = np.arange(n)
+        X = np.stack([4 * st.uniform(1000 * k + 3 * i) - 2, 4 * st.uniform(1000 * k + 3 * i + 1) - 2, 6 + 4 * st.uniform(1000 * k + 3 * i + 2)], 1)
+        R = synth.angle_axis_to_matrix(np.array([0.1 * k, -0.05 * k, 0.02 * k])); t = np.array([0.3, -0.2, 0.4])
+        pc = X @ R.T + t
+        uv = pc[:, :2] / pc[:, 2:] + (1e-3 if k % 2 else 0.0) * np.stack([st.normal(1000 * k + 2 * i + 500), st.normal(1000 * k + 2 * i + 501)], 1)
+        feats.append(uv); worlds.append(X)
+    ns, q, t = ransac.SQPnP(feats, worlds)
+    for k in range(len(feats)):
+        qo, to = ol.sqpnp(feats[k], worlds[k])
+        assert len(qo) == ns[k] and ns[k] >= 1
+        assert np.array_equal(qo, q[k, : ns[k]]) and np.array_equal(to, t[k, : ns[k]])
+    ok, ql, tl = ransac.SQPnP(feats[5], worlds[5])
+    assert ok and np.array_equal(ql[0], q[5, 0])
+    # two points: the reference returns false
+    ok, ql, tl = ransac.SQPnP(feats[0][:2], worlds[0][:2])
+    assert not ok and ql == []
+
+
+@pytest.mark.parametrize("est,kind", [(0, "relative"), (1, "relative"), (2, "absolute"), (4, "absolute")])
 @pytest.mark.parametrize("use_mle", [0, 1])
 def test_inlier_sets_bit_identical_to_oracle(est, kind, use_mle):
     data, offsets, truth = synth.synth_ransac_v1(12, 400, kind, seed=0x5AC50300 + est)
@@ -57,7 +80,8 @@ def test_inlier_sets_bit_identical_to_oracle(est, kind, use_mle):
         assert np.array_equal(o["model"][: MLEN[est]], res["models"][i][: MLEN[est]], equal_nan=True)
         assert abs(o["confidence"] - res["confidence"][i]) <= 1e-15
         # the estimate explains most true inliers
-        assert res["inlier_mask"][sl][truth["inlier"][i]].mean() > 0.6
+        # (the one-iteration SQPnP minimal models are approximate: lower bar)
+        assert res["inlier_mask"][sl][truth["inlier"][i]].mean() > (0.6 if est != 4 else 0.2)
 
 
 def test_golden_fixture_inlier_sets():
@@ -108,6 +132,8 @@ def test_mirror_api_and_error_conventions():
     p.error_thresh = THR[2]
     ok, ap, s3 = ransac.EstimateCalibratedAbsolutePose(p, ransac.RansacType.RANSAC, ransac.PnPType.KNEIP, da)
     assert ok and np.abs(ap.position - ta["position"][0]).max() < 0.05
+    ok, aq, s4 = ransac.EstimateCalibratedAbsolutePose(p, ransac.RansacType.RANSAC, ransac.PnPType.SQPnP, da)
+    assert ok and np.abs(aq.position - ta["position"][0]).max() < 0.25 and len(s4.inliers) > 30
     bad = ransac.RansacParameters()  # error_thresh = -1 -> reference CHECK_GT aborts
     with pytest.raises(capi.TheiaHipError):
         ransac.EstimateRelativePose(bad, ransac.RansacType.RANSAC, data)
