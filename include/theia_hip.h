@@ -197,6 +197,31 @@ int theia_hip_ba_solve(const theia_ba_problem* problem,
                        const theia_ba_options* options,
                        theia_ba_summary* summary);
 
+/* A batch of INDEPENDENT single-view adjustments: problem i optimises the 6
+ * extrinsics cam_ext[i] against its observations [offsets[i], offsets[i+1]) of
+ * CONSTANT homogeneous world points, i.e. N calls of
+ * BundleAdjustView(options, view_id, reconstruction) (bundle_adjustment.cc:220-237;
+ * camera localisation, and RefineModel of the absolute-pose estimator,
+ * estimate_calibrated_absolute_pose.cc:120-153) as one launch: one whole LM solve
+ * per wavefront, no host round trips.  Honoured options: loss type / width,
+ * max_num_iterations, the three tolerances, max_trust_region_radius,
+ * constant_camera_{orientation,position}, orthographic_camera.  summaries[i]
+ * receives success / termination / iterations / initial / final cost (no trace). */
+typedef struct theia_ba_view_batch {
+  int32_t num_problems;
+  const int64_t* offsets;        /* [num_problems+1] observation offsets, offsets[0] = 0 */
+  const double* obs_uv;          /* [total][2] pixels                          */
+  const double* obs_sqrt_info;   /* [total][2] or NULL (= 1, 1)                */
+  const double* points;          /* [total][4] homogeneous world point of each observation */
+  double* cam_ext;               /* [num_problems][6] in/out                   */
+  const double* intrinsics;      /* [num_problems][THEIA_MAX_INTRINSICS]       */
+  const int32_t* model;          /* [num_problems] THEIA_CAM_*                 */
+  const uint8_t* cam_const;      /* [num_problems] THEIA_CAM_CONST_* bits or NULL */
+} theia_ba_view_batch;
+int theia_hip_ba_views_batch(const theia_ba_view_batch* batch,
+                             const theia_ba_options* options,
+                             theia_ba_summary* summaries);
+
 /* Handle API: problem resident in HBM across calls (bench, repeated solves). */
 typedef struct theia_ba_handle_s* theia_ba_handle;
 int theia_hip_ba_create(const theia_ba_problem* problem,

@@ -127,3 +127,35 @@ def solve(problem, options, trace_capacity=256):
     capi.check(capi.lib().theia_hip_ba_solve(C.byref(st), C.byref(options), C.byref(s)))
     tr.finish(s)
     return s, tr
+
+
+def solve_views_batch(offsets, obs_uv, points, cam_ext, intrinsics, model, options, cam_const=None, obs_sqrt_info=None):
+    """theia_hip_ba_views_batch: N independent BundleAdjustView problems
+    (bundle_adjustment.cc:220-237) in one launch.  cam_ext [N][6] is updated in
+    place; returns a list of BaSummary (no traces)."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    num = len(offsets) - 1
+    obs_uv = np.ascontiguousarray(obs_uv, dtype=np.float64).reshape(-1, 2)
+    points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 4)
+    intrinsics = np.ascontiguousarray(intrinsics, dtype=np.float64).reshape(num, capi.THEIA_MAX_INTRINSICS)
+    model = np.ascontiguousarray(model, dtype=np.int32)
+    if not (cam_ext.flags["C_CONTIGUOUS"] and cam_ext.dtype == np.float64 and cam_ext.shape == (num, 6)):
+        raise capi.TheiaHipError(-1, "cam_ext must be a C-contiguous float64 [N][6] array (updated in place)")
+    st = capi.BaViewBatch()
+    st.num_problems = num
+    st.offsets = offsets.ctypes.data_as(C.POINTER(C.c_int64))
+    st.obs_uv = capi.ptr(obs_uv, C.c_double); st.points = capi.ptr(points, C.c_double)
+    st.cam_ext = capi.ptr(cam_ext, C.c_double); st.intrinsics = capi.ptr(intrinsics, C.c_double)
+    st.model = capi.ptr(model, C.c_int32)
+    keep = [offsets, obs_uv, points, intrinsics, model]
+    if cam_const is not None:
+        cc = np.ascontiguousarray(cam_const, dtype=np.uint8); keep.append(cc)
+        st.cam_const = capi.ptr(cc, C.c_uint8)
+    if obs_sqrt_info is not None:
+        si = np.ascontiguousarray(obs_sqrt_info, dtype=np.float64).reshape(-1, 2); keep.append(si)
+        st.obs_sqrt_info = capi.ptr(si, C.c_double)
+    summ = (capi.BaSummary * max(1, num))()
+    L = capi.lib()
+    L.theia_hip_ba_views_batch.argtypes = [C.POINTER(capi.BaViewBatch), C.POINTER(capi.BaOptions), C.POINTER(capi.BaSummary)]
+    capi.check(L.theia_hip_ba_views_batch(C.byref(st), C.byref(options), summ))
+    return [summ[i] for i in range(num)]

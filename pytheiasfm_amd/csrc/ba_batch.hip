@@ -1,0 +1,357 @@
+// ba_batch.hip -- batches of INDEPENDENT small bundle adjustments, one whole
+// Levenberg-Marquardt solve per wavefront, no host round trips.
+//
+// Replaces N calls of BundleAdjustView (bundle_adjustment.cc:220-237: one view's
+// 6 extrinsics against constant tracks -- camera localisation in the incremental
+// pipeline, and the LO-RANSAC refinement of the absolute-pose estimator,
+// estimate_calibrated_absolute_pose.cc:120-153) by one launch.  The pipelines
+// call these from a thread pool, thousands of times per reconstruction
+// (SURVEY 8f rank 1): on a GPU they are one batch.
+//
+// Same trust-region rules as ba_solver.hip (Ceres 2.2 TrustRegionMinimizer +
+// LevenbergMarquardtStrategy, Jacobi scaling, loss corrector), restated for a
+// 6 x 6 system whose model-cost change is  y'g - y'Hy/2.  Lane = observation
+// (stride 64); the 6 x 6 normal equations are wave-reduced in a fixed order.
+#include "ba_device.h"
+#include "theia_hip_internal.h"
+
+#include <chrono>
+#include <cmath>
+#include <vector>
+
+#define HIP_TRY(expr)                                                                             \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return thip::set_error(THEIA_HIP_ERR_INTERNAL, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+namespace thip {
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+struct ViewBatch {
+  int num;
+  const int64_t* offsets;
+  const double2* uv;
+  const double2* si;      // or nullptr
+  const double4* X;
+  double* cam;            // [num][6] in/out
+  const double* intr;     // [num][10]
+  const int* model;
+  const uint8_t* mask;    // [num] frozen extrinsics columns (bit q)
+  int loss_type;
+  double loss_width;
+  int max_iterations;
+  double function_tolerance, gradient_tolerance, parameter_tolerance, max_radius;
+};
+
+struct ViewOut {
+  int success, term, iters, nsucc;
+  double initial_cost, final_cost;
+};
+
+// residual-only cost of the camera `ext` over the wave's observation range
+__device__ double view_cost(const ViewBatch& B, int p, const double* ext, int lane, double* invalid) {
+  const int64_t beg = B.offsets[p], end = B.offsets[p + 1];
+  const int model = B.model[p];
+  const double* intr = B.intr + (size_t)p * THEIA_MAX_INTRINSICS;
+  double cost = 0.0, inv = 0.0;
+  for (int64_t o = beg + lane; o < end; o += 64) {
+    const double2 uv = B.uv[o];
+    double six = 1.0, siy = 1.0;
+    if (B.si) { const double2 s = B.si[o]; six = s.x; siy = s.y; }
+    const double4 Xv = B.X[o];
+    const double X[4] = {Xv.x, Xv.y, Xv.z, Xv.w};
+    ObsLin ol;
+    observe<false, false>(model, ext, intr, X, uv.x, uv.y, six, siy, ol);
+    if (!ol.valid) inv += 1.0;
+    double rho1;
+    cost += 0.5 * loss_eval(B.loss_type, B.loss_width, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
+  }
+  *invalid = wsum(inv);
+  return wsum(cost);
+}
+
+// linearise at `ext`: H (packed lower 21) = J'J, g = J'r, cost; J scaled by `scale`
+__device__ void view_linearize(const ViewBatch& B, int p, const double* ext, const double* scale, unsigned mask,
+                               int lane, double* H, double* g, double* cost, double* invalid) {
+  const int64_t beg = B.offsets[p], end = B.offsets[p + 1];
+  const int model = B.model[p];
+  const double* intr = B.intr + (size_t)p * THEIA_MAX_INTRINSICS;
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+  double inv = 0.0;
+  for (int64_t o = beg + lane; o < end; o += 64) {
+    const double2 uv = B.uv[o];
+    double six = 1.0, siy = 1.0;
+    if (B.si) { const double2 s = B.si[o]; six = s.x; siy = s.y; }
+    const double4 Xv = B.X[o];
+    const double X[4] = {Xv.x, Xv.y, Xv.z, Xv.w};
+    ObsLin ol;
+    observe<true, false>(model, ext, intr, X, uv.x, uv.y, six, siy, ol);
+    if (!ol.valid) inv += 1.0;
+    double rho1;
+    const double rho = loss_eval(B.loss_type, B.loss_width, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
+    const double sr = sqrt(rho1);
+    const double r0 = sr * ol.r[0], r1 = sr * ol.r[1];
+    double J[12];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const double sc = ((mask >> q) & 1u) ? 0.0 : sr * scale[q];
+      J[q] = ol.Jc[q] * sc; J[6 + q] = ol.Jc[6 + q] * sc;
+    }
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int b = 0; b <= a; ++b) acc[k++] += J[a] * J[b] + J[6 + a] * J[6 + b];
+      acc[21 + a] += J[a] * r0 + J[6 + a] * r1;
+    }
+    acc[27] += 0.5 * rho;
+  }
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = wsum(acc[k]);
+#pragma unroll
+  for (int k = 0; k < 21; ++k) H[k] = acc[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) g[k] = acc[21 + k];
+  *cost = acc[27];
+  *invalid = wsum(inv);
+}
+
+__device__ __forceinline__ int tri(int a, int b) { return a * (a + 1) / 2 + b; }
+
+// (H + diag(d)) y = g by Cholesky; false if not positive definite
+__device__ bool solve6(const double* H, const double* d, const double* g, double* y) {
+  double L[21];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = H[tri(i, j)] + (i == j ? d[i] : 0.0);
+      for (int k = 0; k < j; ++k) s -= L[tri(i, k)] * L[tri(j, k)];
+      if (i == j) { if (!(s > 0.0)) return false; L[tri(i, i)] = sqrt(s); }
+      else L[tri(i, j)] = s / L[tri(j, j)];
+    }
+  double z[6];
+  for (int i = 0; i < 6; ++i) {
+    double s = g[i];
+    for (int k = 0; k < i; ++k) s -= L[tri(i, k)] * z[k];
+    z[i] = s / L[tri(i, i)];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double s = z[i];
+    for (int k = i + 1; k < 6; ++k) s -= L[tri(k, i)] * y[k];
+    y[i] = s / L[tri(i, i)];
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_view_lm(ViewBatch B, ViewOut* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= B.num) return;
+  const unsigned mask = B.mask ? B.mask[p] : 0u;
+  double x[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) x[q] = B.cam[(size_t)p * 6 + q];
+  ViewOut R;
+  R.success = 0; R.term = THEIA_TERM_NO_CONVERGENCE; R.iters = 0; R.nsucc = 0; R.initial_cost = 0.0; R.final_cost = 0.0;
+  double scale[6] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+  double H[21], g[6], x_cost, invalid;
+  // Jacobi scaling from the column norms at the initial point (once per solve)
+  view_linearize(B, p, x, scale, mask, lane, H, g, &x_cost, &invalid);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) scale[q] = 1.0 / (1.0 + sqrt(H[tri(q, q)]));
+  const bool all_const = (mask & 0x3fu) == 0x3fu;
+  double radius = 1e4, decrease_factor = 2.0;
+  bool step_successful = true, need_linearize = true;
+  int iter = 0, invalid_steps = 0, term = THEIA_TERM_NO_CONVERGENCE;
+  double x_norm = 0.0, minimum_cost = 0.0, gmax = 0.0;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) x_norm += x[q] * x[q];
+  x_norm = sqrt(x_norm);
+  bool first = true;
+  while (true) {
+    if (need_linearize) {
+      view_linearize(B, p, x, scale, mask, lane, H, g, &x_cost, &invalid);
+      gmax = 0.0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) gmax = fmax(gmax, fabs(g[q] / scale[q]));
+      need_linearize = false;
+    }
+    if (first) {
+      first = false;
+      R.initial_cost = x_cost;
+      minimum_cost = x_cost;
+      if (invalid > 0.0 || !isfinite(x_cost)) { term = THEIA_TERM_FAILURE; R.final_cost = x_cost; break; }
+      if (all_const) { term = THEIA_TERM_CONVERGENCE; break; }
+    }
+    if (iter >= B.max_iterations) { term = THEIA_TERM_NO_CONVERGENCE; break; }
+    if (step_successful && gmax <= B.gradient_tolerance) { term = THEIA_TERM_CONVERGENCE; break; }
+    if (radius <= 1e-32) { term = THEIA_TERM_CONVERGENCE; break; }
+    ++iter;
+    double d[6], y[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) d[q] = fmin(fmax(H[tri(q, q)], 1e-6), 1e32) / radius;
+    const bool pd = solve6(H, d, g, y);
+    // model cost change of the step -y:  y'g - y'Hy/2  (H without the LM diagonal)
+    double yg = 0.0, yHy = 0.0;
+    for (int a = 0; a < 6; ++a) {
+      yg += y[a] * g[a];
+      double row = 0.0;
+      for (int b = 0; b < 6; ++b) row += H[a >= b ? tri(a, b) : tri(b, a)] * y[b];
+      yHy += y[a] * row;
+    }
+    const double mcc = yg - 0.5 * yHy;
+    double cand[6], stepsq = 0.0, xnormsq = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      cand[q] = ((mask >> q) & 1u) ? x[q] : x[q] - y[q] * scale[q];
+      stepsq += (x[q] - cand[q]) * (x[q] - cand[q]);
+      xnormsq += cand[q] * cand[q];
+    }
+    const bool step_valid = pd && isfinite(mcc) && isfinite(stepsq) && mcc > 0.0;
+    if (!step_valid) {
+      if (++invalid_steps >= 5) { term = THEIA_TERM_FAILURE; break; }
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+      continue;
+    }
+    invalid_steps = 0;
+    double cinv;
+    double cand_cost = view_cost(B, p, cand, lane, &cinv);
+    if (cinv > 0.0 || !isfinite(cand_cost)) cand_cost = DBL_MAX;
+    const double step_norm = sqrt(stepsq);
+    if (step_norm <= B.parameter_tolerance * (x_norm + B.parameter_tolerance)) { term = THEIA_TERM_CONVERGENCE; break; }
+    const double cost_change = x_cost - cand_cost;
+    if (fabs(cost_change) <= B.function_tolerance * x_cost) { term = THEIA_TERM_CONVERGENCE; break; }
+    const double rho = cost_change / mcc;
+    if (rho > 1e-3) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) x[q] = cand[q];
+      x_norm = sqrt(xnormsq);
+      const double t = 2.0 * rho - 1.0;
+      radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+      radius = fmin(B.max_radius, radius);
+      decrease_factor = 2.0; step_successful = true; need_linearize = true;
+      R.nsucc++;
+      if (cand_cost < minimum_cost) minimum_cost = cand_cost;
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+    }
+  }
+  R.iters = iter; R.term = term; R.success = term != THEIA_TERM_FAILURE;
+  if (term != THEIA_TERM_FAILURE) R.final_cost = minimum_cost;
+  if (lane == 0) {
+    out[p] = R;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) B.cam[(size_t)p * 6 + q] = x[q];
+  }
+}
+
+template <typename T>
+struct Dev {
+  T* p = nullptr;
+  ~Dev() { if (p) (void)hipFree(p); }
+  int alloc(size_t n) {
+    if (hipMalloc((void**)&p, std::max<size_t>(1, n) * sizeof(T)) != hipSuccess)
+      return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", n * sizeof(T));
+    return 0;
+  }
+  int up(const void* src, size_t n) {
+    int rc = alloc(n);
+    if (rc) return rc;
+    if (n && hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+      return set_error(THEIA_HIP_ERR_INTERNAL, "hipMemcpy H2D failed");
+    return 0;
+  }
+};
+
+}  // namespace
+
+// device-resident variant for callers inside the library (LO-RANSAC)
+int views_batch_device(int num, const int64_t* d_offsets, const double* d_uv, const double* d_si, const double* d_X,
+                       double* d_cam, const double* d_intr, const int* d_model, const uint8_t* d_mask,
+                       const theia_ba_options* o, void* d_out /* ViewOut[num] */, hipStream_t st) {
+  ViewBatch B;
+  B.num = num; B.offsets = d_offsets; B.uv = reinterpret_cast<const double2*>(d_uv);
+  B.si = reinterpret_cast<const double2*>(d_si); B.X = reinterpret_cast<const double4*>(d_X);
+  B.cam = d_cam; B.intr = d_intr; B.model = d_model; B.mask = d_mask;
+  B.loss_type = o->loss_function_type; B.loss_width = o->robust_loss_width; B.max_iterations = o->max_num_iterations;
+  B.function_tolerance = o->function_tolerance; B.gradient_tolerance = o->gradient_tolerance;
+  B.parameter_tolerance = o->parameter_tolerance; B.max_radius = o->max_trust_region_radius;
+  k_view_lm<<<(num + 3) / 4, 256, 0, st>>>(B, static_cast<ViewOut*>(d_out));
+  return 0;
+}
+size_t views_batch_out_bytes() { return sizeof(ViewOut); }
+void views_batch_unpack(const void* host_out, int i, int* success, int* term, int* iters, int* nsucc, double* c0, double* c1) {
+  const ViewOut& r = static_cast<const ViewOut*>(host_out)[i];
+  *success = r.success; *term = r.term; *iters = r.iters; *nsucc = r.nsucc; *c0 = r.initial_cost; *c1 = r.final_cost;
+}
+
+}  // namespace thip
+
+using namespace thip;
+
+extern "C" int theia_hip_ba_views_batch(const theia_ba_view_batch* b, const theia_ba_options* o, theia_ba_summary* summaries) {
+  if (!b || !o) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null batch/options");
+  const int num = b->num_problems;
+  if (num < 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "negative num_problems");
+  if (num == 0) return 0;
+  if (!b->offsets || !b->cam_ext || !b->intrinsics || !b->model || !summaries)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null array in batch");
+  if (b->offsets[0] != 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "offsets[0] must be 0");
+  for (int i = 0; i < num; ++i) {
+    if (b->offsets[i + 1] < b->offsets[i]) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
+    if (b->model[i] < THEIA_CAM_PINHOLE || b->model[i] > THEIA_CAM_ORTHOGRAPHIC)
+      return set_error(THEIA_HIP_ERR_UNSUPPORTED, "camera model %d of problem %d has no HIP kernel", b->model[i], i);
+  }
+  const int64_t total = b->offsets[num];
+  if (total > 0 && (!b->obs_uv || !b->points)) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null observation arrays");
+  if (o->loss_function_type < 0 || o->loss_function_type > THEIA_LOSS_TRUNCATED)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown loss function type");
+  if (o->max_num_iterations < 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "negative max_num_iterations");
+  int rc = thip::ensure_device();
+  if (rc) return rc;
+  std::vector<uint8_t> mask(num);
+  for (int i = 0; i < num; ++i) {
+    unsigned m = b->cam_const ? b->cam_const[i] : 0u;
+    if (o->constant_camera_orientation) m |= THEIA_CAM_CONST_ORIENTATION;
+    if (o->constant_camera_position) m |= THEIA_CAM_CONST_POSITION;
+    if (o->orthographic_camera) m |= THEIA_CAM_CONST_TZ;
+    unsigned cols = 0;
+    if (m & THEIA_CAM_CONST_POSITION) cols |= 0x07;
+    if (m & THEIA_CAM_CONST_ORIENTATION) cols |= 0x38;
+    if (m & THEIA_CAM_CONST_TZ) cols |= 0x04;
+    mask[i] = (uint8_t)cols;
+  }
+  Dev<int64_t> d_off; Dev<double> d_uv, d_si, d_X, d_cam, d_intr; Dev<int> d_model; Dev<uint8_t> d_mask; Dev<char> d_out;
+  if ((rc = d_off.up(b->offsets, num + 1)) || (rc = d_uv.up(b->obs_uv, 2 * total)) || (rc = d_X.up(b->points, 4 * total)) ||
+      (rc = d_cam.up(b->cam_ext, 6 * (size_t)num)) || (rc = d_intr.up(b->intrinsics, THEIA_MAX_INTRINSICS * (size_t)num)) ||
+      (rc = d_model.up(b->model, num)) || (rc = d_mask.up(mask.data(), num)) || (rc = d_out.alloc(views_batch_out_bytes() * num)))
+    return rc;
+  if (b->obs_sqrt_info && (rc = d_si.up(b->obs_sqrt_info, 2 * total))) return rc;
+  const double t0 = now_s();
+  views_batch_device(num, d_off.p, d_uv.p, b->obs_sqrt_info ? d_si.p : nullptr, d_X.p, d_cam.p, d_intr.p, d_model.p, d_mask.p, o,
+                     d_out.p, nullptr);
+  std::vector<char> h_out(views_batch_out_bytes() * num);
+  HIP_TRY(hipMemcpy(h_out.data(), d_out.p, h_out.size(), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(b->cam_ext, d_cam.p, sizeof(double) * 6 * num, hipMemcpyDeviceToHost));
+  const double dt = now_s() - t0;
+  for (int i = 0; i < num; ++i) {
+    theia_ba_summary& S = summaries[i];
+    S.trace_size = 0;
+    views_batch_unpack(h_out.data(), i, &S.success, &S.termination_type, &S.num_iterations, &S.num_successful_steps,
+                       &S.initial_cost, &S.final_cost);
+    S.setup_time_in_seconds = 0.0; S.solve_time_in_seconds = dt / num;
+    S.time_linearize = S.time_solve_reduced = S.time_backsub = S.time_kernel_linearize = 0.0;
+    S.num_linearize_launches = 0;
+  }
+  return 0;
+}

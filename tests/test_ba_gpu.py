@@ -387,3 +387,89 @@ def test_level_scheduled_sparse_cholesky_matches_dense_schedule(monkeypatch):
     assert s0.num_iterations == s1.num_iterations and np.array_equal(t0.accepted, t1.accepted)
     assert rel(t0.cost, t1.cost) <= 1e-11
     assert np.abs(q0.cam_ext - q1.cam_ext).max() <= 1e-9 and np.abs(q0.points - q1.points).max() <= 1e-9
+
+
+def _view_batch(num, seed, models=(0,), noise=0.3):
+    """num independent localisation problems: 30..400 constant points each, perturbed pose."""
+    st = synth.Stream(seed, 0)
+    offs = [0]; uvs = []; Xs = []; cams = []; intr = []; mods = []; truth = []
+    for k in range(num):
+        n = 30 + int(370 * st.uniform(np.array([7 * k]))[0])
+        i = np.arange(n)
+        X = np.stack([6 * st.uniform(10000 * k + 3 * i) - 3, 6 * st.uniform(10000 * k + 3 * i + 1) - 3, 6 * st.uniform(10000 * k + 3 * i + 2) - 3], 1)
+        model = models[k % len(models)]
+        kk = np.zeros(10); kv = CAMERA_MODEL_INTRINSICS[model]; kk[: len(kv)] = kv
+        pos = np.array([10.0, 0.3 * k - 1.0, 0.5]); z = -pos / np.linalg.norm(pos)
+        xa = np.cross([0, 0, 1.0], z); xa /= np.linalg.norm(xa); R = np.stack([xa, np.cross(z, xa), z])
+        ext = np.concatenate([pos, synth.matrix_to_angle_axis(R)])
+        X4 = np.hstack([X, np.ones((n, 1))])
+        truth.append(ext.copy())
+        cams.append(ext + np.concatenate([0.05 * (2 * st.uniform(50 * k + np.arange(3) + 99) - 1), 0.01 * (2 * st.uniform(50 * k + np.arange(3) + 199) - 1)]))
+        uvs.append((model, kk, ext, X4, noise * np.stack([st.normal(10000 * k + 2 * i + 5000), st.normal(10000 * k + 2 * i + 5001)], 1)))
+        Xs.append(X4); intr.append(kk); mods.append(model); offs.append(offs[-1] + n)
+    return offs, uvs, Xs, np.array(cams), np.array(intr), np.array(mods, np.int32), np.array(truth)
+
+
+def test_views_batch_matches_per_problem_oracle():
+    """theia_hip_ba_views_batch = N x BundleAdjustView: every problem follows the
+    oracle's LM on the same one-camera problem (costs, iteration counts, pose)."""
+    num = 24
+    offs, obs, Xs, cams, intr, mods, truth = _view_batch(num, 0xBA7C, models=(0, 5, 2, 1))
+    o, oo = both_options(max_num_iterations=15, use_homogeneous_point_parametrization=0)
+    # observations: project with the ORACLE's evaluate on the true pose (residual = -uv at uv = 0)
+    uv_all = []
+    flats = []
+    for k in range(num):
+        model, kk, ext, X4, nz = obs[k]
+        n = X4.shape[0]
+        fp = capi.FlatProblem(ext[None].copy(), kk[None].copy(), np.array([model], np.int32), np.array([0], np.int32), X4.copy(),
+                              np.zeros((n, 2)), np.zeros(n, np.int32), np.arange(n, dtype=np.int32), point_const=np.ones(n, np.uint8))
+        ok, _, r, _, _ = ol.evaluate(fp, oo)
+        uv = r + nz                      # r = projection - 0
+        uv_all.append(uv)
+        fp.obs_uv = uv.copy(); fp.cam_ext = cams[k][None].copy()
+        flats.append(fp)
+    cam_gpu = cams.copy()
+    summ = ba.solve_views_batch(np.array(offs), np.vstack(uv_all), np.vstack(Xs), cam_gpu, intr, mods, o)
+    for k in range(num):
+        so, _ = ol.solve(flats[k], oo)
+        s = summ[k]
+        assert s.success == so.success and s.termination_type == so.termination_type, k
+        assert s.num_iterations == so.num_iterations and s.num_successful_steps == so.num_successful_steps, k
+        assert abs(s.initial_cost - so.initial_cost) <= 1e-10 * so.initial_cost
+        assert abs(s.final_cost - so.final_cost) <= 1e-9 * so.final_cost
+        assert np.abs(cam_gpu[k] - flats[k].cam_ext[0]).max() <= 1e-9
+        assert np.abs(cam_gpu[k][:3] - truth[k][:3]).max() < 0.05   # localised
+
+
+def test_views_batch_lo_options_and_masks():
+    """The LO-RANSAC refinement settings (HUBER, 2 iterations, estimate_calibrated_absolute_pose.cc:124-129)
+    and constant-position / constant-camera masks."""
+    num = 8
+    offs, obs, Xs, cams, intr, mods, truth = _view_batch(num, 0xBA7D, models=(0,))
+    o, oo = both_options(max_num_iterations=2, use_homogeneous_point_parametrization=0, loss_function_type=1, robust_loss_width=0.5)
+    uv_all, flats = [], []
+    cc = np.array([0, 1, 2, 3, 0, 4, 0, 0], np.uint8)
+    for k in range(num):
+        model, kk, ext, X4, nz = obs[k]
+        n = X4.shape[0]
+        fp = capi.FlatProblem(ext[None].copy(), kk[None].copy(), np.array([model], np.int32), np.array([0], np.int32), X4.copy(),
+                              np.zeros((n, 2)), np.zeros(n, np.int32), np.arange(n, dtype=np.int32), point_const=np.ones(n, np.uint8),
+                              cam_const=np.array([cc[k]], np.uint8))
+        ok, _, r, _, _ = ol.evaluate(fp, ol.default_options())
+        uv = r + nz
+        uv[::7] += 25.0                 # gross outliers for the Huber loss
+        uv_all.append(uv)
+        fp.obs_uv = uv.copy(); fp.cam_ext = cams[k][None].copy()
+        flats.append(fp)
+    cam_gpu = cams.copy()
+    summ = ba.solve_views_batch(np.array(offs), np.vstack(uv_all), np.vstack(Xs), cam_gpu, intr, mods, o, cam_const=cc)
+    for k in range(num):
+        so, _ = ol.solve(flats[k], oo)
+        s = summ[k]
+        assert s.num_iterations == so.num_iterations and s.success == so.success, k
+        assert abs(s.final_cost - so.final_cost) <= 1e-9 * max(so.final_cost, 1e-300), k
+        assert np.abs(cam_gpu[k] - flats[k].cam_ext[0]).max() <= 1e-9
+    assert np.array_equal(cam_gpu[3], cams[3])                       # whole camera constant
+    assert np.array_equal(cam_gpu[1][:3], cams[1][:3]) and not np.array_equal(cam_gpu[1][3:], cams[1][3:])
+    assert cam_gpu[5][2] == cams[5][2]
