@@ -340,6 +340,7 @@ typedef struct theia_ransac_result {
   int64_t hypotheses_evaluated;/* minimal samples fitted + fully scored    */
   int64_t models_scored;       /* models scored against all data           */
   double time_fit_score_seconds; /* device time in the fit+score kernels   */
+  int32_t* num_lo_iterations;  /* [num_problems] RansacSummary::num_lo_iterations, or NULL */
 } theia_ransac_result;
 
 /* Replaces SampleConsensusEstimator<E>::Estimate

@@ -101,7 +101,7 @@ class RansacResult(C.Structure):
                 ("inlier_mask", c_uint8_p), ("num_iterations", c_int32_p),
                 ("confidence", c_double_p),
                 ("hypotheses_evaluated", C.c_int64), ("models_scored", C.c_int64),
-                ("time_fit_score_seconds", C.c_double)]
+                ("time_fit_score_seconds", C.c_double), ("num_lo_iterations", c_int32_p)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)

@@ -39,6 +39,7 @@ __device__ __forceinline__ double wsum(double v) {
 struct ViewBatch {
   int num;
   const int64_t* offsets;
+  const int* counts;      // optional: problem p = [offsets[p], offsets[p] + counts[p]) (device-built batches)
   const double2* uv;
   const double2* si;      // or nullptr
   const double4* X;
@@ -59,7 +60,7 @@ struct ViewOut {
 
 // residual-only cost of the camera `ext` over the wave's observation range
 __device__ double view_cost(const ViewBatch& B, int p, const double* ext, int lane, double* invalid) {
-  const int64_t beg = B.offsets[p], end = B.offsets[p + 1];
+  const int64_t beg = B.offsets[p], end = B.counts ? beg + B.counts[p] : B.offsets[p + 1];
   const int model = B.model[p];
   const double* intr = B.intr + (size_t)p * THEIA_MAX_INTRINSICS;
   double cost = 0.0, inv = 0.0;
@@ -82,7 +83,7 @@ __device__ double view_cost(const ViewBatch& B, int p, const double* ext, int la
 // linearise at `ext`: H (packed lower 21) = J'J, g = J'r, cost; J scaled by `scale`
 __device__ void view_linearize(const ViewBatch& B, int p, const double* ext, const double* scale, unsigned mask,
                                int lane, double* H, double* g, double* cost, double* invalid) {
-  const int64_t beg = B.offsets[p], end = B.offsets[p + 1];
+  const int64_t beg = B.offsets[p], end = B.counts ? beg + B.counts[p] : B.offsets[p + 1];
   const int model = B.model[p];
   const double* intr = B.intr + (size_t)p * THEIA_MAX_INTRINSICS;
   double acc[28];
@@ -276,11 +277,11 @@ struct Dev {
 }  // namespace
 
 // device-resident variant for callers inside the library (LO-RANSAC)
-int views_batch_device(int num, const int64_t* d_offsets, const double* d_uv, const double* d_si, const double* d_X,
+int views_batch_device(int num, const int64_t* d_offsets, const int* d_counts, const double* d_uv, const double* d_si, const double* d_X,
                        double* d_cam, const double* d_intr, const int* d_model, const uint8_t* d_mask,
                        const theia_ba_options* o, void* d_out /* ViewOut[num] */, hipStream_t st) {
   ViewBatch B;
-  B.num = num; B.offsets = d_offsets; B.uv = reinterpret_cast<const double2*>(d_uv);
+  B.num = num; B.offsets = d_offsets; B.counts = d_counts; B.uv = reinterpret_cast<const double2*>(d_uv);
   B.si = reinterpret_cast<const double2*>(d_si); B.X = reinterpret_cast<const double4*>(d_X);
   B.cam = d_cam; B.intr = d_intr; B.model = d_model; B.mask = d_mask;
   B.loss_type = o->loss_function_type; B.loss_width = o->robust_loss_width; B.max_iterations = o->max_num_iterations;
@@ -338,7 +339,7 @@ extern "C" int theia_hip_ba_views_batch(const theia_ba_view_batch* b, const thei
     return rc;
   if (b->obs_sqrt_info && (rc = d_si.up(b->obs_sqrt_info, 2 * total))) return rc;
   const double t0 = now_s();
-  views_batch_device(num, d_off.p, d_uv.p, b->obs_sqrt_info ? d_si.p : nullptr, d_X.p, d_cam.p, d_intr.p, d_model.p, d_mask.p, o,
+  views_batch_device(num, d_off.p, nullptr, d_uv.p, b->obs_sqrt_info ? d_si.p : nullptr, d_X.p, d_cam.p, d_intr.p, d_model.p, d_mask.p, o,
                      d_out.p, nullptr);
   std::vector<char> h_out(views_batch_out_bytes() * num);
   HIP_TRY(hipMemcpy(h_out.data(), d_out.p, h_out.size(), hipMemcpyDeviceToHost));

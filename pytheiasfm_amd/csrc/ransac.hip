@@ -252,6 +252,92 @@ __global__ void k_p3p(int num, const double* __restrict__ corr, double* __restri
   for (int k = 0; k < 12; ++k) t[(size_t)i * 12 + k] = (k < 3 * n) ? tt[k] : 0.0;
 }
 
+// ---- LO-RANSAC refinement of the absolute-pose estimator (RefineModel,
+// estimate_calibrated_absolute_pose.cc:120-153): the events of all problems of a
+// replay round are refined as ONE batch of single-view LM solves (ba_batch.hip).
+// An event = (problem, model source); source: refit from (samples, slot), or the
+// problem's current best model.
+__global__ void k_lo_prepare(int est, int nev, const int* __restrict__ ev_prob, const int* __restrict__ ev_samples,
+                             const int* __restrict__ ev_slot, const int64_t* __restrict__ offsets,
+                             const double* __restrict__ data, const double* __restrict__ cur_models,
+                             double* __restrict__ ev_model, double* __restrict__ ev_cam) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nev) return;
+  const int p = ev_prob[e];
+  double mo[kStride];
+  for (int k = 0; k < kStride; ++k) mo[k] = 0.0;
+  if (ev_slot[e] < 0) {
+    for (int k = 0; k < kStride; ++k) mo[k] = cur_models[(size_t)p * kStride + k];
+  } else {
+    const int m = sample_size(est), ds = datum_size(est);
+    const double* pd = data + (size_t)offsets[p] * ds;
+    double subset[25];
+    for (int i = 0; i < m; ++i) {
+      const int idx = ev_samples[e * 5 + i];
+      for (int k = 0; k < ds; ++k) subset[i * ds + k] = pd[(size_t)idx * ds + k];
+    }
+    double mloc[kMaxCap * kStride];
+    const int nm = estimate_models(est, subset, mloc);
+    if (ev_slot[e] < nm) for (int k = 0; k < kStride; ++k) mo[k] = mloc[ev_slot[e] * kStride + k];
+  }
+  for (int k = 0; k < kStride; ++k) ev_model[(size_t)e * kStride + k] = mo[k];
+  // Camera::SetPosition / SetOrientationFromRotationMatrix
+  double* c = ev_cam + (size_t)e * 6;
+  c[0] = mo[9]; c[1] = mo[10]; c[2] = mo[11];
+  rsc::rot_to_angle_axis(mo, c + 3);
+}
+
+// inliers of the event's model, in data order, compacted as (uv, X, 1) for the view batch; one wave per event
+__global__ __launch_bounds__(64) void k_lo_gather(int est, const int* __restrict__ ev_prob, const int64_t* __restrict__ offsets,
+                                                  const double* __restrict__ data, const double* __restrict__ ev_model,
+                                                  double thresh, const int64_t* __restrict__ ev_off, int* __restrict__ ev_count,
+                                                  double2* __restrict__ uv, double4* __restrict__ X) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const int p = ev_prob[e];
+  const int n = (int)(offsets[p + 1] - offsets[p]);
+  const double* pd = data + (size_t)offsets[p] * 5;
+  double m[kStride];
+  for (int k = 0; k < kStride; ++k) m[k] = ev_model[(size_t)e * kStride + k];
+  int base = 0;
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int i = i0 + lane;
+    bool in = false;
+    if (i < n) in = model_error(est, m, pd + (size_t)i * 5) < thresh;
+    const unsigned long long b = __ballot(in);
+    if (in) {
+      const int pos = base + __popcll(b & ((1ull << lane) - 1ull));
+      const double* d = pd + (size_t)i * 5;
+      uv[ev_off[e] + pos] = make_double2(d[0], d[1]);
+      X[ev_off[e] + pos] = make_double4(d[2], d[3], d[4], 1.0);
+    }
+    base += __popcll(b);
+  }
+  if (lane == 0) ev_count[e] = base;
+}
+
+struct LoOut { int success, term, iters, nsucc; double c0, c1; };   // = ba_batch.hip ViewOut
+
+// refined pose back into the problem's model (written even when RefineModel returns false)
+__global__ void k_lo_finish(int nev, const int* __restrict__ ev_prob, const double* __restrict__ ev_cam,
+                            const LoOut* __restrict__ out, double* __restrict__ cur_models, int* __restrict__ ev_success) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nev) return;
+  const int p = ev_prob[e];
+  const double* c = ev_cam + (size_t)e * 6;
+  double* mo = cur_models + (size_t)p * kStride;
+  rsc::angle_axis_to_rot(c + 3, mo);
+  mo[9] = c[0]; mo[10] = c[1]; mo[11] = c[2];
+  for (int k = 12; k < kStride; ++k) mo[k] = 0.0;
+  ev_success[e] = (out[e].c1 < out[e].c0 && out[e].success) ? 1 : 0;
+}
+
+__global__ void k_select_models(int nprob, const int* __restrict__ use_cur, const double* __restrict__ cur_models,
+                                double* __restrict__ best_models) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nprob || !use_cur[p]) return;
+  for (int k = 0; k < kStride; ++k) best_models[(size_t)p * kStride + k] = cur_models[(size_t)p * kStride + k];
+}
+
 // SQPnP on problems of any size (the directly bound solver, sfm.cc:592): one thread per problem
 __global__ void k_sqpnp(int num, const int64_t* __restrict__ offsets, const double* __restrict__ feat,
                         const double* __restrict__ world, double* __restrict__ quats, double* __restrict__ ts,
@@ -366,6 +452,11 @@ struct ProblemState {
   int best_samples[5];
   int round_iters;
   int kth;  // PROSAC sample counter
+  // replay cursor inside the current round and LO-RANSAC state
+  int base_it, rb, rj;
+  bool round_done, best_refined;
+  double pending_ratio;
+  int num_lo;
 };
 
 #define HIP_TRYR(expr)                                                                               \
@@ -424,7 +515,10 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   if (est == THEIA_EST_ABSOLUTE_POSE_DLS)
     return set_error(THEIA_HIP_ERR_UNSUPPORTED, "the DLS minimal solver has no HIP kernel yet");
   if (est < 0 || est > THEIA_EST_ABSOLUTE_POSE_SQPNP) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
-  if (P.use_lo) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: LO-RANSAC refinement is not built yet (DESIGN.md scope)");
+  const bool abs_pose = est == THEIA_EST_ABSOLUTE_POSE_KNEIP || est == THEIA_EST_ABSOLUTE_POSE_SQPNP;
+  if (P.use_lo && !abs_pose)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: only the absolute-pose RefineModel (BundleAdjustView) is built; "
+                     "the relative-pose one (BundleAdjustTwoViewsAngular) is not yet");
   if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "ExhaustiveSampler makes a hard assumption that the number of samples needed is 2.");
   if (P.ransac_type == THEIA_RANSAC_LMED)
@@ -498,9 +592,65 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     if (P.min_inlier_ratio > 0)
       s.max_iterations = std::min(compute_max_iterations(P, m, P.min_inlier_ratio, log_failure_prob, s.n), P.max_iterations);
     s.it = 0; s.done = s.max_iterations <= 0; s.best_slot = -1; s.kth = 1;
+    s.base_it = 0; s.rb = 0; s.rj = 0; s.round_done = true; s.best_refined = false; s.pending_ratio = 0.0; s.num_lo = 0;
     for (int k = 0; k < 5; ++k) s.best_samples[k] = 0;
   }
   double fit_score_ms = 0.0;
+  // ---- LO-RANSAC (absolute pose): batched RefineModel over a list of events
+  DBuf<int> d_ev_prob, d_ev_samples, d_ev_slot, d_ev_count, d_ev_success, d_lo_model_id;
+  DBuf<int64_t> d_ev_off;
+  DBuf<double> d_ev_model, d_ev_cam, d_lo_uv, d_lo_X, d_cur_models, d_lo_intr;
+  DBuf<char> d_lo_out;
+  theia_ba_options lo_opts;
+  theia_ba_options_default(&lo_opts);
+  lo_opts.max_num_iterations = 2;                        // estimate_calibrated_absolute_pose.cc:124-129
+  lo_opts.use_homogeneous_point_parametrization = 0;
+  lo_opts.intrinsics_to_optimize = THEIA_INTR_NONE;
+  lo_opts.loss_function_type = THEIA_LOSS_HUBER;
+  lo_opts.robust_loss_width = P.error_thresh * 1.5;
+  lo_opts.use_inner_iterations = 0;
+  if (P.use_lo && (rc = d_cur_models.ensure((size_t)nprob * kStride))) return rc;
+  struct LoEvent { int prob, slot; int samples[5]; };
+  // refines every event's model on its inliers; writes the refined pose to d_cur_models[prob]
+  auto run_lo = [&](const std::vector<LoEvent>& evs, std::vector<int>& success) -> int {
+    const int nev = (int)evs.size();
+    success.assign(nev, 0);
+    if (nev == 0) return 0;
+    std::vector<int> hp(nev), hs((size_t)nev * 5), hsl(nev), hmod(nev, THEIA_CAM_PINHOLE);
+    std::vector<int64_t> hoff(nev + 1, 0);
+    std::vector<double> hintr((size_t)nev * THEIA_MAX_INTRINSICS, 0.0);
+    for (int e = 0; e < nev; ++e) {
+      hp[e] = evs[e].prob; hsl[e] = evs[e].slot;
+      for (int k = 0; k < 5; ++k) hs[(size_t)e * 5 + k] = evs[e].samples[k];
+      hoff[e + 1] = hoff[e] + S[evs[e].prob].n;          // capacity: every datum could be an inlier
+      hintr[(size_t)e * THEIA_MAX_INTRINSICS] = 1.0; hintr[(size_t)e * THEIA_MAX_INTRINSICS + 1] = 1.0;   // Camera(): f = 1, aspect 1
+    }
+    int rc2;
+    if ((rc2 = d_ev_prob.ensure(nev)) || (rc2 = d_ev_samples.ensure((size_t)nev * 5)) || (rc2 = d_ev_slot.ensure(nev)) ||
+        (rc2 = d_ev_count.ensure(nev)) || (rc2 = d_ev_success.ensure(nev)) || (rc2 = d_ev_off.ensure(nev + 1)) ||
+        (rc2 = d_ev_model.ensure((size_t)nev * kStride)) || (rc2 = d_ev_cam.ensure((size_t)nev * 6)) ||
+        (rc2 = d_lo_uv.ensure((size_t)hoff[nev] * 2)) || (rc2 = d_lo_X.ensure((size_t)hoff[nev] * 4)) ||
+        (rc2 = d_lo_intr.ensure(hintr.size())) || (rc2 = d_lo_model_id.ensure(nev)) ||
+        (rc2 = d_lo_out.ensure(views_batch_out_bytes() * nev)))
+      return rc2;
+    HIP_TRYR(hipMemcpyAsync(d_ev_prob.p, hp.data(), sizeof(int) * nev, hipMemcpyHostToDevice, st));
+    HIP_TRYR(hipMemcpyAsync(d_ev_samples.p, hs.data(), sizeof(int) * nev * 5, hipMemcpyHostToDevice, st));
+    HIP_TRYR(hipMemcpyAsync(d_ev_slot.p, hsl.data(), sizeof(int) * nev, hipMemcpyHostToDevice, st));
+    HIP_TRYR(hipMemcpyAsync(d_ev_off.p, hoff.data(), sizeof(int64_t) * (nev + 1), hipMemcpyHostToDevice, st));
+    HIP_TRYR(hipMemcpyAsync(d_lo_intr.p, hintr.data(), sizeof(double) * hintr.size(), hipMemcpyHostToDevice, st));
+    HIP_TRYR(hipMemcpyAsync(d_lo_model_id.p, hmod.data(), sizeof(int) * nev, hipMemcpyHostToDevice, st));
+    k_lo_prepare<<<(nev + 63) / 64, 64, 0, st>>>(est, nev, d_ev_prob.p, d_ev_samples.p, d_ev_slot.p, d_off.p, d_data.p,
+                                                 d_cur_models.p, d_ev_model.p, d_ev_cam.p);
+    k_lo_gather<<<nev, 64, 0, st>>>(est, d_ev_prob.p, d_off.p, d_data.p, d_ev_model.p, P.error_thresh, d_ev_off.p, d_ev_count.p,
+                                    reinterpret_cast<double2*>(d_lo_uv.p), reinterpret_cast<double4*>(d_lo_X.p));
+    views_batch_device(nev, d_ev_off.p, d_ev_count.p, d_lo_uv.p, nullptr, d_lo_X.p, d_ev_cam.p, d_lo_intr.p, d_lo_model_id.p,
+                       nullptr, &lo_opts, d_lo_out.p, st);
+    k_lo_finish<<<(nev + 63) / 64, 64, 0, st>>>(nev, d_ev_prob.p, d_ev_cam.p, reinterpret_cast<const LoOut*>(d_lo_out.p),
+                                                d_cur_models.p, d_ev_success.p);
+    HIP_TRYR(hipMemcpyAsync(success.data(), d_ev_success.p, sizeof(int) * nev, hipMemcpyDeviceToHost, st));
+    HIP_TRYR(hipStreamSynchronize(st));
+    return 0;
+  };
   for (int c0 = 0; c0 < nprob; c0 += chunk) {
     const int cn = std::min(chunk, nprob - c0);
     bool first = true;
@@ -559,32 +709,68 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       HIP_TRYR(hipMemcpyAsync(h_ninl.data(), d_ninl.p, sizeof(int) * nh * kMaxModels, hipMemcpyDeviceToHost, st));
       HIP_TRYR(hipStreamSynchronize(st));
       { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) fit_score_ms += ms; }
-      // sequential replay of the acceptance rules (sample_consensus_estimator.h:330-394)
+      // sequential replay of the acceptance rules (sample_consensus_estimator.h:330-394).  With
+      // use_lo a problem pauses at each RefineModel event; the events of all problems are refined
+      // as one batch, then every replay resumes where it stopped.
       for (int q = 0; q < cn; ++q) {
         ProblemState& s = S[c0 + q];
-        if (s.done) continue;
-        const int base_it = s.it;
-        int b = 0;
-        for (; b < s.round_iters && base_it + b < s.max_iterations; ++b) {
-          const size_t hyp = (size_t)q * B + b;
-          const int nm = h_counts[hyp];
-          result->hypotheses_evaluated++;
-          for (int j = 0; j < nm; ++j) {
-            const double cost = h_cost[hyp * kMaxModels + j];
-            const int ninl = h_ninl[hyp * kMaxModels + j];
-            result->models_scored++;
-            const double inlier_ratio = (double)ninl / (double)s.n;
-            if (cost < s.best_cost) {
-              s.best_cost = cost;
-              s.best_slot = j;
-              for (int i = 0; i < m; ++i) s.best_samples[i] = h_samples[hyp * m + i];
-              if (inlier_ratio < m / (double)s.n) continue;
-              s.max_iterations = std::min(compute_max_iterations(P, m, inlier_ratio, log_failure_prob, s.n), s.max_iterations);
+        s.base_it = s.it; s.rb = 0; s.rj = 0; s.round_done = s.done;
+      }
+      std::vector<LoEvent> events;
+      std::vector<int> ev_q, ev_ok;
+      while (true) {
+        events.clear(); ev_q.clear();
+        for (int q = 0; q < cn; ++q) {
+          ProblemState& s = S[c0 + q];
+          if (s.round_done) continue;
+          bool paused = false;
+          // (a hypothesis interrupted by an LO event is finished even if max_iterations dropped meanwhile)
+          while (!paused && s.rb < s.round_iters && (s.rj > 0 || s.base_it + s.rb < s.max_iterations)) {
+            const size_t hyp = (size_t)q * B + s.rb;
+            const int nm = h_counts[hyp];
+            if (s.rj == 0) result->hypotheses_evaluated++;
+            while (s.rj < nm) {
+              const int j = s.rj++;
+              const double cost = h_cost[hyp * kMaxModels + j];
+              const int ninl = h_ninl[hyp * kMaxModels + j];
+              result->models_scored++;
+              const double inlier_ratio = (double)ninl / (double)s.n;
+              if (cost < s.best_cost) {
+                s.best_cost = cost;
+                s.best_slot = j;
+                s.best_refined = false;
+                for (int i = 0; i < m; ++i) s.best_samples[i] = h_samples[hyp * m + i];
+                if (inlier_ratio < m / (double)s.n) continue;
+                if (P.use_lo && s.base_it + s.rb >= P.lo_start_iterations) {   // :373-381
+                  LoEvent ev; ev.prob = c0 + q; ev.slot = j;
+                  for (int i = 0; i < 5; ++i) ev.samples[i] = s.best_samples[i];
+                  events.push_back(ev); ev_q.push_back(q);
+                  s.pending_ratio = inlier_ratio;
+                  paused = true;
+                  break;
+                }
+                s.max_iterations = std::min(compute_max_iterations(P, m, inlier_ratio, log_failure_prob, s.n), s.max_iterations);
+              }
             }
+            if (!paused) { s.rb++; s.rj = 0; }
+          }
+          if (!paused) {
+            s.round_done = true;
+            s.it = s.base_it + s.rb;
+            if (s.it >= s.max_iterations) s.done = true;
           }
         }
-        s.it = base_it + b;
-        if (s.it >= s.max_iterations) s.done = true;
+        if (events.empty()) break;
+        if ((rc = run_lo(events, ev_ok))) return rc;
+        for (size_t e = 0; e < events.size(); ++e) {
+          ProblemState& s = S[events[e].prob];
+          s.best_refined = true;                       // RefineModel overwrites the pose even when it fails
+          if (getenv("THEIA_HIP_RANSAC_DEBUG"))
+            std::fprintf(stderr, "[hip] prob %d it %d slot %d ratio %.17g lo %d\n", events[e].prob, s.base_it + s.rb, events[e].slot, s.pending_ratio, ev_ok[e]);
+          if (!ev_ok[e]) continue;                     // "continue": no max_iterations update
+          s.num_lo++;
+          s.max_iterations = std::min(compute_max_iterations(P, m, s.pending_ratio, log_failure_prob, s.n), s.max_iterations);
+        }
       }
     }
   }
@@ -599,9 +785,26 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   HIP_TRYR(hipMemcpyAsync(d_best_samples.p, best_samples_all.data(), sizeof(int) * nprob * 5, hipMemcpyHostToDevice, st));
   HIP_TRYR(hipMemcpyAsync(d_best_slot.p, best_slot_all.data(), sizeof(int) * nprob, hipMemcpyHostToDevice, st));
   k_refit<<<(nprob + 63) / 64, 64, 0, st>>>(est, nprob, d_off.p, d_data.p, d_best_samples.p, d_best_slot.p, d_best_models.p);
+  if (P.use_lo) {   // the best model of a problem may be the refined pose of its last LO event
+    std::vector<int> use_cur(nprob);
+    for (int p = 0; p < nprob; ++p) use_cur[p] = (S[p].best_refined && S[p].best_slot >= 0) ? 1 : 0;
+    if ((rc = d_ev_slot.ensure(nprob))) return rc;
+    HIP_TRYR(hipMemcpyAsync(d_ev_slot.p, use_cur.data(), sizeof(int) * nprob, hipMemcpyHostToDevice, st));
+    k_select_models<<<(nprob + 63) / 64, 64, 0, st>>>(nprob, d_ev_slot.p, d_cur_models.p, d_best_models.p);
+  }
   {
     dim3 grid((nmax + 255) / 256, nprob);
     k_inlier_mask<<<grid, 256, 0, st>>>(est, nprob, d_off.p, d_data.p, d_best_models.p, P.error_thresh, d_mask.p);
+  }
+  if (P.use_lo) {   // sample_consensus_estimator.h:401-406: one more RefineModel on the final inliers (result unused)
+    HIP_TRYR(hipMemcpyAsync(d_cur_models.p, d_best_models.p, sizeof(double) * nprob * kStride, hipMemcpyDeviceToDevice, st));
+    std::vector<LoEvent> evs;
+    for (int p = 0; p < nprob; ++p)
+      if (S[p].best_slot >= 0) { LoEvent ev; ev.prob = p; ev.slot = -1; for (int k = 0; k < 5; ++k) ev.samples[k] = 0; evs.push_back(ev); }
+    std::vector<int> ok;
+    if ((rc = run_lo(evs, ok))) return rc;
+    for (const LoEvent& ev : evs) S[ev.prob].num_lo++;
+    HIP_TRYR(hipMemcpyAsync(d_best_models.p, d_cur_models.p, sizeof(double) * nprob * kStride, hipMemcpyDeviceToDevice, st));
   }
   HIP_TRYR(hipMemcpyAsync(result->models, d_best_models.p, sizeof(double) * nprob * kStride, hipMemcpyDeviceToHost, st));
   HIP_TRYR(hipMemcpyAsync(result->inlier_mask, d_mask.p, (size_t)total, hipMemcpyDeviceToHost, st));
@@ -612,6 +815,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     for (int64_t i = batch->offsets[p]; i < batch->offsets[p + 1]; ++i) cnt += result->inlier_mask[i];
     result->num_inliers[p] = cnt;
     result->num_iterations[p] = s.it;
+    if (result->num_lo_iterations) result->num_lo_iterations[p] = s.num_lo;
     result->success[p] = 1;
     const double inlier_ratio = (double)cnt / s.n;
     result->confidence[p] = 1.0 - std::pow(1.0 - std::pow(inlier_ratio, (double)m), (double)s.it);

@@ -881,6 +881,55 @@ RDEV int sqpnp(int n, const double* feat, const double* world, double* quats, do
   return nsol;
 }
 
+// ceres/rotation.h RotationMatrixToAngleAxis (via quaternion) and AngleAxisToRotationMatrix, as
+// Camera::SetOrientationFromRotationMatrix / GetOrientationAsRotationMatrix use them
+// (camera.cc:245-261).  R row-major.
+RDEV void rot_to_angle_axis(const double* R, double* aa) {
+  double q[4];
+  const double trace = R[0] + R[4] + R[8];
+  if (trace >= 0.0) {
+    double t = sqrt(trace + 1.0);
+    q[0] = 0.5 * t;
+    t = 0.5 / t;
+    q[1] = (R[7] - R[5]) * t; q[2] = (R[2] - R[6]) * t; q[3] = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 3 + i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
+    q[i + 1] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+    q[j + 1] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+    q[k + 1] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+  }
+  const double s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (s2 > 0.0) {
+    const double st = sqrt(s2), ct = q[0];
+    const double two_theta = 2.0 * ((ct < 0.0) ? atan2(-st, -ct) : atan2(st, ct));
+    const double k = two_theta / st;
+    aa[0] = q[1] * k; aa[1] = q[2] * k; aa[2] = q[3] * k;
+  } else {
+    aa[0] = q[1] * 2.0; aa[1] = q[2] * 2.0; aa[2] = q[3] * 2.0;
+  }
+}
+RDEV void angle_axis_to_rot(const double* aa, double* R) {
+  const double theta2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+  if (theta2 > DBL_EPSILON) {
+    const double theta = sqrt(theta2);
+    const double wx = aa[0] / theta, wy = aa[1] / theta, wz = aa[2] / theta;
+    const double c = cos(theta), s = sin(theta);
+    R[0] = c + wx * wx * (1.0 - c);      R[3] = wz * s + wx * wy * (1.0 - c);  R[6] = -wy * s + wx * wz * (1.0 - c);
+    R[1] = wx * wy * (1.0 - c) - wz * s; R[4] = c + wy * wy * (1.0 - c);       R[7] = wx * s + wy * wz * (1.0 - c);
+    R[2] = wy * s + wx * wz * (1.0 - c); R[5] = -wx * s + wy * wz * (1.0 - c); R[8] = c + wz * wz * (1.0 - c);
+  } else {
+    R[0] = 1.0; R[3] = aa[2]; R[6] = -aa[1];
+    R[1] = -aa[2]; R[4] = 1.0; R[7] = aa[0];
+    R[2] = aa[1]; R[5] = -aa[0]; R[8] = 1.0;
+  }
+}
+
 // ------------------------------------------------------------ five point
 RDEV void mul_deg1(const double* a, const double* b, double* o) {  // five_point_relative_pose.cc:68-92
   o[0] = a[0] * b[0];

@@ -7,3 +7,16 @@ extern thread_local std::string g_last_error;
 int set_error(int code, const char* fmt, ...);
 int ensure_device();  // lazily selects device 0 unless theia_hip_init chose one
 }  // namespace thip
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "theia_hip.h"
+namespace thip {
+// ba_batch.hip: batched single-view LM on device-resident data (one wave per problem);
+// problem p covers [offsets[p], offsets[p+1]) or, with counts, [offsets[p], offsets[p] + counts[p]).
+// d_out receives views_batch_out_bytes() per problem: {int success, term, iters, nsucc; double c0, c1}.
+int views_batch_device(int num, const int64_t* d_offsets, const int* d_counts, const double* d_uv, const double* d_si,
+                       const double* d_X, double* d_cam, const double* d_intr, const int* d_model, const uint8_t* d_mask,
+                       const theia_ba_options* o, void* d_out, hipStream_t st);
+size_t views_batch_out_bytes();
+}  // namespace thip

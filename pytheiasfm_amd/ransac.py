@@ -117,15 +117,16 @@ def estimate_batch(estimator, data, offsets, params):
     b.offsets = capi.ptr(offsets, C.c_int64); b.data = capi.ptr(data, C.c_double)
     success = np.zeros(max(P, 1), dtype=np.int32); models = np.zeros((max(P, 1), capi.THEIA_RANSAC_MODEL_STRIDE))
     ninl = np.zeros(max(P, 1), dtype=np.int32); mask = np.zeros(max(total, 1), dtype=np.uint8)
-    nit = np.zeros(max(P, 1), dtype=np.int32); conf = np.zeros(max(P, 1))
+    nit = np.zeros(max(P, 1), dtype=np.int32); conf = np.zeros(max(P, 1)); nlo = np.zeros(max(P, 1), dtype=np.int32)
     r = capi.RansacResult()
+    r.num_lo_iterations = capi.ptr(nlo, C.c_int32)
     r.success = capi.ptr(success, C.c_int32); r.models = capi.ptr(models, C.c_double)
     r.num_inliers = capi.ptr(ninl, C.c_int32); r.inlier_mask = capi.ptr(mask, C.c_uint8)
     r.num_iterations = capi.ptr(nit, C.c_int32); r.confidence = capi.ptr(conf, C.c_double)
     pc = params.to_c() if isinstance(params, RansacParameters) else params
     capi.check(L.theia_hip_ransac_estimate_batch(C.byref(b), C.byref(pc), C.byref(r)))
     return {"success": success[:P], "models": models[:P], "num_inliers": ninl[:P], "inlier_mask": mask[:total],
-            "num_iterations": nit[:P], "confidence": conf[:P], "hypotheses_evaluated": r.hypotheses_evaluated,
+            "num_iterations": nit[:P], "confidence": conf[:P], "num_lo_iterations": nlo[:P], "hypotheses_evaluated": r.hypotheses_evaluated,
             "models_scored": r.models_scored, "time_fit_score_seconds": r.time_fit_score_seconds}
 
 
@@ -139,6 +140,7 @@ def _single(estimator, ransac_params, ransac_type, data):
     s.num_input_data_points = data.shape[0]
     s.num_iterations = int(res["num_iterations"][0])
     s.confidence = float(res["confidence"][0])
+    s.num_lo_iterations = int(res["num_lo_iterations"][0])
     return bool(res["success"][0]), res["models"][0], s
 
 

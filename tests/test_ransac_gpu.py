@@ -147,6 +147,34 @@ def test_mirror_api_and_error_conventions():
         ransac.EstimateRelativePose(p, ransac.RansacType.RANSAC, data[:3])  # fewer data than the sample size
 
 
+def test_lo_ransac_absolute_pose_follows_oracle():
+    """use_lo (sample_consensus_estimator.h:373-381, 401-406) with the absolute-pose RefineModel run as batched
+    single-view LM solves on the device.  The refinement is FP64 with a different summation order than the
+    oracle's (closed-form vs Jet Jacobians), so models agree to 1e-8 instead of bitwise; control flow
+    (iterations, LO counts) and inlier sets are identical."""
+    data, offsets, truth = synth.synth_ransac_v1(10, 300, "absolute", seed=0x5AC50700, noise_px=1.0)
+    p = ransac.RansacParameters(); p.error_thresh = THR[2]; p.use_mle = True; p.seed = 66
+    p.use_lo = True; p.lo_start_iterations = 5; p.min_iterations = 50; p.failure_probability = 0.001
+    res = ransac.estimate_batch(2, data, offsets, p)
+    plain = ransac.RansacParameters(); plain.error_thresh = THR[2]; plain.use_mle = True; plain.seed = 66
+    plain.min_iterations = 50; plain.failure_probability = 0.001
+    res0 = ransac.estimate_batch(2, data, offsets, plain)
+    err_lo, err_plain = [], []
+    for i in range(10):
+        pc = p.to_c(); pc.seed = 66 + i
+        o = ol.ransac_estimate(2, data[offsets[i]:offsets[i + 1]], pc)
+        nlo = ol.rlib().oracle_last_lo_iterations()
+        sl = slice(offsets[i], offsets[i + 1])
+        assert o["num_iterations"] == res["num_iterations"][i] and nlo == res["num_lo_iterations"][i] and nlo >= 1
+        assert np.abs(o["model"][:12] - res["models"][i][:12]).max() <= 1e-8
+        assert np.array_equal(o["inlier_mask"], res["inlier_mask"][sl])
+        err_lo.append(np.abs(res["models"][i][9:12] - truth["position"][i]).max())
+        err_plain.append(np.abs(res0["models"][i][9:12] - truth["position"][i]).max())
+    assert np.median(err_lo) <= np.median(err_plain) + 1e-3
+    print("LO iterations per problem:", res["num_lo_iterations"])
+    assert res["num_lo_iterations"].sum() > 10      # some in-loop refinements succeeded, not only the final one
+
+
 def test_c5_slice_properties():
     """configs[4] shape (2k correspondences, 4096 hypotheses): size-independent
     properties on a slice -- determinism, inlier count <= N, all problems done."""
