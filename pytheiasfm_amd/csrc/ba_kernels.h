@@ -77,12 +77,12 @@ void launch_colnorm(const DevProblem& P, const double* cam, const double* pts, d
                     double* colsq_p, double* colsq_i, hipStream_t st);
 void launch_build_scale_red(const DevProblem& P, double* scale_red, hipStream_t st);
 void launch_make_scale(int count, const double* colsq, double* scale, hipStream_t st);
-void launch_linearize(const DevProblem& P, const double* cam, const double* pts, double radius,
+void launch_linearize(const DevProblem& P, const double* cam, const double* pts, const double* radius /* device */,
                       const ReduceBuf& rb, double* Vinv, double* gp, double* tile_part,
                       hipStream_t st);
 void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,
                          const int* field_is_max, double* scal, hipStream_t st);
-void launch_finalize_rcs(const DevProblem& P, double radius, const ReduceBuf& rb, hipStream_t st);
+void launch_finalize_rcs(const DevProblem& P, const double* radius /* device */, const ReduceBuf& rb, hipStream_t st);
 void launch_cam_update(const DevProblem& P, const double* cam, const double* y, double* cand_cam,
                        double* cand_intr, double* out_stepsq, double* out_xnormsq, hipStream_t st);
 void launch_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,
@@ -96,7 +96,7 @@ void launch_cost_only(const DevProblem& P, const double* cam, const double* pts,
 
 void launch_long_colnorm(const DevProblem& P, const double* cam, const double* pts, double* colsq_c, double* colsq_p,
                          double* scratch, hipStream_t st);
-void launch_long_linearize(const DevProblem& P, const double* cam, const double* pts, double radius, const ReduceBuf& rb,
+void launch_long_linearize(const DevProblem& P, const double* cam, const double* pts, const double* radius /* device */, const ReduceBuf& rb,
                            double* Vinv, double* gp, double* scratch, hipStream_t st);
 void launch_long_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,
                          double* cand_pts, const double* yc, const double* Vinv, double* scratch, double* scalB,

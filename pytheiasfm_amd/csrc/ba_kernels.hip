@@ -312,13 +312,14 @@ THIP_DEV void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 // global FP64 atomics (first version of this path: correct, not yet tuned).
 template <int PD, bool INTR>
 __global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double* __restrict__ cam,
-                                                      const double* __restrict__ pts, double radius,
+                                                      const double* __restrict__ pts, const double* __restrict__ radius_p,
                                                       double* __restrict__ S, double* __restrict__ rhs,
                                                       double* __restrict__ colsq, double* __restrict__ gc,
                                                       double* __restrict__ Vinv, double* __restrict__ gp,
                                                       double* __restrict__ tile_part,
                                                       double* __restrict__ SI, double* __restrict__ rhsI,
                                                       double* __restrict__ colsqI, double* __restrict__ gcI) {
+  const double radius = *radius_p;
   constexpr int NT = PD * (PD + 1) / 2;
   constexpr int NW = 6 * PD;
   constexpr int NWI = INTR ? THEIA_MAX_INTRINSICS * PD : 1;
@@ -610,12 +611,13 @@ template <int PD> constexpr int rec_stride() { return 12 * PD + 20; }
 
 template <int PD>
 __global__ __launch_bounds__(kBlock) void k_lin_obs(DevProblem P, const double* __restrict__ cam,
-                                                    const double* __restrict__ pts, double radius,
+                                                    const double* __restrict__ pts, const double* __restrict__ radius_p,
                                                     double* __restrict__ Vinv, double* __restrict__ gp,
                                                     double* __restrict__ tile_part) {
   constexpr int NT = PD * (PD + 1) / 2;
   constexpr int NW = 6 * PD;
   constexpr int RS = rec_stride<PD>();
+  const double radius = *radius_p;   // device-resident: the LM step control runs on the GPU
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   if (tile >= P.ntiles) return;
@@ -858,10 +860,11 @@ __global__ __launch_bounds__(1024) void k_reduce_tiles(int ntiles, const double*
 
 // Add the LM diagonal to the camera-side blocks (intrinsics + extrinsics) and
 // fold their gradient into the gradient max-norm: S_dd += clamp(colsq_d) / radius.
-__global__ void k_finalize_rcs(DevProblem P, double radius, double* __restrict__ S,
+__global__ void k_finalize_rcs(DevProblem P, const double* __restrict__ radius_p, double* __restrict__ S,
                                const double* __restrict__ colsq, const double* __restrict__ gc,
                                double* __restrict__ scal) {
   __shared__ double sm[256];
+  const double radius = *radius_p;
   double gmax = 0.0;
   for (int d = threadIdx.x; d < P.n; d += blockDim.x) {
     S[(size_t)d * P.n + d] += fmin(fmax(colsq[d], 1e-6), 1e32) / radius;
@@ -1155,7 +1158,7 @@ __global__ void k_long_accum(DevProblem P, LongView Lv, const double* __restrict
 
 // pass B: per long track: colsq_p (MODE 0) or damped inverse, g_p, gradient max (MODE 1)
 template <int PD, int MODE>
-__global__ void k_long_track(DevProblem P, LongView Lv, double radius, const double* __restrict__ scratch,
+__global__ void k_long_track(DevProblem P, LongView Lv, const double* __restrict__ radius_p, const double* __restrict__ scratch,
                              double* __restrict__ colsq_p, double* __restrict__ Vinv, double* __restrict__ gp,
                              double* __restrict__ scal) {
   constexpr int NT = PD * (PD + 1) / 2;
@@ -1168,6 +1171,7 @@ __global__ void k_long_track(DevProblem P, LongView Lv, double radius, const dou
     return;
   }
   if (P.pt_const[p]) return;
+  const double radius = *radius_p;
   double V[NT], Vi[NT];
   for (int k = 0; k < NT; ++k) V[k] = sc[k];
   for (int a = 0; a < PD; ++a) V[lidx(a, a)] += fmin(fmax(V[lidx(a, a)], 1e-6), 1e32) / radius;
@@ -1327,7 +1331,7 @@ void launch_make_scale(int count, const double* colsq, double* scale, hipStream_
   k_make_scale<<<(count + 255) / 256, 256, 0, st>>>(count, colsq, scale);
 }
 
-void launch_linearize(const DevProblem& P, const double* cam, const double* pts, double radius,
+void launch_linearize(const DevProblem& P, const double* cam, const double* pts, const double* radius,
                       const ReduceBuf& rb, double* Vinv, double* gp, double* tile_part, hipStream_t st) {
   if (P.ntiles == 0) return;
   if (P.rec && P.ni == 0) {
@@ -1365,7 +1369,7 @@ void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const
   k_reduce_tiles<<<1, 1024, 0, st>>>(ntiles, tile_part, nfields, field_to_scal, field_is_max, scal);
 }
 
-void launch_finalize_rcs(const DevProblem& P, double radius, const ReduceBuf& rb, hipStream_t st) {
+void launch_finalize_rcs(const DevProblem& P, const double* radius, const ReduceBuf& rb, hipStream_t st) {
   k_finalize_rcs<<<1, 256, 0, st>>>(P, radius, rb.S, rb.colsq, rb.gc, rb.scal);
 }
 
@@ -1436,15 +1440,15 @@ void launch_long_colnorm(const DevProblem& P, const double* cam, const double* p
   if (P.pd == 3) {
     (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<3>() * v.ntracks, st);
     k_long_accum<3, 0><<<gb, 128, 0, st>>>(P, v, cam, pts, scratch, nullptr, nullptr, nullptr, nullptr, nullptr, colsq_c);
-    k_long_track<3, 0><<<tb, 128, 0, st>>>(P, v, 1.0, scratch, colsq_p, nullptr, nullptr, nullptr);
+    k_long_track<3, 0><<<tb, 128, 0, st>>>(P, v, nullptr, scratch, colsq_p, nullptr, nullptr, nullptr);
   } else {
     (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<4>() * v.ntracks, st);
     k_long_accum<4, 0><<<gb, 128, 0, st>>>(P, v, cam, pts, scratch, nullptr, nullptr, nullptr, nullptr, nullptr, colsq_c);
-    k_long_track<4, 0><<<tb, 128, 0, st>>>(P, v, 1.0, scratch, colsq_p, nullptr, nullptr, nullptr);
+    k_long_track<4, 0><<<tb, 128, 0, st>>>(P, v, nullptr, scratch, colsq_p, nullptr, nullptr, nullptr);
   }
 }
 
-void launch_long_linearize(const DevProblem& P, const double* cam, const double* pts, double radius, const ReduceBuf& rb,
+void launch_long_linearize(const DevProblem& P, const double* cam, const double* pts, const double* radius, const ReduceBuf& rb,
                            double* Vinv, double* gp, double* scratch, hipStream_t st) {
   if (P.long_nobs == 0) return;
   const LongView v = long_view(P);

@@ -5,11 +5,13 @@
 //   (src/theia/sfm/bundle_adjustment/bundle_adjuster.cc:63-89,315-355).
 // LM rules restated from Ceres 2.2 (trust_region_minimizer.cc,
 // levenberg_marquardt_strategy.cc): see DESIGN.md "LM control".
-// All state stays in HBM; per LM iteration the host reads back one 32-double
-// scalar block (one stream sync).
+// All state stays in HBM, including the trust-region step control (k_lm_control):
+// the host enqueues several LM iterations back to back and synchronises once
+// per chunk to read the LM state.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -85,7 +87,19 @@ struct theia_ba_handle_s {
   DevBuf<int> long_obs_index, long_obs_slot, long_track_start, long_track_pt;
   DevBuf<double> long_scratch;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  static constexpr int kMaxChunk = 8;   // LM iterations enqueued per host synchronisation
+  hipEvent_t ev[kMaxChunk][6] = {};
+  DevBuf<char> lm_state;                // LmState (device): radius, cost, counters, termination
+  DevBuf<char> lm_ctl;                  // LmCtl (device): per-run tolerances, caps, trace pointers
+  hipGraph_t graph = nullptr;           // one captured LM iteration (no all-reduce callback, no phase timing)
+  hipGraphExec_t graph_exec = nullptr;
+  bool graph_failed = false;
+  void drop_graph() {
+    if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+    if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+  }
+  DevBuf<double> tr_cost, tr_g, tr_step, tr_radius;
+  DevBuf<int> tr_acc;
   // host-side bookkeeping
   std::vector<int64_t> perm;       // sorted obs index -> original obs index
   std::vector<int> cam_red, grp_red, grp_k;
@@ -122,8 +136,9 @@ struct theia_ba_handle_s {
   bool plan_is_global = true;
 
   ~theia_ba_handle_s() {
+    drop_graph();
     if (plan) chol_plan_destroy(plan);
-    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    for (auto& row : ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
     if (h_scal) (void)hipHostFree(h_scal);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -164,6 +179,129 @@ void project_intrinsics_to_bounds(int model, double* k) {
 }
 
 enum { SB_COST = 0, SB_MCC = 1, SB_STEPSQ = 2, SB_XNORMSQ = 3, SB_INVALID = 4, SB_STEPSQ_CAM = 8, SB_XNORMSQ_CAM = 9 };
+
+// ------------------------------------------------------------ LM step control
+// Trust-region bookkeeping of one solve, resident on the device so that several
+// iterations can be enqueued without a host round trip.
+struct LmState {
+  double radius, decrease_factor, x_cost, x_norm, gmax, minimum_cost, initial_cost;
+  int step_successful, iter, invalid_steps, term, done, first, accepted, num_successful, trace_size, pending_grad,
+      fail_at_first, bodies;
+};
+struct LmCtl {   // per-run control block, device resident so that a captured graph of the iteration stays valid
+  int max_iterations, trace_capacity;
+  double function_tolerance, gradient_tolerance, parameter_tolerance, max_radius, fixed_cost;
+  double *tc, *tg, *ts, *tr;
+  int* ta;
+};
+
+__device__ void lm_trace(LmState* st, const LmCtl& c, double cost, double g, double step, double radius, int acc) {
+  if (!c.tc || st->trace_size >= c.trace_capacity) return;
+  const int k = st->trace_size++;
+  c.tc[k] = cost; c.tg[k] = g; c.ts[k] = step; c.tr[k] = radius; c.ta[k] = acc;
+}
+
+// One pass of the TrustRegionMinimizer loop body (ceres trust_region_minimizer.cc; the
+// same rules the host loop of the first versions applied after each read-back):
+// sa = scalars of the linearisation at x, sb = scalars of the trial step.
+__global__ void k_lm_control(LmState* st, const double* __restrict__ sa, const double* __restrict__ sb,
+                             const LmCtl* __restrict__ cp) {
+  const LmCtl c = *cp;
+  double* tg = c.tg; double* tc = c.tc;
+  st->accepted = 0;
+  if (st->done) return;
+  st->bodies++;
+  const double x_cost = sa[SC_COST];
+  const double gmax = sa[SC_GMAX];
+  st->x_cost = x_cost; st->gmax = gmax;
+  if (st->pending_grad >= 0 && tg) tg[st->pending_grad] = gmax;
+  st->pending_grad = -1;
+  if (st->first) {
+    st->first = 0;
+    st->initial_cost = x_cost + c.fixed_cost;
+    st->minimum_cost = x_cost;
+    if (sa[SC_INVALID] > 0.0 || !isfinite(x_cost)) { st->term = THEIA_TERM_FAILURE; st->fail_at_first = 1; st->done = 1; return; }
+    lm_trace(st, c, x_cost + c.fixed_cost, gmax, 0.0, st->radius, 1);
+  }
+  if (st->iter >= c.max_iterations) { st->term = THEIA_TERM_NO_CONVERGENCE; st->done = 1; return; }
+  if (st->step_successful && gmax <= c.gradient_tolerance) { st->term = THEIA_TERM_CONVERGENCE; st->done = 1; return; }
+  if (st->radius <= 1e-32) { st->term = THEIA_TERM_CONVERGENCE; st->done = 1; return; }
+  st->iter++;
+  const double mcc = sb[SB_MCC];
+  const double stepsq = sb[SB_STEPSQ] + sb[SB_STEPSQ_CAM];
+  const bool solved = sa[SC_NOTPD] == 0.0 && isfinite(mcc) && isfinite(stepsq);
+  if (!(solved && mcc > 0.0)) {
+    if (++st->invalid_steps >= 5) { st->term = THEIA_TERM_FAILURE; st->done = 1; return; }
+    st->radius /= st->decrease_factor; st->decrease_factor *= 2.0; st->step_successful = 0;
+    lm_trace(st, c, x_cost + c.fixed_cost, gmax, 0.0, st->radius, 0);
+    return;
+  }
+  st->invalid_steps = 0;
+  double cand_cost = sb[SB_COST];
+  if (sb[SB_INVALID] > 0.0 || !isfinite(cand_cost)) cand_cost = DBL_MAX;
+  const double step_norm = sqrt(stepsq);
+  if (step_norm <= c.parameter_tolerance * (st->x_norm + c.parameter_tolerance)) {
+    lm_trace(st, c, cand_cost + c.fixed_cost, gmax, step_norm, st->radius, 0);
+    st->term = THEIA_TERM_CONVERGENCE; st->done = 1; return;
+  }
+  const double cost_change = x_cost - cand_cost;
+  if (fabs(cost_change) <= c.function_tolerance * x_cost) {
+    lm_trace(st, c, cand_cost + c.fixed_cost, gmax, step_norm, st->radius, 0);
+    st->term = THEIA_TERM_CONVERGENCE; st->done = 1; return;
+  }
+  const double rho = cost_change / mcc;
+  if (rho > 1e-3) {
+    st->accepted = 1;   // k_lm_accept copies the candidate buffers over the state
+    st->x_norm = sqrt(sb[SB_XNORMSQ] + sb[SB_XNORMSQ_CAM]);
+    st->radius = st->radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3));
+    st->radius = fmin(c.max_radius, st->radius);
+    st->decrease_factor = 2.0; st->step_successful = 1;
+    st->num_successful++;
+    if (cand_cost < st->minimum_cost) st->minimum_cost = cand_cost;
+    if (tc && st->trace_size < c.trace_capacity) st->pending_grad = st->trace_size;
+    lm_trace(st, c, cand_cost + c.fixed_cost, -1.0, step_norm, st->radius, 1);
+  } else {
+    st->radius /= st->decrease_factor; st->decrease_factor *= 2.0; st->step_successful = 0;
+    lm_trace(st, c, cand_cost + c.fixed_cost, gmax, step_norm, st->radius, 0);
+  }
+  // the iteration cap is known now: no further pass is needed to detect it
+  if (st->iter >= c.max_iterations) { st->term = THEIA_TERM_NO_CONVERGENCE; st->done = 1; }
+}
+
+// |x| over the variable parameter blocks (TrustRegionMinimizer's x_norm at the start):
+// out2[0] = points (per track shard), out2[1] = cameras + intrinsics.  One workgroup.
+__global__ __launch_bounds__(1024) void k_xnorm_partial(DevProblem P, const double* __restrict__ cam,
+                                                        const double* __restrict__ pts, const double* __restrict__ intr,
+                                                        double* __restrict__ out2) {
+  __shared__ double s1[1024], s2[1024];
+  double sp = 0.0, sc = 0.0;
+  for (int p = threadIdx.x; p < P.np; p += 1024)
+    if (!P.pt_const[p]) for (int q = 0; q < 4; ++q) sp += pts[4 * (size_t)p + q] * pts[4 * (size_t)p + q];
+  for (int c = threadIdx.x; c < P.nc; c += 1024)
+    if (P.cam_red[c] >= 0) for (int q = 0; q < 6; ++q) sc += cam[6 * c + q] * cam[6 * c + q];
+  if (P.ni)
+    for (int g = threadIdx.x; g < P.ng_total; g += 1024)
+      if (P.grp_red[g] >= 0) for (int q = 0; q < P.grp_k[g]; ++q) sc += intr[(size_t)g * THEIA_MAX_INTRINSICS + q] * intr[(size_t)g * THEIA_MAX_INTRINSICS + q];
+  s1[threadIdx.x] = sp; s2[threadIdx.x] = sc;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { s1[threadIdx.x] += s1[threadIdx.x + s]; s2[threadIdx.x] += s2[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out2[0] = s1[0]; out2[1] = s2[0]; }
+}
+__global__ void k_xnorm_set(LmState* st, const double* __restrict__ in2) { st->x_norm = sqrt(in2[0] + in2[1]); }
+
+// accepted step: the candidate parameters become the state
+__global__ void k_lm_accept(const LmState* __restrict__ st, double* __restrict__ cam, const double* __restrict__ cand_cam, size_t ncam,
+                            double* __restrict__ pts, const double* __restrict__ cand_pts, size_t npts,
+                            double* __restrict__ intr, const double* __restrict__ cand_intr, size_t nintr) {
+  if (!st->accepted) return;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += stride) pts[i] = cand_pts[i];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncam; i += stride) cam[i] = cand_cam[i];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nintr; i += stride) intr[i] = cand_intr[i];
+}
 
 int supported_model(int m) { return m >= THEIA_CAM_PINHOLE && m <= THEIA_CAM_ORTHOGRAPHIC; }
 
@@ -288,12 +426,15 @@ int compute_scale(theia_ba_handle_s* h) {
 }
 
 // enqueue: clear, linearize + Schur, tile reduction, (all-reduce), LM diagonal.
-int enqueue_linearize(theia_ba_handle_s* h, double radius) {
+// The trust-region radius is read from the device-resident LM state.
+// slot < 0: no phase-timing events (graph capture, or timing not requested)
+int enqueue_linearize(theia_ba_handle_s* h, int slot = 0) {
+  const double* radius = &reinterpret_cast<const LmState*>(h->lm_state.p)->radius;
   h->P.intr = h->intr[h->cur].p; h->P.intr_cand = h->intr[1 - h->cur].p;
   HIP_TRY(hipMemsetAsync(h->reduce.p, 0, sizeof(double) * h->reduce.n, h->stream));
-  HIP_TRY(hipEventRecord(h->ev[4], h->stream));
+  if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][4], h->stream));
   launch_linearize(h->P, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->tile_part.p, h->stream);
-  HIP_TRY(hipEventRecord(h->ev[5], h->stream));
+  if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][5], h->stream));
   if (h->ntiles_main) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 4, h->f2s.p, h->fmaxflag.p, h->rb.scal, h->stream);
   launch_long_linearize(h->P, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->long_scratch.p, h->stream);
   // one SUM all-reduce of [S | rhs | colsq | gc | scal[0,8)], one MAX of scal[8,16)
@@ -305,10 +446,10 @@ int enqueue_linearize(theia_ba_handle_s* h, double radius) {
 }
 
 // enqueue: dense solve, candidate cameras, back-substitution + trial cost.
-int enqueue_solve_and_backsub(theia_ba_handle_s* h) {
+int enqueue_solve_and_backsub(theia_ba_handle_s* h, int slot = 0) {
   double* yc = h->rb.rhs;  // the solution overwrites the rhs row
   chol_plan_solve(h->plan, h->rb.S, h->n, h->rb.rhs, h->chol_work.p, h->rb.scal + SC_NOTPD, h->stream);
-  HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+  if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][2], h->stream));
   HIP_TRY(hipMemsetAsync(h->scalB.p, 0, sizeof(double) * 16, h->stream));
   const int nxt = 1 - h->cur;
   launch_cam_update(h->P, h->cam[h->cur].p, yc, h->cam[nxt].p, h->ni ? h->intr[nxt].p : nullptr,
@@ -333,6 +474,7 @@ int sync_plan(theia_ba_handle_s* h) {
   HIP_TRY(hipMemcpyAsync(a.data(), h->reduce.p, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   for (size_t i = 0; i < cnt; ++i) h->tile_adj[i] = a[i] != 0.0 ? 1 : 0;
+  h->drop_graph();
   if (h->plan) chol_plan_destroy(h->plan);
   h->plan = chol_plan_create(h->n, h->tile_adj.data());
   h->plan_is_global = true;
@@ -381,7 +523,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   h->nc = p->num_cameras; h->ng = p->num_groups; h->np = p->num_points; h->nobs = p->num_obs;
   h->pd = o->use_homogeneous_point_parametrization ? 3 : 4;
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
+  for (auto& row : h->ev) for (auto& e : row) HIP_TRY(hipEventCreate(&e));
   HIP_TRY(hipHostMalloc((void**)&h->h_scal, sizeof(double) * 32, hipHostMallocDefault));
 
   // --- problem structure (bundle_adjuster.cc:116-221,357-380,477-527) ---
@@ -547,6 +689,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   AL(Vinv, (size_t)(h->pd * (h->pd + 1) / 2) * h->np); AL(gp, (size_t)h->pd * h->np);
   AL(tile_part, (size_t)5 * std::max(1, h->ntiles_all)); AL(scalB, 16);
   AL(chol_work, dense_cholesky_workspace(h->n));
+  AL(lm_state, sizeof(LmState)); AL(lm_ctl, sizeof(LmCtl));
   {
     // tile co-visibility: two 64-wide tiles of S couple iff a variable track is
     // seen by cameras of both (the Schur complement's block structure)
@@ -689,6 +832,8 @@ int theia_hip_ba_set_options(theia_ba_handle h, const theia_ba_options* o) {
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "structural options differ from the ones the handle was created with");
   if (o->loss_function_type < 0 || o->loss_function_type > THEIA_LOSS_TRUNCATED)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "invalid loss function type");
+  if (o->loss_function_type != h->opt.loss_function_type || o->robust_loss_width != h->opt.robust_loss_width)
+    h->drop_graph();   // the loss is baked into the captured kernel arguments
   h->opt = *o;
   h->P.loss_type = o->loss_function_type;
   h->P.loss_width = o->robust_loss_width;
@@ -726,139 +871,129 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   S->setup_time_in_seconds = 0.0;
   int rc = h->plan_is_global ? 0 : sync_plan(h);
   if (rc) return rc;
+  h->cur = 0;   // state = buffer 0, candidate = buffer 1 (accepted steps are copied back on the device)
   rc = compute_scale(h);
   if (rc) return rc;
-  double radius = 1e4, decrease_factor = 2.0;
-  bool step_successful = true;
-  int iter = 0, invalid_steps = 0, term = THEIA_TERM_NO_CONVERGENCE;
-  double x_cost = 0.0, x_norm = 0.0, gmax = 0.0, minimum_cost = 0.0;
-  bool first = true;
-  // |x| of the variable blocks at the start: cameras on the host side are
-  // cheap, but keep everything on device: a zero-step back-substitution is
-  // not available before the first solve, so compute it from a download.
-  {
-    std::vector<double> hc((size_t)6 * h->nc), hp((size_t)4 * h->np);
-    if (h->nc) HIP_TRY(hipMemcpyAsync(hc.data(), h->cam[h->cur].p, sizeof(double) * hc.size(), hipMemcpyDeviceToHost, h->stream));
-    if (h->np) HIP_TRY(hipMemcpyAsync(hp.data(), h->pts[h->cur].p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    double s = 0.0;
-    if (h->ni) {
-      std::vector<double> hk((size_t)THEIA_MAX_INTRINSICS * h->ng);
-      HIP_TRY(hipMemcpy(hk.data(), h->intr[h->cur].p, sizeof(double) * hk.size(), hipMemcpyDeviceToHost));
-      for (int g = 0; g < h->ng; ++g) if (h->grp_red[g] >= 0)
-        for (int q = 0; q < h->grp_k[g]; ++q) s += hk[(size_t)g * THEIA_MAX_INTRINSICS + q] * hk[(size_t)g * THEIA_MAX_INTRINSICS + q];
-    }
-    for (int c = 0; c < h->nc; ++c) if (h->cam_red[c] >= 0) for (int q = 0; q < 6; ++q) s += hc[6 * c + q] * hc[6 * c + q];
-    double sp = 0.0;
-    for (int p = 0; p < h->np; ++p) if (!h->pt_const[p]) for (int q = 0; q < 4; ++q) sp += hp[4 * (size_t)p + q] * hp[4 * (size_t)p + q];
-    if (h->allreduce) {  // the point part is per shard: sum it over ranks
-      HIP_TRY(hipMemcpyAsync(h->scalB.p, &sp, sizeof(double), hipMemcpyHostToDevice, h->stream));
-      int rc2 = do_allreduce(h, h->scalB.p, 1, THEIA_REDUCE_SUM);
-      if (rc2) return rc2;
-      HIP_TRY(hipMemcpyAsync(&sp, h->scalB.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
-    }
-    x_norm = std::sqrt(s + sp);
+  // device-resident LM state, control block and trace
+  LmState st;
+  std::memset(&st, 0, sizeof(st));
+  st.radius = 1e4; st.decrease_factor = 2.0; st.step_successful = 1; st.first = 1;
+  st.term = THEIA_TERM_NO_CONVERGENCE; st.pending_grad = -1;
+  LmState* dst = reinterpret_cast<LmState*>(h->lm_state.p);
+  HIP_TRY(hipMemcpyAsync(dst, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
+  // |x| of the variable blocks at the start: summed on the device (points per shard, all-reduced)
+  HIP_TRY(hipMemsetAsync(h->scalB.p, 0, sizeof(double) * 16, h->stream));
+  k_xnorm_partial<<<1, 1024, 0, h->stream>>>(h->P, h->cam[0].p, h->pts[0].p, h->intr[0].p, h->scalB.p);
+  rc = do_allreduce(h, h->scalB.p, 1, THEIA_REDUCE_SUM);
+  if (rc) return rc;
+  k_xnorm_set<<<1, 1, 0, h->stream>>>(dst, h->scalB.p);
+  LmCtl ctl;
+  ctl.max_iterations = O.max_num_iterations;
+  ctl.trace_capacity = S->trace_cost ? S->trace_capacity : 0;
+  ctl.function_tolerance = O.function_tolerance; ctl.gradient_tolerance = O.gradient_tolerance;
+  ctl.parameter_tolerance = O.parameter_tolerance; ctl.max_radius = O.max_trust_region_radius; ctl.fixed_cost = h->fixed_cost;
+  const size_t tcap = (size_t)std::max(1, ctl.trace_capacity);
+  if (h->tr_cost.n < tcap) {
+    if ((rc = h->tr_cost.alloc(tcap)) || (rc = h->tr_g.alloc(tcap)) || (rc = h->tr_step.alloc(tcap)) ||
+        (rc = h->tr_radius.alloc(tcap)) || (rc = h->tr_acc.alloc(tcap)))
+      return rc;
   }
-  int pending_grad = -1;  // trace entry of the last accepted step (gradient known one read-back later)
+  ctl.tc = ctl.trace_capacity ? h->tr_cost.p : nullptr;
+  ctl.tg = h->tr_g.p; ctl.ts = h->tr_step.p; ctl.tr = h->tr_radius.p; ctl.ta = h->tr_acc.p;
+  HIP_TRY(hipMemcpyAsync(h->lm_ctl.p, &ctl, sizeof(ctl), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));   // st / ctl are stack objects
+  const LmCtl* dctl = reinterpret_cast<const LmCtl*>(h->lm_ctl.p);
+  const int nxt = 1;
+  // one LM iteration ("body"): linearise + Schur, solve, trial step, step control, accept
+  auto enqueue_body = [&](int slot) -> int {
+    int r;
+    if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][0], h->stream));
+    if ((r = enqueue_linearize(h, slot))) return r;
+    if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][1], h->stream));
+    if ((r = enqueue_solve_and_backsub(h, slot))) return r;
+    if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][3], h->stream));
+    k_lm_control<<<1, 1, 0, h->stream>>>(dst, h->rb.scal, h->scalB.p, dctl);
+    k_lm_accept<<<256, 256, 0, h->stream>>>(dst, h->cam[0].p, h->cam[nxt].p, (size_t)6 * h->nc, h->pts[0].p, h->pts[nxt].p,
+                                            (size_t)4 * h->np, h->intr[0].p, h->intr[nxt].p, h->ni ? (size_t)THEIA_MAX_INTRINSICS * h->ng : 0);
+    return 0;
+  };
+  // Phase timing (HIP events around the kernel groups) is opt-in: THEIA_HIP_PHASE_TIMING=1.
+  // Otherwise, and without an all-reduce callback, the body is captured ONCE into a hipGraph
+  // and replayed: ~45 launches per iteration cost more host time than the GPU needs to run them.
+  const bool timing = getenv("THEIA_HIP_PHASE_TIMING") != nullptr;
+  const char* genv = getenv("THEIA_HIP_LM_GRAPH");
+  const bool want_graph = !timing && !h->allreduce && !h->graph_failed && !(genv && genv[0] == '0');
+  if (want_graph && !h->graph_exec) {
+    bool ok = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+      const int r = enqueue_body(-1);
+      hipGraph_t g = nullptr;
+      const hipError_t e = hipStreamEndCapture(h->stream, &g);
+      ok = (r == 0) && e == hipSuccess && g != nullptr;
+      if (ok) { h->graph = g; ok = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0) == hipSuccess; }
+      else if (g) (void)hipGraphDestroy(g);
+    }
+    if (!ok) { h->drop_graph(); h->graph_failed = true; (void)hipGetLastError(); }
+  }
+  const bool use_graph = want_graph && h->graph_exec;
+  // Several bodies are enqueued per synchronisation; bodies after termination are no-ops for
+  // the state (k_lm_control returns at once) -- their kernels run on unchanged data.
+  const char* chunk_env = getenv("THEIA_HIP_LM_CHUNK");
+  int chunk = chunk_env ? atoi(chunk_env) : 4;
+  chunk = std::max(1, std::min(chunk, (int)theia_ba_handle_s::kMaxChunk));
+  const long long bodies_max = std::max(1, O.max_num_iterations);
+  if (bodies_max <= theia_ba_handle_s::kMaxChunk && !chunk_env) chunk = (int)bodies_max;
+  long long bodies_enqueued = 0;
   while (true) {
-    // the two host-only stop rules are checked before any work is enqueued
-    if (!first && now_s() - t_start >= O.max_solver_time_in_seconds) { term = THEIA_TERM_NO_CONVERGENCE; break; }
-    if (!first && iter >= O.max_num_iterations) { term = THEIA_TERM_NO_CONVERGENCE; break; }
-    // one LM iteration is enqueued speculatively; the host reads back scalars once
-    HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-    rc = enqueue_linearize(h, radius); if (rc) return rc;
-    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-    rc = enqueue_solve_and_backsub(h); if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(h->h_scal, h->rb.scal, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->h_scal + 16, h->scalB.p, sizeof(double) * 16, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+    if (now_s() - t_start >= O.max_solver_time_in_seconds && bodies_enqueued > 0) { st.term = THEIA_TERM_NO_CONVERGENCE; break; }
+    const int nb = (int)std::min<long long>(chunk, bodies_max - bodies_enqueued);
+    if (nb <= 0) break;
+    for (int b = 0; b < nb; ++b) {
+      if (use_graph) HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
+      else if ((rc = enqueue_body(timing ? b : -1))) return rc;
+    }
+    bodies_enqueued += nb;
+    HIP_TRY(hipMemcpyAsync(&st, dst, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    {
+    const int ran = (int)std::min<long long>(nb, std::max<long long>(0, (long long)st.bodies - (bodies_enqueued - nb)));
+    for (int b = 0; timing && b < ran; ++b) {
       float ms = 0.f;
-      if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) S->time_linearize += ms * 1e-3;
-      if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) S->time_solve_reduced += ms * 1e-3;
-      if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) S->time_backsub += ms * 1e-3;
-      if (hipEventElapsedTime(&ms, h->ev[4], h->ev[5]) == hipSuccess) S->time_kernel_linearize += ms * 1e-3;
+      if (hipEventElapsedTime(&ms, h->ev[b][0], h->ev[b][1]) == hipSuccess) S->time_linearize += ms * 1e-3;
+      if (hipEventElapsedTime(&ms, h->ev[b][1], h->ev[b][2]) == hipSuccess) S->time_solve_reduced += ms * 1e-3;
+      if (hipEventElapsedTime(&ms, h->ev[b][2], h->ev[b][3]) == hipSuccess) S->time_backsub += ms * 1e-3;
+      if (hipEventElapsedTime(&ms, h->ev[b][4], h->ev[b][5]) == hipSuccess) S->time_kernel_linearize += ms * 1e-3;
       S->num_linearize_launches++;
     }
-    const double* sa = h->h_scal;
-    const double* sb = h->h_scal + 16;
-    x_cost = sa[SC_COST];
-    gmax = sa[SC_GMAX];
-    if (pending_grad >= 0 && S->trace_gradient_max_norm) S->trace_gradient_max_norm[pending_grad] = gmax;
-    pending_grad = -1;
-    if (first) {
-      first = false;
-      S->initial_cost = x_cost + h->fixed_cost;
-      minimum_cost = x_cost;
-      if (sa[SC_INVALID] > 0.0 || !std::isfinite(x_cost)) {
-        // "Initial residual and Jacobian evaluation failed." -> FAILURE
-        term = THEIA_TERM_FAILURE; S->final_cost = S->initial_cost; break;
-      }
-      trace_push(S, x_cost + h->fixed_cost, gmax, 0.0, radius, 1);
-    }
-    // FinalizeIterationAndCheckIfMinimizerCanContinue
-    if (now_s() - t_start >= O.max_solver_time_in_seconds) { term = THEIA_TERM_NO_CONVERGENCE; break; }
-    if (iter >= O.max_num_iterations) { term = THEIA_TERM_NO_CONVERGENCE; break; }
-    if (step_successful && gmax <= O.gradient_tolerance) { term = THEIA_TERM_CONVERGENCE; break; }
-    if (radius <= 1e-32) { term = THEIA_TERM_CONVERGENCE; break; }
-    ++iter;
-    const double mcc = sb[SB_MCC];
-    const bool solved = sa[SC_NOTPD] == 0.0 && std::isfinite(mcc) && std::isfinite(sb[SB_STEPSQ] + sb[SB_STEPSQ_CAM]);
-    const bool step_valid = solved && mcc > 0.0;
-    if (!step_valid) {
-      if (++invalid_steps >= 5) { term = THEIA_TERM_FAILURE; break; }
-      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
-      trace_push(S, x_cost + h->fixed_cost, gmax, 0.0, radius, 0);
-      if (O.verbose) std::fprintf(stderr, "[theia_hip] %3d invalid step, radius %.3e\n", iter, radius);
-      continue;
-    }
-    invalid_steps = 0;
-    double cand_cost = sb[SB_COST];
-    if (sb[SB_INVALID] > 0.0 || !std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
-    const double step_norm = std::sqrt(sb[SB_STEPSQ] + sb[SB_STEPSQ_CAM]);
-    if (step_norm <= O.parameter_tolerance * (x_norm + O.parameter_tolerance)) {
-      trace_push(S, cand_cost + h->fixed_cost, gmax, step_norm, radius, 0);
-      term = THEIA_TERM_CONVERGENCE; break;
-    }
-    const double cost_change = x_cost - cand_cost;
-    if (std::fabs(cost_change) <= O.function_tolerance * x_cost) {
-      trace_push(S, cand_cost + h->fixed_cost, gmax, step_norm, radius, 0);
-      term = THEIA_TERM_CONVERGENCE; break;
-    }
-    const double relative_decrease = cost_change / mcc;
-    if (relative_decrease > 1e-3) {
-      h->cur = 1 - h->cur;  // candidate buffers become the state
-      x_norm = std::sqrt(sb[SB_XNORMSQ] + sb[SB_XNORMSQ_CAM]);
-      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3));
-      radius = std::min(O.max_trust_region_radius, radius);
-      decrease_factor = 2.0; step_successful = true;
-      S->num_successful_steps++;
-      if (cand_cost < minimum_cost) minimum_cost = cand_cost;
-      // gradient at the new point is produced by the next linearize; the
-      // trace entry is completed there (gmax of the NEXT read-back).
-      if (S->trace_cost && S->trace_size < S->trace_capacity) pending_grad = S->trace_size;
-      trace_push(S, cand_cost + h->fixed_cost, -1.0, step_norm, radius, 1);
-    } else {
-      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
-      trace_push(S, cand_cost + h->fixed_cost, gmax, step_norm, radius, 0);
-    }
-    if (O.verbose)
-      std::fprintf(stderr, "[theia_hip] %3d cost %.6e cand %.6e rho %.3e |g| %.3e |step| %.3e radius %.3e %s\n", iter,
-                   x_cost, cand_cost, relative_decrease, gmax, step_norm, radius, step_successful ? "ok" : "rej");
+    if (st.done) break;
   }
-  // patch the gradient entries of accepted steps (known one read-back later)
+  if (ctl.trace_capacity) {
+    const int k = std::min(st.trace_size, S->trace_capacity);
+    S->trace_size = k;
+    if (k) {
+      HIP_TRY(hipMemcpy(S->trace_cost, h->tr_cost.p, sizeof(double) * k, hipMemcpyDeviceToHost));
+      if (S->trace_gradient_max_norm) HIP_TRY(hipMemcpy(S->trace_gradient_max_norm, h->tr_g.p, sizeof(double) * k, hipMemcpyDeviceToHost));
+      if (S->trace_step_norm) HIP_TRY(hipMemcpy(S->trace_step_norm, h->tr_step.p, sizeof(double) * k, hipMemcpyDeviceToHost));
+      if (S->trace_radius) HIP_TRY(hipMemcpy(S->trace_radius, h->tr_radius.p, sizeof(double) * k, hipMemcpyDeviceToHost));
+      if (S->trace_accepted) HIP_TRY(hipMemcpy(S->trace_accepted, h->tr_acc.p, sizeof(int) * k, hipMemcpyDeviceToHost));
+    }
+  }
+  if (O.verbose)
+    for (int k = 0; k < S->trace_size; ++k)
+      std::fprintf(stderr, "[theia_hip] %3d cost %.6e |g| %.3e |step| %.3e radius %.3e %s\n", k, S->trace_cost[k],
+                   S->trace_gradient_max_norm ? S->trace_gradient_max_norm[k] : 0.0, S->trace_step_norm ? S->trace_step_norm[k] : 0.0,
+                   S->trace_radius ? S->trace_radius[k] : 0.0, (S->trace_accepted && S->trace_accepted[k]) ? "ok" : "rej");
   if (h->stamps.p) {  // development aid: cycle breakdown of one k_linearize workgroup
-    long long st[6];
-    if (hipMemcpy(st, h->stamps.p, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess)
+    long long stp[6];
+    if (hipMemcpy(stp, h->stamps.p, sizeof(stp), hipMemcpyDeviceToHost) == hipSuccess)
       std::fprintf(stderr, "[theia_hip] k_linearize WG cycles: load+jac %lld | seg-reduce %lld | invert+W/T %lld | camera LDS adds %lld | "
-                   "pair blocks %lld | flush %lld (tiles/WG %d, nwg %d)\n", st[0], st[1], st[2], st[3], st[4], st[5], h->tiles_per_wg, h->nwg);
+                   "pair blocks %lld | flush %lld (tiles/WG %d, nwg %d)\n", stp[0], stp[1], stp[2], stp[3], stp[4], stp[5], h->tiles_per_wg, h->nwg);
   }
-  S->num_iterations = iter;
-  S->termination_type = term;
-  S->success = term != THEIA_TERM_FAILURE;
-  if (term != THEIA_TERM_FAILURE || S->final_cost == 0.0) S->final_cost = minimum_cost + h->fixed_cost;
+  S->num_iterations = st.iter;
+  S->num_successful_steps = st.num_successful;
+  S->termination_type = st.term;
+  S->success = st.term != THEIA_TERM_FAILURE;
+  S->initial_cost = st.initial_cost;
+  S->final_cost = st.fail_at_first ? st.initial_cost : st.minimum_cost + h->fixed_cost;
   S->solve_time_in_seconds = now_s() - t_start;
   return 0;
 }
@@ -951,7 +1086,14 @@ int theia_hip_ba_reduced_system(theia_ba_handle h, double radius, int32_t* n_out
   if (!h || !n_out) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
   int rc = compute_scale(h);
   if (rc) return rc;
-  rc = enqueue_linearize(h, radius);
+  {
+    LmState st;
+    std::memset(&st, 0, sizeof(st));
+    st.radius = radius;
+    HIP_TRY(hipMemcpyAsync(h->lm_state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));   // `st` is a stack object
+  }
+  rc = enqueue_linearize(h);
   if (rc) return rc;
   const int n = h->n;
   *n_out = n;
