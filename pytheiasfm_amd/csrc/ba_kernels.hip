@@ -620,9 +620,9 @@ __global__ __launch_bounds__(kBlock) void k_lin_obs(DevProblem P, const double* 
   const double radius = *radius_p;   // device-resident: the LM step control runs on the GPU
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  if (tile >= P.ntiles) return;
-  const int cnt = P.tile_count[tile];
-  const int start = P.tile_start[tile];
+  const bool tile_ok = tile < P.ntiles;
+  const int cnt = tile_ok ? P.tile_count[tile] : 0;
+  const int start = tile_ok ? P.tile_start[tile] : 0;
   LaneLin<PD> L;
   lane_linearize<PD, true>(P, cam, pts, start + lane, lane < cnt, lane, L);
   const int slot = (lane < cnt) ? P.rec_slot[start + lane] : -1;
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_obs(DevProblem P, const double* 
   gmax = wave_max(gmax);
   const double inval = wave_sum((L.active && !L.valid) ? 1.0 : 0.0);
   const double npd = wave_sum((L.active && !pd_ok && sg.head) ? 1.0 : 0.0);
-  if (lane == 0) {
+  if (lane == 0 && tile_ok) {
     tile_part[4 * (size_t)tile + 0] = cost;
     tile_part[4 * (size_t)tile + 1] = gmax;
     tile_part[4 * (size_t)tile + 2] = inval;
@@ -727,7 +727,7 @@ THIP_DEV double wave_reduce_scatter(double (&v)[N], int lane, int& lo, int& cnt)
 
 // the four waves of a workgroup share one list; combine their totals in wave order
 template <int N>
-THIP_DEV double block_combine(double (*part)[N + 1], double tot, int lo, int cnt, int wv, int tid) {
+THIP_DEV double block_combine(double (*part)[40], double tot, int lo, int cnt, int wv, int tid) {
   if (cnt > 0) part[wv][lo] = tot;
   __syncthreads();
   return (tid < N) ? ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) : 0.0;
@@ -742,13 +742,11 @@ THIP_DEV void load_rec(const double* __restrict__ rec, int slot, int off2, doubl
 
 // one workgroup per (camera, chunk of its contiguous records)
 template <int PD>
-__global__ __launch_bounds__(kBlock) void k_schur_diag(DevProblem P, double* __restrict__ S,
-                                                       double* __restrict__ rhs, double* __restrict__ colsq,
-                                                       double* __restrict__ gc) {
+THIP_DEV void schur_diag_item(const DevProblem& P, int item, double (*part)[40], double* __restrict__ S,
+                              double* __restrict__ rhs, double* __restrict__ colsq, double* __restrict__ gc) {
   constexpr int NW = 6 * PD;
-  __shared__ double part[kWavesPerBlock][40];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int* it = P.diag_items + 4 * blockIdx.x;
+  const int* it = P.diag_items + 4 * item;
   const int rc = it[0], beg = it[1], end = it[2], atomic = it[3];
   double acc[39];
 #pragma unroll
@@ -792,11 +790,10 @@ __global__ __launch_bounds__(kBlock) void k_schur_diag(DevProblem P, double* __r
 
 // one workgroup per (block (ri, rj), chunk of its pair list)
 template <int PD>
-__global__ __launch_bounds__(kBlock) void k_schur_blocks(DevProblem P, double* __restrict__ S) {
+THIP_DEV void schur_block_item(const DevProblem& P, int item, double (*part)[40], double* __restrict__ S) {
   constexpr int NW = 6 * PD;
-  __shared__ double part[kWavesPerBlock][37];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int* it = P.blk_items + 5 * blockIdx.x;
+  const int* it = P.blk_items + 5 * item;
   const int ri = it[0], rj = it[1], beg = it[2], end = it[3], atomic = it[4];
   double acc[36];
 #pragma unroll
@@ -824,6 +821,17 @@ __global__ __launch_bounds__(kBlock) void k_schur_blocks(DevProblem P, double* _
   if (ri == rj && b > a) return;   // two observations of one camera in a track: lower part of the diagonal block
   double* dst = S + (size_t)(6 * ri + a) * P.n + 6 * rj + b;
   if (atomic) atomic_add(dst, -tot); else *dst = -tot;
+}
+
+// K2: the camera (diagonal) items and the camera-pair (block) items in ONE launch --
+// they are independent, and at C2 size every launch costs as much as it computes.
+template <int PD>
+__global__ __launch_bounds__(kBlock) void k_schur(DevProblem P, double* __restrict__ S, double* __restrict__ rhs,
+                                                  double* __restrict__ colsq, double* __restrict__ gc) {
+  __shared__ double part[kWavesPerBlock][40];
+  const int b = blockIdx.x;
+  if (b < P.n_blk_items) schur_block_item<PD>(P, b, part, S);        // the long lists first
+  else schur_diag_item<PD>(P, b - P.n_blk_items, part, S, rhs, colsq, gc);
 }
 
 // Deterministic reduction of per-tile partials into the scalar block.
@@ -961,9 +969,9 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
   constexpr int NT = PD * (PD + 1) / 2;
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-  if (tile >= P.ntiles) return;
-  const int cnt = P.tile_count[tile];
-  const int start = P.tile_start[tile];
+  const bool tile_ok = tile < P.ntiles;
+  const int cnt = tile_ok ? P.tile_count[tile] : 0;
+  const int start = tile_ok ? P.tile_start[tile] : 0;
   LaneLin<PD, INTR> L;
   lane_linearize<PD, true, INTR>(P, cam, pts, start + lane, lane < cnt, lane, L);
   const Segment sg = lane_segment(L.p, lane);
@@ -1056,7 +1064,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
   stepsq = wave_sum(stepsq);
   xnormsq = wave_sum(xnormsq);
   const double inval = wave_sum(cvalid ? 0.0 : 1.0);
-  if (lane == 0) {
+  if (lane == 0 && tile_ok) {
     double* tp = tile_part + 5 * (size_t)tile;
     tp[0] = ccost; tp[1] = mcc; tp[2] = stepsq; tp[3] = xnormsq; tp[4] = inval;
   }
@@ -1338,13 +1346,9 @@ void launch_linearize(const DevProblem& P, const double* cam, const double* pts,
     const int g = tile_blocks(P.ntiles);
     if (P.pd == 3) k_lin_obs<3><<<g, kBlock, 0, st>>>(P, cam, pts, radius, Vinv, gp, tile_part);
     else k_lin_obs<4><<<g, kBlock, 0, st>>>(P, cam, pts, radius, Vinv, gp, tile_part);
-    if (P.n_diag_items) {
-      if (P.pd == 3) k_schur_diag<3><<<P.n_diag_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc);
-      else k_schur_diag<4><<<P.n_diag_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc);
-    }
-    if (P.n_blk_items) {
-      if (P.pd == 3) k_schur_blocks<3><<<P.n_blk_items, kBlock, 0, st>>>(P, rb.S);
-      else k_schur_blocks<4><<<P.n_blk_items, kBlock, 0, st>>>(P, rb.S);
+    if (P.n_diag_items + P.n_blk_items) {
+      if (P.pd == 3) k_schur<3><<<P.n_diag_items + P.n_blk_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc);
+      else k_schur<4><<<P.n_diag_items + P.n_blk_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc);
     }
     return;
   }

@@ -796,6 +796,13 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
         q = e;
       }
     }
+    // a camera that sees a track twice also has a (c, c) pair list: both kinds of items then ADD
+    // into the diagonal block (they run in one launch, unordered)
+    {
+      std::vector<char> self(h->ncv, 0);
+      for (size_t k = 0; k + 4 < bitems.size() + 1; k += 5) if (bitems[k] == bitems[k + 1]) self[bitems[k]] = 1;
+      for (size_t k = 0; k + 3 < ditems.size() + 1; k += 4) if (self[ditems[k]]) ditems[k + 3] = 1;
+    }
     h->n_diag_items = (int)ditems.size() / 4; h->n_blk_items = (int)bitems.size() / 5;
     for (auto& pr : pairs) { pr.x = cam_obs[pr.x]; pr.y = cam_obs[pr.y]; }
     UP(diag_items, ditems); UP(cam_obs, cam_obs); UP(blk_items, bitems); UP(blk_pairs, pairs);
