@@ -222,6 +222,15 @@ int theia_hip_ba_views_batch(const theia_ba_view_batch* batch,
                              const theia_ba_options* options,
                              theia_ba_summary* summaries);
 
+/* Every point of `problem` as its OWN problem with all cameras constant: N calls of
+ * BundleAdjustTrack(options, track_id, reconstruction) (bundle_adjustment.cc:262-285; the
+ * per-track refinement after triangulation, estimate_track.cc:289) in one launch, one thread
+ * per track running its whole LM.  problem->points is updated in place; points flagged in
+ * point_const (or without observations) are left alone.  summaries[num_points]. */
+int theia_hip_ba_tracks_batch(const theia_ba_problem* problem,
+                              const theia_ba_options* options,
+                              theia_ba_summary* summaries);
+
 /* Handle API: problem resident in HBM across calls (bench, repeated solves). */
 typedef struct theia_ba_handle_s* theia_ba_handle;
 int theia_hip_ba_create(const theia_ba_problem* problem,

@@ -159,3 +159,16 @@ def solve_views_batch(offsets, obs_uv, points, cam_ext, intrinsics, model, optio
     L.theia_hip_ba_views_batch.argtypes = [C.POINTER(capi.BaViewBatch), C.POINTER(capi.BaOptions), C.POINTER(capi.BaSummary)]
     capi.check(L.theia_hip_ba_views_batch(C.byref(st), C.byref(options), summ))
     return [summ[i] for i in range(num)]
+
+
+def solve_tracks_batch(problem, options):
+    """theia_hip_ba_tracks_batch: every point as an independent BundleAdjustTrack problem
+    (bundle_adjustment.cc:262-285), cameras constant.  problem.points is updated in place;
+    returns a list of BaSummary (one per point)."""
+    st = problem.as_struct()
+    num = problem.points.shape[0]
+    summ = (capi.BaSummary * max(1, num))()
+    L = capi.lib()
+    L.theia_hip_ba_tracks_batch.argtypes = [C.POINTER(capi.BaProblem), C.POINTER(capi.BaOptions), C.POINTER(capi.BaSummary)]
+    capi.check(L.theia_hip_ba_tracks_batch(C.byref(st), C.byref(options), summ))
+    return [summ[i] for i in range(num)]

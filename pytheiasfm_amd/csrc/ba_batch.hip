@@ -256,6 +256,189 @@ __global__ __launch_bounds__(256) void k_view_lm(ViewBatch B, ViewOut* __restric
   }
 }
 
+// ------------------------------------------------------------------ tracks
+// N independent BundleAdjustTrack problems (bundle_adjustment.cc:262-285,389-418 with one track each;
+// estimate_track.cc:289 refines every triangulated track this way from a thread pool): the point is
+// the only variable block, all cameras are constant.  One THREAD per track runs the whole LM.
+struct TrackBatch {
+  int num;                       // points
+  const int64_t* offsets;        // [num+1] into the observation arrays (sorted by point)
+  const double2* uv;
+  const double2* si;             // or nullptr
+  const int* obs_cam;
+  const double* cam;             // [nc][6]
+  const double* intr;            // [ng][10]
+  const int* group_model;
+  const int* cam_group;
+  const uint8_t* pt_const;       // or nullptr
+  double* pts;                   // [num][4] in/out
+  int loss_type;
+  double loss_width;
+  int max_iterations;
+  double function_tolerance, gradient_tolerance, parameter_tolerance, max_radius;
+};
+
+template <int PD>
+__device__ void track_linearize(const TrackBatch& B, int p, const double* X, const double* scale, double* H, double* g,
+                                double* cost, bool* invalid, bool want_jac) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  for (int k = 0; k < NT; ++k) H[k] = 0.0;
+  for (int k = 0; k < PD; ++k) g[k] = 0.0;
+  double c = 0.0;
+  bool inv = false;
+  for (int64_t o = B.offsets[p]; o < B.offsets[p + 1]; ++o) {
+    const int cidx = B.obs_cam[o];
+    const int grp = B.cam_group[cidx];
+    const double2 uv = B.uv[o];
+    double six = 1.0, siy = 1.0;
+    if (B.si) { const double2 s = B.si[o]; six = s.x; siy = s.y; }
+    ObsLin ol;
+    if (want_jac) observe<true, false>(B.group_model[grp], B.cam + 6 * (size_t)cidx, B.intr + (size_t)grp * THEIA_MAX_INTRINSICS, X, uv.x, uv.y, six, siy, ol);
+    else observe<false, false>(B.group_model[grp], B.cam + 6 * (size_t)cidx, B.intr + (size_t)grp * THEIA_MAX_INTRINSICS, X, uv.x, uv.y, six, siy, ol);
+    if (!ol.valid) inv = true;
+    double rho1;
+    const double rho = loss_eval(B.loss_type, B.loss_width, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
+    c += 0.5 * rho;
+    if (!want_jac) continue;
+    const double sr = sqrt(rho1);
+    const double r0 = sr * ol.r[0], r1 = sr * ol.r[1];
+    double J[2 * PD];
+    if (PD == 3) {
+      double Jt[6];
+      to_tangent(X, ol.Jx, Jt);
+      for (int q = 0; q < 3; ++q) { J[q] = Jt[q] * sr * scale[q]; J[PD + q] = Jt[3 + q] * sr * scale[q]; }
+    } else {
+      for (int q = 0; q < PD; ++q) { J[q] = ol.Jx[q] * sr * scale[q]; J[PD + q] = ol.Jx[4 + q] * sr * scale[q]; }
+    }
+    int k = 0;
+    for (int a = 0; a < PD; ++a) {
+      for (int b = 0; b <= a; ++b) H[k++] += J[a] * J[b] + J[PD + a] * J[PD + b];
+      g[a] += J[a] * r0 + J[PD + a] * r1;
+    }
+  }
+  *cost = c; *invalid = inv;
+}
+
+template <int PD>
+__device__ bool solve_small(const double* H, const double* d, const double* g, double* y) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  double L[NT];
+  for (int i = 0; i < PD; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = H[tri(i, j)] + (i == j ? d[i] : 0.0);
+      for (int k = 0; k < j; ++k) s -= L[tri(i, k)] * L[tri(j, k)];
+      if (i == j) { if (!(s > 0.0)) return false; L[tri(i, i)] = sqrt(s); }
+      else L[tri(i, j)] = s / L[tri(j, j)];
+    }
+  double z[PD];
+  for (int i = 0; i < PD; ++i) {
+    double s = g[i];
+    for (int k = 0; k < i; ++k) s -= L[tri(i, k)] * z[k];
+    z[i] = s / L[tri(i, i)];
+  }
+  for (int i = PD - 1; i >= 0; --i) {
+    double s = z[i];
+    for (int k = i + 1; k < PD; ++k) s -= L[tri(k, i)] * y[k];
+    y[i] = s / L[tri(i, i)];
+  }
+  return true;
+}
+
+template <int PD>
+__global__ __launch_bounds__(64) void k_track_lm(TrackBatch B, ViewOut* __restrict__ out) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B.num) return;
+  ViewOut R;
+  R.success = 1; R.term = THEIA_TERM_CONVERGENCE; R.iters = 0; R.nsucc = 0; R.initial_cost = 0.0; R.final_cost = 0.0;
+  double X[4];
+  for (int q = 0; q < 4; ++q) X[q] = B.pts[4 * (size_t)p + q];
+  double scale[PD], H[NT], g[PD], x_cost;
+  for (int q = 0; q < PD; ++q) scale[q] = 1.0;
+  bool invalid;
+  const bool is_const = (B.pt_const && B.pt_const[p]) || B.offsets[p + 1] == B.offsets[p];
+  track_linearize<PD>(B, p, X, scale, H, g, &x_cost, &invalid, true);
+  if (is_const) {   // nothing to optimise: report the cost of its residual blocks
+    R.initial_cost = R.final_cost = x_cost;
+    out[p] = R;
+    return;
+  }
+  for (int q = 0; q < PD; ++q) scale[q] = 1.0 / (1.0 + sqrt(H[tri(q, q)]));
+  double radius = 1e4, decrease_factor = 2.0;
+  bool step_successful = true, need_linearize = true, first = true;
+  int iter = 0, invalid_steps = 0, term = THEIA_TERM_NO_CONVERGENCE;
+  double x_norm = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2] + X[3] * X[3]);
+  double minimum_cost = 0.0, gmax = 0.0;
+  while (true) {
+    if (need_linearize) {
+      track_linearize<PD>(B, p, X, scale, H, g, &x_cost, &invalid, true);
+      gmax = 0.0;
+      for (int q = 0; q < PD; ++q) gmax = fmax(gmax, fabs(g[q] / scale[q]));
+      need_linearize = false;
+    }
+    if (first) {
+      first = false;
+      R.initial_cost = x_cost; minimum_cost = x_cost;
+      if (invalid || !isfinite(x_cost)) { term = THEIA_TERM_FAILURE; R.final_cost = x_cost; break; }
+    }
+    if (iter >= B.max_iterations) { term = THEIA_TERM_NO_CONVERGENCE; break; }
+    if (step_successful && gmax <= B.gradient_tolerance) { term = THEIA_TERM_CONVERGENCE; break; }
+    if (radius <= 1e-32) { term = THEIA_TERM_CONVERGENCE; break; }
+    ++iter;
+    double d[PD], y[PD];
+    for (int q = 0; q < PD; ++q) d[q] = fmin(fmax(H[tri(q, q)], 1e-6), 1e32) / radius;
+    const bool pd = solve_small<PD>(H, d, g, y);
+    double yg = 0.0, yHy = 0.0;
+    for (int a = 0; a < PD; ++a) {
+      yg += y[a] * g[a];
+      double row = 0.0;
+      for (int b = 0; b < PD; ++b) row += H[a >= b ? tri(a, b) : tri(b, a)] * y[b];
+      yHy += y[a] * row;
+    }
+    const double mcc = yg - 0.5 * yHy;
+    double Xp[4] = {X[0], X[1], X[2], X[3]};
+    if (PD == 3) {
+      const double d3[3] = {-y[0] * scale[0], -y[1] * scale[1], -y[2] * scale[2]};
+      sphere_plus(X, d3, Xp);
+    } else {
+      for (int q = 0; q < PD; ++q) Xp[q] = X[q] - y[q] * scale[q];
+    }
+    double stepsq = 0.0, xnormsq = 0.0;
+    for (int q = 0; q < 4; ++q) { stepsq += (X[q] - Xp[q]) * (X[q] - Xp[q]); xnormsq += Xp[q] * Xp[q]; }
+    const bool step_valid = pd && isfinite(mcc) && isfinite(stepsq) && mcc > 0.0;
+    if (!step_valid) {
+      if (++invalid_steps >= 5) { term = THEIA_TERM_FAILURE; break; }
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+      continue;
+    }
+    invalid_steps = 0;
+    double cand_cost, Hd[NT], gd[PD];
+    bool cinv;
+    track_linearize<PD>(B, p, Xp, scale, Hd, gd, &cand_cost, &cinv, false);
+    if (cinv || !isfinite(cand_cost)) cand_cost = DBL_MAX;
+    const double step_norm = sqrt(stepsq);
+    if (step_norm <= B.parameter_tolerance * (x_norm + B.parameter_tolerance)) { term = THEIA_TERM_CONVERGENCE; break; }
+    const double cost_change = x_cost - cand_cost;
+    if (fabs(cost_change) <= B.function_tolerance * x_cost) { term = THEIA_TERM_CONVERGENCE; break; }
+    const double rho = cost_change / mcc;
+    if (rho > 1e-3) {
+      for (int q = 0; q < 4; ++q) X[q] = Xp[q];
+      x_norm = sqrt(xnormsq);
+      const double t = 2.0 * rho - 1.0;
+      radius = fmin(B.max_radius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+      decrease_factor = 2.0; step_successful = true; need_linearize = true;
+      R.nsucc++;
+      if (cand_cost < minimum_cost) minimum_cost = cand_cost;
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+    }
+  }
+  R.iters = iter; R.term = term; R.success = term != THEIA_TERM_FAILURE;
+  if (term != THEIA_TERM_FAILURE) R.final_cost = minimum_cost;
+  out[p] = R;
+  for (int q = 0; q < 4; ++q) B.pts[4 * (size_t)p + q] = X[q];
+}
+
 template <typename T>
 struct Dev {
   T* p = nullptr;
@@ -351,6 +534,79 @@ extern "C" int theia_hip_ba_views_batch(const theia_ba_view_batch* b, const thei
     views_batch_unpack(h_out.data(), i, &S.success, &S.termination_type, &S.num_iterations, &S.num_successful_steps,
                        &S.initial_cost, &S.final_cost);
     S.setup_time_in_seconds = 0.0; S.solve_time_in_seconds = dt / num;
+    S.time_linearize = S.time_solve_reduced = S.time_backsub = S.time_kernel_linearize = 0.0;
+    S.num_linearize_launches = 0;
+  }
+  return 0;
+}
+
+extern "C" int theia_hip_ba_tracks_batch(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_summary* summaries) {
+  if (!p || !o) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null problem/options");
+  const int np = p->num_points;
+  if (np < 0 || p->num_cameras < 0 || p->num_groups < 0 || p->num_obs < 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "negative sizes");
+  if (np == 0) return 0;
+  if (!summaries || !p->points) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null array");
+  if (p->num_obs > 0 && (!p->cam_ext || !p->intrinsics || !p->group_model || !p->cam_group || !p->obs_uv || !p->obs_cam || !p->obs_pt))
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null array in problem");
+  if (p->num_obs >= ((int64_t)1 << 31)) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "num_obs >= 2^31");
+  for (int c = 0; c < p->num_cameras; ++c)
+    if (p->cam_group[c] < 0 || p->cam_group[c] >= p->num_groups) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "cam_group[%d] out of range", c);
+  for (int g = 0; g < p->num_groups; ++g)
+    if (p->group_model[g] < THEIA_CAM_PINHOLE || p->group_model[g] > THEIA_CAM_ORTHOGRAPHIC)
+      return set_error(THEIA_HIP_ERR_UNSUPPORTED, "camera model %d of group %d has no HIP kernel", p->group_model[g], g);
+  for (int64_t i = 0; i < p->num_obs; ++i)
+    if (p->obs_cam[i] < 0 || p->obs_cam[i] >= p->num_cameras || p->obs_pt[i] < 0 || p->obs_pt[i] >= np)
+      return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "observation %lld indexes out of range", (long long)i);
+  if (o->loss_function_type < 0 || o->loss_function_type > THEIA_LOSS_TRUNCATED)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown loss function type");
+  int rc = thip::ensure_device();
+  if (rc) return rc;
+  // observations grouped by point (stable: the reference walks a track's views in its own order; sums differ by rounding only)
+  const int64_t nobs = p->num_obs;
+  std::vector<int64_t> off(np + 1, 0);
+  for (int64_t i = 0; i < nobs; ++i) off[p->obs_pt[i] + 1]++;
+  for (int q = 0; q < np; ++q) off[q + 1] += off[q];
+  std::vector<double> uv(2 * (size_t)nobs), si;
+  std::vector<int> oc((size_t)nobs);
+  if (p->obs_sqrt_info) si.resize(2 * (size_t)nobs);
+  {
+    std::vector<int64_t> fill(off.begin(), off.end() - 1);
+    for (int64_t i = 0; i < nobs; ++i) {
+      const int64_t s = fill[p->obs_pt[i]]++;
+      uv[2 * s] = p->obs_uv[2 * i]; uv[2 * s + 1] = p->obs_uv[2 * i + 1];
+      if (p->obs_sqrt_info) { si[2 * s] = p->obs_sqrt_info[2 * i]; si[2 * s + 1] = p->obs_sqrt_info[2 * i + 1]; }
+      oc[s] = p->obs_cam[i];
+    }
+  }
+  Dev<int64_t> d_off; Dev<double> d_uv, d_si, d_cam, d_intr, d_pts; Dev<int> d_oc, d_gm, d_cg; Dev<uint8_t> d_pc; Dev<char> d_out;
+  if ((rc = d_off.up(off.data(), np + 1)) || (rc = d_uv.up(uv.data(), uv.size())) || (rc = d_oc.up(oc.data(), oc.size())) ||
+      (rc = d_cam.up(p->cam_ext, 6 * (size_t)p->num_cameras)) || (rc = d_intr.up(p->intrinsics, THEIA_MAX_INTRINSICS * (size_t)p->num_groups)) ||
+      (rc = d_gm.up(p->group_model, p->num_groups)) || (rc = d_cg.up(p->cam_group, p->num_cameras)) ||
+      (rc = d_pts.up(p->points, 4 * (size_t)np)) || (rc = d_out.alloc(sizeof(ViewOut) * (size_t)np)))
+    return rc;
+  if (p->obs_sqrt_info && (rc = d_si.up(si.data(), si.size()))) return rc;
+  if (p->point_const && (rc = d_pc.up(p->point_const, np))) return rc;
+  TrackBatch B;
+  B.num = np; B.offsets = d_off.p; B.uv = reinterpret_cast<const double2*>(d_uv.p);
+  B.si = p->obs_sqrt_info ? reinterpret_cast<const double2*>(d_si.p) : nullptr;
+  B.obs_cam = d_oc.p; B.cam = d_cam.p; B.intr = d_intr.p; B.group_model = d_gm.p; B.cam_group = d_cg.p;
+  B.pt_const = p->point_const ? d_pc.p : nullptr; B.pts = d_pts.p;
+  B.loss_type = o->loss_function_type; B.loss_width = o->robust_loss_width; B.max_iterations = o->max_num_iterations;
+  B.function_tolerance = o->function_tolerance; B.gradient_tolerance = o->gradient_tolerance;
+  B.parameter_tolerance = o->parameter_tolerance; B.max_radius = o->max_trust_region_radius;
+  const double t0 = now_s();
+  if (o->use_homogeneous_point_parametrization) k_track_lm<3><<<(np + 63) / 64, 64>>>(B, reinterpret_cast<ViewOut*>(d_out.p));
+  else k_track_lm<4><<<(np + 63) / 64, 64>>>(B, reinterpret_cast<ViewOut*>(d_out.p));
+  std::vector<char> h_out(sizeof(ViewOut) * (size_t)np);
+  HIP_TRY(hipMemcpy(h_out.data(), d_out.p, h_out.size(), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(p->points, d_pts.p, sizeof(double) * 4 * (size_t)np, hipMemcpyDeviceToHost));
+  const double dt = now_s() - t0;
+  for (int i = 0; i < np; ++i) {
+    theia_ba_summary& S = summaries[i];
+    S.trace_size = 0;
+    views_batch_unpack(h_out.data(), i, &S.success, &S.termination_type, &S.num_iterations, &S.num_successful_steps,
+                       &S.initial_cost, &S.final_cost);
+    S.setup_time_in_seconds = 0.0; S.solve_time_in_seconds = dt / np;
     S.time_linearize = S.time_solve_reduced = S.time_backsub = S.time_kernel_linearize = 0.0;
     S.num_linearize_launches = 0;
   }

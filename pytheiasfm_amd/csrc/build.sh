@@ -7,14 +7,16 @@ cd "$(dirname "$0")"
 SRCS=$(ls *.hip)
 mkdir -p _obj
 OBJS=""
+PIDS=""
 for f in $SRCS; do
   o=_obj/${f%.hip}.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find . ../../include -maxdepth 1 -name '*.h' -newer "$o")" ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics \
       -I../../include -I. -c "$f" -o "$o" &
+    PIDS="$PIDS $!"
   fi
   OBJS="$OBJS $o"
 done
-wait
+for p in $PIDS; do wait $p || { echo "compile failed" >&2; exit 1; }; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libtheia_hip.so $OBJS
 echo "built $(realpath ../libtheia_hip.so)"

@@ -306,3 +306,53 @@ def BundleAdjustTracks(reconstruction, options, track_ids):
 def BundleAdjustTrack(reconstruction, options, track_id):
     """bundle_adjustment.cc:261-285."""
     return BundleAdjustTracks(reconstruction, options, [track_id])
+
+
+# --------------------------------------------------------------- batched micro-BA
+# The pipelines call BundleAdjustView / BundleAdjustTrack once per view / per track from a
+# thread pool (estimate_track.cc:176-184,289; camera localisation).  These two helpers run
+# such a list of INDEPENDENT problems as one device batch; each entry is exactly what the
+# single-item function of the reference would solve.
+def BundleAdjustViewsIndependently(reconstruction, options, view_ids):
+    """[BundleAdjustView(reconstruction, options, v) for v in view_ids] as one launch
+    (theia_hip_ba_views_batch).  Returns the list of summaries."""
+    r = reconstruction
+    view_ids = [int(v) for v in view_ids]
+    for v in view_ids:
+        if v < 0 or v >= r.NumViews():
+            raise capi.TheiaHipError(-1, "view id out of range (reference: CHECK_NOTNULL aborts)")
+    sel = [np.nonzero((r.obs_view == v) & r.track_estimated[r.obs_track] & bool(r.view_estimated[v]))[0] for v in view_ids]
+    offsets = np.zeros(len(view_ids) + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([len(s) for s in sel])
+    idx = np.concatenate(sel) if sel else np.zeros(0, dtype=np.int64)
+    cams = np.ascontiguousarray(r.cam_ext[view_ids]) if view_ids else np.zeros((0, 6))
+    cov = r.obs_cov[idx]
+    si = None if (len(cov) == 0 or np.all(cov == 1.0)) else 1.0 / np.sqrt(cov)
+    summ = _ba.solve_views_batch(offsets, r.obs_uv[idx], r.points[r.obs_track[idx]], cams,
+                                 r.group_intrinsics[r.view_group[view_ids]], r.group_model[r.view_group[view_ids]],
+                                 options.to_c(), obs_sqrt_info=si)
+    for k, v in enumerate(view_ids):
+        r.cam_ext[v] = cams[k]
+    return [BundleAdjustmentSummary(s) for s in summ]
+
+
+def BundleAdjustTracksIndependently(reconstruction, options, track_ids):
+    """[BundleAdjustTrack(reconstruction, options, t) for t in track_ids] as one launch
+    (theia_hip_ba_tracks_batch).  Returns the list of summaries."""
+    r = reconstruction
+    track_ids = np.asarray([int(t) for t in track_ids], dtype=np.int64)
+    if len(track_ids) and (track_ids.min() < 0 or track_ids.max() >= r.NumTracks()):
+        raise capi.TheiaHipError(-1, "track id out of range (reference: CHECK_NOTNULL aborts)")
+    local = -np.ones(r.NumTracks(), dtype=np.int64)
+    local[track_ids] = np.arange(len(track_ids))
+    keep = (local[r.obs_track] >= 0) & r.view_estimated[r.obs_view] & r.track_estimated[r.obs_track]
+    cov = r.obs_cov[keep]
+    si = None if (len(cov) == 0 or np.all(cov == 1.0)) else 1.0 / np.sqrt(cov)
+    pts = np.ascontiguousarray(r.points[track_ids])
+    flat = capi.FlatProblem(r.cam_ext.copy(), r.group_intrinsics.copy(), r.group_model, r.view_group, pts, r.obs_uv[keep],
+                            r.obs_view[keep], local[r.obs_track[keep]].astype(np.int32),
+                            point_const=(~r.track_estimated[track_ids]).astype(np.uint8), obs_sqrt_info=si)
+    summ = _ba.solve_tracks_batch(flat, options.to_c())
+    r.points[track_ids] = flat.points
+    _update_inverse_depth(r, track_ids.tolist())
+    return [BundleAdjustmentSummary(s) for s in summ]

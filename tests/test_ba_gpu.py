@@ -162,6 +162,26 @@ def test_mirror_partial_reconstruction_optimises_only_added_groups():
     assert np.array_equal(rec.group_intrinsics[:, 1:5], k0[:, 1:5])
 
 
+def test_mirror_independent_view_and_track_batches():
+    """BundleAdjustView / BundleAdjustTrack lists as one batch equal the one-at-a-time mirror calls."""
+    p = synth.synth_ba_v1(8, 150, seed=63)
+    opts = sfm.BundleAdjustmentOptions(); opts.max_num_iterations = 10
+    ra, rb = sfm.Reconstruction.from_flat(p), sfm.Reconstruction.from_flat(p)
+    sa = sfm.BundleAdjustViewsIndependently(ra, opts, [1, 4, 6])
+    for k, v in enumerate([1, 4, 6]):
+        s1 = sfm.BundleAdjustView(sfm.Reconstruction.from_flat(p), opts, v)
+        assert abs(sa[k].final_cost - s1.final_cost) <= 1e-8 * s1.final_cost and sa[k].final_cost < sa[k].initial_cost
+    assert np.array_equal(ra.cam_ext[[0, 2, 3, 5, 7]], rb.cam_ext[[0, 2, 3, 5, 7]]) and not np.array_equal(ra.cam_ext[1], rb.cam_ext[1])
+    tracks = [0, 3, 77, 149]
+    st = sfm.BundleAdjustTracksIndependently(rb, opts, tracks)
+    for k, t in enumerate(tracks):
+        rc = sfm.Reconstruction.from_flat(p)
+        s1 = sfm.BundleAdjustTrack(rc, opts, t)
+        assert abs(st[k].final_cost - s1.final_cost) <= 1e-8 * max(s1.final_cost, 1e-300)
+        assert np.abs(rb.points[t] - rc.points[t]).max() <= 1e-8
+    assert np.array_equal(rb.points[1], p.points[1]) and np.all(rb.inverse_depth[tracks] > 0)
+
+
 def test_edge_cases_empty_invalid_and_errors():
     o = ba.default_options()
     empty = capi.FlatProblem(np.zeros((0, 6)), np.zeros((1, 7)), [0], np.zeros(0, np.int32), np.zeros((0, 4)),
@@ -473,3 +493,27 @@ def test_views_batch_lo_options_and_masks():
     assert np.array_equal(cam_gpu[3], cams[3])                       # whole camera constant
     assert np.array_equal(cam_gpu[1][:3], cams[1][:3]) and not np.array_equal(cam_gpu[1][3:], cams[1][3:])
     assert cam_gpu[5][2] == cams[5][2]
+
+
+@pytest.mark.parametrize("manifold", [1, 0])
+def test_tracks_batch_matches_per_track_oracle(manifold):
+    """theia_hip_ba_tracks_batch = N x BundleAdjustTrack: each track follows the oracle's LM on the
+    problem "this point variable, everything else constant"."""
+    p = synth.synth_ba_v1(16, 120, seed=0x7AC5, mixed_models=True, sigma_pt=0.05)
+    o, oo = both_options(max_num_iterations=20, use_homogeneous_point_parametrization=manifold)
+    pg = p.copy()
+    pg.point_const = np.zeros(120, np.uint8); pg.point_const[5] = 1
+    summ = ba.solve_tracks_batch(pg, o)
+    assert np.array_equal(pg.points[5], p.points[5]) and summ[5].num_iterations == 0
+    for q in list(range(0, 120, 7)) + [119]:
+        if q == 5:
+            continue
+        sel = p.obs_pt == q
+        fp = capi.FlatProblem(p.cam_ext.copy(), p.intrinsics.copy(), p.group_model, p.cam_group, p.points[q:q + 1].copy(), p.obs_uv[sel],
+                              p.obs_cam[sel], np.zeros(sel.sum(), np.int32), cam_const=np.full(p.cam_ext.shape[0], 3, np.uint8))
+        so, _ = ol.solve(fp, oo)
+        s = summ[q]
+        assert s.success == so.success and s.num_iterations == so.num_iterations and s.num_successful_steps == so.num_successful_steps, q
+        assert abs(s.initial_cost - so.initial_cost) <= 1e-10 * so.initial_cost and abs(s.final_cost - so.final_cost) <= 1e-9 * so.final_cost
+        assert np.abs(pg.points[q] - fp.points[0]).max() <= 1e-9
+    assert np.mean([s.final_cost < s.initial_cost for s in summ if s.num_iterations]) > 0.9
