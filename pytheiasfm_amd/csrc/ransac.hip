@@ -194,6 +194,93 @@ __global__ __launch_bounds__(256) void k_score(int est, int nprob, int B, const 
   ninl[out] = cnt;
 }
 
+// ---- LMED (lmed.h:64-70, lmed_quality_measurement.h:58-130): cost = median of the squared residuals, inliers by the
+// 2.5 * 1.4826 * (1 + 5 / (n - m)) * sqrt(median) rule.  One workgroup per model: squared residuals in LDS, the order
+// statistics by an 8-bit radix select on the IEEE bit patterns (exact: the median is an element, or the mean of two).
+__device__ double lmed_select(const double* sq, int n, int k, int* hist, int* sel) {
+  unsigned long long prefix = 0ull, mask = 0ull;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const unsigned long long key = (unsigned long long)__double_as_longlong(sq[i]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int cum = 0, b = 0;
+      for (; b < 255; ++b) { if (cum + hist[b] > k) break; cum += hist[b]; }
+      sel[0] = b; sel[1] = k - cum;
+    }
+    __syncthreads();
+    prefix |= (unsigned long long)sel[0] << shift;
+    mask |= 255ull << shift;
+    k = sel[1];
+    __syncthreads();
+  }
+  return __longlong_as_double((long long)prefix);
+}
+
+// returns the median (cost); *ninl = inlier count; mask (optional, global) receives the inlier flags
+__device__ double lmed_block(int est, const double* m, const double* pd, int n, int ds, int min_samples, double* sq,
+                             int* hist, int* sel, int* ninl, uint8_t* mask) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { const double r = model_error(est, m, pd + (size_t)i * ds); sq[i] = r * r; }
+  __syncthreads();
+  double median = lmed_select(sq, n, n / 2, hist, sel);
+  if ((n % 2) != 0) median = 0.5 * (lmed_select(sq, n, n / 2 - 1, hist, sel) + median);
+  const double thr = 2.5 * 1.4826 * (1 + 5.0 / (double)((size_t)n - (size_t)min_samples)) * sqrt(median);
+  const double sqt = thr * thr;
+  if (threadIdx.x == 0) sel[2] = 0;
+  __syncthreads();
+  int cnt = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const bool in = sq[i] < sqt;
+    cnt += in ? 1 : 0;
+    if (mask) mask[i] = in ? 1 : 0;
+  }
+  atomicAdd(&sel[2], cnt);
+  __syncthreads();
+  *ninl = sel[2];
+  return median;
+}
+
+__global__ __launch_bounds__(256) void k_score_lmed(int est, int nprob, int B, const int64_t* __restrict__ offsets,
+                                                    const double* __restrict__ data, const double* __restrict__ models,
+                                                    const int* __restrict__ dense_count, const int* __restrict__ tags,
+                                                    double* __restrict__ cost, int* __restrict__ ninl) {
+  extern __shared__ __attribute__((aligned(16))) double sdata[];
+  __shared__ int hist[256], sel[4];
+  __shared__ double m[kStride];
+  const int p = blockIdx.y, slot = blockIdx.x;
+  if (slot >= dense_count[p]) return;
+  const int mm = max_models(est), ds = datum_size(est);
+  const int n = (int)(offsets[p + 1] - offsets[p]);
+  const size_t dense = (size_t)p * B * mm + slot;
+  if (threadIdx.x < kStride) m[threadIdx.x] = models[dense * (size_t)kStride + threadIdx.x];
+  __syncthreads();
+  int cnt;
+  const double med = lmed_block(est, m, data + (size_t)offsets[p] * ds, n, ds, sample_size(est), sdata, hist, sel, &cnt, nullptr);
+  if (threadIdx.x == 0) {
+    const size_t out = (size_t)p * B * mm + tags[dense];
+    cost[out] = med; ninl[out] = cnt;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_inlier_mask_lmed(int est, int nprob, const int64_t* __restrict__ offsets,
+                                                          const double* __restrict__ data, const double* __restrict__ best_models,
+                                                          uint8_t* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) double sdata[];
+  __shared__ int hist[256], sel[4];
+  __shared__ double m[kStride];
+  const int p = blockIdx.x;
+  const int ds = datum_size(est);
+  const int n = (int)(offsets[p + 1] - offsets[p]);
+  if (threadIdx.x < kStride) m[threadIdx.x] = best_models[(size_t)p * kStride + threadIdx.x];
+  __syncthreads();
+  int cnt;
+  lmed_block(est, m, data + (size_t)offsets[p] * ds, n, ds, sample_size(est), sdata, hist, sel, &cnt, mask + offsets[p]);
+}
+
 // final pass: refit the winning hypothesis (deterministic -> identical model)
 // and mark the inliers of every datum (sample_consensus_estimator.h:396-399).
 __global__ void k_refit(int est, int nprob, const int64_t* __restrict__ offsets, const double* __restrict__ data,
@@ -521,9 +608,9 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
                      "the relative-pose one (BundleAdjustTwoViewsAngular) is not yet");
   if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "ExhaustiveSampler makes a hard assumption that the number of samples needed is 2.");
-  if (P.ransac_type == THEIA_RANSAC_LMED)
-    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "LMED (median quality measurement) has no HIP kernel yet");
-  if (P.ransac_type != THEIA_RANSAC_RANSAC && P.ransac_type != THEIA_RANSAC_PROSAC)
+  const bool lmed = P.ransac_type == THEIA_RANSAC_LMED;
+  if (lmed && P.use_lo) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo together with LMED is not built");
+  if (P.ransac_type != THEIA_RANSAC_RANSAC && P.ransac_type != THEIA_RANSAC_PROSAC && !lmed)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown ransac_type");
   const int nprob = batch->num_problems;
   if (nprob < 0 || (nprob > 0 && (!batch->offsets || !batch->data))) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad batch");
@@ -573,6 +660,14 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   DBuf<uint8_t> d_mask;
   std::vector<int> h_samples, h_counts, h_ninl, h_active;
   std::vector<double> h_cost;
+  const size_t lmed_lds = (size_t)nmax * sizeof(double);
+  if (lmed) {
+    if (lmed_lds > 64 * 1024) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "LMED: more than 8192 data per problem (LDS-resident select)");
+    if (lmed_lds > 48 * 1024) {
+      HIP_TRYR(hipFuncSetAttribute((const void*)k_score_lmed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lmed_lds));
+      HIP_TRYR(hipFuncSetAttribute((const void*)k_inlier_mask_lmed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lmed_lds));
+    }
+  }
   const bool use_lds = (size_t)nmax * ds * sizeof(double) <= 96 * 1024;
   const size_t lds_bytes = use_lds ? (size_t)nmax * ds * sizeof(double) : 0;
   if (use_lds && lds_bytes > 48 * 1024) {
@@ -695,7 +790,10 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         dim3 grid((B + 63) / 64, cn);
         k_fit<<<grid, 64, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_models.p, d_counts.p, d_dense.p, d_tags.p);
       }
-      {
+      if (lmed) {
+        dim3 grid(B * kMaxModels, cn);
+        k_score_lmed<<<grid, 256, lmed_lds, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_models.p, d_dense.p, d_tags.p, d_cost.p, d_ninl.p);
+      } else {
         dim3 grid((B * kMaxModels + 255) / 256, cn);
         if (use_lds)
           k_score<true><<<grid, 256, lds_bytes, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_models.p, d_dense.p, d_tags.p, P.error_thresh, P.use_mle, d_cost.p, d_ninl.p);
@@ -792,7 +890,9 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     HIP_TRYR(hipMemcpyAsync(d_ev_slot.p, use_cur.data(), sizeof(int) * nprob, hipMemcpyHostToDevice, st));
     k_select_models<<<(nprob + 63) / 64, 64, 0, st>>>(nprob, d_ev_slot.p, d_cur_models.p, d_best_models.p);
   }
-  {
+  if (lmed) {
+    k_inlier_mask_lmed<<<nprob, 256, lmed_lds, st>>>(est, nprob, d_off.p, d_data.p, d_best_models.p, d_mask.p);
+  } else {
     dim3 grid((nmax + 255) / 256, nprob);
     k_inlier_mask<<<grid, 256, 0, st>>>(est, nprob, d_off.p, d_data.p, d_best_models.p, P.error_thresh, d_mask.p);
   }

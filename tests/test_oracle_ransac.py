@@ -403,3 +403,20 @@ def test_estimate_calibrated_absolute_pose_lo(pj):
     assert e1[1] <= e0[1] + 1e-2                   # never meaningfully worse than the minimal-sample pose
     Rm = r1["model"][0:9].reshape(3, 3)
     assert np.abs(Rm @ Rm.T - np.eye(3)).max() <= 1e-12
+
+
+def test_lmed_quality_measurement_rules():
+    """lmed_quality_measurement.h: even n -> upper middle element, odd n -> mean of the two around it; threshold rule."""
+    data, offsets, truth = synth.synth_ransac_v1(1, 301, "absolute", seed=12, inlier_lo=0.75, inlier_hi=0.75)
+    for n in (301, 300):
+        d = data[:n]
+        prm = ol.default_ransac_params((4 / 1000.0) ** 2, seed=9); prm.ransac_type = 2; prm.min_iterations = 150; prm.max_iterations = 150
+        r = ol.ransac_estimate(2, d, prm)
+        assert r["success"] and r["num_iterations"] == 150
+        m = r["model"]
+        res = np.array([ol.rlib().oracle_model_error(2, capi.ptr(m, C.c_double), capi.ptr(np.ascontiguousarray(d[i]), C.c_double)) for i in range(n)])
+        sq = np.sort(res * res)
+        med = sq[n // 2] if n % 2 == 0 else 0.5 * (sq[n // 2 - 1] + sq[n // 2])
+        thr = 2.5 * 1.4826 * (1 + 5.0 / (n - 3)) * np.sqrt(med)
+        assert np.array_equal(r["inlier_mask"].astype(bool), res * res < thr * thr)
+        assert r["inlier_mask"][truth["inlier"][0][:n]].mean() > 0.8

@@ -139,8 +139,11 @@ def test_mirror_api_and_error_conventions():
         ransac.EstimateRelativePose(bad, ransac.RansacType.RANSAC, data)
     with pytest.raises(capi.TheiaHipError):
         ransac.EstimateRelativePose(p, ransac.RansacType.EXHAUSTIVE, data)   # reference CHECK: sample size must be 2
+    ok, pl, sl = ransac.EstimateRelativePose(p, ransac.RansacType.LMED, data)     # LMED ignores error_thresh for the inliers
+    assert ok and len(sl.inliers) > 50
+    plo = ransac.RansacParameters(); plo.error_thresh = THR[0]; plo.use_lo = True
     with pytest.raises(capi.TheiaHipError):
-        ransac.EstimateRelativePose(p, ransac.RansacType.LMED, data)
+        ransac.EstimateRelativePose(plo, ransac.RansacType.RANSAC, data)             # relative-pose RefineModel: not built
     with pytest.raises(capi.TheiaHipError):
         ransac.EstimateCalibratedAbsolutePose(p, ransac.RansacType.RANSAC, ransac.PnPType.DLS, da)
     with pytest.raises(capi.TheiaHipError):
@@ -173,6 +176,24 @@ def test_lo_ransac_absolute_pose_follows_oracle():
     assert np.median(err_lo) <= np.median(err_plain) + 1e-3
     print("LO iterations per problem:", res["num_lo_iterations"])
     assert res["num_lo_iterations"].sum() > 10      # some in-loop refinements succeeded, not only the final one
+
+
+@pytest.mark.parametrize("est,kind,n", [(0, "relative", 400), (2, "absolute", 301), (1, "relative", 64)])
+def test_lmed_inlier_sets_bit_identical_to_oracle(est, kind, n):
+    """RansacType::LMED (lmed.h:64-70): median-of-squared-residuals cost by an exact radix select, the
+    reference's even / odd median rule, inliers from the 2.5 * 1.4826 * (1 + 5/(n-m)) * sqrt(median) threshold."""
+    data, offsets, truth = synth.synth_ransac_v1(8, n, kind, seed=0x5AC50900 + est, inlier_lo=0.6, inlier_hi=0.9)
+    p = ransac.RansacParameters(); p.error_thresh = THR[est]; p.seed = 71; p.ransac_type = ransac.RansacType.LMED
+    p.min_iterations = 100; p.max_iterations = 300
+    res = ransac.estimate_batch(est, data, offsets, p)
+    for i in range(8):
+        pc = p.to_c(); pc.seed = 71 + i
+        o = ol.ransac_estimate(est, data[offsets[i]:offsets[i + 1]], pc)
+        sl = slice(offsets[i], offsets[i + 1])
+        assert o["num_iterations"] == res["num_iterations"][i] and o["num_inliers"] == res["num_inliers"][i]
+        assert np.array_equal(o["inlier_mask"], res["inlier_mask"][sl])
+        assert np.array_equal(o["model"][: MLEN[est]], res["models"][i][: MLEN[est]], equal_nan=True)
+        assert res["inlier_mask"][sl][truth["inlier"][i]].mean() > 0.6
 
 
 def test_c5_slice_properties():
