@@ -76,9 +76,9 @@ def algorithmic_bytes_linearize(p):
 
 def pmc_traffic_bytes(world):
     """HBM-side bytes per launch of the roofline kernel group, from the committed
-    rocprofv3 PMC passes of this same command (profiles/r1s_pmc_*.csv; FETCH_SIZE
+    rocprofv3 PMC passes of this same command (profiles/r1t_pmc_*.csv; FETCH_SIZE
     and WRITE_SIZE collected in separate passes, KB; the 16-B/lane record gathers
-    of k_schur_* doubled per the gfx950 FETCH_SIZE note of MI355X_MICROARCH.md).
+    of k_schur doubled per the gfx950 FETCH_SIZE note of MI355X_MICROARCH.md).
     None when the files are absent or the run is not the profiled N=1 workload."""
     if world != 1:
         return None
@@ -87,12 +87,12 @@ def pmc_traffic_bytes(world):
     try:
         kb = {}
         for tag in ("fetch_size", "write_size"):
-            with open(os.path.join(base, "r1s_pmc_%s.csv" % tag)) as f:
+            with open(os.path.join(base, "r1t_pmc_%s.csv" % tag)) as f:
                 for row in csv.reader(f):
                     if row and row[0] != "kernel":
                         kb[(tag, row[0])] = float(row[2])
-        fetch = 2.0 * (kb[("fetch_size", "k_schur_blocks<3>")] + kb[("fetch_size", "k_schur_diag<3>")]) + kb[("fetch_size", "k_lin_obs<3>")]
-        write = sum(kb[("write_size", k)] for k in ("k_lin_obs<3>", "k_schur_blocks<3>", "k_schur_diag<3>"))
+        fetch = 2.0 * kb[("fetch_size", "k_schur<3>")] + kb[("fetch_size", "k_lin_obs<3>")]
+        write = sum(kb[("write_size", k)] for k in ("k_lin_obs<3>", "k_schur<3>"))
         return int(1024 * (fetch + write))
     except (OSError, KeyError, ValueError):
         return None
@@ -205,7 +205,7 @@ def main():
                                    + ("" if world == 1 else f", tracks sharded over {world} ranks, RCCL all-reduce of the reduced camera system"),
                        "views": VIEWS, "tracks": TRACKS_PER_GPU * world, "observations": nobs_total,
                        "baseline_config": "BASELINE.json configs[1]" if world == 1 else "configs[1] x N tracks (weak)"},
-            "roofline": {"kernel": "linearize + Schur assembly launch group (k_lin_obs + k_schur_diag + k_schur_blocks)",
+            "roofline": {"kernel": "linearize + Schur assembly launch group (k_lin_obs + k_schur)",
                          "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(world),
