@@ -834,6 +834,324 @@ __global__ __launch_bounds__(kBlock) void k_schur(DevProblem P, double* __restri
   else schur_diag_item<PD>(P, b - P.n_blk_items, part, S, rhs, colsq, gc);
 }
 
+// ------------------------------------- gather-based Schur assembly with intrinsics (A10)
+// The camera-side block of an observation is 16 wide: [intrinsics of its group (10) | extrinsics (6)].
+// Per-observation record (INTR):
+//   {W (6xPD) | T (6xPD) | F (2x6) | r (2) | T g (6) | WI (10xPD) | TI (10xPD) | Fk (2x10) | TI g (10)}
+// with WI = Fk^T E, TI = WI V^-1.  Records are stored (group, camera)-major, so a camera's and a
+// group's records are contiguous.  One workgroup per item; item = {type, row0, col0, beg, end, flags}:
+//   pair items walk a list of (slot a, slot b) of a common track and accumulate  - TA_a WB_b^T :
+//     CC  6x6   T_a  W_b^T   -> S[cam_a , cam_b ]      GG0/GG1  5x10  TI_a[rows] WI_b^T -> S[grp_a, grp_b]
+//     CG  6x10  T_a  WI_b^T  -> S[cam_a , grp_b ]
+//   diagonal items stream a contiguous slot range (per-observation terms):
+//     CD   camera block, rhs, g, column norms (as without intrinsics)
+//     CGD  F^T Fk - T WI^T            -> S[cam, grp of cam]
+//     GD0/GD1  Fk^T Fk - TI WI^T (rows)-> S[grp, grp]   GV  Fk^T r - TI g | Fk^T r | column norms
+// Reduced index: intrinsics slots first (10 per variable group), cameras at ni + 6 rc.
+enum { IT_CC = 0, IT_CG = 1, IT_GG0 = 2, IT_GG1 = 3, IT_CD = 4, IT_CGD = 5, IT_GD0 = 6, IT_GD1 = 7, IT_GV = 8 };
+enum { ITF_ATOMIC = 1, ITF_LOWER = 2 };
+
+template <int PD> constexpr int rec_stride_intr() { return 32 * PD + 50; }
+template <int PD> struct RecI {   // offsets in double2 units
+  static constexpr int W = 0, T = 3 * PD, F = 6 * PD, R = 6 * PD + 6, TG = 6 * PD + 7, WI = 6 * PD + 10,
+                       TI = 11 * PD + 10, FK = 16 * PD + 10, TIG = 16 * PD + 20;
+};
+
+template <int PD, int K>
+THIP_DEV void load_reci(const double* __restrict__ rec, int slot, int off2, double (&w)[K]) {
+  const double2* R = reinterpret_cast<const double2*>(rec + (size_t)slot * rec_stride_intr<PD>()) + off2;
+#pragma unroll
+  for (int k = 0; k < K / 2; ++k) { const double2 t = R[k]; w[2 * k] = t.x; w[2 * k + 1] = t.y; }
+}
+
+// reduce NACC per-thread accumulators over the workgroup and write element e -> dst(e)
+template <int NACC, typename FDST>
+THIP_DEV void finish_item(double (&acc)[NACC], double (*part)[64], bool atomic, double sign, FDST dst_of) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int lo = 0, cnt = NACC;
+  const double tot = wave_reduce_scatter<NACC, 32>(acc, lane, lo, cnt);
+  if (cnt > 0) part[wv][lo] = tot;
+  __syncthreads();
+  if (tid >= NACC) return;
+  const double v = sign * ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+  double* dst = dst_of(tid);
+  if (!dst) return;
+  if (atomic) atomic_add(dst, v); else *dst = v;
+}
+
+// pair item: acc[RA x RB] += TA_a[ra0 + i][:] . WB_b[j][:]
+template <int PD, int RA, int RB>
+THIP_DEV void pair_item(const DevProblem& P, const int* it, int offA2, int offB2, double (*part)[64], double* __restrict__ S) {
+  const int row0 = it[1], col0 = it[2], beg = it[3], end = it[4], flags = it[5];
+  double acc[RA * RB];
+#pragma unroll
+  for (int k = 0; k < RA * RB; ++k) acc[k] = 0.0;
+  for (int q = beg + threadIdx.x; q < end; q += kBlock) {
+    const int2 ab = P.blk_pairs[q];
+    double TA[RA * PD], WB[RB * PD];
+    load_reci<PD>(P.rec, ab.x, offA2, TA);
+    load_reci<PD>(P.rec, ab.y, offB2, WB);
+#pragma unroll
+    for (int a = 0; a < RA; ++a)
+#pragma unroll
+      for (int b = 0; b < RB; ++b) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < PD; ++k) s += TA[a * PD + k] * WB[b * PD + k];
+        acc[a * RB + b] += s;
+      }
+  }
+  const int n = P.n;
+  const bool lower = (flags & ITF_LOWER) != 0;
+  finish_item<RA * RB>(acc, part, (flags & ITF_ATOMIC) != 0, -1.0, [&](int e) -> double* {
+    const int a = e / RB, b = e % RB;
+    if (lower && col0 + b > row0 + a) return nullptr;
+    return S + (size_t)(row0 + a) * n + col0 + b;
+  });
+}
+
+// the same pass with the intrinsics part of the camera-side block (INTR records, see k_schur_intr)
+template <int PD>
+__global__ __launch_bounds__(kBlock) void k_lin_obs_intr(DevProblem P, const double* __restrict__ cam,
+                                                    const double* __restrict__ pts, const double* __restrict__ radius_p,
+                                                    double* __restrict__ Vinv, double* __restrict__ gp,
+                                                    double* __restrict__ tile_part) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  constexpr int NW = 6 * PD;
+  constexpr int RS = rec_stride_intr<PD>();
+  const double radius = *radius_p;   // device-resident: the LM step control runs on the GPU
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const bool tile_ok = tile < P.ntiles;
+  const int cnt = tile_ok ? P.tile_count[tile] : 0;
+  const int start = tile_ok ? P.tile_start[tile] : 0;
+  LaneLin<PD, true> L;
+  lane_linearize<PD, true, true>(P, cam, pts, start + lane, lane < cnt, lane, L);
+  const int slot = (lane < cnt) ? P.rec_slot[start + lane] : -1;
+  const Segment sg = lane_segment(L.p, lane);
+  double in[NT + PD], tot[NT + PD];
+#pragma unroll
+  for (int a = 0; a < PD; ++a) {
+#pragma unroll
+    for (int b = 0; b <= a; ++b) in[lidx(a, b)] = L.Jt[a] * L.Jt[b] + L.Jt[PD + a] * L.Jt[PD + b];
+    in[NT + a] = L.Jt[a] * L.r[0] + L.Jt[PD + a] * L.r[1];
+  }
+  segment_allsum<NT + PD>(sg, in, tot);
+  // every lane of the track inverts the same V (lock-step anyway), no broadcast needed
+  double V[NT], Vi[NT], g[PD];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) V[k] = tot[k];
+#pragma unroll
+  for (int a = 0; a < PD; ++a) { g[a] = tot[NT + a]; V[lidx(a, a)] += fmin(fmax(V[lidx(a, a)], 1e-6), 1e32) / radius; }
+  bool pd_ok = true;
+  if (L.active && !L.pconst) pd_ok = invert_spd<PD>(V, Vi);
+  if (!L.active || L.pconst || !pd_ok) {
+#pragma unroll
+    for (int k = 0; k < NT; ++k) Vi[k] = 0.0;
+  }
+  double gmax = 0.0;
+  if (L.active && sg.head && !L.pconst) {
+#pragma unroll
+    for (int k = 0; k < NT; ++k) Vinv[(size_t)NT * L.p + k] = Vi[k];
+#pragma unroll
+    for (int a = 0; a < PD; ++a) {
+      gp[(size_t)PD * L.p + a] = g[a];
+      gmax = fmax(gmax, fabs(g[a] / P.scale_p[(size_t)PD * L.p + a]));
+    }
+  }
+  if (slot >= 0) {
+    double2* R = reinterpret_cast<double2*>(P.rec + (size_t)slot * RS);
+    double w[NW], t[NW], tg[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < PD; ++b) w[a * PD + b] = L.Jc[a] * L.Jt[b] + L.Jc[6 + a] * L.Jt[PD + b];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int b = 0; b < PD; ++b) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < PD; ++k) s += w[a * PD + k] * sym_get<PD>(Vi, k, b);
+        t[a * PD + b] = s;
+      }
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < PD; ++k) s += t[a * PD + k] * g[k];
+      tg[a] = s;
+    }
+    using O = RecI<PD>;
+#pragma unroll
+    for (int k = 0; k < NW / 2; ++k) R[O::W + k] = make_double2(w[2 * k], w[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < NW / 2; ++k) R[O::T + k] = make_double2(t[2 * k], t[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) R[O::F + k] = make_double2(L.Jc[2 * k], L.Jc[2 * k + 1]);
+    R[O::R] = make_double2(L.r[0], L.r[1]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) R[O::TG + k] = make_double2(tg[2 * k], tg[2 * k + 1]);
+    // intrinsics part: WI = Fk^T E, TI = WI V^-1, TI g
+    double wi[10 * PD], ti[10 * PD], tig[10];
+#pragma unroll
+    for (int a = 0; a < 10; ++a) {
+#pragma unroll
+      for (int b = 0; b < PD; ++b) wi[a * PD + b] = L.Jk[a] * L.Jt[b] + L.Jk[10 + a] * L.Jt[PD + b];
+    }
+#pragma unroll
+    for (int a = 0; a < 10; ++a) {
+#pragma unroll
+      for (int b = 0; b < PD; ++b) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < PD; ++k) s2 += wi[a * PD + k] * sym_get<PD>(Vi, k, b);
+        ti[a * PD + b] = s2;
+      }
+      double s3 = 0.0;
+#pragma unroll
+      for (int k = 0; k < PD; ++k) s3 += ti[a * PD + k] * g[k];
+      tig[a] = s3;
+    }
+#pragma unroll
+    for (int k = 0; k < 5 * PD; ++k) R[O::WI + k] = make_double2(wi[2 * k], wi[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 5 * PD; ++k) R[O::TI + k] = make_double2(ti[2 * k], ti[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) R[O::FK + k] = make_double2(L.Jk[2 * k], L.Jk[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) R[O::TIG + k] = make_double2(tig[2 * k], tig[2 * k + 1]);
+  }
+  const double cost = wave_sum(L.cost);
+  gmax = wave_max(gmax);
+  const double inval = wave_sum((L.active && !L.valid) ? 1.0 : 0.0);
+  const double npd = wave_sum((L.active && !pd_ok && sg.head) ? 1.0 : 0.0);
+  if (lane == 0 && tile_ok) {
+    tile_part[4 * (size_t)tile + 0] = cost;
+    tile_part[4 * (size_t)tile + 1] = gmax;
+    tile_part[4 * (size_t)tile + 2] = inval;
+    tile_part[4 * (size_t)tile + 3] = npd;
+  }
+}
+
+
+// rows [ra0, ra0 + RA) of the group block  Fk^T Fk - TI WI^T  (row0 = first reduced index of the group)
+template <int PD, int RA, int ra0>
+THIP_DEV void gdiag_item(const DevProblem& P, int row0, int beg, int end, bool atomic, double (*part)[64],
+                         double* __restrict__ S) {
+  using O = RecI<PD>;
+  double acc[RA * 10];
+#pragma unroll
+  for (int k = 0; k < RA * 10; ++k) acc[k] = 0.0;
+  for (int q = beg + threadIdx.x; q < end; q += kBlock) {
+    double TI[RA * PD], WI[10 * PD], Jk[20];
+    load_reci<PD>(P.rec, q, O::TI + (ra0 * PD) / 2, TI); load_reci<PD>(P.rec, q, O::WI, WI); load_reci<PD>(P.rec, q, O::FK, Jk);
+#pragma unroll
+    for (int a = 0; a < RA; ++a)
+#pragma unroll
+      for (int b = 0; b < 10; ++b) {
+        double s = Jk[ra0 + a] * Jk[b] + Jk[10 + ra0 + a] * Jk[10 + b];
+#pragma unroll
+        for (int k = 0; k < PD; ++k) s -= TI[a * PD + k] * WI[b * PD + k];
+        acc[a * 10 + b] += s;
+      }
+  }
+  const int n = P.n;
+  finish_item<RA * 10>(acc, part, atomic, 1.0, [&](int e) -> double* {
+    const int a = ra0 + e / 10, b = e % 10;
+    if (b > a) return nullptr;
+    return S + (size_t)(row0 + a) * n + row0 + b;
+  });
+}
+
+template <int PD>
+__global__ __launch_bounds__(kBlock) void k_schur_intr(DevProblem P, double* __restrict__ S, double* __restrict__ rhs,
+                                                       double* __restrict__ colsq, double* __restrict__ gc) {
+  __shared__ double part[kWavesPerBlock][64];
+  using O = RecI<PD>;
+  const int* it = P.blk_items + 6 * blockIdx.x;
+  const int type = it[0], row0 = it[1], col0 = it[2], beg = it[3], end = it[4], flags = it[5];
+  const bool atomic = (flags & ITF_ATOMIC) != 0;
+  const int n = P.n;
+  if (type == IT_CC) { pair_item<PD, 6, 6>(P, it, O::T, O::W, part, S); return; }
+  if (type == IT_CG) { pair_item<PD, 6, 10>(P, it, O::T, O::WI, part, S); return; }
+  // the 10 intrinsics rows are split 4 + 6 (register budget; 4 * PD doubles keep the 16-B alignment)
+  if (type == IT_GG0) { pair_item<PD, 4, 10>(P, it, O::TI, O::WI, part, S); return; }
+  if (type == IT_GG1) { pair_item<PD, 6, 10>(P, it, O::TI + 2 * PD, O::WI, part, S); return; }
+  if (type == IT_CD) {
+    double acc[39];
+#pragma unroll
+    for (int k = 0; k < 39; ++k) acc[k] = 0.0;
+    for (int q = beg + threadIdx.x; q < end; q += kBlock) {
+      double W[6 * PD], T[6 * PD], Jc[12], rt[8];
+      load_reci<PD>(P.rec, q, O::W, W); load_reci<PD>(P.rec, q, O::T, T);
+      load_reci<PD>(P.rec, q, O::F, Jc); load_reci<PD>(P.rec, q, O::R, rt);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+          double s = Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
+#pragma unroll
+          for (int k = 0; k < PD; ++k) s -= T[a * PD + k] * W[b * PD + k];
+          acc[lidx(a, b)] += s;
+        }
+        const double jr = Jc[a] * rt[0] + Jc[6 + a] * rt[1];
+        acc[21 + a] += jr - rt[2 + a];
+        acc[27 + a] += jr;
+        acc[33 + a] += Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a];
+      }
+    }
+    finish_item<39>(acc, part, atomic, 1.0, [&](int e) -> double* {
+      if (e < 21) {
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= e) ++a;
+        return S + (size_t)(row0 + a) * n + row0 + (e - a * (a + 1) / 2);
+      }
+      return (e < 27 ? rhs : (e < 33 ? gc : colsq)) + row0 + (e - 21) % 6;
+    });
+    return;
+  }
+  if (type == IT_CGD) {
+    double acc[60];
+#pragma unroll
+    for (int k = 0; k < 60; ++k) acc[k] = 0.0;
+    for (int q = beg + threadIdx.x; q < end; q += kBlock) {
+      double T[6 * PD], WI[10 * PD], Jc[12], Jk[20];
+      load_reci<PD>(P.rec, q, O::T, T); load_reci<PD>(P.rec, q, O::WI, WI);
+      load_reci<PD>(P.rec, q, O::F, Jc); load_reci<PD>(P.rec, q, O::FK, Jk);
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 10; ++b) {
+          double s = Jc[a] * Jk[b] + Jc[6 + a] * Jk[10 + b];
+#pragma unroll
+          for (int k = 0; k < PD; ++k) s -= T[a * PD + k] * WI[b * PD + k];
+          acc[a * 10 + b] += s;
+        }
+    }
+    finish_item<60>(acc, part, atomic, 1.0, [&](int e) -> double* { return S + (size_t)(row0 + e / 10) * n + col0 + e % 10; });
+    return;
+  }
+  if (type == IT_GD0) { gdiag_item<PD, 4, 0>(P, row0, beg, end, atomic, part, S); return; }
+  if (type == IT_GD1) { gdiag_item<PD, 6, 4>(P, row0, beg, end, atomic, part, S); return; }
+  if (type == IT_GV) {
+    double acc[30];
+#pragma unroll
+    for (int k = 0; k < 30; ++k) acc[k] = 0.0;
+    for (int q = beg + threadIdx.x; q < end; q += kBlock) {
+      double Jk[20], rt[2], tig[10];
+      load_reci<PD>(P.rec, q, O::FK, Jk); load_reci<PD>(P.rec, q, O::R, rt); load_reci<PD>(P.rec, q, O::TIG, tig);
+#pragma unroll
+      for (int a = 0; a < 10; ++a) {
+        const double jr = Jk[a] * rt[0] + Jk[10 + a] * rt[1];
+        acc[a] += jr - tig[a];
+        acc[10 + a] += jr;
+        acc[20 + a] += Jk[a] * Jk[a] + Jk[10 + a] * Jk[10 + a];
+      }
+    }
+    finish_item<30>(acc, part, atomic, 1.0, [&](int e) -> double* { return (e < 10 ? rhs : (e < 20 ? gc : colsq)) + row0 + e % 10; });
+    return;
+  }
+}
+
 // Deterministic reduction of per-tile partials into the scalar block.
 // field f of tile t at tile_part[t*nfields + f]; result -> scal[field_to_scal[f]]
 // (sum, or max if field_is_max[f]).
@@ -1342,6 +1660,16 @@ void launch_make_scale(int count, const double* colsq, double* scale, hipStream_
 void launch_linearize(const DevProblem& P, const double* cam, const double* pts, const double* radius,
                       const ReduceBuf& rb, double* Vinv, double* gp, double* tile_part, hipStream_t st) {
   if (P.ntiles == 0) return;
+  if (P.rec && P.ni > 0) {   // intrinsics optimised: 16-wide camera-side blocks on the gather lists
+    const int g = tile_blocks(P.ntiles);
+    if (P.pd == 3) k_lin_obs_intr<3><<<g, kBlock, 0, st>>>(P, cam, pts, radius, Vinv, gp, tile_part);
+    else k_lin_obs_intr<4><<<g, kBlock, 0, st>>>(P, cam, pts, radius, Vinv, gp, tile_part);
+    if (P.n_blk_items) {
+      if (P.pd == 3) k_schur_intr<3><<<P.n_blk_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc);
+      else k_schur_intr<4><<<P.n_blk_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc);
+    }
+    return;
+  }
   if (P.rec && P.ni == 0) {
     const int g = tile_blocks(P.ntiles);
     if (P.pd == 3) k_lin_obs<3><<<g, kBlock, 0, st>>>(P, cam, pts, radius, Vinv, gp, tile_part);

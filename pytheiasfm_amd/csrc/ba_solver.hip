@@ -808,6 +808,103 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     UP(diag_items, ditems); UP(cam_obs, cam_obs); UP(blk_items, bitems); UP(blk_pairs, pairs);
     AL(rec, (size_t)std::max(1, dbeg[h->ncv]) * (12 * h->pd + 20));
   }
+  if (h->ni > 0 && h->ntiles_main > 0 && !h->long_ntracks && !getenv("THEIA_HIP_LINEARIZE_ATOMIC")) {
+    // Gather lists with intrinsics (k_lin_obs_intr / k_schur_intr): records for every observation whose camera OR
+    // intrinsics group is variable, stored (group, camera)-major; item = {type, row0, col0, beg, end, flags}.
+    enum { IT_CC = 0, IT_CG = 1, IT_GG0 = 2, IT_GG1 = 3, IT_CD = 4, IT_CGD = 5, IT_GD0 = 6, IT_GD1 = 7, IT_GV = 8 };
+    const int64_t nm = h->nobs_main;
+    constexpr int kChunk = 2048;
+    std::vector<int> red(nm), grd(nm);
+    for (int64_t s = 0; s < nm; ++s) { red[s] = h->cam_red[ocam[s]]; grd[s] = h->grp_red[p->cam_group[ocam[s]]]; }
+    // slots: sort the observations that need a record by (group, camera)
+    std::vector<int> order;
+    for (int64_t s = 0; s < nm; ++s) if (red[s] >= 0 || grd[s] >= 0) order.push_back((int)s);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+      if (grd[x] != grd[y]) return grd[x] < grd[y];
+      return red[x] < red[y];
+    });
+    std::vector<int> slot(nm, -1);
+    for (size_t k = 0; k < order.size(); ++k) slot[order[k]] = (int)k;
+    std::vector<int> items;
+    auto push_item = [&](int type, int row0, int col0, int64_t beg, int64_t end, int flags) {
+      const int nchunk = (int)((end - beg + kChunk - 1) / kChunk);
+      for (int k = 0; k < nchunk; ++k) {
+        items.push_back(type); items.push_back(row0); items.push_back(col0);
+        items.push_back((int)(beg + (int64_t)k * kChunk)); items.push_back((int)std::min<int64_t>(end, beg + (int64_t)(k + 1) * kChunk));
+        items.push_back(flags | (nchunk > 1 ? 1 : 0));
+      }
+    };
+    // ---- pair lists: entries (key, a, b) sorted by key; one item (or two halves) per key
+    struct PairE { uint64_t key; int a, b; };
+    std::vector<PairE> cc, cg, gg;
+    for (int64_t s0 = 0; s0 < nm;) {
+      int64_t s1 = s0 + 1;
+      while (s1 < nm && opt[s1] == opt[s0]) ++s1;
+      if (!h->pt_const[opt[s0]])
+        for (int64_t a = s0; a < s1; ++a)
+          for (int64_t b = s0; b < s1; ++b) {
+            if (a == b) continue;
+            if (red[a] >= 0 && red[b] >= 0 && red[a] >= red[b]) cc.push_back({((uint64_t)red[a] << 32) | (uint32_t)red[b], (int)a, (int)b});
+            if (red[a] >= 0 && grd[b] >= 0) cg.push_back({((uint64_t)red[a] << 32) | (uint32_t)grd[b], (int)a, (int)b});
+            if (grd[a] >= 0 && grd[b] >= 0 && grd[a] >= grd[b]) gg.push_back({((uint64_t)grd[a] << 32) | (uint32_t)grd[b], (int)a, (int)b});
+          }
+      s0 = s1;
+    }
+    std::vector<int2> pairs;
+    auto emit_pairs = [&](std::vector<PairE>& v, auto&& per_key) {
+      std::sort(v.begin(), v.end(), [](const PairE& x, const PairE& y) {
+        if (x.key != y.key) return x.key < y.key;
+        return x.a != y.a ? x.a < y.a : x.b < y.b;
+      });
+      for (size_t q = 0; q < v.size();) {
+        size_t e = q + 1;
+        while (e < v.size() && v[e].key == v[q].key) ++e;
+        const int64_t beg = (int64_t)pairs.size();
+        for (size_t k = q; k < e; ++k) pairs.push_back(make_int2(slot[v[k].a], slot[v[k].b]));
+        per_key((int)(v[q].key >> 32), (int)(v[q].key & 0xffffffffu), beg, (int64_t)pairs.size());
+        q = e;
+      }
+    };
+    // cameras seen twice by a track give (c, c) lists: the camera block is then fed by two kinds of items
+    std::vector<char> self(h->ncv, 0);
+    for (const PairE& e : cc) if ((e.key >> 32) == (e.key & 0xffffffffu)) self[e.key >> 32] = 1;
+    emit_pairs(cc, [&](int ra, int rb, int64_t beg, int64_t end) {
+      push_item(IT_CC, h->ni + 6 * ra, h->ni + 6 * rb, beg, end, ra == rb ? 3 : 0);
+    });
+    emit_pairs(cg, [&](int ra, int gb, int64_t beg, int64_t end) { push_item(IT_CG, h->ni + 6 * ra, 10 * gb, beg, end, 1); });
+    emit_pairs(gg, [&](int ga, int gb, int64_t beg, int64_t end) {
+      push_item(IT_GG0, 10 * ga, 10 * gb, beg, end, 1 | (ga == gb ? 2 : 0));
+      push_item(IT_GG1, 10 * ga + 4, 10 * gb, beg, end, 1 | (ga == gb ? 2 : 0));
+    });
+    // (the CG / GG targets also receive the per-observation diagonal items below: always atomic)
+    if (pairs.size() > (size_t)std::numeric_limits<int>::max() - 64)
+      return set_error(THEIA_HIP_ERR_UNSUPPORTED, "too many observation pairs for 32-bit pair lists");
+    // ---- per-observation (diagonal) items over contiguous slot ranges
+    for (size_t q = 0; q < order.size();) {   // per camera (inside its group)
+      size_t e = q + 1;
+      while (e < order.size() && red[order[e]] == red[order[q]] && grd[order[e]] == grd[order[q]]) ++e;
+      const int rc = red[order[q]], gr = grd[order[q]];
+      if (rc >= 0) {
+        push_item(IT_CD, h->ni + 6 * rc, h->ni + 6 * rc, (int64_t)q, (int64_t)e, self[rc] ? 1 : 0);
+        if (gr >= 0) push_item(IT_CGD, h->ni + 6 * rc, 10 * gr, (int64_t)q, (int64_t)e, 1);
+      }
+      q = e;
+    }
+    for (size_t q = 0; q < order.size();) {   // per group
+      size_t e = q + 1;
+      while (e < order.size() && grd[order[e]] == grd[order[q]]) ++e;
+      const int gr = grd[order[q]];
+      if (gr >= 0) {
+        push_item(IT_GD0, 10 * gr, 10 * gr, (int64_t)q, (int64_t)e, 1);
+        push_item(IT_GD1, 10 * gr, 10 * gr, (int64_t)q, (int64_t)e, 1);
+        push_item(IT_GV, 10 * gr, 10 * gr, (int64_t)q, (int64_t)e, 0);
+      }
+      q = e;
+    }
+    h->n_diag_items = 0; h->n_blk_items = (int)items.size() / 6;
+    UP(cam_obs, slot); UP(blk_items, items); UP(blk_pairs, pairs);
+    AL(rec, (size_t)std::max<size_t>(1, order.size()) * (32 * h->pd + 50));
+  }
 #undef UP
 #undef AL
   fill_devproblem(h);
