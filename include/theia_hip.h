@@ -246,6 +246,16 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* summary);
 int theia_hip_ba_download(theia_ba_handle h, theia_ba_problem* problem);
 int theia_hip_ba_destroy(theia_ba_handle h);
 
+/* Covariance blocks at the handle's current state for the two block-diagonal problems behind the
+ * *WithCov entry points (bundle_adjustment.cc:288-386,420-499; GetCovarianceFor{Track,Tracks,View,Views},
+ * bundle_adjuster.cc:660-773 = ceres::Covariance (J'J)^-1 in tangent space, loss applied):
+ *   point_cov[num_points][d][d], d = 3 (homogeneous manifold) or 4: needs every camera constant;
+ *   cam_cov[num_cameras][6][6]: needs every point constant and no partially constant camera.
+ * Either pointer may be NULL.  Entries of constant / unobserved blocks are zero.  NOT yet multiplied
+ * by the empirical variance factor 2 * final_cost / redundancy (the caller's bookkeeping). */
+int theia_hip_ba_covariance(theia_ba_handle h, double* point_cov, double* cam_cov);
+
+
 /* Introspection used by parity tests (device results copied to host):
  *  - per-observation residual r[2] and Jacobian blocks J_cam[2][6],
  *    J_pt[2][pt_dof] (tangent space, loss-corrected, NOT Jacobi-scaled) of

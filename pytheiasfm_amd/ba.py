@@ -65,6 +65,16 @@ class BaHandle:
         capi.check(capi.lib().theia_hip_ba_download(self._h, C.byref(st)))
         return p
 
+    def covariance(self, points=False, cameras=False):
+        """theia_hip_ba_covariance at the current state: (point_cov [np][d][d] or None, cam_cov [nc][6][6] or None)."""
+        L = capi.lib()
+        L.theia_hip_ba_covariance.argtypes = [C.c_void_p, capi.c_double_p, capi.c_double_p]
+        pc = np.zeros((self.problem.points.shape[0], self.pd, self.pd)) if points else None
+        cc = np.zeros((self.problem.cam_ext.shape[0], 6, 6)) if cameras else None
+        capi.check(L.theia_hip_ba_covariance(self._h, capi.ptr(pc, C.c_double) if points else None,
+                                             capi.ptr(cc, C.c_double) if cameras else None))
+        return pc, cc
+
     def evaluate(self):
         n = self.problem.obs_uv.shape[0]
         cost = C.c_double(0)

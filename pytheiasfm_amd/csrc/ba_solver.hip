@@ -1216,6 +1216,85 @@ int theia_hip_ba_evaluate_ex(theia_ba_handle h, double* cost, double* residuals,
   return 0;
 }
 
+// Covariance blocks of the two block-diagonal cases the reference exposes (GetCovarianceFor{Track,Tracks,View,Views},
+// bundle_adjuster.cc:660-773, behind the *WithCov entry points bundle_adjustment.cc:288-386,420-499): tracks against
+// constant cameras (3x3 / 4x4 in the point's tangent space) and views against constant tracks (6x6).  In both the
+// normal matrix J'J is block diagonal, so ceres::Covariance's (J'J)^-1 is the inverse of each block.  J is the
+// loss-corrected, unscaled Jacobian at the current state (Covariance::Options::apply_loss_function = true).
+int theia_hip_ba_covariance(theia_ba_handle h, double* point_cov, double* cam_cov) {
+  if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
+  if (!point_cov && !cam_cov) return 0;
+  if (h->ni) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "covariance with optimised intrinsics is not built");
+  bool any_var_point = false;
+  for (int q = 0; q < h->np; ++q) any_var_point |= !h->pt_const[q];
+  if (point_cov && h->ncv > 0)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "point covariances need all cameras constant (the BundleAdjustTrack(s) problem)");
+  if (cam_cov && any_var_point)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "camera covariances need all points constant (the BundleAdjustView(s) problem)");
+  if (cam_cov)
+    for (int c = 0; c < h->nc; ++c)
+      if (h->cam_red[c] >= 0 && h->cam_mask[c]) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "covariance of a partially constant camera");
+  const int pd = h->pd, NT = pd * (pd + 1) / 2;
+  DevProblem Q = h->P;
+  Q.scale_c = h->ones_c.p; Q.scale_p = h->ones_p.p; Q.scale_i = h->ones_i.p; Q.intr = h->intr[h->cur].p;
+  LmState st;
+  std::memset(&st, 0, sizeof(st));
+  st.radius = 1e300;   // no LM damping: D = clamp(diag) / radius vanishes against the diagonal
+  HIP_TRY(hipMemcpyAsync(h->lm_state.p, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const double* radius = &reinterpret_cast<const LmState*>(h->lm_state.p)->radius;
+  HIP_TRY(hipMemsetAsync(h->reduce.p, 0, sizeof(double) * h->reduce.n, h->stream));
+  if (h->Vinv.n) HIP_TRY(hipMemsetAsync(h->Vinv.p, 0, sizeof(double) * h->Vinv.n, h->stream));
+  launch_linearize(Q, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->tile_part.p, h->stream);
+  launch_long_linearize(Q, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->long_scratch.p, h->stream);
+  if (point_cov) {
+    std::vector<double> vi((size_t)NT * h->np);
+    if (h->np) HIP_TRY(hipMemcpyAsync(vi.data(), h->Vinv.p, sizeof(double) * vi.size(), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int q = 0; q < h->np; ++q)
+      for (int a = 0; a < pd; ++a)
+        for (int b = 0; b < pd; ++b)
+          point_cov[(size_t)q * pd * pd + a * pd + b] = vi[(size_t)NT * q + (a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a)];
+  }
+  if (cam_cov) {
+    const int n = h->n;
+    std::vector<double> S((size_t)n * n);
+    if (n) HIP_TRY(hipMemcpyAsync(S.data(), h->rb.S, sizeof(double) * S.size(), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::fill(cam_cov, cam_cov + 36 * (size_t)h->nc, 0.0);
+    for (int c = 0; c < h->nc; ++c) {
+      const int rc = h->cam_red[c];
+      if (rc < 0) continue;
+      double L[36], Li[36];
+      bool ok = true;
+      for (int i = 0; i < 6 && ok; ++i)
+        for (int j = 0; j <= i; ++j) {
+          double s = S[(size_t)(6 * rc + i) * n + 6 * rc + j];
+          for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
+          if (i == j) { if (!(s > 0.0)) { ok = false; break; } L[i * 6 + i] = std::sqrt(s); }
+          else L[i * 6 + j] = s / L[j * 6 + j];
+        }
+      if (!ok) return set_error(THEIA_HIP_ERR_INTERNAL, "camera %d: J'J is rank deficient (ceres::Covariance::Compute fails)", c);
+      for (int i = 0; i < 6; ++i) {   // Li = L^-1
+        for (int j = 0; j < 6; ++j) Li[i * 6 + j] = 0.0;
+        Li[i * 6 + i] = 1.0 / L[i * 6 + i];
+        for (int j = 0; j < i; ++j) {
+          double s = 0.0;
+          for (int k = j; k < i; ++k) s -= L[i * 6 + k] * Li[k * 6 + j];
+          Li[i * 6 + j] = s / L[i * 6 + i];
+        }
+      }
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) {
+          double s = 0.0;
+          for (int k = std::max(a, b); k < 6; ++k) s += Li[k * 6 + a] * Li[k * 6 + b];
+          cam_cov[(size_t)c * 36 + a * 6 + b] = s;
+        }
+    }
+  }
+  return 0;
+}
+
 int theia_hip_dense_spd_solve(int32_t n, const double* A, const double* b, double* x) {
   if (n < 0 || (n > 0 && (!A || !b || !x))) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
   if (n == 0) return 0;

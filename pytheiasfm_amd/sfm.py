@@ -356,3 +356,68 @@ def BundleAdjustTracksIndependently(reconstruction, options, track_ids):
     r.points[track_ids] = flat.points
     _update_inverse_depth(r, track_ids.tolist())
     return [BundleAdjustmentSummary(s) for s in summ]
+
+
+# ------------------------------------------------------------------- *WithCov
+# bundle_adjustment.cc:288-386,420-499 through bundle_adjustment_wrapper.cc:52-96: the solve, then
+# ceres::Covariance of the (block-diagonal) problem times the empirical variance factor
+# 2 * final_cost / redundancy.  Returned as (summary, covariance(s), variance_factor).
+def _with_cov(reconstruction, options, flat, want_points):
+    c_opts = options.to_c()
+    with _ba.BaHandle(flat, c_opts) as h:
+        s, _ = h.run()
+        h.download(flat)
+        summary = BundleAdjustmentSummary(s)
+        if not summary.success:
+            return summary, None
+        try:
+            pc, cc = h.covariance(points=want_points, cameras=not want_points)
+        except capi.TheiaHipError:
+            summary.success = False      # GetCovarianceFor* returned false
+            return summary, None
+    reconstruction.cam_ext[:] = flat.cam_ext
+    reconstruction.points[:] = flat.points
+    return summary, (pc if want_points else cc)
+
+
+def BundleAdjustTracksWithCov(reconstruction, options, track_ids):
+    """bundle_adjustment.cc:330-386 (forces the homogeneous manifold, :339)."""
+    import copy
+    opts = copy.copy(options)
+    opts.use_homogeneous_point_parametrization = True
+    opts.use_inverse_depth_parametrization = False
+    track_ids = [int(t) for t in track_ids]
+    flat = _flatten(reconstruction, [], track_ids)
+    summary, pc = _with_cov(reconstruction, opts, flat, True)
+    _update_inverse_depth(reconstruction, track_ids)
+    if pc is None:
+        return summary, {}, 1.0
+    nr_obs = int(sum(np.sum((reconstruction.obs_track == t) ) for t in track_ids))   # Track::NumViews()
+    redundancy = nr_obs * 2 - 3.0 * len(track_ids)
+    factor = (2.0 * summary.final_cost) / redundancy
+    return summary, {t: pc[t] * factor for t in track_ids}, factor
+
+
+def BundleAdjustTrackWithCov(reconstruction, options, track_id):
+    """bundle_adjustment.cc:288-327."""
+    summary, covs, factor = BundleAdjustTracksWithCov(reconstruction, options, [track_id])
+    return summary, covs.get(int(track_id), np.eye(3)), factor
+
+
+def BundleAdjustViewsWithCov(reconstruction, options, view_ids):
+    """bundle_adjustment.cc:454-499."""
+    view_ids = [int(v) for v in view_ids]
+    flat = _flatten(reconstruction, view_ids, [])
+    summary, cc = _with_cov(reconstruction, options, flat, False)
+    if cc is None:
+        return summary, {}, 1.0
+    nr_obs = int(sum(np.sum(reconstruction.obs_view == v) for v in view_ids))           # View::NumFeatures()
+    redundancy = nr_obs * 2 - 6.0 * len(view_ids)
+    factor = (2.0 * summary.final_cost) / redundancy
+    return summary, {v: cc[v] * factor for v in view_ids}, factor
+
+
+def BundleAdjustViewWithCov(reconstruction, options, view_id):
+    """bundle_adjustment.cc:420-452."""
+    summary, covs, factor = BundleAdjustViewsWithCov(reconstruction, options, [view_id])
+    return summary, covs.get(int(view_id), np.eye(6)), factor

@@ -182,6 +182,45 @@ def test_mirror_independent_view_and_track_batches():
     assert np.array_equal(rb.points[1], p.points[1]) and np.all(rb.inverse_depth[tracks] > 0)
 
 
+def test_covariance_blocks_match_jacobian_inverse():
+    """*WithCov (bundle_adjustment.cc:288-386,420-499): ceres::Covariance of the block-diagonal problems
+    = inverse of each block of J'J, J from the oracle's Jets at the solution; times 2 * cost / redundancy."""
+    p = synth.synth_ba_v1(10, 200, seed=64, pixel_noise=0.7)
+    opts = sfm.BundleAdjustmentOptions(); opts.max_num_iterations = 30
+    rec = sfm.Reconstruction.from_flat(p)
+    tracks = [3, 50, 199]
+    summ, covs, factor = sfm.BundleAdjustTracksWithCov(rec, opts, tracks)
+    assert summ.success and factor > 0
+    nobs = sum(int(np.sum(p.obs_pt == t)) for t in tracks)
+    assert abs(factor - 2.0 * summ.final_cost / (2 * nobs - 9)) <= 1e-12 * factor
+    flat = sfm._flatten(rec, [], tracks)                      # the solved state
+    ok, _, r, jc, jp = ol.evaluate(flat, ol.default_options())
+    for t in tracks:
+        J = jp[flat.obs_pt == t].reshape(-1, 3)
+        ref = np.linalg.inv(J.T @ J) * factor
+        assert np.abs(covs[t] - ref).max() <= 1e-8 * np.abs(ref).max()
+        assert np.all(np.linalg.eigvalsh(covs[t]) > 0)
+    s1, c1, f1 = sfm.BundleAdjustTrackWithCov(sfm.Reconstruction.from_flat(p), opts, 50)
+    assert s1.success and c1.shape == (3, 3) and f1 > 0
+    # views against constant tracks
+    rec2 = sfm.Reconstruction.from_flat(p)
+    views = [2, 7]
+    sv, cv, fv = sfm.BundleAdjustViewsWithCov(rec2, opts, views)
+    assert sv.success
+    flat2 = sfm._flatten(rec2, views, [])
+    ok, _, r2, jc2, jp2 = ol.evaluate(flat2, ol.default_options())
+    for v in views:
+        J = jc2[flat2.obs_cam == v].reshape(-1, 6)
+        ref = np.linalg.inv(J.T @ J) * fv
+        assert np.abs(cv[v] - ref).max() <= 1e-7 * np.abs(ref).max()
+    s2, c2, f2 = sfm.BundleAdjustViewWithCov(sfm.Reconstruction.from_flat(p), opts, 7)
+    assert s2.success and c2.shape == (6, 6) and np.all(np.linalg.eigvalsh(c2) > 0)
+    # a problem that is not block diagonal has no covariance entry point
+    with ba.BaHandle(p.copy(), ba.default_options()) as h:
+        with pytest.raises(capi.TheiaHipError):
+            h.covariance(points=True)
+
+
 def test_edge_cases_empty_invalid_and_errors():
     o = ba.default_options()
     empty = capi.FlatProblem(np.zeros((0, 6)), np.zeros((1, 7)), [0], np.zeros(0, np.int32), np.zeros((0, 4)),
