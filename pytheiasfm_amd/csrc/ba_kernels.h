@@ -26,9 +26,6 @@ struct DevProblem {
   const int* obs_pt;           // [nobs]
   const int* tile_start;       // [ntiles]
   const int* tile_count;       // [ntiles]
-  int tiles_per_wg, nwg;       // linearize: workgroup b owns tiles [b*tiles_per_wg, ...)
-  const int* wg_base;          // [nwg] first reduced camera of the workgroup's LDS window
-  long long* stamps;           // development: per-phase cycle counts of workgroup 0 (or nullptr)
   // tracks with > 64 observations (slow path, ba_kernels.hip "long tracks")
   int long_nobs, long_ntracks;
   const int* long_obs_index;   // [long_nobs] index into the sorted observation arrays
@@ -48,7 +45,7 @@ struct DevProblem {
   const double* intr_cand;     // [ng][10] candidate intrinsics (back-substitution / trial cost)
   const double* scale_red;     // [n] Jacobi scaling by reduced index (finalize)
   // gather-based Schur assembly (k_lin_obs + k_schur_diag + k_schur_blocks), ni == 0:
-  // static lists built at create(); null = LDS-window / atomic k_linearize
+  // static lists built at create()
   double* rec;                 // [#records][12*pd + 20] per-observation record {W | T | F | r | T g}, camera-major
   const int* rec_slot;         // [nobs_main] record slot of a (sorted) observation, -1 = none
   int n_diag_items, n_blk_items;

@@ -293,307 +293,11 @@ __global__ void k_make_scale(int count, const double* __restrict__ colsq, double
 }
 
 // -------------------------------------------------- linearize + Schur (K1+K2)
-// One workgroup walks a contiguous range of wave tiles (tracks are sorted by
-// their first camera at create()), so the cameras it touches form a short
-// window [base, base + kWin) of the reduced camera ordering.  All Schur blocks
-// S_ij, the camera diagonal blocks and the per-camera vectors of that window
-// are accumulated in LDS (ds_add_f64) and flushed to HBM ONCE per workgroup;
-// only contributions that leave the window (ring wrap-around, very long
-// tracks) go straight to global FP64 atomics.
 // tile_part layout: [ntiles][4] = {cost, gmax_points, invalid, notpd}
-constexpr int kWin = 16;                       // cameras per LDS window
-constexpr int kWinBlocks = kWin * (kWin + 1) / 2;
-
-THIP_DEV void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
-
-// INTR (intrinsics_to_optimize != NONE): S/rhs/colsq/gc point at the CAMERA part of
-// the reduced system (shifted by ni), SI/rhsI/colsqI/gcI at its origin.  The
-// intrinsics blocks are shared by many cameras; their contributions go through
-// global FP64 atomics (first version of this path: correct, not yet tuned).
-template <int PD, bool INTR>
-__global__ __launch_bounds__(kBlock) void k_linearize(DevProblem P, const double* __restrict__ cam,
-                                                      const double* __restrict__ pts, const double* __restrict__ radius_p,
-                                                      double* __restrict__ S, double* __restrict__ rhs,
-                                                      double* __restrict__ colsq, double* __restrict__ gc,
-                                                      double* __restrict__ Vinv, double* __restrict__ gp,
-                                                      double* __restrict__ tile_part,
-                                                      double* __restrict__ SI, double* __restrict__ rhsI,
-                                                      double* __restrict__ colsqI, double* __restrict__ gcI) {
-  const double radius = *radius_p;
-  constexpr int NT = PD * (PD + 1) / 2;
-  constexpr int NW = 6 * PD;
-  constexpr int NWI = INTR ? THEIA_MAX_INTRINSICS * PD : 1;
-  constexpr int WPB = INTR ? 2 : kWavesPerBlock;   // waves per workgroup (LDS budget)
-  __shared__ double sW[WPB][kWave][NW + 1];
-  __shared__ int sRc[WPB][kWave];
-  __shared__ double sWI[INTR ? WPB : 1][INTR ? kWave : 1][NWI + 1];
-  __shared__ int sGr[INTR ? WPB : 1][INTR ? kWave : 1];
-  __shared__ double accS[kWinBlocks][36];       // lower block triangle of the window
-  __shared__ double accC[kWin][18];             // per camera: rhs(6) | g_c(6) | colsq(6)
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  const int n = P.n;
-  const int base = P.wg_base[blockIdx.x];
-  for (int i = threadIdx.x; i < kWinBlocks * 36; i += blockDim.x) (&accS[0][0])[i] = 0.0;
-  for (int i = threadIdx.x; i < kWin * 18; i += blockDim.x) (&accC[0][0])[i] = 0.0;
-  __syncthreads();
-
-  const int tile0 = blockIdx.x * P.tiles_per_wg;
-  long long st_[6] = {0, 0, 0, 0, 0, 0};
-  long long tprev = clock64();
-#define STAMP(k_) do { const long long tn_ = clock64(); st_[k_] += tn_ - tprev; tprev = tn_; } while (0)
-  for (int rnd = 0; rnd < P.tiles_per_wg; rnd += WPB) {
-    const int tile = tile0 + rnd + wv;
-    const bool tile_ok = (rnd + wv < P.tiles_per_wg) && tile < P.ntiles;
-    const int cnt = tile_ok ? P.tile_count[tile] : 0;
-    const int start = tile_ok ? P.tile_start[tile] : 0;
-    LaneLin<PD, INTR> L;
-    lane_linearize<PD, true, INTR>(P, cam, pts, start + lane, lane < cnt, lane, L);
-    const Segment sg = lane_segment(L.p, lane);
-    STAMP(0);
-
-    // V_p (packed lower) and g_p = E^T r : segmented all-reduce
-    double in[NT + PD], tot[NT + PD];
-#pragma unroll
-    for (int a = 0; a < PD; ++a) {
-#pragma unroll
-      for (int b = 0; b <= a; ++b) in[lidx(a, b)] = L.Jt[a] * L.Jt[b] + L.Jt[PD + a] * L.Jt[PD + b];
-      in[NT + a] = L.Jt[a] * L.r[0] + L.Jt[PD + a] * L.r[1];
-    }
-    segment_allsum<NT + PD>(sg, in, tot);
-    STAMP(1);
-
-    double V[NT], Vi[NT], g[PD];
-#pragma unroll
-    for (int k = 0; k < NT; ++k) V[k] = tot[k];
-#pragma unroll
-    for (int a = 0; a < PD; ++a) g[a] = tot[NT + a];
-    // LM diagonal of the point block: clamp(colnorm^2, 1e-6, 1e32) / radius
-#pragma unroll
-    for (int a = 0; a < PD; ++a) V[lidx(a, a)] += fmin(fmax(V[lidx(a, a)], 1e-6), 1e32) / radius;
-    bool pd_ok = true;
-    if (L.active && !L.pconst) pd_ok = invert_spd<PD>(V, Vi);
-    if (!L.active || L.pconst || !pd_ok) {
-#pragma unroll
-      for (int k = 0; k < NT; ++k) Vi[k] = 0.0;
-    }
-    double gmax = 0.0;
-    if (L.active && sg.head && !L.pconst) {
-#pragma unroll
-      for (int k = 0; k < NT; ++k) Vinv[(size_t)NT * L.p + k] = Vi[k];
-#pragma unroll
-      for (int a = 0; a < PD; ++a) {
-        gp[(size_t)PD * L.p + a] = g[a];
-        gmax = fmax(gmax, fabs(g[a] / P.scale_p[(size_t)PD * L.p + a]));
-      }
-    }
-
-    // W = F^T E (6 x PD), T = W Vinv, y = Vinv g
-    double W[NW], T[NW], y[PD];
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int b = 0; b < PD; ++b) W[a * PD + b] = L.Jc[a] * L.Jt[b] + L.Jc[6 + a] * L.Jt[PD + b];
-#pragma unroll
-    for (int a = 0; a < PD; ++a) {
-      double s = 0.0;
-#pragma unroll
-      for (int b = 0; b < PD; ++b) s += sym_get<PD>(Vi, a, b) * g[b];
-      y[a] = s;
-    }
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int b = 0; b < PD; ++b) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < PD; ++k) s += W[a * PD + k] * sym_get<PD>(Vi, k, b);
-        T[a * PD + b] = s;
-      }
-
-    STAMP(2);
-    const int rc = L.rc;
-    const int li = rc - base;
-    const bool in_win = li >= 0 && li < kWin;
-    if (L.active && rc >= 0) {
-      double* Sd = in_win ? &accS[lidx(li, li)][0] : S + (size_t)(6 * rc) * n + 6 * rc;
-      const int ldS = in_win ? 6 : n;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        const double jr = L.Jc[a] * L.r[0] + L.Jc[6 + a] * L.r[1];
-        double wy = 0.0;
-#pragma unroll
-        for (int b = 0; b < PD; ++b) wy += W[a * PD + b] * y[b];
-        const double cs = L.Jc[a] * L.Jc[a] + L.Jc[6 + a] * L.Jc[6 + a];
-        if (in_win) {
-          lds_add(&accC[li][a], jr - wy); lds_add(&accC[li][6 + a], jr); lds_add(&accC[li][12 + a], cs);
-        } else {
-          atomic_add(&rhs[6 * rc + a], jr - wy); atomic_add(&gc[6 * rc + a], jr); atomic_add(&colsq[6 * rc + a], cs);
-        }
-#pragma unroll
-        for (int b = 0; b <= a; ++b) {
-          const double v = L.Jc[a] * L.Jc[b] + L.Jc[6 + a] * L.Jc[6 + b];
-          if (in_win) lds_add(&Sd[a * ldS + b], v); else atomic_add(&Sd[(size_t)a * ldS + b], v);
-        }
-      }
-    }
-
-    // ---- intrinsics block of this observation (global atomics)
-    double TI[NWI];
-    const int gr = L.gr;
-    if constexpr (INTR) {
-      const int nfull = P.n;
-      double WI[NWI];
-#pragma unroll
-      for (int a = 0; a < THEIA_MAX_INTRINSICS; ++a)
-#pragma unroll
-        for (int b = 0; b < PD; ++b) WI[a * PD + b] = L.Jk[a] * L.Jt[b] + L.Jk[THEIA_MAX_INTRINSICS + a] * L.Jt[PD + b];
-#pragma unroll
-      for (int a = 0; a < THEIA_MAX_INTRINSICS; ++a)
-#pragma unroll
-        for (int b = 0; b < PD; ++b) {
-          double sacc = 0.0;
-#pragma unroll
-          for (int k = 0; k < PD; ++k) sacc += WI[a * PD + k] * sym_get<PD>(Vi, k, b);
-          TI[a * PD + b] = sacc;
-        }
-      if (L.active && gr >= 0) {
-        const unsigned fm = P.grp_free[L.g];
-        double* Sg = SI + (size_t)(10 * gr) * nfull + 10 * gr;
-        for (int a = 0; a < THEIA_MAX_INTRINSICS; ++a) {
-          if (!((fm >> a) & 1u)) continue;
-          const double jr = L.Jk[a] * L.r[0] + L.Jk[THEIA_MAX_INTRINSICS + a] * L.r[1];
-          double wy = 0.0;
-          for (int b = 0; b < PD; ++b) wy += WI[a * PD + b] * y[b];
-          atomic_add(&rhsI[10 * gr + a], jr - wy);
-          atomic_add(&gcI[10 * gr + a], jr);
-          atomic_add(&colsqI[10 * gr + a], L.Jk[a] * L.Jk[a] + L.Jk[THEIA_MAX_INTRINSICS + a] * L.Jk[THEIA_MAX_INTRINSICS + a]);
-          for (int b = 0; b <= a; ++b)
-            if ((fm >> b) & 1u)
-              atomic_add(&Sg[(size_t)a * nfull + b], L.Jk[a] * L.Jk[b] + L.Jk[THEIA_MAX_INTRINSICS + a] * L.Jk[THEIA_MAX_INTRINSICS + b]);
-          if (L.rc >= 0)   // camera rows x intrinsics columns: F_c^T F_k
-            for (int e = 0; e < 6; ++e)
-              atomic_add(&SI[(size_t)(P.ni + 6 * L.rc + e) * nfull + 10 * gr + a], L.Jc[e] * L.Jk[a] + L.Jc[6 + e] * L.Jk[THEIA_MAX_INTRINSICS + a]);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < NWI; ++k) sWI[wv][lane][k] = WI[k];
-      sGr[wv][lane] = (L.active && !L.pconst) ? gr : -1;
-    }
-    STAMP(3);
-    // stage W of the tile in LDS, then every lane walks its track's segment
-#pragma unroll
-    for (int k = 0; k < NW; ++k) sW[wv][lane][k] = W[k];
-    sRc[wv][lane] = (L.active && !L.pconst) ? rc : -1;
-    __syncthreads();
-    const bool me = L.active && !L.pconst && rc >= 0;
-    for (int j = 0; j < sg.maxlen; ++j) {
-      // walk the partners in an order rotated by the track's rank in the tile:
-      // tracks that share a camera window then hit DIFFERENT accumulator blocks
-      // in the same ds_add_f64 instruction (no same-address serialisation)
-      int jj = j + sg.rank;
-      jj = (j < sg.len) ? jj % sg.len : 0;
-      const int src = (sg.start + jj) & 63;
-      const int rcs = sRc[wv][src];
-      const bool take = me && (j < sg.len) && rcs >= 0 && rc >= rcs;
-      if constexpr (INTR) {
-        // every ORDERED pair (lane, src) of the track: intrinsics x intrinsics and camera x intrinsics
-        const int grs = sGr[wv][src];
-        if (L.active && !L.pconst && (j < sg.len) && grs >= 0) {
-          const int nfull = P.n;
-          double WIs[NWI];
-#pragma unroll
-          for (int k = 0; k < NWI; ++k) WIs[k] = sWI[wv][src][k];
-          if (gr >= 0 && gr >= grs) {
-            double* Sb2 = SI + (size_t)(10 * gr) * nfull + 10 * grs;
-            for (int a = 0; a < THEIA_MAX_INTRINSICS; ++a)
-              for (int b = 0; b < THEIA_MAX_INTRINSICS; ++b) {
-                if (gr == grs && b > a) continue;
-                double sacc = 0.0;
-#pragma unroll
-                for (int k = 0; k < PD; ++k) sacc += TI[a * PD + k] * WIs[b * PD + k];
-                if (sacc != 0.0) atomic_add(&Sb2[(size_t)a * nfull + b], -sacc);
-              }
-          }
-          if (rc >= 0) {
-            double* Sb3 = SI + (size_t)(P.ni + 6 * rc) * nfull + 10 * grs;
-            for (int a = 0; a < 6; ++a)
-              for (int b = 0; b < THEIA_MAX_INTRINSICS; ++b) {
-                double sacc = 0.0;
-#pragma unroll
-                for (int k = 0; k < PD; ++k) sacc += T[a * PD + k] * WIs[b * PD + k];
-                if (sacc != 0.0) atomic_add(&Sb3[(size_t)a * nfull + b], -sacc);
-              }
-          }
-        }
-      }
-      if (!take) continue;
-      double Ws[NW];
-#pragma unroll
-      for (int k = 0; k < NW; ++k) Ws[k] = sW[wv][src][k];
-      const int lj = rcs - base;
-      const bool blk_in = in_win && lj >= 0;   // lj <= li < kWin
-      double* Sb = blk_in ? &accS[lidx(li, lj)][0] : S + (size_t)(6 * rc) * n + 6 * rcs;
-      const int ldS = blk_in ? 6 : n;
-      const bool diag = rc == rcs;
-#pragma unroll
-      for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int b = 0; b < 6; ++b) {
-          if (diag && b > a) continue;
-          double s = 0.0;
-#pragma unroll
-          for (int k = 0; k < PD; ++k) s += T[a * PD + k] * Ws[b * PD + k];
-          if (blk_in) lds_add(&Sb[a * ldS + b], -s); else atomic_add(&Sb[(size_t)a * ldS + b], -s);
-        }
-    }
-    __syncthreads();  // sW / sRc are reused by the next round
-    STAMP(4);
-
-    // per-tile partials (reduced in fixed order by k_reduce_tiles)
-    const double cost = wave_sum(L.cost);
-    gmax = wave_max(gmax);
-    const double inval = wave_sum((L.active && !L.valid) ? 1.0 : 0.0);
-    const double npd = wave_sum((L.active && !pd_ok) ? 1.0 : 0.0);
-    if (tile_ok && lane == 0) {
-      tile_part[4 * (size_t)tile + 0] = cost;
-      tile_part[4 * (size_t)tile + 1] = gmax;
-      tile_part[4 * (size_t)tile + 2] = inval;
-      tile_part[4 * (size_t)tile + 3] = npd;
-    }
-  }
-
-  // flush the window to HBM: one FP64 atomic per non-zero accumulator entry
-  __syncthreads();
-  const int ncv = P.ncv;
-  for (int e = threadIdx.x; e < kWinBlocks * 36; e += blockDim.x) {
-    const double v = (&accS[0][0])[e];
-    if (v == 0.0) continue;
-    const int blk = e / 36, ab = e % 36;
-    int bi = 0;
-    while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;   // blk = bi (bi+1)/2 + bj
-    const int bj = blk - bi * (bi + 1) / 2;
-    if (base + bi >= ncv) continue;
-    atomic_add(&S[(size_t)(6 * (base + bi) + ab / 6) * n + 6 * (base + bj) + ab % 6], v);
-  }
-  for (int e = threadIdx.x; e < kWin * 18; e += blockDim.x) {
-    const double v = (&accC[0][0])[e];
-    if (v == 0.0) continue;
-    const int c = e / 18, q = e % 18;
-    if (base + c >= ncv) continue;
-    double* dst = q < 6 ? rhs : (q < 12 ? gc : colsq);
-    atomic_add(&dst[6 * (base + c) + q % 6], v);
-  }
-  STAMP(5);
-#undef STAMP
-  if (P.stamps && blockIdx.x == (unsigned)(P.nwg / 2) && threadIdx.x == 0)
-    for (int k = 0; k < 6; ++k) P.stamps[k] = st_[k];
-}
-
-// ------------------------------------------ gather-based Schur assembly (v3)
-// The LDS-window kernel above spends most of its time in ds_add_f64 (measured
-// ~200 cycles per wave instruction) and runs one workgroup per CU.  The
-// problem topology is static, so the scatter is turned into a gather:
+// The first versions scattered the Schur blocks with FP64 atomics (global, then an
+// LDS window per workgroup): ds_add_f64 costs ~200 cycles per wave instruction and
+// the window left one workgroup per CU.  The problem topology is static, so the
+// scatter is a gather:
 //   k_lin_obs     : per wave tile: linearise, V_p / g_p by segmented sums,
 //                   V_p^-1; writes per-point Vinv, g_p and a per-observation
 //                   record {W = F^T E (6 x PD) | F (2 x 6) | r (2)}.  No LDS
@@ -1679,20 +1383,6 @@ void launch_linearize(const DevProblem& P, const double* cam, const double* pts,
       else k_schur<4><<<P.n_diag_items + P.n_blk_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc);
     }
     return;
-  }
-  // camera part of the reduced system: shifted by the intrinsics slots
-  double* Sc = rb.S + (size_t)P.ni * P.n + P.ni;
-  double* rhs_c = rb.rhs + P.ni; double* colsq_c = rb.colsq + P.ni; double* gc_c = rb.gc + P.ni;
-  if (P.ni) {
-    if (P.pd == 3)
-      k_linearize<3, true><<<P.nwg, 128, 0, st>>>(P, cam, pts, radius, Sc, rhs_c, colsq_c, gc_c, Vinv, gp, tile_part, rb.S, rb.rhs, rb.colsq, rb.gc);
-    else
-      k_linearize<4, true><<<P.nwg, 128, 0, st>>>(P, cam, pts, radius, Sc, rhs_c, colsq_c, gc_c, Vinv, gp, tile_part, rb.S, rb.rhs, rb.colsq, rb.gc);
-  } else {
-    if (P.pd == 3)
-      k_linearize<3, false><<<P.nwg, kBlock, 0, st>>>(P, cam, pts, radius, Sc, rhs_c, colsq_c, gc_c, Vinv, gp, tile_part, rb.S, rb.rhs, rb.colsq, rb.gc);
-    else
-      k_linearize<4, false><<<P.nwg, kBlock, 0, st>>>(P, cam, pts, radius, Sc, rhs_c, colsq_c, gc_c, Vinv, gp, tile_part, rb.S, rb.rhs, rb.colsq, rb.gc);
   }
 }
 

@@ -111,12 +111,10 @@ struct theia_ba_handle_s {
   DevBuf<double> scale_i, ones_i, colsq_i0, scale_red;
   DevBuf<int> d_grp_red, d_grp_k;
   DevBuf<unsigned> d_grp_free;
-  DevBuf<int> group_model, cam_group, d_cam_red, obs_cam, obs_pt, tile_start, tile_count, f2s, fmaxflag, wg_base;
-  int tiles_per_wg = 4, nwg = 0;
+  DevBuf<int> group_model, cam_group, d_cam_red, obs_cam, obs_pt, tile_start, tile_count, f2s, fmaxflag;
   DevBuf<uint8_t> d_cam_mask, d_pt_const;
   DevBuf<double2> obs_uv, obs_si;
   DevBuf<double> reduce, Vinv, gp, tile_part, scalB, chol_work;
-  DevBuf<long long> stamps;
   DevBuf<double> rec;                       // per-observation records of the gather-based Schur assembly
   DevBuf<int> diag_items, cam_obs, blk_items;
   DevBuf<int2> blk_pairs;
@@ -372,9 +370,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.cam_red = h->d_cam_red.p; P.cam_mask = h->d_cam_mask.p; P.pt_const = h->d_pt_const.p;
   P.obs_uv = h->obs_uv.p; P.obs_si = h->obs_si.p; P.obs_cam = h->obs_cam.p; P.obs_pt = h->obs_pt.p;
   P.tile_start = h->tile_start.p; P.tile_count = h->tile_count.p;
-  P.tiles_per_wg = h->tiles_per_wg; P.nwg = h->nwg; P.wg_base = h->wg_base.p;
   P.scale_c = h->scale_c.p; P.scale_p = h->scale_p.p;
-  P.stamps = h->stamps.p;
   P.long_nobs = h->long_nobs; P.long_ntracks = h->long_ntracks;
   P.long_obs_index = h->long_obs_index.p; P.long_obs_slot = h->long_obs_slot.p;
   P.long_track_start = h->long_track_start.p; P.long_track_pt = h->long_track_pt.p;
@@ -532,16 +528,6 @@ int sync_plan(theia_ba_handle_s* h) {
   return 0;
 }
 
-void trace_push(theia_ba_summary* S, double cost, double g, double step, double radius, int acc) {
-  if (!S->trace_cost || S->trace_size >= S->trace_capacity) return;
-  const int k = S->trace_size++;
-  S->trace_cost[k] = cost;
-  if (S->trace_gradient_max_norm) S->trace_gradient_max_norm[k] = g;
-  if (S->trace_step_norm) S->trace_step_norm[k] = step;
-  if (S->trace_radius) S->trace_radius[k] = radius;
-  if (S->trace_accepted) S->trace_accepted[k] = acc;
-}
-
 }  // namespace
 
 extern "C" {
@@ -680,23 +666,6 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   h->ntiles_eval = (int)tstart.size();
   build_tiles(cnt_fix, h->nobs_main, false);
   h->ntiles_all = (int)tstart.size();
-  // linearize workgroups: ~2 per CU, each owning a contiguous run of tiles; the
-  // LDS window starts at the first camera of the run's first track
-  {
-    const int target_wg = 512;
-    int tpw = (h->ntiles_main + target_wg - 1) / target_wg;
-    tpw = std::max(4, ((tpw + 3) / 4) * 4);
-    h->tiles_per_wg = tpw;
-    h->nwg = (h->ntiles_main + tpw - 1) / tpw;
-    std::vector<int> wgb(std::max(1, h->nwg), 0);
-    for (int b2 = 0; b2 < h->nwg; ++b2) {
-      const int k = tkey[(size_t)b2 * tpw];
-      wgb[b2] = (k == std::numeric_limits<int>::max()) ? 0 : k;
-    }
-    rc = h->wg_base.upload(wgb, h->stream);
-    if (rc) return rc;
-  }
-
   std::vector<double2> uv(h->nobs), si;
   std::vector<int> ocam(h->nobs), opt(h->nobs);
   if (p->obs_sqrt_info) si.resize(h->nobs);
@@ -775,8 +744,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
       for (int b = 0; b < nt; ++b) h->tile_adj[(size_t)a * nt + b] = h->tile_adj[(size_t)b * nt + a] = 1;
     h->plan = chol_plan_create(h->n, h->tile_adj.data());
   }
-  if (getenv("THEIA_HIP_STAMPS")) AL(stamps, 16);
-  if (h->ni == 0 && h->ncv > 0 && h->ntiles_main > 0 && !getenv("THEIA_HIP_LINEARIZE_ATOMIC")) {
+  if (h->ni == 0 && h->ntiles_main > 0) {
     // Static gather lists of the Schur assembly (k_schur_diag / k_schur_blocks):
     // per reduced camera its observations, per camera pair (ri > rj) the
     // (observation of ri, observation of rj) pairs of their common variable
@@ -859,7 +827,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     UP(diag_items, ditems); UP(cam_obs, cam_obs); UP(blk_items, bitems); UP(blk_pairs, pairs);
     AL(rec, (size_t)std::max(1, dbeg[h->ncv]) * (12 * h->pd + 20));
   }
-  if (h->ni > 0 && h->ntiles_main > 0 && !h->long_ntracks && !getenv("THEIA_HIP_LINEARIZE_ATOMIC")) {
+  if (h->ni > 0 && h->ntiles_main > 0) {
     // Gather lists with intrinsics (k_lin_obs_intr / k_schur_intr): records for every observation whose camera OR
     // intrinsics group is variable, stored (group, camera)-major; item = {type, row0, col0, beg, end, flags}.
     enum { IT_CC = 0, IT_CG = 1, IT_GG0 = 2, IT_GG1 = 3, IT_CD = 4, IT_CGD = 5, IT_GD0 = 6, IT_GD1 = 7, IT_GV = 8 };
@@ -1137,12 +1105,6 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
       std::fprintf(stderr, "[theia_hip] %3d cost %.6e |g| %.3e |step| %.3e radius %.3e %s\n", k, S->trace_cost[k],
                    S->trace_gradient_max_norm ? S->trace_gradient_max_norm[k] : 0.0, S->trace_step_norm ? S->trace_step_norm[k] : 0.0,
                    S->trace_radius ? S->trace_radius[k] : 0.0, (S->trace_accepted && S->trace_accepted[k]) ? "ok" : "rej");
-  if (h->stamps.p) {  // development aid: cycle breakdown of one k_linearize workgroup
-    long long stp[6];
-    if (hipMemcpy(stp, h->stamps.p, sizeof(stp), hipMemcpyDeviceToHost) == hipSuccess)
-      std::fprintf(stderr, "[theia_hip] k_linearize WG cycles: load+jac %lld | seg-reduce %lld | invert+W/T %lld | camera LDS adds %lld | "
-                   "pair blocks %lld | flush %lld (tiles/WG %d, nwg %d)\n", stp[0], stp[1], stp[2], stp[3], stp[4], stp[5], h->tiles_per_wg, h->nwg);
-  }
   S->num_iterations = st.iter;
   S->num_successful_steps = st.num_successful;
   S->termination_type = st.term;
