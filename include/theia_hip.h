@@ -231,6 +231,17 @@ int theia_hip_ba_tracks_batch(const theia_ba_problem* problem,
                               const theia_ba_options* options,
                               theia_ba_summary* summaries);
 
+/* Per-track reprojection sweep = the loop body of SetOutlierTracksToUnestimated
+ * (set_outlier_tracks_to_unestimated.cc:64-139; the same residual as the BA, without Jacobians): for
+ * every point of `problem` over its observations: the mean squared (unweighted) reprojection error, the
+ * number of views that see it at negative depth (Camera::ProjectPoint), and the smallest cosine between
+ * two of its viewing rays (SufficientTriangulationAngle, triangulation.cc:236-250: a track passes when
+ * that cosine is below cos(min_angle); 2.0 when it has fewer than two views).  One thread per track. */
+int theia_hip_track_statistics(const theia_ba_problem* problem,
+                               double* mean_sq_reprojection_error,
+                               int32_t* num_behind_camera,
+                               double* min_ray_cosine);
+
 /* Handle API: problem resident in HBM across calls (bench, repeated solves). */
 typedef struct theia_ba_handle_s* theia_ba_handle;
 int theia_hip_ba_create(const theia_ba_problem* problem,

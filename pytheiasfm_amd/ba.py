@@ -182,3 +182,15 @@ def solve_tracks_batch(problem, options):
     L.theia_hip_ba_tracks_batch.argtypes = [C.POINTER(capi.BaProblem), C.POINTER(capi.BaOptions), C.POINTER(capi.BaSummary)]
     capi.check(L.theia_hip_ba_tracks_batch(C.byref(st), C.byref(options), summ))
     return [summ[i] for i in range(num)]
+
+
+def track_statistics(problem):
+    """theia_hip_track_statistics: (mean squared reprojection error, #views behind the camera,
+    smallest ray cosine) per point."""
+    st = problem.as_struct()
+    num = problem.points.shape[0]
+    err = np.zeros(max(1, num)); nb = np.zeros(max(1, num), dtype=np.int32); mc = np.zeros(max(1, num))
+    L = capi.lib()
+    L.theia_hip_track_statistics.argtypes = [C.POINTER(capi.BaProblem), capi.c_double_p, capi.c_int32_p, capi.c_double_p]
+    capi.check(L.theia_hip_track_statistics(C.byref(st), capi.ptr(err, C.c_double), capi.ptr(nb, C.c_int32), capi.ptr(mc, C.c_double)))
+    return err[:num], nb[:num], mc[:num]

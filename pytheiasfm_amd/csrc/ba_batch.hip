@@ -17,6 +17,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #define HIP_TRY(expr)                                                                             \
@@ -439,6 +440,52 @@ __global__ __launch_bounds__(64) void k_track_lm(TrackBatch B, ViewOut* __restri
   for (int q = 0; q < 4; ++q) B.pts[4 * (size_t)p + q] = X[q];
 }
 
+// ---- per-track reprojection statistics: the sweep of SetOutlierTracksToUnestimated
+// (set_outlier_tracks_to_unestimated.cc:64-139: mean squared reprojection error over the track's views, any view
+// with negative depth, and SufficientTriangulationAngle, triangulation.cc:236-250).  One thread per track.
+__global__ __launch_bounds__(64) void k_track_stats(TrackBatch B, double* __restrict__ mean_sq_err, int* __restrict__ behind,
+                                                    double* __restrict__ min_ray_cos) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B.num) return;
+  double X[4];
+  for (int q = 0; q < 4; ++q) X[q] = B.pts[4 * (size_t)p + q];
+  const double Xh[3] = {X[0] / X[3], X[1] / X[3], X[2] / X[3]};   // track->Point().hnormalized()
+  double sum = 0.0, mincos = 2.0;
+  int nb = 0;
+  const int64_t beg = B.offsets[p], end = B.offsets[p + 1];
+  for (int64_t o = beg; o < end; ++o) {
+    const int c = B.obs_cam[o];
+    const double* ext = B.cam + 6 * (size_t)c;
+    const int grp = B.cam_group[c];
+    // depth = (R (X - w C))_z / w  (Camera::ProjectPoint, camera.cc:206-216)
+    RotTerms rt;
+    rotation_terms(ext + 3, rt);
+    const double px = X[0] - X[3] * ext[0], py = X[1] - X[3] * ext[1], pz = X[2] - X[3] * ext[2];
+    double qz;
+    if (rt.small) qz = pz + (ext[3] * py - ext[4] * px);                     // p + w x p (first order)
+    else qz = rt.R[6] * px + rt.R[7] * py + rt.R[8] * pz;
+    if (qz / X[3] < 0.0) nb++;
+    const double2 uv = B.uv[o];
+    ObsLin ol;
+    observe<false, false>(B.group_model[grp], ext, B.intr + (size_t)grp * THEIA_MAX_INTRINSICS, X, uv.x, uv.y, 1.0, 1.0, ol);
+    sum += ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1];
+    // ray_i . ray_j over the earlier views
+    double ri[3] = {Xh[0] - ext[0], Xh[1] - ext[1], Xh[2] - ext[2]};
+    const double ni = sqrt(ri[0] * ri[0] + ri[1] * ri[1] + ri[2] * ri[2]);
+    ri[0] /= ni; ri[1] /= ni; ri[2] /= ni;
+    for (int64_t o2 = beg; o2 < o; ++o2) {
+      const double* e2 = B.cam + 6 * (size_t)B.obs_cam[o2];
+      double rj[3] = {Xh[0] - e2[0], Xh[1] - e2[1], Xh[2] - e2[2]};
+      const double nj = sqrt(rj[0] * rj[0] + rj[1] * rj[1] + rj[2] * rj[2]);
+      const double d = (ri[0] * (rj[0] / nj) + ri[1] * (rj[1] / nj)) + ri[2] * (rj[2] / nj);
+      mincos = fmin(mincos, d);
+    }
+  }
+  mean_sq_err[p] = sum / (double)(end - beg);
+  behind[p] = nb;
+  min_ray_cos[p] = mincos;
+}
+
 template <typename T>
 struct Dev {
   T* p = nullptr;
@@ -540,12 +587,17 @@ extern "C" int theia_hip_ba_views_batch(const theia_ba_view_batch* b, const thei
   return 0;
 }
 
-extern "C" int theia_hip_ba_tracks_batch(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_summary* summaries) {
-  if (!p || !o) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null problem/options");
+// Shared host part of the per-point batches: validation + observations grouped by point.
+namespace {
+struct PointGrouped {
+  std::vector<int64_t> off;
+  std::vector<double> uv, si;
+  std::vector<int> oc;
+};
+int group_by_point(const theia_ba_problem* p, PointGrouped* G) {
   const int np = p->num_points;
   if (np < 0 || p->num_cameras < 0 || p->num_groups < 0 || p->num_obs < 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "negative sizes");
-  if (np == 0) return 0;
-  if (!summaries || !p->points) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null array");
+  if (np > 0 && !p->points) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null points");
   if (p->num_obs > 0 && (!p->cam_ext || !p->intrinsics || !p->group_model || !p->cam_group || !p->obs_uv || !p->obs_cam || !p->obs_pt))
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null array in problem");
   if (p->num_obs >= ((int64_t)1 << 31)) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "num_obs >= 2^31");
@@ -554,30 +606,42 @@ extern "C" int theia_hip_ba_tracks_batch(const theia_ba_problem* p, const theia_
   for (int g = 0; g < p->num_groups; ++g)
     if (p->group_model[g] < THEIA_CAM_PINHOLE || p->group_model[g] > THEIA_CAM_ORTHOGRAPHIC)
       return set_error(THEIA_HIP_ERR_UNSUPPORTED, "camera model %d of group %d has no HIP kernel", p->group_model[g], g);
-  for (int64_t i = 0; i < p->num_obs; ++i)
+  const int64_t nobs = p->num_obs;
+  for (int64_t i = 0; i < nobs; ++i)
     if (p->obs_cam[i] < 0 || p->obs_cam[i] >= p->num_cameras || p->obs_pt[i] < 0 || p->obs_pt[i] >= np)
       return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "observation %lld indexes out of range", (long long)i);
+  G->off.assign(np + 1, 0);
+  for (int64_t i = 0; i < nobs; ++i) G->off[p->obs_pt[i] + 1]++;
+  for (int q = 0; q < np; ++q) G->off[q + 1] += G->off[q];
+  G->uv.resize(2 * (size_t)nobs); G->oc.resize((size_t)nobs);
+  if (p->obs_sqrt_info) G->si.resize(2 * (size_t)nobs);
+  std::vector<int64_t> fill(G->off.begin(), G->off.end() - 1);
+  for (int64_t i = 0; i < nobs; ++i) {
+    const int64_t s = fill[p->obs_pt[i]]++;
+    G->uv[2 * s] = p->obs_uv[2 * i]; G->uv[2 * s + 1] = p->obs_uv[2 * i + 1];
+    if (p->obs_sqrt_info) { G->si[2 * s] = p->obs_sqrt_info[2 * i]; G->si[2 * s + 1] = p->obs_sqrt_info[2 * i + 1]; }
+    G->oc[s] = p->obs_cam[i];
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" int theia_hip_ba_tracks_batch(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_summary* summaries) {
+  if (!p || !o) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null problem/options");
+  const int np = p->num_points;
+  if (np == 0) return 0;
+  if (!summaries) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null summaries");
   if (o->loss_function_type < 0 || o->loss_function_type > THEIA_LOSS_TRUNCATED)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown loss function type");
-  int rc = thip::ensure_device();
-  if (rc) return rc;
   // observations grouped by point (stable: the reference walks a track's views in its own order; sums differ by rounding only)
-  const int64_t nobs = p->num_obs;
-  std::vector<int64_t> off(np + 1, 0);
-  for (int64_t i = 0; i < nobs; ++i) off[p->obs_pt[i] + 1]++;
-  for (int q = 0; q < np; ++q) off[q + 1] += off[q];
-  std::vector<double> uv(2 * (size_t)nobs), si;
-  std::vector<int> oc((size_t)nobs);
-  if (p->obs_sqrt_info) si.resize(2 * (size_t)nobs);
-  {
-    std::vector<int64_t> fill(off.begin(), off.end() - 1);
-    for (int64_t i = 0; i < nobs; ++i) {
-      const int64_t s = fill[p->obs_pt[i]]++;
-      uv[2 * s] = p->obs_uv[2 * i]; uv[2 * s + 1] = p->obs_uv[2 * i + 1];
-      if (p->obs_sqrt_info) { si[2 * s] = p->obs_sqrt_info[2 * i]; si[2 * s + 1] = p->obs_sqrt_info[2 * i + 1]; }
-      oc[s] = p->obs_cam[i];
-    }
-  }
+  PointGrouped G;
+  int rc = group_by_point(p, &G);
+  if (rc) return rc;
+  if ((rc = thip::ensure_device())) return rc;
+  const std::vector<int64_t>& off = G.off;
+  const std::vector<double>& uv = G.uv;
+  const std::vector<double>& si = G.si;
+  const std::vector<int>& oc = G.oc;
   Dev<int64_t> d_off; Dev<double> d_uv, d_si, d_cam, d_intr, d_pts; Dev<int> d_oc, d_gm, d_cg; Dev<uint8_t> d_pc; Dev<char> d_out;
   if ((rc = d_off.up(off.data(), np + 1)) || (rc = d_uv.up(uv.data(), uv.size())) || (rc = d_oc.up(oc.data(), oc.size())) ||
       (rc = d_cam.up(p->cam_ext, 6 * (size_t)p->num_cameras)) || (rc = d_intr.up(p->intrinsics, THEIA_MAX_INTRINSICS * (size_t)p->num_groups)) ||
@@ -610,5 +674,32 @@ extern "C" int theia_hip_ba_tracks_batch(const theia_ba_problem* p, const theia_
     S.time_linearize = S.time_solve_reduced = S.time_backsub = S.time_kernel_linearize = 0.0;
     S.num_linearize_launches = 0;
   }
+  return 0;
+}
+
+extern "C" int theia_hip_track_statistics(const theia_ba_problem* p, double* mean_sq_reprojection_error, int32_t* num_behind_camera,
+                                          double* min_ray_cosine) {
+  if (!p) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null problem");
+  const int np = p->num_points;
+  if (np == 0) return 0;
+  if (!mean_sq_reprojection_error || !num_behind_camera || !min_ray_cosine) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null output");
+  PointGrouped G;
+  int rc = group_by_point(p, &G);
+  if (rc) return rc;
+  if ((rc = thip::ensure_device())) return rc;
+  Dev<int64_t> d_off; Dev<double> d_uv, d_cam, d_intr, d_pts, d_err, d_cos; Dev<int> d_oc, d_gm, d_cg, d_nb;
+  if ((rc = d_off.up(G.off.data(), np + 1)) || (rc = d_uv.up(G.uv.data(), G.uv.size())) || (rc = d_oc.up(G.oc.data(), G.oc.size())) ||
+      (rc = d_cam.up(p->cam_ext, 6 * (size_t)p->num_cameras)) || (rc = d_intr.up(p->intrinsics, THEIA_MAX_INTRINSICS * (size_t)p->num_groups)) ||
+      (rc = d_gm.up(p->group_model, p->num_groups)) || (rc = d_cg.up(p->cam_group, p->num_cameras)) ||
+      (rc = d_pts.up(p->points, 4 * (size_t)np)) || (rc = d_err.alloc(np)) || (rc = d_cos.alloc(np)) || (rc = d_nb.alloc(np)))
+    return rc;
+  TrackBatch B;
+  std::memset(&B, 0, sizeof(B));
+  B.num = np; B.offsets = d_off.p; B.uv = reinterpret_cast<const double2*>(d_uv.p); B.si = nullptr;
+  B.obs_cam = d_oc.p; B.cam = d_cam.p; B.intr = d_intr.p; B.group_model = d_gm.p; B.cam_group = d_cg.p; B.pts = d_pts.p;
+  k_track_stats<<<(np + 63) / 64, 64>>>(B, d_err.p, d_nb.p, d_cos.p);
+  HIP_TRY(hipMemcpy(mean_sq_reprojection_error, d_err.p, sizeof(double) * np, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(num_behind_camera, d_nb.p, sizeof(int) * np, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(min_ray_cosine, d_cos.p, sizeof(double) * np, hipMemcpyDeviceToHost));
   return 0;
 }

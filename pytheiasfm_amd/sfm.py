@@ -421,3 +421,24 @@ def BundleAdjustViewWithCov(reconstruction, options, view_id):
     """bundle_adjustment.cc:420-452."""
     summary, covs, factor = BundleAdjustViewsWithCov(reconstruction, options, [view_id])
     return summary, covs.get(int(view_id), np.eye(6)), factor
+
+
+def SetOutlierTracksToUnestimated(track_ids, max_inlier_reprojection_error, min_triangulation_angle_degrees, reconstruction):
+    """set_outlier_tracks_to_unestimated.cc:64-139 (the sweep that brackets every full BA in the estimators):
+    un-estimates tracks that reproject behind a camera, whose mean squared reprojection error exceeds the
+    threshold, or that no two views see under a sufficient angle.  Returns the number removed."""
+    r = reconstruction
+    tids = np.asarray([int(t) for t in track_ids], dtype=np.int64)
+    tids = tids[r.track_estimated[tids]] if len(tids) else tids
+    if not len(tids):
+        return 0
+    local = -np.ones(r.NumTracks(), dtype=np.int64)
+    local[tids] = np.arange(len(tids))
+    keep = (local[r.obs_track] >= 0) & r.view_estimated[r.obs_view]
+    flat = capi.FlatProblem(r.cam_ext.copy(), r.group_intrinsics.copy(), r.group_model, r.view_group, np.ascontiguousarray(r.points[tids]),
+                            r.obs_uv[keep], r.obs_view[keep], local[r.obs_track[keep]].astype(np.int32))
+    err, nbehind, mincos = _ba.track_statistics(flat)
+    bad_reproj = (nbehind > 0) | (err > max_inlier_reprojection_error ** 2)
+    bad_angle = ~bad_reproj & ~(mincos < np.cos(np.deg2rad(min_triangulation_angle_degrees)))
+    r.track_estimated[tids[bad_reproj | bad_angle]] = False
+    return int(bad_reproj.sum() + bad_angle.sum())

@@ -221,6 +221,39 @@ def test_covariance_blocks_match_jacobian_inverse():
             h.covariance(points=True)
 
 
+def test_outlier_track_sweep_matches_reference_rules():
+    """SetOutlierTracksToUnestimated (set_outlier_tracks_to_unestimated.cc:64-139) through the mirror vs a
+    plain numpy restatement: behind-camera views, mean squared reprojection error, triangulation angle."""
+    p = synth.synth_ba_v1(12, 300, seed=65, mixed_models=True, pixel_noise=0.5)
+    p.obs_uv[p.obs_pt == 7] += 40.0                       # gross reprojection error
+    p.points[11, :3] = p.cam_ext[p.obs_cam[np.nonzero(p.obs_pt == 11)[0][0]], :3] - 5.0 * (p.points[11, :3] - p.cam_ext[p.obs_cam[np.nonzero(p.obs_pt == 11)[0][0]], :3])  # behind
+    p.points[20, :3] *= 400.0                             # far away: rays nearly parallel
+    rec = sfm.Reconstruction.from_flat(p)
+    removed = sfm.SetOutlierTracksToUnestimated(range(300), 4.0, 1.0, rec)
+    expect_bad = np.zeros(300, bool)
+    for t in range(300):
+        sel = np.nonzero(p.obs_pt == t)[0]
+        X = p.points[t]
+        errs, rays, behind = [], [], False
+        for o in sel:
+            c = p.obs_cam[o]
+            g = p.cam_group[c]
+            uv, _ = synth.project(p.group_model[g], p.intrinsics[g][None], p.cam_ext[c][None], X[None])
+            Rc = synth.angle_axis_to_matrix(p.cam_ext[c, 3:6])
+            depth = (Rc @ (X[:3] - X[3] * p.cam_ext[c, :3]))[2] / X[3]
+            behind |= bool(depth < 0)
+            errs.append(np.sum((uv[0] - p.obs_uv[o]) ** 2))
+            ray = X[:3] / X[3] - p.cam_ext[c, :3]
+            rays.append(ray / np.linalg.norm(ray))
+        bad = behind or np.mean(errs) > 16.0
+        if not bad:
+            cosmin = min(float(rays[i] @ rays[j]) for i in range(len(rays)) for j in range(i + 1, len(rays)))
+            bad = not (cosmin < np.cos(np.deg2rad(1.0)))
+        expect_bad[t] = bad
+    assert expect_bad[[7, 11, 20]].all() and removed == expect_bad.sum()
+    assert np.array_equal(~rec.track_estimated, expect_bad)
+
+
 def test_edge_cases_empty_invalid_and_errors():
     o = ba.default_options()
     empty = capi.FlatProblem(np.zeros((0, 6)), np.zeros((1, 7)), [0], np.zeros(0, np.int32), np.zeros((0, 4)),
