@@ -48,8 +48,14 @@ __host__ __device__ inline int datum_size(int est) {
 
 // EstimateModel of the three estimators (estimate_relative_pose.cc:75-109,
 // estimate_essential_matrix.cc:62-73, estimate_calibrated_absolute_pose.cc:76-118).
+// EST >= 0: compile-time estimator (k_fit: each instantiation carries only its own solver's scratch frame);
+// EST < 0: runtime dispatch on `est`.
+template <int EST = -1>
 __device__ int estimate_models(int est, const double* subset, double* models) {
-  if (est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_ESSENTIAL_MATRIX) {
+  if (EST >= 0) est = EST;
+  constexpr bool any = EST < 0;
+  if ((any || EST == THEIA_EST_RELATIVE_POSE || EST == THEIA_EST_ESSENTIAL_MATRIX) &&
+      (est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_ESSENTIAL_MATRIX)) {
     double E[90];
     const int ne = rsc::five_point(subset, E);
     if (ne == 0) return 0;
@@ -63,7 +69,7 @@ __device__ int estimate_models(int est, const double* subset, double* models) {
     }
     return nm;
   }
-  if (est == THEIA_EST_ABSOLUTE_POSE_KNEIP) {
+  if ((any || EST == THEIA_EST_ABSOLUTE_POSE_KNEIP) && est == THEIA_EST_ABSOLUTE_POSE_KNEIP) {
     double Rs[36], ts[12];
     const int n = rsc::p3p(subset, Rs, ts);
     for (int i = 0; i < n; ++i) {
@@ -76,7 +82,7 @@ __device__ int estimate_models(int est, const double* subset, double* models) {
     }
     return n;
   }
-  if (est == THEIA_EST_ABSOLUTE_POSE_SQPNP) {
+  if ((any || EST == THEIA_EST_ABSOLUTE_POSE_SQPNP) && est == THEIA_EST_ABSOLUTE_POSE_SQPNP) {
     // SQPnP on the 3 sampled correspondences; quaternion -> matrix as the estimator does
     // (estimate_calibrated_absolute_pose.cc:99-106)
     double feat[6], world[9], quats[72], ts[54];
@@ -119,6 +125,7 @@ __device__ inline double model_error(int est, const double* m, const double* d) 
 //   samples : [nprob][B][m] indices into the problem's data
 //   models  : [nprob][B][mm][kStride], mm = max_models(est)
 //   counts  : [nprob][B]
+template <int EST>
 __global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int64_t* __restrict__ offsets,
                                             const double* __restrict__ data, const int* __restrict__ samples,
                                             const int* __restrict__ active_iters, double* __restrict__ models,
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int
     for (int k = 0; k < ds; ++k) subset[i * ds + k] = pd[(size_t)idx * ds + k];
   }
   double mloc[kMaxCap * kStride];
-  const int nm = estimate_models(est, subset, mloc);
+  const int nm = estimate_models<EST>(est, subset, mloc);
   counts[hyp] = nm;
   if (nm == 0) return;
   // append to the problem's DENSE model list (most of the 10 slots per hypothesis
@@ -788,7 +795,14 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       HIP_TRYR(hipEventRecord(ev0, st));
       {
         dim3 grid((B + 63) / 64, cn);
-        k_fit<<<grid, 64, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_models.p, d_counts.p, d_dense.p, d_tags.p);
+#define THIP_FIT(E) k_fit<E><<<grid, 64, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_models.p, d_counts.p, d_dense.p, d_tags.p)
+        switch (est) {
+          case THEIA_EST_RELATIVE_POSE: THIP_FIT(THEIA_EST_RELATIVE_POSE); break;
+          case THEIA_EST_ESSENTIAL_MATRIX: THIP_FIT(THEIA_EST_ESSENTIAL_MATRIX); break;
+          case THEIA_EST_ABSOLUTE_POSE_KNEIP: THIP_FIT(THEIA_EST_ABSOLUTE_POSE_KNEIP); break;
+          default: THIP_FIT(THEIA_EST_ABSOLUTE_POSE_SQPNP); break;
+        }
+#undef THIP_FIT
       }
       if (lmed) {
         dim3 grid(B * kMaxModels, cn);
