@@ -1,4 +1,6 @@
 """GPU: parity of the HIP BA path (through the C-ABI) against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -299,6 +301,30 @@ def test_full_size_c2_properties():
     # mean squared residual at the optimum ~ pixel noise variance (0.5 px)
     n = p.obs_uv.shape[0]
     assert 0.15 < 2.0 * s.final_cost / (2 * n) < 0.30
+
+
+def test_full_size_c4_properties():
+    """BASELINE configs[3] size on one GPU (1000 views / 500k tracks / ~3 M observations, pinhole +
+    double-sphere, n = 6000, 94 tiles): the same size-independent properties, plus the level-scheduled
+    plan against the dense panel chain on the first iterations."""
+    p = synth.ba_config("C4")
+    o = ba.default_options(); o.max_num_iterations = 12
+    with ba.BaHandle(p.copy(), o) as h:
+        s, tr = h.run()
+        assert s.success and s.final_cost < 0.01 * s.initial_cost
+        acc = tr.cost[tr.accepted == 1]
+        assert np.all(np.diff(acc) < 0) and len(acc) >= 5
+        h.reset(p); s2, tr2 = h.run()
+        assert s2.num_iterations == s.num_iterations and rel(tr2.cost, tr.cost) < 1e-12
+    n = p.obs_uv.shape[0]
+    assert 0.15 < 2.0 * s.final_cost / (2 * n) < 0.35
+    o3 = ba.default_options(); o3.max_num_iterations = 3
+    os.environ["THEIA_HIP_DENSE_CHOLESKY"] = "1"
+    try:
+        sd, trd = ba.solve(p.copy(), o3)
+    finally:
+        del os.environ["THEIA_HIP_DENSE_CHOLESKY"]
+    assert rel(trd.cost[: trd.size], tr.cost[: trd.size]) < 1e-9 and np.array_equal(trd.accepted[: trd.size], tr.accepted[: trd.size])
 
 
 @pytest.mark.parametrize("n", [1, 6, 24, 32, 33, 120, 121, 300, 1200])
