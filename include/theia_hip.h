@@ -125,7 +125,20 @@ typedef struct theia_ba_problem {
                                   (reprojection_error.h:94-99) or NULL = 1 */
   const int32_t* obs_cam;      /* [num_obs] camera index                   */
   const int32_t* obs_pt;       /* [num_obs] point index                    */
+  /* Camera priors (View::{Position,Gravity,Orientation}Prior added by AddView / AddViewPriors,
+   * bundle_adjuster.cc:159-172,291-313; functors position_error.h, gravity_error.h,
+   * orientation_error.h: 3 residuals each, no loss).  All optional (NULL); a prior is used when its
+   * bit is set both in cam_prior_mask[c] and in options->prior_mask.  Sharded solves: pass the
+   * priors on exactly ONE rank (cameras are replicated). */
+  const uint8_t* cam_prior_mask;                 /* [num_cameras] THEIA_PRIOR_* bits           */
+  const double* cam_position_prior;              /* [num_cameras][3]                           */
+  const double* cam_position_prior_sqrt_info;    /* [num_cameras][3][3] row-major              */
+  const double* cam_gravity_prior;               /* [num_cameras][3] gravity in the camera frame */
+  const double* cam_gravity_prior_sqrt_info;     /* [num_cameras][3][3]                        */
+  const double* cam_orientation_prior;           /* [num_cameras][3] angle-axis                */
+  const double* cam_orientation_prior_sqrt_info; /* [num_cameras][3][3]                        */
 } theia_ba_problem;
+enum { THEIA_PRIOR_POSITION = 1, THEIA_PRIOR_GRAVITY = 2, THEIA_PRIOR_ORIENTATION = 4 };
 
 /* Mirrors BundleAdjustmentOptions (bundle_adjustment.h:87-167), the fields the
  * HIP backend honours.  The linear-algebra selector fields of the reference
@@ -140,7 +153,8 @@ typedef struct theia_ba_options {
   int32_t orthographic_camera;                   /* (:163) tz constant */
   int32_t use_inner_iterations;  /* (:144) accepted, see DESIGN.md deviation */
   int32_t verbose;               /* (:118) per-iteration table on stderr */
-  int32_t reserved0;
+  int32_t prior_mask;            /* THEIA_PRIOR_* bits: use_position_priors (:154), use_gravity_priors (:166),
+                                    use_orientation_priors (:157) */
   double robust_loss_width;      /* (:91) */
   double function_tolerance;     /* (:148) */
   double gradient_tolerance;     /* (:149) */

@@ -414,6 +414,76 @@ inline void sphere_plus(const double x[4], const double d[3], double out[4]) {
   for (int i = 0; i < 4; ++i) out[i] = nx * (y[i] - v[i] * (beta * vty));
 }
 
+// ----------------------------------------------------------------- camera priors
+// position_error.h:51-59, gravity_error.h:51-65, orientation_error.h:53-64 as one templated function;
+// the SO(3) exp / log / product follow Sophus (so3.hpp: expAndTheta, logAndTheta, operator* with its
+// first-order renormalisation), which is what the reference's orientation prior is autodiff'ed through
+// (Sophus is not under /root/reference: restated from its published source).
+template <typename T>
+inline void so3_exp_quat(const T w[3], T q[4]) {   // q = [w, x, y, z]
+  const T theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  T imag, real;
+  if (scalar_of(theta_sq) < 1e-10 * 1e-10) {
+    const T theta_po4 = theta_sq * theta_sq;
+    imag = T(0.5) - theta_sq * (1.0 / 48.0) + theta_po4 * (1.0 / 3840.0);
+    real = T(1.0) - theta_sq * (1.0 / 8.0) + theta_po4 * (1.0 / 384.0);
+  } else {
+    const T theta = jsqrt(theta_sq);
+    const T half = theta * 0.5;
+    imag = jsin(half) / theta;
+    real = jcos(half);
+  }
+  q[0] = real; q[1] = imag * w[0]; q[2] = imag * w[1]; q[3] = imag * w[2];
+}
+template <typename T>
+inline void so3_log_quat(const T q[4], T t[3]) {
+  const T sn = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  const T w = q[0];
+  T two_atan_nbyw_by_n;
+  if (scalar_of(sn) < 1e-10 * 1e-10) {
+    two_atan_nbyw_by_n = T(2.0) / w - (sn * (2.0 / 3.0)) / (w * w * w);
+  } else {
+    const T n = jsqrt(sn);
+    const T at = (scalar_of(w) < 0.0) ? jatan2(-n, -w) : jatan2(n, w);
+    two_atan_nbyw_by_n = (at * 2.0) / n;
+  }
+  t[0] = two_atan_nbyw_by_n * q[1]; t[1] = two_atan_nbyw_by_n * q[2]; t[2] = two_atan_nbyw_by_n * q[3];
+}
+template <typename T>
+inline void quat_mul_so3(const T a[4], const T b[4], T o[4]) {   // Sophus SO3Base::operator*
+  o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  const T sq = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
+  if (scalar_of(sq) != 1.0) {
+    const T scale = T(2.0) / (T(1.0) + sq);
+    for (int k = 0; k < 4; ++k) o[k] = o[k] * scale;
+  }
+}
+// kind: 1 position, 2 gravity, 4 orientation.  ext = [position(3) | angle-axis(3)]; r = 3 residuals.
+template <typename T>
+inline void camera_prior_residual(int kind, const T* ext, const double* prior, const double* S, T* r) {
+  T v[3];
+  if (kind == 1) {
+    for (int k = 0; k < 3; ++k) v[k] = T(prior[k]) - ext[k];
+  } else if (kind == 2) {
+    const T gw[3] = {T(0.0), T(0.0), T(-1.0)};
+    T gc[3];
+    angle_axis_rotate_point(ext + 3, gw, gc);
+    for (int k = 0; k < 3; ++k) v[k] = gc[k] - prior[k];
+  } else {
+    T qc[4], qp[4], qe[4];
+    const T wp[3] = {T(prior[0]), T(prior[1]), T(prior[2])};
+    so3_exp_quat(ext + 3, qc);
+    so3_exp_quat(wp, qp);
+    qp[1] = -qp[1]; qp[2] = -qp[2]; qp[3] = -qp[3];   // inverse = conjugate
+    quat_mul_so3(qc, qp, qe);
+    so3_log_quat(qe, v);
+  }
+  for (int a = 0; a < 3; ++a) r[a] = v[0] * S[3 * a] + v[1] * S[3 * a + 1] + v[2] * S[3 * a + 2];
+}
+
 }  // namespace
 
 // ===================================================================== C API
@@ -428,11 +498,15 @@ struct oba_problem {
   const uint8_t* cam_const; const uint8_t* group_const;
   double* points; const uint8_t* point_const;
   const double* obs_uv; const double* obs_sqrt_info; const int32_t* obs_cam; const int32_t* obs_pt;
+  const uint8_t* cam_prior_mask;
+  const double* cam_position_prior; const double* cam_position_prior_sqrt_info;
+  const double* cam_gravity_prior; const double* cam_gravity_prior_sqrt_info;
+  const double* cam_orientation_prior; const double* cam_orientation_prior_sqrt_info;
 };
 struct oba_options {
   int32_t loss_function_type, intrinsics_to_optimize, max_num_iterations,
       use_homogeneous_point_parametrization, constant_camera_orientation,
-      constant_camera_position, orthographic_camera, use_inner_iterations, verbose, reserved0;
+      constant_camera_position, orthographic_camera, use_inner_iterations, verbose, prior_mask;
   double robust_loss_width, function_tolerance, gradient_tolerance, parameter_tolerance,
       max_trust_region_radius, max_solver_time_in_seconds;
 };
@@ -540,6 +614,9 @@ struct Oracle {
   // reduced system
   std::vector<double> S, rhs, Vinv, yp, yc;
   int n() const { return ni + 6 * ncv; }
+  // camera priors of variable cameras: 3 residuals each, Jacobian 3 x 6 wrt the extrinsics (masked, scaled)
+  struct Prior { int cam, kind; const double* vec; const double* sqrt_info; double r[3]; double J[18]; };
+  std::vector<Prior> priors;
 };
 
 // reduced index of camera-side column q (0..9 intrinsics, 10..15 extrinsics) of an observation, or -1
@@ -601,6 +678,25 @@ bool evaluate(Oracle& o, const std::vector<double>& cam, const std::vector<doubl
       }
     }
   }
+  // camera priors (no loss function: NULL in bundle_adjuster.cc:627-657)
+  for (Oracle::Prior& pr : o.priors) {
+    const int c = pr.cam;
+    if (!want_jac) {
+      double rr3[3];
+      camera_prior_residual<double>(pr.kind, &cam[6 * c], pr.vec, pr.sqrt_info, rr3);
+      cost += 0.5 * ((rr3[0] * rr3[0] + rr3[1] * rr3[1]) + rr3[2] * rr3[2]);
+      continue;
+    }
+    typedef Jet<6> J6;
+    J6 e[6], rr3[3];
+    for (int q = 0; q < 6; ++q) e[q] = J6(cam[6 * c + q], q);
+    camera_prior_residual<J6>(pr.kind, e, pr.vec, pr.sqrt_info, rr3);
+    for (int a = 0; a < 3; ++a) {
+      pr.r[a] = rr3[a].a;
+      for (int q = 0; q < 6; ++q) pr.J[6 * a + q] = ((o.cam_mask[c] >> q) & 1) ? 0.0 : rr3[a].v[q];
+    }
+    cost += 0.5 * ((pr.r[0] * pr.r[0] + pr.r[1] * pr.r[1]) + pr.r[2] * pr.r[2]);
+  }
   *cost_out = cost;
   return ok;
 }
@@ -618,6 +714,10 @@ void column_norms(Oracle& o, std::vector<double>& nf_, std::vector<double>& np_)
       for (int q = 0; q < pd; ++q) { const double v = o.Jp[(size_t)i * 2 * pd + a * pd + q]; np_[(size_t)pd * p + q] += v * v; }
     }
   }
+  for (const Oracle::Prior& pr : o.priors) {
+    const int base = o.ni + 6 * o.cam_red[pr.cam];
+    for (int a = 0; a < 3; ++a) for (int q = 0; q < 6; ++q) nf_[base + q] += pr.J[6 * a + q] * pr.J[6 * a + q];
+  }
 }
 
 void apply_scaling(Oracle& o) {
@@ -630,6 +730,10 @@ void apply_scaling(Oracle& o) {
       for (int q = 0; q < FW; ++q) { const int col = fcol(o, c, g, q); if (col >= 0) Fr[q] *= o.scale_f[col]; }
       for (int q = 0; q < pd; ++q) o.Jp[(size_t)i * 2 * pd + a * pd + q] *= o.scale_p[(size_t)pd * p + q];
     }
+  }
+  for (Oracle::Prior& pr : o.priors) {
+    const int base = o.ni + 6 * o.cam_red[pr.cam];
+    for (int a = 0; a < 3; ++a) for (int q = 0; q < 6; ++q) pr.J[6 * a + q] *= o.scale_f[base + q];
   }
 }
 
@@ -646,6 +750,10 @@ double compute_gradient(Oracle& o) {
       for (int q = 0; q < FW; ++q) { const int col = fcol(o, c, g, q); if (col >= 0) gf[col] += Fr[q] * ra; }
       for (int q = 0; q < pd; ++q) gp[(size_t)pd * p + q] += o.Jp[(size_t)i * 2 * pd + a * pd + q] * ra;
     }
+  }
+  for (const Oracle::Prior& pr : o.priors) {
+    const int base = o.ni + 6 * o.cam_red[pr.cam];
+    for (int a = 0; a < 3; ++a) for (int q = 0; q < 6; ++q) gf[base + q] += pr.J[6 * a + q] * pr.r[a];
   }
   double gmax = 0.0;
   for (int d = 0; d < o.n(); ++d) gmax = std::max(gmax, std::fabs(gf[d] / o.scale_f[d]));
@@ -717,6 +825,14 @@ bool build_reduced(Oracle& o, double radius, bool add_cam_diag = true) {
       for (int b = 0; b < FW; ++b) if (cols[b] >= 0)
         o.S[(size_t)cols[a] * n + cols[b]] += F0[a] * F0[b] + F1[a] * F1[b];
       o.rhs[cols[a]] += F0[a] * o.r[2 * i] + F1[a] * o.r[2 * i + 1]; }
+  }
+  for (const Oracle::Prior& pr : o.priors) {
+    const int base = o.ni + 6 * o.cam_red[pr.cam];
+    for (int a = 0; a < 6; ++a) {
+      for (int b = 0; b < 6; ++b)
+        o.S[(size_t)(base + a) * n + base + b] += (pr.J[a] * pr.J[b] + pr.J[6 + a] * pr.J[6 + b]) + pr.J[12 + a] * pr.J[12 + b];
+      o.rhs[base + a] += (pr.J[a] * pr.r[0] + pr.J[6 + a] * pr.r[1]) + pr.J[12 + a] * pr.r[2];
+    }
   }
   if (add_cam_diag) for (int d = 0; d < n; ++d) o.S[(size_t)d * n + d] += o.diag_f[d] / radius;
   // eliminate points
@@ -840,6 +956,26 @@ int setup(Oracle& o, const oba_problem* P, const oba_options* O) {
     double rho[3]; loss_evaluate(O->loss_function_type, O->robust_loss_width, res[0] * res[0] + res[1] * res[1], rho);
     o.fixed_cost += 0.5 * rho[0];
   }
+  // camera priors: used when both the camera's bit and the option's bit are set; a prior on a constant
+  // camera is a residual block without variable parameters -> fixed cost
+  o.priors.clear();
+  if (P->cam_prior_mask && O->prior_mask) {
+    const double* vecs[3] = {P->cam_position_prior, P->cam_gravity_prior, P->cam_orientation_prior};
+    const double* infos[3] = {P->cam_position_prior_sqrt_info, P->cam_gravity_prior_sqrt_info, P->cam_orientation_prior_sqrt_info};
+    for (int c = 0; c < o.nc; ++c)
+      for (int k = 0; k < 3; ++k) {
+        const int bit = 1 << k;
+        if (!(P->cam_prior_mask[c] & bit) || !(O->prior_mask & bit) || !vecs[k] || !infos[k]) continue;
+        if (o.cam_red[c] >= 0) {
+          Oracle::Prior pr; pr.cam = c; pr.kind = bit; pr.vec = vecs[k] + 3 * c; pr.sqrt_info = infos[k] + 9 * c;
+          o.priors.push_back(pr);
+        } else {
+          double rr3[3];
+          camera_prior_residual<double>(bit, &o.cam[6 * c], vecs[k] + 3 * c, infos[k] + 9 * c, rr3);
+          o.fixed_cost += 0.5 * ((rr3[0] * rr3[0] + rr3[1] * rr3[1]) + rr3[2] * rr3[2]);
+        }
+      }
+  }
   return 0;
 }
 
@@ -902,6 +1038,15 @@ int oracle_ba_evaluate_ex(const oba_problem* P, const oba_options* O, double* co
   if (jac_pt) std::copy(o.Jp.begin(), o.Jp.end(), jac_pt);
   return ok ? 1 : 0;
 }
+// residual (3) and Jacobian (3 x 6, row-major) of one camera prior by Jets: used to pin the closed forms
+void oracle_camera_prior(int kind, const double* ext, const double* prior, const double* sqrt_info, double* r, double* J) {
+  typedef Jet<6> J6;
+  J6 e[6], rr3[3];
+  for (int q = 0; q < 6; ++q) e[q] = J6(ext[q], q);
+  camera_prior_residual<J6>(kind, e, prior, sqrt_info, rr3);
+  for (int a = 0; a < 3; ++a) { r[a] = rr3[a].a; for (int q = 0; q < 6; ++q) J[6 * a + q] = rr3[a].v[q]; }
+}
+
 int oracle_ba_evaluate(const oba_problem* P, const oba_options* O, double* cost, double* residuals,
                        double* jac_cam, double* jac_pt) {
   return oracle_ba_evaluate_ex(P, O, cost, residuals, jac_cam, jac_pt, nullptr);
@@ -1015,6 +1160,11 @@ int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
           for (int q = 0; q < FW; ++q) { const int col = fcol(o, c, g, q); if (col >= 0) m -= Fr[q] * o.yc[col]; }
           for (int q = 0; q < pd; ++q) m -= o.Jp[(size_t)i * 2 * pd + a * pd + q] * o.yp[(size_t)pd * p + q];
           model_cost_change -= m * (o.r[2 * i + a] + m / 2.0); } }
+      for (const Oracle::Prior& pr : o.priors) {
+        const int base = o.ni + 6 * o.cam_red[pr.cam];
+        for (int a = 0; a < 3; ++a) { double m = 0;
+          for (int q = 0; q < 6; ++q) m -= pr.J[6 * a + q] * o.yc[base + q];
+          model_cost_change -= m * (pr.r[a] + m / 2.0); } }
       step_valid = model_cost_change > 0.0;
     }
     if (!step_valid) {

@@ -36,6 +36,9 @@ class BaProblem(C.Structure):
         ("points", c_double_p), ("point_const", c_uint8_p),
         ("obs_uv", c_double_p), ("obs_sqrt_info", c_double_p), ("obs_cam", c_int32_p),
         ("obs_pt", c_int32_p),
+        ("cam_prior_mask", c_uint8_p), ("cam_position_prior", c_double_p), ("cam_position_prior_sqrt_info", c_double_p),
+        ("cam_gravity_prior", c_double_p), ("cam_gravity_prior_sqrt_info", c_double_p),
+        ("cam_orientation_prior", c_double_p), ("cam_orientation_prior_sqrt_info", c_double_p),
     ]
 
 
@@ -46,7 +49,7 @@ class BaOptions(C.Structure):
         ("max_num_iterations", C.c_int32), ("use_homogeneous_point_parametrization", C.c_int32),
         ("constant_camera_orientation", C.c_int32), ("constant_camera_position", C.c_int32),
         ("orthographic_camera", C.c_int32), ("use_inner_iterations", C.c_int32),
-        ("verbose", C.c_int32), ("reserved0", C.c_int32),
+        ("verbose", C.c_int32), ("prior_mask", C.c_int32),
         ("robust_loss_width", C.c_double), ("function_tolerance", C.c_double),
         ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
         ("max_trust_region_radius", C.c_double), ("max_solver_time_in_seconds", C.c_double),
@@ -69,6 +72,9 @@ class BaSummary(C.Structure):
         ("time_kernel_linearize", C.c_double), ("num_linearize_launches", C.c_int32),
         ("reserved1", C.c_int32),
     ]
+
+
+THEIA_PRIOR_POSITION, THEIA_PRIOR_GRAVITY, THEIA_PRIOR_ORIENTATION = 1, 2, 4
 
 
 class BaViewBatch(C.Structure):
@@ -200,11 +206,29 @@ class FlatProblem:
         assert self.cam_group.shape[0] == self.cam_ext.shape[0]
         assert self.group_model.shape[0] == self.intrinsics.shape[0]
         assert self.obs_cam.shape[0] == self.obs_uv.shape[0] == self.obs_pt.shape[0]
+        # camera priors (set_priors): mask [Nc], three (vector [Nc][3], sqrt information [Nc][3][3]) pairs
+        self.cam_prior_mask = None
+        self.priors = {}
+
+    def set_priors(self, mask, position=None, gravity=None, orientation=None):
+        """Camera priors: mask[c] = THEIA_PRIOR_* bits; each kind = (vectors [Nc][3], sqrt_information [Nc][3][3])."""
+        nc = self.cam_ext.shape[0]
+        self.cam_prior_mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(nc)
+        self.priors = {}
+        for name, pr in (("position", position), ("gravity", gravity), ("orientation", orientation)):
+            if pr is not None:
+                v = np.ascontiguousarray(pr[0], dtype=np.float64).reshape(nc, 3)
+                s = np.ascontiguousarray(pr[1], dtype=np.float64).reshape(nc, 3, 3)
+                self.priors[name] = (v, s)
+        return self
 
     def copy(self):
-        return FlatProblem(self.cam_ext.copy(), self.intrinsics.copy(), self.group_model, self.cam_group,
-                           self.points.copy(), self.obs_uv, self.obs_cam, self.obs_pt,
-                           self.cam_const, self.group_const, self.point_const, self.obs_sqrt_info, self.flags)
+        q = FlatProblem(self.cam_ext.copy(), self.intrinsics.copy(), self.group_model, self.cam_group,
+                        self.points.copy(), self.obs_uv, self.obs_cam, self.obs_pt,
+                        self.cam_const, self.group_const, self.point_const, self.obs_sqrt_info, self.flags)
+        q.cam_prior_mask = self.cam_prior_mask
+        q.priors = dict(self.priors)
+        return q
 
     def as_struct(self):
         p = BaProblem()
@@ -225,6 +249,12 @@ class FlatProblem:
         p.obs_sqrt_info = ptr(self.obs_sqrt_info, C.c_double)
         p.obs_cam = ptr(self.obs_cam, C.c_int32)
         p.obs_pt = ptr(self.obs_pt, C.c_int32)
+        if self.cam_prior_mask is not None:
+            p.cam_prior_mask = ptr(self.cam_prior_mask, C.c_uint8)
+            for name in ("position", "gravity", "orientation"):
+                if name in self.priors:
+                    setattr(p, "cam_%s_prior" % name, ptr(self.priors[name][0], C.c_double))
+                    setattr(p, "cam_%s_prior_sqrt_info" % name, ptr(self.priors[name][1], C.c_double))
         return p
 
 

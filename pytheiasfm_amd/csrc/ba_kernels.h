@@ -52,6 +52,12 @@ struct DevProblem {
   const int* diag_items;       // [n_diag_items][4] {rc, first slot, end slot, atomic}
   const int* blk_items;        // [n_blk_items][5] {ri, rj, beg, end, atomic}
   const int2* blk_pairs;       // (slot of the obs of camera ri, slot of the obs of camera rj) of a common track
+  // camera priors in use (compact list): 3 residuals each on one camera's extrinsics
+  int n_priors;
+  const int* prior_cam;        // [n_priors] camera index
+  const int* prior_kind;       // [n_priors] THEIA_PRIOR_* bit
+  const double* prior_vec;     // [n_priors][3]
+  const double* prior_info;    // [n_priors][9] sqrt information, row-major
 };
 
 // Per-iteration reduced-system workspace: one contiguous buffer so that a
@@ -79,6 +85,13 @@ void launch_linearize(const DevProblem& P, const double* cam, const double* pts,
                       hipStream_t st);
 void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,
                          const int* field_is_max, double* scal, hipStream_t st);
+// camera priors (ba_priors.h).  mode: PRIOR_COLNORM adds the squared column norms of their (unscaled) Jacobians
+// to colsq_c[nc][6]; PRIOR_LINEARIZE adds J'J / J'r / g / column norms / cost to the reduced system at `cam`;
+// PRIOR_TRIAL adds the model-cost change of the step y and the cost at `cand_cam` to scal_cost / scal_mcc;
+// PRIOR_COST adds the cost at `cam` to *scal_cost; PRIOR_FIXED the cost of the priors of CONSTANT cameras.
+enum { PRIOR_COLNORM = 0, PRIOR_LINEARIZE = 1, PRIOR_TRIAL = 2, PRIOR_COST = 3, PRIOR_FIXED = 4 };
+void launch_cam_priors(const DevProblem& P, int mode, const double* cam, const double* cand_cam, const double* y,
+                       const ReduceBuf* rb, double* colsq_c, double* scal_cost, double* scal_mcc, hipStream_t st);
 void launch_finalize_rcs(const DevProblem& P, const double* radius /* device */, const ReduceBuf& rb, hipStream_t st);
 void launch_cam_update(const DevProblem& P, const double* cam, const double* y, double* cand_cam,
                        double* cand_intr, double* out_stepsq, double* out_xnormsq, hipStream_t st);

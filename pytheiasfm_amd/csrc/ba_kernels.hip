@@ -17,6 +17,7 @@
 // (+ camera models), Ceres SchurEliminator semantics for the 3-group ordering of
 // bundle_adjuster.cc:547-577, Ceres LM diagonal (levenberg_marquardt_strategy.cc).
 #include "ba_kernels.h"
+#include "ba_priors.h"
 
 #include "ba_device.h"
 
@@ -1384,6 +1385,69 @@ void launch_linearize(const DevProblem& P, const double* cam, const double* pts,
     }
     return;
   }
+}
+
+// one thread per prior; all updates are FP64 atomics (a handful of priors per camera at most)
+__global__ void k_cam_priors(DevProblem P, int mode, const double* __restrict__ cam, const double* __restrict__ cand,
+                             const double* __restrict__ y, double* __restrict__ S, double* __restrict__ rhs,
+                             double* __restrict__ colsq, double* __restrict__ gc, double* __restrict__ colsq_c,
+                             double* __restrict__ scal_cost, double* __restrict__ scal_mcc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n_priors) return;
+  const int c = P.prior_cam[i], kind = P.prior_kind[i];
+  const int rc = P.cam_red[c];
+  const double* vec = P.prior_vec + 3 * (size_t)i;
+  const double* info = P.prior_info + 9 * (size_t)i;
+  double r[3], J[18];
+  if (mode == PRIOR_FIXED || mode == PRIOR_COST) {
+    if ((mode == PRIOR_FIXED) != (rc < 0)) return;
+    camera_prior(kind, cam + 6 * (size_t)c, vec, info, false, r, J);
+    atomic_add(scal_cost, 0.5 * ((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]));
+    return;
+  }
+  if (rc < 0) return;
+  camera_prior(kind, cam + 6 * (size_t)c, vec, info, true, r, J);
+  const unsigned mask = P.cam_mask[c];
+  for (int q = 0; q < 6; ++q) {
+    const double sc = ((mask >> q) & 1u) ? 0.0 : P.scale_c[6 * c + q];
+    J[q] *= sc; J[6 + q] *= sc; J[12 + q] *= sc;
+  }
+  if (mode == PRIOR_COLNORM) {
+    for (int q = 0; q < 6; ++q) atomic_add(&colsq_c[6 * c + q], (J[q] * J[q] + J[6 + q] * J[6 + q]) + J[12 + q] * J[12 + q]);
+    return;
+  }
+  const int base = P.ni + 6 * rc;
+  if (mode == PRIOR_LINEARIZE) {
+    const int n = P.n;
+    for (int a = 0; a < 6; ++a) {
+      for (int b = 0; b <= a; ++b)
+        atomic_add(&S[(size_t)(base + a) * n + base + b], (J[a] * J[b] + J[6 + a] * J[6 + b]) + J[12 + a] * J[12 + b]);
+      const double jr = (J[a] * r[0] + J[6 + a] * r[1]) + J[12 + a] * r[2];
+      atomic_add(&rhs[base + a], jr);
+      atomic_add(&gc[base + a], jr);
+      atomic_add(&colsq[base + a], (J[a] * J[a] + J[6 + a] * J[6 + a]) + J[12 + a] * J[12 + a]);
+    }
+    atomic_add(scal_cost, 0.5 * ((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]));
+    return;
+  }
+  // PRIOR_TRIAL: model residual change m = -J y, mcc = -m (r + m / 2); cost at the candidate
+  double mcc = 0.0;
+  for (int a = 0; a < 3; ++a) {
+    double m = 0.0;
+    for (int q = 0; q < 6; ++q) m -= J[6 * a + q] * y[base + q];
+    mcc -= m * (r[a] + m / 2.0);
+  }
+  double rc3[3];
+  camera_prior(kind, cand + 6 * (size_t)c, vec, info, false, rc3, J);
+  atomic_add(scal_mcc, mcc);
+  atomic_add(scal_cost, 0.5 * ((rc3[0] * rc3[0] + rc3[1] * rc3[1]) + rc3[2] * rc3[2]));
+}
+
+void launch_cam_priors(const DevProblem& P, int mode, const double* cam, const double* cand_cam, const double* y,
+                       const ReduceBuf* rb, double* colsq_c, double* scal_cost, double* scal_mcc, hipStream_t st) {
+  if (P.n_priors == 0) return;
+  k_cam_priors<<<(P.n_priors + 63) / 64, 64, 0, st>>>(P, mode, cam, cand_cam, y, rb ? rb->S : nullptr, rb ? rb->rhs : nullptr,
+                                                      rb ? rb->colsq : nullptr, rb ? rb->gc : nullptr, colsq_c, scal_cost, scal_mcc);
 }
 
 void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,

@@ -117,6 +117,9 @@ struct theia_ba_handle_s {
   DevBuf<double> reduce, Vinv, gp, tile_part, scalB, chol_work;
   DevBuf<double> rec;                       // per-observation records of the gather-based Schur assembly
   DevBuf<int> diag_items, cam_obs, blk_items;
+  DevBuf<int> prior_cam, prior_kind;        // camera priors in use (compact list)
+  DevBuf<double> prior_vec, prior_info;
+  int n_priors = 0;
   DevBuf<int2> blk_pairs;
   int n_diag_items = 0, n_blk_items = 0;
   double* h_scal = nullptr;  // pinned: [scalA(16) | scalB(16)]
@@ -354,6 +357,7 @@ int validate(const theia_ba_problem* p, const theia_ba_options* o) {
   }
   if (o->intrinsics_to_optimize < 0 || o->intrinsics_to_optimize > THEIA_INTR_ALL)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "invalid intrinsics_to_optimize bit mask");
+  if (o->prior_mask < 0 || o->prior_mask > 7) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "invalid prior_mask");
   if (o->loss_function_type < 0 || o->loss_function_type > THEIA_LOSS_TRUNCATED)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "invalid loss function type");  // reference: LOG(FATAL)
   return 0;
@@ -374,6 +378,8 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.long_nobs = h->long_nobs; P.long_ntracks = h->long_ntracks;
   P.long_obs_index = h->long_obs_index.p; P.long_obs_slot = h->long_obs_slot.p;
   P.long_track_start = h->long_track_start.p; P.long_track_pt = h->long_track_pt.p;
+  P.n_priors = h->n_priors; P.prior_cam = h->prior_cam.p; P.prior_kind = h->prior_kind.p;
+  P.prior_vec = h->prior_vec.p; P.prior_info = h->prior_info.p;
   P.rec = h->rec.p; P.n_diag_items = h->n_diag_items; P.n_blk_items = h->n_blk_items;
   P.diag_items = h->diag_items.p; P.rec_slot = h->cam_obs.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
 }
@@ -441,6 +447,7 @@ int compute_scale(theia_ba_handle_s* h) {
   Q.intr = h->intr[h->cur].p;
   launch_colnorm(Q, h->cam[h->cur].p, h->pts[h->cur].p, h->colsq_c0.p, h->colsq_p0.p, h->colsq_i0.p, h->stream);
   launch_long_colnorm(Q, h->cam[h->cur].p, h->pts[h->cur].p, h->colsq_c0.p, h->colsq_p0.p, h->long_scratch.p, h->stream);
+  launch_cam_priors(Q, PRIOR_COLNORM, h->cam[h->cur].p, nullptr, nullptr, nullptr, h->colsq_c0.p, nullptr, nullptr, h->stream);
   int rc = do_allreduce(h, h->colsq_c0.p, h->colsq_c0.n, THEIA_REDUCE_SUM);
   if (!rc && h->ni) rc = do_allreduce(h, h->colsq_i0.p, h->colsq_i0.n, THEIA_REDUCE_SUM);
   if (rc) return rc;
@@ -464,6 +471,7 @@ int enqueue_linearize(theia_ba_handle_s* h, int slot = 0) {
   if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][5], h->stream));
   if (h->ntiles_main) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 4, h->f2s.p, h->fmaxflag.p, h->rb.scal, h->stream);
   launch_long_linearize(h->P, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->long_scratch.p, h->stream);
+  launch_cam_priors(h->P, PRIOR_LINEARIZE, h->cam[h->cur].p, nullptr, nullptr, &h->rb, nullptr, h->rb.scal + SC_COST, nullptr, h->stream);
   // one SUM all-reduce of [S | rhs | colsq | gc | scal[0,8)], one MAX of scal[8,16)
   int rc = 0;
   if (h->allreduce && h->n_pack_tiles > 0 && h->n > 0) {
@@ -493,6 +501,7 @@ int enqueue_solve_and_backsub(theia_ba_handle_s* h, int slot = 0) {
   launch_backsub(h->P, h->cam[h->cur].p, h->pts[h->cur].p, h->cam[nxt].p, h->pts[nxt].p, yc, h->Vinv.p, h->tile_part.p, h->scalB.p, h->stream);
   if (h->ntiles_main) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 5, h->f2s.p + 8, h->fmaxflag.p + 8, h->scalB.p, h->stream);
   launch_long_backsub(h->P, h->cam[h->cur].p, h->pts[h->cur].p, h->cam[nxt].p, h->pts[nxt].p, yc, h->Vinv.p, h->long_scratch.p, h->scalB.p, h->stream);
+  launch_cam_priors(h->P, PRIOR_TRIAL, h->cam[h->cur].p, h->cam[nxt].p, yc, nullptr, nullptr, h->scalB.p + SB_COST, h->scalB.p + SB_MCC, h->stream);
   return do_allreduce(h, h->scalB.p, 8, THEIA_REDUCE_SUM);
 }
 
@@ -710,6 +719,25 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   AL(tile_part, (size_t)5 * std::max(1, h->ntiles_all)); AL(scalB, 16);
   AL(chol_work, dense_cholesky_workspace(h->n));
   AL(lm_state, sizeof(LmState)); AL(lm_ctl, sizeof(LmCtl));
+  {
+    // camera priors in use: the camera's bit AND the option's bit (bundle_adjuster.cc:159-172,291-313)
+    std::vector<int> pc, pk;
+    std::vector<double> pv, pi;
+    if (p->cam_prior_mask && o->prior_mask) {
+      const double* vecs[3] = {p->cam_position_prior, p->cam_gravity_prior, p->cam_orientation_prior};
+      const double* infos[3] = {p->cam_position_prior_sqrt_info, p->cam_gravity_prior_sqrt_info, p->cam_orientation_prior_sqrt_info};
+      for (int c = 0; c < h->nc; ++c)
+        for (int k = 0; k < 3; ++k) {
+          const int bit = 1 << k;
+          if (!(p->cam_prior_mask[c] & bit) || !(o->prior_mask & bit) || !vecs[k] || !infos[k]) continue;
+          pc.push_back(c); pk.push_back(bit);
+          pv.insert(pv.end(), vecs[k] + 3 * (size_t)c, vecs[k] + 3 * (size_t)c + 3);
+          pi.insert(pi.end(), infos[k] + 9 * (size_t)c, infos[k] + 9 * (size_t)c + 9);
+        }
+    }
+    h->n_priors = (int)pc.size();
+    UP(prior_cam, pc); UP(prior_kind, pk); UP(prior_vec, pv); UP(prior_info, pi);
+  }
   {
     // tile co-visibility: two 64-wide tiles of S couple iff a variable track is
     // seen by cameras of both (the Schur complement's block structure)
@@ -933,6 +961,14 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   double fc = 0.0, inv = 0.0;
   rc = cost_of_tiles(h, h->ntiles_eval, h->ntiles_all - h->ntiles_eval, h->cam[0].p, h->pts[0].p, &fc, &inv);
   if (rc) return rc;
+  if (h->n_priors) {   // priors on constant cameras: residual blocks without variable parameters
+    double pf = 0.0;
+    HIP_TRY(hipMemsetAsync(h->scalB.p, 0, sizeof(double) * 16, h->stream));
+    launch_cam_priors(h->P, PRIOR_FIXED, h->cam[0].p, nullptr, nullptr, nullptr, nullptr, h->scalB.p, nullptr, h->stream);
+    HIP_TRY(hipMemcpyAsync(&pf, h->scalB.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    fc += pf;
+  }
   h->fixed_cost = fc;
   *out = guard.release();
   return 0;
@@ -951,7 +987,7 @@ int theia_hip_ba_set_options(theia_ba_handle h, const theia_ba_options* o) {
   if (o->use_homogeneous_point_parametrization != c.use_homogeneous_point_parametrization ||
       o->constant_camera_orientation != c.constant_camera_orientation ||
       o->constant_camera_position != c.constant_camera_position || o->orthographic_camera != c.orthographic_camera ||
-      o->intrinsics_to_optimize != c.intrinsics_to_optimize)
+      o->intrinsics_to_optimize != c.intrinsics_to_optimize || o->prior_mask != c.prior_mask)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "structural options differ from the ones the handle was created with");
   if (o->loss_function_type < 0 || o->loss_function_type > THEIA_LOSS_TRUNCATED)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "invalid loss function type");
@@ -1150,6 +1186,7 @@ int theia_hip_ba_evaluate_ex(theia_ba_handle h, double* cost, double* residuals,
   HIP_TRY(hipMemsetAsync(h->scalB.p, 0, sizeof(double) * 16, h->stream));
   launch_evaluate(Q, h->cam[h->cur].p, h->pts[h->cur].p, dr.p, djc.p, djp.p, dv.p, h->tile_part.p, h->stream, want_ji ? dji.p : nullptr);
   if (h->ntiles_eval) launch_reduce_tiles(h->ntiles_eval, h->tile_part.p, 2, h->f2s.p + 16, h->fmaxflag.p + 16, h->scalB.p, h->stream);
+  launch_cam_priors(Q, PRIOR_COST, h->cam[h->cur].p, nullptr, nullptr, nullptr, nullptr, h->scalB.p + SB_COST, nullptr, h->stream);
   std::vector<double> hr(2 * nm), hjc(12 * nm), hjp(2 * pd * nm); std::vector<uint8_t> hv(nm);
   if (nm) {
     HIP_TRY(hipMemcpyAsync(hr.data(), dr.p, sizeof(double) * hr.size(), hipMemcpyDeviceToHost, h->stream));

@@ -94,8 +94,7 @@ class BundleAdjustmentOptions:
         self.use_gravity_priors = False
 
     def to_c(self):
-        unsupported = [n for n in ("use_inverse_depth_parametrization", "use_position_priors",
-                                   "use_orientation_priors", "use_depth_priors", "use_gravity_priors",
+        unsupported = [n for n in ("use_inverse_depth_parametrization", "use_depth_priors",
                                    "optimize_for_forward_facing_trajectory") if getattr(self, n)]
         if unsupported:
             raise capi.TheiaHipError(-3, "options not built in the HIP backend yet: " + ", ".join(unsupported))
@@ -103,6 +102,9 @@ class BundleAdjustmentOptions:
         o.loss_function_type = int(self.loss_function_type)
         o.robust_loss_width = float(self.robust_loss_width)
         o.intrinsics_to_optimize = int(self.intrinsics_to_optimize)
+        o.prior_mask = ((capi.THEIA_PRIOR_POSITION if self.use_position_priors else 0) |
+                        (capi.THEIA_PRIOR_GRAVITY if self.use_gravity_priors else 0) |
+                        (capi.THEIA_PRIOR_ORIENTATION if self.use_orientation_priors else 0))
         o.max_num_iterations = int(self.max_num_iterations)
         o.use_homogeneous_point_parametrization = int(bool(self.use_homogeneous_point_parametrization))
         o.constant_camera_orientation = int(bool(self.constant_camera_orientation))
@@ -149,6 +151,9 @@ class Reconstruction:
         self.obs_track = np.zeros(0, dtype=np.int32)
         self.obs_uv = np.zeros((0, 2))
         self.obs_cov = np.zeros((0, 2))  # diagonal of Feature::covariance_
+        # View::{Position,Gravity,Orientation}Prior (+ sqrt information), view.h; mask bits = capi.THEIA_PRIOR_*
+        self.view_prior_mask = None
+        self.view_priors = {}
 
     @classmethod
     def from_flat(cls, p):
@@ -219,10 +224,15 @@ def _flatten(recon, view_ids, track_ids, const_view_ids=()):
     cov = recon.obs_cov[keep]
     if len(cov) and not np.all(cov == 1.0):
         sqrt_info = 1.0 / np.sqrt(cov)
-    return capi.FlatProblem(recon.cam_ext.copy(), recon.group_intrinsics.copy(), recon.group_model,
+    flat = capi.FlatProblem(recon.cam_ext.copy(), recon.group_intrinsics.copy(), recon.group_model,
                             recon.view_group, recon.points.copy(), recon.obs_uv[keep], ov[keep], ot[keep],
                             cam_const=cam_const, group_const=group_const, point_const=point_const,
                             obs_sqrt_info=sqrt_info)
+    if recon.view_prior_mask is not None:
+        # priors are added for the views that went through AddView (bundle_adjuster.cc:159-172)
+        mask = np.where(view_added, recon.view_prior_mask, 0).astype(np.uint8)
+        flat.set_priors(mask, **recon.view_priors)
+    return flat
 
 
 def capi_const_all():

@@ -276,3 +276,16 @@ def ransac_estimate(est, data, params, trace_capacity=0):
     return {"success": ok, "model": model, "inlier_mask": mask, "num_inliers": ninl.value, "num_iterations": nit.value,
             "confidence": conf.value, "models_scored": scored.value,
             "trace": (ti[:k].copy(), tc[:k].copy(), tn[:k].copy())}
+
+
+def camera_prior(kind, ext, prior, sqrt_info):
+    """Residual (3) and Jacobian (3 x 6) of one camera prior through the oracle's Jets."""
+    L = load()
+    dp = capi.c_double_p
+    L.oracle_camera_prior.argtypes = [C.c_int, dp, dp, dp, dp, dp]
+    ext = np.ascontiguousarray(ext, dtype=np.float64); prior = np.ascontiguousarray(prior, dtype=np.float64)
+    S = np.ascontiguousarray(sqrt_info, dtype=np.float64)
+    r = np.zeros(3); J = np.zeros((3, 6))
+    L.oracle_camera_prior(int(kind), capi.ptr(ext, C.c_double), capi.ptr(prior, C.c_double), capi.ptr(S, C.c_double),
+                          capi.ptr(r, C.c_double), capi.ptr(J, C.c_double))
+    return r, J

@@ -615,3 +615,63 @@ def test_tracks_batch_matches_per_track_oracle(manifold):
         assert abs(s.initial_cost - so.initial_cost) <= 1e-10 * so.initial_cost and abs(s.final_cost - so.final_cost) <= 1e-9 * so.final_cost
         assert np.abs(pg.points[q] - fp.points[0]).max() <= 1e-9
     assert np.mean([s.final_cost < s.initial_cost for s in summ if s.num_iterations]) > 0.9
+
+
+def _with_priors(p, seed, kinds=7):
+    """position (GPS-like), gravity and orientation priors on most cameras, ~1 % off the truth."""
+    nc = p.cam_ext.shape[0]
+    st = synth.Stream(seed, 3)
+    i = np.arange(nc)
+    mask = np.where(i % 5 == 4, 0, kinds).astype(np.uint8)          # every fifth camera has none
+    mask[1] = kinds & 1
+    pos = p.cam_ext[:, :3] + 0.02 * np.stack([st.normal(3 * i), st.normal(3 * i + 1), st.normal(3 * i + 2)], 1)
+    R = synth.angle_axis_to_matrix(p.cam_ext[:, 3:])
+    grav = R @ np.array([0, 0, -1.0]) + 0.005 * np.stack([st.normal(3 * i + 100), st.normal(3 * i + 101), st.normal(3 * i + 102)], 1)
+    ori = p.cam_ext[:, 3:] + 0.003 * np.stack([st.normal(3 * i + 200), st.normal(3 * i + 201), st.normal(3 * i + 202)], 1)
+    def info(scale, off):
+        A = np.tile(np.eye(3) * scale, (nc, 1, 1))
+        A[:, 0, 1] = 0.1 * scale * st.normal(i + off); A[:, 2, 0] = -0.2 * scale * st.normal(i + off + 50)
+        return A
+    p.set_priors(mask, position=(pos, info(20.0, 300)), gravity=(grav, info(50.0, 400)), orientation=(ori, info(80.0, 500)))
+    return p
+
+
+@pytest.mark.parametrize("kinds", [1, 2, 4, 7])
+def test_camera_priors_match_oracle(kinds):
+    """A12: position / gravity / orientation priors (3 residuals on the extrinsics, no loss): cost, reduced
+    system (closed-form Jacobians vs Jets), LM trajectory and result vs the oracle; masks and constant cameras."""
+    p = _with_priors(synth.synth_ba_v1(14, 400, seed=0x9A11), 0x9A12)
+    p.cam_const = np.zeros(14, np.uint8); p.cam_const[0] = 3; p.cam_const[2] = 1; p.cam_const[3] = 2
+    o, oo = both_options(prior_mask=kinds, max_num_iterations=15)
+    with ba.BaHandle(p.copy(), o) as h:
+        cost, r, jc, jp, valid = h.evaluate()
+        S, rhs = h.reduced_system(1e4)
+    ok, ocost, orr, ojc, ojp = ol.evaluate(p, oo)
+    assert ocost > ol.evaluate(p, ol.default_options())[1] + 1e-2            # the priors contribute
+    assert abs(cost - ocost) <= 1e-12 * ocost
+    So, ro = ol.reduced_system(p, oo, 1e4)
+    assert rel(S, So) <= 1e-9 and rel(rhs, ro) <= 1e-9
+    pg, po = p.copy(), p.copy()
+    s, tr = ba.solve(pg, o)
+    so, tro = ol.solve(po, oo)
+    assert s.success and s.num_iterations == so.num_iterations and np.array_equal(tr.accepted, tro.accepted)
+    assert rel(tr.cost, tro.cost) <= 1e-8 and abs(s.final_cost - so.final_cost) <= 1e-9 * so.final_cost
+    assert np.abs(pg.cam_ext - po.cam_ext).max() <= 1e-7 and np.abs(pg.points - po.points).max() <= 1e-6
+    assert np.array_equal(pg.cam_ext[0], p.cam_ext[0])
+    # priors pull: without them the result differs
+    q = p.copy(); s0, _ = ba.solve(q, ba.default_options())
+    assert np.abs(q.cam_ext - pg.cam_ext).max() > 1e-6
+
+
+def test_camera_priors_through_the_mirror():
+    p = synth.synth_ba_v1(10, 300, seed=0x9A13)
+    _with_priors(p, 0x9A14)
+    rec = sfm.Reconstruction.from_flat(p)
+    rec.view_prior_mask = p.cam_prior_mask.copy(); rec.view_priors = dict(p.priors)
+    opts = sfm.BundleAdjustmentOptions(); opts.use_position_priors = True; opts.use_gravity_priors = True
+    s = sfm.BundleAdjustReconstruction(opts, rec)
+    flat = sfm._flatten(sfm.Reconstruction.from_flat(p), range(10), range(300))
+    flat.set_priors(p.cam_prior_mask, **p.priors)
+    oo = ol.default_options(); oo.prior_mask = 3
+    so, _ = ol.solve(flat, oo)
+    assert s.success and abs(s.final_cost - so.final_cost) <= 1e-8 * so.final_cost

@@ -62,7 +62,9 @@ def test_options_mirror_defaults_and_unsupported():
     o = sfm.BundleAdjustmentOptions()
     assert o.loss_function_type == sfm.LossFunctionType.TRIVIAL and o.use_inner_iterations and o.max_num_iterations == 100
     assert o.intrinsics_to_optimize == sfm.OptimizeIntrinsicsType.NONE and o.use_homogeneous_point_parametrization
-    o.use_position_priors = True
+    o.use_position_priors = True; o.use_orientation_priors = True
+    assert o.to_c().prior_mask == (capi.THEIA_PRIOR_POSITION | capi.THEIA_PRIOR_ORIENTATION)
+    o.use_depth_priors = True                      # depth priors / inverse depth: not built -> explicit error
     with pytest.raises(capi.TheiaHipError):
         o.to_c()
 

@@ -242,3 +242,29 @@ def test_golden_ba_fixture():
     assert s.num_iterations == int(g["num_iterations"])
     assert np.abs(tr.cost - g["trace_cost"]).max() <= 1e-9 * g["trace_cost"].max()
     assert np.abs(p.cam_ext - g["cam_ext_final"]).max() < 1e-9 and np.abs(p.points - g["points_final"]).max() < 1e-9
+
+
+def test_camera_prior_functors_against_finite_differences_and_closed_forms():
+    """position_error.h / gravity_error.h / orientation_error.h restated with Jets: central differences,
+    and the rotation-matrix form of the orientation residual log(R(w) R(w_prior)^T)."""
+    st = synth.Stream(0x9A10, 0)
+    for trial in range(6):
+        ext = np.concatenate([4 * st.uniform(np.arange(3) + 20 * trial) - 2, (1.5 if trial < 5 else 1e-7) * (2 * st.uniform(np.arange(3) + 20 * trial + 3) - 1)])
+        prior = 2 * st.uniform(np.arange(3) + 20 * trial + 6) - 1
+        S = (2 * st.uniform(np.arange(9) + 20 * trial + 9) - 1).reshape(3, 3) + 2 * np.eye(3)
+        for kind in (1, 2, 4):
+            r, J = ol.camera_prior(kind, ext, prior, S)
+            for q in range(6):
+                hq = 1e-6
+                ep, em = ext.copy(), ext.copy()
+                ep[q] += hq; em[q] -= hq
+                fd = (ol.camera_prior(kind, ep, prior, S)[0] - ol.camera_prior(kind, em, prior, S)[0]) / (2 * hq)
+                assert np.abs(fd - J[:, q]).max() <= 2e-8 * max(1.0, np.abs(J).max()), (kind, q)
+            R = synth.angle_axis_to_matrix(ext[3:])
+            if kind == 1:
+                assert np.abs(r - S @ (prior - ext[:3])).max() <= 1e-14
+            elif kind == 2:
+                assert np.abs(r - S @ (R @ np.array([0, 0, -1.0]) - prior)).max() <= 1e-14
+            else:
+                E = R @ synth.angle_axis_to_matrix(prior).T
+                assert np.abs(r - S @ synth.matrix_to_angle_axis(E)).max() <= 1e-12
