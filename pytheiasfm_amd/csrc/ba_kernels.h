@@ -48,6 +48,7 @@ struct DevProblem {
   // static lists built at create()
   double* rec;                 // [#records][12*pd + 20] per-observation record {W | T | F | r | T g}, camera-major
   const int* rec_slot;         // [nobs_main] record slot of a (sorted) observation, -1 = none
+  const int* slot_obs;         // [#records] inverse: (sorted) observation of a record slot
   int n_diag_items, n_blk_items;
   const int* diag_items;       // [n_diag_items][4] {rc, first slot, end slot, atomic}
   const int* blk_items;        // [n_blk_items][5] {ri, rj, beg, end, atomic}

@@ -46,6 +46,10 @@ THIP_DEV double wave_max(double v) {
 
 THIP_DEV void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
+// item types / flags of the gather lists (see "gather-based Schur assembly with intrinsics")
+enum { IT_CC = 0, IT_CG = 1, IT_GG0 = 2, IT_GG1 = 3, IT_CD = 4, IT_CGD = 5, IT_GD0 = 6, IT_GD1 = 7, IT_GV = 8 };
+enum { ITF_ATOMIC = 1, ITF_LOWER = 2 };
+
 template <int PD, bool INTR = false>
 struct LaneLin {
   double r[2];
@@ -265,8 +269,9 @@ __global__ __launch_bounds__(kBlock) void k_colnorm(DevProblem P, const double* 
   LaneLin<PD, INTR> L;
   lane_linearize<PD, true, INTR>(P, cam, pts, start + lane, lane < cnt, lane, L);
   const Segment sg = lane_segment(L.p, lane);
+  const bool gather = P.slot_obs != nullptr;   // camera / intrinsics columns: k_colnorm_gather (no atomics)
   if constexpr (INTR) {
-    if (L.active && L.gr >= 0) {
+    if (!gather && L.active && L.gr >= 0) {
 #pragma unroll
       for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) {
         const double v = L.Jk[q] * L.Jk[q] + L.Jk[THEIA_MAX_INTRINSICS + q] * L.Jk[THEIA_MAX_INTRINSICS + q];
@@ -282,9 +287,63 @@ __global__ __launch_bounds__(kBlock) void k_colnorm(DevProblem P, const double* 
 #pragma unroll
     for (int q = 0; q < PD; ++q) colsq_p[(size_t)PD * L.p + q] = out[q];
   }
-  if (L.active && L.rc >= 0) {
+  if (!gather && L.active && L.rc >= 0) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) atomic_add(&colsq_c[6 * L.c + q], L.Jc[q] * L.Jc[q] + L.Jc[6 + q] * L.Jc[6 + q]);
+  }
+}
+
+// Column norms of the camera (and intrinsics) blocks by the gather lists: one workgroup per contiguous
+// record range of a camera / group (the diagonal items of the Schur assembly); the lanes re-linearise the
+// range's observations and the workgroup sums 6 (10) squared column norms.  Replaces 6 global FP64 atomics
+// per observation onto a few hundred addresses.
+template <int PD, bool INTR>
+__global__ __launch_bounds__(kBlock) void k_colnorm_gather(DevProblem P, const double* __restrict__ cam,
+                                                           const double* __restrict__ pts,
+                                                           double* __restrict__ colsq_c, double* __restrict__ colsq_i) {
+  __shared__ double part[kWavesPerBlock][16];
+  __shared__ int s_idx;
+  int beg, end, atomic, group_item = 0;
+  if constexpr (INTR) {
+    const int* it = P.blk_items + 6 * blockIdx.x;
+    if (it[0] != IT_CD && it[0] != IT_GV) return;
+    group_item = it[0] == IT_GV;
+    beg = it[3]; end = it[4]; atomic = it[5] & ITF_ATOMIC;
+  } else {
+    if ((int)blockIdx.x >= P.n_diag_items) return;
+    const int* it = P.diag_items + 4 * blockIdx.x;
+    beg = it[1]; end = it[2]; atomic = it[3];
+  }
+  constexpr int NV = INTR ? 10 : 6;
+  double acc[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int q = beg + threadIdx.x; q < end; q += kBlock) {
+    LaneLin<PD, INTR> L;
+    lane_linearize<PD, true, INTR>(P, cam, pts, P.slot_obs[q], true, lane, L);
+    if (q == beg) s_idx = group_item ? L.g : L.c;
+    if (group_item) {
+      if constexpr (INTR) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[k] += L.Jk[k] * L.Jk[k] + L.Jk[10 + k] * L.Jk[10 + k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] += L.Jc[k] * L.Jc[k] + L.Jc[6 + k] * L.Jc[6 + k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) part[wv][k] = v;
+  }
+  __syncthreads();
+  const int nv = group_item ? 10 : 6;
+  if ((int)threadIdx.x < nv) {
+    const double v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    double* dst = group_item ? &colsq_i[(size_t)s_idx * THEIA_MAX_INTRINSICS + threadIdx.x] : &colsq_c[6 * (size_t)s_idx + threadIdx.x];
+    if (atomic) atomic_add(dst, v); else *dst = v;
   }
 }
 
@@ -553,8 +612,6 @@ __global__ __launch_bounds__(kBlock) void k_schur(DevProblem P, double* __restri
 //     CGD  F^T Fk - T WI^T            -> S[cam, grp of cam]
 //     GD0/GD1  Fk^T Fk - TI WI^T (rows)-> S[grp, grp]   GV  Fk^T r - TI g | Fk^T r | column norms
 // Reduced index: intrinsics slots first (10 per variable group), cameras at ni + 6 rc.
-enum { IT_CC = 0, IT_CG = 1, IT_GG0 = 2, IT_GG1 = 3, IT_CD = 4, IT_CGD = 5, IT_GD0 = 6, IT_GD1 = 7, IT_GV = 8 };
-enum { ITF_ATOMIC = 1, ITF_LOWER = 2 };
 
 template <int PD> constexpr int rec_stride_intr() { return 32 * PD + 50; }
 template <int PD> struct RecI {   // offsets in double2 units
@@ -864,28 +921,35 @@ __global__ __launch_bounds__(1024) void k_reduce_tiles(int ntiles, const double*
                                                        int nfields, const int* __restrict__ f2s,
                                                        const int* __restrict__ fmaxflag,
                                                        double* __restrict__ scal) {
-  __shared__ double sm[1024];
-  for (int f = 0; f < nfields; ++f) {
-    const bool ismax = fmaxflag[f] != 0;
-    double acc = 0.0;
-    for (int t = threadIdx.x; t < ntiles; t += 1024) {
-      const double v = part[(size_t)t * nfields + f];
-      acc = ismax ? fmax(acc, v) : acc + v;
-    }
-    sm[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-      if ((int)threadIdx.x < s) {
-        const double o = sm[threadIdx.x + s];
-        sm[threadIdx.x] = ismax ? fmax(sm[threadIdx.x], o) : sm[threadIdx.x] + o;
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      if (ismax) scal[f2s[f]] = fmax(scal[f2s[f]], sm[0]);
-      else scal[f2s[f]] += sm[0];
-    }
-    __syncthreads();
+  // every thread folds its tiles for ALL fields (independent loads in flight), a wave shuffle tree per
+  // field, then the 16 wave results are combined by wave 0: fixed order, one __syncthreads
+  __shared__ double sm[8][16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double acc[8];
+  bool ismax[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) { acc[f] = 0.0; ismax[f] = f < nfields && fmaxflag[f] != 0; }
+  for (int t = threadIdx.x; t < ntiles; t += 1024) {
+    const double* row = part + (size_t)t * nfields;
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+      if (f < nfields) { const double v = row[f]; acc[f] = ismax[f] ? fmax(acc[f], v) : acc[f] + v; }
+  }
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    if (f >= nfields) break;
+    double v = acc[f];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, kWave); v = ismax[f] ? fmax(v, o) : v + o; }
+    if (lane == 0) sm[f][wv] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < (unsigned)nfields) {
+    const int f = threadIdx.x;
+    double v = sm[f][0];
+    for (int w = 1; w < 16; ++w) v = ismax[f] ? fmax(v, sm[f][w]) : v + sm[f][w];
+    if (ismax[f]) scal[f2s[f]] = fmax(scal[f2s[f]], v);
+    else scal[f2s[f]] += v;
   }
 }
 
@@ -1349,6 +1413,14 @@ void launch_colnorm(const DevProblem& P, const double* cam, const double* pts, d
   } else {
     if (P.pd == 3) k_colnorm<3, false><<<nb, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_p, colsq_i);
     else k_colnorm<4, false><<<nb, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_p, colsq_i);
+  }
+  if (!P.slot_obs) return;
+  if (P.ni && P.n_blk_items) {
+    if (P.pd == 3) k_colnorm_gather<3, true><<<P.n_blk_items, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_i);
+    else k_colnorm_gather<4, true><<<P.n_blk_items, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_i);
+  } else if (!P.ni && P.n_diag_items) {
+    if (P.pd == 3) k_colnorm_gather<3, false><<<P.n_diag_items, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_i);
+    else k_colnorm_gather<4, false><<<P.n_diag_items, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_i);
   }
 }
 

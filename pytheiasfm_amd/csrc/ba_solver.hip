@@ -116,7 +116,7 @@ struct theia_ba_handle_s {
   DevBuf<double2> obs_uv, obs_si;
   DevBuf<double> reduce, Vinv, gp, tile_part, scalB, chol_work;
   DevBuf<double> rec;                       // per-observation records of the gather-based Schur assembly
-  DevBuf<int> diag_items, cam_obs, blk_items;
+  DevBuf<int> diag_items, cam_obs, blk_items, slot_obs;
   DevBuf<int> prior_cam, prior_kind;        // camera priors in use (compact list)
   DevBuf<double> prior_vec, prior_info;
   int n_priors = 0;
@@ -381,7 +381,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.n_priors = h->n_priors; P.prior_cam = h->prior_cam.p; P.prior_kind = h->prior_kind.p;
   P.prior_vec = h->prior_vec.p; P.prior_info = h->prior_info.p;
   P.rec = h->rec.p; P.n_diag_items = h->n_diag_items; P.n_blk_items = h->n_blk_items;
-  P.diag_items = h->diag_items.p; P.rec_slot = h->cam_obs.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
+  P.diag_items = h->diag_items.p; P.rec_slot = h->cam_obs.p; P.slot_obs = h->slot_obs.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
 }
 
 int upload_parameters(theia_ba_handle_s* h, const theia_ba_problem* p) {
@@ -852,6 +852,11 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     }
     h->n_diag_items = (int)ditems.size() / 4; h->n_blk_items = (int)bitems.size() / 5;
     for (auto& pr : pairs) { pr.x = cam_obs[pr.x]; pr.y = cam_obs[pr.y]; }
+    {
+      std::vector<int> sobs(std::max(1, dbeg[h->ncv]), 0);
+      for (int64_t s2 = 0; s2 < nm; ++s2) if (cam_obs[s2] >= 0) sobs[cam_obs[s2]] = (int)s2;
+      UP(slot_obs, sobs);
+    }
     UP(diag_items, ditems); UP(cam_obs, cam_obs); UP(blk_items, bitems); UP(blk_pairs, pairs);
     AL(rec, (size_t)std::max(1, dbeg[h->ncv]) * (12 * h->pd + 20));
   }
@@ -949,6 +954,11 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
       q = e;
     }
     h->n_diag_items = 0; h->n_blk_items = (int)items.size() / 6;
+    {
+      std::vector<int> sobs(order.begin(), order.end());
+      if (sobs.empty()) sobs.push_back(0);
+      UP(slot_obs, sobs);
+    }
     UP(cam_obs, slot); UP(blk_items, items); UP(blk_pairs, pairs);
     AL(rec, (size_t)std::max<size_t>(1, order.size()) * (32 * h->pd + 50));
   }
