@@ -50,5 +50,113 @@ def main():
     print("wrote ba_small.npz, ransac_small.npz")
 
 
+
+
+# ---------------------------------------------------------------- second set
+# camera_models.npz   per camera model 64 (extrinsics, intrinsics, point, pixel) tuples, edge cases included
+#                     (small rotation angle, point behind / beside the camera, homogeneous w != 1, double-sphere
+#                     and EUCM invalid regions): functor return value, residual and the three Jacobian blocks.
+# ba_variants.npz     a 10-view scene solved three ways: intrinsics FOCAL|RADIAL, camera priors, HUBER loss with
+#                     partially constant cameras: LM traces and final parameters.
+# ransac_variants.npz SQPnP solutions of fixed inputs; PROSAC / LMED / LO-RANSAC runs (masks, models, iterations).
+CAMERA_MODEL_INTRINSICS = {
+    0: [900.0, 1.02, 0.001, 640.0, 360.0, -0.05, 0.01],
+    1: [850.0, 0.98, 0.002, 600.0, 400.0, -0.04, 0.008, 0.0005, 0.001, -0.0007],
+    2: [500.0, 1.01, 0.0, 640.0, 480.0, -0.01, 0.002, -0.0003, 0.00004],
+    3: [700.0, 1.0, 640.0, 360.0, 0.6],
+    4: [800.0, 1.0, 640.0, 360.0, -1e-7],
+    5: [600.0, 1.0, 0.0, 640.0, 360.0, -0.2, 0.55],
+    6: [600.0, 1.0, 0.0, 640.0, 360.0, 0.6, 1.1],
+    7: [1.5, 1.0, 0.0, 320.0, 240.0, 0.01, 0.001],   # (magnification >= 1: the focal-length bound, bundle_adjuster.cc:406)
+}
+
+
+def second_set():
+    out = {}
+    for model, k in CAMERA_MODEL_INTRINSICS.items():
+        st = synth.Stream(0x601D00 + model, 0)
+        n = 64
+        ext = np.zeros((n, 6)); X = np.zeros((n, 4)); uv = np.zeros((n, 2))
+        for i in range(n):
+            u = st.uniform(np.arange(16) + 100 * i)
+            ext[i, :3] = 2 * u[0:3] - 1
+            ext[i, 3:] = (0.8 if i % 8 else 1e-9) * (2 * u[3:6] - 1)          # every 8th: small-angle branch
+            w = 1.0 if i % 4 else 0.25 + 2 * u[6]
+            depth = (4 + 6 * u[7]) if i % 16 != 5 else -(1 + u[7])             # some behind the camera
+            lateral = 1.5 if i % 16 != 9 else 40.0                              # some far off axis (invalid regions)
+            Xc = np.array([lateral * (2 * u[8] - 1), lateral * (2 * u[9] - 1), depth])
+            R = synth.angle_axis_to_matrix(ext[i, 3:])
+            X[i, :3] = w * (R.T @ Xc + ext[i, :3]); X[i, 3] = w
+            uv[i] = [1280 * u[10], 720 * u[11]]
+        ok = np.zeros(n, dtype=np.uint8); res = np.zeros((n, 2)); Je = np.zeros((n, 2, 6)); Ji = np.zeros((n, 2, len(k))); Jp = np.zeros((n, 2, 4))
+        for i in range(n):
+            o, r, a, b, c = ol.reprojection_error(model, ext[i], k, X[i], uv[i], sqrt_info=[1.0 + 0.1 * (i % 3), 0.9])
+            ok[i] = 1 if o else 0; res[i] = r; Je[i] = a; Ji[i] = b; Jp[i] = c
+        for name, arr in (("ext", ext), ("X", X), ("uv", uv), ("ok", ok), ("res", res), ("Je", Je), ("Ji", Ji), ("Jp", Jp)):
+            out[f"m{model}_{name}"] = arr
+        out[f"m{model}_intr"] = np.array(k)
+    np.savez_compressed(os.path.join(HERE, "camera_models.npz"), **out)
+
+    # BA variants
+    out = {}
+    base = synth.synth_ba_v1(10, 150, seed=0xBA5E0400, num_groups=3, mixed_models=True)
+    for name, kw in (("intr", dict(intrinsics_to_optimize=0x11)), ("priors", dict(prior_mask=7)), ("huber", dict(loss_function_type=1, robust_loss_width=1.5))):
+        p = base.copy()
+        if name == "priors":
+            nc = 10
+            i = np.arange(nc)
+            mask = np.where(i % 4 == 3, 0, 7).astype(np.uint8)
+            pos = p.cam_ext[:, :3] + 0.03 * np.sin(1.0 + i)[:, None]
+            grav = synth.angle_axis_to_matrix(p.cam_ext[:, 3:]) @ np.array([0, 0, -1.0]) + 0.01 * np.cos(i)[:, None]
+            ori = p.cam_ext[:, 3:] + 0.004 * np.sin(2.0 * i)[:, None]
+            info = lambda s: np.tile(np.eye(3) * s + 0.05 * s * np.array([[0, 1, 0], [0, 0, 0], [-1, 0, 0]]), (nc, 1, 1))
+            p.set_priors(mask, position=(pos, info(20.0)), gravity=(grav, info(50.0)), orientation=(ori, info(80.0)))
+            for key, (v, s_) in p.priors.items():
+                out[f"priors_{key}"] = v; out[f"priors_{key}_info"] = s_
+            out["priors_mask"] = mask
+        if name == "huber":
+            p.cam_const = np.array([3, 0, 1, 2, 0, 4, 0, 0, 0, 0], dtype=np.uint8)
+            p.obs_uv = p.obs_uv.copy(); p.obs_uv[::11] += 30.0
+            out["huber_cam_const"] = p.cam_const; out["huber_obs_uv"] = p.obs_uv
+        o = ol.default_options()
+        for kk, vv in kw.items():
+            setattr(o, kk, vv)
+        o.max_num_iterations = 25
+        s, tr = ol.solve(p, o)
+        out[f"{name}_trace_cost"] = tr.cost; out[f"{name}_trace_accepted"] = tr.accepted; out[f"{name}_trace_radius"] = tr.radius
+        out[f"{name}_cam_ext"] = p.cam_ext; out[f"{name}_points"] = p.points; out[f"{name}_intrinsics"] = p.intrinsics
+        out[f"{name}_final_cost"] = s.final_cost; out[f"{name}_num_iterations"] = s.num_iterations
+    for key in ("cam_ext", "intrinsics", "group_model", "cam_group", "points", "obs_uv", "obs_cam", "obs_pt"):
+        out[f"base_{key}"] = getattr(base, key)
+    np.savez_compressed(os.path.join(HERE, "ba_variants.npz"), **out)
+
+    # RANSAC variants
+    out = {}
+    st = synth.Stream(0x601D50, 0)
+    for k, n in enumerate((3, 4, 12, 100)):
+        i = np.arange(n)
+        X = np.stack([4 * st.uniform(1000 * k + 3 * i) - 2, 4 * st.uniform(1000 * k + 3 * i + 1) - 2, 6 + 4 * st.uniform(1000 * k + 3 * i + 2)], 1)
+        R = synth.angle_axis_to_matrix(np.array([0.12 * (k + 1), -0.07, 0.03 * k])); t = np.array([0.3, -0.2, 0.4])
+        pc = X @ R.T + t
+        uv = pc[:, :2] / pc[:, 2:] + 5e-4 * np.stack([st.normal(1000 * k + 2 * i + 500), st.normal(1000 * k + 2 * i + 501)], 1)
+        q, ts = ol.sqpnp(uv, X)
+        out[f"sqpnp{k}_uv"] = uv; out[f"sqpnp{k}_X"] = X; out[f"sqpnp{k}_q"] = q; out[f"sqpnp{k}_t"] = ts
+    data, offsets, _ = synth.synth_ransac_v1(3, 150, "absolute", seed=0x5AC50A00, noise_px=1.0)
+    out["abs_data"] = data; out["abs_offsets"] = offsets
+    for name, est, setup in (("prosac", 2, dict(ransac_type=1)), ("lmed", 2, dict(ransac_type=2, min_iterations=120, max_iterations=200)),
+                             ("sqpnp", 4, dict()), ("lo", 2, dict(use_lo=1, lo_start_iterations=5, min_iterations=50, use_mle=1))):
+        masks, models, iters = [], [], []
+        for i in range(3):
+            prm = ol.default_ransac_params((4 / 1000.0) ** 2, 66 + i)
+            for kk, vv in setup.items():
+                setattr(prm, kk, vv)
+            r = ol.ransac_estimate(est, data[offsets[i]:offsets[i + 1]], prm)
+            masks.append(r["inlier_mask"]); models.append(r["model"][:12]); iters.append(r["num_iterations"])
+        out[f"{name}_masks"] = np.stack(masks); out[f"{name}_models"] = np.stack(models); out[f"{name}_iters"] = np.array(iters)
+    np.savez_compressed(os.path.join(HERE, "ransac_variants.npz"), **out)
+    print("wrote camera_models.npz, ba_variants.npz, ransac_variants.npz")
+
+
 if __name__ == "__main__":
     main()
+    second_set()

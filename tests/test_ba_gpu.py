@@ -675,3 +675,44 @@ def test_camera_priors_through_the_mirror():
     oo = ol.default_options(); oo.prior_mask = 3
     so, _ = ol.solve(flat, oo)
     assert s.success and abs(s.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+
+
+def test_golden_camera_model_vectors_on_gpu():
+    """tests/golden/camera_models.npz (64 tuples per model, edge cases included) through the HIP evaluate path:
+    functor return value, residual, d/d extrinsics, d/d intrinsics, d/d point (ambient 4)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "camera_models.npz"))
+    for model in range(8):
+        k = g[f"m{model}_intr"]
+        n = g[f"m{model}_ext"].shape[0]
+        intr = np.zeros((n, 10)); intr[:, : len(k)] = k
+        si = np.stack([1.0 + 0.1 * (np.arange(n) % 3), np.full(n, 0.9)], 1)
+        p = capi.FlatProblem(g[f"m{model}_ext"], intr, np.full(n, model, np.int32), np.arange(n, dtype=np.int32), g[f"m{model}_X"],
+                             g[f"m{model}_uv"], np.arange(n, dtype=np.int32), np.arange(n, dtype=np.int32), obs_sqrt_info=si)
+        o = ba.default_options(); o.use_homogeneous_point_parametrization = 0; o.intrinsics_to_optimize = 0x3f
+        with ba.BaHandle(p, o) as h:
+            cost, r, jc, jp, ji, valid = h.evaluate_ex()
+        ok = g[f"m{model}_ok"].astype(bool)
+        assert np.array_equal(valid.astype(bool), ok)
+        assert np.abs(r[ok] - g[f"m{model}_res"][ok]).max() <= 1e-9
+        for mine, ref in ((jc, g[f"m{model}_Je"]), (jp, g[f"m{model}_Jp"]), (ji[:, :, : len(k)], g[f"m{model}_Ji"])):
+            scale = np.abs(ref[ok]).max(axis=(0, 1), keepdims=True)
+            assert (np.abs(mine[ok] - ref[ok]) / np.maximum(scale, 1e-300)).max() <= 1e-9, model
+
+
+@pytest.mark.parametrize("name,kw", [("intr", dict(intrinsics_to_optimize=0x11)), ("priors", dict(prior_mask=7)),
+                                     ("huber", dict(loss_function_type=1, robust_loss_width=1.5))])
+def test_golden_ba_variants_on_gpu(name, kw):
+    from tests.test_oracle_ba import _variant_problem
+    v = np.load(os.path.join(os.path.dirname(__file__), "golden", "ba_variants.npz"))
+    base = capi.FlatProblem(v["base_cam_ext"], v["base_intrinsics"], v["base_group_model"], v["base_cam_group"], v["base_points"],
+                            v["base_obs_uv"], v["base_obs_cam"], v["base_obs_pt"])
+    p = _variant_problem(v, base, name)
+    o = ba.default_options()
+    for kk, vv in kw.items():
+        setattr(o, kk, vv)
+    o.max_num_iterations = 25
+    s, tr = ba.solve(p, o)
+    assert s.num_iterations == int(v[f"{name}_num_iterations"]) and np.array_equal(tr.accepted, v[f"{name}_trace_accepted"])
+    assert rel(tr.cost, v[f"{name}_trace_cost"]) <= 1e-8
+    assert np.abs(p.cam_ext - v[f"{name}_cam_ext"]).max() <= 1e-7 and rel(p.intrinsics, v[f"{name}_intrinsics"]) <= 1e-7
+    assert np.abs(p.points - v[f"{name}_points"]).max() <= 1e-6

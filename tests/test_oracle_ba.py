@@ -3,6 +3,7 @@ finite differences, manifold / loss identities, Schur step against the dense
 normal equations, the LM loop against scipy, and the reference's threshold
 tests (bundle_adjustment_test.cc:76-115,117-207)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -268,3 +269,41 @@ def test_camera_prior_functors_against_finite_differences_and_closed_forms():
             else:
                 E = R @ synth.angle_axis_to_matrix(prior).T
                 assert np.abs(r - S @ synth.matrix_to_angle_axis(E)).max() <= 1e-12
+
+
+def test_golden_camera_models_and_ba_variants():
+    """The oracle reproduces its committed fixtures (tests/golden/make_oracle_golden.py): per-model residuals and
+    Jacobians incl. the edge cases, and the LM traces of the intrinsics / priors / robust-loss variants."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "camera_models.npz"))
+    for model in range(8):
+        k = g[f"m{model}_intr"]
+        n = g[f"m{model}_ext"].shape[0]
+        assert 0 < g[f"m{model}_ok"].sum() <= n
+        for i in range(n):
+            ok, r, Je, Ji, Jp = ol.reprojection_error(model, g[f"m{model}_ext"][i], k, g[f"m{model}_X"][i], g[f"m{model}_uv"][i],
+                                                      sqrt_info=[1.0 + 0.1 * (i % 3), 0.9])
+            assert (1 if ok else 0) == g[f"m{model}_ok"][i]
+            for a, b in ((r, g[f"m{model}_res"][i]), (Je, g[f"m{model}_Je"][i]), (Ji, g[f"m{model}_Ji"][i]), (Jp, g[f"m{model}_Jp"][i])):
+                assert np.allclose(a, b, rtol=1e-13, atol=1e-13, equal_nan=True)
+    v = np.load(os.path.join(os.path.dirname(__file__), "golden", "ba_variants.npz"))
+    base = capi.FlatProblem(v["base_cam_ext"], v["base_intrinsics"], v["base_group_model"], v["base_cam_group"], v["base_points"],
+                            v["base_obs_uv"], v["base_obs_cam"], v["base_obs_pt"])
+    for name, kw in (("intr", dict(intrinsics_to_optimize=0x11)), ("priors", dict(prior_mask=7)), ("huber", dict(loss_function_type=1, robust_loss_width=1.5))):
+        p = _variant_problem(v, base, name)
+        o = ol.default_options()
+        for kk, vv in kw.items():
+            setattr(o, kk, vv)
+        o.max_num_iterations = 25
+        s, tr = ol.solve(p, o)
+        assert s.num_iterations == int(v[f"{name}_num_iterations"]) and np.array_equal(tr.accepted, v[f"{name}_trace_accepted"])
+        assert np.allclose(tr.cost, v[f"{name}_trace_cost"], rtol=1e-11)
+        assert np.abs(p.cam_ext - v[f"{name}_cam_ext"]).max() <= 1e-9 and np.abs(p.intrinsics - v[f"{name}_intrinsics"]).max() <= 1e-7
+
+
+def _variant_problem(v, base, name):
+    p = base.copy()
+    if name == "priors":
+        p.set_priors(v["priors_mask"], **{k: (v[f"priors_{k}"], v[f"priors_{k}_info"]) for k in ("position", "gravity", "orientation")})
+    if name == "huber":
+        p.cam_const = np.ascontiguousarray(v["huber_cam_const"]); p.obs_uv = np.ascontiguousarray(v["huber_obs_uv"])
+    return p

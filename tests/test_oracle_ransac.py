@@ -420,3 +420,21 @@ def test_lmed_quality_measurement_rules():
         thr = 2.5 * 1.4826 * (1 + 5.0 / (n - 3)) * np.sqrt(med)
         assert np.array_equal(r["inlier_mask"].astype(bool), res * res < thr * thr)
         assert r["inlier_mask"][truth["inlier"][0][:n]].mean() > 0.8
+
+
+def test_golden_ransac_variants():
+    """The oracle reproduces tests/golden/ransac_variants.npz: SQPnP solutions, PROSAC / LMED / SQPnP / LO-RANSAC runs."""
+    g = np.load(os.path.join(HERE, "golden", "ransac_variants.npz"))
+    for k in range(4):
+        q, t = ol.sqpnp(g[f"sqpnp{k}_uv"], g[f"sqpnp{k}_X"])
+        assert np.array_equal(q, g[f"sqpnp{k}_q"]) and np.array_equal(t, g[f"sqpnp{k}_t"])
+    data, offsets = g["abs_data"], g["abs_offsets"]
+    for name, est, setup in (("prosac", 2, dict(ransac_type=1)), ("lmed", 2, dict(ransac_type=2, min_iterations=120, max_iterations=200)),
+                             ("sqpnp", 4, dict()), ("lo", 2, dict(use_lo=1, lo_start_iterations=5, min_iterations=50, use_mle=1))):
+        for i in range(3):
+            prm = ol.default_ransac_params((4 / 1000.0) ** 2, 66 + i)
+            for kk, vv in setup.items():
+                setattr(prm, kk, vv)
+            r = ol.ransac_estimate(est, data[offsets[i]:offsets[i + 1]], prm)
+            assert r["num_iterations"] == g[f"{name}_iters"][i] and np.array_equal(r["inlier_mask"], g[f"{name}_masks"][i])
+            assert np.allclose(r["model"][:12], g[f"{name}_models"][i], rtol=0, atol=1e-13, equal_nan=True)

@@ -227,3 +227,26 @@ def test_prosac_inlier_sets_bit_identical_to_oracle(est, kind):
         assert np.array_equal(o["inlier_mask"], res["inlier_mask"][sl]) and o["num_iterations"] == res["num_iterations"][i]
         assert np.array_equal(o["model"][: MLEN[est]], res["models"][i][: MLEN[est]], equal_nan=True)
         assert res["num_inliers"][i] > 0.8 * truth["inlier"][i].sum()
+
+
+def test_golden_ransac_variants_on_gpu():
+    """tests/golden/ransac_variants.npz through the HIP path: SQPnP solutions bitwise; PROSAC / LMED / SQPnP runs
+    bitwise; LO-RANSAC masks and iterations identical, models to 1e-9."""
+    g = np.load(os.path.join(HERE, "golden", "ransac_variants.npz"))
+    ns, q, t = ransac.SQPnP([g[f"sqpnp{k}_uv"] for k in range(4)], [g[f"sqpnp{k}_X"] for k in range(4)])
+    for k in range(4):
+        assert ns[k] == len(g[f"sqpnp{k}_q"]) and np.array_equal(q[k, : ns[k]], g[f"sqpnp{k}_q"]) and np.array_equal(t[k, : ns[k]], g[f"sqpnp{k}_t"])
+    data, offsets = g["abs_data"], g["abs_offsets"]
+    for name, est, setup in (("prosac", 2, dict(ransac_type=1)), ("lmed", 2, dict(ransac_type=2, min_iterations=120, max_iterations=200)),
+                             ("sqpnp", 4, dict()), ("lo", 2, dict(use_lo=True, lo_start_iterations=5, min_iterations=50, use_mle=True))):
+        p = ransac.RansacParameters(); p.error_thresh = THR[2]; p.seed = 66
+        for kk, vv in setup.items():
+            setattr(p, kk, vv)
+        res = ransac.estimate_batch(est, data, offsets, p)
+        assert np.array_equal(res["num_iterations"], g[f"{name}_iters"])
+        for i in range(3):
+            assert np.array_equal(res["inlier_mask"][offsets[i]:offsets[i + 1]], g[f"{name}_masks"][i])
+            if name == "lo":
+                assert np.abs(res["models"][i][:12] - g[f"{name}_models"][i]).max() <= 1e-9
+            else:
+                assert np.array_equal(res["models"][i][:12], g[f"{name}_models"][i], equal_nan=True)
