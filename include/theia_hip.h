@@ -337,9 +337,12 @@ typedef struct theia_ransac_params {
 } theia_ransac_params;
 
 /* RansacType: RANSAC = RandomSampler + InlierSupport/MLE; PROSAC = ProsacSampler
- * (prosac_sampler.cc:53-128, data sorted by quality, best first); LMED and
- * EXHAUSTIVE are rejected (EXHAUSTIVE CHECK-fails in the reference for every
- * estimator here: its sampler requires a sample size of 2). */
+ * (prosac_sampler.cc:53-128, data sorted by quality, best first); LMED =
+ * RandomSampler + LmedQualityMeasurement (lmed.h:64-70); EXHAUSTIVE =
+ * ExhaustiveSampler (exhaustive_sampler.cc:45-79: every pair in order), which
+ * CHECK-fails in the reference unless the estimator's sample size is 2, so it
+ * is accepted for THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION only and returns
+ * THEIA_HIP_ERR_INVALID_ARGUMENT with the reference's message otherwise. */
 enum { THEIA_RANSAC_RANSAC = 0, THEIA_RANSAC_PROSAC = 1, THEIA_RANSAC_LMED = 2, THEIA_RANSAC_EXHAUSTIVE = 3 };
 
 void theia_ransac_params_default(theia_ransac_params* p);
@@ -353,14 +356,29 @@ enum {
   /* EstimateCalibratedAbsolutePose, estimate_calibrated_absolute_pose.cc:176-190 */
   THEIA_EST_ABSOLUTE_POSE_KNEIP = 2,
   THEIA_EST_ABSOLUTE_POSE_DLS = 3,
-  THEIA_EST_ABSOLUTE_POSE_SQPNP = 4
+  THEIA_EST_ABSOLUTE_POSE_SQPNP = 4,
+  /* EstimateFundamentalMatrix, estimators/estimate_fundamental_matrix.cc:105-121
+   * (normalised 8-point + squared Sampson distance; the error threshold is in
+   * squared pixels as in the reference) */
+  THEIA_EST_FUNDAMENTAL_MATRIX = 5,
+  /* EstimateHomography, estimators/estimate_homography.cc:120-135 (4-point DLT,
+   * asymmetric transfer error) */
+  THEIA_EST_HOMOGRAPHY = 6,
+  /* EstimateDominantPlaneFromPoints, estimate_dominant_plane_from_points.cc:95-107
+   * (error = point-to-plane distance, not squared) */
+  THEIA_EST_DOMINANT_PLANE = 7,
+  /* EstimateRelativePoseWithKnownOrientation,
+   * estimate_relative_pose_with_known_orientation.cc:66-81 (2 correspondences) */
+  THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION = 8
 };
 
 /* A batch of independent estimation problems ("pairs").  Datum layout:
  *   relative pose / essential: FeatureCorrespondence = [x1 y1 x2 y2]
  *     (matching/feature_correspondence.h; only Feature::point_ is used)
+ *     (also fundamental matrix, homography, known-orientation relative pose)
  *   absolute pose: FeatureCorrespondence2D3D = [u v X Y Z]
- *     (sfm/feature_correspondence_2d_3d.h:42-49)                           */
+ *     (sfm/feature_correspondence_2d_3d.h:42-49)
+ *   dominant plane: Eigen::Vector3d = [X Y Z]                              */
 typedef struct theia_ransac_batch {
   int32_t estimator;           /* THEIA_EST_*                              */
   int32_t num_problems;
@@ -371,7 +389,10 @@ typedef struct theia_ransac_batch {
 /* Result per problem.  model layout:
  *   RELATIVE_POSE:    E(9, row-major) R(9, row-major) position(3)  = 21
  *   ESSENTIAL_MATRIX: E(9)                                          = 9
- *   ABSOLUTE_POSE_*:  R(9, row-major) position(3)                   = 12 */
+ *   ABSOLUTE_POSE_*:  R(9, row-major) position(3)                   = 12
+ *   FUNDAMENTAL_MATRIX / HOMOGRAPHY: 3x3 row-major                  = 9
+ *   DOMINANT_PLANE:   point(3) unit_normal(3)                       = 6
+ *   RELATIVE_POSE_KNOWN_ORIENTATION: unit position of camera 2      = 3 */
 #define THEIA_RANSAC_MODEL_STRIDE 21
 typedef struct theia_ransac_result {
   int32_t* success;            /* [num_problems] Estimate() return value   */

@@ -35,16 +35,29 @@ namespace {
 constexpr int kMaxCap = 18;   // largest EstimateModel output of any estimator (SQPnP: 18 solutions)
 // models per sample an estimator can return = slot stride of the per-hypothesis arrays
 __host__ __device__ inline int max_models(int est) {
+  if (est >= THEIA_EST_FUNDAMENTAL_MATRIX) return 1;
   return est == THEIA_EST_ABSOLUTE_POSE_SQPNP ? 18 : (est == THEIA_EST_ABSOLUTE_POSE_KNEIP ? 4 : 10);
 }
 constexpr int kStride = THEIA_RANSAC_MODEL_STRIDE;
 
 __host__ __device__ inline int sample_size(int est) {
-  return (est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_ESSENTIAL_MATRIX) ? 5 : 3;
+  switch (est) {
+    case THEIA_EST_RELATIVE_POSE: case THEIA_EST_ESSENTIAL_MATRIX: return 5;
+    case THEIA_EST_FUNDAMENTAL_MATRIX: return 8;
+    case THEIA_EST_HOMOGRAPHY: return 4;
+    case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: return 2;
+    default: return 3;
+  }
 }
 __host__ __device__ inline int datum_size(int est) {
-  return (est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_ESSENTIAL_MATRIX) ? 4 : 5;
+  switch (est) {
+    case THEIA_EST_ABSOLUTE_POSE_KNEIP: case THEIA_EST_ABSOLUTE_POSE_DLS: case THEIA_EST_ABSOLUTE_POSE_SQPNP: return 5;
+    case THEIA_EST_DOMINANT_PLANE: return 3;
+    default: return 4;
+  }
 }
+constexpr int kMaxSample = 8;            // largest minimal sample (8-point fundamental matrix)
+constexpr int kMaxSampleDoubles = 32;   // 8 correspondences x 4
 
 // EstimateModel of the three estimators (estimate_relative_pose.cc:75-109,
 // estimate_essential_matrix.cc:62-73, estimate_calibrated_absolute_pose.cc:76-118).
@@ -102,6 +115,17 @@ __device__ int estimate_models(int est, const double* subset, double* models) {
     }
     return n;
   }
+  // single-model estimators (estimate_fundamental_matrix.cc:64-78, estimate_homography.cc:72-88,
+  // estimate_dominant_plane_from_points.cc:62-81, estimate_relative_pose_with_known_orientation.cc:31-45)
+  if ((any || EST >= THEIA_EST_FUNDAMENTAL_MATRIX) && est >= THEIA_EST_FUNDAMENTAL_MATRIX) {
+    bool ok = false;
+    for (int k = 0; k < kStride; ++k) models[k] = 0.0;
+    if (est == THEIA_EST_FUNDAMENTAL_MATRIX) ok = rsc::eight_point_fundamental(subset, models);
+    else if (est == THEIA_EST_HOMOGRAPHY) ok = rsc::four_point_homography(subset, models);
+    else if (est == THEIA_EST_DOMINANT_PLANE) ok = rsc::plane_from_three_points(subset, models);
+    else if (est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION) ok = rsc::two_point_relative_position(subset, models);
+    return ok ? 1 : 0;
+  }
   return 0;
 }
 
@@ -112,7 +136,10 @@ __device__ inline double model_error(int est, const double* m, const double* d) 
     if (rsc::in_front(d, m + 9, m + 18)) return rsc::sampson(m, d);
     return DBL_MAX;
   }
-  if (est == THEIA_EST_ESSENTIAL_MATRIX) return rsc::sampson(m, d);
+  if (est == THEIA_EST_ESSENTIAL_MATRIX || est == THEIA_EST_FUNDAMENTAL_MATRIX) return rsc::sampson(m, d);
+  if (est == THEIA_EST_HOMOGRAPHY) return rsc::homography_error(m, d);
+  if (est == THEIA_EST_DOMINANT_PLANE) return rsc::plane_error(m, d);
+  if (est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION) return rsc::known_orientation_error(m, d);
   const double dx = d[2] - m[9], dy = d[3] - m[10], dz = d[4] - m[11];
   const double px = (m[0] * dx + m[1] * dy) + m[2] * dz;
   const double py = (m[3] * dx + m[4] * dy) + m[5] * dz;
@@ -139,7 +166,7 @@ __global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int
   if (b >= active_iters[p]) { counts[hyp] = 0; return; }
   const int m = sample_size(est), ds = datum_size(est);
   const double* pd = data + (size_t)offsets[p] * ds;
-  double subset[25];
+  double subset[kMaxSampleDoubles];
   for (int i = 0; i < m; ++i) {
     const int idx = samples[hyp * m + i];
     for (int k = 0; k < ds; ++k) subset[i * ds + k] = pd[(size_t)idx * ds + k];
@@ -300,9 +327,9 @@ __global__ void k_refit(int est, int nprob, const int64_t* __restrict__ offsets,
   if (best_slot[p] < 0) return;
   const int m = sample_size(est), ds = datum_size(est);
   const double* pd = data + (size_t)offsets[p] * ds;
-  double subset[25];
+  double subset[kMaxSampleDoubles];
   for (int i = 0; i < m; ++i) {
-    const int idx = best_samples[p * 5 + i];
+    const int idx = best_samples[p * kMaxSample + i];
     for (int k = 0; k < ds; ++k) subset[i * ds + k] = pd[(size_t)idx * ds + k];
   }
   double mloc[kMaxCap * kStride];
@@ -365,7 +392,7 @@ __global__ void k_lo_prepare(int est, int nev, const int* __restrict__ ev_prob, 
   } else {
     const int m = sample_size(est), ds = datum_size(est);
     const double* pd = data + (size_t)offsets[p] * ds;
-    double subset[25];
+    double subset[kMaxSampleDoubles];
     for (int i = 0; i < m; ++i) {
       const int idx = ev_samples[e * 5 + i];
       for (int k = 0; k < ds; ++k) subset[i * ds + k] = pd[(size_t)idx * ds + k];
@@ -543,9 +570,10 @@ struct ProblemState {
   int max_iterations, it, n;
   bool done;
   int best_slot;
-  int best_samples[5];
+  int best_samples[kMaxSample];
   int round_iters;
   int kth;  // PROSAC sample counter
+  int ex_i, ex_j;  // ExhaustiveSampler cursor (exhaustive_sampler.cc:48,61-79)
   // replay cursor inside the current round and LO-RANSAC state
   int base_it, rb, rj;
   bool round_done, best_refined;
@@ -608,16 +636,18 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   const int est = batch->estimator;
   if (est == THEIA_EST_ABSOLUTE_POSE_DLS)
     return set_error(THEIA_HIP_ERR_UNSUPPORTED, "the DLS minimal solver has no HIP kernel yet");
-  if (est < 0 || est > THEIA_EST_ABSOLUTE_POSE_SQPNP) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
+  if (est < 0 || est > THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
   const bool abs_pose = est == THEIA_EST_ABSOLUTE_POSE_KNEIP || est == THEIA_EST_ABSOLUTE_POSE_SQPNP;
   if (P.use_lo && !abs_pose)
     return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: only the absolute-pose RefineModel (BundleAdjustView) is built; "
                      "the relative-pose one (BundleAdjustTwoViewsAngular) is not yet");
-  if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE)
+  // exhaustive_sampler.cc:49-51 CHECK
+  if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE && sample_size(est) != 2)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "ExhaustiveSampler makes a hard assumption that the number of samples needed is 2.");
   const bool lmed = P.ransac_type == THEIA_RANSAC_LMED;
   if (lmed && P.use_lo) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo together with LMED is not built");
-  if (P.ransac_type != THEIA_RANSAC_RANSAC && P.ransac_type != THEIA_RANSAC_PROSAC && !lmed)
+  if (P.ransac_type != THEIA_RANSAC_RANSAC && P.ransac_type != THEIA_RANSAC_PROSAC && !lmed &&
+      P.ransac_type != THEIA_RANSAC_EXHAUSTIVE)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown ransac_type");
   const int nprob = batch->num_problems;
   if (nprob < 0 || (nprob > 0 && (!batch->offsets || !batch->data))) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad batch");
@@ -681,7 +711,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     HIP_TRYR(hipFuncSetAttribute((const void*)k_score<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   }
 
-  std::vector<int> best_samples_all((size_t)nprob * 5, 0), best_slot_all(nprob, -1);
+  std::vector<int> best_samples_all((size_t)nprob * kMaxSample, 0), best_slot_all(nprob, -1);
   std::vector<ProblemState> S(nprob);
   for (int p = 0; p < nprob; ++p) {
     ProblemState& s = S[p];
@@ -693,9 +723,9 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     s.max_iterations = P.max_iterations;
     if (P.min_inlier_ratio > 0)
       s.max_iterations = std::min(compute_max_iterations(P, m, P.min_inlier_ratio, log_failure_prob, s.n), P.max_iterations);
-    s.it = 0; s.done = s.max_iterations <= 0; s.best_slot = -1; s.kth = 1;
+    s.it = 0; s.done = s.max_iterations <= 0; s.best_slot = -1; s.kth = 1; s.ex_i = 0; s.ex_j = 1;
     s.base_it = 0; s.rb = 0; s.rj = 0; s.round_done = true; s.best_refined = false; s.pending_ratio = 0.0; s.num_lo = 0;
-    for (int k = 0; k < 5; ++k) s.best_samples[k] = 0;
+    for (int k = 0; k < kMaxSample; ++k) s.best_samples[k] = 0;
   }
   double fit_score_ms = 0.0;
   // ---- LO-RANSAC (absolute pose): batched RefineModel over a list of events
@@ -712,7 +742,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   lo_opts.robust_loss_width = P.error_thresh * 1.5;
   lo_opts.use_inner_iterations = 0;
   if (P.use_lo && (rc = d_cur_models.ensure((size_t)nprob * kStride))) return rc;
-  struct LoEvent { int prob, slot; int samples[5]; };
+  struct LoEvent { int prob, slot; int samples[8]; };
   // refines every event's model on its inliers; writes the refined pose to d_cur_models[prob]
   auto run_lo = [&](const std::vector<LoEvent>& evs, std::vector<int>& success) -> int {
     const int nev = (int)evs.size();
@@ -778,6 +808,14 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         int* out = h_samples.data() + (size_t)q * B * m;
         for (int b = 0; b < s.round_iters; ++b) {
           if (P.ransac_type == THEIA_RANSAC_PROSAC) { prosac_sample(s.rng, s.n, m, s.kth++, out + (size_t)b * m); continue; }
+          if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE) {   // all pairs (i, j > i), wrapping around
+            out[(size_t)b * 2] = s.ex_i; out[(size_t)b * 2 + 1] = s.ex_j;
+            if (++s.ex_j >= s.n) {
+              if (++s.ex_i >= s.n - 1) s.ex_i = 0;
+              s.ex_j = s.ex_i + 1;
+            }
+            continue;
+          }
           for (int i = 0; i < m; ++i) {
             std::swap(s.idx[i], s.idx[s.rng.rand_int(i, s.n - 1)]);
             out[(size_t)b * m + i] = s.idx[i];
@@ -800,7 +838,11 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
           case THEIA_EST_RELATIVE_POSE: THIP_FIT(THEIA_EST_RELATIVE_POSE); break;
           case THEIA_EST_ESSENTIAL_MATRIX: THIP_FIT(THEIA_EST_ESSENTIAL_MATRIX); break;
           case THEIA_EST_ABSOLUTE_POSE_KNEIP: THIP_FIT(THEIA_EST_ABSOLUTE_POSE_KNEIP); break;
-          default: THIP_FIT(THEIA_EST_ABSOLUTE_POSE_SQPNP); break;
+          case THEIA_EST_ABSOLUTE_POSE_SQPNP: THIP_FIT(THEIA_EST_ABSOLUTE_POSE_SQPNP); break;
+          case THEIA_EST_FUNDAMENTAL_MATRIX: THIP_FIT(THEIA_EST_FUNDAMENTAL_MATRIX); break;
+          case THEIA_EST_HOMOGRAPHY: THIP_FIT(THEIA_EST_HOMOGRAPHY); break;
+          case THEIA_EST_DOMINANT_PLANE: THIP_FIT(THEIA_EST_DOMINANT_PLANE); break;
+          default: THIP_FIT(THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION); break;
         }
 #undef THIP_FIT
       }
@@ -889,12 +931,12 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   // final models + inlier masks
   for (int p = 0; p < nprob; ++p) {
     best_slot_all[p] = S[p].best_slot;
-    for (int k = 0; k < 5; ++k) best_samples_all[(size_t)p * 5 + k] = S[p].best_samples[k];
+    for (int k = 0; k < kMaxSample; ++k) best_samples_all[(size_t)p * kMaxSample + k] = S[p].best_samples[k];
   }
-  if ((rc = d_best_samples.ensure((size_t)nprob * 5)) || (rc = d_best_slot.ensure(nprob)) ||
+  if ((rc = d_best_samples.ensure((size_t)nprob * kMaxSample)) || (rc = d_best_slot.ensure(nprob)) ||
       (rc = d_best_models.ensure((size_t)nprob * kStride)) || (rc = d_mask.ensure((size_t)total)))
     return rc;
-  HIP_TRYR(hipMemcpyAsync(d_best_samples.p, best_samples_all.data(), sizeof(int) * nprob * 5, hipMemcpyHostToDevice, st));
+  HIP_TRYR(hipMemcpyAsync(d_best_samples.p, best_samples_all.data(), sizeof(int) * nprob * kMaxSample, hipMemcpyHostToDevice, st));
   HIP_TRYR(hipMemcpyAsync(d_best_slot.p, best_slot_all.data(), sizeof(int) * nprob, hipMemcpyHostToDevice, st));
   k_refit<<<(nprob + 63) / 64, 64, 0, st>>>(est, nprob, d_off.p, d_data.p, d_best_samples.p, d_best_slot.p, d_best_models.p);
   if (P.use_lo) {   // the best model of a problem may be the refined pose of its last LO event

@@ -1098,6 +1098,200 @@ RDEV double sampson(const double* F, const double* c) {
   return num * num / den;
 }
 
+// ---------------------------------------------------------------------------
+// Uncalibrated two-view models, plane and known-orientation position
+// ---------------------------------------------------------------------------
+// row-major 3x3 product, each entry accumulated left to right
+RDEV void matmul3(const double* A, const double* B, double* C) {
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) C[3 * r + c] = (A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c]) + A[3 * r + 2] * B[6 + c];
+}
+
+// NormalizeImagePoints (sfm/pose/util.cc:81-112): centroid to the origin, RMS
+// distance sqrt(2).  pts: n points, `stride` doubles apart; T row-major 3x3.
+RDEV void normalize_image_points(const double* pts, int stride, int n, double* out, double* T) {
+  double cx = 0.0, cy = 0.0;
+  for (int i = 0; i < n; ++i) { cx += pts[i * stride]; cy += pts[i * stride + 1]; }
+  cx /= n; cy /= n;
+  double ss = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double dx = pts[i * stride] - cx, dy = pts[i * stride + 1] - cy;
+    ss += dx * dx;
+    ss += dy * dy;
+  }
+  const double rms_mean_dist = sqrt(ss / n);
+  const double norm_factor = sqrt(2.0) / rms_mean_dist;
+  T[0] = norm_factor; T[1] = 0.0; T[2] = -1.0 * norm_factor * cx;
+  T[3] = 0.0; T[4] = norm_factor; T[5] = -1.0 * norm_factor * cy;
+  T[6] = 0.0; T[7] = 0.0; T[8] = 1.0;
+  for (int i = 0; i < n; ++i) {
+    const double x = pts[i * stride], y = pts[i * stride + 1];
+    const double hx = (T[0] * x + T[1] * y) + T[2];
+    const double hy = (T[3] * x + T[4] * y) + T[5];
+    const double hz = (T[6] * x + T[7] * y) + T[8];
+    out[2 * i] = hx / hz; out[2 * i + 1] = hy / hz;
+  }
+}
+
+// NormalizedEightPointFundamentalMatrix for exactly 8 correspondences
+// (sfm/pose/eight_point_fundamental_matrix.cc:50-112: the minimal case takes
+// the kernel of the 8x9 constraint matrix from a full-pivot LU).
+// corr: 8 x [x1 y1 x2 y2]; F row-major with x2^T F x1 = 0.
+RDEV bool eight_point_fundamental(const double* corr, double* F) {
+  double n1[16], n2[16], T1[9], T2[9];
+  normalize_image_points(corr, 4, 8, n1, T1);
+  normalize_image_points(corr + 2, 4, 8, n2, T2);
+  double A[72];
+  for (int i = 0; i < 8; ++i) {
+    const double x1 = n1[2 * i], y1 = n1[2 * i + 1], x2 = n2[2 * i], y2 = n2[2 * i + 1];
+    double* r = A + 9 * i;
+    r[0] = x1 * x2; r[1] = y1 * x2; r[2] = x2;
+    r[3] = x1 * y2; r[4] = y1 * y2; r[5] = y2;
+    r[6] = x1; r[7] = y1; r[8] = 1.0;
+  }
+  FullPivLU f;
+  fullpiv_lu(A, 8, 9, f);
+  const double premult = fabs(f.maxpivot) * (DBL_EPSILON * 8.0);
+  int rank = 0;
+  for (int i = 0; i < f.nonzero_pivots; ++i) rank += fabs(A[i * 9 + i]) > premult;
+  if (9 - rank != 1) return false;   // dimensionOfKernel() != 1
+  int cidx[9];
+  for (int j = 0; j < 9; ++j) cidx[j] = j;
+  for (int k = 0; k < f.size; ++k) dswap(cidx[k], cidx[f.colt[k]]);
+  double X[8];
+  for (int i = 7; i >= 0; --i) {
+    double s = A[i * 9 + 8];
+    for (int j = i + 1; j < 8; ++j) s -= A[i * 9 + j] * X[j];
+    X[i] = s / A[i * 9 + i];
+  }
+  double v[9];
+  for (int i = 0; i < 9; ++i) v[i] = 0.0;
+  for (int i = 0; i < 8; ++i) v[cidx[i]] = -X[i];
+  v[cidx[8]] = 1.0;
+  // rank-2 projection of the (lazily transposed, :96-105) matrix: row-major reading of v
+  double U[9], S[3], V[9];
+  svd3(v, U, S, V);
+  S[2] = 0.0;
+  double US[9], Fr[9];
+  for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) US[3 * r + k] = U[3 * r + k] * S[k];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) Fr[3 * r + c] = (US[3 * r] * V[3 * c] + US[3 * r + 1] * V[3 * c + 1]) + US[3 * r + 2] * V[3 * c + 2];
+  // undo the normalisation: T2^T F T1 (:107-109)
+  double T2t[9], tmp[9];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) T2t[3 * r + c] = T2[3 * c + r];
+  matmul3(T2t, Fr, tmp);
+  matmul3(tmp, T1, F);
+  return true;
+}
+
+// Eigen's 3x3 inverse (Eigen/src/LU/InverseImpl.h compute_inverse<Matrix3d>:
+// cofactors of column 0 give the determinant, inverse = cofactor^T / det)
+RDEV double cofactor3(const double* m, int i, int j) {
+  const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m[3 * i1 + j1] * m[3 * i2 + j2] - m[3 * i1 + j2] * m[3 * i2 + j1];
+}
+RDEV void inverse3(const double* m, double* inv) {
+  const double c00 = cofactor3(m, 0, 0), c10 = cofactor3(m, 1, 0), c20 = cofactor3(m, 2, 0);
+  const double det = (c00 * m[0] + c10 * m[3]) + c20 * m[6];
+  const double invdet = 1.0 / det;
+  inv[0] = c00 * invdet; inv[1] = c10 * invdet; inv[2] = c20 * invdet;
+  inv[3] = cofactor3(m, 0, 1) * invdet; inv[4] = cofactor3(m, 1, 1) * invdet; inv[5] = cofactor3(m, 2, 1) * invdet;
+  inv[6] = cofactor3(m, 0, 2) * invdet; inv[7] = cofactor3(m, 1, 2) * invdet; inv[8] = cofactor3(m, 2, 2) * invdet;
+}
+
+// FourPointHomography for exactly 4 correspondences (sfm/pose/four_point_homography.cc:54-105):
+// normalised DLT, null vector = last right singular vector of A^T A.
+// corr: 4 x [x1 y1 x2 y2]; H row-major with x2 ~ H x1.
+RDEV bool four_point_homography(const double* corr, double* H) {
+  double n1[8], n2[8], T1[9], T2[9];
+  normalize_image_points(corr, 4, 4, n1, T1);
+  normalize_image_points(corr + 2, 4, 4, n2, T2);
+  double A[72];
+  for (int i = 0; i < 4; ++i) {
+    const double x1 = n1[2 * i], y1 = n1[2 * i + 1], x2 = n2[2 * i], y2 = n2[2 * i + 1];
+    double* r = A + 18 * i;
+    r[0] = 0.0; r[1] = 0.0; r[2] = 0.0; r[3] = -x1; r[4] = -y1; r[5] = -1.0; r[6] = x1 * y2; r[7] = y1 * y2; r[8] = y2;
+    r[9] = x1; r[10] = y1; r[11] = 1.0; r[12] = 0.0; r[13] = 0.0; r[14] = 0.0; r[15] = -x1 * x2; r[16] = -y1 * x2; r[17] = -x2;
+  }
+  double M[81];
+  for (int a = 0; a < 9; ++a)
+    for (int b = 0; b < 9; ++b) {
+      double s = 0.0;
+      for (int k = 0; k < 8; ++k) s += A[9 * k + a] * A[9 * k + b];
+      M[9 * a + b] = s;
+    }
+  double U[81], S[9], V[81];
+  svd_sq<9>(M, U, S, V);
+  double Hn[9];
+  for (int k = 0; k < 9; ++k) Hn[k] = V[9 * k + 8];
+  double T2i[9], tmp[9];
+  inverse3(T2, T2i);
+  matmul3(T2i, Hn, tmp);
+  matmul3(tmp, T1, H);
+  return true;
+}
+
+// asymmetric transfer error of HomographyEstimator::Error (estimate_homography.cc:106-112)
+RDEV double homography_error(const double* H, const double* c) {
+  const double x = c[0], y = c[1];
+  const double px = (H[0] * x + H[1] * y) + H[2];
+  const double py = (H[3] * x + H[4] * y) + H[5];
+  const double pz = (H[6] * x + H[7] * y) + H[8];
+  const double ex = c[2] - px / pz, ey = c[3] - py / pz;
+  return ex * ex + ey * ey;
+}
+
+// DominantPlaneEstimator::EstimateModel (estimate_dominant_plane_from_points.cc:62-81).
+// pts: 3 x [X Y Z]; model = point(3) unit_normal(3).
+RDEV bool plane_from_three_points(const double* pts, double* model) {
+  const double a[3] = {pts[3] - pts[0], pts[4] - pts[1], pts[5] - pts[2]};
+  const double b[3] = {pts[6] - pts[0], pts[7] - pts[1], pts[8] - pts[2]};
+  const double cr[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+  const double n2 = (cr[0] * cr[0] + cr[1] * cr[1]) + cr[2] * cr[2];
+  if (n2 < 1e-6) return false;
+  const double nrm = sqrt(n2);
+  for (int k = 0; k < 3; ++k) { model[k] = pts[k]; model[3 + k] = cr[k] / nrm; }
+  return true;
+}
+// point-to-plane distance (:84-86; NOT squared)
+RDEV double plane_error(const double* model, const double* p) {
+  return fabs((model[3] * (p[0] - model[0]) + model[4] * (p[1] - model[1])) + model[5] * (p[2] - model[2]));
+}
+
+// RelativePoseFromTwoPointsWithKnownRotation
+// (sfm/pose/relative_pose_from_two_points_with_known_rotation.cc:51-88):
+// kernel of the 2x3 epipolar constraint, normalised.  corr: 2 x [x1 y1 x2 y2].
+RDEV bool two_point_relative_position(const double* corr, double* pos) {
+  double A[6];
+  for (int i = 0; i < 2; ++i) {
+    const double x1 = corr[4 * i], y1 = corr[4 * i + 1], x2 = corr[4 * i + 2], y2 = corr[4 * i + 3];
+    A[3 * i] = -y1 + y2;
+    A[3 * i + 1] = -x2 + x1;
+    A[3 * i + 2] = y1 * x2 - x1 * y2;
+  }
+  FullPivLU f;
+  fullpiv_lu(A, 2, 3, f);
+  const double premult = fabs(f.maxpivot) * (DBL_EPSILON * 2.0);
+  int rank = 0;
+  for (int i = 0; i < f.nonzero_pivots; ++i) rank += fabs(A[i * 3 + i]) > premult;
+  if (3 - rank != 1) return false;
+  int cidx[3] = {0, 1, 2};
+  for (int k = 0; k < f.size; ++k) dswap(cidx[k], cidx[f.colt[k]]);
+  double X[2];
+  X[1] = A[5] / A[4];
+  X[0] = (A[2] - A[1] * X[1]) / A[0];
+  double v[3] = {0.0, 0.0, 0.0};
+  v[cidx[0]] = -X[0]; v[cidx[1]] = -X[1]; v[cidx[2]] = 1.0;
+  const double nrm = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+  for (int k = 0; k < 3; ++k) pos[k] = v[k] / nrm;
+  return true;
+}
+// Sampson distance under E = [-position]_x (estimate_relative_pose_with_known_orientation.cc:52-58)
+RDEV double known_orientation_error(const double* pos, const double* c) {
+  const double E[9] = {0.0, pos[2], -pos[1], -pos[2], 0.0, pos[0], pos[1], -pos[0], 0.0};
+  return sampson(E, c);
+}
+
 // essential_matrix_utils.cc:57-80,109-149.  Returns #points in front.
 RDEV int best_pose_from_E(const double* E, const double* corr, int ncorr, double* Rout, double* posout) {
   double U[9], S[3], V[9];

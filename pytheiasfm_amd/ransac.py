@@ -29,6 +29,7 @@ class PnPType(enum.IntEnum):  # estimate_calibrated_absolute_pose.h:54
 
 
 EST_RELATIVE_POSE, EST_ESSENTIAL_MATRIX, EST_ABS_KNEIP, EST_ABS_DLS, EST_ABS_SQPNP = range(5)
+EST_FUNDAMENTAL_MATRIX, EST_HOMOGRAPHY, EST_DOMINANT_PLANE, EST_RELATIVE_POSE_KNOWN_ORIENTATION = range(5, 9)
 
 
 class RansacParameters:
@@ -161,6 +162,38 @@ def EstimateCalibratedAbsolutePose(ransac_params, ransac_type, pnp_type, normali
     est = {PnPType.KNEIP: EST_ABS_KNEIP, PnPType.DLS: EST_ABS_DLS, PnPType.SQPnP: EST_ABS_SQPNP}[PnPType(pnp_type)]
     ok, m, s = _single(est, ransac_params, ransac_type, normalized_correspondences)
     return ok, CalibratedAbsolutePose(m), s
+
+
+class Plane:  # estimate_dominant_plane_from_points.h:48-51
+    def __init__(self, m):
+        self.point = m[0:3].copy()
+        self.unit_normal = m[3:6].copy()
+
+
+def EstimateFundamentalMatrix(ransac_params, ransac_type, correspondences):
+    """estimate_fundamental_matrix.cc:105-121.  correspondences: (N,4) x1 y1 x2 y2 in pixels;
+    error_thresh is a squared Sampson distance in pixels^2."""
+    ok, m, s = _single(EST_FUNDAMENTAL_MATRIX, ransac_params, ransac_type, correspondences)
+    return ok, m[0:9].reshape(3, 3).copy(), s
+
+
+def EstimateHomography(ransac_params, ransac_type, correspondences):
+    """estimate_homography.cc:120-135.  correspondences: (N,4) x1 y1 x2 y2; x2 ~ H x1."""
+    ok, m, s = _single(EST_HOMOGRAPHY, ransac_params, ransac_type, correspondences)
+    return ok, m[0:9].reshape(3, 3).copy(), s
+
+
+def EstimateDominantPlaneFromPoints(ransac_params, ransac_type, points):
+    """estimate_dominant_plane_from_points.cc:95-107.  points: (N,3)."""
+    ok, m, s = _single(EST_DOMINANT_PLANE, ransac_params, ransac_type, points)
+    return ok, Plane(m), s
+
+
+def EstimateRelativePoseWithKnownOrientation(ransac_params, ransac_type, rotated_correspondences):
+    """estimate_relative_pose_with_known_orientation.cc:66-81.  correspondences: (N,4), features
+    rotated into a common frame; returns the unit position of camera 2."""
+    ok, m, s = _single(EST_RELATIVE_POSE_KNOWN_ORIENTATION, ransac_params, ransac_type, rotated_correspondences)
+    return ok, m[0:3].copy(), s
 
 
 def FivePointRelativePose(image1_points, image2_points):

@@ -284,11 +284,17 @@ def synth_ransac_v1(num_problems, num_corr, kind="relative", seed=0x5AC50000, fo
     uniform in the normalised image.
       kind = "relative": data [P*N][4] = (x1 y1 x2 y2), FeatureCorrespondence
       kind = "absolute": data [P*N][5] = (u v X Y Z),   FeatureCorrespondence2D3D
+      kind = "fundamental": as "relative" but in pixels (focal, principal point 500,400)
+      kind = "homography":  as "fundamental" with the 3-D points on one plane per problem
+      kind = "known_orientation": as "relative" with identity rotation (features already rotated)
+      kind = "plane": data [P*N][3] = 3-D points, inliers within noise_px/focal of a plane
     Returns data, offsets, truth dict."""
     P, N = int(num_problems), int(num_corr)
     sp = Stream(seed, 11)
     pi = np.arange(P)
     R = _random_rotations(sp, pi, np.deg2rad(30.0))                       # (P,3,3)
+    if kind == "known_orientation":
+        R = np.broadcast_to(np.eye(3), (P, 3, 3)).copy()
     t = np.stack([sp.normal(8 * pi + (1 << 33)), sp.normal(8 * pi + 1 + (1 << 33)), sp.normal(8 * pi + 2 + (1 << 33))], axis=1)
     t /= np.linalg.norm(t, axis=1, keepdims=True)
     ratio = inlier_lo + (inlier_hi - inlier_lo) * sp.uniform(pi + (1 << 34))
@@ -297,6 +303,16 @@ def synth_ransac_v1(num_problems, num_corr, kind="relative", seed=0x5AC50000, fo
     depth = 4.0 + 6.0 * sd.uniform(6 * gi)
     x1 = 0.5 * (2.0 * sd.uniform(6 * gi + 1) - 1.0)
     y1 = 0.5 * (2.0 * sd.uniform(6 * gi + 2) - 1.0)
+    plane_n = plane_d = None
+    if kind in ("homography", "plane"):
+        # one plane per problem, n . X = d with n within ~25 deg of the optical axis
+        plane_n = np.stack([0.4 * (2.0 * sp.uniform(8 * pi + 3 + (1 << 35)) - 1.0),
+                            0.4 * (2.0 * sp.uniform(8 * pi + 4 + (1 << 35)) - 1.0), np.ones(P)], axis=1)
+        plane_n /= np.linalg.norm(plane_n, axis=1, keepdims=True)
+        plane_d = 5.0 + 3.0 * sp.uniform(8 * pi + 5 + (1 << 35))
+        on_plane = plane_d[:, None] / (plane_n[:, None, 0] * x1 + plane_n[:, None, 1] * y1 + plane_n[:, None, 2])
+        if kind == "homography":
+            depth = on_plane
     X = np.stack([x1 * depth, y1 * depth, depth], axis=2)                 # (P,N,3) in camera-1 / world frame
     X2 = np.einsum("pij,pnj->pni", R, X) + t[:, None, :]
     x2 = X2[:, :, :2] / X2[:, :, 2:3]
@@ -312,6 +328,17 @@ def synth_ransac_v1(num_problems, num_corr, kind="relative", seed=0x5AC50000, fo
     elif kind == "absolute":
         uv = np.where(is_in[:, :, None], x2 + nz[:, :, 2:], out2)
         data = np.concatenate([uv, X], axis=2).reshape(P * N, 5)
+    elif kind in ("fundamental", "homography", "known_orientation"):
+        a = np.stack([x1, y1], axis=2) + nz[:, :, :2]
+        b = np.where(is_in[:, :, None], x2 + nz[:, :, 2:], out2)
+        if kind != "known_orientation":
+            pp = np.array([500.0, 400.0])
+            a = a * focal + pp
+            b = b * focal + pp
+        data = np.concatenate([a, b], axis=2).reshape(P * N, 4)
+    elif kind == "plane":
+        Xp = np.stack([x1 * on_plane, y1 * on_plane, on_plane], axis=2) + nz[:, :, :1] * plane_n[:, None, :]
+        data = np.where(is_in[:, :, None], Xp, X).reshape(P * N, 3)
     else:
         raise ValueError(kind)
     # shuffle within each problem so inliers are not a prefix
@@ -319,5 +346,6 @@ def synth_ransac_v1(num_problems, num_corr, kind="relative", seed=0x5AC50000, fo
     data = data.reshape(P, N, -1)[np.arange(P)[:, None], perm].reshape(P * N, -1)
     is_in = is_in[np.arange(P)[:, None], perm]
     offsets = (np.arange(P + 1) * N).astype(np.int64)
-    truth = {"R": R, "t": t, "position": -np.einsum("pji,pj->pi", R, t), "inlier": is_in, "ratio": ratio}
+    truth = {"R": R, "t": t, "position": -np.einsum("pji,pj->pi", R, t), "inlier": is_in, "ratio": ratio,
+             "plane_normal": plane_n, "plane_d": plane_d}
     return np.ascontiguousarray(data), offsets, truth

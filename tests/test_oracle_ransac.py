@@ -438,3 +438,126 @@ def test_golden_ransac_variants():
             r = ol.ransac_estimate(est, data[offsets[i]:offsets[i + 1]], prm)
             assert r["num_iterations"] == g[f"{name}_iters"][i] and np.array_equal(r["inlier_mask"], g[f"{name}_masks"][i])
             assert np.allclose(r["model"][:12], g[f"{name}_models"][i], rtol=0, atol=1e-13, equal_nan=True)
+
+
+# ---- uncalibrated / plane / known-orientation estimators (R14) ----
+
+EIGHT_PTS = [(-1, 3, 3), (1, -1, 2), (-1, 1, 2), (2, 1, 3), (-1, -3, 2), (1, -2, 1), (-1, 4, 2), (-2, 2, 3)]
+
+
+def _two_view(points, R, t):
+    P = np.array(points, dtype=np.float64)
+    x1 = P[:, :2] / P[:, 2:]
+    P2 = P @ R.T + np.asarray(t, dtype=np.float64)
+    return x1, P2[:, :2] / P2[:, 2:]
+
+
+def test_eight_point_known_answers():
+    """eight_point_fundamental_matrix_test.cc:148-250: exact data -> the epipolar constraint holds
+    and F is the essential matrix up to scale; a repeated point has no solution."""
+    R = rot((0, 0, 1), 13.0)
+    for t in [(1.0, 0.5, 1.5), (1.0, 0.5, 0.0)]:
+        x1, x2 = _two_view(EIGHT_PTS, R, t)
+        m = ol.estimate_models(5, np.hstack([x1, x2]))
+        assert len(m) == 1
+        F = m[0][:9].reshape(3, 3)
+        assert np.all(m[0][9:] == 0)
+        assert max(sampson(F, x1[i], x2[i]) for i in range(8)) < 1e-20
+        assert abs(np.linalg.det(F / np.linalg.norm(F))) < 1e-14
+        E = cross_mat(t) @ R
+        c = np.sum(F * E) / (np.linalg.norm(F) * np.linalg.norm(E))
+        assert abs(abs(c) - 1.0) < 1e-10
+    pts = list(EIGHT_PTS); pts[1] = pts[0]
+    x1, x2 = _two_view(pts, R, (1.0, 0.5, 0.0))
+    assert len(ol.estimate_models(5, np.hstack([x1, x2]))) == 0
+
+
+def test_eight_point_pixel_coordinates_are_normalised():
+    """The Hartley normalisation (pose/util.cc:81-112) keeps the solve well conditioned in pixels."""
+    R = rot((0.2, 1, 0.1), 9.0); t = (0.8, -0.1, 0.3)
+    x1, x2 = _two_view(EIGHT_PTS, R, t)
+    K = np.array([[900.0, 0, 640], [0, 900.0, 360], [0, 0, 1]])
+    p1 = x1 * 900.0 + K[:2, 2]; p2 = x2 * 900.0 + K[:2, 2]
+    F = ol.estimate_models(5, np.hstack([p1, p2]))[0][:9].reshape(3, 3)
+    assert max(sampson(F, p1[i], p2[i]) for i in range(8)) < 1e-16
+    Fe = np.linalg.inv(K).T @ cross_mat(t) @ R @ np.linalg.inv(K)
+    c = np.sum(F * Fe) / (np.linalg.norm(F) * np.linalg.norm(Fe))
+    assert abs(abs(c) - 1.0) < 1e-8
+
+
+def test_four_point_homography_known_answers():
+    """four_point_homography_test.cc:128-205: coplanar points, H = R + t n^T / d up to scale."""
+    R = rot((0, 0, 1), 13.0); t = np.array([1.0, 0.5, 1.5])
+    n = np.array([0.1, -0.2, 1.0]); n /= np.linalg.norm(n); d = 6.0
+    xy = np.array([(-0.4, 0.3), (0.35, -0.25), (0.3, 0.4), (-0.2, -0.45)])
+    depth = d / (xy @ n[:2] + n[2])
+    pts = np.column_stack([xy * depth[:, None], depth])
+    x1, x2 = _two_view(pts, R, t)
+    m = ol.estimate_models(6, np.hstack([x1, x2]))
+    assert len(m) == 1
+    H = m[0][:9].reshape(3, 3)
+    Ht = R + np.outer(t, n) / d
+    c = np.sum(H * Ht) / (np.linalg.norm(H) * np.linalg.norm(Ht))
+    assert abs(abs(c) - 1.0) < 1e-10
+    for i in range(4):
+        q = H @ np.append(x1[i], 1.0)
+        assert np.linalg.norm(q[:2] / q[2] - x2[i]) < 1e-12
+
+
+def test_plane_and_known_orientation_minimal_solvers():
+    """estimate_dominant_plane_from_points.cc:62-81 and
+    relative_pose_from_two_points_with_known_rotation.cc:51-88."""
+    p = np.array([[0.0, 0, 1], [1, 0, 1.5], [0, 2, 0.5]])
+    m = ol.estimate_models(7, p)
+    assert len(m) == 1
+    nrm = np.cross(p[1] - p[0], p[2] - p[0]); nrm /= np.linalg.norm(nrm)
+    assert np.allclose(m[0][:3], p[0]) and np.allclose(m[0][3:6], nrm, atol=1e-15)
+    # collinear (|cross|^2 < 1e-6) -> no model
+    assert len(ol.estimate_models(7, np.array([[0.0, 0, 0], [1, 1, 1], [2, 2, 2.0000001]]))) == 0
+    # two correspondences under pure translation: position = -t / |t|
+    t = np.array([0.3, -0.2, 0.9])
+    x1, x2 = _two_view([(-1, 3, 3), (1, -1, 2)], np.eye(3), t)
+    m = ol.estimate_models(8, np.hstack([x1, x2]))
+    assert len(m) == 1
+    pos = m[0][:3]
+    assert abs(np.linalg.norm(pos) - 1.0) < 1e-15
+    assert abs(abs(pos @ (t / np.linalg.norm(t))) - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("kind,est,thresh", [("fundamental", 5, 4.0), ("homography", 6, 16.0),
+                                             ("plane", 7, 0.004), ("known_orientation", 8, (2.0 / 1000.0) ** 2)])
+def test_new_estimators_recover_the_synthetic_inliers(kind, est, thresh):
+    data, offsets, truth = synth.synth_ransac_v1(2, 300, kind=kind, seed=0x5AC51400, inlier_lo=0.45, inlier_hi=0.7)
+    for p in range(2):
+        d = data[offsets[p]:offsets[p + 1]]
+        prm = ol.default_ransac_params(thresh, seed=7 + p)
+        prm.failure_probability = 0.001
+        r = ol.ransac_estimate(est, d, prm)
+        assert r["success"]
+        tin = truth["inlier"][p]
+        mask = r["inlier_mask"].astype(bool)
+        # nearly all true inliers are found and few outliers slip in
+        assert (mask & tin).sum() >= 0.75 * tin.sum()
+        assert (mask & ~tin).sum() <= 0.1 * tin.sum() + 3
+        if kind == "plane":
+            nrm = r["model"][3:6]
+            assert abs(abs(nrm @ truth["plane_normal"][p]) - 1.0) < 1e-4
+        if kind == "known_orientation":
+            pos = r["model"][:3]
+            assert abs(abs(pos @ truth["position"][p]) - 1.0) < 1e-3
+
+
+def test_exhaustive_sampler_enumerates_pairs_in_order():
+    """exhaustive_sampler.cc:61-79: (0,1), (0,2), ..., (0,n-1), (1,2), ... wrapping around."""
+    data, offsets, _ = synth.synth_ransac_v1(1, 6, "known_orientation", seed=9, inlier_lo=1.0, inlier_hi=1.0)
+    pairs = [(i, j) for i in range(6) for j in range(i + 1, 6)]
+    for k in (1, 2, 5, 6, 15, 16):
+        prm = ol.default_ransac_params(1e-30, seed=0)   # nothing is an inlier: the last... first best model is kept
+        prm.ransac_type = 3; prm.min_iterations = k; prm.max_iterations = k
+        r = ol.ransac_estimate(8, data, prm, trace_capacity=64)
+        assert r["num_iterations"] == k
+    # with a generous threshold and one iteration the model is the (0, 1) pair's
+    prm = ol.default_ransac_params(1.0, seed=0); prm.ransac_type = 3; prm.min_iterations = 1; prm.max_iterations = 1
+    r = ol.ransac_estimate(8, data, prm)
+    assert np.array_equal(r["model"][:3], ol.estimate_models(8, data[[0, 1]])[0][:3])
+    assert len(pairs) == 15

@@ -250,3 +250,70 @@ def test_golden_ransac_variants_on_gpu():
                 assert np.abs(res["models"][i][:12] - g[f"{name}_models"][i]).max() <= 1e-9
             else:
                 assert np.array_equal(res["models"][i][:12], g[f"{name}_models"][i], equal_nan=True)
+
+
+NEW_EST = [("fundamental", 5, 4.0, 9), ("homography", 6, 16.0, 9), ("plane", 7, 0.004, 6),
+           ("known_orientation", 8, (2.0 / 1000.0) ** 2, 3)]
+
+
+@pytest.mark.parametrize("kind,est,thresh,mlen", NEW_EST)
+@pytest.mark.parametrize("rtype", [0, 1, 2])
+def test_uncalibrated_and_plane_estimators_bit_identical_to_oracle(kind, est, thresh, mlen, rtype):
+    """EstimateFundamentalMatrix / EstimateHomography / EstimateDominantPlaneFromPoints /
+    EstimateRelativePoseWithKnownOrientation under RANSAC, PROSAC and LMED: same inlier set,
+    iteration count and model as the oracle, problem by problem."""
+    data, offsets, truth = synth.synth_ransac_v1(6, 350, kind, seed=0x5AC51400 + est, inlier_lo=0.45, inlier_hi=0.7)
+    p = ransac.RansacParameters(); p.error_thresh = thresh; p.seed = 91; p.failure_probability = 0.001
+    pc0 = p.to_c(); pc0.ransac_type = rtype
+    res = ransac.estimate_batch(est, data, offsets, pc0)
+    for i in range(6):
+        pc = p.to_c(); pc.seed = 91 + i; pc.ransac_type = rtype
+        o = ol.ransac_estimate(est, data[offsets[i]:offsets[i + 1]], pc)
+        sl = slice(offsets[i], offsets[i + 1])
+        assert np.array_equal(o["inlier_mask"], res["inlier_mask"][sl])
+        assert o["num_iterations"] == res["num_iterations"][i] and o["num_inliers"] == res["num_inliers"][i]
+        assert np.array_equal(o["model"][:mlen], res["models"][i][:mlen])
+        assert np.all(res["models"][i][mlen:] == 0)
+        if rtype == 0:
+            assert res["inlier_mask"][sl][truth["inlier"][i]].mean() > 0.6
+
+
+def test_exhaustive_ransac_pairs_bit_identical_to_oracle():
+    """ExhaustiveRansac (exhaustive_sampler.cc:45-79) is only valid for 2-sample estimators."""
+    data, offsets, truth = synth.synth_ransac_v1(5, 120, "known_orientation", seed=0x5AC51500, inlier_lo=0.45, inlier_hi=0.7)
+    p = ransac.RansacParameters(); p.error_thresh = (2.0 / 1000.0) ** 2; p.seed = 1
+    pc = p.to_c(); pc.ransac_type = 3
+    res = ransac.estimate_batch(8, data, offsets, pc)
+    for i in range(5):
+        o = ol.ransac_estimate(8, data[offsets[i]:offsets[i + 1]], pc)
+        sl = slice(offsets[i], offsets[i + 1])
+        assert np.array_equal(o["inlier_mask"], res["inlier_mask"][sl])
+        assert o["num_iterations"] == res["num_iterations"][i]
+        assert np.array_equal(o["model"][:3], res["models"][i][:3])
+        # the first ~100 pairs all contain datum 0, so the fit is only as good as that datum
+        assert res["num_inliers"][i] >= 2
+    # any other estimator: the reference CHECK-fails
+    d2, o2, _ = synth.synth_ransac_v1(1, 50, "relative", seed=2)
+    with pytest.raises(Exception, match="number of samples needed is 2"):
+        ransac.estimate_batch(0, d2, o2, pc)
+
+
+def test_new_estimator_mirror_functions():
+    data, _, truth = synth.synth_ransac_v1(1, 300, "fundamental", seed=5, inlier_lo=0.6, inlier_hi=0.6)
+    p = ransac.RansacParameters(); p.error_thresh = 4.0; p.seed = 3
+    ok, F, s = ransac.EstimateFundamentalMatrix(p, ransac.RansacType.RANSAC, data)
+    assert ok and F.shape == (3, 3) and abs(np.linalg.det(F / np.linalg.norm(F))) < 1e-10 and len(s.inliers) > 100
+    data, _, truth = synth.synth_ransac_v1(1, 300, "homography", seed=6, inlier_lo=0.6, inlier_hi=0.6)
+    p.error_thresh = 16.0
+    ok, H, s = ransac.EstimateHomography(p, ransac.RansacType.RANSAC, data)
+    assert ok and len(s.inliers) > 100
+    q = np.column_stack([data[s.inliers, :2], np.ones(len(s.inliers))]) @ H.T
+    assert np.max(np.sum((q[:, :2] / q[:, 2:] - data[s.inliers, 2:]) ** 2, axis=1)) < 16.0
+    data, _, truth = synth.synth_ransac_v1(1, 300, "plane", seed=7, inlier_lo=0.6, inlier_hi=0.6)
+    p.error_thresh = 0.004
+    ok, plane, s = ransac.EstimateDominantPlaneFromPoints(p, ransac.RansacType.LMED, data)
+    assert ok and abs(abs(plane.unit_normal @ truth["plane_normal"][0]) - 1.0) < 1e-3
+    data, _, truth = synth.synth_ransac_v1(1, 300, "known_orientation", seed=8, inlier_lo=0.6, inlier_hi=0.6)
+    p.error_thresh = (2.0 / 1000.0) ** 2
+    ok, pos, s = ransac.EstimateRelativePoseWithKnownOrientation(p, ransac.RansacType.RANSAC, data)
+    assert ok and abs(abs(pos @ truth["position"][0]) - 1.0) < 1e-3
