@@ -95,7 +95,7 @@ void launch_cam_priors(const DevProblem& P, int mode, const double* cam, const d
                        const ReduceBuf* rb, double* colsq_c, double* scal_cost, double* scal_mcc, hipStream_t st);
 void launch_finalize_rcs(const DevProblem& P, const double* radius /* device */, const ReduceBuf& rb, hipStream_t st);
 void launch_cam_update(const DevProblem& P, const double* cam, const double* y, double* cand_cam,
-                       double* cand_intr, double* out_stepsq, double* out_xnormsq, hipStream_t st);
+                       double* cand_intr, double* out_stepsq, double* out_xnormsq, hipStream_t st, double* zero16 = nullptr);
 void launch_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,
                     double* cand_pts, const double* yc, const double* Vinv, double* tile_part,
                     double* scal, hipStream_t st);

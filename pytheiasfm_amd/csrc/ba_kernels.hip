@@ -995,7 +995,8 @@ __global__ void k_build_scale_red(DevProblem P, double* __restrict__ scale_red) 
 // their bounds, bundle_adjuster.cc:406-427); their |step|^2 and |x+|^2.
 __global__ void k_cam_update(DevProblem P, const double* __restrict__ cam, const double* __restrict__ y,
                              double* __restrict__ cand, double* __restrict__ cand_intr,
-                             double* __restrict__ out_stepsq, double* __restrict__ out_xnormsq) {
+                             double* __restrict__ out_stepsq, double* __restrict__ out_xnormsq,
+                             double* __restrict__ zero16) {
   __shared__ double s1[256], s2[256];
   double st = 0.0, xn = 0.0;
   const double* yc = y + P.ni;
@@ -1040,7 +1041,11 @@ __global__ void k_cam_update(DevProblem P, const double* __restrict__ cam, const
     if ((int)threadIdx.x < s) { s1[threadIdx.x] += s1[threadIdx.x + s]; s2[threadIdx.x] += s2[threadIdx.x + s]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { *out_stepsq = s1[0]; *out_xnormsq = s2[0]; }
+  if (threadIdx.x == 0) {
+    // first kernel of the trial-step group: it also clears the group's scalar block (saves a memset node)
+    if (zero16) for (int k = 0; k < 16; ++k) zero16[k] = 0.0;
+    *out_stepsq = s1[0]; *out_xnormsq = s2[0];
+  }
 }
 
 // ------------------------------- back-substitution + candidate + trial cost
@@ -1532,8 +1537,8 @@ void launch_finalize_rcs(const DevProblem& P, const double* radius, const Reduce
 }
 
 void launch_cam_update(const DevProblem& P, const double* cam, const double* y, double* cand_cam,
-                       double* cand_intr, double* out_stepsq, double* out_xnormsq, hipStream_t st) {
-  k_cam_update<<<1, 256, 0, st>>>(P, cam, y, cand_cam, cand_intr, out_stepsq, out_xnormsq);
+                       double* cand_intr, double* out_stepsq, double* out_xnormsq, hipStream_t st, double* zero16) {
+  k_cam_update<<<1, 256, 0, st>>>(P, cam, y, cand_cam, cand_intr, out_stepsq, out_xnormsq, zero16);
 }
 
 void launch_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,

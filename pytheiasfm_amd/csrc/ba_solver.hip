@@ -494,10 +494,9 @@ int enqueue_solve_and_backsub(theia_ba_handle_s* h, int slot = 0) {
   double* yc = h->rb.rhs;  // the solution overwrites the rhs row
   chol_plan_solve(h->plan, h->rb.S, h->n, h->rb.rhs, h->chol_work.p, h->rb.scal + SC_NOTPD, h->stream);
   if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][2], h->stream));
-  HIP_TRY(hipMemsetAsync(h->scalB.p, 0, sizeof(double) * 16, h->stream));
   const int nxt = 1 - h->cur;
   launch_cam_update(h->P, h->cam[h->cur].p, yc, h->cam[nxt].p, h->ni ? h->intr[nxt].p : nullptr,
-                    h->scalB.p + SB_STEPSQ_CAM, h->scalB.p + SB_XNORMSQ_CAM, h->stream);
+                    h->scalB.p + SB_STEPSQ_CAM, h->scalB.p + SB_XNORMSQ_CAM, h->stream, h->scalB.p);
   launch_backsub(h->P, h->cam[h->cur].p, h->pts[h->cur].p, h->cam[nxt].p, h->pts[nxt].p, yc, h->Vinv.p, h->tile_part.p, h->scalB.p, h->stream);
   if (h->ntiles_main) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 5, h->f2s.p + 8, h->fmaxflag.p + 8, h->scalB.p, h->stream);
   launch_long_backsub(h->P, h->cam[h->cur].p, h->pts[h->cur].p, h->cam[nxt].p, h->pts[nxt].p, yc, h->Vinv.p, h->long_scratch.p, h->scalB.p, h->stream);

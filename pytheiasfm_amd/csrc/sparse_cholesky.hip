@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_sp_update(double* __restrict__ A, int l
 // x_K = Linv_K^T (y_K - sum_I L(I,K)^T x_I), I over the (already solved) ancestors
 __global__ __launch_bounds__(256) void k_sp_back(const double* __restrict__ A, int lda, const int* __restrict__ items,
                                                  const int* __restrict__ srcs, const double* __restrict__ Linv,
-                                                 const double* __restrict__ y, double* __restrict__ x) {
+                                                 const double* y, double* x) {   // x may alias y (in place)
   __shared__ double xs[NB], yk[NB], part[4][NB];
   const int* it = items + 5 * blockIdx.x;
   const int k0 = it[0], nb = it[1], sbeg = it[3], send = it[4];
@@ -395,7 +395,10 @@ void chol_plan_solve(const CholPlan* pl, double* A, int lda, double* b, double* 
   if (n <= 0) return;
   if (pl->dense) { dense_cholesky_solve(n, A, lda, b, work, fail_flag, st); return; }
   double* Linv = work;
-  double* x = work + (size_t)pl->nt * NB * NB;
+  // back-substitution in place when the solution goes where the rhs row lives (the caller's layout): a tile
+  // reads only its OWN y and the x of tiles solved by earlier launches
+  const bool inplace = (b == A + (size_t)n * lda);
+  double* x = inplace ? b : work + (size_t)pl->nt * NB * NB;
   const int* pg = pl->prog;
   if (pl->nsymm) k_sp_symm<<<pl->nsymm, 256, 0, st>>>(A, lda, pg + pl->symm_off);
   for (const Level& lv : pl->lev) {
@@ -408,7 +411,7 @@ void chol_plan_solve(const CholPlan* pl, double* A, int lda, double* b, double* 
     const Level& lv = pl->lev[l];
     k_sp_back<<<lv.nback, 256, 0, st>>>(A, lda, pg + lv.back_off, pg + lv.back_src_off, Linv, y, x);
   }
-  (void)hipMemcpyAsync(b, x, sizeof(double) * n, hipMemcpyDeviceToDevice, st);
+  if (!inplace) (void)hipMemcpyAsync(b, x, sizeof(double) * n, hipMemcpyDeviceToDevice, st);
 }
 
 }  // namespace thip
