@@ -369,7 +369,12 @@ enum {
   THEIA_EST_DOMINANT_PLANE = 7,
   /* EstimateRelativePoseWithKnownOrientation,
    * estimate_relative_pose_with_known_orientation.cc:66-81 (2 correspondences) */
-  THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION = 8
+  THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION = 8,
+  /* EstimateUncalibratedRelativePose, estimate_uncalibrated_relative_pose.cc:204-220:
+   * 8-point F, focal lengths from F, E = K2 F K1 decomposed with the cheirality vote;
+   * data in pixels with the principal point removed.  estimator_params = {min, max}
+   * focal length (both >= 1 to be applied, as in the reference). */
+  THEIA_EST_UNCALIBRATED_RELATIVE_POSE = 9
 };
 
 /* A batch of independent estimation problems ("pairs").  Datum layout:
@@ -384,6 +389,7 @@ typedef struct theia_ransac_batch {
   int32_t num_problems;
   const int64_t* offsets;      /* [num_problems+1] datum offsets           */
   const double* data;          /* [offsets[num_problems]][datum_size]      */
+  const double* estimator_params; /* estimator constants (see THEIA_EST_*), or NULL */
 } theia_ransac_batch;
 
 /* Result per problem.  model layout:
@@ -392,8 +398,9 @@ typedef struct theia_ransac_batch {
  *   ABSOLUTE_POSE_*:  R(9, row-major) position(3)                   = 12
  *   FUNDAMENTAL_MATRIX / HOMOGRAPHY: 3x3 row-major                  = 9
  *   DOMINANT_PLANE:   point(3) unit_normal(3)                       = 6
- *   RELATIVE_POSE_KNOWN_ORIENTATION: unit position of camera 2      = 3 */
-#define THEIA_RANSAC_MODEL_STRIDE 21
+ *   RELATIVE_POSE_KNOWN_ORIENTATION: unit position of camera 2      = 3
+ *   UNCALIBRATED_RELATIVE_POSE: F(9) R(9) position(3) focal_length1 focal_length2 = 23 */
+#define THEIA_RANSAC_MODEL_STRIDE 24
 typedef struct theia_ransac_result {
   int32_t* success;            /* [num_problems] Estimate() return value   */
   double* models;              /* [num_problems][THEIA_RANSAC_MODEL_STRIDE]*/

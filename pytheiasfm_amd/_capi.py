@@ -12,7 +12,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtheia_hip.so")
 
 THEIA_MAX_INTRINSICS = 10
-THEIA_RANSAC_MODEL_STRIDE = 21
+THEIA_RANSAC_MODEL_STRIDE = 24
+# error codes (include/theia_hip.h:26-33)
+THEIA_HIP_ERR_INVALID_ARGUMENT, THEIA_HIP_ERR_NO_DEVICE, THEIA_HIP_ERR_UNSUPPORTED = -1, -2, -3
+THEIA_HIP_ERR_OUT_OF_MEMORY, THEIA_HIP_ERR_INTERNAL = -4, -5
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -99,7 +102,7 @@ class RansacParams(C.Structure):
 
 class RansacBatch(C.Structure):
     _fields_ = [("estimator", C.c_int32), ("num_problems", C.c_int32),
-                ("offsets", c_int64_p), ("data", c_double_p)]
+                ("offsets", c_int64_p), ("data", c_double_p), ("estimator_params", c_double_p)]
 
 
 class RansacResult(C.Structure):

@@ -43,7 +43,7 @@ constexpr int kStride = THEIA_RANSAC_MODEL_STRIDE;
 __host__ __device__ inline int sample_size(int est) {
   switch (est) {
     case THEIA_EST_RELATIVE_POSE: case THEIA_EST_ESSENTIAL_MATRIX: return 5;
-    case THEIA_EST_FUNDAMENTAL_MATRIX: return 8;
+    case THEIA_EST_FUNDAMENTAL_MATRIX: case THEIA_EST_UNCALIBRATED_RELATIVE_POSE: return 8;
     case THEIA_EST_HOMOGRAPHY: return 4;
     case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: return 2;
     default: return 3;
@@ -63,8 +63,11 @@ constexpr int kMaxSampleDoubles = 32;   // 8 correspondences x 4
 // estimate_essential_matrix.cc:62-73, estimate_calibrated_absolute_pose.cc:76-118).
 // EST >= 0: compile-time estimator (k_fit: each instantiation carries only its own solver's scratch frame);
 // EST < 0: runtime dispatch on `est`.
+// estimator constants that are not data (UncalibratedRelativePoseEstimator's min / max focal length)
+struct EstParams { double min_focal, max_focal; };
+
 template <int EST = -1>
-__device__ int estimate_models(int est, const double* subset, double* models) {
+__device__ int estimate_models(int est, const double* subset, double* models, EstParams ep = EstParams{0.0, 0.0}) {
   if (EST >= 0) est = EST;
   constexpr bool any = EST < 0;
   if ((any || EST == THEIA_EST_RELATIVE_POSE || EST == THEIA_EST_ESSENTIAL_MATRIX) &&
@@ -120,7 +123,11 @@ __device__ int estimate_models(int est, const double* subset, double* models) {
   if ((any || EST >= THEIA_EST_FUNDAMENTAL_MATRIX) && est >= THEIA_EST_FUNDAMENTAL_MATRIX) {
     bool ok = false;
     for (int k = 0; k < kStride; ++k) models[k] = 0.0;
-    if (est == THEIA_EST_FUNDAMENTAL_MATRIX) ok = rsc::eight_point_fundamental(subset, models);
+    if (est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE) {
+      const double mm[2] = {ep.min_focal, ep.max_focal};
+      ok = rsc::uncalibrated_relative_pose(subset, mm, models);
+    }
+    else if (est == THEIA_EST_FUNDAMENTAL_MATRIX) ok = rsc::eight_point_fundamental(subset, models);
     else if (est == THEIA_EST_HOMOGRAPHY) ok = rsc::four_point_homography(subset, models);
     else if (est == THEIA_EST_DOMINANT_PLANE) ok = rsc::plane_from_three_points(subset, models);
     else if (est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION) ok = rsc::two_point_relative_position(subset, models);
@@ -140,6 +147,7 @@ __device__ inline double model_error(int est, const double* m, const double* d) 
   if (est == THEIA_EST_HOMOGRAPHY) return rsc::homography_error(m, d);
   if (est == THEIA_EST_DOMINANT_PLANE) return rsc::plane_error(m, d);
   if (est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION) return rsc::known_orientation_error(m, d);
+  if (est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE) return rsc::uncalibrated_relative_pose_error(m, d);
   const double dx = d[2] - m[9], dy = d[3] - m[10], dz = d[4] - m[11];
   const double px = (m[0] * dx + m[1] * dy) + m[2] * dz;
   const double py = (m[3] * dx + m[4] * dy) + m[5] * dz;
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int
                                             const double* __restrict__ data, const int* __restrict__ samples,
                                             const int* __restrict__ active_iters, double* __restrict__ models,
                                             int* __restrict__ counts, int* __restrict__ dense_count,
-                                            int* __restrict__ tags) {
+                                            int* __restrict__ tags, EstParams ep) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int p = blockIdx.y;
   if (b >= B || p >= nprob) return;
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int
     for (int k = 0; k < ds; ++k) subset[i * ds + k] = pd[(size_t)idx * ds + k];
   }
   double mloc[kMaxCap * kStride];
-  const int nm = estimate_models<EST>(est, subset, mloc);
+  const int nm = estimate_models<EST>(est, subset, mloc, ep);
   counts[hyp] = nm;
   if (nm == 0) return;
   // append to the problem's DENSE model list (most of the 10 slots per hypothesis
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(256) void k_inlier_mask_lmed(int est, int nprob, co
 // and mark the inliers of every datum (sample_consensus_estimator.h:396-399).
 __global__ void k_refit(int est, int nprob, const int64_t* __restrict__ offsets, const double* __restrict__ data,
                         const int* __restrict__ best_samples, const int* __restrict__ best_slot,
-                        double* __restrict__ out_models) {
+                        double* __restrict__ out_models, EstParams ep) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nprob) return;
   double* mo = out_models + (size_t)p * kStride;
@@ -333,7 +341,7 @@ __global__ void k_refit(int est, int nprob, const int64_t* __restrict__ offsets,
     for (int k = 0; k < ds; ++k) subset[i * ds + k] = pd[(size_t)idx * ds + k];
   }
   double mloc[kMaxCap * kStride];
-  const int nm = estimate_models(est, subset, mloc);
+  const int nm = estimate_models(est, subset, mloc, ep);
   const int j = best_slot[p];
   if (j < nm) for (int k = 0; k < kStride; ++k) mo[k] = mloc[j * kStride + k];
 }
@@ -634,9 +642,14 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   if (!(P.failure_probability < 1.0) || !(P.failure_probability > 0.0)) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "failure_probability must be in (0, 1)");
   if (P.max_iterations < P.min_iterations) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "max_iterations < min_iterations");
   const int est = batch->estimator;
+  EstParams ep{0.0, 0.0};
+  if (est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE && batch->estimator_params) {
+    ep.min_focal = batch->estimator_params[0];
+    ep.max_focal = batch->estimator_params[1];
+  }
   if (est == THEIA_EST_ABSOLUTE_POSE_DLS)
     return set_error(THEIA_HIP_ERR_UNSUPPORTED, "the DLS minimal solver has no HIP kernel yet");
-  if (est < 0 || est > THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
+  if (est < 0 || est > THEIA_EST_UNCALIBRATED_RELATIVE_POSE) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
   const bool abs_pose = est == THEIA_EST_ABSOLUTE_POSE_KNEIP || est == THEIA_EST_ABSOLUTE_POSE_SQPNP;
   if (P.use_lo && !abs_pose)
     return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: only the absolute-pose RefineModel (BundleAdjustView) is built; "
@@ -833,7 +846,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       HIP_TRYR(hipEventRecord(ev0, st));
       {
         dim3 grid((B + 63) / 64, cn);
-#define THIP_FIT(E) k_fit<E><<<grid, 64, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_models.p, d_counts.p, d_dense.p, d_tags.p)
+#define THIP_FIT(E) k_fit<E><<<grid, 64, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, ep)
         switch (est) {
           case THEIA_EST_RELATIVE_POSE: THIP_FIT(THEIA_EST_RELATIVE_POSE); break;
           case THEIA_EST_ESSENTIAL_MATRIX: THIP_FIT(THEIA_EST_ESSENTIAL_MATRIX); break;
@@ -842,7 +855,8 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
           case THEIA_EST_FUNDAMENTAL_MATRIX: THIP_FIT(THEIA_EST_FUNDAMENTAL_MATRIX); break;
           case THEIA_EST_HOMOGRAPHY: THIP_FIT(THEIA_EST_HOMOGRAPHY); break;
           case THEIA_EST_DOMINANT_PLANE: THIP_FIT(THEIA_EST_DOMINANT_PLANE); break;
-          default: THIP_FIT(THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION); break;
+          case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: THIP_FIT(THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION); break;
+          default: THIP_FIT(THEIA_EST_UNCALIBRATED_RELATIVE_POSE); break;
         }
 #undef THIP_FIT
       }
@@ -938,7 +952,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     return rc;
   HIP_TRYR(hipMemcpyAsync(d_best_samples.p, best_samples_all.data(), sizeof(int) * nprob * kMaxSample, hipMemcpyHostToDevice, st));
   HIP_TRYR(hipMemcpyAsync(d_best_slot.p, best_slot_all.data(), sizeof(int) * nprob, hipMemcpyHostToDevice, st));
-  k_refit<<<(nprob + 63) / 64, 64, 0, st>>>(est, nprob, d_off.p, d_data.p, d_best_samples.p, d_best_slot.p, d_best_models.p);
+  k_refit<<<(nprob + 63) / 64, 64, 0, st>>>(est, nprob, d_off.p, d_data.p, d_best_samples.p, d_best_slot.p, d_best_models.p, ep);
   if (P.use_lo) {   // the best model of a problem may be the refined pose of its last LO event
     std::vector<int> use_cur(nprob);
     for (int p = 0; p < nprob; ++p) use_cur[p] = (S[p].best_refined && S[p].best_slot >= 0) ? 1 : 0;

@@ -1330,6 +1330,77 @@ RDEV int best_pose_from_E(const double* E, const double* corr, int ncorr, double
   return bestcount;
 }
 
+// FocalLengthsFromFundamentalMatrix (sfm/pose/fundamental_matrix_util.cc:57-130).
+// F row-major.  Epipoles = last right singular vectors of F and F^T.
+RDEV bool focal_lengths_from_fundamental(const double* F, double* f1, double* f2) {
+  double U[9], S[3], V[9], Ft[9];
+  svd3(F, U, S, V);
+  const double e1[3] = {V[2], V[5], V[8]};
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Ft[3 * r + c] = F[3 * c + r];
+  svd3(Ft, U, S, V);
+  const double e2[3] = {V[2], V[5], V[8]};
+  if (e1[0] == 0 || e2[0] == 0) return false;
+  const double theta1 = atan2(-e1[1], e1[0]);
+  const double theta2 = atan2(-e2[1], e2[0]);
+  const double R1[9] = {cos(theta1), -sin(theta1), 0.0, sin(theta1), cos(theta1), 0.0, 0.0, 0.0, 1.0};
+  const double R2[9] = {cos(theta2), -sin(theta2), 0.0, sin(theta2), cos(theta2), 0.0, 0.0, 0.0, 1.0};
+  double R1t[9], tmp[9], rotF[9];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R1t[3 * r + c] = R1[3 * c + r];
+  matmul3(R2, F, tmp);
+  matmul3(tmp, R1t, rotF);
+  double re1[3], re2[3];
+  for (int r = 0; r < 3; ++r) {
+    re1[r] = (R1[3 * r] * e1[0] + R1[3 * r + 1] * e1[1]) + R1[3 * r + 2] * e1[2];
+    re2[r] = (R2[3 * r] * e2[0] + R2[3 * r + 1] * e2[1]) + R2[3 * r + 2] * e2[2];
+  }
+  const double d2i[3] = {1.0 / re2[2], 1.0, 1.0 / (-re2[0])};
+  const double d1i[3] = {1.0 / re1[2], 1.0, 1.0 / (-re1[0])};
+  const double a = (d2i[0] * rotF[0]) * d1i[0];
+  const double b = (d2i[0] * rotF[1]) * d1i[1];
+  const double c = (d2i[1] * rotF[3]) * d1i[0];
+  const double d = (d2i[1] * rotF[4]) * d1i[1];
+  const double f1sq = (-a * c * re1[0] * re1[0]) / (a * c * re1[2] * re1[2] + b * d);
+  const double f2sq = (-a * b * re2[0] * re2[0]) / (a * b * re2[2] * re2[2] + c * d);
+  if (f1sq < 0 || f2sq < 0) return false;
+  *f1 = sqrt(f1sq);
+  *f2 = sqrt(f2sq);
+  return true;
+}
+
+// UncalibratedRelativePoseEstimator::EstimateModel (estimate_uncalibrated_relative_pose.cc:83-138).
+// corr: 8 x [x1 y1 x2 y2], principal point removed; minmax = {min, max} focal length or null.
+// model: F(9) R(9) position(3) focal_length1 focal_length2
+RDEV bool uncalibrated_relative_pose(const double* corr, const double* minmax, double* model) {
+  double* F = model;
+  if (!eight_point_fundamental(corr, F)) return false;
+  double f1, f2;
+  if (!focal_lengths_from_fundamental(F, &f1, &f2)) return false;
+  if (minmax && minmax[0] >= 1.0 && minmax[1] >= 1.0) {
+    if (f1 < minmax[0] || f2 < minmax[0] || f1 > minmax[1] || f2 > minmax[1]) return false;
+  }
+  // EssentialMatrixFromFundamentalMatrix (fundamental_matrix_util.cc:239-249): diag(f2,f2,1) F diag(f1,f1,1)
+  const double dl[3] = {f2, f2, 1.0}, dr[3] = {f1, f1, 1.0};
+  double E[9];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) E[3 * r + c] = (dl[r] * F[3 * r + c]) * dr[c];
+  double nc[32];
+  for (int i = 0; i < 8; ++i) {
+    nc[4 * i] = corr[4 * i] / f1; nc[4 * i + 1] = corr[4 * i + 1] / f1;
+    nc[4 * i + 2] = corr[4 * i + 2] / f2; nc[4 * i + 3] = corr[4 * i + 3] / f2;
+  }
+  best_pose_from_E(E, nc, 8, model + 9, model + 18);
+  model[21] = f1; model[22] = f2;
+  return true;
+}
+
+// UncalibratedRelativePoseEstimator::Error (:181-196): cheirality on the focal-normalised
+// correspondence, then the Sampson distance under F in (centred) pixels
+RDEV double uncalibrated_relative_pose_error(const double* m, const double* d) {
+  const double nd[4] = {d[0] / m[21], d[1] / m[21], d[2] / m[22], d[3] / m[22]};
+  if (!in_front(nd, m + 9, m + 18)) return DBL_MAX;
+  return sampson(m, d);
+}
+
+
 // ----------------------------------------------------------------- P3P
 // math/find_polynomial_roots_companion_matrix.cc for degree >= 3 (the quartic
 // of P3P): normalise, companion matrix, power-of-two balancing (gamma = 0.9),

@@ -30,6 +30,7 @@ class PnPType(enum.IntEnum):  # estimate_calibrated_absolute_pose.h:54
 
 EST_RELATIVE_POSE, EST_ESSENTIAL_MATRIX, EST_ABS_KNEIP, EST_ABS_DLS, EST_ABS_SQPNP = range(5)
 EST_FUNDAMENTAL_MATRIX, EST_HOMOGRAPHY, EST_DOMINANT_PLANE, EST_RELATIVE_POSE_KNOWN_ORIENTATION = range(5, 9)
+EST_UNCALIBRATED_RELATIVE_POSE = 9
 
 
 class RansacParameters:
@@ -105,7 +106,7 @@ def _sig():
     return L
 
 
-def estimate_batch(estimator, data, offsets, params):
+def estimate_batch(estimator, data, offsets, params, estimator_params=None):
     """theia_hip_ransac_estimate_batch.  data [total][datum], offsets [P+1].
     Returns dict of per-problem arrays."""
     L = _sig()
@@ -116,6 +117,8 @@ def estimate_batch(estimator, data, offsets, params):
     b = capi.RansacBatch()
     b.estimator = int(estimator); b.num_problems = P
     b.offsets = capi.ptr(offsets, C.c_int64); b.data = capi.ptr(data, C.c_double)
+    ep = None if estimator_params is None else np.ascontiguousarray(estimator_params, dtype=np.float64)
+    b.estimator_params = None if ep is None else capi.ptr(ep, C.c_double)
     success = np.zeros(max(P, 1), dtype=np.int32); models = np.zeros((max(P, 1), capi.THEIA_RANSAC_MODEL_STRIDE))
     ninl = np.zeros(max(P, 1), dtype=np.int32); mask = np.zeros(max(total, 1), dtype=np.uint8)
     nit = np.zeros(max(P, 1), dtype=np.int32); conf = np.zeros(max(P, 1)); nlo = np.zeros(max(P, 1), dtype=np.int32)
@@ -131,11 +134,11 @@ def estimate_batch(estimator, data, offsets, params):
             "models_scored": r.models_scored, "time_fit_score_seconds": r.time_fit_score_seconds}
 
 
-def _single(estimator, ransac_params, ransac_type, data):
+def _single(estimator, ransac_params, ransac_type, data, estimator_params=None):
     data = np.ascontiguousarray(data, dtype=np.float64)
     pc = ransac_params.to_c()
     pc.ransac_type = int(RansacType(ransac_type))
-    res = estimate_batch(estimator, data, np.array([0, data.shape[0]], dtype=np.int64), pc)
+    res = estimate_batch(estimator, data, np.array([0, data.shape[0]], dtype=np.int64), pc, estimator_params)
     s = RansacSummary()
     s.inliers = np.nonzero(res["inlier_mask"])[0].tolist()
     s.num_input_data_points = data.shape[0]
@@ -194,6 +197,23 @@ def EstimateRelativePoseWithKnownOrientation(ransac_params, ransac_type, rotated
     rotated into a common frame; returns the unit position of camera 2."""
     ok, m, s = _single(EST_RELATIVE_POSE_KNOWN_ORIENTATION, ransac_params, ransac_type, rotated_correspondences)
     return ok, m[0:3].copy(), s
+
+
+class UncalibratedRelativePose:  # estimate_uncalibrated_relative_pose.h:51-57
+    def __init__(self, m):
+        self.fundamental_matrix = m[0:9].reshape(3, 3).copy()
+        self.rotation = m[9:18].reshape(3, 3).copy()
+        self.position = m[18:21].copy()
+        self.focal_length1 = float(m[21])
+        self.focal_length2 = float(m[22])
+
+
+def EstimateUncalibratedRelativePose(ransac_params, ransac_type, centered_correspondences, min_max_focal_length=(1.0, 1.7976931348623157e308)):
+    """estimate_uncalibrated_relative_pose.cc:204-220.  correspondences: (N,4) pixels with the
+    principal point removed."""
+    ok, m, s = _single(EST_UNCALIBRATED_RELATIVE_POSE, ransac_params, ransac_type, centered_correspondences,
+                       np.asarray(min_max_focal_length, dtype=np.float64))
+    return ok, UncalibratedRelativePose(m), s
 
 
 def FivePointRelativePose(image1_points, image2_points):

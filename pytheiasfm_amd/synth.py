@@ -285,6 +285,7 @@ def synth_ransac_v1(num_problems, num_corr, kind="relative", seed=0x5AC50000, fo
       kind = "relative": data [P*N][4] = (x1 y1 x2 y2), FeatureCorrespondence
       kind = "absolute": data [P*N][5] = (u v X Y Z),   FeatureCorrespondence2D3D
       kind = "fundamental": as "relative" but in pixels (focal, principal point 500,400)
+      kind = "uncalibrated": pixels with the principal point removed, focal lengths f and 1.25 f
       kind = "homography":  as "fundamental" with the 3-D points on one plane per problem
       kind = "known_orientation": as "relative" with identity rotation (features already rotated)
       kind = "plane": data [P*N][3] = 3-D points, inliers within noise_px/focal of a plane
@@ -328,10 +329,13 @@ def synth_ransac_v1(num_problems, num_corr, kind="relative", seed=0x5AC50000, fo
     elif kind == "absolute":
         uv = np.where(is_in[:, :, None], x2 + nz[:, :, 2:], out2)
         data = np.concatenate([uv, X], axis=2).reshape(P * N, 5)
-    elif kind in ("fundamental", "homography", "known_orientation"):
+    elif kind in ("fundamental", "homography", "known_orientation", "uncalibrated"):
         a = np.stack([x1, y1], axis=2) + nz[:, :, :2]
         b = np.where(is_in[:, :, None], x2 + nz[:, :, 2:], out2)
-        if kind != "known_orientation":
+        if kind == "uncalibrated":
+            a = a * focal
+            b = b * (1.25 * focal)
+        elif kind != "known_orientation":
             pp = np.array([500.0, 400.0])
             a = a * focal + pp
             b = b * focal + pp

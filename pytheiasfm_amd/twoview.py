@@ -1,0 +1,195 @@
+"""Host-side mirror of the two-view geometric verification front-end
+(sfm/estimate_twoview_info.cc:133-305): EstimateTwoViewInfo = feature
+normalisation + EstimateRelativePose (both views calibrated) or
+EstimateUncalibratedRelativePose (otherwise) + TwoViewInfo bookkeeping.  The
+RANSAC itself runs on the device through theia_hip_ransac_estimate_batch; a list
+of image pairs goes down as ONE batch per (branch, error threshold) group.
+
+Only the feature normalisation of the PINHOLE prior without radial distortion is
+done here (pinhole_camera_model.h:214-241 with the undistortion being the
+identity); any other prior raises, so that the caller keeps its CPU path.
+"""
+import numpy as np
+
+from . import _capi as capi
+from . import ransac as _ransac
+
+
+class Prior:  # camera_intrinsics_prior.h:55-80
+    def __init__(self, n):
+        self.is_set = False
+        self.value = [0.0] * n
+
+
+class CameraIntrinsicsPrior:  # camera_intrinsics_prior.h:83-111 (the fields this path reads)
+    def __init__(self):
+        self.image_width = 0
+        self.image_height = 0
+        self.camera_intrinsics_model_type = "PINHOLE"
+        self.focal_length = Prior(1)
+        self.principal_point = Prior(2)
+        self.aspect_ratio = Prior(1)
+        self.skew = Prior(1)
+        self.radial_distortion = Prior(4)
+
+
+class EstimateTwoViewInfoOptions:  # estimate_twoview_info.h:51-81
+    def __init__(self):
+        self.ransac_type = _ransac.RansacType.RANSAC
+        self.max_sampson_error_pixels = 6.0
+        self.expected_ransac_confidence = 0.9999
+        self.min_ransac_iterations = 10
+        self.max_ransac_iterations = 1000
+        self.use_mle = True
+        self.use_lo = False
+        self.lo_start_iterations = 10
+        self.min_focal_length = 1.0
+        self.max_focal_length = 1.7976931348623157e308
+        self.seed = 0   # RandomNumberGenerator seed (options.rng in the reference)
+
+
+class TwoViewInfo:  # twoview_info.h:54-86
+    def __init__(self):
+        self.focal_length_1 = 0.0
+        self.focal_length_2 = 0.0
+        self.position_2 = np.zeros(3)
+        self.rotation_2 = np.zeros(3)
+        self.num_verified_matches = 0
+        self.num_homography_inliers = 0
+        self.visibility_score = 0
+        self.scale_estimate = -1.0
+
+
+def ComputeResolutionScaledThreshold(threshold_pixels, image_width, image_height):
+    """reconstruction_estimator_utils.cc:98-110"""
+    if image_width == 0 and image_height == 0:
+        return threshold_pixels
+    return threshold_pixels * float(max(image_width, image_height)) / 1024.0
+
+
+def _pinhole_from_prior(prior):
+    """PinholeCameraModel::SetFromCameraIntrinsicsPriors (pinhole_camera_model.cc:74-107) on a
+    default-constructed model (focal 1, aspect 1, skew 0, principal point 0)."""
+    if prior.camera_intrinsics_model_type != "PINHOLE":
+        raise capi.TheiaHipError(capi.THEIA_HIP_ERR_UNSUPPORTED,
+                                 "two-view feature normalisation: only the PINHOLE prior is built")
+    if prior.radial_distortion.is_set and any(v != 0.0 for v in prior.radial_distortion.value[:2]):
+        raise capi.TheiaHipError(capi.THEIA_HIP_ERR_UNSUPPORTED,
+                                 "two-view feature normalisation with radial distortion is not built")
+    f, pp = 1.0, [0.0, 0.0]
+    if prior.focal_length.is_set:
+        f = prior.focal_length.value[0]
+    elif prior.image_width != 0 and prior.image_height != 0:
+        f = 1.2 * float(max(prior.image_width, prior.image_height))
+    if prior.principal_point.is_set:
+        pp = [prior.principal_point.value[0], prior.principal_point.value[1]]
+    elif prior.image_width != 0 and prior.image_height != 0:
+        pp = [prior.image_width / 2.0, prior.image_height / 2.0]
+    ar = prior.aspect_ratio.value[0] if prior.aspect_ratio.is_set else 1.0
+    skew = prior.skew.value[0] if prior.skew.is_set else 0.0
+    return f, ar, skew, pp
+
+
+def NormalizeFeatures(prior1, prior2, correspondences):
+    """estimate_twoview_info.cc:67-102: pixels -> camera coordinates; when either focal length
+    prior is missing both focal lengths are reset to 1 (only the principal point is removed)."""
+    c = np.ascontiguousarray(correspondences, dtype=np.float64).reshape(-1, 4)
+    cams = [_pinhole_from_prior(prior1), _pinhole_from_prior(prior2)]
+    if not prior1.focal_length.is_set or not prior2.focal_length.is_set:
+        cams = [(1.0, ar, sk, pp) for (_, ar, sk, pp) in cams]
+    out = np.empty_like(c)
+    for k, (f, ar, sk, pp) in enumerate(cams):
+        y = (c[:, 2 * k + 1] - pp[1]) / (f * ar)
+        x = (c[:, 2 * k] - pp[0] - y * sk) / f
+        out[:, 2 * k] = x
+        out[:, 2 * k + 1] = y
+    return out
+
+
+def _rotation_to_angle_axis(R):
+    """Eigen::AngleAxisd(Matrix3d): through the quaternion (Geometry/AngleAxis.h)."""
+    R = np.asarray(R, dtype=np.float64)
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2.0
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    else:
+        i = int(np.argmax(np.diag(R))); j = (i + 1) % 3; k = (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2.0
+        q = np.zeros(4)
+        q[1 + i] = 0.25 * s
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    n = np.linalg.norm(q[1:])
+    if q[0] < 0:
+        n = -n
+    if abs(n) < 1e-300:
+        return np.zeros(3)
+    angle = 2.0 * np.arctan2(n, abs(q[0]))
+    return angle * q[1:] / n
+
+
+def _ransac_params(options, error_thresh):
+    p = _ransac.RansacParameters()
+    p.failure_probability = 1.0 - options.expected_ransac_confidence
+    p.min_iterations = options.min_ransac_iterations
+    p.max_iterations = options.max_ransac_iterations
+    p.use_lo = options.use_lo
+    p.lo_start_iterations = options.lo_start_iterations
+    p.error_thresh = error_thresh
+    p.use_mle = options.use_mle
+    p.seed = options.seed
+    pc = p.to_c()
+    pc.ransac_type = int(_ransac.RansacType(options.ransac_type))
+    return pc
+
+
+def EstimateTwoViewInfoBatch(options, priors1, priors2, correspondences_list):
+    """EstimateTwoViewInfo for a list of image pairs.  Returns a list of
+    (success, TwoViewInfo, inlier_indices).  Pair i of a group uses RandomNumberGenerator(seed + its
+    rank inside the group), groups = pairs with the same branch and error threshold."""
+    n = len(correspondences_list)
+    results = [None] * n
+    groups = {}
+    for i in range(n):
+        p1, p2 = priors1[i], priors2[i]
+        calibrated = p1.focal_length.is_set and p2.focal_length.is_set
+        t1 = ComputeResolutionScaledThreshold(options.max_sampson_error_pixels, p1.image_width, p1.image_height)
+        t2 = ComputeResolutionScaledThreshold(options.max_sampson_error_pixels, p2.image_width, p2.image_height)
+        thresh = t1 * t2
+        if calibrated:   # estimate_twoview_info.cc:169-171
+            thresh = thresh / (p1.focal_length.value[0] * p2.focal_length.value[0])
+        groups.setdefault((calibrated, thresh), []).append(i)
+    for (calibrated, thresh), idx in groups.items():
+        data = [NormalizeFeatures(priors1[i], priors2[i], correspondences_list[i]) for i in idx]
+        offsets = np.zeros(len(idx) + 1, dtype=np.int64)
+        offsets[1:] = np.cumsum([d.shape[0] for d in data])
+        est = _ransac.EST_RELATIVE_POSE if calibrated else _ransac.EST_UNCALIBRATED_RELATIVE_POSE
+        eparams = None if calibrated else np.array([options.min_focal_length, options.max_focal_length])
+        res = _ransac.estimate_batch(est, np.concatenate(data, axis=0), offsets, _ransac_params(options, thresh), eparams)
+        for k, i in enumerate(idx):
+            ok = bool(res["success"][k])
+            info = TwoViewInfo()
+            inliers = []
+            if ok:
+                m = res["models"][k]
+                info.rotation_2 = _rotation_to_angle_axis(m[9:18].reshape(3, 3))
+                info.position_2 = m[18:21].copy()
+                if calibrated:
+                    info.focal_length_1 = priors1[i].focal_length.value[0]
+                    info.focal_length_2 = priors2[i].focal_length.value[0]
+                else:
+                    info.focal_length_1 = float(m[21]); info.focal_length_2 = float(m[22])
+                inliers = np.nonzero(res["inlier_mask"][offsets[k]:offsets[k + 1]])[0].tolist()
+                info.num_verified_matches = len(inliers)
+                # estimate_twoview_info.cc:190-193: the visibility score is computed from
+                # *inlier_indices BEFORE the inliers are stored in it, i.e. from an empty list
+                info.visibility_score = 0
+            results[i] = (ok, info, inliers)
+    return results
+
+
+def EstimateTwoViewInfo(options, intrinsics1, intrinsics2, correspondences):
+    """estimate_twoview_info.cc:262-305 -> (success, TwoViewInfo, inlier_indices)."""
+    return EstimateTwoViewInfoBatch(options, [intrinsics1], [intrinsics2], [correspondences])[0]

@@ -225,7 +225,7 @@ def rot_quat_roundtrip(R):
 
 def estimate_models(est, subset):
     subset = np.ascontiguousarray(subset, dtype=np.float64)
-    m = np.zeros((18, 21))
+    m = np.zeros((18, capi.THEIA_RANSAC_MODEL_STRIDE))
     n = rlib().oracle_estimate_models(est, capi.ptr(subset, C.c_double), capi.ptr(m, C.c_double))
     return m[:n]
 
@@ -261,10 +261,15 @@ def default_ransac_params(error_thresh, seed=0):
     return p
 
 
+def set_estimator_params(p):
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    rlib().oracle_set_estimator_params(capi.ptr(p, C.c_double), len(p))
+
+
 def ransac_estimate(est, data, params, trace_capacity=0):
     data = np.ascontiguousarray(data, dtype=np.float64)
     n = data.shape[0]
-    model = np.zeros(21); mask = np.zeros(n, dtype=np.uint8)
+    model = np.zeros(capi.THEIA_RANSAC_MODEL_STRIDE); mask = np.zeros(n, dtype=np.uint8)
     ninl = C.c_int32(0); nit = C.c_int32(0); conf = C.c_double(0); scored = C.c_int64(0)
     cap = max(1, trace_capacity)
     ti = np.zeros(cap, dtype=np.int32); tc = np.zeros(cap); tn = np.zeros(cap, dtype=np.int32); ts = C.c_int32(0)

@@ -126,3 +126,40 @@ def test_world_size_2_reduction_of_the_reduced_camera_system():
         assert pr.exitcode == 0
     s_err, r_err, pts_ok = res
     assert s_err < 1e-12 and r_err < 1e-10 and pts_ok
+
+
+def test_two_view_front_end_host_logic():
+    """estimate_twoview_info.cc:67-102,155-171 + reconstruction_estimator_utils.cc:98-110."""
+    from pytheiasfm_amd import twoview as tv
+    assert tv.ComputeResolutionScaledThreshold(6.0, 0, 0) == 6.0
+    assert tv.ComputeResolutionScaledThreshold(6.0, 2048, 1536) == 12.0
+    p1 = tv.CameraIntrinsicsPrior(); p1.image_width = 1000; p1.image_height = 800
+    p1.focal_length.is_set = True; p1.focal_length.value = [900.0]
+    p2 = tv.CameraIntrinsicsPrior(); p2.image_width = 640; p2.image_height = 480
+    p2.focal_length.is_set = True; p2.focal_length.value = [700.0]
+    p2.principal_point.is_set = True; p2.principal_point.value = [300.0, 250.0]
+    c = np.array([[600.0, 500.0, 400.0, 300.0]])
+    n = tv.NormalizeFeatures(p1, p2, c)
+    assert np.allclose(n, [[(600 - 500) / 900.0, (500 - 400) / 900.0, (400 - 300) / 700.0, (300 - 250) / 700.0]])
+    # one focal length missing: both are reset to 1, only the principal point is removed
+    p2.focal_length.is_set = False
+    n = tv.NormalizeFeatures(p1, p2, c)
+    assert np.allclose(n, [[100.0, 100.0, 100.0, 50.0]])
+    # skew and aspect ratio (pinhole_camera_model.h:228-232)
+    p2.focal_length.is_set = True
+    p2.aspect_ratio.is_set = True; p2.aspect_ratio.value = [1.1]; p2.skew.is_set = True; p2.skew.value = [2.0]
+    n = tv.NormalizeFeatures(p1, p2, c)
+    y = (300 - 250) / (700.0 * 1.1)
+    assert np.allclose(n[0, 2:], [(400 - 300 - y * 2.0) / 700.0, y])
+    # unsupported priors are refused, not approximated
+    p2.radial_distortion.is_set = True; p2.radial_distortion.value = [0.1, 0, 0, 0]
+    with pytest.raises(Exception, match="radial distortion"):
+        tv.NormalizeFeatures(p1, p2, c)
+    p1.camera_intrinsics_model_type = "FISHEYE"
+    with pytest.raises(Exception, match="PINHOLE"):
+        tv.NormalizeFeatures(p1, p1, c)
+    # Eigen::AngleAxisd(R)
+    from pytheiasfm_amd import synth
+    for w in ([0.1, -0.2, 0.3], [2.0, 1.0, -1.5], [0.0, 0.0, 0.0], [3.0, 0.2, 0.1]):
+        w = np.array(w)
+        assert np.allclose(tv._rotation_to_angle_axis(synth.angle_axis_to_matrix(w)), w, atol=1e-12)

@@ -561,3 +561,43 @@ def test_exhaustive_sampler_enumerates_pairs_in_order():
     r = ol.ransac_estimate(8, data, prm)
     assert np.array_equal(r["model"][:3], ol.estimate_models(8, data[[0, 1]])[0][:3])
     assert len(pairs) == 15
+
+
+def test_uncalibrated_relative_pose_minimal_model():
+    """estimate_uncalibrated_relative_pose.cc:83-138 on exact data: the focal lengths
+    (fundamental_matrix_util.cc:57-130), rotation and position direction come back."""
+    R = rot((0.3, 1.0, -0.2), 14.0); position = np.array([0.9, 0.15, -0.3])
+    t = -R @ position
+    x1, x2 = _two_view(EIGHT_PTS, R, t)
+    f1, f2 = 820.0, 1130.0
+    corr = np.hstack([x1 * f1, x2 * f2])
+    ol.set_estimator_params([1.0, 1e9])
+    m = ol.estimate_models(9, corr)
+    assert len(m) == 1
+    m = m[0]
+    assert abs(m[21] - f1) < 1e-6 * f1 and abs(m[22] - f2) < 1e-6 * f2
+    Rm = m[9:18].reshape(3, 3)
+    assert np.degrees(np.arccos(np.clip((np.trace(R @ Rm.T) - 1) / 2, -1, 1))) < 1e-6
+    assert abs(m[18:21] @ position / np.linalg.norm(position) - 1.0) < 1e-10
+    F = m[:9].reshape(3, 3)
+    assert max(sampson(F, corr[i, :2], corr[i, 2:]) for i in range(8)) < 1e-16
+    # focal-length bounds reject the model (:103-109)
+    ol.set_estimator_params([1.0, 1000.0])
+    assert len(ol.estimate_models(9, corr)) == 0
+    ol.set_estimator_params([900.0, 1e9])
+    assert len(ol.estimate_models(9, corr)) == 0
+    # bounds below 1 are ignored
+    ol.set_estimator_params([0.0, 0.0])
+    assert len(ol.estimate_models(9, corr)) == 1
+
+
+def test_estimate_uncalibrated_relative_pose_on_synthetic_pairs():
+    data, offsets, truth = synth.synth_ransac_v1(2, 300, kind="uncalibrated", seed=0x5AC51600, inlier_lo=0.5, inlier_hi=0.7,
+                                                 noise_px=0.3)
+    ol.set_estimator_params([1.0, 1e9])
+    for p in range(2):
+        prm = ol.default_ransac_params(4.0, seed=17 + p); prm.failure_probability = 0.001
+        r = ol.ransac_estimate(9, data[offsets[p]:offsets[p + 1]], prm)
+        assert r["success"]
+        tin = truth["inlier"][p]; mask = r["inlier_mask"].astype(bool)
+        assert (mask & tin).sum() >= 0.7 * tin.sum() and (mask & ~tin).sum() <= 0.1 * tin.sum() + 3

@@ -317,3 +317,60 @@ def test_new_estimator_mirror_functions():
     p.error_thresh = (2.0 / 1000.0) ** 2
     ok, pos, s = ransac.EstimateRelativePoseWithKnownOrientation(p, ransac.RansacType.RANSAC, data)
     assert ok and abs(abs(pos @ truth["position"][0]) - 1.0) < 1e-3
+
+
+@pytest.mark.parametrize("rtype", [0, 1])
+def test_uncalibrated_relative_pose_follows_oracle(rtype):
+    """EstimateUncalibratedRelativePose: same inlier sets and iteration counts as the oracle; the model goes
+    through atan2 / sin / cos of two math libraries, so it is compared to a tolerance."""
+    data, offsets, truth = synth.synth_ransac_v1(6, 300, "uncalibrated", seed=0x5AC51600, inlier_lo=0.5, inlier_hi=0.7,
+                                                 noise_px=0.3)
+    p = ransac.RansacParameters(); p.error_thresh = 4.0; p.seed = 17; p.failure_probability = 0.001
+    pc0 = p.to_c(); pc0.ransac_type = rtype
+    mm = np.array([1.0, 1e9])
+    res = ransac.estimate_batch(9, data, offsets, pc0, mm)
+    ol.set_estimator_params(mm)
+    for i in range(6):
+        pc = p.to_c(); pc.seed = 17 + i; pc.ransac_type = rtype
+        o = ol.ransac_estimate(9, data[offsets[i]:offsets[i + 1]], pc)
+        sl = slice(offsets[i], offsets[i + 1])
+        assert np.array_equal(o["inlier_mask"], res["inlier_mask"][sl])
+        assert o["num_iterations"] == res["num_iterations"][i]
+        assert np.allclose(o["model"][:23], res["models"][i][:23], rtol=1e-9, atol=1e-12)
+        if rtype == 0:
+            assert res["inlier_mask"][sl][truth["inlier"][i]].mean() > 0.6
+    # focal bounds that exclude the truth (1000 / 1250): whatever survives respects them
+    pc0.max_iterations = 2000   # nothing good to find: without a cap the adaptive bound never drops
+    res = ransac.estimate_batch(9, data, offsets, pc0, np.array([1.0, 500.0]))
+    ok = res["success"].astype(bool)
+    assert np.all(res["models"][ok, 21:23] <= 500.0) and np.all(res["models"][ok, 21:23] >= 1.0)
+    assert np.all(res["num_inliers"] < 0.3 * 300)
+
+
+def test_estimate_two_view_info_both_branches():
+    from pytheiasfm_amd import twoview as tv
+    opts = tv.EstimateTwoViewInfoOptions(); opts.seed = 5; opts.max_sampson_error_pixels = 2.0
+    # calibrated pairs: pixels = normalised * 1000 + (500, 400)
+    data, offsets, truth = synth.synth_ransac_v1(3, 400, "fundamental", seed=0x5AC51700, inlier_lo=0.6, inlier_hi=0.8)
+    pr = tv.CameraIntrinsicsPrior(); pr.image_width = 1000; pr.image_height = 800
+    pr.focal_length.is_set = True; pr.focal_length.value = [1000.0]
+    pr.principal_point.is_set = True; pr.principal_point.value = [500.0, 400.0]
+    corr = [data[offsets[i]:offsets[i + 1]] for i in range(3)]
+    out = tv.EstimateTwoViewInfoBatch(opts, [pr] * 3, [pr] * 3, corr)
+    for i, (ok, info, inl) in enumerate(out):
+        assert ok and info.focal_length_1 == 1000.0 and info.num_verified_matches == len(inl) > 150
+        assert info.visibility_score == 0   # the reference's empty-list quirk
+        R = synth.angle_axis_to_matrix(info.rotation_2)
+        ang = np.degrees(np.arccos(np.clip((np.trace(R @ truth["R"][i].T) - 1) / 2, -1, 1)))
+        assert ang < 1.0 and abs(info.position_2 @ truth["position"][i]) > 0.99
+    # single-pair entry point = rank 0 of a batch of one
+    ok, info, inl = tv.EstimateTwoViewInfo(opts, pr, pr, corr[0])
+    assert ok and inl == out[0][2]
+    # uncalibrated: no focal prior; principal point from the image size
+    data, offsets, truth = synth.synth_ransac_v1(2, 400, "uncalibrated", seed=0x5AC51701, inlier_lo=0.6, inlier_hi=0.8, noise_px=0.3)
+    pu = tv.CameraIntrinsicsPrior(); pu.image_width = 1000; pu.image_height = 800
+    corr = [data[offsets[i]:offsets[i + 1]] + np.array([500.0, 400.0, 500.0, 400.0]) for i in range(2)]
+    out = tv.EstimateTwoViewInfoBatch(opts, [pu] * 2, [pu] * 2, corr)
+    for i, (ok, info, inl) in enumerate(out):
+        assert ok and len(inl) > 120
+        assert abs(info.focal_length_1 / 1000.0 - 1.0) < 0.2 and abs(info.focal_length_2 / 1250.0 - 1.0) < 0.2
