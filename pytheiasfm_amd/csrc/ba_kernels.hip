@@ -370,8 +370,31 @@ __global__ void k_make_scale(int count, const double* __restrict__ colsq, double
 // Lanes accumulate in registers and a shuffle reduce-scatter leaves element e
 // of the block in lane(e): no atomics (except for lists split into chunks),
 // fixed summation order, each S entry written once.
-// record of one observation: {W (6 x PD) | T = W V^-1 (6 x PD) | F (2 x 6) | r (2) | T g_p (6)}
-template <int PD> constexpr int rec_stride() { return 12 * PD + 20; }
+// record of one observation: {W = F^T E (6 x PD) | F (2 x 6) | r (2)} = 32 doubles (two 128-B lines) for PD = 3.
+// T = W V^-1 and T g_p are NOT stored: the readers rebuild them from the per-point V^-1 / g_p (L2 resident)
+// with the arithmetic below -- 43 % fewer record bytes written and re-read per linearisation.
+template <int PD> constexpr int rec_stride() { return 6 * PD + 14; }
+
+// T = W V^-1 (6 x PD) and optionally T g, in the order the records used to be built
+template <int PD>
+THIP_DEV void rec_T(const double (&w)[6 * PD], const double (&Vi)[PD * (PD + 1) / 2], double (&t)[6 * PD]) {
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < PD; ++b) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < PD; ++k) s += w[a * PD + k] * sym_get<PD>(Vi, k, b);
+      t[a * PD + b] = s;
+    }
+}
+template <int PD>
+THIP_DEV void load_vinv(const double* __restrict__ Vinv, int p, double (&Vi)[PD * (PD + 1) / 2]) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  const double2* V2 = reinterpret_cast<const double2*>(Vinv + (size_t)NT * p);   // NT = 6 / 10: 16-B aligned rows
+#pragma unroll
+  for (int k = 0; k < NT / 2; ++k) { const double2 v = V2[k]; Vi[2 * k] = v.x; Vi[2 * k + 1] = v.y; }
+}
 
 template <int PD>
 __global__ __launch_bounds__(kBlock) void k_lin_obs(DevProblem P, const double* __restrict__ cam,
@@ -423,34 +446,16 @@ __global__ __launch_bounds__(kBlock) void k_lin_obs(DevProblem P, const double* 
   }
   if (slot >= 0) {
     double2* R = reinterpret_cast<double2*>(P.rec + (size_t)slot * RS);
-    double w[NW], t[NW], tg[6];
+    double w[NW];
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
       for (int b = 0; b < PD; ++b) w[a * PD + b] = L.Jc[a] * L.Jt[b] + L.Jc[6 + a] * L.Jt[PD + b];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-#pragma unroll
-      for (int b = 0; b < PD; ++b) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < PD; ++k) s += w[a * PD + k] * sym_get<PD>(Vi, k, b);
-        t[a * PD + b] = s;
-      }
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < PD; ++k) s += t[a * PD + k] * g[k];
-      tg[a] = s;
-    }
-#pragma unroll
     for (int k = 0; k < NW / 2; ++k) R[k] = make_double2(w[2 * k], w[2 * k + 1]);
 #pragma unroll
-    for (int k = 0; k < NW / 2; ++k) R[NW / 2 + k] = make_double2(t[2 * k], t[2 * k + 1]);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) R[NW + k] = make_double2(L.Jc[2 * k], L.Jc[2 * k + 1]);
-    R[NW + 6] = make_double2(L.r[0], L.r[1]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) R[NW + 7 + k] = make_double2(tg[2 * k], tg[2 * k + 1]);
+    for (int k = 0; k < 6; ++k) R[NW / 2 + k] = make_double2(L.Jc[2 * k], L.Jc[2 * k + 1]);
+    R[NW / 2 + 6] = make_double2(L.r[0], L.r[1]);
   }
   const double cost = wave_sum(L.cost);
   gmax = wave_max(gmax);
@@ -507,7 +512,8 @@ THIP_DEV void load_rec(const double* __restrict__ rec, int slot, int off2, doubl
 // one workgroup per (camera, chunk of its contiguous records)
 template <int PD>
 THIP_DEV void schur_diag_item(const DevProblem& P, int item, double (*part)[40], double* __restrict__ S,
-                              double* __restrict__ rhs, double* __restrict__ colsq, double* __restrict__ gc) {
+                              double* __restrict__ rhs, double* __restrict__ colsq, double* __restrict__ gc,
+                              const double* __restrict__ Vinv, const double* __restrict__ gp) {
   constexpr int NW = 6 * PD;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int* it = P.diag_items + 4 * item;
@@ -516,11 +522,23 @@ THIP_DEV void schur_diag_item(const DevProblem& P, int item, double (*part)[40],
 #pragma unroll
   for (int k = 0; k < 39; ++k) acc[k] = 0.0;
   for (int q = beg + tid; q < end; q += kBlock) {
-    double W[NW], T[NW], Jc[12], rt[8];
+    double W[NW], T[NW], Jc[12], rt[8], Vi[PD * (PD + 1) / 2];
+    const int p = P.slot_pt[q];
     load_rec<PD>(P.rec, q, 0, W);
-    load_rec<PD>(P.rec, q, NW / 2, T);
-    load_rec<PD>(P.rec, q, NW, Jc);
-    load_rec<PD>(P.rec, q, NW + 6, rt);   // r (2) | T g (6)
+    load_rec<PD>(P.rec, q, NW / 2, Jc);
+    {
+      const double2 r2 = reinterpret_cast<const double2*>(P.rec + (size_t)q * rec_stride<PD>())[NW / 2 + 6];
+      rt[0] = r2.x; rt[1] = r2.y;
+    }
+    load_vinv<PD>(Vinv, p, Vi);
+    rec_T<PD>(W, Vi, T);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {   // T g_p
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < PD; ++k) s += T[a * PD + k] * gp[(size_t)PD * p + k];
+      rt[2 + a] = s;
+    }
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
 #pragma unroll
@@ -554,7 +572,8 @@ THIP_DEV void schur_diag_item(const DevProblem& P, int item, double (*part)[40],
 
 // one workgroup per (block (ri, rj), chunk of its pair list)
 template <int PD>
-THIP_DEV void schur_block_item(const DevProblem& P, int item, double (*part)[40], double* __restrict__ S) {
+THIP_DEV void schur_block_item(const DevProblem& P, int item, double (*part)[40], double* __restrict__ S,
+                               const double* __restrict__ Vinv) {
   constexpr int NW = 6 * PD;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int* it = P.blk_items + 5 * item;
@@ -564,9 +583,11 @@ THIP_DEV void schur_block_item(const DevProblem& P, int item, double (*part)[40]
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
   for (int q = beg + tid; q < end; q += kBlock) {
     const int2 ab = P.blk_pairs[q];
-    double T[NW], Wb[NW];
-    load_rec<PD>(P.rec, ab.x, NW / 2, T);
+    double Wa[NW], T[NW], Wb[NW], Vi[PD * (PD + 1) / 2];
+    load_rec<PD>(P.rec, ab.x, 0, Wa);
     load_rec<PD>(P.rec, ab.y, 0, Wb);
+    load_vinv<PD>(Vinv, P.blk_pair_pt[q], Vi);
+    rec_T<PD>(Wa, Vi, T);
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -591,11 +612,12 @@ THIP_DEV void schur_block_item(const DevProblem& P, int item, double (*part)[40]
 // they are independent, and at C2 size every launch costs as much as it computes.
 template <int PD>
 __global__ __launch_bounds__(kBlock) void k_schur(DevProblem P, double* __restrict__ S, double* __restrict__ rhs,
-                                                  double* __restrict__ colsq, double* __restrict__ gc) {
+                                                  double* __restrict__ colsq, double* __restrict__ gc,
+                                                  const double* __restrict__ Vinv, const double* __restrict__ gp) {
   __shared__ double part[kWavesPerBlock][40];
   const int b = blockIdx.x;
-  if (b < P.n_blk_items) schur_block_item<PD>(P, b, part, S);        // the long lists first
-  else schur_diag_item<PD>(P, b - P.n_blk_items, part, S, rhs, colsq, gc);
+  if (b < P.n_blk_items) schur_block_item<PD>(P, b, part, S, Vinv);        // the long lists first
+  else schur_diag_item<PD>(P, b - P.n_blk_items, part, S, rhs, colsq, gc, Vinv, gp);
 }
 
 // ------------------------------------- gather-based Schur assembly with intrinsics (A10)
@@ -1457,8 +1479,8 @@ void launch_linearize(const DevProblem& P, const double* cam, const double* pts,
     if (P.pd == 3) k_lin_obs<3><<<g, kBlock, 0, st>>>(P, cam, pts, radius, Vinv, gp, tile_part);
     else k_lin_obs<4><<<g, kBlock, 0, st>>>(P, cam, pts, radius, Vinv, gp, tile_part);
     if (P.n_diag_items + P.n_blk_items) {
-      if (P.pd == 3) k_schur<3><<<P.n_diag_items + P.n_blk_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc);
-      else k_schur<4><<<P.n_diag_items + P.n_blk_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc);
+      if (P.pd == 3) k_schur<3><<<P.n_diag_items + P.n_blk_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc, Vinv, gp);
+      else k_schur<4><<<P.n_diag_items + P.n_blk_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc, Vinv, gp);
     }
     return;
   }

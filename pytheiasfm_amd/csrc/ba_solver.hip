@@ -116,7 +116,7 @@ struct theia_ba_handle_s {
   DevBuf<double2> obs_uv, obs_si;
   DevBuf<double> reduce, Vinv, gp, tile_part, scalB, chol_work;
   DevBuf<double> rec;                       // per-observation records of the gather-based Schur assembly
-  DevBuf<int> diag_items, cam_obs, blk_items, slot_obs;
+  DevBuf<int> diag_items, cam_obs, blk_items, slot_obs, slot_pt, blk_pair_pt;
   DevBuf<int> prior_cam, prior_kind;        // camera priors in use (compact list)
   DevBuf<double> prior_vec, prior_info;
   int n_priors = 0;
@@ -381,7 +381,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.n_priors = h->n_priors; P.prior_cam = h->prior_cam.p; P.prior_kind = h->prior_kind.p;
   P.prior_vec = h->prior_vec.p; P.prior_info = h->prior_info.p;
   P.rec = h->rec.p; P.n_diag_items = h->n_diag_items; P.n_blk_items = h->n_blk_items;
-  P.diag_items = h->diag_items.p; P.rec_slot = h->cam_obs.p; P.slot_obs = h->slot_obs.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
+  P.diag_items = h->diag_items.p; P.rec_slot = h->cam_obs.p; P.slot_obs = h->slot_obs.p; P.slot_pt = h->slot_pt.p; P.blk_pair_pt = h->blk_pair_pt.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
 }
 
 int upload_parameters(theia_ba_handle_s* h, const theia_ba_problem* p) {
@@ -715,6 +715,9 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   h->rb.S = h->reduce.p; h->rb.rhs = h->rb.S + nn; h->rb.colsq = h->rb.rhs + h->n; h->rb.gc = h->rb.colsq + h->n;
   h->rb.scal = h->rb.gc + h->n;
   AL(Vinv, (size_t)(h->pd * (h->pd + 1) / 2) * h->np); AL(gp, (size_t)h->pd * h->np);
+  // constant points are never written: the Schur readers rebuild T = W V^-1 from these arrays and need zeros there
+  if (h->Vinv.n) HIP_TRY(hipMemsetAsync(h->Vinv.p, 0, sizeof(double) * h->Vinv.n, st));
+  if (h->gp.n) HIP_TRY(hipMemsetAsync(h->gp.p, 0, sizeof(double) * h->gp.n, st));
   AL(tile_part, (size_t)5 * std::max(1, h->ntiles_all)); AL(scalB, 16);
   AL(chol_work, dense_cholesky_workspace(h->n));
   AL(lm_state, sizeof(LmState)); AL(lm_ctl, sizeof(LmCtl));
@@ -850,14 +853,22 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
       for (size_t k = 0; k + 3 < ditems.size() + 1; k += 4) if (self[ditems[k]]) ditems[k + 3] = 1;
     }
     h->n_diag_items = (int)ditems.size() / 4; h->n_blk_items = (int)bitems.size() / 5;
+    {
+      std::vector<int> ppt(pairs.size());
+      for (size_t q = 0; q < pairs.size(); ++q) ppt[q] = opt[pairs[q].x];
+      UP(blk_pair_pt, ppt);
+    }
     for (auto& pr : pairs) { pr.x = cam_obs[pr.x]; pr.y = cam_obs[pr.y]; }
     {
       std::vector<int> sobs(std::max(1, dbeg[h->ncv]), 0);
       for (int64_t s2 = 0; s2 < nm; ++s2) if (cam_obs[s2] >= 0) sobs[cam_obs[s2]] = (int)s2;
       UP(slot_obs, sobs);
+      std::vector<int> spt(sobs.size(), 0);
+      for (int64_t s2 = 0; s2 < nm; ++s2) if (cam_obs[s2] >= 0) spt[cam_obs[s2]] = opt[s2];
+      UP(slot_pt, spt);
     }
     UP(diag_items, ditems); UP(cam_obs, cam_obs); UP(blk_items, bitems); UP(blk_pairs, pairs);
-    AL(rec, (size_t)std::max(1, dbeg[h->ncv]) * (12 * h->pd + 20));
+    AL(rec, (size_t)std::max(1, dbeg[h->ncv]) * (6 * h->pd + 14));
   }
   if (h->ni > 0 && h->ntiles_main > 0) {
     // Gather lists with intrinsics (k_lin_obs_intr / k_schur_intr): records for every observation whose camera OR
