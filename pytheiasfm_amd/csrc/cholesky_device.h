@@ -86,18 +86,15 @@ __device__ __forceinline__ void potrf64_wave(double* __restrict__ A, int lda, in
   // (clamped address, value selected afterwards): a predicated load compiles to
   // branch + load + s_waitcnt per row, i.e. 64 serialised memory round trips.
   {
+    // all 64 row loads are in flight before the first use: one exposed memory latency
     const int ic = min(i, nb - 1);
+    double v[NB];
 #pragma unroll
-    for (int rb = 0; rb < NB; rb += 16) {
-      double v[16];
+    for (int r = 0; r < NB; ++r) v[r] = A[(size_t)(k0 + min(r, nb - 1)) * lda + k0 + ic];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) v[q] = A[(size_t)(k0 + min(rb + q, nb - 1)) * lda + k0 + ic];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int r = rb + q;
-        Ls[r][i] = (r < nb && i <= r) ? v[q] : ((r == i) ? 1.0 : 0.0);
-        Zs[r][i] = 0.0;
-      }
+    for (int r = 0; r < NB; ++r) {
+      Ls[r][i] = (r < nb && i <= r) ? v[r] : ((r == i) ? 1.0 : 0.0);
+      Zs[r][i] = 0.0;
     }
   }
   __syncthreads();
@@ -164,9 +161,20 @@ __device__ __forceinline__ void potrf64_wave(double* __restrict__ A, int lda, in
 #ifdef THIP_POTRF_STAMPS
   if (i == 0) { THIP_POTRF_STAMPS[8] = tsub_[0]; THIP_POTRF_STAMPS[9] = tsub_[1]; THIP_POTRF_STAMPS[10] = tsub_[2]; }
 #endif
-#pragma unroll 16
-  for (int r = 0; r < NB; ++r)
-    if (r < nb && i <= r) A[(size_t)(k0 + r) * lda + k0 + i] = Ls[r][i];
+  // Whole rows are stored (the zeros of Ls above the diagonal land in the tile's upper triangle, which
+  // nothing reads: S is symmetric-lower and rebuilt by every linearisation), so the only predicates are
+  // the lane mask i < nb (hoisted) and the uniform r < nb; LDS reads are batched ahead of the stores.
+  if (i < nb) {
+#pragma unroll
+    for (int rb = 0; rb < NB; rb += 16) {
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = Ls[rb + q][i];
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (rb + q < nb) A[(size_t)(k0 + rb + q) * lda + k0 + i] = v[q];
+    }
+  }
   if (bad && i == 0) unsafeAtomicAdd(fail_flag, 1.0);
   PSTAMP(2);
   // ---- inverse: four 16 x 16 triangular inverses, lane (q, c) owns column c of block q
