@@ -149,15 +149,21 @@ def main():
         opts.max_num_iterations = int(m)
         h.set_options(opts)
 
-    def run_iterations(k):
+    h.reset(pristine)
+    h.snapshot()   # the perturbed initial state stays in HBM: the timed region has no host round trip for inputs
+
+    def run_iterations(k, from_host=False):
         """Exactly k LM iterations as ceil(k / ITERS_PER_SOLVE) solves, each from
-        the perturbed initial state (parameters re-uploaded outside the kernels)."""
+        the perturbed initial state (device-resident snapshot; from_host: re-uploaded over PCIe)."""
         done = 0
         acc = {"lin_kernel": 0.0, "launches": 0, "lin": 0.0, "solve": 0.0, "backsub": 0.0}
         while done < k:
             m = min(ITERS_PER_SOLVE, k - done)
             set_max_iters(m)
-            h.reset(pristine)
+            if from_host:
+                h.reset(pristine)
+            else:
+                h.restore()
             s, _ = h.run(trace_capacity=1)
             if s.num_iterations != m:
                 raise RuntimeError(f"solve stopped after {s.num_iterations} of {m} iterations (term {s.termination_type})")
@@ -180,6 +186,12 @@ def main():
     acc = run_iterations(min(args.steps, 50))
     del os.environ["THEIA_HIP_PHASE_TIMING"]
     barrier()
+    # for the record: the same solves with the parameters re-uploaded from host memory per solve
+    tp0 = time.perf_counter()
+    npcie = min(args.steps, 50)
+    run_iterations(npcie, from_host=True)
+    barrier()
+    pcie_it_per_s = npcie / (time.perf_counter() - tp0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -196,6 +208,7 @@ def main():
             "metric": "BA residuals/sec (LM-iterations/sec x observations); RANSAC hypotheses/sec alongside",
             "value": res_per_s, "unit": "residuals/s",
             "lm_iterations_per_sec": it_per_s,
+            "lm_iterations_per_sec_pcie_inclusive": pcie_it_per_s,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

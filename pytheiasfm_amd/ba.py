@@ -55,6 +55,18 @@ class BaHandle:
         st = (problem or self.problem).as_struct()
         capi.check(capi.lib().theia_hip_ba_reset_parameters(self._h, C.byref(st)))
 
+    def snapshot(self):
+        """Keep a device-resident copy of the current parameters (theia_hip_ba_snapshot_parameters)."""
+        L = capi.lib()
+        L.theia_hip_ba_snapshot_parameters.argtypes = [C.c_void_p]
+        capi.check(L.theia_hip_ba_snapshot_parameters(self._h))
+
+    def restore(self):
+        """Back to the snapshot without touching the host (theia_hip_ba_restore_parameters)."""
+        L = capi.lib()
+        L.theia_hip_ba_restore_parameters.argtypes = [C.c_void_p]
+        capi.check(L.theia_hip_ba_restore_parameters(self._h))
+
     def set_options(self, options):
         capi.check(capi.lib().theia_hip_ba_set_options(self._h, C.byref(options)))
         self.options = options

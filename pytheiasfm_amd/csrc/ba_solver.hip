@@ -107,6 +107,9 @@ struct theia_ba_handle_s {
   std::vector<uint8_t> cam_mask, pt_const;
   int ni = 0, ngv = 0;
   // device buffers
+  DevBuf<double> snap_cam, snap_pts, snap_intr;   // theia_hip_ba_snapshot_parameters
+  DevBuf<double> xnorm_part;
+  bool has_snapshot = false;
   DevBuf<double> cam[2], pts[2], intr[2], scale_c, scale_p, ones_c, ones_p, colsq_c0, colsq_p0;
   DevBuf<double> scale_i, ones_i, colsq_i0, scale_red;
   DevBuf<int> d_grp_red, d_grp_k;
@@ -274,26 +277,39 @@ __global__ void k_lm_control(LmState* st, const double* __restrict__ sa, const d
 }
 
 // |x| over the variable parameter blocks (TrustRegionMinimizer's x_norm at the start):
-// out2[0] = points (per track shard), out2[1] = cameras + intrinsics.  One workgroup.
-__global__ __launch_bounds__(1024) void k_xnorm_partial(DevProblem P, const double* __restrict__ cam,
-                                                        const double* __restrict__ pts, const double* __restrict__ intr,
-                                                        double* __restrict__ out2) {
-  __shared__ double s1[1024], s2[1024];
+// out2[0] = points (per track shard), out2[1] = cameras + intrinsics.  kXnormBlocks workgroups write their
+// partial sums to part[b][2]; k_xnorm_reduce adds them in block order (no atomics: the norm is reproducible).
+constexpr int kXnormBlocks = 64;
+__global__ __launch_bounds__(256) void k_xnorm_partial(DevProblem P, const double* __restrict__ cam,
+                                                       const double* __restrict__ pts, const double* __restrict__ intr,
+                                                       double* __restrict__ part) {
+  __shared__ double s1[256], s2[256];
   double sp = 0.0, sc = 0.0;
-  for (int p = threadIdx.x; p < P.np; p += 1024)
-    if (!P.pt_const[p]) for (int q = 0; q < 4; ++q) sp += pts[4 * (size_t)p + q] * pts[4 * (size_t)p + q];
-  for (int c = threadIdx.x; c < P.nc; c += 1024)
-    if (P.cam_red[c] >= 0) for (int q = 0; q < 6; ++q) sc += cam[6 * c + q] * cam[6 * c + q];
-  if (P.ni)
-    for (int g = threadIdx.x; g < P.ng_total; g += 1024)
-      if (P.grp_red[g] >= 0) for (int q = 0; q < P.grp_k[g]; ++q) sc += intr[(size_t)g * THEIA_MAX_INTRINSICS + q] * intr[(size_t)g * THEIA_MAX_INTRINSICS + q];
+  const int t0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+  for (int p = t0; p < P.np; p += stride) {
+    const double4 x = reinterpret_cast<const double4*>(pts)[p];   // unconditional load, masked sum
+    const double m = P.pt_const[p] ? 0.0 : 1.0;
+    sp += m * (((x.x * x.x + x.y * x.y) + x.z * x.z) + x.w * x.w);
+  }
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < P.nc; c += 256)
+      if (P.cam_red[c] >= 0) for (int q = 0; q < 6; ++q) sc += cam[6 * c + q] * cam[6 * c + q];
+    if (P.ni)
+      for (int g = threadIdx.x; g < P.ng_total; g += 256)
+        if (P.grp_red[g] >= 0) for (int q = 0; q < P.grp_k[g]; ++q) sc += intr[(size_t)g * THEIA_MAX_INTRINSICS + q] * intr[(size_t)g * THEIA_MAX_INTRINSICS + q];
+  }
   s1[threadIdx.x] = sp; s2[threadIdx.x] = sc;
   __syncthreads();
-  for (int s = 512; s > 0; s >>= 1) {
+  for (int s = 128; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) { s1[threadIdx.x] += s1[threadIdx.x + s]; s2[threadIdx.x] += s2[threadIdx.x + s]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { out2[0] = s1[0]; out2[1] = s2[0]; }
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = s1[0]; part[2 * blockIdx.x + 1] = s2[0]; }
+}
+__global__ void k_xnorm_reduce(const double* __restrict__ part, int nblocks, double* __restrict__ out2) {
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < nblocks; ++k) { a += part[2 * k]; b += part[2 * k + 1]; }
+  out2[0] = a; out2[1] = b;
 }
 __global__ void k_xnorm_set(LmState* st, const double* __restrict__ in2) { st->x_norm = sqrt(in2[0] + in2[1]); }
 
@@ -1001,6 +1017,32 @@ int theia_hip_ba_reset_parameters(theia_ba_handle h, const theia_ba_problem* p) 
   return upload_parameters(h, p);
 }
 
+int theia_hip_ba_snapshot_parameters(theia_ba_handle h) {
+  if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
+  int rc;
+  if ((rc = h->snap_cam.alloc(h->cam[0].n)) || (rc = h->snap_pts.alloc(h->pts[0].n)) || (rc = h->snap_intr.alloc(h->intr[0].n))) return rc;
+  const int c = h->cur;
+  if (h->cam[c].n) HIP_TRY(hipMemcpyAsync(h->snap_cam.p, h->cam[c].p, sizeof(double) * h->cam[c].n, hipMemcpyDeviceToDevice, h->stream));
+  if (h->pts[c].n) HIP_TRY(hipMemcpyAsync(h->snap_pts.p, h->pts[c].p, sizeof(double) * h->pts[c].n, hipMemcpyDeviceToDevice, h->stream));
+  if (h->intr[c].n) HIP_TRY(hipMemcpyAsync(h->snap_intr.p, h->intr[c].p, sizeof(double) * h->intr[c].n, hipMemcpyDeviceToDevice, h->stream));
+  h->has_snapshot = true;
+  return 0;
+}
+
+int theia_hip_ba_restore_parameters(theia_ba_handle h) {
+  if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
+  if (!h->has_snapshot) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "no snapshot taken on this handle");
+  for (int k = 0; k < 2; ++k) {
+    if (h->cam[k].n) HIP_TRY(hipMemcpyAsync(h->cam[k].p, h->snap_cam.p, sizeof(double) * h->cam[k].n, hipMemcpyDeviceToDevice, h->stream));
+    if (h->pts[k].n) HIP_TRY(hipMemcpyAsync(h->pts[k].p, h->snap_pts.p, sizeof(double) * h->pts[k].n, hipMemcpyDeviceToDevice, h->stream));
+    if (h->intr[k].n) HIP_TRY(hipMemcpyAsync(h->intr[k].p, h->snap_intr.p, sizeof(double) * h->intr[k].n, hipMemcpyDeviceToDevice, h->stream));
+  }
+  h->cur = 0;
+  h->P.intr = h->intr[0].p; h->P.intr_cand = h->intr[1].p;
+  h->have_scale = false;
+  return 0;
+}
+
 int theia_hip_ba_set_options(theia_ba_handle h, const theia_ba_options* o) {
   if (!h || !o) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
   const theia_ba_options& c = h->opt;
@@ -1062,7 +1104,9 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   HIP_TRY(hipMemcpyAsync(dst, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
   // |x| of the variable blocks at the start: summed on the device (points per shard, all-reduced)
   HIP_TRY(hipMemsetAsync(h->scalB.p, 0, sizeof(double) * 16, h->stream));
-  k_xnorm_partial<<<1, 1024, 0, h->stream>>>(h->P, h->cam[0].p, h->pts[0].p, h->intr[0].p, h->scalB.p);
+  if (h->xnorm_part.n < 2 * (size_t)kXnormBlocks && (rc = h->xnorm_part.alloc(2 * kXnormBlocks))) return rc;
+  k_xnorm_partial<<<kXnormBlocks, 256, 0, h->stream>>>(h->P, h->cam[0].p, h->pts[0].p, h->intr[0].p, h->xnorm_part.p);
+  k_xnorm_reduce<<<1, 1, 0, h->stream>>>(h->xnorm_part.p, kXnormBlocks, h->scalB.p);
   rc = do_allreduce(h, h->scalB.p, 1, THEIA_REDUCE_SUM);
   if (rc) return rc;
   k_xnorm_set<<<1, 1, 0, h->stream>>>(dst, h->scalB.p);
