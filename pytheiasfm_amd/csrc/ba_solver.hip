@@ -587,6 +587,16 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   for (auto& row : h->ev) for (auto& e : row) HIP_TRY(hipEventCreate(&e));
   HIP_TRY(hipHostMalloc((void**)&h->h_scal, sizeof(double) * 32, hipHostMallocDefault));
 
+  // THEIA_HIP_CREATE_TIMING=1: wall time of the create() stages on stderr
+  const bool ctiming = getenv("THEIA_HIP_CREATE_TIMING") != nullptr;
+  auto ct0 = std::chrono::steady_clock::now();
+  auto tick = [&](const char* what) {
+    if (!ctiming) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "theia_hip create: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - ct0).count());
+    ct0 = t;
+  };
+  tick("stream + events");
   // --- problem structure (bundle_adjuster.cc:116-221,357-380,477-527) ---
   std::vector<uint8_t> cam_used(h->nc, 0), pt_used(h->np, 0);
   for (int64_t i = 0; i < h->nobs; ++i) { cam_used[p->obs_cam[i]] = 1; pt_used[p->obs_pt[i]] = 1; }
@@ -702,6 +712,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   hipStream_t st = h->stream;
 #define UP(buf, vec) do { rc = h->buf.upload(vec, st); if (rc) return rc; } while (0)
 #define AL(buf, cnt) do { rc = h->buf.alloc(cnt); if (rc) return rc; } while (0)
+  tick("structure, sort, tiles");
   UP(obs_uv, uv); UP(obs_si, si); UP(obs_cam, ocam); UP(obs_pt, opt);
   UP(tile_start, tstart); UP(tile_count, tcount);
   UP(long_obs_index, l_obs); UP(long_obs_slot, l_slot); UP(long_track_start, l_start); UP(long_track_pt, l_pt);
@@ -737,6 +748,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   AL(tile_part, (size_t)5 * std::max(1, h->ntiles_all)); AL(scalB, 16);
   AL(chol_work, dense_cholesky_workspace(h->n));
   AL(lm_state, sizeof(LmState)); AL(lm_ctl, sizeof(LmCtl));
+  tick("allocations + uploads");
   {
     // camera priors in use: the camera's bit AND the option's bit (bundle_adjuster.cc:159-172,291-313)
     std::vector<int> pc, pk;
@@ -788,7 +800,9 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     // shared intrinsics couple with every camera of their group: treat as dense
     for (int a = 0; a < (h->ni + 63) / 64; ++a)
       for (int b = 0; b < nt; ++b) h->tile_adj[(size_t)a * nt + b] = h->tile_adj[(size_t)b * nt + a] = 1;
+    tick("priors + tile adjacency");
     h->plan = chol_plan_create(h->n, h->tile_adj.data());
+    tick("K3 plan");
   }
   if (h->ni == 0 && h->ntiles_main > 0) {
     // Static gather lists of the Schur assembly (k_schur_diag / k_schur_blocks):
@@ -843,11 +857,22 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
       for_each_pair([&](int a, int b) { pairs[f[red[a]]++] = make_int2(a, b); });
     }
     std::vector<int> bitems;
+    // each row is ordered by (column camera, a, b).  The pairs of a row were generated in ascending (a, b)
+    // (tracks are contiguous and visited in order), so a STABLE counting sort on the column camera is enough.
+    {
+      std::vector<int64_t> cnt(h->ncv + 1);
+      std::vector<int2> tmp;
+      for (int c = 0; c < h->ncv; ++c) {
+        const int64_t b0 = rbeg[c], b1 = rbeg[c + 1];
+        if (b1 - b0 < 2) continue;
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (int64_t q = b0; q < b1; ++q) cnt[red[pairs[q].y] + 1]++;
+        for (int k = 0; k < h->ncv; ++k) cnt[k + 1] += cnt[k];
+        tmp.assign(pairs.begin() + b0, pairs.begin() + b1);
+        for (const int2& pr : tmp) pairs[b0 + cnt[red[pr.y]]++] = pr;
+      }
+    }
     for (int c = 0; c < h->ncv; ++c) {
-      std::sort(pairs.begin() + rbeg[c], pairs.begin() + rbeg[c + 1], [&](const int2& x, const int2& y) {
-        if (red[x.y] != red[y.y]) return red[x.y] < red[y.y];
-        return x.x != y.x ? x.x < y.x : x.y < y.y;
-      });
       for (int64_t q = rbeg[c]; q < rbeg[c + 1];) {
         int64_t e = q + 1;
         const int rj = red[pairs[q].y];
@@ -929,11 +954,22 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
       s0 = s1;
     }
     std::vector<int2> pairs;
+    // entries are generated in ascending (a, b): two stable counting passes (low, then high half of the key)
+    // order them by (key, a, b) without a comparison sort
+    const size_t nbucket = (size_t)std::max(h->ncv, h->ngv) + 2;
     auto emit_pairs = [&](std::vector<PairE>& v, auto&& per_key) {
-      std::sort(v.begin(), v.end(), [](const PairE& x, const PairE& y) {
-        if (x.key != y.key) return x.key < y.key;
-        return x.a != y.a ? x.a < y.a : x.b < y.b;
-      });
+      {
+        std::vector<PairE> tmp(v.size());
+        std::vector<size_t> cnt(nbucket + 1);
+        for (int pass = 0; pass < 2; ++pass) {
+          const int sh = pass == 0 ? 0 : 32;
+          std::fill(cnt.begin(), cnt.end(), 0);
+          for (const PairE& e : v) cnt[(size_t)((e.key >> sh) & 0xffffffffu) + 1]++;
+          for (size_t k = 0; k < nbucket; ++k) cnt[k + 1] += cnt[k];
+          for (const PairE& e : v) tmp[cnt[(size_t)((e.key >> sh) & 0xffffffffu)]++] = e;
+          v.swap(tmp);
+        }
+      }
       for (size_t q = 0; q < v.size();) {
         size_t e = q + 1;
         while (e < v.size() && v[e].key == v[q].key) ++e;
@@ -990,9 +1026,11 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   }
 #undef UP
 #undef AL
+  tick("gather lists");
   fill_devproblem(h);
   rc = upload_parameters(h, p);
   if (rc) return rc;
+  tick("parameter upload");
   // fixed cost
   double fc = 0.0, inv = 0.0;
   rc = cost_of_tiles(h, h->ntiles_eval, h->ntiles_all - h->ntiles_eval, h->cam[0].p, h->pts[0].p, &fc, &inv);
@@ -1006,6 +1044,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     fc += pf;
   }
   h->fixed_cost = fc;
+  tick("fixed cost");
   *out = guard.release();
   return 0;
 }
