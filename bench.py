@@ -144,6 +144,7 @@ def main():
     h = ba.BaHandle(prob, opts)
     if world > 1:
         h.set_allreduce(tdist.make_torch_allreduce(local_rank))
+        h.set_shard(rank, world)
 
     def set_max_iters(m):
         opts.max_num_iterations = int(m)

@@ -265,6 +265,11 @@ int theia_hip_ba_reset_parameters(theia_ba_handle h,
 /* Device-resident copy of the handle's current parameters (cameras, points,
  * intrinsics), and the way back: repeated solves from the same start without a
  * host round trip (bench.py: the timed region starts with its inputs in HBM). */
+/* Optional, sharded solves: this rank's index and the number of ranks of the
+ * all-reduce group.  With it the MAX-reduced scalar (gradient max-norm) rides in
+ * the SUM all-reduce of the reduced camera system (one slot per rank), saving one
+ * collective per LM iteration; without it a separate MAX all-reduce is issued. */
+int theia_hip_ba_set_shard(theia_ba_handle h, int32_t rank, int32_t world_size);
 int theia_hip_ba_snapshot_parameters(theia_ba_handle h);
 int theia_hip_ba_restore_parameters(theia_ba_handle h);
 /* Replace the solver-control options of a handle (iteration cap, tolerances,

@@ -55,6 +55,12 @@ class BaHandle:
         st = (problem or self.problem).as_struct()
         capi.check(capi.lib().theia_hip_ba_reset_parameters(self._h, C.byref(st)))
 
+    def set_shard(self, rank, world_size):
+        """theia_hip_ba_set_shard: lets the MAX scalar ride in the SUM all-reduce (one collective less per iteration)."""
+        L = capi.lib()
+        L.theia_hip_ba_set_shard.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        capi.check(L.theia_hip_ba_set_shard(self._h, int(rank), int(world_size)))
+
     def snapshot(self):
         """Keep a device-resident copy of the current parameters (theia_hip_ba_snapshot_parameters)."""
         L = capi.lib()

@@ -141,6 +141,7 @@ struct theia_ba_handle_s {
   // multi-rank: only the structurally non-zero lower 64x64 tiles of S travel through the all-reduce
   DevBuf<int2> pack_tiles;
   DevBuf<double> pack_buf;
+  int shard_rank = -1, shard_world = 0;   // theia_hip_ba_set_shard
   int n_pack_tiles = 0;
 
   ~theia_ba_handle_s() {
@@ -280,6 +281,7 @@ __global__ void k_lm_control(LmState* st, const double* __restrict__ sa, const d
 // out2[0] = points (per track shard), out2[1] = cameras + intrinsics.  kXnormBlocks workgroups write their
 // partial sums to part[b][2]; k_xnorm_reduce adds them in block order (no atomics: the norm is reproducible).
 constexpr int kXnormBlocks = 64;
+constexpr int kMaxShardSlots = 1024;   // ranks whose MAX scalar fits in the packed SUM all-reduce
 __global__ __launch_bounds__(256) void k_xnorm_partial(DevProblem P, const double* __restrict__ cam,
                                                        const double* __restrict__ pts, const double* __restrict__ intr,
                                                        double* __restrict__ part) {
@@ -317,7 +319,8 @@ __global__ void k_xnorm_set(LmState* st, const double* __restrict__ in2) { st->x
 // structurally non-zero tiles is zero on every rank, so only those tiles are summed across ranks
 // (C2: 39 tiles = 1.3 MB instead of the 11.5 MB dense matrix).
 __global__ __launch_bounds__(256) void k_pack_rcs(int n, const double* __restrict__ base, const int2* __restrict__ tiles,
-                                                  int ntiles, double* __restrict__ pack, int to_pack) {
+                                                  int ntiles, double* __restrict__ pack, int to_pack, int rank,
+                                                  int world) {
   const int b = blockIdx.x;
   if (b < ntiles) {
     const int r0 = tiles[b].x * 64, c0 = tiles[b].y * 64;
@@ -337,6 +340,18 @@ __global__ __launch_bounds__(256) void k_pack_rcs(int n, const double* __restric
   double* pk = pack + (size_t)ntiles * 4096;
   for (size_t e = (size_t)(b - ntiles) * 256 + threadIdx.x; e < tail; e += (size_t)(gridDim.x - ntiles) * 256) {
     if (to_pack) pk[e] = src[e]; else src[e] = pk[e];
+  }
+  // the MAX-reduced scalar (gradient max-norm, >= 0) in one slot per rank of the SUM all-reduce
+  if (world > 0 && b == ntiles && threadIdx.x == 0) {
+    double* slots = pk + tail;
+    double* gmax = src + (size_t)3 * n + SC_GMAX;   // scal = [.. | colsq | gc | scal[16]]
+    if (to_pack) {
+      for (int r = 0; r < world; ++r) slots[r] = (r == rank) ? *gmax : 0.0;
+    } else {
+      double m = 0.0;
+      for (int r = 0; r < world; ++r) m = fmax(m, slots[r]);
+      *gmax = m;
+    }
   }
 }
 
@@ -488,18 +503,23 @@ int enqueue_linearize(theia_ba_handle_s* h, int slot = 0) {
   if (h->ntiles_main) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 4, h->f2s.p, h->fmaxflag.p, h->rb.scal, h->stream);
   launch_long_linearize(h->P, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->long_scratch.p, h->stream);
   launch_cam_priors(h->P, PRIOR_LINEARIZE, h->cam[h->cur].p, nullptr, nullptr, &h->rb, nullptr, h->rb.scal + SC_COST, nullptr, h->stream);
-  // one SUM all-reduce of [S | rhs | colsq | gc | scal[0,8)], one MAX of scal[8,16)
+  // one SUM all-reduce of [S | rhs | colsq | gc | scal[0,8)], one MAX of scal[8,16) (folded into the SUM as
+  // per-rank slots when the shard geometry is known)
   int rc = 0;
+  bool max_done = false;
   if (h->allreduce && h->n_pack_tiles > 0 && h->n > 0) {
     const int tail_blocks = (int)((3 * (size_t)h->n + 8 + 255) / 256);
     const int grid = h->n_pack_tiles + std::max(1, std::min(tail_blocks, 64));
-    k_pack_rcs<<<grid, 256, 0, h->stream>>>(h->n, h->reduce.p, h->pack_tiles.p, h->n_pack_tiles, h->pack_buf.p, 1);
-    rc = do_allreduce(h, h->pack_buf.p, (size_t)h->n_pack_tiles * 4096 + 3 * (size_t)h->n + 8, THEIA_REDUCE_SUM);
-    k_pack_rcs<<<grid, 256, 0, h->stream>>>(h->n, h->reduce.p, h->pack_tiles.p, h->n_pack_tiles, h->pack_buf.p, 0);
+    const int world = (h->shard_world > 0 && h->shard_rank >= 0 && h->shard_rank < h->shard_world && h->shard_world <= kMaxShardSlots)
+                          ? h->shard_world : 0;
+    k_pack_rcs<<<grid, 256, 0, h->stream>>>(h->n, h->reduce.p, h->pack_tiles.p, h->n_pack_tiles, h->pack_buf.p, 1, h->shard_rank, world);
+    rc = do_allreduce(h, h->pack_buf.p, (size_t)h->n_pack_tiles * 4096 + 3 * (size_t)h->n + 8 + world, THEIA_REDUCE_SUM);
+    k_pack_rcs<<<grid, 256, 0, h->stream>>>(h->n, h->reduce.p, h->pack_tiles.p, h->n_pack_tiles, h->pack_buf.p, 0, h->shard_rank, world);
+    max_done = world > 0;
   } else {
     rc = do_allreduce(h, h->reduce.p, (size_t)h->n * h->n + 3 * (size_t)h->n + 8, THEIA_REDUCE_SUM);
   }
-  if (!rc) rc = do_allreduce(h, h->rb.scal + 8, 8, THEIA_REDUCE_MAX);
+  if (!rc && !max_done) rc = do_allreduce(h, h->rb.scal + 8, 8, THEIA_REDUCE_MAX);
   if (rc) return rc;
   launch_finalize_rcs(h->P, radius, h->rb, h->stream);
   return 0;
@@ -545,7 +565,7 @@ int sync_plan(theia_ba_handle_s* h) {
         if (i == j || h->tile_adj[(size_t)i * nt + j]) tiles.push_back(make_int2(i, j));
     h->n_pack_tiles = (int)tiles.size();
     int rc2 = h->pack_tiles.upload(tiles, h->stream);
-    if (!rc2) rc2 = h->pack_buf.alloc((size_t)tiles.size() * 4096 + 3 * (size_t)h->n + 8);
+    if (!rc2) rc2 = h->pack_buf.alloc((size_t)tiles.size() * 4096 + 3 * (size_t)h->n + 8 + kMaxShardSlots);
     if (rc2) return rc2;
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
@@ -1054,6 +1074,13 @@ int theia_hip_ba_reset_parameters(theia_ba_handle h, const theia_ba_problem* p) 
   if (p->num_cameras != h->nc || p->num_points != h->np || p->num_groups != h->ng)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "problem shape differs from the handle's");
   return upload_parameters(h, p);
+}
+
+int theia_hip_ba_set_shard(theia_ba_handle h, int32_t rank, int32_t world_size) {
+  if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
+  if (world_size < 1 || rank < 0 || rank >= world_size) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "rank / world_size out of range");
+  h->shard_rank = rank; h->shard_world = world_size;
+  return 0;
 }
 
 int theia_hip_ba_snapshot_parameters(theia_ba_handle h) {

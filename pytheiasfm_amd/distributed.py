@@ -33,9 +33,13 @@ def make_torch_allreduce(device_index, group=None):
     import torch.distributed as dist
 
     streams = {}
+    views = {}   # (ptr, count) -> tensor view: the library reduces the same few buffers every iteration
 
     def allreduce(ptr, count, op, stream):
-        t = torch.as_tensor(_DevArray(ptr, count), device=torch.device("cuda", device_index))
+        t = views.get((ptr, count))
+        if t is None:
+            t = torch.as_tensor(_DevArray(ptr, count), device=torch.device("cuda", device_index))
+            views[(ptr, count)] = t
         ext = streams.get(stream)
         if ext is None:
             ext = torch.cuda.ExternalStream(stream, device=torch.device("cuda", device_index))

@@ -43,5 +43,17 @@ def test_allreduce_callback_path_world_size_1():
         n = 6 * 16
         assert (3 * 4096 + 3 * n + 8, tdist.REDUCE_SUM) in calls and (8, tdist.REDUCE_MAX) in calls
         assert (4, tdist.REDUCE_MAX) in calls and (n, tdist.REDUCE_SUM) in calls
+        # with the shard geometry known the gradient max-norm rides in the packed SUM (one slot per rank):
+        # no 8-double MAX any more, same solve; the gradient norm of the trace proves the slot survived
+        calls.clear()
+        with ba.BaHandle(shard, o) as h:
+            h.set_allreduce(counting)
+            h.set_shard(0, 1)
+            s2, tr2 = h.run()
+            out2 = h.download(shard.copy())
+        assert (3 * 4096 + 3 * n + 8 + 1, tdist.REDUCE_SUM) in calls and (8, tdist.REDUCE_MAX) not in calls
+        assert s2.num_iterations == s.num_iterations and s2.final_cost == s.final_cost
+        assert np.array_equal(out2.cam_ext, out.cam_ext) and np.array_equal(out2.points, out.points)
+        assert np.array_equal(np.asarray(tr2.gradient_max_norm), np.asarray(tr.gradient_max_norm))
     finally:
         dist.destroy_process_group()
