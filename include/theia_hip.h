@@ -256,6 +256,31 @@ int theia_hip_track_statistics(const theia_ba_problem* problem,
                                int32_t* num_behind_camera,
                                double* min_ray_cosine);
 
+/* TrackEstimator::EstimateTrack (estimate_track.cc:206-319) for every point of `problem` that is
+ * not flagged in point_const, triangulation_method = MIDPOINT (the default, estimate_track.h:82):
+ *   1. fewer than two observations, or no pair of viewing rays further apart than
+ *      min_triangulation_angle_degrees (SufficientTriangulationAngle, triangulation.cc:236-250) -> bad angle;
+ *   2. TriangulateMidpoint (triangulation.cc:130-157): sum (I - d d^T) X = sum (I - d d^T) o, Cholesky;
+ *      not positive definite -> failed triangulation; the point becomes (X, 1);
+ *   3. bundle_adjustment: BundleAdjustTrack on that point (= theia_hip_ba_tracks_batch), !success -> rejected;
+ *   4. AcceptableReprojectionError (estimate_track.cc:93-117): any view with Camera::ProjectPoint < 0, or a mean
+ *      squared reprojection error >= max_acceptable_reprojection_error_pixels^2 -> bad reprojection.
+ * One thread per track for every stage.  obs_ray_dir[num_obs][3] = Camera::PixelToUnitDepthRay(feature).normalized()
+ * of each observation (the caller's camera classes undistort; estimate_track.cc:76-77), origins are the camera
+ * positions.  problem->points is written for every track that reached stage 2 (as the reference writes
+ * track->MutablePoint() before it knows the outcome).  estimated[num_points]: 1 = SetEstimated(true).
+ * counters: {bad angles, failed triangulations, bad reprojections, rejected by the track BA}. */
+typedef struct theia_track_estimate_options {
+  double min_triangulation_angle_degrees;           /* estimate_track.h:69, default 3.0 */
+  double max_acceptable_reprojection_error_pixels;  /* :64, default 5.0 */
+  int32_t bundle_adjustment;                        /* :73, default 1 */
+  int32_t reserved;
+} theia_track_estimate_options;
+int theia_hip_estimate_tracks(const theia_ba_problem* problem, const double* obs_ray_dir,
+                              const theia_ba_options* ba_options,
+                              const theia_track_estimate_options* options,
+                              uint8_t* estimated, int32_t counters[4]);
+
 /* Handle API: problem resident in HBM across calls (bench, repeated solves). */
 typedef struct theia_ba_handle_s* theia_ba_handle;
 int theia_hip_ba_create(const theia_ba_problem* problem,

@@ -212,3 +212,28 @@ def track_statistics(problem):
     L.theia_hip_track_statistics.argtypes = [C.POINTER(capi.BaProblem), capi.c_double_p, capi.c_int32_p, capi.c_double_p]
     capi.check(L.theia_hip_track_statistics(C.byref(st), capi.ptr(err, C.c_double), capi.ptr(nb, C.c_int32), capi.ptr(mc, C.c_double)))
     return err[:num], nb[:num], mc[:num]
+
+
+def estimate_tracks(problem, obs_ray_dir, ba_options, min_triangulation_angle_degrees=3.0,
+                    max_acceptable_reprojection_error_pixels=5.0, bundle_adjustment=True):
+    """theia_hip_estimate_tracks: TrackEstimator::EstimateTrack (MIDPOINT) for every non-constant point of
+    `problem`; problem.points is updated in place.  Returns (estimated [num_points] bool,
+    {"bad_angles", "failed_triangulations", "bad_reprojections", "ba_failures"})."""
+    st = problem.as_struct()
+    num = problem.points.shape[0]
+    rays = np.ascontiguousarray(obs_ray_dir, dtype=np.float64).reshape(-1, 3)
+    if rays.shape[0] != problem.obs_uv.shape[0]:
+        raise capi.TheiaHipError(-1, "one viewing ray per observation expected")
+    eo = capi.TrackEstimateOptions()
+    eo.min_triangulation_angle_degrees = float(min_triangulation_angle_degrees)
+    eo.max_acceptable_reprojection_error_pixels = float(max_acceptable_reprojection_error_pixels)
+    eo.bundle_adjustment = int(bool(bundle_adjustment))
+    est = np.zeros(max(1, num), dtype=np.uint8)
+    cnt = (C.c_int32 * 4)()
+    L = capi.lib()
+    L.theia_hip_estimate_tracks.argtypes = [C.POINTER(capi.BaProblem), capi.c_double_p, C.POINTER(capi.BaOptions),
+                                            C.POINTER(capi.TrackEstimateOptions), capi.c_uint8_p, C.POINTER(C.c_int32)]
+    capi.check(L.theia_hip_estimate_tracks(C.byref(st), capi.ptr(rays, C.c_double), C.byref(ba_options), C.byref(eo),
+                                           capi.ptr(est, C.c_uint8), cnt))
+    return est[:num].astype(bool), {"bad_angles": cnt[0], "failed_triangulations": cnt[1], "bad_reprojections": cnt[2],
+                                    "ba_failures": cnt[3]}

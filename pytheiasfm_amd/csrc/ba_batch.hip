@@ -486,6 +486,50 @@ __global__ __launch_bounds__(64) void k_track_stats(TrackBatch B, double* __rest
   min_ray_cos[p] = mincos;
 }
 
+// Stage 1 + 2 of TrackEstimator::EstimateTrack, one thread per track: the triangulation-angle test on the
+// supplied viewing rays and TriangulateMidpoint.  status: 0 = triangulated, 1 = bad angle, 2 = failed
+// triangulation, 3 = skipped (constant point).
+__global__ __launch_bounds__(64) void k_track_triangulate(TrackBatch B, const double* __restrict__ rays, double cos_min_angle,
+                                                          int* __restrict__ status) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= B.num) return;
+  if (B.pt_const && B.pt_const[p]) { status[p] = 3; return; }
+  const int64_t beg = B.offsets[p], end = B.offsets[p + 1];
+  bool ok_angle = false;
+  for (int64_t i = beg; i < end && !ok_angle; ++i)
+    for (int64_t j = i + 1; j < end; ++j) {
+      const double d = (rays[3 * i] * rays[3 * j] + rays[3 * i + 1] * rays[3 * j + 1]) + rays[3 * i + 2] * rays[3 * j + 2];
+      if (d < cos_min_angle) { ok_angle = true; break; }
+    }
+  if (end - beg < 2 || !ok_angle) { status[p] = 1; return; }
+  // A = sum (I - d d^T), b = sum (I - d d^T) o  (the 4th row / column of the reference's 4 x 4 system is n X_w = n)
+  double A[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};   // A lower: 00 10 11 20 21 22
+  for (int64_t i = beg; i < end; ++i) {
+    const double* d = rays + 3 * i;
+    const double* o = B.cam + 6 * (size_t)B.obs_cam[i];
+    const double t00 = 1.0 - d[0] * d[0], t10 = -(d[1] * d[0]), t11 = 1.0 - d[1] * d[1];
+    const double t20 = -(d[2] * d[0]), t21 = -(d[2] * d[1]), t22 = 1.0 - d[2] * d[2];
+    A[0] += t00; A[1] += t10; A[2] += t11; A[3] += t20; A[4] += t21; A[5] += t22;
+    b[0] += (t00 * o[0] + t10 * o[1]) + t20 * o[2];
+    b[1] += (t10 * o[0] + t11 * o[1]) + t21 * o[2];
+    b[2] += (t20 * o[0] + t21 * o[1]) + t22 * o[2];
+  }
+  // Eigen::LLT: a non-positive pivot is a NumericalIssue
+  if (!(A[0] > 0.0)) { status[p] = 2; return; }
+  const double l00 = sqrt(A[0]), l10 = A[1] / l00, l20 = A[3] / l00;
+  const double d11 = A[2] - l10 * l10;
+  if (!(d11 > 0.0)) { status[p] = 2; return; }
+  const double l11 = sqrt(d11), l21 = (A[4] - l20 * l10) / l11;
+  const double d22 = A[5] - (l20 * l20 + l21 * l21);
+  if (!(d22 > 0.0)) { status[p] = 2; return; }
+  const double l22 = sqrt(d22);
+  const double y0 = b[0] / l00, y1 = (b[1] - l10 * y0) / l11, y2 = (b[2] - (l20 * y0 + l21 * y1)) / l22;
+  const double x2 = y2 / l22, x1 = (y1 - l21 * x2) / l11, x0 = (y0 - (l10 * x1 + l20 * x2)) / l00;
+  double* X = B.pts + 4 * (size_t)p;
+  X[0] = x0; X[1] = x1; X[2] = x2; X[3] = 1.0;
+  status[p] = 0;
+}
+
 template <typename T>
 struct Dev {
   T* p = nullptr;
@@ -701,5 +745,91 @@ extern "C" int theia_hip_track_statistics(const theia_ba_problem* p, double* mea
   HIP_TRY(hipMemcpy(mean_sq_reprojection_error, d_err.p, sizeof(double) * np, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(num_behind_camera, d_nb.p, sizeof(int) * np, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(min_ray_cosine, d_cos.p, sizeof(double) * np, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+
+extern "C" int theia_hip_estimate_tracks(const theia_ba_problem* p, const double* obs_ray_dir, const theia_ba_options* o,
+                                         const theia_track_estimate_options* eo, uint8_t* estimated, int32_t counters[4]) {
+  if (!p || !o || !eo) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null problem/options");
+  const int np = p->num_points;
+  if (counters) for (int k = 0; k < 4; ++k) counters[k] = 0;
+  if (np == 0) return 0;
+  if (!estimated || !counters) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null output");
+  if (p->num_obs > 0 && !obs_ray_dir) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null viewing rays");
+  if (o->loss_function_type < 0 || o->loss_function_type > THEIA_LOSS_TRUNCATED)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown loss function type");
+  PointGrouped G;
+  int rc = group_by_point(p, &G);
+  if (rc) return rc;
+  if ((rc = thip::ensure_device())) return rc;
+  // the viewing rays in the grouped order
+  const int64_t nobs = p->num_obs;
+  std::vector<double> rays(3 * (size_t)nobs);
+  {
+    std::vector<int64_t> fill(G.off.begin(), G.off.end() - 1);
+    for (int64_t i = 0; i < nobs; ++i) {
+      const int64_t s = fill[p->obs_pt[i]]++;
+      for (int k = 0; k < 3; ++k) rays[3 * s + k] = obs_ray_dir[3 * i + k];
+    }
+  }
+  Dev<int64_t> d_off; Dev<double> d_uv, d_si, d_cam, d_intr, d_pts, d_rays, d_err, d_cos; Dev<int> d_oc, d_gm, d_cg, d_status, d_nb;
+  Dev<uint8_t> d_pc; Dev<char> d_out;
+  if ((rc = d_off.up(G.off.data(), np + 1)) || (rc = d_uv.up(G.uv.data(), G.uv.size())) || (rc = d_oc.up(G.oc.data(), G.oc.size())) ||
+      (rc = d_cam.up(p->cam_ext, 6 * (size_t)p->num_cameras)) || (rc = d_intr.up(p->intrinsics, THEIA_MAX_INTRINSICS * (size_t)p->num_groups)) ||
+      (rc = d_gm.up(p->group_model, p->num_groups)) || (rc = d_cg.up(p->cam_group, p->num_cameras)) ||
+      (rc = d_pts.up(p->points, 4 * (size_t)np)) || (rc = d_rays.up(rays.data(), rays.size())) || (rc = d_status.alloc(np)) ||
+      (rc = d_out.alloc(sizeof(ViewOut) * (size_t)np)) || (rc = d_err.alloc(np)) || (rc = d_cos.alloc(np)) || (rc = d_nb.alloc(np)))
+    return rc;
+  if (p->obs_sqrt_info && (rc = d_si.up(G.si.data(), G.si.size()))) return rc;
+  if (p->point_const && (rc = d_pc.up(p->point_const, np))) return rc;
+  TrackBatch B;
+  std::memset(&B, 0, sizeof(B));
+  B.num = np; B.offsets = d_off.p; B.uv = reinterpret_cast<const double2*>(d_uv.p);
+  B.si = p->obs_sqrt_info ? reinterpret_cast<const double2*>(d_si.p) : nullptr;
+  B.obs_cam = d_oc.p; B.cam = d_cam.p; B.intr = d_intr.p; B.group_model = d_gm.p; B.cam_group = d_cg.p;
+  B.pt_const = p->point_const ? d_pc.p : nullptr; B.pts = d_pts.p;
+  B.loss_type = o->loss_function_type; B.loss_width = o->robust_loss_width; B.max_iterations = o->max_num_iterations;
+  B.function_tolerance = o->function_tolerance; B.gradient_tolerance = o->gradient_tolerance;
+  B.parameter_tolerance = o->parameter_tolerance; B.max_radius = o->max_trust_region_radius;
+  const int grid = (np + 63) / 64;
+  const double kPi = 3.14159265358979323846;
+  k_track_triangulate<<<grid, 64>>>(B, d_rays.p, cos(eo->min_triangulation_angle_degrees * kPi / 180.0), d_status.p);
+  std::vector<int> status(np);
+  HIP_TRY(hipMemcpy(status.data(), d_status.p, sizeof(int) * np, hipMemcpyDeviceToHost));
+  // the track BA and the reprojection sweep run on the triangulated tracks only: everything else is "constant"
+  std::vector<uint8_t> skip(np);
+  for (int i = 0; i < np; ++i) skip[i] = status[i] != 0;
+  Dev<uint8_t> d_skip;
+  if ((rc = d_skip.up(skip.data(), np))) return rc;
+  B.pt_const = d_skip.p;
+  std::vector<char> h_out;
+  if (eo->bundle_adjustment) {
+    if (o->use_homogeneous_point_parametrization) k_track_lm<3><<<grid, 64>>>(B, reinterpret_cast<ViewOut*>(d_out.p));
+    else k_track_lm<4><<<grid, 64>>>(B, reinterpret_cast<ViewOut*>(d_out.p));
+    h_out.resize(sizeof(ViewOut) * (size_t)np);
+    HIP_TRY(hipMemcpy(h_out.data(), d_out.p, h_out.size(), hipMemcpyDeviceToHost));
+  }
+  k_track_stats<<<grid, 64>>>(B, d_err.p, d_nb.p, d_cos.p);
+  std::vector<double> err(np);
+  std::vector<int> nb(np);
+  HIP_TRY(hipMemcpy(err.data(), d_err.p, sizeof(double) * np, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(nb.data(), d_nb.p, sizeof(int) * np, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(p->points, d_pts.p, sizeof(double) * 4 * (size_t)np, hipMemcpyDeviceToHost));
+  const double sq_max = eo->max_acceptable_reprojection_error_pixels * eo->max_acceptable_reprojection_error_pixels;
+  for (int i = 0; i < np; ++i) {
+    estimated[i] = 0;
+    if (status[i] == 3) continue;
+    if (status[i] == 1) { counters[0]++; continue; }
+    if (status[i] == 2) { counters[1]++; continue; }
+    if (eo->bundle_adjustment) {
+      int success = 0, term = 0, nit = 0, nsucc = 0;
+      double c0 = 0.0, c1 = 0.0;
+      views_batch_unpack(h_out.data(), i, &success, &term, &nit, &nsucc, &c0, &c1);
+      if (!success) { counters[3]++; continue; }
+    }
+    if (nb[i] > 0 || !(err[i] < sq_max)) { counters[2]++; continue; }
+    estimated[i] = 1;
+  }
   return 0;
 }

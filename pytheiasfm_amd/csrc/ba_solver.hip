@@ -1242,6 +1242,7 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
       else if ((rc = enqueue_body(timing ? b : -1))) return rc;
     }
     bodies_enqueued += nb;
+    HIP_TRY(hipGetLastError());   // a rejected launch configuration would otherwise go unnoticed
     HIP_TRY(hipMemcpyAsync(&st, dst, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     const int ran = (int)std::min<long long>(nb, std::max<long long>(0, (long long)st.bodies - (bodies_enqueued - nb)));

@@ -875,6 +875,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       HIP_TRYR(hipMemcpyAsync(h_counts.data(), d_counts.p, sizeof(int) * nh, hipMemcpyDeviceToHost, st));
       HIP_TRYR(hipMemcpyAsync(h_cost.data(), d_cost.p, sizeof(double) * nh * kMaxModels, hipMemcpyDeviceToHost, st));
       HIP_TRYR(hipMemcpyAsync(h_ninl.data(), d_ninl.p, sizeof(int) * nh * kMaxModels, hipMemcpyDeviceToHost, st));
+      HIP_TRYR(hipGetLastError());
       HIP_TRYR(hipStreamSynchronize(st));
       { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) fit_score_ms += ms; }
       // sequential replay of the acceptance rules (sample_consensus_estimator.h:330-394).  With
@@ -978,6 +979,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   }
   HIP_TRYR(hipMemcpyAsync(result->models, d_best_models.p, sizeof(double) * nprob * kStride, hipMemcpyDeviceToHost, st));
   HIP_TRYR(hipMemcpyAsync(result->inlier_mask, d_mask.p, (size_t)total, hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipGetLastError());
   HIP_TRYR(hipStreamSynchronize(st));
   for (int p = 0; p < nprob; ++p) {
     const ProblemState& s = S[p];

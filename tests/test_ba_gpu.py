@@ -716,3 +716,69 @@ def test_golden_ba_variants_on_gpu(name, kw):
     assert rel(tr.cost, v[f"{name}_trace_cost"]) <= 1e-8
     assert np.abs(p.cam_ext - v[f"{name}_cam_ext"]).max() <= 1e-7 and rel(p.intrinsics, v[f"{name}_intrinsics"]) <= 1e-7
     assert np.abs(p.points - v[f"{name}_points"]).max() <= 1e-6
+
+
+def _midpoint(origins, dirs):
+    """TriangulateMidpoint (triangulation.cc:130-157) restated with numpy."""
+    A = np.zeros((3, 3)); b = np.zeros(3)
+    for o_, d in zip(origins, dirs):
+        T = np.eye(3) - np.outer(d, d)
+        A += T; b += T @ o_
+    try:
+        np.linalg.cholesky(A)
+    except np.linalg.LinAlgError:
+        return None
+    return np.linalg.solve(A, b)
+
+
+def test_estimate_tracks_follows_track_estimator_rules():
+    """theia_hip_estimate_tracks = TrackEstimator::EstimateTrack with MIDPOINT triangulation: the angle test,
+    the midpoint, the per-track BA (against the oracle's LM from the same start) and the reprojection test."""
+    p = synth.synth_ba_v1(12, 90, seed=0xE577, sigma_pt=0.0, sigma_pos=0.0, sigma_rot_deg=0.0, pixel_noise=0.5)
+    o, oo = both_options(max_num_iterations=15)
+    truth = p.points.copy()
+    # viewing rays from the camera centres through the (noisy) pixels ~ truth direction + a little noise
+    C_ = p.cam_ext[p.obs_cam, :3]
+    X = truth[p.obs_pt, :3] / truth[p.obs_pt, 3:]
+    st = synth.Stream(0xE578, 1)
+    i = np.arange(len(p.obs_pt))
+    rays = X - C_ + 2e-3 * np.stack([st.normal(3 * i), st.normal(3 * i + 1), st.normal(3 * i + 2)], 1)
+    rays /= np.linalg.norm(rays, axis=1, keepdims=True)
+    pg = p.copy()
+    pg.points[:] = 0.0; pg.points[:, 3] = 1.0            # nothing is known about the points beforehand
+    pg.point_const = np.zeros(90, np.uint8); pg.point_const[7] = 1      # "already estimated": left alone
+    # track 3: all rays (nearly) parallel -> bad angle; track 4: one observation only
+    sel3 = np.flatnonzero(p.obs_pt == 3)
+    rays[sel3] = rays[sel3[0]]
+    keep = np.ones(len(p.obs_pt), bool); sel4 = np.flatnonzero(p.obs_pt == 4); keep[sel4[1:]] = False
+    # track 5: an observation far off -> fails the reprojection test
+    sel5 = np.flatnonzero(p.obs_pt == 5); pg.obs_uv[sel5[0]] += 400.0
+    for name in ("obs_uv", "obs_cam", "obs_pt"):
+        setattr(pg, name, np.ascontiguousarray(getattr(pg, name)[keep]))
+    rays_k = np.ascontiguousarray(rays[keep])
+    est, cnt = ba.estimate_tracks(pg, rays_k, o, 3.0, 5.0, True)
+    assert not est[3] and not est[4] and not est[5] and not est[7]
+    assert cnt["bad_angles"] == 2 and cnt["bad_reprojections"] >= 1 and cnt["failed_triangulations"] == 0
+    assert np.array_equal(pg.points[7], [0, 0, 0, 1])
+    assert est.sum() >= 80
+    cos_min = np.cos(np.deg2rad(3.0))
+    for q in range(0, 90, 6):
+        sel = np.flatnonzero(pg.obs_pt == q)
+        d = rays_k[sel]
+        ok_angle = len(sel) >= 2 and bool(np.any(np.triu(d @ d.T < cos_min, 1)))
+        if not ok_angle or q == 7:
+            assert not est[q]
+            continue
+        X0 = _midpoint(pg.cam_ext[pg.obs_cam[sel], :3], d)
+        fp = capi.FlatProblem(pg.cam_ext.copy(), pg.intrinsics.copy(), pg.group_model, pg.cam_group, np.append(X0, 1.0)[None].copy(),
+                              pg.obs_uv[sel], pg.obs_cam[sel], np.zeros(len(sel), np.int32),
+                              cam_const=np.full(pg.cam_ext.shape[0], 3, np.uint8))
+        so, _ = ol.solve(fp, oo)
+        assert np.abs(pg.points[q] - fp.points[0]).max() <= 1e-8 * max(1.0, np.abs(fp.points[0]).max()), q
+        err, nb, _ = ba.track_statistics(fp)
+        assert est[q] == bool(so.success and nb[0] == 0 and err[0] < 25.0), q
+    # without the BA the point is the midpoint itself
+    pg2 = pg.copy(); pg2.points[:] = 0.0; pg2.points[:, 3] = 1.0
+    est2, _ = ba.estimate_tracks(pg2, rays_k, o, 3.0, 5.0, False)
+    sel = np.flatnonzero(pg2.obs_pt == 12)
+    assert np.allclose(pg2.points[12, :3], _midpoint(pg2.cam_ext[pg2.obs_cam[sel], :3], rays_k[sel]), rtol=1e-12, atol=1e-12)
