@@ -913,6 +913,31 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
       for (size_t k = 0; k + 4 < bitems.size() + 1; k += 5) if (bitems[k] == bitems[k + 1]) self[bitems[k]] = 1;
       for (size_t k = 0; k + 3 < ditems.size() + 1; k += 4) if (self[ditems[k]]) ditems[k + 3] = 1;
     }
+    // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch order, a speed matter only).  All items whose
+    // ROW camera is c are placed on XCD c % 8, so that camera's records are fetched into one L2 and re-used by its
+    // block items and its diagonal item instead of being pulled into all eight.
+    if (!getenv("THEIA_HIP_NO_XCD_ORDER")) {
+      auto reorder = [&](std::vector<int>& items, int stride, int first_wg) {
+        const int n = (int)items.size() / stride;
+        std::vector<std::vector<int>> bucket(8);
+        for (int k = 0; k < n; ++k) bucket[items[(size_t)k * stride] & 7].push_back(k);
+        std::vector<size_t> head(8, 0);
+        std::vector<int> out;
+        out.reserve(items.size());
+        for (int pos = 0; pos < n; ++pos) {
+          int x = (first_wg + pos) & 7;
+          if (head[x] >= bucket[x].size()) {   // that XCD's list is exhausted: take from the fullest one
+            size_t best = 0;
+            for (int y = 0; y < 8; ++y) { const size_t left = bucket[y].size() - head[y]; if (left > best) { best = left; x = y; } }
+          }
+          const int k = bucket[x][head[x]++];
+          out.insert(out.end(), items.begin() + (size_t)k * stride, items.begin() + (size_t)(k + 1) * stride);
+        }
+        items.swap(out);
+      };
+      reorder(bitems, 5, 0);
+      reorder(ditems, 4, (int)bitems.size() / 5);
+    }
     h->n_diag_items = (int)ditems.size() / 4; h->n_blk_items = (int)bitems.size() / 5;
     {
       std::vector<int> ppt(pairs.size());
