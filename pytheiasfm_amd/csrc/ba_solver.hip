@@ -126,6 +126,7 @@ struct theia_ba_handle_s {
   DevBuf<int2> blk_pairs;
   int n_diag_items = 0, n_blk_items = 0;
   double* h_scal = nullptr;  // pinned: [scalA(16) | scalB(16)]
+  char* h_state = nullptr;   // pinned: LmState read-back
   int cur = 0;
   bool have_scale = false;
   double fixed_cost = 0.0;
@@ -149,6 +150,7 @@ struct theia_ba_handle_s {
     if (plan) chol_plan_destroy(plan);
     for (auto& row : ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
     if (h_scal) (void)hipHostFree(h_scal);
+    if (h_state) (void)hipHostFree(h_state);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -314,6 +316,8 @@ __global__ void k_xnorm_reduce(const double* __restrict__ part, int nblocks, dou
   out2[0] = a; out2[1] = b;
 }
 __global__ void k_xnorm_set(LmState* st, const double* __restrict__ in2) { st->x_norm = sqrt(in2[0] + in2[1]); }
+__global__ void k_lm_init_state(LmState* dst, LmState v) { *dst = v; }
+__global__ void k_lm_init_ctl(LmCtl* dst, LmCtl v) { *dst = v; }
 
 // Packed all-reduce buffer: [tiles (64x64, zero padded) | rhs | colsq | g_c | 8 scalars].  S outside the
 // structurally non-zero tiles is zero on every rank, so only those tiles are summed across ranks
@@ -606,6 +610,8 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   for (auto& row : h->ev) for (auto& e : row) HIP_TRY(hipEventCreate(&e));
   HIP_TRY(hipHostMalloc((void**)&h->h_scal, sizeof(double) * 32, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&h->h_state, 1024, hipHostMallocDefault));
+  static_assert(sizeof(LmState) <= 1024, "pinned read-back block too small");
 
   // THEIA_HIP_CREATE_TIMING=1: wall time of the create() stages on stderr
   const bool ctiming = getenv("THEIA_HIP_CREATE_TIMING") != nullptr;
@@ -1084,8 +1090,8 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     double pf = 0.0;
     HIP_TRY(hipMemsetAsync(h->scalB.p, 0, sizeof(double) * 16, h->stream));
     launch_cam_priors(h->P, PRIOR_FIXED, h->cam[0].p, nullptr, nullptr, nullptr, nullptr, h->scalB.p, nullptr, h->stream);
-    HIP_TRY(hipMemcpyAsync(&pf, h->scalB.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(&pf, h->scalB.p, sizeof(double), hipMemcpyDeviceToHost));
     fc += pf;
   }
   h->fixed_cost = fc;
@@ -1161,10 +1167,11 @@ int theia_hip_ba_set_allreduce(theia_ba_handle h, theia_allreduce_fn fn, void* c
 
 int theia_hip_ba_download(theia_ba_handle h, theia_ba_problem* p) {
   if (!h || !p) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
-  if (h->nc) HIP_TRY(hipMemcpyAsync(p->cam_ext, h->cam[h->cur].p, sizeof(double) * 6 * h->nc, hipMemcpyDeviceToHost, h->stream));
-  if (h->np) HIP_TRY(hipMemcpyAsync(p->points, h->pts[h->cur].p, sizeof(double) * 4 * h->np, hipMemcpyDeviceToHost, h->stream));
-  if (h->ng && h->ni) HIP_TRY(hipMemcpyAsync(p->intrinsics, h->intr[h->cur].p, sizeof(double) * THEIA_MAX_INTRINSICS * h->ng, hipMemcpyDeviceToHost, h->stream));
+  // caller-owned (pageable) destinations: drain the stream, then blocking copies
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->nc) HIP_TRY(hipMemcpy(p->cam_ext, h->cam[h->cur].p, sizeof(double) * 6 * h->nc, hipMemcpyDeviceToHost));
+  if (h->np) HIP_TRY(hipMemcpy(p->points, h->pts[h->cur].p, sizeof(double) * 4 * h->np, hipMemcpyDeviceToHost));
+  if (h->ng && h->ni) HIP_TRY(hipMemcpy(p->intrinsics, h->intr[h->cur].p, sizeof(double) * THEIA_MAX_INTRINSICS * h->ng, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1192,7 +1199,9 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   st.radius = 1e4; st.decrease_factor = 2.0; st.step_successful = 1; st.first = 1;
   st.term = THEIA_TERM_NO_CONVERGENCE; st.pending_grad = -1;
   LmState* dst = reinterpret_cast<LmState*>(h->lm_state.p);
-  HIP_TRY(hipMemcpyAsync(dst, &st, sizeof(st), hipMemcpyHostToDevice, h->stream));
+  // the initial state and the control block travel as kernel arguments (k_lm_init): no host buffer whose
+  // lifetime would need a synchronisation before the first iteration
+  k_lm_init_state<<<1, 1, 0, h->stream>>>(dst, st);
   // |x| of the variable blocks at the start: summed on the device (points per shard, all-reduced)
   HIP_TRY(hipMemsetAsync(h->scalB.p, 0, sizeof(double) * 16, h->stream));
   if (h->xnorm_part.n < 2 * (size_t)kXnormBlocks && (rc = h->xnorm_part.alloc(2 * kXnormBlocks))) return rc;
@@ -1214,8 +1223,7 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   }
   ctl.tc = ctl.trace_capacity ? h->tr_cost.p : nullptr;
   ctl.tg = h->tr_g.p; ctl.ts = h->tr_step.p; ctl.tr = h->tr_radius.p; ctl.ta = h->tr_acc.p;
-  HIP_TRY(hipMemcpyAsync(h->lm_ctl.p, &ctl, sizeof(ctl), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));   // st / ctl are stack objects
+  k_lm_init_ctl<<<1, 1, 0, h->stream>>>(reinterpret_cast<LmCtl*>(h->lm_ctl.p), ctl);
   const LmCtl* dctl = reinterpret_cast<const LmCtl*>(h->lm_ctl.p);
   const int nxt = 1;
   // one LM iteration ("body"): linearise + Schur, solve, trial step, step control, accept
@@ -1268,8 +1276,12 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
     }
     bodies_enqueued += nb;
     HIP_TRY(hipGetLastError());   // a rejected launch configuration would otherwise go unnoticed
-    HIP_TRY(hipMemcpyAsync(&st, dst, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    // read-back through the handle's pinned block (an asynchronous D2H copy into pageable memory is not reliably
+    // complete at the next synchronisation on this runtime: seen with the 8-byte trace arrays, which therefore
+    // use blocking copies below)
+    HIP_TRY(hipMemcpyAsync(h->h_state, dst, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    std::memcpy(&st, h->h_state, sizeof(st));
     const int ran = (int)std::min<long long>(nb, std::max<long long>(0, (long long)st.bodies - (bodies_enqueued - nb)));
     for (int b = 0; timing && b < ran; ++b) {
       float ms = 0.f;
@@ -1487,11 +1499,11 @@ int theia_hip_ba_reduced_system(theia_ba_handle h, double radius, int32_t* n_out
   const int n = h->n;
   *n_out = n;
   if ((int64_t)n * n > capacity) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "capacity too small for %d x %d", n, n);
-  if (n) {
-    HIP_TRY(hipMemcpyAsync(S, h->rb.S, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(rhs, h->rb.rhs, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
-  }
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (n) {
+    HIP_TRY(hipMemcpy(S, h->rb.S, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rhs, h->rb.rhs, sizeof(double) * n, hipMemcpyDeviceToHost));
+  }
   for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) S[(size_t)i * n + j] = S[(size_t)j * n + i];
   return 0;
 }

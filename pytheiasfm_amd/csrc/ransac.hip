@@ -977,10 +977,11 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     for (const LoEvent& ev : evs) S[ev.prob].num_lo++;
     HIP_TRYR(hipMemcpyAsync(d_best_models.p, d_cur_models.p, sizeof(double) * nprob * kStride, hipMemcpyDeviceToDevice, st));
   }
-  HIP_TRYR(hipMemcpyAsync(result->models, d_best_models.p, sizeof(double) * nprob * kStride, hipMemcpyDeviceToHost, st));
-  HIP_TRYR(hipMemcpyAsync(result->inlier_mask, d_mask.p, (size_t)total, hipMemcpyDeviceToHost, st));
   HIP_TRYR(hipGetLastError());
   HIP_TRYR(hipStreamSynchronize(st));
+  // caller-owned (pageable) destinations: blocking copies after the stream has drained
+  HIP_TRYR(hipMemcpy(result->models, d_best_models.p, sizeof(double) * nprob * kStride, hipMemcpyDeviceToHost));
+  HIP_TRYR(hipMemcpy(result->inlier_mask, d_mask.p, (size_t)total, hipMemcpyDeviceToHost));
   for (int p = 0; p < nprob; ++p) {
     const ProblemState& s = S[p];
     int cnt = 0;
