@@ -409,7 +409,11 @@ enum {
    * 8-point F, focal lengths from F, E = K2 F K1 decomposed with the cheirality vote;
    * data in pixels with the principal point removed.  estimator_params = {min, max}
    * focal length (both >= 1 to be applied, as in the reference). */
-  THEIA_EST_UNCALIBRATED_RELATIVE_POSE = 9
+  THEIA_EST_UNCALIBRATED_RELATIVE_POSE = 9,
+  /* EstimateAbsolutePoseWithKnownOrientation, estimate_absolute_pose_with_known_orientation.cc:132-153:
+   * 2 correspondences [u v X Y Z] whose features the caller has rotated into the world frame
+   * (RotateCorrespondences, :53-72); model = camera position (3) */
+  THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION = 10
 };
 
 /* A batch of independent estimation problems ("pairs").  Datum layout:

@@ -45,13 +45,14 @@ __host__ __device__ inline int sample_size(int est) {
     case THEIA_EST_RELATIVE_POSE: case THEIA_EST_ESSENTIAL_MATRIX: return 5;
     case THEIA_EST_FUNDAMENTAL_MATRIX: case THEIA_EST_UNCALIBRATED_RELATIVE_POSE: return 8;
     case THEIA_EST_HOMOGRAPHY: return 4;
-    case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: return 2;
+    case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: return 2;
     default: return 3;
   }
 }
 __host__ __device__ inline int datum_size(int est) {
   switch (est) {
-    case THEIA_EST_ABSOLUTE_POSE_KNEIP: case THEIA_EST_ABSOLUTE_POSE_DLS: case THEIA_EST_ABSOLUTE_POSE_SQPNP: return 5;
+    case THEIA_EST_ABSOLUTE_POSE_KNEIP: case THEIA_EST_ABSOLUTE_POSE_DLS: case THEIA_EST_ABSOLUTE_POSE_SQPNP:
+    case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: return 5;
     case THEIA_EST_DOMINANT_PLANE: return 3;
     default: return 4;
   }
@@ -127,6 +128,7 @@ __device__ int estimate_models(int est, const double* subset, double* models, Es
       const double mm[2] = {ep.min_focal, ep.max_focal};
       ok = rsc::uncalibrated_relative_pose(subset, mm, models);
     }
+    else if (est == THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION) ok = rsc::position_from_two_rays(subset, models);
     else if (est == THEIA_EST_FUNDAMENTAL_MATRIX) ok = rsc::eight_point_fundamental(subset, models);
     else if (est == THEIA_EST_HOMOGRAPHY) ok = rsc::four_point_homography(subset, models);
     else if (est == THEIA_EST_DOMINANT_PLANE) ok = rsc::plane_from_three_points(subset, models);
@@ -148,6 +150,7 @@ __device__ inline double model_error(int est, const double* m, const double* d) 
   if (est == THEIA_EST_DOMINANT_PLANE) return rsc::plane_error(m, d);
   if (est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION) return rsc::known_orientation_error(m, d);
   if (est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE) return rsc::uncalibrated_relative_pose_error(m, d);
+  if (est == THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION) return rsc::known_orientation_abs_error(m, d);
   const double dx = d[2] - m[9], dy = d[3] - m[10], dz = d[4] - m[11];
   const double px = (m[0] * dx + m[1] * dy) + m[2] * dz;
   const double py = (m[3] * dx + m[4] * dy) + m[5] * dz;
@@ -649,7 +652,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   }
   if (est == THEIA_EST_ABSOLUTE_POSE_DLS)
     return set_error(THEIA_HIP_ERR_UNSUPPORTED, "the DLS minimal solver has no HIP kernel yet");
-  if (est < 0 || est > THEIA_EST_UNCALIBRATED_RELATIVE_POSE) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
+  if (est < 0 || est > THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
   const bool abs_pose = est == THEIA_EST_ABSOLUTE_POSE_KNEIP || est == THEIA_EST_ABSOLUTE_POSE_SQPNP;
   if (P.use_lo && !abs_pose)
     return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: only the absolute-pose RefineModel (BundleAdjustView) is built; "
@@ -856,7 +859,8 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
           case THEIA_EST_HOMOGRAPHY: THIP_FIT(THEIA_EST_HOMOGRAPHY); break;
           case THEIA_EST_DOMINANT_PLANE: THIP_FIT(THEIA_EST_DOMINANT_PLANE); break;
           case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: THIP_FIT(THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION); break;
-          default: THIP_FIT(THEIA_EST_UNCALIBRATED_RELATIVE_POSE); break;
+          case THEIA_EST_UNCALIBRATED_RELATIVE_POSE: THIP_FIT(THEIA_EST_UNCALIBRATED_RELATIVE_POSE); break;
+          default: THIP_FIT(THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION); break;
         }
 #undef THIP_FIT
       }

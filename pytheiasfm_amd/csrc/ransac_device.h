@@ -1330,6 +1330,118 @@ RDEV int best_pose_from_E(const double* E, const double* corr, int ncorr, double
   return bestcount;
 }
 
+// Eigen::ColPivHouseholderQR of a 4 x 3 system, rank() and solve() (Eigen/src/QR/ColPivHouseholderQR.h:
+// computeInPlace, rank with the default threshold eps * diagonalSize, _solve_impl), restated for
+// PositionFromTwoRays.  A row-major 4 x 3 (destroyed), b (destroyed).  Returns the rank.
+RDEV int colpiv_qr_solve_4x3(double* A, double* b, double* x) {
+  const int rows = 4, cols = 3, size = 3;
+  double hcoef[3], norm_upd[3], norm_dir[3];
+  int transp[3];
+  for (int k = 0; k < cols; ++k) {
+    double s2 = 0.0;
+    for (int r = 0; r < rows; ++r) s2 += A[r * cols + k] * A[r * cols + k];
+    norm_upd[k] = norm_dir[k] = sqrt(s2);
+  }
+  double maxn = fmax(norm_upd[0], fmax(norm_upd[1], norm_upd[2]));
+  const double threshold_helper = (maxn * DBL_EPSILON) * (maxn * DBL_EPSILON) / (double)rows;
+  const double norm_downdate_threshold = sqrt(DBL_EPSILON);
+  int nonzero_pivots = size;
+  double maxpivot = 0.0;
+  for (int k = 0; k < size; ++k) {
+    int big = k;
+    for (int j = k + 1; j < cols; ++j) if (norm_upd[j] > norm_upd[big]) big = j;
+    const double big_sq = norm_upd[big] * norm_upd[big];
+    if (nonzero_pivots == size && big_sq < threshold_helper * (double)(rows - k)) nonzero_pivots = k;
+    transp[k] = big;
+    if (k != big) {
+      for (int r = 0; r < rows; ++r) dswap(A[r * cols + k], A[r * cols + big]);
+      dswap(norm_upd[k], norm_upd[big]);
+      dswap(norm_dir[k], norm_dir[big]);
+    }
+    // makeHouseholderInPlace on A(k:, k)
+    const double c0 = A[k * cols + k];
+    double tail = 0.0;
+    for (int r = k + 1; r < rows; ++r) tail += A[r * cols + k] * A[r * cols + k];
+    double tau, beta;
+    if (tail <= DBL_MIN) {
+      tau = 0.0; beta = c0;
+      for (int r = k + 1; r < rows; ++r) A[r * cols + k] = 0.0;
+    } else {
+      beta = sqrt(c0 * c0 + tail);
+      if (c0 >= 0.0) beta = -beta;
+      for (int r = k + 1; r < rows; ++r) A[r * cols + k] /= (c0 - beta);
+      tau = (beta - c0) / beta;
+    }
+    hcoef[k] = tau;
+    A[k * cols + k] = beta;
+    if (fabs(beta) > maxpivot) maxpivot = fabs(beta);
+    // apply H_k = I - tau v v^T (v = [1; essential]) to the remaining columns
+    for (int j = k + 1; j < cols; ++j) {
+      double tmp = A[k * cols + j];
+      for (int r = k + 1; r < rows; ++r) tmp += A[r * cols + k] * A[r * cols + j];
+      A[k * cols + j] -= tau * tmp;
+      for (int r = k + 1; r < rows; ++r) A[r * cols + j] -= tau * A[r * cols + k] * tmp;
+    }
+    for (int j = k + 1; j < cols; ++j) {
+      if (norm_upd[j] != 0.0) {
+        double temp = fabs(A[k * cols + j]) / norm_upd[j];
+        temp = (1.0 + temp) * (1.0 - temp);
+        temp = temp < 0.0 ? 0.0 : temp;
+        const double q = norm_upd[j] / norm_dir[j];
+        const double temp2 = temp * (q * q);
+        if (temp2 <= norm_downdate_threshold) {
+          double s2 = 0.0;
+          for (int r = k + 1; r < rows; ++r) s2 += A[r * cols + j] * A[r * cols + j];
+          norm_dir[j] = sqrt(s2);
+          norm_upd[j] = norm_dir[j];
+        } else {
+          norm_upd[j] *= sqrt(temp);
+        }
+      }
+    }
+  }
+  const double premult = fabs(maxpivot) * (DBL_EPSILON * (double)size);
+  int rank = 0;
+  for (int i = 0; i < nonzero_pivots; ++i) rank += fabs(A[i * cols + i]) > premult;
+  // c = Q^T b, then back-substitution on the leading block, then the column permutation
+  for (int k = 0; k < nonzero_pivots; ++k) {
+    double tmp = b[k];
+    for (int r = k + 1; r < rows; ++r) tmp += A[r * cols + k] * b[r];
+    b[k] -= hcoef[k] * tmp;
+    for (int r = k + 1; r < rows; ++r) b[r] -= hcoef[k] * A[r * cols + k] * tmp;
+  }
+  double y[3] = {0.0, 0.0, 0.0};
+  for (int i = nonzero_pivots - 1; i >= 0; --i) {
+    double s = b[i];
+    for (int j = i + 1; j < nonzero_pivots; ++j) s -= A[i * cols + j] * y[j];
+    y[i] = s / A[i * cols + i];
+  }
+  int perm[3] = {0, 1, 2};
+  for (int k = 0; k < size; ++k) dswap(perm[k], perm[transp[k]]);
+  for (int i = 0; i < 3; ++i) x[i] = 0.0;
+  for (int i = 0; i < nonzero_pivots; ++i) x[perm[i]] = y[i];
+  return rank;
+}
+
+// PositionFromTwoRays (sfm/pose/position_from_two_rays.cc:55-83).  corr: 2 x [u v X Y Z], features
+// already rotated into the world frame.
+RDEV bool position_from_two_rays(const double* corr, double* pos) {
+  double A[12], b[4];
+  for (int i = 0; i < 2; ++i) {
+    const double u = corr[5 * i], v = corr[5 * i + 1], X = corr[5 * i + 2], Y = corr[5 * i + 3], Z = corr[5 * i + 4];
+    A[6 * i] = 1.0; A[6 * i + 1] = 0.0; A[6 * i + 2] = -u;
+    A[6 * i + 3] = 0.0; A[6 * i + 4] = 1.0; A[6 * i + 5] = -v;
+    b[2 * i] = X - u * Z; b[2 * i + 1] = Y - v * Z;
+  }
+  return colpiv_qr_solve_4x3(A, b, pos) == 3;
+}
+// AbsolutePoseWithKnownOrientationEstimator::Error (estimate_absolute_pose_with_known_orientation.cc:113-120)
+RDEV double known_orientation_abs_error(const double* pos, const double* d) {
+  const double px = d[2] - pos[0], py = d[3] - pos[1], pz = d[4] - pos[2];
+  const double ex = px / pz - d[0], ey = py / pz - d[1];
+  return ex * ex + ey * ey;
+}
+
 // FocalLengthsFromFundamentalMatrix (sfm/pose/fundamental_matrix_util.cc:57-130).
 // F row-major.  Epipoles = last right singular vectors of F and F^T.
 RDEV bool focal_lengths_from_fundamental(const double* F, double* f1, double* f2) {

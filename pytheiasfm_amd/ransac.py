@@ -31,6 +31,7 @@ class PnPType(enum.IntEnum):  # estimate_calibrated_absolute_pose.h:54
 EST_RELATIVE_POSE, EST_ESSENTIAL_MATRIX, EST_ABS_KNEIP, EST_ABS_DLS, EST_ABS_SQPNP = range(5)
 EST_FUNDAMENTAL_MATRIX, EST_HOMOGRAPHY, EST_DOMINANT_PLANE, EST_RELATIVE_POSE_KNOWN_ORIENTATION = range(5, 9)
 EST_UNCALIBRATED_RELATIVE_POSE = 9
+EST_ABSOLUTE_POSE_KNOWN_ORIENTATION = 10
 
 
 class RansacParameters:
@@ -214,6 +215,25 @@ def EstimateUncalibratedRelativePose(ransac_params, ransac_type, centered_corres
     ok, m, s = _single(EST_UNCALIBRATED_RELATIVE_POSE, ransac_params, ransac_type, centered_correspondences,
                        np.asarray(min_max_focal_length, dtype=np.float64))
     return ok, UncalibratedRelativePose(m), s
+
+
+def RotateCorrespondences(normalized_correspondences, camera_orientation):
+    """estimate_absolute_pose_with_known_orientation.cc:53-72: features into the world frame with the
+    camera-to-world rotation (transpose of the angle-axis world-to-camera rotation)."""
+    from . import synth
+    c = np.ascontiguousarray(normalized_correspondences, dtype=np.float64).reshape(-1, 5)
+    R = synth.angle_axis_to_matrix(np.asarray(camera_orientation, dtype=np.float64))
+    ray = np.column_stack([c[:, :2], np.ones(len(c))]) @ R   # rows: R^T [u v 1]
+    out = c.copy()
+    out[:, :2] = ray[:, :2] / ray[:, 2:]
+    return out
+
+
+def EstimateAbsolutePoseWithKnownOrientation(ransac_params, ransac_type, camera_orientation, normalized_correspondences):
+    """estimate_absolute_pose_with_known_orientation.cc:132-153 -> (success, camera_position, summary)."""
+    rot = RotateCorrespondences(normalized_correspondences, camera_orientation)
+    ok, m, s = _single(EST_ABSOLUTE_POSE_KNOWN_ORIENTATION, ransac_params, ransac_type, rot)
+    return ok, m[0:3].copy(), s
 
 
 def FivePointRelativePose(image1_points, image2_points):

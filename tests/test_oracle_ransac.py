@@ -601,3 +601,39 @@ def test_estimate_uncalibrated_relative_pose_on_synthetic_pairs():
         assert r["success"]
         tin = truth["inlier"][p]; mask = r["inlier_mask"].astype(bool)
         assert (mask & tin).sum() >= 0.7 * tin.sum() and (mask & ~tin).sum() <= 0.1 * tin.sum() + 3
+
+
+def test_position_from_two_rays_and_pivoted_qr():
+    """position_from_two_rays.cc:55-83 (ColPivHouseholderQR of the 4 x 3 system): exact data give the camera
+    position; noisy data give numpy's least-squares solution; a repeated correspondence has rank 2."""
+    st = synth.Stream(0xAB5, 1)
+    for k in range(20):
+        i = np.arange(6) + 10 * k
+        c = np.array([st.normal(i[:3]).tolist()])[0] * 0.5
+        X = np.stack([st.normal(i + 100), st.normal(i + 200), 5.0 + st.uniform(i + 300)], 1)[:2]
+        uv = (X - c)[:, :2] / (X - c)[:, 2:]
+        m = ol.estimate_models(10, np.hstack([uv, X]))
+        assert len(m) == 1 and np.allclose(m[0][:3], c, atol=1e-12)
+        uvn = uv + 1e-3 * np.stack([st.normal(i[:2] + 400), st.normal(i[:2] + 500)], 1)
+        A = np.array([[1, 0, -uvn[0, 0]], [0, 1, -uvn[0, 1]], [1, 0, -uvn[1, 0]], [0, 1, -uvn[1, 1]]])
+        b = np.array([X[0, 0] - uvn[0, 0] * X[0, 2], X[0, 1] - uvn[0, 1] * X[0, 2],
+                      X[1, 0] - uvn[1, 0] * X[1, 2], X[1, 1] - uvn[1, 1] * X[1, 2]])
+        ref = np.linalg.lstsq(A, b, rcond=None)[0]
+        m = ol.estimate_models(10, np.hstack([uvn, X]))
+        assert np.allclose(m[0][:3], ref, rtol=1e-11, atol=1e-11)
+    same = np.hstack([uv[:1], X[:1]])
+    assert len(ol.estimate_models(10, np.vstack([same, same]))) == 0
+
+
+def test_estimate_absolute_pose_with_known_orientation_scene():
+    data, offsets, truth = synth.synth_ransac_v1(2, 300, kind="absolute", seed=0x5AC51800, inlier_lo=0.5, inlier_hi=0.7)
+    from pytheiasfm_amd import ransac as rs
+    for p in range(2):
+        aa = synth.matrix_to_angle_axis(truth["R"][p])
+        rot = rs.RotateCorrespondences(data[offsets[p]:offsets[p + 1]], aa)
+        prm = ol.default_ransac_params((4.0 / 1000.0) ** 2, seed=3 + p); prm.failure_probability = 0.001
+        r = ol.ransac_estimate(10, rot, prm)
+        assert r["success"]
+        tin = truth["inlier"][p]; mask = r["inlier_mask"].astype(bool)
+        assert (mask & tin).sum() >= 0.75 * tin.sum() and (mask & ~tin).sum() <= 0.1 * tin.sum() + 3
+        assert np.linalg.norm(r["model"][:3] - truth["position"][p]) < 0.05

@@ -374,3 +374,30 @@ def test_estimate_two_view_info_both_branches():
     for i, (ok, info, inl) in enumerate(out):
         assert ok and len(inl) > 120
         assert abs(info.focal_length_1 / 1000.0 - 1.0) < 0.2 and abs(info.focal_length_2 / 1250.0 - 1.0) < 0.2
+
+
+@pytest.mark.parametrize("rtype", [0, 1, 2, 3])
+def test_absolute_pose_with_known_orientation_bit_identical_to_oracle(rtype):
+    """EstimateAbsolutePoseWithKnownOrientation (2-sample: RANSAC, PROSAC, LMED and EXHAUSTIVE all apply)."""
+    data, offsets, truth = synth.synth_ransac_v1(5, 250, "absolute", seed=0x5AC51800, inlier_lo=0.5, inlier_hi=0.7)
+    rot = np.concatenate([ransac.RotateCorrespondences(data[offsets[i]:offsets[i + 1]], synth.matrix_to_angle_axis(truth["R"][i]))
+                          for i in range(5)])
+    p = ransac.RansacParameters(); p.error_thresh = (4.0 / 1000.0) ** 2; p.seed = 29; p.failure_probability = 0.001
+    pc0 = p.to_c(); pc0.ransac_type = rtype
+    if rtype == 3:
+        pc0.max_iterations = 3000
+    res = ransac.estimate_batch(10, rot, offsets, pc0)
+    for i in range(5):
+        pc = p.to_c(); pc.seed = 29 + i; pc.ransac_type = rtype
+        if rtype == 3:
+            pc.max_iterations = 3000
+        o = ol.ransac_estimate(10, rot[offsets[i]:offsets[i + 1]], pc)
+        sl = slice(offsets[i], offsets[i + 1])
+        assert np.array_equal(o["inlier_mask"], res["inlier_mask"][sl])
+        assert o["num_iterations"] == res["num_iterations"][i]
+        assert np.array_equal(o["model"][:3], res["models"][i][:3])
+        if rtype == 0:
+            assert np.linalg.norm(res["models"][i][:3] - truth["position"][i]) < 0.05
+    ok, pos, s = ransac.EstimateAbsolutePoseWithKnownOrientation(p, ransac.RansacType.RANSAC, synth.matrix_to_angle_axis(truth["R"][0]),
+                                                                 data[offsets[0]:offsets[1]])
+    assert ok and np.linalg.norm(pos - truth["position"][0]) < 0.05
