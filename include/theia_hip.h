@@ -137,8 +137,18 @@ typedef struct theia_ba_problem {
   const double* cam_gravity_prior_sqrt_info;     /* [num_cameras][3][3]                        */
   const double* cam_orientation_prior;           /* [num_cameras][3] angle-axis                */
   const double* cam_orientation_prior_sqrt_info; /* [num_cameras][3][3]                        */
+  /* Depth priors (BundleAdjuster::AddDepthPriorErrorResidual, bundle_adjuster.cc:154-156,643-650;
+   * DepthPriorError, depth_prior_error.h): every feature with depth_prior != 0 of a solve with
+   * use_depth_priors contributes ONE more residual block on (extrinsics, point),
+   *   d = (R (X - w C))_z - depth_prior,  weighted by 1 / sqrt(depth_prior_variance),
+   * under its own loss (options.robust_loss_width_depth_prior).  Here such a block is one more
+   * OBSERVATION ROW of kind THEIA_OBS_DEPTH_PRIOR on the same camera and point:
+   *   obs_uv = (depth_prior, 0), obs_sqrt_info = (1 / sqrt(variance), any) (obs_sqrt_info then required).
+   * NULL = every row is a reprojection error. */
+  const uint8_t* obs_kind;                       /* [num_obs] THEIA_OBS_* or NULL              */
 } theia_ba_problem;
 enum { THEIA_PRIOR_POSITION = 1, THEIA_PRIOR_GRAVITY = 2, THEIA_PRIOR_ORIENTATION = 4 };
+enum { THEIA_OBS_REPROJECTION = 0, THEIA_OBS_DEPTH_PRIOR = 1 };
 
 /* Mirrors BundleAdjustmentOptions (bundle_adjustment.h:87-167), the fields the
  * HIP backend honours.  The linear-algebra selector fields of the reference
@@ -161,6 +171,7 @@ typedef struct theia_ba_options {
   double parameter_tolerance;    /* (:150) */
   double max_trust_region_radius;/* (:151) */
   double max_solver_time_in_seconds; /* (:141) */
+  double robust_loss_width_depth_prior; /* (:94) width of the loss on THEIA_OBS_DEPTH_PRIOR rows */
 } theia_ba_options;
 
 void theia_ba_options_default(theia_ba_options* o);

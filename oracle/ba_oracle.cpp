@@ -321,6 +321,8 @@ inline bool project(int model, const T* k, const T* p, T* pixel) {
   }
 }
 
+const int kDepthRow = 1000;   // pseudo camera model of an observation row that is a depth prior
+
 // reprojection_error.h:54-110.  Returns the functor's boolean; the residual is
 // written even when the model reports "invalid" (:100-109).
 template <typename T>
@@ -331,6 +333,13 @@ inline bool reprojection_error(int model, const T* ext, const T* intr, const T* 
   if (sq < 1e-8) return false;
   T rot[3];
   angle_axis_rotate_point(ext + 3, adj, rot);
+  if (model == kDepthRow) {
+    // DepthPriorError (depth_prior_error.h): sqrt_information * (rotated_point[2] - depth_prior); one residual,
+    // carried as the first of the two rows of an observation (the second is identically zero)
+    res[0] = sqrt_info[0] * (rot[2] - uv[0]);
+    res[1] = T(0.0);
+    return true;
+  }
   T pix[2];
   const bool ok = project(model, intr, rot, pix);
   res[0] = sqrt_info[0] * (pix[0] - uv[0]);
@@ -502,13 +511,14 @@ struct oba_problem {
   const double* cam_position_prior; const double* cam_position_prior_sqrt_info;
   const double* cam_gravity_prior; const double* cam_gravity_prior_sqrt_info;
   const double* cam_orientation_prior; const double* cam_orientation_prior_sqrt_info;
+  const uint8_t* obs_kind;   // 1 = DepthPriorError row (depth_prior_error.h), NULL / 0 = reprojection error
 };
 struct oba_options {
   int32_t loss_function_type, intrinsics_to_optimize, max_num_iterations,
       use_homogeneous_point_parametrization, constant_camera_orientation,
       constant_camera_position, orthographic_camera, use_inner_iterations, verbose, prior_mask;
   double robust_loss_width, function_tolerance, gradient_tolerance, parameter_tolerance,
-      max_trust_region_radius, max_solver_time_in_seconds;
+      max_trust_region_radius, max_solver_time_in_seconds, robust_loss_width_depth_prior;
 };
 struct oba_summary {
   int32_t success, termination_type, num_iterations, num_successful_steps;
@@ -637,7 +647,9 @@ bool evaluate(Oracle& o, const std::vector<double>& cam, const std::vector<doubl
     if (o.obs_fixed[i]) continue;
     const int c = P.obs_cam[i], p = P.obs_pt[i];
     const int g = P.cam_group[c];
-    const int model = P.group_model[g];
+    const bool depth_row = P.obs_kind && P.obs_kind[i];
+    const int model = depth_row ? kDepthRow : P.group_model[g];
+    const double loss_width = depth_row ? o.O.robust_loss_width_depth_prior : o.O.robust_loss_width;
     const double* intr = &intrv[(size_t)g * kMaxIntr];
     const double* si = P.obs_sqrt_info ? P.obs_sqrt_info + 2 * i : one;
     double res[2];
@@ -645,7 +657,7 @@ bool evaluate(Oracle& o, const std::vector<double>& cam, const std::vector<doubl
       if (!reprojection_error<double>(model, &cam[6 * c], intr, &pts[4 * p], P.obs_uv + 2 * i, si, res))
         ok = false;
       double rho[3];
-      loss_evaluate(o.O.loss_function_type, o.O.robust_loss_width, res[0] * res[0] + res[1] * res[1], rho);
+      loss_evaluate(o.O.loss_function_type, loss_width, res[0] * res[0] + res[1] * res[1], rho);
       cost += 0.5 * rho[0];
       continue;
     }
@@ -658,7 +670,7 @@ bool evaluate(Oracle& o, const std::vector<double>& cam, const std::vector<doubl
     res[0] = rr[0].a; res[1] = rr[1].a;
     const double s = res[0] * res[0] + res[1] * res[1];
     double rho[3];
-    loss_evaluate(o.O.loss_function_type, o.O.robust_loss_width, s, rho);
+    loss_evaluate(o.O.loss_function_type, loss_width, s, rho);
     cost += 0.5 * rho[0];
     // ceres/corrector.cc: every loss here has rho'' <= 0 -> residual and
     // Jacobian are both scaled by sqrt(rho').
@@ -951,9 +963,12 @@ int setup(Oracle& o, const oba_problem* P, const oba_options* O) {
   for (int64_t i = 0; i < o.nobs; ++i) if (o.obs_fixed[i]) {
     const int c = P->obs_cam[i], p = P->obs_pt[i], g = P->cam_group[c];
     double res[2] = {0, 0};
-    reprojection_error<double>(P->group_model[g], &o.cam[6 * c], &o.intr[(size_t)g * kMaxIntr],
+    const bool depth_row = P->obs_kind && P->obs_kind[i];
+    reprojection_error<double>(depth_row ? kDepthRow : P->group_model[g], &o.cam[6 * c], &o.intr[(size_t)g * kMaxIntr],
                                &o.pts[4 * p], P->obs_uv + 2 * i, P->obs_sqrt_info ? P->obs_sqrt_info + 2 * i : one, res);
-    double rho[3]; loss_evaluate(O->loss_function_type, O->robust_loss_width, res[0] * res[0] + res[1] * res[1], rho);
+    double rho[3];
+    loss_evaluate(O->loss_function_type, depth_row ? O->robust_loss_width_depth_prior : O->robust_loss_width,
+                  res[0] * res[0] + res[1] * res[1], rho);
     o.fixed_cost += 0.5 * rho[0];
   }
   // camera priors: used when both the camera's bit and the option's bit are set; a prior on a constant
@@ -1014,6 +1029,7 @@ extern "C" {
 
 void oracle_ba_options_default(oba_options* o) {
   std::memset(o, 0, sizeof(*o));
+  o->robust_loss_width_depth_prior = 0.01;   // bundle_adjustment.h:94
   o->loss_function_type = 0; o->robust_loss_width = 2.0; o->intrinsics_to_optimize = 0;
   o->max_num_iterations = 100; o->use_homogeneous_point_parametrization = 1;
   o->use_inner_iterations = 1; o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10;

@@ -42,6 +42,7 @@ class BaProblem(C.Structure):
         ("cam_prior_mask", c_uint8_p), ("cam_position_prior", c_double_p), ("cam_position_prior_sqrt_info", c_double_p),
         ("cam_gravity_prior", c_double_p), ("cam_gravity_prior_sqrt_info", c_double_p),
         ("cam_orientation_prior", c_double_p), ("cam_orientation_prior_sqrt_info", c_double_p),
+        ("obs_kind", c_uint8_p),
     ]
 
 
@@ -56,6 +57,7 @@ class BaOptions(C.Structure):
         ("robust_loss_width", C.c_double), ("function_tolerance", C.c_double),
         ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
         ("max_trust_region_radius", C.c_double), ("max_solver_time_in_seconds", C.c_double),
+        ("robust_loss_width_depth_prior", C.c_double),
     ]
 
 
@@ -218,6 +220,24 @@ class FlatProblem:
         # camera priors (set_priors): mask [Nc], three (vector [Nc][3], sqrt information [Nc][3][3]) pairs
         self.cam_prior_mask = None
         self.priors = {}
+        # depth-prior rows (add_depth_priors): obs_kind [N] uint8 or None
+        self.obs_kind = None
+
+    def add_depth_priors(self, obs_index, depth, variance=1.0):
+        """One DepthPriorError row (depth_prior_error.h) per listed observation: a new observation row of kind
+        THEIA_OBS_DEPTH_PRIOR on the same camera and point, obs_uv = (depth, 0), sqrt_info = (1/sqrt(variance), 1)."""
+        idx = np.asarray(obs_index, dtype=np.int64).reshape(-1)
+        depth = np.broadcast_to(np.asarray(depth, dtype=np.float64), idx.shape)
+        var = np.broadcast_to(np.asarray(variance, dtype=np.float64), idx.shape)
+        n0 = self.obs_uv.shape[0]
+        kind = np.zeros(n0, np.uint8) if self.obs_kind is None else self.obs_kind
+        si = np.ones((n0, 2)) if self.obs_sqrt_info is None else self.obs_sqrt_info
+        self.obs_uv = np.ascontiguousarray(np.vstack([self.obs_uv, np.column_stack([depth, np.zeros(len(idx))])]))
+        self.obs_sqrt_info = np.ascontiguousarray(np.vstack([si, np.column_stack([1.0 / np.sqrt(var), np.ones(len(idx))])]))
+        self.obs_cam = np.ascontiguousarray(np.concatenate([self.obs_cam, self.obs_cam[idx]]).astype(np.int32))
+        self.obs_pt = np.ascontiguousarray(np.concatenate([self.obs_pt, self.obs_pt[idx]]).astype(np.int32))
+        self.obs_kind = np.ascontiguousarray(np.concatenate([kind, np.ones(len(idx), np.uint8)]))
+        return self
 
     def set_priors(self, mask, position=None, gravity=None, orientation=None):
         """Camera priors: mask[c] = THEIA_PRIOR_* bits; each kind = (vectors [Nc][3], sqrt_information [Nc][3][3])."""
@@ -237,6 +257,7 @@ class FlatProblem:
                         self.cam_const, self.group_const, self.point_const, self.obs_sqrt_info, self.flags)
         q.cam_prior_mask = self.cam_prior_mask
         q.priors = dict(self.priors)
+        q.obs_kind = self.obs_kind
         return q
 
     def as_struct(self):
@@ -258,6 +279,7 @@ class FlatProblem:
         p.obs_sqrt_info = ptr(self.obs_sqrt_info, C.c_double)
         p.obs_cam = ptr(self.obs_cam, C.c_int32)
         p.obs_pt = ptr(self.obs_pt, C.c_int32)
+        p.obs_kind = ptr(self.obs_kind, C.c_uint8)
         if self.cam_prior_mask is not None:
             p.cam_prior_mask = ptr(self.cam_prior_mask, C.c_uint8)
             for name in ("position", "gravity", "orientation"):

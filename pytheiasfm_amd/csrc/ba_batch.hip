@@ -645,6 +645,10 @@ int group_by_point(const theia_ba_problem* p, PointGrouped* G) {
   if (p->num_obs > 0 && (!p->cam_ext || !p->intrinsics || !p->group_model || !p->cam_group || !p->obs_uv || !p->obs_cam || !p->obs_pt))
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null array in problem");
   if (p->num_obs >= ((int64_t)1 << 31)) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "num_obs >= 2^31");
+  if (p->obs_kind)
+    for (int64_t i = 0; i < p->num_obs; ++i)
+      if (p->obs_kind[i] != THEIA_OBS_REPROJECTION)
+        return set_error(THEIA_HIP_ERR_UNSUPPORTED, "depth-prior rows are not built for the per-track / per-view batch entry points");
   for (int c = 0; c < p->num_cameras; ++c)
     if (p->cam_group[c] < 0 || p->cam_group[c] >= p->num_groups) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "cam_group[%d] out of range", c);
   for (int g = 0; g < p->num_groups; ++g)

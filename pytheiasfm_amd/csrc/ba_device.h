@@ -88,8 +88,22 @@ THIP_DEV void rotation_dq_dw(const double w[3], const double p[3], const RotTerm
 // validity boolean.  Derivatives are those of the branch taken.
 // WANT_KJAC additionally returns Jk (2 x THEIA_MAX_INTRINSICS, row-major): the
 // derivatives wrt the intrinsics block (zero beyond the model's K parameters).
+// Pseudo camera model of an observation row that is a depth prior (DepthPriorError, depth_prior_error.h):
+// "pixel" = (q_z, 0), so that the generic residual sqrt_info * (pixel - obs_uv) is
+// (sqrt_information * (rotated_point[2] - depth_prior), 0) with the matching Jacobian rows.
+constexpr int THIP_MODEL_DEPTH_ROW = 1000;
+
 template <bool WANT_JAC, bool WANT_KJAC = false>
 THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2], double Jq[6], double* Jk = nullptr) {
+  if (model == THIP_MODEL_DEPTH_ROW) {
+    uv[0] = q[2]; uv[1] = 0.0;
+    if (WANT_JAC) { Jq[0] = 0.0; Jq[1] = 0.0; Jq[2] = 1.0; Jq[3] = 0.0; Jq[4] = 0.0; Jq[5] = 0.0; }
+    if (WANT_KJAC) {
+#pragma unroll
+      for (int i = 0; i < 2 * THEIA_MAX_INTRINSICS; ++i) Jk[i] = 0.0;
+    }
+    return true;
+  }
   double dx = 0.0, dy = 0.0;                                  // distorted normalised point
   double ddx[3] = {0.0, 0.0, 0.0}, ddy[3] = {0.0, 0.0, 0.0};  // d(dx)/dq, d(dy)/dq
   // d(dx)/d(distortion parameter p), d(dy)/d(p) for p >= 5 (or 4 for the no-skew layouts)

@@ -104,7 +104,8 @@ THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam
 #pragma unroll
   for (int i = 0; i < 6; ++i) ext[i] = cam[6 * c + i];
   const int g = P.cam_group[c];
-  const int model = P.group_model[g];
+  const bool depth_row = P.obs_kind && P.obs_kind[o];
+  const int model = depth_row ? THIP_MODEL_DEPTH_ROW : P.group_model[g];
   const double* intr = P.intr + (size_t)g * THEIA_MAX_INTRINSICS;
   L.g = g;
   typename std::conditional<INTR, ObsLinK, ObsLin>::type ol;
@@ -112,7 +113,7 @@ THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam
   L.valid = ol.valid;
   const double s = ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1];
   double rho1;
-  const double rho = loss_eval(P.loss_type, P.loss_width, s, &rho1);
+  const double rho = loss_eval(P.loss_type, depth_row ? P.loss_width_depth : P.loss_width, s, &rho1);
   L.cost = 0.5 * rho;
   const double sr = sqrt(rho1);
   L.r[0] = sr * ol.r[0];
@@ -1168,10 +1169,11 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
     if (P.obs_si) { const double2 s = P.obs_si[start + lane]; six = s.x; siy = s.y; }
     ObsLin ol;
     const double* kc = (INTR ? P.intr_cand : P.intr) + (size_t)g * THEIA_MAX_INTRINSICS;
-    observe<false>(P.group_model[g], ext, kc, Xp, uv.x, uv.y, six, siy, ol);
+    const bool depth_row = P.obs_kind && P.obs_kind[start + lane];
+    observe<false>(depth_row ? THIP_MODEL_DEPTH_ROW : P.group_model[g], ext, kc, Xp, uv.x, uv.y, six, siy, ol);
     cvalid = ol.valid;
     double rho1;
-    ccost = 0.5 * loss_eval(P.loss_type, P.loss_width, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
+    ccost = 0.5 * loss_eval(P.loss_type, depth_row ? P.loss_width_depth : P.loss_width, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
   }
   ccost = wave_sum(ccost);
   mcc = wave_sum(mcc);
@@ -1418,9 +1420,10 @@ __global__ void k_long_back2(DevProblem P, LongView Lv, const double* __restrict
   double six = 1.0, siy = 1.0;
   if (P.obs_si) { const double2 s = P.obs_si[o]; six = s.x; siy = s.y; }
   ObsLin ol;
-  observe<false>(P.group_model[g], ext, P.intr + (size_t)g * THEIA_MAX_INTRINSICS, Xp, uv.x, uv.y, six, siy, ol);
+  const bool depth_row = P.obs_kind && P.obs_kind[o];
+  observe<false>(depth_row ? THIP_MODEL_DEPTH_ROW : P.group_model[g], ext, P.intr + (size_t)g * THEIA_MAX_INTRINSICS, Xp, uv.x, uv.y, six, siy, ol);
   double rho1;
-  const double cc = 0.5 * loss_eval(P.loss_type, P.loss_width, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
+  const double cc = 0.5 * loss_eval(P.loss_type, depth_row ? P.loss_width_depth : P.loss_width, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
   atomic_add(&scalB[0], cc); atomic_add(&scalB[1], mcc);
   if (!ol.valid) atomic_add(&scalB[4], 1.0);
 }

@@ -117,6 +117,7 @@ struct theia_ba_handle_s {
   DevBuf<int> group_model, cam_group, d_cam_red, obs_cam, obs_pt, tile_start, tile_count, f2s, fmaxflag;
   DevBuf<uint8_t> d_cam_mask, d_pt_const;
   DevBuf<double2> obs_uv, obs_si;
+  DevBuf<uint8_t> obs_kind;
   DevBuf<double> reduce, Vinv, gp, tile_part, scalB, chol_work;
   DevBuf<double> rec;                       // per-observation records of the gather-based Schur assembly
   DevBuf<int> diag_items, cam_obs, blk_items, slot_obs, slot_pt, blk_pair_pt;
@@ -393,6 +394,17 @@ int validate(const theia_ba_problem* p, const theia_ba_options* o) {
   if (o->intrinsics_to_optimize < 0 || o->intrinsics_to_optimize > THEIA_INTR_ALL)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "invalid intrinsics_to_optimize bit mask");
   if (o->prior_mask < 0 || o->prior_mask > 7) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "invalid prior_mask");
+  if (p->obs_kind) {
+    bool any = false;
+    for (int64_t i = 0; i < p->num_obs; ++i) {
+      if (p->obs_kind[i] > THEIA_OBS_DEPTH_PRIOR) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "obs_kind[%lld] is not a THEIA_OBS_* value", (long long)i);
+      any = any || p->obs_kind[i] == THEIA_OBS_DEPTH_PRIOR;
+    }
+    if (any && !p->obs_sqrt_info)
+      return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "depth-prior rows need obs_sqrt_info (1 / sqrt(depth_prior_variance))");
+    if (any && !(o->robust_loss_width_depth_prior > 0.0))
+      return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "robust_loss_width_depth_prior must be positive");
+  }
   if (o->loss_function_type < 0 || o->loss_function_type > THEIA_LOSS_TRUNCATED)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "invalid loss function type");  // reference: LOG(FATAL)
   return 0;
@@ -408,6 +420,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.scale_i = h->scale_i.p; P.scale_red = h->scale_red.p;
   P.cam_red = h->d_cam_red.p; P.cam_mask = h->d_cam_mask.p; P.pt_const = h->d_pt_const.p;
   P.obs_uv = h->obs_uv.p; P.obs_si = h->obs_si.p; P.obs_cam = h->obs_cam.p; P.obs_pt = h->obs_pt.p;
+  P.obs_kind = h->obs_kind.n ? h->obs_kind.p : nullptr; P.loss_width_depth = h->opt.robust_loss_width_depth_prior;
   P.tile_start = h->tile_start.p; P.tile_count = h->tile_count.p;
   P.scale_c = h->scale_c.p; P.scale_p = h->scale_p.p;
   P.long_nobs = h->long_nobs; P.long_ntracks = h->long_ntracks;
@@ -593,6 +606,7 @@ void theia_ba_options_default(theia_ba_options* o) {
   o->parameter_tolerance = 1e-8;
   o->max_trust_region_radius = 1e12;
   o->max_solver_time_in_seconds = 3600.0;
+  o->robust_loss_width_depth_prior = 0.01;   // bundle_adjustment.h:94
 }
 
 int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_handle* out) {
@@ -740,6 +754,11 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
 #define AL(buf, cnt) do { rc = h->buf.alloc(cnt); if (rc) return rc; } while (0)
   tick("structure, sort, tiles");
   UP(obs_uv, uv); UP(obs_si, si); UP(obs_cam, ocam); UP(obs_pt, opt);
+  if (p->obs_kind) {   // depth-prior rows (sorted like the other observation arrays)
+    std::vector<uint8_t> okind(h->nobs);
+    for (int64_t s = 0; s < h->nobs; ++s) okind[s] = p->obs_kind[h->perm[s]];
+    UP(obs_kind, okind);
+  }
   UP(tile_start, tstart); UP(tile_count, tcount);
   UP(long_obs_index, l_obs); UP(long_obs_slot, l_slot); UP(long_track_start, l_start); UP(long_track_pt, l_pt);
   AL(long_scratch, (size_t)14 * std::max(1, h->long_ntracks));
@@ -1150,11 +1169,13 @@ int theia_hip_ba_set_options(theia_ba_handle h, const theia_ba_options* o) {
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "structural options differ from the ones the handle was created with");
   if (o->loss_function_type < 0 || o->loss_function_type > THEIA_LOSS_TRUNCATED)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "invalid loss function type");
-  if (o->loss_function_type != h->opt.loss_function_type || o->robust_loss_width != h->opt.robust_loss_width)
+  if (o->loss_function_type != h->opt.loss_function_type || o->robust_loss_width != h->opt.robust_loss_width ||
+      o->robust_loss_width_depth_prior != h->opt.robust_loss_width_depth_prior)
     h->drop_graph();   // the loss is baked into the captured kernel arguments
   h->opt = *o;
   h->P.loss_type = o->loss_function_type;
   h->P.loss_width = o->robust_loss_width;
+  h->P.loss_width_depth = o->robust_loss_width_depth_prior;
   return 0;
 }
 

@@ -94,13 +94,14 @@ class BundleAdjustmentOptions:
         self.use_gravity_priors = False
 
     def to_c(self):
-        unsupported = [n for n in ("use_inverse_depth_parametrization", "use_depth_priors",
+        unsupported = [n for n in ("use_inverse_depth_parametrization",
                                    "optimize_for_forward_facing_trajectory") if getattr(self, n)]
         if unsupported:
             raise capi.TheiaHipError(-3, "options not built in the HIP backend yet: " + ", ".join(unsupported))
         o = _ba.default_options()
         o.loss_function_type = int(self.loss_function_type)
         o.robust_loss_width = float(self.robust_loss_width)
+        o.robust_loss_width_depth_prior = float(self.robust_loss_width_depth_prior)
         o.intrinsics_to_optimize = int(self.intrinsics_to_optimize)
         o.prior_mask = ((capi.THEIA_PRIOR_POSITION if self.use_position_priors else 0) |
                         (capi.THEIA_PRIOR_GRAVITY if self.use_gravity_priors else 0) |
@@ -151,6 +152,9 @@ class Reconstruction:
         self.obs_track = np.zeros(0, dtype=np.int32)
         self.obs_uv = np.zeros((0, 2))
         self.obs_cov = np.zeros((0, 2))  # diagonal of Feature::covariance_
+        # Feature::depth_prior_ / depth_prior_variance_ (feature.h:58-61); None = no feature carries a depth prior
+        self.obs_depth_prior = None
+        self.obs_depth_prior_variance = None
         # View::{Position,Gravity,Orientation}Prior (+ sqrt information), view.h; mask bits = capi.THEIA_PRIOR_*
         self.view_prior_mask = None
         self.view_priors = {}
@@ -189,7 +193,7 @@ class Reconstruction:
         return list(range(self.NumTracks()))
 
 
-def _flatten(recon, view_ids, track_ids, const_view_ids=()):
+def _flatten(recon, view_ids, track_ids, const_view_ids=(), options=None):
     """BundleAdjuster::AddView (:116-173) for `view_ids` (+ const views), then
     AddTrack (:175-221) for `track_ids`."""
     nv, nt = recon.NumViews(), recon.NumTracks()
@@ -228,6 +232,14 @@ def _flatten(recon, view_ids, track_ids, const_view_ids=()):
                             recon.view_group, recon.points.copy(), recon.obs_uv[keep], ov[keep], ot[keep],
                             cam_const=cam_const, group_const=group_const, point_const=point_const,
                             obs_sqrt_info=sqrt_info)
+    if options is not None and options.use_depth_priors and recon.obs_depth_prior is not None:
+        # AddView adds a DepthPriorError block for every feature of the view with depth_prior != 0
+        # (bundle_adjuster.cc:152-156); observations reached only through AddTrack get none (:175-221)
+        kept = np.flatnonzero(keep)
+        rows = np.flatnonzero(view_added[ov[kept]] & (recon.obs_depth_prior[kept] != 0.0))
+        if len(rows):
+            var = np.ones(len(rows)) if recon.obs_depth_prior_variance is None else recon.obs_depth_prior_variance[kept][rows]
+            flat.add_depth_priors(rows, recon.obs_depth_prior[kept][rows], var)
     if recon.view_prior_mask is not None:
         # priors are added for the views that went through AddView (bundle_adjuster.cc:159-172)
         mask = np.where(view_added, recon.view_prior_mask, 0).astype(np.uint8)
@@ -269,7 +281,7 @@ def _run(options, recon, flat):
 
 def BundleAdjustReconstruction(options, reconstruction):
     """bundle_adjustment.cc:188-217 (argument order of the pybind wrapper)."""
-    flat = _flatten(reconstruction, reconstruction.ViewIds(), reconstruction.TrackIds())
+    flat = _flatten(reconstruction, reconstruction.ViewIds(), reconstruction.TrackIds(), options=options)
     summary = _run(options, reconstruction, flat)
     _update_inverse_depth(reconstruction, reconstruction.TrackIds())
     return summary
@@ -277,7 +289,7 @@ def BundleAdjustReconstruction(options, reconstruction):
 
 def BundleAdjustPartialReconstruction(options, view_ids, track_ids, reconstruction):
     """bundle_adjustment.cc:111-143."""
-    flat = _flatten(reconstruction, view_ids, track_ids)
+    flat = _flatten(reconstruction, view_ids, track_ids, options=options)
     summary = _run(options, reconstruction, flat)
     # reference quirk (:134-135): the post-update list carries len(track_ids)
     # leading zeros, i.e. track 0 is also "updated" -- harmless, reproduced.
@@ -288,7 +300,7 @@ def BundleAdjustPartialReconstruction(options, view_ids, track_ids, reconstructi
 
 def BundleAdjustPartialViewsConstant(options, var_view_ids, const_view_ids, reconstruction):
     """bundle_adjustment.cc:146-185."""
-    flat = _flatten(reconstruction, var_view_ids, reconstruction.TrackIds(), const_view_ids=const_view_ids)
+    flat = _flatten(reconstruction, var_view_ids, reconstruction.TrackIds(), const_view_ids=const_view_ids, options=options)
     summary = _run(options, reconstruction, flat)
     _update_inverse_depth(reconstruction, reconstruction.TrackIds())
     return summary
@@ -296,7 +308,7 @@ def BundleAdjustPartialViewsConstant(options, var_view_ids, const_view_ids, reco
 
 def BundleAdjustViews(reconstruction, options, view_ids):
     """bundle_adjustment.cc:240-258 (wrapper argument order :14-17)."""
-    flat = _flatten(reconstruction, view_ids, [])
+    flat = _flatten(reconstruction, view_ids, [], options=options)
     return _run(options, reconstruction, flat)
 
 
@@ -307,7 +319,7 @@ def BundleAdjustView(reconstruction, options, view_id):
 
 def BundleAdjustTracks(reconstruction, options, track_ids):
     """bundle_adjustment.cc:389-418."""
-    flat = _flatten(reconstruction, [], track_ids)
+    flat = _flatten(reconstruction, [], track_ids, options=options)
     summary = _run(options, reconstruction, flat)
     _update_inverse_depth(reconstruction, track_ids)
     return summary
@@ -327,6 +339,8 @@ def BundleAdjustViewsIndependently(reconstruction, options, view_ids):
     """[BundleAdjustView(reconstruction, options, v) for v in view_ids] as one launch
     (theia_hip_ba_views_batch).  Returns the list of summaries."""
     r = reconstruction
+    if options.use_depth_priors and r.obs_depth_prior is not None and np.any(r.obs_depth_prior != 0.0):
+        raise capi.TheiaHipError(-3, "depth priors are not built for the batched single-view solves")
     view_ids = [int(v) for v in view_ids]
     for v in view_ids:
         if v < 0 or v >= r.NumViews():

@@ -100,7 +100,8 @@ def second_set():
     # BA variants
     out = {}
     base = synth.synth_ba_v1(10, 150, seed=0xBA5E0400, num_groups=3, mixed_models=True)
-    for name, kw in (("intr", dict(intrinsics_to_optimize=0x11)), ("priors", dict(prior_mask=7)), ("huber", dict(loss_function_type=1, robust_loss_width=1.5))):
+    for name, kw in (("intr", dict(intrinsics_to_optimize=0x11)), ("priors", dict(prior_mask=7)), ("huber", dict(loss_function_type=1, robust_loss_width=1.5)),
+                     ("depth", dict(loss_function_type=1, robust_loss_width_depth_prior=0.4))):
         p = base.copy()
         if name == "priors":
             nc = 10
@@ -114,6 +115,15 @@ def second_set():
             for key, (v, s_) in p.priors.items():
                 out[f"priors_{key}"] = v; out[f"priors_{key}_info"] = s_
             out["priors_mask"] = mask
+        if name == "depth":
+            # depth priors on every 4th observation: the depth at the start + a deterministic offset, variance 0.01
+            idx = np.arange(0, p.obs_uv.shape[0], 4)
+            R = synth.angle_axis_to_matrix(p.cam_ext[p.obs_cam[idx], 3:])
+            X = p.points[p.obs_pt[idx]]
+            q = np.einsum("nij,nj->ni", R, X[:, :3] - X[:, 3:] * p.cam_ext[p.obs_cam[idx], :3])
+            depth = q[:, 2] + 0.05 * np.sin(0.7 * idx)
+            p.add_depth_priors(idx, depth, 0.01)
+            out["depth_idx"] = idx; out["depth_value"] = depth
         if name == "huber":
             p.cam_const = np.array([3, 0, 1, 2, 0, 4, 0, 0, 0, 0], dtype=np.uint8)
             p.obs_uv = p.obs_uv.copy(); p.obs_uv[::11] += 30.0

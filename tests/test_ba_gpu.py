@@ -700,7 +700,8 @@ def test_golden_camera_model_vectors_on_gpu():
 
 
 @pytest.mark.parametrize("name,kw", [("intr", dict(intrinsics_to_optimize=0x11)), ("priors", dict(prior_mask=7)),
-                                     ("huber", dict(loss_function_type=1, robust_loss_width=1.5))])
+                                     ("huber", dict(loss_function_type=1, robust_loss_width=1.5)),
+                                     ("depth", dict(loss_function_type=1, robust_loss_width_depth_prior=0.4))])
 def test_golden_ba_variants_on_gpu(name, kw):
     from tests.test_oracle_ba import _variant_problem
     v = np.load(os.path.join(os.path.dirname(__file__), "golden", "ba_variants.npz"))
@@ -782,3 +783,59 @@ def test_estimate_tracks_follows_track_estimator_rules():
     est2, _ = ba.estimate_tracks(pg2, rays_k, o, 3.0, 5.0, False)
     sel = np.flatnonzero(pg2.obs_pt == 12)
     assert np.allclose(pg2.points[12, :3], _midpoint(pg2.cam_ext[pg2.obs_cam[sel], :3], rays_k[sel]), rtol=1e-12, atol=1e-12)
+
+
+def _with_depth_priors(p, cam_gt, pts_gt, every=3, variance=1e-4, noise=0.005, seed=0xDE97):
+    """Depth priors (noisy true depth) on every `every`-th observation."""
+    idx = np.arange(0, p.obs_uv.shape[0], every)
+    X = pts_gt[p.obs_pt[idx]]
+    R = synth.angle_axis_to_matrix(cam_gt[p.obs_cam[idx], 3:])
+    q = np.einsum("nij,nj->ni", R, X[:, :3] - X[:, 3:] * cam_gt[p.obs_cam[idx], :3])
+    st = synth.Stream(seed, 5)
+    return p.add_depth_priors(idx, q[:, 2] + noise * st.normal(np.arange(len(idx))), variance)
+
+
+@pytest.mark.parametrize("loss,intr", [(0, 0), (1, 0), (3, 0), (0, 9)])
+def test_depth_prior_rows_match_oracle(loss, intr):
+    """A12 depth priors (DepthPriorError as observation rows of kind 1, own loss width): cost, residual and
+    Jacobian rows, reduced system, LM trajectory and result vs the oracle; also with intrinsics optimised and
+    with a robust loss."""
+    p, cam_gt, pts_gt = synth.synth_ba_v1(14, 400, seed=0xDE91, return_truth=True)
+    n0 = p.obs_uv.shape[0]
+    _with_depth_priors(p, cam_gt, pts_gt)
+    o, oo = both_options(max_num_iterations=12, loss_function_type=loss, intrinsics_to_optimize=intr,
+                         robust_loss_width_depth_prior=0.5)
+    with ba.BaHandle(p.copy(), o) as h:
+        cost, r, jc, jp, valid = h.evaluate()
+        S, rhs = h.reduced_system(1e4)
+    ok, ocost, orr, ojc, ojp = ol.evaluate(p, oo)
+    assert abs(cost - ocost) <= 1e-12 * ocost
+    assert rel(r, orr) <= 1e-10 and rel(jc, ojc) <= 1e-9 and rel(jp, ojp) <= 1e-9
+    assert np.all(np.asarray(r).reshape(-1, 2)[n0:, 1] == 0.0) and np.abs(np.asarray(r).reshape(-1, 2)[n0:, 0]).max() > 0.1
+    So, ro = ol.reduced_system(p, oo, 1e4)
+    assert rel(S, So) <= 1e-9 and rel(rhs, ro) <= 1e-9
+    pg, po = p.copy(), p.copy()
+    s, tr = ba.solve(pg, o)
+    so, tro = ol.solve(po, oo)
+    assert s.success and s.num_iterations == so.num_iterations and np.array_equal(tr.accepted, tro.accepted)
+    assert rel(tr.cost, tro.cost) <= 1e-8 and abs(s.final_cost - so.final_cost) <= 1e-9 * so.final_cost
+    assert np.abs(pg.cam_ext - po.cam_ext).max() <= 1e-7 and np.abs(pg.points - po.points).max() <= 1e-6
+    # the rows matter: the same problem without them ends elsewhere
+    q = capi.FlatProblem(p.cam_ext.copy(), p.intrinsics.copy(), p.group_model, p.cam_group, p.points.copy(), p.obs_uv[:n0],
+                         p.obs_cam[:n0], p.obs_pt[:n0], cam_const=p.cam_const)
+    ba.solve(q, o)
+    assert np.abs(q.points - pg.points).max() > 1e-6
+
+
+def test_depth_prior_rows_are_validated():
+    p, cam_gt, pts_gt = synth.synth_ba_v1(6, 50, seed=0xDE92, return_truth=True)
+    _with_depth_priors(p, cam_gt, pts_gt)
+    o = ba.default_options()
+    bad = p.copy(); bad.obs_kind = bad.obs_kind.copy(); bad.obs_kind[0] = 2
+    with pytest.raises(capi.TheiaHipError, match="THEIA_OBS"):
+        ba.solve(bad, o)
+    bad = p.copy(); bad.obs_sqrt_info = None
+    with pytest.raises(capi.TheiaHipError, match="obs_sqrt_info"):
+        ba.solve(bad, o)
+    with pytest.raises(capi.TheiaHipError, match="depth-prior rows"):
+        ba.solve_tracks_batch(p.copy(), o)

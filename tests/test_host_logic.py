@@ -64,9 +64,33 @@ def test_options_mirror_defaults_and_unsupported():
     assert o.intrinsics_to_optimize == sfm.OptimizeIntrinsicsType.NONE and o.use_homogeneous_point_parametrization
     o.use_position_priors = True; o.use_orientation_priors = True
     assert o.to_c().prior_mask == (capi.THEIA_PRIOR_POSITION | capi.THEIA_PRIOR_ORIENTATION)
-    o.use_depth_priors = True                      # depth priors / inverse depth: not built -> explicit error
+    o.use_depth_priors = True; o.robust_loss_width_depth_prior = 0.25
+    assert o.to_c().robust_loss_width_depth_prior == 0.25   # depth priors travel as observation rows (see _flatten)
+    o.use_inverse_depth_parametrization = True     # inverse depth: not built -> explicit error
     with pytest.raises(capi.TheiaHipError):
         o.to_c()
+
+
+def test_flatten_emits_depth_prior_rows_for_added_views_only():
+    """bundle_adjuster.cc:152-156: a DepthPriorError per feature with depth_prior != 0 of the views that went
+    through AddView, when use_depth_priors is set; none for observations reached through AddTrack."""
+    p = synth.synth_ba_v1(5, 30, seed=0xF1A7)
+    rec = sfm.Reconstruction.from_flat(p)
+    n = len(rec.obs_view)
+    rec.obs_depth_prior = np.where(np.arange(n) % 2 == 0, 4.0 + 0.01 * np.arange(n), 0.0)
+    rec.obs_depth_prior_variance = np.full(n, 0.04)
+    o = sfm.BundleAdjustmentOptions(); o.use_depth_priors = True
+    flat = sfm._flatten(rec, rec.ViewIds(), rec.TrackIds(), options=o)
+    extra = flat.obs_uv.shape[0] - n
+    assert extra == (rec.obs_depth_prior != 0).sum() and flat.obs_kind[n:].all() and not flat.obs_kind[:n].any()
+    assert np.array_equal(flat.obs_uv[n:, 0], rec.obs_depth_prior[rec.obs_depth_prior != 0])
+    assert np.allclose(flat.obs_sqrt_info[n:, 0], 5.0) and np.array_equal(flat.obs_cam[n:], rec.obs_view[rec.obs_depth_prior != 0])
+    # only view 2 goes through AddView: its features carry priors, the others (reached via AddTrack) do not
+    flat = sfm._flatten(rec, [2], rec.TrackIds(), options=o)
+    k = flat.obs_uv.shape[0] - n
+    assert k == ((rec.obs_depth_prior != 0) & (rec.obs_view == 2)).sum() and np.all(flat.obs_cam[n:] == 2)
+    o.use_depth_priors = False
+    assert sfm._flatten(rec, rec.ViewIds(), rec.TrackIds(), options=o).obs_kind is None
 
 
 def test_shard_tracks_partitions_every_track_once():

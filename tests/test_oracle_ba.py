@@ -288,7 +288,8 @@ def test_golden_camera_models_and_ba_variants():
     v = np.load(os.path.join(os.path.dirname(__file__), "golden", "ba_variants.npz"))
     base = capi.FlatProblem(v["base_cam_ext"], v["base_intrinsics"], v["base_group_model"], v["base_cam_group"], v["base_points"],
                             v["base_obs_uv"], v["base_obs_cam"], v["base_obs_pt"])
-    for name, kw in (("intr", dict(intrinsics_to_optimize=0x11)), ("priors", dict(prior_mask=7)), ("huber", dict(loss_function_type=1, robust_loss_width=1.5))):
+    for name, kw in (("intr", dict(intrinsics_to_optimize=0x11)), ("priors", dict(prior_mask=7)), ("huber", dict(loss_function_type=1, robust_loss_width=1.5)),
+                     ("depth", dict(loss_function_type=1, robust_loss_width_depth_prior=0.4))):
         p = _variant_problem(v, base, name)
         o = ol.default_options()
         for kk, vv in kw.items():
@@ -306,4 +307,53 @@ def _variant_problem(v, base, name):
         p.set_priors(v["priors_mask"], **{k: (v[f"priors_{k}"], v[f"priors_{k}_info"]) for k in ("position", "gravity", "orientation")})
     if name == "huber":
         p.cam_const = np.ascontiguousarray(v["huber_cam_const"]); p.obs_uv = np.ascontiguousarray(v["huber_obs_uv"])
+    if name == "depth":
+        p.add_depth_priors(v["depth_idx"], v["depth_value"], 0.01)
     return p
+
+
+def test_depth_prior_rows_residual_jacobian_and_solve():
+    """A12, DepthPriorError (depth_prior_error.h) as observation rows of kind 1: residual
+    sqrt_info * ((R (X - w C))_z - depth), zero second row, Jet Jacobians vs central differences, its own loss
+    width, and a solve in which the priors pull the depths of noisy points."""
+    p, cam_gt, pts_gt = synth.synth_ba_v1(6, 40, seed=0xDEB7, return_truth=True)
+    truth = {"cam_ext": cam_gt, "points": pts_gt}
+    # true depths of the first 60 observations, variance 1e-4
+    idx = np.arange(60)
+    Xt = truth["points"][p.obs_pt[idx]]
+    R = synth.angle_axis_to_matrix(truth["cam_ext"][p.obs_cam[idx], 3:])
+    q = np.einsum("nij,nj->ni", R, Xt[:, :3] - Xt[:, 3:] * truth["cam_ext"][p.obs_cam[idx], :3])
+    n0 = p.obs_uv.shape[0]
+    pd = p.copy().add_depth_priors(idx, q[:, 2], 1e-4)
+    assert pd.obs_uv.shape[0] == n0 + 60 and pd.obs_kind[n0:].all() and not pd.obs_kind[:n0].any()
+    o = ol.default_options(); o.max_num_iterations = 0
+    ok, cost, r, Jc, Jp, Ji = ol.evaluate_ex(pd, o)
+    r = r.reshape(-1, 2)
+    # residual rows of the priors at the (perturbed) start
+    Rs = synth.angle_axis_to_matrix(pd.cam_ext[pd.obs_cam[n0:], 3:])
+    Xs = pd.points[pd.obs_pt[n0:]]
+    qs = np.einsum("nij,nj->ni", Rs, Xs[:, :3] - Xs[:, 3:] * pd.cam_ext[pd.obs_cam[n0:], :3])
+    assert np.allclose(r[n0:, 0], 100.0 * (qs[:, 2] - q[:, 2]), rtol=1e-12, atol=1e-12) and np.all(r[n0:, 1] == 0)
+    # Jacobian of one prior row wrt the camera by central differences
+    k = n0 + 7
+    c = pd.obs_cam[k]
+    Jc = Jc.reshape(-1, 2, 6)
+    for a in range(6):
+        h = 1e-6
+        pp, pm = pd.copy(), pd.copy()
+        pp.cam_ext[c, a] += h; pm.cam_ext[c, a] -= h
+        rp = ol.evaluate_ex(pp, o)[2].reshape(-1, 2)[k, 0]; rm = ol.evaluate_ex(pm, o)[2].reshape(-1, 2)[k, 0]
+        assert abs((rp - rm) / (2 * h) - Jc[k, 0, a]) <= 1e-5 * max(1.0, abs(Jc[k, 0, a]))
+        assert Jc[k, 1, a] == 0.0
+    # the loss on the prior rows uses robust_loss_width_depth_prior
+    o1 = ol.default_options(); o1.loss_function_type = 1; o1.max_num_iterations = 0
+    o2 = ol.default_options(); o2.loss_function_type = 1; o2.max_num_iterations = 0; o2.robust_loss_width_depth_prior = 10.0
+    assert ol.evaluate_ex(pd, o1)[1] < ol.evaluate_ex(pd, o2)[1]
+    # solve: with the priors the depth residuals shrink
+    os_ = ol.default_options(); os_.max_num_iterations = 10
+    s, _ = ol.solve(pd, os_)
+    assert s.success and s.final_cost < s.initial_cost
+    Rf = synth.angle_axis_to_matrix(pd.cam_ext[pd.obs_cam[n0:], 3:])
+    Xf = pd.points[pd.obs_pt[n0:]]
+    qf = np.einsum("nij,nj->ni", Rf, Xf[:, :3] - Xf[:, 3:] * pd.cam_ext[pd.obs_cam[n0:], :3])
+    assert np.abs(qf[:, 2] - q[:, 2]).mean() < 0.2 * np.abs(qs[:, 2] - q[:, 2]).mean()
