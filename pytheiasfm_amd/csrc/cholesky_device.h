@@ -248,5 +248,157 @@ __device__ __forceinline__ void potrf64_wave(double* __restrict__ A, int lda, in
 #undef PSUB0
 }
 
+
+// The same factorisation + inverse by a 256-thread workgroup (4 waves).  The in-panel sweep is inherently
+// one wave's work (wave 0); everything else is spread over the four waves: the tile load and the stores
+// (16 rows per wave), the trailing 16 x 16 MFMA updates of a panel (6, 3, 1 tiles: one tile per wave and
+// round), the two 32-level inverse products (one per wave) and the four 16 x 16 tiles of each 64-level
+// product.  Same arithmetic per entry as potrf64_wave (the MFMA tiles are the same tiles), so the two
+// functions return identical bits.
+__device__ __forceinline__ void potrf64_wg(double* __restrict__ A, int lda, int k0, int nb,
+                                           double* __restrict__ Linv, double* __restrict__ fail_flag) {
+  __shared__ double Ls[NB][LDP];
+  __shared__ double Zs[NB][LDP];
+  __shared__ double rdiag[NB];
+  const int tid = threadIdx.x, wv = tid >> 6, i = tid & 63;
+  const int li = i & 15, lk = i >> 4;
+  {
+    // wave w loads rows 16w .. 16w+15 (unconditional clamped loads, all in flight)
+    const int ic = min(i, nb - 1);
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = A[(size_t)(k0 + min(16 * wv + q, nb - 1)) * lda + k0 + ic];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int r = 16 * wv + q;
+      Ls[r][i] = (r < nb && i <= r) ? v[q] : ((r == i) ? 1.0 : 0.0);
+      Zs[r][i] = 0.0;
+    }
+  }
+  __syncthreads();
+  int bad = 0;
+  for (int p = 0; p < 4; ++p) {
+    const int c0 = 16 * p;
+    if (wv == 0) {
+      double r16[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) r16[j] = Ls[i][c0 + j];
+      double rs[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        double d = readlane_d(r16[j], c0 + j);
+        if (!(d > 0.0)) { bad = 1; d = 1.0; }
+        double w = __builtin_amdgcn_rcp(d);
+        w = __builtin_fma(w, __builtin_fma(-d, w, 1.0), w);
+        w = __builtin_fma(w, __builtin_fma(-d, w, 1.0), w);
+        const double t = r16[j] * w;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) r16[k] = __builtin_fma(-t, readlane_d(r16[j], c0 + k), r16[k]);
+        rs[j] = d;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const double d = rs[j];
+        double rinv = __builtin_amdgcn_rsq(d);
+        rinv = rinv * (1.5 - (0.5 * d) * (rinv * rinv));
+        rinv = rinv * (1.5 - (0.5 * d) * (rinv * rinv));
+        rs[j] = rinv;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (i == 0) rdiag[c0 + j] = rs[j];
+        r16[j] = (i >= c0 + j) ? r16[j] * rs[j] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) Ls[i][c0 + j] = r16[j];
+    }
+    __syncthreads();
+    // trailing tiles (ti >= tj > p), one per wave and round:  C -= L[ti][p] L[tj][p]^T
+    {
+      int t = 0;
+      for (int ti = p + 1; ti < 4; ++ti)
+        for (int tj = p + 1; tj <= ti; ++tj, ++t) {
+          if ((t & 3) != wv) continue;
+          double4_t c;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) c[reg] = Ls[16 * ti + lk + 4 * reg][16 * tj + li];
+          c = wave_gemm16([&](int r, int k) { return -Ls[16 * ti + r][c0 + k]; },
+                          [&](int k, int cc) { return Ls[16 * tj + cc][c0 + k]; }, c, i);
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) Ls[16 * ti + lk + 4 * reg][16 * tj + li] = c[reg];
+        }
+    }
+    __syncthreads();
+  }
+  // L back to global: wave w stores rows 16w .. 16w+15 (whole rows, see potrf64_wave)
+  if (i < nb) {
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = Ls[16 * wv + q][i];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (16 * wv + q < nb) A[(size_t)(k0 + 16 * wv + q) * lda + k0 + i] = v[q];
+  }
+  if (bad && tid == 0) unsafeAtomicAdd(fail_flag, 1.0);
+  // ---- inverse: the four 16 x 16 triangular inverses (wave 0, lane (q, c) owns column c of block q)
+  if (wv == 0) {
+    const int q = i >> 4, c = i & 15;
+    double z[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double s0 = (r == c) ? 1.0 : 0.0, s1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < r; ++k) {
+        const double t = Ls[16 * q + r][16 * q + k] * z[k];
+        if (k & 1) s1 -= t; else s0 -= t;
+      }
+      z[r] = (s0 + s1) * rdiag[16 * q + r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Zs[16 * q + r][16 * q + c] = z[r];
+  }
+  __syncthreads();
+  // ---- 32-level (waves 0 and 1, one diagonal pair each): Z[q1][q0] = -Z[q1][q1] (L[q1][q0] Z[q0][q0])
+  if (wv < 2) {
+    const int q0 = 2 * wv, q1 = 2 * wv + 1;
+    double4_t t = (double4_t){0.0, 0.0, 0.0, 0.0};
+    t = wave_gemm16([&](int r, int k) { return Ls[16 * q1 + r][16 * q0 + k]; },
+                    [&](int k, int cc) { return Zs[16 * q0 + k][16 * q0 + cc]; }, t, i);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) Ls[16 * q0 + lk + 4 * reg][16 * q1 + li] = t[reg];
+  }
+  __syncthreads();
+  if (wv < 2) {
+    const int q0 = 2 * wv, q1 = 2 * wv + 1;
+    double4_t t = (double4_t){0.0, 0.0, 0.0, 0.0};
+    t = wave_gemm16([&](int r, int k) { return Zs[16 * q1 + r][16 * q1 + k]; },
+                    [&](int k, int cc) { return Ls[16 * q0 + k][16 * q1 + cc]; }, t, i);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) Zs[16 * q1 + lk + 4 * reg][16 * q0 + li] = -t[reg];
+  }
+  __syncthreads();
+  // ---- 64-level: Z21 = -Z22 (L21 Z11); wave w owns the 16 x 16 tile (ti, tj) = (w >> 1, w & 1) of both products
+  {
+    const int ti = wv >> 1, tj = wv & 1;
+    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 4)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[32 + 16 * ti + li][kk + lk], Zs[kk + lk][16 * tj + li], acc, 0, 0, 0);
+    __syncthreads();   // every wave has read its L21 rows / Z11 columns before T overwrites Ls[0..31][32..63]
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) Ls[16 * ti + lk + 4 * reg][32 + 16 * tj + li] = acc[reg];
+    __syncthreads();
+    acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 4)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Zs[32 + 16 * ti + li][32 + kk + lk], Ls[kk + lk][32 + 16 * tj + li], acc, 0, 0, 0);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) Zs[32 + 16 * ti + lk + 4 * reg][16 * tj + li] = -acc[reg];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) Linv[(16 * wv + q) * NB + i] = Zs[16 * wv + q][i];
+}
+
 }  // namespace chol
 }  // namespace thip

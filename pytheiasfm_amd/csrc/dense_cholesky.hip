@@ -27,9 +27,9 @@ namespace {
 
 using namespace chol;
 
-__global__ __launch_bounds__(64) void k_potrf(double* __restrict__ A, int lda, int k0, int nb,
-                                              double* __restrict__ Linv, double* __restrict__ fail_flag) {
-  potrf64_wave(A, lda, k0, nb, Linv, fail_flag);
+__global__ __launch_bounds__(256) void k_potrf(double* __restrict__ A, int lda, int k0, int nb,
+                                               double* __restrict__ Linv, double* __restrict__ fail_flag) {
+  potrf64_wg(A, lda, k0, nb, Linv, fail_flag);
 }
 
 // A21 <- A21 * L11^-T for rows [k0 + nb, nrows): X[r][j] = sum_i P[r][i] Z[j][i].
@@ -195,7 +195,7 @@ void dense_cholesky_solve(int n, double* A, int lda, double* b, double* work, do
     const int nb = (n - k0 < NB) ? (n - k0) : NB;
     const int below = nrows - (k0 + nb);
     double* Zk = Linv + (size_t)kb * NB * NB;
-    k_potrf<<<1, 64, 0, st>>>(A, lda, k0, nb, Zk, fail_flag);
+    k_potrf<<<1, 256, 0, st>>>(A, lda, k0, nb, Zk, fail_flag);
     if (below > 0) {
       k_trsm<<<(below + 127) / 128, 256, 0, st>>>(A, lda, nrows, k0, nb, Zk);
       const int tiles = (below + 63) / 64;

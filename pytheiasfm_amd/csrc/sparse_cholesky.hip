@@ -35,10 +35,10 @@ using namespace chol;
 // back  : {k0, nb, slot, sbeg, send}             sources: {row0, h}
 // symm  : {r0, h, c0, w}   dst tile (r0, c0) <- transpose of tile (c0, r0)
 
-__global__ __launch_bounds__(64) void k_sp_potrf(double* __restrict__ A, int lda, const int* __restrict__ items,
-                                                 double* __restrict__ Linv, double* __restrict__ fail_flag) {
+__global__ __launch_bounds__(256) void k_sp_potrf(double* __restrict__ A, int lda, const int* __restrict__ items,
+                                                  double* __restrict__ Linv, double* __restrict__ fail_flag) {
   const int* it = items + 3 * blockIdx.x;
-  potrf64_wave(A, lda, it[0], it[1], Linv + (size_t)it[2] * NB * NB, fail_flag);
+  potrf64_wg(A, lda, it[0], it[1], Linv + (size_t)it[2] * NB * NB, fail_flag);
 }
 
 // stage a 64 x 64 tile (h valid rows, w valid columns, zero padded) in LDS; 16
@@ -402,7 +402,7 @@ void chol_plan_solve(const CholPlan* pl, double* A, int lda, double* b, double* 
   const int* pg = pl->prog;
   if (pl->nsymm) k_sp_symm<<<pl->nsymm, 256, 0, st>>>(A, lda, pg + pl->symm_off);
   for (const Level& lv : pl->lev) {
-    k_sp_potrf<<<lv.npotrf, 64, 0, st>>>(A, lda, pg + lv.potrf_off, Linv, fail_flag);
+    k_sp_potrf<<<lv.npotrf, 256, 0, st>>>(A, lda, pg + lv.potrf_off, Linv, fail_flag);
     if (lv.ntrsm) k_sp_trsm<<<lv.ntrsm, 256, 0, st>>>(A, lda, pg + lv.trsm_off, Linv);
     if (lv.nupd) k_sp_update<<<lv.nupd, 256, 0, st>>>(A, lda, pg + lv.upd_off, pg + lv.upd_src_off);
   }
