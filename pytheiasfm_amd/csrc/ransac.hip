@@ -27,6 +27,9 @@
 
 #include "ransac_device.h"
 #include "theia_hip.h"
+#include <atomic>
+#include <thread>
+
 #include "theia_hip_internal.h"
 
 namespace thip {
@@ -526,6 +529,25 @@ struct Mt19937 {
 };
 
 // sample_consensus_estimator.h:252-297
+// Host-side loops over independent problems (sample streams, acceptance replay) on a few threads.
+// THEIA_HIP_HOST_THREADS caps the count (default min(hardware threads, 16); 1 = serial).
+template <class F>
+void host_parallel_for(int n, F&& fn) {
+  static const unsigned cap = [] {
+    const char* e = getenv("THEIA_HIP_HOST_THREADS");
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return e ? (unsigned)std::max(1, atoi(e)) : std::min(hw, 16u);
+  }();
+  const unsigned nt = std::min<unsigned>(cap, (unsigned)std::max(1, n / 4));
+  if (nt < 2) { for (int i = 0; i < n; ++i) fn(i); return; }
+  std::atomic<int> next{0};
+  std::vector<std::thread> th;
+  th.reserve(nt);
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&] { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); });
+  for (auto& t : th) t.join();
+}
+
 int compute_max_iterations(const theia_ransac_params& P, double min_sample_size, double inlier_ratio,
                            double log_failure_prob, int total) {
   if (inlier_ratio == 1.0) return P.min_iterations;
@@ -819,7 +841,8 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       first = false;
       // the sample stream of the round (RandomSampler::Sample, persistent permutation)
       h_samples.assign((size_t)cn * B * m, 0);
-      for (int q = 0; q < cn; ++q) {
+      // problems are independent (own generator, own slice): host threads share them out
+      host_parallel_for(cn, [&](int q) {
         ProblemState& s = S[c0 + q];
         int* out = h_samples.data() + (size_t)q * B * m;
         for (int b = 0; b < s.round_iters; ++b) {
@@ -837,7 +860,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
             out[(size_t)b * m + i] = s.idx[i];
           }
         }
-      }
+      });
       const size_t nh = (size_t)cn * B;
       if ((rc = d_samples.ensure(nh * m)) || (rc = d_counts.ensure(nh)) || (rc = d_models.ensure(nh * kMaxModels * kStride)) ||
           (rc = d_cost.ensure(nh * kMaxModels)) || (rc = d_ninl.ensure(nh * kMaxModels)) || (rc = d_active.ensure(cn)) ||
@@ -891,22 +914,25 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       }
       std::vector<LoEvent> events;
       std::vector<int> ev_q, ev_ok;
+      std::atomic<long long> n_hyp{0}, n_scored{0};
       while (true) {
         events.clear(); ev_q.clear();
-        for (int q = 0; q < cn; ++q) {
+        // without LO nothing is shared between the problems' replays (the counters are atomics): host threads
+        auto replay_one = [&](int q) {
           ProblemState& s = S[c0 + q];
-          if (s.round_done) continue;
+          if (s.round_done) return;
+          long long my_hyp = 0, my_scored = 0;
           bool paused = false;
           // (a hypothesis interrupted by an LO event is finished even if max_iterations dropped meanwhile)
           while (!paused && s.rb < s.round_iters && (s.rj > 0 || s.base_it + s.rb < s.max_iterations)) {
             const size_t hyp = (size_t)q * B + s.rb;
             const int nm = h_counts[hyp];
-            if (s.rj == 0) result->hypotheses_evaluated++;
+            if (s.rj == 0) my_hyp++;
             while (s.rj < nm) {
               const int j = s.rj++;
               const double cost = h_cost[hyp * kMaxModels + j];
               const int ninl = h_ninl[hyp * kMaxModels + j];
-              result->models_scored++;
+              my_scored++;
               const double inlier_ratio = (double)ninl / (double)s.n;
               if (cost < s.best_cost) {
                 s.best_cost = cost;
@@ -932,7 +958,10 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
             s.it = s.base_it + s.rb;
             if (s.it >= s.max_iterations) s.done = true;
           }
-        }
+          n_hyp += my_hyp; n_scored += my_scored;
+        };
+        if (P.use_lo) { for (int q = 0; q < cn; ++q) replay_one(q); }   // LO events are collected in problem order
+        else host_parallel_for(cn, replay_one);
         if (events.empty()) break;
         if ((rc = run_lo(events, ev_ok))) return rc;
         for (size_t e = 0; e < events.size(); ++e) {
@@ -945,6 +974,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
           s.max_iterations = std::min(compute_max_iterations(P, m, s.pending_ratio, log_failure_prob, s.n), s.max_iterations);
         }
       }
+      result->hypotheses_evaluated += n_hyp.load(); result->models_scored += n_scored.load();
     }
   }
   // final models + inlier masks
