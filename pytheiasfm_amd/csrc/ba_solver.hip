@@ -609,6 +609,267 @@ void theia_ba_options_default(theia_ba_options* o) {
   o->robust_loss_width_depth_prior = 0.01;   // bundle_adjustment.h:94
 }
 
+#define UP(buf, vec) do { rc = h->buf.upload(vec, st); if (rc) return rc; } while (0)
+#define AL(buf, cnt) do { rc = h->buf.alloc(cnt); if (rc) return rc; } while (0)
+// Static gather lists of the Schur assembly without intrinsics (k_lin_obs / k_schur); see create().
+int build_gather_lists(theia_ba_handle_s* h, const std::vector<int>& ocam, const std::vector<int>& opt,
+                       const std::vector<int>& l_obs) {
+  int rc = 0;
+  hipStream_t st = h->stream;
+  // Static gather lists of the Schur assembly (k_schur_diag / k_schur_blocks):
+  // per reduced camera its observations, per camera pair (ri > rj) the
+  // (observation of ri, observation of rj) pairs of their common variable
+  // tracks.  Tracks of the slow path (> 64 observations) assemble themselves.
+  const int64_t nm = h->nobs_main;
+  std::vector<char> is_long(nm, 0);
+  for (int s2 : l_obs) is_long[s2] = 1;
+  std::vector<int> red(nm);
+  for (int64_t s = 0; s < nm; ++s) red[s] = is_long[s] ? -1 : h->cam_red[ocam[s]];
+  constexpr int kChunk = 2048;
+  std::vector<int> dbeg(h->ncv + 1, 0);
+  for (int64_t s = 0; s < nm; ++s) if (red[s] >= 0) dbeg[red[s] + 1]++;
+  for (int c = 0; c < h->ncv; ++c) dbeg[c + 1] += dbeg[c];
+  // records are stored camera-major: slot of observation s = its rank in its camera's list
+  std::vector<int> cam_obs(nm, -1);   // = rec_slot
+  {
+    std::vector<int> f(dbeg.begin(), dbeg.end() - 1);
+    for (int64_t s = 0; s < nm; ++s) if (red[s] >= 0) cam_obs[s] = f[red[s]]++;
+  }
+  std::vector<int> ditems;
+  for (int c = 0; c < h->ncv; ++c) {
+    const int nchunk = (dbeg[c + 1] - dbeg[c] + kChunk - 1) / kChunk;
+    for (int k = 0; k < nchunk; ++k) {
+      ditems.push_back(c); ditems.push_back(dbeg[c] + k * kChunk);
+      ditems.push_back(std::min(dbeg[c + 1], dbeg[c] + (k + 1) * kChunk)); ditems.push_back(nchunk > 1 ? 1 : 0);
+    }
+  }
+  // pairs, bucketed by row camera then sorted by column camera
+  std::vector<int64_t> rbeg(h->ncv + 1, 0);
+  auto for_each_pair = [&](auto&& fn) {
+    for (int64_t s0 = 0; s0 < nm;) {
+      int64_t s1 = s0 + 1;
+      while (s1 < nm && opt[s1] == opt[s0]) ++s1;
+      if (!is_long[s0] && !h->pt_const[opt[s0]])
+        for (int64_t a = s0; a < s1; ++a) {
+          if (red[a] < 0) continue;
+          for (int64_t b = s0; b < s1; ++b)
+            if (red[b] >= 0 && (red[a] > red[b] || (red[a] == red[b] && a != b))) fn((int)a, (int)b);
+        }
+      s0 = s1;
+    }
+  };
+  for_each_pair([&](int a, int) { rbeg[red[a] + 1]++; });
+  for (int c = 0; c < h->ncv; ++c) rbeg[c + 1] += rbeg[c];
+  if (rbeg[h->ncv] > (int64_t)std::numeric_limits<int>::max() - 64)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "too many camera pairs for 32-bit pair lists");
+  std::vector<int2> pairs(rbeg[h->ncv]);
+  {
+    std::vector<int64_t> f(rbeg.begin(), rbeg.end() - 1);
+    for_each_pair([&](int a, int b) { pairs[f[red[a]]++] = make_int2(a, b); });
+  }
+  std::vector<int> bitems;
+  // each row is ordered by (column camera, a, b).  The pairs of a row were generated in ascending (a, b)
+  // (tracks are contiguous and visited in order), so a STABLE counting sort on the column camera is enough.
+  {
+    std::vector<int64_t> cnt(h->ncv + 1);
+    std::vector<int2> tmp;
+    for (int c = 0; c < h->ncv; ++c) {
+      const int64_t b0 = rbeg[c], b1 = rbeg[c + 1];
+      if (b1 - b0 < 2) continue;
+      std::fill(cnt.begin(), cnt.end(), 0);
+      for (int64_t q = b0; q < b1; ++q) cnt[red[pairs[q].y] + 1]++;
+      for (int k = 0; k < h->ncv; ++k) cnt[k + 1] += cnt[k];
+      tmp.assign(pairs.begin() + b0, pairs.begin() + b1);
+      for (const int2& pr : tmp) pairs[b0 + cnt[red[pr.y]]++] = pr;
+    }
+  }
+  for (int c = 0; c < h->ncv; ++c) {
+    for (int64_t q = rbeg[c]; q < rbeg[c + 1];) {
+      int64_t e = q + 1;
+      const int rj = red[pairs[q].y];
+      while (e < rbeg[c + 1] && red[pairs[e].y] == rj) ++e;
+      const int nchunk = (int)((e - q + kChunk - 1) / kChunk);
+      for (int k = 0; k < nchunk; ++k) {
+        bitems.push_back(c); bitems.push_back(rj); bitems.push_back((int)(q + (int64_t)k * kChunk));
+        bitems.push_back((int)std::min<int64_t>(e, q + (int64_t)(k + 1) * kChunk));
+        bitems.push_back((nchunk > 1 || rj == c) ? 1 : 0);
+      }
+      q = e;
+    }
+  }
+  // a camera that sees a track twice also has a (c, c) pair list: both kinds of items then ADD
+  // into the diagonal block (they run in one launch, unordered)
+  {
+    std::vector<char> self(h->ncv, 0);
+    for (size_t k = 0; k + 4 < bitems.size() + 1; k += 5) if (bitems[k] == bitems[k + 1]) self[bitems[k]] = 1;
+    for (size_t k = 0; k + 3 < ditems.size() + 1; k += 4) if (self[ditems[k]]) ditems[k + 3] = 1;
+  }
+  // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch order, a speed matter only).  All items whose
+  // ROW camera is c are placed on XCD c % 8, so that camera's records are fetched into one L2 and re-used by its
+  // block items and its diagonal item instead of being pulled into all eight.
+  if (!getenv("THEIA_HIP_NO_XCD_ORDER")) {
+    auto reorder = [&](std::vector<int>& items, int stride, int first_wg) {
+      const int n = (int)items.size() / stride;
+      std::vector<std::vector<int>> bucket(8);
+      for (int k = 0; k < n; ++k) bucket[items[(size_t)k * stride] & 7].push_back(k);
+      std::vector<size_t> head(8, 0);
+      std::vector<int> out;
+      out.reserve(items.size());
+      for (int pos = 0; pos < n; ++pos) {
+        int x = (first_wg + pos) & 7;
+        if (head[x] >= bucket[x].size()) {   // that XCD's list is exhausted: take from the fullest one
+          size_t best = 0;
+          for (int y = 0; y < 8; ++y) { const size_t left = bucket[y].size() - head[y]; if (left > best) { best = left; x = y; } }
+        }
+        const int k = bucket[x][head[x]++];
+        out.insert(out.end(), items.begin() + (size_t)k * stride, items.begin() + (size_t)(k + 1) * stride);
+      }
+      items.swap(out);
+    };
+    reorder(bitems, 5, 0);
+    reorder(ditems, 4, (int)bitems.size() / 5);
+  }
+  h->n_diag_items = (int)ditems.size() / 4; h->n_blk_items = (int)bitems.size() / 5;
+  {
+    std::vector<int> ppt(pairs.size());
+    for (size_t q = 0; q < pairs.size(); ++q) ppt[q] = opt[pairs[q].x];
+    UP(blk_pair_pt, ppt);
+  }
+  for (auto& pr : pairs) { pr.x = cam_obs[pr.x]; pr.y = cam_obs[pr.y]; }
+  {
+    std::vector<int> sobs(std::max(1, dbeg[h->ncv]), 0);
+    for (int64_t s2 = 0; s2 < nm; ++s2) if (cam_obs[s2] >= 0) sobs[cam_obs[s2]] = (int)s2;
+    UP(slot_obs, sobs);
+    std::vector<int> spt(sobs.size(), 0);
+    for (int64_t s2 = 0; s2 < nm; ++s2) if (cam_obs[s2] >= 0) spt[cam_obs[s2]] = opt[s2];
+    UP(slot_pt, spt);
+  }
+  UP(diag_items, ditems); UP(cam_obs, cam_obs); UP(blk_items, bitems); UP(blk_pairs, pairs);
+  AL(rec, (size_t)std::max(1, dbeg[h->ncv]) * (6 * h->pd + 14));
+  return 0;
+}
+
+// The gather lists when intrinsics are optimised (k_lin_obs_intr / k_schur_intr); see create().
+int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, const std::vector<int>& ocam,
+                            const std::vector<int>& opt) {
+  int rc = 0;
+  hipStream_t st = h->stream;
+  // Gather lists with intrinsics (k_lin_obs_intr / k_schur_intr): records for every observation whose camera OR
+  // intrinsics group is variable, stored (group, camera)-major; item = {type, row0, col0, beg, end, flags}.
+  enum { IT_CC = 0, IT_CG = 1, IT_GG0 = 2, IT_GG1 = 3, IT_CD = 4, IT_CGD = 5, IT_GD0 = 6, IT_GD1 = 7, IT_GV = 8 };
+  const int64_t nm = h->nobs_main;
+  constexpr int kChunk = 2048;
+  std::vector<int> red(nm), grd(nm);
+  for (int64_t s = 0; s < nm; ++s) { red[s] = h->cam_red[ocam[s]]; grd[s] = h->grp_red[p->cam_group[ocam[s]]]; }
+  // slots: sort the observations that need a record by (group, camera)
+  std::vector<int> order;
+  for (int64_t s = 0; s < nm; ++s) if (red[s] >= 0 || grd[s] >= 0) order.push_back((int)s);
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+    if (grd[x] != grd[y]) return grd[x] < grd[y];
+    return red[x] < red[y];
+  });
+  std::vector<int> slot(nm, -1);
+  for (size_t k = 0; k < order.size(); ++k) slot[order[k]] = (int)k;
+  std::vector<int> items;
+  auto push_item = [&](int type, int row0, int col0, int64_t beg, int64_t end, int flags) {
+    const int nchunk = (int)((end - beg + kChunk - 1) / kChunk);
+    for (int k = 0; k < nchunk; ++k) {
+      items.push_back(type); items.push_back(row0); items.push_back(col0);
+      items.push_back((int)(beg + (int64_t)k * kChunk)); items.push_back((int)std::min<int64_t>(end, beg + (int64_t)(k + 1) * kChunk));
+      items.push_back(flags | (nchunk > 1 ? 1 : 0));
+    }
+  };
+  // ---- pair lists: entries (key, a, b) sorted by key; one item (or two halves) per key
+  struct PairE { uint64_t key; int a, b; };
+  std::vector<PairE> cc, cg, gg;
+  for (int64_t s0 = 0; s0 < nm;) {
+    int64_t s1 = s0 + 1;
+    while (s1 < nm && opt[s1] == opt[s0]) ++s1;
+    if (!h->pt_const[opt[s0]])
+      for (int64_t a = s0; a < s1; ++a)
+        for (int64_t b = s0; b < s1; ++b) {
+          if (a == b) continue;
+          if (red[a] >= 0 && red[b] >= 0 && red[a] >= red[b]) cc.push_back({((uint64_t)red[a] << 32) | (uint32_t)red[b], (int)a, (int)b});
+          if (red[a] >= 0 && grd[b] >= 0) cg.push_back({((uint64_t)red[a] << 32) | (uint32_t)grd[b], (int)a, (int)b});
+          if (grd[a] >= 0 && grd[b] >= 0 && grd[a] >= grd[b]) gg.push_back({((uint64_t)grd[a] << 32) | (uint32_t)grd[b], (int)a, (int)b});
+        }
+    s0 = s1;
+  }
+  std::vector<int2> pairs;
+  // entries are generated in ascending (a, b): two stable counting passes (low, then high half of the key)
+  // order them by (key, a, b) without a comparison sort
+  const size_t nbucket = (size_t)std::max(h->ncv, h->ngv) + 2;
+  auto emit_pairs = [&](std::vector<PairE>& v, auto&& per_key) {
+    {
+      std::vector<PairE> tmp(v.size());
+      std::vector<size_t> cnt(nbucket + 1);
+      for (int pass = 0; pass < 2; ++pass) {
+        const int sh = pass == 0 ? 0 : 32;
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (const PairE& e : v) cnt[(size_t)((e.key >> sh) & 0xffffffffu) + 1]++;
+        for (size_t k = 0; k < nbucket; ++k) cnt[k + 1] += cnt[k];
+        for (const PairE& e : v) tmp[cnt[(size_t)((e.key >> sh) & 0xffffffffu)]++] = e;
+        v.swap(tmp);
+      }
+    }
+    for (size_t q = 0; q < v.size();) {
+      size_t e = q + 1;
+      while (e < v.size() && v[e].key == v[q].key) ++e;
+      const int64_t beg = (int64_t)pairs.size();
+      for (size_t k = q; k < e; ++k) pairs.push_back(make_int2(slot[v[k].a], slot[v[k].b]));
+      per_key((int)(v[q].key >> 32), (int)(v[q].key & 0xffffffffu), beg, (int64_t)pairs.size());
+      q = e;
+    }
+  };
+  // cameras seen twice by a track give (c, c) lists: the camera block is then fed by two kinds of items
+  std::vector<char> self(h->ncv, 0);
+  for (const PairE& e : cc) if ((e.key >> 32) == (e.key & 0xffffffffu)) self[e.key >> 32] = 1;
+  emit_pairs(cc, [&](int ra, int rb, int64_t beg, int64_t end) {
+    push_item(IT_CC, h->ni + 6 * ra, h->ni + 6 * rb, beg, end, ra == rb ? 3 : 0);
+  });
+  emit_pairs(cg, [&](int ra, int gb, int64_t beg, int64_t end) { push_item(IT_CG, h->ni + 6 * ra, 10 * gb, beg, end, 1); });
+  emit_pairs(gg, [&](int ga, int gb, int64_t beg, int64_t end) {
+    push_item(IT_GG0, 10 * ga, 10 * gb, beg, end, 1 | (ga == gb ? 2 : 0));
+    push_item(IT_GG1, 10 * ga + 4, 10 * gb, beg, end, 1 | (ga == gb ? 2 : 0));
+  });
+  // (the CG / GG targets also receive the per-observation diagonal items below: always atomic)
+  if (pairs.size() > (size_t)std::numeric_limits<int>::max() - 64)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "too many observation pairs for 32-bit pair lists");
+  // ---- per-observation (diagonal) items over contiguous slot ranges
+  for (size_t q = 0; q < order.size();) {   // per camera (inside its group)
+    size_t e = q + 1;
+    while (e < order.size() && red[order[e]] == red[order[q]] && grd[order[e]] == grd[order[q]]) ++e;
+    const int rc = red[order[q]], gr = grd[order[q]];
+    if (rc >= 0) {
+      push_item(IT_CD, h->ni + 6 * rc, h->ni + 6 * rc, (int64_t)q, (int64_t)e, self[rc] ? 1 : 0);
+      if (gr >= 0) push_item(IT_CGD, h->ni + 6 * rc, 10 * gr, (int64_t)q, (int64_t)e, 1);
+    }
+    q = e;
+  }
+  for (size_t q = 0; q < order.size();) {   // per group
+    size_t e = q + 1;
+    while (e < order.size() && grd[order[e]] == grd[order[q]]) ++e;
+    const int gr = grd[order[q]];
+    if (gr >= 0) {
+      push_item(IT_GD0, 10 * gr, 10 * gr, (int64_t)q, (int64_t)e, 1);
+      push_item(IT_GD1, 10 * gr, 10 * gr, (int64_t)q, (int64_t)e, 1);
+      push_item(IT_GV, 10 * gr, 10 * gr, (int64_t)q, (int64_t)e, 0);
+    }
+    q = e;
+  }
+  h->n_diag_items = 0; h->n_blk_items = (int)items.size() / 6;
+  {
+    std::vector<int> sobs(order.begin(), order.end());
+    if (sobs.empty()) sobs.push_back(0);
+    UP(slot_obs, sobs);
+  }
+  UP(cam_obs, slot); UP(blk_items, items); UP(blk_pairs, pairs);
+  AL(rec, (size_t)std::max<size_t>(1, order.size()) * (32 * h->pd + 50));
+  return 0;
+}
+
+#undef UP
+#undef AL
 int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_handle* out) {
   if (!out) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle pointer");
   *out = nullptr;
@@ -849,251 +1110,8 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     h->plan = chol_plan_create(h->n, h->tile_adj.data());
     tick("K3 plan");
   }
-  if (h->ni == 0 && h->ntiles_main > 0) {
-    // Static gather lists of the Schur assembly (k_schur_diag / k_schur_blocks):
-    // per reduced camera its observations, per camera pair (ri > rj) the
-    // (observation of ri, observation of rj) pairs of their common variable
-    // tracks.  Tracks of the slow path (> 64 observations) assemble themselves.
-    const int64_t nm = h->nobs_main;
-    std::vector<char> is_long(nm, 0);
-    for (int s2 : l_obs) is_long[s2] = 1;
-    std::vector<int> red(nm);
-    for (int64_t s = 0; s < nm; ++s) red[s] = is_long[s] ? -1 : h->cam_red[ocam[s]];
-    constexpr int kChunk = 2048;
-    std::vector<int> dbeg(h->ncv + 1, 0);
-    for (int64_t s = 0; s < nm; ++s) if (red[s] >= 0) dbeg[red[s] + 1]++;
-    for (int c = 0; c < h->ncv; ++c) dbeg[c + 1] += dbeg[c];
-    // records are stored camera-major: slot of observation s = its rank in its camera's list
-    std::vector<int> cam_obs(nm, -1);   // = rec_slot
-    {
-      std::vector<int> f(dbeg.begin(), dbeg.end() - 1);
-      for (int64_t s = 0; s < nm; ++s) if (red[s] >= 0) cam_obs[s] = f[red[s]]++;
-    }
-    std::vector<int> ditems;
-    for (int c = 0; c < h->ncv; ++c) {
-      const int nchunk = (dbeg[c + 1] - dbeg[c] + kChunk - 1) / kChunk;
-      for (int k = 0; k < nchunk; ++k) {
-        ditems.push_back(c); ditems.push_back(dbeg[c] + k * kChunk);
-        ditems.push_back(std::min(dbeg[c + 1], dbeg[c] + (k + 1) * kChunk)); ditems.push_back(nchunk > 1 ? 1 : 0);
-      }
-    }
-    // pairs, bucketed by row camera then sorted by column camera
-    std::vector<int64_t> rbeg(h->ncv + 1, 0);
-    auto for_each_pair = [&](auto&& fn) {
-      for (int64_t s0 = 0; s0 < nm;) {
-        int64_t s1 = s0 + 1;
-        while (s1 < nm && opt[s1] == opt[s0]) ++s1;
-        if (!is_long[s0] && !h->pt_const[opt[s0]])
-          for (int64_t a = s0; a < s1; ++a) {
-            if (red[a] < 0) continue;
-            for (int64_t b = s0; b < s1; ++b)
-              if (red[b] >= 0 && (red[a] > red[b] || (red[a] == red[b] && a != b))) fn((int)a, (int)b);
-          }
-        s0 = s1;
-      }
-    };
-    for_each_pair([&](int a, int) { rbeg[red[a] + 1]++; });
-    for (int c = 0; c < h->ncv; ++c) rbeg[c + 1] += rbeg[c];
-    if (rbeg[h->ncv] > (int64_t)std::numeric_limits<int>::max() - 64)
-      return set_error(THEIA_HIP_ERR_UNSUPPORTED, "too many camera pairs for 32-bit pair lists");
-    std::vector<int2> pairs(rbeg[h->ncv]);
-    {
-      std::vector<int64_t> f(rbeg.begin(), rbeg.end() - 1);
-      for_each_pair([&](int a, int b) { pairs[f[red[a]]++] = make_int2(a, b); });
-    }
-    std::vector<int> bitems;
-    // each row is ordered by (column camera, a, b).  The pairs of a row were generated in ascending (a, b)
-    // (tracks are contiguous and visited in order), so a STABLE counting sort on the column camera is enough.
-    {
-      std::vector<int64_t> cnt(h->ncv + 1);
-      std::vector<int2> tmp;
-      for (int c = 0; c < h->ncv; ++c) {
-        const int64_t b0 = rbeg[c], b1 = rbeg[c + 1];
-        if (b1 - b0 < 2) continue;
-        std::fill(cnt.begin(), cnt.end(), 0);
-        for (int64_t q = b0; q < b1; ++q) cnt[red[pairs[q].y] + 1]++;
-        for (int k = 0; k < h->ncv; ++k) cnt[k + 1] += cnt[k];
-        tmp.assign(pairs.begin() + b0, pairs.begin() + b1);
-        for (const int2& pr : tmp) pairs[b0 + cnt[red[pr.y]]++] = pr;
-      }
-    }
-    for (int c = 0; c < h->ncv; ++c) {
-      for (int64_t q = rbeg[c]; q < rbeg[c + 1];) {
-        int64_t e = q + 1;
-        const int rj = red[pairs[q].y];
-        while (e < rbeg[c + 1] && red[pairs[e].y] == rj) ++e;
-        const int nchunk = (int)((e - q + kChunk - 1) / kChunk);
-        for (int k = 0; k < nchunk; ++k) {
-          bitems.push_back(c); bitems.push_back(rj); bitems.push_back((int)(q + (int64_t)k * kChunk));
-          bitems.push_back((int)std::min<int64_t>(e, q + (int64_t)(k + 1) * kChunk));
-          bitems.push_back((nchunk > 1 || rj == c) ? 1 : 0);
-        }
-        q = e;
-      }
-    }
-    // a camera that sees a track twice also has a (c, c) pair list: both kinds of items then ADD
-    // into the diagonal block (they run in one launch, unordered)
-    {
-      std::vector<char> self(h->ncv, 0);
-      for (size_t k = 0; k + 4 < bitems.size() + 1; k += 5) if (bitems[k] == bitems[k + 1]) self[bitems[k]] = 1;
-      for (size_t k = 0; k + 3 < ditems.size() + 1; k += 4) if (self[ditems[k]]) ditems[k + 3] = 1;
-    }
-    // XCD-aware order: workgroup b runs on XCD b % 8 (observed dispatch order, a speed matter only).  All items whose
-    // ROW camera is c are placed on XCD c % 8, so that camera's records are fetched into one L2 and re-used by its
-    // block items and its diagonal item instead of being pulled into all eight.
-    if (!getenv("THEIA_HIP_NO_XCD_ORDER")) {
-      auto reorder = [&](std::vector<int>& items, int stride, int first_wg) {
-        const int n = (int)items.size() / stride;
-        std::vector<std::vector<int>> bucket(8);
-        for (int k = 0; k < n; ++k) bucket[items[(size_t)k * stride] & 7].push_back(k);
-        std::vector<size_t> head(8, 0);
-        std::vector<int> out;
-        out.reserve(items.size());
-        for (int pos = 0; pos < n; ++pos) {
-          int x = (first_wg + pos) & 7;
-          if (head[x] >= bucket[x].size()) {   // that XCD's list is exhausted: take from the fullest one
-            size_t best = 0;
-            for (int y = 0; y < 8; ++y) { const size_t left = bucket[y].size() - head[y]; if (left > best) { best = left; x = y; } }
-          }
-          const int k = bucket[x][head[x]++];
-          out.insert(out.end(), items.begin() + (size_t)k * stride, items.begin() + (size_t)(k + 1) * stride);
-        }
-        items.swap(out);
-      };
-      reorder(bitems, 5, 0);
-      reorder(ditems, 4, (int)bitems.size() / 5);
-    }
-    h->n_diag_items = (int)ditems.size() / 4; h->n_blk_items = (int)bitems.size() / 5;
-    {
-      std::vector<int> ppt(pairs.size());
-      for (size_t q = 0; q < pairs.size(); ++q) ppt[q] = opt[pairs[q].x];
-      UP(blk_pair_pt, ppt);
-    }
-    for (auto& pr : pairs) { pr.x = cam_obs[pr.x]; pr.y = cam_obs[pr.y]; }
-    {
-      std::vector<int> sobs(std::max(1, dbeg[h->ncv]), 0);
-      for (int64_t s2 = 0; s2 < nm; ++s2) if (cam_obs[s2] >= 0) sobs[cam_obs[s2]] = (int)s2;
-      UP(slot_obs, sobs);
-      std::vector<int> spt(sobs.size(), 0);
-      for (int64_t s2 = 0; s2 < nm; ++s2) if (cam_obs[s2] >= 0) spt[cam_obs[s2]] = opt[s2];
-      UP(slot_pt, spt);
-    }
-    UP(diag_items, ditems); UP(cam_obs, cam_obs); UP(blk_items, bitems); UP(blk_pairs, pairs);
-    AL(rec, (size_t)std::max(1, dbeg[h->ncv]) * (6 * h->pd + 14));
-  }
-  if (h->ni > 0 && h->ntiles_main > 0) {
-    // Gather lists with intrinsics (k_lin_obs_intr / k_schur_intr): records for every observation whose camera OR
-    // intrinsics group is variable, stored (group, camera)-major; item = {type, row0, col0, beg, end, flags}.
-    enum { IT_CC = 0, IT_CG = 1, IT_GG0 = 2, IT_GG1 = 3, IT_CD = 4, IT_CGD = 5, IT_GD0 = 6, IT_GD1 = 7, IT_GV = 8 };
-    const int64_t nm = h->nobs_main;
-    constexpr int kChunk = 2048;
-    std::vector<int> red(nm), grd(nm);
-    for (int64_t s = 0; s < nm; ++s) { red[s] = h->cam_red[ocam[s]]; grd[s] = h->grp_red[p->cam_group[ocam[s]]]; }
-    // slots: sort the observations that need a record by (group, camera)
-    std::vector<int> order;
-    for (int64_t s = 0; s < nm; ++s) if (red[s] >= 0 || grd[s] >= 0) order.push_back((int)s);
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-      if (grd[x] != grd[y]) return grd[x] < grd[y];
-      return red[x] < red[y];
-    });
-    std::vector<int> slot(nm, -1);
-    for (size_t k = 0; k < order.size(); ++k) slot[order[k]] = (int)k;
-    std::vector<int> items;
-    auto push_item = [&](int type, int row0, int col0, int64_t beg, int64_t end, int flags) {
-      const int nchunk = (int)((end - beg + kChunk - 1) / kChunk);
-      for (int k = 0; k < nchunk; ++k) {
-        items.push_back(type); items.push_back(row0); items.push_back(col0);
-        items.push_back((int)(beg + (int64_t)k * kChunk)); items.push_back((int)std::min<int64_t>(end, beg + (int64_t)(k + 1) * kChunk));
-        items.push_back(flags | (nchunk > 1 ? 1 : 0));
-      }
-    };
-    // ---- pair lists: entries (key, a, b) sorted by key; one item (or two halves) per key
-    struct PairE { uint64_t key; int a, b; };
-    std::vector<PairE> cc, cg, gg;
-    for (int64_t s0 = 0; s0 < nm;) {
-      int64_t s1 = s0 + 1;
-      while (s1 < nm && opt[s1] == opt[s0]) ++s1;
-      if (!h->pt_const[opt[s0]])
-        for (int64_t a = s0; a < s1; ++a)
-          for (int64_t b = s0; b < s1; ++b) {
-            if (a == b) continue;
-            if (red[a] >= 0 && red[b] >= 0 && red[a] >= red[b]) cc.push_back({((uint64_t)red[a] << 32) | (uint32_t)red[b], (int)a, (int)b});
-            if (red[a] >= 0 && grd[b] >= 0) cg.push_back({((uint64_t)red[a] << 32) | (uint32_t)grd[b], (int)a, (int)b});
-            if (grd[a] >= 0 && grd[b] >= 0 && grd[a] >= grd[b]) gg.push_back({((uint64_t)grd[a] << 32) | (uint32_t)grd[b], (int)a, (int)b});
-          }
-      s0 = s1;
-    }
-    std::vector<int2> pairs;
-    // entries are generated in ascending (a, b): two stable counting passes (low, then high half of the key)
-    // order them by (key, a, b) without a comparison sort
-    const size_t nbucket = (size_t)std::max(h->ncv, h->ngv) + 2;
-    auto emit_pairs = [&](std::vector<PairE>& v, auto&& per_key) {
-      {
-        std::vector<PairE> tmp(v.size());
-        std::vector<size_t> cnt(nbucket + 1);
-        for (int pass = 0; pass < 2; ++pass) {
-          const int sh = pass == 0 ? 0 : 32;
-          std::fill(cnt.begin(), cnt.end(), 0);
-          for (const PairE& e : v) cnt[(size_t)((e.key >> sh) & 0xffffffffu) + 1]++;
-          for (size_t k = 0; k < nbucket; ++k) cnt[k + 1] += cnt[k];
-          for (const PairE& e : v) tmp[cnt[(size_t)((e.key >> sh) & 0xffffffffu)]++] = e;
-          v.swap(tmp);
-        }
-      }
-      for (size_t q = 0; q < v.size();) {
-        size_t e = q + 1;
-        while (e < v.size() && v[e].key == v[q].key) ++e;
-        const int64_t beg = (int64_t)pairs.size();
-        for (size_t k = q; k < e; ++k) pairs.push_back(make_int2(slot[v[k].a], slot[v[k].b]));
-        per_key((int)(v[q].key >> 32), (int)(v[q].key & 0xffffffffu), beg, (int64_t)pairs.size());
-        q = e;
-      }
-    };
-    // cameras seen twice by a track give (c, c) lists: the camera block is then fed by two kinds of items
-    std::vector<char> self(h->ncv, 0);
-    for (const PairE& e : cc) if ((e.key >> 32) == (e.key & 0xffffffffu)) self[e.key >> 32] = 1;
-    emit_pairs(cc, [&](int ra, int rb, int64_t beg, int64_t end) {
-      push_item(IT_CC, h->ni + 6 * ra, h->ni + 6 * rb, beg, end, ra == rb ? 3 : 0);
-    });
-    emit_pairs(cg, [&](int ra, int gb, int64_t beg, int64_t end) { push_item(IT_CG, h->ni + 6 * ra, 10 * gb, beg, end, 1); });
-    emit_pairs(gg, [&](int ga, int gb, int64_t beg, int64_t end) {
-      push_item(IT_GG0, 10 * ga, 10 * gb, beg, end, 1 | (ga == gb ? 2 : 0));
-      push_item(IT_GG1, 10 * ga + 4, 10 * gb, beg, end, 1 | (ga == gb ? 2 : 0));
-    });
-    // (the CG / GG targets also receive the per-observation diagonal items below: always atomic)
-    if (pairs.size() > (size_t)std::numeric_limits<int>::max() - 64)
-      return set_error(THEIA_HIP_ERR_UNSUPPORTED, "too many observation pairs for 32-bit pair lists");
-    // ---- per-observation (diagonal) items over contiguous slot ranges
-    for (size_t q = 0; q < order.size();) {   // per camera (inside its group)
-      size_t e = q + 1;
-      while (e < order.size() && red[order[e]] == red[order[q]] && grd[order[e]] == grd[order[q]]) ++e;
-      const int rc = red[order[q]], gr = grd[order[q]];
-      if (rc >= 0) {
-        push_item(IT_CD, h->ni + 6 * rc, h->ni + 6 * rc, (int64_t)q, (int64_t)e, self[rc] ? 1 : 0);
-        if (gr >= 0) push_item(IT_CGD, h->ni + 6 * rc, 10 * gr, (int64_t)q, (int64_t)e, 1);
-      }
-      q = e;
-    }
-    for (size_t q = 0; q < order.size();) {   // per group
-      size_t e = q + 1;
-      while (e < order.size() && grd[order[e]] == grd[order[q]]) ++e;
-      const int gr = grd[order[q]];
-      if (gr >= 0) {
-        push_item(IT_GD0, 10 * gr, 10 * gr, (int64_t)q, (int64_t)e, 1);
-        push_item(IT_GD1, 10 * gr, 10 * gr, (int64_t)q, (int64_t)e, 1);
-        push_item(IT_GV, 10 * gr, 10 * gr, (int64_t)q, (int64_t)e, 0);
-      }
-      q = e;
-    }
-    h->n_diag_items = 0; h->n_blk_items = (int)items.size() / 6;
-    {
-      std::vector<int> sobs(order.begin(), order.end());
-      if (sobs.empty()) sobs.push_back(0);
-      UP(slot_obs, sobs);
-    }
-    UP(cam_obs, slot); UP(blk_items, items); UP(blk_pairs, pairs);
-    AL(rec, (size_t)std::max<size_t>(1, order.size()) * (32 * h->pd + 50));
-  }
+  if (h->ni == 0 && h->ntiles_main > 0 && (rc = build_gather_lists(h, ocam, opt, l_obs))) return rc;
+  if (h->ni > 0 && h->ntiles_main > 0 && (rc = build_gather_lists_intr(h, p, ocam, opt))) return rc;
 #undef UP
 #undef AL
   tick("gather lists");
