@@ -46,13 +46,12 @@ struct DevProblem {
   const double* scale_red;     // [n] Jacobi scaling by reduced index (finalize)
   // gather-based Schur assembly (k_lin_obs + k_schur_diag + k_schur_blocks), ni == 0:
   // static lists built at create()
-  double* rec;                 // per-observation records, camera-major: [#records][6*pd + 14] = {W | F | r} without
-                               // intrinsics (T = W V^-1 and T g are rebuilt by the reader from Vinv / gp of slot_pt),
+  double* rec;                 // per-observation records, camera-major: [#records][6*pd + 14] = {What | F | r} without
+                               // intrinsics (What = W Li^T with V^-1 = Li^T Li; gp holds ghat = Li g of slot_pt),
                                // [#records][32*pd + 50] with intrinsics (ba_kernels.hip)
   const uint8_t* obs_kind;     // [nobs] (sorted order) THEIA_OBS_* or null: depth-prior rows use the pseudo model
   double loss_width_depth;     // robust_loss_width_depth_prior
   const int* slot_pt;          // [#records] point of a record slot (records without intrinsics)
-  const int* blk_pair_pt;      // [#pairs] point of a pair (same: saves the dependent slot_pt lookup)
   const int* rec_slot;         // [nobs_main] record slot of a (sorted) observation, -1 = none
   const int* slot_obs;         // [#records] inverse: (sorted) observation of a record slot
   int n_diag_items, n_blk_items;

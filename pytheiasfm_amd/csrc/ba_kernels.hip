@@ -207,7 +207,7 @@ THIP_DEV constexpr int lidx(int a, int b) { return a * (a + 1) / 2 + b; }  // a 
 
 // SPD inverse (packed lower) through Cholesky; false if not positive definite.
 template <int PD>
-THIP_DEV bool invert_spd(const double (&V)[PD * (PD + 1) / 2], double (&Vi)[PD * (PD + 1) / 2]) {
+THIP_DEV bool invert_spd(const double (&V)[PD * (PD + 1) / 2], double (&Vi)[PD * (PD + 1) / 2], double (*Li_out)[PD] = nullptr) {
   double Lm[PD][PD];
   bool ok = true;
 #pragma unroll
@@ -244,6 +244,12 @@ THIP_DEV bool invert_spd(const double (&V)[PD * (PD + 1) / 2], double (&Vi)[PD *
       for (int k = a; k < PD; ++k) s += Li[k][a] * Li[k][b];
       Vi[lidx(a, b)] = s;
     }
+  if (Li_out) {
+#pragma unroll
+    for (int a = 0; a < PD; ++a)
+#pragma unroll
+      for (int b = 0; b < PD; ++b) Li_out[a][b] = (b <= a) ? Li[a][b] : 0.0;
+  }
   return ok;
 }
 
@@ -371,31 +377,11 @@ __global__ void k_make_scale(int count, const double* __restrict__ colsq, double
 // Lanes accumulate in registers and a shuffle reduce-scatter leaves element e
 // of the block in lane(e): no atomics (except for lists split into chunks),
 // fixed summation order, each S entry written once.
-// record of one observation: {W = F^T E (6 x PD) | F (2 x 6) | r (2)} = 32 doubles (two 128-B lines) for PD = 3.
-// T = W V^-1 and T g_p are NOT stored: the readers rebuild them from the per-point V^-1 / g_p (L2 resident)
-// with the arithmetic below -- 43 % fewer record bytes written and re-read per linearisation.
+// record of one observation: {What = F^T E Li^T (6 x PD) | F (2 x 6) | r (2)} = 32 doubles (two 128-B lines) for
+// PD = 3, where V_p^-1 = Li^T Li (Li = inverse of the Cholesky factor of the damped point block).  Everything the
+// Schur complement needs is a product of two such rows:  W_a V^-1 W_b^T = What_a What_b^T  and
+// W V^-1 g_p = What ghat_p with ghat_p = Li g_p (stored per point in `gp`) -- no per-pair V^-1 gather, no T.
 template <int PD> constexpr int rec_stride() { return 6 * PD + 14; }
-
-// T = W V^-1 (6 x PD) and optionally T g, in the order the records used to be built
-template <int PD>
-THIP_DEV void rec_T(const double (&w)[6 * PD], const double (&Vi)[PD * (PD + 1) / 2], double (&t)[6 * PD]) {
-#pragma unroll
-  for (int a = 0; a < 6; ++a)
-#pragma unroll
-    for (int b = 0; b < PD; ++b) {
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < PD; ++k) s += w[a * PD + k] * sym_get<PD>(Vi, k, b);
-      t[a * PD + b] = s;
-    }
-}
-template <int PD>
-THIP_DEV void load_vinv(const double* __restrict__ Vinv, int p, double (&Vi)[PD * (PD + 1) / 2]) {
-  constexpr int NT = PD * (PD + 1) / 2;
-  const double2* V2 = reinterpret_cast<const double2*>(Vinv + (size_t)NT * p);   // NT = 6 / 10: 16-B aligned rows
-#pragma unroll
-  for (int k = 0; k < NT / 2; ++k) { const double2 v = V2[k]; Vi[2 * k] = v.x; Vi[2 * k + 1] = v.y; }
-}
 
 template <int PD>
 __global__ __launch_bounds__(kBlock) void k_lin_obs(DevProblem P, const double* __restrict__ cam,
@@ -430,10 +416,19 @@ __global__ __launch_bounds__(kBlock) void k_lin_obs(DevProblem P, const double* 
 #pragma unroll
   for (int a = 0; a < PD; ++a) { g[a] = tot[NT + a]; V[lidx(a, a)] += fmin(fmax(V[lidx(a, a)], 1e-6), 1e32) / radius; }
   bool pd_ok = true;
-  if (L.active && !L.pconst) pd_ok = invert_spd<PD>(V, Vi);
+  double Li[PD][PD];
+#pragma unroll
+  for (int a = 0; a < PD; ++a)
+#pragma unroll
+    for (int b = 0; b < PD; ++b) Li[a][b] = 0.0;
+  if (L.active && !L.pconst) pd_ok = invert_spd<PD>(V, Vi, Li);
   if (!L.active || L.pconst || !pd_ok) {
 #pragma unroll
     for (int k = 0; k < NT; ++k) Vi[k] = 0.0;
+#pragma unroll
+    for (int a = 0; a < PD; ++a)
+#pragma unroll
+      for (int b = 0; b < PD; ++b) Li[a][b] = 0.0;
   }
   double gmax = 0.0;
   if (L.active && sg.head && !L.pconst) {
@@ -441,17 +436,29 @@ __global__ __launch_bounds__(kBlock) void k_lin_obs(DevProblem P, const double* 
     for (int k = 0; k < NT; ++k) Vinv[(size_t)NT * L.p + k] = Vi[k];
 #pragma unroll
     for (int a = 0; a < PD; ++a) {
-      gp[(size_t)PD * L.p + a] = g[a];
+      double gh = 0.0;   // ghat = Li g (the Schur readers' side of W V^-1 g)
+#pragma unroll
+      for (int k = 0; k <= a; ++k) gh += Li[a][k] * g[k];
+      gp[(size_t)PD * L.p + a] = gh;
       gmax = fmax(gmax, fabs(g[a] / P.scale_p[(size_t)PD * L.p + a]));
     }
   }
   if (slot >= 0) {
     double2* R = reinterpret_cast<double2*>(P.rec + (size_t)slot * RS);
-    double w[NW];
+    double w0[NW], w[NW];
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
-      for (int b = 0; b < PD; ++b) w[a * PD + b] = L.Jc[a] * L.Jt[b] + L.Jc[6 + a] * L.Jt[PD + b];
+      for (int b = 0; b < PD; ++b) w0[a * PD + b] = L.Jc[a] * L.Jt[b] + L.Jc[6 + a] * L.Jt[PD + b];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)   // What = W Li^T
+#pragma unroll
+      for (int b = 0; b < PD; ++b) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int k = 0; k <= b; ++k) sacc += w0[a * PD + k] * Li[b][k];
+        w[a * PD + b] = sacc;
+      }
 #pragma unroll
     for (int k = 0; k < NW / 2; ++k) R[k] = make_double2(w[2 * k], w[2 * k + 1]);
 #pragma unroll
@@ -514,7 +521,7 @@ THIP_DEV void load_rec(const double* __restrict__ rec, int slot, int off2, doubl
 template <int PD>
 THIP_DEV void schur_diag_item(const DevProblem& P, int item, double (*part)[40], double* __restrict__ S,
                               double* __restrict__ rhs, double* __restrict__ colsq, double* __restrict__ gc,
-                              const double* __restrict__ Vinv, const double* __restrict__ gp) {
+                              const double* __restrict__ gp) {
   constexpr int NW = 6 * PD;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int* it = P.diag_items + 4 * item;
@@ -523,21 +530,19 @@ THIP_DEV void schur_diag_item(const DevProblem& P, int item, double (*part)[40],
 #pragma unroll
   for (int k = 0; k < 39; ++k) acc[k] = 0.0;
   for (int q = beg + tid; q < end; q += kBlock) {
-    double W[NW], T[NW], Jc[12], rt[8], Vi[PD * (PD + 1) / 2];
+    double W[NW], Jc[12], rt[8];
     const int p = P.slot_pt[q];
-    load_rec<PD>(P.rec, q, 0, W);
+    load_rec<PD>(P.rec, q, 0, W);          // What
     load_rec<PD>(P.rec, q, NW / 2, Jc);
     {
       const double2 r2 = reinterpret_cast<const double2*>(P.rec + (size_t)q * rec_stride<PD>())[NW / 2 + 6];
       rt[0] = r2.x; rt[1] = r2.y;
     }
-    load_vinv<PD>(Vinv, p, Vi);
-    rec_T<PD>(W, Vi, T);
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {   // T g_p
+    for (int a = 0; a < 6; ++a) {   // W V^-1 g_p = What ghat_p
       double s = 0.0;
 #pragma unroll
-      for (int k = 0; k < PD; ++k) s += T[a * PD + k] * gp[(size_t)PD * p + k];
+      for (int k = 0; k < PD; ++k) s += W[a * PD + k] * gp[(size_t)PD * p + k];
       rt[2 + a] = s;
     }
 #pragma unroll
@@ -546,7 +551,7 @@ THIP_DEV void schur_diag_item(const DevProblem& P, int item, double (*part)[40],
       for (int b = 0; b <= a; ++b) {
         double s = Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
 #pragma unroll
-        for (int k = 0; k < PD; ++k) s -= T[a * PD + k] * W[b * PD + k];
+        for (int k = 0; k < PD; ++k) s -= W[a * PD + k] * W[b * PD + k];
         acc[lidx(a, b)] += s;
       }
       const double jr = Jc[a] * rt[0] + Jc[6 + a] * rt[1];
@@ -573,8 +578,7 @@ THIP_DEV void schur_diag_item(const DevProblem& P, int item, double (*part)[40],
 
 // one workgroup per (block (ri, rj), chunk of its pair list)
 template <int PD>
-THIP_DEV void schur_block_item(const DevProblem& P, int item, double (*part)[40], double* __restrict__ S,
-                               const double* __restrict__ Vinv) {
+THIP_DEV void schur_block_item(const DevProblem& P, int item, double (*part)[40], double* __restrict__ S) {
   constexpr int NW = 6 * PD;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int* it = P.blk_items + 5 * item;
@@ -584,11 +588,9 @@ THIP_DEV void schur_block_item(const DevProblem& P, int item, double (*part)[40]
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
   for (int q = beg + tid; q < end; q += kBlock) {
     const int2 ab = P.blk_pairs[q];
-    double Wa[NW], T[NW], Wb[NW], Vi[PD * (PD + 1) / 2];
-    load_rec<PD>(P.rec, ab.x, 0, Wa);
+    double T[NW], Wb[NW];                  // What_a, What_b
+    load_rec<PD>(P.rec, ab.x, 0, T);
     load_rec<PD>(P.rec, ab.y, 0, Wb);
-    load_vinv<PD>(Vinv, P.blk_pair_pt[q], Vi);
-    rec_T<PD>(Wa, Vi, T);
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -614,11 +616,11 @@ THIP_DEV void schur_block_item(const DevProblem& P, int item, double (*part)[40]
 template <int PD>
 __global__ __launch_bounds__(kBlock) void k_schur(DevProblem P, double* __restrict__ S, double* __restrict__ rhs,
                                                   double* __restrict__ colsq, double* __restrict__ gc,
-                                                  const double* __restrict__ Vinv, const double* __restrict__ gp) {
+                                                  const double* __restrict__ gp) {
   __shared__ double part[kWavesPerBlock][40];
   const int b = blockIdx.x;
-  if (b < P.n_blk_items) schur_block_item<PD>(P, b, part, S, Vinv);        // the long lists first
-  else schur_diag_item<PD>(P, b - P.n_blk_items, part, S, rhs, colsq, gc, Vinv, gp);
+  if (b < P.n_blk_items) schur_block_item<PD>(P, b, part, S);        // the long lists first
+  else schur_diag_item<PD>(P, b - P.n_blk_items, part, S, rhs, colsq, gc, gp);
 }
 
 // ------------------------------------- gather-based Schur assembly with intrinsics (A10)
@@ -1482,8 +1484,8 @@ void launch_linearize(const DevProblem& P, const double* cam, const double* pts,
     if (P.pd == 3) k_lin_obs<3><<<g, kBlock, 0, st>>>(P, cam, pts, radius, Vinv, gp, tile_part);
     else k_lin_obs<4><<<g, kBlock, 0, st>>>(P, cam, pts, radius, Vinv, gp, tile_part);
     if (P.n_diag_items + P.n_blk_items) {
-      if (P.pd == 3) k_schur<3><<<P.n_diag_items + P.n_blk_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc, Vinv, gp);
-      else k_schur<4><<<P.n_diag_items + P.n_blk_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc, Vinv, gp);
+      if (P.pd == 3) k_schur<3><<<P.n_diag_items + P.n_blk_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc, gp);
+      else k_schur<4><<<P.n_diag_items + P.n_blk_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc, gp);
     }
     return;
   }

@@ -120,7 +120,7 @@ struct theia_ba_handle_s {
   DevBuf<uint8_t> obs_kind;
   DevBuf<double> reduce, Vinv, gp, tile_part, scalB, chol_work;
   DevBuf<double> rec;                       // per-observation records of the gather-based Schur assembly
-  DevBuf<int> diag_items, cam_obs, blk_items, slot_obs, slot_pt, blk_pair_pt;
+  DevBuf<int> diag_items, cam_obs, blk_items, slot_obs, slot_pt;
   DevBuf<int> prior_cam, prior_kind;        // camera priors in use (compact list)
   DevBuf<double> prior_vec, prior_info;
   int n_priors = 0;
@@ -429,7 +429,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.n_priors = h->n_priors; P.prior_cam = h->prior_cam.p; P.prior_kind = h->prior_kind.p;
   P.prior_vec = h->prior_vec.p; P.prior_info = h->prior_info.p;
   P.rec = h->rec.p; P.n_diag_items = h->n_diag_items; P.n_blk_items = h->n_blk_items;
-  P.diag_items = h->diag_items.p; P.rec_slot = h->cam_obs.p; P.slot_obs = h->slot_obs.p; P.slot_pt = h->slot_pt.p; P.blk_pair_pt = h->blk_pair_pt.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
+  P.diag_items = h->diag_items.p; P.rec_slot = h->cam_obs.p; P.slot_obs = h->slot_obs.p; P.slot_pt = h->slot_pt.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
 }
 
 int upload_parameters(theia_ba_handle_s* h, const theia_ba_problem* p) {
@@ -730,11 +730,6 @@ int build_gather_lists(theia_ba_handle_s* h, const std::vector<int>& ocam, const
     reorder(ditems, 4, (int)bitems.size() / 5);
   }
   h->n_diag_items = (int)ditems.size() / 4; h->n_blk_items = (int)bitems.size() / 5;
-  {
-    std::vector<int> ppt(pairs.size());
-    for (size_t q = 0; q < pairs.size(); ++q) ppt[q] = opt[pairs[q].x];
-    UP(blk_pair_pt, ppt);
-  }
   for (auto& pr : pairs) { pr.x = cam_obs[pr.x]; pr.y = cam_obs[pr.y]; }
   {
     std::vector<int> sobs(std::max(1, dbeg[h->ncv]), 0);
