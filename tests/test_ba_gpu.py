@@ -839,3 +839,44 @@ def test_depth_prior_rows_are_validated():
         ba.solve(bad, o)
     with pytest.raises(capi.TheiaHipError, match="depth-prior rows"):
         ba.solve_tracks_batch(p.copy(), o)
+
+
+def test_entry_points_are_reentrant_across_host_threads():
+    """SURVEY 8(b) threading: the pipelines call BundleAdjustTrack / the estimators from thread-pool workers; ctypes
+    releases the GIL, so concurrent calls really overlap.  Concurrent solves must equal the sequential ones."""
+    import threading
+    from pytheiasfm_amd import ransac
+    probs = [synth.synth_ba_v1(10 + k, 300 + 40 * k, seed=0x7EAD00 + k) for k in range(4)]
+    o = ba.default_options(); o.max_num_iterations = 8
+    ref = []
+    for p in probs:
+        q = p.copy(); s, _ = ba.solve(q, o); ref.append((s.final_cost, s.num_iterations, q.cam_ext.copy(), q.points.copy()))
+    data, offsets, _ = synth.synth_ransac_v1(6, 300, "relative", seed=0x7EAD10)
+    rp = ransac.RansacParameters(); rp.error_thresh = (2 / 1000.0) ** 2; rp.seed = 5
+    rref = ransac.estimate_batch(0, data, offsets, rp)
+    out = [None] * 4; rout = [None] * 2; errs = []
+
+    def ba_worker(k):
+        try:
+            for _ in range(3):
+                q = probs[k].copy(); s, _ = ba.solve(q, o)
+                out[k] = (s.final_cost, s.num_iterations, q.cam_ext.copy(), q.points.copy())
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    def ransac_worker(k):
+        try:
+            for _ in range(3):
+                rout[k] = ransac.estimate_batch(0, data, offsets, rp)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=ba_worker, args=(k,)) for k in range(4)] + [threading.Thread(target=ransac_worker, args=(k,)) for k in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    for k in range(4):
+        assert out[k][1] == ref[k][1] and out[k][0] == ref[k][0]
+        assert np.array_equal(out[k][2], ref[k][2]) and np.array_equal(out[k][3], ref[k][3])
+    for k in range(2):
+        assert np.array_equal(rout[k]["inlier_mask"], rref["inlier_mask"]) and np.array_equal(rout[k]["num_iterations"], rref["num_iterations"])
