@@ -167,6 +167,44 @@ def second_set():
     print("wrote camera_models.npz, ba_variants.npz, ransac_variants.npz")
 
 
+NEW_ESTIMATORS = (("fundamental", 5, 4.0, 9), ("homography", 6, 16.0, 9), ("plane", 7, 0.004, 6),
+                  ("known_orientation", 8, (2.0 / 1000.0) ** 2, 3), ("uncalibrated", 9, 4.0, 23))
+
+
+def third_set():
+    """R14 estimators + the exhaustive sampler: data, inlier masks, iteration counts, models."""
+    out = {}
+    for kind, est, thresh, mlen in NEW_ESTIMATORS:
+        data, offsets, _ = synth.synth_ransac_v1(3, 120, kind, seed=0x5AC52000 + est, inlier_lo=0.5, inlier_hi=0.7,
+                                                 noise_px=0.3 if kind == "uncalibrated" else 1.0)
+        out[f"{kind}_data"] = data; out[f"{kind}_offsets"] = offsets
+        ol.set_estimator_params([1.0, 1e9])
+        for rtype in ((0, 1, 2, 3) if kind == "known_orientation" else (0, 1, 2)):
+            masks, models, iters = [], [], []
+            for i in range(3):
+                prm = ol.default_ransac_params(thresh, 40 + i); prm.ransac_type = rtype; prm.failure_probability = 0.001
+                if rtype == 3:
+                    prm.max_iterations = 500
+                r = ol.ransac_estimate(est, data[offsets[i]:offsets[i + 1]], prm)
+                masks.append(r["inlier_mask"]); models.append(r["model"][:mlen]); iters.append(r["num_iterations"])
+            out[f"{kind}_t{rtype}_masks"] = np.stack(masks); out[f"{kind}_t{rtype}_models"] = np.stack(models)
+            out[f"{kind}_t{rtype}_iters"] = np.array(iters)
+    # absolute position with known orientation: rotated correspondences
+    data, offsets, truth = synth.synth_ransac_v1(3, 120, "absolute", seed=0x5AC52010, inlier_lo=0.5, inlier_hi=0.7)
+    from pytheiasfm_amd import ransac as rs
+    rot = np.concatenate([rs.RotateCorrespondences(data[offsets[i]:offsets[i + 1]], synth.matrix_to_angle_axis(truth["R"][i])) for i in range(3)])
+    out["abs_known_data"] = rot; out["abs_known_offsets"] = offsets
+    masks, models, iters = [], [], []
+    for i in range(3):
+        prm = ol.default_ransac_params((4.0 / 1000.0) ** 2, 40 + i); prm.failure_probability = 0.001
+        r = ol.ransac_estimate(10, rot[offsets[i]:offsets[i + 1]], prm)
+        masks.append(r["inlier_mask"]); models.append(r["model"][:3]); iters.append(r["num_iterations"])
+    out["abs_known_t0_masks"] = np.stack(masks); out["abs_known_t0_models"] = np.stack(models); out["abs_known_t0_iters"] = np.array(iters)
+    np.savez_compressed(os.path.join(HERE, "ransac_estimators.npz"), **out)
+    print("wrote ransac_estimators.npz")
+
+
 if __name__ == "__main__":
     main()
     second_set()
+    third_set()

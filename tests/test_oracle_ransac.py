@@ -637,3 +637,29 @@ def test_estimate_absolute_pose_with_known_orientation_scene():
         tin = truth["inlier"][p]; mask = r["inlier_mask"].astype(bool)
         assert (mask & tin).sum() >= 0.75 * tin.sum() and (mask & ~tin).sum() <= 0.1 * tin.sum() + 3
         assert np.linalg.norm(r["model"][:3] - truth["position"][p]) < 0.05
+
+
+def _golden_estimator_runs():
+    """(kind, estimator, threshold, model length, ransac types) of tests/golden/ransac_estimators.npz."""
+    from tests.golden.make_oracle_golden import NEW_ESTIMATORS
+    for kind, est, thresh, mlen in NEW_ESTIMATORS:
+        yield kind, est, thresh, mlen, ((0, 1, 2, 3) if kind == "known_orientation" else (0, 1, 2))
+    yield "abs_known", 10, (4.0 / 1000.0) ** 2, 3, (0,)
+
+
+def test_golden_ransac_estimators():
+    """The oracle reproduces tests/golden/ransac_estimators.npz (fundamental matrix, homography, plane, known-orientation
+    relative / absolute position, uncalibrated relative pose; RANSAC / PROSAC / LMED / EXHAUSTIVE)."""
+    g = np.load(os.path.join(HERE, "golden", "ransac_estimators.npz"))
+    ol.set_estimator_params([1.0, 1e9])
+    for kind, est, thresh, mlen, rtypes in _golden_estimator_runs():
+        data, offsets = g[f"{kind}_data"], g[f"{kind}_offsets"]
+        for rtype in rtypes:
+            for i in range(3):
+                prm = ol.default_ransac_params(thresh, 40 + i); prm.ransac_type = rtype; prm.failure_probability = 0.001
+                if rtype == 3:
+                    prm.max_iterations = 500
+                r = ol.ransac_estimate(est, data[offsets[i]:offsets[i + 1]], prm)
+                assert r["num_iterations"] == g[f"{kind}_t{rtype}_iters"][i], (kind, rtype, i)
+                assert np.array_equal(r["inlier_mask"], g[f"{kind}_t{rtype}_masks"][i])
+                assert np.allclose(r["model"][:mlen], g[f"{kind}_t{rtype}_models"][i], rtol=0, atol=1e-13)

@@ -401,3 +401,24 @@ def test_absolute_pose_with_known_orientation_bit_identical_to_oracle(rtype):
     ok, pos, s = ransac.EstimateAbsolutePoseWithKnownOrientation(p, ransac.RansacType.RANSAC, synth.matrix_to_angle_axis(truth["R"][0]),
                                                                  data[offsets[0]:offsets[1]])
     assert ok and np.linalg.norm(pos - truth["position"][0]) < 0.05
+
+
+def test_golden_ransac_estimators_on_gpu():
+    """tests/golden/ransac_estimators.npz through the HIP path: inlier masks and iteration counts identical; models
+    identical (to 1e-9 for the uncalibrated relative pose, whose focal-length extraction uses atan2 / sin / cos)."""
+    from tests.test_oracle_ransac import _golden_estimator_runs
+    g = np.load(os.path.join(HERE, "golden", "ransac_estimators.npz"))
+    for kind, est, thresh, mlen, rtypes in _golden_estimator_runs():
+        data, offsets = g[f"{kind}_data"], g[f"{kind}_offsets"]
+        for rtype in rtypes:
+            p = ransac.RansacParameters(); p.error_thresh = thresh; p.seed = 40; p.failure_probability = 0.001
+            pc = p.to_c(); pc.ransac_type = rtype
+            if rtype == 3:
+                pc.max_iterations = 500
+            res = ransac.estimate_batch(est, data, offsets, pc, np.array([1.0, 1e9]))
+            assert np.array_equal(res["num_iterations"], g[f"{kind}_t{rtype}_iters"]), (kind, rtype)
+            assert np.array_equal(res["inlier_mask"].reshape(3, -1), g[f"{kind}_t{rtype}_masks"])
+            if est == 9:
+                assert np.allclose(res["models"][:, :mlen], g[f"{kind}_t{rtype}_models"], rtol=1e-9, atol=1e-12)
+            else:
+                assert np.array_equal(res["models"][:, :mlen], g[f"{kind}_t{rtype}_models"])
