@@ -466,3 +466,62 @@ def SetOutlierTracksToUnestimated(track_ids, max_inlier_reprojection_error, min_
     bad_angle = ~bad_reproj & ~(mincos < np.cos(np.deg2rad(min_triangulation_angle_degrees)))
     r.track_estimated[tids[bad_reproj | bad_angle]] = False
     return int(bad_reproj.sum() + bad_angle.sum())
+
+
+def _select_good_tracks(r, view_ids, track_len, track_err, long_track_length_threshold, image_grid_cell_size_pixels,
+                        min_num_optimized_tracks_per_view):
+    """The selection rules of select_good_tracks_for_bundle_adjustment.cc:164-320 on precomputed per-track statistics
+    (track_len = number of estimated views seeing the track, track_err = mean squared reprojection error).
+    Reference semantics kept as they are written: a grid cell keeps the MINIMUM of (truncated length, error)
+    (`std::min_element` with pair `operator<`, :62-66), and the top-up of a view takes its candidates in ascending
+    TRACK ID order (`partial_sort` of pair<TrackId, statistics>, :246-249).  Where the reference iterates hash
+    containers (views in the second pass) this walks ascending ids."""
+    view_ids = sorted(int(v) for v in view_ids if r.view_estimated[int(v)])
+    est_obs = r.view_estimated[r.obs_view] & r.track_estimated[r.obs_track]
+    tl = np.minimum(track_len, long_track_length_threshold)
+    selected = np.zeros(r.NumTracks(), dtype=bool)
+    inv = 1.0 / image_grid_cell_size_pixels
+    by_view = {}
+    order = np.argsort(r.obs_view, kind="stable")
+    bounds = np.searchsorted(r.obs_view[order], np.arange(r.NumViews() + 1))
+    for v in view_ids:
+        idx = order[bounds[v]:bounds[v + 1]]
+        by_view[v] = idx[est_obs[idx]]
+    for v in view_ids:                                   # best track of every image grid cell
+        idx = by_view[v]
+        if not len(idx):
+            continue
+        cell = (r.obs_uv[idx] * inv).astype(np.int64)    # Eigen cast<int>: truncation toward zero
+        t = r.obs_track[idx]
+        key = np.lexsort((track_err[t], tl[t], cell[:, 1], cell[:, 0]))
+        c = cell[key]
+        first = np.ones(len(key), dtype=bool)
+        first[1:] = np.any(c[1:] != c[:-1], axis=1)
+        selected[t[key][first]] = True
+    for v in view_ids:                                   # at least K optimised tracks per view
+        t = r.obs_track[by_view[v]]
+        nopt = int(selected[t].sum())
+        if nopt >= min_num_optimized_tracks_per_view or nopt == len(t):
+            continue
+        need = min(min_num_optimized_tracks_per_view - nopt, len(t) - nopt)
+        cand = np.sort(t[~selected[t]])
+        selected[cand[:need]] = True
+    return np.flatnonzero(selected)
+
+
+def SelectGoodTracksForBundleAdjustment(reconstruction, long_track_length_threshold, image_grid_cell_size_pixels,
+                                        min_num_optimized_tracks_per_view, view_ids=None):
+    """select_good_tracks_for_bundle_adjustment.cc:263-320 -> (True, track ids to optimise).  The per-track mean
+    squared reprojection errors (ComputeTrackStatistics, :79-140: the expensive part) come from
+    theia_hip_track_statistics over the estimated views."""
+    r = reconstruction
+    if view_ids is None:
+        view_ids = [v for v in range(r.NumViews()) if r.view_estimated[v]]
+    keep = r.view_estimated[r.obs_view] & r.track_estimated[r.obs_track]
+    flat = capi.FlatProblem(r.cam_ext.copy(), r.group_intrinsics.copy(), r.group_model, r.view_group, r.points.copy(),
+                            r.obs_uv[keep], r.obs_view[keep], r.obs_track[keep])
+    err, _, _ = _ba.track_statistics(flat)
+    track_len = np.bincount(r.obs_track[keep], minlength=r.NumTracks())
+    sel = _select_good_tracks(r, view_ids, track_len, np.nan_to_num(err, nan=0.0), long_track_length_threshold,
+                              image_grid_cell_size_pixels, min_num_optimized_tracks_per_view)
+    return True, sel.tolist()

@@ -880,3 +880,26 @@ def test_entry_points_are_reentrant_across_host_threads():
         assert np.array_equal(out[k][2], ref[k][2]) and np.array_equal(out[k][3], ref[k][3])
     for k in range(2):
         assert np.array_equal(rout[k]["inlier_mask"], rref["inlier_mask"]) and np.array_equal(rout[k]["num_iterations"], rref["num_iterations"])
+
+
+def test_select_good_tracks_for_bundle_adjustment_mirror():
+    """SelectGoodTracksForBundleAdjustment: device track statistics (mean squared reprojection error over the
+    estimated views) = the oracle's residuals, and the selection covers every view with K tracks."""
+    p = synth.synth_ba_v1(12, 400, seed=0x5E1EC7)
+    rec = sfm.Reconstruction.from_flat(p)
+    rec.view_estimated[3] = False; rec.track_estimated[::17] = False
+    ok, sel = sfm.SelectGoodTracksForBundleAdjustment(rec, 10, 200, 25)
+    assert ok and len(sel) > 0 and all(rec.track_estimated[t] for t in sel)
+    keep = rec.view_estimated[rec.obs_view] & rec.track_estimated[rec.obs_track]
+    _, _, r, _, _ = ol.evaluate(p, ol.default_options())
+    sq = (np.asarray(r).reshape(-1, 2) ** 2).sum(1)
+    err = np.bincount(rec.obs_track[keep], weights=sq[keep], minlength=400) / np.maximum(1, np.bincount(rec.obs_track[keep], minlength=400))
+    ref = sfm._select_good_tracks(rec, [v for v in range(12) if rec.view_estimated[v]], np.bincount(rec.obs_track[keep], minlength=400),
+                                  err, 10, 200, 25)
+    assert sel == ref.tolist()
+    chosen = np.zeros(400, bool); chosen[sel] = True
+    for v in range(12):
+        if not rec.view_estimated[v]:
+            continue
+        t = rec.obs_track[(rec.obs_view == v) & keep]
+        assert chosen[t].sum() >= min(25, len(t))

@@ -187,3 +187,31 @@ def test_two_view_front_end_host_logic():
     for w in ([0.1, -0.2, 0.3], [2.0, 1.0, -1.5], [0.0, 0.0, 0.0], [3.0, 0.2, 0.1]):
         w = np.array(w)
         assert np.allclose(tv._rotation_to_angle_axis(synth.angle_axis_to_matrix(w)), w, atol=1e-12)
+
+
+def test_select_good_tracks_rules():
+    """select_good_tracks_for_bundle_adjustment.cc:164-320 on hand-made statistics: one track per grid cell (minimum
+    of (truncated length, error)), then top-up in ascending track id until a view has K optimised tracks."""
+    r = sfm.Reconstruction()
+    r.cam_ext = np.zeros((2, 6)); r.view_estimated = np.array([True, True]); r.view_group = np.zeros(2, np.int32)
+    r.group_model = np.zeros(1, np.int32); r.group_intrinsics = np.zeros((1, 10))
+    nt = 8
+    r.points = np.zeros((nt, 4)); r.track_estimated = np.ones(nt, dtype=bool); r.track_estimated[7] = False
+    # view 0 sees tracks 0..5 and 7: cells (0,0): {0,1,2}, (1,0): {3}, (0,1): {4,5,7}; view 1 sees 0, 5, 6 in one cell
+    uv0 = {0: (10, 10), 1: (20, 30), 2: (90, 99), 3: (150, 20), 4: (5, 120), 5: (60, 180), 7: (50, 150)}
+    uv1 = {0: (10, 10), 5: (20, 20), 6: (30, 30)}
+    ov, ot, ouv = [], [], []
+    for t, p in uv0.items(): ov.append(0); ot.append(t); ouv.append(p)
+    for t, p in uv1.items(): ov.append(1); ot.append(t); ouv.append(p)
+    r.obs_view = np.array(ov, np.int32); r.obs_track = np.array(ot, np.int32); r.obs_uv = np.array(ouv, float)
+    tlen = np.array([2, 2, 3, 5, 9, 2, 1, 1]); terr = np.array([0.5, 0.2, 0.1, 1.0, 0.3, 0.4, 0.9, 0.0])
+    # threshold 4 truncates track 4's length to 4.  Cell winners: view 0: (0,0) -> track 1 (length 2, error 0.2 < 0.5),
+    # (1,0) -> 3, (0,1) -> 5 (length 2 beats truncated 4; 7 is not estimated); view 1: one cell {0, 5, 6} -> 6 (length 1)
+    sel = sfm._select_good_tracks(r, [0, 1], tlen, terr, 4, 100, 0)
+    assert sel.tolist() == [1, 3, 5, 6]
+    # K = 5: view 0 has 3 optimised of 6 estimated -> adds the lowest ids 0, 2; view 1 then has {0, 5, 6} = all
+    sel = sfm._select_good_tracks(r, [0, 1], tlen, terr, 4, 100, 5)
+    assert sel.tolist() == [0, 1, 2, 3, 5, 6]
+    # K larger than the view: everything estimated in it
+    sel = sfm._select_good_tracks(r, [0], tlen, terr, 4, 100, 50)
+    assert sel.tolist() == [0, 1, 2, 3, 4, 5]
