@@ -157,6 +157,8 @@ def lib():
             pass
     L = C.CDLL(LIB_PATH)
     L.theia_hip_last_error.restype = C.c_char_p
+    if os.environ.get("THEIA_HIP_ABORT_TRACE") == "1":   # development aid: native backtrace on SIGABRT / SIGSEGV
+        L.theia_hip_debug_install_abort_trace()
     L.theia_hip_version.restype = C.c_char_p
     L.theia_hip_ba_create.argtypes = [C.POINTER(BaProblem), C.POINTER(BaOptions), C.POINTER(C.c_void_p)]
     L.theia_hip_ba_run.argtypes = [C.c_void_p, C.POINTER(BaSummary)]

@@ -98,7 +98,11 @@ void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const
 enum { PRIOR_COLNORM = 0, PRIOR_LINEARIZE = 1, PRIOR_TRIAL = 2, PRIOR_COST = 3, PRIOR_FIXED = 4 };
 void launch_cam_priors(const DevProblem& P, int mode, const double* cam, const double* cand_cam, const double* y,
                        const ReduceBuf* rb, double* colsq_c, double* scal_cost, double* scal_mcc, hipStream_t st);
-void launch_finalize_rcs(const DevProblem& P, const double* radius /* device */, const ReduceBuf& rb, hipStream_t st);
+// tile_part != null: the kernel first folds the per-tile partial sums of the linearisation into rb.scal
+// (= launch_reduce_tiles cfg 0), saving that launch; only when no all-reduce sits between the two.
+void launch_finalize_rcs(const DevProblem& P, const double* radius /* device */, const ReduceBuf& rb, hipStream_t st,
+                         int ntiles = 0, const double* tile_part = nullptr, const int* f2s = nullptr,
+                         const int* fmaxflag = nullptr);
 void launch_cam_update(const DevProblem& P, const double* cam, const double* y, double* cand_cam,
                        double* cand_intr, double* out_stepsq, double* out_xnormsq, hipStream_t st, double* zero16 = nullptr);
 void launch_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,
@@ -133,5 +137,45 @@ CholPlan* chol_plan_create(int n, const uint8_t* adj);
 void chol_plan_destroy(CholPlan* plan);
 int chol_plan_levels(const CholPlan* plan);
 void chol_plan_solve(const CholPlan* plan, double* A, int lda, double* b, double* work, double* fail_flag, hipStream_t st);
+
+#ifdef __HIPCC__
+// Deterministic reduction of per-tile partials into a scalar block by ONE workgroup of 1024 threads:
+// field f of tile t at part[t * nfields + f]; result -> scal[f2s[f]] (sum, or max if fmaxflag[f]).
+// Every thread folds its tiles for all fields, a wave shuffle tree per field, the 16 wave results are combined
+// in wave order.  Ends with a workgroup barrier: the scalars are visible to every thread afterwards.
+__device__ __forceinline__ void reduce_tiles_body(int ntiles, const double* __restrict__ part, int nfields,
+                                                  const int* __restrict__ f2s, const int* __restrict__ fmaxflag,
+                                                  double* __restrict__ scal, double (*sm)[16]) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double acc[8];
+  bool ismax[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) { acc[f] = 0.0; ismax[f] = f < nfields && fmaxflag[f] != 0; }
+  for (int t = threadIdx.x; t < ntiles; t += 1024) {
+    const double* row = part + (size_t)t * nfields;
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+      if (f < nfields) { const double v = row[f]; acc[f] = ismax[f] ? fmax(acc[f], v) : acc[f] + v; }
+  }
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    if (f >= nfields) break;
+    double v = acc[f];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = ismax[f] ? fmax(v, o) : v + o; }
+    if (lane == 0) sm[f][wv] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < (unsigned)nfields) {
+    const int f = threadIdx.x;
+    double v = sm[f][0];
+    for (int w = 1; w < 16; ++w) v = ismax[f] ? fmax(v, sm[f][w]) : v + sm[f][w];
+    if (ismax[f]) scal[f2s[f]] = fmax(scal[f2s[f]], v);
+    else scal[f2s[f]] += v;
+  }
+  __threadfence_block();
+  __syncthreads();
+}
+#endif
 
 }  // namespace thip

@@ -946,44 +946,20 @@ __global__ __launch_bounds__(1024) void k_reduce_tiles(int ntiles, const double*
                                                        int nfields, const int* __restrict__ f2s,
                                                        const int* __restrict__ fmaxflag,
                                                        double* __restrict__ scal) {
-  // every thread folds its tiles for ALL fields (independent loads in flight), a wave shuffle tree per
-  // field, then the 16 wave results are combined by wave 0: fixed order, one __syncthreads
   __shared__ double sm[8][16];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  double acc[8];
-  bool ismax[8];
-#pragma unroll
-  for (int f = 0; f < 8; ++f) { acc[f] = 0.0; ismax[f] = f < nfields && fmaxflag[f] != 0; }
-  for (int t = threadIdx.x; t < ntiles; t += 1024) {
-    const double* row = part + (size_t)t * nfields;
-#pragma unroll
-    for (int f = 0; f < 8; ++f)
-      if (f < nfields) { const double v = row[f]; acc[f] = ismax[f] ? fmax(acc[f], v) : acc[f] + v; }
-  }
-#pragma unroll
-  for (int f = 0; f < 8; ++f) {
-    if (f >= nfields) break;
-    double v = acc[f];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, kWave); v = ismax[f] ? fmax(v, o) : v + o; }
-    if (lane == 0) sm[f][wv] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < (unsigned)nfields) {
-    const int f = threadIdx.x;
-    double v = sm[f][0];
-    for (int w = 1; w < 16; ++w) v = ismax[f] ? fmax(v, sm[f][w]) : v + sm[f][w];
-    if (ismax[f]) scal[f2s[f]] = fmax(scal[f2s[f]], v);
-    else scal[f2s[f]] += v;
-  }
+  reduce_tiles_body(ntiles, part, nfields, f2s, fmaxflag, scal, sm);
 }
 
 // Add the LM diagonal to the camera-side blocks (intrinsics + extrinsics) and
 // fold their gradient into the gradient max-norm: S_dd += clamp(colsq_d) / radius.
-__global__ void k_finalize_rcs(DevProblem P, const double* __restrict__ radius_p, double* __restrict__ S,
-                               const double* __restrict__ colsq, const double* __restrict__ gc,
-                               double* __restrict__ scal) {
-  __shared__ double sm[256];
+// One workgroup of 1024 threads; with tile_part it starts with the tile reduction of the linearisation.
+__global__ __launch_bounds__(1024) void k_finalize_rcs(DevProblem P, const double* __restrict__ radius_p, double* __restrict__ S,
+                                                       const double* __restrict__ colsq, const double* __restrict__ gc,
+                                                       double* __restrict__ scal, int ntiles, const double* __restrict__ tile_part,
+                                                       const int* __restrict__ f2s, const int* __restrict__ fmaxflag) {
+  __shared__ double sm[1024];
+  __shared__ double smr[8][16];
+  if (tile_part) reduce_tiles_body(ntiles, tile_part, 4, f2s, fmaxflag, scal, smr);
   const double radius = *radius_p;
   double gmax = 0.0;
   for (int d = threadIdx.x; d < P.n; d += blockDim.x) {
@@ -1559,8 +1535,9 @@ void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const
   k_reduce_tiles<<<1, 1024, 0, st>>>(ntiles, tile_part, nfields, field_to_scal, field_is_max, scal);
 }
 
-void launch_finalize_rcs(const DevProblem& P, const double* radius, const ReduceBuf& rb, hipStream_t st) {
-  k_finalize_rcs<<<1, 256, 0, st>>>(P, radius, rb.S, rb.colsq, rb.gc, rb.scal);
+void launch_finalize_rcs(const DevProblem& P, const double* radius, const ReduceBuf& rb, hipStream_t st, int ntiles,
+                         const double* tile_part, const int* f2s, const int* fmaxflag) {
+  k_finalize_rcs<<<1, 1024, 0, st>>>(P, radius, rb.S, rb.colsq, rb.gc, rb.scal, ntiles, tile_part, f2s, fmaxflag);
 }
 
 void launch_cam_update(const DevProblem& P, const double* cam, const double* y, double* cand_cam,

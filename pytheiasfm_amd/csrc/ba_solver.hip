@@ -69,7 +69,13 @@ struct DevBuf {
   int upload(const std::vector<T>& h, hipStream_t st) {
     int rc = alloc(h.size());
     if (rc) return rc;
-    if (!h.empty()) HIP_TRY(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    // The source is a (usually temporary) pageable vector: the copy must have left it before upload() returns.
+    // An asynchronous copy from pageable memory is normally staged at once, but not reliably when several host
+    // threads load the runtime at the same time (seen as garbage index lists -> GPU memory faults).
+    if (!h.empty()) {
+      HIP_TRY(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
     return 0;
   }
 };
@@ -216,8 +222,8 @@ __device__ void lm_trace(LmState* st, const LmCtl& c, double cost, double g, dou
 // One pass of the TrustRegionMinimizer loop body (ceres trust_region_minimizer.cc; the
 // same rules the host loop of the first versions applied after each read-back):
 // sa = scalars of the linearisation at x, sb = scalars of the trial step.
-__global__ void k_lm_control(LmState* st, const double* __restrict__ sa, const double* __restrict__ sb,
-                             const LmCtl* __restrict__ cp) {
+__device__ void lm_control_body(LmState* st, const double* __restrict__ sa, const double* __restrict__ sb,
+                                const LmCtl* __restrict__ cp) {
   const LmCtl c = *cp;
   double* tg = c.tg; double* tc = c.tc;
   st->accepted = 0;
@@ -278,6 +284,20 @@ __global__ void k_lm_control(LmState* st, const double* __restrict__ sa, const d
   }
   // the iteration cap is known now: no further pass is needed to detect it
   if (st->iter >= c.max_iterations) { st->term = THEIA_TERM_NO_CONVERGENCE; st->done = 1; }
+}
+
+__global__ void k_lm_control(LmState* st, const double* __restrict__ sa, const double* __restrict__ sb,
+                             const LmCtl* __restrict__ cp) {
+  lm_control_body(st, sa, sb, cp);
+}
+// The tile reduction of the trial step (launch_reduce_tiles cfg 1 -> scalB) and the step control in one launch.
+__global__ __launch_bounds__(1024) void k_reduce_control(int ntiles, const double* __restrict__ part,
+                                                         const int* __restrict__ f2s, const int* __restrict__ fmaxflag,
+                                                         LmState* st, const double* __restrict__ sa, double* __restrict__ sb,
+                                                         const LmCtl* __restrict__ cp) {
+  __shared__ double sm[8][16];
+  thip::reduce_tiles_body(ntiles, part, 5, f2s, fmaxflag, sb, sm);
+  if (threadIdx.x == 0) lm_control_body(st, sa, sb, cp);
 }
 
 // |x| over the variable parameter blocks (TrustRegionMinimizer's x_norm at the start):
@@ -517,7 +537,9 @@ int enqueue_linearize(theia_ba_handle_s* h, int slot = 0) {
   if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][4], h->stream));
   launch_linearize(h->P, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->tile_part.p, h->stream);
   if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][5], h->stream));
-  if (h->ntiles_main) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 4, h->f2s.p, h->fmaxflag.p, h->rb.scal, h->stream);
+  // without an all-reduce (and without phase timing) the tile reduction rides in k_finalize_rcs: one launch less
+  const bool fuse_reduce = !h->allreduce && slot < 0 && h->ntiles_main > 0;
+  if (h->ntiles_main && !fuse_reduce) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 4, h->f2s.p, h->fmaxflag.p, h->rb.scal, h->stream);
   launch_long_linearize(h->P, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->long_scratch.p, h->stream);
   launch_cam_priors(h->P, PRIOR_LINEARIZE, h->cam[h->cur].p, nullptr, nullptr, &h->rb, nullptr, h->rb.scal + SC_COST, nullptr, h->stream);
   // one SUM all-reduce of [S | rhs | colsq | gc | scal[0,8)], one MAX of scal[8,16) (folded into the SUM as
@@ -538,12 +560,14 @@ int enqueue_linearize(theia_ba_handle_s* h, int slot = 0) {
   }
   if (!rc && !max_done) rc = do_allreduce(h, h->rb.scal + 8, 8, THEIA_REDUCE_MAX);
   if (rc) return rc;
-  launch_finalize_rcs(h->P, radius, h->rb, h->stream);
+  if (fuse_reduce) launch_finalize_rcs(h->P, radius, h->rb, h->stream, h->ntiles_main, h->tile_part.p, h->f2s.p, h->fmaxflag.p);
+  else launch_finalize_rcs(h->P, radius, h->rb, h->stream);
   return 0;
 }
 
 // enqueue: dense solve, candidate cameras, back-substitution + trial cost.
-int enqueue_solve_and_backsub(theia_ba_handle_s* h, int slot = 0) {
+// defer_reduce: the tile reduction of the trial step is left to k_reduce_control (no all-reduce in between).
+int enqueue_solve_and_backsub(theia_ba_handle_s* h, int slot = 0, bool defer_reduce = false) {
   double* yc = h->rb.rhs;  // the solution overwrites the rhs row
   chol_plan_solve(h->plan, h->rb.S, h->n, h->rb.rhs, h->chol_work.p, h->rb.scal + SC_NOTPD, h->stream);
   if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][2], h->stream));
@@ -551,7 +575,7 @@ int enqueue_solve_and_backsub(theia_ba_handle_s* h, int slot = 0) {
   launch_cam_update(h->P, h->cam[h->cur].p, yc, h->cam[nxt].p, h->ni ? h->intr[nxt].p : nullptr,
                     h->scalB.p + SB_STEPSQ_CAM, h->scalB.p + SB_XNORMSQ_CAM, h->stream, h->scalB.p);
   launch_backsub(h->P, h->cam[h->cur].p, h->pts[h->cur].p, h->cam[nxt].p, h->pts[nxt].p, yc, h->Vinv.p, h->tile_part.p, h->scalB.p, h->stream);
-  if (h->ntiles_main) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 5, h->f2s.p + 8, h->fmaxflag.p + 8, h->scalB.p, h->stream);
+  if (h->ntiles_main && !defer_reduce) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 5, h->f2s.p + 8, h->fmaxflag.p + 8, h->scalB.p, h->stream);
   launch_long_backsub(h->P, h->cam[h->cur].p, h->pts[h->cur].p, h->cam[nxt].p, h->pts[nxt].p, yc, h->Vinv.p, h->long_scratch.p, h->scalB.p, h->stream);
   launch_cam_priors(h->P, PRIOR_TRIAL, h->cam[h->cur].p, h->cam[nxt].p, yc, nullptr, nullptr, h->scalB.p + SB_COST, h->scalB.p + SB_MCC, h->stream);
   return do_allreduce(h, h->scalB.p, 8, THEIA_REDUCE_SUM);
@@ -1266,9 +1290,11 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
     if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][0], h->stream));
     if ((r = enqueue_linearize(h, slot))) return r;
     if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][1], h->stream));
-    if ((r = enqueue_solve_and_backsub(h, slot))) return r;
+    const bool fuse = !h->allreduce && slot < 0 && h->ntiles_main > 0;   // tile reduction inside the control kernel
+    if ((r = enqueue_solve_and_backsub(h, slot, fuse))) return r;
     if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][3], h->stream));
-    k_lm_control<<<1, 1, 0, h->stream>>>(dst, h->rb.scal, h->scalB.p, dctl);
+    if (fuse) k_reduce_control<<<1, 1024, 0, h->stream>>>(h->ntiles_main, h->tile_part.p, h->f2s.p + 8, h->fmaxflag.p + 8, dst, h->rb.scal, h->scalB.p, dctl);
+    else k_lm_control<<<1, 1, 0, h->stream>>>(dst, h->rb.scal, h->scalB.p, dctl);
     k_lm_accept<<<256, 256, 0, h->stream>>>(dst, h->cam[0].p, h->cam[nxt].p, (size_t)6 * h->nc, h->pts[0].p, h->pts[nxt].p,
                                             (size_t)4 * h->np, h->intr[0].p, h->intr[nxt].p, h->ni ? (size_t)THEIA_MAX_INTRINSICS * h->ng : 0);
     return 0;
@@ -1278,7 +1304,11 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   // and replayed: ~45 launches per iteration cost more host time than the GPU needs to run them.
   const bool timing = getenv("THEIA_HIP_PHASE_TIMING") != nullptr;
   const char* genv = getenv("THEIA_HIP_LM_GRAPH");
-  const bool want_graph = !timing && !h->allreduce && !h->graph_failed && !(genv && genv[0] == '0');
+  // hipGraph replay is opt-in (THEIA_HIP_LM_GRAPH=1): it measured no faster than direct launches (the iteration
+  // is bounded by the dependent kernels, not by host enqueue time), and a stream capture in one host thread makes
+  // legacy-stream calls of other threads fail ("would make the legacy stream depend on a capturing blocking
+  // stream") -- the entry points must stay callable concurrently from a thread pool.
+  const bool want_graph = !timing && !h->allreduce && !h->graph_failed && (genv && genv[0] == '1');
   if (want_graph && !h->graph_exec) {
     bool ok = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
     if (ok) {

@@ -28,6 +28,7 @@
 #include "ransac_device.h"
 #include "theia_hip.h"
 #include <atomic>
+#include <mutex>
 #include <thread>
 
 #include "theia_hip_internal.h"
@@ -529,6 +530,15 @@ struct Mt19937 {
 };
 
 // sample_consensus_estimator.h:252-297
+// The minimal-solver kernels need ~11 KB of scratch per lane; the runtime sizes a queue's scratch arena
+// for a full chip of such waves, and two queues asking for it at the same time end in
+// HSA_STATUS_ERROR_OUT_OF_RESOURCES (queue abort).  Calls from several host threads therefore take turns for the
+// launch -> synchronise sections that run those kernels; the host-side parts (sample streams, replay) overlap.
+std::recursive_mutex& scratch_mutex() {
+  static std::recursive_mutex m;
+  return m;
+}
+
 // Host-side loops over independent problems (sample streams, acceptance replay) on a few threads.
 // THEIA_HIP_HOST_THREADS caps the count (default min(hardware threads, 16); 1 = serial).
 template <class F>
@@ -786,6 +796,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     const int nev = (int)evs.size();
     success.assign(nev, 0);
     if (nev == 0) return 0;
+    std::lock_guard<std::recursive_mutex> scratch_lock(scratch_mutex());
     std::vector<int> hp(nev), hs((size_t)nev * 5), hsl(nev), hmod(nev, THEIA_CAM_PINHOLE);
     std::vector<int64_t> hoff(nev + 1, 0);
     std::vector<double> hintr((size_t)nev * THEIA_MAX_INTRINSICS, 0.0);
@@ -869,6 +880,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       HIP_TRYR(hipMemsetAsync(d_dense.p, 0, sizeof(int) * cn, st));
       HIP_TRYR(hipMemcpyAsync(d_samples.p, h_samples.data(), sizeof(int) * nh * m, hipMemcpyHostToDevice, st));
       HIP_TRYR(hipMemcpyAsync(d_active.p, h_active.data(), sizeof(int) * cn, hipMemcpyHostToDevice, st));
+      std::unique_lock<std::recursive_mutex> scratch_lock(scratch_mutex());
       HIP_TRYR(hipEventRecord(ev0, st));
       {
         dim3 grid((B + 63) / 64, cn);
@@ -904,6 +916,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       HIP_TRYR(hipMemcpyAsync(h_ninl.data(), d_ninl.p, sizeof(int) * nh * kMaxModels, hipMemcpyDeviceToHost, st));
       HIP_TRYR(hipGetLastError());
       HIP_TRYR(hipStreamSynchronize(st));
+      scratch_lock.unlock();
       { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) fit_score_ms += ms; }
       // sequential replay of the acceptance rules (sample_consensus_estimator.h:330-394).  With
       // use_lo a problem pauses at each RefineModel event; the events of all problems are refined
@@ -985,11 +998,13 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   if ((rc = d_best_samples.ensure((size_t)nprob * kMaxSample)) || (rc = d_best_slot.ensure(nprob)) ||
       (rc = d_best_models.ensure((size_t)nprob * kStride)) || (rc = d_mask.ensure((size_t)total)))
     return rc;
+  std::lock_guard<std::recursive_mutex> final_scratch_lock(scratch_mutex());
   HIP_TRYR(hipMemcpyAsync(d_best_samples.p, best_samples_all.data(), sizeof(int) * nprob * kMaxSample, hipMemcpyHostToDevice, st));
   HIP_TRYR(hipMemcpyAsync(d_best_slot.p, best_slot_all.data(), sizeof(int) * nprob, hipMemcpyHostToDevice, st));
   k_refit<<<(nprob + 63) / 64, 64, 0, st>>>(est, nprob, d_off.p, d_data.p, d_best_samples.p, d_best_slot.p, d_best_models.p, ep);
+  std::vector<int> use_cur;   // source of an asynchronous upload: lives until the final synchronisation
   if (P.use_lo) {   // the best model of a problem may be the refined pose of its last LO event
-    std::vector<int> use_cur(nprob);
+    use_cur.resize(nprob);
     for (int p = 0; p < nprob; ++p) use_cur[p] = (S[p].best_refined && S[p].best_slot >= 0) ? 1 : 0;
     if ((rc = d_ev_slot.ensure(nprob))) return rc;
     HIP_TRYR(hipMemcpyAsync(d_ev_slot.p, use_cur.data(), sizeof(int) * nprob, hipMemcpyHostToDevice, st));
@@ -1032,6 +1047,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
 }
 
 int theia_hip_five_point_relative_pose(int32_t num, const double* corr, double* essential_matrices, int32_t* num_solutions) {
+  std::lock_guard<std::recursive_mutex> scratch_lock(scratch_mutex());
   if (num < 0 || (num > 0 && (!corr || !essential_matrices || !num_solutions))) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
   if (num == 0) return 0;
   int rc = ensure_device();
@@ -1046,6 +1062,7 @@ int theia_hip_five_point_relative_pose(int32_t num, const double* corr, double* 
 }
 
 int theia_hip_pose_from_three_points(int32_t num, const double* corr2d3d, double* rotations, double* translations, int32_t* num_solutions) {
+  std::lock_guard<std::recursive_mutex> scratch_lock(scratch_mutex());
   if (num < 0 || (num > 0 && (!corr2d3d || !rotations || !translations || !num_solutions))) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
   if (num == 0) return 0;
   int rc = ensure_device();
@@ -1062,6 +1079,7 @@ int theia_hip_pose_from_three_points(int32_t num, const double* corr2d3d, double
 
 int theia_hip_sqpnp(int32_t num, const int64_t* offsets, const double* features, const double* world_points,
                     double* quaternions, double* translations, int32_t* num_solutions) {
+  std::lock_guard<std::recursive_mutex> scratch_lock(scratch_mutex());
   if (num < 0 || (num > 0 && (!offsets || !features || !world_points || !quaternions || !translations || !num_solutions)))
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
   if (num == 0) return 0;

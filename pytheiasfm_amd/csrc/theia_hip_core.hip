@@ -1,6 +1,10 @@
 // theia_hip_core.hip -- device selection, error reporting, version.
 #include <hip/hip_runtime.h>
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include <atomic>
 #include <cstring>
 
@@ -58,5 +62,20 @@ int theia_hip_device_count(int* count) {
 const char* theia_hip_last_error(void) { return thip::g_last_error.c_str(); }
 
 const char* theia_hip_version(void) { return "pytheiasfm_amd 0.1.0 (gfx950)"; }
+
+// Development aid (THEIA_HIP_ABORT_TRACE=1 in pytheiasfm_amd/_capi.py): native backtrace on SIGABRT / SIGSEGV.
+static void thip_abort_trace(int sig) {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "theia_hip: fatal signal, native backtrace:\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+void theia_hip_debug_install_abort_trace(void) {
+  signal(SIGABRT, thip_abort_trace);
+  signal(SIGSEGV, thip_abort_trace);
+}
 
 }  // extern "C"
