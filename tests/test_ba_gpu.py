@@ -871,7 +871,22 @@ def test_entry_points_are_reentrant_across_host_threads():
         except Exception as e:   # noqa: BLE001
             errs.append(e)
 
-    th = [threading.Thread(target=ba_worker, args=(k,)) for k in range(4)] + [threading.Thread(target=ransac_worker, args=(k,)) for k in range(2)]
+    # the batched per-track entry points as well (they run on the legacy stream)
+    tp = synth.synth_ba_v1(12, 500, seed=0x7EAD20)
+    tb_ref = tp.copy(); ba.solve_tracks_batch(tb_ref, o)
+    st_ref = ba.track_statistics(tp)
+    tb_out = [None] * 2
+
+    def track_worker(k):
+        try:
+            for _ in range(3):
+                q = tp.copy(); ba.solve_tracks_batch(q, o)
+                tb_out[k] = (q.points.copy(), ba.track_statistics(tp))
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    th = ([threading.Thread(target=ba_worker, args=(k,)) for k in range(4)] + [threading.Thread(target=ransac_worker, args=(k,)) for k in range(2)]
+          + [threading.Thread(target=track_worker, args=(k,)) for k in range(2)])
     for t in th: t.start()
     for t in th: t.join()
     assert not errs, errs
@@ -880,6 +895,8 @@ def test_entry_points_are_reentrant_across_host_threads():
         assert np.array_equal(out[k][2], ref[k][2]) and np.array_equal(out[k][3], ref[k][3])
     for k in range(2):
         assert np.array_equal(rout[k]["inlier_mask"], rref["inlier_mask"]) and np.array_equal(rout[k]["num_iterations"], rref["num_iterations"])
+        assert np.array_equal(tb_out[k][0], tb_ref.points)
+        assert all(np.array_equal(x, y) for x, y in zip(tb_out[k][1], st_ref))
 
 
 def test_select_good_tracks_for_bundle_adjustment_mirror():
