@@ -76,7 +76,7 @@ def algorithmic_bytes_linearize(p):
 
 def pmc_traffic_bytes(world):
     """HBM-side bytes per launch of the roofline kernel group, from the committed
-    rocprofv3 PMC passes of this same command (profiles/r1w_pmc_*.csv; FETCH_SIZE
+    rocprofv3 PMC passes of this same command (profiles/r1x_pmc_*.csv; FETCH_SIZE
     and WRITE_SIZE collected in separate passes, KB; the 16-B/lane record gathers
     of k_schur doubled per the gfx950 FETCH_SIZE note of MI355X_MICROARCH.md).
     None when the files are absent or the run is not the profiled N=1 workload."""
@@ -87,7 +87,7 @@ def pmc_traffic_bytes(world):
     try:
         kb = {}
         for tag in ("fetch_size", "write_size"):
-            with open(os.path.join(base, "r1w_pmc_%s.csv" % tag)) as f:
+            with open(os.path.join(base, "r1x_pmc_%s.csv" % tag)) as f:
                 for row in csv.reader(f):
                     if row and row[0] != "kernel":
                         kb[(tag, row[0])] = float(row[2])
