@@ -151,11 +151,23 @@ __device__ __forceinline__ void reduce_tiles_body(int ntiles, const double* __re
   bool ismax[8];
 #pragma unroll
   for (int f = 0; f < 8; ++f) { acc[f] = 0.0; ismax[f] = f < nfields && fmaxflag[f] != 0; }
-  for (int t = threadIdx.x; t < ntiles; t += 1024) {
-    const double* row = part + (size_t)t * nfields;
+  // four tiles per thread and step, all loads (clamped, unconditional) in flight before the first use;
+  // the accumulation order of a thread is unchanged (t, t + 1024, t + 2048, ...)
+  for (int t0 = threadIdx.x; t0 < ntiles; t0 += 4096) {
+    double v[4][8];
 #pragma unroll
-    for (int f = 0; f < 8; ++f)
-      if (f < nfields) { const double v = row[f]; acc[f] = ismax[f] ? fmax(acc[f], v) : acc[f] + v; }
+    for (int u = 0; u < 4; ++u) {
+      const double* row = part + (size_t)min(t0 + 1024 * u, ntiles - 1) * nfields;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) v[u][f] = row[min(f, nfields - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (t0 + 1024 * u >= ntiles) break;
+#pragma unroll
+      for (int f = 0; f < 8; ++f)
+        if (f < nfields) acc[f] = ismax[f] ? fmax(acc[f], v[u][f]) : acc[f] + v[u][f];
+    }
   }
 #pragma unroll
   for (int f = 0; f < 8; ++f) {
