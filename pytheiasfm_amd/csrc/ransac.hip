@@ -686,9 +686,12 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     return set_error(THEIA_HIP_ERR_UNSUPPORTED, "the DLS minimal solver has no HIP kernel yet");
   if (est < 0 || est > THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
   const bool abs_pose = est == THEIA_EST_ABSOLUTE_POSE_KNEIP || est == THEIA_EST_ABSOLUTE_POSE_SQPNP;
-  if (P.use_lo && !abs_pose)
-    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: only the absolute-pose RefineModel (BundleAdjustView) is built; "
-                     "the relative-pose one (BundleAdjustTwoViewsAngular) is not yet");
+  // estimators that keep Estimator::RefineModel's default "return true" (solvers/estimator.h:86-88): LO only counts
+  const bool trivial_refine = est == THEIA_EST_ESSENTIAL_MATRIX || est == THEIA_EST_DOMINANT_PLANE ||
+                              est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION || est == THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION;
+  if (P.use_lo && !abs_pose && !trivial_refine)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: only the absolute-pose RefineModel (BundleAdjustView) and the trivial ones are "
+                     "built; the BA-based RefineModels of the relative-pose / fundamental / homography estimators are not yet");
   // exhaustive_sampler.cc:49-51 CHECK
   if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE && sample_size(est) != 2)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "ExhaustiveSampler makes a hard assumption that the number of samples needed is 2.");
@@ -953,7 +956,9 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
                 s.best_refined = false;
                 for (int i = 0; i < m; ++i) s.best_samples[i] = h_samples[hyp * m + i];
                 if (inlier_ratio < m / (double)s.n) continue;
-                if (P.use_lo && s.base_it + s.rb >= P.lo_start_iterations) {   // :373-381
+                if (P.use_lo && trivial_refine && s.base_it + s.rb >= P.lo_start_iterations) {
+                  s.num_lo++;   // RefineModel = "return true": nothing changes but the counter
+                } else if (P.use_lo && s.base_it + s.rb >= P.lo_start_iterations) {   // :373-381
                   LoEvent ev; ev.prob = c0 + q; ev.slot = j;
                   for (int i = 0; i < 5; ++i) ev.samples[i] = s.best_samples[i];
                   events.push_back(ev); ev_q.push_back(q);
@@ -1003,7 +1008,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   HIP_TRYR(hipMemcpyAsync(d_best_slot.p, best_slot_all.data(), sizeof(int) * nprob, hipMemcpyHostToDevice, st));
   k_refit<<<(nprob + 63) / 64, 64, 0, st>>>(est, nprob, d_off.p, d_data.p, d_best_samples.p, d_best_slot.p, d_best_models.p, ep);
   std::vector<int> use_cur;   // source of an asynchronous upload: lives until the final synchronisation
-  if (P.use_lo) {   // the best model of a problem may be the refined pose of its last LO event
+  if (P.use_lo && !trivial_refine) {   // the best model of a problem may be the refined pose of its last LO event
     use_cur.resize(nprob);
     for (int p = 0; p < nprob; ++p) use_cur[p] = (S[p].best_refined && S[p].best_slot >= 0) ? 1 : 0;
     if ((rc = d_ev_slot.ensure(nprob))) return rc;
@@ -1016,7 +1021,9 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     dim3 grid((nmax + 255) / 256, nprob);
     k_inlier_mask<<<grid, 256, 0, st>>>(est, nprob, d_off.p, d_data.p, d_best_models.p, P.error_thresh, d_mask.p);
   }
-  if (P.use_lo) {   // sample_consensus_estimator.h:401-406: one more RefineModel on the final inliers (result unused)
+  if (P.use_lo && trivial_refine) {   // :401-406 with RefineModel = "return true": the counter only
+    for (int p = 0; p < nprob; ++p) if (S[p].best_slot >= 0) S[p].num_lo++;
+  } else if (P.use_lo) {   // sample_consensus_estimator.h:401-406: one more RefineModel on the final inliers (result unused)
     HIP_TRYR(hipMemcpyAsync(d_cur_models.p, d_best_models.p, sizeof(double) * nprob * kStride, hipMemcpyDeviceToDevice, st));
     std::vector<LoEvent> evs;
     for (int p = 0; p < nprob; ++p)

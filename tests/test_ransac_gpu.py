@@ -422,3 +422,22 @@ def test_golden_ransac_estimators_on_gpu():
                 assert np.allclose(res["models"][:, :mlen], g[f"{kind}_t{rtype}_models"], rtol=1e-9, atol=1e-12)
             else:
                 assert np.array_equal(res["models"][:, :mlen], g[f"{kind}_t{rtype}_models"])
+
+
+@pytest.mark.parametrize("kind,est,thresh", [("relative", 1, (2 / 1000.0) ** 2), ("plane", 7, 0.004),
+                                             ("known_orientation", 8, (2 / 1000.0) ** 2)])
+def test_lo_with_default_refine_model_only_counts(kind, est, thresh):
+    """Estimators that keep Estimator::RefineModel's default "return true" (solvers/estimator.h:86-88): with use_lo
+    the run is the plain one, num_lo_iterations counts the accepted improvements after lo_start_iterations + 1."""
+    data, offsets, _ = synth.synth_ransac_v1(4, 300, kind, seed=0x5AC53000 + est, inlier_lo=0.5, inlier_hi=0.7)
+    p = ransac.RansacParameters(); p.error_thresh = thresh; p.seed = 23
+    plain = ransac.estimate_batch(est, data, offsets, p)
+    p.use_lo = True; p.lo_start_iterations = 5
+    lo = ransac.estimate_batch(est, data, offsets, p)
+    assert np.array_equal(lo["inlier_mask"], plain["inlier_mask"]) and np.array_equal(lo["num_iterations"], plain["num_iterations"])
+    assert np.array_equal(lo["models"], plain["models"]) and np.all(lo["num_lo_iterations"] >= 1)
+    for i in range(4):
+        pc = p.to_c(); pc.seed = 23 + i
+        o = ol.ransac_estimate(est, data[offsets[i]:offsets[i + 1]], pc)
+        assert o["num_iterations"] == lo["num_iterations"][i] and np.array_equal(o["inlier_mask"], lo["inlier_mask"][offsets[i]:offsets[i + 1]])
+        assert ol.rlib().oracle_last_lo_iterations() == lo["num_lo_iterations"][i]
