@@ -247,6 +247,26 @@ int theia_hip_ba_views_batch(const theia_ba_view_batch* batch,
                              const theia_ba_options* options,
                              theia_ba_summary* summaries);
 
+/* A batch of INDEPENDENT two-view angular adjustments: problem i refines the relative
+ * rotation (angle-axis) and the unit position of view 2 against the angular epipolar
+ * error of its correspondences [offsets[i], offsets[i+1]), i.e. N calls of
+ * BundleAdjustTwoViewsAngular(options, correspondences, &info)
+ * (bundle_adjust_two_views.cc:189-246, residual angular_epipolar_error.h:54-91, bound at
+ * src/pytheia/sfm/sfm.cc:1620) -- also RefineModel of the relative-pose estimator
+ * (estimate_relative_pose.cc:111-138).  The position moves on SphereManifold<3>; the
+ * linear solver is the caller's CGNR + JACOBI (inexact steps, Ceres' q-tolerance rule).
+ * Honoured options: loss type / width, max_num_iterations, the three tolerances,
+ * max_trust_region_radius.  Normalised image coordinates. */
+typedef struct theia_ba_two_view_batch {
+  int32_t num_problems;
+  const int64_t* offsets;          /* [num_problems+1], offsets[0] = 0                      */
+  const double* correspondences;   /* [total][4] = (x1, y1, x2, y2)                          */
+  double* rotation_position;       /* [num_problems][6] in/out: TwoViewInfo::rotation_2 | position_2 */
+} theia_ba_two_view_batch;
+int theia_hip_ba_two_views_angular_batch(const theia_ba_two_view_batch* batch,
+                                         const theia_ba_options* options,
+                                         theia_ba_summary* summaries);
+
 /* Every point of `problem` as its OWN problem with all cameras constant: N calls of
  * BundleAdjustTrack(options, track_id, reconstruction) (bundle_adjustment.cc:262-285; the
  * per-track refinement after triangulation, estimate_track.cc:289) in one launch, one thread
@@ -374,7 +394,9 @@ typedef struct theia_ransac_params {
   int32_t min_iterations;
   int32_t max_iterations;
   int32_t use_mle;
-  int32_t use_lo;              /* accepted; LO refinement is a "next" row */
+  int32_t use_lo;              /* LO-RANSAC: RefineModel of the absolute-pose (BundleAdjustView) and relative-pose
+                                  (BundleAdjustTwoViewsAngular) estimators as device batches, the default "return
+                                  true" of the others; fundamental / homography / uncalibrated: ERR_UNSUPPORTED */
   int32_t lo_start_iterations;
   int32_t use_Tdd_test;        /* reference: "Not currently implemented"  */
   uint32_t seed;               /* seeds the mt19937 stream (util/random.cc:60-66),

@@ -1250,3 +1250,319 @@ int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
 }
 
 }  // extern "C"
+
+// ============================================================ two views, angular epipolar error
+// BundleAdjustTwoViewsAngular (bundle_adjust_two_views.cc:189-246) as RefineModel of the relative-pose
+// estimator calls it (estimate_relative_pose.cc:111-138): parameter blocks rotation_2 (3) and position_2
+// (3, SphereManifold<3>), one AngularEpipolarError residual (angular_epipolar_error.h:54-91) per
+// correspondence under one loss, TRUST_REGION / LEVENBERG_MARQUARDT with linear_solver_type CGNR and the
+// JACOBI preconditioner.  Ceres is not under /root/reference: CgnrSolver / ConjugateGradientsSolver /
+// BlockSparseJacobiPreconditioner are restated from the published 2.2 sources (cgnr_solver.cc,
+// conjugate_gradients_solver.h, block_random_access_diagonal_matrix.cc: Invert = llt().solve(I)).
+// Inner iterations are not restated (as everywhere in this oracle).
+namespace {
+
+template <typename T>
+inline void angle_axis_to_rotation_matrix(const T aa[3], T R[9]) {   // ceres/rotation.h; R(i, j) = R[3 i + j]
+  const T theta2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+  if (theta2 > std::numeric_limits<double>::epsilon()) {
+    const T theta = jsqrt(theta2);
+    const T wx = aa[0] / theta, wy = aa[1] / theta, wz = aa[2] / theta;
+    const T costheta = jcos(theta), sintheta = jsin(theta);
+    R[0] = costheta + wx * wx * (1.0 - costheta);
+    R[3] = wz * sintheta + wx * wy * (1.0 - costheta);
+    R[6] = -wy * sintheta + wx * wz * (1.0 - costheta);
+    R[1] = wx * wy * (1.0 - costheta) - wz * sintheta;
+    R[4] = costheta + wy * wy * (1.0 - costheta);
+    R[7] = wx * sintheta + wy * wz * (1.0 - costheta);
+    R[2] = wy * sintheta + wx * wz * (1.0 - costheta);
+    R[5] = -wx * sintheta + wy * wz * (1.0 - costheta);
+    R[8] = costheta + wz * wz * (1.0 - costheta);
+  } else {
+    R[0] = T(1.0); R[3] = aa[2]; R[6] = -aa[1];
+    R[1] = -aa[2]; R[4] = T(1.0); R[7] = aa[0];
+    R[2] = aa[1]; R[5] = -aa[0]; R[8] = T(1.0);
+  }
+}
+
+template <typename T>
+inline T dot3t(const T* a, const T* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+// AngularEpipolarError::operator() -- always "true"; 1000 when the square root would be imaginary
+template <typename T>
+inline T angular_epipolar_error(const T rotation[3], const T translation[3], const double* c) {
+  const T f1[3] = {T(c[0]), T(c[1]), T(1.0)}, f2[3] = {T(c[2]), T(c[3]), T(1.0)};
+  T R[9];
+  angle_axis_to_rotation_matrix(rotation, R);
+  T M[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) M[3 * i + j] = T(i == j ? 1.0 : 0.0) - translation[i] * translation[j];
+  T u[3], w[3], Mf1[3], Mw[3];
+  for (int i = 0; i < 3; ++i) u[i] = (R[3 * i] * f2[0] + R[3 * i + 1] * f2[1]) + R[3 * i + 2] * f2[2];
+  for (int i = 0; i < 3; ++i) w[i] = (R[i] * f2[0] + R[3 + i] * f2[1]) + R[6 + i] * f2[2];
+  for (int i = 0; i < 3; ++i) Mf1[i] = (M[3 * i] * f1[0] + M[3 * i + 1] * f1[1]) + M[3 * i + 2] * f1[2];
+  for (int i = 0; i < 3; ++i) Mw[i] = (M[3 * i] * w[0] + M[3 * i + 1] * w[1]) + M[3 * i + 2] * w[2];
+  const T a = dot3t(f1, Mf1) + dot3t(u, Mw);
+  const T cr[3] = {f1[1] * w[2] - f1[2] * w[1], f1[2] * w[0] - f1[0] * w[2], f1[0] * w[1] - f1[1] * w[0]};
+  const T b_sqrt = dot3t(translation, cr);
+  const T sqrt_term = (a * a) / 4.0 - b_sqrt * b_sqrt;
+  if (sqrt_term < 0.0) return T(1000.0);
+  return a / 2.0 - jsqrt(sqrt_term);
+}
+
+inline void householder3(const double x[3], double v[3], double* beta) {
+  const double sigma = x[0] * x[0] + x[1] * x[1];
+  v[0] = x[0]; v[1] = x[1]; v[2] = 1.0;
+  *beta = 0.0;
+  if (sigma <= std::numeric_limits<double>::epsilon()) { if (x[2] < 0.0) *beta = 2.0; return; }
+  const double mu = std::sqrt(x[2] * x[2] + sigma);
+  const double v_pivot = (x[2] <= 0.0) ? x[2] - mu : -sigma / (x[2] + mu);
+  *beta = 2.0 * v_pivot * v_pivot / (sigma + v_pivot * v_pivot);
+  v[0] /= v_pivot; v[1] /= v_pivot;
+}
+inline void sphere3_plus(const double x[3], const double d[2], double out[3]) {
+  const double nd = std::sqrt(d[0] * d[0] + d[1] * d[1]);
+  if (nd == 0.0) { for (int i = 0; i < 3; ++i) out[i] = x[i]; return; }
+  double v[3], beta; householder3(x, v, &beta);
+  const double nx = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  const double sbd = std::sin(nd) / nd;
+  const double y[3] = {sbd * d[0], sbd * d[1], std::cos(nd)};
+  const double vty = v[0] * y[0] + v[1] * y[1] + v[2] * y[2];
+  for (int i = 0; i < 3; ++i) out[i] = nx * (y[i] - v[i] * (beta * vty));
+}
+inline void sphere3_plus_jacobian(const double x[3], double J[6]) {
+  double v[3], beta; householder3(x, v, &beta);
+  const double nx = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 2; ++c) J[r * 2 + c] = nx * ((r == c ? 1.0 : 0.0) - beta * v[r] * v[c]);
+}
+
+struct TwoViewLin {
+  std::vector<double> J;   // n x 5, loss-corrected, column-scaled
+  std::vector<double> r;   // n, loss-corrected
+  double g[5];             // J_unscaled' r
+  double colsq[5];         // squared column norms of the loss-corrected UNSCALED Jacobian
+  double cost;
+};
+
+inline double two_view_cost(int64_t n, const double* corr, int loss_type, double loss_width, const double x[6]) {
+  double cost = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    const double r = angular_epipolar_error<double>(x, x + 3, corr + 4 * i);
+    double rho[3]; loss_evaluate(loss_type, loss_width, r * r, rho);
+    cost += 0.5 * rho[0];
+  }
+  return cost;
+}
+
+inline void two_view_linearize(int64_t n, const double* corr, int loss_type, double loss_width, const double x[6],
+                               const double* scale, TwoViewLin& L) {
+  typedef Jet<6> J6;
+  L.J.assign((size_t)n * 5, 0.0); L.r.assign(n, 0.0); L.cost = 0.0;
+  for (int q = 0; q < 5; ++q) { L.g[q] = 0.0; L.colsq[q] = 0.0; }
+  double PJ[6]; sphere3_plus_jacobian(x + 3, PJ);
+  J6 rot[3], tr[3];
+  for (int q = 0; q < 3; ++q) { rot[q] = J6(x[q], q); tr[q] = J6(x[3 + q], 3 + q); }
+  for (int64_t i = 0; i < n; ++i) {
+    const J6 e = angular_epipolar_error<J6>(rot, tr, corr + 4 * i);
+    double rho[3]; loss_evaluate(loss_type, loss_width, e.a * e.a, rho);
+    const double sr = std::sqrt(rho[1]);
+    L.cost += 0.5 * rho[0];
+    double j[5];
+    for (int q = 0; q < 3; ++q) j[q] = e.v[q];
+    for (int q = 0; q < 2; ++q) j[3 + q] = (e.v[3] * PJ[q] + e.v[4] * PJ[2 + q]) + e.v[5] * PJ[4 + q];
+    const double rr = sr * e.a;
+    L.r[i] = rr;
+    for (int q = 0; q < 5; ++q) {
+      const double ju = sr * j[q];
+      L.g[q] += ju * rr; L.colsq[q] += ju * ju;
+      L.J[(size_t)i * 5 + q] = ju * scale[q];
+    }
+  }
+}
+
+inline bool zero_or_inf(double v) { return v == 0.0 || std::isinf(v); }
+
+inline void spd_inverse(int n, const double* A, double* Ai) {   // llt().solve(Identity)
+  double Lm[9];
+  for (int j = 0; j < n; ++j) {
+    double s = A[j * n + j];
+    for (int k = 0; k < j; ++k) s -= Lm[j * n + k] * Lm[j * n + k];
+    const double d = std::sqrt(s);
+    Lm[j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double v = A[i * n + j];
+      for (int k = 0; k < j; ++k) v -= Lm[i * n + k] * Lm[j * n + k];
+      Lm[i * n + j] = v / d;
+    }
+  }
+  for (int c = 0; c < n; ++c) {
+    double z[3];
+    for (int i = 0; i < n; ++i) {
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int k = 0; k < i; ++k) s -= Lm[i * n + k] * z[k];
+      z[i] = s / Lm[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double s = z[i];
+      for (int k = i + 1; k < n; ++k) s -= Lm[k * n + i] * Ai[k * n + c];
+      Ai[i * n + c] = s / Lm[i * n + i];
+    }
+  }
+}
+
+// y ~ argmin |J y - r|^2 + |D y|^2 by preconditioned CG on the normal equations; false = FAILURE
+inline bool cgnr_solve(int64_t n, const std::vector<double>& J, const std::vector<double>& res, const double* D2, double* y) {
+  auto Amul = [&](const double* v, double* o) {   // CgnrLinearOperator: J'(J v) + D^2 v
+    for (int q = 0; q < 5; ++q) o[q] = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+      const double* row = &J[(size_t)i * 5];
+      double z = 0.0;
+      for (int q = 0; q < 5; ++q) z += row[q] * v[q];
+      for (int q = 0; q < 5; ++q) o[q] += row[q] * z;
+    }
+    for (int q = 0; q < 5; ++q) o[q] += D2[q] * v[q];
+  };
+  double b[5] = {0, 0, 0, 0, 0};
+  for (int64_t i = 0; i < n; ++i) for (int q = 0; q < 5; ++q) b[q] += J[(size_t)i * 5 + q] * res[i];
+  for (int q = 0; q < 5; ++q) y[q] = 0.0;
+  double nb = 0.0;
+  for (int q = 0; q < 5; ++q) nb += b[q] * b[q];
+  if (std::sqrt(nb) == 0.0) return true;
+  double B3[9] = {0}, B2[4] = {0}, I3[9], I2[4];
+  for (int64_t i = 0; i < n; ++i) {
+    const double* row = &J[(size_t)i * 5];
+    for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) B3[a * 3 + c] += row[a] * row[c];
+    for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) B2[a * 2 + c] += row[3 + a] * row[3 + c];
+  }
+  for (int a = 0; a < 3; ++a) B3[a * 3 + a] += D2[a];
+  for (int a = 0; a < 2; ++a) B2[a * 2 + a] += D2[3 + a];
+  spd_inverse(3, B3, I3);
+  spd_inverse(2, B2, I2);
+  double r[5], z[5], pv[5], qv[5], tmp[5];
+  for (int q = 0; q < 5; ++q) r[q] = b[q];
+  double rho = 1.0, Q0 = -0.0;
+  for (int it = 1;; ++it) {
+    for (int a = 0; a < 3; ++a) z[a] = (I3[a * 3] * r[0] + I3[a * 3 + 1] * r[1]) + I3[a * 3 + 2] * r[2];
+    for (int a = 0; a < 2; ++a) z[3 + a] = I2[a * 2] * r[3] + I2[a * 2 + 1] * r[4];
+    const double last_rho = rho;
+    rho = 0.0;
+    for (int q = 0; q < 5; ++q) rho += r[q] * z[q];
+    if (zero_or_inf(rho)) return false;
+    if (it == 1) { for (int q = 0; q < 5; ++q) pv[q] = z[q]; }
+    else {
+      const double beta = rho / last_rho;
+      if (zero_or_inf(beta)) return false;
+      for (int q = 0; q < 5; ++q) pv[q] = z[q] + beta * pv[q];
+    }
+    Amul(pv, qv);
+    double pq = 0.0;
+    for (int q = 0; q < 5; ++q) pq += pv[q] * qv[q];
+    if (pq <= 0.0 || std::isinf(pq)) return true;   // NO_CONVERGENCE ("matrix is indefinite"): usable
+    const double alpha = rho / pq;
+    if (std::isinf(alpha)) return false;
+    for (int q = 0; q < 5; ++q) y[q] = y[q] + alpha * pv[q];
+    if (it % 10 == 0) { Amul(y, tmp); for (int q = 0; q < 5; ++q) r[q] = b[q] - tmp[q]; }
+    else { for (int q = 0; q < 5; ++q) r[q] = r[q] - alpha * qv[q]; }
+    double Q1 = 0.0;
+    for (int q = 0; q < 5; ++q) Q1 += y[q] * (b[q] + r[q]);
+    Q1 = -Q1;
+    const double zeta = it * (Q1 - Q0) / Q1;
+    if (zeta < 0.1) return true;
+    Q0 = Q1;
+    if (it >= 500) return true;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// pose = rotation_2 | position_2 (in/out); out_int = {success, termination, iterations, successful steps};
+// out_cost = {initial, final}
+int oracle_two_views_angular(int64_t n, const double* corr, int loss_type, double loss_width, int max_num_iterations,
+                             double function_tolerance, double gradient_tolerance, double parameter_tolerance,
+                             double max_trust_region_radius, double* pose, int* out_int, double* out_cost) {
+  double x[6];
+  for (int q = 0; q < 6; ++q) x[q] = pose[q];
+  double scale[5] = {1, 1, 1, 1, 1};
+  TwoViewLin L;
+  two_view_linearize(n, corr, loss_type, loss_width, x, scale, L);
+  for (int q = 0; q < 5; ++q) scale[q] = 1.0 / (1.0 + std::sqrt(L.colsq[q]));
+  double radius = 1e4, decrease_factor = 2.0;
+  bool step_successful = true, need_linearize = true, first = true;
+  int iter = 0, invalid_steps = 0, term = 1, nsucc = 0;
+  double x_norm = 0.0, minimum_cost = 0.0, gmax = 0.0, x_cost = 0.0, initial_cost = 0.0;
+  for (int q = 0; q < 6; ++q) x_norm += x[q] * x[q];
+  x_norm = std::sqrt(x_norm);
+  while (true) {
+    if (need_linearize) {
+      two_view_linearize(n, corr, loss_type, loss_width, x, scale, L);
+      x_cost = L.cost;
+      double ng[5], xp[3];
+      for (int q = 0; q < 5; ++q) ng[q] = -L.g[q];
+      sphere3_plus(x + 3, ng + 3, xp);
+      gmax = 0.0;
+      for (int q = 0; q < 3; ++q) gmax = std::max(gmax, std::max(std::fabs(x[q] - (x[q] + ng[q])), std::fabs(x[3 + q] - xp[q])));
+      need_linearize = false;
+    }
+    if (first) {
+      first = false;
+      initial_cost = minimum_cost = x_cost;
+      if (!std::isfinite(x_cost)) { term = 2; break; }
+    }
+    if (iter >= max_num_iterations) { term = 1; break; }
+    if (step_successful && gmax <= gradient_tolerance) { term = 0; break; }
+    if (radius <= 1e-32) { term = 0; break; }
+    ++iter;
+    double d[5], y[5];
+    for (int q = 0; q < 5; ++q) d[q] = std::min(std::max(L.colsq[q] * scale[q] * scale[q], 1e-6), 1e32) / radius;
+    const bool solved = cgnr_solve(n, L.J, L.r, d, y);
+    // model_cost_change = -m'(r + m/2), m = J (-y)
+    double mcc = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+      double m = 0.0;
+      for (int q = 0; q < 5; ++q) m -= L.J[(size_t)i * 5 + q] * y[q];
+      mcc -= m * (L.r[i] + m / 2.0);
+    }
+    double cand[6], dl[5], stepsq = 0.0, xnormsq = 0.0;
+    for (int q = 0; q < 5; ++q) dl[q] = -y[q] * scale[q];
+    for (int q = 0; q < 3; ++q) cand[q] = x[q] + dl[q];
+    sphere3_plus(x + 3, dl + 3, cand + 3);
+    for (int q = 0; q < 6; ++q) { stepsq += (x[q] - cand[q]) * (x[q] - cand[q]); xnormsq += cand[q] * cand[q]; }
+    const bool step_valid = solved && std::isfinite(mcc) && std::isfinite(stepsq) && mcc > 0.0;
+    if (!step_valid) {
+      if (++invalid_steps >= 5) { term = 2; break; }
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+      continue;
+    }
+    invalid_steps = 0;
+    double cand_cost = two_view_cost(n, corr, loss_type, loss_width, cand);
+    if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+    const double step_norm = std::sqrt(stepsq);
+    if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) { term = 0; break; }
+    const double cost_change = x_cost - cand_cost;
+    if (std::fabs(cost_change) <= function_tolerance * x_cost) { term = 0; break; }
+    const double relative_decrease = cost_change / mcc;
+    if (relative_decrease > 1e-3) {
+      for (int q = 0; q < 6; ++q) x[q] = cand[q];
+      x_norm = std::sqrt(xnormsq);
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3));
+      radius = std::min(max_trust_region_radius, radius);
+      decrease_factor = 2.0; step_successful = true; need_linearize = true;
+      nsucc++;
+      if (cand_cost < minimum_cost) minimum_cost = cand_cost;
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+    }
+  }
+  for (int q = 0; q < 6; ++q) pose[q] = x[q];
+  out_int[0] = term != 2; out_int[1] = term; out_int[2] = iter; out_int[3] = nsucc;
+  out_cost[0] = initial_cost; out_cost[1] = term != 2 ? minimum_cost : x_cost;
+  return 0;
+}
+
+double oracle_angular_epipolar_error(const double* rotation, const double* position, const double* corr) {
+  return angular_epipolar_error<double>(rotation, position, corr);
+}
+
+}  // extern "C"

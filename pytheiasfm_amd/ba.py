@@ -189,6 +189,29 @@ def solve_views_batch(offsets, obs_uv, points, cam_ext, intrinsics, model, optio
     return [summ[i] for i in range(num)]
 
 
+def solve_two_views_angular_batch(offsets, correspondences, rotation_position, options):
+    """theia_hip_ba_two_views_angular_batch: N independent BundleAdjustTwoViewsAngular problems
+    (bundle_adjust_two_views.cc:189-246) in one launch.  correspondences [total][4] = (x1, y1, x2, y2)
+    in normalised image coordinates; rotation_position [N][6] (rotation_2 | position_2) is updated in
+    place; returns a list of BaSummary (no traces)."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    num = len(offsets) - 1
+    corr = np.ascontiguousarray(correspondences, dtype=np.float64).reshape(-1, 4)
+    rp = rotation_position
+    if not (rp.flags["C_CONTIGUOUS"] and rp.dtype == np.float64 and rp.shape == (num, 6)):
+        raise capi.TheiaHipError(-1, "rotation_position must be a C-contiguous float64 [N][6] array (updated in place)")
+    st = capi.BaTwoViewBatch()
+    st.num_problems = num
+    st.offsets = offsets.ctypes.data_as(C.POINTER(C.c_int64))
+    st.correspondences = capi.ptr(corr, C.c_double)
+    st.rotation_position = capi.ptr(rp, C.c_double)
+    summ = (capi.BaSummary * max(1, num))()
+    L = capi.lib()
+    L.theia_hip_ba_two_views_angular_batch.argtypes = [C.POINTER(capi.BaTwoViewBatch), C.POINTER(capi.BaOptions), C.POINTER(capi.BaSummary)]
+    capi.check(L.theia_hip_ba_two_views_angular_batch(C.byref(st), C.byref(options), summ))
+    return [summ[i] for i in range(num)]
+
+
 def solve_tracks_batch(problem, options):
     """theia_hip_ba_tracks_batch: every point as an independent BundleAdjustTrack problem
     (bundle_adjustment.cc:262-285), cameras constant.  problem.points is updated in place;

@@ -417,13 +417,19 @@ __global__ void k_lo_prepare(int est, int nev, const int* __restrict__ ev_prob, 
     if (ev_slot[e] < nm) for (int k = 0; k < kStride; ++k) mo[k] = mloc[ev_slot[e] * kStride + k];
   }
   for (int k = 0; k < kStride; ++k) ev_model[(size_t)e * kStride + k] = mo[k];
-  // Camera::SetPosition / SetOrientationFromRotationMatrix
   double* c = ev_cam + (size_t)e * 6;
+  if (est == THEIA_EST_RELATIVE_POSE) {   // TwoViewInfo{rotation_2, position_2} of RefineModel (estimate_relative_pose.cc:115-118)
+    rsc::eigen_rot_to_rotvec(mo + 9, c);
+    c[3] = mo[18]; c[4] = mo[19]; c[5] = mo[20];
+    return;
+  }
+  // Camera::SetPosition / SetOrientationFromRotationMatrix
   c[0] = mo[9]; c[1] = mo[10]; c[2] = mo[11];
   rsc::rot_to_angle_axis(mo, c + 3);
 }
 
-// inliers of the event's model, in data order, compacted as (uv, X, 1) for the view batch; one wave per event
+// inliers of the event's model, in data order, compacted as (uv, X, 1) for the view batch (absolute pose) or as
+// correspondences for the two-view batch (relative pose); one wave per event
 __global__ __launch_bounds__(64) void k_lo_gather(int est, const int* __restrict__ ev_prob, const int64_t* __restrict__ offsets,
                                                   const double* __restrict__ data, const double* __restrict__ ev_model,
                                                   double thresh, const int64_t* __restrict__ ev_off, int* __restrict__ ev_count,
@@ -431,20 +437,25 @@ __global__ __launch_bounds__(64) void k_lo_gather(int est, const int* __restrict
   const int e = blockIdx.x, lane = threadIdx.x;
   const int p = ev_prob[e];
   const int n = (int)(offsets[p + 1] - offsets[p]);
-  const double* pd = data + (size_t)offsets[p] * 5;
+  const int ds = datum_size(est);
+  const double* pd = data + (size_t)offsets[p] * ds;
   double m[kStride];
   for (int k = 0; k < kStride; ++k) m[k] = ev_model[(size_t)e * kStride + k];
   int base = 0;
   for (int i0 = 0; i0 < n; i0 += 64) {
     const int i = i0 + lane;
     bool in = false;
-    if (i < n) in = model_error(est, m, pd + (size_t)i * 5) < thresh;
+    if (i < n) in = model_error(est, m, pd + (size_t)i * ds) < thresh;
     const unsigned long long b = __ballot(in);
     if (in) {
       const int pos = base + __popcll(b & ((1ull << lane) - 1ull));
-      const double* d = pd + (size_t)i * 5;
-      uv[ev_off[e] + pos] = make_double2(d[0], d[1]);
-      X[ev_off[e] + pos] = make_double4(d[2], d[3], d[4], 1.0);
+      const double* d = pd + (size_t)i * ds;
+      if (est == THEIA_EST_RELATIVE_POSE) {   // the correspondence itself (x1, y1, x2, y2)
+        X[ev_off[e] + pos] = make_double4(d[0], d[1], d[2], d[3]);
+      } else {
+        uv[ev_off[e] + pos] = make_double2(d[0], d[1]);
+        X[ev_off[e] + pos] = make_double4(d[2], d[3], d[4], 1.0);
+      }
     }
     base += __popcll(b);
   }
@@ -454,13 +465,24 @@ __global__ __launch_bounds__(64) void k_lo_gather(int est, const int* __restrict
 struct LoOut { int success, term, iters, nsucc; double c0, c1; };   // = ba_batch.hip ViewOut
 
 // refined pose back into the problem's model (written even when RefineModel returns false)
-__global__ void k_lo_finish(int nev, const int* __restrict__ ev_prob, const double* __restrict__ ev_cam,
-                            const LoOut* __restrict__ out, double* __restrict__ cur_models, int* __restrict__ ev_success) {
+__global__ void k_lo_finish(int est, int nev, const int* __restrict__ ev_prob, const double* __restrict__ ev_cam,
+                            const double* __restrict__ ev_model, const LoOut* __restrict__ out, double* __restrict__ cur_models,
+                            int* __restrict__ ev_success) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nev) return;
   const int p = ev_prob[e];
   const double* c = ev_cam + (size_t)e * 6;
   double* mo = cur_models + (size_t)p * kStride;
+  if (est == THEIA_EST_RELATIVE_POSE) {
+    // estimate_relative_pose.cc:130-135: rotation and position are replaced, the essential matrix of the model is NOT
+    // recomputed (Error keeps scoring the Sampson distance of the unrefined E); success = the cost went down
+    for (int k = 0; k < 9; ++k) mo[k] = ev_model[(size_t)e * kStride + k];
+    rsc::eigen_rotvec_to_rot(c, mo + 9);
+    mo[18] = c[3]; mo[19] = c[4]; mo[20] = c[5];
+    for (int k = 21; k < kStride; ++k) mo[k] = 0.0;
+    ev_success[e] = (out[e].c1 < out[e].c0) ? 1 : 0;
+    return;
+  }
   rsc::angle_axis_to_rot(c + 3, mo);
   mo[9] = c[0]; mo[10] = c[1]; mo[11] = c[2];
   for (int k = 12; k < kStride; ++k) mo[k] = 0.0;
@@ -689,9 +711,11 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   // estimators that keep Estimator::RefineModel's default "return true" (solvers/estimator.h:86-88): LO only counts
   const bool trivial_refine = est == THEIA_EST_ESSENTIAL_MATRIX || est == THEIA_EST_DOMINANT_PLANE ||
                               est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION || est == THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION;
-  if (P.use_lo && !abs_pose && !trivial_refine)
-    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: only the absolute-pose RefineModel (BundleAdjustView) and the trivial ones are "
-                     "built; the BA-based RefineModels of the relative-pose / fundamental / homography estimators are not yet");
+  const bool rel_pose = est == THEIA_EST_RELATIVE_POSE;
+  if (P.use_lo && !abs_pose && !rel_pose && !trivial_refine)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: the RefineModels of the absolute-pose (BundleAdjustView) and relative-pose "
+                     "(BundleAdjustTwoViewsAngular) estimators and the trivial ones are built; OptimizeFundamentalMatrix / "
+                     "OptimizeHomography / the uncalibrated one are not yet");
   // exhaustive_sampler.cc:49-51 CHECK
   if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE && sample_size(est) != 2)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "ExhaustiveSampler makes a hard assumption that the number of samples needed is 2.");
@@ -779,7 +803,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     for (int k = 0; k < kMaxSample; ++k) s.best_samples[k] = 0;
   }
   double fit_score_ms = 0.0;
-  // ---- LO-RANSAC (absolute pose): batched RefineModel over a list of events
+  // ---- LO-RANSAC (absolute / relative pose): batched RefineModel over a list of events
   DBuf<int> d_ev_prob, d_ev_samples, d_ev_slot, d_ev_count, d_ev_success, d_lo_model_id;
   DBuf<int64_t> d_ev_off;
   DBuf<double> d_ev_model, d_ev_cam, d_lo_uv, d_lo_X, d_cur_models, d_lo_intr;
@@ -792,6 +816,11 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   lo_opts.loss_function_type = THEIA_LOSS_HUBER;
   lo_opts.robust_loss_width = P.error_thresh * 1.5;
   lo_opts.use_inner_iterations = 0;
+  if (rel_pose) {                                        // estimate_relative_pose.cc:120-126
+    lo_opts.max_num_iterations = 15;
+    lo_opts.loss_function_type = THEIA_LOSS_TRUNCATED;
+    lo_opts.robust_loss_width = P.error_thresh;
+  }
   if (P.use_lo && (rc = d_cur_models.ensure((size_t)nprob * kStride))) return rc;
   struct LoEvent { int prob, slot; int samples[8]; };
   // refines every event's model on its inliers; writes the refined pose to d_cur_models[prob]
@@ -827,10 +856,13 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
                                                  d_cur_models.p, d_ev_model.p, d_ev_cam.p);
     k_lo_gather<<<nev, 64, 0, st>>>(est, d_ev_prob.p, d_off.p, d_data.p, d_ev_model.p, P.error_thresh, d_ev_off.p, d_ev_count.p,
                                     reinterpret_cast<double2*>(d_lo_uv.p), reinterpret_cast<double4*>(d_lo_X.p));
-    views_batch_device(nev, d_ev_off.p, d_ev_count.p, d_lo_uv.p, nullptr, d_lo_X.p, d_ev_cam.p, d_lo_intr.p, d_lo_model_id.p,
-                       nullptr, &lo_opts, d_lo_out.p, st);
-    k_lo_finish<<<(nev + 63) / 64, 64, 0, st>>>(nev, d_ev_prob.p, d_ev_cam.p, reinterpret_cast<const LoOut*>(d_lo_out.p),
-                                                d_cur_models.p, d_ev_success.p);
+    if (rel_pose)
+      twoview_batch_device(nev, d_ev_off.p, d_ev_count.p, d_lo_X.p, d_ev_cam.p, &lo_opts, d_lo_out.p, st);
+    else
+      views_batch_device(nev, d_ev_off.p, d_ev_count.p, d_lo_uv.p, nullptr, d_lo_X.p, d_ev_cam.p, d_lo_intr.p, d_lo_model_id.p,
+                         nullptr, &lo_opts, d_lo_out.p, st);
+    k_lo_finish<<<(nev + 63) / 64, 64, 0, st>>>(est, nev, d_ev_prob.p, d_ev_cam.p, d_ev_model.p,
+                                                reinterpret_cast<const LoOut*>(d_lo_out.p), d_cur_models.p, d_ev_success.p);
     HIP_TRYR(hipMemcpyAsync(success.data(), d_ev_success.p, sizeof(int) * nev, hipMemcpyDeviceToHost, st));
     HIP_TRYR(hipStreamSynchronize(st));
     return 0;

@@ -930,6 +930,54 @@ RDEV void angle_axis_to_rot(const double* aa, double* R) {
   }
 }
 
+// Eigen::AngleAxisd(Matrix3d) (Quaternion.h quaternionbase_assign_impl<.., 3, 3> then AngleAxis.h
+// operator=(QuaternionBase)) scaled to a rotation vector, and AngleAxisd::toRotationMatrix with
+// angle = |v|, axis = v / angle -- RelativePoseEstimator::RefineModel converts this way
+// (estimate_relative_pose.cc:116-118,131-134; a zero vector gives NaNs there too).  R row-major.
+RDEV void eigen_rot_to_rotvec(const double* R, double* v) {
+  double q[4];   // x y z w
+  double t = (R[0] + R[4]) + R[8];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 3 + i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+    q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+    q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+  }
+  double n = sqrt((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);
+  double angle, axis[3];
+  if (n != 0.0) {
+    angle = 2.0 * atan2(n, fabs(q[3]));
+    if (q[3] < 0.0) n = -n;
+    axis[0] = q[0] / n; axis[1] = q[1] / n; axis[2] = q[2] / n;
+  } else {
+    angle = 0.0; axis[0] = 1.0; axis[1] = 0.0; axis[2] = 0.0;
+  }
+  v[0] = angle * axis[0]; v[1] = angle * axis[1]; v[2] = angle * axis[2];
+}
+RDEV void eigen_rotvec_to_rot(const double* v, double* R) {
+  const double angle = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+  const double ax[3] = {v[0] / angle, v[1] / angle, v[2] / angle};
+  const double s = sin(angle), c = cos(angle);
+  const double sa[3] = {s * ax[0], s * ax[1], s * ax[2]};
+  const double ca[3] = {(1.0 - c) * ax[0], (1.0 - c) * ax[1], (1.0 - c) * ax[2]};
+  double tmp;
+  tmp = ca[0] * ax[1]; R[1] = tmp - sa[2]; R[3] = tmp + sa[2];
+  tmp = ca[0] * ax[2]; R[2] = tmp + sa[1]; R[6] = tmp - sa[1];
+  tmp = ca[1] * ax[2]; R[5] = tmp - sa[0]; R[7] = tmp + sa[0];
+  R[0] = ca[0] * ax[0] + c; R[4] = ca[1] * ax[1] + c; R[8] = ca[2] * ax[2] + c;
+}
+
 // ------------------------------------------------------------ five point
 RDEV void mul_deg1(const double* a, const double* b, double* o) {  // five_point_relative_pose.cc:68-92
   o[0] = a[0] * b[0];

@@ -19,4 +19,8 @@ int views_batch_device(int num, const int64_t* d_offsets, const int* d_counts, c
                        const double* d_X, double* d_cam, const double* d_intr, const int* d_model, const uint8_t* d_mask,
                        const theia_ba_options* o, void* d_out, hipStream_t st);
 size_t views_batch_out_bytes();
+// twoview_lm.hip: batched BundleAdjustTwoViewsAngular on device-resident (x1, y1, x2, y2) rows; d_pose = [num][6]
+// (rotation_2 | position_2) in/out; d_out as for views_batch_device.
+int twoview_batch_device(int num, const int64_t* d_offsets, const int* d_counts, const double* d_corr, double* d_pose,
+                         const theia_ba_options* o, void* d_out, hipStream_t st);
 }  // namespace thip

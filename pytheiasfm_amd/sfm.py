@@ -335,6 +335,29 @@ def BundleAdjustTrack(reconstruction, options, track_id):
 # thread pool (estimate_track.cc:176-184,289; camera localisation).  These two helpers run
 # such a list of INDEPENDENT problems as one device batch; each entry is exactly what the
 # single-item function of the reference would solve.
+def BundleAdjustTwoViewsAngular(options, correspondences, two_view_info):
+    """bundle_adjust_two_views.cc:189-246 through its pybind wrapper (bundle_adjustment_wrapper.cc:5-12):
+    refines two_view_info.rotation_2 / position_2 in place against the angular epipolar error of the
+    normalised correspondences [(x1, y1, x2, y2)]; returns the summary."""
+    s = BundleAdjustTwoViewsAngularBatch(options, [correspondences], [two_view_info])
+    return s[0]
+
+
+def BundleAdjustTwoViewsAngularBatch(options, correspondences_list, two_view_infos):
+    """N pairs as one launch (one wave per pair)."""
+    n = len(correspondences_list)
+    corr = [np.asarray(c, dtype=np.float64).reshape(-1, 4) for c in correspondences_list]
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([len(c) for c in corr])
+    rp = np.array([np.concatenate([np.asarray(i.rotation_2, dtype=np.float64), np.asarray(i.position_2, dtype=np.float64)])
+                   for i in two_view_infos], dtype=np.float64).reshape(n, 6)
+    summ = _ba.solve_two_views_angular_batch(offsets, np.vstack(corr) if n else np.zeros((0, 4)), rp, options.to_c())
+    for k, info in enumerate(two_view_infos):
+        info.rotation_2 = rp[k, :3].copy()
+        info.position_2 = rp[k, 3:].copy()
+    return [BundleAdjustmentSummary(c) for c in summ]
+
+
 def BundleAdjustViewsIndependently(reconstruction, options, view_ids):
     """[BundleAdjustView(reconstruction, options, v) for v in view_ids] as one launch
     (theia_hip_ba_views_batch).  Returns the list of summaries."""

@@ -204,7 +204,47 @@ def third_set():
     print("wrote ransac_estimators.npz")
 
 
+def two_view_cases():
+    """(correspondences, start pose) of the BundleAdjustTwoViewsAngular vectors: inliers of synthetic pairs, perturbed truth."""
+    data, off, truth = synth.synth_ransac_v1(4, 200, kind="relative", noise_px=0.5, seed=0x5AC52100)
+    for p in range(4):
+        c = data[off[p]:off[p + 1]][truth["inlier"][p]]
+        w = synth.matrix_to_angle_axis(truth["R"][p]); pos = truth["position"][p] / np.linalg.norm(truth["position"][p])
+        x0 = np.concatenate([w + 0.005 * (p + 1), pos + 0.01 * (p - 1.5)]); x0[3:] /= np.linalg.norm(x0[3:])
+        yield c, x0
+
+
+def fourth_set():
+    """Relative-pose LO-RANSAC (RefineModel = BundleAdjustTwoViewsAngular) and the two-view adjustment itself."""
+    from pytheiasfm_amd import ba
+    out = {}
+    o = ba.default_options(); o.max_num_iterations = 15; o.loss_function_type = 6; o.robust_loss_width = 2e-4
+    for k, (c, x0) in enumerate(two_view_cases()):
+        pose, s = ol.two_views_angular(c, x0, o)
+        out[f"tv{k}_corr"] = c; out[f"tv{k}_x0"] = x0; out[f"tv{k}_pose"] = pose
+        out[f"tv{k}_ints"] = np.array([s["success"], s["termination_type"], s["num_iterations"], s["num_successful_steps"]])
+        out[f"tv{k}_costs"] = np.array([s["initial_cost"], s["final_cost"]])
+    data, offsets, _ = synth.synth_ransac_v1(3, 150, "relative", seed=0x5AC52101, inlier_lo=0.5, inlier_hi=0.7)
+    out["rel_data"] = data; out["rel_offsets"] = offsets
+    masks, models, iters, nlo = [], [], [], []
+    for i in range(3):
+        prm = ol.default_ransac_params((2.0 / 1000.0) ** 2, 50 + i)
+        prm.use_mle = 1; prm.use_lo = 1; prm.lo_start_iterations = 5; prm.min_iterations = 50; prm.failure_probability = 0.001
+        r = ol.ransac_estimate(0, data[offsets[i]:offsets[i + 1]], prm)
+        masks.append(r["inlier_mask"]); models.append(r["model"][:21]); iters.append(r["num_iterations"])
+        nlo.append(ol.rlib().oracle_last_lo_iterations())
+    out["rel_lo_masks"] = np.stack(masks); out["rel_lo_models"] = np.stack(models); out["rel_lo_iters"] = np.array(iters)
+    out["rel_lo_nlo"] = np.array(nlo)
+    np.savez_compressed(os.path.join(HERE, "two_view_lo.npz"), **out)
+    print("wrote two_view_lo.npz")
+
+
 if __name__ == "__main__":
+    import sys
+    if "--only-fourth" in sys.argv:
+        fourth_set()
+        sys.exit(0)
     main()
     second_set()
     third_set()
+    fourth_set()

@@ -920,3 +920,34 @@ def test_select_good_tracks_for_bundle_adjustment_mirror():
             continue
         t = rec.obs_track[(rec.obs_view == v) & keep]
         assert chosen[t].sum() >= min(25, len(t))
+
+
+def test_two_views_angular_batch_follows_oracle():
+    """theia_hip_ba_two_views_angular_batch = N x BundleAdjustTwoViewsAngular (bundle_adjust_two_views.cc:189-246):
+    one wave per pair, closed-form Jacobians of the angular epipolar error, SphereManifold<3> position, CGNR steps.
+    Against the Jet-based oracle: same iteration / step counts, poses to 1e-9, costs to 1e-9 relative."""
+    data, off, truth = synth.synth_ransac_v1(12, 500, kind="relative", noise_px=0.5, seed=0x5AC50C00)
+    corr, offs, x0s = [], [0], []
+    for p in range(12):
+        c = data[off[p]:off[p + 1]][truth["inlier"][p]]
+        w = synth.matrix_to_angle_axis(truth["R"][p]); pos = truth["position"][p] / np.linalg.norm(truth["position"][p])
+        x0 = np.concatenate([w + 0.004 * (p % 3 + 1), pos + 0.01 * ((p % 4) - 1.5)]); x0[3:] /= np.linalg.norm(x0[3:])
+        corr.append(c); offs.append(offs[-1] + len(c)); x0s.append(x0)
+    # an empty problem and one whose residuals all lie beyond the truncation width
+    corr.append(np.zeros((0, 4))); offs.append(offs[-1]); x0s.append(np.array([0.1, 0.2, 0.3, 0.0, 0.0, 1.0]))
+    corr.append(data[off[0]:off[1]][~truth["inlier"][0]][:40] * 3.0); offs.append(offs[-1] + 40); x0s.append(np.array([0.1, -0.2, 0.05, 0.0, 0.6, 0.8]))
+    corr = np.vstack(corr); x0s = np.array(x0s)
+    for loss, width in ((6, 2e-4), (0, 1.0), (1, 1e-5)):
+        o = ba.default_options(); o.max_num_iterations = 15; o.loss_function_type = loss; o.robust_loss_width = width
+        pose = x0s.copy()
+        summ = ba.solve_two_views_angular_batch(offs, corr, pose, o)
+        for p in range(len(x0s)):
+            ref, s = ol.two_views_angular(corr[offs[p]:offs[p + 1]], x0s[p], o)
+            assert summ[p].num_iterations == s["num_iterations"] and summ[p].num_successful_steps == s["num_successful_steps"], (loss, p)
+            assert summ[p].termination_type == s["termination_type"] and summ[p].success == s["success"]
+            assert np.abs(pose[p] - ref).max() <= 1e-9, (loss, p, np.abs(pose[p] - ref).max())
+            assert abs(summ[p].initial_cost - s["initial_cost"]) <= 1e-9 * max(s["initial_cost"], 1e-300) + 1e-300
+            assert abs(summ[p].final_cost - s["final_cost"]) <= 1e-9 * max(s["final_cost"], 1e-300) + 1e-20
+            if p < 12 and loss == 6:
+                assert summ[p].final_cost < summ[p].initial_cost and abs(np.linalg.norm(pose[p][3:]) - 1.0) <= 1e-14
+        assert np.array_equal(pose[12], x0s[12]) and summ[12].num_iterations == 0

@@ -663,3 +663,108 @@ def test_golden_ransac_estimators():
                 assert r["num_iterations"] == g[f"{kind}_t{rtype}_iters"][i], (kind, rtype, i)
                 assert np.array_equal(r["inlier_mask"], g[f"{kind}_t{rtype}_masks"][i])
                 assert np.allclose(r["model"][:mlen], g[f"{kind}_t{rtype}_models"][i], rtol=0, atol=1e-13)
+
+
+# ---------------------------------------------------------------- relative-pose RefineModel (LO-RANSAC)
+def _angular_error_numpy(w, t, c):
+    """angular_epipolar_error.h:54-91 written independently with numpy (Rodrigues from scipy-free formula)."""
+    th = np.linalg.norm(w)
+    K = cross_mat(w / th) if th > 0 else np.zeros((3, 3))
+    R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    f1 = np.array([c[0], c[1], 1.0]); f2 = np.array([c[2], c[3], 1.0])
+    M = np.eye(3) - np.outer(t, t)
+    a = f1 @ M @ f1 + (R @ f2) @ M @ (R.T @ f2)
+    b = t @ np.cross(f1, R.T @ f2)
+    s = a * a / 4 - b * b
+    return 1000.0 if s < 0 else a / 2 - np.sqrt(s)
+
+
+def test_angular_epipolar_error_against_numpy():
+    obl = ol
+    st = synth.Stream(77, 1)
+    i = np.arange(40)
+    W = 0.4 * np.stack([st.normal(3 * i), st.normal(3 * i + 1), st.normal(3 * i + 2)], 1)
+    T = np.stack([st.normal(3 * i + 200), st.normal(3 * i + 201), st.normal(3 * i + 202)], 1)
+    T /= np.linalg.norm(T, axis=1, keepdims=True)
+    Cc = np.stack([st.uniform(4 * i + 400), st.uniform(4 * i + 401), st.uniform(4 * i + 402), st.uniform(4 * i + 403)], 1) - 0.5
+    for k in range(40):
+        e = obl.angular_epipolar_error(W[k], T[k], Cc[k])
+        assert abs(e - _angular_error_numpy(W[k], T[k], Cc[k])) <= 1e-13
+    # exact pose, exact correspondence: zero; a non-unit "position" can make the root imaginary -> 1000 (the functor never fails)
+    assert obl.angular_epipolar_error(np.zeros(3), np.array([1.0, 0, 0]), np.array([0.1, 0.2, 0.3, 0.2])) == pytest.approx(0.0, abs=1e-15)
+    assert obl.angular_epipolar_error(np.zeros(3), np.array([3.0, 0, 0]), np.array([0.0, 1.0, 0.0, -1.0])) == 1000.0
+
+
+def test_two_views_angular_oracle_converges_on_exact_correspondences():
+    """BundleAdjustTwoViewsAngular as RefineModel configures it (TRUNCATED, 15 iterations, CGNR): from a perturbed
+    pose the cost of noise-free correspondences falls by orders of magnitude, the position stays on the unit sphere."""
+    obl = ol
+    from pytheiasfm_amd import ba
+    data, off, truth = synth.synth_ransac_v1(4, 300, kind="relative", noise_px=0.0, seed=0x5AC50A00)
+    for p in range(1, 4):
+        c = data[off[p]:off[p + 1]][truth["inlier"][p]]
+        w = synth.matrix_to_angle_axis(truth["R"][p]); pos = truth["position"][p] / np.linalg.norm(truth["position"][p])
+        o = ba.default_options(); o.max_num_iterations = 15; o.loss_function_type = 6; o.robust_loss_width = 1e-3
+        x0 = np.concatenate([w + 0.01, pos + 0.02]); x0[3:] /= np.linalg.norm(x0[3:])
+        pose, s = obl.two_views_angular(c, x0, o)
+        assert s["success"] and s["final_cost"] < 1e-6 * s["initial_cost"] and s["num_successful_steps"] >= 3
+        assert abs(np.linalg.norm(pose[3:]) - 1.0) <= 1e-14
+        assert np.abs(pose[:3] - w).max() < np.abs(x0[:3] - w).max() and np.abs(pose[3:] - pos).max() < np.abs(x0[3:] - pos).max()
+    # every residual beyond the truncation width: zero gradient, immediate convergence, pose untouched
+    o = ba.default_options(); o.max_num_iterations = 15; o.loss_function_type = 6; o.robust_loss_width = 1e-12
+    c = data[off[0]:off[1]][~truth["inlier"][0]][:50]
+    x0 = np.array([0.1, -0.2, 0.05, 0.0, 0.6, 0.8])
+    pose, s = obl.two_views_angular(c, x0, o)
+    assert s["num_iterations"] == 0 and np.array_equal(pose, x0) and s["final_cost"] == s["initial_cost"]
+
+
+@pytest.mark.parametrize("ri", range(2))
+@pytest.mark.parametrize("pj", range(2))
+def test_estimate_relative_pose_lo(ri, pj):
+    """estimate_relative_pose_test.cc OutliersWithNoise_LO (:252-281): 70 % inliers, 1 px noise, use_lo from iteration 5.
+    RefineModel replaces rotation and position and leaves the model's essential matrix alone."""
+    R, position = REL_ROT[ri], REL_POS[pj] * (1.3 / 0.7 if pj == 0 else 1.0)
+    pts = grid_points()
+    t = -R @ position; t = t / np.linalg.norm(t)
+    st = synth.Stream(65, 50 + 10 * ri + pj)
+    x1 = pts[:, :2] / pts[:, 2:]
+    p2 = pts @ R.T + t
+    x2 = p2[:, :2] / p2[:, 2:]
+    out = np.arange(27) >= 0.7 * 27
+    x1[out] = 2 * np.stack([st.uniform(4 * np.arange(27)), st.uniform(4 * np.arange(27) + 1)], 1)[out] - 1
+    x2[out] = 2 * np.stack([st.uniform(4 * np.arange(27) + 2), st.uniform(4 * np.arange(27) + 3)], 1)[out] - 1
+    x1 = x1 + 1e-3 * np.stack([st.normal(4 * np.arange(27) + 500), st.normal(4 * np.arange(27) + 501)], 1)
+    x2 = x2 + 1e-3 * np.stack([st.normal(4 * np.arange(27) + 502), st.normal(4 * np.arange(27) + 503)], 1)
+    prm = ol.default_ransac_params((2.0 / 1000.0) ** 2, seed=65)
+    prm.use_mle = 1; prm.failure_probability = 0.001; prm.use_lo = 1; prm.lo_start_iterations = 5
+    r = ol.ransac_estimate(0, np.hstack([x1, x2]), prm)
+    nlo = ol.rlib().oracle_last_lo_iterations()
+    assert r["success"] and r["num_inliers"] > 5 and nlo >= 1
+    E = r["model"][0:9].reshape(3, 3); Rm = r["model"][9:18].reshape(3, 3); pos = r["model"][18:21]
+    ang = np.degrees(np.arccos(np.clip((np.trace(R @ Rm.T) - 1) / 2, -1, 1)))
+    tdiff = np.degrees(np.arccos(np.clip(position / np.linalg.norm(position) @ pos, -1, 1)))
+    assert ang < 5.0 and tdiff < 5.0
+    assert np.abs(Rm @ Rm.T - np.eye(3)).max() <= 1e-12 and abs(np.linalg.norm(pos) - 1.0) <= 1e-12
+    # the essential matrix is the minimal sample's: rank 2 with two equal singular values, but no longer [t]x R of the refined pose
+    sv = np.linalg.svd(E, compute_uv=False)
+    assert sv[2] <= 1e-9 * sv[0] and abs(sv[0] - sv[1]) <= 1e-6 * sv[0]
+
+
+def test_golden_two_view_lo():
+    """The oracle reproduces tests/golden/two_view_lo.npz: BundleAdjustTwoViewsAngular vectors and relative-pose LO-RANSAC runs."""
+    from pytheiasfm_amd import ba
+    g = np.load(os.path.join(HERE, "golden", "two_view_lo.npz"))
+    o = ba.default_options(); o.max_num_iterations = 15; o.loss_function_type = 6; o.robust_loss_width = 2e-4
+    for k in range(4):
+        pose, s = ol.two_views_angular(g[f"tv{k}_corr"], g[f"tv{k}_x0"], o)
+        assert np.allclose(pose, g[f"tv{k}_pose"], rtol=0, atol=1e-13)
+        assert [s["success"], s["termination_type"], s["num_iterations"], s["num_successful_steps"]] == list(g[f"tv{k}_ints"])
+        assert np.allclose([s["initial_cost"], s["final_cost"]], g[f"tv{k}_costs"], rtol=1e-12, atol=0)
+    data, offsets = g["rel_data"], g["rel_offsets"]
+    for i in range(3):
+        prm = ol.default_ransac_params((2.0 / 1000.0) ** 2, 50 + i)
+        prm.use_mle = 1; prm.use_lo = 1; prm.lo_start_iterations = 5; prm.min_iterations = 50; prm.failure_probability = 0.001
+        r = ol.ransac_estimate(0, data[offsets[i]:offsets[i + 1]], prm)
+        assert r["num_iterations"] == g["rel_lo_iters"][i] and ol.rlib().oracle_last_lo_iterations() == g["rel_lo_nlo"][i] >= 1
+        assert np.array_equal(r["inlier_mask"], g["rel_lo_masks"][i])
+        assert np.allclose(r["model"][:21], g["rel_lo_models"][i], rtol=0, atol=1e-13)

@@ -143,7 +143,7 @@ def test_mirror_api_and_error_conventions():
     assert ok and len(sl.inliers) > 50
     plo = ransac.RansacParameters(); plo.error_thresh = THR[0]; plo.use_lo = True
     with pytest.raises(capi.TheiaHipError):
-        ransac.EstimateRelativePose(plo, ransac.RansacType.RANSAC, data)             # relative-pose RefineModel: not built
+        ransac.EstimateFundamentalMatrix(plo, ransac.RansacType.RANSAC, data)        # OptimizeFundamentalMatrix RefineModel: not built
     with pytest.raises(capi.TheiaHipError):
         ransac.EstimateCalibratedAbsolutePose(p, ransac.RansacType.RANSAC, ransac.PnPType.DLS, da)
     with pytest.raises(capi.TheiaHipError):
@@ -176,6 +176,37 @@ def test_lo_ransac_absolute_pose_follows_oracle():
     assert np.median(err_lo) <= np.median(err_plain) + 1e-3
     print("LO iterations per problem:", res["num_lo_iterations"])
     assert res["num_lo_iterations"].sum() > 10      # some in-loop refinements succeeded, not only the final one
+
+
+def test_lo_ransac_relative_pose_follows_oracle():
+    """use_lo with the relative-pose RefineModel (estimate_relative_pose.cc:111-138) run as batched
+    BundleAdjustTwoViewsAngular solves on the device (twoview_lm.hip: TRUNCATED loss, <= 15 LM iterations with
+    CGNR steps).  Closed-form vs Jet Jacobians and wave vs sequential sums: refined poses agree to 1e-8, control
+    flow (iterations, LO counts) and inlier sets are identical; the essential matrix stays the minimal sample's."""
+    data, offsets, truth = synth.synth_ransac_v1(10, 300, "relative", seed=0x5AC50B00, noise_px=1.0)
+    p = ransac.RansacParameters(); p.error_thresh = THR[0]; p.use_mle = True; p.seed = 67
+    p.use_lo = True; p.lo_start_iterations = 5; p.min_iterations = 50; p.failure_probability = 0.001
+    res = ransac.estimate_batch(0, data, offsets, p)
+    plain = ransac.RansacParameters(); plain.error_thresh = THR[0]; plain.use_mle = True; plain.seed = 67
+    plain.min_iterations = 50; plain.failure_probability = 0.001
+    res0 = ransac.estimate_batch(0, data, offsets, plain)
+    moved = 0
+    for i in range(10):
+        pc = p.to_c(); pc.seed = 67 + i
+        o = ol.ransac_estimate(0, data[offsets[i]:offsets[i + 1]], pc)
+        nlo = ol.rlib().oracle_last_lo_iterations()
+        sl = slice(offsets[i], offsets[i + 1])
+        assert o["num_iterations"] == res["num_iterations"][i] and nlo == res["num_lo_iterations"][i] and nlo >= 1
+        assert np.array_equal(o["model"][:9], res["models"][i][:9])                  # E: untouched by the refinement
+        assert np.abs(o["model"][9:21] - res["models"][i][9:21]).max() <= 1e-8
+        assert np.array_equal(o["inlier_mask"], res["inlier_mask"][sl])
+        Rm = res["models"][i][9:18].reshape(3, 3)
+        assert np.abs(Rm @ Rm.T - np.eye(3)).max() <= 1e-12 and abs(np.linalg.norm(res["models"][i][18:21]) - 1) <= 1e-12
+        moved += np.abs(res["models"][i][9:21] - res0["models"][i][9:21]).max() > 1e-9
+        ang = np.degrees(np.arccos(np.clip((np.trace(truth["R"][i] @ Rm.T) - 1) / 2, -1, 1)))
+        assert ang < 2.0
+    print("LO iterations per problem:", res["num_lo_iterations"])
+    assert moved >= 8 and res["num_lo_iterations"].sum() > 10
 
 
 @pytest.mark.parametrize("est,kind,n", [(0, "relative", 400), (2, "absolute", 301), (1, "relative", 64)])
@@ -366,6 +397,25 @@ def test_estimate_two_view_info_both_branches():
     # single-pair entry point = rank 0 of a batch of one
     ok, info, inl = tv.EstimateTwoViewInfo(opts, pr, pr, corr[0])
     assert ok and inl == out[0][2]
+    # the pipelines' setting (ransac_use_lo, reconstruction_estimator_options.h:133): LO through the two-view angular batch
+    olo = tv.EstimateTwoViewInfoOptions(); olo.seed = 5; olo.max_sampson_error_pixels = 2.0; olo.use_lo = True; olo.lo_start_iterations = 5
+    out_lo = tv.EstimateTwoViewInfoBatch(olo, [pr] * 3, [pr] * 3, corr)
+    for i, (ok, info, inl) in enumerate(out_lo):
+        R = synth.angle_axis_to_matrix(info.rotation_2)
+        ang = np.degrees(np.arccos(np.clip((np.trace(R @ truth["R"][i].T) - 1) / 2, -1, 1)))
+        assert ok and len(inl) > 150 and ang < 1.0 and abs(info.position_2 @ truth["position"][i]) > 0.99
+        assert abs(np.linalg.norm(info.position_2) - 1.0) <= 1e-12
+    # BundleAdjustTwoViewsAngular as a bound function: refines a TwoViewInfo in place
+    from pytheiasfm_amd import sfm
+    info = tv.TwoViewInfo()
+    info.rotation_2 = synth.matrix_to_angle_axis(truth["R"][0]) + 0.01
+    info.position_2 = truth["position"][0] / np.linalg.norm(truth["position"][0])
+    nrm = (corr[0] - np.array([500.0, 400.0, 500.0, 400.0])) / 1000.0
+    bo = sfm.BundleAdjustmentOptions(); bo.max_num_iterations = 15; bo.loss_function_type = sfm.LossFunctionType.TRUNCATED
+    bo.robust_loss_width = 1e-4
+    summ = sfm.BundleAdjustTwoViewsAngular(bo, nrm[truth["inlier"][0]], info)
+    assert summ.success and summ.final_cost < summ.initial_cost
+    assert np.abs(info.rotation_2 - synth.matrix_to_angle_axis(truth["R"][0])).max() < 5e-3
     # uncalibrated: no focal prior; principal point from the image size
     data, offsets, truth = synth.synth_ransac_v1(2, 400, "uncalibrated", seed=0x5AC51701, inlier_lo=0.6, inlier_hi=0.8, noise_px=0.3)
     pu = tv.CameraIntrinsicsPrior(); pu.image_width = 1000; pu.image_height = 800
@@ -441,3 +491,27 @@ def test_lo_with_default_refine_model_only_counts(kind, est, thresh):
         o = ol.ransac_estimate(est, data[offsets[i]:offsets[i + 1]], pc)
         assert o["num_iterations"] == lo["num_iterations"][i] and np.array_equal(o["inlier_mask"], lo["inlier_mask"][offsets[i]:offsets[i + 1]])
         assert ol.rlib().oracle_last_lo_iterations() == lo["num_lo_iterations"][i]
+
+
+def test_golden_two_view_lo_on_device():
+    """tests/golden/two_view_lo.npz through the C-ABI: the BundleAdjustTwoViewsAngular vectors (poses to 1e-9, same
+    step counts) and the relative-pose LO-RANSAC runs (iterations, LO counts, inlier masks identical, poses to 1e-8)."""
+    from pytheiasfm_amd import ba
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "two_view_lo.npz"))
+    o = ba.default_options(); o.max_num_iterations = 15; o.loss_function_type = 6; o.robust_loss_width = 2e-4
+    corr = [g[f"tv{k}_corr"] for k in range(4)]
+    offs = np.concatenate([[0], np.cumsum([len(c) for c in corr])])
+    pose = np.array([g[f"tv{k}_x0"] for k in range(4)])
+    summ = ba.solve_two_views_angular_batch(offs, np.vstack(corr), pose, o)
+    for k in range(4):
+        assert np.abs(pose[k] - g[f"tv{k}_pose"]).max() <= 1e-9
+        assert [summ[k].success, summ[k].termination_type, summ[k].num_iterations, summ[k].num_successful_steps] == list(g[f"tv{k}_ints"])
+        assert np.allclose([summ[k].initial_cost, summ[k].final_cost], g[f"tv{k}_costs"], rtol=1e-9, atol=0)
+    p = ransac.RansacParameters(); p.error_thresh = (2.0 / 1000.0) ** 2; p.seed = 50; p.use_mle = True
+    p.use_lo = True; p.lo_start_iterations = 5; p.min_iterations = 50; p.failure_probability = 0.001
+    res = ransac.estimate_batch(0, g["rel_data"], g["rel_offsets"], p)
+    assert np.array_equal(res["num_iterations"], g["rel_lo_iters"]) and np.array_equal(res["num_lo_iterations"], g["rel_lo_nlo"])
+    for i in range(3):
+        assert np.array_equal(res["inlier_mask"][g["rel_offsets"][i]:g["rel_offsets"][i + 1]], g["rel_lo_masks"][i])
+        assert np.array_equal(res["models"][i][:9], g["rel_lo_models"][i][:9])
+        assert np.abs(res["models"][i][9:21] - g["rel_lo_models"][i][9:21]).max() <= 1e-8
