@@ -254,11 +254,16 @@ int theia_hip_ba_views_batch(const theia_ba_view_batch* batch,
  * (bundle_adjust_two_views.cc:189-246, residual angular_epipolar_error.h:54-91, bound at
  * src/pytheia/sfm/sfm.cc:1620) -- also RefineModel of the relative-pose estimator
  * (estimate_relative_pose.cc:111-138).  The position moves on SphereManifold<3>; the
- * linear solver is the caller's CGNR + JACOBI (inexact steps, Ceres' q-tolerance rule).
+ * linear solver is selected by linear_solver: EXACT = the solution of the 5 x 5 normal
+ * equations (any direct BundleAdjustmentOptions::linear_solver_type, the default), CGNR =
+ * conjugate gradients with the JACOBI preconditioner and Ceres' q-tolerance rule, an
+ * inexact step (what the relative-pose RefineModel selects).
  * Honoured options: loss type / width, max_num_iterations, the three tolerances,
  * max_trust_region_radius.  Normalised image coordinates. */
+enum { THEIA_TWO_VIEW_EXACT = 0, THEIA_TWO_VIEW_CGNR = 1 };
 typedef struct theia_ba_two_view_batch {
   int32_t num_problems;
+  int32_t linear_solver;           /* THEIA_TWO_VIEW_*                                       */
   const int64_t* offsets;          /* [num_problems+1], offsets[0] = 0                      */
   const double* correspondences;   /* [total][4] = (x1, y1, x2, y2)                          */
   double* rotation_position;       /* [num_problems][6] in/out: TwoViewInfo::rotation_2 | position_2 */
@@ -395,8 +400,9 @@ typedef struct theia_ransac_params {
   int32_t max_iterations;
   int32_t use_mle;
   int32_t use_lo;              /* LO-RANSAC: RefineModel of the absolute-pose (BundleAdjustView) and relative-pose
-                                  (BundleAdjustTwoViewsAngular) estimators as device batches, the default "return
-                                  true" of the others; fundamental / homography / uncalibrated: ERR_UNSUPPORTED */
+                                  (BundleAdjustTwoViewsAngular; also the uncalibrated one) estimators as device
+                                  batches, the default "return true" of the others; fundamental matrix /
+                                  homography: ERR_UNSUPPORTED */
   int32_t lo_start_iterations;
   int32_t use_Tdd_test;        /* reference: "Not currently implemented"  */
   uint32_t seed;               /* seeds the mt19937 stream (util/random.cc:60-66),

@@ -1479,9 +1479,10 @@ extern "C" {
 
 // pose = rotation_2 | position_2 (in/out); out_int = {success, termination, iterations, successful steps};
 // out_cost = {initial, final}
+// linear_solver: 0 = exact solve of the normal equations (the direct solver types), 1 = CGNR + JACOBI
 int oracle_two_views_angular(int64_t n, const double* corr, int loss_type, double loss_width, int max_num_iterations,
                              double function_tolerance, double gradient_tolerance, double parameter_tolerance,
-                             double max_trust_region_radius, double* pose, int* out_int, double* out_cost) {
+                             double max_trust_region_radius, int linear_solver, double* pose, int* out_int, double* out_cost) {
   double x[6];
   for (int q = 0; q < 6; ++q) x[q] = pose[q];
   double scale[5] = {1, 1, 1, 1, 1};
@@ -1516,7 +1517,18 @@ int oracle_two_views_angular(int64_t n, const double* corr, int loss_type, doubl
     ++iter;
     double d[5], y[5];
     for (int q = 0; q < 5; ++q) d[q] = std::min(std::max(L.colsq[q] * scale[q] * scale[q], 1e-6), 1e32) / radius;
-    const bool solved = cgnr_solve(n, L.J, L.r, d, y);
+    bool solved;
+    if (linear_solver == 1) solved = cgnr_solve(n, L.J, L.r, d, y);
+    else {   // (J'J + D^2) y = J'r by dense Cholesky
+      std::vector<double> A(25, 0.0), b(5, 0.0);
+      for (int64_t i = 0; i < n; ++i) {
+        const double* row = &L.J[(size_t)i * 5];
+        for (int a2 = 0; a2 < 5; ++a2) { b[a2] += row[a2] * L.r[i]; for (int c2 = 0; c2 <= a2; ++c2) A[a2 * 5 + c2] += row[a2] * row[c2]; }
+      }
+      for (int a2 = 0; a2 < 5; ++a2) A[a2 * 5 + a2] += d[a2];
+      solved = dense_cholesky_solve(5, A, b);
+      for (int q = 0; q < 5; ++q) { y[q] = b[q]; if (!std::isfinite(y[q])) solved = false; }
+    }
     // model_cost_change = -m'(r + m/2), m = J (-y)
     double mcc = 0.0;
     for (int64_t i = 0; i < n; ++i) {

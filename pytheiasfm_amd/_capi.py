@@ -94,8 +94,8 @@ class BaViewBatch(C.Structure):
 class BaTwoViewBatch(C.Structure):
     """theia_ba_two_view_batch."""
     _fields_ = [
-        ("num_problems", C.c_int32), ("offsets", C.POINTER(C.c_int64)), ("correspondences", c_double_p),
-        ("rotation_position", c_double_p),
+        ("num_problems", C.c_int32), ("linear_solver", C.c_int32), ("offsets", C.POINTER(C.c_int64)),
+        ("correspondences", c_double_p), ("rotation_position", c_double_p),
     ]
 
 

@@ -189,11 +189,15 @@ def solve_views_batch(offsets, obs_uv, points, cam_ext, intrinsics, model, optio
     return [summ[i] for i in range(num)]
 
 
-def solve_two_views_angular_batch(offsets, correspondences, rotation_position, options):
+TWO_VIEW_EXACT, TWO_VIEW_CGNR = 0, 1
+
+
+def solve_two_views_angular_batch(offsets, correspondences, rotation_position, options, linear_solver=TWO_VIEW_EXACT):
     """theia_hip_ba_two_views_angular_batch: N independent BundleAdjustTwoViewsAngular problems
     (bundle_adjust_two_views.cc:189-246) in one launch.  correspondences [total][4] = (x1, y1, x2, y2)
     in normalised image coordinates; rotation_position [N][6] (rotation_2 | position_2) is updated in
-    place; returns a list of BaSummary (no traces)."""
+    place; returns a list of BaSummary (no traces).  linear_solver: TWO_VIEW_EXACT (any direct
+    linear_solver_type) or TWO_VIEW_CGNR (ceres::CGNR + JACOBI, inexact steps)."""
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     num = len(offsets) - 1
     corr = np.ascontiguousarray(correspondences, dtype=np.float64).reshape(-1, 4)
@@ -202,6 +206,7 @@ def solve_two_views_angular_batch(offsets, correspondences, rotation_position, o
         raise capi.TheiaHipError(-1, "rotation_position must be a C-contiguous float64 [N][6] array (updated in place)")
     st = capi.BaTwoViewBatch()
     st.num_problems = num
+    st.linear_solver = int(linear_solver)
     st.offsets = offsets.ctypes.data_as(C.POINTER(C.c_int64))
     st.correspondences = capi.ptr(corr, C.c_double)
     st.rotation_position = capi.ptr(rp, C.c_double)

@@ -396,7 +396,7 @@ __global__ void k_p3p(int num, const double* __restrict__ corr, double* __restri
 __global__ void k_lo_prepare(int est, int nev, const int* __restrict__ ev_prob, const int* __restrict__ ev_samples,
                              const int* __restrict__ ev_slot, const int64_t* __restrict__ offsets,
                              const double* __restrict__ data, const double* __restrict__ cur_models,
-                             double* __restrict__ ev_model, double* __restrict__ ev_cam) {
+                             double* __restrict__ ev_model, double* __restrict__ ev_cam, EstParams ep) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nev) return;
   const int p = ev_prob[e];
@@ -409,16 +409,17 @@ __global__ void k_lo_prepare(int est, int nev, const int* __restrict__ ev_prob, 
     const double* pd = data + (size_t)offsets[p] * ds;
     double subset[kMaxSampleDoubles];
     for (int i = 0; i < m; ++i) {
-      const int idx = ev_samples[e * 5 + i];
+      const int idx = ev_samples[e * kMaxSample + i];
       for (int k = 0; k < ds; ++k) subset[i * ds + k] = pd[(size_t)idx * ds + k];
     }
     double mloc[kMaxCap * kStride];
-    const int nm = estimate_models(est, subset, mloc);
+    const int nm = estimate_models(est, subset, mloc, ep);
     if (ev_slot[e] < nm) for (int k = 0; k < kStride; ++k) mo[k] = mloc[ev_slot[e] * kStride + k];
   }
   for (int k = 0; k < kStride; ++k) ev_model[(size_t)e * kStride + k] = mo[k];
   double* c = ev_cam + (size_t)e * 6;
-  if (est == THEIA_EST_RELATIVE_POSE) {   // TwoViewInfo{rotation_2, position_2} of RefineModel (estimate_relative_pose.cc:115-118)
+  if (est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE) {
+    // TwoViewInfo{rotation_2, position_2} of RefineModel (estimate_relative_pose.cc:115-118, estimate_uncalibrated_relative_pose.cc:157-160)
     rsc::eigen_rot_to_rotvec(mo + 9, c);
     c[3] = mo[18]; c[4] = mo[19]; c[5] = mo[20];
     return;
@@ -452,6 +453,8 @@ __global__ __launch_bounds__(64) void k_lo_gather(int est, const int* __restrict
       const double* d = pd + (size_t)i * ds;
       if (est == THEIA_EST_RELATIVE_POSE) {   // the correspondence itself (x1, y1, x2, y2)
         X[ev_off[e] + pos] = make_double4(d[0], d[1], d[2], d[3]);
+      } else if (est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE) {   // normalised by the model's focal lengths (:146-155)
+        X[ev_off[e] + pos] = make_double4(d[0] / m[21], d[1] / m[21], d[2] / m[22], d[3] / m[22]);
       } else {
         uv[ev_off[e] + pos] = make_double2(d[0], d[1]);
         X[ev_off[e] + pos] = make_double4(d[2], d[3], d[4], 1.0);
@@ -473,14 +476,15 @@ __global__ void k_lo_finish(int est, int nev, const int* __restrict__ ev_prob, c
   const int p = ev_prob[e];
   const double* c = ev_cam + (size_t)e * 6;
   double* mo = cur_models + (size_t)p * kStride;
-  if (est == THEIA_EST_RELATIVE_POSE) {
-    // estimate_relative_pose.cc:130-135: rotation and position are replaced, the essential matrix of the model is NOT
-    // recomputed (Error keeps scoring the Sampson distance of the unrefined E); success = the cost went down
-    for (int k = 0; k < 9; ++k) mo[k] = ev_model[(size_t)e * kStride + k];
+  if (est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE) {
+    // estimate_relative_pose.cc:130-135 / estimate_uncalibrated_relative_pose.cc:170-175: rotation and position are
+    // replaced, the essential (fundamental) matrix and the focal lengths of the model are NOT recomputed -- Error keeps
+    // scoring the Sampson distance of the unrefined matrix.  Success = the cost went down (and, uncalibrated, no FAILURE).
+    for (int k = 0; k < kStride; ++k) mo[k] = ev_model[(size_t)e * kStride + k];
     rsc::eigen_rotvec_to_rot(c, mo + 9);
     mo[18] = c[3]; mo[19] = c[4]; mo[20] = c[5];
-    for (int k = 21; k < kStride; ++k) mo[k] = 0.0;
-    ev_success[e] = (out[e].c1 < out[e].c0) ? 1 : 0;
+    const bool ok = out[e].c1 < out[e].c0;
+    ev_success[e] = (est == THEIA_EST_RELATIVE_POSE ? ok : (ok && out[e].success)) ? 1 : 0;
     return;
   }
   rsc::angle_axis_to_rot(c + 3, mo);
@@ -711,11 +715,11 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   // estimators that keep Estimator::RefineModel's default "return true" (solvers/estimator.h:86-88): LO only counts
   const bool trivial_refine = est == THEIA_EST_ESSENTIAL_MATRIX || est == THEIA_EST_DOMINANT_PLANE ||
                               est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION || est == THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION;
-  const bool rel_pose = est == THEIA_EST_RELATIVE_POSE;
-  if (P.use_lo && !abs_pose && !rel_pose && !trivial_refine)
-    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: the RefineModels of the absolute-pose (BundleAdjustView) and relative-pose "
-                     "(BundleAdjustTwoViewsAngular) estimators and the trivial ones are built; OptimizeFundamentalMatrix / "
-                     "OptimizeHomography / the uncalibrated one are not yet");
+  const bool rel_pose = est == THEIA_EST_RELATIVE_POSE, uncal_pose = est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE;
+  if (P.use_lo && !abs_pose && !rel_pose && !uncal_pose && !trivial_refine)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: the RefineModels of the absolute-pose (BundleAdjustView) and the calibrated / "
+                     "uncalibrated relative-pose (BundleAdjustTwoViewsAngular) estimators and the trivial ones are built; "
+                     "OptimizeFundamentalMatrix / OptimizeHomography are not yet");
   // exhaustive_sampler.cc:49-51 CHECK
   if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE && sample_size(est) != 2)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "ExhaustiveSampler makes a hard assumption that the number of samples needed is 2.");
@@ -821,6 +825,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     lo_opts.loss_function_type = THEIA_LOSS_TRUNCATED;
     lo_opts.robust_loss_width = P.error_thresh;
   }
+  if (uncal_pose) lo_opts.max_num_iterations = 10;      // estimate_uncalibrated_relative_pose.cc:162-165 (HUBER, 1.5 x thresh)
   if (P.use_lo && (rc = d_cur_models.ensure((size_t)nprob * kStride))) return rc;
   struct LoEvent { int prob, slot; int samples[8]; };
   // refines every event's model on its inliers; writes the refined pose to d_cur_models[prob]
@@ -829,17 +834,17 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     success.assign(nev, 0);
     if (nev == 0) return 0;
     std::lock_guard<std::recursive_mutex> scratch_lock(scratch_mutex());
-    std::vector<int> hp(nev), hs((size_t)nev * 5), hsl(nev), hmod(nev, THEIA_CAM_PINHOLE);
+    std::vector<int> hp(nev), hs((size_t)nev * kMaxSample), hsl(nev), hmod(nev, THEIA_CAM_PINHOLE);
     std::vector<int64_t> hoff(nev + 1, 0);
     std::vector<double> hintr((size_t)nev * THEIA_MAX_INTRINSICS, 0.0);
     for (int e = 0; e < nev; ++e) {
       hp[e] = evs[e].prob; hsl[e] = evs[e].slot;
-      for (int k = 0; k < 5; ++k) hs[(size_t)e * 5 + k] = evs[e].samples[k];
+      for (int k = 0; k < kMaxSample; ++k) hs[(size_t)e * kMaxSample + k] = evs[e].samples[k];
       hoff[e + 1] = hoff[e] + S[evs[e].prob].n;          // capacity: every datum could be an inlier
       hintr[(size_t)e * THEIA_MAX_INTRINSICS] = 1.0; hintr[(size_t)e * THEIA_MAX_INTRINSICS + 1] = 1.0;   // Camera(): f = 1, aspect 1
     }
     int rc2;
-    if ((rc2 = d_ev_prob.ensure(nev)) || (rc2 = d_ev_samples.ensure((size_t)nev * 5)) || (rc2 = d_ev_slot.ensure(nev)) ||
+    if ((rc2 = d_ev_prob.ensure(nev)) || (rc2 = d_ev_samples.ensure((size_t)nev * kMaxSample)) || (rc2 = d_ev_slot.ensure(nev)) ||
         (rc2 = d_ev_count.ensure(nev)) || (rc2 = d_ev_success.ensure(nev)) || (rc2 = d_ev_off.ensure(nev + 1)) ||
         (rc2 = d_ev_model.ensure((size_t)nev * kStride)) || (rc2 = d_ev_cam.ensure((size_t)nev * 6)) ||
         (rc2 = d_lo_uv.ensure((size_t)hoff[nev] * 2)) || (rc2 = d_lo_X.ensure((size_t)hoff[nev] * 4)) ||
@@ -847,17 +852,17 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         (rc2 = d_lo_out.ensure(views_batch_out_bytes() * nev)))
       return rc2;
     HIP_TRYR(hipMemcpyAsync(d_ev_prob.p, hp.data(), sizeof(int) * nev, hipMemcpyHostToDevice, st));
-    HIP_TRYR(hipMemcpyAsync(d_ev_samples.p, hs.data(), sizeof(int) * nev * 5, hipMemcpyHostToDevice, st));
+    HIP_TRYR(hipMemcpyAsync(d_ev_samples.p, hs.data(), sizeof(int) * nev * kMaxSample, hipMemcpyHostToDevice, st));
     HIP_TRYR(hipMemcpyAsync(d_ev_slot.p, hsl.data(), sizeof(int) * nev, hipMemcpyHostToDevice, st));
     HIP_TRYR(hipMemcpyAsync(d_ev_off.p, hoff.data(), sizeof(int64_t) * (nev + 1), hipMemcpyHostToDevice, st));
     HIP_TRYR(hipMemcpyAsync(d_lo_intr.p, hintr.data(), sizeof(double) * hintr.size(), hipMemcpyHostToDevice, st));
     HIP_TRYR(hipMemcpyAsync(d_lo_model_id.p, hmod.data(), sizeof(int) * nev, hipMemcpyHostToDevice, st));
     k_lo_prepare<<<(nev + 63) / 64, 64, 0, st>>>(est, nev, d_ev_prob.p, d_ev_samples.p, d_ev_slot.p, d_off.p, d_data.p,
-                                                 d_cur_models.p, d_ev_model.p, d_ev_cam.p);
+                                                 d_cur_models.p, d_ev_model.p, d_ev_cam.p, ep);
     k_lo_gather<<<nev, 64, 0, st>>>(est, d_ev_prob.p, d_off.p, d_data.p, d_ev_model.p, P.error_thresh, d_ev_off.p, d_ev_count.p,
                                     reinterpret_cast<double2*>(d_lo_uv.p), reinterpret_cast<double4*>(d_lo_X.p));
-    if (rel_pose)
-      twoview_batch_device(nev, d_ev_off.p, d_ev_count.p, d_lo_X.p, d_ev_cam.p, &lo_opts, d_lo_out.p, st);
+    if (rel_pose || uncal_pose)   // the relative-pose RefineModel asks for CGNR, the uncalibrated one keeps the direct default
+      twoview_batch_device(nev, d_ev_off.p, d_ev_count.p, d_lo_X.p, d_ev_cam.p, &lo_opts, rel_pose ? 1 : 0, d_lo_out.p, st);
     else
       views_batch_device(nev, d_ev_off.p, d_ev_count.p, d_lo_uv.p, nullptr, d_lo_X.p, d_ev_cam.p, d_lo_intr.p, d_lo_model_id.p,
                          nullptr, &lo_opts, d_lo_out.p, st);
@@ -992,7 +997,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
                   s.num_lo++;   // RefineModel = "return true": nothing changes but the counter
                 } else if (P.use_lo && s.base_it + s.rb >= P.lo_start_iterations) {   // :373-381
                   LoEvent ev; ev.prob = c0 + q; ev.slot = j;
-                  for (int i = 0; i < 5; ++i) ev.samples[i] = s.best_samples[i];
+                  for (int i = 0; i < kMaxSample; ++i) ev.samples[i] = s.best_samples[i];
                   events.push_back(ev); ev_q.push_back(q);
                   s.pending_ratio = inlier_ratio;
                   paused = true;
@@ -1059,7 +1064,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     HIP_TRYR(hipMemcpyAsync(d_cur_models.p, d_best_models.p, sizeof(double) * nprob * kStride, hipMemcpyDeviceToDevice, st));
     std::vector<LoEvent> evs;
     for (int p = 0; p < nprob; ++p)
-      if (S[p].best_slot >= 0) { LoEvent ev; ev.prob = p; ev.slot = -1; for (int k = 0; k < 5; ++k) ev.samples[k] = 0; evs.push_back(ev); }
+      if (S[p].best_slot >= 0) { LoEvent ev; ev.prob = p; ev.slot = -1; for (int k = 0; k < kMaxSample; ++k) ev.samples[k] = 0; evs.push_back(ev); }
     std::vector<int> ok;
     if ((rc = run_lo(evs, ok))) return rc;
     for (const LoEvent& ev : evs) S[ev.prob].num_lo++;

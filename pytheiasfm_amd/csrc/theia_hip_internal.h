@@ -20,7 +20,7 @@ int views_batch_device(int num, const int64_t* d_offsets, const int* d_counts, c
                        const theia_ba_options* o, void* d_out, hipStream_t st);
 size_t views_batch_out_bytes();
 // twoview_lm.hip: batched BundleAdjustTwoViewsAngular on device-resident (x1, y1, x2, y2) rows; d_pose = [num][6]
-// (rotation_2 | position_2) in/out; d_out as for views_batch_device.
+// (rotation_2 | position_2) in/out; cgnr = 1: CGNR + JACOBI steps, 0: exact normal-equation solve; d_out as for views_batch_device.
 int twoview_batch_device(int num, const int64_t* d_offsets, const int* d_counts, const double* d_corr, double* d_pose,
-                         const theia_ba_options* o, void* d_out, hipStream_t st);
+                         const theia_ba_options* o, int cgnr, void* d_out, hipStream_t st);
 }  // namespace thip

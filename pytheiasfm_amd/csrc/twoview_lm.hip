@@ -14,6 +14,8 @@
 // the two parameter blocks and stopped by Ceres' q-tolerance rule (eta = 0.1) -- an INEXACT step,
 // which is part of the behaviour and is restated (cgnr5).  The 5 x 5 normal matrix is formed
 // explicitly (wave reduction, fixed order), so  A p = H p + D^2 p  where Ceres evaluates J'(J p).
+// With the default options (SPARSE_SCHUR; RefineModel of the uncalibrated relative-pose estimator,
+// estimate_uncalibrated_relative_pose.cc:142-176) the step is the exact solution (solve5).
 #include "ba_device.h"
 #include "theia_hip_internal.h"
 
@@ -49,6 +51,7 @@ struct TwoViewBatch {
   double loss_width;
   int max_iterations;
   double function_tolerance, gradient_tolerance, parameter_tolerance, max_radius;
+  int cgnr;                 // 1: the CGNR + JACOBI inexact step; 0: exact solve of the normal equations
 };
 
 struct TwoViewOut {   // = ba_batch.hip ViewOut
@@ -319,6 +322,30 @@ __device__ bool cgnr5(const double* H, const double* D2, const double* g, double
   }
 }
 
+// (H + diag(d)) y = g by Cholesky (the direct solvers: SPARSE_SCHUR / DENSE_* of the caller's options); false if not PD
+__device__ bool solve5(const double* H, const double* d, const double* g, double* y) {
+  double L[15];
+  for (int i = 0; i < 5; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = H[tri(i, j)] + (i == j ? d[i] : 0.0);
+      for (int k = 0; k < j; ++k) s -= L[tri(i, k)] * L[tri(j, k)];
+      if (i == j) { if (!(s > 0.0)) return false; L[tri(i, i)] = sqrt(s); }
+      else L[tri(i, j)] = s / L[tri(j, j)];
+    }
+  double z[5];
+  for (int i = 0; i < 5; ++i) {
+    double s = g[i];
+    for (int k = 0; k < i; ++k) s -= L[tri(i, k)] * z[k];
+    z[i] = s / L[tri(i, i)];
+  }
+  for (int i = 4; i >= 0; --i) {
+    double s = z[i];
+    for (int k = i + 1; k < 5; ++k) s -= L[tri(k, i)] * y[k];
+    y[i] = s / L[tri(i, i)];
+  }
+  return true;
+}
+
 __global__ __launch_bounds__(256) void k_twoview_lm(TwoViewBatch B, TwoViewOut* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -367,7 +394,7 @@ __global__ __launch_bounds__(256) void k_twoview_lm(TwoViewBatch B, TwoViewOut* 
     double d[5], y[5];
 #pragma unroll
     for (int q = 0; q < 5; ++q) d[q] = fmin(fmax(H[tri(q, q)], 1e-6), 1e32) / radius;
-    const bool solved = cgnr5(H, d, g, y);
+    const bool solved = B.cgnr ? cgnr5(H, d, g, y) : solve5(H, d, g, y);
     // model cost change of the step -y:  y'g - y'Hy/2  (H without the LM diagonal)
     double yg = 0.0, yHy = 0.0;
     for (int a = 0; a < 5; ++a) {
@@ -447,13 +474,14 @@ struct Dev {
 
 // device-resident variant for callers inside the library (LO-RANSAC); d_out = views_batch_out_bytes() per problem
 int twoview_batch_device(int num, const int64_t* d_offsets, const int* d_counts, const double* d_corr, double* d_pose,
-                         const theia_ba_options* o, void* d_out, hipStream_t st) {
+                         const theia_ba_options* o, int cgnr, void* d_out, hipStream_t st) {
   static_assert(sizeof(TwoViewOut) == 32, "layout shared with ba_batch.hip ViewOut");
   TwoViewBatch B;
   B.num = num; B.offsets = d_offsets; B.counts = d_counts; B.corr = reinterpret_cast<const double4*>(d_corr); B.pose = d_pose;
   B.loss_type = o->loss_function_type; B.loss_width = o->robust_loss_width; B.max_iterations = o->max_num_iterations;
   B.function_tolerance = o->function_tolerance; B.gradient_tolerance = o->gradient_tolerance;
   B.parameter_tolerance = o->parameter_tolerance; B.max_radius = o->max_trust_region_radius;
+  B.cgnr = cgnr;
   k_twoview_lm<<<(num + 3) / 4, 256, 0, st>>>(B, static_cast<TwoViewOut*>(d_out));
   return 0;
 }
@@ -477,6 +505,8 @@ extern "C" int theia_hip_ba_two_views_angular_batch(const theia_ba_two_view_batc
   if (o->loss_function_type < 0 || o->loss_function_type > THEIA_LOSS_TRUNCATED)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown loss function type");
   if (o->max_num_iterations < 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "negative max_num_iterations");
+  if (b->linear_solver != THEIA_TWO_VIEW_EXACT && b->linear_solver != THEIA_TWO_VIEW_CGNR)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown linear_solver %d", b->linear_solver);
   int rc = thip::ensure_device();
   if (rc) return rc;
   Dev<int64_t> d_off; Dev<double> d_corr, d_pose; Dev<char> d_out;
@@ -484,7 +514,7 @@ extern "C" int theia_hip_ba_two_views_angular_batch(const theia_ba_two_view_batc
       (rc = d_pose.up(b->rotation_position, 6 * (size_t)num)) || (rc = d_out.alloc(sizeof(TwoViewOut) * num)))
     return rc;
   const double t0 = now_s();
-  twoview_batch_device(num, d_off.p, nullptr, d_corr.p, d_pose.p, o, d_out.p, nullptr);
+  twoview_batch_device(num, d_off.p, nullptr, d_corr.p, d_pose.p, o, b->linear_solver == THEIA_TWO_VIEW_CGNR, d_out.p, nullptr);
   std::vector<TwoViewOut> h_out(num);
   HIP_TRY(hipMemcpy(h_out.data(), d_out.p, sizeof(TwoViewOut) * num, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(b->rotation_position, d_pose.p, sizeof(double) * 6 * num, hipMemcpyDeviceToHost));

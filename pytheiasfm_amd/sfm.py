@@ -351,7 +351,9 @@ def BundleAdjustTwoViewsAngularBatch(options, correspondences_list, two_view_inf
     offsets[1:] = np.cumsum([len(c) for c in corr])
     rp = np.array([np.concatenate([np.asarray(i.rotation_2, dtype=np.float64), np.asarray(i.position_2, dtype=np.float64)])
                    for i in two_view_infos], dtype=np.float64).reshape(n, 6)
-    summ = _ba.solve_two_views_angular_batch(offsets, np.vstack(corr) if n else np.zeros((0, 4)), rp, options.to_c())
+    cgnr = str(getattr(options, "linear_solver_type", "")).upper().endswith("CGNR")   # every other type is a direct solve
+    summ = _ba.solve_two_views_angular_batch(offsets, np.vstack(corr) if n else np.zeros((0, 4)), rp, options.to_c(),
+                                             _ba.TWO_VIEW_CGNR if cgnr else _ba.TWO_VIEW_EXACT)
     for k, info in enumerate(two_view_infos):
         info.rotation_2 = rp[k, :3].copy()
         info.position_2 = rp[k, 3:].copy()

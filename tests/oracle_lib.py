@@ -296,18 +296,19 @@ def camera_prior(kind, ext, prior, sqrt_info):
     return r, J
 
 
-def two_views_angular(corr, rotation_position, options):
-    """oracle_two_views_angular: BundleAdjustTwoViewsAngular of ONE pair; returns (pose[6], dict)."""
+def two_views_angular(corr, rotation_position, options, linear_solver=1):
+    """oracle_two_views_angular: BundleAdjustTwoViewsAngular of ONE pair; returns (pose[6], dict).
+    linear_solver: 1 = CGNR + JACOBI (the relative-pose RefineModel), 0 = exact normal-equation solve."""
     L = load()
     dp = capi.c_double_p
     L.oracle_two_views_angular.argtypes = [C.c_int64, dp, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double,
-                                           C.c_double, dp, capi.c_int32_p, dp]
+                                           C.c_double, C.c_int, dp, capi.c_int32_p, dp]
     corr = np.ascontiguousarray(corr, dtype=np.float64).reshape(-1, 4)
     pose = np.array(rotation_position, dtype=np.float64).reshape(6).copy()
     oi = np.zeros(4, dtype=np.int32); oc = np.zeros(2)
     L.oracle_two_views_angular(len(corr), capi.ptr(corr, C.c_double), options.loss_function_type, options.robust_loss_width,
                                options.max_num_iterations, options.function_tolerance, options.gradient_tolerance,
-                               options.parameter_tolerance, options.max_trust_region_radius, capi.ptr(pose, C.c_double),
+                               options.parameter_tolerance, options.max_trust_region_radius, int(linear_solver), capi.ptr(pose, C.c_double),
                                capi.ptr(oi, C.c_int32), capi.ptr(oc, C.c_double))
     return pose, dict(success=int(oi[0]), termination_type=int(oi[1]), num_iterations=int(oi[2]),
                       num_successful_steps=int(oi[3]), initial_cost=float(oc[0]), final_cost=float(oc[1]))

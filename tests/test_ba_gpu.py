@@ -939,15 +939,16 @@ def test_two_views_angular_batch_follows_oracle():
     corr = np.vstack(corr); x0s = np.array(x0s)
     for loss, width in ((6, 2e-4), (0, 1.0), (1, 1e-5)):
         o = ba.default_options(); o.max_num_iterations = 15; o.loss_function_type = loss; o.robust_loss_width = width
-        pose = x0s.copy()
-        summ = ba.solve_two_views_angular_batch(offs, corr, pose, o)
-        for p in range(len(x0s)):
-            ref, s = ol.two_views_angular(corr[offs[p]:offs[p + 1]], x0s[p], o)
-            assert summ[p].num_iterations == s["num_iterations"] and summ[p].num_successful_steps == s["num_successful_steps"], (loss, p)
-            assert summ[p].termination_type == s["termination_type"] and summ[p].success == s["success"]
-            assert np.abs(pose[p] - ref).max() <= 1e-9, (loss, p, np.abs(pose[p] - ref).max())
-            assert abs(summ[p].initial_cost - s["initial_cost"]) <= 1e-9 * max(s["initial_cost"], 1e-300) + 1e-300
-            assert abs(summ[p].final_cost - s["final_cost"]) <= 1e-9 * max(s["final_cost"], 1e-300) + 1e-20
-            if p < 12 and loss == 6:
-                assert summ[p].final_cost < summ[p].initial_cost and abs(np.linalg.norm(pose[p][3:]) - 1.0) <= 1e-14
-        assert np.array_equal(pose[12], x0s[12]) and summ[12].num_iterations == 0
+        for solver in (ba.TWO_VIEW_CGNR, ba.TWO_VIEW_EXACT):
+            pose = x0s.copy()
+            summ = ba.solve_two_views_angular_batch(offs, corr, pose, o, solver)
+            for p in range(len(x0s)):
+                ref, s = ol.two_views_angular(corr[offs[p]:offs[p + 1]], x0s[p], o, solver)
+                assert summ[p].num_iterations == s["num_iterations"] and summ[p].num_successful_steps == s["num_successful_steps"], (loss, p)
+                assert summ[p].termination_type == s["termination_type"] and summ[p].success == s["success"]
+                assert np.abs(pose[p] - ref).max() <= 1e-9, (loss, p, np.abs(pose[p] - ref).max())
+                assert abs(summ[p].initial_cost - s["initial_cost"]) <= 1e-9 * max(s["initial_cost"], 1e-300) + 1e-300
+                assert abs(summ[p].final_cost - s["final_cost"]) <= 1e-9 * max(s["final_cost"], 1e-300) + 1e-20
+                if p < 12 and loss == 6:
+                    assert summ[p].final_cost < summ[p].initial_cost and abs(np.linalg.norm(pose[p][3:]) - 1.0) <= 1e-14
+            assert np.array_equal(pose[12], x0s[12]) and summ[12].num_iterations == 0

@@ -378,6 +378,32 @@ def test_uncalibrated_relative_pose_follows_oracle(rtype):
     assert np.all(res["num_inliers"] < 0.3 * 300)
 
 
+def test_lo_ransac_uncalibrated_relative_pose_follows_oracle():
+    """use_lo with UncalibratedRelativePoseEstimator::RefineModel (estimate_uncalibrated_relative_pose.cc:142-176):
+    BundleAdjustTwoViewsAngular on the correspondences divided by the model's focal lengths, HUBER 1.5 x threshold,
+    <= 10 iterations, exact steps.  F and the focal lengths stay, (R, position) are refined."""
+    data, offsets, truth = synth.synth_ransac_v1(6, 300, "uncalibrated", seed=0x5AC51610, inlier_lo=0.5, inlier_hi=0.7,
+                                                 noise_px=0.3)
+    p = ransac.RansacParameters(); p.error_thresh = 4.0; p.seed = 19; p.failure_probability = 0.001
+    p.use_lo = True; p.lo_start_iterations = 5; p.min_iterations = 50
+    mm = np.array([1.0, 1e9])
+    res = ransac.estimate_batch(9, data, offsets, p, mm)
+    ol.set_estimator_params(mm)
+    for i in range(6):
+        pc = p.to_c(); pc.seed = 19 + i
+        o = ol.ransac_estimate(9, data[offsets[i]:offsets[i + 1]], pc)
+        nlo = ol.rlib().oracle_last_lo_iterations()
+        sl = slice(offsets[i], offsets[i + 1])
+        assert o["num_iterations"] == res["num_iterations"][i] and nlo == res["num_lo_iterations"][i] and nlo >= 1
+        assert np.array_equal(o["inlier_mask"], res["inlier_mask"][sl])
+        assert np.allclose(o["model"][:9], res["models"][i][:9], rtol=1e-9, atol=1e-12)          # F
+        assert np.allclose(o["model"][21:23], res["models"][i][21:23], rtol=1e-9, atol=0)       # focal lengths
+        assert np.abs(o["model"][9:21] - res["models"][i][9:21]).max() <= 1e-7
+        Rm = res["models"][i][9:18].reshape(3, 3)
+        assert np.abs(Rm @ Rm.T - np.eye(3)).max() <= 1e-12
+    assert res["num_lo_iterations"].sum() >= 6
+
+
 def test_estimate_two_view_info_both_branches():
     from pytheiasfm_amd import twoview as tv
     opts = tv.EstimateTwoViewInfoOptions(); opts.seed = 5; opts.max_sampson_error_pixels = 2.0
@@ -502,7 +528,7 @@ def test_golden_two_view_lo_on_device():
     corr = [g[f"tv{k}_corr"] for k in range(4)]
     offs = np.concatenate([[0], np.cumsum([len(c) for c in corr])])
     pose = np.array([g[f"tv{k}_x0"] for k in range(4)])
-    summ = ba.solve_two_views_angular_batch(offs, np.vstack(corr), pose, o)
+    summ = ba.solve_two_views_angular_batch(offs, np.vstack(corr), pose, o, ba.TWO_VIEW_CGNR)
     for k in range(4):
         assert np.abs(pose[k] - g[f"tv{k}_pose"]).max() <= 1e-9
         assert [summ[k].success, summ[k].termination_type, summ[k].num_iterations, summ[k].num_successful_steps] == list(g[f"tv{k}_ints"])
