@@ -193,3 +193,168 @@ def EstimateTwoViewInfoBatch(options, priors1, priors2, correspondences_list):
 def EstimateTwoViewInfo(options, intrinsics1, intrinsics2, correspondences):
     """estimate_twoview_info.cc:262-305 -> (success, TwoViewInfo, inlier_indices)."""
     return EstimateTwoViewInfoBatch(options, [intrinsics1], [intrinsics2], [correspondences])[0]
+
+
+# ------------------------------------------------------------------------------------------------
+# Two-view BA and the geometric verification of a match list (two_view_match_geometric_verification.cc)
+
+class TwoViewBundleAdjustmentOptions:  # bundle_adjust_two_views.h:52-57
+    def __init__(self):
+        from . import sfm as _sfm
+        self.ba_options = _sfm.BundleAdjustmentOptions()
+        self.constant_camera1_intrinsics = True
+        self.constant_camera2_intrinsics = True
+
+
+def BundleAdjustTwoViews(options, correspondences, camera1, camera2, points3d):
+    """bundle_adjust_two_views.cc:110-185: camera 1 fixed, camera 2's six extrinsics and (unless held constant) the two
+    focal lengths free, every triangulated point a free XYZW 4-vector, no loss function; its own SetSolverOptions
+    (:60-72) takes only max_num_iterations from the options.  camera = dict(ext[6], intr[<=10], model); both cameras
+    and points3d [N][4] are updated in place.  One theia_hip_ba_solve."""
+    from . import ba as _ba, sfm as _sfm
+    c = np.ascontiguousarray(correspondences, dtype=np.float64).reshape(-1, 4)
+    n = c.shape[0]
+    pts = points3d
+    if not (isinstance(pts, np.ndarray) and pts.dtype == np.float64 and pts.shape == (n, 4) and pts.flags["C_CONTIGUOUS"]):
+        raise capi.TheiaHipError(capi.THEIA_HIP_ERR_INVALID_ARGUMENT, "points3d must be a C-contiguous float64 [N][4] array, one per correspondence")
+    intr = np.zeros((2, capi.THEIA_MAX_INTRINSICS))
+    for k, cam in enumerate((camera1, camera2)):
+        v = np.asarray(cam["intr"], dtype=np.float64); intr[k, :len(v)] = v
+    flat = capi.FlatProblem(np.array([camera1["ext"], camera2["ext"]], dtype=np.float64), intr,
+                            [int(camera1["model"]), int(camera2["model"])], [0, 1], pts,
+                            np.concatenate([c[:, 0:2], c[:, 2:4]]),
+                            np.concatenate([np.zeros(n, np.int32), np.ones(n, np.int32)]),
+                            np.concatenate([np.arange(n), np.arange(n)]).astype(np.int32),
+                            cam_const=[3, 0],
+                            group_const=[int(bool(options.constant_camera1_intrinsics)), int(bool(options.constant_camera2_intrinsics))])
+    o = _sfm.BundleAdjustmentOptions()          # Ceres' own defaults are the option defaults here
+    o.max_num_iterations = options.ba_options.max_num_iterations
+    o.use_homogeneous_point_parametrization = False
+    o.intrinsics_to_optimize = _sfm.OptimizeIntrinsicsType.FOCAL_LENGTH
+    o.use_inner_iterations = False
+    s, _ = _ba.solve(flat, o.to_c())
+    camera1["ext"][:] = flat.cam_ext[0]; camera2["ext"][:] = flat.cam_ext[1]
+    camera1["intr"][:] = flat.intrinsics[0][:len(camera1["intr"])]; camera2["intr"][:] = flat.intrinsics[1][:len(camera2["intr"])]
+    pts[:] = flat.points
+    return _sfm.BundleAdjustmentSummary(s)
+
+
+class TwoViewMatchGeometricVerificationOptions:  # two_view_match_geometric_verification.h:51-99
+    def __init__(self):
+        self.estimate_twoview_info_options = EstimateTwoViewInfoOptions()
+        self.min_num_inlier_matches = 30
+        self.guided_matching = False
+        self.bundle_adjustment = True
+        self.triangulation_max_reprojection_error = 15.0
+        self.min_triangulation_angle_degrees = 4.0
+        self.final_max_reprojection_error = 5.0
+
+
+def _setup_cameras(prior1, prior2, info):
+    """SetupCameras (two_view_match_geometric_verification.cc:56-68): pinhole cameras from the priors with the
+    estimated focal lengths; camera 1 at the origin."""
+    cams = []
+    for prior, f, ext in ((prior1, info.focal_length_1, np.zeros(6)),
+                          (prior2, info.focal_length_2, np.concatenate([info.position_2, info.rotation_2]))):
+        _, ar, skew, pp = _pinhole_from_prior(prior)
+        cams.append({"ext": np.array(ext, dtype=np.float64), "intr": np.array([f, ar, skew, pp[0], pp[1], 0.0, 0.0]), "model": 0})
+    return cams
+
+
+def _rays(cam, uv):
+    """Camera::PixelToUnitDepthRay(pixel).normalized() of a distortion-free pinhole camera (camera.cc:177-196)."""
+    from . import synth as _synth
+    f, ar, skew, px, py = cam["intr"][:5]
+    y = (uv[:, 1] - py) / (f * ar)
+    x = (uv[:, 0] - px - y * skew) / f
+    d = np.stack([x, y, np.ones_like(x)], axis=1)
+    R = _synth.angle_axis_to_matrix(cam["ext"][3:6])
+    d = d @ R          # R^T d, row-wise
+    return d / np.linalg.norm(d, axis=1, keepdims=True)
+
+
+def _per_view_reprojection(cams, corr, pts):
+    """Squared reprojection error and the depth sign of every (point, view) pair, on the device: each pair becomes a
+    one-observation track of theia_hip_track_statistics."""
+    from . import ba as _ba
+    n = corr.shape[0]
+    intr = np.zeros((2, capi.THEIA_MAX_INTRINSICS)); intr[0, :7] = cams[0]["intr"]; intr[1, :7] = cams[1]["intr"]
+    flat = capi.FlatProblem(np.array([cams[0]["ext"], cams[1]["ext"]]), intr, [0, 0], [0, 1], np.concatenate([pts, pts]),
+                            np.concatenate([corr[:, 0:2], corr[:, 2:4]]),
+                            np.concatenate([np.zeros(n, np.int32), np.ones(n, np.int32)]), np.arange(2 * n, dtype=np.int32))
+    err, behind, _ = _ba.track_statistics(flat)
+    return err.reshape(2, n), behind.reshape(2, n)
+
+
+def VerifyMatchesBatch(options, priors1, priors2, correspondences_list):
+    """TwoViewMatchGeometricVerification::VerifyMatches (two_view_match_geometric_verification.cc:114-183) for a list of
+    image pairs given as pixel correspondences [(x1, y1, x2, y2)] (the reference indexes keypoint lists).  Returns a
+    list of (success, TwoViewInfo, verified_indices).  The homography count (:331-368) and EstimateTwoViewInfo run as
+    two RANSAC batches over all pairs, triangulation and the reprojection filters as device sweeps, the two-view BA as
+    one solve per pair.  Guided matching needs descriptors and is not built.  Stated deviation: the reference draws the
+    homography and the relative-pose samples from ONE generator in sequence; here both batches start from `seed`."""
+    from . import ba as _ba
+    if options.guided_matching:
+        raise capi.TheiaHipError(capi.THEIA_HIP_ERR_UNSUPPORTED, "guided matching (descriptor search along epipolar lines) is not built")
+    n = len(correspondences_list)
+    corr = [np.ascontiguousarray(c, dtype=np.float64).reshape(-1, 4) for c in correspondences_list]
+    results = [(False, TwoViewInfo(), []) for _ in range(n)]
+    live = [i for i in range(n) if len(corr[i]) >= options.min_num_inlier_matches]   # :117-119
+    if not live:
+        return results
+    eo = options.estimate_twoview_info_options
+    # CountHomographyInliers: camera1_/camera2_ are still default-constructed there (image size 0 x 0), so the
+    # resolution scaling leaves the threshold at max_sampson_error_pixels^2
+    hp = _ransac_params(eo, eo.max_sampson_error_pixels * eo.max_sampson_error_pixels)
+    hp.use_lo = 0                                   # a fresh RansacParameters: use_lo keeps its default
+    offsets = np.zeros(len(live) + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([len(corr[i]) for i in live])
+    hres = _ransac.estimate_batch(_ransac.EST_HOMOGRAPHY, np.concatenate([corr[i] for i in live]), offsets, hp)
+    tv = EstimateTwoViewInfoBatch(eo, [priors1[i] for i in live], [priors2[i] for i in live], [corr[i] for i in live])
+    for k, i in enumerate(live):
+        ok, info, inliers = tv[k]
+        info.num_homography_inliers = int(hres["num_inliers"][k])
+        if not ok or len(inliers) < options.min_num_inlier_matches:
+            results[i] = (False, info, [])
+            continue
+        idx = np.asarray(inliers, dtype=np.int64)
+        c = corr[i][idx]
+        if options.bundle_adjustment and len(idx) > options.min_num_inlier_matches:
+            cams = _setup_cameras(priors1[i], priors2[i], info)
+            # TriangulatePoints (:186-257): angle test, midpoint, both reprojection errors below the threshold
+            rays = np.concatenate([_rays(cams[0], c[:, 0:2]), _rays(cams[1], c[:, 2:4])])
+            m = len(idx)
+            intr = np.zeros((2, capi.THEIA_MAX_INTRINSICS)); intr[0, :7] = cams[0]["intr"]; intr[1, :7] = cams[1]["intr"]
+            flat = capi.FlatProblem(np.array([cams[0]["ext"], cams[1]["ext"]]), intr, [0, 0], [0, 1], np.zeros((m, 4)),
+                                    np.concatenate([c[:, 0:2], c[:, 2:4]]),
+                                    np.concatenate([np.zeros(m, np.int32), np.ones(m, np.int32)]),
+                                    np.concatenate([np.arange(m), np.arange(m)]).astype(np.int32))
+            est, _ = _ba.estimate_tracks(flat, rays, _ba.default_options(), options.min_triangulation_angle_degrees, 1e150, False)
+            err, behind = _per_view_reprojection(cams, c, flat.points)
+            lim = options.triangulation_max_reprojection_error ** 2
+            keep = est & (behind.sum(0) == 0) & (err[0] < lim) & (err[1] < lim)
+            idx, c, pts = idx[keep], c[keep], np.ascontiguousarray(flat.points[keep])
+            if len(idx) < options.min_num_inlier_matches:          # :271-273
+                results[i] = (False, info, [])
+                continue
+            bo = TwoViewBundleAdjustmentOptions()
+            bo.constant_camera1_intrinsics = priors1[i].focal_length.is_set
+            bo.constant_camera2_intrinsics = priors2[i].focal_length.is_set
+            summ = BundleAdjustTwoViews(bo, c, cams[0], cams[1], pts)
+            if not summ.success:
+                results[i] = (False, info, [])
+                continue
+            err, behind = _per_view_reprojection(cams, c, pts)
+            lim = options.final_max_reprojection_error ** 2
+            keep = (behind.sum(0) == 0) & (err[0] < lim) & (err[1] < lim)
+            idx = idx[keep]
+            info.rotation_2 = cams[1]["ext"][3:6].copy()
+            info.position_2 = cams[1]["ext"][0:3] / np.linalg.norm(cams[1]["ext"][0:3])
+            info.focal_length_1 = float(cams[0]["intr"][0]); info.focal_length_2 = float(cams[1]["intr"][0])
+        info.num_verified_matches = len(idx)
+        results[i] = (len(idx) > options.min_num_inlier_matches, info, idx.tolist())
+    return results
+
+
+def VerifyMatches(options, intrinsics1, intrinsics2, correspondences):
+    return VerifyMatchesBatch(options, [intrinsics1], [intrinsics2], [correspondences])[0]

@@ -541,3 +541,41 @@ def test_golden_two_view_lo_on_device():
         assert np.array_equal(res["inlier_mask"][g["rel_offsets"][i]:g["rel_offsets"][i + 1]], g["rel_lo_masks"][i])
         assert np.array_equal(res["models"][i][:9], g["rel_lo_models"][i][:9])
         assert np.abs(res["models"][i][9:21] - g["rel_lo_models"][i][9:21]).max() <= 1e-8
+
+
+def test_two_view_match_geometric_verification():
+    """TwoViewMatchGeometricVerification::VerifyMatches on synthetic pairs (pixels = normalised * 1000 + (500, 400)):
+    homography count, two-view info, triangulation filter, BundleAdjustTwoViews, final reprojection filter."""
+    from pytheiasfm_amd import twoview as tv
+    data, offsets, truth = synth.synth_ransac_v1(3, 400, "fundamental", seed=0x5AC51800, inlier_lo=0.6, inlier_hi=0.8, noise_px=0.5)
+    pr = tv.CameraIntrinsicsPrior(); pr.image_width = 1000; pr.image_height = 800
+    pr.focal_length.is_set = True; pr.focal_length.value = [1000.0]
+    pr.principal_point.is_set = True; pr.principal_point.value = [500.0, 400.0]
+    corr = [data[offsets[i]:offsets[i + 1]] for i in range(3)] + [data[:20]]       # the last pair has too few matches
+    vo = tv.TwoViewMatchGeometricVerificationOptions()
+    vo.estimate_twoview_info_options.seed = 7; vo.estimate_twoview_info_options.max_sampson_error_pixels = 2.0
+    vo.estimate_twoview_info_options.use_lo = True; vo.estimate_twoview_info_options.lo_start_iterations = 5
+    out = tv.VerifyMatchesBatch(vo, [pr] * 4, [pr] * 4, corr)
+    assert out[3][0] is False and out[3][2] == []
+    plain = tv.EstimateTwoViewInfoBatch(vo.estimate_twoview_info_options, [pr] * 3, [pr] * 3, corr[:3])
+    for i in range(3):
+        ok, info, idx = out[i]
+        assert ok and info.num_verified_matches == len(idx) > 150
+        inl = truth["inlier"][i]
+        assert inl[idx].mean() > 0.97                                  # almost no outlier survives both filters
+        assert set(idx) <= set(plain[i][2])                            # BA only removes matches
+        R = synth.angle_axis_to_matrix(info.rotation_2)
+        ang = np.degrees(np.arccos(np.clip((np.trace(R @ truth["R"][i].T) - 1) / 2, -1, 1)))
+        Rp = synth.angle_axis_to_matrix(plain[i][1].rotation_2)
+        angp = np.degrees(np.arccos(np.clip((np.trace(Rp @ truth["R"][i].T) - 1) / 2, -1, 1)))
+        assert ang < 0.3 and ang <= angp + 0.05 and abs(np.linalg.norm(info.position_2) - 1) < 1e-12
+        assert info.position_2 @ truth["position"][i] / np.linalg.norm(truth["position"][i]) > 0.999
+        assert info.focal_length_1 == 1000.0 and 0 <= info.num_homography_inliers < len(corr[i])
+    # without the two-view BA the verified matches are the RANSAC inliers
+    vo.bundle_adjustment = False
+    out2 = tv.VerifyMatchesBatch(vo, [pr] * 3, [pr] * 3, corr[:3])
+    for i in range(3):
+        assert out2[i][0] and out2[i][2] == plain[i][2]
+    vo.guided_matching = True
+    with pytest.raises(capi.TheiaHipError):
+        tv.VerifyMatches(vo, pr, pr, corr[0])
