@@ -41,6 +41,8 @@ struct DevProblem {
   const int* grp_k;            // [ng] number of parameters K of the group's model
   const int* grp_red;          // [ng] reduced group index or -1
   const unsigned* grp_free;    // [ng] bit q = parameter q is free
+  const unsigned* red_free;    // [#variable groups] the same mask by reduced group index
+  int intr_rows;               // intrinsics rows stored per record: 10, or 4 compact rows (k-th free parameter)
   const double* scale_i;       // [ng][10] Jacobi scaling of the intrinsics columns
   const double* intr_cand;     // [ng][10] candidate intrinsics (back-substitution / trial cost)
   const double* scale_red;     // [n] Jacobi scaling by reduced index (finalize)
@@ -48,7 +50,7 @@ struct DevProblem {
   // static lists built at create()
   double* rec;                 // per-observation records, camera-major: [#records][6*pd + 14] = {What | F | r} without
                                // intrinsics (What = W Li^T with V^-1 = Li^T Li; gp holds ghat = Li g of slot_pt),
-                               // [#records][32*pd + 50] with intrinsics (ba_kernels.hip)
+                               // [#records][12*pd + 20 + 2*KI*pd + 3*KI] with intrinsics, KI = intr_rows (ba_kernels.hip)
   const uint8_t* obs_kind;     // [nobs] (sorted order) THEIA_OBS_* or null: depth-prior rows use the pseudo model
   double loss_width_depth;     // robust_loss_width_depth_prior
   const int* slot_pt;          // [#records] point of a record slot (records without intrinsics)

@@ -638,15 +638,26 @@ __global__ __launch_bounds__(kBlock) void k_schur(DevProblem P, double* __restri
 //     GD0/GD1  Fk^T Fk - TI WI^T (rows)-> S[grp, grp]   GV  Fk^T r - TI g | Fk^T r | column norms
 // Reduced index: intrinsics slots first (10 per variable group), cameras at ni + 6 rc.
 
-template <int PD> constexpr int rec_stride_intr() { return 32 * PD + 50; }
-template <int PD> struct RecI {   // offsets in double2 units
+// KI = stored intrinsics rows per record: 10 (row = parameter index) or, when no variable group frees more than four
+// parameters (the pipelines' FOCAL_LENGTH | RADIAL_DISTORTION frees three), 4 COMPACT rows: row k = the k-th free
+// parameter of the observation's group (zero beyond the group's count).  The pair passes stream these rows, so the
+// compact form cuts their traffic and FMAs by 2.5x.
+template <int PD, int KI> constexpr int rec_stride_intr() { return 12 * PD + 20 + 2 * KI * PD + 3 * KI; }
+template <int PD, int KI> struct RecI {   // offsets in double2 units
   static constexpr int W = 0, T = 3 * PD, F = 6 * PD, R = 6 * PD + 6, TG = 6 * PD + 7, WI = 6 * PD + 10,
-                       TI = 11 * PD + 10, FK = 16 * PD + 10, TIG = 16 * PD + 20;
+                       TI = WI + KI * PD / 2, FK = TI + KI * PD / 2, TIG = FK + KI;
 };
+// parameter index (0..9) of stored row k of a group with free mask fm, or -1
+template <int KI>
+THIP_DEV int row_param(unsigned fm, int k) {
+  if (KI == THEIA_MAX_INTRINSICS) return k;
+  for (int j = 0; j < k; ++j) fm &= fm - 1u;
+  return fm ? __ffs(fm) - 1 : -1;
+}
 
-template <int PD, int K>
+template <int PD, int KI, int K>
 THIP_DEV void load_reci(const double* __restrict__ rec, int slot, int off2, double (&w)[K]) {
-  const double2* R = reinterpret_cast<const double2*>(rec + (size_t)slot * rec_stride_intr<PD>()) + off2;
+  const double2* R = reinterpret_cast<const double2*>(rec + (size_t)slot * rec_stride_intr<PD, KI>()) + off2;
 #pragma unroll
   for (int k = 0; k < K / 2; ++k) { const double2 t = R[k]; w[2 * k] = t.x; w[2 * k + 1] = t.y; }
 }
@@ -666,9 +677,10 @@ THIP_DEV void finish_item(double (&acc)[NACC], double (*part)[64], bool atomic, 
   if (atomic) atomic_add(dst, v); else *dst = v;
 }
 
-// pair item: acc[RA x RB] += TA_a[ra0 + i][:] . WB_b[j][:]
-template <int PD, int RA, int RB>
-THIP_DEV void pair_item(const DevProblem& P, const int* it, int offA2, int offB2, double (*part)[64], double* __restrict__ S) {
+// pair item: acc[RA x RB] += TA_a[ra0 + i][:] . WB_b[j][:]; GA / GB: the row / column side is an intrinsics block
+// (stored row -> parameter index through the group's free mask), ra0 = first stored row of the item
+template <int PD, int KI, int RA, int RB, bool GA, bool GB>
+THIP_DEV void pair_item(const DevProblem& P, const int* it, int offA2, int offB2, int ra0, double (*part)[64], double* __restrict__ S) {
   const int row0 = it[1], col0 = it[2], beg = it[3], end = it[4], flags = it[5];
   double acc[RA * RB];
 #pragma unroll
@@ -676,8 +688,8 @@ THIP_DEV void pair_item(const DevProblem& P, const int* it, int offA2, int offB2
   for (int q = beg + threadIdx.x; q < end; q += kBlock) {
     const int2 ab = P.blk_pairs[q];
     double TA[RA * PD], WB[RB * PD];
-    load_reci<PD>(P.rec, ab.x, offA2, TA);
-    load_reci<PD>(P.rec, ab.y, offB2, WB);
+    load_reci<PD, KI>(P.rec, ab.x, offA2, TA);
+    load_reci<PD, KI>(P.rec, ab.y, offB2, WB);
 #pragma unroll
     for (int a = 0; a < RA; ++a)
 #pragma unroll
@@ -690,22 +702,25 @@ THIP_DEV void pair_item(const DevProblem& P, const int* it, int offA2, int offB2
   }
   const int n = P.n;
   const bool lower = (flags & ITF_LOWER) != 0;
+  const unsigned fma_ = GA ? P.red_free[row0 / THEIA_MAX_INTRINSICS] : 0u, fmb_ = GB ? P.red_free[col0 / THEIA_MAX_INTRINSICS] : 0u;
   finish_item<RA * RB>(acc, part, (flags & ITF_ATOMIC) != 0, -1.0, [&](int e) -> double* {
-    const int a = e / RB, b = e % RB;
+    int a = e / RB, b = e % RB;
+    if (GA) { a = row_param<KI>(fma_, ra0 + a); if (a < 0) return nullptr; }
+    if (GB) { b = row_param<KI>(fmb_, b); if (b < 0) return nullptr; }
     if (lower && col0 + b > row0 + a) return nullptr;
     return S + (size_t)(row0 + a) * n + col0 + b;
   });
 }
 
 // the same pass with the intrinsics part of the camera-side block (INTR records, see k_schur_intr)
-template <int PD>
+template <int PD, int KI>
 __global__ __launch_bounds__(kBlock) void k_lin_obs_intr(DevProblem P, const double* __restrict__ cam,
                                                     const double* __restrict__ pts, const double* __restrict__ radius_p,
                                                     double* __restrict__ Vinv, double* __restrict__ gp,
                                                     double* __restrict__ tile_part) {
   constexpr int NT = PD * (PD + 1) / 2;
   constexpr int NW = 6 * PD;
-  constexpr int RS = rec_stride_intr<PD>();
+  constexpr int RS = rec_stride_intr<PD, KI>();
   const double radius = *radius_p;   // device-resident: the LM step control runs on the GPU
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -767,7 +782,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_obs_intr(DevProblem P, const dou
       for (int k = 0; k < PD; ++k) s += t[a * PD + k] * g[k];
       tg[a] = s;
     }
-    using O = RecI<PD>;
+    using O = RecI<PD, KI>;
 #pragma unroll
     for (int k = 0; k < NW / 2; ++k) R[O::W + k] = make_double2(w[2 * k], w[2 * k + 1]);
 #pragma unroll
@@ -777,15 +792,33 @@ __global__ __launch_bounds__(kBlock) void k_lin_obs_intr(DevProblem P, const dou
     R[O::R] = make_double2(L.r[0], L.r[1]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) R[O::TG + k] = make_double2(tg[2 * k], tg[2 * k + 1]);
-    // intrinsics part: WI = Fk^T E, TI = WI V^-1, TI g
-    double wi[10 * PD], ti[10 * PD], tig[10];
+    // intrinsics part: WI = Fk^T E, TI = WI V^-1, TI g (KI stored rows)
+    double jk[2 * KI];
+    if (KI == THEIA_MAX_INTRINSICS) {
 #pragma unroll
-    for (int a = 0; a < 10; ++a) {
+      for (int k = 0; k < 2 * KI; ++k) jk[k] = L.Jk[k];
+    } else {
+      unsigned fm = L.gr >= 0 ? P.red_free[L.gr] : 0u;
 #pragma unroll
-      for (int b = 0; b < PD; ++b) wi[a * PD + b] = L.Jk[a] * L.Jt[b] + L.Jk[10 + a] * L.Jt[PD + b];
+      for (int k = 0; k < KI; ++k) {
+        double v0 = 0.0, v1 = 0.0;
+        if (fm) {
+          const int q = __ffs(fm) - 1;
+          fm &= fm - 1u;
+#pragma unroll
+          for (int j = 0; j < THEIA_MAX_INTRINSICS; ++j) if (j == q) { v0 = L.Jk[j]; v1 = L.Jk[THEIA_MAX_INTRINSICS + j]; }
+        }
+        jk[k] = v0; jk[KI + k] = v1;
+      }
+    }
+    double wi[KI * PD], ti[KI * PD], tig[KI];
+#pragma unroll
+    for (int a = 0; a < KI; ++a) {
+#pragma unroll
+      for (int b = 0; b < PD; ++b) wi[a * PD + b] = jk[a] * L.Jt[b] + jk[KI + a] * L.Jt[PD + b];
     }
 #pragma unroll
-    for (int a = 0; a < 10; ++a) {
+    for (int a = 0; a < KI; ++a) {
 #pragma unroll
       for (int b = 0; b < PD; ++b) {
         double s2 = 0.0;
@@ -799,13 +832,13 @@ __global__ __launch_bounds__(kBlock) void k_lin_obs_intr(DevProblem P, const dou
       tig[a] = s3;
     }
 #pragma unroll
-    for (int k = 0; k < 5 * PD; ++k) R[O::WI + k] = make_double2(wi[2 * k], wi[2 * k + 1]);
+    for (int k = 0; k < KI * PD / 2; ++k) R[O::WI + k] = make_double2(wi[2 * k], wi[2 * k + 1]);
 #pragma unroll
-    for (int k = 0; k < 5 * PD; ++k) R[O::TI + k] = make_double2(ti[2 * k], ti[2 * k + 1]);
+    for (int k = 0; k < KI * PD / 2; ++k) R[O::TI + k] = make_double2(ti[2 * k], ti[2 * k + 1]);
 #pragma unroll
-    for (int k = 0; k < 10; ++k) R[O::FK + k] = make_double2(L.Jk[2 * k], L.Jk[2 * k + 1]);
+    for (int k = 0; k < KI; ++k) R[O::FK + k] = make_double2(jk[2 * k], jk[2 * k + 1]);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) R[O::TIG + k] = make_double2(tig[2 * k], tig[2 * k + 1]);
+    for (int k = 0; k < KI / 2; ++k) R[O::TIG + k] = make_double2(tig[2 * k], tig[2 * k + 1]);
   }
   const double cost = wave_sum(L.cost);
   gmax = wave_max(gmax);
@@ -821,56 +854,60 @@ __global__ __launch_bounds__(kBlock) void k_lin_obs_intr(DevProblem P, const dou
 
 
 // rows [ra0, ra0 + RA) of the group block  Fk^T Fk - TI WI^T  (row0 = first reduced index of the group)
-template <int PD, int RA, int ra0>
+template <int PD, int KI, int RA, int ra0>
 THIP_DEV void gdiag_item(const DevProblem& P, int row0, int beg, int end, bool atomic, double (*part)[64],
                          double* __restrict__ S) {
-  using O = RecI<PD>;
-  double acc[RA * 10];
+  using O = RecI<PD, KI>;
+  double acc[RA * KI];
 #pragma unroll
-  for (int k = 0; k < RA * 10; ++k) acc[k] = 0.0;
+  for (int k = 0; k < RA * KI; ++k) acc[k] = 0.0;
   for (int q = beg + threadIdx.x; q < end; q += kBlock) {
-    double TI[RA * PD], WI[10 * PD], Jk[20];
-    load_reci<PD>(P.rec, q, O::TI + (ra0 * PD) / 2, TI); load_reci<PD>(P.rec, q, O::WI, WI); load_reci<PD>(P.rec, q, O::FK, Jk);
+    double TI[RA * PD], WI[KI * PD], Jk[2 * KI];
+    load_reci<PD, KI>(P.rec, q, O::TI + (ra0 * PD) / 2, TI); load_reci<PD, KI>(P.rec, q, O::WI, WI); load_reci<PD, KI>(P.rec, q, O::FK, Jk);
 #pragma unroll
     for (int a = 0; a < RA; ++a)
 #pragma unroll
-      for (int b = 0; b < 10; ++b) {
-        double s = Jk[ra0 + a] * Jk[b] + Jk[10 + ra0 + a] * Jk[10 + b];
+      for (int b = 0; b < KI; ++b) {
+        double s = Jk[ra0 + a] * Jk[b] + Jk[KI + ra0 + a] * Jk[KI + b];
 #pragma unroll
         for (int k = 0; k < PD; ++k) s -= TI[a * PD + k] * WI[b * PD + k];
-        acc[a * 10 + b] += s;
+        acc[a * KI + b] += s;
       }
   }
   const int n = P.n;
-  finish_item<RA * 10>(acc, part, atomic, 1.0, [&](int e) -> double* {
-    const int a = ra0 + e / 10, b = e % 10;
-    if (b > a) return nullptr;
+  const unsigned fm = P.red_free[row0 / THEIA_MAX_INTRINSICS];
+  finish_item<RA * KI>(acc, part, atomic, 1.0, [&](int e) -> double* {
+    const int a = row_param<KI>(fm, ra0 + e / KI), b = row_param<KI>(fm, e % KI);
+    if (a < 0 || b < 0 || b > a) return nullptr;
     return S + (size_t)(row0 + a) * n + row0 + b;
   });
 }
 
-template <int PD>
+template <int PD, int KI>
 __global__ __launch_bounds__(kBlock) void k_schur_intr(DevProblem P, double* __restrict__ S, double* __restrict__ rhs,
                                                        double* __restrict__ colsq, double* __restrict__ gc) {
   __shared__ double part[kWavesPerBlock][64];
-  using O = RecI<PD>;
+  using O = RecI<PD, KI>;
   const int* it = P.blk_items + 6 * blockIdx.x;
   const int type = it[0], row0 = it[1], col0 = it[2], beg = it[3], end = it[4], flags = it[5];
   const bool atomic = (flags & ITF_ATOMIC) != 0;
   const int n = P.n;
-  if (type == IT_CC) { pair_item<PD, 6, 6>(P, it, O::T, O::W, part, S); return; }
-  if (type == IT_CG) { pair_item<PD, 6, 10>(P, it, O::T, O::WI, part, S); return; }
-  // the 10 intrinsics rows are split 4 + 6 (register budget; 4 * PD doubles keep the 16-B alignment)
-  if (type == IT_GG0) { pair_item<PD, 4, 10>(P, it, O::TI, O::WI, part, S); return; }
-  if (type == IT_GG1) { pair_item<PD, 6, 10>(P, it, O::TI + 2 * PD, O::WI, part, S); return; }
+  if (type == IT_CC) { pair_item<PD, KI, 6, 6, false, false>(P, it, O::T, O::W, 0, part, S); return; }
+  if (type == IT_CG) { pair_item<PD, KI, 6, KI, false, true>(P, it, O::T, O::WI, 0, part, S); return; }
+  // ten intrinsics rows are split 4 + 6 (register budget; 4 * PD doubles keep the 16-B alignment); four compact rows are one item
+  if (type == IT_GG0) { pair_item<PD, KI, 4, KI, true, true>(P, it, O::TI, O::WI, 0, part, S); return; }
+  if (KI == THEIA_MAX_INTRINSICS && type == IT_GG1) {
+    pair_item<PD, KI, KI - 4 ? KI - 4 : 2, KI, true, true>(P, it, O::TI + 2 * PD, O::WI, 4, part, S);
+    return;
+  }
   if (type == IT_CD) {
     double acc[39];
 #pragma unroll
     for (int k = 0; k < 39; ++k) acc[k] = 0.0;
     for (int q = beg + threadIdx.x; q < end; q += kBlock) {
       double W[6 * PD], T[6 * PD], Jc[12], rt[8];
-      load_reci<PD>(P.rec, q, O::W, W); load_reci<PD>(P.rec, q, O::T, T);
-      load_reci<PD>(P.rec, q, O::F, Jc); load_reci<PD>(P.rec, q, O::R, rt);
+      load_reci<PD, KI>(P.rec, q, O::W, W); load_reci<PD, KI>(P.rec, q, O::T, T);
+      load_reci<PD, KI>(P.rec, q, O::F, Jc); load_reci<PD, KI>(P.rec, q, O::R, rt);
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
 #pragma unroll
@@ -897,44 +934,52 @@ __global__ __launch_bounds__(kBlock) void k_schur_intr(DevProblem P, double* __r
     return;
   }
   if (type == IT_CGD) {
-    double acc[60];
+    double acc[6 * KI];
 #pragma unroll
-    for (int k = 0; k < 60; ++k) acc[k] = 0.0;
+    for (int k = 0; k < 6 * KI; ++k) acc[k] = 0.0;
     for (int q = beg + threadIdx.x; q < end; q += kBlock) {
-      double T[6 * PD], WI[10 * PD], Jc[12], Jk[20];
-      load_reci<PD>(P.rec, q, O::T, T); load_reci<PD>(P.rec, q, O::WI, WI);
-      load_reci<PD>(P.rec, q, O::F, Jc); load_reci<PD>(P.rec, q, O::FK, Jk);
+      double T[6 * PD], WI[KI * PD], Jc[12], Jk[2 * KI];
+      load_reci<PD, KI>(P.rec, q, O::T, T); load_reci<PD, KI>(P.rec, q, O::WI, WI);
+      load_reci<PD, KI>(P.rec, q, O::F, Jc); load_reci<PD, KI>(P.rec, q, O::FK, Jk);
 #pragma unroll
       for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int b = 0; b < 10; ++b) {
-          double s = Jc[a] * Jk[b] + Jc[6 + a] * Jk[10 + b];
+        for (int b = 0; b < KI; ++b) {
+          double s = Jc[a] * Jk[b] + Jc[6 + a] * Jk[KI + b];
 #pragma unroll
           for (int k = 0; k < PD; ++k) s -= T[a * PD + k] * WI[b * PD + k];
-          acc[a * 10 + b] += s;
+          acc[a * KI + b] += s;
         }
     }
-    finish_item<60>(acc, part, atomic, 1.0, [&](int e) -> double* { return S + (size_t)(row0 + e / 10) * n + col0 + e % 10; });
+    const unsigned fm = P.red_free[col0 / THEIA_MAX_INTRINSICS];
+    finish_item<6 * KI>(acc, part, atomic, 1.0, [&](int e) -> double* {
+      const int b = row_param<KI>(fm, e % KI);
+      return b < 0 ? nullptr : S + (size_t)(row0 + e / KI) * n + col0 + b;
+    });
     return;
   }
-  if (type == IT_GD0) { gdiag_item<PD, 4, 0>(P, row0, beg, end, atomic, part, S); return; }
-  if (type == IT_GD1) { gdiag_item<PD, 6, 4>(P, row0, beg, end, atomic, part, S); return; }
+  if (type == IT_GD0) { gdiag_item<PD, KI, 4, 0>(P, row0, beg, end, atomic, part, S); return; }
+  if (KI == THEIA_MAX_INTRINSICS && type == IT_GD1) { gdiag_item<PD, KI, KI - 4 ? KI - 4 : 2, KI - 4 ? 4 : 0>(P, row0, beg, end, atomic, part, S); return; }
   if (type == IT_GV) {
-    double acc[30];
+    double acc[3 * KI];
 #pragma unroll
-    for (int k = 0; k < 30; ++k) acc[k] = 0.0;
+    for (int k = 0; k < 3 * KI; ++k) acc[k] = 0.0;
     for (int q = beg + threadIdx.x; q < end; q += kBlock) {
-      double Jk[20], rt[2], tig[10];
-      load_reci<PD>(P.rec, q, O::FK, Jk); load_reci<PD>(P.rec, q, O::R, rt); load_reci<PD>(P.rec, q, O::TIG, tig);
+      double Jk[2 * KI], rt[2], tig[KI];
+      load_reci<PD, KI>(P.rec, q, O::FK, Jk); load_reci<PD, KI>(P.rec, q, O::R, rt); load_reci<PD, KI>(P.rec, q, O::TIG, tig);
 #pragma unroll
-      for (int a = 0; a < 10; ++a) {
-        const double jr = Jk[a] * rt[0] + Jk[10 + a] * rt[1];
+      for (int a = 0; a < KI; ++a) {
+        const double jr = Jk[a] * rt[0] + Jk[KI + a] * rt[1];
         acc[a] += jr - tig[a];
-        acc[10 + a] += jr;
-        acc[20 + a] += Jk[a] * Jk[a] + Jk[10 + a] * Jk[10 + a];
+        acc[KI + a] += jr;
+        acc[2 * KI + a] += Jk[a] * Jk[a] + Jk[KI + a] * Jk[KI + a];
       }
     }
-    finish_item<30>(acc, part, atomic, 1.0, [&](int e) -> double* { return (e < 10 ? rhs : (e < 20 ? gc : colsq)) + row0 + e % 10; });
+    const unsigned fm = P.red_free[row0 / THEIA_MAX_INTRINSICS];
+    finish_item<3 * KI>(acc, part, atomic, 1.0, [&](int e) -> double* {
+      const int b = row_param<KI>(fm, e % KI);
+      return b < 0 ? nullptr : (e < KI ? rhs : (e < 2 * KI ? gc : colsq)) + row0 + b;
+    });
     return;
   }
 }
@@ -1447,12 +1492,14 @@ void launch_linearize(const DevProblem& P, const double* cam, const double* pts,
   if (P.ntiles == 0) return;
   if (P.rec && P.ni > 0) {   // intrinsics optimised: 16-wide camera-side blocks on the gather lists
     const int g = tile_blocks(P.ntiles);
-    if (P.pd == 3) k_lin_obs_intr<3><<<g, kBlock, 0, st>>>(P, cam, pts, radius, Vinv, gp, tile_part);
-    else k_lin_obs_intr<4><<<g, kBlock, 0, st>>>(P, cam, pts, radius, Vinv, gp, tile_part);
-    if (P.n_blk_items) {
-      if (P.pd == 3) k_schur_intr<3><<<P.n_blk_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc);
-      else k_schur_intr<4><<<P.n_blk_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc);
-    }
+#define THIP_INTR(PD_, KI_)                                                                              \
+    do {                                                                                                   \
+      k_lin_obs_intr<PD_, KI_><<<g, kBlock, 0, st>>>(P, cam, pts, radius, Vinv, gp, tile_part);            \
+      if (P.n_blk_items) k_schur_intr<PD_, KI_><<<P.n_blk_items, kBlock, 0, st>>>(P, rb.S, rb.rhs, rb.colsq, rb.gc); \
+    } while (0)
+    if (P.pd == 3) { if (P.intr_rows == 4) THIP_INTR(3, 4); else THIP_INTR(3, 10); }
+    else { if (P.intr_rows == 4) THIP_INTR(4, 4); else THIP_INTR(4, 10); }
+#undef THIP_INTR
     return;
   }
   if (P.rec && P.ni == 0) {

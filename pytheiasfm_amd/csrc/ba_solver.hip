@@ -119,7 +119,8 @@ struct theia_ba_handle_s {
   DevBuf<double> cam[2], pts[2], intr[2], scale_c, scale_p, ones_c, ones_p, colsq_c0, colsq_p0;
   DevBuf<double> scale_i, ones_i, colsq_i0, scale_red;
   DevBuf<int> d_grp_red, d_grp_k;
-  DevBuf<unsigned> d_grp_free;
+  DevBuf<unsigned> d_grp_free, d_red_free;
+  int intr_rows = 10;            // intrinsics rows per gather record (ba_kernels.hip RecI): 10, or 4 compact rows
   DevBuf<int> group_model, cam_group, d_cam_red, obs_cam, obs_pt, tile_start, tile_count, f2s, fmaxflag;
   DevBuf<uint8_t> d_cam_mask, d_pt_const;
   DevBuf<double2> obs_uv, obs_si;
@@ -437,6 +438,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.intr = h->intr[h->cur].p; P.intr_cand = h->intr[1 - h->cur].p;
   P.group_model = h->group_model.p; P.cam_group = h->cam_group.p;
   P.ni = h->ni; P.ng_total = h->ng; P.grp_red = h->d_grp_red.p; P.grp_free = h->d_grp_free.p; P.grp_k = h->d_grp_k.p;
+  P.red_free = h->d_red_free.p; P.intr_rows = h->intr_rows;
   P.scale_i = h->scale_i.p; P.scale_red = h->scale_red.p;
   P.cam_red = h->d_cam_red.p; P.cam_mask = h->d_cam_mask.p; P.pt_const = h->d_pt_const.p;
   P.obs_uv = h->obs_uv.p; P.obs_si = h->obs_si.p; P.obs_cam = h->obs_cam.p; P.obs_pt = h->obs_pt.p;
@@ -847,9 +849,10 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
     push_item(IT_CC, h->ni + 6 * ra, h->ni + 6 * rb, beg, end, ra == rb ? 3 : 0);
   });
   emit_pairs(cg, [&](int ra, int gb, int64_t beg, int64_t end) { push_item(IT_CG, h->ni + 6 * ra, 10 * gb, beg, end, 1); });
+  const bool compact = h->intr_rows == 4;   // four compact intrinsics rows: one GG / GD item instead of the 4 + 6 split
   emit_pairs(gg, [&](int ga, int gb, int64_t beg, int64_t end) {
     push_item(IT_GG0, 10 * ga, 10 * gb, beg, end, 1 | (ga == gb ? 2 : 0));
-    push_item(IT_GG1, 10 * ga + 4, 10 * gb, beg, end, 1 | (ga == gb ? 2 : 0));
+    if (!compact) push_item(IT_GG1, 10 * ga, 10 * gb, beg, end, 1 | (ga == gb ? 2 : 0));
   });
   // (the CG / GG targets also receive the per-observation diagonal items below: always atomic)
   if (pairs.size() > (size_t)std::numeric_limits<int>::max() - 64)
@@ -871,7 +874,7 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
     const int gr = grd[order[q]];
     if (gr >= 0) {
       push_item(IT_GD0, 10 * gr, 10 * gr, (int64_t)q, (int64_t)e, 1);
-      push_item(IT_GD1, 10 * gr, 10 * gr, (int64_t)q, (int64_t)e, 1);
+      if (!compact) push_item(IT_GD1, 10 * gr, 10 * gr, (int64_t)q, (int64_t)e, 1);
       push_item(IT_GV, 10 * gr, 10 * gr, (int64_t)q, (int64_t)e, 0);
     }
     q = e;
@@ -883,7 +886,7 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
     UP(slot_obs, sobs);
   }
   UP(cam_obs, slot); UP(blk_items, items); UP(blk_pairs, pairs);
-  AL(rec, (size_t)std::max<size_t>(1, order.size()) * (32 * h->pd + 50));
+  AL(rec, (size_t)std::max<size_t>(1, order.size()) * (12 * h->pd + 20 + 2 * h->intr_rows * h->pd + 3 * h->intr_rows));
   return 0;
 }
 
@@ -1047,6 +1050,15 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   UP(group_model, gm); UP(cam_group, cg);
   for (int k = 0; k < 2; ++k) { AL(cam[k], (size_t)6 * h->nc); AL(pts[k], (size_t)4 * h->np); AL(intr[k], (size_t)THEIA_MAX_INTRINSICS * h->ng); }
   UP(d_grp_red, h->grp_red); UP(d_grp_free, h->grp_free); UP(d_grp_k, h->grp_k);
+  {
+    std::vector<unsigned> rf((size_t)std::max(1, h->ngv), 0u);
+    int most = 0;
+    for (int g = 0; g < h->ng; ++g)
+      if (h->grp_red[g] >= 0) { rf[h->grp_red[g]] = h->grp_free[g]; most = std::max(most, __builtin_popcount(h->grp_free[g])); }
+    UP(d_red_free, rf);
+    const char* force = getenv("THEIA_HIP_INTR_ROWS");
+    h->intr_rows = (most <= 4 && !(force && atoi(force) == 10)) ? 4 : 10;
+  }
   {
     std::vector<double> ones_i((size_t)THEIA_MAX_INTRINSICS * h->ng, 1.0);
     UP(ones_i, ones_i); UP(scale_i, ones_i);

@@ -952,3 +952,28 @@ def test_two_views_angular_batch_follows_oracle():
                 if p < 12 and loss == 6:
                     assert summ[p].final_cost < summ[p].initial_cost and abs(np.linalg.norm(pose[p][3:]) - 1.0) <= 1e-14
             assert np.array_equal(pose[12], x0s[12]) and summ[12].num_iterations == 0
+
+
+def test_compact_intrinsics_rows_equal_full_rows():
+    """When no group frees more than four intrinsics the gather records keep four COMPACT intrinsics rows
+    (ba_kernels.hip RecI<PD, 4>) instead of ten: the reduced camera system and the solve are the same as with the
+    full rows (THEIA_HIP_INTR_ROWS=10 forces them) up to the summation order."""
+    p = synth.synth_ba_v1(16, 900, seed=977, num_groups=3, fix_gauge=True, pixel_noise=0.3)
+    o = ba.default_options(); o.intrinsics_to_optimize = INTR_FOCAL_RADIAL; o.max_num_iterations = 6
+    out = []
+    for rows in ("4", "10"):
+        os.environ["THEIA_HIP_INTR_ROWS"] = rows
+        try:
+            h = ba.BaHandle(p.copy(), o)
+            S, rhs = h.reduced_system(1e4)
+            n = S.shape[0]
+            q = p.copy()
+            s, tr = ba.solve(q, o)
+            out.append((n, S, rhs, q, s, tr))
+        finally:
+            del os.environ["THEIA_HIP_INTR_ROWS"]
+    a, b = out
+    assert a[0] == b[0] and rel(a[1], b[1]) <= 1e-12 and rel(a[2], b[2]) <= 1e-11
+    assert a[4].num_iterations == b[4].num_iterations and np.array_equal(a[5].accepted, b[5].accepted)
+    assert rel(a[3].intrinsics, b[3].intrinsics) <= 1e-9 and np.abs(a[3].cam_ext - b[3].cam_ext).max() <= 1e-8
+    assert not np.array_equal(a[3].intrinsics[:, 0], p.intrinsics[:, 0])
