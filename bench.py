@@ -76,7 +76,7 @@ def algorithmic_bytes_linearize(p):
 
 def pmc_traffic_bytes(world):
     """HBM-side bytes per launch of the roofline kernel group, from the committed
-    rocprofv3 PMC passes of this same command (profiles/r1x_pmc_*.csv; FETCH_SIZE
+    rocprofv3 PMC passes of this same command (profiles/r1z_pmc_*.csv; FETCH_SIZE
     and WRITE_SIZE collected in separate passes, KB; the 16-B/lane record gathers
     of k_schur doubled per the gfx950 FETCH_SIZE note of MI355X_MICROARCH.md).
     None when the files are absent or the run is not the profiled N=1 workload."""
@@ -87,7 +87,7 @@ def pmc_traffic_bytes(world):
     try:
         kb = {}
         for tag in ("fetch_size", "write_size"):
-            with open(os.path.join(base, "r1x_pmc_%s.csv" % tag)) as f:
+            with open(os.path.join(base, "r1z_pmc_%s.csv" % tag)) as f:
                 for row in csv.reader(f):
                     if row and row[0] != "kernel":
                         kb[(tag, row[0])] = float(row[2])
@@ -173,6 +173,9 @@ def main():
             acc["lin"] += s.time_linearize; acc["solve"] += s.time_solve_reduced; acc["backsub"] += s.time_backsub
         return acc
 
+    # initialisation, not part of the W warm-up steps: a fresh box idles at its lowest clock level and W = 10
+    # iterations last 5 ms -- run the workload for a few hundred ms first so the timed region sees settled clocks
+    run_iterations(400)
     if args.warmup > 0:
         run_iterations(args.warmup)
     barrier()
@@ -180,9 +183,9 @@ def main():
     run_iterations(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    # Kernel-group durations for the roofline: the timed region above replays the LM iteration as a
-    # hipGraph (no events inside); the same workload is run once more with HIP events around the
-    # kernel groups on the library's stream (THEIA_HIP_PHASE_TIMING=1 -> direct launches).
+    # Kernel-group durations for the roofline: the timed region above has no events inside; the same
+    # workload is run once more with HIP events around the kernel groups on the library's stream
+    # (THEIA_HIP_PHASE_TIMING=1).
     os.environ["THEIA_HIP_PHASE_TIMING"] = "1"
     acc = run_iterations(min(args.steps, 50))
     del os.environ["THEIA_HIP_PHASE_TIMING"]
