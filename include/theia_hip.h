@@ -272,6 +272,17 @@ int theia_hip_ba_two_views_angular_batch(const theia_ba_two_view_batch* batch,
                                          const theia_ba_options* options,
                                          theia_ba_summary* summaries);
 
+/* A batch of INDEPENDENT homography refinements = N calls of OptimizeHomography(options,
+ * correspondences, &homography) (bundle_adjust_two_views.cc:298-358; RefineModel of the homography
+ * estimator, estimate_homography.cc:89-104): the nine entries of H against the symmetric geometric
+ * distance (homography_error.h:45-95: H x1 - x2 and H^-1 x2 - x1, four residuals under one loss),
+ * direct linear solver, result divided by H(2,2).  homographies [num_problems][9] row-major in/out;
+ * correspondences [total][4] = (x1, y1, x2, y2).  Honoured options as for the two-view batch. */
+int theia_hip_optimize_homography_batch(int32_t num_problems, const int64_t* offsets,
+                                        const double* correspondences, double* homographies,
+                                        const theia_ba_options* options,
+                                        theia_ba_summary* summaries);
+
 /* Every point of `problem` as its OWN problem with all cameras constant: N calls of
  * BundleAdjustTrack(options, track_id, reconstruction) (bundle_adjustment.cc:262-285; the
  * per-track refinement after triangulation, estimate_track.cc:289) in one launch, one thread
@@ -400,9 +411,9 @@ typedef struct theia_ransac_params {
   int32_t max_iterations;
   int32_t use_mle;
   int32_t use_lo;              /* LO-RANSAC: RefineModel of the absolute-pose (BundleAdjustView) and relative-pose
-                                  (BundleAdjustTwoViewsAngular; also the uncalibrated one) estimators as device
-                                  batches, the default "return true" of the others; fundamental matrix /
-                                  homography: ERR_UNSUPPORTED */
+                                  (BundleAdjustTwoViewsAngular; also the uncalibrated one) and homography
+                                  (OptimizeHomography) estimators as device batches, the default "return true"
+                                  of the others; fundamental matrix: ERR_UNSUPPORTED */
   int32_t lo_start_iterations;
   int32_t use_Tdd_test;        /* reference: "Not currently implemented"  */
   uint32_t seed;               /* seeds the mt19937 stream (util/random.cc:60-66),

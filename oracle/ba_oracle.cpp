@@ -39,6 +39,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -1568,6 +1569,140 @@ int oracle_two_views_angular(int64_t n, const double* corr, int loss_type, doubl
     }
   }
   for (int q = 0; q < 6; ++q) pose[q] = x[q];
+  out_int[0] = term != 2; out_int[1] = term; out_int[2] = iter; out_int[3] = nsucc;
+  out_cost[0] = initial_cost; out_cost[1] = term != 2 ? minimum_cost : x_cost;
+  return 0;
+}
+
+// OptimizeHomography (bundle_adjust_two_views.cc:298-358) on H in Eigen's column-major storage order (in/out,
+// divided by H(2,2) at the end); SymmetricGeometricDistanceTerms (homography_error.h:45-73) through Jets, with
+// Eigen's cofactor 3 x 3 inverse; dense Cholesky for the direct solver.
+int oracle_optimize_homography(int64_t n, const double* corr, int loss_type, double loss_width, int max_num_iterations,
+                               double function_tolerance, double gradient_tolerance, double parameter_tolerance,
+                               double max_trust_region_radius, double* Hcm, int* out_int, double* out_cost) {
+  typedef Jet<9> J9;
+  auto residuals = [&](const auto* H, const double* c, auto* r) {
+    typedef typename std::remove_cv<typename std::remove_reference<decltype(H[0])>::type>::type T;
+    auto cof = [&](int i, int j) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      return H[i1 + 3 * j1] * H[i2 + 3 * j2] - H[i1 + 3 * j2] * H[i2 + 3 * j1];
+    };
+    const T c0 = cof(0, 0), c1 = cof(1, 0), c2 = cof(2, 0);
+    const T det = (c0 * H[0] + c1 * H[1]) + c2 * H[2];
+    const T invdet = 1.0 / det;
+    T G[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) G[i + 3 * j] = (i == 0) ? ((j == 0 ? c0 : (j == 1 ? c1 : c2)) * invdet) : cof(j, i) * invdet;
+    const double x[3] = {c[0], c[1], 1.0}, y[3] = {c[2], c[3], 1.0};
+    T p[3], q[3];
+    for (int i = 0; i < 3; ++i) {
+      p[i] = (H[i] * x[0] + H[i + 3] * x[1]) + H[i + 6] * x[2];
+      q[i] = (G[i] * y[0] + G[i + 3] * y[1]) + G[i + 6] * y[2];
+    }
+    r[0] = p[0] / p[2] - y[0]; r[1] = p[1] / p[2] - y[1];
+    r[2] = q[0] / q[2] - x[0]; r[3] = q[1] / q[2] - x[1];
+  };
+  auto cost_of = [&](const double* H) {
+    double cost = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+      double r[4]; residuals(H, corr + 4 * i, r);
+      double rho[3]; loss_evaluate(loss_type, loss_width, (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]), rho);
+      cost += 0.5 * rho[0];
+    }
+    return cost;
+  };
+  std::vector<double> Jm, rm;   // 4n x 9 (loss-corrected, scaled), 4n
+  double g[9], colsq[9], scale[9];
+  for (int q = 0; q < 9; ++q) scale[q] = 1.0;
+  auto linearize = [&](const double* H, double* cost) {
+    Jm.assign((size_t)n * 36, 0.0); rm.assign((size_t)n * 4, 0.0); *cost = 0.0;
+    for (int q = 0; q < 9; ++q) { g[q] = 0.0; colsq[q] = 0.0; }
+    J9 Hj[9];
+    for (int q = 0; q < 9; ++q) Hj[q] = J9(H[q], q);
+    for (int64_t i = 0; i < n; ++i) {
+      J9 r[4]; residuals(Hj, corr + 4 * i, r);
+      double rho[3]; loss_evaluate(loss_type, loss_width, (r[0].a * r[0].a + r[1].a * r[1].a) + (r[2].a * r[2].a + r[3].a * r[3].a), rho);
+      const double sr = std::sqrt(rho[1]);
+      *cost += 0.5 * rho[0];
+      for (int e = 0; e < 4; ++e) {
+        const double rr = sr * r[e].a;
+        rm[(size_t)i * 4 + e] = rr;
+        for (int q = 0; q < 9; ++q) {
+          const double ju = sr * r[e].v[q];
+          g[q] += ju * rr; colsq[q] += ju * ju;
+          Jm[((size_t)i * 4 + e) * 9 + q] = ju * scale[q];
+        }
+      }
+    }
+  };
+  double x[9];
+  for (int q = 0; q < 9; ++q) x[q] = Hcm[q];
+  double x_cost = 0.0;
+  linearize(x, &x_cost);
+  for (int q = 0; q < 9; ++q) scale[q] = 1.0 / (1.0 + std::sqrt(colsq[q]));
+  double radius = 1e4, decrease_factor = 2.0;
+  bool step_successful = true, need_linearize = true, first = true;
+  int iter = 0, invalid_steps = 0, term = 1, nsucc = 0;
+  double x_norm = 0.0, minimum_cost = 0.0, gmax = 0.0, initial_cost = 0.0;
+  for (int q = 0; q < 9; ++q) x_norm += x[q] * x[q];
+  x_norm = std::sqrt(x_norm);
+  while (true) {
+    if (need_linearize) {
+      linearize(x, &x_cost);
+      gmax = 0.0;
+      for (int q = 0; q < 9; ++q) gmax = std::max(gmax, std::fabs(g[q]));
+      need_linearize = false;
+    }
+    if (first) { first = false; initial_cost = minimum_cost = x_cost; if (!std::isfinite(x_cost)) { term = 2; break; } }
+    if (iter >= max_num_iterations) { term = 1; break; }
+    if (step_successful && gmax <= gradient_tolerance) { term = 0; break; }
+    if (radius <= 1e-32) { term = 0; break; }
+    ++iter;
+    std::vector<double> A(81, 0.0), b(9, 0.0);
+    for (size_t i = 0; i < rm.size(); ++i) {
+      const double* row = &Jm[i * 9];
+      for (int a2 = 0; a2 < 9; ++a2) { b[a2] += row[a2] * rm[i]; for (int c2 = 0; c2 <= a2; ++c2) A[a2 * 9 + c2] += row[a2] * row[c2]; }
+    }
+    for (int q = 0; q < 9; ++q) A[q * 9 + q] += std::min(std::max(colsq[q] * scale[q] * scale[q], 1e-6), 1e32) / radius;
+    bool solved = dense_cholesky_solve(9, A, b);
+    double y[9];
+    for (int q = 0; q < 9; ++q) { y[q] = b[q]; if (!std::isfinite(y[q])) solved = false; }
+    double mcc = 0.0;
+    for (size_t i = 0; i < rm.size(); ++i) {
+      double m = 0.0;
+      for (int q = 0; q < 9; ++q) m -= Jm[i * 9 + q] * y[q];
+      mcc -= m * (rm[i] + m / 2.0);
+    }
+    double cand[9], stepsq = 0.0, xnormsq = 0.0;
+    for (int q = 0; q < 9; ++q) { cand[q] = x[q] - y[q] * scale[q]; stepsq += (x[q] - cand[q]) * (x[q] - cand[q]); xnormsq += cand[q] * cand[q]; }
+    const bool step_valid = solved && std::isfinite(mcc) && std::isfinite(stepsq) && mcc > 0.0;
+    if (!step_valid) {
+      if (++invalid_steps >= 5) { term = 2; break; }
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+      continue;
+    }
+    invalid_steps = 0;
+    double cand_cost = cost_of(cand);
+    if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+    const double step_norm = std::sqrt(stepsq);
+    if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) { term = 0; break; }
+    const double cost_change = x_cost - cand_cost;
+    if (std::fabs(cost_change) <= function_tolerance * x_cost) { term = 0; break; }
+    const double relative_decrease = cost_change / mcc;
+    if (relative_decrease > 1e-3) {
+      for (int q = 0; q < 9; ++q) x[q] = cand[q];
+      x_norm = std::sqrt(xnormsq);
+      radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3));
+      radius = std::min(max_trust_region_radius, radius);
+      decrease_factor = 2.0; step_successful = true; need_linearize = true;
+      nsucc++;
+      if (cand_cost < minimum_cost) minimum_cost = cand_cost;
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+    }
+  }
+  const double h22 = x[8];
+  for (int q = 0; q < 9; ++q) Hcm[q] = x[q] / h22;
   out_int[0] = term != 2; out_int[1] = term; out_int[2] = iter; out_int[3] = nsucc;
   out_cost[0] = initial_cost; out_cost[1] = term != 2 ? minimum_cost : x_cost;
   return 0;

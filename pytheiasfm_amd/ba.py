@@ -217,6 +217,24 @@ def solve_two_views_angular_batch(offsets, correspondences, rotation_position, o
     return [summ[i] for i in range(num)]
 
 
+def optimize_homography_batch(offsets, correspondences, homographies, options):
+    """theia_hip_optimize_homography_batch: N independent OptimizeHomography problems (bundle_adjust_two_views.cc:298-358).
+    homographies [N][3][3] (row-major) is updated in place (and divided by H(2,2)); returns a list of BaSummary."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    num = len(offsets) - 1
+    corr = np.ascontiguousarray(correspondences, dtype=np.float64).reshape(-1, 4)
+    H = homographies
+    if not (H.flags["C_CONTIGUOUS"] and H.dtype == np.float64 and H.size == 9 * num):
+        raise capi.TheiaHipError(-1, "homographies must be a C-contiguous float64 [N][3][3] array (updated in place)")
+    summ = (capi.BaSummary * max(1, num))()
+    L = capi.lib()
+    L.theia_hip_optimize_homography_batch.argtypes = [C.c_int32, C.POINTER(C.c_int64), capi.c_double_p, capi.c_double_p,
+                                                      C.POINTER(capi.BaOptions), C.POINTER(capi.BaSummary)]
+    capi.check(L.theia_hip_optimize_homography_batch(num, offsets.ctypes.data_as(C.POINTER(C.c_int64)), capi.ptr(corr, C.c_double),
+                                                     capi.ptr(H, C.c_double), C.byref(options), summ))
+    return [summ[i] for i in range(num)]
+
+
 def solve_tracks_batch(problem, options):
     """theia_hip_ba_tracks_batch: every point as an independent BundleAdjustTrack problem
     (bundle_adjustment.cc:262-285), cameras constant.  problem.points is updated in place;

@@ -417,6 +417,12 @@ __global__ void k_lo_prepare(int est, int nev, const int* __restrict__ ev_prob, 
     if (ev_slot[e] < nm) for (int k = 0; k < kStride; ++k) mo[k] = mloc[ev_slot[e] * kStride + k];
   }
   for (int k = 0; k < kStride; ++k) ev_model[(size_t)e * kStride + k] = mo[k];
+  if (est == THEIA_EST_HOMOGRAPHY) {   // homography->data(): Eigen's column-major storage order, nine doubles per event
+    double* hc = ev_cam + (size_t)e * 9;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) hc[i + 3 * j] = mo[3 * i + j];
+    return;
+  }
   double* c = ev_cam + (size_t)e * 6;
   if (est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE) {
     // TwoViewInfo{rotation_2, position_2} of RefineModel (estimate_relative_pose.cc:115-118, estimate_uncalibrated_relative_pose.cc:157-160)
@@ -451,7 +457,7 @@ __global__ __launch_bounds__(64) void k_lo_gather(int est, const int* __restrict
     if (in) {
       const int pos = base + __popcll(b & ((1ull << lane) - 1ull));
       const double* d = pd + (size_t)i * ds;
-      if (est == THEIA_EST_RELATIVE_POSE) {   // the correspondence itself (x1, y1, x2, y2)
+      if (est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_HOMOGRAPHY) {   // the correspondence itself (x1, y1, x2, y2)
         X[ev_off[e] + pos] = make_double4(d[0], d[1], d[2], d[3]);
       } else if (est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE) {   // normalised by the model's focal lengths (:146-155)
         X[ev_off[e] + pos] = make_double4(d[0] / m[21], d[1] / m[21], d[2] / m[22], d[3] / m[22]);
@@ -474,8 +480,16 @@ __global__ void k_lo_finish(int est, int nev, const int* __restrict__ ev_prob, c
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nev) return;
   const int p = ev_prob[e];
-  const double* c = ev_cam + (size_t)e * 6;
   double* mo = cur_models + (size_t)p * kStride;
+  if (est == THEIA_EST_HOMOGRAPHY) {   // estimate_homography.cc:100-103: H (already divided by H(2,2)) replaces the model
+    const double* hc = ev_cam + (size_t)e * 9;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) mo[3 * i + j] = hc[i + 3 * j];
+    for (int k = 9; k < kStride; ++k) mo[k] = 0.0;
+    ev_success[e] = (out[e].c1 < out[e].c0) ? 1 : 0;
+    return;
+  }
+  const double* c = ev_cam + (size_t)e * 6;
   if (est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE) {
     // estimate_relative_pose.cc:130-135 / estimate_uncalibrated_relative_pose.cc:170-175: rotation and position are
     // replaced, the essential (fundamental) matrix and the focal lengths of the model are NOT recomputed -- Error keeps
@@ -716,10 +730,11 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   const bool trivial_refine = est == THEIA_EST_ESSENTIAL_MATRIX || est == THEIA_EST_DOMINANT_PLANE ||
                               est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION || est == THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION;
   const bool rel_pose = est == THEIA_EST_RELATIVE_POSE, uncal_pose = est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE;
-  if (P.use_lo && !abs_pose && !rel_pose && !uncal_pose && !trivial_refine)
-    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: the RefineModels of the absolute-pose (BundleAdjustView) and the calibrated / "
-                     "uncalibrated relative-pose (BundleAdjustTwoViewsAngular) estimators and the trivial ones are built; "
-                     "OptimizeFundamentalMatrix / OptimizeHomography are not yet");
+  const bool homog = est == THEIA_EST_HOMOGRAPHY;
+  if (P.use_lo && !abs_pose && !rel_pose && !uncal_pose && !homog && !trivial_refine)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: the RefineModels of the absolute-pose (BundleAdjustView), the calibrated / "
+                     "uncalibrated relative-pose (BundleAdjustTwoViewsAngular) and the homography (OptimizeHomography) estimators "
+                     "and the trivial ones are built; OptimizeFundamentalMatrix is not yet");
   // exhaustive_sampler.cc:49-51 CHECK
   if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE && sample_size(est) != 2)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "ExhaustiveSampler makes a hard assumption that the number of samples needed is 2.");
@@ -820,7 +835,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   lo_opts.loss_function_type = THEIA_LOSS_HUBER;
   lo_opts.robust_loss_width = P.error_thresh * 1.5;
   lo_opts.use_inner_iterations = 0;
-  if (rel_pose) {                                        // estimate_relative_pose.cc:120-126
+  if (rel_pose || homog) {                               // estimate_relative_pose.cc:120-126, estimate_homography.cc:94-98
     lo_opts.max_num_iterations = 15;
     lo_opts.loss_function_type = THEIA_LOSS_TRUNCATED;
     lo_opts.robust_loss_width = P.error_thresh;
@@ -846,7 +861,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     int rc2;
     if ((rc2 = d_ev_prob.ensure(nev)) || (rc2 = d_ev_samples.ensure((size_t)nev * kMaxSample)) || (rc2 = d_ev_slot.ensure(nev)) ||
         (rc2 = d_ev_count.ensure(nev)) || (rc2 = d_ev_success.ensure(nev)) || (rc2 = d_ev_off.ensure(nev + 1)) ||
-        (rc2 = d_ev_model.ensure((size_t)nev * kStride)) || (rc2 = d_ev_cam.ensure((size_t)nev * 6)) ||
+        (rc2 = d_ev_model.ensure((size_t)nev * kStride)) || (rc2 = d_ev_cam.ensure((size_t)nev * 9)) ||
         (rc2 = d_lo_uv.ensure((size_t)hoff[nev] * 2)) || (rc2 = d_lo_X.ensure((size_t)hoff[nev] * 4)) ||
         (rc2 = d_lo_intr.ensure(hintr.size())) || (rc2 = d_lo_model_id.ensure(nev)) ||
         (rc2 = d_lo_out.ensure(views_batch_out_bytes() * nev)))
@@ -861,7 +876,9 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
                                                  d_cur_models.p, d_ev_model.p, d_ev_cam.p, ep);
     k_lo_gather<<<nev, 64, 0, st>>>(est, d_ev_prob.p, d_off.p, d_data.p, d_ev_model.p, P.error_thresh, d_ev_off.p, d_ev_count.p,
                                     reinterpret_cast<double2*>(d_lo_uv.p), reinterpret_cast<double4*>(d_lo_X.p));
-    if (rel_pose || uncal_pose)   // the relative-pose RefineModel asks for CGNR, the uncalibrated one keeps the direct default
+    if (homog)
+      homography_batch_device(nev, d_ev_off.p, d_ev_count.p, d_lo_X.p, d_ev_cam.p, &lo_opts, d_lo_out.p, st);
+    else if (rel_pose || uncal_pose)   // the relative-pose RefineModel asks for CGNR, the uncalibrated one keeps the direct default
       twoview_batch_device(nev, d_ev_off.p, d_ev_count.p, d_lo_X.p, d_ev_cam.p, &lo_opts, rel_pose ? 1 : 0, d_lo_out.p, st);
     else
       views_batch_device(nev, d_ev_off.p, d_ev_count.p, d_lo_uv.p, nullptr, d_lo_X.p, d_ev_cam.p, d_lo_intr.p, d_lo_model_id.p,

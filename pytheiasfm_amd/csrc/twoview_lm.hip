@@ -452,6 +452,223 @@ __global__ __launch_bounds__(256) void k_twoview_lm(TwoViewBatch B, TwoViewOut* 
   }
 }
 
+// ------------------------------------------------------------------ homography refinement
+// N independent OptimizeHomography problems (bundle_adjust_two_views.cc:298-358): the nine entries of H (no manifold)
+// against the symmetric geometric distance of every correspondence (homography_error.h:45-95: forward H x1 - x2 and
+// backward H^-1 x2 - x1, four residuals, one loss over them), default (direct) linear solver; finally H /= H(2, 2).
+// RefineModel of the homography estimator (estimate_homography.cc:89-104) calls it with the TRUNCATED loss of width
+// error_thresh and at most 15 iterations.  Parameters in Eigen's storage order: k = i + 3 j for H(i, j).
+struct HomographyBatch {
+  int num;
+  const int64_t* offsets;
+  const int* counts;
+  const double4* corr;      // (x1, y1, x2, y2)
+  double* H;                // [num][9] in/out, column-major
+  int loss_type;
+  double loss_width;
+  int max_iterations;
+  double function_tolerance, gradient_tolerance, parameter_tolerance, max_radius;
+};
+
+// Eigen's 3 x 3 inverse (InverseImpl.h compute_inverse<.., 3>): cofactors and the determinant along column 0
+__device__ __forceinline__ double cof3(const double* m, int i, int j) {   // m column-major
+  const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m[i1 + 3 * j1] * m[i2 + 3 * j2] - m[i1 + 3 * j2] * m[i2 + 3 * j1];
+}
+__device__ void inverse3_cm(const double* m, double* r) {
+  const double c0 = cof3(m, 0, 0), c1 = cof3(m, 1, 0), c2 = cof3(m, 2, 0);
+  const double det = (c0 * m[0] + c1 * m[1]) + c2 * m[2];
+  const double invdet = 1.0 / det;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r[i + 3 * j] = (i == 0) ? ((j == 0 ? c0 : (j == 1 ? c1 : c2)) * invdet) : cof3(m, j, i) * invdet;
+}
+
+// the four residuals and (WANT_JAC) their 4 x 9 Jacobian (row-major)
+template <bool WANT_JAC>
+__device__ void homography_residuals(const double* H, const double* G, const double4 c, double* r, double* J) {
+  const double x[3] = {c.x, c.y, 1.0}, y[3] = {c.z, c.w, 1.0};
+  double p[3], q[3];
+  for (int i = 0; i < 3; ++i) {
+    p[i] = (H[i] * x[0] + H[i + 3] * x[1]) + H[i + 6] * x[2];
+    q[i] = (G[i] * y[0] + G[i + 3] * y[1]) + G[i + 6] * y[2];
+  }
+  const double u = p[0] / p[2], v = p[1] / p[2], a = q[0] / q[2], b = q[1] / q[2];
+  r[0] = u - y[0]; r[1] = v - y[1]; r[2] = a - x[0]; r[3] = b - x[1];
+  if (!WANT_JAC) return;
+  for (int j = 0; j < 3; ++j)
+    for (int i = 0; i < 3; ++i) {
+      const int k = i + 3 * j;
+      // forward: d(p_i)/dH(i, j) = x_j
+      J[k] = (i == 0 ? x[j] / p[2] : 0.0) - (i == 2 ? u * x[j] / p[2] : 0.0);
+      J[9 + k] = (i == 1 ? x[j] / p[2] : 0.0) - (i == 2 ? v * x[j] / p[2] : 0.0);
+      // backward: dq/dH(i, j) = -G[:, i] q_j
+      J[18 + k] = -q[j] * (G[0 + 3 * i] - a * G[2 + 3 * i]) / q[2];
+      J[27 + k] = -q[j] * (G[1 + 3 * i] - b * G[2 + 3 * i]) / q[2];
+    }
+}
+
+__device__ double homography_cost(const HomographyBatch& B, int p, const double* H, int lane) {
+  const int64_t beg = B.offsets[p], end = B.counts ? beg + B.counts[p] : B.offsets[p + 1];
+  double G[9];
+  inverse3_cm(H, G);
+  double cost = 0.0;
+  for (int64_t o = beg + lane; o < end; o += 64) {
+    double r[4];
+    homography_residuals<false>(H, G, B.corr[o], r, nullptr);
+    double rho1;
+    cost += 0.5 * loss_eval(B.loss_type, B.loss_width, (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]), &rho1);
+  }
+  return wsum(cost);
+}
+
+__device__ void homography_linearize(const HomographyBatch& B, int p, const double* H, const double* scale, int lane,
+                                     double* A, double* g, double* cost) {
+  const int64_t beg = B.offsets[p], end = B.counts ? beg + B.counts[p] : B.offsets[p + 1];
+  double G[9];
+  inverse3_cm(H, G);
+  double acc[55];
+#pragma unroll
+  for (int k = 0; k < 55; ++k) acc[k] = 0.0;
+  for (int64_t o = beg + lane; o < end; o += 64) {
+    double r[4], J[36];
+    homography_residuals<true>(H, G, B.corr[o], r, J);
+    double rho1;
+    const double rho = loss_eval(B.loss_type, B.loss_width, (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]), &rho1);
+    const double sr = sqrt(rho1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      r[e] *= sr;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) J[9 * e + q] *= sr * scale[q];
+    }
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+#pragma unroll
+      for (int b = 0; b <= a; ++b) acc[k++] += (J[a] * J[b] + J[9 + a] * J[9 + b]) + (J[18 + a] * J[18 + b] + J[27 + a] * J[27 + b]);
+      acc[45 + a] += (J[a] * r[0] + J[9 + a] * r[1]) + (J[18 + a] * r[2] + J[27 + a] * r[3]);
+    }
+    acc[54] += 0.5 * rho;
+  }
+#pragma unroll
+  for (int k = 0; k < 55; ++k) acc[k] = wsum(acc[k]);
+  for (int k = 0; k < 45; ++k) A[k] = acc[k];
+  for (int k = 0; k < 9; ++k) g[k] = acc[45 + k];
+  *cost = acc[54];
+}
+
+__device__ bool solve9(const double* A, const double* d, const double* g, double* y) {
+  double L[45];
+  for (int i = 0; i < 9; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = A[tri(i, j)] + (i == j ? d[i] : 0.0);
+      for (int k = 0; k < j; ++k) s -= L[tri(i, k)] * L[tri(j, k)];
+      if (i == j) { if (!(s > 0.0)) return false; L[tri(i, i)] = sqrt(s); }
+      else L[tri(i, j)] = s / L[tri(j, j)];
+    }
+  double z[9];
+  for (int i = 0; i < 9; ++i) {
+    double s = g[i];
+    for (int k = 0; k < i; ++k) s -= L[tri(i, k)] * z[k];
+    z[i] = s / L[tri(i, i)];
+  }
+  for (int i = 8; i >= 0; --i) {
+    double s = z[i];
+    for (int k = i + 1; k < 9; ++k) s -= L[tri(k, i)] * y[k];
+    y[i] = s / L[tri(i, i)];
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_homography_lm(HomographyBatch B, TwoViewOut* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= B.num) return;
+  double x[9];
+  for (int q = 0; q < 9; ++q) x[q] = B.H[(size_t)p * 9 + q];
+  TwoViewOut R;
+  R.success = 0; R.term = THEIA_TERM_NO_CONVERGENCE; R.iters = 0; R.nsucc = 0; R.initial_cost = 0.0; R.final_cost = 0.0;
+  double scale[9];
+  for (int q = 0; q < 9; ++q) scale[q] = 1.0;
+  double A[45], g[9], x_cost;
+  homography_linearize(B, p, x, scale, lane, A, g, &x_cost);
+  for (int q = 0; q < 9; ++q) scale[q] = 1.0 / (1.0 + sqrt(A[tri(q, q)]));
+  double radius = 1e4, decrease_factor = 2.0;
+  bool step_successful = true, need_linearize = true, first = true;
+  int iter = 0, invalid_steps = 0, term = THEIA_TERM_NO_CONVERGENCE;
+  double x_norm = 0.0, minimum_cost = 0.0, gmax = 0.0;
+  for (int q = 0; q < 9; ++q) x_norm += x[q] * x[q];
+  x_norm = sqrt(x_norm);
+  while (true) {
+    if (need_linearize) {
+      homography_linearize(B, p, x, scale, lane, A, g, &x_cost);
+      gmax = 0.0;
+      for (int q = 0; q < 9; ++q) gmax = fmax(gmax, fabs(g[q] / scale[q]));
+      need_linearize = false;
+    }
+    if (first) {
+      first = false;
+      R.initial_cost = x_cost;
+      minimum_cost = x_cost;
+      if (!isfinite(x_cost)) { term = THEIA_TERM_FAILURE; break; }
+    }
+    if (iter >= B.max_iterations) { term = THEIA_TERM_NO_CONVERGENCE; break; }
+    if (step_successful && gmax <= B.gradient_tolerance) { term = THEIA_TERM_CONVERGENCE; break; }
+    if (radius <= 1e-32) { term = THEIA_TERM_CONVERGENCE; break; }
+    ++iter;
+    double d[9], y[9];
+    for (int q = 0; q < 9; ++q) d[q] = fmin(fmax(A[tri(q, q)], 1e-6), 1e32) / radius;
+    const bool solved = solve9(A, d, g, y);
+    double yg = 0.0, yAy = 0.0;
+    for (int a = 0; a < 9; ++a) {
+      yg += y[a] * g[a];
+      double row = 0.0;
+      for (int b = 0; b < 9; ++b) row += A[a >= b ? tri(a, b) : tri(b, a)] * y[b];
+      yAy += y[a] * row;
+    }
+    const double mcc = yg - 0.5 * yAy;
+    double cand[9], stepsq = 0.0, xnormsq = 0.0;
+    for (int q = 0; q < 9; ++q) {
+      cand[q] = x[q] - y[q] * scale[q];
+      stepsq += (x[q] - cand[q]) * (x[q] - cand[q]);
+      xnormsq += cand[q] * cand[q];
+    }
+    const bool step_valid = solved && isfinite(mcc) && isfinite(stepsq) && mcc > 0.0;
+    if (!step_valid) {
+      if (++invalid_steps >= 5) { term = THEIA_TERM_FAILURE; break; }
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+      continue;
+    }
+    invalid_steps = 0;
+    double cand_cost = homography_cost(B, p, cand, lane);
+    if (!isfinite(cand_cost)) cand_cost = DBL_MAX;
+    const double step_norm = sqrt(stepsq);
+    if (step_norm <= B.parameter_tolerance * (x_norm + B.parameter_tolerance)) { term = THEIA_TERM_CONVERGENCE; break; }
+    const double cost_change = x_cost - cand_cost;
+    if (fabs(cost_change) <= B.function_tolerance * x_cost) { term = THEIA_TERM_CONVERGENCE; break; }
+    const double rho = cost_change / mcc;
+    if (rho > 1e-3) {
+      for (int q = 0; q < 9; ++q) x[q] = cand[q];
+      x_norm = sqrt(xnormsq);
+      const double t = 2.0 * rho - 1.0;
+      radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+      radius = fmin(B.max_radius, radius);
+      decrease_factor = 2.0; step_successful = true; need_linearize = true;
+      R.nsucc++;
+      if (cand_cost < minimum_cost) minimum_cost = cand_cost;
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+    }
+  }
+  R.iters = iter; R.term = term; R.success = term != THEIA_TERM_FAILURE;
+  R.final_cost = term != THEIA_TERM_FAILURE ? minimum_cost : x_cost;
+  if (lane == 0) {
+    out[p] = R;
+    const double h22 = x[8];   // (*homography) /= (*homography)(2, 2): the divisor is the last element in storage order
+    for (int q = 0; q < 9; ++q) B.H[(size_t)p * 9 + q] = x[q] / h22;
+  }
+}
+
 template <typename T>
 struct Dev {
   T* p = nullptr;
@@ -483,6 +700,18 @@ int twoview_batch_device(int num, const int64_t* d_offsets, const int* d_counts,
   B.parameter_tolerance = o->parameter_tolerance; B.max_radius = o->max_trust_region_radius;
   B.cgnr = cgnr;
   k_twoview_lm<<<(num + 3) / 4, 256, 0, st>>>(B, static_cast<TwoViewOut*>(d_out));
+  return 0;
+}
+
+// device-resident OptimizeHomography batch; d_H = [num][9] column-major in/out
+int homography_batch_device(int num, const int64_t* d_offsets, const int* d_counts, const double* d_corr, double* d_H,
+                            const theia_ba_options* o, void* d_out, hipStream_t st) {
+  HomographyBatch B;
+  B.num = num; B.offsets = d_offsets; B.counts = d_counts; B.corr = reinterpret_cast<const double4*>(d_corr); B.H = d_H;
+  B.loss_type = o->loss_function_type; B.loss_width = o->robust_loss_width; B.max_iterations = o->max_num_iterations;
+  B.function_tolerance = o->function_tolerance; B.gradient_tolerance = o->gradient_tolerance;
+  B.parameter_tolerance = o->parameter_tolerance; B.max_radius = o->max_trust_region_radius;
+  k_homography_lm<<<(num + 3) / 4, 256, 0, st>>>(B, static_cast<TwoViewOut*>(d_out));
   return 0;
 }
 
@@ -519,6 +748,52 @@ extern "C" int theia_hip_ba_two_views_angular_batch(const theia_ba_two_view_batc
   HIP_TRY(hipMemcpy(h_out.data(), d_out.p, sizeof(TwoViewOut) * num, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(b->rotation_position, d_pose.p, sizeof(double) * 6 * num, hipMemcpyDeviceToHost));
   const double dt = now_s() - t0;
+  for (int i = 0; i < num; ++i) {
+    theia_ba_summary& S = summaries[i];
+    S.trace_size = 0;
+    S.success = h_out[i].success; S.termination_type = h_out[i].term; S.num_iterations = h_out[i].iters;
+    S.num_successful_steps = h_out[i].nsucc; S.initial_cost = h_out[i].initial_cost; S.final_cost = h_out[i].final_cost;
+    S.setup_time_in_seconds = 0.0; S.solve_time_in_seconds = dt / num;
+    S.time_linearize = S.time_solve_reduced = S.time_backsub = S.time_kernel_linearize = 0.0;
+    S.num_linearize_launches = 0;
+  }
+  return 0;
+}
+
+extern "C" int theia_hip_optimize_homography_batch(int32_t num_problems, const int64_t* offsets, const double* correspondences,
+                                                   double* homographies, const theia_ba_options* o, theia_ba_summary* summaries) {
+  if (!o) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null options");
+  const int num = num_problems;
+  if (num < 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "negative num_problems");
+  if (num == 0) return 0;
+  if (!offsets || !homographies || !summaries) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null array");
+  if (offsets[0] != 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "offsets[0] must be 0");
+  for (int i = 0; i < num; ++i)
+    if (offsets[i + 1] < offsets[i]) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
+  const int64_t total = offsets[num];
+  if (total > 0 && !correspondences) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null correspondences");
+  if (o->loss_function_type < 0 || o->loss_function_type > THEIA_LOSS_TRUNCATED)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown loss function type");
+  if (o->max_num_iterations < 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "negative max_num_iterations");
+  int rc = thip::ensure_device();
+  if (rc) return rc;
+  std::vector<double> hcm((size_t)num * 9);   // row-major at the boundary, Eigen's column-major storage order inside
+  for (int p = 0; p < num; ++p)
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) hcm[(size_t)p * 9 + i + 3 * j] = homographies[(size_t)p * 9 + 3 * i + j];
+  Dev<int64_t> d_off; Dev<double> d_corr, d_H; Dev<char> d_out;
+  if ((rc = d_off.up(offsets, num + 1)) || (rc = d_corr.up(correspondences, 4 * total)) || (rc = d_H.up(hcm.data(), hcm.size())) ||
+      (rc = d_out.alloc(sizeof(TwoViewOut) * num)))
+    return rc;
+  const double t0 = now_s();
+  homography_batch_device(num, d_off.p, nullptr, d_corr.p, d_H.p, o, d_out.p, nullptr);
+  std::vector<TwoViewOut> h_out(num);
+  HIP_TRY(hipMemcpy(h_out.data(), d_out.p, sizeof(TwoViewOut) * num, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(hcm.data(), d_H.p, sizeof(double) * hcm.size(), hipMemcpyDeviceToHost));
+  const double dt = now_s() - t0;
+  for (int p = 0; p < num; ++p)
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) homographies[(size_t)p * 9 + 3 * i + j] = hcm[(size_t)p * 9 + i + 3 * j];
   for (int i = 0; i < num; ++i) {
     theia_ba_summary& S = summaries[i];
     S.trace_size = 0;

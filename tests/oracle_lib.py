@@ -320,3 +320,20 @@ def angular_epipolar_error(rotation, position, corr):
     L.oracle_angular_epipolar_error.argtypes = [capi.c_double_p] * 3
     r, t, c = (np.ascontiguousarray(a, dtype=np.float64) for a in (rotation, position, corr))
     return L.oracle_angular_epipolar_error(capi.ptr(r, C.c_double), capi.ptr(t, C.c_double), capi.ptr(c, C.c_double))
+
+
+def optimize_homography(corr, H, options):
+    """oracle_optimize_homography of ONE pair; H row-major 3x3; returns (H_refined row-major, dict)."""
+    L = load()
+    dp = capi.c_double_p
+    L.oracle_optimize_homography.argtypes = [C.c_int64, dp, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double,
+                                             C.c_double, dp, capi.c_int32_p, dp]
+    corr = np.ascontiguousarray(corr, dtype=np.float64).reshape(-1, 4)
+    hcm = np.ascontiguousarray(np.asarray(H, dtype=np.float64).reshape(3, 3).T).reshape(9).copy()   # column-major storage
+    oi = np.zeros(4, dtype=np.int32); oc = np.zeros(2)
+    L.oracle_optimize_homography(len(corr), capi.ptr(corr, C.c_double), options.loss_function_type, options.robust_loss_width,
+                                 options.max_num_iterations, options.function_tolerance, options.gradient_tolerance,
+                                 options.parameter_tolerance, options.max_trust_region_radius, capi.ptr(hcm, C.c_double),
+                                 capi.ptr(oi, C.c_int32), capi.ptr(oc, C.c_double))
+    return hcm.reshape(3, 3).T.copy(), dict(success=int(oi[0]), termination_type=int(oi[1]), num_iterations=int(oi[2]),
+                                            num_successful_steps=int(oi[3]), initial_cost=float(oc[0]), final_cost=float(oc[1]))

@@ -768,3 +768,46 @@ def test_golden_two_view_lo():
         assert r["num_iterations"] == g["rel_lo_iters"][i] and ol.rlib().oracle_last_lo_iterations() == g["rel_lo_nlo"][i] >= 1
         assert np.array_equal(r["inlier_mask"], g["rel_lo_masks"][i])
         assert np.allclose(r["model"][:21], g["rel_lo_models"][i], rtol=0, atol=1e-13)
+
+
+def _homography_scene(seed, n=120, noise=0.5):
+    """Pixel correspondences of a plane seen by two cameras: x2 ~ H x1 (+ noise)."""
+    st = synth.Stream(seed, 3)
+    i = np.arange(n)
+    H = np.array([[1.02, 0.03, 12.0], [-0.02, 0.98, -7.0], [1e-5, -2e-5, 1.0]])
+    x1 = np.stack([1000 * st.uniform(2 * i), 800 * st.uniform(2 * i + 1)], 1)
+    p = np.hstack([x1, np.ones((n, 1))]) @ H.T
+    x2 = p[:, :2] / p[:, 2:] + noise * np.stack([st.normal(2 * i + 500), st.normal(2 * i + 501)], 1)
+    x1 = x1 + noise * np.stack([st.normal(2 * i + 900), st.normal(2 * i + 901)], 1)
+    return H, np.hstack([x1, x2])
+
+
+def test_optimize_homography_oracle():
+    """OptimizeHomography (bundle_adjust_two_views.cc:298-358): from a perturbed H the symmetric transfer cost falls to
+    the noise level, the result is normalised by H(2,2); the residual terms agree with numpy."""
+    from pytheiasfm_amd import ba
+    H, corr = _homography_scene(5)
+    H0 = H * 1.7 + np.array([[0.01, -0.01, 3.0], [0.01, 0.0, -2.0], [1e-6, 0, 0.0]])
+    o = ba.default_options(); o.max_num_iterations = 15; o.loss_function_type = 0
+    Hr, s = ol.optimize_homography(corr, H0, o)
+    def cost(Hm):
+        x1 = np.hstack([corr[:, :2], np.ones((len(corr), 1))]); x2 = np.hstack([corr[:, 2:], np.ones((len(corr), 1))])
+        f = x1 @ Hm.T; b = x2 @ np.linalg.inv(Hm).T
+        return 0.5 * (((f[:, :2] / f[:, 2:] - corr[:, 2:]) ** 2).sum() + ((b[:, :2] / b[:, 2:] - corr[:, :2]) ** 2).sum())
+    assert abs(s["initial_cost"] - cost(H0)) <= 1e-9 * cost(H0) and abs(s["final_cost"] - cost(Hr)) <= 1e-9 * cost(Hr)
+    assert s["success"] and s["final_cost"] < 0.1 * s["initial_cost"] and Hr[2, 2] == 1.0
+    assert np.abs(Hr - H).max() < 0.5 and np.abs(Hr[:2, :2] - H[:2, :2]).max() < 5e-3
+    assert s["final_cost"] / len(corr) < 2.0 * 0.5 ** 2 * 2      # ~ four residuals of 0.5 px noise
+
+
+def test_estimate_homography_lo():
+    """use_lo with HomographyEstimator::RefineModel (estimate_homography.cc:89-104)."""
+    data, offsets, truth = synth.synth_ransac_v1(2, 300, "homography", seed=0x5AC52200, inlier_lo=0.6, inlier_hi=0.7)
+    for i in range(2):
+        prm = ol.default_ransac_params(16.0, seed=70 + i); prm.failure_probability = 0.001
+        r0 = ol.ransac_estimate(6, data[offsets[i]:offsets[i + 1]], prm)
+        prm.use_lo = 1; prm.lo_start_iterations = 5; prm.min_iterations = 30
+        r1 = ol.ransac_estimate(6, data[offsets[i]:offsets[i + 1]], prm)
+        nlo = ol.rlib().oracle_last_lo_iterations()
+        assert r1["success"] and nlo >= 1 and r1["model"][8] == 1.0
+        assert r1["inlier_mask"][truth["inlier"][i]].mean() > 0.9 and r1["num_inliers"] >= 0.95 * r0["num_inliers"]

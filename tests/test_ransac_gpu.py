@@ -579,3 +579,39 @@ def test_two_view_match_geometric_verification():
     vo.guided_matching = True
     with pytest.raises(capi.TheiaHipError):
         tv.VerifyMatches(vo, pr, pr, corr[0])
+
+
+def test_optimize_homography_batch_and_lo_follow_oracle():
+    """theia_hip_optimize_homography_batch = N x OptimizeHomography, and use_lo of the homography estimator
+    (estimate_homography.cc:89-104) through it: same step counts / iteration counts / LO counts / inlier masks as the
+    oracle, refined H to 1e-8 relative."""
+    from pytheiasfm_amd import ba
+    from tests.test_oracle_ransac import _homography_scene
+    corr, Hs, H0s = [], [], []
+    for k in range(5):
+        H, c = _homography_scene(20 + k, n=100 + 30 * k)
+        corr.append(c); Hs.append(H)
+        H0s.append(H * (1.0 + 0.3 * k) + np.array([[0.01, -0.01, 2.0 + k], [0.01, 0.0, -2.0], [1e-6, 0, 0.0]]))
+    offs = np.concatenate([[0], np.cumsum([len(c) for c in corr])])
+    for loss, width in ((0, 1.0), (6, 50.0), (1, 2.0)):
+        o = ba.default_options(); o.max_num_iterations = 15; o.loss_function_type = loss; o.robust_loss_width = width
+        Hd = np.array(H0s)
+        summ = ba.optimize_homography_batch(offs, np.vstack(corr), Hd, o)
+        for k in range(5):
+            Hr, s = ol.optimize_homography(corr[k], H0s[k], o)
+            assert summ[k].num_iterations == s["num_iterations"] and summ[k].num_successful_steps == s["num_successful_steps"], (loss, k)
+            assert np.abs(Hd[k] - Hr).max() <= 1e-8 * np.abs(Hr).max(), (loss, k)
+            assert abs(summ[k].final_cost - s["final_cost"]) <= 1e-8 * s["final_cost"] and Hd[k][2, 2] == 1.0
+    data, offsets, truth = synth.synth_ransac_v1(6, 300, "homography", seed=0x5AC52300, inlier_lo=0.5, inlier_hi=0.7)
+    p = ransac.RansacParameters(); p.error_thresh = 16.0; p.seed = 81; p.failure_probability = 0.001
+    p.use_lo = True; p.lo_start_iterations = 5; p.min_iterations = 30
+    res = ransac.estimate_batch(6, data, offsets, p)
+    for i in range(6):
+        pc = p.to_c(); pc.seed = 81 + i
+        o = ol.ransac_estimate(6, data[offsets[i]:offsets[i + 1]], pc)
+        nlo = ol.rlib().oracle_last_lo_iterations()
+        sl = slice(offsets[i], offsets[i + 1])
+        assert o["num_iterations"] == res["num_iterations"][i] and nlo == res["num_lo_iterations"][i] and nlo >= 1
+        assert np.array_equal(o["inlier_mask"], res["inlier_mask"][sl])
+        assert np.abs(o["model"][:9] - res["models"][i][:9]).max() <= 1e-8 * np.abs(o["model"][:9]).max()
+        assert res["models"][i][8] == 1.0
