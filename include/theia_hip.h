@@ -283,6 +283,17 @@ int theia_hip_optimize_homography_batch(int32_t num_problems, const int64_t* off
                                         const theia_ba_options* options,
                                         theia_ba_summary* summaries);
 
+/* N calls of OptimizeFundamentalMatrix(options, correspondences, &F) (bundle_adjust_two_views.cc:248-296;
+ * RefineModel of the fundamental-matrix estimator, estimate_fundamental_matrix.cc:53-90): F moves on the
+ * 7-dof manifold of fundamental_matrix_parameterization.h:15-75 (Plus through the SVD of the current F:
+ * every accepted step re-normalises F to singular values (1, sigma, 0)) against one squared-Sampson
+ * residual per correspondence (sampson_error.h:21-33); no loss function (options->loss_function_type
+ * must be TRIVIAL), direct solver.  fundamental_matrices [num_problems][9] row-major in/out. */
+int theia_hip_optimize_fundamental_matrix_batch(int32_t num_problems, const int64_t* offsets,
+                                                const double* correspondences, double* fundamental_matrices,
+                                                const theia_ba_options* options,
+                                                theia_ba_summary* summaries);
+
 /* Every point of `problem` as its OWN problem with all cameras constant: N calls of
  * BundleAdjustTrack(options, track_id, reconstruction) (bundle_adjustment.cc:262-285; the
  * per-track refinement after triangulation, estimate_track.cc:289) in one launch, one thread
@@ -411,9 +422,9 @@ typedef struct theia_ransac_params {
   int32_t max_iterations;
   int32_t use_mle;
   int32_t use_lo;              /* LO-RANSAC: RefineModel of the absolute-pose (BundleAdjustView) and relative-pose
-                                  (BundleAdjustTwoViewsAngular; also the uncalibrated one) and homography
-                                  (OptimizeHomography) estimators as device batches, the default "return true"
-                                  of the others; fundamental matrix: ERR_UNSUPPORTED */
+                                  (BundleAdjustTwoViewsAngular; also the uncalibrated one), homography
+                                  (OptimizeHomography) and fundamental-matrix (OptimizeFundamentalMatrix)
+                                  estimators as device batches, the default "return true" of the others */
   int32_t lo_start_iterations;
   int32_t use_Tdd_test;        /* reference: "Not currently implemented"  */
   uint32_t seed;               /* seeds the mt19937 stream (util/random.cc:60-66),

@@ -235,6 +235,24 @@ def optimize_homography_batch(offsets, correspondences, homographies, options):
     return [summ[i] for i in range(num)]
 
 
+def optimize_fundamental_matrix_batch(offsets, correspondences, fundamental_matrices, options):
+    """theia_hip_optimize_fundamental_matrix_batch: N independent OptimizeFundamentalMatrix problems
+    (bundle_adjust_two_views.cc:248-296).  fundamental_matrices [N][3][3] (row-major) is updated in place."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    num = len(offsets) - 1
+    corr = np.ascontiguousarray(correspondences, dtype=np.float64).reshape(-1, 4)
+    F = fundamental_matrices
+    if not (F.flags["C_CONTIGUOUS"] and F.dtype == np.float64 and F.size == 9 * num):
+        raise capi.TheiaHipError(-1, "fundamental_matrices must be a C-contiguous float64 [N][3][3] array (updated in place)")
+    summ = (capi.BaSummary * max(1, num))()
+    L = capi.lib()
+    L.theia_hip_optimize_fundamental_matrix_batch.argtypes = [C.c_int32, C.POINTER(C.c_int64), capi.c_double_p, capi.c_double_p,
+                                                              C.POINTER(capi.BaOptions), C.POINTER(capi.BaSummary)]
+    capi.check(L.theia_hip_optimize_fundamental_matrix_batch(num, offsets.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                             capi.ptr(corr, C.c_double), capi.ptr(F, C.c_double), C.byref(options), summ))
+    return [summ[i] for i in range(num)]
+
+
 def solve_tracks_batch(problem, options):
     """theia_hip_ba_tracks_batch: every point as an independent BundleAdjustTrack problem
     (bundle_adjustment.cc:262-285), cameras constant.  problem.points is updated in place;

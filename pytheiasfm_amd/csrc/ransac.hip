@@ -417,6 +417,11 @@ __global__ void k_lo_prepare(int est, int nev, const int* __restrict__ ev_prob, 
     if (ev_slot[e] < nm) for (int k = 0; k < kStride; ++k) mo[k] = mloc[ev_slot[e] * kStride + k];
   }
   for (int k = 0; k < kStride; ++k) ev_model[(size_t)e * kStride + k] = mo[k];
+  if (est == THEIA_EST_FUNDAMENTAL_MATRIX) {   // nine doubles per event, row-major
+    double* fc = ev_cam + (size_t)e * 9;
+    for (int k = 0; k < 9; ++k) fc[k] = mo[k];
+    return;
+  }
   if (est == THEIA_EST_HOMOGRAPHY) {   // homography->data(): Eigen's column-major storage order, nine doubles per event
     double* hc = ev_cam + (size_t)e * 9;
     for (int i = 0; i < 3; ++i)
@@ -457,7 +462,7 @@ __global__ __launch_bounds__(64) void k_lo_gather(int est, const int* __restrict
     if (in) {
       const int pos = base + __popcll(b & ((1ull << lane) - 1ull));
       const double* d = pd + (size_t)i * ds;
-      if (est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_HOMOGRAPHY) {   // the correspondence itself (x1, y1, x2, y2)
+      if (est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_HOMOGRAPHY || est == THEIA_EST_FUNDAMENTAL_MATRIX) {   // the correspondence itself
         X[ev_off[e] + pos] = make_double4(d[0], d[1], d[2], d[3]);
       } else if (est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE) {   // normalised by the model's focal lengths (:146-155)
         X[ev_off[e] + pos] = make_double4(d[0] / m[21], d[1] / m[21], d[2] / m[22], d[3] / m[22]);
@@ -481,6 +486,13 @@ __global__ void k_lo_finish(int est, int nev, const int* __restrict__ ev_prob, c
   if (e >= nev) return;
   const int p = ev_prob[e];
   double* mo = cur_models + (size_t)p * kStride;
+  if (est == THEIA_EST_FUNDAMENTAL_MATRIX) {   // estimate_fundamental_matrix.cc:82-90
+    const double* fc = ev_cam + (size_t)e * 9;
+    for (int k = 0; k < 9; ++k) mo[k] = fc[k];
+    for (int k = 9; k < kStride; ++k) mo[k] = 0.0;
+    ev_success[e] = (out[e].c1 < out[e].c0 && out[e].success) ? 1 : 0;
+    return;
+  }
   if (est == THEIA_EST_HOMOGRAPHY) {   // estimate_homography.cc:100-103: H (already divided by H(2,2)) replaces the model
     const double* hc = ev_cam + (size_t)e * 9;
     for (int i = 0; i < 3; ++i)
@@ -730,11 +742,9 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   const bool trivial_refine = est == THEIA_EST_ESSENTIAL_MATRIX || est == THEIA_EST_DOMINANT_PLANE ||
                               est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION || est == THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION;
   const bool rel_pose = est == THEIA_EST_RELATIVE_POSE, uncal_pose = est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE;
-  const bool homog = est == THEIA_EST_HOMOGRAPHY;
-  if (P.use_lo && !abs_pose && !rel_pose && !uncal_pose && !homog && !trivial_refine)
-    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo: the RefineModels of the absolute-pose (BundleAdjustView), the calibrated / "
-                     "uncalibrated relative-pose (BundleAdjustTwoViewsAngular) and the homography (OptimizeHomography) estimators "
-                     "and the trivial ones are built; OptimizeFundamentalMatrix is not yet");
+  const bool homog = est == THEIA_EST_HOMOGRAPHY, fund = est == THEIA_EST_FUNDAMENTAL_MATRIX;
+  // every estimator's RefineModel is built: BundleAdjustView (absolute pose), BundleAdjustTwoViewsAngular ((un)calibrated
+  // relative pose), OptimizeHomography, OptimizeFundamentalMatrix, and the default "return true" of the rest
   // exhaustive_sampler.cc:49-51 CHECK
   if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE && sample_size(est) != 2)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "ExhaustiveSampler makes a hard assumption that the number of samples needed is 2.");
@@ -840,6 +850,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     lo_opts.loss_function_type = THEIA_LOSS_TRUNCATED;
     lo_opts.robust_loss_width = P.error_thresh;
   }
+  if (fund) { lo_opts.max_num_iterations = 2; lo_opts.loss_function_type = THEIA_LOSS_TRIVIAL; }   // estimate_fundamental_matrix.cc:56-57
   if (uncal_pose) lo_opts.max_num_iterations = 10;      // estimate_uncalibrated_relative_pose.cc:162-165 (HUBER, 1.5 x thresh)
   if (P.use_lo && (rc = d_cur_models.ensure((size_t)nprob * kStride))) return rc;
   struct LoEvent { int prob, slot; int samples[8]; };
@@ -876,7 +887,9 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
                                                  d_cur_models.p, d_ev_model.p, d_ev_cam.p, ep);
     k_lo_gather<<<nev, 64, 0, st>>>(est, d_ev_prob.p, d_off.p, d_data.p, d_ev_model.p, P.error_thresh, d_ev_off.p, d_ev_count.p,
                                     reinterpret_cast<double2*>(d_lo_uv.p), reinterpret_cast<double4*>(d_lo_X.p));
-    if (homog)
+    if (fund)
+      fundamental_batch_device(nev, d_ev_off.p, d_ev_count.p, d_lo_X.p, d_ev_cam.p, &lo_opts, d_lo_out.p, st);
+    else if (homog)
       homography_batch_device(nev, d_ev_off.p, d_ev_count.p, d_lo_X.p, d_ev_cam.p, &lo_opts, d_lo_out.p, st);
     else if (rel_pose || uncal_pose)   // the relative-pose RefineModel asks for CGNR, the uncalibrated one keeps the direct default
       twoview_batch_device(nev, d_ev_off.p, d_ev_count.p, d_lo_X.p, d_ev_cam.p, &lo_opts, rel_pose ? 1 : 0, d_lo_out.p, st);

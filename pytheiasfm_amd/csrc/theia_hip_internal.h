@@ -23,6 +23,9 @@ size_t views_batch_out_bytes();
 // (rotation_2 | position_2) in/out; cgnr = 1: CGNR + JACOBI steps, 0: exact normal-equation solve; d_out as for views_batch_device.
 int twoview_batch_device(int num, const int64_t* d_offsets, const int* d_counts, const double* d_corr, double* d_pose,
                          const theia_ba_options* o, int cgnr, void* d_out, hipStream_t st);
+// twoview_lm.hip: batched OptimizeFundamentalMatrix (no loss); d_F = [num][9] row-major in/out
+int fundamental_batch_device(int num, const int64_t* d_offsets, const int* d_counts, const double* d_corr, double* d_F,
+                             const theia_ba_options* o, void* d_out, hipStream_t st);
 // twoview_lm.hip: batched OptimizeHomography; d_H = [num][9] in Eigen's column-major storage order, in/out (normalised by H(2,2))
 int homography_batch_device(int num, const int64_t* d_offsets, const int* d_counts, const double* d_corr, double* d_H,
                             const theia_ba_options* o, void* d_out, hipStream_t st);

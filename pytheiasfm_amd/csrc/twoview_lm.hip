@@ -17,6 +17,7 @@
 // With the default options (SPARSE_SCHUR; RefineModel of the uncalibrated relative-pose estimator,
 // estimate_uncalibrated_relative_pose.cc:142-176) the step is the exact solution (solve5).
 #include "ba_device.h"
+#include "ransac_device.h"
 #include "theia_hip_internal.h"
 
 #include <chrono>
@@ -669,6 +670,238 @@ __global__ __launch_bounds__(256) void k_homography_lm(HomographyBatch B, TwoVie
   }
 }
 
+// ------------------------------------------------------------------ fundamental matrix refinement
+// N independent OptimizeFundamentalMatrix problems (bundle_adjust_two_views.cc:248-296): F moves on the 7-dof manifold
+// of fundamental_matrix_parameterization.h:15-75 -- F = U diag(1, sigma, 0) V', Plus(F, d) = (U R(d[0:3])) diag(1,
+// s1/s0 + d[6], 0) (V R(d[3:6]))' from the SVD of the CURRENT F (so every accepted step also re-normalises F) -- against
+// the squared Sampson distance of each correspondence as ONE residual (sampson_error.h:21-33), no loss, direct solver.
+// RefineModel of the fundamental-matrix estimator (estimate_fundamental_matrix.cc:53-90) runs it for 2 iterations.
+// The Jacobian of Plus at d = 0 (Ceres gets it by autodiff) is closed form in the columns u_i, v_i of U, V.
+struct FundBatch {
+  int num;
+  const int64_t* offsets;
+  const int* counts;
+  const double4* corr;
+  double* F;                // [num][9] row-major in/out
+  int max_iterations;
+  double function_tolerance, gradient_tolerance, parameter_tolerance, max_radius;
+};
+
+__device__ void fund_plus(const double* F, const double* d, double* Fo) {
+  double U[9], S[3], V[9], R1[9], R2[9], Un[9], Vn[9];
+  rsc::svd3(F, U, S, V);
+  aa_to_rot(d, R1);
+  aa_to_rot(d + 3, R2);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      Un[3 * i + j] = (U[3 * i] * R1[j] + U[3 * i + 1] * R1[3 + j]) + U[3 * i + 2] * R1[6 + j];
+      Vn[3 * i + j] = (V[3 * i] * R2[j] + V[3 * i + 1] * R2[3 + j]) + V[3 * i + 2] * R2[6 + j];
+    }
+  const double sigma = S[1] / S[0] + d[6];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Fo[3 * i + j] = Un[3 * i] * Vn[3 * j] + sigma * Un[3 * i + 1] * Vn[3 * j + 1];
+}
+// PJ[k][q] = d Plus(F, d)[k] / d d[q] at d = 0, k = 3 i + j
+__device__ void fund_plus_jacobian(const double* F, double* PJ) {
+  double U[9], S[3], V[9];
+  rsc::svd3(F, U, S, V);
+  const double s0 = S[1] / S[0];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const double* u = U + 3 * i;   // u[c] = U(i, c)
+      const double* v = V + 3 * j;   // v[c] = V(j, c)
+      double* o = PJ + 7 * (3 * i + j);
+      o[0] = s0 * u[2] * v[1];
+      o[1] = -u[2] * v[0];
+      o[2] = u[1] * v[0] - s0 * u[0] * v[1];
+      o[3] = s0 * u[1] * v[2];
+      o[4] = -u[0] * v[2];
+      o[5] = u[0] * v[1] - s0 * u[1] * v[0];
+      o[6] = u[1] * v[1];
+    }
+}
+// SampsonError::operator() and (WANT_JAC) its gradient wrt the nine entries of F (row-major)
+template <bool WANT_JAC>
+__device__ double sampson_residual(const double* F, const double4 c, double* J) {
+  const double x1[3] = {c.x, c.y, 1.0}, x2[3] = {c.z, c.w, 1.0};
+  double e[3];
+  for (int i = 0; i < 3; ++i) e[i] = (F[3 * i] * x1[0] + F[3 * i + 1] * x1[1]) + F[3 * i + 2] * x1[2];
+  const double N = (x2[0] * e[0] + x2[1] * e[1]) + x2[2] * e[2];
+  const double d0 = (x2[0] * F[0] + x2[1] * F[3]) + x2[2] * F[6];
+  const double d1 = (x2[0] * F[1] + x2[1] * F[4]) + x2[2] * F[7];
+  const double D = ((d0 * d0 + d1 * d1) + e[0] * e[0]) + e[1] * e[1];
+  if (WANT_JAC) {
+    const double a = 2.0 * N / D, b = N * N / (D * D);
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double dD = 0.0;
+        if (j == 0) dD += 2.0 * d0 * x2[i];
+        if (j == 1) dD += 2.0 * d1 * x2[i];
+        if (i == 0) dD += 2.0 * e[0] * x1[j];
+        if (i == 1) dD += 2.0 * e[1] * x1[j];
+        J[3 * i + j] = a * x2[i] * x1[j] - b * dD;
+      }
+  }
+  return N * N / D;
+}
+__device__ double fund_cost(const FundBatch& B, int p, const double* F, int lane) {
+  const int64_t beg = B.offsets[p], end = B.counts ? beg + B.counts[p] : B.offsets[p + 1];
+  double cost = 0.0;
+  for (int64_t o = beg + lane; o < end; o += 64) {
+    const double r = sampson_residual<false>(F, B.corr[o], nullptr);
+    cost += 0.5 * (r * r);
+  }
+  return wsum(cost);
+}
+__device__ void fund_linearize(const FundBatch& B, int p, const double* F, const double* scale, int lane,
+                               double* A, double* g, double* cost) {
+  const int64_t beg = B.offsets[p], end = B.counts ? beg + B.counts[p] : B.offsets[p + 1];
+  double PJ[63];
+  fund_plus_jacobian(F, PJ);
+  double acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+  for (int64_t o = beg + lane; o < end; o += 64) {
+    double Ja[9], J[7];
+    const double r = sampson_residual<true>(F, B.corr[o], Ja);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) t += Ja[k] * PJ[7 * k + q];
+      J[q] = t * scale[q];
+    }
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 7; ++a) {
+#pragma unroll
+      for (int b = 0; b <= a; ++b) acc[k++] += J[a] * J[b];
+      acc[28 + a] += J[a] * r;
+    }
+    acc[35] += 0.5 * (r * r);
+  }
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = wsum(acc[k]);
+  for (int k = 0; k < 28; ++k) A[k] = acc[k];
+  for (int k = 0; k < 7; ++k) g[k] = acc[28 + k];
+  *cost = acc[35];
+}
+__device__ bool solve7(const double* A, const double* d, const double* g, double* y) {
+  double L[28];
+  for (int i = 0; i < 7; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = A[tri(i, j)] + (i == j ? d[i] : 0.0);
+      for (int k = 0; k < j; ++k) s -= L[tri(i, k)] * L[tri(j, k)];
+      if (i == j) { if (!(s > 0.0)) return false; L[tri(i, i)] = sqrt(s); }
+      else L[tri(i, j)] = s / L[tri(j, j)];
+    }
+  double z[7];
+  for (int i = 0; i < 7; ++i) {
+    double s = g[i];
+    for (int k = 0; k < i; ++k) s -= L[tri(i, k)] * z[k];
+    z[i] = s / L[tri(i, i)];
+  }
+  for (int i = 6; i >= 0; --i) {
+    double s = z[i];
+    for (int k = i + 1; k < 7; ++k) s -= L[tri(k, i)] * y[k];
+    y[i] = s / L[tri(i, i)];
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_fundamental_lm(FundBatch B, TwoViewOut* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= B.num) return;
+  double x[9];
+  for (int q = 0; q < 9; ++q) x[q] = B.F[(size_t)p * 9 + q];
+  TwoViewOut R;
+  R.success = 0; R.term = THEIA_TERM_NO_CONVERGENCE; R.iters = 0; R.nsucc = 0; R.initial_cost = 0.0; R.final_cost = 0.0;
+  double scale[7];
+  for (int q = 0; q < 7; ++q) scale[q] = 1.0;
+  double A[28], g[7], x_cost;
+  fund_linearize(B, p, x, scale, lane, A, g, &x_cost);
+  for (int q = 0; q < 7; ++q) scale[q] = 1.0 / (1.0 + sqrt(A[tri(q, q)]));
+  double radius = 1e4, decrease_factor = 2.0;
+  bool step_successful = true, need_linearize = true, first = true;
+  int iter = 0, invalid_steps = 0, term = THEIA_TERM_NO_CONVERGENCE;
+  double x_norm = 0.0, minimum_cost = 0.0, gmax = 0.0;
+  for (int q = 0; q < 9; ++q) x_norm += x[q] * x[q];
+  x_norm = sqrt(x_norm);
+  while (true) {
+    if (need_linearize) {
+      fund_linearize(B, p, x, scale, lane, A, g, &x_cost);
+      // gradient_max_norm = |x - Plus(x, -gradient)|_inf: Plus re-normalises F, so this is rarely small
+      double ng[7], xp[9];
+      for (int q = 0; q < 7; ++q) ng[q] = -(g[q] / scale[q]);
+      fund_plus(x, ng, xp);
+      gmax = 0.0;
+      for (int q = 0; q < 9; ++q) gmax = fmax(gmax, fabs(x[q] - xp[q]));
+      need_linearize = false;
+    }
+    if (first) {
+      first = false;
+      R.initial_cost = x_cost;
+      minimum_cost = x_cost;
+      if (!isfinite(x_cost)) { term = THEIA_TERM_FAILURE; break; }
+    }
+    if (iter >= B.max_iterations) { term = THEIA_TERM_NO_CONVERGENCE; break; }
+    if (step_successful && gmax <= B.gradient_tolerance) { term = THEIA_TERM_CONVERGENCE; break; }
+    if (radius <= 1e-32) { term = THEIA_TERM_CONVERGENCE; break; }
+    ++iter;
+    double d[7], y[7];
+    for (int q = 0; q < 7; ++q) d[q] = fmin(fmax(A[tri(q, q)], 1e-6), 1e32) / radius;
+    const bool solved = solve7(A, d, g, y);
+    double yg = 0.0, yAy = 0.0;
+    for (int a = 0; a < 7; ++a) {
+      yg += y[a] * g[a];
+      double row = 0.0;
+      for (int b = 0; b < 7; ++b) row += A[a >= b ? tri(a, b) : tri(b, a)] * y[b];
+      yAy += y[a] * row;
+    }
+    const double mcc = yg - 0.5 * yAy;
+    double cand[9], dl[7], stepsq = 0.0, xnormsq = 0.0;
+    for (int q = 0; q < 7; ++q) dl[q] = -y[q] * scale[q];
+    fund_plus(x, dl, cand);
+    for (int q = 0; q < 9; ++q) {
+      stepsq += (x[q] - cand[q]) * (x[q] - cand[q]);
+      xnormsq += cand[q] * cand[q];
+    }
+    const bool step_valid = solved && isfinite(mcc) && isfinite(stepsq) && mcc > 0.0;
+    if (!step_valid) {
+      if (++invalid_steps >= 5) { term = THEIA_TERM_FAILURE; break; }
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+      continue;
+    }
+    invalid_steps = 0;
+    double cand_cost = fund_cost(B, p, cand, lane);
+    if (!isfinite(cand_cost)) cand_cost = DBL_MAX;
+    const double step_norm = sqrt(stepsq);
+    if (step_norm <= B.parameter_tolerance * (x_norm + B.parameter_tolerance)) { term = THEIA_TERM_CONVERGENCE; break; }
+    const double cost_change = x_cost - cand_cost;
+    if (fabs(cost_change) <= B.function_tolerance * x_cost) { term = THEIA_TERM_CONVERGENCE; break; }
+    const double rho = cost_change / mcc;
+    if (rho > 1e-3) {
+      for (int q = 0; q < 9; ++q) x[q] = cand[q];
+      x_norm = sqrt(xnormsq);
+      const double t = 2.0 * rho - 1.0;
+      radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+      radius = fmin(B.max_radius, radius);
+      decrease_factor = 2.0; step_successful = true; need_linearize = true;
+      R.nsucc++;
+      if (cand_cost < minimum_cost) minimum_cost = cand_cost;
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+    }
+  }
+  R.iters = iter; R.term = term; R.success = term != THEIA_TERM_FAILURE;
+  R.final_cost = term != THEIA_TERM_FAILURE ? minimum_cost : x_cost;
+  if (lane == 0) {
+    out[p] = R;
+    for (int q = 0; q < 9; ++q) B.F[(size_t)p * 9 + q] = x[q];
+  }
+}
+
 template <typename T>
 struct Dev {
   T* p = nullptr;
@@ -700,6 +933,18 @@ int twoview_batch_device(int num, const int64_t* d_offsets, const int* d_counts,
   B.parameter_tolerance = o->parameter_tolerance; B.max_radius = o->max_trust_region_radius;
   B.cgnr = cgnr;
   k_twoview_lm<<<(num + 3) / 4, 256, 0, st>>>(B, static_cast<TwoViewOut*>(d_out));
+  return 0;
+}
+
+// device-resident OptimizeFundamentalMatrix batch; d_F = [num][9] row-major in/out
+int fundamental_batch_device(int num, const int64_t* d_offsets, const int* d_counts, const double* d_corr, double* d_F,
+                             const theia_ba_options* o, void* d_out, hipStream_t st) {
+  FundBatch B;
+  B.num = num; B.offsets = d_offsets; B.counts = d_counts; B.corr = reinterpret_cast<const double4*>(d_corr); B.F = d_F;
+  B.max_iterations = o->max_num_iterations;
+  B.function_tolerance = o->function_tolerance; B.gradient_tolerance = o->gradient_tolerance;
+  B.parameter_tolerance = o->parameter_tolerance; B.max_radius = o->max_trust_region_radius;
+  k_fundamental_lm<<<(num + 3) / 4, 256, 0, st>>>(B, static_cast<TwoViewOut*>(d_out));
   return 0;
 }
 
@@ -794,6 +1039,46 @@ extern "C" int theia_hip_optimize_homography_batch(int32_t num_problems, const i
   for (int p = 0; p < num; ++p)
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) homographies[(size_t)p * 9 + 3 * i + j] = hcm[(size_t)p * 9 + i + 3 * j];
+  for (int i = 0; i < num; ++i) {
+    theia_ba_summary& S = summaries[i];
+    S.trace_size = 0;
+    S.success = h_out[i].success; S.termination_type = h_out[i].term; S.num_iterations = h_out[i].iters;
+    S.num_successful_steps = h_out[i].nsucc; S.initial_cost = h_out[i].initial_cost; S.final_cost = h_out[i].final_cost;
+    S.setup_time_in_seconds = 0.0; S.solve_time_in_seconds = dt / num;
+    S.time_linearize = S.time_solve_reduced = S.time_backsub = S.time_kernel_linearize = 0.0;
+    S.num_linearize_launches = 0;
+  }
+  return 0;
+}
+
+extern "C" int theia_hip_optimize_fundamental_matrix_batch(int32_t num_problems, const int64_t* offsets, const double* correspondences,
+                                                           double* fundamental_matrices, const theia_ba_options* o,
+                                                           theia_ba_summary* summaries) {
+  if (!o) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null options");
+  const int num = num_problems;
+  if (num < 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "negative num_problems");
+  if (num == 0) return 0;
+  if (!offsets || !fundamental_matrices || !summaries) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null array");
+  if (offsets[0] != 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "offsets[0] must be 0");
+  for (int i = 0; i < num; ++i)
+    if (offsets[i + 1] < offsets[i]) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
+  const int64_t total = offsets[num];
+  if (total > 0 && !correspondences) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null correspondences");
+  if (o->loss_function_type != THEIA_LOSS_TRIVIAL)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "OptimizeFundamentalMatrix adds its residuals without a loss function");
+  if (o->max_num_iterations < 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "negative max_num_iterations");
+  int rc = thip::ensure_device();
+  if (rc) return rc;
+  Dev<int64_t> d_off; Dev<double> d_corr, d_F; Dev<char> d_out;
+  if ((rc = d_off.up(offsets, num + 1)) || (rc = d_corr.up(correspondences, 4 * total)) ||
+      (rc = d_F.up(fundamental_matrices, 9 * (size_t)num)) || (rc = d_out.alloc(sizeof(TwoViewOut) * num)))
+    return rc;
+  const double t0 = now_s();
+  fundamental_batch_device(num, d_off.p, nullptr, d_corr.p, d_F.p, o, d_out.p, nullptr);
+  std::vector<TwoViewOut> h_out(num);
+  HIP_TRY(hipMemcpy(h_out.data(), d_out.p, sizeof(TwoViewOut) * num, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(fundamental_matrices, d_F.p, sizeof(double) * 9 * num, hipMemcpyDeviceToHost));
+  const double dt = now_s() - t0;
   for (int i = 0; i < num; ++i) {
     theia_ba_summary& S = summaries[i];
     S.trace_size = 0;

@@ -337,3 +337,19 @@ def optimize_homography(corr, H, options):
                                  capi.ptr(oi, C.c_int32), capi.ptr(oc, C.c_double))
     return hcm.reshape(3, 3).T.copy(), dict(success=int(oi[0]), termination_type=int(oi[1]), num_iterations=int(oi[2]),
                                             num_successful_steps=int(oi[3]), initial_cost=float(oc[0]), final_cost=float(oc[1]))
+
+
+def optimize_fundamental(corr, F, options):
+    """oracle_optimize_fundamental of ONE pair (F row-major 3x3); returns (F_refined, dict)."""
+    L = rlib()
+    dp = capi.c_double_p
+    L.oracle_optimize_fundamental.argtypes = [C.c_int64, dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp,
+                                              capi.c_int32_p, dp]
+    corr = np.ascontiguousarray(corr, dtype=np.float64).reshape(-1, 4)
+    Fm = np.array(F, dtype=np.float64).reshape(9).copy()
+    oi = np.zeros(4, dtype=np.int32); oc = np.zeros(2)
+    L.oracle_optimize_fundamental(len(corr), capi.ptr(corr, C.c_double), options.max_num_iterations, options.function_tolerance,
+                                  options.gradient_tolerance, options.parameter_tolerance, options.max_trust_region_radius,
+                                  capi.ptr(Fm, C.c_double), capi.ptr(oi, C.c_int32), capi.ptr(oc, C.c_double))
+    return Fm.reshape(3, 3), dict(success=int(oi[0]), termination_type=int(oi[1]), num_iterations=int(oi[2]),
+                                  num_successful_steps=int(oi[3]), initial_cost=float(oc[0]), final_cost=float(oc[1]))

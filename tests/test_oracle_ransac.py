@@ -811,3 +811,65 @@ def test_estimate_homography_lo():
         nlo = ol.rlib().oracle_last_lo_iterations()
         assert r1["success"] and nlo >= 1 and r1["model"][8] == 1.0
         assert r1["inlier_mask"][truth["inlier"][i]].mean() > 0.9 and r1["num_inliers"] >= 0.95 * r0["num_inliers"]
+
+
+def _fundamental_scene(seed, n=150, noise=0.5):
+    data, offsets, truth = synth.synth_ransac_v1(1, n, "fundamental", seed=seed, inlier_lo=1.0, inlier_hi=1.0, noise_px=noise)
+    K = np.array([[1000.0, 0, 500], [0, 1000.0, 400], [0, 0, 1]])
+    E = cross_mat(truth["t"][0]) @ truth["R"][0]
+    F = np.linalg.inv(K).T @ E @ np.linalg.inv(K)
+    return F / np.linalg.norm(F), data
+
+
+def test_fundamental_manifold_and_sampson_derivatives():
+    """fundamental_matrix_parameterization.h Plus and its Jacobian at zero, sampson_error.h and its gradient:
+    the closed forms against central differences; Plus(F, 0) is the rank-2, sigma_0 = 1 normalisation of F."""
+    L = ol.rlib(); dp = capi.c_double_p
+    L.oracle_fund_plus.argtypes = [dp, dp, dp]; L.oracle_fund_plus_jacobian.argtypes = [dp, dp]
+    L.oracle_sampson_residual.argtypes = [dp, dp, dp]; L.oracle_sampson_residual.restype = C.c_double
+    F, data = _fundamental_scene(0x5AC52400)
+    F = np.ascontiguousarray(F + 1e-3 * np.arange(9).reshape(3, 3) / 9.0)           # full rank, arbitrary scale
+    def plus(d):
+        out = np.zeros(9); dd = np.ascontiguousarray(d, dtype=np.float64)
+        L.oracle_fund_plus(capi.ptr(F, C.c_double), capi.ptr(dd, C.c_double), capi.ptr(out, C.c_double)); return out
+    F0 = plus(np.zeros(7)).reshape(3, 3)
+    sv = np.linalg.svd(F0, compute_uv=False); svF = np.linalg.svd(F, compute_uv=False)
+    assert abs(sv[0] - 1) <= 1e-12 and abs(sv[1] - svF[1] / svF[0]) <= 1e-12 and sv[2] <= 1e-12
+    PJ = np.zeros(63); L.oracle_fund_plus_jacobian(capi.ptr(F, C.c_double), capi.ptr(PJ, C.c_double)); PJ = PJ.reshape(9, 7)
+    h = 1e-6
+    for q in range(7):
+        e = np.zeros(7); e[q] = h
+        fd = (plus(e) - plus(-e)) / (2 * h)
+        assert np.abs(fd - PJ[:, q]).max() <= 1e-8, q
+    for c in data[:20]:
+        cc = np.ascontiguousarray(c); J = np.zeros(9)
+        r = L.oracle_sampson_residual(capi.ptr(F, C.c_double), capi.ptr(cc, C.c_double), capi.ptr(J, C.c_double))
+        x1 = np.array([c[0], c[1], 1.0]); x2 = np.array([c[2], c[3], 1.0])
+        Fx = F @ x1; Ftx = F.T @ x2
+        assert abs(r - (x2 @ Fx) ** 2 / (Fx[0] ** 2 + Fx[1] ** 2 + Ftx[0] ** 2 + Ftx[1] ** 2)) <= 1e-12 * max(r, 1e-30)
+        for k in range(9):
+            Fp = F.copy().reshape(9); Fm = Fp.copy(); hk = 1e-5 * max(abs(Fp[k]), 1e-3); Fp[k] += hk; Fm[k] -= hk
+            rp = L.oracle_sampson_residual(capi.ptr(Fp, C.c_double), capi.ptr(cc, C.c_double), None)
+            rm_ = L.oracle_sampson_residual(capi.ptr(Fm, C.c_double), capi.ptr(cc, C.c_double), None)
+            assert abs((rp - rm_) / (2 * hk) - J[k]) <= 1e-4 * max(abs(J[k]), 1.0)
+
+
+def test_optimize_fundamental_oracle_and_lo():
+    """OptimizeFundamentalMatrix from a perturbed F: the Sampson cost falls, the result is rank 2 with sigma_0 = 1;
+    use_lo of EstimateFundamentalMatrix (RefineModel: 2 iterations) keeps / improves the inlier set."""
+    from pytheiasfm_amd import ba
+    F, data = _fundamental_scene(0x5AC52401)
+    F0 = F + 2e-8 * np.array([[1.0, -2, 300], [2, 1, -200], [-300, 200, 5e4]])
+    o = ba.default_options(); o.max_num_iterations = 20
+    Fr, s = ol.optimize_fundamental(data, F0, o)
+    sv = np.linalg.svd(Fr, compute_uv=False)
+    assert s["success"] and s["final_cost"] < 0.2 * s["initial_cost"] and abs(sv[0] - 1) <= 1e-12 and sv[2] <= 1e-12
+    data, offsets, truth = synth.synth_ransac_v1(2, 300, "fundamental", seed=0x5AC52402, inlier_lo=0.6, inlier_hi=0.7)
+    for i in range(2):
+        prm = ol.default_ransac_params(4.0, seed=90 + i); prm.failure_probability = 0.001
+        r0 = ol.ransac_estimate(5, data[offsets[i]:offsets[i + 1]], prm)
+        prm.use_lo = 1; prm.lo_start_iterations = 5; prm.min_iterations = 30
+        r1 = ol.ransac_estimate(5, data[offsets[i]:offsets[i + 1]], prm)
+        nlo = ol.rlib().oracle_last_lo_iterations()
+        assert r1["success"] and nlo >= 1 and r1["num_inliers"] >= 0.9 * r0["num_inliers"]
+        assert r1["inlier_mask"][truth["inlier"][i]].mean() > 0.75

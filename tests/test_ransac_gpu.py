@@ -142,8 +142,9 @@ def test_mirror_api_and_error_conventions():
     ok, pl, sl = ransac.EstimateRelativePose(p, ransac.RansacType.LMED, data)     # LMED ignores error_thresh for the inliers
     assert ok and len(sl.inliers) > 50
     plo = ransac.RansacParameters(); plo.error_thresh = THR[0]; plo.use_lo = True
+    plo.ransac_type = ransac.RansacType.LMED
     with pytest.raises(capi.TheiaHipError):
-        ransac.EstimateFundamentalMatrix(plo, ransac.RansacType.RANSAC, data)        # OptimizeFundamentalMatrix RefineModel: not built
+        ransac.estimate_batch(0, data, np.array([0, len(data)]), plo)                # use_lo together with LMED: not built
     with pytest.raises(capi.TheiaHipError):
         ransac.EstimateCalibratedAbsolutePose(p, ransac.RansacType.RANSAC, ransac.PnPType.DLS, da)
     with pytest.raises(capi.TheiaHipError):
@@ -615,3 +616,41 @@ def test_optimize_homography_batch_and_lo_follow_oracle():
         assert np.array_equal(o["inlier_mask"], res["inlier_mask"][sl])
         assert np.abs(o["model"][:9] - res["models"][i][:9]).max() <= 1e-8 * np.abs(o["model"][:9]).max()
         assert res["models"][i][8] == 1.0
+
+
+def test_optimize_fundamental_matrix_batch_and_lo_follow_oracle():
+    """theia_hip_optimize_fundamental_matrix_batch = N x OptimizeFundamentalMatrix (SVD manifold, Sampson residual), and
+    use_lo of the fundamental-matrix estimator (2 iterations, estimate_fundamental_matrix.cc:53-90) through it."""
+    from pytheiasfm_amd import ba
+    from tests.test_oracle_ransac import _fundamental_scene
+    corr, F0s = [], []
+    for k in range(5):
+        F, c = _fundamental_scene(0x5AC52500 + k, n=120 + 20 * k)
+        corr.append(c)
+        F0s.append(F * (1.0 + k) + (k + 1) * 1e-8 * np.array([[1.0, -2, 300], [2, 1, -200], [-300, 200, 5e4]]))
+    offs = np.concatenate([[0], np.cumsum([len(c) for c in corr])])
+    for iters in (2, 12):
+        o = ba.default_options(); o.max_num_iterations = iters
+        Fd = np.array(F0s)
+        summ = ba.optimize_fundamental_matrix_batch(offs, np.vstack(corr), Fd, o)
+        for k in range(5):
+            Fr, s = ol.optimize_fundamental(corr[k], F0s[k], o)
+            assert summ[k].num_iterations == s["num_iterations"] and summ[k].num_successful_steps == s["num_successful_steps"], (iters, k)
+            assert np.abs(Fd[k] - Fr).max() <= 1e-8 * np.abs(Fr).max(), (iters, k, np.abs(Fd[k] - Fr).max())
+            assert abs(summ[k].final_cost - s["final_cost"]) <= 1e-7 * s["final_cost"]
+            assert summ[k].final_cost <= summ[k].initial_cost
+    o.loss_function_type = 1
+    with pytest.raises(capi.TheiaHipError):
+        ba.optimize_fundamental_matrix_batch(offs, np.vstack(corr), np.array(F0s), o)     # the reference adds no loss function
+    data, offsets, truth = synth.synth_ransac_v1(6, 300, "fundamental", seed=0x5AC52600, inlier_lo=0.5, inlier_hi=0.7)
+    p = ransac.RansacParameters(); p.error_thresh = 4.0; p.seed = 93; p.failure_probability = 0.001
+    p.use_lo = True; p.lo_start_iterations = 5; p.min_iterations = 30
+    res = ransac.estimate_batch(5, data, offsets, p)
+    for i in range(6):
+        pc = p.to_c(); pc.seed = 93 + i
+        oo = ol.ransac_estimate(5, data[offsets[i]:offsets[i + 1]], pc)
+        nlo = ol.rlib().oracle_last_lo_iterations()
+        sl = slice(offsets[i], offsets[i + 1])
+        assert oo["num_iterations"] == res["num_iterations"][i] and nlo == res["num_lo_iterations"][i] and nlo >= 1
+        assert np.array_equal(oo["inlier_mask"], res["inlier_mask"][sl])
+        assert np.abs(oo["model"][:9] - res["models"][i][:9]).max() <= 1e-8 * np.abs(oo["model"][:9]).max()
