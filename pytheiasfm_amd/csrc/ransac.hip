@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int
                                             const double* __restrict__ data, const int* __restrict__ samples,
                                             const int* __restrict__ active_iters, double* __restrict__ models,
                                             int* __restrict__ counts, int* __restrict__ dense_count,
-                                            int* __restrict__ tags, EstParams ep) {
+                                            int* __restrict__ tags, int* __restrict__ hyp_base, EstParams ep) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int p = blockIdx.y;
   if (b >= B || p >= nprob) return;
@@ -194,6 +194,7 @@ __global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int
   // are empty: scoring a dense list keeps every lane of k_score busy); the tag
   // remembers (iteration, slot) so the host replays in sample order.
   const int base = atomicAdd(&dense_count[p], nm);
+  hyp_base[hyp] = base;   // where this hypothesis' models start in the dense list (LO events fetch their model from there)
   double* mo = models + ((size_t)p * B * mm + base) * (size_t)kStride;
   int* tg = tags + (size_t)p * B * mm + base;
   for (int j = 0; j < nm; ++j) {
@@ -394,7 +395,9 @@ __global__ void k_p3p(int num, const double* __restrict__ corr, double* __restri
 // An event = (problem, model source); source: refit from (samples, slot), or the
 // problem's current best model.
 __global__ void k_lo_prepare(int est, int nev, const int* __restrict__ ev_prob, const int* __restrict__ ev_samples,
-                             const int* __restrict__ ev_slot, const int64_t* __restrict__ offsets,
+                             const int* __restrict__ ev_slot, const int* __restrict__ ev_hyp, int round_B,
+                             const double* __restrict__ round_models, const int* __restrict__ hyp_base,
+                             const int64_t* __restrict__ offsets,
                              const double* __restrict__ data, const double* __restrict__ cur_models,
                              double* __restrict__ ev_model, double* __restrict__ ev_cam, EstParams ep) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -404,6 +407,13 @@ __global__ void k_lo_prepare(int est, int nev, const int* __restrict__ ev_prob, 
   for (int k = 0; k < kStride; ++k) mo[k] = 0.0;
   if (ev_slot[e] < 0) {
     for (int k = 0; k < kStride; ++k) mo[k] = cur_models[(size_t)p * kStride + k];
+  } else if (ev_hyp[e] >= 0) {
+    // an event of the round being replayed: its model is still in the round's dense list (k_fit), the same bits a
+    // refit would give -- a single-thread five-point refit costs ~2 ms of latency per LO batch
+    const int h = ev_hyp[e];
+    const int q = h / round_B;   // problem inside the chunk
+    const double* src = round_models + ((size_t)q * round_B * max_models(est) + hyp_base[h] + ev_slot[e]) * (size_t)kStride;
+    for (int k = 0; k < kStride; ++k) mo[k] = src[k];
   } else {
     const int m = sample_size(est), ds = datum_size(est);
     const double* pd = data + (size_t)offsets[p] * ds;
@@ -797,6 +807,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   chunk = std::min(chunk, nprob);
 
   DBuf<int> d_samples, d_counts, d_ninl, d_active, d_best_samples, d_best_slot, d_dense, d_tags;
+  DBuf<int> d_hyp_base;   // [problem][iteration] first dense model of the hypothesis (k_fit)
   DBuf<double> d_models, d_cost, d_best_models;
   DBuf<uint8_t> d_mask;
   std::vector<int> h_samples, h_counts, h_ninl, h_active;
@@ -833,7 +844,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   }
   double fit_score_ms = 0.0;
   // ---- LO-RANSAC (absolute / relative pose): batched RefineModel over a list of events
-  DBuf<int> d_ev_prob, d_ev_samples, d_ev_slot, d_ev_count, d_ev_success, d_lo_model_id;
+  DBuf<int> d_ev_prob, d_ev_samples, d_ev_slot, d_ev_hyp, d_ev_count, d_ev_success, d_lo_model_id;
   DBuf<int64_t> d_ev_off;
   DBuf<double> d_ev_model, d_ev_cam, d_lo_uv, d_lo_X, d_cur_models, d_lo_intr;
   DBuf<char> d_lo_out;
@@ -853,18 +864,19 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   if (fund) { lo_opts.max_num_iterations = 2; lo_opts.loss_function_type = THEIA_LOSS_TRIVIAL; }   // estimate_fundamental_matrix.cc:56-57
   if (uncal_pose) lo_opts.max_num_iterations = 10;      // estimate_uncalibrated_relative_pose.cc:162-165 (HUBER, 1.5 x thresh)
   if (P.use_lo && (rc = d_cur_models.ensure((size_t)nprob * kStride))) return rc;
-  struct LoEvent { int prob, slot; int samples[8]; };
+  struct LoEvent { int prob, slot, hyp; int samples[8]; };   // hyp: (problem in chunk) * B + iteration of the round, or -1
+  int lo_round_B = 0;
   // refines every event's model on its inliers; writes the refined pose to d_cur_models[prob]
   auto run_lo = [&](const std::vector<LoEvent>& evs, std::vector<int>& success) -> int {
     const int nev = (int)evs.size();
     success.assign(nev, 0);
     if (nev == 0) return 0;
     std::lock_guard<std::recursive_mutex> scratch_lock(scratch_mutex());
-    std::vector<int> hp(nev), hs((size_t)nev * kMaxSample), hsl(nev), hmod(nev, THEIA_CAM_PINHOLE);
+    std::vector<int> hp(nev), hs((size_t)nev * kMaxSample), hsl(nev), hmod(nev, THEIA_CAM_PINHOLE), hhyp(nev);
     std::vector<int64_t> hoff(nev + 1, 0);
     std::vector<double> hintr((size_t)nev * THEIA_MAX_INTRINSICS, 0.0);
     for (int e = 0; e < nev; ++e) {
-      hp[e] = evs[e].prob; hsl[e] = evs[e].slot;
+      hp[e] = evs[e].prob; hsl[e] = evs[e].slot; hhyp[e] = evs[e].hyp;
       for (int k = 0; k < kMaxSample; ++k) hs[(size_t)e * kMaxSample + k] = evs[e].samples[k];
       hoff[e + 1] = hoff[e] + S[evs[e].prob].n;          // capacity: every datum could be an inlier
       hintr[(size_t)e * THEIA_MAX_INTRINSICS] = 1.0; hintr[(size_t)e * THEIA_MAX_INTRINSICS + 1] = 1.0;   // Camera(): f = 1, aspect 1
@@ -880,10 +892,13 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     HIP_TRYR(hipMemcpyAsync(d_ev_prob.p, hp.data(), sizeof(int) * nev, hipMemcpyHostToDevice, st));
     HIP_TRYR(hipMemcpyAsync(d_ev_samples.p, hs.data(), sizeof(int) * nev * kMaxSample, hipMemcpyHostToDevice, st));
     HIP_TRYR(hipMemcpyAsync(d_ev_slot.p, hsl.data(), sizeof(int) * nev, hipMemcpyHostToDevice, st));
+    if ((rc2 = d_ev_hyp.ensure(nev))) return rc2;
+    HIP_TRYR(hipMemcpyAsync(d_ev_hyp.p, hhyp.data(), sizeof(int) * nev, hipMemcpyHostToDevice, st));
     HIP_TRYR(hipMemcpyAsync(d_ev_off.p, hoff.data(), sizeof(int64_t) * (nev + 1), hipMemcpyHostToDevice, st));
     HIP_TRYR(hipMemcpyAsync(d_lo_intr.p, hintr.data(), sizeof(double) * hintr.size(), hipMemcpyHostToDevice, st));
     HIP_TRYR(hipMemcpyAsync(d_lo_model_id.p, hmod.data(), sizeof(int) * nev, hipMemcpyHostToDevice, st));
-    k_lo_prepare<<<(nev + 63) / 64, 64, 0, st>>>(est, nev, d_ev_prob.p, d_ev_samples.p, d_ev_slot.p, d_off.p, d_data.p,
+    k_lo_prepare<<<(nev + 63) / 64, 64, 0, st>>>(est, nev, d_ev_prob.p, d_ev_samples.p, d_ev_slot.p, d_ev_hyp.p, lo_round_B,
+                                                 d_models.p, d_hyp_base.p, d_off.p, d_data.p,
                                                  d_cur_models.p, d_ev_model.p, d_ev_cam.p, ep);
     k_lo_gather<<<nev, 64, 0, st>>>(est, d_ev_prob.p, d_off.p, d_data.p, d_ev_model.p, P.error_thresh, d_ev_off.p, d_ev_count.p,
                                     reinterpret_cast<double2*>(d_lo_uv.p), reinterpret_cast<double4*>(d_lo_X.p));
@@ -945,7 +960,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       const size_t nh = (size_t)cn * B;
       if ((rc = d_samples.ensure(nh * m)) || (rc = d_counts.ensure(nh)) || (rc = d_models.ensure(nh * kMaxModels * kStride)) ||
           (rc = d_cost.ensure(nh * kMaxModels)) || (rc = d_ninl.ensure(nh * kMaxModels)) || (rc = d_active.ensure(cn)) ||
-          (rc = d_dense.ensure(cn)) || (rc = d_tags.ensure(nh * kMaxModels)))
+          (rc = d_dense.ensure(cn)) || (rc = d_tags.ensure(nh * kMaxModels)) || (rc = d_hyp_base.ensure(nh)))
         return rc;
       HIP_TRYR(hipMemsetAsync(d_dense.p, 0, sizeof(int) * cn, st));
       HIP_TRYR(hipMemcpyAsync(d_samples.p, h_samples.data(), sizeof(int) * nh * m, hipMemcpyHostToDevice, st));
@@ -954,7 +969,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       HIP_TRYR(hipEventRecord(ev0, st));
       {
         dim3 grid((B + 63) / 64, cn);
-#define THIP_FIT(E) k_fit<E><<<grid, 64, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, ep)
+#define THIP_FIT(E) k_fit<E><<<grid, 64, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p, ep)
         switch (est) {
           case THEIA_EST_RELATIVE_POSE: THIP_FIT(THEIA_EST_RELATIVE_POSE); break;
           case THEIA_EST_ESSENTIAL_MATRIX: THIP_FIT(THEIA_EST_ESSENTIAL_MATRIX); break;
@@ -995,6 +1010,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         ProblemState& s = S[c0 + q];
         s.base_it = s.it; s.rb = 0; s.rj = 0; s.round_done = s.done;
       }
+      lo_round_B = B;
       std::vector<LoEvent> events;
       std::vector<int> ev_q, ev_ok;
       std::atomic<long long> n_hyp{0}, n_scored{0};
@@ -1026,7 +1042,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
                 if (P.use_lo && trivial_refine && s.base_it + s.rb >= P.lo_start_iterations) {
                   s.num_lo++;   // RefineModel = "return true": nothing changes but the counter
                 } else if (P.use_lo && s.base_it + s.rb >= P.lo_start_iterations) {   // :373-381
-                  LoEvent ev; ev.prob = c0 + q; ev.slot = j;
+                  LoEvent ev; ev.prob = c0 + q; ev.slot = j; ev.hyp = (int)hyp;
                   for (int i = 0; i < kMaxSample; ++i) ev.samples[i] = s.best_samples[i];
                   events.push_back(ev); ev_q.push_back(q);
                   s.pending_ratio = inlier_ratio;
@@ -1094,7 +1110,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     HIP_TRYR(hipMemcpyAsync(d_cur_models.p, d_best_models.p, sizeof(double) * nprob * kStride, hipMemcpyDeviceToDevice, st));
     std::vector<LoEvent> evs;
     for (int p = 0; p < nprob; ++p)
-      if (S[p].best_slot >= 0) { LoEvent ev; ev.prob = p; ev.slot = -1; for (int k = 0; k < kMaxSample; ++k) ev.samples[k] = 0; evs.push_back(ev); }
+      if (S[p].best_slot >= 0) { LoEvent ev; ev.prob = p; ev.slot = -1; ev.hyp = -1; for (int k = 0; k < kMaxSample; ++k) ev.samples[k] = 0; evs.push_back(ev); }
     std::vector<int> ok;
     if ((rc = run_lo(evs, ok))) return rc;
     for (const LoEvent& ev : evs) S[ev.prob].num_lo++;
