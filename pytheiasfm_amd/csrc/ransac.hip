@@ -354,6 +354,19 @@ __global__ void k_refit(int est, int nprob, const int64_t* __restrict__ offsets,
   if (j < nm) for (int k = 0; k < kStride; ++k) mo[k] = mloc[j * kStride + k];
 }
 
+// after a round's replay: the problems whose best model changed in this round copy it out of the round's dense model
+// list (the final models then need no refit: a single-thread five-point solve is ~2 ms of latency)
+__global__ void k_save_best(int est, int n, const int* __restrict__ prob, const int* __restrict__ hyp, const int* __restrict__ slot,
+                            int round_B, const double* __restrict__ round_models, const int* __restrict__ hyp_base,
+                            double* __restrict__ best_models) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * kStride) return;
+  const int e = i / kStride, k = i % kStride;
+  const int h = hyp[e], q = h / round_B;
+  best_models[(size_t)prob[e] * kStride + k] =
+      round_models[((size_t)q * round_B * max_models(est) + hyp_base[h] + slot[e]) * (size_t)kStride + k];
+}
+
 __global__ void k_inlier_mask(int est, int nprob, const int64_t* __restrict__ offsets, const double* __restrict__ data,
                               const double* __restrict__ best_models, double thresh, uint8_t* __restrict__ mask) {
   const int p = blockIdx.y;
@@ -675,6 +688,7 @@ struct ProblemState {
   int max_iterations, it, n;
   bool done;
   int best_slot;
+  int best_hyp = -1;          // hypothesis (chunk-local problem * B + iteration) of the best model, if set in this round
   int best_samples[kMaxSample];
   int round_iters;
   int kth;  // PROSAC sample counter
@@ -808,6 +822,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
 
   DBuf<int> d_samples, d_counts, d_ninl, d_active, d_best_samples, d_best_slot, d_dense, d_tags;
   DBuf<int> d_hyp_base;   // [problem][iteration] first dense model of the hypothesis (k_fit)
+  DBuf<int> d_save;       // {problem, hypothesis, slot} triples of k_save_best
   DBuf<double> d_models, d_cost, d_best_models;
   DBuf<uint8_t> d_mask;
   std::vector<int> h_samples, h_counts, h_ninl, h_active;
@@ -864,6 +879,8 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   if (fund) { lo_opts.max_num_iterations = 2; lo_opts.loss_function_type = THEIA_LOSS_TRIVIAL; }   // estimate_fundamental_matrix.cc:56-57
   if (uncal_pose) lo_opts.max_num_iterations = 10;      // estimate_uncalibrated_relative_pose.cc:162-165 (HUBER, 1.5 x thresh)
   if (P.use_lo && (rc = d_cur_models.ensure((size_t)nprob * kStride))) return rc;
+  if ((rc = d_best_models.ensure((size_t)nprob * kStride))) return rc;
+  HIP_TRYR(hipMemsetAsync(d_best_models.p, 0, sizeof(double) * nprob * kStride, st));
   struct LoEvent { int prob, slot, hyp; int samples[8]; };   // hyp: (problem in chunk) * B + iteration of the round, or -1
   int lo_round_B = 0;
   // refines every event's model on its inliers; writes the refined pose to d_cur_models[prob]
@@ -1008,7 +1025,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       // as one batch, then every replay resumes where it stopped.
       for (int q = 0; q < cn; ++q) {
         ProblemState& s = S[c0 + q];
-        s.base_it = s.it; s.rb = 0; s.rj = 0; s.round_done = s.done;
+        s.base_it = s.it; s.rb = 0; s.rj = 0; s.round_done = s.done; s.best_hyp = -1;
       }
       lo_round_B = B;
       std::vector<LoEvent> events;
@@ -1036,6 +1053,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
               if (cost < s.best_cost) {
                 s.best_cost = cost;
                 s.best_slot = j;
+                s.best_hyp = (int)hyp;
                 s.best_refined = false;
                 for (int i = 0; i < m; ++i) s.best_samples[i] = h_samples[hyp * m + i];
                 if (inlier_ratio < m / (double)s.n) continue;
@@ -1075,6 +1093,24 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
           s.max_iterations = std::min(compute_max_iterations(P, m, s.pending_ratio, log_failure_prob, s.n), s.max_iterations);
         }
       }
+      {   // best models found in this round -> d_best_models
+        std::vector<int> sp, sh, ss;
+        for (int q = 0; q < cn; ++q) {
+          const ProblemState& s = S[c0 + q];
+          if (s.best_hyp >= 0) { sp.push_back(c0 + q); sh.push_back(s.best_hyp); ss.push_back(s.best_slot); }
+        }
+        if (!sp.empty()) {
+          const int ns = (int)sp.size();
+          if ((rc = d_save.ensure((size_t)3 * ns))) return rc;
+          std::lock_guard<std::recursive_mutex> save_lock(scratch_mutex());
+          HIP_TRYR(hipMemcpyAsync(d_save.p, sp.data(), sizeof(int) * ns, hipMemcpyHostToDevice, st));
+          HIP_TRYR(hipMemcpyAsync(d_save.p + ns, sh.data(), sizeof(int) * ns, hipMemcpyHostToDevice, st));
+          HIP_TRYR(hipMemcpyAsync(d_save.p + 2 * ns, ss.data(), sizeof(int) * ns, hipMemcpyHostToDevice, st));
+          k_save_best<<<(ns * kStride + 255) / 256, 256, 0, st>>>(est, ns, d_save.p, d_save.p + ns, d_save.p + 2 * ns, B, d_models.p,
+                                                                  d_hyp_base.p, d_best_models.p);
+          HIP_TRYR(hipStreamSynchronize(st));   // the host vectors above are the sources of asynchronous uploads
+        }
+      }
       result->hypotheses_evaluated += n_hyp.load(); result->models_scored += n_scored.load();
     }
   }
@@ -1089,7 +1125,10 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   std::lock_guard<std::recursive_mutex> final_scratch_lock(scratch_mutex());
   HIP_TRYR(hipMemcpyAsync(d_best_samples.p, best_samples_all.data(), sizeof(int) * nprob * kMaxSample, hipMemcpyHostToDevice, st));
   HIP_TRYR(hipMemcpyAsync(d_best_slot.p, best_slot_all.data(), sizeof(int) * nprob, hipMemcpyHostToDevice, st));
-  k_refit<<<(nprob + 63) / 64, 64, 0, st>>>(est, nprob, d_off.p, d_data.p, d_best_samples.p, d_best_slot.p, d_best_models.p, ep);
+  // d_best_models already holds every problem's best model (k_save_best); THEIA_HIP_RANSAC_REFIT=1 recomputes them from the
+  // best samples instead (the same bits: the solver is deterministic)
+  if (getenv("THEIA_HIP_RANSAC_REFIT"))
+    k_refit<<<(nprob + 63) / 64, 64, 0, st>>>(est, nprob, d_off.p, d_data.p, d_best_samples.p, d_best_slot.p, d_best_models.p, ep);
   std::vector<int> use_cur;   // source of an asynchronous upload: lives until the final synchronisation
   if (P.use_lo && !trivial_refine) {   // the best model of a problem may be the refined pose of its last LO event
     use_cur.resize(nprob);
