@@ -977,3 +977,34 @@ def test_compact_intrinsics_rows_equal_full_rows():
     assert a[4].num_iterations == b[4].num_iterations and np.array_equal(a[5].accepted, b[5].accepted)
     assert rel(a[3].intrinsics, b[3].intrinsics) <= 1e-9 and np.abs(a[3].cam_ext - b[3].cam_ext).max() <= 1e-8
     assert not np.array_equal(a[3].intrinsics[:, 0], p.intrinsics[:, 0])
+
+
+def test_bundle_adjust_two_views_mirror_matches_oracle():
+    """twoview.BundleAdjustTwoViews (bundle_adjust_two_views.cc:110-185): camera 1 fixed, camera 2 free, XYZW points
+    without a manifold, focal lengths free unless held constant -- against the oracle on the same flat problem."""
+    from pytheiasfm_amd import twoview as tv
+    data, offsets, truth = synth.synth_ransac_v1(1, 120, "fundamental", seed=0x5AC52700, inlier_lo=1.0, inlier_hi=1.0, noise_px=0.5)
+    corr = data[:120]
+    R, t = truth["R"][0], truth["t"][0]
+    ext2 = np.concatenate([truth["position"][0] + 0.01, synth.matrix_to_angle_axis(R) + 0.005])
+    x1 = (corr[:, :2] - np.array([500.0, 400.0])) / 1000.0
+    depth = 6.0 + 0.3 * np.sin(np.arange(120))
+    pts = np.column_stack([x1 * depth[:, None], depth, np.ones(120)])        # rough points on the first camera's rays
+    for const2 in (True, False):
+        cam1 = {"ext": np.zeros(6), "intr": np.array([1000.0, 1, 0, 500, 400, 0, 0]), "model": 0}
+        cam2 = {"ext": ext2.copy(), "intr": np.array([1010.0, 1, 0, 500, 400, 0, 0]), "model": 0}
+        p3 = np.ascontiguousarray(pts.copy())
+        bo = tv.TwoViewBundleAdjustmentOptions(); bo.constant_camera2_intrinsics = const2; bo.ba_options.max_num_iterations = 20
+        summ = tv.BundleAdjustTwoViews(bo, corr, cam1, cam2, p3)
+        flat = capi.FlatProblem(np.array([np.zeros(6), ext2]), np.array([[1000.0, 1, 0, 500, 400, 0, 0], [1010.0, 1, 0, 500, 400, 0, 0]]),
+                                [0, 0], [0, 1], pts.copy(), np.concatenate([corr[:, :2], corr[:, 2:]]),
+                                np.concatenate([np.zeros(120, np.int32), np.ones(120, np.int32)]),
+                                np.concatenate([np.arange(120), np.arange(120)]).astype(np.int32), cam_const=[3, 0],
+                                group_const=[1, int(const2)])
+        o, oo = both_options(max_num_iterations=20, intrinsics_to_optimize=0x01, use_homogeneous_point_parametrization=0)
+        so, tro = ol.solve(flat, oo)
+        assert summ.success and summ.final_cost < 0.01 * summ.initial_cost
+        assert rel(summ.final_cost, so.final_cost) <= 1e-8 and np.abs(cam2["ext"] - flat.cam_ext[1]).max() <= 1e-6
+        assert np.array_equal(cam1["ext"], np.zeros(6)) and cam1["intr"][0] == 1000.0
+        assert (cam2["intr"][0] == 1010.0) == const2 and rel(cam2["intr"], flat.intrinsics[1][:7]) <= 1e-7
+        assert rel(p3, flat.points) <= 1e-6
