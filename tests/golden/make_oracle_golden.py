@@ -235,6 +235,35 @@ def fourth_set():
         nlo.append(ol.rlib().oracle_last_lo_iterations())
     out["rel_lo_masks"] = np.stack(masks); out["rel_lo_models"] = np.stack(models); out["rel_lo_iters"] = np.array(iters)
     out["rel_lo_nlo"] = np.array(nlo)
+    # OptimizeHomography / OptimizeFundamentalMatrix vectors and the LO runs of the estimators that call them
+    from tests.test_oracle_ransac import _homography_scene, _fundamental_scene
+    oh = ba.default_options(); oh.max_num_iterations = 15; oh.loss_function_type = 6; oh.robust_loss_width = 50.0
+    of = ba.default_options(); of.max_num_iterations = 2
+    for k in range(2):
+        H, c = _homography_scene(40 + k, n=90 + 20 * k)
+        H0 = H * (1.0 + 0.5 * k) + np.array([[0.01, -0.01, 2.0 + k], [0.01, 0.0, -2.0], [1e-6, 0, 0.0]])
+        Hr, s_ = ol.optimize_homography(c, H0, oh)
+        out[f"hom{k}_corr"] = c; out[f"hom{k}_H0"] = H0; out[f"hom{k}_H"] = Hr
+        out[f"hom{k}_ints"] = np.array([s_["num_iterations"], s_["num_successful_steps"]]); out[f"hom{k}_costs"] = np.array([s_["initial_cost"], s_["final_cost"]])
+        F, c = _fundamental_scene(0x5AC52800 + k, n=100 + 20 * k)
+        F0 = F * (1.0 + k) + (k + 2) * 1e-8 * np.array([[1.0, -2, 300], [2, 1, -200], [-300, 200, 5e4]])
+        Fr, s_ = ol.optimize_fundamental(c, F0, of)
+        out[f"fund{k}_corr"] = c; out[f"fund{k}_F0"] = F0; out[f"fund{k}_F"] = Fr
+        out[f"fund{k}_ints"] = np.array([s_["num_iterations"], s_["num_successful_steps"]]); out[f"fund{k}_costs"] = np.array([s_["initial_cost"], s_["final_cost"]])
+    ol.set_estimator_params([1.0, 1e9])
+    for kind, est, thresh, mlen in (("fundamental", 5, 4.0, 9), ("homography", 6, 16.0, 9), ("uncalibrated", 9, 4.0, 23)):
+        data, offsets, _ = synth.synth_ransac_v1(2, 150, kind, seed=0x5AC52900 + est, inlier_lo=0.5, inlier_hi=0.7,
+                                                 noise_px=0.3 if kind == "uncalibrated" else 1.0)
+        out[f"lo_{kind}_data"] = data; out[f"lo_{kind}_offsets"] = offsets
+        masks, models, iters, nlo = [], [], [], []
+        for i in range(2):
+            prm = ol.default_ransac_params(thresh, 60 + i); prm.failure_probability = 0.001
+            prm.use_lo = 1; prm.lo_start_iterations = 5; prm.min_iterations = 30
+            r = ol.ransac_estimate(est, data[offsets[i]:offsets[i + 1]], prm)
+            masks.append(r["inlier_mask"]); models.append(r["model"][:mlen]); iters.append(r["num_iterations"])
+            nlo.append(ol.rlib().oracle_last_lo_iterations())
+        out[f"lo_{kind}_masks"] = np.stack(masks); out[f"lo_{kind}_models"] = np.stack(models)
+        out[f"lo_{kind}_iters"] = np.array(iters); out[f"lo_{kind}_nlo"] = np.array(nlo)
     np.savez_compressed(os.path.join(HERE, "two_view_lo.npz"), **out)
     print("wrote two_view_lo.npz")
 

@@ -873,3 +873,30 @@ def test_optimize_fundamental_oracle_and_lo():
         nlo = ol.rlib().oracle_last_lo_iterations()
         assert r1["success"] and nlo >= 1 and r1["num_inliers"] >= 0.9 * r0["num_inliers"]
         assert r1["inlier_mask"][truth["inlier"][i]].mean() > 0.75
+
+
+LO_GOLDEN = (("fundamental", 5, 4.0, 9), ("homography", 6, 16.0, 9), ("uncalibrated", 9, 4.0, 23))
+
+
+def test_golden_refine_model_vectors():
+    """tests/golden/two_view_lo.npz, second part: OptimizeHomography / OptimizeFundamentalMatrix vectors and the LO-RANSAC runs
+    of the fundamental-matrix, homography and uncalibrated relative-pose estimators."""
+    from pytheiasfm_amd import ba
+    g = np.load(os.path.join(HERE, "golden", "two_view_lo.npz"))
+    oh = ba.default_options(); oh.max_num_iterations = 15; oh.loss_function_type = 6; oh.robust_loss_width = 50.0
+    of = ba.default_options(); of.max_num_iterations = 2
+    for k in range(2):
+        Hr, s = ol.optimize_homography(g[f"hom{k}_corr"], g[f"hom{k}_H0"], oh)
+        assert np.allclose(Hr, g[f"hom{k}_H"], rtol=1e-12, atol=0) and [s["num_iterations"], s["num_successful_steps"]] == list(g[f"hom{k}_ints"])
+        Fr, s = ol.optimize_fundamental(g[f"fund{k}_corr"], g[f"fund{k}_F0"], of)
+        assert np.allclose(Fr, g[f"fund{k}_F"], rtol=1e-11, atol=1e-15) and [s["num_iterations"], s["num_successful_steps"]] == list(g[f"fund{k}_ints"])
+    ol.set_estimator_params([1.0, 1e9])
+    for kind, est, thresh, mlen in LO_GOLDEN:
+        data, offsets = g[f"lo_{kind}_data"], g[f"lo_{kind}_offsets"]
+        for i in range(2):
+            prm = ol.default_ransac_params(thresh, 60 + i); prm.failure_probability = 0.001
+            prm.use_lo = 1; prm.lo_start_iterations = 5; prm.min_iterations = 30
+            r = ol.ransac_estimate(est, data[offsets[i]:offsets[i + 1]], prm)
+            assert r["num_iterations"] == g[f"lo_{kind}_iters"][i] and ol.rlib().oracle_last_lo_iterations() == g[f"lo_{kind}_nlo"][i]
+            assert np.array_equal(r["inlier_mask"], g[f"lo_{kind}_masks"][i])
+            assert np.allclose(r["model"][:mlen], g[f"lo_{kind}_models"][i], rtol=1e-11, atol=1e-14)

@@ -654,3 +654,31 @@ def test_optimize_fundamental_matrix_batch_and_lo_follow_oracle():
         assert oo["num_iterations"] == res["num_iterations"][i] and nlo == res["num_lo_iterations"][i] and nlo >= 1
         assert np.array_equal(oo["inlier_mask"], res["inlier_mask"][sl])
         assert np.abs(oo["model"][:9] - res["models"][i][:9]).max() <= 1e-8 * np.abs(oo["model"][:9]).max()
+
+
+def test_golden_refine_model_vectors_on_device():
+    """The second part of tests/golden/two_view_lo.npz through the C-ABI."""
+    from pytheiasfm_amd import ba
+    from tests.test_oracle_ransac import LO_GOLDEN
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "two_view_lo.npz"))
+    oh = ba.default_options(); oh.max_num_iterations = 15; oh.loss_function_type = 6; oh.robust_loss_width = 50.0
+    of = ba.default_options(); of.max_num_iterations = 2
+    for name, fn, opt, key0, key in (("hom", ba.optimize_homography_batch, oh, "H0", "H"), ("fund", ba.optimize_fundamental_matrix_batch, of, "F0", "F")):
+        corr = [g[f"{name}{k}_corr"] for k in range(2)]
+        offs = np.concatenate([[0], np.cumsum([len(c) for c in corr])])
+        M = np.array([g[f"{name}{k}_{key0}"] for k in range(2)])
+        summ = fn(offs, np.vstack(corr), M, opt)
+        for k in range(2):
+            assert np.abs(M[k] - g[f"{name}{k}_{key}"]).max() <= 1e-8 * np.abs(g[f"{name}{k}_{key}"]).max()
+            assert [summ[k].num_iterations, summ[k].num_successful_steps] == list(g[f"{name}{k}_ints"])
+            assert np.allclose([summ[k].initial_cost, summ[k].final_cost], g[f"{name}{k}_costs"], rtol=1e-7, atol=0)
+    for kind, est, thresh, mlen in LO_GOLDEN:
+        p = ransac.RansacParameters(); p.error_thresh = thresh; p.seed = 60; p.failure_probability = 0.001
+        p.use_lo = True; p.lo_start_iterations = 5; p.min_iterations = 30
+        res = ransac.estimate_batch(est, g[f"lo_{kind}_data"], g[f"lo_{kind}_offsets"], p, np.array([1.0, 1e9]) if est == 9 else None)
+        assert np.array_equal(res["num_iterations"], g[f"lo_{kind}_iters"]) and np.array_equal(res["num_lo_iterations"], g[f"lo_{kind}_nlo"])
+        off = g[f"lo_{kind}_offsets"]
+        for i in range(2):
+            assert np.array_equal(res["inlier_mask"][off[i]:off[i + 1]], g[f"lo_{kind}_masks"][i])
+            ref = g[f"lo_{kind}_models"][i]
+            assert np.abs(res["models"][i][:mlen] - ref).max() <= 1e-7 * max(1.0, np.abs(ref).max())
