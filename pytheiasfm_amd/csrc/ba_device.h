@@ -363,9 +363,11 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
 }
 
 // Residual (and optionally Jacobians) of one observation.
+// `t` = rotation_terms(ext + 3): per-camera quantities, computed per observation by observe() or once per camera and
+// iteration by the callers that keep them in HBM (ba_fused.hip: k_cam_prep).
 template <bool WANT_JAC, bool WANT_KJAC = false, typename OL = ObsLin>
-THIP_DEV void observe(int model, const double* ext, const double* intr, const double X[4],
-                      double u0, double v0, double six, double siy, OL& o) {
+THIP_DEV void observe_rot(int model, const double* ext, const RotTerms& t, const double* intr, const double X[4],
+                          double u0, double v0, double six, double siy, OL& o) {
   const double p[3] = {X[0] - X[3] * ext[0], X[1] - X[3] * ext[1], X[2] - X[3] * ext[2]};
   const double sq = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
   if (sq < 1e-8) {  // reprojection_error.h:78-80 -> functor returns false
@@ -374,8 +376,6 @@ THIP_DEV void observe(int model, const double* ext, const double* intr, const do
     if constexpr (WANT_KJAC) { for (int i = 0; i < 2 * THEIA_MAX_INTRINSICS; ++i) o.Jk[i] = 0.0; }
     return;
   }
-  RotTerms t;
-  rotation_terms(ext + 3, t);
   const double q[3] = {t.R[0] * p[0] + t.R[1] * p[1] + t.R[2] * p[2],
                        t.R[3] * p[0] + t.R[4] * p[1] + t.R[5] * p[2],
                        t.R[6] * p[0] + t.R[7] * p[1] + t.R[8] * p[2]};
@@ -412,6 +412,35 @@ THIP_DEV void observe(int model, const double* ext, const double* intr, const do
       o.Jx[4 * a + 3] = -s[a] * (A0 * ext[0] + A1 * ext[1] + A2 * ext[2]);
     }
   }
+}
+
+template <bool WANT_JAC, bool WANT_KJAC = false, typename OL = ObsLin>
+THIP_DEV void observe(int model, const double* ext, const double* intr, const double X[4],
+                      double u0, double v0, double six, double siy, OL& o) {
+  RotTerms t;
+  rotation_terms(ext + 3, t);
+  observe_rot<WANT_JAC, WANT_KJAC, OL>(model, ext, t, intr, X, u0, v0, six, siy, o);
+}
+
+// Per-camera block kept in HBM by k_cam_prep: {position (3), angle-axis (3), R (9), A, B, cA, cB, small} = 20 doubles.
+constexpr int kCamRot = 20;
+THIP_DEV void camrot_store(const double* ext, double* o) {
+  RotTerms t;
+  rotation_terms(ext + 3, t);
+  for (int i = 0; i < 6; ++i) o[i] = ext[i];
+  for (int i = 0; i < 9; ++i) o[6 + i] = t.R[i];
+  o[15] = t.A; o[16] = t.B; o[17] = t.cA; o[18] = t.cB; o[19] = t.small ? 1.0 : 0.0;
+}
+THIP_DEV void camrot_load(const double* __restrict__ cr, double ext[6], RotTerms& t) {
+  const double2* c2 = reinterpret_cast<const double2*>(cr);   // 160-B blocks, 16-B aligned
+  double v[kCamRot];
+#pragma unroll
+  for (int i = 0; i < kCamRot / 2; ++i) { const double2 q = c2[i]; v[2 * i] = q.x; v[2 * i + 1] = q.y; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) ext[i] = v[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) t.R[i] = v[6 + i];
+  t.A = v[15]; t.B = v[16]; t.cA = v[17]; t.cB = v[18]; t.small = v[19] != 0.0;
 }
 
 // ceres/loss_function.cc + theia TruncatedLoss (loss_functions.cc:40-44).

@@ -5,6 +5,19 @@
 
 namespace thip {
 
+// One workgroup of the fused linearise + Schur kernel (ba_fused.hip): consecutive wave tiles whose tracks see at
+// most kFusedMaxCams variable cameras.  Sub-chunks of 4 tiles are linearised into LDS; the pair products
+// What_a What_b^T of every track are accumulated in registers by the lane that owns the target block (la, lb).
+struct FusedRun {
+  int tile0, ntiles;     // wave tiles of the run
+  int cam_off, W;        // local camera table: frun_cams[cam_off + lc] = reduced camera index (ascending)
+  int tgt_off, ntgt;     // target blocks: frun_tgt[tgt_off + k] = la | lb << 8 (lb <= la)
+  int part_off;          // doubles offset of the run's partial sums: [ntgt][36] then [W][6][9]
+  int G;                 // waves per track slice: 1, 2 or 4 (64 * G >= max(ntgt, 6 W))
+};
+constexpr int kFusedMaxCams = 22;        // -> at most 253 target blocks = one per thread
+constexpr int kFusedTileTracks = 32;     // tracks per wave tile (128 per sub-chunk)
+
 // Device-resident problem (SoA, observations sorted by point and packed into
 // wave tiles of <= 64 observations that never split a point).
 struct DevProblem {
@@ -60,6 +73,19 @@ struct DevProblem {
   const int* diag_items;       // [n_diag_items][4] {rc, first slot, end slot, atomic}
   const int* blk_items;        // [n_blk_items][5] {ri, rj, beg, end, atomic}
   const int2* blk_pairs;       // (slot of the obs of camera ri, slot of the obs of camera rj) of a common track
+  // fused linearise + Schur (ba_fused.hip), ni == 0: static plan built at create()
+  int n_fruns;
+  const FusedRun* fruns;
+  const int* frun_cams;
+  const unsigned short* frun_tgt;
+  const uint8_t* obs_lc;       // [nobs_main] local camera index inside the run, 0xFF = constant camera
+  const uint8_t* obs_tl;       // [nobs_main] track index inside the sub-chunk
+  const int* tile_trk_end;     // [ntiles] tracks of the sub-chunk up to and including this tile
+  double* fpart;               // per-run partial sums
+  double* camrot;              // [nc][kCamRot] per-camera rotation terms at the linearisation point (k_cam_prep)
+  int n_sum_items;
+  const int* sum_items;        // [n_sum_items][6] {ri, rj, tbeg, tend, dbeg, dend} into sum_src
+  const int* sum_src;          // offsets into fpart
   // camera priors in use (compact list): 3 residuals each on one camera's extrinsics
   int n_priors;
   const int* prior_cam;        // [n_priors] camera index
@@ -91,6 +117,9 @@ void launch_make_scale(int count, const double* colsq, double* scale, hipStream_
 void launch_linearize(const DevProblem& P, const double* cam, const double* pts, const double* radius /* device */,
                       const ReduceBuf& rb, double* Vinv, double* gp, double* tile_part,
                       hipStream_t st);
+// fused path: k_cam_prep + k_lin_schur + k_schur_sum (S blocks are WRITTEN, the buffer must be clear where nothing lands)
+void launch_linearize_fused(const DevProblem& P, const double* cam, const double* pts, const double* radius /* device */,
+                            const ReduceBuf& rb, double* Vinv, double* tile_part, hipStream_t st);
 void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,
                          const int* field_is_max, double* scal, hipStream_t st);
 // camera priors (ba_priors.h).  mode: PRIOR_COLNORM adds the squared column norms of their (unscaled) Jacobians

@@ -133,6 +133,14 @@ struct theia_ba_handle_s {
   int n_priors = 0;
   DevBuf<int2> blk_pairs;
   int n_diag_items = 0, n_blk_items = 0;
+  // fused linearise + Schur plan (ba_fused.hip)
+  bool use_fused = false;
+  DevBuf<FusedRun> fruns;
+  DevBuf<int> frun_cams, tile_trk_end, sum_items, sum_src;
+  DevBuf<unsigned short> frun_tgt;
+  DevBuf<uint8_t> obs_lc, obs_tl;
+  DevBuf<double> fpart, camrot, camrot_cand;
+  int n_fruns = 0, n_sum_items = 0;
   double* h_scal = nullptr;  // pinned: [scalA(16) | scalB(16)]
   char* h_state = nullptr;   // pinned: LmState read-back
   int cur = 0;
@@ -451,6 +459,9 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.n_priors = h->n_priors; P.prior_cam = h->prior_cam.p; P.prior_kind = h->prior_kind.p;
   P.prior_vec = h->prior_vec.p; P.prior_info = h->prior_info.p;
   P.rec = h->rec.p; P.n_diag_items = h->n_diag_items; P.n_blk_items = h->n_blk_items;
+  P.n_fruns = h->use_fused ? h->n_fruns : 0; P.fruns = h->fruns.p; P.frun_cams = h->frun_cams.p; P.frun_tgt = h->frun_tgt.p;
+  P.obs_lc = h->obs_lc.p; P.obs_tl = h->obs_tl.p; P.tile_trk_end = h->tile_trk_end.p; P.fpart = h->fpart.p; P.camrot = h->camrot.p;
+  P.n_sum_items = h->n_sum_items; P.sum_items = h->sum_items.p; P.sum_src = h->sum_src.p;
   P.diag_items = h->diag_items.p; P.rec_slot = h->cam_obs.p; P.slot_obs = h->slot_obs.p; P.slot_pt = h->slot_pt.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
 }
 
@@ -638,8 +649,9 @@ void theia_ba_options_default(theia_ba_options* o) {
 #define UP(buf, vec) do { rc = h->buf.upload(vec, st); if (rc) return rc; } while (0)
 #define AL(buf, cnt) do { rc = h->buf.alloc(cnt); if (rc) return rc; } while (0)
 // Static gather lists of the Schur assembly without intrinsics (k_lin_obs / k_schur); see create().
+// with_pairs = false (fused Schur assembly): only the per-camera observation lists the column-norm pass uses.
 int build_gather_lists(theia_ba_handle_s* h, const std::vector<int>& ocam, const std::vector<int>& opt,
-                       const std::vector<int>& l_obs) {
+                       const std::vector<int>& l_obs, bool with_pairs = true) {
   int rc = 0;
   hipStream_t st = h->stream;
   // Static gather lists of the Schur assembly (k_schur_diag / k_schur_blocks):
@@ -668,6 +680,14 @@ int build_gather_lists(theia_ba_handle_s* h, const std::vector<int>& ocam, const
       ditems.push_back(c); ditems.push_back(dbeg[c] + k * kChunk);
       ditems.push_back(std::min(dbeg[c + 1], dbeg[c] + (k + 1) * kChunk)); ditems.push_back(nchunk > 1 ? 1 : 0);
     }
+  }
+  if (!with_pairs) {
+    h->n_diag_items = (int)ditems.size() / 4; h->n_blk_items = 0;
+    std::vector<int> sobs(std::max(1, dbeg[h->ncv]), 0);
+    for (int64_t s2 = 0; s2 < nm; ++s2) if (cam_obs[s2] >= 0) sobs[cam_obs[s2]] = (int)s2;
+    UP(slot_obs, sobs);
+    UP(diag_items, ditems);
+    return 0;
   }
   // pairs, bucketed by row camera then sorted by column camera
   std::vector<int64_t> rbeg(h->ncv + 1, 0);
@@ -890,6 +910,158 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Plan of the fused linearise + Schur kernel (ba_fused.hip): wave tiles, runs, local camera tables, target
+// blocks, and the per-S-block lists of partial sums.  Replaces build_tiles() for the main tiles.
+//   off    : [np + 1] offsets of the tracks (by rank) into the sorted observation arrays
+//   sred   : [nobs_main] reduced camera index of a sorted observation (-1 = constant camera)
+//   skey   : [np] ordering key of a track rank (its first variable camera)
+// Tracks that do not fit the fused kernel (more than 64 observations, more than kFusedMaxCams variable cameras,
+// a camera seen twice) go to the per-observation slow path (k_long_*), like the > 64 ones before.
+struct FusedHost {
+  std::vector<FusedRun> runs;
+  std::vector<int> cams, tile_trk_end, sum_items, sum_src;
+  std::vector<unsigned short> tgts;
+  std::vector<uint8_t> obs_lc, obs_tl;
+  size_t part_doubles = 0;
+};
+void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& off, const std::vector<int>& porder,
+                      const std::vector<int>& sred, const std::vector<int>& skey, std::vector<int>& tstart,
+                      std::vector<int>& tcount, std::vector<int>& tkey, std::vector<int>& l_obs, std::vector<int>& l_slot,
+                      std::vector<int>& l_start, std::vector<int>& l_pt, FusedHost& fp) {
+  const int np = h->np;
+  const int64_t nm = h->nobs_main;
+  fp.obs_lc.assign((size_t)std::max<int64_t>(1, nm), 0xff);
+  fp.obs_tl.assign((size_t)std::max<int64_t>(1, nm), 0);
+  const char* rm = getenv("THEIA_HIP_FUSED_RUN_OBS");
+  const int64_t run_max = rm ? std::max(64, atoi(rm)) : std::max<int64_t>(256, std::min<int64_t>(4096, nm / 768));
+  // current tile / run
+  int64_t t_start = 0, t_len = 0;
+  int t_tracks = 0, sc_tracks = 0;
+  int run_tile0 = 0, run_ntiles = 0, run_key0 = -1;
+  int64_t run_obs = 0;
+  std::vector<int> run_cams;           // sorted, unique
+  std::vector<int64_t> run_pairs;      // sorted unique keys hi * 2^32 | lo of co-visible reduced cameras (hi >= lo)
+  std::vector<int> tc, uni;
+  std::vector<int64_t> tp, upairs;
+
+  auto close_tile = [&](int q_end) {
+    if (!t_len) return;
+    tstart.push_back((int)t_start); tcount.push_back((int)t_len); tkey.push_back(run_key0 < 0 ? 0 : run_key0);
+    (void)q_end;
+    fp.tile_trk_end.push_back(sc_tracks);
+    run_ntiles++;
+    t_len = 0; t_tracks = 0;
+  };
+  auto finalize_run = [&]() {
+    if (!run_ntiles) { run_cams.clear(); run_pairs.clear(); run_obs = 0; run_key0 = -1; return; }
+    FusedRun r;
+    r.tile0 = run_tile0; r.ntiles = run_ntiles;
+    r.cam_off = (int)fp.cams.size(); r.W = (int)run_cams.size();
+    fp.cams.insert(fp.cams.end(), run_cams.begin(), run_cams.end());
+    r.tgt_off = (int)fp.tgts.size(); r.ntgt = (int)run_pairs.size();
+    for (int64_t key : run_pairs) {   // ascending (hi, lo) -> ascending (la, lb)
+      const int hi = (int)(key >> 32), lo = (int)(key & 0xffffffff);
+      const int la = (int)(std::lower_bound(run_cams.begin(), run_cams.end(), hi) - run_cams.begin());
+      const int lb = (int)(std::lower_bound(run_cams.begin(), run_cams.end(), lo) - run_cams.begin());
+      fp.tgts.push_back((unsigned short)(la | (lb << 8)));
+    }
+    const int need = std::max(r.ntgt, 6 * r.W);
+    r.G = need <= 64 ? 1 : (need <= 128 ? 2 : 4);
+    r.part_off = (int)fp.part_doubles;
+    fp.part_doubles += (size_t)r.ntgt * 36 + (size_t)r.W * 54;
+    for (int t = run_tile0; t < run_tile0 + run_ntiles; ++t)
+      for (int s = tstart[t]; s < tstart[t] + tcount[t]; ++s)
+        if (sred[s] >= 0) fp.obs_lc[s] = (uint8_t)(std::lower_bound(run_cams.begin(), run_cams.end(), sred[s]) - run_cams.begin());
+    fp.runs.push_back(r);
+    run_tile0 += run_ntiles; run_ntiles = 0; run_obs = 0; run_key0 = -1;
+    run_cams.clear(); run_pairs.clear();
+  };
+  auto push_long = [&](int q) {
+    const int slot = (int)l_pt.size();
+    l_pt.push_back(porder[q]);
+    for (int64_t c = off[q]; c < off[q + 1]; ++c) { l_obs.push_back((int)c); l_slot.push_back(slot); }
+    l_start.push_back((int)l_obs.size());
+  };
+  run_tile0 = (int)tstart.size();
+  for (int q = 0; q < np; ++q) {
+    const int64_t L = off[q + 1] - off[q];
+    if (L == 0) continue;
+    // the track's variable cameras
+    tc.clear();
+    for (int64_t s = off[q]; s < off[q + 1]; ++s) if (sred[s] >= 0) tc.push_back(sred[s]);
+    std::sort(tc.begin(), tc.end());
+    const bool dup = std::adjacent_find(tc.begin(), tc.end()) != tc.end();
+    if (L > 64 || dup || (int)tc.size() > kFusedMaxCams) {
+      close_tile(q);            // tiles are contiguous observation ranges
+      push_long(q);
+      continue;
+    }
+    tp.clear();
+    for (size_t a = 0; a < tc.size(); ++a)
+      for (size_t b = 0; b <= a; ++b) tp.push_back(((int64_t)tc[a] << 32) | (uint32_t)tc[b]);
+    std::sort(tp.begin(), tp.end());
+    // would the run still fit?
+    uni.clear();
+    std::set_union(run_cams.begin(), run_cams.end(), tc.begin(), tc.end(), std::back_inserter(uni));
+    upairs.clear();
+    std::set_union(run_pairs.begin(), run_pairs.end(), tp.begin(), tp.end(), std::back_inserter(upairs));
+    bool new_run = (int)uni.size() > kFusedMaxCams || upairs.size() > 253;
+    if (!new_run && run_obs >= run_max / 4) {
+      // keep a run inside one slice geometry (<= 64 targets, <= 10 cameras) and inside one key when it is large enough
+      const bool small_now = run_pairs.size() <= 64 && run_cams.size() <= 10;
+      const bool small_after = upairs.size() <= 64 && uni.size() <= 10;
+      if ((small_now && !small_after) || skey[q] != run_key0) new_run = true;
+    }
+    if (new_run) {
+      close_tile(q);
+      finalize_run();
+      uni = tc; upairs = tp;
+    }
+    if (t_len + L > 64 || t_tracks >= kFusedTileTracks) {
+      close_tile(q);
+      if (run_ntiles % 4 == 0 && run_obs >= run_max) { finalize_run(); uni = tc; upairs = tp; }
+    }
+    if (t_len == 0) {
+      t_start = off[q];
+      if (run_ntiles % 4 == 0) sc_tracks = 0;
+      if (run_key0 < 0) run_key0 = skey[q];
+    }
+    for (int64_t s = off[q]; s < off[q + 1]; ++s) fp.obs_tl[s] = (uint8_t)sc_tracks;
+    sc_tracks++; t_tracks++; t_len += L; run_obs += L;
+    run_cams.swap(uni); run_pairs.swap(upairs);
+  }
+  close_tile(np);
+  finalize_run();
+  // per S block: the partial sums that feed it, in run order
+  struct Ent { int64_t key; int src; int isd; };
+  std::vector<Ent> ents;
+  for (const FusedRun& r : fp.runs) {
+    for (int k = 0; k < r.ntgt; ++k) {
+      const unsigned us = fp.tgts[r.tgt_off + k];
+      const int ri = fp.cams[r.cam_off + (us & 0xff)], rj = fp.cams[r.cam_off + (us >> 8)];
+      ents.push_back({((int64_t)ri << 32) | (uint32_t)rj, r.part_off + 36 * k, 0});
+    }
+    for (int lc = 0; lc < r.W; ++lc) {
+      const int ri = fp.cams[r.cam_off + lc];
+      ents.push_back({((int64_t)ri << 32) | (uint32_t)ri, r.part_off + 36 * r.ntgt + 54 * lc, 1});
+    }
+  }
+  std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key != b.key ? a.key < b.key : a.isd < b.isd; });
+  for (size_t q = 0; q < ents.size();) {
+    size_t e = q;
+    while (e < ents.size() && ents[e].key == ents[q].key) ++e;
+    size_t m = q;
+    while (m < e && !ents[m].isd) ++m;
+    fp.sum_items.push_back((int)(ents[q].key >> 32)); fp.sum_items.push_back((int)(ents[q].key & 0xffffffff));
+    fp.sum_items.push_back((int)q); fp.sum_items.push_back((int)m);
+    fp.sum_items.push_back((int)m); fp.sum_items.push_back((int)e);
+    q = e;
+  }
+  fp.sum_src.reserve(ents.size());
+  for (const Ent& en : ents) fp.sum_src.push_back(en.src);
+}
+
 #undef UP
 #undef AL
 int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_handle* out) {
@@ -1012,7 +1184,36 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     if (curlen) { tstart.push_back((int)(base + cur0)); tcount.push_back((int)curlen); tkey.push_back(curkey); }
     return 0;
   };
-  build_tiles(cnt_main, 0, true);
+  // Schur assembly without intrinsics: the fused kernel (ba_fused.hip) unless most of the problem would not fit it
+  // (tracks that see a camera twice -- e.g. depth-prior rows -- or more than kFusedMaxCams cameras take the
+  // per-observation slow path there); THEIA_HIP_SCHUR_GATHER=1 selects the first-generation gather kernels.
+  FusedHost fplan;
+  h->use_fused = h->ni == 0 && h->nobs_main > 0 && !getenv("THEIA_HIP_SCHUR_GATHER");
+  std::vector<int> sred;
+  if (h->use_fused) {
+    sred.resize(h->nobs_main);
+    for (int64_t s = 0; s < h->nobs_main; ++s) sred[s] = h->cam_red[p->obs_cam[h->perm[s]]];
+    int64_t misfit = 0;
+    std::vector<int> tc;
+    for (int q = 0; q < h->np; ++q) {
+      const int64_t L = cnt_main[q + 1] - cnt_main[q];
+      if (L < 2 || L > 64) continue;
+      tc.clear();
+      for (int64_t s = cnt_main[q]; s < cnt_main[q + 1]; ++s) if (sred[s] >= 0) tc.push_back(sred[s]);
+      std::sort(tc.begin(), tc.end());
+      if ((int)tc.size() > kFusedMaxCams || std::adjacent_find(tc.begin(), tc.end()) != tc.end()) misfit += L;
+    }
+    if (misfit * 20 > h->nobs_main) h->use_fused = false;
+  }
+  if (h->use_fused) {
+    std::vector<int> skey(h->np);
+    for (int q = 0; q < h->np; ++q) skey[q] = pkey[porder[q]];
+    build_fused_plan(h, cnt_main, porder, sred, skey, tstart, tcount, tkey, l_obs, l_slot, l_start, l_pt, fplan);
+    if (fplan.part_doubles > (size_t)std::numeric_limits<int>::max() / 2)
+      return set_error(THEIA_HIP_ERR_UNSUPPORTED, "partial-sum buffer of the fused Schur assembly exceeds 32-bit offsets");
+  } else {
+    build_tiles(cnt_main, 0, true);
+  }
   h->ntiles_main = (int)tstart.size();
   // evaluation-only tiles over the long tracks' observations (no per-track sums there)
   h->long_nobs = (int)l_obs.size(); h->long_ntracks = (int)l_pt.size();
@@ -1141,7 +1342,16 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     h->plan = chol_plan_create(h->n, h->tile_adj.data());
     tick("K3 plan");
   }
-  if (h->ni == 0 && h->ntiles_main > 0 && (rc = build_gather_lists(h, ocam, opt, l_obs))) return rc;
+  if (h->ni == 0 && h->ntiles_main > 0 && (rc = build_gather_lists(h, ocam, opt, l_obs, !h->use_fused))) return rc;
+  if (h->use_fused) {
+    h->n_fruns = (int)fplan.runs.size(); h->n_sum_items = (int)fplan.sum_items.size() / 6;
+    fplan.tile_trk_end.resize(std::max<size_t>(1, fplan.tile_trk_end.size()));
+    if (fplan.runs.empty()) fplan.runs.push_back(FusedRun{0, 0, 0, 0, 0, 0, 0, 1});
+    UP(fruns, fplan.runs); UP(frun_cams, fplan.cams); UP(frun_tgt, fplan.tgts); UP(obs_lc, fplan.obs_lc); UP(obs_tl, fplan.obs_tl);
+    UP(tile_trk_end, fplan.tile_trk_end); UP(sum_items, fplan.sum_items); UP(sum_src, fplan.sum_src);
+    AL(fpart, std::max<size_t>(1, fplan.part_doubles));
+    AL(camrot, (size_t)20 * std::max(1, h->nc)); AL(camrot_cand, (size_t)20 * std::max(1, h->nc));
+  }
   if (h->ni > 0 && h->ntiles_main > 0 && (rc = build_gather_lists_intr(h, p, ocam, opt))) return rc;
 #undef UP
 #undef AL

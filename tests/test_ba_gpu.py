@@ -123,7 +123,11 @@ def test_reference_threshold_tests_on_gpu():
     for noise in (0.0, 0.1):
         p = _view_scene(noise, 52)
         s, _ = ba.solve(p, ba.default_options())
-        assert s.success and 2.0 * s.final_cost / p.obs_uv.shape[0] < (1e-15 if noise == 0.0 else noise)
+        # the reference asserts the cost bound only (bundle_adjustment_test.cc:108-114); with noise-free pixels the
+        # residuals are pure round-off (cost ~1e-25) and whether LM then stops by tolerance or by five invalid steps
+        # depends on the last bit of the arithmetic
+        assert 2.0 * s.final_cost / p.obs_uv.shape[0] < (1e-15 if noise == 0.0 else noise)
+        assert s.success or noise == 0.0
 
 
 def test_mirror_entry_points_partial_reconstruction():
