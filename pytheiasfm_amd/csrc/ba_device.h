@@ -422,8 +422,11 @@ THIP_DEV void observe(int model, const double* ext, const double* intr, const do
   observe_rot<WANT_JAC, WANT_KJAC, OL>(model, ext, t, intr, X, u0, v0, six, siy, o);
 }
 
-// Per-camera block kept in HBM by k_cam_prep: {position (3), angle-axis (3), R (9), A, B, cA, cB, small} = 20 doubles.
-constexpr int kCamRot = 20;
+// Per-camera block kept in HBM by k_cam_prep, so that an observation needs ONE dependent gather for everything keyed
+// by its camera: {position (3), angle-axis (3), R (9), A, B, cA, cB, small | Jacobi scaling of the six extrinsics
+// columns (0 = frozen column) | intrinsics of the camera's group (10) | model, reduced index, pad (2)} = 40 doubles.
+constexpr int kCamRot = 40;
+constexpr int kCamRotScale = 20, kCamRotIntr = 26, kCamRotModel = 36, kCamRotRed = 37;
 THIP_DEV void camrot_store(const double* ext, double* o) {
   RotTerms t;
   rotation_terms(ext + 3, t);
@@ -431,11 +434,15 @@ THIP_DEV void camrot_store(const double* ext, double* o) {
   for (int i = 0; i < 9; ++i) o[6 + i] = t.R[i];
   o[15] = t.A; o[16] = t.B; o[17] = t.cA; o[18] = t.cB; o[19] = t.small ? 1.0 : 0.0;
 }
-THIP_DEV void camrot_load(const double* __restrict__ cr, double ext[6], RotTerms& t) {
-  const double2* c2 = reinterpret_cast<const double2*>(cr);   // 160-B blocks, 16-B aligned
-  double v[kCamRot];
+template <int N>
+THIP_DEV void load_d2(const double* __restrict__ src, double (&v)[N]) {   // 16-B aligned source, N even
+  const double2* c2 = reinterpret_cast<const double2*>(src);
 #pragma unroll
-  for (int i = 0; i < kCamRot / 2; ++i) { const double2 q = c2[i]; v[2 * i] = q.x; v[2 * i + 1] = q.y; }
+  for (int i = 0; i < N / 2; ++i) { const double2 q = c2[i]; v[2 * i] = q.x; v[2 * i + 1] = q.y; }
+}
+THIP_DEV void camrot_load(const double* __restrict__ cr, double ext[6], RotTerms& t) {
+  double v[20];
+  load_d2<20>(cr, v);
 #pragma unroll
   for (int i = 0; i < 6; ++i) ext[i] = v[i];
 #pragma unroll

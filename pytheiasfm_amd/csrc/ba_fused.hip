@@ -32,60 +32,68 @@
 namespace thip {
 namespace {
 
-constexpr int kSub = 4 * kWave;                       // observations per sub-chunk
-constexpr int kSubTracks = 4 * kFusedTileTracks;      // 128
 constexpr int kRowBytes = 24;                         // slot-table row: kFusedMaxCams rounded up to 8
-constexpr int kAux = 14;                              // F (12) | r (2)
 static_assert(kFusedMaxCams <= kRowBytes, "slot-table row too short");
 
-__global__ __launch_bounds__(256) void k_cam_prep(int nc, const double* __restrict__ cam, double* __restrict__ camrot) {
+__global__ __launch_bounds__(256) void k_cam_prep(DevProblem P, const double* __restrict__ cam, const double* __restrict__ intr,
+                                                  double* __restrict__ camrot) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < nc) camrot_store(cam + 6 * (size_t)c, camrot + (size_t)kCamRot * c);
+  if (c >= P.nc) return;
+  double* o = camrot + (size_t)kCamRot * c;
+  camrot_store(cam + 6 * (size_t)c, o);
+  const unsigned mask = P.cam_mask[c];
+  for (int q = 0; q < 6; ++q) o[kCamRotScale + q] = ((mask >> q) & 1u) ? 0.0 : P.scale_c[6 * c + q];
+  const int g = P.cam_group[c];
+  for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) o[kCamRotIntr + q] = intr[(size_t)g * THEIA_MAX_INTRINSICS + q];
+  o[kCamRotModel] = (double)P.group_model[g];
+  o[kCamRotRed] = (double)P.cam_red[c];
+  o[38] = 0.0; o[39] = 0.0;
 }
 
-// tile_part layout as k_lin_obs: [ntiles][4] = {cost, gmax_points, invalid, notpd}
-template <int PD>
-__global__ __launch_bounds__(256, 2) void k_lin_schur(DevProblem P, const double* __restrict__ pts,
-                                                      const double* __restrict__ radius_p, double* __restrict__ Vinv,
-                                                      double* __restrict__ tile_part) {
+// Track-local OR of one int per lane (log-step, as segment_allsum_log); every lane of the track gets the result.
+THIP_DEV unsigned segment_or(const Segment& s, int lane, unsigned v) {
+  const int pos = lane - s.start;
+  for (int d = 1; d < s.maxlen; d <<= 1) {
+    const unsigned o = (unsigned)__shfl_down((int)v, d, kWave);
+    if (pos + d < s.len) v |= o;
+  }
+  return (unsigned)__shfl((int)v, s.start, kWave);
+}
+
+// LDS record of one observation: {F (2 x 6) | Ehat = E Li^T (2 x PD) | r (2)}, padded to an odd number of 16-B pieces
+// (lanes reading consecutive records then fall on distinct bank groups).  What = F^T Ehat is never formed: the block
+// product is  What_a What_b^T = F_a^T (Ehat_a Ehat_b^T) F_b  -- a 2 x 2 core between the two camera Jacobians,
+// the same 108 FMAs (PD = 3) from 20 stored doubles instead of 32.
+#ifndef THIP_FUSED_WAVES
+#define THIP_FUSED_WAVES 2   // workgroups per CU the register allocation aims at (LDS allows 3)
+#endif
+#ifdef THIP_PHASE_L_CALL
+#define THIP_PHASE_L_ATTR __attribute__((noinline))
+#else
+#define THIP_PHASE_L_ATTR __forceinline__
+#endif
+template <int PD> constexpr int rec_doubles() { return PD == 3 ? 22 : 26; }
+
+// Phase L of one sub-chunk (lane = observation): linearise, reduce V_p / g_p over the track, invert, leave the record
+// {F | Ehat | r} and the track's slot-table row in LDS.  NOT inlined on purpose: the caller keeps 45 FP64 accumulators
+// alive across this phase; as a call they are saved once around it (callee-saved registers) instead of pushing the
+// register allocation of the pair-product loop into scratch.
+template <int PD, int TPS>
+__device__ THIP_PHASE_L_ATTR void fused_phase_l(const DevProblem* __restrict__ Pp, const FusedRun* __restrict__ runp,
+                                                        const double* __restrict__ pts, double inv_radius, int sc,
+                                                        double* __restrict__ Vinv, double* __restrict__ tile_part,
+                                                        double* __restrict__ s_rec, double* __restrict__ s_ghat,
+                                                        uint8_t* __restrict__ s_tslot, unsigned* __restrict__ s_tmask) {
   constexpr int NT = PD * (PD + 1) / 2;
-  constexpr int NW = 6 * PD;
-  __shared__ __attribute__((aligned(16))) double s_what[kSub * NW];
-  __shared__ __attribute__((aligned(16))) double s_aux[kSub * kAux];
-  __shared__ double s_ghat[kSubTracks * PD];
-  __shared__ uint8_t s_tslot[kSubTracks * kRowBytes];   // (track, local camera) -> record slot, valid where the mask bit is set
-  __shared__ unsigned s_tmask[2][kSubTracks];            // local cameras of a track (double buffered: cleared one sub-chunk ahead)
-
-  const FusedRun run = P.fruns[blockIdx.x];
-  const double radius = *radius_p;
+  constexpr int RD = rec_doubles<PD>();
+  const DevProblem& P = *Pp;
+  const FusedRun& run = *runp;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // phase-S role of this lane
-  const int G = run.G, S = 4 / G;
-  const int slice = wv / G, tix = (wv % G) * 64 + lane;
-  const bool has_tgt = tix < run.ntgt;
-  int la = 0, lb = 0;
-  if (has_tgt) { const unsigned us = P.frun_tgt[run.tgt_off + tix]; la = us & 0xffu; lb = us >> 8; }
-  const bool has_d = tix < 6 * run.W;
-  const int dlc = has_d ? tix / 6 : 0, da = tix % 6;
-  double acc[36], dacc[9];
-#pragma unroll
-  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) dacc[k] = 0.0;
-
-  if (tid < kSubTracks) s_tmask[0][tid] = 0u;
-  __syncthreads();
-
-  const int nsc = (run.ntiles + 3) >> 2;
-  for (int sc = 0; sc < nsc; ++sc) {
-    const int buf = sc & 1;
-    // ------------------------------------------------------------------ phase L: lane = observation
-    {
-      const int tile = run.tile0 + 4 * sc + wv;
+      const int tile = run.tile0 + TPS * sc + wv;
       const bool tile_ok = tile < run.tile0 + run.ntiles;
       const int cnt = tile_ok ? P.tile_count[tile] : 0;
       const int start = tile_ok ? P.tile_start[tile] : 0;
-      const bool active = lane < cnt;
+      const bool active = lane < cnt && !(P.fused_dbg & 2);
       LaneLin<PD> L;
       lane_linearize<PD, true, false, true>(P, P.camrot, pts, start + lane, active, lane, L);
       const Segment sg = lane_segment(L.p, lane);
@@ -97,11 +105,15 @@ __global__ __launch_bounds__(256, 2) void k_lin_schur(DevProblem P, const double
         tot[NT + a] = L.Jt[a] * L.r[0] + L.Jt[PD + a] * L.r[1];
       }
       segment_allsum_log<NT + PD>(sg, lane, tot);
+      const int o = start + lane;
+      const int tl = active ? P.obs_tl[o] : 0;
+      const unsigned lc = active ? P.obs_lc[o] : 0xffu;
+      const unsigned tmask = segment_or(sg, lane, (active && lc != 0xffu) ? (1u << lc) : 0u);
       double V[NT], Vi[NT], g[PD];
 #pragma unroll
       for (int q = 0; q < NT; ++q) V[q] = tot[q];
 #pragma unroll
-      for (int a = 0; a < PD; ++a) { g[a] = tot[NT + a]; V[lidx(a, a)] += fmin(fmax(V[lidx(a, a)], 1e-6), 1e32) / radius; }
+      for (int a = 0; a < PD; ++a) { g[a] = tot[NT + a]; V[lidx(a, a)] += fmin(fmax(V[lidx(a, a)], 1e-6), 1e32) * inv_radius; }
       bool pd_ok = true;
       double Li[PD][PD];
 #pragma unroll
@@ -118,20 +130,15 @@ __global__ __launch_bounds__(256, 2) void k_lin_schur(DevProblem P, const double
           for (int b = 0; b < PD; ++b) Li[a][b] = 0.0;
       }
       double gmax = 0.0;
-      const int o = start + lane;
-      const int tl = active ? P.obs_tl[o] : 0;
-      const unsigned lc = active ? P.obs_lc[o] : 0xffu;
       if (active && sg.head) {
-        double gh[PD];
 #pragma unroll
         for (int a = 0; a < PD; ++a) {   // ghat = Li g
           double s = 0.0;
 #pragma unroll
           for (int q = 0; q <= a; ++q) s += Li[a][q] * g[q];
-          gh[a] = s;
+          s_ghat[tl * PD + a] = s;
         }
-#pragma unroll
-        for (int a = 0; a < PD; ++a) s_ghat[tl * PD + a] = gh[a];
+        s_tmask[tl] = tmask;
         if (!L.pconst) {
 #pragma unroll
           for (int q = 0; q < NT; ++q) Vinv[(size_t)NT * L.p + q] = Vi[q];
@@ -141,29 +148,23 @@ __global__ __launch_bounds__(256, 2) void k_lin_schur(DevProblem P, const double
       }
       if (active && lc != 0xffu) {
         const int slot = wv * 64 + lane;
-        double w0[NW], w[NW];
+        double eh[2 * PD];   // Ehat = E Li^T
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-          for (int b = 0; b < PD; ++b) w0[a * PD + b] = L.Jc[a] * L.Jt[b] + L.Jc[6 + a] * L.Jt[PD + b];
-#pragma unroll
-        for (int a = 0; a < 6; ++a)   // What = W Li^T
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int b = 0; b < PD; ++b) {
             double s = 0.0;
 #pragma unroll
-            for (int q = 0; q <= b; ++q) s += w0[a * PD + q] * Li[b][q];
-            w[a * PD + b] = s;
+            for (int q = 0; q <= b; ++q) s += L.Jt[i * PD + q] * Li[b][q];
+            eh[i * PD + b] = s;
           }
-        double2* R = reinterpret_cast<double2*>(s_what + slot * NW);
+        double2* R = reinterpret_cast<double2*>(s_rec + slot * RD);
 #pragma unroll
-        for (int q = 0; q < NW / 2; ++q) R[q] = make_double2(w[2 * q], w[2 * q + 1]);
-        double2* A2 = reinterpret_cast<double2*>(s_aux + slot * kAux);
+        for (int q = 0; q < 6; ++q) R[q] = make_double2(L.Jc[2 * q], L.Jc[2 * q + 1]);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) A2[q] = make_double2(L.Jc[2 * q], L.Jc[2 * q + 1]);
-        A2[6] = make_double2(L.r[0], L.r[1]);
+        for (int q = 0; q < PD; ++q) R[6 + q] = make_double2(eh[2 * q], eh[2 * q + 1]);
+        R[6 + PD] = make_double2(L.r[0], L.r[1]);
         s_tslot[tl * kRowBytes + lc] = (uint8_t)slot;
-        atomicOr(&s_tmask[buf][tl], 1u << lc);
       }
       const double cost = wave_sum(L.cost);
       gmax = wave_max(gmax);
@@ -175,91 +176,177 @@ __global__ __launch_bounds__(256, 2) void k_lin_schur(DevProblem P, const double
         tile_part[4 * (size_t)tile + 2] = inval;
         tile_part[4 * (size_t)tile + 3] = npd;
       }
-    }
+}
+
+// tile_part layout as k_lin_obs: [ntiles][4] = {cost, gmax_points, invalid, notpd}
+template <int PD, int TPS>
+__global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevProblem P, const double* __restrict__ pts,
+                                                           const double* __restrict__ radius_p,
+                                                           double* __restrict__ Vinv, double* __restrict__ tile_part) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  constexpr int RD = rec_doubles<PD>();
+  constexpr int OE = 12, OR = 12 + 2 * PD;           // offsets of Ehat and r inside a record
+  constexpr int SUB = TPS * kWave;                    // observations per sub-chunk
+  constexpr int SUBT = TPS * kFusedTileTracks;        // tracks per sub-chunk
+  constexpr int NWV = TPS;                            // waves of the workgroup
+  __shared__ __attribute__((aligned(16))) double s_rec[SUB * RD];
+  __shared__ double s_ghat[SUBT * PD];
+  __shared__ uint8_t s_tslot[SUBT * kRowBytes];   // (track, local camera) -> record slot, valid where the mask bit is set
+  __shared__ unsigned s_tmask[SUBT];              // local cameras of a track
+  static_assert(SUB * 18 <= SUB * RD, "slice-combination scratch does not fit the record buffer");
+
+  __shared__ DevProblem s_P;     // phase L is a real call: it reads the problem through these LDS copies
+  __shared__ FusedRun s_run;
+  const FusedRun run = P.fruns[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) { s_P = P; s_run = run; }
+  const int nsc = (run.ntiles + TPS - 1) / TPS;
+  const double radius = *radius_p;
+  const double inv_radius = 1.0 / radius;
+  __syncthreads();
+
+  // ---- phase-S role: which target block / per-camera row this lane owns, which tracks it walks
+  const int G = run.gp & 0xff, PS = run.gp >> 8; // waves per slice (1, 2, 4) / slices per wave (>= 1, only with G == 1)
+  int tix, t0, tstride;
+  bool slice_ok = true;
+  const int B = 64 / PS;
+  if (G == 1) { const int g = lane / B; tix = lane - g * B; slice_ok = g < PS; t0 = wv * PS + g; tstride = NWV * PS; }
+  else { tix = (wv % G) * 64 + lane; t0 = wv / G; tstride = NWV / G; }
+  const bool has_tgt = slice_ok && tix < run.ntgt;
+  int la = 0, lb = 0;
+  if (has_tgt) { const unsigned us = P.frun_tgt[run.tgt_off + tix]; la = us & 0xffu; lb = us >> 8; }
+  const int dix = (G == 1) ? lane : tix;         // per-camera rows: lanes of the wave (G == 1) / of the wave group
+  const bool has_d = dix < 6 * run.W;
+  const int dlc = has_d ? dix / 6 : 0, da = dix % 6;
+  const int dP = (G == 1) ? PS : 1, dbase = (G == 1) ? wv * PS : wv / G;
+  const unsigned tbits = has_tgt ? ((1u << la) | (1u << lb)) : 0xffffffffu;   // no target: never a subset (bit 31 unused)
+  const unsigned dbit = has_d ? (1u << dlc) : 0x80000000u;
+  double acc[36], dacc[9];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dacc[k] = 0.0;
+
+  for (int sc = 0; sc < nsc; ++sc) {
+    // ------------------------------------------------------------------ phase L: lane = observation
+    fused_phase_l<PD, TPS>(&s_P, &s_run, pts, inv_radius, sc, Vinv, tile_part, s_rec, s_ghat, s_tslot, s_tmask);
     __syncthreads();
     // ------------------------------------------------------------------ phase S: lane = target block
-    {
-      // the other slot table is free now: clear it for the next sub-chunk
-      if (tid < kSubTracks) s_tmask[buf ^ 1][tid] = 0u;
-      const int last_tile = min(run.tile0 + 4 * sc + 3, run.tile0 + run.ntiles - 1);
+    if (!(P.fused_dbg & 1)) {
+      const int last_tile = min(run.tile0 + TPS * sc + TPS - 1, run.tile0 + run.ntiles - 1);
       const int ntr = P.tile_trk_end[last_tile];
-      const unsigned tbits = has_tgt ? ((1u << la) | (1u << lb)) : 0xffffffffu;   // no target: never a subset (bit 31 unused)
-      const unsigned dbit = has_d ? (1u << dlc) : 0x80000000u;
-      for (int t = slice; t < ntr; t += S) {
-        const uint8_t* row = s_tslot + t * kRowBytes;
-        const unsigned mask = s_tmask[buf][t];
-        const unsigned sa = row[la], sb = row[lb], sd = row[dlc];
-        if ((mask & tbits) == tbits) {
-          double A[NW], B[NW];
-          const double2* pa = reinterpret_cast<const double2*>(s_what + sa * NW);
-          const double2* pb = reinterpret_cast<const double2*>(s_what + sb * NW);
+#pragma unroll 1
+      for (int base = 0; base < ntr; base += tstride) {   // wave-uniform trip count
+        // pair products: lane = target block (la, lb) of the track slice it serves
+        {
+          const int t = base + t0;
+          const unsigned mask = (slice_ok && t < ntr) ? s_tmask[t] : 0u;
+          if ((mask & tbits) == tbits) {
+            const unsigned ca = s_tslot[t * kRowBytes + la], cb = s_tslot[t * kRowBytes + lb];
+            double Fa[12], Ea[2 * PD], Fb[12], Eb[2 * PD];
+            const double2* pa = reinterpret_cast<const double2*>(s_rec + ca * RD);
+            const double2* pb = reinterpret_cast<const double2*>(s_rec + cb * RD);
 #pragma unroll
-          for (int q = 0; q < NW / 2; ++q) { const double2 u = pa[q]; A[2 * q] = u.x; A[2 * q + 1] = u.y; }
+            for (int q = 0; q < 6; ++q) { const double2 u = pa[q]; Fa[2 * q] = u.x; Fa[2 * q + 1] = u.y; }
 #pragma unroll
-          for (int q = 0; q < NW / 2; ++q) { const double2 u = pb[q]; B[2 * q] = u.x; B[2 * q + 1] = u.y; }
+            for (int q = 0; q < PD; ++q) { const double2 u = pa[6 + q]; Ea[2 * q] = u.x; Ea[2 * q + 1] = u.y; }
 #pragma unroll
-          for (int a = 0; a < 6; ++a)
+            for (int q = 0; q < 6; ++q) { const double2 u = pb[q]; Fb[2 * q] = u.x; Fb[2 * q + 1] = u.y; }
 #pragma unroll
-            for (int b = 0; b < 6; ++b) {
-              double s = acc[a * 6 + b];
+            for (int q = 0; q < PD; ++q) { const double2 u = pb[6 + q]; Eb[2 * q] = u.x; Eb[2 * q + 1] = u.y; }
+            double M[2][2];   // Ehat_a Ehat_b^T
 #pragma unroll
-              for (int q = 0; q < PD; ++q) s += A[a * PD + q] * B[b * PD + q];
-              acc[a * 6 + b] = s;
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                double sm = 0.0;
+#pragma unroll
+                for (int q = 0; q < PD; ++q) sm += Ea[i * PD + q] * Eb[j * PD + q];
+                M[i][j] = sm;
+              }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+              const double t0v = Fa[a] * M[0][0] + Fa[6 + a] * M[1][0];   // (F_a^T M)[a][0..1]
+              const double t1v = Fa[a] * M[0][1] + Fa[6 + a] * M[1][1];
+#pragma unroll
+              for (int b2 = 0; b2 < 6; ++b2) acc[a * 6 + b2] += t0v * Fb[b2] + t1v * Fb[6 + b2];
             }
+          }
         }
-        if (mask & dbit) {
-          double F[12], r2[2];
-          const double2* px = reinterpret_cast<const double2*>(s_aux + sd * kAux);
+        // per-observation terms: lane = (local camera, row), over the dP tracks this wave serves in the step
+#pragma unroll 1
+        for (int g2 = 0; g2 < dP; ++g2) {
+          const int t = base + dbase + g2;
+          const unsigned mask = (t < ntr) ? s_tmask[t] : 0u;
+          if (mask & dbit) {
+            const unsigned sd = s_tslot[t * kRowBytes + dlc];
+            double F[12], E[2 * PD], r2[2];
+            const double2* px = reinterpret_cast<const double2*>(s_rec + sd * RD);
 #pragma unroll
-          for (int q = 0; q < 6; ++q) { const double2 u = px[q]; F[2 * q] = u.x; F[2 * q + 1] = u.y; }
-          { const double2 u = px[6]; r2[0] = u.x; r2[1] = u.y; }
-          double fa0 = 0.0, fa1 = 0.0;   // F[da], F[6 + da] without dynamic register indexing
+            for (int q = 0; q < 6; ++q) { const double2 u = px[q]; F[2 * q] = u.x; F[2 * q + 1] = u.y; }
 #pragma unroll
-          for (int q = 0; q < 6; ++q) { if (q == da) { fa0 = F[q]; fa1 = F[6 + q]; } }
+            for (int q = 0; q < PD; ++q) { const double2 u = px[6 + q]; E[2 * q] = u.x; E[2 * q + 1] = u.y; }
+            { const double2 u = px[6 + PD]; r2[0] = u.x; r2[1] = u.y; }
+            double fa0 = 0.0, fa1 = 0.0;   // F[da], F[6 + da] without dynamic register indexing
 #pragma unroll
-          for (int q = 0; q < 6; ++q) dacc[q] += fa0 * F[q] + fa1 * F[6 + q];
-          const double jr = fa0 * r2[0] + fa1 * r2[1];
-          double wg = 0.0;
+            for (int q = 0; q < 6; ++q) { if (q == da) { fa0 = F[q]; fa1 = F[6 + q]; } }
 #pragma unroll
-          for (int q = 0; q < PD; ++q) wg += s_what[sd * NW + da * PD + q] * s_ghat[t * PD + q];
-          dacc[6] += jr - wg;
-          dacc[7] += jr;
-          dacc[8] += fa0 * fa0 + fa1 * fa1;
+            for (int q = 0; q < 6; ++q) dacc[q] += fa0 * F[q] + fa1 * F[6 + q];
+            double eg0 = 0.0, eg1 = 0.0;   // What ghat = F^T (Ehat ghat)
+#pragma unroll
+            for (int q = 0; q < PD; ++q) { const double gq = s_ghat[t * PD + q]; eg0 += E[q] * gq; eg1 += E[PD + q] * gq; }
+            const double jr = fa0 * r2[0] + fa1 * r2[1];
+            dacc[6] += jr - (fa0 * eg0 + fa1 * eg1);
+            dacc[7] += jr;
+            dacc[8] += fa0 * fa0 + fa1 * fa1;
+          }
         }
       }
     }
     __syncthreads();
   }
   // ---------------------------------------------------------------- combine the track slices, fixed order
-  double* scratch = s_what;   // 256 x 18 doubles
+  double* scratch = s_rec;   // SUB x 18 doubles
   double* out = P.fpart + run.part_off;
+  const int nrep = (G == 1) ? NWV * PS : NWV / G;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < 2; ++h) {   // fully unrolled: acc[] must only ever see constant indices (else it lives in scratch)
     if (h) __syncthreads();
 #pragma unroll
     for (int q = 0; q < 18; ++q) scratch[tid * 18 + q] = acc[18 * h + q];
     __syncthreads();
-    if (slice == 0 && has_tgt) {
+    if (has_tgt && tid == tix) {   // the first replica of the target adds the others, in slice order
+      double v[18];
 #pragma unroll
-      for (int q = 0; q < 18; ++q) {
-        double v = scratch[tid * 18 + q];
-        for (int s = 1; s < S; ++s) v += scratch[(tid + s * G * 64) * 18 + q];
-        out[(size_t)tix * 36 + 18 * h + q] = v;
+      for (int q = 0; q < 18; ++q) v[q] = scratch[tid * 18 + q];
+#pragma unroll 1
+      for (int r = 1; r < nrep; ++r) {
+        const int oth = (G == 1) ? ((r / PS) * 64 + (r % PS) * B + tix) : (tix + r * G * 64);
+#pragma unroll
+        for (int q = 0; q < 18; ++q) v[q] += scratch[oth * 18 + q];
       }
+#pragma unroll
+      for (int q = 0; q < 18; ++q) out[(size_t)tix * 36 + 18 * h + q] = v[q];
     }
   }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 9; ++q) scratch[tid * 9 + q] = dacc[q];
   __syncthreads();
-  if (slice == 0 && has_d) {
-    double* od = out + (size_t)run.ntgt * 36 + (size_t)tix * 9;
+  if (has_d && tid == dix) {
+    const int nrd = (G == 1) ? NWV : NWV / G;
+    double v[9];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
-      double v = scratch[tid * 9 + q];
-      for (int s = 1; s < S; ++s) v += scratch[(tid + s * G * 64) * 9 + q];
-      od[q] = v;
+    for (int q = 0; q < 9; ++q) v[q] = scratch[tid * 9 + q];
+#pragma unroll 1
+    for (int r = 1; r < nrd; ++r) {
+      const int oth = (G == 1) ? (r * 64 + dix) : (dix + r * G * 64);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) v[q] += scratch[oth * 9 + q];
     }
+    double* od = out + (size_t)run.ntgt * 36 + (size_t)dix * 9;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) od[q] = v[q];
   }
 }
 
@@ -300,12 +387,16 @@ __global__ __launch_bounds__(256) void k_schur_sum(int nitems, const int* __rest
 
 }  // namespace
 
+void launch_cam_prep(const DevProblem& P, const double* cam, const double* intr, double* camrot, hipStream_t st) {
+  if (P.nc > 0) k_cam_prep<<<(P.nc + 255) / 256, 256, 0, st>>>(P, cam, intr, camrot);
+}
+
 void launch_linearize_fused(const DevProblem& P, const double* cam, const double* pts, const double* radius,
                             const ReduceBuf& rb, double* Vinv, double* tile_part, hipStream_t st) {
   if (P.n_fruns == 0) return;
-  k_cam_prep<<<(P.nc + 255) / 256, 256, 0, st>>>(P.nc, cam, P.camrot);
-  if (P.pd == 3) k_lin_schur<3><<<P.n_fruns, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
-  else k_lin_schur<4><<<P.n_fruns, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
+  launch_cam_prep(P, cam, P.intr, P.camrot, st);
+  if (P.pd == 3) k_lin_schur<3, 4><<<P.n_fruns, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
+  else k_lin_schur<4, 4><<<P.n_fruns, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
   if (P.n_sum_items)
     k_schur_sum<<<(P.n_sum_items + 3) / 4, 256, 0, st>>>(P.n_sum_items, P.sum_items, P.sum_src, P.fpart, rb.S, P.n, rb.rhs,
                                                          rb.gc, rb.colsq);

@@ -13,8 +13,10 @@ struct FusedRun {
   int cam_off, W;        // local camera table: frun_cams[cam_off + lc] = reduced camera index (ascending)
   int tgt_off, ntgt;     // target blocks: frun_tgt[tgt_off + k] = la | lb << 8 (lb <= la)
   int part_off;          // doubles offset of the run's partial sums: [ntgt][36] then [W][6][9]
-  int G;                 // waves per track slice: 1, 2 or 4 (64 * G >= max(ntgt, 6 W))
+  int gp;                // G | PS << 8.  G = consumer waves per track slice: 1, 2 or 4 (64 G >= max(ntgt, 6 W));
+                         // PS = track slices per consumer wave (only with G == 1): floor(64 / PS) >= ntgt, 6 W <= 64
 };
+inline int fused_tiles_per_subchunk(int) { return 4; }   // one wave per tile, 256-thread workgroups
 constexpr int kFusedMaxCams = 22;        // -> at most 253 target blocks = one per thread
 constexpr int kFusedTileTracks = 32;     // tracks per wave tile (128 per sub-chunk)
 
@@ -82,7 +84,9 @@ struct DevProblem {
   const uint8_t* obs_tl;       // [nobs_main] track index inside the sub-chunk
   const int* tile_trk_end;     // [ntiles] tracks of the sub-chunk up to and including this tile
   double* fpart;               // per-run partial sums
-  double* camrot;              // [nc][kCamRot] per-camera rotation terms at the linearisation point (k_cam_prep)
+  double* camrot;              // [nc][kCamRot] per-camera blocks at the linearisation point (k_cam_prep), null = not in use
+  double* camrot_cand;         // the same for the candidate cameras of the trial step (back-substitution)
+  int fused_dbg;               // development switches (THEIA_HIP_FUSED_DBG): 1 = skip phase S, 2 = skip phase L arithmetic
   int n_sum_items;
   const int* sum_items;        // [n_sum_items][6] {ri, rj, tbeg, tend, dbeg, dend} into sum_src
   const int* sum_src;          // offsets into fpart
@@ -120,6 +124,8 @@ void launch_linearize(const DevProblem& P, const double* cam, const double* pts,
 // fused path: k_cam_prep + k_lin_schur + k_schur_sum (S blocks are WRITTEN, the buffer must be clear where nothing lands)
 void launch_linearize_fused(const DevProblem& P, const double* cam, const double* pts, const double* radius /* device */,
                             const ReduceBuf& rb, double* Vinv, double* tile_part, hipStream_t st);
+// per-camera blocks (rotation terms, masked scaling, intrinsics) of `cam` -> camrot (ba_fused.hip)
+void launch_cam_prep(const DevProblem& P, const double* cam, const double* intr, double* camrot, hipStream_t st);
 void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,
                          const int* field_is_max, double* scal, hipStream_t st);
 // camera priors (ba_priors.h).  mode: PRIOR_COLNORM adds the squared column norms of their (unscaled) Jacobians

@@ -863,7 +863,9 @@ __global__ void k_cam_update(DevProblem P, const double* __restrict__ cam, const
 
 // ------------------------------- back-substitution + candidate + trial cost
 // tile_part: [ntiles][5] = {cand_cost, mcc, stepsq, xnormsq, invalid}
-template <int PD, bool INTR>
+// ROT: the per-camera blocks of k_cam_prep (P.camrot for the state, P.camrot_cand for the candidate cameras) replace
+// the per-observation sincos and the chained camera -> group -> intrinsics gathers.
+template <int PD, bool INTR, bool ROT = false>
 __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* __restrict__ cam,
                                                     const double* __restrict__ pts,
                                                     const double* __restrict__ cand_cam,
@@ -878,7 +880,8 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
   const int cnt = tile_ok ? P.tile_count[tile] : 0;
   const int start = tile_ok ? P.tile_start[tile] : 0;
   LaneLin<PD, INTR> L;
-  lane_linearize<PD, true, INTR>(P, cam, pts, start + lane, lane < cnt, lane, L);
+  if constexpr (ROT) lane_linearize<PD, true, INTR, true>(P, P.camrot, pts, start + lane, lane < cnt, lane, L);
+  else lane_linearize<PD, true, INTR>(P, cam, pts, start + lane, lane < cnt, lane, L);
   const Segment sg = lane_segment(L.p, lane);
   // m_c = F y_c   (yc points at the camera part; the intrinsics part sits ni before it)
   double mc[2] = {0.0, 0.0};
@@ -904,7 +907,13 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
   double in[PD], tsum[PD];
 #pragma unroll
   for (int q = 0; q < PD; ++q) in[q] = L.Jt[q] * (L.r[0] - mc[0]) + L.Jt[PD + q] * (L.r[1] - mc[1]);
-  segment_allsum<PD>(sg, in, tsum);
+  if constexpr (ROT) {
+#pragma unroll
+    for (int q = 0; q < PD; ++q) tsum[q] = in[q];
+    segment_allsum_log<PD>(sg, lane, tsum);
+  } else {
+    segment_allsum<PD>(sg, in, tsum);
+  }
   double Vi[NT];
 #pragma unroll
   for (int k = 0; k < NT; ++k) Vi[k] = (L.active && !L.pconst) ? Vinv[(size_t)NT * L.p + k] : 0.0;
@@ -951,19 +960,29 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
   bool cvalid = true;
   if (L.active) {
     double ext[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) ext[i] = cand_cam[6 * L.c + i];
-    const int g = P.cam_group[L.c];
     const double2 uv = P.obs_uv[start + lane];
     double six = 1.0, siy = 1.0;
     if (P.obs_si) { const double2 s = P.obs_si[start + lane]; six = s.x; siy = s.y; }
     ObsLin ol;
-    const double* kc = (INTR ? P.intr_cand : P.intr) + (size_t)g * THEIA_MAX_INTRINSICS;
     const bool depth_row = P.obs_kind && P.obs_kind[start + lane];
-    observe<false>(depth_row ? THIP_MODEL_DEPTH_ROW : P.group_model[g], ext, kc, Xp, uv.x, uv.y, six, siy, ol);
+    if constexpr (ROT) {
+      const double* cr = P.camrot_cand + (size_t)kCamRot * L.c;
+      RotTerms rt;
+      double kc[12];
+      camrot_load(cr, ext, rt);
+      load_d2<12>(cr + kCamRotIntr, kc);   // intrinsics (10) | model | reduced index
+      observe_rot<false>(depth_row ? THIP_MODEL_DEPTH_ROW : (int)kc[kCamRotModel - kCamRotIntr], ext, rt, kc, Xp, uv.x, uv.y, six, siy, ol);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ext[i] = cand_cam[6 * L.c + i];
+      const int g = P.cam_group[L.c];
+      const double* kc = (INTR ? P.intr_cand : P.intr) + (size_t)g * THEIA_MAX_INTRINSICS;
+      observe<false>(depth_row ? THIP_MODEL_DEPTH_ROW : P.group_model[g], ext, kc, Xp, uv.x, uv.y, six, siy, ol);
+    }
     cvalid = ol.valid;
+    const double s2 = ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1];
     double rho1;
-    ccost = 0.5 * loss_eval(P.loss_type, depth_row ? P.loss_width_depth : P.loss_width, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
+    ccost = 0.5 * (P.loss_type == THEIA_LOSS_TRIVIAL ? s2 : loss_eval(P.loss_type, depth_row ? P.loss_width_depth : P.loss_width, s2, &rho1));
   }
   ccost = wave_sum(ccost);
   mcc = wave_sum(mcc);
@@ -1369,6 +1388,12 @@ void launch_backsub(const DevProblem& P, const double* cam, const double* pts, c
   (void)scal;
   if (P.ntiles == 0) return;
   const double* ycc = yc + P.ni;  // camera part of the solution
+  if (!P.ni && P.n_fruns > 0 && P.camrot && P.camrot_cand) {   // fused path: the state's blocks are in P.camrot already
+    launch_cam_prep(P, cand_cam, P.intr, P.camrot_cand, st);
+    if (P.pd == 3) k_backsub<3, false, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
+    else k_backsub<4, false, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
+    return;
+  }
   if (P.ni) {
     if (P.pd == 3) k_backsub<3, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
     else k_backsub<4, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);

@@ -75,10 +75,11 @@ THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam
   }
   L.X[0] = L.X[1] = L.X[2] = 0.0; L.X[3] = 1.0;
   if (!active) return;
-  const int c = P.obs_cam[o];
-  const int p = P.obs_pt[o];
+  int c = P.obs_cam[o];
+  int p = P.obs_pt[o];
+  if constexpr (ROT) { if (P.fused_dbg & 4) { c = 0; p = lane & 7; } }   // development: cache-resident gathers (wrong results)
   L.c = c; L.p = p;
-  L.rc = P.cam_red[c];
+  if constexpr (!ROT) L.rc = P.cam_red[c];
   L.pconst = P.pt_const[p] != 0;
   const double2 uv = P.obs_uv[o];
   double six = 1.0, siy = 1.0;
@@ -87,33 +88,46 @@ THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam
   L.X[0] = Xv.x; L.X[1] = Xv.y; L.X[2] = Xv.z; L.X[3] = Xv.w;
   double ext[6];
   RotTerms rt;
+  double blk[20];          // ROT: [scale (6) | intrinsics (10) | model, reduced index, pad] of the camera's block
+  const bool depth_row = P.obs_kind && P.obs_kind[o];
+  int g = 0, model;
+  const double* intr;
   if constexpr (ROT) {
-    camrot_load(cam + (size_t)kCamRot * c, ext, rt);
+    const double* cr = cam + (size_t)kCamRot * c;
+    camrot_load(cr, ext, rt);
+    load_d2<20>(cr + kCamRotScale, blk);
+    L.rc = (int)blk[kCamRotRed - kCamRotScale];
+    model = depth_row ? THIP_MODEL_DEPTH_ROW : (int)blk[kCamRotModel - kCamRotScale];
+    intr = blk + (kCamRotIntr - kCamRotScale);
   } else {
 #pragma unroll
     for (int i = 0; i < 6; ++i) ext[i] = cam[6 * c + i];
+    g = P.cam_group[c];
+    model = depth_row ? THIP_MODEL_DEPTH_ROW : P.group_model[g];
+    intr = P.intr + (size_t)g * THEIA_MAX_INTRINSICS;
   }
-  const int g = P.cam_group[c];
-  const bool depth_row = P.obs_kind && P.obs_kind[o];
-  const int model = depth_row ? THIP_MODEL_DEPTH_ROW : P.group_model[g];
-  const double* intr = P.intr + (size_t)g * THEIA_MAX_INTRINSICS;
   L.g = g;
   typename std::conditional<INTR, ObsLinK, ObsLin>::type ol;
   if constexpr (ROT) observe_rot<WANT_JAC, INTR && WANT_JAC>(model, ext, rt, intr, L.X, uv.x, uv.y, six, siy, ol);
   else observe<WANT_JAC, INTR && WANT_JAC>(model, ext, intr, L.X, uv.x, uv.y, six, siy, ol);
   L.valid = ol.valid;
   const double s = ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1];
-  double rho1;
-  const double rho = loss_eval(P.loss_type, depth_row ? P.loss_width_depth : P.loss_width, s, &rho1);
+  double rho1 = 1.0, rho = s, sr = 1.0;
+  if (P.loss_type != THEIA_LOSS_TRIVIAL) {   // uniform branch: the trivial loss needs no corrector (and no sqrt)
+    rho = loss_eval(P.loss_type, depth_row ? P.loss_width_depth : P.loss_width, s, &rho1);
+    sr = sqrt(rho1);
+  }
   L.cost = 0.5 * rho;
-  const double sr = sqrt(rho1);
   L.r[0] = sr * ol.r[0];
   L.r[1] = sr * ol.r[1];
   if (WANT_JAC) {
-    const unsigned mask = P.cam_mask[c];
+    unsigned mask = 0u;
+    if constexpr (!ROT) mask = P.cam_mask[c];
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-      const double sc = ((mask >> q) & 1u) ? 0.0 : sr * P.scale_c[6 * c + q];
+      double sc;
+      if constexpr (ROT) sc = sr * blk[q];   // frozen columns carry a zero scale in the block
+      else sc = ((mask >> q) & 1u) ? 0.0 : sr * P.scale_c[6 * c + q];
       L.Jc[q] = ol.Jc[q] * sc;
       L.Jc[6 + q] = ol.Jc[6 + q] * sc;
     }

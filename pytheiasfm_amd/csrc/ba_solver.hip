@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -460,7 +461,8 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.prior_vec = h->prior_vec.p; P.prior_info = h->prior_info.p;
   P.rec = h->rec.p; P.n_diag_items = h->n_diag_items; P.n_blk_items = h->n_blk_items;
   P.n_fruns = h->use_fused ? h->n_fruns : 0; P.fruns = h->fruns.p; P.frun_cams = h->frun_cams.p; P.frun_tgt = h->frun_tgt.p;
-  P.obs_lc = h->obs_lc.p; P.obs_tl = h->obs_tl.p; P.tile_trk_end = h->tile_trk_end.p; P.fpart = h->fpart.p; P.camrot = h->camrot.p;
+  P.obs_lc = h->obs_lc.p; P.obs_tl = h->obs_tl.p; P.tile_trk_end = h->tile_trk_end.p; P.fpart = h->fpart.p; P.camrot = h->camrot.p; P.camrot_cand = h->camrot_cand.p;
+  { const char* dbg = getenv("THEIA_HIP_FUSED_DBG"); P.fused_dbg = dbg ? atoi(dbg) : 0; }
   P.n_sum_items = h->n_sum_items; P.sum_items = h->sum_items.p; P.sum_src = h->sum_src.p;
   P.diag_items = h->diag_items.p; P.rec_slot = h->cam_obs.p; P.slot_obs = h->slot_obs.p; P.slot_pt = h->slot_pt.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
 }
@@ -931,6 +933,14 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
                       std::vector<int>& l_start, std::vector<int>& l_pt, FusedHost& fp) {
   const int np = h->np;
   const int64_t nm = h->nobs_main;
+  const int tps = fused_tiles_per_subchunk(h->pd);
+  // track slices per consumer wave for a run of ntgt target blocks over W cameras (0 = needs more than one wave)
+  auto packing = [](size_t ntgt, size_t W) -> int {
+    if (ntgt > 64 || 6 * W > 64) return 0;
+    static const int cand[6] = {10, 6, 4, 3, 2, 1};
+    for (int c : cand) if ((size_t)(64 / c) >= ntgt) return c;
+    return 1;
+  };
   fp.obs_lc.assign((size_t)std::max<int64_t>(1, nm), 0xff);
   fp.obs_tl.assign((size_t)std::max<int64_t>(1, nm), 0);
   const char* rm = getenv("THEIA_HIP_FUSED_RUN_OBS");
@@ -967,7 +977,8 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
       fp.tgts.push_back((unsigned short)(la | (lb << 8)));
     }
     const int need = std::max(r.ntgt, 6 * r.W);
-    r.G = need <= 64 ? 1 : (need <= 128 ? 2 : 4);
+    const int G = need <= 64 ? 1 : (need <= 128 ? 2 : 4);
+    r.gp = G | ((G == 1 ? std::max(1, packing((size_t)r.ntgt, (size_t)r.W)) : 1) << 8);
     r.part_off = (int)fp.part_doubles;
     fp.part_doubles += (size_t)r.ntgt * 36 + (size_t)r.W * 54;
     for (int t = run_tile0; t < run_tile0 + run_ntiles; ++t)
@@ -1007,12 +1018,10 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
     upairs.clear();
     std::set_union(run_pairs.begin(), run_pairs.end(), tp.begin(), tp.end(), std::back_inserter(upairs));
     bool new_run = (int)uni.size() > kFusedMaxCams || upairs.size() > 253;
-    if (!new_run && run_obs >= run_max / 4) {
-      // keep a run inside one slice geometry (<= 64 targets, <= 10 cameras) and inside one key when it is large enough
-      const bool small_now = run_pairs.size() <= 64 && run_cams.size() <= 10;
-      const bool small_after = upairs.size() <= 64 && uni.size() <= 10;
-      if ((small_now && !small_after) || skey[q] != run_key0) new_run = true;
-    }
+    // a run keeps its packing level (track slices per wave) once it has some work, and stays inside one
+    // first-camera key once it is large enough
+    if (!new_run && run_obs >= 64 && packing(upairs.size(), uni.size()) < packing(run_pairs.size(), run_cams.size())) new_run = true;
+    if (!new_run && run_obs >= run_max / 4 && skey[q] != run_key0) new_run = true;
     if (new_run) {
       close_tile(q);
       finalize_run();
@@ -1020,11 +1029,15 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
     }
     if (t_len + L > 64 || t_tracks >= kFusedTileTracks) {
       close_tile(q);
-      if (run_ntiles % 4 == 0 && run_obs >= run_max) { finalize_run(); uni = tc; upairs = tp; }
+      // runs that need several waves per track slice walk their tracks (almost) serially: keep them short, so that
+      // many workgroups share that work instead of a few long ones setting the kernel's duration
+      const size_t need = std::max(run_pairs.size(), 6 * run_cams.size());
+      const int64_t cap = need <= 64 ? run_max : (need <= 128 ? run_max / 4 : 1);
+      if (run_ntiles % tps == 0 && run_obs >= cap) { finalize_run(); uni = tc; upairs = tp; }
     }
     if (t_len == 0) {
       t_start = off[q];
-      if (run_ntiles % 4 == 0) sc_tracks = 0;
+      if (run_ntiles % tps == 0) sc_tracks = 0;
       if (run_key0 < 0) run_key0 = skey[q];
     }
     for (int64_t s = off[q]; s < off[q + 1]; ++s) fp.obs_tl[s] = (uint8_t)sc_tracks;
@@ -1139,7 +1152,22 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   }
   std::vector<int> porder(h->np), prank(h->np);
   for (int q = 0; q < h->np; ++q) porder[q] = q;
-  std::stable_sort(porder.begin(), porder.end(), [&](int x, int y) { return pkey[x] < pkey[y]; });
+  // Inside one first-camera key, short tracks come first (classes by number of variable cameras): the fused Schur
+  // kernel packs several short tracks into one wave step when a run of tracks touches few target blocks.
+  std::vector<int> skey_pt(h->np);
+  {
+    std::vector<int> nvar(h->np, 0);
+    for (int64_t i = 0; i < h->nobs; ++i) if (h->cam_red[p->obs_cam[i]] >= 0) nvar[p->obs_pt[i]]++;
+    for (int q = 0; q < h->np; ++q) {
+      // measured at 1k views / 500k tracks: {<= 6 | >= 7} 0.70 ms, {<= 3 | 4..6 | >= 7} 0.76 ms, one class 0.75 ms
+      static const int ncls = getenv("THEIA_HIP_FUSED_CLASSES") ? atoi(getenv("THEIA_HIP_FUSED_CLASSES")) : 2;
+      static const int cut0 = getenv("THEIA_HIP_FUSED_CUT0") ? atoi(getenv("THEIA_HIP_FUSED_CUT0")) : 6;
+      const int cls = ncls == 2 ? (nvar[q] <= cut0 ? 0 : 2) : (nvar[q] <= 3 ? 0 : (nvar[q] <= 6 ? 1 : 2));
+      static const bool noclass = getenv("THEIA_HIP_FUSED_NOCLASS") != nullptr;
+      skey_pt[q] = pkey[q] == std::numeric_limits<int>::max() ? pkey[q] : ((h->ni == 0 && !noclass) ? pkey[q] * 4 + cls : pkey[q]);
+    }
+  }
+  std::stable_sort(porder.begin(), porder.end(), [&](int x, int y) { return skey_pt[x] < skey_pt[y]; });
   for (int r = 0; r < h->np; ++r) prank[porder[r]] = r;
   // offsets indexed by track RANK
   std::vector<int64_t> cnt_main(h->np + 1, 0), cnt_fix(h->np + 1, 0);
@@ -1207,7 +1235,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   }
   if (h->use_fused) {
     std::vector<int> skey(h->np);
-    for (int q = 0; q < h->np; ++q) skey[q] = pkey[porder[q]];
+    for (int q = 0; q < h->np; ++q) skey[q] = pkey[porder[q]];   // run boundaries follow the first-camera key
     build_fused_plan(h, cnt_main, porder, sred, skey, tstart, tcount, tkey, l_obs, l_slot, l_start, l_pt, fplan);
     if (fplan.part_doubles > (size_t)std::numeric_limits<int>::max() / 2)
       return set_error(THEIA_HIP_ERR_UNSUPPORTED, "partial-sum buffer of the fused Schur assembly exceeds 32-bit offsets");
@@ -1346,11 +1374,19 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   if (h->use_fused) {
     h->n_fruns = (int)fplan.runs.size(); h->n_sum_items = (int)fplan.sum_items.size() / 6;
     fplan.tile_trk_end.resize(std::max<size_t>(1, fplan.tile_trk_end.size()));
-    if (fplan.runs.empty()) fplan.runs.push_back(FusedRun{0, 0, 0, 0, 0, 0, 0, 1});
+    if (ctiming) {   // THEIA_HIP_CREATE_TIMING: shape of the fused plan
+      std::map<int, std::pair<int, int>> by;   // gp -> (runs, sub-chunks)
+      long long nsc = 0;
+      for (const FusedRun& r : fplan.runs) { auto& e = by[r.gp]; e.first++; e.second += (r.ntiles + 3) / 4; nsc += (r.ntiles + 3) / 4; }
+      fprintf(stderr, "theia_hip fused plan: %zu runs, %lld sub-chunks (%.1f obs each), %zu partial doubles, %d sum items\n",
+              fplan.runs.size(), nsc, nsc ? (double)h->nobs_main / nsc : 0.0, fplan.part_doubles, h->n_sum_items);
+      for (auto& kv : by) fprintf(stderr, "  G=%d slices/wave=%d: %d runs, %d sub-chunks\n", kv.first & 0xff, kv.first >> 8, kv.second.first, kv.second.second);
+    }
+    if (fplan.runs.empty()) fplan.runs.push_back(FusedRun{0, 0, 0, 0, 0, 0, 0, 1 | (1 << 8)});
     UP(fruns, fplan.runs); UP(frun_cams, fplan.cams); UP(frun_tgt, fplan.tgts); UP(obs_lc, fplan.obs_lc); UP(obs_tl, fplan.obs_tl);
     UP(tile_trk_end, fplan.tile_trk_end); UP(sum_items, fplan.sum_items); UP(sum_src, fplan.sum_src);
     AL(fpart, std::max<size_t>(1, fplan.part_doubles));
-    AL(camrot, (size_t)20 * std::max(1, h->nc)); AL(camrot_cand, (size_t)20 * std::max(1, h->nc));
+    AL(camrot, (size_t)40 * std::max(1, h->nc)); AL(camrot_cand, (size_t)40 * std::max(1, h->nc));
   }
   if (h->ni > 0 && h->ntiles_main > 0 && (rc = build_gather_lists_intr(h, p, ocam, opt))) return rc;
 #undef UP
