@@ -1,18 +1,18 @@
 #!/usr/bin/env python
-"""bench.py -- BA LM-iterations/s + residuals/s (and RANSAC hypotheses/s) on
-N x MI355X, with the kernel roofline and the CPU baseline in the same JSON line.
+"""bench.py -- BA LM-iterations/s + residuals/s and RANSAC hypotheses/s on N x MI355X, with the kernel rooflines
+and the CPU baseline (host cores of the same box) in the same JSON line.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is ONE Levenberg-Marquardt iteration of the BA hot path (Jacobian
-evaluation + Schur elimination + reduced-camera solve + back-substitution +
-trial-cost evaluation) on a synthetic reconstruction resident in HBM.
-N = 1 runs BASELINE.json configs[1] (200 views / 50k tracks, pinhole).  For
-N > 1 the track set grows with N (50k tracks per GPU, same 200 views): tracks
-are sharded over ranks and the reduced camera system is all-reduced with RCCL
-every iteration -> weak scaling; `value` = residual blocks linearised per
-second over all ranks.
+A "step" is ONE Levenberg-Marquardt iteration of the BA hot path (Jacobian evaluation + Schur elimination +
+reduced-camera solve + back-substitution + trial-cost evaluation) on a synthetic reconstruction resident in HBM.
+
+Headline workload (`north_star`, BASELINE.json configs[3] on one GPU): synth_ba_v1 "C4" = 1000 views / 500 000 tracks
+/ ~3.0 M observations, mixed pinhole + double-sphere cameras.  N > 1 runs the SAME problem with its tracks sharded
+over the ranks (strong scaling) and the reduced camera system all-reduced with RCCL every iteration.
+Secondary blocks of the same line: "c2" (configs[1], 200 views / 50k tracks), "ransac" (configs[4]: 10 000 pairs x
+2000 correspondences x 4096 hypotheses, five-point relative pose and SQPnP absolute pose).
 """
 import argparse
 import json
@@ -26,11 +26,10 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-VIEWS = 200
-TRACKS_PER_GPU = 50000
-SEED = 0xBA5E0002
-ITERS_PER_SOLVE = 5  # the LM iterations the default tolerances run on this scene; more would hit exact convergence
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+ITERS_PER_SOLVE = 8      # LM iterations per solve from the perturbed start (tolerances off: exactly this many)
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = FP64 matrix peak (half of the guide's 157.3 TF FP32 vector rate)
+PROFILE_TAG = "r2"       # committed rocprofv3 PMC passes of this command: profiles/<tag>_pmc_{fetch,write}_size.csv
 
 
 def bench_options(ba, max_iters):
@@ -45,7 +44,7 @@ def bench_options(ba, max_iters):
 
 
 def algorithmic_bytes_linearize(p):
-    """DESIGN.md "algorithmic bytes": what one linearize+Schur launch must move.
+    """DESIGN.md "algorithmic bytes": what one linearize + Schur launch group must move.
     reads : 24 B / observation (uv f64x2 + two int32 indices)
             48 B / camera + 56 B / intrinsics group + 32 B / point (parameters)
             48 B / camera + 24 B / point (Jacobi scaling)
@@ -65,7 +64,7 @@ def algorithmic_bytes_linearize(p):
             ia = start[sel] + a; ib = start[sel] + b
             ca, cb = cam[ia], cam[ib]
             hi, lo = np.maximum(ca, cb), np.minimum(ca, cb)
-            pairs.append(hi * nc + lo)
+            pairs.append(np.unique(hi * nc + lo))
     up = np.unique(np.concatenate(pairs)) if pairs else np.zeros(0, dtype=np.int64)
     ndiag = int(np.sum(up // nc == up % nc))
     nnz = 21 * ndiag + 36 * (len(up) - ndiag)
@@ -75,36 +74,165 @@ def algorithmic_bytes_linearize(p):
 
 
 def pmc_traffic_bytes(world):
-    """HBM-side bytes per launch of the roofline kernel group, from the committed
-    rocprofv3 PMC passes of this same command (profiles/r1z_pmc_*.csv; FETCH_SIZE
-    and WRITE_SIZE collected in separate passes, KB; the 16-B/lane record gathers
-    of k_schur doubled per the gfx950 FETCH_SIZE note of MI355X_MICROARCH.md).
-    None when the files are absent or the run is not the profiled N=1 workload."""
+    """HBM-side bytes per launch of the roofline kernel group (k_cam_prep + k_lin_schur + k_schur_sum), from the
+    committed rocprofv3 PMC passes of this same command at N = 1 (profiles/<tag>_pmc_*.csv, collected past the
+    Infinity Cache: 1.1 GB working set; FETCH_SIZE and WRITE_SIZE in separate passes, KB per dispatch; FETCH doubled
+    per the gfx950 note of MI355X_MICROARCH.md -- the observation / parameter streams are 16 B / lane reads)."""
     if world != 1:
         return None
     import csv
-    base = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    base = os.path.join(ROOT, "profiles")
     try:
         kb = {}
         for tag in ("fetch_size", "write_size"):
-            with open(os.path.join(base, "r1z_pmc_%s.csv" % tag)) as f:
+            with open(os.path.join(base, "%s_pmc_%s.csv" % (PROFILE_TAG, tag))) as f:
                 for row in csv.reader(f):
                     if row and row[0] != "kernel":
                         kb[(tag, row[0])] = float(row[2])
-        fetch = 2.0 * kb[("fetch_size", "k_schur<3>")] + kb[("fetch_size", "k_lin_obs<3>")]
-        write = sum(kb[("write_size", k)] for k in ("k_lin_obs<3>", "k_schur<3>"))
+        group = [k for (t, k) in kb if t == "fetch_size" and (k.startswith("k_lin_schur") or k.startswith("k_schur_sum") or k.startswith("k_cam_prep"))]
+        if not any(k.startswith("k_lin_schur") for k in group):
+            return None
+        fetch = sum(2.0 * kb[("fetch_size", k)] for k in group)
+        write = sum(kb.get(("write_size", k), 0.0) for k in group)
         return int(1024 * (fetch + write))
     except (OSError, KeyError, ValueError):
         return None
 
 
+class BaRunner:
+    """K LM iterations as ceil(K / ITERS_PER_SOLVE) solves, each from the device-resident perturbed start."""
+
+    def __init__(self, ba, prob, pristine):
+        self.ba = ba
+        self.opts = bench_options(ba, ITERS_PER_SOLVE)
+        self.h = ba.BaHandle(prob, self.opts)
+        self.pristine = pristine
+
+    def prepare(self):
+        self.h.reset(self.pristine)
+        self.h.snapshot()   # the perturbed initial state stays in HBM: the timed region has no host round trip for inputs
+
+    def run(self, k, from_host=False):
+        done = 0
+        acc = {"lin_kernel": 0.0, "launches": 0, "lin": 0.0, "solve": 0.0, "backsub": 0.0}
+        while done < k:
+            m = min(ITERS_PER_SOLVE, k - done)
+            self.opts.max_num_iterations = int(m)
+            self.h.set_options(self.opts)
+            if from_host:
+                self.h.reset(self.pristine)
+            else:
+                self.h.restore()
+            s, _ = self.h.run(trace_capacity=1)
+            if s.num_iterations != m:
+                raise RuntimeError(f"solve stopped after {s.num_iterations} of {m} iterations (term {s.termination_type})")
+            done += m
+            acc["lin_kernel"] += s.time_kernel_linearize; acc["launches"] += s.num_linearize_launches
+            acc["lin"] += s.time_linearize; acc["solve"] += s.time_solve_reduced; acc["backsub"] += s.time_backsub
+        return acc
+
+    def phase_timed(self, k):
+        os.environ["THEIA_HIP_PHASE_TIMING"] = "1"
+        try:
+            return self.run(k)
+        finally:
+            del os.environ["THEIA_HIP_PHASE_TIMING"]
+
+
+def cpu_ba_baseline(pristine, nobs_total, threads, n_it, what):
+    """The oracle ("port", oracle/ba_oracle.cpp: Jet autodiff + Schur elimination + envelope Cholesky) on the host."""
+    from tests import oracle_lib as ol
+    oo = ol.default_options()
+    oo.max_num_iterations = n_it
+    oo.function_tolerance = 0.0; oo.gradient_tolerance = 0.0; oo.parameter_tolerance = 0.0
+    oo.use_inner_iterations = 0
+    pc = pristine.copy()
+    prev = ol.set_threads(threads)
+    try:
+        t0 = time.perf_counter()
+        so, _ = ol.solve(pc, oo, trace_capacity=1)
+        dt = time.perf_counter() - t0
+    finally:
+        ol.set_threads(prev)
+    it_s = so.num_iterations / max(so.solve_time_in_seconds, 1e-9)   # LM loop only (setup excluded, as on the GPU side)
+    return {"value": nobs_total * it_s, "unit": "residuals/s", "lm_iterations_per_sec": it_s, "cores": threads, "kind": "port",
+            "sample": f"{so.num_iterations} LM iterations of {what} (oracle/ba_oracle.cpp, FP64, Jet autodiff + Schur + envelope "
+                      f"Cholesky, OpenMP over observations / camera chunks), {dt:.1f} s wall incl. {so.setup_time_in_seconds:.1f} s setup",
+            "phase_s": {"linearize_schur": so.time_linearize, "reduced_solve": so.time_solve_reduced, "backsub_trial_cost": so.time_backsub}}
+
+
+def ransac_block(cpu_baseline, host_cores):
+    """BASELINE.json configs[4] on one GPU: 10 000 pairs x 2000 correspondences x 4096 hypotheses, five-point relative
+    pose and SQPnP absolute pose (DLS: see DESIGN.md).  FLOP/s: SURVEY.md 8d counts (score: 85 FLOP per model and
+    correspondence; fit: per-solve counts of the restated solvers)."""
+    from pytheiasfm_amd import ransac, synth
+    PAIRS, CORR, HYPS, CHUNK = 10000, 2000, 4096, 1000
+    out = {"workload": f"synth_ransac_v1 C5: {PAIRS} pairs x {CORR} correspondences x {HYPS} hypotheses (min = max iterations), InlierSupport",
+           "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS}
+    legs = (("five_point_relative_pose", ransac.EST_RELATIVE_POSE, "relative", (2.0 / 1000.0) ** 2, 2.5e4, 85.0),
+            ("sqpnp_absolute_pose", ransac.EST_ABS_SQPNP, "absolute", (4.0 / 1000.0) ** 2, 3.0e4, 30.0))
+    for name, est, kind, thresh, fit_flop, score_flop in legs:
+        p = ransac.RansacParameters(); p.error_thresh = thresh; p.min_iterations = HYPS; p.max_iterations = HYPS; p.seed = 1
+        tot = {"hyp": 0, "models": 0, "wall": 0.0, "fit": 0.0, "score": 0.0, "kern": 0.0}
+        first = None
+        for c in range(PAIRS // CHUNK):
+            data, offsets, _ = synth.synth_ransac_v1(CHUNK, CORR, kind, seed=0x5AC50005 + 977 * c)
+            if c == 0:
+                ransac.estimate_batch(est, data[: offsets[8]], offsets[:9], p)  # warm-up
+                first = (data, offsets)
+            p.seed = 1 + c * CHUNK
+            t0 = time.perf_counter()
+            res = ransac.estimate_batch(est, data, offsets, p)
+            tot["wall"] += time.perf_counter() - t0
+            tot["hyp"] += int(res["hypotheses_evaluated"]); tot["models"] += int(res["models_scored"])
+            tot["fit"] += res["time_fit_seconds"]; tot["score"] += res["time_score_seconds"]; tot["kern"] += res["time_fit_score_seconds"]
+        leg = {"hypotheses_per_sec": tot["hyp"] / tot["wall"],
+               "hypotheses_per_sec_kernels_only": tot["hyp"] / max(tot["kern"], 1e-12),
+               "hypotheses": tot["hyp"], "models_scored": tot["models"], "wall_s": tot["wall"],
+               "kernel_s": {"fit": tot["fit"], "score": tot["score"]},
+               "roofline_fit": {"bound": "fp64-vector", "achieved": tot["hyp"] * fit_flop / max(tot["fit"], 1e-12) / 1e12,
+                                "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "flop_per_solve": fit_flop},
+               "roofline_score": {"bound": "fp64-vector", "achieved": tot["models"] * CORR * score_flop / max(tot["score"], 1e-12) / 1e12,
+                                  "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "flop_per_model_correspondence": score_flop},
+               "note": "wall time includes the PCIe upload of the correspondences, host sample generation and host replay"}
+        for r in ("roofline_fit", "roofline_score"):
+            leg[r]["frac"] = leg[r]["achieved"] / FP64_VECTOR_PEAK_TFLOPS
+        if cpu_baseline:
+            from concurrent.futures import ThreadPoolExecutor
+            from tests import oracle_lib as ol
+            data, offsets = first
+            hy = 1024
+
+            def one(i):
+                pc = p.to_c(); pc.min_iterations = hy; pc.max_iterations = hy; pc.seed = 1 + i
+                ol.ransac_estimate(est, data[offsets[i]:offsets[i + 1]], pc)
+            t0 = time.perf_counter()
+            for i in range(8):
+                one(i)
+            dt1 = time.perf_counter() - t0
+            nall = min(CHUNK, max(8, 4 * host_cores))
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=host_cores) as ex:   # ctypes releases the GIL: one oracle call per thread
+                list(ex.map(one, range(nall)))
+            dta = time.perf_counter() - t0
+            leg["cpu_baseline"] = {"value": nall * hy / dta, "unit": "hypotheses/s", "cores": host_cores, "kind": "port",
+                                   "sample": f"{nall} pairs x {hy} hypotheses x {CORR} correspondences, one pair per host thread "
+                                             f"(oracle/ransac_oracle.cpp, the reference's sequential loop per pair), {dta:.1f} s"}
+            leg["cpu_baseline_single_thread"] = {"value": 8 * hy / dt1, "unit": "hypotheses/s", "cores": 1, "kind": "port",
+                                                 "sample": f"8 pairs x {hy} hypotheses, {dt1:.1f} s"}
+            leg["speedup_vs_cpu_baseline"] = leg["hypotheses_per_sec"] / leg["cpu_baseline"]["value"]
+        out[name] = leg
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ransac", action="store_true")
+    ap.add_argument("--no-c2", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,13 +253,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    # ---- workload (synthetic, deterministic)
-    full = synth.synth_ba_v1(VIEWS, TRACKS_PER_GPU * world, seed=SEED)
+    # ---- headline workload (synthetic, deterministic): C4, strong-sharded over the ranks
+    full = synth.ba_config("C4")
     nobs_total = full.obs_uv.shape[0]
-    if world > 1:
-        prob, _ = synth.shard_tracks(full, rank, world)
-    else:
-        prob = full
+    nviews, ntracks = full.cam_ext.shape[0], full.points.shape[0]
+    prob = synth.shard_tracks(full, rank, world)[0] if world > 1 else full
     pristine = prob.copy()
 
     def barrier():
@@ -140,60 +266,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    opts = bench_options(ba, ITERS_PER_SOLVE)
-    h = ba.BaHandle(prob, opts)
+    R = BaRunner(ba, prob, pristine)
     if world > 1:
-        h.set_allreduce(tdist.make_torch_allreduce(local_rank))
-        h.set_shard(rank, world)
-
-    def set_max_iters(m):
-        opts.max_num_iterations = int(m)
-        h.set_options(opts)
-
-    h.reset(pristine)
-    h.snapshot()   # the perturbed initial state stays in HBM: the timed region has no host round trip for inputs
-
-    def run_iterations(k, from_host=False):
-        """Exactly k LM iterations as ceil(k / ITERS_PER_SOLVE) solves, each from
-        the perturbed initial state (device-resident snapshot; from_host: re-uploaded over PCIe)."""
-        done = 0
-        acc = {"lin_kernel": 0.0, "launches": 0, "lin": 0.0, "solve": 0.0, "backsub": 0.0}
-        while done < k:
-            m = min(ITERS_PER_SOLVE, k - done)
-            set_max_iters(m)
-            if from_host:
-                h.reset(pristine)
-            else:
-                h.restore()
-            s, _ = h.run(trace_capacity=1)
-            if s.num_iterations != m:
-                raise RuntimeError(f"solve stopped after {s.num_iterations} of {m} iterations (term {s.termination_type})")
-            done += m
-            acc["lin_kernel"] += s.time_kernel_linearize; acc["launches"] += s.num_linearize_launches
-            acc["lin"] += s.time_linearize; acc["solve"] += s.time_solve_reduced; acc["backsub"] += s.time_backsub
-        return acc
-
-    # initialisation, not part of the W warm-up steps: a fresh box idles at its lowest clock level and W = 10
-    # iterations last 5 ms -- run the workload for a few hundred ms first so the timed region sees settled clocks
-    run_iterations(400)
+        R.h.set_allreduce(tdist.make_torch_allreduce(local_rank))
+        R.h.set_shard(rank, world)
+    R.prepare()
+    info = R.h.plan_info()
+    # initialisation, not part of the W warm-up steps: a fresh box idles at its lowest clock level -- run the workload
+    # for a few hundred ms first so that the timed region sees settled clocks
+    R.run(160)
     if args.warmup > 0:
-        run_iterations(args.warmup)
+        R.run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    run_iterations(args.steps)
+    R.run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    # Kernel-group durations for the roofline: the timed region above has no events inside; the same
-    # workload is run once more with HIP events around the kernel groups on the library's stream
-    # (THEIA_HIP_PHASE_TIMING=1).
-    os.environ["THEIA_HIP_PHASE_TIMING"] = "1"
-    acc = run_iterations(min(args.steps, 50))
-    del os.environ["THEIA_HIP_PHASE_TIMING"]
+    # Kernel-group durations for the rooflines: the timed region above has no events inside; the same workload is run
+    # once more with HIP events around the kernel groups on the library's stream (THEIA_HIP_PHASE_TIMING=1).
+    acc = R.phase_timed(max(ITERS_PER_SOLVE, min(args.steps, 40)))
     barrier()
     # for the record (DESIGN.md): the same solves with the parameters re-uploaded from host memory per solve
     tp0 = time.perf_counter()
-    npcie = min(args.steps, 50)
-    run_iterations(npcie, from_host=True)
+    npcie = max(ITERS_PER_SOLVE, min(args.steps, 40))
+    R.run(npcie, from_host=True)
     barrier()
     pcie_it_per_s = npcie / (time.perf_counter() - tp0)
     if world > 1:
@@ -204,63 +300,85 @@ def main():
     out = None
     if rank == 0:
         it_per_s = args.steps / elapsed
-        res_per_s = nobs_total * args.steps / elapsed
-        abytes = algorithmic_bytes_linearize(prob)
-        avg_lin = acc["lin_kernel"] / max(1, acc["launches"])
-        achieved = abytes / avg_lin / 1e9 if avg_lin > 0 else 0.0
+        abytes = algorithmic_bytes_linearize(full) if world == 1 else None
+        nl = max(1, acc["launches"])
+        avg_lin = acc["lin_kernel"] / nl
+        achieved = abytes / avg_lin / 1e9 if (abytes and avg_lin > 0) else 0.0
+        k3_s = acc["solve"] / nl
         out = {
             "metric": "BA residuals/sec (LM-iterations/sec x observations); RANSAC hypotheses/sec alongside",
-            "value": res_per_s, "unit": "residuals/s",
+            "value": nobs_total * it_per_s, "unit": "residuals/s",
             "lm_iterations_per_sec": it_per_s,
             "lm_iterations_per_sec_pcie_inclusive": pcie_it_per_s,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synth_ba_v1: {VIEWS} views / {TRACKS_PER_GPU * world} tracks / {nobs_total} observations, pinhole, "
-                                   f"TRIVIAL loss, intrinsics NONE, homogeneous-manifold points, {ITERS_PER_SOLVE} LM iterations per solve"
+            "config": {"workload": f"synth_ba_v1 C4: {nviews} views / {ntracks} tracks / {nobs_total} observations, mixed pinhole + "
+                                   f"double-sphere (8 intrinsics groups), TRIVIAL loss, intrinsics NONE, homogeneous-manifold points, "
+                                   f"{ITERS_PER_SOLVE} LM iterations per solve"
                                    + ("" if world == 1 else f", tracks sharded over {world} ranks, RCCL all-reduce of the reduced camera system"),
-                       "views": VIEWS, "tracks": TRACKS_PER_GPU * world, "observations": nobs_total,
-                       "baseline_config": "BASELINE.json configs[1]" if world == 1 else "configs[1] x N tracks (weak)"},
-            "roofline": {"kernel": "linearize + Schur assembly launch group (k_lin_obs + k_schur)",
+                       "views": nviews, "tracks": ntracks, "observations": nobs_total,
+                       "baseline_config": "BASELINE.json configs[3] (north_star target configuration) on %d GPU%s" % (world, "" if world == 1 else "s"),
+                       "reduced_system_n": info["n"], "k3_levels": info["k3_levels"], "fused_kernel_runs": info["fused_runs"],
+                       "slow_path_tracks": info["slow_path_tracks"]},
+            "roofline": {"kernel": "linearize + Schur assembly launch group (k_cam_prep + k_lin_schur + k_schur_sum)",
                          "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(world),
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": 1e3 * avg_lin,
                          "launches": acc["launches"],
-                         "timing": "HIP events around the kernel group, instrumented pass of the same workload right after the timed region"},
-            "phase_ms_per_iteration": {"linearize_schur": 1e3 * acc["lin"] / max(1, acc["launches"]),
-                                       "reduced_solve": 1e3 * acc["solve"] / max(1, acc["launches"]),
-                                       "backsub_trial_cost": 1e3 * acc["backsub"] / max(1, acc["launches"])},
+                         "timing": "HIP events around the kernel group on the library's stream, instrumented pass of the same workload right after the timed region",
+                         "note": "FP64 issue bound in practice (DESIGN.md 3.4): 1.35 G pair-product FMAs + the linearisation per launch"},
+            "roofline_k3": {"kernel": "reduced-camera solve (tile-sparse level-scheduled Cholesky, FP64 MFMA trsm / update)",
+                            "bound": "mfma", "achieved": info["k3_flops"] / k3_s / 1e12 if k3_s > 0 else 0.0,
+                            "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": (info["k3_flops"] / k3_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if k3_s > 0 else 0.0,
+                            "flops_per_solve": info["k3_flops"], "avg_solve_ms": 1e3 * k3_s},
+            "phase_ms_per_iteration": {"linearize_schur": 1e3 * acc["lin"] / nl, "reduced_solve": 1e3 * acc["solve"] / nl,
+                                       "backsub_trial_cost": 1e3 * acc["backsub"] / nl},
         }
-    h.close()
+    R.h.close()
+
+    host_cores = os.cpu_count() or 1
+    if rank == 0 and world == 1 and not args.no_c2:
+        # secondary block: BASELINE.json configs[1] (the round-1 headline), same measurement
+        c2 = synth.ba_config("C2")
+        R2 = BaRunner(ba, c2, c2.copy())
+        R2.prepare()
+        R2.run(400)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); R2.run(200); torch.cuda.synchronize(); e2 = time.perf_counter() - t0
+        a2 = R2.phase_timed(48)
+        ab2 = algorithmic_bytes_linearize(c2)
+        l2 = a2["lin_kernel"] / max(1, a2["launches"])
+        out["c2"] = {"workload": f"synth_ba_v1 C2: 200 views / 50000 tracks / {c2.obs_uv.shape[0]} observations, pinhole (BASELINE.json configs[1])",
+                     "lm_iterations_per_sec": 200 / e2, "residuals_per_sec": c2.obs_uv.shape[0] * 200 / e2, "ms_per_step": 1e3 * e2 / 200,
+                     "roofline": {"bound": "hbm", "achieved": ab2 / l2 / 1e9 if l2 > 0 else 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": (ab2 / l2 / 1e9 / HBM_PEAK_GBPS) if l2 > 0 else 0.0, "traffic": None,
+                                  "algorithmic_bytes_per_launch": ab2, "avg_launch_ms": 1e3 * l2},
+                     "phase_ms_per_iteration": {"linearize_schur": 1e3 * a2["lin"] / max(1, a2["launches"]),
+                                                "reduced_solve": 1e3 * a2["solve"] / max(1, a2["launches"]),
+                                                "backsub_trial_cost": 1e3 * a2["backsub"] / max(1, a2["launches"])}}
+        R2.h.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # CPU baseline: the oracle ("port"), bounded sample of the same workload
-        from tests import oracle_lib as ol
-        oo = ol.default_options()
-        n_it = 40
-        oo.max_num_iterations = n_it
-        oo.function_tolerance = 0.0; oo.gradient_tolerance = 0.0; oo.parameter_tolerance = 0.0
-        oo.use_inner_iterations = 0
-        pc = pristine.copy()
-        t0 = time.perf_counter()
-        so, _ = ol.solve(pc, oo, trace_capacity=1)
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": nobs_total * so.num_iterations / dt, "unit": "residuals/s",
-                               "lm_iterations_per_sec": so.num_iterations / dt,
-                               "cores": 1, "kind": "port",
-                               "sample": f"{so.num_iterations} LM iterations of the same {VIEWS}-view/{TRACKS_PER_GPU}-track problem "
-                                         f"(oracle/ba_oracle.cpp, scalar FP64, Jet autodiff + Schur + dense Cholesky), {dt:.1f} s",
-                               "host_cores_available": os.cpu_count()}
+        what = f"the same {nviews}-view / {ntracks}-track problem"
+        # all-cores leg: the thread count that runs fastest on this host (the oracle's OpenMP loops stop scaling where
+        # the dense reduced matrix and the Jacobian arrays saturate the memory system), each tried on 3 LM iterations
+        tried = {}
+        for th in sorted({host_cores, max(1, host_cores // 2), max(1, host_cores // 4), min(host_cores, 32)}, reverse=True):
+            tried[th] = cpu_ba_baseline(pristine, nobs_total, th, 3, what)
+        best = max(tried, key=lambda k: tried[k]["value"])
+        out["cpu_baseline"] = tried[best]
+        out["cpu_baseline"]["host_cores_available"] = host_cores
+        out["cpu_baseline"]["threads_tried_iterations_per_sec"] = {str(k): v["lm_iterations_per_sec"] for k, v in tried.items()}
+        out["cpu_baseline_single_thread"] = cpu_ba_baseline(pristine, nobs_total, 1, 1, what)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        out["speedup_vs_cpu_single_thread"] = out["value"] / out["cpu_baseline_single_thread"]["value"]
 
     if rank == 0 and world == 1 and not args.no_ransac:
-        try:
-            from pytheiasfm_amd import ransac
-            out["ransac"] = ransac.bench(cpu_baseline=not args.no_cpu_baseline)
-        except ImportError:
-            pass
+        out["ransac"] = ransac_block(not args.no_cpu_baseline, host_cores)
 
     if rank == 0:
         print(json.dumps(out))

@@ -364,6 +364,13 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* summary);
 int theia_hip_ba_download(theia_ba_handle h, theia_ba_problem* problem);
 int theia_hip_ba_destroy(theia_ba_handle h);
 
+/* Shape of the device plan of a handle, for roofline accounting (bench.py): reduced system size, elimination-tree
+ * levels and FP64 flops of one reduced-camera solve (K3), workgroups ("runs") of the fused linearise + Schur kernel
+ * (0 = the gather kernels are in use), tracks on the per-observation slow path.  Any pointer may be NULL. */
+int theia_hip_ba_plan_info(theia_ba_handle h, int32_t* n, int32_t* k3_levels, double* k3_flops, int32_t* fused_runs,
+                           int32_t* slow_path_tracks);
+
+
 /* Covariance blocks at the handle's current state for the two block-diagonal problems behind the
  * *WithCov entry points (bundle_adjustment.cc:288-386,420-499; GetCovarianceFor{Track,Tracks,View,Views},
  * bundle_adjuster.cc:660-773 = ceres::Covariance (J'J)^-1 in tangent space, loss applied):
@@ -513,6 +520,8 @@ typedef struct theia_ransac_result {
   int64_t models_scored;       /* models scored against all data           */
   double time_fit_score_seconds; /* device time in the fit+score kernels   */
   int32_t* num_lo_iterations;  /* [num_problems] RansacSummary::num_lo_iterations, or NULL */
+  double time_fit_seconds;     /* device time of the model-fit kernels (HIP events on the library's stream) */
+  double time_score_seconds;   /* device time of the scoring kernels                                        */
 } theia_ransac_result;
 
 /* Replaces SampleConsensusEstimator<E>::Estimate

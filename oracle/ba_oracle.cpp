@@ -42,7 +42,15 @@
 #include <type_traits>
 #include <vector>
 
+#include <omp.h>
+
 namespace {
+
+// Threads of the "all host cores" CPU baseline (bench.py cpu_baseline): 1 = the serial code path every test and
+// golden fixture runs (bitwise unchanged); > 1 parallelises the per-observation / per-point loops with OpenMP.
+// Sums are then taken in a different (still fixed) order, i.e. results agree with the serial ones to rounding.
+int g_threads = 1;
+#define OBA_PAR_FOR _Pragma("omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)")
 
 // ------------------------------------------------------------------ Jets
 // Forward-mode dual number, the same construction Ceres' AutoDiffCostFunction
@@ -641,10 +649,12 @@ bool evaluate(Oracle& o, const std::vector<double>& cam, const std::vector<doubl
               bool want_jac, double* cost_out) {
   const oba_problem& P = *o.P;
   double cost = 0.0;
-  bool ok = true;
+  int bad = 0;
   const double one[2] = {1.0, 1.0};
   const int pd = o.pd;
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1) reduction(+ : cost) reduction(+ : bad)
   for (int64_t i = 0; i < o.nobs; ++i) {
+    bool ok = true;
     if (o.obs_fixed[i]) continue;
     const int c = P.obs_cam[i], p = P.obs_pt[i];
     const int g = P.cam_group[c];
@@ -660,6 +670,7 @@ bool evaluate(Oracle& o, const std::vector<double>& cam, const std::vector<doubl
       double rho[3];
       loss_evaluate(o.O.loss_function_type, loss_width, res[0] * res[0] + res[1] * res[1], rho);
       cost += 0.5 * rho[0];
+      if (!ok) bad++;
       continue;
     }
     typedef Jet<20> J;  // 6 extrinsics + 10 intrinsics + 4 point, as AutoDiffCostFunction<.., 2, 6, K, 4>
@@ -690,7 +701,9 @@ bool evaluate(Oracle& o, const std::vector<double>& cam, const std::vector<doubl
         o.Jp[(size_t)i * 2 * pd + a * pd + q] = o.pt_const[p] ? 0.0 : sr * v;
       }
     }
+    if (!ok) bad++;
   }
+  bool ok = bad == 0;
   // camera priors (no loss function: NULL in bundle_adjuster.cc:627-657)
   for (Oracle::Prior& pr : o.priors) {
     const int c = pr.cam;
@@ -718,6 +731,26 @@ bool evaluate(Oracle& o, const std::vector<double>& cam, const std::vector<doubl
 void column_norms(Oracle& o, std::vector<double>& nf_, std::vector<double>& np_) {
   const oba_problem& P = *o.P; const int pd = o.pd;
   std::fill(nf_.begin(), nf_.end(), 0.0); std::fill(np_.begin(), np_.end(), 0.0);
+  if (g_threads > 1) {
+    // points: one thread per point (CSR by point); camera side: per-thread vectors added in thread order
+    OBA_PAR_FOR
+    for (int p = 0; p < o.np; ++p)
+      for (int64_t k = o.pt_off[p]; k < o.pt_off[p + 1]; ++k) { const int64_t i = o.pt_obs[k];
+        for (int a = 0; a < 2; ++a) for (int q = 0; q < pd; ++q) { const double v = o.Jp[(size_t)i * 2 * pd + a * pd + q]; np_[(size_t)pd * p + q] += v * v; } }
+    std::vector<std::vector<double>> loc(g_threads, std::vector<double>(nf_.size(), 0.0));
+#pragma omp parallel num_threads(g_threads)
+    {
+      std::vector<double>& mine = loc[omp_get_thread_num()];
+#pragma omp for schedule(static)
+      for (int64_t i = 0; i < o.nobs; ++i) {
+        if (o.obs_fixed[i]) continue;
+        const int c = P.obs_cam[i], g = P.cam_group[c];
+        for (int a = 0; a < 2; ++a) { const double* Fr = &o.F[((size_t)i * 2 + a) * FW];
+          for (int q = 0; q < FW; ++q) { const int col = fcol(o, c, g, q); if (col >= 0) mine[col] += Fr[q] * Fr[q]; } }
+      }
+    }
+    for (int t = 0; t < g_threads; ++t) for (size_t d = 0; d < nf_.size(); ++d) nf_[d] += loc[t][d];
+  } else
   for (int64_t i = 0; i < o.nobs; ++i) {
     if (o.obs_fixed[i]) continue;
     const int c = P.obs_cam[i], p = P.obs_pt[i], g = P.cam_group[c];
@@ -735,6 +768,7 @@ void column_norms(Oracle& o, std::vector<double>& nf_, std::vector<double>& np_)
 
 void apply_scaling(Oracle& o) {
   const oba_problem& P = *o.P; const int pd = o.pd;
+  OBA_PAR_FOR
   for (int64_t i = 0; i < o.nobs; ++i) {
     if (o.obs_fixed[i]) continue;
     const int c = P.obs_cam[i], p = P.obs_pt[i], g = P.cam_group[c];
@@ -754,6 +788,25 @@ void apply_scaling(Oracle& o) {
 double compute_gradient(Oracle& o) {
   const oba_problem& P = *o.P; const int pd = o.pd;
   std::vector<double> gf(o.n(), 0.0), gp((size_t)pd * o.np, 0.0);
+  if (g_threads > 1) {
+    OBA_PAR_FOR
+    for (int p = 0; p < o.np; ++p)
+      for (int64_t k = o.pt_off[p]; k < o.pt_off[p + 1]; ++k) { const int64_t i = o.pt_obs[k];
+        for (int a = 0; a < 2; ++a) for (int q = 0; q < pd; ++q) gp[(size_t)pd * p + q] += o.Jp[(size_t)i * 2 * pd + a * pd + q] * o.r[2 * i + a]; }
+    std::vector<std::vector<double>> loc(g_threads, std::vector<double>(gf.size(), 0.0));
+#pragma omp parallel num_threads(g_threads)
+    {
+      std::vector<double>& mine = loc[omp_get_thread_num()];
+#pragma omp for schedule(static)
+      for (int64_t i = 0; i < o.nobs; ++i) {
+        if (o.obs_fixed[i]) continue;
+        const int c = P.obs_cam[i], g = P.cam_group[c];
+        for (int a = 0; a < 2; ++a) { const double ra = o.r[2 * i + a]; const double* Fr = &o.F[((size_t)i * 2 + a) * FW];
+          for (int q = 0; q < FW; ++q) { const int col = fcol(o, c, g, q); if (col >= 0) mine[col] += Fr[q] * ra; } }
+      }
+    }
+    for (int t = 0; t < g_threads; ++t) for (size_t d = 0; d < gf.size(); ++d) gf[d] += loc[t][d];
+  } else
   for (int64_t i = 0; i < o.nobs; ++i) {
     if (o.obs_fixed[i]) continue;
     const int c = P.obs_cam[i], p = P.obs_pt[i], g = P.cam_group[c];
@@ -794,27 +847,36 @@ bool invert_spd(int n, const double* A, double* Ainv) {
   return true;
 }
 
-// dense in-place Cholesky of the lower triangle (row-major), then solve.
+// In-place Cholesky of the lower triangle (row-major), then solve.  The factorisation only visits the ENVELOPE of
+// the matrix (row i from its first structural non-zero f(i) on; the factor has the same envelope): on the banded
+// reduced systems of camera rings this is O(n b^2) instead of O(n^3 / 3).  Entries skipped are exact zeros, so the
+// factor is bitwise that of the plain dense loops; the backward substitution runs row-wise (contiguous memory) and
+// therefore adds its terms in descending row order.
 bool dense_cholesky_solve(int n, std::vector<double>& A, std::vector<double>& b) {
+  std::vector<int> first(n);
+  for (int i = 0; i < n; ++i) { const double* Ai = &A[(size_t)i * n]; int f = 0; while (f < i && Ai[f] == 0.0) ++f; first[i] = f; }
   for (int j = 0; j < n; ++j) {
     double* Aj = &A[(size_t)j * n];
     double d = Aj[j];
-    for (int k = 0; k < j; ++k) d -= Aj[k] * Aj[k];
+    for (int k = first[j]; k < j; ++k) d -= Aj[k] * Aj[k];
     if (!(d > 0.0) || !std::isfinite(d)) return false;
     const double ljj = std::sqrt(d);
     Aj[j] = ljj;
     const double inv = 1.0 / ljj;
     for (int i = j + 1; i < n; ++i) {
+      if (first[i] > j) continue;   // (i, j) outside the envelope: stays zero
       double* Ai = &A[(size_t)i * n];
       double s = Ai[j];
-      for (int k = 0; k < j; ++k) s -= Ai[k] * Aj[k];
+      for (int k = std::max(first[i], first[j]); k < j; ++k) s -= Ai[k] * Aj[k];
       Ai[j] = s * inv;
     }
   }
   for (int i = 0; i < n; ++i) { double s = b[i]; const double* Ai = &A[(size_t)i * n];
-    for (int k = 0; k < i; ++k) s -= Ai[k] * b[k]; b[i] = s / Ai[i]; }
-  for (int i = n - 1; i >= 0; --i) { double s = b[i];
-    for (int k = i + 1; k < n; ++k) s -= A[(size_t)k * n + i] * b[k]; b[i] = s / A[(size_t)i * n + i]; }
+    for (int k = first[i]; k < i; ++k) s -= Ai[k] * b[k]; b[i] = s / Ai[i]; }
+  // backward substitution by columns of L^T = rows of L: x_i known -> subtract from the rows above inside the envelope
+  for (int i = n - 1; i >= 0; --i) { const double* Ai = &A[(size_t)i * n];
+    b[i] /= Ai[i];
+    for (int k = first[i]; k < i; ++k) b[k] -= Ai[k] * b[i]; }
   return true;
 }
 
@@ -823,14 +885,59 @@ bool dense_cholesky_solve(int n, std::vector<double>& A, std::vector<double>& b)
 //   ete = sum E^T E + D_p^2 ; lhs -= (F^T E) ete^-1 (E^T F) ; rhs -= (F^T E) ete^-1 (E^T b)
 // with lhs initialised to F^T F + D_c^2 (groups 1 and 2 = intrinsics and
 // extrinsics blocks, bundle_adjuster.cc:547-563, are NOT eliminated).
+// One point's elimination (ceres SchurEliminator::ChunkDiagonalBlockAndGradient / UpdateRhs / ChunkOuterProduct):
+// V^-1 into o.Vinv, then S and rhs updates.
+static bool eliminate_point(Oracle& o, int p, double radius, std::vector<double>& W, std::vector<int>& wc) {
+  const oba_problem& P = *o.P; const int pd = o.pd; const int n = o.n();
+  const int64_t b0 = o.pt_off[p], b1 = o.pt_off[p + 1];
+  if (b0 == b1) return true;
+  double V[16] = {0}, gp[4] = {0};
+  for (int64_t t = b0; t < b1; ++t) { const int64_t i = o.pt_obs[t];
+    const double* E = &o.Jp[(size_t)i * 2 * pd];
+    for (int a = 0; a < pd; ++a) { for (int b = 0; b < pd; ++b) V[a * pd + b] += E[a] * E[b] + E[pd + a] * E[pd + b];
+      gp[a] += E[a] * o.r[2 * i] + E[pd + a] * o.r[2 * i + 1]; } }
+  for (int a = 0; a < pd; ++a) V[a * pd + a] += o.diag_p[(size_t)pd * p + a] / radius;
+  double* Vi = &o.Vinv[(size_t)p * pd * pd];
+  if (!invert_spd(pd, V, Vi)) return false;
+  const int L = (int)(b1 - b0);
+  W.assign((size_t)L * FW * pd, 0.0); wc.assign((size_t)L * FW, -1);
+  for (int t = 0; t < L; ++t) { const int64_t i = o.pt_obs[b0 + t];
+    const int c = P.obs_cam[i], g = P.cam_group[c];
+    const double* F0 = &o.F[((size_t)i * 2) * FW]; const double* F1 = F0 + FW; const double* E = &o.Jp[(size_t)i * 2 * pd];
+    for (int a = 0; a < FW; ++a) { wc[(size_t)t * FW + a] = fcol(o, c, g, a);
+      for (int b = 0; b < pd; ++b) W[((size_t)t * FW + a) * pd + b] = F0[a] * E[b] + F1[a] * E[pd + b]; } }
+  double Vig[4];
+  for (int a = 0; a < pd; ++a) { double s = 0; for (int b = 0; b < pd; ++b) s += Vi[a * pd + b] * gp[b]; Vig[a] = s; }
+  for (int t = 0; t < L; ++t) {
+    for (int a = 0; a < FW; ++a) { const int ca = wc[(size_t)t * FW + a]; if (ca < 0) continue;
+      const double* Wt = &W[((size_t)t * FW + a) * pd];
+      double WV[4];
+      for (int b = 0; b < pd; ++b) { double s = 0; for (int k = 0; k < pd; ++k) s += Wt[k] * Vi[k * pd + b]; WV[b] = s; }
+      double s0 = 0; for (int b = 0; b < pd; ++b) s0 += Wt[b] * Vig[b];
+      o.rhs[ca] -= s0;
+      for (int u = 0; u < L; ++u) for (int b = 0; b < FW; ++b) { const int cb = wc[(size_t)u * FW + b]; if (cb < 0) continue;
+        const double* Wu = &W[((size_t)u * FW + b) * pd];
+        double s = 0; for (int k = 0; k < pd; ++k) s += WV[k] * Wu[k];
+        o.S[(size_t)ca * n + cb] -= s; }
+    }
+  }
+  return true;
+}
+
 bool build_reduced(Oracle& o, double radius, bool add_cam_diag = true) {
-  const oba_problem& P = *o.P; const int pd = o.pd;
+  const oba_problem& P = *o.P;
   const int n = o.n();
-  o.S.assign((size_t)n * n, 0.0); o.rhs.assign(n, 0.0);
-  o.Vinv.assign((size_t)o.np * pd * pd, 0.0);
-  int cols[FW];
-  for (int64_t i = 0; i < o.nobs; ++i) {
-    if (o.obs_fixed[i]) continue;
+  if (g_threads > 1 && o.S.size() == (size_t)n * n) {   // zero by rows in parallel (also spreads the pages over the NUMA nodes)
+    OBA_PAR_FOR
+    for (int r = 0; r < n; ++r) std::fill(o.S.begin() + (size_t)r * n, o.S.begin() + (size_t)(r + 1) * n, 0.0);
+  } else {
+    o.S.assign((size_t)n * n, 0.0);
+  }
+  o.rhs.assign(n, 0.0);
+  o.Vinv.assign((size_t)o.np * o.pd * o.pd, 0.0);
+  // F^T F and F^T r of one observation
+  auto obs_term = [&](int64_t i) {
+    int cols[FW];
     const int c = P.obs_cam[i], g = P.cam_group[c];
     for (int q = 0; q < FW; ++q) cols[q] = fcol(o, c, g, q);
     const double* F0 = &o.F[((size_t)i * 2) * FW]; const double* F1 = F0 + FW;
@@ -838,6 +945,50 @@ bool build_reduced(Oracle& o, double radius, bool add_cam_diag = true) {
       for (int b = 0; b < FW; ++b) if (cols[b] >= 0)
         o.S[(size_t)cols[a] * n + cols[b]] += F0[a] * F0[b] + F1[a] * F1[b];
       o.rhs[cols[a]] += F0[a] * o.r[2 * i] + F1[a] * o.r[2 * i + 1]; }
+  };
+  bool ok = true;
+  if (g_threads > 1 && o.ni == 0 && o.ncv > 0) {
+    // All-cores baseline (extrinsics only).  Every update of a point touches the S rows of the point's own cameras.
+    // Points are bucketed by their lowest reduced camera into chunks of `width` cameras; a point whose cameras span
+    // less than `width` only writes rows of its own chunk and of the next one, so the even chunks can run
+    // concurrently, then the odd ones; the remaining (far-spanning) points run serially at the end.  Inside a
+    // chunk the order is the serial one: the result does not depend on thread scheduling.
+    std::vector<int> lo(o.np, -1), hi(o.np, -1);
+    for (int p = 0; p < o.np; ++p)
+      for (int64_t k = o.pt_off[p]; k < o.pt_off[p + 1]; ++k) { const int rc = o.cam_red[P.obs_cam[o.pt_obs[k]]];
+        if (rc < 0) continue; if (lo[p] < 0 || rc < lo[p]) lo[p] = rc; if (rc > hi[p]) hi[p] = rc; }
+    int span = 1;
+    { std::vector<int> sp; for (int p = 0; p < o.np; ++p) if (lo[p] >= 0) sp.push_back(hi[p] - lo[p] + 1);
+      if (!sp.empty()) { std::nth_element(sp.begin(), sp.begin() + (sp.size() * 98) / 100, sp.end()); span = sp[(sp.size() * 98) / 100]; } }
+    const int width = std::max(span, (o.ncv + 2 * g_threads - 1) / (2 * g_threads));
+    const int nchunk = (o.ncv + width - 1) / width;
+    std::vector<std::vector<int>> bucket(nchunk);
+    std::vector<int> far;
+    for (int p = 0; p < o.np; ++p) {
+      if (o.pt_off[p] == o.pt_off[p + 1]) continue;
+      if (lo[p] < 0) { far.push_back(p); continue; }   // only constant cameras: no S rows, but V^-1 is still needed
+      if (hi[p] - lo[p] + 1 <= width) bucket[lo[p] / width].push_back(p);
+      else far.push_back(p);
+    }
+    int fail = 0;
+    for (int phase = 0; phase < 2; ++phase) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads) reduction(+ : fail)
+      for (int k = phase; k < nchunk; k += 2) {
+        std::vector<double> W; std::vector<int> wc;
+        for (int p : bucket[k]) {
+          for (int64_t t = o.pt_off[p]; t < o.pt_off[p + 1]; ++t) if (!o.obs_fixed[o.pt_obs[t]]) obs_term(o.pt_obs[t]);
+          if (!o.pt_const[p] && !eliminate_point(o, p, radius, W, wc)) fail++;
+        }
+      }
+    }
+    { std::vector<double> W; std::vector<int> wc;
+      for (int p : far) {
+        for (int64_t t = o.pt_off[p]; t < o.pt_off[p + 1]; ++t) if (!o.obs_fixed[o.pt_obs[t]]) obs_term(o.pt_obs[t]);
+        if (!o.pt_const[p] && !eliminate_point(o, p, radius, W, wc)) fail++;
+      } }
+    ok = fail == 0;
+  } else {
+    for (int64_t i = 0; i < o.nobs; ++i) if (!o.obs_fixed[i]) obs_term(i);
   }
   for (const Oracle::Prior& pr : o.priors) {
     const int base = o.ni + 6 * o.cam_red[pr.cam];
@@ -848,43 +999,13 @@ bool build_reduced(Oracle& o, double radius, bool add_cam_diag = true) {
     }
   }
   if (add_cam_diag) for (int d = 0; d < n; ++d) o.S[(size_t)d * n + d] += o.diag_f[d] / radius;
+  if (g_threads > 1 && o.ni == 0 && o.ncv > 0) return ok;
   // eliminate points
   std::vector<double> W;  // per obs of the point: F^T E (FW x pd)
   std::vector<int> wc;
   for (int p = 0; p < o.np; ++p) {
     if (o.pt_const[p]) continue;
-    const int64_t b0 = o.pt_off[p], b1 = o.pt_off[p + 1];
-    if (b0 == b1) continue;
-    double V[16] = {0}, gp[4] = {0};
-    for (int64_t t = b0; t < b1; ++t) { const int64_t i = o.pt_obs[t];
-      const double* E = &o.Jp[(size_t)i * 2 * pd];
-      for (int a = 0; a < pd; ++a) { for (int b = 0; b < pd; ++b) V[a * pd + b] += E[a] * E[b] + E[pd + a] * E[pd + b];
-        gp[a] += E[a] * o.r[2 * i] + E[pd + a] * o.r[2 * i + 1]; } }
-    for (int a = 0; a < pd; ++a) V[a * pd + a] += o.diag_p[(size_t)pd * p + a] / radius;
-    double* Vi = &o.Vinv[(size_t)p * pd * pd];
-    if (!invert_spd(pd, V, Vi)) return false;
-    const int L = (int)(b1 - b0);
-    W.assign((size_t)L * FW * pd, 0.0); wc.assign((size_t)L * FW, -1);
-    for (int t = 0; t < L; ++t) { const int64_t i = o.pt_obs[b0 + t];
-      const int c = P.obs_cam[i], g = P.cam_group[c];
-      const double* F0 = &o.F[((size_t)i * 2) * FW]; const double* F1 = F0 + FW; const double* E = &o.Jp[(size_t)i * 2 * pd];
-      for (int a = 0; a < FW; ++a) { wc[(size_t)t * FW + a] = fcol(o, c, g, a);
-        for (int b = 0; b < pd; ++b) W[((size_t)t * FW + a) * pd + b] = F0[a] * E[b] + F1[a] * E[pd + b]; } }
-    double Vig[4];
-    for (int a = 0; a < pd; ++a) { double s = 0; for (int b = 0; b < pd; ++b) s += Vi[a * pd + b] * gp[b]; Vig[a] = s; }
-    for (int t = 0; t < L; ++t) {
-      for (int a = 0; a < FW; ++a) { const int ca = wc[(size_t)t * FW + a]; if (ca < 0) continue;
-        const double* Wt = &W[((size_t)t * FW + a) * pd];
-        double WV[4];
-        for (int b = 0; b < pd; ++b) { double s = 0; for (int k = 0; k < pd; ++k) s += Wt[k] * Vi[k * pd + b]; WV[b] = s; }
-        double s0 = 0; for (int b = 0; b < pd; ++b) s0 += Wt[b] * Vig[b];
-        o.rhs[ca] -= s0;
-        for (int u = 0; u < L; ++u) for (int b = 0; b < FW; ++b) { const int cb = wc[(size_t)u * FW + b]; if (cb < 0) continue;
-          const double* Wu = &W[((size_t)u * FW + b) * pd];
-          double s = 0; for (int k = 0; k < pd; ++k) s += WV[k] * Wu[k];
-          o.S[(size_t)ca * n + cb] -= s; }
-      }
-    }
+    if (!eliminate_point(o, p, radius, W, wc)) return false;
   }
   return true;
 }
@@ -893,6 +1014,7 @@ bool build_reduced(Oracle& o, double radius, bool add_cam_diag = true) {
 void back_substitute(Oracle& o) {
   const oba_problem& P = *o.P; const int pd = o.pd;
   o.yp.assign((size_t)o.np * pd, 0.0);
+  OBA_PAR_FOR
   for (int p = 0; p < o.np; ++p) {
     if (o.pt_const[p]) continue;
     double t[4] = {0};
@@ -1027,6 +1149,10 @@ void lm_diagonal(Oracle& o) {
 }  // namespace
 
 extern "C" {
+
+// Threads of the all-cores CPU baseline (1 = the serial reference path of the tests); returns the previous value.
+int oracle_ba_set_threads(int n) { const int prev = g_threads; g_threads = n < 1 ? 1 : n; return prev; }
+int oracle_ba_max_threads() { return omp_get_max_threads(); }
 
 void oracle_ba_options_default(oba_options* o) {
   std::memset(o, 0, sizeof(*o));
@@ -1170,6 +1296,7 @@ int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
     if (solved) {
       back_substitute(o);
       // step = -y ; model_residuals = Js * step ; mcc = -m.(r + m/2)
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1) reduction(+ : model_cost_change)
       for (int64_t i = 0; i < o.nobs; ++i) { if (o.obs_fixed[i]) continue;
         const int c = P->obs_cam[i], p = P->obs_pt[i], g = P->cam_group[c];
         for (int a = 0; a < 2; ++a) { double m = 0;
@@ -1201,6 +1328,7 @@ int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
     for (int c = 0; c < o.nc; ++c) { const int rc2 = o.cam_red[c]; if (rc2 < 0) continue;
       for (int q = 0; q < 6; ++q) if (!((o.cam_mask[c] >> q) & 1))
         o.ccam[6 * c + q] = o.cam[6 * c + q] + (-o.yc[o.ni + 6 * rc2 + q]) * o.scale_f[o.ni + 6 * rc2 + q]; }
+    OBA_PAR_FOR
     for (int p = 0; p < o.np; ++p) { if (o.pt_const[p]) continue;
       double d[4]; for (int q = 0; q < pd; ++q) d[q] = -o.yp[(size_t)pd * p + q] * o.scale_p[(size_t)pd * p + q];
       if (pd == 3) sphere_plus(&o.pts[4 * p], d, &o.cpts[4 * p]);

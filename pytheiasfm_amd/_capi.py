@@ -126,7 +126,8 @@ class RansacResult(C.Structure):
                 ("inlier_mask", c_uint8_p), ("num_iterations", c_int32_p),
                 ("confidence", c_double_p),
                 ("hypotheses_evaluated", C.c_int64), ("models_scored", C.c_int64),
-                ("time_fit_score_seconds", C.c_double), ("num_lo_iterations", c_int32_p)]
+                ("time_fit_score_seconds", C.c_double), ("num_lo_iterations", c_int32_p),
+                ("time_fit_seconds", C.c_double), ("time_score_seconds", C.c_double)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
@@ -137,7 +138,7 @@ EXPORTED_SYMBOLS = [
     "theia_hip_version", "theia_ba_options_default", "theia_hip_ba_solve", "theia_hip_ba_views_batch", "theia_hip_ba_two_views_angular_batch", "theia_hip_optimize_homography_batch", "theia_hip_optimize_fundamental_matrix_batch", "theia_hip_ba_tracks_batch", "theia_hip_track_statistics", "theia_hip_ba_create",
     "theia_hip_ba_reset_parameters", "theia_hip_estimate_tracks", "theia_hip_ba_set_shard", "theia_hip_ba_snapshot_parameters", "theia_hip_ba_restore_parameters", "theia_hip_ba_set_options", "theia_hip_ba_run", "theia_hip_ba_download",
     "theia_hip_ba_destroy", "theia_hip_ba_covariance", "theia_hip_ba_evaluate", "theia_hip_ba_evaluate_ex", "theia_hip_ba_reduced_system",
-    "theia_hip_ba_set_allreduce", "theia_hip_dense_spd_solve", "theia_ransac_params_default",
+    "theia_hip_ba_set_allreduce", "theia_hip_ba_plan_info", "theia_hip_dense_spd_solve", "theia_ransac_params_default",
     "theia_hip_ransac_estimate_batch", "theia_hip_five_point_relative_pose",
     "theia_hip_pose_from_three_points", "theia_hip_sqpnp",
 ]

@@ -61,6 +61,15 @@ class BaHandle:
         L.theia_hip_ba_set_shard.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         capi.check(L.theia_hip_ba_set_shard(self._h, int(rank), int(world_size)))
 
+    def plan_info(self):
+        """theia_hip_ba_plan_info: reduced size, K3 levels / flops per solve, fused-kernel runs, slow-path tracks."""
+        L = capi.lib()
+        L.theia_hip_ba_plan_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        n = C.c_int32(0); lv = C.c_int32(0); fl = C.c_double(0.0); runs = C.c_int32(0); slow = C.c_int32(0)
+        capi.check(L.theia_hip_ba_plan_info(self._h, C.byref(n), C.byref(lv), C.byref(fl), C.byref(runs), C.byref(slow)))
+        return {"n": n.value, "k3_levels": lv.value, "k3_flops": fl.value, "fused_runs": runs.value, "slow_path_tracks": slow.value}
+
     def snapshot(self):
         """Keep a device-resident copy of the current parameters (theia_hip_ba_snapshot_parameters)."""
         L = capi.lib()

@@ -128,6 +128,11 @@ void launch_linearize_fused(const DevProblem& P, const double* cam, const double
 void launch_cam_prep(const DevProblem& P, const double* cam, const double* intr, double* camrot, hipStream_t st);
 void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,
                          const int* field_is_max, double* scal, hipStream_t st);
+// first stage of a two-stage reduction: kReduceBlocks workgroups fold contiguous slices of the per-tile partials into
+// out[kReduceBlocks][nfields] (fixed order); the one-workgroup consumers then reduce kReduceBlocks rows instead of ntiles
+constexpr int kReduceBlocks = 128;
+void launch_reduce_tiles_stage1(int ntiles, const double* tile_part, int nfields, const int* field_is_max, double* out,
+                                hipStream_t st);
 // camera priors (ba_priors.h).  mode: PRIOR_COLNORM adds the squared column norms of their (unscaled) Jacobians
 // to colsq_c[nc][6]; PRIOR_LINEARIZE adds J'J / J'r / g / column norms / cost to the reduced system at `cam`;
 // PRIOR_TRIAL adds the model-cost change of the step y and the cost at `cand_cam` to scal_cost / scal_mcc;
@@ -172,7 +177,10 @@ void dense_cholesky_solve(int n, double* A, int lda, double* b, double* work, do
 struct CholPlan;
 CholPlan* chol_plan_create(int n, const uint8_t* adj);
 void chol_plan_destroy(CholPlan* plan);
+// zero the tiles of A the plan's assembly / factorisation touch; false = dense plan (the caller clears everything)
+bool chol_plan_clear(const CholPlan* plan, double* A, int lda, hipStream_t st);
 int chol_plan_levels(const CholPlan* plan);
+double chol_plan_flops(const CholPlan* plan);   // FP64 flops of one solve on the plan (n^3 / 3 for the dense schedule)
 void chol_plan_solve(const CholPlan* plan, double* A, int lda, double* b, double* work, double* fail_flag, hipStream_t st);
 
 #ifdef __HIPCC__

@@ -762,6 +762,40 @@ __global__ __launch_bounds__(1024) void k_reduce_tiles(int ntiles, const double*
   reduce_tiles_body(ntiles, part, nfields, f2s, fmaxflag, scal, sm);
 }
 
+__global__ __launch_bounds__(256) void k_reduce_tiles_stage1(int ntiles, const double* __restrict__ part, int nfields,
+                                                             const int* __restrict__ fmaxflag, double* __restrict__ out) {
+  __shared__ double sm[8][4];
+  const int nb = gridDim.x, b = blockIdx.x;
+  const int per = (ntiles + nb - 1) / nb;
+  const int t0 = b * per, t1 = min(ntiles, t0 + per);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  double acc[8];
+  bool ismax[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) { acc[f] = 0.0; ismax[f] = f < nfields && fmaxflag[f] != 0; }
+  for (int t = t0 + (int)threadIdx.x; t < t1; t += 256) {
+    const double* row = part + (size_t)t * nfields;
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+      if (f < nfields) { const double v = row[f]; acc[f] = ismax[f] ? fmax(acc[f], v) : acc[f] + v; }
+  }
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    if (f >= nfields) break;
+    double v = acc[f];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(v, off, 64); v = ismax[f] ? fmax(v, o) : v + o; }
+    if (lane == 0) sm[f][wv] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nfields) {
+    const int f = threadIdx.x;
+    double v = sm[f][0];
+    for (int w = 1; w < 4; ++w) v = ismax[f] ? fmax(v, sm[f][w]) : v + sm[f][w];
+    out[(size_t)b * nfields + f] = v;
+  }
+}
+
 // Add the LM diagonal to the camera-side blocks (intrinsics + extrinsics) and
 // fold their gradient into the gradient max-norm: S_dd += clamp(colsq_d) / radius.
 // One workgroup of 1024 threads; with tile_part it starts with the tile reduction of the linearisation.
@@ -1370,6 +1404,11 @@ void launch_cam_priors(const DevProblem& P, int mode, const double* cam, const d
 void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,
                          const int* field_is_max, double* scal, hipStream_t st) {
   k_reduce_tiles<<<1, 1024, 0, st>>>(ntiles, tile_part, nfields, field_to_scal, field_is_max, scal);
+}
+
+void launch_reduce_tiles_stage1(int ntiles, const double* tile_part, int nfields, const int* field_is_max, double* out,
+                                hipStream_t st) {
+  k_reduce_tiles_stage1<<<kReduceBlocks, 256, 0, st>>>(ntiles, tile_part, nfields, field_is_max, out);
 }
 
 void launch_finalize_rcs(const DevProblem& P, const double* radius, const ReduceBuf& rb, hipStream_t st, int ntiles,

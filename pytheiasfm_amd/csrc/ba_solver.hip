@@ -126,7 +126,7 @@ struct theia_ba_handle_s {
   DevBuf<uint8_t> d_cam_mask, d_pt_const;
   DevBuf<double2> obs_uv, obs_si;
   DevBuf<uint8_t> obs_kind;
-  DevBuf<double> reduce, Vinv, gp, tile_part, scalB, chol_work;
+  DevBuf<double> reduce, Vinv, gp, tile_part, red_part, scalB, chol_work;
   DevBuf<double> rec;                       // per-observation records of the gather-based Schur assembly
   DevBuf<int> diag_items, cam_obs, blk_items, slot_obs, slot_pt;
   DevBuf<int> prior_cam, prior_kind;        // camera priors in use (compact list)
@@ -548,7 +548,12 @@ int compute_scale(theia_ba_handle_s* h) {
 int enqueue_linearize(theia_ba_handle_s* h, int slot = 0) {
   const double* radius = &reinterpret_cast<const LmState*>(h->lm_state.p)->radius;
   h->P.intr = h->intr[h->cur].p; h->P.intr_cand = h->intr[1 - h->cur].p;
-  HIP_TRY(hipMemsetAsync(h->reduce.p, 0, sizeof(double) * h->reduce.n, h->stream));
+  // clear the reduced system: the tiles the K3 plan knows (assembly + fill) and the vector tail; everything else in
+  // the n x n buffer is never written (it was zeroed once at create())
+  if (h->n > 0 && !(h->allreduce && h->n_pack_tiles == 0) && chol_plan_clear(h->plan, h->rb.S, h->n, h->stream))
+    HIP_TRY(hipMemsetAsync(h->rb.rhs, 0, sizeof(double) * (h->reduce.n - (size_t)h->n * h->n), h->stream));
+  else
+    HIP_TRY(hipMemsetAsync(h->reduce.p, 0, sizeof(double) * h->reduce.n, h->stream));
   if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][4], h->stream));
   launch_linearize(h->P, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->tile_part.p, h->stream);
   if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][5], h->stream));
@@ -575,7 +580,10 @@ int enqueue_linearize(theia_ba_handle_s* h, int slot = 0) {
   }
   if (!rc && !max_done) rc = do_allreduce(h, h->rb.scal + 8, 8, THEIA_REDUCE_MAX);
   if (rc) return rc;
-  if (fuse_reduce) launch_finalize_rcs(h->P, radius, h->rb, h->stream, h->ntiles_main, h->tile_part.p, h->f2s.p, h->fmaxflag.p);
+  if (fuse_reduce && h->ntiles_main > 4 * kReduceBlocks) {   // two stages: one workgroup over 50k tile rows costs 45 us
+    launch_reduce_tiles_stage1(h->ntiles_main, h->tile_part.p, 4, h->fmaxflag.p, h->red_part.p, h->stream);
+    launch_finalize_rcs(h->P, radius, h->rb, h->stream, kReduceBlocks, h->red_part.p, h->f2s.p, h->fmaxflag.p);
+  } else if (fuse_reduce) launch_finalize_rcs(h->P, radius, h->rb, h->stream, h->ntiles_main, h->tile_part.p, h->f2s.p, h->fmaxflag.p);
   else launch_finalize_rcs(h->P, radius, h->rb, h->stream);
   return 0;
 }
@@ -614,6 +622,7 @@ int sync_plan(theia_ba_handle_s* h) {
   if (h->plan) chol_plan_destroy(h->plan);
   h->plan = chol_plan_create(h->n, h->tile_adj.data());
   h->plan_is_global = true;
+  HIP_TRY(hipMemsetAsync(h->reduce.p, 0, sizeof(double) * h->reduce.n, h->stream));   // tiles only the old plan touched
   {
     std::vector<int2> tiles;
     for (int i = 0; i < nt; ++i)
@@ -1304,6 +1313,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   }
   const size_t nn = (size_t)h->n * h->n;
   AL(reduce, nn + 3 * (size_t)h->n + SC_COUNT);
+  if (h->reduce.n) HIP_TRY(hipMemsetAsync(h->reduce.p, 0, sizeof(double) * h->reduce.n, st));
   h->rb.base = h->reduce.p; h->rb.count = h->reduce.n;
   h->rb.S = h->reduce.p; h->rb.rhs = h->rb.S + nn; h->rb.colsq = h->rb.rhs + h->n; h->rb.gc = h->rb.colsq + h->n;
   h->rb.scal = h->rb.gc + h->n;
@@ -1311,7 +1321,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   // constant points are never written: the Schur readers rebuild T = W V^-1 from these arrays and need zeros there
   if (h->Vinv.n) HIP_TRY(hipMemsetAsync(h->Vinv.p, 0, sizeof(double) * h->Vinv.n, st));
   if (h->gp.n) HIP_TRY(hipMemsetAsync(h->gp.p, 0, sizeof(double) * h->gp.n, st));
-  AL(tile_part, (size_t)5 * std::max(1, h->ntiles_all)); AL(scalB, 16);
+  AL(tile_part, (size_t)5 * std::max(1, h->ntiles_all)); AL(scalB, 16); AL(red_part, (size_t)8 * kReduceBlocks);
   AL(chol_work, dense_cholesky_workspace(h->n));
   AL(lm_state, sizeof(LmState)); AL(lm_ctl, sizeof(LmCtl));
   tick("allocations + uploads");
@@ -1481,6 +1491,17 @@ int theia_hip_ba_set_allreduce(theia_ba_handle h, theia_allreduce_fn fn, void* c
   return 0;
 }
 
+int theia_hip_ba_plan_info(theia_ba_handle h, int32_t* n, int32_t* k3_levels, double* k3_flops, int32_t* fused_runs,
+                           int32_t* slow_path_tracks) {
+  if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
+  if (n) *n = h->n;
+  if (k3_levels) *k3_levels = chol_plan_levels(h->plan);
+  if (k3_flops) *k3_flops = chol_plan_flops(h->plan);
+  if (fused_runs) *fused_runs = h->use_fused ? h->n_fruns : 0;
+  if (slow_path_tracks) *slow_path_tracks = h->long_ntracks;
+  return 0;
+}
+
 int theia_hip_ba_download(theia_ba_handle h, theia_ba_problem* p) {
   if (!h || !p) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
   // caller-owned (pageable) destinations: drain the stream, then blocking copies
@@ -1551,7 +1572,10 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
     const bool fuse = !h->allreduce && slot < 0 && h->ntiles_main > 0;   // tile reduction inside the control kernel
     if ((r = enqueue_solve_and_backsub(h, slot, fuse))) return r;
     if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][3], h->stream));
-    if (fuse) k_reduce_control<<<1, 1024, 0, h->stream>>>(h->ntiles_main, h->tile_part.p, h->f2s.p + 8, h->fmaxflag.p + 8, dst, h->rb.scal, h->scalB.p, dctl);
+    if (fuse && h->ntiles_main > 4 * kReduceBlocks) {
+      launch_reduce_tiles_stage1(h->ntiles_main, h->tile_part.p, 5, h->fmaxflag.p + 8, h->red_part.p, h->stream);
+      k_reduce_control<<<1, 1024, 0, h->stream>>>(kReduceBlocks, h->red_part.p, h->f2s.p + 8, h->fmaxflag.p + 8, dst, h->rb.scal, h->scalB.p, dctl);
+    } else if (fuse) k_reduce_control<<<1, 1024, 0, h->stream>>>(h->ntiles_main, h->tile_part.p, h->f2s.p + 8, h->fmaxflag.p + 8, dst, h->rb.scal, h->scalB.p, dctl);
     else k_lm_control<<<1, 1, 0, h->stream>>>(dst, h->rb.scal, h->scalB.p, dctl);
     k_lm_accept<<<256, 256, 0, h->stream>>>(dst, h->cam[0].p, h->cam[nxt].p, (size_t)6 * h->nc, h->pts[0].p, h->pts[nxt].p,
                                             (size_t)4 * h->np, h->intr[0].p, h->intr[nxt].p, h->ni ? (size_t)THEIA_MAX_INTRINSICS * h->ng : 0);

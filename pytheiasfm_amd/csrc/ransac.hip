@@ -783,6 +783,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
                     !result->num_iterations || !result->confidence))
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null result array");
   result->hypotheses_evaluated = 0; result->models_scored = 0; result->time_fit_score_seconds = 0.0;
+  result->time_fit_seconds = 0.0; result->time_score_seconds = 0.0;
   if (nprob == 0) return 0;
   int rc = ensure_device();
   if (rc) return rc;
@@ -799,9 +800,10 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   hipStream_t st;
   HIP_TRYR(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sguard{st};
-  hipEvent_t ev0, ev1;
-  HIP_TRYR(hipEventCreate(&ev0)); HIP_TRYR(hipEventCreate(&ev1));
-  struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } eguard{ev0, ev1};
+  hipEvent_t ev0, ev1, evm;
+  HIP_TRYR(hipEventCreate(&ev0)); HIP_TRYR(hipEventCreate(&ev1)); HIP_TRYR(hipEventCreate(&evm));
+  struct EvGuard { hipEvent_t a, b, c; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c); } } eguard{ev0, ev1, evm};
+  double fit_ms = 0.0, score_ms = 0.0;
 
   DBuf<double> d_data; DBuf<int64_t> d_off;
   if ((rc = d_data.ensure((size_t)total * ds)) || (rc = d_off.ensure(nprob + 1))) return rc;
@@ -1001,6 +1003,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         }
 #undef THIP_FIT
       }
+      HIP_TRYR(hipEventRecord(evm, st));
       if (lmed) {
         dim3 grid(B * kMaxModels, cn);
         k_score_lmed<<<grid, 256, lmed_lds, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_models.p, d_dense.p, d_tags.p, d_cost.p, d_ninl.p);
@@ -1019,7 +1022,9 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       HIP_TRYR(hipGetLastError());
       HIP_TRYR(hipStreamSynchronize(st));
       scratch_lock.unlock();
-      { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) fit_score_ms += ms; }
+      { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) fit_score_ms += ms;
+        if (hipEventElapsedTime(&ms, ev0, evm) == hipSuccess) fit_ms += ms;
+        if (hipEventElapsedTime(&ms, evm, ev1) == hipSuccess) score_ms += ms; }
       // sequential replay of the acceptance rules (sample_consensus_estimator.h:330-394).  With
       // use_lo a problem pauses at each RefineModel event; the events of all problems are refined
       // as one batch, then every replay resumes where it stopped.
@@ -1172,6 +1177,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     result->confidence[p] = 1.0 - std::pow(1.0 - std::pow(inlier_ratio, (double)m), (double)s.it);
   }
   result->time_fit_score_seconds = fit_score_ms * 1e-3;
+  result->time_fit_seconds = fit_ms * 1e-3; result->time_score_seconds = score_ms * 1e-3;
   return 0;
 }
 

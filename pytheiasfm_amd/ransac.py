@@ -132,7 +132,8 @@ def estimate_batch(estimator, data, offsets, params, estimator_params=None):
     capi.check(L.theia_hip_ransac_estimate_batch(C.byref(b), C.byref(pc), C.byref(r)))
     return {"success": success[:P], "models": models[:P], "num_inliers": ninl[:P], "inlier_mask": mask[:total],
             "num_iterations": nit[:P], "confidence": conf[:P], "num_lo_iterations": nlo[:P], "hypotheses_evaluated": r.hypotheses_evaluated,
-            "models_scored": r.models_scored, "time_fit_score_seconds": r.time_fit_score_seconds}
+            "models_scored": r.models_scored, "time_fit_score_seconds": r.time_fit_score_seconds,
+            "time_fit_seconds": r.time_fit_seconds, "time_score_seconds": r.time_score_seconds}
 
 
 def _single(estimator, ransac_params, ransac_type, data, estimator_params=None):
@@ -290,49 +291,3 @@ def SQPnP(feature_positions, world_points):
     if single:
         return bool(ns[0] > 0), [q[0, k] for k in range(ns[0])], [t[0, k] for k in range(ns[0])]
     return ns, q, t
-
-
-def smoke_check():
-    """Small batch through the C-ABI, checked against the oracle (inlier sets
-    bit-identical under the same seed)."""
-    from . import synth
-    from tests import oracle_lib as ol
-    data, offsets, _ = synth.synth_ransac_v1(4, 200, "relative", seed=0x5AC50001)
-    p = RansacParameters(); p.error_thresh = (2.0 / 1000.0) ** 2; p.min_iterations = 64; p.max_iterations = 64; p.seed = 65
-    res = estimate_batch(EST_RELATIVE_POSE, data, offsets, p)
-    for i in range(4):
-        pc = p.to_c(); pc.seed = p.seed + i
-        o = ol.ransac_estimate(EST_RELATIVE_POSE, data[offsets[i]:offsets[i + 1]], pc)
-        assert np.array_equal(o["inlier_mask"], res["inlier_mask"][offsets[i]:offsets[i + 1]]), f"inlier set differs on problem {i}"
-        assert o["num_iterations"] == res["num_iterations"][i]
-    print(f"smoke RANSAC ok: 4 problems x 64 hypotheses, inlier sets identical to the oracle ({res['num_inliers']})")
-
-
-def bench(cpu_baseline=True, problems=256, corr=2000, hyps=4096):
-    """RANSAC hypotheses/s on a bounded slice of BASELINE.json configs[4]
-    (2k correspondences / pair, 4096 hypotheses, FivePointRelativePose)."""
-    from . import synth
-    data, offsets, _ = synth.synth_ransac_v1(problems, corr, "relative", seed=0x5AC50005)
-    p = RansacParameters(); p.error_thresh = (2.0 / 1000.0) ** 2; p.min_iterations = hyps; p.max_iterations = hyps; p.seed = 1
-    estimate_batch(EST_RELATIVE_POSE, data[: offsets[8]], offsets[:9], p)  # warm-up
-    t0 = time.perf_counter()
-    res = estimate_batch(EST_RELATIVE_POSE, data, offsets, p)
-    dt = time.perf_counter() - t0
-    out = {"workload": f"synth_ransac_v1: {problems} pairs x {corr} correspondences x {hyps} hypotheses, five-point relative pose, InlierSupport",
-           "hypotheses_per_sec": res["hypotheses_evaluated"] / dt,
-           "hypotheses_per_sec_kernels_only": res["hypotheses_evaluated"] / max(res["time_fit_score_seconds"], 1e-12),
-           "models_scored": int(res["models_scored"]), "wall_s": dt, "kernel_s": res["time_fit_score_seconds"],
-           "note": "wall time includes the PCIe upload of correspondences, host sample generation and host replay"}
-    if cpu_baseline:
-        from tests import oracle_lib as ol
-        pc = p.to_c(); pc.min_iterations = 2048; pc.max_iterations = 2048
-        t0 = time.perf_counter()
-        nprob = 64
-        for i in range(nprob):
-            pc.seed = p.seed + i
-            ol.ransac_estimate(EST_RELATIVE_POSE, data[offsets[i]:offsets[i + 1]], pc)
-        dtc = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": nprob * 2048 / dtc, "unit": "hypotheses/s", "cores": 1, "kind": "port",
-                               "sample": f"{nprob} pairs x 2048 hypotheses x {corr} correspondences (oracle/ransac_oracle.cpp), {dtc:.1f} s"}
-        out["speedup_vs_cpu_baseline"] = out["hypotheses_per_sec"] / out["cpu_baseline"]["value"]
-    return out

@@ -42,4 +42,4 @@ for kind, est, thr in (("relative", 0, (2 / 1000.0) ** 2), ("relative", 1, (2 / 
             if not ok:
                 print("  mismatch", i, o["num_iterations"], res["num_iterations"][i], o["num_inliers"], res["num_inliers"][i])
         print(f"est {est} mle {use_mle}: mismatching problems {nbad}/8; iters {res['num_iterations']} inliers {res['num_inliers']} true {truth['inlier'].sum(1)} time {dt:.3f}")
-print(ransac.bench(cpu_baseline=True, problems=64))
+# (the RANSAC throughput bench lives in bench.py: ransac_block)

@@ -353,3 +353,12 @@ def optimize_fundamental(corr, F, options):
                                   capi.ptr(Fm, C.c_double), capi.ptr(oi, C.c_int32), capi.ptr(oc, C.c_double))
     return Fm.reshape(3, 3), dict(success=int(oi[0]), termination_type=int(oi[1]), num_iterations=int(oi[2]),
                                   num_successful_steps=int(oi[3]), initial_cost=float(oc[0]), final_cost=float(oc[1]))
+
+
+def set_threads(n):
+    """Threads of the oracle's all-cores BA baseline mode (1 = the serial reference path); returns the previous value."""
+    return int(load().oracle_ba_set_threads(int(n)))
+
+
+def max_threads():
+    return int(load().oracle_ba_max_threads())
