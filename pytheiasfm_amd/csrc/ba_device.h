@@ -93,8 +93,16 @@ THIP_DEV void rotation_dq_dw(const double w[3], const double p[3], const RotTerm
 // (sqrt_information * (rotated_point[2] - depth_prior), 0) with the matching Jacobian rows.
 constexpr int THIP_MODEL_DEPTH_ROW = 1000;
 
-template <bool WANT_JAC, bool WANT_KJAC = false>
+// MODELS: compile-time set of camera models a kernel instance carries (bit = THEIA_CAM_*).  The FOV and fisheye
+// models evaluate tan / atan / atan2, whose polynomial constants the compiler hoists into registers for the whole
+// kernel; instances for problems without them (kModelsNoTrig) shed that register pressure and code.
+constexpr unsigned kModelsAll = 0xffu;
+constexpr unsigned kModelsNoTrig = 0xffu & ~((1u << THEIA_CAM_FOV) | (1u << THEIA_CAM_FISHEYE));
+template <bool WANT_JAC, bool WANT_KJAC = false, unsigned MODELS = kModelsAll>
 THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2], double Jq[6], double* Jk = nullptr) {
+  if constexpr (MODELS != kModelsAll) {
+    if (model >= 0 && model < 8 && !((MODELS >> model) & 1u)) model = -1;   // not in this instance: the default branch
+  }
   if (model == THIP_MODEL_DEPTH_ROW) {
     uv[0] = q[2]; uv[1] = 0.0;
     if (WANT_JAC) { Jq[0] = 0.0; Jq[1] = 0.0; Jq[2] = 1.0; Jq[3] = 0.0; Jq[4] = 0.0; Jq[5] = 0.0; }
@@ -156,6 +164,7 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
       }
       break; }
     case THEIA_CAM_FOV: {
+      if constexpr ((MODELS >> THEIA_CAM_FOV) & 1u) {
       // fov_camera_model.h:156-258  [f a cx cy omega]
       planar = true;
       x = q[0] / q[2]; y = q[1] / q[2];
@@ -185,6 +194,7 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
       dx = rd * x; dy = rd * y;
       if (WANT_KJAC) { pdx[4] = gw * x; pdy[4] = gw * y; }
       if (WANT_JAC) { dxx = rd + 2.0 * x * x * g; dxy = 2.0 * x * y * g; dyx = dxy; dyy = rd + 2.0 * y * y * g; }
+      }
       break; }
     case THEIA_CAM_ORTHOGRAPHIC: {
       // orthographic_camera_model.h:162-240: distortion on (q0, q1), no depth division
@@ -199,6 +209,7 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
       if (WANT_KJAC) { pdx[5] = q[0] * r2; pdy[5] = q[1] * r2; pdx[6] = q[0] * r2 * r2; pdy[6] = q[1] * r2 * r2; }
       break; }
     case THEIA_CAM_FISHEYE: {
+      if constexpr ((MODELS >> THEIA_CAM_FISHEYE) & 1u) {
       // fisheye_camera_model.h:163-272  [.., k1 k2 k3 k4]
       const double r2 = q[0] * q[0] + q[1] * q[1];
       if (r2 < 1e-8) {
@@ -228,6 +239,7 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
 #pragma unroll
           for (int i = 0; i < 4; ++i) { pdx[5 + i] = sgn * tp * q[0] / r; pdy[5 + i] = sgn * tp * q[1] / r; tp *= t2; }
         }
+      }
       }
       break; }
     case THEIA_CAM_DOUBLE_SPHERE: {
@@ -365,7 +377,7 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
 // Residual (and optionally Jacobians) of one observation.
 // `t` = rotation_terms(ext + 3): per-camera quantities, computed per observation by observe() or once per camera and
 // iteration by the callers that keep them in HBM (ba_fused.hip: k_cam_prep).
-template <bool WANT_JAC, bool WANT_KJAC = false, typename OL = ObsLin>
+template <bool WANT_JAC, bool WANT_KJAC = false, typename OL = ObsLin, unsigned MODELS = kModelsAll>
 THIP_DEV void observe_rot(int model, const double* ext, const RotTerms& t, const double* intr, const double X[4],
                           double u0, double v0, double six, double siy, OL& o) {
   const double p[3] = {X[0] - X[3] * ext[0], X[1] - X[3] * ext[1], X[2] - X[3] * ext[2]};
@@ -381,10 +393,10 @@ THIP_DEV void observe_rot(int model, const double* ext, const RotTerms& t, const
                        t.R[6] * p[0] + t.R[7] * p[1] + t.R[8] * p[2]};
   double uv[2], Jq[6];
   if constexpr (WANT_KJAC) {
-    o.valid = project<WANT_JAC, true>(model, intr, q, uv, Jq, o.Jk);
+    o.valid = project<WANT_JAC, true, MODELS>(model, intr, q, uv, Jq, o.Jk);
     for (int i = 0; i < THEIA_MAX_INTRINSICS; ++i) { o.Jk[i] *= six; o.Jk[THEIA_MAX_INTRINSICS + i] *= siy; }
   } else {
-    o.valid = project<WANT_JAC, false>(model, intr, q, uv, Jq);
+    o.valid = project<WANT_JAC, false, MODELS>(model, intr, q, uv, Jq);
   }
   o.r[0] = six * (uv[0] - u0);
   o.r[1] = siy * (uv[1] - v0);

@@ -29,6 +29,9 @@
 // V^-1 out, and the partial blocks (ntgt * 288 B + W * 432 B per run, written and read once).
 #include "ba_lane.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace thip {
 namespace {
 
@@ -78,7 +81,7 @@ template <int PD> constexpr int rec_doubles() { return PD == 3 ? 22 : 26; }
 // {F | Ehat | r} and the track's slot-table row in LDS.  NOT inlined on purpose: the caller keeps 45 FP64 accumulators
 // alive across this phase; as a call they are saved once around it (callee-saved registers) instead of pushing the
 // register allocation of the pair-product loop into scratch.
-template <int PD, int TPS>
+template <int PD, int TPS, unsigned MODELS>
 __device__ THIP_PHASE_L_ATTR void fused_phase_l(const DevProblem* __restrict__ Pp, const FusedRun* __restrict__ runp,
                                                         const double* __restrict__ pts, double inv_radius, int sc,
                                                         double* __restrict__ Vinv, double* __restrict__ tile_part,
@@ -95,7 +98,7 @@ __device__ THIP_PHASE_L_ATTR void fused_phase_l(const DevProblem* __restrict__ P
       const int start = tile_ok ? P.tile_start[tile] : 0;
       const bool active = lane < cnt && !(P.fused_dbg & 2);
       LaneLin<PD> L;
-      lane_linearize<PD, true, false, true>(P, P.camrot, pts, start + lane, active, lane, L);
+      lane_linearize<PD, true, false, true, MODELS>(P, P.camrot, pts, start + lane, active, lane, L);
       const Segment sg = lane_segment(L.p, lane);
       double tot[NT + PD];
 #pragma unroll
@@ -179,7 +182,7 @@ __device__ THIP_PHASE_L_ATTR void fused_phase_l(const DevProblem* __restrict__ P
 }
 
 // tile_part layout as k_lin_obs: [ntiles][4] = {cost, gmax_points, invalid, notpd}
-template <int PD, int TPS>
+template <int PD, int TPS, unsigned MODELS>
 __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevProblem P, const double* __restrict__ pts,
                                                            const double* __restrict__ radius_p,
                                                            double* __restrict__ Vinv, double* __restrict__ tile_part) {
@@ -197,12 +200,17 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
 
   __shared__ DevProblem s_P;     // phase L is a real call: it reads the problem through these LDS copies
   __shared__ FusedRun s_run;
-  const FusedRun run = P.fruns[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) { s_P = P; s_run = run; }
-  const int nsc = (run.ntiles + TPS - 1) / TPS;
+  if (tid == 0) s_P = P;
   const double radius = *radius_p;
   const double inv_radius = 1.0 / radius;
+  // persistent workgroups: a few hundred of them walk the runs round robin (per-workgroup set-up -- and what the
+  // register allocator parks in scratch at entry -- is paid once per workgroup, not once per run)
+  for (int run_idx = blockIdx.x; run_idx < P.n_fruns; run_idx += gridDim.x) {
+  const FusedRun run = P.fruns[run_idx];
+  __syncthreads();   // the previous run's slice combination is done with the LDS scratch (and s_run)
+  if (tid == 0) s_run = run;
+  const int nsc = (run.ntiles + TPS - 1) / TPS;
   __syncthreads();
 
   // ---- phase-S role: which target block / per-camera row this lane owns, which tracks it walks
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
 
   for (int sc = 0; sc < nsc; ++sc) {
     // ------------------------------------------------------------------ phase L: lane = observation
-    fused_phase_l<PD, TPS>(&s_P, &s_run, pts, inv_radius, sc, Vinv, tile_part, s_rec, s_ghat, s_tslot, s_tmask);
+    fused_phase_l<PD, TPS, MODELS>(&s_P, &s_run, pts, inv_radius, sc, Vinv, tile_part, s_rec, s_ghat, s_tslot, s_tmask);
     __syncthreads();
     // ------------------------------------------------------------------ phase S: lane = target block
     if (!(P.fused_dbg & 1)) {
@@ -348,6 +356,7 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
 #pragma unroll
     for (int q = 0; q < 9; ++q) od[q] = v[q];
   }
+  }   // runs of this workgroup
 }
 
 // One wave per S block (ri, rj): the partial blocks of the runs that touch it are added in run order and the block
@@ -395,8 +404,16 @@ void launch_linearize_fused(const DevProblem& P, const double* cam, const double
                             const ReduceBuf& rb, double* Vinv, double* tile_part, hipStream_t st) {
   if (P.n_fruns == 0) return;
   launch_cam_prep(P, cam, P.intr, P.camrot, st);
-  if (P.pd == 3) k_lin_schur<3, 4><<<P.n_fruns, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
-  else k_lin_schur<4, 4><<<P.n_fruns, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
+  static const int wgs = [] { const char* e = getenv("THEIA_HIP_FUSED_WGS"); return e ? std::max(1, atoi(e)) : 512; }();   // 2 per CU
+  const int grid = std::min(P.n_fruns, wgs);
+  const bool trig = (P.model_mask & ~kModelsNoTrig) != 0;   // FOV / fisheye groups present
+  if (P.pd == 3) {
+    if (trig) k_lin_schur<3, 4, kModelsAll><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
+    else k_lin_schur<3, 4, kModelsNoTrig><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
+  } else {
+    if (trig) k_lin_schur<4, 4, kModelsAll><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
+    else k_lin_schur<4, 4, kModelsNoTrig><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
+  }
   if (P.n_sum_items)
     k_schur_sum<<<(P.n_sum_items + 3) / 4, 256, 0, st>>>(P.n_sum_items, P.sum_items, P.sum_src, P.fpart, rb.S, P.n, rb.rhs,
                                                          rb.gc, rb.colsq);

@@ -86,6 +86,7 @@ struct DevProblem {
   double* fpart;               // per-run partial sums
   double* camrot;              // [nc][kCamRot] per-camera blocks at the linearisation point (k_cam_prep), null = not in use
   double* camrot_cand;         // the same for the candidate cameras of the trial step (back-substitution)
+  unsigned model_mask;         // bit m = some intrinsics group uses camera model m (picks the kernel instance)
   int fused_dbg;               // development switches (THEIA_HIP_FUSED_DBG): 1 = skip phase S, 2 = skip phase L arithmetic
   int n_sum_items;
   const int* sum_items;        // [n_sum_items][6] {ri, rj, tbeg, tend, dbeg, dend} into sum_src

@@ -50,7 +50,7 @@ struct LaneLin {
 // Load one observation and linearise it: loss-corrected, column-masked,
 // Jacobi-scaled, tangent-space blocks.  WANT_JAC=false: residual/cost only.
 // ROT: `cam` is the per-camera block array of k_cam_prep (kCamRot doubles per camera) instead of [nc][6].
-template <int PD, bool WANT_JAC, bool INTR = false, bool ROT = false>
+template <int PD, bool WANT_JAC, bool INTR = false, bool ROT = false, unsigned MODELS = kModelsAll>
 THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam,
                              const double* __restrict__ pts, int o, bool active, int lane,
                              LaneLin<PD, INTR>& L) {
@@ -108,7 +108,7 @@ THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam
   }
   L.g = g;
   typename std::conditional<INTR, ObsLinK, ObsLin>::type ol;
-  if constexpr (ROT) observe_rot<WANT_JAC, INTR && WANT_JAC>(model, ext, rt, intr, L.X, uv.x, uv.y, six, siy, ol);
+  if constexpr (ROT) observe_rot<WANT_JAC, INTR && WANT_JAC, typename std::conditional<INTR, ObsLinK, ObsLin>::type, MODELS>(model, ext, rt, intr, L.X, uv.x, uv.y, six, siy, ol);
   else observe<WANT_JAC, INTR && WANT_JAC>(model, ext, intr, L.X, uv.x, uv.y, six, siy, ol);
   L.valid = ol.valid;
   const double s = ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1];

@@ -136,6 +136,7 @@ struct theia_ba_handle_s {
   int n_diag_items = 0, n_blk_items = 0;
   // fused linearise + Schur plan (ba_fused.hip)
   bool use_fused = false;
+  unsigned model_mask = 0xffu;          // camera models present in the problem
   DevBuf<FusedRun> fruns;
   DevBuf<int> frun_cams, tile_trk_end, sum_items, sum_src;
   DevBuf<unsigned short> frun_tgt;
@@ -463,6 +464,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.n_fruns = h->use_fused ? h->n_fruns : 0; P.fruns = h->fruns.p; P.frun_cams = h->frun_cams.p; P.frun_tgt = h->frun_tgt.p;
   P.obs_lc = h->obs_lc.p; P.obs_tl = h->obs_tl.p; P.tile_trk_end = h->tile_trk_end.p; P.fpart = h->fpart.p; P.camrot = h->camrot.p; P.camrot_cand = h->camrot_cand.p;
   { const char* dbg = getenv("THEIA_HIP_FUSED_DBG"); P.fused_dbg = dbg ? atoi(dbg) : 0; }
+  P.model_mask = h->model_mask;
   P.n_sum_items = h->n_sum_items; P.sum_items = h->sum_items.p; P.sum_src = h->sum_src.p;
   P.diag_items = h->diag_items.p; P.rec_slot = h->cam_obs.p; P.slot_obs = h->slot_obs.p; P.slot_pt = h->slot_pt.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
 }
@@ -1285,6 +1287,8 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   AL(long_scratch, (size_t)14 * std::max(1, h->long_ntracks));
   UP(d_cam_red, h->cam_red); UP(d_cam_mask, h->cam_mask); UP(d_pt_const, h->pt_const);
   std::vector<int> gm(p->group_model, p->group_model + h->ng), cg(p->cam_group, p->cam_group + h->nc);
+  h->model_mask = 0u;
+  for (int g = 0; g < h->ng; ++g) h->model_mask |= 1u << p->group_model[g];
   UP(group_model, gm); UP(cam_group, cg);
   for (int k = 0; k < 2; ++k) { AL(cam[k], (size_t)6 * h->nc); AL(pts[k], (size_t)4 * h->np); AL(intr[k], (size_t)THEIA_MAX_INTRINSICS * h->ng); }
   UP(d_grp_red, h->grp_red); UP(d_grp_free, h->grp_free); UP(d_grp_k, h->grp_k);

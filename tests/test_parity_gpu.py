@@ -1,0 +1,321 @@
+"""Parity at size and solver checks that do NOT go through the oracle's transcription of the minimal solvers.
+
+* LM trajectories of the HIP path against the CPU oracle at BASELINE sizes C2 (200 views / 50k tracks) and C4 (1000 /
+  500k): cost / radius / accept sequences to 1e-9, gauge-fixed parameters to the north_star tolerance 1e-6 relative.
+* Device five-point / P3P / SQPnP / 8-point / 4-point solvers against numpy (np.linalg.svd / eig / lstsq): solution
+  sets, constraint residuals and recovery of the generating pose on thousands of random instances.  The numpy
+  five-point solver below is derived here from the algebra (constraint polynomials fitted by interpolation, action
+  matrix of multiplication by x in the quotient ring), it shares no table with csrc/ransac_device.h or the oracle.
+* The reference's own test scenes through the GPU mirror with the reference's thresholds:
+  estimate_relative_pose_test.cc:60-196, estimate_calibrated_absolute_pose_test.cc:60-215 (KNEIP and SQPnP),
+  lmed_test.cc:108-140 (quality measure of the correct model: restated on the dominant-plane estimator, the line
+  estimator there is test-local).
+"""
+import numpy as np
+import pytest
+
+from pytheiasfm_amd import ba, ransac, synth
+from tests import oracle_lib as ol
+from tests.test_oracle_ransac import ABS_POS, ABS_ROT, REL_POS, REL_ROT, grid_points
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(b).max(), 1e-300)
+
+
+def both_options(**kw):
+    o, oo = ba.default_options(), ol.default_options()
+    for k, v in kw.items():
+        setattr(o, k, v); setattr(oo, k, v)
+    return o, oo
+
+
+# ------------------------------------------------------------------------------------------------ BA at size
+def _trace_parity(p, iters, ptol):
+    o, oo = both_options(max_num_iterations=iters, function_tolerance=0.0, gradient_tolerance=0.0, parameter_tolerance=0.0)
+    pg, po = p.copy(), p.copy()
+    s, tr = ba.solve(pg, o)
+    so, tro = ol.solve(po, oo)
+    assert s.success == so.success == 1
+    assert s.num_iterations == so.num_iterations == iters and tr.size == tro.size
+    assert np.array_equal(tr.accepted, tro.accepted)
+    assert rel(tr.cost, tro.cost) <= 1e-9 and rel(tr.radius, tro.radius) <= 1e-9          # LM trace, 1e-9 relative
+    assert rel(tr.step_norm, tro.step_norm) <= 1e-6
+    assert abs(s.final_cost - so.final_cost) <= 1e-9 * so.final_cost
+    # north_star: point / pose parameters within 1e-6 relative
+    scale_c = np.abs(po.cam_ext).max(); scale_p = np.abs(po.points).max()
+    assert np.abs(pg.cam_ext - po.cam_ext).max() <= ptol * scale_c and np.abs(pg.points - po.points).max() <= ptol * scale_p
+    return s
+
+
+def test_lm_trajectory_matches_oracle_c2():
+    """BASELINE.json configs[1]: 200 views / 50k tracks / ~300k observations, eight LM iterations from the perturbed
+    start, gauge fixed by two constant views."""
+    p = synth.synth_ba_v1(200, 50000, seed=0xBA5E0001, fix_gauge=True)
+    assert p.obs_uv.shape[0] > 290000
+    _trace_parity(p, 8, 1e-6)
+
+
+def test_lm_trajectory_matches_oracle_c2_mixed_models_free_gauge():
+    """The same size with pinhole + double-sphere groups and no gauge constraint (BundleAdjustReconstruction fixes
+    nothing): the trajectories must still coincide step for step."""
+    p = synth.synth_ba_v1(200, 50000, seed=0xBA5E0007, mixed_models=True)
+    _trace_parity(p, 5, 1e-6)
+
+
+def test_lm_trajectory_matches_oracle_c4():
+    """north_star size on one GPU (1000 views / 500k tracks / 3.0 M observations, mixed models): three LM iterations
+    against the serial oracle (~4 s each on the host)."""
+    p = synth.ba_config("C4")
+    assert p.obs_uv.shape[0] > 2900000
+    _trace_parity(p, 3, 1e-6)
+
+
+# ------------------------------------------------------------------------------- minimal solvers against numpy
+def _random_rotation(rng, max_deg):
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+    return synth.angle_axis_to_matrix(ax * np.deg2rad(max_deg) * rng.uniform())
+
+
+def _five_point_numpy(x1, x2):
+    """All real essential matrices through five correspondences, with numpy only.
+    E = x E1 + y E2 + z E3 + E4 over the null space of the epipolar constraints (SVD); the ten cubic constraints
+    det E = 0, 2 E E^T E - tr(E E^T) E = 0 are fitted as polynomials in (x, y, z) by least squares on random
+    evaluation points; Gauss-Jordan on the cubic monomials leaves the multiplication-by-x matrix of the quotient ring,
+    whose eigenvectors carry the solutions."""
+    A = np.stack([np.outer(np.append(b, 1.0), np.append(a, 1.0)).ravel() for a, b in zip(x1, x2)])
+    N = np.linalg.svd(A)[2][5:].reshape(4, 3, 3)
+
+    def mono(v):
+        x, y, z = v
+        return np.array([x ** 3, x * x * y, x * y * y, y ** 3, x * x * z, x * y * z, y * y * z, x * z * z, y * z * z, z ** 3,
+                         x * x, x * y, y * y, x * z, y * z, z * z, x, y, z, 1.0])
+
+    def cons(v):
+        E = v[0] * N[0] + v[1] * N[1] + v[2] * N[2] + N[3]
+        EEt = E @ E.T
+        return np.append((2.0 * EEt @ E - np.trace(EEt) * E).ravel(), np.linalg.det(E))
+
+    rs = np.random.default_rng(12345)
+    P = rs.normal(size=(80, 3))
+    C = np.linalg.lstsq(np.stack([mono(v) for v in P]), np.stack([cons(v) for v in P]), rcond=None)[0].T   # 10 x 20
+    B = np.linalg.solve(C[:, :10], C[:, 10:])        # reduced system: cubic monomial k = - B[k] . basis
+    M = np.zeros((10, 10))
+    for row, k in enumerate((0, 1, 2, 4, 5, 7)):     # x * {x^2, xy, y^2, xz, yz, z^2} = x^3, x^2 y, x y^2, x^2 z, x y z, x z^2
+        M[row] = -B[k]
+    M[6, 0] = M[7, 1] = M[8, 3] = M[9, 6] = 1.0      # x * {x, y, z, 1} = x^2, xy, xz, x
+    w, V = np.linalg.eig(M.T)
+    sols = []
+    for k in range(10):
+        if abs(w[k].imag) > 1e-9 * max(1.0, abs(w[k])):
+            continue
+        v = (V[6:9, k] / V[9, k]).real
+        E = v[0] * N[0] + v[1] * N[1] + v[2] * N[2] + N[3]
+        sols.append(E / np.linalg.norm(E))
+    return sols
+
+
+def _same_up_to_sign(A, B):
+    return min(np.abs(A - B).max(), np.abs(A + B).max())
+
+
+def test_five_point_device_solutions_against_numpy():
+    rng = np.random.default_rng(7)
+    n = 1500
+    x1s, x2s, Es = [], [], []
+    for _ in range(n):
+        R = _random_rotation(rng, 30.0); t = rng.normal(size=3); t /= np.linalg.norm(t)
+        X = np.stack([rng.uniform(-2, 2, 5), rng.uniform(-2, 2, 5), rng.uniform(4, 10, 5)], 1)
+        X2 = X @ R.T + t
+        x1s.append(X[:, :2] / X[:, 2:]); x2s.append(X2[:, :2] / X2[:, 2:])
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        Es.append(tx @ R)
+    ns, Ed = ransac.FivePointRelativePose(np.stack(x1s), np.stack(x2s))
+    assert ns.min() >= 1 and ns.max() <= 10
+    matched = 0
+    for i in range(n):
+        dev = [Ed[i, k] / np.linalg.norm(Ed[i, k]) for k in range(ns[i])]
+        # every device solution satisfies the defining constraints on ITS OWN scale
+        for E in dev:
+            assert abs(np.linalg.det(E)) <= 1e-9
+            assert np.abs(2.0 * E @ E.T @ E - np.trace(E @ E.T) * E).max() <= 1e-9
+            for a, b in zip(x1s[i], x2s[i]):
+                assert abs(np.append(b, 1.0) @ E @ np.append(a, 1.0)) <= 1e-9
+        Et = Es[i] / np.linalg.norm(Es[i])
+        assert min(_same_up_to_sign(E, Et) for E in dev) <= 1e-7           # the generating E is among them
+        ref = _five_point_numpy(x1s[i], x2s[i])
+        if len(ref) == len(dev) and all(min(_same_up_to_sign(E, F) for F in dev) <= 1e-6 for E in ref):
+            matched += 1
+    # identical solution SETS wherever both eigen-solvers resolve the same real roots (near-double roots may be split
+    # differently by np.linalg.eig and the device's hqr2)
+    assert matched >= 0.98 * n, matched
+
+
+def test_p3p_device_solutions_verify_and_contain_the_truth():
+    rng = np.random.default_rng(8)
+    n = 10000
+    feats, world, Rs, cs = [], [], [], []
+    for _ in range(n):
+        R = _random_rotation(rng, 40.0); c = rng.uniform(-1, 1, 3)
+        X = np.stack([rng.uniform(-2, 2, 3), rng.uniform(-2, 2, 3), rng.uniform(4, 9, 3)], 1)
+        pc = (X - c) @ R.T
+        feats.append(pc[:, :2] / pc[:, 2:]); world.append(X); Rs.append(R); cs.append(c)
+    ns, Rd, td = ransac.PoseFromThreePoints(np.stack(feats), np.stack(world))
+    found = 0
+    for i in range(n):
+        best = np.inf
+        for k in range(ns[i]):
+            R, t = Rd[i, k], td[i, k]
+            if not np.all(np.isfinite(R)) or not np.all(np.isfinite(t)):
+                continue   # the reference feeds the real parts of complex roots to the back-substitution (NaN poses)
+            assert np.abs(R @ R.T - np.eye(3)).max() <= 1e-9 and abs(np.linalg.det(R) - 1.0) <= 1e-9
+            pc = world[i] @ R.T + t
+            if np.abs(pc[:, :2] / pc[:, 2:] - feats[i]).max() <= 1e-8:   # complex-root leftovers do not reproject
+                best = min(best, np.abs(R - Rs[i]).max() + np.abs(-R.T @ t - cs[i]).max())
+        found += best <= 1e-6
+    assert found >= 0.999 * n, found
+
+
+def test_sqpnp_recovers_the_generating_pose():
+    rng = np.random.default_rng(9)
+    feats, world, Rs, ts = [], [], [], []
+    for i in range(2000):
+        npt = 4 + i % 9
+        R = _random_rotation(rng, 40.0); c = rng.uniform(-1, 1, 3)
+        X = np.stack([rng.uniform(-2, 2, npt), rng.uniform(-2, 2, npt), rng.uniform(4, 9, npt)], 1)
+        pc = (X - c) @ R.T
+        feats.append(pc[:, :2] / pc[:, 2:]); world.append(X); Rs.append(R); ts.append(-R @ c)
+    ns, q, t = ransac.SQPnP(feats, world)
+    ok = 0
+    for i in range(len(feats)):
+        best = np.inf
+        for k in range(ns[i]):
+            w, x, y, z = q[i, k]
+            R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                          [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                          [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+            best = min(best, np.abs(R - Rs[i]).max() + np.abs(t[i, k] - ts[i]).max())
+        ok += best <= 1e-6
+    assert ok >= 0.995 * len(feats), ok
+
+
+def _hartley(x):
+    c = x.mean(0); d = np.sqrt(((x - c) ** 2).sum(1)).mean()
+    s = np.sqrt(2.0) / d
+    return np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1.0]])
+
+
+def test_eight_point_and_four_point_models_against_numpy_svd():
+    rng = np.random.default_rng(10)
+    prm = ransac.RansacParameters(); prm.min_iterations = 1; prm.max_iterations = 1; prm.seed = 3
+    for trial in range(40):
+        R = _random_rotation(rng, 20.0); t = rng.normal(size=3); t /= np.linalg.norm(t)
+        K = np.array([[800.0, 0, 500], [0, 800.0, 400], [0, 0, 1]])
+        # fundamental matrix: exactly eight correspondences, so every sample is the whole set
+        X = np.stack([rng.uniform(-2, 2, 8), rng.uniform(-2, 2, 8), rng.uniform(4, 9, 8)], 1)
+        p1 = X @ K.T; p2 = (X @ R.T + t) @ K.T
+        x1 = p1[:, :2] / p1[:, 2:]; x2 = p2[:, :2] / p2[:, 2:]
+        prm.error_thresh = 1e-6
+        ok, F, s = ransac.EstimateFundamentalMatrix(prm, ransac.RansacType.RANSAC, np.hstack([x1, x2]))
+        assert ok and len(s.inliers) == 8
+        T1, T2 = _hartley(x1), _hartley(x2)
+        a = np.c_[x1, np.ones(8)] @ T1.T; b = np.c_[x2, np.ones(8)] @ T2.T
+        Fn = np.linalg.svd(np.stack([np.outer(q, p).ravel() for p, q in zip(a, b)]))[2][-1].reshape(3, 3)
+        U, S, Vt = np.linalg.svd(Fn); Fn = U @ np.diag([S[0], S[1], 0.0]) @ Vt
+        Fn = T2.T @ Fn @ T1
+        assert _same_up_to_sign(F / np.linalg.norm(F), Fn / np.linalg.norm(Fn)) <= 1e-8
+        assert abs(np.linalg.det(F / np.linalg.norm(F))) <= 1e-12
+        # homography: four coplanar points
+        n = np.array([0.1, -0.2, 1.0]); n /= np.linalg.norm(n); d = 6.0
+        xy = rng.uniform(-0.4, 0.4, (4, 2)); depth = d / (n[0] * xy[:, 0] + n[1] * xy[:, 1] + n[2])
+        Xp = np.c_[xy * depth[:, None], depth]
+        q1 = Xp @ K.T; q2 = (Xp @ R.T + t) @ K.T
+        y1 = q1[:, :2] / q1[:, 2:]; y2 = q2[:, :2] / q2[:, 2:]
+        prm.error_thresh = 1e-6
+        ok, H, s = ransac.EstimateHomography(prm, ransac.RansacType.RANSAC, np.hstack([y1, y2]))
+        assert ok and len(s.inliers) == 4
+        T1, T2 = _hartley(y1), _hartley(y2)
+        a = np.c_[y1, np.ones(4)] @ T1.T; b = np.c_[y2, np.ones(4)] @ T2.T
+        rows = []
+        for p, q in zip(a, b):
+            rows.append(np.concatenate([-p, np.zeros(3), q[0] * p])); rows.append(np.concatenate([np.zeros(3), -p, q[1] * p]))
+        Hn = np.linalg.svd(np.stack(rows))[2][-1].reshape(3, 3)
+        Hn = np.linalg.inv(T2) @ Hn @ T1
+        assert _same_up_to_sign(H / np.linalg.norm(H), Hn / np.linalg.norm(Hn)) <= 1e-8
+        w = np.c_[y1, np.ones(4)] @ H.T
+        assert np.abs(w[:, :2] / w[:, 2:] - y2).max() <= 1e-7
+
+
+# --------------------------------------------------------------------- the reference's own scenes on the GPU
+@pytest.mark.parametrize("ri", range(2))
+@pytest.mark.parametrize("pj", range(2))
+@pytest.mark.parametrize("mode", ["clean", "noise", "outliers"])
+def test_reference_relative_pose_scenes_on_gpu(ri, pj, mode):
+    """estimate_relative_pose_test.cc ExecuteRandomTest (AllInliersNoNoise :118-150, AllInliersWithNoise :152-185,
+    OutliersNoNoise :187-220): rotation / position angular errors under the reference's thresholds."""
+    R, position = REL_ROT[ri], REL_POS[pj] * (1.0 if mode == "clean" else 1.3 / 0.7 if pj == 0 else 1.0)
+    pts = grid_points()
+    t = -R @ position; t = t / np.linalg.norm(t)
+    st = synth.Stream(65, 10 * ri + pj)
+    x1 = pts[:, :2] / pts[:, 2:]
+    p2 = pts @ R.T + t
+    x2 = p2[:, :2] / p2[:, 2:]
+    out = np.arange(27) >= (0.7 if mode == "outliers" else 1.0) * 27
+    x1[out] = 2 * np.stack([st.uniform(4 * np.arange(27)), st.uniform(4 * np.arange(27) + 1)], 1)[out] - 1
+    x2[out] = 2 * np.stack([st.uniform(4 * np.arange(27) + 2), st.uniform(4 * np.arange(27) + 3)], 1)[out] - 1
+    if mode == "noise":
+        x1 = x1 + 1e-3 * np.stack([st.normal(4 * np.arange(27) + 500), st.normal(4 * np.arange(27) + 501)], 1)
+        x2 = x2 + 1e-3 * np.stack([st.normal(4 * np.arange(27) + 502), st.normal(4 * np.arange(27) + 503)], 1)
+    prm = ransac.RansacParameters(); prm.error_thresh = (2.0 / 1000.0) ** 2; prm.seed = 65
+    prm.use_mle = True; prm.failure_probability = 0.0001
+    ok, pose, s = ransac.EstimateRelativePose(prm, ransac.RansacType.RANSAC, np.hstack([x1, x2]))
+    assert ok and len(s.inliers) > 5
+    ang = np.degrees(np.arccos(np.clip((np.trace(R @ pose.rotation.T) - 1) / 2, -1, 1)))
+    tdiff = np.degrees(np.arccos(np.clip(position / np.linalg.norm(position) @ pose.position, -1, 1)))
+    tol = 1e-4 if mode == "clean" else 5.0
+    assert ang < tol and tdiff < tol
+
+
+@pytest.mark.parametrize("pnp", ["KNEIP", "SQPnP"])
+@pytest.mark.parametrize("ri", range(3))
+@pytest.mark.parametrize("pj", range(2))
+@pytest.mark.parametrize("mode", ["clean", "noise", "outliers"])
+def test_reference_absolute_pose_scenes_on_gpu(pnp, ri, pj, mode):
+    """estimate_calibrated_absolute_pose_test.cc ExecuteRandomTest, PnPType KNEIP and SQPnP."""
+    R, position = ABS_ROT[ri], ABS_POS[pj]
+    st = synth.Stream(66, 10 * ri + pj)
+    i = np.arange(100)
+    X = np.stack([4 * st.uniform(3 * i) - 2, 4 * st.uniform(3 * i + 1) - 2, 6 + 4 * st.uniform(3 * i + 2)], 1)
+    pc = (X - position) @ R.T
+    uv = pc[:, :2] / pc[:, 2:]
+    if mode == "outliers":
+        out = i >= 70
+        uv[out] = 2 * np.stack([st.uniform(2 * i + 900), st.uniform(2 * i + 901)], 1)[out] - 1
+    if mode == "noise":
+        uv = uv + 1e-3 * np.stack([st.normal(2 * i + 700), st.normal(2 * i + 701)], 1)
+    prm = ransac.RansacParameters(); prm.error_thresh = (4.0 / 1000.0) ** 2; prm.seed = 66
+    prm.use_mle = True; prm.failure_probability = 0.001; prm.min_iterations = 50
+    ok, pose, s = ransac.EstimateCalibratedAbsolutePose(prm, ransac.RansacType.RANSAC, getattr(ransac.PnPType, pnp), np.hstack([uv, X]))
+    assert ok and len(s.inliers) > 3
+    tol = 1e-4 if mode != "noise" else 1e-2
+    cos_r = abs(np.sum(R * pose.rotation)) / (np.linalg.norm(R) * np.linalg.norm(pose.rotation))
+    cos_p = abs(position @ pose.position) / (np.linalg.norm(position) * np.linalg.norm(pose.position))
+    assert cos_r >= 1 - tol and cos_p >= 1 - tol
+
+
+def test_reference_lmed_scene_on_gpu():
+    """lmed_test.cc:108-140 (5000 inliers with N(0, 0.1) noise, 2500 uniform outliers; the correct model's LMED cost
+    is below 0.5 and about two thirds of the data are inliers), restated on the dominant-plane estimator."""
+    st = synth.Stream(52, 3)
+    i = np.arange(5000); j = np.arange(2500)
+    inl = np.stack([100 * st.uniform(3 * i), 100 * st.uniform(3 * i + 1), 0.1 * st.normal(i + 50000)], 1)
+    outl = np.stack([100 * st.uniform(3 * j + 100000), 100 * st.uniform(3 * j + 100001), 200 * st.uniform(3 * j + 100002) - 100], 1)
+    pts = np.vstack([inl, outl])
+    pts = pts[np.argsort(st.uniform(np.arange(7500) + 900000))]   # reshuffle
+    prm = ransac.RansacParameters(); prm.error_thresh = 0.5; prm.seed = 52; prm.min_iterations = 100; prm.max_iterations = 1000
+    ok, plane, s = ransac.EstimateDominantPlaneFromPoints(prm, ransac.RansacType.LMED, pts)
+    assert ok
+    assert abs(abs(plane.unit_normal[2]) - 1.0) < 1e-3 and abs(plane.point @ plane.unit_normal) < 0.5
+    assert abs(len(s.inliers) / 7500.0 - 0.666) < 0.1
