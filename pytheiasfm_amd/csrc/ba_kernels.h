@@ -158,7 +158,7 @@ void launch_cost_only(const DevProblem& P, const double* cam, const double* pts,
                       double* scal, hipStream_t st);
 
 void launch_long_colnorm(const DevProblem& P, const double* cam, const double* pts, double* colsq_c, double* colsq_p,
-                         double* scratch, hipStream_t st);
+                         double* scratch, hipStream_t st, double* colsq_i = nullptr);
 void launch_long_linearize(const DevProblem& P, const double* cam, const double* pts, const double* radius /* device */, const ReduceBuf& rb,
                            double* Vinv, double* gp, double* scratch, hipStream_t st);
 void launch_long_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,

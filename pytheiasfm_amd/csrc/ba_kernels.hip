@@ -1084,18 +1084,44 @@ THIP_DEV void atomic_max_nonneg(double* p, double v) {
   atomicMax(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v));
 }
 
+// The camera-side block of one observation as reduced columns: [free intrinsics of its group (10) | extrinsics (6)]
+// with intrinsics, the six extrinsics columns without.  col < 0 = constant column.
+template <int PD, bool INTR>
+struct CamSide {
+  static constexpr int N = INTR ? 16 : 6;
+  double F0[N], F1[N];
+  int col[N];
+};
+template <int PD, bool INTR>
+THIP_DEV void cam_side(const DevProblem& P, const LaneLin<PD, INTR>& L, CamSide<PD, INTR>& C) {
+  constexpr int O = INTR ? THEIA_MAX_INTRINSICS : 0;
+  if constexpr (INTR) {
+    const unsigned fm = L.gr >= 0 ? P.grp_free[L.g] : 0u;
+#pragma unroll
+    for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) {
+      C.F0[q] = L.Jk[q]; C.F1[q] = L.Jk[THEIA_MAX_INTRINSICS + q];
+      C.col[q] = ((fm >> q) & 1u) ? 10 * L.gr + q : -1;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    C.F0[O + q] = L.Jc[q]; C.F1[O + q] = L.Jc[6 + q];
+    C.col[O + q] = L.rc >= 0 ? P.ni + 6 * L.rc + q : -1;
+  }
+}
+
 // pass A: per-observation linearisation -> per-track V/g (scratch), camera terms.
 //   MODE 0: column norms only (Jacobi scaling pass); MODE 1: linearize.
-template <int PD, int MODE>
+template <int PD, int MODE, bool INTR>
 __global__ void k_long_accum(DevProblem P, LongView Lv, const double* __restrict__ cam, const double* __restrict__ pts,
                              double* __restrict__ scratch, double* __restrict__ S, double* __restrict__ rhs,
                              double* __restrict__ colsq, double* __restrict__ gc, double* __restrict__ scal,
-                             double* __restrict__ colsq_c0) {
+                             double* __restrict__ colsq_c0, double* __restrict__ colsq_i0) {
   constexpr int NT = PD * (PD + 1) / 2;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= Lv.nobs) return;
-  LaneLin<PD> L;
-  lane_linearize<PD, true>(P, cam, pts, Lv.obs_index[t], true, 0, L);
+  LaneLin<PD, INTR> L;
+  lane_linearize<PD, true, INTR>(P, cam, pts, Lv.obs_index[t], true, 0, L);
   double* sc = scratch + (size_t)Lv.obs_slot[t] * (NT + PD);
 #pragma unroll
   for (int a = 0; a < PD; ++a) {
@@ -1106,19 +1132,31 @@ __global__ void k_long_accum(DevProblem P, LongView Lv, const double* __restrict
   if (MODE == 0) {
     if (L.rc >= 0)
       for (int q = 0; q < 6; ++q) atomic_add(&colsq_c0[6 * L.c + q], L.Jc[q] * L.Jc[q] + L.Jc[6 + q] * L.Jc[6 + q]);
+    if constexpr (INTR) {
+      if (L.gr >= 0)
+        for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) {
+          const double v = L.Jk[q] * L.Jk[q] + L.Jk[THEIA_MAX_INTRINSICS + q] * L.Jk[THEIA_MAX_INTRINSICS + q];
+          if (v != 0.0) atomic_add(&colsq_i0[(size_t)L.g * THEIA_MAX_INTRINSICS + q], v);
+        }
+    }
     return;
   }
   atomic_add(&scal[SC_COST], L.cost);
   if (!L.valid) atomic_add(&scal[SC_INVALID], 1.0);
-  if (L.rc >= 0) {
-    const int n = P.n, rc = L.rc;
-    double* Sd = S + (size_t)(6 * rc) * n + 6 * rc;
-    for (int a = 0; a < 6; ++a) {
-      const double jr = L.Jc[a] * L.r[0] + L.Jc[6 + a] * L.r[1];
-      atomic_add(&rhs[6 * rc + a], jr);
-      atomic_add(&gc[6 * rc + a], jr);
-      atomic_add(&colsq[6 * rc + a], L.Jc[a] * L.Jc[a] + L.Jc[6 + a] * L.Jc[6 + a]);
-      for (int b = 0; b <= a; ++b) atomic_add(&Sd[(size_t)a * n + b], L.Jc[a] * L.Jc[b] + L.Jc[6 + a] * L.Jc[6 + b]);
+  CamSide<PD, INTR> C;
+  cam_side<PD, INTR>(P, L, C);
+  const int n = P.n;
+  for (int a = 0; a < C.N; ++a) {
+    const int ca = C.col[a];
+    if (ca < 0) continue;
+    const double jr = C.F0[a] * L.r[0] + C.F1[a] * L.r[1];
+    atomic_add(&rhs[ca], jr);
+    atomic_add(&gc[ca], jr);
+    atomic_add(&colsq[ca], C.F0[a] * C.F0[a] + C.F1[a] * C.F1[a]);
+    for (int b = 0; b < C.N; ++b) {
+      const int cb = C.col[b];
+      if (cb < 0 || cb > ca) continue;   // lower triangle of S
+      atomic_add(&S[(size_t)ca * n + cb], C.F0[a] * C.F0[b] + C.F1[a] * C.F1[b]);
     }
   }
 }
@@ -1155,22 +1193,27 @@ __global__ void k_long_track(DevProblem P, LongView Lv, const double* __restrict
 
 // pass C: Schur products of long tracks: thread = observation i, walks the
 // track's observations j (re-linearised), S_ij -= W_i V^-1 W_j^T, rhs -= W_i V^-1 g.
-template <int PD>
+template <int PD, bool INTR>
 __global__ void k_long_schur(DevProblem P, LongView Lv, const double* __restrict__ cam, const double* __restrict__ pts,
                              const double* __restrict__ Vinv, const double* __restrict__ gp, double* __restrict__ S,
                              double* __restrict__ rhs) {
   constexpr int NT = PD * (PD + 1) / 2;
-  constexpr int NW = 6 * PD;
+  constexpr int NC = CamSide<PD, INTR>::N;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= Lv.nobs) return;
-  LaneLin<PD> L;
-  lane_linearize<PD, true>(P, cam, pts, Lv.obs_index[t], true, 0, L);
-  if (L.rc < 0 || L.pconst) return;
-  double Vi[NT], T[NW];
+  LaneLin<PD, INTR> L;
+  lane_linearize<PD, true, INTR>(P, cam, pts, Lv.obs_index[t], true, 0, L);
+  if (L.pconst) return;
+  CamSide<PD, INTR> C;
+  cam_side<PD, INTR>(P, L, C);
+  bool any = false;
+  for (int a = 0; a < NC; ++a) any = any || C.col[a] >= 0;
+  if (!any) return;
+  double Vi[NT], T[NC * PD];
   for (int k = 0; k < NT; ++k) Vi[k] = Vinv[(size_t)NT * L.p + k];
-  for (int a = 0; a < 6; ++a) {
+  for (int a = 0; a < NC; ++a) {
     double W[PD];
-    for (int b = 0; b < PD; ++b) W[b] = L.Jc[a] * L.Jt[b] + L.Jc[6 + a] * L.Jt[PD + b];
+    for (int b = 0; b < PD; ++b) W[b] = C.F0[a] * L.Jt[b] + C.F1[a] * L.Jt[PD + b];
     double wy = 0.0;
     for (int b = 0; b < PD; ++b) {
       double s = 0.0;
@@ -1178,53 +1221,67 @@ __global__ void k_long_schur(DevProblem P, LongView Lv, const double* __restrict
       T[a * PD + b] = s;
       wy += s * gp[(size_t)PD * L.p + b];   // (W Vinv) g = W (Vinv g)
     }
-    atomic_add(&rhs[6 * L.rc + a], -wy);
+    if (C.col[a] >= 0) atomic_add(&rhs[C.col[a]], -wy);
   }
   const int n = P.n, slot = Lv.obs_slot[t];
   for (int u = Lv.track_start[slot]; u < Lv.track_start[slot + 1]; ++u) {
-    LaneLin<PD> M;
-    lane_linearize<PD, true>(P, cam, pts, Lv.obs_index[u], true, 0, M);
-    if (M.rc < 0 || L.rc < M.rc) continue;
-    double* Sb = S + (size_t)(6 * L.rc) * n + 6 * M.rc;
-    const bool diag = L.rc == M.rc;
-    for (int a = 0; a < 6; ++a)
-      for (int b = 0; b < 6; ++b) {
-        if (diag && b > a) continue;
+    LaneLin<PD, INTR> M;
+    lane_linearize<PD, true, INTR>(P, cam, pts, Lv.obs_index[u], true, 0, M);
+    CamSide<PD, INTR> D;
+    cam_side<PD, INTR>(P, M, D);
+    for (int a = 0; a < NC; ++a) {
+      const int ca = C.col[a];
+      if (ca < 0) continue;
+      for (int b = 0; b < NC; ++b) {
+        const int cb = D.col[b];
+        if (cb < 0 || cb > ca) continue;   // every ordered pair (t, u) lands once in the lower triangle
         double s = 0.0;
-        for (int k = 0; k < PD; ++k) s += T[a * PD + k] * (M.Jc[b] * M.Jt[k] + M.Jc[6 + b] * M.Jt[PD + k]);
-        atomic_add(&Sb[(size_t)a * n + b], -s);
+        for (int k = 0; k < PD; ++k) s += T[a * PD + k] * (D.F0[b] * M.Jt[k] + D.F1[b] * M.Jt[PD + k]);
+        atomic_add(&S[(size_t)ca * n + cb], -s);
       }
+    }
   }
 }
 
+// F y over the camera-side block of an observation (y = solution of the reduced system, all columns)
+template <int PD, bool INTR>
+THIP_DEV void cam_side_apply(const CamSide<PD, INTR>& C, const double* __restrict__ y, double (&m)[2]) {
+  m[0] = m[1] = 0.0;
+  for (int q = 0; q < C.N; ++q)
+    if (C.col[q] >= 0) { m[0] += C.F0[q] * y[C.col[q]]; m[1] += C.F1[q] * y[C.col[q]]; }
+}
+
 // back-substitution, pass 1: t_p = sum E^T (r - F y_c) into the scratch
-template <int PD>
+template <int PD, bool INTR>
 __global__ void k_long_back1(DevProblem P, LongView Lv, const double* __restrict__ cam, const double* __restrict__ pts,
-                             const double* __restrict__ yc, double* __restrict__ scratch) {
+                             const double* __restrict__ y, double* __restrict__ scratch) {
   constexpr int NT = PD * (PD + 1) / 2;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= Lv.nobs) return;
-  LaneLin<PD> L;
-  lane_linearize<PD, true>(P, cam, pts, Lv.obs_index[t], true, 0, L);
-  double mc[2] = {0.0, 0.0};
-  if (L.rc >= 0)
-    for (int q = 0; q < 6; ++q) { mc[0] += L.Jc[q] * yc[6 * L.rc + q]; mc[1] += L.Jc[6 + q] * yc[6 * L.rc + q]; }
+  LaneLin<PD, INTR> L;
+  lane_linearize<PD, true, INTR>(P, cam, pts, Lv.obs_index[t], true, 0, L);
+  CamSide<PD, INTR> C;
+  cam_side<PD, INTR>(P, L, C);
+  double mc[2];
+  cam_side_apply<PD, INTR>(C, y, mc);
   double* sc = scratch + (size_t)Lv.obs_slot[t] * (NT + PD);
   for (int q = 0; q < PD; ++q) atomic_add(&sc[q], L.Jt[q] * (L.r[0] - mc[0]) + L.Jt[PD + q] * (L.r[1] - mc[1]));
 }
 
 // back-substitution, pass 2: y_p, model cost change, candidate point + trial cost
-template <int PD>
+template <int PD, bool INTR>
 __global__ void k_long_back2(DevProblem P, LongView Lv, const double* __restrict__ cam, const double* __restrict__ pts,
                              const double* __restrict__ cand_cam, double* __restrict__ cand_pts,
-                             const double* __restrict__ yc, const double* __restrict__ Vinv,
+                             const double* __restrict__ y, const double* __restrict__ Vinv,
                              const double* __restrict__ scratch, double* __restrict__ scalB) {
   constexpr int NT = PD * (PD + 1) / 2;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= Lv.nobs) return;
   const int o = Lv.obs_index[t];
-  LaneLin<PD> L;
-  lane_linearize<PD, true>(P, cam, pts, o, true, 0, L);
+  LaneLin<PD, INTR> L;
+  lane_linearize<PD, true, INTR>(P, cam, pts, o, true, 0, L);
+  CamSide<PD, INTR> C;
+  cam_side<PD, INTR>(P, L, C);
   const int slot = Lv.obs_slot[t];
   const double* sc = scratch + (size_t)slot * (NT + PD);
   double yp[PD];
@@ -1236,10 +1293,11 @@ __global__ void k_long_back2(DevProblem P, LongView Lv, const double* __restrict
     }
     yp[a] = s;
   }
+  double mcv[2];
+  cam_side_apply<PD, INTR>(C, y, mcv);
   double mcc = 0.0;
   for (int a = 0; a < 2; ++a) {
-    double m = 0.0;
-    if (L.rc >= 0) for (int q = 0; q < 6; ++q) m -= L.Jc[6 * a + q] * yc[6 * L.rc + q];
+    double m = -mcv[a];
     for (int q = 0; q < PD; ++q) m -= L.Jt[a * PD + q] * yp[q];
     mcc -= m * (L.r[a] + m / 2.0);
   }
@@ -1264,7 +1322,8 @@ __global__ void k_long_back2(DevProblem P, LongView Lv, const double* __restrict
   if (P.obs_si) { const double2 s = P.obs_si[o]; six = s.x; siy = s.y; }
   ObsLin ol;
   const bool depth_row = P.obs_kind && P.obs_kind[o];
-  observe<false>(depth_row ? THIP_MODEL_DEPTH_ROW : P.group_model[g], ext, P.intr + (size_t)g * THEIA_MAX_INTRINSICS, Xp, uv.x, uv.y, six, siy, ol);
+  const double* kc = (INTR ? P.intr_cand : P.intr) + (size_t)g * THEIA_MAX_INTRINSICS;
+  observe<false>(depth_row ? THIP_MODEL_DEPTH_ROW : P.group_model[g], ext, kc, Xp, uv.x, uv.y, six, siy, ol);
   double rho1;
   const double cc = 0.5 * loss_eval(P.loss_type, depth_row ? P.loss_width_depth : P.loss_width, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
   atomic_add(&scalB[0], cc); atomic_add(&scalB[1], mcc);
@@ -1482,19 +1541,19 @@ template <int PD> constexpr int long_stride() { return PD * (PD + 1) / 2 + PD; }
 }  // namespace
 
 void launch_long_colnorm(const DevProblem& P, const double* cam, const double* pts, double* colsq_c, double* colsq_p,
-                         double* scratch, hipStream_t st) {
+                         double* scratch, hipStream_t st, double* colsq_i) {
   if (P.long_nobs == 0) return;
   const LongView v = long_view(P);
   const int gb = (v.nobs + 127) / 128, tb = (v.ntracks + 127) / 128;
-  if (P.pd == 3) {
-    (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<3>() * v.ntracks, st);
-    k_long_accum<3, 0><<<gb, 128, 0, st>>>(P, v, cam, pts, scratch, nullptr, nullptr, nullptr, nullptr, nullptr, colsq_c);
-    k_long_track<3, 0><<<tb, 128, 0, st>>>(P, v, nullptr, scratch, colsq_p, nullptr, nullptr, nullptr);
-  } else {
-    (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<4>() * v.ntracks, st);
-    k_long_accum<4, 0><<<gb, 128, 0, st>>>(P, v, cam, pts, scratch, nullptr, nullptr, nullptr, nullptr, nullptr, colsq_c);
-    k_long_track<4, 0><<<tb, 128, 0, st>>>(P, v, nullptr, scratch, colsq_p, nullptr, nullptr, nullptr);
-  }
+#define THIP_LONG(PD_, INTR_)                                                                                          \
+  do {                                                                                                                 \
+    (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<PD_>() * v.ntracks, st);                             \
+    k_long_accum<PD_, 0, INTR_><<<gb, 128, 0, st>>>(P, v, cam, pts, scratch, nullptr, nullptr, nullptr, nullptr, nullptr, colsq_c, colsq_i); \
+    k_long_track<PD_, 0><<<tb, 128, 0, st>>>(P, v, nullptr, scratch, colsq_p, nullptr, nullptr, nullptr);              \
+  } while (0)
+  if (P.pd == 3) { if (P.ni) THIP_LONG(3, true); else THIP_LONG(3, false); }
+  else { if (P.ni) THIP_LONG(4, true); else THIP_LONG(4, false); }
+#undef THIP_LONG
 }
 
 void launch_long_linearize(const DevProblem& P, const double* cam, const double* pts, const double* radius, const ReduceBuf& rb,
@@ -1502,34 +1561,34 @@ void launch_long_linearize(const DevProblem& P, const double* cam, const double*
   if (P.long_nobs == 0) return;
   const LongView v = long_view(P);
   const int gb = (v.nobs + 127) / 128, tb = (v.ntracks + 127) / 128;
-  if (P.pd == 3) {
-    (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<3>() * v.ntracks, st);
-    k_long_accum<3, 1><<<gb, 128, 0, st>>>(P, v, cam, pts, scratch, rb.S, rb.rhs, rb.colsq, rb.gc, rb.scal, nullptr);
-    k_long_track<3, 1><<<tb, 128, 0, st>>>(P, v, radius, scratch, nullptr, Vinv, gp, rb.scal);
-    k_long_schur<3><<<gb, 128, 0, st>>>(P, v, cam, pts, Vinv, gp, rb.S, rb.rhs);
-  } else {
-    (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<4>() * v.ntracks, st);
-    k_long_accum<4, 1><<<gb, 128, 0, st>>>(P, v, cam, pts, scratch, rb.S, rb.rhs, rb.colsq, rb.gc, rb.scal, nullptr);
-    k_long_track<4, 1><<<tb, 128, 0, st>>>(P, v, radius, scratch, nullptr, Vinv, gp, rb.scal);
-    k_long_schur<4><<<gb, 128, 0, st>>>(P, v, cam, pts, Vinv, gp, rb.S, rb.rhs);
-  }
+#define THIP_LONG(PD_, INTR_)                                                                                          \
+  do {                                                                                                                 \
+    (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<PD_>() * v.ntracks, st);                             \
+    k_long_accum<PD_, 1, INTR_><<<gb, 128, 0, st>>>(P, v, cam, pts, scratch, rb.S, rb.rhs, rb.colsq, rb.gc, rb.scal, nullptr, nullptr); \
+    k_long_track<PD_, 1><<<tb, 128, 0, st>>>(P, v, radius, scratch, nullptr, Vinv, gp, rb.scal);                       \
+    k_long_schur<PD_, INTR_><<<gb, 128, 0, st>>>(P, v, cam, pts, Vinv, gp, rb.S, rb.rhs);                              \
+  } while (0)
+  if (P.pd == 3) { if (P.ni) THIP_LONG(3, true); else THIP_LONG(3, false); }
+  else { if (P.ni) THIP_LONG(4, true); else THIP_LONG(4, false); }
+#undef THIP_LONG
 }
 
+// yc = the whole solution vector of the reduced system (intrinsics columns first)
 void launch_long_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,
                          double* cand_pts, const double* yc, const double* Vinv, double* scratch, double* scalB,
                          hipStream_t st) {
   if (P.long_nobs == 0) return;
   const LongView v = long_view(P);
   const int gb = (v.nobs + 127) / 128;
-  if (P.pd == 3) {
-    (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<3>() * v.ntracks, st);
-    k_long_back1<3><<<gb, 128, 0, st>>>(P, v, cam, pts, yc, scratch);
-    k_long_back2<3><<<gb, 128, 0, st>>>(P, v, cam, pts, cand_cam, cand_pts, yc, Vinv, scratch, scalB);
-  } else {
-    (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<4>() * v.ntracks, st);
-    k_long_back1<4><<<gb, 128, 0, st>>>(P, v, cam, pts, yc, scratch);
-    k_long_back2<4><<<gb, 128, 0, st>>>(P, v, cam, pts, cand_cam, cand_pts, yc, Vinv, scratch, scalB);
-  }
+#define THIP_LONG(PD_, INTR_)                                                                                          \
+  do {                                                                                                                 \
+    (void)hipMemsetAsync(scratch, 0, sizeof(double) * long_stride<PD_>() * v.ntracks, st);                             \
+    k_long_back1<PD_, INTR_><<<gb, 128, 0, st>>>(P, v, cam, pts, yc, scratch);                                         \
+    k_long_back2<PD_, INTR_><<<gb, 128, 0, st>>>(P, v, cam, pts, cand_cam, cand_pts, yc, Vinv, scratch, scalB);        \
+  } while (0)
+  if (P.pd == 3) { if (P.ni) THIP_LONG(3, true); else THIP_LONG(3, false); }
+  else { if (P.ni) THIP_LONG(4, true); else THIP_LONG(4, false); }
+#undef THIP_LONG
 }
 
 }  // namespace thip

@@ -126,7 +126,7 @@ struct theia_ba_handle_s {
   DevBuf<uint8_t> d_cam_mask, d_pt_const;
   DevBuf<double2> obs_uv, obs_si;
   DevBuf<uint8_t> obs_kind;
-  DevBuf<double> reduce, Vinv, gp, tile_part, red_part, scalB, chol_work;
+  DevBuf<double> reduce, Vinv, gp, tile_part, red_part, scalB, chol_work, stop_flag;
   DevBuf<double> rec;                       // per-observation records of the gather-based Schur assembly
   DevBuf<int> diag_items, cam_obs, blk_items, slot_obs, slot_pt;
   DevBuf<int> prior_cam, prior_kind;        // camera priors in use (compact list)
@@ -143,7 +143,7 @@ struct theia_ba_handle_s {
   DevBuf<uint8_t> obs_lc, obs_tl;
   DevBuf<double> fpart, camrot, camrot_cand;
   int n_fruns = 0, n_sum_items = 0;
-  double* h_scal = nullptr;  // pinned: [scalA(16) | scalB(16)]
+  double* h_scal = nullptr;  // pinned: [scalA(16) | scalB(16) | stop flag out / in (2) | spare]
   char* h_state = nullptr;   // pinned: LmState read-back
   int cur = 0;
   bool have_scale = false;
@@ -531,7 +531,7 @@ int compute_scale(theia_ba_handle_s* h) {
   Q.scale_i = h->ones_i.p;
   Q.intr = h->intr[h->cur].p;
   launch_colnorm(Q, h->cam[h->cur].p, h->pts[h->cur].p, h->colsq_c0.p, h->colsq_p0.p, h->colsq_i0.p, h->stream);
-  launch_long_colnorm(Q, h->cam[h->cur].p, h->pts[h->cur].p, h->colsq_c0.p, h->colsq_p0.p, h->long_scratch.p, h->stream);
+  launch_long_colnorm(Q, h->cam[h->cur].p, h->pts[h->cur].p, h->colsq_c0.p, h->colsq_p0.p, h->long_scratch.p, h->stream, h->colsq_i0.p);
   launch_cam_priors(Q, PRIOR_COLNORM, h->cam[h->cur].p, nullptr, nullptr, nullptr, h->colsq_c0.p, nullptr, nullptr, h->stream);
   int rc = do_allreduce(h, h->colsq_c0.p, h->colsq_c0.n, THEIA_REDUCE_SUM);
   if (!rc && h->ni) rc = do_allreduce(h, h->colsq_i0.p, h->colsq_i0.n, THEIA_REDUCE_SUM);
@@ -805,7 +805,7 @@ int build_gather_lists(theia_ba_handle_s* h, const std::vector<int>& ocam, const
 
 // The gather lists when intrinsics are optimised (k_lin_obs_intr / k_schur_intr); see create().
 int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, const std::vector<int>& ocam,
-                            const std::vector<int>& opt) {
+                            const std::vector<int>& opt, const std::vector<int>& l_obs) {
   int rc = 0;
   hipStream_t st = h->stream;
   // Gather lists with intrinsics (k_lin_obs_intr / k_schur_intr): records for every observation whose camera OR
@@ -815,6 +815,7 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
   constexpr int kChunk = 2048;
   std::vector<int> red(nm), grd(nm);
   for (int64_t s = 0; s < nm; ++s) { red[s] = h->cam_red[ocam[s]]; grd[s] = h->grp_red[p->cam_group[ocam[s]]]; }
+  for (int s2 : l_obs) { red[s2] = -1; grd[s2] = -1; }   // tracks of the slow path (k_long_*) assemble themselves
   // slots: sort the observations that need a record by (group, camera)
   std::vector<int> order;
   for (int64_t s = 0; s < nm; ++s) if (red[s] >= 0 || grd[s] >= 0) order.push_back((int)s);
@@ -1102,7 +1103,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   h->pd = o->use_homogeneous_point_parametrization ? 3 : 4;
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   for (auto& row : h->ev) for (auto& e : row) HIP_TRY(hipEventCreate(&e));
-  HIP_TRY(hipHostMalloc((void**)&h->h_scal, sizeof(double) * 32, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&h->h_scal, sizeof(double) * 40, hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&h->h_state, 1024, hipHostMallocDefault));
   static_assert(sizeof(LmState) <= 1024, "pinned read-back block too small");
 
@@ -1306,8 +1307,6 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     UP(ones_i, ones_i); UP(scale_i, ones_i);
   }
   AL(colsq_i0, (size_t)THEIA_MAX_INTRINSICS * h->ng); AL(scale_red, (size_t)std::max(1, h->n));
-  if (h->ni && h->long_ntracks)
-    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "intrinsics optimisation together with tracks of more than 64 observations is not built yet");
   std::vector<double> ones_c((size_t)6 * h->nc, 1.0), ones_p((size_t)h->pd * h->np, 1.0);
   UP(ones_c, ones_c); UP(ones_p, ones_p); UP(scale_c, ones_c); UP(scale_p, ones_p);
   AL(colsq_c0, (size_t)6 * h->nc); AL(colsq_p0, (size_t)h->pd * h->np);
@@ -1402,7 +1401,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     AL(fpart, std::max<size_t>(1, fplan.part_doubles));
     AL(camrot, (size_t)40 * std::max(1, h->nc)); AL(camrot_cand, (size_t)40 * std::max(1, h->nc));
   }
-  if (h->ni > 0 && h->ntiles_main > 0 && (rc = build_gather_lists_intr(h, p, ocam, opt))) return rc;
+  if (h->ni > 0 && h->ntiles_main > 0 && (rc = build_gather_lists_intr(h, p, ocam, opt, l_obs))) return rc;
 #undef UP
 #undef AL
   tick("gather lists");
@@ -1617,7 +1616,22 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   if (bodies_max <= theia_ba_handle_s::kMaxChunk && !chunk_env) chunk = (int)bodies_max;
   long long bodies_enqueued = 0;
   while (true) {
-    if (now_s() - t_start >= O.max_solver_time_in_seconds && bodies_enqueued > 0) { st.term = THEIA_TERM_NO_CONVERGENCE; break; }
+    {
+      // max_solver_time_in_seconds: every other LM decision comes from all-reduced device state, so in a sharded solve
+      // this one is made collective too (MAX over the ranks' own clocks) -- a rank that stopped alone would leave the
+      // others waiting in their next all-reduce.
+      double expired = (now_s() - t_start >= O.max_solver_time_in_seconds && bodies_enqueued > 0) ? 1.0 : 0.0;
+      if (h->allreduce && bodies_enqueued > 0) {
+        if (h->stop_flag.n < 8 && (rc = h->stop_flag.alloc(8))) return rc;
+        h->h_scal[32] = expired;
+        HIP_TRY(hipMemcpyAsync(h->stop_flag.p, h->h_scal + 32, sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if ((rc = do_allreduce(h, h->stop_flag.p, 1, THEIA_REDUCE_MAX))) return rc;
+        HIP_TRY(hipMemcpyAsync(h->h_scal + 33, h->stop_flag.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        expired = h->h_scal[33];
+      }
+      if (expired != 0.0) { st.term = THEIA_TERM_NO_CONVERGENCE; break; }
+    }
     const int nb = (int)std::min<long long>(chunk, bodies_max - bodies_enqueued);
     if (nb <= 0) break;
     for (int b = 0; b < nb; ++b) {

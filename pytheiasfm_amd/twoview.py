@@ -130,7 +130,10 @@ def _rotation_to_angle_axis(R):
     return angle * q[1:] / n
 
 
-def _ransac_params(options, error_thresh):
+def _ransac_params(options, error_thresh, use_mle=None):
+    """RansacParameters as the reference fills them.  use_mle: EstimateTwoViewInfoCalibrated copies options.use_mle
+    (estimate_twoview_info.cc:167) and so does the homography inlier count; EstimateTwoViewInfoUncalibrated never
+    assigns it (:204-232), i.e. the uncalibrated branch always scores with InlierSupport (RansacParameters default)."""
     p = _ransac.RansacParameters()
     p.failure_probability = 1.0 - options.expected_ransac_confidence
     p.min_iterations = options.min_ransac_iterations
@@ -138,7 +141,7 @@ def _ransac_params(options, error_thresh):
     p.use_lo = options.use_lo
     p.lo_start_iterations = options.lo_start_iterations
     p.error_thresh = error_thresh
-    p.use_mle = options.use_mle
+    p.use_mle = options.use_mle if use_mle is None else use_mle
     p.seed = options.seed
     pc = p.to_c()
     pc.ransac_type = int(_ransac.RansacType(options.ransac_type))
@@ -167,7 +170,7 @@ def EstimateTwoViewInfoBatch(options, priors1, priors2, correspondences_list):
         offsets[1:] = np.cumsum([d.shape[0] for d in data])
         est = _ransac.EST_RELATIVE_POSE if calibrated else _ransac.EST_UNCALIBRATED_RELATIVE_POSE
         eparams = None if calibrated else np.array([options.min_focal_length, options.max_focal_length])
-        res = _ransac.estimate_batch(est, np.concatenate(data, axis=0), offsets, _ransac_params(options, thresh), eparams)
+        res = _ransac.estimate_batch(est, np.concatenate(data, axis=0), offsets, _ransac_params(options, thresh, use_mle=options.use_mle if calibrated else False), eparams)
         for k, i in enumerate(idx):
             ok = bool(res["success"][k])
             info = TwoViewInfo()

@@ -424,6 +424,26 @@ def test_long_tracks_slow_path_matches_oracle(manifold):
     assert np.abs(pg.cam_ext - po.cam_ext).max() <= 1e-7 and np.abs(pg.points - po.points).max() <= 1e-7
 
 
+@pytest.mark.parametrize("intr", [0x11, 0x3f])
+def test_long_tracks_with_intrinsics_match_oracle(intr):
+    """The pipelines' default (FOCAL_LENGTH | RADIAL_DISTORTION, reconstruction_estimator_options.h:281-283) on a scene
+    with tracks of more than 64 observations: the slow path carries the 16-wide camera-side block."""
+    p = _with_long_tracks()
+    assert np.bincount(p.obs_pt).max() == 80
+    o, oo = both_options(intrinsics_to_optimize=intr)
+    with ba.BaHandle(p.copy(), o) as h:
+        S, rhs = h.reduced_system(1e4)
+    So, ro = ol.reduced_system(p, oo, 1e4)
+    assert S.shape == So.shape and rel(S, So) <= 1e-10 and rel(rhs, ro) <= 1e-10
+    pg, po = p.copy(), p.copy()
+    s, tr = ba.solve(pg, o)
+    so, tro = ol.solve(po, oo)
+    assert s.success and s.num_iterations == so.num_iterations and np.array_equal(tr.accepted, tro.accepted)
+    assert rel(tr.cost, tro.cost) <= 1e-9
+    assert np.abs(pg.cam_ext - po.cam_ext).max() <= 1e-7 and np.abs(pg.points - po.points).max() <= 1e-7
+    assert np.abs(pg.intrinsics - po.intrinsics).max() <= 1e-6 * np.abs(po.intrinsics).max()
+
+
 INTR_ALL = 0x3f
 INTR_FOCAL_RADIAL = 0x11   # pipeline default (reconstruction_estimator_options.h:281-283)
 

@@ -451,6 +451,18 @@ def test_estimate_two_view_info_both_branches():
     for i, (ok, info, inl) in enumerate(out):
         assert ok and len(inl) > 120
         assert abs(info.focal_length_1 / 1000.0 - 1.0) < 0.2 and abs(info.focal_length_2 / 1250.0 - 1.0) < 0.2
+    # EstimateTwoViewInfoUncalibrated never assigns ransac_options.use_mle (estimate_twoview_info.cc:204-232): with the
+    # default EstimateTwoViewInfoOptions.use_mle = true the uncalibrated branch still scores with InlierSupport.
+    assert opts.use_mle
+    thr = tv.ComputeResolutionScaledThreshold(opts.max_sampson_error_pixels, 1000, 800) ** 2
+    ol.set_estimator_params([opts.min_focal_length, opts.max_focal_length])
+    for i, (ok, info, inl) in enumerate(out):
+        pc = ol.default_ransac_params(thr, seed=opts.seed + i)
+        pc.failure_probability = 1.0 - opts.expected_ransac_confidence
+        pc.min_iterations = opts.min_ransac_iterations; pc.max_iterations = opts.max_ransac_iterations
+        pc.use_mle = 0
+        o = ol.ransac_estimate(9, tv.NormalizeFeatures(pu, pu, corr[i]), pc)
+        assert sorted(np.nonzero(o["inlier_mask"])[0].tolist()) == sorted(inl) and o["num_iterations"] > 0
 
 
 @pytest.mark.parametrize("rtype", [0, 1, 2, 3])
