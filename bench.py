@@ -161,7 +161,7 @@ def cpu_ba_baseline(pristine, nobs_total, threads, n_it, what):
             "phase_s": {"linearize_schur": so.time_linearize, "reduced_solve": so.time_solve_reduced, "backsub_trial_cost": so.time_backsub}}
 
 
-def ransac_block(cpu_baseline, host_cores):
+def ransac_block(cpu_baseline, host_cores, rank=0, world=1):
     """BASELINE.json configs[4] on one GPU: 10 000 pairs x 2000 correspondences x 4096 hypotheses, five-point relative
     pose and SQPnP absolute pose (DLS: see DESIGN.md).  FLOP/s: SURVEY.md 8d counts (score: 85 FLOP per model and
     correspondence; fit: per-solve counts of the restated solvers)."""
@@ -175,9 +175,9 @@ def ransac_block(cpu_baseline, host_cores):
         p = ransac.RansacParameters(); p.error_thresh = thresh; p.min_iterations = HYPS; p.max_iterations = HYPS; p.seed = 1
         tot = {"hyp": 0, "models": 0, "wall": 0.0, "fit": 0.0, "score": 0.0, "kern": 0.0}
         first = None
-        for c in range(PAIRS // CHUNK):
+        for c in range(rank, PAIRS // CHUNK, world):   # (whole chunks of pairs per rank: same round-robin deal, coarser grain)
             data, offsets, _ = synth.synth_ransac_v1(CHUNK, CORR, kind, seed=0x5AC50005 + 977 * c)
-            if c == 0:
+            if first is None:
                 ransac.estimate_batch(est, data[: offsets[8]], offsets[:9], p)  # warm-up
                 first = (data, offsets)
             p.seed = 1 + c * CHUNK
@@ -267,9 +267,16 @@ def main():
         torch.cuda.synchronize()
 
     R = BaRunner(ba, prob, pristine)
+    comm = None
     if world > 1:
-        R.h.set_allreduce(tdist.make_torch_allreduce(local_rank))
-        R.h.set_shard(rank, world)
+        # the library issues ncclAllReduce itself (theia_hip_ba_set_rccl); THEIA_HIP_BENCH_TORCH_ALLREDUCE=1 keeps the
+        # torch.distributed callback of round 1 for comparison
+        if os.environ.get("THEIA_HIP_BENCH_TORCH_ALLREDUCE"):
+            R.h.set_allreduce(tdist.make_torch_allreduce(local_rank))
+            R.h.set_shard(rank, world)
+        else:
+            comm = tdist.NativeRccl(rank, world)
+            comm.attach(R.h)
     R.prepare()
     info = R.h.plan_info()
     # initialisation, not part of the W warm-up steps: a fresh box idles at its lowest clock level -- run the workload
@@ -339,6 +346,8 @@ def main():
                                        "backsub_trial_cost": 1e3 * acc["backsub"] / nl},
         }
     R.h.close()
+    if comm is not None:
+        comm.close()
 
     host_cores = os.cpu_count() or 1
     if rank == 0 and world == 1 and not args.no_c2:
@@ -377,8 +386,19 @@ def main():
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         out["speedup_vs_cpu_single_thread"] = out["value"] / out["cpu_baseline_single_thread"]["value"]
 
-    if rank == 0 and world == 1 and not args.no_ransac:
+    if world == 1 and not args.no_ransac:
         out["ransac"] = ransac_block(not args.no_cpu_baseline, host_cores)
+    elif not args.no_ransac:
+        # configs[4] on N GPUs: the 10 000 pairs are dealt round robin over the ranks, no collective on the data path
+        rb = ransac_block(False, host_cores, rank=rank, world=world)
+        t = torch.tensor([[rb[k]["wall_s"], float(rb[k]["hypotheses"])] for k in ("five_point_relative_pose", "sqpnp_absolute_pose")],
+                         dtype=torch.float64, device="cuda")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            out["ransac"] = {"workload": rb["workload"] + f", pairs sharded round robin over {world} ranks",
+                             "five_point_relative_pose": {"hypotheses_per_sec": float(tsum[0, 1] / tmax[0, 0]), "hypotheses": float(tsum[0, 1]), "wall_s_max_over_ranks": float(tmax[0, 0])},
+                             "sqpnp_absolute_pose": {"hypotheses_per_sec": float(tsum[1, 1] / tmax[1, 0]), "hypotheses": float(tsum[1, 1]), "wall_s_max_over_ranks": float(tmax[1, 0])}}
 
     if rank == 0:
         print(json.dumps(out))

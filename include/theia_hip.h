@@ -419,6 +419,17 @@ typedef int (*theia_allreduce_fn)(void* ctx, void* device_buffer,
 int theia_hip_ba_set_allreduce(theia_ba_handle h, theia_allreduce_fn fn,
                                void* ctx);
 
+/* The same all-reduce issued by the library itself: `ncclAllReduce` (RCCL) on the solve's own HIP stream, no host
+ * callback inside the LM iteration.  librccl is looked up at run time (the copy the process already loaded, else
+ * /opt/rocm/lib): no link-time dependency.  Rank 0 obtains the 128-byte id and hands it to the other ranks by any
+ * channel the host has; every rank then creates its communicator and attaches it to its handle (which also declares
+ * the shard geometry, as theia_hip_ba_set_shard).  The communicator outlives the handles using it and is destroyed
+ * by the host. */
+int theia_hip_rccl_unique_id(void* out128);
+int theia_hip_rccl_comm_create(const void* id128, int32_t rank, int32_t world_size, void** comm_out);
+int theia_hip_rccl_comm_destroy(void* comm);
+int theia_hip_ba_set_rccl(theia_ba_handle h, void* comm, int32_t rank, int32_t world_size);
+
 /* ------------------------------------------------------------------ RANSAC */
 /* src/theia/solvers/sample_consensus_estimator.h:58-126 */
 typedef struct theia_ransac_params {
@@ -497,6 +508,8 @@ typedef struct theia_ransac_batch {
   const int64_t* offsets;      /* [num_problems+1] datum offsets           */
   const double* data;          /* [offsets[num_problems]][datum_size]      */
   const double* estimator_params; /* estimator constants (see THEIA_EST_*), or NULL */
+  const uint32_t* seeds;       /* [num_problems] RandomNumberGenerator seed of each problem, or NULL = params.seed + index.
+                                  Lets a caller keep a pair's sample stream when it re-batches or shards the pairs. */
 } theia_ransac_batch;
 
 /* Result per problem.  model layout:

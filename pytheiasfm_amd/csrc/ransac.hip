@@ -848,7 +848,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   for (int p = 0; p < nprob; ++p) {
     ProblemState& s = S[p];
     s.n = (int)(batch->offsets[p + 1] - batch->offsets[p]);
-    s.rng.seed(P.seed + (uint32_t)p);
+    s.rng.seed(batch->seeds ? batch->seeds[p] : P.seed + (uint32_t)p);
     s.idx.resize(s.n);
     for (int i = 0; i < s.n; ++i) s.idx[i] = i;
     s.best_cost = std::numeric_limits<double>::max();

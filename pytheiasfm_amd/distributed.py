@@ -76,3 +76,82 @@ def gather_points(shard_points, track_ids, num_points_total, group=None):
     t = torch.from_numpy(full)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return full
+
+
+class NativeRccl:
+    """RCCL communicator owned by libtheia_hip.so (theia_hip_rccl_*): the sharded solve then issues ncclAllReduce
+    itself on its own stream.  The 128-byte unique id travels from rank 0 through torch.distributed's object
+    broadcast (any host channel would do); torch takes no part in the LM iterations afterwards."""
+
+    def __init__(self, rank, world_size, group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        L = capi.lib()
+        L.theia_hip_rccl_unique_id.argtypes = [C.c_void_p]
+        L.theia_hip_rccl_comm_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.theia_hip_rccl_comm_destroy.argtypes = [C.c_void_p]
+        L.theia_hip_ba_set_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            capi.check(L.theia_hip_rccl_unique_id(buf))
+        box = [bytes(buf.raw)]
+        if world_size > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        self._id = C.create_string_buffer(box[0], 128)
+        self._comm = C.c_void_p(None)
+        capi.check(L.theia_hip_rccl_comm_create(self._id, int(rank), int(world_size), C.byref(self._comm)))
+        self.rank, self.world_size = int(rank), int(world_size)
+
+    def attach(self, handle):
+        """handle: ba.BaHandle.  Replaces any all-reduce callback; also declares the shard geometry."""
+        capi.check(capi.lib().theia_hip_ba_set_rccl(handle._h, self._comm, self.rank, self.world_size))
+
+    def close(self):
+        if self._comm:
+            capi.lib().theia_hip_rccl_comm_destroy(self._comm)
+            self._comm = None
+
+
+def shard_problems(num_problems, rank, world_size):
+    """RANSAC over several GPUs: image pairs are independent units, dealt round robin; no collective
+    on the data path.  Returns the global indices of this rank's problems."""
+    return np.arange(int(rank), int(num_problems), int(world_size), dtype=np.int64)
+
+
+def estimate_batch_sharded(estimator, data, offsets, params, rank, world_size, estimator_params=None, gather=True, group=None):
+    """theia_hip_ransac_estimate_batch on this rank's share of the problems (pairs[rank::world_size]); problem i keeps
+    the seed it has in the unsharded batch (params.seed + i).  With gather, every rank receives the per-problem
+    results of the whole batch (host-side all_gather_object: results only, never correspondences)."""
+    from . import ransac
+    offsets = np.asarray(offsets, dtype=np.int64)
+    P = len(offsets) - 1
+    mine = shard_problems(P, rank, world_size)
+    pc = params.to_c() if isinstance(params, ransac.RansacParameters) else params
+    base_seed = int(pc.seed)
+    parts = [np.asarray(data[offsets[i]:offsets[i + 1]]) for i in mine]
+    loc_off = np.zeros(len(mine) + 1, dtype=np.int64)
+    if len(mine):
+        loc_off[1:] = np.cumsum([p.shape[0] for p in parts])
+    out = {"index": mine, "success": np.zeros(0, np.int32), "models": np.zeros((0, capi.THEIA_RANSAC_MODEL_STRIDE)),
+           "num_inliers": np.zeros(0, np.int32), "num_iterations": np.zeros(0, np.int32), "inlier_masks": [],
+           "hypotheses_evaluated": 0, "models_scored": 0, "time_fit_seconds": 0.0, "time_score_seconds": 0.0}
+    if len(mine):
+        # one batched launch; every problem keeps the seed it has in the unsharded batch (params.seed + global index)
+        r = ransac.estimate_batch(estimator, np.concatenate(parts, axis=0), loc_off, pc, estimator_params, seeds=base_seed + mine)
+        out["success"] = r["success"]; out["models"] = r["models"]; out["num_inliers"] = r["num_inliers"]
+        out["num_iterations"] = r["num_iterations"]
+        out["inlier_masks"] = [r["inlier_mask"][loc_off[k]:loc_off[k + 1]] for k in range(len(mine))]
+        for key in ("hypotheses_evaluated", "models_scored", "time_fit_seconds", "time_score_seconds"):
+            out[key] = r[key]
+    if not gather or world_size == 1:
+        return out
+    import torch.distributed as dist
+    boxes = [None] * world_size
+    dist.all_gather_object(boxes, {k: out[k] for k in ("index", "success", "models", "num_inliers", "num_iterations", "inlier_masks")}, group=group)
+    full = {"success": np.zeros(P, np.int32), "models": np.zeros((P, capi.THEIA_RANSAC_MODEL_STRIDE)), "num_inliers": np.zeros(P, np.int32),
+            "num_iterations": np.zeros(P, np.int32), "inlier_masks": [None] * P}
+    for b in boxes:
+        for k, i in enumerate(b["index"]):
+            full["success"][i] = b["success"][k]; full["models"][i] = b["models"][k]; full["num_inliers"][i] = b["num_inliers"][k]
+            full["num_iterations"][i] = b["num_iterations"][k]; full["inlier_masks"][i] = b["inlier_masks"][k]
+    return full

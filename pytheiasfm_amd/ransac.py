@@ -107,9 +107,9 @@ def _sig():
     return L
 
 
-def estimate_batch(estimator, data, offsets, params, estimator_params=None):
-    """theia_hip_ransac_estimate_batch.  data [total][datum], offsets [P+1].
-    Returns dict of per-problem arrays."""
+def estimate_batch(estimator, data, offsets, params, estimator_params=None, seeds=None):
+    """theia_hip_ransac_estimate_batch.  data [total][datum], offsets [P+1]; seeds: optional per-problem
+    RandomNumberGenerator seeds (default params.seed + problem index).  Returns dict of per-problem arrays."""
     L = _sig()
     data = np.ascontiguousarray(data, dtype=np.float64)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
@@ -120,6 +120,10 @@ def estimate_batch(estimator, data, offsets, params, estimator_params=None):
     b.offsets = capi.ptr(offsets, C.c_int64); b.data = capi.ptr(data, C.c_double)
     ep = None if estimator_params is None else np.ascontiguousarray(estimator_params, dtype=np.float64)
     b.estimator_params = None if ep is None else capi.ptr(ep, C.c_double)
+    sd = None if seeds is None else np.ascontiguousarray(np.asarray(seeds, dtype=np.int64) & 0xFFFFFFFF, dtype=np.uint32)
+    if sd is not None and sd.shape[0] != P:
+        raise capi.TheiaHipError(-1, "seeds must hold one entry per problem")
+    b.seeds = None if sd is None else sd.ctypes.data_as(C.POINTER(C.c_uint32))
     success = np.zeros(max(P, 1), dtype=np.int32); models = np.zeros((max(P, 1), capi.THEIA_RANSAC_MODEL_STRIDE))
     ninl = np.zeros(max(P, 1), dtype=np.int32); mask = np.zeros(max(total, 1), dtype=np.uint8)
     nit = np.zeros(max(P, 1), dtype=np.int32); conf = np.zeros(max(P, 1)); nlo = np.zeros(max(P, 1), dtype=np.int32)

@@ -57,3 +57,84 @@ def test_allreduce_callback_path_world_size_1():
         assert np.array_equal(np.asarray(tr2.gradient_max_norm), np.asarray(tr.gradient_max_norm))
     finally:
         dist.destroy_process_group()
+
+
+def test_native_rccl_path_world_size_1():
+    """The library calling ncclAllReduce itself (theia_hip_rccl_* / theia_hip_ba_set_rccl): same solve as the callback
+    path and as the unsharded one.  (A world_size-2 run of the same code needs two GPUs: see the skip below.)"""
+    p = synth.synth_ba_v1(16, 800, seed=81)
+    shard, ids = synth.shard_tracks(p, 0, 1)
+    o = ba.default_options()
+    comm = tdist.NativeRccl(0, 1)
+    try:
+        with ba.BaHandle(shard, o) as h:
+            comm.attach(h)
+            s, tr = h.run()
+            out = h.download(shard.copy())
+    finally:
+        comm.close()
+    ref = p.copy()
+    s0, tr0 = ba.solve(ref, o)
+    assert s.num_iterations == s0.num_iterations and abs(s.final_cost - s0.final_cost) <= 1e-9 * s0.final_cost
+    assert np.abs(out.cam_ext - ref.cam_ext).max() <= 1e-8 and np.abs(out.points - ref.points).max() <= 1e-8
+
+
+def _native_ws2_worker(rank, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    from pytheiasfm_amd import _capi as capi
+    capi.check(capi.lib().theia_hip_init(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=2)   # host channel for the 128-byte id only
+    p = synth.synth_ba_v1(16, 800, seed=81)
+    shard, ids = synth.shard_tracks(p, rank, 2)
+    comm = tdist.NativeRccl(rank, 2)
+    with ba.BaHandle(shard, ba.default_options()) as h:
+        comm.attach(h)
+        s, _ = h.run()
+        out = h.download(shard.copy())
+    comm.close()
+    q.put((rank, s.num_iterations, s.final_cost, out.cam_ext))
+    dist.destroy_process_group()
+
+
+def test_native_rccl_path_world_size_2_product_path():
+    """The PRODUCT path on two ranks (two GPUs, one process each): both ranks must agree with the unsharded solve."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the round's GPU box has one)")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 1000
+    procs = [ctx.Process(target=_native_ws2_worker, args=(r, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    ref = synth.synth_ba_v1(16, 800, seed=81)
+    s0, _ = ba.solve(ref, ba.default_options())
+    for rank, nit, cost, cams in res:
+        assert nit == s0.num_iterations and abs(cost - s0.final_cost) <= 1e-9 * s0.final_cost
+        assert np.abs(cams - ref.cam_ext).max() <= 1e-8
+
+
+def test_ransac_pair_sharding_keeps_per_pair_results():
+    """pairs dealt round robin over the ranks, no collective.  Every pair keeps its sample stream
+    (seed + global index), so the union of the shards equals the unsharded batch bit for bit."""
+    from pytheiasfm_amd import ransac
+    data, offsets, _ = synth.synth_ransac_v1(7, 300, "relative", seed=0x5AC50101)
+    prm = ransac.RansacParameters(); prm.error_thresh = (2.0 / 1000.0) ** 2; prm.min_iterations = 64; prm.max_iterations = 64; prm.seed = 11
+    full = ransac.estimate_batch(ransac.EST_RELATIVE_POSE, data, offsets, prm)
+    seen = np.zeros(7, dtype=bool)
+    for rank in range(3):
+        r = tdist.estimate_batch_sharded(ransac.EST_RELATIVE_POSE, data, offsets, prm, rank, 3, gather=False)
+        assert r["index"].tolist() == list(range(rank, 7, 3))
+        for k, i in enumerate(r["index"]):
+            seen[i] = True
+            assert np.array_equal(r["inlier_masks"][k], full["inlier_mask"][offsets[i]:offsets[i + 1]])
+            assert r["num_iterations"][k] == full["num_iterations"][i] and np.array_equal(r["models"][k], full["models"][i])
+    assert seen.all()

@@ -152,6 +152,16 @@ def test_world_size_2_reduction_of_the_reduced_camera_system():
     assert s_err < 1e-12 and r_err < 1e-10 and pts_ok
 
 
+def test_ransac_pair_partition_is_a_round_robin_cover():
+    """RANSAC over N GPUs: every pair belongs to exactly one rank."""
+    from pytheiasfm_amd import distributed as tdist
+    for P, W in ((0, 4), (1, 4), (10, 3), (10000, 8)):
+        parts = [tdist.shard_problems(P, r, W) for r in range(W)]
+        allp = np.sort(np.concatenate(parts)) if P else np.zeros(0, dtype=np.int64)
+        assert np.array_equal(allp, np.arange(P))
+        assert max(len(x) for x in parts) - min(len(x) for x in parts) <= 1
+
+
 def test_two_view_front_end_host_logic():
     """estimate_twoview_info.cc:67-102,155-171 + reconstruction_estimator_utils.cc:98-110."""
     from pytheiasfm_amd import twoview as tv
