@@ -566,6 +566,17 @@ int theia_hip_sqpnp(int32_t num, const int64_t* offsets, const double* features,
                     const double* world_points, double* quaternions,
                     double* translations, int32_t* num_solutions);
 
+/* DlsPnp (sfm/pose/dls_pnp.h:56-67, bound in src/pytheia/sfm/sfm.cc:577), batched like theia_hip_sqpnp; up to 27
+ * solutions per problem: quaternions[num][27][4] = [w x y z] (world -> camera), translations[num][27][3], zero padded.
+ * The reference mixes a random linear form into the Macaulay matrix: 100 * Eigen::Vector4d::Random() =
+ * four std::rand() draws per call, never seeded (dls_pnp.cc:134).  Problem i takes the draws of the
+ * call_index[i]-th DlsPnp call of a process (call_index == NULL: i).  theia_hip_dls_macaulay_terms returns those
+ * terms, out[num_calls][4], from the library's restatement of glibc's rand() (host only, needs no GPU). */
+int theia_hip_dls_pnp(int32_t num, const int64_t* offsets, const double* features,
+                      const double* world_points, const int64_t* call_index,
+                      double* quaternions, double* translations, int32_t* num_solutions);
+void theia_hip_dls_macaulay_terms(int64_t first_call, int64_t num_calls, double* out);
+
 #ifdef __cplusplus
 }
 #endif

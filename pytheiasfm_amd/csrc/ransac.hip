@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "ransac_device.h"
+#include "dls_device.h"
 #include "theia_hip.h"
 #include <atomic>
 #include <mutex>
@@ -36,10 +37,11 @@
 namespace thip {
 namespace {
 
-constexpr int kMaxCap = 18;   // largest EstimateModel output of any estimator (SQPnP: 18 solutions)
+constexpr int kMaxCap = 18;   // largest EstimateModel output of the thread-per-hypothesis solvers (SQPnP: 18 solutions)
 // models per sample an estimator can return = slot stride of the per-hypothesis arrays
 __host__ __device__ inline int max_models(int est) {
   if (est >= THEIA_EST_FUNDAMENTAL_MATRIX) return 1;
+  if (est == THEIA_EST_ABSOLUTE_POSE_DLS) return dlsdev::kMaxSolutions;
   return est == THEIA_EST_ABSOLUTE_POSE_SQPNP ? 18 : (est == THEIA_EST_ABSOLUTE_POSE_KNEIP ? 4 : 10);
 }
 constexpr int kStride = THEIA_RANSAC_MODEL_STRIDE;
@@ -563,6 +565,114 @@ __global__ void k_sqpnp(int num, const int64_t* __restrict__ offsets, const doub
   for (int k = 0; k < 54; ++k) ts[(size_t)i * 54 + k] = (k < 3 * n) ? t[k] : 0.0;
 }
 
+
+// ---- DLS-PnP hypotheses (estimate_calibrated_absolute_pose.cc:89-97): two kernels instead of k_fit (dls_device.h).
+// k_dls_a: one wave per (problem, iteration); uvals holds the four Macaulay terms of every DlsPnp call of a process
+// (iteration it of a problem = call it: the reference never seeds rand(), and one Estimate() is one process here).
+__global__ __launch_bounds__(64) void k_dls_a(int nprob, int B, const int64_t* __restrict__ offsets,
+                                              const double* __restrict__ data, const int* __restrict__ samples,
+                                              const int* __restrict__ active_iters, const int* __restrict__ iter_base,
+                                              const double* __restrict__ uvals, double* __restrict__ action,
+                                              double* __restrict__ tfac, int* __restrict__ okflag) {
+  __shared__ dlsdev::WaveLds L;
+  const int b = blockIdx.x, p = blockIdx.y;
+  if (b >= active_iters[p]) return;
+  const size_t hyp = (size_t)p * B + b;
+  const double* pd = data + (size_t)offsets[p] * 5;
+  const bool ok = dlsdev::stage_a(L, 3, pd, 5, pd + 2, 5, samples + hyp * 3, uvals + 4 * (size_t)(iter_base[p] + b),
+                                  action + hyp * 729, tfac + hyp * 27);
+  if (threadIdx.x == 0) okflag[hyp] = ok ? 1 : 0;
+}
+
+__global__ __launch_bounds__(64) void k_dls_b(int nprob, int B, const int64_t* __restrict__ offsets,
+                                              const double* __restrict__ data, const int* __restrict__ samples,
+                                              const int* __restrict__ active_iters, const double* __restrict__ action,
+                                              const double* __restrict__ tfac, const int* __restrict__ okflag,
+                                              double* __restrict__ models, int* __restrict__ counts,
+                                              int* __restrict__ dense_count, int* __restrict__ tags, int* __restrict__ hyp_base) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.y;
+  if (b >= B || p >= nprob) return;
+  const size_t hyp = (size_t)p * B + b;
+  if (b >= active_iters[p]) { counts[hyp] = 0; return; }
+  int nm = 0;
+  double quats[4 * dlsdev::kMaxSolutions], ts[3 * dlsdev::kMaxSolutions];
+  if (okflag[hyp]) {
+    double H[729], V[729], tf[27];
+    const double* a = action + hyp * 729;
+    for (int k = 0; k < 729; ++k) H[k] = a[k];
+    for (int k = 0; k < 27; ++k) tf[k] = tfac[hyp * 27 + k];
+    const double* pd = data + (size_t)offsets[p] * 5;
+    nm = dlsdev::stage_b(H, V, tf, 3, pd + 2, 5, samples + hyp * 3, quats, ts);
+  }
+  counts[hyp] = nm;
+  if (nm == 0) return;
+  const int mm = dlsdev::kMaxSolutions;
+  const int base = atomicAdd(&dense_count[p], nm);
+  hyp_base[hyp] = base;
+  double* mo = models + ((size_t)p * B * mm + base) * (size_t)kStride;
+  int* tg = tags + (size_t)p * B * mm + base;
+  for (int j = 0; j < nm; ++j) {
+    double R[9];
+    rsc::quat_to_rot(quats + 4 * j, R);
+    const double* t = ts + 3 * j;
+    double* m = mo + (size_t)j * kStride;
+    for (int k = 0; k < 9; ++k) m[k] = R[k];
+    for (int c = 0; c < 3; ++c) m[9 + c] = -((R[c] * t[0] + R[3 + c] * t[1]) + R[6 + c] * t[2]);
+    for (int k = 12; k < kStride; ++k) m[k] = 0.0;
+    tg[j] = b * mm + j;
+  }
+}
+
+// DlsPnp on problems of any size (the directly bound solver, sfm.cc:577): a wave per problem, then a thread per problem
+__global__ __launch_bounds__(64) void k_dls_solve_a(const int64_t* __restrict__ offsets, const double* __restrict__ feat,
+                                                    const double* __restrict__ world, const double* __restrict__ uvals,
+                                                    double* __restrict__ action, double* __restrict__ tfac, int* __restrict__ okflag) {
+  __shared__ dlsdev::WaveLds L;
+  const int i = blockIdx.x;
+  const int64_t o = offsets[i];
+  const int n = (int)(offsets[i + 1] - o);
+  bool ok = false;
+  if (n >= 3) ok = dlsdev::stage_a(L, n, feat + 2 * o, 2, world + 3 * o, 3, nullptr, uvals + 4 * (size_t)i, action + (size_t)i * 729, tfac + (size_t)i * 27);
+  if (threadIdx.x == 0) okflag[i] = ok ? 1 : 0;
+}
+__global__ __launch_bounds__(64) void k_dls_solve_b(int num, const int64_t* __restrict__ offsets, const double* __restrict__ world,
+                                                    const double* __restrict__ action, const double* __restrict__ tfac,
+                                                    const int* __restrict__ okflag, double* __restrict__ quats,
+                                                    double* __restrict__ ts, int* __restrict__ nsol) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= num) return;
+  double q[4 * dlsdev::kMaxSolutions], t[3 * dlsdev::kMaxSolutions];
+  int n = 0;
+  if (okflag[i]) {
+    double H[729], V[729], tf[27];
+    for (int k = 0; k < 729; ++k) H[k] = action[(size_t)i * 729 + k];
+    for (int k = 0; k < 27; ++k) tf[k] = tfac[(size_t)i * 27 + k];
+    const int64_t o = offsets[i];
+    n = dlsdev::stage_b(H, V, tf, (int)(offsets[i + 1] - o), world + 3 * o, 3, nullptr, q, t);
+  }
+  nsol[i] = n;
+  for (int k = 0; k < 4 * dlsdev::kMaxSolutions; ++k) quats[(size_t)i * 4 * dlsdev::kMaxSolutions + k] = (k < 4 * n) ? q[k] : 0.0;
+  for (int k = 0; k < 3 * dlsdev::kMaxSolutions; ++k) ts[(size_t)i * 3 * dlsdev::kMaxSolutions + k] = (k < 3 * n) ? t[k] : 0.0;
+}
+
+// the index tables of the polynomial system live in constant memory, built once per process
+int ensure_dls_tables() {
+  static std::once_flag once;
+  static int rc = 0;
+  std::call_once(once, [] {
+    dls::Tables t;
+    dls::build_tables(&t);
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(dlsdev::c_tab), &t, sizeof(t));
+    if (e != hipSuccess) rc = set_error(THEIA_HIP_ERR_NO_DEVICE, "hipMemcpyToSymbol(dls tables) failed: %s", hipGetErrorString(e));
+  });
+  return rc;
+}
+// Macaulay terms of DlsPnp calls [0, ncalls) of a process
+void dls_terms(std::vector<double>& u, dls::GlibcRand& gen, size_t ncalls) {
+  while (u.size() < 4 * ncalls) u.push_back(dls::macaulay_term_from_rand(gen.next()));
+}
+
 // ------------------------------------------------------------------ host side
 // std::mt19937 + libstdc++ uniform_int_distribution<int> (Lemire), i.e. the
 // stream RandomNumberGenerator::RandInt draws (util/random.cc:46-84).
@@ -758,10 +868,9 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     ep.min_focal = batch->estimator_params[0];
     ep.max_focal = batch->estimator_params[1];
   }
-  if (est == THEIA_EST_ABSOLUTE_POSE_DLS)
-    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "the DLS minimal solver has no HIP kernel yet");
+  const bool dls_est = est == THEIA_EST_ABSOLUTE_POSE_DLS;
   if (est < 0 || est > THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
-  const bool abs_pose = est == THEIA_EST_ABSOLUTE_POSE_KNEIP || est == THEIA_EST_ABSOLUTE_POSE_SQPNP;
+  const bool abs_pose = est == THEIA_EST_ABSOLUTE_POSE_KNEIP || est == THEIA_EST_ABSOLUTE_POSE_SQPNP || dls_est;
   // estimators that keep Estimator::RefineModel's default "return true" (solvers/estimator.h:86-88): LO only counts
   const bool trivial_refine = est == THEIA_EST_ESSENTIAL_MATRIX || est == THEIA_EST_DOMINANT_PLANE ||
                               est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION || est == THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION;
@@ -787,6 +896,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   if (nprob == 0) return 0;
   int rc = ensure_device();
   if (rc) return rc;
+  if (dls_est && (rc = ensure_dls_tables())) return rc;
   const int m = sample_size(est), ds = datum_size(est);
   const int64_t total = batch->offsets[nprob];
   int nmax = 0;
@@ -826,6 +936,8 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   DBuf<int> d_hyp_base;   // [problem][iteration] first dense model of the hypothesis (k_fit)
   DBuf<int> d_save;       // {problem, hypothesis, slot} triples of k_save_best
   DBuf<double> d_models, d_cost, d_best_models;
+  DBuf<double> d_dls_action, d_dls_tfac, d_dls_u; DBuf<int> d_dls_ok, d_iter_base;   // DLS: stage A -> stage B
+  std::vector<double> h_dls_u; dls::GlibcRand dls_gen; std::vector<int> h_iter_base;
   DBuf<uint8_t> d_mask;
   std::vector<int> h_samples, h_counts, h_ninl, h_active;
   std::vector<double> h_cost;
@@ -986,7 +1098,27 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       HIP_TRYR(hipMemcpyAsync(d_active.p, h_active.data(), sizeof(int) * cn, hipMemcpyHostToDevice, st));
       std::unique_lock<std::recursive_mutex> scratch_lock(scratch_mutex());
       HIP_TRYR(hipEventRecord(ev0, st));
-      {
+      if (dls_est) {
+        h_iter_base.assign(cn, 0);
+        int calls = 0;
+        for (int q = 0; q < cn; ++q) { h_iter_base[q] = S[c0 + q].it; calls = std::max(calls, S[c0 + q].it + S[c0 + q].round_iters); }
+        const size_t had = h_dls_u.size();
+        dls_terms(h_dls_u, dls_gen, (size_t)calls);
+        if ((rc = d_dls_action.ensure(nh * 729)) || (rc = d_dls_tfac.ensure(nh * 27)) || (rc = d_dls_ok.ensure(nh)) ||
+            (rc = d_iter_base.ensure(cn)))
+          return rc;
+        if (h_dls_u.size() != had || d_dls_u.cap < h_dls_u.size()) {
+          if ((rc = d_dls_u.ensure(std::max<size_t>(h_dls_u.size(), 4 * 4096)))) return rc;
+          HIP_TRYR(hipMemcpyAsync(d_dls_u.p, h_dls_u.data(), sizeof(double) * h_dls_u.size(), hipMemcpyHostToDevice, st));
+        }
+        HIP_TRYR(hipMemcpyAsync(d_iter_base.p, h_iter_base.data(), sizeof(int) * cn, hipMemcpyHostToDevice, st));
+        HIP_TRYR(hipEventRecord(ev0, st));   // (re-recorded: the uploads above are not part of the fit time)
+        k_dls_a<<<dim3(B, cn), 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_iter_base.p, d_dls_u.p,
+                                            d_dls_action.p, d_dls_tfac.p, d_dls_ok.p);
+        k_dls_b<<<dim3((B + 63) / 64, cn), 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_dls_action.p,
+                                                        d_dls_tfac.p, d_dls_ok.p, d_models.p, d_counts.p, d_dense.p, d_tags.p,
+                                                        d_hyp_base.p);
+      } else {
         dim3 grid((B + 63) / 64, cn);
 #define THIP_FIT(E) k_fit<E><<<grid, 64, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p, ep)
         switch (est) {
@@ -1132,7 +1264,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   HIP_TRYR(hipMemcpyAsync(d_best_slot.p, best_slot_all.data(), sizeof(int) * nprob, hipMemcpyHostToDevice, st));
   // d_best_models already holds every problem's best model (k_save_best); THEIA_HIP_RANSAC_REFIT=1 recomputes them from the
   // best samples instead (the same bits: the solver is deterministic)
-  if (getenv("THEIA_HIP_RANSAC_REFIT"))
+  if (getenv("THEIA_HIP_RANSAC_REFIT") && !dls_est)
     k_refit<<<(nprob + 63) / 64, 64, 0, st>>>(est, nprob, d_off.p, d_data.p, d_best_samples.p, d_best_slot.p, d_best_models.p, ep);
   std::vector<int> use_cur;   // source of an asynchronous upload: lives until the final synchronisation
   if (P.use_lo && !trivial_refine) {   // the best model of a problem may be the refined pose of its last LO event
@@ -1236,6 +1368,55 @@ int theia_hip_sqpnp(int32_t num, const int64_t* offsets, const double* features,
   k_sqpnp<<<(num + 63) / 64, 64>>>(num, dof.p, df.p, dw.p, dq.p, dt.p, dn.p);
   HIP_TRYR(hipMemcpy(quaternions, dq.p, sizeof(double) * num * 72, hipMemcpyDeviceToHost));
   HIP_TRYR(hipMemcpy(translations, dt.p, sizeof(double) * num * 54, hipMemcpyDeviceToHost));
+  HIP_TRYR(hipMemcpy(num_solutions, dn.p, sizeof(int) * num, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+void theia_hip_dls_macaulay_terms(int64_t first_call, int64_t num_calls, double* out) {
+  if (first_call < 0 || num_calls <= 0 || !out) return;
+  std::vector<double> u; dls::GlibcRand gen;
+  dls_terms(u, gen, (size_t)(first_call + num_calls));
+  std::memcpy(out, u.data() + 4 * first_call, sizeof(double) * 4 * num_calls);
+}
+
+int theia_hip_dls_pnp(int32_t num, const int64_t* offsets, const double* features, const double* world_points,
+                      const int64_t* call_index, double* quaternions, double* translations, int32_t* num_solutions) {
+  std::lock_guard<std::recursive_mutex> scratch_lock(scratch_mutex());
+  if (num < 0 || (num > 0 && (!offsets || !features || !world_points || !quaternions || !translations || !num_solutions)))
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+  if (num == 0) return 0;
+  int rc = thip::ensure_device();
+  if (rc || (rc = ensure_dls_tables())) return rc;
+  if (offsets[0] != 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "offsets[0] must be 0");
+  int64_t max_call = num - 1;
+  for (int i = 0; i < num; ++i) {
+    if (offsets[i + 1] < offsets[i]) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
+    if (call_index) {
+      if (call_index[i] < 0 || call_index[i] > (1 << 26)) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "call_index out of range");
+      max_call = std::max(max_call, call_index[i]);
+    }
+  }
+  const int64_t total = offsets[num];
+  std::vector<double> uall, u((size_t)num * 4); dls::GlibcRand gen;
+  dls_terms(uall, gen, (size_t)max_call + 1);
+  for (int i = 0; i < num; ++i) std::memcpy(&u[(size_t)4 * i], &uall[(size_t)4 * (call_index ? call_index[i] : i)], 4 * sizeof(double));
+  constexpr int NS = dlsdev::kMaxSolutions;
+  DBuf<double> df, dw, dq, dt, du, da, dtf; DBuf<int> dn, dok; DBuf<int64_t> dof;
+  if ((rc = df.ensure((size_t)std::max<int64_t>(1, total) * 2)) || (rc = dw.ensure((size_t)std::max<int64_t>(1, total) * 3)) ||
+      (rc = dq.ensure((size_t)num * 4 * NS)) || (rc = dt.ensure((size_t)num * 3 * NS)) || (rc = dn.ensure(num)) || (rc = dof.ensure(num + 1)) ||
+      (rc = du.ensure((size_t)num * 4)) || (rc = da.ensure((size_t)num * 729)) || (rc = dtf.ensure((size_t)num * 27)) || (rc = dok.ensure(num)))
+    return rc;
+  if (total) {
+    HIP_TRYR(hipMemcpy(df.p, features, sizeof(double) * total * 2, hipMemcpyHostToDevice));
+    HIP_TRYR(hipMemcpy(dw.p, world_points, sizeof(double) * total * 3, hipMemcpyHostToDevice));
+  }
+  HIP_TRYR(hipMemcpy(dof.p, offsets, sizeof(int64_t) * (num + 1), hipMemcpyHostToDevice));
+  HIP_TRYR(hipMemcpy(du.p, u.data(), sizeof(double) * num * 4, hipMemcpyHostToDevice));
+  k_dls_solve_a<<<num, 64>>>(dof.p, df.p, dw.p, du.p, da.p, dtf.p, dok.p);
+  k_dls_solve_b<<<(num + 63) / 64, 64>>>(num, dof.p, dw.p, da.p, dtf.p, dok.p, dq.p, dt.p, dn.p);
+  HIP_TRYR(hipGetLastError());
+  HIP_TRYR(hipMemcpy(quaternions, dq.p, sizeof(double) * num * 4 * NS, hipMemcpyDeviceToHost));
+  HIP_TRYR(hipMemcpy(translations, dt.p, sizeof(double) * num * 3 * NS, hipMemcpyDeviceToHost));
   HIP_TRYR(hipMemcpy(num_solutions, dn.p, sizeof(int) * num, hipMemcpyDeviceToHost));
   return 0;
 }

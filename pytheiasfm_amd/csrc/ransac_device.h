@@ -63,12 +63,26 @@ RDEV void fullpiv_lu(double* A, int rows, int cols, FullPivLU& f) {
 // n x n row-major matrix, n <= 10.  H is destroyed.  wr/wi: eigenvalues; if V
 // is non-null it receives the (un-normalised) eigenvectors of the REAL
 // eigenvalues in the corresponding columns (row-major n x n).
+// complex division (xr + i xi) / (yr + i yi), Smith's scaling (EISPACK cdiv)
+RDEV inline void eig_cdiv(double xr, double xi, double yr, double yi, double* cr, double* ci) {
+  if (fabs(yr) > fabs(yi)) {
+    const double r = yi / yr, d = yr + r * yi;
+    *cr = (xr + r * xi) / d; *ci = (xi - r * xr) / d;
+  } else {
+    const double r = yr / yi, d = yi + r * yr;
+    *cr = (r * xr + xi) / d; *ci = (r * xi - xr) / d;
+  }
+}
 const int EIG_MAXN = 10;
-RDEV bool eig_real_general(int nn, double* H, double* wr, double* wi, double* V) {
+// MAXN: largest n of the instantiation (sizes the one local array).  CPLX: also back-substitute the complex
+// conjugate pairs (EISPACK hqr2 convention: for wi[j] > 0 the columns j, j + 1 of V hold the real and the
+// imaginary part of the eigenvector of wr[j] + i wi[j]; the DLS solver reads them, dls_pnp.cc:147-161).
+template <int MAXN, bool CPLX>
+RDEV bool eig_general_t(int nn, double* H, double* wr, double* wi, double* V) {
 #define HH(i, j) H[(i) * nn + (j)]
 #define VV(i, j) V[(i) * nn + (j)]
   const int low = 0, high = nn - 1;
-  double ort[EIG_MAXN];
+  double ort[MAXN];
   // ---- orthes: reduce to Hessenberg form
   for (int m = low + 1; m <= high - 1; ++m) {
     double scale = 0.0;
@@ -241,6 +255,48 @@ RDEV bool eig_real_general(int nn, double* H, double* wr, double* wi, double* V)
   // back-substitution for the REAL eigenvectors of the quasi-triangular form
   for (n = nn - 1; n >= 0; --n) {
     p = wr[n]; q = wi[n];
+    if (CPLX && q < 0 && n > 0) {   // second member of a conjugate pair: columns n - 1 (real part) and n (imaginary part)
+      int l = n - 1;
+      if (fabs(HH(n, n - 1)) > fabs(HH(n - 1, n))) {
+        HH(n - 1, n - 1) = q / HH(n, n - 1);
+        HH(n - 1, n) = -(HH(n, n) - p) / HH(n, n - 1);
+      } else {
+        double cr, ci;
+        eig_cdiv(0.0, -HH(n - 1, n), HH(n - 1, n - 1) - p, q, &cr, &ci);
+        HH(n - 1, n - 1) = cr; HH(n - 1, n) = ci;
+      }
+      HH(n, n - 1) = 0.0; HH(n, n) = 1.0;
+      double lastra = 0.0, lastsa = 0.0, lastw = 0.0;
+      for (int i = n - 2; i >= 0; --i) {
+        double ra = 0.0, sa = 0.0;
+        for (int j = l; j <= n; ++j) { ra = ra + HH(i, j) * HH(j, n - 1); sa = sa + HH(i, j) * HH(j, n); }
+        w = HH(i, i) - p;
+        if (wi[i] < 0.0) { lastw = w; lastra = ra; lastsa = sa; continue; }
+        l = i;
+        double cr, ci;
+        if (wi[i] == 0.0) {
+          eig_cdiv(-ra, -sa, w, q, &cr, &ci);
+          HH(i, n - 1) = cr; HH(i, n) = ci;
+        } else {
+          x = HH(i, i + 1); y = HH(i + 1, i);
+          double vr = (wr[i] - p) * (wr[i] - p) + wi[i] * wi[i] - q * q;
+          const double vi = (wr[i] - p) * 2.0 * q;
+          if (vr == 0.0 && vi == 0.0) vr = eps * norm * (fabs(w) + fabs(q) + fabs(x) + fabs(y) + fabs(lastw));
+          eig_cdiv(x * lastra - lastw * ra + q * sa, x * lastsa - lastw * sa - q * ra, vr, vi, &cr, &ci);
+          HH(i, n - 1) = cr; HH(i, n) = ci;
+          if (fabs(x) > (fabs(lastw) + fabs(q))) {
+            HH(i + 1, n - 1) = (-ra - w * HH(i, n - 1) + q * HH(i, n)) / x;
+            HH(i + 1, n) = (-sa - w * HH(i, n) - q * HH(i, n - 1)) / x;
+          } else {
+            eig_cdiv(-lastra - y * HH(i, n - 1), -lastsa - y * HH(i, n), lastw, q, &cr, &ci);
+            HH(i + 1, n - 1) = cr; HH(i + 1, n) = ci;
+          }
+        }
+        t = fmax(fabs(HH(i, n - 1)), fabs(HH(i, n)));
+        if ((eps * t) * t > 1) for (int j = i; j <= n; ++j) { HH(j, n - 1) = HH(j, n - 1) / t; HH(j, n) = HH(j, n) / t; }
+      }
+      continue;
+    }
     if (q != 0) continue;
     int l = n;
     HH(n, n) = 1.0;
@@ -269,7 +325,7 @@ RDEV bool eig_real_general(int nn, double* H, double* wr, double* wi, double* V)
   }
   // back transformation (only the real-eigenvalue columns are meaningful)
   for (int j = nn - 1; j >= low; --j) {
-    if (wi[j] != 0) continue;
+    if (!CPLX && wi[j] != 0) continue;
     for (int i = low; i <= high; ++i) {
       z = 0.0;
       for (int k = low; k <= j; ++k) z = z + VV(i, k) * HH(k, j);
@@ -279,6 +335,9 @@ RDEV bool eig_real_general(int nn, double* H, double* wr, double* wi, double* V)
   return true;
 #undef HH
 #undef VV
+}
+RDEV inline bool eig_real_general(int nn, double* H, double* wr, double* wi, double* V) {
+  return eig_general_t<EIG_MAXN, false>(nn, H, wr, wi, V);
 }
 
 // Two-sided Jacobi SVD of a 3x3 row-major matrix (the algorithm of

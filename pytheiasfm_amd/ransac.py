@@ -102,6 +102,10 @@ def _sig():
                                                        capi.c_int32_p]
         L.theia_hip_sqpnp.argtypes = [C.c_int32, C.POINTER(C.c_int64), capi.c_double_p, capi.c_double_p, capi.c_double_p,
                                       capi.c_double_p, capi.c_int32_p]
+        L.theia_hip_dls_pnp.argtypes = [C.c_int32, C.POINTER(C.c_int64), capi.c_double_p, capi.c_double_p, C.POINTER(C.c_int64),
+                                        capi.c_double_p, capi.c_double_p, capi.c_int32_p]
+        L.theia_hip_dls_macaulay_terms.argtypes = [C.c_int64, C.c_int64, capi.c_double_p]
+        L.theia_hip_dls_macaulay_terms.restype = None
         L.theia_ransac_params_default.argtypes = [C.POINTER(capi.RansacParams)]
         L._ransac_ready = True
     return L
@@ -295,3 +299,43 @@ def SQPnP(feature_positions, world_points):
     if single:
         return bool(ns[0] > 0), [q[0, k] for k in range(ns[0])], [t[0, k] for k in range(ns[0])]
     return ns, q, t
+
+
+def DlsPnp(feature_positions, world_points, call_index=None):
+    """sfm.cc:577 / dls_pnp.cc:67-200.  One problem: (N, 2) and (N, 3) arrays (N >= 3) ->
+    (success, [quaternion wxyz], [translation]).  A list of problems is solved as one batch and returns
+    (num_solutions, quaternions[num][27][4], translations[num][27][3]).  call_index: which DlsPnp call of a process each
+    problem stands for (it selects the four std::rand() draws of the reference's random Macaulay terms; default: 0 for a
+    single problem, 0, 1, 2, ... for a list)."""
+    single = isinstance(feature_positions, np.ndarray) and feature_positions.ndim == 2
+    fl = [np.asarray(feature_positions, dtype=np.float64)] if single else [np.asarray(f, dtype=np.float64) for f in feature_positions]
+    wl = [np.asarray(world_points, dtype=np.float64)] if single else [np.asarray(w, dtype=np.float64) for w in world_points]
+    if len(fl) != len(wl) or any(f.shape[0] != w.shape[0] for f, w in zip(fl, wl)):
+        raise capi.TheiaHipError(-1, "feature_positions / world_points size mismatch")
+    if any(f.shape[0] < 3 for f in fl):
+        raise capi.TheiaHipError(-1, "Check failed: feature_position.size() >= 3")   # dls_pnp.cc:71
+    num = len(fl)
+    offsets = np.zeros(num + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([f.shape[0] for f in fl])
+    feat = np.ascontiguousarray(np.concatenate(fl, axis=0).reshape(-1, 2)) if num else np.zeros((0, 2))
+    world = np.ascontiguousarray(np.concatenate(wl, axis=0).reshape(-1, 3)) if num else np.zeros((0, 3))
+    ci = None
+    if call_index is not None:
+        ci = np.ascontiguousarray(np.atleast_1d(np.asarray(call_index, dtype=np.int64)))
+        if ci.shape[0] != num:
+            raise capi.TheiaHipError(-1, "call_index: one entry per problem")
+    q = np.zeros((num, 27, 4)); t = np.zeros((num, 27, 3)); ns = np.zeros(num, dtype=np.int32)
+    capi.check(_sig().theia_hip_dls_pnp(num, offsets.ctypes.data_as(C.POINTER(C.c_int64)), capi.ptr(feat, C.c_double),
+                                        capi.ptr(world, C.c_double), ci.ctypes.data_as(C.POINTER(C.c_int64)) if ci is not None else None,
+                                        capi.ptr(q, C.c_double), capi.ptr(t, C.c_double), capi.ptr(ns, C.c_int32)))
+    if single:
+        return bool(ns[0] > 0), [q[0, k] for k in range(ns[0])], [t[0, k] for k in range(ns[0])]
+    return ns, q, t
+
+
+def dls_macaulay_terms(first_call, num_calls):
+    """The reference's 100 * Eigen::Vector4d::Random() of DlsPnp calls [first_call, first_call + num_calls) of a process
+    that never seeded rand() (dls_pnp.cc:134): (num_calls, 4).  Host only."""
+    out = np.zeros((int(num_calls), 4))
+    _sig().theia_hip_dls_macaulay_terms(int(first_call), int(num_calls), capi.ptr(out, C.c_double))
+    return out

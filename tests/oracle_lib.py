@@ -209,6 +209,44 @@ def sqpnp(feat, world):
     return q[:n], t[:n]
 
 
+def dls_pnp(feat, world, call_index=0, details=False):
+    """DLS-PnP (dls_pnp.cc:67-200) with the Macaulay terms of the call_index-th call of a process: quaternions [w x y z]
+    and translations; details=True adds the Jacobian cubics (3 x 5 x 5 x 5 exponent grids), the 27 x 27 action matrix, u."""
+    feat = np.ascontiguousarray(feat, dtype=np.float64).reshape(-1, 2)
+    world = np.ascontiguousarray(world, dtype=np.float64).reshape(-1, 3)
+    q = np.zeros((27, 4)); t = np.zeros((27, 3)); fc = np.zeros((3, 5, 5, 5)); act = np.zeros((27, 27)); u = np.zeros(4)
+    L = rlib()
+    dp = capi.c_double_p
+    L.oracle_dls_pnp.argtypes = [C.c_int, dp, dp, C.c_int, dp, dp, dp, dp, dp]
+    n = L.oracle_dls_pnp(feat.shape[0], capi.ptr(feat, C.c_double), capi.ptr(world, C.c_double), int(call_index),
+                         capi.ptr(q, C.c_double), capi.ptr(t, C.c_double), capi.ptr(fc, C.c_double), capi.ptr(act, C.c_double),
+                         capi.ptr(u, C.c_double))
+    if details:
+        return q[:n], t[:n], fc, act, u
+    return q[:n], t[:n]
+
+
+def libc_rand(count):
+    out = np.zeros(count, dtype=np.int32)
+    L = rlib()
+    L.oracle_libc_rand.argtypes = [C.c_int, capi.c_int32_p]
+    L.oracle_libc_rand.restype = None
+    L.oracle_libc_rand(count, capi.ptr(out, C.c_int32))
+    return out
+
+
+def eig_complex(A):
+    """orthes + hqr2 with the complex pairs (n <= 27): (ok, wr, wi, V) in the EISPACK column convention."""
+    A = np.ascontiguousarray(A, dtype=np.float64).copy()
+    n = A.shape[0]
+    wr = np.zeros(n); wi = np.zeros(n); V = np.zeros((n, n))
+    L = rlib()
+    dp = capi.c_double_p
+    L.oracle_eig_complex.argtypes = [C.c_int, dp, dp, dp, dp]
+    ok = L.oracle_eig_complex(n, capi.ptr(A, C.c_double), capi.ptr(wr, C.c_double), capi.ptr(wi, C.c_double), capi.ptr(V, C.c_double))
+    return ok, wr, wi, V
+
+
 def svd9(A):
     A = np.ascontiguousarray(A, dtype=np.float64)
     U = np.zeros((9, 9)); S = np.zeros(9); V = np.zeros((9, 9))
@@ -225,7 +263,7 @@ def rot_quat_roundtrip(R):
 
 def estimate_models(est, subset):
     subset = np.ascontiguousarray(subset, dtype=np.float64)
-    m = np.zeros((18, capi.THEIA_RANSAC_MODEL_STRIDE))
+    m = np.zeros((27, capi.THEIA_RANSAC_MODEL_STRIDE))
     n = rlib().oracle_estimate_models(est, capi.ptr(subset, C.c_double), capi.ptr(m, C.c_double))
     return m[:n]
 

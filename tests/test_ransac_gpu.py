@@ -145,8 +145,8 @@ def test_mirror_api_and_error_conventions():
     plo.ransac_type = ransac.RansacType.LMED
     with pytest.raises(capi.TheiaHipError):
         ransac.estimate_batch(0, data, np.array([0, len(data)]), plo)                # use_lo together with LMED: not built
-    with pytest.raises(capi.TheiaHipError):
-        ransac.EstimateCalibratedAbsolutePose(p, ransac.RansacType.RANSAC, ransac.PnPType.DLS, da)
+    ok, ad, s5 = ransac.EstimateCalibratedAbsolutePose(p, ransac.RansacType.RANSAC, ransac.PnPType.DLS, da)
+    assert ok and np.abs(ad.position - ta["position"][0]).max() < 0.25 and len(s5.inliers) > 30
     with pytest.raises(capi.TheiaHipError):
         ransac.EstimateRelativePose(p, ransac.RansacType.RANSAC, data[:3])  # fewer data than the sample size
 
