@@ -163,19 +163,23 @@ def cpu_ba_baseline(pristine, nobs_total, threads, n_it, what):
 
 def ransac_block(cpu_baseline, host_cores, rank=0, world=1):
     """BASELINE.json configs[4] on one GPU: 10 000 pairs x 2000 correspondences x 4096 hypotheses, five-point relative
-    pose and SQPnP absolute pose (DLS: see DESIGN.md).  FLOP/s: SURVEY.md 8d counts (score: 85 FLOP per model and
+    pose, SQPnP and DLS absolute pose (DLS on a tenth of the pairs).  FLOP/s: SURVEY.md 8d counts (score: 85 FLOP per model and
     correspondence; fit: per-solve counts of the restated solvers)."""
     from pytheiasfm_amd import ransac, synth
     PAIRS, CORR, HYPS, CHUNK = 10000, 2000, 4096, 1000
     out = {"workload": f"synth_ransac_v1 C5: {PAIRS} pairs x {CORR} correspondences x {HYPS} hypotheses (min = max iterations), InlierSupport",
            "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS}
-    legs = (("five_point_relative_pose", ransac.EST_RELATIVE_POSE, "relative", (2.0 / 1000.0) ** 2, 2.5e4, 85.0),
-            ("sqpnp_absolute_pose", ransac.EST_ABS_SQPNP, "absolute", (4.0 / 1000.0) ** 2, 3.0e4, 30.0))
-    for name, est, kind, thresh, fit_flop, score_flop in legs:
+    # (name, estimator, data kind, threshold, FLOP per minimal solve, FLOP per model x correspondence, chunks of 1000 pairs run)
+    # DLS: ~0.23 MFLOP for the blocked Macaulay elimination + ~0.35 MFLOP for the 27 x 27 eigen-decomposition per solve; one
+    # chunk of the 10 (1000 pairs x 4096 hypotheses) keeps the default run inside a few minutes
+    legs = (("five_point_relative_pose", ransac.EST_RELATIVE_POSE, "relative", (2.0 / 1000.0) ** 2, 2.5e4, 85.0, PAIRS // CHUNK),
+            ("sqpnp_absolute_pose", ransac.EST_ABS_SQPNP, "absolute", (4.0 / 1000.0) ** 2, 3.0e4, 30.0, PAIRS // CHUNK),
+            ("dls_absolute_pose", ransac.EST_ABS_DLS, "absolute", (4.0 / 1000.0) ** 2, 5.8e5, 30.0, max(1, world)))
+    for name, est, kind, thresh, fit_flop, score_flop, nchunks in legs:
         p = ransac.RansacParameters(); p.error_thresh = thresh; p.min_iterations = HYPS; p.max_iterations = HYPS; p.seed = 1
         tot = {"hyp": 0, "models": 0, "wall": 0.0, "fit": 0.0, "score": 0.0, "kern": 0.0}
         first = None
-        for c in range(rank, PAIRS // CHUNK, world):   # (whole chunks of pairs per rank: same round-robin deal, coarser grain)
+        for c in range(rank, nchunks, world):   # (whole chunks of pairs per rank: same round-robin deal, coarser grain)
             data, offsets, _ = synth.synth_ransac_v1(CHUNK, CORR, kind, seed=0x5AC50005 + 977 * c)
             if first is None:
                 ransac.estimate_batch(est, data[: offsets[8]], offsets[:9], p)  # warm-up
@@ -195,6 +199,8 @@ def ransac_block(cpu_baseline, host_cores, rank=0, world=1):
                "roofline_score": {"bound": "fp64-vector", "achieved": tot["models"] * CORR * score_flop / max(tot["score"], 1e-12) / 1e12,
                                   "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "flop_per_model_correspondence": score_flop},
                "note": "wall time includes the PCIe upload of the correspondences, host sample generation and host replay"}
+        if nchunks != PAIRS // CHUNK:
+            leg["sample"] = f"{nchunks * CHUNK} of the {PAIRS} pairs (x {CORR} correspondences x {HYPS} hypotheses)"
         for r in ("roofline_fit", "roofline_score"):
             leg[r]["frac"] = leg[r]["achieved"] / FP64_VECTOR_PEAK_TFLOPS
         if cpu_baseline:
@@ -391,14 +397,16 @@ def main():
     elif not args.no_ransac:
         # configs[4] on N GPUs: the 10 000 pairs are dealt round robin over the ranks, no collective on the data path
         rb = ransac_block(False, host_cores, rank=rank, world=world)
-        t = torch.tensor([[rb[k]["wall_s"], float(rb[k]["hypotheses"])] for k in ("five_point_relative_pose", "sqpnp_absolute_pose")],
+        names = ("five_point_relative_pose", "sqpnp_absolute_pose", "dls_absolute_pose")
+        t = torch.tensor([[rb[k]["wall_s"], float(rb[k]["hypotheses"])] for k in names],
                          dtype=torch.float64, device="cuda")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         if rank == 0:
-            out["ransac"] = {"workload": rb["workload"] + f", pairs sharded round robin over {world} ranks",
-                             "five_point_relative_pose": {"hypotheses_per_sec": float(tsum[0, 1] / tmax[0, 0]), "hypotheses": float(tsum[0, 1]), "wall_s_max_over_ranks": float(tmax[0, 0])},
-                             "sqpnp_absolute_pose": {"hypotheses_per_sec": float(tsum[1, 1] / tmax[1, 0]), "hypotheses": float(tsum[1, 1]), "wall_s_max_over_ranks": float(tmax[1, 0])}}
+            out["ransac"] = {"workload": rb["workload"] + f", pairs sharded round robin over {world} ranks"}
+            for k, nm in enumerate(names):
+                out["ransac"][nm] = {"hypotheses_per_sec": float(tsum[k, 1] / tmax[k, 0]), "hypotheses": float(tsum[k, 1]),
+                                     "wall_s_max_over_ranks": float(tmax[k, 0])}
 
     if rank == 0:
         print(json.dumps(out))
