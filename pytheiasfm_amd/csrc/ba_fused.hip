@@ -370,20 +370,35 @@ __global__ __launch_bounds__(256) void k_schur_sum(int nitems, const int* __rest
   if (it >= nitems) return;
   const int* d = items + 6 * it;
   const int ri = d[0], rj = d[1], tbeg = d[2], tend = d[3], dbeg = d[4], dend = d[5];
+  // the sources of a block are added in run order (fixed), but their loads are independent: eight in flight
+  auto sum_sources = [&](int qb, int qe, int off) {
+    double v = 0.0;
+    int q = qb;
+    for (; q + 8 <= qe; q += 8) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = part[(size_t)src[q + u] + off];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = (q + u < qe) ? part[(size_t)src[min(q + u, qe - 1)] + off] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (q + u < qe) v += t[u];
+    return v;
+  };
   if (ri != rj) {
     if (lane >= 36) return;
-    double v = 0.0;
-    for (int q = tbeg; q < tend; ++q) v += part[(size_t)src[q] + lane];
+    const double v = (tend > tbeg) ? sum_sources(tbeg, tend, lane) : 0.0;
     S[(size_t)(6 * ri + lane / 6) * n + 6 * rj + lane % 6] = -v;
     return;
   }
   if (lane >= 54) return;
   const int a = lane / 9, j = lane % 9;
-  double v = 0.0;
-  for (int q = dbeg; q < dend; ++q) v += part[(size_t)src[q] + lane];
+  const double v = (dend > dbeg) ? sum_sources(dbeg, dend, lane) : 0.0;
   if (j < 6) {
-    double w = 0.0;
-    for (int q = tbeg; q < tend; ++q) w += part[(size_t)src[q] + a * 6 + j];
+    const double w = (tend > tbeg) ? sum_sources(tbeg, tend, a * 6 + j) : 0.0;
     if (j <= a) S[(size_t)(6 * ri + a) * n + 6 * ri + j] = v - w;
   } else if (j == 6) {
     rhs[6 * ri + a] = v;

@@ -116,12 +116,15 @@ __device__ __forceinline__ void potrf64_wave(double* __restrict__ A, int lda, in
     for (int j = 0; j < 16; ++j) {
       double d = readlane_d(r16[j], c0 + j);
       if (!(d > 0.0)) { bad = 1; d = 1.0; }
+      // products s_ij s_kj first (they do not wait for 1 / d); the chain per column is then
+      // pivot -> rcp -> one Newton step (v_rcp_f64 carries ~26 bits, one step leaves < 2 ulp) -> one FMA
+      double pk[16];
+#pragma unroll
+      for (int k = j + 1; k < 16; ++k) pk[k] = r16[j] * readlane_d(r16[j], c0 + k);
       double w = __builtin_amdgcn_rcp(d);
       w = __builtin_fma(w, __builtin_fma(-d, w, 1.0), w);
-      w = __builtin_fma(w, __builtin_fma(-d, w, 1.0), w);
-      const double t = r16[j] * w;
 #pragma unroll
-      for (int k = j + 1; k < 16; ++k) r16[k] = __builtin_fma(-t, readlane_d(r16[j], c0 + k), r16[k]);
+      for (int k = j + 1; k < 16; ++k) r16[k] = __builtin_fma(-pk[k], w, r16[k]);
       rs[j] = d;
     }
     // 16 independent rsqrt refinements (v_rsq_f64 seed + two Newton steps, full
@@ -288,12 +291,15 @@ __device__ __forceinline__ void potrf64_wg(double* __restrict__ A, int lda, int 
       for (int j = 0; j < 16; ++j) {
         double d = readlane_d(r16[j], c0 + j);
         if (!(d > 0.0)) { bad = 1; d = 1.0; }
+        // products s_ij s_kj first (they do not wait for 1 / d); the chain per column is then
+        // pivot -> rcp -> one Newton step (v_rcp_f64 carries ~26 bits, one step leaves < 2 ulp) -> one FMA
+        double pk[16];
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) pk[k] = r16[j] * readlane_d(r16[j], c0 + k);
         double w = __builtin_amdgcn_rcp(d);
         w = __builtin_fma(w, __builtin_fma(-d, w, 1.0), w);
-        w = __builtin_fma(w, __builtin_fma(-d, w, 1.0), w);
-        const double t = r16[j] * w;
 #pragma unroll
-        for (int k = j + 1; k < 16; ++k) r16[k] = __builtin_fma(-t, readlane_d(r16[j], c0 + k), r16[k]);
+        for (int k = j + 1; k < 16; ++k) r16[k] = __builtin_fma(-pk[k], w, r16[k]);
         rs[j] = d;
       }
 #pragma unroll
