@@ -70,9 +70,8 @@ struct DevBuf {
   int upload(const std::vector<T>& h, hipStream_t st) {
     int rc = alloc(h.size());
     if (rc) return rc;
-    // The source is a (usually temporary) pageable vector: the copy must have left it before upload() returns.
-    // An asynchronous copy from pageable memory is normally staged at once, but not reliably when several host
-    // threads load the runtime at the same time (seen as garbage index lists -> GPU memory faults).
+    // The source is a (usually temporary) pageable vector: the copy must have left it before upload() returns
+    // (large pageable sources are pinned and read by the DMA engine later, not staged at the call).
     if (!h.empty()) {
       HIP_TRY(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
       HIP_TRY(hipStreamSynchronize(st));
@@ -1640,9 +1639,8 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
     }
     bodies_enqueued += nb;
     HIP_TRY(hipGetLastError());   // a rejected launch configuration would otherwise go unnoticed
-    // read-back through the handle's pinned block (an asynchronous D2H copy into pageable memory is not reliably
-    // complete at the next synchronisation on this runtime: seen with the 8-byte trace arrays, which therefore
-    // use blocking copies below)
+    // read-back through the handle's pinned block: an asynchronous copy needs a peer that outlives the call (HIP may
+    // pin pageable pages and run the DMA later; stack temporaries were the round-1 corruption)
     HIP_TRY(hipMemcpyAsync(h->h_state, dst, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     std::memcpy(&st, h->h_state, sizeof(st));
