@@ -1148,6 +1148,266 @@ void lm_diagonal(Oracle& o) {
 
 }  // namespace
 
+
+// ============================================================ inner iterations
+// Ceres 2.2 CoordinateDescentMinimizer (coordinate_descent_minimizer.cc:113-262) as TrustRegionMinimizer runs it after
+// every candidate (DoInnerIterationsIfNeeded): the reference hands it its elimination ordering REVERSED
+// (bundle_adjuster.cc:329-333): independent set 0 = camera extrinsics, 1 = intrinsics groups, 2 = points.  Every
+// non-constant block is minimised alone, all others fixed at their current values, by a fresh trust-region solve with
+// default Minimizer::Options (LM, DENSE_QR, <= 50 iterations, 1e-6 / 1e-10 / 1e-8, radius 1e4, Jacobi scaling) over the
+// residual blocks that depend on it.  Restated with normal equations + Cholesky (same step as the QR of [J; D] up to
+// round-off) and Jets that carry only the block's parameters.
+namespace {
+
+template <int N>
+bool inner_chol_solve(const double* H /* N x N full */, const double* d, const double* g, double* y) {
+  double L[N * N];
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = H[i * N + j] + (i == j ? d[i] : 0.0);
+      for (int k = 0; k < j; ++k) s -= L[i * N + k] * L[j * N + k];
+      if (i == j) { if (!(s > 0.0)) return false; L[i * N + i] = std::sqrt(s); }
+      else L[i * N + j] = s / L[j * N + j];
+    }
+  double z[N];
+  for (int i = 0; i < N; ++i) { double s = g[i]; for (int k = 0; k < i; ++k) s -= L[i * N + k] * z[k]; z[i] = s / L[i * N + i]; }
+  for (int i = N - 1; i >= 0; --i) { double s = z[i]; for (int k = i + 1; k < N; ++k) s -= L[k * N + i] * y[k]; y[i] = s / L[i * N + i]; }
+  return true;
+}
+
+// lin(x, J-scale, H, g, &cost) -> false if a functor failed; costf(x, &cost) likewise; plus(x, tangent step, out)
+template <int N, int NA, class Lin, class CostF, class Plus>
+void inner_block_lm(double* x, Lin lin, CostF costf, Plus plus) {
+  double scale[N], H[N * N], g[N], x_cost = 0.0;
+  for (int q = 0; q < N; ++q) scale[q] = 1.0;
+  if (!lin(x, scale, H, g, &x_cost) || !std::isfinite(x_cost)) return;
+  for (int q = 0; q < N; ++q) scale[q] = 1.0 / (1.0 + std::sqrt(H[q * N + q]));
+  double radius = 1e4, decrease_factor = 2.0, x_norm = 0.0, gmax = 0.0;
+  for (int q = 0; q < NA; ++q) x_norm += x[q] * x[q];
+  x_norm = std::sqrt(x_norm);
+  bool step_successful = true, need_lin = true;
+  int iter = 0, invalid_steps = 0;
+  while (true) {
+    if (need_lin) {
+      lin(x, scale, H, g, &x_cost);
+      gmax = 0.0;
+      for (int q = 0; q < N; ++q) gmax = std::max(gmax, std::fabs(g[q] / scale[q]));
+      need_lin = false;
+    }
+    if (iter >= 50) break;
+    if (step_successful && gmax <= 1e-10) break;
+    if (radius <= 1e-32) break;
+    ++iter;
+    double d[N], y[N];
+    for (int q = 0; q < N; ++q) d[q] = std::min(std::max(H[q * N + q], 1e-6), 1e32) / radius;
+    const bool pd = inner_chol_solve<N>(H, d, g, y);
+    double yg = 0.0, yHy = 0.0;
+    for (int a = 0; a < N; ++a) { yg += y[a] * g[a]; double row = 0.0; for (int b = 0; b < N; ++b) row += H[a * N + b] * y[b]; yHy += y[a] * row; }
+    const double mcc = yg - 0.5 * yHy;
+    double step[N], xc[NA], stepsq = 0.0, xnormsq = 0.0;
+    for (int q = 0; q < N; ++q) step[q] = -y[q] * scale[q];
+    plus(x, step, xc);
+    for (int q = 0; q < NA; ++q) { stepsq += (x[q] - xc[q]) * (x[q] - xc[q]); xnormsq += xc[q] * xc[q]; }
+    if (!(pd && std::isfinite(mcc) && std::isfinite(stepsq) && mcc > 0.0)) {
+      if (++invalid_steps >= 5) break;
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+      continue;
+    }
+    invalid_steps = 0;
+    double cand_cost;
+    if (!costf(xc, &cand_cost) || !std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
+    if (std::sqrt(stepsq) <= 1e-8 * (x_norm + 1e-8)) break;
+    const double cost_change = x_cost - cand_cost;
+    if (std::fabs(cost_change) <= 1e-6 * x_cost) break;
+    const double rho = cost_change / mcc;
+    if (rho > 1e-3) {
+      for (int q = 0; q < NA; ++q) x[q] = xc[q];
+      x_norm = std::sqrt(xnormsq);
+      radius = std::min(1e16, radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)));
+      decrease_factor = 2.0; step_successful = true; need_lin = true;
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+    }
+  }
+}
+
+// accumulate one residual row pair (already loss-weighted) with its N-column Jacobian rows
+template <int N>
+inline void inner_add_rows(int nrows, const double* res, const double* J /* nrows x N */, double* H, double* g) {
+  for (int a = 0; a < nrows; ++a)
+    for (int i = 0; i < N; ++i) {
+      g[i] += J[a * N + i] * res[a];
+      for (int j = 0; j < N; ++j) H[i * N + j] += J[a * N + i] * J[a * N + j];
+    }
+}
+
+void coordinate_descent(const Oracle& o, std::vector<double>& cam, std::vector<double>& pts, std::vector<double>& intr) {
+  const oba_problem& P = *o.P;
+  const double one[2] = {1.0, 1.0};
+  // observation lists by camera and by group (the residual blocks that depend on the block)
+  std::vector<std::vector<int64_t>> by_cam(o.nc), by_grp(o.ng);
+  for (int64_t i = 0; i < o.nobs; ++i) {
+    if (o.obs_fixed[i]) continue;
+    by_cam[P.obs_cam[i]].push_back(i);
+    if (!(P.obs_kind && P.obs_kind[i])) by_grp[P.cam_group[P.obs_cam[i]]].push_back(i);
+  }
+  auto obs_model = [&](int64_t i) { return (P.obs_kind && P.obs_kind[i]) ? kDepthRow : P.group_model[P.cam_group[P.obs_cam[i]]]; };
+  auto obs_width = [&](int64_t i) { return (P.obs_kind && P.obs_kind[i]) ? o.O.robust_loss_width_depth_prior : o.O.robust_loss_width; };
+  // development switch shared with the device (THEIA_HIP_INNER_SKIP: bit 0 cameras, 1 intrinsics, 2 points)
+  const char* skip_env = getenv("THEIA_HIP_INNER_SKIP");
+  const int skip = skip_env ? atoi(skip_env) : 0;
+  // ---- set 0: camera extrinsics
+  for (int c = 0; c < o.nc; ++c) {
+    if (skip & 1) break;
+    if (o.cam_red[c] < 0) continue;
+    const unsigned mask = o.cam_mask[c];
+    if ((mask & 0x3fu) == 0x3fu) continue;
+    const int g = P.cam_group[c];
+    auto run = [&](const double* x, const double* scale, bool want_jac, double* H, double* gg, double* cost) {
+      bool ok = true;
+      double cst = 0.0;
+      if (want_jac) { for (int k = 0; k < 36; ++k) H[k] = 0.0; for (int k = 0; k < 6; ++k) gg[k] = 0.0; }
+      for (int64_t i : by_cam[c]) {
+        const int p = P.obs_pt[i];
+        const double* si = P.obs_sqrt_info ? P.obs_sqrt_info + 2 * i : one;
+        double res[2], J[12];
+        if (want_jac) {
+          typedef Jet<6> J6;
+          J6 e[6], k[kMaxIntr], X[4], rr[2];
+          for (int q = 0; q < 6; ++q) e[q] = J6(x[q], q);
+          for (int q = 0; q < kMaxIntr; ++q) k[q] = J6(intr[(size_t)g * kMaxIntr + q]);
+          for (int q = 0; q < 4; ++q) X[q] = J6(pts[4 * (size_t)p + q]);
+          if (!reprojection_error<J6>(obs_model(i), e, k, X, P.obs_uv + 2 * i, si, rr)) ok = false;
+          for (int a = 0; a < 2; ++a) { res[a] = rr[a].a; for (int q = 0; q < 6; ++q) J[6 * a + q] = rr[a].v[q]; }
+        } else if (!reprojection_error<double>(obs_model(i), x, &intr[(size_t)g * kMaxIntr], &pts[4 * (size_t)p], P.obs_uv + 2 * i, si, res)) ok = false;
+        double rho[3];
+        loss_evaluate(o.O.loss_function_type, obs_width(i), res[0] * res[0] + res[1] * res[1], rho);
+        cst += 0.5 * rho[0];
+        if (!want_jac) continue;
+        const double sr = std::sqrt(rho[1]);
+        for (int a = 0; a < 2; ++a) { res[a] *= sr; for (int q = 0; q < 6; ++q) J[6 * a + q] *= ((mask >> q) & 1u) ? 0.0 : sr * scale[q]; }
+        inner_add_rows<6>(2, res, J, H, gg);
+      }
+      for (const Oracle::Prior& pr : o.priors) {
+        if (pr.cam != c) continue;
+        double r3[3], J[18];
+        if (want_jac) {
+          typedef Jet<6> J6;
+          J6 e[6], rr[3];
+          for (int q = 0; q < 6; ++q) e[q] = J6(x[q], q);
+          camera_prior_residual<J6>(pr.kind, e, pr.vec, pr.sqrt_info, rr);
+          for (int a = 0; a < 3; ++a) { r3[a] = rr[a].a; for (int q = 0; q < 6; ++q) J[6 * a + q] = ((mask >> q) & 1u) ? 0.0 : rr[a].v[q] * scale[q]; }
+        } else camera_prior_residual<double>(pr.kind, x, pr.vec, pr.sqrt_info, r3);
+        cst += 0.5 * (r3[0] * r3[0] + r3[1] * r3[1] + r3[2] * r3[2]);
+        if (want_jac) inner_add_rows<6>(3, r3, J, H, gg);
+      }
+      *cost = cst;
+      return ok;
+    };
+    inner_block_lm<6, 6>(&cam[6 * (size_t)c],
+        [&](const double* x, const double* scale, double* H, double* gg, double* cost) { return run(x, scale, true, H, gg, cost); },
+        [&](const double* x, double* cost) { return run(x, nullptr, false, nullptr, nullptr, cost); },
+        [&](const double* x, const double* step, double* out) { for (int q = 0; q < 6; ++q) out[q] = ((mask >> q) & 1u) ? x[q] : x[q] + step[q]; });
+  }
+  // ---- set 1: intrinsics groups
+  for (int g = 0; g < o.ng; ++g) {
+    if (skip & 2) break;
+    if (o.grp_red[g] < 0 || !o.grp_free[g]) continue;
+    const unsigned fm = o.grp_free[g];
+    auto run = [&](const double* x, const double* scale, bool want_jac, double* H, double* gg, double* cost) {
+      bool ok = true;
+      double cst = 0.0;
+      if (want_jac) { for (int k = 0; k < 100; ++k) H[k] = 0.0; for (int k = 0; k < 10; ++k) gg[k] = 0.0; }
+      for (int64_t i : by_grp[g]) {
+        const int c = P.obs_cam[i], p = P.obs_pt[i];
+        const double* si = P.obs_sqrt_info ? P.obs_sqrt_info + 2 * i : one;
+        double res[2], J[20];
+        if (want_jac) {
+          typedef Jet<10> JK;
+          JK e[6], k[kMaxIntr], X[4], rr[2];
+          for (int q = 0; q < 6; ++q) e[q] = JK(cam[6 * (size_t)c + q]);
+          for (int q = 0; q < kMaxIntr; ++q) k[q] = JK(x[q], q);
+          for (int q = 0; q < 4; ++q) X[q] = JK(pts[4 * (size_t)p + q]);
+          if (!reprojection_error<JK>(P.group_model[g], e, k, X, P.obs_uv + 2 * i, si, rr)) ok = false;
+          for (int a = 0; a < 2; ++a) { res[a] = rr[a].a; for (int q = 0; q < 10; ++q) J[10 * a + q] = rr[a].v[q]; }
+        } else if (!reprojection_error<double>(P.group_model[g], &cam[6 * (size_t)c], x, &pts[4 * (size_t)p], P.obs_uv + 2 * i, si, res)) ok = false;
+        double rho[3];
+        loss_evaluate(o.O.loss_function_type, o.O.robust_loss_width, res[0] * res[0] + res[1] * res[1], rho);
+        cst += 0.5 * rho[0];
+        if (!want_jac) continue;
+        const double sr = std::sqrt(rho[1]);
+        for (int a = 0; a < 2; ++a) { res[a] *= sr; for (int q = 0; q < 10; ++q) J[10 * a + q] *= ((fm >> q) & 1u) ? sr * scale[q] : 0.0; }
+        inner_add_rows<10>(2, res, J, H, gg);
+      }
+      *cost = cst;
+      return ok;
+    };
+    inner_block_lm<10, 10>(&intr[(size_t)g * kMaxIntr],
+        [&](const double* x, const double* scale, double* H, double* gg, double* cost) { return run(x, scale, true, H, gg, cost); },
+        [&](const double* x, double* cost) { return run(x, nullptr, false, nullptr, nullptr, cost); },
+        [&](const double* x, const double* step, double* out) { for (int q = 0; q < 10; ++q) out[q] = ((fm >> q) & 1u) ? x[q] + step[q] : x[q]; });
+  }
+  // ---- set 2: points
+  const int pd = o.pd;
+  for (int p = 0; p < o.np; ++p) {
+    if (skip & 4) break;
+    if (o.pt_const[p] || o.pt_off[p] == o.pt_off[p + 1]) continue;
+    auto run = [&](const double* x, const double* scale, bool want_jac, double* H, double* gg, double* cost, int n) {
+      bool ok = true;
+      double cst = 0.0;
+      if (want_jac) { for (int k = 0; k < n * n; ++k) H[k] = 0.0; for (int k = 0; k < n; ++k) gg[k] = 0.0; }
+      double PJ[12];
+      if (want_jac && pd == 3) sphere_plus_jacobian(x, PJ);
+      for (int64_t kk = o.pt_off[p]; kk < o.pt_off[p + 1]; ++kk) {
+        const int64_t i = o.pt_obs[kk];
+        if (o.obs_fixed[i]) continue;
+        const int c = P.obs_cam[i], g = P.cam_group[c];
+        const double* si = P.obs_sqrt_info ? P.obs_sqrt_info + 2 * i : one;
+        double res[2], J4[8];
+        if (want_jac) {
+          typedef Jet<4> J4T;
+          J4T e[6], k[kMaxIntr], X[4], rr[2];
+          for (int q = 0; q < 6; ++q) e[q] = J4T(cam[6 * (size_t)c + q]);
+          for (int q = 0; q < kMaxIntr; ++q) k[q] = J4T(intr[(size_t)g * kMaxIntr + q]);
+          for (int q = 0; q < 4; ++q) X[q] = J4T(x[q], q);
+          if (!reprojection_error<J4T>(obs_model(i), e, k, X, P.obs_uv + 2 * i, si, rr)) ok = false;
+          for (int a = 0; a < 2; ++a) { res[a] = rr[a].a; for (int q = 0; q < 4; ++q) J4[4 * a + q] = rr[a].v[q]; }
+        } else if (!reprojection_error<double>(obs_model(i), &cam[6 * (size_t)c], &intr[(size_t)g * kMaxIntr], x, P.obs_uv + 2 * i, si, res)) ok = false;
+        double rho[3];
+        loss_evaluate(o.O.loss_function_type, obs_width(i), res[0] * res[0] + res[1] * res[1], rho);
+        cst += 0.5 * rho[0];
+        if (!want_jac) continue;
+        const double sr = std::sqrt(rho[1]);
+        double J[8];
+        for (int a = 0; a < 2; ++a) {
+          res[a] *= sr;
+          for (int q = 0; q < n; ++q) {
+            double v;
+            if (pd == 3) { v = 0.0; for (int t = 0; t < 4; ++t) v += J4[4 * a + t] * PJ[t * 3 + q]; }
+            else v = J4[4 * a + q];
+            J[n * a + q] = v * sr * scale[q];
+          }
+        }
+        if (n == 3) inner_add_rows<3>(2, res, J, H, gg); else inner_add_rows<4>(2, res, J, H, gg);
+      }
+      *cost = cst;
+      return ok;
+    };
+    if (pd == 3)
+      inner_block_lm<3, 4>(&pts[4 * (size_t)p],
+          [&](const double* x, const double* scale, double* H, double* gg, double* cost) { return run(x, scale, true, H, gg, cost, 3); },
+          [&](const double* x, double* cost) { return run(x, nullptr, false, nullptr, nullptr, cost, 3); },
+          [&](const double* x, const double* step, double* out) { sphere_plus(x, step, out); });
+    else
+      inner_block_lm<4, 4>(&pts[4 * (size_t)p],
+          [&](const double* x, const double* scale, double* H, double* gg, double* cost) { return run(x, scale, true, H, gg, cost, 4); },
+          [&](const double* x, double* cost) { return run(x, nullptr, false, nullptr, nullptr, cost, 4); },
+          [&](const double* x, const double* step, double* out) { for (int q = 0; q < 4; ++q) out[q] = x[q] + step[q]; });
+  }
+}
+
+}  // namespace
+
 extern "C" {
 
 // Threads of the all-cores CPU baseline (1 = the serial reference path of the tests); returns the previous value.
@@ -1275,6 +1535,7 @@ int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
   trace_push(S, x_cost + o.fixed_cost, gmax, 0.0, radius, 1);
   int term = 1;
   const int n = o.n();
+  bool inner_enabled = O->use_inner_iterations != 0;
   while (true) {
     // FinalizeIterationAndCheckIfMinimizerCanContinue
     if (now_s() - t1 >= O->max_solver_time_in_seconds) { term = 1; break; }
@@ -1335,6 +1596,21 @@ int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
       else for (int q = 0; q < 4; ++q) o.cpts[4 * p + q] = o.pts[4 * p + q] + d[q]; }
     double cand_cost;
     if (!evaluate(o, o.ccam, o.cpts, o.cintr, false, &cand_cost)) cand_cost = std::numeric_limits<double>::max();
+    // TrustRegionMinimizer::DoInnerIterationsIfNeeded (trust_region_minimizer.cc)
+    bool inner_useful = false;
+    if (inner_enabled && cand_cost < std::numeric_limits<double>::max()) {
+      std::vector<double> icam = o.ccam, ipts = o.cpts, iintr = o.cintr;
+      coordinate_descent(o, icam, ipts, iintr);
+      double inner_cost;
+      if (evaluate(o, icam, ipts, iintr, false, &inner_cost)) {
+        o.ccam.swap(icam); o.cpts.swap(ipts); o.cintr.swap(iintr);
+        model_cost_change += cand_cost - inner_cost;
+        inner_useful = inner_cost < x_cost;
+        const double progress = 1.0 - inner_cost / cand_cost;
+        inner_enabled = progress > 1e-3;   // inner_iteration_tolerance
+        cand_cost = inner_cost;
+      }
+    }
     S->time_backsub += now_s() - ts;
     // ParameterToleranceReached
     double sn = 0;
@@ -1349,7 +1625,7 @@ int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
     if (std::fabs(cost_change) <= O->function_tolerance * x_cost) {
       trace_push(S, cand_cost + o.fixed_cost, gmax, step_norm, radius, 0); term = 0; break; }
     const double relative_decrease = cost_change / model_cost_change;
-    if (relative_decrease > 1e-3) {
+    if (inner_useful || relative_decrease > 1e-3) {
       o.cam.swap(o.ccam); o.pts.swap(o.cpts); o.intr.swap(o.cintr);
       x_norm = state_norm(o, o.cam, o.pts, o.intr);
       double tl2 = now_s();

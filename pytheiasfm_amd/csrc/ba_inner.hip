@@ -1,0 +1,480 @@
+// Inner iterations of the bundle adjustment (Ceres 2.2 TrustRegionMinimizer::DoInnerIterationsIfNeeded +
+// CoordinateDescentMinimizer, enabled by default: bundle_adjustment.h:144, wired at bundle_adjuster.cc:75,329-333).
+//
+// After every trust-region candidate Ceres runs one sweep of block coordinate descent over the reversed elimination
+// ordering the reference hands it (`inner_iteration_ordering->Reverse()`): group 0 = camera extrinsics, 1 = shared
+// intrinsics, 2 = points.  The blocks of a group are independent (no residual touches two of them), each is minimised
+// ALONE -- every other block held at its current value, later groups see the earlier groups' results -- by a fresh
+// Levenberg-Marquardt solve with the default Minimizer::Options (coordinate_descent_minimizer.cc:229-262: LM, DENSE_QR,
+// at most 50 iterations, tolerances 1e-6 / 1e-10 / 1e-8, initial radius 1e4, Jacobi scaling) over the residual blocks
+// that depend on it, loss functions included.
+//
+// On the device the three groups are three launches over the candidate buffers:
+//   k_inner_views   one WAVE per variable camera: lane = observation of the camera's list (built at create()), 6 x 6
+//                   normal equations by wave reduction (the camera's prior rows included);
+//   k_inner_groups  one WORKGROUP per variable intrinsics group: 10 x 10 over every observation of the group's cameras;
+//   k_inner_tracks  one THREAD per variable point: PD x PD (SphereManifold<4> tangent or plain XYZW).
+// Every kernel reads a device flag first (inner iterations switch themselves off when their relative progress drops
+// below inner_iteration_tolerance = 1e-3, trust_region_minimizer.cc) and returns at once when it is clear.
+// The normal equations are solved by Cholesky instead of Ceres' QR of [J; D]: the same step up to round-off.
+#include "ba_kernels.h"
+#include "ba_device.h"
+#include "ba_priors.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace thip {
+namespace {
+
+constexpr int kInnerMaxIterations = 50;              // Solver::Options defaults behind Minimizer::Options()
+constexpr double kInnerFunctionTolerance = 1e-6, kInnerGradientTolerance = 1e-10, kInnerParameterTolerance = 1e-8;
+constexpr double kInnerMaxRadius = 1e16;
+
+__device__ __forceinline__ int itri(int a, int b) { return a * (a + 1) / 2 + b; }
+
+template <int N>
+__device__ bool chol_solve_small(const double* H, const double* d, const double* g, double* y) {
+  constexpr int NT = N * (N + 1) / 2;
+  double L[NT];
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = H[itri(i, j)] + (i == j ? d[i] : 0.0);
+      for (int k = 0; k < j; ++k) s -= L[itri(i, k)] * L[itri(j, k)];
+      if (i == j) { if (!(s > 0.0)) return false; L[itri(i, i)] = sqrt(s); }
+      else L[itri(i, j)] = s / L[itri(j, j)];
+    }
+  double z[N];
+  for (int i = 0; i < N; ++i) {
+    double s = g[i];
+    for (int k = 0; k < i; ++k) s -= L[itri(i, k)] * z[k];
+    z[i] = s / L[itri(i, i)];
+  }
+  for (int i = N - 1; i >= 0; --i) {
+    double s = z[i];
+    for (int k = i + 1; k < N; ++k) s -= L[itri(k, i)] * y[k];
+    y[i] = s / L[itri(i, i)];
+  }
+  return true;
+}
+
+// One block's LM solve (trust_region_minimizer.cc with LevenbergMarquardtStrategy, the rules of ba_solver.hip's
+// lm_control_body).  Every thread of the team runs this loop with the same values; only the functors cooperate:
+//   lin(x, scale, H, g, &cost, &invalid)   J'J (packed lower), J'r of the scaled Jacobian, cost, invalid functor
+//   cost(xc, &invalid)                      cost only
+//   plus(x, step /* tangent, already scaled */, xc)   x (+) step in the ambient space (NA doubles)
+template <int N, int NA, class Lin, class Cost, class Plus>
+__device__ void block_lm(double* x, Lin&& lin, Cost&& cost, Plus&& plus) {
+  constexpr int NT = N * (N + 1) / 2;
+  double scale[N], H[NT], g[N], x_cost = 0.0;
+  bool invalid = false;
+  for (int q = 0; q < N; ++q) scale[q] = 1.0;
+  lin(x, scale, H, g, &x_cost, &invalid);
+  if (invalid || !isfinite(x_cost)) return;   // "if the optimization is a failure ... it won't change the parameters"
+  for (int q = 0; q < N; ++q) scale[q] = 1.0 / (1.0 + sqrt(H[itri(q, q)]));
+  double radius = 1e4, decrease_factor = 2.0;
+  bool step_successful = true, need_linearize = true;
+  int iter = 0, invalid_steps = 0;
+  double x_norm = 0.0, gmax = 0.0;
+  for (int q = 0; q < NA; ++q) x_norm += x[q] * x[q];
+  x_norm = sqrt(x_norm);
+  while (true) {
+    if (need_linearize) {
+      lin(x, scale, H, g, &x_cost, &invalid);
+      gmax = 0.0;
+      for (int q = 0; q < N; ++q) gmax = fmax(gmax, fabs(g[q] / scale[q]));
+      need_linearize = false;
+    }
+    if (iter >= kInnerMaxIterations) break;
+    if (step_successful && gmax <= kInnerGradientTolerance) break;
+    if (radius <= 1e-32) break;
+    ++iter;
+    double d[N], y[N];
+    for (int q = 0; q < N; ++q) d[q] = fmin(fmax(H[itri(q, q)], 1e-6), 1e32) / radius;
+    const bool pd = chol_solve_small<N>(H, d, g, y);
+    double yg = 0.0, yHy = 0.0;
+    for (int a = 0; a < N; ++a) {
+      yg += y[a] * g[a];
+      double row = 0.0;
+      for (int b = 0; b < N; ++b) row += H[a >= b ? itri(a, b) : itri(b, a)] * y[b];
+      yHy += y[a] * row;
+    }
+    const double mcc = yg - 0.5 * yHy;
+    double step[N], xc[NA], stepsq = 0.0, xnormsq = 0.0;
+    for (int q = 0; q < N; ++q) step[q] = -y[q] * scale[q];
+    plus(x, step, xc);
+    for (int q = 0; q < NA; ++q) { stepsq += (x[q] - xc[q]) * (x[q] - xc[q]); xnormsq += xc[q] * xc[q]; }
+    if (!(pd && isfinite(mcc) && isfinite(stepsq) && mcc > 0.0)) {
+      if (++invalid_steps >= 5) break;
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+      continue;
+    }
+    invalid_steps = 0;
+    bool cinv = false;
+    double cand_cost = cost(xc, &cinv);
+    if (cinv || !isfinite(cand_cost)) cand_cost = DBL_MAX;
+    if (sqrt(stepsq) <= kInnerParameterTolerance * (x_norm + kInnerParameterTolerance)) break;
+    const double cost_change = x_cost - cand_cost;
+    if (fabs(cost_change) <= kInnerFunctionTolerance * x_cost) break;
+    const double rho = cost_change / mcc;
+    if (rho > 1e-3) {
+      for (int q = 0; q < NA; ++q) x[q] = xc[q];
+      x_norm = sqrt(xnormsq);
+      const double t = 2.0 * rho - 1.0;
+      radius = fmin(kInnerMaxRadius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+      decrease_factor = 2.0; step_successful = true; need_linearize = true;
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
+    }
+  }
+}
+
+__device__ __forceinline__ double wave_sum64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+struct ObsRef { double2 uv; double six, siy; int cam, pt; bool depth_row; };
+__device__ __forceinline__ ObsRef load_obs(const InnerArgs& A, int o) {
+  ObsRef r;
+  r.uv = A.P.obs_uv[o];
+  // the optional arrays always point at mapped memory here (launch_inner_* substitutes obs_uv / obs_cam when they are
+  // absent): the compiler was seen hoisting these loads above the null test
+  const double2 si = A.P.obs_si[o];
+  r.six = A.has_si ? si.x : 1.0; r.siy = A.has_si ? si.y : 1.0;
+  r.cam = A.P.obs_cam[o]; r.pt = A.P.obs_pt[o];
+  r.depth_row = A.has_kind && A.P.obs_kind[o];
+  return r;
+}
+__device__ __forceinline__ double obs_loss(const InnerArgs& A, const ObsRef& r, double s, double* rho1) {
+  return loss_eval(A.P.loss_type, r.depth_row ? A.P.loss_width_depth : A.P.loss_width, s, rho1);
+}
+
+// ------------------------------------------------------------------ cameras
+__global__ __launch_bounds__(256) void k_inner_views(InnerArgs A) {
+  if (!*A.gate) return;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= A.P.nc || A.P.cam_red[c] < 0) return;
+  const unsigned mask = A.P.cam_mask[c];
+  if ((mask & 0x3fu) == 0x3fu) return;
+  const int beg = A.cam_obs_off[c], end = A.cam_obs_off[c + 1];
+  const int grp = A.P.cam_group[c];
+  const int model = A.P.group_model[grp];
+  double intr[THEIA_MAX_INTRINSICS];
+  for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) intr[q] = A.intr[(size_t)grp * THEIA_MAX_INTRINSICS + q];
+  double x[6];
+  for (int q = 0; q < 6; ++q) x[q] = A.cam[6 * (size_t)c + q];
+
+  auto accumulate = [&](const double* ext, const double* scale, bool want_jac, double* H, double* g, double* cost_out, bool* invalid) {
+    double acc[28];
+    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+    double inv = 0.0;
+    for (int i = beg + lane; i < end; i += 64) {
+      const ObsRef ob = load_obs(A, A.cam_obs_idx[i]);
+      const double4 Xv = reinterpret_cast<const double4*>(A.pts)[ob.pt];
+      const double X[4] = {Xv.x, Xv.y, Xv.z, Xv.w};
+      ObsLin ol;
+      const int m = ob.depth_row ? THIP_MODEL_DEPTH_ROW : model;
+      if (want_jac) observe<true, false>(m, ext, intr, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
+      else observe<false, false>(m, ext, intr, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
+      if (!ol.valid) inv += 1.0;
+      double rho1;
+      acc[27] += 0.5 * obs_loss(A, ob, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
+      if (!want_jac) continue;
+      const double sr = sqrt(rho1);
+      const double r0 = sr * ol.r[0], r1 = sr * ol.r[1];
+      double J[12];
+      for (int q = 0; q < 6; ++q) {
+        const double sc = ((mask >> q) & 1u) ? 0.0 : sr * scale[q];
+        J[q] = ol.Jc[q] * sc; J[6 + q] = ol.Jc[6 + q] * sc;
+      }
+      int k = 0;
+      for (int a = 0; a < 6; ++a) {
+        for (int b = 0; b <= a; ++b) acc[k++] += J[a] * J[b] + J[6 + a] * J[6 + b];
+        acc[21 + a] += J[a] * r0 + J[6 + a] * r1;
+      }
+    }
+    // the camera's prior rows (3 residuals each, no loss): bundle_adjuster.cc:291-313
+    for (int i = lane; i < A.P.n_priors; i += 64) {
+      if (A.P.prior_cam[i] != c) continue;
+      double r[3], Jp[18];
+      camera_prior(A.P.prior_kind[i], ext, A.P.prior_vec + 3 * (size_t)i, A.P.prior_info + 9 * (size_t)i, want_jac, r, Jp);
+      acc[27] += 0.5 * ((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+      if (!want_jac) continue;
+      for (int row = 0; row < 3; ++row) {
+        double J[6];
+        for (int q = 0; q < 6; ++q) J[q] = ((mask >> q) & 1u) ? 0.0 : Jp[6 * row + q] * scale[q];
+        int k = 0;
+        for (int a = 0; a < 6; ++a) {
+          for (int b = 0; b <= a; ++b) acc[k++] += J[a] * J[b];
+          acc[21 + a] += J[a] * r[row];
+        }
+      }
+    }
+    for (int k = 0; k < 28; ++k) acc[k] = wave_sum64(acc[k]);
+    if (H) { for (int k = 0; k < 21; ++k) H[k] = acc[k]; for (int k = 0; k < 6; ++k) g[k] = acc[21 + k]; }
+    *cost_out = acc[27];
+    *invalid = wave_sum64(inv) > 0.0;
+  };
+  block_lm<6, 6>(
+      x,
+      [&](const double* xx, const double* scale, double* H, double* g, double* cost, bool* invalid) { accumulate(xx, scale, true, H, g, cost, invalid); },
+      [&](const double* xc, bool* invalid) { double cst; accumulate(xc, nullptr, false, nullptr, nullptr, &cst, invalid); return cst; },
+      [&](const double* xx, const double* step, double* xc) { for (int q = 0; q < 6; ++q) xc[q] = ((mask >> q) & 1u) ? xx[q] : xx[q] + step[q]; });
+  if (lane == 0) for (int q = 0; q < 6; ++q) A.cam[6 * (size_t)c + q] = x[q];
+}
+
+// ------------------------------------------------------------------ shared intrinsics
+__global__ __launch_bounds__(256) void k_inner_groups(InnerArgs A) {
+  if (!*A.gate) return;
+  __shared__ double red[4][68];
+  const int grp = blockIdx.x;
+  if (grp >= A.P.ng_total || A.P.grp_red[grp] < 0) return;
+  const unsigned free_mask = A.P.grp_free[grp];
+  if (!free_mask) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int model = A.P.group_model[grp];
+  const int beg = A.grp_obs_off[grp], end = A.grp_obs_off[grp + 1];
+  constexpr int K = THEIA_MAX_INTRINSICS;
+  double x[K];
+  for (int q = 0; q < K; ++q) x[q] = A.intr[(size_t)grp * K + q];
+
+  auto accumulate = [&](const double* kk, const double* scale, bool want_jac, double* H, double* g, double* cost_out, bool* invalid) {
+    double acc[67];
+    for (int k = 0; k < 67; ++k) acc[k] = 0.0;
+    for (int i = beg + tid; i < end; i += 256) {
+      const ObsRef ob = load_obs(A, A.grp_obs_idx[i]);
+      if (ob.depth_row) {   // a depth-prior row does not depend on the intrinsics: constant in this block's problem
+        continue;
+      }
+      const double4 Xv = reinterpret_cast<const double4*>(A.pts)[ob.pt];
+      const double X[4] = {Xv.x, Xv.y, Xv.z, Xv.w};
+      ObsLinK ol;
+      if (want_jac) observe<true, true, ObsLinK>(model, A.cam + 6 * (size_t)ob.cam, kk, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
+      else observe<false, false, ObsLinK>(model, A.cam + 6 * (size_t)ob.cam, kk, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
+      if (!ol.valid) acc[66] += 1.0;
+      double rho1;
+      acc[65] += 0.5 * obs_loss(A, ob, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
+      if (!want_jac) continue;
+      const double sr = sqrt(rho1);
+      const double r0 = sr * ol.r[0], r1 = sr * ol.r[1];
+      double J[2 * K];
+      for (int q = 0; q < K; ++q) {
+        const double sc = ((free_mask >> q) & 1u) ? sr * scale[q] : 0.0;
+        J[q] = ol.Jk[q] * sc; J[K + q] = ol.Jk[K + q] * sc;
+      }
+      int k = 0;
+      for (int a = 0; a < K; ++a) {
+        for (int b = 0; b <= a; ++b) acc[k++] += J[a] * J[b] + J[K + a] * J[K + b];
+        acc[55 + a] += J[a] * r0 + J[K + a] * r1;
+      }
+    }
+    __syncthreads();
+    for (int k = 0; k < 67; ++k) {
+      const double v = wave_sum64(acc[k]);
+      if (lane == 0) red[wv][k] = v;
+    }
+    __syncthreads();
+    for (int k = 0; k < 67; ++k) acc[k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    if (H) { for (int k = 0; k < 55; ++k) H[k] = acc[k]; for (int k = 0; k < K; ++k) g[k] = acc[55 + k]; }
+    *cost_out = acc[65];
+    *invalid = acc[66] > 0.0;
+  };
+  block_lm<K, K>(
+      x,
+      [&](const double* xx, const double* scale, double* H, double* g, double* cost, bool* invalid) { accumulate(xx, scale, true, H, g, cost, invalid); },
+      [&](const double* xc, bool* invalid) { double cst; accumulate(xc, nullptr, false, nullptr, nullptr, &cst, invalid); return cst; },
+      [&](const double* xx, const double* step, double* xc) { for (int q = 0; q < K; ++q) xc[q] = ((free_mask >> q) & 1u) ? xx[q] + step[q] : xx[q]; });
+  if (tid == 0) for (int q = 0; q < K; ++q) A.intr[(size_t)grp * K + q] = x[q];
+}
+
+// ------------------------------------------------------------------ points
+// accumulate() is kept out of line on purpose: with it inlined into the LM loop, hipcc 7.2 -O2 / -O3 produced wrong
+// steps for this per-thread kernel (the -O1 build, the build with the body behind a call, and the two cooperative
+// kernels above all agree with the oracle to 1e-14; scripts/gpu_check_inner.py with THEIA_HIP_INNER_SKIP=3).
+template <int PD>
+struct TrackFn {
+  const InnerArgs* A;
+  int beg, end;
+  __device__ __attribute__((noinline)) void accumulate(const double* X, const double* scale, bool want_jac, double* H, double* g, double* cost_out, bool* invalid) const {
+    constexpr int NT = PD * (PD + 1) / 2;
+    const InnerArgs& Ar = *A;
+    if (want_jac) { for (int k = 0; k < NT; ++k) H[k] = 0.0; for (int k = 0; k < PD; ++k) g[k] = 0.0; }
+    double cst = 0.0;
+    bool inv = false;
+    for (int o = beg; o < end; ++o) {
+      const ObsRef ob = load_obs(Ar, o);
+      const int grp = Ar.P.cam_group[ob.cam];
+      const int m = ob.depth_row ? THIP_MODEL_DEPTH_ROW : Ar.P.group_model[grp];
+      const double* ext = Ar.cam + 6 * (size_t)ob.cam;
+      const double* kk = Ar.intr + (size_t)grp * THEIA_MAX_INTRINSICS;
+      ObsLin ol;
+      if (want_jac) observe<true, false>(m, ext, kk, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
+      else observe<false, false>(m, ext, kk, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
+      if (!ol.valid) inv = true;
+      double rho1;
+      cst += 0.5 * obs_loss(Ar, ob, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
+      if (!want_jac) continue;
+      const double sr = sqrt(rho1);
+      const double r0 = sr * ol.r[0], r1 = sr * ol.r[1];
+      double J[2 * PD];
+      if (PD == 3) {
+        double Jt[6];
+        to_tangent(X, ol.Jx, Jt);
+        for (int q = 0; q < 3; ++q) { J[q] = Jt[q] * sr * scale[q]; J[PD + q] = Jt[3 + q] * sr * scale[q]; }
+      } else {
+        for (int q = 0; q < PD; ++q) { J[q] = ol.Jx[q] * sr * scale[q]; J[PD + q] = ol.Jx[4 + q] * sr * scale[q]; }
+      }
+      int k = 0;
+      for (int a = 0; a < PD; ++a) {
+        for (int b = 0; b <= a; ++b) H[k++] += J[a] * J[b] + J[PD + a] * J[PD + b];
+        g[a] += J[a] * r0 + J[PD + a] * r1;
+      }
+    }
+    *cost_out = cst; *invalid = inv;
+  }
+};
+template <int PD> struct TrackLin {
+  TrackFn<PD> f;
+  __device__ void operator()(const double* x, const double* scale, double* H, double* g, double* cost, bool* invalid) const { f.accumulate(x, scale, true, H, g, cost, invalid); }
+};
+template <int PD> struct TrackCost {
+  TrackFn<PD> f;
+  __device__ double operator()(const double* xc, bool* invalid) const { double c; f.accumulate(xc, nullptr, false, nullptr, nullptr, &c, invalid); return c; }
+};
+template <int PD> struct TrackPlus {
+  __device__ void operator()(const double* x, const double* step, double* xc) const {
+    if (PD == 3) { const double d3[3] = {step[0], step[1], step[2]}; sphere_plus(x, d3, xc); }
+    else for (int q = 0; q < 4; ++q) xc[q] = x[q] + step[q];
+  }
+};
+
+template <int PD>
+__global__ __launch_bounds__(64) void k_inner_tracks(InnerArgs A) {
+  if (!*A.gate) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= A.ntracks) return;
+  const int beg = A.trk_off[t], end = A.trk_off[t + 1];
+  if (end <= beg) return;
+  const int p = A.P.obs_pt[beg];
+  if (A.P.pt_const[p]) return;
+  double x[4];
+  for (int q = 0; q < 4; ++q) x[q] = A.pts[4 * (size_t)p + q];
+  const TrackFn<PD> fn{&A, beg, end};
+  block_lm<PD, 4>(x, TrackLin<PD>{fn}, TrackCost<PD>{fn}, TrackPlus<PD>{});
+  for (int q = 0; q < 4; ++q) A.pts[4 * (size_t)p + q] = x[q];
+}
+
+// |x - x_inner|^2 and |x_inner|^2 over the variable blocks (ParameterToleranceReached measures the step to the point
+// the inner iterations ended at): out[0] = step^2, out[1] = |x_inner|^2.  One workgroup, fixed order.
+__global__ __launch_bounds__(1024) void k_inner_norms(InnerArgs A, const double* __restrict__ cam0, const double* __restrict__ pts0,
+                                                      const double* __restrict__ intr0, double* __restrict__ out) {
+  __shared__ double s1[1024], s2[1024];
+  double a = 0.0, b = 0.0;
+  const int tid = threadIdx.x;
+  for (int p = tid; p < A.P.np; p += 1024) {
+    if (A.P.pt_const[p]) continue;
+    for (int q = 0; q < 4; ++q) { const double u = A.pts[4 * (size_t)p + q], v = pts0[4 * (size_t)p + q]; a += (u - v) * (u - v); b += u * u; }
+  }
+  for (int c = tid; c < A.P.nc; c += 1024) {
+    if (A.P.cam_red[c] < 0) continue;
+    for (int q = 0; q < 6; ++q) { const double u = A.cam[6 * (size_t)c + q], v = cam0[6 * (size_t)c + q]; a += (u - v) * (u - v); b += u * u; }
+  }
+  if (A.P.ni)
+    for (int g = tid; g < A.P.ng_total; g += 1024) {
+      if (A.P.grp_red[g] < 0) continue;
+      for (int q = 0; q < A.P.grp_k[g]; ++q) {
+        const double u = A.intr[(size_t)g * THEIA_MAX_INTRINSICS + q], v = intr0[(size_t)g * THEIA_MAX_INTRINSICS + q];
+        a += (u - v) * (u - v); b += u * u;
+      }
+    }
+  s1[tid] = a; s2[tid] = b;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if (tid < s) { s1[tid] += s1[tid + s]; s2[tid] += s2[tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) { out[0] = s1[0]; out[1] = s2[0]; }
+}
+
+// cost at the inner-iteration point: every observation row (tiles or not), then the camera priors; two fixed-order stages
+__global__ __launch_bounds__(256) void k_inner_cost(InnerArgs A, double* __restrict__ part) {
+  if (!*A.gate) return;
+  __shared__ double s1[256], s2[256];
+  double cst = 0.0, inv = 0.0;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < A.nobs; o += (int64_t)gridDim.x * 256) {
+    const ObsRef ob = load_obs(A, (int)o);
+    const int grp = A.P.cam_group[ob.cam];
+    const double4 Xv = reinterpret_cast<const double4*>(A.pts)[ob.pt];
+    const double X[4] = {Xv.x, Xv.y, Xv.z, Xv.w};
+    ObsLin ol;
+    observe<false, false>(ob.depth_row ? THIP_MODEL_DEPTH_ROW : A.P.group_model[grp], A.cam + 6 * (size_t)ob.cam,
+                          A.intr + (size_t)grp * THEIA_MAX_INTRINSICS, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
+    if (!ol.valid) inv += 1.0;
+    double rho1;
+    cst += 0.5 * obs_loss(A, ob, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
+  }
+  s1[threadIdx.x] = cst; s2[threadIdx.x] = inv;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { s1[threadIdx.x] += s1[threadIdx.x + s]; s2[threadIdx.x] += s2[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = s1[0]; part[2 * blockIdx.x + 1] = s2[0]; }
+}
+__global__ __launch_bounds__(256) void k_inner_cost_reduce(InnerArgs A, const double* __restrict__ part, int nblocks, double* __restrict__ out) {
+  if (!*A.gate) return;
+  __shared__ double s1[256], s2[256];
+  double cst = 0.0, inv = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) { cst += part[2 * b]; inv += part[2 * b + 1]; }
+  for (int i = threadIdx.x; i < A.P.n_priors; i += 256) {
+    if (A.P.cam_red[A.P.prior_cam[i]] < 0) continue;   // priors of constant cameras sit in the fixed cost
+    double r[3], Jp[18];
+    camera_prior(A.P.prior_kind[i], A.cam + 6 * (size_t)A.P.prior_cam[i], A.P.prior_vec + 3 * (size_t)i, A.P.prior_info + 9 * (size_t)i, false, r, Jp);
+    cst += 0.5 * ((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+  }
+  s1[threadIdx.x] = cst; s2[threadIdx.x] = inv;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { s1[threadIdx.x] += s1[threadIdx.x + s]; s2[threadIdx.x] += s2[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = s1[0]; out[1] = s2[0]; }
+}
+
+}  // namespace
+
+// optional observation arrays -> always-valid pointers + flags (see load_obs)
+static InnerArgs normalised(const InnerArgs& in) {
+  InnerArgs A = in;
+  A.has_si = in.P.obs_si != nullptr; A.has_kind = in.P.obs_kind != nullptr;
+  if (!A.has_si) A.P.obs_si = in.P.obs_uv;
+  if (!A.has_kind) A.P.obs_kind = reinterpret_cast<const uint8_t*>(in.P.obs_cam);
+  return A;
+}
+
+void launch_inner_cost(const InnerArgs& A0, double* part, double* out2, hipStream_t st) {
+  const InnerArgs A = normalised(A0);
+  const int nb = (int)std::max<int64_t>(1, std::min<int64_t>(kInnerCostBlocks, (A.nobs + 255) / 256));
+  k_inner_cost<<<nb, 256, 0, st>>>(A, part);
+  k_inner_cost_reduce<<<1, 256, 0, st>>>(A, part, nb, out2);
+}
+
+void launch_inner_sweep(const InnerArgs& A0, hipStream_t st) {
+  const InnerArgs A = normalised(A0);
+  static const int skip = [] { const char* e = getenv("THEIA_HIP_INNER_SKIP"); return e ? atoi(e) : 0; }();   // development switch
+  if (A.P.nc > 0 && !(skip & 1)) k_inner_views<<<(A.P.nc + 3) / 4, 256, 0, st>>>(A);
+  if (A.P.ni > 0 && A.P.ng_total > 0 && !(skip & 2)) k_inner_groups<<<A.P.ng_total, 256, 0, st>>>(A);
+  if (A.ntracks > 0 && !(skip & 4)) {
+    if (A.P.pd == 3) k_inner_tracks<3><<<(A.ntracks + 63) / 64, 64, 0, st>>>(A);
+    else k_inner_tracks<4><<<(A.ntracks + 63) / 64, 64, 0, st>>>(A);
+  }
+}
+void launch_inner_norms(const InnerArgs& A, const double* cam0, const double* pts0, const double* intr0, double* out2, hipStream_t st) {
+  k_inner_norms<<<1, 1024, 0, st>>>(A, cam0, pts0, intr0, out2);
+}
+
+}  // namespace thip

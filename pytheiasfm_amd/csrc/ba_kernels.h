@@ -115,6 +115,29 @@ enum {  // indices into ReduceBuf::scal: [0,8) are SUM-reduced, [8,16) MAX-reduc
   SC_COUNT = 16
 };
 
+// Inner iterations (ba_inner.hip): one sweep of block coordinate descent over the parameter buffers cam / pts / intr
+// (cameras, then shared intrinsics, then points), each block by its own LM solve.
+struct InnerArgs {
+  DevProblem P;                 // topology, masks, loss (P.intr is not used: the intrinsics come from `intr`)
+  const int* cam_obs_off;       // [nc + 1] per camera: range of cam_obs_idx
+  const int* cam_obs_idx;       // (sorted) observation indices of the camera
+  const int* grp_obs_off;       // [ng + 1], [..]: the same per intrinsics group (only with variable intrinsics)
+  const int* grp_obs_idx;
+  const int* trk_off;           // [ntracks + 1] observation ranges of the tracks in the sorted arrays
+  int ntracks;
+  int64_t nobs;                 // observations that enter the cost (sorted arrays, fixed residual blocks excluded)
+  double* cam; double* pts; double* intr;   // in / out
+  const int* gate;              // device flag: 0 = return at once
+  int has_si = 0, has_kind = 0;  // set by the launchers: P.obs_si / P.obs_kind are real (otherwise valid stand-ins)
+};
+void launch_inner_sweep(const InnerArgs& A, hipStream_t st);
+// out[0] = |x0 - x|^2, out[1] = |x|^2 over the variable blocks
+void launch_inner_norms(const InnerArgs& A, const double* cam0, const double* pts0, const double* intr0, double* out2, hipStream_t st);
+// cost of every residual block at (cam, pts, intr): out[0] = sum rho / 2 (+ camera priors), out[1] > 0 if a functor failed;
+// part: scratch of 2 * kInnerCostBlocks doubles
+constexpr int kInnerCostBlocks = 512;
+void launch_inner_cost(const InnerArgs& A, double* part, double* out2, hipStream_t st);
+
 void launch_colnorm(const DevProblem& P, const double* cam, const double* pts, double* colsq_c,
                     double* colsq_p, double* colsq_i, hipStream_t st);
 void launch_build_scale_red(const DevProblem& P, double* scale_red, hipStream_t st);

@@ -129,6 +129,12 @@ struct theia_ba_handle_s {
   DevBuf<double> rec;                       // per-observation records of the gather-based Schur assembly
   DevBuf<int> diag_items, cam_obs, blk_items, slot_obs, slot_pt;
   DevBuf<int> prior_cam, prior_kind;        // camera priors in use (compact list)
+  // inner iterations (ba_inner.hip): observation lists by camera / group / track, a third parameter buffer the sweep
+  // works on, its scalars {step^2, |x|^2, cost, invalid}, the gate flag
+  bool inner = false;
+  DevBuf<int> in_cam_off, in_cam_idx, in_grp_off, in_grp_idx, in_trk_off, in_gate;
+  DevBuf<double> in_cam, in_pts, in_intr, in_scal, in_part;
+  int in_ntracks = 0;
   DevBuf<double> prior_vec, prior_info;
   int n_priors = 0;
   DevBuf<int2> blk_pairs;
@@ -215,12 +221,15 @@ struct LmState {
   double radius, decrease_factor, x_cost, x_norm, gmax, minimum_cost, initial_cost;
   int step_successful, iter, invalid_steps, term, done, first, accepted, num_successful, trace_size, pending_grad,
       fail_at_first, bodies;
+  int inner_enabled;   // inner iterations still running (they switch themselves off: inner_iteration_tolerance)
+  int use_inner;       // this body's candidate is the point the inner iterations ended at (k_lm_accept copies that one)
 };
 struct LmCtl {   // per-run control block, device resident so that a captured graph of the iteration stays valid
   int max_iterations, trace_capacity;
   double function_tolerance, gradient_tolerance, parameter_tolerance, max_radius, fixed_cost;
   double *tc, *tg, *ts, *tr;
   int* ta;
+  const double* inner_scal;   // [4] = {|x - x_inner|^2, |x_inner|^2, cost at x_inner, invalid}, null = no inner iterations
 };
 
 __device__ void lm_trace(LmState* st, const LmCtl& c, double cost, double g, double step, double radius, int acc) {
@@ -236,7 +245,7 @@ __device__ void lm_control_body(LmState* st, const double* __restrict__ sa, cons
                                 const LmCtl* __restrict__ cp) {
   const LmCtl c = *cp;
   double* tg = c.tg; double* tc = c.tc;
-  st->accepted = 0;
+  st->accepted = 0; st->use_inner = 0;
   if (st->done) return;
   st->bodies++;
   const double x_cost = sa[SC_COST];
@@ -255,8 +264,8 @@ __device__ void lm_control_body(LmState* st, const double* __restrict__ sa, cons
   if (st->step_successful && gmax <= c.gradient_tolerance) { st->term = THEIA_TERM_CONVERGENCE; st->done = 1; return; }
   if (st->radius <= 1e-32) { st->term = THEIA_TERM_CONVERGENCE; st->done = 1; return; }
   st->iter++;
-  const double mcc = sb[SB_MCC];
-  const double stepsq = sb[SB_STEPSQ] + sb[SB_STEPSQ_CAM];
+  double mcc = sb[SB_MCC];
+  double stepsq = sb[SB_STEPSQ] + sb[SB_STEPSQ_CAM];
   const bool solved = sa[SC_NOTPD] == 0.0 && isfinite(mcc) && isfinite(stepsq);
   if (!(solved && mcc > 0.0)) {
     if (++st->invalid_steps >= 5) { st->term = THEIA_TERM_FAILURE; st->done = 1; return; }
@@ -267,6 +276,21 @@ __device__ void lm_control_body(LmState* st, const double* __restrict__ sa, cons
   st->invalid_steps = 0;
   double cand_cost = sb[SB_COST];
   if (sb[SB_INVALID] > 0.0 || !isfinite(cand_cost)) cand_cost = DBL_MAX;
+  // TrustRegionMinimizer::DoInnerIterationsIfNeeded: the sweep ran on a copy of the candidate (k_inner_gate said so
+  // from the same quantities); its result replaces the candidate unless the evaluation there failed
+  bool inner_useful = false;
+  double xnormsq = sb[SB_XNORMSQ] + sb[SB_XNORMSQ_CAM];
+  if (c.inner_scal && st->inner_enabled && cand_cost < DBL_MAX) {
+    const double inner_cost = c.inner_scal[2];
+    if (c.inner_scal[3] == 0.0 && isfinite(inner_cost)) {
+      st->use_inner = 1;
+      mcc += cand_cost - inner_cost;
+      inner_useful = inner_cost < x_cost;
+      st->inner_enabled = (1.0 - inner_cost / cand_cost) > 1e-3;   // inner_iteration_tolerance
+      cand_cost = inner_cost;
+      stepsq = c.inner_scal[0]; xnormsq = c.inner_scal[1];
+    }
+  }
   const double step_norm = sqrt(stepsq);
   if (step_norm <= c.parameter_tolerance * (st->x_norm + c.parameter_tolerance)) {
     lm_trace(st, c, cand_cost + c.fixed_cost, gmax, step_norm, st->radius, 0);
@@ -278,9 +302,9 @@ __device__ void lm_control_body(LmState* st, const double* __restrict__ sa, cons
     st->term = THEIA_TERM_CONVERGENCE; st->done = 1; return;
   }
   const double rho = cost_change / mcc;
-  if (rho > 1e-3) {
+  if (inner_useful || rho > 1e-3) {   // IsStepSuccessful
     st->accepted = 1;   // k_lm_accept copies the candidate buffers over the state
-    st->x_norm = sqrt(sb[SB_XNORMSQ] + sb[SB_XNORMSQ_CAM]);
+    st->x_norm = sqrt(xnormsq);
     st->radius = st->radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3));
     st->radius = fmin(c.max_radius, st->radius);
     st->decrease_factor = 2.0; st->step_successful = 1;
@@ -391,10 +415,22 @@ __global__ __launch_bounds__(256) void k_pack_rcs(int n, const double* __restric
 }
 
 // accepted step: the candidate parameters become the state
+// Will this body's control pass run inner iterations?  The same conditions lm_control_body applies, from the same inputs.
+__global__ void k_inner_gate(const LmState* __restrict__ st, const double* __restrict__ sa, const double* __restrict__ sb,
+                             int* __restrict__ gate) {
+  const double mcc = sb[SB_MCC], stepsq = sb[SB_STEPSQ] + sb[SB_STEPSQ_CAM], cand = sb[SB_COST];
+  const bool valid = sa[SC_NOTPD] == 0.0 && isfinite(mcc) && isfinite(stepsq) && mcc > 0.0;
+  *gate = (!st->done && st->inner_enabled && valid && sb[SB_INVALID] == 0.0 && isfinite(cand)) ? 1 : 0;
+}
+
+// use_inner: the accepted point is the one the inner iterations ended at (in_*), not the trust-region candidate
 __global__ void k_lm_accept(const LmState* __restrict__ st, double* __restrict__ cam, const double* __restrict__ cand_cam, size_t ncam,
                             double* __restrict__ pts, const double* __restrict__ cand_pts, size_t npts,
-                            double* __restrict__ intr, const double* __restrict__ cand_intr, size_t nintr) {
+                            double* __restrict__ intr, const double* __restrict__ cand_intr, size_t nintr,
+                            const double* __restrict__ in_cam = nullptr, const double* __restrict__ in_pts = nullptr,
+                            const double* __restrict__ in_intr = nullptr) {
   if (!st->accepted) return;
+  if (st->use_inner) { cand_cam = in_cam; cand_pts = in_pts; if (nintr) cand_intr = in_intr; }
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += stride) pts[i] = cand_pts[i];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncam; i += stride) cam[i] = cand_cam[i];
@@ -1277,6 +1313,32 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
 #define AL(buf, cnt) do { rc = h->buf.alloc(cnt); if (rc) return rc; } while (0)
   tick("structure, sort, tiles");
   UP(obs_uv, uv); UP(obs_si, si); UP(obs_cam, ocam); UP(obs_pt, opt);
+  h->inner = h->opt.use_inner_iterations != 0 && h->nobs_main > 0;
+  if (h->inner) {
+    // residual blocks that depend on a block: the camera's / the group's / the track's observations among the
+    // non-fixed ones [0, nobs_main) of the sorted arrays (depth-prior rows do not depend on the intrinsics)
+    const int64_t nm = h->nobs_main;
+    std::vector<int> coff(h->nc + 1, 0), cidx(nm), goff(h->ng + 1, 0), gidx, toff;
+    for (int64_t s = 0; s < nm; ++s) coff[ocam[s] + 1]++;
+    for (int c = 0; c < h->nc; ++c) coff[c + 1] += coff[c];
+    { std::vector<int> fill(coff.begin(), coff.end() - 1); for (int64_t s = 0; s < nm; ++s) cidx[fill[ocam[s]]++] = (int)s; }
+    if (h->ni) {
+      auto is_depth = [&](int64_t s) { return p->obs_kind && p->obs_kind[h->perm[s]]; };
+      for (int64_t s = 0; s < nm; ++s) if (!is_depth(s)) goff[p->cam_group[ocam[s]] + 1]++;
+      for (int g = 0; g < h->ng; ++g) goff[g + 1] += goff[g];
+      gidx.resize(goff[h->ng]);
+      std::vector<int> fill(goff.begin(), goff.end() - 1);
+      for (int64_t s = 0; s < nm; ++s) if (!is_depth(s)) gidx[fill[p->cam_group[ocam[s]]]++] = (int)s;
+    }
+    toff.push_back(0);
+    for (int64_t s = 1; s <= nm; ++s) if (s == nm || opt[s] != opt[s - 1]) toff.push_back((int)s);
+    h->in_ntracks = (int)toff.size() - 1;
+    if (gidx.empty()) gidx.push_back(0);
+    UP(in_cam_off, coff); UP(in_cam_idx, cidx); UP(in_grp_off, goff); UP(in_grp_idx, gidx); UP(in_trk_off, toff);
+    AL(in_cam, (size_t)6 * std::max(1, h->nc)); AL(in_pts, (size_t)4 * std::max(1, h->np));
+    AL(in_intr, (size_t)THEIA_MAX_INTRINSICS * std::max(1, h->ng));
+    AL(in_scal, 8); AL(in_part, 2 * (size_t)kInnerCostBlocks); AL(in_gate, 4);
+  }
   if (p->obs_kind) {   // depth-prior rows (sorted like the other observation arrays)
     std::vector<uint8_t> okind(h->nobs);
     for (int64_t s = 0; s < h->nobs; ++s) okind[s] = p->obs_kind[h->perm[s]];
@@ -1474,6 +1536,8 @@ int theia_hip_ba_set_options(theia_ba_handle h, const theia_ba_options* o) {
       o->constant_camera_position != c.constant_camera_position || o->orthographic_camera != c.orthographic_camera ||
       o->intrinsics_to_optimize != c.intrinsics_to_optimize || o->prior_mask != c.prior_mask)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "structural options differ from the ones the handle was created with");
+  if (o->use_inner_iterations && !h->inner && h->nobs_main > 0)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "use_inner_iterations: the handle was created without the inner-iteration lists");
   if (o->loss_function_type < 0 || o->loss_function_type > THEIA_LOSS_TRUNCATED)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "invalid loss function type");
   if (o->loss_function_type != h->opt.loss_function_type || o->robust_loss_width != h->opt.robust_loss_width ||
@@ -1537,6 +1601,9 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   std::memset(&st, 0, sizeof(st));
   st.radius = 1e4; st.decrease_factor = 2.0; st.step_successful = 1; st.first = 1;
   st.term = THEIA_TERM_NO_CONVERGENCE; st.pending_grad = -1;
+  // inner iterations need every residual block of a camera on this rank: not in sharded solves
+  const bool inner = h->inner && O.use_inner_iterations != 0 && !h->allreduce;
+  st.inner_enabled = inner ? 1 : 0;
   LmState* dst = reinterpret_cast<LmState*>(h->lm_state.p);
   // the initial state and the control block travel as kernel arguments (k_lm_init): no host buffer whose
   // lifetime would need a synchronisation before the first iteration
@@ -1562,6 +1629,7 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   }
   ctl.tc = ctl.trace_capacity ? h->tr_cost.p : nullptr;
   ctl.tg = h->tr_g.p; ctl.ts = h->tr_step.p; ctl.tr = h->tr_radius.p; ctl.ta = h->tr_acc.p;
+  ctl.inner_scal = inner ? h->in_scal.p : nullptr;
   k_lm_init_ctl<<<1, 1, 0, h->stream>>>(reinterpret_cast<LmCtl*>(h->lm_ctl.p), ctl);
   const LmCtl* dctl = reinterpret_cast<const LmCtl*>(h->lm_ctl.p);
   const int nxt = 1;
@@ -1571,8 +1639,24 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
     if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][0], h->stream));
     if ((r = enqueue_linearize(h, slot))) return r;
     if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][1], h->stream));
-    const bool fuse = !h->allreduce && slot < 0 && h->ntiles_main > 0;   // tile reduction inside the control kernel
+    const bool fuse = !h->allreduce && !inner && slot < 0 && h->ntiles_main > 0;   // tile reduction inside the control kernel
     if ((r = enqueue_solve_and_backsub(h, slot, fuse))) return r;
+    if (inner) {
+      // DoInnerIterationsIfNeeded: one sweep of block coordinate descent on a copy of the candidate, its cost and its
+      // distance from x; every kernel returns at once when the gate is closed (step invalid, inner iterations off, done)
+      k_inner_gate<<<1, 1, 0, h->stream>>>(dst, h->rb.scal, h->scalB.p, h->in_gate.p);
+      HIP_TRY(hipMemcpyAsync(h->in_cam.p, h->cam[nxt].p, sizeof(double) * 6 * h->nc, hipMemcpyDeviceToDevice, h->stream));
+      HIP_TRY(hipMemcpyAsync(h->in_pts.p, h->pts[nxt].p, sizeof(double) * 4 * h->np, hipMemcpyDeviceToDevice, h->stream));
+      HIP_TRY(hipMemcpyAsync(h->in_intr.p, (h->ni ? h->intr[nxt].p : h->intr[0].p), sizeof(double) * THEIA_MAX_INTRINSICS * h->ng, hipMemcpyDeviceToDevice, h->stream));
+      InnerArgs IA;
+      IA.P = h->P;
+      IA.cam_obs_off = h->in_cam_off.p; IA.cam_obs_idx = h->in_cam_idx.p; IA.grp_obs_off = h->in_grp_off.p; IA.grp_obs_idx = h->in_grp_idx.p;
+      IA.trk_off = h->in_trk_off.p; IA.ntracks = h->in_ntracks; IA.nobs = h->nobs_main;
+      IA.cam = h->in_cam.p; IA.pts = h->in_pts.p; IA.intr = h->in_intr.p; IA.gate = h->in_gate.p;
+      launch_inner_sweep(IA, h->stream);
+      launch_inner_norms(IA, h->cam[0].p, h->pts[0].p, h->intr[0].p, h->in_scal.p, h->stream);
+      launch_inner_cost(IA, h->in_part.p, h->in_scal.p + 2, h->stream);
+    }
     if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][3], h->stream));
     if (fuse && h->ntiles_main > 4 * kReduceBlocks) {
       launch_reduce_tiles_stage1(h->ntiles_main, h->tile_part.p, 5, h->fmaxflag.p + 8, h->red_part.p, h->stream);
@@ -1580,7 +1664,8 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
     } else if (fuse) k_reduce_control<<<1, 1024, 0, h->stream>>>(h->ntiles_main, h->tile_part.p, h->f2s.p + 8, h->fmaxflag.p + 8, dst, h->rb.scal, h->scalB.p, dctl);
     else k_lm_control<<<1, 1, 0, h->stream>>>(dst, h->rb.scal, h->scalB.p, dctl);
     k_lm_accept<<<256, 256, 0, h->stream>>>(dst, h->cam[0].p, h->cam[nxt].p, (size_t)6 * h->nc, h->pts[0].p, h->pts[nxt].p,
-                                            (size_t)4 * h->np, h->intr[0].p, h->intr[nxt].p, h->ni ? (size_t)THEIA_MAX_INTRINSICS * h->ng : 0);
+                                            (size_t)4 * h->np, h->intr[0].p, h->intr[nxt].p, h->ni ? (size_t)THEIA_MAX_INTRINSICS * h->ng : 0,
+                                            h->in_cam.p, h->in_pts.p, h->in_intr.p);
     return 0;
   };
   // Phase timing (HIP events around the kernel groups) is opt-in: THEIA_HIP_PHASE_TIMING=1.
@@ -1592,7 +1677,7 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   // is bounded by the dependent kernels, not by host enqueue time), and a stream capture in one host thread makes
   // legacy-stream calls of other threads fail ("would make the legacy stream depend on a capturing blocking
   // stream") -- the entry points must stay callable concurrently from a thread pool.
-  const bool want_graph = !timing && !h->allreduce && !h->graph_failed && (genv && genv[0] == '1');
+  const bool want_graph = !timing && !h->allreduce && !inner && !h->graph_failed && (genv && genv[0] == '1');
   if (want_graph && !h->graph_exec) {
     bool ok = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
     if (ok) {

@@ -306,8 +306,19 @@ def BundleAdjustPartialViewsConstant(options, var_view_ids, const_view_ids, reco
     return summary
 
 
+def _no_inner(options):
+    """BundleAdjustView(s) / BundleAdjustTrack(s) and their WithCov variants copy the options and switch the inner
+    iterations off (bundle_adjustment.cc:225,245,267,296,338,395,427,461; they also ask for DENSE_QR, which has no
+    meaning here)."""
+    import copy
+    o = copy.copy(options)
+    o.use_inner_iterations = False
+    return o
+
+
 def BundleAdjustViews(reconstruction, options, view_ids):
     """bundle_adjustment.cc:240-258 (wrapper argument order :14-17)."""
+    options = _no_inner(options)
     flat = _flatten(reconstruction, view_ids, [], options=options)
     return _run(options, reconstruction, flat)
 
@@ -319,6 +330,7 @@ def BundleAdjustView(reconstruction, options, view_id):
 
 def BundleAdjustTracks(reconstruction, options, track_ids):
     """bundle_adjustment.cc:389-418."""
+    options = _no_inner(options)
     flat = _flatten(reconstruction, [], track_ids, options=options)
     summary = _run(options, reconstruction, flat)
     _update_inverse_depth(reconstruction, track_ids)
@@ -431,8 +443,7 @@ def _with_cov(reconstruction, options, flat, want_points):
 
 def BundleAdjustTracksWithCov(reconstruction, options, track_ids):
     """bundle_adjustment.cc:330-386 (forces the homogeneous manifold, :339)."""
-    import copy
-    opts = copy.copy(options)
+    opts = _no_inner(options)
     opts.use_homogeneous_point_parametrization = True
     opts.use_inverse_depth_parametrization = False
     track_ids = [int(t) for t in track_ids]
@@ -456,6 +467,7 @@ def BundleAdjustTrackWithCov(reconstruction, options, track_id):
 def BundleAdjustViewsWithCov(reconstruction, options, view_ids):
     """bundle_adjustment.cc:454-499."""
     view_ids = [int(v) for v in view_ids]
+    options = _no_inner(options)
     flat = _flatten(reconstruction, view_ids, [])
     summary, cc = _with_cov(reconstruction, options, flat, False)
     if cc is None:

@@ -22,6 +22,7 @@ def test_allreduce_callback_path_world_size_1():
         p = synth.synth_ba_v1(16, 800, seed=81)
         shard, ids = synth.shard_tracks(p, 0, 1)
         o = ba.default_options()
+        o.use_inner_iterations = 0   # a sharded solve has no inner iterations (a camera's residual blocks live on every rank)
         calls = []
         cb = tdist.make_torch_allreduce(0)
 
@@ -64,7 +65,7 @@ def test_native_rccl_path_world_size_1():
     path and as the unsharded one.  (A world_size-2 run of the same code needs two GPUs: see the skip below.)"""
     p = synth.synth_ba_v1(16, 800, seed=81)
     shard, ids = synth.shard_tracks(p, 0, 1)
-    o = ba.default_options()
+    o = ba.default_options(); o.use_inner_iterations = 0
     comm = tdist.NativeRccl(0, 1)
     try:
         with ba.BaHandle(shard, o) as h:
@@ -90,7 +91,8 @@ def _native_ws2_worker(rank, port, q):
     p = synth.synth_ba_v1(16, 800, seed=81)
     shard, ids = synth.shard_tracks(p, rank, 2)
     comm = tdist.NativeRccl(rank, 2)
-    with ba.BaHandle(shard, ba.default_options()) as h:
+    o = ba.default_options(); o.use_inner_iterations = 0
+    with ba.BaHandle(shard, o) as h:
         comm.attach(h)
         s, _ = h.run()
         out = h.download(shard.copy())
@@ -116,7 +118,8 @@ def test_native_rccl_path_world_size_2_product_path():
         pr.join(timeout=60)
         assert pr.exitcode == 0
     ref = synth.synth_ba_v1(16, 800, seed=81)
-    s0, _ = ba.solve(ref, ba.default_options())
+    o = ba.default_options(); o.use_inner_iterations = 0
+    s0, _ = ba.solve(ref, o)
     for rank, nit, cost, cams in res:
         assert nit == s0.num_iterations and abs(cost - s0.final_cost) <= 1e-9 * s0.final_cost
         assert np.abs(cams - ref.cam_ext).max() <= 1e-8

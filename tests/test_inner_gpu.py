@@ -1,0 +1,85 @@
+"""GPU: inner iterations (ba_inner.hip: coordinate descent over cameras, shared intrinsics, points after every
+trust-region candidate; on by default like the reference) against the oracle's restatement of Ceres'
+CoordinateDescentMinimizer.  The block solves stop on relative tolerances (1e-6 function, 1e-8 parameter), so two
+implementations agree to those tolerances, not to the last bit: costs 1e-6, parameters 1e-5 of their scale."""
+import numpy as np
+import pytest
+
+from pytheiasfm_amd import ba, sfm, synth
+from tests import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(p, iters=12, **kw):
+    out = []
+    for mod in (ba, ol):
+        q = p.copy(); o = mod.default_options(); o.max_num_iterations = iters
+        assert o.use_inner_iterations == 1
+        for k, v in kw.items():
+            setattr(o, k, v)
+        s, tr = mod.solve(q, o)
+        out.append((q, s, tr))
+    return out
+
+
+def _compare(g, o, ptol=1e-5):
+    (qg, sg, tg), (qo, so, to) = g, o
+    assert sg.success and so.success
+    assert sg.num_iterations == so.num_iterations and sg.num_successful_steps == so.num_successful_steps
+    n = min(len(tg.cost), len(to.cost))
+    assert list(tg.accepted[:n]) == list(to.accepted[:n])
+    assert np.allclose(tg.cost[:n], to.cost[:n], rtol=1e-6)
+    assert abs(sg.final_cost - so.final_cost) <= 1e-6 * so.final_cost
+    for a, b in ((qg.cam_ext, qo.cam_ext), (qg.points, qo.points), (qg.intrinsics, qo.intrinsics)):
+        assert np.abs(a - b).max() <= ptol * max(1.0, np.abs(b).max())
+
+
+INTR = int(sfm.OptimizeIntrinsicsType.FOCAL_LENGTH | sfm.OptimizeIntrinsicsType.RADIAL_DISTORTION)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(loss_function_type=1, robust_loss_width=2.0), dict(intrinsics_to_optimize=INTR),
+                                dict(use_homogeneous_point_parametrization=0), dict(loss_function_type=3, robust_loss_width=3.0, intrinsics_to_optimize=INTR),
+                                dict(constant_camera_orientation=1), dict(constant_camera_position=1)],
+                         ids=["trivial", "huber", "intrinsics", "xyzw", "cauchy+intrinsics", "const-orientation", "const-position"])
+def test_inner_iterations_follow_the_oracle(kw):
+    p = synth.synth_ba_v1(8, 300, seed=5)
+    g, o = _both(p, **kw)
+    _compare(g, o)
+
+
+def test_inner_iterations_c1_and_mixed_models():
+    for p in (synth.ba_config("C1"), synth.synth_ba_v1(12, 500, seed=9, mixed_models=True)):
+        g, o = _both(p)
+        _compare(g, o)
+
+
+def test_inner_iterations_with_constant_blocks_priors_and_depth_rows():
+    p = synth.synth_ba_v1(10, 400, seed=21)
+    rng = np.random.default_rng(3)
+    p.cam_const = np.zeros(10, dtype=np.uint8); p.cam_const[0] = 3; p.cam_const[4] = 1
+    p.point_const = (rng.uniform(size=400) < 0.1).astype(np.uint8)
+    nc = 10
+    mask = np.zeros(nc, dtype=np.uint8); mask[[1, 2, 5]] = [1, 2, 4]
+    eye = np.tile(np.eye(3) * 3.0, (nc, 1, 1))
+    p.set_priors(mask, position=(p.cam_ext[:, :3] + 0.01, eye), gravity=(np.tile([0.0, 0.0, -1.0], (nc, 1)), eye),
+                 orientation=(p.cam_ext[:, 3:] + 0.005, eye))
+    p.add_depth_priors(np.arange(0, 200, 7), 6.0, variance=0.25)
+    g, o = _both(p, prior_mask=7)
+    _compare(g, o)
+
+
+def test_inner_on_beats_inner_off_per_iteration_and_handles_set_options():
+    p = synth.synth_ba_v1(8, 300, seed=5)
+    res = {}
+    for inner in (1, 0):
+        q = p.copy(); o = ba.default_options(); o.use_inner_iterations = inner; o.max_num_iterations = 1
+        s, tr = ba.solve(q, o)
+        res[inner] = tr.cost[1]
+    assert res[1] < 0.995 * res[0]
+    # a handle created without the lists refuses to switch them on later (the lists are built at create())
+    o = ba.default_options(); o.use_inner_iterations = 0
+    with ba.BaHandle(p.copy(), o) as h:
+        o.use_inner_iterations = 1
+        with pytest.raises(Exception):
+            h.set_options(o)
