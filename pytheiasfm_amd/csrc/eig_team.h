@@ -1,0 +1,328 @@
+// Real general eigen-decomposition by a TEAM of lanes with the matrices in LDS: the same algorithm, the same
+// arithmetic per matrix entry and the same summation order as the one-thread eig_general_t (ransac_device.h: EISPACK
+// orthes + hqr2 as Eigen's EigenSolver runs them), so the results are bit-identical to it -- but the n x n work arrays
+// live on chip instead of in per-lane scratch, where the QR sweeps of 64 independent matrices per wave moved
+// ~200 KB of HBM traffic per 10 x 10 matrix (measured on k_fit: FETCH + WRITE = 3.2 TB/s).
+//
+// Every lane of the team calls eig_team() with the same arguments and keeps the same scalar state; loops over a row or
+// a column of the matrix are dealt out by team lane (tl), dot products stay sequential inside one lane.  The team is a
+// contiguous, TEAM-aligned group of lanes of ONE wave (lockstep): team_sync() only has to stop the compiler from
+// moving LDS accesses across it.  Teams of the same wave may diverge from each other (different deflation
+// histories); nothing here uses wave-wide collectives.
+//   H  n x n row-major, in: the matrix, out: quasi-triangular Schur form (destroyed)
+//   V  n x n, out: eigenvectors (hqr2 column convention; complex pairs only with CPLX)
+//   X  n x n work array (the back-substituted vectors before the back-transformation)
+//   wr, wi, ort: n doubles each
+#ifndef THEIA_HIP_EIG_TEAM_H_
+#define THEIA_HIP_EIG_TEAM_H_
+
+#include <hip/hip_runtime.h>
+
+#include "ransac_device.h"
+
+namespace thip {
+namespace rsc {
+
+__device__ __forceinline__ void team_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int TEAM, bool CPLX>
+__device__ bool eig_team(int nn, double* __restrict__ H, double* __restrict__ V, double* __restrict__ X,
+                         double* __restrict__ wr, double* __restrict__ wi, double* __restrict__ ort, int tl) {
+#define HH(i, j) H[(i) * nn + (j)]
+#define VV(i, j) V[(i) * nn + (j)]
+#define XX(i, j) X[(i) * nn + (j)]
+  const int low = 0, high = nn - 1;
+  // ---- orthes
+  for (int m = low + 1; m <= high - 1; ++m) {
+    double scale = 0.0;
+    for (int i = m; i <= high; ++i) scale += fabs(HH(i, m - 1));
+    if (scale != 0.0) {
+      for (int i = m + tl; i <= high; i += TEAM) ort[i] = HH(i, m - 1) / scale;
+      team_sync();
+      double h = 0.0;
+      for (int i = high; i >= m; --i) h += ort[i] * ort[i];
+      double g = sqrt(h);
+      const double om = ort[m];
+      if (om > 0) g = -g;
+      h = h - om * g;
+      team_sync();
+      if (tl == 0) ort[m] = om - g;
+      team_sync();
+      for (int j = m + tl; j < nn; j += TEAM) {
+        double f = 0.0;
+        for (int i = high; i >= m; --i) f += ort[i] * HH(i, j);
+        f = f / h;
+        for (int i = m; i <= high; ++i) HH(i, j) -= f * ort[i];
+      }
+      team_sync();
+      for (int i = tl; i <= high; i += TEAM) {
+        double f = 0.0;
+        for (int j = high; j >= m; --j) f += ort[j] * HH(i, j);
+        f = f / h;
+        for (int j = m; j <= high; ++j) HH(i, j) -= f * ort[j];
+      }
+      team_sync();
+      if (tl == 0) { ort[m] = scale * ort[m]; HH(m, m - 1) = scale * g; }
+      team_sync();
+    } else {
+      if (tl == 0) ort[m] = 0.0;
+      team_sync();
+    }
+  }
+  for (int e = tl; e < nn * nn; e += TEAM) V[e] = (e / nn == e % nn) ? 1.0 : 0.0;
+  team_sync();
+  for (int m = high - 1; m >= low + 1; --m) {
+    if (HH(m, m - 1) != 0.0) {
+      for (int i = m + 1 + tl; i <= high; i += TEAM) ort[i] = HH(i, m - 1);
+      team_sync();
+      for (int j = m + tl; j <= high; j += TEAM) {
+        double g = 0.0;
+        for (int i = m; i <= high; ++i) g += ort[i] * VV(i, j);
+        g = (g / ort[m]) / HH(m, m - 1);
+        for (int i = m; i <= high; ++i) VV(i, j) += g * ort[i];
+      }
+      team_sync();
+    }
+  }
+  // ---- hqr2
+  int n = nn - 1;
+  const double eps = 2.220446049250313e-16;
+  double exshift = 0.0;
+  double p = 0, q = 0, r = 0, s = 0, z = 0, t, w, x, y;
+  double norm = 0.0;
+  for (int i = 0; i < nn; ++i)
+    for (int j = (i - 1 > 0 ? i - 1 : 0); j < nn; ++j) norm += fabs(HH(i, j));
+  int iter = 0, total_iter = 0;
+  while (n >= low) {
+    int l = n;
+    while (l > low) {
+      s = fabs(HH(l - 1, l - 1)) + fabs(HH(l, l));
+      if (s == 0.0) s = norm;
+      if (fabs(HH(l, l - 1)) < eps * s) break;
+      l--;
+    }
+    if (l == n) {  // one root
+      const double v = HH(n, n) + exshift;
+      team_sync();
+      if (tl == 0) { HH(n, n) = v; wr[n] = v; wi[n] = 0.0; }
+      team_sync();
+      n--; iter = 0;
+    } else if (l == n - 1) {  // two roots
+      w = HH(n, n - 1) * HH(n - 1, n);
+      p = (HH(n - 1, n - 1) - HH(n, n)) / 2.0;
+      q = p * p + w;
+      z = sqrt(fabs(q));
+      const double hnn = HH(n, n) + exshift, hmm = HH(n - 1, n - 1) + exshift;
+      x = hnn;
+      const double xl = HH(n, n - 1);
+      team_sync();
+      if (tl == 0) { HH(n, n) = hnn; HH(n - 1, n - 1) = hmm; }
+      team_sync();
+      if (q >= 0) {  // real pair
+        z = (p >= 0) ? p + z : p - z;
+        double w0 = x + z, w1 = w0;
+        if (z != 0.0) w1 = x - w / z;
+        if (tl == 0) { wr[n - 1] = w0; wr[n] = w1; wi[n - 1] = 0.0; wi[n] = 0.0; }
+        x = xl;
+        s = fabs(x) + fabs(z);
+        p = x / s; q = z / s;
+        r = sqrt(p * p + q * q);
+        p = p / r; q = q / r;
+        for (int j = n - 1 + tl; j < nn; j += TEAM) { const double zz = HH(n - 1, j); HH(n - 1, j) = q * zz + p * HH(n, j); HH(n, j) = q * HH(n, j) - p * zz; }
+        team_sync();
+        for (int i = tl; i <= n; i += TEAM) { const double zz = HH(i, n - 1); HH(i, n - 1) = q * zz + p * HH(i, n); HH(i, n) = q * HH(i, n) - p * zz; }
+        for (int i = low + tl; i <= high; i += TEAM) { const double zz = VV(i, n - 1); VV(i, n - 1) = q * zz + p * VV(i, n); VV(i, n) = q * VV(i, n) - p * zz; }
+        team_sync();
+      } else {  // complex pair
+        if (tl == 0) { wr[n - 1] = x + p; wr[n] = x + p; wi[n - 1] = z; wi[n] = -z; }
+        team_sync();
+      }
+      n = n - 2; iter = 0;
+    } else {
+      x = HH(n, n); y = 0.0; w = 0.0;
+      if (l < n) { y = HH(n - 1, n - 1); w = HH(n, n - 1) * HH(n - 1, n); }
+      if (iter == 10) {  // Wilkinson's original ad hoc shift
+        exshift += x;
+        team_sync();
+        for (int i = low + tl; i <= n; i += TEAM) HH(i, i) -= x;
+        team_sync();
+        s = fabs(HH(n, n - 1)) + fabs(HH(n - 1, n - 2));
+        x = y = 0.75 * s;
+        w = -0.4375 * s * s;
+      }
+      if (iter == 30) {  // MATLAB's new ad hoc shift
+        s = (y - x) / 2.0;
+        s = s * s + w;
+        if (s > 0) {
+          s = sqrt(s);
+          if (y < x) s = -s;
+          s = x - w / ((y - x) / 2.0 + s);
+          team_sync();
+          for (int i = low + tl; i <= n; i += TEAM) HH(i, i) -= s;
+          team_sync();
+          exshift += s;
+          x = y = w = 0.964;
+        }
+      }
+      iter = iter + 1;
+      if (++total_iter > 40 * nn) return false;
+      int m = n - 2;
+      while (m >= l) {
+        z = HH(m, m);
+        r = x - z; s = y - z;
+        p = (r * s - w) / HH(m + 1, m) + HH(m, m + 1);
+        q = HH(m + 1, m + 1) - z - r - s;
+        r = HH(m + 2, m + 1);
+        s = fabs(p) + fabs(q) + fabs(r);
+        p = p / s; q = q / s; r = r / s;
+        if (m == l) break;
+        if (fabs(HH(m, m - 1)) * (fabs(q) + fabs(r)) <
+            eps * (fabs(p) * (fabs(HH(m - 1, m - 1)) + fabs(z) + fabs(HH(m + 1, m + 1))))) break;
+        m--;
+      }
+      team_sync();
+      for (int i = m + 2 + tl; i <= n; i += TEAM) { HH(i, i - 2) = 0.0; if (i > m + 2) HH(i, i - 3) = 0.0; }
+      team_sync();
+      for (int k = m; k <= n - 1; ++k) {
+        const bool notlast = (k != n - 1);
+        if (k != m) {
+          p = HH(k, k - 1); q = HH(k + 1, k - 1);
+          r = notlast ? HH(k + 2, k - 1) : 0.0;
+          x = fabs(p) + fabs(q) + fabs(r);
+          if (x == 0.0) continue;
+          p = p / x; q = q / x; r = r / x;
+        }
+        s = sqrt(p * p + q * q + r * r);
+        if (p < 0) s = -s;
+        if (s != 0) {
+          team_sync();   // every lane has read H(k.., k - 1) before lane 0 overwrites it
+          if (tl == 0) {
+            if (k != m) HH(k, k - 1) = -s * x;
+            else if (l != m) HH(k, k - 1) = -HH(k, k - 1);
+          }
+          p = p + s; x = p / s; y = q / s; z = r / s; q = q / p; r = r / p;
+          team_sync();
+          for (int j = k + tl; j < nn; j += TEAM) {
+            double pp = HH(k, j) + q * HH(k + 1, j);
+            if (notlast) { pp = pp + r * HH(k + 2, j); HH(k + 2, j) = HH(k + 2, j) - pp * z; }
+            HH(k, j) = HH(k, j) - pp * x;
+            HH(k + 1, j) = HH(k + 1, j) - pp * y;
+          }
+          team_sync();
+          const int imax = (n < k + 3) ? n : k + 3;
+          for (int i = tl; i <= imax; i += TEAM) {
+            double pp = x * HH(i, k) + y * HH(i, k + 1);
+            if (notlast) { pp = pp + z * HH(i, k + 2); HH(i, k + 2) = HH(i, k + 2) - pp * r; }
+            HH(i, k) = HH(i, k) - pp;
+            HH(i, k + 1) = HH(i, k + 1) - pp * q;
+          }
+          for (int i = low + tl; i <= high; i += TEAM) {
+            double pp = x * VV(i, k) + y * VV(i, k + 1);
+            if (notlast) { pp = pp + z * VV(i, k + 2); VV(i, k + 2) = VV(i, k + 2) - pp * r; }
+            VV(i, k) = VV(i, k) - pp;
+            VV(i, k + 1) = VV(i, k + 1) - pp * q;
+          }
+          team_sync();
+        }
+      }
+    }
+  }
+  team_sync();
+  if (norm == 0.0) return true;
+  // ---- back-substitution: one lane per eigenvalue column.  The sequential routine overwrites column n of H with the
+  // vector while columns < n still hold the triangular form; here the vectors go to X so that the columns are independent
+  // (column n reads T(i, j) for j <= n only through H, and its own entries through X).
+  for (int e = tl; e < nn * nn; e += TEAM) X[e] = 0.0;
+  team_sync();
+  for (n = nn - 1 - tl; n >= 0; n -= TEAM) {
+    p = wr[n]; q = wi[n];
+    if (CPLX && q < 0 && n > 0) {   // second member of a pair: real part in column n - 1, imaginary part in column n
+      int l = n - 1;
+      double a11, a12;
+      if (fabs(HH(n, n - 1)) > fabs(HH(n - 1, n))) {
+        a11 = q / HH(n, n - 1);
+        a12 = -(HH(n, n) - p) / HH(n, n - 1);
+      } else {
+        eig_cdiv(0.0, -HH(n - 1, n), HH(n - 1, n - 1) - p, q, &a11, &a12);
+      }
+      XX(n - 1, n - 1) = a11; XX(n - 1, n) = a12;
+      XX(n, n - 1) = 0.0; XX(n, n) = 1.0;
+      double lastra = 0.0, lastsa = 0.0, lastw = 0.0;
+      for (int i = n - 2; i >= 0; --i) {
+        double ra = 0.0, sa = 0.0;
+        for (int j = l; j <= n; ++j) { ra = ra + HH(i, j) * XX(j, n - 1); sa = sa + HH(i, j) * XX(j, n); }
+        w = HH(i, i) - p;
+        if (wi[i] < 0.0) { lastw = w; lastra = ra; lastsa = sa; continue; }
+        l = i;
+        double cr, ci;
+        if (wi[i] == 0.0) {
+          eig_cdiv(-ra, -sa, w, q, &cr, &ci);
+          XX(i, n - 1) = cr; XX(i, n) = ci;
+        } else {
+          x = HH(i, i + 1); y = HH(i + 1, i);
+          double vr = (wr[i] - p) * (wr[i] - p) + wi[i] * wi[i] - q * q;
+          const double vi = (wr[i] - p) * 2.0 * q;
+          if (vr == 0.0 && vi == 0.0) vr = eps * norm * (fabs(w) + fabs(q) + fabs(x) + fabs(y) + fabs(lastw));
+          eig_cdiv(x * lastra - lastw * ra + q * sa, x * lastsa - lastw * sa - q * ra, vr, vi, &cr, &ci);
+          XX(i, n - 1) = cr; XX(i, n) = ci;
+          if (fabs(x) > (fabs(lastw) + fabs(q))) {
+            XX(i + 1, n - 1) = (-ra - w * XX(i, n - 1) + q * XX(i, n)) / x;
+            XX(i + 1, n) = (-sa - w * XX(i, n) - q * XX(i, n - 1)) / x;
+          } else {
+            eig_cdiv(-lastra - y * XX(i, n - 1), -lastsa - y * XX(i, n), lastw, q, &cr, &ci);
+            XX(i + 1, n - 1) = cr; XX(i + 1, n) = ci;
+          }
+        }
+        t = fmax(fabs(XX(i, n - 1)), fabs(XX(i, n)));
+        if ((eps * t) * t > 1) for (int j = i; j <= n; ++j) { XX(j, n - 1) = XX(j, n - 1) / t; XX(j, n) = XX(j, n) / t; }
+      }
+      continue;
+    }
+    if (q != 0) continue;
+    int l = n;
+    XX(n, n) = 1.0;
+    for (int i = n - 1; i >= 0; --i) {
+      w = HH(i, i) - p;
+      r = 0.0;
+      for (int j = l; j <= n; ++j) r = r + HH(i, j) * XX(j, n);
+      if (wi[i] < 0.0) { z = w; s = r; }
+      else {
+        l = i;
+        if (wi[i] == 0.0) {
+          if (w != 0.0) XX(i, n) = -r / w;
+          else XX(i, n) = -r / (eps * norm);
+        } else {
+          x = HH(i, i + 1); y = HH(i + 1, i);
+          q = (wr[i] - p) * (wr[i] - p) + wi[i] * wi[i];
+          t = (x * s - z * r) / q;
+          XX(i, n) = t;
+          if (fabs(x) > fabs(z)) XX(i + 1, n) = (-r - w * t) / x;
+          else XX(i + 1, n) = (-s - y * t) / z;
+        }
+        t = fabs(XX(i, n));
+        if ((eps * t) * t > 1) for (int j = i; j <= n; ++j) XX(j, n) = XX(j, n) / t;
+      }
+    }
+  }
+  team_sync();
+  // ---- back-transformation V <- V X, row i by lane (column j in descending order, in place as in the sequential code)
+  for (int i = low + tl; i <= high; i += TEAM)
+    for (int j = nn - 1; j >= low; --j) {
+      if (!CPLX && wi[j] != 0) continue;
+      z = 0.0;
+      for (int k = low; k <= j; ++k) z = z + VV(i, k) * XX(k, j);
+      VV(i, j) = z;
+    }
+  team_sync();
+  return true;
+#undef HH
+#undef VV
+#undef XX
+}
+
+}  // namespace rsc
+}  // namespace thip
+#endif

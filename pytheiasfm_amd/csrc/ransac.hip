@@ -27,6 +27,7 @@
 
 #include "ransac_device.h"
 #include "dls_device.h"
+#include "eig_team.h"
 #include "theia_hip.h"
 #include <atomic>
 #include <mutex>
@@ -566,6 +567,106 @@ __global__ void k_sqpnp(int num, const int64_t* __restrict__ offsets, const doub
 }
 
 
+// ---- five-point hypotheses (relative pose / essential matrix) in three stages instead of k_fit: the 10 x 10
+// eigen-decomposition -- 27 k read-modify-writes of its two work matrices per hypothesis, which as per-lane scratch were
+// ~200 KB of HBM traffic each -- runs on chip, a team of 16 lanes per matrix (eig_team.h, bit-identical to the one-thread
+// routine); before it one thread per hypothesis builds the null space and the action matrix, after it one thread per
+// hypothesis turns the real eigenvectors into essential matrices and poses exactly as estimate_models() does.
+constexpr int kFpWs = 136;    // per hypothesis: null space N (9 x 4) | action matrix M (10 x 10)
+constexpr int kFpTeam = 16, kFpTeamsPerWave = 64 / kFpTeam;
+__global__ __launch_bounds__(64) void k_fit5_a(int nprob, int B, const int64_t* __restrict__ offsets, const double* __restrict__ data,
+                                               const int* __restrict__ samples, const int* __restrict__ active_iters,
+                                               double* __restrict__ ws, int* __restrict__ ok) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.y;
+  if (b >= B || p >= nprob) return;
+  const size_t hyp = (size_t)p * B + b;
+  if (b >= active_iters[p]) { ok[hyp] = 0; return; }
+  const double* pd = data + (size_t)offsets[p] * 4;
+  double subset[20];
+  for (int i = 0; i < 5; ++i) {
+    const int idx = samples[hyp * 5 + i];
+    for (int k = 0; k < 4; ++k) subset[i * 4 + k] = pd[(size_t)idx * 4 + k];
+  }
+  double N[36], M[100];
+  const bool good = rsc::five_point_pre(subset, N, M);
+  ok[hyp] = good ? 1 : 0;
+  if (!good) return;
+  double* w = ws + hyp * kFpWs;
+  for (int k = 0; k < 36; ++k) w[k] = N[k];
+  for (int k = 0; k < 100; ++k) w[36 + k] = M[k];
+}
+
+__global__ __launch_bounds__(64) void k_fit5_b(size_t nhyp, const int* __restrict__ ok, const double* __restrict__ ws,
+                                               double* __restrict__ sol, int* __restrict__ solmask) {
+  __shared__ double lds[kFpTeamsPerWave][330];   // H (100) | V (100) | X (100) | wr | wi | ort
+  const int team = threadIdx.x / kFpTeam, tl = threadIdx.x % kFpTeam;
+  const size_t hyp = (size_t)blockIdx.x * kFpTeamsPerWave + team;
+  if (hyp >= nhyp) return;
+  if (!ok[hyp]) { if (tl == 0) solmask[hyp] = 0; return; }
+  double* H = lds[team]; double* V = H + 100; double* X = V + 100; double* wr = X + 100; double* wi = wr + 10; double* ort = wi + 10;
+  const double* M = ws + hyp * kFpWs + 36;
+  for (int e = tl; e < 100; e += kFpTeam) H[e] = M[e];
+  rsc::team_sync();
+  const bool good = rsc::eig_team<kFpTeam, false>(10, H, V, X, wr, wi, ort, tl);
+  int bit = 0;
+  if (good && tl < 10 && wi[tl] == 0.0) {   // only real solutions (five_point_relative_pose.cc:281-284)
+    double v4[4];
+    rsc::five_point_v4(V, tl, v4);
+    for (int k = 0; k < 4; ++k) sol[(hyp * 10 + tl) * 4 + k] = v4[k];
+    bit = 1 << tl;
+  }
+  for (int o = kFpTeam / 2; o >= 1; o >>= 1) bit |= __shfl_xor(bit, o, kFpTeam);
+  if (tl == 0) solmask[hyp] = bit;
+}
+
+template <int EST>
+__global__ __launch_bounds__(64) void k_fit5_c(int nprob, int B, const int64_t* __restrict__ offsets, const double* __restrict__ data,
+                                               const int* __restrict__ samples, const int* __restrict__ active_iters,
+                                               const double* __restrict__ ws, const double* __restrict__ sol,
+                                               const int* __restrict__ solmask, double* __restrict__ models,
+                                               int* __restrict__ counts, int* __restrict__ dense_count, int* __restrict__ tags,
+                                               int* __restrict__ hyp_base) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.y;
+  if (b >= B || p >= nprob) return;
+  const size_t hyp = (size_t)p * B + b;
+  if (b >= active_iters[p]) { counts[hyp] = 0; return; }
+  const int mask = solmask[hyp];
+  if (!mask) { counts[hyp] = 0; return; }
+  const double* pd = data + (size_t)offsets[p] * 4;
+  double subset[20];
+  for (int i = 0; i < 5; ++i) {
+    const int idx = samples[hyp * 5 + i];
+    for (int k = 0; k < 4; ++k) subset[i * 4 + k] = pd[(size_t)idx * 4 + k];
+  }
+  double N[36];
+  for (int k = 0; k < 36; ++k) N[k] = ws[hyp * kFpWs + k];
+  double mloc[10 * kStride];
+  int nm = 0;
+  for (int i = 0; i < 10; ++i) {
+    if (!((mask >> i) & 1)) continue;
+    double v4[4];
+    for (int k = 0; k < 4; ++k) v4[k] = sol[(hyp * 10 + i) * 4 + k];
+    double* m = mloc + kStride * nm;
+    rsc::five_point_E(N, v4, m);
+    if (EST == THEIA_EST_ESSENTIAL_MATRIX) { for (int k = 9; k < kStride; ++k) m[k] = 0.0; nm++; continue; }
+    const int nfront = rsc::best_pose_from_E(m, subset, 5, m + 9, m + 18);
+    if (nfront >= 4) nm++;
+  }
+  counts[hyp] = nm;
+  if (nm == 0) return;
+  const int mm = 10;
+  const int base = atomicAdd(&dense_count[p], nm);
+  hyp_base[hyp] = base;
+  double* mo = models + ((size_t)p * B * mm + base) * (size_t)kStride;
+  int* tg = tags + (size_t)p * B * mm + base;
+  for (int j = 0; j < nm; ++j) {
+    for (int k = 0; k < kStride; ++k) mo[j * kStride + k] = mloc[j * kStride + k];
+    tg[j] = b * mm + j;
+  }
+}
+
 // ---- DLS-PnP hypotheses (estimate_calibrated_absolute_pose.cc:89-97): two kernels instead of k_fit (dls_device.h).
 // k_dls_a: one wave per (problem, iteration); uvals holds the four Macaulay terms of every DlsPnp call of a process
 // (iteration it of a problem = call it: the reference never seeds rand(), and one Estimate() is one process here).
@@ -937,6 +1038,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   DBuf<int> d_save;       // {problem, hypothesis, slot} triples of k_save_best
   DBuf<double> d_models, d_cost, d_best_models;
   DBuf<double> d_dls_action, d_dls_tfac, d_dls_u; DBuf<int> d_dls_ok, d_iter_base;   // DLS: stage A -> stage B
+  DBuf<double> d_fp_ws, d_fp_sol; DBuf<int> d_fp_ok, d_fp_mask;   // five-point: stages a -> b -> c
   std::vector<double> h_dls_u; dls::GlibcRand dls_gen; std::vector<int> h_iter_base;
   DBuf<uint8_t> d_mask;
   std::vector<int> h_samples, h_counts, h_ninl, h_active;
@@ -1118,6 +1220,18 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         k_dls_b<<<dim3((B + 63) / 64, cn), 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_dls_action.p,
                                                         d_dls_tfac.p, d_dls_ok.p, d_models.p, d_counts.p, d_dense.p, d_tags.p,
                                                         d_hyp_base.p);
+      } else if ((est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_ESSENTIAL_MATRIX) && !getenv("THEIA_HIP_FIT_ONE_KERNEL")) {
+        if ((rc = d_fp_ws.ensure(nh * kFpWs)) || (rc = d_fp_sol.ensure(nh * 40)) || (rc = d_fp_ok.ensure(nh)) || (rc = d_fp_mask.ensure(nh)))
+          return rc;
+        dim3 grid((B + 63) / 64, cn);
+        k_fit5_a<<<grid, 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_ok.p);
+        k_fit5_b<<<(unsigned)((nh + kFpTeamsPerWave - 1) / kFpTeamsPerWave), 64, 0, st>>>(nh, d_fp_ok.p, d_fp_ws.p, d_fp_sol.p, d_fp_mask.p);
+        if (est == THEIA_EST_RELATIVE_POSE)
+          k_fit5_c<THEIA_EST_RELATIVE_POSE><<<grid, 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_sol.p,
+                                                                d_fp_mask.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
+        else
+          k_fit5_c<THEIA_EST_ESSENTIAL_MATRIX><<<grid, 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_sol.p,
+                                                                   d_fp_mask.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
       } else {
         dim3 grid((B + 63) / 64, cn);
 #define THIP_FIT(E) k_fit<E><<<grid, 64, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p, ep)

@@ -1074,7 +1074,8 @@ RDEV void mul_deg2_deg1(const double* a, const double* b, double* o) {  // :96-1
 }
 
 // corr: 5 x [x1 y1 x2 y2]; E: up to 10 row-major 3x3.  Returns #solutions.
-RDEV int five_point(const double* corr, double* E) {
+// Steps 1-3 of the five-point solver: null space N (9 x 4) and the 10 x 10 action matrix M (false: rank deficient)
+__device__ __attribute__((noinline)) bool five_point_pre(const double* corr, double* N, double* M) {
   // Step 1: 5x9 epipolar constraint rows (:228-236)
   double A[45];
   for (int i = 0; i < 5; ++i) {
@@ -1088,7 +1089,7 @@ RDEV int five_point(const double* corr, double* E) {
   const double premult = fabs(f.maxpivot) * (DBL_EPSILON * 5.0);
   int rank = 0;
   for (int i = 0; i < f.nonzero_pivots; ++i) rank += fabs(A[i * 9 + i]) > premult;
-  if (9 - rank != 4) return 0;
+  if (9 - rank != 4) return false;
   int cidx[9];
   for (int j = 0; j < 9; ++j) cidx[j] = j;
   for (int k = 0; k < f.size; ++k) dswap(cidx[k], cidx[f.colt[k]]);
@@ -1100,8 +1101,7 @@ RDEV int five_point(const double* corr, double* E) {
       for (int j = i + 1; j < 5; ++j) s -= A[i * 9 + j] * X[j * 4 + c];
       X[i * 4 + c] = s / A[i * 9 + i];
     }
-  double N[36];  // null_space 9 x 4
-  for (int i = 0; i < 36; ++i) N[i] = 0.0;
+  for (int i = 0; i < 36; ++i) N[i] = 0.0;   // null_space 9 x 4
   for (int i = 0; i < 5; ++i) for (int c = 0; c < 4; ++c) N[cidx[i] * 4 + c] = -X[i * 4 + c];
   for (int c = 0; c < 4; ++c) N[cidx[5 + c] * 4 + c] = 1.0;
   // null_space_matrix[i][j] = row (3*j + i) of N  (:254-257)
@@ -1153,26 +1153,36 @@ RDEV int five_point(const double* corr, double* E) {
   double El[100];  // eliminated matrix: row gidx[i] = B row i
   for (int i = 0; i < 10; ++i) for (int j = 0; j < 10; ++j) El[gidx[i] * 10 + j] = B[i * 10 + j];
   // action matrix (:265-273)
-  double M[100];
   for (int i = 0; i < 100; ++i) M[i] = 0.0;
   const int src[6] = {0, 1, 2, 4, 5, 7};
   for (int r = 0; r < 6; ++r) for (int j = 0; j < 10; ++j) M[r * 10 + j] = El[src[r] * 10 + j];
   M[6 * 10 + 0] = -1.0; M[7 * 10 + 1] = -1.0; M[8 * 10 + 3] = -1.0; M[9 * 10 + 6] = -1.0;
+  return true;
+}
+// the last four entries of the NORMALISED eigenvector in column i of Vv (10 x 10 row-major): Eigen normalises
+RDEV void five_point_v4(const double* Vv, int i, double* v4) {
+  double nrm = 0.0;
+  for (int k = 0; k < 10; ++k) nrm += Vv[k * 10 + i] * Vv[k * 10 + i];
+  nrm = sqrt(nrm);
+  for (int k = 0; k < 4; ++k) v4[k] = Vv[(6 + k) * 10 + i] / nrm;
+}
+// Map<Matrix<9,1>>(ematrix.data()) = null_space * v  (column-major 3x3) -> E row-major
+RDEV void five_point_E(const double* N, const double* v4, double* Eo) {
+  double e9[9];
+  for (int rI = 0; rI < 9; ++rI) e9[rI] = ((N[rI * 4] * v4[0] + N[rI * 4 + 1] * v4[1]) + N[rI * 4 + 2] * v4[2]) + N[rI * 4 + 3] * v4[3];
+  for (int c = 0; c < 3; ++c) for (int rr = 0; rr < 3; ++rr) Eo[rr * 3 + c] = e9[c * 3 + rr];
+}
+RDEV int five_point(const double* corr, double* E) {
+  double N[36], M[100];
+  if (!five_point_pre(corr, N, M)) return 0;
   double wr[10], wi[10], Vv[100];
   if (!eig_real_general(10, M, wr, wi, Vv)) return 0;
   int ns_out = 0;
   for (int i = 0; i < 10; ++i) {
     if (wi[i] != 0) continue;  // only real solutions (:281-284)
-    double nrm = 0.0;
-    for (int k = 0; k < 10; ++k) nrm += Vv[k * 10 + i] * Vv[k * 10 + i];
-    nrm = sqrt(nrm);  // Eigen normalises eigenvectors
     double v4[4];
-    for (int k = 0; k < 4; ++k) v4[k] = Vv[(6 + k) * 10 + i] / nrm;
-    // Map<Matrix<9,1>>(ematrix.data()) = null_space * v  (column-major 3x3)
-    double e9[9];
-    for (int rI = 0; rI < 9; ++rI) e9[rI] = ((N[rI * 4] * v4[0] + N[rI * 4 + 1] * v4[1]) + N[rI * 4 + 2] * v4[2]) + N[rI * 4 + 3] * v4[3];
-    double* Eo = E + 9 * ns_out;
-    for (int c = 0; c < 3; ++c) for (int rr = 0; rr < 3; ++rr) Eo[rr * 3 + c] = e9[c * 3 + rr];
+    five_point_v4(Vv, i, v4);
+    five_point_E(N, v4, E + 9 * ns_out);
     ns_out++;
   }
   return ns_out;
