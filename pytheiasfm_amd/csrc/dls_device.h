@@ -7,9 +7,10 @@
 //            27 reduced columns minus the already solved lower-degree rows.  Lane = column of the augmented block
 //            [B_dd | rhs] (at most 36 + 27 = 63 columns), one row operation per step; 115 k FMAs instead of the 0.5 M of
 //            the dense 93 x 93 solve.  Output: the 27 x 27 multiplication matrix of f0 and the 3 x 9 translation factor.
-//   stage B  one THREAD per problem: real Schur form + eigenvectors of the 27 x 27 matrix (orthes + hqr2, complex pairs
-//            included), root extraction and the reference's solution filter.  The QR sweep is a chain of dependent
-//            FP64 operations: a wave per problem would spend it at one lane's pace, 64 problems per wave do not.
+//   stage B  real Schur form + eigenvectors of the 27 x 27 matrix (orthes + hqr2, complex pairs included), root
+//            extraction and the reference's solution filter.  In the RANSAC path a TEAM of 32 lanes per matrix with the
+//            three 27 x 27 work arrays in LDS (eig_team.h); one thread per problem with the arrays in scratch for the
+//            directly bound solver (the scratch version moved ~2.7 MB of HBM traffic per matrix).
 #ifndef THEIA_HIP_DLS_DEVICE_H_
 #define THEIA_HIP_DLS_DEVICE_H_
 
@@ -229,56 +230,60 @@ __device__ inline bool stage_a(WaveLds& L, int npts, const double* __restrict__ 
   return L.flag == 0;
 }
 
-// Stage B: eigenvectors -> (quaternion [w x y z], translation) of every admissible root, in eigenvalue-column order
-// (dls_pnp.cc:147-198).  H, V: 729-double work arrays of the calling thread.
+// One eigenvector column -> (quaternion [w x y z], translation) if it is an admissible root (dls_pnp.cc:147-198):
+// V (27 x 27, hqr2 column convention), wi: imaginary parts of the eigenvalues.
+__device__ inline bool column_solution(const double* V, const double* wi, int i, const double* __restrict__ tfac, int npts,
+                                       const double* __restrict__ world, int wstride, const int* __restrict__ index,
+                                       double* quat, double* tr) {
+  const int re_col = wi[i] < 0 ? i - 1 : i;
+  if (re_col < 0) return false;
+  const bool cplx = wi[i] != 0.0;
+  const double sg = wi[i] < 0 ? -1.0 : 1.0;
+  const double d_re = V[re_col], d_im = cplx ? sg * V[re_col + 1] : 0.0;   // row 0
+  if (d_re == 0.0 && d_im == 0.0) return false;
+  double sr[3], si[3];
+  const int rows[3] = {9, 3, 1};
+  for (int k = 0; k < 3; ++k) {
+    const double a = V[27 * rows[k] + re_col], b = cplx ? sg * V[27 * rows[k] + re_col + 1] : 0.0;
+    rsc::eig_cdiv(a, b, d_re, d_im, &sr[k], &si[k]);
+  }
+  const double kEps = 1e-6;
+  if (!(fabs(si[0]) < kEps && fabs(si[1]) < kEps && fabs(si[2]) < kEps)) return false;
+  // Quaterniond(1, s1, s2, s3).inverse().normalized()
+  const double n2 = ((1.0 + sr[0] * sr[0]) + sr[1] * sr[1]) + sr[2] * sr[2];
+  const double qi[4] = {1.0 / n2, -sr[0] / n2, -sr[1] / n2, -sr[2] / n2};
+  const double nq = sqrt(((qi[0] * qi[0] + qi[1] * qi[1]) + qi[2] * qi[2]) + qi[3] * qi[3]);
+  const double qs[4] = {qi[0] / nq, qi[1] / nq, qi[2] / nq, qi[3] / nq};
+  const double m2 = ((qs[0] * qs[0] + qs[1] * qs[1]) + qs[2] * qs[2]) + qs[3] * qs[3];
+  const double qv[4] = {qs[0] / m2, -qs[1] / m2, -qs[2] / m2, -qs[3] / m2};
+  double Rm[9], Rs[9], t[3];
+  rsc::quat_to_rot(qv, Rm);
+  for (int r = 0; r < 3; ++r) {
+    double s = 0.0;
+    for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) s += tfac[9 * r + 3 * c + k] * Rm[3 * k + c];
+    t[r] = s;
+  }
+  rsc::quat_to_rot(qs, Rs);
+  for (int j = 0; j < npts; ++j) {
+    const int id = index ? index[j] : j;
+    const double* X = world + (size_t)id * wstride;
+    const double z = ((Rs[6] * X[0] + Rs[7] * X[1]) + Rs[8] * X[2]) + t[2];
+    if (z < 0) return false;
+  }
+  for (int k = 0; k < 4; ++k) quat[k] = qs[k];
+  for (int k = 0; k < 3; ++k) tr[k] = t[k];
+  return true;
+}
+
+// Stage B, one thread per problem (the directly bound solver): H, V = 729-double work arrays of the calling thread.
 __device__ inline int stage_b(double* H, double* V, const double* __restrict__ tfac, int npts,
                               const double* __restrict__ world, int wstride, const int* __restrict__ index,
                               double* quats, double* ts) {
   double wr[27], wi[27];
   if (!rsc::eig_general_t<27, true>(27, H, wr, wi, V)) return 0;
   int ns = 0;
-  for (int i = 0; i < 27; ++i) {
-    const int re_col = wi[i] < 0 ? i - 1 : i;
-    if (re_col < 0) continue;
-    const bool cplx = wi[i] != 0.0;
-    const double sg = wi[i] < 0 ? -1.0 : 1.0;
-    const double d_re = V[re_col], d_im = cplx ? sg * V[re_col + 1] : 0.0;   // row 0
-    if (d_re == 0.0 && d_im == 0.0) continue;
-    double sr[3], si[3];
-    const int rows[3] = {9, 3, 1};
-    for (int k = 0; k < 3; ++k) {
-      const double a = V[27 * rows[k] + re_col], b = cplx ? sg * V[27 * rows[k] + re_col + 1] : 0.0;
-      rsc::eig_cdiv(a, b, d_re, d_im, &sr[k], &si[k]);
-    }
-    const double kEps = 1e-6;
-    if (!(fabs(si[0]) < kEps && fabs(si[1]) < kEps && fabs(si[2]) < kEps)) continue;
-    // Quaterniond(1, s1, s2, s3).inverse().normalized()
-    const double n2 = ((1.0 + sr[0] * sr[0]) + sr[1] * sr[1]) + sr[2] * sr[2];
-    const double qi[4] = {1.0 / n2, -sr[0] / n2, -sr[1] / n2, -sr[2] / n2};
-    const double nq = sqrt(((qi[0] * qi[0] + qi[1] * qi[1]) + qi[2] * qi[2]) + qi[3] * qi[3]);
-    const double qs[4] = {qi[0] / nq, qi[1] / nq, qi[2] / nq, qi[3] / nq};
-    const double m2 = ((qs[0] * qs[0] + qs[1] * qs[1]) + qs[2] * qs[2]) + qs[3] * qs[3];
-    const double qv[4] = {qs[0] / m2, -qs[1] / m2, -qs[2] / m2, -qs[3] / m2};
-    double Rm[9], Rs[9], t[3];
-    rsc::quat_to_rot(qv, Rm);
-    for (int r = 0; r < 3; ++r) {
-      double s = 0.0;
-      for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) s += tfac[9 * r + 3 * c + k] * Rm[3 * k + c];
-      t[r] = s;
-    }
-    rsc::quat_to_rot(qs, Rs);
-    bool front = true;
-    for (int j = 0; j < npts && front; ++j) {
-      const int id = index ? index[j] : j;
-      const double* X = world + (size_t)id * wstride;
-      const double z = ((Rs[6] * X[0] + Rs[7] * X[1]) + Rs[8] * X[2]) + t[2];
-      if (z < 0) front = false;
-    }
-    if (!front) continue;
-    for (int k = 0; k < 4; ++k) quats[4 * ns + k] = qs[k];
-    for (int k = 0; k < 3; ++k) ts[3 * ns + k] = t[k];
-    ns++;
-  }
+  for (int i = 0; i < 27; ++i)
+    if (column_solution(V, wi, i, tfac, npts, world, wstride, index, quats + 4 * ns, ts + 3 * ns)) ns++;
   return ns;
 }
 

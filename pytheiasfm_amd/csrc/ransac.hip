@@ -725,6 +725,50 @@ __global__ __launch_bounds__(64) void k_dls_b(int nprob, int B, const int64_t* _
   }
 }
 
+// stage B on chip: a team of 32 lanes per hypothesis, H / V / X in LDS (eig_team.h), lanes 0..26 turn one eigenvector
+// column each into a pose, kept in column order by a team prefix sum
+constexpr int kDlsTeam = 32, kDlsTeamsPerWave = 64 / kDlsTeam, kDlsTeamLds = 3 * 729 + 81;
+__global__ __launch_bounds__(64) void k_dls_b_team(size_t nhyp, int B, const int64_t* __restrict__ offsets,
+                                                   const double* __restrict__ data, const int* __restrict__ samples,
+                                                   const int* __restrict__ active_iters, const double* __restrict__ action,
+                                                   const double* __restrict__ tfac, const int* __restrict__ okflag,
+                                                   double* __restrict__ models, int* __restrict__ counts,
+                                                   int* __restrict__ dense_count, int* __restrict__ tags, int* __restrict__ hyp_base) {
+  __shared__ double lds[kDlsTeamsPerWave][kDlsTeamLds];
+  const int team = threadIdx.x / kDlsTeam, tl = threadIdx.x % kDlsTeam;
+  const size_t hyp = (size_t)blockIdx.x * kDlsTeamsPerWave + team;
+  if (hyp >= nhyp) return;
+  const int p = (int)(hyp / B), b = (int)(hyp % B);
+  if (b >= active_iters[p] || !okflag[hyp]) { if (tl == 0) counts[hyp] = 0; return; }
+  double* H = lds[team]; double* V = H + 729; double* X = V + 729; double* wr = X + 729; double* wi = wr + 27; double* ort = wi + 27;
+  const double* a = action + hyp * 729;
+  for (int e = tl; e < 729; e += kDlsTeam) H[e] = a[e];
+  rsc::team_sync();
+  const bool good = rsc::eig_team<kDlsTeam, true>(27, H, V, X, wr, wi, ort, tl);
+  double quat[4], tr[3];
+  bool keep = false;
+  if (good && tl < 27) {
+    const double* pd = data + (size_t)offsets[p] * 5;
+    keep = dlsdev::column_solution(V, wi, tl, tfac + hyp * 27, 3, pd + 2, 5, samples + hyp * 3, quat, tr);
+  }
+  // rank of this lane's solution among the team's (column order) and the team's count
+  int incl = keep ? 1 : 0;
+  for (int o = 1; o < kDlsTeam; o <<= 1) { const int v = __shfl_up(incl, o, kDlsTeam); if (tl >= o) incl += v; }
+  const int nm = __shfl(incl, kDlsTeam - 1, kDlsTeam);
+  int base = 0;
+  if (tl == 0) { counts[hyp] = nm; if (nm) { base = atomicAdd(&dense_count[p], nm); hyp_base[hyp] = base; } }
+  base = __shfl(base, 0, kDlsTeam);
+  if (!keep) return;
+  const int mm = dlsdev::kMaxSolutions, j = incl - 1;
+  double* m = models + ((size_t)p * B * mm + base + j) * (size_t)kStride;
+  double R[9];
+  rsc::quat_to_rot(quat, R);
+  for (int k = 0; k < 9; ++k) m[k] = R[k];
+  for (int c = 0; c < 3; ++c) m[9 + c] = -((R[c] * tr[0] + R[3 + c] * tr[1]) + R[6 + c] * tr[2]);
+  for (int k = 12; k < kStride; ++k) m[k] = 0.0;
+  tags[(size_t)p * B * mm + base + j] = b * mm + j;
+}
+
 // DlsPnp on problems of any size (the directly bound solver, sfm.cc:577): a wave per problem, then a thread per problem
 __global__ __launch_bounds__(64) void k_dls_solve_a(const int64_t* __restrict__ offsets, const double* __restrict__ feat,
                                                     const double* __restrict__ world, const double* __restrict__ uvals,
@@ -1217,9 +1261,14 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         HIP_TRYR(hipEventRecord(ev0, st));   // (re-recorded: the uploads above are not part of the fit time)
         k_dls_a<<<dim3(B, cn), 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_iter_base.p, d_dls_u.p,
                                             d_dls_action.p, d_dls_tfac.p, d_dls_ok.p);
-        k_dls_b<<<dim3((B + 63) / 64, cn), 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_dls_action.p,
-                                                        d_dls_tfac.p, d_dls_ok.p, d_models.p, d_counts.p, d_dense.p, d_tags.p,
-                                                        d_hyp_base.p);
+        if (getenv("THEIA_HIP_DLS_THREAD_EIG"))
+          k_dls_b<<<dim3((B + 63) / 64, cn), 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_dls_action.p,
+                                                          d_dls_tfac.p, d_dls_ok.p, d_models.p, d_counts.p, d_dense.p, d_tags.p,
+                                                          d_hyp_base.p);
+        else
+          k_dls_b_team<<<(unsigned)((nh + kDlsTeamsPerWave - 1) / kDlsTeamsPerWave), 64, 0, st>>>(
+              nh, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_dls_action.p, d_dls_tfac.p, d_dls_ok.p, d_models.p,
+              d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
       } else if ((est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_ESSENTIAL_MATRIX) && !getenv("THEIA_HIP_FIT_ONE_KERNEL")) {
         if ((rc = d_fp_ws.ensure(nh * kFpWs)) || (rc = d_fp_sol.ensure(nh * 40)) || (rc = d_fp_ok.ensure(nh)) || (rc = d_fp_mask.ensure(nh)))
           return rc;
