@@ -577,6 +577,10 @@ int theia_hip_dls_pnp(int32_t num, const int64_t* offsets, const double* feature
                       double* quaternions, double* translations, int32_t* num_solutions);
 void theia_hip_dls_macaulay_terms(int64_t first_call, int64_t num_calls, double* out);
 
+/* The batch entry points above keep their device workspace (up to 6 GiB) in a process-wide cache between calls;
+ * this returns it to the runtime. */
+void theia_hip_release_scratch(void);
+
 #ifdef __cplusplus
 }
 #endif

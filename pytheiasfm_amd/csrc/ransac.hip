@@ -963,18 +963,66 @@ struct ProblemState {
                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);   \
   } while (0)
 
+// Device blocks of a batch call come from a small process-wide cache: a verification pipeline calls the batch entry
+// points back to back with the same shapes, and hipMalloc / hipFree of the GB-sized model workspace cost more than the
+// kernels of a 1000-pair chunk.  Blocks are reused when they are at most twice the request; the cache keeps at most
+// kPoolLimit bytes (the rest goes back to the runtime), theia_hip_release_scratch() empties it.
+struct DevPool {
+  struct Block { void* p; size_t bytes; };
+  std::mutex mu;
+  std::vector<Block> free_blocks;
+  size_t held = 0;
+  static constexpr size_t kPoolLimit = (size_t)6 << 30;
+  void* take(size_t bytes, size_t* got) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      int best = -1;
+      for (int i = 0; i < (int)free_blocks.size(); ++i)
+        if (free_blocks[i].bytes >= bytes && free_blocks[i].bytes <= 2 * bytes + 4096 &&
+            (best < 0 || free_blocks[i].bytes < free_blocks[best].bytes)) best = i;
+      if (best >= 0) {
+        Block b = free_blocks[best];
+        free_blocks.erase(free_blocks.begin() + best);
+        held -= b.bytes; *got = b.bytes;
+        return b.p;
+      }
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {   // make room and try once more
+      release();
+      if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    }
+    *got = bytes;
+    return p;
+  }
+  void give(void* p, size_t bytes) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (held + bytes <= kPoolLimit) { free_blocks.push_back(Block{p, bytes}); held += bytes; return; }
+    }
+    (void)hipFree(p);
+  }
+  void release() {
+    std::vector<Block> blocks;
+    { std::lock_guard<std::mutex> lk(mu); blocks.swap(free_blocks); held = 0; }
+    for (const Block& b : blocks) (void)hipFree(b.p);
+  }
+};
+DevPool& dev_pool() { static DevPool pool; return pool; }
+
 template <typename T>
 struct DBuf {
   T* p = nullptr;
-  size_t cap = 0;
-  ~DBuf() { if (p) (void)hipFree(p); }
+  size_t cap = 0, bytes = 0;
+  ~DBuf() { if (p) dev_pool().give(p, bytes); }
   int ensure(size_t count) {
     if (count <= cap) return 0;
-    if (p) (void)hipFree(p);
-    p = nullptr; cap = 0;
-    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
-    if (e != hipSuccess) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", count * sizeof(T), hipGetErrorString(e));
-    cap = count;
+    if (p) dev_pool().give(p, bytes);
+    p = nullptr; cap = 0; bytes = 0;
+    size_t got = 0;
+    p = static_cast<T*>(dev_pool().take(std::max<size_t>(count * sizeof(T), 256), &got));
+    if (!p) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", count * sizeof(T));
+    bytes = got; cap = got / sizeof(T);
     return 0;
   }
 };
@@ -1194,6 +1242,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     HIP_TRYR(hipStreamSynchronize(st));
     return 0;
   };
+  const bool host_timing = getenv("THEIA_HIP_RANSAC_TIMING") != nullptr;
   for (int c0 = 0; c0 < nprob; c0 += chunk) {
     const int cn = std::min(chunk, nprob - c0);
     bool first = true;
@@ -1213,6 +1262,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       if (B == 0) break;
       first = false;
       // the sample stream of the round (RandomSampler::Sample, persistent permutation)
+      const auto tp0 = std::chrono::steady_clock::now();
       h_samples.assign((size_t)cn * B * m, 0);
       // problems are independent (own generator, own slice): host threads share them out
       host_parallel_for(cn, [&](int q) {
@@ -1234,6 +1284,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
           }
         }
       });
+      const auto tp1 = std::chrono::steady_clock::now();
       const size_t nh = (size_t)cn * B;
       if ((rc = d_samples.ensure(nh * m)) || (rc = d_counts.ensure(nh)) || (rc = d_models.ensure(nh * kMaxModels * kStride)) ||
           (rc = d_cost.ensure(nh * kMaxModels)) || (rc = d_ninl.ensure(nh * kMaxModels)) || (rc = d_active.ensure(cn)) ||
@@ -1317,6 +1368,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       HIP_TRYR(hipGetLastError());
       HIP_TRYR(hipStreamSynchronize(st));
       scratch_lock.unlock();
+      const auto tp2 = std::chrono::steady_clock::now();
       { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) fit_score_ms += ms;
         if (hipEventElapsedTime(&ms, ev0, evm) == hipSuccess) fit_ms += ms;
         if (hipEventElapsedTime(&ms, evm, ev1) == hipSuccess) score_ms += ms; }
@@ -1392,6 +1444,12 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
           s.num_lo++;
           s.max_iterations = std::min(compute_max_iterations(P, m, s.pending_ratio, log_failure_prob, s.n), s.max_iterations);
         }
+      }
+      if (host_timing) {
+        const auto tp3 = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[theia_hip ransac] chunk %d+%d round B=%d: samples %.1f ms, upload + kernels + download %.1f ms, replay %.1f ms\n",
+                     c0, cn, B, ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3));
       }
       {   // best models found in this round -> d_best_models
         std::vector<int> sp, sh, ss;
@@ -1583,5 +1641,7 @@ int theia_hip_dls_pnp(int32_t num, const int64_t* offsets, const double* feature
   HIP_TRYR(hipMemcpy(num_solutions, dn.p, sizeof(int) * num, hipMemcpyDeviceToHost));
   return 0;
 }
+
+void theia_hip_release_scratch(void) { dev_pool().release(); }
 
 }  // extern "C"
