@@ -86,8 +86,9 @@ def pmc_traffic_bytes(world):
         kb = {}
         for tag in ("fetch_size", "write_size"):
             with open(os.path.join(base, "%s_pmc_%s.csv" % (PROFILE_TAG, tag))) as f:
-                for row in csv.reader(f):
-                    if row and row[0] != "kernel":
+                for line in f:
+                    row = line.rstrip("\n").rsplit(",", 2)      # template arguments carry commas: split from the right
+                    if len(row) == 3 and row[0] != "kernel":
                         kb[(tag, row[0])] = float(row[2])
         group = [k for (t, k) in kb if t == "fetch_size" and (k.startswith("k_lin_schur") or k.startswith("k_schur_sum") or k.startswith("k_cam_prep"))]
         if not any(k.startswith("k_lin_schur") for k in group):
