@@ -94,8 +94,7 @@ class BundleAdjustmentOptions:
         self.use_gravity_priors = False
 
     def to_c(self):
-        unsupported = [n for n in ("use_inverse_depth_parametrization",
-                                   "optimize_for_forward_facing_trajectory") if getattr(self, n)]
+        unsupported = [n for n in ("use_inverse_depth_parametrization",) if getattr(self, n)]
         if unsupported:
             raise capi.TheiaHipError(-3, "options not built in the HIP backend yet: " + ", ".join(unsupported))
         o = _ba.default_options()
@@ -272,7 +271,18 @@ def _update_inverse_depth(recon, track_ids):
 
 
 def _run(options, recon, flat):
-    s, _ = _ba.solve(flat, options.to_c())
+    c_opts = options.to_c()
+    if getattr(options, "optimize_for_forward_facing_trajectory", False):
+        # bundle_adjuster.cc:547-563: intrinsics and extrinsics share elimination group 1.  The reduced system is the same
+        # one (only Ceres' fill-reducing order inside it changes).  But the reference hands the REVERSED ordering to the inner
+        # iterations (bundle_adjuster.cc:329-333), whose first set is then {extrinsics, intrinsics}: not an independent set
+        # when any intrinsics block is variable, Ceres rejects it (CoordinateDescentMinimizer::IsOrderingValid) and Solve
+        # returns FAILURE without touching the parameters.
+        if c_opts.use_inner_iterations and c_opts.intrinsics_to_optimize != 0:
+            fail = BundleAdjustmentSummary()
+            fail.success = False
+            return fail
+    s, _ = _ba.solve(flat, c_opts)
     recon.cam_ext[:] = flat.cam_ext
     recon.points[:] = flat.points
     recon.group_intrinsics[:] = flat.intrinsics   # shared CameraIntrinsicsModel parameters (:388-389)

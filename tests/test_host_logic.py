@@ -69,6 +69,16 @@ def test_options_mirror_defaults_and_unsupported():
     o.use_inverse_depth_parametrization = True     # inverse depth: not built -> explicit error
     with pytest.raises(capi.TheiaHipError):
         o.to_c()
+    # forward-facing trajectories: same reduced system; with inner iterations AND variable intrinsics Ceres rejects the
+    # reversed ordering (its first set {extrinsics, intrinsics} is not independent) and the solve fails untouched
+    f = sfm.BundleAdjustmentOptions(); f.optimize_for_forward_facing_trajectory = True
+    assert f.to_c().use_inner_iterations == 1
+    f.intrinsics_to_optimize = sfm.OptimizeIntrinsicsType.FOCAL_LENGTH
+    p = synth.synth_ba_v1(4, 40, seed=3)
+    rec = sfm.Reconstruction.from_flat(p)
+    before = rec.cam_ext.copy()
+    summ = sfm.BundleAdjustReconstruction(f, rec)       # returns before any device call
+    assert not summ.success and np.array_equal(rec.cam_ext, before)
 
 
 def test_flatten_emits_depth_prior_rows_for_added_views_only():

@@ -83,3 +83,17 @@ def test_inner_on_beats_inner_off_per_iteration_and_handles_set_options():
         o.use_inner_iterations = 1
         with pytest.raises(Exception):
             h.set_options(o)
+
+
+def test_forward_facing_option_is_the_same_reduced_system():
+    """optimize_for_forward_facing_trajectory (bundle_adjuster.cc:547-563) only collapses Ceres' elimination groups 1 and 2:
+    same Schur complement, same steps; the inner iterations keep working while the intrinsics are constant."""
+    p = synth.synth_ba_v1(8, 300, seed=5)
+    out = []
+    for flag in (False, True):
+        rec = sfm.Reconstruction.from_flat(p)
+        o = sfm.BundleAdjustmentOptions(); o.max_num_iterations = 8; o.optimize_for_forward_facing_trajectory = flag
+        s = sfm.BundleAdjustReconstruction(o, rec)
+        out.append((s, rec))
+    assert out[0][0].success and out[1][0].success and out[0][0].final_cost == out[1][0].final_cost
+    assert np.array_equal(out[0][1].cam_ext, out[1][1].cam_ext)
