@@ -101,7 +101,7 @@ enum {
 /* problem flags: a track shard of a multi-GPU solve keeps every non-constant
  * camera in the reduced system (also those it does not observe) so that all
  * ranks index the reduced camera system identically. */
-enum { THEIA_BA_FLAG_KEEP_UNOBSERVED_CAMERAS = 0x1 };
+enum { THEIA_BA_FLAG_KEEP_UNOBSERVED_CAMERAS = 0x1, THEIA_BA_FLAG_INVERSE_DEPTH = 0x2 };
 
 typedef struct theia_ba_problem {
   int32_t num_cameras;
@@ -146,6 +146,16 @@ typedef struct theia_ba_problem {
    *   obs_uv = (depth_prior, 0), obs_sqrt_info = (1 / sqrt(variance), any) (obs_sqrt_info then required).
    * NULL = every row is a reprojection error. */
   const uint8_t* obs_kind;                       /* [num_obs] THEIA_OBS_* or NULL              */
+  /* Inverse-depth parametrisation (BundleAdjustmentOptions::use_inverse_depth_parametrization; BundleAdjuster::AddInvTrack,
+   * bundle_adjuster.cc:223-289; functors camera/reprojection_error.h:173-286): with THEIA_BA_FLAG_INVERSE_DEPTH the
+   * variable of track t is point_inverse_depth[t] = Track::InverseDepth() along point_ref_bearing[t] =
+   * Track::ReferenceBearingVector() in the frame of view point_ref_cam[t] = Track::ReferenceViewId(); `points` is not
+   * read (the caller's UpdateHomogeneousPoint rebuilds it afterwards, bundle_adjustment.cc:47-65).  Every residual block
+   * touches the reference camera, the observing camera and the inverse depth.  Only through theia_hip_ba_solve;
+   * intrinsics constant, no priors / depth rows / inner iterations in this mode. */
+  const int32_t* point_ref_cam;                  /* [num_points] camera index of the reference view */
+  const double* point_ref_bearing;               /* [num_points][3]                                 */
+  double* point_inverse_depth;                   /* [num_points] in/out, > 0                        */
 } theia_ba_problem;
 enum { THEIA_PRIOR_POSITION = 1, THEIA_PRIOR_GRAVITY = 2, THEIA_PRIOR_ORIENTATION = 4 };
 enum { THEIA_OBS_REPROJECTION = 0, THEIA_OBS_DEPTH_PRIOR = 1 };

@@ -43,6 +43,7 @@ class BaProblem(C.Structure):
         ("cam_gravity_prior", c_double_p), ("cam_gravity_prior_sqrt_info", c_double_p),
         ("cam_orientation_prior", c_double_p), ("cam_orientation_prior_sqrt_info", c_double_p),
         ("obs_kind", c_uint8_p),
+        ("point_ref_cam", c_int32_p), ("point_ref_bearing", c_double_p), ("point_inverse_depth", c_double_p),
     ]
 
 
@@ -80,6 +81,7 @@ class BaSummary(C.Structure):
 
 
 THEIA_PRIOR_POSITION, THEIA_PRIOR_GRAVITY, THEIA_PRIOR_ORIENTATION = 1, 2, 4
+THEIA_BA_FLAG_KEEP_UNOBSERVED_CAMERAS, THEIA_BA_FLAG_INVERSE_DEPTH = 1, 2
 
 
 class BaViewBatch(C.Structure):
@@ -235,6 +237,8 @@ class FlatProblem:
         self.priors = {}
         # depth-prior rows (add_depth_priors): obs_kind [N] uint8 or None
         self.obs_kind = None
+        # inverse-depth parametrisation (set_inverse_depth)
+        self.point_ref_cam = None; self.point_ref_bearing = None; self.point_inverse_depth = None
 
     def add_depth_priors(self, obs_index, depth, variance=1.0):
         """One DepthPriorError row (depth_prior_error.h) per listed observation: a new observation row of kind
@@ -271,7 +275,18 @@ class FlatProblem:
         q.cam_prior_mask = self.cam_prior_mask
         q.priors = dict(self.priors)
         q.obs_kind = self.obs_kind
+        if self.point_ref_cam is not None:
+            q.set_inverse_depth(self.point_ref_cam, self.point_ref_bearing, self.point_inverse_depth.copy())
         return q
+
+    def set_inverse_depth(self, ref_cam, bearing, inverse_depth):
+        """Inverse-depth parametrisation (THEIA_BA_FLAG_INVERSE_DEPTH): per point the reference camera index,
+        Track::ReferenceBearingVector() and Track::InverseDepth() (in / out); `points` is ignored by the solve."""
+        n = self.points.shape[0]
+        self.point_ref_cam = np.ascontiguousarray(ref_cam, dtype=np.int32).reshape(n)
+        self.point_ref_bearing = np.ascontiguousarray(bearing, dtype=np.float64).reshape(n, 3)
+        self.point_inverse_depth = np.ascontiguousarray(inverse_depth, dtype=np.float64).reshape(n)
+        self.flags |= THEIA_BA_FLAG_INVERSE_DEPTH
 
     def as_struct(self):
         p = BaProblem()
@@ -293,6 +308,10 @@ class FlatProblem:
         p.obs_cam = ptr(self.obs_cam, C.c_int32)
         p.obs_pt = ptr(self.obs_pt, C.c_int32)
         p.obs_kind = ptr(self.obs_kind, C.c_uint8)
+        if self.point_ref_cam is not None:
+            p.point_ref_cam = ptr(self.point_ref_cam, C.c_int32)
+            p.point_ref_bearing = ptr(self.point_ref_bearing, C.c_double)
+            p.point_inverse_depth = ptr(self.point_inverse_depth, C.c_double)
         if self.cam_prior_mask is not None:
             p.cam_prior_mask = ptr(self.cam_prior_mask, C.c_uint8)
             for name in ("position", "gravity", "orientation"):

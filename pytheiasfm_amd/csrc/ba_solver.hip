@@ -1125,6 +1125,7 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
 #undef UP
 #undef AL
 int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_handle* out) {
+  if (p && (p->flags & THEIA_BA_FLAG_INVERSE_DEPTH)) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse depth: use theia_hip_ba_solve (no handle API in this mode)");
   if (!out) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle pointer");
   *out = nullptr;
   int rc = validate(p, o);
@@ -1768,6 +1769,10 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
 
 int theia_hip_ba_solve(const theia_ba_problem* problem, const theia_ba_options* options, theia_ba_summary* summary) {
   if (!summary) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null summary");
+  if (problem && options && (problem->flags & THEIA_BA_FLAG_INVERSE_DEPTH)) {
+    const int vrc = validate(problem, options);
+    return vrc ? vrc : ba_solve_inverse_depth(problem, options, summary);
+  }
   const double t0 = now_s();
   theia_ba_handle h = nullptr;
   int rc = theia_hip_ba_create(problem, options, &h);

@@ -29,4 +29,6 @@ int fundamental_batch_device(int num, const int64_t* d_offsets, const int* d_cou
 // twoview_lm.hip: batched OptimizeHomography; d_H = [num][9] in Eigen's column-major storage order, in/out (normalised by H(2,2))
 int homography_batch_device(int num, const int64_t* d_offsets, const int* d_counts, const double* d_corr, double* d_H,
                             const theia_ba_options* o, void* d_out, hipStream_t st);
+// ba_invdepth.hip: bundle adjustment with the inverse-depth track parametrisation (THEIA_BA_FLAG_INVERSE_DEPTH)
+int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_summary* S);
 }  // namespace thip

@@ -94,9 +94,6 @@ class BundleAdjustmentOptions:
         self.use_gravity_priors = False
 
     def to_c(self):
-        unsupported = [n for n in ("use_inverse_depth_parametrization",) if getattr(self, n)]
-        if unsupported:
-            raise capi.TheiaHipError(-3, "options not built in the HIP backend yet: " + ", ".join(unsupported))
         o = _ba.default_options()
         o.loss_function_type = int(self.loss_function_type)
         o.robust_loss_width = float(self.robust_loss_width)
@@ -147,6 +144,7 @@ class Reconstruction:
         self.track_estimated = np.zeros(0, dtype=bool)
         self.track_reference_view = np.zeros(0, dtype=np.int64)
         self.inverse_depth = np.zeros(0)
+        self.track_reference_bearing = np.zeros((0, 3))   # Track::ReferenceBearingVector()
         self.obs_view = np.zeros(0, dtype=np.int32)
         self.obs_track = np.zeros(0, dtype=np.int32)
         self.obs_uv = np.zeros((0, 2))
@@ -177,6 +175,7 @@ class Reconstruction:
         first[tr] = r.obs_view[order][idx]
         r.track_reference_view = first
         r.inverse_depth = np.zeros(nt)
+        r.track_reference_bearing = np.zeros((nt, 3))
         return r
 
     def NumViews(self):
@@ -270,6 +269,58 @@ def _update_inverse_depth(recon, track_ids):
     recon.inverse_depth[ti] = 1.0 / depth
 
 
+def _flatten_inverse_depth(recon, track_ids, const_view_ids=()):
+    """BundleAdjuster::AddInvTrack(track, false) for every listed track (bundle_adjuster.cc:223-289): one residual block per
+    estimated view of an estimated track WITH a reference view (tracks without one are skipped with an error log), every
+    camera variable unless set constant afterwards; the point block is the track's inverse depth."""
+    nt = recon.NumTracks()
+    added = np.zeros(nt, dtype=bool)
+    ti = np.asarray(list(track_ids), dtype=np.int64)
+    if len(ti):
+        added[ti] = True
+    added &= recon.track_estimated & (recon.track_reference_view != kInvalidViewId)
+    ov, ot = recon.obs_view, recon.obs_track
+    keep = recon.view_estimated[ov] & added[ot]
+    cam_const = np.zeros(recon.NumViews(), dtype=np.uint8)
+    if len(const_view_ids):
+        cam_const[np.asarray(list(const_view_ids), dtype=np.int64)] = capi_const_all()
+    sqrt_info = None
+    cov = recon.obs_cov[keep]
+    if len(cov) and not np.all(cov == 1.0):
+        sqrt_info = 1.0 / np.sqrt(cov)
+    flat = capi.FlatProblem(recon.cam_ext.copy(), recon.group_intrinsics.copy(), recon.group_model, recon.view_group,
+                            recon.points.copy(), recon.obs_uv[keep], ov[keep], ot[keep], cam_const=cam_const,
+                            point_const=(~added).astype(np.uint8), obs_sqrt_info=sqrt_info)
+    ref = np.where(recon.track_reference_view == kInvalidViewId, 0, recon.track_reference_view)
+    rho = np.where(added, recon.inverse_depth, 1.0)
+    flat.set_inverse_depth(ref, recon.track_reference_bearing, rho)
+    return flat, added
+
+
+def _update_homogeneous_point(recon, track_mask):
+    """UpdateHomogeneousPoint (bundle_adjustment.cc:47-65): X = R_ref^T (bearing / inverse_depth) + c_ref for estimated tracks
+    with a positive inverse depth."""
+    ti = np.flatnonzero(track_mask & recon.track_estimated & (recon.inverse_depth > 0.0))
+    if not len(ti):
+        return
+    ce = recon.cam_ext[recon.track_reference_view[ti]]
+    R = angle_axis_to_matrix(ce[:, 3:6])
+    b = recon.track_reference_bearing[ti] / recon.inverse_depth[ti, None]
+    recon.points[ti, :3] = np.einsum("nji,nj->ni", R, b) + ce[:, :3]
+    recon.points[ti, 3] = 1.0
+
+
+def _run_inverse_depth(options, recon, track_ids, const_view_ids=()):
+    flat, added = _flatten_inverse_depth(recon, track_ids, const_view_ids)
+    c_opts = options.to_c()
+    c_opts.use_inner_iterations = 0      # the reference passes no inner ordering in this mode (bundle_adjuster.cc:329-333)
+    s, _ = _ba.solve(flat, c_opts)
+    recon.cam_ext[:] = flat.cam_ext
+    recon.inverse_depth[added] = flat.point_inverse_depth[added]
+    _update_homogeneous_point(recon, added)
+    return BundleAdjustmentSummary(s)
+
+
 def _run(options, recon, flat):
     c_opts = options.to_c()
     if getattr(options, "optimize_for_forward_facing_trajectory", False):
@@ -291,6 +342,8 @@ def _run(options, recon, flat):
 
 def BundleAdjustReconstruction(options, reconstruction):
     """bundle_adjustment.cc:188-217 (argument order of the pybind wrapper)."""
+    if options.use_inverse_depth_parametrization:
+        return _run_inverse_depth(options, reconstruction, reconstruction.TrackIds())
     flat = _flatten(reconstruction, reconstruction.ViewIds(), reconstruction.TrackIds(), options=options)
     summary = _run(options, reconstruction, flat)
     _update_inverse_depth(reconstruction, reconstruction.TrackIds())
@@ -299,6 +352,8 @@ def BundleAdjustReconstruction(options, reconstruction):
 
 def BundleAdjustPartialReconstruction(options, view_ids, track_ids, reconstruction):
     """bundle_adjustment.cc:111-143."""
+    if options.use_inverse_depth_parametrization:
+        return _run_inverse_depth(options, reconstruction, track_ids)
     flat = _flatten(reconstruction, view_ids, track_ids, options=options)
     summary = _run(options, reconstruction, flat)
     # reference quirk (:134-135): the post-update list carries len(track_ids)
@@ -310,6 +365,8 @@ def BundleAdjustPartialReconstruction(options, view_ids, track_ids, reconstructi
 
 def BundleAdjustPartialViewsConstant(options, var_view_ids, const_view_ids, reconstruction):
     """bundle_adjustment.cc:146-185."""
+    if options.use_inverse_depth_parametrization:
+        return _run_inverse_depth(options, reconstruction, reconstruction.TrackIds(), const_view_ids)
     flat = _flatten(reconstruction, var_view_ids, reconstruction.TrackIds(), const_view_ids=const_view_ids, options=options)
     summary = _run(options, reconstruction, flat)
     _update_inverse_depth(reconstruction, reconstruction.TrackIds())

@@ -63,6 +63,21 @@ def reprojection_error(model, ext, intr, X, uv, sqrt_info=None):
     return ok, res, Je, Ji, Jp
 
 
+def solve_inverse_depth(problem, options, trace_capacity=256):
+    """Dense-LM oracle of the inverse-depth parametrisation (oracle/ba_oracle.cpp: oracle_ba_solve_inverse_depth);
+    problem.cam_ext and problem.point_inverse_depth are updated in place."""
+    L = load()
+    tr = capi.Trace(trace_capacity)
+    s = capi.BaSummary()
+    tr.attach(s)
+    st = problem.as_struct()
+    rc = L.oracle_ba_solve_inverse_depth(C.byref(st), capi.ptr(problem.point_ref_cam, C.c_int32), capi.ptr(problem.point_ref_bearing, C.c_double),
+                                         capi.ptr(problem.point_inverse_depth, C.c_double), C.byref(options), C.byref(s))
+    assert rc == 0, rc
+    tr.finish(s)
+    return s, tr
+
+
 def evaluate(problem, options):
     L = load()
     pd = 3 if options.use_homogeneous_point_parametrization else 4

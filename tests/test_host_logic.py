@@ -66,9 +66,8 @@ def test_options_mirror_defaults_and_unsupported():
     assert o.to_c().prior_mask == (capi.THEIA_PRIOR_POSITION | capi.THEIA_PRIOR_ORIENTATION)
     o.use_depth_priors = True; o.robust_loss_width_depth_prior = 0.25
     assert o.to_c().robust_loss_width_depth_prior == 0.25   # depth priors travel as observation rows (see _flatten)
-    o.use_inverse_depth_parametrization = True     # inverse depth: not built -> explicit error
-    with pytest.raises(capi.TheiaHipError):
-        o.to_c()
+    o.use_inverse_depth_parametrization = True     # travels as a problem flag (THEIA_BA_FLAG_INVERSE_DEPTH), not as an option
+    assert o.to_c().max_num_iterations == 100
     # forward-facing trajectories: same reduced system; with inner iterations AND variable intrinsics Ceres rejects the
     # reversed ordering (its first set {extrinsics, intrinsics} is not independent) and the solve fails untouched
     f = sfm.BundleAdjustmentOptions(); f.optimize_for_forward_facing_trajectory = True
