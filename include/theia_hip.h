@@ -517,7 +517,8 @@ typedef struct theia_ransac_batch {
   int32_t num_problems;
   const int64_t* offsets;      /* [num_problems+1] datum offsets           */
   const double* data;          /* [offsets[num_problems]][datum_size]      */
-  const double* estimator_params; /* estimator constants (see THEIA_EST_*), or NULL */
+  const double* estimator_params; /* estimator constants (see THEIA_EST_*), or NULL; required (not NULL) for
+                                   * THEIA_EST_UNCALIBRATED_RELATIVE_POSE */
   const uint32_t* seeds;       /* [num_problems] RandomNumberGenerator seed of each problem, or NULL = params.seed + index.
                                   Lets a caller keep a pair's sample stream when it re-batches or shards the pairs. */
 } theia_ransac_batch;
@@ -532,7 +533,9 @@ typedef struct theia_ransac_batch {
  *   UNCALIBRATED_RELATIVE_POSE: F(9) R(9) position(3) focal_length1 focal_length2 = 23 */
 #define THEIA_RANSAC_MODEL_STRIDE 24
 typedef struct theia_ransac_result {
-  int32_t* success;            /* [num_problems] Estimate() return value   */
+  int32_t* success;            /* [num_problems] Estimate() return value; 0 (with no inliers and a zero
+                                * model) for a problem with fewer data than the minimal sample, where the
+                                * reference's sampler CHECK-fails -- the rest of the batch still runs */
   double* models;              /* [num_problems][THEIA_RANSAC_MODEL_STRIDE]*/
   int32_t* num_inliers;        /* [num_problems]                           */
   uint8_t* inlier_mask;        /* [offsets[num_problems]] 1 = inlier       */

@@ -1057,6 +1057,8 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   if (P.max_iterations < P.min_iterations) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "max_iterations < min_iterations");
   const int est = batch->estimator;
   EstParams ep{0.0, 0.0};
+  if (est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE && !batch->estimator_params)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "the uncalibrated relative-pose estimator needs estimator_params = {min, max focal length}");
   if (est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE && batch->estimator_params) {
     ep.min_focal = batch->estimator_params[0];
     ep.max_focal = batch->estimator_params[1];
@@ -1093,10 +1095,13 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   const int m = sample_size(est), ds = datum_size(est);
   const int64_t total = batch->offsets[nprob];
   int nmax = 0;
+  std::vector<uint8_t> undersized(nprob, 0);
   for (int p = 0; p < nprob; ++p) {
     const int64_t n = batch->offsets[p + 1] - batch->offsets[p];
     if (n <= 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "Cannot perform estimation with 0 data measurements!");
-    if (n < m) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "problem %d has fewer data than the sample size", p);
+    // fewer data than the minimal sample: the reference's sampler cannot be initialised for this problem (CHECK).  In a
+    // batch only that problem fails (success = 0, no inliers, zero model); the others run.
+    if (n < m) undersized[p] = 1;
     if (n > (1 << 30)) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "problem too large");
     nmax = std::max(nmax, (int)n);
   }
@@ -1161,7 +1166,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     s.max_iterations = P.max_iterations;
     if (P.min_inlier_ratio > 0)
       s.max_iterations = std::min(compute_max_iterations(P, m, P.min_inlier_ratio, log_failure_prob, s.n), P.max_iterations);
-    s.it = 0; s.done = s.max_iterations <= 0; s.best_slot = -1; s.kth = 1; s.ex_i = 0; s.ex_j = 1;
+    s.it = 0; s.done = s.max_iterations <= 0 || undersized[p]; s.best_slot = -1; s.kth = 1; s.ex_i = 0; s.ex_j = 1;
     s.base_it = 0; s.rb = 0; s.rj = 0; s.round_done = true; s.best_refined = false; s.pending_ratio = 0.0; s.num_lo = 0;
     for (int k = 0; k < kMaxSample; ++k) s.best_samples[k] = 0;
   }
@@ -1502,7 +1507,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     k_inlier_mask<<<grid, 256, 0, st>>>(est, nprob, d_off.p, d_data.p, d_best_models.p, P.error_thresh, d_mask.p);
   }
   if (P.use_lo && trivial_refine) {   // :401-406 with RefineModel = "return true": the counter only
-    for (int p = 0; p < nprob; ++p) if (S[p].best_slot >= 0) S[p].num_lo++;
+    for (int p = 0; p < nprob; ++p) S[p].num_lo++;   // "++summary->num_lo_iterations" is unconditional
   } else if (P.use_lo) {   // sample_consensus_estimator.h:401-406: one more RefineModel on the final inliers (result unused)
     HIP_TRYR(hipMemcpyAsync(d_cur_models.p, d_best_models.p, sizeof(double) * nprob * kStride, hipMemcpyDeviceToDevice, st));
     std::vector<LoEvent> evs;
@@ -1510,7 +1515,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       if (S[p].best_slot >= 0) { LoEvent ev; ev.prob = p; ev.slot = -1; ev.hyp = -1; for (int k = 0; k < kMaxSample; ++k) ev.samples[k] = 0; evs.push_back(ev); }
     std::vector<int> ok;
     if ((rc = run_lo(evs, ok))) return rc;
-    for (const LoEvent& ev : evs) S[ev.prob].num_lo++;
+    for (int p = 0; p < nprob; ++p) S[p].num_lo++;   // unconditional in the reference, also when no model was found
     HIP_TRYR(hipMemcpyAsync(d_best_models.p, d_cur_models.p, sizeof(double) * nprob * kStride, hipMemcpyDeviceToDevice, st));
   }
   HIP_TRYR(hipGetLastError());
@@ -1528,6 +1533,10 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     result->success[p] = 1;
     const double inlier_ratio = (double)cnt / s.n;
     result->confidence[p] = 1.0 - std::pow(1.0 - std::pow(inlier_ratio, (double)m), (double)s.it);
+    if (undersized[p]) {
+      result->success[p] = 0; result->num_inliers[p] = 0; result->confidence[p] = 0.0;
+      for (int64_t i = batch->offsets[p]; i < batch->offsets[p + 1]; ++i) result->inlier_mask[i] = 0;
+    }
   }
   result->time_fit_score_seconds = fit_score_ms * 1e-3;
   result->time_fit_seconds = fit_ms * 1e-3; result->time_score_seconds = score_ms * 1e-3;

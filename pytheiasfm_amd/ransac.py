@@ -144,10 +144,16 @@ def estimate_batch(estimator, data, offsets, params, estimator_params=None, seed
             "time_fit_seconds": r.time_fit_seconds, "time_score_seconds": r.time_score_seconds}
 
 
+_SAMPLE_SIZE = {0: 5, 1: 5, 2: 3, 3: 3, 4: 3, 5: 8, 6: 4, 7: 3, 8: 2, 9: 8, 10: 2}   # Estimator::SampleSize() by THEIA_EST_*
+
+
 def _single(estimator, ransac_params, ransac_type, data, estimator_params=None):
     data = np.ascontiguousarray(data, dtype=np.float64)
     pc = ransac_params.to_c()
     pc.ransac_type = int(RansacType(ransac_type))
+    if data.shape[0] < _SAMPLE_SIZE[estimator]:
+        # a single Estimate() call: the reference's sampler CHECKs (random_sampler.cc:53-58); in a batch the C-ABI fails that pair only
+        raise capi.TheiaHipError(capi.THEIA_HIP_ERR_INVALID_ARGUMENT, "fewer data than the minimal sample size")
     res = estimate_batch(estimator, data, np.array([0, data.shape[0]], dtype=np.int64), pc, estimator_params)
     s = RansacSummary()
     s.inliers = np.nonzero(res["inlier_mask"])[0].tolist()

@@ -235,6 +235,7 @@ def BundleAdjustTwoViews(options, correspondences, camera1, camera2, points3d):
     o.use_homogeneous_point_parametrization = False
     o.intrinsics_to_optimize = _sfm.OptimizeIntrinsicsType.FOCAL_LENGTH
     o.use_inner_iterations = False
+    o.max_trust_region_radius = 1e16            # bundle_adjust_two_views.cc:61-72 leaves Ceres' default, not BundleAdjuster's 1e12
     s, _ = _ba.solve(flat, o.to_c())
     camera1["ext"][:] = flat.cam_ext[0]; camera2["ext"][:] = flat.cam_ext[1]
     camera1["intr"][:] = flat.intrinsics[0][:len(camera1["intr"])]; camera2["intr"][:] = flat.intrinsics[1][:len(camera2["intr"])]

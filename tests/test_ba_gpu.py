@@ -1030,7 +1030,8 @@ def test_bundle_adjust_two_views_mirror_matches_oracle():
                                 np.concatenate([np.arange(120), np.arange(120)]).astype(np.int32), cam_const=[3, 0],
                                 group_const=[1, int(const2)])
         # bundle_adjust_two_views.cc:61-72 builds its own solver options: no inner iterations
-        o, oo = both_options(max_num_iterations=20, intrinsics_to_optimize=0x01, use_homogeneous_point_parametrization=0, use_inner_iterations=0)
+        o, oo = both_options(max_num_iterations=20, intrinsics_to_optimize=0x01, use_homogeneous_point_parametrization=0, use_inner_iterations=0,
+                             max_trust_region_radius=1e16)
         so, tro = ol.solve(flat, oo)
         assert summ.success and summ.final_cost < 0.01 * summ.initial_cost
         assert rel(summ.final_cost, so.final_cost) <= 1e-8 and np.abs(cam2["ext"] - flat.cam_ext[1]).max() <= 1e-6

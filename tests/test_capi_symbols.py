@@ -33,7 +33,7 @@ def test_version_and_error_strings():
 
 def test_struct_layouts_match_header_sizes():
     # plain-C layout: 3 int32 + flags + int64 + 12 pointers
-    assert ctypes.sizeof(capi.BaProblem) == 4 * 4 + 8 + 20 * 8   # + 7 camera-prior pointers + obs_kind
+    assert ctypes.sizeof(capi.BaProblem) == 4 * 4 + 8 + 23 * 8   # + 7 camera-prior pointers + obs_kind + 3 inverse-depth pointers
     assert ctypes.sizeof(capi.BaOptions) == 10 * 4 + 7 * 8
     assert ctypes.sizeof(capi.RansacParams) == 3 * 8 + 8 * 4
     assert ctypes.sizeof(capi.BaSummary) == 4 * 4 + 4 * 8 + 2 * 4 + 5 * 8 + 3 * 8 + 8 + 2 * 4

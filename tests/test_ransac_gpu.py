@@ -149,6 +149,17 @@ def test_mirror_api_and_error_conventions():
     assert ok and np.abs(ad.position - ta["position"][0]).max() < 0.25 and len(s5.inliers) > 30
     with pytest.raises(capi.TheiaHipError):
         ransac.EstimateRelativePose(p, ransac.RansacType.RANSAC, data[:3])  # fewer data than the sample size
+    # in a batch an undersized pair fails alone (success 0, no inliers); its neighbours are unaffected
+    d2, o2, _ = synth.synth_ransac_v1(3, 100, "relative", seed=0x5AC50710)
+    small = np.concatenate([d2[o2[0]:o2[1]], d2[o2[1]:o2[1] + 3], d2[o2[2]:o2[3]]])
+    so = np.array([0, o2[1] - o2[0], o2[1] - o2[0] + 3, o2[1] - o2[0] + 3 + o2[3] - o2[2]])
+    pb = ransac.RansacParameters(); pb.error_thresh = THR[0]; pb.seed = 5
+    rb = ransac.estimate_batch(0, small, so, pb, seeds=[5, 6, 7])
+    full = ransac.estimate_batch(0, d2, o2, pb, seeds=[5, 6, 7])
+    assert list(rb["success"]) == [1, 0, 1] and rb["num_inliers"][1] == 0 and not rb["inlier_mask"][so[1]:so[2]].any()
+    assert np.array_equal(rb["models"][[0, 2]], full["models"][[0, 2]]) and np.array_equal(rb["num_inliers"][[0, 2]], full["num_inliers"][[0, 2]])
+    with pytest.raises(capi.TheiaHipError):
+        ransac.estimate_batch(ransac.EST_UNCALIBRATED_RELATIVE_POSE, data, np.array([0, len(data)]), p)   # no focal-length range given
 
 
 def test_lo_ransac_absolute_pose_follows_oracle():
