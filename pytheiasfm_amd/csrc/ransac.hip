@@ -860,14 +860,29 @@ struct Mt19937 {
 };
 
 // sample_consensus_estimator.h:252-297
-// The minimal-solver kernels need ~11 KB of scratch per lane; the runtime sizes a queue's scratch arena
-// for a full chip of such waves, and two queues asking for it at the same time end in
-// HSA_STATUS_ERROR_OUT_OF_RESOURCES (queue abort).  Calls from several host threads therefore take turns for the
-// launch -> synchronise sections that run those kernels; the host-side parts (sample streams, replay) overlap.
-std::recursive_mutex& scratch_mutex() {
-  static std::recursive_mutex m;
-  return m;
+// The minimal-solver kernels need up to ~12 KB of scratch per lane; the runtime sizes a hardware queue's
+// scratch arena for a full chip of such waves, and two queues asking for it at the same time end in
+// HSA_STATUS_ERROR_OUT_OF_RESOURCES (queue abort).  Every RANSAC kernel of the process therefore goes to ONE stream
+// (= one hardware queue, one arena), whichever host thread enqueues it: calls from a thread pool interleave their
+// launches on it (each call owns its buffers, the stream keeps each call's own order) and wait for their OWN work
+// through an event -- no host-side lock, nobody waits for another caller's synchronisation.
+hipStream_t solver_stream() {
+  static hipStream_t s = [] {
+    hipStream_t x = nullptr;
+    if (hipStreamCreateWithFlags(&x, hipStreamNonBlocking) != hipSuccess) x = nullptr;
+    return x;
+  }();
+  return s;
 }
+struct CallSync {   // "my work on the shared stream is done"
+  hipEvent_t e = nullptr;
+  CallSync() { (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); }
+  ~CallSync() { if (e) (void)hipEventDestroy(e); }
+  hipError_t wait(hipStream_t st) {
+    hipError_t r = hipEventRecord(e, st);
+    return r != hipSuccess ? r : hipEventSynchronize(e);
+  }
+};
 
 // Host-side loops over independent problems (sample streams, acceptance replay) on a few threads.
 // THEIA_HIP_HOST_THREADS caps the count (default min(hardware threads, 16); 1 = serial).
@@ -1105,9 +1120,9 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     if (n > (1 << 30)) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "problem too large");
     nmax = std::max(nmax, (int)n);
   }
-  hipStream_t st;
-  HIP_TRYR(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sguard{st};
+  hipStream_t st = solver_stream();
+  if (!st) return set_error(THEIA_HIP_ERR_NO_DEVICE, "could not create the solver stream");
+  CallSync mine;
   hipEvent_t ev0, ev1, evm;
   HIP_TRYR(hipEventCreate(&ev0)); HIP_TRYR(hipEventCreate(&ev1)); HIP_TRYR(hipEventCreate(&evm));
   struct EvGuard { hipEvent_t a, b, c; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c); } } eguard{ev0, ev1, evm};
@@ -1201,7 +1216,6 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     const int nev = (int)evs.size();
     success.assign(nev, 0);
     if (nev == 0) return 0;
-    std::lock_guard<std::recursive_mutex> scratch_lock(scratch_mutex());
     std::vector<int> hp(nev), hs((size_t)nev * kMaxSample), hsl(nev), hmod(nev, THEIA_CAM_PINHOLE), hhyp(nev);
     std::vector<int64_t> hoff(nev + 1, 0);
     std::vector<double> hintr((size_t)nev * THEIA_MAX_INTRINSICS, 0.0);
@@ -1244,7 +1258,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     k_lo_finish<<<(nev + 63) / 64, 64, 0, st>>>(est, nev, d_ev_prob.p, d_ev_cam.p, d_ev_model.p,
                                                 reinterpret_cast<const LoOut*>(d_lo_out.p), d_cur_models.p, d_ev_success.p);
     HIP_TRYR(hipMemcpyAsync(success.data(), d_ev_success.p, sizeof(int) * nev, hipMemcpyDeviceToHost, st));
-    HIP_TRYR(hipStreamSynchronize(st));
+    HIP_TRYR(mine.wait(st));
     return 0;
   };
   const bool host_timing = getenv("THEIA_HIP_RANSAC_TIMING") != nullptr;
@@ -1298,7 +1312,6 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       HIP_TRYR(hipMemsetAsync(d_dense.p, 0, sizeof(int) * cn, st));
       HIP_TRYR(hipMemcpyAsync(d_samples.p, h_samples.data(), sizeof(int) * nh * m, hipMemcpyHostToDevice, st));
       HIP_TRYR(hipMemcpyAsync(d_active.p, h_active.data(), sizeof(int) * cn, hipMemcpyHostToDevice, st));
-      std::unique_lock<std::recursive_mutex> scratch_lock(scratch_mutex());
       HIP_TRYR(hipEventRecord(ev0, st));
       if (dls_est) {
         h_iter_base.assign(cn, 0);
@@ -1371,8 +1384,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       HIP_TRYR(hipMemcpyAsync(h_cost.data(), d_cost.p, sizeof(double) * nh * kMaxModels, hipMemcpyDeviceToHost, st));
       HIP_TRYR(hipMemcpyAsync(h_ninl.data(), d_ninl.p, sizeof(int) * nh * kMaxModels, hipMemcpyDeviceToHost, st));
       HIP_TRYR(hipGetLastError());
-      HIP_TRYR(hipStreamSynchronize(st));
-      scratch_lock.unlock();
+      HIP_TRYR(mine.wait(st));
       const auto tp2 = std::chrono::steady_clock::now();
       { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) fit_score_ms += ms;
         if (hipEventElapsedTime(&ms, ev0, evm) == hipSuccess) fit_ms += ms;
@@ -1465,13 +1477,12 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         if (!sp.empty()) {
           const int ns = (int)sp.size();
           if ((rc = d_save.ensure((size_t)3 * ns))) return rc;
-          std::lock_guard<std::recursive_mutex> save_lock(scratch_mutex());
           HIP_TRYR(hipMemcpyAsync(d_save.p, sp.data(), sizeof(int) * ns, hipMemcpyHostToDevice, st));
           HIP_TRYR(hipMemcpyAsync(d_save.p + ns, sh.data(), sizeof(int) * ns, hipMemcpyHostToDevice, st));
           HIP_TRYR(hipMemcpyAsync(d_save.p + 2 * ns, ss.data(), sizeof(int) * ns, hipMemcpyHostToDevice, st));
           k_save_best<<<(ns * kStride + 255) / 256, 256, 0, st>>>(est, ns, d_save.p, d_save.p + ns, d_save.p + 2 * ns, B, d_models.p,
                                                                   d_hyp_base.p, d_best_models.p);
-          HIP_TRYR(hipStreamSynchronize(st));   // the host vectors above are the sources of asynchronous uploads
+          HIP_TRYR(mine.wait(st));   // the host vectors above are the sources of asynchronous uploads
         }
       }
       result->hypotheses_evaluated += n_hyp.load(); result->models_scored += n_scored.load();
@@ -1485,7 +1496,6 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   if ((rc = d_best_samples.ensure((size_t)nprob * kMaxSample)) || (rc = d_best_slot.ensure(nprob)) ||
       (rc = d_best_models.ensure((size_t)nprob * kStride)) || (rc = d_mask.ensure((size_t)total)))
     return rc;
-  std::lock_guard<std::recursive_mutex> final_scratch_lock(scratch_mutex());
   HIP_TRYR(hipMemcpyAsync(d_best_samples.p, best_samples_all.data(), sizeof(int) * nprob * kMaxSample, hipMemcpyHostToDevice, st));
   HIP_TRYR(hipMemcpyAsync(d_best_slot.p, best_slot_all.data(), sizeof(int) * nprob, hipMemcpyHostToDevice, st));
   // d_best_models already holds every problem's best model (k_save_best); THEIA_HIP_RANSAC_REFIT=1 recomputes them from the
@@ -1519,7 +1529,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     HIP_TRYR(hipMemcpyAsync(d_best_models.p, d_cur_models.p, sizeof(double) * nprob * kStride, hipMemcpyDeviceToDevice, st));
   }
   HIP_TRYR(hipGetLastError());
-  HIP_TRYR(hipStreamSynchronize(st));
+  HIP_TRYR(mine.wait(st));
   // caller-owned (pageable) destinations: blocking copies after the stream has drained
   HIP_TRYR(hipMemcpy(result->models, d_best_models.p, sizeof(double) * nprob * kStride, hipMemcpyDeviceToHost));
   HIP_TRYR(hipMemcpy(result->inlier_mask, d_mask.p, (size_t)total, hipMemcpyDeviceToHost));
@@ -1544,44 +1554,54 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
 }
 
 int theia_hip_five_point_relative_pose(int32_t num, const double* corr, double* essential_matrices, int32_t* num_solutions) {
-  std::lock_guard<std::recursive_mutex> scratch_lock(scratch_mutex());
   if (num < 0 || (num > 0 && (!corr || !essential_matrices || !num_solutions))) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
   if (num == 0) return 0;
   int rc = ensure_device();
   if (rc) return rc;
+  hipStream_t st = solver_stream();
+  if (!st) return set_error(THEIA_HIP_ERR_NO_DEVICE, "could not create the solver stream");
+  CallSync mine;
   DBuf<double> dc, de; DBuf<int> dn;
   if ((rc = dc.ensure((size_t)num * 20)) || (rc = de.ensure((size_t)num * 90)) || (rc = dn.ensure(num))) return rc;
-  HIP_TRYR(hipMemcpy(dc.p, corr, sizeof(double) * num * 20, hipMemcpyHostToDevice));
-  k_five_point<<<(num + 63) / 64, 64>>>(num, dc.p, de.p, dn.p);
-  HIP_TRYR(hipMemcpy(essential_matrices, de.p, sizeof(double) * num * 90, hipMemcpyDeviceToHost));
-  HIP_TRYR(hipMemcpy(num_solutions, dn.p, sizeof(int) * num, hipMemcpyDeviceToHost));
+  HIP_TRYR(hipMemcpyAsync(dc.p, corr, sizeof(double) * num * 20, hipMemcpyHostToDevice, st));
+  k_five_point<<<(num + 63) / 64, 64, 0, st>>>(num, dc.p, de.p, dn.p);
+  HIP_TRYR(hipMemcpyAsync(essential_matrices, de.p, sizeof(double) * num * 90, hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipMemcpyAsync(num_solutions, dn.p, sizeof(int) * num, hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipGetLastError());
+  HIP_TRYR(mine.wait(st));
   return 0;
 }
 
 int theia_hip_pose_from_three_points(int32_t num, const double* corr2d3d, double* rotations, double* translations, int32_t* num_solutions) {
-  std::lock_guard<std::recursive_mutex> scratch_lock(scratch_mutex());
   if (num < 0 || (num > 0 && (!corr2d3d || !rotations || !translations || !num_solutions))) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
   if (num == 0) return 0;
   int rc = ensure_device();
   if (rc) return rc;
+  hipStream_t st = solver_stream();
+  if (!st) return set_error(THEIA_HIP_ERR_NO_DEVICE, "could not create the solver stream");
+  CallSync mine;
   DBuf<double> dc, dr, dt; DBuf<int> dn;
   if ((rc = dc.ensure((size_t)num * 15)) || (rc = dr.ensure((size_t)num * 36)) || (rc = dt.ensure((size_t)num * 12)) || (rc = dn.ensure(num))) return rc;
-  HIP_TRYR(hipMemcpy(dc.p, corr2d3d, sizeof(double) * num * 15, hipMemcpyHostToDevice));
-  k_p3p<<<(num + 63) / 64, 64>>>(num, dc.p, dr.p, dt.p, dn.p);
-  HIP_TRYR(hipMemcpy(rotations, dr.p, sizeof(double) * num * 36, hipMemcpyDeviceToHost));
-  HIP_TRYR(hipMemcpy(translations, dt.p, sizeof(double) * num * 12, hipMemcpyDeviceToHost));
-  HIP_TRYR(hipMemcpy(num_solutions, dn.p, sizeof(int) * num, hipMemcpyDeviceToHost));
+  HIP_TRYR(hipMemcpyAsync(dc.p, corr2d3d, sizeof(double) * num * 15, hipMemcpyHostToDevice, st));
+  k_p3p<<<(num + 63) / 64, 64, 0, st>>>(num, dc.p, dr.p, dt.p, dn.p);
+  HIP_TRYR(hipMemcpyAsync(rotations, dr.p, sizeof(double) * num * 36, hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipMemcpyAsync(translations, dt.p, sizeof(double) * num * 12, hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipMemcpyAsync(num_solutions, dn.p, sizeof(int) * num, hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipGetLastError());
+  HIP_TRYR(mine.wait(st));
   return 0;
 }
 
 int theia_hip_sqpnp(int32_t num, const int64_t* offsets, const double* features, const double* world_points,
                     double* quaternions, double* translations, int32_t* num_solutions) {
-  std::lock_guard<std::recursive_mutex> scratch_lock(scratch_mutex());
   if (num < 0 || (num > 0 && (!offsets || !features || !world_points || !quaternions || !translations || !num_solutions)))
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
   if (num == 0) return 0;
   int rc = thip::ensure_device();
   if (rc) return rc;
+  hipStream_t st = solver_stream();
+  if (!st) return set_error(THEIA_HIP_ERR_NO_DEVICE, "could not create the solver stream");
+  CallSync mine;
   for (int i = 0; i < num; ++i)
     if (offsets[i + 1] < offsets[i]) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
   const int64_t total = offsets[num] - offsets[0];
@@ -1591,14 +1611,16 @@ int theia_hip_sqpnp(int32_t num, const int64_t* offsets, const double* features,
       (rc = dq.ensure((size_t)num * 72)) || (rc = dt.ensure((size_t)num * 54)) || (rc = dn.ensure(num)) || (rc = dof.ensure(num + 1)))
     return rc;
   if (total) {
-    HIP_TRYR(hipMemcpy(df.p, features, sizeof(double) * total * 2, hipMemcpyHostToDevice));
-    HIP_TRYR(hipMemcpy(dw.p, world_points, sizeof(double) * total * 3, hipMemcpyHostToDevice));
+    HIP_TRYR(hipMemcpyAsync(df.p, features, sizeof(double) * total * 2, hipMemcpyHostToDevice, st));
+    HIP_TRYR(hipMemcpyAsync(dw.p, world_points, sizeof(double) * total * 3, hipMemcpyHostToDevice, st));
   }
-  HIP_TRYR(hipMemcpy(dof.p, offsets, sizeof(int64_t) * (num + 1), hipMemcpyHostToDevice));
-  k_sqpnp<<<(num + 63) / 64, 64>>>(num, dof.p, df.p, dw.p, dq.p, dt.p, dn.p);
-  HIP_TRYR(hipMemcpy(quaternions, dq.p, sizeof(double) * num * 72, hipMemcpyDeviceToHost));
-  HIP_TRYR(hipMemcpy(translations, dt.p, sizeof(double) * num * 54, hipMemcpyDeviceToHost));
-  HIP_TRYR(hipMemcpy(num_solutions, dn.p, sizeof(int) * num, hipMemcpyDeviceToHost));
+  HIP_TRYR(hipMemcpyAsync(dof.p, offsets, sizeof(int64_t) * (num + 1), hipMemcpyHostToDevice, st));
+  k_sqpnp<<<(num + 63) / 64, 64, 0, st>>>(num, dof.p, df.p, dw.p, dq.p, dt.p, dn.p);
+  HIP_TRYR(hipMemcpyAsync(quaternions, dq.p, sizeof(double) * num * 72, hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipMemcpyAsync(translations, dt.p, sizeof(double) * num * 54, hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipMemcpyAsync(num_solutions, dn.p, sizeof(int) * num, hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipGetLastError());
+  HIP_TRYR(mine.wait(st));
   return 0;
 }
 
@@ -1611,12 +1633,14 @@ void theia_hip_dls_macaulay_terms(int64_t first_call, int64_t num_calls, double*
 
 int theia_hip_dls_pnp(int32_t num, const int64_t* offsets, const double* features, const double* world_points,
                       const int64_t* call_index, double* quaternions, double* translations, int32_t* num_solutions) {
-  std::lock_guard<std::recursive_mutex> scratch_lock(scratch_mutex());
   if (num < 0 || (num > 0 && (!offsets || !features || !world_points || !quaternions || !translations || !num_solutions)))
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
   if (num == 0) return 0;
   int rc = thip::ensure_device();
   if (rc || (rc = ensure_dls_tables())) return rc;
+  hipStream_t st = solver_stream();
+  if (!st) return set_error(THEIA_HIP_ERR_NO_DEVICE, "could not create the solver stream");
+  CallSync mine;
   if (offsets[0] != 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "offsets[0] must be 0");
   int64_t max_call = num - 1;
   for (int i = 0; i < num; ++i) {
@@ -1637,17 +1661,19 @@ int theia_hip_dls_pnp(int32_t num, const int64_t* offsets, const double* feature
       (rc = du.ensure((size_t)num * 4)) || (rc = da.ensure((size_t)num * 729)) || (rc = dtf.ensure((size_t)num * 27)) || (rc = dok.ensure(num)))
     return rc;
   if (total) {
-    HIP_TRYR(hipMemcpy(df.p, features, sizeof(double) * total * 2, hipMemcpyHostToDevice));
-    HIP_TRYR(hipMemcpy(dw.p, world_points, sizeof(double) * total * 3, hipMemcpyHostToDevice));
+    HIP_TRYR(hipMemcpyAsync(df.p, features, sizeof(double) * total * 2, hipMemcpyHostToDevice, st));
+    HIP_TRYR(hipMemcpyAsync(dw.p, world_points, sizeof(double) * total * 3, hipMemcpyHostToDevice, st));
   }
-  HIP_TRYR(hipMemcpy(dof.p, offsets, sizeof(int64_t) * (num + 1), hipMemcpyHostToDevice));
-  HIP_TRYR(hipMemcpy(du.p, u.data(), sizeof(double) * num * 4, hipMemcpyHostToDevice));
-  k_dls_solve_a<<<num, 64>>>(dof.p, df.p, dw.p, du.p, da.p, dtf.p, dok.p);
-  k_dls_solve_b<<<(num + 63) / 64, 64>>>(num, dof.p, dw.p, da.p, dtf.p, dok.p, dq.p, dt.p, dn.p);
+  HIP_TRYR(hipMemcpyAsync(dof.p, offsets, sizeof(int64_t) * (num + 1), hipMemcpyHostToDevice, st));
+  HIP_TRYR(hipMemcpyAsync(du.p, u.data(), sizeof(double) * num * 4, hipMemcpyHostToDevice, st));
+  k_dls_solve_a<<<num, 64, 0, st>>>(dof.p, df.p, dw.p, du.p, da.p, dtf.p, dok.p);
+  k_dls_solve_b<<<(num + 63) / 64, 64, 0, st>>>(num, dof.p, dw.p, da.p, dtf.p, dok.p, dq.p, dt.p, dn.p);
   HIP_TRYR(hipGetLastError());
-  HIP_TRYR(hipMemcpy(quaternions, dq.p, sizeof(double) * num * 4 * NS, hipMemcpyDeviceToHost));
-  HIP_TRYR(hipMemcpy(translations, dt.p, sizeof(double) * num * 3 * NS, hipMemcpyDeviceToHost));
-  HIP_TRYR(hipMemcpy(num_solutions, dn.p, sizeof(int) * num, hipMemcpyDeviceToHost));
+  HIP_TRYR(hipMemcpyAsync(quaternions, dq.p, sizeof(double) * num * 4 * NS, hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipMemcpyAsync(translations, dt.p, sizeof(double) * num * 3 * NS, hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipMemcpyAsync(num_solutions, dn.p, sizeof(int) * num, hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipGetLastError());
+  HIP_TRYR(mine.wait(st));
   return 0;
 }
 

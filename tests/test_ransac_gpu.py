@@ -705,3 +705,49 @@ def test_golden_refine_model_vectors_on_device():
             assert np.array_equal(res["inlier_mask"][off[i]:off[i + 1]], g[f"lo_{kind}_masks"][i])
             ref = g[f"lo_{kind}_models"][i]
             assert np.abs(res["models"][i][:mlen] - ref).max() <= 1e-7 * max(1.0, np.abs(ref).max())
+
+
+def test_estimators_called_from_a_thread_pool_share_one_queue():
+    """The pipelines run the estimators from thread-pool workers.  Every RANSAC kernel goes to the library's one solver
+    stream (one hardware queue = one scratch arena for the scratch-heavy minimal solvers) without a host-side lock:
+    six threads running different estimators at once -- five-point, SQPnP, DLS, LO-RANSAC absolute pose and the
+    single-problem solvers -- return the bits of the sequential calls."""
+    import threading
+    rel, orel, _ = synth.synth_ransac_v1(8, 300, "relative", seed=0x5AC50901)
+    ab, oab, _ = synth.synth_ransac_v1(8, 300, "absolute", seed=0x5AC50902)
+    five, _, _ = synth.synth_ransac_v1(200, 5, "relative", seed=0x5AC50903, inlier_lo=1.0, inlier_hi=1.0)
+    c5 = five.reshape(200, 5, 4)
+    prel = ransac.RansacParameters(); prel.error_thresh = THR[0]; prel.seed = 9; prel.min_iterations = 200; prel.max_iterations = 400
+    pabs = ransac.RansacParameters(); pabs.error_thresh = THR[2]; pabs.seed = 10; pabs.min_iterations = 100; pabs.max_iterations = 200
+    plo = ransac.RansacParameters(); plo.error_thresh = THR[2]; plo.seed = 11; plo.use_lo = True; plo.lo_start_iterations = 5
+    plo.min_iterations = 50; plo.max_iterations = 100
+    jobs = [
+        lambda: ransac.estimate_batch(ransac.EST_RELATIVE_POSE, rel, orel, prel),
+        lambda: ransac.estimate_batch(ransac.EST_ABS_SQPNP, ab, oab, pabs),
+        lambda: ransac.estimate_batch(ransac.EST_ABS_DLS, ab, oab, pabs),
+        lambda: ransac.estimate_batch(ransac.EST_ABS_KNEIP, ab, oab, plo),
+        lambda: ransac.estimate_batch(ransac.EST_ESSENTIAL_MATRIX, rel, orel, prel),
+        lambda: ransac.FivePointRelativePose(c5[:, :, :2], c5[:, :, 2:]),
+    ]
+
+    def same(a, b):
+        if isinstance(a, dict):
+            return all(np.array_equal(a[k], b[k]) for k in ("success", "models", "num_inliers", "inlier_mask", "num_iterations", "num_lo_iterations"))
+        return all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b))
+
+    ref = [j() for j in jobs]
+    out = [None] * len(jobs); errs = []
+
+    def worker(k):
+        try:
+            for _ in range(3):
+                out[k] = jobs[k]()
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(len(jobs))]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    for k in range(len(jobs)):
+        assert same(ref[k], out[k]), k
