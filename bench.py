@@ -330,7 +330,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"synth_ba_v1 C4: {nviews} views / {ntracks} tracks / {nobs_total} observations, mixed pinhole + "
                                    f"double-sphere (8 intrinsics groups), TRIVIAL loss, intrinsics NONE, homogeneous-manifold points, "
-                                   f"{ITERS_PER_SOLVE} LM iterations per solve"
+                                   f"{ITERS_PER_SOLVE} LM iterations per solve, use_inner_iterations = false on the GPU and the CPU leg "
+                                   f"(the trust-region step of north_star alone; the reference's default = true is measured in "
+                                   f"\"with_inner_iterations\")"
                                    + ("" if world == 1 else f", tracks sharded over {world} ranks, RCCL all-reduce of the reduced camera system"),
                        "views": nviews, "tracks": ntracks, "observations": nobs_total,
                        "baseline_config": "BASELINE.json configs[3] (north_star target configuration) on %d GPU%s" % (world, "" if world == 1 else "s"),
@@ -357,6 +359,23 @@ def main():
         comm.close()
 
     host_cores = os.cpu_count() or 1
+    if rank == 0 and world == 1:
+        # the reference's DEFAULT options run Ceres' inner iterations after every accepted step (bundle_adjustment.h:144):
+        # the same problem with use_inner_iterations = true, for the record (not the headline: the inner sweeps are per-block
+        # LM solves outside north_star's hot path)
+        oi = bench_options(ba, ITERS_PER_SOLVE); oi.use_inner_iterations = 1
+        hi = ba.BaHandle(pristine.copy(), oi)
+        hi.reset(pristine); hi.snapshot()
+        hi.restore(); hi.run(trace_capacity=1)
+        torch.cuda.synchronize(); ti0 = time.perf_counter()
+        nrep = 2
+        for _ in range(nrep):
+            hi.restore(); si, _ = hi.run(trace_capacity=1)
+        torch.cuda.synchronize(); ti = time.perf_counter() - ti0
+        out["with_inner_iterations"] = {"lm_iterations_per_sec": nrep * si.num_iterations / ti,
+                                        "ms_per_step": 1e3 * ti / (nrep * si.num_iterations), "iterations_per_solve": si.num_iterations,
+                                        "note": "use_inner_iterations = true (reference default): coordinate descent over cameras then points after each accepted step"}
+        del hi
     if rank == 0 and world == 1 and not args.no_c2:
         # secondary block: BASELINE.json configs[1] (the round-1 headline), same measurement
         c2 = synth.ba_config("C2")

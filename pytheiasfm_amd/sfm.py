@@ -572,6 +572,14 @@ def SetOutlierTracksToUnestimated(track_ids, max_inlier_reprojection_error, min_
     return int(bad_reproj.sum() + bad_angle.sum())
 
 
+def RemoveOutlierTracks(tracks_to_check, max_reprojection_error_in_pixels, min_triangulation_angle_degrees, reconstruction):
+    """incremental_reconstruction_estimator.cc:599-610 / hybrid_reconstruction_estimator.cc:850-861: the estimators'
+    sweep around every (partial) BA = SetOutlierTracksToUnestimated with the estimator's own angle option; returns the
+    number of points removed (the reference only logs it)."""
+    return SetOutlierTracksToUnestimated(tracks_to_check, max_reprojection_error_in_pixels, min_triangulation_angle_degrees,
+                                         reconstruction)
+
+
 def _select_good_tracks(r, view_ids, track_len, track_err, long_track_length_threshold, image_grid_cell_size_pixels,
                         min_num_optimized_tracks_per_view):
     """The selection rules of select_good_tracks_for_bundle_adjustment.cc:164-320 on precomputed per-track statistics

@@ -258,6 +258,8 @@ def test_outlier_track_sweep_matches_reference_rules():
         expect_bad[t] = bad
     assert expect_bad[[7, 11, 20]].all() and removed == expect_bad.sum()
     assert np.array_equal(~rec.track_estimated, expect_bad)
+    rec2 = sfm.Reconstruction.from_flat(p)   # the estimators' wrapper (incremental_reconstruction_estimator.cc:599-610)
+    assert sfm.RemoveOutlierTracks(range(300), 4.0, 1.0, rec2) == removed and np.array_equal(rec2.track_estimated, rec.track_estimated)
 
 
 def test_edge_cases_empty_invalid_and_errors():
