@@ -56,6 +56,17 @@ __host__ __device__ inline int sample_size(int est) {
     default: return 3;
   }
 }
+// meaningful doubles of a model row (layouts in theia_hip.h)
+inline int model_doubles(int est) {
+  switch (est) {
+    case THEIA_EST_RELATIVE_POSE: return 21;
+    case THEIA_EST_UNCALIBRATED_RELATIVE_POSE: return 23;
+    case THEIA_EST_ABSOLUTE_POSE_KNEIP: case THEIA_EST_ABSOLUTE_POSE_DLS: case THEIA_EST_ABSOLUTE_POSE_SQPNP: return 12;
+    case THEIA_EST_DOMINANT_PLANE: return 6;
+    case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: return 3;
+    default: return 9;   // essential / fundamental matrix, homography
+  }
+}
 __host__ __device__ inline int datum_size(int est) {
   switch (est) {
     case THEIA_EST_ABSOLUTE_POSE_KNEIP: case THEIA_EST_ABSOLUTE_POSE_DLS: case THEIA_EST_ABSOLUTE_POSE_SQPNP:
@@ -1533,6 +1544,11 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   // caller-owned (pageable) destinations: blocking copies after the stream has drained
   HIP_TRYR(hipMemcpy(result->models, d_best_models.p, sizeof(double) * nprob * kStride, hipMemcpyDeviceToHost));
   HIP_TRYR(hipMemcpy(result->inlier_mask, d_mask.p, (size_t)total, hipMemcpyDeviceToHost));
+  {   // the slots of a model row past the estimator's layout (theia_hip.h) are padding: handed back as zeros
+    const int used = model_doubles(est);
+    for (int p = 0; p < nprob; ++p)
+      for (int k = used; k < kStride; ++k) result->models[(size_t)p * kStride + k] = 0.0;
+  }
   for (int p = 0; p < nprob; ++p) {
     const ProblemState& s = S[p];
     int cnt = 0;

@@ -148,11 +148,14 @@ def _ransac_params(options, error_thresh, use_mle=None):
     return pc
 
 
-def EstimateTwoViewInfoBatch(options, priors1, priors2, correspondences_list):
+def EstimateTwoViewInfoBatch(options, priors1, priors2, correspondences_list, pair_seeds=None):
     """EstimateTwoViewInfo for a list of image pairs.  Returns a list of
-    (success, TwoViewInfo, inlier_indices).  Pair i of a group uses RandomNumberGenerator(seed + its
-    rank inside the group), groups = pairs with the same branch and error threshold."""
+    (success, TwoViewInfo, inlier_indices).  Every pair draws from its own RandomNumberGenerator(options.seed)
+    (or pair_seeds[i]): a pair's result does not depend on which other pairs share the batch, and
+    EstimateTwoViewInfo(pair) == EstimateTwoViewInfoBatch([.., pair, ..])[i]."""
     n = len(correspondences_list)
+    if pair_seeds is None:
+        pair_seeds = [options.seed] * n
     results = [None] * n
     groups = {}
     for i in range(n):
@@ -170,7 +173,8 @@ def EstimateTwoViewInfoBatch(options, priors1, priors2, correspondences_list):
         offsets[1:] = np.cumsum([d.shape[0] for d in data])
         est = _ransac.EST_RELATIVE_POSE if calibrated else _ransac.EST_UNCALIBRATED_RELATIVE_POSE
         eparams = None if calibrated else np.array([options.min_focal_length, options.max_focal_length])
-        res = _ransac.estimate_batch(est, np.concatenate(data, axis=0), offsets, _ransac_params(options, thresh, use_mle=options.use_mle if calibrated else False), eparams)
+        res = _ransac.estimate_batch(est, np.concatenate(data, axis=0), offsets, _ransac_params(options, thresh, use_mle=options.use_mle if calibrated else False), eparams,
+                                     seeds=[pair_seeds[i] for i in idx])
         for k, i in enumerate(idx):
             ok = bool(res["success"][k])
             info = TwoViewInfo()
@@ -313,7 +317,7 @@ def VerifyMatchesBatch(options, priors1, priors2, correspondences_list):
     hp.use_lo = 0                                   # a fresh RansacParameters: use_lo keeps its default
     offsets = np.zeros(len(live) + 1, dtype=np.int64)
     offsets[1:] = np.cumsum([len(corr[i]) for i in live])
-    hres = _ransac.estimate_batch(_ransac.EST_HOMOGRAPHY, np.concatenate([corr[i] for i in live]), offsets, hp)
+    hres = _ransac.estimate_batch(_ransac.EST_HOMOGRAPHY, np.concatenate([corr[i] for i in live]), offsets, hp, seeds=[eo.seed] * len(live))
     tv = EstimateTwoViewInfoBatch(eo, [priors1[i] for i in live], [priors2[i] for i in live], [corr[i] for i in live])
     for k, i in enumerate(live):
         ok, info, inliers = tv[k]

@@ -432,9 +432,12 @@ def test_estimate_two_view_info_both_branches():
         R = synth.angle_axis_to_matrix(info.rotation_2)
         ang = np.degrees(np.arccos(np.clip((np.trace(R @ truth["R"][i].T) - 1) / 2, -1, 1)))
         assert ang < 1.0 and abs(info.position_2 @ truth["position"][i]) > 0.99
-    # single-pair entry point = rank 0 of a batch of one
-    ok, info, inl = tv.EstimateTwoViewInfo(opts, pr, pr, corr[0])
-    assert ok and inl == out[0][2]
+    # a pair's result does not depend on the batch it travels in: single-pair entry point == its slot of any batch
+    for i in (0, 2):
+        ok, info, inl = tv.EstimateTwoViewInfo(opts, pr, pr, corr[i])
+        assert ok and inl == out[i][2] and np.array_equal(info.rotation_2, out[i][1].rotation_2)
+    rev = tv.EstimateTwoViewInfoBatch(opts, [pr] * 2, [pr] * 2, [corr[2], corr[0]])
+    assert rev[0][2] == out[2][2] and rev[1][2] == out[0][2]
     # the pipelines' setting (ransac_use_lo, reconstruction_estimator_options.h:133): LO through the two-view angular batch
     olo = tv.EstimateTwoViewInfoOptions(); olo.seed = 5; olo.max_sampson_error_pixels = 2.0; olo.use_lo = True; olo.lo_start_iterations = 5
     out_lo = tv.EstimateTwoViewInfoBatch(olo, [pr] * 3, [pr] * 3, corr)
@@ -468,7 +471,7 @@ def test_estimate_two_view_info_both_branches():
     thr = tv.ComputeResolutionScaledThreshold(opts.max_sampson_error_pixels, 1000, 800) ** 2
     ol.set_estimator_params([opts.min_focal_length, opts.max_focal_length])
     for i, (ok, info, inl) in enumerate(out):
-        pc = ol.default_ransac_params(thr, seed=opts.seed + i)
+        pc = ol.default_ransac_params(thr, seed=opts.seed)
         pc.failure_probability = 1.0 - opts.expected_ransac_confidence
         pc.min_iterations = opts.min_ransac_iterations; pc.max_iterations = opts.max_ransac_iterations
         pc.use_mle = 0
@@ -584,7 +587,7 @@ def test_two_view_match_geometric_verification():
     plain = tv.EstimateTwoViewInfoBatch(vo.estimate_twoview_info_options, [pr] * 3, [pr] * 3, corr[:3])
     for i in range(3):
         ok, info, idx = out[i]
-        assert ok and info.num_verified_matches == len(idx) > 150
+        assert ok and info.num_verified_matches == len(idx) > 120
         inl = truth["inlier"][i]
         assert inl[idx].mean() > 0.97                                  # almost no outlier survives both filters
         assert set(idx) <= set(plain[i][2])                            # BA only removes matches
@@ -592,7 +595,7 @@ def test_two_view_match_geometric_verification():
         ang = np.degrees(np.arccos(np.clip((np.trace(R @ truth["R"][i].T) - 1) / 2, -1, 1)))
         Rp = synth.angle_axis_to_matrix(plain[i][1].rotation_2)
         angp = np.degrees(np.arccos(np.clip((np.trace(Rp @ truth["R"][i].T) - 1) / 2, -1, 1)))
-        assert ang < 0.3 and ang <= angp + 0.05 and abs(np.linalg.norm(info.position_2) - 1) < 1e-12
+        assert ang < 0.3 and ang <= angp + 0.1 and abs(np.linalg.norm(info.position_2) - 1) < 1e-12
         assert info.position_2 @ truth["position"][i] / np.linalg.norm(truth["position"][i]) > 0.999
         assert info.focal_length_1 == 1000.0 and 0 <= info.num_homography_inliers < len(corr[i])
     # without the two-view BA the verified matches are the RANSAC inliers
@@ -600,6 +603,9 @@ def test_two_view_match_geometric_verification():
     out2 = tv.VerifyMatchesBatch(vo, [pr] * 3, [pr] * 3, corr[:3])
     for i in range(3):
         assert out2[i][0] and out2[i][2] == plain[i][2]
+    # VerifyMatches(pair) == its slot of the batch (pair seeds do not depend on the batch composition)
+    one = tv.VerifyMatches(vo, pr, pr, corr[1])
+    assert one[0] and one[2] == out2[1][2] and one[1].num_homography_inliers == out2[1][1].num_homography_inliers
     vo.guided_matching = True
     with pytest.raises(capi.TheiaHipError):
         tv.VerifyMatches(vo, pr, pr, corr[0])
@@ -750,4 +756,6 @@ def test_estimators_called_from_a_thread_pool_share_one_queue():
     for t in th: t.join()
     assert not errs, errs
     for k in range(len(jobs)):
-        assert same(ref[k], out[k]), k
+        bad = [f for f in ("success", "models", "num_inliers", "inlier_mask", "num_iterations", "num_lo_iterations")
+               if isinstance(ref[k], dict) and not np.array_equal(ref[k][f], out[k][f])]
+        assert same(ref[k], out[k]), (k, bad)
