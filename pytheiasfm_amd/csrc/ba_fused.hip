@@ -237,13 +237,9 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
 
   for (int sc = 0; sc < nsc; ++sc) {
     // ------------------------------------------------------------------ phase L: lane = observation
-#ifdef THIP_PHASE_L_CALL
+    // the problem is read through its LDS copy: with the kernel-argument struct (SGPR bases, global instead of flat loads)
+    // the timing is the same and 11 more VGPRs spill (WRITE_SIZE +50 MB per launch at 1000 views / 500k tracks)
     fused_phase_l<PD, TPS, MODELS>(&s_P, &s_run, pts, inv_radius, sc, Vinv, tile_part, s_rec, s_ghat, s_tslot, s_tmask);
-#else
-    // inlined: the problem's pointers stay kernel arguments (SGPR bases, global_load with a 32-bit lane offset instead of
-    // flat loads through 64-bit VGPR addresses read back from LDS)
-    fused_phase_l<PD, TPS, MODELS>(&P, &run, pts, inv_radius, sc, Vinv, tile_part, s_rec, s_ghat, s_tslot, s_tmask);
-#endif
     __syncthreads();
     // ------------------------------------------------------------------ phase S: lane = target block
     if (!(P.fused_dbg & 1)) {
