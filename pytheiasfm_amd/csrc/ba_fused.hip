@@ -75,7 +75,7 @@ THIP_DEV unsigned segment_or(const Segment& s, int lane, unsigned v) {
 #else
 #define THIP_PHASE_L_ATTR __forceinline__
 #endif
-template <int PD> constexpr int rec_doubles() { return PD == 3 ? 22 : 26; }
+template <int PD> constexpr int rec_doubles() { return PD == 3 ? 22 : 26; }   // 12 + 2 PD + 2 + 2 used
 
 // Phase L of one sub-chunk (lane = observation): linearise, reduce V_p / g_p over the track, invert, leave the record
 // {F | Ehat | r} and the track's slot-table row in LDS.  NOT inlined on purpose: the caller keeps 45 FP64 accumulators
@@ -85,7 +85,7 @@ template <int PD, int TPS, unsigned MODELS>
 __device__ THIP_PHASE_L_ATTR void fused_phase_l(const DevProblem* __restrict__ Pp, const FusedRun* __restrict__ runp,
                                                         const double* __restrict__ pts, double inv_radius, int sc,
                                                         double* __restrict__ Vinv, double* __restrict__ tile_part,
-                                                        double* __restrict__ s_rec, double* __restrict__ s_ghat,
+                                                        double* __restrict__ s_rec,
                                                         uint8_t* __restrict__ s_tslot, unsigned* __restrict__ s_tmask) {
   constexpr int NT = PD * (PD + 1) / 2;
   constexpr int RD = rec_doubles<PD>();
@@ -133,14 +133,15 @@ __device__ THIP_PHASE_L_ATTR void fused_phase_l(const DevProblem* __restrict__ P
           for (int b = 0; b < PD; ++b) Li[a][b] = 0.0;
       }
       double gmax = 0.0;
+      double gh[PD];   // ghat = Li g, in every lane of the track (the record carries r - Ehat ghat)
+#pragma unroll
+      for (int a = 0; a < PD; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q <= a; ++q) s += Li[a][q] * g[q];
+        gh[a] = s;
+      }
       if (active && sg.head) {
-#pragma unroll
-        for (int a = 0; a < PD; ++a) {   // ghat = Li g
-          double s = 0.0;
-#pragma unroll
-          for (int q = 0; q <= a; ++q) s += Li[a][q] * g[q];
-          s_ghat[tl * PD + a] = s;
-        }
         s_tmask[tl] = tmask;
         if (!L.pconst) {
 #pragma unroll
@@ -167,6 +168,15 @@ __device__ THIP_PHASE_L_ATTR void fused_phase_l(const DevProblem* __restrict__ P
 #pragma unroll
         for (int q = 0; q < PD; ++q) R[6 + q] = make_double2(eh[2 * q], eh[2 * q + 1]);
         R[6 + PD] = make_double2(L.r[0], L.r[1]);
+        double v1[2];   // r - Ehat ghat: the camera's rhs row is F^T (r - Ehat ghat)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          double sm = 0.0;
+#pragma unroll
+          for (int b = 0; b < PD; ++b) sm += eh[i * PD + b] * gh[b];
+          v1[i] = L.r[i] - sm;
+        }
+        R[6 + PD + 1] = make_double2(v1[0], v1[1]);
         s_tslot[tl * kRowBytes + lc] = (uint8_t)slot;
       }
       const double cost = wave_sum(L.cost);
@@ -193,7 +203,6 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
   constexpr int SUBT = TPS * kFusedTileTracks;        // tracks per sub-chunk
   constexpr int NWV = TPS;                            // waves of the workgroup
   __shared__ __attribute__((aligned(16))) double s_rec[SUB * RD];
-  __shared__ double s_ghat[SUBT * PD];
   __shared__ uint8_t s_tslot[SUBT * kRowBytes];   // (track, local camera) -> record slot, valid where the mask bit is set
   __shared__ unsigned s_tmask[SUBT];              // local cameras of a track
   static_assert(SUB * 18 <= SUB * RD, "slice-combination scratch does not fit the record buffer");
@@ -229,17 +238,20 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
   const int dP = (G == 1) ? PS : 1, dbase = (G == 1) ? wv * PS : wv / G;
   const unsigned tbits = has_tgt ? ((1u << la) | (1u << lb)) : 0xffffffffu;   // no target: never a subset (bit 31 unused)
   const unsigned dbit = has_d ? (1u << dlc) : 0x80000000u;
-  double acc[36], dacc[9];
+  // a DIAGONAL target (la == lb) accumulates  What What^T - F^T F  (its 2 x 2 core is  Ehat Ehat^T - I): the camera's
+  // F^T F rides the pair products, the per-observation lanes keep three sums (rhs, gradient, column norm) only
+  const double diag_core = (has_tgt && la == lb) ? 1.0 : 0.0;
+  double acc[36], dacc[3];
 #pragma unroll
   for (int k = 0; k < 36; ++k) acc[k] = 0.0;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) dacc[k] = 0.0;
+  for (int k = 0; k < 3; ++k) dacc[k] = 0.0;
 
   for (int sc = 0; sc < nsc; ++sc) {
     // ------------------------------------------------------------------ phase L: lane = observation
     // the problem is read through its LDS copy: with the kernel-argument struct (SGPR bases, global instead of flat loads)
     // the timing is the same and 11 more VGPRs spill (WRITE_SIZE +50 MB per launch at 1000 views / 500k tracks)
-    fused_phase_l<PD, TPS, MODELS>(&s_P, &s_run, pts, inv_radius, sc, Vinv, tile_part, s_rec, s_ghat, s_tslot, s_tmask);
+    fused_phase_l<PD, TPS, MODELS>(&s_P, &s_run, pts, inv_radius, sc, Vinv, tile_part, s_rec, s_tslot, s_tmask);
     __syncthreads();
     // ------------------------------------------------------------------ phase S: lane = target block
     if (!(P.fused_dbg & 1)) {
@@ -274,6 +286,7 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
                 for (int q = 0; q < PD; ++q) sm += Ea[i * PD + q] * Eb[j * PD + q];
                 M[i][j] = sm;
               }
+            M[0][0] -= diag_core; M[1][1] -= diag_core;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
               const double t0v = Fa[a] * M[0][0] + Fa[6 + a] * M[1][0];   // (F_a^T M)[a][0..1]
@@ -290,25 +303,13 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
           const unsigned mask = (t < ntr) ? s_tmask[t] : 0u;
           if (mask & dbit) {
             const unsigned sd = s_tslot[t * kRowBytes + dlc];
-            double F[12], E[2 * PD], r2[2];
             const double2* px = reinterpret_cast<const double2*>(s_rec + sd * RD);
-#pragma unroll
-            for (int q = 0; q < 6; ++q) { const double2 u = px[q]; F[2 * q] = u.x; F[2 * q + 1] = u.y; }
-#pragma unroll
-            for (int q = 0; q < PD; ++q) { const double2 u = px[6 + q]; E[2 * q] = u.x; E[2 * q + 1] = u.y; }
-            { const double2 u = px[6 + PD]; r2[0] = u.x; r2[1] = u.y; }
-            double fa0 = 0.0, fa1 = 0.0;   // F[da], F[6 + da] without dynamic register indexing
-#pragma unroll
-            for (int q = 0; q < 6; ++q) { if (q == da) { fa0 = F[q]; fa1 = F[6 + q]; } }
-#pragma unroll
-            for (int q = 0; q < 6; ++q) dacc[q] += fa0 * F[q] + fa1 * F[6 + q];
-            double eg0 = 0.0, eg1 = 0.0;   // What ghat = F^T (Ehat ghat)
-#pragma unroll
-            for (int q = 0; q < PD; ++q) { const double gq = s_ghat[t * PD + q]; eg0 += E[q] * gq; eg1 += E[PD + q] * gq; }
-            const double jr = fa0 * r2[0] + fa1 * r2[1];
-            dacc[6] += jr - (fa0 * eg0 + fa1 * eg1);
-            dacc[7] += jr;
-            dacc[8] += fa0 * fa0 + fa1 * fa1;
+            const double2 rr = px[6 + PD], rv = px[6 + PD + 1];   // r,  r - Ehat ghat
+            // column da of F: two LDS reads (no dynamic register indexing)
+            const double fa0 = s_rec[sd * RD + da], fa1 = s_rec[sd * RD + 6 + da];
+            dacc[0] += fa0 * rv.x + fa1 * rv.y;
+            dacc[1] += fa0 * rr.x + fa1 * rr.y;
+            dacc[2] += fa0 * fa0 + fa1 * fa1;
           }
         }
       }
@@ -341,22 +342,22 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 9; ++q) scratch[tid * 9 + q] = dacc[q];
+  for (int q = 0; q < 3; ++q) scratch[tid * 3 + q] = dacc[q];
   __syncthreads();
   if (has_d && tid == dix) {
     const int nrd = (G == 1) ? NWV : NWV / G;
-    double v[9];
+    double v[3];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) v[q] = scratch[tid * 9 + q];
+    for (int q = 0; q < 3; ++q) v[q] = scratch[tid * 3 + q];
 #pragma unroll 1
     for (int r = 1; r < nrd; ++r) {
       const int oth = (G == 1) ? (r * 64 + dix) : (dix + r * G * 64);
 #pragma unroll
-      for (int q = 0; q < 9; ++q) v[q] += scratch[oth * 9 + q];
+      for (int q = 0; q < 3; ++q) v[q] += scratch[oth * 3 + q];
     }
-    double* od = out + (size_t)run.ntgt * 36 + (size_t)dix * 9;
+    double* od = out + (size_t)run.ntgt * 36 + (size_t)dix * 3;   // [local camera][row][rhs, gradient, column norm]
 #pragma unroll
-    for (int q = 0; q < 9; ++q) od[q] = v[q];
+    for (int q = 0; q < 3; ++q) od[q] = v[q];
   }
   }   // runs of this workgroup
 }
@@ -398,11 +399,13 @@ __global__ __launch_bounds__(256) void k_schur_sum(int nitems, const int* __rest
   }
   if (lane >= 54) return;
   const int a = lane / 9, j = lane % 9;
-  const double v = (dend > dbeg) ? sum_sources(dbeg, dend, lane) : 0.0;
-  if (j < 6) {
+  if (j < 6) {   // the diagonal target's sum is  What What^T - F^T F
     const double w = (tend > tbeg) ? sum_sources(tbeg, tend, a * 6 + j) : 0.0;
-    if (j <= a) S[(size_t)(6 * ri + a) * n + 6 * ri + j] = v - w;
-  } else if (j == 6) {
+    if (j <= a) S[(size_t)(6 * ri + a) * n + 6 * ri + j] = -w;
+    return;
+  }
+  const double v = (dend > dbeg) ? sum_sources(dbeg, dend, a * 3 + (j - 6)) : 0.0;
+  if (j == 6) {
     rhs[6 * ri + a] = v;
   } else if (j == 7) {
     gc[6 * ri + a] = v;

@@ -1027,7 +1027,7 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
     const int G = need <= 64 ? 1 : (need <= 128 ? 2 : 4);
     r.gp = G | ((G == 1 ? std::max(1, packing((size_t)r.ntgt, (size_t)r.W)) : 1) << 8);
     r.part_off = (int)fp.part_doubles;
-    fp.part_doubles += (size_t)r.ntgt * 36 + (size_t)r.W * 54;
+    fp.part_doubles += (size_t)r.ntgt * 36 + (size_t)r.W * 18;
     for (int t = run_tile0; t < run_tile0 + run_ntiles; ++t)
       for (int s = tstart[t]; s < tstart[t] + tcount[t]; ++s)
         if (sred[s] >= 0) fp.obs_lc[s] = (uint8_t)(std::lower_bound(run_cams.begin(), run_cams.end(), sred[s]) - run_cams.begin());
@@ -1104,7 +1104,7 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
     }
     for (int lc = 0; lc < r.W; ++lc) {
       const int ri = fp.cams[r.cam_off + lc];
-      ents.push_back({((int64_t)ri << 32) | (uint32_t)ri, r.part_off + 36 * r.ntgt + 54 * lc, 1});
+      ents.push_back({((int64_t)ri << 32) | (uint32_t)ri, r.part_off + 36 * r.ntgt + 18 * lc, 1});
     }
   }
   std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key != b.key ? a.key < b.key : a.isd < b.isd; });
