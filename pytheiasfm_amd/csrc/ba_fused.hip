@@ -179,10 +179,10 @@ __device__ THIP_PHASE_L_ATTR void fused_phase_l(const DevProblem* __restrict__ P
         R[6 + PD + 1] = make_double2(v1[0], v1[1]);
         s_tslot[tl * kRowBytes + lc] = (uint8_t)slot;
       }
-      const double cost = wave_sum(L.cost);
-      gmax = wave_max(gmax);
-      const double inval = wave_sum((active && !L.valid) ? 1.0 : 0.0);
-      const double npd = wave_sum((active && !pd_ok && sg.head) ? 1.0 : 0.0);
+      const double cost = wave_sum_all(L.cost);
+      gmax = wave_max_all(gmax);
+      const double inval = wave_count(active && !L.valid);
+      const double npd = wave_count(active && !pd_ok && sg.head);
       if (lane == 0 && tile_ok) {
         tile_part[4 * (size_t)tile + 0] = cost;
         tile_part[4 * (size_t)tile + 1] = gmax;

@@ -1018,11 +1018,11 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
     double rho1;
     ccost = 0.5 * (P.loss_type == THEIA_LOSS_TRIVIAL ? s2 : loss_eval(P.loss_type, depth_row ? P.loss_width_depth : P.loss_width, s2, &rho1));
   }
-  ccost = wave_sum(ccost);
-  mcc = wave_sum(mcc);
-  stepsq = wave_sum(stepsq);
-  xnormsq = wave_sum(xnormsq);
-  const double inval = wave_sum(cvalid ? 0.0 : 1.0);
+  ccost = wave_sum_all(ccost);   // no lane has left the kernel: the DPP reductions apply
+  mcc = wave_sum_all(mcc);
+  stepsq = wave_sum_all(stepsq);
+  xnormsq = wave_sum_all(xnormsq);
+  const double inval = wave_count(!cvalid);
   if (lane == 0 && tile_ok) {
     double* tp = tile_part + 5 * (size_t)tile;
     tp[0] = ccost; tp[1] = mcc; tp[2] = stepsq; tp[3] = xnormsq; tp[4] = inval;

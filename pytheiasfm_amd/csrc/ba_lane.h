@@ -28,6 +28,35 @@ THIP_DEV double wave_max(double v) {
   return v;
 }
 
+// The same reductions without the LDS crossbar (ds_bpermute): DPP moves inside the rows of 16 lanes, then the four row
+// totals through v_readlane.  ALL 64 lanes must be active at the call (a disabled lane's row total would be stale);
+// every lane receives the same bits.  The summation tree differs from wave_sum's butterfly.
+template <int CTRL>
+THIP_DEV double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+THIP_DEV double readlane_d(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+THIP_DEV double wave_sum_all(double v) {
+  v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);   // row_half_mirror
+  v += dpp_move<0x140>(v);   // row_mirror
+  return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+THIP_DEV double wave_max_all(double v) {
+  v = fmax(v, dpp_move<0xB1>(v));
+  v = fmax(v, dpp_move<0x4E>(v));
+  v = fmax(v, dpp_move<0x141>(v));
+  v = fmax(v, dpp_move<0x140>(v));
+  return fmax(fmax(readlane_d(v, 0), readlane_d(v, 16)), fmax(readlane_d(v, 32), readlane_d(v, 48)));
+}
+THIP_DEV double wave_count(bool pred) { return (double)__popcll(__ballot(pred)); }
+
 THIP_DEV void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
 // item types / flags of the gather lists (see "gather-based Schur assembly with intrinsics")

@@ -991,7 +991,7 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
   fp.obs_lc.assign((size_t)std::max<int64_t>(1, nm), 0xff);
   fp.obs_tl.assign((size_t)std::max<int64_t>(1, nm), 0);
   const char* rm = getenv("THEIA_HIP_FUSED_RUN_OBS");
-  const int64_t run_max = rm ? std::max(64, atoi(rm)) : std::max<int64_t>(256, std::min<int64_t>(4096, nm / 768));
+  const int64_t run_max = rm ? std::max(64, atoi(rm)) : std::max<int64_t>(256, std::min<int64_t>(2304, nm / 768));   // 3.0 M observations: 1536..2816 0.54 ms, 3907 0.575, 6144 0.59, 1024 0.64
   // current tile / run
   int64_t t_start = 0, t_len = 0;
   int t_tracks = 0, sc_tracks = 0;
@@ -1207,9 +1207,10 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     std::vector<int> nvar(h->np, 0);
     for (int64_t i = 0; i < h->nobs; ++i) if (h->cam_red[p->obs_cam[i]] >= 0) nvar[p->obs_pt[i]]++;
     for (int q = 0; q < h->np; ++q) {
-      // measured at 1k views / 500k tracks: {<= 6 | >= 7} 0.70 ms, {<= 3 | 4..6 | >= 7} 0.76 ms, one class 0.75 ms
+      // measured at 1k views / 500k tracks (K1 + K2 launch group): {<= 7 | >= 8} 0.575 ms, {<= 6 | >= 7} 0.599, {<= 5 | >= 6} 0.670,
+      // {<= 8 | >= 9} 0.646, {<= 3 | 4..6 | >= 7} 0.636, one class 0.593
       static const int ncls = getenv("THEIA_HIP_FUSED_CLASSES") ? atoi(getenv("THEIA_HIP_FUSED_CLASSES")) : 2;
-      static const int cut0 = getenv("THEIA_HIP_FUSED_CUT0") ? atoi(getenv("THEIA_HIP_FUSED_CUT0")) : 6;
+      static const int cut0 = getenv("THEIA_HIP_FUSED_CUT0") ? atoi(getenv("THEIA_HIP_FUSED_CUT0")) : 7;
       const int cls = ncls == 2 ? (nvar[q] <= cut0 ? 0 : 2) : (nvar[q] <= 3 ? 0 : (nvar[q] <= 6 ? 1 : 2));
       static const bool noclass = getenv("THEIA_HIP_FUSED_NOCLASS") != nullptr;
       skey_pt[q] = pkey[q] == std::numeric_limits<int>::max() ? pkey[q] : ((h->ni == 0 && !noclass) ? pkey[q] * 4 + cls : pkey[q]);
