@@ -99,7 +99,7 @@ __device__ THIP_PHASE_L_ATTR void fused_phase_l(const DevProblem* __restrict__ P
       const bool active = lane < cnt && !(P.fused_dbg & 2);
       LaneLin<PD> L;
       lane_linearize<PD, true, false, true, MODELS>(P, P.camrot, pts, start + lane, active, lane, L);
-      const Segment sg = lane_segment(L.p, lane);
+      const Segment sg = lane_segment_all(L.p, lane);
       double tot[NT + PD];
 #pragma unroll
       for (int a = 0; a < PD; ++a) {

@@ -916,7 +916,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
   LaneLin<PD, INTR> L;
   if constexpr (ROT) lane_linearize<PD, true, INTR, true>(P, P.camrot, pts, start + lane, lane < cnt, lane, L);
   else lane_linearize<PD, true, INTR>(P, cam, pts, start + lane, lane < cnt, lane, L);
-  const Segment sg = lane_segment(L.p, lane);
+  const Segment sg = lane_segment_all(L.p, lane);
   // m_c = F y_c   (yc points at the camera part; the intrinsics part sits ni before it)
   double mc[2] = {0.0, 0.0};
   if (L.active && L.rc >= 0) {

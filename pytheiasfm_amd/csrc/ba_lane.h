@@ -219,6 +219,30 @@ THIP_DEV Segment lane_segment(int p, int lane) {
   return s;
 }
 
+// lane_segment for call sites where all 64 lanes are active: the neighbour through a DPP wave shift and the longest
+// segment through DPP maxima instead of seven ds_bpermute round trips.
+THIP_DEV Segment lane_segment_all(int p, int lane) {
+  const int prev = __builtin_amdgcn_update_dpp(p, p, 0x138, 0xf, 0xf, false);   // wave_shr:1 (lane 0 keeps its own value)
+  const bool head = (lane == 0) || (p != prev);
+  const unsigned long long H = __ballot(head);
+  const unsigned long long low = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+  Segment s;
+  s.head = head;
+  s.start = 63 - __clzll((long long)(H & low));
+  s.rank = __popcll(H & low) - 1;
+  const unsigned long long Hn = H & ~low;
+  const int end = Hn ? (__ffsll((long long)Hn) - 1) : 64;
+  s.len = end - s.start;
+  int m = s.len;
+  m = max(m, __builtin_amdgcn_update_dpp(0, m, 0xB1, 0xf, 0xf, false));
+  m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x4E, 0xf, 0xf, false));
+  m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x141, 0xf, 0xf, false));
+  m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x140, 0xf, 0xf, false));
+  s.maxlen = max(max(__builtin_amdgcn_readlane(m, 0), __builtin_amdgcn_readlane(m, 16)),
+                 max(__builtin_amdgcn_readlane(m, 32), __builtin_amdgcn_readlane(m, 48)));
+  return s;
+}
+
 // Sum `N` per-lane values over the lanes of the segment, in lane order; every
 // lane of the segment receives the (bitwise identical) total.
 template <int N>
