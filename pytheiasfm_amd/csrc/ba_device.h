@@ -16,6 +16,25 @@ namespace thip {
 
 #define THIP_DEV __device__ __forceinline__
 
+// sqrt of the BA kernels.  THIP_LEAN_SQRT (the large-solve kernels, ba_fused.hip / ba_kernels.hip): v_rsq_f64, one
+// Goldschmidt step and two residual corrections -- the compiler's own expansion without its range scaling (arguments
+// below 2^-767), its class selects (inf) and 12 of its 22 instructions; arguments here are sums of squares of scene
+// quantities.  0 -> 0, negative -> NaN as sqrt().  Elsewhere (micro-BA batches, RANSAC refinement): sqrt().
+#ifdef THIP_LEAN_SQRT
+__device__ __forceinline__ double fsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  return x == 0.0 ? 0.0 : g;
+}
+#else
+__device__ __forceinline__ double fsqrt(double x) { return sqrt(x); }
+#endif
+
 struct ObsLin {        // linearisation of one observation (unscaled, uncorrected)
   double r[2];         // residual
   double Jc[12];       // 2x6 wrt [position | angle-axis]
@@ -38,7 +57,7 @@ struct RotTerms {
 THIP_DEV void rotation_terms(const double w[3], RotTerms& t) {
   const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
   if (th2 > DBL_EPSILON) {
-    const double th = sqrt(th2);
+    const double th = fsqrt(th2);
     double s, c;
     sincos(th, &s, &c);
     const double A = s / th;
@@ -182,7 +201,7 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
         g = -8.0 * th * th * th / (3.0 * omega);
         gw = (-2.0 * dth * (4.0 * ru2 * th * th - 3.0) - 2.0 * th * (8.0 * ru2 * th * dth)) / (3.0 * omega) - rd / omega;
       } else {
-        const double ru = sqrt(ru2);
+        const double ru = fsqrt(ru2);
         const double th = tan(omega / 2.0);
         const double dth = 0.5 * (1.0 + th * th);
         const double at = atan(2.0 * ru * th);
@@ -216,7 +235,7 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
         dx = q[0]; dy = q[1];
         if (WANT_JAC) { ddx[0] = 1.0; ddy[1] = 1.0; }
       } else {
-        const double r = sqrt(r2);
+        const double r = fsqrt(r2);
         const double az = fabs(q[2]);
         const double th = atan2(r, az);
         const double t2 = th * th;
@@ -246,12 +265,12 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
       // double_sphere_camera_model.h:160-249
       const double alpha = k[6], xi = k[5];
       const double r2 = q[0] * q[0] + q[1] * q[1];
-      const double d1 = sqrt(r2 + q[2] * q[2]);
+      const double d1 = fsqrt(r2 + q[2] * q[2]);
       const double w1 = alpha > 0.5 ? (1.0 - alpha) / alpha : alpha / (1.0 - alpha);
-      const double w2 = (w1 + xi) / sqrt(2.0 * w1 * xi + xi * xi + 1.0);
+      const double w2 = (w1 + xi) / fsqrt(2.0 * w1 * xi + xi * xi + 1.0);
       if (q[2] <= -w2 * d1) ok = false;
       const double kk = xi * d1 + q[2];
-      const double d2 = sqrt(r2 + kk * kk);
+      const double d2 = fsqrt(r2 + kk * kk);
       const double n = alpha * d2 + (1.0 - alpha) * kk;
       dx = q[0] / n; dy = q[1] / n;
       if (WANT_JAC) {
@@ -277,7 +296,7 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
       // extended_unified_camera_model.h:161-249  [.., alpha, beta]
       const double alpha = k[5], beta = k[6];
       const double r2 = q[0] * q[0] + q[1] * q[1];
-      const double rho = sqrt(beta * r2 + q[2] * q[2]);
+      const double rho = fsqrt(beta * r2 + q[2] * q[2]);
       const double n = alpha * rho + (1.0 - alpha) * q[2];
       bool zero = n < 1e-3;
       if (!zero && alpha > 0.5) zero = (q[2] / n) < (alpha - 1.0) / (alpha + alpha - 1.0);
@@ -307,7 +326,7 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
       const double inner = 1.0 - 4.0 * k[4] * ru2;
       double scale = 1.0, g = 0.0;  // g = d scale / d(ru2)
       if (!(fabs(denom) < DBL_EPSILON || inner < 0.0)) {
-        const double sq = sqrt(inner);
+        const double sq = fsqrt(inner);
         scale = (1.0 - sq) / denom;
         g = ((2.0 * k[4] / sq) * denom - (1.0 - sq) * (2.0 * k[4])) / (denom * denom);
       }
@@ -329,7 +348,7 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
         Jk[2] = 1.0;                                                Jk[THEIA_MAX_INTRINSICS + 3] = 1.0;
         double gk = 0.0;  // d scale / d k  at fixed ru2
         if (!(fabs(denom) < DBL_EPSILON || inner < 0.0)) {
-          const double sq = sqrt(inner);
+          const double sq = fsqrt(inner);
           gk = ((2.0 * ru2 / sq) * denom - (1.0 - sq) * (2.0 * ru2)) / (denom * denom);
         }
         Jk[4] = ux * gk;                                            Jk[THEIA_MAX_INTRINSICS + 4] = uy * gk;
@@ -469,10 +488,10 @@ THIP_DEV double loss_eval(int type, double a, double s, double* rho1) {
   switch (type) {
     case THEIA_LOSS_HUBER: {
       const double b = a * a;
-      if (s > b) { const double r = sqrt(s); *rho1 = fmax(DBL_MIN, a / r); return 2.0 * a * r - b; }
+      if (s > b) { const double r = fsqrt(s); *rho1 = fmax(DBL_MIN, a / r); return 2.0 * a * r - b; }
       *rho1 = 1.0; return s; }
     case THEIA_LOSS_SOFTLONE: {
-      const double b = a * a; const double sum = 1.0 + s / b; const double tmp = sqrt(sum);
+      const double b = a * a; const double sum = 1.0 + s / b; const double tmp = fsqrt(sum);
       *rho1 = fmax(DBL_MIN, 1.0 / tmp); return 2.0 * b * (tmp - 1.0); }
     case THEIA_LOSS_CAUCHY: {
       const double b = a * a; const double sum = 1.0 + s / b;
@@ -497,7 +516,7 @@ THIP_DEV void householder4(const double x[4], double v[4], double& beta) {
   v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = 1.0;
   beta = 0.0;
   if (sigma <= DBL_EPSILON) { if (x[3] < 0.0) beta = 2.0; return; }
-  const double mu = sqrt(x[3] * x[3] + sigma);
+  const double mu = fsqrt(x[3] * x[3] + sigma);
   const double vp = (x[3] <= 0.0) ? x[3] - mu : -sigma / (x[3] + mu);
   beta = 2.0 * vp * vp / (sigma + vp * vp);
   v[0] /= vp; v[1] /= vp; v[2] /= vp;
@@ -507,7 +526,7 @@ THIP_DEV void householder4(const double x[4], double v[4], double& beta) {
 THIP_DEV void to_tangent(const double X[4], const double Jx[8], double Jt[6]) {
   double v[4], beta;
   householder4(X, v, beta);
-  const double nx = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2] + X[3] * X[3]);
+  const double nx = fsqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2] + X[3] * X[3]);
   for (int a = 0; a < 2; ++a) {
     const double* j = Jx + 4 * a;
     const double jv = j[0] * v[0] + j[1] * v[1] + j[2] * v[2] + j[3] * v[3];
@@ -516,11 +535,11 @@ THIP_DEV void to_tangent(const double X[4], const double Jx[8], double Jt[6]) {
 }
 
 THIP_DEV void sphere_plus(const double x[4], const double d[3], double out[4]) {
-  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const double nd = fsqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
   if (nd == 0.0) { out[0] = x[0]; out[1] = x[1]; out[2] = x[2]; out[3] = x[3]; return; }
   double v[4], beta;
   householder4(x, v, beta);
-  const double nx = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+  const double nx = fsqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
   double s, c;
   sincos(nd, &s, &c);
   const double sbd = s / nd;
@@ -533,16 +552,16 @@ THIP_DEV void sphere_plus(const double x[4], const double d[3], double out[4]) {
 // V = [v00 v10 v11 v20 v21 v22] lower; returns false if not positive definite.
 THIP_DEV bool invert_spd3(const double V[6], double Vi[6]) {
   if (!(V[0] > 0.0)) return false;
-  const double l00 = sqrt(V[0]);
+  const double l00 = fsqrt(V[0]);
   const double l10 = V[1] / l00;
   const double d11 = V[2] - l10 * l10;
   if (!(d11 > 0.0)) return false;
-  const double l11 = sqrt(d11);
+  const double l11 = fsqrt(d11);
   const double l20 = V[3] / l00;
   const double l21 = (V[4] - l20 * l10) / l11;
   const double d22 = V[5] - l20 * l20 - l21 * l21;
   if (!(d22 > 0.0)) return false;
-  const double l22 = sqrt(d22);
+  const double l22 = fsqrt(d22);
   // inverse of L (lower)
   const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
   const double i10 = -l10 * i00 * i11;

@@ -27,6 +27,7 @@
 //
 // HBM traffic per LM iteration: the 24 B / observation stream + one byte pair of plan indices, the parameters,
 // V^-1 out, and the partial blocks (ntgt * 288 B + W * 432 B per run, written and read once).
+#define THIP_LEAN_SQRT 1   // ba_device.h: fsqrt() without range scaling / class selects
 #include "ba_lane.h"
 
 #include <algorithm>

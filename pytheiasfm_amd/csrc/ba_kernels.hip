@@ -16,6 +16,7 @@
 // Reference arithmetic restated: src/theia/sfm/camera/reprojection_error.h:54-110
 // (+ camera models), Ceres SchurEliminator semantics for the 3-group ordering of
 // bundle_adjuster.cc:547-577, Ceres LM diagonal (levenberg_marquardt_strategy.cc).
+#define THIP_LEAN_SQRT 1   // ba_device.h: fsqrt() without range scaling / class selects
 #include "ba_kernels.h"
 #include "ba_priors.h"
 

@@ -144,7 +144,7 @@ THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam
   double rho1 = 1.0, rho = s, sr = 1.0;
   if (P.loss_type != THEIA_LOSS_TRIVIAL) {   // uniform branch: the trivial loss needs no corrector (and no sqrt)
     rho = loss_eval(P.loss_type, depth_row ? P.loss_width_depth : P.loss_width, s, &rho1);
-    sr = sqrt(rho1);
+    sr = fsqrt(rho1);
   }
   L.cost = 0.5 * rho;
   L.r[0] = sr * ol.r[0];
@@ -292,7 +292,7 @@ THIP_DEV bool invert_spd(const double (&V)[PD * (PD + 1) / 2], double (&Vi)[PD *
       double s = V[lidx(i, j)];
 #pragma unroll
       for (int k = 0; k < j; ++k) s -= Lm[i][k] * Lm[j][k];
-      if (i == j) { if (!(s > 0.0)) ok = false; Lm[i][i] = sqrt(s); }
+      if (i == j) { if (!(s > 0.0)) ok = false; Lm[i][i] = fsqrt(s); }
       else Lm[i][j] = s / Lm[j][j];
     }
   }
