@@ -42,6 +42,7 @@ static_assert(kFusedMaxCams <= kRowBytes, "slot-table row too short");
 __global__ __launch_bounds__(256) void k_cam_prep(DevProblem P, const double* __restrict__ cam, const double* __restrict__ intr,
                                                   double* __restrict__ camrot) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && P.frun_next) *P.frun_next = 0;   // head of k_lin_schur's run queue (the next kernel on the stream)
   if (c >= P.nc) return;
   double* o = camrot + (size_t)kCamRot * c;
   camrot_store(cam + 6 * (size_t)c, o);
@@ -214,11 +215,15 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
   if (tid == 0) s_P = P;
   const double radius = *radius_p;
   const double inv_radius = 1.0 / radius;
-  // persistent workgroups: a few hundred of them walk the runs round robin (per-workgroup set-up -- and what the
+  // persistent workgroups: a few hundred of them take runs from a queue (per-workgroup set-up -- and what the
   // register allocator parks in scratch at entry -- is paid once per workgroup, not once per run)
-  for (int run_idx = blockIdx.x; run_idx < P.n_fruns; run_idx += gridDim.x) {
-  const FusedRun run = P.fruns[run_idx];
-  __syncthreads();   // the previous run's slice combination is done with the LDS scratch (and s_run)
+  __shared__ int s_next;
+  for (;;) {
+  __syncthreads();   // the previous run's slice combination is done with the LDS scratch (and s_run, s_next)
+  if (tid == 0) s_next = atomicAdd(P.frun_next, 1);   // runs are taken from a queue, longest first (ba_solver.hip)
+  __syncthreads();
+  if (s_next >= P.n_fruns) break;
+  const FusedRun run = P.fruns[P.frun_order[s_next]];
   if (tid == 0) s_run = run;
   const int nsc = (run.ntiles + TPS - 1) / TPS;
   __syncthreads();

@@ -12,7 +12,7 @@ struct FusedRun {
   int tile0, ntiles;     // wave tiles of the run
   int cam_off, W;        // local camera table: frun_cams[cam_off + lc] = reduced camera index (ascending)
   int tgt_off, ntgt;     // target blocks: frun_tgt[tgt_off + k] = la | lb << 8 (lb <= la)
-  int part_off;          // doubles offset of the run's partial sums: [ntgt][36] then [W][6][9]
+  int part_off;          // doubles offset of the run's partial sums: [ntgt][36] then [W][6][3]
   int gp;                // G | PS << 8.  G = consumer waves per track slice: 1, 2 or 4 (64 G >= max(ntgt, 6 W));
                          // PS = track slices per consumer wave (only with G == 1): floor(64 / PS) >= ntgt, 6 W <= 64
 };
@@ -78,6 +78,8 @@ struct DevProblem {
   // fused linearise + Schur (ba_fused.hip), ni == 0: static plan built at create()
   int n_fruns;
   const FusedRun* fruns;
+  const int* frun_order;       // [n_fruns] run indices, most expensive first: the order in which workgroups take runs
+  int* frun_next;              // work-queue head of k_lin_schur (zeroed by k_cam_prep before every launch)
   const int* frun_cams;
   const unsigned short* frun_tgt;
   const uint8_t* obs_lc;       // [nobs_main] local camera index inside the run, 0xFF = constant camera

@@ -143,7 +143,7 @@ struct theia_ba_handle_s {
   bool use_fused = false;
   unsigned model_mask = 0xffu;          // camera models present in the problem
   DevBuf<FusedRun> fruns;
-  DevBuf<int> frun_cams, tile_trk_end, sum_items, sum_src;
+  DevBuf<int> frun_cams, tile_trk_end, sum_items, sum_src, frun_order, frun_next;
   DevBuf<unsigned short> frun_tgt;
   DevBuf<uint8_t> obs_lc, obs_tl;
   DevBuf<double> fpart, camrot, camrot_cand;
@@ -496,7 +496,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.n_priors = h->n_priors; P.prior_cam = h->prior_cam.p; P.prior_kind = h->prior_kind.p;
   P.prior_vec = h->prior_vec.p; P.prior_info = h->prior_info.p;
   P.rec = h->rec.p; P.n_diag_items = h->n_diag_items; P.n_blk_items = h->n_blk_items;
-  P.n_fruns = h->use_fused ? h->n_fruns : 0; P.fruns = h->fruns.p; P.frun_cams = h->frun_cams.p; P.frun_tgt = h->frun_tgt.p;
+  P.n_fruns = h->use_fused ? h->n_fruns : 0; P.fruns = h->fruns.p; P.frun_order = h->frun_order.p; P.frun_next = h->frun_next.p; P.frun_cams = h->frun_cams.p; P.frun_tgt = h->frun_tgt.p;
   P.obs_lc = h->obs_lc.p; P.obs_tl = h->obs_tl.p; P.tile_trk_end = h->tile_trk_end.p; P.fpart = h->fpart.p; P.camrot = h->camrot.p; P.camrot_cand = h->camrot_cand.p;
   { const char* dbg = getenv("THEIA_HIP_FUSED_DBG"); P.fused_dbg = dbg ? atoi(dbg) : 0; }
   P.model_mask = h->model_mask;
@@ -1459,6 +1459,16 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
       for (auto& kv : by) fprintf(stderr, "  G=%d slices/wave=%d: %d runs, %d sub-chunks\n", kv.first & 0xff, kv.first >> 8, kv.second.first, kv.second.second);
     }
     if (fplan.runs.empty()) fplan.runs.push_back(FusedRun{0, 0, 0, 0, 0, 0, 0, 1 | (1 << 8)});
+    {   // the workgroups of k_lin_schur take runs from a queue, the most expensive first (cost ~ wave tiles, weighted by the
+        // target blocks a wave step covers): the kernel ends when the last run does, and with ~4 runs per workgroup a
+        // static round robin left workgroups with one run more than others waiting for them
+      std::vector<int> order(fplan.runs.size());
+      for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+      auto cost = [&](int i) { const FusedRun& r = fplan.runs[i]; return (long long)r.ntiles * (64 + r.ntgt); };
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
+      UP(frun_order, order);
+      AL(frun_next, 1);
+    }
     UP(fruns, fplan.runs); UP(frun_cams, fplan.cams); UP(frun_tgt, fplan.tgts); UP(obs_lc, fplan.obs_lc); UP(obs_tl, fplan.obs_tl);
     UP(tile_trk_end, fplan.tile_trk_end); UP(sum_items, fplan.sum_items); UP(sum_src, fplan.sum_src);
     AL(fpart, std::max<size_t>(1, fplan.part_doubles));
