@@ -44,15 +44,7 @@ __global__ __launch_bounds__(256) void k_cam_prep(DevProblem P, const double* __
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && P.frun_next) *P.frun_next = 0;   // head of k_lin_schur's run queue (the next kernel on the stream)
   if (c >= P.nc) return;
-  double* o = camrot + (size_t)kCamRot * c;
-  camrot_store(cam + 6 * (size_t)c, o);
-  const unsigned mask = P.cam_mask[c];
-  for (int q = 0; q < 6; ++q) o[kCamRotScale + q] = ((mask >> q) & 1u) ? 0.0 : P.scale_c[6 * c + q];
-  const int g = P.cam_group[c];
-  for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) o[kCamRotIntr + q] = intr[(size_t)g * THEIA_MAX_INTRINSICS + q];
-  o[kCamRotModel] = (double)P.group_model[g];
-  o[kCamRotRed] = (double)P.cam_red[c];
-  o[38] = 0.0; o[39] = 0.0;
+  cam_prep_one(P, c, cam + 6 * (size_t)c, intr, camrot);
 }
 
 // Track-local OR of one int per lane (log-step, as segment_allsum_log); every lane of the track gets the result.

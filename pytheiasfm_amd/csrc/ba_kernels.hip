@@ -809,17 +809,32 @@ __global__ __launch_bounds__(1024) void k_finalize_rcs(DevProblem P, const doubl
   if (tile_part) reduce_tiles_body(ntiles, tile_part, 4, f2s, fmaxflag, scal, smr);
   const double radius = *radius_p;
   double gmax = 0.0;
-  for (int d = threadIdx.x; d < P.n; d += blockDim.x) {
-    S[(size_t)d * P.n + d] += fmin(fmax(colsq[d], 1e-6), 1e32) / radius;
-    gmax = fmax(gmax, fabs(gc[d] / P.scale_red[d]));
+  // eight diagonal entries per thread and pass, every load issued before the first store (a read-modify-write loop over
+  // S would take one memory round trip per entry: the compiler cannot move a load of S above the previous store to S)
+  for (int base = 0; base < P.n; base += 8 * 1024) {
+    double sv[8], cv[8], gv[8], sr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int d = min(base + k * 1024 + (int)threadIdx.x, P.n - 1);
+      sv[k] = S[(size_t)d * P.n + d]; cv[k] = colsq[d]; gv[k] = gc[d]; sr[k] = P.scale_red[d];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int d = base + k * 1024 + (int)threadIdx.x;
+      if (d < P.n) {
+        S[(size_t)d * P.n + d] = sv[k] + fmin(fmax(cv[k], 1e-6), 1e32) / radius;
+        gmax = fmax(gmax, fabs(gv[k] / sr[k]));
+      }
+    }
   }
-  sm[threadIdx.x] = gmax;
+  gmax = wave_max(gmax);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = gmax;
   __syncthreads();
-  for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    double v = sm[0];
+    for (int w = 1; w < 16; ++w) v = fmax(v, sm[w]);
+    scal[SC_GMAX] = fmax(scal[SC_GMAX], v);
   }
-  if (threadIdx.x == 0) scal[SC_GMAX] = fmax(scal[SC_GMAX], sm[0]);
 }
 
 // Jacobi scaling by reduced index (frozen columns: 1).  One workgroup.
@@ -845,7 +860,7 @@ __global__ void k_cam_update(DevProblem P, const double* __restrict__ cam, const
                              double* __restrict__ cand, double* __restrict__ cand_intr,
                              double* __restrict__ out_stepsq, double* __restrict__ out_xnormsq,
                              double* __restrict__ zero16) {
-  __shared__ double s1[256], s2[256];
+  __shared__ double s1[1024], s2[1024];
   double st = 0.0, xn = 0.0;
   const double* yc = y + P.ni;
   for (int c = threadIdx.x; c < P.nc; c += blockDim.x) {
@@ -1478,7 +1493,7 @@ void launch_finalize_rcs(const DevProblem& P, const double* radius, const Reduce
 
 void launch_cam_update(const DevProblem& P, const double* cam, const double* y, double* cand_cam,
                        double* cand_intr, double* out_stepsq, double* out_xnormsq, hipStream_t st, double* zero16) {
-  k_cam_update<<<1, 256, 0, st>>>(P, cam, y, cand_cam, cand_intr, out_stepsq, out_xnormsq, zero16);
+  k_cam_update<<<1, 1024, 0, st>>>(P, cam, y, cand_cam, cand_intr, out_stepsq, out_xnormsq, zero16);
 }
 
 void launch_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,
@@ -1488,6 +1503,7 @@ void launch_backsub(const DevProblem& P, const double* cam, const double* pts, c
   if (P.ntiles == 0) return;
   const double* ycc = yc + P.ni;  // camera part of the solution
   if (!P.ni && P.n_fruns > 0 && P.camrot && P.camrot_cand) {   // fused path: the state's blocks are in P.camrot already
+    // (folding this into k_cam_update's single workgroup was slower: 26 us against 13 + 7)
     launch_cam_prep(P, cand_cam, P.intr, P.camrot_cand, st);
     if (P.pd == 3) k_backsub<3, false, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
     else k_backsub<4, false, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);

@@ -194,6 +194,20 @@ THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam
   }
 }
 
+// The 40-double block of one camera (layout: ba_device.h, kCamRot): extrinsics + rotation terms, masked Jacobi scale,
+// the intrinsics of its group, model id, reduced index.  k_cam_prep (state) and k_cam_update (candidate) write them.
+THIP_DEV void cam_prep_one(const DevProblem& P, int c, const double* ext, const double* __restrict__ intr, double* __restrict__ camrot) {
+  double* o = camrot + (size_t)kCamRot * c;
+  camrot_store(ext, o);
+  const unsigned mask = P.cam_mask[c];
+  for (int q = 0; q < 6; ++q) o[kCamRotScale + q] = ((mask >> q) & 1u) ? 0.0 : P.scale_c[6 * c + q];
+  const int g = P.cam_group[c];
+  for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) o[kCamRotIntr + q] = intr[(size_t)g * THEIA_MAX_INTRINSICS + q];
+  o[kCamRotModel] = (double)P.group_model[g];
+  o[kCamRotRed] = (double)P.cam_red[c];
+  o[38] = 0.0; o[39] = 0.0;
+}
+
 struct Segment {
   int start, len, maxlen, rank;  // rank = index of the track inside its tile
   bool head;
