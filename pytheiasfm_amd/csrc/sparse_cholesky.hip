@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
 #include <map>
 #include <vector>
 
@@ -395,6 +396,11 @@ CholPlan* chol_plan_create(int n, const uint8_t* adj) {
       pl->nclear++;
     };
     for (int K = 0; K < nt; ++K) { add(K, K); for (int I : best.below[K]) add(I, K); }
+  }
+  if (getenv("THEIA_HIP_CREATE_TIMING")) {   // shape of the schedule
+    fprintf(stderr, "theia_hip K3 plan: n = %d, %d tiles, %d levels, %lld factor tiles, %.1f MFLOP\n", n, nt, pl->nlev, best.ntiles, pl->flops * 1e-6);
+    for (int l = 0; l < pl->nlev; ++l)
+      fprintf(stderr, "  level %d: potrf %d, trsm %d, update targets %d\n", l, pl->lev[l].npotrf, pl->lev[l].ntrsm, pl->lev[l].nupd);
   }
   if (prog.empty()) prog.push_back(0);
   if (hipMalloc((void**)&pl->prog, sizeof(int) * prog.size()) != hipSuccess ||
