@@ -134,7 +134,8 @@ struct InnerArgs {
 };
 void launch_inner_sweep(const InnerArgs& A, hipStream_t st);
 // out[0] = |x0 - x|^2, out[1] = |x|^2 over the variable blocks
-void launch_inner_norms(const InnerArgs& A, const double* cam0, const double* pts0, const double* intr0, double* out2, hipStream_t st);
+void launch_inner_norms(const InnerArgs& A, const double* cam0, const double* pts0, const double* intr0, double* out2, double* part,
+                        hipStream_t st);   // part: scratch of 2 * kInnerCostBlocks doubles
 // cost of every residual block at (cam, pts, intr): out[0] = sum rho / 2 (+ camera priors), out[1] > 0 if a functor failed;
 // part: scratch of 2 * kInnerCostBlocks doubles
 constexpr int kInnerCostBlocks = 512;

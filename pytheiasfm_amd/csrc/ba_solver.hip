@@ -1666,7 +1666,7 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
       IA.trk_off = h->in_trk_off.p; IA.ntracks = h->in_ntracks; IA.nobs = h->nobs_main;
       IA.cam = h->in_cam.p; IA.pts = h->in_pts.p; IA.intr = h->in_intr.p; IA.gate = h->in_gate.p;
       launch_inner_sweep(IA, h->stream);
-      launch_inner_norms(IA, h->cam[0].p, h->pts[0].p, h->intr[0].p, h->in_scal.p, h->stream);
+      launch_inner_norms(IA, h->cam[0].p, h->pts[0].p, h->intr[0].p, h->in_scal.p, h->in_part.p, h->stream);   // in_part: free until launch_inner_cost
       launch_inner_cost(IA, h->in_part.p, h->in_scal.p + 2, h->stream);
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][3], h->stream));
