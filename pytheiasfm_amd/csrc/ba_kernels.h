@@ -154,7 +154,7 @@ void launch_linearize_fused(const DevProblem& P, const double* cam, const double
 // per-camera blocks (rotation terms, masked scaling, intrinsics) of `cam` -> camrot (ba_fused.hip)
 void launch_cam_prep(const DevProblem& P, const double* cam, const double* intr, double* camrot, hipStream_t st);
 void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,
-                         const int* field_is_max, double* scal, hipStream_t st);
+                         const int* field_is_max, double* scal, hipStream_t st, double* red_part = nullptr);
 // first stage of a two-stage reduction: kReduceBlocks workgroups fold contiguous slices of the per-tile partials into
 // out[kReduceBlocks][nfields] (fixed order); the one-workgroup consumers then reduce kReduceBlocks rows instead of ntiles
 constexpr int kReduceBlocks = 128;

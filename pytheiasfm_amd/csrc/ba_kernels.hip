@@ -1477,7 +1477,12 @@ void launch_cam_priors(const DevProblem& P, int mode, const double* cam, const d
 }
 
 void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,
-                         const int* field_is_max, double* scal, hipStream_t st) {
+                         const int* field_is_max, double* scal, hipStream_t st, double* red_part) {
+  if (red_part && ntiles > 4 * kReduceBlocks) {   // two fixed-order stages: one workgroup over 50k tile rows costs 50 us
+    k_reduce_tiles_stage1<<<kReduceBlocks, 256, 0, st>>>(ntiles, tile_part, nfields, field_is_max, red_part);
+    k_reduce_tiles<<<1, 1024, 0, st>>>(kReduceBlocks, red_part, nfields, field_to_scal, field_is_max, scal);
+    return;
+  }
   k_reduce_tiles<<<1, 1024, 0, st>>>(ntiles, tile_part, nfields, field_to_scal, field_is_max, scal);
 }
 

@@ -596,7 +596,7 @@ int enqueue_linearize(theia_ba_handle_s* h, int slot = 0) {
   if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][5], h->stream));
   // without an all-reduce (and without phase timing) the tile reduction rides in k_finalize_rcs: one launch less
   const bool fuse_reduce = !h->allreduce && slot < 0 && h->ntiles_main > 0;
-  if (h->ntiles_main && !fuse_reduce) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 4, h->f2s.p, h->fmaxflag.p, h->rb.scal, h->stream);
+  if (h->ntiles_main && !fuse_reduce) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 4, h->f2s.p, h->fmaxflag.p, h->rb.scal, h->stream, h->red_part.p);
   launch_long_linearize(h->P, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->long_scratch.p, h->stream);
   launch_cam_priors(h->P, PRIOR_LINEARIZE, h->cam[h->cur].p, nullptr, nullptr, &h->rb, nullptr, h->rb.scal + SC_COST, nullptr, h->stream);
   // one SUM all-reduce of [S | rhs | colsq | gc | scal[0,8)], one MAX of scal[8,16) (folded into the SUM as
@@ -635,7 +635,7 @@ int enqueue_solve_and_backsub(theia_ba_handle_s* h, int slot = 0, bool defer_red
   launch_cam_update(h->P, h->cam[h->cur].p, yc, h->cam[nxt].p, h->ni ? h->intr[nxt].p : nullptr,
                     h->scalB.p + SB_STEPSQ_CAM, h->scalB.p + SB_XNORMSQ_CAM, h->stream, h->scalB.p);
   launch_backsub(h->P, h->cam[h->cur].p, h->pts[h->cur].p, h->cam[nxt].p, h->pts[nxt].p, yc, h->Vinv.p, h->tile_part.p, h->scalB.p, h->stream);
-  if (h->ntiles_main && !defer_reduce) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 5, h->f2s.p + 8, h->fmaxflag.p + 8, h->scalB.p, h->stream);
+  if (h->ntiles_main && !defer_reduce) launch_reduce_tiles(h->ntiles_main, h->tile_part.p, 5, h->f2s.p + 8, h->fmaxflag.p + 8, h->scalB.p, h->stream, h->red_part.p);
   launch_long_backsub(h->P, h->cam[h->cur].p, h->pts[h->cur].p, h->cam[nxt].p, h->pts[nxt].p, yc, h->Vinv.p, h->long_scratch.p, h->scalB.p, h->stream);
   launch_cam_priors(h->P, PRIOR_TRIAL, h->cam[h->cur].p, h->cam[nxt].p, yc, nullptr, nullptr, h->scalB.p + SB_COST, h->scalB.p + SB_MCC, h->stream);
   return do_allreduce(h, h->scalB.p, 8, THEIA_REDUCE_SUM);
