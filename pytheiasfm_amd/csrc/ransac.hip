@@ -28,6 +28,7 @@
 #include "ransac_device.h"
 #include "dls_device.h"
 #include "eig_team.h"
+#include "svd_team.h"
 #include "theia_hip.h"
 #include <atomic>
 #include <mutex>
@@ -629,6 +630,84 @@ __global__ __launch_bounds__(64) void k_fit5_b(size_t nhyp, const int* __restric
   }
   for (int o = kFpTeam / 2; o >= 1; o >>= 1) bit |= __shfl_xor(bit, o, kFpTeam);
   if (tl == 0) solmask[hyp] = bit;
+}
+
+// ---- SQPnP fit in three stages (sqpnp_pre -> 9 x 9 SVD by teams of nine lanes in LDS -> sqpnp_post): the SVD was 77 % of
+// the one-thread-per-hypothesis kernel, whose 12.6 KB of arrays per lane lived in scratch.
+// ws per hypothesis: [Omega 81 | P 27 | centroid 3 | U 81 | S 9]
+constexpr int kSqWs = 201, kSqTeam = 9, kSqTeamsPerWave = 7;
+__global__ __launch_bounds__(64) void k_sqp_a(int nprob, int B, const int64_t* __restrict__ offsets, const double* __restrict__ data,
+                                              const int* __restrict__ samples, const int* __restrict__ active_iters,
+                                              double* __restrict__ ws, int* __restrict__ ok) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.y;
+  if (b >= B || p >= nprob) return;
+  const size_t hyp = (size_t)p * B + b;
+  if (b >= active_iters[p]) { ok[hyp] = 0; return; }
+  const double* pd = data + (size_t)offsets[p] * 5;
+  double feat[6], world[9];
+  for (int i = 0; i < 3; ++i) {
+    const int idx = samples[hyp * 3 + i];
+    feat[2 * i] = pd[(size_t)idx * 5]; feat[2 * i + 1] = pd[(size_t)idx * 5 + 1];
+    for (int k = 0; k < 3; ++k) world[3 * i + k] = pd[(size_t)idx * 5 + 2 + k];
+  }
+  double Om[81], P[27], mean[3];
+  const bool good = rsc::sqpnp_pre(3, feat, world, Om, P, mean);
+  ok[hyp] = good ? 1 : 0;
+  if (!good) return;
+  double* w = ws + hyp * kSqWs;
+  for (int k = 0; k < 81; ++k) w[k] = Om[k];
+  for (int k = 0; k < 27; ++k) w[81 + k] = P[k];
+  for (int k = 0; k < 3; ++k) w[108 + k] = mean[k];
+}
+
+__global__ __launch_bounds__(64) void k_sqp_b(size_t nhyp, const int* __restrict__ ok, double* __restrict__ ws) {
+  __shared__ double lds[kSqTeamsPerWave][81 + 81 + 9];   // W | U | S
+  const int team = threadIdx.x / kSqTeam, tl = threadIdx.x % kSqTeam;
+  if (team >= kSqTeamsPerWave) return;
+  const size_t hyp = (size_t)blockIdx.x * kSqTeamsPerWave + team;
+  if (hyp >= nhyp || !ok[hyp]) return;
+  double* W = lds[team]; double* U = W + 81; double* S = U + 81;
+  double* w = ws + hyp * kSqWs;
+  rsc::svd9_team(w, W, U, S, tl);
+  for (int i = 0; i < 9; ++i) w[111 + i * 9 + tl] = U[i * 9 + tl];
+  w[192 + tl] = S[tl];
+}
+
+__global__ __launch_bounds__(64) void k_sqp_c(int nprob, int B, const int* __restrict__ active_iters, const int* __restrict__ ok,
+                                              const double* __restrict__ ws, double* __restrict__ models, int* __restrict__ counts,
+                                              int* __restrict__ dense_count, int* __restrict__ tags, int* __restrict__ hyp_base) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.y;
+  if (b >= B || p >= nprob) return;
+  const size_t hyp = (size_t)p * B + b;
+  if (b >= active_iters[p] || !ok[hyp]) { counts[hyp] = 0; return; }
+  const double* w = ws + hyp * kSqWs;
+  double Om[81], P[27], mean[3], U[81], S[9];
+  for (int k = 0; k < 81; ++k) Om[k] = w[k];
+  for (int k = 0; k < 27; ++k) P[k] = w[81 + k];
+  for (int k = 0; k < 3; ++k) mean[k] = w[108 + k];
+  for (int k = 0; k < 81; ++k) U[k] = w[111 + k];
+  for (int k = 0; k < 9; ++k) S[k] = w[192 + k];
+  double quats[72], ts[54];
+  const int nm = rsc::sqpnp_post(Om, P, mean, U, S, quats, ts);
+  counts[hyp] = nm;
+  if (nm == 0) return;
+  constexpr int mm = 18;   // max_models(THEIA_EST_ABSOLUTE_POSE_SQPNP)
+  const int base = atomicAdd(&dense_count[p], nm);
+  hyp_base[hyp] = base;
+  double* mo = models + ((size_t)p * B * mm + base) * (size_t)kStride;
+  int* tg = tags + (size_t)p * B * mm + base;
+  for (int j = 0; j < nm; ++j) {   // quaternion -> matrix as the estimator does (estimate_calibrated_absolute_pose.cc:99-106)
+    double R[9];
+    rsc::quat_to_rot(quats + 4 * j, R);
+    const double* t = ts + 3 * j;
+    double* m = mo + (size_t)j * kStride;
+    for (int k = 0; k < 9; ++k) m[k] = R[k];
+    for (int c = 0; c < 3; ++c) m[9 + c] = -((R[c] * t[0] + R[3 + c] * t[1]) + R[6 + c] * t[2]);
+    for (int k = 12; k < kStride; ++k) m[k] = 0.0;
+    tg[j] = b * mm + j;
+  }
 }
 
 template <int EST>
@@ -1361,6 +1440,12 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         else
           k_fit5_c<THEIA_EST_ESSENTIAL_MATRIX><<<grid, 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_sol.p,
                                                                    d_fp_mask.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
+      } else if (est == THEIA_EST_ABSOLUTE_POSE_SQPNP && !getenv("THEIA_HIP_FIT_ONE_KERNEL")) {
+        if ((rc = d_fp_ws.ensure(nh * kSqWs)) || (rc = d_fp_ok.ensure(nh))) return rc;
+        dim3 grid((B + 63) / 64, cn);
+        k_sqp_a<<<grid, 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_ok.p);
+        k_sqp_b<<<(unsigned)((nh + kSqTeamsPerWave - 1) / kSqTeamsPerWave), 64, 0, st>>>(nh, d_fp_ok.p, d_fp_ws.p);
+        k_sqp_c<<<grid, 64, 0, st>>>(cn, B, d_active.p, d_fp_ok.p, d_fp_ws.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
       } else {
         dim3 grid((B + 63) / 64, cn);
 #define THIP_FIT(E) k_fit<E><<<grid, 64, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p, ep)

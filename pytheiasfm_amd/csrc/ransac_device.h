@@ -832,12 +832,13 @@ RDEV void apply_P(const double* P, const double* rh, double* t) {
 }
 }  // namespace sqp
 
-// SQPnP (sqpnp.cc:58-353).  feat: n x [x y], world: n x [X Y Z].  Writes up to 18
-// solutions: quaternions [w x y z] (of the row-major rotation r_hat) and translations.
-RDEV int sqpnp(int n, const double* feat, const double* world, double* quats, double* ts) {
+// SQPnP (sqpnp.cc:58-353) in three pieces, so that the RANSAC fit can run the 9 x 9 SVD between them as a team of lanes
+// (svd_team.h): sqpnp_pre = Omega, P and the centroid (sqpnp.cc:100-231), sqpnp_post = everything after the SVD
+// (:236-353); sqpnp() = pre, svd_sq<9>, post in one thread (single-problem entry point, any number of points).
+__device__ __attribute__((noinline)) bool sqpnp_pre(int n, const double* feat, const double* world, double* Om, double* P, double* mean) {
   using namespace sqp;
-  if (n < 3) return 0;
-  double Om[81], QA[27];
+  if (n < 3) return false;
+  double QA[27];
   for (int i = 0; i < 81; ++i) Om[i] = 0.0;
   for (int i = 0; i < 27; ++i) QA[i] = 0.0;
 #define OM(i, j) Om[(i) * 9 + (j)]
@@ -869,7 +870,6 @@ RDEV int sqpnp(int n, const double* feat, const double* world, double* quats, do
   const double Q[9] = {sum_w, 0, -sum_wx, 0, sum_w, -sum_wy, -sum_wx, -sum_wy, sum_wx2y2};
   double Qinv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   invert_symmetric3(Q, Qinv);
-  double P[27];
   for (int a = 0; a < 3; ++a)
     for (int j = 0; j < 9; ++j) {
       double acc = 0.0;
@@ -884,13 +884,18 @@ RDEV int sqpnp(int n, const double* feat, const double* world, double* quats, do
     }
 #undef OM
 #undef QAA
-  double U[81], S[9], V[81];
-  svd_sq<9>(Om, U, S, V);
+  const double inv_n = 1.0 / n;
+  mean[0] = sum_X * inv_n; mean[1] = sum_Y * inv_n; mean[2] = sum_Z * inv_n;
+  return true;
+}
+
+// Writes up to 18 solutions: quaternions [w x y z] (of the row-major rotation r_hat) and translations.
+__device__ __attribute__((noinline)) int sqpnp_post(const double* Om, const double* P, const double* mean, const double* U, const double* S,
+                                                   double* quats, double* ts) {
+  using namespace sqp;
   int num_null = 0;
   while (num_null <= 7 && S[7 - num_null] < SQP_RANK_TOL) num_null++;
   if (++num_null > 6) return 0;
-  const double inv_n = 1.0 / n;
-  const double mean[3] = {sum_X * inv_n, sum_Y * inv_n, sum_Z * inv_n};
   double min_sq_error = DBL_MAX;
   const int nep = num_null > 0 ? num_null : 1;
   Sol sols[18];
@@ -938,6 +943,20 @@ RDEV int sqpnp(int n, const double* feat, const double* world, double* quats, do
     for (int k = 0; k < 3; ++k) ts[3 * i + k] = sols[i].t[k];
   }
   return nsol;
+}
+
+// feat: n x [x y], world: n x [X Y Z].
+RDEV int sqpnp(int n, const double* feat, const double* world, double* quats, double* ts) {
+  double Om[81], P[27], mean[3];
+  if (!sqpnp_pre(n, feat, world, Om, P, mean)) return 0;
+  double U[81], S[9], V[81];
+#ifdef THIP_SQPNP_SKIP_SVD   // development (timing only, wrong results): how much of the solver is the 9 x 9 SVD
+  for (int i = 0; i < 81; ++i) { U[i] = (i % 10 == 0) ? 1.0 : 0.0; V[i] = U[i]; }
+  for (int i = 0; i < 9; ++i) S[i] = fabs(Om[i * 10]) * (i < 6 ? 1.0 : 1e-12);
+#else
+  svd_sq<9>(Om, U, S, V);
+#endif
+  return sqpnp_post(Om, P, mean, U, S, quats, ts);
 }
 
 // ceres/rotation.h RotationMatrixToAngleAxis (via quaternion) and AngleAxisToRotationMatrix, as
