@@ -991,7 +991,7 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
   fp.obs_lc.assign((size_t)std::max<int64_t>(1, nm), 0xff);
   fp.obs_tl.assign((size_t)std::max<int64_t>(1, nm), 0);
   const char* rm = getenv("THEIA_HIP_FUSED_RUN_OBS");
-  const int64_t run_max = rm ? std::max(64, atoi(rm)) : std::max<int64_t>(256, std::min<int64_t>(1344, nm / 768));   // 3.0 M observations, runs taken from the queue: 1280..1408 0.46 ms, 1024 0.47, 2304 0.48, 512 0.49
+  const int64_t run_max = rm ? std::max(64, atoi(rm)) : std::max<int64_t>(256, std::min<int64_t>(1344, nm / 600));   // 3.0 M observations, runs taken from the queue: 1280..1408 0.46 ms, 1024 0.47, 2304 0.48, 512 0.49
   // current tile / run
   int64_t t_start = 0, t_len = 0;
   int t_tracks = 0, sc_tracks = 0;
