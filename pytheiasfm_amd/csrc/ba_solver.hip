@@ -21,6 +21,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ba_kernels.h"
@@ -179,6 +180,26 @@ struct theia_ba_handle_s {
 };
 
 namespace {
+// Host-side loops over independent index ranges on a few threads (handle creation at millions of observations).
+// THEIA_HIP_HOST_THREADS caps the count (default min(hardware threads, 8); 1 = serial).
+template <class F>
+void host_chunks(int64_t n, F&& fn) {
+  static const unsigned cap = [] {
+    const char* e = getenv("THEIA_HIP_HOST_THREADS");
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return e ? (unsigned)std::max(1, atoi(e)) : std::min(hw, 8u);
+  }();
+  if (n < 262144 || cap <= 1) { fn((int64_t)0, n); return; }
+  const int64_t per = (n + cap - 1) / cap;
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < cap; ++t) {
+    const int64_t a = std::min<int64_t>(n, t * per), b = std::min<int64_t>(n, a + per);
+    if (a < b) th.emplace_back([&fn, a, b] { fn(a, b); });
+  }
+  fn((int64_t)0, std::min<int64_t>(n, per));
+  for (auto& x : th) x.join();
+}
+
 
 // Free intrinsics of a model under an OptimizeIntrinsicsType mask
 // (GetSubsetFromOptimizeIntrinsicsType of every *_camera_model.cc, e.g.
@@ -1216,7 +1237,22 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
       skey_pt[q] = pkey[q] == std::numeric_limits<int>::max() ? pkey[q] : ((h->ni == 0 && !noclass) ? pkey[q] * 4 + cls : pkey[q]);
     }
   }
-  std::stable_sort(porder.begin(), porder.end(), [&](int x, int y) { return skey_pt[x] < skey_pt[y]; });
+  tick("  structure: masks, keys");
+  {   // stable counting sort by key (keys are < 4 * (#variable cameras) + 4, or INT_MAX = no variable camera: last bucket)
+    int maxkey = -1;
+    for (int q = 0; q < h->np; ++q) if (skey_pt[q] != std::numeric_limits<int>::max()) maxkey = std::max(maxkey, skey_pt[q]);
+    if (maxkey >= 0 && (int64_t)maxkey < 8 * (int64_t)h->np + 1024) {
+      const int nb = maxkey + 2;
+      std::vector<int> head(nb + 1, 0);
+      auto bucket = [&](int q) { return skey_pt[q] == std::numeric_limits<int>::max() ? nb - 1 : skey_pt[q]; };
+      for (int q = 0; q < h->np; ++q) head[bucket(q) + 1]++;
+      for (int b = 0; b < nb; ++b) head[b + 1] += head[b];
+      for (int q = 0; q < h->np; ++q) porder[head[bucket(q)]++] = q;
+    } else {
+      std::stable_sort(porder.begin(), porder.end(), [&](int x, int y) { return skey_pt[x] < skey_pt[y]; });
+    }
+  }
+  tick("  structure: sort tracks");
   for (int r = 0; r < h->np; ++r) prank[porder[r]] = r;
   // offsets indexed by track RANK
   std::vector<int64_t> cnt_main(h->np + 1, 0), cnt_fix(h->np + 1, 0);
@@ -1265,6 +1301,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   // (tracks that see a camera twice -- e.g. depth-prior rows -- or more than kFusedMaxCams cameras take the
   // per-observation slow path there); THEIA_HIP_SCHUR_GATHER=1 selects the first-generation gather kernels.
   FusedHost fplan;
+  tick("  structure: permutation");
   h->use_fused = h->ni == 0 && h->nobs_main > 0 && !getenv("THEIA_HIP_SCHUR_GATHER");
   std::vector<int> sred;
   if (h->use_fused) {
@@ -1282,6 +1319,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     }
     if (misfit * 20 > h->nobs_main) h->use_fused = false;
   }
+  tick("  structure: fit check");
   if (h->use_fused) {
     std::vector<int> skey(h->np);
     for (int q = 0; q < h->np; ++q) skey[q] = pkey[porder[q]];   // run boundaries follow the first-camera key
@@ -1291,6 +1329,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   } else {
     build_tiles(cnt_main, 0, true);
   }
+  tick("  structure: fused plan / tiles");
   h->ntiles_main = (int)tstart.size();
   // evaluation-only tiles over the long tracks' observations (no per-track sums there)
   h->long_nobs = (int)l_obs.size(); h->long_ntracks = (int)l_pt.size();
@@ -1304,12 +1343,14 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   std::vector<double2> uv(h->nobs), si;
   std::vector<int> ocam(h->nobs), opt(h->nobs);
   if (p->obs_sqrt_info) si.resize(h->nobs);
-  for (int64_t s = 0; s < h->nobs; ++s) {
-    const int64_t i = h->perm[s];
-    uv[s] = make_double2(p->obs_uv[2 * i], p->obs_uv[2 * i + 1]);
-    if (p->obs_sqrt_info) si[s] = make_double2(p->obs_sqrt_info[2 * i], p->obs_sqrt_info[2 * i + 1]);
-    ocam[s] = p->obs_cam[i]; opt[s] = p->obs_pt[i];
-  }
+  host_chunks(h->nobs, [&](int64_t s0, int64_t s1) {   // gathers through the permutation: independent per observation
+    for (int64_t s = s0; s < s1; ++s) {
+      const int64_t i = h->perm[s];
+      uv[s] = make_double2(p->obs_uv[2 * i], p->obs_uv[2 * i + 1]);
+      if (p->obs_sqrt_info) si[s] = make_double2(p->obs_sqrt_info[2 * i], p->obs_sqrt_info[2 * i + 1]);
+      ocam[s] = p->obs_cam[i]; opt[s] = p->obs_pt[i];
+    }
+  });
   hipStream_t st = h->stream;
 #define UP(buf, vec) do { rc = h->buf.upload(vec, st); if (rc) return rc; } while (0)
 #define AL(buf, cnt) do { rc = h->buf.alloc(cnt); if (rc) return rc; } while (0)
