@@ -39,6 +39,7 @@ struct ObsLin {        // linearisation of one observation (unscaled, uncorrecte
   double r[2];         // residual
   double Jc[12];       // 2x6 wrt [position | angle-axis]
   double Jx[8];        // 2x4 wrt homogeneous point (ambient)
+  double dc[2];        // DIRC only: J_cam * delta_cam, the directional derivative along one camera step (Jc is not formed)
   bool valid;          // functor return value
 };
 struct ObsLinK : ObsLin {
@@ -100,6 +101,21 @@ THIP_DEV void rotation_dq_dw(const double w[3], const double p[3], const RotTerm
   M[2] = -A * p[1] + B * p[2] * w[0] + w[2] * h0;
   M[5] = A * p[0] + B * p[2] * w[1] + w[2] * h1;
   M[8] = B * p[2] * w[2] + Bd + w[2] * h2;
+}
+
+// The step of one camera as {D, v}: d(R(w) p)/dw dw = D p for every p (the columns of rotation_dq_dw summed with the
+// weights dw: D = A [dw]x + B (w dw^T + dw w^T) + (w . dw) H,  H = -A I + cA [w]x + cB w w^T, 0 for small angles),
+// v = R dC.  out: 12 doubles.
+THIP_DEV void camera_step_direction(const double w[3], const RotTerms& t, const double dC[3], const double dw[3], double out[12]) {
+  const double wd = w[0] * dw[0] + w[1] * dw[1] + w[2] * dw[2];
+  const double hA = t.small ? 0.0 : -t.A * wd, hcA = t.small ? 0.0 : t.cA * wd, hcB = t.small ? 0.0 : t.cB * wd;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      out[3 * i + j] = t.B * (w[i] * dw[j] + dw[i] * w[j]) + hcB * w[i] * w[j] + (i == j ? hA : 0.0);
+  // skew parts: [a]x = (0, -a2, a1; a2, 0, -a0; -a1, a0, 0) for a = A dw + hcA w
+  const double a0 = t.A * dw[0] + hcA * w[0], a1 = t.A * dw[1] + hcA * w[1], a2 = t.A * dw[2] + hcA * w[2];
+  out[1] -= a2; out[2] += a1; out[3] += a2; out[5] -= a0; out[6] -= a1; out[7] += a0;
+  for (int i = 0; i < 3; ++i) out[9 + i] = t.R[3 * i] * dC[0] + t.R[3 * i + 1] * dC[1] + t.R[3 * i + 2] * dC[2];
 }
 
 // Projection pi(k, q) and its 2x3 Jacobian wrt q for the eight camera models of
@@ -396,14 +412,17 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
 // Residual (and optionally Jacobians) of one observation.
 // `t` = rotation_terms(ext + 3): per-camera quantities, computed per observation by observe() or once per camera and
 // iteration by the callers that keep them in HBM (ba_fused.hip: k_cam_prep).
-template <bool WANT_JAC, bool WANT_KJAC = false, typename OL = ObsLin, unsigned MODELS = kModelsAll>
+// DIRC: `dir` = {D (3 x 3, row-major), v (3)} of the camera's step (k_cam_update): instead of the 2 x 6 camera block the
+// functor returns o.dc = J_cam delta_cam = s * Jq (D p - w v)  (d(R p)/d(omega) delta_omega = D p is linear in p,
+// dq/dC delta_C = -w R delta_C = -w v); o.Jc is left untouched.
+template <bool WANT_JAC, bool WANT_KJAC = false, typename OL = ObsLin, unsigned MODELS = kModelsAll, bool DIRC = false>
 THIP_DEV void observe_rot(int model, const double* ext, const RotTerms& t, const double* intr, const double X[4],
-                          double u0, double v0, double six, double siy, OL& o) {
+                          double u0, double v0, double six, double siy, OL& o, const double* dir = nullptr) {
   const double p[3] = {X[0] - X[3] * ext[0], X[1] - X[3] * ext[1], X[2] - X[3] * ext[2]};
   const double sq = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
   if (sq < 1e-8) {  // reprojection_error.h:78-80 -> functor returns false
     o.valid = false; o.r[0] = 0.0; o.r[1] = 0.0;
-    if (WANT_JAC) { for (int i = 0; i < 12; ++i) o.Jc[i] = 0.0; for (int i = 0; i < 8; ++i) o.Jx[i] = 0.0; }
+    if (WANT_JAC) { for (int i = 0; i < 12; ++i) o.Jc[i] = 0.0; for (int i = 0; i < 8; ++i) o.Jx[i] = 0.0; o.dc[0] = 0.0; o.dc[1] = 0.0; }
     if constexpr (WANT_KJAC) { for (int i = 0; i < 2 * THEIA_MAX_INTRINSICS; ++i) o.Jk[i] = 0.0; }
     return;
   }
@@ -421,7 +440,12 @@ THIP_DEV void observe_rot(int model, const double* ext, const RotTerms& t, const
   o.r[1] = siy * (uv[1] - v0);
   if (WANT_JAC) {
     double M[9];
-    rotation_dq_dw(ext + 3, p, t, M);
+    double u[3] = {0.0, 0.0, 0.0};
+    if constexpr (DIRC) {
+      for (int i = 0; i < 3; ++i) u[i] = (dir[3 * i] * p[0] + dir[3 * i + 1] * p[1] + dir[3 * i + 2] * p[2]) - X[3] * dir[9 + i];
+    } else {
+      rotation_dq_dw(ext + 3, p, t, M);
+    }
     const double s[2] = {six, siy};
     for (int a = 0; a < 2; ++a) {
       const double* jq = Jq + 3 * a;
@@ -429,6 +453,9 @@ THIP_DEV void observe_rot(int model, const double* ext, const RotTerms& t, const
       const double A0 = jq[0] * t.R[0] + jq[1] * t.R[3] + jq[2] * t.R[6];
       const double A1 = jq[0] * t.R[1] + jq[1] * t.R[4] + jq[2] * t.R[7];
       const double A2 = jq[0] * t.R[2] + jq[1] * t.R[5] + jq[2] * t.R[8];
+      if constexpr (DIRC) {
+        o.dc[a] = s[a] * (jq[0] * u[0] + jq[1] * u[1] + jq[2] * u[2]);
+      } else {
       // dq/dC = -w R
       o.Jc[6 * a + 0] = -s[a] * X[3] * A0;
       o.Jc[6 * a + 1] = -s[a] * X[3] * A1;
@@ -436,6 +463,7 @@ THIP_DEV void observe_rot(int model, const double* ext, const RotTerms& t, const
       o.Jc[6 * a + 3] = s[a] * (jq[0] * M[0] + jq[1] * M[3] + jq[2] * M[6]);
       o.Jc[6 * a + 4] = s[a] * (jq[0] * M[1] + jq[1] * M[4] + jq[2] * M[7]);
       o.Jc[6 * a + 5] = s[a] * (jq[0] * M[2] + jq[1] * M[5] + jq[2] * M[8]);
+      }
       // dq/dX = [R | -R C]
       o.Jx[4 * a + 0] = s[a] * A0;
       o.Jx[4 * a + 1] = s[a] * A1;

@@ -39,12 +39,25 @@ namespace {
 constexpr int kRowBytes = 24;                         // slot-table row: kFusedMaxCams rounded up to 8
 static_assert(kFusedMaxCams <= kRowBytes, "slot-table row too short");
 
+// ycam (candidate launch only): the camera part of the solved step y; the step of every camera is then also left as
+// {D, v} in P.camdir (camera_step_direction, from the STATE's rotation terms in P.camrot) for k_backsub.
 __global__ __launch_bounds__(256) void k_cam_prep(DevProblem P, const double* __restrict__ cam, const double* __restrict__ intr,
-                                                  double* __restrict__ camrot) {
+                                                  double* __restrict__ camrot, const double* __restrict__ ycam) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && P.frun_next) *P.frun_next = 0;   // head of k_lin_schur's run queue (the next kernel on the stream)
   if (c >= P.nc) return;
   cam_prep_one(P, c, cam + 6 * (size_t)c, intr, camrot);
+  if (ycam && P.camdir) {
+    const int rc = P.cam_red[c];
+    const unsigned mask = P.cam_mask[c];
+    double dl[6], ext[6], out[12];
+    for (int q = 0; q < 6; ++q)   // exactly the step k_cam_update added to the free columns
+      dl[q] = (rc >= 0 && !((mask >> q) & 1u)) ? (-ycam[6 * rc + q]) * P.scale_c[6 * c + q] : 0.0;
+    RotTerms rt;
+    camrot_load(P.camrot + (size_t)kCamRot * c, ext, rt);
+    camera_step_direction(ext + 3, rt, dl, dl + 3, out);
+    for (int k = 0; k < 12; ++k) P.camdir[(size_t)12 * c + k] = out[k];
+  }
 }
 
 // Track-local OR of one int per lane (log-step, as segment_allsum_log); every lane of the track gets the result.
@@ -414,8 +427,8 @@ __global__ __launch_bounds__(256) void k_schur_sum(int nitems, const int* __rest
 
 }  // namespace
 
-void launch_cam_prep(const DevProblem& P, const double* cam, const double* intr, double* camrot, hipStream_t st) {
-  if (P.nc > 0) k_cam_prep<<<(P.nc + 255) / 256, 256, 0, st>>>(P, cam, intr, camrot);
+void launch_cam_prep(const DevProblem& P, const double* cam, const double* intr, double* camrot, hipStream_t st, const double* ycam) {
+  if (P.nc > 0) k_cam_prep<<<(P.nc + 255) / 256, 256, 0, st>>>(P, cam, intr, camrot, ycam);
 }
 
 void launch_linearize_fused(const DevProblem& P, const double* cam, const double* pts, const double* radius,

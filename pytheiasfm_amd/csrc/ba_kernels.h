@@ -88,6 +88,7 @@ struct DevProblem {
   double* fpart;               // per-run partial sums
   double* camrot;              // [nc][kCamRot] per-camera blocks at the linearisation point (k_cam_prep), null = not in use
   double* camrot_cand;         // the same for the candidate cameras of the trial step (back-substitution)
+  double* camdir;              // [nc][12] the trial step of each camera as {D (3 x 3), v (3)} (camera_step_direction; k_cam_update)
   unsigned model_mask;         // bit m = some intrinsics group uses camera model m (picks the kernel instance)
   int fused_dbg;               // development switches (THEIA_HIP_FUSED_DBG): 1 = skip phase S, 2 = skip phase L arithmetic
   int n_sum_items;
@@ -152,7 +153,7 @@ void launch_linearize(const DevProblem& P, const double* cam, const double* pts,
 void launch_linearize_fused(const DevProblem& P, const double* cam, const double* pts, const double* radius /* device */,
                             const ReduceBuf& rb, double* Vinv, double* tile_part, hipStream_t st);
 // per-camera blocks (rotation terms, masked scaling, intrinsics) of `cam` -> camrot (ba_fused.hip)
-void launch_cam_prep(const DevProblem& P, const double* cam, const double* intr, double* camrot, hipStream_t st);
+void launch_cam_prep(const DevProblem& P, const double* cam, const double* intr, double* camrot, hipStream_t st, const double* ycam = nullptr);
 void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,
                          const int* field_is_max, double* scal, hipStream_t st, double* red_part = nullptr);
 // first stage of a two-stage reduction: kReduceBlocks workgroups fold contiguous slices of the per-tile partials into

@@ -930,12 +930,16 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
   const int cnt = tile_ok ? P.tile_count[tile] : 0;
   const int start = tile_ok ? P.tile_start[tile] : 0;
   LaneLin<PD, INTR> L;
-  if constexpr (ROT) lane_linearize<PD, true, INTR, true>(P, P.camrot, pts, start + lane, lane < cnt, lane, L);
+  constexpr bool DIRC = ROT && !INTR;   // the camera block only ever multiplies y_c here: directional derivative instead
+  if constexpr (DIRC) lane_linearize<PD, true, INTR, true, kModelsAll, true>(P, P.camrot, pts, start + lane, lane < cnt, lane, L);
+  else if constexpr (ROT) lane_linearize<PD, true, INTR, true>(P, P.camrot, pts, start + lane, lane < cnt, lane, L);
   else lane_linearize<PD, true, INTR>(P, cam, pts, start + lane, lane < cnt, lane, L);
   const Segment sg = lane_segment_all(L.p, lane);
   // m_c = F y_c   (yc points at the camera part; the intrinsics part sits ni before it)
   double mc[2] = {0.0, 0.0};
-  if (L.active && L.rc >= 0) {
+  if constexpr (DIRC) {
+    mc[0] = L.mc[0]; mc[1] = L.mc[1];   // zero for constant cameras (their {D, v} is zero) and inactive lanes
+  } else if (L.active && L.rc >= 0) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       const double yv = yc[6 * L.rc + q];
@@ -1509,7 +1513,7 @@ void launch_backsub(const DevProblem& P, const double* cam, const double* pts, c
   const double* ycc = yc + P.ni;  // camera part of the solution
   if (!P.ni && P.n_fruns > 0 && P.camrot && P.camrot_cand) {   // fused path: the state's blocks are in P.camrot already
     // (folding this into k_cam_update's single workgroup was slower: 26 us against 13 + 7)
-    launch_cam_prep(P, cand_cam, P.intr, P.camrot_cand, st);
+    launch_cam_prep(P, cand_cam, P.intr, P.camrot_cand, st, ycc);   // + the cameras' steps as {D, v} (P.camdir)
     if (P.pd == 3) k_backsub<3, false, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
     else k_backsub<4, false, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
     return;

@@ -70,6 +70,7 @@ struct LaneLin {
   double Jt[2 * PD];
   double Jk[INTR ? 2 * THEIA_MAX_INTRINSICS : 1];  // 2 x 10 wrt the intrinsics block (INTR only)
   double X[4];
+  double mc[2];   // DIRC only: F y_c (loss-corrected), the camera part of the model residual
   double cost;
   int c, p, rc;
   int g, gr;   // intrinsics group and its reduced index (-1 = constant)
@@ -79,7 +80,8 @@ struct LaneLin {
 // Load one observation and linearise it: loss-corrected, column-masked,
 // Jacobi-scaled, tangent-space blocks.  WANT_JAC=false: residual/cost only.
 // ROT: `cam` is the per-camera block array of k_cam_prep (kCamRot doubles per camera) instead of [nc][6].
-template <int PD, bool WANT_JAC, bool INTR = false, bool ROT = false, unsigned MODELS = kModelsAll>
+// DIRC (with ROT): the camera block is replaced by its product with the camera's step (P.camdir, k_cam_update): L.mc = F y_c.
+template <int PD, bool WANT_JAC, bool INTR = false, bool ROT = false, unsigned MODELS = kModelsAll, bool DIRC = false>
 THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam,
                              const double* __restrict__ pts, int o, bool active, int lane,
                              LaneLin<PD, INTR>& L) {
@@ -103,6 +105,7 @@ THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam
     for (int i = 0; i < 2 * PD; ++i) L.Jt[i] = 0.0;
   }
   L.X[0] = L.X[1] = L.X[2] = 0.0; L.X[3] = 1.0;
+  L.mc[0] = L.mc[1] = 0.0;
   if (!active) return;
   int c = P.obs_cam[o];
   int p = P.obs_pt[o];
@@ -137,7 +140,11 @@ THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam
   }
   L.g = g;
   typename std::conditional<INTR, ObsLinK, ObsLin>::type ol;
-  if constexpr (ROT) observe_rot<WANT_JAC, INTR && WANT_JAC, typename std::conditional<INTR, ObsLinK, ObsLin>::type, MODELS>(model, ext, rt, intr, L.X, uv.x, uv.y, six, siy, ol);
+  if constexpr (ROT && DIRC) {
+    double dir[12];
+    load_d2<12>(P.camdir + (size_t)12 * c, dir);
+    observe_rot<WANT_JAC, INTR && WANT_JAC, typename std::conditional<INTR, ObsLinK, ObsLin>::type, MODELS, true>(model, ext, rt, intr, L.X, uv.x, uv.y, six, siy, ol, dir);
+  } else if constexpr (ROT) observe_rot<WANT_JAC, INTR && WANT_JAC, typename std::conditional<INTR, ObsLinK, ObsLin>::type, MODELS>(model, ext, rt, intr, L.X, uv.x, uv.y, six, siy, ol);
   else observe<WANT_JAC, INTR && WANT_JAC>(model, ext, intr, L.X, uv.x, uv.y, six, siy, ol);
   L.valid = ol.valid;
   const double s = ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1];
@@ -152,6 +159,9 @@ THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam
   if (WANT_JAC) {
     unsigned mask = 0u;
     if constexpr (!ROT) mask = P.cam_mask[c];
+    if constexpr (DIRC) {   // y = -(delta / scale): F y_c = sr J (scale y) = -sr J delta
+      L.mc[0] = -sr * ol.dc[0]; L.mc[1] = -sr * ol.dc[1];
+    } else {
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       double sc;
@@ -159,6 +169,7 @@ THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam
       else sc = ((mask >> q) & 1u) ? 0.0 : sr * P.scale_c[6 * c + q];
       L.Jc[q] = ol.Jc[q] * sc;
       L.Jc[6 + q] = ol.Jc[6 + q] * sc;
+    }
     }
     if constexpr (INTR) {
       L.gr = P.grp_red[g];

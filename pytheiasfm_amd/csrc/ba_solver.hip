@@ -147,7 +147,7 @@ struct theia_ba_handle_s {
   DevBuf<int> frun_cams, tile_trk_end, sum_items, sum_src, frun_order, frun_next;
   DevBuf<unsigned short> frun_tgt;
   DevBuf<uint8_t> obs_lc, obs_tl;
-  DevBuf<double> fpart, camrot, camrot_cand;
+  DevBuf<double> fpart, camrot, camrot_cand, camdir;
   int n_fruns = 0, n_sum_items = 0;
   double* h_scal = nullptr;  // pinned: [scalA(16) | scalB(16) | stop flag out / in (2) | spare]
   char* h_state = nullptr;   // pinned: LmState read-back
@@ -518,7 +518,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.prior_vec = h->prior_vec.p; P.prior_info = h->prior_info.p;
   P.rec = h->rec.p; P.n_diag_items = h->n_diag_items; P.n_blk_items = h->n_blk_items;
   P.n_fruns = h->use_fused ? h->n_fruns : 0; P.fruns = h->fruns.p; P.frun_order = h->frun_order.p; P.frun_next = h->frun_next.p; P.frun_cams = h->frun_cams.p; P.frun_tgt = h->frun_tgt.p;
-  P.obs_lc = h->obs_lc.p; P.obs_tl = h->obs_tl.p; P.tile_trk_end = h->tile_trk_end.p; P.fpart = h->fpart.p; P.camrot = h->camrot.p; P.camrot_cand = h->camrot_cand.p;
+  P.obs_lc = h->obs_lc.p; P.obs_tl = h->obs_tl.p; P.tile_trk_end = h->tile_trk_end.p; P.fpart = h->fpart.p; P.camrot = h->camrot.p; P.camrot_cand = h->camrot_cand.p; P.camdir = h->camdir.p;
   { const char* dbg = getenv("THEIA_HIP_FUSED_DBG"); P.fused_dbg = dbg ? atoi(dbg) : 0; }
   P.model_mask = h->model_mask;
   P.n_sum_items = h->n_sum_items; P.sum_items = h->sum_items.p; P.sum_src = h->sum_src.p;
@@ -1513,7 +1513,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     UP(fruns, fplan.runs); UP(frun_cams, fplan.cams); UP(frun_tgt, fplan.tgts); UP(obs_lc, fplan.obs_lc); UP(obs_tl, fplan.obs_tl);
     UP(tile_trk_end, fplan.tile_trk_end); UP(sum_items, fplan.sum_items); UP(sum_src, fplan.sum_src);
     AL(fpart, std::max<size_t>(1, fplan.part_doubles));
-    AL(camrot, (size_t)40 * std::max(1, h->nc)); AL(camrot_cand, (size_t)40 * std::max(1, h->nc));
+    AL(camrot, (size_t)40 * std::max(1, h->nc)); AL(camrot_cand, (size_t)40 * std::max(1, h->nc)); AL(camdir, (size_t)12 * std::max(1, h->nc));
   }
   if (h->ni > 0 && h->ntiles_main > 0 && (rc = build_gather_lists_intr(h, p, ocam, opt, l_obs))) return rc;
 #undef UP
