@@ -916,6 +916,7 @@ __global__ void k_cam_update(DevProblem P, const double* __restrict__ cam, const
 // ROT: the per-camera blocks of k_cam_prep (P.camrot for the state, P.camrot_cand for the candidate cameras) replace
 // the per-observation sincos and the chained camera -> group -> intrinsics gathers.
 template <int PD, bool INTR, bool ROT = false>
+// (148 VGPRs = three waves per SIMD; capped at 128 for four, 24 of them spill and the kernel takes 55 us longer)
 __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* __restrict__ cam,
                                                     const double* __restrict__ pts,
                                                     const double* __restrict__ cand_cam,
