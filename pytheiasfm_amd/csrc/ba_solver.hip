@@ -21,6 +21,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -993,6 +994,7 @@ struct FusedHost {
   std::vector<int> cams, tile_trk_end, sum_items, sum_src;
   std::vector<unsigned short> tgts;
   std::vector<uint8_t> obs_lc, obs_tl;
+  std::vector<uint8_t> tile_adj;   // [nt][nt] 64-wide tiles of S coupled by a variable track (the K3 plan's input)
   size_t part_doubles = 0;
 };
 void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& off, const std::vector<int>& porder,
@@ -1018,10 +1020,38 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
   int t_tracks = 0, sc_tracks = 0;
   int run_tile0 = 0, run_ntiles = 0, run_key0 = -1;
   int64_t run_obs = 0;
-  std::vector<int> run_cams;           // sorted, unique
-  std::vector<int64_t> run_pairs;      // sorted unique keys hi * 2^32 | lo of co-visible reduced cameras (hi >= lo)
-  std::vector<int> tc, uni;
-  std::vector<int64_t> tp, upairs;
+  // cameras / co-visible camera pairs of the open run: membership through per-run stamps (a sorted-set union per track
+  // cost 64 ms at 500k tracks), the lists are sorted once when the run closes
+  std::vector<int> run_cams;           // unique, sorted by finalize_run
+  std::vector<int64_t> run_pairs;      // unique keys hi * 2^32 | lo of co-visible reduced cameras (hi >= lo), sorted by finalize_run
+  std::vector<int> tc;
+  std::vector<int64_t> tp;
+  int serial = 1, prev_serial = 0;
+  std::vector<int> prev_tc;
+  std::vector<int> cam_stamp((size_t)std::max(1, h->ncv), 0);
+  std::vector<uint8_t> cam_local((size_t)std::max(1, h->ncv), 0);   // camera -> index in the closing run's sorted table
+  constexpr int kPairSlots = 2048;     // > 4 x 253
+  std::vector<int64_t> pair_key(kPairSlots, 0);
+  std::vector<int> pair_stamp(kPairSlots, 0);
+  auto pair_slot = [&](int64_t key) -> int {   // slot holding `key` in this run, or the free slot where it would go
+    unsigned hsh = ((unsigned)(key >> 32) * 0x9E3779B1u) ^ ((unsigned)key * 0x85EBCA77u);
+    int sl = (int)(hsh >> 21) & (kPairSlots - 1);
+    while (pair_stamp[sl] == serial && pair_key[sl] != key) sl = (sl + 1) & (kPairSlots - 1);
+    return sl;
+  };
+  const int adj_nt = (h->n + 63) / 64;
+  fp.tile_adj.assign((size_t)adj_nt * adj_nt, 0);
+  std::vector<int> tl;
+  auto mark_tiles = [&](int q) {   // tile co-visibility of a variable track (tc: its variable cameras, ascending)
+    if (h->pt_const[porder[q]]) return;
+    tl.clear();
+    for (int rcam : tc) {
+      const int s0 = h->ni + 6 * rcam;
+      if (tl.empty() || tl.back() != s0 / 64) tl.push_back(s0 / 64);
+      if ((s0 + 5) / 64 != s0 / 64) tl.push_back((s0 + 5) / 64);
+    }
+    for (int a : tl) for (int b : tl) fp.tile_adj[(size_t)a * adj_nt + b] = 1;
+  };
 
   auto close_tile = [&](int q_end) {
     if (!t_len) return;
@@ -1032,16 +1062,17 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
     t_len = 0; t_tracks = 0;
   };
   auto finalize_run = [&]() {
-    if (!run_ntiles) { run_cams.clear(); run_pairs.clear(); run_obs = 0; run_key0 = -1; return; }
+    if (!run_ntiles) { run_cams.clear(); run_pairs.clear(); run_obs = 0; run_key0 = -1; ++serial; return; }
+    std::sort(run_cams.begin(), run_cams.end());
+    std::sort(run_pairs.begin(), run_pairs.end());
     FusedRun r;
     r.tile0 = run_tile0; r.ntiles = run_ntiles;
     r.cam_off = (int)fp.cams.size(); r.W = (int)run_cams.size();
     fp.cams.insert(fp.cams.end(), run_cams.begin(), run_cams.end());
     r.tgt_off = (int)fp.tgts.size(); r.ntgt = (int)run_pairs.size();
+    for (size_t i = 0; i < run_cams.size(); ++i) cam_local[run_cams[i]] = (uint8_t)i;   // local index by table, not by search
     for (int64_t key : run_pairs) {   // ascending (hi, lo) -> ascending (la, lb)
-      const int hi = (int)(key >> 32), lo = (int)(key & 0xffffffff);
-      const int la = (int)(std::lower_bound(run_cams.begin(), run_cams.end(), hi) - run_cams.begin());
-      const int lb = (int)(std::lower_bound(run_cams.begin(), run_cams.end(), lo) - run_cams.begin());
+      const int la = cam_local[(int)(key >> 32)], lb = cam_local[(int)(key & 0xffffffff)];
       fp.tgts.push_back((unsigned short)(la | (lb << 8)));
     }
     const int need = std::max(r.ntgt, 6 * r.W);
@@ -1051,10 +1082,10 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
     fp.part_doubles += (size_t)r.ntgt * 36 + (size_t)r.W * 18;
     for (int t = run_tile0; t < run_tile0 + run_ntiles; ++t)
       for (int s = tstart[t]; s < tstart[t] + tcount[t]; ++s)
-        if (sred[s] >= 0) fp.obs_lc[s] = (uint8_t)(std::lower_bound(run_cams.begin(), run_cams.end(), sred[s]) - run_cams.begin());
+        if (sred[s] >= 0) fp.obs_lc[s] = cam_local[sred[s]];
     fp.runs.push_back(r);
     run_tile0 += run_ntiles; run_ntiles = 0; run_obs = 0; run_key0 = -1;
-    run_cams.clear(); run_pairs.clear();
+    run_cams.clear(); run_pairs.clear(); ++serial;
   };
   auto push_long = [&](int q) {
     const int slot = (int)l_pt.size();
@@ -1071,29 +1102,31 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
     for (int64_t s = off[q]; s < off[q + 1]; ++s) if (sred[s] >= 0) tc.push_back(sred[s]);
     std::sort(tc.begin(), tc.end());
     const bool dup = std::adjacent_find(tc.begin(), tc.end()) != tc.end();
+    mark_tiles(q);
     if (L > 64 || dup || (int)tc.size() > kFusedMaxCams) {
       close_tile(q);            // tiles are contiguous observation ranges
       push_long(q);
       continue;
     }
-    tp.clear();
-    for (size_t a = 0; a < tc.size(); ++a)
-      for (size_t b = 0; b <= a; ++b) tp.push_back(((int64_t)tc[a] << 32) | (uint32_t)tc[b]);
-    std::sort(tp.begin(), tp.end());
-    // would the run still fit?
-    uni.clear();
-    std::set_union(run_cams.begin(), run_cams.end(), tc.begin(), tc.end(), std::back_inserter(uni));
-    upairs.clear();
-    std::set_union(run_pairs.begin(), run_pairs.end(), tp.begin(), tp.end(), std::back_inserter(upairs));
-    bool new_run = (int)uni.size() > kFusedMaxCams || upairs.size() > 253;
+    // the camera set of the previous track of this run again (tracks are ordered by first camera: common): nothing new
+    const bool same_set = serial == prev_serial && tc == prev_tc;
+    size_t ucams = run_cams.size(), upairs = run_pairs.size();
+    if (!same_set) {
+      tp.clear();
+      for (size_t a = 0; a < tc.size(); ++a)
+        for (size_t b = 0; b <= a; ++b) tp.push_back(((int64_t)tc[a] << 32) | (uint32_t)tc[b]);
+      // would the run still fit?  sizes of the unions with the run's sets
+      for (int c : tc) ucams += cam_stamp[c] != serial;
+      for (int64_t key : tp) upairs += pair_stamp[pair_slot(key)] != serial;
+    }
+    bool new_run = (int)ucams > kFusedMaxCams || upairs > 253;
     // a run keeps its packing level (track slices per wave) once it has some work, and stays inside one
     // first-camera key once it is large enough
-    if (!new_run && run_obs >= 64 && packing(upairs.size(), uni.size()) < packing(run_pairs.size(), run_cams.size())) new_run = true;
+    if (!new_run && run_obs >= 64 && packing(upairs, ucams) < packing(run_pairs.size(), run_cams.size())) new_run = true;
     if (!new_run && run_obs >= run_max / 4 && skey[q] != run_key0) new_run = true;
     if (new_run) {
       close_tile(q);
       finalize_run();
-      uni = tc; upairs = tp;
     }
     if (t_len + L > 64 || t_tracks >= kFusedTileTracks) {
       close_tile(q);
@@ -1101,7 +1134,7 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
       // many workgroups share that work instead of a few long ones setting the kernel's duration
       const size_t need = std::max(run_pairs.size(), 6 * run_cams.size());
       const int64_t cap = need <= 64 ? run_max : (need <= 128 ? run_max / 4 : 1);
-      if (run_ntiles % tps == 0 && run_obs >= cap) { finalize_run(); uni = tc; upairs = tp; }
+      if (run_ntiles % tps == 0 && run_obs >= cap) finalize_run();
     }
     if (t_len == 0) {
       t_start = off[q];
@@ -1110,10 +1143,32 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
     }
     for (int64_t s = off[q]; s < off[q + 1]; ++s) fp.obs_tl[s] = (uint8_t)sc_tracks;
     sc_tracks++; t_tracks++; t_len += L; run_obs += L;
-    run_cams.swap(uni); run_pairs.swap(upairs);
+    // the track joins the open run
+    if (!(same_set && serial == prev_serial)) {   // (a run closed above: the sets are empty again and tp may be stale)
+      if (same_set) {
+        tp.clear();
+        for (size_t a = 0; a < tc.size(); ++a)
+          for (size_t b = 0; b <= a; ++b) tp.push_back(((int64_t)tc[a] << 32) | (uint32_t)tc[b]);
+      }
+      for (int c : tc) if (cam_stamp[c] != serial) { cam_stamp[c] = serial; run_cams.push_back(c); }
+      for (int64_t key : tp) {
+        const int sl = pair_slot(key);
+        if (pair_stamp[sl] != serial) { pair_stamp[sl] = serial; pair_key[sl] = key; run_pairs.push_back(key); }
+      }
+      prev_tc = tc; prev_serial = serial;
+    }
   }
   close_tile(np);
   finalize_run();
+  const bool ptiming = getenv("THEIA_HIP_CREATE_TIMING") != nullptr;
+  auto pt0 = std::chrono::steady_clock::now();
+  auto ptick = [&](const char* what) {
+    if (!ptiming) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "theia_hip create:     fused plan: %-18s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - pt0).count());
+    pt0 = t;
+  };
+  ptick("(since runs built)");
   // per S block: the partial sums that feed it, in run order
   struct Ent { int64_t key; int src; int isd; };
   std::vector<Ent> ents;
@@ -1141,6 +1196,7 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
   }
   fp.sum_src.reserve(ents.size());
   for (const Ent& en : ents) fp.sum_src.push_back(en.src);
+  ptick("sum items");
 }
 
 #undef UP
@@ -1306,18 +1362,22 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   std::vector<int> sred;
   if (h->use_fused) {
     sred.resize(h->nobs_main);
-    for (int64_t s = 0; s < h->nobs_main; ++s) sred[s] = h->cam_red[p->obs_cam[h->perm[s]]];
-    int64_t misfit = 0;
-    std::vector<int> tc;
-    for (int q = 0; q < h->np; ++q) {
-      const int64_t L = cnt_main[q + 1] - cnt_main[q];
-      if (L < 2 || L > 64) continue;
-      tc.clear();
-      for (int64_t s = cnt_main[q]; s < cnt_main[q + 1]; ++s) if (sred[s] >= 0) tc.push_back(sred[s]);
-      std::sort(tc.begin(), tc.end());
-      if ((int)tc.size() > kFusedMaxCams || std::adjacent_find(tc.begin(), tc.end()) != tc.end()) misfit += L;
-    }
-    if (misfit * 20 > h->nobs_main) h->use_fused = false;
+    host_chunks(h->nobs_main, [&](int64_t s0, int64_t s1) { for (int64_t s = s0; s < s1; ++s) sred[s] = h->cam_red[p->obs_cam[h->perm[s]]]; });
+    std::atomic<long long> misfit{0};
+    host_chunks(h->np, [&](int64_t q0, int64_t q1) {   // tracks are independent
+      std::vector<int> tc;
+      long long mine = 0;
+      for (int64_t q = q0; q < q1; ++q) {
+        const int64_t L = cnt_main[q + 1] - cnt_main[q];
+        if (L < 2 || L > 64) continue;
+        tc.clear();
+        for (int64_t s = cnt_main[q]; s < cnt_main[q + 1]; ++s) if (sred[s] >= 0) tc.push_back(sred[s]);
+        std::sort(tc.begin(), tc.end());
+        if ((int)tc.size() > kFusedMaxCams || std::adjacent_find(tc.begin(), tc.end()) != tc.end()) mine += L;
+      }
+      misfit += mine;
+    });
+    if (misfit.load() * 20 > h->nobs_main) h->use_fused = false;
   }
   tick("  structure: fit check");
   if (h->use_fused) {
@@ -1456,6 +1516,9 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     // seen by cameras of both (the Schur complement's block structure)
     const int nt = (h->n + 63) / 64;
     h->tile_adj.assign((size_t)nt * nt, 0);
+    if (h->use_fused && fplan.tile_adj.size() == (size_t)nt * nt) {
+      h->tile_adj = fplan.tile_adj;   // marked track by track while the fused plan was built (same rule as below)
+    } else {
     std::vector<int64_t> off(h->np + 1, 0);
     for (int64_t i = 0; i < h->nobs; ++i)
       if (h->cam_red[p->obs_cam[i]] >= 0 && !h->pt_const[p->obs_pt[i]]) off[p->obs_pt[i] + 1]++;
@@ -1479,6 +1542,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
       std::sort(tl.begin(), tl.end());
       tl.erase(std::unique(tl.begin(), tl.end()), tl.end());
       for (int a : tl) for (int b : tl) h->tile_adj[(size_t)a * nt + b] = 1;
+    }
     }
     // shared intrinsics couple with every camera of their group: treat as dense
     for (int a = 0; a < (h->ni + 63) / 64; ++a)
