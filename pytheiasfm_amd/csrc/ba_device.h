@@ -39,7 +39,7 @@ struct ObsLin {        // linearisation of one observation (unscaled, uncorrecte
   double r[2];         // residual
   double Jc[12];       // 2x6 wrt [position | angle-axis]
   double Jx[8];        // 2x4 wrt homogeneous point (ambient)
-  double dc[2];        // DIRC only: J_cam * delta_cam, the directional derivative along one camera step (Jc is not formed)
+  double dc0, dc1;     // DIRC only: J_cam * delta_cam (rows u, v), the directional derivative along one camera step (Jc is not formed)
   bool valid;          // functor return value
 };
 struct ObsLinK : ObsLin {
@@ -420,9 +420,10 @@ THIP_DEV void observe_rot(int model, const double* ext, const RotTerms& t, const
                           double u0, double v0, double six, double siy, OL& o, const double* dir = nullptr) {
   const double p[3] = {X[0] - X[3] * ext[0], X[1] - X[3] * ext[1], X[2] - X[3] * ext[2]};
   const double sq = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+  o.dc0 = 0.0; o.dc1 = 0.0;
   if (sq < 1e-8) {  // reprojection_error.h:78-80 -> functor returns false
     o.valid = false; o.r[0] = 0.0; o.r[1] = 0.0;
-    if (WANT_JAC) { for (int i = 0; i < 12; ++i) o.Jc[i] = 0.0; for (int i = 0; i < 8; ++i) o.Jx[i] = 0.0; o.dc[0] = 0.0; o.dc[1] = 0.0; }
+    if (WANT_JAC) { for (int i = 0; i < 12; ++i) o.Jc[i] = 0.0; for (int i = 0; i < 8; ++i) o.Jx[i] = 0.0; }
     if constexpr (WANT_KJAC) { for (int i = 0; i < 2 * THEIA_MAX_INTRINSICS; ++i) o.Jk[i] = 0.0; }
     return;
   }
@@ -447,14 +448,16 @@ THIP_DEV void observe_rot(int model, const double* ext, const RotTerms& t, const
       rotation_dq_dw(ext + 3, p, t, M);
     }
     const double s[2] = {six, siy};
-    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {   // (unrolled: o.dc[a] / o.Jc[6 a + ..] must be register indices, not a scratch array)
       const double* jq = Jq + 3 * a;
       // A = Jq R  (1x3)
       const double A0 = jq[0] * t.R[0] + jq[1] * t.R[3] + jq[2] * t.R[6];
       const double A1 = jq[0] * t.R[1] + jq[1] * t.R[4] + jq[2] * t.R[7];
       const double A2 = jq[0] * t.R[2] + jq[1] * t.R[5] + jq[2] * t.R[8];
       if constexpr (DIRC) {
-        o.dc[a] = s[a] * (jq[0] * u[0] + jq[1] * u[1] + jq[2] * u[2]);
+        const double dv = s[a] * (jq[0] * u[0] + jq[1] * u[1] + jq[2] * u[2]);
+        if (a == 0) o.dc0 = dv; else o.dc1 = dv;
       } else {
       // dq/dC = -w R
       o.Jc[6 * a + 0] = -s[a] * X[3] * A0;
@@ -555,9 +558,11 @@ THIP_DEV void to_tangent(const double X[4], const double Jx[8], double Jt[6]) {
   double v[4], beta;
   householder4(X, v, beta);
   const double nx = fsqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2] + X[3] * X[3]);
+#pragma unroll
   for (int a = 0; a < 2; ++a) {
     const double* j = Jx + 4 * a;
     const double jv = j[0] * v[0] + j[1] * v[1] + j[2] * v[2] + j[3] * v[3];
+#pragma unroll
     for (int c = 0; c < 3; ++c) Jt[3 * a + c] = nx * (j[c] - beta * v[c] * jv);
   }
 }

@@ -160,7 +160,7 @@ THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam
     unsigned mask = 0u;
     if constexpr (!ROT) mask = P.cam_mask[c];
     if constexpr (DIRC) {   // y = -(delta / scale): F y_c = sr J (scale y) = -sr J delta
-      L.mc[0] = -sr * ol.dc[0]; L.mc[1] = -sr * ol.dc[1];
+      L.mc[0] = -sr * ol.dc0; L.mc[1] = -sr * ol.dc1;
     } else {
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
