@@ -376,6 +376,16 @@ def main():
                                         "ms_per_step": 1e3 * ti / (nrep * si.num_iterations), "iterations_per_solve": si.num_iterations,
                                         "note": "use_inner_iterations = true (reference default): coordinate descent over cameras then points after each accepted step"}
         del hi
+    if rank == 0 and world == 1:
+        # what one theia_hip_ba_solve call costs end to end (BundleAdjustReconstruction through the boundary: host-side
+        # structure analysis + uploads + 25 LM iterations + download), for the record next to the steady-state rate
+        o1 = ba.default_options(); o1.max_num_iterations = 25; o1.use_inner_iterations = 0
+        o1.function_tolerance = o1.gradient_tolerance = o1.parameter_tolerance = 0.0
+        q1 = pristine.copy()
+        t10 = time.perf_counter(); s1, _ = ba.solve(q1, o1, trace_capacity=1); t11 = time.perf_counter()
+        out["one_shot_call"] = {"workload": "theia_hip_ba_solve on the same problem from host arrays, 25 LM iterations",
+                                "total_ms": 1e3 * (t11 - t10), "iterations": int(s1.num_iterations),
+                                "note": "handle creation (host-side plan of 3.0 M observations) dominates: see DESIGN.md 3.4"}
     if rank == 0 and world == 1 and not args.no_c2:
         # secondary block: BASELINE.json configs[1] (the round-1 headline), same measurement
         c2 = synth.ba_config("C2")
