@@ -997,11 +997,20 @@ struct FusedHost {
   std::vector<uint8_t> tile_adj;   // [nt][nt] 64-wide tiles of S coupled by a variable track (the K3 plan's input)
   size_t part_doubles = 0;
 };
-void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& off, const std::vector<int>& porder,
-                      const std::vector<int>& sred, const std::vector<int>& skey, std::vector<int>& tstart,
-                      std::vector<int>& tcount, std::vector<int>& tkey, std::vector<int>& l_obs, std::vector<int>& l_slot,
-                      std::vector<int>& l_start, std::vector<int>& l_pt, FusedHost& fp) {
-  const int np = h->np;
+// One contiguous range [q_begin, q_end) of track ranks -> the tiles / runs / long tracks of that range, with tile, camera-table,
+// target and partial-sum offsets relative to the segment (merge_fused_segments rebases them).  obs_lc / obs_tl are indexed
+// by observation: segments write disjoint parts of the shared arrays.
+struct FusedSegment {
+  std::vector<int> tstart, tcount, tkey, l_obs, l_slot, l_start, l_pt;
+  FusedHost fp;
+};
+void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>& off, const std::vector<int>& porder,
+                         const std::vector<int>& sred, const std::vector<int>& skey, int q_begin, int q_end,
+                         uint8_t* obs_lc, uint8_t* obs_tl, FusedSegment& seg) {
+  std::vector<int>& tstart = seg.tstart; std::vector<int>& tcount = seg.tcount; std::vector<int>& tkey = seg.tkey;
+  std::vector<int>& l_obs = seg.l_obs; std::vector<int>& l_slot = seg.l_slot; std::vector<int>& l_start = seg.l_start;
+  std::vector<int>& l_pt = seg.l_pt;
+  FusedHost& fp = seg.fp;
   const int64_t nm = h->nobs_main;
   const int tps = fused_tiles_per_subchunk(h->pd);
   // track slices per consumer wave for a run of ntgt target blocks over W cameras (0 = needs more than one wave)
@@ -1011,8 +1020,6 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
     for (int c : cand) if ((size_t)(64 / c) >= ntgt) return c;
     return 1;
   };
-  fp.obs_lc.assign((size_t)std::max<int64_t>(1, nm), 0xff);
-  fp.obs_tl.assign((size_t)std::max<int64_t>(1, nm), 0);
   const char* rm = getenv("THEIA_HIP_FUSED_RUN_OBS");
   const int64_t run_max = rm ? std::max(64, atoi(rm)) : std::max<int64_t>(256, std::min<int64_t>(1344, nm / 600));   // 3.0 M observations, runs taken from the queue: 1280..1408 0.46 ms, 1024 0.47, 2304 0.48, 512 0.49
   // current tile / run
@@ -1082,7 +1089,7 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
     fp.part_doubles += (size_t)r.ntgt * 36 + (size_t)r.W * 18;
     for (int t = run_tile0; t < run_tile0 + run_ntiles; ++t)
       for (int s = tstart[t]; s < tstart[t] + tcount[t]; ++s)
-        if (sred[s] >= 0) fp.obs_lc[s] = cam_local[sred[s]];
+        if (sred[s] >= 0) obs_lc[s] = cam_local[sred[s]];
     fp.runs.push_back(r);
     run_tile0 += run_ntiles; run_ntiles = 0; run_obs = 0; run_key0 = -1;
     run_cams.clear(); run_pairs.clear(); ++serial;
@@ -1094,7 +1101,7 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
     l_start.push_back((int)l_obs.size());
   };
   run_tile0 = (int)tstart.size();
-  for (int q = 0; q < np; ++q) {
+  for (int q = q_begin; q < q_end; ++q) {
     const int64_t L = off[q + 1] - off[q];
     if (L == 0) continue;
     // the track's variable cameras
@@ -1141,7 +1148,7 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
       if (run_ntiles % tps == 0) sc_tracks = 0;
       if (run_key0 < 0) run_key0 = skey[q];
     }
-    for (int64_t s = off[q]; s < off[q + 1]; ++s) fp.obs_tl[s] = (uint8_t)sc_tracks;
+    for (int64_t s = off[q]; s < off[q + 1]; ++s) obs_tl[s] = (uint8_t)sc_tracks;
     sc_tracks++; t_tracks++; t_len += L; run_obs += L;
     // the track joins the open run
     if (!(same_set && serial == prev_serial)) {   // (a run closed above: the sets are empty again and tp may be stale)
@@ -1158,8 +1165,36 @@ void build_fused_plan(const theia_ba_handle_s* h, const std::vector<int64_t>& of
       prev_tc = tc; prev_serial = serial;
     }
   }
-  close_tile(np);
+  close_tile(q_end);
   finalize_run();
+}
+
+// The segments in order -> one plan (offsets rebased), then per S block the partial sums that feed it, in run order.
+void merge_fused_segments(const theia_ba_handle_s* h, std::vector<FusedSegment>& segs, std::vector<int>& tstart, std::vector<int>& tcount,
+                          std::vector<int>& tkey, std::vector<int>& l_obs, std::vector<int>& l_slot, std::vector<int>& l_start,
+                          std::vector<int>& l_pt, FusedHost& fp) {
+  const int adj_nt = (h->n + 63) / 64;
+  fp.tile_adj.assign((size_t)adj_nt * adj_nt, 0);
+  for (FusedSegment& sg : segs) {
+    const int tile0 = (int)tstart.size(), cam0 = (int)fp.cams.size(), tgt0 = (int)fp.tgts.size();
+    const int slot0 = (int)l_pt.size(), lobs0 = (int)l_obs.size();
+    tstart.insert(tstart.end(), sg.tstart.begin(), sg.tstart.end());
+    tcount.insert(tcount.end(), sg.tcount.begin(), sg.tcount.end());
+    tkey.insert(tkey.end(), sg.tkey.begin(), sg.tkey.end());
+    for (FusedRun r : sg.fp.runs) {
+      r.tile0 += tile0; r.cam_off += cam0; r.tgt_off += tgt0; r.part_off += (int)fp.part_doubles;
+      fp.runs.push_back(r);
+    }
+    fp.part_doubles += sg.fp.part_doubles;
+    fp.cams.insert(fp.cams.end(), sg.fp.cams.begin(), sg.fp.cams.end());
+    fp.tgts.insert(fp.tgts.end(), sg.fp.tgts.begin(), sg.fp.tgts.end());
+    fp.tile_trk_end.insert(fp.tile_trk_end.end(), sg.fp.tile_trk_end.begin(), sg.fp.tile_trk_end.end());
+    l_obs.insert(l_obs.end(), sg.l_obs.begin(), sg.l_obs.end());
+    for (int v : sg.l_slot) l_slot.push_back(v + slot0);
+    for (int v : sg.l_start) l_start.push_back(v + lobs0);
+    l_pt.insert(l_pt.end(), sg.l_pt.begin(), sg.l_pt.end());
+    for (size_t i = 0; i < fp.tile_adj.size(); ++i) fp.tile_adj[i] |= sg.fp.tile_adj[i];
+  }
   const bool ptiming = getenv("THEIA_HIP_CREATE_TIMING") != nullptr;
   auto pt0 = std::chrono::steady_clock::now();
   auto ptick = [&](const char* what) {
@@ -1383,7 +1418,28 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   if (h->use_fused) {
     std::vector<int> skey(h->np);
     for (int q = 0; q < h->np; ++q) skey[q] = pkey[porder[q]];   // run boundaries follow the first-camera key
-    build_fused_plan(h, cnt_main, porder, sred, skey, tstart, tcount, tkey, l_obs, l_slot, l_start, l_pt, fplan);
+    // eight segments of tracks, cut where the first-camera key changes, built on host threads and merged in order (the
+    // segment count is fixed: the plan -- and with it the summation order of S -- does not depend on the machine)
+    constexpr int kSegs = 8;
+    std::vector<int> cut{0};
+    if (h->np >= 65536)
+      for (int k = 1; k < kSegs; ++k) {
+        int q = (int)((int64_t)h->np * k / kSegs);
+        while (q < h->np && q > 0 && skey[q] == skey[q - 1]) ++q;
+        if (q > cut.back() && q < h->np) cut.push_back(q);
+      }
+    cut.push_back(h->np);
+    std::vector<FusedSegment> segs(cut.size() - 1);
+    fplan.obs_lc.assign((size_t)std::max<int64_t>(1, h->nobs_main), 0xff);
+    fplan.obs_tl.assign((size_t)std::max<int64_t>(1, h->nobs_main), 0);
+    {
+      std::vector<std::thread> th;
+      for (size_t k = 1; k < segs.size(); ++k)
+        th.emplace_back([&, k] { build_fused_segment(h, cnt_main, porder, sred, skey, cut[k], cut[k + 1], fplan.obs_lc.data(), fplan.obs_tl.data(), segs[k]); });
+      build_fused_segment(h, cnt_main, porder, sred, skey, cut[0], cut[1], fplan.obs_lc.data(), fplan.obs_tl.data(), segs[0]);
+      for (auto& x : th) x.join();
+    }
+    merge_fused_segments(h, segs, tstart, tcount, tkey, l_obs, l_slot, l_start, l_pt, fplan);
     if (fplan.part_doubles > (size_t)std::numeric_limits<int>::max() / 2)
       return set_error(THEIA_HIP_ERR_UNSUPPORTED, "partial-sum buffer of the fused Schur assembly exceeds 32-bit offsets");
   } else {
@@ -1895,9 +1951,14 @@ int theia_hip_ba_solve(const theia_ba_problem* problem, const theia_ba_options* 
   if (rc) return rc;
   const double t1 = now_s();
   rc = theia_hip_ba_run(h, summary);
+  const double t2 = now_s();
   if (!rc) rc = theia_hip_ba_download(h, const_cast<theia_ba_problem*>(problem));
+  const double t3 = now_s();
   summary->setup_time_in_seconds = t1 - t0;
   theia_hip_ba_destroy(h);
+  if (getenv("THEIA_HIP_CREATE_TIMING"))
+    fprintf(stderr, "theia_hip ba_solve: create %.2f ms, run %.2f ms, download %.2f ms, destroy %.2f ms\n", 1e3 * (t1 - t0), 1e3 * (t2 - t1),
+            1e3 * (t3 - t2), 1e3 * (now_s() - t3));
   return rc;
 }
 
