@@ -1267,7 +1267,8 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   tick("stream + events");
   // --- problem structure (bundle_adjuster.cc:116-221,357-380,477-527) ---
   std::vector<uint8_t> cam_used(h->nc, 0), pt_used(h->np, 0);
-  for (int64_t i = 0; i < h->nobs; ++i) { cam_used[p->obs_cam[i]] = 1; pt_used[p->obs_pt[i]] = 1; }
+  std::vector<uint8_t> grp_used(h->ng, 0);
+  for (int64_t i = 0; i < h->nobs; ++i) { cam_used[p->obs_cam[i]] = 1; pt_used[p->obs_pt[i]] = 1; grp_used[p->cam_group[p->obs_cam[i]]] = 1; }
   h->cam_red.assign(h->nc, -1); h->cam_mask.assign(h->nc, 0x3f); h->pt_const.assign(h->np, 1);
   h->ncv = 0;
   for (int c = 0; c < h->nc; ++c) {
@@ -1283,8 +1284,6 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   }
   // intrinsics blocks (bundle_adjuster.cc:382-460): constant when nothing is optimised
   // or the caller marked the group constant, otherwise a subset manifold
-  std::vector<uint8_t> grp_used(h->ng, 0);
-  for (int64_t i = 0; i < h->nobs; ++i) grp_used[p->cam_group[p->obs_cam[i]]] = 1;
   h->grp_red.assign(h->ng, -1); h->grp_free.assign(h->ng, 0u); h->grp_k.assign(h->ng, 0);
   h->ngv = 0;
   for (int g = 0; g < h->ng; ++g) {
@@ -1305,10 +1304,11 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   // are evaluated once ("fixed cost", ceres reduced program).
   std::vector<uint8_t> fixed(h->nobs, 0);
   std::vector<int> pkey(h->np, std::numeric_limits<int>::max());
+  std::vector<int> nvar(h->np, 0);   // variable cameras of a track (one pass over the observations for all three)
   for (int64_t i = 0; i < h->nobs; ++i) {
     const int rc = h->cam_red[p->obs_cam[i]];
     fixed[i] = (rc < 0 && h->grp_red[p->cam_group[p->obs_cam[i]]] < 0 && h->pt_const[p->obs_pt[i]]) ? 1 : 0;
-    if (rc >= 0 && rc < pkey[p->obs_pt[i]]) pkey[p->obs_pt[i]] = rc;
+    if (rc >= 0) { nvar[p->obs_pt[i]]++; if (rc < pkey[p->obs_pt[i]]) pkey[p->obs_pt[i]] = rc; }
   }
   std::vector<int> porder(h->np), prank(h->np);
   for (int q = 0; q < h->np; ++q) porder[q] = q;
@@ -1316,8 +1316,6 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   // kernel packs several short tracks into one wave step when a run of tracks touches few target blocks.
   std::vector<int> skey_pt(h->np);
   {
-    std::vector<int> nvar(h->np, 0);
-    for (int64_t i = 0; i < h->nobs; ++i) if (h->cam_red[p->obs_cam[i]] >= 0) nvar[p->obs_pt[i]]++;
     for (int q = 0; q < h->np; ++q) {
       // measured at 1k views / 500k tracks (K1 + K2 launch group): {<= 7 | >= 8} 0.575 ms, {<= 6 | >= 7} 0.599, {<= 5 | >= 6} 0.670,
       // {<= 8 | >= 9} 0.646, {<= 3 | 4..6 | >= 7} 0.636, one class 0.593
