@@ -257,6 +257,27 @@ int theia_hip_ba_views_batch(const theia_ba_view_batch* batch,
                              const theia_ba_options* options,
                              theia_ba_summary* summaries);
 
+/* A batch of INDEPENDENT two-view bundle adjustments: N calls of BundleAdjustTwoViews(options, correspondences,
+ * &camera1, &camera2, &points) (bundle_adjust_two_views.cc:110-185; the refinement step of
+ * TwoViewMatchGeometricVerification::VerifyMatches, two_view_match_geometric_verification.cc:259-289) as one launch, one
+ * LM solve per wavefront.  Camera 1 is held constant, camera 2 moves, the focal length of a camera moves unless
+ * const_intrinsics says otherwise (lower bound 1), the points move as XYZW vectors without a manifold; reprojection
+ * residuals in both views, trivial loss, Ceres' solver defaults as that function sets them (no inner iterations; pass
+ * max_trust_region_radius = 1e16).  Honoured options: max_num_iterations, the three tolerances,
+ * max_trust_region_radius.  The same arithmetic as theia_hip_ba_solve on the same flat problem. */
+typedef struct theia_ba_two_view_full_batch {
+  int32_t num_problems;
+  const int64_t* offsets;          /* [num_problems+1] correspondence offsets, offsets[0] = 0            */
+  const double* correspondences;   /* [total][4] = (x1, y1, x2, y2) pixels                                */
+  double* cam_ext;                 /* [num_problems][2][6]: camera 1 (constant), camera 2 (in/out)       */
+  double* intrinsics;              /* [num_problems][2][THEIA_MAX_INTRINSICS]; the focal lengths in/out  */
+  const int32_t* model;            /* [num_problems][2] THEIA_CAM_*                                      */
+  const uint8_t* const_intrinsics; /* [num_problems][2] 1 = the camera's focal length is held constant   */
+  double* points;                  /* [total][4] XYZW of every correspondence, in/out                    */
+} theia_ba_two_view_full_batch;
+int theia_hip_ba_two_views_batch(const theia_ba_two_view_full_batch* batch, const theia_ba_options* options,
+                                 theia_ba_summary* summaries);
+
 /* A batch of INDEPENDENT two-view angular adjustments: problem i refines the relative
  * rotation (angle-axis) and the unit position of view 2 against the angular epipolar
  * error of its correspondences [offsets[i], offsets[i+1]), i.e. N calls of

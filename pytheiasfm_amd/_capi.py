@@ -101,6 +101,15 @@ class BaTwoViewBatch(C.Structure):
     ]
 
 
+class BaTwoViewFullBatch(C.Structure):
+    """theia_ba_two_view_full_batch."""
+    _fields_ = [
+        ("num_problems", C.c_int32), ("offsets", C.POINTER(C.c_int64)), ("correspondences", c_double_p),
+        ("cam_ext", c_double_p), ("intrinsics", c_double_p), ("model", C.POINTER(C.c_int32)),
+        ("const_intrinsics", C.POINTER(C.c_uint8)), ("points", c_double_p),
+    ]
+
+
 class RansacParams(C.Structure):
     """theia_ransac_params."""
     _fields_ = [
@@ -138,7 +147,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
 # every symbol include/theia_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTED_SYMBOLS = [
     "theia_hip_init", "theia_hip_shutdown", "theia_hip_device_count", "theia_hip_last_error",
-    "theia_hip_version", "theia_ba_options_default", "theia_hip_ba_solve", "theia_hip_ba_views_batch", "theia_hip_ba_two_views_angular_batch", "theia_hip_optimize_homography_batch", "theia_hip_optimize_fundamental_matrix_batch", "theia_hip_ba_tracks_batch", "theia_hip_track_statistics", "theia_hip_ba_create",
+    "theia_hip_version", "theia_ba_options_default", "theia_hip_ba_solve", "theia_hip_ba_views_batch", "theia_hip_ba_two_views_angular_batch", "theia_hip_ba_two_views_batch", "theia_hip_optimize_homography_batch", "theia_hip_optimize_fundamental_matrix_batch", "theia_hip_ba_tracks_batch", "theia_hip_track_statistics", "theia_hip_ba_create",
     "theia_hip_ba_reset_parameters", "theia_hip_estimate_tracks", "theia_hip_ba_set_shard", "theia_hip_ba_snapshot_parameters", "theia_hip_ba_restore_parameters", "theia_hip_ba_set_options", "theia_hip_ba_run", "theia_hip_ba_download",
     "theia_hip_ba_destroy", "theia_hip_ba_covariance", "theia_hip_ba_evaluate", "theia_hip_ba_evaluate_ex", "theia_hip_ba_reduced_system",
     "theia_hip_ba_set_allreduce", "theia_hip_ba_plan_info", "theia_hip_rccl_unique_id", "theia_hip_rccl_comm_create",

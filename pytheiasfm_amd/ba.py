@@ -226,6 +226,33 @@ def solve_two_views_angular_batch(offsets, correspondences, rotation_position, o
     return [summ[i] for i in range(num)]
 
 
+def solve_two_views_batch(offsets, correspondences, cam_ext, intrinsics, model, const_intrinsics, points, options):
+    """theia_hip_ba_two_views_batch: N independent BundleAdjustTwoViews problems (bundle_adjust_two_views.cc:110-185) in one
+    launch.  correspondences [total][4] pixels; cam_ext [N][2][6] (camera 2 updated), intrinsics [N][2][10] (focal lengths
+    updated unless const_intrinsics [N][2]), model [N][2], points [total][4] XYZW (updated).  Returns a list of BaSummary."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    num = len(offsets) - 1
+    corr = np.ascontiguousarray(correspondences, dtype=np.float64).reshape(-1, 4)
+    model = np.ascontiguousarray(model, dtype=np.int32).reshape(num, 2)
+    kc = np.ascontiguousarray(const_intrinsics, dtype=np.uint8).reshape(num, 2)
+    for name, a, shape in (("cam_ext", cam_ext, (num, 2, 6)), ("intrinsics", intrinsics, (num, 2, capi.THEIA_MAX_INTRINSICS)),
+                           ("points", points, (corr.shape[0], 4))):
+        if not (a.flags["C_CONTIGUOUS"] and a.dtype == np.float64 and a.shape == shape):
+            raise capi.TheiaHipError(-1, f"{name} must be a C-contiguous float64 array of shape {shape} (updated in place)")
+    st = capi.BaTwoViewFullBatch()
+    st.num_problems = num
+    st.offsets = offsets.ctypes.data_as(C.POINTER(C.c_int64))
+    st.correspondences = capi.ptr(corr, C.c_double)
+    st.cam_ext = capi.ptr(cam_ext, C.c_double); st.intrinsics = capi.ptr(intrinsics, C.c_double)
+    st.model = capi.ptr(model, C.c_int32); st.const_intrinsics = capi.ptr(kc, C.c_uint8)
+    st.points = capi.ptr(points, C.c_double)
+    summ = (capi.BaSummary * max(1, num))()
+    L = capi.lib()
+    L.theia_hip_ba_two_views_batch.argtypes = [C.POINTER(capi.BaTwoViewFullBatch), C.POINTER(capi.BaOptions), C.POINTER(capi.BaSummary)]
+    capi.check(L.theia_hip_ba_two_views_batch(C.byref(st), C.byref(options), summ))
+    return [summ[i] for i in range(num)]
+
+
 def optimize_homography_batch(offsets, correspondences, homographies, options):
     """theia_hip_optimize_homography_batch: N independent OptimizeHomography problems (bundle_adjust_two_views.cc:298-358).
     homographies [N][3][3] (row-major) is updated in place (and divided by H(2,2)); returns a list of BaSummary."""

@@ -213,12 +213,54 @@ class TwoViewBundleAdjustmentOptions:  # bundle_adjust_two_views.h:52-57
         self.constant_camera2_intrinsics = True
 
 
-def BundleAdjustTwoViews(options, correspondences, camera1, camera2, points3d):
+def _two_view_ba_options(options):
+    from . import sfm as _sfm
+    o = _sfm.BundleAdjustmentOptions()          # Ceres' own defaults are the option defaults here
+    o.max_num_iterations = options.ba_options.max_num_iterations
+    o.use_homogeneous_point_parametrization = False
+    o.intrinsics_to_optimize = _sfm.OptimizeIntrinsicsType.FOCAL_LENGTH
+    o.use_inner_iterations = False
+    o.max_trust_region_radius = 1e16            # bundle_adjust_two_views.cc:61-72 leaves Ceres' default, not BundleAdjuster's 1e12
+    return o
+
+
+def BundleAdjustTwoViewsBatch(options_list, correspondences_list, cameras1, cameras2, points_list):
+    """N x BundleAdjustTwoViews as ONE launch (theia_hip_ba_two_views_batch, one LM solve per wavefront).  All pairs take
+    options_list[0].ba_options.max_num_iterations; cameras and points are updated in place.  Returns the summaries."""
+    from . import ba as _ba, sfm as _sfm
+    num = len(correspondences_list)
+    if num == 0:
+        return []
+    corr = [np.ascontiguousarray(c, dtype=np.float64).reshape(-1, 4) for c in correspondences_list]
+    offsets = np.zeros(num + 1, dtype=np.int64); offsets[1:] = np.cumsum([len(c) for c in corr])
+    cam_ext = np.zeros((num, 2, 6)); intr = np.zeros((num, 2, capi.THEIA_MAX_INTRINSICS))
+    model = np.zeros((num, 2), np.int32); kconst = np.zeros((num, 2), np.uint8)
+    for i in range(num):
+        pts = points_list[i]
+        if not (isinstance(pts, np.ndarray) and pts.dtype == np.float64 and pts.shape == (len(corr[i]), 4) and pts.flags["C_CONTIGUOUS"]):
+            raise capi.TheiaHipError(capi.THEIA_HIP_ERR_INVALID_ARGUMENT, "points3d must be a C-contiguous float64 [N][4] array, one per correspondence")
+        for k, cam in enumerate((cameras1[i], cameras2[i])):
+            cam_ext[i, k] = cam["ext"]; v = np.asarray(cam["intr"], dtype=np.float64); intr[i, k, :len(v)] = v; model[i, k] = int(cam["model"])
+        kconst[i] = (int(bool(options_list[i].constant_camera1_intrinsics)), int(bool(options_list[i].constant_camera2_intrinsics)))
+    allpts = np.ascontiguousarray(np.concatenate(points_list, axis=0))
+    summ = _ba.solve_two_views_batch(offsets, np.concatenate(corr, axis=0), cam_ext, intr, model, kconst, allpts,
+                                     _two_view_ba_options(options_list[0]).to_c())
+    for i in range(num):
+        cameras2[i]["ext"][:] = cam_ext[i, 1]
+        cameras1[i]["intr"][:] = intr[i, 0][:len(cameras1[i]["intr"])]; cameras2[i]["intr"][:] = intr[i, 1][:len(cameras2[i]["intr"])]
+        points_list[i][:] = allpts[offsets[i]:offsets[i + 1]]
+    return [_sfm.BundleAdjustmentSummary(s) for s in summ]
+
+
+def BundleAdjustTwoViews(options, correspondences, camera1, camera2, points3d, batched=True):
     """bundle_adjust_two_views.cc:110-185: camera 1 fixed, camera 2's six extrinsics and (unless held constant) the two
     focal lengths free, every triangulated point a free XYZW 4-vector, no loss function; its own SetSolverOptions
     (:60-72) takes only max_num_iterations from the options.  camera = dict(ext[6], intr[<=10], model); both cameras
-    and points3d [N][4] are updated in place.  One theia_hip_ba_solve."""
+    and points3d [N][4] are updated in place.  batched (default): a batch of one through theia_hip_ba_two_views_batch;
+    batched=False: theia_hip_ba_solve on the flat problem (the same arithmetic; the parity tests compare the two)."""
     from . import ba as _ba, sfm as _sfm
+    if batched:
+        return BundleAdjustTwoViewsBatch([options], [correspondences], [camera1], [camera2], [points3d])[0]
     c = np.ascontiguousarray(correspondences, dtype=np.float64).reshape(-1, 4)
     n = c.shape[0]
     pts = points3d
@@ -234,12 +276,7 @@ def BundleAdjustTwoViews(options, correspondences, camera1, camera2, points3d):
                             np.concatenate([np.arange(n), np.arange(n)]).astype(np.int32),
                             cam_const=[3, 0],
                             group_const=[int(bool(options.constant_camera1_intrinsics)), int(bool(options.constant_camera2_intrinsics))])
-    o = _sfm.BundleAdjustmentOptions()          # Ceres' own defaults are the option defaults here
-    o.max_num_iterations = options.ba_options.max_num_iterations
-    o.use_homogeneous_point_parametrization = False
-    o.intrinsics_to_optimize = _sfm.OptimizeIntrinsicsType.FOCAL_LENGTH
-    o.use_inner_iterations = False
-    o.max_trust_region_radius = 1e16            # bundle_adjust_two_views.cc:61-72 leaves Ceres' default, not BundleAdjuster's 1e12
+    o = _two_view_ba_options(options)
     s, _ = _ba.solve(flat, o.to_c())
     camera1["ext"][:] = flat.cam_ext[0]; camera2["ext"][:] = flat.cam_ext[1]
     camera1["intr"][:] = flat.intrinsics[0][:len(camera1["intr"])]; camera2["intr"][:] = flat.intrinsics[1][:len(camera2["intr"])]
@@ -294,12 +331,50 @@ def _per_view_reprojection(cams, corr, pts):
     return err.reshape(2, n), behind.reshape(2, n)
 
 
+def _pairs_flat(cams_list, corr_list, pts_list, one_track_per_view):
+    """The pairs of a batch as ONE flat problem (cameras 2 i and 2 i + 1, one intrinsics group per camera): per pair first
+    the observations of camera 1, then those of camera 2.  one_track_per_view: every (point, view) is its own track (the
+    per-view statistics); otherwise a point is one track seen by both cameras (triangulation)."""
+    num = len(corr_list)
+    cam_ext = np.zeros((2 * num, 6)); intr = np.zeros((2 * num, capi.THEIA_MAX_INTRINSICS))
+    for i, cams in enumerate(cams_list):
+        for k in range(2):
+            cam_ext[2 * i + k] = cams[k]["ext"]; intr[2 * i + k, :7] = cams[k]["intr"]
+    ns = [len(c) for c in corr_list]
+    uv = np.concatenate([np.concatenate([c[:, 0:2], c[:, 2:4]]) for c in corr_list])
+    ocam = np.concatenate([np.concatenate([np.full(n, 2 * i, np.int32), np.full(n, 2 * i + 1, np.int32)]) for i, n in enumerate(ns)])
+    if one_track_per_view:
+        pts = np.concatenate([np.concatenate([p, p]) for p in pts_list])
+        opt = np.arange(2 * sum(ns), dtype=np.int32)
+    else:
+        pts = np.zeros((sum(ns), 4)) if pts_list is None else np.concatenate(pts_list)
+        base = np.concatenate([[0], np.cumsum(ns)[:-1]])
+        opt = np.concatenate([np.concatenate([b + np.arange(n), b + np.arange(n)]) for b, n in zip(base, ns)]).astype(np.int32)
+    flat = capi.FlatProblem(cam_ext, intr, np.zeros(2 * num, np.int32), np.arange(2 * num, dtype=np.int32), np.ascontiguousarray(pts),
+                            uv, ocam, opt)
+    return flat, ns
+
+
+def _per_view_reprojection_batch(cams_list, corr_list, pts_list):
+    """_per_view_reprojection of every pair in ONE theia_hip_track_statistics call: a list of (err [2][n], behind [2][n])."""
+    from . import ba as _ba
+    if not corr_list:
+        return []
+    flat, ns = _pairs_flat(cams_list, corr_list, pts_list, True)
+    err, behind, _ = _ba.track_statistics(flat)
+    out, o = [], 0
+    for n in ns:
+        out.append((err[o:o + 2 * n].reshape(2, n), behind[o:o + 2 * n].reshape(2, n)))
+        o += 2 * n
+    return out
+
+
 def VerifyMatchesBatch(options, priors1, priors2, correspondences_list):
     """TwoViewMatchGeometricVerification::VerifyMatches (two_view_match_geometric_verification.cc:114-183) for a list of
     image pairs given as pixel correspondences [(x1, y1, x2, y2)] (the reference indexes keypoint lists).  Returns a
     list of (success, TwoViewInfo, verified_indices).  The homography count (:331-368) and EstimateTwoViewInfo run as
-    two RANSAC batches over all pairs, triangulation and the reprojection filters as device sweeps, the two-view BA as
-    one solve per pair.  Guided matching needs descriptors and is not built.  Stated deviation: the reference draws the
+    two RANSAC batches over all pairs, triangulation and the reprojection filters as device sweeps, the two-view BA of all
+    pairs as one launch (theia_hip_ba_two_views_batch).  Guided matching needs descriptors and is not built.  Stated deviation: the reference draws the
     homography and the relative-pose samples from ONE generator in sequence; here both batches start from `seed`."""
     from . import ba as _ba
     if options.guided_matching:
@@ -319,6 +394,7 @@ def VerifyMatchesBatch(options, priors1, priors2, correspondences_list):
     offsets[1:] = np.cumsum([len(corr[i]) for i in live])
     hres = _ransac.estimate_batch(_ransac.EST_HOMOGRAPHY, np.concatenate([corr[i] for i in live]), offsets, hp, seeds=[eo.seed] * len(live))
     tv = EstimateTwoViewInfoBatch(eo, [priors1[i] for i in live], [priors2[i] for i in live], [corr[i] for i in live])
+    cand = []   # pairs that go through the two-view BA: [i, info, idx, c, cams]
     for k, i in enumerate(live):
         ok, info, inliers = tv[k]
         info.num_homography_inliers = int(hres["num_inliers"][k])
@@ -326,39 +402,48 @@ def VerifyMatchesBatch(options, priors1, priors2, correspondences_list):
             results[i] = (False, info, [])
             continue
         idx = np.asarray(inliers, dtype=np.int64)
-        c = corr[i][idx]
         if options.bundle_adjustment and len(idx) > options.min_num_inlier_matches:
-            cams = _setup_cameras(priors1[i], priors2[i], info)
-            # TriangulatePoints (:186-257): angle test, midpoint, both reprojection errors below the threshold
-            rays = np.concatenate([_rays(cams[0], c[:, 0:2]), _rays(cams[1], c[:, 2:4])])
-            m = len(idx)
-            intr = np.zeros((2, capi.THEIA_MAX_INTRINSICS)); intr[0, :7] = cams[0]["intr"]; intr[1, :7] = cams[1]["intr"]
-            flat = capi.FlatProblem(np.array([cams[0]["ext"], cams[1]["ext"]]), intr, [0, 0], [0, 1], np.zeros((m, 4)),
-                                    np.concatenate([c[:, 0:2], c[:, 2:4]]),
-                                    np.concatenate([np.zeros(m, np.int32), np.ones(m, np.int32)]),
-                                    np.concatenate([np.arange(m), np.arange(m)]).astype(np.int32))
-            est, _ = _ba.estimate_tracks(flat, rays, _ba.default_options(), options.min_triangulation_angle_degrees, 1e150, False)
-            err, behind = _per_view_reprojection(cams, c, flat.points)
-            lim = options.triangulation_max_reprojection_error ** 2
-            keep = est & (behind.sum(0) == 0) & (err[0] < lim) & (err[1] < lim)
-            idx, c, pts = idx[keep], c[keep], np.ascontiguousarray(flat.points[keep])
+            cand.append([i, info, idx, corr[i][idx], _setup_cameras(priors1[i], priors2[i], info)])
+            continue
+        info.num_verified_matches = len(idx)
+        results[i] = (len(idx) > options.min_num_inlier_matches, info, idx.tolist())
+    todo = []   # (i, info, idx, c, pts, cams, options) of the pairs that reach BundleAdjustTwoViews
+    if cand:
+        # TriangulatePoints (:186-257) of all pairs as one device sweep: angle test, midpoint; then both reprojection
+        # errors below the threshold (one statistics sweep)
+        flat, ns = _pairs_flat([t[4] for t in cand], [t[3] for t in cand], None, False)
+        rays = np.concatenate([np.concatenate([_rays(t[4][0], t[3][:, 0:2]), _rays(t[4][1], t[3][:, 2:4])]) for t in cand])
+        est, _ = _ba.estimate_tracks(flat, rays, _ba.default_options(), options.min_triangulation_angle_degrees, 1e150, False)
+        bounds = np.concatenate([[0], np.cumsum(ns)])
+        pts_all = [np.ascontiguousarray(flat.points[bounds[j]:bounds[j + 1]]) for j in range(len(cand))]
+        stats = _per_view_reprojection_batch([t[4] for t in cand], [t[3] for t in cand], pts_all)
+        lim = options.triangulation_max_reprojection_error ** 2
+        for j, (i, info, idx, c, cams) in enumerate(cand):
+            err, behind = stats[j]
+            keep = est[bounds[j]:bounds[j + 1]] & (behind.sum(0) == 0) & (err[0] < lim) & (err[1] < lim)
+            idx, c, pts = idx[keep], c[keep], np.ascontiguousarray(pts_all[j][keep])
             if len(idx) < options.min_num_inlier_matches:          # :271-273
                 results[i] = (False, info, [])
                 continue
             bo = TwoViewBundleAdjustmentOptions()
             bo.constant_camera1_intrinsics = priors1[i].focal_length.is_set
             bo.constant_camera2_intrinsics = priors2[i].focal_length.is_set
-            summ = BundleAdjustTwoViews(bo, c, cams[0], cams[1], pts)
-            if not summ.success:
-                results[i] = (False, info, [])
-                continue
-            err, behind = _per_view_reprojection(cams, c, pts)
-            lim = options.final_max_reprojection_error ** 2
-            keep = (behind.sum(0) == 0) & (err[0] < lim) & (err[1] < lim)
-            idx = idx[keep]
-            info.rotation_2 = cams[1]["ext"][3:6].copy()
-            info.position_2 = cams[1]["ext"][0:3] / np.linalg.norm(cams[1]["ext"][0:3])
-            info.focal_length_1 = float(cams[0]["intr"][0]); info.focal_length_2 = float(cams[1]["intr"][0])
+            todo.append((i, info, idx, c, pts, cams, bo))
+    # BundleAdjustTwoViews of every surviving pair as ONE launch (one LM solve per wavefront), then the final filter
+    summs = BundleAdjustTwoViewsBatch([t[6] for t in todo], [t[3] for t in todo], [t[5][0] for t in todo], [t[5][1] for t in todo],
+                                      [t[4] for t in todo])
+    good = [t for t, sm in zip(todo, summs) if sm.success]
+    for t, sm in zip(todo, summs):
+        if not sm.success:
+            results[t[0]] = (False, t[1], [])
+    stats = _per_view_reprojection_batch([t[5] for t in good], [t[3] for t in good], [t[4] for t in good])
+    lim = options.final_max_reprojection_error ** 2
+    for (i, info, idx, c, pts, cams, bo), (err, behind) in zip(good, stats):
+        keep = (behind.sum(0) == 0) & (err[0] < lim) & (err[1] < lim)
+        idx = idx[keep]
+        info.rotation_2 = cams[1]["ext"][3:6].copy()
+        info.position_2 = cams[1]["ext"][0:3] / np.linalg.norm(cams[1]["ext"][0:3])
+        info.focal_length_1 = float(cams[0]["intr"][0]); info.focal_length_2 = float(cams[1]["intr"][0])
         info.num_verified_matches = len(idx)
         results[i] = (len(idx) > options.min_num_inlier_matches, info, idx.tolist())
     return results
