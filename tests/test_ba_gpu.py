@@ -1044,22 +1044,25 @@ def test_bundle_adjust_two_views_mirror_matches_oracle():
 
 def test_two_view_ba_batch_matches_the_general_solver():
     """theia_hip_ba_two_views_batch = N x BundleAdjustTwoViews (bundle_adjust_two_views.cc:110-185), one LM per wavefront:
-    every pair against theia_hip_ba_solve on the same flat problem (the mirror's per-pair path), which the oracle pins."""
+    every pair of a ragged batch (8 .. 130 points, focal lengths free / constant in every combination) against
+    theia_hip_ba_solve on the same flat problem (the mirror's per-pair path), which the oracle pins."""
     from pytheiasfm_amd import twoview as tv
-    npairs, n = 6, 90
-    data, offsets, truth = synth.synth_ransac_v1(npairs, n, "fundamental", seed=0x5AC52800, inlier_lo=1.0, inlier_hi=1.0, noise_px=0.5)
+    ns = [90, 40, 130, 64, 65, 8]
+    npairs = len(ns)
+    data, offsets, truth = synth.synth_ransac_v1(npairs, 130, "fundamental", seed=0x5AC52800, inlier_lo=1.0, inlier_hi=1.0, noise_px=0.5)
+    off = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
     cam_ext = np.zeros((npairs, 2, 6)); intr = np.zeros((npairs, 2, capi.THEIA_MAX_INTRINSICS))
-    pts = np.zeros((npairs * n, 4)); kconst = np.zeros((npairs, 2), np.uint8)
+    pts = np.zeros((off[-1], 4)); kconst = np.zeros((npairs, 2), np.uint8); allc = np.zeros((off[-1], 4))
     ref = []
-    for i in range(npairs):
-        corr = data[offsets[i]:offsets[i + 1]]
+    for i, n in enumerate(ns):
+        corr = data[offsets[i]:offsets[i] + n]
         ext2 = np.concatenate([truth["position"][i] + 0.01, synth.matrix_to_angle_axis(truth["R"][i]) + 0.004])
         depth = 6.0 + 0.3 * np.sin(np.arange(n) + i)
         x1 = (corr[:, :2] - np.array([500.0, 400.0])) / 1000.0
         p3 = np.column_stack([x1 * depth[:, None], depth, np.ones(n)])
         const = (i % 2 == 0, i % 3 == 0)
         cam_ext[i, 1] = ext2; intr[i, 0, :5] = [1000.0, 1, 0, 500, 400]; intr[i, 1, :5] = [1010.0, 1, 0, 500, 400]
-        pts[i * n:(i + 1) * n] = p3; kconst[i] = const
+        pts[off[i]:off[i + 1]] = p3; kconst[i] = const; allc[off[i]:off[i + 1]] = corr
         cam1 = {"ext": np.zeros(6), "intr": np.array([1000.0, 1, 0, 500, 400, 0, 0]), "model": 0}
         cam2 = {"ext": ext2.copy(), "intr": np.array([1010.0, 1, 0, 500, 400, 0, 0]), "model": 0}
         q3 = np.ascontiguousarray(p3.copy())
@@ -1068,7 +1071,7 @@ def test_two_view_ba_batch_matches_the_general_solver():
         summ = tv.BundleAdjustTwoViews(bo, corr, cam1, cam2, q3, batched=False)
         ref.append((summ, cam2["ext"].copy(), cam1["intr"][0], cam2["intr"][0], q3))
     o = ba.default_options(); o.max_num_iterations = 20; o.max_trust_region_radius = 1e16; o.use_inner_iterations = 0
-    out = ba.solve_two_views_batch(offsets, data, cam_ext, intr, np.zeros((npairs, 2), np.int32), kconst, pts, o)
+    out = ba.solve_two_views_batch(off, allc, cam_ext, intr, np.zeros((npairs, 2), np.int32), kconst, pts, o)
     for i in range(npairs):
         s, (rs, ext2, f1, f2, q3) = out[i], ref[i]
         assert s.success == rs.success and s.num_iterations == rs.num_iterations, (i, s.num_iterations, rs.num_iterations)
@@ -1076,4 +1079,14 @@ def test_two_view_ba_batch_matches_the_general_solver():
         assert np.abs(cam_ext[i, 1] - ext2).max() <= 1e-7 and np.array_equal(cam_ext[i, 0], np.zeros(6))
         assert rel(intr[i, 0, 0], f1) <= 1e-8 and rel(intr[i, 1, 0], f2) <= 1e-8
         assert (intr[i, 0, 0] == 1000.0) == bool(kconst[i, 0]) and (intr[i, 1, 0] == 1010.0) == bool(kconst[i, 1])
-        assert rel(pts[i * n:(i + 1) * n], q3) <= 1e-6
+        assert rel(pts[off[i]:off[i + 1]], q3) <= 1e-6
+    # a point behind camera 1 at the start: the functor fails, the pair's solve reports failure like the general solver
+    bad = pts[:ns[0]].copy(); bad[3, 2] = -5.0
+    ce = cam_ext[:1].copy(); ki = intr[:1].copy()
+    sb = ba.solve_two_views_batch(np.array([0, ns[0]]), allc[:ns[0]], ce, ki, np.zeros((1, 2), np.int32), kconst[:1], bad, o)[0]
+    q = bad.copy(); q[:] = pts[:ns[0]]; q[3, 2] = -5.0
+    cam1 = {"ext": np.zeros(6), "intr": ki[0, 0, :7].copy(), "model": 0}; cam2 = {"ext": ce[0, 1].copy(), "intr": ki[0, 1, :7].copy(), "model": 0}
+    bo = tv.TwoViewBundleAdjustmentOptions(); bo.constant_camera1_intrinsics = bool(kconst[0, 0]); bo.constant_camera2_intrinsics = bool(kconst[0, 1])
+    bo.ba_options.max_num_iterations = 20
+    rsb = tv.BundleAdjustTwoViews(bo, allc[:ns[0]], cam1, cam2, np.ascontiguousarray(q), batched=False)
+    assert bool(sb.success) == bool(rsb.success)
