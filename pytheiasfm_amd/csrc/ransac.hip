@@ -683,14 +683,10 @@ __global__ __launch_bounds__(64) void k_sqp_c(int nprob, int B, const int* __res
   const size_t hyp = (size_t)p * B + b;
   if (b >= active_iters[p] || !ok[hyp]) { counts[hyp] = 0; return; }
   const double* w = ws + hyp * kSqWs;
-  double Om[81], P[27], mean[3], U[81], S[9];
-  for (int k = 0; k < 81; ++k) Om[k] = w[k];
-  for (int k = 0; k < 27; ++k) P[k] = w[81 + k];
-  for (int k = 0; k < 3; ++k) mean[k] = w[108 + k];
-  for (int k = 0; k < 81; ++k) U[k] = w[111 + k];
-  for (int k = 0; k < 9; ++k) S[k] = w[192 + k];
   double quats[72], ts[54];
-  const int nm = rsc::sqpnp_post(Om, P, mean, U, S, quats, ts);
+  // Omega, P, the centroid, U and S are read where they lie (201 doubles of the workspace row): copies in per-lane arrays
+  // would double the scratch frame of this kernel
+  const int nm = rsc::sqpnp_post(w, w + 81, w + 108, w + 111, w + 192, quats, ts);
   counts[hyp] = nm;
   if (nm == 0) return;
   constexpr int mm = 18;   // max_models(THEIA_EST_ABSOLUTE_POSE_SQPNP)
