@@ -234,3 +234,33 @@ def test_select_good_tracks_rules():
     # K larger than the view: everything estimated in it
     sel = sfm._select_good_tracks(r, [0], tlen, terr, 4, 100, 50)
     assert sel.tolist() == [0, 1, 2, 3, 4, 5]
+
+
+def test_pairs_of_a_verification_batch_as_one_flat_problem():
+    """twoview._pairs_flat: the pairs of VerifyMatchesBatch as ONE flat problem for the triangulation and the per-view
+    statistics sweeps -- cameras 2 i / 2 i + 1, per pair the observations of camera 1 then of camera 2, a point either
+    one track seen twice or one track per view.  Pure host logic (no device call)."""
+    from pytheiasfm_amd import twoview as tv
+    rng = np.random.default_rng(5)
+    ns = [7, 3, 11]
+    corr = [rng.normal(size=(n, 4)) for n in ns]
+    pts = [rng.normal(size=(n, 4)) for n in ns]
+    cams = [[{"ext": rng.normal(size=6), "intr": np.array([900.0 + 10 * i + k, 1, 0, 500, 400, 0, 0]), "model": 0} for k in range(2)]
+            for i in range(3)]
+    flat, got = tv._pairs_flat(cams, corr, pts, False)
+    assert got == ns and flat.cam_ext.shape == (6, 6) and flat.points.shape == (sum(ns), 4) and flat.obs_uv.shape == (2 * sum(ns), 2)
+    base = 0
+    o = 0
+    for i, n in enumerate(ns):
+        assert np.array_equal(flat.cam_ext[2 * i], cams[i][0]["ext"]) and flat.intrinsics[2 * i + 1, 0] == cams[i][1]["intr"][0]
+        assert np.array_equal(flat.obs_cam[o:o + n], np.full(n, 2 * i)) and np.array_equal(flat.obs_cam[o + n:o + 2 * n], np.full(n, 2 * i + 1))
+        assert np.array_equal(flat.obs_pt[o:o + n], base + np.arange(n)) and np.array_equal(flat.obs_pt[o + n:o + 2 * n], base + np.arange(n))
+        assert np.array_equal(flat.obs_uv[o:o + n], corr[i][:, 0:2]) and np.array_equal(flat.obs_uv[o + n:o + 2 * n], corr[i][:, 2:4])
+        assert np.array_equal(flat.points[base:base + n], pts[i])
+        base += n; o += 2 * n
+    flat2, _ = tv._pairs_flat(cams, corr, pts, True)
+    assert flat2.points.shape == (2 * sum(ns), 4) and np.array_equal(flat2.obs_pt, np.arange(2 * sum(ns)))
+    assert np.array_equal(flat2.points[:ns[0]], pts[0]) and np.array_equal(flat2.points[ns[0]:2 * ns[0]], pts[0])
+    assert np.array_equal(flat2.obs_cam, flat.obs_cam) and np.array_equal(flat2.cam_group, np.arange(6))
+    empty, _ = tv._pairs_flat(cams, corr, None, False)
+    assert empty.points.shape == (sum(ns), 4) and not empty.points.any()
