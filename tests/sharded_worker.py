@@ -1,0 +1,61 @@
+"""Worker of tests/test_distributed_gpu.py::test_sharded_solve_two_ranks_on_one_gpu: one rank of a world_size-2 sharded BA
+solve.  Both ranks share cuda:0 (RCCL refuses two ranks on one device), so the all-reduce callback goes through the
+host with gloo: device buffer -> host, dist.all_reduce, host -> device, all on the library's stream.  Everything else
+-- the track shards, the packed reduced system, the per-rank slots of the gradient maximum, the device-side step control
+over collectives -- is the product path of a two-GPU run.  Prints one JSON line."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from pytheiasfm_amd import ba, distributed as tdist, synth
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    streams, views = {}, {}
+
+    def allreduce(ptr, count, op, stream):
+        t = views.get((ptr, count))
+        if t is None:
+            t = torch.as_tensor(tdist._DevArray(ptr, count), device=torch.device("cuda", 0)); views[(ptr, count)] = t
+        ext = streams.get(stream)
+        if ext is None:
+            ext = torch.cuda.ExternalStream(stream, device=torch.device("cuda", 0)); streams[stream] = ext
+        with torch.cuda.stream(ext):
+            host = t.cpu()                      # waits for the work enqueued on the library's stream so far
+            dist.all_reduce(host, op=dist.ReduceOp.MAX if op == tdist.REDUCE_MAX else dist.ReduceOp.SUM)
+            t.copy_(host)                       # enqueued on the same stream, ahead of what the library enqueues next
+        return 0
+
+    mixed = bool(int(os.environ.get("SHARD_MIXED", "0")))
+    p = synth.synth_ba_v1(24, 1500, seed=0x5AD00 + int(mixed), mixed_models=mixed)
+    o = ba.default_options(); o.use_inner_iterations = 0; o.max_num_iterations = 12
+    ref = p.copy()
+    s0, tr0 = ba.solve(ref, o)
+    shard, ids = synth.shard_tracks(p, rank, world)
+    with ba.BaHandle(shard, o) as h:
+        h.set_allreduce(allreduce)
+        h.set_shard(rank, world)
+        s, tr = h.run()
+        out = h.download(shard.copy())
+    res = {
+        "rank": rank, "iterations": int(s.num_iterations), "ref_iterations": int(s0.num_iterations),
+        "final_cost": float(s.final_cost), "ref_final_cost": float(s0.final_cost),
+        "cam_err": float(np.abs(out.cam_ext - ref.cam_ext).max()),
+        "pts_err": float(np.abs(out.points - ref.points[ids]).max()),
+        "trace_cost_err": float(np.abs(np.asarray(tr.cost)[:tr.size] - np.asarray(tr0.cost)[:tr0.size]).max() / s0.initial_cost) if tr.size == tr0.size else 1.0,
+        "tracks": int(len(ids)),
+    }
+    print("RESULT " + json.dumps(res), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
