@@ -100,6 +100,33 @@ def pmc_traffic_bytes(world):
         return None
 
 
+def mfma_util(levels, solve_s):
+    """MFMA busy cycles of one K3 solve (committed counter pass: per-launch means x launches per solve) over the cycles
+    the chip's 1024 SIMDs offer in the measured solve time at 2.1 GHz."""
+    m = mfma_busy_cycles()
+    if not m or solve_s <= 0 or levels <= 0:
+        return None
+    busy = levels * (m["k_sp_potrf"] + m["k_sp_trsm"]) + max(0, levels - 1) * m["k_sp_update"]
+    return {"busy_cycles_per_solve": busy, "frac": busy / (1024 * 2.1e9 * solve_s),
+            "source": "profiles/%s_sq_counters.txt (SQ_VALU_MFMA_BUSY_CYCLES per launch) x launches per solve / (1024 SIMDs x 2.1 GHz x solve time)" % PROFILE_TAG}
+
+
+def mfma_busy_cycles():
+    """SQ_VALU_MFMA_BUSY_CYCLES per launch of the K3 kernels from the committed counter pass of this command
+    (profiles/<tag>_sq_counters.txt, `scripts/pmc_kernel.sh "SQ_VALU_MFMA_BUSY_CYCLES ..."`), or None."""
+    import ast
+    out = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "%s_sq_counters.txt" % PROFILE_TAG)) as f:
+            for line in f:
+                for k in ("k_sp_potrf", "k_sp_trsm", "k_sp_update"):
+                    if line.startswith(k + " {") and "SQ_VALU_MFMA_BUSY_CYCLES" in line:
+                        out[k] = float(ast.literal_eval(line[len(k) + 1:].strip())["SQ_VALU_MFMA_BUSY_CYCLES"])
+    except (OSError, ValueError, SyntaxError, KeyError):
+        return None
+    return out if len(out) == 3 else None
+
+
 class BaRunner:
     """K LM iterations as ceil(K / ITERS_PER_SOLVE) solves, each from the device-resident perturbed start."""
 
@@ -350,7 +377,8 @@ def main():
                             "bound": "mfma", "achieved": info["k3_flops"] / k3_s / 1e12 if k3_s > 0 else 0.0,
                             "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": (info["k3_flops"] / k3_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if k3_s > 0 else 0.0,
-                            "flops_per_solve": info["k3_flops"], "avg_solve_ms": 1e3 * k3_s},
+                            "flops_per_solve": info["k3_flops"], "avg_solve_ms": 1e3 * k3_s,
+                            "mfma_utilisation": mfma_util(info["k3_levels"], k3_s)},
             "phase_ms_per_iteration": {"linearize_schur": 1e3 * acc["lin"] / nl, "reduced_solve": 1e3 * acc["solve"] / nl,
                                        "backsub_trial_cost": 1e3 * acc["backsub"] / nl},
         }
