@@ -28,6 +28,7 @@
 #include "ba_kernels.h"
 #include "theia_hip.h"
 #include "theia_hip_internal.h"
+#include "pools.h"
 
 namespace thip {
 
@@ -58,25 +59,35 @@ static double now_s() {
 
 template <typename T>
 struct DevBuf {
+  // Blocks come from the library's device cache (pools.h): creating a handle makes ~80 allocations, and at a million
+  // observations hipMalloc + hipFree were ~15 ms of a 100 ms create().  A cached block is handed out without a device
+  // synchronisation, so the owner makes sure no kernel still uses a buffer when it goes back (the handle's destructor
+  // waits for its stream; a re-allocation waits for the device).
   T* p = nullptr;
-  size_t n = 0;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  size_t n = 0, bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) dev_pool().give(p, bytes); }
   int alloc(size_t count) {
-    if (p) { (void)hipFree(p); p = nullptr; }
+    if (p) { (void)hipDeviceSynchronize(); dev_pool().give(p, bytes); p = nullptr; bytes = 0; }
     n = count;
     if (count == 0) return 0;
-    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
-    if (e != hipSuccess) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    size_t got = 0;
+    p = static_cast<T*>(dev_pool().take(std::max<size_t>(count * sizeof(T), 256), &got));
+    if (!p) { n = 0; return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", count * sizeof(T)); }
+    bytes = got;
     return 0;
   }
-  int upload(const std::vector<T>& h, hipStream_t st) {
-    int rc = alloc(h.size());
+  int upload(const std::vector<T>& h, hipStream_t st) { return upload(h.data(), h.size(), st, false); }
+  // pinned = the source is a pinned block that outlives the copy (the caller synchronises the stream before it lets go)
+  int upload(const T* src, size_t count, hipStream_t st, bool pinned) {
+    int rc = alloc(count);
     if (rc) return rc;
-    // The source is a (usually temporary) pageable vector: the copy must have left it before upload() returns
-    // (large pageable sources are pinned and read by the DMA engine later, not staged at the call).
-    if (!h.empty()) {
-      HIP_TRY(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
-      HIP_TRY(hipStreamSynchronize(st));
+    // A pageable source (usually a temporary vector) must have been read before upload() returns.
+    if (count) {
+      HIP_TRY(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, st));
+      if (!pinned) HIP_TRY(hipStreamSynchronize(st));
     }
     return 0;
   }
@@ -171,6 +182,7 @@ struct theia_ba_handle_s {
   int n_pack_tiles = 0;
 
   ~theia_ba_handle_s() {
+    if (stream) (void)hipStreamSynchronize(stream);   // the buffers below go back to the device cache, not to hipFree
     drop_graph();
     if (plan) chol_plan_destroy(plan);
     for (auto& row : ev) for (auto& e : row) if (e) (void)hipEventDestroy(e);
@@ -720,7 +732,7 @@ void theia_ba_options_default(theia_ba_options* o) {
 #define AL(buf, cnt) do { rc = h->buf.alloc(cnt); if (rc) return rc; } while (0)
 // Static gather lists of the Schur assembly without intrinsics (k_lin_obs / k_schur); see create().
 // with_pairs = false (fused Schur assembly): only the per-camera observation lists the column-norm pass uses.
-int build_gather_lists(theia_ba_handle_s* h, const std::vector<int>& ocam, const std::vector<int>& opt,
+int build_gather_lists(theia_ba_handle_s* h, const int* ocam, const int* opt,
                        const std::vector<int>& l_obs, bool with_pairs = true) {
   int rc = 0;
   hipStream_t st = h->stream;
@@ -861,8 +873,8 @@ int build_gather_lists(theia_ba_handle_s* h, const std::vector<int>& ocam, const
 }
 
 // The gather lists when intrinsics are optimised (k_lin_obs_intr / k_schur_intr); see create().
-int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, const std::vector<int>& ocam,
-                            const std::vector<int>& opt, const std::vector<int>& l_obs) {
+int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, const int* ocam,
+                            const int* opt, const std::vector<int>& l_obs) {
   int rc = 0;
   hipStream_t st = h->stream;
   // Gather lists with intrinsics (k_lin_obs_intr / k_schur_intr): records for every observation whose camera OR
@@ -1268,7 +1280,16 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   // --- problem structure (bundle_adjuster.cc:116-221,357-380,477-527) ---
   std::vector<uint8_t> cam_used(h->nc, 0), pt_used(h->np, 0);
   std::vector<uint8_t> grp_used(h->ng, 0);
-  for (int64_t i = 0; i < h->nobs; ++i) { cam_used[p->obs_cam[i]] = 1; pt_used[p->obs_pt[i]] = 1; grp_used[p->cam_group[p->obs_cam[i]]] = 1; }
+  {   // cameras with observations: flags per host thread, merged (the tracks' flags come with the key pass below)
+    std::mutex mu;
+    host_chunks(h->nobs, [&](int64_t i0, int64_t i1) {
+      std::vector<uint8_t> mine(h->nc, 0);
+      for (int64_t i = i0; i < i1; ++i) mine[p->obs_cam[i]] = 1;
+      std::lock_guard<std::mutex> lk(mu);
+      for (int c = 0; c < h->nc; ++c) cam_used[c] |= mine[c];
+    });
+    for (int c = 0; c < h->nc; ++c) if (cam_used[c]) grp_used[p->cam_group[c]] = 1;
+  }
   h->cam_red.assign(h->nc, -1); h->cam_mask.assign(h->nc, 0x3f); h->pt_const.assign(h->np, 1);
   h->ncv = 0;
   for (int c = 0; c < h->nc; ++c) {
@@ -1295,7 +1316,6 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   }
   h->ni = THEIA_MAX_INTRINSICS * h->ngv;
   h->n = h->ni + 6 * h->ncv;
-  for (int q = 0; q < h->np; ++q) h->pt_const[q] = ((p->point_const && p->point_const[q]) || !pt_used[q]) ? 1 : 0;
 
   // Tracks are visited in the order of their first (lowest) variable camera of
   // the reduced ordering, so that a workgroup's tile range touches a short
@@ -1304,12 +1324,24 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   // are evaluated once ("fixed cost", ceres reduced program).
   std::vector<uint8_t> fixed(h->nobs, 0);
   std::vector<int> pkey(h->np, std::numeric_limits<int>::max());
-  std::vector<int> nvar(h->np, 0);   // variable cameras of a track (one pass over the observations for all three)
-  for (int64_t i = 0; i < h->nobs; ++i) {
-    const int rc = h->cam_red[p->obs_cam[i]];
-    fixed[i] = (rc < 0 && h->grp_red[p->cam_group[p->obs_cam[i]]] < 0 && h->pt_const[p->obs_pt[i]]) ? 1 : 0;
-    if (rc >= 0) { nvar[p->obs_pt[i]]++; if (rc < pkey[p->obs_pt[i]]) pkey[p->obs_pt[i]] = rc; }
-  }
+  std::vector<int> nvar(h->np, 0);   // variable cameras of a track
+  host_chunks(h->nobs, [&](int64_t i0, int64_t i1) {   // an observed track is constant iff the caller marked it
+    for (int64_t i = i0; i < i1; ++i)
+      fixed[i] = (h->cam_red[p->obs_cam[i]] < 0 && h->grp_red[p->cam_group[p->obs_cam[i]]] < 0 &&
+                  p->point_const && p->point_const[p->obs_pt[i]]) ? 1 : 0;
+  });
+  // per-track sums on host threads: every thread scans all observations and keeps those of its own range of tracks (the
+  // writes of the threads are disjoint and each thread's working set is its share of the arrays)
+  host_chunks(h->np, [&](int64_t q0, int64_t q1) {
+    for (int64_t i = 0; i < h->nobs; ++i) {
+      const int q = p->obs_pt[i];
+      if (q < q0 || q >= q1) continue;
+      pt_used[q] = 1;
+      const int rc = h->cam_red[p->obs_cam[i]];
+      if (rc >= 0) { nvar[q]++; if (rc < pkey[q]) pkey[q] = rc; }
+    }
+  });
+  for (int q = 0; q < h->np; ++q) h->pt_const[q] = ((p->point_const && p->point_const[q]) || !pt_used[q]) ? 1 : 0;
   std::vector<int> porder(h->np), prank(h->np);
   for (int q = 0; q < h->np; ++q) porder[q] = q;
   // Inside one first-camera key, short tracks come first (classes by number of variable cameras): the fused Schur
@@ -1345,16 +1377,28 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   for (int r = 0; r < h->np; ++r) prank[porder[r]] = r;
   // offsets indexed by track RANK
   std::vector<int64_t> cnt_main(h->np + 1, 0), cnt_fix(h->np + 1, 0);
-  for (int64_t i = 0; i < h->nobs; ++i) (fixed[i] ? cnt_fix : cnt_main)[prank[p->obs_pt[i]] + 1]++;
+  HBuf<int> orank;   // rank of an observation's track (pinned block of the host cache: reused, no page faults)
+  if (!orank.resize((size_t)std::max<int64_t>(1, h->nobs))) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %lld observations failed", (long long)h->nobs);
+  host_chunks(h->nobs, [&](int64_t i0, int64_t i1) { for (int64_t i = i0; i < i1; ++i) orank[i] = prank[p->obs_pt[i]]; });
+  host_chunks(h->np, [&](int64_t r0, int64_t r1) {   // threads own ranges of ranks, as above
+    for (int64_t i = 0; i < h->nobs; ++i) {
+      const int r = orank[i];
+      if (r < r0 || r >= r1) continue;
+      (fixed[i] ? cnt_fix : cnt_main)[r + 1]++;
+    }
+  });
   for (int q = 0; q < h->np; ++q) { cnt_main[q + 1] += cnt_main[q]; cnt_fix[q + 1] += cnt_fix[q]; }
   h->nobs_main = cnt_main[h->np];
   h->perm.assign(h->nobs, 0);
   {
     std::vector<int64_t> fm(cnt_main.begin(), cnt_main.end() - 1), ff(cnt_fix.begin(), cnt_fix.end() - 1);
-    for (int64_t i = 0; i < h->nobs; ++i) {
-      const int q = prank[p->obs_pt[i]];
-      if (fixed[i]) h->perm[h->nobs_main + ff[q]++] = i; else h->perm[fm[q]++] = i;
-    }
+    host_chunks(h->np, [&](int64_t r0, int64_t r1) {   // observations of a track keep their input order
+      for (int64_t i = 0; i < h->nobs; ++i) {
+        const int q = orank[i];
+        if (q < r0 || q >= r1) continue;
+        if (fixed[i]) h->perm[h->nobs_main + ff[q]++] = i; else h->perm[fm[q]++] = i;
+      }
+    });
   }
   // wave tiles: <= 64 observations, never splitting a track
   std::vector<int> tstart, tcount, tkey;
@@ -1454,9 +1498,15 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   h->ntiles_eval = (int)tstart.size();
   build_tiles(cnt_fix, h->nobs_main, false);
   h->ntiles_all = (int)tstart.size();
-  std::vector<double2> uv(h->nobs), si;
-  std::vector<int> ocam(h->nobs), opt(h->nobs);
-  if (p->obs_sqrt_info) si.resize(h->nobs);
+  // The sorted observation arrays are staged in pinned blocks of the library's host cache: 24 bytes per observation of
+  // fresh pageable vectors cost more in page faults than the gather itself, and the copies below run as plain DMA.
+  HBuf<double2> uv, si;
+  HBuf<int> ocam_b, opt_b;
+  if (!uv.resize((size_t)h->nobs) || !ocam_b.resize((size_t)h->nobs) || !opt_b.resize((size_t)h->nobs) ||
+      (p->obs_sqrt_info && !si.resize((size_t)h->nobs)))
+    return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "pinned staging of %lld observations failed", (long long)h->nobs);
+  int* const ocam = ocam_b.data();
+  int* const opt = opt_b.data();
   host_chunks(h->nobs, [&](int64_t s0, int64_t s1) {   // gathers through the permutation: independent per observation
     for (int64_t s = s0; s < s1; ++s) {
       const int64_t i = h->perm[s];
@@ -1469,7 +1519,9 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
 #define UP(buf, vec) do { rc = h->buf.upload(vec, st); if (rc) return rc; } while (0)
 #define AL(buf, cnt) do { rc = h->buf.alloc(cnt); if (rc) return rc; } while (0)
   tick("structure, sort, tiles");
-  UP(obs_uv, uv); UP(obs_si, si); UP(obs_cam, ocam); UP(obs_pt, opt);
+#define UPP(buf, src, cnt) do { rc = h->buf.upload(src, cnt, st, true); if (rc) return rc; } while (0)
+  UPP(obs_uv, uv.data(), (size_t)h->nobs); UPP(obs_si, si.data(), si.n); UPP(obs_cam, ocam, (size_t)h->nobs); UPP(obs_pt, opt, (size_t)h->nobs);
+#undef UPP
   h->inner = h->opt.use_inner_iterations != 0 && h->nobs_main > 0;
   if (h->inner) {
     // residual blocks that depend on a block: the camera's / the group's / the track's observations among the

@@ -35,6 +35,7 @@
 #include <thread>
 
 #include "theia_hip_internal.h"
+#include "pools.h"
 
 namespace thip {
 namespace {
@@ -1065,135 +1066,6 @@ struct ProblemState {
       return set_error(e_ == hipErrorOutOfMemory ? THEIA_HIP_ERR_OUT_OF_MEMORY : THEIA_HIP_ERR_NO_DEVICE, \
                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);   \
   } while (0)
-
-// Device blocks of a batch call come from a small process-wide cache: a verification pipeline calls the batch entry
-// points back to back with the same shapes, and hipMalloc / hipFree of the GB-sized model workspace cost more than the
-// kernels of a 1000-pair chunk.  Blocks are reused when they are at most twice the request; the cache keeps at most
-// kPoolLimit bytes (the rest goes back to the runtime), theia_hip_release_scratch() empties it.
-struct DevPool {
-  struct Block { void* p; size_t bytes; };
-  std::mutex mu;
-  std::vector<Block> free_blocks;
-  size_t held = 0;
-  static constexpr size_t kPoolLimit = (size_t)6 << 30;
-  void* take(size_t bytes, size_t* got) {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      int best = -1;
-      for (int i = 0; i < (int)free_blocks.size(); ++i)
-        if (free_blocks[i].bytes >= bytes && free_blocks[i].bytes <= 2 * bytes + 4096 &&
-            (best < 0 || free_blocks[i].bytes < free_blocks[best].bytes)) best = i;
-      if (best >= 0) {
-        Block b = free_blocks[best];
-        free_blocks.erase(free_blocks.begin() + best);
-        held -= b.bytes; *got = b.bytes;
-        return b.p;
-      }
-    }
-    void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) {   // make room and try once more
-      release();
-      if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-    }
-    *got = bytes;
-    return p;
-  }
-  void give(void* p, size_t bytes) {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      if (held + bytes <= kPoolLimit) { free_blocks.push_back(Block{p, bytes}); held += bytes; return; }
-    }
-    (void)hipFree(p);
-  }
-  void release() {
-    std::vector<Block> blocks;
-    { std::lock_guard<std::mutex> lk(mu); blocks.swap(free_blocks); held = 0; }
-    for (const Block& b : blocks) (void)hipFree(b.p);
-  }
-};
-DevPool& dev_pool() { static DevPool pool; return pool; }
-
-template <typename T>
-struct DBuf {
-  T* p = nullptr;
-  size_t cap = 0, bytes = 0;
-  ~DBuf() { if (p) dev_pool().give(p, bytes); }
-  int ensure(size_t count) {
-    if (count <= cap) return 0;
-    if (p) dev_pool().give(p, bytes);
-    p = nullptr; cap = 0; bytes = 0;
-    size_t got = 0;
-    p = static_cast<T*>(dev_pool().take(std::max<size_t>(count * sizeof(T), 256), &got));
-    if (!p) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", count * sizeof(T));
-    bytes = got; cap = got / sizeof(T);
-    return 0;
-  }
-};
-
-// Pinned host blocks for the per-round transfers (sample indices up, counts / costs / inlier counts down): pageable
-// vectors made the D2H copies of a round 4.6 ms against 24 ms of kernels (the DMA engine stages through bounce
-// buffers); pinned memory is expensive to allocate, so the blocks are cached like the device blocks above.
-struct HostPool {
-  struct Block { void* p; size_t bytes; };
-  std::mutex mu;
-  std::vector<Block> free_blocks;
-  size_t held = 0;
-  static constexpr size_t kPoolLimit = (size_t)2 << 30;
-  void* take(size_t bytes, size_t* got) {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      int best = -1;
-      for (int i = 0; i < (int)free_blocks.size(); ++i)
-        if (free_blocks[i].bytes >= bytes && free_blocks[i].bytes <= 2 * bytes + 4096 &&
-            (best < 0 || free_blocks[i].bytes < free_blocks[best].bytes)) best = i;
-      if (best >= 0) {
-        Block b = free_blocks[best];
-        free_blocks.erase(free_blocks.begin() + best);
-        held -= b.bytes; *got = b.bytes;
-        return b.p;
-      }
-    }
-    void* p = nullptr;
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
-    *got = bytes;
-    return p;
-  }
-  void give(void* p, size_t bytes) {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      if (held + bytes <= kPoolLimit) { free_blocks.push_back(Block{p, bytes}); held += bytes; return; }
-    }
-    (void)hipHostFree(p);
-  }
-  void release() {
-    std::vector<Block> blocks;
-    { std::lock_guard<std::mutex> lk(mu); blocks.swap(free_blocks); held = 0; }
-    for (const Block& b : blocks) (void)hipHostFree(b.p);
-  }
-};
-HostPool& host_pool() { static HostPool pool; return pool; }
-
-template <typename T>
-struct HBuf {   // the std::vector calls the driver used, on a pinned block (contents are NOT preserved by a growing resize)
-  T* p = nullptr;
-  size_t cap = 0, bytes = 0, n = 0;
-  ~HBuf() { if (p) host_pool().give(p, bytes); }
-  bool reserve(size_t count) {
-    if (count <= cap) return true;
-    if (p) host_pool().give(p, bytes);
-    p = nullptr; cap = 0; bytes = 0;
-    size_t got = 0;
-    p = static_cast<T*>(host_pool().take(std::max<size_t>(count * sizeof(T), 4096), &got));
-    if (!p) return false;
-    bytes = got; cap = got / sizeof(T);
-    return true;
-  }
-  bool resize(size_t count) { if (!reserve(count)) return false; n = count; return true; }
-  bool assign(size_t count, T v) { if (!resize(count)) return false; for (size_t i = 0; i < count; ++i) p[i] = v; return true; }
-  T* data() { return p; }
-  T& operator[](size_t i) { return p[i]; }
-  const T& operator[](size_t i) const { return p[i]; }
-};
 
 }  // namespace
 }  // namespace thip
