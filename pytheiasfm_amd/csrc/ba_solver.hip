@@ -195,13 +195,27 @@ struct theia_ba_handle_s {
 namespace {
 // Host-side loops over independent index ranges on a few threads (handle creation at millions of observations).
 // THEIA_HIP_HOST_THREADS caps the count (default min(hardware threads, 8); 1 = serial).
-template <class F>
-void host_chunks(int64_t n, F&& fn) {
+unsigned host_thread_cap() {
   static const unsigned cap = [] {
     const char* e = getenv("THEIA_HIP_HOST_THREADS");
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     return e ? (unsigned)std::max(1, atoi(e)) : std::min(hw, 8u);
   }();
+  return cap;
+}
+// fn(k) for the parts k = 0 .. nparts-1 of a fixed partition (the result must not depend on who runs which part)
+template <class F>
+void host_parts(int nparts, bool threaded, F&& fn) {
+  const unsigned cap = threaded ? std::min<unsigned>(host_thread_cap(), (unsigned)nparts) : 1u;
+  if (cap <= 1) { for (int k = 0; k < nparts; ++k) fn(k); return; }
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < cap; ++t) th.emplace_back([&fn, t, cap, nparts] { for (int k = (int)t; k < nparts; k += (int)cap) fn(k); });
+  for (int k = 0; k < nparts; k += (int)cap) fn(k);
+  for (auto& x : th) x.join();
+}
+template <class F>
+void host_chunks(int64_t n, F&& fn) {
+  const unsigned cap = host_thread_cap();
   if (n < 262144 || cap <= 1) { fn((int64_t)0, n); return; }
   const int64_t per = (n + cap - 1) / cap;
   std::vector<std::thread> th;
@@ -405,6 +419,9 @@ __global__ void k_xnorm_reduce(const double* __restrict__ part, int nblocks, dou
   out2[0] = a; out2[1] = b;
 }
 __global__ void k_xnorm_set(LmState* st, const double* __restrict__ in2) { st->x_norm = sqrt(in2[0] + in2[1]); }
+__global__ void k_fill_value(double* x, size_t n, double v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] = v;
+}
 __global__ void k_lm_init_state(LmState* dst, LmState v) { *dst = v; }
 __global__ void k_lm_init_ctl(LmCtl* dst, LmCtl v) { *dst = v; }
 
@@ -741,11 +758,48 @@ int build_gather_lists(theia_ba_handle_s* h, const int* ocam, const int* opt,
   // (observation of ri, observation of rj) pairs of their common variable
   // tracks.  Tracks of the slow path (> 64 observations) assemble themselves.
   const int64_t nm = h->nobs_main;
-  std::vector<char> is_long(nm, 0);
+  std::vector<char> is_long(l_obs.empty() ? 0 : nm, 0);
   for (int s2 : l_obs) is_long[s2] = 1;
-  std::vector<int> red(nm);
-  for (int64_t s = 0; s < nm; ++s) red[s] = is_long[s] ? -1 : h->cam_red[ocam[s]];
   constexpr int kChunk = 2048;
+  if (!with_pairs) {
+    // Fused Schur assembly: only the cameras' observation lists are needed (column norms of the camera blocks,
+    // k_colnorm_gather) -- a stable counting sort by reduced camera over a fixed partition of the observations, on host
+    // threads, written into a pinned block.
+    constexpr int kParts = 8;
+    auto red_of = [&](int64_t s) { return (!is_long.empty() && is_long[s]) ? -1 : h->cam_red[ocam[s]]; };
+    std::vector<std::vector<int>> fill(kParts, std::vector<int>(std::max(1, h->ncv), 0));
+    const bool threaded = nm >= 262144;
+    host_parts(kParts, threaded, [&](int k) {
+      for (int64_t s = nm * k / kParts; s < nm * (k + 1) / kParts; ++s) { const int r = red_of(s); if (r >= 0) fill[k][r]++; }
+    });
+    std::vector<int> dbeg(h->ncv + 1, 0);
+    for (int c = 0; c < h->ncv; ++c) {
+      int at = dbeg[c];
+      for (int k = 0; k < kParts; ++k) { const int cnt = fill[k][c]; fill[k][c] = at; at += cnt; }
+      dbeg[c + 1] = at;
+    }
+    HBuf<int> sobs;
+    const size_t nrec = (size_t)std::max(1, dbeg[h->ncv]);
+    if (!sobs.resize(nrec)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %zu records failed", nrec);
+    sobs[0] = 0;
+    host_parts(kParts, threaded, [&](int k) {
+      for (int64_t s = nm * k / kParts; s < nm * (k + 1) / kParts; ++s) { const int r = red_of(s); if (r >= 0) sobs[fill[k][r]++] = (int)s; }
+    });
+    std::vector<int> ditems;
+    for (int c = 0; c < h->ncv; ++c) {
+      const int nchunk = (dbeg[c + 1] - dbeg[c] + kChunk - 1) / kChunk;
+      for (int k = 0; k < nchunk; ++k) {
+        ditems.push_back(c); ditems.push_back(dbeg[c] + k * kChunk);
+        ditems.push_back(std::min(dbeg[c + 1], dbeg[c] + (k + 1) * kChunk)); ditems.push_back(nchunk > 1 ? 1 : 0);
+      }
+    }
+    h->n_diag_items = (int)ditems.size() / 4; h->n_blk_items = 0;
+    if ((rc = h->slot_obs.upload(sobs.data(), nrec, st, true))) return rc;
+    UP(diag_items, ditems);   // pageable: synchronises the stream, the pinned block above is free after it
+    return 0;
+  }
+  std::vector<int> red(nm);
+  for (int64_t s = 0; s < nm; ++s) red[s] = (!is_long.empty() && is_long[s]) ? -1 : h->cam_red[ocam[s]];
   std::vector<int> dbeg(h->ncv + 1, 0);
   for (int64_t s = 0; s < nm; ++s) if (red[s] >= 0) dbeg[red[s] + 1]++;
   for (int c = 0; c < h->ncv; ++c) dbeg[c + 1] += dbeg[c];
@@ -763,21 +817,13 @@ int build_gather_lists(theia_ba_handle_s* h, const int* ocam, const int* opt,
       ditems.push_back(std::min(dbeg[c + 1], dbeg[c] + (k + 1) * kChunk)); ditems.push_back(nchunk > 1 ? 1 : 0);
     }
   }
-  if (!with_pairs) {
-    h->n_diag_items = (int)ditems.size() / 4; h->n_blk_items = 0;
-    std::vector<int> sobs(std::max(1, dbeg[h->ncv]), 0);
-    for (int64_t s2 = 0; s2 < nm; ++s2) if (cam_obs[s2] >= 0) sobs[cam_obs[s2]] = (int)s2;
-    UP(slot_obs, sobs);
-    UP(diag_items, ditems);
-    return 0;
-  }
   // pairs, bucketed by row camera then sorted by column camera
   std::vector<int64_t> rbeg(h->ncv + 1, 0);
   auto for_each_pair = [&](auto&& fn) {
     for (int64_t s0 = 0; s0 < nm;) {
       int64_t s1 = s0 + 1;
       while (s1 < nm && opt[s1] == opt[s0]) ++s1;
-      if (!is_long[s0] && !h->pt_const[opt[s0]])
+      if ((is_long.empty() || !is_long[s0]) && !h->pt_const[opt[s0]])
         for (int64_t a = s0; a < s1; ++a) {
           if (red[a] < 0) continue;
           for (int64_t b = s0; b < s1; ++b)
@@ -1577,8 +1623,9 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     UP(ones_i, ones_i); UP(scale_i, ones_i);
   }
   AL(colsq_i0, (size_t)THEIA_MAX_INTRINSICS * h->ng); AL(scale_red, (size_t)std::max(1, h->n));
-  std::vector<double> ones_c((size_t)6 * h->nc, 1.0), ones_p((size_t)h->pd * h->np, 1.0);
-  UP(ones_c, ones_c); UP(ones_p, ones_p); UP(scale_c, ones_c); UP(scale_p, ones_p);
+  AL(ones_c, (size_t)6 * h->nc); AL(ones_p, (size_t)h->pd * h->np); AL(scale_c, (size_t)6 * h->nc); AL(scale_p, (size_t)h->pd * h->np);
+  for (DevBuf<double>* b : {&h->ones_c, &h->ones_p, &h->scale_c, &h->scale_p})   // filled on the device
+    if (b->n) k_fill_value<<<(unsigned)std::min<size_t>(1024, (b->n + 255) / 256), 256, 0, st>>>(b->p, b->n, 1.0);
   AL(colsq_c0, (size_t)6 * h->nc); AL(colsq_p0, (size_t)h->pd * h->np);
   {
     std::vector<int> a(&kCfgF2S[0][0], &kCfgF2S[0][0] + 24), b(&kCfgMax[0][0], &kCfgMax[0][0] + 24);
