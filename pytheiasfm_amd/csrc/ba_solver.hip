@@ -120,7 +120,7 @@ struct theia_ba_handle_s {
   DevBuf<double> tr_cost, tr_g, tr_step, tr_radius;
   DevBuf<int> tr_acc;
   // host-side bookkeeping
-  std::vector<int64_t> perm;       // sorted obs index -> original obs index
+  HBuf<int64_t> perm;              // sorted obs index -> original obs index (a block of the pinned host cache: no page faults)
   std::vector<int> cam_red, grp_red, grp_k;
   std::vector<unsigned> grp_free;
   std::vector<uint8_t> cam_mask, pt_const;
@@ -1063,7 +1063,7 @@ struct FusedSegment {
   FusedHost fp;
 };
 void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>& off, const std::vector<int>& porder,
-                         const std::vector<int>& sred, const std::vector<int>& skey, int q_begin, int q_end,
+                         const int* sred, const std::vector<int>& skey, int q_begin, int q_end,
                          uint8_t* obs_lc, uint8_t* obs_tl, FusedSegment& seg) {
   std::vector<int>& tstart = seg.tstart; std::vector<int>& tcount = seg.tcount; std::vector<int>& tkey = seg.tkey;
   std::vector<int>& l_obs = seg.l_obs; std::vector<int>& l_slot = seg.l_slot; std::vector<int>& l_start = seg.l_start;
@@ -1435,7 +1435,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   });
   for (int q = 0; q < h->np; ++q) { cnt_main[q + 1] += cnt_main[q]; cnt_fix[q + 1] += cnt_fix[q]; }
   h->nobs_main = cnt_main[h->np];
-  h->perm.assign(h->nobs, 0);
+  if (!h->perm.resize((size_t)std::max<int64_t>(1, h->nobs))) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %lld observations failed", (long long)h->nobs);
   {
     std::vector<int64_t> fm(cnt_main.begin(), cnt_main.end() - 1), ff(cnt_fix.begin(), cnt_fix.end() - 1);
     host_chunks(h->np, [&](int64_t r0, int64_t r1) {   // observations of a track keep their input order
@@ -1482,9 +1482,11 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   FusedHost fplan;
   tick("  structure: permutation");
   h->use_fused = h->ni == 0 && h->nobs_main > 0 && !getenv("THEIA_HIP_SCHUR_GATHER");
-  std::vector<int> sred;
+  HBuf<int> sred_b;
+  int* sred = nullptr;
   if (h->use_fused) {
-    sred.resize(h->nobs_main);
+    if (!sred_b.resize((size_t)h->nobs_main)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %lld observations failed", (long long)h->nobs_main);
+    sred = sred_b.data();
     host_chunks(h->nobs_main, [&](int64_t s0, int64_t s1) { for (int64_t s = s0; s < s1; ++s) sred[s] = h->cam_red[p->obs_cam[h->perm[s]]]; });
     std::atomic<long long> misfit{0};
     host_chunks(h->np, [&](int64_t q0, int64_t q1) {   // tracks are independent
