@@ -611,8 +611,11 @@ int theia_hip_dls_pnp(int32_t num, const int64_t* offsets, const double* feature
                       double* quaternions, double* translations, int32_t* num_solutions);
 void theia_hip_dls_macaulay_terms(int64_t first_call, int64_t num_calls, double* out);
 
-/* The batch entry points above keep their device workspace (up to 6 GiB) and the pinned host blocks of their per-round
- * transfers (up to 2 GiB) in process-wide caches between calls; this returns both to the runtime.  All RANSAC kernels of
+/* The batch entry points above keep their device workspace and the pinned host blocks of their per-round transfers in
+ * process-wide caches between calls (up to 6 GiB of device memory and 2 GiB of pinned host memory); the buffers of a
+ * destroyed BA handle and the host staging of theia_hip_ba_create go to the same caches, so that a pipeline that
+ * solves problem after problem does not pay hipMalloc / hipFree and page faults each time.  This returns both caches
+ * to the runtime.  All RANSAC kernels of
  * the process run on one library-owned stream; calls from several host threads are safe and overlap their host work. */
 void theia_hip_release_scratch(void);
 
