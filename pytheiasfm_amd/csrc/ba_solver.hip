@@ -195,13 +195,10 @@ struct theia_ba_handle_s {
 namespace {
 // Host-side loops over independent index ranges on a few threads (handle creation at millions of observations).
 // THEIA_HIP_HOST_THREADS caps the count (default min(hardware threads, 8); 1 = serial).
-unsigned host_thread_cap() {
-  static const unsigned cap = [] {
-    const char* e = getenv("THEIA_HIP_HOST_THREADS");
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    return e ? (unsigned)std::max(1, atoi(e)) : std::min(hw, 8u);
-  }();
-  return cap;
+unsigned host_thread_cap() {   // read per call (a handful per create()): tests switch it inside one process
+  const char* e = getenv("THEIA_HIP_HOST_THREADS");
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  return e ? (unsigned)std::max(1, atoi(e)) : std::min(hw, 8u);
 }
 // fn(k) for the parts k = 0 .. nparts-1 of a fixed partition (the result must not depend on who runs which part)
 template <class F>

@@ -331,6 +331,14 @@ def test_full_size_c4_properties():
     finally:
         del os.environ["THEIA_HIP_DENSE_CHOLESKY"]
     assert rel(trd.cost[: trd.size], tr.cost[: trd.size]) < 1e-9 and np.array_equal(trd.accepted[: trd.size], tr.accepted[: trd.size])
+    # the host-side plan (threaded structure passes, fused plan in fixed segments) does not depend on the number of
+    # host threads: the serial build walks the same trajectory bit for bit
+    os.environ["THEIA_HIP_HOST_THREADS"] = "1"
+    try:
+        s1, tr1 = ba.solve(p.copy(), o3)
+    finally:
+        del os.environ["THEIA_HIP_HOST_THREADS"]
+    assert np.array_equal(tr1.cost[: tr1.size], tr.cost[: tr1.size]) and np.array_equal(tr1.step_norm[: tr1.size], tr.step_norm[: tr1.size])
 
 
 @pytest.mark.parametrize("n", [1, 6, 24, 32, 33, 120, 121, 300, 1200])
