@@ -75,6 +75,8 @@ struct DevProblem {
   const int* diag_items;       // [n_diag_items][4] {rc, first slot, end slot, atomic}
   const int* blk_items;        // [n_blk_items][5] {ri, rj, beg, end, atomic}
   const int2* blk_pairs;       // (slot of the obs of camera ri, slot of the obs of camera rj) of a common track
+  const int* pt_sum_slot;      // [np] or null: pseudo-record slot of a track's summed intrinsics fields (k_lin_obs_intr), -1 = none
+  const uint8_t* slot_in_sum;  // [#records] or null: the observation's track is summed (its own pair term is in the sum)
   // fused linearise + Schur (ba_fused.hip), ni == 0: static plan built at create()
   int n_fruns;
   const FusedRun* fruns;

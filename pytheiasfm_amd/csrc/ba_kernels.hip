@@ -529,6 +529,9 @@ __global__ __launch_bounds__(kBlock) void k_lin_obs_intr(DevProblem P, const dou
       gmax = fmax(gmax, fabs(g[a] / P.scale_p[(size_t)PD * L.p + a]));
     }
   }
+  double wi[KI * PD];   // WI = Fk^T E of the lane's observation (zero without a record or a variable group)
+#pragma unroll
+  for (int k = 0; k < KI * PD; ++k) wi[k] = 0.0;
   if (slot >= 0) {
     double2* R = reinterpret_cast<double2*>(P.rec + (size_t)slot * RS);
     double w[NW], t[NW], tg[6];
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_obs_intr(DevProblem P, const dou
         jk[k] = v0; jk[KI + k] = v1;
       }
     }
-    double wi[KI * PD], ti[KI * PD], tig[KI];
+    double ti[KI * PD], tig[KI];
 #pragma unroll
     for (int a = 0; a < KI; ++a) {
 #pragma unroll
@@ -608,6 +611,35 @@ __global__ __launch_bounds__(kBlock) void k_lin_obs_intr(DevProblem P, const dou
 #pragma unroll
     for (int k = 0; k < KI / 2; ++k) R[O::TIG + k] = make_double2(tig[2 * k], tig[2 * k + 1]);
   }
+  if (P.pt_sum_slot) {
+    // Tracks whose observations share one variable intrinsics group: the sums of WI and TI = WI V^-1 over the track go to
+    // a pseudo-record, and the camera x group / group x group pair lists hold (observation, sum) and (sum, sum) pairs
+    // instead of every ordered pair of the track's observations (build_gather_lists_intr).
+    const int ps = (L.active && sg.head && !L.pconst) ? P.pt_sum_slot[L.p] : -1;
+    double wsum[KI * PD];
+#pragma unroll
+    for (int k = 0; k < KI * PD; ++k) wsum[k] = wi[k];
+    if (__ballot(ps >= 0) != 0ull) segment_allsum_log<KI * PD>(sg, lane, wsum);   // (wave-uniform: no track of this tile is summed)
+    if (ps >= 0) {
+      using O = RecI<PD, KI>;
+      double2* R = reinterpret_cast<double2*>(P.rec + (size_t)ps * RS);
+      double tsum[KI * PD];
+#pragma unroll
+      for (int a = 0; a < KI; ++a)
+#pragma unroll
+        for (int b = 0; b < PD; ++b) {
+          double s2 = 0.0;
+#pragma unroll
+          for (int k = 0; k < PD; ++k) s2 += wsum[a * PD + k] * sym_get<PD>(Vi, k, b);
+          tsum[a * PD + b] = s2;
+        }
+#pragma unroll
+      for (int k = 0; k < KI * PD / 2; ++k) {
+        R[O::WI + k] = make_double2(wsum[2 * k], wsum[2 * k + 1]);
+        R[O::TI + k] = make_double2(tsum[2 * k], tsum[2 * k + 1]);
+      }
+    }
+  }
   const double cost = wave_sum(L.cost);
   gmax = wave_max(gmax);
   const double inval = wave_sum((L.active && !L.valid) ? 1.0 : 0.0);
@@ -631,14 +663,17 @@ THIP_DEV void gdiag_item(const DevProblem& P, int row0, int beg, int end, bool a
   for (int k = 0; k < RA * KI; ++k) acc[k] = 0.0;
   for (int q = beg + threadIdx.x; q < end; q += kBlock) {
     double TI[RA * PD], WI[KI * PD], Jk[2 * KI];
+    const bool noself = P.slot_in_sum && P.slot_in_sum[q];   // the observation's own TI WI^T term is in its track's sum
     load_reci<PD, KI>(P.rec, q, O::TI + (ra0 * PD) / 2, TI); load_reci<PD, KI>(P.rec, q, O::WI, WI); load_reci<PD, KI>(P.rec, q, O::FK, Jk);
 #pragma unroll
     for (int a = 0; a < RA; ++a)
 #pragma unroll
       for (int b = 0; b < KI; ++b) {
         double s = Jk[ra0 + a] * Jk[b] + Jk[KI + ra0 + a] * Jk[KI + b];
+        if (!noself) {
 #pragma unroll
-        for (int k = 0; k < PD; ++k) s -= TI[a * PD + k] * WI[b * PD + k];
+          for (int k = 0; k < PD; ++k) s -= TI[a * PD + k] * WI[b * PD + k];
+        }
         acc[a * KI + b] += s;
       }
   }
@@ -707,6 +742,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_intr(DevProblem P, double* __r
     for (int k = 0; k < 6 * KI; ++k) acc[k] = 0.0;
     for (int q = beg + threadIdx.x; q < end; q += kBlock) {
       double T[6 * PD], WI[KI * PD], Jc[12], Jk[2 * KI];
+      const bool noself = P.slot_in_sum && P.slot_in_sum[q];   // (the (observation, track sum) pair carries T_a WI_a^T)
       load_reci<PD, KI>(P.rec, q, O::T, T); load_reci<PD, KI>(P.rec, q, O::WI, WI);
       load_reci<PD, KI>(P.rec, q, O::F, Jc); load_reci<PD, KI>(P.rec, q, O::FK, Jk);
 #pragma unroll
@@ -714,8 +750,10 @@ __global__ __launch_bounds__(kBlock) void k_schur_intr(DevProblem P, double* __r
 #pragma unroll
         for (int b = 0; b < KI; ++b) {
           double s = Jc[a] * Jk[b] + Jc[6 + a] * Jk[KI + b];
+          if (!noself) {
 #pragma unroll
-          for (int k = 0; k < PD; ++k) s -= T[a * PD + k] * WI[b * PD + k];
+            for (int k = 0; k < PD; ++k) s -= T[a * PD + k] * WI[b * PD + k];
+          }
           acc[a * KI + b] += s;
         }
     }

@@ -151,6 +151,9 @@ struct theia_ba_handle_s {
   DevBuf<double> prior_vec, prior_info;
   int n_priors = 0;
   DevBuf<int2> blk_pairs;
+  DevBuf<int> pt_sum_slot;   // [np] pseudo-record of a track's summed intrinsics fields, -1 = none (build_gather_lists_intr)
+  DevBuf<uint8_t> slot_in_sum;   // [#records] the observation's track is summed
+  int n_trk_sums = 0;
   int n_diag_items = 0, n_blk_items = 0;
   // fused linearise + Schur plan (ba_fused.hip)
   bool use_fused = false;
@@ -550,6 +553,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.model_mask = h->model_mask;
   P.n_sum_items = h->n_sum_items; P.sum_items = h->sum_items.p; P.sum_src = h->sum_src.p;
   P.diag_items = h->diag_items.p; P.rec_slot = h->cam_obs.p; P.slot_obs = h->slot_obs.p; P.slot_pt = h->slot_pt.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
+  P.pt_sum_slot = h->n_trk_sums ? h->pt_sum_slot.p : nullptr; P.slot_in_sum = h->n_trk_sums ? h->slot_in_sum.p : nullptr;
 }
 
 int upload_parameters(theia_ba_handle_s* h, const theia_ba_problem* p) {
@@ -946,20 +950,48 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
       items.push_back(flags | (nchunk > 1 ? 1 : 0));
     }
   };
-  // ---- pair lists: entries (key, a, b) sorted by key; one item (or two halves) per key
+  // ---- pair lists: entries (key, slot a, slot b) sorted by key; one item (or two halves) per key
+  // Camera x camera blocks take every ordered pair of observations of a track.  For the blocks with an intrinsics group
+  // on one or both sides, a track whose observations share ONE variable group is represented by the SUM of their
+  // intrinsics fields (a pseudo-record behind the real ones, written by k_lin_obs_intr from a segmented wave sum):
+  // Sum_b T_a WI_b^T = T_a (Sum_b WI_b)^T, so the track gives L (observation, sum) pairs and one (sum, sum) pair instead
+  // of 2 L (L - 1) ordered pairs.  The sum includes b == a, so the per-observation items leave that term out for the
+  // observations of such a track (slot_in_sum).  Tracks that see several variable groups keep their explicit pairs.
+  // THEIA_HIP_INTR_PAIRS=1 keeps the lists of the first version (no sums).
   struct PairE { uint64_t key; int a, b; };
   std::vector<PairE> cc, cg, gg;
+  const bool track_sums = !getenv("THEIA_HIP_INTR_PAIRS");
+  const int nslots = (int)order.size();
+  std::vector<int> pt_sum(track_sums ? h->np : 0, -1);   // pseudo-record slot of a track, -1 = none
+  std::vector<uint8_t> slot_sum(track_sums ? std::max(1, nslots) : 0, 0);
+  int nsums = 0;
   for (int64_t s0 = 0; s0 < nm;) {
     int64_t s1 = s0 + 1;
     while (s1 < nm && opt[s1] == opt[s0]) ++s1;
-    if (!h->pt_const[opt[s0]])
+    if (!h->pt_const[opt[s0]]) {
+      int g_one = -1, ng_var = 0;   // changes of variable group along the track (a group left and seen again counts twice:
+                                    // such a track keeps its pairs, like the long tracks, whose entries are all -1)
+      for (int64_t b2 = s0; b2 < s1; ++b2)
+        if (grd[b2] >= 0 && grd[b2] != g_one) { g_one = grd[b2]; ++ng_var; }
+      const bool sum_mode = track_sums && ng_var == 1;
       for (int64_t a = s0; a < s1; ++a)
         for (int64_t b = s0; b < s1; ++b) {
           if (a == b) continue;
-          if (red[a] >= 0 && red[b] >= 0 && red[a] >= red[b]) cc.push_back({((uint64_t)red[a] << 32) | (uint32_t)red[b], (int)a, (int)b});
-          if (red[a] >= 0 && grd[b] >= 0) cg.push_back({((uint64_t)red[a] << 32) | (uint32_t)grd[b], (int)a, (int)b});
-          if (grd[a] >= 0 && grd[b] >= 0 && grd[a] >= grd[b]) gg.push_back({((uint64_t)grd[a] << 32) | (uint32_t)grd[b], (int)a, (int)b});
+          if (red[a] >= 0 && red[b] >= 0 && red[a] >= red[b]) cc.push_back({((uint64_t)red[a] << 32) | (uint32_t)red[b], slot[a], slot[b]});
+          if (sum_mode) continue;
+          if (red[a] >= 0 && grd[b] >= 0) cg.push_back({((uint64_t)red[a] << 32) | (uint32_t)grd[b], slot[a], slot[b]});
+          if (grd[a] >= 0 && grd[b] >= 0 && grd[a] >= grd[b]) gg.push_back({((uint64_t)grd[a] << 32) | (uint32_t)grd[b], slot[a], slot[b]});
         }
+      if (sum_mode) {
+        const int ps = nslots + nsums++;
+        pt_sum[opt[s0]] = ps;
+        for (int64_t a = s0; a < s1; ++a) {
+          if (slot[a] >= 0) slot_sum[slot[a]] = 1;
+          if (red[a] >= 0) cg.push_back({((uint64_t)red[a] << 32) | (uint32_t)g_one, slot[a], ps});
+        }
+        gg.push_back({((uint64_t)g_one << 32) | (uint32_t)g_one, ps, ps});
+      }
+    }
     s0 = s1;
   }
   std::vector<int2> pairs;
@@ -983,7 +1015,7 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
       size_t e = q + 1;
       while (e < v.size() && v[e].key == v[q].key) ++e;
       const int64_t beg = (int64_t)pairs.size();
-      for (size_t k = q; k < e; ++k) pairs.push_back(make_int2(slot[v[k].a], slot[v[k].b]));
+      for (size_t k = q; k < e; ++k) pairs.push_back(make_int2(v[k].a, v[k].b));
       per_key((int)(v[q].key >> 32), (int)(v[q].key & 0xffffffffu), beg, (int64_t)pairs.size());
       q = e;
     }
@@ -1032,7 +1064,9 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
     UP(slot_obs, sobs);
   }
   UP(cam_obs, slot); UP(blk_items, items); UP(blk_pairs, pairs);
-  AL(rec, (size_t)std::max<size_t>(1, order.size()) * (12 * h->pd + 20 + 2 * h->intr_rows * h->pd + 3 * h->intr_rows));
+  h->n_trk_sums = nsums;
+  if (nsums) { UP(pt_sum_slot, pt_sum); UP(slot_in_sum, slot_sum); }
+  AL(rec, (std::max<size_t>(1, order.size()) + (size_t)h->n_trk_sums) * (12 * h->pd + 20 + 2 * h->intr_rows * h->pd + 3 * h->intr_rows));
   return 0;
 }
 

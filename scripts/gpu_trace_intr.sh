@@ -4,7 +4,7 @@ set -u
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_intr
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_intr -o ks -- python "$R/scripts/gpu_time_intr.py" > /tmp/intr_trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_intr -o ks -- python "$R/scripts/${INTR_SCRIPT:-gpu_time_intr.py}" > /tmp/intr_trace.log 2>&1
 tail -4 /tmp/intr_trace.log
 f=$(find /tmp/prof_intr -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'

@@ -1017,6 +1017,37 @@ def test_compact_intrinsics_rows_equal_full_rows():
     assert not np.array_equal(a[3].intrinsics[:, 0], p.intrinsics[:, 0])
 
 
+@pytest.mark.parametrize("groups,which", [(1, "focal_radial"), (2, "focal_radial"), (4, "focal_radial"), (1, "all"), (3, "all")])
+def test_intrinsics_track_sums_equal_pair_lists_and_oracle(groups, which):
+    """Tracks whose observations share one variable intrinsics group enter the camera x group and group x group blocks
+    through the SUM of their intrinsics fields (pseudo-records written by k_lin_obs_intr) instead of through every
+    ordered pair of observations (build_gather_lists_intr): the reduced system equals the one of the per-pair lists
+    (THEIA_HIP_INTR_PAIRS=1) up to the summation order, and the oracle's; the LM trajectory follows.  One group: every
+    track is summed; 2 - 4 interleaved groups: summed tracks and tracks with explicit pairs share cameras and blocks."""
+    p = synth.synth_ba_v1(14, 1100, seed=0x7A5 + groups, num_groups=groups, fix_gauge=True, pixel_noise=0.3)
+    intr = INTR_FOCAL_RADIAL if which == "focal_radial" else INTR_ALL
+    o, oo = both_options(intrinsics_to_optimize=intr, max_num_iterations=6)
+    out = []
+    for pairs in (False, True):
+        if pairs:
+            os.environ["THEIA_HIP_INTR_PAIRS"] = "1"
+        try:
+            with ba.BaHandle(p.copy(), o) as h:
+                S, rhs = h.reduced_system(1e4)
+            q = p.copy()
+            s, tr = ba.solve(q, o)
+            out.append((S, rhs, q, s, tr))
+        finally:
+            os.environ.pop("THEIA_HIP_INTR_PAIRS", None)
+    a, b = out
+    assert a[0].shape == b[0].shape and rel(a[0], b[0]) <= 1e-12 and rel(a[1], b[1]) <= 1e-11
+    So, ro = ol.reduced_system(p, oo, 1e4)
+    assert rel(a[0], So) <= 1e-9 and rel(a[1], ro) <= 1e-9
+    assert a[3].num_iterations == b[3].num_iterations and np.array_equal(a[4].accepted, b[4].accepted)
+    assert rel(a[2].intrinsics, b[2].intrinsics) <= 1e-9 and np.abs(a[2].cam_ext - b[2].cam_ext).max() <= 1e-8
+    assert not np.array_equal(a[2].intrinsics[:, 0], p.intrinsics[:, 0])
+
+
 def test_bundle_adjust_two_views_mirror_matches_oracle():
     """twoview.BundleAdjustTwoViews (bundle_adjust_two_views.cc:110-185): camera 1 fixed, camera 2 free, XYZW points
     without a manifold, focal lengths free unless held constant -- against the oracle on the same flat problem."""
