@@ -922,6 +922,14 @@ int build_gather_lists(theia_ba_handle_s* h, const int* ocam, const int* opt,
 // The gather lists when intrinsics are optimised (k_lin_obs_intr / k_schur_intr); see create().
 int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, const int* ocam,
                             const int* opt, const std::vector<int>& l_obs) {
+  const bool itiming = getenv("THEIA_HIP_CREATE_TIMING") != nullptr;
+  double it0 = now_s();
+  auto itick = [&](const char* what) {
+    if (!itiming) return;
+    const double t = now_s();
+    fprintf(stderr, "theia_hip create:     intrinsics lists: %-24s %8.2f ms\n", what, 1e3 * (t - it0));
+    it0 = t;
+  };
   int rc = 0;
   hipStream_t st = h->stream;
   // Gather lists with intrinsics (k_lin_obs_intr / k_schur_intr): records for every observation whose camera OR
@@ -935,12 +943,20 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
   // slots: sort the observations that need a record by (group, camera)
   std::vector<int> order;
   for (int64_t s = 0; s < nm; ++s) if (red[s] >= 0 || grd[s] >= 0) order.push_back((int)s);
-  std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-    if (grd[x] != grd[y]) return grd[x] < grd[y];
-    return red[x] < red[y];
-  });
+  {   // stable sort by (group, camera): two counting passes, camera first (keys start at -1)
+    std::vector<int> tmp(order.size());
+    for (int pass = 0; pass < 2; ++pass) {
+      const std::vector<int>& key = pass == 0 ? red : grd;
+      std::vector<size_t> cnt((size_t)(pass == 0 ? h->ncv : h->ngv) + 2, 0);
+      for (int x : order) cnt[(size_t)(key[x] + 1) + 1]++;
+      for (size_t k = 0; k + 1 < cnt.size(); ++k) cnt[k + 1] += cnt[k];
+      for (int x : order) tmp[cnt[(size_t)(key[x] + 1)]++] = x;
+      order.swap(tmp);
+    }
+  }
   std::vector<int> slot(nm, -1);
   for (size_t k = 0; k < order.size(); ++k) slot[order[k]] = (int)k;
+  itick("record order");
   std::vector<int> items;
   auto push_item = [&](int type, int row0, int col0, int64_t beg, int64_t end, int flags) {
     const int nchunk = (int)((end - beg + kChunk - 1) / kChunk);
@@ -962,6 +978,16 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
   std::vector<PairE> cc, cg, gg;
   const bool track_sums = !getenv("THEIA_HIP_INTR_PAIRS");
   const int nslots = (int)order.size();
+  {   // room for the entries up front (an upper bound: untouched pages cost nothing, growing by doubling copies 100s of MB)
+    size_t sum_l2 = 0;
+    for (int64_t s0 = 0; s0 < nm;) {
+      int64_t s1 = s0 + 1;
+      while (s1 < nm && opt[s1] == opt[s0]) ++s1;
+      if (!h->pt_const[opt[s0]]) sum_l2 += (size_t)(s1 - s0) * (size_t)(s1 - s0);
+      s0 = s1;
+    }
+    cc.reserve(sum_l2 / 2 + (size_t)nm); cg.reserve(sum_l2); gg.reserve(sum_l2);
+  }
   std::vector<int> pt_sum(track_sums ? h->np : 0, -1);   // pseudo-record slot of a track, -1 = none
   std::vector<uint8_t> slot_sum(track_sums ? std::max(1, nslots) : 0, 0);
   int nsums = 0;
@@ -994,20 +1020,31 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
     }
     s0 = s1;
   }
+  itick("pair entries");
   std::vector<int2> pairs;
+  pairs.reserve(cc.size() + cg.size() + gg.size());
   // entries are generated in ascending (a, b): two stable counting passes (low, then high half of the key)
   // order them by (key, a, b) without a comparison sort
   const size_t nbucket = (size_t)std::max(h->ncv, h->ngv) + 2;
   auto emit_pairs = [&](std::vector<PairE>& v, auto&& per_key) {
-    {
-      std::vector<PairE> tmp(v.size());
-      std::vector<size_t> cnt(nbucket + 1);
+    {   // each pass over a fixed 8-way partition of the entries with per-part histograms, on host threads (stable)
+      constexpr int kParts = 8;
+      const size_t nv = v.size();
+      const bool threaded = nv >= 262144;
+      std::vector<PairE> tmp(nv);
+      std::vector<std::vector<size_t>> cnt(kParts, std::vector<size_t>(nbucket));
       for (int pass = 0; pass < 2; ++pass) {
         const int sh = pass == 0 ? 0 : 32;
-        std::fill(cnt.begin(), cnt.end(), 0);
-        for (const PairE& e : v) cnt[(size_t)((e.key >> sh) & 0xffffffffu) + 1]++;
-        for (size_t k = 0; k < nbucket; ++k) cnt[k + 1] += cnt[k];
-        for (const PairE& e : v) tmp[cnt[(size_t)((e.key >> sh) & 0xffffffffu)]++] = e;
+        host_parts(kParts, threaded, [&](int k) {
+          std::fill(cnt[k].begin(), cnt[k].end(), 0);
+          for (size_t i = nv * k / kParts; i < nv * (k + 1) / kParts; ++i) cnt[k][(size_t)((v[i].key >> sh) & 0xffffffffu)]++;
+        });
+        size_t at = 0;
+        for (size_t b = 0; b < nbucket; ++b)
+          for (int k = 0; k < kParts; ++k) { const size_t c = cnt[k][b]; cnt[k][b] = at; at += c; }
+        host_parts(kParts, threaded, [&](int k) {
+          for (size_t i = nv * k / kParts; i < nv * (k + 1) / kParts; ++i) tmp[cnt[k][(size_t)((v[i].key >> sh) & 0xffffffffu)]++] = v[i];
+        });
         v.swap(tmp);
       }
     }
@@ -1033,6 +1070,7 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
     if (!compact) push_item(IT_GG1, 10 * ga, 10 * gb, beg, end, 1 | (ga == gb ? 2 : 0));
   });
   // (the CG / GG targets also receive the per-observation diagonal items below: always atomic)
+  itick("sorted pair lists");
   if (pairs.size() > (size_t)std::numeric_limits<int>::max() - 64)
     return set_error(THEIA_HIP_ERR_UNSUPPORTED, "too many observation pairs for 32-bit pair lists");
   // ---- per-observation (diagonal) items over contiguous slot ranges
@@ -1064,6 +1102,7 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
     UP(slot_obs, sobs);
   }
   UP(cam_obs, slot); UP(blk_items, items); UP(blk_pairs, pairs);
+  itick("items + uploads");
   h->n_trk_sums = nsums;
   if (nsums) { UP(pt_sum_slot, pt_sum); UP(slot_in_sum, slot_sum); }
   AL(rec, (std::max<size_t>(1, order.size()) + (size_t)h->n_trk_sums) * (12 * h->pd + 20 + 2 * h->intr_rows * h->pd + 3 * h->intr_rows));
