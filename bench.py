@@ -404,6 +404,22 @@ def main():
                                         "ms_per_step": 1e3 * ti / (nrep * si.num_iterations), "iterations_per_solve": si.num_iterations,
                                         "note": "use_inner_iterations = true (reference default): coordinate descent over cameras then points after each accepted step"}
         del hi
+        # the pipelines' default intrinsics subset (FOCAL_LENGTH | RADIAL_DISTORTION, reconstruction_estimator_options.h:281-283)
+        # on the same problem: the camera-side blocks are 6 + 10 wide and take the gather kernels, not the fused one
+        ok = bench_options(ba, ITERS_PER_SOLVE); ok.intrinsics_to_optimize = 0x01 | 0x10
+        tk0 = time.perf_counter(); hk = ba.BaHandle(pristine.copy(), ok); tk1 = time.perf_counter()
+        hk.reset(pristine); hk.snapshot()
+        hk.restore(); hk.run(trace_capacity=1)
+        torch.cuda.synchronize(); tk2 = time.perf_counter()
+        for _ in range(nrep):
+            hk.restore(); sk, _ = hk.run(trace_capacity=1)
+        torch.cuda.synchronize(); tk = time.perf_counter() - tk2
+        out["with_intrinsics"] = {"lm_iterations_per_sec": nrep * sk.num_iterations / tk,
+                                  "ms_per_step": 1e3 * tk / (nrep * sk.num_iterations), "iterations_per_solve": sk.num_iterations,
+                                  "handle_creation_ms": 1e3 * (tk1 - tk0),
+                                  "note": "intrinsics_to_optimize = FOCAL_LENGTH | RADIAL_DISTORTION over the problem's 8 shared groups "
+                                          "(k_lin_obs_intr + k_schur_intr, DESIGN.md 3.4); not the headline configuration"}
+        del hk
     if rank == 0 and world == 1:
         # what one theia_hip_ba_solve call costs end to end (BundleAdjustReconstruction through the boundary: host-side
         # structure analysis + uploads + 25 LM iterations + download), for the record next to the steady-state rate
