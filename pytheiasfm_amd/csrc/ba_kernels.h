@@ -77,6 +77,9 @@ struct DevProblem {
   const int2* blk_pairs;       // (slot of the obs of camera ri, slot of the obs of camera rj) of a common track
   const int* pt_sum_slot;      // [np] or null: pseudo-record slot of a track's summed intrinsics fields (k_lin_obs_intr), -1 = none
   const uint8_t* slot_in_sum;  // [#records] or null: the observation's track is summed (its own pair term is in the sum)
+  const uint8_t* pt_sum_cnt;   // [np]: pseudo-records (summed groups) of a track, pt_sum_slot[p] .. + cnt - 1
+  const int* sum_group;        // [#pseudo-records] reduced group of pseudo-record sum_base + j
+  int sum_base;
   // fused linearise + Schur (ba_fused.hip), ni == 0: static plan built at create()
   int n_fruns;
   const FusedRun* fruns;

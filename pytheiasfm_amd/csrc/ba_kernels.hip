@@ -612,31 +612,37 @@ __global__ __launch_bounds__(kBlock) void k_lin_obs_intr(DevProblem P, const dou
     for (int k = 0; k < KI / 2; ++k) R[O::TIG + k] = make_double2(tig[2 * k], tig[2 * k + 1]);
   }
   if (P.pt_sum_slot) {
-    // Tracks whose observations share one variable intrinsics group: the sums of WI and TI = WI V^-1 over the track go to
-    // a pseudo-record, and the camera x group / group x group pair lists hold (observation, sum) and (sum, sum) pairs
-    // instead of every ordered pair of the track's observations (build_gather_lists_intr).
-    const int ps = (L.active && sg.head && !L.pconst) ? P.pt_sum_slot[L.p] : -1;
-    double wsum[KI * PD];
+    // Tracks that see few variable intrinsics groups: the sums of WI and TI = WI V^-1 over the track's observations of a
+    // group go to a pseudo-record per group, and the camera x group / group x group pair lists hold (observation, sum)
+    // and (sum, sum) pairs instead of every ordered pair of the track's observations (build_gather_lists_intr).
+    const int base = (L.active && !L.pconst) ? P.pt_sum_slot[L.p] : -1;   // (every lane of the track: same values)
+    const int ngt = base >= 0 ? (int)P.pt_sum_cnt[L.p] : 0;
+    int nsum = 0;   // wave-uniform: most summed groups of a track of this tile (0: nothing to do)
+    for (int k = 1; k <= 4; ++k) if (__ballot(ngt >= k) != 0ull) nsum = k;
+    for (int k = 0; k < nsum; ++k) {
+      const int gk = k < ngt ? P.sum_group[base - P.sum_base + k] : -2;
+      double wsum[KI * PD];
 #pragma unroll
-    for (int k = 0; k < KI * PD; ++k) wsum[k] = wi[k];
-    if (__ballot(ps >= 0) != 0ull) segment_allsum_log<KI * PD>(sg, lane, wsum);   // (wave-uniform: no track of this tile is summed)
-    if (ps >= 0) {
-      using O = RecI<PD, KI>;
-      double2* R = reinterpret_cast<double2*>(P.rec + (size_t)ps * RS);
-      double tsum[KI * PD];
+      for (int j = 0; j < KI * PD; ++j) wsum[j] = (L.gr == gk) ? wi[j] : 0.0;
+      segment_allsum_log<KI * PD>(sg, lane, wsum);
+      if (sg.head && k < ngt) {
+        using O = RecI<PD, KI>;
+        double2* R = reinterpret_cast<double2*>(P.rec + (size_t)(base + k) * RS);
+        double tsum[KI * PD];
 #pragma unroll
-      for (int a = 0; a < KI; ++a)
+        for (int a = 0; a < KI; ++a)
 #pragma unroll
-        for (int b = 0; b < PD; ++b) {
-          double s2 = 0.0;
+          for (int b = 0; b < PD; ++b) {
+            double s2 = 0.0;
 #pragma unroll
-          for (int k = 0; k < PD; ++k) s2 += wsum[a * PD + k] * sym_get<PD>(Vi, k, b);
-          tsum[a * PD + b] = s2;
+            for (int q = 0; q < PD; ++q) s2 += wsum[a * PD + q] * sym_get<PD>(Vi, q, b);
+            tsum[a * PD + b] = s2;
+          }
+#pragma unroll
+        for (int j = 0; j < KI * PD / 2; ++j) {
+          R[O::WI + j] = make_double2(wsum[2 * j], wsum[2 * j + 1]);
+          R[O::TI + j] = make_double2(tsum[2 * j], tsum[2 * j + 1]);
         }
-#pragma unroll
-      for (int k = 0; k < KI * PD / 2; ++k) {
-        R[O::WI + k] = make_double2(wsum[2 * k], wsum[2 * k + 1]);
-        R[O::TI + k] = make_double2(tsum[2 * k], tsum[2 * k + 1]);
       }
     }
   }

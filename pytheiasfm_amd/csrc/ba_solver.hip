@@ -153,6 +153,9 @@ struct theia_ba_handle_s {
   DevBuf<int2> blk_pairs;
   DevBuf<int> pt_sum_slot;   // [np] pseudo-record of a track's summed intrinsics fields, -1 = none (build_gather_lists_intr)
   DevBuf<uint8_t> slot_in_sum;   // [#records] the observation's track is summed
+  DevBuf<uint8_t> pt_sum_cnt;    // [np] number of summed groups (pseudo-records) of a track
+  DevBuf<int> sum_group;         // [#pseudo-records] reduced group index
+  int sum_base = 0;              // first pseudo-record slot
   int n_trk_sums = 0;
   int n_diag_items = 0, n_blk_items = 0;
   // fused linearise + Schur plan (ba_fused.hip)
@@ -554,6 +557,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.n_sum_items = h->n_sum_items; P.sum_items = h->sum_items.p; P.sum_src = h->sum_src.p;
   P.diag_items = h->diag_items.p; P.rec_slot = h->cam_obs.p; P.slot_obs = h->slot_obs.p; P.slot_pt = h->slot_pt.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
   P.pt_sum_slot = h->n_trk_sums ? h->pt_sum_slot.p : nullptr; P.slot_in_sum = h->n_trk_sums ? h->slot_in_sum.p : nullptr;
+  P.pt_sum_cnt = h->n_trk_sums ? h->pt_sum_cnt.p : nullptr; P.sum_group = h->n_trk_sums ? h->sum_group.p : nullptr; P.sum_base = h->sum_base;
 }
 
 int upload_parameters(theia_ba_handle_s* h, const theia_ba_problem* p) {
@@ -968,8 +972,8 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
   };
   // ---- pair lists: entries (key, slot a, slot b) sorted by key; one item (or two halves) per key
   // Camera x camera blocks take every ordered pair of observations of a track.  For the blocks with an intrinsics group
-  // on one or both sides, a track whose observations share ONE variable group is represented by the SUM of their
-  // intrinsics fields (a pseudo-record behind the real ones, written by k_lin_obs_intr from a segmented wave sum):
+  // on one or both sides, a track that sees few variable groups is represented by the SUMS of its observations'
+  // intrinsics fields, one per group (pseudo-records behind the real ones, written by k_lin_obs_intr from segmented wave sums):
   // Sum_b T_a WI_b^T = T_a (Sum_b WI_b)^T, so the track gives L (observation, sum) pairs and one (sum, sum) pair instead
   // of 2 L (L - 1) ordered pairs.  The sum includes b == a, so the per-observation items leave that term out for the
   // observations of such a track (slot_in_sum).  Tracks that see several variable groups keep their explicit pairs.
@@ -990,16 +994,29 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
   }
   std::vector<int> pt_sum(track_sums ? h->np : 0, -1);   // pseudo-record slot of a track, -1 = none
   std::vector<uint8_t> slot_sum(track_sums ? std::max(1, nslots) : 0, 0);
+  std::vector<uint8_t> pt_cnt(track_sums ? h->np : 0, 0);   // number of summed groups of a track
+  std::vector<int> sum_group;                               // group of a pseudo-record
   int nsums = 0;
   for (int64_t s0 = 0; s0 < nm;) {
     int64_t s1 = s0 + 1;
     while (s1 < nm && opt[s1] == opt[s0]) ++s1;
     if (!h->pt_const[opt[s0]]) {
-      int g_one = -1, ng_var = 0;   // changes of variable group along the track (a group left and seen again counts twice:
-                                    // such a track keeps its pairs, like the long tracks, whose entries are all -1)
-      for (int64_t b2 = s0; b2 < s1; ++b2)
-        if (grd[b2] >= 0 && grd[b2] != g_one) { g_one = grd[b2]; ++ng_var; }
-      const bool sum_mode = track_sums && ng_var == 1;
+      // the track's variable groups in order of first appearance (long tracks carry -1 everywhere: none).  A track is
+      // summed per group when that shortens its lists: one group, or fewer groups (at most kMaxSumGroups) than
+      // observations of variable groups
+      constexpr int kMaxSumGroups = 4;
+      int tgs[kMaxSumGroups], ntg = 0, lg = 0;
+      bool many = false;
+      for (int64_t b2 = s0; b2 < s1; ++b2) {
+        if (grd[b2] < 0) continue;
+        ++lg;
+        bool seen = false;
+        for (int k = 0; k < ntg; ++k) seen |= tgs[k] == grd[b2];
+        if (seen) continue;
+        if (ntg == kMaxSumGroups) { many = true; break; }
+        tgs[ntg++] = grd[b2];
+      }
+      const bool sum_mode = track_sums && !many && ntg >= 1 && (ntg == 1 || ntg < lg);
       for (int64_t a = s0; a < s1; ++a)
         for (int64_t b = s0; b < s1; ++b) {
           if (a == b) continue;
@@ -1009,13 +1026,18 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
           if (grd[a] >= 0 && grd[b] >= 0 && grd[a] >= grd[b]) gg.push_back({((uint64_t)grd[a] << 32) | (uint32_t)grd[b], slot[a], slot[b]});
         }
       if (sum_mode) {
-        const int ps = nslots + nsums++;
-        pt_sum[opt[s0]] = ps;
+        const int ps = nslots + nsums;   // pseudo-records ps .. ps + ntg - 1, one per group
+        nsums += ntg;
+        pt_sum[opt[s0]] = ps; pt_cnt[opt[s0]] = (uint8_t)ntg;
+        for (int k = 0; k < ntg; ++k) sum_group.push_back(tgs[k]);
         for (int64_t a = s0; a < s1; ++a) {
           if (slot[a] >= 0) slot_sum[slot[a]] = 1;
-          if (red[a] >= 0) cg.push_back({((uint64_t)red[a] << 32) | (uint32_t)g_one, slot[a], ps});
+          if (red[a] >= 0)
+            for (int k = 0; k < ntg; ++k) cg.push_back({((uint64_t)red[a] << 32) | (uint32_t)tgs[k], slot[a], ps + k});
         }
-        gg.push_back({((uint64_t)g_one << 32) | (uint32_t)g_one, ps, ps});
+        for (int k = 0; k < ntg; ++k)
+          for (int k2 = 0; k2 < ntg; ++k2)
+            if (tgs[k] >= tgs[k2]) gg.push_back({((uint64_t)tgs[k] << 32) | (uint32_t)tgs[k2], ps + k, ps + k2});
       }
     }
     s0 = s1;
@@ -1104,7 +1126,8 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
   UP(cam_obs, slot); UP(blk_items, items); UP(blk_pairs, pairs);
   itick("items + uploads");
   h->n_trk_sums = nsums;
-  if (nsums) { UP(pt_sum_slot, pt_sum); UP(slot_in_sum, slot_sum); }
+  h->sum_base = nslots;
+  if (nsums) { UP(pt_sum_slot, pt_sum); UP(slot_in_sum, slot_sum); UP(pt_sum_cnt, pt_cnt); UP(sum_group, sum_group); }
   AL(rec, (std::max<size_t>(1, order.size()) + (size_t)h->n_trk_sums) * (12 * h->pd + 20 + 2 * h->intr_rows * h->pd + 3 * h->intr_rows));
   return 0;
 }
