@@ -1017,13 +1017,14 @@ def test_compact_intrinsics_rows_equal_full_rows():
     assert not np.array_equal(a[3].intrinsics[:, 0], p.intrinsics[:, 0])
 
 
-@pytest.mark.parametrize("groups,which", [(1, "focal_radial"), (2, "focal_radial"), (4, "focal_radial"), (1, "all"), (3, "all")])
+@pytest.mark.parametrize("groups,which", [(1, "focal_radial"), (2, "focal_radial"), (4, "focal_radial"), (7, "focal_radial"), (1, "all"), (3, "all")])
 def test_intrinsics_track_sums_equal_pair_lists_and_oracle(groups, which):
     """Tracks whose observations share one variable intrinsics group enter the camera x group and group x group blocks
     through the SUM of their intrinsics fields (pseudo-records written by k_lin_obs_intr) instead of through every
     ordered pair of observations (build_gather_lists_intr): the reduced system equals the one of the per-pair lists
     (THEIA_HIP_INTR_PAIRS=1) up to the summation order, and the oracle's; the LM trajectory follows.  One group: every
-    track is summed; 2 - 4 interleaved groups: summed tracks and tracks with explicit pairs share cameras and blocks."""
+    track is summed; 2 - 4 interleaved groups: one sum per group of a track, next to tracks that keep explicit pairs
+    (as many groups as observations); 7 groups: tracks beyond the four-group limit too, sharing cameras and blocks."""
     p = synth.synth_ba_v1(14, 1100, seed=0x7A5 + groups, num_groups=groups, fix_gauge=True, pixel_noise=0.3)
     intr = INTR_FOCAL_RADIAL if which == "focal_radial" else INTR_ALL
     o, oo = both_options(intrinsics_to_optimize=intr, max_num_iterations=6)
