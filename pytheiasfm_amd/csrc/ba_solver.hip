@@ -785,7 +785,7 @@ int build_gather_lists(theia_ba_handle_s* h, const int* ocam, const int* opt,
     }
     HBuf<int> sobs;
     const size_t nrec = (size_t)std::max(1, dbeg[h->ncv]);
-    if (!sobs.resize(nrec)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %zu records failed", nrec);
+    if (!sobs.resize(nrec, true)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %zu records failed", nrec);
     sobs[0] = 0;
     host_parts(kParts, threaded, [&](int k) {
       for (int64_t s = nm * k / kParts; s < nm * (k + 1) / kParts; ++s) { const int r = red_of(s); if (r >= 0) sobs[fill[k][r]++] = (int)s; }
@@ -799,7 +799,7 @@ int build_gather_lists(theia_ba_handle_s* h, const int* ocam, const int* opt,
       }
     }
     h->n_diag_items = (int)ditems.size() / 4; h->n_blk_items = 0;
-    if ((rc = h->slot_obs.upload(sobs.data(), nrec, st, true))) return rc;
+    if ((rc = h->slot_obs.upload(sobs.data(), nrec, st, sobs.pinned()))) return rc;
     UP(diag_items, ditems);   // pageable: synchronises the stream, the pinned block above is free after it
     return 0;
   }
@@ -1517,7 +1517,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   // offsets indexed by track RANK
   std::vector<int64_t> cnt_main(h->np + 1, 0), cnt_fix(h->np + 1, 0);
   HBuf<int> orank;   // rank of an observation's track (pinned block of the host cache: reused, no page faults)
-  if (!orank.resize((size_t)std::max<int64_t>(1, h->nobs))) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %lld observations failed", (long long)h->nobs);
+  if (!orank.resize((size_t)std::max<int64_t>(1, h->nobs), true)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %lld observations failed", (long long)h->nobs);
   host_chunks(h->nobs, [&](int64_t i0, int64_t i1) { for (int64_t i = i0; i < i1; ++i) orank[i] = prank[p->obs_pt[i]]; });
   host_chunks(h->np, [&](int64_t r0, int64_t r1) {   // threads own ranges of ranks, as above
     for (int64_t i = 0; i < h->nobs; ++i) {
@@ -1528,7 +1528,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   });
   for (int q = 0; q < h->np; ++q) { cnt_main[q + 1] += cnt_main[q]; cnt_fix[q + 1] += cnt_fix[q]; }
   h->nobs_main = cnt_main[h->np];
-  if (!h->perm.resize((size_t)std::max<int64_t>(1, h->nobs))) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %lld observations failed", (long long)h->nobs);
+  if (!h->perm.resize((size_t)std::max<int64_t>(1, h->nobs), true)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %lld observations failed", (long long)h->nobs);
   {
     std::vector<int64_t> fm(cnt_main.begin(), cnt_main.end() - 1), ff(cnt_fix.begin(), cnt_fix.end() - 1);
     host_chunks(h->np, [&](int64_t r0, int64_t r1) {   // observations of a track keep their input order
@@ -1578,7 +1578,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   HBuf<int> sred_b;
   int* sred = nullptr;
   if (h->use_fused) {
-    if (!sred_b.resize((size_t)h->nobs_main)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %lld observations failed", (long long)h->nobs_main);
+    if (!sred_b.resize((size_t)h->nobs_main, true)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %lld observations failed", (long long)h->nobs_main);
     sred = sred_b.data();
     host_chunks(h->nobs_main, [&](int64_t s0, int64_t s1) { for (int64_t s = s0; s < s1; ++s) sred[s] = h->cam_red[p->obs_cam[h->perm[s]]]; });
     std::atomic<long long> misfit{0};
@@ -1643,8 +1643,8 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   // fresh pageable vectors cost more in page faults than the gather itself, and the copies below run as plain DMA.
   HBuf<double2> uv, si;
   HBuf<int> ocam_b, opt_b;
-  if (!uv.resize((size_t)h->nobs) || !ocam_b.resize((size_t)h->nobs) || !opt_b.resize((size_t)h->nobs) ||
-      (p->obs_sqrt_info && !si.resize((size_t)h->nobs)))
+  if (!uv.resize((size_t)h->nobs, true) || !ocam_b.resize((size_t)h->nobs, true) || !opt_b.resize((size_t)h->nobs, true) ||
+      (p->obs_sqrt_info && !si.resize((size_t)h->nobs, true)))
     return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "pinned staging of %lld observations failed", (long long)h->nobs);
   int* const ocam = ocam_b.data();
   int* const opt = opt_b.data();
@@ -1660,8 +1660,9 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
 #define UP(buf, vec) do { rc = h->buf.upload(vec, st); if (rc) return rc; } while (0)
 #define AL(buf, cnt) do { rc = h->buf.alloc(cnt); if (rc) return rc; } while (0)
   tick("structure, sort, tiles");
-#define UPP(buf, src, cnt) do { rc = h->buf.upload(src, cnt, st, true); if (rc) return rc; } while (0)
-  UPP(obs_uv, uv.data(), (size_t)h->nobs); UPP(obs_si, si.data(), si.n); UPP(obs_cam, ocam, (size_t)h->nobs); UPP(obs_pt, opt, (size_t)h->nobs);
+#define UPP(buf, src, cnt, pin) do { rc = h->buf.upload(src, cnt, st, pin); if (rc) return rc; } while (0)
+  UPP(obs_uv, uv.data(), (size_t)h->nobs, uv.pinned()); UPP(obs_si, si.data(), si.n, si.pinned());
+  UPP(obs_cam, ocam, (size_t)h->nobs, ocam_b.pinned()); UPP(obs_pt, opt, (size_t)h->nobs, opt_b.pinned());
 #undef UPP
   h->inner = h->opt.use_inner_iterations != 0 && h->nobs_main > 0;
   if (h->inner) {

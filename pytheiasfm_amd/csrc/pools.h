@@ -127,19 +127,35 @@ template <typename T>
 struct HBuf {   // the std::vector calls the driver used, on a pinned block (contents are NOT preserved by a growing resize)
   T* p = nullptr;
   size_t cap = 0, bytes = 0, n = 0;
-  ~HBuf() { if (p) host_pool().give(p, bytes); }
-  bool reserve(size_t count) {
+  bool pageable = false;   // the pinned allocation failed and the caller accepts plain memory (handle creation at sizes
+                           // beyond what the host lets a process pin): copies from it must be synchronised at the call
+  HBuf() = default;
+  HBuf(const HBuf&) = delete;
+  HBuf& operator=(const HBuf&) = delete;
+  ~HBuf() { drop(); }
+  void drop() {
+    if (p) { if (pageable) std::free(p); else host_pool().give(p, bytes); }
+    p = nullptr; cap = 0; bytes = 0; pageable = false;
+  }
+  bool reserve(size_t count, bool allow_pageable = false) {
     if (count <= cap) return true;
-    if (p) host_pool().give(p, bytes);
-    p = nullptr; cap = 0; bytes = 0;
+    drop();
     size_t got = 0;
-    p = static_cast<T*>(host_pool().take(std::max<size_t>(count * sizeof(T), 4096), &got));
+    const size_t want = std::max<size_t>(count * sizeof(T), 4096);
+    const bool skip_pinned = allow_pageable && getenv("THEIA_HIP_NO_PINNED") != nullptr;   // (test switch for the fallback)
+    if (!skip_pinned) p = static_cast<T*>(host_pool().take(want, &got));
+    if (!p && allow_pageable) {
+      (void)hipGetLastError();
+      p = static_cast<T*>(std::malloc(want));
+      got = want; pageable = p != nullptr;
+    }
     if (!p) return false;
     bytes = got; cap = got / sizeof(T);
     return true;
   }
-  bool resize(size_t count) { if (!reserve(count)) return false; n = count; return true; }
+  bool resize(size_t count, bool allow_pageable = false) { if (!reserve(count, allow_pageable)) return false; n = count; return true; }
   bool assign(size_t count, T v) { if (!resize(count)) return false; for (size_t i = 0; i < count; ++i) p[i] = v; return true; }
+  bool pinned() const { return !pageable; }
   T* data() { return p; }
   T& operator[](size_t i) { return p[i]; }
   const T& operator[](size_t i) const { return p[i]; }

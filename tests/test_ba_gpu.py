@@ -339,6 +339,14 @@ def test_full_size_c4_properties():
     finally:
         del os.environ["THEIA_HIP_HOST_THREADS"]
     assert np.array_equal(tr1.cost[: tr1.size], tr.cost[: tr1.size]) and np.array_equal(tr1.step_norm[: tr1.size], tr.step_norm[: tr1.size])
+    # ... nor on where the host staging lives: pinned blocks of the library cache, or plain memory when the host does
+    # not let the process pin that much (THEIA_HIP_NO_PINNED forces the fallback)
+    os.environ["THEIA_HIP_NO_PINNED"] = "1"
+    try:
+        s4, tr4 = ba.solve(p.copy(), o3)
+    finally:
+        del os.environ["THEIA_HIP_NO_PINNED"]
+    assert np.array_equal(tr4.cost[: tr4.size], tr.cost[: tr4.size]) and np.array_equal(tr4.step_norm[: tr4.size], tr.step_norm[: tr4.size])
 
 
 @pytest.mark.parametrize("n", [1, 6, 24, 32, 33, 120, 121, 300, 1200])
