@@ -1793,6 +1793,14 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
       for (int a : tl) for (int b : tl) h->tile_adj[(size_t)a * nt + b] = 1;
     }
     }
+    // a variable camera's own 6 x 6 block is written whether or not any of its tracks is variable (F^T F, priors):
+    // its tile(s), and the off-diagonal tile when its rows straddle a 64-row boundary, always belong to the plan
+    for (int rcam = 0; rcam < h->ncv; ++rcam) {
+      const int s0 = h->ni + 6 * rcam, a = s0 / 64, b = (s0 + 5) / 64;
+      h->tile_adj[(size_t)a * nt + a] = 1;
+      h->tile_adj[(size_t)b * nt + b] = 1;
+      h->tile_adj[(size_t)a * nt + b] = h->tile_adj[(size_t)b * nt + a] = 1;
+    }
     // shared intrinsics couple with every camera of their group: treat as dense
     for (int a = 0; a < (h->ni + 63) / 64; ++a)
       for (int b = 0; b < nt; ++b) h->tile_adj[(size_t)a * nt + b] = h->tile_adj[(size_t)b * nt + a] = 1;

@@ -313,7 +313,23 @@ def _update_homogeneous_point(recon, track_mask):
 def _run_inverse_depth(options, recon, track_ids, const_view_ids=()):
     flat, added = _flatten_inverse_depth(recon, track_ids, const_view_ids)
     c_opts = options.to_c()
-    c_opts.use_inner_iterations = 0      # the reference passes no inner ordering in this mode (bundle_adjuster.cc:329-333)
+    # Only AddInvTrack runs in this mode (bundle_adjustment.cc:119-123,155-162,194-198): no view is ever entered into
+    # optimized_camera_intrinsics_groups_, so every intrinsics group the tracks touch is "potentially constant" and is
+    # frozen by SetCameraIntrinsicsParameterization (bundle_adjuster.cc:441-459) whatever intrinsics_to_optimize says.
+    c_opts.intrinsics_to_optimize = 0
+    # Stated deviation: with use_inner_iterations the reference hands Ceres NO inner ordering in this mode
+    # (bundle_adjuster.cc:328-333), and Ceres then builds its own independent-set ordering from its hash-ordered
+    # parameter graph -- not reproducible outside Ceres.  The sweeps are switched off here; the LM trajectory of a
+    # default-options call can therefore differ from the reference's after the first accepted step.
+    c_opts.use_inner_iterations = 0
+    # AddViewPriors (bundle_adjuster.cc:290-313) does run in this mode; the inverse-depth kernels carry no prior rows yet:
+    # refuse loudly instead of dropping the residual blocks.
+    wanted = ((capi.THEIA_PRIOR_POSITION if options.use_position_priors else 0) |
+              (capi.THEIA_PRIOR_GRAVITY if options.use_gravity_priors else 0) |
+              (capi.THEIA_PRIOR_ORIENTATION if options.use_orientation_priors else 0))
+    if wanted and recon.view_prior_mask is not None and np.any(np.asarray(recon.view_prior_mask) & wanted):
+        raise capi.TheiaHipError(capi.THEIA_HIP_ERR_UNSUPPORTED,
+                                 "inverse-depth bundle adjustment with camera priors is not built")
     s, _ = _ba.solve(flat, c_opts)
     recon.cam_ext[:] = flat.cam_ext
     recon.inverse_depth[added] = flat.point_inverse_depth[added]

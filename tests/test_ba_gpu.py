@@ -117,6 +117,34 @@ def test_constant_blocks_fixed_cost_and_masks():
     assert np.abs(pg.cam_ext - po.cam_ext).max() <= 1e-8 and np.abs(pg.points - po.points).max() <= 1e-8
 
 
+def test_views_against_constant_points_straddling_tile_boundaries():
+    """BundleAdjustViews-shaped problem: 40 variable cameras, every point constant.  The cameras at reduced index 10, 21,
+    31, ... have their 6 rows across a 64-row tile boundary of the reduced system; their diagonal block then lives in
+    three tiles, and no variable track marks any of them.  The tile-sparse plan must equal the dense schedule and the
+    oracle (every camera is an independent 6 x 6 problem)."""
+    p = synth.synth_ba_v1(40, 1500, seed=77)
+    p.point_const = np.ones(1500, np.uint8)
+    o, oo = both_options(max_num_iterations=6)
+    pg, pd_, po = p.copy(), p.copy(), p.copy()
+    s, tr = ba.solve(pg, o)
+    os.environ["THEIA_HIP_DENSE_CHOLESKY"] = "1"
+    try:
+        sd, trd = ba.solve(pd_, o)
+    finally:
+        del os.environ["THEIA_HIP_DENSE_CHOLESKY"]
+    so, tro = ol.solve(po, oo)
+    assert s.num_iterations == sd.num_iterations == so.num_iterations
+    assert rel(tr.cost[: tr.size], trd.cost[: trd.size]) < 1e-12 and np.array_equal(tr.accepted[: tr.size], trd.accepted[: trd.size])
+    assert abs(s.final_cost - so.final_cost) <= 1e-9 * so.final_cost
+    assert np.abs(pg.cam_ext - po.cam_ext).max() <= 1e-8 and np.abs(pg.cam_ext - pd_.cam_ext).max() <= 1e-10
+    assert np.array_equal(pg.points, p.points)
+    with ba.BaHandle(p.copy(), o) as h:   # two reduced systems in a row: nothing may accumulate across the per-iteration clear
+        S1, r1 = h.reduced_system(1e4)
+        S2, r2 = h.reduced_system(1e4)
+    So, ro = ol.reduced_system(p, oo, 1e4)
+    assert np.array_equal(S1, S2) and rel(S1, So) <= 1e-10 and rel(r1, ro) <= 1e-10
+
+
 def test_reference_threshold_tests_on_gpu():
     """bundle_adjustment_test.cc thresholds through the Python mirror."""
     from tests.test_oracle_ba import _view_scene

@@ -97,3 +97,25 @@ def test_five_point_verification_of_the_view_pairs_matches_the_oracle():
         Rm = res["models"][k][9:18].reshape(3, 3)
         ang = np.degrees(np.arccos(np.clip((np.trace(Rm @ Rrel.T) - 1) / 2, -1, 1)))
         assert ang < 1.0, ((i, j), ang)
+
+
+def test_reference_points_are_stationary_points_of_the_device_cost():
+    """tests/test_fountain.py::test_reference_points_are_stationary_points_of_the_oracle_cost through the HIP path: started at
+    the points Ceres left in fountain11.bin (cameras constant, TRIVIAL loss, SphereManifold<4>), the device LM stops by
+    Ceres' own rules without moving 16 560 of the 16 616 tracks (relative move < 1e-9), exactly the oracle's set; and the
+    batched per-track entry point (theia_hip_ba_tracks_batch = N x BundleAdjustTrack, the call that produced those points in
+    the reference) leaves the same tracks in place."""
+    from tests.test_fountain import stationary_tracks
+    d = ft.load()
+    o = ba.default_options(); o.max_num_iterations = 10
+    still, move, rel_dec, pg = stationary_tracks(d, ba.solve, o)
+    oo = ol.default_options(); oo.max_num_iterations = 10
+    still_o, _, _, po = stationary_tracks(d, ol.solve, oo)
+    assert still.sum() >= 16560 and np.array_equal(still, still_o)
+    assert move[still].max() < 1e-9 and abs(rel_dec) < 1e-6
+    assert np.abs(pg.points - po.points).max() <= 1e-9 * np.abs(po.points).max()
+    # N x BundleAdjustTrack in one launch (one LM per thread)
+    pt = ft.flat_problem(d, d["cam_ext"].copy(), d["points"].copy())
+    ba.solve_tracks_batch(pt, o)
+    mv = np.linalg.norm(pt.points - d["points"], axis=1) / np.linalg.norm(d["points"], axis=1)
+    assert (mv[still] < 1e-9).all() and (mv < 1e-9).sum() >= 16560
