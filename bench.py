@@ -239,7 +239,7 @@ def ransac_block(cpu_baseline, host_cores, rank=0, world=1):
 
             def one(i):
                 pc = p.to_c(); pc.min_iterations = hy; pc.max_iterations = hy; pc.seed = 1 + i
-                ol.ransac_estimate(est, data[offsets[i]:offsets[i + 1]], pc)
+                return ol.ransac_estimate(est, data[offsets[i]:offsets[i + 1]], pc)
             t0 = time.perf_counter()
             for i in range(8):
                 one(i)
@@ -247,8 +247,18 @@ def ransac_block(cpu_baseline, host_cores, rank=0, world=1):
             nall = min(CHUNK, max(8, 4 * host_cores))
             t0 = time.perf_counter()
             with ThreadPoolExecutor(max_workers=host_cores) as ex:   # ctypes releases the GIL: one oracle call per thread
-                list(ex.map(one, range(nall)))
+                ora = list(ex.map(one, range(nall)))
             dta = time.perf_counter() - t0
+            # inlier-set equality count of the GPU path against the CPU path on the same pairs / seeds
+            # (the CPU-baseline sample: the first `nall` pairs of the leg at `hy` iterations)
+            pe = ransac.RansacParameters(); pe.error_thresh = thresh; pe.min_iterations = hy; pe.max_iterations = hy; pe.seed = 1
+            rg = ransac.estimate_batch(est, data[: offsets[nall]], offsets[: nall + 1], pe)
+            eq = [bool(np.array_equal(ora[i]["inlier_mask"], rg["inlier_mask"][offsets[i]:offsets[i + 1]])) for i in range(nall)]
+            sym = [int((ora[i]["inlier_mask"] != rg["inlier_mask"][offsets[i]:offsets[i + 1]]).sum()) for i in range(nall)]
+            leg["inlier_set_equality"] = {"pairs_equal": int(sum(eq)), "pairs_compared": nall, "max_symmetric_difference": int(max(sym)),
+                                          "iterations_equal": int(sum(int(ora[i]["num_iterations"]) == int(rg["num_iterations"][i]) for i in range(nall))),
+                                          "sample": f"first {nall} pairs x {hy} hypotheses x {CORR} correspondences, per-pair seeds 1 + i, "
+                                                    "GPU path against oracle/ransac_oracle.cpp"}
             leg["cpu_baseline"] = {"value": nall * hy / dta, "unit": "hypotheses/s", "cores": host_cores, "kind": "port",
                                    "sample": f"{nall} pairs x {hy} hypotheses x {CORR} correspondences, one pair per host thread "
                                              f"(oracle/ransac_oracle.cpp, the reference's sequential loop per pair), {dta:.1f} s"}
