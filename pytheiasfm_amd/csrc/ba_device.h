@@ -486,9 +486,9 @@ THIP_DEV void observe(int model, const double* ext, const double* intr, const do
 
 // Per-camera block kept in HBM by k_cam_prep, so that an observation needs ONE dependent gather for everything keyed
 // by its camera: {position (3), angle-axis (3), R (9), A, B, cA, cB, small | Jacobi scaling of the six extrinsics
-// columns (0 = frozen column) | intrinsics of the camera's group (10) | model, reduced index, pad (2)} = 40 doubles.
+// columns (0 = frozen column) | intrinsics of the camera's group (10) | model, reduced index, group, pad} = 40 doubles.
 constexpr int kCamRot = 40;
-constexpr int kCamRotScale = 20, kCamRotIntr = 26, kCamRotModel = 36, kCamRotRed = 37;
+constexpr int kCamRotScale = 20, kCamRotIntr = 26, kCamRotModel = 36, kCamRotRed = 37, kCamRotGroup = 38;
 THIP_DEV void camrot_store(const double* ext, double* o) {
   RotTerms t;
   rotation_terms(ext + 3, t);

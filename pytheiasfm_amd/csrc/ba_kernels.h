@@ -19,6 +19,9 @@ struct FusedRun {
 inline int fused_tiles_per_subchunk(int) { return 4; }   // one wave per tile, 256-thread workgroups
 constexpr int kFusedMaxCams = 22;        // -> at most 253 target blocks = one per thread
 constexpr int kFusedTileTracks = 32;     // tracks per wave tile (128 per sub-chunk)
+// fused assembly with intrinsics (ba_fused_intr.hip): compound camera blocks [extrinsics (6) | compact intrinsics rows (4)]
+constexpr int kFusedIntrRows = 4, kFusedIntrWidth = 6 + kFusedIntrRows;
+constexpr int kFusedMaxCamsIntr = 12;    // -> at most 78 target blocks x 3 lanes
 
 // Device-resident problem (SoA, observations sorted by point and packed into
 // wave tiles of <= 64 observations that never split a point).
@@ -99,6 +102,10 @@ struct DevProblem {
   int n_sum_items;
   const int* sum_items;        // [n_sum_items][6] {ri, rj, tbeg, tend, dbeg, dend} into sum_src
   const int* sum_src;          // offsets into fpart
+  // fused_bw > 0 (ba_fused_intr.hip): the camera-side blocks are fused_bw wide, a local camera of a run is a camera with a
+  // variable extrinsics block OR a variable intrinsics group, sum_items / sum_src are the generic lists of k_sum_items
+  // (n_sum_items first-level items followed by n_sum_items2 second-level ones; sources are int pairs)
+  int fused_bw, n_sum_items2;
   // camera priors in use (compact list): 3 residuals each on one camera's extrinsics
   int n_priors;
   const int* prior_cam;        // [n_priors] camera index
@@ -157,6 +164,10 @@ void launch_linearize(const DevProblem& P, const double* cam, const double* pts,
 // fused path: k_cam_prep + k_lin_schur + k_schur_sum (S blocks are WRITTEN, the buffer must be clear where nothing lands)
 void launch_linearize_fused(const DevProblem& P, const double* cam, const double* pts, const double* radius /* device */,
                             const ReduceBuf& rb, double* Vinv, double* tile_part, hipStream_t st);
+void launch_linearize_fused_intr(const DevProblem& P, const double* cam, const double* pts, const double* radius /* device */,
+                                 const ReduceBuf& rb, double* Vinv, double* tile_part, hipStream_t st);
+// colsq_c[nc][6] / colsq_i[ng][10] += the squared column norms k_sum_items left by reduced index (Jacobi scaling)
+void launch_scatter_colsq(const DevProblem& P, const double* colsq_red, double* colsq_c, double* colsq_i, hipStream_t st);
 // per-camera blocks (rotation terms, masked scaling, intrinsics) of `cam` -> camrot (ba_fused.hip)
 void launch_cam_prep(const DevProblem& P, const double* cam, const double* intr, double* camrot, hipStream_t st, const double* ycam = nullptr);
 void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,

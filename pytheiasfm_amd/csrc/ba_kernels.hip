@@ -44,7 +44,8 @@ __global__ __launch_bounds__(kBlock) void k_colnorm(DevProblem P, const double* 
   LaneLin<PD, INTR> L;
   lane_linearize<PD, true, INTR>(P, cam, pts, start + lane, lane < cnt, lane, L);
   const Segment sg = lane_segment(L.p, lane);
-  const bool gather = P.slot_obs != nullptr;   // camera / intrinsics columns: k_colnorm_gather (no atomics)
+  // camera / intrinsics columns: k_colnorm_gather, or the fused kernel itself (compute_scale), no atomics
+  const bool gather = P.slot_obs != nullptr || P.fused_bw > 0;
   if constexpr (INTR) {
     if (!gather && L.active && L.gr >= 0) {
 #pragma unroll
@@ -1438,6 +1439,10 @@ void launch_linearize(const DevProblem& P, const double* cam, const double* pts,
     launch_linearize_fused(P, cam, pts, radius, rb, Vinv, tile_part, st);
     return;
   }
+  if (P.n_fruns > 0 && P.fused_bw > 0) {   // the same with compound [extrinsics | intrinsics] blocks (ba_fused_intr.hip)
+    launch_linearize_fused_intr(P, cam, pts, radius, rb, Vinv, tile_part, st);
+    return;
+  }
   if (P.rec && P.ni > 0) {   // intrinsics optimised: 16-wide camera-side blocks on the gather lists
     const int g = tile_blocks(P.ntiles);
 #define THIP_INTR(PD_, KI_)                                                                              \
@@ -1561,6 +1566,13 @@ void launch_backsub(const DevProblem& P, const double* cam, const double* pts, c
     launch_cam_prep(P, cand_cam, P.intr, P.camrot_cand, st, ycc);   // + the cameras' steps as {D, v} (P.camdir)
     if (P.pd == 3) k_backsub<3, false, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
     else k_backsub<4, false, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
+    return;
+  }
+  if (P.ni && P.fused_bw > 0 && P.n_fruns > 0 && P.camrot && P.camrot_cand) {
+    // fused path with intrinsics: the state's blocks are in P.camrot; the candidate cameras with the candidate intrinsics
+    launch_cam_prep(P, cand_cam, P.intr_cand, P.camrot_cand, st);
+    if (P.pd == 3) k_backsub<3, true, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
+    else k_backsub<4, true, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
     return;
   }
   if (P.ni) {

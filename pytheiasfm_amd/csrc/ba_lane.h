@@ -129,6 +129,7 @@ THIP_DEV void lane_linearize(const DevProblem& P, const double* __restrict__ cam
     camrot_load(cr, ext, rt);
     load_d2<20>(cr + kCamRotScale, blk);
     L.rc = (int)blk[kCamRotRed - kCamRotScale];
+    if constexpr (INTR) g = (int)blk[kCamRotGroup - kCamRotScale];
     model = depth_row ? THIP_MODEL_DEPTH_ROW : (int)blk[kCamRotModel - kCamRotScale];
     intr = blk + (kCamRotIntr - kCamRotScale);
   } else {
@@ -216,7 +217,7 @@ THIP_DEV void cam_prep_one(const DevProblem& P, int c, const double* ext, const 
   for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) o[kCamRotIntr + q] = intr[(size_t)g * THEIA_MAX_INTRINSICS + q];
   o[kCamRotModel] = (double)P.group_model[g];
   o[kCamRotRed] = (double)P.cam_red[c];
-  o[38] = 0.0; o[39] = 0.0;
+  o[kCamRotGroup] = (double)g; o[39] = 0.0;
 }
 
 struct Segment {

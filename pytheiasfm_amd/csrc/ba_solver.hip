@@ -122,6 +122,11 @@ struct theia_ba_handle_s {
   // host-side bookkeeping
   HBuf<int64_t> perm;              // sorted obs index -> original obs index (a block of the pinned host cache: no page faults)
   std::vector<int> cam_red, grp_red, grp_k;
+  // cameras that take part in the fused Schur assembly: a variable extrinsics block OR (fused_bw > 0) a variable intrinsics
+  // group.  cam_part[c] = index among them in camera order (-1 = none), part_cam = inverse.  Without variable intrinsics
+  // this is cam_red.
+  std::vector<int> cam_part, part_cam;
+  int ncp = 0, fused_bw = 0, n_sum_items2 = 0;
   std::vector<unsigned> grp_free;
   std::vector<uint8_t> cam_mask, pt_const;
   int ni = 0, ngv = 0;
@@ -555,6 +560,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   { const char* dbg = getenv("THEIA_HIP_FUSED_DBG"); P.fused_dbg = dbg ? atoi(dbg) : 0; }
   P.model_mask = h->model_mask;
   P.n_sum_items = h->n_sum_items; P.sum_items = h->sum_items.p; P.sum_src = h->sum_src.p;
+  P.fused_bw = h->use_fused ? h->fused_bw : 0; P.n_sum_items2 = h->n_sum_items2;
   P.diag_items = h->diag_items.p; P.rec_slot = h->cam_obs.p; P.slot_obs = h->slot_obs.p; P.slot_pt = h->slot_pt.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
   P.pt_sum_slot = h->n_trk_sums ? h->pt_sum_slot.p : nullptr; P.slot_in_sum = h->n_trk_sums ? h->slot_in_sum.p : nullptr;
   P.pt_sum_cnt = h->n_trk_sums ? h->pt_sum_cnt.p : nullptr; P.sum_group = h->n_trk_sums ? h->sum_group.p : nullptr; P.sum_base = h->sum_base;
@@ -622,6 +628,13 @@ int compute_scale(theia_ba_handle_s* h) {
   Q.scale_i = h->ones_i.p;
   Q.intr = h->intr[h->cur].p;
   launch_colnorm(Q, h->cam[h->cur].p, h->pts[h->cur].p, h->colsq_c0.p, h->colsq_p0.p, h->colsq_i0.p, h->stream);
+  if (Q.fused_bw > 0 && Q.n_fruns > 0) {
+    // camera and intrinsics columns: one pass of the fused kernel over unit scales -- its per-(camera, row) lanes already
+    // sum the squared column norms, k_sum_items leaves them by reduced index, the group columns summed over the group's
+    // cameras (fixed order, no atomics).  The reduced system it writes on the way is cleared by the first linearisation.
+    launch_linearize_fused_intr(Q, h->cam[h->cur].p, h->pts[h->cur].p, h->ones_c.p /* radius 1 */, h->rb, h->Vinv.p, h->tile_part.p, h->stream);
+    launch_scatter_colsq(Q, h->rb.colsq, h->colsq_c0.p, h->colsq_i0.p, h->stream);
+  }
   launch_long_colnorm(Q, h->cam[h->cur].p, h->pts[h->cur].p, h->colsq_c0.p, h->colsq_p0.p, h->long_scratch.p, h->stream, h->colsq_i0.p);
   launch_cam_priors(Q, PRIOR_COLNORM, h->cam[h->cur].p, nullptr, nullptr, nullptr, h->colsq_c0.p, nullptr, nullptr, h->stream);
   int rc = do_allreduce(h, h->colsq_c0.p, h->colsq_c0.n, THEIA_REDUCE_SUM);
@@ -1164,11 +1177,18 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
   FusedHost& fp = seg.fp;
   const int64_t nm = h->nobs_main;
   const int tps = fused_tiles_per_subchunk(h->pd);
+  // geometry of the consumer lanes: lanes per target block, rows per local camera, partial-sum doubles (ba_fused.hip:
+  // one lane per 6 x 6 block; ba_fused_intr.hip: 3 or 4 lanes per compound block, stored 10 x 10)
+  const int bw = h->fused_bw;
+  const size_t lanes_tgt = bw == 0 ? 1 : (bw == 9 ? 3 : 4), rows_cam = bw == 0 ? 6 : (size_t)bw;
+  const size_t part_tgt = bw == 0 ? 36 : 100, part_cam = bw == 0 ? 18 : 30;
+  const int max_cams = bw == 0 ? kFusedMaxCams : (bw == 9 ? kFusedMaxCamsIntr : 10);
+  const size_t max_tgts = bw == 0 ? 253 : 256 / lanes_tgt;
   // track slices per consumer wave for a run of ntgt target blocks over W cameras (0 = needs more than one wave)
-  auto packing = [](size_t ntgt, size_t W) -> int {
-    if (ntgt > 64 || 6 * W > 64) return 0;
+  auto packing = [&](size_t ntgt, size_t W) -> int {
+    if (lanes_tgt * ntgt > 64 || rows_cam * W > 64) return 0;
     static const int cand[6] = {10, 6, 4, 3, 2, 1};
-    for (int c : cand) if ((size_t)(64 / c) >= ntgt) return c;
+    for (int c : cand) if ((size_t)(64 / c) >= lanes_tgt * ntgt) return c;
     return 1;
   };
   const char* rm = getenv("THEIA_HIP_FUSED_RUN_OBS");
@@ -1186,8 +1206,8 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
   std::vector<int64_t> tp;
   int serial = 1, prev_serial = 0;
   std::vector<int> prev_tc;
-  std::vector<int> cam_stamp((size_t)std::max(1, h->ncv), 0);
-  std::vector<uint8_t> cam_local((size_t)std::max(1, h->ncv), 0);   // camera -> index in the closing run's sorted table
+  std::vector<int> cam_stamp((size_t)std::max(1, h->ncp), 0);
+  std::vector<uint8_t> cam_local((size_t)std::max(1, h->ncp), 0);   // camera -> index in the closing run's sorted table
   constexpr int kPairSlots = 2048;     // > 4 x 253
   std::vector<int64_t> pair_key(kPairSlots, 0);
   std::vector<int> pair_stamp(kPairSlots, 0);
@@ -1203,7 +1223,9 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
   auto mark_tiles = [&](int q) {   // tile co-visibility of a variable track (tc: its variable cameras, ascending)
     if (h->pt_const[porder[q]]) return;
     tl.clear();
-    for (int rcam : tc) {
+    for (int pcam : tc) {
+      const int rcam = h->cam_red[h->part_cam[pcam]];   // (participating camera -> reduced camera; constant: no rows in S)
+      if (rcam < 0) continue;
       const int s0 = h->ni + 6 * rcam;
       if (tl.empty() || tl.back() != s0 / 64) tl.push_back(s0 / 64);
       if ((s0 + 5) / 64 != s0 / 64) tl.push_back((s0 + 5) / 64);
@@ -1233,11 +1255,11 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
       const int la = cam_local[(int)(key >> 32)], lb = cam_local[(int)(key & 0xffffffff)];
       fp.tgts.push_back((unsigned short)(la | (lb << 8)));
     }
-    const int need = std::max(r.ntgt, 6 * r.W);
+    const int need = (int)std::max(lanes_tgt * r.ntgt, rows_cam * r.W);
     const int G = need <= 64 ? 1 : (need <= 128 ? 2 : 4);
     r.gp = G | ((G == 1 ? std::max(1, packing((size_t)r.ntgt, (size_t)r.W)) : 1) << 8);
     r.part_off = (int)fp.part_doubles;
-    fp.part_doubles += (size_t)r.ntgt * 36 + (size_t)r.W * 18;
+    fp.part_doubles += (size_t)r.ntgt * part_tgt + (size_t)r.W * part_cam;
     for (int t = run_tile0; t < run_tile0 + run_ntiles; ++t)
       for (int s = tstart[t]; s < tstart[t] + tcount[t]; ++s)
         if (sred[s] >= 0) obs_lc[s] = cam_local[sred[s]];
@@ -1261,7 +1283,7 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
     std::sort(tc.begin(), tc.end());
     const bool dup = std::adjacent_find(tc.begin(), tc.end()) != tc.end();
     mark_tiles(q);
-    if (L > 64 || dup || (int)tc.size() > kFusedMaxCams) {
+    if (L > 64 || dup || (int)tc.size() > max_cams) {
       close_tile(q);            // tiles are contiguous observation ranges
       push_long(q);
       continue;
@@ -1277,7 +1299,7 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
       for (int c : tc) ucams += cam_stamp[c] != serial;
       for (int64_t key : tp) upairs += pair_stamp[pair_slot(key)] != serial;
     }
-    bool new_run = (int)ucams > kFusedMaxCams || upairs > 253;
+    bool new_run = (int)ucams > max_cams || upairs > max_tgts;
     // a run keeps its packing level (track slices per wave) once it has some work, and stays inside one
     // first-camera key once it is large enough
     if (!new_run && run_obs >= 64 && packing(upairs, ucams) < packing(run_pairs.size(), run_cams.size())) new_run = true;
@@ -1290,8 +1312,10 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
       close_tile(q);
       // runs that need several waves per track slice walk their tracks (almost) serially: keep them short, so that
       // many workgroups share that work instead of a few long ones setting the kernel's duration
-      const size_t need = std::max(run_pairs.size(), 6 * run_cams.size());
-      const int64_t cap = need <= 64 ? run_max : (need <= 128 ? run_max / 4 : 1);
+      const size_t need = std::max(lanes_tgt * run_pairs.size(), rows_cam * run_cams.size());
+      // (compound blocks: nearly every run needs the whole workgroup per track slice, and a run's partial blocks are 44 KB --
+      // one run per sub-chunk wrote 420 MB of them per iteration at 1000 views / 500k tracks)
+      const int64_t cap = bw ? run_max : (need <= 64 ? run_max : (need <= 128 ? run_max / 4 : 1));
       if (run_ntiles % tps == 0 && run_obs >= cap) finalize_run();
     }
     if (t_len == 0) {
@@ -1318,6 +1342,102 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
   }
   close_tile(q_end);
   finalize_run();
+}
+
+// Sum lists of the fused assembly with intrinsics (k_sum_items, ba_fused_intr.hip): per block of S (camera x camera,
+// camera x group, group x group) and per vector block (rhs / gradient / column norms of a camera or a group) the pieces of
+// the runs' partial blocks that feed it, in run order.  A run's target (la, lb) holds the compound block
+// [cam_a | intr_a] x [cam_b | intr_b] as if the two cameras owned their intrinsics; the intrinsics rows / columns of every
+// camera of a group land on the group's (bundle_adjuster.cc:463-475: the cameras of a group share ONE parameter block).
+// Lists longer than 2 x chunk go through intermediate sums (SK_CHUNK items) and a second-level item.
+void build_sum_items_intr(theia_ba_handle_s* h, const int* cam_group, FusedHost& fp, int* n_items1, int* n_items2) {
+  constexpr int SK_BLOCK = 0, SK_LOWER = 1, SK_VEC = 2, SK_CHUNK = 3;
+  const int KI = h->fused_bw - 6, ni = h->ni;
+  struct Ent { int64_t key; int off, code, dims; };   // dims = nr | nc << 4 | kind << 8 | rgrp << 12 | cgrp << 13
+  std::vector<Ent> ents;
+  auto src_code = [](int r0, int c0, int tr, int stride) { return r0 | (c0 << 4) | (tr << 8) | (stride << 16); };
+  auto dims = [](int nr, int nc, int kind, int rg, int cg) { return nr | (nc << 4) | (kind << 8) | (rg << 12) | (cg << 13); };
+  auto key_blk = [](int row0, int col0) { return ((int64_t)row0 << 30) | (int64_t)col0; };
+  auto key_vec = [](int row0) { return ((int64_t)1 << 60) | ((int64_t)row0 << 30); };
+  size_t reserve = 0;
+  for (const FusedRun& r : fp.runs) reserve += (size_t)r.ntgt * 5 + (size_t)r.W * 2;
+  ents.reserve(reserve);
+  for (const FusedRun& r : fp.runs) {
+    auto cam_of = [&](int l) { return h->part_cam[fp.cams[r.cam_off + l]]; };
+    for (int k = 0; k < r.ntgt; ++k) {
+      const unsigned us = fp.tgts[r.tgt_off + k];
+      const int la = us & 0xff, lb = us >> 8;
+      const int ca = cam_of(la), cb = cam_of(lb);
+      const int rca = h->cam_red[ca], rcb = h->cam_red[cb], ga = h->grp_red[cam_group[ca]], gb = h->grp_red[cam_group[cb]];
+      const int base = r.part_off + 100 * k;
+      if (rca >= 0 && rcb >= 0)
+        ents.push_back({key_blk(ni + 6 * rca, ni + 6 * rcb), base, src_code(0, 0, 0, 10), dims(6, 6, la == lb ? SK_LOWER : SK_BLOCK, 0, 0)});
+      if (rca >= 0 && gb >= 0)
+        ents.push_back({key_blk(ni + 6 * rca, 10 * gb), base, src_code(0, 6, 0, 10), dims(6, KI, SK_BLOCK, 0, 1)});
+      if (la != lb && rcb >= 0 && ga >= 0)
+        ents.push_back({key_blk(ni + 6 * rcb, 10 * ga), base, src_code(6, 0, 1, 10), dims(6, KI, SK_BLOCK, 0, 1)});
+      if (ga >= 0 && gb >= 0) {
+        if (ga > gb) ents.push_back({key_blk(10 * ga, 10 * gb), base, src_code(6, 6, 0, 10), dims(KI, KI, SK_BLOCK, 1, 1)});
+        else if (ga < gb) ents.push_back({key_blk(10 * gb, 10 * ga), base, src_code(6, 6, 1, 10), dims(KI, KI, SK_BLOCK, 1, 1)});
+        else {
+          ents.push_back({key_blk(10 * ga, 10 * ga), base, src_code(6, 6, 0, 10), dims(KI, KI, SK_LOWER, 1, 1)});
+          if (la != lb) ents.push_back({key_blk(10 * ga, 10 * ga), base, src_code(6, 6, 1, 10), dims(KI, KI, SK_LOWER, 1, 1)});
+        }
+      }
+    }
+    for (int l = 0; l < r.W; ++l) {
+      const int c = cam_of(l), rc = h->cam_red[c], gr = h->grp_red[cam_group[c]];
+      const int base = r.part_off + 100 * r.ntgt + 30 * l;
+      if (rc >= 0) ents.push_back({key_vec(ni + 6 * rc), base, src_code(0, 0, 0, 3), dims(6, 3, SK_VEC, 0, 0)});
+      if (gr >= 0) ents.push_back({key_vec(10 * gr), base, src_code(6, 0, 0, 3), dims(KI, 3, SK_VEC, 1, 0)});
+    }
+  }
+  std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key < b.key; });
+  std::vector<int> items1, items2, src2;
+  fp.sum_src.clear();
+  fp.sum_src.reserve(2 * ents.size());
+  for (const Ent& e : ents) { fp.sum_src.push_back(e.off); fp.sum_src.push_back(e.code); }
+  size_t chunk_off = fp.part_doubles;
+  auto push = [](std::vector<int>& v, int row0, int col0, int code, int beg, int end, int dst) {
+    v.push_back(row0); v.push_back(col0); v.push_back(code); v.push_back(beg); v.push_back(end); v.push_back(dst);
+  };
+  const int nsrc1 = (int)ents.size();
+  for (size_t q = 0; q < ents.size();) {
+    size_t e = q;
+    while (e < ents.size() && ents[e].key == ents[q].key) ++e;
+    const int row0 = (int)((ents[q].key >> 30) & 0x3fffffff), col0 = (int)(ents[q].key & 0x3fffffff);
+    const int code = ents[q].dims, nr = code & 15, nc = (code >> 4) & 15;
+    const size_t cnt = e - q;
+    size_t ch = 256;
+    while (ch * ch < cnt) ++ch;
+    if (cnt <= 2 * ch) {
+      push(items1, row0, col0, code, (int)q, (int)e, 0);
+    } else {
+      const int beg2 = nsrc1 + (int)src2.size() / 2;
+      for (size_t c0 = q; c0 < e; c0 += ch) {
+        push(items1, 0, 0, (code & 0xff) | (SK_CHUNK << 8), (int)c0, (int)std::min(e, c0 + ch), (int)chunk_off);
+        src2.push_back((int)chunk_off); src2.push_back(nc << 16);
+        chunk_off += (size_t)nr * nc;
+      }
+      push(items2, row0, col0, code, beg2, nsrc1 + (int)src2.size() / 2, 0);
+    }
+    q = e;
+  }
+  fp.sum_src.insert(fp.sum_src.end(), src2.begin(), src2.end());
+  if (getenv("THEIA_HIP_CREATE_TIMING")) {
+    size_t longest = 0, nchunk = 0;
+    for (size_t k = 0; k < items1.size(); k += 6) {
+      longest = std::max<size_t>(longest, (size_t)(items1[k + 4] - items1[k + 3]));
+      nchunk += ((items1[k + 2] >> 8) & 15) == SK_CHUNK;
+    }
+    fprintf(stderr, "theia_hip sum lists: %zu first-level items (%zu chunks), %zu second-level, %d + %zu sources, longest list %zu, "
+            "%zu partial doubles + %zu chunk doubles\n", items1.size() / 6, nchunk, items2.size() / 6, nsrc1, src2.size() / 2, longest,
+            fp.part_doubles, chunk_off - fp.part_doubles);
+  }
+  fp.part_doubles = chunk_off;
+  *n_items1 = (int)items1.size() / 6; *n_items2 = (int)items2.size() / 6;
+  fp.sum_items = items1;
+  fp.sum_items.insert(fp.sum_items.end(), items2.begin(), items2.end());
 }
 
 // The segments in order -> one plan (offsets rebased), then per S block the partial sums that feed it, in run order.
@@ -1355,6 +1475,7 @@ void merge_fused_segments(const theia_ba_handle_s* h, std::vector<FusedSegment>&
     pt0 = t;
   };
   ptick("(since runs built)");
+  if (h->fused_bw) return;   // compound blocks: build_sum_items_intr (create())
   // per S block: the partial sums that feed it, in run order
   struct Ent { int64_t key; int src; int isd; };
   std::vector<Ent> ents;
@@ -1387,7 +1508,15 @@ void merge_fused_segments(const theia_ba_handle_s* h, std::vector<FusedSegment>&
 
 #undef UP
 #undef AL
+// (private return code of ba_create_impl: the fused intrinsics plan does not fit this problem, build it again on the gather lists)
+constexpr int kRetryWithoutFusedIntr = 0x7a11;
+static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_handle* out, bool allow_fused_intr);
 int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_handle* out) {
+  int rc = ba_create_impl(p, o, out, true);
+  if (rc == kRetryWithoutFusedIntr) rc = ba_create_impl(p, o, out, false);
+  return rc;
+}
+static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_handle* out, bool allow_fused_intr) {
   if (p && (p->flags & THEIA_BA_FLAG_INVERSE_DEPTH)) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse depth: use theia_hip_ba_solve (no handle API in this mode)");
   if (!out) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle pointer");
   *out = nullptr;
@@ -1455,6 +1584,16 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   }
   h->ni = THEIA_MAX_INTRINSICS * h->ngv;
   h->n = h->ni + 6 * h->ncv;
+  {   // fused assembly with intrinsics (ba_fused_intr.hip): compact rows, at most four free parameters per group
+    int most = 0;
+    for (int g = 0; g < h->ng; ++g) if (h->grp_red[g] >= 0) most = std::max(most, __builtin_popcount(h->grp_free[g]));
+    const char* force = getenv("THEIA_HIP_INTR_ROWS");
+    h->fused_bw = (allow_fused_intr && h->ni > 0 && most <= 4 && !(force && atoi(force) == 10) && !getenv("THEIA_HIP_INTR_GATHER")) ? (most <= 3 ? 9 : 10) : 0;
+    h->cam_part.assign(h->nc, -1);
+    h->ncp = 0;
+    for (int c = 0; c < h->nc; ++c)
+      if (h->cam_red[c] >= 0 || (h->fused_bw && cam_used[c] && h->grp_red[p->cam_group[c]] >= 0)) { h->cam_part[c] = h->ncp++; h->part_cam.push_back(c); }
+  }
 
   // Tracks are visited in the order of their first (lowest) variable camera of
   // the reduced ordering, so that a workgroup's tile range touches a short
@@ -1476,7 +1615,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
       const int q = p->obs_pt[i];
       if (q < q0 || q >= q1) continue;
       pt_used[q] = 1;
-      const int rc = h->cam_red[p->obs_cam[i]];
+      const int rc = h->cam_part[p->obs_cam[i]];
       if (rc >= 0) { nvar[q]++; if (rc < pkey[q]) pkey[q] = rc; }
     }
   });
@@ -1494,7 +1633,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
       static const int cut0 = getenv("THEIA_HIP_FUSED_CUT0") ? atoi(getenv("THEIA_HIP_FUSED_CUT0")) : 7;
       const int cls = ncls == 2 ? (nvar[q] <= cut0 ? 0 : 2) : (nvar[q] <= 3 ? 0 : (nvar[q] <= 6 ? 1 : 2));
       static const bool noclass = getenv("THEIA_HIP_FUSED_NOCLASS") != nullptr;
-      skey_pt[q] = pkey[q] == std::numeric_limits<int>::max() ? pkey[q] : ((h->ni == 0 && !noclass) ? pkey[q] * 4 + cls : pkey[q]);
+      skey_pt[q] = pkey[q] == std::numeric_limits<int>::max() ? pkey[q] : (((h->ni == 0 || h->fused_bw) && !noclass) ? pkey[q] * 4 + cls : pkey[q]);
     }
   }
   tick("  structure: masks, keys");
@@ -1574,13 +1713,14 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   // per-observation slow path there); THEIA_HIP_SCHUR_GATHER=1 selects the first-generation gather kernels.
   FusedHost fplan;
   tick("  structure: permutation");
-  h->use_fused = h->ni == 0 && h->nobs_main > 0 && !getenv("THEIA_HIP_SCHUR_GATHER");
+  h->use_fused = (h->ni == 0 || h->fused_bw) && h->nobs_main > 0 && !getenv("THEIA_HIP_SCHUR_GATHER");
+  const int fused_max_cams = h->fused_bw == 0 ? kFusedMaxCams : (h->fused_bw == 9 ? kFusedMaxCamsIntr : 10);
   HBuf<int> sred_b;
   int* sred = nullptr;
   if (h->use_fused) {
     if (!sred_b.resize((size_t)h->nobs_main, true)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %lld observations failed", (long long)h->nobs_main);
     sred = sred_b.data();
-    host_chunks(h->nobs_main, [&](int64_t s0, int64_t s1) { for (int64_t s = s0; s < s1; ++s) sred[s] = h->cam_red[p->obs_cam[h->perm[s]]]; });
+    host_chunks(h->nobs_main, [&](int64_t s0, int64_t s1) { for (int64_t s = s0; s < s1; ++s) sred[s] = h->cam_part[p->obs_cam[h->perm[s]]]; });
     std::atomic<long long> misfit{0};
     host_chunks(h->np, [&](int64_t q0, int64_t q1) {   // tracks are independent
       std::vector<int> tc;
@@ -1591,11 +1731,12 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
         tc.clear();
         for (int64_t s = cnt_main[q]; s < cnt_main[q + 1]; ++s) if (sred[s] >= 0) tc.push_back(sred[s]);
         std::sort(tc.begin(), tc.end());
-        if ((int)tc.size() > kFusedMaxCams || std::adjacent_find(tc.begin(), tc.end()) != tc.end()) mine += L;
+        if ((int)tc.size() > fused_max_cams || std::adjacent_find(tc.begin(), tc.end()) != tc.end()) mine += L;
       }
       misfit += mine;
     });
     if (misfit.load() * 20 > h->nobs_main) h->use_fused = false;
+    if (!h->use_fused && h->fused_bw) return kRetryWithoutFusedIntr;   // the keys above speak of participating cameras: start over
   }
   tick("  structure: fit check");
   if (h->use_fused) {
@@ -1623,6 +1764,12 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
       for (auto& x : th) x.join();
     }
     merge_fused_segments(h, segs, tstart, tcount, tkey, l_obs, l_slot, l_start, l_pt, fplan);
+    if (h->fused_bw) {
+      int n1 = 0, n2 = 0;
+      build_sum_items_intr(h, p->cam_group, fplan, &n1, &n2);
+      h->n_sum_items2 = n2;
+      tick("  structure: sum lists (intrinsics)");
+    }
     if (fplan.part_doubles > (size_t)std::numeric_limits<int>::max() / 2)
       return set_error(THEIA_HIP_ERR_UNSUPPORTED, "partial-sum buffer of the fused Schur assembly exceeds 32-bit offsets");
   } else {
@@ -1810,7 +1957,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   }
   if (h->ni == 0 && h->ntiles_main > 0 && (rc = build_gather_lists(h, ocam, opt, l_obs, !h->use_fused))) return rc;
   if (h->use_fused) {
-    h->n_fruns = (int)fplan.runs.size(); h->n_sum_items = (int)fplan.sum_items.size() / 6;
+    h->n_fruns = (int)fplan.runs.size(); h->n_sum_items = (int)fplan.sum_items.size() / 6 - h->n_sum_items2;
     fplan.tile_trk_end.resize(std::max<size_t>(1, fplan.tile_trk_end.size()));
     if (ctiming) {   // THEIA_HIP_CREATE_TIMING: shape of the fused plan
       std::map<int, std::pair<int, int>> by;   // gp -> (runs, sub-chunks)
@@ -1826,7 +1973,8 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
         // static round robin left workgroups with one run more than others waiting for them
       std::vector<int> order(fplan.runs.size());
       for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-      auto cost = [&](int i) { const FusedRun& r = fplan.runs[i]; return (long long)r.ntiles * (64 + r.ntgt); };
+      const int lanes_tgt = h->fused_bw == 0 ? 1 : (h->fused_bw == 9 ? 3 : 4);
+      auto cost = [&](int i) { const FusedRun& r = fplan.runs[i]; return (long long)r.ntiles * (64 + lanes_tgt * r.ntgt); };
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
       UP(frun_order, order);
       AL(frun_next, 1);
@@ -1836,7 +1984,7 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
     AL(fpart, std::max<size_t>(1, fplan.part_doubles));
     AL(camrot, (size_t)40 * std::max(1, h->nc)); AL(camrot_cand, (size_t)40 * std::max(1, h->nc)); AL(camdir, (size_t)12 * std::max(1, h->nc));
   }
-  if (h->ni > 0 && h->ntiles_main > 0 && (rc = build_gather_lists_intr(h, p, ocam, opt, l_obs))) return rc;
+  if (h->ni > 0 && !h->use_fused && h->ntiles_main > 0 && (rc = build_gather_lists_intr(h, p, ocam, opt, l_obs))) return rc;
 #undef UP
 #undef AL
   tick("gather lists");

@@ -15,7 +15,7 @@ for f in $SRCS; do
     # kernels of the large solve are compared at 1e-9 .. 1e-12 and take the FMAs (half the FP64 issue slots)
     # (and reciprocal-based division: 1 ulp, far inside those bounds)
     CONTRACT=off
-    case "$f" in ba_fused.hip|ba_kernels.hip) CONTRACT="fast -freciprocal-math -fno-math-errno -fapprox-func" ;; esac
+    case "$f" in ba_fused.hip|ba_fused_intr.hip|ba_kernels.hip) CONTRACT="fast -freciprocal-math -fno-math-errno -fapprox-func" ;; esac
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=$CONTRACT -munsafe-fp-atomics \
       -I../../include -I. -c "$f" -o "$o" &
     PIDS="$PIDS $!"

@@ -1166,3 +1166,42 @@ def test_two_view_ba_batch_matches_the_general_solver():
     bo.ba_options.max_num_iterations = 20
     rsb = tv.BundleAdjustTwoViews(bo, allc[:ns[0]], cam1, cam2, np.ascontiguousarray(q), batched=False)
     assert bool(sb.success) == bool(rsb.success)
+
+
+@pytest.mark.parametrize("groups,intr,manifold,mixed", [(1, 0x11, 1, False), (3, 0x11, 1, True), (7, 0x11, 0, False),
+                                                          (2, 0x13, 1, False), (8, 0x11, 1, True)])
+def test_fused_intrinsics_assembly_matches_gather_kernels_and_oracle(groups, intr, manifold, mixed):
+    """Intrinsics free (FOCAL_LENGTH | RADIAL_DISTORTION: three compact rows; with ASPECT_RATIO: four): the fused kernel of
+    ba_fused_intr.hip -- compound [extrinsics | intrinsics] blocks per camera pair, the groups' rows summed afterwards
+    (k_sum_items) -- against the first-generation gather kernels (THEIA_HIP_INTR_GATHER=1) and the oracle: reduced system,
+    LM trajectory, parameters.  fix_gauge holds two cameras constant whose intrinsics groups stay variable (they take part
+    in the runs with a zero extrinsics block); mixed = pinhole + double-sphere groups; manifold 0 = XYZW points."""
+    p = synth.synth_ba_v1(24, 2500, seed=0x1F5 + groups, num_groups=groups, fix_gauge=True, pixel_noise=0.3, mixed_models=mixed)
+    o, oo = both_options(intrinsics_to_optimize=intr, max_num_iterations=6, use_homogeneous_point_parametrization=manifold)
+    res = []
+    for gather in (False, True):
+        if gather:
+            os.environ["THEIA_HIP_INTR_GATHER"] = "1"
+        try:
+            with ba.BaHandle(p.copy(), o) as h:
+                S, rhs = h.reduced_system(1e4)
+                S2, rhs2 = h.reduced_system(1e4)
+                assert np.array_equal(S, S2) and np.array_equal(rhs, rhs2)      # written, not accumulated; fixed order
+            q = p.copy()
+            s, tr = ba.solve(q, o)
+            res.append((S, rhs, q, s, tr))
+        finally:
+            os.environ.pop("THEIA_HIP_INTR_GATHER", None)
+    a, b = res
+    So, ro = ol.reduced_system(p, oo, 1e4)
+    assert a[0].shape == b[0].shape == So.shape
+    assert rel(a[0], b[0]) <= 1e-12 and rel(a[1], b[1]) <= 1e-11
+    assert rel(a[0], So) <= 1e-10 and rel(a[1], ro) <= 1e-10
+    qo = p.copy()
+    so, tro = ol.solve(qo, oo)
+    assert a[3].num_iterations == b[3].num_iterations == so.num_iterations
+    n = a[4].size
+    assert np.array_equal(a[4].accepted[:n], tro.accepted[:n]) and rel(a[4].cost[:n], tro.cost[:n]) <= 1e-9
+    assert rel(a[2].intrinsics, qo.intrinsics) <= 1e-9 and np.abs(a[2].cam_ext - qo.cam_ext).max() <= 1e-8
+    assert np.abs(a[2].points - qo.points).max() <= 1e-8
+    assert not np.array_equal(a[2].intrinsics[:, 0], p.intrinsics[:, 0])
