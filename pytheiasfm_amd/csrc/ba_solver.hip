@@ -2123,8 +2123,11 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   std::memset(&st, 0, sizeof(st));
   st.radius = 1e4; st.decrease_factor = 2.0; st.step_successful = 1; st.first = 1;
   st.term = THEIA_TERM_NO_CONVERGENCE; st.pending_grad = -1;
-  // inner iterations need every residual block of a camera on this rank: not in sharded solves
-  const bool inner = h->inner && O.use_inner_iterations != 0 && !h->allreduce;
+  // inner iterations need every residual block of a camera on this rank: a sharded solve that asks for them (the
+  // reference's default, bundle_adjustment.h:144) is refused instead of silently walking another trajectory
+  if (h->allreduce && O.use_inner_iterations != 0 && h->nobs > 0)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_inner_iterations in a sharded solve is not built: set it to 0 on every rank");
+  const bool inner = h->inner && O.use_inner_iterations != 0;
   st.inner_enabled = inner ? 1 : 0;
   LmState* dst = reinterpret_cast<LmState*>(h->lm_state.p);
   // the initial state and the control block travel as kernel arguments (k_lm_init): no host buffer whose

@@ -130,6 +130,62 @@ __global__ __launch_bounds__(256) void k_sp_update(double* __restrict__ A, int l
     }
 }
 
+// Deferred updates of the dense border (the shared-intrinsics tiles, ordered last): a target (I, J) with both tiles in
+// the border receives a source from EVERY camera tile, and it is not read before the border's own levels.  Instead of one
+// workgroup walking 30+ sources per level, the whole list is cut into chunks summed by separate workgroups
+// (k_sp_update_partial -> scratch tiles) and added in chunk order (k_sp_update_reduce) right before the first border level.
+// partial item: {row0, h, col0, w, sbeg, send, slot}; reduce item: {row0, h, col0, w, slot0, nslots, diag}
+__global__ __launch_bounds__(256) void k_sp_update_partial(const double* __restrict__ A, int lda, const int* __restrict__ items,
+                                                           const int* __restrict__ srcs, double* __restrict__ scratch) {
+  __shared__ double Pr[NB][LDP];
+  __shared__ double Pc[NB][LDP];
+  const int* it = items + 7 * blockIdx.x;
+  const int row0 = it[0], h = it[1], col0 = it[2], w = it[3], sbeg = it[4], send = it[5];
+  double* out = scratch + (size_t)it[6] * NB * NB;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  double4_t acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int s = sbeg; s < send; ++s) {
+    const int k0 = srcs[2 * s], nb = srcs[2 * s + 1];
+    if (s > sbeg) __syncthreads();
+    load_tile(Pr, A, lda, row0, h, k0, nb, tid);
+    load_tile(Pc, A, lda, col0, w, k0, nb, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < NB; kk += 4) {
+      const double a = Pr[16 * wv + li][kk + lk];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Pc[16 * q + li][kk + lk], acc[q], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) out[(16 * wv + lk + 4 * reg) * NB + 16 * q + li] = acc[q][reg];
+}
+
+__global__ __launch_bounds__(256) void k_sp_update_reduce(double* __restrict__ A, int lda, const int* __restrict__ items,
+                                                          const double* __restrict__ scratch) {
+  // 16 workgroups per target, one element per thread, the chunk tiles added in slot order with eight loads in flight
+  const int* it = items + 7 * (blockIdx.x >> 4);
+  const int row0 = it[0], h = it[1], col0 = it[2], w = it[3], slot0 = it[4], nslots = it[5], diag = it[6];
+  const int e = (blockIdx.x & 15) * 256 + threadIdx.x, r = e >> 6, c = e & 63;
+  if (r >= h || c >= w || (diag && c > r)) return;
+  const double* src = scratch + (size_t)slot0 * NB * NB + e;
+  double v = 0.0;
+  int s = 0;
+  for (; s + 8 <= nslots; s += 8) {
+    double t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(s + u) * NB * NB];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  for (; s < nslots; ++s) v += src[(size_t)s * NB * NB];
+  A[(size_t)(row0 + r) * lda + col0 + c] -= v;
+}
+
 // x_K = Linv_K^T (y_K - sum_I L(I,K)^T x_I), I over the (already solved) ancestors
 __global__ __launch_bounds__(256) void k_sp_back(const double* __restrict__ A, int lda, const int* __restrict__ items,
                                                  const int* __restrict__ srcs, const double* __restrict__ Linv,
@@ -292,8 +348,11 @@ struct CholPlan {
   int symm_off = 0, nsymm = 0;
   int clear_off = 0, nclear = 0;   // {r0, h, c0, w} of every structure tile (fill included) at its physical lower position
   double flops = 0.0;              // FP64 flops of one factorisation + solve on this schedule (useful ones: h x w x nb extents)
+  // deferred border updates (k_sp_update_partial / k_sp_update_reduce), run before level def_level
+  int def_level = -1, def_part_off = 0, n_def_part = 0, def_src_off = 0, def_red_off = 0, n_def_red = 0;
   int* prog = nullptr;   // device
-  ~CholPlan() { if (prog) (void)hipFree(prog); }
+  double* scratch = nullptr;   // device: partial tiles of the deferred updates
+  ~CholPlan() { if (prog) (void)hipFree(prog); if (scratch) (void)hipFree(scratch); }
 };
 
 CholPlan* chol_plan_create(int n, const uint8_t* adj) {
@@ -336,6 +395,14 @@ CholPlan* chol_plan_create(int n, const uint8_t* adj) {
   auto hh = [&](int I) { return I == nt ? 1 : std::min(NB, n - perm[I] * NB); };
   std::vector<int> prog;
   pl->lev.resize(best.nlev);
+  // border = the dense nodes when they close the order: targets inside it collect their sources over all earlier levels
+  int first_border = nt;
+  if (!dense_nodes.empty() && !getenv("THEIA_HIP_NO_DEFERRED_BORDER")) {
+    first_border = nt - (int)dense_nodes.size();
+    for (size_t k = 0; k < dense_nodes.size(); ++k) if (perm[first_border + (int)k] != dense_nodes[k]) first_border = nt;   // natural order won
+  }
+  const int border_level = first_border < nt ? best.level[first_border] : best.nlev;
+  std::map<std::pair<int, int>, std::vector<int>> deferred;
   for (int l = 0; l < best.nlev; ++l) {
     Level& lv = pl->lev[l];
     std::vector<int> ks;
@@ -351,8 +418,13 @@ CholPlan* chol_plan_create(int n, const uint8_t* adj) {
       for (int I : s) { prog.push_back(r0(I)); prog.push_back(hh(I)); prog.push_back(r0(K)); prog.push_back(hh(K)); prog.push_back(K); lv.ntrsm++;
         pl->flops += 2.0 * hh(I) * (double)hh(K) * hh(K); }
       for (size_t a = 0; a < s.size(); ++a)
-        for (size_t b = 0; b <= a; ++b)
-          if (s[b] != nt) targets[{s[a], s[b]}].push_back(K);
+        for (size_t b = 0; b <= a; ++b) {
+          if (s[b] == nt) continue;
+          // (s[a] >= s[b]: both in the border, or the rhs row against a border tile -- the forward substitution of the
+          // border rows is not read before the border's levels either)
+          const bool defer = l < border_level && s[b] >= first_border;
+          (defer ? deferred : targets)[{s[a], s[b]}].push_back(K);
+        }
     }
     lv.upd_off = (int)prog.size(); lv.nupd = (int)targets.size();
     std::vector<int> srcs;
@@ -377,6 +449,35 @@ CholPlan* chol_plan_create(int n, const uint8_t* adj) {
     }
     lv.back_src_off = (int)prog.size();
     prog.insert(prog.end(), bsrc.begin(), bsrc.end());
+  }
+  if (!deferred.empty()) {
+    constexpr int kChunk = 6;   // sources per partial workgroup
+    pl->def_level = border_level;
+    std::vector<int> part, red, srcs;
+    int slot = 0;
+    for (auto& kv : deferred) {
+      const int I = kv.first.first, J = kv.first.second;
+      const int slot0 = slot;
+      for (size_t c0 = 0; c0 < kv.second.size(); c0 += kChunk) {
+        part.push_back(r0(I)); part.push_back(hh(I)); part.push_back(r0(J)); part.push_back(hh(J));
+        part.push_back((int)srcs.size() / 2);
+        for (size_t k = c0; k < std::min(kv.second.size(), c0 + kChunk); ++k) {
+          const int K = kv.second[k];
+          srcs.push_back(r0(K)); srcs.push_back(hh(K)); pl->flops += 2.0 * hh(I) * (double)hh(J) * hh(K);
+        }
+        part.push_back((int)srcs.size() / 2);
+        part.push_back(slot++);
+      }
+      red.push_back(r0(I)); red.push_back(hh(I)); red.push_back(r0(J)); red.push_back(hh(J));
+      red.push_back(slot0); red.push_back(slot - slot0); red.push_back(I == J ? 1 : 0);
+    }
+    pl->def_part_off = (int)prog.size(); pl->n_def_part = (int)part.size() / 7;
+    prog.insert(prog.end(), part.begin(), part.end());
+    pl->def_src_off = (int)prog.size();
+    prog.insert(prog.end(), srcs.begin(), srcs.end());
+    pl->def_red_off = (int)prog.size(); pl->n_def_red = (int)red.size() / 7;
+    prog.insert(prog.end(), red.begin(), red.end());
+    if (hipMalloc((void**)&pl->scratch, sizeof(double) * (size_t)slot * NB * NB) != hipSuccess) { pl->scratch = nullptr; pl->dense = true; pl->lev.clear(); return pl; }
   }
   // tiles of the factor structure that sit in the physical upper triangle
   pl->symm_off = (int)prog.size();
@@ -447,7 +548,12 @@ void chol_plan_solve(const CholPlan* pl, double* A, int lda, double* b, double* 
   double* x = inplace ? b : work + (size_t)pl->nt * NB * NB;
   const int* pg = pl->prog;
   if (pl->nsymm) k_sp_symm<<<pl->nsymm, 256, 0, st>>>(A, lda, pg + pl->symm_off);
+  int li = 0;
   for (const Level& lv : pl->lev) {
+    if (li++ == pl->def_level && pl->n_def_part) {
+      k_sp_update_partial<<<pl->n_def_part, 256, 0, st>>>(A, lda, pg + pl->def_part_off, pg + pl->def_src_off, pl->scratch);
+      k_sp_update_reduce<<<pl->n_def_red * 16, 256, 0, st>>>(A, lda, pg + pl->def_red_off, pl->scratch);
+    }
     k_sp_potrf<<<lv.npotrf, 256, 0, st>>>(A, lda, pg + lv.potrf_off, Linv, fail_flag);
     if (lv.ntrsm) k_sp_trsm<<<lv.ntrsm, 256, 0, st>>>(A, lda, pg + lv.trsm_off, Linv);
     if (lv.nupd) k_sp_update<<<lv.nupd, 256, 0, st>>>(A, lda, pg + lv.upd_off, pg + lv.upd_src_off);

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from pytheiasfm_amd import ba, distributed as tdist, synth
+from pytheiasfm_amd import _capi as capi, ba, distributed as tdist, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -56,6 +56,13 @@ def test_allreduce_callback_path_world_size_1():
         assert s2.num_iterations == s.num_iterations and s2.final_cost == s.final_cost
         assert np.array_equal(out2.cam_ext, out.cam_ext) and np.array_equal(out2.points, out.points)
         assert np.array_equal(np.asarray(tr2.gradient_max_norm), np.asarray(tr.gradient_max_norm))
+        # the reference's default use_inner_iterations = true cannot be honoured across shards: refused, not ignored
+        oi = ba.default_options(); oi.use_inner_iterations = 1
+        with ba.BaHandle(shard, oi) as h:
+            h.set_allreduce(cb)
+            with pytest.raises(capi.TheiaHipError) as ei:
+                h.run()
+            assert ei.value.code == capi.THEIA_HIP_ERR_UNSUPPORTED
     finally:
         dist.destroy_process_group()
 
