@@ -191,18 +191,18 @@ def cpu_ba_baseline(pristine, nobs_total, threads, n_it, what):
 
 def ransac_block(cpu_baseline, host_cores, rank=0, world=1):
     """BASELINE.json configs[4] on one GPU: 10 000 pairs x 2000 correspondences x 4096 hypotheses, five-point relative
-    pose, SQPnP and DLS absolute pose (DLS on a tenth of the pairs).  FLOP/s: SURVEY.md 8d counts (score: 85 FLOP per model and
+    pose, SQPnP and DLS absolute pose.  FLOP/s: SURVEY.md 8d counts (score: 85 FLOP per model and
     correspondence; fit: per-solve counts of the restated solvers)."""
     from pytheiasfm_amd import ransac, synth
     PAIRS, CORR, HYPS, CHUNK = 10000, 2000, 4096, 1000
     out = {"workload": f"synth_ransac_v1 C5: {PAIRS} pairs x {CORR} correspondences x {HYPS} hypotheses (min = max iterations), InlierSupport",
            "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS}
     # (name, estimator, data kind, threshold, FLOP per minimal solve, FLOP per model x correspondence, chunks of 1000 pairs run)
-    # DLS: ~0.23 MFLOP for the blocked Macaulay elimination + ~0.35 MFLOP for the 27 x 27 eigen-decomposition per solve; one
-    # chunk of the 10 (1000 pairs x 4096 hypotheses) keeps the default run inside a few minutes
+    # DLS: ~0.23 MFLOP for the blocked Macaulay elimination + ~0.35 MFLOP for the 27 x 27 eigen-decomposition per solve
+    # (all ten chunks: 40.96 M hypotheses, about half a minute)
     legs = (("five_point_relative_pose", ransac.EST_RELATIVE_POSE, "relative", (2.0 / 1000.0) ** 2, 2.5e4, 85.0, PAIRS // CHUNK),
             ("sqpnp_absolute_pose", ransac.EST_ABS_SQPNP, "absolute", (4.0 / 1000.0) ** 2, 3.0e4, 30.0, PAIRS // CHUNK),
-            ("dls_absolute_pose", ransac.EST_ABS_DLS, "absolute", (4.0 / 1000.0) ** 2, 5.8e5, 30.0, max(1, world)))
+            ("dls_absolute_pose", ransac.EST_ABS_DLS, "absolute", (4.0 / 1000.0) ** 2, 5.8e5, 30.0, PAIRS // CHUNK))
     for name, est, kind, thresh, fit_flop, score_flop, nchunks in legs:
         p = ransac.RansacParameters(); p.error_thresh = thresh; p.min_iterations = HYPS; p.max_iterations = HYPS; p.seed = 1
         tot = {"hyp": 0, "models": 0, "wall": 0.0, "fit": 0.0, "score": 0.0, "kern": 0.0}
@@ -355,6 +355,8 @@ def main():
         nl = max(1, acc["launches"])
         avg_lin = acc["lin_kernel"] / nl
         achieved = abytes / avg_lin / 1e9 if (abytes and avg_lin > 0) else 0.0
+        Ltrk = np.bincount(prob.obs_pt)      # this rank's tracks (all of them at N = 1)
+        afma = float(108.0 * np.sum(Ltrk * (Ltrk + 1) // 2) + 300.0 * prob.obs_uv.shape[0])
         k3_s = acc["solve"] / nl
         out = {
             "metric": "BA residuals/sec (LM-iterations/sec x observations); RANSAC hypotheses/sec alongside",
@@ -382,7 +384,12 @@ def main():
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": 1e3 * avg_lin,
                          "launches": acc["launches"],
                          "timing": "HIP events around the kernel group on the library's stream, instrumented pass of the same workload right after the timed region",
-                         "note": "FP64 issue bound in practice (DESIGN.md 3.4): 1.35 G pair-product FMAs + the linearisation per launch"},
+                         # the governing roofline of this arithmetic: algorithmic FP64 FMAs of the launch group
+                         # -- 108 per pair of observations of a track (diagonal included) + ~300 per linearised observation --
+                         # over the launch time, against the FP64 vector peak (39.3 T FMA/s = 78.6 TFLOP/s)
+                         "fp64_vector_frac": (afma / avg_lin / (0.5e12 * FP64_VECTOR_PEAK_TFLOPS)) if avg_lin > 0 else 0.0,
+                         "algorithmic_fma_per_launch": afma,
+                         "note": "FP64 latency / issue bound in practice (DESIGN.md 3.4): the pair-product FMAs + the linearisation per launch"},
             "roofline_k3": {"kernel": "reduced-camera solve (tile-sparse level-scheduled Cholesky, FP64 MFMA trsm / update)",
                             "bound": "mfma", "achieved": info["k3_flops"] / k3_s / 1e12 if k3_s > 0 else 0.0,
                             "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -415,7 +422,7 @@ def main():
                                         "note": "use_inner_iterations = true (reference default): coordinate descent over cameras then points after each accepted step"}
         del hi
         # the pipelines' default intrinsics subset (FOCAL_LENGTH | RADIAL_DISTORTION, reconstruction_estimator_options.h:281-283)
-        # on the same problem: the camera-side blocks are 6 + 10 wide and take the gather kernels, not the fused one
+        # on the same problem: compound [extrinsics | intrinsics] camera blocks in the fused kernel of ba_fused_intr.hip
         ok = bench_options(ba, ITERS_PER_SOLVE); ok.intrinsics_to_optimize = 0x01 | 0x10
         tk0 = time.perf_counter(); hk = ba.BaHandle(pristine.copy(), ok); tk1 = time.perf_counter()
         hk.reset(pristine); hk.snapshot()
@@ -428,7 +435,7 @@ def main():
                                   "ms_per_step": 1e3 * tk / (nrep * sk.num_iterations), "iterations_per_solve": sk.num_iterations,
                                   "handle_creation_ms": 1e3 * (tk1 - tk0),
                                   "note": "intrinsics_to_optimize = FOCAL_LENGTH | RADIAL_DISTORTION over the problem's 8 shared groups "
-                                          "(k_lin_obs_intr + k_schur_intr, DESIGN.md 3.4); not the headline configuration"}
+                                          "(k_lin_schur_i + k_sum_items: fused, records in LDS, DESIGN.md 3.5); not the headline configuration"}
         del hk
     if rank == 0 and world == 1:
         # what one theia_hip_ba_solve call costs end to end (BundleAdjustReconstruction through the boundary: host-side

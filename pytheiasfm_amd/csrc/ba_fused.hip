@@ -303,7 +303,8 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
               const double t0v = Fa[a] * M[0][0] + Fa[6 + a] * M[1][0];   // (F_a^T M)[a][0..1]
               const double t1v = Fa[a] * M[0][1] + Fa[6 + a] * M[1][1];
 #pragma unroll
-              for (int b2 = 0; b2 < 6; ++b2) acc[a * 6 + b2] += t0v * Fb[b2] + t1v * Fb[6 + b2];
+              for (int b2 = 0; b2 < 6; ++b2)   // two chained FMAs: `acc += x y + z w` compiles to mul + fma + add (no reassociation)
+                acc[a * 6 + b2] = __builtin_fma(t1v, Fb[6 + b2], __builtin_fma(t0v, Fb[b2], acc[a * 6 + b2]));
             }
           }
         }
@@ -318,9 +319,9 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
             const double2 rr = px[6 + PD], rv = px[6 + PD + 1];   // r,  r - Ehat ghat
             // column da of F: two LDS reads (no dynamic register indexing)
             const double fa0 = s_rec[sd * RD + da], fa1 = s_rec[sd * RD + 6 + da];
-            dacc[0] += fa0 * rv.x + fa1 * rv.y;
-            dacc[1] += fa0 * rr.x + fa1 * rr.y;
-            dacc[2] += fa0 * fa0 + fa1 * fa1;
+            dacc[0] = __builtin_fma(fa1, rv.y, __builtin_fma(fa0, rv.x, dacc[0]));
+            dacc[1] = __builtin_fma(fa1, rr.y, __builtin_fma(fa0, rr.x, dacc[1]));
+            dacc[2] = __builtin_fma(fa1, fa1, __builtin_fma(fa0, fa0, dacc[2]));
           }
         }
       }

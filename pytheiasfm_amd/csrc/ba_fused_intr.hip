@@ -294,7 +294,8 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
                 for (int a = 0; a < kRPL; ++a)
 #pragma unroll
                   for (int q = 0; q < 5; ++q)
-                    if (5 * hb + q < BW) acc[a * BW + 5 * hb + q] += t0v[a] * Fb0[q] + t1v[a] * Fb1[q];
+                    if (5 * hb + q < BW)   // two chained FMAs (`acc += x y + z w` compiles to mul + fma + add)
+                      acc[a * BW + 5 * hb + q] = __builtin_fma(t1v[a], Fb1[q], __builtin_fma(t0v[a], Fb0[q], acc[a * BW + 5 * hb + q]));
               }
             }
           }
@@ -307,9 +308,9 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
               const double2* px = reinterpret_cast<const double2*>(s_rec + sd * RD);
               const double2 rr = px[kBWP + PD], rv = px[kBWP + PD + 1];
               const double fa0 = s_rec[sd * RD + da], fa1 = s_rec[sd * RD + kBWP + da];
-              dacc[0] += fa0 * rv.x + fa1 * rv.y;
-              dacc[1] += fa0 * rr.x + fa1 * rr.y;
-              dacc[2] += fa0 * fa0 + fa1 * fa1;
+              dacc[0] = __builtin_fma(fa1, rv.y, __builtin_fma(fa0, rv.x, dacc[0]));
+              dacc[1] = __builtin_fma(fa1, rr.y, __builtin_fma(fa0, rr.x, dacc[1]));
+              dacc[2] = __builtin_fma(fa1, fa1, __builtin_fma(fa0, fa0, dacc[2]));
             }
           }
         }
