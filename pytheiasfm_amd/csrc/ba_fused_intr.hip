@@ -85,6 +85,20 @@ __device__ __forceinline__ void fusedi_phase_l(const DevProblem* __restrict__ Pp
       jk[k] = v0; jk[KR + k] = v1;
     }
   }
+  const int o = start + lane;
+  const int tl = active ? P.obs_tl[o] : 0;
+  const unsigned lc = active ? P.obs_lc[o] : 0xffu;
+  // the camera-side rows of the record leave the registers at once (20 doubles that nothing below needs again)
+  if (active && lc != 0xffu) {
+    double2* R = reinterpret_cast<double2*>(s_rec + (wv * 64 + lane) * RD);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) R[5 * i + q] = make_double2(L.Jc[6 * i + 2 * q], L.Jc[6 * i + 2 * q + 1]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) R[5 * i + 3 + q] = make_double2(jk[KR * i + 2 * q], jk[KR * i + 2 * q + 1]);
+    }
+  }
   const Segment sg = lane_segment_all(L.p, lane);
   double tot[NT + PD];
 #pragma unroll
@@ -94,9 +108,6 @@ __device__ __forceinline__ void fusedi_phase_l(const DevProblem* __restrict__ Pp
     tot[NT + a] = L.Jt[a] * L.r[0] + L.Jt[PD + a] * L.r[1];
   }
   segment_allsum_log<NT + PD>(sg, lane, tot);
-  const int o = start + lane;
-  const int tl = active ? P.obs_tl[o] : 0;
-  const unsigned lc = active ? P.obs_lc[o] : 0xffu;
   const unsigned tmask = segment_or_i(sg, lane, (active && lc != 0xffu) ? (1u << lc) : 0u);
   double V[NT], Vi[NT], g[PD];
 #pragma unroll
@@ -149,13 +160,6 @@ __device__ __forceinline__ void fusedi_phase_l(const DevProblem* __restrict__ Pp
         eh[i * PD + b] = s;
       }
     double2* R = reinterpret_cast<double2*>(s_rec + slot * RD);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) R[5 * i + q] = make_double2(L.Jc[6 * i + 2 * q], L.Jc[6 * i + 2 * q + 1]);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) R[5 * i + 3 + q] = make_double2(jk[KR * i + 2 * q], jk[KR * i + 2 * q + 1]);
-    }
 #pragma unroll
     for (int q = 0; q < PD; ++q) R[kBWP + q] = make_double2(eh[2 * q], eh[2 * q + 1]);
     R[kBWP + PD] = make_double2(L.r[0], L.r[1]);
@@ -216,26 +220,8 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
     const int nsc = (run.ntiles + TPS - 1) / TPS;
     __syncthreads();
 
-    // ---- phase-S role.  lix = lane index inside the track slice this lane serves: target block lix / NS, rows
-    // sub_row0(lix % NS) .. of it; for the per-observation terms lane (local camera, row) = dix
     const int G = run.gp & 0xff, PS = run.gp >> 8;
-    int lix, t0, tstride;
-    bool slice_ok = true;
     const int B = 64 / PS;
-    if (G == 1) { const int g = lane / B; lix = lane - g * B; slice_ok = g < PS; t0 = wv * PS + g; tstride = NWV * PS; }
-    else { lix = (wv % G) * 64 + lane; t0 = wv / G; tstride = NWV / G; }
-    const int tix = lix / NS, sub = lix - tix * NS;
-    const int row0 = sub_row0<KI>(sub);
-    const bool has_tgt = slice_ok && tix < run.ntgt;
-    int la = 0, lb = 0;
-    if (has_tgt) { const unsigned us = P.frun_tgt[run.tgt_off + tix]; la = us & 0xffu; lb = us >> 8; }
-    const int dix = (G == 1) ? lane : lix;
-    const bool has_d = dix < BW * run.W;
-    const int dlc = has_d ? dix / BW : 0, da = dix % BW;
-    const int dP = (G == 1) ? PS : 1, dbase = (G == 1) ? wv * PS : wv / G;
-    const unsigned tbits = has_tgt ? ((1u << la) | (1u << lb)) : 0xffffffffu;
-    const unsigned dbit = has_d ? (1u << dlc) : 0x80000000u;
-    const double diag_core = (has_tgt && la == lb) ? 1.0 : 0.0;
     double acc[NA], dacc[3];
 #pragma unroll
     for (int k = 0; k < NA; ++k) acc[k] = 0.0;
@@ -246,6 +232,25 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
       fusedi_phase_l<PD, TPS, MODELS>(&s_P, &s_run, pts, inv_radius, sc, Vinv, tile_part, s_rec, s_tslot, s_tmask);
       __syncthreads();
       {
+        // ---- phase-S role (recomputed per sub-chunk: a dozen integers that need not stay in registers across phase L).  lix = lane index inside the track slice this lane serves: target block lix / NS, rows
+      // sub_row0(lix % NS) .. of it; for the per-observation terms lane (local camera, row) = dix
+      int lix, t0, tstride;
+      bool slice_ok = true;
+      if (G == 1) { const int g = lane / B; lix = lane - g * B; slice_ok = g < PS; t0 = wv * PS + g; tstride = NWV * PS; }
+      else { lix = (wv % G) * 64 + lane; t0 = wv / G; tstride = NWV / G; }
+      const int tix = lix / NS, sub = lix - tix * NS;
+      const int row0 = sub_row0<KI>(sub);
+      const bool has_tgt = slice_ok && tix < run.ntgt;
+      int la = 0, lb = 0;
+      if (has_tgt) { const unsigned us = P.frun_tgt[run.tgt_off + tix]; la = us & 0xffu; lb = us >> 8; }
+      const int dix = (G == 1) ? lane : lix;
+      const bool has_d = dix < BW * run.W;
+      const int dlc = has_d ? dix / BW : 0, da = dix % BW;
+      const int dP = (G == 1) ? PS : 1, dbase = (G == 1) ? wv * PS : wv / G;
+      const unsigned tbits = has_tgt ? ((1u << la) | (1u << lb)) : 0xffffffffu;
+      const unsigned dbit = has_d ? (1u << dlc) : 0x80000000u;
+      const double diag_core = (has_tgt && la == lb) ? 1.0 : 0.0;
+
         const int last_tile = min(run.tile0 + TPS * sc + TPS - 1, run.tile0 + run.ntiles - 1);
         const int ntr = P.tile_trk_end[last_tile];
 #pragma unroll 1
@@ -318,6 +323,24 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
       __syncthreads();
     }
     // ---- combine the track slices in a fixed order; the first replica of a lane role writes the rows it owns
+    // (the lane's role again:  lix = lane index inside the track slice this lane serves: target block lix / NS, rows
+    // sub_row0(lix % NS) .. of it; for the per-observation terms lane (local camera, row) = dix
+    int lix, t0, tstride;
+    bool slice_ok = true;
+    if (G == 1) { const int g = lane / B; lix = lane - g * B; slice_ok = g < PS; t0 = wv * PS + g; tstride = NWV * PS; }
+    else { lix = (wv % G) * 64 + lane; t0 = wv / G; tstride = NWV / G; }
+    const int tix = lix / NS, sub = lix - tix * NS;
+    const int row0 = sub_row0<KI>(sub);
+    const bool has_tgt = slice_ok && tix < run.ntgt;
+    int la = 0, lb = 0;
+    if (has_tgt) { const unsigned us = P.frun_tgt[run.tgt_off + tix]; la = us & 0xffu; lb = us >> 8; }
+    const int dix = (G == 1) ? lane : lix;
+    const bool has_d = dix < BW * run.W;
+    const int dlc = has_d ? dix / BW : 0, da = dix % BW;
+    const int dP = (G == 1) ? PS : 1, dbase = (G == 1) ? wv * PS : wv / G;
+    const unsigned tbits = has_tgt ? ((1u << la) | (1u << lb)) : 0xffffffffu;
+    const unsigned dbit = has_d ? (1u << dlc) : 0x80000000u;
+    const double diag_core = (has_tgt && la == lb) ? 1.0 : 0.0;
     double* scratch = s_rec;   // NA doubles per thread (NA <= RD)
     double* out = P.fpart + run.part_off;
     const int nrep = (G == 1) ? NWV * PS : NWV / G;
