@@ -264,7 +264,6 @@ def ransac_block(cpu_baseline, host_cores, rank=0, world=1):
                                              f"(oracle/ransac_oracle.cpp, the reference's sequential loop per pair), {dta:.1f} s"}
             leg["cpu_baseline_single_thread"] = {"value": 8 * hy / dt1, "unit": "hypotheses/s", "cores": 1, "kind": "port",
                                                  "sample": f"8 pairs x {hy} hypotheses, {dt1:.1f} s"}
-            leg["speedup_vs_cpu_baseline"] = leg["hypotheses_per_sec"] / leg["cpu_baseline"]["value"]
         out[name] = leg
     return out
 
@@ -480,8 +479,10 @@ def main():
         out["cpu_baseline"]["host_cores_available"] = host_cores
         out["cpu_baseline"]["threads_tried_iterations_per_sec"] = {str(k): v["lm_iterations_per_sec"] for k, v in tried.items()}
         out["cpu_baseline_single_thread"] = cpu_ba_baseline(pristine, nobs_total, 1, 1, what)
-        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        out["speedup_vs_cpu_single_thread"] = out["value"] / out["cpu_baseline_single_thread"]["value"]
+        # (no GPU / CPU ratio is quoted: the port stops scaling at a fraction of the host's cores -- `cores` is the thread count
+        # that ran fastest, `threads_tried_iterations_per_sec` the others -- and the roofline fractions above, not a ratio
+        # against it, say how good the kernels are)
+        out["cpu_baseline"]["phase_s_note"] = "parallel Jet evaluation and two-phase camera-chunk Schur elimination; the envelope Cholesky of the reduced system is one thread"
 
     if world == 1 and not args.no_ransac:
         out["ransac"] = ransac_block(not args.no_cpu_baseline, host_cores)

@@ -172,14 +172,16 @@ __global__ __launch_bounds__(256) void k_inner_views(InnerArgs A) {
     double acc[28];
     for (int k = 0; k < 28; ++k) acc[k] = 0.0;
     double inv = 0.0;
+    RotTerms rt;   // one camera, one rotation: the terms once per evaluation, not once per observation (observe() = these + observe_rot())
+    rotation_terms(ext + 3, rt);
     for (int i = beg + lane; i < end; i += 64) {
       const ObsRef ob = load_obs(A, A.cam_obs_idx[i]);
       const double4 Xv = reinterpret_cast<const double4*>(A.pts)[ob.pt];
       const double X[4] = {Xv.x, Xv.y, Xv.z, Xv.w};
       ObsLin ol;
       const int m = ob.depth_row ? THIP_MODEL_DEPTH_ROW : model;
-      if (want_jac) observe<true, false>(m, ext, intr, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
-      else observe<false, false>(m, ext, intr, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
+      if (want_jac) observe_rot<true, false>(m, ext, rt, intr, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
+      else observe_rot<false, false>(m, ext, rt, intr, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
       if (!ol.valid) inv += 1.0;
       double rho1;
       acc[27] += 0.5 * obs_loss(A, ob, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
@@ -295,7 +297,11 @@ __global__ __launch_bounds__(256) void k_inner_groups(InnerArgs A) {
 // accumulate() is kept out of line on purpose: with it inlined into the LM loop, hipcc 7.2 -O2 / -O3 produced wrong
 // steps for this per-thread kernel (the -O1 build, the build with the body behind a call, and the two cooperative
 // kernels above all agree with the oracle to 1e-14; scripts/gpu_check_inner.py with THEIA_HIP_INNER_SKIP=3).
-template <int PD>
+// ROT: the cameras' rotation terms, intrinsics and model come from the 40-double blocks k_inner_cam_blocks left in
+// P.camrot_cand after the camera / intrinsics sweeps (ba_device.h kCamRot) -- one gather instead of a sincos and the
+// camera -> group -> intrinsics chain per observation and LM iteration; observe() = rotation_terms() + observe_rot(), so
+// the bits are the same.
+template <int PD, bool ROT>
 struct TrackFn {
   const InnerArgs* A;
   int beg, end;
@@ -307,13 +313,24 @@ struct TrackFn {
     bool inv = false;
     for (int o = beg; o < end; ++o) {
       const ObsRef ob = load_obs(Ar, o);
-      const int grp = Ar.P.cam_group[ob.cam];
-      const int m = ob.depth_row ? THIP_MODEL_DEPTH_ROW : Ar.P.group_model[grp];
-      const double* ext = Ar.cam + 6 * (size_t)ob.cam;
-      const double* kk = Ar.intr + (size_t)grp * THEIA_MAX_INTRINSICS;
       ObsLin ol;
-      if (want_jac) observe<true, false>(m, ext, kk, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
-      else observe<false, false>(m, ext, kk, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
+      if constexpr (ROT) {
+        const double* cr = Ar.P.camrot_cand + (size_t)kCamRot * ob.cam;
+        double ext[6], kc[12];
+        RotTerms rt;
+        camrot_load(cr, ext, rt);
+        load_d2<12>(cr + kCamRotIntr, kc);   // intrinsics (10) | model | reduced index
+        const int m = ob.depth_row ? THIP_MODEL_DEPTH_ROW : (int)kc[kCamRotModel - kCamRotIntr];
+        if (want_jac) observe_rot<true, false>(m, ext, rt, kc, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
+        else observe_rot<false, false>(m, ext, rt, kc, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
+      } else {
+        const int grp = Ar.P.cam_group[ob.cam];
+        const int m = ob.depth_row ? THIP_MODEL_DEPTH_ROW : Ar.P.group_model[grp];
+        const double* ext = Ar.cam + 6 * (size_t)ob.cam;
+        const double* kk = Ar.intr + (size_t)grp * THEIA_MAX_INTRINSICS;
+        if (want_jac) observe<true, false>(m, ext, kk, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
+        else observe<false, false>(m, ext, kk, X, ob.uv.x, ob.uv.y, ob.six, ob.siy, ol);
+      }
       if (!ol.valid) inv = true;
       double rho1;
       cst += 0.5 * obs_loss(Ar, ob, ol.r[0] * ol.r[0] + ol.r[1] * ol.r[1], &rho1);
@@ -337,12 +354,12 @@ struct TrackFn {
     *cost_out = cst; *invalid = inv;
   }
 };
-template <int PD> struct TrackLin {
-  TrackFn<PD> f;
+template <int PD, bool ROT> struct TrackLin {
+  TrackFn<PD, ROT> f;
   __device__ void operator()(const double* x, const double* scale, double* H, double* g, double* cost, bool* invalid) const { f.accumulate(x, scale, true, H, g, cost, invalid); }
 };
-template <int PD> struct TrackCost {
-  TrackFn<PD> f;
+template <int PD, bool ROT> struct TrackCost {
+  TrackFn<PD, ROT> f;
   __device__ double operator()(const double* xc, bool* invalid) const { double c; f.accumulate(xc, nullptr, false, nullptr, nullptr, &c, invalid); return c; }
 };
 template <int PD> struct TrackPlus {
@@ -352,7 +369,22 @@ template <int PD> struct TrackPlus {
   }
 };
 
-template <int PD>
+// the cameras at the inner-iteration point (after the camera and intrinsics sweeps) as k_cam_prep-style blocks
+__global__ __launch_bounds__(256) void k_inner_cam_blocks(InnerArgs A) {
+  if (!*A.gate) return;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= A.P.nc) return;
+  double* o = A.P.camrot_cand + (size_t)kCamRot * c;
+  camrot_store(A.cam + 6 * (size_t)c, o);
+  const int g = A.P.cam_group[c];
+  for (int q = 0; q < 6; ++q) o[kCamRotScale + q] = 0.0;   // (not read by the track solves)
+  for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) o[kCamRotIntr + q] = A.intr[(size_t)g * THEIA_MAX_INTRINSICS + q];
+  o[kCamRotModel] = (double)A.P.group_model[g];
+  o[kCamRotRed] = (double)A.P.cam_red[c];
+  o[kCamRotGroup] = (double)g; o[39] = 0.0;
+}
+
+template <int PD, bool ROT>
 __global__ __launch_bounds__(64) void k_inner_tracks(InnerArgs A) {
   if (!*A.gate) return;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -363,8 +395,8 @@ __global__ __launch_bounds__(64) void k_inner_tracks(InnerArgs A) {
   if (A.P.pt_const[p]) return;
   double x[4];
   for (int q = 0; q < 4; ++q) x[q] = A.pts[4 * (size_t)p + q];
-  const TrackFn<PD> fn{&A, beg, end};
-  block_lm<PD, 4>(x, TrackLin<PD>{fn}, TrackCost<PD>{fn}, TrackPlus<PD>{});
+  const TrackFn<PD, ROT> fn{&A, beg, end};
+  block_lm<PD, 4>(x, TrackLin<PD, ROT>{fn}, TrackCost<PD, ROT>{fn}, TrackPlus<PD>{});
   for (int q = 0; q < 4; ++q) A.pts[4 * (size_t)p + q] = x[q];
 }
 
@@ -489,8 +521,13 @@ void launch_inner_sweep(const InnerArgs& A0, hipStream_t st) {
   if (A.P.nc > 0 && !(skip & 1)) k_inner_views<<<(A.P.nc + 3) / 4, 256, 0, st>>>(A);
   if (A.P.ni > 0 && A.P.ng_total > 0 && !(skip & 2)) k_inner_groups<<<A.P.ng_total, 256, 0, st>>>(A);
   if (A.ntracks > 0 && !(skip & 4)) {
-    if (A.P.pd == 3) k_inner_tracks<3><<<(A.ntracks + 63) / 64, 64, 0, st>>>(A);
-    else k_inner_tracks<4><<<(A.ntracks + 63) / 64, 64, 0, st>>>(A);
+    const int nb = (A.ntracks + 63) / 64;
+    if (A.P.camrot_cand && !getenv("THEIA_HIP_INNER_NO_ROT")) {   // fused path: per-camera blocks (free between the trial step and the next one)
+      k_inner_cam_blocks<<<(A.P.nc + 255) / 256, 256, 0, st>>>(A);
+      if (A.P.pd == 3) k_inner_tracks<3, true><<<nb, 64, 0, st>>>(A); else k_inner_tracks<4, true><<<nb, 64, 0, st>>>(A);
+    } else {
+      if (A.P.pd == 3) k_inner_tracks<3, false><<<nb, 64, 0, st>>>(A); else k_inner_tracks<4, false><<<nb, 64, 0, st>>>(A);
+    }
   }
 }
 void launch_inner_norms(const InnerArgs& A, const double* cam0, const double* pts0, const double* intr0, double* out2, double* part,
