@@ -50,7 +50,15 @@ THIP_DEV unsigned segment_or_i(const Segment& s, int lane, unsigned v) {
   return (unsigned)__shfl((int)v, s.start, kWave);
 }
 
-template <int PD, int TPS, unsigned MODELS>
+// k-th set bit of a compile-time mask (-1: fewer bits)
+constexpr int nth_bit(unsigned m, int k) {
+  for (int q = 0; q < 32; ++q) if ((m >> q) & 1u) { if (k == 0) return q; --k; }
+  return -1;
+}
+
+// KMASK != 0: every variable group frees exactly the parameters KMASK (known at create()): the compact rows are picked
+// at compile time and the Jacobian columns of the other intrinsics are never computed.  KMASK == 0: per-lane masks.
+template <int PD, int TPS, unsigned MODELS, unsigned KMASK>
 __device__ __forceinline__ void fusedi_phase_l(const DevProblem* __restrict__ Pp, const FusedRun* __restrict__ runp,
                                                const double* __restrict__ pts, double inv_radius, int sc,
                                                double* __restrict__ Vinv, double* __restrict__ tile_part,
@@ -71,7 +79,14 @@ __device__ __forceinline__ void fusedi_phase_l(const DevProblem* __restrict__ Pp
   lane_linearize<PD, true, true, true, MODELS>(P, P.camrot, pts, start + lane, active, lane, L);
   // compact intrinsics rows: row k = the k-th free parameter of the camera's group (L.Jk is masked and scaled already)
   double jk[2 * KR];
-  {
+  if constexpr (KMASK != 0u) {
+    constexpr int Q[KR] = {nth_bit(KMASK, 0), nth_bit(KMASK, 1), nth_bit(KMASK, 2), nth_bit(KMASK, 3)};
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {   // (L.Jk is zero for an inactive lane or a constant group)
+      jk[k] = Q[k] >= 0 ? L.Jk[Q[k] >= 0 ? Q[k] : 0] : 0.0;
+      jk[KR + k] = Q[k] >= 0 ? L.Jk[THEIA_MAX_INTRINSICS + (Q[k] >= 0 ? Q[k] : 0)] : 0.0;
+    }
+  } else {
     unsigned fm = (active && L.gr >= 0) ? P.red_free[L.gr] : 0u;
 #pragma unroll
     for (int k = 0; k < KR; ++k) {
@@ -188,7 +203,7 @@ __device__ __forceinline__ void fusedi_phase_l(const DevProblem* __restrict__ Pp
 
 // KI = 3 or 4: compact intrinsics rows in use (the widest free mask of the problem's groups); partial blocks are always
 // stored kBWP x kBWP, rows / columns >= 6 + KI are never written or read.
-template <int PD, int TPS, unsigned MODELS, int KI>
+template <int PD, int TPS, unsigned MODELS, int KI, unsigned KMASK>
 __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const double* __restrict__ pts,
                                                              const double* __restrict__ radius_p,
                                                              double* __restrict__ Vinv, double* __restrict__ tile_part) {
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
     for (int k = 0; k < 3; ++k) dacc[k] = 0.0;
 
     for (int sc = 0; sc < nsc; ++sc) {
-      fusedi_phase_l<PD, TPS, MODELS>(&s_P, &s_run, pts, inv_radius, sc, Vinv, tile_part, s_rec, s_tslot, s_tmask);
+      fusedi_phase_l<PD, TPS, MODELS, KMASK>(&s_P, &s_run, pts, inv_radius, sc, Vinv, tile_part, s_rec, s_tslot, s_tmask);
       __syncthreads();
       {
         // ---- phase-S role (recomputed per sub-chunk: a dozen integers that need not stay in registers across phase L).  lix = lane index inside the track slice this lane serves: target block lix / NS, rows
@@ -473,10 +488,14 @@ void launch_linearize_fused_intr(const DevProblem& P, const double* cam, const d
   static const int wgs = [] { const char* e = getenv("THEIA_HIP_FUSED_WGS"); return e ? std::max(1, atoi(e)) : 512; }();
   const int grid = std::min(P.n_fruns, wgs);
   const bool trig = (P.model_mask & ~kModelsNoTrig) != 0;
+// FOCAL_LENGTH | RADIAL_DISTORTION on the perspective / double-sphere / unified models (parameters 0, 5, 6): the pipelines' default
+constexpr unsigned kMaskFocalRadial = (1u << 0) | (3u << 5);
 #define THIP_LSI(PD_, M_)                                                                                    \
   do {                                                                                                         \
-    if (P.fused_bw == 9) k_lin_schur_i<PD_, 4, M_, 3><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);  \
-    else k_lin_schur_i<PD_, 4, M_, 4><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);                  \
+    if (P.fused_bw == 9 && P.fused_kmask == kMaskFocalRadial)                                                     \
+      k_lin_schur_i<PD_, 4, M_, 3, kMaskFocalRadial><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);         \
+    else if (P.fused_bw == 9) k_lin_schur_i<PD_, 4, M_, 3, 0u><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part); \
+    else k_lin_schur_i<PD_, 4, M_, 4, 0u><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);                  \
   } while (0)
   if (P.pd == 3) { if (trig) THIP_LSI(3, kModelsAll); else THIP_LSI(3, kModelsNoTrig); }
   else { if (trig) THIP_LSI(4, kModelsAll); else THIP_LSI(4, kModelsNoTrig); }

@@ -106,6 +106,7 @@ struct DevProblem {
   // variable extrinsics block OR a variable intrinsics group, sum_items / sum_src are the generic lists of k_sum_items
   // (n_sum_items first-level items followed by n_sum_items2 second-level ones; sources are int pairs)
   int fused_bw, n_sum_items2;
+  unsigned fused_kmask;        // the free-parameter mask every variable intrinsics group shares, 0 = they differ
   // camera priors in use (compact list): 3 residuals each on one camera's extrinsics
   int n_priors;
   const int* prior_cam;        // [n_priors] camera index

@@ -960,7 +960,8 @@ __global__ void k_cam_update(DevProblem P, const double* __restrict__ cam, const
 // tile_part: [ntiles][5] = {cand_cost, mcc, stepsq, xnormsq, invalid}
 // ROT: the per-camera blocks of k_cam_prep (P.camrot for the state, P.camrot_cand for the candidate cameras) replace
 // the per-observation sincos and the chained camera -> group -> intrinsics gathers.
-template <int PD, bool INTR, bool ROT = false>
+// KMASK != 0 (INTR): every variable group frees exactly these intrinsics; the Jacobian columns of the others are never formed
+template <int PD, bool INTR, bool ROT = false, unsigned KMASK = 0u>
 // (148 VGPRs = three waves per SIMD; capped at 128 for four, 24 of them spill and the kernel takes 55 us longer)
 __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* __restrict__ cam,
                                                     const double* __restrict__ pts,
@@ -998,6 +999,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(DevProblem P, const double* 
       const double* yi = yc - P.ni + 10 * L.gr;
 #pragma unroll
       for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) {
+        if (KMASK != 0u && !((KMASK >> q) & 1u)) continue;   // (a frozen parameter's step is zero)
         mc[0] += L.Jk[q] * yi[q];
         mc[1] += L.Jk[THEIA_MAX_INTRINSICS + q] * yi[q];
       }
@@ -1571,8 +1573,14 @@ void launch_backsub(const DevProblem& P, const double* cam, const double* pts, c
   if (P.ni && P.fused_bw > 0 && P.n_fruns > 0 && P.camrot && P.camrot_cand) {
     // fused path with intrinsics: the state's blocks are in P.camrot; the candidate cameras with the candidate intrinsics
     launch_cam_prep(P, cand_cam, P.intr_cand, P.camrot_cand, st);
-    if (P.pd == 3) k_backsub<3, true, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
-    else k_backsub<4, true, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
+    constexpr unsigned kFR = (1u << 0) | (3u << 5);   // FOCAL_LENGTH | RADIAL_DISTORTION (ba_fused_intr.hip: kMaskFocalRadial)
+    if (P.fused_kmask == kFR) {
+      if (P.pd == 3) k_backsub<3, true, true, kFR><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
+      else k_backsub<4, true, true, kFR><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
+    } else {
+      if (P.pd == 3) k_backsub<3, true, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
+      else k_backsub<4, true, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
+    }
     return;
   }
   if (P.ni) {

@@ -127,6 +127,7 @@ struct theia_ba_handle_s {
   // this is cam_red.
   std::vector<int> cam_part, part_cam;
   int ncp = 0, fused_bw = 0, n_sum_items2 = 0;
+  unsigned fused_kmask = 0;
   std::vector<unsigned> grp_free;
   std::vector<uint8_t> cam_mask, pt_const;
   int ni = 0, ngv = 0;
@@ -560,7 +561,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   { const char* dbg = getenv("THEIA_HIP_FUSED_DBG"); P.fused_dbg = dbg ? atoi(dbg) : 0; }
   P.model_mask = h->model_mask;
   P.n_sum_items = h->n_sum_items; P.sum_items = h->sum_items.p; P.sum_src = h->sum_src.p;
-  P.fused_bw = h->use_fused ? h->fused_bw : 0; P.n_sum_items2 = h->n_sum_items2;
+  P.fused_bw = h->use_fused ? h->fused_bw : 0; P.n_sum_items2 = h->n_sum_items2; P.fused_kmask = h->fused_kmask;
   P.diag_items = h->diag_items.p; P.rec_slot = h->cam_obs.p; P.slot_obs = h->slot_obs.p; P.slot_pt = h->slot_pt.p; P.blk_items = h->blk_items.p; P.blk_pairs = h->blk_pairs.p;
   P.pt_sum_slot = h->n_trk_sums ? h->pt_sum_slot.p : nullptr; P.slot_in_sum = h->n_trk_sums ? h->slot_in_sum.p : nullptr;
   P.pt_sum_cnt = h->n_trk_sums ? h->pt_sum_cnt.p : nullptr; P.sum_group = h->n_trk_sums ? h->sum_group.p : nullptr; P.sum_base = h->sum_base;
@@ -1589,6 +1590,12 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
     for (int g = 0; g < h->ng; ++g) if (h->grp_red[g] >= 0) most = std::max(most, __builtin_popcount(h->grp_free[g]));
     const char* force = getenv("THEIA_HIP_INTR_ROWS");
     h->fused_bw = (allow_fused_intr && h->ni > 0 && most <= 4 && !(force && atoi(force) == 10) && !getenv("THEIA_HIP_INTR_GATHER")) ? (most <= 3 ? 9 : 10) : 0;
+    h->fused_kmask = 0;
+    {
+      bool first = true, same = true;
+      for (int g = 0; g < h->ng; ++g) if (h->grp_red[g] >= 0) { if (first) { h->fused_kmask = h->grp_free[g]; first = false; } else if (h->grp_free[g] != h->fused_kmask) same = false; }
+      if (!same) h->fused_kmask = 0;
+    }
     h->cam_part.assign(h->nc, -1);
     h->ncp = 0;
     for (int c = 0; c < h->nc; ++c)
