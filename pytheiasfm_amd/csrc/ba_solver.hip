@@ -1409,7 +1409,7 @@ void build_sum_items_intr(theia_ba_handle_s* h, const int* cam_group, FusedHost&
     const int row0 = (int)((ents[q].key >> 30) & 0x3fffffff), col0 = (int)(ents[q].key & 0x3fffffff);
     const int code = ents[q].dims, nr = code & 15, nc = (code >> 4) & 15;
     const size_t cnt = e - q;
-    size_t ch = 256;
+    size_t ch = 96;   // sources per first-level chunk: a wave adds them with 64 / (nr nc) lane groups, eight loads in flight each
     while (ch * ch < cnt) ++ch;
     if (cnt <= 2 * ch) {
       push(items1, row0, col0, code, (int)q, (int)e, 0);
