@@ -225,6 +225,7 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) s_P = P;
   const double inv_radius = 1.0 / *radius_p;
+  const bool colnorm_only = (P.fused_dbg & 8) != 0;   // compute_scale: only the per-(camera, row) sums are read afterwards
   for (;;) {
     __syncthreads();
     if (tid == 0) s_next = atomicAdd(P.frun_next, 1);
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
         const int ntr = P.tile_trk_end[last_tile];
 #pragma unroll 1
         for (int base = 0; base < ntr; base += tstride) {
-          {
+          if (!colnorm_only) {
             const int t = base + t0;
             const unsigned mask = (slice_ok && t < ntr) ? s_tmask[t] : 0u;
             if ((mask & tbits) == tbits) {

@@ -633,6 +633,7 @@ int compute_scale(theia_ba_handle_s* h) {
     // camera and intrinsics columns: one pass of the fused kernel over unit scales -- its per-(camera, row) lanes already
     // sum the squared column norms, k_sum_items leaves them by reduced index, the group columns summed over the group's
     // cameras (fixed order, no atomics).  The reduced system it writes on the way is cleared by the first linearisation.
+    Q.fused_dbg |= 8;   // (no pair products in this pass)
     launch_linearize_fused_intr(Q, h->cam[h->cur].p, h->pts[h->cur].p, h->ones_c.p /* radius 1 */, h->rb, h->Vinv.p, h->tile_part.p, h->stream);
     launch_scatter_colsq(Q, h->rb.colsq, h->colsq_c0.p, h->colsq_i0.p, h->stream);
   }
@@ -1303,7 +1304,15 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
     bool new_run = (int)ucams > max_cams || upairs > max_tgts;
     // a run keeps its packing level (track slices per wave) once it has some work, and stays inside one
     // first-camera key once it is large enough
-    if (!new_run && run_obs >= 64 && packing(upairs, ucams) < packing(run_pairs.size(), run_cams.size())) new_run = true;
+    // (compound blocks: the level is the number of track slices a workgroup walks in parallel -- 4 / G, or 4 PS with one
+    // wave per slice -- so that a run of short tracks, two slices, does not absorb the long tracks of the same cameras)
+    auto level = [&](size_t ntgt, size_t W) -> int {
+      const int pk = packing(ntgt, W);
+      if (bw == 0 || pk > 0) return bw == 0 ? pk : 4;   // (one wave per slice: four slices or more, all the same to this rule)
+      const size_t need = std::max(lanes_tgt * ntgt, rows_cam * W);
+      return need <= 128 ? 2 : 1;
+    };
+    if (!new_run && run_obs >= 64 && level(upairs, ucams) < level(run_pairs.size(), run_cams.size())) new_run = true;
     if (!new_run && run_obs >= run_max / 4 && skey[q] != run_key0) new_run = true;
     if (new_run) {
       close_tile(q);
@@ -1638,7 +1647,10 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
       // {<= 8 | >= 9} 0.646, {<= 3 | 4..6 | >= 7} 0.636, one class 0.593
       static const int ncls = getenv("THEIA_HIP_FUSED_CLASSES") ? atoi(getenv("THEIA_HIP_FUSED_CLASSES")) : 2;
       static const int cut0 = getenv("THEIA_HIP_FUSED_CUT0") ? atoi(getenv("THEIA_HIP_FUSED_CUT0")) : 7;
-      const int cls = ncls == 2 ? (nvar[q] <= cut0 ? 0 : 2) : (nvar[q] <= 3 ? 0 : (nvar[q] <= 6 ? 1 : 2));
+      int cls = ncls == 2 ? (nvar[q] <= cut0 ? 0 : 2) : (nvar[q] <= 3 ? 0 : (nvar[q] <= 6 ? 1 : 2));
+      // compound blocks (three or four lanes per target): four classes, by the number of track slices a workgroup can walk
+      // in parallel -- <= 3 cameras and 4 .. 6: four slices; 7: two; more: one
+      if (h->fused_bw && !getenv("THEIA_HIP_FUSED_CLASSES")) cls = nvar[q] <= 3 ? 0 : (nvar[q] <= 6 ? 1 : (nvar[q] <= 7 ? 2 : 3));
       static const bool noclass = getenv("THEIA_HIP_FUSED_NOCLASS") != nullptr;
       skey_pt[q] = pkey[q] == std::numeric_limits<int>::max() ? pkey[q] : (((h->ni == 0 || h->fused_bw) && !noclass) ? pkey[q] * 4 + cls : pkey[q]);
     }
