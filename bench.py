@@ -29,7 +29,7 @@ import numpy as np  # noqa: E402
 ITERS_PER_SOLVE = 8      # LM iterations per solve from the perturbed start (tolerances off: exactly this many)
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = FP64 matrix peak (half of the guide's 157.3 TF FP32 vector rate)
-PROFILE_TAG = "r2"       # committed rocprofv3 PMC passes of this command: profiles/<tag>_pmc_{fetch,write}_size.csv
+PROFILE_TAG = "r3"       # committed rocprofv3 PMC passes of this command: profiles/<tag>_pmc_{fetch,write}_size.csv
 
 
 def bench_options(ba, max_iters):
@@ -97,6 +97,22 @@ def pmc_traffic_bytes(world):
         write = sum(kb.get(("write_size", k), 0.0) for k in group)
         return int(1024 * (fetch + write))
     except (OSError, KeyError, ValueError):
+        return None
+
+
+def counters_stale():
+    """True when the kernel sources differ from the ones the committed counter passes were collected on
+    (profiles/<tag>_collected_at.json: sha256 prefixes written by scripts/refresh_profiles.sh), None when unknown."""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, "profiles", "%s_collected_at.json" % PROFILE_TAG)) as f:
+            ref = json.load(f)
+        for fn, h in ref.items():
+            with open(os.path.join(ROOT, fn), "rb") as g:
+                if hashlib.sha256(g.read()).hexdigest()[:16] != h:
+                    return True
+        return False
+    except (OSError, ValueError):
         return None
 
 
@@ -380,6 +396,8 @@ def main():
                          "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(world),
+                         "traffic_source": "profiles/%s_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command, committed)" % PROFILE_TAG,
+                         "traffic_source_stale": counters_stale(),   # True: the kernels changed since those passes
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": 1e3 * avg_lin,
                          "launches": acc["launches"],
                          "timing": "HIP events around the kernel group on the library's stream, instrumented pass of the same workload right after the timed region",
@@ -482,7 +500,9 @@ def main():
         # (no GPU / CPU ratio is quoted: the port stops scaling at a fraction of the host's cores -- `cores` is the thread count
         # that ran fastest, `threads_tried_iterations_per_sec` the others -- and the roofline fractions above, not a ratio
         # against it, say how good the kernels are)
-        out["cpu_baseline"]["phase_s_note"] = "parallel Jet evaluation and two-phase camera-chunk Schur elimination; the envelope Cholesky of the reduced system is one thread"
+        out["cpu_baseline"]["phase_s_note"] = ("parallel Jet evaluation and two-phase camera-chunk Schur elimination (phase_s.linearize_schur: the part that "
+                                                "stops scaling -- at most ncv / (2 x track span) chunks run concurrently, and the Jet buffers saturate the "
+                                                "memory system); the envelope Cholesky of the reduced system is one thread")
 
     if world == 1 and not args.no_ransac:
         out["ransac"] = ransac_block(not args.no_cpu_baseline, host_cores)

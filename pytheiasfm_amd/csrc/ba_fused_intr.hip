@@ -7,12 +7,12 @@
 // camera of a run as if it owned its intrinsics: per pair of cameras (a, b) that share a track it accumulates the
 // (6 + KI) x (6 + KI) block
 //       Jc_a^T (Ehat_a Ehat_b^T - [a == b] I) Jc_b        (Ehat = E Li^T, V^-1 = Li^T Li, as in ba_fused.hip)
-// in registers, three lanes per block (four rows each), the records {Jc | Ehat | r | r - Ehat ghat} staying in LDS.
+// in registers, three (four) lanes per block with three rows each, the records {Jc | Ehat | r | r - Ehat ghat} staying in LDS.
 // Sharing is applied afterwards, where it is linear: the intrinsics rows / columns of all cameras of a group are SUMMED
 // into the group's rows / columns of S by k_sum_items (S_shared = P^T S_private P with P the 0/1 map from per-camera
 // intrinsics to the group's).  No group sums per track, no pair lists, no records in HBM (the first generation,
 // k_lin_obs_intr + k_schur_intr, moved 14 GB per iteration at 1000 views / 500k tracks for 0.14 GB of algorithmic
-// traffic); the price is 2.8x the block products of the camera-only kernel.
+// traffic); the price is (6 + KI)^2 / 36 = 2.25x (2.8x) the block products of the camera-only kernel.
 //
 // Partial sums of a run: [ntgt][BW x BW] then [W][BW][3] (rhs, gradient, squared column norm).  k_sum_items adds, per
 // block of S, the listed pieces of those partial blocks in list order (fixed, bitwise reproducible) and WRITES the block;

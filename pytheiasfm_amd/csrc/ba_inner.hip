@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void k_inner_groups(InnerArgs A) {
 // ------------------------------------------------------------------ points
 // accumulate() is kept out of line on purpose: with it inlined into the LM loop, hipcc 7.2 -O2 / -O3 produced wrong
 // steps for this per-thread kernel (the -O1 build, the build with the body behind a call, and the two cooperative
-// kernels above all agree with the oracle to 1e-14; scripts/gpu_check_inner.py with THEIA_HIP_INNER_SKIP=3).
+// kernels above all agree with the oracle to 1e-14; tests/test_inner_gpu.py with THEIA_HIP_INNER_SKIP=3).
 // ROT: the cameras' rotation terms, intrinsics and model come from the 40-double blocks k_inner_cam_blocks left in
 // P.camrot_cand after the camera / intrinsics sweeps (ba_device.h kCamRot) -- one gather instead of a sincos and the
 // camera -> group -> intrinsics chain per observation and LM iteration; observe() = rotation_terms() + observe_rot(), so
