@@ -258,6 +258,61 @@ def test_eight_point_and_four_point_models_against_numpy_svd():
         assert np.abs(w[:, :2] / w[:, 2:] - y2).max() <= 1e-7
 
 
+def test_plane_known_orientation_and_uncalibrated_models_against_numpy():
+    """The four estimators whose device code still shared its transcription with the oracle (Weak 3), against
+    numpy on exactly-minimal data sets (one iteration, the sample is the whole set): the dominant plane through three points,
+    the relative position with known orientation (kernel of the 2 x 3 epipolar constraint), the absolute position with known
+    orientation (4 x 3 least squares), and the uncalibrated relative pose (focal lengths from the fundamental matrix of a
+    synthetic pair with KNOWN focal lengths, the essential matrix of the normalised pair, the pose)."""
+    rng = np.random.default_rng(77)
+    prm = ransac.RansacParameters(); prm.min_iterations = 1; prm.max_iterations = 1; prm.seed = 5; prm.error_thresh = 1e-6
+    for trial in range(40):
+        # --- plane through three points (estimate_dominant_plane_from_points.cc:62-81)
+        P3 = rng.normal(size=(3, 3)) * 2.0
+        ok, pl, s = ransac.EstimateDominantPlaneFromPoints(prm, ransac.RansacType.RANSAC, P3)
+        nn = np.cross(P3[1] - P3[0], P3[2] - P3[0]); nn /= np.linalg.norm(nn)
+        assert ok and abs(abs(pl.unit_normal @ nn) - 1.0) <= 1e-12 and np.abs((P3 - pl.point) @ pl.unit_normal).max() <= 1e-12
+        # --- relative position with known orientation: both rays already in a common frame, x2 ~ x1-frame point minus c
+        c = rng.normal(size=3); c /= np.linalg.norm(c)
+        X = np.stack([rng.uniform(-2, 2, 2), rng.uniform(-2, 2, 2), rng.uniform(4, 9, 2)], 1)
+        x1 = X[:, :2] / X[:, 2:]; X2 = X - c; x2 = X2[:, :2] / X2[:, 2:]
+        ok, pos, s = ransac.EstimateRelativePoseWithKnownOrientation(prm, ransac.RansacType.RANSAC, np.hstack([x1, x2]))
+        A = np.stack([np.cross(np.r_[a, 1.0], np.r_[b, 1.0]) for a, b in zip(x1, x2)])   # (x1 x x2) . c = 0
+        kern = np.linalg.svd(A)[2][-1]
+        assert ok and abs(abs(pos @ kern) - 1.0) <= 1e-9 and abs(abs(pos @ c) - 1.0) <= 1e-9 and abs(np.linalg.norm(pos) - 1.0) <= 1e-14
+        # --- absolute position with known orientation (position_from_two_rays.cc:55-83): two world points, rays in the world frame
+        cpos = rng.normal(size=3)
+        Xw = cpos + np.stack([rng.uniform(-2, 2, 2), rng.uniform(-2, 2, 2), rng.uniform(4, 9, 2)], 1)
+        d = Xw - cpos; uv = d[:, :2] / d[:, 2:]
+        ok, pos, s = ransac.EstimateAbsolutePoseWithKnownOrientation(prm, ransac.RansacType.RANSAC, np.zeros(3), np.hstack([uv, Xw]))
+        rows, rhs = [], []
+        for (u, v), Xk in zip(uv, Xw):
+            rows += [[1.0, 0.0, -u], [0.0, 1.0, -v]]; rhs += [Xk[0] - u * Xk[2], Xk[1] - v * Xk[2]]
+        ls = np.linalg.lstsq(np.array(rows), np.array(rhs), rcond=None)[0]
+        assert ok and np.abs(pos - ls).max() <= 1e-9 and np.abs(pos - cpos).max() <= 1e-9
+    # --- uncalibrated relative pose: eight correspondences of a pair with focal lengths 900 / 1100
+    hits = 0
+    for trial in range(60):
+        R = _random_rotation(rng, 25.0); t = rng.normal(size=3); t /= np.linalg.norm(t)
+        f1, f2 = 900.0, 1100.0
+        X = np.stack([rng.uniform(-2, 2, 8), rng.uniform(-2, 2, 8), rng.uniform(4, 9, 8)], 1)
+        Y = X @ R.T + t
+        c1 = f1 * X[:, :2] / X[:, 2:]; c2 = f2 * Y[:, :2] / Y[:, 2:]
+        prm.error_thresh = 1e-4
+        ok, m, s = ransac.EstimateUncalibratedRelativePose(prm, ransac.RansacType.RANSAC, np.hstack([c1, c2]))
+        if not ok:
+            continue   # (FocalLengthsFromFundamentalMatrix is ill-posed near fixating configurations: the reference fails there too)
+        F = m.fundamental_matrix
+        e = np.einsum("ni,ij,nj->n", np.c_[c2, np.ones(8)], F, np.c_[c1, np.ones(8)])
+        assert np.abs(e).max() <= 1e-7 * np.linalg.norm(F) * f1 * f2 and abs(np.linalg.det(F / np.linalg.norm(F))) <= 1e-10
+        if abs(m.focal_length1 / f1 - 1) < 1e-4 and abs(m.focal_length2 / f2 - 1) < 1e-4:
+            hits += 1
+            ang = np.degrees(np.arccos(np.clip((np.trace(m.rotation @ R.T) - 1) / 2, -1, 1)))
+            cgt = -R.T @ t
+            assert ang < 1e-2 and abs(abs(m.position @ cgt) / np.linalg.norm(cgt) - 1) < 1e-6, (ang, m.position, cgt)
+    assert hits >= 40, hits
+
+
 # --------------------------------------------------------------------- the reference's own scenes on the GPU
 @pytest.mark.parametrize("ri", range(2))
 @pytest.mark.parametrize("pj", range(2))
