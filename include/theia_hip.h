@@ -523,7 +523,19 @@ enum {
   /* EstimateAbsolutePoseWithKnownOrientation, estimate_absolute_pose_with_known_orientation.cc:132-153:
    * 2 correspondences [u v X Y Z] whose features the caller has rotated into the world frame
    * (RotateCorrespondences, :53-72); model = camera position (3) */
-  THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION = 10
+  THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION = 10,
+  /* EstimateTriangulation, estimate_triangulation.cc:69-166: one problem = one track, datum = one observation WITH ITS
+   * CAMERA (PointObservation, :53-58), 33 doubles:
+   *   [0..11]  projection matrix [R | -R c], row-major 3 x 4 (:122-129)
+   *   [12..13] normalised feature = hnormalized(PixelToNormalizedCoordinates(pixel)) (:132-135, the caller's camera class)
+   *   [14..15] observed pixel
+   *   [16..21] camera extrinsics: position (3), angle-axis (3)      [22] camera model (THEIA_CAM_*)     [23..32] intrinsics
+   * Minimal sample = 2 observations -> Triangulate() (triangulation.cc:109-125: essential matrix of the two poses, the
+   * optimal image-point correction, DLT by the 4 x 4 SVD), kept only if the point is in front of both cameras (:82-87);
+   * Error = squared pixel reprojection error through Camera::ProjectPoint, DBL_MAX when the depth is not positive (:92-101).
+   * model = homogeneous point (4).  The reference runs EXHAUSTIVE over all pairs for <= 15 observations with
+   * min = max iterations = n (n - 1) / 2, RANSAC otherwise (:147-159): the caller passes that choice in the parameters. */
+  THEIA_EST_TRIANGULATION = 11
 };
 
 /* A batch of independent estimation problems ("pairs").  Datum layout:
@@ -532,7 +544,8 @@ enum {
  *     (also fundamental matrix, homography, known-orientation relative pose)
  *   absolute pose: FeatureCorrespondence2D3D = [u v X Y Z]
  *     (sfm/feature_correspondence_2d_3d.h:42-49)
- *   dominant plane: Eigen::Vector3d = [X Y Z]                              */
+ *   dominant plane: Eigen::Vector3d = [X Y Z]
+ *   triangulation: one observation with its camera, 33 doubles (THEIA_EST_TRIANGULATION) */
 typedef struct theia_ransac_batch {
   int32_t estimator;           /* THEIA_EST_*                              */
   int32_t num_problems;

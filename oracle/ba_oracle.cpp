@@ -564,6 +564,17 @@ int oracle_reprojection_error(int model, const double* ext, const double* intr, 
   return ok ? 1 : 0;
 }
 
+// Camera::ProjectPoint (src/theia/sfm/camera/camera.cc:206-216): adjusted = X.head<3>() - X[3] position, rotated by the
+// angle-axis, pixel = CameraToPixelCoordinates(rotated); returns the depth rotated.z / X[3].  Used by the RANSAC oracle's
+// TriangulationEstimator::Error (ransac_oracle.cpp).
+double oracle_camera_project_point(int model, const double* ext, const double* intr, const double* X, double* pixel) {
+  const double adj[3] = {X[0] - X[3] * ext[0], X[1] - X[3] * ext[1], X[2] - X[3] * ext[2]};
+  double rot[3];
+  angle_axis_rotate_point(ext + 3, adj, rot);
+  if (pixel) project(model, intr, rot, pixel);
+  return rot[2] / X[3];
+}
+
 void oracle_loss_evaluate(int type, double a, double s, double* rho) { loss_evaluate(type, a, s, rho); }
 void oracle_sphere_plus(const double* x, const double* d, double* out) { sphere_plus(x, d, out); }
 void oracle_sphere_plus_jacobian(const double* x, double* J) { sphere_plus_jacobian(x, J); }

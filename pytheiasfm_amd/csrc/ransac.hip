@@ -25,6 +25,7 @@
 #include <limits>
 #include <vector>
 
+#include "ba_device.h"      // the camera models' projection (TriangulationEstimator::Error)
 #include "ransac_device.h"
 #include "dls_device.h"
 #include "eig_team.h"
@@ -54,7 +55,8 @@ __host__ __device__ inline int sample_size(int est) {
     case THEIA_EST_RELATIVE_POSE: case THEIA_EST_ESSENTIAL_MATRIX: return 5;
     case THEIA_EST_FUNDAMENTAL_MATRIX: case THEIA_EST_UNCALIBRATED_RELATIVE_POSE: return 8;
     case THEIA_EST_HOMOGRAPHY: return 4;
-    case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: return 2;
+    case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION:
+    case THEIA_EST_TRIANGULATION: return 2;
     default: return 3;
   }
 }
@@ -66,19 +68,24 @@ inline int model_doubles(int est) {
     case THEIA_EST_ABSOLUTE_POSE_KNEIP: case THEIA_EST_ABSOLUTE_POSE_DLS: case THEIA_EST_ABSOLUTE_POSE_SQPNP: return 12;
     case THEIA_EST_DOMINANT_PLANE: return 6;
     case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: return 3;
+    case THEIA_EST_TRIANGULATION: return 4;
     default: return 9;   // essential / fundamental matrix, homography
   }
 }
+constexpr int kTriDatum = 33;   // PointObservation row of THEIA_EST_TRIANGULATION (theia_hip.h)
 __host__ __device__ inline int datum_size(int est) {
   switch (est) {
     case THEIA_EST_ABSOLUTE_POSE_KNEIP: case THEIA_EST_ABSOLUTE_POSE_DLS: case THEIA_EST_ABSOLUTE_POSE_SQPNP:
     case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: return 5;
     case THEIA_EST_DOMINANT_PLANE: return 3;
+    case THEIA_EST_TRIANGULATION: return kTriDatum;
     default: return 4;
   }
 }
 constexpr int kMaxSample = 8;            // largest minimal sample (8-point fundamental matrix)
-constexpr int kMaxSampleDoubles = 32;   // 8 correspondences x 4
+constexpr int kMaxSampleDoubles = 2 * kTriDatum;   // 8 correspondences x 4, or two observations with their cameras
+// the sample buffer of a k_fit instance: 32 doubles for the correspondence estimators (their kernels keep the frame they had)
+template <int EST> constexpr int sample_doubles() { return (EST == THEIA_EST_TRIANGULATION || EST < 0) ? kMaxSampleDoubles : 32; }
 
 // EstimateModel of the three estimators (estimate_relative_pose.cc:75-109,
 // estimate_essential_matrix.cc:62-73, estimate_calibrated_absolute_pose.cc:76-118).
@@ -149,6 +156,7 @@ __device__ int estimate_models(int est, const double* subset, double* models, Es
       ok = rsc::uncalibrated_relative_pose(subset, mm, models);
     }
     else if (est == THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION) ok = rsc::position_from_two_rays(subset, models);
+    else if (est == THEIA_EST_TRIANGULATION) ok = rsc::triangulate_two_views(subset, models);
     else if (est == THEIA_EST_FUNDAMENTAL_MATRIX) ok = rsc::eight_point_fundamental(subset, models);
     else if (est == THEIA_EST_HOMOGRAPHY) ok = rsc::four_point_homography(subset, models);
     else if (est == THEIA_EST_DOMINANT_PLANE) ok = rsc::plane_from_three_points(subset, models);
@@ -158,9 +166,28 @@ __device__ int estimate_models(int est, const double* subset, double* models, Es
   return 0;
 }
 
+// TriangulationEstimator::Error (estimate_triangulation.cc:92-101): Camera::ProjectPoint (camera.cc:206-216) of the
+// homogeneous point -- adjusted = X.head<3>() - X[3] c, rotated by the angle-axis, pixel through the camera model (the
+// BA kernels' projection, ba_device.h), depth = rotated.z / X[3] -- then the squared pixel error, DBL_MAX behind the camera.
+__device__ inline double triangulation_error(const double* X, const double* d) {
+  const double* ext = d + 16;
+  const double p[3] = {X[0] - X[3] * ext[0], X[1] - X[3] * ext[1], X[2] - X[3] * ext[2]};
+  RotTerms rt;
+  rotation_terms(ext + 3, rt);
+  const double q[3] = {(rt.R[0] * p[0] + rt.R[1] * p[1]) + rt.R[2] * p[2], (rt.R[3] * p[0] + rt.R[4] * p[1]) + rt.R[5] * p[2],
+                       (rt.R[6] * p[0] + rt.R[7] * p[1]) + rt.R[8] * p[2]};
+  const double depth = q[2] / X[3];
+  if (depth <= 0.0) return DBL_MAX;
+  double uv[2], Jq[6];
+  project<false>((int)d[22], d + 23, q, uv, Jq);
+  const double ex = d[14] - uv[0], ey = d[15] - uv[1];
+  return ex * ex + ey * ey;
+}
+
 // Estimator::Error (estimate_relative_pose.cc:142-151, estimate_essential_matrix.cc:77-83,
 // estimate_calibrated_absolute_pose.cc:158-167)
 __device__ inline double model_error(int est, const double* m, const double* d) {
+  if (est == THEIA_EST_TRIANGULATION) return triangulation_error(m, d);
   if (est == THEIA_EST_RELATIVE_POSE) {
     if (rsc::in_front(d, m + 9, m + 18)) return rsc::sampson(m, d);
     return DBL_MAX;
@@ -197,7 +224,7 @@ __global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int
   if (b >= active_iters[p]) { counts[hyp] = 0; return; }
   const int m = sample_size(est), ds = datum_size(est);
   const double* pd = data + (size_t)offsets[p] * ds;
-  double subset[kMaxSampleDoubles];
+  double subset[sample_doubles<EST>()];
   for (int i = 0; i < m; ++i) {
     const int idx = samples[hyp * m + i];
     for (int k = 0; k < ds; ++k) subset[i * ds + k] = pd[(size_t)idx * ds + k];
@@ -1104,11 +1131,12 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     ep.max_focal = batch->estimator_params[1];
   }
   const bool dls_est = est == THEIA_EST_ABSOLUTE_POSE_DLS;
-  if (est < 0 || est > THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
+  if (est < 0 || est > THEIA_EST_TRIANGULATION) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
   const bool abs_pose = est == THEIA_EST_ABSOLUTE_POSE_KNEIP || est == THEIA_EST_ABSOLUTE_POSE_SQPNP || dls_est;
   // estimators that keep Estimator::RefineModel's default "return true" (solvers/estimator.h:86-88): LO only counts
   const bool trivial_refine = est == THEIA_EST_ESSENTIAL_MATRIX || est == THEIA_EST_DOMINANT_PLANE ||
-                              est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION || est == THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION;
+                              est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION || est == THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION ||
+                              est == THEIA_EST_TRIANGULATION;
   const bool rel_pose = est == THEIA_EST_RELATIVE_POSE, uncal_pose = est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE;
   const bool homog = est == THEIA_EST_HOMOGRAPHY, fund = est == THEIA_EST_FUNDAMENTAL_MATRIX;
   // every estimator's RefineModel is built: BundleAdjustView (absolute pose), BundleAdjustTwoViewsAngular ((un)calibrated
@@ -1394,6 +1422,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
           case THEIA_EST_DOMINANT_PLANE: THIP_FIT(THEIA_EST_DOMINANT_PLANE); break;
           case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: THIP_FIT(THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION); break;
           case THEIA_EST_UNCALIBRATED_RELATIVE_POSE: THIP_FIT(THEIA_EST_UNCALIBRATED_RELATIVE_POSE); break;
+          case THEIA_EST_TRIANGULATION: THIP_FIT(THEIA_EST_TRIANGULATION); break;
           default: THIP_FIT(THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION); break;
         }
 #undef THIP_FIT

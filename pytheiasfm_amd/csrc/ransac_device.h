@@ -1578,6 +1578,64 @@ RDEV double known_orientation_abs_error(const double* pos, const double* d) {
   return ex * ex + ey * ey;
 }
 
+// ---- EstimateTriangulation (estimate_triangulation.cc:69-101, triangulation.cc:66-125,160-175,
+// essential_matrix_utils.cc:86-107).  obs: two PointObservation rows of 33 doubles (layout: theia_hip.h).
+// Triangulate(): E from the two projection matrices, Lindstrom's optimal image points, DLT null vector.
+RDEV bool triangulate_two_views(const double* obs, double* X) {
+  const double* P1 = obs;
+  const double* P2 = obs + 33;
+  const double x1[2] = {obs[12], obs[13]}, x2[2] = {obs[33 + 12], obs[33 + 13]};
+  // relative_rotation = R1 R2^T, translation = (t1 - relative_rotation t2).normalized(), E = [t]x relative_rotation
+  double Rr[9], t[3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Rr[3 * i + j] = (P1[4 * i] * P2[4 * j] + P1[4 * i + 1] * P2[4 * j + 1]) + P1[4 * i + 2] * P2[4 * j + 2];
+  for (int i = 0; i < 3; ++i) t[i] = P1[4 * i + 3] - ((Rr[3 * i] * P2[3] + Rr[3 * i + 1] * P2[7]) + Rr[3 * i + 2] * P2[11]);
+  const double tn = sqrt((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]);
+  for (int i = 0; i < 3; ++i) t[i] /= tn;
+  double E[9];
+  for (int j = 0; j < 3; ++j) {
+    E[j] = -t[2] * Rr[3 + j] + t[1] * Rr[6 + j];
+    E[3 + j] = t[2] * Rr[j] - t[0] * Rr[6 + j];
+    E[6 + j] = -t[1] * Rr[j] + t[0] * Rr[3 + j];
+  }
+  // FindOptimalImagePoints (triangulation.cc:66-103)
+  const double p1[3] = {x1[0], x1[1], 1.0}, p2[3] = {x2[0], x2[1], 1.0};
+  double l1[2], l2[2];   // epipolar_line1 = S E p2, epipolar_line2 = S E^T p1
+  for (int i = 0; i < 2; ++i) {
+    l1[i] = (E[3 * i] * p2[0] + E[3 * i + 1] * p2[1]) + E[3 * i + 2] * p2[2];
+    l2[i] = (E[i] * p1[0] + E[3 + i] * p1[1]) + E[6 + i] * p1[2];
+  }
+  const double Et[4] = {E[0], E[1], E[3], E[4]};   // top-left 2 x 2
+  const double a = l1[0] * (Et[0] * l2[0] + Et[1] * l2[1]) + l1[1] * (Et[2] * l2[0] + Et[3] * l2[1]);
+  const double b = ((l1[0] * l1[0] + l1[1] * l1[1]) + (l2[0] * l2[0] + l2[1] * l2[1])) / 2.0;
+  double c = 0.0;
+  for (int i = 0; i < 3; ++i) c += p1[i] * ((E[3 * i] * p2[0] + E[3 * i + 1] * p2[1]) + E[3 * i + 2] * p2[2]);
+  const double d = sqrt(b * b - a * c);
+  double lambda = c / (b + d);
+  {
+    const double n1[2] = {l1[0] - lambda * (Et[0] * l1[0] + Et[1] * l1[1]), l1[1] - lambda * (Et[2] * l1[0] + Et[3] * l1[1])};
+    const double n2[2] = {l2[0] - lambda * (Et[0] * l2[0] + Et[2] * l2[1]), l2[1] - lambda * (Et[1] * l2[0] + Et[3] * l2[1])};
+    l1[0] = n1[0]; l1[1] = n1[1]; l2[0] = n2[0]; l2[1] = n2[1];
+  }
+  lambda *= (2.0 * d) / ((l1[0] * l1[0] + l1[1] * l1[1]) + (l2[0] * l2[0] + l2[1] * l2[1]));
+  const double c1[2] = {p1[0] - lambda * l1[0], p1[1] - lambda * l1[1]};   // hnormalized(): the third coordinate stays 1
+  const double c2[2] = {p2[0] - lambda * l2[0], p2[1] - lambda * l2[1]};
+  // TriangulateDLT (triangulation.cc:160-175): last right singular vector of the 4 x 4 design matrix
+  double A[16], U[16], S[4], V[16];
+  for (int j = 0; j < 4; ++j) {
+    A[j] = c1[0] * P1[8 + j] - P1[j];
+    A[4 + j] = c1[1] * P1[8 + j] - P1[4 + j];
+    A[8 + j] = c2[0] * P2[8 + j] - P2[j];
+    A[12 + j] = c2[1] * P2[8 + j] - P2[4 + j];
+  }
+  svd_sq<4>(A, U, S, V);
+  for (int i = 0; i < 4; ++i) X[i] = V[4 * i + 3];
+  // IsPointInFrontOfCamera for both (estimate_triangulation.cc:62-66,82-87)
+  const double z1 = ((X[0] * P1[8] + X[1] * P1[9]) + X[2] * P1[10]) + X[3] * P1[11];
+  const double z2 = ((X[0] * P2[8] + X[1] * P2[9]) + X[2] * P2[10]) + X[3] * P2[11];
+  return z1 > 0.0 && z2 > 0.0;
+}
+
 // FocalLengthsFromFundamentalMatrix (sfm/pose/fundamental_matrix_util.cc:57-130).
 // F row-major.  Epipoles = last right singular vectors of F and F^T.
 RDEV bool focal_lengths_from_fundamental(const double* F, double* f1, double* f2) {

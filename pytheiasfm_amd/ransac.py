@@ -6,13 +6,14 @@ Same names / argument order as the pybind wrappers
 (estimators_wrapper.cc:41-57,130-142): Estimate*(ransac_params, ransac_type,
 ..., correspondences) -> (success, model, RansacSummary).
 """
+import copy
 import ctypes as C
 import enum
 import time
 
 import numpy as np
 
-from . import _capi as capi
+from . import _capi as capi, synth
 
 
 class RansacType(enum.IntEnum):  # create_and_initialize_ransac_variant.h:52
@@ -32,6 +33,7 @@ EST_RELATIVE_POSE, EST_ESSENTIAL_MATRIX, EST_ABS_KNEIP, EST_ABS_DLS, EST_ABS_SQP
 EST_FUNDAMENTAL_MATRIX, EST_HOMOGRAPHY, EST_DOMINANT_PLANE, EST_RELATIVE_POSE_KNOWN_ORIENTATION = range(5, 9)
 EST_UNCALIBRATED_RELATIVE_POSE = 9
 EST_ABSOLUTE_POSE_KNOWN_ORIENTATION = 10
+EST_TRIANGULATION = 11
 
 
 class RansacParameters:
@@ -144,7 +146,7 @@ def estimate_batch(estimator, data, offsets, params, estimator_params=None, seed
             "time_fit_seconds": r.time_fit_seconds, "time_score_seconds": r.time_score_seconds}
 
 
-_SAMPLE_SIZE = {0: 5, 1: 5, 2: 3, 3: 3, 4: 3, 5: 8, 6: 4, 7: 3, 8: 2, 9: 8, 10: 2}   # Estimator::SampleSize() by THEIA_EST_*
+_SAMPLE_SIZE = {0: 5, 1: 5, 2: 3, 3: 3, 4: 3, 5: 8, 6: 4, 7: 3, 8: 2, 9: 8, 10: 2, 11: 2}   # Estimator::SampleSize() by THEIA_EST_*
 
 
 def _single(estimator, ransac_params, ransac_type, data, estimator_params=None):
@@ -235,7 +237,6 @@ def EstimateUncalibratedRelativePose(ransac_params, ransac_type, centered_corres
 def RotateCorrespondences(normalized_correspondences, camera_orientation):
     """estimate_absolute_pose_with_known_orientation.cc:53-72: features into the world frame with the
     camera-to-world rotation (transpose of the angle-axis world-to-camera rotation)."""
-    from . import synth
     c = np.ascontiguousarray(normalized_correspondences, dtype=np.float64).reshape(-1, 5)
     R = synth.angle_axis_to_matrix(np.asarray(camera_orientation, dtype=np.float64))
     ray = np.column_stack([c[:, :2], np.ones(len(c))]) @ R   # rows: R^T [u v 1]
@@ -249,6 +250,112 @@ def EstimateAbsolutePoseWithKnownOrientation(ransac_params, ransac_type, camera_
     rot = RotateCorrespondences(normalized_correspondences, camera_orientation)
     ok, m, s = _single(EST_ABSOLUTE_POSE_KNOWN_ORIENTATION, ransac_params, ransac_type, rot)
     return ok, m[0:3].copy(), s
+
+
+class Camera:  # the slice of sfm/camera/camera.h the triangulation estimator reads
+    """position (3), angle-axis orientation (3), THEIA_CAM_* model id and that model's intrinsics (up to 10, the
+    C-ABI's layout: focal, aspect ratio, skew, principal point x y, then the model's distortion parameters)."""
+
+    def __init__(self, position, orientation, intrinsics, model=0):
+        self.position = np.asarray(position, dtype=np.float64).reshape(3)
+        self.orientation = np.asarray(orientation, dtype=np.float64).reshape(3)
+        self.model = int(model)
+        k = np.asarray(intrinsics, dtype=np.float64).ravel()
+        if k.shape[0] > 10:
+            raise capi.TheiaHipError(capi.THEIA_HIP_ERR_INVALID_ARGUMENT, "a camera model holds at most 10 intrinsics")
+        self.intrinsics = np.zeros(10)
+        self.intrinsics[:k.shape[0]] = k
+
+    def projection_matrix(self):
+        """[R | -R c] (estimate_triangulation.cc:127-133: the calibration is NOT part of it)."""
+        R = synth.angle_axis_to_matrix(self.orientation)
+        return np.column_stack([R, -R @ self.position])
+
+    def pixel_to_normalized(self, pixel):
+        """Camera::PixelToNormalizedCoordinates(pixel).hnormalized() for the pinhole model
+        (pinhole_camera_model.h:208-241: remove the calibration, then the fixed-point undistortion of :263-298)."""
+        if self.model != 0:
+            raise capi.TheiaHipError(capi.THEIA_HIP_ERR_UNSUPPORTED,
+                                     "pixel_to_normalized mirrors the pinhole model only; pass normalized_features for the others")
+        f, a, s, cx, cy, k1, k2 = self.intrinsics[:7]
+        y = (float(pixel[1]) - cy) / (f * a)
+        x = (float(pixel[0]) - cx - y * s) / f
+        ux, uy = x, y
+        for _ in range(100):
+            px, py = ux, uy
+            r2 = ux * ux + uy * uy
+            d = 1.0 + r2 * (k1 + k2 * r2)
+            ux, uy = x / d, y / d
+            if abs(ux - px) < 1e-10 and abs(uy - py) < 1e-10:
+                break
+        return np.array([ux, uy])
+
+
+def triangulation_observations(cameras, features, normalized_features=None):
+    """The THEIA_EST_TRIANGULATION datum of every observation (theia_hip.h): the PointObservation of
+    estimate_triangulation.cc:55-60 flattened to 33 doubles."""
+    n = len(cameras)
+    feats = np.asarray(features, dtype=np.float64).reshape(n, 2)
+    out = np.zeros((n, 33))
+    for i, cam in enumerate(cameras):
+        out[i, 0:12] = cam.projection_matrix().ravel()
+        out[i, 12:14] = cam.pixel_to_normalized(feats[i]) if normalized_features is None else np.asarray(normalized_features[i], dtype=np.float64)[:2]
+        out[i, 14:16] = feats[i]
+        out[i, 16:19] = cam.position
+        out[i, 19:22] = cam.orientation
+        out[i, 22] = cam.model
+        out[i, 23:33] = cam.intrinsics
+    return out
+
+
+def EstimateTriangulation(ransac_params, cameras, features, normalized_features=None):
+    """estimate_triangulation.cc:111-166 -> (success, triangulated_point (4, homogeneous), summary).  Up to 15
+    observations: EXHAUSTIVE with min = max iterations = n (n - 1) / 2 (:143-153), otherwise plain RANSAC."""
+    if len(cameras) != len(features):
+        raise capi.TheiaHipError(capi.THEIA_HIP_ERR_INVALID_ARGUMENT, "one feature per camera")   # CHECK_EQ :116
+    n = len(cameras)
+    if n < 2:
+        return False, np.zeros(4), RansacSummary()   # :122-124
+    data = triangulation_observations(cameras, features, normalized_features)
+    params, rtype = ransac_params, RansacType.RANSAC
+    if n <= 15:
+        params = copy.copy(ransac_params)
+        params.min_iterations = params.max_iterations = n * (n - 1) // 2
+        rtype = RansacType.EXHAUSTIVE
+    ok, m, s = _single(EST_TRIANGULATION, params, rtype, data)
+    return ok, m[0:4].copy(), s
+
+
+def EstimateTriangulationBatch(ransac_params, tracks):
+    """Many EstimateTriangulation calls in a few launches (what TrackEstimator::EstimateTracks,
+    sfm/track_estimator.cc, does track by track on its thread pool).  tracks: sequence of (cameras, features[,
+    normalized_features]).  Tracks with the same observation count n <= 15 share one EXHAUSTIVE batch (iterations =
+    n (n - 1) / 2 each, as a single call would set), all longer tracks share one RANSAC batch; problem i draws from
+    RandomNumberGenerator(ransac_params.seed + i).  Returns (success [T], points [T, 4], inlier index lists)."""
+    T = len(tracks)
+    success = np.zeros(T, dtype=bool); points = np.zeros((T, 4)); inliers = [[] for _ in range(T)]
+    data, groups = [None] * T, {}
+    for i, tr in enumerate(tracks):
+        n = len(tr[0])
+        if n != len(tr[1]):
+            raise capi.TheiaHipError(capi.THEIA_HIP_ERR_INVALID_ARGUMENT, "one feature per camera")
+        if n < 2:
+            continue
+        data[i] = triangulation_observations(tr[0], tr[1], tr[2] if len(tr) > 2 else None)
+        groups.setdefault(n if n <= 15 else 0, []).append(i)
+    for n, idx in sorted(groups.items()):
+        pc = ransac_params.to_c()
+        pc.ransac_type = int(RansacType.RANSAC)
+        if n:
+            pc.min_iterations = pc.max_iterations = n * (n - 1) // 2
+            pc.ransac_type = int(RansacType.EXHAUSTIVE)
+        offsets = np.concatenate([[0], np.cumsum([data[i].shape[0] for i in idx])]).astype(np.int64)
+        res = estimate_batch(EST_TRIANGULATION, np.concatenate([data[i] for i in idx]), offsets, pc,
+                             seeds=[int(ransac_params.seed) + i for i in idx])
+        for k, i in enumerate(idx):
+            success[i] = bool(res["success"][k]); points[i] = res["models"][k][:4]
+            inliers[i] = np.nonzero(res["inlier_mask"][offsets[k]:offsets[k + 1]])[0].tolist()
+    return success, points, inliers
 
 
 def FivePointRelativePose(image1_points, image2_points):

@@ -900,3 +900,79 @@ def test_golden_refine_model_vectors():
             assert r["num_iterations"] == g[f"lo_{kind}_iters"][i] and ol.rlib().oracle_last_lo_iterations() == g[f"lo_{kind}_nlo"][i]
             assert np.array_equal(r["inlier_mask"], g[f"lo_{kind}_masks"][i])
             assert np.allclose(r["model"][:mlen], g[f"lo_{kind}_models"][i], rtol=1e-11, atol=1e-14)
+
+
+def _tri_params(thresh=1.0, seed=151, min_it=5):
+    pc = ol.default_ransac_params(thresh, seed=seed)
+    pc.min_iterations = min_it
+    return pc
+
+
+def test_estimate_triangulation_scenes_of_the_reference_test():
+    """estimate_triangulation_test.cc:103-166 restated against the oracle: two views give the point to 1e-6 with both
+    observations inliers; ten observations and two outliers (EXHAUSTIVE over all 66 pairs) give it with >= 6 inliers."""
+    from pytheiasfm_amd import ransac
+    from tests import tri_scenes
+    cams, feats = tri_scenes.scene(2, 0, 1)
+    pc = _tri_params(min_it=1); pc.min_iterations = pc.max_iterations = 1; pc.ransac_type = 3
+    o = ol.ransac_estimate(11, ransac.triangulation_observations(cams, feats), pc)
+    X = o["model"][:4]
+    assert o["success"] and o["num_inliers"] == 2 and np.linalg.norm(X[:3] / X[3] - tri_scenes.POINT[:3]) < 1e-6
+    cams, feats = tri_scenes.scene(10, 2, 2)
+    pc = _tri_params(); pc.min_iterations = pc.max_iterations = 66; pc.ransac_type = 3
+    o = ol.ransac_estimate(11, ransac.triangulation_observations(cams, feats), pc)
+    X = o["model"][:4]
+    assert o["success"] and o["num_iterations"] == 66
+    assert np.linalg.norm(X[:3] / X[3] - tri_scenes.POINT[:3]) < 1e-6
+    assert np.nonzero(o["inlier_mask"])[0].tolist() == list(range(10))
+
+
+def test_estimate_triangulation_error_is_the_reprojection_error_of_the_camera_model():
+    """TriangulationEstimator::Error = |pixel - Camera::ProjectPoint|^2 with DBL_MAX behind the camera: the inlier set
+    of a noisy 40-observation RANSAC run equals the numpy reprojection test of the returned point, for a distorted
+    pinhole and a double-sphere camera."""
+    from pytheiasfm_amd import ransac
+    from tests import tri_scenes
+    for model, intr, seed in ((synth.CAM_PINHOLE, synth.PINHOLE_INTR, 3), (synth.CAM_DOUBLE_SPHERE, synth.DOUBLE_SPHERE_INTR, 4)):
+        cams, feats = tri_scenes.scene(32, 8, seed, model=model, intrinsics=intr, spread=0.05, noise=0.4)
+        # normalized features of the true model: the ray direction through the pixel (the pinhole fixed point or, for the
+        # double sphere, the camera-frame direction of the point itself for the inlying observations)
+        norm = np.zeros((40, 2))
+        for i, c in enumerate(cams):
+            if model == synth.CAM_PINHOLE:
+                norm[i] = c.pixel_to_normalized(feats[i])
+            else:
+                q = synth.angle_axis_to_matrix(c.orientation) @ (tri_scenes.POINT[:3] - c.position)
+                norm[i] = q[:2] / q[2] + (feats[i] - synth.project(model, c.intrinsics[None], np.concatenate([c.position, c.orientation])[None], tri_scenes.POINT[None])[0][0]) / intr[0]
+        data = ransac.triangulation_observations(cams, feats, norm)
+        pc = _tri_params(thresh=4.0, seed=7, min_it=50)
+        o = ol.ransac_estimate(11, data, pc)
+        assert o["success"]
+        X = o["model"][:4]
+        ext = np.array([np.concatenate([c.position, c.orientation]) for c in cams])
+        K = np.array([c.intrinsics for c in cams])
+        uv, ok = synth.project(model, K, ext, np.tile(X, (40, 1)))
+        depth = np.einsum("nij,nj->ni", synth.angle_axis_to_matrix(ext[:, 3:]), X[:3] - X[3] * ext[:, :3])[:, 2] / X[3]
+        e = np.sum((uv - feats) ** 2, axis=1)
+        expect = (e < 4.0) & (depth > 0)
+        assert np.array_equal(o["inlier_mask"].astype(bool), expect)
+        assert expect[:32].sum() >= 24 and np.linalg.norm(X[:3] / X[3] - tri_scenes.POINT[:3]) < 0.2
+
+
+def test_estimate_triangulation_mirror_host_logic():
+    """estimate_triangulation.cc:116-124: CHECK_EQ on the sizes, false below two observations (no device needed)."""
+    from pytheiasfm_amd import ransac
+    from tests import tri_scenes
+    cams, feats = tri_scenes.scene(1, 0, 5)
+    ok, X, s = ransac.EstimateTriangulation(ransac.RansacParameters(), cams, feats)
+    assert not ok
+    with pytest.raises(capi.TheiaHipError):
+        ransac.EstimateTriangulation(ransac.RansacParameters(), cams, np.zeros((2, 2)))
+    # pixel -> normalized inverts the pinhole projection (fixed point of pinhole_camera_model.h:263-298)
+    cam = ransac.Camera([0.1, -0.2, 0.3], [0.02, -0.01, 0.03], synth.PINHOLE_INTR)
+    n = cam.pixel_to_normalized(np.array([1200.0, 300.0]))
+    f, a, sk, cx, cy, k1, k2 = synth.PINHOLE_INTR
+    r2 = n @ n; d = 1 + r2 * (k1 + k2 * r2)
+    assert np.allclose([f * n[0] * d + sk * n[1] * d + cx, f * a * n[1] * d + cy], [1200.0, 300.0], atol=1e-6)
+    P = cam.projection_matrix()
+    assert np.allclose(P[:, :3] @ cam.position + P[:, 3], 0.0, atol=1e-15)
