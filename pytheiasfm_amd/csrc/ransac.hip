@@ -29,6 +29,7 @@
 #include "ransac_device.h"
 #include "dls_device.h"
 #include "eig_team.h"
+#include "fit5_team.h"
 #include "svd_team.h"
 #include "theia_hip.h"
 #include <atomic>
@@ -607,55 +608,56 @@ __global__ void k_sqpnp(int num, const int64_t* __restrict__ offsets, const doub
 }
 
 
-// ---- five-point hypotheses (relative pose / essential matrix) in three stages instead of k_fit: the 10 x 10
-// eigen-decomposition -- 27 k read-modify-writes of its two work matrices per hypothesis, which as per-lane scratch were
-// ~200 KB of HBM traffic each -- runs on chip, a team of 16 lanes per matrix (eig_team.h, bit-identical to the one-thread
-// routine); before it one thread per hypothesis builds the null space and the action matrix, after it one thread per
-// hypothesis turns the real eigenvectors into essential matrices and poses exactly as estimate_models() does.
+// ---- five-point hypotheses (relative pose / essential matrix) in three stages instead of k_fit: the null space, the
+// constraint matrix and its elimination (5 KB of work arrays per hypothesis) and the 10 x 10 eigen-decomposition (27 k
+// read-modify-writes of its two work matrices) were per-lane scratch, i.e. HBM traffic (~200 KB per hypothesis for the
+// eigen-solver alone); both run on chip now, by teams of lanes per hypothesis with the arrays in LDS (fit5_team.h,
+// eig_team.h: bit-identical to the one-thread routines).  After them one thread per hypothesis turns the real
+// eigenvectors into essential matrices and poses exactly as estimate_models() does.
 constexpr int kFpWs = 136;    // per hypothesis: null space N (9 x 4) | action matrix M (10 x 10)
-constexpr int kFpTeam = 16, kFpTeamsPerWave = 64 / kFpTeam;
-__global__ __launch_bounds__(64) void k_fit5_a(int nprob, int B, const int64_t* __restrict__ offsets, const double* __restrict__ data,
-                                               const int* __restrict__ samples, const int* __restrict__ active_iters,
-                                               double* __restrict__ ws, int* __restrict__ ok) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int p = blockIdx.y;
-  if (b >= B || p >= nprob) return;
-  const size_t hyp = (size_t)p * B + b;
-  if (b >= active_iters[p]) { ok[hyp] = 0; return; }
-  const double* pd = data + (size_t)offsets[p] * 4;
-  double subset[20];
-  for (int i = 0; i < 5; ++i) {
-    const int idx = samples[hyp * 5 + i];
-    for (int k = 0; k < 4; ++k) subset[i * 4 + k] = pd[(size_t)idx * 4 + k];
-  }
-  double N[36], M[100];
-  const bool good = rsc::five_point_pre(subset, N, M);
-  ok[hyp] = good ? 1 : 0;
-  if (!good) return;
+
+// stage A by teams of 16 lanes with the work arrays in LDS (fit5_team.h): N and M bit-identical to five_point_pre()
+constexpr int kFpPreTeam = 16;
+__global__ __launch_bounds__(64, 4) void k_fit5_a_team(int nprob, int B, const int64_t* __restrict__ offsets, const double* __restrict__ data,
+                                                    const int* __restrict__ samples, const int* __restrict__ active_iters,
+                                                    double* __restrict__ ws, int* __restrict__ ok) {
+  __shared__ double lds[64 / kFpPreTeam][rsc::kFit5TeamLds];
+  const int team = threadIdx.x / kFpPreTeam, tl = threadIdx.x % kFpPreTeam;
+  const size_t hyp = (size_t)blockIdx.x * (64 / kFpPreTeam) + team;
+  if (hyp >= (size_t)nprob * B) return;
+  const int p = (int)(hyp / B), b = (int)(hyp % B);
+  if (b >= active_iters[p]) { if (tl == 0) ok[hyp] = 0; return; }
   double* w = ws + hyp * kFpWs;
-  for (int k = 0; k < 36; ++k) w[k] = N[k];
-  for (int k = 0; k < 100; ++k) w[36 + k] = M[k];
+  const bool good = rsc::five_point_pre_team<kFpPreTeam>(data + (size_t)offsets[p] * 4, samples + hyp * 5, lds[team], w, w + 36, tl);
+  if (tl == 0) ok[hyp] = good ? 1 : 0;
 }
 
-__global__ __launch_bounds__(64) void k_fit5_b(size_t nhyp, const int* __restrict__ ok, const double* __restrict__ ws,
+// stage B: teams of 8 lanes (eig_team.h), H and V in LDS, the work array X of the back-substitution in the hypothesis' own
+// action-matrix slot in HBM (free once H is on chip).  The kernel is bound by the number of matrices resident per CU --
+// the eigen-iteration is one dependent chain per matrix -- i.e. by LDS per matrix: 1.8 KB here (87 matrices per CU), and
+// the same time with 16 or 8 lanes per team (measured), so the narrower team only halves the LDS per wave.
+constexpr int kFpTeam = 8, kFpTeamsPerWave = 64 / kFpTeam;
+__global__ __launch_bounds__(64) void k_fit5_b(size_t nhyp, const int* __restrict__ ok, double* __restrict__ ws,
                                                double* __restrict__ sol, int* __restrict__ solmask) {
-  __shared__ double lds[kFpTeamsPerWave][330];   // H (100) | V (100) | X (100) | wr | wi | ort
+  __shared__ double lds[kFpTeamsPerWave][230];   // H (100) | V (100) | wr | wi | ort
   const int team = threadIdx.x / kFpTeam, tl = threadIdx.x % kFpTeam;
   const size_t hyp = (size_t)blockIdx.x * kFpTeamsPerWave + team;
   if (hyp >= nhyp) return;
   if (!ok[hyp]) { if (tl == 0) solmask[hyp] = 0; return; }
-  double* H = lds[team]; double* V = H + 100; double* X = V + 100; double* wr = X + 100; double* wi = wr + 10; double* ort = wi + 10;
-  const double* M = ws + hyp * kFpWs + 36;
+  double* H = lds[team]; double* V = H + 100; double* wr = V + 100; double* wi = wr + 10; double* ort = wi + 10;
+  double* M = ws + hyp * kFpWs + 36;
+  double* X = M;
   for (int e = tl; e < 100; e += kFpTeam) H[e] = M[e];
   rsc::team_sync();
   const bool good = rsc::eig_team<kFpTeam, false>(10, H, V, X, wr, wi, ort, tl);
   int bit = 0;
-  if (good && tl < 10 && wi[tl] == 0.0) {   // only real solutions (five_point_relative_pose.cc:281-284)
-    double v4[4];
-    rsc::five_point_v4(V, tl, v4);
-    for (int k = 0; k < 4; ++k) sol[(hyp * 10 + tl) * 4 + k] = v4[k];
-    bit = 1 << tl;
-  }
+  for (int c = tl; c < 10; c += kFpTeam)
+    if (good && wi[c] == 0.0) {   // only real solutions (five_point_relative_pose.cc:281-284)
+      double v4[4];
+      rsc::five_point_v4(V, c, v4);
+      for (int k = 0; k < 4; ++k) sol[(hyp * 10 + c) * 4 + k] = v4[k];
+      bit |= 1 << c;
+    }
   for (int o = kFpTeam / 2; o >= 1; o >>= 1) bit |= __shfl_xor(bit, o, kFpTeam);
   if (tl == 0) solmask[hyp] = bit;
 }
@@ -1395,7 +1397,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         if ((rc = d_fp_ws.ensure(nh * kFpWs)) || (rc = d_fp_sol.ensure(nh * 40)) || (rc = d_fp_ok.ensure(nh)) || (rc = d_fp_mask.ensure(nh)))
           return rc;
         dim3 grid((B + 63) / 64, cn);
-        k_fit5_a<<<grid, 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_ok.p);
+        k_fit5_a_team<<<(unsigned)((nh + 3) / 4), 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_ok.p);
         k_fit5_b<<<(unsigned)((nh + kFpTeamsPerWave - 1) / kFpTeamsPerWave), 64, 0, st>>>(nh, d_fp_ok.p, d_fp_ws.p, d_fp_sol.p, d_fp_mask.p);
         if (est == THEIA_EST_RELATIVE_POSE)
           k_fit5_c<THEIA_EST_RELATIVE_POSE><<<grid, 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_sol.p,
