@@ -232,6 +232,10 @@ __device__ inline bool stage_a(WaveLds& L, int npts, const double* __restrict__ 
 
 // One eigenvector column -> (quaternion [w x y z], translation) if it is an admissible root (dls_pnp.cc:147-198):
 // V (27 x 27, hqr2 column convention), wi: imaginary parts of the eigenvalues.
+// COMPACT: V holds only the four rows read here, in the order {0, 9, 3, 1} (eig_team's kept rows).
+constexpr int kKeptRows = 4;
+__device__ __constant__ const int kKeptRow[kKeptRows] = {0, 9, 3, 1};
+template <bool COMPACT = false>
 __device__ inline bool column_solution(const double* V, const double* wi, int i, const double* __restrict__ tfac, int npts,
                                        const double* __restrict__ world, int wstride, const int* __restrict__ index,
                                        double* quat, double* tr) {
@@ -242,7 +246,7 @@ __device__ inline bool column_solution(const double* V, const double* wi, int i,
   const double d_re = V[re_col], d_im = cplx ? sg * V[re_col + 1] : 0.0;   // row 0
   if (d_re == 0.0 && d_im == 0.0) return false;
   double sr[3], si[3];
-  const int rows[3] = {9, 3, 1};
+  const int rows[3] = {COMPACT ? 1 : 9, COMPACT ? 2 : 3, COMPACT ? 3 : 1};
   for (int k = 0; k < 3; ++k) {
     const double a = V[27 * rows[k] + re_col], b = cplx ? sg * V[27 * rows[k] + re_col + 1] : 0.0;
     rsc::eig_cdiv(a, b, d_re, d_im, &sr[k], &si[k]);

@@ -28,12 +28,23 @@ __device__ __forceinline__ void team_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-template <int TEAM, bool CPLX>
-__device__ bool eig_team(int nn, double* __restrict__ H, double* __restrict__ V, double* __restrict__ X,
-                         double* __restrict__ wr, double* __restrict__ wi, double* __restrict__ ort, int tl) {
+//
+// NR > 0 (a caller that reads only NR rows of the eigenvector matrix, e.g. DLS: rows 0, 9, 3, 1): once the Householder
+// reflectors are accumulated, every later operation on V combines COLUMNS of one row -- the rows never mix again -- so
+// only the NR wanted rows (keep[0 .. NR - 1]) are carried through hqr2 and the back-transformation, in Vk (NR x n, LDS).
+// The full V of the accumulation lives in V, which may then be slow memory (the work array X is not in use yet: the two
+// can share storage).  Same arithmetic per entry, so the kept rows equal those of the full computation bit for bit.
+template <int TEAM, bool CPLX, int NR = 0>
+__device__ bool eig_team(int nn, double* __restrict__ H, double* V, double* X,
+                         double* __restrict__ wr, double* __restrict__ wi, double* __restrict__ ort, int tl,
+                         double* __restrict__ Vk = nullptr, const int* __restrict__ keep = nullptr) {
 #define HH(i, j) H[(i) * nn + (j)]
 #define VV(i, j) V[(i) * nn + (j)]
 #define XX(i, j) X[(i) * nn + (j)]
+  // rows of the eigenvector matrix after the accumulation: all of V, or the kept rows in Vk
+  const int vrows = NR > 0 ? NR : nn;
+  double* const VR = NR > 0 ? Vk : V;
+#define VRR(i, j) VR[(i) * nn + (j)]
   const int low = 0, high = nn - 1;
   // ---- orthes
   for (int m = low + 1; m <= high - 1; ++m) {
@@ -87,6 +98,10 @@ __device__ bool eig_team(int nn, double* __restrict__ H, double* __restrict__ V,
       team_sync();
     }
   }
+  if constexpr (NR > 0) {
+    for (int e = tl; e < NR * nn; e += TEAM) Vk[e] = VV(keep[e / nn], e % nn);
+    team_sync();
+  }
   // ---- hqr2
   int n = nn - 1;
   const double eps = 2.220446049250313e-16;
@@ -134,7 +149,7 @@ __device__ bool eig_team(int nn, double* __restrict__ H, double* __restrict__ V,
         for (int j = n - 1 + tl; j < nn; j += TEAM) { const double zz = HH(n - 1, j); HH(n - 1, j) = q * zz + p * HH(n, j); HH(n, j) = q * HH(n, j) - p * zz; }
         team_sync();
         for (int i = tl; i <= n; i += TEAM) { const double zz = HH(i, n - 1); HH(i, n - 1) = q * zz + p * HH(i, n); HH(i, n) = q * HH(i, n) - p * zz; }
-        for (int i = low + tl; i <= high; i += TEAM) { const double zz = VV(i, n - 1); VV(i, n - 1) = q * zz + p * VV(i, n); VV(i, n) = q * VV(i, n) - p * zz; }
+        for (int i = tl; i < vrows; i += TEAM) { const double zz = VRR(i, n - 1); VRR(i, n - 1) = q * zz + p * VRR(i, n); VRR(i, n) = q * VRR(i, n) - p * zz; }
         team_sync();
       } else {  // complex pair
         if (tl == 0) { wr[n - 1] = x + p; wr[n] = x + p; wi[n - 1] = z; wi[n] = -z; }
@@ -219,11 +234,11 @@ __device__ bool eig_team(int nn, double* __restrict__ H, double* __restrict__ V,
             HH(i, k) = HH(i, k) - pp;
             HH(i, k + 1) = HH(i, k + 1) - pp * q;
           }
-          for (int i = low + tl; i <= high; i += TEAM) {
-            double pp = x * VV(i, k) + y * VV(i, k + 1);
-            if (notlast) { pp = pp + z * VV(i, k + 2); VV(i, k + 2) = VV(i, k + 2) - pp * r; }
-            VV(i, k) = VV(i, k) - pp;
-            VV(i, k + 1) = VV(i, k + 1) - pp * q;
+          for (int i = tl; i < vrows; i += TEAM) {
+            double pp = x * VRR(i, k) + y * VRR(i, k + 1);
+            if (notlast) { pp = pp + z * VRR(i, k + 2); VRR(i, k + 2) = VRR(i, k + 2) - pp * r; }
+            VRR(i, k) = VRR(i, k) - pp;
+            VRR(i, k + 1) = VRR(i, k + 1) - pp * q;
           }
           team_sync();
         }
@@ -309,18 +324,19 @@ __device__ bool eig_team(int nn, double* __restrict__ H, double* __restrict__ V,
   }
   team_sync();
   // ---- back-transformation V <- V X, row i by lane (column j in descending order, in place as in the sequential code)
-  for (int i = low + tl; i <= high; i += TEAM)
+  for (int i = tl; i < vrows; i += TEAM)
     for (int j = nn - 1; j >= low; --j) {
       if (!CPLX && wi[j] != 0) continue;
       z = 0.0;
-      for (int k = low; k <= j; ++k) z = z + VV(i, k) * XX(k, j);
-      VV(i, j) = z;
+      for (int k = low; k <= j; ++k) z = z + VRR(i, k) * XX(k, j);
+      VRR(i, j) = z;
     }
   team_sync();
   return true;
 #undef HH
 #undef VV
 #undef XX
+#undef VRR
 }
 
 }  // namespace rsc

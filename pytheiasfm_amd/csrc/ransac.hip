@@ -843,7 +843,7 @@ __global__ __launch_bounds__(64) void k_dls_b(int nprob, int B, const int64_t* _
 
 // stage B on chip: a team of 32 lanes per hypothesis, H / V / X in LDS (eig_team.h), lanes 0..26 turn one eigenvector
 // column each into a pose, kept in column order by a team prefix sum
-constexpr int kDlsTeam = 32, kDlsTeamsPerWave = 64 / kDlsTeam, kDlsTeamLds = 2 * 729 + 81;   // H | V | wr, wi, ort
+constexpr int kDlsTeam = 32, kDlsTeamsPerWave = 64 / kDlsTeam, kDlsTeamLds = 729 + 27 * dlsdev::kKeptRows + 81;   // H | kept rows of V | wr, wi, ort
 __global__ __launch_bounds__(64) void k_dls_b_team(size_t nhyp, int B, const int64_t* __restrict__ offsets,
                                                    const double* __restrict__ data, const int* __restrict__ samples,
                                                    const int* __restrict__ active_iters, double* __restrict__ action,
@@ -856,18 +856,23 @@ __global__ __launch_bounds__(64) void k_dls_b_team(size_t nhyp, int B, const int
   if (hyp >= nhyp) return;
   const int p = (int)(hyp / B), b = (int)(hyp % B);
   if (b >= active_iters[p] || !okflag[hyp]) { if (tl == 0) counts[hyp] = 0; return; }
-  // H and V in LDS; the work array X of the back-substitution lives in the hypothesis' own action-matrix slot in HBM (free
-  // once H is on chip): 24.6 instead of 36.3 KB of LDS per wave = six instead of four resident waves per CU
-  double* H = lds[team]; double* V = H + 729; double* wr = V + 729; double* wi = wr + 27; double* ort = wi + 27;
+  // The kernel is bound by the matrices resident per CU (one dependent chain each), i.e. by LDS per matrix.  H stays in
+  // LDS; the work array X of the back-substitution lives in the hypothesis' own action-matrix slot in HBM (free once H is
+  // on chip); so does the full eigenvector matrix while the Householder reflectors are accumulated -- after that only the
+  // four rows column_solution() reads are carried (eig_team.h, NR): 14.7 instead of 24.6 KB of LDS per wave = ten
+  // instead of six resident waves per CU
+  double* H = lds[team]; double* Vk = H + 729; double* wr = Vk + 27 * dlsdev::kKeptRows; double* wi = wr + 27; double* ort = wi + 27;
   double* a = action + hyp * 729;
   for (int e = tl; e < 729; e += kDlsTeam) H[e] = a[e];
   rsc::team_sync();
-  const bool good = rsc::eig_team<kDlsTeam, true>(27, H, V, a, wr, wi, ort, tl);
+  int nn = 27;
+  asm volatile("" : "+s"(nn));   // the order stays a run-time value: with the literal the loops unroll into 250 VGPRs (two waves per SIMD)
+  const bool good = rsc::eig_team<kDlsTeam, true, dlsdev::kKeptRows>(nn, H, a, a, wr, wi, ort, tl, Vk, dlsdev::kKeptRow);
   double quat[4], tr[3];
   bool keep = false;
   if (good && tl < 27) {
     const double* pd = data + (size_t)offsets[p] * 5;
-    keep = dlsdev::column_solution(V, wi, tl, tfac + hyp * 27, 3, pd + 2, 5, samples + hyp * 3, quat, tr);
+    keep = dlsdev::column_solution<true>(Vk, wi, tl, tfac + hyp * 27, 3, pd + 2, 5, samples + hyp * 3, quat, tr);
   }
   // rank of this lane's solution among the team's (column order) and the team's count
   int incl = keep ? 1 : 0;
