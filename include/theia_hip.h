@@ -151,8 +151,11 @@ typedef struct theia_ba_problem {
    * variable of track t is point_inverse_depth[t] = Track::InverseDepth() along point_ref_bearing[t] =
    * Track::ReferenceBearingVector() in the frame of view point_ref_cam[t] = Track::ReferenceViewId(); `points` is not
    * read (the caller's UpdateHomogeneousPoint rebuilds it afterwards, bundle_adjustment.cc:47-65).  Every residual block
-   * touches the reference camera, the observing camera and the inverse depth.  Only through theia_hip_ba_solve;
-   * intrinsics constant, no priors / depth rows / inner iterations in this mode. */
+   * touches the reference camera, the observing camera, the intrinsics group of the observing camera
+   * (bundle_adjuster.cc:594-622; optimised on the subset of options.intrinsics_to_optimize unless group_const) and the
+   * inverse depth; the camera priors enter as AddViewPriors adds them (bundle_adjuster.cc:289-313: the views that observe
+   * a track or are the reference view of one).  Only through theia_hip_ba_solve; no depth rows / inner iterations in this
+   * mode; a track may be observed through at most 8 variable intrinsics groups (THEIA_HIP_ERR_UNSUPPORTED beyond). */
   const int32_t* point_ref_cam;                  /* [num_points] camera index of the reference view */
   const double* point_ref_bearing;               /* [num_points][3]                                 */
   double* point_inverse_depth;                   /* [num_points] in/out, > 0                        */

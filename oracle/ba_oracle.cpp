@@ -2136,12 +2136,15 @@ double oracle_angular_epipolar_error(const double* rotation, const double* posit
 // inverse depth) or, for the reference view's own feature, InvReprojectionPoseError (:232-286).  Restated with Jets over
 // exactly those parameters and solved as ONE dense Levenberg-Marquardt problem (normal equations of the full scaled
 // Jacobian, no Schur complement): the same steps Ceres' exact SPARSE_SCHUR solve produces, reached another way than
-// the device's per-track elimination.  Intrinsics stay constant, no camera priors, no inner iterations (the reference
-// passes no inner ordering in this mode and leaves the choice to Ceres' graph heuristic).
+// the device's per-track elimination.  The intrinsics of a group are a parameter block of every residual of its cameras
+// (optimised on the subset of BundleAdjustmentOptions::intrinsics_to_optimize, bundle_adjuster.cc:382-460, bounds as the
+// main path: box projection of the step); AddViewPriors (bundle_adjuster.cc:289-313) adds the position / gravity /
+// orientation prior rows of the optimised views (no loss function).  No inner iterations (the reference passes no
+// inner ordering in this mode and leaves the choice to Ceres' graph heuristic).
 namespace {
 
 template <typename T>
-inline bool inv_reprojection_error(int model, const T* ext_ref, const T* ext_oth, bool same_view, const double* intr,
+inline bool inv_reprojection_error(int model, const T* ext_ref, const T* ext_oth, bool same_view, const T* k,
                                    const double* bearing, const T& rho, const double uv[2], const double si[2], T* res) {
   T p_ref[3] = {T(bearing[0]) / rho, T(bearing[1]) / rho, T(bearing[2]) / rho};
   T pc[3];
@@ -2155,8 +2158,6 @@ inline bool inv_reprojection_error(int model, const T* ext_ref, const T* ext_oth
     T d[3] = {pw[0] + ext_ref[0] - ext_oth[0], pw[1] + ext_ref[1] - ext_oth[1], pw[2] + ext_ref[2] - ext_oth[2]};
     angle_axis_rotate_point(ext_oth + 3, d, pc);                       // R_oth (X_w - c_oth)
   }
-  T k[kMaxIntr];
-  for (int q = 0; q < kMaxIntr; ++q) k[q] = T(intr[q]);
   T pix[2];
   const bool ok = project(model, k, pc, pix);
   res[0] = si[0] * (pix[0] - uv[0]);
@@ -2168,12 +2169,12 @@ inline bool inv_reprojection_error(int model, const T* ext_ref, const T* ext_oth
 
 extern "C" int oracle_ba_solve_inverse_depth(oba_problem* P, const int32_t* point_ref_cam, const double* point_ref_bearing,
                                               double* point_inverse_depth, const oba_options* O, oba_summary* S) {
-  const int nc = P->num_cameras, np = P->num_points;
+  const int nc = P->num_cameras, np = P->num_points, ng = P->num_groups;
   const int64_t nobs = P->num_obs;
   S->trace_size = 0; S->success = 0; S->num_iterations = 0; S->num_successful_steps = 0;
   const double one[2] = {1.0, 1.0};
   // variable blocks: cameras that see a variable track (as reference or as observer) and are not constant
-  std::vector<uint8_t> cam_mask(nc, 0), cam_used(nc, 0);
+  std::vector<uint8_t> cam_mask(nc, 0), cam_used(nc, 0), grp_used(ng, 0);
   for (int c = 0; c < nc; ++c) {
     unsigned m = 0;
     const int cc = P->cam_const ? P->cam_const[c] : 0;
@@ -2181,37 +2182,67 @@ extern "C" int oracle_ba_solve_inverse_depth(oba_problem* P, const int32_t* poin
     if ((cc & 2) || O->constant_camera_orientation) m |= 0x38;
     cam_mask[c] = (uint8_t)m;
   }
-  for (int64_t i = 0; i < nobs; ++i) { cam_used[P->obs_cam[i]] = 1; cam_used[point_ref_cam[P->obs_pt[i]]] = 1; }
-  std::vector<int> cam_col(nc, -1), pt_col(np, -1);
+  for (int64_t i = 0; i < nobs; ++i) { cam_used[P->obs_cam[i]] = 1; cam_used[point_ref_cam[P->obs_pt[i]]] = 1; grp_used[P->cam_group[P->obs_cam[i]]] = 1; }
+  std::vector<int> cam_col(nc, -1), pt_col(np, -1), grp_col((size_t)ng * kMaxIntr, -1);
+  std::vector<uint8_t> grp_var(ng, 0);
   int ncol = 0;
   for (int c = 0; c < nc; ++c) if (cam_used[c] && (cam_mask[c] & 0x3f) != 0x3f) { cam_col[c] = ncol; ncol += 6; }
+  for (int g = 0; g < ng; ++g) {   // one column per free parameter of a variable group (SubsetManifold)
+    const unsigned fm = intrinsics_free_mask(P->group_model[g], O->intrinsics_to_optimize);
+    if ((P->group_const && P->group_const[g]) || fm == 0 || !grp_used[g]) continue;
+    grp_var[g] = 1;
+    for (int q = 0; q < kMaxIntr; ++q) if ((fm >> q) & 1u) grp_col[(size_t)g * kMaxIntr + q] = ncol++;
+  }
   std::vector<uint8_t> pt_used(np, 0);
   for (int64_t i = 0; i < nobs; ++i) pt_used[P->obs_pt[i]] = 1;
   for (int p = 0; p < np; ++p) if (pt_used[p] && !(P->point_const && P->point_const[p])) pt_col[p] = ncol++;
   std::vector<double> cam(P->cam_ext, P->cam_ext + 6 * (size_t)nc), rho(point_inverse_depth, point_inverse_depth + np);
-  std::vector<double> J, r(2 * (size_t)nobs);
+  std::vector<double> intr(P->intrinsics, P->intrinsics + (size_t)kMaxIntr * ng);
+  for (int g = 0; g < ng; ++g) if (grp_var[g]) project_intrinsics_to_bounds(P->group_model[g], &intr[(size_t)g * kMaxIntr]);
+  // camera priors (AddViewPriors): rows of the optimised views; on a constant camera a fixed cost
+  struct Prior { int cam, kind; const double* vec; const double* sqrt_info; };
+  std::vector<Prior> priors;
+  double fixed_cost = 0.0;
+  if (P->cam_prior_mask && O->prior_mask) {
+    const double* vecs[3] = {P->cam_position_prior, P->cam_gravity_prior, P->cam_orientation_prior};
+    const double* infos[3] = {P->cam_position_prior_sqrt_info, P->cam_gravity_prior_sqrt_info, P->cam_orientation_prior_sqrt_info};
+    for (int c = 0; c < nc; ++c)
+      for (int k = 0; k < 3; ++k) {
+        const int bit = 1 << k;
+        if (!cam_used[c] || !(P->cam_prior_mask[c] & bit) || !(O->prior_mask & bit) || !vecs[k] || !infos[k]) continue;
+        if (cam_col[c] >= 0) priors.push_back(Prior{c, bit, vecs[k] + 3 * c, infos[k] + 9 * c});
+        else {
+          double r3[3];
+          camera_prior_residual<double>(bit, &cam[6 * (size_t)c], vecs[k] + 3 * c, infos[k] + 9 * c, r3);
+          fixed_cost += 0.5 * ((r3[0] * r3[0] + r3[1] * r3[1]) + r3[2] * r3[2]);
+        }
+      }
+  }
+  const int64_t nrow = 2 * nobs + 3 * (int64_t)priors.size();
+  std::vector<double> J, r((size_t)nrow);
 
-  auto evaluate = [&](const std::vector<double>& cm, const std::vector<double>& rh, bool want_jac, double* cost) {
+  auto evaluate = [&](const std::vector<double>& cm, const std::vector<double>& rh, const std::vector<double>& kk, bool want_jac, double* cost) {
     bool ok = true;
     double cst = 0.0;
-    if (want_jac) J.assign((size_t)2 * nobs * ncol, 0.0);
+    if (want_jac) J.assign((size_t)nrow * ncol, 0.0);
     for (int64_t i = 0; i < nobs; ++i) {
-      const int c = P->obs_cam[i], p = P->obs_pt[i], cr = point_ref_cam[p];
-      const int model = P->group_model[P->cam_group[c]];
-      const double* intr = P->intrinsics + (size_t)P->cam_group[c] * kMaxIntr;
+      const int c = P->obs_cam[i], p = P->obs_pt[i], cr = point_ref_cam[p], g = P->cam_group[c];
+      const int model = P->group_model[g];
+      const double* ki = &kk[(size_t)g * kMaxIntr];
       const double* si = P->obs_sqrt_info ? P->obs_sqrt_info + 2 * i : one;
       const bool same = c == cr;
       double res[2];
-      typedef Jet<13> JT;
+      typedef Jet<13 + kMaxIntr> JT;
       JT rr[2];
       if (want_jac) {
-        JT er[6], eo[6];
+        JT er[6], eo[6], kj[kMaxIntr];
         for (int q = 0; q < 6; ++q) { er[q] = JT(cm[6 * (size_t)cr + q], q); eo[q] = same ? er[q] : JT(cm[6 * (size_t)c + q], 6 + q); }
+        for (int q = 0; q < kMaxIntr; ++q) kj[q] = JT(ki[q], 13 + q);
         const JT rj(rh[p], 12);
-        if (!inv_reprojection_error<JT>(model, er, eo, same, intr, point_ref_bearing + 3 * (size_t)p, rj, P->obs_uv + 2 * i, si, rr)) ok = false;
+        if (!inv_reprojection_error<JT>(model, er, eo, same, kj, point_ref_bearing + 3 * (size_t)p, rj, P->obs_uv + 2 * i, si, rr)) ok = false;
         res[0] = rr[0].a; res[1] = rr[1].a;
       } else {
-        if (!inv_reprojection_error<double>(model, &cm[6 * (size_t)cr], &cm[6 * (size_t)c], same, intr, point_ref_bearing + 3 * (size_t)p,
+        if (!inv_reprojection_error<double>(model, &cm[6 * (size_t)cr], &cm[6 * (size_t)c], same, ki, point_ref_bearing + 3 * (size_t)p,
                                             rh[p], P->obs_uv + 2 * i, si, res)) ok = false;
       }
       double lr[3];
@@ -2224,37 +2255,53 @@ extern "C" int oracle_ba_solve_inverse_depth(oba_problem* P, const int32_t* poin
         double* row = &J[((size_t)2 * i + a) * ncol];
         if (cam_col[cr] >= 0) for (int q = 0; q < 6; ++q) if (!((cam_mask[cr] >> q) & 1)) row[cam_col[cr] + q] += sr * rr[a].v[q];
         if (!same && cam_col[c] >= 0) for (int q = 0; q < 6; ++q) if (!((cam_mask[c] >> q) & 1)) row[cam_col[c] + q] += sr * rr[a].v[6 + q];
+        for (int q = 0; q < kMaxIntr; ++q) { const int gc = grp_col[(size_t)g * kMaxIntr + q]; if (gc >= 0) row[gc] += sr * rr[a].v[13 + q]; }
         if (pt_col[p] >= 0) row[pt_col[p]] += sr * rr[a].v[12];
+      }
+    }
+    for (size_t k = 0; k < priors.size(); ++k) {
+      const Prior& pr = priors[k];
+      typedef Jet<6> J6;
+      J6 e[6], r3[3];
+      for (int q = 0; q < 6; ++q) e[q] = J6(cm[6 * (size_t)pr.cam + q], q);
+      camera_prior_residual<J6>(pr.kind, e, pr.vec, pr.sqrt_info, r3);
+      for (int a = 0; a < 3; ++a) {
+        cst += 0.5 * r3[a].a * r3[a].a;
+        if (!want_jac) continue;
+        const int64_t rw = 2 * nobs + 3 * (int64_t)k + a;
+        r[rw] = r3[a].a;
+        for (int q = 0; q < 6; ++q) if (!((cam_mask[pr.cam] >> q) & 1)) J[(size_t)rw * ncol + cam_col[pr.cam] + q] += r3[a].v[q];
       }
     }
     *cost = cst;
     return ok;
   };
-  auto state_norm = [&](const std::vector<double>& cm, const std::vector<double>& rh) {
+  auto state_norm = [&](const std::vector<double>& cm, const std::vector<double>& rh, const std::vector<double>& kk) {
     double sn = 0.0;
+    for (int g = 0; g < ng; ++g) if (grp_var[g]) { const int K = intrinsics_size(P->group_model[g]); for (int q = 0; q < K; ++q) sn += kk[(size_t)g * kMaxIntr + q] * kk[(size_t)g * kMaxIntr + q]; }
     for (int c = 0; c < nc; ++c) if (cam_col[c] >= 0) for (int q = 0; q < 6; ++q) sn += cm[6 * (size_t)c + q] * cm[6 * (size_t)c + q];
     for (int p = 0; p < np; ++p) if (pt_col[p] >= 0) sn += rh[p] * rh[p];
     return std::sqrt(sn);
   };
   double x_cost;
-  if (!evaluate(cam, rho, true, &x_cost)) { S->termination_type = 2; S->initial_cost = S->final_cost = x_cost; return 0; }
+  if (!evaluate(cam, rho, intr, true, &x_cost)) { S->termination_type = 2; S->initial_cost = S->final_cost = x_cost + fixed_cost; return 0; }
   // Jacobi scaling from the column norms at the start
   std::vector<double> scale(ncol, 1.0), g(ncol), H, y(ncol), diag(ncol);
-  for (int k = 0; k < ncol; ++k) { double sq = 0.0; for (int64_t rw = 0; rw < 2 * nobs; ++rw) sq += J[(size_t)rw * ncol + k] * J[(size_t)rw * ncol + k]; scale[k] = 1.0 / (1.0 + std::sqrt(sq)); }
+  for (int k = 0; k < ncol; ++k) { double sq = 0.0; for (int64_t rw = 0; rw < nrow; ++rw) sq += J[(size_t)rw * ncol + k] * J[(size_t)rw * ncol + k]; scale[k] = 1.0 / (1.0 + std::sqrt(sq)); }
   auto apply_scale_and_gradient = [&]() {
-    for (int64_t rw = 0; rw < 2 * nobs; ++rw) for (int k = 0; k < ncol; ++k) J[(size_t)rw * ncol + k] *= scale[k];
+    for (int64_t rw = 0; rw < nrow; ++rw) for (int k = 0; k < ncol; ++k) J[(size_t)rw * ncol + k] *= scale[k];
     double gm = 0.0;
-    for (int k = 0; k < ncol; ++k) { double s2 = 0.0; for (int64_t rw = 0; rw < 2 * nobs; ++rw) s2 += J[(size_t)rw * ncol + k] * r[rw]; g[k] = s2; gm = std::max(gm, std::fabs(s2 / scale[k])); }
+    for (int k = 0; k < ncol; ++k) { double s2 = 0.0; for (int64_t rw = 0; rw < nrow; ++rw) s2 += J[(size_t)rw * ncol + k] * r[rw]; g[k] = s2; gm = std::max(gm, std::fabs(s2 / scale[k])); }
     return gm;
   };
   double gmax = apply_scale_and_gradient();
-  double x_norm = state_norm(cam, rho);
-  S->initial_cost = x_cost;
+  double x_norm = state_norm(cam, rho, intr);
+  S->initial_cost = x_cost + fixed_cost;
   double radius = 1e4, decrease_factor = 2.0, minimum_cost = x_cost;
   bool step_successful = true, reuse = false;
   int iter = 0, invalid_steps = 0, term = 1;
-  trace_push(S, x_cost, gmax, 0.0, radius, 1);
-  std::vector<double> ccam, crho;
+  trace_push(S, x_cost + fixed_cost, gmax, 0.0, radius, 1);
+  std::vector<double> ccam, crho, cintr;
   while (true) {
     if (iter >= O->max_num_iterations) { term = 1; break; }
     if (step_successful && gmax <= O->gradient_tolerance) { term = 0; break; }
@@ -2262,7 +2309,7 @@ extern "C" int oracle_ba_solve_inverse_depth(oba_problem* P, const int32_t* poin
     ++iter;
     if (!reuse) {
       H.assign((size_t)ncol * ncol, 0.0);
-      for (int64_t rw = 0; rw < 2 * nobs; ++rw) {
+      for (int64_t rw = 0; rw < nrow; ++rw) {
         const double* row = &J[(size_t)rw * ncol];
         for (int a = 0; a < ncol; ++a) { if (row[a] == 0.0) continue; for (int b = 0; b <= a; ++b) H[(size_t)a * ncol + b] += row[a] * row[b]; }
       }
@@ -2284,7 +2331,7 @@ extern "C" int oracle_ba_solve_inverse_depth(oba_problem* P, const int32_t* poin
     if (solved) {
       for (int i = 0; i < ncol; ++i) { double s2 = g[i]; for (int k = 0; k < i; ++k) s2 -= L[(size_t)i * ncol + k] * y[k]; y[i] = s2 / L[(size_t)i * ncol + i]; }
       for (int i = ncol - 1; i >= 0; --i) { double s2 = y[i]; for (int k = i + 1; k < ncol; ++k) s2 -= L[(size_t)k * ncol + i] * y[k]; y[i] = s2 / L[(size_t)i * ncol + i]; }
-      for (int64_t rw = 0; rw < 2 * nobs; ++rw) {
+      for (int64_t rw = 0; rw < nrow; ++rw) {
         double m = 0.0;
         const double* row = &J[(size_t)rw * ncol];
         for (int k = 0; k < ncol; ++k) m -= row[k] * y[k];
@@ -2294,42 +2341,46 @@ extern "C" int oracle_ba_solve_inverse_depth(oba_problem* P, const int32_t* poin
     if (!(solved && std::isfinite(model_cost_change) && model_cost_change > 0.0)) {
       if (++invalid_steps >= 5) { term = 2; break; }
       radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
-      trace_push(S, x_cost, gmax, 0.0, radius, 0);
+      trace_push(S, x_cost + fixed_cost, gmax, 0.0, radius, 0);
       continue;
     }
     invalid_steps = 0;
-    ccam = cam; crho = rho;
+    ccam = cam; crho = rho; cintr = intr;
     for (int c = 0; c < nc; ++c) if (cam_col[c] >= 0) for (int q = 0; q < 6; ++q) if (!((cam_mask[c] >> q) & 1))
       ccam[6 * (size_t)c + q] = cam[6 * (size_t)c + q] - y[cam_col[c] + q] * scale[cam_col[c] + q];
+    for (int gq = 0; gq < ng * kMaxIntr; ++gq) if (grp_col[gq] >= 0) cintr[gq] = intr[gq] - y[grp_col[gq]] * scale[grp_col[gq]];
+    for (int gi = 0; gi < ng; ++gi) if (grp_var[gi]) project_intrinsics_to_bounds(P->group_model[gi], &cintr[(size_t)gi * kMaxIntr]);
     for (int p = 0; p < np; ++p) if (pt_col[p] >= 0) crho[p] = rho[p] - y[pt_col[p]] * scale[pt_col[p]];
     double cand_cost;
-    if (!evaluate(ccam, crho, false, &cand_cost)) cand_cost = std::numeric_limits<double>::max();
+    if (!evaluate(ccam, crho, cintr, false, &cand_cost)) cand_cost = std::numeric_limits<double>::max();
     double sn = 0.0;
     for (int c = 0; c < nc; ++c) if (cam_col[c] >= 0) for (int q = 0; q < 6; ++q) { const double d = cam[6 * (size_t)c + q] - ccam[6 * (size_t)c + q]; sn += d * d; }
+    for (int gq = 0; gq < ng * kMaxIntr; ++gq) if (grp_var[gq / kMaxIntr]) { const double d = intr[gq] - cintr[gq]; sn += d * d; }
     for (int p = 0; p < np; ++p) if (pt_col[p] >= 0) { const double d = rho[p] - crho[p]; sn += d * d; }
     const double step_norm = std::sqrt(sn);
-    if (step_norm <= O->parameter_tolerance * (x_norm + O->parameter_tolerance)) { trace_push(S, cand_cost, gmax, step_norm, radius, 0); term = 0; break; }
+    if (step_norm <= O->parameter_tolerance * (x_norm + O->parameter_tolerance)) { trace_push(S, cand_cost + fixed_cost, gmax, step_norm, radius, 0); term = 0; break; }
     const double cost_change = x_cost - cand_cost;
-    if (std::fabs(cost_change) <= O->function_tolerance * x_cost) { trace_push(S, cand_cost, gmax, step_norm, radius, 0); term = 0; break; }
+    if (std::fabs(cost_change) <= O->function_tolerance * x_cost) { trace_push(S, cand_cost + fixed_cost, gmax, step_norm, radius, 0); term = 0; break; }
     const double relative_decrease = cost_change / model_cost_change;
     if (relative_decrease > 1e-3) {
-      cam.swap(ccam); rho.swap(crho);
-      x_norm = state_norm(cam, rho);
-      evaluate(cam, rho, true, &x_cost);
+      cam.swap(ccam); rho.swap(crho); intr.swap(cintr);
+      x_norm = state_norm(cam, rho, intr);
+      evaluate(cam, rho, intr, true, &x_cost);
       gmax = apply_scale_and_gradient();
       radius = std::min(O->max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3)));
       decrease_factor = 2.0; reuse = false; step_successful = true;
       S->num_successful_steps++;
       if (x_cost < minimum_cost) minimum_cost = x_cost;
-      trace_push(S, x_cost, gmax, step_norm, radius, 1);
+      trace_push(S, x_cost + fixed_cost, gmax, step_norm, radius, 1);
     } else {
       radius /= decrease_factor; decrease_factor *= 2.0; step_successful = false;
-      trace_push(S, cand_cost, gmax, step_norm, radius, 0);
+      trace_push(S, cand_cost + fixed_cost, gmax, step_norm, radius, 0);
     }
   }
   S->num_iterations = iter; S->termination_type = term; S->success = term != 2;
-  S->final_cost = minimum_cost;
+  S->final_cost = minimum_cost + fixed_cost;
   std::copy(cam.begin(), cam.end(), P->cam_ext);
+  std::copy(intr.begin(), intr.end(), P->intrinsics);
   std::copy(rho.begin(), rho.end(), point_inverse_depth);
   return 0;
 }

@@ -322,14 +322,10 @@ def _run_inverse_depth(options, recon, track_ids, const_view_ids=()):
     # parameter graph -- not reproducible outside Ceres.  The sweeps are switched off here; the LM trajectory of a
     # default-options call can therefore differ from the reference's after the first accepted step.
     c_opts.use_inner_iterations = 0
-    # AddViewPriors (bundle_adjuster.cc:290-313) does run in this mode; the inverse-depth kernels carry no prior rows yet:
-    # refuse loudly instead of dropping the residual blocks.
-    wanted = ((capi.THEIA_PRIOR_POSITION if options.use_position_priors else 0) |
-              (capi.THEIA_PRIOR_GRAVITY if options.use_gravity_priors else 0) |
-              (capi.THEIA_PRIOR_ORIENTATION if options.use_orientation_priors else 0))
-    if wanted and recon.view_prior_mask is not None and np.any(np.asarray(recon.view_prior_mask) & wanted):
-        raise capi.TheiaHipError(capi.THEIA_HIP_ERR_UNSUPPORTED,
-                                 "inverse-depth bundle adjustment with camera priors is not built")
+    # AddViewPriors (bundle_adjuster.cc:290-313) runs in this mode over optimized_views_ = the views that observe an added
+    # track or are the reference view of one: exactly the cameras the library counts as used (ba_invdepth.hip)
+    if recon.view_prior_mask is not None:
+        flat.set_priors(np.asarray(recon.view_prior_mask, dtype=np.uint8), **recon.view_priors)
     s, _ = _ba.solve(flat, c_opts)
     recon.cam_ext[:] = flat.cam_ext
     recon.inverse_depth[added] = flat.point_inverse_depth[added]

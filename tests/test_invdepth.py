@@ -60,3 +60,41 @@ def test_world_points_of_the_solution_reproject_at_noise_level():
     assert np.sqrt((r ** 2).sum(axis=1).mean()) < 3.0          # 1 px feature noise, the reference ray carries its own
     X = idp.world_points(q)
     assert np.isfinite(X).all()
+
+
+def test_oracle_with_free_intrinsics_and_a_position_prior_reaches_the_scipy_minimum():
+    """FOCAL_LENGTH | RADIAL_DISTORTION of the shared group free (a parameter block of every residual of its cameras,
+    bundle_adjuster.cc:594-622) and a position prior on two cameras (AddViewPriors, sqrt information 3 I): the dense-LM
+    oracle against scipy on the same residual vector (reprojection rows + 3 prior rows per camera)."""
+    p = idp.make(6, 60, seed=7)
+    p.intrinsics[:, 5] = -0.02          # some distortion to estimate
+    p.cam_group[:] = 0                   # one shared group
+    p.cam_const = np.zeros(6, dtype=np.uint8); p.cam_const[0] = 3; p.cam_const[1] = 1
+    mask = np.zeros(6, dtype=np.uint8); mask[2] = 1; mask[4] = 1
+    prior = p.cam_ext[:, :3] + 0.01
+    info = np.tile(3.0 * np.eye(3), (6, 1, 1))
+    p.set_priors(mask, position=(prior, info))
+    o = ol.default_options(); o.max_num_iterations = 80; o.use_inner_iterations = 0
+    o.intrinsics_to_optimize = 0x01 | 0x10; o.prior_mask = 1
+    o.function_tolerance = 1e-15; o.parameter_tolerance = 1e-15; o.gradient_tolerance = 1e-15
+    q = p.copy()
+    s, tr = ol.solve_inverse_depth(q, o)
+    assert s.success and s.final_cost < s.initial_cost
+    assert not np.array_equal(q.intrinsics[0, [0, 5, 6]], p.intrinsics[0, [0, 5, 6]])
+    assert np.array_equal(q.intrinsics[0, [1, 2, 3, 4]], p.intrinsics[0, [1, 2, 3, 4]])    # not in the subset
+
+    free = np.ones((6, 6), dtype=bool); free[0] = False; free[1, :3] = False
+    nf = int(free.sum())
+
+    def fun(x):
+        pp = p.copy()
+        cam = p.cam_ext.copy(); cam[free] = x[:nf]
+        pp.intrinsics[0, [0, 5, 6]] = x[nf:nf + 3]
+        r = _residuals(pp, cam, x[nf + 3:]).reshape(-1)
+        pr = np.concatenate([3.0 * (prior[c] - cam[c, :3]) for c in (2, 4)])    # PositionError: sqrt_info (prior - position)
+        return np.concatenate([r, pr])
+    x0 = np.concatenate([p.cam_ext[free], p.intrinsics[0, [0, 5, 6]], p.point_inverse_depth])
+    assert abs(0.5 * (fun(x0) ** 2).sum() - s.initial_cost) <= 1e-9 * s.initial_cost
+    ls = least_squares(fun, x0, method="trf", x_scale="jac", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=400)
+    assert abs(ls.cost - s.final_cost) <= 1e-7 * s.final_cost, (ls.cost, s.final_cost)
+    assert np.abs(ls.x[nf:nf + 3] - q.intrinsics[0, [0, 5, 6]]).max() <= 1e-4 * np.abs(ls.x[nf:nf + 3]).max()

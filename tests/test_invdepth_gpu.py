@@ -28,6 +28,7 @@ def _compare(g, o):
     assert list(tg.accepted) == list(to.accepted)
     assert np.allclose(tg.cost, to.cost, rtol=1e-9) and np.allclose(tg.gradient_max_norm, to.gradient_max_norm, rtol=1e-6, atol=1e-9)
     assert np.abs(qg.cam_ext - qo.cam_ext).max() <= 1e-8 and np.abs(qg.point_inverse_depth - qo.point_inverse_depth).max() <= 1e-8
+    assert np.allclose(qg.intrinsics, qo.intrinsics, rtol=1e-9, atol=1e-12)
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(loss_function_type=1, robust_loss_width=2.0), dict(constant_camera_orientation=1),
@@ -65,13 +66,92 @@ def test_mirror_api_updates_the_homogeneous_points():
     assert np.abs(rec.points - idp.world_points(q)).max() <= 1e-7          # UpdateHomogeneousPoint
 
 
+@pytest.mark.parametrize("mask", [0x01, 0x01 | 0x10, 0x01 | 0x02 | 0x08, 0x3f], ids=["focal", "focal+radial", "focal+aspect+pp", "all"])
+def test_inverse_depth_with_free_intrinsics_follows_the_oracle(mask):
+    """The intrinsics of the observing camera's group are a parameter block of every inverse-depth residual
+    (bundle_adjuster.cc:594-622) and are optimised on the subset of intrinsics_to_optimize when their views are optimised
+    (BundleAdjuster::AddView + AddInvTrack through the registration API): shared groups (8 cameras, 3 groups), gauge fixed
+    by one constant camera and one constant position."""
+    p = idp.make(8, 300, seed=21)
+    p.cam_group = (np.arange(8) % 3).astype(np.int32)
+    p.intrinsics[:, 5] = -0.03
+    p.cam_const = np.zeros(8, dtype=np.uint8); p.cam_const[0] = 3; p.cam_const[1] = 1
+    g, o = _both(p, iters=12, intrinsics_to_optimize=mask, function_tolerance=1e-12)
+    _compare(g, o)
+    assert not np.array_equal(g[0].intrinsics[:3, 0], p.intrinsics[:3, 0])
+    assert g[1].final_cost < 0.5 * g[1].initial_cost
+
+
+def test_inverse_depth_with_a_constant_group_and_huber_loss():
+    p = idp.make(8, 300, seed=22)
+    p.cam_group = (np.arange(8) % 2).astype(np.int32)
+    p.group_const = np.array([0, 1, 0, 0, 0, 0, 0, 0], dtype=np.uint8)
+    p.cam_const = np.zeros(8, dtype=np.uint8); p.cam_const[0] = 3; p.cam_const[1] = 1
+    g, o = _both(p, iters=12, intrinsics_to_optimize=0x11, loss_function_type=1, robust_loss_width=2.0)
+    _compare(g, o)
+    assert np.array_equal(g[0].intrinsics[1], p.intrinsics[1]) and not np.array_equal(g[0].intrinsics[0], p.intrinsics[0])
+
+
+@pytest.mark.parametrize("kinds", [1, 2, 4, 7], ids=["position", "gravity", "orientation", "all"])
+def test_inverse_depth_with_camera_priors_follows_the_oracle(kinds):
+    """AddViewPriors (bundle_adjuster.cc:289-313) in inverse-depth mode: prior rows of the optimised views, none on a view
+    that is not part of the problem, a fixed cost for a prior on a constant camera."""
+    p = idp.make(8, 300, seed=23)
+    rng = np.random.default_rng(3)
+    mask = np.zeros(8, dtype=np.uint8); mask[[0, 2, 3, 6]] = 7
+    p.cam_const = np.zeros(8, dtype=np.uint8); p.cam_const[0] = 3          # its priors are a fixed cost
+    info = lambda sc: np.stack([sc * (np.eye(3) + 0.05 * rng.normal(size=(3, 3))) for _ in range(8)])
+    from pytheiasfm_amd import synth
+    grav = np.stack([synth.angle_axis_to_matrix(w[None])[0] @ np.array([0.0, 0.0, -1.0]) for w in p.cam_ext[:, 3:]]) + 0.01 * rng.normal(size=(8, 3))
+    p.set_priors(mask, position=(p.cam_ext[:, :3] + 0.02 * rng.normal(size=(8, 3)), info(4.0)),
+                 gravity=(grav, info(20.0)), orientation=(p.cam_ext[:, 3:] + 0.01 * rng.normal(size=(8, 3)), info(30.0)))
+    g, o = _both(p, iters=12, prior_mask=kinds)
+    _compare(g, o)
+    g0, o0 = _both(p, iters=12, prior_mask=0)
+    assert abs(g[1].final_cost - g0[1].final_cost) > 1e-6 * g0[1].final_cost    # the rows changed the problem
+
+
+def test_inverse_depth_intrinsics_and_priors_together():
+    p = idp.make(10, 400, seed=24)
+    p.cam_group = (np.arange(10) % 2).astype(np.int32)
+    mask = np.zeros(10, dtype=np.uint8); mask[[1, 4, 7]] = 1
+    p.set_priors(mask, position=(p.cam_ext[:, :3] + 0.01, np.tile(5.0 * np.eye(3), (10, 1, 1))))
+    p.cam_const = np.zeros(10, dtype=np.uint8); p.cam_const[0] = 3
+    g, o = _both(p, iters=15, intrinsics_to_optimize=0x11, prior_mask=1, loss_function_type=3, robust_loss_width=3.0)
+    _compare(g, o)
+
+
 def test_unsupported_combinations_are_rejected():
     p = idp.make(4, 40, seed=2)
-    o = ba.default_options(); o.intrinsics_to_optimize = 1
-    with pytest.raises(capi.TheiaHipError):
-        ba.solve(p.copy(), o)
     with pytest.raises(capi.TheiaHipError):
         ba.BaHandle(p.copy(), ba.default_options())       # no handle API in this mode
     bad = p.copy(); bad.point_inverse_depth[3] = -1.0
     with pytest.raises(capi.TheiaHipError):
         ba.solve(bad, ba.default_options())
+
+
+def test_mirror_api_passes_the_view_priors():
+    """BundleAdjustReconstruction with use_inverse_depth_parametrization runs AddViewPriors (bundle_adjustment.cc:194-198):
+    the mirror hands the priors of the reconstruction's views to the library; intrinsics stay constant in this entry
+    point whatever intrinsics_to_optimize says (no view goes through AddView: bundle_adjuster.cc:441-459)."""
+    p = idp.make(8, 200, seed=31)
+    mask = np.zeros(8, dtype=np.uint8); mask[[1, 2, 5, 6]] = 1     # four positions: more than a similarity can absorb
+    sign = np.where(np.arange(8) % 2 == 0, 1.0, -1.0)[:, None]      # not a rigid shift of the scene (that would cost nothing)
+    pri = (p.cam_ext[:, :3] + 0.3 * sign, np.tile(20.0 * np.eye(3), (8, 1, 1)))
+    p.set_priors(mask, position=pri)
+    rec = sfm.Reconstruction.from_flat(p)
+    rec.track_reference_view = p.point_ref_cam.astype(np.int64)
+    rec.track_reference_bearing = p.point_ref_bearing.copy()
+    rec.inverse_depth = p.point_inverse_depth.copy()
+    rec.view_prior_mask = mask.copy(); rec.view_priors = dict(position=pri)
+    opts = sfm.BundleAdjustmentOptions(); opts.use_inverse_depth_parametrization = True; opts.max_num_iterations = 15
+    opts.use_position_priors = True
+    opts.intrinsics_to_optimize = 0x11
+    s = sfm.BundleAdjustReconstruction(opts, rec)
+    q = p.copy(); o = ol.default_options(); o.max_num_iterations = 15; o.use_inner_iterations = 0; o.prior_mask = 1
+    so, _ = ol.solve_inverse_depth(q, o)
+    assert s.success and abs(s.final_cost - so.final_cost) <= 1e-9 * so.final_cost
+    assert np.abs(rec.cam_ext - q.cam_ext).max() <= 1e-8 and np.array_equal(rec.group_intrinsics, p.intrinsics)
+    q0 = p.copy(); o.prior_mask = 0
+    s0, _ = ol.solve_inverse_depth(q0, o)
+    assert abs(s0.final_cost - so.final_cost) > 1e-6 * so.final_cost
