@@ -538,7 +538,17 @@ enum {
    * Error = squared pixel reprojection error through Camera::ProjectPoint, DBL_MAX when the depth is not positive (:92-101).
    * model = homogeneous point (4).  The reference runs EXHAUSTIVE over all pairs for <= 15 observations with
    * min = max iterations = n (n - 1) / 2, RANSAC otherwise (:147-159): the caller passes that choice in the parameters. */
-  THEIA_EST_TRIANGULATION = 11
+  THEIA_EST_TRIANGULATION = 11,
+  /* EstimateRadialHomographyMatrix (estimate_radial_distortion_homography.cc:52-111): datum =
+   * RadialDistortionFeatureCorrespondence (estimate_radial_distortion_homography.h:56-70), 12 doubles:
+   *   [0,1] feature_left  [2,3] feature_right (pixels, principal point removed)  [4,5] normalized_feature_left
+   *   [6,7] normalized_feature_right  [8] focal_length_estimate_left  [9] focal_length_estimate_right
+   *   [10] min_radial_distortion  [11] max_radial_distortion (read from the first datum of a sample, as the reference does).
+   * EstimateModel = SixPointRadialDistortionHomography (six_point_radial_distortion_homography.cc:62-148: null space of
+   * the 6 x 8 constraint, a quadratic, least-squares direction of a 6 x 5 system), up to two models per sample; Error =
+   * CheckRadialSymmetricError (:201-239).  model = RadialHomographyResult: H (9, row-major), l1, l2 (then H^-1, 9 doubles,
+   * kept for the scoring kernels). */
+  THEIA_EST_RADIAL_HOMOGRAPHY = 12
 };
 
 /* A batch of independent estimation problems ("pairs").  Datum layout:
@@ -548,7 +558,8 @@ enum {
  *   absolute pose: FeatureCorrespondence2D3D = [u v X Y Z]
  *     (sfm/feature_correspondence_2d_3d.h:42-49)
  *   dominant plane: Eigen::Vector3d = [X Y Z]
- *   triangulation: one observation with its camera, 33 doubles (THEIA_EST_TRIANGULATION) */
+ *   triangulation: one observation with its camera, 33 doubles (THEIA_EST_TRIANGULATION)
+ *   radial-distortion homography: RadialDistortionFeatureCorrespondence, 12 doubles (THEIA_EST_RADIAL_HOMOGRAPHY) */
 typedef struct theia_ransac_batch {
   int32_t estimator;           /* THEIA_EST_*                              */
   int32_t num_problems;

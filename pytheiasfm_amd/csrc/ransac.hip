@@ -45,6 +45,7 @@ namespace {
 constexpr int kMaxCap = 18;   // largest EstimateModel output of the thread-per-hypothesis solvers (SQPnP: 18 solutions)
 // models per sample an estimator can return = slot stride of the per-hypothesis arrays
 __host__ __device__ inline int max_models(int est) {
+  if (est == THEIA_EST_RADIAL_HOMOGRAPHY) return 2;
   if (est >= THEIA_EST_FUNDAMENTAL_MATRIX) return 1;
   if (est == THEIA_EST_ABSOLUTE_POSE_DLS) return dlsdev::kMaxSolutions;
   return est == THEIA_EST_ABSOLUTE_POSE_SQPNP ? 18 : (est == THEIA_EST_ABSOLUTE_POSE_KNEIP ? 4 : 10);
@@ -56,6 +57,7 @@ __host__ __device__ inline int sample_size(int est) {
     case THEIA_EST_RELATIVE_POSE: case THEIA_EST_ESSENTIAL_MATRIX: return 5;
     case THEIA_EST_FUNDAMENTAL_MATRIX: case THEIA_EST_UNCALIBRATED_RELATIVE_POSE: return 8;
     case THEIA_EST_HOMOGRAPHY: return 4;
+    case THEIA_EST_RADIAL_HOMOGRAPHY: return 6;
     case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION:
     case THEIA_EST_TRIANGULATION: return 2;
     default: return 3;
@@ -70,6 +72,7 @@ inline int model_doubles(int est) {
     case THEIA_EST_DOMINANT_PLANE: return 6;
     case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: return 3;
     case THEIA_EST_TRIANGULATION: return 4;
+    case THEIA_EST_RADIAL_HOMOGRAPHY: return 20;   // H | l1 | l2 | H^-1
     default: return 9;   // essential / fundamental matrix, homography
   }
 }
@@ -80,13 +83,15 @@ __host__ __device__ inline int datum_size(int est) {
     case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: return 5;
     case THEIA_EST_DOMINANT_PLANE: return 3;
     case THEIA_EST_TRIANGULATION: return kTriDatum;
+    case THEIA_EST_RADIAL_HOMOGRAPHY: return rsc::kRadHomDatum;
     default: return 4;
   }
 }
 constexpr int kMaxSample = 8;            // largest minimal sample (8-point fundamental matrix)
-constexpr int kMaxSampleDoubles = 2 * kTriDatum;   // 8 correspondences x 4, or two observations with their cameras
+constexpr int kMaxSampleDoubles = 6 * rsc::kRadHomDatum;   // 8 correspondences x 4, two observations with their cameras (66), six radial-distortion correspondences (72)
+static_assert(kMaxSampleDoubles >= 2 * kTriDatum, "sample buffer");
 // the sample buffer of a k_fit instance: 32 doubles for the correspondence estimators (their kernels keep the frame they had)
-template <int EST> constexpr int sample_doubles() { return (EST == THEIA_EST_TRIANGULATION || EST < 0) ? kMaxSampleDoubles : 32; }
+template <int EST> constexpr int sample_doubles() { return (EST == THEIA_EST_TRIANGULATION || EST == THEIA_EST_RADIAL_HOMOGRAPHY || EST < 0) ? kMaxSampleDoubles : 32; }
 
 // EstimateModel of the three estimators (estimate_relative_pose.cc:75-109,
 // estimate_essential_matrix.cc:62-73, estimate_calibrated_absolute_pose.cc:76-118).
@@ -147,6 +152,8 @@ __device__ int estimate_models(int est, const double* subset, double* models, Es
     }
     return n;
   }
+  if ((any || EST == THEIA_EST_RADIAL_HOMOGRAPHY) && est == THEIA_EST_RADIAL_HOMOGRAPHY)   // estimate_radial_distortion_homography.cc:62-77
+    return rsc::radial_homography_six_point(subset, models, kStride);
   // single-model estimators (estimate_fundamental_matrix.cc:64-78, estimate_homography.cc:72-88,
   // estimate_dominant_plane_from_points.cc:62-81, estimate_relative_pose_with_known_orientation.cc:31-45)
   if ((any || EST >= THEIA_EST_FUNDAMENTAL_MATRIX) && est >= THEIA_EST_FUNDAMENTAL_MATRIX) {
@@ -189,6 +196,7 @@ __device__ inline double triangulation_error(const double* X, const double* d) {
 // estimate_calibrated_absolute_pose.cc:158-167)
 __device__ inline double model_error(int est, const double* m, const double* d) {
   if (est == THEIA_EST_TRIANGULATION) return triangulation_error(m, d);
+  if (est == THEIA_EST_RADIAL_HOMOGRAPHY) return rsc::radial_homography_error(m, d);
   if (est == THEIA_EST_RELATIVE_POSE) {
     if (rsc::in_front(d, m + 9, m + 18)) return rsc::sampson(m, d);
     return DBL_MAX;
@@ -1138,12 +1146,12 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     ep.max_focal = batch->estimator_params[1];
   }
   const bool dls_est = est == THEIA_EST_ABSOLUTE_POSE_DLS;
-  if (est < 0 || est > THEIA_EST_TRIANGULATION) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
+  if (est < 0 || est > THEIA_EST_RADIAL_HOMOGRAPHY) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
   const bool abs_pose = est == THEIA_EST_ABSOLUTE_POSE_KNEIP || est == THEIA_EST_ABSOLUTE_POSE_SQPNP || dls_est;
   // estimators that keep Estimator::RefineModel's default "return true" (solvers/estimator.h:86-88): LO only counts
   const bool trivial_refine = est == THEIA_EST_ESSENTIAL_MATRIX || est == THEIA_EST_DOMINANT_PLANE ||
                               est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION || est == THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION ||
-                              est == THEIA_EST_TRIANGULATION;
+                              est == THEIA_EST_TRIANGULATION || est == THEIA_EST_RADIAL_HOMOGRAPHY;
   const bool rel_pose = est == THEIA_EST_RELATIVE_POSE, uncal_pose = est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE;
   const bool homog = est == THEIA_EST_HOMOGRAPHY, fund = est == THEIA_EST_FUNDAMENTAL_MATRIX;
   // every estimator's RefineModel is built: BundleAdjustView (absolute pose), BundleAdjustTwoViewsAngular ((un)calibrated
@@ -1430,6 +1438,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
           case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: THIP_FIT(THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION); break;
           case THEIA_EST_UNCALIBRATED_RELATIVE_POSE: THIP_FIT(THEIA_EST_UNCALIBRATED_RELATIVE_POSE); break;
           case THEIA_EST_TRIANGULATION: THIP_FIT(THEIA_EST_TRIANGULATION); break;
+          case THEIA_EST_RADIAL_HOMOGRAPHY: THIP_FIT(THEIA_EST_RADIAL_HOMOGRAPHY); break;
           default: THIP_FIT(THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION); break;
         }
 #undef THIP_FIT

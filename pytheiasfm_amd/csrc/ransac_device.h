@@ -1863,5 +1863,159 @@ RDEV int p3p(const double* corr, double* Rs, double* ts) {
 }
 
 
+
+// ------------------------------------------------------------ radial-distortion homography
+// sfm/pose/six_point_radial_distortion_homography.cc:62-241, estimators/estimate_radial_distortion_homography.cc:52-111.
+//
+// Right singular vectors by one-sided Jacobi (Hestenes) on the columns of an M x N row-major matrix: V (N x N, row-major),
+// columns ordered by decreasing singular value S.  The reference asks Eigen's JacobiSVD for ComputeFullV of a 6 x 8 and a
+// 6 x 5 matrix and reads the columns of the smallest singular values; the null space / least-squares direction they span is
+// what enters the solver (any basis of the 6 x 8 matrix' null space gives the same homography up to scale).
+template <int M, int N>
+RDEV void right_singular_vectors(const double* Ain, double* V, double* S) {
+  double W[M * N];
+  double fro = 0.0;
+  for (int i = 0; i < M * N; ++i) { W[i] = Ain[i]; fro += Ain[i] * Ain[i]; }
+  for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) V[i * N + j] = (i == j) ? 1.0 : 0.0;
+  const double tiny2 = (1e-28 * fro > DBL_MIN) ? 1e-28 * fro : DBL_MIN;   // columns below 1e-14 of the matrix norm are null columns
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    bool rotated = false;
+    for (int p = 0; p < N - 1; ++p)
+      for (int q = p + 1; q < N; ++q) {
+        double alpha = 0.0, beta = 0.0, gamma = 0.0;
+        for (int i = 0; i < M; ++i) { const double a = W[i * N + p], b = W[i * N + q]; alpha += a * a; beta += b * b; gamma += a * b; }
+        if (alpha < tiny2 || beta < tiny2) continue;
+        if (!(fabs(gamma) > 2.0 * DBL_EPSILON * sqrt(alpha * beta))) continue;
+        rotated = true;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int i = 0; i < M; ++i) {
+          const double a = W[i * N + p], b = W[i * N + q];
+          W[i * N + p] = c * a - s * b; W[i * N + q] = s * a + c * b;
+        }
+        for (int i = 0; i < N; ++i) {
+          const double a = V[i * N + p], b = V[i * N + q];
+          V[i * N + p] = c * a - s * b; V[i * N + q] = s * a + c * b;
+        }
+      }
+    if (!rotated) break;
+  }
+  for (int j = 0; j < N; ++j) { double s2 = 0.0; for (int i = 0; i < M; ++i) s2 += W[i * N + j] * W[i * N + j]; S[j] = sqrt(s2); }
+  for (int i = 0; i < N; ++i) {  // selection sort, descending
+    int best = i;
+    for (int j = i + 1; j < N; ++j) if (S[j] > S[best]) best = j;
+    if (best != i) {
+      dswap(S[i], S[best]);
+      for (int k = 0; k < N; ++k) dswap(V[k * N + i], V[k * N + best]);
+    }
+  }
+}
+
+// Eigen's 3 x 3 inverse (Inverse_impl.h compute_inverse_size3_helper): cofactors over the determinant.  Row-major.
+RDEV void inverse3_cofactor(const double* m, double* r) {
+#define COF(i, j) (m[3 * (((i) + 1) % 3) + (((j) + 1) % 3)] * m[3 * (((i) + 2) % 3) + (((j) + 2) % 3)] - \
+                   m[3 * (((i) + 1) % 3) + (((j) + 2) % 3)] * m[3 * (((i) + 2) % 3) + (((j) + 1) % 3)])
+  const double c00 = COF(0, 0), c10 = COF(1, 0), c20 = COF(2, 0);
+  const double det = (c00 * m[0] + c10 * m[3]) + c20 * m[6];
+  const double invdet = 1.0 / det;
+  r[0] = c00 * invdet; r[1] = c10 * invdet; r[2] = c20 * invdet;
+  r[3] = COF(0, 1) * invdet; r[4] = COF(1, 1) * invdet; r[5] = COF(2, 1) * invdet;
+  r[6] = COF(0, 2) * invdet; r[7] = COF(1, 2) * invdet; r[8] = COF(2, 2) * invdet;
+#undef COF
+}
+
+constexpr int kRadHomDatum = 12;   // [feature_left (2) | feature_right (2) | normalized left (2) | normalized right (2) | f_left f_right | lmin lmax]
+// SixPointRadialDistortionHomography on six data rows; models: up to two rows of `stride` doubles
+// {H (9, row-major) | l1 | l2 | H^-1 (9)}.  Returns the number of results (the reference's bool is "the quadratic had a real
+// root"; solutions outside [lmin, lmax] are dropped, so zero results with a true return is possible there as well).
+RDEV int radial_homography_six_point(const double* d, double* models, int stride) {
+  double Mx[48], u2[6], x2[6];
+  const double lmin = d[10], lmax = d[11];
+  for (int i = 0; i < 6; ++i) {
+    const double* r = d + kRadHomDatum * i;
+    const double x0 = r[4], x1 = r[5], u0 = r[6], u1 = r[7];
+    u2[i] = u0 * u0 + u1 * u1;
+    x2[i] = x0 * x0 + x1 * x1;
+    double* m = Mx + 8 * i;
+    m[0] = -x1 * u0; m[1] = -x1 * u1; m[2] = -x1; m[3] = x0 * u0; m[4] = x0 * u1; m[5] = x0; m[6] = -x1 * u2[i]; m[7] = x0 * u2[i];
+  }
+  double V1[64], S1[8];
+  right_singular_vectors<6, 8>(Mx, V1, S1);
+#define V1E(r, c) V1[(r) * 8 + (c)]
+  const double a = -V1E(2, 6) * V1E(7, 6) + V1E(5, 6) * V1E(6, 6);
+  const double b = ((-V1E(2, 6) * V1E(7, 7) - V1E(2, 7) * V1E(7, 6)) + V1E(5, 6) * V1E(6, 7)) + V1E(5, 7) * V1E(6, 6);
+  const double c = -V1E(2, 7) * V1E(7, 7) + V1E(5, 7) * V1E(6, 7);
+  const double dd = b * b - 4.0 * a * c;
+  int nsols = 0;
+  double rs[2] = {0.0, 0.0};
+  if ((dd < 100.0 * DBL_EPSILON) && (-dd < 100.0 * DBL_EPSILON)) { nsols = 1; rs[0] = (-b) / (2.0 * a); }
+  else if (dd > 0.0) { nsols = 2; const double d2 = sqrt(dd); rs[0] = (-b + d2) / (2.0 * a); rs[1] = (-b - d2) / (2.0 * a); }
+  else return 0;
+  int nres = 0;
+  for (int s = 0; s < nsols; ++s) {
+    double n[8];
+    for (int k = 0; k < 8; ++k) n[k] = rs[s] * V1E(k, 6) + V1E(k, 7);
+    const double l2 = n[6] / n[2];
+    if (l2 < lmin || l2 > lmax || !(l2 == l2)) continue;
+    double T[30];
+    for (int i = 0; i < 6; ++i) {
+      const double* r = d + kRadHomDatum * i;
+      const double x0 = r[4], u0 = r[6], u1 = r[7];
+      const double u3 = 1.0 + l2 * u2[i];
+      const double rr = (n[0] * u0 + n[1] * u1) + n[2] * u3;
+      T[5 * i + 0] = -Mx[8 * i + 3]; T[5 * i + 1] = -Mx[8 * i + 4]; T[5 * i + 2] = -x0 * u3; T[5 * i + 3] = x2[i] * rr; T[5 * i + 4] = rr;
+    }
+    double V2[25], S2[5];
+    right_singular_vectors<6, 5>(T, V2, S2);
+    const double v4 = V2[4 * 5 + 4];
+    const double v[4] = {V2[0 * 5 + 4] / v4, V2[1 * 5 + 4] / v4, V2[2 * 5 + 4] / v4, V2[3 * 5 + 4] / v4};
+    const double l1 = v[3];
+    if (l1 < lmin || l1 > lmax || !(l1 == l1)) continue;
+    double* m = models + (size_t)stride * nres;
+    for (int k = 0; k < stride; ++k) m[k] = 0.0;
+    for (int k = 0; k < 6; ++k) m[k] = n[k];
+    m[6] = v[0]; m[7] = v[1]; m[8] = v[2];
+    m[9] = l1; m[10] = l2;
+    inverse3_cofactor(m, m + 11);
+    nres++;
+  }
+#undef V1E
+  return nres;
+}
+
+// division-model helpers of six_point_radial_distortion_homography.cc:151-193
+RDEV void radhom_distort(const double* p3, double f, double l, double* out) {
+  const double px = f * p3[0] / p3[2], py = f * p3[1] / p3[2];
+  const double r_u_sq = px * px + py * py;
+  const double denom = 2.0 * l * r_u_sq;
+  const double inner = 1.0 - 4.0 * l * r_u_sq;
+  if (fabs(denom) < DBL_EPSILON || inner < 0.0) { out[0] = px; out[1] = py; }
+  else { const double scale = (1.0 - sqrt(inner)) / denom; out[0] = px * scale; out[1] = py * scale; }
+}
+RDEV void radhom_undistort(const double* p2, double f, double l, double* out3) {
+  const double r_d_sq = p2[0] * p2[0] + p2[1] * p2[1];
+  const double und = 1.0 / (1.0 + l * r_d_sq);
+  out3[0] = p2[0] * und / f; out3[1] = p2[1] * und / f; out3[2] = 1.0;
+}
+// CheckRadialSymmetricError (:201-239) with the model row {H | l1 | l2 | H^-1}
+RDEV double radial_homography_error(const double* m, const double* d) {
+  const double f1 = d[8], f2 = d[9];
+  const double l1s = m[9] / (f1 * f1), l2s = m[10] / (f2 * f2);
+  double bl[3], br[3], y[3], z[3], pl[2], pr[2];
+  radhom_undistort(d, f1, l1s, bl);
+  radhom_undistort(d + 2, f2, l2s, br);
+  for (int i = 0; i < 3; ++i) {
+    y[i] = (m[3 * i] * br[0] + m[3 * i + 1] * br[1]) + m[3 * i + 2] * br[2];                   // ray 2 in camera 1
+    z[i] = (m[11 + 3 * i] * bl[0] + m[11 + 3 * i + 1] * bl[1]) + m[11 + 3 * i + 2] * bl[2];    // ray 1 in camera 2
+  }
+  const double yz = y[2], zz = z[2];
+  for (int i = 0; i < 3; ++i) { y[i] /= yz; z[i] /= zz; }
+  radhom_distort(y, f1, l1s, pl);
+  radhom_distort(z, f2, l2s, pr);
+  const double dlx = d[0] - pl[0], dly = d[1] - pl[1], drx = d[2] - pr[0], dry = d[3] - pr[1];
+  return 0.5 * ((dlx * dlx + dly * dly) + (drx * drx + dry * dry));
+}
+
 }  // namespace rsc
 }  // namespace thip

@@ -34,6 +34,7 @@ EST_FUNDAMENTAL_MATRIX, EST_HOMOGRAPHY, EST_DOMINANT_PLANE, EST_RELATIVE_POSE_KN
 EST_UNCALIBRATED_RELATIVE_POSE = 9
 EST_ABSOLUTE_POSE_KNOWN_ORIENTATION = 10
 EST_TRIANGULATION = 11
+EST_RADIAL_HOMOGRAPHY = 12
 
 
 class RansacParameters:
@@ -146,7 +147,7 @@ def estimate_batch(estimator, data, offsets, params, estimator_params=None, seed
             "time_fit_seconds": r.time_fit_seconds, "time_score_seconds": r.time_score_seconds}
 
 
-_SAMPLE_SIZE = {0: 5, 1: 5, 2: 3, 3: 3, 4: 3, 5: 8, 6: 4, 7: 3, 8: 2, 9: 8, 10: 2, 11: 2}   # Estimator::SampleSize() by THEIA_EST_*
+_SAMPLE_SIZE = {0: 5, 1: 5, 2: 3, 3: 3, 4: 3, 5: 8, 6: 4, 7: 3, 8: 2, 9: 8, 10: 2, 11: 2, 12: 6}   # Estimator::SampleSize() by THEIA_EST_*
 
 
 def _single(estimator, ransac_params, ransac_type, data, estimator_params=None):
@@ -356,6 +357,45 @@ def EstimateTriangulationBatch(ransac_params, tracks):
             success[i] = bool(res["success"][k]); points[i] = res["models"][k][:4]
             inliers[i] = np.nonzero(res["inlier_mask"][offsets[k]:offsets[k + 1]])[0].tolist()
     return success, points, inliers
+
+
+class RadialDistortionFeatureCorrespondence:  # estimate_radial_distortion_homography.h:56-70, same fields and defaults
+    def __init__(self, feature_left=(0.0, 0.0), feature_right=(0.0, 0.0), normalized_feature_left=(0.0, 0.0),
+                 normalized_feature_right=(0.0, 0.0)):
+        self.feature_left = np.asarray(feature_left, dtype=np.float64)
+        self.feature_right = np.asarray(feature_right, dtype=np.float64)
+        self.normalized_feature_left = np.asarray(normalized_feature_left, dtype=np.float64)
+        self.normalized_feature_right = np.asarray(normalized_feature_right, dtype=np.float64)
+        self.focal_length_estimate_left = 1000.0
+        self.focal_length_estimate_right = 1000.0
+        self.min_radial_distortion = -5.0
+        self.max_radial_distortion = 0.0
+
+    def row(self):
+        return np.concatenate([self.feature_left, self.feature_right, self.normalized_feature_left, self.normalized_feature_right,
+                               [self.focal_length_estimate_left, self.focal_length_estimate_right,
+                                self.min_radial_distortion, self.max_radial_distortion]])
+
+
+class RadialHomographyResult:  # six_point_radial_distortion_homography.h: H, l1, l2
+    def __init__(self, m):
+        self.H = np.array(m[0:9]).reshape(3, 3)
+        self.l1 = float(m[9])
+        self.l2 = float(m[10])
+
+
+def radial_correspondence_rows(correspondences):
+    """(N, 12) rows of THEIA_EST_RADIAL_HOMOGRAPHY from a list of RadialDistortionFeatureCorrespondence (or an array
+    already in that layout)."""
+    if isinstance(correspondences, np.ndarray):
+        return np.ascontiguousarray(correspondences, dtype=np.float64).reshape(-1, 12)
+    return np.array([c.row() for c in correspondences], dtype=np.float64).reshape(-1, 12)
+
+
+def EstimateRadialHomographyMatrix(ransac_params, ransac_type, normalized_correspondences):
+    """estimate_radial_distortion_homography.cc:90-111 -> (success, RadialHomographyResult, summary)."""
+    ok, m, s = _single(EST_RADIAL_HOMOGRAPHY, ransac_params, ransac_type, radial_correspondence_rows(normalized_correspondences))
+    return ok, RadialHomographyResult(m), s
 
 
 def FivePointRelativePose(image1_points, image2_points):

@@ -276,6 +276,12 @@ def rot_quat_roundtrip(R):
     return q, R2
 
 
+def model_error(est, model, datum):
+    """Estimator::Error of one datum under one model row (oracle_model_error)."""
+    model = np.ascontiguousarray(model, dtype=np.float64); datum = np.ascontiguousarray(datum, dtype=np.float64)
+    return float(rlib().oracle_model_error(int(est), capi.ptr(model, C.c_double), capi.ptr(datum, C.c_double)))
+
+
 def estimate_models(est, subset):
     subset = np.ascontiguousarray(subset, dtype=np.float64)
     m = np.zeros((27, capi.THEIA_RANSAC_MODEL_STRIDE))

@@ -870,3 +870,47 @@ def test_estimate_triangulation_follows_oracle_and_numpy():
         sure = np.abs(e - 4.0) > 1e-6
         assert np.array_equal(((e < 4.0) & (depth > 0))[sure], np.isin(np.arange(n), inliers[t])[sure])
     assert nbig >= 20 and success.sum() >= 55
+
+
+@pytest.mark.parametrize("rtype", [0, 1, 2])
+def test_radial_distortion_homography_follows_oracle_and_numpy(rtype):
+    """EstimateRadialHomographyMatrix (estimate_radial_distortion_homography.cc:52-111): 6 pairs of planar scenes with
+    division-model distortion, gross outliers and pixel noise, RANSAC / PROSAC / LMED; inlier sets and iteration counts
+    equal to the CPU oracle's under the same per-pair seeds, models to 1e-12, and the inlier set re-derived in numpy
+    (numpy's own 3 x 3 inverse) from the returned H, l1, l2."""
+    from tests import radhom_scenes as rh
+    rng = np.random.default_rng(17)
+    f1, f2 = 1200.0, 1300.0
+    data, offsets, truth = [], [0], []
+    for pair in range(6):
+        n = 150 + 30 * pair
+        k1, k2 = -rng.uniform(0.5, 3.0) * 1e-7, -rng.uniform(0.5, 3.0) * 1e-7
+        pts = np.column_stack([rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), np.full(n, 4.0 + 0.2 * pair)])
+        R = synth.angle_axis_to_matrix(rng.uniform(-0.15, 0.15, (1, 3)))[0]
+        rows = rh.rows(pts, R, rng.uniform(-0.5, 0.5, 3), f1, f2, k1, k2, 0.3, rng)
+        out = rng.uniform(size=n) < 0.25
+        rows[out, 2:4] = rng.uniform(-600, 600, (int(out.sum()), 2)); rows[out, 6:8] = rows[out, 2:4] / f2
+        data.append(rows); offsets.append(offsets[-1] + n); truth.append((k1 * f1 * f1, k2 * f2 * f2, out))
+    data = np.concatenate(data); offsets = np.array(offsets, dtype=np.int64)
+    p = ransac.RansacParameters(); p.error_thresh = 2.0 ** 2; p.min_iterations = 150; p.failure_probability = 1e-3; p.seed = 41
+    pc0 = p.to_c(); pc0.ransac_type = rtype
+    res = ransac.estimate_batch(ransac.EST_RADIAL_HOMOGRAPHY, data, offsets, pc0)
+    for i in range(6):
+        sl = slice(offsets[i], offsets[i + 1])
+        pc = p.to_c(); pc.seed = 41 + i; pc.ransac_type = rtype
+        o = ol.ransac_estimate(12, data[sl], pc)
+        assert bool(o["success"]) == bool(res["success"][i]) and o["success"]
+        assert np.array_equal(o["inlier_mask"], res["inlier_mask"][sl])
+        assert o["num_iterations"] == res["num_iterations"][i]
+        m = res["models"][i]
+        assert np.allclose(o["model"][:20], m[:20], rtol=1e-12, atol=1e-14)
+        H = m[:9].reshape(3, 3)
+        e = np.array([rh.symmetric_error(H, m[9], m[10], r[0:2], r[2:4], f1, f2) for r in data[sl]])
+        if rtype != 2:      # (LMED picks its own inlier threshold)
+            sure = np.abs(e - 4.0) > 1e-6
+            assert np.array_equal((e < 4.0)[sure], res["inlier_mask"][sl].astype(bool)[sure])
+        l1, l2, out = truth[i]
+        assert abs(m[9] - l1) < 0.1 and abs(m[10] - l2) < 0.1
+        assert res["inlier_mask"][sl][~out].mean() > 0.85
+    ok, rhr, s = ransac.EstimateRadialHomographyMatrix(p, ransac.RansacType.RANSAC, data[offsets[0]:offsets[1]])
+    assert ok and abs(rhr.l1 - truth[0][0]) < 0.1 and rhr.H.shape == (3, 3) and len(s.inliers) > 100
