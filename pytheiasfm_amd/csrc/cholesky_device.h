@@ -258,11 +258,12 @@ __device__ __forceinline__ void potrf64_wave(double* __restrict__ A, int lda, in
 // round), the two 32-level inverse products (one per wave) and the four 16 x 16 tiles of each 64-level
 // product.  Same arithmetic per entry as potrf64_wave (the MFMA tiles are the same tiles), so the two
 // functions return identical bits.
-__device__ __forceinline__ void potrf64_wg(double* __restrict__ A, int lda, int k0, int nb,
-                                           double* __restrict__ Linv, double* __restrict__ fail_flag) {
-  __shared__ double Ls[NB][LDP];
-  __shared__ double Zs[NB][LDP];
-  __shared__ double rdiag[NB];
+// potrf64_wg_core: the work arrays are the caller's (Ls ends as scratch, Zs holds the inverse factor when it returns,
+// after a workgroup barrier).  STORE_L = false leaves A untouched (k_sp_potrf_trsm: other workgroups factor the same tile at
+// the same time); Linv / fail_flag may be null.
+template <bool STORE_L>
+__device__ __forceinline__ void potrf64_wg_core(double* __restrict__ A, int lda, int k0, int nb, double (*Ls)[LDP], double (*Zs)[LDP],
+                                                double* rdiag, double* __restrict__ Linv, double* __restrict__ fail_flag) {
   const int tid = threadIdx.x, wv = tid >> 6, i = tid & 63;
   const int li = i & 15, lk = i >> 4;
   {
@@ -337,7 +338,7 @@ __device__ __forceinline__ void potrf64_wg(double* __restrict__ A, int lda, int 
     __syncthreads();
   }
   // L back to global: wave w stores rows 16w .. 16w+15 (whole rows, see potrf64_wave)
-  if (i < nb) {
+  if (STORE_L && i < nb) {
     double v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = Ls[16 * wv + q][i];
@@ -345,7 +346,7 @@ __device__ __forceinline__ void potrf64_wg(double* __restrict__ A, int lda, int 
     for (int q = 0; q < 16; ++q)
       if (16 * wv + q < nb) A[(size_t)(k0 + 16 * wv + q) * lda + k0 + i] = v[q];
   }
-  if (bad && tid == 0) unsafeAtomicAdd(fail_flag, 1.0);
+  if (bad && tid == 0 && fail_flag) unsafeAtomicAdd(fail_flag, 1.0);
   // ---- inverse: the four 16 x 16 triangular inverses (wave 0, lane (q, c) owns column c of block q)
   if (wv == 0) {
     const int q = i >> 4, c = i & 15;
@@ -402,8 +403,18 @@ __device__ __forceinline__ void potrf64_wg(double* __restrict__ A, int lda, int 
     for (int reg = 0; reg < 4; ++reg) Zs[32 + 16 * ti + lk + 4 * reg][16 * tj + li] = -acc[reg];
   }
   __syncthreads();
+  if (Linv) {
 #pragma unroll
-  for (int q = 0; q < 16; ++q) Linv[(16 * wv + q) * NB + i] = Zs[16 * wv + q][i];
+    for (int q = 0; q < 16; ++q) Linv[(16 * wv + q) * NB + i] = Zs[16 * wv + q][i];
+  }
+}
+
+__device__ __forceinline__ void potrf64_wg(double* __restrict__ A, int lda, int k0, int nb,
+                                           double* __restrict__ Linv, double* __restrict__ fail_flag) {
+  __shared__ double Ls[NB][LDP];
+  __shared__ double Zs[NB][LDP];
+  __shared__ double rdiag[NB];
+  potrf64_wg_core<true>(A, lda, k0, nb, Ls, Zs, rdiag, Linv, fail_flag);
 }
 
 }  // namespace chol

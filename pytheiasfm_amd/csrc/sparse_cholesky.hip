@@ -90,6 +90,50 @@ __global__ __launch_bounds__(256) void k_sp_trsm(double* __restrict__ A, int lda
     }
 }
 
+// k_sp_potrf and k_sp_trsm of a level in ONE launch: the workgroup of an off-diagonal tile (I, K) factors the diagonal tile
+// K itself -- in LDS, the same arithmetic as its owner, so the same bits -- and goes straight on to X = P Linv^T with the
+// inverse factor still on chip.  Redundant arithmetic on otherwise idle CUs for one dependent launch less per level
+// (a level has <= ~130 such tiles on 256 CUs).  Nobody stores L(K, K): the diagonal tile is read by every workgroup of its
+// column while it is being factored, and neither the updates nor the back-substitution read it (they use Linv).
+//   blocks [0, npotrf): owners {k0, nb, slot} -> Linv, fail flag;  blocks npotrf ..: {row0, h, k0, nb, slot}
+__global__ __launch_bounds__(256) void k_sp_potrf_trsm(double* __restrict__ A, int lda, const int* __restrict__ potrf_items, int npotrf,
+                                                       const int* __restrict__ trsm_items, double* __restrict__ Linv,
+                                                       double* __restrict__ fail_flag) {
+  __shared__ double Ls[NB][LDP];
+  __shared__ double Zs[NB][LDP];
+  __shared__ double rdiag[NB];
+  if ((int)blockIdx.x < npotrf) {
+    const int* it = potrf_items + 3 * blockIdx.x;
+    potrf64_wg_core<false>(A, lda, it[0], it[1], Ls, Zs, rdiag, Linv + (size_t)it[2] * NB * NB, fail_flag);
+    return;
+  }
+  const int* it = trsm_items + 5 * (blockIdx.x - npotrf);
+  const int row0 = it[0], h = it[1], k0 = it[2], nb = it[3];
+  const int tid = threadIdx.x;
+  potrf64_wg_core<false>(A, lda, k0, nb, Ls, Zs, rdiag, nullptr, nullptr);
+  __syncthreads();
+  load_tile(Ls, A, lda, row0, h, k0, nb, tid);   // P
+  __syncthreads();
+  const int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  if (16 * wv >= h) return;
+  double4_t acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < NB; kk += 4) {
+    const double a = Ls[16 * wv + li][kk + lk];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Zs[16 * q + li][kk + lk], acc[q], 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int r = 16 * wv + lk + 4 * reg, c = 16 * q + li;
+      if (r < h && c < nb) A[(size_t)(row0 + r) * lda + k0 + c] = acc[q][reg];
+    }
+}
+
 // C(I,J) -= sum over the level's sources K of L(I,K) L(J,K)^T, fixed order
 __global__ __launch_bounds__(256) void k_sp_update(double* __restrict__ A, int lda, const int* __restrict__ items,
                                                    const int* __restrict__ srcs) {
@@ -554,8 +598,13 @@ void chol_plan_solve(const CholPlan* pl, double* A, int lda, double* b, double* 
       k_sp_update_partial<<<pl->n_def_part, 256, 0, st>>>(A, lda, pg + pl->def_part_off, pg + pl->def_src_off, pl->scratch);
       k_sp_update_reduce<<<pl->n_def_red * 16, 256, 0, st>>>(A, lda, pg + pl->def_red_off, pl->scratch);
     }
-    k_sp_potrf<<<lv.npotrf, 256, 0, st>>>(A, lda, pg + lv.potrf_off, Linv, fail_flag);
-    if (lv.ntrsm) k_sp_trsm<<<lv.ntrsm, 256, 0, st>>>(A, lda, pg + lv.trsm_off, Linv);
+    static const bool split = getenv("THEIA_HIP_K3_SPLIT_TRSM") != nullptr;   // development: the two launches
+    if (split) {
+      k_sp_potrf<<<lv.npotrf, 256, 0, st>>>(A, lda, pg + lv.potrf_off, Linv, fail_flag);
+      if (lv.ntrsm) k_sp_trsm<<<lv.ntrsm, 256, 0, st>>>(A, lda, pg + lv.trsm_off, Linv);
+    } else {
+      k_sp_potrf_trsm<<<lv.npotrf + lv.ntrsm, 256, 0, st>>>(A, lda, pg + lv.potrf_off, lv.npotrf, pg + lv.trsm_off, Linv, fail_flag);
+    }
     if (lv.nupd) k_sp_update<<<lv.nupd, 256, 0, st>>>(A, lda, pg + lv.upd_off, pg + lv.upd_src_off);
   }
   const double* y = A + (size_t)n * lda;
