@@ -409,7 +409,9 @@ int theia_hip_ba_plan_info(theia_ba_handle h, int32_t* n, int32_t* k3_levels, do
  * *WithCov entry points (bundle_adjustment.cc:288-386,420-499; GetCovarianceFor{Track,Tracks,View,Views},
  * bundle_adjuster.cc:660-773 = ceres::Covariance (J'J)^-1 in tangent space, loss applied):
  *   point_cov[num_points][d][d], d = 3 (homogeneous manifold) or 4: needs every camera constant;
- *   cam_cov[num_cameras][6][6]: needs every point constant and no partially constant camera.
+ *   cam_cov[num_cameras][6][6]: needs every point constant and no partially constant camera.  With optimised intrinsics
+ *   the cameras of a group are coupled through the group's columns: the extrinsics blocks of the dense inverse of J'J are
+ *   returned (reduced systems up to 2048 columns: a *WithCov call covers a handful of views).
  * Either pointer may be NULL.  Entries of constant / unobserved blocks are zero.  NOT yet multiplied
  * by the empirical variance factor 2 * final_cost / redundancy (the caller's bookkeeping). */
 int theia_hip_ba_covariance(theia_ba_handle h, double* point_cov, double* cam_cov);

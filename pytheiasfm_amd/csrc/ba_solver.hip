@@ -2391,7 +2391,12 @@ int theia_hip_ba_evaluate_ex(theia_ba_handle h, double* cost, double* residuals,
 int theia_hip_ba_covariance(theia_ba_handle h, double* point_cov, double* cam_cov) {
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
   if (!point_cov && !cam_cov) return 0;
-  if (h->ni) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "covariance with optimised intrinsics is not built");
+  // Optimised intrinsics couple the cameras of a group: J'J of the views problem is an arrow, not block diagonal, and the
+  // extrinsics blocks of its inverse need the whole factor (dense, on the host: a *WithCov call covers a handful of views).
+  constexpr int kMaxCovWithIntrinsics = 2048;
+  if (h->ni && point_cov) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "point covariances with optimised intrinsics are not built");
+  if (h->ni && h->n > kMaxCovWithIntrinsics)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "camera covariances with optimised intrinsics: reduced system of %d > %d columns", h->n, kMaxCovWithIntrinsics);
   bool any_var_point = false;
   for (int q = 0; q < h->np; ++q) any_var_point |= !h->pt_const[q];
   if (point_cov && h->ncv > 0)
@@ -2429,6 +2434,44 @@ int theia_hip_ba_covariance(theia_ba_handle h, double* point_cov, double* cam_co
     if (n) HIP_TRY(hipMemcpyAsync(S.data(), h->rb.S, sizeof(double) * S.size(), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     std::fill(cam_cov, cam_cov + 36 * (size_t)h->nc, 0.0);
+    if (h->ni) {
+      // (J'J)^-1 through the dense Cholesky factor of the lower triangle: Li = L^-1, covariance(a, b) = sum_k Li(k, a) Li(k, b).
+      // Frozen intrinsics slots are empty rows with a tiny diagonal (clamp / radius): they decouple.
+      std::vector<double> Lf((size_t)n * n, 0.0), Li((size_t)n * n, 0.0);
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+          double v = S[(size_t)i * n + j];
+          const double* li = &Lf[(size_t)i * n];
+          const double* lj = &Lf[(size_t)j * n];
+          for (int k = 0; k < j; ++k) v -= li[k] * lj[k];
+          if (i == j) {
+            if (v == 0.0 && i < h->ni && S[(size_t)i * n + i] == 0.0) v = 1.0;   // slot of a parameter outside the optimised subset: no column
+            if (!(v > 0.0)) return set_error(THEIA_HIP_ERR_INTERNAL, "J'J is rank deficient at column %d (ceres::Covariance::Compute fails)", i);
+            Lf[(size_t)i * n + i] = std::sqrt(v);
+          } else Lf[(size_t)i * n + j] = v / Lf[(size_t)j * n + j];
+        }
+      for (int j = 0; j < n; ++j) {   // column j of L^-1 by forward substitution
+        Li[(size_t)j * n + j] = 1.0 / Lf[(size_t)j * n + j];
+        for (int i = j + 1; i < n; ++i) {
+          double v = 0.0;
+          const double* li = &Lf[(size_t)i * n];
+          for (int k = j; k < i; ++k) v -= li[k] * Li[(size_t)k * n + j];
+          Li[(size_t)i * n + j] = v / li[i];
+        }
+      }
+      for (int c = 0; c < h->nc; ++c) {
+        const int rc = h->cam_red[c];
+        if (rc < 0) continue;
+        const int o = h->ni + 6 * rc;
+        for (int a = 0; a < 6; ++a)
+          for (int b = 0; b < 6; ++b) {
+            double v = 0.0;
+            for (int k = o + std::max(a, b); k < n; ++k) v += Li[(size_t)k * n + o + a] * Li[(size_t)k * n + o + b];
+            cam_cov[(size_t)c * 36 + a * 6 + b] = v;
+          }
+      }
+      return 0;
+    }
     for (int c = 0; c < h->nc; ++c) {
       const int rc = h->cam_red[c];
       if (rc < 0) continue;

@@ -517,6 +517,7 @@ def _with_cov(reconstruction, options, flat, want_points):
             return summary, None
     reconstruction.cam_ext[:] = flat.cam_ext
     reconstruction.points[:] = flat.points
+    reconstruction.group_intrinsics[:] = flat.intrinsics
     return summary, (pc if want_points else cc)
 
 

@@ -1206,3 +1206,42 @@ def test_fused_intrinsics_assembly_matches_gather_kernels_and_oracle(groups, int
     assert rel(a[2].intrinsics, qo.intrinsics) <= 1e-9 and np.abs(a[2].cam_ext - qo.cam_ext).max() <= 1e-8
     assert np.abs(a[2].points - qo.points).max() <= 1e-8
     assert not np.array_equal(a[2].intrinsics[:, 0], p.intrinsics[:, 0])
+
+
+def test_view_covariances_with_optimised_intrinsics():
+    """BundleAdjustViewsWithCov with FOCAL_LENGTH | RADIAL_DISTORTION free: the views share intrinsics groups, J'J is an arrow
+    (group columns against every camera of the group) and ceres::Covariance returns the extrinsics blocks of its inverse.
+    Reference value: numpy inverse of J'J assembled from the oracle's Jets (J_ext, J_intr per observation)."""
+    p = synth.synth_ba_v1(9, 250, seed=71, pixel_noise=0.6, num_groups=2)
+    opts = sfm.BundleAdjustmentOptions(); opts.max_num_iterations = 25
+    opts.intrinsics_to_optimize = 0x01 | 0x10      # FOCAL_LENGTH | RADIAL_DISTORTION
+    rec = sfm.Reconstruction.from_flat(p)
+    views = [1, 2, 4, 6, 7]
+    sv, cv, fv = sfm.BundleAdjustViewsWithCov(rec, opts, views)
+    assert sv.success and fv > 0
+    flat = sfm._flatten(rec, views, [], options=opts)            # the solved state
+    cols, ncol = {}, 0
+    for v in views:
+        cols[("c", v)] = ncol; ncol += 6
+    free = [0, 5, 6]                                             # pinhole: focal length, two radial terms
+    for g in sorted(set(int(flat.cam_group[v]) for v in views)):
+        cols[("g", g)] = ncol; ncol += len(free)
+    rows = []
+    for i in np.flatnonzero(np.isin(flat.obs_cam, views)):
+        c = int(flat.obs_cam[i]); g = int(flat.cam_group[c])
+        ok, r, Je, Ji, Jp = ol.reprojection_error(int(flat.group_model[g]), flat.cam_ext[c], flat.intrinsics[g][:7], flat.points[flat.obs_pt[i]], flat.obs_uv[i])
+        J = np.zeros((2, ncol))
+        J[:, cols[("c", c)]:cols[("c", c)] + 6] = Je
+        J[:, cols[("g", g)]:cols[("g", g)] + len(free)] = Ji[:, free]
+        rows.append(J)
+    J = np.concatenate(rows)
+    cov = np.linalg.inv(J.T @ J) * fv
+    for v in views:
+        o = cols[("c", v)]
+        ref = cov[o:o + 6, o:o + 6]
+        assert np.abs(cv[v] - ref).max() <= 1e-6 * np.abs(ref).max()
+        assert np.all(np.linalg.eigvalsh(cv[v]) > 0)
+    # the coupling matters: the block-diagonal inverse is a different (smaller) matrix
+    o = cols[("c", views[0])]
+    Jb = J[:, o:o + 6]
+    assert np.abs(np.linalg.inv(Jb.T @ Jb) * fv - cv[views[0]]).max() > 1e-3 * np.abs(cv[views[0]]).max()
