@@ -481,10 +481,11 @@ struct Buf {
       return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", count * sizeof(T));
     return 0;
   }
-  int upload(const std::vector<T>& h) {
+  int upload(const std::vector<T>& h, hipStream_t st) {   // (the vector outlives the copy: synchronised here)
     int rc = alloc(h.size());
     if (rc) return rc;
-    if (!h.empty() && hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+    if (!h.empty() && (hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess ||
+                       hipStreamSynchronize(st) != hipSuccess))
       return set_error(THEIA_HIP_ERR_NO_DEVICE, "hipMemcpy failed");
     return 0;
   }
@@ -614,6 +615,11 @@ int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o,
   const int npri = (int)prior_cam.size();
   std::vector<double> si(2 * (size_t)nobs, 1.0);
   if (p->obs_sqrt_info) std::memcpy(si.data(), p->obs_sqrt_info, sizeof(double) * 2 * nobs);
+  // ---- a stream of this call (non-blocking: the entry points stay callable from a thread pool; the legacy stream would
+  // serialise against every other stream of the process)
+  struct StreamGuard { hipStream_t s = nullptr; ~StreamGuard() { if (s) (void)hipStreamDestroy(s); } } sg;
+  HIP_TRY(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
+  hipStream_t st = sg.s;
   // ---- device buffers
   Buf<double> d_intr[2], d_scale_i, d_colsq_i, d_pvec, d_pinfo, d_bearing, d_uv, d_si, d_cam[2], d_rho[2], d_scale_c, d_scale_r, d_scale_red, d_recs, d_red, d_vinv, d_grho, d_scal, d_radius, d_work, d_colsq_c, d_colsq_r;
   Buf<int> d_gm, d_cg, d_cred, d_pref, d_ocam, d_opt, d_pobs, d_gred, d_gk, d_pcam, d_pkind;
@@ -627,14 +633,14 @@ int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o,
   std::vector<int> hgm(p->group_model, p->group_model + ng), hcg(p->cam_group, p->cam_group + nc), hpref(p->point_ref_cam, p->point_ref_cam + np);
   std::vector<int> hoc(p->obs_cam, p->obs_cam + nobs), hop(p->obs_pt, p->obs_pt + nobs);
   const size_t red_count = (size_t)n * n + 3 * (size_t)n;   // S | rhs | colsq | gc
-  if ((rc = d_intr[0].upload(hintr)) || (rc = d_intr[1].upload(hintr)) || (rc = d_scale_i.alloc((size_t)kKW * ng)) ||
-      (rc = d_colsq_i.alloc((size_t)kKW * ng)) || (rc = d_gred.upload(grp_red)) || (rc = d_gk.upload(grp_k)) ||
-      (rc = d_gfree.upload(grp_free)) || (rc = d_pcam.upload(prior_cam)) || (rc = d_pkind.upload(prior_kind)) ||
-      (rc = d_pvec.upload(prior_vec)) || (rc = d_pinfo.upload(prior_info)) || (rc = d_bearing.upload(hb)) || (rc = d_uv.upload(huv)) || (rc = d_si.upload(si)) ||
-      (rc = d_cam[0].upload(hcam)) || (rc = d_cam[1].upload(hcam)) || (rc = d_rho[0].upload(hrho)) || (rc = d_rho[1].upload(hrho)) ||
-      (rc = d_gm.upload(hgm)) || (rc = d_cg.upload(hcg)) || (rc = d_cred.upload(cam_red)) || (rc = d_pref.upload(hpref)) ||
-      (rc = d_ocam.upload(hoc)) || (rc = d_opt.upload(hop)) || (rc = d_pobs.upload(pt_obs)) || (rc = d_cmask.upload(cam_mask)) ||
-      (rc = d_pconst.upload(pt_const)) || (rc = d_poff.upload(pt_off)) || (rc = d_scale_c.alloc(6 * (size_t)nc)) ||
+  if ((rc = d_intr[0].upload(hintr, st)) || (rc = d_intr[1].upload(hintr, st)) || (rc = d_scale_i.alloc((size_t)kKW * ng)) ||
+      (rc = d_colsq_i.alloc((size_t)kKW * ng)) || (rc = d_gred.upload(grp_red, st)) || (rc = d_gk.upload(grp_k, st)) ||
+      (rc = d_gfree.upload(grp_free, st)) || (rc = d_pcam.upload(prior_cam, st)) || (rc = d_pkind.upload(prior_kind, st)) ||
+      (rc = d_pvec.upload(prior_vec, st)) || (rc = d_pinfo.upload(prior_info, st)) || (rc = d_bearing.upload(hb, st)) || (rc = d_uv.upload(huv, st)) || (rc = d_si.upload(si, st)) ||
+      (rc = d_cam[0].upload(hcam, st)) || (rc = d_cam[1].upload(hcam, st)) || (rc = d_rho[0].upload(hrho, st)) || (rc = d_rho[1].upload(hrho, st)) ||
+      (rc = d_gm.upload(hgm, st)) || (rc = d_cg.upload(hcg, st)) || (rc = d_cred.upload(cam_red, st)) || (rc = d_pref.upload(hpref, st)) ||
+      (rc = d_ocam.upload(hoc, st)) || (rc = d_opt.upload(hop, st)) || (rc = d_pobs.upload(pt_obs, st)) || (rc = d_cmask.upload(cam_mask, st)) ||
+      (rc = d_pconst.upload(pt_const, st)) || (rc = d_poff.upload(pt_off, st)) || (rc = d_scale_c.alloc(6 * (size_t)nc)) ||
       (rc = d_scale_r.alloc(np)) || (rc = d_scale_red.alloc(std::max(1, n))) || (rc = d_recs.alloc((size_t)kRec * nobs)) ||
       (rc = d_red.alloc(std::max<size_t>(1, red_count))) || (rc = d_vinv.alloc(np)) || (rc = d_grho.alloc(np)) ||
       (rc = d_scal.alloc(ID_SCALARS)) || (rc = d_radius.alloc(1)) || (rc = d_work.alloc(dense_cholesky_workspace(std::max(1, n)))) ||
@@ -650,11 +656,14 @@ int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o,
   P.loss_type = o->loss_function_type; P.loss_width = o->robust_loss_width;
   CholPlan* plan = chol_plan_create(n, nullptr);
   struct PlanGuard { CholPlan* pl; ~PlanGuard() { chol_plan_destroy(pl); } } guard{plan};
-  hipStream_t st = nullptr;
   const int ob = (int)((nobs + 255) / 256), tb = (np + 63) / 64, cb = (std::max(nc, ng) + 63) / 64, pb = (npri + 63) / 64;
   double* dS = d_red.p; double* drhs = dS + (size_t)n * n; double* dcolsq = drhs + n; double* dgc = dcolsq + n;
   double hs[ID_SCALARS];
-  auto read_scal = [&]() -> int { HIP_TRY(hipMemcpy(hs, d_scal.p, sizeof(hs), hipMemcpyDeviceToHost)); return 0; };
+  auto read_scal = [&]() -> int {
+    HIP_TRY(hipMemcpyAsync(hs, d_scal.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+  };
   auto cost_at = [&](const double* cam, const double* rho, const double* intr, double* cost, bool* ok) -> int {
     HIP_TRY(hipMemsetAsync(d_scal.p, 0, sizeof(hs), st));
     if (nobs) k_id_obs<<<ob, 256, 0, st>>>(P, cam, rho, intr, 0, nullptr, d_scal.p, nullptr, nullptr, nullptr);
@@ -760,9 +769,10 @@ int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o,
   }
   S->num_iterations = iter; S->termination_type = term; S->success = term != THEIA_TERM_FAILURE;
   S->final_cost = minimum_cost + fixed_cost;
-  if (ngv) HIP_TRY(hipMemcpy(p->intrinsics, d_intr[cur].p, sizeof(double) * (size_t)kKW * ng, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(p->cam_ext, d_cam[cur].p, sizeof(double) * 6 * nc, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(p->point_inverse_depth, d_rho[cur].p, sizeof(double) * np, hipMemcpyDeviceToHost));
+  if (ngv) HIP_TRY(hipMemcpyAsync(p->intrinsics, d_intr[cur].p, sizeof(double) * (size_t)kKW * ng, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(p->cam_ext, d_cam[cur].p, sizeof(double) * 6 * nc, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(p->point_inverse_depth, d_rho[cur].p, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   S->solve_time_in_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   S->setup_time_in_seconds = 0.0;
   return 0;
