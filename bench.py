@@ -90,8 +90,9 @@ def pmc_traffic_bytes(world):
                     row = line.rstrip("\n").rsplit(",", 2)      # template arguments carry commas: split from the right
                     if len(row) == 3 and row[0] != "kernel":
                         kb[(tag, row[0])] = float(row[2])
-        group = [k for (t, k) in kb if t == "fetch_size" and (k.startswith("k_lin_schur") or k.startswith("k_schur_sum") or k.startswith("k_cam_prep"))]
-        if not any(k.startswith("k_lin_schur") for k in group):
+        # (the headline kernel only: "k_lin_schur<": the same trace also holds k_lin_schur_i of the with_intrinsics block)
+        group = [k for (t, k) in kb if t == "fetch_size" and (k.startswith("k_lin_schur<") or k.startswith("k_schur_sum") or k.startswith("k_cam_prep"))]
+        if not any(k.startswith("k_lin_schur<") for k in group):
             return None
         fetch = sum(2.0 * kb[("fetch_size", k)] for k in group)
         write = sum(kb.get(("write_size", k), 0.0) for k in group)
@@ -122,7 +123,7 @@ def mfma_util(levels, solve_s):
     m = mfma_busy_cycles()
     if not m or solve_s <= 0 or levels <= 0:
         return None
-    busy = levels * (m["k_sp_potrf"] + m["k_sp_trsm"]) + max(0, levels - 1) * m["k_sp_update"]
+    busy = levels * m["k_sp_potrf_trsm"] + max(0, levels - 1) * m["k_sp_update"]
     return {"busy_cycles_per_solve": busy, "frac": busy / (1024 * 2.1e9 * solve_s),
             "source": "profiles/%s_sq_counters.txt (SQ_VALU_MFMA_BUSY_CYCLES per launch) x launches per solve / (1024 SIMDs x 2.1 GHz x solve time)" % PROFILE_TAG}
 
@@ -135,12 +136,12 @@ def mfma_busy_cycles():
     try:
         with open(os.path.join(ROOT, "profiles", "%s_sq_counters.txt" % PROFILE_TAG)) as f:
             for line in f:
-                for k in ("k_sp_potrf", "k_sp_trsm", "k_sp_update"):
+                for k in ("k_sp_potrf_trsm", "k_sp_update"):
                     if line.startswith(k + " {") and "SQ_VALU_MFMA_BUSY_CYCLES" in line:
                         out[k] = float(ast.literal_eval(line[len(k) + 1:].strip())["SQ_VALU_MFMA_BUSY_CYCLES"])
     except (OSError, ValueError, SyntaxError, KeyError):
         return None
-    return out if len(out) == 3 else None
+    return out if len(out) == 2 else None
 
 
 class BaRunner:

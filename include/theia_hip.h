@@ -550,7 +550,17 @@ enum {
    * the 6 x 8 constraint, a quadratic, least-squares direction of a 6 x 5 system), up to two models per sample; Error =
    * CheckRadialSymmetricError (:201-239).  model = RadialHomographyResult: H (9, row-major), l1, l2 (then H^-1, 9 doubles,
    * kept for the scoring kernels). */
-  THEIA_EST_RADIAL_HOMOGRAPHY = 12
+  THEIA_EST_RADIAL_HOMOGRAPHY = 12,
+  /* EstimateSimilarityTransformation2D3D (estimate_similarity_transformation_2d_3d.cc:72-178): datum =
+   * CameraAndFeatureCorrespondence2D3D (sfm/similarity_transformation.h / estimators header), 26 doubles:
+   *   [0..2] camera.PixelToUnitDepthRay(observation).normalized() (world frame; precomputed per datum: it does not depend on
+   *          the model)   [3..6] point3d (homogeneous)   [7,8] observation pixel   [9..14] camera extrinsics: position,
+   *          angle-axis   [15] camera model (THEIA_CAM_*)   [16..25] intrinsics.
+   * EstimateModel = GdlsSimilarityTransform on four data (gdls_similarity_transform.cc:67-228: the DLS pipeline with the
+   * generalised cost matrix; Macaulay terms of one Estimate() counted from 0 as for DLS), up to 27 models; Error = squared
+   * pixel error of the camera moved by the transformation (TransformCamera), DBL_MAX behind it.
+   * model = SimilarityTransformation: rotation (9, row-major), translation (3), scale. */
+  THEIA_EST_SIMILARITY_2D3D = 13
 };
 
 /* A batch of independent estimation problems ("pairs").  Datum layout:
@@ -561,7 +571,8 @@ enum {
  *     (sfm/feature_correspondence_2d_3d.h:42-49)
  *   dominant plane: Eigen::Vector3d = [X Y Z]
  *   triangulation: one observation with its camera, 33 doubles (THEIA_EST_TRIANGULATION)
- *   radial-distortion homography: RadialDistortionFeatureCorrespondence, 12 doubles (THEIA_EST_RADIAL_HOMOGRAPHY) */
+ *   radial-distortion homography: RadialDistortionFeatureCorrespondence, 12 doubles (THEIA_EST_RADIAL_HOMOGRAPHY)
+ *   similarity 2D-3D: CameraAndFeatureCorrespondence2D3D, 26 doubles (THEIA_EST_SIMILARITY_2D3D) */
 typedef struct theia_ransac_batch {
   int32_t estimator;           /* THEIA_EST_*                              */
   int32_t num_problems;

@@ -254,3 +254,129 @@ inline int dls_pnp(int n, const double* feat, const double* world, const double 
   }
   return ns;
 }
+
+
+// ------------------------------------------------------------------------------------------------ gDLS
+// GdlsSimilarityTransform (sfm/transformation/gdls_similarity_transform.cc:67-228): the generalised-camera form of the same
+// problem -- rays c_i + alpha_i x_i from camera positions c_i, unknown rotation, translation AND scale with
+// s c_i + alpha_i x_i = R X_i + t.  Scale and translation are linear in vec(R) (:80-117: the 4 x 4 matrix H and the 4 x 9
+// helper), the cost matrix is sum W^T (I - x x^T) W with W = L(X) - c scale_factor + translation_factor (:119-133), and from
+// there on it is DLS: Jacobian cubics, Macaulay matrix with its own Vector4d::Random() equation, eigenvectors (:135-175).
+inline bool gdls_inverse4(const double* a, double* inv) {   // Eigen's Matrix4d::inverse(): adjugate over determinant
+  auto m3 = [&](int r0, int r1, int r2, int c0, int c1, int c2) {
+    return a[4 * r0 + c0] * (a[4 * r1 + c1] * a[4 * r2 + c2] - a[4 * r1 + c2] * a[4 * r2 + c1]) -
+           a[4 * r0 + c1] * (a[4 * r1 + c0] * a[4 * r2 + c2] - a[4 * r1 + c2] * a[4 * r2 + c0]) +
+           a[4 * r0 + c2] * (a[4 * r1 + c0] * a[4 * r2 + c1] - a[4 * r1 + c1] * a[4 * r2 + c0]);
+  };
+  double cof[16];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      int rr[3], cc[3], k = 0, l = 0;
+      for (int i = 0; i < 4; ++i) { if (i != r) rr[k++] = i; if (i != c) cc[l++] = i; }
+      const double minor = m3(rr[0], rr[1], rr[2], cc[0], cc[1], cc[2]);
+      cof[4 * r + c] = ((r + c) & 1) ? -minor : minor;
+    }
+  const double det = ((a[0] * cof[0] + a[1] * cof[1]) + a[2] * cof[2]) + a[3] * cof[3];
+  if (det == 0.0) return false;
+  for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) inv[4 * r + c] = cof[4 * c + r] / det;
+  return true;
+}
+
+// origin / dir (unit) / world: n x 3 each.  Returns the number of solutions: quats [w x y z] (soln_rotation), ts, scales.
+inline int gdls_similarity(int n, const double* origin, const double* dir, const double* world, const double u[4],
+                           double* quats, double* ts, double* scales) {
+  if (n < 4) return 0;
+  auto left_mult = [](const double* X, double* L) {
+    for (int i = 0; i < 27; ++i) L[i] = 0.0;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) L[9 * r + 3 * r + c] = X[c];
+  };
+  double Hinv[16], sv[36];
+  for (int i = 0; i < 16; ++i) Hinv[i] = 0.0;
+  for (int i = 0; i < 36; ++i) sv[i] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double* c = origin + 3 * i; const double* x = dir + 3 * i;
+    const double cd = (c[0] * x[0] + c[1] * x[1]) + c[2] * x[2];
+    Hinv[0] += ((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]) - cd * cd;
+    for (int r = 0; r < 3; ++r) {
+      const double t = -c[r] + cd * x[r];
+      Hinv[4 * (r + 1)] += t; Hinv[r + 1] += t;
+      for (int k = 0; k < 3; ++k) Hinv[4 * (r + 1) + k + 1] += (r == k ? 1.0 : 0.0) - x[r] * x[k];
+    }
+    double L[27]; left_mult(world + 3 * i, L);
+    for (int cc = 0; cc < 9; ++cc) {
+      double s0 = 0.0;
+      for (int k = 0; k < 3; ++k) s0 += (c[k] - cd * x[k]) * L[9 * k + cc];
+      sv[cc] += s0;
+      for (int r = 0; r < 3; ++r) {
+        double s1 = 0.0;
+        for (int k = 0; k < 3; ++k) s1 += (x[r] * x[k] - (r == k ? 1.0 : 0.0)) * L[9 * k + cc];
+        sv[9 * (r + 1) + cc] += s1;
+      }
+    }
+  }
+  double Hm[16];
+  if (!gdls_inverse4(Hinv, Hm)) return 0;
+  double sf[9], Tf[27];
+  for (int cc = 0; cc < 9; ++cc)
+    for (int r = 0; r < 4; ++r) {
+      double s2 = 0.0;
+      for (int k = 0; k < 4; ++k) s2 += Hm[4 * r + k] * sv[9 * k + cc];
+      if (r == 0) sf[cc] = s2; else Tf[9 * (r - 1) + cc] = s2;
+    }
+  double D[81];
+  for (int i = 0; i < 81; ++i) D[i] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double* c = origin + 3 * i; const double* x = dir + 3 * i;
+    double W[27]; left_mult(world + 3 * i, W);
+    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 9; ++cc) W[9 * r + cc] += Tf[9 * r + cc] - c[r] * sf[cc];
+    double PW[27];   // (I - x x^T) W
+    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 9; ++cc) {
+      double s2 = 0.0;
+      for (int k = 0; k < 3; ++k) s2 += ((r == k ? 1.0 : 0.0) - x[r] * x[k]) * W[9 * k + cc];
+      PW[9 * r + cc] = s2;
+    }
+    for (int a = 0; a < 9; ++a) for (int b = 0; b < 9; ++b) { double s2 = 0.0; for (int k = 0; k < 3; ++k) s2 += W[9 * k + a] * PW[9 * k + b]; D[9 * a + b] += s2; }
+  }
+  double A[729], V[729], wr[27], wi[27];
+  if (!dls_action_from_cost(D, u, nullptr, A)) return 0;
+  if (!eig_general_t<27, true>(27, A, wr, wi, V)) return 0;
+  int ns = 0;
+  for (int i = 0; i < 27; ++i) {
+    const int re_col = wi[i] < 0 ? i - 1 : i;
+    const double sg = wi[i] < 0 ? -1.0 : 1.0;
+    auto comp = [&](int row, double* re, double* im) { *re = V[27 * row + re_col]; *im = wi[i] == 0 ? 0.0 : sg * V[27 * row + re_col + 1]; };
+    double d_re, d_im; comp(0, &d_re, &d_im);
+    if (d_re == 0.0 && d_im == 0.0) continue;
+    double sr[3], si[3];
+    const int rows[3] = {9, 3, 1};
+    for (int k = 0; k < 3; ++k) { double a, b; comp(rows[k], &a, &b); eig_cdiv(a, b, d_re, d_im, &sr[k], &si[k]); }
+    const double kEps = 1e-6;
+    if (!(std::fabs(si[0]) < kEps && std::fabs(si[1]) < kEps && std::fabs(si[2]) < kEps)) continue;
+    double q[4] = {1.0, sr[0], sr[1], sr[2]};
+    const double n2 = ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3];
+    double qi[4] = {q[0] / n2, -q[1] / n2, -q[2] / n2, -q[3] / n2};
+    const double nq = std::sqrt(((qi[0] * qi[0] + qi[1] * qi[1]) + qi[2] * qi[2]) + qi[3] * qi[3]);
+    double qs[4] = {qi[0] / nq, qi[1] / nq, qi[2] / nq, qi[3] / nq};   // soln_rotation
+    const double m2 = ((qs[0] * qs[0] + qs[1] * qs[1]) + qs[2] * qs[2]) + qs[3] * qs[3];
+    const double qv[4] = {qs[0] / m2, -qs[1] / m2, -qs[2] / m2, -qs[3] / m2};
+    double Rm[9]; quat_to_rot(qv, Rm);   // rot_mat = soln_rotation.inverse().toRotationMatrix(); rot_vec = its column-major data
+    double t[3], sc = 0.0;
+    for (int r = 0; r < 3; ++r) { double s2 = 0.0; for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) s2 += Tf[9 * r + 3 * c + k] * Rm[3 * k + c]; t[r] = s2; }
+    for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) sc += sf[3 * c + k] * Rm[3 * k + c];
+    // every point in front of its ray: (FromTwoVectors(x, e_z) * (R X + t - s c)).z = x . (R X + t - s c) >= 0  (:199-218)
+    double Rs[9]; quat_to_rot(qs, Rs);
+    bool front = true;
+    for (int j = 0; j < n && front; ++j) {
+      const double* X = world + 3 * j; const double* c = origin + 3 * j; const double* x = dir + 3 * j;
+      double p[3];
+      for (int r = 0; r < 3; ++r) p[r] = (((Rs[3 * r] * X[0] + Rs[3 * r + 1] * X[1]) + Rs[3 * r + 2] * X[2]) + t[r]) - sc * c[r];
+      if ((x[0] * p[0] + x[1] * p[1]) + x[2] * p[2] < 0) front = false;
+    }
+    if (!front) continue;
+    for (int k = 0; k < 4; ++k) quats[4 * ns + k] = qs[k];
+    for (int k = 0; k < 3; ++k) ts[3 * ns + k] = t[k];
+    scales[ns] = sc;
+    ns++;
+  }
+  return ns;
+}

@@ -35,6 +35,7 @@ struct WaveLds {
   double X[kXRows * kReduced];
   double f[60];
   double T[27];
+  double sf[9];   // gDLS: the scale factor row
   double u[4];
   int flag;
 };
@@ -45,15 +46,96 @@ __device__ inline double wave_allsum(double v) {
   return v;
 }
 
+// Eigen's Matrix4d::inverse() restated as adjugate over determinant (oracle/dls_oracle.h: gdls_inverse4)
+__device__ inline bool inverse4(const double* a, double* inv) {
+  auto m3 = [&](int r0, int r1, int r2, int c0, int c1, int c2) {
+    return a[4 * r0 + c0] * (a[4 * r1 + c1] * a[4 * r2 + c2] - a[4 * r1 + c2] * a[4 * r2 + c1]) -
+           a[4 * r0 + c1] * (a[4 * r1 + c0] * a[4 * r2 + c2] - a[4 * r1 + c2] * a[4 * r2 + c0]) +
+           a[4 * r0 + c2] * (a[4 * r1 + c0] * a[4 * r2 + c1] - a[4 * r1 + c1] * a[4 * r2 + c0]);
+  };
+  double cof[16];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int r0 = r == 0 ? 1 : 0, r1 = r <= 1 ? 2 : 1, r2 = r <= 2 ? 3 : 2;
+      const int c0 = c == 0 ? 1 : 0, c1 = c <= 1 ? 2 : 1, c2 = c <= 2 ? 3 : 2;
+      const double minor = m3(r0, r1, r2, c0, c1, c2);
+      cof[4 * r + c] = ((r + c) & 1) ? -minor : minor;
+    }
+  const double det = ((a[0] * cof[0] + a[1] * cof[1]) + a[2] * cof[2]) + a[3] * cof[3];
+  if (det == 0.0) return false;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) inv[4 * r + c] = cof[4 * c + r] / det;
+  return true;
+}
+
 // points: feat[i * fstride + {0,1}], world[i * wstride + {0,1,2}] for i = index ? index[k] : k, k < npts.
 // Writes action[729] (row-major) and tfac[27]; returns false when a pivot vanished (degenerate sample).
+// GDLS (GdlsSimilarityTransform, gdls_similarity_transform.cc:67-175): feat holds the UNIT ray direction (3), world the
+// homogeneous point (4: hnormalized here), origin the ray origin (3); tfac = translation factor (27) | scale factor (9).
+template <bool GDLS = false>
 __device__ inline bool stage_a(WaveLds& L, int npts, const double* __restrict__ feat, int fstride,
                                const double* __restrict__ world, int wstride, const int* __restrict__ index,
-                               const double* __restrict__ u4, double* __restrict__ action, double* __restrict__ tfac) {
+                               const double* __restrict__ u4, double* __restrict__ action, double* __restrict__ tfac,
+                               const double* __restrict__ origin = nullptr, int ostride = 0) {
   const int lane = threadIdx.x & 63;
   const dls::Tables& tb = c_tab;
   if (lane < 4) L.u[lane] = u4[lane];
   if (lane == 0) L.flag = 0;
+  if constexpr (GDLS) {
+    // ---- sums over the rays: the 4 x 4 matrix H^-1 (:80-96) and the 4 x 9 helper (:101-117)
+    double hs[16], sv[36];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hs[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) sv[k] = 0.0;
+    for (int i = lane; i < npts; i += 64) {
+      const int id = index ? index[i] : i;
+      const double* xx = feat + (size_t)id * fstride; const double* cc = origin + (size_t)id * ostride; const double* ww = world + (size_t)id * wstride;
+      const double x[3] = {xx[0], xx[1], xx[2]}, c[3] = {cc[0], cc[1], cc[2]}, X[3] = {ww[0] / ww[3], ww[1] / ww[3], ww[2] / ww[3]};
+      const double cd = (c[0] * x[0] + c[1] * x[1]) + c[2] * x[2];
+      hs[0] += ((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]) - cd * cd;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double t = -c[r] + cd * x[r];
+        hs[4 * (r + 1)] += t; hs[r + 1] += t;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) hs[4 * (r + 1) + k + 1] += (r == k ? 1.0 : 0.0) - x[r] * x[k];
+      }
+      // L(X)[k][col] = X[col % 3] when col / 3 == k: the sums over k collapse to k = col / 3
+#pragma unroll
+      for (int col = 0; col < 9; ++col) {
+        const int k = col / 3;
+        const double lx = X[col % 3];
+        sv[col] += (c[k] - cd * x[k]) * lx;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) sv[9 * (r + 1) + col] += (x[r] * x[k] - (r == k ? 1.0 : 0.0)) * lx;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) hs[k] = wave_allsum(hs[k]);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) sv[k] = wave_allsum(sv[k]);
+    double Hm[16];
+    if (!inverse4(hs, Hm)) { if (lane == 0) L.flag = 1; for (int k = 0; k < 16; ++k) Hm[k] = 0.0; }
+    if (lane < 36) {
+      const int r = lane / 9, col = lane % 9;
+      double s2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double pre = 0.0, hk = 0.0;   // sv[9 k + col], Hm[4 r + k]: compile-time register indices only
+#pragma unroll
+        for (int cc2 = 0; cc2 < 9; ++cc2) pre = (cc2 == col) ? sv[9 * k + cc2] : pre;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) hk = (rr == r) ? Hm[4 * rr + k] : hk;
+        s2 += hk * pre;
+      }
+      if (r == 0) L.sf[col] = s2; else L.T[9 * (r - 1) + col] = s2;
+    }
+  } else {
   // ---- sums over the points: sum n n^T (6 unique) and sum (n n^T - I)_{ab} X_c (27)
   double acc[33];
 #pragma unroll
@@ -99,8 +181,10 @@ __device__ inline bool stage_a(WaveLds& L, int npts, const double* __restrict__ 
       L.T[lane] = s;
     }
   }
+  }   // !GDLS
   __syncthreads();
   // ---- D = sum (L(X) + T)^T (I - n n^T) (L(X) + T)   (dls_pnp.cc:111-118): lane = entry (alpha, beta), two passes
+  // (gDLS: W = L(X) - c scale_factor + T, gdls_similarity_transform.cc:123-133)
   double* Dm = L.aug;          // 81
   double* g = L.aug + 128;     // 90
   for (int e = lane; e < 81; e += 64) {
@@ -108,14 +192,24 @@ __device__ inline bool stage_a(WaveLds& L, int npts, const double* __restrict__ 
     double d = 0.0;
     for (int i = 0; i < npts; ++i) {
       const int id = index ? index[i] : i;
+      double n[3], wa[3], wb[3];
+      if constexpr (GDLS) {
+        const double* xx = feat + (size_t)id * fstride; const double* cc = origin + (size_t)id * ostride; const double* ww = world + (size_t)id * wstride;
+        n[0] = xx[0]; n[1] = xx[1]; n[2] = xx[2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          wa[a] = (al / 3 == a ? ww[al % 3] / ww[3] : 0.0) + (L.T[9 * a + al] - cc[a] * L.sf[al]);
+          wb[a] = (be / 3 == a ? ww[be % 3] / ww[3] : 0.0) + (L.T[9 * a + be] - cc[a] * L.sf[be]);
+        }
+      } else {
       const double fx = feat[(size_t)id * fstride], fy = feat[(size_t)id * fstride + 1];
       const double nrm = sqrt((fx * fx + fy * fy) + 1.0);
-      const double n[3] = {fx / nrm, fy / nrm, 1.0 / nrm};
-      double wa[3], wb[3];
+      n[0] = fx / nrm; n[1] = fy / nrm; n[2] = 1.0 / nrm;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         wa[a] = L.T[9 * a + al] + (al / 3 == a ? world[(size_t)id * wstride + al % 3] : 0.0);
         wb[a] = L.T[9 * a + be] + (be / 3 == a ? world[(size_t)id * wstride + be % 3] : 0.0);
+      }
       }
       // wa^T (I - n n^T) wb = wa.wb - (n.wa)(n.wb)
       const double dab = (wa[0] * wb[0] + wa[1] * wb[1]) + wa[2] * wb[2];
@@ -226,6 +320,7 @@ __device__ inline bool stage_a(WaveLds& L, int npts, const double* __restrict__ 
     action[e] = a;
   }
   if (lane < 27) tfac[lane] = L.T[lane];
+  if (GDLS && lane < 9) tfac[27 + lane] = L.sf[lane];
   __syncthreads();
   return L.flag == 0;
 }
@@ -278,6 +373,55 @@ __device__ inline bool column_solution(const double* V, const double* wi, int i,
   for (int k = 0; k < 3; ++k) tr[k] = t[k];
   return true;
 }
+
+// gDLS: one eigenvector column -> (quaternion [w x y z] = soln_rotation, translation, scale) if it is an admissible root
+// (gdls_similarity_transform.cc:176-226).  V: the four kept rows {0, 9, 3, 1} (COMPACT layout of column_solution).
+// tfac: translation factor (27) | scale factor (9).  Rays: dir / origin / homogeneous world point of the npts sampled data.
+__device__ inline bool column_solution_gdls(const double* V, const double* wi, int i, const double* __restrict__ tfac, int npts,
+                                            const double* __restrict__ data, int stride, int dir_off, int org_off, int wld_off,
+                                            const int* __restrict__ index, double* quat, double* tr, double* scale) {
+  const int re_col = wi[i] < 0 ? i - 1 : i;
+  if (re_col < 0) return false;
+  const bool cplx = wi[i] != 0.0;
+  const double sg = wi[i] < 0 ? -1.0 : 1.0;
+  const double d_re = V[re_col], d_im = cplx ? sg * V[re_col + 1] : 0.0;   // row 0
+  if (d_re == 0.0 && d_im == 0.0) return false;
+  double sr[3], si[3];
+  for (int k = 0; k < 3; ++k) {
+    const double a = V[27 * (k + 1) + re_col], b = cplx ? sg * V[27 * (k + 1) + re_col + 1] : 0.0;
+    rsc::eig_cdiv(a, b, d_re, d_im, &sr[k], &si[k]);
+  }
+  const double kEps = 1e-6;
+  if (!(fabs(si[0]) < kEps && fabs(si[1]) < kEps && fabs(si[2]) < kEps)) return false;
+  const double n2 = ((1.0 + sr[0] * sr[0]) + sr[1] * sr[1]) + sr[2] * sr[2];
+  const double qi[4] = {1.0 / n2, -sr[0] / n2, -sr[1] / n2, -sr[2] / n2};
+  const double nq = sqrt(((qi[0] * qi[0] + qi[1] * qi[1]) + qi[2] * qi[2]) + qi[3] * qi[3]);
+  const double qs[4] = {qi[0] / nq, qi[1] / nq, qi[2] / nq, qi[3] / nq};
+  const double m2 = ((qs[0] * qs[0] + qs[1] * qs[1]) + qs[2] * qs[2]) + qs[3] * qs[3];
+  const double qv[4] = {qs[0] / m2, -qs[1] / m2, -qs[2] / m2, -qs[3] / m2};
+  double Rm[9], Rs[9], t[3], sc = 0.0;
+  rsc::quat_to_rot(qv, Rm);
+  for (int r = 0; r < 3; ++r) {
+    double s = 0.0;
+    for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) s += tfac[9 * r + 3 * c + k] * Rm[3 * k + c];
+    t[r] = s;
+  }
+  for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) sc += tfac[27 + 3 * c + k] * Rm[3 * k + c];
+  rsc::quat_to_rot(qs, Rs);
+  for (int j = 0; j < npts; ++j) {   // every point in front of its ray: x . (R X + t - s c) >= 0
+    const double* d = data + (size_t)(index ? index[j] : j) * stride;
+    const double* x = d + dir_off; const double* c = d + org_off; const double* w = d + wld_off;
+    const double X[3] = {w[0] / w[3], w[1] / w[3], w[2] / w[3]};
+    double p[3];
+    for (int r = 0; r < 3; ++r) p[r] = (((Rs[3 * r] * X[0] + Rs[3 * r + 1] * X[1]) + Rs[3 * r + 2] * X[2]) + t[r]) - sc * c[r];
+    if ((x[0] * p[0] + x[1] * p[1]) + x[2] * p[2] < 0) return false;
+  }
+  for (int k = 0; k < 4; ++k) quat[k] = qs[k];
+  for (int k = 0; k < 3; ++k) tr[k] = t[k];
+  *scale = sc;
+  return true;
+}
+
 
 // Stage B, one thread per problem (the directly bound solver): H, V = 729-double work arrays of the calling thread.
 __device__ inline int stage_b(double* H, double* V, const double* __restrict__ tfac, int npts,

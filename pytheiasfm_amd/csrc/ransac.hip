@@ -46,6 +46,7 @@ constexpr int kMaxCap = 18;   // largest EstimateModel output of the thread-per-
 // models per sample an estimator can return = slot stride of the per-hypothesis arrays
 __host__ __device__ inline int max_models(int est) {
   if (est == THEIA_EST_RADIAL_HOMOGRAPHY) return 2;
+  if (est == THEIA_EST_SIMILARITY_2D3D) return dlsdev::kMaxSolutions;
   if (est >= THEIA_EST_FUNDAMENTAL_MATRIX) return 1;
   if (est == THEIA_EST_ABSOLUTE_POSE_DLS) return dlsdev::kMaxSolutions;
   return est == THEIA_EST_ABSOLUTE_POSE_SQPNP ? 18 : (est == THEIA_EST_ABSOLUTE_POSE_KNEIP ? 4 : 10);
@@ -56,7 +57,7 @@ __host__ __device__ inline int sample_size(int est) {
   switch (est) {
     case THEIA_EST_RELATIVE_POSE: case THEIA_EST_ESSENTIAL_MATRIX: return 5;
     case THEIA_EST_FUNDAMENTAL_MATRIX: case THEIA_EST_UNCALIBRATED_RELATIVE_POSE: return 8;
-    case THEIA_EST_HOMOGRAPHY: return 4;
+    case THEIA_EST_HOMOGRAPHY: case THEIA_EST_SIMILARITY_2D3D: return 4;
     case THEIA_EST_RADIAL_HOMOGRAPHY: return 6;
     case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION:
     case THEIA_EST_TRIANGULATION: return 2;
@@ -73,10 +74,12 @@ inline int model_doubles(int est) {
     case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: return 3;
     case THEIA_EST_TRIANGULATION: return 4;
     case THEIA_EST_RADIAL_HOMOGRAPHY: return 20;   // H | l1 | l2 | H^-1
+    case THEIA_EST_SIMILARITY_2D3D: return 13;     // rotation | translation | scale
     default: return 9;   // essential / fundamental matrix, homography
   }
 }
 constexpr int kTriDatum = 33;   // PointObservation row of THEIA_EST_TRIANGULATION (theia_hip.h)
+constexpr int kSimDatum = 26;   // CameraAndFeatureCorrespondence2D3D row of THEIA_EST_SIMILARITY_2D3D: dir (3) | point (4) | pixel (2) | extrinsics (6) | model | intrinsics (10)
 __host__ __device__ inline int datum_size(int est) {
   switch (est) {
     case THEIA_EST_ABSOLUTE_POSE_KNEIP: case THEIA_EST_ABSOLUTE_POSE_DLS: case THEIA_EST_ABSOLUTE_POSE_SQPNP:
@@ -84,6 +87,7 @@ __host__ __device__ inline int datum_size(int est) {
     case THEIA_EST_DOMINANT_PLANE: return 3;
     case THEIA_EST_TRIANGULATION: return kTriDatum;
     case THEIA_EST_RADIAL_HOMOGRAPHY: return rsc::kRadHomDatum;
+    case THEIA_EST_SIMILARITY_2D3D: return kSimDatum;
     default: return 4;
   }
 }
@@ -194,7 +198,27 @@ __device__ inline double triangulation_error(const double* X, const double* d) {
 
 // Estimator::Error (estimate_relative_pose.cc:142-151, estimate_essential_matrix.cc:77-83,
 // estimate_calibrated_absolute_pose.cc:158-167)
+// GdlsSimilarityTransformationEstimator::Error (estimate_similarity_transformation_2d_3d.cc:137-155) with TransformCamera
+// (:52-70): new position = s R c + t, new orientation = R_cam R^T, then Camera::ProjectPoint; DBL_MAX at negative depth.
+__device__ inline double similarity_error(const double* m, const double* d) {
+  const double* X = d + 3; const double* c = d + 9;
+  double np[3], a[3], b[3];
+  for (int r = 0; r < 3; ++r) np[r] = m[12] * ((m[3 * r] * c[0] + m[3 * r + 1] * c[1]) + m[3 * r + 2] * c[2]) + m[9 + r];
+  for (int r = 0; r < 3; ++r) a[r] = X[r] - X[3] * np[r];
+  for (int r = 0; r < 3; ++r) b[r] = (m[r] * a[0] + m[3 + r] * a[1]) + m[6 + r] * a[2];   // R^T a
+  RotTerms rt;
+  rotation_terms(d + 12, rt);
+  const double q[3] = {(rt.R[0] * b[0] + rt.R[1] * b[1]) + rt.R[2] * b[2], (rt.R[3] * b[0] + rt.R[4] * b[1]) + rt.R[5] * b[2],
+                       (rt.R[6] * b[0] + rt.R[7] * b[1]) + rt.R[8] * b[2]};
+  if (q[2] / X[3] < 0.0) return DBL_MAX;
+  double uv[2], Jq[6];
+  project<false>((int)d[15], d + 16, q, uv, Jq);
+  const double ex = d[7] - uv[0], ey = d[8] - uv[1];
+  return ex * ex + ey * ey;
+}
+
 __device__ inline double model_error(int est, const double* m, const double* d) {
+  if (est == THEIA_EST_SIMILARITY_2D3D) return similarity_error(m, d);
   if (est == THEIA_EST_TRIANGULATION) return triangulation_error(m, d);
   if (est == THEIA_EST_RADIAL_HOMOGRAPHY) return rsc::radial_homography_error(m, d);
   if (est == THEIA_EST_RELATIVE_POSE) {
@@ -900,6 +924,65 @@ __global__ __launch_bounds__(64) void k_dls_b_team(size_t nhyp, int B, const int
   tags[(size_t)p * B * mm + base + j] = b * mm + j;
 }
 
+// ---- gDLS similarity hypotheses (estimate_similarity_transformation_2d_3d.cc:85-133): the DLS pipeline on four
+// camera-bearing correspondences -- stage A with the generalised cost matrix, the same eigen stage, solutions with scale
+__global__ __launch_bounds__(64) void k_gdls_a(int nprob, int B, const int64_t* __restrict__ offsets,
+                                               const double* __restrict__ data, const int* __restrict__ samples,
+                                               const int* __restrict__ active_iters, const int* __restrict__ iter_base,
+                                               const double* __restrict__ uvals, double* __restrict__ action,
+                                               double* __restrict__ tfac, int* __restrict__ okflag) {
+  __shared__ dlsdev::WaveLds L;
+  const int b = blockIdx.x, p = blockIdx.y;
+  if (b >= active_iters[p]) return;
+  const size_t hyp = (size_t)p * B + b;
+  const double* pd = data + (size_t)offsets[p] * kSimDatum;
+  const bool ok = dlsdev::stage_a<true>(L, 4, pd, kSimDatum, pd + 3, kSimDatum, samples + hyp * 4, uvals + 4 * (size_t)(iter_base[p] + b),
+                                        action + hyp * 729, tfac + hyp * 36, pd + 9, kSimDatum);
+  if (threadIdx.x == 0) okflag[hyp] = ok ? 1 : 0;
+}
+
+__global__ __launch_bounds__(64) void k_gdls_b_team(size_t nhyp, int B, const int64_t* __restrict__ offsets,
+                                                    const double* __restrict__ data, const int* __restrict__ samples,
+                                                    const int* __restrict__ active_iters, double* __restrict__ action,
+                                                    const double* __restrict__ tfac, const int* __restrict__ okflag,
+                                                    double* __restrict__ models, int* __restrict__ counts,
+                                                    int* __restrict__ dense_count, int* __restrict__ tags, int* __restrict__ hyp_base) {
+  __shared__ double lds[kDlsTeamsPerWave][kDlsTeamLds];
+  const int team = threadIdx.x / kDlsTeam, tl = threadIdx.x % kDlsTeam;
+  const size_t hyp = (size_t)blockIdx.x * kDlsTeamsPerWave + team;
+  if (hyp >= nhyp) return;
+  const int p = (int)(hyp / B), b = (int)(hyp % B);
+  if (b >= active_iters[p] || !okflag[hyp]) { if (tl == 0) counts[hyp] = 0; return; }
+  double* H = lds[team]; double* Vk = H + 729; double* wr = Vk + 27 * dlsdev::kKeptRows; double* wi = wr + 27; double* ort = wi + 27;
+  double* a = action + hyp * 729;
+  for (int e = tl; e < 729; e += kDlsTeam) H[e] = a[e];
+  rsc::team_sync();
+  int nn = 27;
+  asm volatile("" : "+s"(nn));
+  const bool good = rsc::eig_team<kDlsTeam, true, dlsdev::kKeptRows>(nn, H, a, a, wr, wi, ort, tl, Vk, dlsdev::kKeptRow);
+  double quat[4], tr[3], sc = 0.0;
+  bool keep = false;
+  if (good && tl < 27)
+    keep = dlsdev::column_solution_gdls(Vk, wi, tl, tfac + hyp * 36, 4, data + (size_t)offsets[p] * kSimDatum, kSimDatum, 0, 9, 3,
+                                        samples + hyp * 4, quat, tr, &sc);
+  int incl = keep ? 1 : 0;
+  for (int o = 1; o < kDlsTeam; o <<= 1) { const int v = __shfl_up(incl, o, kDlsTeam); if (tl >= o) incl += v; }
+  const int nm = __shfl(incl, kDlsTeam - 1, kDlsTeam);
+  int base = 0;
+  if (tl == 0) { counts[hyp] = nm; if (nm) { base = atomicAdd(&dense_count[p], nm); hyp_base[hyp] = base; } }
+  base = __shfl(base, 0, kDlsTeam);
+  if (!keep) return;
+  const int mm = dlsdev::kMaxSolutions, j = incl - 1;
+  double* m = models + ((size_t)p * B * mm + base + j) * (size_t)kStride;
+  double Rs[9];
+  rsc::quat_to_rot(quat, Rs);
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) m[3 * r + c] = Rs[3 * c + r];                              // rotation = R^T
+  for (int r = 0; r < 3; ++r) m[9 + r] = (m[3 * r] * -tr[0] + m[3 * r + 1] * -tr[1]) + m[3 * r + 2] * -tr[2];       // rotation * -t
+  m[12] = sc;
+  for (int k = 13; k < kStride; ++k) m[k] = 0.0;
+  tags[(size_t)p * B * mm + base + j] = b * mm + j;
+}
+
 // DlsPnp on problems of any size (the directly bound solver, sfm.cc:577): a wave per problem, then a thread per problem
 __global__ __launch_bounds__(64) void k_dls_solve_a(const int64_t* __restrict__ offsets, const double* __restrict__ feat,
                                                     const double* __restrict__ world, const double* __restrict__ uvals,
@@ -1145,13 +1228,14 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     ep.min_focal = batch->estimator_params[0];
     ep.max_focal = batch->estimator_params[1];
   }
-  const bool dls_est = est == THEIA_EST_ABSOLUTE_POSE_DLS;
-  if (est < 0 || est > THEIA_EST_RADIAL_HOMOGRAPHY) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
-  const bool abs_pose = est == THEIA_EST_ABSOLUTE_POSE_KNEIP || est == THEIA_EST_ABSOLUTE_POSE_SQPNP || dls_est;
+  const bool gdls_est = est == THEIA_EST_SIMILARITY_2D3D;
+  const bool dls_est = est == THEIA_EST_ABSOLUTE_POSE_DLS || gdls_est;   // the Macaulay pipeline: stage A -> eigen stage
+  if (est < 0 || est > THEIA_EST_SIMILARITY_2D3D) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
+  const bool abs_pose = est == THEIA_EST_ABSOLUTE_POSE_KNEIP || est == THEIA_EST_ABSOLUTE_POSE_SQPNP || (dls_est && !gdls_est);
   // estimators that keep Estimator::RefineModel's default "return true" (solvers/estimator.h:86-88): LO only counts
   const bool trivial_refine = est == THEIA_EST_ESSENTIAL_MATRIX || est == THEIA_EST_DOMINANT_PLANE ||
                               est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION || est == THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION ||
-                              est == THEIA_EST_TRIANGULATION || est == THEIA_EST_RADIAL_HOMOGRAPHY;
+                              est == THEIA_EST_TRIANGULATION || est == THEIA_EST_RADIAL_HOMOGRAPHY || est == THEIA_EST_SIMILARITY_2D3D;
   const bool rel_pose = est == THEIA_EST_RELATIVE_POSE, uncal_pose = est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE;
   const bool homog = est == THEIA_EST_HOMOGRAPHY, fund = est == THEIA_EST_FUNDAMENTAL_MATRIX;
   // every estimator's RefineModel is built: BundleAdjustView (absolute pose), BundleAdjustTwoViewsAngular ((un)calibrated
@@ -1387,7 +1471,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         for (int q = 0; q < cn; ++q) { h_iter_base[q] = S[c0 + q].it; calls = std::max(calls, S[c0 + q].it + S[c0 + q].round_iters); }
         const size_t had = h_dls_u.size();
         dls_terms(h_dls_u, dls_gen, (size_t)calls);
-        if ((rc = d_dls_action.ensure(nh * 729)) || (rc = d_dls_tfac.ensure(nh * 27)) || (rc = d_dls_ok.ensure(nh)) ||
+        if ((rc = d_dls_action.ensure(nh * 729)) || (rc = d_dls_tfac.ensure(nh * 36)) || (rc = d_dls_ok.ensure(nh)) ||
             (rc = d_iter_base.ensure(cn)))
           return rc;
         if (h_dls_u.size() != had || d_dls_u.cap < h_dls_u.size()) {
@@ -1396,6 +1480,13 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         }
         HIP_TRYR(hipMemcpyAsync(d_iter_base.p, h_iter_base.data(), sizeof(int) * cn, hipMemcpyHostToDevice, st));
         HIP_TRYR(hipEventRecord(ev0, st));   // (re-recorded: the uploads above are not part of the fit time)
+        if (gdls_est) {
+          k_gdls_a<<<dim3(B, cn), 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_iter_base.p, d_dls_u.p,
+                                               d_dls_action.p, d_dls_tfac.p, d_dls_ok.p);
+          k_gdls_b_team<<<(unsigned)((nh + kDlsTeamsPerWave - 1) / kDlsTeamsPerWave), 64, 0, st>>>(
+              nh, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_dls_action.p, d_dls_tfac.p, d_dls_ok.p, d_models.p,
+              d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
+        } else {
         k_dls_a<<<dim3(B, cn), 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_iter_base.p, d_dls_u.p,
                                             d_dls_action.p, d_dls_tfac.p, d_dls_ok.p);
         if (getenv("THEIA_HIP_DLS_THREAD_EIG"))
@@ -1406,6 +1497,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
           k_dls_b_team<<<(unsigned)((nh + kDlsTeamsPerWave - 1) / kDlsTeamsPerWave), 64, 0, st>>>(
               nh, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_dls_action.p, d_dls_tfac.p, d_dls_ok.p, d_models.p,
               d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
+        }
       } else if ((est == THEIA_EST_RELATIVE_POSE || est == THEIA_EST_ESSENTIAL_MATRIX) && !getenv("THEIA_HIP_FIT_ONE_KERNEL")) {
         if ((rc = d_fp_ws.ensure(nh * kFpWs)) || (rc = d_fp_sol.ensure(nh * 40)) || (rc = d_fp_ok.ensure(nh)) || (rc = d_fp_mask.ensure(nh)))
           return rc;

@@ -35,6 +35,7 @@ EST_UNCALIBRATED_RELATIVE_POSE = 9
 EST_ABSOLUTE_POSE_KNOWN_ORIENTATION = 10
 EST_TRIANGULATION = 11
 EST_RADIAL_HOMOGRAPHY = 12
+EST_SIMILARITY_2D3D = 13
 
 
 class RansacParameters:
@@ -147,7 +148,7 @@ def estimate_batch(estimator, data, offsets, params, estimator_params=None, seed
             "time_fit_seconds": r.time_fit_seconds, "time_score_seconds": r.time_score_seconds}
 
 
-_SAMPLE_SIZE = {0: 5, 1: 5, 2: 3, 3: 3, 4: 3, 5: 8, 6: 4, 7: 3, 8: 2, 9: 8, 10: 2, 11: 2, 12: 6}   # Estimator::SampleSize() by THEIA_EST_*
+_SAMPLE_SIZE = {0: 5, 1: 5, 2: 3, 3: 3, 4: 3, 5: 8, 6: 4, 7: 3, 8: 2, 9: 8, 10: 2, 11: 2, 12: 6, 13: 4}   # Estimator::SampleSize() by THEIA_EST_*
 
 
 def _single(estimator, ransac_params, ransac_type, data, estimator_params=None):
@@ -396,6 +397,50 @@ def EstimateRadialHomographyMatrix(ransac_params, ransac_type, normalized_corres
     """estimate_radial_distortion_homography.cc:90-111 -> (success, RadialHomographyResult, summary)."""
     ok, m, s = _single(EST_RADIAL_HOMOGRAPHY, ransac_params, ransac_type, radial_correspondence_rows(normalized_correspondences))
     return ok, RadialHomographyResult(m), s
+
+
+class SimilarityTransformation:  # sfm/similarity_transformation.h: rotation, translation, scale
+    def __init__(self, m):
+        self.rotation = np.array(m[0:9]).reshape(3, 3)
+        self.translation = np.array(m[9:12])
+        self.scale = float(m[12])
+
+
+class CameraAndFeatureCorrespondence2D3D:  # estimate_similarity_transformation_2d_3d.h: camera, observation, point3d
+    def __init__(self, camera, observation, point3d):
+        self.camera = camera
+        self.observation = np.asarray(observation, dtype=np.float64).reshape(2)
+        p = np.asarray(point3d, dtype=np.float64).ravel()
+        self.point3d = p if p.shape[0] == 4 else np.append(p, 1.0)
+
+
+def pixel_to_unit_depth_ray(camera, pixel):
+    """Camera::PixelToUnitDepthRay (camera.cc:232-243): R^T [normalized coordinates; 1] (pinhole mirror of the unprojection)."""
+    n = camera.pixel_to_normalized(pixel)
+    return synth.angle_axis_to_matrix(camera.orientation).T @ np.array([n[0], n[1], 1.0])
+
+
+def similarity_correspondence_rows(correspondences, ray_directions=None):
+    """(N, 26) rows of THEIA_EST_SIMILARITY_2D3D.  ray_directions: optional (N, 3) world-frame rays of the observations
+    (any length) for camera models whose unprojection the mirror does not carry."""
+    out = np.zeros((len(correspondences), 26))
+    for i, c in enumerate(correspondences):
+        ray = pixel_to_unit_depth_ray(c.camera, c.observation) if ray_directions is None else np.asarray(ray_directions[i], dtype=np.float64)
+        out[i, 0:3] = ray / np.linalg.norm(ray)
+        out[i, 3:7] = c.point3d
+        out[i, 7:9] = c.observation
+        out[i, 9:12] = c.camera.position
+        out[i, 12:15] = c.camera.orientation
+        out[i, 15] = c.camera.model
+        out[i, 16:26] = c.camera.intrinsics
+    return out
+
+
+def EstimateSimilarityTransformation2D3D(ransac_params, ransac_type, correspondences, ray_directions=None):
+    """estimate_similarity_transformation_2d_3d.cc:161-178 -> (success, SimilarityTransformation, summary)."""
+    rows = correspondences if isinstance(correspondences, np.ndarray) else similarity_correspondence_rows(correspondences, ray_directions)
+    ok, m, s = _single(EST_SIMILARITY_2D3D, ransac_params, ransac_type, rows)
+    return ok, SimilarityTransformation(m), s
 
 
 def FivePointRelativePose(image1_points, image2_points):

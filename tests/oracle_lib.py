@@ -276,6 +276,20 @@ def rot_quat_roundtrip(R):
     return q, R2
 
 
+def gdls_similarity(origin, direction, world, call_index=0):
+    """GdlsSimilarityTransform (gdls_similarity_transform.cc:67-228): rotations as quaternions [w x y z], translations, scales
+    with  s c_i + alpha_i x_i = R X_i + t."""
+    L = rlib()
+    dp = capi.c_double_p
+    L.oracle_gdls_similarity.argtypes = [C.c_int, dp, dp, dp, C.c_int, dp, dp, dp]
+    o = np.ascontiguousarray(origin, dtype=np.float64); d = np.ascontiguousarray(direction, dtype=np.float64)
+    w = np.ascontiguousarray(world, dtype=np.float64)
+    q = np.zeros((27, 4)); t = np.zeros((27, 3)); sc = np.zeros(27)
+    n = L.oracle_gdls_similarity(o.shape[0], capi.ptr(o, C.c_double), capi.ptr(d, C.c_double), capi.ptr(w, C.c_double), int(call_index),
+                                 capi.ptr(q, C.c_double), capi.ptr(t, C.c_double), capi.ptr(sc, C.c_double))
+    return q[:n], t[:n], sc[:n]
+
+
 def model_error(est, model, datum):
     """Estimator::Error of one datum under one model row (oracle_model_error)."""
     model = np.ascontiguousarray(model, dtype=np.float64); datum = np.ascontiguousarray(datum, dtype=np.float64)

@@ -1034,3 +1034,58 @@ def test_estimate_radial_homography_matrix_with_outliers():
     assert np.array_equal((e < 4.0)[sure], o["inlier_mask"].astype(bool)[sure])
     assert o["inlier_mask"][~out].mean() > 0.9 and o["inlier_mask"][out].mean() < 0.05
     assert abs(m[9] - k1 * f1 * f1) < 0.05 and abs(m[10] - k2 * f2 * f2) < 0.05
+
+
+def test_gdls_similarity_transform_reference_scenes():
+    """gdls_similarity_transform_test.cc:158-215 restated: 4 (8) points seen from 4 camera centres under rotation 13 degrees
+    about z, t = (1, 1, 1), s = 2.5; noise-free: a solution within the reference's bounds (rotation 1e-4 degrees, squared
+    translation error 1e-6, relative scale 1e-6) and rays reproduced."""
+    from tests import gdls_scenes as gs
+    R, t, s = gs.rotation_z(13.0), np.array([1.0, 1.0, 1.0]), 2.5
+    pts4 = [[-1.0, 3.0, 3.0], [1.0, -1.0, 2.0], [-1.0, 1.0, 2.0], [2.0, 1.0, 3.0]]
+    pts8 = pts4 + [[-1.0, -3.0, 2.0], [1.0, -2.0, 1.0], [-1.0, 4.0, 2.0], [-2.0, 2.0, 3.0]]
+    for pts, centers in ((pts4, [[-1.0, 0, 0], [0.0, 0, 0], [2.0, 0, 0], [3.0, 0, 0]]), (pts8, [[0, 1.0, 0], [0, 0, 0], [0, 2.0, 0], [0, 3.0, 0]])):
+        origins, rays = gs.generalised(pts, centers, R, t, s)
+        q, tt, sc = ol.gdls_similarity(origins, rays, pts)
+        assert len(q) >= 1
+        matched = False
+        for i in range(len(q)):
+            Rq = gs.quat_to_matrix(q[i])
+            ang = np.arccos(np.clip((np.trace(Rq.T @ R) - 1.0) / 2.0, -1.0, 1.0))
+            # every returned solution reproduces the rays (reprojection < 1 / 512 in the ray frame)
+            p = (np.asarray(pts) @ Rq.T + tt[i]) / sc[i] - origins
+            p /= np.linalg.norm(p, axis=1, keepdims=True)
+            assert np.abs(np.cross(p, rays)).max() < 1.0 / 512.0
+            if ang < np.deg2rad(1e-4) and np.sum((tt[i] - t) ** 2) < 1e-6 and abs(sc[i] - s) / s < 1e-6:
+                matched = True
+        assert matched
+
+
+def test_estimate_similarity_transformation_2d_3d_with_outliers():
+    """EstimateSimilarityTransformation2D3D through the oracle's RANSAC: a rig of five pinhole cameras in its own frame,
+    120 correspondences with 25 % outliers and 0.5 px noise: the similarity that moves the rig onto the world cameras is
+    recovered and the inlier set equals a numpy statement of the error (TransformCamera + projection)."""
+    from pytheiasfm_amd import ransac
+    from tests import gdls_scenes as gs
+    corr, truth = gs.cameras(5, 120, seed=3, outlier_frac=0.25, noise=0.5)
+    rows = ransac.similarity_correspondence_rows(corr)
+    pc = ol.default_ransac_params(3.0 ** 2, seed=9); pc.min_iterations = 100; pc.failure_probability = 1e-3
+    o = ol.ransac_estimate(13, rows, pc)
+    assert o["success"]
+    m = o["model"]
+    Rs, ts, ss = m[:9].reshape(3, 3), m[9:12], m[12]
+    assert np.abs(Rs - truth["R"]).max() < 5e-3 and np.abs(ts - truth["t"]).max() < 5e-2 and abs(ss - truth["s"]) < 2e-2
+    e = np.zeros(len(corr)); depth = np.zeros(len(corr))
+    for i, c in enumerate(corr):
+        pos = ss * Rs @ c.camera.position + ts
+        Rc = synth.angle_axis_to_matrix(c.camera.orientation[None])[0] @ Rs.T
+        q = Rc @ (c.point3d[:3] - c.point3d[3] * pos)
+        depth[i] = q[2] / c.point3d[3]
+        f, a, sk, cx, cy = c.camera.intrinsics[:5]
+        x, y = q[0] / q[2], q[1] / q[2]
+        uv = np.array([f * x + sk * y + cx, f * a * y + cy])
+        e[i] = np.sum((uv - c.observation) ** 2)
+    expect = (e < 9.0) & (depth >= 0)
+    sure = np.abs(e - 9.0) > 1e-6
+    assert np.array_equal(expect[sure], o["inlier_mask"].astype(bool)[sure])
+    assert o["inlier_mask"][~truth["outlier"]].mean() > 0.9 and o["inlier_mask"][truth["outlier"]].mean() < 0.1

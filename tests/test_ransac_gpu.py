@@ -914,3 +914,53 @@ def test_radial_distortion_homography_follows_oracle_and_numpy(rtype):
         assert res["inlier_mask"][sl][~out].mean() > 0.85
     ok, rhr, s = ransac.EstimateRadialHomographyMatrix(p, ransac.RansacType.RANSAC, data[offsets[0]:offsets[1]])
     assert ok and abs(rhr.l1 - truth[0][0]) < 0.1 and rhr.H.shape == (3, 3) and len(s.inliers) > 100
+
+
+@pytest.mark.parametrize("rtype", [0, 2])
+def test_similarity_transformation_2d_3d_follows_oracle_and_numpy(rtype):
+    """EstimateSimilarityTransformation2D3D (gDLS, estimate_similarity_transformation_2d_3d.cc:72-178): 5 rigs, outliers and
+    noise.  Device and oracle take different elimination routes through the Macaulay system (as for DLS): the
+    pairs with identical inlier sets are counted, the support may differ by a few borderline correspondences, the
+    transformation agrees at the solver's accuracy and matches the planted one; inlier sets re-derived in numpy."""
+    from tests import gdls_scenes as gs
+    data, offsets, truths, corrs = [], [0], [], []
+    for r in range(5):
+        corr, truth = gs.cameras(4 + r % 2, 100 + 20 * r, seed=40 + r, outlier_frac=0.2, noise=0.5, scale=1.2 + 0.3 * r)
+        rows = ransac.similarity_correspondence_rows(corr)
+        data.append(rows); offsets.append(offsets[-1] + len(rows)); truths.append(truth); corrs.append(corr)
+    data = np.concatenate(data); offsets = np.array(offsets, dtype=np.int64)
+    p = ransac.RansacParameters(); p.error_thresh = 3.0 ** 2; p.min_iterations = 100; p.failure_probability = 1e-3; p.seed = 5
+    pc0 = p.to_c(); pc0.ransac_type = rtype
+    res = ransac.estimate_batch(ransac.EST_SIMILARITY_2D3D, data, offsets, pc0)
+    equal = 0
+    for i in range(5):
+        sl = slice(offsets[i], offsets[i + 1])
+        pc = p.to_c(); pc.seed = 5 + i; pc.ransac_type = rtype
+        o = ol.ransac_estimate(13, data[sl], pc)
+        assert o["success"] and res["success"][i]
+        same = np.array_equal(o["inlier_mask"], res["inlier_mask"][sl])
+        equal += int(same)
+        assert abs(int(o["num_inliers"]) - int(res["num_inliers"][i])) <= 3
+        m = res["models"][i]
+        Rs, ts, ss = m[:9].reshape(3, 3), m[9:12], m[12]
+        tr = truths[i]
+        assert np.abs(Rs - tr["R"]).max() < 1e-2 and np.abs(ts - tr["t"]).max() < 0.1 and abs(ss - tr["s"]) < 0.05
+        if same and o["num_iterations"] == res["num_iterations"][i]:
+            assert np.abs(m[:13] - o["model"][:13]).max() < 1e-3
+        if rtype == 0:
+            e = np.zeros(offsets[i + 1] - offsets[i]); depth = np.zeros_like(e)
+            for k, c in enumerate(corrs[i]):
+                pos = ss * Rs @ c.camera.position + ts
+                Rc = synth.angle_axis_to_matrix(c.camera.orientation[None])[0] @ Rs.T
+                q = Rc @ (c.point3d[:3] - c.point3d[3] * pos)
+                depth[k] = q[2] / c.point3d[3]
+                f, a, sk, cx, cy = c.camera.intrinsics[:5]
+                uv = np.array([f * q[0] / q[2] + sk * q[1] / q[2] + cx, f * a * q[1] / q[2] + cy])
+                e[k] = np.sum((uv - c.observation) ** 2)
+            sure = np.abs(e - 9.0) > 1e-6
+            assert np.array_equal(((e < 9.0) & (depth >= 0))[sure], res["inlier_mask"][sl].astype(bool)[sure])
+            assert res["inlier_mask"][sl][~tr["outlier"]].mean() > 0.9
+    print(f"\n[gDLS] inlier sets identical on {equal} of 5 rigs")
+    assert equal >= 3
+    ok, sim, s = ransac.EstimateSimilarityTransformation2D3D(p, ransac.RansacType.RANSAC, corrs[0])
+    assert ok and abs(sim.scale - truths[0]["s"]) < 0.05 and sim.rotation.shape == (3, 3)
