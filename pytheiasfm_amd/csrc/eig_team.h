@@ -35,7 +35,7 @@ __device__ __forceinline__ void team_sync() {
 // The full V of the accumulation lives in V, which may then be slow memory (the work array X is not in use yet: the two
 // can share storage).  Same arithmetic per entry, so the kept rows equal those of the full computation bit for bit.
 template <int TEAM, bool CPLX, int NR = 0>
-__device__ bool eig_team(int nn, double* __restrict__ H, double* V, double* X,
+__device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double* V, double* X,
                          double* __restrict__ wr, double* __restrict__ wi, double* __restrict__ ort, int tl,
                          double* __restrict__ Vk = nullptr, const int* __restrict__ keep = nullptr) {
 #define HH(i, j) H[(i) * nn + (j)]
