@@ -281,13 +281,20 @@ __global__ __launch_bounds__(64) void k_fit(int est, int nprob, int B, const int
 
 // K6: one thread per (problem, iteration, model slot); block = 256 slots of ONE
 // problem, whose correspondences are staged in LDS when they fit.
-template <bool USE_LDS>
-__global__ __launch_bounds__(256) void k_score(int est, int nprob, int B, const int64_t* __restrict__ offsets,
+// EST >= 0: the estimator is a compile-time constant (the error functions of the others drop out: the run-time dispatch
+// keeps all of them -- the eight camera models of the triangulation error included -- in one 192-VGPR kernel at two waves
+// per SIMD); EST < 0: run-time dispatch on `est`.
+// The specialised instances run 512 slots per workgroup: the LDS copy of a problem's correspondences (64 - 80 KB at
+// 2000 per pair) allows two workgroups per CU, i.e. four waves per SIMD instead of two.
+constexpr int score_threads(int est) { return est >= 0 ? 512 : 256; }
+template <bool USE_LDS, int EST = -1>
+__global__ __launch_bounds__(score_threads(EST)) void k_score(int est_rt, int nprob, int B, const int64_t* __restrict__ offsets,
                                                const double* __restrict__ data, const double* __restrict__ models,
                                                const int* __restrict__ dense_count, const int* __restrict__ tags,
                                                double thresh, int use_mle, double* __restrict__ cost,
                                                int* __restrict__ ninl) {
   extern __shared__ __attribute__((aligned(16))) double sdata[];
+  const int est = EST >= 0 ? EST : est_rt;
   const int p = blockIdx.y;
   const int nmodels = dense_count[p];
   if ((int)(blockIdx.x * blockDim.x) >= nmodels) return;  // whole block beyond the dense list
@@ -748,7 +755,7 @@ __global__ __launch_bounds__(64) void k_sqp_c(int nprob, int B, const int* __res
   double quats[72], ts[54];
   // Omega, P, the centroid, U and S are read where they lie (201 doubles of the workspace row): copies in per-lane arrays
   // would double the scratch frame of this kernel
-  const int nm = rsc::sqpnp_post(w, w + 81, w + 108, w + 111, w + 192, quats, ts);
+  const int nm = rsc::sqpnp_post_impl(w, w + 81, w + 108, w + 111, w + 192, quats, ts);
   counts[hyp] = nm;
   if (nm == 0) return;
   constexpr int mm = 18;   // max_models(THEIA_EST_ABSOLUTE_POSE_SQPNP)
@@ -1540,11 +1547,20 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         dim3 grid(B * kMaxModels, cn);
         k_score_lmed<<<grid, 256, lmed_lds, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_models.p, d_dense.p, d_tags.p, d_cost.p, d_ninl.p);
       } else {
-        dim3 grid((B * kMaxModels + 255) / 256, cn);
-        if (use_lds)
-          k_score<true><<<grid, 256, lds_bytes, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_models.p, d_dense.p, d_tags.p, P.error_thresh, P.use_mle, d_cost.p, d_ninl.p);
-        else
-          k_score<false><<<grid, 256, 0, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_models.p, d_dense.p, d_tags.p, P.error_thresh, P.use_mle, d_cost.p, d_ninl.p);
+#define THIP_SCORE(L, E, BYTES) k_score<L, E><<<dim3((B * kMaxModels + score_threads(E) - 1) / score_threads(E), cn), score_threads(E), BYTES, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_models.p, d_dense.p, d_tags.p, P.error_thresh, P.use_mle, d_cost.p, d_ninl.p)
+        if (use_lds) {
+          if (est == THEIA_EST_RELATIVE_POSE) THIP_SCORE(true, THEIA_EST_RELATIVE_POSE, lds_bytes);
+          else if (est == THEIA_EST_ESSENTIAL_MATRIX) THIP_SCORE(true, THEIA_EST_ESSENTIAL_MATRIX, lds_bytes);
+          else if (est == THEIA_EST_ABSOLUTE_POSE_KNEIP) THIP_SCORE(true, THEIA_EST_ABSOLUTE_POSE_KNEIP, lds_bytes);
+          else if (est == THEIA_EST_ABSOLUTE_POSE_DLS) THIP_SCORE(true, THEIA_EST_ABSOLUTE_POSE_DLS, lds_bytes);
+          else if (est == THEIA_EST_ABSOLUTE_POSE_SQPNP) THIP_SCORE(true, THEIA_EST_ABSOLUTE_POSE_SQPNP, lds_bytes);
+          else THIP_SCORE(true, -1, lds_bytes);
+        } else {
+          if (est == THEIA_EST_RELATIVE_POSE) THIP_SCORE(false, THEIA_EST_RELATIVE_POSE, 0);
+          else if (est == THEIA_EST_ABSOLUTE_POSE_SQPNP) THIP_SCORE(false, THEIA_EST_ABSOLUTE_POSE_SQPNP, 0);
+          else THIP_SCORE(false, -1, 0);
+        }
+#undef THIP_SCORE
       }
       HIP_TRYR(hipEventRecord(ev1, st));
       if (!h_counts.resize(nh) || !h_cost.resize(nh * kMaxModels) || !h_ninl.resize(nh * kMaxModels))

@@ -584,8 +584,18 @@ RDEV void nearest_rotation_svd(const double* e, double* r) {
       r[i + 3 * j] = acc;
     }
 }
-RDEV double norm9(const double* v) { double s2 = 0.0; for (int i = 0; i < 9; ++i) s2 += v[i] * v[i]; return sqrt(s2); }
-RDEV double dot9(const double* a, const double* b) { double s2 = 0.0; for (int i = 0; i < 9; ++i) s2 += a[i] * b[i]; return s2; }
+RDEV double norm9(const double* v) {
+  double s2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) s2 += v[i] * v[i];
+  return sqrt(s2);
+}
+RDEV double dot9(const double* a, const double* b) {
+  double s2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) s2 += a[i] * b[i];
+  return s2;
+}
 
 // sqpnp_helper.cc:317-493.  H: 9x6, N: 9x3, K: 6x6 (row-major)
 RDEV void row_and_null_space(const double* r, double* H, double* Nn, double* K) {
@@ -662,61 +672,102 @@ RDEV void row_and_null_space(const double* r, double* H, double* Nn, double* K) 
   KK(5, 3) = r[6] * HH(0, 3) + r[7] * HH(1, 3) + r[8] * HH(2, 3);
   KK(5, 4) = r[6] * HH(0, 4) + r[7] * HH(1, 4) + r[8] * HH(2, 4) + r[0] * HH(6, 4) + r[1] * HH(7, 4) + r[2] * HH(8, 4);
   KK(5, 5) = r[6] * HH(0, 5) + r[7] * HH(1, 5) + r[8] * HH(2, 5) + r[0] * HH(6, 5) + r[1] * HH(7, 5) + r[2] * HH(8, 5);
-  // projector onto the null space of H; Pn is symmetric, columns stored as Pc[col][row]
-  double Pc[9][9];
-  for (int i = 0; i < 9; ++i)
-    for (int j = 0; j < 9; ++j) {
-      double acc = 0.0;
-      for (int k = 0; k < 6; ++k) acc += HH(i, k) * HH(j, k);
-      Pc[j][i] = ((i == j) ? 1.0 : 0.0) - acc;
+  // projector onto the null space of H, Pn = I - H H^T (symmetric; column j: Pn(i, j) = [i == j] - sum_k H(i, k) H(j, k)).
+  // The 9 x 9 array of the reference is not kept: three of its columns are picked by data-dependent indices, which forces a
+  // per-lane array into scratch memory (the candidate loop of k_sqp_c was bound by exactly that traffic).  Columns are
+  // recomputed where they are used -- the same expression, so the same bits: column i of a loop over i with compile-time
+  // indices, a picked column from the picked row of H (selected by compares, not by address).
+#define PN_COLUMN_STATIC(i, out)                                              \
+  _Pragma("unroll") for (int r_ = 0; r_ < 9; ++r_) {                           \
+    double acc_ = 0.0;                                                         \
+    _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) acc_ += HH(r_, k_) * HH(i, k_); \
+    out[r_] = ((r_ == (i)) ? 1.0 : 0.0) - acc_;                                \
+  }
+  auto pn_column_picked = [&](int idx, double* out) {
+    double hsel[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      double v = 0.0;
+#pragma unroll
+      for (int rr = 0; rr < 9; ++rr) v = (rr == idx) ? HH(rr, k) : v;
+      hsel[k] = v;
     }
+#pragma unroll
+    for (int rr = 0; rr < 9; ++rr) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc += HH(rr, k) * hsel[k];
+      out[rr] = ((rr == idx) ? 1.0 : 0.0) - acc;
+    }
+  };
   int index1 = -1, index2 = -1, index3 = -1;
   double max_norm1 = DBL_MIN, min_dot12 = DBL_MAX, min_dot1323 = DBL_MAX;
   double col_norms[9];
+#pragma unroll
   for (int i = 0; i < 9; ++i) {
-    col_norms[i] = norm9(Pc[i]);
+    double col[9];
+    PN_COLUMN_STATIC(i, col)
+    col_norms[i] = norm9(col);
     if (col_norms[i] >= norm_threshold && max_norm1 < col_norms[i]) { max_norm1 = col_norms[i]; index1 = i; }
   }
   if (index1 < 0) index1 = 0;   // the reference indexes with -1 here (undefined); never seen on rank-3 input
-  const double* v1 = Pc[index1];
+  double v1[9], v2[9], v3[9];
+  pn_column_picked(index1, v1);
+#pragma unroll
   for (int i = 0; i < 9; ++i) NN(i, 0) = v1[i] * (1.0 / max_norm1);
+  double c1v[9];   // |Pn_i . v1| / |Pn_i|: the second search reads the same values again
+#pragma unroll
   for (int i = 0; i < 9; ++i) {
+    c1v[i] = 0.0;
     if (i == index1) continue;
     if (col_norms[i] >= norm_threshold) {
-      const double c1 = fabs(dot9(Pc[i], v1) / col_norms[i]);
+      double col[9];
+      PN_COLUMN_STATIC(i, col)
+      const double c1 = fabs(dot9(col, v1) / col_norms[i]);
+      c1v[i] = c1;
       if (c1 <= min_dot12) { index2 = i; min_dot12 = c1; }
     }
   }
   if (index2 < 0) index2 = (index1 + 1) % 9;
-  const double* v2 = Pc[index2];
+  pn_column_picked(index2, v2);
   {
     double n0[9];
+#pragma unroll
     for (int i = 0; i < 9; ++i) n0[i] = NN(i, 0);
     const double d = dot9(v2, n0);
     double t[9];
+#pragma unroll
     for (int i = 0; i < 9; ++i) t[i] = v2[i] - d * n0[i];
     const double nrm = norm9(t);
+#pragma unroll
     for (int i = 0; i < 9; ++i) NN(i, 1) = t[i] / nrm;
   }
+#pragma unroll
   for (int i = 0; i < 9; ++i) {
     if (i == index2 || i == index1) continue;
     if (col_norms[i] >= norm_threshold) {
-      const double c1 = fabs(dot9(Pc[i], v1) / col_norms[i]);
-      const double c2 = fabs(dot9(Pc[i], v2) / col_norms[i]);
+      double col[9];
+      PN_COLUMN_STATIC(i, col)
+      const double c1 = c1v[i];
+      const double c2 = fabs(dot9(col, v2) / col_norms[i]);
       if (c1 + c2 <= min_dot1323) { index3 = i; min_dot1323 = c2 + c2; }   // sic (sqpnp_helper.cc:480)
     }
   }
   if (index3 < 0) index3 = (index2 + 1) % 9;
-  const double* v3 = Pc[index3];
+  pn_column_picked(index3, v3);
   {
     double n0[9], n1[9];
+#pragma unroll
     for (int i = 0; i < 9; ++i) { n0[i] = NN(i, 0); n1[i] = NN(i, 1); }
     const double d1 = dot9(v3, n1), d0 = dot9(v3, n0);
     double t[9];
+#pragma unroll
     for (int i = 0; i < 9; ++i) t[i] = v3[i] - (d1 * n1[i]) - (d0 * n0[i]);
     const double nrm = norm9(t);
+#pragma unroll
     for (int i = 0; i < 9; ++i) NN(i, 2) = t[i] / nrm;
   }
+#undef PN_COLUMN_STATIC
 #undef HH
 #undef KK
 #undef NN
@@ -890,8 +941,10 @@ __device__ __attribute__((noinline)) bool sqpnp_pre(int n, const double* feat, c
 }
 
 // Writes up to 18 solutions: quaternions [w x y z] (of the row-major rotation r_hat) and translations.
-__device__ __attribute__((noinline)) int sqpnp_post(const double* Om, const double* P, const double* mean, const double* U, const double* S,
-                                                   double* quats, double* ts) {
+// (the body is inlined into k_sqp_c: as a separate function it is compiled for the default 1024-thread workgroup, i.e. with a
+// budget of 128 VGPRs, and spent its time on ~2000 spill reloads per call; a 64-thread kernel may use the whole register file)
+__device__ __forceinline__ int sqpnp_post_impl(const double* Om, const double* P, const double* mean, const double* U, const double* S,
+                                               double* quats, double* ts) {
   using namespace sqp;
   int num_null = 0;
   while (num_null <= 7 && S[7 - num_null] < SQP_RANK_TOL) num_null++;
@@ -943,6 +996,10 @@ __device__ __attribute__((noinline)) int sqpnp_post(const double* Om, const doub
     for (int k = 0; k < 3; ++k) ts[3 * i + k] = sols[i].t[k];
   }
   return nsol;
+}
+__device__ __attribute__((noinline)) int sqpnp_post(const double* Om, const double* P, const double* mean, const double* U, const double* S,
+                                                   double* quats, double* ts) {
+  return sqpnp_post_impl(Om, P, mean, U, S, quats, ts);
 }
 
 // feat: n x [x y], world: n x [X Y Z].
