@@ -1312,7 +1312,8 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   DBuf<double> d_fp_ws, d_fp_sol; DBuf<int> d_fp_ok, d_fp_mask;   // five-point: stages a -> b -> c
   std::vector<double> h_dls_u; dls::GlibcRand dls_gen; std::vector<int> h_iter_base;
   DBuf<uint8_t> d_mask;
-  HBuf<int> h_samples, h_counts, h_ninl, h_active;   // pinned: sources / destinations of the per-round transfers
+  HBuf<int> h_samples2[2], h_counts, h_ninl, h_active2[2];   // pinned: sources / destinations of the per-round transfers (samples / active
+                                                             // counts twice: the next chunk's first round is drawn while the GPU works)
   HBuf<double> h_cost;
   const size_t lmed_lds = (size_t)nmax * sizeof(double);
   if (lmed) {
@@ -1421,47 +1422,58 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     return 0;
   };
   const bool host_timing = getenv("THEIA_HIP_RANSAC_TIMING") != nullptr;
+  // one round of a chunk on the host: iterations per problem and the sample stream (RandomSampler::Sample with its
+  // persistent permutation, PROSAC, EXHAUSTIVE); problems are independent (own generator, own slice): host threads share them
+  auto gen_round = [&](int c0, int cn, bool first, HBuf<int>& act, HBuf<int>& smp, int* B_out) -> int {
+    int B = 0;
+    if (!act.assign(cn, 0)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+    for (int q = 0; q < cn; ++q) {
+      ProblemState& s = S[c0 + q];
+      s.round_iters = 0;
+      if (s.done) continue;
+      const int cap = first ? first_round : next_round;
+      s.round_iters = std::min(cap, s.max_iterations - s.it);
+      act[q] = s.round_iters;
+      B = std::max(B, s.round_iters);
+    }
+    *B_out = B;
+    if (B == 0) return 0;
+    if (!smp.resize((size_t)cn * B * m)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+    host_parallel_for(cn, [&](int q) {
+      ProblemState& s = S[c0 + q];
+      int* out = smp.data() + (size_t)q * B * m;
+      for (int b = 0; b < s.round_iters; ++b) {
+        if (P.ransac_type == THEIA_RANSAC_PROSAC) { prosac_sample(s.rng, s.n, m, s.kth++, out + (size_t)b * m); continue; }
+        if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE) {   // all pairs (i, j > i), wrapping around
+          out[(size_t)b * 2] = s.ex_i; out[(size_t)b * 2 + 1] = s.ex_j;
+          if (++s.ex_j >= s.n) {
+            if (++s.ex_i >= s.n - 1) s.ex_i = 0;
+            s.ex_j = s.ex_i + 1;
+          }
+          continue;
+        }
+        for (int i = 0; i < m; ++i) {
+          std::swap(s.idx[i], s.idx[s.rng.rand_int(i, s.n - 1)]);
+          out[(size_t)b * m + i] = s.idx[i];
+        }
+      }
+      for (size_t e = (size_t)s.round_iters * m; e < (size_t)B * m; ++e) out[e] = 0;   // iterations beyond this problem's round
+    });
+    return 0;
+  };
+  int bufi = 0, pre_c0 = -1, pre_B = 0;   // pre_*: the first round of chunk pre_c0 already sits in buffer 1 - bufi
   for (int c0 = 0; c0 < nprob; c0 += chunk) {
     const int cn = std::min(chunk, nprob - c0);
     bool first = true;
     while (true) {
-      // iterations of this round per problem
       int B = 0;
-      if (!h_active.assign(cn, 0)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
-      for (int q = 0; q < cn; ++q) {
-        ProblemState& s = S[c0 + q];
-        s.round_iters = 0;
-        if (s.done) continue;
-        const int cap = first ? first_round : next_round;
-        s.round_iters = std::min(cap, s.max_iterations - s.it);
-        h_active[q] = s.round_iters;
-        B = std::max(B, s.round_iters);
-      }
+      const auto tp0 = std::chrono::steady_clock::now();
+      if (first && pre_c0 == c0) { bufi ^= 1; B = pre_B; pre_c0 = -1; }
+      else if ((rc = gen_round(c0, cn, first, h_active2[bufi], h_samples2[bufi], &B))) return rc;
+      HBuf<int>& h_active = h_active2[bufi];
+      HBuf<int>& h_samples = h_samples2[bufi];
       if (B == 0) break;
       first = false;
-      // the sample stream of the round (RandomSampler::Sample, persistent permutation)
-      const auto tp0 = std::chrono::steady_clock::now();
-      if (!h_samples.assign((size_t)cn * B * m, 0)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
-      // problems are independent (own generator, own slice): host threads share them out
-      host_parallel_for(cn, [&](int q) {
-        ProblemState& s = S[c0 + q];
-        int* out = h_samples.data() + (size_t)q * B * m;
-        for (int b = 0; b < s.round_iters; ++b) {
-          if (P.ransac_type == THEIA_RANSAC_PROSAC) { prosac_sample(s.rng, s.n, m, s.kth++, out + (size_t)b * m); continue; }
-          if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE) {   // all pairs (i, j > i), wrapping around
-            out[(size_t)b * 2] = s.ex_i; out[(size_t)b * 2 + 1] = s.ex_j;
-            if (++s.ex_j >= s.n) {
-              if (++s.ex_i >= s.n - 1) s.ex_i = 0;
-              s.ex_j = s.ex_i + 1;
-            }
-            continue;
-          }
-          for (int i = 0; i < m; ++i) {
-            std::swap(s.idx[i], s.idx[s.rng.rand_int(i, s.n - 1)]);
-            out[(size_t)b * m + i] = s.idx[i];
-          }
-        }
-      });
       const auto tp1 = std::chrono::steady_clock::now();
       const size_t nh = (size_t)cn * B;
       if ((rc = d_samples.ensure(nh * m)) || (rc = d_counts.ensure(nh)) || (rc = d_models.ensure(nh * kMaxModels * kStride)) ||
@@ -1569,6 +1581,12 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       HIP_TRYR(hipMemcpyAsync(h_cost.data(), d_cost.p, sizeof(double) * nh * kMaxModels, hipMemcpyDeviceToHost, st));
       HIP_TRYR(hipMemcpyAsync(h_ninl.data(), d_ninl.p, sizeof(int) * nh * kMaxModels, hipMemcpyDeviceToHost, st));
       HIP_TRYR(hipGetLastError());
+      // while the GPU fits and scores this round: the first round of the next chunk (its problems are not touched before)
+      if (pre_c0 < 0 && c0 + chunk < nprob) {
+        const int nc0 = c0 + chunk;
+        if ((rc = gen_round(nc0, std::min(chunk, nprob - nc0), true, h_active2[1 - bufi], h_samples2[1 - bufi], &pre_B))) return rc;
+        pre_c0 = nc0;
+      }
       HIP_TRYR(mine.wait(st));
       const auto tp2 = std::chrono::steady_clock::now();
       { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) fit_score_ms += ms;
