@@ -283,11 +283,21 @@ __device__ inline bool stage_a(WaveLds& L, int npts, const double* __restrict__ 
       }
       __syncthreads();
       const double rp = 1.0 / L.aug[k * kAugCols + k];
-      if (lane > k && lane < ncol)
-        for (int r = k + 1; r < nd; ++r) {
+      if (lane > k && lane < ncol) {
+        // four rows per step: the LDS reads of a step are in flight together (the rolled loop paid one LDS round trip per row)
+        int r = k + 1;
+        for (; r + 4 <= nd; r += 4) {
+          double lv[4], av[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { lv[u] = L.aug[(r + u) * kAugCols + k]; av[u] = L.aug[(r + u) * kAugCols + lane]; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) L.aug[(r + u) * kAugCols + lane] = av[u] - (lv[u] * rp) * pk;
+        }
+        for (; r < nd; ++r) {
           const double l = L.aug[r * kAugCols + k] * rp;
           L.aug[r * kAugCols + lane] -= l * pk;
         }
+      }
       __syncthreads();
     }
     // back-substitution, column oriented: solve x_c, then retire it from the rows above
