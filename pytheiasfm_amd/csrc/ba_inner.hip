@@ -384,8 +384,11 @@ __global__ __launch_bounds__(256) void k_inner_cam_blocks(InnerArgs A) {
   o[kCamRotGroup] = (double)g; o[39] = 0.0;
 }
 
+#ifndef THIP_INNER_TRACK_WAVES
+#define THIP_INNER_TRACK_WAVES 2   // measured at C4: 1.70 (one wave per SIMD), 1.67 (two), 1.73 (three), 1.80 ms (four) per LM iteration
+#endif
 template <int PD, bool ROT>
-__global__ __launch_bounds__(64) void k_inner_tracks(InnerArgs A) {
+__global__ __launch_bounds__(64, THIP_INNER_TRACK_WAVES) void k_inner_tracks(InnerArgs A) {
   if (!*A.gate) return;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= A.ntracks) return;

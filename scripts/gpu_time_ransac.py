@@ -9,8 +9,11 @@ leg = sys.argv[1] if len(sys.argv) > 1 else "five_point"
 NP = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 est, kind, thr = {"five_point": (ransac.EST_RELATIVE_POSE, "relative", (2.0 / 1000.0) ** 2),
                   "sqpnp": (ransac.EST_ABS_SQPNP, "absolute", (4.0 / 1000.0) ** 2),
-                  "kneip": (ransac.EST_ABS_KNEIP, "absolute", (4.0 / 1000.0) ** 2),
-                  "dls": (ransac.EST_ABS_DLS, "absolute", (4.0 / 1000.0) ** 2)}[leg]
+                  "dls": (ransac.EST_ABS_DLS, "absolute", (4.0 / 1000.0) ** 2),
+                  "fundamental": (ransac.EST_FUNDAMENTAL_MATRIX, "relative", (2.0 / 1000.0) ** 2),
+                  "homography": (ransac.EST_HOMOGRAPHY, "relative", (2.0 / 1000.0) ** 2),
+                  "essential": (ransac.EST_ESSENTIAL_MATRIX, "relative", (2.0 / 1000.0) ** 2),
+                  "kneip": (ransac.EST_ABS_KNEIP, "absolute", (4.0 / 1000.0) ** 2)}[leg]
 data, offsets, _ = synth.synth_ransac_v1(NP, 2000, kind, seed=0x5AC50005)
 p = ransac.RansacParameters(); p.error_thresh = thr; p.min_iterations = 4096; p.max_iterations = 4096; p.seed = 1
 ransac.estimate_batch(est, data[:offsets[8]], offsets[:9], p)
