@@ -822,6 +822,60 @@ __global__ __launch_bounds__(64) void k_fit5_c(int nprob, int B, const int64_t* 
   }
 }
 
+// ---- homography hypotheses in three stages (as SQPnP: the 9 x 9 Jacobi SVD of A^T A was 2.3 KB of dynamically indexed
+// per-lane arrays in scratch, 49 ns per hypothesis): M, T1, T2 per thread -> svd9_team with V -> H per thread.
+// ws per hypothesis: [M 81 | T1 9 | T2 9 | Hn 9]
+constexpr int kHomWs = 108;
+__global__ __launch_bounds__(64) void k_hom_a(int nprob, int B, const int64_t* __restrict__ offsets, const double* __restrict__ data,
+                                              const int* __restrict__ samples, const int* __restrict__ active_iters,
+                                              double* __restrict__ ws) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.y;
+  if (b >= B || p >= nprob || b >= active_iters[p]) return;
+  const size_t hyp = (size_t)p * B + b;
+  const double* pd = data + (size_t)offsets[p] * 4;
+  double subset[16], M[81], T1[9], T2[9];
+  for (int i = 0; i < 4; ++i) {
+    const int idx = samples[hyp * 4 + i];
+    for (int k = 0; k < 4; ++k) subset[i * 4 + k] = pd[(size_t)idx * 4 + k];
+  }
+  rsc::four_point_homography_pre(subset, M, T1, T2);
+  double* w = ws + hyp * kHomWs;
+  for (int k = 0; k < 81; ++k) w[k] = M[k];
+  for (int k = 0; k < 9; ++k) { w[81 + k] = T1[k]; w[90 + k] = T2[k]; }
+}
+__global__ __launch_bounds__(64) void k_hom_b(size_t nhyp, int B, const int* __restrict__ active_iters, double* __restrict__ ws) {
+  __shared__ double lds[kSqTeamsPerWave][81 + 81 + 81 + 9];   // W | U | V | S
+  const int team = threadIdx.x / kSqTeam, tl = threadIdx.x % kSqTeam;
+  if (team >= kSqTeamsPerWave) return;
+  const size_t hyp = (size_t)blockIdx.x * kSqTeamsPerWave + team;
+  if (hyp >= nhyp || (int)(hyp % B) >= active_iters[hyp / B]) return;
+  double* W = lds[team]; double* U = W + 81; double* V = U + 81; double* S = V + 81;
+  double* w = ws + hyp * kHomWs;
+  rsc::svd9_team(w, W, U, S, tl, V);
+  w[99 + tl] = V[9 * tl + 8];   // the last right singular vector
+}
+__global__ __launch_bounds__(64) void k_hom_c(int nprob, int B, const int* __restrict__ active_iters, const double* __restrict__ ws,
+                                              double* __restrict__ models, int* __restrict__ counts, int* __restrict__ dense_count,
+                                              int* __restrict__ tags, int* __restrict__ hyp_base) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.y;
+  if (b >= B || p >= nprob) return;
+  const size_t hyp = (size_t)p * B + b;
+  if (b >= active_iters[p]) { counts[hyp] = 0; return; }
+  const double* w = ws + hyp * kHomWs;
+  double Hn[9], T1[9], T2[9], H[9];
+  for (int k = 0; k < 9; ++k) { T1[k] = w[81 + k]; T2[k] = w[90 + k]; Hn[k] = w[99 + k]; }
+  rsc::four_point_homography_post(Hn, T1, T2, H);
+  counts[hyp] = 1;
+  const int base = atomicAdd(&dense_count[p], 1);
+  hyp_base[hyp] = base;
+  double* mo = models + ((size_t)p * B + base) * (size_t)kStride;   // max_models = 1
+  for (int k = 0; k < 9; ++k) mo[k] = H[k];
+  for (int k = 9; k < kStride; ++k) mo[k] = 0.0;
+  tags[(size_t)p * B + base] = b;
+}
+
 // ---- DLS-PnP hypotheses (estimate_calibrated_absolute_pose.cc:89-97): two kernels instead of k_fit (dls_device.h).
 // k_dls_a: one wave per (problem, iteration); uvals holds the four Macaulay terms of every DlsPnp call of a process
 // (iteration it of a problem = call it: the reference never seeds rand(), and one Estimate() is one process here).
@@ -1529,6 +1583,12 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         else
           k_fit5_c<THEIA_EST_ESSENTIAL_MATRIX><<<grid, 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_sol.p,
                                                                    d_fp_mask.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
+      } else if (est == THEIA_EST_HOMOGRAPHY && !getenv("THEIA_HIP_FIT_ONE_KERNEL")) {
+        if ((rc = d_fp_ws.ensure(nh * kHomWs))) return rc;
+        dim3 grid((B + 63) / 64, cn);
+        k_hom_a<<<grid, 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p);
+        k_hom_b<<<(unsigned)((nh + kSqTeamsPerWave - 1) / kSqTeamsPerWave), 64, 0, st>>>(nh, B, d_active.p, d_fp_ws.p);
+        k_hom_c<<<grid, 64, 0, st>>>(cn, B, d_active.p, d_fp_ws.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
       } else if (est == THEIA_EST_ABSOLUTE_POSE_SQPNP && !getenv("THEIA_HIP_FIT_ONE_KERNEL")) {
         if ((rc = d_fp_ws.ensure(nh * kSqWs)) || (rc = d_fp_ok.ensure(nh))) return rc;
         dim3 grid((B + 63) / 64, cn);

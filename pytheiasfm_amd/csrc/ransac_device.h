@@ -1395,6 +1395,33 @@ RDEV void inverse3(const double* m, double* inv) {
 // FourPointHomography for exactly 4 correspondences (sfm/pose/four_point_homography.cc:54-105):
 // normalised DLT, null vector = last right singular vector of A^T A.
 // corr: 4 x [x1 y1 x2 y2]; H row-major with x2 ~ H x1.
+// four_point_homography in two pieces around the 9 x 9 SVD (the RANSAC fit runs it by teams of lanes, svd_team.h):
+// M = A^T A of the normalised DLT system and the two normalisations, then H = T2^-1 Hn T1 from the last right singular vector
+RDEV void four_point_homography_pre(const double* corr, double* M, double* T1, double* T2) {
+  double n1[8], n2[8];
+  normalize_image_points(corr, 4, 4, n1, T1);
+  normalize_image_points(corr + 2, 4, 4, n2, T2);
+  double A[72];
+  for (int i = 0; i < 4; ++i) {
+    const double x1 = n1[2 * i], y1 = n1[2 * i + 1], x2 = n2[2 * i], y2 = n2[2 * i + 1];
+    double* r = A + 18 * i;
+    r[0] = 0.0; r[1] = 0.0; r[2] = 0.0; r[3] = -x1; r[4] = -y1; r[5] = -1.0; r[6] = x1 * y2; r[7] = y1 * y2; r[8] = y2;
+    r[9] = x1; r[10] = y1; r[11] = 1.0; r[12] = 0.0; r[13] = 0.0; r[14] = 0.0; r[15] = -x1 * x2; r[16] = -y1 * x2; r[17] = -x2;
+  }
+  for (int a = 0; a < 9; ++a)
+    for (int b = 0; b < 9; ++b) {
+      double s = 0.0;
+      for (int k = 0; k < 8; ++k) s += A[9 * k + a] * A[9 * k + b];
+      M[9 * a + b] = s;
+    }
+}
+RDEV void four_point_homography_post(const double* Hn, const double* T1, const double* T2, double* H) {
+  double T2i[9], tmp[9];
+  inverse3(T2, T2i);
+  matmul3(T2i, Hn, tmp);
+  matmul3(tmp, T1, H);
+}
+
 RDEV bool four_point_homography(const double* corr, double* H) {
   double n1[8], n2[8], T1[9], T2[9];
   normalize_image_points(corr, 4, 4, n1, T1);

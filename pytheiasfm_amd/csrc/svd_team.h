@@ -18,12 +18,14 @@ namespace thip {
 namespace rsc {
 
 // A: 81 doubles (row-major, global or LDS), W / U: 81 doubles of LDS each, S: 9 doubles of LDS.  tl in [0, 9).
+// V (optional, 81 doubles of LDS): the right singular vectors, accumulated and sorted as svd_sq<9> does.
 __device__ inline void svd9_team(const double* __restrict__ A, double* __restrict__ W, double* __restrict__ U,
-                                 double* __restrict__ S, int tl) {
+                                 double* __restrict__ S, int tl, double* __restrict__ V = nullptr) {
   constexpr int N = 9;
   for (int i = 0; i < N; ++i) {   // lane tl: column tl
     W[i * N + tl] = A[i * N + tl];
     U[i * N + tl] = (i == tl) ? 1.0 : 0.0;
+    if (V) V[i * N + tl] = (i == tl) ? 1.0 : 0.0;
   }
   team_sync();
   double scale = 0.0;
@@ -66,6 +68,10 @@ __device__ inline void svd9_team(const double* __restrict__ A, double* __restric
           {   // columns p, q of W (entry tl)
             const double a = W[tl * N + p], b = W[tl * N + q];
             W[tl * N + p] = jc * a - js * b; W[tl * N + q] = js * a + jc * b;
+            if (V) {
+              const double va = V[tl * N + p], vb = V[tl * N + q];
+              V[tl * N + p] = jc * va - js * vb; V[tl * N + q] = js * va + jc * vb;
+            }
           }
           team_sync();
           maxdiag = fmax(maxdiag, fmax(fabs(W[p * N + p]), fabs(W[q * N + q])));
@@ -85,6 +91,7 @@ __device__ inline void svd9_team(const double* __restrict__ A, double* __restric
     if (best != i) {
       if (tl == 0) { const double t = S[i]; S[i] = S[best]; S[best] = t; }
       const double t = U[tl * N + i]; U[tl * N + i] = U[tl * N + best]; U[tl * N + best] = t;
+      if (V) { const double v = V[tl * N + i]; V[tl * N + i] = V[tl * N + best]; V[tl * N + best] = v; }
     }
     team_sync();
   }
