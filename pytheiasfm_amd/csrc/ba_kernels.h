@@ -235,7 +235,7 @@ void chol_plan_solve(const CholPlan* plan, double* A, int lda, double* b, double
 // in wave order.  Ends with a workgroup barrier: the scalars are visible to every thread afterwards.
 __device__ __forceinline__ void reduce_tiles_body(int ntiles, const double* __restrict__ part, int nfields,
                                                   const int* __restrict__ f2s, const int* __restrict__ fmaxflag,
-                                                  double* __restrict__ scal, double (*sm)[16]) {
+                                                  double* __restrict__ scal, double (*sm)[16], bool atomic_max = false) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   double acc[8];
   bool ismax[8];
@@ -272,7 +272,10 @@ __device__ __forceinline__ void reduce_tiles_body(int ntiles, const double* __re
     const int f = threadIdx.x;
     double v = sm[f][0];
     for (int w = 1; w < 16; ++w) v = ismax[f] ? fmax(v, sm[f][w]) : v + sm[f][w];
-    if (ismax[f]) scal[f2s[f]] = fmax(scal[f2s[f]], v);
+    // atomic_max: other workgroups of the same launch fold their own maxima into the same scalar (non-negative values: the
+    // IEEE bit patterns order like the numbers; a maximum does not depend on the order of its operands)
+    if (ismax[f] && atomic_max) { if (v == v) atomicMax(reinterpret_cast<unsigned long long*>(&scal[f2s[f]]), (unsigned long long)__double_as_longlong(v)); }
+    else if (ismax[f]) scal[f2s[f]] = fmax(scal[f2s[f]], v);
     else scal[f2s[f]] += v;
   }
   __threadfence_block();

@@ -844,33 +844,23 @@ __global__ __launch_bounds__(256) void k_reduce_tiles_stage1(int ntiles, const d
 
 // Add the LM diagonal to the camera-side blocks (intrinsics + extrinsics) and
 // fold their gradient into the gradient max-norm: S_dd += clamp(colsq_d) / radius.
-// One workgroup of 1024 threads; with tile_part it starts with the tile reduction of the linearisation.
+// ceil(n / 1024) workgroups of 1024 threads, one diagonal entry per thread (the entries are n + 1 doubles apart: one cache
+// line each -- a single workgroup over n = 6000 was bound by what one CU keeps in flight, 22 us); with tile_part workgroup 0
+// starts with the tile reduction of the linearisation.  The maxima meet in scal[SC_GMAX] through an atomic maximum.
 __global__ __launch_bounds__(1024) void k_finalize_rcs(DevProblem P, const double* __restrict__ radius_p, double* __restrict__ S,
                                                        const double* __restrict__ colsq, const double* __restrict__ gc,
                                                        double* __restrict__ scal, int ntiles, const double* __restrict__ tile_part,
                                                        const int* __restrict__ f2s, const int* __restrict__ fmaxflag) {
-  __shared__ double sm[1024];
+  __shared__ double sm[16];
   __shared__ double smr[8][16];
-  if (tile_part) reduce_tiles_body(ntiles, tile_part, 4, f2s, fmaxflag, scal, smr);
+  if (tile_part && blockIdx.x == 0) reduce_tiles_body(ntiles, tile_part, 4, f2s, fmaxflag, scal, smr, true);
   const double radius = *radius_p;
   double gmax = 0.0;
-  // eight diagonal entries per thread and pass, every load issued before the first store (a read-modify-write loop over
-  // S would take one memory round trip per entry: the compiler cannot move a load of S above the previous store to S)
-  for (int base = 0; base < P.n; base += 8 * 1024) {
-    double sv[8], cv[8], gv[8], sr[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int d = min(base + k * 1024 + (int)threadIdx.x, P.n - 1);
-      sv[k] = S[(size_t)d * P.n + d]; cv[k] = colsq[d]; gv[k] = gc[d]; sr[k] = P.scale_red[d];
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int d = base + k * 1024 + (int)threadIdx.x;
-      if (d < P.n) {
-        S[(size_t)d * P.n + d] = sv[k] + fmin(fmax(cv[k], 1e-6), 1e32) / radius;
-        gmax = fmax(gmax, fabs(gv[k] / sr[k]));
-      }
-    }
+  const int d = blockIdx.x * 1024 + (int)threadIdx.x;
+  if (d < P.n) {
+    const double sv = S[(size_t)d * P.n + d], cv = colsq[d], gv = gc[d], sr = P.scale_red[d];
+    S[(size_t)d * P.n + d] = sv + fmin(fmax(cv, 1e-6), 1e32) / radius;
+    gmax = fabs(gv / sr);
   }
   gmax = wave_max(gmax);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = gmax;
@@ -878,7 +868,7 @@ __global__ __launch_bounds__(1024) void k_finalize_rcs(DevProblem P, const doubl
   if (threadIdx.x == 0) {
     double v = sm[0];
     for (int w = 1; w < 16; ++w) v = fmax(v, sm[w]);
-    scal[SC_GMAX] = fmax(scal[SC_GMAX], v);
+    if (v == v) atomicMax(reinterpret_cast<unsigned long long*>(&scal[SC_GMAX]), (unsigned long long)__double_as_longlong(v));   // (fmax drops a NaN too)
   }
 }
 
@@ -1549,7 +1539,7 @@ void launch_reduce_tiles_stage1(int ntiles, const double* tile_part, int nfields
 
 void launch_finalize_rcs(const DevProblem& P, const double* radius, const ReduceBuf& rb, hipStream_t st, int ntiles,
                          const double* tile_part, const int* f2s, const int* fmaxflag) {
-  k_finalize_rcs<<<1, 1024, 0, st>>>(P, radius, rb.S, rb.colsq, rb.gc, rb.scal, ntiles, tile_part, f2s, fmaxflag);
+  k_finalize_rcs<<<std::max(1, (P.n + 1023) / 1024), 1024, 0, st>>>(P, radius, rb.S, rb.colsq, rb.gc, rb.scal, ntiles, tile_part, f2s, fmaxflag);
 }
 
 void launch_cam_update(const DevProblem& P, const double* cam, const double* y, double* cand_cam,
