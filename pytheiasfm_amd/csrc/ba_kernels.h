@@ -223,7 +223,8 @@ struct CholPlan;
 CholPlan* chol_plan_create(int n, const uint8_t* adj);
 void chol_plan_destroy(CholPlan* plan);
 // zero the tiles of A the plan's assembly / factorisation touch; false = dense plan (the caller clears everything)
-bool chol_plan_clear(const CholPlan* plan, double* A, int lda, hipStream_t st);
+// tail / tail_count: a vector of doubles to zero in the same launch (null / 0: none)
+bool chol_plan_clear(const CholPlan* plan, double* A, int lda, hipStream_t st, double* tail = nullptr, size_t tail_count = 0);
 int chol_plan_levels(const CholPlan* plan);
 double chol_plan_flops(const CholPlan* plan);   // FP64 flops of one solve on the plan (n^3 / 3 for the dense schedule)
 void chol_plan_solve(const CholPlan* plan, double* A, int lda, double* b, double* work, double* fail_flag, hipStream_t st);

@@ -658,9 +658,9 @@ int enqueue_linearize(theia_ba_handle_s* h, int slot = 0) {
   h->P.intr = h->intr[h->cur].p; h->P.intr_cand = h->intr[1 - h->cur].p;
   // clear the reduced system: the tiles the K3 plan knows (assembly + fill) and the vector tail; everything else in
   // the n x n buffer is never written (it was zeroed once at create())
-  if (h->n > 0 && !(h->allreduce && h->n_pack_tiles == 0) && chol_plan_clear(h->plan, h->rb.S, h->n, h->stream))
-    HIP_TRY(hipMemsetAsync(h->rb.rhs, 0, sizeof(double) * (h->reduce.n - (size_t)h->n * h->n), h->stream));
-  else
+  if (h->n > 0 && !(h->allreduce && h->n_pack_tiles == 0) &&
+      chol_plan_clear(h->plan, h->rb.S, h->n, h->stream, h->rb.rhs, h->reduce.n - (size_t)h->n * h->n)) {
+  } else
     HIP_TRY(hipMemsetAsync(h->reduce.p, 0, sizeof(double) * h->reduce.n, h->stream));
   if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][4], h->stream));
   launch_linearize(h->P, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->tile_part.p, h->stream);

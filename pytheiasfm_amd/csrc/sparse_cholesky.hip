@@ -557,7 +557,15 @@ CholPlan* chol_plan_create(int n, const uint8_t* adj) {
 }
 
 namespace {
-__global__ __launch_bounds__(256) void k_sp_clear(double* __restrict__ A, int lda, const int* __restrict__ items) {
+// blocks [0, nclear): one structure tile each; blocks beyond: the vector tail behind the matrix (rhs | colsq | gc | scalars),
+// 4096 doubles per block -- the memset that used to follow as its own 4.7-us fill kernel
+__global__ __launch_bounds__(256) void k_sp_clear(double* __restrict__ A, int lda, const int* __restrict__ items, int nclear,
+                                                  double* __restrict__ tail, size_t tail_count) {
+  if ((int)blockIdx.x >= nclear) {
+    const size_t b0 = (size_t)(blockIdx.x - nclear) * 4096;
+    for (size_t e = b0 + threadIdx.x; e < tail_count && e < b0 + 4096; e += 256) tail[e] = 0.0;
+    return;
+  }
   const int* it = items + 4 * blockIdx.x;
   const int r0 = it[0], h = it[1], c0 = it[2], w = it[3];
   for (int e = threadIdx.x; e < NB * NB; e += 256) {
@@ -567,9 +575,10 @@ __global__ __launch_bounds__(256) void k_sp_clear(double* __restrict__ A, int ld
 }
 }  // namespace
 
-bool chol_plan_clear(const CholPlan* pl, double* A, int lda, hipStream_t st) {
+bool chol_plan_clear(const CholPlan* pl, double* A, int lda, hipStream_t st, double* tail, size_t tail_count) {
   if (!pl || pl->dense || pl->nclear == 0) return false;
-  k_sp_clear<<<pl->nclear, 256, 0, st>>>(A, lda, pl->prog + pl->clear_off);
+  const int tb = tail ? (int)((tail_count + 4095) / 4096) : 0;
+  k_sp_clear<<<pl->nclear + tb, 256, 0, st>>>(A, lda, pl->prog + pl->clear_off, pl->nclear, tail, tail_count);
   return true;
 }
 
