@@ -290,13 +290,17 @@ __device__ __forceinline__ void potrf64_wg_core(double* __restrict__ A, int lda,
       double rs[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        double d = readlane_d(r16[j], c0 + j);
+        // column j goes through LDS: every lane stores its entry, the pivot and the 15 - j multipliers come back as
+        // broadcast reads (one ds_read_b64 each, issued back to back) instead of two v_readlane + hazard slots per value
+        Ls[i][c0 + j] = r16[j];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        double d = Ls[c0 + j][c0 + j];
         if (!(d > 0.0)) { bad = 1; d = 1.0; }
         // products s_ij s_kj first (they do not wait for 1 / d); the chain per column is then
         // pivot -> rcp -> one Newton step (v_rcp_f64 carries ~26 bits, one step leaves < 2 ulp) -> one FMA
         double pk[16];
 #pragma unroll
-        for (int k = j + 1; k < 16; ++k) pk[k] = r16[j] * readlane_d(r16[j], c0 + k);
+        for (int k = j + 1; k < 16; ++k) pk[k] = r16[j] * Ls[c0 + k][c0 + j];
         double w = __builtin_amdgcn_rcp(d);
         w = __builtin_fma(w, __builtin_fma(-d, w, 1.0), w);
 #pragma unroll
