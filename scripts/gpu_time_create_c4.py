@@ -1,0 +1,12 @@
+"""GPU box: handle creation time at C4 (host-side plan), with THEIA_HIP_CREATE_TIMING=1 the stages are printed."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pytheiasfm_amd import ba, synth
+p = synth.ba_config("C4")
+o = ba.default_options(); o.max_num_iterations = 8
+if len(sys.argv) > 1:
+    o.intrinsics_to_optimize = int(sys.argv[1], 0)
+h = ba.BaHandle(p.copy(), o); h.close()
+for _ in range(3):
+    t0 = time.perf_counter(); h = ba.BaHandle(p.copy(), o); dt = time.perf_counter() - t0; h.close()
+    print("C4 handle creation %.1f ms" % (1e3 * dt), flush=True)

@@ -26,7 +26,9 @@ def _compare(g, o):
     (qg, sg, tg), (qo, so, to) = g, o
     assert sg.success and so.success and sg.num_iterations == so.num_iterations
     assert list(tg.accepted) == list(to.accepted)
-    assert np.allclose(tg.cost, to.cost, rtol=1e-9) and np.allclose(tg.gradient_max_norm, to.gradient_max_norm, rtol=1e-6, atol=1e-9)
+    # (the device sums with FP64 atomics: a gradient eight orders below its start carries their rounding, run to run)
+    assert np.allclose(tg.cost, to.cost, rtol=1e-9)
+    assert np.allclose(tg.gradient_max_norm, to.gradient_max_norm, rtol=1e-6, atol=1e-9 * max(1.0, float(to.gradient_max_norm[0])))
     assert np.abs(qg.cam_ext - qo.cam_ext).max() <= 1e-8 and np.abs(qg.point_inverse_depth - qo.point_inverse_depth).max() <= 1e-8
     assert np.allclose(qg.intrinsics, qo.intrinsics, rtol=1e-9, atol=1e-12)
 
