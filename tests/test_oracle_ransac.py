@@ -12,7 +12,7 @@ import pytest
 import ctypes as C
 
 from pytheiasfm_amd import _capi as capi, synth
-from tests import oracle_lib as ol
+from tests import oracle_lib as ol, p4pf_scenes as ps
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -1089,3 +1089,63 @@ def test_estimate_similarity_transformation_2d_3d_with_outliers():
     sure = np.abs(e - 9.0) > 1e-6
     assert np.array_equal(expect[sure], o["inlier_mask"].astype(bool)[sure])
     assert o["inlier_mask"][~truth["outlier"]].mean() > 0.9 and o["inlier_mask"][truth["outlier"]].mean() < 0.1
+
+
+# ---------------------------------------------------------------- P4Pf (uncalibrated absolute pose)
+def _best_reprojection(models, X, px):
+    errs = [np.linalg.norm(ps.project(m[:12].reshape(3, 4), X) - px, axis=1).max() for m in models]
+    return (min(errs), int(np.argmin(errs))) if errs else (np.inf, -1)
+
+
+def test_p4pf_reference_basic_vectors():
+    """four_point_focal_length_test.cc:119-146 (BasicTest): f = 800, the listed pose and four world points; one of the
+    solutions reprojects the four points within 1e-4 px (BasicTest) / 10 px with 0.5 px noise (BasicNoiseTest)."""
+    P, X, px = ps.basic_scene()
+    m = ol.estimate_models(ps.EST, np.concatenate([px, X], axis=1))
+    assert 1 <= len(m) <= 10
+    err, j = _best_reprojection(m, X, px)
+    assert err < 1e-4
+    Pm = m[j][:12].reshape(3, 4)
+    assert abs(np.linalg.norm(Pm[0, :3]) - 800.0) < 1e-6 and np.abs(Pm / Pm[2, 3] - P / P[2, 3]).max() < 1e-6
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        noisy = px + rng.normal(0.0, 0.5, px.shape)
+        err, _ = _best_reprojection(ol.estimate_models(ps.EST, np.concatenate([noisy, X], axis=1)), X, noisy)
+        assert err < 10.0
+
+
+def test_p4pf_random_scenes_and_the_action_matrix():
+    """RandomTest (:148-187, tolerance 0.1 px) over 200 scenes, and the elimination itself: the action matrix of z has the
+    depth of the fourth point as an eigenvalue with eigenvector [1, z, y, x, w, ...] of the true solution."""
+    rng = np.random.default_rng(7)
+    errs, resid = [], []
+    for _ in range(300):
+        P, X, px, focal = ps.random_scene(rng)
+        sub = np.concatenate([px, X], axis=1)
+        errs.append(_best_reprojection(ol.estimate_models(ps.EST, sub), X, px)[0])
+        T = np.zeros((10, 10))
+        assert ol.rlib().oracle_p4pf_action(capi.ptr(np.ascontiguousarray(sub), C.c_double), capi.ptr(T, C.c_double)) == 1
+        depth = (P @ np.concatenate([X, np.ones((4, 1))], axis=1).T)[2]
+        fvar = np.linalg.norm(px, axis=1).mean()
+        x, y, z, w = depth[1] / depth[0], depth[2] / depth[0], depth[3] / depth[0], (focal / fvar) ** 2
+        v = np.array([1.0, z, y, x, w, z * z, y * z, x * z, w * z, w * y])
+        resid.append(np.abs(T @ v - z * v).max() / (abs(z) * np.abs(v).max()))
+    errs, resid = np.array(errs), np.array(resid)
+    assert np.median(errs) < 1e-7 and np.mean(errs < 0.1) >= 0.99   # a minimal solver: a few ill-conditioned draws in a thousand
+    assert np.median(resid) < 1e-10 and np.percentile(resid, 99) < 1e-5
+
+
+def test_estimate_uncalibrated_absolute_pose_with_outliers():
+    """EstimateUncalibratedAbsolutePose through the oracle's RANSAC loop: 150 correspondences, 30 % outliers, 0.5 px noise;
+    the inlier set equals a numpy statement of the squared reprojection error of the winning projection matrix."""
+    rng = np.random.default_rng(11)
+    data, P, focal, good = ps.ransac_scene(rng, 150)
+    pc = ol.default_ransac_params(2.0 ** 2, seed=5); pc.failure_probability = 1e-3
+    o = ol.ransac_estimate(ps.EST, data, pc)
+    assert o["success"]
+    Pm = o["model"][:12].reshape(3, 4)
+    assert abs(np.linalg.norm(Pm[0, :3]) / np.linalg.norm(Pm[2, :3]) - focal) < 0.03 * focal
+    e = np.sum((ps.project(Pm, data[:, 2:5]) - data[:, :2]) ** 2, axis=1)
+    sure = np.abs(e - 4.0) > 1e-6
+    assert np.array_equal((e < 4.0)[sure], o["inlier_mask"].astype(bool)[sure])
+    assert o["inlier_mask"][good].mean() > 0.85 and o["inlier_mask"][~good].mean() < 0.05
