@@ -560,7 +560,14 @@ enum {
    * generalised cost matrix; Macaulay terms of one Estimate() counted from 0 as for DLS), up to 27 models; Error = squared
    * pixel error of the camera moved by the transformation (TransformCamera), DBL_MAX behind it.
    * model = SimilarityTransformation: rotation (9, row-major), translation (3), scale. */
-  THEIA_EST_SIMILARITY_2D3D = 13
+  THEIA_EST_SIMILARITY_2D3D = 13,
+  /* EstimateUncalibratedAbsolutePose (estimate_uncalibrated_absolute_pose.cc:60-141): datum = FeatureCorrespondence2D3D
+   * [u v X Y Z] with the principal point removed from the pixel; sample = 4; EstimateModel = FourPointPoseAndFocalLength
+   * (P4Pf, four_point_focal_length.cc:100-222), up to 10 models; Error = squared reprojection error of the projection
+   * matrix (:88-97, no cheirality test).  model = the 3 x 4 projection matrix K [R | t], row-major (12 doubles); the
+   * reference's DecomposeProjectionMatrix step (:124-138: rotation, position, focal length) is left to the caller (the
+   * Python mirror does it).  The elimination template is not the reference's generated one. */
+  THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE = 14
 };
 
 /* A batch of independent estimation problems ("pairs").  Datum layout:
@@ -572,7 +579,8 @@ enum {
  *   dominant plane: Eigen::Vector3d = [X Y Z]
  *   triangulation: one observation with its camera, 33 doubles (THEIA_EST_TRIANGULATION)
  *   radial-distortion homography: RadialDistortionFeatureCorrespondence, 12 doubles (THEIA_EST_RADIAL_HOMOGRAPHY)
- *   similarity 2D-3D: CameraAndFeatureCorrespondence2D3D, 26 doubles (THEIA_EST_SIMILARITY_2D3D) */
+ *   similarity 2D-3D: CameraAndFeatureCorrespondence2D3D, 26 doubles (THEIA_EST_SIMILARITY_2D3D)
+ *   uncalibrated absolute pose: FeatureCorrespondence2D3D = [u v X Y Z], pixels with the principal point removed */
 typedef struct theia_ransac_batch {
   int32_t estimator;           /* THEIA_EST_*                              */
   int32_t num_problems;
@@ -591,7 +599,8 @@ typedef struct theia_ransac_batch {
  *   FUNDAMENTAL_MATRIX / HOMOGRAPHY: 3x3 row-major                  = 9
  *   DOMINANT_PLANE:   point(3) unit_normal(3)                       = 6
  *   RELATIVE_POSE_KNOWN_ORIENTATION: unit position of camera 2      = 3
- *   UNCALIBRATED_RELATIVE_POSE: F(9) R(9) position(3) focal_length1 focal_length2 = 23 */
+ *   UNCALIBRATED_RELATIVE_POSE: F(9) R(9) position(3) focal_length1 focal_length2 = 23
+ *   UNCALIBRATED_ABSOLUTE_POSE: projection matrix 3 x 4, row-major    = 12 */
 #define THEIA_RANSAC_MODEL_STRIDE 24
 typedef struct theia_ransac_result {
   int32_t* success;            /* [num_problems] Estimate() return value; 0 (with no inliers and a zero
@@ -650,6 +659,11 @@ int theia_hip_dls_pnp(int32_t num, const int64_t* offsets, const double* feature
                       const double* world_points, const int64_t* call_index,
                       double* quaternions, double* translations, int32_t* num_solutions);
 void theia_hip_dls_macaulay_terms(int64_t first_call, int64_t num_calls, double* out);
+/* P4Pf (FourPointPoseAndFocalLength, sfm/pose/four_point_focal_length.cc:100-222; bound in pose_wrapper.cc), batched:
+ * corr2d3d = [num][4][5] (u v X Y Z, principal point removed), projection_matrices = [num][10][12] (3 x 4 row-major,
+ * zero padded), num_solutions[num] (0 for a degenerate sample; the reference returns -1 there). */
+int theia_hip_four_point_pose_and_focal_length(int32_t num, const double* corr2d3d, double* projection_matrices,
+                                               int32_t* num_solutions);
 
 /* The batch entry points above keep their device workspace and the pinned host blocks of their per-round transfers in
  * process-wide caches between calls (up to 6 GiB of device memory and 2 GiB of pinned host memory); the buffers of a

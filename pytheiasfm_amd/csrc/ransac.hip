@@ -31,6 +31,7 @@
 #include "eig_team.h"
 #include "fit5_team.h"
 #include "svd_team.h"
+#include "p4pf_device.h"
 #include "theia_hip.h"
 #include <atomic>
 #include <mutex>
@@ -47,6 +48,7 @@ constexpr int kMaxCap = 18;   // largest EstimateModel output of the thread-per-
 __host__ __device__ inline int max_models(int est) {
   if (est == THEIA_EST_RADIAL_HOMOGRAPHY) return 2;
   if (est == THEIA_EST_SIMILARITY_2D3D) return dlsdev::kMaxSolutions;
+  if (est == THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE) return 10;
   if (est >= THEIA_EST_FUNDAMENTAL_MATRIX) return 1;
   if (est == THEIA_EST_ABSOLUTE_POSE_DLS) return dlsdev::kMaxSolutions;
   return est == THEIA_EST_ABSOLUTE_POSE_SQPNP ? 18 : (est == THEIA_EST_ABSOLUTE_POSE_KNEIP ? 4 : 10);
@@ -57,7 +59,7 @@ __host__ __device__ inline int sample_size(int est) {
   switch (est) {
     case THEIA_EST_RELATIVE_POSE: case THEIA_EST_ESSENTIAL_MATRIX: return 5;
     case THEIA_EST_FUNDAMENTAL_MATRIX: case THEIA_EST_UNCALIBRATED_RELATIVE_POSE: return 8;
-    case THEIA_EST_HOMOGRAPHY: case THEIA_EST_SIMILARITY_2D3D: return 4;
+    case THEIA_EST_HOMOGRAPHY: case THEIA_EST_SIMILARITY_2D3D: case THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE: return 4;
     case THEIA_EST_RADIAL_HOMOGRAPHY: return 6;
     case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION:
     case THEIA_EST_TRIANGULATION: return 2;
@@ -70,6 +72,7 @@ inline int model_doubles(int est) {
     case THEIA_EST_RELATIVE_POSE: return 21;
     case THEIA_EST_UNCALIBRATED_RELATIVE_POSE: return 23;
     case THEIA_EST_ABSOLUTE_POSE_KNEIP: case THEIA_EST_ABSOLUTE_POSE_DLS: case THEIA_EST_ABSOLUTE_POSE_SQPNP: return 12;
+    case THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE: return 12;   // projection matrix, row-major 3 x 4
     case THEIA_EST_DOMINANT_PLANE: return 6;
     case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: return 3;
     case THEIA_EST_TRIANGULATION: return 4;
@@ -83,7 +86,7 @@ constexpr int kSimDatum = 26;   // CameraAndFeatureCorrespondence2D3D row of THE
 __host__ __device__ inline int datum_size(int est) {
   switch (est) {
     case THEIA_EST_ABSOLUTE_POSE_KNEIP: case THEIA_EST_ABSOLUTE_POSE_DLS: case THEIA_EST_ABSOLUTE_POSE_SQPNP:
-    case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: return 5;
+    case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: case THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE: return 5;
     case THEIA_EST_DOMINANT_PLANE: return 3;
     case THEIA_EST_TRIANGULATION: return kTriDatum;
     case THEIA_EST_RADIAL_HOMOGRAPHY: return rsc::kRadHomDatum;
@@ -218,6 +221,7 @@ __device__ inline double similarity_error(const double* m, const double* d) {
 }
 
 __device__ inline double model_error(int est, const double* m, const double* d) {
+  if (est == THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE) return p4pfdev::reprojection_error(m, d);
   if (est == THEIA_EST_SIMILARITY_2D3D) return similarity_error(m, d);
   if (est == THEIA_EST_TRIANGULATION) return triangulation_error(m, d);
   if (est == THEIA_EST_RADIAL_HOMOGRAPHY) return rsc::radial_homography_error(m, d);
@@ -676,6 +680,7 @@ __global__ __launch_bounds__(64, 4) void k_fit5_a_team(int nprob, int B, const i
 // the eigen-iteration is one dependent chain per matrix -- i.e. by LDS per matrix: 1.8 KB here (87 matrices per CU), and
 // the same time with 16 or 8 lanes per team (measured), so the narrower team only halves the LDS per wave.
 constexpr int kFpTeam = 8, kFpTeamsPerWave = 64 / kFpTeam;
+template <bool P4PF = false>   // P4PF: the same eigen stage for the P4Pf action matrix; sol = rows 0..4 of the real eigenvectors
 __global__ __launch_bounds__(64) void k_fit5_b(size_t nhyp, const int* __restrict__ ok, double* __restrict__ ws,
                                                double* __restrict__ sol, int* __restrict__ solmask) {
   __shared__ double lds[kFpTeamsPerWave][230];   // H (100) | V (100) | wr | wi | ort
@@ -692,9 +697,13 @@ __global__ __launch_bounds__(64) void k_fit5_b(size_t nhyp, const int* __restric
   int bit = 0;
   for (int c = tl; c < 10; c += kFpTeam)
     if (good && wi[c] == 0.0) {   // only real solutions (five_point_relative_pose.cc:281-284)
-      double v4[4];
-      rsc::five_point_v4(V, c, v4);
-      for (int k = 0; k < 4; ++k) sol[(hyp * 10 + c) * 4 + k] = v4[k];
+      if (P4PF) {
+        for (int k = 0; k < 5; ++k) sol[(hyp * 10 + c) * 5 + k] = V[k * 10 + c];
+      } else {
+        double v4[4];
+        rsc::five_point_v4(V, c, v4);
+        for (int k = 0; k < 4; ++k) sol[(hyp * 10 + c) * 4 + k] = v4[k];
+      }
       bit |= 1 << c;
     }
   for (int o = kFpTeam / 2; o >= 1; o >>= 1) bit |= __shfl_xor(bit, o, kFpTeam);
@@ -818,6 +827,58 @@ __global__ __launch_bounds__(64) void k_fit5_c(int nprob, int B, const int64_t* 
   int* tg = tags + (size_t)p * B * mm + base;
   for (int j = 0; j < nm; ++j) {
     for (int k = 0; k < kStride; ++k) mo[j * kStride + k] = mloc[j * kStride + k];
+    tg[j] = b * mm + j;
+  }
+}
+
+// ---- P4Pf hypotheses (uncalibrated absolute pose) in three stages (p4pf_device.h): the transposed elimination template by one
+// workgroup per hypothesis in LDS -> the five-point kernel's 10 x 10 eigen stage -> one thread per hypothesis for the
+// projection matrices.  ws per hypothesis: [normalisation 36 | action matrix 100] (the five-point layout: kFpWs).
+static_assert(p4pfdev::kWs == kFpWs, "the P4Pf workspace row shares the five-point eigen stage");
+__global__ __launch_bounds__(p4pfdev::kThreads) void k_p4pf_a(int nprob, int B, const int64_t* __restrict__ offsets, const double* __restrict__ data,
+                                                            const int* __restrict__ samples, const int* __restrict__ active_iters,
+                                                            double* __restrict__ ws, int* __restrict__ ok) {
+  extern __shared__ __attribute__((aligned(16))) double sm_p4pf[];
+  const size_t hyp = blockIdx.x;
+  const int p = (int)(hyp / B), b = (int)(hyp % B);
+  if (b >= active_iters[p]) { if (threadIdx.x == 0) ok[hyp] = 0; return; }
+  const bool good = p4pfdev::p4pf_action_wg(data + (size_t)offsets[p] * 5, samples + hyp * 4, sm_p4pf, ws + hyp * kFpWs);
+  if (threadIdx.x == 0) ok[hyp] = good ? 1 : 0;
+}
+
+__global__ __launch_bounds__(64) void k_p4pf_c(int nprob, int B, const int* __restrict__ active_iters, const double* __restrict__ ws,
+                                               const double* __restrict__ sol, const int* __restrict__ solmask, double* __restrict__ models,
+                                               int* __restrict__ counts, int* __restrict__ dense_count, int* __restrict__ tags,
+                                               int* __restrict__ hyp_base) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.y;
+  if (b >= B || p >= nprob) return;
+  const size_t hyp = (size_t)p * B + b;
+  if (b >= active_iters[p]) { counts[hyp] = 0; return; }
+  const int mask = solmask[hyp];
+  if (!mask) { counts[hyp] = 0; return; }
+  double N[p4pfdev::kNorm];
+  for (int k = 0; k < p4pfdev::kNorm; ++k) N[k] = ws[hyp * kFpWs + k];
+  double mloc[10 * 12];
+  int nm = 0;
+  for (int i = 0; i < 10; ++i) {
+    if (!((mask >> i) & 1)) continue;
+    const double* v = sol + (hyp * 10 + i) * 5;
+    const double w = v[4] / v[0];
+    if (!(w >= 0.0)) continue;   // negative or NaN focal length^2 (four_point_focal_length_helper.cc:917-921)
+    p4pfdev::projection_from_solution(N, w, v[3] / v[0], v[2] / v[0], v[1] / v[0], mloc + 12 * nm);
+    nm++;
+  }
+  counts[hyp] = nm;
+  if (nm == 0) return;
+  const int mm = 10;
+  const int base = atomicAdd(&dense_count[p], nm);
+  hyp_base[hyp] = base;
+  double* mo = models + ((size_t)p * B * mm + base) * (size_t)kStride;
+  int* tg = tags + (size_t)p * B * mm + base;
+  for (int j = 0; j < nm; ++j) {
+    for (int k = 0; k < 12; ++k) mo[j * kStride + k] = mloc[j * 12 + k];
+    for (int k = 12; k < kStride; ++k) mo[j * kStride + k] = 0.0;
     tg[j] = b * mm + j;
   }
 }
@@ -1077,6 +1138,17 @@ __global__ __launch_bounds__(64) void k_dls_solve_b(int num, const int64_t* __re
 }
 
 // the index tables of the polynomial system live in constant memory, built once per process
+// k_p4pf_a needs 70 KB of dynamic LDS (above the 64 KB default)
+int p4pf_kernel_ready() {
+  static std::once_flag once;
+  static int status = 0;
+  std::call_once(once, [] {
+    const hipError_t e = hipFuncSetAttribute((const void*)k_p4pf_a, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p4pfdev::kLdsBytes);
+    if (e != hipSuccess) status = set_error(THEIA_HIP_ERR_NO_DEVICE, hipGetErrorString(e));
+  });
+  return status;
+}
+
 int ensure_dls_tables() {
   static std::once_flag once;
   static int rc = 0;
@@ -1291,12 +1363,13 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   }
   const bool gdls_est = est == THEIA_EST_SIMILARITY_2D3D;
   const bool dls_est = est == THEIA_EST_ABSOLUTE_POSE_DLS || gdls_est;   // the Macaulay pipeline: stage A -> eigen stage
-  if (est < 0 || est > THEIA_EST_SIMILARITY_2D3D) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
+  if (est < 0 || est > THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
   const bool abs_pose = est == THEIA_EST_ABSOLUTE_POSE_KNEIP || est == THEIA_EST_ABSOLUTE_POSE_SQPNP || (dls_est && !gdls_est);
   // estimators that keep Estimator::RefineModel's default "return true" (solvers/estimator.h:86-88): LO only counts
   const bool trivial_refine = est == THEIA_EST_ESSENTIAL_MATRIX || est == THEIA_EST_DOMINANT_PLANE ||
                               est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION || est == THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION ||
-                              est == THEIA_EST_TRIANGULATION || est == THEIA_EST_RADIAL_HOMOGRAPHY || est == THEIA_EST_SIMILARITY_2D3D;
+                              est == THEIA_EST_TRIANGULATION || est == THEIA_EST_RADIAL_HOMOGRAPHY || est == THEIA_EST_SIMILARITY_2D3D ||
+                              est == THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE;
   const bool rel_pose = est == THEIA_EST_RELATIVE_POSE, uncal_pose = est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE;
   const bool homog = est == THEIA_EST_HOMOGRAPHY, fund = est == THEIA_EST_FUNDAMENTAL_MATRIX;
   // every estimator's RefineModel is built: BundleAdjustView (absolute pose), BundleAdjustTwoViewsAngular ((un)calibrated
@@ -1576,13 +1649,21 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
           return rc;
         dim3 grid((B + 63) / 64, cn);
         k_fit5_a_team<<<(unsigned)((nh + 3) / 4), 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_ok.p);
-        k_fit5_b<<<(unsigned)((nh + kFpTeamsPerWave - 1) / kFpTeamsPerWave), 64, 0, st>>>(nh, d_fp_ok.p, d_fp_ws.p, d_fp_sol.p, d_fp_mask.p);
+        k_fit5_b<false><<<(unsigned)((nh + kFpTeamsPerWave - 1) / kFpTeamsPerWave), 64, 0, st>>>(nh, d_fp_ok.p, d_fp_ws.p, d_fp_sol.p, d_fp_mask.p);
         if (est == THEIA_EST_RELATIVE_POSE)
           k_fit5_c<THEIA_EST_RELATIVE_POSE><<<grid, 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_sol.p,
                                                                 d_fp_mask.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
         else
           k_fit5_c<THEIA_EST_ESSENTIAL_MATRIX><<<grid, 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_sol.p,
                                                                    d_fp_mask.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
+      } else if (est == THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE) {
+        if ((rc = d_fp_ws.ensure(nh * kFpWs)) || (rc = d_fp_sol.ensure(nh * 50)) || (rc = d_fp_ok.ensure(nh)) || (rc = d_fp_mask.ensure(nh)))
+          return rc;
+        if ((rc = p4pf_kernel_ready())) return rc;
+        dim3 grid((B + 63) / 64, cn);
+        k_p4pf_a<<<(unsigned)nh, p4pfdev::kThreads, p4pfdev::kLdsBytes, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_ok.p);
+        k_fit5_b<true><<<(unsigned)((nh + kFpTeamsPerWave - 1) / kFpTeamsPerWave), 64, 0, st>>>(nh, d_fp_ok.p, d_fp_ws.p, d_fp_sol.p, d_fp_mask.p);
+        k_p4pf_c<<<grid, 64, 0, st>>>(cn, B, d_active.p, d_fp_ws.p, d_fp_sol.p, d_fp_mask.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
       } else if (est == THEIA_EST_HOMOGRAPHY && !getenv("THEIA_HIP_FIT_ONE_KERNEL")) {
         if ((rc = d_fp_ws.ensure(nh * kHomWs))) return rc;
         dim3 grid((B + 63) / 64, cn);
@@ -1837,6 +1918,45 @@ int theia_hip_five_point_relative_pose(int32_t num, const double* corr, double* 
   HIP_TRYR(hipMemcpyAsync(num_solutions, dn.p, sizeof(int) * num, hipMemcpyDeviceToHost, st));
   HIP_TRYR(hipGetLastError());
   HIP_TRYR(mine.wait(st));
+  return 0;
+}
+
+int theia_hip_four_point_pose_and_focal_length(int32_t num, const double* corr2d3d, double* projection_matrices, int32_t* num_solutions) {
+  if (num < 0 || (num > 0 && (!corr2d3d || !projection_matrices || !num_solutions))) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+  if (num == 0) return 0;
+  int rc = ensure_device();
+  if (rc || (rc = p4pf_kernel_ready())) return rc;
+  hipStream_t st = solver_stream();
+  if (!st) return set_error(THEIA_HIP_ERR_NO_DEVICE, "could not create the solver stream");
+  CallSync mine;
+  // one problem of four data per call row, one hypothesis each with the identity sample: the RANSAC stages as they are
+  DBuf<double> dc, dws, dsol, dmod; DBuf<int> dn, dok, dmask, dsamp, dact, ddense, dtags, dbase; DBuf<int64_t> doff;
+  const size_t n = (size_t)num;
+  if ((rc = dc.ensure(n * 20)) || (rc = dws.ensure(n * kFpWs)) || (rc = dsol.ensure(n * 50)) || (rc = dmod.ensure(n * 10 * kStride)) ||
+      (rc = dn.ensure(n)) || (rc = dok.ensure(n)) || (rc = dmask.ensure(n)) || (rc = dsamp.ensure(n * 4)) || (rc = dact.ensure(n)) ||
+      (rc = ddense.ensure(n)) || (rc = dtags.ensure(n * 10)) || (rc = dbase.ensure(n)) || (rc = doff.ensure(n + 1)))
+    return rc;
+  std::vector<int64_t> off(n + 1);
+  std::vector<int> samp(n * 4), act(n, 1);
+  for (size_t i = 0; i <= n; ++i) off[i] = (int64_t)(4 * i);
+  for (size_t i = 0; i < n * 4; ++i) samp[i] = (int)(i % 4);
+  HIP_TRYR(hipMemcpyAsync(dc.p, corr2d3d, sizeof(double) * n * 20, hipMemcpyHostToDevice, st));
+  HIP_TRYR(hipMemcpyAsync(doff.p, off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, st));
+  HIP_TRYR(hipMemcpyAsync(dsamp.p, samp.data(), sizeof(int) * n * 4, hipMemcpyHostToDevice, st));
+  HIP_TRYR(hipMemcpyAsync(dact.p, act.data(), sizeof(int) * n, hipMemcpyHostToDevice, st));
+  HIP_TRYR(hipMemsetAsync(ddense.p, 0, sizeof(int) * n, st));
+  HIP_TRYR(hipMemsetAsync(dmod.p, 0, sizeof(double) * n * 10 * kStride, st));
+  k_p4pf_a<<<(unsigned)n, p4pfdev::kThreads, p4pfdev::kLdsBytes, st>>>(num, 1, doff.p, dc.p, dsamp.p, dact.p, dws.p, dok.p);
+  k_fit5_b<true><<<(unsigned)((n + kFpTeamsPerWave - 1) / kFpTeamsPerWave), 64, 0, st>>>(n, dok.p, dws.p, dsol.p, dmask.p);
+  k_p4pf_c<<<dim3(1, num), 64, 0, st>>>(num, 1, dact.p, dws.p, dsol.p, dmask.p, dmod.p, dn.p, ddense.p, dtags.p, dbase.p);
+  std::vector<double> hm(n * 10 * kStride);
+  HIP_TRYR(hipMemcpyAsync(hm.data(), dmod.p, sizeof(double) * hm.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipMemcpyAsync(num_solutions, dn.p, sizeof(int) * n, hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipGetLastError());
+  HIP_TRYR(mine.wait(st));
+  for (size_t i = 0; i < n; ++i)
+    for (int j = 0; j < 10; ++j)
+      for (int k = 0; k < 12; ++k) projection_matrices[(i * 10 + j) * 12 + k] = j < num_solutions[i] ? hm[(i * 10 + j) * kStride + k] : 0.0;
   return 0;
 }
 

@@ -36,6 +36,7 @@ EST_ABSOLUTE_POSE_KNOWN_ORIENTATION = 10
 EST_TRIANGULATION = 11
 EST_RADIAL_HOMOGRAPHY = 12
 EST_SIMILARITY_2D3D = 13
+EST_UNCALIBRATED_ABSOLUTE_POSE = 14
 
 
 class RansacParameters:
@@ -109,6 +110,7 @@ def _sig():
         L.theia_hip_dls_pnp.argtypes = [C.c_int32, C.POINTER(C.c_int64), capi.c_double_p, capi.c_double_p, C.POINTER(C.c_int64),
                                         capi.c_double_p, capi.c_double_p, capi.c_int32_p]
         L.theia_hip_dls_macaulay_terms.argtypes = [C.c_int64, C.c_int64, capi.c_double_p]
+        L.theia_hip_four_point_pose_and_focal_length.argtypes = [C.c_int32, capi.c_double_p, capi.c_double_p, capi.c_int32_p]
         L.theia_hip_dls_macaulay_terms.restype = None
         L.theia_ransac_params_default.argtypes = [C.POINTER(capi.RansacParams)]
         L._ransac_ready = True
@@ -148,7 +150,7 @@ def estimate_batch(estimator, data, offsets, params, estimator_params=None, seed
             "time_fit_seconds": r.time_fit_seconds, "time_score_seconds": r.time_score_seconds}
 
 
-_SAMPLE_SIZE = {0: 5, 1: 5, 2: 3, 3: 3, 4: 3, 5: 8, 6: 4, 7: 3, 8: 2, 9: 8, 10: 2, 11: 2, 12: 6, 13: 4}   # Estimator::SampleSize() by THEIA_EST_*
+_SAMPLE_SIZE = {0: 5, 1: 5, 2: 3, 3: 3, 4: 3, 5: 8, 6: 4, 7: 3, 8: 2, 9: 8, 10: 2, 11: 2, 12: 6, 13: 4, 14: 4}   # Estimator::SampleSize() by THEIA_EST_*
 
 
 def _single(estimator, ransac_params, ransac_type, data, estimator_params=None):
@@ -441,6 +443,62 @@ def EstimateSimilarityTransformation2D3D(ransac_params, ransac_type, corresponde
     rows = correspondences if isinstance(correspondences, np.ndarray) else similarity_correspondence_rows(correspondences, ray_directions)
     ok, m, s = _single(EST_SIMILARITY_2D3D, ransac_params, ransac_type, rows)
     return ok, SimilarityTransformation(m), s
+
+
+class UncalibratedAbsolutePose:  # estimate_uncalibrated_absolute_pose.h:48-52
+    def __init__(self, rotation, position, focal_length):
+        self.rotation = rotation
+        self.position = position
+        self.focal_length = focal_length
+
+
+def DecomposeProjectionMatrix(pmatrix):
+    """sfm/camera/projection_matrix_utils.cc:74-117: P = K [R | -R c] -> (success, K, angle-axis rotation, position) by the
+    RQ decomposition of the left 3 x 3 block, the rotation projected onto SO(3), K made positive on its diagonal."""
+    import scipy.linalg
+    P = np.asarray(pmatrix, dtype=np.float64).reshape(3, 4)
+    Rk, Q = scipy.linalg.rq(P[:, :3])
+    U, _, Vt = np.linalg.svd(Q)                      # ProjectToRotationMatrix (util/util.h / rotation utilities)
+    Rm = U @ Vt
+    if np.linalg.det(Rm) < 0:
+        Rm = -Rm
+    k_det = np.linalg.det(Rk)
+    if k_det == 0:
+        return False, np.zeros((3, 3)), np.zeros(3), np.zeros(3)
+    K = Rk.copy() if k_det > 0 else -Rk
+    for i in range(3):
+        if K[i, i] < 0:
+            K[:, i] *= -1.0
+            Rm[i, :] *= -1.0
+    t = scipy.linalg.solve_triangular(K, P[:, 3], lower=False)
+    position = -Rm.T @ t if k_det > 0 else Rm.T @ t
+    return True, K, synth.matrix_to_angle_axis(Rm[None])[0], position
+
+
+def EstimateUncalibratedAbsolutePose(ransac_params, ransac_type, normalized_correspondences):
+    """estimate_uncalibrated_absolute_pose.cc:106-141.  correspondences: (N, 5) u v X Y Z, pixels with the principal point
+    removed.  RANSAC over P4Pf samples on the device, then DecomposeProjectionMatrix of the winning projection matrix."""
+    ok, m, s = _single(EST_UNCALIBRATED_ABSOLUTE_POSE, ransac_params, ransac_type, normalized_correspondences)
+    good, K, aa, position = DecomposeProjectionMatrix(m[:12])
+    rotation = synth.angle_axis_to_matrix(aa[None])[0]
+    return ok, UncalibratedAbsolutePose(rotation, position, K[0, 0] / K[2, 2] if good else 0.0), s
+
+
+def FourPointPoseAndFocalLength(feature_vectors, world_points):
+    """pose_wrapper.cc / four_point_focal_length.cc:100-222 (P4Pf, four 2D-3D correspondences per problem; batched when the
+    inputs carry a leading batch dimension): (number of solutions, list of 3 x 4 projection matrices)."""
+    a = np.asarray(feature_vectors, dtype=np.float64); b = np.asarray(world_points, dtype=np.float64)
+    single = a.ndim == 2
+    if single:
+        a, b = a[None], b[None]
+    corr = np.ascontiguousarray(np.concatenate([a, b], axis=2))
+    num = corr.shape[0]
+    Pm = np.zeros((num, 10, 3, 4)); ns = np.zeros(num, dtype=np.int32)
+    capi.check(_sig().theia_hip_four_point_pose_and_focal_length(num, capi.ptr(corr, C.c_double), capi.ptr(Pm, C.c_double),
+                                                                  capi.ptr(ns, C.c_int32)))
+    if single:
+        return (int(ns[0]) if ns[0] > 0 else -1), [Pm[0, k] for k in range(ns[0])]
+    return ns, Pm
 
 
 def FivePointRelativePose(image1_points, image2_points):

@@ -238,10 +238,15 @@ def write_header(rows, others, targets, B):
         f.write("constexpr int kRows = %d;\nconstexpr int kOthers = %d;\nconstexpr int kTargets = %d;\nconstexpr int kBasis = %d;\n"
                 "constexpr int kElim = kOthers + kTargets;\nconstexpr int kCols = kElim + kBasis;\n\n" % (len(rows), len(others), len(targets), len(B)))
         idx = {m: i for i, m in enumerate(cols)}
-        f.write("constexpr int kMaxTerms = 12;\nconstexpr uint8_t kPolyTerms[4] = {%s};\n" % ", ".join(str(len(p)) for p in POLYS))
-        f.write("constexpr uint8_t kRowCol[kRows][kMaxTerms] = {%s};   // column of term t of row r (canonical term order of the generator's POLYS)\n"
+        f.write("constexpr int kMaxTerms = 12;\n")
+        f.write("// initialiser lists as macros: the device side instantiates the same tables in __constant__ memory\n")
+        f.write("#define THIP_P4PF_POLY_TERMS {%s}\n" % ", ".join(str(len(p)) for p in POLYS))
+        f.write("#define THIP_P4PF_ROW_COL {%s}\n"
                 % ", ".join("{" + ", ".join(str(idx[mono_mul(m, mu)]) for m, _ in POLYS[k]) + "}" for k, mu in rows))
-        f.write("constexpr uint8_t kRowPoly[kRows] = {%s};\n" % ", ".join(str(k) for k, _ in rows))
+        f.write("#define THIP_P4PF_ROW_POLY {%s}\n" % ", ".join(str(k) for k, _ in rows))
+        f.write("constexpr uint8_t kPolyTerms[4] = THIP_P4PF_POLY_TERMS;\n")
+        f.write("constexpr uint8_t kRowCol[kRows][kMaxTerms] = THIP_P4PF_ROW_COL;   // column of term t of row r (canonical term order of the generator's POLYS)\n")
+        f.write("constexpr uint8_t kRowPoly[kRows] = THIP_P4PF_ROW_POLY;\n")
         f.write("constexpr uint8_t kRowMul[kRows][4] = {%s};\n" % ", ".join("{%d, %d, %d, %d}" % mu for _, mu in rows))
         f.write("constexpr uint8_t kColMono[kCols][4] = {%s};\n" % ", ".join("{%d, %d, %d, %d}" % m for m in cols))
         f.write("\n}  // namespace p4pf\n}  // namespace thip\n\n#endif\n")

@@ -1,5 +1,5 @@
 """GPU box: one RANSAC leg at the C5 shape (pairs x 2000 correspondences x 4096 hypotheses), kernel-time split.
-usage: gpu_time_ransac.py <five_point|sqpnp|dls|kneip> [pairs]"""
+usage: gpu_time_ransac.py <five_point|sqpnp|dls|kneip|p4pf|...> [pairs]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
@@ -13,6 +13,7 @@ est, kind, thr = {"five_point": (ransac.EST_RELATIVE_POSE, "relative", (2.0 / 10
                   "fundamental": (ransac.EST_FUNDAMENTAL_MATRIX, "relative", (2.0 / 1000.0) ** 2),
                   "homography": (ransac.EST_HOMOGRAPHY, "relative", (2.0 / 1000.0) ** 2),
                   "essential": (ransac.EST_ESSENTIAL_MATRIX, "relative", (2.0 / 1000.0) ** 2),
+                  "p4pf": (ransac.EST_UNCALIBRATED_ABSOLUTE_POSE, "absolute", (4.0 / 1000.0) ** 2),
                   "kneip": (ransac.EST_ABS_KNEIP, "absolute", (4.0 / 1000.0) ** 2)}[leg]
 data, offsets, _ = synth.synth_ransac_v1(NP, 2000, kind, seed=0x5AC50005)
 p = ransac.RansacParameters(); p.error_thresh = thr; p.min_iterations = 4096; p.max_iterations = 4096; p.seed = 1

@@ -264,3 +264,19 @@ def test_pairs_of_a_verification_batch_as_one_flat_problem():
     assert np.array_equal(flat2.obs_cam, flat.obs_cam) and np.array_equal(flat2.cam_group, np.arange(6))
     empty, _ = tv._pairs_flat(cams, corr, None, False)
     assert empty.points.shape == (sum(ns), 4) and not empty.points.any()
+
+
+def test_decompose_projection_matrix_recovers_calibration_rotation_and_position():
+    """DecomposeProjectionMatrix (projection_matrix_utils.cc:74-117) as the uncalibrated absolute-pose mirror uses it: random
+    K [R | -R c] at any overall sign and scale gives back K (positive diagonal), R and c."""
+    from pytheiasfm_amd import ransac, synth
+    rng = np.random.default_rng(2)
+    for _ in range(20):
+        K = np.array([[rng.uniform(300, 900), rng.uniform(-2, 2), rng.uniform(-20, 20)], [0, rng.uniform(300, 900), rng.uniform(-20, 20)], [0, 0, 1.0]])
+        R = synth.angle_axis_to_matrix(rng.uniform(-1, 1, (1, 3)))[0]
+        c = rng.uniform(-2, 2, 3)
+        P = K @ np.concatenate([R, (-R @ c)[:, None]], axis=1) * rng.choice([-1.0, 1.0]) * rng.uniform(0.5, 2.0)
+        ok, Kd, aa, pos = ransac.DecomposeProjectionMatrix(P)
+        assert ok and np.all(np.diag(Kd) > 0)
+        assert np.abs(Kd / Kd[2, 2] - K).max() < 1e-8 and np.abs(pos - c).max() < 1e-9
+        assert np.abs(synth.angle_axis_to_matrix(aa[None])[0] - R).max() < 1e-9

@@ -964,3 +964,69 @@ def test_similarity_transformation_2d_3d_follows_oracle_and_numpy(rtype):
     assert equal >= 3
     ok, sim, s = ransac.EstimateSimilarityTransformation2D3D(p, ransac.RansacType.RANSAC, corrs[0])
     assert ok and abs(sim.scale - truths[0]["s"]) < 0.05 and sim.rotation.shape == (3, 3)
+
+
+def test_p4pf_minimal_solver_bitwise_against_oracle():
+    """FourPointPoseAndFocalLength (P4Pf) through the C-ABI: the reference's BasicTest vector
+    (four_point_focal_length_test.cc:119-146) and 400 random scenes, noise-free and with 0.5 px noise: the number of
+    solutions and every projection matrix bit-identical to the oracle's (same template, same operation order)."""
+    from tests import p4pf_scenes as ps
+    rng = np.random.default_rng(23)
+    P, X, px = ps.basic_scene()
+    feats, worlds, truth = [px], [X], [P]
+    for i in range(400):
+        Pi, Xi, pxi, _ = ps.random_scene(rng)
+        feats.append(pxi + (rng.normal(0.0, 0.5, pxi.shape) if i % 2 == 0 else 0.0)); worlds.append(Xi); truth.append(Pi)   # odd rows of the batch carry noise
+    ns, Pm = ransac.FourPointPoseAndFocalLength(np.array(feats), np.array(worlds))
+    exact = 0
+    for i in range(len(feats)):
+        mo = ol.estimate_models(ps.EST, np.concatenate([feats[i], worlds[i]], axis=1))
+        assert len(mo) == ns[i]
+        assert np.array_equal(mo[:, :12].reshape(-1, 3, 4), Pm[i, : ns[i]], equal_nan=True)
+        if i % 2 == 0 and ns[i]:
+            err = min(np.linalg.norm(ps.project(Pm[i, k], worlds[i]) - feats[i], axis=1).max() for k in range(ns[i]))
+            exact += int(err < 0.1)
+    assert ns[0] >= 1 and exact >= 0.99 * 201
+    err0 = min(np.linalg.norm(ps.project(Pm[0, k], X) - px, axis=1).max() for k in range(ns[0]))
+    assert err0 < 1e-4
+    n1, sols = ransac.FourPointPoseAndFocalLength(px, X)
+    assert n1 == ns[0] and np.array_equal(np.array(sols), Pm[0, : ns[0]])
+
+
+@pytest.mark.parametrize("rtype", [0, 1, 2])
+def test_uncalibrated_absolute_pose_bit_identical_to_oracle(rtype):
+    """EstimateUncalibratedAbsolutePose (estimate_uncalibrated_absolute_pose.cc:60-141): 8 cameras with outliers and noise,
+    RANSAC / PROSAC / LMED: inlier sets, iteration counts and projection matrices equal to the oracle's, the inlier set
+    re-derived in numpy from the returned projection matrix, the focal length recovered through DecomposeProjectionMatrix."""
+    from tests import p4pf_scenes as ps
+    rng = np.random.default_rng(31)
+    data, offsets, truth = [], [0], []
+    for i in range(8):
+        rows, P, focal, good = ps.ransac_scene(rng, 120 + 20 * i, outlier_fraction=0.25)
+        data.append(rows); offsets.append(offsets[-1] + len(rows)); truth.append((P, focal, good))
+    data = np.concatenate(data); offsets = np.array(offsets, dtype=np.int64)
+    p = ransac.RansacParameters(); p.error_thresh = 2.0 ** 2; p.min_iterations = 100; p.failure_probability = 1e-3; p.seed = 77
+    pc0 = p.to_c(); pc0.ransac_type = rtype
+    res = ransac.estimate_batch(ransac.EST_UNCALIBRATED_ABSOLUTE_POSE, data, offsets, pc0)
+    for i in range(8):
+        sl = slice(offsets[i], offsets[i + 1])
+        pc = p.to_c(); pc.seed = 77 + i; pc.ransac_type = rtype
+        o = ol.ransac_estimate(ps.EST, data[sl], pc)
+        assert bool(o["success"]) == bool(res["success"][i]) and o["success"]
+        assert np.array_equal(o["inlier_mask"], res["inlier_mask"][sl])
+        assert o["num_iterations"] == res["num_iterations"][i]
+        assert np.array_equal(o["model"][:12], res["models"][i][:12])
+        Pm = res["models"][i][:12].reshape(3, 4)
+        P, focal, good = truth[i]
+        if rtype != 2:
+            e = np.sum((ps.project(Pm, data[sl, 2:5]) - data[sl, :2]) ** 2, axis=1)
+            sure = np.abs(e - 4.0) > 1e-6
+            assert np.array_equal((e < 4.0)[sure], res["inlier_mask"][sl].astype(bool)[sure])
+        ok, K, aa, pos = ransac.DecomposeProjectionMatrix(Pm)
+        assert ok and abs(K[0, 0] / K[2, 2] - focal) < 0.05 * focal
+        assert res["inlier_mask"][sl][good].mean() > 0.8
+    ok, pose, s = ransac.EstimateUncalibratedAbsolutePose(p, ransac.RansacType.RANSAC, data[offsets[0]:offsets[1]])
+    P, focal, good = truth[0]
+    Rt = np.linalg.inv(np.diag([focal, focal, 1.0])) @ P
+    assert ok and abs(pose.focal_length - focal) < 0.05 * focal and np.abs(pose.rotation - Rt[:, :3]).max() < 0.05
+    assert np.abs(pose.position + Rt[:, :3].T @ Rt[:, 3]).max() < 0.2 and len(s.inliers) > 60
