@@ -7,8 +7,8 @@
 // operation order this file keeps so that the two agree bit for bit.
 //
 //   stage A  p4pf_action_wg     one WORKGROUP (256 threads) per hypothesis, the 94 x 82 transposed system in LDS (62 KB):
-//                               partial-pivot elimination (wave 0 picks the pivot, one factor per row, four waves update
-//                               rows k+1.. over the lanes' columns), column-oriented back-substitution, action matrix
+//                               partial-pivot elimination (two barriers per step), back-substitution by one wave per
+//                               right-hand side without barriers, action matrix
 //   stage B  eig_team           the 10 x 10 eigen-decomposition by 8-lane teams (the five-point kernel's)
 //   stage C  p4pf_projection    one thread per hypothesis: real eigenvectors -> depths, focal length, rigid alignment
 #ifndef THEIA_HIP_P4PF_DEVICE_H_
@@ -26,7 +26,8 @@ constexpr int kLd = kRows + kTargets;                  // row of the transposed 
 constexpr int kNorm = 31;                              // fn 8 | wn 12 | mean 3 | wvar | fvar | g 6
 constexpr int kWs = 36 + 100;                          // per hypothesis in HBM: normalisation (kNorm of 36) | action matrix
 constexpr int kThreads = 256;
-constexpr size_t kLdsBytes = sizeof(double) * (kElim * kLd + kRows * kBasis + kElim + 4 * kMaxTerms) + sizeof(int) * (kElim + 4);
+constexpr int kLdP = kLd + 1;                         // LDS row stride: odd, so that the lanes of a column access spread over the banks
+constexpr size_t kLdsBytes = sizeof(double) * ((kElim + 1) * kLdP + kRows * kBasis + kElim + 1 + kRows + 4 * kMaxTerms) + sizeof(int) * (4 + 128 + 4 * kLd);
 
 __constant__ uint8_t c_poly_terms[4] = THIP_P4PF_POLY_TERMS;
 __constant__ uint8_t c_row_col[kRows][kMaxTerms] = THIP_P4PF_ROW_COL;
@@ -78,14 +79,26 @@ RDEV void coefficients(const double* N, double* c) {
 
 // Stage A, called by every thread of a 256-thread workgroup.  sm: kLdsBytes of LDS.  Writes the normalisation (kNorm doubles)
 // and the 10 x 10 action matrix to ws; returns false (uniformly) for a degenerate sample or a vanishing pivot.
+//
+// Same arithmetic as oracle/p4pf_oracle.h action_matrix(), arranged for the machine: rows are swapped physically instead of
+// through a permutation (no dependent index load in front of every access; pure data movement), every wave finds the pivot
+// of a step by itself (no barrier between the search and the factors), the factors, the row swap and the pivot's value are
+// written in the same phase (the swap leaves column k alone, which is all that phase reads), the update runs over the
+// compacted lists of the rows with a non-zero factor and of the non-zero entries of the pivot row (the template is sparse:
+// a sixth of the dense element updates; skipping is exact, |f| <= 1), four independent rows per pass, and the back-substitution runs
+// without workgroup barriers, one wave per right-hand side with the right-hand side in registers (column-oriented, the
+// oracle's order: e_i -= U[i][k] y_k for descending k).  Two barriers per elimination step.
 __device__ inline bool p4pf_action_wg(const double* __restrict__ pd, const int* __restrict__ sample, double* sm, double* __restrict__ ws) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double* G = sm;                          // [kElim][kLd]
-  double* Bm = G + kElim * kLd;            // [kRows][kBasis]
-  double* fac = Bm + kRows * kBasis;       // [kElim]
-  double* coef = fac + kElim;              // [4][kMaxTerms]
-  int* perm = (int*)(coef + 4 * kMaxTerms);   // [kElim]
-  int* flag = perm + kElim;                // [0] ok, [1] pivot row of the step
+  double* G = sm;                          // [kElim][kLdP]
+  double* Bm = G + (kElim + 1) * kLdP;     // [kRows][kBasis]   (row kElim of G: spare, written by out-of-range update slots)
+  double* fac = Bm + kRows * kBasis;       // [kElim + 1], fac[kElim] = 0 (spare row)
+  double* pivv = fac + kElim + 1;          // [kRows] pivots
+  double* coef = pivv + kRows;             // [4][kMaxTerms]
+  int* flag = (int*)(coef + 4 * kMaxTerms);   // [4]
+  int* cnt = flag + 2;                     // [2] non-zero factors found by waves 0 and 1
+  int* rowlist = flag + 4;                 // [128] their rows
+  int* collist = rowlist + 128;            // [4][kLd] per wave: columns with a non-zero pivot-row entry
   if (tid == 0) {
     double subset[20];
     for (int i = 0; i < 4; ++i) for (int k = 0; k < 5; ++k) subset[5 * i + k] = pd[(size_t)sample[i] * 5 + k];
@@ -99,66 +112,98 @@ __device__ inline bool p4pf_action_wg(const double* __restrict__ pd, const int* 
       for (int t = 0; t < kNorm; ++t) ws[t] = N[t];
     }
   }
-  for (int e = tid; e < kElim * kLd + kRows * kBasis; e += kThreads) G[e] = 0.0;
-  if (tid < kElim) perm[tid] = tid;
+  for (int e = tid; e < (kElim + 1) * kLdP + kRows * kBasis + kElim + 1; e += kThreads) G[e] = 0.0;   // G, Bm, fac
   __syncthreads();
   if (!flag[0]) return false;
   if (tid < kRows) {   // template row r = column r of the transposed system
     const int k = c_row_poly[tid];
     for (int t = 0; t < c_poly_terms[k]; ++t) {
       const int col = c_row_col[tid][t];
-      if (col < kElim) G[col * kLd + tid] = coef[k * kMaxTerms + t]; else Bm[tid * kBasis + (col - kElim)] = coef[k * kMaxTerms + t];
+      if (col < kElim) G[col * kLdP + tid] = coef[k * kMaxTerms + t]; else Bm[tid * kBasis + (col - kElim)] = coef[k * kMaxTerms + t];
     }
   }
-  if (tid < kTargets) G[(kOthers + tid) * kLd + kRows + tid] = 1.0;
+  if (tid < kTargets) G[(kOthers + tid) * kLdP + kRows + tid] = 1.0;
   __syncthreads();
   for (int k = 0; k < kRows; ++k) {
-    if (wave == 0) {   // pivot: the largest |G[perm[i]][k]| over i >= k, the first one on ties
-      double best = -1.0; int bi = kElim;
-      for (int i = k + lane; i < kElim; i += 64) {
-        const double v = fabs(G[perm[i] * kLd + k]);
-        if (v > best) { best = v; bi = i; }
+    // pivot: the largest |G[i][k]| over i >= k, the first one on ties (every wave for itself)
+    const int ia = k + lane, ib = ia + 64;
+    const double va = ia < kElim ? fabs(G[ia * kLdP + k]) : -1.0, vb = ib < kElim ? fabs(G[ib * kLdP + k]) : -1.0;
+    double best = fmax(va, vb);
+    for (int o = 32; o >= 1; o >>= 1) best = fmax(best, __shfl_xor(best, o));
+    const unsigned long long ma = __ballot(va == best), mb = __ballot(vb == best);
+    const int bi = ma ? k + __ffsll((long long)ma) - 1 : (mb ? k + 64 + __ffsll((long long)mb) - 1 : kElim);
+    if (!(best > 0.0)) return false;   // the same verdict in every wave
+    const double piv = G[bi * kLdP + k];
+    if (wave < 2) {                    // factor of row i (rows k and bi change places: row bi will hold the old row k),
+      const int i = k + 1 + tid;       // and the list of the rows with a non-zero factor: the template is sparse
+      double f = 0.0;
+      if (i < kElim) {
+        const double v = G[(i == bi ? k : i) * kLdP + k];
+        f = (v == 0.0) ? 0.0 : v / piv;
+        fac[i] = f;
       }
-      for (int o = 32; o >= 1; o >>= 1) {
-        const double ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      const unsigned long long nz = __ballot(f != 0.0);
+      if (f != 0.0) rowlist[wave * 64 + __popcll(nz & ((1ull << lane) - 1ull))] = i;
+      if (lane == 0) cnt[wave] = __popcll(nz);
+    }
+    {
+      const int j = k + 1 + tid;       // swap of the columns right of k
+      if (j < kLd && bi != k) {
+        const double a = G[k * kLdP + j], b = G[bi * kLdP + j];
+        G[k * kLdP + j] = b; G[bi * kLdP + j] = a;
       }
-      if (lane == 0) {
-        if (!(best > 0.0)) flag[0] = 0;
-        if (bi < kElim) { const int t = perm[k]; perm[k] = perm[bi]; perm[bi] = t; }
-      }
+      if (tid == 0) pivv[k] = piv;
     }
     __syncthreads();
-    if (!flag[0]) return false;
-    const int prow = perm[k];
-    const double piv = G[prow * kLd + k];
-    if (tid > k && tid < kElim) {
-      const double v = G[perm[tid] * kLd + k];
-      fac[tid] = (v == 0.0) ? 0.0 : v / piv;
-    }
-    __syncthreads();
-    for (int i = k + 1 + wave; i < kElim; i += 4) {
-      const double f = fac[i];
-      if (f == 0.0) continue;
-      double* row = G + perm[i] * kLd;
-      for (int j = k + 1 + lane; j < kLd; j += 64) row[j] = row[j] - f * G[prow * kLd + j];
+    // update: lanes over the NON-ZERO entries of the pivot row (x - f * 0 = x: |f| <= 1 by the pivoting), the wave's share of
+    // the rows with a non-zero factor four at a time (slots past the end go to the spare row kElim, factor 0)
+    const int n0r = cnt[0], nr = n0r + cnt[1];
+    const int j0 = k + 1 + lane, j1 = j0 + 64;
+    const bool nz0 = j0 < kLd && G[k * kLdP + j0] != 0.0, nz1 = j1 < kLd && G[k * kLdP + j1] != 0.0;
+    const unsigned long long m0 = __ballot(nz0), m1 = __ballot(nz1);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int* cl = collist + wave * kLd;
+    const int n0c = __popcll(m0), nc = n0c + __popcll(m1);
+    if (nz0) cl[__popcll(m0 & lt)] = j0;
+    if (nz1) cl[n0c + __popcll(m1 & lt)] = j1;
+    rsc::team_sync();
+    for (int c = lane; c < nc; c += 64) {
+      const int j = cl[c];
+      const double pr = G[k * kLdP + j];
+      for (int t = wave; t < nr; t += 16) {
+        const int t1 = t + 4, t2 = t + 8, t3 = t + 12;
+        const int i0 = t < n0r ? rowlist[t] : rowlist[64 + t - n0r];
+        const int i1 = t1 < nr ? (t1 < n0r ? rowlist[t1] : rowlist[64 + t1 - n0r]) : kElim;
+        const int i2 = t2 < nr ? (t2 < n0r ? rowlist[t2] : rowlist[64 + t2 - n0r]) : kElim;
+        const int i3 = t3 < nr ? (t3 < n0r ? rowlist[t3] : rowlist[64 + t3 - n0r]) : kElim;
+        const double f0 = fac[i0], f1 = fac[i1], f2 = fac[i2], f3 = fac[i3];
+        double* r0 = G + i0 * kLdP + j; double* r1 = G + i1 * kLdP + j; double* r2 = G + i2 * kLdP + j; double* r3 = G + i3 * kLdP + j;
+        const double x0 = *r0, x1 = *r1, x2 = *r2, x3 = *r3;
+        *r0 = x0 - f0 * pr; *r1 = x1 - f1 * pr; *r2 = x2 - f2 * pr; *r3 = x3 - f3 * pr;
+      }
     }
     __syncthreads();
   }
-  // back-substitution, column-oriented: Y[k][q] overwrites the right-hand side of row perm[k]
-  for (int k = kRows - 1; k >= 0; --k) {
-    double* pr = G + perm[k] * kLd;
-    if (tid < kTargets) pr[kRows + tid] = pr[kRows + tid] / pr[k];
-    __syncthreads();
-    const int q = tid & 7;
-    if (q < kTargets)
-      for (int i = tid >> 3; i < k; i += kThreads / 8) {
-        double* row = G + perm[i] * kLd;
-        const double a = row[k];
-        if (a != 0.0) row[kRows + q] = row[kRows + q] - a * pr[kRows + q];
-      }
-    __syncthreads();
+  // back-substitution, column-oriented, one wave per right-hand side with e in registers; wave 0 carries the fifth one
+  // through the same loop (two independent chains)
+  {
+    const int q = wave, q2 = kTargets - 1;
+    const bool two = wave == 0;
+    double e0 = lane < kRows ? G[lane * kLdP + kRows + q] : 0.0;
+    double e1 = lane + 64 < kRows ? G[(lane + 64) * kLdP + kRows + q] : 0.0;
+    double h0 = (two && lane < kRows) ? G[lane * kLdP + kRows + q2] : 0.0;
+    double h1 = (two && lane + 64 < kRows) ? G[(lane + 64) * kLdP + kRows + q2] : 0.0;
+    for (int k = kRows - 1; k >= 0; --k) {
+      const double pk = pivv[k];
+      const double ek = k >= 64 ? __shfl(e1, k - 64) : __shfl(e0, k);
+      const double hk = k >= 64 ? __shfl(h1, k - 64) : __shfl(h0, k);
+      const double y = ek / pk, y2 = hk / pk;
+      if (lane == 0) { G[k * kLdP + kRows + q] = y; if (two) G[k * kLdP + kRows + q2] = y2; }
+      if (lane < k) { const double a = G[lane * kLdP + k]; if (a != 0.0) { e0 = e0 - a * y; h0 = h0 - a * y2; } }
+      if (lane + 64 < k) { const double a = G[(lane + 64) * kLdP + k]; if (a != 0.0) { e1 = e1 - a * y; h1 = h1 - a * y2; } }
+    }
   }
+  __syncthreads();
   double* T = ws + 36;
   if (tid < 50) {
     T[tid] = (tid == 1 || tid == 15 || tid == 26 || tid == 37 || tid == 48) ? 1.0 : 0.0;   // z * {1, z, y, x, w}: rows 0..4
@@ -166,7 +211,7 @@ __device__ inline bool p4pf_action_wg(const double* __restrict__ pd, const int* 
     double acc = 0.0;
     for (int r = 0; r < kRows; ++r) {
       const double b = Bm[r * kBasis + j];
-      if (b != 0.0) acc += G[perm[r] * kLd + kRows + i] * b;
+      if (b != 0.0) acc += G[r * kLdP + kRows + i] * b;
     }
     T[(5 + i) * 10 + j] = -acc;
   }
