@@ -23,6 +23,21 @@ from .synth import angle_axis_to_matrix
 
 kInvalidViewId = 0xFFFFFFFF
 
+# handles of the most recent full / partial BA problems (ba.ProblemCache): a BA call on an unchanged topology skips
+# theia_hip_ba_create.  set_problem_cache(0) switches it off, clear_problem_cache() frees the device memory it holds.
+_problem_cache = _ba.ProblemCache(capacity=1)
+
+
+def set_problem_cache(capacity):
+    global _problem_cache
+    _problem_cache.clear()
+    _problem_cache = _ba.ProblemCache(capacity=capacity)
+    return _problem_cache
+
+
+def clear_problem_cache():
+    _problem_cache.clear()
+
 
 class LossFunctionType(enum.IntEnum):  # create_loss_function.h:52-60
     TRIVIAL = 0
@@ -185,10 +200,19 @@ class Reconstruction:
         return self.points.shape[0]
 
     def ViewIds(self):
-        return list(range(self.NumViews()))
+        return range(self.NumViews())
 
     def TrackIds(self):
-        return list(range(self.NumTracks()))
+        return range(self.NumTracks())
+
+
+def _ids(ids):
+    """id lists of the mirror -> int64 array (a range -- ViewIds() / TrackIds() -- without walking it in Python)"""
+    if isinstance(ids, range):
+        return np.arange(ids.start, ids.stop, ids.step, dtype=np.int64)
+    if isinstance(ids, np.ndarray):
+        return ids.astype(np.int64, copy=False).reshape(-1)
+    return np.asarray(list(ids), dtype=np.int64)
 
 
 def _flatten(recon, view_ids, track_ids, const_view_ids=(), options=None):
@@ -196,38 +220,43 @@ def _flatten(recon, view_ids, track_ids, const_view_ids=(), options=None):
     AddTrack (:175-221) for `track_ids`."""
     nv, nt = recon.NumViews(), recon.NumTracks()
     view_added = np.zeros(nv, dtype=bool)
-    vi = np.asarray(list(view_ids) + list(const_view_ids), dtype=np.int64)
+    vi = np.concatenate([_ids(view_ids), _ids(const_view_ids)])
     if len(vi):
         if vi.min() < 0 or vi.max() >= nv:
             raise capi.TheiaHipError(-1, "view id out of range (reference: CHECK_NOTNULL aborts)")
         view_added[vi] = True
     view_added &= recon.view_estimated
     track_added = np.zeros(nt, dtype=bool)
-    ti = np.asarray(list(track_ids), dtype=np.int64)
+    ti = _ids(track_ids)
     if len(ti):
         if ti.min() < 0 or ti.max() >= nt:
             raise capi.TheiaHipError(-1, "track id out of range (reference: CHECK_NOTNULL aborts)")
         track_added[ti] = True
     track_added &= recon.track_estimated
     ov, ot = recon.obs_view, recon.obs_track
-    est = recon.view_estimated[ov] & recon.track_estimated[ot]
-    keep = est & (view_added[ov] | track_added[ot])
+    if recon.view_estimated.all() and recon.track_estimated.all() and (view_added.all() or track_added.all()):
+        keep = np.ones(len(ov), dtype=bool)      # every observation enters: skip the four 3 M-row gathers
+    else:
+        est = recon.view_estimated[ov] & recon.track_estimated[ot]
+        keep = est & (view_added[ov] | track_added[ot])
     cam_const = np.zeros(nv, dtype=np.uint8)
     # cameras reached only through AddTrack are frozen (:204)
     cam_const[~view_added] = capi_const_all()
     if len(const_view_ids):
-        cam_const[np.asarray(list(const_view_ids), dtype=np.int64)] = capi_const_all()
+        cam_const[_ids(const_view_ids)] = capi_const_all()
     point_const = (~track_added).astype(np.uint8)  # SetTrackConstant (:149) unless AddTrack'ed
     # an intrinsics group is optimised iff one of its views went through AddView
     # (:130-133); groups reached only through AddTrack stay constant (:442-455)
     group_const = np.ones(recon.group_intrinsics.shape[0], dtype=np.uint8)
     group_const[recon.view_group[view_added]] = 0
     sqrt_info = None
-    cov = recon.obs_cov[keep]
+    everything = bool(keep.all())       # the full BA of an all-estimated reconstruction: no 3 M-row boolean gathers
+    cov = recon.obs_cov if everything else recon.obs_cov[keep]
     if len(cov) and not np.all(cov == 1.0):
         sqrt_info = 1.0 / np.sqrt(cov)
     flat = capi.FlatProblem(recon.cam_ext.copy(), recon.group_intrinsics.copy(), recon.group_model,
-                            recon.view_group, recon.points.copy(), recon.obs_uv[keep], ov[keep], ot[keep],
+                            recon.view_group, recon.points.copy(), recon.obs_uv if everything else recon.obs_uv[keep],
+                            ov if everything else ov[keep], ot if everything else ot[keep],
                             cam_const=cam_const, group_const=group_const, point_const=point_const,
                             obs_sqrt_info=sqrt_info)
     if options is not None and options.use_depth_priors and recon.obs_depth_prior is not None:
@@ -252,7 +281,7 @@ def capi_const_all():
 def _update_inverse_depth(recon, track_ids):
     """UpdateInverseDepth (bundle_adjustment.cc:69-83): inverse depth of the
     track in its reference view, Camera::ProjectPoint depth (camera.cc:206-216)."""
-    ti = np.asarray(list(track_ids), dtype=np.int64)
+    ti = _ids(track_ids)
     if not len(ti):
         return
     ti = ti[recon.track_estimated[ti]]
@@ -263,9 +292,9 @@ def _update_inverse_depth(recon, track_ids):
         return
     X = recon.points[ti]
     ce = recon.cam_ext[ref]
-    R = angle_axis_to_matrix(ce[:, 3:6])
+    row2 = angle_axis_to_matrix(recon.cam_ext[:, 3:6])[:, 2, :]   # one rotation per VIEW, not per track
     p = X[:, :3] - X[:, 3:4] * ce[:, :3]
-    depth = np.einsum("nj,nj->n", R[:, 2, :], p) / X[:, 3]
+    depth = np.einsum("nj,nj->n", row2[ref], p) / X[:, 3]
     recon.inverse_depth[ti] = 1.0 / depth
 
 
@@ -283,7 +312,7 @@ def _flatten_inverse_depth(recon, track_ids, const_view_ids=()):
     keep = recon.view_estimated[ov] & added[ot]
     cam_const = np.zeros(recon.NumViews(), dtype=np.uint8)
     if len(const_view_ids):
-        cam_const[np.asarray(list(const_view_ids), dtype=np.int64)] = capi_const_all()
+        cam_const[_ids(const_view_ids)] = capi_const_all()
     sqrt_info = None
     cov = recon.obs_cov[keep]
     if len(cov) and not np.all(cov == 1.0):
@@ -345,7 +374,7 @@ def _run(options, recon, flat):
             fail = BundleAdjustmentSummary()
             fail.success = False
             return fail
-    s, _ = _ba.solve(flat, c_opts)
+    s, _ = _problem_cache.solve(flat, c_opts)
     recon.cam_ext[:] = flat.cam_ext
     recon.points[:] = flat.points
     recon.group_intrinsics[:] = flat.intrinsics   # shared CameraIntrinsicsModel parameters (:388-389)

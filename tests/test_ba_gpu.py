@@ -1245,3 +1245,38 @@ def test_view_covariances_with_optimised_intrinsics():
     o = cols[("c", views[0])]
     Jb = J[:, o:o + 6]
     assert np.abs(np.linalg.inv(Jb.T @ Jb) * fv - cv[views[0]]).max() > 1e-3 * np.abs(cv[views[0]]).max()
+
+
+def test_problem_cache_reuses_the_handle_on_unchanged_topology():
+    """SURVEY 8(f) row 4 (problem-IR cache): BundleAdjustReconstruction twice on the same topology with different
+    parameters = one theia_hip_ba_create; the cached solve equals the one-shot theia_hip_ba_solve (1e-10); an edit of
+    the topology (one track set unestimated) or of the options builds a new handle."""
+    import copy
+    p = synth.synth_ba_v1(24, 4000, seed=11, mixed_models=True)
+    opts = sfm.BundleAdjustmentOptions(); opts.max_num_iterations = 6
+    rng = np.random.default_rng(3)
+
+    def perturbed():
+        r = sfm.Reconstruction.from_flat(p)
+        r.cam_ext = r.cam_ext + rng.normal(0.0, 1e-3, r.cam_ext.shape)
+        r.points[:, :3] += rng.normal(0.0, 1e-2, (r.points.shape[0], 3))
+        return r
+
+    cache = sfm.set_problem_cache(1)
+    try:
+        for round_ in range(3):
+            r = perturbed()
+            ref = copy.deepcopy(r)
+            s = sfm.BundleAdjustReconstruction(opts, r)
+            flat = sfm._flatten(ref, ref.ViewIds(), ref.TrackIds(), options=opts)
+            s0, _ = ba.solve(flat, opts.to_c())
+            assert s.success and s.num_iterations == s0.num_iterations and abs(s.final_cost - s0.final_cost) <= 1e-12 * s0.final_cost
+            assert np.allclose(r.cam_ext, flat.cam_ext, rtol=1e-10, atol=1e-12) and np.allclose(r.points, flat.points, rtol=1e-10, atol=1e-12)
+            assert np.allclose(r.group_intrinsics, flat.intrinsics, rtol=1e-10, atol=1e-12)
+        assert (cache.misses, cache.hits) == (1, 2)
+        r = perturbed(); r.track_estimated[17] = False
+        assert sfm.BundleAdjustReconstruction(opts, r).success and cache.misses == 2
+        o2 = copy.copy(opts); o2.max_num_iterations = 3
+        assert sfm.BundleAdjustReconstruction(o2, perturbed()).success and cache.misses == 3 and len(cache._handles) == 1
+    finally:
+        sfm.set_problem_cache(1)

@@ -280,3 +280,26 @@ def test_decompose_projection_matrix_recovers_calibration_rotation_and_position(
         assert ok and np.all(np.diag(Kd) > 0)
         assert np.abs(Kd / Kd[2, 2] - K).max() < 1e-8 and np.abs(pos - c).max() < 1e-9
         assert np.abs(synth.angle_axis_to_matrix(aa[None])[0] - R).max() < 1e-9
+
+
+def test_problem_fingerprint_separates_topology_from_parameters():
+    """ba.problem_fingerprint (the key of the problem-IR cache): unchanged by what a solve changes (extrinsics, intrinsics,
+    points), changed by any edit of the topology, the observations, the constant masks, the priors or the options."""
+    from pytheiasfm_amd import ba, synth
+    p = synth.synth_ba_v1(12, 300, seed=5)
+    o = ba.default_options() if os.path.exists(capi.LIB_PATH) else None
+    k0 = ba.problem_fingerprint(p, o)
+    q = p.copy()
+    q.cam_ext += 0.01; q.points[:, :3] += 0.1; q.intrinsics[:, 0] *= 1.01
+    assert ba.problem_fingerprint(q, o) == k0
+    keys = {k0}
+    q = p.copy(); q.obs_uv = q.obs_uv.copy(); q.obs_uv[7, 0] += 1e-9; keys.add(ba.problem_fingerprint(q, o))
+    q = p.copy(); q.obs_cam = q.obs_cam.copy(); q.obs_cam[3] = (q.obs_cam[3] + 1) % 12; keys.add(ba.problem_fingerprint(q, o))
+    q = p.copy(); q.point_const = np.zeros(300, np.uint8); q.point_const[5] = 1; keys.add(ba.problem_fingerprint(q, o))
+    q = p.copy(); q.set_priors(np.ones(12, np.uint8), position=(np.zeros((12, 3)), np.tile(np.eye(3), (12, 1, 1)))); keys.add(ba.problem_fingerprint(q, o))
+    q = p.copy(); q.add_depth_priors([1, 2], [3.0, 4.0]); keys.add(ba.problem_fingerprint(q, o))
+    r = synth.synth_ba_v1(12, 299, seed=5); keys.add(ba.problem_fingerprint(r, o))
+    assert len(keys) == 7
+    if o is not None:
+        o2 = ba.default_options(); o2.max_num_iterations = o.max_num_iterations + 1
+        assert ba.problem_fingerprint(p, o2) != k0
