@@ -360,13 +360,14 @@ __device__ double lmed_select(const double* sq, int n, int k, int* hist, int* se
 
 // returns the median (cost); *ninl = inlier count; mask (optional, global) receives the inlier flags
 __device__ double lmed_block(int est, const double* m, const double* pd, int n, int ds, int min_samples, double* sq,
-                             int* hist, int* sel, int* ninl, uint8_t* mask) {
+                             int* hist, int* sel, int* ninl, uint8_t* mask, double* sqt_out = nullptr) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) { const double r = model_error(est, m, pd + (size_t)i * ds); sq[i] = r * r; }
   __syncthreads();
   double median = lmed_select(sq, n, n / 2, hist, sel);
   if ((n % 2) != 0) median = 0.5 * (lmed_select(sq, n, n / 2 - 1, hist, sel) + median);
   const double thr = 2.5 * 1.4826 * (1 + 5.0 / (double)((size_t)n - (size_t)min_samples)) * sqrt(median);
   const double sqt = thr * thr;
+  if (sqt_out && threadIdx.x == 0) *sqt_out = sqt;
   if (threadIdx.x == 0) sel[2] = 0;
   __syncthreads();
   int cnt = 0;
@@ -416,6 +417,23 @@ __global__ __launch_bounds__(256) void k_inlier_mask_lmed(int est, int nprob, co
   __syncthreads();
   int cnt;
   lmed_block(est, m, data + (size_t)offsets[p] * ds, n, ds, sample_size(est), sdata, hist, sel, &cnt, mask + offsets[p]);
+}
+
+// LO under LMED: the inliers RefineModel sees are the quality measurement's own (r^2 < its median-derived bound): the bound of
+// every LO event's model, for k_lo_gather
+__global__ __launch_bounds__(256) void k_lo_lmed_bound(int est, const int* __restrict__ ev_prob, const int64_t* __restrict__ offsets,
+                                                       const double* __restrict__ data, const double* __restrict__ ev_model,
+                                                       double* __restrict__ ev_sqt) {
+  extern __shared__ __attribute__((aligned(16))) double sdata[];
+  __shared__ int hist[256], sel[4];
+  __shared__ double m[kStride];
+  const int e = blockIdx.x, p = ev_prob[e];
+  const int ds = datum_size(est);
+  const int n = (int)(offsets[p + 1] - offsets[p]);
+  if (threadIdx.x < kStride) m[threadIdx.x] = ev_model[(size_t)e * kStride + threadIdx.x];
+  __syncthreads();
+  int cnt;
+  lmed_block(est, m, data + (size_t)offsets[p] * ds, n, ds, sample_size(est), sdata, hist, sel, &cnt, nullptr, ev_sqt + e);
 }
 
 // final pass: refit the winning hypothesis (deterministic -> identical model)
@@ -554,7 +572,8 @@ __global__ void k_lo_prepare(int est, int nev, const int* __restrict__ ev_prob, 
 // correspondences for the two-view batch (relative pose); one wave per event
 __global__ __launch_bounds__(64) void k_lo_gather(int est, const int* __restrict__ ev_prob, const int64_t* __restrict__ offsets,
                                                   const double* __restrict__ data, const double* __restrict__ ev_model,
-                                                  double thresh, const int64_t* __restrict__ ev_off, int* __restrict__ ev_count,
+                                                  double thresh, const double* __restrict__ ev_sqt /* LMED: per-event bound on r^2, else null */,
+                                                  const int64_t* __restrict__ ev_off, int* __restrict__ ev_count,
                                                   double2* __restrict__ uv, double4* __restrict__ X) {
   const int e = blockIdx.x, lane = threadIdx.x;
   const int p = ev_prob[e];
@@ -567,7 +586,10 @@ __global__ __launch_bounds__(64) void k_lo_gather(int est, const int* __restrict
   for (int i0 = 0; i0 < n; i0 += 64) {
     const int i = i0 + lane;
     bool in = false;
-    if (i < n) in = model_error(est, m, pd + (size_t)i * ds) < thresh;
+    if (i < n) {
+      const double r = model_error(est, m, pd + (size_t)i * ds);
+      in = ev_sqt ? (r * r < ev_sqt[e]) : (r < thresh);
+    }
     const unsigned long long b = __ballot(in);
     if (in) {
       const int pos = base + __popcll(b & ((1ull << lane) - 1ull));
@@ -1378,7 +1400,6 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE && sample_size(est) != 2)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "ExhaustiveSampler makes a hard assumption that the number of samples needed is 2.");
   const bool lmed = P.ransac_type == THEIA_RANSAC_LMED;
-  if (lmed && P.use_lo) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_lo together with LMED is not built");
   if (P.ransac_type != THEIA_RANSAC_RANSAC && P.ransac_type != THEIA_RANSAC_PROSAC && !lmed &&
       P.ransac_type != THEIA_RANSAC_EXHAUSTIVE)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown ransac_type");
@@ -1448,6 +1469,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     if (lmed_lds > 48 * 1024) {
       HIP_TRYR(hipFuncSetAttribute((const void*)k_score_lmed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lmed_lds));
       HIP_TRYR(hipFuncSetAttribute((const void*)k_inlier_mask_lmed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lmed_lds));
+      HIP_TRYR(hipFuncSetAttribute((const void*)k_lo_lmed_bound, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lmed_lds));
     }
   }
   const bool use_lds = (size_t)nmax * ds * sizeof(double) <= 96 * 1024;
@@ -1476,7 +1498,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   // ---- LO-RANSAC (absolute / relative pose): batched RefineModel over a list of events
   DBuf<int> d_ev_prob, d_ev_samples, d_ev_slot, d_ev_hyp, d_ev_count, d_ev_success, d_lo_model_id;
   DBuf<int64_t> d_ev_off;
-  DBuf<double> d_ev_model, d_ev_cam, d_lo_uv, d_lo_X, d_cur_models, d_lo_intr;
+  DBuf<double> d_ev_model, d_ev_cam, d_lo_uv, d_lo_X, d_cur_models, d_lo_intr, d_ev_sqt;
   DBuf<char> d_lo_out;
   theia_ba_options lo_opts;
   theia_ba_options_default(&lo_opts);
@@ -1531,7 +1553,11 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     k_lo_prepare<<<(nev + 63) / 64, 64, 0, st>>>(est, nev, d_ev_prob.p, d_ev_samples.p, d_ev_slot.p, d_ev_hyp.p, lo_round_B,
                                                  d_models.p, d_hyp_base.p, d_off.p, d_data.p,
                                                  d_cur_models.p, d_ev_model.p, d_ev_cam.p, ep);
-    k_lo_gather<<<nev, 64, 0, st>>>(est, d_ev_prob.p, d_off.p, d_data.p, d_ev_model.p, P.error_thresh, d_ev_off.p, d_ev_count.p,
+    if (lmed) {
+      if ((rc2 = d_ev_sqt.ensure(nev))) return rc2;
+      k_lo_lmed_bound<<<nev, 256, lmed_lds, st>>>(est, d_ev_prob.p, d_off.p, d_data.p, d_ev_model.p, d_ev_sqt.p);
+    }
+    k_lo_gather<<<nev, 64, 0, st>>>(est, d_ev_prob.p, d_off.p, d_data.p, d_ev_model.p, P.error_thresh, lmed ? d_ev_sqt.p : nullptr, d_ev_off.p, d_ev_count.p,
                                     reinterpret_cast<double2*>(d_lo_uv.p), reinterpret_cast<double4*>(d_lo_X.p));
     if (fund)
       fundamental_batch_device(nev, d_ev_off.p, d_ev_count.p, d_lo_X.p, d_ev_cam.p, &lo_opts, d_lo_out.p, st);

@@ -143,8 +143,8 @@ def test_mirror_api_and_error_conventions():
     assert ok and len(sl.inliers) > 50
     plo = ransac.RansacParameters(); plo.error_thresh = THR[0]; plo.use_lo = True
     plo.ransac_type = ransac.RansacType.LMED
-    with pytest.raises(capi.TheiaHipError):
-        ransac.estimate_batch(0, data, np.array([0, len(data)]), plo)                # use_lo together with LMED: not built
+    rlo = ransac.estimate_batch(0, data, np.array([0, len(data)]), plo)              # use_lo together with LMED
+    assert rlo["success"][0] and rlo["num_lo_iterations"][0] >= 1
     ok, ad, s5 = ransac.EstimateCalibratedAbsolutePose(p, ransac.RansacType.RANSAC, ransac.PnPType.DLS, da)
     assert ok and np.abs(ad.position - ta["position"][0]).max() < 0.25 and len(s5.inliers) > 30
     with pytest.raises(capi.TheiaHipError):
@@ -188,6 +188,26 @@ def test_lo_ransac_absolute_pose_follows_oracle():
     assert np.median(err_lo) <= np.median(err_plain) + 1e-3
     print("LO iterations per problem:", res["num_lo_iterations"])
     assert res["num_lo_iterations"].sum() > 10      # some in-loop refinements succeeded, not only the final one
+
+
+@pytest.mark.parametrize("est,kind", [(2, "absolute"), (0, "relative"), (1, "relative")])
+def test_lo_under_lmed_follows_oracle(est, kind):
+    """use_lo with RansacType::LMED: RefineModel sees the inliers of the LMED quality measurement (r^2 below its
+    median-derived bound, lmed_quality_measurement.h:58-130), not the error_thresh ones: control flow (iterations, LO counts)
+    and inlier sets identical to the oracle's, models to the LO refinement's 1e-8 (the essential-matrix estimator keeps the
+    default RefineModel: counters only)."""
+    data, offsets, truth = synth.synth_ransac_v1(8, 250, kind, seed=0x5AC50710, noise_px=1.0)
+    p = ransac.RansacParameters(); p.error_thresh = THR[est]; p.seed = 91; p.ransac_type = ransac.RansacType.LMED
+    p.use_lo = True; p.lo_start_iterations = 5; p.min_iterations = 60; p.max_iterations = 300; p.failure_probability = 0.001
+    res = ransac.estimate_batch(est, data, offsets, p)
+    for i in range(8):
+        pc = p.to_c(); pc.seed = 91 + i
+        sl = slice(offsets[i], offsets[i + 1])
+        o = ol.ransac_estimate(est, data[sl], pc)
+        nlo = ol.rlib().oracle_last_lo_iterations()
+        assert o["num_iterations"] == res["num_iterations"][i] and nlo == res["num_lo_iterations"][i] and nlo >= 1
+        assert np.array_equal(o["inlier_mask"], res["inlier_mask"][sl])
+        assert np.abs(o["model"][:MLEN[est]] - res["models"][i][:MLEN[est]]).max() <= 1e-8
 
 
 def test_lo_ransac_relative_pose_follows_oracle():
