@@ -349,11 +349,14 @@ int theia_hip_track_statistics(const theia_ba_problem* problem,
                                double* min_ray_cosine);
 
 /* TrackEstimator::EstimateTrack (estimate_track.cc:206-319) for every point of `problem` that is
- * not flagged in point_const, triangulation_method = MIDPOINT (the default, estimate_track.h:82):
+ * not flagged in point_const.  With triangulation_method = MIDPOINT (the default, estimate_track.h:82):
  *   1. fewer than two observations, or no pair of viewing rays further apart than
  *      min_triangulation_angle_degrees (SufficientTriangulationAngle, triangulation.cc:236-250) -> bad angle;
  *   2. TriangulateMidpoint (triangulation.cc:130-157): sum (I - d d^T) X = sum (I - d d^T) o, Cholesky;
  *      not positive definite -> failed triangulation; the point becomes (X, 1);
+ *      SVD / L2_MINIMIZATION: TriangulateNViewSVD / TriangulateNView (triangulation.cc:178-214) on the pixels and
+ *      Camera::GetProjectionMatrix of every observation (computed here from the extrinsics and the model's focal length,
+ *      aspect ratio, skew and principal point); the homogeneous point is defined up to sign, as in the reference;
  *   3. bundle_adjustment: BundleAdjustTrack on that point (= theia_hip_ba_tracks_batch), !success -> rejected;
  *   4. AcceptableReprojectionError (estimate_track.cc:93-117): any view with Camera::ProjectPoint < 0, or a mean
  *      squared reprojection error >= max_acceptable_reprojection_error_pixels^2 -> bad reprojection.
@@ -366,7 +369,7 @@ typedef struct theia_track_estimate_options {
   double min_triangulation_angle_degrees;           /* estimate_track.h:69, default 3.0 */
   double max_acceptable_reprojection_error_pixels;  /* :64, default 5.0 */
   int32_t bundle_adjustment;                        /* :73, default 1 */
-  int32_t reserved;
+  int32_t triangulation_method;                     /* :82, TriangulationMethodType: 0 MIDPOINT (default), 1 SVD, 2 L2_MINIMIZATION */
 } theia_track_estimate_options;
 int theia_hip_estimate_tracks(const theia_ba_problem* problem, const double* obs_ray_dir,
                               const theia_ba_options* ba_options,

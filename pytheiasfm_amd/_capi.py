@@ -124,7 +124,7 @@ class RansacParams(C.Structure):
 class TrackEstimateOptions(C.Structure):
     """theia_track_estimate_options (TrackEstimator::Options, estimate_track.h:58-83)."""
     _fields_ = [("min_triangulation_angle_degrees", C.c_double), ("max_acceptable_reprojection_error_pixels", C.c_double),
-                ("bundle_adjustment", C.c_int32), ("reserved", C.c_int32)]
+                ("bundle_adjustment", C.c_int32), ("triangulation_method", C.c_int32)]
 
 
 class RansacBatch(C.Structure):

@@ -385,9 +385,9 @@ def track_statistics(problem):
 
 
 def estimate_tracks(problem, obs_ray_dir, ba_options, min_triangulation_angle_degrees=3.0,
-                    max_acceptable_reprojection_error_pixels=5.0, bundle_adjustment=True):
-    """theia_hip_estimate_tracks: TrackEstimator::EstimateTrack (MIDPOINT) for every non-constant point of
-    `problem`; problem.points is updated in place.  Returns (estimated [num_points] bool,
+                    max_acceptable_reprojection_error_pixels=5.0, bundle_adjustment=True, triangulation_method=0):
+    """theia_hip_estimate_tracks: TrackEstimator::EstimateTrack for every non-constant point of `problem`
+    (triangulation_method = TriangulationMethodType: 0 MIDPOINT, 1 SVD, 2 L2_MINIMIZATION); problem.points is updated in place.  Returns (estimated [num_points] bool,
     {"bad_angles", "failed_triangulations", "bad_reprojections", "ba_failures"})."""
     st = problem.as_struct()
     num = problem.points.shape[0]
@@ -398,6 +398,7 @@ def estimate_tracks(problem, obs_ray_dir, ba_options, min_triangulation_angle_de
     eo.min_triangulation_angle_degrees = float(min_triangulation_angle_degrees)
     eo.max_acceptable_reprojection_error_pixels = float(max_acceptable_reprojection_error_pixels)
     eo.bundle_adjustment = int(bool(bundle_adjustment))
+    eo.triangulation_method = int(triangulation_method)
     est = np.zeros(max(1, num), dtype=np.uint8)
     cnt = (C.c_int32 * 4)()
     L = capi.lib()

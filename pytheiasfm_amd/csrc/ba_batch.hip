@@ -486,11 +486,120 @@ __global__ __launch_bounds__(64) void k_track_stats(TrackBatch B, double* __rest
   min_ray_cos[p] = mincos;
 }
 
+// ---- N-view triangulation of the other two TriangulationMethodType values (estimate_track.cc:239-257) ----
+// Camera::GetProjectionMatrix (camera.cc:195-200): K [R | -R c], K = [f s cx; 0 f a cy; 0 0 1] from the model's own
+// focal length / aspect ratio / skew / principal point slots (FOV and division-undistortion have no skew slot).
+__device__ inline void track_projection_matrix(int model, const double* k, const double* ext, double* P) {
+  RotTerms rt;
+  rotation_terms(ext + 3, rt);
+  const bool noskew = model == THEIA_CAM_FOV || model == THEIA_CAM_DIVISION_UNDISTORTION;
+  const double f = k[0], fa = k[0] * k[1], sk = noskew ? 0.0 : k[2];
+  const double cx = noskew ? k[2] : k[3], cy = noskew ? k[3] : k[4];
+  double Rt[12];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) Rt[4 * r + c] = rt.R[3 * r + c];
+    Rt[4 * r + 3] = -((rt.R[3 * r] * ext[0] + rt.R[3 * r + 1] * ext[1]) + rt.R[3 * r + 2] * ext[2]);
+  }
+  for (int c = 0; c < 4; ++c) {
+    P[c] = (f * Rt[c] + sk * Rt[4 + c]) + cx * Rt[8 + c];
+    P[4 + c] = fa * Rt[4 + c] + cy * Rt[8 + c];
+    P[8 + c] = Rt[8 + c];
+  }
+}
+
+// eigenvector of the smallest eigenvalue of a symmetric 4 x 4 matrix (cyclic Jacobi; A row-major, destroyed)
+__device__ inline void smallest_eigenvector4(double* A, double* x) {
+  double V[16];
+  for (int i = 0; i < 16; ++i) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < 4; ++i) { diag += A[5 * i] * A[5 * i]; for (int j = i + 1; j < 4; ++j) off += A[4 * i + j] * A[4 * i + j]; }
+    if (!(off > 1e-34 * diag)) break;
+    for (int pI = 0; pI < 3; ++pI)
+      for (int q = pI + 1; q < 4; ++q) {
+        const double apq = A[4 * pI + q];
+        if (apq == 0.0) continue;
+        const double theta = (A[5 * q] - A[5 * pI]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < 4; ++k) {   // A <- A J
+          const double akp = A[4 * k + pI], akq = A[4 * k + q];
+          A[4 * k + pI] = c * akp - sn * akq; A[4 * k + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < 4; ++k) {   // A <- J^T A
+          const double apk = A[4 * pI + k], aqk = A[4 * q + k];
+          A[4 * pI + k] = c * apk - sn * aqk; A[4 * q + k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double vkp = V[4 * k + pI], vkq = V[4 * k + q];
+          V[4 * k + pI] = c * vkp - sn * vkq; V[4 * k + q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  int best = 0;
+  for (int i = 1; i < 4; ++i) if (A[5 * i] < A[5 * best]) best = i;
+  for (int k = 0; k < 4; ++k) x[k] = V[4 * k + best];
+}
+
+// TriangulateNView (triangulation.cc:197-214, L2_MINIMIZATION): the eigenvector of the smallest eigenvalue of
+// sum C^T C, C = (I - n n^T) P with n the normalised homogeneous pixel.  TriangulateNViewSVD (:178-194, SVD): the first
+// four entries of the right singular vector of the smallest singular value of the 3N x (4 + N) matrix [-P_i | e_i x_i]:
+// eliminating the N scale unknowns from its normal equations leaves, for the eigenvalue mu,
+//     [ sum C^T C - mu (I + sum b_i b_i^T / (d_i (d_i - mu))) ] X = 0,   b_i = P_i^T x_i, d_i = x_i^T x_i, lambda_i = b_i.X / (d_i - mu)
+// -- the L2 matrix at mu = 0 -- solved by a few fixed-point steps on mu (the Rayleigh quotient of the full vector);
+// the result carries the reference's normalisation (unit norm over all 4 + N entries).  The sign is arbitrary, as Eigen's is.
+__device__ inline void triangulate_nview(const TrackBatch& B, int64_t beg, int64_t end, bool svd, double* X) {
+  double mu = 0.0;
+  double x[4] = {0.0, 0.0, 0.0, 1.0};
+  const int rounds = svd ? 4 : 1;
+  for (int round = 0; round < rounds; ++round) {
+    double D[16];
+    for (int i = 0; i < 16; ++i) D[i] = 0.0;
+    for (int64_t i = beg; i < end; ++i) {
+      const int c = B.obs_cam[i], grp = B.cam_group[c];
+      double P[12];
+      track_projection_matrix(B.group_model[grp], B.intr + (size_t)grp * THEIA_MAX_INTRINSICS, B.cam + 6 * (size_t)c, P);
+      const double u = B.uv[i].x, v = B.uv[i].y;
+      const double d = (u * u + v * v) + 1.0, nrm = sqrt(d);
+      const double n[3] = {u / nrm, v / nrm, 1.0 / nrm};
+      double t[4], C[12];
+      for (int k = 0; k < 4; ++k) t[k] = (n[0] * P[k] + n[1] * P[4 + k]) + n[2] * P[8 + k];
+      for (int r = 0; r < 3; ++r) for (int k = 0; k < 4; ++k) C[4 * r + k] = P[4 * r + k] - n[r] * t[k];
+      for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) D[4 * a + b] += (C[a] * C[b] + C[4 + a] * C[4 + b]) + C[8 + a] * C[8 + b];
+      if (mu != 0.0) {   // - mu b b^T / (d (d - mu)) with b = P^T x = nrm * t, i.e. - mu / (d - mu) t t^T
+        const double w = mu / (d - mu);
+        for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) D[4 * a + b] -= w * (t[a] * t[b]);
+      }
+    }
+    if (mu != 0.0) for (int a = 0; a < 4; ++a) D[5 * a] -= mu;
+    smallest_eigenvector4(D, x);
+    if (!svd) break;
+    // Rayleigh quotient of the full vector (X, lambda): v^T M v = sum |P X - lambda x|^2
+    double num = 0.0, den = (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+    for (int64_t i = beg; i < end; ++i) {
+      const int c = B.obs_cam[i], grp = B.cam_group[c];
+      double P[12];
+      track_projection_matrix(B.group_model[grp], B.intr + (size_t)grp * THEIA_MAX_INTRINSICS, B.cam + 6 * (size_t)c, P);
+      const double xi[3] = {B.uv[i].x, B.uv[i].y, 1.0};
+      const double d = (xi[0] * xi[0] + xi[1] * xi[1]) + 1.0;
+      double px[3];
+      for (int r = 0; r < 3; ++r) px[r] = ((P[4 * r] * x[0] + P[4 * r + 1] * x[1]) + P[4 * r + 2] * x[2]) + P[4 * r + 3] * x[3];
+      const double lam = ((xi[0] * px[0] + xi[1] * px[1]) + xi[2] * px[2]) / (d - mu);
+      for (int r = 0; r < 3; ++r) { const double e = px[r] - lam * xi[r]; num += e * e; }
+      den += lam * lam;
+    }
+    mu = num / den;
+    if (round == rounds - 1) { const double sc = 1.0 / sqrt(den); for (int k = 0; k < 4; ++k) x[k] *= sc; }
+  }
+  for (int k = 0; k < 4; ++k) X[k] = x[k];
+}
+
 // Stage 1 + 2 of TrackEstimator::EstimateTrack, one thread per track: the triangulation-angle test on the
 // supplied viewing rays and TriangulateMidpoint.  status: 0 = triangulated, 1 = bad angle, 2 = failed
 // triangulation, 3 = skipped (constant point).
 __global__ __launch_bounds__(64) void k_track_triangulate(TrackBatch B, const double* __restrict__ rays, double cos_min_angle,
-                                                          int* __restrict__ status) {
+                                                          int method /* 0 MIDPOINT, 1 SVD, 2 L2_MINIMIZATION */, int* __restrict__ status) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= B.num) return;
   if (B.pt_const && B.pt_const[p]) { status[p] = 3; return; }
@@ -502,6 +611,11 @@ __global__ __launch_bounds__(64) void k_track_triangulate(TrackBatch B, const do
       if (d < cos_min_angle) { ok_angle = true; break; }
     }
   if (end - beg < 2 || !ok_angle) { status[p] = 1; return; }
+  if (method == 1 || method == 2) {   // TriangulateNViewSVD / TriangulateNView: always "true" (triangulation.cc:193,213)
+    triangulate_nview(B, beg, end, method == 1, B.pts + 4 * (size_t)p);
+    status[p] = 0;
+    return;
+  }
   // A = sum (I - d d^T), b = sum (I - d d^T) o  (the 4th row / column of the reference's 4 x 4 system is n X_w = n)
   double A[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};   // A lower: 00 10 11 20 21 22
   for (int64_t i = beg; i < end; ++i) {
@@ -761,6 +875,8 @@ extern "C" int theia_hip_estimate_tracks(const theia_ba_problem* p, const double
   if (np == 0) return 0;
   if (!estimated || !counters) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null output");
   if (p->num_obs > 0 && !obs_ray_dir) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null viewing rays");
+  if (eo->triangulation_method < 0 || eo->triangulation_method > 2)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown triangulation method (0 MIDPOINT, 1 SVD, 2 L2_MINIMIZATION)");
   if (o->loss_function_type < 0 || o->loss_function_type > THEIA_LOSS_TRUNCATED)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown loss function type");
   PointGrouped G;
@@ -798,7 +914,7 @@ extern "C" int theia_hip_estimate_tracks(const theia_ba_problem* p, const double
   B.parameter_tolerance = o->parameter_tolerance; B.max_radius = o->max_trust_region_radius;
   const int grid = (np + 63) / 64;
   const double kPi = 3.14159265358979323846;
-  k_track_triangulate<<<grid, 64>>>(B, d_rays.p, cos(eo->min_triangulation_angle_degrees * kPi / 180.0), d_status.p);
+  k_track_triangulate<<<grid, 64>>>(B, d_rays.p, cos(eo->min_triangulation_angle_degrees * kPi / 180.0), eo->triangulation_method, d_status.p);
   std::vector<int> status(np);
   HIP_TRY(hipMemcpy(status.data(), d_status.p, sizeof(int) * np, hipMemcpyDeviceToHost));
   // the track BA and the reprojection sweep run on the triangulated tracks only: everything else is "constant"

@@ -859,6 +859,71 @@ def test_estimate_tracks_follows_track_estimator_rules():
     assert np.allclose(pg2.points[12, :3], _midpoint(pg2.cam_ext[pg2.obs_cam[sel], :3], rays_k[sel]), rtol=1e-12, atol=1e-12)
 
 
+def _projection_matrix(ext, k, model):
+    """Camera::GetProjectionMatrix (camera.cc:195-200): K [R | -R c]."""
+    R = synth.angle_axis_to_matrix(ext[None, 3:6])[0]
+    noskew = model in (3, 4)   # THEIA_CAM_FOV, THEIA_CAM_DIVISION_UNDISTORTION: no skew slot
+    f, a = k[0], k[1]
+    sk, cx, cy = (0.0, k[2], k[3]) if noskew else (k[2], k[3], k[4])
+    K = np.array([[f, sk, cx], [0.0, f * a, cy], [0.0, 0.0, 1.0]])
+    return K @ np.concatenate([R, (-R @ ext[:3])[:, None]], axis=1)
+
+
+@pytest.mark.parametrize("method", [1, 2])
+def test_estimate_tracks_svd_and_l2_triangulation(method):
+    """TriangulationMethodType SVD / L2_MINIMIZATION (estimate_track.cc:239-257): without the track BA the point is
+    TriangulateNViewSVD / TriangulateNView (triangulation.cc:178-214) of the pixels and the cameras' projection matrices,
+    restated here with numpy's SVD of the 3N x (4 + N) design matrix / eigh of the 4 x 4 one (defined up to sign); with the
+    BA the tracks end where the MIDPOINT start ends (same minimum), and the counters follow the same rules."""
+    p = synth.synth_ba_v1(14, 120, seed=0xE5A1, sigma_pt=0.0, sigma_pos=0.0, sigma_rot_deg=0.0, pixel_noise=0.5)   # pinhole: the linear methods ignore any distortion
+    o, _ = both_options(max_num_iterations=15, use_inner_iterations=0)
+    C_ = p.cam_ext[p.obs_cam, :3]
+    X = p.points[p.obs_pt, :3] / p.points[p.obs_pt, 3:]
+    rays = X - C_; rays /= np.linalg.norm(rays, axis=1, keepdims=True)
+    pg = p.copy(); pg.points[:] = 0.0; pg.points[:, 3] = 1.0
+    est, cnt = ba.estimate_tracks(pg, rays, o, 1.0, 5.0, False, triangulation_method=method)
+    worst, dist = 0.0, []
+    for q in range(120):
+        sel = np.flatnonzero(pg.obs_pt == q)
+        d = rays[sel]
+        if len(sel) < 2 or not np.any(np.triu(d @ d.T < np.cos(np.deg2rad(1.0)), 1)):
+            assert not est[q]
+            continue
+        Ps = [_projection_matrix(pg.cam_ext[c], pg.intrinsics[pg.cam_group[c]], int(pg.group_model[pg.cam_group[c]])) for c in pg.obs_cam[sel]]
+        n = len(sel)
+        if method == 1:
+            A = np.zeros((3 * n, 4 + n))
+            for i, (P, uv) in enumerate(zip(Ps, pg.obs_uv[sel])):
+                A[3 * i:3 * i + 3, :4] = -P
+                A[3 * i:3 * i + 3, 4 + i] = [uv[0], uv[1], 1.0]
+            ref = np.linalg.svd(A)[2][-1][:4]
+        else:
+            D = np.zeros((4, 4))
+            for P, uv in zip(Ps, pg.obs_uv[sel]):
+                nn = np.array([uv[0], uv[1], 1.0]); nn /= np.linalg.norm(nn)
+                Cm = P - np.outer(nn, nn) @ P
+                D += Cm.T @ Cm
+            ref = np.linalg.eigh(D)[1][:, 0]
+        got = pg.points[q]
+        sgn = np.sign(got @ ref)
+        worst = max(worst, np.abs(got * sgn - ref).max() / np.abs(ref).max())
+        dist.append(np.linalg.norm(got[:3] / got[3] - p.points[q, :3] / p.points[q, 3]))
+    assert worst < 1e-7, worst
+    assert np.median(dist) < 0.05      # 0.5 px noise, lens distortion ignored by the linear methods: near the planted points
+    assert cnt["failed_triangulations"] == 0 and est.sum() >= 100
+    # with the track BA: the same minimum as from the midpoint start
+    pa = p.copy(); pa.points[:] = 0.0; pa.points[:, 3] = 1.0
+    pb = p.copy(); pb.points[:] = 0.0; pb.points[:, 3] = 1.0
+    ea, _ = ba.estimate_tracks(pa, rays, o, 1.0, 5.0, True, triangulation_method=method)
+    eb, _ = ba.estimate_tracks(pb, rays, o, 1.0, 5.0, True, triangulation_method=0)
+    both = ea & eb
+    assert both.sum() >= 100
+    Xa = pa.points[both, :3] / pa.points[both, 3:]; Xb = pb.points[both, :3] / pb.points[both, 3:]
+    assert np.abs(Xa - Xb).max() < 1e-4
+    with pytest.raises(capi.TheiaHipError):
+        ba.estimate_tracks(pa, rays, o, 1.0, 5.0, True, triangulation_method=3)
+
+
 def _with_depth_priors(p, cam_gt, pts_gt, every=3, variance=1e-4, noise=0.005, seed=0xDE97):
     """Depth priors (noisy true depth) on every `every`-th observation."""
     idx = np.arange(0, p.obs_uv.shape[0], every)
