@@ -1465,7 +1465,8 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   HBuf<double> h_cost;
   const size_t lmed_lds = (size_t)nmax * sizeof(double);
   if (lmed) {
-    if (lmed_lds > 64 * 1024) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "LMED: more than 8192 data per problem (LDS-resident select)");
+    // the squared residuals of a model stay in LDS for the radix select: 160 KB per workgroup on gfx950, 8 KB kept for the rest
+    if (lmed_lds > 152 * 1024) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "LMED: more than 19456 data per problem (LDS-resident select)");
     if (lmed_lds > 48 * 1024) {
       HIP_TRYR(hipFuncSetAttribute((const void*)k_score_lmed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lmed_lds));
       HIP_TRYR(hipFuncSetAttribute((const void*)k_inlier_mask_lmed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lmed_lds));
