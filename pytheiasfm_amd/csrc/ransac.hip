@@ -315,7 +315,7 @@ __global__ __launch_bounds__(score_threads(EST)) void k_score(int est_rt, int np
   if (slot >= nmodels) return;
   const int mm = max_models(est);
   const size_t dense = (size_t)p * B * mm + slot;
-  const size_t out = (size_t)p * B * mm + tags[dense];  // [hyp][slot] position
+  const size_t out = dense;   // scores stay in the dense order of the models (hyp_base[hyp] + slot): the host downloads them packed
   double m[kStride];
   const double* mo = models + dense * (size_t)kStride;
 #pragma unroll
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_score_lmed(int est, int nprob, int B, c
   int cnt;
   const double med = lmed_block(est, m, data + (size_t)offsets[p] * ds, n, ds, sample_size(est), sdata, hist, sel, &cnt, nullptr);
   if (threadIdx.x == 0) {
-    const size_t out = (size_t)p * B * mm + tags[dense];
+    const size_t out = dense;
     cost[out] = med; ninl[out] = cnt;
   }
 }
@@ -470,6 +470,20 @@ __global__ void k_save_best(int est, int n, const int* __restrict__ prob, const 
   const int h = hyp[e], q = h / round_B;
   best_models[(size_t)prob[e] * kStride + k] =
       round_models[((size_t)q * round_B * max_models(est) + hyp_base[h] + slot[e]) * (size_t)kStride + k];
+}
+
+// scores of a round, packed over the problems of the chunk for the download: problem q's dense_count[q] entries (stride
+// B * mm on the device) go to [prefix[q], prefix[q + 1]).  The host reads model j of hypothesis h at prefix[q] + hyp_base[h] + j.
+__global__ void k_pack_scores(int B, int mm, const int* __restrict__ dense_count, const int* __restrict__ prefix,
+                              const double* __restrict__ cost, const int* __restrict__ ninl, double* __restrict__ pcost,
+                              int* __restrict__ pninl) {
+  const int q = blockIdx.y;
+  const int n = dense_count[q];
+  const size_t src = (size_t)q * B * mm;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    pcost[prefix[q] + i] = cost[src + i];
+    pninl[prefix[q] + i] = ninl[src + i];
+  }
 }
 
 __global__ void k_inlier_mask(int est, int nprob, const int64_t* __restrict__ offsets, const double* __restrict__ data,
@@ -1456,6 +1470,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   DBuf<int> d_hyp_base;   // [problem][iteration] first dense model of the hypothesis (k_fit)
   DBuf<int> d_save;       // {problem, hypothesis, slot} triples of k_save_best
   DBuf<double> d_models, d_cost, d_best_models;
+  DBuf<double> d_pcost; DBuf<int> d_pninl, d_prefix;   // the round's scores packed for the download (k_pack_scores)
   DBuf<double> d_dls_action, d_dls_tfac, d_dls_u; DBuf<int> d_dls_ok, d_iter_base;   // DLS: stage A -> stage B
   DBuf<double> d_fp_ws, d_fp_sol; DBuf<int> d_fp_ok, d_fp_mask;   // five-point: stages a -> b -> c
   std::vector<double> h_dls_u; dls::GlibcRand dls_gen; std::vector<int> h_iter_base;
@@ -1463,6 +1478,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   HBuf<int> h_samples2[2], h_counts, h_ninl, h_active2[2];   // pinned: sources / destinations of the per-round transfers (samples / active
                                                              // counts twice: the next chunk's first round is drawn while the GPU works)
   HBuf<double> h_cost;
+  HBuf<int> h_hyp_base, h_prefix;   // per hypothesis: first model in its problem's dense order; per problem: first packed score
   const size_t lmed_lds = (size_t)nmax * sizeof(double);
   if (lmed) {
     // the squared residuals of a model stay in LDS for the radix select: 160 KB per workgroup on gfx950, 8 KB kept for the rest
@@ -1743,11 +1759,11 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
 #undef THIP_SCORE
       }
       HIP_TRYR(hipEventRecord(ev1, st));
-      if (!h_counts.resize(nh) || !h_cost.resize(nh * kMaxModels) || !h_ninl.resize(nh * kMaxModels))
+      if (!h_counts.resize(nh) || !h_hyp_base.resize(nh) || !h_prefix.resize((size_t)cn + 1))
         return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
       HIP_TRYR(hipMemcpyAsync(h_counts.data(), d_counts.p, sizeof(int) * nh, hipMemcpyDeviceToHost, st));
-      HIP_TRYR(hipMemcpyAsync(h_cost.data(), d_cost.p, sizeof(double) * nh * kMaxModels, hipMemcpyDeviceToHost, st));
-      HIP_TRYR(hipMemcpyAsync(h_ninl.data(), d_ninl.p, sizeof(int) * nh * kMaxModels, hipMemcpyDeviceToHost, st));
+      HIP_TRYR(hipMemcpyAsync(h_hyp_base.data(), d_hyp_base.p, sizeof(int) * nh, hipMemcpyDeviceToHost, st));
+      HIP_TRYR(hipMemcpyAsync(h_prefix.data() + 1, d_dense.p, sizeof(int) * cn, hipMemcpyDeviceToHost, st));
       HIP_TRYR(hipGetLastError());
       // while the GPU fits and scores this round: the first round of the next chunk (its problems are not touched before)
       if (pre_c0 < 0 && c0 + chunk < nprob) {
@@ -1756,6 +1772,24 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         pre_c0 = nc0;
       }
       HIP_TRYR(mine.wait(st));
+      {   // the scores, packed: only the models that exist travel (all max_models slots of every hypothesis were 100 - 270 MB a round)
+        h_prefix.data()[0] = 0;
+        int most = 0;
+        for (int q = 0; q < cn; ++q) { most = std::max(most, h_prefix.data()[q + 1]); h_prefix.data()[q + 1] += h_prefix.data()[q]; }
+        const size_t total_models = (size_t)h_prefix.data()[cn];
+        if (!h_cost.resize(std::max<size_t>(1, total_models)) || !h_ninl.resize(std::max<size_t>(1, total_models)))
+          return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+        if (total_models > 0) {
+          if ((rc = d_prefix.ensure((size_t)cn + 1)) || (rc = d_pcost.ensure(total_models)) || (rc = d_pninl.ensure(total_models))) return rc;
+          HIP_TRYR(hipMemcpyAsync(d_prefix.p, h_prefix.data(), sizeof(int) * ((size_t)cn + 1), hipMemcpyHostToDevice, st));
+          k_pack_scores<<<dim3((unsigned)std::min(64, (most + 255) / 256), cn), 256, 0, st>>>(B, kMaxModels, d_dense.p, d_prefix.p, d_cost.p, d_ninl.p,
+                                                                                          d_pcost.p, d_pninl.p);
+          HIP_TRYR(hipMemcpyAsync(h_cost.data(), d_pcost.p, sizeof(double) * total_models, hipMemcpyDeviceToHost, st));
+          HIP_TRYR(hipMemcpyAsync(h_ninl.data(), d_pninl.p, sizeof(int) * total_models, hipMemcpyDeviceToHost, st));
+          HIP_TRYR(hipGetLastError());
+          HIP_TRYR(mine.wait(st));
+        }
+      }
       const auto tp2 = std::chrono::steady_clock::now();
       { float ms = 0.f; if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) fit_score_ms += ms;
         if (hipEventElapsedTime(&ms, ev0, evm) == hipSuccess) fit_ms += ms;
@@ -1786,8 +1820,9 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
             if (s.rj == 0) my_hyp++;
             while (s.rj < nm) {
               const int j = s.rj++;
-              const double cost = h_cost[hyp * kMaxModels + j];
-              const int ninl = h_ninl[hyp * kMaxModels + j];
+              const size_t at = (size_t)h_prefix.data()[q] + (size_t)h_hyp_base[hyp] + (size_t)j;
+              const double cost = h_cost[at];
+              const int ninl = h_ninl[at];
               my_scored++;
               const double inlier_ratio = (double)ninl / (double)s.n;
               if (cost < s.best_cost) {
