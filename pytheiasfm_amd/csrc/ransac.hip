@@ -322,10 +322,26 @@ __global__ __launch_bounds__(score_threads(EST)) void k_score(int est_rt, int np
   for (int k = 0; k < kStride; ++k) m[k] = mo[k];
   int cnt = 0;
   double mle = 0.0;
-  for (int i = 0; i < n; ++i) {
-    const double r = model_error(est, m, pd + (size_t)i * ds);
-    if (r < thresh) { cnt++; mle += r; }
-    else mle += thresh;
+  if (EST == THEIA_EST_RELATIVE_POSE || EST == THEIA_EST_ESSENTIAL_MATRIX) {
+    // Sampson error without its division wherever the comparison is decided by the margin (ransac_device.h quotient_below)
+    for (int i = 0; i < n; ++i) {
+      const double* d = pd + (size_t)i * ds;
+      bool in = false;
+      double r = 0.0;
+      if (EST == THEIA_EST_ESSENTIAL_MATRIX || rsc::in_front(d, m + 9, m + 18)) {
+        double a, den;
+        rsc::sampson_parts(m, d, &a, &den);
+        in = rsc::quotient_below(a, den, thresh, use_mle != 0, &r);
+      }
+      if (in) { cnt++; mle += r; }
+      else mle += thresh;
+    }
+  } else {
+    for (int i = 0; i < n; ++i) {
+      const double r = model_error(est, m, pd + (size_t)i * ds);
+      if (r < thresh) { cnt++; mle += r; }
+      else mle += thresh;
+    }
   }
   cost[out] = use_mle ? mle : (double)(n - cnt);
   ninl[out] = cnt;

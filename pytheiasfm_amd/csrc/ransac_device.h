@@ -1291,6 +1291,32 @@ RDEV double sampson(const double* F, const double* c) {
   return num * num / den;
 }
 
+// The same error as numerator and denominator (r = a / den): the scoring kernel decides r < thresh without the FP64 division
+// whenever a is clear of thresh * den by more than the roundings involved, and divides only at the boundary or when the value
+// itself is needed (MLE score of an inlier) -- the decisions and sums are those of the divided form, bit for bit.
+RDEV void sampson_parts(const double* F, const double* c, double* a, double* den_out) {
+  const double x0 = c[0], x1 = c[1], y0 = c[2], y1 = c[3];
+  const double ex0 = (F[0] * x0 + F[1] * x1) + F[2];
+  const double ex1 = (F[3] * x0 + F[4] * x1) + F[5];
+  const double ex2 = (F[6] * x0 + F[7] * x1) + F[8];
+  const double num = (y0 * ex0 + y1 * ex1) + ex2;
+  const double dn0 = (y0 * F[0] + y1 * F[3]) + F[6];
+  const double dn1 = (y0 * F[1] + y1 * F[4]) + F[7];
+  *den_out = ((dn0 * dn0 + dn1 * dn1) + ex0 * ex0) + ex1 * ex1;
+  *a = num * num;
+}
+// fl(a / den) < thresh ?  *r receives the quotient when it had to be (or was asked to be) computed, else stays untouched.
+// |fl(t den) - t den| <= eps t den and |fl(a / den) - a / den| <= eps a / den (eps = 2^-53): a margin of 2^-50 covers both.
+RDEV bool quotient_below(double a, double den, double thresh, bool want_value, double* r) {
+  const double td = thresh * den;
+  const double lo = td * (1.0 - 0x1p-50), hi = td * (1.0 + 0x1p-50);
+  if (!want_value && a > hi) return false;
+  if (!want_value && a < lo) return true;
+  if (a > hi) return false;          // an outlier's value is never used
+  *r = a / den;
+  return *r < thresh;
+}
+
 // ---------------------------------------------------------------------------
 // Uncalibrated two-view models, plane and known-orientation position
 // ---------------------------------------------------------------------------
