@@ -11,12 +11,35 @@
 
 namespace thip {
 
+// A block can go back to a cache while work that uses it is still queued (a buffer that grows between rounds, the
+// destructors on an error return): the cache therefore tags a returned block with an event recorded on the stream the
+// returning thread is working on (PoolStreamScope, set by the entry points that enqueue on the shared solver stream) and
+// the next taker waits for that event -- in the normal case it completed long ago and the wait is a flag test.  Threads
+// without a scope (the BA handle, which synchronises its own stream before it lets go) return blocks untagged.
+inline hipStream_t& pool_stream() { static thread_local hipStream_t s = nullptr; return s; }
+struct PoolStreamScope {
+  hipStream_t prev;
+  explicit PoolStreamScope(hipStream_t s) : prev(pool_stream()) { pool_stream() = s; }
+  ~PoolStreamScope() { pool_stream() = prev; }
+  PoolStreamScope(const PoolStreamScope&) = delete;
+  PoolStreamScope& operator=(const PoolStreamScope&) = delete;
+};
+inline hipEvent_t pool_mark() {
+  hipStream_t s = pool_stream();
+  if (!s) return nullptr;
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); return nullptr; }
+  if (hipEventRecord(e, s) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(e); (void)hipStreamSynchronize(s); return nullptr; }
+  return e;
+}
+inline void pool_wait(hipEvent_t e) { if (e) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); } }
+
 // Device blocks of a batch call come from a small process-wide cache: a verification pipeline calls the batch entry
 // points back to back with the same shapes, and hipMalloc / hipFree of the GB-sized model workspace cost more than the
 // kernels of a 1000-pair chunk.  Blocks are reused when they are at most twice the request; the cache keeps at most
 // kPoolLimit bytes (the rest goes back to the runtime), theia_hip_release_scratch() empties it.
 struct DevPool {
-  struct Block { void* p; size_t bytes; int dev; };
+  struct Block { void* p; size_t bytes; int dev; hipEvent_t ev; };
   std::mutex mu;
   std::vector<Block> free_blocks;
   size_t held = 0;
@@ -24,6 +47,7 @@ struct DevPool {
   void* take(size_t bytes, size_t* got) {
     int dev = 0;
     (void)hipGetDevice(&dev);   // a block belongs to the device it was allocated on
+    Block taken{nullptr, 0, 0, nullptr};
     {
       std::lock_guard<std::mutex> lk(mu);
       int best = -1;
@@ -31,12 +55,12 @@ struct DevPool {
         if (free_blocks[i].dev == dev && free_blocks[i].bytes >= bytes && free_blocks[i].bytes <= 2 * bytes + 4096 &&
             (best < 0 || free_blocks[i].bytes < free_blocks[best].bytes)) best = i;
       if (best >= 0) {
-        Block b = free_blocks[best];
+        taken = free_blocks[best];
         free_blocks.erase(free_blocks.begin() + best);
-        held -= b.bytes; *got = b.bytes;
-        return b.p;
+        held -= taken.bytes; *got = taken.bytes;
       }
     }
+    if (taken.p) { pool_wait(taken.ev); return taken.p; }   // (outside the lock)
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) {   // make room and try once more
       release();
@@ -49,16 +73,18 @@ struct DevPool {
     int dev = 0;
     (void)hipGetDevice(&dev);
     static const bool off = getenv("THEIA_HIP_NO_POOL") != nullptr;   // diagnostic: every block goes back to the runtime
+    hipEvent_t ev = pool_mark();
     {
       std::lock_guard<std::mutex> lk(mu);
-      if (!off && held + bytes <= kPoolLimit) { free_blocks.push_back(Block{p, bytes, dev}); held += bytes; return; }
+      if (!off && held + bytes <= kPoolLimit) { free_blocks.push_back(Block{p, bytes, dev, ev}); held += bytes; return; }
     }
+    pool_wait(ev);
     (void)hipFree(p);
   }
   void release() {
     std::vector<Block> blocks;
     { std::lock_guard<std::mutex> lk(mu); blocks.swap(free_blocks); held = 0; }
-    for (const Block& b : blocks) (void)hipFree(b.p);
+    for (const Block& b : blocks) { pool_wait(b.ev); (void)hipFree(b.p); }
   }
 };
 inline DevPool& dev_pool() { static DevPool pool; return pool; }
@@ -84,12 +110,13 @@ struct DBuf {
 // vectors made the D2H copies of a round 4.6 ms against 24 ms of kernels (the DMA engine stages through bounce
 // buffers); pinned memory is expensive to allocate, so the blocks are cached like the device blocks above.
 struct HostPool {
-  struct Block { void* p; size_t bytes; };
+  struct Block { void* p; size_t bytes; hipEvent_t ev; };
   std::mutex mu;
   std::vector<Block> free_blocks;
   size_t held = 0;
   static constexpr size_t kPoolLimit = (size_t)2 << 30;
   void* take(size_t bytes, size_t* got) {
+    Block taken{nullptr, 0, nullptr};
     {
       std::lock_guard<std::mutex> lk(mu);
       int best = -1;
@@ -97,28 +124,30 @@ struct HostPool {
         if (free_blocks[i].bytes >= bytes && free_blocks[i].bytes <= 2 * bytes + 4096 &&
             (best < 0 || free_blocks[i].bytes < free_blocks[best].bytes)) best = i;
       if (best >= 0) {
-        Block b = free_blocks[best];
+        taken = free_blocks[best];
         free_blocks.erase(free_blocks.begin() + best);
-        held -= b.bytes; *got = b.bytes;
-        return b.p;
+        held -= taken.bytes; *got = taken.bytes;
       }
     }
+    if (taken.p) { pool_wait(taken.ev); return taken.p; }
     void* p = nullptr;
     if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
     *got = bytes;
     return p;
   }
   void give(void* p, size_t bytes) {
+    hipEvent_t ev = pool_mark();
     {
       std::lock_guard<std::mutex> lk(mu);
-      if (held + bytes <= kPoolLimit) { free_blocks.push_back(Block{p, bytes}); held += bytes; return; }
+      if (held + bytes <= kPoolLimit) { free_blocks.push_back(Block{p, bytes, ev}); held += bytes; return; }
     }
+    pool_wait(ev);
     (void)hipHostFree(p);
   }
   void release() {
     std::vector<Block> blocks;
     { std::lock_guard<std::mutex> lk(mu); blocks.swap(free_blocks); held = 0; }
-    for (const Block& b : blocks) (void)hipHostFree(b.p);
+    for (const Block& b : blocks) { pool_wait(b.ev); (void)hipHostFree(b.p); }
   }
 };
 inline HostPool& host_pool() { static HostPool pool; return pool; }

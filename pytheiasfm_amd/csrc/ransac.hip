@@ -1458,6 +1458,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     nmax = std::max(nmax, (int)n);
   }
   hipStream_t st = solver_stream();
+  PoolStreamScope pool_scope(st);   // blocks this call hands back to the caches are tagged with an event on this stream (pools.h)
   if (!st) return set_error(THEIA_HIP_ERR_NO_DEVICE, "could not create the solver stream");
   CallSync mine;
   hipEvent_t ev0, ev1, evm;
@@ -1986,6 +1987,7 @@ int theia_hip_five_point_relative_pose(int32_t num, const double* corr, double* 
   int rc = ensure_device();
   if (rc) return rc;
   hipStream_t st = solver_stream();
+  PoolStreamScope pool_scope(st);   // blocks this call hands back to the caches are tagged with an event on this stream (pools.h)
   if (!st) return set_error(THEIA_HIP_ERR_NO_DEVICE, "could not create the solver stream");
   CallSync mine;
   DBuf<double> dc, de; DBuf<int> dn;
@@ -2005,6 +2007,7 @@ int theia_hip_four_point_pose_and_focal_length(int32_t num, const double* corr2d
   int rc = ensure_device();
   if (rc || (rc = p4pf_kernel_ready())) return rc;
   hipStream_t st = solver_stream();
+  PoolStreamScope pool_scope(st);   // blocks this call hands back to the caches are tagged with an event on this stream (pools.h)
   if (!st) return set_error(THEIA_HIP_ERR_NO_DEVICE, "could not create the solver stream");
   CallSync mine;
   // one problem of four data per call row, one hypothesis each with the identity sample: the RANSAC stages as they are
@@ -2044,6 +2047,7 @@ int theia_hip_pose_from_three_points(int32_t num, const double* corr2d3d, double
   int rc = ensure_device();
   if (rc) return rc;
   hipStream_t st = solver_stream();
+  PoolStreamScope pool_scope(st);   // blocks this call hands back to the caches are tagged with an event on this stream (pools.h)
   if (!st) return set_error(THEIA_HIP_ERR_NO_DEVICE, "could not create the solver stream");
   CallSync mine;
   DBuf<double> dc, dr, dt; DBuf<int> dn;
@@ -2066,6 +2070,7 @@ int theia_hip_sqpnp(int32_t num, const int64_t* offsets, const double* features,
   int rc = thip::ensure_device();
   if (rc) return rc;
   hipStream_t st = solver_stream();
+  PoolStreamScope pool_scope(st);   // blocks this call hands back to the caches are tagged with an event on this stream (pools.h)
   if (!st) return set_error(THEIA_HIP_ERR_NO_DEVICE, "could not create the solver stream");
   CallSync mine;
   for (int i = 0; i < num; ++i)
@@ -2105,6 +2110,7 @@ int theia_hip_dls_pnp(int32_t num, const int64_t* offsets, const double* feature
   int rc = thip::ensure_device();
   if (rc || (rc = ensure_dls_tables())) return rc;
   hipStream_t st = solver_stream();
+  PoolStreamScope pool_scope(st);   // blocks this call hands back to the caches are tagged with an event on this stream (pools.h)
   if (!st) return set_error(THEIA_HIP_ERR_NO_DEVICE, "could not create the solver stream");
   CallSync mine;
   if (offsets[0] != 0) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "offsets[0] must be 0");

@@ -47,6 +47,7 @@ int theia_hip_init(int device_ordinal) {
 }
 
 int theia_hip_shutdown(void) {
+  theia_hip_release_scratch();   // the block caches (up to 6 GiB of device and 2 GiB of pinned host memory) go back to the runtime
   thip::g_device.store(-1);
   return 0;
 }
