@@ -376,7 +376,8 @@ int theia_hip_estimate_tracks(const theia_ba_problem* problem, const double* obs
                               const theia_track_estimate_options* options,
                               uint8_t* estimated, int32_t counters[4]);
 
-/* Handle API: problem resident in HBM across calls (bench, repeated solves). */
+/* Handle API: problem resident in HBM across calls (bench, repeated solves).  Problems with THEIA_BA_FLAG_INVERSE_DEPTH
+ * support create / reset_parameters / set_options / run / download / destroy (the other calls return ERR_UNSUPPORTED). */
 typedef struct theia_ba_handle_s* theia_ba_handle;
 int theia_hip_ba_create(const theia_ba_problem* problem,
                         const theia_ba_options* options, theia_ba_handle* out);

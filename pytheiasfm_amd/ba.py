@@ -169,14 +169,14 @@ def solve(problem, options, trace_capacity=256):
 def problem_fingerprint(problem, options=None):
     """128-bit fingerprint of everything a handle is BUILT from -- the topology (observation -> camera / point indices,
     camera -> group, models, constant masks, observation kinds, prior masks), the observations themselves and the
-    options -- and nothing a solve CHANGES (extrinsics, intrinsics, points).  Two problems with the same fingerprint can
+    options -- and nothing a solve CHANGES (extrinsics, intrinsics, points, inverse depths).  Two problems with the same fingerprint can
     share one theia_hip_ba_create: the second only re-uploads its parameters (theia_hip_ba_reset_parameters)."""
     import xxhash
     h = xxhash.xxh3_128()
     p = problem
     h.update(np.array([p.cam_ext.shape[0], p.intrinsics.shape[0], p.points.shape[0], p.obs_uv.shape[0], p.flags], dtype=np.int64).tobytes())
     arrays = [p.obs_cam, p.obs_pt, p.obs_uv, p.obs_sqrt_info, p.group_model, p.cam_group, p.cam_const, p.group_const,
-              p.point_const, p.obs_kind, p.cam_prior_mask]
+              p.point_const, p.obs_kind, p.cam_prior_mask, p.point_ref_cam, p.point_ref_bearing]
     for name in ("position", "gravity", "orientation"):
         pr = p.priors.get(name)
         arrays += [None, None] if pr is None else [pr[0], pr[1]]
@@ -198,7 +198,7 @@ class ProblemCache:
     3 M observations into tiles, the fused kernel's run plan, the K3 schedule, 63-72 ms at C4 -- costs as much as sixty LM
     iterations.  The cache keeps the `capacity` most recently used handles (device-resident plan + observations) keyed by
     problem_fingerprint(); a hit re-uploads the parameters (1000 cameras + 500 000 points: < 2 ms) and runs.
-    The inverse-depth path has no handle and is never cached."""
+    Inverse-depth problems are cached the same way (their handle keeps structure, observations and the reduced-system plan)."""
 
     def __init__(self, capacity=1):
         self.capacity = int(capacity)
@@ -213,7 +213,7 @@ class ProblemCache:
 
     def solve(self, problem, options, trace_capacity=256):
         """As ba.solve(): parameters of `problem` are updated in place; returns (summary, trace)."""
-        if self.capacity <= 0 or (problem.flags & capi.THEIA_BA_FLAG_INVERSE_DEPTH) or problem.obs_uv.shape[0] == 0:
+        if self.capacity <= 0 or problem.obs_uv.shape[0] == 0:
             return solve(problem, options, trace_capacity)
         key = problem_fingerprint(problem, options)
         h = self._handles.pop(key, None)

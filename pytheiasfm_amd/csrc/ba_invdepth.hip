@@ -531,20 +531,43 @@ void trace_push(theia_ba_summary* S, double cost, double g, double step, double 
   if (S->trace_accepted) S->trace_accepted[k] = acc;
 }
 
-}  // namespace
 
-int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_summary* S) {
-  const auto t_start = std::chrono::steady_clock::now();
+// The inverse-depth problem resident on the device: structure, observation arrays, reduced-system plan (create), parameters
+// (upload_parameters), the LM loop (run) and the way back (download).  theia_hip_ba_solve is create + run + download; the
+// handle API (theia_hip_ba_create / reset_parameters / run / download / destroy) keeps the object between calls.
+struct IdHandle {
+  int nc = 0, np = 0, ng = 0, n = 0, ncam6 = 0, ngv = 0, npri = 0;
+  int64_t nobs = 0;
+  std::vector<int> grp_red, h_group_model;
+  struct StreamGuard { hipStream_t s = nullptr; ~StreamGuard() { if (s) (void)hipStreamDestroy(s); } } sg;
+  hipStream_t st = nullptr;
+  Buf<double> d_intr[2], d_scale_i, d_colsq_i, d_pvec, d_pinfo, d_bearing, d_uv, d_si, d_cam[2], d_rho[2], d_scale_c, d_scale_r, d_scale_red, d_recs, d_red, d_vinv, d_grho, d_scal, d_radius, d_work, d_colsq_c, d_colsq_r;
+  Buf<int> d_gm, d_cg, d_cred, d_pref, d_ocam, d_opt, d_pobs, d_gred, d_gk, d_pcam, d_pkind;
+  Buf<unsigned> d_gfree;
+  Buf<uint8_t> d_cmask, d_pconst;
+  Buf<int64_t> d_poff;
+  IdProblem P;
+  CholPlan* plan = nullptr;
+  size_t red_count = 0;
+  int cur = 0;
+  theia_ba_options created_with;   // the structural options a later run must repeat
+  ~IdHandle() { if (st) (void)hipStreamSynchronize(st); chol_plan_destroy(plan); }
+  int create(const theia_ba_problem* p, const theia_ba_options* o);
+  int upload_parameters(const theia_ba_problem* p);
+  int run(const theia_ba_options* o, theia_ba_summary* S);
+  int download(theia_ba_problem* p);
+};
+
+int IdHandle::create(const theia_ba_problem* p, const theia_ba_options* o) {
   if (!p->point_ref_cam || !p->point_ref_bearing || !p->point_inverse_depth)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "inverse depth: point_ref_cam / point_ref_bearing / point_inverse_depth missing");
   if (p->obs_kind)
     return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse depth together with depth-prior rows is not built");
   int rc = ensure_device();
   if (rc) return rc;
-  const int nc = p->num_cameras, np = p->num_points, ng = p->num_groups;
-  const int64_t nobs = p->num_obs;
-  S->trace_size = 0; S->success = 0; S->num_iterations = 0; S->num_successful_steps = 0;
-  S->time_linearize = S->time_solve_reduced = S->time_backsub = 0.0; S->time_kernel_linearize = 0.0; S->num_linearize_launches = 0;
+  nc = p->num_cameras; np = p->num_points; ng = p->num_groups;
+  nobs = p->num_obs;
+  created_with = *o;
   // ---- structure: blocks, observation lists by track
   std::vector<uint8_t> cam_mask(nc, 0), cam_used(nc, 0), pt_const(np, 0);
   for (int c = 0; c < nc; ++c) {
@@ -570,11 +593,12 @@ int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o,
   for (int c = 0; c < nc; ++c) if (cam_used[c] && (cam_mask[c] & 0x3f) != 0x3f) cam_red[c] = ncv++;
   // intrinsics groups (bundle_adjuster.cc:382-460): variable on the subset of intrinsics_to_optimize unless the caller marked
   // the group constant or none of its cameras observes a track
-  std::vector<int> grp_red(ng, -1), grp_k(ng, 0);
+  grp_red.assign(ng, -1);
+  std::vector<int> grp_k(ng, 0);
   std::vector<unsigned> grp_free(ng, 0u);
   std::vector<uint8_t> grp_used(ng, 0);
   for (int64_t i = 0; i < nobs; ++i) grp_used[p->cam_group[p->obs_cam[i]]] = 1;
-  int ngv = 0;
+  ngv = 0;
   for (int g = 0; g < ng; ++g) {
     grp_k[g] = id_intrinsics_size(p->group_model[g]);
     const unsigned fm = id_free_mask(p->group_model[g], o->intrinsics_to_optimize);
@@ -596,7 +620,7 @@ int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o,
       }
     }
   }
-  const int ncam6 = 6 * ncv, n = ncam6 + kKW * ngv;
+  ncam6 = 6 * ncv; n = ncam6 + kKW * ngv;
   // camera priors of the views in the problem (AddViewPriors)
   std::vector<int> prior_cam, prior_kind;
   std::vector<double> prior_vec, prior_info;
@@ -612,32 +636,24 @@ int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o,
         prior_info.insert(prior_info.end(), infos[k] + 9 * (size_t)c, infos[k] + 9 * (size_t)c + 9);
       }
   }
-  const int npri = (int)prior_cam.size();
+  npri = (int)prior_cam.size();
   std::vector<double> si(2 * (size_t)nobs, 1.0);
   if (p->obs_sqrt_info) std::memcpy(si.data(), p->obs_sqrt_info, sizeof(double) * 2 * nobs);
-  // ---- a stream of this call (non-blocking: the entry points stay callable from a thread pool; the legacy stream would
+  // ---- a stream of this object (non-blocking: the entry points stay callable from a thread pool; the legacy stream would
   // serialise against every other stream of the process)
-  struct StreamGuard { hipStream_t s = nullptr; ~StreamGuard() { if (s) (void)hipStreamDestroy(s); } } sg;
   HIP_TRY(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
-  hipStream_t st = sg.s;
-  // ---- device buffers
-  Buf<double> d_intr[2], d_scale_i, d_colsq_i, d_pvec, d_pinfo, d_bearing, d_uv, d_si, d_cam[2], d_rho[2], d_scale_c, d_scale_r, d_scale_red, d_recs, d_red, d_vinv, d_grho, d_scal, d_radius, d_work, d_colsq_c, d_colsq_r;
-  Buf<int> d_gm, d_cg, d_cred, d_pref, d_ocam, d_opt, d_pobs, d_gred, d_gk, d_pcam, d_pkind;
-  Buf<unsigned> d_gfree;
-  Buf<uint8_t> d_cmask, d_pconst;
-  Buf<int64_t> d_poff;
-  std::vector<double> hintr(p->intrinsics, p->intrinsics + (size_t)THEIA_MAX_INTRINSICS * ng);
-  for (int g = 0; g < ng; ++g) if (grp_red[g] >= 0) id_project_to_bounds_host(p->group_model[g], &hintr[(size_t)g * kKW]);   // the initial point, as Ceres does
+  st = sg.s;
+  h_group_model.assign(p->group_model, p->group_model + ng);
   std::vector<double> hb(p->point_ref_bearing, p->point_ref_bearing + 3 * (size_t)np);
-  std::vector<double> huv(p->obs_uv, p->obs_uv + 2 * nobs), hcam(p->cam_ext, p->cam_ext + 6 * (size_t)nc), hrho(p->point_inverse_depth, p->point_inverse_depth + np);
+  std::vector<double> huv(p->obs_uv, p->obs_uv + 2 * nobs);
   std::vector<int> hgm(p->group_model, p->group_model + ng), hcg(p->cam_group, p->cam_group + nc), hpref(p->point_ref_cam, p->point_ref_cam + np);
   std::vector<int> hoc(p->obs_cam, p->obs_cam + nobs), hop(p->obs_pt, p->obs_pt + nobs);
-  const size_t red_count = (size_t)n * n + 3 * (size_t)n;   // S | rhs | colsq | gc
-  if ((rc = d_intr[0].upload(hintr, st)) || (rc = d_intr[1].upload(hintr, st)) || (rc = d_scale_i.alloc((size_t)kKW * ng)) ||
+  red_count = (size_t)n * n + 3 * (size_t)n;   // S | rhs | colsq | gc
+  if ((rc = d_intr[0].alloc((size_t)kKW * ng)) || (rc = d_intr[1].alloc((size_t)kKW * ng)) || (rc = d_scale_i.alloc((size_t)kKW * ng)) ||
       (rc = d_colsq_i.alloc((size_t)kKW * ng)) || (rc = d_gred.upload(grp_red, st)) || (rc = d_gk.upload(grp_k, st)) ||
       (rc = d_gfree.upload(grp_free, st)) || (rc = d_pcam.upload(prior_cam, st)) || (rc = d_pkind.upload(prior_kind, st)) ||
       (rc = d_pvec.upload(prior_vec, st)) || (rc = d_pinfo.upload(prior_info, st)) || (rc = d_bearing.upload(hb, st)) || (rc = d_uv.upload(huv, st)) || (rc = d_si.upload(si, st)) ||
-      (rc = d_cam[0].upload(hcam, st)) || (rc = d_cam[1].upload(hcam, st)) || (rc = d_rho[0].upload(hrho, st)) || (rc = d_rho[1].upload(hrho, st)) ||
+      (rc = d_cam[0].alloc(6 * (size_t)nc)) || (rc = d_cam[1].alloc(6 * (size_t)nc)) || (rc = d_rho[0].alloc(np)) || (rc = d_rho[1].alloc(np)) ||
       (rc = d_gm.upload(hgm, st)) || (rc = d_cg.upload(hcg, st)) || (rc = d_cred.upload(cam_red, st)) || (rc = d_pref.upload(hpref, st)) ||
       (rc = d_ocam.upload(hoc, st)) || (rc = d_opt.upload(hop, st)) || (rc = d_pobs.upload(pt_obs, st)) || (rc = d_cmask.upload(cam_mask, st)) ||
       (rc = d_pconst.upload(pt_const, st)) || (rc = d_poff.upload(pt_off, st)) || (rc = d_scale_c.alloc(6 * (size_t)nc)) ||
@@ -646,7 +662,6 @@ int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o,
       (rc = d_scal.alloc(ID_SCALARS)) || (rc = d_radius.alloc(1)) || (rc = d_work.alloc(dense_cholesky_workspace(std::max(1, n)))) ||
       (rc = d_colsq_c.alloc(6 * (size_t)nc)) || (rc = d_colsq_r.alloc(np)))
     return rc;
-  IdProblem P;
   P.nc = nc; P.np = np; P.nobs = nobs; P.n = n;
   P.ng = ng; P.ncam6 = ncam6; P.grp_red = d_gred.p; P.grp_free = d_gfree.p; P.grp_k = d_gk.p; P.scale_i = d_scale_i.p;
   P.n_priors = npri; P.prior_cam = d_pcam.p; P.prior_kind = d_pkind.p; P.prior_vec = d_pvec.p; P.prior_info = d_pinfo.p;
@@ -654,8 +669,42 @@ int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o,
   P.pt_ref = d_pref.p; P.bearing = d_bearing.p; P.obs_uv = reinterpret_cast<const double2*>(d_uv.p); P.obs_si = reinterpret_cast<const double2*>(d_si.p);
   P.obs_cam = d_ocam.p; P.obs_pt = d_opt.p; P.pt_off = d_poff.p; P.pt_obs = d_pobs.p; P.scale_c = d_scale_c.p; P.scale_r = d_scale_r.p;
   P.loss_type = o->loss_function_type; P.loss_width = o->robust_loss_width;
-  CholPlan* plan = chol_plan_create(n, nullptr);
-  struct PlanGuard { CholPlan* pl; ~PlanGuard() { chol_plan_destroy(pl); } } guard{plan};
+  plan = chol_plan_create(n, nullptr);
+  return upload_parameters(p);
+}
+
+// extrinsics, intrinsics (projected onto their bounds: the initial point, as Ceres does) and inverse depths of `p`
+int IdHandle::upload_parameters(const theia_ba_problem* p) {
+  if (p->num_cameras != nc || p->num_points != np || p->num_groups != ng)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "problem shape differs from the handle's");
+  if (!p->point_inverse_depth) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "inverse depth: point_inverse_depth missing");
+  std::vector<double> hintr(p->intrinsics, p->intrinsics + (size_t)THEIA_MAX_INTRINSICS * ng);
+  for (int g = 0; g < ng; ++g) if (grp_red[g] >= 0) id_project_to_bounds_host(h_group_model[g], &hintr[(size_t)g * kKW]);
+  for (int k = 0; k < 2; ++k) {
+    if (ng) HIP_TRY(hipMemcpyAsync(d_intr[k].p, hintr.data(), sizeof(double) * hintr.size(), hipMemcpyHostToDevice, st));
+    if (nc) HIP_TRY(hipMemcpyAsync(d_cam[k].p, p->cam_ext, sizeof(double) * 6 * (size_t)nc, hipMemcpyHostToDevice, st));
+    if (np) HIP_TRY(hipMemcpyAsync(d_rho[k].p, p->point_inverse_depth, sizeof(double) * (size_t)np, hipMemcpyHostToDevice, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));   // the sources are the caller's (and a local) arrays
+  cur = 0;
+  return 0;
+}
+
+int IdHandle::run(const theia_ba_options* o, theia_ba_summary* S) {
+  const auto t_start = std::chrono::steady_clock::now();
+  if (o->intrinsics_to_optimize != created_with.intrinsics_to_optimize || o->constant_camera_position != created_with.constant_camera_position ||
+      o->constant_camera_orientation != created_with.constant_camera_orientation || o->prior_mask != created_with.prior_mask)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "structural options differ from the ones the handle was created with");
+  int rc = 0;
+  S->trace_size = 0; S->success = 0; S->num_iterations = 0; S->num_successful_steps = 0;
+  S->time_linearize = S->time_solve_reduced = S->time_backsub = 0.0; S->time_kernel_linearize = 0.0; S->num_linearize_launches = 0;
+  P.loss_type = o->loss_function_type; P.loss_width = o->robust_loss_width;
+  if (cur != 0) {   // the state of a previous run: continue from it in slot 0
+    if (ng) HIP_TRY(hipMemcpyAsync(d_intr[0].p, d_intr[1].p, sizeof(double) * (size_t)kKW * ng, hipMemcpyDeviceToDevice, st));
+    if (nc) HIP_TRY(hipMemcpyAsync(d_cam[0].p, d_cam[1].p, sizeof(double) * 6 * (size_t)nc, hipMemcpyDeviceToDevice, st));
+    if (np) HIP_TRY(hipMemcpyAsync(d_rho[0].p, d_rho[1].p, sizeof(double) * (size_t)np, hipMemcpyDeviceToDevice, st));
+    cur = 0;
+  }
   const int ob = (int)((nobs + 255) / 256), tb = (np + 63) / 64, cb = (std::max(nc, ng) + 63) / 64, pb = (npri + 63) / 64;
   double* dS = d_red.p; double* drhs = dS + (size_t)n * n; double* dcolsq = drhs + n; double* dgc = dcolsq + n;
   double hs[ID_SCALARS];
@@ -693,7 +742,6 @@ int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o,
     *out = std::sqrt(hs[0]);
     return 0;
   };
-  int cur = 0;
   double radius = 1e4, decrease_factor = 2.0, x_cost = 0.0, gmax = 0.0, x_norm = 0.0, fixed_cost = 0.0;
   auto linearize = [&]() -> int {   // records, reduced system with the damping of `radius`, gradient max
     HIP_TRY(hipMemcpyAsync(d_radius.p, &radius, sizeof(double), hipMemcpyHostToDevice, st));
@@ -769,13 +817,47 @@ int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o,
   }
   S->num_iterations = iter; S->termination_type = term; S->success = term != THEIA_TERM_FAILURE;
   S->final_cost = minimum_cost + fixed_cost;
-  if (ngv) HIP_TRY(hipMemcpyAsync(p->intrinsics, d_intr[cur].p, sizeof(double) * (size_t)kKW * ng, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(p->cam_ext, d_cam[cur].p, sizeof(double) * 6 * nc, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(p->point_inverse_depth, d_rho[cur].p, sizeof(double) * np, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   S->solve_time_in_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   S->setup_time_in_seconds = 0.0;
   return 0;
 }
+
+int IdHandle::download(theia_ba_problem* p) {
+  if (p->num_cameras != nc || p->num_points != np || p->num_groups != ng)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "problem shape differs from the handle's");
+  if (ngv) HIP_TRY(hipMemcpyAsync(p->intrinsics, d_intr[cur].p, sizeof(double) * (size_t)kKW * ng, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(p->cam_ext, d_cam[cur].p, sizeof(double) * 6 * nc, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(p->point_inverse_depth, d_rho[cur].p, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return 0;
+}
+
+}  // namespace
+
+int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_summary* S) {
+  const auto t_start = std::chrono::steady_clock::now();
+  IdHandle h;
+  int rc = h.create(p, o);
+  if (rc || (rc = h.run(o, S))) return rc;
+  if (S->termination_type == THEIA_TERM_FAILURE && S->num_iterations == 0) return 0;   // invalid start: the parameters stay as given
+  rc = h.download(const_cast<theia_ba_problem*>(p));
+  S->solve_time_in_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  return rc;
+}
+
+// the handle API's view of the object (ba_solver.hip)
+int id_handle_create(const theia_ba_problem* p, const theia_ba_options* o, void** out) {
+  IdHandle* h = new (std::nothrow) IdHandle();
+  if (!h) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "out of host memory");
+  const int rc = h->create(p, o);
+  if (rc) { delete h; return rc; }
+  *out = h;
+  return 0;
+}
+int id_handle_reset(void* h, const theia_ba_problem* p) { return static_cast<IdHandle*>(h)->upload_parameters(p); }
+int id_handle_run(void* h, const theia_ba_options* o, theia_ba_summary* S) { return static_cast<IdHandle*>(h)->run(o, S); }
+int id_handle_download(void* h, theia_ba_problem* p) { return static_cast<IdHandle*>(h)->download(p); }
+void id_handle_destroy(void* h) { delete static_cast<IdHandle*>(h); }
 
 }  // namespace thip

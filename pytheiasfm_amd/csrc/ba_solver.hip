@@ -99,6 +99,7 @@ using namespace thip;
 
 struct theia_ba_handle_s {
   theia_ba_options opt;
+  void* idh = nullptr;   // inverse-depth problems (THEIA_BA_FLAG_INVERSE_DEPTH) live in their own object (ba_invdepth.hip): create / reset / run / download only
   int nc = 0, ng = 0, np = 0, ncv = 0, n = 0, pd = 3;
   int64_t nobs = 0, nobs_main = 0;
   int ntiles_main = 0, ntiles_eval = 0, ntiles_all = 0;  // linearize tiles < + long-track eval tiles < + fixed tiles
@@ -194,6 +195,7 @@ struct theia_ba_handle_s {
   int n_pack_tiles = 0;
 
   ~theia_ba_handle_s() {
+    if (idh) thip::id_handle_destroy(idh);
     if (stream) (void)hipStreamSynchronize(stream);   // the buffers below go back to the device cache, not to hipFree
     drop_graph();
     if (plan) chol_plan_destroy(plan);
@@ -1527,11 +1529,18 @@ int theia_hip_ba_create(const theia_ba_problem* p, const theia_ba_options* o, th
   return rc;
 }
 static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_handle* out, bool allow_fused_intr) {
-  if (p && (p->flags & THEIA_BA_FLAG_INVERSE_DEPTH)) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse depth: use theia_hip_ba_solve (no handle API in this mode)");
   if (!out) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle pointer");
   *out = nullptr;
   int rc = validate(p, o);
   if (rc) return rc;
+  if (p->flags & THEIA_BA_FLAG_INVERSE_DEPTH) {
+    std::unique_ptr<theia_ba_handle_s> hi(new theia_ba_handle_s());
+    hi->opt = *o;
+    hi->nc = p->num_cameras; hi->ng = p->num_groups; hi->np = p->num_points; hi->nobs = p->num_obs;
+    if ((rc = thip::id_handle_create(p, o, &hi->idh))) return rc;
+    *out = hi.release();
+    return 0;
+  }
   rc = thip::ensure_device();
   if (rc) return rc;
   theia_ba_handle_s* h = new theia_ba_handle_s();
@@ -2031,6 +2040,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
 
 int theia_hip_ba_reset_parameters(theia_ba_handle h, const theia_ba_problem* p) {
   if (!h || !p) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (h->idh) return thip::id_handle_reset(h->idh, p);
   if (p->num_cameras != h->nc || p->num_points != h->np || p->num_groups != h->ng)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "problem shape differs from the handle's");
   return upload_parameters(h, p);
@@ -2044,6 +2054,7 @@ int theia_hip_ba_set_shard(theia_ba_handle h, int32_t rank, int32_t world_size) 
 }
 
 int theia_hip_ba_snapshot_parameters(theia_ba_handle h) {
+  if (h && h->idh) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse-depth handle: snapshot is not built in this mode");
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
   int rc;
   if ((rc = h->snap_cam.alloc(h->cam[0].n)) || (rc = h->snap_pts.alloc(h->pts[0].n)) || (rc = h->snap_intr.alloc(h->intr[0].n))) return rc;
@@ -2056,6 +2067,7 @@ int theia_hip_ba_snapshot_parameters(theia_ba_handle h) {
 }
 
 int theia_hip_ba_restore_parameters(theia_ba_handle h) {
+  if (h && h->idh) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse-depth handle: restore is not built in this mode");
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
   if (!h->has_snapshot) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "no snapshot taken on this handle");
   for (int k = 0; k < 2; ++k) {
@@ -2071,6 +2083,13 @@ int theia_hip_ba_restore_parameters(theia_ba_handle h) {
 
 int theia_hip_ba_set_options(theia_ba_handle h, const theia_ba_options* o) {
   if (!h || !o) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (h->idh) {   // the run checks the structural options against the ones the object was created with
+    if (o->intrinsics_to_optimize != h->opt.intrinsics_to_optimize || o->constant_camera_position != h->opt.constant_camera_position ||
+        o->constant_camera_orientation != h->opt.constant_camera_orientation || o->prior_mask != h->opt.prior_mask)
+      return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "structural options differ from the ones the handle was created with");
+    h->opt = *o;
+    return 0;
+  }
   const theia_ba_options& c = h->opt;
   if (o->use_homogeneous_point_parametrization != c.use_homogeneous_point_parametrization ||
       o->constant_camera_orientation != c.constant_camera_orientation ||
@@ -2092,6 +2111,7 @@ int theia_hip_ba_set_options(theia_ba_handle h, const theia_ba_options* o) {
 }
 
 int theia_hip_ba_set_allreduce(theia_ba_handle h, theia_allreduce_fn fn, void* ctx) {
+  if (h && h->idh) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse-depth handle: sharding is not built in this mode");
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
   h->allreduce = fn; h->allreduce_ctx = ctx;
   h->plan_is_global = (fn == nullptr);   // the K3 schedule must cover every rank's tracks
@@ -2100,6 +2120,7 @@ int theia_hip_ba_set_allreduce(theia_ba_handle h, theia_allreduce_fn fn, void* c
 
 int theia_hip_ba_plan_info(theia_ba_handle h, int32_t* n, int32_t* k3_levels, double* k3_flops, int32_t* fused_runs,
                            int32_t* slow_path_tracks) {
+  if (h && h->idh) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse-depth handle: plan info is not built in this mode");
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
   if (n) *n = h->n;
   if (k3_levels) *k3_levels = chol_plan_levels(h->plan);
@@ -2111,6 +2132,7 @@ int theia_hip_ba_plan_info(theia_ba_handle h, int32_t* n, int32_t* k3_levels, do
 
 int theia_hip_ba_download(theia_ba_handle h, theia_ba_problem* p) {
   if (!h || !p) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (h->idh) return thip::id_handle_download(h->idh, p);
   // caller-owned (pageable) destinations: drain the stream, then blocking copies
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (h->nc) HIP_TRY(hipMemcpy(p->cam_ext, h->cam[h->cur].p, sizeof(double) * 6 * h->nc, hipMemcpyDeviceToHost));
@@ -2126,6 +2148,7 @@ int theia_hip_ba_destroy(theia_ba_handle h) {
 
 int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   if (!h || !S) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (h->idh) return thip::id_handle_run(h->idh, &h->opt, S);
   const theia_ba_options& O = h->opt;
   const double t_start = now_s();
   S->trace_size = 0; S->success = 0; S->num_iterations = 0; S->num_successful_steps = 0;
@@ -2339,6 +2362,7 @@ int theia_hip_ba_evaluate(theia_ba_handle h, double* cost, double* residuals, do
 
 int theia_hip_ba_evaluate_ex(theia_ba_handle h, double* cost, double* residuals, double* jac_cam, double* jac_pt,
                              double* jac_intr, uint8_t* valid) {
+  if (h && h->idh) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse-depth handle: evaluate is not built in this mode");
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
   const int pd = h->pd;
   DevBuf<double> dr, djc, djp, dji; DevBuf<uint8_t> dv;
@@ -2389,6 +2413,7 @@ int theia_hip_ba_evaluate_ex(theia_ba_handle h, double* cost, double* residuals,
 // normal matrix J'J is block diagonal, so ceres::Covariance's (J'J)^-1 is the inverse of each block.  J is the
 // loss-corrected, unscaled Jacobian at the current state (Covariance::Options::apply_loss_function = true).
 int theia_hip_ba_covariance(theia_ba_handle h, double* point_cov, double* cam_cov) {
+  if (h && h->idh) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse-depth handle: covariance is not built in this mode");
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
   if (!point_cov && !cam_cov) return 0;
   // Optimised intrinsics couple the cameras of a group: J'J of the views problem is an arrow, not block diagonal, and the
@@ -2527,6 +2552,7 @@ int theia_hip_dense_spd_solve(int32_t n, const double* A, const double* b, doubl
 }
 
 int theia_hip_ba_reduced_system(theia_ba_handle h, double radius, int32_t* n_out, double* S, double* rhs, int64_t capacity) {
+  if (h && h->idh) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse-depth handle: the reduced-system dump is not built in this mode");
   if (!h || !n_out) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
   int rc = compute_scale(h);
   if (rc) return rc;

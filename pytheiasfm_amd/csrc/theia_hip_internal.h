@@ -31,4 +31,10 @@ int homography_batch_device(int num, const int64_t* d_offsets, const int* d_coun
                             const theia_ba_options* o, void* d_out, hipStream_t st);
 // ba_invdepth.hip: bundle adjustment with the inverse-depth track parametrisation (THEIA_BA_FLAG_INVERSE_DEPTH)
 int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_summary* S);
+// the same problem as a device-resident object behind the handle API (theia_hip_ba_create with THEIA_BA_FLAG_INVERSE_DEPTH)
+int id_handle_create(const theia_ba_problem* p, const theia_ba_options* o, void** out);
+int id_handle_reset(void* h, const theia_ba_problem* p);
+int id_handle_run(void* h, const theia_ba_options* o, theia_ba_summary* S);
+int id_handle_download(void* h, theia_ba_problem* p);
+void id_handle_destroy(void* h);
 }  // namespace thip

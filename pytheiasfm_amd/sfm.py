@@ -355,7 +355,7 @@ def _run_inverse_depth(options, recon, track_ids, const_view_ids=()):
     # track or are the reference view of one: exactly the cameras the library counts as used (ba_invdepth.hip)
     if recon.view_prior_mask is not None:
         flat.set_priors(np.asarray(recon.view_prior_mask, dtype=np.uint8), **recon.view_priors)
-    s, _ = _ba.solve(flat, c_opts)
+    s, _ = _problem_cache.solve(flat, c_opts)
     recon.cam_ext[:] = flat.cam_ext
     recon.inverse_depth[added] = flat.point_inverse_depth[added]
     _update_homogeneous_point(recon, added)

@@ -125,11 +125,53 @@ def test_inverse_depth_intrinsics_and_priors_together():
 
 def test_unsupported_combinations_are_rejected():
     p = idp.make(4, 40, seed=2)
+    h = ba.BaHandle(p.copy(), ba.default_options())
     with pytest.raises(capi.TheiaHipError):
-        ba.BaHandle(p.copy(), ba.default_options())       # no handle API in this mode
+        h.covariance(points=True)                          # the handle of this mode: create / reset / run / download only
+    h.close()
     bad = p.copy(); bad.point_inverse_depth[3] = -1.0
     with pytest.raises(capi.TheiaHipError):
         ba.solve(bad, ba.default_options())
+
+
+def test_inverse_depth_handle_equals_the_one_shot_solve():
+    """theia_hip_ba_create / reset_parameters / run / download with THEIA_BA_FLAG_INVERSE_DEPTH (intrinsics free, a prior):
+    the handle's run equals theia_hip_ba_solve of the same problem, a reset with other parameters equals the one-shot solve
+    of those, a second run continues from the first one's end, and the problem cache of the mirror re-uses the handle."""
+    p = idp.make(10, 400, seed=41)
+    mask = np.zeros(10, dtype=np.uint8); mask[[2, 6]] = 1
+    p.set_priors(mask, position=(p.cam_ext[:, :3] + 0.01, np.tile(5.0 * np.eye(3), (10, 1, 1))))
+    o = ba.default_options(); o.max_num_iterations = 6; o.use_inner_iterations = 0; o.intrinsics_to_optimize = 0x11; o.prior_mask = 1
+
+    def close(a, b):
+        assert np.allclose(a.cam_ext, b.cam_ext, rtol=1e-9, atol=1e-11) and np.allclose(a.intrinsics, b.intrinsics, rtol=1e-9, atol=1e-12)
+        assert np.allclose(a.point_inverse_depth, b.point_inverse_depth, rtol=1e-9, atol=1e-12)
+
+    one = p.copy(); s1, t1 = ba.solve(one, o)
+    hp = p.copy(); h = ba.BaHandle(hp, o)
+    s2, t2 = h.run(); h.download(hp)
+    assert s2.num_iterations == s1.num_iterations and np.allclose(t2.cost, t1.cost, rtol=1e-10)
+    close(hp, one)
+    # continue: the next run starts where the first ended = a one-shot solve from that state
+    cont = one.copy(); s3, _ = ba.solve(cont, o)
+    s4, _ = h.run(); h.download(hp)
+    assert s4.num_iterations == s3.num_iterations and abs(s4.final_cost - s3.final_cost) <= 1e-9 * s3.final_cost
+    close(hp, cont)
+    # reset with perturbed parameters
+    q = p.copy(); q.cam_ext[:, :3] += 0.003; q.point_inverse_depth *= 1.01
+    ref = q.copy(); s5, _ = ba.solve(ref, o)
+    h.reset(q); s6, _ = h.run(); h.download(q)
+    assert s6.num_iterations == s5.num_iterations
+    close(q, ref)
+    o2 = ba.default_options(); o2.max_num_iterations = 6; o2.use_inner_iterations = 0; o2.intrinsics_to_optimize = 0; o2.prior_mask = 1
+    with pytest.raises(capi.TheiaHipError):
+        h.set_options(o2)                                  # structural option changed
+    h.close()
+    cache = ba.ProblemCache(1)
+    a = p.copy(); cache.solve(a, o); b = p.copy(); b.cam_ext[:, :3] += 0.003; cache.solve(b, o)
+    assert (cache.misses, cache.hits) == (1, 1)
+    close(a, one)
+    cache.clear()
 
 
 def test_mirror_api_passes_the_view_priors():
