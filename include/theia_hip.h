@@ -459,6 +459,17 @@ typedef int (*theia_allreduce_fn)(void* ctx, void* device_buffer,
 int theia_hip_ba_set_allreduce(theia_ba_handle h, theia_allreduce_fn fn,
                                void* ctx);
 
+/* Inner iterations (options.use_inner_iterations, the reference's default) in a sharded solve.  A camera's residual blocks
+ * are spread over the track shards, so each rank is given the FULL problem's observations once: after every trust-region
+ * candidate the shards' candidate points are summed into the full point set (one all-reduce of 4 * num_points doubles),
+ * every rank sweeps ALL cameras and intrinsics groups over the full observation set -- the same sums on every rank, nothing
+ * to exchange afterwards --, then its own tracks, and the cost and the step norms of the sweep are all-reduced (4 doubles).
+ * `full_problem`: the unsharded problem (same cameras and groups as the shard; every point, observation and camera prior);
+ * point_global_index[shard points] = index of each of the shard's points in it.  The handle must have been created with
+ * use_inner_iterations = 1.  Without this call a sharded run with inner iterations returns ERR_UNSUPPORTED.  The camera /
+ * group sweeps are not divided among the ranks (the track sweep and everything outside the inner iterations are). */
+int theia_hip_ba_set_inner_global(theia_ba_handle h, const theia_ba_problem* full_problem, const int64_t* point_global_index);
+
 /* The same all-reduce issued by the library itself: `ncclAllReduce` (RCCL) on the solve's own HIP stream, no host
  * callback inside the LM iteration.  librccl is looked up at run time (the copy the process already loaded, else
  * /opt/rocm/lib): no link-time dependency.  Rank 0 obtains the 128-byte id and hands it to the other ranks by any

@@ -61,6 +61,15 @@ class BaHandle:
         L.theia_hip_ba_set_shard.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         capi.check(L.theia_hip_ba_set_shard(self._h, int(rank), int(world_size)))
 
+    def set_inner_global(self, full_problem, point_global_index):
+        """theia_hip_ba_set_inner_global: inner iterations in a sharded solve -- the unsharded problem's observations (and
+        priors) and the global index of each of this shard's points."""
+        L = capi.lib()
+        L.theia_hip_ba_set_inner_global.argtypes = [C.c_void_p, C.POINTER(capi.BaProblem), C.POINTER(C.c_int64)]
+        idx = np.ascontiguousarray(point_global_index, dtype=np.int64)
+        st = full_problem.as_struct()
+        capi.check(L.theia_hip_ba_set_inner_global(self._h, C.byref(st), idx.ctypes.data_as(C.POINTER(C.c_int64))))
+
     def plan_info(self):
         """theia_hip_ba_plan_info: reduced size, K3 levels / flops per solve, fused-kernel runs, slow-path tracks."""
         L = capi.lib()

@@ -408,25 +408,26 @@ __global__ __launch_bounds__(64, THIP_INNER_TRACK_WAVES) void k_inner_tracks(Inn
 // workgroups over contiguous slices of the blocks (one workgroup over 500k points took 0.44 ms), then one workgroup
 // over their partial sums.
 __global__ __launch_bounds__(256) void k_inner_norms(InnerArgs A, const double* __restrict__ cam0, const double* __restrict__ pts0,
-                                                     const double* __restrict__ intr0, double* __restrict__ part) {
+                                                     const double* __restrict__ intr0, double* __restrict__ part, int which) {
+  // which: 0 = every variable block, 1 = the points only (a track shard's share), 2 = cameras + intrinsics only
   __shared__ double s1[256], s2[256];
   double a = 0.0, b = 0.0;
   const int tid = threadIdx.x, nb = gridDim.x, blk = blockIdx.x;
-  {
+  if (which != 2) {
     const int per = (A.P.np + nb - 1) / nb, p0 = blk * per, p1 = min(A.P.np, p0 + per);
     for (int p = p0 + tid; p < p1; p += 256) {
       if (A.P.pt_const[p]) continue;
       for (int q = 0; q < 4; ++q) { const double u = A.pts[4 * (size_t)p + q], v = pts0[4 * (size_t)p + q]; a += (u - v) * (u - v); b += u * u; }
     }
   }
-  {
+  if (which != 1) {
     const int per = (A.P.nc + nb - 1) / nb, c0 = blk * per, c1 = min(A.P.nc, c0 + per);
     for (int c = c0 + tid; c < c1; c += 256) {
       if (A.P.cam_red[c] < 0) continue;
       for (int q = 0; q < 6; ++q) { const double u = A.cam[6 * (size_t)c + q], v = cam0[6 * (size_t)c + q]; a += (u - v) * (u - v); b += u * u; }
     }
   }
-  if (A.P.ni && blk == 0)
+  if (which != 1 && A.P.ni && blk == 0)
     for (int g = tid; g < A.P.ng_total; g += 256) {
       if (A.P.grp_red[g] < 0) continue;
       for (int q = 0; q < A.P.grp_k[g]; ++q) {
@@ -500,6 +501,18 @@ __global__ __launch_bounds__(256) void k_inner_cost_reduce(InnerArgs A, const do
   if (threadIdx.x == 0) { out[0] = s1[0]; out[1] = s2[0]; }
 }
 
+// sharded solves: this shard's candidate points at their global indices (the rest of the buffer is zero: the ranks' buffers
+// are SUMMED into the full point set), and the sweep's scalars put together after the all-reduce
+__global__ void k_inner_scatter_points(int np, const double* __restrict__ pts, const int* __restrict__ global_index, double* __restrict__ gpts) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= np) return;
+  const double4 v = reinterpret_cast<const double4*>(pts)[p];
+  reinterpret_cast<double4*>(gpts)[global_index[p]] = v;
+}
+__global__ void k_inner_combine(const double* __restrict__ reduced4, const double* __restrict__ cam2, double* __restrict__ out4) {
+  out4[0] = reduced4[0] + cam2[0]; out4[1] = reduced4[1] + cam2[1]; out4[2] = reduced4[2]; out4[3] = reduced4[3];
+}
+
 }  // namespace
 
 // optional observation arrays -> always-valid pointers + flags (see load_obs)
@@ -518,12 +531,12 @@ void launch_inner_cost(const InnerArgs& A0, double* part, double* out2, hipStrea
   k_inner_cost_reduce<<<1, 256, 0, st>>>(A, part, nb, out2);
 }
 
-void launch_inner_sweep(const InnerArgs& A0, hipStream_t st) {
+void launch_inner_sweep(const InnerArgs& A0, hipStream_t st, int stages) {   // stages: 1 cameras, 2 intrinsics groups, 4 points
   const InnerArgs A = normalised(A0);
   static const int skip = [] { const char* e = getenv("THEIA_HIP_INNER_SKIP"); return e ? atoi(e) : 0; }();   // development switch
-  if (A.P.nc > 0 && !(skip & 1)) k_inner_views<<<(A.P.nc + 3) / 4, 256, 0, st>>>(A);
-  if (A.P.ni > 0 && A.P.ng_total > 0 && !(skip & 2)) k_inner_groups<<<A.P.ng_total, 256, 0, st>>>(A);
-  if (A.ntracks > 0 && !(skip & 4)) {
+  if (A.P.nc > 0 && (stages & 1) && !(skip & 1)) k_inner_views<<<(A.P.nc + 3) / 4, 256, 0, st>>>(A);
+  if (A.P.ni > 0 && A.P.ng_total > 0 && (stages & 2) && !(skip & 2)) k_inner_groups<<<A.P.ng_total, 256, 0, st>>>(A);
+  if (A.ntracks > 0 && (stages & 4) && !(skip & 4)) {
     const int nb = (A.ntracks + 63) / 64;
     if (A.P.camrot_cand && !getenv("THEIA_HIP_INNER_NO_ROT")) {   // fused path: per-camera blocks (free between the trial step and the next one)
       k_inner_cam_blocks<<<(A.P.nc + 255) / 256, 256, 0, st>>>(A);
@@ -534,9 +547,16 @@ void launch_inner_sweep(const InnerArgs& A0, hipStream_t st) {
   }
 }
 void launch_inner_norms(const InnerArgs& A, const double* cam0, const double* pts0, const double* intr0, double* out2, double* part,
-                        hipStream_t st) {
-  k_inner_norms<<<kInnerCostBlocks, 256, 0, st>>>(A, cam0, pts0, intr0, part);
+                        hipStream_t st, int which) {
+  k_inner_norms<<<kInnerCostBlocks, 256, 0, st>>>(A, cam0, pts0, intr0, part, which);
   k_inner_norms_reduce<<<1, 256, 0, st>>>(kInnerCostBlocks, part, out2);
+}
+
+void launch_inner_scatter_points(int np, const double* pts, const int* global_index, double* gpts, hipStream_t st) {
+  if (np > 0) k_inner_scatter_points<<<(np + 255) / 256, 256, 0, st>>>(np, pts, global_index, gpts);
+}
+void launch_inner_combine(const double* reduced4, const double* cam2, double* out4, hipStream_t st) {
+  k_inner_combine<<<1, 1, 0, st>>>(reduced4, cam2, out4);
 }
 
 }  // namespace thip

@@ -146,10 +146,13 @@ struct InnerArgs {
   const int* gate;              // device flag: 0 = return at once
   int has_si = 0, has_kind = 0;  // set by the launchers: P.obs_si / P.obs_kind are real (otherwise valid stand-ins)
 };
-void launch_inner_sweep(const InnerArgs& A, hipStream_t st);
+void launch_inner_sweep(const InnerArgs& A, hipStream_t st, int stages = 7);   // stages: 1 cameras, 2 intrinsics groups, 4 points
 // out[0] = |x0 - x|^2, out[1] = |x|^2 over the variable blocks
 void launch_inner_norms(const InnerArgs& A, const double* cam0, const double* pts0, const double* intr0, double* out2, double* part,
-                        hipStream_t st);   // part: scratch of 2 * kInnerCostBlocks doubles
+                        hipStream_t st, int which = 0);   // part: scratch of 2 * kInnerCostBlocks doubles; which: 0 all blocks, 1 points, 2 cameras + intrinsics
+// sharded inner iterations: a shard's candidate points into the (zeroed) global point buffer; the sweep's scalars
+void launch_inner_scatter_points(int np, const double* pts, const int* global_index, double* gpts, hipStream_t st);
+void launch_inner_combine(const double* reduced4, const double* cam2, double* out4, hipStream_t st);
 // cost of every residual block at (cam, pts, intr): out[0] = sum rho / 2 (+ camera priors), out[1] > 0 if a functor failed;
 // part: scratch of 2 * kInnerCostBlocks doubles
 constexpr int kInnerCostBlocks = 512;

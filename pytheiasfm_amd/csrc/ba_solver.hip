@@ -154,6 +154,15 @@ struct theia_ba_handle_s {
   bool inner = false;
   DevBuf<int> in_cam_off, in_cam_idx, in_grp_off, in_grp_idx, in_trk_off, in_gate;
   DevBuf<double> in_cam, in_pts, in_intr, in_scal, in_part;
+  // inner iterations of a SHARDED solve (theia_hip_ba_set_inner_global): every rank sweeps all cameras and intrinsics groups
+  // over the FULL observation set (the same sums on every rank: no exchange of their results), its own tracks afterwards
+  bool inner_global = false;
+  int g_np = 0, g_npriors = 0;
+  int64_t g_nobs = 0;
+  DevBuf<double2> g_uv, g_si;
+  DevBuf<int> g_cam, g_pt, g_cam_off, g_cam_idx, g_grp_off, g_grp_idx, g_pidx, g_prior_cam, g_prior_kind;
+  DevBuf<uint8_t> g_kind;
+  DevBuf<double> g_pts, g_prior_vec, g_prior_info, g_stage;
   int in_ntracks = 0;
   DevBuf<double> prior_vec, prior_info;
   int n_priors = 0;
@@ -2118,6 +2127,71 @@ int theia_hip_ba_set_allreduce(theia_ba_handle h, theia_allreduce_fn fn, void* c
   return 0;
 }
 
+int theia_hip_ba_set_inner_global(theia_ba_handle h, const theia_ba_problem* full, const int64_t* point_global_index) {
+  if (!h || !full || (h->np > 0 && !point_global_index)) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (h->idh) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse-depth handle: sharding is not built in this mode");
+  if (!h->inner) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "the handle was created without use_inner_iterations");
+  if (full->num_cameras != h->nc || full->num_groups != h->ng)
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "the full problem must carry the shard's cameras and intrinsics groups");
+  if (full->num_obs > 0 && (!full->obs_uv || !full->obs_cam || !full->obs_pt)) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null observation array");
+  const int64_t nobs = full->num_obs;
+  const int gnp = full->num_points;
+  if (nobs >= (int64_t)1 << 31) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "more than 2^31 observations");
+  std::vector<int> gp(h->np);
+  for (int i = 0; i < h->np; ++i) {
+    if (point_global_index[i] < 0 || point_global_index[i] >= gnp) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "point_global_index out of range");
+    gp[i] = (int)point_global_index[i];
+  }
+  for (int64_t i = 0; i < nobs; ++i)
+    if (full->obs_cam[i] < 0 || full->obs_cam[i] >= h->nc || full->obs_pt[i] < 0 || full->obs_pt[i] >= gnp)
+      return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "observation index out of range");
+  hipStream_t st = h->stream;
+  int rc = 0;
+  // observation lists by camera and by intrinsics group (depth-prior rows do not depend on the intrinsics), in the caller's order
+  std::vector<int> coff(h->nc + 1, 0), cidx(nobs), goff(h->ng + 1, 0), gidx;
+  for (int64_t i = 0; i < nobs; ++i) coff[full->obs_cam[i] + 1]++;
+  for (int c = 0; c < h->nc; ++c) coff[c + 1] += coff[c];
+  { std::vector<int> fill(coff.begin(), coff.end() - 1); for (int64_t i = 0; i < nobs; ++i) cidx[fill[full->obs_cam[i]]++] = (int)i; }
+  if (h->ni) {
+    auto is_depth = [&](int64_t i) { return full->obs_kind && full->obs_kind[i]; };
+    for (int64_t i = 0; i < nobs; ++i) if (!is_depth(i)) goff[full->cam_group[full->obs_cam[i]] + 1]++;
+    for (int g = 0; g < h->ng; ++g) goff[g + 1] += goff[g];
+    gidx.resize(goff[h->ng]);
+    std::vector<int> fill(goff.begin(), goff.end() - 1);
+    for (int64_t i = 0; i < nobs; ++i) if (!is_depth(i)) gidx[fill[full->cam_group[full->obs_cam[i]]]++] = (int)i;
+  }
+  if (gidx.empty()) gidx.push_back(0);
+  std::vector<int> pc, pk;
+  std::vector<double> pv, pi;
+  if (full->cam_prior_mask && h->opt.prior_mask) {   // the priors of ALL cameras: the shards carry them on one rank only
+    const double* vecs[3] = {full->cam_position_prior, full->cam_gravity_prior, full->cam_orientation_prior};
+    const double* infos[3] = {full->cam_position_prior_sqrt_info, full->cam_gravity_prior_sqrt_info, full->cam_orientation_prior_sqrt_info};
+    for (int c = 0; c < h->nc; ++c)
+      for (int k = 0; k < 3; ++k) {
+        const int bit = 1 << k;
+        if (!(full->cam_prior_mask[c] & bit) || !(h->opt.prior_mask & bit) || !vecs[k] || !infos[k]) continue;
+        pc.push_back(c); pk.push_back(bit);
+        pv.insert(pv.end(), vecs[k] + 3 * (size_t)c, vecs[k] + 3 * (size_t)c + 3);
+        pi.insert(pi.end(), infos[k] + 9 * (size_t)c, infos[k] + 9 * (size_t)c + 9);
+      }
+  }
+  h->g_npriors = (int)pc.size(); h->g_np = gnp; h->g_nobs = nobs;
+  std::vector<int> oc(full->obs_cam, full->obs_cam + nobs), op(full->obs_pt, full->obs_pt + nobs);
+  if ((rc = h->g_uv.upload(reinterpret_cast<const double2*>(full->obs_uv), (size_t)nobs, st, false)) ||
+      (rc = h->g_cam.upload(oc, st)) || (rc = h->g_pt.upload(op, st)) || (rc = h->g_cam_off.upload(coff, st)) || (rc = h->g_cam_idx.upload(cidx, st)) ||
+      (rc = h->g_grp_off.upload(goff, st)) || (rc = h->g_grp_idx.upload(gidx, st)) || (rc = h->g_pidx.upload(gp, st)) ||
+      (rc = h->g_prior_cam.upload(pc, st)) || (rc = h->g_prior_kind.upload(pk, st)) || (rc = h->g_prior_vec.upload(pv, st)) ||
+      (rc = h->g_prior_info.upload(pi, st)) || (rc = h->g_pts.alloc((size_t)4 * std::max(1, gnp))) || (rc = h->g_stage.alloc(8)))
+    return rc;
+  if (full->obs_sqrt_info) { if ((rc = h->g_si.upload(reinterpret_cast<const double2*>(full->obs_sqrt_info), (size_t)nobs, st, false))) return rc; }
+  else if ((rc = h->g_si.alloc(0))) return rc;
+  if (full->obs_kind) { if ((rc = h->g_kind.upload(full->obs_kind, (size_t)nobs, st, false))) return rc; }
+  else if ((rc = h->g_kind.alloc(0))) return rc;
+  HIP_TRY(hipStreamSynchronize(st));   // the sources above are local vectors and the caller's arrays
+  h->inner_global = true;
+  return 0;
+}
+
 int theia_hip_ba_plan_info(theia_ba_handle h, int32_t* n, int32_t* k3_levels, double* k3_flops, int32_t* fused_runs,
                            int32_t* slow_path_tracks) {
   if (h && h->idh) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse-depth handle: plan info is not built in this mode");
@@ -2167,8 +2241,8 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   st.term = THEIA_TERM_NO_CONVERGENCE; st.pending_grad = -1;
   // inner iterations need every residual block of a camera on this rank: a sharded solve that asks for them (the
   // reference's default, bundle_adjustment.h:144) is refused instead of silently walking another trajectory
-  if (h->allreduce && O.use_inner_iterations != 0 && h->nobs > 0)
-    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_inner_iterations in a sharded solve is not built: set it to 0 on every rank");
+  if (h->allreduce && O.use_inner_iterations != 0 && h->nobs > 0 && !h->inner_global)
+    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "use_inner_iterations in a sharded solve needs theia_hip_ba_set_inner_global on every rank (or set it to 0 on every rank)");
   const bool inner = h->inner && O.use_inner_iterations != 0;
   st.inner_enabled = inner ? 1 : 0;
   LmState* dst = reinterpret_cast<LmState*>(h->lm_state.p);
@@ -2220,9 +2294,30 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
       IA.cam_obs_off = h->in_cam_off.p; IA.cam_obs_idx = h->in_cam_idx.p; IA.grp_obs_off = h->in_grp_off.p; IA.grp_obs_idx = h->in_grp_idx.p;
       IA.trk_off = h->in_trk_off.p; IA.ntracks = h->in_ntracks; IA.nobs = h->nobs_main;
       IA.cam = h->in_cam.p; IA.pts = h->in_pts.p; IA.intr = h->in_intr.p; IA.gate = h->in_gate.p;
+      if (h->allreduce && h->inner_global) {
+        // the full candidate point set: every shard's points at their global indices, summed over the ranks
+        HIP_TRY(hipMemsetAsync(h->g_pts.p, 0, sizeof(double) * 4 * (size_t)h->g_np, h->stream));
+        launch_inner_scatter_points(h->np, h->in_pts.p, h->g_pidx.p, h->g_pts.p, h->stream);
+        if ((r = do_allreduce(h, h->g_pts.p, (size_t)4 * h->g_np, THEIA_REDUCE_SUM))) return r;
+        InnerArgs IG = IA;      // cameras and groups over the full observation set, identically on every rank
+        IG.P.obs_uv = h->g_uv.p; IG.P.obs_si = h->g_si.n ? h->g_si.p : nullptr; IG.P.obs_cam = h->g_cam.p; IG.P.obs_pt = h->g_pt.p;
+        IG.P.obs_kind = h->g_kind.n ? h->g_kind.p : nullptr; IG.P.np = h->g_np; IG.P.nobs = h->g_nobs;
+        IG.P.n_priors = h->g_npriors; IG.P.prior_cam = h->g_prior_cam.p; IG.P.prior_kind = h->g_prior_kind.p;
+        IG.P.prior_vec = h->g_prior_vec.p; IG.P.prior_info = h->g_prior_info.p;
+        IG.cam_obs_off = h->g_cam_off.p; IG.cam_obs_idx = h->g_cam_idx.p; IG.grp_obs_off = h->g_grp_off.p; IG.grp_obs_idx = h->g_grp_idx.p;
+        IG.pts = h->g_pts.p; IG.ntracks = 0; IG.nobs = h->g_nobs;
+        launch_inner_sweep(IG, h->stream, 3);
+        launch_inner_sweep(IA, h->stream, 4);   // this shard's tracks against the swept cameras
+        launch_inner_norms(IA, h->cam[0].p, h->pts[0].p, h->intr[0].p, h->g_stage.p, h->in_part.p, h->stream, 1);
+        launch_inner_cost(IA, h->in_part.p, h->g_stage.p + 2, h->stream);
+        if ((r = do_allreduce(h, h->g_stage.p, 4, THEIA_REDUCE_SUM))) return r;
+        launch_inner_norms(IA, h->cam[0].p, h->pts[0].p, h->intr[0].p, h->g_stage.p + 4, h->in_part.p, h->stream, 2);
+        launch_inner_combine(h->g_stage.p, h->g_stage.p + 4, h->in_scal.p, h->stream);
+      } else {
       launch_inner_sweep(IA, h->stream);
       launch_inner_norms(IA, h->cam[0].p, h->pts[0].p, h->intr[0].p, h->in_scal.p, h->in_part.p, h->stream);   // in_part: free until launch_inner_cost
       launch_inner_cost(IA, h->in_part.p, h->in_scal.p + 2, h->stream);
+      }
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][3], h->stream));
     if (fuse && h->ntiles_main > 4 * kReduceBlocks) {

@@ -150,19 +150,21 @@ def test_ransac_pair_sharding_keeps_per_pair_results():
     assert seen.all()
 
 
-@pytest.mark.parametrize("mixed", [0, 1])
-def test_sharded_solve_two_ranks_on_one_gpu(mixed):
+@pytest.mark.parametrize("mixed,inner", [(0, 0), (1, 0), (0, 1), (1, 1), (1, 2)])
+def test_sharded_solve_two_ranks_on_one_gpu(mixed, inner):
     """The product path of a two-rank sharded solve, run by two processes on the ONE GPU of the test box: track shards,
     packed reduced system, per-rank gradient slots, device-side LM control across collectives.  RCCL refuses two ranks
     on one device, so the collective itself goes through the host with gloo (tests/sharded_worker.py); both ranks must
-    reproduce the unsharded solve (same iteration count, costs to 1e-9, parameters to 1e-8)."""
+    reproduce the unsharded solve (same iteration count, costs to 1e-9, parameters to 1e-8).  inner = 1: with inner iterations
+    (theia_hip_ba_set_inner_global: the camera sweeps over the full observation set on every rank, the points per shard);
+    inner = 2: the same with FOCAL | RADIAL free and position priors (held by rank 0 only, as a sharded solve requires)."""
     import json
     import subprocess
     import sys
-    port = str(29700 + os.getpid() % 200 + 7 * mixed)
+    port = str(29700 + os.getpid() % 200 + 7 * mixed + 17 * inner)
     procs = []
     for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, SHARD_MIXED=str(mixed))
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, SHARD_MIXED=str(mixed), SHARD_INNER=str(inner))
         procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), "sharded_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -184,5 +186,5 @@ def test_sharded_solve_two_ranks_on_one_gpu(mixed):
     for r in res:
         assert r["iterations"] == r["ref_iterations"], r
         assert abs(r["final_cost"] - r["ref_final_cost"]) <= 1e-9 * r["ref_final_cost"], r
-        assert r["cam_err"] <= 1e-8 and r["pts_err"] <= 1e-8 and r["trace_cost_err"] <= 1e-9, r
+        assert r["cam_err"] <= 1e-8 and r["pts_err"] <= 1e-8 and r["trace_cost_err"] <= 1e-9 and r["intr_err"] <= 1e-8, r
     assert res[0]["final_cost"] == res[1]["final_cost"]   # both ranks hold the all-reduced cost bit for bit
