@@ -466,8 +466,9 @@ int theia_hip_ba_set_allreduce(theia_ba_handle h, theia_allreduce_fn fn,
  * to exchange afterwards --, then its own tracks, and the cost and the step norms of the sweep are all-reduced (4 doubles).
  * `full_problem`: the unsharded problem (same cameras and groups as the shard; every point, observation and camera prior);
  * point_global_index[shard points] = index of each of the shard's points in it.  The handle must have been created with
- * use_inner_iterations = 1.  Without this call a sharded run with inner iterations returns ERR_UNSUPPORTED.  The camera /
- * group sweeps are not divided among the ranks (the track sweep and everything outside the inner iterations are). */
+ * use_inner_iterations = 1.  Without this call a sharded run with inner iterations returns ERR_UNSUPPORTED.  When the
+ * shard geometry is known (theia_hip_ba_set_shard / set_rccl) the cameras and the groups are dealt to the ranks by index and
+ * their results summed (two more small all-reduces); otherwise every rank sweeps all of them. */
 int theia_hip_ba_set_inner_global(theia_ba_handle h, const theia_ba_problem* full_problem, const int64_t* point_global_index);
 
 /* The same all-reduce issued by the library itself: `ncclAllReduce` (RCCL) on the solve's own HIP stream, no host

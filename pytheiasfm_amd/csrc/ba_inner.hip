@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256) void k_inner_views(InnerArgs A) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= A.P.nc || A.P.cam_red[c] < 0) return;
+  if (A.own_world > 1 && c % A.own_world != A.own_rank) return;   // another rank sweeps this camera
   const unsigned mask = A.P.cam_mask[c];
   if ((mask & 0x3fu) == 0x3fu) return;
   const int beg = A.cam_obs_off[c], end = A.cam_obs_off[c + 1];
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(256) void k_inner_groups(InnerArgs A) {
   __shared__ double red[4][68];
   const int grp = blockIdx.x;
   if (grp >= A.P.ng_total || A.P.grp_red[grp] < 0) return;
+  if (A.own_world > 1 && grp % A.own_world != A.own_rank) return;
   const unsigned free_mask = A.P.grp_free[grp];
   if (!free_mask) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -509,6 +511,11 @@ __global__ void k_inner_scatter_points(int np, const double* __restrict__ pts, c
   const double4 v = reinterpret_cast<const double4*>(pts)[p];
   reinterpret_cast<double4*>(gpts)[global_index[p]] = v;
 }
+__global__ void k_inner_keep_owned(double* __restrict__ x, int nblocks, int stride, int rank, int world) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nblocks * stride) return;
+  if ((i / stride) % world != rank) x[i] = 0.0;
+}
 __global__ void k_inner_combine(const double* __restrict__ reduced4, const double* __restrict__ cam2, double* __restrict__ out4) {
   out4[0] = reduced4[0] + cam2[0]; out4[1] = reduced4[1] + cam2[1]; out4[2] = reduced4[2]; out4[3] = reduced4[3];
 }
@@ -554,6 +561,10 @@ void launch_inner_norms(const InnerArgs& A, const double* cam0, const double* pt
 
 void launch_inner_scatter_points(int np, const double* pts, const int* global_index, double* gpts, hipStream_t st) {
   if (np > 0) k_inner_scatter_points<<<(np + 255) / 256, 256, 0, st>>>(np, pts, global_index, gpts);
+}
+void launch_inner_keep_owned(double* x, int nblocks, int stride, int rank, int world, hipStream_t st) {
+  const int n = nblocks * stride;
+  if (n > 0) k_inner_keep_owned<<<(n + 255) / 256, 256, 0, st>>>(x, nblocks, stride, rank, world);
 }
 void launch_inner_combine(const double* reduced4, const double* cam2, double* out4, hipStream_t st) {
   k_inner_combine<<<1, 1, 0, st>>>(reduced4, cam2, out4);

@@ -145,6 +145,7 @@ struct InnerArgs {
   double* cam; double* pts; double* intr;   // in / out
   const int* gate;              // device flag: 0 = return at once
   int has_si = 0, has_kind = 0;  // set by the launchers: P.obs_si / P.obs_kind are real (otherwise valid stand-ins)
+  int own_rank = 0, own_world = 1;   // sharded inner iterations: this launch sweeps the cameras / groups with index % own_world == own_rank
 };
 void launch_inner_sweep(const InnerArgs& A, hipStream_t st, int stages = 7);   // stages: 1 cameras, 2 intrinsics groups, 4 points
 // out[0] = |x0 - x|^2, out[1] = |x|^2 over the variable blocks
@@ -153,6 +154,8 @@ void launch_inner_norms(const InnerArgs& A, const double* cam0, const double* pt
 // sharded inner iterations: a shard's candidate points into the (zeroed) global point buffer; the sweep's scalars
 void launch_inner_scatter_points(int np, const double* pts, const int* global_index, double* gpts, hipStream_t st);
 void launch_inner_combine(const double* reduced4, const double* cam2, double* out4, hipStream_t st);
+// blocks of `stride` doubles: keep those with index % world == rank, zero the others (the ranks' buffers are then summed)
+void launch_inner_keep_owned(double* x, int nblocks, int stride, int rank, int world, hipStream_t st);
 // cost of every residual block at (cam, pts, intr): out[0] = sum rho / 2 (+ camera priors), out[1] > 0 if a functor failed;
 // part: scratch of 2 * kInnerCostBlocks doubles
 constexpr int kInnerCostBlocks = 512;

@@ -2306,7 +2306,22 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
         IG.P.prior_vec = h->g_prior_vec.p; IG.P.prior_info = h->g_prior_info.p;
         IG.cam_obs_off = h->g_cam_off.p; IG.cam_obs_idx = h->g_cam_idx.p; IG.grp_obs_off = h->g_grp_off.p; IG.grp_obs_idx = h->g_grp_idx.p;
         IG.pts = h->g_pts.p; IG.ntracks = 0; IG.nobs = h->g_nobs;
-        launch_inner_sweep(IG, h->stream, 3);
+        // with the shard geometry known the cameras (then the groups) are dealt to the ranks by index and the results summed
+        // (the non-owned entries zeroed: x + 0 is exact, every rank ends with the same bits); otherwise every rank sweeps all
+        const bool deal = h->shard_world > 1 && h->shard_rank >= 0 && h->shard_rank < h->shard_world;
+        if (deal) { IG.own_rank = h->shard_rank; IG.own_world = h->shard_world; }
+        launch_inner_sweep(IG, h->stream, 1);
+        if (deal) {
+          launch_inner_keep_owned(h->in_cam.p, h->nc, 6, h->shard_rank, h->shard_world, h->stream);
+          if ((r = do_allreduce(h, h->in_cam.p, (size_t)6 * h->nc, THEIA_REDUCE_SUM))) return r;
+        }
+        if (h->ni > 0) {
+          launch_inner_sweep(IG, h->stream, 2);
+          if (deal) {
+            launch_inner_keep_owned(h->in_intr.p, h->ng, THEIA_MAX_INTRINSICS, h->shard_rank, h->shard_world, h->stream);
+            if ((r = do_allreduce(h, h->in_intr.p, (size_t)THEIA_MAX_INTRINSICS * h->ng, THEIA_REDUCE_SUM))) return r;
+          }
+        }
         launch_inner_sweep(IA, h->stream, 4);   // this shard's tracks against the swept cameras
         launch_inner_norms(IA, h->cam[0].p, h->pts[0].p, h->intr[0].p, h->g_stage.p, h->in_part.p, h->stream, 1);
         launch_inner_cost(IA, h->in_part.p, h->g_stage.p + 2, h->stream);
