@@ -669,7 +669,30 @@ int IdHandle::create(const theia_ba_problem* p, const theia_ba_options* o) {
   P.pt_ref = d_pref.p; P.bearing = d_bearing.p; P.obs_uv = reinterpret_cast<const double2*>(d_uv.p); P.obs_si = reinterpret_cast<const double2*>(d_si.p);
   P.obs_cam = d_ocam.p; P.obs_pt = d_opt.p; P.pt_off = d_poff.p; P.pt_obs = d_pobs.p; P.scale_c = d_scale_c.p; P.scale_r = d_scale_r.p;
   P.loss_type = o->loss_function_type; P.loss_width = o->robust_loss_width;
-  plan = chol_plan_create(n, nullptr);
+  {
+    // tile co-visibility of the reduced system (64-wide tiles): every block a track writes couples the slots of its reference
+    // camera, its observing cameras and their intrinsics groups pairwise; a camera's / group's own tiles always belong
+    const int nt = (std::max(1, n) + 63) / 64;
+    std::vector<uint8_t> adj((size_t)nt * nt, 0);
+    std::vector<int> tl;
+    auto push_slot = [&](int o, int len) { for (int t = o / 64; t <= (o + len - 1) / 64; ++t) tl.push_back(t); };
+    for (int q = 0; q < np; ++q) {
+      if (pt_off[q + 1] == pt_off[q]) continue;
+      tl.clear();
+      if (cam_red[p->point_ref_cam[q]] >= 0) push_slot(6 * cam_red[p->point_ref_cam[q]], 6);
+      for (int64_t k = pt_off[q]; k < pt_off[q + 1]; ++k) {
+        const int c = p->obs_cam[pt_obs[k]];
+        if (cam_red[c] >= 0) push_slot(6 * cam_red[c], 6);
+        if (grp_red[p->cam_group[c]] >= 0) push_slot(ncam6 + kKW * grp_red[p->cam_group[c]], kKW);
+      }
+      std::sort(tl.begin(), tl.end());
+      tl.erase(std::unique(tl.begin(), tl.end()), tl.end());
+      for (int a : tl) for (int b : tl) adj[(size_t)a * nt + b] = 1;
+    }
+    for (int c = 0; c < nc; ++c) if (cam_red[c] >= 0) { tl.clear(); push_slot(6 * cam_red[c], 6); for (int a : tl) for (int b : tl) adj[(size_t)a * nt + b] = 1; }
+    for (int g = 0; g < ng; ++g) if (grp_red[g] >= 0) { tl.clear(); push_slot(ncam6 + kKW * grp_red[g], kKW); for (int a : tl) for (int b : tl) adj[(size_t)a * nt + b] = 1; }
+    plan = chol_plan_create(n, (n > 0 && !getenv("THEIA_HIP_INVDEPTH_DENSE")) ? adj.data() : nullptr);
+  }
   return upload_parameters(p);
 }
 
@@ -745,7 +768,9 @@ int IdHandle::run(const theia_ba_options* o, theia_ba_summary* S) {
   double radius = 1e4, decrease_factor = 2.0, x_cost = 0.0, gmax = 0.0, x_norm = 0.0, fixed_cost = 0.0;
   auto linearize = [&]() -> int {   // records, reduced system with the damping of `radius`, gradient max
     HIP_TRY(hipMemcpyAsync(d_radius.p, &radius, sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(d_red.p, 0, sizeof(double) * std::max<size_t>(1, red_count), st));
+    // only the tiles the plan's assembly and factorisation touch are cleared (the whole n x n buffer with the dense plan)
+    if (!(n > 0 && chol_plan_clear(plan, dS, n, st, drhs, 3 * (size_t)n)))
+      HIP_TRY(hipMemsetAsync(d_red.p, 0, sizeof(double) * std::max<size_t>(1, red_count), st));
     HIP_TRY(hipMemsetAsync(d_scal.p, 0, sizeof(hs), st));
     if (nobs) k_id_obs<<<ob, 256, 0, st>>>(P, d_cam[cur].p, d_rho[cur].p, d_intr[cur].p, 1, d_recs.p, d_scal.p, nullptr, nullptr, nullptr);
     if (np) k_id_track<<<tb, 64, 0, st>>>(P, d_recs.p, d_radius.p, dS, drhs, dgc, dcolsq, d_vinv.p, d_grho.p, d_scal.p);

@@ -134,6 +134,22 @@ def test_unsupported_combinations_are_rejected():
         ba.solve(bad, ba.default_options())
 
 
+@pytest.mark.parametrize("intr", [0, 0x11])
+def test_inverse_depth_tile_sparse_reduced_system(intr, monkeypatch):
+    """64 cameras on a ring (n = 384 + 10 per free group: six 64-wide tiles, banded co-visibility): the reduced system is
+    factored by the tile-sparse level-scheduled Cholesky of the main path (the plan built from the tracks' reference /
+    observing cameras and groups); the LM trace equals the oracle's dense LM and the dense schedule of the same library."""
+    p = idp.make(64, 1500, seed=57)
+    p.cam_group = (np.arange(64) % 2).astype(np.int32)
+    g, o = _both(p, iters=8, intrinsics_to_optimize=intr)
+    _compare(g, o)
+    monkeypatch.setenv("THEIA_HIP_INVDEPTH_DENSE", "1")
+    q = p.copy(); od = ba.default_options(); od.max_num_iterations = 8; od.use_inner_iterations = 0; od.intrinsics_to_optimize = intr
+    sd, td = ba.solve(q, od)
+    assert sd.num_iterations == g[1].num_iterations and np.allclose(td.cost, g[2].cost, rtol=1e-11)
+    assert np.abs(q.cam_ext - g[0].cam_ext).max() <= 1e-9
+
+
 def test_inverse_depth_handle_equals_the_one_shot_solve():
     """theia_hip_ba_create / reset_parameters / run / download with THEIA_BA_FLAG_INVERSE_DEPTH (intrinsics free, a prior):
     the handle's run equals theia_hip_ba_solve of the same problem, a reset with other parameters equals the one-shot solve
