@@ -178,39 +178,42 @@ __global__ __launch_bounds__(256) void k_id_obs(IdProblem P, const double* __res
 
 // S(r0 .., c0 ..) += sgn * A^T B for a 2 x nr block A and a 2 x ncw block B (row strides sa / sb), r0 >= c0: the lower
 // triangle of the reduced system; on the diagonal (r0 == c0) only j <= i
-__device__ inline void add_block(double* S, int n, int r0, int nr, int c0, int ncw, const double* A, int sa, const double* B, int sb, double sgn) {
-  for (int i = 0; i < nr; ++i)
-    for (int j = 0; j < ncw; ++j) {
-      if (r0 == c0 && j > i) continue;
-      const double v = A[i] * B[j] + A[sa + i] * B[sb + j];
-      if (v != 0.0) atomicAdd(&S[(size_t)(r0 + i) * n + c0 + j], sgn * v);
-    }
+// (called by every lane of the track's wave: lane `ln` takes the entries e = ln, ln + 64, ... of the block)
+__device__ inline void add_block(int ln, double* S, int n, int r0, int nr, int c0, int ncw, const double* A, int sa, const double* B, int sb, double sgn) {
+  for (int e = ln; e < nr * ncw; e += 64) {
+    const int i = e / ncw, j = e - i * ncw;
+    if (r0 == c0 && j > i) continue;
+    const double v = A[i] * B[j] + A[sa + i] * B[sb + j];
+    if (v != 0.0) atomicAdd(&S[(size_t)(r0 + i) * n + c0 + j], sgn * v);
+  }
 }
 // S(r0 .., c0 ..) += sgn * a b^T (vectors), r0 >= c0
-__device__ inline void add_outer(double* S, int n, int r0, int nr, int c0, int ncw, const double* a, const double* b, double sgn) {
-  for (int i = 0; i < nr; ++i)
-    for (int j = 0; j < ncw; ++j) {
-      if (r0 == c0 && j > i) continue;
-      const double v = a[i] * b[j];
-      if (v != 0.0) atomicAdd(&S[(size_t)(r0 + i) * n + c0 + j], sgn * v);
-    }
+__device__ inline void add_outer(int ln, double* S, int n, int r0, int nr, int c0, int ncw, const double* a, const double* b, double sgn) {
+  for (int e = ln; e < nr * ncw; e += 64) {
+    const int i = e / ncw, j = e - i * ncw;
+    if (r0 == c0 && j > i) continue;
+    const double v = a[i] * b[j];
+    if (v != 0.0) atomicAdd(&S[(size_t)(r0 + i) * n + c0 + j], sgn * v);
+  }
 }
 // the same with the two blocks in either order of their offsets
-__device__ inline void add_outer_any(double* S, int n, int ra, int na, const double* a, int rb, int nb, const double* b, double sgn) {
-  if (ra >= rb) add_outer(S, n, ra, na, rb, nb, a, b, sgn); else add_outer(S, n, rb, nb, ra, na, b, a, sgn);
+__device__ inline void add_outer_any(int ln, double* S, int n, int ra, int na, const double* a, int rb, int nb, const double* b, double sgn) {
+  if (ra >= rb) add_outer(ln, S, n, ra, na, rb, nb, a, b, sgn); else add_outer(ln, S, n, rb, nb, ra, na, b, a, sgn);
 }
-__device__ inline void add_block_any(double* S, int n, int ra, int na, const double* A, int sa, int rb, int nb, const double* B, int sb, double sgn) {
-  if (ra >= rb) add_block(S, n, ra, na, rb, nb, A, sa, B, sb, sgn); else add_block(S, n, rb, nb, ra, na, B, sb, A, sa, sgn);
+__device__ inline void add_block_any(int ln, double* S, int n, int ra, int na, const double* A, int sa, int rb, int nb, const double* B, int sb, double sgn) {
+  if (ra >= rb) add_block(ln, S, n, ra, na, rb, nb, A, sa, B, sb, sgn); else add_block(ln, S, n, rb, nb, ra, na, B, sb, A, sa, sgn);
 }
 
-// One thread per track: the camera-side normal equations of its rows (reference camera, observing camera, intrinsics group
+// One WAVE per track (a thread per track left the device almost empty: 60 000 threads issuing ~1800 atomics each in a row;
+// every lane now carries the track's sums -- cheap, and each is needed for the outer products -- and the lanes share the
+// entries of every block that goes to S): the camera-side normal equations of its rows (reference camera, observing camera, intrinsics group
 // of the observing camera), v = e^T e, the LM-damped inverse, and the rank-one Schur update over the blocks of the track.
 // S lower triangle, rhs, gc, colsq (scaled), vinv / g_rho out.
 __global__ __launch_bounds__(64) void k_id_track(IdProblem P, const double* __restrict__ recs, const double* __restrict__ radius_p,
                                                  double* __restrict__ S, double* __restrict__ rhs, double* __restrict__ gc,
                                                  double* __restrict__ colsq, double* __restrict__ vinv, double* __restrict__ grho,
                                                  double* __restrict__ scal) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.x, ln = threadIdx.x;
   if (p >= P.np) return;
   const int64_t b0 = P.pt_off[p], b1 = P.pt_off[p + 1];
   if (b1 == b0) return;
@@ -229,35 +232,39 @@ __global__ __launch_bounds__(64) void k_id_track(IdProblem P, const double* __re
     for (int q = 0; q < 6; ++q) wref[q] += R[q] * R[24] + R[6 + q] * R[25];
     // direct camera-side terms of this row: J^T J over its blocks, J^T r
     if (rr >= 0) {
-      add_block(S, n, oref, 6, oref, 6, R, 6, R, 6, 1.0);
-      for (int q = 0; q < 6; ++q) {
+      add_block(ln, S, n, oref, 6, oref, 6, R, 6, R, 6, 1.0);
+      if (ln < 6) {
+        const int q = ln;
         const double gq = R[q] * R[26] + R[6 + q] * R[27];
         atomicAdd(&rhs[oref + q], gq); atomicAdd(&gc[oref + q], gq);
         atomicAdd(&colsq[oref + q], R[q] * R[q] + R[6 + q] * R[6 + q]);
       }
     }
     if (c != cr && rc >= 0) {
-      add_block(S, n, ooth, 6, ooth, 6, R + 12, 6, R + 12, 6, 1.0);
-      for (int q = 0; q < 6; ++q) {
+      add_block(ln, S, n, ooth, 6, ooth, 6, R + 12, 6, R + 12, 6, 1.0);
+      if (ln < 6) {
+        const int q = ln;
         const double gq = R[12 + q] * R[26] + R[18 + q] * R[27];
         atomicAdd(&rhs[ooth + q], gq); atomicAdd(&gc[ooth + q], gq);
         atomicAdd(&colsq[ooth + q], R[12 + q] * R[12 + q] + R[18 + q] * R[18 + q]);
       }
-      if (rr >= 0) add_block_any(S, n, ooth, 6, R + 12, 6, oref, 6, R, 6, 1.0);
+      if (rr >= 0) add_block_any(ln, S, n, ooth, 6, R + 12, 6, oref, 6, R, 6, 1.0);
     }
     if (gr >= 0) {
       const double* K = R + kRecK;
-      add_block(S, n, ogrp, kKW, ogrp, kKW, K, kKW, K, kKW, 1.0);
-      if (rr >= 0) add_block(S, n, ogrp, kKW, oref, 6, K, kKW, R, 6, 1.0);               // group blocks lie below the cameras
-      if (c != cr && rc >= 0) add_block(S, n, ogrp, kKW, ooth, 6, K, kKW, R + 12, 6, 1.0);
+      add_block(ln, S, n, ogrp, kKW, ogrp, kKW, K, kKW, K, kKW, 1.0);
+      if (rr >= 0) add_block(ln, S, n, ogrp, kKW, oref, 6, K, kKW, R, 6, 1.0);               // group blocks lie below the cameras
+      if (c != cr && rc >= 0) add_block(ln, S, n, ogrp, kKW, ooth, 6, K, kKW, R + 12, 6, 1.0);
       int s = 0;
       while (s < ngs && gslot[s] != gr) ++s;
       if (s == ngs) { gslot[ngs++] = gr; for (int q = 0; q < kKW; ++q) wg[s][q] = 0.0; }   // (the host rejects > kMaxTrackGroups)
       for (int q = 0; q < kKW; ++q) {
-        const double gq = K[q] * R[26] + K[kKW + q] * R[27];
-        if (gq != 0.0) { atomicAdd(&rhs[ogrp + q], gq); atomicAdd(&gc[ogrp + q], gq); }
-        const double cq = K[q] * K[q] + K[kKW + q] * K[kKW + q];
-        if (cq != 0.0) atomicAdd(&colsq[ogrp + q], cq);
+        if (q == ln) {
+          const double gq = K[q] * R[26] + K[kKW + q] * R[27];
+          if (gq != 0.0) { atomicAdd(&rhs[ogrp + q], gq); atomicAdd(&gc[ogrp + q], gq); }
+          const double cq = K[q] * K[q] + K[kKW + q] * K[kKW + q];
+          if (cq != 0.0) atomicAdd(&colsq[ogrp + q], cq);
+        }
         wg[s][q] += K[q] * R[24] + K[kKW + q] * R[25];
       }
     }
@@ -265,20 +272,19 @@ __global__ __launch_bounds__(64) void k_id_track(IdProblem P, const double* __re
   if (P.pt_const[p]) return;
   const double d = fmin(fmax(v, 1e-6), 1e32) / *radius_p;
   const double vi = 1.0 / (v + d);
-  vinv[p] = vi; grho[p] = g;
-  atomic_max_nonneg(&scal[ID_GMAX], fabs(g / P.scale_r[p]));
+  if (ln == 0) { vinv[p] = vi; grho[p] = g; atomic_max_nonneg(&scal[ID_GMAX], fabs(g / P.scale_r[p])); }
   // Schur complement of the track: S -= w w^T vi, rhs -= w vi g over the blocks of the track; w_ref = sum over all rows,
   // w_c = F_c^T e of the row of camera c, w_g = sum over the rows of group g
   if (rr >= 0) {
-    add_outer(S, n, oref, 6, oref, 6, wref, wref, -vi);
-    for (int i = 0; i < 6; ++i) atomicAdd(&rhs[oref + i], -wref[i] * vi * g);
+    add_outer(ln, S, n, oref, 6, oref, 6, wref, wref, -vi);
+    if (ln < 6) atomicAdd(&rhs[oref + ln], -wref[ln] * vi * g);
   }
   for (int s = 0; s < ngs; ++s) {
     const int og = P.ncam6 + kKW * gslot[s];
-    add_outer(S, n, og, kKW, og, kKW, wg[s], wg[s], -vi);
-    for (int s2 = 0; s2 < s; ++s2) add_outer_any(S, n, og, kKW, wg[s], P.ncam6 + kKW * gslot[s2], kKW, wg[s2], -vi);
-    if (rr >= 0) add_outer(S, n, og, kKW, oref, 6, wg[s], wref, -vi);
-    for (int q = 0; q < kKW; ++q) if (wg[s][q] != 0.0) atomicAdd(&rhs[og + q], -wg[s][q] * vi * g);
+    add_outer(ln, S, n, og, kKW, og, kKW, wg[s], wg[s], -vi);
+    for (int s2 = 0; s2 < s; ++s2) add_outer_any(ln, S, n, og, kKW, wg[s], P.ncam6 + kKW * gslot[s2], kKW, wg[s2], -vi);
+    if (rr >= 0) add_outer(ln, S, n, og, kKW, oref, 6, wg[s], wref, -vi);
+    for (int q = 0; q < kKW; ++q) if (q == ln && wg[s][q] != 0.0) atomicAdd(&rhs[og + q], -wg[s][q] * vi * g);
   }
   for (int64_t k = b0; k < b1; ++k) {
     const int o = P.pt_obs[k];
@@ -287,10 +293,10 @@ __global__ __launch_bounds__(64) void k_id_track(IdProblem P, const double* __re
     const double* R = recs + (size_t)kRec * o;
     double wa[6];
     for (int q = 0; q < 6; ++q) wa[q] = R[12 + q] * R[24] + R[18 + q] * R[25];
-    add_outer(S, n, 6 * rc, 6, 6 * rc, 6, wa, wa, -vi);
-    for (int i = 0; i < 6; ++i) atomicAdd(&rhs[6 * rc + i], -wa[i] * vi * g);
-    if (rr >= 0) add_outer_any(S, n, 6 * rc, 6, wa, oref, 6, wref, -vi);
-    for (int s = 0; s < ngs; ++s) add_outer(S, n, P.ncam6 + kKW * gslot[s], kKW, 6 * rc, 6, wg[s], wa, -vi);
+    add_outer(ln, S, n, 6 * rc, 6, 6 * rc, 6, wa, wa, -vi);
+    for (int i = 0; i < 6; ++i) if (i == ln) atomicAdd(&rhs[6 * rc + i], -wa[i] * vi * g);
+    if (rr >= 0) add_outer_any(ln, S, n, 6 * rc, 6, wa, oref, 6, wref, -vi);
+    for (int s = 0; s < ngs; ++s) add_outer(ln, S, n, P.ncam6 + kKW * gslot[s], kKW, 6 * rc, 6, wg[s], wa, -vi);
     for (int64_t k2 = b0; k2 < k; ++k2) {
       const int o2 = P.pt_obs[k2];
       const int c2 = P.obs_cam[o2], rc2 = P.cam_red[c2];
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(64) void k_id_track(IdProblem P, const double* __re
       const double* R2 = recs + (size_t)kRec * o2;
       double wb[6];
       for (int q = 0; q < 6; ++q) wb[q] = R2[12 + q] * R2[24] + R2[18 + q] * R2[25];
-      add_outer_any(S, n, 6 * rc, 6, wa, 6 * rc2, 6, wb, -vi);
+      add_outer_any(ln, S, n, 6 * rc, 6, wa, 6 * rc2, 6, wb, -vi);
     }
   }
 }
@@ -773,7 +779,7 @@ int IdHandle::run(const theia_ba_options* o, theia_ba_summary* S) {
       HIP_TRY(hipMemsetAsync(d_red.p, 0, sizeof(double) * std::max<size_t>(1, red_count), st));
     HIP_TRY(hipMemsetAsync(d_scal.p, 0, sizeof(hs), st));
     if (nobs) k_id_obs<<<ob, 256, 0, st>>>(P, d_cam[cur].p, d_rho[cur].p, d_intr[cur].p, 1, d_recs.p, d_scal.p, nullptr, nullptr, nullptr);
-    if (np) k_id_track<<<tb, 64, 0, st>>>(P, d_recs.p, d_radius.p, dS, drhs, dgc, dcolsq, d_vinv.p, d_grho.p, d_scal.p);
+    if (np) k_id_track<<<np, 64, 0, st>>>(P, d_recs.p, d_radius.p, dS, drhs, dgc, dcolsq, d_vinv.p, d_grho.p, d_scal.p);
     if (npri) k_id_priors<<<pb, 64, 0, st>>>(P, d_cam[cur].p, 1, dS, drhs, dgc, dcolsq, nullptr, nullptr, d_scal.p);
     if (n) k_id_finalize<<<1, 256, 0, st>>>(n, d_radius.p, dS, dcolsq, dgc, d_scale_red.p, d_scal.p);
     int r2 = read_scal();
