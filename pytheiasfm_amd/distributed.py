@@ -78,6 +78,16 @@ def gather_points(shard_points, track_ids, num_points_total, group=None):
     return full
 
 
+def exchange_owned_blocks(blocks, rank, world_size, allreduce):
+    """The exchange step of the sharded inner iterations (theia_hip_ba_set_inner_global; csrc/ba_solver.hip): block i of
+    `blocks` ([n][k], float64) was swept by rank i % world_size; every rank zeroes the blocks it does not own and the buffers
+    are summed -- x + 0 is exact, so every rank ends with every owner's bits.  In place; returns `blocks`."""
+    owned = (np.arange(blocks.shape[0]) % world_size) == rank
+    blocks[~owned] = 0.0
+    allreduce(blocks.reshape(-1))
+    return blocks
+
+
 class NativeRccl:
     """RCCL communicator owned by libtheia_hip.so (theia_hip_rccl_*): the sharded solve then issues ncclAllReduce
     itself on its own stream.  The 128-byte unique id travels from rank 0 through torch.distributed's object

@@ -161,6 +161,51 @@ def test_world_size_2_reduction_of_the_reduced_camera_system():
     assert s_err < 1e-12 and r_err < 1e-10 and pts_ok
 
 
+def _gloo_inner_exchange_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pytheiasfm_amd import distributed as tdist
+    p = synth.synth_ba_v1(9, 150, seed=0xBA5E0301)
+    sh, ids = synth.shard_tracks(p, rank, world)
+    allreduce = tdist.make_host_allreduce()
+    # 1. the full candidate point set: every shard's points at their global indices, summed
+    rng = np.random.default_rng(7)
+    cand = p.points * (1.0 + 1e-3 * rng.standard_normal(p.points.shape))      # the same "candidate" on every rank
+    full = tdist.gather_points(cand[ids], ids, p.points.shape[0])
+    # 2. cameras dealt to the ranks by index: the owner's result reaches every rank bit for bit
+    swept = p.cam_ext + 1e-2 * np.sin(np.arange(p.cam_ext.size)).reshape(p.cam_ext.shape)   # what the owner computes
+    mine = p.cam_ext.copy()                                                                # non-owners hold something else
+    own = (np.arange(len(mine)) % world) == rank
+    mine[own] = swept[own]
+    out = tdist.exchange_owned_blocks(mine, rank, world, allreduce)
+    # 3. the sweep's scalars: the point shares summed over the ranks, the camera share added once
+    part = np.array([float((cand[ids, :3] ** 2).sum()), 0.0])
+    allreduce(part)
+    q.put((rank, bool(np.array_equal(full, cand)), bool(np.array_equal(out, swept)), float(part[0]), float((cand[:, :3] ** 2).sum())))
+    dist.destroy_process_group()
+
+
+def test_world_size_2_exchange_of_the_sharded_inner_iterations():
+    """The collectives of a sharded solve's inner iterations (theia_hip_ba_set_inner_global) on two CPU ranks with gloo:
+    zero-filled buffers summed into the full point set / the dealt cameras (exact: x + 0), the point share of a norm
+    summed over the shards."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_inner_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert {r[0] for r in res} == {0, 1}
+    for _, pts_ok, cams_ok, s, ref in res:
+        assert pts_ok and cams_ok and abs(s - ref) <= 1e-12 * ref
+
+
 def test_ransac_pair_partition_is_a_round_robin_cover():
     """RANSAC over N GPUs: every pair belongs to exactly one rank."""
     from pytheiasfm_amd import distributed as tdist
