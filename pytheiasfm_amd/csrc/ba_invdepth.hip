@@ -204,11 +204,30 @@ __device__ inline void add_block_any(int ln, double* S, int n, int ra, int na, c
   if (ra >= rb) add_block(ln, S, n, ra, na, rb, nb, A, sa, B, sb, sgn); else add_block(ln, S, n, rb, nb, ra, na, B, sb, A, sa, sgn);
 }
 
+// S(ra .., rb ..) (lower triangle: the block with the larger offset gives the rows) += A^T B - vi a b^T for two 2 x 6 blocks
+// A, B (rows 6 apart) and their Schur vectors a, b: the direct and the Schur term of a camera pair in ONE atomic per entry
+__device__ inline void add_pair(int ln, double* S, int n, int oa, const double* A, const double* a, int ob, const double* B, const double* b, double vi) {
+  if (ln >= 36) return;
+  const int i = ln / 6, j = ln - 6 * i;
+  if (oa == ob) {
+    if (j > i) return;
+    const double v = (A[i] * B[j] + A[6 + i] * B[6 + j]) - vi * (a[i] * b[j]);
+    if (v != 0.0) atomicAdd(&S[(size_t)(oa + i) * n + ob + j], v);
+  } else if (oa > ob) {
+    const double v = (A[i] * B[j] + A[6 + i] * B[6 + j]) - vi * (a[i] * b[j]);
+    if (v != 0.0) atomicAdd(&S[(size_t)(oa + i) * n + ob + j], v);
+  } else {
+    const double v = (B[i] * A[j] + B[6 + i] * A[6 + j]) - vi * (b[i] * a[j]);
+    if (v != 0.0) atomicAdd(&S[(size_t)(ob + i) * n + oa + j], v);
+  }
+}
+
 // One WAVE per track (a thread per track left the device almost empty: 60 000 threads issuing ~1800 atomics each in a row;
-// every lane now carries the track's sums -- cheap, and each is needed for the outer products -- and the lanes share the
-// entries of every block that goes to S): the camera-side normal equations of its rows (reference camera, observing camera, intrinsics group
-// of the observing camera), v = e^T e, the LM-damped inverse, and the rank-one Schur update over the blocks of the track.
-// S lower triangle, rhs, gc, colsq (scaled), vinv / g_rho out.
+// every lane carries the track's sums -- cheap, and each is needed for the outer products -- and the lanes share the entries
+// of every block that goes to S): the camera-side normal equations of its rows (reference camera, observing camera, intrinsics
+// group of the observing camera), v = e^T e, the LM-damped inverse, and the rank-one Schur update over the blocks of the
+// track.  The direct term J^T J and the Schur term of a camera block / camera pair are folded into one atomic per entry
+// (the reference camera's diagonal block: one instead of one per row).  S lower triangle, rhs, gc, colsq (scaled), vinv / g_rho out.
 __global__ __launch_bounds__(64) void k_id_track(IdProblem P, const double* __restrict__ recs, const double* __restrict__ radius_p,
                                                  double* __restrict__ S, double* __restrict__ rhs, double* __restrict__ gc,
                                                  double* __restrict__ colsq, double* __restrict__ vinv, double* __restrict__ grho,
@@ -222,6 +241,10 @@ __global__ __launch_bounds__(64) void k_id_track(IdProblem P, const double* __re
   double v = 0.0, g = 0.0, wref[6] = {0, 0, 0, 0, 0, 0};
   int gslot[kMaxTrackGroups], ngs = 0;           // reduced indices of the variable groups this track is seen through
   double wg[kMaxTrackGroups][kKW];               // sum over the rows of a group of F_k^T e
+  // this lane's entry (i, j) of the reference camera's diagonal block (lower triangle) and, for lanes < 6, its rhs / colsq row
+  const int ei = ln / 6, ej = ln - 6 * (ln / 6);
+  const bool ref_entry = rr >= 0 && ln < 36 && ej <= ei;
+  double dref = 0.0, gref = 0.0, cref = 0.0;
   for (int64_t k = b0; k < b1; ++k) {
     const int o = P.pt_obs[k];
     const double* R = recs + (size_t)kRec * o;
@@ -230,26 +253,8 @@ __global__ __launch_bounds__(64) void k_id_track(IdProblem P, const double* __re
     v += R[24] * R[24] + R[25] * R[25];
     g += R[24] * R[26] + R[25] * R[27];
     for (int q = 0; q < 6; ++q) wref[q] += R[q] * R[24] + R[6 + q] * R[25];
-    // direct camera-side terms of this row: J^T J over its blocks, J^T r
-    if (rr >= 0) {
-      add_block(ln, S, n, oref, 6, oref, 6, R, 6, R, 6, 1.0);
-      if (ln < 6) {
-        const int q = ln;
-        const double gq = R[q] * R[26] + R[6 + q] * R[27];
-        atomicAdd(&rhs[oref + q], gq); atomicAdd(&gc[oref + q], gq);
-        atomicAdd(&colsq[oref + q], R[q] * R[q] + R[6 + q] * R[6 + q]);
-      }
-    }
-    if (c != cr && rc >= 0) {
-      add_block(ln, S, n, ooth, 6, ooth, 6, R + 12, 6, R + 12, 6, 1.0);
-      if (ln < 6) {
-        const int q = ln;
-        const double gq = R[12 + q] * R[26] + R[18 + q] * R[27];
-        atomicAdd(&rhs[ooth + q], gq); atomicAdd(&gc[ooth + q], gq);
-        atomicAdd(&colsq[ooth + q], R[12 + q] * R[12 + q] + R[18 + q] * R[18 + q]);
-      }
-      if (rr >= 0) add_block_any(ln, S, n, ooth, 6, R + 12, 6, oref, 6, R, 6, 1.0);
-    }
+    if (ref_entry) dref += R[ei] * R[ej] + R[6 + ei] * R[6 + ej];
+    if (rr >= 0 && ln < 6) { gref += R[ln] * R[26] + R[6 + ln] * R[27]; cref += R[ln] * R[ln] + R[6 + ln] * R[6 + ln]; }
     if (gr >= 0) {
       const double* K = R + kRecK;
       add_block(ln, S, n, ogrp, kKW, ogrp, kKW, K, kKW, K, kKW, 1.0);
@@ -269,23 +274,30 @@ __global__ __launch_bounds__(64) void k_id_track(IdProblem P, const double* __re
       }
     }
   }
-  if (P.pt_const[p]) return;
-  const double d = fmin(fmax(v, 1e-6), 1e32) / *radius_p;
-  const double vi = 1.0 / (v + d);
-  if (ln == 0) { vinv[p] = vi; grho[p] = g; atomic_max_nonneg(&scal[ID_GMAX], fabs(g / P.scale_r[p])); }
-  // Schur complement of the track: S -= w w^T vi, rhs -= w vi g over the blocks of the track; w_ref = sum over all rows,
-  // w_c = F_c^T e of the row of camera c, w_g = sum over the rows of group g
+  const bool pconst = P.pt_const[p] != 0;
+  double vi = 0.0;        // a constant track keeps the direct terms only
+  if (!pconst) {
+    const double d = fmin(fmax(v, 1e-6), 1e32) / *radius_p;
+    vi = 1.0 / (v + d);
+    if (ln == 0) { vinv[p] = vi; grho[p] = g; atomic_max_nonneg(&scal[ID_GMAX], fabs(g / P.scale_r[p])); }
+  }
+  // the reference camera: J^T J of all rows minus the Schur term, J^T r minus w vi g
   if (rr >= 0) {
-    add_outer(ln, S, n, oref, 6, oref, 6, wref, wref, -vi);
-    if (ln < 6) atomicAdd(&rhs[oref + ln], -wref[ln] * vi * g);
+    if (ref_entry) { const double val = dref - vi * (wref[ei] * wref[ej]); if (val != 0.0) atomicAdd(&S[(size_t)(oref + ei) * n + oref + ej], val); }
+    if (ln < 6) {
+      double wl = 0.0;
+      for (int q = 0; q < 6; ++q) if (q == ln) wl = wref[q];
+      atomicAdd(&rhs[oref + ln], gref - wl * vi * g); atomicAdd(&gc[oref + ln], gref); atomicAdd(&colsq[oref + ln], cref);
+    }
   }
-  for (int s = 0; s < ngs; ++s) {
-    const int og = P.ncam6 + kKW * gslot[s];
-    add_outer(ln, S, n, og, kKW, og, kKW, wg[s], wg[s], -vi);
-    for (int s2 = 0; s2 < s; ++s2) add_outer_any(ln, S, n, og, kKW, wg[s], P.ncam6 + kKW * gslot[s2], kKW, wg[s2], -vi);
-    if (rr >= 0) add_outer(ln, S, n, og, kKW, oref, 6, wg[s], wref, -vi);
-    for (int q = 0; q < kKW; ++q) if (q == ln && wg[s][q] != 0.0) atomicAdd(&rhs[og + q], -wg[s][q] * vi * g);
-  }
+  if (!pconst)
+    for (int s = 0; s < ngs; ++s) {
+      const int og = P.ncam6 + kKW * gslot[s];
+      add_outer(ln, S, n, og, kKW, og, kKW, wg[s], wg[s], -vi);
+      for (int s2 = 0; s2 < s; ++s2) add_outer_any(ln, S, n, og, kKW, wg[s], P.ncam6 + kKW * gslot[s2], kKW, wg[s2], -vi);
+      if (rr >= 0) add_outer(ln, S, n, og, kKW, oref, 6, wg[s], wref, -vi);
+      for (int q = 0; q < kKW; ++q) if (q == ln && wg[s][q] != 0.0) atomicAdd(&rhs[og + q], -wg[s][q] * vi * g);
+    }
   for (int64_t k = b0; k < b1; ++k) {
     const int o = P.pt_obs[k];
     const int c = P.obs_cam[o], rc = P.cam_red[c];
@@ -293,9 +305,16 @@ __global__ __launch_bounds__(64) void k_id_track(IdProblem P, const double* __re
     const double* R = recs + (size_t)kRec * o;
     double wa[6];
     for (int q = 0; q < 6; ++q) wa[q] = R[12 + q] * R[24] + R[18 + q] * R[25];
-    add_outer(ln, S, n, 6 * rc, 6, 6 * rc, 6, wa, wa, -vi);
-    for (int i = 0; i < 6; ++i) if (i == ln) atomicAdd(&rhs[6 * rc + i], -wa[i] * vi * g);
-    if (rr >= 0) add_outer_any(ln, S, n, 6 * rc, 6, wa, oref, 6, wref, -vi);
+    add_pair(ln, S, n, 6 * rc, R + 12, wa, 6 * rc, R + 12, wa, vi);                    // own diagonal block: direct + Schur
+    if (rr >= 0) add_pair(ln, S, n, 6 * rc, R + 12, wa, oref, R, wref, vi);            // with the reference camera
+    if (ln < 6) {
+      double wl = 0.0;
+      for (int q = 0; q < 6; ++q) if (q == ln) wl = wa[q];
+      const double gq = R[12 + ln] * R[26] + R[18 + ln] * R[27];
+      atomicAdd(&rhs[6 * rc + ln], gq - wl * vi * g); atomicAdd(&gc[6 * rc + ln], gq);
+      atomicAdd(&colsq[6 * rc + ln], R[12 + ln] * R[12 + ln] + R[18 + ln] * R[18 + ln]);
+    }
+    if (pconst) continue;
     for (int s = 0; s < ngs; ++s) add_outer(ln, S, n, P.ncam6 + kKW * gslot[s], kKW, 6 * rc, 6, wg[s], wa, -vi);
     for (int64_t k2 = b0; k2 < k; ++k2) {
       const int o2 = P.pt_obs[k2];
