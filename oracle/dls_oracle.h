@@ -1,12 +1,18 @@
 // TEST INFRASTRUCTURE (CPU oracle) -- DLS-PnP, restated from the reference's formulation (sfm/pose/dls_pnp.cc:67-200):
 // cost matrix -> Jacobian cubics -> dense 120 x 120 Macaulay matrix -> Schur complement through a dense partial-pivot
 // LU of the 93 x 93 block (dls_pnp.cc:143-146) -> eigenvectors of the 27 x 27 multiplication matrix -> poses.
-// Deliberately NOT the device's route: the polynomial system is derived here by generic polynomial arithmetic on
-// exponent grids (the cost quartic J' = rbar^T D rbar is expanded and differentiated), the non-reduced monomials are
-// kept in plain lexicographic order (so the LU really pivots across the whole block), and every step is sequential.
+// The polynomial system is derived here by generic polynomial arithmetic on exponent grids (the cost quartic
+// J' = rbar^T D rbar is expanded and differentiated) and every step is sequential.  The ROWS and COLUMNS of the 93 x 93
+// block are the reference's (dls_layout.h, recovered from the structure of dls_impl.cc:340-754 by
+// scripts/gen_dls_layout.py): the order decides the pivot sequence and every rounding of the elimination, so the LU
+// below walks the same pivots as the reference's partialPivLu() (first maximum of the column, rows swapped) with a
+// plain right-looking elimination (fused multiply-adds, as a -march=native build of the reference contracts them),
+// a column-oriented back-substitution and M00 - M01 X accumulated in ascending column order.  Since round 4 the device
+// follows exactly this route (csrc/dls_device.h), so DLS / gDLS hypotheses are bit-identical, not merely close.
 // The reference's expanded coefficient formulas (dls_impl.cc:62-338) and index table (dls_impl.cc:340-754) are pinned
 // through tests/golden/dls_reference_vectors.json (made by tests/golden/make_dls_golden.py from the reference text).
 // Included by ransac_oracle.cpp inside its anonymous namespace (needs eig_general_t, quat_to_rot).
+#include "dls_layout.h"
 
 struct DlsPoly {   // polynomial in (s1, s2, s3), exponents 0..4 each
   double c[5][5][5];
@@ -53,16 +59,21 @@ inline void dls_rbar(DlsPoly r[9]) {
   }
 }
 
-struct DlsMonomials {   // 120 monomials of degree <= 7: 27 reduced first (index 9a + 3b + c), then the rest lexicographically
+struct DlsMonomials {   // 120 monomials of degree <= 7: 27 reduced first (index 9a + 3b + c), then the reference's column order
   int e[120][3];
   int index[8][8][8];
+  int row_poly[120], row_mul[120][3];   // row r = f_{row_poly[r]} * monomial row_mul[r] (f_0 = the random linear form)
   DlsMonomials() {
     std::memset(index, -1, sizeof(index));
     int n = 0;
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) for (int c = 0; c < 3; ++c) { e[n][0] = a; e[n][1] = b; e[n][2] = c; index[a][b][c] = n++; }
-    for (int a = 0; a <= 7; ++a) for (int b = 0; a + b <= 7; ++b) for (int c = 0; a + b + c <= 7; ++c) {
-      if (a <= 2 && b <= 2 && c <= 2) continue;
-      e[n][0] = a; e[n][1] = b; e[n][2] = c; index[a][b][c] = n++;
+    for (int k = 0; k < thip::dls_layout::kBlock; ++k) {
+      for (int v = 0; v < 3; ++v) e[n][v] = thip::dls_layout::kColMono[k][v];
+      index[e[n][0]][e[n][1]][e[n][2]] = n; n++;
+    }
+    for (int r = 0; r < 120; ++r) {
+      row_poly[r] = r < 27 ? 0 : thip::dls_layout::kRowPoly[r - 27];
+      for (int v = 0; v < 3; ++v) row_mul[r][v] = r < 27 ? e[r][v] : thip::dls_layout::kRowMul[r - 27][v];
     }
   }
 };
@@ -97,7 +108,7 @@ inline void dls_macaulay_terms(int call_index, double u[4]) {   // the 4 draws o
 }
 
 // 27 x 27 multiplication matrix of f0 = u0 + u1 s1 + u2 s2 + u3 s3 from the 9 x 9 cost matrix D (dls_pnp.cc:120-146)
-inline bool dls_action_from_cost(const double* D, const double* u, double* fcoef_out, double* A) {
+inline bool dls_action_from_cost(const double* D, const double* u, double* fcoef_out, double* A, double* macaulay_out = nullptr) {
   // J' = rbar^T D rbar as a quartic, f_i = dJ'/ds_i
   DlsPoly rb[9];
   dls_rbar(rb);
@@ -110,18 +121,18 @@ inline bool dls_action_from_cost(const double* D, const double* u, double* fcoef
   f[0].c[0][0][0] = u[0]; f[0].c[1][0][0] = u[1]; f[0].c[0][1][0] = u[2]; f[0].c[0][0][1] = u[3];
   for (int v = 0; v < 3; ++v) f[1 + v] = dls_diff(J, v);
   if (fcoef_out) for (int v = 0; v < 3; ++v) for (int i = 0; i < 125; ++i) fcoef_out[125 * v + i] = (&f[1 + v].c[0][0][0])[i];
-  // Macaulay matrix
+  // Macaulay matrix in the reference's layout
   static const DlsMonomials mon;
   std::vector<double> M(120 * 120, 0.0);
   for (int row = 0; row < 120; ++row) {
-    const int* e = mon.e[row];
-    int which = 0, sh[3] = {e[0], e[1], e[2]};
-    if (row >= 27) { which = e[0] >= 3 ? 1 : (e[1] >= 3 ? 2 : 3); sh[which - 1] -= 3; }
+    const int which = mon.row_poly[row];
+    const int* sh = mon.row_mul[row];
     for (int a = 0; a < 4; ++a) for (int b = 0; a + b < 4; ++b) for (int c = 0; a + b + c < 4; ++c) {
       const double v = f[which].c[a][b][c];
       if (v != 0.0) M[(size_t)row * 120 + mon.index[sh[0] + a][sh[1] + b][sh[2] + c]] = v;
     }
   }
+  if (macaulay_out) for (int i = 0; i < 14400; ++i) macaulay_out[i] = M[i];
   // Schur complement: M00 - M01 * lu(M11).solve(M10), dense partial-pivot LU of the 93 x 93 block with the 27 right-hand sides
   const int nb = 93, nr = 27, w = nb + nr;
   std::vector<double> Aug((size_t)nb * w);
@@ -137,18 +148,21 @@ inline bool dls_action_from_cost(const double* D, const double* u, double* fcoef
     for (int r = k + 1; r < nb; ++r) {
       const double l = Aug[(size_t)r * w + k] / Aug[(size_t)k * w + k];
       if (l == 0.0) continue;
-      for (int c = k + 1; c < w; ++c) Aug[(size_t)r * w + c] -= l * Aug[(size_t)k * w + c];
+      for (int c = k + 1; c < w; ++c) Aug[(size_t)r * w + c] = __builtin_fma(-l, Aug[(size_t)k * w + c], Aug[(size_t)r * w + c]);
     }
   }
-  for (int k = nb - 1; k >= 0; --k)
-    for (int c = 0; c < nr; ++c) {
-      double s = Aug[(size_t)k * w + nb + c];
-      for (int j = k + 1; j < nb; ++j) s -= Aug[(size_t)k * w + j] * Aug[(size_t)j * w + nb + c];
-      Aug[(size_t)k * w + nb + c] = s / Aug[(size_t)k * w + k];
+  // column-oriented back-substitution: x_k = rhs_k / u_kk, then retired from the rows above
+  for (int k = nb - 1; k >= 0; --k) {
+    for (int c = 0; c < nr; ++c) Aug[(size_t)k * w + nb + c] = Aug[(size_t)k * w + nb + c] / Aug[(size_t)k * w + k];
+    for (int i = 0; i < k; ++i) {
+      const double u_ik = Aug[(size_t)i * w + k];
+      if (u_ik == 0.0) continue;
+      for (int c = 0; c < nr; ++c) Aug[(size_t)i * w + nb + c] = __builtin_fma(-u_ik, Aug[(size_t)k * w + nb + c], Aug[(size_t)i * w + nb + c]);
     }
+  }
   for (int r = 0; r < 27; ++r) for (int c = 0; c < 27; ++c) {
     double s = M[(size_t)r * 120 + c];
-    for (int j = 0; j < nb; ++j) { const double m01 = M[(size_t)r * 120 + 27 + j]; if (m01 != 0.0) s -= m01 * Aug[(size_t)j * w + nb + c]; }
+    for (int j = 0; j < nb; ++j) { const double m01 = M[(size_t)r * 120 + 27 + j]; if (m01 != 0.0) s = __builtin_fma(-m01, Aug[(size_t)j * w + nb + c], s); }
     A[27 * r + c] = s;
   }
   return true;

@@ -1,16 +1,27 @@
 // DLS-PnP on the device (the reference: sfm/pose/dls_pnp.cc:67-200).  Two stages per minimal problem:
 //
-//   stage A  one WAVE per problem, everything in LDS (31.8 KB, five problems per CU): cost matrix, the three Jacobian
-//            cubics, then the Schur complement of the Macaulay matrix WITHOUT forming it.  With the non-reduced monomials
-//            ordered by degree the 93 x 93 block is block upper triangular (dls_tables.h), so its partial-pivot LU is
-//            five small LUs (3, 9, 18, 27, 36 rows, cubic coefficients only); the right-hand sides of a block are the
-//            27 reduced columns minus the already solved lower-degree rows.  Lane = column of the augmented block
-//            [B_dd | rhs] (at most 36 + 27 = 63 columns), one row operation per step; 115 k FMAs instead of the 0.5 M of
-//            the dense 93 x 93 solve.  Output: the 27 x 27 multiplication matrix of f0 and the 3 x 9 translation factor.
+//   stage A  one WORKGROUP of 192 threads per problem.  Cost matrix, the cost quartic, the three Jacobian cubics, then the
+//            Schur complement of the Macaulay matrix by the REFERENCE'S route: a dense partial-pivot LU of the 93 x 93
+//            block in the generated table's row / column order (dls_layout.h) with the 27 reduced columns as right-hand
+//            sides (dls_pnp.cc:143-146), a column-oriented back-substitution and M00 - M01 X.  Every entry sees exactly
+//            the operations of oracle/dls_oracle.h in the same order (first-maximum pivots, l = a / pivot, one fused
+//            multiply-add per update, x = rhs / u_kk), so the 27 x 27 result -- and with it every hypothesis, inlier set
+//            and cost -- is BIT-IDENTICAL to the sequential restatement (round 3 eliminated degree by degree: a faster
+//            but different route, 978 of 1000 pairs equal).
+//            The augmented 93 x 120 matrix lives in REGISTERS: lane = (column group g = tid / 32, row group rg = tid % 32)
+//            holds rows 3 rg + {0, 1, 2} at the columns 6 i + g -- 60 doubles.  Columns are dealt cyclically so that all
+//            groups shrink together; after every six steps the lane's columns move down one register (folded into the
+//            destination of that step's multiply-adds), so the pivot column is always register 0 of the half-wave g = k % 6
+//            and every register index is a compile-time constant inside a rolled loop.  Per step: pivot search inside one
+//            half-wave (butterfly), the factors l = a / pivot to LDS, barrier, the six lanes that hold the pivot row
+//            broadcast it through LDS (and keep its part right of the diagonal for the back-substitution: 34 KB
+//            triangular store), barrier, 3 x (20 - k / 6) multiply-adds per lane.  Rows are never moved: the oracle's
+//            swap is bookkeeping of positions (ties go to the smallest POSITION, as the sequential scan takes them).
+//            40 KB of LDS per workgroup: four problems per CU.
 //   stage B  real Schur form + eigenvectors of the 27 x 27 matrix (orthes + hqr2, complex pairs included), root
 //            extraction and the reference's solution filter.  In the RANSAC path a TEAM of 32 lanes per matrix with the
-//            three 27 x 27 work arrays in LDS (eig_team.h); one thread per problem with the arrays in scratch for the
-//            directly bound solver (the scratch version moved ~2.7 MB of HBM traffic per matrix).
+//            work arrays in LDS (eig_team.h); one thread per problem with the arrays in scratch for the
+//            directly bound solver.
 #ifndef THEIA_HIP_DLS_DEVICE_H_
 #define THEIA_HIP_DLS_DEVICE_H_
 
@@ -23,28 +34,30 @@ namespace thip {
 namespace dlsdev {
 
 using dls::kReduced;
-using dls::kMaxBlock;
-constexpr int kAugCols = kMaxBlock + kReduced;   // 63
-constexpr int kXRows = 60;   // solved rows kept: the 57 monomials of degree 3..6 and the 3 of degree 7 the result reads
+using dls::kBlock;
+constexpr int kThreads = dls::kThreads;
 constexpr int kMaxSolutions = 27;
+constexpr int kUSize = kBlock * (kBlock - 1) / 2;   // rows of U right of the diagonal, row k at u_off(k)
+__host__ __device__ constexpr int u_off(int k) { return (kBlock - 1) * k - k * (k - 1) / 2; }
 
 __constant__ dls::Tables c_tab;
 
-struct WaveLds {
-  double aug[kMaxBlock * kAugCols];
-  double X[kXRows * kReduced];
+struct WgLds {
+  double U[kUSize + 2];
+  union {
+    struct { double Dm[81]; double J[36]; double hinv[16]; double traw[36]; } fe;   // front end
+    double pbuf[2][144];                                                           // pivot row of a step, by step parity
+  };
+  double lbuf[2][96];    // factors of a step by parity; the back-substitution's solved row lives in lbuf[parity][0..31]
+  double diag[96];
   double f[60];
   double T[27];
-  double sf[9];   // gDLS: the scale factor row
+  double sf[9];          // gDLS: the scale factor row
   double u[4];
+  int pinfo[2][2];       // (row that holds the pivot, its position) by parity
   int flag;
+  unsigned char prow_of[96];
 };
-
-__device__ inline double wave_allsum(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 
 // Eigen's Matrix4d::inverse() restated as adjugate over determinant (oracle/dls_oracle.h: gdls_inverse4)
 __device__ inline bool inverse4(const double* a, double* inv) {
@@ -72,123 +85,196 @@ __device__ inline bool inverse4(const double* a, double* inv) {
   return true;
 }
 
+// One elimination step k = 6 o + S with NL live registers per row (NL >= 20 - o).  SHIFT (S == 5): the step's results
+// land one register lower, so that the next six steps find their pivot columns in register 0 again.
+// pos[q]: position of the lane's row q in the oracle's (swapped) row order; a row pivoted at step j keeps pos = j, so
+// "still a candidate" is k <= pos < 93 (the padding rows 93..95 start at their own index and never are).
+#define THIP_DLS_FENCE() asm volatile("" ::: "memory")
+template <int NL, int Q>
+__device__ __forceinline__ void lu_pivot_row_out(WgLds& L, const double (&a)[3][20], int par, int k, int o, int g) {
+  double* ub = L.U + (u_off(k) - k - 1);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int col = 6 * (i + o) + g;
+    L.pbuf[par][col] = a[Q][i];
+    if (col > k && col < kBlock) ub[col] = a[Q][i];
+  }
+}
+template <int NL, int S>
+__device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)[3], int k, int o, int g, int rg) {
+  const int par = k & 1;
+  if (g == S) {   // this half-wave holds column k in register 0: pivot = first maximum in POSITION order
+    double bv = 0.0; int bp = 1 << 20;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const bool cand = pos[q] >= k && pos[q] < kBlock;
+      if (cand && (fabs(a[q][0]) > fabs(bv) || (fabs(a[q][0]) == fabs(bv) && pos[q] < bp))) { bv = a[q][0]; bp = pos[q]; }
+    }
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+      const double ov = __shfl_xor(bv, m, 32);
+      const int op = __shfl_xor(bp, m, 32);
+      if (fabs(ov) > fabs(bv) || (fabs(ov) == fabs(bv) && op < bp)) { bv = ov; bp = op; }
+    }
+    if (bv == 0.0) { L.flag = 1; bv = 1.0; }   // singular block: the oracle gives up (no models); finish harmlessly
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const bool cand = pos[q] >= k && pos[q] < kBlock, mine = cand && pos[q] == bp;
+      L.lbuf[par][3 * rg + q] = (!cand || mine) ? 0.0 : a[q][0] / bv;
+      if (mine) { L.pinfo[par][0] = 3 * rg + q; L.pinfo[par][1] = bp; L.diag[k] = bv; L.prow_of[k] = (unsigned char)(3 * rg + q); }
+    }
+  }
+  __syncthreads();
+  const int pr = __builtin_amdgcn_readfirstlane(L.pinfo[par][0]), pp = __builtin_amdgcn_readfirstlane(L.pinfo[par][1]);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    if (pos[q] == pp) pos[q] = k;
+    else if (pos[q] == k) pos[q] = pp;
+  }
+  // the six lanes of the pivot row broadcast it and keep its part right of the diagonal (pr is uniform: no selects)
+  const int prg = pr / 3, pq = pr - 3 * prg;
+  if (pq == 0) { if (rg == prg) lu_pivot_row_out<NL, 0>(L, a, par, k, o, g); }
+  else if (pq == 1) { if (rg == prg) lu_pivot_row_out<NL, 1>(L, a, par, k, o, g); }
+  else { if (rg == prg) lu_pivot_row_out<NL, 2>(L, a, par, k, o, g); }
+  __syncthreads();
+  double l[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) l[q] = -L.lbuf[par][3 * rg + q];
+  const double* pb = &L.pbuf[par][6 * o + g];
+  constexpr int I0 = (S == 5) ? 1 : 0, D = (S == 5) ? 1 : 0;
+#pragma unroll
+  for (int c0 = I0; c0 < NL; c0 += 4) {   // four columns at a time: their LDS reads in flight together, no more
+    double pv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (c0 + j < NL) pv[j] = pb[6 * (c0 + j)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c0 + j < NL) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a[q][c0 + j - D] = __builtin_fma(l[q], pv[j], a[q][c0 + j]);
+      }
+    THIP_DLS_FENCE();
+  }
+  if (S == 5) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a[q][NL - 1] = 0.0;
+  }
+}
+
+template <int NL>
+__device__ __forceinline__ void lu_six(WgLds& L, double (&a)[3][20], int (&pos)[3], int o, int g, int rg) {
+  const int k = 6 * o;
+  lu_step<NL, 0>(L, a, pos, k, o, g, rg);
+  lu_step<NL, 1>(L, a, pos, k + 1, o, g, rg);
+  lu_step<NL, 2>(L, a, pos, k + 2, o, g, rg);
+  if (k + 3 >= kBlock) return;   // 93 = 15 * 6 + 3
+  lu_step<NL, 3>(L, a, pos, k + 3, o, g, rg);
+  lu_step<NL, 4>(L, a, pos, k + 4, o, g, rg);
+  lu_step<NL, 5>(L, a, pos, k + 5, o, g, rg);
+}
+
+// back-substitution step: the lanes of the row pivoted at step k (row Q of row group prg) solve its five right-hand sides
+template <int Q>
+__device__ __forceinline__ void bs_solve_row(WgLds& L, const double (&a)[3][20], int par, int k, int g, double* __restrict__ Xn, int slot) {
+  const double dg = L.diag[k];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const double x = a[Q][i] / dg;
+    L.lbuf[par][6 * i + g] = x;
+    const int c = 6 * i + g - 3;
+    if (slot != 255 && c >= 0 && c < kReduced) Xn[slot * kReduced + c] = x;
+  }
+}
+
 // points: feat[i * fstride + {0,1}], world[i * wstride + {0,1,2}] for i = index ? index[k] : k, k < npts.
 // Writes action[729] (row-major) and tfac[27]; returns false when a pivot vanished (degenerate sample).
 // GDLS (GdlsSimilarityTransform, gdls_similarity_transform.cc:67-175): feat holds the UNIT ray direction (3), world the
 // homogeneous point (4: hnormalized here), origin the ray origin (3); tfac = translation factor (27) | scale factor (9).
+// Called by all 192 threads of a workgroup; every sum runs in the order of oracle/dls_oracle.h (points in sequence).
 template <bool GDLS = false>
-__device__ inline bool stage_a(WaveLds& L, int npts, const double* __restrict__ feat, int fstride,
+__device__ __forceinline__ bool stage_a(WgLds& L, int npts, const double* __restrict__ feat, int fstride,
                                const double* __restrict__ world, int wstride, const int* __restrict__ index,
                                const double* __restrict__ u4, double* __restrict__ action, double* __restrict__ tfac,
                                const double* __restrict__ origin = nullptr, int ostride = 0) {
-  const int lane = threadIdx.x & 63;
+  const int tid = threadIdx.x;
+  const int g = tid >> 5, rg = tid & 31;
   const dls::Tables& tb = c_tab;
-  if (lane < 4) L.u[lane] = u4[lane];
-  if (lane == 0) L.flag = 0;
+  if (tid < 4) L.u[tid] = u4[tid];
+  if (tid == 0) L.flag = 0;
   if constexpr (GDLS) {
-    // ---- sums over the rays: the 4 x 4 matrix H^-1 (:80-96) and the 4 x 9 helper (:101-117)
-    double hs[16], sv[36];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) hs[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 36; ++k) sv[k] = 0.0;
-    for (int i = lane; i < npts; i += 64) {
-      const int id = index ? index[i] : i;
-      const double* xx = feat + (size_t)id * fstride; const double* cc = origin + (size_t)id * ostride; const double* ww = world + (size_t)id * wstride;
-      const double x[3] = {xx[0], xx[1], xx[2]}, c[3] = {cc[0], cc[1], cc[2]}, X[3] = {ww[0] / ww[3], ww[1] / ww[3], ww[2] / ww[3]};
-      const double cd = (c[0] * x[0] + c[1] * x[1]) + c[2] * x[2];
-      hs[0] += ((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]) - cd * cd;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const double t = -c[r] + cd * x[r];
-        hs[4 * (r + 1)] += t; hs[r + 1] += t;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) hs[4 * (r + 1) + k + 1] += (r == k ? 1.0 : 0.0) - x[r] * x[k];
+    // ---- sums over the rays: the 4 x 4 matrix H^-1 (:80-96) and the 4 x 9 helper (:101-117), one entry per lane
+    if (tid < 16 + 36) {
+      double acc = 0.0;
+      for (int i = 0; i < npts; ++i) {
+        const int id = index ? index[i] : i;
+        const double* xx = feat + (size_t)id * fstride; const double* cc = origin + (size_t)id * ostride; const double* ww = world + (size_t)id * wstride;
+        const double x[3] = {xx[0], xx[1], xx[2]}, c[3] = {cc[0], cc[1], cc[2]};
+        const double cd = (c[0] * x[0] + c[1] * x[1]) + c[2] * x[2];
+        if (tid < 16) {
+          const int r = tid >> 2, k = tid & 3;
+          if (tid == 0) acc += ((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]) - cd * cd;
+          else if (r == 0 || k == 0) { const int a = r + k - 1; acc += -c[a] + cd * x[a]; }
+          else acc += (r == k ? 1.0 : 0.0) - x[r - 1] * x[k - 1];
+        } else {
+          const int e = tid - 16, r = e / 9, col = e % 9, kk = col / 3;
+          const double lx = ww[col % 3] / ww[3];
+          if (r == 0) acc += (c[kk] - cd * x[kk]) * lx;
+          else acc += (x[r - 1] * x[kk] - (r - 1 == kk ? 1.0 : 0.0)) * lx;
+        }
       }
-      // L(X)[k][col] = X[col % 3] when col / 3 == k: the sums over k collapse to k = col / 3
-#pragma unroll
-      for (int col = 0; col < 9; ++col) {
-        const int k = col / 3;
-        const double lx = X[col % 3];
-        sv[col] += (c[k] - cd * x[k]) * lx;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) sv[9 * (r + 1) + col] += (x[r] * x[k] - (r == k ? 1.0 : 0.0)) * lx;
-      }
+      if (tid < 16) L.fe.hinv[tid] = acc; else L.fe.traw[tid - 16] = acc;
     }
+    __syncthreads();
+    if (tid < 36) {
+      double Hm[16], hs[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) hs[k] = wave_allsum(hs[k]);
-#pragma unroll
-    for (int k = 0; k < 36; ++k) sv[k] = wave_allsum(sv[k]);
-    double Hm[16];
-    if (!inverse4(hs, Hm)) { if (lane == 0) L.flag = 1; for (int k = 0; k < 16; ++k) Hm[k] = 0.0; }
-    if (lane < 36) {
-      const int r = lane / 9, col = lane % 9;
+      for (int k = 0; k < 16; ++k) hs[k] = L.fe.hinv[k];
+      if (!inverse4(hs, Hm)) { L.flag = 1; for (int k = 0; k < 16; ++k) Hm[k] = 0.0; }
+      const int r = tid / 9, col = tid % 9;
       double s2 = 0.0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        double pre = 0.0, hk = 0.0;   // sv[9 k + col], Hm[4 r + k]: compile-time register indices only
-#pragma unroll
-        for (int cc2 = 0; cc2 < 9; ++cc2) pre = (cc2 == col) ? sv[9 * k + cc2] : pre;
+        double hk = 0.0;   // Hm[4 r + k]: compile-time register indices only
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) hk = (rr == r) ? Hm[4 * rr + k] : hk;
-        s2 += hk * pre;
+        s2 += hk * L.fe.traw[9 * k + col];
       }
       if (r == 0) L.sf[col] = s2; else L.T[9 * (r - 1) + col] = s2;
     }
   } else {
-  // ---- sums over the points: sum n n^T (6 unique) and sum (n n^T - I)_{ab} X_c (27)
-  double acc[33];
-#pragma unroll
-  for (int k = 0; k < 33; ++k) acc[k] = 0.0;
-  for (int i = lane; i < npts; i += 64) {
-    const int id = index ? index[i] : i;
-    const double fx = feat[(size_t)id * fstride], fy = feat[(size_t)id * fstride + 1];
-    const double nrm = sqrt((fx * fx + fy * fy) + 1.0);
-    const double n[3] = {fx / nrm, fy / nrm, 1.0 / nrm};
-    const double X[3] = {world[(size_t)id * wstride], world[(size_t)id * wstride + 1], world[(size_t)id * wstride + 2]};
-    acc[0] += n[0] * n[0]; acc[1] += n[0] * n[1]; acc[2] += n[0] * n[2];
-    acc[3] += n[1] * n[1]; acc[4] += n[1] * n[2]; acc[5] += n[2] * n[2];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        const double m = n[a] * n[b] - (a == b ? 1.0 : 0.0);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc[6 + 9 * a + 3 * b + c] += m * X[c];
+    // ---- H^-1 = n I - sum n n^T (dls_pnp.cc:90-94) and sum (n n^T - I) L(X) (:98-103), one entry per lane
+    if (tid < 9 + 27) {
+      const int r = tid < 9 ? tid / 3 : (tid - 9) / 9, c = tid < 9 ? tid % 3 : ((tid - 9) % 9) / 3;
+      double acc = (tid < 9 && r == c) ? (double)npts : 0.0;
+      for (int i = 0; i < npts; ++i) {
+        const int id = index ? index[i] : i;
+        const double fx = feat[(size_t)id * fstride], fy = feat[(size_t)id * fstride + 1];
+        const double nrm = sqrt((fx * fx + fy * fy) + 1.0);
+        const double b[3] = {fx / nrm, fy / nrm, 1.0 / nrm};
+        const double br = r == 0 ? b[0] : (r == 1 ? b[1] : b[2]), bc = c == 0 ? b[0] : (c == 1 ? b[1] : b[2]);
+        if (tid < 9) acc -= br * bc;
+        else acc += (br * bc - (r == c ? 1.0 : 0.0)) * world[(size_t)id * wstride + (tid - 9) % 3];
       }
-  }
-#pragma unroll
-  for (int k = 0; k < 33; ++k) acc[k] = wave_allsum(acc[k]);
-  // H = (n I - sum n n^T)^-1 (dls_pnp.cc:90-94), translation_factor = H * sum (n n^T - I) L(X) (dls_pnp.cc:98-105)
-  {
-    const double a0 = (double)npts - acc[0], a1 = -acc[1], a2 = -acc[2], a4 = (double)npts - acc[3], a5 = -acc[4], a8 = (double)npts - acc[5];
-    const double c00 = a4 * a8 - a5 * a5, c01 = a5 * a2 - a1 * a8, c02 = a1 * a5 - a4 * a2;
-    const double det = (a0 * c00 + a1 * c01) + a2 * c02;
-    const double id = 1.0 / det;
-    const double Hm[9] = {c00 * id, c01 * id, c02 * id,
-                          c01 * id, (a0 * a8 - a2 * a2) * id, (a2 * a1 - a0 * a5) * id,
-                          c02 * id, (a2 * a1 - a0 * a5) * id, (a0 * a4 - a1 * a1) * id};
-    if (lane < 27) {
-      const int r = lane / 9, c = lane % 9;
-      double s = 0.0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        double pre = 0.0;   // acc[6 + 9 k + c], compile-time indices only
-#pragma unroll
-        for (int cc = 0; cc < 9; ++cc) pre = (cc == c) ? acc[6 + 9 * k + cc] : pre;
-        s += Hm[3 * r + k] * pre;
-      }
-      L.T[lane] = s;
+      if (tid < 9) L.fe.hinv[tid] = acc; else L.fe.traw[tid - 9] = acc;
+    }
+    __syncthreads();
+    if (tid < 27) {   // translation_factor = H * (...)  (:105), H by cofactors as Eigen's 3 x 3 inverse
+      const double* a = L.fe.hinv;
+      const double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+      const double det = (a[0] * c00 + a[1] * c01) + a[2] * c02;
+      const double id = 1.0 / det;
+      const int r = tid / 9, c = tid % 9;
+      double h0, h1, h2;
+      if (r == 0) { h0 = c00 * id; h1 = (a[2] * a[7] - a[1] * a[8]) * id; h2 = (a[1] * a[5] - a[2] * a[4]) * id; }
+      else if (r == 1) { h0 = c01 * id; h1 = (a[0] * a[8] - a[2] * a[6]) * id; h2 = (a[2] * a[3] - a[0] * a[5]) * id; }
+      else { h0 = c02 * id; h1 = (a[1] * a[6] - a[0] * a[7]) * id; h2 = (a[0] * a[4] - a[1] * a[3]) * id; }
+      L.T[tid] = (h0 * L.fe.traw[c] + h1 * L.fe.traw[9 + c]) + h2 * L.fe.traw[18 + c];
     }
   }
-  }   // !GDLS
   __syncthreads();
-  // ---- D = sum (L(X) + T)^T (I - n n^T) (L(X) + T)   (dls_pnp.cc:111-118): lane = entry (alpha, beta), two passes
-  // (gDLS: W = L(X) - c scale_factor + T, gdls_similarity_transform.cc:123-133)
-  double* Dm = L.aug;          // 81
-  double* g = L.aug + 128;     // 90
-  for (int e = lane; e < 81; e += 64) {
-    const int al = e / 9, be = e % 9;
+  // ---- D = sum W^T (I - n n^T) W, W = L(X) + T (dls_pnp.cc:111-118; gDLS: W = L(X) - c scale_factor + T, :123-133)
+  if (tid < 81) {
+    const int al = tid / 9, be = tid % 9;
     double d = 0.0;
     for (int i = 0; i < npts; ++i) {
       const int id = index ? index[i] : i;
@@ -202,136 +288,104 @@ __device__ inline bool stage_a(WaveLds& L, int npts, const double* __restrict__ 
           wb[a] = (be / 3 == a ? ww[be % 3] / ww[3] : 0.0) + (L.T[9 * a + be] - cc[a] * L.sf[be]);
         }
       } else {
-      const double fx = feat[(size_t)id * fstride], fy = feat[(size_t)id * fstride + 1];
-      const double nrm = sqrt((fx * fx + fy * fy) + 1.0);
-      n[0] = fx / nrm; n[1] = fy / nrm; n[2] = 1.0 / nrm;
+        const double fx = feat[(size_t)id * fstride], fy = feat[(size_t)id * fstride + 1];
+        const double nrm = sqrt((fx * fx + fy * fy) + 1.0);
+        n[0] = fx / nrm; n[1] = fy / nrm; n[2] = 1.0 / nrm;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        wa[a] = L.T[9 * a + al] + (al / 3 == a ? world[(size_t)id * wstride + al % 3] : 0.0);
-        wb[a] = L.T[9 * a + be] + (be / 3 == a ? world[(size_t)id * wstride + be % 3] : 0.0);
+        for (int a = 0; a < 3; ++a) {
+          wa[a] = (al / 3 == a ? world[(size_t)id * wstride + al % 3] : 0.0) + L.T[9 * a + al];
+          wb[a] = (be / 3 == a ? world[(size_t)id * wstride + be % 3] : 0.0) + L.T[9 * a + be];
+        }
       }
+      // PW = (I - n n^T) W column be, then column al of W against it
+      double s2 = 0.0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        double pw = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pw += ((r == k ? 1.0 : 0.0) - n[r] * n[k]) * wb[k];
+        s2 += wa[r] * pw;
       }
-      // wa^T (I - n n^T) wb = wa.wb - (n.wa)(n.wb)
-      const double dab = (wa[0] * wb[0] + wa[1] * wb[1]) + wa[2] * wb[2];
-      const double na = (n[0] * wa[0] + n[1] * wa[1]) + n[2] * wa[2];
-      const double nb = (n[0] * wb[0] + n[1] * wb[1]) + n[2] * wb[2];
-      d += dab - na * nb;
+      d += s2;
     }
-    Dm[e] = d;
+    L.fe.Dm[tid] = d;
   }
   __syncthreads();
-  // ---- g_k = ((D + D^T) rbar)_k over the 10 monomials of degree <= 2; f_i = sum_k (d rbar_k / d s_i) g_k
-  for (int e = lane; e < 90; e += 64) {
-    const int k = e / 10, m = e % 10;
+  // ---- the cost quartic J' = sum_ab D_ab (rbar_a rbar_b), one coefficient per lane, (a, b) in row-major order
+  if (tid < dls::kJMono) {
     double s = 0.0;
-    for (int l = 0; l < 9; ++l) { const int c = tb.R[l][m]; if (c) s += (double)c * (Dm[9 * k + l] + Dm[9 * l + k]); }
-    g[e] = s;
+    for (int ab = 0; ab < 81; ++ab) { const int c = tb.P[ab][tid]; if (c) s += L.fe.Dm[ab] * (double)c; }
+    L.fe.J[tid] = s;
   }
   __syncthreads();
-  if (lane < 60) {
-    const int i = lane / 20, m3 = lane % 20;
-    double s = 0.0;
-    for (int k = 0; k < 9; ++k)
-      for (int q = 0; q < 4; ++q) {
-        const int c = tb.dR[i][k][q], m2 = tb.div3[m3][q];
-        if (c && m2 >= 0) s += (double)c * g[10 * k + m2];
+  if (tid < 60) L.f[tid] = (double)tb.fmul[tid] * L.fe.J[tb.fsrc[tid]];   // f_i = dJ'/ds_i
+  __syncthreads();
+  // ---- the augmented block [M11 | M10] into registers
+  double a[3][20];
+  {
+    const uint32_t* code = reinterpret_cast<const uint32_t*>(tb.init[tid]);
+#pragma unroll
+    for (int w = 0; w < 15; ++w) {
+      const uint32_t cw = code[w];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int cd = (cw >> (8 * b)) & 255;
+        a[(4 * w + b) / 20][(4 * w + b) % 20] = cd ? L.f[cd - 1] : 0.0;
       }
-    L.f[lane] = s;
+    }
   }
-  __syncthreads();
-  // ---- the five diagonal blocks, ascending degree
-  for (int bi = 0; bi < 5; ++bi) {
-    const int r0 = tb.blk_off[bi], nd = tb.blk_off[bi + 1] - r0, ncol = nd + kReduced;
-    for (int e = lane; e < nd * kAugCols; e += 64) L.aug[e] = 0.0;
+  int pos[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) pos[q] = 3 * rg + q;
+  __syncthreads();   // the front end's arrays share the pivot-row buffer
+  // ---- elimination (oracle: dls_action_from_cost)
+  for (int o = 0; o < 4; ++o) lu_six<20>(L, a, pos, o, g, rg);
+  for (int o = 4; o < 8; ++o) lu_six<16>(L, a, pos, o, g, rg);
+  for (int o = 8; o < 12; ++o) lu_six<12>(L, a, pos, o, g, rg);
+  for (int o = 12; o < 16; ++o) lu_six<8>(L, a, pos, o, g, rg);
+  // ---- back-substitution, column oriented: register i < 5 of a row now holds right-hand side 6 (i + 15) + g - 93
+  double* Xn = action;   // the solved rows the result reads wait in the problem's own output slot
+  __syncthreads();       // the solved rows go through the factor buffer the last step may still be read from
+  for (int k = kBlock - 1; k >= 0; --k) {
+    const int par = k & 1;
+    const int pr = __builtin_amdgcn_readfirstlane((int)L.prow_of[k]);
+    const int prg = pr / 3, pq = pr - 3 * prg, slot = tb.xslot[k];
+    if (pq == 0) { if (rg == prg) bs_solve_row<0>(L, a, par, k, g, Xn, slot); }
+    else if (pq == 1) { if (rg == prg) bs_solve_row<1>(L, a, par, k, g, Xn, slot); }
+    else { if (rg == prg) bs_solve_row<2>(L, a, par, k, g, Xn, slot); }
     __syncthreads();
-    for (int t = lane; t < nd * 20; t += 64) {
-      const int r = t / 20, nu = t % 20;
-      const int col = tb.col_of[r0 + r][nu];
-      const double coef = L.f[20 * tb.row_poly[r0 + r] + nu];
-      if (col < kReduced) L.aug[r * kAugCols + nd + col] = coef;
-      else if (col - kReduced >= r0) L.aug[r * kAugCols + (col - kReduced - r0)] = coef;
-    }
-    __syncthreads();
-    if (bi > 0) {
-      for (int t = lane; t < nd * kReduced; t += 64) {
-        const int r = t / kReduced, j = t % kReduced;
-        const double* fr = L.f + 20 * tb.row_poly[r0 + r];
-        double s = 0.0;
-        for (int nu = 0; nu < 10; ++nu) {   // the terms of degree < 3 land on lower-degree columns
-          const int col = tb.col_of[r0 + r][nu];
-          if (col >= kReduced) s += fr[nu] * L.X[(col - kReduced) * kReduced + j];
-        }
-        L.aug[r * kAugCols + nd + j] -= s;
-      }
-      __syncthreads();
-    }
-    // partial-pivot elimination, lane = column
-    for (int k = 0; k < nd; ++k) {
-      double best = -1.0; int prow = k;
-      if (lane >= k && lane < nd) { best = fabs(L.aug[lane * kAugCols + k]); prow = lane; }
+    double x[5];
 #pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) {
-        const double ob = __shfl_xor(best, o, 64);
-        const int op = __shfl_xor(prow, o, 64);
-        if (ob > best || (ob == best && op < prow)) { best = ob; prow = op; }
-      }
-      if (!(best > 0.0)) { if (lane == 0) L.flag = 1; best = 1.0; }
-      double pk = 0.0;
-      if (lane < ncol) {
-        pk = L.aug[prow * kAugCols + lane];
-        if (prow != k) { L.aug[prow * kAugCols + lane] = L.aug[k * kAugCols + lane]; L.aug[k * kAugCols + lane] = pk; }
-      }
-      __syncthreads();
-      const double rp = 1.0 / L.aug[k * kAugCols + k];
-      if (lane > k && lane < ncol) {
-        // four rows per step: the LDS reads of a step are in flight together (the rolled loop paid one LDS round trip per row)
-        int r = k + 1;
-        for (; r + 4 <= nd; r += 4) {
-          double lv[4], av[4];
+    for (int i = 0; i < 5; ++i) x[i] = L.lbuf[par][6 * i + g];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { lv[u] = L.aug[(r + u) * kAugCols + k]; av[u] = L.aug[(r + u) * kAugCols + lane]; }
+    for (int q = 0; q < 3; ++q)
+      if (pos[q] < k) {
+        const double u = -L.U[u_off(pos[q]) + k - pos[q] - 1];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) L.aug[(r + u) * kAugCols + lane] = av[u] - (lv[u] * rp) * pk;
-        }
-        for (; r < nd; ++r) {
-          const double l = L.aug[r * kAugCols + k] * rp;
-          L.aug[r * kAugCols + lane] -= l * pk;
-        }
+        for (int i = 0; i < 5; ++i) a[q][i] = __builtin_fma(u, x[i], a[q][i]);
       }
-      __syncthreads();
-    }
-    // back-substitution, column oriented: solve x_c, then retire it from the rows above
-    const int c_stop = (bi == 4) ? nd - 3 : 0;   // the degree-7 block: only its last three rows are read afterwards
-    for (int c = nd - 1; c >= c_stop; --c) {
-      if (lane < kReduced) {
-        const double x = L.aug[c * kAugCols + nd + lane] / L.aug[c * kAugCols + c];
-        L.aug[c * kAugCols + nd + lane] = x;
-        const int xr = (bi == 4) ? (57 + c - (nd - 3)) : (r0 + c);
-        L.X[xr * kReduced + lane] = x;
-      }
-      __syncthreads();
-      for (int t = lane; t < (c - c_stop) * kReduced; t += 64) {
-        const int i = c_stop + t / kReduced, j = t % kReduced;
-        L.aug[i * kAugCols + nd + j] -= L.aug[i * kAugCols + c] * L.aug[c * kAugCols + nd + j];
-      }
-      __syncthreads();
-    }
   }
-  // ---- action matrix: row j = coefficients of f0 * mu_j reduced to the 27 reduced monomials
-  for (int e = lane; e < kReduced * kReduced; e += 64) {
-    const int j = e / kReduced, j2 = e % kReduced;
-    double a = 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col = tb.mul[j][q];
-      if (col < kReduced) a += (col == j2) ? L.u[q] : 0.0;
-      else a -= L.u[q] * L.X[((col < kReduced + 57) ? col - kReduced : col - 60) * kReduced + j2];
-    }
-    action[e] = a;
-  }
-  if (lane < 27) tfac[lane] = L.T[lane];
-  if (GDLS && lane < 9) tfac[27 + lane] = L.sf[lane];
+  __threadfence_block();
   __syncthreads();
+  // ---- M00 - M01 X, the columns of M01 in ascending order
+  double res[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int e = tid + kThreads * t;
+    res[t] = 0.0;
+    if (e < kReduced * kReduced) {
+      const int r = e / kReduced, c = e % kReduced;
+      const int cd = tb.m00[r][c];
+      double s = cd ? L.u[cd - 1] : 0.0;
+      for (int m = 0; m < tb.m01n[r]; ++m) s = __builtin_fma(-L.u[tb.m01q[r][m]], Xn[tb.xslot[tb.m01j[r][m]] * kReduced + c], s);
+      res[t] = s;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { const int e = tid + kThreads * t; if (e < kReduced * kReduced) action[e] = res[t]; }
+  if (tid < 27) tfac[tid] = L.T[tid];
+  if (GDLS && tid < 9) tfac[27 + tid] = L.sf[tid];
   return L.flag == 0;
 }
 

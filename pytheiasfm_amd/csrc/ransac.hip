@@ -990,14 +990,14 @@ __global__ __launch_bounds__(64) void k_hom_c(int nprob, int B, const int* __res
 }
 
 // ---- DLS-PnP hypotheses (estimate_calibrated_absolute_pose.cc:89-97): two kernels instead of k_fit (dls_device.h).
-// k_dls_a: one wave per (problem, iteration); uvals holds the four Macaulay terms of every DlsPnp call of a process
+// k_dls_a: one workgroup of 192 threads per (problem, iteration); uvals holds the four Macaulay terms of every DlsPnp call of a process
 // (iteration it of a problem = call it: the reference never seeds rand(), and one Estimate() is one process here).
-__global__ __launch_bounds__(64) void k_dls_a(int nprob, int B, const int64_t* __restrict__ offsets,
+__global__ __launch_bounds__(dlsdev::kThreads, 3) void k_dls_a(int nprob, int B, const int64_t* __restrict__ offsets,
                                               const double* __restrict__ data, const int* __restrict__ samples,
                                               const int* __restrict__ active_iters, const int* __restrict__ iter_base,
                                               const double* __restrict__ uvals, double* __restrict__ action,
                                               double* __restrict__ tfac, int* __restrict__ okflag) {
-  __shared__ dlsdev::WaveLds L;
+  __shared__ dlsdev::WgLds L;
   const int b = blockIdx.x, p = blockIdx.y;
   if (b >= active_iters[p]) return;
   const size_t hyp = (size_t)p * B + b;
@@ -1100,12 +1100,12 @@ __global__ __launch_bounds__(64) void k_dls_b_team(size_t nhyp, int B, const int
 
 // ---- gDLS similarity hypotheses (estimate_similarity_transformation_2d_3d.cc:85-133): the DLS pipeline on four
 // camera-bearing correspondences -- stage A with the generalised cost matrix, the same eigen stage, solutions with scale
-__global__ __launch_bounds__(64) void k_gdls_a(int nprob, int B, const int64_t* __restrict__ offsets,
+__global__ __launch_bounds__(dlsdev::kThreads, 3) void k_gdls_a(int nprob, int B, const int64_t* __restrict__ offsets,
                                                const double* __restrict__ data, const int* __restrict__ samples,
                                                const int* __restrict__ active_iters, const int* __restrict__ iter_base,
                                                const double* __restrict__ uvals, double* __restrict__ action,
                                                double* __restrict__ tfac, int* __restrict__ okflag) {
-  __shared__ dlsdev::WaveLds L;
+  __shared__ dlsdev::WgLds L;
   const int b = blockIdx.x, p = blockIdx.y;
   if (b >= active_iters[p]) return;
   const size_t hyp = (size_t)p * B + b;
@@ -1158,10 +1158,10 @@ __global__ __launch_bounds__(64) void k_gdls_b_team(size_t nhyp, int B, const in
 }
 
 // DlsPnp on problems of any size (the directly bound solver, sfm.cc:577): a wave per problem, then a thread per problem
-__global__ __launch_bounds__(64) void k_dls_solve_a(const int64_t* __restrict__ offsets, const double* __restrict__ feat,
+__global__ __launch_bounds__(dlsdev::kThreads, 3) void k_dls_solve_a(const int64_t* __restrict__ offsets, const double* __restrict__ feat,
                                                     const double* __restrict__ world, const double* __restrict__ uvals,
                                                     double* __restrict__ action, double* __restrict__ tfac, int* __restrict__ okflag) {
-  __shared__ dlsdev::WaveLds L;
+  __shared__ dlsdev::WgLds L;
   const int i = blockIdx.x;
   const int64_t o = offsets[i];
   const int n = (int)(offsets[i + 1] - o);
@@ -1689,13 +1689,13 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         HIP_TRYR(hipMemcpyAsync(d_iter_base.p, h_iter_base.data(), sizeof(int) * cn, hipMemcpyHostToDevice, st));
         HIP_TRYR(hipEventRecord(ev0, st));   // (re-recorded: the uploads above are not part of the fit time)
         if (gdls_est) {
-          k_gdls_a<<<dim3(B, cn), 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_iter_base.p, d_dls_u.p,
+          k_gdls_a<<<dim3(B, cn), dlsdev::kThreads, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_iter_base.p, d_dls_u.p,
                                                d_dls_action.p, d_dls_tfac.p, d_dls_ok.p);
           k_gdls_b_team<<<(unsigned)((nh + kDlsTeamsPerWave - 1) / kDlsTeamsPerWave), 64, 0, st>>>(
               nh, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_dls_action.p, d_dls_tfac.p, d_dls_ok.p, d_models.p,
               d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
         } else {
-        k_dls_a<<<dim3(B, cn), 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_iter_base.p, d_dls_u.p,
+        k_dls_a<<<dim3(B, cn), dlsdev::kThreads, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_iter_base.p, d_dls_u.p,
                                             d_dls_action.p, d_dls_tfac.p, d_dls_ok.p);
         if (getenv("THEIA_HIP_DLS_THREAD_EIG"))
           k_dls_b<<<dim3((B + 63) / 64, cn), 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_dls_action.p,
@@ -2140,7 +2140,7 @@ int theia_hip_dls_pnp(int32_t num, const int64_t* offsets, const double* feature
   }
   HIP_TRYR(hipMemcpyAsync(dof.p, offsets, sizeof(int64_t) * (num + 1), hipMemcpyHostToDevice, st));
   HIP_TRYR(hipMemcpyAsync(du.p, u.data(), sizeof(double) * num * 4, hipMemcpyHostToDevice, st));
-  k_dls_solve_a<<<num, 64, 0, st>>>(dof.p, df.p, dw.p, du.p, da.p, dtf.p, dok.p);
+  k_dls_solve_a<<<num, dlsdev::kThreads, 0, st>>>(dof.p, df.p, dw.p, du.p, da.p, dtf.p, dok.p);
   k_dls_solve_b<<<(num + 63) / 64, 64, 0, st>>>(num, dof.p, dw.p, da.p, dtf.p, dok.p, dq.p, dt.p, dn.p);
   HIP_TRYR(hipGetLastError());
   HIP_TRYR(hipMemcpyAsync(quaternions, dq.p, sizeof(double) * num * 4 * NS, hipMemcpyDeviceToHost, st));

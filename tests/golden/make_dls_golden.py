@@ -4,8 +4,9 @@ polynomial system is evaluated from its text: the 60 expanded Jacobian-coefficie
 (index, value) list of CreateMacaulayMatrix (sfm/pose/dls_impl.cc:62-754) are parsed and run through numpy on random
 inputs.  What is stored is data only:
   * per case: a random 9 x 9 cost matrix D, the terms u, the values of the three Jacobian cubics as (exponents, value)
-    lists, and the 27 eigenvalues of the Schur complement of the reference's Macaulay matrix (dls_pnp.cc:143-146) --
-    invariant under the row / column order of the matrix, so any correct construction must reproduce them.
+    lists, the 27 eigenvalues of the Schur complement of the reference's Macaulay matrix (dls_pnp.cc:143-146) --
+    invariant under the row / column order of the matrix, so any correct construction must reproduce them -- and, for
+    the first two cases, the non-zero entries (row, column, value) of that matrix: the layout partialPivLu() walks.
 Also writes tests/golden/libc_rand.json: the first values of the real glibc rand() (tests/golden/make_rand_golden.c)."""
 import json
 import os
@@ -73,6 +74,9 @@ def main():
             "schur_eigenvalues": [[z.real, z.imag] for z in ev],
             "cond_M11": float(np.linalg.cond(M[27:, 27:])),
         })
+        if case < 2:   # the matrix itself, entry by entry (row, column, value): pins the LAYOUT the elimination walks
+            rr, cc = np.nonzero(M)
+            cases[-1]["macaulay"] = [[int(r), int(c), float(M[r, c])] for r, c in zip(rr, cc)]
     json.dump({"source": "sfm/pose/dls_impl.cc:62-754 evaluated by tests/golden/make_dls_golden.py", "cases": cases},
               open(os.path.join(HERE, "dls_reference_vectors.json"), "w"), indent=0)
     exe = "/tmp/make_rand_golden"

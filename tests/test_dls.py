@@ -54,6 +54,33 @@ def test_polynomial_system_matches_the_reference_tables():
             ev.pop(j)
 
 
+def test_macaulay_layout_is_the_reference_table_entry_by_entry():
+    """The oracle's 120 x 120 Macaulay matrix equals the reference's (dls_impl.cc:340-754 evaluated from its text) entry by
+    entry -- same rows, same column order -- so its partial-pivot LU of the 93 x 93 block walks the pivots the reference's
+    partialPivLu() walks (dls_pnp.cc:143-146).  The layout itself comes from scripts/gen_dls_layout.py."""
+    g = json.load(open(os.path.join(GOLD, "dls_reference_vectors.json")))
+    L = ol.rlib()
+    import ctypes as C
+    dp = C.POINTER(C.c_double)
+    checked = 0
+    for case in g["cases"]:
+        if "macaulay" not in case:
+            continue
+        D = np.array(case["D"]); u = np.array(case["u"]); M = np.zeros((120, 120)); A = np.zeros((27, 27))
+        assert L.oracle_dls_macaulay(D.ctypes.data_as(dp), u.ctypes.data_as(dp), M.ctypes.data_as(dp), A.ctypes.data_as(dp))
+        ref = np.zeros((120, 120))
+        for r, c, v in case["macaulay"]:
+            ref[r, c] = v
+        assert np.count_nonzero(ref) == 1968
+        assert np.array_equal(M != 0, ref != 0)
+        assert np.abs(M - ref).max() <= 1e-12 * np.abs(ref).max()
+        # and the Schur complement through numpy's LU of exactly that block
+        S = ref[:27, :27] - ref[:27, 27:] @ np.linalg.solve(ref[27:, 27:], ref[27:, :27])
+        assert np.abs(A - S).max() <= 1e-7 * max(1.0, np.abs(S).max()), np.abs(A - S).max()
+        checked += 1
+    assert checked == 2
+
+
 def test_eigen_solver_with_complex_pairs_matches_numpy():
     rng = np.random.default_rng(3)
     for n in (4, 9, 27):
