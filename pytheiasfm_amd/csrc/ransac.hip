@@ -989,24 +989,8 @@ __global__ __launch_bounds__(64) void k_hom_c(int nprob, int B, const int* __res
   tags[(size_t)p * B + base] = b;
 }
 
-// ---- DLS-PnP hypotheses (estimate_calibrated_absolute_pose.cc:89-97): two kernels instead of k_fit (dls_device.h).
-// k_dls_a: one workgroup of 192 threads per (problem, iteration); uvals holds the four Macaulay terms of every DlsPnp call of a process
-// (iteration it of a problem = call it: the reference never seeds rand(), and one Estimate() is one process here).
-__global__ __launch_bounds__(dlsdev::kThreads, 3) void k_dls_a(int nprob, int B, const int64_t* __restrict__ offsets,
-                                              const double* __restrict__ data, const int* __restrict__ samples,
-                                              const int* __restrict__ active_iters, const int* __restrict__ iter_base,
-                                              const double* __restrict__ uvals, double* __restrict__ action,
-                                              double* __restrict__ tfac, int* __restrict__ okflag) {
-  __shared__ dlsdev::WgLds L;
-  const int b = blockIdx.x, p = blockIdx.y;
-  if (b >= active_iters[p]) return;
-  const size_t hyp = (size_t)p * B + b;
-  const double* pd = data + (size_t)offsets[p] * 5;
-  const bool ok = dlsdev::stage_a(L, 3, pd, 5, pd + 2, 5, samples + hyp * 3, uvals + 4 * (size_t)(iter_base[p] + b),
-                                  action + hyp * 729, tfac + hyp * 27);
-  if (threadIdx.x == 0) okflag[hyp] = ok ? 1 : 0;
-}
-
+// ---- DLS-PnP hypotheses (estimate_calibrated_absolute_pose.cc:89-97): stage A = dls_kernels.hip (launch_dls_stage_a), then the
+// eigen stage below.
 __global__ __launch_bounds__(64) void k_dls_b(int nprob, int B, const int64_t* __restrict__ offsets,
                                               const double* __restrict__ data, const int* __restrict__ samples,
                                               const int* __restrict__ active_iters, const double* __restrict__ action,
@@ -1098,23 +1082,6 @@ __global__ __launch_bounds__(64) void k_dls_b_team(size_t nhyp, int B, const int
   tags[(size_t)p * B * mm + base + j] = b * mm + j;
 }
 
-// ---- gDLS similarity hypotheses (estimate_similarity_transformation_2d_3d.cc:85-133): the DLS pipeline on four
-// camera-bearing correspondences -- stage A with the generalised cost matrix, the same eigen stage, solutions with scale
-__global__ __launch_bounds__(dlsdev::kThreads, 3) void k_gdls_a(int nprob, int B, const int64_t* __restrict__ offsets,
-                                               const double* __restrict__ data, const int* __restrict__ samples,
-                                               const int* __restrict__ active_iters, const int* __restrict__ iter_base,
-                                               const double* __restrict__ uvals, double* __restrict__ action,
-                                               double* __restrict__ tfac, int* __restrict__ okflag) {
-  __shared__ dlsdev::WgLds L;
-  const int b = blockIdx.x, p = blockIdx.y;
-  if (b >= active_iters[p]) return;
-  const size_t hyp = (size_t)p * B + b;
-  const double* pd = data + (size_t)offsets[p] * kSimDatum;
-  const bool ok = dlsdev::stage_a<true>(L, 4, pd, kSimDatum, pd + 3, kSimDatum, samples + hyp * 4, uvals + 4 * (size_t)(iter_base[p] + b),
-                                        action + hyp * 729, tfac + hyp * 36, pd + 9, kSimDatum);
-  if (threadIdx.x == 0) okflag[hyp] = ok ? 1 : 0;
-}
-
 __global__ __launch_bounds__(64) void k_gdls_b_team(size_t nhyp, int B, const int64_t* __restrict__ offsets,
                                                     const double* __restrict__ data, const int* __restrict__ samples,
                                                     const int* __restrict__ active_iters, double* __restrict__ action,
@@ -1157,18 +1124,7 @@ __global__ __launch_bounds__(64) void k_gdls_b_team(size_t nhyp, int B, const in
   tags[(size_t)p * B * mm + base + j] = b * mm + j;
 }
 
-// DlsPnp on problems of any size (the directly bound solver, sfm.cc:577): a wave per problem, then a thread per problem
-__global__ __launch_bounds__(dlsdev::kThreads, 3) void k_dls_solve_a(const int64_t* __restrict__ offsets, const double* __restrict__ feat,
-                                                    const double* __restrict__ world, const double* __restrict__ uvals,
-                                                    double* __restrict__ action, double* __restrict__ tfac, int* __restrict__ okflag) {
-  __shared__ dlsdev::WgLds L;
-  const int i = blockIdx.x;
-  const int64_t o = offsets[i];
-  const int n = (int)(offsets[i + 1] - o);
-  bool ok = false;
-  if (n >= 3) ok = dlsdev::stage_a(L, n, feat + 2 * o, 2, world + 3 * o, 3, nullptr, uvals + 4 * (size_t)i, action + (size_t)i * 729, tfac + (size_t)i * 27);
-  if (threadIdx.x == 0) okflag[i] = ok ? 1 : 0;
-}
+// DlsPnp on problems of any size (the directly bound solver, sfm.cc:577): stage A per workgroup (dls_kernels.hip), then a thread per problem
 __global__ __launch_bounds__(64) void k_dls_solve_b(int num, const int64_t* __restrict__ offsets, const double* __restrict__ world,
                                                     const double* __restrict__ action, const double* __restrict__ tfac,
                                                     const int* __restrict__ okflag, double* __restrict__ quats,
@@ -1201,17 +1157,6 @@ int p4pf_kernel_ready() {
   return status;
 }
 
-int ensure_dls_tables() {
-  static std::once_flag once;
-  static int rc = 0;
-  std::call_once(once, [] {
-    dls::Tables t;
-    dls::build_tables(&t);
-    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(dlsdev::c_tab), &t, sizeof(t));
-    if (e != hipSuccess) rc = set_error(THEIA_HIP_ERR_NO_DEVICE, "hipMemcpyToSymbol(dls tables) failed: %s", hipGetErrorString(e));
-  });
-  return rc;
-}
 // Macaulay terms of DlsPnp calls [0, ncalls) of a process
 void dls_terms(std::vector<double>& u, dls::GlibcRand& gen, size_t ncalls) {
   while (u.size() < 4 * ncalls) u.push_back(dls::macaulay_term_from_rand(gen.next()));
@@ -1443,7 +1388,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   if (nprob == 0) return 0;
   int rc = ensure_device();
   if (rc) return rc;
-  if (dls_est && (rc = ensure_dls_tables())) return rc;
+  if (dls_est && (rc = dls_ensure_tables())) return rc;
   const int m = sample_size(est), ds = datum_size(est);
   const int64_t total = batch->offsets[nprob];
   int nmax = 0;
@@ -1689,14 +1634,14 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         HIP_TRYR(hipMemcpyAsync(d_iter_base.p, h_iter_base.data(), sizeof(int) * cn, hipMemcpyHostToDevice, st));
         HIP_TRYR(hipEventRecord(ev0, st));   // (re-recorded: the uploads above are not part of the fit time)
         if (gdls_est) {
-          k_gdls_a<<<dim3(B, cn), dlsdev::kThreads, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_iter_base.p, d_dls_u.p,
-                                               d_dls_action.p, d_dls_tfac.p, d_dls_ok.p);
+          launch_dls_stage_a(true, kSimDatum, cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_iter_base.p, d_dls_u.p,
+                             d_dls_action.p, d_dls_tfac.p, d_dls_ok.p, st);
           k_gdls_b_team<<<(unsigned)((nh + kDlsTeamsPerWave - 1) / kDlsTeamsPerWave), 64, 0, st>>>(
               nh, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_dls_action.p, d_dls_tfac.p, d_dls_ok.p, d_models.p,
               d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
         } else {
-        k_dls_a<<<dim3(B, cn), dlsdev::kThreads, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_iter_base.p, d_dls_u.p,
-                                            d_dls_action.p, d_dls_tfac.p, d_dls_ok.p);
+        launch_dls_stage_a(false, 5, cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_iter_base.p, d_dls_u.p,
+                           d_dls_action.p, d_dls_tfac.p, d_dls_ok.p, st);
         if (getenv("THEIA_HIP_DLS_THREAD_EIG"))
           k_dls_b<<<dim3((B + 63) / 64, cn), 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_dls_action.p,
                                                           d_dls_tfac.p, d_dls_ok.p, d_models.p, d_counts.p, d_dense.p, d_tags.p,
@@ -2110,7 +2055,7 @@ int theia_hip_dls_pnp(int32_t num, const int64_t* offsets, const double* feature
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
   if (num == 0) return 0;
   int rc = thip::ensure_device();
-  if (rc || (rc = ensure_dls_tables())) return rc;
+  if (rc || (rc = dls_ensure_tables())) return rc;
   hipStream_t st = solver_stream();
   PoolStreamScope pool_scope(st);   // blocks this call hands back to the caches are tagged with an event on this stream (pools.h)
   if (!st) return set_error(THEIA_HIP_ERR_NO_DEVICE, "could not create the solver stream");
@@ -2140,7 +2085,7 @@ int theia_hip_dls_pnp(int32_t num, const int64_t* offsets, const double* feature
   }
   HIP_TRYR(hipMemcpyAsync(dof.p, offsets, sizeof(int64_t) * (num + 1), hipMemcpyHostToDevice, st));
   HIP_TRYR(hipMemcpyAsync(du.p, u.data(), sizeof(double) * num * 4, hipMemcpyHostToDevice, st));
-  k_dls_solve_a<<<num, dlsdev::kThreads, 0, st>>>(dof.p, df.p, dw.p, du.p, da.p, dtf.p, dok.p);
+  launch_dls_solve_a(num, dof.p, df.p, dw.p, du.p, da.p, dtf.p, dok.p, st);
   k_dls_solve_b<<<(num + 63) / 64, 64, 0, st>>>(num, dof.p, dw.p, da.p, dtf.p, dok.p, dq.p, dt.p, dn.p);
   HIP_TRYR(hipGetLastError());
   HIP_TRYR(hipMemcpyAsync(quaternions, dq.p, sizeof(double) * num * 4 * NS, hipMemcpyDeviceToHost, st));

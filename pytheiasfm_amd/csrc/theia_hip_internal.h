@@ -29,6 +29,14 @@ int fundamental_batch_device(int num, const int64_t* d_offsets, const int* d_cou
 // twoview_lm.hip: batched OptimizeHomography; d_H = [num][9] in Eigen's column-major storage order, in/out (normalised by H(2,2))
 int homography_batch_device(int num, const int64_t* d_offsets, const int* d_counts, const double* d_corr, double* d_H,
                             const theia_ba_options* o, void* d_out, hipStream_t st);
+// dls_kernels.hip: stage A of the DLS / gDLS minimal solver (Macaulay elimination) for B hypotheses of nprob problems, and for
+// whole problems (the directly bound DlsPnp); dls_ensure_tables uploads the index tables once per process.
+int dls_ensure_tables();
+void launch_dls_stage_a(bool gdls, int datum_stride, int nprob, int B, const int64_t* offsets, const double* data, const int* samples,
+                        const int* active_iters, const int* iter_base, const double* uvals, double* action, double* tfac, int* okflag,
+                        hipStream_t st);
+void launch_dls_solve_a(int num, const int64_t* offsets, const double* feat, const double* world, const double* uvals, double* action,
+                        double* tfac, int* okflag, hipStream_t st);
 // ba_invdepth.hip: bundle adjustment with the inverse-depth track parametrisation (THEIA_BA_FLAG_INVERSE_DEPTH)
 int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_summary* S);
 // the same problem as a device-resident object behind the handle API (theia_hip_ba_create with THEIA_BA_FLAG_INVERSE_DEPTH)
