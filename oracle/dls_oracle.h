@@ -151,9 +151,10 @@ inline bool dls_action_from_cost(const double* D, const double* u, double* fcoef
       for (int c = k + 1; c < w; ++c) Aug[(size_t)r * w + c] = __builtin_fma(-l, Aug[(size_t)k * w + c], Aug[(size_t)r * w + c]);
     }
   }
-  // column-oriented back-substitution: x_k = rhs_k / u_kk, then retired from the rows above
+  // column-oriented back-substitution: x_k = rhs_k * (1 / u_kk), then retired from the rows above
   for (int k = nb - 1; k >= 0; --k) {
-    for (int c = 0; c < nr; ++c) Aug[(size_t)k * w + nb + c] = Aug[(size_t)k * w + nb + c] / Aug[(size_t)k * w + k];
+    const double inv_ukk = 1.0 / Aug[(size_t)k * w + k];   // Eigen's triangular solve with a matrix right-hand side multiplies by the inverted diagonal
+    for (int c = 0; c < nr; ++c) Aug[(size_t)k * w + nb + c] = Aug[(size_t)k * w + nb + c] * inv_ukk;
     for (int i = 0; i < k; ++i) {
       const double u_ik = Aug[(size_t)i * w + k];
       if (u_ik == 0.0) continue;

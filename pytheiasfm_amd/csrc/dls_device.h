@@ -5,7 +5,7 @@
 //            block in the generated table's row / column order (dls_layout.h) with the 27 reduced columns as right-hand
 //            sides (dls_pnp.cc:143-146), a column-oriented back-substitution and M00 - M01 X.  Every entry sees exactly
 //            the operations of oracle/dls_oracle.h in the same order (first-maximum pivots, l = a / pivot, one fused
-//            multiply-add per update, x = rhs / u_kk), so the 27 x 27 result -- and with it every hypothesis, inlier set
+//            multiply-add per update, x = rhs * (1 / u_kk)), so the 27 x 27 result -- and with it every hypothesis, inlier set
 //            and cost -- is BIT-IDENTICAL to the sequential restatement (round 3 eliminated degree by degree: a faster
 //            but different route, 978 of 1000 pairs equal).
 //            The augmented 93 x 120 matrix lives in REGISTERS: lane = (column group g = tid / 32, row group rg = tid % 32)

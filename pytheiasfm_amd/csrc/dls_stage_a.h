@@ -102,7 +102,7 @@ __device__ __forceinline__ void lu_pivot_row_out(double* __restrict__ ub, const 
   for (int i = 0; i < NL; ++i) ub[6 * i] = a[Q][i];
 }
 template <int NL, bool SHIFT>
-__device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)[3], int k, int s, int g, int rg) {
+__device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)[3], int k, int s, int g, int rg, int urow) {
   const int par = k & 1;
   if ((g >> 1) == (s >> 1)) {   // the wave whose half s & 1 holds column k in register 0 (the other half rides along)
     // pivot = first maximum in POSITION order: largest |a|, then smallest position
@@ -126,7 +126,7 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
       for (int q = 0; q < 3; ++q) {
         const bool cand = pos[q] >= k && pos[q] < kBlock, mine = cand && pos[q] == gp;
         L.lbuf[par][3 * rg + q] = (!cand || mine) ? 0.0 : a[q][0] / piv;
-        if (mine) { L.pinfo[par][0] = 3 * rg + q; L.pinfo[par][1] = gp; L.diag[k] = piv; L.prow_of[k] = (unsigned char)(3 * rg + q); }
+        if (mine) { L.pinfo[par][0] = 3 * rg + q; L.pinfo[par][1] = gp; L.diag[k] = 1.0 / piv; L.prow_of[k] = (unsigned char)(3 * rg + q); }
       }
     }
   }
@@ -138,7 +138,7 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
     else if (pos[q] == k) pos[q] = pp;
   }
   // the six lanes of the pivot row put it where everybody reads it (pr is uniform: no selects)
-  double* ub = L.U + u_base(k) + g;
+  double* ub = L.U + urow + g;   // urow = u_base(k)
   const int prg = pr / 3, pq = pr - 3 * prg;
   if (pq == 0) { if (rg == prg) lu_pivot_row_out<NL, 0>(ub, a); }
   else if (pq == 1) { if (rg == prg) lu_pivot_row_out<NL, 1>(ub, a); }
@@ -168,20 +168,21 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
 }
 
 template <int NL>
-__device__ __forceinline__ void lu_six(WgLds& L, double (&a)[3][20], int (&pos)[3], int o, int g, int rg) {
-  const int k = 6 * o, ns = (k + 6 <= kBlock) ? 5 : kBlock - k;   // 93 = 15 * 6 + 3
-  for (int s = 0; s < ns; ++s) lu_step<NL, false>(L, a, pos, k + s, s, g, rg);
-  if (k + 6 <= kBlock) lu_step<NL, true>(L, a, pos, k + 5, 5, g, rg);
+__device__ __forceinline__ void lu_six(WgLds& L, double (&a)[3][20], int (&pos)[3], int o, int g, int rg, int& urow) {
+  const int k = 6 * o, ns = (k + 6 <= kBlock) ? 5 : kBlock - k, len = kBlock - k;   // 93 = 15 * 6 + 3
+#pragma nounroll
+  for (int s = 0; s < ns; ++s, urow += len) lu_step<NL, false>(L, a, pos, k + s, s, g, rg, urow);
+  if (k + 6 <= kBlock) { lu_step<NL, true>(L, a, pos, k + 5, 5, g, rg, urow); urow += len; }
 }
 
 // back-substitution step: the lanes of the row pivoted at step k (row Q of row group prg) solve its five right-hand sides
 template <int Q>
 __device__ __forceinline__ void bs_solve_row(WgLds& L, const double (&a)[3][20], int par, int k, int g, double* __restrict__ Xn, int slot) {
   if (Q == 0) asm volatile("; solved row = register row 0"); else if (Q == 1) asm volatile("; solved row = register row 1"); else asm volatile("; solved row = register row 2");
-  const double dg = L.diag[k];
+  const double inv_ukk = L.diag[k];   // 1 / u_kk, inverted once when the pivot was found
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
-    const double x = a[Q][i] / dg;
+    const double x = a[Q][i] * inv_ukk;
     L.lbuf[par][6 * i + g] = x;
     const int c = 6 * i + g - 3;
     if (slot != 255 && c >= 0 && c < kReduced) Xn[slot * kReduced + c] = x;
@@ -341,13 +342,17 @@ __device__ __forceinline__ bool stage_a(WgLds& L, int npts, const double* __rest
   for (int q = 0; q < 3; ++q) pos[q] = 3 * rg + q;
   __syncthreads();   // the front end's arrays share the pivot-row store
   // ---- elimination (oracle: dls_action_from_cost)
-  for (int o = 0; o < 4; ++o) lu_six<20>(L, a, pos, o, g, rg);
-  for (int o = 4; o < 8; ++o) lu_six<16>(L, a, pos, o, g, rg);
-  for (int o = 8; o < 12; ++o) lu_six<12>(L, a, pos, o, g, rg);
-  for (int o = 12; o < 16; ++o) lu_six<8>(L, a, pos, o, g, rg);
+  int urow = 0;   // u_base(k), carried along
+  for (int o = 0; o < 4; ++o) lu_six<20>(L, a, pos, o, g, rg, urow);
+  for (int o = 4; o < 8; ++o) lu_six<16>(L, a, pos, o, g, rg, urow);
+  for (int o = 8; o < 12; ++o) lu_six<12>(L, a, pos, o, g, rg, urow);
+  for (int o = 12; o < 16; ++o) lu_six<8>(L, a, pos, o, g, rg, urow);
   // ---- back-substitution, column oriented: register i < 5 of a row now holds right-hand side 6 (i + 15) + g - 93
   double* Xn = action;   // the solved rows the result reads wait in the problem's own output slot
   __syncthreads();       // the solved rows go through the factor buffer the last step may still be read from
+  int ucol[3];   // entry (pos[q], k) of the pivot-row store sits at ucol[q] + k
+#pragma unroll
+  for (int q = 0; q < 3; ++q) ucol[q] = pos[q] < kBlock ? u_base(pos[q]) - 6 * (pos[q] / 6) : 0;
   for (int k = kBlock - 1; k >= 0; --k) {
     const int par = k & 1;
     const int pr = __builtin_amdgcn_readfirstlane((int)L.prow_of[k]);
@@ -362,7 +367,7 @@ __device__ __forceinline__ bool stage_a(WgLds& L, int npts, const double* __rest
 #pragma unroll
     for (int q = 0; q < 3; ++q)
       if (pos[q] < k) {
-        const double u = -L.U[u_base(pos[q]) + k - 6 * (pos[q] / 6)];
+        const double u = -L.U[ucol[q] + k];
 #pragma unroll
         for (int i = 0; i < 5; ++i) a[q][i] = __builtin_fma(u, x[i], a[q][i]);
       }
