@@ -215,11 +215,12 @@ def ransac_block(cpu_baseline, host_cores, rank=0, world=1):
     out = {"workload": f"synth_ransac_v1 C5: {PAIRS} pairs x {CORR} correspondences x {HYPS} hypotheses (min = max iterations), InlierSupport",
            "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS}
     # (name, estimator, data kind, threshold, FLOP per minimal solve, FLOP per model x correspondence, chunks of 1000 pairs run)
-    # DLS: ~0.23 MFLOP for the blocked Macaulay elimination + ~0.35 MFLOP for the 27 x 27 eigen-decomposition per solve
+    # DLS: the reference's dense route -- 2/3 93^3 + 2 93^2 27 = 1.0 MFLOP for the partial-pivot LU of the Macaulay block with its 27
+    # right-hand sides (dls_pnp.cc:143-146) + ~0.35 MFLOP for the 27 x 27 eigen-decomposition per solve
     # (all ten chunks: 40.96 M hypotheses, about half a minute)
     legs = (("five_point_relative_pose", ransac.EST_RELATIVE_POSE, "relative", (2.0 / 1000.0) ** 2, 2.5e4, 85.0, PAIRS // CHUNK),
             ("sqpnp_absolute_pose", ransac.EST_ABS_SQPNP, "absolute", (4.0 / 1000.0) ** 2, 3.0e4, 30.0, PAIRS // CHUNK),
-            ("dls_absolute_pose", ransac.EST_ABS_DLS, "absolute", (4.0 / 1000.0) ** 2, 5.8e5, 30.0, PAIRS // CHUNK))
+            ("dls_absolute_pose", ransac.EST_ABS_DLS, "absolute", (4.0 / 1000.0) ** 2, 1.35e6, 30.0, PAIRS // CHUNK))
     for name, est, kind, thresh, fit_flop, score_flop, nchunks in legs:
         p = ransac.RansacParameters(); p.error_thresh = thresh; p.min_iterations = HYPS; p.max_iterations = HYPS; p.seed = 1
         tot = {"hyp": 0, "models": 0, "wall": 0.0, "fit": 0.0, "score": 0.0, "kern": 0.0}
