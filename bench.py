@@ -294,11 +294,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ransac", action="store_true")
     ap.add_argument("--no-c2", action="store_true")
+    ap.add_argument("--one-gpu-dry-run", action="store_true",
+                    help="with --gpus N under torch.distributed.run: all N ranks share cuda:0 and the collective goes through the host "
+                         "(gloo); everything else is the multi-GPU code path -- a rehearsal of the SCALE run on a one-GPU box, not a measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dry = bool(args.one_gpu_dry_run) and world > 1
+    if dry:
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
@@ -312,7 +318,11 @@ def main():
     capi.check(capi.lib().theia_hip_init(local_rank))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if dry else "cuda"   # where the few scalar reductions of this script live
 
     # ---- headline workload (synthetic, deterministic): C4, strong-sharded over the ranks
     full = synth.ba_config("C4")
@@ -332,7 +342,10 @@ def main():
     if world > 1:
         # the library issues ncclAllReduce itself (theia_hip_ba_set_rccl); THEIA_HIP_BENCH_TORCH_ALLREDUCE=1 keeps the
         # torch.distributed callback of round 1 for comparison
-        if os.environ.get("THEIA_HIP_BENCH_TORCH_ALLREDUCE"):
+        if dry:
+            R.h.set_allreduce(tdist.make_host_staged_allreduce(0))
+            R.h.set_shard(rank, world)
+        elif os.environ.get("THEIA_HIP_BENCH_TORCH_ALLREDUCE"):
             R.h.set_allreduce(tdist.make_torch_allreduce(local_rank))
             R.h.set_shard(rank, world)
         else:
@@ -361,7 +374,7 @@ def main():
     barrier()
     pcie_it_per_s = npcie / (time.perf_counter() - tp0)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -513,7 +526,7 @@ def main():
         rb = ransac_block(False, host_cores, rank=rank, world=world)
         names = ("five_point_relative_pose", "sqpnp_absolute_pose", "dls_absolute_pose")
         t = torch.tensor([[rb[k]["wall_s"], float(rb[k]["hypotheses"])] for k in names],
-                         dtype=torch.float64, device="cuda")
+                         dtype=torch.float64, device=red_dev)
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         if rank == 0:
@@ -522,6 +535,9 @@ def main():
                 out["ransac"][nm] = {"hypotheses_per_sec": float(tsum[k, 1] / tmax[k, 0]), "hypotheses": float(tsum[k, 1]),
                                      "wall_s_max_over_ranks": float(tmax[k, 0])}
 
+    if rank == 0 and dry:
+        out["dry_run_one_gpu"] = {"ranks": world, "collective": "gloo through the host (RCCL refuses two ranks on one device)",
+                                  "note": "a rehearsal of the multi-GPU code path of this script on one device: NOT a scaling measurement"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

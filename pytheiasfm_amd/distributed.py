@@ -51,6 +51,32 @@ def make_torch_allreduce(device_index, group=None):
     return allreduce
 
 
+def make_host_staged_allreduce(device_index, group=None):
+    """All-reduce callback for BaHandle.set_allreduce when several ranks share ONE device (RCCL refuses two ranks on one
+    GPU): device buffer -> host, gloo all-reduce, host -> device, all ordered on the library's stream.  Everything else of a
+    sharded solve -- track shards, the packed reduced system, the per-rank gradient slots, the device-side step control
+    across collectives -- is the product path of a multi-GPU run (tests/sharded_worker.py, bench.py --one-gpu-dry-run)."""
+    import torch
+    import torch.distributed as dist
+
+    streams, views = {}, {}
+
+    def allreduce(ptr, count, op, stream):
+        t = views.get((ptr, count))
+        if t is None:
+            t = torch.as_tensor(_DevArray(ptr, count), device=torch.device("cuda", device_index)); views[(ptr, count)] = t
+        ext = streams.get(stream)
+        if ext is None:
+            ext = torch.cuda.ExternalStream(stream, device=torch.device("cuda", device_index)); streams[stream] = ext
+        with torch.cuda.stream(ext):
+            host = t.cpu()                      # waits for the work enqueued on the library's stream so far
+            dist.all_reduce(host, op=dist.ReduceOp.MAX if op == REDUCE_MAX else dist.ReduceOp.SUM, group=group)
+            t.copy_(host)                       # enqueued on the same stream, ahead of what the library enqueues next
+        return 0
+
+    return allreduce
+
+
 def make_host_allreduce(group=None):
     """CPU (gloo) variant used by the world_size-2 tests: reduces a host numpy
     buffer in place.  Signature (array, op)."""

@@ -19,20 +19,7 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    streams, views = {}, {}
-
-    def allreduce(ptr, count, op, stream):
-        t = views.get((ptr, count))
-        if t is None:
-            t = torch.as_tensor(tdist._DevArray(ptr, count), device=torch.device("cuda", 0)); views[(ptr, count)] = t
-        ext = streams.get(stream)
-        if ext is None:
-            ext = torch.cuda.ExternalStream(stream, device=torch.device("cuda", 0)); streams[stream] = ext
-        with torch.cuda.stream(ext):
-            host = t.cpu()                      # waits for the work enqueued on the library's stream so far
-            dist.all_reduce(host, op=dist.ReduceOp.MAX if op == tdist.REDUCE_MAX else dist.ReduceOp.SUM)
-            t.copy_(host)                       # enqueued on the same stream, ahead of what the library enqueues next
-        return 0
+    allreduce = tdist.make_host_staged_allreduce(0)
 
     mixed = bool(int(os.environ.get("SHARD_MIXED", "0")))
     inner = int(os.environ.get("SHARD_INNER", "0"))     # 1: inner iterations, 2: inner iterations with free intrinsics + a prior
