@@ -154,8 +154,12 @@ typedef struct theia_ba_problem {
    * touches the reference camera, the observing camera, the intrinsics group of the observing camera
    * (bundle_adjuster.cc:594-622; optimised on the subset of options.intrinsics_to_optimize unless group_const) and the
    * inverse depth; the camera priors enter as AddViewPriors adds them (bundle_adjuster.cc:289-313: the views that observe
-   * a track or are the reference view of one).  Only through theia_hip_ba_solve; no depth rows / inner iterations in this
-   * mode; a track may be observed through at most 8 variable intrinsics groups (THEIA_HIP_ERR_UNSUPPORTED beyond). */
+   * a track or are the reference view of one).  Through theia_hip_ba_solve and the handle API (create / reset_parameters /
+   * set_options / run / download; covariance, evaluation and sharding: THEIA_HIP_ERR_UNSUPPORTED); no depth rows / inner
+   * iterations in this mode; a track may be observed through at most 8 variable intrinsics groups (ERR_UNSUPPORTED beyond).
+   * REFERENCE PARITY: the reference's BundleAdjust*Reconstruction entry points never optimise intrinsics in this mode
+   * (only AddInvTrack runs, no view enters optimized_camera_intrinsics_groups_: bundle_adjuster.cc:441-459), so a caller
+   * that mirrors them passes options.intrinsics_to_optimize = 0 (the Python mirror does). */
   const int32_t* point_ref_cam;                  /* [num_points] camera index of the reference view */
   const double* point_ref_bearing;               /* [num_points][3]                                 */
   double* point_inverse_depth;                   /* [num_points] in/out, > 0                        */

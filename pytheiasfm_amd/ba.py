@@ -180,8 +180,12 @@ def problem_fingerprint(problem, options=None):
     camera -> group, models, constant masks, observation kinds, prior masks), the observations themselves and the
     options -- and nothing a solve CHANGES (extrinsics, intrinsics, points, inverse depths).  Two problems with the same fingerprint can
     share one theia_hip_ba_create: the second only re-uploads its parameters (theia_hip_ba_reset_parameters)."""
-    import xxhash
-    h = xxhash.xxh3_128()
+    try:
+        import xxhash
+        h = xxhash.xxh3_128()
+    except ImportError:          # no xxhash on this machine: the standard library's 128-bit BLAKE2b (slower, same role)
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
     p = problem
     h.update(np.array([p.cam_ext.shape[0], p.intrinsics.shape[0], p.points.shape[0], p.obs_uv.shape[0], p.flags], dtype=np.int64).tobytes())
     arrays = [p.obs_cam, p.obs_pt, p.obs_uv, p.obs_sqrt_info, p.group_model, p.cam_group, p.cam_const, p.group_const,
@@ -210,38 +214,56 @@ class ProblemCache:
     Inverse-depth problems are cached the same way (their handle keeps structure, observations and the reduced-system plan)."""
 
     def __init__(self, capacity=1):
+        import threading
         self.capacity = int(capacity)
-        self._handles = {}      # fingerprint -> BaHandle, insertion order = recency
+        self._handles = {}      # fingerprint -> idle BaHandle, insertion order = recency (a running handle is NOT in here)
+        self._lock = threading.Lock()
         self.hits = 0
         self.misses = 0
 
     def clear(self):
-        for h in self._handles.values():
+        with self._lock:
+            hs, self._handles = list(self._handles.values()), {}
+        for h in hs:
             h.close()
-        self._handles = {}
 
     def solve(self, problem, options, trace_capacity=256):
         """As ba.solve(): parameters of `problem` are updated in place; returns (summary, trace)."""
         if self.capacity <= 0 or problem.obs_uv.shape[0] == 0:
             return solve(problem, options, trace_capacity)
         key = problem_fingerprint(problem, options)
-        h = self._handles.pop(key, None)
+        # a handle leaves the dictionary while it runs (ctypes releases the GIL inside run()): a second thread solving the
+        # same topology builds its own handle, and no eviction can destroy a handle somebody is running
+        with self._lock:
+            h = self._handles.pop(key, None)
         if h is not None:
             try:
                 h.reset(problem)
-                self.hits += 1
+                with self._lock:
+                    self.hits += 1
             except capi.TheiaHipError:
                 h.close(); h = None
         if h is None:
             h = BaHandle(problem, options)
             h.problem = None          # the handle owns device copies only: do not pin the creating problem's host arrays
-            self.misses += 1
-        self._handles[key] = h
-        while len(self._handles) > self.capacity:
-            old = next(iter(self._handles))
-            self._handles.pop(old).close()
-        s, tr = h.run(trace_capacity)
-        h.download(problem)
+            with self._lock:
+                self.misses += 1
+        try:
+            s, tr = h.run(trace_capacity)
+            h.download(problem)
+        except Exception:
+            h.close()
+            raise
+        evict = []
+        with self._lock:
+            dup = self._handles.pop(key, None)     # another thread finished the same topology first: keep ours, drop theirs
+            if dup is not None:
+                evict.append(dup)
+            self._handles[key] = h
+            while len(self._handles) > self.capacity:
+                evict.append(self._handles.pop(next(iter(self._handles))))
+        for e in evict:
+            e.close()
         return s, tr
 
 

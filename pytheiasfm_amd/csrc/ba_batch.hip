@@ -546,12 +546,15 @@ __device__ inline void smallest_eigenvector4(double* A, double* x) {
 // four entries of the right singular vector of the smallest singular value of the 3N x (4 + N) matrix [-P_i | e_i x_i]:
 // eliminating the N scale unknowns from its normal equations leaves, for the eigenvalue mu,
 //     [ sum C^T C - mu (I + sum b_i b_i^T / (d_i (d_i - mu))) ] X = 0,   b_i = P_i^T x_i, d_i = x_i^T x_i, lambda_i = b_i.X / (d_i - mu)
-// -- the L2 matrix at mu = 0 -- solved by a few fixed-point steps on mu (the Rayleigh quotient of the full vector);
-// the result carries the reference's normalisation (unit norm over all 4 + N entries).  The sign is arbitrary, as Eigen's is.
+// -- the L2 matrix at mu = 0 -- solved by fixed-point steps on mu (the Rayleigh quotient of the full vector) until mu stops
+// moving (relative 1e-13, at most 24 steps; well-conditioned tracks take 2 - 3).  A track on which the iteration does not
+// settle (two nearly equal smallest eigenvalues) keeps the L2 solution of the first step.
+// The result carries the reference's normalisation (unit norm over all 4 + N entries).  The sign is arbitrary, as Eigen's is.
 __device__ inline void triangulate_nview(const TrackBatch& B, int64_t beg, int64_t end, bool svd, double* X) {
   double mu = 0.0;
-  double x[4] = {0.0, 0.0, 0.0, 1.0};
-  const int rounds = svd ? 4 : 1;
+  double x[4] = {0.0, 0.0, 0.0, 1.0}, x_l2[4] = {0.0, 0.0, 0.0, 1.0};
+  const int rounds = svd ? 24 : 1;
+  bool settled = !svd;
   for (int round = 0; round < rounds; ++round) {
     double D[16];
     for (int i = 0; i < 16; ++i) D[i] = 0.0;
@@ -575,6 +578,7 @@ __device__ inline void triangulate_nview(const TrackBatch& B, int64_t beg, int64
     if (mu != 0.0) for (int a = 0; a < 4; ++a) D[5 * a] -= mu;
     smallest_eigenvector4(D, x);
     if (!svd) break;
+    if (round == 0) for (int k = 0; k < 4; ++k) x_l2[k] = x[k];
     // Rayleigh quotient of the full vector (X, lambda): v^T M v = sum |P X - lambda x|^2
     double num = 0.0, den = (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
     for (int64_t i = beg; i < end; ++i) {
@@ -589,10 +593,12 @@ __device__ inline void triangulate_nview(const TrackBatch& B, int64_t beg, int64
       for (int r = 0; r < 3; ++r) { const double e = px[r] - lam * xi[r]; num += e * e; }
       den += lam * lam;
     }
-    mu = num / den;
-    if (round == rounds - 1) { const double sc = 1.0 / sqrt(den); for (int k = 0; k < 4; ++k) x[k] *= sc; }
+    const double mu_new = num / den;
+    settled = fabs(mu_new - mu) <= 1e-13 * mu_new || mu_new == mu;
+    mu = mu_new;
+    if (settled || round == rounds - 1) { const double sc = 1.0 / sqrt(den); for (int k = 0; k < 4; ++k) x[k] *= sc; break; }
   }
-  for (int k = 0; k < 4; ++k) X[k] = x[k];
+  for (int k = 0; k < 4; ++k) X[k] = settled ? x[k] : x_l2[k];
 }
 
 // Stage 1 + 2 of TrackEstimator::EstimateTrack, one thread per track: the triangulation-angle test on the

@@ -564,6 +564,7 @@ struct IdHandle {
   int nc = 0, np = 0, ng = 0, n = 0, ncam6 = 0, ngv = 0, npri = 0;
   int64_t nobs = 0;
   std::vector<int> grp_red, h_group_model;
+  std::vector<uint8_t> h_pt_observed;   // tracks with at least one observation: their inverse depth must be positive
   struct StreamGuard { hipStream_t s = nullptr; ~StreamGuard() { if (s) (void)hipStreamDestroy(s); } } sg;
   hipStream_t st = nullptr;
   Buf<double> d_intr[2], d_scale_i, d_colsq_i, d_pvec, d_pinfo, d_bearing, d_uv, d_si, d_cam[2], d_rho[2], d_scale_c, d_scale_r, d_scale_red, d_recs, d_red, d_vinv, d_grho, d_scal, d_radius, d_work, d_colsq_c, d_colsq_r;
@@ -610,6 +611,8 @@ int IdHandle::create(const theia_ba_problem* p, const theia_ba_options* o) {
     cam_used[p->obs_cam[i]] = 1; cam_used[p->point_ref_cam[pt]] = 1;
     pt_off[pt + 1]++;
   }
+  h_pt_observed.assign(np, 0);
+  for (int pt = 0; pt < np; ++pt) h_pt_observed[pt] = pt_off[pt + 1] > 0;
   for (int q = 0; q < np; ++q) { pt_const[q] = (p->point_const && p->point_const[q]) ? 1 : 0; pt_off[q + 1] += pt_off[q]; }
   std::vector<int> pt_obs(nobs);
   { std::vector<int64_t> fill(pt_off.begin(), pt_off.end() - 1); for (int64_t i = 0; i < nobs; ++i) pt_obs[fill[p->obs_pt[i]]++] = (int)i; }
@@ -726,6 +729,8 @@ int IdHandle::upload_parameters(const theia_ba_problem* p) {
   if (p->num_cameras != nc || p->num_points != np || p->num_groups != ng)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "problem shape differs from the handle's");
   if (!p->point_inverse_depth) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "inverse depth: point_inverse_depth missing");
+  for (int pt = 0; pt < np; ++pt)   // what create() checks: a reset must not smuggle in what a fresh handle would refuse
+    if (h_pt_observed[pt] && !(p->point_inverse_depth[pt] > 0.0)) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "track %d: inverse depth must be positive", pt);
   std::vector<double> hintr(p->intrinsics, p->intrinsics + (size_t)THEIA_MAX_INTRINSICS * ng);
   for (int g = 0; g < ng; ++g) if (grp_red[g] >= 0) id_project_to_bounds_host(h_group_model[g], &hintr[(size_t)g * kKW]);
   for (int k = 0; k < 2; ++k) {

@@ -1456,7 +1456,14 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   const bool use_lds = (size_t)nmax * ds * sizeof(double) <= 96 * 1024;
   const size_t lds_bytes = use_lds ? (size_t)nmax * ds * sizeof(double) : 0;
   if (use_lds && lds_bytes > 48 * 1024) {
-    HIP_TRYR(hipFuncSetAttribute((const void*)k_score<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    // every instance that can be launched below opts in (the compile-time-estimator instances are kernels of their own)
+    const void* fn = (const void*)k_score<true>;
+    if (est == THEIA_EST_RELATIVE_POSE) fn = (const void*)k_score<true, THEIA_EST_RELATIVE_POSE>;
+    else if (est == THEIA_EST_ESSENTIAL_MATRIX) fn = (const void*)k_score<true, THEIA_EST_ESSENTIAL_MATRIX>;
+    else if (est == THEIA_EST_ABSOLUTE_POSE_KNEIP) fn = (const void*)k_score<true, THEIA_EST_ABSOLUTE_POSE_KNEIP>;
+    else if (est == THEIA_EST_ABSOLUTE_POSE_DLS) fn = (const void*)k_score<true, THEIA_EST_ABSOLUTE_POSE_DLS>;
+    else if (est == THEIA_EST_ABSOLUTE_POSE_SQPNP) fn = (const void*)k_score<true, THEIA_EST_ABSOLUTE_POSE_SQPNP>;
+    HIP_TRYR(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   }
 
   std::vector<int> best_samples_all((size_t)nprob * kMaxSample, 0), best_slot_all(nprob, -1);

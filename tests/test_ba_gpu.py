@@ -869,13 +869,15 @@ def _projection_matrix(ext, k, model):
     return K @ np.concatenate([R, (-R @ ext[:3])[:, None]], axis=1)
 
 
+@pytest.mark.parametrize("noise", [0.5, 8.0])
 @pytest.mark.parametrize("method", [1, 2])
-def test_estimate_tracks_svd_and_l2_triangulation(method):
+def test_estimate_tracks_svd_and_l2_triangulation(method, noise):
     """TriangulationMethodType SVD / L2_MINIMIZATION (estimate_track.cc:239-257): without the track BA the point is
     TriangulateNViewSVD / TriangulateNView (triangulation.cc:178-214) of the pixels and the cameras' projection matrices,
     restated here with numpy's SVD of the 3N x (4 + N) design matrix / eigh of the 4 x 4 one (defined up to sign); with the
-    BA the tracks end where the MIDPOINT start ends (same minimum), and the counters follow the same rules."""
-    p = synth.synth_ba_v1(14, 120, seed=0xE5A1, sigma_pt=0.0, sigma_pos=0.0, sigma_rot_deg=0.0, pixel_noise=0.5)   # pinhole: the linear methods ignore any distortion
+    BA the tracks end where the MIDPOINT start ends (same minimum), and the counters follow the same rules.  The 8-pixel case is
+    the one where the SVD's eigenvalue mu is not small against the L2 matrix: the fixed point has to be iterated to convergence."""
+    p = synth.synth_ba_v1(14, 120, seed=0xE5A1, sigma_pt=0.0, sigma_pos=0.0, sigma_rot_deg=0.0, pixel_noise=noise)   # pinhole: the linear methods ignore any distortion
     o, _ = both_options(max_num_iterations=15, use_inner_iterations=0)
     C_ = p.cam_ext[p.obs_cam, :3]
     X = p.points[p.obs_pt, :3] / p.points[p.obs_pt, 3:]
@@ -909,8 +911,11 @@ def test_estimate_tracks_svd_and_l2_triangulation(method):
         worst = max(worst, np.abs(got * sgn - ref).max() / np.abs(ref).max())
         dist.append(np.linalg.norm(got[:3] / got[3] - p.points[q, :3] / p.points[q, 3]))
     assert worst < 1e-7, worst
-    assert np.median(dist) < 0.05      # 0.5 px noise, lens distortion ignored by the linear methods: near the planted points
-    assert cnt["failed_triangulations"] == 0 and est.sum() >= 100
+    assert np.median(dist) < 0.1 * noise      # lens distortion ignored by the linear methods: near the planted points
+    assert cnt["failed_triangulations"] == 0
+    if noise > 1.0:      # (most of these tracks then fail the 5-pixel reprojection test of EstimateTrack: the points were compared above)
+        return
+    assert est.sum() >= 100
     # with the track BA: the same minimum as from the midpoint start
     pa = p.copy(); pa.points[:] = 0.0; pa.points[:, 3] = 1.0
     pb = p.copy(); pb.points[:] = 0.0; pb.points[:, 3] = 1.0
