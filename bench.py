@@ -469,6 +469,21 @@ def main():
                                   "note": "intrinsics_to_optimize = FOCAL_LENGTH | RADIAL_DISTORTION over the problem's 8 shared groups "
                                           "(k_lin_schur_i + k_sum_items: fused, records in LDS, DESIGN.md 3.5); not the headline configuration"}
         del hk
+        # the pipelines' REAL default: both of the above at once (reconstruction_estimator_options.h:281-283 frees FOCAL_LENGTH |
+        # RADIAL_DISTORTION, bundle_adjustment.h:144 leaves use_inner_iterations on)
+        ob = bench_options(ba, ITERS_PER_SOLVE); ob.intrinsics_to_optimize = 0x01 | 0x10; ob.use_inner_iterations = 1
+        hb = ba.BaHandle(pristine.copy(), ob)
+        hb.reset(pristine); hb.snapshot()
+        hb.restore(); hb.run(trace_capacity=1)
+        torch.cuda.synchronize(); tb0 = time.perf_counter()
+        for _ in range(nrep):
+            hb.restore(); sb, _ = hb.run(trace_capacity=1)
+        torch.cuda.synchronize(); tb = time.perf_counter() - tb0
+        out["pipeline_default"] = {"lm_iterations_per_sec": nrep * sb.num_iterations / tb,
+                                   "ms_per_step": 1e3 * tb / (nrep * sb.num_iterations), "iterations_per_solve": sb.num_iterations,
+                                   "note": "intrinsics_to_optimize = FOCAL_LENGTH | RADIAL_DISTORTION AND use_inner_iterations = true: what "
+                                           "BundleAdjustReconstruction runs with inside the reference's pipelines; not the headline configuration"}
+        del hb
     if rank == 0 and world == 1:
         # what one theia_hip_ba_solve call costs end to end (BundleAdjustReconstruction through the boundary: host-side
         # structure analysis + uploads + 25 LM iterations + download), for the record next to the steady-state rate
