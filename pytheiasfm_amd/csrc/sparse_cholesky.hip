@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <vector>
 
@@ -309,8 +310,58 @@ struct Orderer {
   }
   std::vector<int> vis;
 
+  // Small node sets are ordered EXACTLY: the height of the elimination tree is the tree-depth of the induced graph,
+  //   td(G) = max over the components of G;  td(connected G) = 1 + min over v of td(G - v),
+  // by memoised recursion over vertex subsets (<= 8 nodes: 256 subsets).  The separator heuristic below leaves pieces
+  // like {a - b - c with a ~ c} (the short last tile of a ring makes one) that cost a level more than they have to.
+  static constexpr int kExact = 8;
+  void order_exact(const std::vector<int>& nodes) {
+    const int m = (int)nodes.size();
+    std::vector<unsigned> adjm(m, 0);
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j < m; ++j)
+        if (i != j && std::find(nbr[nodes[i]].begin(), nbr[nodes[i]].end(), nodes[j]) != nbr[nodes[i]].end()) adjm[i] |= 1u << j;
+    std::vector<signed char> td(1u << m, -1), pick(1u << m, -1);
+    auto component = [&](unsigned mask, int seed) {
+      unsigned comp = 1u << seed, frontier = comp;
+      while (frontier) {
+        unsigned next = 0;
+        for (int i = 0; i < m; ++i) if (frontier >> i & 1u) next |= adjm[i] & mask & ~comp;
+        comp |= next; frontier = next;
+      }
+      return comp;
+    };
+    // depth of a CONNECTED subset
+    std::function<int(unsigned)> solve = [&](unsigned mask) -> int {
+      if (td[mask] >= 0) return td[mask];
+      if (!(mask & (mask - 1))) { td[mask] = 1; pick[mask] = (signed char)__builtin_ctz(mask); return 1; }
+      int best = 127, bv = -1;
+      for (int v = 0; v < m; ++v) {
+        if (!(mask >> v & 1u)) continue;
+        unsigned rest = mask & ~(1u << v);
+        int worst = 0;
+        while (rest && worst < best - 1) {
+          const unsigned c = component(rest, __builtin_ctz(rest));
+          worst = std::max(worst, solve(c));
+          rest &= ~c;
+        }
+        if (!rest && worst + 1 < best) { best = worst + 1; bv = v; }
+      }
+      td[mask] = (signed char)best; pick[mask] = (signed char)bv;
+      return best;
+    };
+    std::function<void(unsigned)> emit = [&](unsigned mask) {   // mask: connected
+      const int v = pick[mask];
+      unsigned rest = mask & ~(1u << v);
+      while (rest) { const unsigned c = component(rest, __builtin_ctz(rest)); emit(c); rest &= ~c; }
+      out.push_back(nodes[v]);
+    };
+    unsigned all = (m >= 32) ? ~0u : ((1u << m) - 1u);
+    while (all) { const unsigned c = component(all, __builtin_ctz(all)); solve(c); emit(c); all &= ~c; }
+  }
+
   void order(std::vector<int> nodes) {
-    if (nodes.size() <= 2) { for (int v : nodes) out.push_back(v); return; }
+    if ((int)nodes.size() <= kExact) { std::sort(nodes.begin(), nodes.end()); order_exact(nodes); return; }
     const int tag = ++stamp;
     for (int v : nodes) mark[v] = tag;
     std::vector<int> comp = bfs(nodes[0], tag);
@@ -544,6 +595,11 @@ CholPlan* chol_plan_create(int n, const uint8_t* adj) {
   }
   if (getenv("THEIA_HIP_CREATE_TIMING")) {   // shape of the schedule
     fprintf(stderr, "theia_hip K3 plan: n = %d, %d tiles, %d levels, %lld factor tiles, %.1f MFLOP\n", n, nt, pl->nlev, best.ntiles, pl->flops * 1e-6);
+    if (getenv("THEIA_HIP_K3_DEBUG")) {
+      fprintf(stderr, "  degrees:"); for (int i = 0; i < nt; ++i) fprintf(stderr, " %d", deg[i]); fprintf(stderr, "\n  order (tile:level):");
+      for (int I = 0; I < nt; ++I) fprintf(stderr, " %d:%d", perm[I], best.level[I]); fprintf(stderr, "\n");
+      for (int i = 0; i < nt; ++i) { fprintf(stderr, "  nbr[%d]:", i); for (int j = 0; j < nt; ++j) if (i != j && adj[(size_t)i * nt + j]) fprintf(stderr, " %d", j); fprintf(stderr, "\n"); }
+    }
     for (int l = 0; l < pl->nlev; ++l)
       fprintf(stderr, "  level %d: potrf %d, trsm %d, update targets %d\n", l, pl->lev[l].npotrf, pl->lev[l].ntrsm, pl->lev[l].nupd);
   }
