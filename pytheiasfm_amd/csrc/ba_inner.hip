@@ -231,10 +231,18 @@ __global__ __launch_bounds__(256) void k_inner_views(InnerArgs A) {
 }
 
 // ------------------------------------------------------------------ shared intrinsics
+// grp_wgs workgroups per group (round 4; one workgroup walked all of a group's observations per LM pass: 7.7 ms per sweep
+// at C4 with eight groups of 375 000 observations).  Every workgroup of a group runs the SAME LM loop on the SAME sums: a pass
+// over the observations is dealt to the workgroups, each leaves its 67 partial sums in global memory, they meet at a
+// per-group arrival counter, and every one of them adds the partials in workgroup order -- identical bits everywhere, so the
+// control flow stays in step without any further exchange.  The workgroups of a group must be resident together: the
+// launch is cooperative (launch_inner_sweep), and falls back to one workgroup per group where that is not possible.
 __global__ __launch_bounds__(256) void k_inner_groups(InnerArgs A) {
   if (!*A.gate) return;
   __shared__ double red[4][68];
-  const int grp = blockIdx.x;
+  __shared__ double tot[68];
+  const int NB = A.grp_wgs > 1 ? A.grp_wgs : 1;
+  const int grp = blockIdx.x / NB, sub = blockIdx.x - grp * NB;
   if (grp >= A.P.ng_total || A.P.grp_red[grp] < 0) return;
   if (A.own_world > 1 && grp % A.own_world != A.own_rank) return;
   const unsigned free_mask = A.P.grp_free[grp];
@@ -245,11 +253,12 @@ __global__ __launch_bounds__(256) void k_inner_groups(InnerArgs A) {
   constexpr int K = THEIA_MAX_INTRINSICS;
   double x[K];
   for (int q = 0; q < K; ++q) x[q] = A.intr[(size_t)grp * K + q];
+  int pass = 0;   // barriers passed so far: the same number in every workgroup of the group
 
   auto accumulate = [&](const double* kk, const double* scale, bool want_jac, double* H, double* g, double* cost_out, bool* invalid) {
     double acc[67];
     for (int k = 0; k < 67; ++k) acc[k] = 0.0;
-    for (int i = beg + tid; i < end; i += 256) {
+    for (int i = beg + sub * 256 + tid; i < end; i += 256 * NB) {
       const ObsRef ob = load_obs(A, A.grp_obs_idx[i]);
       if (ob.depth_row) {   // a depth-prior row does not depend on the intrinsics: constant in this block's problem
         continue;
@@ -282,7 +291,30 @@ __global__ __launch_bounds__(256) void k_inner_groups(InnerArgs A) {
       if (lane == 0) red[wv][k] = v;
     }
     __syncthreads();
-    for (int k = 0; k < 67; ++k) acc[k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    if (NB > 1) {
+      double* part = A.grp_part + ((size_t)grp * 2 + (pass & 1)) * NB * kInnerGroupSums;
+      if (tid < 67) part[(size_t)sub * kInnerGroupSums + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_fetch_add(A.grp_bar + grp, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const int want = NB * (pass + 1);
+        while (__hip_atomic_load(A.grp_bar + grp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (tid < 67) {
+        double v = 0.0;
+        for (int w = 0; w < NB; ++w) v += __builtin_nontemporal_load(part + (size_t)w * kInnerGroupSums + tid);
+        tot[tid] = v;
+      }
+      ++pass;
+      __syncthreads();
+      for (int k = 0; k < 67; ++k) acc[k] = tot[k];
+      __syncthreads();
+    } else {
+      for (int k = 0; k < 67; ++k) acc[k] = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    }
     if (H) { for (int k = 0; k < 55; ++k) H[k] = acc[k]; for (int k = 0; k < K; ++k) g[k] = acc[55 + k]; }
     *cost_out = acc[65];
     *invalid = acc[66] > 0.0;
@@ -292,7 +324,7 @@ __global__ __launch_bounds__(256) void k_inner_groups(InnerArgs A) {
       [&](const double* xx, const double* scale, double* H, double* g, double* cost, bool* invalid) { accumulate(xx, scale, true, H, g, cost, invalid); },
       [&](const double* xc, bool* invalid) { double cst; accumulate(xc, nullptr, false, nullptr, nullptr, &cst, invalid); return cst; },
       [&](const double* xx, const double* step, double* xc) { for (int q = 0; q < K; ++q) xc[q] = ((free_mask >> q) & 1u) ? xx[q] + step[q] : xx[q]; });
-  if (tid == 0) for (int q = 0; q < K; ++q) A.intr[(size_t)grp * K + q] = x[q];
+  if (tid == 0 && sub == 0) for (int q = 0; q < K; ++q) A.intr[(size_t)grp * K + q] = x[q];
 }
 
 // ------------------------------------------------------------------ points
@@ -542,7 +574,23 @@ void launch_inner_sweep(const InnerArgs& A0, hipStream_t st, int stages) {   // 
   const InnerArgs A = normalised(A0);
   static const int skip = [] { const char* e = getenv("THEIA_HIP_INNER_SKIP"); return e ? atoi(e) : 0; }();   // development switch
   if (A.P.nc > 0 && (stages & 1) && !(skip & 1)) k_inner_views<<<(A.P.nc + 3) / 4, 256, 0, st>>>(A);
-  if (A.P.ni > 0 && A.P.ng_total > 0 && (stages & 2) && !(skip & 2)) k_inner_groups<<<A.P.ng_total, 256, 0, st>>>(A);
+  if (A.P.ni > 0 && A.P.ng_total > 0 && (stages & 2) && !(skip & 2)) {
+    // several workgroups per group need all of them resident at once: a cooperative launch guarantees that (or fails);
+    // not inside a stream capture, and one workgroup per group whenever it is refused
+    bool done = false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    static const bool single = getenv("THEIA_HIP_INNER_GROUPS_SINGLE") != nullptr;
+    if (A.grp_wgs > 1 && A.grp_part && A.grp_bar && cap == hipStreamCaptureStatusNone && !single) {
+      if (hipMemsetAsync(A.grp_bar, 0, sizeof(int) * (size_t)A.P.ng_total, st) == hipSuccess) {
+        InnerArgs Ac = A;
+        void* args[] = {&Ac};
+        const hipError_t e = hipLaunchCooperativeKernel((const void*)k_inner_groups, dim3((unsigned)(A.P.ng_total * A.grp_wgs)), dim3(256), args, 0, st);
+        if (e == hipSuccess) done = true; else (void)hipGetLastError();
+      }
+    }
+    if (!done) { InnerArgs A1 = A; A1.grp_wgs = 1; k_inner_groups<<<A.P.ng_total, 256, 0, st>>>(A1); }
+  }
   if (A.ntracks > 0 && (stages & 4) && !(skip & 4)) {
     const int nb = (A.ntracks + 63) / 64;
     if (A.P.camrot_cand && !getenv("THEIA_HIP_INNER_NO_ROT")) {   // fused path: per-camera blocks (free between the trial step and the next one)

@@ -1,5 +1,6 @@
 // ba_kernels.h -- launch interface of the BA device kernels (internal).
 #pragma once
+#include <algorithm>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
@@ -146,7 +147,13 @@ struct InnerArgs {
   const int* gate;              // device flag: 0 = return at once
   int has_si = 0, has_kind = 0;  // set by the launchers: P.obs_si / P.obs_kind are real (otherwise valid stand-ins)
   int own_rank = 0, own_world = 1;   // sharded inner iterations: this launch sweeps the cameras / groups with index % own_world == own_rank
+  // the intrinsics sweep with grp_wgs > 1 workgroups per group (co-resident: cooperative launch): per group and pass parity
+  // grp_wgs partial sums of kInnerGroupSums doubles in grp_part, arrival counters in grp_bar (zeroed before the launch)
+  double* grp_part = nullptr; int* grp_bar = nullptr; int grp_wgs = 1;
 };
+constexpr int kInnerGroupSums = 68;        // 55 (J'J, packed) + 10 (J'r) + cost + invalid count (+ 1 pad)
+constexpr int kInnerGroupMaxWgs = 32;
+inline int inner_group_wgs(int ng_total) { return std::max(1, std::min(kInnerGroupMaxWgs, 512 / std::max(1, ng_total))); }
 void launch_inner_sweep(const InnerArgs& A, hipStream_t st, int stages = 7);   // stages: 1 cameras, 2 intrinsics groups, 4 points
 // out[0] = |x0 - x|^2, out[1] = |x|^2 over the variable blocks
 void launch_inner_norms(const InnerArgs& A, const double* cam0, const double* pts0, const double* intr0, double* out2, double* part,

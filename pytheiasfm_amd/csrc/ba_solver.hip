@@ -152,7 +152,8 @@ struct theia_ba_handle_s {
   // inner iterations (ba_inner.hip): observation lists by camera / group / track, a third parameter buffer the sweep
   // works on, its scalars {step^2, |x|^2, cost, invalid}, the gate flag
   bool inner = false;
-  DevBuf<int> in_cam_off, in_cam_idx, in_grp_off, in_grp_idx, in_trk_off, in_gate;
+  DevBuf<int> in_cam_off, in_cam_idx, in_grp_off, in_grp_idx, in_trk_off, in_gate, in_grp_bar;
+  DevBuf<double> in_grp_part;   // partial sums of the intrinsics sweep, inner_group_wgs() workgroups per group
   DevBuf<double> in_cam, in_pts, in_intr, in_scal, in_part;
   // inner iterations of a SHARDED solve (theia_hip_ba_set_inner_global): every rank sweeps all cameras and intrinsics groups
   // over the FULL observation set (the same sums on every rank: no exchange of their results), its own tracks afterwards
@@ -1873,6 +1874,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
     AL(in_cam, (size_t)6 * std::max(1, h->nc)); AL(in_pts, (size_t)4 * std::max(1, h->np));
     AL(in_intr, (size_t)THEIA_MAX_INTRINSICS * std::max(1, h->ng));
     AL(in_scal, 8); AL(in_part, 2 * (size_t)kInnerCostBlocks); AL(in_gate, 4);
+    if (h->ni && inner_group_wgs(h->ng) > 1) { AL(in_grp_part, (size_t)h->ng * 2 * inner_group_wgs(h->ng) * kInnerGroupSums); AL(in_grp_bar, (size_t)std::max(1, h->ng)); }
   }
   if (p->obs_kind) {   // depth-prior rows (sorted like the other observation arrays)
     std::vector<uint8_t> okind(h->nobs);
@@ -2294,6 +2296,7 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
       IA.cam_obs_off = h->in_cam_off.p; IA.cam_obs_idx = h->in_cam_idx.p; IA.grp_obs_off = h->in_grp_off.p; IA.grp_obs_idx = h->in_grp_idx.p;
       IA.trk_off = h->in_trk_off.p; IA.ntracks = h->in_ntracks; IA.nobs = h->nobs_main;
       IA.cam = h->in_cam.p; IA.pts = h->in_pts.p; IA.intr = h->in_intr.p; IA.gate = h->in_gate.p;
+      IA.grp_part = h->in_grp_part.p; IA.grp_bar = h->in_grp_bar.p; IA.grp_wgs = h->in_grp_part.p ? inner_group_wgs(h->ng) : 1;
       if (h->allreduce && h->inner_global) {
         // the full candidate point set: every shard's points at their global indices, summed over the ranks
         HIP_TRY(hipMemsetAsync(h->g_pts.p, 0, sizeof(double) * 4 * (size_t)h->g_np, h->stream));

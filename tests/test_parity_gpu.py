@@ -79,42 +79,7 @@ def _random_rotation(rng, max_deg):
     return synth.angle_axis_to_matrix(ax * np.deg2rad(max_deg) * rng.uniform())
 
 
-def _five_point_numpy(x1, x2):
-    """All real essential matrices through five correspondences, with numpy only.
-    E = x E1 + y E2 + z E3 + E4 over the null space of the epipolar constraints (SVD); the ten cubic constraints
-    det E = 0, 2 E E^T E - tr(E E^T) E = 0 are fitted as polynomials in (x, y, z) by least squares on random
-    evaluation points; Gauss-Jordan on the cubic monomials leaves the multiplication-by-x matrix of the quotient ring,
-    whose eigenvectors carry the solutions."""
-    A = np.stack([np.outer(np.append(b, 1.0), np.append(a, 1.0)).ravel() for a, b in zip(x1, x2)])
-    N = np.linalg.svd(A)[2][5:].reshape(4, 3, 3)
-
-    def mono(v):
-        x, y, z = v
-        return np.array([x ** 3, x * x * y, x * y * y, y ** 3, x * x * z, x * y * z, y * y * z, x * z * z, y * z * z, z ** 3,
-                         x * x, x * y, y * y, x * z, y * z, z * z, x, y, z, 1.0])
-
-    def cons(v):
-        E = v[0] * N[0] + v[1] * N[1] + v[2] * N[2] + N[3]
-        EEt = E @ E.T
-        return np.append((2.0 * EEt @ E - np.trace(EEt) * E).ravel(), np.linalg.det(E))
-
-    rs = np.random.default_rng(12345)
-    P = rs.normal(size=(80, 3))
-    C = np.linalg.lstsq(np.stack([mono(v) for v in P]), np.stack([cons(v) for v in P]), rcond=None)[0].T   # 10 x 20
-    B = np.linalg.solve(C[:, :10], C[:, 10:])        # reduced system: cubic monomial k = - B[k] . basis
-    M = np.zeros((10, 10))
-    for row, k in enumerate((0, 1, 2, 4, 5, 7)):     # x * {x^2, xy, y^2, xz, yz, z^2} = x^3, x^2 y, x y^2, x^2 z, x y z, x z^2
-        M[row] = -B[k]
-    M[6, 0] = M[7, 1] = M[8, 3] = M[9, 6] = 1.0      # x * {x, y, z, 1} = x^2, xy, xz, x
-    w, V = np.linalg.eig(M)              # M b(x, y, z) = x b(x, y, z) at every solution: right eigenvectors
-    sols = []
-    for k in range(10):
-        if abs(w[k].imag) > 1e-9 * max(1.0, abs(w[k])):
-            continue
-        v = (V[6:9, k] / V[9, k]).real
-        E = v[0] * N[0] + v[1] * N[1] + v[2] * N[2] + N[3]
-        sols.append(E / np.linalg.norm(E))
-    return sols
+from tests.numpy_routes import five_point as _five_point_numpy   # noqa: E402  (moved: also the RANSAC replay of test_independent_routes_gpu.py)
 
 
 def _same_up_to_sign(A, B):
