@@ -21,8 +21,9 @@ def test_numpy_dls_route_finds_the_oracles_solutions():
         sols = nr.dls_pnp(feat, world, ransac.dls_macaulay_terms(k, 1)[0])
         # the generating pose is found by both
         truth = sc.quat_to_rot(qq)
-        assert min(np.abs(R - truth).max() for R, _ in sols) < 1e-3      # (a minimal sample can be ill-conditioned: DLS's own accuracy)
-        assert min(np.abs(sc.quat_to_rot(q) - truth).max() for q in qo) < 1e-3
+        tol = 1e-2 if n == 3 else 1e-6      # (a minimal sample can be ill-conditioned: the elimination's own accuracy)
+        assert min(np.abs(R - truth).max() for R, _ in sols) < tol
+        assert min(np.abs(sc.quat_to_rot(q) - truth).max() for q in qo) < tol
         total += 1
         same += len(sols) == len(qo) and all(min(np.abs(sc.quat_to_rot(q) - R).max() + np.abs(tt - tn).max() for R, tn in sols) < 1e-6
                                              for q, tt in zip(qo, to))
