@@ -21,7 +21,7 @@ def test_numpy_dls_route_finds_the_oracles_solutions():
         sols = nr.dls_pnp(feat, world, ransac.dls_macaulay_terms(k, 1)[0])
         # the generating pose is found by both
         truth = sc.quat_to_rot(qq)
-        tol = 1e-2 if n == 3 else 1e-6      # (a minimal sample can be ill-conditioned: the elimination's own accuracy)
+        tol = 1e-2 if n == 3 else 1e-4      # (a minimal sample can be ill-conditioned: the elimination's own accuracy)
         assert min(np.abs(R - truth).max() for R, _ in sols) < tol
         assert min(np.abs(sc.quat_to_rot(q) - truth).max() for q in qo) < tol
         total += 1
