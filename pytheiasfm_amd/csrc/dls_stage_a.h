@@ -20,7 +20,7 @@ struct WgLds {
     struct { double Dm[81]; double J[36]; double hinv[16]; double traw[36]; double f[60]; } fe;   // front end
     double U[kUStore];                                                                          // elimination
   };
-  double lbuf[2][96];    // factors of a step by parity; the back-substitution's solved row lives in lbuf[parity][0..31]
+  double lbuf[2][96];    // factors of a step by parity
   double diag[96];
   double T[27];
   double sf[9];          // gDLS: the scale factor row
@@ -175,18 +175,12 @@ __device__ __forceinline__ void lu_six(WgLds& L, double (&a)[3][20], int (&pos)[
   if (k + 6 <= kBlock) { lu_step<NL, true>(L, a, pos, k + 5, 5, g, rg, urow); urow += len; }
 }
 
-// back-substitution step: the lanes of the row pivoted at step k (row Q of row group prg) solve its five right-hand sides
+// back-substitution step: row Q of every lane times 1 / u_kk -- only the lanes of row group prg hold the row pivoted at
+// step k; the others compute along and their values are never read
 template <int Q>
-__device__ __forceinline__ void bs_solve_row(WgLds& L, const double (&a)[3][20], int par, int k, int g, double* __restrict__ Xn, int slot) {
-  if (Q == 0) asm volatile("; solved row = register row 0"); else if (Q == 1) asm volatile("; solved row = register row 1"); else asm volatile("; solved row = register row 2");
-  const double inv_ukk = L.diag[k];   // 1 / u_kk, inverted once when the pivot was found
+__device__ __forceinline__ void bs_scale_row(const double (&a)[3][20], double inv_ukk, double (&xq)[5]) {
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const double x = a[Q][i] * inv_ukk;
-    L.lbuf[par][6 * i + g] = x;
-    const int c = 6 * i + g - 3;
-    if (slot != 255 && c >= 0 && c < kReduced) Xn[slot * kReduced + c] = x;
-  }
+  for (int i = 0; i < 5; ++i) xq[i] = a[Q][i] * inv_ukk;
 }
 
 // points: feat[i * fstride + {0,1}], world[i * wstride + {0,1,2}] for i = index ? index[k] : k, k < npts.
@@ -348,22 +342,35 @@ __device__ __forceinline__ bool stage_a(WgLds& L, int npts, const double* __rest
   for (int o = 8; o < 12; ++o) lu_six<12>(L, a, pos, o, g, rg, urow);
   for (int o = 12; o < 16; ++o) lu_six<8>(L, a, pos, o, g, rg, urow);
   // ---- back-substitution, column oriented: register i < 5 of a row now holds right-hand side 6 (i + 15) + g - 93
+  // A right-hand side never leaves its column group: the 32 lanes of a half-wave hold its entries of all 96 rows, so every
+  // half-wave runs the whole substitution on its own five columns: nothing crosses a wave and there is no barrier in the loop
+  // (the pivot-row store is read-only here).
   double* Xn = action;   // the solved rows the result reads wait in the problem's own output slot
-  __syncthreads();       // the solved rows go through the factor buffer the last step may still be read from
+  __syncthreads();   // the factor buffer of the last elimination step becomes the hand-over buffer below
   int ucol[3];   // entry (pos[q], k) of the pivot-row store sits at ucol[q] + k
 #pragma unroll
   for (int q = 0; q < 3; ++q) ucol[q] = pos[q] < kBlock ? u_base(pos[q]) - 6 * (pos[q] / 6) : 0;
   for (int k = kBlock - 1; k >= 0; --k) {
-    const int par = k & 1;
     const int pr = __builtin_amdgcn_readfirstlane((int)L.prow_of[k]);
     const int prg = pr / 3, pq = pr - 3 * prg, slot = tb.xslot[k];
-    if (pq == 0) { if (rg == prg) bs_solve_row<0>(L, a, par, k, g, Xn, slot); }
-    else if (pq == 1) { if (rg == prg) bs_solve_row<1>(L, a, par, k, g, Xn, slot); }
-    else { if (rg == prg) bs_solve_row<2>(L, a, par, k, g, Xn, slot); }
-    __syncthreads();
-    double x[5];
+    const double inv_ukk = L.diag[k];   // 1 / u_kk, inverted once when the pivot was found
+    double xq[5], x[5];
+    if (pq == 0) bs_scale_row<0>(a, inv_ukk, xq); else if (pq == 1) bs_scale_row<1>(a, inv_ukk, xq); else bs_scale_row<2>(a, inv_ukk, xq);
+    // the lane of row group prg hands its five values to the rest of its half-wave through LDS: writer and readers are
+    // lanes of one wave (LDS operations of a wave complete in order), so a wavefront fence is all the ordering it takes
+    double* xb = &L.lbuf[0][8 * g];
+    if (rg == prg) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) x[i] = L.lbuf[par][6 * i + g];
+      for (int i = 0; i < 5; ++i) xb[i] = xq[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int i = 0; i < 5; ++i) x[i] = xb[i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (rg == prg && slot != 255) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) { const int c = 6 * i + g - 3; if (c >= 0 && c < kReduced) Xn[slot * kReduced + c] = x[i]; }
+    }
 #pragma unroll
     for (int q = 0; q < 3; ++q)
       if (pos[q] < k) {
