@@ -153,7 +153,7 @@ struct InnerArgs {
 };
 constexpr int kInnerGroupSums = 68;        // 55 (J'J, packed) + 10 (J'r) + cost + invalid count (+ 1 pad)
 constexpr int kInnerGroupMaxWgs = 32;
-inline int inner_group_wgs(int ng_total) { return std::max(1, std::min(kInnerGroupMaxWgs, 512 / std::max(1, ng_total))); }
+inline int inner_group_wgs(int ng_total) { return std::max(1, std::min(kInnerGroupMaxWgs, 256 / std::max(1, ng_total))); }   // <= 256 co-resident workgroups (one per CU at this kernel's register count: 512 were refused)
 void launch_inner_sweep(const InnerArgs& A, hipStream_t st, int stages = 7);   // stages: 1 cameras, 2 intrinsics groups, 4 points
 // out[0] = |x0 - x|^2, out[1] = |x|^2 over the variable blocks
 void launch_inner_norms(const InnerArgs& A, const double* cam0, const double* pts0, const double* intr0, double* out2, double* part,

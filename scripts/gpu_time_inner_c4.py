@@ -1,4 +1,5 @@
-"""GPU box: LM iteration time at C4 with the reference's default use_inner_iterations = true."""
+"""GPU box: LM iteration time at C4 with the reference's default use_inner_iterations = true; argument: intrinsics_to_optimize mask
+(0x11 = FOCAL_LENGTH | RADIAL_DISTORTION: the pipelines' default)."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,6 +8,8 @@ p = synth.ba_config("C4")
 o = ba.default_options(); o.max_num_iterations = 8
 o.function_tolerance = o.gradient_tolerance = o.parameter_tolerance = 0.0
 o.use_inner_iterations = 1
+if len(sys.argv) > 1:
+    o.intrinsics_to_optimize = int(sys.argv[1], 0)
 h = ba.BaHandle(p.copy(), o)
 h.reset(p); h.snapshot(); h.restore(); h.run(trace_capacity=1)
 torch.cuda.synchronize(); t0 = time.perf_counter()
