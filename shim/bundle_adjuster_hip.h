@@ -65,6 +65,12 @@ class BundleAdjuster {
   void SetTrackVariable(TrackId track);            // :529-536
 
   BundleAdjustmentSummary Optimize();              // :315-355
+  // GetCovarianceForTracks (:705-741) after Optimize() with every camera constant: covariance[i] is the 3 x 3 tangent-space
+  // block of tracks[i] (row-major; SphereManifold<4>), as ceres::Covariance returns it.  NOT multiplied by the empirical
+  // variance factor (bundle_adjustment.cc:312-320 does that bookkeeping).  False + error() on failure.
+  bool GetCovarianceForTracks(const std::vector<TrackId>& tracks, std::vector<std::vector<double>>* covariances);
+  // GetCovarianceForViews (:743-773) with every track constant: the 6 x 6 block of each view's extrinsics.
+  bool GetCovarianceForViews(const std::vector<ViewId>& views, std::vector<std::vector<double>>* covariances);
   const std::string& error() const { return error_; }
 
  private:
@@ -77,7 +83,19 @@ class BundleAdjuster {
   std::vector<uint8_t> cam_const_, point_const_;
   std::vector<double> obs_uv_, obs_sqrt_info_;
   std::string error_;
+  bool covariances(std::vector<double>* point_cov, std::vector<double>* cam_cov);
 };
+
+// bundle_adjustment.cc:220-260 / :262-285: N x BundleAdjustView (one camera against constant points) and BundleAdjustTrack for
+// every track of a flat problem, each as ONE device launch (theia_hip_ba_views_batch / theia_hip_ba_tracks_batch).
+struct ViewProblem {                     // one BundleAdjustView call
+  double* extrinsics;                    // [6] in / out
+  const double* intrinsics; int num_intrinsics; int camera_model;
+  std::vector<double> features;          // [n][2] pixels
+  std::vector<double> points;            // [n][4] the tracks' homogeneous points (constant)
+};
+bool BundleAdjustViews(const BundleAdjustmentOptions& options, std::vector<ViewProblem>* views,
+                       std::vector<BundleAdjustmentSummary>* summaries, std::string* error);
 
 // SampleConsensusEstimator front ends (sfm/estimators/estimate_relative_pose.h:49-70, estimate_calibrated_absolute_pose.h):
 // one call per image pair list, all pairs as one device batch.
@@ -95,6 +113,37 @@ struct RelativePose { double essential_matrix[9], rotation[9], position[3]; };
 bool EstimateRelativePoseBatch(const RansacParameters& params, const std::vector<std::vector<double>>& correspondences,
                                std::vector<bool>* success, std::vector<RelativePose>* poses, std::vector<RansacSummary>* summaries,
                                std::string* error);
+
+
+// Every other SampleConsensusEstimator front end of sfm/estimators/ goes through one routine: `estimator` = THEIA_EST_*,
+// data[p] = the flattened data of problem p (datum layouts: include/theia_hip.h), models[p] = THEIA_RANSAC_MODEL_STRIDE
+// doubles in the layout of that estimator.  ransac_type = THEIA_RANSAC_* (create_and_initialize_ransac_variant.h:52).
+struct EstimatorBatchResult {
+  std::vector<bool> success;
+  std::vector<std::vector<double>> models;
+  std::vector<RansacSummary> summaries;
+};
+bool EstimateBatch(int estimator, int ransac_type, const RansacParameters& params, const std::vector<std::vector<double>>& data,
+                   const double* estimator_params, EstimatorBatchResult* result, std::string* error);
+
+// The reference's names over it (one call = all problems as one device batch).  correspondences: [x1 y1 x2 y2] x n;
+// correspondences_2d_3d: [u v X Y Z] x n.
+enum class PnPType { KNEIP = 0, DLS = 1, SQPnP = 2 };            // estimate_calibrated_absolute_pose.h:52
+struct CalibratedAbsolutePose { double rotation[9], position[3]; };
+bool EstimateCalibratedAbsolutePoseBatch(const RansacParameters& params, int ransac_type, PnPType pnp_type,
+                                         const std::vector<std::vector<double>>& correspondences_2d_3d, std::vector<bool>* success,
+                                         std::vector<CalibratedAbsolutePose>* poses, std::vector<RansacSummary>* summaries, std::string* error);
+inline bool EstimateEssentialMatrixBatch(const RansacParameters& p, int t, const std::vector<std::vector<double>>& c, EstimatorBatchResult* r, std::string* e) { return EstimateBatch(THEIA_EST_ESSENTIAL_MATRIX, t, p, c, nullptr, r, e); }
+inline bool EstimateFundamentalMatrixBatch(const RansacParameters& p, int t, const std::vector<std::vector<double>>& c, EstimatorBatchResult* r, std::string* e) { return EstimateBatch(THEIA_EST_FUNDAMENTAL_MATRIX, t, p, c, nullptr, r, e); }
+inline bool EstimateHomographyBatch(const RansacParameters& p, int t, const std::vector<std::vector<double>>& c, EstimatorBatchResult* r, std::string* e) { return EstimateBatch(THEIA_EST_HOMOGRAPHY, t, p, c, nullptr, r, e); }
+inline bool EstimateDominantPlaneFromPointsBatch(const RansacParameters& p, int t, const std::vector<std::vector<double>>& pts, EstimatorBatchResult* r, std::string* e) { return EstimateBatch(THEIA_EST_DOMINANT_PLANE, t, p, pts, nullptr, r, e); }
+inline bool EstimateRelativePoseWithKnownOrientationBatch(const RansacParameters& p, int t, const std::vector<std::vector<double>>& c, EstimatorBatchResult* r, std::string* e) { return EstimateBatch(THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION, t, p, c, nullptr, r, e); }
+inline bool EstimateAbsolutePoseWithKnownOrientationBatch(const RansacParameters& p, int t, const std::vector<std::vector<double>>& c, EstimatorBatchResult* r, std::string* e) { return EstimateBatch(THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION, t, p, c, nullptr, r, e); }
+inline bool EstimateUncalibratedRelativePoseBatch(const RansacParameters& p, int t, const double min_max_focal_length[2], const std::vector<std::vector<double>>& c, EstimatorBatchResult* r, std::string* e) { return EstimateBatch(THEIA_EST_UNCALIBRATED_RELATIVE_POSE, t, p, c, min_max_focal_length, r, e); }
+inline bool EstimateUncalibratedAbsolutePoseBatch(const RansacParameters& p, int t, const std::vector<std::vector<double>>& c, EstimatorBatchResult* r, std::string* e) { return EstimateBatch(THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE, t, p, c, nullptr, r, e); }
+inline bool EstimateTriangulationBatch(const RansacParameters& p, int t, const std::vector<std::vector<double>>& obs33, EstimatorBatchResult* r, std::string* e) { return EstimateBatch(THEIA_EST_TRIANGULATION, t, p, obs33, nullptr, r, e); }
+inline bool EstimateRadialHomographyMatrixBatch(const RansacParameters& p, int t, const std::vector<std::vector<double>>& c12, EstimatorBatchResult* r, std::string* e) { return EstimateBatch(THEIA_EST_RADIAL_HOMOGRAPHY, t, p, c12, nullptr, r, e); }
+inline bool EstimateSimilarityTransformation2D3DBatch(const RansacParameters& p, int t, const std::vector<std::vector<double>>& c26, EstimatorBatchResult* r, std::string* e) { return EstimateBatch(THEIA_EST_SIMILARITY_2D3D, t, p, c26, nullptr, r, e); }
 
 }  // namespace theia_hip_shim
 #endif

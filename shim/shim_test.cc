@@ -1,5 +1,6 @@
 // Exercises the C++ shim end to end on the device: a synthetic pinhole scene built with plain C++ (no Theia types),
-// perturbed, adjusted through BundleAdjuster::Optimize(); then a batch of relative-pose RANSAC problems.
+// perturbed, adjusted through BundleAdjuster::Optimize(); then batches of relative-pose, absolute-pose (KNEIP / DLS / SQPnP) and
+// fundamental-matrix RANSAC problems, BundleAdjustView for every camera as one launch, and track covariances.
 // Prints one "ok" line per check and exits non-zero on failure (tests/test_shim_gpu.py runs it).
 #include <cmath>
 #include <cstdio>
@@ -104,5 +105,111 @@ int main() {
     if (!ok[p] || sums[p].inliers.size() < 250 || !(ang < 1.0)) { std::printf("FAIL: relative pose\n"); return 1; }
   }
   std::printf("ok relative pose batch\n");
+
+  // ---- calibrated absolute pose, the three PnP types, 5 problems each as one batch; the same data through the
+  // fundamental-matrix / homography front ends of the generic routine would be meaningless, so those get their own data
+  {
+    std::vector<std::vector<double>> c23(5);
+    std::vector<std::vector<double>> wtrue(5), ctrue(5);
+    for (int p = 0; p < 5; ++p) {
+      const double w[3] = {0.2 * U(gen), 0.2 * U(gen), 0.2 * U(gen)};
+      const double c[3] = {U(gen), U(gen), -6.0 + U(gen)};
+      wtrue[p] = {w[0], w[1], w[2]}; ctrue[p] = {c[0], c[1], c[2]};
+      for (int i = 0; i < 300; ++i) {
+        const double X[3] = {2 * U(gen), 2 * U(gen), 2 * U(gen)};
+        const double d[3] = {X[0] - c[0], X[1] - c[1], X[2] - c[2]};
+        double q[3];
+        rotate(w, d, q);
+        double u = q[0] / q[2] + 5e-4 * N(gen), v = q[1] / q[2] + 5e-4 * N(gen);
+        if (i % 5 == 0) { u = U(gen); v = U(gen); }   // 20 % outliers
+        c23[p].insert(c23[p].end(), {u, v, X[0], X[1], X[2]});
+      }
+    }
+    RansacParameters ap;
+    ap.error_thresh = 3e-3 * 3e-3; ap.min_iterations = 100; ap.max_iterations = 1000; ap.seed = 11;
+    const PnPType types[3] = {PnPType::KNEIP, PnPType::DLS, PnPType::SQPnP};
+    const char* names[3] = {"KNEIP", "DLS", "SQPnP"};
+    for (int k = 0; k < 3; ++k) {
+      std::vector<bool> aok; std::vector<CalibratedAbsolutePose> ap_out; std::vector<RansacSummary> asum; std::string aerr;
+      if (!EstimateCalibratedAbsolutePoseBatch(ap, THEIA_RANSAC_RANSAC, types[k], c23, &aok, &ap_out, &asum, &aerr)) { std::printf("FAIL: %s\n", aerr.c_str()); return 1; }
+      for (int p = 0; p < 5; ++p) {
+        double perr = 0.0;
+        for (int i = 0; i < 3; ++i) perr = std::fmax(perr, std::fabs(ap_out[p].position[i] - ctrue[p][i]));
+        std::printf("absolute pose %s %d: success %d, %zu inliers of 300, position error %.2e\n", names[k], p, (int)aok[p], asum[p].inliers.size(), perr);
+        // (SQPnP answers a minimal sample with ONE SQP iteration, sqpnp.cc:33-34: approximate models, fewer inliers)
+        const bool sq = types[k] == PnPType::SQPnP;
+        if (!aok[p] || asum[p].inliers.size() < (sq ? 120u : 200u) || !(perr < (sq ? 0.15 : 0.05))) { std::printf("FAIL: absolute pose %s\n", names[k]); return 1; }
+      }
+    }
+    std::printf("ok calibrated absolute pose batches\n");
+  }
+  // ---- the generic front end under the reference's other names: fundamental matrix on the relative-pose pairs (pixels)
+  {
+    std::vector<std::vector<double>> px = corr;
+    for (auto& c : px) for (double& x : c) x = 800.0 * x;   // pixels, principal point removed
+    RansacParameters fp;
+    fp.error_thresh = 2.0 * 2.0; fp.min_iterations = 200; fp.max_iterations = 2000; fp.seed = 3;
+    EstimatorBatchResult fr; std::string ferr;
+    if (!EstimateFundamentalMatrixBatch(fp, THEIA_RANSAC_RANSAC, px, &fr, &ferr)) { std::printf("FAIL: %s\n", ferr.c_str()); return 1; }
+    for (int p = 0; p < 6; ++p) {
+      std::printf("fundamental matrix %d: success %d, %zu inliers of 400\n", p, (int)fr.success[p], fr.summaries[p].inliers.size());
+      if (!fr.success[p] || fr.summaries[p].inliers.size() < 250) { std::printf("FAIL: fundamental matrix\n"); return 1; }
+    }
+    std::printf("ok fundamental matrix batch\n");
+  }
+  // ---- BundleAdjustView for every camera as one launch: perturbed cameras against the (now adjusted) points
+  {
+    std::vector<double> cam2 = cam;
+    std::vector<ViewProblem> vp(nv);
+    for (int v = 0; v < nv; ++v) {
+      vp[v].extrinsics = &cam2[6 * v]; vp[v].intrinsics = intr; vp[v].num_intrinsics = 7; vp[v].camera_model = THEIA_CAM_PINHOLE;
+      for (int t = 0; t < nt; ++t) {
+        const double* e = &cam[6 * v];
+        const double d[3] = {pts[4 * t] / pts[4 * t + 3] - e[0], pts[4 * t + 1] / pts[4 * t + 3] - e[1], pts[4 * t + 2] / pts[4 * t + 3] - e[2]};
+        double q[3];
+        rotate(e + 3, d, q);
+        if (q[2] <= 0.1) continue;
+        vp[v].features.insert(vp[v].features.end(), {intr[0] * q[0] / q[2] + intr[3], intr[0] * intr[1] * q[1] / q[2] + intr[4]});
+        vp[v].points.insert(vp[v].points.end(), {pts[4 * t], pts[4 * t + 1], pts[4 * t + 2], pts[4 * t + 3]});
+      }
+      for (int q = 0; q < 6; ++q) cam2[6 * v + q] += (q < 3 ? 0.03 : 0.005) * N(gen);
+    }
+    BundleAdjustmentOptions vo; vo.max_num_iterations = 30;
+    std::vector<BundleAdjustmentSummary> vs; std::string verr;
+    if (!BundleAdjustViews(vo, &vp, &vs, &verr)) { std::printf("FAIL: %s\n", verr.c_str()); return 1; }
+    double worst = 0.0;
+    for (int v = 0; v < nv; ++v) for (int q = 0; q < 6; ++q) worst = std::fmax(worst, std::fabs(cam2[6 * v + q] - cam[6 * v + q]));
+    std::printf("BundleAdjustViews: %d views, largest distance from the generating camera %.2e\n", nv, worst);
+    if (!(worst < 1e-6)) { std::printf("FAIL: BundleAdjustViews\n"); return 1; }
+    std::printf("ok view batch\n");
+  }
+  // ---- GetCovarianceForTracks: every camera constant (BundleAdjustTracksWithCov, bundle_adjustment.cc:420-460)
+  {
+    BundleAdjustmentOptions co; co.max_num_iterations = 5;
+    BundleAdjuster cb(co);
+    cb.AddIntrinsicsGroup(0, THEIA_CAM_PINHOLE, intr, 7);
+    for (int v = 0; v < nv; ++v) { cb.AddCamera(v, &cam[6 * v], 0); }
+    for (int t = 0; t < 50; ++t) cb.AddTrack(t, &pts[4 * t]);
+    const double cov1[2] = {1.0, 1.0};
+    for (int t = 0; t < 50; ++t)
+      for (int v = 0; v < nv; ++v) {
+        const double* e = &cam[6 * v];
+        const double d[3] = {pts[4 * t] / pts[4 * t + 3] - e[0], pts[4 * t + 1] / pts[4 * t + 3] - e[1], pts[4 * t + 2] / pts[4 * t + 3] - e[2]};
+        double q[3];
+        rotate(e + 3, d, q);
+        if (q[2] <= 0.1) continue;
+        const double uv[2] = {intr[0] * q[0] / q[2] + intr[3], intr[0] * intr[1] * q[1] / q[2] + intr[4]};
+        cb.AddObservation(v, t, uv, cov1);
+      }
+    for (int v = 0; v < nv; ++v) cb.SetCameraExtrinsicsConstant(v);
+    std::vector<std::vector<double>> covs;
+    if (!cb.GetCovarianceForTracks({0, 7, 49}, &covs)) { std::printf("FAIL: %s\n", cb.error().c_str()); return 1; }
+    for (const auto& c : covs) {
+      const bool sym = std::fabs(c[1] - c[3]) < 1e-12 * std::fabs(c[0]) + 1e-30 && std::fabs(c[2] - c[6]) < 1e-12 * std::fabs(c[0]) + 1e-30;
+      std::printf("track covariance diag %.3e %.3e %.3e\n", c[0], c[4], c[8]);
+      if (c.size() != 9 || !(c[0] > 0 && c[4] > 0 && c[8] > 0) || !sym) { std::printf("FAIL: covariance\n"); return 1; }
+    }
+    std::printf("ok track covariances\n");
+  }
   return 0;
 }

@@ -25,4 +25,6 @@ def test_shim_runs_bundle_adjustment_and_ransac_on_the_device():
     _build()
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "ok bundle adjustment" in r.stdout and "ok relative pose batch" in r.stdout
+    for line in ("ok bundle adjustment", "ok relative pose batch", "ok calibrated absolute pose batches", "ok fundamental matrix batch",
+                 "ok view batch", "ok track covariances"):
+        assert line in r.stdout, r.stdout
