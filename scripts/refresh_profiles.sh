@@ -32,6 +32,13 @@ bash "$R/scripts/prof_intr.sh" refresh/intr 8 > "$OUT/intr_summary.txt" 2>&1
 cp "$R/gpurun_out/refresh/intr/kernel_stats.csv" "$OUT/intr_kernel_stats.csv" 2>/dev/null
 bash "$R/scripts/pmc_kernel.sh" "FETCH_SIZE" scripts/gpu_time_intr_c4.py 8 > "$OUT/intr_pmc_fetch_size.txt" 2>&1
 bash "$R/scripts/pmc_kernel.sh" "WRITE_SIZE" scripts/gpu_time_intr_c4.py 8 > "$OUT/intr_pmc_write_size.txt" 2>&1
+# DLS leg at the C5 shape: kernel trace + the SQ counter passes of stage A / stage B (250 pairs)
+bash "$R/scripts/prof_ransac_leg.sh" dls 1000 > "$OUT/dls_summary.txt" 2>&1
+cp "$R/gpurun_out/dls_prof/kernel_stats.csv" "$OUT/dls_kernel_stats.csv" 2>/dev/null
+bash "$R/scripts/pmc_sq_ransac.sh" dls 250 > "$OUT/sq_dls.txt" 2>&1
+# the pipelines' default configuration (FOCAL | RADIAL free + inner iterations) at C4: kernel trace
+bash "$R/scripts/prof_script.sh" default_prof scripts/gpu_time_inner_c4.py 0x11 > "$OUT/default_summary.txt" 2>&1
+cp "$R/gpurun_out/default_prof/kernel_stats.csv" "$OUT/default_kernel_stats.csv" 2>/dev/null
 # what the counters were collected on: hashes of the kernel sources (bench.py compares them with the tree it runs in)
 python - "$R" > "$OUT/collected_at.json" <<'PY'
 import hashlib, json, os, sys
