@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256) void k_inner_groups(InnerArgs A) {
   double x[K];
   for (int q = 0; q < K; ++q) x[q] = A.intr[(size_t)grp * K + q];
   int pass = 0;   // barriers passed so far: the same number in every workgroup of the group
+  bool aborted = false;   // a partner workgroup did not arrive (see the arrival loop): leave without a result
 
   auto accumulate = [&](const double* kk, const double* scale, bool want_jac, double* H, double* g, double* cost_out, bool* invalid) {
     double acc[67];
@@ -299,13 +300,27 @@ __global__ __launch_bounds__(256) void k_inner_groups(InnerArgs A) {
       if (tid == 0) {
         __hip_atomic_fetch_add(A.grp_bar + grp, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         const int want = NB * (pass + 1);
-        while (__hip_atomic_load(A.grp_bar + grp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
+        int* abort_flag = A.grp_bar + A.P.ng_total;
+        int polls = 0, gone = 0;
+        while (__hip_atomic_load(A.grp_bar + grp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          // a partner that never arrives (its workgroup is not resident: two such launches of different processes can split
+          // the CUs between them) must not hang the device: after ~0.1 s every workgroup leaves, nothing is written, and the
+          // one-workgroup-per-group launch that always follows redoes the groups that are not marked done
+          if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || ++polls > A.grp_max_polls) {
+            __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gone = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        red[0][67] = gone ? 1.0 : 0.0;
       }
       __syncthreads();
+      if (red[0][67] != 0.0) { aborted = true; }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       if (tid < 67) {
         double v = 0.0;
-        for (int w = 0; w < NB; ++w) v += __builtin_nontemporal_load(part + (size_t)w * kInnerGroupSums + tid);
+        if (!aborted) for (int w = 0; w < NB; ++w) v += __builtin_nontemporal_load(part + (size_t)w * kInnerGroupSums + tid);
         tot[tid] = v;
       }
       ++pass;
@@ -319,12 +334,24 @@ __global__ __launch_bounds__(256) void k_inner_groups(InnerArgs A) {
     *cost_out = acc[65];
     *invalid = acc[66] > 0.0;
   };
+  if (NB == 1 && A.grp_bar && A.grp_bar[A.P.ng_total + 1 + grp]) return;   // the follow-up launch: this group is done
   block_lm<K, K>(
       x,
-      [&](const double* xx, const double* scale, double* H, double* g, double* cost, bool* invalid) { accumulate(xx, scale, true, H, g, cost, invalid); },
-      [&](const double* xc, bool* invalid) { double cst; accumulate(xc, nullptr, false, nullptr, nullptr, &cst, invalid); return cst; },
+      [&](const double* xx, const double* scale, double* H, double* g, double* cost, bool* invalid) {
+        if (aborted) { for (int k = 0; k < 55; ++k) H[k] = 0.0; for (int k = 0; k < K; ++k) g[k] = 0.0; *cost = 0.0; *invalid = true; return; }
+        accumulate(xx, scale, true, H, g, cost, invalid);
+        if (aborted) *invalid = true; },
+      [&](const double* xc, bool* invalid) {
+        if (aborted) { *invalid = true; return 0.0; }
+        double cst; accumulate(xc, nullptr, false, nullptr, nullptr, &cst, invalid);
+        if (aborted) *invalid = true;
+        return cst; },
       [&](const double* xx, const double* step, double* xc) { for (int q = 0; q < K; ++q) xc[q] = ((free_mask >> q) & 1u) ? xx[q] + step[q] : xx[q]; });
-  if (tid == 0 && sub == 0) for (int q = 0; q < K; ++q) A.intr[(size_t)grp * K + q] = x[q];
+  if (aborted) return;
+  if (tid == 0 && sub == 0) {
+    for (int q = 0; q < K; ++q) A.intr[(size_t)grp * K + q] = x[q];
+    if (A.grp_bar) A.grp_bar[A.P.ng_total + 1 + grp] = 1;
+  }
 }
 
 // ------------------------------------------------------------------ points
@@ -582,14 +609,20 @@ void launch_inner_sweep(const InnerArgs& A0, hipStream_t st, int stages) {   // 
     (void)hipStreamIsCapturing(st, &cap);
     static const bool single = getenv("THEIA_HIP_INNER_GROUPS_SINGLE") != nullptr;
     if (A.grp_wgs > 1 && A.grp_part && A.grp_bar && cap == hipStreamCaptureStatusNone && !single) {
-      if (hipMemsetAsync(A.grp_bar, 0, sizeof(int) * (size_t)A.P.ng_total, st) == hipSuccess) {
+      if (hipMemsetAsync(A.grp_bar, 0, sizeof(int) * (2 * (size_t)A.P.ng_total + 2), st) == hipSuccess) {
         InnerArgs Ac = A;
+        // (development / test switch: THEIA_HIP_INNER_GROUPS_MAX_POLLS=0 makes the first waiting workgroup give up at once,
+        // which exercises the give-up-and-redo path of the follow-up launch)
+        static const int max_polls = [] { const char* e = getenv("THEIA_HIP_INNER_GROUPS_MAX_POLLS"); return e ? atoi(e) : 200000; }();
+        Ac.grp_max_polls = max_polls;
         void* args[] = {&Ac};
         const hipError_t e = hipLaunchCooperativeKernel((const void*)k_inner_groups, dim3((unsigned)(A.P.ng_total * A.grp_wgs)), dim3(256), args, 0, st);
         if (e == hipSuccess) done = true; else (void)hipGetLastError();
       }
     }
-    if (!done) { InnerArgs A1 = A; A1.grp_wgs = 1; k_inner_groups<<<A.P.ng_total, 256, 0, st>>>(A1); }
+    // one workgroup per group: the whole sweep when the cooperative launch was not possible, otherwise the safety net that
+    // returns at once for every group the cooperative launch marked done (all of them, unless it had to give up)
+    { InnerArgs A1 = A; A1.grp_wgs = 1; if (!done) A1.grp_bar = nullptr; k_inner_groups<<<A.P.ng_total, 256, 0, st>>>(A1); }
   }
   if (A.ntracks > 0 && (stages & 4) && !(skip & 4)) {
     const int nb = (A.ntracks + 63) / 64;

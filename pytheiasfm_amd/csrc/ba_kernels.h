@@ -148,8 +148,8 @@ struct InnerArgs {
   int has_si = 0, has_kind = 0;  // set by the launchers: P.obs_si / P.obs_kind are real (otherwise valid stand-ins)
   int own_rank = 0, own_world = 1;   // sharded inner iterations: this launch sweeps the cameras / groups with index % own_world == own_rank
   // the intrinsics sweep with grp_wgs > 1 workgroups per group (co-resident: cooperative launch): per group and pass parity
-  // grp_wgs partial sums of kInnerGroupSums doubles in grp_part, arrival counters in grp_bar (zeroed before the launch)
-  double* grp_part = nullptr; int* grp_bar = nullptr; int grp_wgs = 1;
+  // grp_wgs partial sums of kInnerGroupSums doubles in grp_part, arrival counters in grp_bar ([ng] counters | abort flag | [ng] done flags | pad, zeroed before the launch)
+  double* grp_part = nullptr; int* grp_bar = nullptr; int grp_wgs = 1; int grp_max_polls = 200000;
 };
 constexpr int kInnerGroupSums = 68;        // 55 (J'J, packed) + 10 (J'r) + cost + invalid count (+ 1 pad)
 constexpr int kInnerGroupMaxWgs = 32;

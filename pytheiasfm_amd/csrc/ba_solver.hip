@@ -1874,7 +1874,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
     AL(in_cam, (size_t)6 * std::max(1, h->nc)); AL(in_pts, (size_t)4 * std::max(1, h->np));
     AL(in_intr, (size_t)THEIA_MAX_INTRINSICS * std::max(1, h->ng));
     AL(in_scal, 8); AL(in_part, 2 * (size_t)kInnerCostBlocks); AL(in_gate, 4);
-    if (h->ni && inner_group_wgs(h->ng) > 1) { AL(in_grp_part, (size_t)h->ng * 2 * inner_group_wgs(h->ng) * kInnerGroupSums); AL(in_grp_bar, (size_t)std::max(1, h->ng)); }
+    if (h->ni && inner_group_wgs(h->ng) > 1) { AL(in_grp_part, (size_t)h->ng * 2 * inner_group_wgs(h->ng) * kInnerGroupSums); AL(in_grp_bar, 2 * (size_t)std::max(1, h->ng) + 2); }
   }
   if (p->obs_kind) {   // depth-prior rows (sorted like the other observation arrays)
     std::vector<uint8_t> okind(h->nobs);

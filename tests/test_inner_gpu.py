@@ -97,3 +97,19 @@ def test_forward_facing_option_is_the_same_reduced_system():
         out.append((s, rec))
     assert out[0][0].success and out[1][0].success and out[0][0].final_cost == out[1][0].final_cost
     assert np.array_equal(out[0][1].cam_ext, out[1][1].cam_ext)
+
+
+def test_group_sweep_gives_up_and_redoes_when_its_workgroups_cannot_meet():
+    """The shared-intrinsics sweep runs on several co-resident workgroups per group that meet at arrival counters
+    (k_inner_groups).  If partners never arrive -- two such launches of different processes could split the CUs -- every
+    workgroup leaves after a bounded number of polls and the one-workgroup launch that always follows redoes the groups
+    that are not marked done.  THEIA_HIP_INNER_GROUPS_MAX_POLLS=0 forces that path (the switch is read once per process,
+    hence the subprocess): the intrinsics cases must still follow the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, THEIA_HIP_INNER_GROUPS_MAX_POLLS="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(root, "tests", "test_inner_gpu.py"),
+                        "-k", "intrinsics and follow_the_oracle"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
