@@ -1,6 +1,7 @@
 // ba_kernels.h -- launch interface of the BA device kernels (internal).
 #pragma once
 #include <algorithm>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
@@ -202,7 +203,7 @@ void launch_cam_priors(const DevProblem& P, int mode, const double* cam, const d
 // (= launch_reduce_tiles cfg 0), saving that launch; only when no all-reduce sits between the two.
 void launch_finalize_rcs(const DevProblem& P, const double* radius /* device */, const ReduceBuf& rb, hipStream_t st,
                          int ntiles = 0, const double* tile_part = nullptr, const int* f2s = nullptr,
-                         const int* fmaxflag = nullptr);
+                         const int* fmaxflag = nullptr, const uint8_t* tile_cls = nullptr, int want_cls = 0);
 void launch_cam_update(const DevProblem& P, const double* cam, const double* y, double* cand_cam,
                        double* cand_intr, double* out_stepsq, double* out_xnormsq, hipStream_t st, double* zero16 = nullptr);
 void launch_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,
@@ -234,6 +235,11 @@ void dense_cholesky_solve(int n, double* A, int lda, double* b, double* work, do
 // solve; falls back to the dense schedule when the structure offers nothing.
 struct CholPlan;
 CholPlan* chol_plan_create(int n, const uint8_t* adj);
+// a rank's plan of a sharded solve (sparse_cholesky.hip): its private tile columns first, the shared ones above them
+CholPlan* chol_plan_create_sharded(int n, const uint8_t* adj, const uint8_t* tile_class);
+void chol_plan_solve_phase(const CholPlan* plan, int phase, double* A, int lda, double* b, double* work, double* fail_flag, hipStream_t st);
+int chol_plan_split_level(const CholPlan* plan);
+const std::vector<int>& chol_plan_shared_tiles(const CholPlan* plan);
 void chol_plan_destroy(CholPlan* plan);
 // zero the tiles of A the plan's assembly / factorisation touch; false = dense plan (the caller clears everything)
 // tail / tail_count: a vector of doubles to zero in the same launch (null / 0: none)

@@ -850,14 +850,16 @@ __global__ __launch_bounds__(256) void k_reduce_tiles_stage1(int ntiles, const d
 __global__ __launch_bounds__(1024) void k_finalize_rcs(DevProblem P, const double* __restrict__ radius_p, double* __restrict__ S,
                                                        const double* __restrict__ colsq, const double* __restrict__ gc,
                                                        double* __restrict__ scal, int ntiles, const double* __restrict__ tile_part,
-                                                       const int* __restrict__ f2s, const int* __restrict__ fmaxflag) {
+                                                       const int* __restrict__ f2s, const int* __restrict__ fmaxflag,
+                                                       const uint8_t* __restrict__ tile_cls, int want_cls) {
   __shared__ double sm[16];
   __shared__ double smr[8][16];
   if (tile_part && blockIdx.x == 0) reduce_tiles_body(ntiles, tile_part, 4, f2s, fmaxflag, scal, smr, true);
   const double radius = *radius_p;
   double gmax = 0.0;
   const int d = blockIdx.x * 1024 + (int)threadIdx.x;
-  if (d < P.n) {
+  // tile_cls (sharded solve with a distributed K3): only the columns of the 64-wide tiles of class want_cls
+  if (d < P.n && (!tile_cls || tile_cls[d >> 6] == want_cls)) {
     const double sv = S[(size_t)d * P.n + d], cv = colsq[d], gv = gc[d], sr = P.scale_red[d];
     S[(size_t)d * P.n + d] = sv + fmin(fmax(cv, 1e-6), 1e32) / radius;
     gmax = fabs(gv / sr);
@@ -1538,8 +1540,9 @@ void launch_reduce_tiles_stage1(int ntiles, const double* tile_part, int nfields
 }
 
 void launch_finalize_rcs(const DevProblem& P, const double* radius, const ReduceBuf& rb, hipStream_t st, int ntiles,
-                         const double* tile_part, const int* f2s, const int* fmaxflag) {
-  k_finalize_rcs<<<std::max(1, (P.n + 1023) / 1024), 1024, 0, st>>>(P, radius, rb.S, rb.colsq, rb.gc, rb.scal, ntiles, tile_part, f2s, fmaxflag);
+                         const double* tile_part, const int* f2s, const int* fmaxflag, const uint8_t* tile_cls, int want_cls) {
+  k_finalize_rcs<<<std::max(1, (P.n + 1023) / 1024), 1024, 0, st>>>(P, radius, rb.S, rb.colsq, rb.gc, rb.scal, ntiles, tile_part, f2s, fmaxflag,
+                                                                     tile_cls, want_cls);
 }
 
 void launch_cam_update(const DevProblem& P, const double* cam, const double* y, double* cand_cam,

@@ -202,6 +202,11 @@ struct theia_ba_handle_s {
   DevBuf<int2> pack_tiles;
   DevBuf<double> pack_buf;
   int shard_rank = -1, shard_world = 0;   // theia_hip_ba_set_shard
+  // distributed K3 of a sharded solve (sync_plan): every rank factors the tile columns only its own tracks touch before the
+  // all-reduce, which then carries the shared tiles only; tile_cls: 0 shared, 1 this rank's, 2 another rank's
+  bool dist_k3 = false;
+  std::vector<uint8_t> tile_adj_local, tile_cls, tile_touch;   // tile_touch: this rank's observations / priors write into the tile column
+  DevBuf<uint8_t> d_tile_cls;
   int n_pack_tiles = 0;
 
   ~theia_ba_handle_s() {
@@ -486,6 +491,16 @@ __global__ __launch_bounds__(256) void k_pack_rcs(int n, const double* __restric
   }
 }
 
+// distributed K3: after the back-substitution a rank holds the step of its own private columns and of the shared ones; the
+// columns of other ranks' private tiles are zeroed, the shared ones kept on rank 0 only, and one SUM all-reduce of the n
+// doubles (x + 0 is exact) gives every rank the whole camera step
+__global__ void k_y_own(int n, double* __restrict__ y, const uint8_t* __restrict__ tile_cls, int rank) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  const int c = tile_cls[d >> 6];
+  if (!(c == 1 || (c == 0 && rank == 0))) y[d] = 0.0;
+}
+
 // accepted step: the candidate parameters become the state
 // Will this body's control pass run inner iterations?  The same conditions lm_control_body applies, from the same inputs.
 __global__ void k_inner_gate(const LmState* __restrict__ st, const double* __restrict__ sa, const double* __restrict__ sb,
@@ -686,6 +701,12 @@ int enqueue_linearize(theia_ba_handle_s* h, int slot = 0) {
   // per-rank slots when the shard geometry is known)
   int rc = 0;
   bool max_done = false;
+  if (h->dist_k3) {
+    // the rank's private columns: LM diagonal, then their factorisation from this rank's sums alone (their Schur
+    // complement lands in the shared tiles and the shared rows of the rhs, which the all-reduce sums next)
+    launch_finalize_rcs(h->P, radius, h->rb, h->stream, 0, nullptr, nullptr, nullptr, h->d_tile_cls.p, 1);
+    chol_plan_solve_phase(h->plan, 0, h->rb.S, h->n, h->rb.rhs, h->chol_work.p, h->rb.scal + SC_NOTPD, h->stream);
+  }
   if (h->allreduce && h->n_pack_tiles > 0 && h->n > 0) {
     const int tail_blocks = (int)((3 * (size_t)h->n + 8 + 255) / 256);
     const int grid = h->n_pack_tiles + std::max(1, std::min(tail_blocks, 64));
@@ -704,6 +725,7 @@ int enqueue_linearize(theia_ba_handle_s* h, int slot = 0) {
     launch_reduce_tiles_stage1(h->ntiles_main, h->tile_part.p, 4, h->fmaxflag.p, h->red_part.p, h->stream);
     launch_finalize_rcs(h->P, radius, h->rb, h->stream, kReduceBlocks, h->red_part.p, h->f2s.p, h->fmaxflag.p);
   } else if (fuse_reduce) launch_finalize_rcs(h->P, radius, h->rb, h->stream, h->ntiles_main, h->tile_part.p, h->f2s.p, h->fmaxflag.p);
+  else if (h->dist_k3) launch_finalize_rcs(h->P, radius, h->rb, h->stream, 0, nullptr, nullptr, nullptr, h->d_tile_cls.p, 0);   // the shared columns
   else launch_finalize_rcs(h->P, radius, h->rb, h->stream);
   return 0;
 }
@@ -712,6 +734,12 @@ int enqueue_linearize(theia_ba_handle_s* h, int slot = 0) {
 // defer_reduce: the tile reduction of the trial step is left to k_reduce_control (no all-reduce in between).
 int enqueue_solve_and_backsub(theia_ba_handle_s* h, int slot = 0, bool defer_reduce = false) {
   double* yc = h->rb.rhs;  // the solution overwrites the rhs row
+  if (h->dist_k3) {
+    chol_plan_solve_phase(h->plan, 1, h->rb.S, h->n, h->rb.rhs, h->chol_work.p, h->rb.scal + SC_NOTPD, h->stream);
+    k_y_own<<<(h->n + 255) / 256, 256, 0, h->stream>>>(h->n, yc, h->d_tile_cls.p, h->shard_rank);
+    const int rcy = do_allreduce(h, yc, (size_t)h->n, THEIA_REDUCE_SUM);
+    if (rcy) return rcy;
+  } else
   chol_plan_solve(h->plan, h->rb.S, h->n, h->rb.rhs, h->chol_work.p, h->rb.scal + SC_NOTPD, h->stream);
   if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][2], h->stream));
   const int nxt = 1 - h->cur;
@@ -729,9 +757,11 @@ int enqueue_solve_and_backsub(theia_ba_handle_s* h, int slot = 0, bool defer_red
 int sync_plan(theia_ba_handle_s* h) {
   const int nt = (h->n + 63) / 64;
   const size_t cnt = (size_t)nt * nt;
+  h->dist_k3 = false;
   if (cnt == 0 || !h->allreduce) { h->plan_is_global = true; return 0; }
+  if (h->tile_adj_local.size() != cnt) h->tile_adj_local = h->tile_adj;   // this rank's own structure (tile_adj becomes the union)
   std::vector<double> a(cnt);
-  for (size_t i = 0; i < cnt; ++i) a[i] = h->tile_adj[i];
+  for (size_t i = 0; i < cnt; ++i) a[i] = h->tile_adj_local[i];
   HIP_TRY(hipMemcpyAsync(h->reduce.p, a.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
   int rc = do_allreduce(h, h->reduce.p, cnt, THEIA_REDUCE_MAX);
   if (rc) return rc;
@@ -740,11 +770,54 @@ int sync_plan(theia_ba_handle_s* h) {
   for (size_t i = 0; i < cnt; ++i) h->tile_adj[i] = a[i] != 0.0 ? 1 : 0;
   h->drop_graph();
   if (h->plan) chol_plan_destroy(h->plan);
-  h->plan = chol_plan_create(h->n, h->tile_adj.data());
+  h->plan = nullptr;
+  // Distributed K3 (round 4): with the shard geometry declared (set_shard / set_rccl), no intrinsics columns and more than one
+  // rank, a tile column that only ONE rank's tracks touch is factored by that rank alone, before the all-reduce, which then
+  // carries the shared tiles only.  Every rank takes the same decision from the same all-reduced numbers.
+  const bool geom = h->shard_world > 1 && h->shard_rank >= 0 && h->shard_rank < h->shard_world && h->shard_world <= kMaxShardSlots;
+  if (geom && h->ni == 0 && nt > 2 && !getenv("THEIA_HIP_K3_REPLICATED")) {
+    std::vector<double> t(nt + 1, 0.0);
+    for (int i = 0; i < nt; ++i) t[i] = (i < (int)h->tile_touch.size() && h->tile_touch[i]) ? 1.0 : 0.0;
+    HIP_TRY(hipMemcpyAsync(h->reduce.p, t.data(), sizeof(double) * nt, hipMemcpyHostToDevice, h->stream));
+    if ((rc = do_allreduce(h, h->reduce.p, (size_t)nt, THEIA_REDUCE_SUM))) return rc;
+    std::vector<double> c(nt);
+    HIP_TRY(hipMemcpyAsync(c.data(), h->reduce.p, sizeof(double) * nt, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->tile_cls.assign(nt, 0);
+    int nmine = 0;
+    for (int i = 0; i < nt; ++i)
+      if (c[i] == 1.0) { h->tile_cls[i] = t[i] != 0.0 ? 1 : 2; nmine += t[i] != 0.0; }
+    CholPlan* pl = chol_plan_create_sharded(h->n, h->tile_adj.data(), h->tile_cls.data());
+    double bad = pl ? 0.0 : 1.0;      // agreed between the ranks: one rank without a level schedule keeps everybody replicated
+    HIP_TRY(hipMemcpyAsync(h->reduce.p, &bad, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if ((rc = do_allreduce(h, h->reduce.p, 1, THEIA_REDUCE_MAX))) { if (pl) chol_plan_destroy(pl); return rc; }
+    HIP_TRY(hipMemcpyAsync(&bad, h->reduce.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (bad == 0.0) {
+      h->plan = pl; h->dist_k3 = true;
+      if ((rc = h->d_tile_cls.upload(h->tile_cls, h->stream))) return rc;
+      if (getenv("THEIA_HIP_CREATE_TIMING"))
+        fprintf(stderr, "theia_hip distributed K3: rank %d of %d, %d of %d tiles private, %d levels before the all-reduce, %zu shared tiles in it\n",
+                h->shard_rank, h->shard_world, nmine, nt, chol_plan_split_level(pl), chol_plan_shared_tiles(pl).size() / 2);
+    } else {
+      if (getenv("THEIA_HIP_CREATE_TIMING"))
+        fprintf(stderr, "theia_hip distributed K3: rank %d of %d keeps the replicated plan (%d of %d tiles private here; %s)\n", h->shard_rank,
+                h->shard_world, nmine, nt, pl ? "another rank has no level schedule" : "no level schedule for this rank's structure");
+      if (pl) chol_plan_destroy(pl);
+    }
+  } else if (getenv("THEIA_HIP_CREATE_TIMING") && h->shard_world > 1)
+    fprintf(stderr, "theia_hip distributed K3: not taken (shard geometry %d/%d, %d intrinsics columns, %d tiles)\n", h->shard_rank, h->shard_world, h->ni, nt);
+  if (!h->plan) h->plan = chol_plan_create(h->n, h->tile_adj.data());
   h->plan_is_global = true;
   HIP_TRY(hipMemsetAsync(h->reduce.p, 0, sizeof(double) * h->reduce.n, h->stream));   // tiles only the old plan touched
   {
     std::vector<int2> tiles;
+    if (h->dist_k3) {
+      const std::vector<int>& st = chol_plan_shared_tiles(h->plan);
+      for (size_t k = 0; k + 1 < st.size(); k += 2) tiles.push_back(make_int2(st[k], st[k + 1]));
+      if (tiles.empty()) tiles.push_back(make_int2(0, 0));   // (the packed path needs one)
+    } else
     for (int i = 0; i < nt; ++i)
       for (int j = 0; j <= i; ++j)
         if (i == j || h->tile_adj[(size_t)i * nt + j]) tiles.push_back(make_int2(i, j));
@@ -1986,6 +2059,15 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
       h->tile_adj[(size_t)a * nt + a] = 1;
       h->tile_adj[(size_t)b * nt + b] = 1;
       h->tile_adj[(size_t)a * nt + b] = h->tile_adj[(size_t)b * nt + a] = 1;
+    }
+    // which tile columns THIS problem (a rank's shard) writes into: cameras it observes (any point, constant ones included:
+    // their F^T F lands on the diagonal) or holds a prior for.  The distributed K3 of a sharded solve asks for it (sync_plan).
+    h->tile_touch.assign(nt, 0);
+    for (int c = 0; c < h->nc; ++c) {
+      const bool prior = p->cam_prior_mask && o->prior_mask && (p->cam_prior_mask[c] & o->prior_mask);
+      if ((!cam_used[c] && !prior) || h->cam_red[c] < 0) continue;
+      const int s0 = h->ni + 6 * h->cam_red[c];
+      h->tile_touch[s0 / 64] = 1; h->tile_touch[(s0 + 5) / 64] = 1;
     }
     // shared intrinsics couple with every camera of their group: treat as dense
     for (int a = 0; a < (h->ni + 63) / 64; ++a)

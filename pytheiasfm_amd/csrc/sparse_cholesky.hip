@@ -445,22 +445,67 @@ struct CholPlan {
   double flops = 0.0;              // FP64 flops of one factorisation + solve on this schedule (useful ones: h x w x nb extents)
   // deferred border updates (k_sp_update_partial / k_sp_update_reduce), run before level def_level
   int def_level = -1, def_part_off = 0, n_def_part = 0, def_src_off = 0, def_red_off = 0, n_def_red = 0;
+  // sharded plan (chol_plan_create_sharded): levels [0, lev_split) factor the tile columns only THIS rank's tracks touch --
+  // from this rank's partial sums, before the all-reduce --, levels [lev_split, nlev) the shared columns every rank factors
+  // after it; shared_tiles = the (tile row, tile column) positions the all-reduce has to sum.  lev_split = 0 otherwise.
+  int lev_split = 0;
+  std::vector<int> shared_tiles;
   int* prog = nullptr;   // device
   double* scratch = nullptr;   // device: partial tiles of the deferred updates
   ~CholPlan() { if (prog) (void)hipFree(prog); if (scratch) (void)hipFree(scratch); }
 };
 
-CholPlan* chol_plan_create(int n, const uint8_t* adj) {
+namespace {
+CholPlan* chol_plan_create_impl(int n, const uint8_t* adj_in, const uint8_t* tile_class);
+}
+CholPlan* chol_plan_create(int n, const uint8_t* adj) { return chol_plan_create_impl(n, adj, nullptr); }
+// tile_class[nt]: 0 = shared (touched by the tracks of two or more ranks), 1 = private to THIS rank, 2 = private to another
+// rank (not part of this rank's system).  adj: the union of the ranks' tile structures.  Null when the structure offers no
+// level schedule (the caller then keeps the replicated plan; the decision has to be agreed between the ranks).
+CholPlan* chol_plan_create_sharded(int n, const uint8_t* adj, const uint8_t* tile_class) {
+  CholPlan* pl = chol_plan_create_impl(n, adj, tile_class);
+  if (pl && pl->dense) { delete pl; return nullptr; }
+  return pl;
+}
+namespace {
+CholPlan* chol_plan_create_impl(int n, const uint8_t* adj_in, const uint8_t* tile_class) {
   CholPlan* pl = new CholPlan();
   pl->n = n;
   const int nt = (n + NB - 1) / NB;
   pl->nt = nt;
-  if (n <= 0 || nt <= 2 || !adj || getenv("THEIA_HIP_DENSE_CHOLESKY")) return pl;
+  if (n <= 0 || nt <= 2 || !adj_in || getenv("THEIA_HIP_DENSE_CHOLESKY")) return pl;
+  // Sharded: eliminating a rank's private columns fills the shared tiles its tracks tie together -- on THAT rank; the sum of
+  // the ranks' Schur complements has the union of those fills, so the shared part of every rank's structure gets the
+  // clique of shared neighbours of every connected set of private tiles (anybody's).  Tiles of other ranks leave the graph.
+  std::vector<uint8_t> adj_own;
+  const uint8_t* adj = adj_in;
+  if (tile_class) {
+    adj_own.assign(adj_in, adj_in + (size_t)nt * nt);
+    std::vector<int> comp(nt, -1);
+    int ncomp = 0;
+    for (int s0 = 0; s0 < nt; ++s0) {
+      if (tile_class[s0] == 0 || comp[s0] >= 0) continue;
+      std::vector<int> q{s0}, shared_nb;
+      comp[s0] = ncomp;
+      for (size_t i = 0; i < q.size(); ++i)
+        for (int j = 0; j < nt; ++j) {
+          if (j == q[i] || !adj_in[(size_t)q[i] * nt + j]) continue;
+          if (tile_class[j] == 0) shared_nb.push_back(j);
+          else if (comp[j] < 0) { comp[j] = ncomp; q.push_back(j); }
+        }
+      for (int a : shared_nb) for (int b : shared_nb) if (a != b) adj_own[(size_t)a * nt + b] = 1;
+      ++ncomp;
+    }
+    for (int i = 0; i < nt; ++i)
+      if (tile_class[i] == 2)
+        for (int j = 0; j < nt; ++j) adj_own[(size_t)i * nt + j] = adj_own[(size_t)j * nt + i] = 0;
+    adj = adj_own.data();
+  }
   // tile graph without the (near) dense nodes, which are ordered last
   std::vector<int> deg(nt, 0);
   for (int i = 0; i < nt; ++i) for (int j = 0; j < nt; ++j) if (i != j && adj[(size_t)i * nt + j]) deg[i]++;
   std::vector<char> is_dense(nt, 0);
-  for (int i = 0; i < nt; ++i) is_dense[i] = (deg[i] >= std::max(8, nt / 2)) ? 1 : 0;
+  for (int i = 0; i < nt; ++i) is_dense[i] = (!tile_class && deg[i] >= std::max(8, nt / 2)) ? 1 : 0;
   std::vector<std::vector<int>> nbr(nt);
   std::vector<int> sparse_nodes, dense_nodes;
   for (int i = 0; i < nt; ++i) {
@@ -472,7 +517,37 @@ CholPlan* chol_plan_create(int n, const uint8_t* adj) {
   for (int i = 0; i < nt; ++i) natural[i] = i;
   std::vector<int> perm = natural;
   Symbolic best = symbolic(nt, adj, natural);
-  if (!sparse_nodes.empty()) {
+  if (tile_class) {
+    // private columns first (nested dissection of their own graph), then the shared ones (of theirs, fill included: the
+    // same order on every rank), then the tiles that are not this rank's
+    std::vector<std::vector<int>> nb1(nt), nb0(nt);
+    std::vector<int> mine, shared, other;
+    for (int i = 0; i < nt; ++i) {
+      (tile_class[i] == 1 ? mine : (tile_class[i] == 0 ? shared : other)).push_back(i);
+      for (int j = 0; j < nt; ++j) {
+        if (i == j || !adj[(size_t)i * nt + j]) continue;
+        if (tile_class[i] == 1 && tile_class[j] == 1) nb1[i].push_back(j);
+        if (tile_class[i] == 0 && tile_class[j] == 0) nb0[i].push_back(j);
+      }
+    }
+    std::vector<int> cand;
+    if (!mine.empty()) { Orderer o1(nb1); o1.order(mine); cand = o1.out; }
+    if (!shared.empty()) { Orderer o0(nb0); o0.order(shared); cand.insert(cand.end(), o0.out.begin(), o0.out.end()); }
+    cand.insert(cand.end(), other.begin(), other.end());
+    if ((int)cand.size() != nt) return pl;
+    perm = cand;
+    best = symbolic(nt, adj, perm);
+    // two phases: every shared column above every private one
+    int lp = 0;
+    for (int K = 0; K < nt; ++K) if (tile_class[perm[K]] == 1) lp = std::max(lp, best.level[K] + 1);
+    for (int K = 0; K < nt; ++K) {
+      if (tile_class[perm[K]] == 0) best.level[K] = std::max(best.level[K], lp);
+      if (!best.below[K].empty()) best.level[best.below[K][0]] = std::max(best.level[best.below[K][0]], best.level[K] + 1);
+    }
+    best.nlev = 0;
+    for (int K = 0; K < nt; ++K) if (tile_class[perm[K]] != 2) best.nlev = std::max(best.nlev, best.level[K] + 1);
+    pl->lev_split = lp;
+  } else if (!sparse_nodes.empty()) {
     Orderer od(nbr);
     od.order(sparse_nodes);
     std::vector<int> cand = od.out;
@@ -501,7 +576,7 @@ CholPlan* chol_plan_create(int n, const uint8_t* adj) {
   for (int l = 0; l < best.nlev; ++l) {
     Level& lv = pl->lev[l];
     std::vector<int> ks;
-    for (int K = 0; K < nt; ++K) if (best.level[K] == l) ks.push_back(K);
+    for (int K = 0; K < nt; ++K) if (best.level[K] == l && !(tile_class && tile_class[perm[K]] == 2)) ks.push_back(K);
     lv.potrf_off = (int)prog.size(); lv.npotrf = (int)ks.size();
     for (int K : ks) { prog.push_back(r0(K)); prog.push_back(hh(K)); prog.push_back(K);
       const double nb = hh(K); pl->flops += nb * nb * nb / 3.0 + nb * nb * nb / 3.0; }   // factor + triangular inverse
@@ -591,7 +666,15 @@ CholPlan* chol_plan_create(int n, const uint8_t* adj) {
       prog.push_back(pr * NB); prog.push_back(std::min(NB, n - pr * NB)); prog.push_back(pc * NB); prog.push_back(std::min(NB, n - pc * NB));
       pl->nclear++;
     };
-    for (int K = 0; K < nt; ++K) { add(K, K); for (int I : best.below[K]) add(I, K); }
+    for (int K = 0; K < nt; ++K) { if (tile_class && tile_class[perm[K]] == 2) continue; add(K, K); for (int I : best.below[K]) add(I, K); }
+    // what the all-reduce of a sharded solve sums: the shared columns of the factor structure, at the positions the
+    // factorisation works on
+    if (tile_class)
+      for (int K = 0; K < nt; ++K) {
+        if (tile_class[perm[K]] != 0) continue;
+        pl->shared_tiles.push_back(perm[K]); pl->shared_tiles.push_back(perm[K]);
+        for (int I : best.below[K]) { pl->shared_tiles.push_back(perm[I]); pl->shared_tiles.push_back(perm[K]); }
+      }
   }
   if (getenv("THEIA_HIP_CREATE_TIMING")) {   // shape of the schedule
     fprintf(stderr, "theia_hip K3 plan: n = %d, %d tiles, %d levels, %lld factor tiles, %.1f MFLOP\n", n, nt, pl->nlev, best.ntiles, pl->flops * 1e-6);
@@ -611,6 +694,7 @@ CholPlan* chol_plan_create(int n, const uint8_t* adj) {
   }
   return pl;
 }
+}  // namespace
 
 namespace {
 // blocks [0, nclear): one structure tile each; blocks beyond: the vector tail behind the matrix (rhs | colsq | gc | scalars),
@@ -646,38 +730,50 @@ double chol_plan_flops(const CholPlan* pl) {
 }
 int chol_plan_levels(const CholPlan* pl) { return pl && !pl->dense ? pl->nlev : (pl ? pl->nt : 0); }
 
-void chol_plan_solve(const CholPlan* pl, double* A, int lda, double* b, double* work, double* fail_flag, hipStream_t st) {
+// phase 0: mirror + forward levels [0, lev_split) (a sharded plan's private columns; nothing but the mirror otherwise);
+// phase 1: forward levels [lev_split, nlev), then the whole back-substitution.  chol_plan_solve = both.
+void chol_plan_solve_phase(const CholPlan* pl, int phase, double* A, int lda, double* b, double* work, double* fail_flag, hipStream_t st) {
   const int n = pl->n;
   if (n <= 0) return;
-  if (pl->dense) { dense_cholesky_solve(n, A, lda, b, work, fail_flag, st); return; }
+  if (pl->dense) { if (phase == 1) dense_cholesky_solve(n, A, lda, b, work, fail_flag, st); return; }
   double* Linv = work;
   // back-substitution in place when the solution goes where the rhs row lives (the caller's layout): a tile
   // reads only its OWN y and the x of tiles solved by earlier launches
   const bool inplace = (b == A + (size_t)n * lda);
   double* x = inplace ? b : work + (size_t)pl->nt * NB * NB;
   const int* pg = pl->prog;
-  if (pl->nsymm) k_sp_symm<<<pl->nsymm, 256, 0, st>>>(A, lda, pg + pl->symm_off);
-  int li = 0;
-  for (const Level& lv : pl->lev) {
-    if (li++ == pl->def_level && pl->n_def_part) {
+  if (phase == 0 && pl->nsymm) k_sp_symm<<<pl->nsymm, 256, 0, st>>>(A, lda, pg + pl->symm_off);
+  const int l0 = phase == 0 ? 0 : pl->lev_split, l1 = phase == 0 ? pl->lev_split : (int)pl->lev.size();
+  for (int li = l0; li < l1; ++li) {
+    const Level& lv = pl->lev[li];
+    if (li == pl->def_level && pl->n_def_part) {
       k_sp_update_partial<<<pl->n_def_part, 256, 0, st>>>(A, lda, pg + pl->def_part_off, pg + pl->def_src_off, pl->scratch);
       k_sp_update_reduce<<<pl->n_def_red * 16, 256, 0, st>>>(A, lda, pg + pl->def_red_off, pl->scratch);
     }
     static const bool split = getenv("THEIA_HIP_K3_SPLIT_TRSM") != nullptr;   // development: the two launches
     if (split) {
-      k_sp_potrf<<<lv.npotrf, 256, 0, st>>>(A, lda, pg + lv.potrf_off, Linv, fail_flag);
+      if (lv.npotrf) k_sp_potrf<<<lv.npotrf, 256, 0, st>>>(A, lda, pg + lv.potrf_off, Linv, fail_flag);
       if (lv.ntrsm) k_sp_trsm<<<lv.ntrsm, 256, 0, st>>>(A, lda, pg + lv.trsm_off, Linv);
-    } else {
+    } else if (lv.npotrf + lv.ntrsm) {
       k_sp_potrf_trsm<<<lv.npotrf + lv.ntrsm, 256, 0, st>>>(A, lda, pg + lv.potrf_off, lv.npotrf, pg + lv.trsm_off, Linv, fail_flag);
     }
     if (lv.nupd) k_sp_update<<<lv.nupd, 256, 0, st>>>(A, lda, pg + lv.upd_off, pg + lv.upd_src_off);
   }
+  if (phase == 0) return;
   const double* y = A + (size_t)n * lda;
   for (int l = (int)pl->lev.size() - 1; l >= 0; --l) {
     const Level& lv = pl->lev[l];
-    k_sp_back<<<lv.nback, 256, 0, st>>>(A, lda, pg + lv.back_off, pg + lv.back_src_off, Linv, y, x);
+    if (lv.nback) k_sp_back<<<lv.nback, 256, 0, st>>>(A, lda, pg + lv.back_off, pg + lv.back_src_off, Linv, y, x);
   }
   if (!inplace) (void)hipMemcpyAsync(b, x, sizeof(double) * n, hipMemcpyDeviceToDevice, st);
 }
+
+void chol_plan_solve(const CholPlan* pl, double* A, int lda, double* b, double* work, double* fail_flag, hipStream_t st) {
+  chol_plan_solve_phase(pl, 0, A, lda, b, work, fail_flag, st);
+  chol_plan_solve_phase(pl, 1, A, lda, b, work, fail_flag, st);
+}
+int chol_plan_split_level(const CholPlan* pl) { return pl && !pl->dense ? pl->lev_split : 0; }
+// (tile row, tile column) pairs, two ints each, of the tiles a sharded plan's all-reduce has to carry
+const std::vector<int>& chol_plan_shared_tiles(const CholPlan* pl) { return pl->shared_tiles; }
 
 }  // namespace thip

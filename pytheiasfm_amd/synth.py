@@ -247,25 +247,31 @@ def ba_config(name, **kw):
 
 
 def shard_tracks(problem, rank, world_size):
-    """Multi-GPU partition: tracks (with their observations) are
-    dealt to ranks in contiguous blocks balanced by sum L^2 (Schur work);
-    cameras and intrinsics are replicated.  Returns the rank's FlatProblem and
-    the global indices of its tracks."""
+    """Multi-GPU partition: tracks (with their observations) are dealt to ranks in blocks balanced by
+    sum L^2 (Schur work) that are contiguous in CAMERA order -- tracks sorted by the first camera that sees them -- so
+    that a rank's tracks see a window of the cameras: the columns of the reduced camera system that only one rank touches
+    are then factored by that rank alone (the distributed K3 of csrc/ba_solver.hip: sync_plan).  Cameras and intrinsics
+    are replicated.  Returns the rank's FlatProblem and the global indices of its tracks (ascending)."""
     npts = problem.points.shape[0]
     L = np.bincount(problem.obs_pt, minlength=npts).astype(np.float64)
-    w = np.cumsum(L * L)
+    first_cam = np.full(npts, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(first_cam, problem.obs_pt, problem.obs_cam.astype(np.int64))
+    order = np.argsort(first_cam, kind="stable")
+    w = np.cumsum((L * L)[order])
     total = w[-1] if npts else 0.0
     bounds = np.searchsorted(w, total * np.arange(1, world_size) / world_size, side="left")
     edges = np.concatenate([[0], bounds, [npts]]).astype(np.int64)
-    lo, hi = edges[rank], edges[rank + 1]
-    sel = (problem.obs_pt >= lo) & (problem.obs_pt < hi)
-    pc = None if problem.point_const is None else problem.point_const[lo:hi]
+    ids = np.sort(order[edges[rank]:edges[rank + 1]])
+    local = np.full(npts, -1, dtype=np.int64)
+    local[ids] = np.arange(len(ids))
+    sel = local[problem.obs_pt] >= 0
+    pc = None if problem.point_const is None else problem.point_const[ids]
     si = None if problem.obs_sqrt_info is None else problem.obs_sqrt_info[sel]
     shard = FlatProblem(problem.cam_ext.copy(), problem.intrinsics.copy(), problem.group_model,
-                        problem.cam_group, problem.points[lo:hi].copy(), problem.obs_uv[sel],
-                        problem.obs_cam[sel], problem.obs_pt[sel] - lo, cam_const=problem.cam_const,
+                        problem.cam_group, problem.points[ids].copy(), problem.obs_uv[sel],
+                        problem.obs_cam[sel], local[problem.obs_pt[sel]].astype(problem.obs_pt.dtype), cam_const=problem.cam_const,
                         group_const=problem.group_const, point_const=pc, obs_sqrt_info=si, flags=problem.flags | 1)
-    return shard, np.arange(lo, hi)
+    return shard, ids
 
 
 # --------------------------------------------------------------------- RANSAC

@@ -188,3 +188,47 @@ def test_sharded_solve_two_ranks_on_one_gpu(mixed, inner):
         assert abs(r["final_cost"] - r["ref_final_cost"]) <= 1e-9 * r["ref_final_cost"], r
         assert r["cam_err"] <= 1e-8 and r["pts_err"] <= 1e-8 and r["trace_cost_err"] <= 1e-9 and r["intr_err"] <= 1e-8, r
     assert res[0]["final_cost"] == res[1]["final_cost"]   # both ranks hold the all-reduced cost bit for bit
+
+
+@pytest.mark.parametrize("world,mixed,priors", [(2, 0, 0), (3, 1, 0), (4, 0, 1)])
+def test_distributed_k3_ranks_on_one_gpu(world, mixed, priors):
+    """The distributed reduced-camera solve of a sharded run (round 4): with the shard geometry declared
+    a tile column that only one rank's tracks touch is factored by that rank alone BEFORE the all-reduce, which then carries the
+    shared tiles only; the shared top is factored by every rank, the private parts are back-substituted locally and the camera
+    step is summed.  160 views on a ring (15 tiles of the reduced system), 2 / 3 / 4 ranks as processes on the one GPU of the
+    box with the collective staged through the host: every rank must reproduce the unsharded solve (iteration counts equal,
+    costs to 1e-9, parameters to 1e-8), with priors held by rank 0 on cameras other ranks own, and must report the same cost
+    bit for bit.  THEIA_HIP_K3_REPLICATED=1 keeps the replicated solve of the earlier rounds."""
+    import json
+    import subprocess
+    import sys
+    port = str(29900 + os.getpid() % 90 + 3 * world)
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, SHARD_MIXED=str(mixed),
+                   SHARD_INNER="0", SHARD_VIEWS="160", SHARD_TRACKS="9000", SHARD_PRIORS=str(priors), THEIA_HIP_CREATE_TIMING="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), "sharded_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    res = []
+    for o, pr in zip(outs, procs):
+        assert pr.returncode == 0, o[-3000:]
+        assert "theia_hip distributed K3: rank" in o, o[-3000:]      # the distributed plan was taken, not the replicated one
+        line = [l for l in o.splitlines() if l.startswith("RESULT ")]
+        assert line, o[-3000:]
+        res.append(json.loads(line[-1][7:]))
+    assert {r["rank"] for r in res} == set(range(world)) and sum(r["tracks"] for r in res) == 9000
+    for r in res:
+        assert r["iterations"] == r["ref_iterations"], r
+        assert abs(r["final_cost"] - r["ref_final_cost"]) <= 1e-9 * r["ref_final_cost"], r
+        assert r["cam_err"] <= 1e-8 and r["pts_err"] <= 1e-8 and r["trace_cost_err"] <= 1e-9, r
+    assert len({r["final_cost"] for r in res}) == 1
+    print("\n" + "\n".join(l for o in outs for l in o.splitlines() if "distributed K3" in l))
