@@ -290,6 +290,34 @@ def gdls_similarity(origin, direction, world, call_index=0):
     return q[:n], t[:n], sc[:n]
 
 
+def upnp_action_matrix(A, b, want_template=False):
+    """BuildActionMatrixUsingSymmetry (oracle/upnp_oracle.h): 8 x 8 action matrix [, the 141 x 149 template before the
+    elimination, the reduced 8 x 24 input matrix]."""
+    L = rlib()
+    dp = capi.c_double_p
+    L.oracle_upnp_action_matrix.argtypes = [dp, dp, dp, dp, dp]
+    A = np.ascontiguousarray(A, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+    act = np.zeros((8, 8)); T = np.zeros((141, 149)); M1 = np.zeros((8, 24))
+    L.oracle_upnp_action_matrix(capi.ptr(A, C.c_double), capi.ptr(b, C.c_double), capi.ptr(act, C.c_double),
+                                capi.ptr(T, C.c_double) if want_template else None, capi.ptr(M1, C.c_double) if want_template else None)
+    return (act, T, M1) if want_template else act
+
+
+def upnp_estimate_pose(origin, direction, world, state=None):
+    """Upnp::EstimatePose (upnp.cc:462-493).  state: the [A | b] (110) of the estimator object, updated in place (None = a
+    fresh object).  Returns quaternions [w x y z], translations, state."""
+    L = rlib()
+    dp = capi.c_double_p
+    L.oracle_upnp_estimate_pose.argtypes = [C.c_int, dp, dp, dp, dp, dp, dp]
+    o = np.ascontiguousarray(origin, dtype=np.float64); d = np.ascontiguousarray(direction, dtype=np.float64)
+    w = np.ascontiguousarray(world, dtype=np.float64)
+    st = np.zeros(110) if state is None else state
+    q = np.zeros((8, 4)); t = np.zeros((8, 3))
+    n = L.oracle_upnp_estimate_pose(o.shape[0], capi.ptr(o, C.c_double), capi.ptr(d, C.c_double), capi.ptr(w, C.c_double),
+                                    capi.ptr(st, C.c_double), capi.ptr(q, C.c_double), capi.ptr(t, C.c_double))
+    return q[:n], t[:n], st
+
+
 def model_error(est, model, datum):
     """Estimator::Error of one datum under one model row (oracle_model_error)."""
     model = np.ascontiguousarray(model, dtype=np.float64); datum = np.ascontiguousarray(datum, dtype=np.float64)
