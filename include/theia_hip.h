@@ -587,7 +587,17 @@ enum {
    * matrix (:88-97, no cheirality test).  model = the 3 x 4 projection matrix K [R | t], row-major (12 doubles); the
    * reference's DecomposeProjectionMatrix step (:124-138: rotation, position, focal length) is left to the caller (the
    * Python mirror does it).  The elimination template is not the reference's generated one. */
-  THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE = 14
+  THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE = 14,
+  /* EstimateRigidTransformation2D3D (estimate_rigid_transformation_2d_3d.cc:62-182): datum = CameraAndFeatureCorrespondence2D3D in
+   * the 26-double row of THEIA_EST_SIMILARITY_2D3D ([0..2] the observation's normalised world-frame ray, [3..6] point3d, [7,8]
+   * pixel, [9..14] camera position | angle-axis, [15] camera model, [16..25] intrinsics); the overload for
+   * FeatureCorrespondence2D3D (:159-182) is the same call with identity pinhole cameras (focal length 1).  Sample = 4;
+   * EstimateModel = Upnp::EstimatePose (pose/upnp.cc:462-493: the 8-solution symmetric template, eliminated by the reference's own
+   * Gauss-Jordan), up to 8 models; Error = squared pixel error of R X + t seen by the datum's camera, DBL_MAX behind it (:116-129).
+   * As in the reference, the estimator's UPnP cost parameters ACCUMULATE over the samples of one Estimate() call (upnp.cc:191-200
+   * adds to a member of the one Upnp object the estimator keeps): hypothesis k is solved from the samples 0 .. k.
+   * model = RigidTransformation: rotation (9, row-major), translation (3). */
+  THEIA_EST_RIGID_TRANSFORMATION_2D3D = 15
 };
 
 /* A batch of independent estimation problems ("pairs").  Datum layout:
@@ -599,7 +609,7 @@ enum {
  *   dominant plane: Eigen::Vector3d = [X Y Z]
  *   triangulation: one observation with its camera, 33 doubles (THEIA_EST_TRIANGULATION)
  *   radial-distortion homography: RadialDistortionFeatureCorrespondence, 12 doubles (THEIA_EST_RADIAL_HOMOGRAPHY)
- *   similarity 2D-3D: CameraAndFeatureCorrespondence2D3D, 26 doubles (THEIA_EST_SIMILARITY_2D3D)
+ *   similarity 2D-3D, rigid transformation 2D-3D: CameraAndFeatureCorrespondence2D3D, 26 doubles (THEIA_EST_SIMILARITY_2D3D)
  *   uncalibrated absolute pose: FeatureCorrespondence2D3D = [u v X Y Z], pixels with the principal point removed */
 typedef struct theia_ransac_batch {
   int32_t estimator;           /* THEIA_EST_*                              */
@@ -620,7 +630,8 @@ typedef struct theia_ransac_batch {
  *   DOMINANT_PLANE:   point(3) unit_normal(3)                       = 6
  *   RELATIVE_POSE_KNOWN_ORIENTATION: unit position of camera 2      = 3
  *   UNCALIBRATED_RELATIVE_POSE: F(9) R(9) position(3) focal_length1 focal_length2 = 23
- *   UNCALIBRATED_ABSOLUTE_POSE: projection matrix 3 x 4, row-major    = 12 */
+ *   UNCALIBRATED_ABSOLUTE_POSE: projection matrix 3 x 4, row-major    = 12
+ *   RIGID_TRANSFORMATION_2D3D: R(9, row-major) translation(3)        = 12 */
 #define THEIA_RANSAC_MODEL_STRIDE 24
 typedef struct theia_ransac_result {
   int32_t* success;            /* [num_problems] Estimate() return value; 0 (with no inliers and a zero

@@ -17,7 +17,8 @@ for f in $SRCS; do
     CONTRACT=off
     case "$f" in ba_fused.hip|ba_fused_intr.hip|ba_kernels.hip) CONTRACT="fast -freciprocal-math -fno-math-errno -fapprox-func" ;; esac
     # the DLS elimination keeps a 93 x 120 matrix in registers; common-code sinking would index it at run time (dls_stage_a.h)
-    case "$f" in dls_kernels.hip) CONTRACT="off -mllvm -simplifycfg-sink-common=false" ;; esac
+    # (upnp_kernels.hip: the same for its 141 x 149 template)
+    case "$f" in dls_kernels.hip|upnp_kernels.hip) CONTRACT="off -mllvm -simplifycfg-sink-common=false" ;; esac
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=$CONTRACT -munsafe-fp-atomics \
       -I../../include -I. -c "$f" -o "$o" &
     PIDS="$PIDS $!"

@@ -49,6 +49,7 @@ __host__ __device__ inline int max_models(int est) {
   if (est == THEIA_EST_RADIAL_HOMOGRAPHY) return 2;
   if (est == THEIA_EST_SIMILARITY_2D3D) return dlsdev::kMaxSolutions;
   if (est == THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE) return 10;
+  if (est == THEIA_EST_RIGID_TRANSFORMATION_2D3D) return 8;
   if (est >= THEIA_EST_FUNDAMENTAL_MATRIX) return 1;
   if (est == THEIA_EST_ABSOLUTE_POSE_DLS) return dlsdev::kMaxSolutions;
   return est == THEIA_EST_ABSOLUTE_POSE_SQPNP ? 18 : (est == THEIA_EST_ABSOLUTE_POSE_KNEIP ? 4 : 10);
@@ -59,7 +60,8 @@ __host__ __device__ inline int sample_size(int est) {
   switch (est) {
     case THEIA_EST_RELATIVE_POSE: case THEIA_EST_ESSENTIAL_MATRIX: return 5;
     case THEIA_EST_FUNDAMENTAL_MATRIX: case THEIA_EST_UNCALIBRATED_RELATIVE_POSE: return 8;
-    case THEIA_EST_HOMOGRAPHY: case THEIA_EST_SIMILARITY_2D3D: case THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE: return 4;
+    case THEIA_EST_HOMOGRAPHY: case THEIA_EST_SIMILARITY_2D3D: case THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE:
+    case THEIA_EST_RIGID_TRANSFORMATION_2D3D: return 4;
     case THEIA_EST_RADIAL_HOMOGRAPHY: return 6;
     case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION:
     case THEIA_EST_TRIANGULATION: return 2;
@@ -73,6 +75,7 @@ inline int model_doubles(int est) {
     case THEIA_EST_UNCALIBRATED_RELATIVE_POSE: return 23;
     case THEIA_EST_ABSOLUTE_POSE_KNEIP: case THEIA_EST_ABSOLUTE_POSE_DLS: case THEIA_EST_ABSOLUTE_POSE_SQPNP: return 12;
     case THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE: return 12;   // projection matrix, row-major 3 x 4
+    case THEIA_EST_RIGID_TRANSFORMATION_2D3D: return 12;    // rotation | translation
     case THEIA_EST_DOMINANT_PLANE: return 6;
     case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: return 3;
     case THEIA_EST_TRIANGULATION: return 4;
@@ -90,7 +93,7 @@ __host__ __device__ inline int datum_size(int est) {
     case THEIA_EST_DOMINANT_PLANE: return 3;
     case THEIA_EST_TRIANGULATION: return kTriDatum;
     case THEIA_EST_RADIAL_HOMOGRAPHY: return rsc::kRadHomDatum;
-    case THEIA_EST_SIMILARITY_2D3D: return kSimDatum;
+    case THEIA_EST_SIMILARITY_2D3D: case THEIA_EST_RIGID_TRANSFORMATION_2D3D: return kSimDatum;
     default: return 4;
   }
 }
@@ -220,9 +223,28 @@ __device__ inline double similarity_error(const double* m, const double* d) {
   return ex * ex + ey * ey;
 }
 
+// NonCentralCameraPoseEstimator::Error (estimate_rigid_transformation_2d_3d.cc:116-129): R X + t through the datum's camera
+// (Camera::ProjectPoint), DBL_MAX at negative depth.
+__device__ inline double rigid_error(const double* m, const double* d) {
+  const double* X = d + 3; const double* c = d + 9;
+  const double h[3] = {X[0] / X[3], X[1] / X[3], X[2] / X[3]};
+  double a[3];
+  for (int r = 0; r < 3; ++r) a[r] = (((m[3 * r] * h[0] + m[3 * r + 1] * h[1]) + m[3 * r + 2] * h[2]) + m[9 + r]) - 1.0 * c[r];
+  RotTerms rt;
+  rotation_terms(d + 12, rt);
+  const double q[3] = {(rt.R[0] * a[0] + rt.R[1] * a[1]) + rt.R[2] * a[2], (rt.R[3] * a[0] + rt.R[4] * a[1]) + rt.R[5] * a[2],
+                       (rt.R[6] * a[0] + rt.R[7] * a[1]) + rt.R[8] * a[2]};
+  if (q[2] / 1.0 < 0.0) return DBL_MAX;
+  double uv[2], Jq[6];
+  project<false>((int)d[15], d + 16, q, uv, Jq);
+  const double ex = d[7] - uv[0], ey = d[8] - uv[1];
+  return ex * ex + ey * ey;
+}
+
 __device__ inline double model_error(int est, const double* m, const double* d) {
   if (est == THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE) return p4pfdev::reprojection_error(m, d);
   if (est == THEIA_EST_SIMILARITY_2D3D) return similarity_error(m, d);
+  if (est == THEIA_EST_RIGID_TRANSFORMATION_2D3D) return rigid_error(m, d);
   if (est == THEIA_EST_TRIANGULATION) return triangulation_error(m, d);
   if (est == THEIA_EST_RADIAL_HOMOGRAPHY) return rsc::radial_homography_error(m, d);
   if (est == THEIA_EST_RELATIVE_POSE) {
@@ -1360,13 +1382,13 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   }
   const bool gdls_est = est == THEIA_EST_SIMILARITY_2D3D;
   const bool dls_est = est == THEIA_EST_ABSOLUTE_POSE_DLS || gdls_est;   // the Macaulay pipeline: stage A -> eigen stage
-  if (est < 0 || est > THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
+  if (est < 0 || est > THEIA_EST_RIGID_TRANSFORMATION_2D3D) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
   const bool abs_pose = est == THEIA_EST_ABSOLUTE_POSE_KNEIP || est == THEIA_EST_ABSOLUTE_POSE_SQPNP || (dls_est && !gdls_est);
   // estimators that keep Estimator::RefineModel's default "return true" (solvers/estimator.h:86-88): LO only counts
   const bool trivial_refine = est == THEIA_EST_ESSENTIAL_MATRIX || est == THEIA_EST_DOMINANT_PLANE ||
                               est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION || est == THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION ||
                               est == THEIA_EST_TRIANGULATION || est == THEIA_EST_RADIAL_HOMOGRAPHY || est == THEIA_EST_SIMILARITY_2D3D ||
-                              est == THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE;
+                              est == THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE || est == THEIA_EST_RIGID_TRANSFORMATION_2D3D;
   const bool rel_pose = est == THEIA_EST_RELATIVE_POSE, uncal_pose = est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE;
   const bool homog = est == THEIA_EST_HOMOGRAPHY, fund = est == THEIA_EST_FUNDAMENTAL_MATRIX;
   // every estimator's RefineModel is built: BundleAdjustView (absolute pose), BundleAdjustTwoViewsAngular ((un)calibrated
@@ -1389,6 +1411,8 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   int rc = ensure_device();
   if (rc) return rc;
   if (dls_est && (rc = dls_ensure_tables())) return rc;
+  const bool upnp_est = est == THEIA_EST_RIGID_TRANSFORMATION_2D3D;
+  if (upnp_est && (rc = upnp_ensure_tables())) return rc;
   const int m = sample_size(est), ds = datum_size(est);
   const int64_t total = batch->offsets[nprob];
   int nmax = 0;
@@ -1466,6 +1490,11 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     HIP_TRYR(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   }
 
+  DBuf<double> d_upnp_state;   // UPnP: the estimator's accumulating cost parameters per problem (upnp_kernels.hip)
+  if (upnp_est) {
+    if ((rc = d_upnp_state.ensure((size_t)nprob * upnp_state_doubles()))) return rc;
+    HIP_TRYR(hipMemsetAsync(d_upnp_state.p, 0, sizeof(double) * (size_t)nprob * upnp_state_doubles(), st));
+  }
   std::vector<int> best_samples_all((size_t)nprob * kMaxSample, 0), best_slot_all(nprob, -1);
   std::vector<ProblemState> S(nprob);
   for (int p = 0; p < nprob; ++p) {
@@ -1670,6 +1699,10 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         else
           k_fit5_c<THEIA_EST_ESSENTIAL_MATRIX><<<grid, 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_sol.p,
                                                                    d_fp_mask.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
+      } else if (upnp_est) {
+        if ((rc = d_fp_ws.ensure(nh * (size_t)upnp_workspace_doubles()))) return rc;
+        launch_upnp_fit(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_upnp_state.p + (size_t)c0 * upnp_state_doubles(), d_fp_ws.p,
+                        d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p, st);
       } else if (est == THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE) {
         if ((rc = d_fp_ws.ensure(nh * kFpWs)) || (rc = d_fp_sol.ensure(nh * 50)) || (rc = d_fp_ok.ensure(nh)) || (rc = d_fp_mask.ensure(nh)))
           return rc;

@@ -37,6 +37,13 @@ void launch_dls_stage_a(bool gdls, int datum_stride, int nprob, int B, const int
                         hipStream_t st);
 void launch_dls_solve_a(int num, const int64_t* offsets, const double* feat, const double* world, const double* uvals, double* action,
                         double* tfac, int* okflag, hipStream_t st);
+// upnp_kernels.hip: the UPnP hypotheses of THEIA_EST_RIGID_TRANSFORMATION_2D3D for B iterations of nprob problems.  state: the
+// estimator's accumulating cost parameters, [nprob][upnp_state_doubles()], zero before the first round; ws: [nprob * B][upnp_workspace_doubles()]
+int upnp_ensure_tables();
+int upnp_workspace_doubles();
+int upnp_state_doubles();
+void launch_upnp_fit(int nprob, int B, const int64_t* offsets, const double* data, const int* samples, const int* active_iters,
+                     double* state, double* ws, double* models, int* counts, int* dense_count, int* tags, int* hyp_base, hipStream_t st);
 // ba_invdepth.hip: bundle adjustment with the inverse-depth track parametrisation (THEIA_BA_FLAG_INVERSE_DEPTH)
 int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_summary* S);
 // the same problem as a device-resident object behind the handle API (theia_hip_ba_create with THEIA_BA_FLAG_INVERSE_DEPTH)

@@ -37,6 +37,7 @@ EST_TRIANGULATION = 11
 EST_RADIAL_HOMOGRAPHY = 12
 EST_SIMILARITY_2D3D = 13
 EST_UNCALIBRATED_ABSOLUTE_POSE = 14
+EST_RIGID_TRANSFORMATION_2D3D = 15
 
 
 class RansacParameters:
@@ -150,7 +151,7 @@ def estimate_batch(estimator, data, offsets, params, estimator_params=None, seed
             "time_fit_seconds": r.time_fit_seconds, "time_score_seconds": r.time_score_seconds}
 
 
-_SAMPLE_SIZE = {0: 5, 1: 5, 2: 3, 3: 3, 4: 3, 5: 8, 6: 4, 7: 3, 8: 2, 9: 8, 10: 2, 11: 2, 12: 6, 13: 4, 14: 4}   # Estimator::SampleSize() by THEIA_EST_*
+_SAMPLE_SIZE = {0: 5, 1: 5, 2: 3, 3: 3, 4: 3, 5: 8, 6: 4, 7: 3, 8: 2, 9: 8, 10: 2, 11: 2, 12: 6, 13: 4, 14: 4, 15: 4}   # Estimator::SampleSize() by THEIA_EST_*
 
 
 def _single(estimator, ransac_params, ransac_type, data, estimator_params=None):
@@ -443,6 +444,39 @@ def EstimateSimilarityTransformation2D3D(ransac_params, ransac_type, corresponde
     rows = correspondences if isinstance(correspondences, np.ndarray) else similarity_correspondence_rows(correspondences, ray_directions)
     ok, m, s = _single(EST_SIMILARITY_2D3D, ransac_params, ransac_type, rows)
     return ok, SimilarityTransformation(m), s
+
+
+class RigidTransformation:  # sfm/rigid_transformation.h: rotation, translation
+    def __init__(self, m):
+        self.rotation = np.array(m[0:9]).reshape(3, 3)
+        self.translation = np.array(m[9:12])
+
+
+def central_correspondence_rows(normalized_correspondences):
+    """(N, 26) rows for the FeatureCorrespondence2D3D overload of EstimateRigidTransformation2D3D
+    (estimate_rigid_transformation_2d_3d.cc:159-182): [u v X Y Z] seen by identity pinhole cameras of focal length 1."""
+    c = np.ascontiguousarray(normalized_correspondences, dtype=np.float64).reshape(-1, 5)
+    out = np.zeros((c.shape[0], 26))
+    ray = np.concatenate([c[:, 0:2], np.ones((c.shape[0], 1))], axis=1)
+    out[:, 0:3] = ray / np.linalg.norm(ray, axis=1, keepdims=True)
+    out[:, 3:6] = c[:, 2:5]; out[:, 6] = 1.0
+    out[:, 7:9] = c[:, 0:2]
+    out[:, 15] = 0                      # THEIA_CAM_PINHOLE
+    out[:, 16] = 1.0; out[:, 17] = 1.0  # focal length, aspect ratio
+    return out
+
+
+def EstimateRigidTransformation2D3D(ransac_params, ransac_type, correspondences, ray_directions=None):
+    """estimate_rigid_transformation_2d_3d.cc:137-182 -> (success, RigidTransformation, summary).  correspondences: a list of
+    CameraAndFeatureCorrespondence2D3D, their (N, 26) rows, or (N, 5) normalised FeatureCorrespondence2D3D [u v X Y Z] (the
+    central-camera overload).  UPnP on four correspondences per sample; as in the reference the estimator's cost parameters
+    accumulate over the samples of the call (include/theia_hip.h)."""
+    if isinstance(correspondences, np.ndarray):
+        rows = central_correspondence_rows(correspondences) if correspondences.shape[1] == 5 else correspondences
+    else:
+        rows = similarity_correspondence_rows(correspondences, ray_directions)
+    ok, m, s = _single(EST_RIGID_TRANSFORMATION_2D3D, ransac_params, ransac_type, rows)
+    return ok, RigidTransformation(m), s
 
 
 class UncalibratedAbsolutePose:  # estimate_uncalibrated_absolute_pose.h:48-52

@@ -105,7 +105,7 @@ int datum_doubles(int estimator) {
     case THEIA_EST_DOMINANT_PLANE: return 3;
     case THEIA_EST_TRIANGULATION: return 33;
     case THEIA_EST_RADIAL_HOMOGRAPHY: return 12;
-    case THEIA_EST_SIMILARITY_2D3D: return 26;
+    case THEIA_EST_SIMILARITY_2D3D: case THEIA_EST_RIGID_TRANSFORMATION_2D3D: return 26;
     default: return 4;
   }
 }

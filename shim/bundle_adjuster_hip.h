@@ -145,5 +145,7 @@ inline bool EstimateTriangulationBatch(const RansacParameters& p, int t, const s
 inline bool EstimateRadialHomographyMatrixBatch(const RansacParameters& p, int t, const std::vector<std::vector<double>>& c12, EstimatorBatchResult* r, std::string* e) { return EstimateBatch(THEIA_EST_RADIAL_HOMOGRAPHY, t, p, c12, nullptr, r, e); }
 inline bool EstimateSimilarityTransformation2D3DBatch(const RansacParameters& p, int t, const std::vector<std::vector<double>>& c26, EstimatorBatchResult* r, std::string* e) { return EstimateBatch(THEIA_EST_SIMILARITY_2D3D, t, p, c26, nullptr, r, e); }
 
+inline bool EstimateRigidTransformation2D3DBatch(const RansacParameters& p, int t, const std::vector<std::vector<double>>& c26, EstimatorBatchResult* r, std::string* e) { return EstimateBatch(THEIA_EST_RIGID_TRANSFORMATION_2D3D, t, p, c26, nullptr, r, e); }
+
 }  // namespace theia_hip_shim
 #endif
