@@ -220,13 +220,18 @@ def ransac_block(cpu_baseline, host_cores, rank=0, world=1):
     # (all ten chunks: 40.96 M hypotheses, about half a minute)
     legs = (("five_point_relative_pose", ransac.EST_RELATIVE_POSE, "relative", (2.0 / 1000.0) ** 2, 2.5e4, 85.0, PAIRS // CHUNK),
             ("sqpnp_absolute_pose", ransac.EST_ABS_SQPNP, "absolute", (4.0 / 1000.0) ** 2, 3.0e4, 30.0, PAIRS // CHUNK),
-            ("dls_absolute_pose", ransac.EST_ABS_DLS, "absolute", (4.0 / 1000.0) ** 2, 1.35e6, 30.0, PAIRS // CHUNK))
+            ("dls_absolute_pose", ransac.EST_ABS_DLS, "absolute", (4.0 / 1000.0) ** 2, 1.35e6, 30.0, PAIRS // CHUNK),
+            # UPnP (EstimateRigidTransformation2D3D, central overload): one chunk; 2/3 141^3 + 2 141^2 8 = 2.2 MFLOP for the reference's
+            # Gauss-Jordan of the 141 x 149 template per solve (build_upnp_action_matrix_using_symmetry.cc:2487)
+            ("upnp_rigid_transformation", ransac.EST_RIGID_TRANSFORMATION_2D3D, "rigid", (4.0 / 1000.0) ** 2, 2.2e6, 40.0, 1))
     for name, est, kind, thresh, fit_flop, score_flop, nchunks in legs:
         p = ransac.RansacParameters(); p.error_thresh = thresh; p.min_iterations = HYPS; p.max_iterations = HYPS; p.seed = 1
         tot = {"hyp": 0, "models": 0, "wall": 0.0, "fit": 0.0, "score": 0.0, "kern": 0.0}
         first = None
         for c in range(rank, nchunks, world):   # (whole chunks of pairs per rank: same round-robin deal, coarser grain)
-            data, offsets, _ = synth.synth_ransac_v1(CHUNK, CORR, kind, seed=0x5AC50005 + 977 * c)
+            data, offsets, _ = synth.synth_ransac_v1(CHUNK, CORR, "absolute" if kind == "rigid" else kind, seed=0x5AC50005 + 977 * c)
+            if kind == "rigid":
+                data = ransac.central_correspondence_rows(data)   # [u v X Y Z] as seen by identity pinhole cameras (26 doubles per datum)
             if first is None:
                 ransac.estimate_batch(est, data[: offsets[8]], offsets[:9], p)  # warm-up
                 first = (data, offsets)
@@ -236,7 +241,7 @@ def ransac_block(cpu_baseline, host_cores, rank=0, world=1):
             tot["wall"] += time.perf_counter() - t0
             tot["hyp"] += int(res["hypotheses_evaluated"]); tot["models"] += int(res["models_scored"])
             tot["fit"] += res["time_fit_seconds"]; tot["score"] += res["time_score_seconds"]; tot["kern"] += res["time_fit_score_seconds"]
-        leg = {"hypotheses_per_sec": tot["hyp"] / tot["wall"],
+        leg = {"hypotheses_per_sec": tot["hyp"] / max(tot["wall"], 1e-12),   # (a rank that got no chunk of a short leg reports zeros)
                "hypotheses_per_sec_kernels_only": tot["hyp"] / max(tot["kern"], 1e-12),
                "hypotheses": tot["hyp"], "models_scored": tot["models"], "wall_s": tot["wall"],
                "kernel_s": {"fit": tot["fit"], "score": tot["score"]},
@@ -253,7 +258,7 @@ def ransac_block(cpu_baseline, host_cores, rank=0, world=1):
             from concurrent.futures import ThreadPoolExecutor
             from tests import oracle_lib as ol
             data, offsets = first
-            hy = 1024
+            hy = 1024 if est != ransac.EST_RIGID_TRANSFORMATION_2D3D else 256   # (the UPnP oracle: a dense 141 x 149 elimination per hypothesis)
 
             def one(i):
                 pc = p.to_c(); pc.min_iterations = hy; pc.max_iterations = hy; pc.seed = 1 + i

@@ -139,91 +139,124 @@ struct WgLds {
   double M1[192];
   double LU[49], inv[49], out[168];
   int perm[8];
-  double colbuf[2][kRowsPad];
+  double colbuf[2][kRowsPad];   // column k by POSITION
   double rowraw[2][kColsPad], rowbuf[2][kColsPad];
-  int posrow[kRowsPad];
   double blk[20][29];
 };
 
-// one elimination step with the pivot column at local index LC (0 while the registers still shift)
-template <int LC>
-__device__ __forceinline__ void gj_step(WgLds& L, double (&a)[kNRL][kNCL], int (&mypos)[kNRL], int k, int g, int rg) {
+// wave-wide reductions on the DPP network (rows of 16 lanes, then the four row results through v_readlane)
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_d(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+  v = fmax(v, dpp_move_d<0xB1>(v));    // quad_perm [1,0,3,2]
+  v = fmax(v, dpp_move_d<0x4E>(v));    // quad_perm [2,3,0,1]
+  v = fmax(v, dpp_move_d<0x141>(v));   // row_half_mirror
+  v = fmax(v, dpp_move_d<0x140>(v));   // row_mirror
+  return fmax(fmax(readlane_d(v, 0), readlane_d(v, 16)), fmax(readlane_d(v, 32), readlane_d(v, 48)));
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// One elimination step with the pivot column at local index LC (0 while the registers still shift) and NL live local columns
+// (the rest hold the zeros that were shifted in).  mypos[i]: the POSITION of the thread's row i in the reference's swapped row
+// order -- the column of step k is published by position, so the pivot search, the multipliers and the swap need no row table.
+template <int LC, int NL>
+__device__ __forceinline__ void gj_step(WgLds& L, double (&a)[kNRL][kNCL], int (&mypos)[kNRL], int k, int g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int gk = k & (kCG - 1), buf = k & 1;
   if (g == gk) {
 #pragma unroll
-    for (int i = 0; i < kNRL; ++i) L.colbuf[buf][kNRL * rg + i] = a[i][LC];
+    for (int i = 0; i < kNRL; ++i) L.colbuf[buf][mypos[i]] = a[i][LC];
   }
   __syncthreads();
+  double l[kNRL];
+#pragma unroll
+  for (int i = 0; i < kNRL; ++i) l[i] = L.colbuf[buf][mypos[i]];
   // first maximum over the positions k .. 139 (gauss_jordan.h:46-63 with ending_row = the last row: `row < ending_row`)
   int bpos = k;
   if (k < 140) {
     double babs = -1.0;
-    bpos = 1 << 20;
+    int mine = 1 << 20;
     for (int pos = k + lane; pos < 140; pos += 64) {
-      const double v = fabs(L.colbuf[buf][L.posrow[pos]]);
-      if (v > babs) { babs = v; bpos = pos; }
+      const double v = fabs(L.colbuf[buf][pos]);
+      if (v > babs) { babs = v; mine = pos; }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double oa = __shfl_xor(babs, off, 64);
-      const int op = __shfl_xor(bpos, off, 64);
-      if (oa > babs || (oa == babs && op < bpos)) { babs = oa; bpos = op; }
-    }
+    const double m = wave_max_d(babs);
+    bpos = wave_min_i(babs == m ? mine : (1 << 20));
   }
-  const int rp = L.posrow[bpos], rk = L.posrow[k];
-  const double piv = L.colbuf[buf][rp];
+  const double piv = L.colbuf[buf][bpos];
+  // the pivot row as it stands (three register-indexed copies, at most one taken), then the swap of the two positions
+  if (mypos[0] == bpos) {
 #pragma unroll
-  for (int i = 0; i < kNRL; ++i) {
-    const int row = kNRL * rg + i;
-    if (row == rp) mypos[i] = k; else if (row == rk) mypos[i] = bpos;
+    for (int j = 0; j < NL; ++j) L.rowraw[buf][kCG * j + g] = a[0][j];
+  } else if (mypos[1] == bpos) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) L.rowraw[buf][kCG * j + g] = a[1][j];
+  } else if (mypos[2] == bpos) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) L.rowraw[buf][kCG * j + g] = a[2][j];
   }
-  const int rgp = rp / kNRL, slot = rp - kNRL * rgp;
-  if (rg == rgp) {   // the pivot row as it stands (three register-indexed copies, one taken)
-    if (slot == 0) {
 #pragma unroll
-      for (int j = 0; j < kNCL; ++j) L.rowraw[buf][kCG * j + g] = a[0][j];
-    } else if (slot == 1) {
-#pragma unroll
-      for (int j = 0; j < kNCL; ++j) L.rowraw[buf][kCG * j + g] = a[1][j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < kNCL; ++j) L.rowraw[buf][kCG * j + g] = a[2][j];
-    }
-  }
+  for (int i = 0; i < kNRL; ++i) mypos[i] = mypos[i] == bpos ? k : (mypos[i] == k ? bpos : mypos[i]);
   __syncthreads();
-  if (tid == 0) { L.posrow[k] = rp; L.posrow[bpos] = rk; }   // (read again only after the next step's first barrier)
-  if (tid < kColsPad) L.rowbuf[buf][tid] = (tid == kCG * LC + gk) ? 1.0 : L.rowraw[buf][tid] / piv;   // row /= pivot; (k, k) = 1
+  if (tid < kCG * NL) L.rowbuf[buf][tid] = (tid == kCG * LC + gk) ? 1.0 : L.rowraw[buf][tid] / piv;   // row /= pivot; (k, k) = 1
   __syncthreads();
-  double prow[kNCL];
+  double prow[NL];
 #pragma unroll
-  for (int j = 0; j < kNCL; ++j) prow[j] = L.rowbuf[buf][kCG * j + g];
-  if (rg == rgp) {
-    if (slot == 0) {
+  for (int j = 0; j < NL; ++j) prow[j] = L.rowbuf[buf][kCG * j + g];
+  if (mypos[0] == k) {
 #pragma unroll
-      for (int j = 0; j < kNCL; ++j) a[0][j] = prow[j];
-    } else if (slot == 1) {
+    for (int j = 0; j < NL; ++j) a[0][j] = prow[j];
+  } else if (mypos[1] == k) {
 #pragma unroll
-      for (int j = 0; j < kNCL; ++j) a[1][j] = prow[j];
-    } else {
+    for (int j = 0; j < NL; ++j) a[1][j] = prow[j];
+  } else if (mypos[2] == k) {
 #pragma unroll
-      for (int j = 0; j < kNCL; ++j) a[2][j] = prow[j];
-    }
+    for (int j = 0; j < NL; ++j) a[2][j] = prow[j];
   }
 #pragma unroll
   for (int i = 0; i < kNRL; ++i) {
-    const double l = L.colbuf[buf][kNRL * rg + i];
-    if (mypos[i] > k && !(fabs(l) < 1e-9)) {
+    if (mypos[i] > k && !(fabs(l[i]) < 1e-9)) {
 #pragma unroll
-      for (int j = 0; j < kNCL; ++j) a[i][j] = a[i][j] - l * prow[j];
+      for (int j = 0; j < NL; ++j) a[i][j] = a[i][j] - l[i] * prow[j];
     }
   }
 }
 
-template <int LC>
-__device__ __forceinline__ void gj_steps(WgLds& L, double (&a)[kNRL][kNCL], int (&mypos)[kNRL], int k0, int k1, int g, int rg) {
+template <int LC, int NL>
+__device__ __forceinline__ void gj_steps(WgLds& L, double (&a)[kNRL][kNCL], int (&mypos)[kNRL], int k0, int k1, int g) {
 #pragma nounroll
-  for (int k = k0; k < k1; ++k) gj_step<LC>(L, a, mypos, k, g, rg);
+  for (int k = k0; k < k1; ++k) gj_step<LC, NL>(L, a, mypos, k, g);
+}
+
+// eight steps on local column 0, then the registers move one column down
+template <int NL>
+__device__ __forceinline__ void gj_block(WgLds& L, double (&a)[kNRL][kNCL], int (&mypos)[kNRL], int s0, int s1, int g) {
+#pragma nounroll
+  for (int s = s0; s < s1; ++s) {
+    gj_steps<0, NL>(L, a, mypos, kCG * s, kCG * s + kCG, g);
+    if (s < kMaxShift) {
+#pragma unroll
+      for (int i = 0; i < kNRL; ++i) {
+#pragma unroll
+        for (int j = 0; j + 1 < NL; ++j) a[i][j] = a[i][j + 1];
+        a[i][NL - 1] = 0.0;
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(kThreads) void k_upnp_a(int B, const int* __restrict__ active_iters, double* __restrict__ ws) {
@@ -233,7 +266,6 @@ __global__ __launch_bounds__(kThreads) void k_upnp_a(int B, const int* __restric
   double* w = ws + ((size_t)p * B + b) * kWs;
   const int tid = threadIdx.x, g = tid / kRG, rg = tid % kRG;
   if (tid < kStateDoubles) L.Ab[tid] = w[kWsA + tid];
-  if (tid < kRowsPad) L.posrow[tid] = tid;
   __syncthreads();
   // ---- the input matrix (build_upnp_action_matrix_using_symmetry.cc:2349-2468)
   if (tid < 96) {
@@ -319,22 +351,15 @@ __global__ __launch_bounds__(kThreads) void k_upnp_a(int B, const int* __restric
       a[i][j] = s == 255 ? 0.0 : L.M1[s];
     }
   }
-  // ---- GaussJordan(140, 121): top-down over all 141 rows
-#pragma nounroll
-  for (int s = 0; s <= kMaxShift; ++s) {
-    gj_steps<0>(L, a, mypos, kCG * s, kCG * s + kCG, g, rg);
-    if (s < kMaxShift) {
-#pragma unroll
-      for (int i = 0; i < kNRL; ++i) {
-#pragma unroll
-        for (int j = 0; j + 1 < kNCL; ++j) a[i][j] = a[i][j + 1];
-        a[i][kNCL - 1] = 0.0;
-      }
-    }
-  }
-  gj_steps<1>(L, a, mypos, 120, 128, g, rg);
-  gj_steps<2>(L, a, mypos, 128, 136, g, rg);
-  gj_steps<3>(L, a, mypos, 136, 141, g, rg);
+  // ---- GaussJordan(140, 121): top-down over all 141 rows.  After s shifts the local column j stands for 8 (j + s) + g <= 148,
+  // i.e. 19 - s live registers per row
+  gj_block<19>(L, a, mypos, 0, 4, g);
+  gj_block<15>(L, a, mypos, 4, 8, g);
+  gj_block<11>(L, a, mypos, 8, 12, g);
+  gj_block<7>(L, a, mypos, 12, kMaxShift + 1, g);
+  gj_steps<1, 5>(L, a, mypos, 120, 128, g);
+  gj_steps<2, 5>(L, a, mypos, 128, 136, g);
+  gj_steps<3, 5>(L, a, mypos, 136, 141, g);
   // ---- bottom-up over the rows 140 .. 121 (gauss_jordan.h:152-193), columns 121 .. 148 (the others are never read again)
 #pragma unroll
   for (int i = 0; i < kNRL; ++i) {

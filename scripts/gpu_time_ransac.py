@@ -14,8 +14,11 @@ est, kind, thr = {"five_point": (ransac.EST_RELATIVE_POSE, "relative", (2.0 / 10
                   "homography": (ransac.EST_HOMOGRAPHY, "relative", (2.0 / 1000.0) ** 2),
                   "essential": (ransac.EST_ESSENTIAL_MATRIX, "relative", (2.0 / 1000.0) ** 2),
                   "p4pf": (ransac.EST_UNCALIBRATED_ABSOLUTE_POSE, "absolute", (4.0 / 1000.0) ** 2),
+                  "upnp": (ransac.EST_RIGID_TRANSFORMATION_2D3D, "absolute", (4.0 / 1000.0) ** 2),
                   "kneip": (ransac.EST_ABS_KNEIP, "absolute", (4.0 / 1000.0) ** 2)}[leg]
 data, offsets, _ = synth.synth_ransac_v1(NP, 2000, kind, seed=0x5AC50005)
+if leg == "upnp":
+    data = ransac.central_correspondence_rows(data)   # [u v X Y Z] seen by identity pinhole cameras (the central overload)
 p = ransac.RansacParameters(); p.error_thresh = thr; p.min_iterations = 4096; p.max_iterations = 4096; p.seed = 1
 ransac.estimate_batch(est, data[:offsets[8]], offsets[:9], p)
 t0 = time.perf_counter()

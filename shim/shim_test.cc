@@ -143,6 +143,41 @@ int main() {
     }
     std::printf("ok calibrated absolute pose batches\n");
   }
+  // ---- EstimateRigidTransformation2D3D (UPnP), the central overload: [u v X Y Z] as 26-double rows of identity pinhole cameras.
+  // No outliers: the reference's estimator accumulates its cost parameters over the samples (include/theia_hip.h), so it is not robust
+  {
+    std::vector<std::vector<double>> c26(4);
+    std::vector<std::vector<double>> ttrue(4);
+    for (int p = 0; p < 4; ++p) {
+      const double w[3] = {0.2 * U(gen), 0.2 * U(gen), 0.2 * U(gen)};
+      const double c[3] = {U(gen), U(gen), -6.0 + U(gen)};
+      const double mc[3] = {-c[0], -c[1], -c[2]};
+      double t[3];
+      rotate(w, mc, t);                        // R X + t with t = -R c
+      ttrue[p] = {t[0], t[1], t[2]};
+      for (int i = 0; i < 200; ++i) {
+        const double X[3] = {2 * U(gen), 2 * U(gen), 2 * U(gen)};
+        const double d[3] = {X[0] - c[0], X[1] - c[1], X[2] - c[2]};
+        double q[3];
+        rotate(w, d, q);
+        const double u = q[0] / q[2] + 2e-4 * N(gen), v = q[1] / q[2] + 2e-4 * N(gen);
+        const double n = std::sqrt(u * u + v * v + 1.0);
+        double row[26] = {u / n, v / n, 1.0 / n, X[0], X[1], X[2], 1.0, u, v, 0, 0, 0, 0, 0, 0, (double)THEIA_CAM_PINHOLE, 1.0, 1.0, 0, 0, 0, 0, 0, 0, 0, 0};
+        c26[p].insert(c26[p].end(), row, row + 26);
+      }
+    }
+    RansacParameters up;
+    up.error_thresh = 2e-3 * 2e-3; up.min_iterations = 100; up.max_iterations = 500; up.seed = 21;
+    EstimatorBatchResult ur; std::string uerr;
+    if (!EstimateRigidTransformation2D3DBatch(up, THEIA_RANSAC_RANSAC, c26, &ur, &uerr)) { std::printf("FAIL: %s\n", uerr.c_str()); return 1; }
+    for (int p = 0; p < 4; ++p) {
+      double terr = 0.0;
+      for (int i = 0; i < 3; ++i) terr = std::fmax(terr, std::fabs(ur.models[p][9 + i] - ttrue[p][i]));
+      std::printf("rigid transformation (UPnP) %d: success %d, %zu inliers of 200, translation error %.2e\n", p, (int)ur.success[p], ur.summaries[p].inliers.size(), terr);
+      if (!ur.success[p] || ur.summaries[p].inliers.size() < 150 || !(terr < 0.05)) { std::printf("FAIL: rigid transformation\n"); return 1; }
+    }
+    std::printf("ok rigid transformation batch\n");
+  }
   // ---- the generic front end under the reference's other names: fundamental matrix on the relative-pose pairs (pixels)
   {
     std::vector<std::vector<double>> px = corr;
