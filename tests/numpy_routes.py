@@ -231,3 +231,189 @@ def ransac_inlier_support(samples, fit, errors, thresh, ndata):
             if cost < best_cost:
                 best_cost, best, mask = cost, m, inl
     return mask, best
+
+
+# ------------------------------------------------------------------------------------------------ more estimators (round 4)
+def sampson_errors(F, x1h, x2h):
+    """SquaredSampsonDistance (pose/util.cc:56-68) for a matrix with x2^T F x1 = 0, vectorised."""
+    Fx1 = x1h @ F.T; Ftx2 = x2h @ F
+    num = (x2h * Fx1).sum(1) ** 2
+    return num / (Fx1[:, 0] ** 2 + Fx1[:, 1] ** 2 + Ftx2[:, 0] ** 2 + Ftx2[:, 1] ** 2)
+
+
+def _normalise(pts):
+    """NormalizeImagePoints (pose/util.cc:81-112): centroid to the origin, RMS distance sqrt(2)."""
+    c = pts.mean(0)
+    s = np.sqrt(2.0) / np.sqrt(((pts - c) ** 2).sum() / len(pts))
+    T = np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1.0]])
+    return (pts - c) * s, T
+
+
+def eight_point(x1, x2):
+    """NormalizedEightPointFundamentalMatrix (pose/eight_point_fundamental_matrix.cc:54-120): the null vector of the 8 x 9
+    constraint matrix by numpy's SVD (the reference: FullPivLU kernel), rank 2 by SVD, normalisation undone."""
+    n1, T1 = _normalise(x1); n2, T2 = _normalise(x2)
+    A = np.c_[n2[:, :1] * n1, n2[:, :1], n2[:, 1:2] * n1, n2[:, 1:2], n1, np.ones(len(n1))]
+    _, s, Vt = np.linalg.svd(A)
+    if len(n1) == 8 and s[7] < 1e-12 * s[0]:
+        return []                                  # dimensionOfKernel() != 1
+    F = Vt[-1].reshape(3, 3)
+    U, sv, Vt2 = np.linalg.svd(F)
+    F = U @ np.diag([sv[0], sv[1], 0.0]) @ Vt2
+    return [T2.T @ F @ T1]
+
+
+def four_point_homography(x1, x2):
+    """FourPointHomography (pose/four_point_homography.cc:69-102): DLT on normalised points, null vector of A^T A."""
+    n1, T1 = _normalise(x1); n2, T2 = _normalise(x2)
+    rows = []
+    for (a, b), (u, v) in zip(n1, n2):
+        rows.append([0, 0, 0, -a, -b, -1, a * v, b * v, v])
+        rows.append([a, b, 1, 0, 0, 0, -a * u, -b * u, -u])
+    A = np.array(rows)
+    w, V = np.linalg.eigh(A.T @ A)
+    return [np.linalg.inv(T2) @ V[:, 0].reshape(3, 3) @ T1]
+
+
+def homography_errors(H, x1h, x2):
+    p = x1h @ H.T
+    return ((x2 - p[:, :2] / p[:, 2:3]) ** 2).sum(1)
+
+
+def p3p_kneip(feat, world):
+    """PoseFromThreePoints (pose/perspective_three_point.cc:56-300) re-typed from Kneip's paper: the quartic in cos(theta) solved by
+    np.roots (LAPACK's eigenvalues of the companion matrix; the reference: its own companion-matrix solver), and -- as the reference
+    does -- the REAL PARTS of all four roots are back-substituted.  Returns [(R, t)] with x ~ R X + t."""
+    f = np.c_[feat, np.ones(3)]
+    f = f / np.linalg.norm(f, axis=1, keepdims=True)
+    P = np.array(world, dtype=np.float64)
+    if (np.cross(P[1] - P[0], P[2] - P[0]) ** 2).sum() < 1e-6:
+        return []
+
+    def cam_frame(f):
+        e1 = f[0]
+        e3 = np.cross(f[0], f[1]); e3 /= np.linalg.norm(e3)
+        return np.array([e1, np.cross(e3, e1), e3])
+    T = cam_frame(f)
+    f3 = T @ f[2]
+    if f3[2] > 0:
+        f = f[[1, 0, 2]]; P = P[[1, 0, 2]]
+        T = cam_frame(f)
+        f3 = T @ f[2]
+    n1 = (P[1] - P[0]) / np.linalg.norm(P[1] - P[0])
+    n3 = np.cross(n1, P[2] - P[0]); n3 /= np.linalg.norm(n3)
+    N = np.array([n1, np.cross(n3, n1), n3])
+    P3 = N @ (P[2] - P[0])
+    d12 = np.linalg.norm(P[1] - P[0])
+    f1, f2 = f3[0] / f3[2], f3[1] / f3[2]
+    p1, p2 = P3[0], P3[1]
+    cb = f[0] @ f[1]
+    b = 1.0 / (1.0 - cb * cb) - 1.0
+    b = -np.sqrt(b) if cb < 0 else np.sqrt(b)
+    c = [-f2 ** 2 * p2 ** 4 - p2 ** 4 * f1 ** 2 - p2 ** 4,
+         2 * p2 ** 3 * d12 * b + 2 * f2 ** 2 * p2 ** 3 * d12 * b - 2 * f2 * p2 ** 3 * f1 * d12,
+         -f2 ** 2 * p2 ** 2 * p1 ** 2 - f2 ** 2 * p2 ** 2 * d12 ** 2 * b ** 2 - f2 ** 2 * p2 ** 2 * d12 ** 2 + f2 ** 2 * p2 ** 4 + p2 ** 4 * f1 ** 2
+         + 2 * p1 * p2 ** 2 * d12 + 2 * f1 * f2 * p1 * p2 ** 2 * d12 * b - p2 ** 2 * p1 ** 2 * f1 ** 2 + 2 * p1 * p2 ** 2 * f2 ** 2 * d12
+         - p2 ** 2 * d12 ** 2 * b ** 2 - 2 * p1 ** 2 * p2 ** 2,
+         2 * p1 ** 2 * p2 * d12 * b + 2 * f2 * p2 ** 3 * f1 * d12 - 2 * f2 ** 2 * p2 ** 3 * d12 * b - 2 * p1 * p2 * d12 ** 2 * b,
+         -2 * f2 * p2 ** 2 * f1 * p1 * d12 * b + f2 ** 2 * p2 ** 2 * d12 ** 2 + 2 * p1 ** 3 * d12 - p1 ** 2 * d12 ** 2 + f2 ** 2 * p2 ** 2 * p1 ** 2
+         - p1 ** 4 - 2 * f2 ** 2 * p2 ** 2 * p1 * d12 + p2 ** 2 * f1 ** 2 * p1 ** 2 + f2 ** 2 * p2 ** 2 * d12 ** 2 * b ** 2]
+    out = []
+    with np.errstate(all="ignore"):
+        for ct in np.real(np.roots(c)):
+            cot = (-f1 * p1 / f2 - ct * p2 + d12 * b) / (-f1 * ct * p2 / f2 + p1 - d12)
+            st = np.sqrt(1 - ct * ct)
+            sa = np.sqrt(1 / (cot * cot + 1)); ca = np.sqrt(1 - sa * sa)
+            if cot < 0:
+                ca = -ca
+            C = P[0] + N.T @ np.array([d12 * ca * (sa * b + ca), ct * d12 * sa * (sa * b + ca), st * d12 * sa * (sa * b + ca)])
+            Q = np.array([[-ca, -sa * ct, -sa * st], [sa, -ca * ct, -ca * st], [0, -st, ct]])
+            R = (N.T @ Q.T @ T).T
+            out.append((R, -R @ C))
+    return out
+
+
+class UpnpRoute:
+    """EstimateRigidTransformation2D3D's hypotheses (pose/upnp.cc) with numpy / LAPACK: the cost parameters from the paper's
+    formulas in matrix form, the input equations by generic polynomial differentiation of the quartic cost, the reference's
+    141 x 149 template (layout: oracle/upnp_layout.h, data) reduced by ONE np.linalg.solve instead of its Gauss-Jordan, the
+    action matrix' eigenvectors by np.linalg.eig.  The estimator's accumulating state (upnp.cc:191-200) is kept.  Complex
+    eigenvector pairs are skipped: their real parts depend on the phase convention of the eigen-solver (Eigen: hqr2's)."""
+    S = [(2, 0, 0, 0), (0, 2, 0, 0), (0, 0, 2, 0), (0, 0, 0, 2), (1, 1, 0, 0), (1, 0, 1, 0), (1, 0, 0, 1), (0, 1, 1, 0), (0, 1, 0, 1), (0, 0, 1, 1)]
+
+    def __init__(self, layout_path):
+        import re
+        txt = open(layout_path).read()
+        self.row_eq = [int(v) for v in re.search(r"kRowEq\[141\] = \{(.*?)\};", txt, re.S).group(1).split(",")]
+        quad = lambda name: np.array([[int(v) for v in m] for m in re.findall(r"\{(-?\d+), (-?\d+), (-?\d+), (-?\d+)\}", re.search(name + r"\[\d+\]\[4\] = \{(.*?)\};", txt, re.S).group(1))])
+        self.row_mul, self.col_mono = quad("kRowMul"), quad("kColMono")
+        cubic = sorted(((a, b, c, d) for a in range(4) for b in range(4) for c in range(4) for d in range(4) if a + b + c + d == 3), key=lambda e: (e[3], e[2], e[1]))
+        self.mono = cubic + [(1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1)]
+        col_of = {tuple(e): c for c, e in enumerate(self.col_mono)}
+        self.place = []
+        for r in range(141):
+            eq = self.row_eq[r]
+            sup = [10, 12, 15, 19, 23] if eq == 7 else sorted({eq, 7, 8, 9} | set(range(11, 24)))
+            for j in sup:
+                self.place.append((r, col_of[tuple(self.row_mul[r] + np.array(self.mono[j]))], eq, j))
+        self.A = np.zeros((10, 10)); self.b = np.zeros(10)
+
+    @staticmethod
+    def _phi(X):
+        x, y, z = X
+        return np.array([[x, x, -x, -x, 0, 2 * z, -2 * y, 2 * y, 2 * z, 0],
+                         [y, -y, y, -y, -2 * z, 0, 2 * x, 2 * x, 0, 2 * z],
+                         [z, -z, -z, z, 2 * y, -2 * x, 0, 0, 2 * x, 2 * y]])
+
+    def fit(self, origin, direction, world):
+        n = len(world)
+        F = [np.outer(f, f) for f in direction]
+        H = np.linalg.inv(n * np.eye(3) - sum(F))
+        V = [H @ (Fi - np.eye(3)) for Fi in F]
+        Phi = [self._phi(X) for X in world]
+        G = sum(Vi @ Pi for Vi, Pi in zip(V, Phi)); J = sum(Vi @ o for Vi, o in zip(V, origin))
+        for Fi, Pi, o in zip(F, Phi, origin):
+            Ai = (Fi - np.eye(3)) @ (Pi + G); bi = -(Fi - np.eye(3)) @ (o + J)
+            self.A += Ai.T @ Ai; self.b += Ai.T @ bi
+        # gradient of s^T A s + 2 b^T s in the quaternion, by polynomial arithmetic on exponent 4-tuples
+        cost = {}
+        for p in range(10):
+            for q in range(10):
+                e = tuple(x + y for x, y in zip(self.S[p], self.S[q]))
+                cost[e] = cost.get(e, 0.0) + self.A[p, q]
+            cost[self.S[p]] = cost.get(self.S[p], 0.0) + 2.0 * self.b[p]
+        M = np.zeros((8, 24))
+        for i in range(4):
+            for e, c in cost.items():
+                if e[i]:
+                    d = list(e); d[i] -= 1
+                    M[i, self.mono.index(tuple(d))] += e[i] * c
+            for k in range(4):
+                e = [0, 0, 0, 0]; e[k] += 2; e[i] += 1
+                M[4 + i, self.mono.index(tuple(e))] = 1.0
+            M[4 + i, 20 + i] = -1.0
+        M[:7] = np.linalg.solve(M[:7, :7], M[:7])
+        M[:7] -= np.outer(M[:7, 10] / M[7, 10], M[7])
+        T = np.zeros((141, 149))
+        for r, c, eq, j in self.place:
+            T[r, c] = M[eq, j]
+        Xr = np.linalg.solve(T[:, :141], T[:, 141:])
+        act = np.zeros((8, 8)); act[:4] = -Xr[121:125]; act[4:, :4] = np.eye(4)
+        w, Vec = np.linalg.eig(act)
+        quats = []
+        for k in range(8):
+            if abs(w[k].imag) > abs(w[k].real) * 1e-12:
+                continue
+            q = np.real(Vec[4:8, k]); q = q / np.linalg.norm(q)
+            if not any(2 * np.arctan2(np.linalg.norm(q[0] * -p[1:] + p[0] * q[1:] + np.cross(q[1:], -p[1:])), abs(q @ p)) < np.deg2rad(0.1) for p in quats):
+                quats.append(q)
+        out = []
+        for q in quats:
+            w0, x, y, z = q
+            R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w0), 2 * (x * z + y * w0)],
+                          [2 * (x * y + z * w0), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w0)],
+                          [2 * (x * z - y * w0), 2 * (y * z + x * w0), 1 - 2 * (x * x + y * y)]])
+            t = sum(Vi @ (R @ X - o) for Vi, X, o in zip(V, world, origin))
+            if all(((R @ X + t - o) @ f) >= 0 for X, o, f in zip(world, origin, direction)):   # in front, seen along the ray
+                out.append((R, t))
+        return out

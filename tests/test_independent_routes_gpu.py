@@ -5,6 +5,8 @@ device with an oracle that keeps the device's operation order; here the arithmet
 numpy's SVD), so an inlier set can legitimately move by a correspondence whose residual sits within rounding of the
 threshold, or to an equally supported model.  What is asserted is the COUNT of pairs with identical inlier sets and that
 the support never differs by more than a few correspondences (VERDICT r3, item 9 iii)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -27,6 +29,39 @@ def _replay(leg, data, offsets, thr, seed0):
             samples = ol.sampler_stream(seed0 + i, len(d), 5, HYPS)
             fit = lambda it, idx: nr.relative_pose_models(x1[idx], x2[idx], nr.five_point)
             err = lambda m: nr.relative_pose_errors(m, x1h, x2h)
+        elif leg == "essential":                      # EssentialMatrixEstimator: the same solver, pure Sampson error (no cheirality)
+            x1, x2 = d[:, :2], d[:, 2:4]
+            x1h = np.c_[x1, np.ones(len(d))]; x2h = np.c_[x2, np.ones(len(d))]
+            samples = ol.sampler_stream(seed0 + i, len(d), 5, HYPS)
+            fit = lambda it, idx: nr.five_point(x1[idx], x2[idx])
+            err = lambda E: nr.sampson_errors(E, x1h, x2h)
+        elif leg == "fundamental":
+            x1, x2 = d[:, :2], d[:, 2:4]
+            x1h = np.c_[x1, np.ones(len(d))]; x2h = np.c_[x2, np.ones(len(d))]
+            samples = ol.sampler_stream(seed0 + i, len(d), 8, HYPS)
+            fit = lambda it, idx: nr.eight_point(x1[idx], x2[idx])
+            err = lambda F: nr.sampson_errors(F, x1h, x2h)
+        elif leg == "homography":
+            x1, x2 = d[:, :2], d[:, 2:4]
+            x1h = np.c_[x1, np.ones(len(d))]
+            samples = ol.sampler_stream(seed0 + i, len(d), 4, HYPS)
+            fit = lambda it, idx: nr.four_point_homography(x1[idx], x2[idx])
+            err = lambda H: nr.homography_errors(H, x1h, x2)
+        elif leg == "p3p":
+            feat, world = d[:, :2], d[:, 2:5]
+            samples = ol.sampler_stream(seed0 + i, len(d), 3, HYPS)
+            fit = lambda it, idx: nr.p3p_kneip(feat[idx], world[idx])
+            err = lambda m: nr.absolute_pose_errors(m, feat, world)
+        elif leg == "upnp":                           # the central overload: identity pinhole cameras, 26-double rows
+            feat, world = d[:, 7:9], d[:, 3:6]
+            route = nr.UpnpRoute(os.path.join(os.path.dirname(__file__), "..", "oracle", "upnp_layout.h"))
+            samples = ol.sampler_stream(seed0 + i, len(d), 4, HYPS)
+            fit = lambda it, idx, route=route: route.fit(d[idx, 9:12], d[idx, 0:3], world[idx])
+            def err(m):
+                pc = world @ m[0].T + m[1]
+                e = ((pc[:, :2] / pc[:, 2:3] - feat) ** 2).sum(1)
+                e[pc[:, 2] < 0] = np.inf
+                return e
         else:
             feat, world = d[:, :2], d[:, 2:5]
             samples = ol.sampler_stream(seed0 + i, len(d), 3, HYPS)
@@ -37,11 +72,37 @@ def _replay(leg, data, offsets, thr, seed0):
     return out
 
 
-@pytest.mark.parametrize("leg", ["five_point", "dls"])
+def _planar_pairs(seed):
+    """NP pairs of a plane seen by two views: x2 ~ H x1 with 1e-3 noise, 30 % outliers (normalised coordinates)."""
+    rng = np.random.default_rng(seed)
+    data, offsets = [], [0]
+    for _ in range(NP):
+        R = synth.angle_axis_to_matrix(rng.normal(0, 0.15, 3)); t = rng.normal(0, 0.3, 3); n = np.array([0.1 * rng.normal(), 0.1 * rng.normal(), 1.0])
+        H = R + np.outer(t, n) / 4.0
+        x1 = rng.uniform(-0.5, 0.5, (CORR, 2))
+        p = np.c_[x1, np.ones(CORR)] @ H.T
+        x2 = p[:, :2] / p[:, 2:3] + rng.normal(0, 1e-3, (CORR, 2))
+        out = rng.uniform(size=CORR) < 0.3
+        x2[out] = rng.uniform(-0.6, 0.6, (int(out.sum()), 2))
+        data.append(np.c_[x1, x2]); offsets.append(offsets[-1] + CORR)
+    return np.concatenate(data), np.array(offsets, dtype=np.int64)
+
+
+@pytest.mark.parametrize("leg", ["five_point", "dls", "essential", "fundamental", "homography", "p3p", "upnp"])
 def test_c5_shape_inlier_sets_against_an_independent_numpy_route(leg):
     est, kind, thr = {"five_point": (ransac.EST_RELATIVE_POSE, "relative", (2.0 / 1000.0) ** 2),
-                      "dls": (ransac.EST_ABS_DLS, "absolute", (4.0 / 1000.0) ** 2)}[leg]
-    data, offsets, truth = synth.synth_ransac_v1(NP, CORR, kind, seed=0x5AC50005)
+                      "dls": (ransac.EST_ABS_DLS, "absolute", (4.0 / 1000.0) ** 2),
+                      "essential": (ransac.EST_ESSENTIAL_MATRIX, "relative", (2.0 / 1000.0) ** 2),
+                      "fundamental": (ransac.EST_FUNDAMENTAL_MATRIX, "relative", (2.0 / 1000.0) ** 2),
+                      "homography": (ransac.EST_HOMOGRAPHY, "planar", (3.0 / 1000.0) ** 2),
+                      "p3p": (ransac.EST_ABS_KNEIP, "absolute", (4.0 / 1000.0) ** 2),
+                      "upnp": (ransac.EST_RIGID_TRANSFORMATION_2D3D, "absolute", (4.0 / 1000.0) ** 2)}[leg]
+    if kind == "planar":
+        data, offsets = _planar_pairs(0x5AC5)
+    else:
+        data, offsets, truth = synth.synth_ransac_v1(NP, CORR, kind, seed=0x5AC50005)
+    if leg == "upnp":
+        data = ransac.central_correspondence_rows(data)
     p = ransac.RansacParameters(); p.error_thresh = thr; p.min_iterations = HYPS; p.max_iterations = HYPS; p.seed = 1
     res = ransac.estimate_batch(est, data, offsets, p)
     masks = _replay(leg, data, offsets, thr, p.seed)
