@@ -597,7 +597,20 @@ enum {
    * As in the reference, the estimator's UPnP cost parameters ACCUMULATE over the samples of one Estimate() call (upnp.cc:191-200
    * adds to a member of the one Upnp object the estimator keeps): hypothesis k is solved from the samples 0 .. k.
    * model = RigidTransformation: rotation (9, row-major), translation (3). */
-  THEIA_EST_RIGID_TRANSFORMATION_2D3D = 15
+  THEIA_EST_RIGID_TRANSFORMATION_2D3D = 15,
+  /* EstimateRadialDistUncalibratedAbsolutePose (estimate_radial_dist_uncalibrated_absolute_pose.cc:163-189): datum =
+   * FeatureCorrespondence2D3D [u v X Y Z] (pixels with the principal point removed, as they were observed: distorted); sample = 4;
+   * EstimateModel = FourPointsPoseFocalLengthRadialDistortion (pose/four_point_focal_length_radial_distortion.cc:68-288 and
+   * _helper.cc: the 40 x 50 elimination template reduced through Eigen::FullPivLU of its transposed 37 x 40 block, 13 x 13 action
+   * matrix), up to 13 models; Error = squared distance between the feature and the projection distorted by the division model,
+   * 1e10 when the translation's z is negative (:130-147).  estimator_params (required) = RadialDistUncalibratedAbsolutePoseMetaData
+   * {max_focal_length, min_focal_length, max_radial_distortion, min_radial_distortion} and a fifth entry "first call of the
+   * process" (0 / 1).  The solver multiplies its null-space basis by a "random rotation" made from three RandDouble(-0.5, 0.5)
+   * (:134-141), and every RandomNumberGenerator object of the reference shares ONE std::mt19937 (util/random.cc:46-66): the draws
+   * come out of the SAMPLER's stream, three after every sample -- reproduced here; with the fifth entry set, the stream is re-seeded
+   * with 42 after the first sample, as the solver's function-static RandomNumberGenerator(42) does the first time it runs in a
+   * process.  model = rotation (9, row-major), translation (3), focal_length, radial_distortion. */
+  THEIA_EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE = 16
 };
 
 /* A batch of independent estimation problems ("pairs").  Datum layout:
@@ -610,14 +623,15 @@ enum {
  *   triangulation: one observation with its camera, 33 doubles (THEIA_EST_TRIANGULATION)
  *   radial-distortion homography: RadialDistortionFeatureCorrespondence, 12 doubles (THEIA_EST_RADIAL_HOMOGRAPHY)
  *   similarity 2D-3D, rigid transformation 2D-3D: CameraAndFeatureCorrespondence2D3D, 26 doubles (THEIA_EST_SIMILARITY_2D3D)
- *   uncalibrated absolute pose: FeatureCorrespondence2D3D = [u v X Y Z], pixels with the principal point removed */
+ *   uncalibrated absolute pose (with or without radial distortion): FeatureCorrespondence2D3D = [u v X Y Z], pixels with the
+ *     principal point removed */
 typedef struct theia_ransac_batch {
   int32_t estimator;           /* THEIA_EST_*                              */
   int32_t num_problems;
   const int64_t* offsets;      /* [num_problems+1] datum offsets           */
   const double* data;          /* [offsets[num_problems]][datum_size]      */
   const double* estimator_params; /* estimator constants (see THEIA_EST_*), or NULL; required (not NULL) for
-                                   * THEIA_EST_UNCALIBRATED_RELATIVE_POSE */
+                                   * THEIA_EST_UNCALIBRATED_RELATIVE_POSE and THEIA_EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE */
   const uint32_t* seeds;       /* [num_problems] RandomNumberGenerator seed of each problem, or NULL = params.seed + index.
                                   Lets a caller keep a pair's sample stream when it re-batches or shards the pairs. */
 } theia_ransac_batch;
@@ -631,7 +645,8 @@ typedef struct theia_ransac_batch {
  *   RELATIVE_POSE_KNOWN_ORIENTATION: unit position of camera 2      = 3
  *   UNCALIBRATED_RELATIVE_POSE: F(9) R(9) position(3) focal_length1 focal_length2 = 23
  *   UNCALIBRATED_ABSOLUTE_POSE: projection matrix 3 x 4, row-major    = 12
- *   RIGID_TRANSFORMATION_2D3D: R(9, row-major) translation(3)        = 12 */
+ *   RIGID_TRANSFORMATION_2D3D: R(9, row-major) translation(3)        = 12
+ *   RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE: R(9) translation(3) focal_length radial_distortion = 14 */
 #define THEIA_RANSAC_MODEL_STRIDE 24
 typedef struct theia_ransac_result {
   int32_t* success;            /* [num_problems] Estimate() return value; 0 (with no inliers and a zero
@@ -695,6 +710,16 @@ void theia_hip_dls_macaulay_terms(int64_t first_call, int64_t num_calls, double*
  * zero padded), num_solutions[num] (0 for a degenerate sample; the reference returns -1 there). */
 int theia_hip_four_point_pose_and_focal_length(int32_t num, const double* corr2d3d, double* projection_matrices,
                                                int32_t* num_solutions);
+/* P4Pfr (FourPointsPoseFocalLengthRadialDistortion, sfm/pose/four_point_focal_length_radial_distortion.cc:68-288; bound in
+ * pose_wrapper.cc:189-215 / src/pytheia/sfm/sfm.cc:581), batched: corr2d3d = [num][4][5] (u v X Y Z, distorted pixels with the
+ * principal point removed); limits = {max_focal_length, min_focal_length, max_radial_distortion, min_radial_distortion}
+ * (RadialDistUncalibratedAbsolutePoseMetaData; the reference's CHECKs -> THEIA_HIP_ERR_INVALID_ARGUMENT); rotation_draws =
+ * [num][3] the three RandDouble(-0.5, 0.5) each call takes from the process-wide generator (:134-138), or NULL = the draws of the
+ * first num calls of a fresh process (the solver's static RandomNumberGenerator(42)).  models = [num][13][14]: rotation (9,
+ * row-major), translation (3), focal length, radial distortion, zero padded; num_solutions[num] = solutions that passed the
+ * focal-length / distortion range tests. */
+int theia_hip_four_point_focal_length_radial_distortion(int32_t num, const double* corr2d3d, const double* limits,
+                                                        const double* rotation_draws, double* models, int32_t* num_solutions);
 
 /* The batch entry points above keep their device workspace and the pinned host blocks of their per-round transfers in
  * process-wide caches between calls (up to 6 GiB of device memory and 2 GiB of pinned host memory); the buffers of a

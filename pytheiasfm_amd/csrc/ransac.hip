@@ -50,6 +50,7 @@ __host__ __device__ inline int max_models(int est) {
   if (est == THEIA_EST_SIMILARITY_2D3D) return dlsdev::kMaxSolutions;
   if (est == THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE) return 10;
   if (est == THEIA_EST_RIGID_TRANSFORMATION_2D3D) return 8;
+  if (est == THEIA_EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE) return 13;
   if (est >= THEIA_EST_FUNDAMENTAL_MATRIX) return 1;
   if (est == THEIA_EST_ABSOLUTE_POSE_DLS) return dlsdev::kMaxSolutions;
   return est == THEIA_EST_ABSOLUTE_POSE_SQPNP ? 18 : (est == THEIA_EST_ABSOLUTE_POSE_KNEIP ? 4 : 10);
@@ -61,7 +62,7 @@ __host__ __device__ inline int sample_size(int est) {
     case THEIA_EST_RELATIVE_POSE: case THEIA_EST_ESSENTIAL_MATRIX: return 5;
     case THEIA_EST_FUNDAMENTAL_MATRIX: case THEIA_EST_UNCALIBRATED_RELATIVE_POSE: return 8;
     case THEIA_EST_HOMOGRAPHY: case THEIA_EST_SIMILARITY_2D3D: case THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE:
-    case THEIA_EST_RIGID_TRANSFORMATION_2D3D: return 4;
+    case THEIA_EST_RIGID_TRANSFORMATION_2D3D: case THEIA_EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE: return 4;
     case THEIA_EST_RADIAL_HOMOGRAPHY: return 6;
     case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION:
     case THEIA_EST_TRIANGULATION: return 2;
@@ -76,6 +77,7 @@ inline int model_doubles(int est) {
     case THEIA_EST_ABSOLUTE_POSE_KNEIP: case THEIA_EST_ABSOLUTE_POSE_DLS: case THEIA_EST_ABSOLUTE_POSE_SQPNP: return 12;
     case THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE: return 12;   // projection matrix, row-major 3 x 4
     case THEIA_EST_RIGID_TRANSFORMATION_2D3D: return 12;    // rotation | translation
+    case THEIA_EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE: return 14;   // rotation | translation | focal length | radial distortion
     case THEIA_EST_DOMINANT_PLANE: return 6;
     case THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION: case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: return 3;
     case THEIA_EST_TRIANGULATION: return 4;
@@ -89,7 +91,8 @@ constexpr int kSimDatum = 26;   // CameraAndFeatureCorrespondence2D3D row of THE
 __host__ __device__ inline int datum_size(int est) {
   switch (est) {
     case THEIA_EST_ABSOLUTE_POSE_KNEIP: case THEIA_EST_ABSOLUTE_POSE_DLS: case THEIA_EST_ABSOLUTE_POSE_SQPNP:
-    case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: case THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE: return 5;
+    case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: case THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE:
+    case THEIA_EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE: return 5;
     case THEIA_EST_DOMINANT_PLANE: return 3;
     case THEIA_EST_TRIANGULATION: return kTriDatum;
     case THEIA_EST_RADIAL_HOMOGRAPHY: return rsc::kRadHomDatum;
@@ -241,7 +244,28 @@ __device__ inline double rigid_error(const double* m, const double* d) {
   return ex * ex + ey * ey;
 }
 
+// RadialDistUncalibratedAbsolutePoseEstimator::Error (estimate_radial_dist_uncalibrated_absolute_pose.cc:130-147) with DistortPoint
+// (:56-74): the projection with the model's focal length, distorted by the division model, against the feature; 1e10 when the
+// translation's z is negative.  m: rotation (9) | translation (3) | focal length | distortion; d: [u v X Y Z]
+__device__ inline double radial_dist_error(const double* m, const double* d) {
+  if (m[11] < 0.0) return 1.0e10;
+  double p[3];
+  for (int r = 0; r < 3; ++r) p[r] = ((m[3 * r] * d[2] + m[3 * r + 1] * d[3]) + m[3 * r + 2] * d[4]) + m[9 + r];
+  const double kp[3] = {m[12] * p[0], m[12] * p[1], 1.0 * p[2]};
+  const double x = kp[0] / kp[2], y = kp[1] / kp[2];
+  const double r2 = x * x + y * y;
+  const double denom = 2.0 * m[13] * r2, inner = 1.0 - 4.0 * m[13] * r2;
+  double dx = x, dy = y;
+  if (!(fabs(denom) < 1e-15 || inner < 0.0)) {
+    const double sc = (1.0 - sqrt(inner)) / denom;
+    dx = x * sc; dy = y * sc;
+  }
+  const double ex = dx - d[0], ey = dy - d[1];
+  return ex * ex + ey * ey;
+}
+
 __device__ inline double model_error(int est, const double* m, const double* d) {
+  if (est == THEIA_EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE) return radial_dist_error(m, d);
   if (est == THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE) return p4pfdev::reprojection_error(m, d);
   if (est == THEIA_EST_SIMILARITY_2D3D) return similarity_error(m, d);
   if (est == THEIA_EST_RIGID_TRANSFORMATION_2D3D) return rigid_error(m, d);
@@ -1207,6 +1231,15 @@ struct Mt19937 {
     y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
     return y;
   }
+  // libstdc++ std::uniform_real_distribution<double>(lo, hi): generate_canonical<double, 53> = two 32-bit draws (g0 + g1 * 2^32) / 2^64
+  // (nextafter(1, 0) should the quotient round to 1), then * (hi - lo) + lo -- RandomNumberGenerator::RandDouble (util/random.cc:68-72)
+  double rand_double(double lo, double hi) {
+    double sum = 0.0, tmp = 1.0;
+    for (int k = 0; k < 2; ++k) { sum += (double)next() * tmp; tmp *= 4294967296.0; }
+    double ret = sum / tmp;
+    if (ret >= 1.0) ret = std::nextafter(1.0, 0.0);
+    return ret * (hi - lo) + lo;
+  }
   int rand_int(int lo, int hi) {
     const uint32_t urange = (uint32_t)hi - (uint32_t)lo;
     uint32_t ret;
@@ -1382,13 +1415,14 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   }
   const bool gdls_est = est == THEIA_EST_SIMILARITY_2D3D;
   const bool dls_est = est == THEIA_EST_ABSOLUTE_POSE_DLS || gdls_est;   // the Macaulay pipeline: stage A -> eigen stage
-  if (est < 0 || est > THEIA_EST_RIGID_TRANSFORMATION_2D3D) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
+  if (est < 0 || est > THEIA_EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "unknown estimator id");
   const bool abs_pose = est == THEIA_EST_ABSOLUTE_POSE_KNEIP || est == THEIA_EST_ABSOLUTE_POSE_SQPNP || (dls_est && !gdls_est);
   // estimators that keep Estimator::RefineModel's default "return true" (solvers/estimator.h:86-88): LO only counts
   const bool trivial_refine = est == THEIA_EST_ESSENTIAL_MATRIX || est == THEIA_EST_DOMINANT_PLANE ||
                               est == THEIA_EST_RELATIVE_POSE_KNOWN_ORIENTATION || est == THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION ||
                               est == THEIA_EST_TRIANGULATION || est == THEIA_EST_RADIAL_HOMOGRAPHY || est == THEIA_EST_SIMILARITY_2D3D ||
-                              est == THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE || est == THEIA_EST_RIGID_TRANSFORMATION_2D3D;
+                              est == THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE || est == THEIA_EST_RIGID_TRANSFORMATION_2D3D ||
+                              est == THEIA_EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE;
   const bool rel_pose = est == THEIA_EST_RELATIVE_POSE, uncal_pose = est == THEIA_EST_UNCALIBRATED_RELATIVE_POSE;
   const bool homog = est == THEIA_EST_HOMOGRAPHY, fund = est == THEIA_EST_FUNDAMENTAL_MATRIX;
   // every estimator's RefineModel is built: BundleAdjustView (absolute pose), BundleAdjustTwoViewsAngular ((un)calibrated
@@ -1413,6 +1447,23 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   if (dls_est && (rc = dls_ensure_tables())) return rc;
   const bool upnp_est = est == THEIA_EST_RIGID_TRANSFORMATION_2D3D;
   if (upnp_est && (rc = upnp_ensure_tables())) return rc;
+  // P4Pfr: estimator_params = RadialDistUncalibratedAbsolutePoseMetaData {max focal length, min focal length, max distortion, min
+  // distortion} [, first call of the process (the solver's static generator re-seeds the shared stream with 42)]
+  const bool p4pfr_est = est == THEIA_EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE;
+  double p4pfr_limits[4] = {0.0, 0.0, 0.0, 0.0};
+  bool p4pfr_first_call = false;
+  if (p4pfr_est) {
+    if (!batch->estimator_params)
+      return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "the radial-distortion absolute-pose estimator needs estimator_params = {max focal length, min focal length, max distortion, min distortion, first call (0 / 1)}");
+    for (int k = 0; k < 4; ++k) p4pfr_limits[k] = batch->estimator_params[k];
+    p4pfr_first_call = batch->estimator_params[4] != 0.0;
+    // the reference CHECKs these (four_point_focal_length_radial_distortion.cc:82-90)
+    if (!(p4pfr_limits[1] >= 0.0 && p4pfr_limits[0] >= 0.0 && p4pfr_limits[0] >= p4pfr_limits[1] && p4pfr_limits[2] <= 0.0 && p4pfr_limits[3] <= 0.0 &&
+          p4pfr_limits[2] <= p4pfr_limits[3]))
+      return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "P4Pfr: needs 0 <= min focal length <= max focal length and max distortion <= min distortion <= 0");
+    if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "the exhaustive sampler draws pairs: sample size 4 does not fit");
+    if ((rc = p4pfr_ensure_tables())) return rc;
+  }
   const int m = sample_size(est), ds = datum_size(est);
   const int64_t total = batch->offsets[nprob];
   int nmax = 0;
@@ -1463,6 +1514,8 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   DBuf<double> d_fp_ws, d_fp_sol; DBuf<int> d_fp_ok, d_fp_mask;   // five-point: stages a -> b -> c
   std::vector<double> h_dls_u; dls::GlibcRand dls_gen; std::vector<int> h_iter_base;
   DBuf<uint8_t> d_mask;
+  HBuf<double> h_rot2[2];   // P4Pfr: the "random rotation" matrix of every hypothesis of a round (made where its draws are taken)
+  DBuf<double> d_rot;
   HBuf<int> h_samples2[2], h_counts, h_ninl, h_active2[2];   // pinned: sources / destinations of the per-round transfers (samples / active
                                                              // counts twice: the next chunk's first round is drawn while the GPU works)
   HBuf<double> h_cost;
@@ -1594,7 +1647,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   const bool host_timing = getenv("THEIA_HIP_RANSAC_TIMING") != nullptr;
   // one round of a chunk on the host: iterations per problem and the sample stream (RandomSampler::Sample with its
   // persistent permutation, PROSAC, EXHAUSTIVE); problems are independent (own generator, own slice): host threads share them
-  auto gen_round = [&](int c0, int cn, bool first, HBuf<int>& act, HBuf<int>& smp, int* B_out) -> int {
+  auto gen_round = [&](int c0, int cn, bool first, HBuf<int>& act, HBuf<int>& smp, HBuf<double>& rotb, int* B_out) -> int {
     int B = 0;
     if (!act.assign(cn, 0)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
     for (int q = 0; q < cn; ++q) {
@@ -1609,11 +1662,22 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     *B_out = B;
     if (B == 0) return 0;
     if (!smp.resize((size_t)cn * B * m)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+    if (p4pfr_est && !rotb.resize((size_t)cn * B * 9)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
     host_parallel_for(cn, [&](int q) {
       ProblemState& s = S[c0 + q];
       int* out = smp.data() + (size_t)q * B * m;
+      // P4Pfr takes three RandDouble(-0.5, 0.5) from the SAME generator after every sample (every RandomNumberGenerator object
+      // shares one std::mt19937, util/random.cc:46-66); the solver's static RandomNumberGenerator(42) re-seeds that generator the
+      // first time it runs in a process (four_point_focal_length_radial_distortion.cc:134-138)
+      auto p4pfr_draws = [&](int b) {
+        if (!p4pfr_est) return;
+        if (p4pfr_first_call && s.it + b == 0) s.rng.seed(42);
+        double v[3];
+        for (int k = 0; k < 3; ++k) v[k] = s.rng.rand_double(-0.5, 0.5);
+        p4pfr_rotation_from_draws(v, rotb.data() + ((size_t)q * B + b) * 9);
+      };
       for (int b = 0; b < s.round_iters; ++b) {
-        if (P.ransac_type == THEIA_RANSAC_PROSAC) { prosac_sample(s.rng, s.n, m, s.kth++, out + (size_t)b * m); continue; }
+        if (P.ransac_type == THEIA_RANSAC_PROSAC) { prosac_sample(s.rng, s.n, m, s.kth++, out + (size_t)b * m); p4pfr_draws(b); continue; }
         if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE) {   // all pairs (i, j > i), wrapping around
           out[(size_t)b * 2] = s.ex_i; out[(size_t)b * 2 + 1] = s.ex_j;
           if (++s.ex_j >= s.n) {
@@ -1626,6 +1690,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
           std::swap(s.idx[i], s.idx[s.rng.rand_int(i, s.n - 1)]);
           out[(size_t)b * m + i] = s.idx[i];
         }
+        p4pfr_draws(b);
       }
       for (size_t e = (size_t)s.round_iters * m; e < (size_t)B * m; ++e) out[e] = 0;   // iterations beyond this problem's round
     });
@@ -1639,7 +1704,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       int B = 0;
       const auto tp0 = std::chrono::steady_clock::now();
       if (first && pre_c0 == c0) { bufi ^= 1; B = pre_B; pre_c0 = -1; }
-      else if ((rc = gen_round(c0, cn, first, h_active2[bufi], h_samples2[bufi], &B))) return rc;
+      else if ((rc = gen_round(c0, cn, first, h_active2[bufi], h_samples2[bufi], h_rot2[bufi], &B))) return rc;
       HBuf<int>& h_active = h_active2[bufi];
       HBuf<int>& h_samples = h_samples2[bufi];
       if (B == 0) break;
@@ -1699,6 +1764,12 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         else
           k_fit5_c<THEIA_EST_ESSENTIAL_MATRIX><<<grid, 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_sol.p,
                                                                    d_fp_mask.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
+      } else if (p4pfr_est) {
+        if ((rc = d_fp_ws.ensure(nh * (size_t)p4pfr_workspace_doubles())) || (rc = d_rot.ensure(nh * 9))) return rc;
+        HIP_TRYR(hipMemcpyAsync(d_rot.p, h_rot2[bufi].data(), sizeof(double) * nh * 9, hipMemcpyHostToDevice, st));
+        HIP_TRYR(hipEventRecord(ev0, st));   // (re-recorded: the upload above is not part of the fit time)
+        launch_p4pfr_fit(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_rot.p, p4pfr_limits, d_fp_ws.p, d_models.p, d_counts.p, d_dense.p,
+                         d_tags.p, d_hyp_base.p, st);
       } else if (upnp_est) {
         if ((rc = d_fp_ws.ensure(nh * (size_t)upnp_workspace_doubles()))) return rc;
         launch_upnp_fit(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_upnp_state.p + (size_t)c0 * upnp_state_doubles(), d_fp_ws.p,
@@ -1772,7 +1843,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       // while the GPU fits and scores this round: the first round of the next chunk (its problems are not touched before)
       if (pre_c0 < 0 && c0 + chunk < nprob) {
         const int nc0 = c0 + chunk;
-        if ((rc = gen_round(nc0, std::min(chunk, nprob - nc0), true, h_active2[1 - bufi], h_samples2[1 - bufi], &pre_B))) return rc;
+        if ((rc = gen_round(nc0, std::min(chunk, nprob - nc0), true, h_active2[1 - bufi], h_samples2[1 - bufi], h_rot2[1 - bufi], &pre_B))) return rc;
         pre_c0 = nc0;
       }
       HIP_TRYR(mine.wait(st));
@@ -2025,6 +2096,57 @@ int theia_hip_four_point_pose_and_focal_length(int32_t num, const double* corr2d
   for (size_t i = 0; i < n; ++i)
     for (int j = 0; j < 10; ++j)
       for (int k = 0; k < 12; ++k) projection_matrices[(i * 10 + j) * 12 + k] = j < num_solutions[i] ? hm[(i * 10 + j) * kStride + k] : 0.0;
+  return 0;
+}
+
+int theia_hip_four_point_focal_length_radial_distortion(int32_t num, const double* corr2d3d, const double* limits, const double* rotation_draws,
+                                                        double* models, int32_t* num_solutions) {
+  if (num < 0 || !limits || (num > 0 && (!corr2d3d || !models || !num_solutions))) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+  if (!(limits[1] >= 0.0 && limits[0] >= 0.0 && limits[0] >= limits[1] && limits[2] <= 0.0 && limits[3] <= 0.0 && limits[2] <= limits[3]))
+    return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "P4Pfr: needs 0 <= min focal length <= max focal length and max distortion <= min distortion <= 0");
+  if (num == 0) return 0;
+  int rc = ensure_device();
+  if (rc || (rc = p4pfr_ensure_tables())) return rc;
+  hipStream_t st = solver_stream();
+  PoolStreamScope pool_scope(st);   // blocks this call hands back to the caches are tagged with an event on this stream (pools.h)
+  if (!st) return set_error(THEIA_HIP_ERR_NO_DEVICE, "could not create the solver stream");
+  CallSync mine;
+  // one problem of four data per call row, one hypothesis each with the identity sample: the RANSAC stages as they are
+  constexpr int kMm = 13, kMd = 14;
+  DBuf<double> dc, dws, dmod, drot; DBuf<int> dn, dsamp, dact, ddense, dtags, dbase; DBuf<int64_t> doff;
+  const size_t n = (size_t)num;
+  if ((rc = dc.ensure(n * 20)) || (rc = dws.ensure(n * (size_t)p4pfr_workspace_doubles())) || (rc = dmod.ensure(n * kMm * kStride)) || (rc = drot.ensure(n * 9)) ||
+      (rc = dn.ensure(n)) || (rc = dsamp.ensure(n * 4)) || (rc = dact.ensure(n)) || (rc = ddense.ensure(n)) || (rc = dtags.ensure(n * kMm)) ||
+      (rc = dbase.ensure(n)) || (rc = doff.ensure(n + 1)))
+    return rc;
+  std::vector<int64_t> off(n + 1);
+  std::vector<int> samp(n * 4), act(n, 1);
+  std::vector<double> rot(n * 9);
+  for (size_t i = 0; i <= n; ++i) off[i] = (int64_t)(4 * i);
+  for (size_t i = 0; i < n * 4; ++i) samp[i] = (int)(i % 4);
+  Mt19937 g;
+  g.seed(42);   // rotation_draws == NULL: the calls of a fresh process, in order (the solver's static RandomNumberGenerator(42))
+  for (size_t i = 0; i < n; ++i) {
+    double v[3];
+    for (int k = 0; k < 3; ++k) v[k] = rotation_draws ? rotation_draws[3 * i + k] : g.rand_double(-0.5, 0.5);
+    p4pfr_rotation_from_draws(v, rot.data() + 9 * i);
+  }
+  HIP_TRYR(hipMemcpyAsync(dc.p, corr2d3d, sizeof(double) * n * 20, hipMemcpyHostToDevice, st));
+  HIP_TRYR(hipMemcpyAsync(doff.p, off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, st));
+  HIP_TRYR(hipMemcpyAsync(dsamp.p, samp.data(), sizeof(int) * n * 4, hipMemcpyHostToDevice, st));
+  HIP_TRYR(hipMemcpyAsync(dact.p, act.data(), sizeof(int) * n, hipMemcpyHostToDevice, st));
+  HIP_TRYR(hipMemcpyAsync(drot.p, rot.data(), sizeof(double) * n * 9, hipMemcpyHostToDevice, st));
+  HIP_TRYR(hipMemsetAsync(ddense.p, 0, sizeof(int) * n, st));
+  HIP_TRYR(hipMemsetAsync(dmod.p, 0, sizeof(double) * n * kMm * kStride, st));
+  launch_p4pfr_fit(num, 1, doff.p, dc.p, dsamp.p, dact.p, drot.p, limits, dws.p, dmod.p, dn.p, ddense.p, dtags.p, dbase.p, st);
+  std::vector<double> hm(n * kMm * kStride);
+  HIP_TRYR(hipMemcpyAsync(hm.data(), dmod.p, sizeof(double) * hm.size(), hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipMemcpyAsync(num_solutions, dn.p, sizeof(int) * n, hipMemcpyDeviceToHost, st));
+  HIP_TRYR(hipGetLastError());
+  HIP_TRYR(mine.wait(st));
+  for (size_t i = 0; i < n; ++i)
+    for (int j = 0; j < kMm; ++j)
+      for (int k = 0; k < kMd; ++k) models[(i * kMm + j) * kMd + k] = j < num_solutions[i] ? hm[(i * kMm + j) * kStride + k] : 0.0;
   return 0;
 }
 

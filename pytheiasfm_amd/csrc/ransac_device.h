@@ -356,13 +356,9 @@ RDEV void jacobi_rot_sym(double x, double y, double z, double* c, double* s) {
   *c = n;
 }
 
-RDEV void svd3(const double* Ain, double* U, double* S, double* V) {
-  double W[9];
-  double scale = 0.0;
-  for (int i = 0; i < 9; ++i) scale = fmax(scale, fabs(Ain[i]));
-  if (scale == 0.0) scale = 1.0;
-  for (int i = 0; i < 9; ++i) W[i] = Ain[i] / scale;
-  for (int i = 0; i < 9; ++i) { U[i] = (i % 4 == 0) ? 1.0 : 0.0; V[i] = U[i]; }
+// the sweeps, the sign fix and the sort on a work matrix W (destroyed); U, V hold their starting values (identity, or the
+// preconditioner's: p4pfr_kernels.hip starts U at a column permutation)
+RDEV void svd3_sweeps(double* W, double* U, double* S, double* V) {
   const double precision = 2.0 * DBL_EPSILON;
   double maxdiag = fmax(fabs(W[0]), fmax(fabs(W[4]), fabs(W[8])));
   bool finished = false;
@@ -423,6 +419,16 @@ RDEV void svd3(const double* Ain, double* U, double* S, double* V) {
       for (int k = 0; k < 3; ++k) { dswap(U[k * 3 + i], U[k * 3 + best]); dswap(V[k * 3 + i], V[k * 3 + best]); }
     }
   }
+}
+
+RDEV void svd3(const double* Ain, double* U, double* S, double* V) {
+  double W[9];
+  double scale = 0.0;
+  for (int i = 0; i < 9; ++i) scale = fmax(scale, fabs(Ain[i]));
+  if (scale == 0.0) scale = 1.0;
+  for (int i = 0; i < 9; ++i) W[i] = Ain[i] / scale;
+  for (int i = 0; i < 9; ++i) { U[i] = (i % 4 == 0) ? 1.0 : 0.0; V[i] = U[i]; }
+  svd3_sweeps(W, U, S, V);
   for (int i = 0; i < 3; ++i) S[i] *= scale;
 }
 

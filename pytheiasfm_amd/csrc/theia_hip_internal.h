@@ -44,6 +44,15 @@ int upnp_workspace_doubles();
 int upnp_state_doubles();
 void launch_upnp_fit(int nprob, int B, const int64_t* offsets, const double* data, const int* samples, const int* active_iters,
                      double* state, double* ws, double* models, int* counts, int* dense_count, int* tags, int* hyp_base, hipStream_t st);
+// p4pfr_kernels.hip: the P4Pfr hypotheses of THEIA_EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE for B iterations of nprob problems.
+// rot: [nprob * B][9] the "random rotation" matrix of every hypothesis (p4pfr_rotation_from_draws of its three RandDouble draws, made
+// on the host); limits: {max focal length, min focal length, max distortion, min distortion}; ws: [nprob * B][p4pfr_workspace_doubles()]
+int p4pfr_ensure_tables();
+int p4pfr_workspace_doubles();
+void p4pfr_rotation_from_draws(const double* v, double* R);
+void launch_p4pfr_fit(int nprob, int B, const int64_t* offsets, const double* data, const int* samples, const int* active_iters,
+                      const double* rot, const double* limits, double* ws, double* models, int* counts, int* dense_count, int* tags,
+                      int* hyp_base, hipStream_t st);
 // ba_invdepth.hip: bundle adjustment with the inverse-depth track parametrisation (THEIA_BA_FLAG_INVERSE_DEPTH)
 int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_summary* S);
 // the same problem as a device-resident object behind the handle API (theia_hip_ba_create with THEIA_BA_FLAG_INVERSE_DEPTH)

@@ -38,6 +38,7 @@ EST_RADIAL_HOMOGRAPHY = 12
 EST_SIMILARITY_2D3D = 13
 EST_UNCALIBRATED_ABSOLUTE_POSE = 14
 EST_RIGID_TRANSFORMATION_2D3D = 15
+EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE = 16
 
 
 class RansacParameters:
@@ -112,6 +113,8 @@ def _sig():
                                         capi.c_double_p, capi.c_double_p, capi.c_int32_p]
         L.theia_hip_dls_macaulay_terms.argtypes = [C.c_int64, C.c_int64, capi.c_double_p]
         L.theia_hip_four_point_pose_and_focal_length.argtypes = [C.c_int32, capi.c_double_p, capi.c_double_p, capi.c_int32_p]
+        L.theia_hip_four_point_focal_length_radial_distortion.argtypes = [C.c_int32, capi.c_double_p, capi.c_double_p, capi.c_double_p,
+                                                                          capi.c_double_p, capi.c_int32_p]
         L.theia_hip_dls_macaulay_terms.restype = None
         L.theia_ransac_params_default.argtypes = [C.POINTER(capi.RansacParams)]
         L._ransac_ready = True
@@ -151,7 +154,7 @@ def estimate_batch(estimator, data, offsets, params, estimator_params=None, seed
             "time_fit_seconds": r.time_fit_seconds, "time_score_seconds": r.time_score_seconds}
 
 
-_SAMPLE_SIZE = {0: 5, 1: 5, 2: 3, 3: 3, 4: 3, 5: 8, 6: 4, 7: 3, 8: 2, 9: 8, 10: 2, 11: 2, 12: 6, 13: 4, 14: 4, 15: 4}   # Estimator::SampleSize() by THEIA_EST_*
+_SAMPLE_SIZE = {0: 5, 1: 5, 2: 3, 3: 3, 4: 3, 5: 8, 6: 4, 7: 3, 8: 2, 9: 8, 10: 2, 11: 2, 12: 6, 13: 4, 14: 4, 15: 4, 16: 4}   # Estimator::SampleSize() by THEIA_EST_*
 
 
 def _single(estimator, ransac_params, ransac_type, data, estimator_params=None):
@@ -533,6 +536,58 @@ def FourPointPoseAndFocalLength(feature_vectors, world_points):
     if single:
         return (int(ns[0]) if ns[0] > 0 else -1), [Pm[0, k] for k in range(ns[0])]
     return ns, Pm
+
+
+class RadialDistUncalibratedAbsolutePoseMetaData:  # estimate_radial_dist_uncalibrated_absolute_pose.h:55-61
+    def __init__(self, min_focal_length=200.0, max_focal_length=10000.0, min_radial_distortion=-1e-9, max_radial_distortion=-1e-5):
+        self.min_focal_length = min_focal_length
+        self.max_focal_length = max_focal_length
+        self.min_radial_distortion = min_radial_distortion
+        self.max_radial_distortion = max_radial_distortion
+
+    def limits(self):
+        return np.array([self.max_focal_length, self.min_focal_length, self.max_radial_distortion, self.min_radial_distortion])
+
+
+class RadialDistUncalibratedAbsolutePose:  # estimate_radial_dist_uncalibrated_absolute_pose.h:48-53
+    def __init__(self, m):
+        self.rotation = np.array(m[0:9]).reshape(3, 3)
+        self.translation = np.array(m[9:12])
+        self.focal_length = float(m[12])
+        self.radial_distortion = float(m[13])
+
+
+def EstimateRadialDistUncalibratedAbsolutePose(ransac_params, ransac_type, normalized_correspondences, meta_data, first_call_in_process=False):
+    """estimate_radial_dist_uncalibrated_absolute_pose.cc:163-189 -> (success, RadialDistUncalibratedAbsolutePose, summary).
+    correspondences: (N, 5) u v X Y Z, the observed (distorted) pixels with the principal point removed.  RANSAC over P4Pfr
+    samples on the device.  The solver's "random rotation" draws come out of the sampler's stream, as in the reference
+    (include/theia_hip.h); first_call_in_process: the stream is re-seeded with 42 after the first sample, which is what the
+    solver's static generator does the first time it runs in a process."""
+    ep = np.concatenate([meta_data.limits(), [1.0 if first_call_in_process else 0.0]])
+    ok, m, s = _single(EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE, ransac_params, ransac_type, normalized_correspondences, ep)
+    return ok, RadialDistUncalibratedAbsolutePose(m), s
+
+
+def FourPointsPoseFocalLengthRadialDistortion(feature_vectors, world_points, meta_data, rotation_draws=None):
+    """pose_wrapper.cc:189-215 / four_point_focal_length_radial_distortion.cc:68-288 (P4Pfr, four 2D-3D correspondences per problem;
+    batched when the inputs carry a leading batch dimension): (success, rotations, translations, radial distortions, focal lengths).
+    rotation_draws: the three RandDouble(-0.5, 0.5) of every call ((num, 3)); None = the calls of a fresh process in order."""
+    a = np.asarray(feature_vectors, dtype=np.float64); b = np.asarray(world_points, dtype=np.float64)
+    single = a.ndim == 2
+    if single:
+        a, b = a[None], b[None]
+    corr = np.ascontiguousarray(np.concatenate([a, b], axis=2))
+    num = corr.shape[0]
+    lim = np.ascontiguousarray(meta_data.limits(), dtype=np.float64)
+    rd = None if rotation_draws is None else np.ascontiguousarray(np.asarray(rotation_draws, dtype=np.float64).reshape(num, 3))
+    M = np.zeros((num, 13, 14)); ns = np.zeros(num, dtype=np.int32)
+    capi.check(_sig().theia_hip_four_point_focal_length_radial_distortion(num, capi.ptr(corr, C.c_double), capi.ptr(lim, C.c_double),
+                                                                           None if rd is None else capi.ptr(rd, C.c_double),
+                                                                           capi.ptr(M, C.c_double), capi.ptr(ns, C.c_int32)))
+    if single:
+        k = int(ns[0])
+        return k > 0, [M[0, j, :9].reshape(3, 3) for j in range(k)], [M[0, j, 9:12] for j in range(k)], [M[0, j, 13] for j in range(k)], [M[0, j, 12] for j in range(k)]
+    return ns, M
 
 
 def FivePointRelativePose(image1_points, image2_points):

@@ -318,6 +318,57 @@ def upnp_estimate_pose(origin, direction, world, state=None):
     return q[:n], t[:n], st
 
 
+def p4pfr_solve(feat, world, rot_vec, limits, want_matrices=False):
+    """FourPointsPoseFocalLengthRadialDistortion (oracle/p4pfr_oracle.h).  feat (4, 2), world (4, 3), rot_vec: the three
+    RandDouble(-0.5, 0.5) draws of the call, limits: (max focal, min focal, max distortion, min distortion).  Returns the models
+    (n, 14) = rotation (9, row-major) | translation | focal length | radial distortion [, the 40 x 50 template, the action matrix]."""
+    L = rlib()
+    dp = capi.c_double_p
+    L.oracle_p4pfr_solve.argtypes = [dp, dp, dp, dp, dp, dp, dp]
+    f = np.ascontiguousarray(feat, dtype=np.float64); w = np.ascontiguousarray(world, dtype=np.float64)
+    rv = np.ascontiguousarray(rot_vec, dtype=np.float64); lim = np.ascontiguousarray(limits, dtype=np.float64)
+    m = np.zeros((13, 14)); T = np.zeros((40, 50)); A = np.zeros((13, 13))
+    n = L.oracle_p4pfr_solve(capi.ptr(f, C.c_double), capi.ptr(w, C.c_double), capi.ptr(rv, C.c_double), capi.ptr(lim, C.c_double),
+                             capi.ptr(m, C.c_double), capi.ptr(T, C.c_double) if want_matrices else None,
+                             capi.ptr(A, C.c_double) if want_matrices else None)
+    return (m[:n], T, A) if want_matrices else m[:n]
+
+
+def p4pfr_template(Nn, D, d0, U0):
+    """The 40 x 50 elimination template from the null-space basis (8, 4), D (3, 9), d(0) and the first normalised world point."""
+    L = rlib()
+    dp = capi.c_double_p
+    L.oracle_p4pfr_template.argtypes = [dp, dp, C.c_double, dp, dp]
+    Nn = np.ascontiguousarray(Nn, dtype=np.float64); D = np.ascontiguousarray(D, dtype=np.float64); U0 = np.ascontiguousarray(U0, dtype=np.float64)
+    T = np.zeros((40, 50))
+    L.oracle_p4pfr_template(capi.ptr(Nn, C.c_double), capi.ptr(D, C.c_double), float(d0), capi.ptr(U0, C.c_double), capi.ptr(T, C.c_double))
+    return T
+
+
+def p4pfr_logged_draws(fn):
+    """Runs fn() with the oracle's record of the P4Pfr "random rotation" draws switched on; returns (fn's result, draws (k, 3))."""
+    L = rlib()
+    L.oracle_p4pfr_logged_draws.argtypes = [capi.c_double_p, C.c_int]
+    L.oracle_p4pfr_log_draws(1)
+    try:
+        r = fn()
+        n = L.oracle_p4pfr_logged_draws(None, 0)
+        out = np.zeros(max(n, 1))
+        L.oracle_p4pfr_logged_draws(capi.ptr(out, C.c_double), n)
+    finally:
+        L.oracle_p4pfr_log_draws(0)
+    return r, out[:n].reshape(-1, 3)
+
+
+def mt_randdouble_stream(seed, n, lo, hi):
+    """n draws of std::uniform_real_distribution<double>(lo, hi) on std::mt19937(seed) (= RandomNumberGenerator::RandDouble)."""
+    L = rlib()
+    L.oracle_mt_randdouble_stream.argtypes = [C.c_uint32, C.c_int, C.c_double, C.c_double, capi.c_double_p]
+    out = np.zeros(n)
+    L.oracle_mt_randdouble_stream(seed, n, lo, hi, capi.ptr(out, C.c_double))
+    return out
+
+
 def model_error(est, model, datum):
     """Estimator::Error of one datum under one model row (oracle_model_error)."""
     model = np.ascontiguousarray(model, dtype=np.float64); datum = np.ascontiguousarray(datum, dtype=np.float64)
