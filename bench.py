@@ -223,21 +223,29 @@ def ransac_block(cpu_baseline, host_cores, rank=0, world=1):
             ("dls_absolute_pose", ransac.EST_ABS_DLS, "absolute", (4.0 / 1000.0) ** 2, 1.35e6, 30.0, PAIRS // CHUNK),
             # UPnP (EstimateRigidTransformation2D3D, central overload): one chunk; 2/3 141^3 + 2 141^2 8 = 2.2 MFLOP for the reference's
             # Gauss-Jordan of the 141 x 149 template per solve (build_upnp_action_matrix_using_symmetry.cc:2487)
-            ("upnp_rigid_transformation", ransac.EST_RIGID_TRANSFORMATION_2D3D, "rigid", (4.0 / 1000.0) ** 2, 2.2e6, 40.0, 1))
+            ("upnp_rigid_transformation", ransac.EST_RIGID_TRANSFORMATION_2D3D, "rigid", (4.0 / 1000.0) ** 2, 2.2e6, 40.0, 1),
+            # P4Pfr (EstimateRadialDistUncalibratedAbsolutePose): one chunk, the correspondences seen by a camera of focal length 1000 with
+            # division-model distortion -1e-7 (pixels); per solve ~47 kFLOP for the full-pivot LU of the 37 x 40 block with its seven
+            # right-hand sides, ~55 kFLOP for the 13 x 13 eigen-decomposition, ~15 kFLOP for the template and the normalisation
+            ("p4pfr_radial_dist_absolute_pose", ransac.EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE, "radial", 4.0 ** 2, 1.2e5, 35.0, 1))
+    p4pfr_ep = np.array([2000.0, 100.0, -1e-5, -1e-9, 0.0])   # RadialDistUncalibratedAbsolutePoseMetaData of the reference's test + "not the first call"
     for name, est, kind, thresh, fit_flop, score_flop, nchunks in legs:
         p = ransac.RansacParameters(); p.error_thresh = thresh; p.min_iterations = HYPS; p.max_iterations = HYPS; p.seed = 1
         tot = {"hyp": 0, "models": 0, "wall": 0.0, "fit": 0.0, "score": 0.0, "kern": 0.0}
         first = None
         for c in range(rank, nchunks, world):   # (whole chunks of pairs per rank: same round-robin deal, coarser grain)
-            data, offsets, _ = synth.synth_ransac_v1(CHUNK, CORR, "absolute" if kind == "rigid" else kind, seed=0x5AC50005 + 977 * c)
+            data, offsets, TRUTH = synth.synth_ransac_v1(CHUNK, CORR, "absolute" if kind in ("rigid", "radial") else kind, seed=0x5AC50005 + 977 * c)
             if kind == "rigid":
                 data = ransac.central_correspondence_rows(data)   # [u v X Y Z] as seen by identity pinhole cameras (26 doubles per datum)
+            if kind == "radial":
+                data = ransac.radial_dist_correspondence_rows(ransac.shift_world_along_optical_axis(data, offsets, TRUTH["R"], 2.0), 1000.0, -1e-7)
+            ep = p4pfr_ep if kind == "radial" else None
             if first is None:
-                ransac.estimate_batch(est, data[: offsets[8]], offsets[:9], p)  # warm-up
+                ransac.estimate_batch(est, data[: offsets[8]], offsets[:9], p, ep)  # warm-up
                 first = (data, offsets)
             p.seed = 1 + c * CHUNK
             t0 = time.perf_counter()
-            res = ransac.estimate_batch(est, data, offsets, p)
+            res = ransac.estimate_batch(est, data, offsets, p, ep)
             tot["wall"] += time.perf_counter() - t0
             tot["hyp"] += int(res["hypotheses_evaluated"]); tot["models"] += int(res["models_scored"])
             tot["fit"] += res["time_fit_seconds"]; tot["score"] += res["time_score_seconds"]; tot["kern"] += res["time_fit_score_seconds"]
@@ -260,6 +268,10 @@ def ransac_block(cpu_baseline, host_cores, rank=0, world=1):
             data, offsets = first
             hy = 1024 if est != ransac.EST_RIGID_TRANSFORMATION_2D3D else 256   # (the UPnP oracle: a dense 141 x 149 elimination per hypothesis)
 
+            ep = p4pfr_ep if kind == "radial" else None
+            if ep is not None:
+                ol.set_estimator_params(ep)    # (process-wide in the oracle: this leg is the only one that reads them)
+
             def one(i):
                 pc = p.to_c(); pc.min_iterations = hy; pc.max_iterations = hy; pc.seed = 1 + i
                 return ol.ransac_estimate(est, data[offsets[i]:offsets[i + 1]], pc)
@@ -275,7 +287,7 @@ def ransac_block(cpu_baseline, host_cores, rank=0, world=1):
             # inlier-set equality count of the GPU path against the CPU path on the same pairs / seeds
             # (the CPU-baseline sample: the first `nall` pairs of the leg at `hy` iterations)
             pe = ransac.RansacParameters(); pe.error_thresh = thresh; pe.min_iterations = hy; pe.max_iterations = hy; pe.seed = 1
-            rg = ransac.estimate_batch(est, data[: offsets[nall]], offsets[: nall + 1], pe)
+            rg = ransac.estimate_batch(est, data[: offsets[nall]], offsets[: nall + 1], pe, ep)
             eq = [bool(np.array_equal(ora[i]["inlier_mask"], rg["inlier_mask"][offsets[i]:offsets[i + 1]])) for i in range(nall)]
             sym = [int((ora[i]["inlier_mask"] != rg["inlier_mask"][offsets[i]:offsets[i + 1]]).sum()) for i in range(nall)]
             leg["inlier_set_equality"] = {"pairs_equal": int(sum(eq)), "pairs_compared": nall, "max_symmetric_difference": int(max(sym)),

@@ -557,6 +557,30 @@ class RadialDistUncalibratedAbsolutePose:  # estimate_radial_dist_uncalibrated_a
         self.radial_distortion = float(m[13])
 
 
+def shift_world_along_optical_axis(correspondences, offsets, rotations, shift):
+    """X' = X - R^T (0, 0, shift) per problem: the same images under the pose (R, t + (0, 0, shift)).  The radial-distortion
+    estimator's Error rejects every model whose translation has a negative z (estimate_radial_dist_uncalibrated_absolute_pose.cc:
+    137-139), so a synthetic scene for it needs t_z >= 0; synth_ransac_v1's unit translations have t_z in [-1, 1]."""
+    c = np.ascontiguousarray(correspondences, dtype=np.float64).reshape(-1, 5).copy()
+    for i in range(len(offsets) - 1):
+        c[offsets[i]:offsets[i + 1], 2:5] -= rotations[i].T @ np.array([0.0, 0.0, shift])
+    return c
+
+
+def radial_dist_correspondence_rows(normalized_correspondences, focal_length, radial_distortion):
+    """(N, 5) rows [u v X Y Z] of normalised (focal length 1, undistorted) correspondences as a camera of the given focal length
+    and division-model distortion observes them: pixels f * (u, v), distorted as DistortPoint does
+    (estimate_radial_dist_uncalibrated_absolute_pose.cc:56-74).  For synthetic workloads (bench.py, the parity tests)."""
+    c = np.ascontiguousarray(normalized_correspondences, dtype=np.float64).reshape(-1, 5).copy()
+    px = c[:, :2] * focal_length
+    r2 = np.sum(px * px, axis=1)
+    den = 2.0 * radial_distortion * r2; inner = 1.0 - 4.0 * radial_distortion * r2
+    keep = (np.abs(den) < 1e-15) | (inner < 0.0)
+    scale = np.where(keep, 1.0, (1.0 - np.sqrt(np.maximum(inner, 0.0))) / np.where(keep, 1.0, den))
+    c[:, :2] = px * scale[:, None]
+    return c
+
+
 def EstimateRadialDistUncalibratedAbsolutePose(ransac_params, ransac_type, normalized_correspondences, meta_data, first_call_in_process=False):
     """estimate_radial_dist_uncalibrated_absolute_pose.cc:163-189 -> (success, RadialDistUncalibratedAbsolutePose, summary).
     correspondences: (N, 5) u v X Y Z, the observed (distorted) pixels with the principal point removed.  RANSAC over P4Pfr

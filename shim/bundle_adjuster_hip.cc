@@ -101,7 +101,8 @@ void to_c_options(const BundleAdjustmentOptions& o, theia_ba_options* O) {
 int datum_doubles(int estimator) {
   switch (estimator) {
     case THEIA_EST_ABSOLUTE_POSE_KNEIP: case THEIA_EST_ABSOLUTE_POSE_DLS: case THEIA_EST_ABSOLUTE_POSE_SQPNP:
-    case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: case THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE: return 5;
+    case THEIA_EST_ABSOLUTE_POSE_KNOWN_ORIENTATION: case THEIA_EST_UNCALIBRATED_ABSOLUTE_POSE:
+    case THEIA_EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE: return 5;
     case THEIA_EST_DOMINANT_PLANE: return 3;
     case THEIA_EST_TRIANGULATION: return 33;
     case THEIA_EST_RADIAL_HOMOGRAPHY: return 12;

@@ -147,5 +147,10 @@ inline bool EstimateSimilarityTransformation2D3DBatch(const RansacParameters& p,
 
 inline bool EstimateRigidTransformation2D3DBatch(const RansacParameters& p, int t, const std::vector<std::vector<double>>& c26, EstimatorBatchResult* r, std::string* e) { return EstimateBatch(THEIA_EST_RIGID_TRANSFORMATION_2D3D, t, p, c26, nullptr, r, e); }
 
+// EstimateRadialDistUncalibratedAbsolutePose (estimate_radial_dist_uncalibrated_absolute_pose.h:63-83): meta = {max_focal_length,
+// min_focal_length, max_radial_distortion, min_radial_distortion, first call of the process (0 / 1)}; rows [u v X Y Z]; model =
+// rotation (9) | translation (3) | focal_length | radial_distortion
+inline bool EstimateRadialDistUncalibratedAbsolutePoseBatch(const RansacParameters& p, int t, const double meta[5], const std::vector<std::vector<double>>& c, EstimatorBatchResult* r, std::string* e) { return EstimateBatch(THEIA_EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE, t, p, c, meta, r, e); }
+
 }  // namespace theia_hip_shim
 #endif

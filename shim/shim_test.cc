@@ -178,6 +178,41 @@ int main() {
     }
     std::printf("ok rigid transformation batch\n");
   }
+  // ---- EstimateRadialDistUncalibratedAbsolutePose (P4Pfr): pixels of a camera with focal length 900 and division-model distortion -2e-7
+  {
+    const double f = 900.0, kd = -2e-7;
+    std::vector<std::vector<double>> c5(4);
+    for (int p = 0; p < 4; ++p) {
+      const double w[3] = {0.2 * U(gen), 0.2 * U(gen), 0.2 * U(gen)};
+      const double t[3] = {0.5 * U(gen), 0.5 * U(gen), 0.2};
+      for (int i = 0; i < 200; ++i) {
+        const double X[3] = {3 * U(gen), 3 * U(gen), 7.0 + 2 * U(gen)};
+        double q[3];
+        rotate(w, X, q);
+        for (int k = 0; k < 3; ++k) q[k] += t[k];
+        double u = f * q[0] / q[2], v = f * q[1] / q[2];
+        if (i % 5 == 4) { u = 400.0 * U(gen); v = 400.0 * U(gen); }            // 20 % outliers
+        else {                                                                   // DistortPoint (:56-74) + 0.3 px of noise
+          const double r2 = u * u + v * v, den = 2.0 * kd * r2, inner = 1.0 - 4.0 * kd * r2;
+          if (!(std::fabs(den) < 1e-15 || inner < 0.0)) { const double sc = (1.0 - std::sqrt(inner)) / den; u *= sc; v *= sc; }
+          u += 0.3 * N(gen); v += 0.3 * N(gen);
+        }
+        const double row[5] = {u, v, X[0], X[1], X[2]};
+        c5[p].insert(c5[p].end(), row, row + 5);
+      }
+    }
+    RansacParameters rp;
+    rp.error_thresh = 1.5 * 1.5; rp.min_iterations = 200; rp.max_iterations = 2000; rp.seed = 11;
+    const double meta[5] = {2000.0, 100.0, -1e-5, -1e-9, 0.0};
+    EstimatorBatchResult rr; std::string rerr;
+    if (!EstimateRadialDistUncalibratedAbsolutePoseBatch(rp, THEIA_RANSAC_RANSAC, meta, c5, &rr, &rerr)) { std::printf("FAIL: %s\n", rerr.c_str()); return 1; }
+    for (int p = 0; p < 4; ++p) {
+      std::printf("radial-distortion absolute pose (P4Pfr) %d: success %d, %zu inliers of 200, focal length %.1f, distortion %.2e\n", p, (int)rr.success[p],
+                  rr.summaries[p].inliers.size(), rr.models[p][12], rr.models[p][13]);
+      if (!rr.success[p] || rr.summaries[p].inliers.size() < 140 || !(std::fabs(rr.models[p][12] - f) < 0.05 * f)) { std::printf("FAIL: radial-distortion absolute pose\n"); return 1; }
+    }
+    std::printf("ok radial-distortion absolute pose batch\n");
+  }
   // ---- the generic front end under the reference's other names: fundamental matrix on the relative-pose pairs (pixels)
   {
     std::vector<std::vector<double>> px = corr;

@@ -417,3 +417,187 @@ class UpnpRoute:
             if all(((R @ X + t - o) @ f) >= 0 for X, o, f in zip(world, origin, direction)):   # in front, seen along the ray
                 out.append((R, t))
         return out
+
+
+# ------------------------------------------------------------------------------------------------ P4Pfr (round 4)
+class LibstdcxxStream:
+    """std::mt19937 with libstdc++'s uniform_int_distribution<int> (Lemire) and uniform_real_distribution<double>
+    (generate_canonical: two 32-bit draws), written from the library's documented algorithms on numpy's MT19937 core
+    (np.random.RandomState(seed) runs init_genrand(seed), as std::mt19937::seed does; bytes(4) is one 32-bit output)."""
+
+    def __init__(self, seed):
+        self.seed(seed)
+
+    def seed(self, seed):
+        self.rs = np.random.RandomState(int(seed))
+
+    def next(self):
+        return int.from_bytes(self.rs.bytes(4), "little")
+
+    def rand_int(self, lo, hi):
+        urange = hi - lo
+        if urange == 0xFFFFFFFF:
+            return self.next() + lo
+        rng = urange + 1
+        product = self.next() * rng
+        low = product & 0xFFFFFFFF
+        if low < rng:
+            threshold = (2 ** 32 - rng) % rng
+            while low < threshold:
+                product = self.next() * rng
+                low = product & 0xFFFFFFFF
+        return (product >> 32) + lo
+
+    def rand_double(self, lo, hi):
+        s = float(self.next()) + float(self.next()) * 4294967296.0       # exact products; ONE rounding in the sum, as in double arithmetic
+        r = s / 18446744073709551616.0
+        if r >= 1.0:
+            r = np.nextafter(1.0, 0.0)
+        return r * (hi - lo) + lo
+
+    def p4pfr_rounds(self, n, iters, first_call=False):
+        """RandomSampler::Sample (partial Fisher-Yates on a persistent index vector) followed by the solver's three draws."""
+        idx = list(range(n))
+        samples, draws = [], []
+        for it in range(iters):
+            for i in range(4):
+                j = self.rand_int(i, n - 1)
+                idx[i], idx[j] = idx[j], idx[i]
+            samples.append(idx[:4])
+            if first_call and it == 0:
+                self.seed(42)
+            draws.append([self.rand_double(-0.5, 0.5) for _ in range(3)])
+        return np.array(samples), np.array(draws)
+
+
+class P4pfrRoute:
+    """EstimateRadialDistUncalibratedAbsolutePose's hypotheses with numpy / LAPACK: SVD for the normalising rotation and for the
+    null space of the 5 x 8 system (the reference: JacobiSVD and HouseholderQR), least squares for the particular solution and
+    for D (FullPivLU / ColPivHouseholderQR), the ten equations by generic polynomial arithmetic on exponent tuples from the
+    definitions of the projection-matrix rows (the cubic forms' terms and the rows / columns of the template are read from
+    oracle/p4pfr_layout.h as data), the template reduced by np.linalg.lstsq (minimum-norm alpha; Eigen's FullPivLU solve keeps the
+    free unknowns at zero -- any alpha with alpha^T C0 = b gives the same action matrix on the solutions), np.linalg.eig."""
+
+    def __init__(self, layout_path):
+        import re
+        txt = open(layout_path).read()
+
+        def table(name, width):
+            body = re.search(name + r"\[\d+\](?:\[\d+\])* = \{(.*?)\};", txt, re.S).group(1)
+            return np.array([int(v) for v in re.findall(r"-?\d+", body)]).reshape(-1, width)
+        self.col = [tuple(r) for r in table("kColMono", 5)]
+        self.row_eq = table("kRowEq", 1).ravel()
+        self.row_mul = table("kRowMul", 5)
+        nterm = table("kCubicTerms", 1).ravel()
+        cub = table("kCubic", 4).reshape(5, -1, 4)
+        self.cubic = [cub[f, :nterm[f]] for f in range(5)]
+        self.am_row = table("kAmRow", 1).ravel()
+        self.cidx = {m: c for c, m in enumerate(self.col)}
+
+    @staticmethod
+    def _mul(a, b):
+        out = {}
+        for ea, ca in a.items():
+            for eb, cb in b.items():
+                e = tuple(x + y for x, y in zip(ea, eb))
+                out[e] = out.get(e, 0.0) + ca * cb
+        return out
+
+    @staticmethod
+    def _add(a, b, s=1.0):
+        out = dict(a)
+        for e, c in b.items():
+            out[e] = out.get(e, 0.0) + s * c
+        return out
+
+    def fit(self, feat, world, draws, limits):
+        A1, A2, A3, K, Wv, ONE = (1, 0, 0, 0, 0), (0, 1, 0, 0, 0), (0, 0, 1, 0, 0), (0, 0, 0, 1, 0), (0, 0, 0, 0, 1), (0, 0, 0, 0, 0)
+        d = (feat ** 2).sum(1)
+        t0 = world.mean(0)
+        Xc = (world - t0).T                                   # 3 x 4
+        Us = np.linalg.svd(Xc)[0]
+        if np.linalg.det(Us) < 0:
+            Us[:, 0] *= -1
+        R0 = Us.T
+        U = R0 @ Xc
+        scale = np.linalg.norm(U, axis=0).mean(); U = U / scale
+        U4 = np.vstack([U, np.ones(4)])
+        f0 = np.linalg.norm(feat, axis=1).mean(); u = (feat / f0).T     # 2 x 4
+        k0 = d.mean(); d = d / k0
+        M = np.zeros((5, 8)); b = np.zeros(5)
+        M[0, :4] = U4[:, 0]; M[1, 4:] = U4[:, 0]; b[:2] = u[:, 0]
+        for k in range(1, 4):
+            M[k + 1, :4] = u[1, k] * U4[:, k]; M[k + 1, 4:] = -u[0, k] * U4[:, k]
+        Nn = np.zeros((8, 4))
+        ang = np.linalg.norm(draws)
+        Kx = np.array([[0, -draws[2], draws[1]], [draws[2], 0, -draws[0]], [-draws[1], draws[0], 0]])
+        Rr = np.cos(ang) * np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * np.outer(draws, draws)     # AngleAxis on the raw vector
+        Nn[:, :3] = np.linalg.svd(M)[2][5:].T @ Rr
+        Nn[:, 3] = np.linalg.lstsq(M, b, rcond=None)[0]
+        UN1 = U4[:, 1:].T @ Nn[:4]; UN2 = U4[:, 1:].T @ Nn[4:]
+        B = np.zeros((6, 9)); C = np.zeros((6, 3))
+        for h, UN in enumerate((UN1, UN2)):
+            B[3 * h:3 * h + 3, :3] = UN[:, :3]; B[3 * h:3 * h + 3, 3:7] = d[1:, None] * UN; B[3 * h:3 * h + 3, 8] = UN[:, 3]
+            B[3 * h:3 * h + 3, 7] = -u[h, 1:] * U[2, 1:]
+            C[3 * h:3 * h + 3] = u[h, 1:, None] * np.stack([U[0, 1:], U[1, 1:], np.ones(3)], axis=1)
+        D = np.linalg.lstsq(C, B, rcond=None)[0]              # 3 x 9
+        lin = lambda row: {A1: row[0], A2: row[1], A3: row[2], ONE: row[3]}
+        tm = [A1, A2, A3, (1, 0, 0, 1, 0), (0, 1, 0, 1, 0), (0, 0, 1, 1, 0), K, Wv, ONE]
+        p1 = [lin(Nn[r]) for r in range(3)]; p2 = [lin(Nn[4 + r]) for r in range(3)]
+        p3 = [{tm[c]: D[0, c] for c in range(9)}, {tm[c]: D[1, c] for c in range(9)}, {Wv: 1.0}]
+        p3w = {tm[c]: D[2, c] for c in range(9)}
+        dot = lambda x, y: self._add(self._add(self._mul(x[0], y[0]), self._mul(x[1], y[1])), self._mul(x[2], y[2]))
+        q = p1 + p2
+        eqs = [dot(p2, p3), dot(p1, p3), dot(p1, p2), self._add(dot(p1, p1), dot(p2, p2), -1.0)]
+        for form in self.cubic:
+            e = {}
+            for i, j, l, c in form:
+                e = self._add(e, self._mul(self._mul(q[i], q[j]), p3[l]), float(c))
+            eqs.append(e)
+        e9 = self._add({ONE: 1.0, K: d[0]}, p3w, -1.0)
+        for r in range(3):
+            e9 = self._add(e9, p3[r], -U[r, 0])
+        eqs.append(e9)
+        T = np.zeros((40, 50))
+        for r in range(40):
+            for e, c in eqs[self.row_eq[r]].items():
+                T[r, self.cidx[tuple(x + y for x, y in zip(e, self.row_mul[r]))]] = c
+        bm = np.zeros((7, 37)); bm[np.arange(7), 30 + np.arange(7)] = -1.0
+        alpha = np.linalg.lstsq(T[:, :37].T, bm.T, rcond=None)[0]          # 40 x 7
+        RR = np.vstack([alpha.T @ T[:, 37:], np.eye(13)])
+        w, V = np.linalg.eig(RR[self.am_row])
+        V = V / V[0]
+        out = []
+        for j in range(13):
+            if abs(V[5, j].imag) > 1e-6:
+                continue
+            a = np.array([V[5, j].real, V[7, j].real, w[j].real, 1.0]); k = V[1, j].real; P33 = V[3, j].real
+            P12 = Nn @ a
+            tmp = np.array([a[0], a[1], a[2], k * a[0], k * a[1], k * a[2], k, P33, 1.0])
+            P3 = D @ tmp
+            P = np.vstack([P12[:4], P12[4:], [P3[0], P3[1], P33, P3[2]]])
+            P = P / np.linalg.norm(P[2, :3])
+            f = np.linalg.norm(P[0, :3])
+            focal = f * f0; rd = k / k0
+            if focal < limits[1] or focal > limits[0] or rd < limits[2] or rd > limits[3] or rd > 0.0:
+                continue
+            Rt = np.diag([1 / f, 1 / f, 1.0]) @ P
+            if np.linalg.det(Rt[:, :3]) < 0:
+                Rt = -Rt
+            R = Rt[:, :3] @ R0
+            out.append((R, Rt[:, 3] * scale - R @ t0, focal, rd))
+        return out
+
+
+def radial_dist_errors(model, feat, world):
+    """RadialDistUncalibratedAbsolutePoseEstimator::Error, vectorised."""
+    R, t, focal, rd = model
+    if t[2] < 0.0:
+        return np.full(len(feat), 1e10)
+    pc = world @ R.T + t
+    x = focal * pc[:, :2] / pc[:, 2:3]
+    r2 = (x * x).sum(1)
+    den = 2.0 * rd * r2; inner = 1.0 - 4.0 * rd * r2
+    keep = (np.abs(den) < 1e-15) | (inner < 0.0)
+    sc = np.where(keep, 1.0, (1.0 - np.sqrt(np.maximum(inner, 0.0))) / np.where(keep, 1.0, den))
+    return ((x * sc[:, None] - feat) ** 2).sum(1)

@@ -76,3 +76,46 @@ def test_numpy_routes_replay_the_oracles_ransac_on_cpu():
                     return e
             mask, _ = nr.ransac_inlier_support(samples, fit, err, thr, len(d))
             assert np.array_equal(mask, o["inlier_mask"].astype(bool)), (leg, i, int(mask.sum()), int(o["inlier_mask"].sum()))
+
+
+def test_python_libstdcxx_stream_matches_the_golden_interleaving():
+    """The stream the numpy P4Pfr route replays -- RandInt and RandDouble interleaved on one std::mt19937, written in Python on
+    numpy's MT19937 core -- against what the real libstdc++ produced (golden/make_randdouble_golden.cpp)."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mt19937_randdouble.json")))
+    for key, first_call in (("interleaved", False), ("interleaved_first_call", True)):
+        s = nr.LibstdcxxStream(g[key]["seed"])
+        for it, row in enumerate(g[key]["rounds"]):
+            assert [s.rand_int(i, g[key]["n"] - 1) for i in range(4)] == row[:4]
+            if first_call and it == 0:
+                s.seed(42)
+            assert [s.rand_double(-0.5, 0.5) for _ in range(3)] == row[4:7]
+
+
+def test_numpy_p4pfr_route_replays_the_oracles_ransac_on_cpu():
+    """The numpy / LAPACK P4Pfr route (SVD null space, least-squares reduction of the template, np.linalg.eig, its own Python
+    restatement of the interleaved sample / draw stream) against the oracle's RANSAC loop: identical inlier sets."""
+    import os
+    from pytheiasfm_amd import synth
+    NP, CORR, HY, thr = 3, 300, 96, 4.0 ** 2
+    route = nr.P4pfrRoute(os.path.join(os.path.dirname(__file__), "..", "oracle", "p4pfr_layout.h"))
+    limits = [2000.0, 100.0, -1e-5, -1e-9]
+    data, offsets, TRUTH = synth.synth_ransac_v1(NP, CORR, "absolute", seed=0x5AC50005, noise_px=0.5, inlier_lo=0.7, inlier_hi=0.9)
+    data = ransac.radial_dist_correspondence_rows(ransac.shift_world_along_optical_axis(data, offsets, TRUTH["R"], 2.0), 1000.0, -1e-7)
+    for first_call in (0.0, 1.0):
+        ol.set_estimator_params(limits + [first_call])
+        try:
+            for i in range(NP):
+                d = data[offsets[i]:offsets[i + 1]]
+                pc = ol.default_ransac_params(thr, seed=1 + i); pc.min_iterations = HY; pc.max_iterations = HY
+                o = ol.ransac_estimate(16, d, pc)
+                samples, draws = nr.LibstdcxxStream(1 + i).p4pfr_rounds(len(d), HY, first_call=bool(first_call))
+                feat, world = d[:, :2], d[:, 2:5]
+                fit = lambda it, idx: route.fit(feat[idx], world[idx], draws[it], limits)
+                err = lambda mm: nr.radial_dist_errors(mm, feat, world)
+                mask, _ = nr.ransac_inlier_support(samples, fit, err, thr, len(d))
+                assert np.array_equal(mask, o["inlier_mask"].astype(bool)), (first_call, i, int(mask.sum()), int(o["inlier_mask"].sum()))
+                assert mask.sum() > 0.2 * len(d)      # (a minimal sample with half a pixel of noise: the focal length is a few per cent off)
+        finally:
+            ol.set_estimator_params([0.0] * 5)

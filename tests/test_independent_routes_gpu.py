@@ -17,6 +17,7 @@ from tests import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 NP, CORR, HYPS = 6, 2000, 768
+P4PFR_LIMITS = [2000.0, 100.0, -1e-5, -1e-9]      # RadialDistUncalibratedAbsolutePoseMetaData of the reference's estimator test
 
 
 def _replay(leg, data, offsets, thr, seed0):
@@ -52,6 +53,12 @@ def _replay(leg, data, offsets, thr, seed0):
             samples = ol.sampler_stream(seed0 + i, len(d), 3, HYPS)
             fit = lambda it, idx: nr.p3p_kneip(feat[idx], world[idx])
             err = lambda m: nr.absolute_pose_errors(m, feat, world)
+        elif leg == "p4pfr":                          # samples and the solver's draws from ONE stream (numpy_routes.LibstdcxxStream)
+            feat, world = d[:, :2], d[:, 2:5]
+            route = nr.P4pfrRoute(os.path.join(os.path.dirname(__file__), "..", "oracle", "p4pfr_layout.h"))
+            samples, draws = nr.LibstdcxxStream(seed0 + i).p4pfr_rounds(len(d), HYPS)
+            fit = lambda it, idx, route=route, draws=draws: route.fit(feat[idx], world[idx], draws[it], P4PFR_LIMITS)
+            err = lambda m: nr.radial_dist_errors(m, feat, world)
         elif leg == "upnp":                           # the central overload: identity pinhole cameras, 26-double rows
             feat, world = d[:, 7:9], d[:, 3:6]
             route = nr.UpnpRoute(os.path.join(os.path.dirname(__file__), "..", "oracle", "upnp_layout.h"))
@@ -88,7 +95,7 @@ def _planar_pairs(seed):
     return np.concatenate(data), np.array(offsets, dtype=np.int64)
 
 
-@pytest.mark.parametrize("leg", ["five_point", "dls", "essential", "fundamental", "homography", "p3p", "upnp"])
+@pytest.mark.parametrize("leg", ["five_point", "dls", "essential", "fundamental", "homography", "p3p", "upnp", "p4pfr"])
 def test_c5_shape_inlier_sets_against_an_independent_numpy_route(leg):
     est, kind, thr = {"five_point": (ransac.EST_RELATIVE_POSE, "relative", (2.0 / 1000.0) ** 2),
                       "dls": (ransac.EST_ABS_DLS, "absolute", (4.0 / 1000.0) ** 2),
@@ -96,15 +103,20 @@ def test_c5_shape_inlier_sets_against_an_independent_numpy_route(leg):
                       "fundamental": (ransac.EST_FUNDAMENTAL_MATRIX, "relative", (2.0 / 1000.0) ** 2),
                       "homography": (ransac.EST_HOMOGRAPHY, "planar", (3.0 / 1000.0) ** 2),
                       "p3p": (ransac.EST_ABS_KNEIP, "absolute", (4.0 / 1000.0) ** 2),
-                      "upnp": (ransac.EST_RIGID_TRANSFORMATION_2D3D, "absolute", (4.0 / 1000.0) ** 2)}[leg]
+                      "upnp": (ransac.EST_RIGID_TRANSFORMATION_2D3D, "absolute", (4.0 / 1000.0) ** 2),
+                      "p4pfr": (ransac.EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE, "absolute", 4.0 ** 2)}[leg]
     if kind == "planar":
         data, offsets = _planar_pairs(0x5AC5)
     else:
-        data, offsets, truth = synth.synth_ransac_v1(NP, CORR, kind, seed=0x5AC50005)
+        data, offsets, TRUTH = synth.synth_ransac_v1(NP, CORR, kind, seed=0x5AC50005)
     if leg == "upnp":
         data = ransac.central_correspondence_rows(data)
+    ep = None
+    if leg == "p4pfr":
+        data = ransac.radial_dist_correspondence_rows(ransac.shift_world_along_optical_axis(data, offsets, TRUTH["R"], 2.0), 1000.0, -1e-7)    # pixels of a camera with focal length 1000, distortion -1e-7
+        ep = np.array(P4PFR_LIMITS + [0.0])
     p = ransac.RansacParameters(); p.error_thresh = thr; p.min_iterations = HYPS; p.max_iterations = HYPS; p.seed = 1
-    res = ransac.estimate_batch(est, data, offsets, p)
+    res = ransac.estimate_batch(est, data, offsets, p, ep)
     masks = _replay(leg, data, offsets, thr, p.seed)
     equal, worst = 0, 0
     for i in range(NP):

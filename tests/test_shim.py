@@ -25,6 +25,6 @@ def test_shim_runs_bundle_adjustment_and_ransac_on_the_device():
     _build()
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    for line in ("ok bundle adjustment", "ok relative pose batch", "ok calibrated absolute pose batches", "ok rigid transformation batch", "ok fundamental matrix batch",
+    for line in ("ok bundle adjustment", "ok relative pose batch", "ok calibrated absolute pose batches", "ok rigid transformation batch", "ok radial-distortion absolute pose batch", "ok fundamental matrix batch",
                  "ok view batch", "ok track covariances"):
         assert line in r.stdout, r.stdout
