@@ -318,6 +318,17 @@ def upnp_estimate_pose(origin, direction, world, state=None):
     return q[:n], t[:n], st
 
 
+def best_pose_from_essential(E, corr):
+    """GetBestPoseFromEssentialMatrix (essential_matrix_utils.cc:109-149): (points in front, rotation, position)."""
+    L = rlib()
+    dp = capi.c_double_p
+    L.oracle_best_pose_from_essential.argtypes = [dp, dp, C.c_int, dp, dp]
+    E = np.ascontiguousarray(E, dtype=np.float64); c = np.ascontiguousarray(corr, dtype=np.float64).reshape(-1, 4)
+    R = np.zeros((3, 3)); pos = np.zeros(3)
+    n = L.oracle_best_pose_from_essential(capi.ptr(E, C.c_double), capi.ptr(c, C.c_double), len(c), capi.ptr(R, C.c_double), capi.ptr(pos, C.c_double))
+    return n, R, pos
+
+
 def p4pfr_solve(feat, world, rot_vec, limits, want_matrices=False):
     """FourPointsPoseFocalLengthRadialDistortion (oracle/p4pfr_oracle.h).  feat (4, 2), world (4, 3), rot_vec: the three
     RandDouble(-0.5, 0.5) draws of the call, limits: (max focal, min focal, max distortion, min distortion).  Returns the models

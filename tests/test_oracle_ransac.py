@@ -1149,3 +1149,25 @@ def test_estimate_uncalibrated_absolute_pose_with_outliers():
     sure = np.abs(e - 4.0) > 1e-6
     assert np.array_equal((e < 4.0)[sure], o["inlier_mask"].astype(bool)[sure])
     assert o["inlier_mask"][good].mean() > 0.85 and o["inlier_mask"][~good].mean() < 0.05
+
+
+@pytest.mark.parametrize("num_outliers", [0, 50])
+def test_get_best_pose_from_essential_matrix_reference_scenes(num_outliers):
+    """essential_matrix_utils_test.cc:130-199 (GetBestPoseFromEssentialMatrix AllInliers / MostlyInliers), restated: 100 poses
+    (rotation <= 15 degrees, unit translation), 100 points around (0, 0, 100) in front of both cameras and `num_outliers` around
+    (0, 0, -100) behind them, E = [t]x R without noise.  The reference's criteria: the number of points in front is exactly the
+    number of inliers, rotation and position within 1e-12 (Frobenius / Euclidean).  Also DecomposeEssentialMatrix's test (:55-84):
+    one of the two rotations and +-translation match the generating pose."""
+    rng = np.random.default_rng(51 + num_outliers)
+    for _ in range(100):
+        aa = rng.normal(size=3); aa *= np.deg2rad(15.0 * rng.uniform()) / np.linalg.norm(aa)
+        K = np.array([[0, -aa[2], aa[1]], [aa[2], 0, -aa[0]], [-aa[1], aa[0], 0]]); th = np.linalg.norm(aa)
+        R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+        t = rng.uniform(-1, 1, 3); t /= np.linalg.norm(t)
+        E = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
+        X = np.concatenate([rng.uniform(-1, 1, (100, 3)) + [0, 0, 100], rng.uniform(-1, 1, (num_outliers, 3)) + [0, 0, -100]])
+        Y = X @ R.T + t
+        corr = np.concatenate([X[:, :2] / X[:, 2:3], Y[:, :2] / Y[:, 2:3]], axis=1)
+        n, Re, pe = ol.best_pose_from_essential(E, corr)
+        assert n == 100
+        assert np.linalg.norm(R - Re) < 1e-12 and np.linalg.norm(-R.T @ t - pe) < 1e-12
