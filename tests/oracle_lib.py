@@ -318,6 +318,16 @@ def upnp_estimate_pose(origin, direction, world, state=None):
     return q[:n], t[:n], st
 
 
+def focal_lengths_from_fundamental(F):
+    """FocalLengthsFromFundamentalMatrix (fundamental_matrix_util.cc:57-130): (ok, f1, f2)."""
+    L = rlib()
+    L.oracle_focal_lengths_from_fundamental.argtypes = [capi.c_double_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    F = np.ascontiguousarray(F, dtype=np.float64)
+    f1 = C.c_double(0); f2 = C.c_double(0)
+    ok = L.oracle_focal_lengths_from_fundamental(capi.ptr(F, C.c_double), C.byref(f1), C.byref(f2))
+    return bool(ok), f1.value, f2.value
+
+
 def best_pose_from_essential(E, corr):
     """GetBestPoseFromEssentialMatrix (essential_matrix_utils.cc:109-149): (points in front, rotation, position)."""
     L = rlib()

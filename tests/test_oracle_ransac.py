@@ -1171,3 +1171,19 @@ def test_get_best_pose_from_essential_matrix_reference_scenes(num_outliers):
         n, Re, pe = ol.best_pose_from_essential(E, corr)
         assert n == 100
         assert np.linalg.norm(R - Re) < 1e-12 and np.linalg.norm(-R.T @ t - pe) < 1e-12
+
+
+def test_focal_lengths_from_fundamental_matrix_reference_scenes():
+    """fundamental_matrix_util_test.cc:54-80 (FundamentalMatrixUtil.FocalLengths), restated: 100 random poses (angle-axis in
+    [-1, 1]^3, unit translation), F = K2^-1 [t]x R K1^-1 (ComposeFundamentalMatrix :251-269) with focal lengths 800 and 1000;
+    the reference's criterion: both recovered within 1e-6."""
+    rng = np.random.default_rng(51)
+    for _ in range(100):
+        aa = rng.uniform(-1, 1, 3); th = np.linalg.norm(aa); ax = aa / th
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+        t = rng.uniform(-1, 1, 3); t /= np.linalg.norm(t)
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        F = np.diag([1 / 1000.0, 1 / 1000.0, 1.0]) @ tx @ R @ np.diag([1 / 800.0, 1 / 800.0, 1.0])
+        ok, f1, f2 = ol.focal_lengths_from_fundamental(F)
+        assert ok and abs(f1 - 800.0) < 1e-6 and abs(f2 - 1000.0) < 1e-6, (f1, f2)
