@@ -601,3 +601,105 @@ def radial_dist_errors(model, feat, world):
     keep = (np.abs(den) < 1e-15) | (inner < 0.0)
     sc = np.where(keep, 1.0, (1.0 - np.sqrt(np.maximum(inner, 0.0))) / np.where(keep, 1.0, den))
     return ((x * sc[:, None] - feat) ** 2).sum(1)
+
+
+# ------------------------------------------------------------------------------------------------ four small estimators (round 4)
+def plane_from_points(pts):
+    """DominantPlaneEstimator::EstimateModel: the plane through three points -- the normal as the direction of least variance of
+    the centred points (numpy SVD; the reference: a cross product), the sample's first point on the plane; collinear samples
+    (|cross product|^2 < 1e-6, estimate_dominant_plane_from_points.cc:70-74) give no model."""
+    a, b = pts[1] - pts[0], pts[2] - pts[0]
+    if np.sum(np.cross(a, b) ** 2) < 1e-6:
+        return []
+    n = np.linalg.svd(pts - pts.mean(0))[2][-1]
+    return [(pts[0], n)]
+
+
+def plane_errors(model, pts):
+    p0, n = model
+    return np.abs((pts - p0) @ n)                     # point-to-plane distance, not squared (:84-86)
+
+
+def two_point_position(x1, x2):
+    """RelativePoseFromTwoPointsWithKnownRotation: the null vector of the 2 x 3 epipolar constraint by numpy's SVD (the
+    reference: a FullPivLU kernel), normalised; sign as the reference's kernel vector has it (the free variable = +1 in the LU's
+    column order is reproduced by fixing the sign through the largest-magnitude convention below)."""
+    A = np.array([[-x1[i, 1] + x2[i, 1], -x2[i, 0] + x1[i, 0], x1[i, 1] * x2[i, 0] - x1[i, 0] * x2[i, 1]] for i in range(2)])
+    s = np.linalg.svd(A, compute_uv=False)
+    if s[1] <= 2 * np.finfo(float).eps * 2.0 * s[0]:
+        return []
+    v = np.linalg.svd(A)[2][-1]
+    return [v / np.linalg.norm(v)]
+
+
+def known_orientation_errors(pos, x1h, x2h):
+    E = np.array([[0.0, pos[2], -pos[1]], [-pos[2], 0.0, pos[0]], [pos[1], -pos[0], 0.0]])
+    return sampson_errors(E, x1h, x2h)               # the Sampson distance does not see the sign of the position
+
+
+def position_from_rays(feat, world):
+    """PositionFromTwoRays: least squares of the 4 x 3 system (numpy lstsq; the reference: ColPivHouseholderQR)."""
+    A = np.zeros((4, 3)); b = np.zeros(4)
+    for i in range(2):
+        u, v = feat[i]; X, Y, Z = world[i]
+        A[2 * i] = [1.0, 0.0, -u]; A[2 * i + 1] = [0.0, 1.0, -v]
+        b[2 * i] = X - u * Z; b[2 * i + 1] = Y - v * Z
+    x, _, rank, _ = np.linalg.lstsq(A, b, rcond=None)
+    return [x] if rank == 3 else []
+
+
+def known_orientation_abs_errors(pos, feat, world):
+    p = world - pos
+    return ((p[:, :2] / p[:, 2:3] - feat) ** 2).sum(1)
+
+
+def focal_lengths_bougnoux(F):
+    """Focal lengths of the two cameras from a fundamental matrix with both principal points at the origin -- Bougnoux's closed
+    form (f1^2 = -(p2^T [e2]x I~ F p1)(p1^T F^T p2) / (p2^T [e2]x I~ F I~ F^T p2), p = (0, 0, 1), I~ = diag(1, 1, 0)); the
+    reference rotates the epipoles onto the x axis and solves the resulting 2 x 2 (fundamental_matrix_util.cc:57-130)."""
+    It = np.diag([1.0, 1.0, 0.0]); p = np.array([0.0, 0.0, 1.0])
+
+    def one(F):
+        e2 = np.linalg.svd(F.T)[2][-1]
+        ex = np.array([[0, -e2[2], e2[1]], [e2[2], 0, -e2[0]], [-e2[1], e2[0], 0]])
+        return -(p @ ex @ It @ F @ p) * (p @ F.T @ p) / (p @ ex @ It @ F @ It @ F.T @ p)
+    return one(F), one(F.T)
+
+
+def uncalibrated_relative_pose_models(x1, x2, min_max_focal):
+    """UncalibratedRelativePoseEstimator::EstimateModel (estimate_uncalibrated_relative_pose.cc:83-138): 8-point F (numpy SVD),
+    focal lengths by Bougnoux's formula, E = K2 F K1, the pose with the most points in front."""
+    out = []
+    for F in eight_point(x1, x2):
+        f1sq, f2sq = focal_lengths_bougnoux(F)
+        if not (f1sq > 0 and f2sq > 0):
+            continue
+        f1, f2 = np.sqrt(f1sq), np.sqrt(f2sq)
+        lo, hi = min_max_focal
+        if lo >= 1.0 and hi >= 1.0 and (f1 < lo or f2 < lo or f1 > hi or f2 > hi):
+            continue
+        E = np.diag([f2, f2, 1.0]) @ F @ np.diag([f1, f1, 1.0])
+        n1 = x1 / f1; n2 = x2 / f2
+        x1h = np.c_[n1, np.ones(len(n1))]; x2h = np.c_[n2, np.ones(len(n2))]
+        U, _, Vt = np.linalg.svd(E)
+        if np.linalg.det(U) < 0:
+            U[:, 2] *= -1
+        if np.linalg.det(Vt) < 0:
+            Vt[2] *= -1
+        Dm = np.array([[0.0, 1, 0], [-1, 0, 0], [0, 0, 1]])
+        R1, R2 = U @ Dm @ Vt, U @ Dm.T @ Vt
+        tr = U[:, 2] / np.linalg.norm(U[:, 2])
+        cands = [(R1, -R1.T @ tr), (R1, R1.T @ tr), (R2, -R2.T @ tr), (R2, R2.T @ tr)]
+        votes = [int(_in_front(x1h, x2h, R, pp).sum()) for R, pp in cands]
+        k = int(np.argmax(votes))
+        out.append((F, cands[k][0], cands[k][1], f1, f2))
+    return out
+
+
+def uncalibrated_relative_pose_errors(model, x1, x2):
+    F, R, pos, f1, f2 = model
+    x1h = np.c_[x1, np.ones(len(x1))]; x2h = np.c_[x2, np.ones(len(x2))]
+    err = sampson_errors(F, x1h, x2h)
+    n1h = np.c_[x1 / f1, np.ones(len(x1))]; n2h = np.c_[x2 / f2, np.ones(len(x2))]
+    err[~_in_front(n1h, n2h, R, pos)] = np.inf
+    return err

@@ -119,3 +119,56 @@ def test_numpy_p4pfr_route_replays_the_oracles_ransac_on_cpu():
                 assert mask.sum() > 0.2 * len(d)      # (a minimal sample with half a pixel of noise: the focal length is a few per cent off)
         finally:
             ol.set_estimator_params([0.0] * 5)
+
+
+def _small_leg(leg, NP, CORR, seed):
+    """(estimator id, data, offsets, sample size, threshold, estimator params) of one of the four small estimators."""
+    from pytheiasfm_amd import synth
+    if leg == "plane":
+        data, offsets, _ = synth.synth_ransac_v1(NP, CORR, "plane", seed=seed)
+        return 7, data, offsets, 3, 0.004, None
+    if leg == "rel_known":
+        data, offsets, _ = synth.synth_ransac_v1(NP, CORR, "known_orientation", seed=seed)
+        return 8, data, offsets, 2, (2.0 / 1000.0) ** 2, None
+    if leg == "abs_known":
+        data, offsets, truth = synth.synth_ransac_v1(NP, CORR, "absolute", seed=seed)
+        rot = [ransac.RotateCorrespondences(data[offsets[i]:offsets[i + 1]], synth.matrix_to_angle_axis(truth["R"][i])) for i in range(NP)]
+        return 10, np.concatenate(rot), offsets, 2, (4.0 / 1000.0) ** 2, None
+    # (eight-point samples: inlier ratios of 0.75 - 0.9, so that a few hundred hypotheses hold all-inlier samples)
+    data, offsets, _ = synth.synth_ransac_v1(NP, CORR, "uncalibrated", seed=seed, noise_px=0.3, inlier_lo=0.75, inlier_hi=0.9)
+    return 9, data, offsets, 8, 4.0, np.array([1.0, 1e9])
+
+
+def small_leg_route(leg, d, ep):
+    """(fit, err) closures of the numpy route of one small estimator on the data of one problem."""
+    if leg == "plane":
+        return (lambda it, idx: nr.plane_from_points(d[idx])), (lambda m: nr.plane_errors(m, d))
+    if leg == "rel_known":
+        x1, x2 = d[:, :2], d[:, 2:4]
+        x1h = np.c_[x1, np.ones(len(d))]; x2h = np.c_[x2, np.ones(len(d))]
+        return (lambda it, idx: nr.two_point_position(x1[idx], x2[idx])), (lambda m: nr.known_orientation_errors(m, x1h, x2h))
+    if leg == "abs_known":
+        feat, world = d[:, :2], d[:, 2:5]
+        return (lambda it, idx: nr.position_from_rays(feat[idx], world[idx])), (lambda m: nr.known_orientation_abs_errors(m, feat, world))
+    x1, x2 = d[:, :2], d[:, 2:4]
+    return (lambda it, idx: nr.uncalibrated_relative_pose_models(x1[idx], x2[idx], ep)), (lambda m: nr.uncalibrated_relative_pose_errors(m, x1, x2))
+
+
+def test_numpy_routes_of_the_small_estimators_replay_the_oracles_ransac_on_cpu():
+    """Dominant plane (SVD normal instead of the cross product), known-orientation relative position (SVD null vector instead of
+    the FullPivLU kernel), known-orientation absolute position (lstsq instead of ColPivHouseholderQR), uncalibrated relative pose
+    (numpy 8-point, Bougnoux's focal-length formula instead of the reference's epipole rotation, numpy SVD decomposition):
+    identical inlier sets against the oracle's RANSAC loop."""
+    NP, CORR, HY = 2, 300, 96
+    for leg in ("plane", "rel_known", "abs_known", "uncalibrated"):
+        est, data, offsets, m, thr, ep = _small_leg(leg, NP, CORR, 0x5AC50005)
+        if ep is not None:
+            ol.set_estimator_params(ep)
+        for i in range(NP):
+            d = data[offsets[i]:offsets[i + 1]]
+            pc = ol.default_ransac_params(thr, seed=1 + i); pc.min_iterations = HY; pc.max_iterations = HY
+            o = ol.ransac_estimate(est, d, pc)
+            fit, err = small_leg_route(leg, d, ep)
+            mask, _ = nr.ransac_inlier_support(ol.sampler_stream(1 + i, len(d), m, HY), fit, err, thr, len(d))
+            assert np.array_equal(mask, o["inlier_mask"].astype(bool)), (leg, i, int(mask.sum()), int(o["inlier_mask"].sum()))
+            assert mask.sum() > 0.2 * len(d), (leg, i, int(mask.sum()))

@@ -128,3 +128,26 @@ def test_c5_shape_inlier_sets_against_an_independent_numpy_route(leg):
     print(f"\n[independent route] {leg}: inlier sets identical on {equal} of {NP} pairs ({CORR} correspondences x {HYPS} hypotheses); "
           f"largest symmetric difference {worst} correspondences")
     assert equal >= NP - 2 and worst <= 12, (equal, worst)
+
+
+@pytest.mark.parametrize("leg", ["plane", "rel_known", "abs_known", "uncalibrated"])
+def test_c5_shape_inlier_sets_of_the_small_estimators_against_a_numpy_route(leg):
+    """The same comparison for four more estimators (numpy routes: tests/numpy_routes.py, round 4): dominant plane,
+    known-orientation relative / absolute position, uncalibrated relative pose."""
+    from tests.test_independent_routes import _small_leg, small_leg_route
+    est, data, offsets, m, thr, ep = _small_leg(leg, NP, CORR, 0x5AC50005)
+    p = ransac.RansacParameters(); p.error_thresh = thr; p.min_iterations = HYPS; p.max_iterations = HYPS; p.seed = 1
+    res = ransac.estimate_batch(est, data, offsets, p, ep)
+    equal, worst = 0, 0
+    for i in range(NP):
+        d = data[offsets[i]:offsets[i + 1]]
+        fit, err = small_leg_route(leg, d, ep)
+        mask, _ = nr.ransac_inlier_support(ol.sampler_stream(p.seed + i, len(d), m, HYPS), fit, err, thr, len(d))
+        dm = res["inlier_mask"][offsets[i]:offsets[i + 1]].astype(bool)
+        diff = int((dm != mask).sum())
+        equal += diff == 0
+        worst = max(worst, diff)
+        assert abs(int(dm.sum()) - int(mask.sum())) <= 3, (leg, i, int(dm.sum()), int(mask.sum()))
+    print(f"\n[independent route] {leg}: inlier sets identical on {equal} of {NP} pairs ({CORR} correspondences x {HYPS} hypotheses); "
+          f"largest symmetric difference {worst} correspondences")
+    assert equal >= NP - 2 and worst <= 12, (equal, worst)
