@@ -356,13 +356,15 @@ __global__ __launch_bounds__(64) void k_p4pfr_a(int B, const int* __restrict__ a
   // Eigen::FullPivLU::compute on the 37 x 40 block, lane = column (the right-hand sides take the row operations along)
   int nonzero = kElim;
   double maxpivot = 0.0;
+  // the search of step k rides in the update of step k - 1 (each lane sees the new entries of its column as it writes them);
+  // only step 0 scans on its own.  best / brow: the first strict maximum of |column| over the rows that remain.
+  double best = -1.0; int brow = 0;
+  if (lane < kRows)
+    for (int i = 0; i < kElim; ++i) {
+      const double a = fabs(M[i * kLd + lane]);
+      if (a > best) { best = a; brow = i; }
+    }
   for (int k = 0; k < kElim; ++k) {
-    double best = -1.0; int brow = k;
-    if (lane >= k && lane < kRows)
-      for (int i = k; i < kElim; ++i) {
-        const double a = fabs(M[i * kLd + lane]);
-        if (a > best) { best = a; brow = i; }
-      }
     // the first strict maximum in column-major order: the largest value, in the lowest column that holds it
     double gbest = best;
     for (int s = 32; s > 0; s >>= 1) gbest = fmax(gbest, __shfl_xor(gbest, s));
@@ -381,9 +383,16 @@ __global__ __launch_bounds__(64) void k_p4pfr_a(int B, const int* __restrict__ a
     const double piv = M[k * kLd + k];
     if (lane > k && lane < kElim) M[lane * kLd + k] /= piv;
     __syncthreads();
+    best = -1.0; brow = k + 1;
     if (lane > k && lane < kLd) {
       const double ukj = M[k * kLd + lane];
-      for (int i = k + 1; i < kElim; ++i) M[i * kLd + lane] -= M[i * kLd + k] * ukj;
+      const bool searched = lane < kRows;
+      for (int i = k + 1; i < kElim; ++i) {
+        const double v = M[i * kLd + lane] - M[i * kLd + k] * ukj;
+        M[i * kLd + lane] = v;
+        const double a = fabs(v);
+        if (searched && a > best) { best = a; brow = i; }
+      }
     }
     __syncthreads();
   }

@@ -350,6 +350,11 @@ def _run_inverse_depth(options, recon, track_ids, const_view_ids=()):
     # (bundle_adjuster.cc:328-333), and Ceres then builds its own independent-set ordering from its hash-ordered
     # parameter graph -- not reproducible outside Ceres.  The sweeps are switched off here; the LM trajectory of a
     # default-options call can therefore differ from the reference's after the first accepted step.
+    if c_opts.use_inner_iterations:
+        import warnings
+        warnings.warn("inverse-depth bundle adjustment: use_inner_iterations is not reproducible outside Ceres in this mode (no inner "
+                      "ordering is handed over, bundle_adjuster.cc:328-333) and is switched off; see DESIGN.md section 2", RuntimeWarning,
+                      stacklevel=3)
     c_opts.use_inner_iterations = 0
     # AddViewPriors (bundle_adjuster.cc:290-313) runs in this mode over optimized_views_ = the views that observe an added
     # track or are the reference view of one: exactly the cameras the library counts as used (ba_invdepth.hip)

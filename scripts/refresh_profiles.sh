@@ -36,6 +36,9 @@ bash "$R/scripts/pmc_kernel.sh" "WRITE_SIZE" scripts/gpu_time_intr_c4.py 8 > "$O
 bash "$R/scripts/prof_ransac_leg.sh" dls 1000 > "$OUT/dls_summary.txt" 2>&1
 cp "$R/gpurun_out/dls_prof/kernel_stats.csv" "$OUT/dls_kernel_stats.csv" 2>/dev/null
 bash "$R/scripts/pmc_sq_ransac.sh" dls 250 > "$OUT/sq_dls.txt" 2>&1
+# P4Pfr leg at the C5 shape (1000 pairs x 2000 x 4096): kernel trace
+bash "$R/scripts/prof_ransac_leg.sh" p4pfr 1000 > "$OUT/p4pfr_summary.txt" 2>&1
+cp "$R/gpurun_out/p4pfr_prof/kernel_stats.csv" "$OUT/p4pfr_kernel_stats.csv" 2>/dev/null
 # the pipelines' default configuration (FOCAL | RADIAL free + inner iterations) at C4: kernel trace
 bash "$R/scripts/prof_script.sh" default_prof scripts/gpu_time_inner_c4.py 0x11 > "$OUT/default_summary.txt" 2>&1
 cp "$R/gpurun_out/default_prof/kernel_stats.csv" "$OUT/default_kernel_stats.csv" 2>/dev/null
