@@ -703,3 +703,86 @@ def uncalibrated_relative_pose_errors(model, x1, x2):
     n1h = np.c_[x1 / f1, np.ones(len(x1))]; n2h = np.c_[x2 / f2, np.ones(len(x2))]
     err[~_in_front(n1h, n2h, R, pos)] = np.inf
     return err
+
+
+# ------------------------------------------------------------------------------------------------ P4Pf (round 4)
+class P4pfRoute:
+    """EstimateUncalibratedAbsolutePose's hypotheses (P4Pf: four_point_focal_length.cc:100-222) with numpy / LAPACK: the four
+    inner-product equations of the rigid point configuration written from the geometry by generic polynomial arithmetic on
+    exponent tuples (x, y, z = depths of points b, c, d relative to a; w = focal length squared), the rows / columns of the
+    elimination template read from oracle/p4pf_tables.h as data, the targets reduced onto the basis by ONE np.linalg.lstsq on the
+    transposed system (the oracle / the device: partial-pivot elimination), np.linalg.eig, the similarity alignment by numpy SVD."""
+
+    def __init__(self, tables_path):
+        import re
+        txt = open(tables_path).read()
+
+        def table(name, width):
+            body = re.search(name + r"\[[A-Za-z0-9]+\](?:\[\d+\])? = \{(.*?)\};", txt, re.S).group(1)
+            return np.array([int(v) for v in re.findall(r"\d+", body)]).reshape(-1, width)
+        self.row_poly = [int(v) for v in re.search(r"THIP_P4PF_ROW_POLY \{(.*?)\}", txt).group(1).split(",")]
+        self.row_mul = table("kRowMul", 4)
+        self.col = {tuple(m): c for c, m in enumerate(table("kColMono", 4))}
+        assert len(self.row_poly) == 77 and len(self.col) == 104
+
+    def fit(self, feat, world):
+        mean = world.mean(0); wn = world - mean
+        wvar = np.linalg.norm(wn, axis=1).mean(); wn = wn / wvar
+        fvar = np.linalg.norm(feat, axis=1).mean(); fn = feat / fvar
+        g = [np.sum((wn[i] - wn[j]) ** 2) for i in range(4) for j in range(i + 1, 4)]
+        if np.prod(g) < 1e-15:
+            return []
+        X, Y, Z, W, ONE = (1, 0, 0, 0), (0, 1, 0, 0), (0, 0, 1, 0), (0, 0, 0, 1), (0, 0, 0, 0)
+        dep = [{ONE: 1.0}, {X: 1.0}, {Y: 1.0}, {Z: 1.0}]
+        mul, add = P4pfrRoute._mul, P4pfrRoute._add
+
+        def ip(i, j):      # X_i . X_j = dep_i dep_j (pt_i . pt_j + w)
+            return mul(mul(dep[i], dep[j]), {ONE: float(fn[i] @ fn[j]), W: 1.0})
+
+        def diff_dot(i, j):  # (X_i - X_a) . (X_j - X_a)
+            return add(add(add(ip(i, j), ip(0, i), -1.0), ip(0, j), -1.0), ip(0, 0))
+        dd = float((wn[3] - wn[0]) @ (wn[3] - wn[0]))
+        ks = [float((wn[1] - wn[0]) @ (wn[2] - wn[0])) / dd, float((wn[2] - wn[0]) @ (wn[2] - wn[0])) / dd,
+              float((wn[1] - wn[0]) @ (wn[3] - wn[0])) / dd, float((wn[2] - wn[0]) @ (wn[3] - wn[0])) / dd]
+        ad2 = diff_dot(3, 3)
+        polys = [add(diff_dot(1, 2), ad2, -ks[0]), add(diff_dot(2, 2), ad2, -ks[1]), add(diff_dot(1, 3), ad2, -ks[2]), add(diff_dot(2, 3), ad2, -ks[3])]
+        A = np.zeros((77, 104))
+        for r in range(77):
+            for e, c in polys[self.row_poly[r]].items():
+                A[r, self.col[tuple(a + b for a, b in zip(e, self.row_mul[r]))]] += c
+        E = np.zeros((94, 5)); E[89 + np.arange(5), np.arange(5)] = 1.0
+        Yc, res, rank, _ = np.linalg.lstsq(A[:, :94].T, E, rcond=None)
+        if rank < 77:
+            return []
+        T = np.zeros((10, 10))
+        T[0, 1] = T[1, 5] = T[2, 6] = T[3, 7] = T[4, 8] = 1.0
+        T[5:] = -(Yc.T @ A[:, 94:])
+        wv, V = np.linalg.eig(T)
+        out = []
+        for i in range(10):
+            if wv[i].imag != 0.0:
+                continue
+            v = (V[:, i] / V[0, i]).real
+            w = v[4]
+            if not w >= 0.0:
+                continue
+            f = np.sqrt(w)
+            depth = np.array([1.0, v[3], v[2], v[1]])
+            Ac = np.c_[fn * depth[:, None], f * depth]
+            ratios = [np.sqrt(gij / np.sum((Ac[i0] - Ac[j0]) ** 2)) for gij, (i0, j0) in zip(g, [(a, b) for a in range(4) for b in range(a + 1, 4)])]
+            Ac = Ac * np.mean(ratios)
+            m1, m2 = wn.mean(0), Ac.mean(0)
+            p1 = wn - m1; p2 = Ac - m2
+            p1 = p1 / np.linalg.norm(p1, axis=1, keepdims=True); p2 = p2 / np.linalg.norm(p2, axis=1, keepdims=True)
+            U, _, Vt = np.linalg.svd(p2.T @ p1)
+            S = np.diag([1.0, 1.0, -1.0 if np.linalg.det(U @ Vt) < 0 else 1.0])
+            R = U @ S @ Vt
+            t = wvar * (m2 - R @ m1) - R @ mean
+            fo = f * fvar
+            out.append(np.vstack([fo * np.r_[R[0], t[0]], fo * np.r_[R[1], t[1]], np.r_[R[2], t[2]]]))
+        return out
+
+
+def projection_errors(Pm, feat, world):
+    p = np.c_[world, np.ones(len(world))] @ Pm.T
+    return ((p[:, :2] / p[:, 2:3] - feat) ** 2).sum(1)

@@ -134,6 +134,10 @@ def _small_leg(leg, NP, CORR, seed):
         data, offsets, truth = synth.synth_ransac_v1(NP, CORR, "absolute", seed=seed)
         rot = [ransac.RotateCorrespondences(data[offsets[i]:offsets[i + 1]], synth.matrix_to_angle_axis(truth["R"][i])) for i in range(NP)]
         return 10, np.concatenate(rot), offsets, 2, (4.0 / 1000.0) ** 2, None
+    if leg == "p4pf":       # the features in pixels of a camera with focal length 1000 (principal point removed)
+        data, offsets, _ = synth.synth_ransac_v1(NP, CORR, "absolute", seed=seed, inlier_lo=0.6, inlier_hi=0.85)
+        data = data.copy(); data[:, :2] *= 1000.0
+        return 14, data, offsets, 4, 4.0 ** 2, None
     # (eight-point samples: inlier ratios of 0.75 - 0.9, so that a few hundred hypotheses hold all-inlier samples)
     data, offsets, _ = synth.synth_ransac_v1(NP, CORR, "uncalibrated", seed=seed, noise_px=0.3, inlier_lo=0.75, inlier_hi=0.9)
     return 9, data, offsets, 8, 4.0, np.array([1.0, 1e9])
@@ -150,6 +154,11 @@ def small_leg_route(leg, d, ep):
     if leg == "abs_known":
         feat, world = d[:, :2], d[:, 2:5]
         return (lambda it, idx: nr.position_from_rays(feat[idx], world[idx])), (lambda m: nr.known_orientation_abs_errors(m, feat, world))
+    if leg == "p4pf":
+        import os
+        feat, world = d[:, :2], d[:, 2:5]
+        route = nr.P4pfRoute(os.path.join(os.path.dirname(__file__), "..", "oracle", "p4pf_tables.h"))
+        return (lambda it, idx: route.fit(feat[idx], world[idx])), (lambda m: nr.projection_errors(m, feat, world))
     x1, x2 = d[:, :2], d[:, 2:4]
     return (lambda it, idx: nr.uncalibrated_relative_pose_models(x1[idx], x2[idx], ep)), (lambda m: nr.uncalibrated_relative_pose_errors(m, x1, x2))
 
@@ -157,10 +166,11 @@ def small_leg_route(leg, d, ep):
 def test_numpy_routes_of_the_small_estimators_replay_the_oracles_ransac_on_cpu():
     """Dominant plane (SVD normal instead of the cross product), known-orientation relative position (SVD null vector instead of
     the FullPivLU kernel), known-orientation absolute position (lstsq instead of ColPivHouseholderQR), uncalibrated relative pose
-    (numpy 8-point, Bougnoux's focal-length formula instead of the reference's epipole rotation, numpy SVD decomposition):
-    identical inlier sets against the oracle's RANSAC loop."""
+    (numpy 8-point, Bougnoux's focal-length formula instead of the reference's epipole rotation, numpy SVD decomposition), P4Pf (the
+    four equations by polynomial arithmetic from the geometry, the template reduced by one lstsq, numpy eig / SVD): identical inlier
+    sets against the oracle's RANSAC loop."""
     NP, CORR, HY = 2, 300, 96
-    for leg in ("plane", "rel_known", "abs_known", "uncalibrated"):
+    for leg in ("plane", "rel_known", "abs_known", "uncalibrated", "p4pf"):
         est, data, offsets, m, thr, ep = _small_leg(leg, NP, CORR, 0x5AC50005)
         if ep is not None:
             ol.set_estimator_params(ep)

@@ -130,10 +130,10 @@ def test_c5_shape_inlier_sets_against_an_independent_numpy_route(leg):
     assert equal >= NP - 2 and worst <= 12, (equal, worst)
 
 
-@pytest.mark.parametrize("leg", ["plane", "rel_known", "abs_known", "uncalibrated"])
+@pytest.mark.parametrize("leg", ["plane", "rel_known", "abs_known", "uncalibrated", "p4pf"])
 def test_c5_shape_inlier_sets_of_the_small_estimators_against_a_numpy_route(leg):
     """The same comparison for four more estimators (numpy routes: tests/numpy_routes.py, round 4): dominant plane,
-    known-orientation relative / absolute position, uncalibrated relative pose."""
+    known-orientation relative / absolute position, uncalibrated relative pose, uncalibrated absolute pose (P4Pf)."""
     from tests.test_independent_routes import _small_leg, small_leg_route
     est, data, offsets, m, thr, ep = _small_leg(leg, NP, CORR, 0x5AC50005)
     p = ransac.RansacParameters(); p.error_thresh = thr; p.min_iterations = HYPS; p.max_iterations = HYPS; p.seed = 1
