@@ -786,3 +786,66 @@ class P4pfRoute:
 def projection_errors(Pm, feat, world):
     p = np.c_[world, np.ones(len(world))] @ Pm.T
     return ((p[:, :2] / p[:, 2:3] - feat) ** 2).sum(1)
+
+
+# ------------------------------------------------------------------------------------------------ radial-distortion homography (round 4)
+def radial_homography_models(rows):
+    """SixPointRadialDistortionHomography (six_point_radial_distortion_homography.cc:62-149) on six correspondences (rows of 12:
+    pixels left / right, normalised left / right, f1 f2, lmin lmax): the two-dimensional null space of the 6 x 8 system by numpy's
+    SVD (the reference: JacobiSVD; the oracle / the device: one-sided Jacobi), the quadratic that makes the combination a
+    homography row pair, then the 6 x 5 system for the third row and l1 (numpy SVD), numpy's own 3 x 3 inverse."""
+    x = rows[:, 4:6]; u = rows[:, 6:8]
+    lmin, lmax = rows[0, 10], rows[0, 11]
+    u2 = (u * u).sum(1); x2 = (x * x).sum(1)
+    M = np.c_[-x[:, 1:2] * u, -x[:, 1], x[:, 0:1] * u, x[:, 0], -x[:, 1] * u2, x[:, 0] * u2]
+    N = np.linalg.svd(M)[2][6:].T                                # 8 x 2: a basis of the null space (any basis serves)
+    a = -N[2, 0] * N[7, 0] + N[5, 0] * N[6, 0]
+    b = -N[2, 0] * N[7, 1] - N[2, 1] * N[7, 0] + N[5, 0] * N[6, 1] + N[5, 1] * N[6, 0]
+    c = -N[2, 1] * N[7, 1] + N[5, 1] * N[6, 1]
+    dd = b * b - 4 * a * c
+    eps = 100.0 * np.finfo(float).eps
+    if abs(dd) < eps:
+        roots = [-b / (2 * a)]
+    elif dd > 0:
+        roots = [(-b + np.sqrt(dd)) / (2 * a), (-b - np.sqrt(dd)) / (2 * a)]
+    else:
+        return []
+    out = []
+    for r in roots:
+        n = r * N[:, 0] + N[:, 1]
+        l2 = n[6] / n[2]
+        if not (lmin <= l2 <= lmax):
+            continue
+        u3 = 1.0 + l2 * u2
+        rr = n[0] * u[:, 0] + n[1] * u[:, 1] + n[2] * u3
+        T = np.c_[-x[:, 0] * u[:, 0], -x[:, 0] * u[:, 1], -x[:, 0] * u3, x2 * rr, rr]
+        v = np.linalg.svd(T)[2][-1]
+        v = v[:4] / v[4]
+        l1 = v[3]
+        if not (lmin <= l1 <= lmax):
+            continue
+        H = np.array([n[0:3], n[3:6], v[0:3]])
+        out.append((H, np.linalg.inv(H), l1, l2))
+    return out
+
+
+def radial_homography_errors(model, rows):
+    """CheckRadialSymmetricError (:201-239), vectorised."""
+    H, Hi, l1, l2 = model
+    f1, f2 = rows[0, 8], rows[0, 9]
+    l1s, l2s = l1 / (f1 * f1), l2 / (f2 * f2)
+
+    def undist(p, f, l):
+        return np.c_[p / (f * (1.0 + l * (p * p).sum(1)))[:, None], np.ones(len(p))]
+
+    def dist(p3, f, l):
+        p = f * p3[:, :2] / p3[:, 2:3]
+        r2 = (p * p).sum(1)
+        den = 2.0 * l * r2; inner = 1.0 - 4.0 * l * r2
+        keep = (np.abs(den) < np.finfo(float).eps) | (inner < 0.0)
+        sc = np.where(keep, 1.0, (1.0 - np.sqrt(np.maximum(inner, 0.0))) / np.where(keep, 1.0, den))
+        return p * sc[:, None]
+    pl, pr = rows[:, 0:2], rows[:, 2:4]
+    bl, br = undist(pl, f1, l1s), undist(pr, f2, l2s)
+    dl = pl - dist(br @ H.T, f1, l1s); dr = pr - dist(bl @ Hi.T, f2, l2s)
+    return 0.5 * ((dl * dl).sum(1) + (dr * dr).sum(1))

@@ -134,6 +134,20 @@ def _small_leg(leg, NP, CORR, seed):
         data, offsets, truth = synth.synth_ransac_v1(NP, CORR, "absolute", seed=seed)
         rot = [ransac.RotateCorrespondences(data[offsets[i]:offsets[i + 1]], synth.matrix_to_angle_axis(truth["R"][i])) for i in range(NP)]
         return 10, np.concatenate(rot), offsets, 2, (4.0 / 1000.0) ** 2, None
+    if leg == "radhom":     # planar scenes through two cameras with division-model distortion, 25 % gross outliers (pixels)
+        from tests import radhom_scenes as rh
+        rng = np.random.default_rng(seed & 0xFFFF)
+        f1, f2 = 1200.0, 1300.0
+        data = []
+        for pair in range(NP):
+            k1, k2 = -rng.uniform(0.5, 3.0) * 1e-7, -rng.uniform(0.5, 3.0) * 1e-7
+            pts = np.column_stack([rng.uniform(-2, 2, CORR), rng.uniform(-2, 2, CORR), np.full(CORR, 4.0 + 0.2 * pair)])
+            R = synth.angle_axis_to_matrix(rng.uniform(-0.15, 0.15, (1, 3)))[0]
+            rows = rh.rows(pts, R, rng.uniform(-0.5, 0.5, 3), f1, f2, k1, k2, 0.3, rng)
+            out = rng.uniform(size=CORR) < 0.25
+            rows[out, 2:4] = rng.uniform(-600, 600, (int(out.sum()), 2)); rows[out, 6:8] = rows[out, 2:4] / f2
+            data.append(rows)
+        return 12, np.concatenate(data), (np.arange(NP + 1) * CORR).astype(np.int64), 6, 2.0 ** 2, None
     if leg == "p4pf":       # the features in pixels of a camera with focal length 1000 (principal point removed)
         data, offsets, _ = synth.synth_ransac_v1(NP, CORR, "absolute", seed=seed, inlier_lo=0.6, inlier_hi=0.85)
         data = data.copy(); data[:, :2] *= 1000.0
@@ -154,6 +168,8 @@ def small_leg_route(leg, d, ep):
     if leg == "abs_known":
         feat, world = d[:, :2], d[:, 2:5]
         return (lambda it, idx: nr.position_from_rays(feat[idx], world[idx])), (lambda m: nr.known_orientation_abs_errors(m, feat, world))
+    if leg == "radhom":
+        return (lambda it, idx: nr.radial_homography_models(d[idx])), (lambda m: nr.radial_homography_errors(m, d))
     if leg == "p4pf":
         import os
         feat, world = d[:, :2], d[:, 2:5]
@@ -170,7 +186,7 @@ def test_numpy_routes_of_the_small_estimators_replay_the_oracles_ransac_on_cpu()
     four equations by polynomial arithmetic from the geometry, the template reduced by one lstsq, numpy eig / SVD): identical inlier
     sets against the oracle's RANSAC loop."""
     NP, CORR, HY = 2, 300, 96
-    for leg in ("plane", "rel_known", "abs_known", "uncalibrated", "p4pf"):
+    for leg in ("plane", "rel_known", "abs_known", "uncalibrated", "p4pf", "radhom"):
         est, data, offsets, m, thr, ep = _small_leg(leg, NP, CORR, 0x5AC50005)
         if ep is not None:
             ol.set_estimator_params(ep)

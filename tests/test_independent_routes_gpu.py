@@ -130,7 +130,7 @@ def test_c5_shape_inlier_sets_against_an_independent_numpy_route(leg):
     assert equal >= NP - 2 and worst <= 12, (equal, worst)
 
 
-@pytest.mark.parametrize("leg", ["plane", "rel_known", "abs_known", "uncalibrated", "p4pf"])
+@pytest.mark.parametrize("leg", ["plane", "rel_known", "abs_known", "uncalibrated", "p4pf", "radhom"])
 def test_c5_shape_inlier_sets_of_the_small_estimators_against_a_numpy_route(leg):
     """The same comparison for four more estimators (numpy routes: tests/numpy_routes.py, round 4): dominant plane,
     known-orientation relative / absolute position, uncalibrated relative pose, uncalibrated absolute pose (P4Pf)."""
