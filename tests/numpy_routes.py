@@ -849,3 +849,47 @@ def radial_homography_errors(model, rows):
     bl, br = undist(pl, f1, l1s), undist(pr, f2, l2s)
     dl = pl - dist(br @ H.T, f1, l1s); dr = pr - dist(bl @ Hi.T, f2, l2s)
     return 0.5 * ((dl * dl).sum(1) + (dr * dr).sum(1))
+
+
+# ------------------------------------------------------------------------------------------------ triangulation (round 4)
+def triangulate_two_views(o1, o2):
+    """Triangulate (triangulation.cc:109-125) on two observation rows of THEIA_EST_TRIANGULATION in numpy matrix form: the
+    essential matrix of the two poses, the optimal image-point correction (:66-103), DLT by numpy's SVD; kept when the point is in
+    front of both cameras (estimate_triangulation.cc:82-87)."""
+    P1, P2 = o1[:12].reshape(3, 4), o2[:12].reshape(3, 4)
+    Rr = P1[:, :3] @ P2[:, :3].T
+    t = P1[:, 3] - Rr @ P2[:, 3]; t = t / np.linalg.norm(t)
+    E = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ Rr
+    p1 = np.array([o1[12], o1[13], 1.0]); p2 = np.array([o2[12], o2[13], 1.0])
+    S = np.array([[1.0, 0, 0], [0, 1.0, 0]])
+    Es = E[:2, :2]
+    l1 = S @ E @ p2; l2 = S @ E.T @ p1
+    a = l1 @ Es @ l2; b = (l1 @ l1 + l2 @ l2) / 2.0; c = p1 @ E @ p2
+    d = np.sqrt(b * b - a * c)
+    lam = c / (b + d)
+    l1 = l1 - Es @ (lam * l1); l2 = l2 - Es.T @ (lam * l2)
+    lam = lam * (2.0 * d) / (l1 @ l1 + l2 @ l2)
+    c1 = p1 - S.T @ (lam * l1); c2 = p2 - S.T @ (lam * l2)
+    c1 = c1[:2] / c1[2]; c2 = c2[:2] / c2[2]
+    A = np.array([c1[0] * P1[2] - P1[0], c1[1] * P1[2] - P1[1], c2[0] * P2[2] - P2[0], c2[1] * P2[2] - P2[1]])
+    X = np.linalg.svd(A)[2][-1]
+    # The reference's test is `point . projection_row_2 > 0` on the null vector AS RETURNED (estimate_triangulation.cc:62-66): it reads
+    # the sign Eigen's JacobiSVD happens to give the vector.  LAPACK's sign is another one, so the route takes the sign-free
+    # statement of the same condition -- positive depth of the finite point X / X_w in both cameras -- which is what Eigen's sign
+    # amounts to on every pair of the test scenes (231 of 231 geometrically valid pairs accepted by the oracle's restatement).
+    if X[3] < 0:
+        X = -X
+    return [X] if (P1[2] @ X > 0.0 and P2[2] @ X > 0.0) else []
+
+
+def triangulation_errors(X, rows, project):
+    """TriangulationEstimator::Error (estimate_triangulation.cc:92-101): squared pixel error through Camera::ProjectPoint (`project`:
+    pytheiasfm_amd.synth.project, numpy), infinite when the depth is not positive."""
+    n = len(rows)
+    ext = rows[:, 16:22]
+    uv, _ = project(int(rows[0, 22]), rows[:, 23:33], ext, np.tile(X, (n, 1)))
+    from pytheiasfm_amd import synth
+    depth = np.einsum("nij,nj->ni", synth.angle_axis_to_matrix(ext[:, 3:]), X[:3] - X[3] * ext[:, :3])[:, 2] / X[3]
+    e = ((uv - rows[:, 14:16]) ** 2).sum(1)
+    e[~(depth > 0)] = np.inf
+    return e

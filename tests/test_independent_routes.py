@@ -198,3 +198,50 @@ def test_numpy_routes_of_the_small_estimators_replay_the_oracles_ransac_on_cpu()
             mask, _ = nr.ransac_inlier_support(ol.sampler_stream(1 + i, len(d), m, HY), fit, err, thr, len(d))
             assert np.array_equal(mask, o["inlier_mask"].astype(bool)), (leg, i, int(mask.sum()), int(o["inlier_mask"].sum()))
             assert mask.sum() > 0.2 * len(d), (leg, i, int(mask.sum()))
+
+
+def triangulation_tracks(num, seed):
+    """Tracks shaped like estimate_triangulation_test.cc:57-99 (tests/tri_scenes.py): 2 .. 40 observations, up to a quarter of them
+    outliers, 0.3 px noise."""
+    from pytheiasfm_amd import synth
+    from tests import tri_scenes
+    rng = np.random.default_rng(seed)
+    tracks = []
+    for t in range(num):
+        n = int(rng.integers(3, 41))
+        nout = int(rng.integers(0, max(1, n // 4) + 1)) if n > 4 else 0
+        tracks.append(tri_scenes.scene(n - nout, nout, 2000 + t, intrinsics=synth.PINHOLE_INTR, spread=0.1, noise=0.3))
+    return tracks
+
+
+def triangulation_replay(rows, seed, thr, iters):
+    """The numpy route's inlier set for one track: EXHAUSTIVE over all pairs for <= 15 observations (estimate_triangulation.cc:
+    147-159), the random sampler otherwise."""
+    from pytheiasfm_amd import synth
+    n = len(rows)
+    if n <= 15:
+        samples = [(i, j) for i in range(n - 1) for j in range(i + 1, n)]
+    else:
+        samples = ol.sampler_stream(seed, n, 2, iters)
+    fit = lambda it, idx: nr.triangulate_two_views(rows[idx[0]], rows[idx[1]])
+    err = lambda X: nr.triangulation_errors(X, rows, synth.project)
+    return nr.ransac_inlier_support(samples, fit, err, thr, n)[0]
+
+
+def test_numpy_triangulation_route_replays_the_oracles_ransac_on_cpu():
+    """EstimateTriangulation: numpy matrix algebra for the essential matrix / the optimal correction / the DLT (LAPACK SVD), the
+    camera projection of pytheiasfm_amd.synth for the error -- identical inlier sets against the oracle's loop, track by track."""
+    thr, iters = 4.0, 60
+    same = 0
+    tracks = triangulation_tracks(24, 5)
+    for t, (cams, feats) in enumerate(tracks):
+        rows = ransac.triangulation_observations(cams, feats)
+        n = len(rows)
+        pc = ol.default_ransac_params(thr, seed=77 + t); pc.min_iterations = iters; pc.max_iterations = iters
+        if n <= 15:
+            pc.min_iterations = pc.max_iterations = n * (n - 1) // 2; pc.ransac_type = 3
+        o = ol.ransac_estimate(11, rows, pc)
+        mask = triangulation_replay(rows, 77 + t, thr, iters)
+        assert np.array_equal(mask, o["inlier_mask"].astype(bool)), (t, n, int(mask.sum()), int(o["inlier_mask"].sum()))
+        same += 1
+    assert same == len(tracks)

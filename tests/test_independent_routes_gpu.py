@@ -151,3 +151,21 @@ def test_c5_shape_inlier_sets_of_the_small_estimators_against_a_numpy_route(leg)
     print(f"\n[independent route] {leg}: inlier sets identical on {equal} of {NP} pairs ({CORR} correspondences x {HYPS} hypotheses); "
           f"largest symmetric difference {worst} correspondences")
     assert equal >= NP - 2 and worst <= 12, (equal, worst)
+
+
+def test_triangulation_inlier_sets_against_a_numpy_route():
+    """EstimateTriangulation (one problem = one track: EXHAUSTIVE over the pairs for <= 15 observations, the random sampler
+    otherwise) against the numpy route of tests/numpy_routes.py -- matrix algebra + LAPACK SVD for the two-view triangulation, the
+    Python camera model for the error: the count of tracks with identical inlier sets."""
+    from tests.test_independent_routes import triangulation_tracks, triangulation_replay
+    tracks = triangulation_tracks(120, 5)
+    p = ransac.RansacParameters(); p.error_thresh = 4.0; p.min_iterations = 60; p.max_iterations = 60; p.seed = 77
+    success, points, inliers = ransac.EstimateTriangulationBatch(p, tracks)
+    equal = 0
+    for t, (cams, feats) in enumerate(tracks):
+        rows = ransac.triangulation_observations(cams, feats)
+        mask = triangulation_replay(rows, 77 + t, 4.0, 60)
+        got = np.isin(np.arange(len(rows)), inliers[t]) if success[t] else np.zeros(len(rows), dtype=bool)
+        equal += bool(np.array_equal(mask, got))
+    print(f"\n[independent route] triangulation: inlier sets identical on {equal} of {len(tracks)} tracks")
+    assert equal >= len(tracks) - 2, equal
