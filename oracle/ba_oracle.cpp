@@ -45,6 +45,7 @@
 #include <omp.h>
 
 namespace {
+int g_armijo_checks = 0, g_armijo_failures = 0;   // LM iterations with free (= bounded) intrinsics / those whose full step fails Armijo's test
 
 // Threads of the "all host cores" CPU baseline (bench.py cpu_baseline): 1 = the serial code path every test and
 // golden fixture runs (bitwise unchanged); > 1 parallelises the per-observation / per-point loops with OpenMP.
@@ -1519,6 +1520,12 @@ int oracle_ba_reduced_partial(const oba_problem* P, const oba_options* O, double
 }
 
 // The LM loop: ceres::Solve as configured by bundle_adjuster.cc:63-89,315-355.
+void oracle_ba_armijo_stats(int* checks, int* failures, int reset) {
+  if (checks) *checks = g_armijo_checks;
+  if (failures) *failures = g_armijo_failures;
+  if (reset) g_armijo_checks = g_armijo_failures = 0;
+}
+
 int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
   const double t0 = now_s();
   Oracle o; int rc = setup(o, P, O); if (rc) return rc;
@@ -1563,24 +1570,24 @@ int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
     if (solved) { o.yc = o.rhs; solved = n == 0 ? true : dense_cholesky_solve(n, o.S, o.yc);
       for (double v : o.yc) if (!std::isfinite(v)) solved = false; }
     S->time_solve_reduced += now_s() - ts; ts = now_s();
-    double model_cost_change = 0.0;
+    double model_cost_change = 0.0, gdot = 0.0;   // gdot = gradient . step = sum r . (J step): the slope Ceres' projected line search starts from
     bool step_valid = solved;
     if (solved) {
       back_substitute(o);
       // step = -y ; model_residuals = Js * step ; mcc = -m.(r + m/2)
-#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1) reduction(+ : model_cost_change)
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1) reduction(+ : model_cost_change, gdot)
       for (int64_t i = 0; i < o.nobs; ++i) { if (o.obs_fixed[i]) continue;
         const int c = P->obs_cam[i], p = P->obs_pt[i], g = P->cam_group[c];
         for (int a = 0; a < 2; ++a) { double m = 0;
           const double* Fr = &o.F[((size_t)i * 2 + a) * FW];
           for (int q = 0; q < FW; ++q) { const int col = fcol(o, c, g, q); if (col >= 0) m -= Fr[q] * o.yc[col]; }
           for (int q = 0; q < pd; ++q) m -= o.Jp[(size_t)i * 2 * pd + a * pd + q] * o.yp[(size_t)pd * p + q];
-          model_cost_change -= m * (o.r[2 * i + a] + m / 2.0); } }
+          model_cost_change -= m * (o.r[2 * i + a] + m / 2.0); gdot += m * o.r[2 * i + a]; } }
       for (const Oracle::Prior& pr : o.priors) {
         const int base = o.ni + 6 * o.cam_red[pr.cam];
         for (int a = 0; a < 3; ++a) { double m = 0;
           for (int q = 0; q < 6; ++q) m -= pr.J[6 * a + q] * o.yc[base + q];
-          model_cost_change -= m * (pr.r[a] + m / 2.0); } }
+          model_cost_change -= m * (pr.r[a] + m / 2.0); gdot += m * pr.r[a]; } }
       step_valid = model_cost_change > 0.0;
     }
     if (!step_valid) {
@@ -1607,6 +1614,11 @@ int oracle_ba_solve(oba_problem* P, const oba_options* O, oba_summary* S) {
       else for (int q = 0; q < 4; ++q) o.cpts[4 * p + q] = o.pts[4 * p + q] + d[q]; }
     double cand_cost;
     if (!evaluate(o, o.ccam, o.cpts, o.cintr, false, &cand_cost)) cand_cost = std::numeric_limits<double>::max();
+    // Ceres' TrustRegionMinimizer runs a projected Armijo line search along the step whenever a parameter block has bounds
+    // (trust_region_minimizer.cc DoLineSearch; the reference bounds the intrinsics, bundle_adjuster.cc:406-427) and shortens the
+    // step when cost(x + step) > cost(x) + 1e-4 gradient . step.  Not restated (box projection + the rho test); what IS
+    // recorded is whether the search would have left the step alone, so that the tests can tell the trajectories it cannot touch.
+    if (o.ni > 0) { ++g_armijo_checks; if (!(cand_cost <= x_cost + 1e-4 * gdot)) ++g_armijo_failures; }
     // TrustRegionMinimizer::DoInnerIterationsIfNeeded (trust_region_minimizer.cc)
     bool inner_useful = false;
     if (inner_enabled && cand_cost < std::numeric_limits<double>::max()) {

@@ -148,6 +148,15 @@ def colnorms(problem, options):
     return out
 
 
+def armijo_stats(reset=True):
+    """(LM iterations with free intrinsics since the last reset, those whose full step fails cost(x + step) <= cost(x) + 1e-4
+    gradient . step): where Ceres' projected line search (bounded intrinsics) would have shortened the step."""
+    L = load()
+    a = C.c_int(0); b = C.c_int(0)
+    L.oracle_ba_armijo_stats(C.byref(a), C.byref(b), 1 if reset else 0)
+    return a.value, b.value
+
+
 def solve(problem, options, trace_capacity=256):
     """Runs the oracle LM loop; problem parameters are updated in place."""
     L = load()

@@ -357,3 +357,37 @@ def test_depth_prior_rows_residual_jacobian_and_solve():
     Xf = pd.points[pd.obs_pt[n0:]]
     qf = np.einsum("nij,nj->ni", Rf, Xf[:, :3] - Xf[:, 3:] * pd.cam_ext[pd.obs_cam[n0:], :3])
     assert np.abs(qf[:, 2] - q[:, 2]).mean() < 0.2 * np.abs(qs[:, 2] - q[:, 2]).mean()
+
+
+def test_projected_line_search_would_not_have_shortened_a_step():
+    """Ceres runs a projected Armijo line search along the trust-region step whenever a parameter block is bounded (the reference
+    bounds the intrinsics it frees, bundle_adjuster.cc:406-427) and SHORTENS the step when cost(x + step) > cost(x) + 1e-4 g . step;
+    the oracle and the library keep the projection but not the search (stated deviations).  The oracle records the
+    test's outcome per LM iteration: on the trajectories the parity tests follow with free intrinsics -- C1 with FOCAL | RADIAL
+    and with every intrinsic free, with and without inner iterations, under HUBER / CAUCHY, C2, and the real fountain-P11 scene -- the full step passes it in EVERY iteration, i.e. the search would have returned step size 1 and changed nothing."""
+    from pytheiasfm_amd import synth
+    from tests import fountain as ft
+
+    def run(p, **kw):
+        o = ol.default_options()
+        for k, v in kw.items():
+            setattr(o, k, v)
+        ol.armijo_stats(True)
+        s, _ = ol.solve(p, o)
+        checks, failures = ol.armijo_stats(True)
+        assert s.success and checks == s.num_iterations and checks >= 3, (checks, s.num_iterations)
+        return failures
+    total = 0
+    for intr in (0x11, 0x3F):
+        for inner in (0, 1):
+            total += run(synth.ba_config("C1"), intrinsics_to_optimize=intr, use_inner_iterations=inner, max_num_iterations=30)
+    total += run(synth.ba_config("C2"), intrinsics_to_optimize=0x11, use_inner_iterations=0, max_num_iterations=30)   # (all eight C2 variants: 0 as well)
+    for loss in (1, 3):
+        total += run(synth.ba_config("C1"), intrinsics_to_optimize=0x11, loss_function_type=loss, robust_loss_width=2.0, max_num_iterations=30)
+    total += run(ft.flat_problem(ft.load()), intrinsics_to_optimize=0x11, max_num_iterations=20)
+    assert total == 0
+    # without free intrinsics nothing is bounded: no search, nothing counted
+    o = ol.default_options(); o.max_num_iterations = 5
+    ol.armijo_stats(True)
+    ol.solve(synth.ba_config("C1"), o)
+    assert ol.armijo_stats(True) == (0, 0)
