@@ -133,6 +133,10 @@ def estimate_batch(estimator, data, offsets, params, estimator_params=None, seed
     b.estimator = int(estimator); b.num_problems = P
     b.offsets = capi.ptr(offsets, C.c_int64); b.data = capi.ptr(data, C.c_double)
     ep = None if estimator_params is None else np.ascontiguousarray(estimator_params, dtype=np.float64)
+    # (the C side reads a fixed number of entries: two focal-length limits, or the radial-distortion metadata + first-call flag)
+    need = {EST_UNCALIBRATED_RELATIVE_POSE: 2, EST_RADIAL_DIST_UNCALIBRATED_ABSOLUTE_POSE: 5}.get(int(estimator), 0)
+    if ep is not None and ep.size < need:
+        raise capi.TheiaHipError(capi.THEIA_HIP_ERR_INVALID_ARGUMENT, f"estimator {int(estimator)} reads {need} estimator_params, got {ep.size}")
     b.estimator_params = None if ep is None else capi.ptr(ep, C.c_double)
     sd = None if seeds is None else np.ascontiguousarray(np.asarray(seeds, dtype=np.int64) & 0xFFFFFFFF, dtype=np.uint32)
     if sd is not None and sd.shape[0] != P:
