@@ -434,7 +434,8 @@ __global__ __launch_bounds__(64) void k_p4pfr_a(int B, const int* __restrict__ a
 
 // ---------------------------------------------------------------- eigenvectors -> solutions -> models
 constexpr int kTeam = 8, kTeamsPerWave = 64 / kTeam;
-constexpr int kEigLds = 3 * kBasis * kBasis + 3 * kBasis;
+constexpr int kEigX = 16 + kBasis * (kModel + 1);          // the work array X of the eigen stage, reused for the candidates' slots (>= 13 x 13)
+constexpr int kEigLds = 2 * kBasis * kBasis + kEigX + 3 * kBasis;
 __global__ __launch_bounds__(64) void k_p4pfr_b(size_t nhyp, int B, const int* __restrict__ active_iters, const double* __restrict__ ws,
                                                 double max_f, double min_f, double max_d, double min_d, double* __restrict__ models,
                                                 int* __restrict__ counts, int* __restrict__ dense_count, int* __restrict__ tags, int* __restrict__ hyp_base) {
@@ -446,54 +447,57 @@ __global__ __launch_bounds__(64) void k_p4pfr_b(size_t nhyp, int B, const int* _
   if (b >= active_iters[p]) { if (tl == 0) counts[hyp] = 0; return; }
   const double* w = ws + hyp * kWs;
   constexpr int n = kBasis;
-  double* H = lds[team]; double* V = H + n * n; double* Xw = V + n * n; double* wr = Xw + n * n; double* wi = wr + n; double* ort = wi + n;
+  double* H = lds[team]; double* V = H + n * n; double* Xw = V + n * n; double* wr = Xw + kEigX; double* wi = wr + n; double* ort = wi + n;
   for (int e = tl; e < n * n; e += kTeam) H[e] = w[kWsAct + e];
   rsc::team_sync();
   const bool good = rsc::eig_team<kTeam, true>(n, H, V, Xw, wr, wi, ort, tl);
   rsc::team_sync();
-  if (tl != 0) return;
-  if (!good) { counts[hyp] = 0; return; }
+  if (!good) { if (tl == 0) counts[hyp] = 0; return; }
   // helper.cc:1384-1408: columns over their first row, |Im a1| <= 1e-6, real parts (EigenSolver::eigenvectors(): a column is real
-  // when |Im lambda| <= 1e-12 |Re lambda| or it is the last one, else columns j, j + 1 are re +- i im; each normalised)
+  // when |Im lambda| <= 1e-12 |Re lambda| or it is the last one, else columns j, j + 1 are re +- i im; each normalised).  The
+  // thirteen candidates -- slot k = real column k, or the first / second member of the pair that covers column k -- are dealt to
+  // the team's lanes (the eigen stage leaves seven of eight lanes idle otherwise); lane 0 then collects them in slot order, so the
+  // models come out in the order of the one-lane loop, each from the same arithmetic.
+  double* kind = Xw;                 // [n]: 0 real, 1 first of a pair, 2 second of a pair   (Xw is free after the eigen stage)
+  double* slot = Xw + 16;            // [n][kModel + 1]: valid flag | model
+  if (tl == 0)
+    for (int j = 0; j < n; ++j) {
+      const bool real = fabs(wi[j]) <= fabs(wr[j]) * 1e-12 || j + 1 == n;
+      kind[j] = real ? 0.0 : 1.0;
+      if (!real) { kind[j + 1] = 2.0; ++j; }
+    }
+  rsc::team_sync();
+  const double* R0 = w + kWsR0; const double* t0 = w + kWsT0; const double* Nn = w + kWsN; const double* Dm = w + kWsD;
+  const double scale = w[kWsScale], f0 = w[kWsF0], k0 = w[kWsK0];
   const int rows[4] = {kRowA1, kRowA2, kRowK, kRowW};
-  double sols[5 * kMaxModels];
-  int nsol = 0;
-  for (int j = 0; j < n; ++j) {
-    const bool real = fabs(wi[j]) <= fabs(wr[j]) * 1e-12 || j + 1 == n;
+  for (int k = tl; k < n; k += kTeam) {
+    double* out = slot + (kModel + 1) * k;
+    out[0] = 0.0;
+    const int kd = (int)kind[k];
+    const bool real = kd == 0;
+    const int j = kd == 2 ? k - 1 : k;             // first column of the pair (or the real column)
+    const double sg = kd == 2 ? -1.0 : 1.0;        // the conjugate member
     double nrm2 = 0.0;
     for (int i = 0; i < n; ++i) nrm2 += real ? V[n * i + j] * V[n * i + j] : V[n * i + j] * V[n * i + j] + V[n * i + j + 1] * V[n * i + j + 1];
     const double nrm = sqrt(nrm2);
-    for (int c = 0; c < (real ? 1 : 2); ++c) {
-      const double sg = c ? -1.0 : 1.0;
-      const double v0r = V[j] / nrm, v0i = real ? 0.0 : sg * V[j + 1] / nrm;
-      double re[4], im[4];
-      for (int k = 0; k < 4; ++k) {
-        const double xr = V[n * rows[k] + j] / nrm, xi = real ? 0.0 : sg * V[n * rows[k] + j + 1] / nrm;
-        if (real) { re[k] = xr / v0r; im[k] = 0.0; }
-        else rsc::eig_cdiv(xr, xi, v0r, v0i, &re[k], &im[k]);
-      }
-      if (im[0] < -1e-6 || im[0] > 1e-6) continue;
-      double* s = sols + 5 * nsol++;
-      s[0] = re[0]; s[1] = re[1]; s[2] = wr[j]; s[3] = re[2]; s[4] = re[3];
+    const double v0r = V[j] / nrm, v0i = real ? 0.0 : sg * V[j + 1] / nrm;
+    double re[4], im[4];
+    for (int q = 0; q < 4; ++q) {
+      const double xr = V[n * rows[q] + j] / nrm, xi = real ? 0.0 : sg * V[n * rows[q] + j + 1] / nrm;
+      if (real) { re[q] = xr / v0r; im[q] = 0.0; }
+      else rsc::eig_cdiv(xr, xi, v0r, v0i, &re[q], &im[q]);
     }
-    if (!real) ++j;
-  }
-  // four_point_focal_length_radial_distortion.cc:219-285
-  const double* R0 = w + kWsR0; const double* t0 = w + kWsT0; const double* Nn = w + kWsN; const double* Dm = w + kWsD;
-  const double scale = w[kWsScale], f0 = w[kWsF0], k0 = w[kWsK0];
-  double keep[kModel * kMaxModels];
-  int nm = 0;
-  for (int s = 0; s < nsol; ++s) {
-    const double* v = sols + 5 * s;
-    const double k = v[3], P33 = v[4];
-    const double alpha[4] = {v[0], v[1], v[2], 1.0};
+    if (im[0] < -1e-6 || im[0] > 1e-6) continue;
+    // four_point_focal_length_radial_distortion.cc:219-285
+    const double kk = re[2], P33 = re[3];
+    const double alpha[4] = {re[0], re[1], wr[j], 1.0};
     double P[12];
     for (int r = 0; r < 8; ++r) {
       double a = 0.0;
       for (int c = 0; c < 4; ++c) a += Nn[r * 4 + c] * alpha[c];
       P[r] = a;
     }
-    const double tmp[9] = {alpha[0], alpha[1], alpha[2], k * alpha[0], k * alpha[1], k * alpha[2], k, P33, 1.0};
+    const double tmp[9] = {alpha[0], alpha[1], alpha[2], kk * alpha[0], kk * alpha[1], kk * alpha[2], kk, P33, 1.0};
     double p3[3];
     for (int r = 0; r < 3; ++r) {
       double a = 0.0;
@@ -506,7 +510,7 @@ __global__ __launch_bounds__(64) void k_p4pfr_b(size_t nhyp, int B, const int* _
     const double f = sqrt((P[0] * P[0] + P[1] * P[1]) + P[2] * P[2]);
     const double focal = f * f0;
     if (focal < min_f || focal > max_f) continue;
-    const double rd = k / k0;
+    const double rd = kk / k0;
     if (rd < max_d || rd > min_d || rd > 0.0) continue;
     double Rt[12];
     const double kf = 1.0 / f;
@@ -516,22 +520,31 @@ __global__ __launch_bounds__(64) void k_p4pfr_b(size_t nhyp, int B, const int* _
     double RR0[9];
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c) RR0[r * 3 + c] = (Rt[4 * r] * R0[c] + Rt[4 * r + 1] * R0[3 + c]) + Rt[4 * r + 2] * R0[6 + c];
-    double* m = keep + kModel * nm++;
+    double* m = out + 1;
     for (int r = 0; r < 3; ++r) m[9 + r] = Rt[4 * r + 3] * scale - ((RR0[3 * r] * t0[0] + RR0[3 * r + 1] * t0[1]) + RR0[3 * r + 2] * t0[2]);
     for (int i = 0; i < 9; ++i) m[i] = RR0[i];
     m[12] = focal; m[13] = rd;
+    out[0] = 1.0;
   }
+  rsc::team_sync();
+  if (tl != 0) return;
+  int nm = 0;
+  for (int k = 0; k < n; ++k) nm += slot[(kModel + 1) * k] != 0.0;
   counts[hyp] = nm;
   if (nm == 0) return;
   const int base = atomicAdd(&dense_count[p], nm);
   hyp_base[hyp] = base;
   double* mo = models + ((size_t)p * B * kMaxModels + base) * (size_t)THEIA_RANSAC_MODEL_STRIDE;
   int* tg = tags + (size_t)p * B * kMaxModels + base;
-  for (int j = 0; j < nm; ++j) {
-    double* m = mo + (size_t)j * THEIA_RANSAC_MODEL_STRIDE;
-    for (int k = 0; k < kModel; ++k) m[k] = keep[kModel * j + k];
-    for (int k = kModel; k < THEIA_RANSAC_MODEL_STRIDE; ++k) m[k] = 0.0;
-    tg[j] = b * kMaxModels + j;
+  int jm = 0;
+  for (int k = 0; k < n; ++k) {
+    const double* sl = slot + (kModel + 1) * k;
+    if (sl[0] == 0.0) continue;
+    double* m = mo + (size_t)jm * THEIA_RANSAC_MODEL_STRIDE;
+    for (int q = 0; q < kModel; ++q) m[q] = sl[1 + q];
+    for (int q = kModel; q < THEIA_RANSAC_MODEL_STRIDE; ++q) m[q] = 0.0;
+    tg[jm] = b * kMaxModels + jm;
+    ++jm;
   }
 }
 
