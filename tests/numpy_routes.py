@@ -123,7 +123,78 @@ class _DlsSystem:
         return out
 
 
+    def solve_gdls(self, origin, direction, world, u):
+        """GdlsSimilarityTransform (sfm/transformation/gdls_similarity_transform.cc:67-228) in matrix form: rays c_i + alpha x_i,
+        s c_i + alpha_i x_i = R X_i + t.  Scale and translation z = (s, t) are eliminated as the least-squares solution of
+        sum |P_i (L_i r + A_i z)|^2 (P_i = I - x_i x_i^T, A_i = [-c_i | I], L_i r = R X_i), the cost matrix is sum W_i^T P_i W_i with
+        W_i = L_i + A_i Z, and from there on it is DLS.  Returns (R, t, s) with s c + alpha x = R X + t."""
+        n = len(world)
+        x = direction / np.linalg.norm(direction, axis=1, keepdims=True)
+        P = np.eye(3)[None] - x[:, :, None] * x[:, None, :]
+        A = np.concatenate([-origin[:, :, None], np.broadcast_to(np.eye(3), (n, 3, 3))], axis=2)        # n x 3 x 4
+        L = np.zeros((n, 3, 9))
+        for r in range(3):
+            L[:, r, 3 * r:3 * r + 3] = world
+        Hm = np.einsum("nia,nij,njb->ab", A, P, A)
+        Z = -np.linalg.solve(Hm, np.einsum("nia,nij,njb->ab", A, P, L))                                  # 4 x 9
+        Wm = L + np.einsum("nia,ab->nib", A, Z)
+        D = np.einsum("nia,nij,njb->ab", Wm, P, Wm)
+        coef = {0: np.asarray(u, dtype=np.float64)}
+        for v in range(3):
+            coef[v + 1] = self.T[v] @ D.ravel()
+        vals = np.array([coef[q // 100][q % 100] for q in self.src])
+        M = np.zeros((120, 120))
+        M[self.rows, self.cols] = vals
+        S = M[:27, :27] - M[:27, 27:] @ np.linalg.solve(M[27:, 27:], M[27:, :27])
+        _, V = np.linalg.eig(S)
+        out = []
+        for i in range(27):
+            if V[0, i] == 0:
+                continue
+            sv = V[[9, 3, 1], i] / V[0, i]
+            if np.abs(sv.imag).max() >= 1e-6:
+                continue
+            q = np.array([1.0, -sv[0].real, -sv[1].real, -sv[2].real]); q /= np.linalg.norm(q)
+            w_, a, b, c = q
+            R = np.array([[1 - 2 * (b * b + c * c), 2 * (a * b - w_ * c), 2 * (a * c + w_ * b)],
+                          [2 * (a * b + w_ * c), 1 - 2 * (a * a + c * c), 2 * (b * c - w_ * a)],
+                          [2 * (a * c - w_ * b), 2 * (b * c + w_ * a), 1 - 2 * (a * a + b * b)]])
+            z = Z @ R.ravel()
+            sc, t = z[0], z[1:]
+            if (((world @ R.T + t - sc * origin) * x).sum(1) < 0).any():
+                continue
+            out.append((R, t, sc))
+        return out
+
+
 _dls = None
+
+
+def gdls_similarity_models(rows, u):
+    """SimilarityTransformation2D3DEstimator::EstimateModel (estimate_similarity_transformation_2d_3d.cc:85-133) on four 26-double
+    rows: (rotation, translation, scale) = (R^T, -R^T t, s) of every gDLS solution."""
+    global _dls
+    if _dls is None:
+        _dls = _DlsSystem()
+    sols = _dls.solve_gdls(rows[:, 9:12], rows[:, 0:3], rows[:, 3:6] / rows[:, 6:7], u)
+    return [(R.T, -R.T @ t, sc) for R, t, sc in sols]
+
+
+def similarity_errors(model, rows, project):
+    """SimilarityTransformation2D3DEstimator::Error (:137-155) with TransformCamera (:52-70): the datum's camera moved to
+    s R c + t with orientation R_cam R^T sees the world point; squared pixel error, infinite at negative depth."""
+    from pytheiasfm_amd import synth
+    Rm, tm, sc = model
+    n = len(rows)
+    pos = sc * rows[:, 9:12] @ Rm.T + tm
+    a = rows[:, 3:6] - rows[:, 6:7] * pos
+    b = np.c_[a @ Rm, rows[:, 6]]                                   # R^T a, homogeneous
+    ext = np.c_[np.zeros((n, 3)), rows[:, 12:15]]
+    uv, _ = project(int(rows[0, 15]), rows[:, 16:26], ext, b)
+    depth = np.einsum("nij,nj->ni", synth.angle_axis_to_matrix(rows[:, 12:15]), b[:, :3])[:, 2] / b[:, 3]
+    e = ((uv - rows[:, 7:9]) ** 2).sum(1)
+    e[depth < 0] = np.inf
+    return e
 
 
 def dls_pnp(feat, world, u):

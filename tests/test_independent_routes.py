@@ -245,3 +245,39 @@ def test_numpy_triangulation_route_replays_the_oracles_ransac_on_cpu():
         assert np.array_equal(mask, o["inlier_mask"].astype(bool)), (t, n, int(mask.sum()), int(o["inlier_mask"].sum()))
         same += 1
     assert same == len(tracks)
+
+
+def gdls_rigs(num, points, seed):
+    """Rigs of pinhole cameras in a frame that differs from the world by a similarity (tests/gdls_scenes.py), 20 % outliers,
+    half a pixel of noise: (rows (N, 26), offsets)."""
+    from tests import gdls_scenes as gs
+    data, offsets = [], [0]
+    for r in range(num):
+        corr, _ = gs.cameras(4 + r % 2, points, seed=seed + r, outlier_frac=0.2, noise=0.5, scale=1.2 + 0.3 * r)
+        rows = ransac.similarity_correspondence_rows(corr)
+        data.append(rows); offsets.append(offsets[-1] + len(rows))
+    return np.concatenate(data), np.array(offsets, dtype=np.int64)
+
+
+def gdls_replay(rows, seed, thr, iters):
+    """The numpy route's inlier set for one rig: iteration k of a problem takes the Macaulay terms of gDLS call k of a process."""
+    from pytheiasfm_amd import synth
+    terms = ransac.dls_macaulay_terms(0, iters)
+    fit = lambda it, idx: nr.gdls_similarity_models(rows[idx], terms[it])
+    err = lambda m: nr.similarity_errors(m, rows, synth.project)
+    return nr.ransac_inlier_support(ol.sampler_stream(seed, len(rows), 4, iters), fit, err, thr, len(rows))[0]
+
+
+def test_numpy_gdls_route_replays_the_oracles_ransac_on_cpu():
+    """EstimateSimilarityTransformation2D3D: the gDLS cost in matrix form (scale and translation eliminated by one 4 x 4 solve), the
+    DLS Macaulay system of the numpy route, LAPACK solve / eig, the Python camera model for the error -- identical inlier sets
+    against the oracle's loop."""
+    thr, iters = 3.0 ** 2, 64
+    data, offsets = gdls_rigs(3, 120, 40)
+    for i in range(3):
+        rows = data[offsets[i]:offsets[i + 1]]
+        pc = ol.default_ransac_params(thr, seed=5 + i); pc.min_iterations = iters; pc.max_iterations = iters
+        o = ol.ransac_estimate(13, rows, pc)
+        mask = gdls_replay(rows, 5 + i, thr, iters)
+        assert np.array_equal(mask, o["inlier_mask"].astype(bool)), (i, int(mask.sum()), int(o["inlier_mask"].sum()))
+        assert mask.sum() > 0.5 * len(rows)

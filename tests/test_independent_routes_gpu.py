@@ -169,3 +169,25 @@ def test_triangulation_inlier_sets_against_a_numpy_route():
         equal += bool(np.array_equal(mask, got))
     print(f"\n[independent route] triangulation: inlier sets identical on {equal} of {len(tracks)} tracks")
     assert equal >= len(tracks) - 2, equal
+
+
+def test_gdls_similarity_inlier_sets_against_a_numpy_route():
+    """EstimateSimilarityTransformation2D3D (gDLS) at the configs[4] shape -- 6 rigs x 2000 correspondences x 768 hypotheses --
+    against the numpy route (matrix-form cost, LAPACK solve / eig, Python camera model)."""
+    from tests.test_independent_routes import gdls_rigs, gdls_replay
+    data, offsets = gdls_rigs(NP, CORR, 400)
+    thr = 3.0 ** 2
+    p = ransac.RansacParameters(); p.error_thresh = thr; p.min_iterations = HYPS; p.max_iterations = HYPS; p.seed = 1
+    res = ransac.estimate_batch(ransac.EST_SIMILARITY_2D3D, data, offsets, p)
+    equal, worst = 0, 0
+    for i in range(NP):
+        rows = data[offsets[i]:offsets[i + 1]]
+        mask = gdls_replay(rows, p.seed + i, thr, HYPS)
+        dm = res["inlier_mask"][offsets[i]:offsets[i + 1]].astype(bool)
+        diff = int((dm != mask).sum())
+        equal += diff == 0
+        worst = max(worst, diff)
+        assert abs(int(dm.sum()) - int(mask.sum())) <= 3, (i, int(dm.sum()), int(mask.sum()))
+    print(f"\n[independent route] gdls: inlier sets identical on {equal} of {NP} rigs ({CORR} correspondences x {HYPS} hypotheses); "
+          f"largest symmetric difference {worst} correspondences")
+    assert equal >= NP - 2 and worst <= 12, (equal, worst)
