@@ -304,6 +304,39 @@ def ransac_inlier_support(samples, fit, errors, thresh, ndata):
     return mask, best
 
 
+def ransac_replay(samples, fit, errors, thresh, ndata, mode="support", min_samples=0):
+    """The reference's loop (sample_consensus_estimator.h:300-415, min = max iterations) under its three quality measurements:
+    "support" = InlierSupport (cost = outliers), "mle" = MLEQualityMeasurement (sum of min(r, thresh) left to right,
+    mle_quality_measurement.h:58-71), "lmed" = LmedQualityMeasurement (lmed_quality_measurement.h:58-120, with its quirks: the
+    estimator's -- already squared -- errors are squared again, an ODD count averages the two middle values, the inlier bound is
+    OpenCV's 2.5 x 1.4826 (1 + 5 / (n - m)) sqrt(median)).  The first strictly smaller cost wins.  Returns the inlier mask."""
+    best_cost = np.inf
+    mask = np.zeros(ndata, dtype=bool)
+    for it, idx in enumerate(samples):
+        for m in fit(it, idx):
+            e = errors(m)
+            if mode == "support":
+                inl = e < thresh; cost = ndata - int(inl.sum())
+            elif mode == "mle":
+                inl = e < thresh
+                cost = 0.0
+                for v, ok in zip(e, inl):            # sequential, as the reference adds them
+                    cost += v if ok else thresh
+            else:
+                with np.errstate(over="ignore", invalid="ignore"):
+                    sq = np.sort(e * e)
+                med = sq[ndata // 2]
+                if ndata % 2 != 0:
+                    med = 0.5 * (sq[ndata // 2 - 1] + med)
+                bound = (2.5 * 1.4826 * (1 + 5.0 / (ndata - min_samples)) * np.sqrt(med)) ** 2
+                with np.errstate(over="ignore", invalid="ignore"):
+                    inl = (e * e) < bound
+                cost = med
+            if cost < best_cost:
+                best_cost, mask = cost, inl
+    return mask
+
+
 # ------------------------------------------------------------------------------------------------ more estimators (round 4)
 def sampson_errors(F, x1h, x2h):
     """SquaredSampsonDistance (pose/util.cc:56-68) for a matrix with x2^T F x1 = 0, vectorised."""

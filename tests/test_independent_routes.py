@@ -281,3 +281,21 @@ def test_numpy_gdls_route_replays_the_oracles_ransac_on_cpu():
         mask = gdls_replay(rows, 5 + i, thr, iters)
         assert np.array_equal(mask, o["inlier_mask"].astype(bool)), (i, int(mask.sum()), int(o["inlier_mask"].sum()))
         assert mask.sum() > 0.5 * len(rows)
+
+
+def test_numpy_replay_of_the_mle_and_lmed_quality_measurements_on_cpu():
+    """The loop's other two scorers, replayed in numpy (tests/numpy_routes.ransac_replay) with numpy estimators: MLE (use_mle) and
+    LMED -- with the reference's quirks (errors squared twice, the odd-count median) -- against the oracle: identical inlier sets."""
+    NP, CORR, HY = 2, 301, 96            # an odd count: the averaged median
+    for leg, m in (("rel_known", 2), ("plane", 3), ("abs_known", 2)):
+        est, data, offsets, m, thr, ep = _small_leg(leg, NP, CORR, 0x5AC50105)
+        for mode in ("mle", "lmed"):
+            for i in range(NP):
+                d = data[offsets[i]:offsets[i + 1]]
+                pc = ol.default_ransac_params(thr, seed=3 + i); pc.min_iterations = HY; pc.max_iterations = HY
+                pc.use_mle = 1 if mode == "mle" else 0
+                pc.ransac_type = 2 if mode == "lmed" else 0
+                o = ol.ransac_estimate(est, d, pc)
+                fit, err = small_leg_route(leg, d, ep)
+                mask = nr.ransac_replay(ol.sampler_stream(3 + i, len(d), m, HY), fit, err, thr, len(d), mode, m)
+                assert np.array_equal(mask, o["inlier_mask"].astype(bool)), (leg, mode, i, int(mask.sum()), int(o["inlier_mask"].sum()))

@@ -191,3 +191,25 @@ def test_gdls_similarity_inlier_sets_against_a_numpy_route():
     print(f"\n[independent route] gdls: inlier sets identical on {equal} of {NP} rigs ({CORR} correspondences x {HYPS} hypotheses); "
           f"largest symmetric difference {worst} correspondences")
     assert equal >= NP - 2 and worst <= 12, (equal, worst)
+
+
+@pytest.mark.parametrize("mode", ["mle", "lmed"])
+def test_mle_and_lmed_inlier_sets_against_a_numpy_replay(mode):
+    """MLEQualityMeasurement and LmedQualityMeasurement (the reference's quirks included: errors squared twice, the odd-count
+    median) replayed in numpy with numpy estimators, against the device: 6 pairs x 2001 data x 256 hypotheses per estimator."""
+    from tests.test_independent_routes import _small_leg, small_leg_route
+    hy, total, equal = 256, 0, 0
+    for leg in ("rel_known", "plane", "abs_known"):
+        est, data, offsets, m, thr, ep = _small_leg(leg, NP, CORR + 1, 0x5AC50105)
+        p = ransac.RansacParameters(); p.error_thresh = thr; p.min_iterations = hy; p.max_iterations = hy; p.seed = 3
+        p.use_mle = mode == "mle"
+        pc = p.to_c(); pc.ransac_type = 2 if mode == "lmed" else 0
+        res = ransac.estimate_batch(est, data, offsets, pc, ep)
+        for i in range(NP):
+            d = data[offsets[i]:offsets[i + 1]]
+            fit, err = small_leg_route(leg, d, ep)
+            mask = nr.ransac_replay(ol.sampler_stream(3 + i, len(d), m, hy), fit, err, thr, len(d), mode, m)
+            total += 1
+            equal += bool(np.array_equal(mask, res["inlier_mask"][offsets[i]:offsets[i + 1]].astype(bool)))
+    print(f"\n[independent replay] {mode}: inlier sets identical on {equal} of {total} problems")
+    assert equal >= total - 1, (equal, total)
