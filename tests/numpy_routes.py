@@ -559,6 +559,41 @@ class LibstdcxxStream:
             r = np.nextafter(1.0, 0.0)
         return r * (hi - lo) + lo
 
+    def prosac_samples(self, num_data, m, iters):
+        """ProsacSampler::Sample (solvers/prosac_sampler.cc:66-128) for the first `iters` samples of an Estimate() call: the growth
+        function of Chum & Matas (t_n from 20 000 convergence iterations), m distinct draws from the top n, or m - 1 from the top
+        n - 1 plus the point at position n (the reference pushes index n, not n - 1)."""
+        import math
+        out = []
+        for kth in range(1, iters + 1):
+            t_n = 20000.0
+            n = m
+            for i in range(m):
+                t_n *= float(n - i) / (num_data - i)
+            t_n_prime = 1.0
+            for t in range(1, kth + 1):
+                if t > t_n_prime and n < num_data:
+                    t_n_plus1 = (t_n * (n + 1.0)) / (n + 1.0 - m)
+                    t_n_prime += math.ceil(t_n_plus1 - t_n)
+                    t_n = t_n_plus1
+                    n += 1
+            sub = []
+            if t_n_prime < kth:
+                for _ in range(m):
+                    r = self.rand_int(0, n - 1)
+                    while r in sub:
+                        r = self.rand_int(0, n - 1)
+                    sub.append(r)
+            else:
+                for _ in range(m - 1):
+                    r = self.rand_int(0, n - 2)
+                    while r in sub:
+                        r = self.rand_int(0, n - 2)
+                    sub.append(r)
+                sub.append(n)
+            out.append(sub)
+        return np.array(out)
+
     def p4pfr_rounds(self, n, iters, first_call=False):
         """RandomSampler::Sample (partial Fisher-Yates on a persistent index vector) followed by the solver's three draws."""
         idx = list(range(n))

@@ -299,3 +299,23 @@ def test_numpy_replay_of_the_mle_and_lmed_quality_measurements_on_cpu():
                 fit, err = small_leg_route(leg, d, ep)
                 mask = nr.ransac_replay(ol.sampler_stream(3 + i, len(d), m, HY), fit, err, thr, len(d), mode, m)
                 assert np.array_equal(mask, o["inlier_mask"].astype(bool)), (leg, mode, i, int(mask.sum()), int(o["inlier_mask"].sum()))
+
+
+def test_numpy_replay_of_the_prosac_sampler_on_cpu():
+    """ProsacSampler restated in Python on the Python libstdc++ stream (numpy_routes.LibstdcxxStream.prosac_samples), numpy
+    estimators, InlierSupport: identical inlier sets against the oracle's PROSAC runs (data sorted inliers-first, a valid quality
+    order for the synthetic pairs)."""
+    from pytheiasfm_amd import synth
+    NP, CORR, HY = 3, 300, 120
+    for leg, kind, est, m, thr in (("rel_known", "known_orientation", 8, 2, (2.0 / 1000.0) ** 2), ("plane", "plane", 7, 3, 0.004)):
+        data, offsets, truth = synth.synth_ransac_v1(NP, CORR, kind, seed=0x5AC50205)
+        for i in range(NP):
+            sl = slice(offsets[i], offsets[i + 1])
+            d = data[sl][np.argsort(~truth["inlier"][i], kind="stable")]
+            pc = ol.default_ransac_params(thr, seed=11 + i); pc.min_iterations = HY; pc.max_iterations = HY; pc.ransac_type = 1
+            o = ol.ransac_estimate(est, d, pc)
+            fit, err = small_leg_route(leg, d, None)
+            samples = nr.LibstdcxxStream(11 + i).prosac_samples(len(d), m, HY)
+            mask = nr.ransac_replay(samples, fit, err, thr, len(d))
+            assert np.array_equal(mask, o["inlier_mask"].astype(bool)), (leg, i, int(mask.sum()), int(o["inlier_mask"].sum()))
+            assert mask.sum() > 0.25 * len(d)

@@ -213,3 +213,26 @@ def test_mle_and_lmed_inlier_sets_against_a_numpy_replay(mode):
             equal += bool(np.array_equal(mask, res["inlier_mask"][offsets[i]:offsets[i + 1]].astype(bool)))
     print(f"\n[independent replay] {mode}: inlier sets identical on {equal} of {total} problems")
     assert equal >= total - 1, (equal, total)
+
+
+def test_prosac_inlier_sets_against_a_numpy_replay():
+    """The PROSAC sampler restated in Python on the Python libstdc++ stream + numpy estimators against the device's PROSAC runs
+    (6 pairs x 2000 data x 300 hypotheses, two estimators)."""
+    from tests.test_independent_routes import small_leg_route
+    hy, total, equal = 300, 0, 0
+    for leg, kind, est, m, thr in (("rel_known", "known_orientation", 8, 2, (2.0 / 1000.0) ** 2), ("plane", "plane", 7, 3, 0.004)):
+        data, offsets, truth = synth.synth_ransac_v1(NP, CORR, kind, seed=0x5AC50205)
+        for i in range(NP):   # quality order: true inliers first
+            sl = slice(offsets[i], offsets[i + 1])
+            data[sl] = data[sl][np.argsort(~truth["inlier"][i], kind="stable")]
+        p = ransac.RansacParameters(); p.error_thresh = thr; p.min_iterations = hy; p.max_iterations = hy; p.seed = 11
+        p.ransac_type = ransac.RansacType.PROSAC
+        res = ransac.estimate_batch(est, data, offsets, p)
+        for i in range(NP):
+            d = data[offsets[i]:offsets[i + 1]]
+            fit, err = small_leg_route(leg, d, None)
+            mask = nr.ransac_replay(nr.LibstdcxxStream(11 + i).prosac_samples(len(d), m, hy), fit, err, thr, len(d))
+            total += 1
+            equal += bool(np.array_equal(mask, res["inlier_mask"][offsets[i]:offsets[i + 1]].astype(bool)))
+    print(f"\n[independent replay] prosac: inlier sets identical on {equal} of {total} problems")
+    assert equal >= total - 1, (equal, total)
