@@ -391,3 +391,43 @@ def test_projected_line_search_would_not_have_shortened_a_step():
     ol.armijo_stats(True)
     ol.solve(synth.ba_config("C1"), o)
     assert ol.armijo_stats(True) == (0, 0)
+
+
+LM_SCENARIOS = {
+    # name: (views, tracks, seed, generator arguments).  "rejections": starts so far off that steps are REJECTED (the radius halves,
+    # quarters, ...) and taken again -- the branches a near-converged start never enters
+    "plain": (6, 60, 0xBA5E0100, dict()),
+    "rejections_a": (5, 40, 0xBA5E0204, dict(sigma_pos=4.0, sigma_rot_deg=35.0, sigma_pt=3.0, fix_gauge=True)),
+    "rejections_b": (5, 40, 0xBA5E0207, dict(sigma_pos=3.0, sigma_rot_deg=25.0, sigma_pt=2.5, fix_gauge=True)),
+}
+
+
+def compare_with_independent_lm(name, solve):
+    """Runs `solve` (the oracle's or the library's solver: problem, options -> summary, trace) and tests/independent_lm.py on one
+    scenario; asserts the same accept / reject sequence, costs, radii, step norms and final parameters."""
+    from tests import independent_lm as il
+    nv, nt, seed, kw = LM_SCENARIOS[name]
+    p = synth.synth_ba_v1(nv, nt, seed=seed, num_groups=2, **kw)
+    o = ol.default_options()
+    o.use_homogeneous_point_parametrization = 0; o.use_inner_iterations = 0; o.max_num_iterations = 40
+    ps = p.copy()
+    s, tr = solve(ps, o)
+    trace, cam, pts = il.solve(p, max_num_iterations=40)
+    assert s.success and len(trace) == tr.size
+    assert [t[4] for t in trace] == [int(a) for a in tr.accepted]
+    if name != "plain":
+        assert 0 in [t[4] for t in trace][:-1]                     # a step was rejected and retaken
+    for k in range(tr.size):
+        assert abs(trace[k][0] - tr.cost[k]) <= 1e-6 * tr.cost[k], (k, trace[k][0], tr.cost[k])
+        assert abs(trace[k][3] - tr.radius[k]) <= 1e-8 * tr.radius[k], (k, trace[k][3], tr.radius[k])
+        assert abs(trace[k][2] - tr.step_norm[k]) <= 1e-7 * max(tr.step_norm[k], 1e-12), (k, trace[k][2], tr.step_norm[k])
+    assert np.abs(cam - ps.cam_ext).max() < 1e-7 and np.abs(pts - ps.points).max() < 1e-7
+
+
+@pytest.mark.parametrize("name", list(LM_SCENARIOS))
+def test_lm_trajectory_matches_an_independent_autograd_implementation(name):
+    """The oracle's LM trajectory against tests/independent_lm.py: the residual in torch with REVERSE-mode autodiff Jacobians, the full
+    (cameras + points) normal equations by numpy Cholesky instead of the Schur complement, Ceres' trust-region rules restated a
+    second time.  Same accept / reject sequence (rejected-and-retaken steps included), costs to 1e-6, radii to 1e-8, parameters
+    to 1e-7 (measured: 1e-8 .. 1e-12)."""
+    compare_with_independent_lm(name, lambda p, o: ol.solve(p, o))
