@@ -1,14 +1,20 @@
-"""An INDEPENDENT restatement of the BA solve for small problems, used to pin the oracle's LM trajectory (tests/test_oracle_ba.py):
+"""An INDEPENDENT restatement of the BA solve for small problems, used to pin the oracle's and the library's LM trajectories
+(tests/test_oracle_ba.py, tests/test_parity_gpu.py):
   * the reprojection residual (camera/reprojection_error.h:54-110 + pinhole_camera_model.h:181-260) written in torch (float64) and
     differentiated by torch.func -- reverse-mode autodiff, no code or derivation shared with oracle/ (forward-mode Jets) or csrc/
     (closed forms);
-  * the FULL normal equations (cameras and points together, dense, numpy Cholesky) instead of the Schur complement;
+  * the FULL normal equations (intrinsics, cameras and points together, dense, numpy Cholesky) instead of the Schur complement;
   * Ceres' trust-region rules (TrustRegionMinimizer + LevenbergMarquardtStrategy, 2.2) restated from their description: Jacobi
     scaling 1 / (1 + |column|) fixed at the initial point, D^2 = clamp(diag(J^T J), 1e-6, 1e32) / radius, model cost change
     -m . (r + m / 2), step valid iff it is positive (else radius /= 2, 4, 8 ...; five in a row fail), parameter / function
-    tolerance before the acceptance test, rho > 1e-3 accepts with radius /= max(1 / 3, 1 - (2 rho - 1)^3), gradient tolerance after
-    successful steps only.
-Plain XYZW points (use_homogeneous_point_parametrization = 0: four free coordinates), pinhole cameras, trivial loss."""
+    tolerance before the acceptance test, rho > 1e-3 accepts with radius /= max(1 / 3, 1 - (2 rho - 1)^3) capped at BundleAdjustmentOptions' max_trust_region_radius
+    (1e12, bundle_adjustment.h), gradient tolerance after
+    successful steps only;
+  * optionally: the homogeneous point on ceres::SphereManifold<4> (Householder form of Plus and its Jacobian, written from the
+    manifold's definition: x (+) d = |x| H(x)^T [sin|d| d / |d|; cos|d|]), the robust losses HUBER / CAUCHY with Ceres' corrector
+    for rho'' <= 0 (residual and Jacobian scaled by sqrt(rho')), and shared intrinsics blocks with a subset of free parameters
+    (SubsetManifold) and the reference's lower bound on the focal length (bundle_adjuster.cc:406-409) by projection.
+Pinhole cameras."""
 import numpy as np
 import torch
 from torch.func import jacrev, vmap
@@ -17,8 +23,7 @@ from torch.func import jacrev, vmap
 def _residual(cam, pt, intr, uv):
     C, w = cam[:3], cam[3:6]
     p = pt[:3] - pt[3] * C
-    th2 = (w * w).sum()
-    th = torch.sqrt(th2)
+    th = torch.sqrt((w * w).sum())
     k = w / th
     q = p * torch.cos(th) + torch.linalg.cross(k, p) * torch.sin(th) + k * (k @ p) * (1.0 - torch.cos(th))
     x, y = q[0] / q[2], q[1] / q[2]
@@ -30,63 +35,141 @@ def _residual(cam, pt, intr, uv):
     return torch.stack([u - uv[0], v - uv[1]])
 
 
-_jac = vmap(jacrev(_residual, argnums=(0, 1)))
+_jac = vmap(jacrev(_residual, argnums=(0, 1, 2)))
 _res = vmap(_residual)
 
 
+def householder(x):
+    """v, beta with (I - beta v v^T) x = |x| e_n (the last axis), v_n = 1: the reflection SphereManifold is built on."""
+    n = len(x)
+    sigma = float(x[:n - 1] @ x[:n - 1])
+    v = x.copy(); v[n - 1] = 1.0
+    xp = x[n - 1]
+    if sigma <= np.finfo(float).eps ** 2:
+        return v, (2.0 if xp < 0 else 0.0)
+    mu = np.sqrt(xp * xp + sigma)
+    vp = xp - mu if xp <= 0 else -sigma / (xp + mu)
+    beta = 2.0 * vp * vp / (sigma + vp * vp)
+    v[:n - 1] /= vp
+    return v, beta
+
+
+def sphere_plus(x, d):
+    nd = np.linalg.norm(d)
+    if nd == 0.0:
+        return x.copy()
+    v, beta = householder(x)
+    y = np.append(np.sin(nd) / nd * d, np.cos(nd))
+    return np.linalg.norm(x) * (y - v * (beta * (v @ y)))
+
+
+def sphere_plus_jacobian(x):
+    v, beta = householder(x)
+    H = np.eye(len(x)) - beta * np.outer(v, v)
+    return np.linalg.norm(x) * H[:, :len(x) - 1]
+
+
+def loss(kind, a, s):
+    """rho(s), rho'(s) of ceres::{Trivial, Huber, Cauchy}Loss at squared norm s."""
+    if kind == "huber":
+        b = a * a
+        return np.where(s > b, 2.0 * a * np.sqrt(np.maximum(s, 1e-300)) - b, s), np.where(s > b, a / np.sqrt(np.maximum(s, 1e-300)), 1.0)
+    if kind == "cauchy":
+        b = a * a
+        return b * np.log1p(s / b), 1.0 / (1.0 + s / b)
+    return s, np.ones_like(s)
+
+
 class Problem:
-    def __init__(self, flat):
-        self.cam = torch.tensor(np.array(flat.cam_ext), dtype=torch.float64)
-        self.pts = torch.tensor(np.array(flat.points), dtype=torch.float64)
-        grp = np.asarray(flat.cam_group)
-        self.oc = torch.tensor(np.asarray(flat.obs_cam), dtype=torch.long)
-        self.op = torch.tensor(np.asarray(flat.obs_pt), dtype=torch.long)
-        self.intr = torch.tensor(np.asarray(flat.intrinsics)[grp[np.asarray(flat.obs_cam)]], dtype=torch.float64)
+    def __init__(self, flat, manifold, loss_kind, loss_width, free_intr):
+        self.cam = np.array(flat.cam_ext, dtype=np.float64)
+        self.pts = np.array(flat.points, dtype=np.float64)
+        self.intr = np.array(flat.intrinsics, dtype=np.float64)
+        self.grp = np.asarray(flat.cam_group)
+        self.oc = np.asarray(flat.obs_cam); self.op = np.asarray(flat.obs_pt)
         self.uv = torch.tensor(np.asarray(flat.obs_uv), dtype=torch.float64)
-        cc = np.asarray(flat.cam_const) if flat.cam_const is not None else np.zeros(len(grp), np.uint8)
-        self.var_cam = np.nonzero(cc == 0)[0]
+        cc = np.asarray(flat.cam_const) if flat.cam_const is not None else np.zeros(len(self.grp), np.uint8)
         assert np.all((cc == 0) | (cc == 3)), "whole cameras constant or free"
-        self.col_cam = {int(c): 6 * i for i, c in enumerate(self.var_cam)}
-        self.n = 6 * len(self.var_cam) + 4 * self.pts.shape[0]
+        self.manifold, self.loss_kind, self.loss_width = manifold, loss_kind, loss_width
+        self.free = list(free_intr) if free_intr else []
+        self.pd = 3 if manifold else 4
+        ng = self.intr.shape[0] if self.free else 0
+        self.col_intr = {g: len(self.free) * g for g in range(ng)}
+        off = len(self.free) * ng
+        self.var_cam = np.nonzero(cc == 0)[0]
+        self.col_cam = {int(c): off + 6 * i for i, c in enumerate(self.var_cam)}
+        self.off_pts = off + 6 * len(self.var_cam)
+        self.n = self.off_pts + self.pd * self.pts.shape[0]
+        if self.free:
+            self.intr[:, 0] = np.maximum(self.intr[:, 0], 1.0)
 
-    def evaluate(self, cam, pts, jac):
-        r = _res(cam[self.oc], pts[self.op], self.intr, self.uv).numpy().reshape(-1)
+    def evaluate(self, cam, pts, intr, jac):
+        """cost, corrected residuals, corrected tangent-space Jacobian (or None)"""
+        tc, tp = torch.tensor(cam[self.oc]), torch.tensor(pts[self.op])
+        ti = torch.tensor(intr[self.grp[self.oc]])
+        r = _res(tc, tp, ti, self.uv).numpy()
+        s = (r * r).sum(1)
+        rho, rho1 = loss(self.loss_kind, self.loss_width, s)
+        cost = 0.5 * float(rho.sum())
+        sr = np.sqrt(rho1)
+        rc = (r * sr[:, None]).reshape(-1)
         if not jac:
-            return r, None
-        jc, jp = _jac(cam[self.oc], pts[self.op], self.intr, self.uv)
-        J = np.zeros((len(r), self.n))
-        off = 6 * len(self.var_cam)
+            return cost, rc, None
+        jc, jp, ji = (t.numpy() for t in _jac(tc, tp, ti, self.uv))
+        J = np.zeros((len(rc), self.n))
+        PJ = {}
         for i in range(len(self.oc)):
-            c, p = int(self.oc[i]), int(self.op[i])
+            c, p, g = int(self.oc[i]), int(self.op[i]), int(self.grp[self.oc[i]])
+            rows = slice(2 * i, 2 * i + 2)
+            if self.free:
+                J[rows, self.col_intr[g]:self.col_intr[g] + len(self.free)] += sr[i] * ji[i][:, self.free]
             if c in self.col_cam:
-                J[2 * i:2 * i + 2, self.col_cam[c]:self.col_cam[c] + 6] = jc[i].numpy()
-            J[2 * i:2 * i + 2, off + 4 * p:off + 4 * p + 4] = jp[i].numpy()
-        return r, J
+                J[rows, self.col_cam[c]:self.col_cam[c] + 6] = sr[i] * jc[i]
+            if self.manifold:
+                if p not in PJ:
+                    PJ[p] = sphere_plus_jacobian(pts[p])
+                J[rows, self.off_pts + 3 * p:self.off_pts + 3 * p + 3] = sr[i] * (jp[i] @ PJ[p])
+            else:
+                J[rows, self.off_pts + 4 * p:self.off_pts + 4 * p + 4] = sr[i] * jp[i]
+        return cost, rc, J
 
-    def plus(self, cam, pts, delta):
-        cam = cam.clone(); pts = pts.clone()
-        off = 6 * len(self.var_cam)
+    def plus(self, cam, pts, intr, delta):
+        cam, pts, intr = cam.copy(), pts.copy(), intr.copy()
+        for g, col in self.col_intr.items():
+            intr[g, self.free] += delta[col:col + len(self.free)]
+            intr[g, 0] = max(intr[g, 0], 1.0)                       # ParameterBlock::Plus projects onto the bounds
         for c, col in self.col_cam.items():
-            cam[c] += torch.tensor(delta[col:col + 6])
-        pts += torch.tensor(delta[off:].reshape(-1, 4))
-        return cam, pts
+            cam[c] += delta[col:col + 6]
+        dp = delta[self.off_pts:].reshape(-1, self.pd)
+        if self.manifold:
+            for p in range(len(pts)):
+                pts[p] = sphere_plus(pts[p], dp[p])
+        else:
+            pts += dp
+        return cam, pts, intr
 
-    def state_norm(self, cam, pts):
-        return float(np.sqrt(sum(float((cam[c] ** 2).sum()) for c in self.col_cam) + float((pts ** 2).sum())))
+    def norms(self, cam, pts, intr, cam2=None, pts2=None, intr2=None):
+        """|x| over the variable blocks, or |x - x2| (Ceres: in the ambient parameters)"""
+        acc = 0.0
+        for g in self.col_intr:
+            acc += float(((intr[g] - (intr2[g] if intr2 is not None else 0.0)) ** 2).sum())
+        for c in self.col_cam:
+            acc += float(((cam[c] - (cam2[c] if cam2 is not None else 0.0)) ** 2).sum())
+        acc += float(((pts - (pts2 if pts2 is not None else 0.0)) ** 2).sum())
+        return np.sqrt(acc)
 
 
-def solve(flat, max_num_iterations=50, function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8):
-    """Returns a list of (cost, gradient max norm, step norm, radius, accepted) per trace entry -- the entries the oracle and the
-    library record -- and the final (cameras, points)."""
-    P = Problem(flat)
-    cam, pts = P.cam, P.pts
-    r, J = P.evaluate(cam, pts, True)
-    x_cost = 0.5 * float(r @ r)
+def solve(flat, max_num_iterations=50, function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8,
+          max_trust_region_radius=1e12, manifold=False, loss_kind="trivial", loss_width=1.0, free_intr=None):
+    """Returns the trace -- (cost, gradient max norm, step norm, radius, accepted) per entry, as the oracle and the library record
+    it -- and the final (cameras, points, intrinsics)."""
+    P = Problem(flat, manifold, loss_kind, loss_width, free_intr)
+    cam, pts, intr = P.cam, P.pts, P.intr
+    x_cost, r, J = P.evaluate(cam, pts, intr, True)
     scale = 1.0 / (1.0 + np.sqrt((J * J).sum(0)))
     Js = J * scale
-    g = J.T @ r
-    gmax = float(np.abs(g).max())
-    x_norm = P.state_norm(cam, pts)
+    gmax = float(np.abs(J.T @ r).max())
+    x_norm = P.norms(cam, pts, intr)
     radius, decrease = 1e4, 2.0
     trace = [(x_cost, gmax, 0.0, radius, 1)]
     it, invalid, successful = 0, 0, True
@@ -115,11 +198,11 @@ def solve(flat, max_num_iterations=50, function_tolerance=1e-6, gradient_toleran
             trace.append((x_cost, gmax, 0.0, radius, 0))
             continue
         invalid = 0
-        delta = -y * scale
-        ccam, cpts = P.plus(cam, pts, delta)
-        rc, _ = P.evaluate(ccam, cpts, False)
-        cand = 0.5 * float(rc @ rc) if np.all(np.isfinite(rc)) else np.inf
-        step_norm = float(np.linalg.norm(delta))
+        ccam, cpts, cintr = P.plus(cam, pts, intr, -y * scale)
+        cand, rc, _ = P.evaluate(ccam, cpts, cintr, False)
+        if not np.all(np.isfinite(rc)):
+            cand = np.inf
+        step_norm = P.norms(cam, pts, intr, ccam, cpts, cintr)
         if step_norm <= parameter_tolerance * (x_norm + parameter_tolerance):
             trace.append((cand, gmax, step_norm, radius, 0)); break
         change = x_cost - cand
@@ -127,16 +210,15 @@ def solve(flat, max_num_iterations=50, function_tolerance=1e-6, gradient_toleran
             trace.append((cand, gmax, step_norm, radius, 0)); break
         rho = change / mcc
         if rho > 1e-3:
-            cam, pts = ccam, cpts
-            x_norm = P.state_norm(cam, pts)
-            r, J = P.evaluate(cam, pts, True)
-            x_cost = 0.5 * float(r @ r)
+            cam, pts, intr = ccam, cpts, cintr
+            x_norm = P.norms(cam, pts, intr)
+            x_cost, r, J = P.evaluate(cam, pts, intr, True)
             Js = J * scale
             gmax = float(np.abs(J.T @ r).max())
-            radius = min(1e16, radius / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3))
+            radius = min(max_trust_region_radius, radius / max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3))
             decrease = 2.0; successful = True
             trace.append((x_cost, gmax, step_norm, radius, 1))
         else:
             radius /= decrease; decrease *= 2.0; successful = False
             trace.append((cand, gmax, step_norm, radius, 0))
-    return trace, cam.numpy(), pts.numpy()
+    return trace, cam, pts, intr

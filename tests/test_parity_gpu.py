@@ -371,18 +371,20 @@ def test_reference_lmed_scene_on_gpu():
     assert abs(len(s.inliers) / 7500.0 - 0.666) < 0.1
 
 
-@pytest.mark.parametrize("name", ["plain", "rejections_a", "rejections_b"])
+@pytest.mark.parametrize("name", ["plain", "rejections_a", "rejections_b", "manifold", "manifold_rejections", "huber", "cauchy",
+                                  "focal_radial", "all_intrinsics"])
 def test_library_lm_trajectory_matches_an_independent_autograd_implementation(name):
     """The LIBRARY's LM trajectory (closed-form Jacobians, fused Schur assembly, tile Cholesky, device-side step control) against
     tests/independent_lm.py -- torch reverse-mode autodiff, the full normal equations by numpy Cholesky, Ceres' trust-region rules
-    restated independently -- on the scenarios of tests/test_oracle_ba.py, two of which reject and retake steps: the same
-    accept / reject sequence, costs to 1e-6, radii to 1e-8, parameters to 1e-7."""
+    restated independently -- on the scenarios of tests/test_oracle_ba.py (plain and SphereManifold points, starts that reject and
+    retake steps, Huber / Cauchy, free focal + radial and all-seven intrinsics): the same accept / reject sequence, costs to 1e-6,
+    radii to 1e-8, parameters to 1e-7."""
     from pytheiasfm_amd import ba
-    from tests.test_oracle_ba import compare_with_independent_lm
+    from tests.test_oracle_ba import compare_with_independent_lm, LM_OPTION_FIELDS
 
     def solve(p, oo):
         o = ba.default_options()
-        o.use_homogeneous_point_parametrization = oo.use_homogeneous_point_parametrization
-        o.use_inner_iterations = oo.use_inner_iterations; o.max_num_iterations = oo.max_num_iterations
+        for f in LM_OPTION_FIELDS:
+            setattr(o, f, getattr(oo, f))
         return ba.solve(p, o)
     compare_with_independent_lm(name, solve)
