@@ -22,6 +22,9 @@
 #include <memory>
 #include <string>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <unistd.h>
 #include <thread>
 #include <vector>
 
@@ -57,6 +60,37 @@ static double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// Small pageable sources (the ~60 index / flag vectors of a create()) are copied into pinned blocks that live until the
+// end of the call, so that their uploads queue behind the big ones instead of each waiting for the stream: a create() at
+// 3 M observations spent ~5 ms in those waits -- the DMA of the 72 MB of sorted observations in front of them -- while the
+// host had the K3 plan and the gather lists still to build.  The scope synchronises the stream before it lets go.
+struct StageArena {
+  std::vector<std::unique_ptr<HBuf<char>>> blocks;
+  size_t used = 0;
+  hipStream_t stream = nullptr;
+  void* put(const void* src, size_t bytes) {
+    const size_t al = (bytes + 63) & ~(size_t)63;
+    if (blocks.empty() || used + al > blocks.back()->cap) {
+      std::unique_ptr<HBuf<char>> b(new HBuf<char>);
+      if (!b->reserve(std::max<size_t>(al, (size_t)4 << 20))) return nullptr;
+      blocks.push_back(std::move(b)); used = 0;
+    }
+    void* dst = blocks.back()->p + used;
+    std::memcpy(dst, src, bytes);
+    used += al;
+    return dst;
+  }
+};
+inline StageArena*& stage_arena() { static thread_local StageArena* a = nullptr; return a; }
+struct StageScope {
+  StageArena arena;
+  StageArena* prev;
+  explicit StageScope(hipStream_t st) : prev(stage_arena()) { arena.stream = st; stage_arena() = &arena; }
+  ~StageScope() { stage_arena() = prev; (void)hipStreamSynchronize(arena.stream); }
+  StageScope(const StageScope&) = delete;
+  StageScope& operator=(const StageScope&) = delete;
+};
+
 template <typename T>
 struct DevBuf {
   // Blocks come from the library's device cache (pools.h): creating a handle makes ~80 allocations, and at a million
@@ -86,6 +120,9 @@ struct DevBuf {
     if (rc) return rc;
     // A pageable source (usually a temporary vector) must have been read before upload() returns.
     if (count) {
+      StageArena* a = stage_arena();
+      if (!pinned && a && a->stream == st && count * sizeof(T) <= ((size_t)32 << 20))
+        if (const void* staged = a->put(src, count * sizeof(T))) { src = static_cast<const T*>(staged); pinned = true; }
       HIP_TRY(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, st));
       if (!pinned) HIP_TRY(hipStreamSynchronize(st));
     }
@@ -223,20 +260,84 @@ struct theia_ba_handle_s {
 
 namespace {
 // Host-side loops over independent index ranges on a few threads (handle creation at millions of observations).
-// THEIA_HIP_HOST_THREADS caps the count (default min(hardware threads, 8); 1 = serial).
+// THEIA_HIP_HOST_THREADS caps the count (default min(hardware threads, 32); 1 = serial).
 unsigned host_thread_cap() {   // read per call (a handful per create()): tests switch it inside one process
   const char* e = getenv("THEIA_HIP_HOST_THREADS");
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  return e ? (unsigned)std::max(1, atoi(e)) : std::min(hw, 8u);
+  return e ? (unsigned)std::max(1, atoi(e)) : std::min(hw, 32u);
 }
+// A small persistent team of host threads for these loops: a create() at 3 M observations runs ~15 parallel regions, and
+// starting + joining 15 - 31 threads for each of them cost more than some of the regions themselves.  One region at a time
+// (a second caller -- entry points are re-entrant across host threads -- falls back to threads of its own); the workers are
+// started on first use, re-started after a fork, and take the parts of a region from a shared counter (the results of a
+// region never depend on who runs which part).
+class HostTeam {
+  std::mutex use_;                       // one region at a time
+  std::mutex mu_;
+  std::condition_variable work_, done_;
+  std::vector<std::thread> workers_;
+  const std::function<void(int)>* job_ = nullptr;
+  int nparts_ = 0, wanted_ = 0, active_ = 0;
+  std::atomic<int> next_{0};
+  uint64_t gen_ = 0;
+  pid_t pid_ = 0;
+  void worker(int id) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(int)>* job;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        work_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (id >= wanted_) continue;     // this region uses fewer workers
+        job = job_;
+      }
+      for (int k = next_.fetch_add(1, std::memory_order_relaxed); k < nparts_; k = next_.fetch_add(1, std::memory_order_relaxed)) (*job)(k);
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--active_ == 0) done_.notify_one();
+    }
+  }
+ public:
+  // false: the team is busy (the caller runs the region with threads of its own)
+  bool run(int nparts, unsigned cap, const std::function<void(int)>& fn) {
+    std::unique_lock<std::mutex> use(use_, std::try_to_lock);
+    if (!use.owns_lock()) return false;
+    if (pid_ != getpid()) {              // first use, or the child of a fork (threads do not survive one)
+      for (auto& t : workers_) t.detach();
+      workers_.clear();
+      pid_ = getpid();
+    }
+    const int helpers = (int)cap - 1;
+    while ((int)workers_.size() < helpers) { const int id = (int)workers_.size(); workers_.emplace_back([this, id] { worker(id); }); }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      job_ = &fn; nparts_ = nparts; wanted_ = helpers; active_ = helpers;
+      next_.store(0, std::memory_order_relaxed);
+      ++gen_;
+    }
+    work_.notify_all();
+    for (int k = next_.fetch_add(1, std::memory_order_relaxed); k < nparts; k = next_.fetch_add(1, std::memory_order_relaxed)) fn(k);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return active_ == 0; });
+    job_ = nullptr;
+    return true;
+  }
+};
+HostTeam& host_team() { static HostTeam* team = new HostTeam; return *team; }   // never destroyed: its threads wait for work until the process ends
+
+thread_local bool g_in_host_region = false;
 // fn(k) for the parts k = 0 .. nparts-1 of a fixed partition (the result must not depend on who runs which part)
 template <class F>
 void host_parts(int nparts, bool threaded, F&& fn) {
-  const unsigned cap = threaded ? std::min<unsigned>(host_thread_cap(), (unsigned)nparts) : 1u;
+  bool& in_region = g_in_host_region;   // a region started inside a region runs on its caller alone
+  const unsigned cap = (threaded && !in_region) ? std::min<unsigned>(host_thread_cap(), (unsigned)nparts) : 1u;
   if (cap <= 1) { for (int k = 0; k < nparts; ++k) fn(k); return; }
+  struct Flag { bool& f; explicit Flag(bool& x) : f(x) { f = true; } ~Flag() { f = false; } };
+  const std::function<void(int)> job = [&fn](int k) { Flag g(g_in_host_region); fn(k); };
+  if (host_team().run(nparts, cap, job)) return;
   std::vector<std::thread> th;
-  for (unsigned t = 1; t < cap; ++t) th.emplace_back([&fn, t, cap, nparts] { for (int k = (int)t; k < nparts; k += (int)cap) fn(k); });
-  for (int k = 0; k < nparts; k += (int)cap) fn(k);
+  for (unsigned t = 1; t < cap; ++t) th.emplace_back([&job, t, cap, nparts] { for (int k = (int)t; k < nparts; k += (int)cap) job(k); });
+  for (int k = 0; k < nparts; k += (int)cap) job(k);
   for (auto& x : th) x.join();
 }
 template <class F>
@@ -244,13 +345,10 @@ void host_chunks(int64_t n, F&& fn) {
   const unsigned cap = host_thread_cap();
   if (n < 262144 || cap <= 1) { fn((int64_t)0, n); return; }
   const int64_t per = (n + cap - 1) / cap;
-  std::vector<std::thread> th;
-  for (unsigned t = 1; t < cap; ++t) {
-    const int64_t a = std::min<int64_t>(n, t * per), b = std::min<int64_t>(n, a + per);
-    if (a < b) th.emplace_back([&fn, a, b] { fn(a, b); });
-  }
-  fn((int64_t)0, std::min<int64_t>(n, per));
-  for (auto& x : th) x.join();
+  host_parts((int)cap, true, [&](int t) {
+    const int64_t a = std::min<int64_t>(n, (int64_t)t * per), b = std::min<int64_t>(n, a + per);
+    if (a < b) fn(a, b);
+  });
 }
 
 
@@ -540,9 +638,18 @@ int validate(const theia_ba_problem* p, const theia_ba_options* o) {
   for (int g = 0; g < p->num_groups; ++g)
     if (!supported_model(p->group_model[g]))
       return set_error(THEIA_HIP_ERR_UNSUPPORTED, "camera model %d of group %d has no HIP kernel yet", p->group_model[g], g);
-  for (int64_t i = 0; i < p->num_obs; ++i) {
-    if (p->obs_cam[i] < 0 || p->obs_cam[i] >= p->num_cameras || p->obs_pt[i] < 0 || p->obs_pt[i] >= p->num_points)
-      return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "observation %lld indexes out of range", (long long)i);
+  {   // (on host threads at millions of observations; the first offender is reported whoever finds it)
+    std::atomic<int64_t> first_bad{std::numeric_limits<int64_t>::max()};
+    host_chunks(p->num_obs, [&](int64_t i0, int64_t i1) {
+      for (int64_t i = i0; i < i1; ++i)
+        if (p->obs_cam[i] < 0 || p->obs_cam[i] >= p->num_cameras || p->obs_pt[i] < 0 || p->obs_pt[i] >= p->num_points) {
+          int64_t cur = first_bad.load();
+          while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {}
+          return;
+        }
+    });
+    if (first_bad.load() != std::numeric_limits<int64_t>::max())
+      return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "observation %lld indexes out of range", (long long)first_bad.load());
   }
   if (o->intrinsics_to_optimize < 0 || o->intrinsics_to_optimize > THEIA_INTR_ALL)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "invalid intrinsics_to_optimize bit mask");
@@ -870,7 +977,7 @@ int build_gather_lists(theia_ba_handle_s* h, const int* ocam, const int* opt,
     // Fused Schur assembly: only the cameras' observation lists are needed (column norms of the camera blocks,
     // k_colnorm_gather) -- a stable counting sort by reduced camera over a fixed partition of the observations, on host
     // threads, written into a pinned block.
-    constexpr int kParts = 8;
+    constexpr int kParts = 32;
     auto red_of = [&](int64_t s) { return (!is_long.empty() && is_long[s]) ? -1 : h->cam_red[ocam[s]]; };
     std::vector<std::vector<int>> fill(kParts, std::vector<int>(std::max(1, h->ncv), 0));
     const bool threaded = nm >= 262144;
@@ -1585,7 +1692,22 @@ void merge_fused_segments(const theia_ba_handle_s* h, std::vector<FusedSegment>&
       ents.push_back({((int64_t)ri << 32) | (uint32_t)ri, r.part_off + 36 * r.ntgt + 18 * lc, 1});
     }
   }
-  std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.key != b.key ? a.key < b.key : a.isd < b.isd; });
+  {   // order (row camera, column camera, block pieces before diagonal pieces, run order): three stable counting passes, least
+      // significant key first (std::stable_sort on the 230 k entries of the 1000-view configuration took 2.3 ms of the create())
+    const int nb = std::max(2, h->ncp) + 1;
+    std::vector<Ent> tmp(ents.size());
+    std::vector<int> head((size_t)nb + 1);
+    auto pass = [&](std::vector<Ent>& from, std::vector<Ent>& to, auto&& digit) {
+      std::fill(head.begin(), head.end(), 0);
+      for (const Ent& en : from) head[(size_t)digit(en) + 1]++;
+      for (int b = 0; b < nb; ++b) head[b + 1] += head[b];
+      for (const Ent& en : from) to[(size_t)head[digit(en)]++] = en;
+    };
+    pass(ents, tmp, [](const Ent& en) { return en.isd; });
+    pass(tmp, ents, [](const Ent& en) { return (int)(en.key & 0xffffffff); });
+    pass(ents, tmp, [](const Ent& en) { return (int)(en.key >> 32); });
+    ents.swap(tmp);
+  }
   for (size_t q = 0; q < ents.size();) {
     size_t e = q;
     while (e < ents.size() && ents[e].key == ents[q].key) ++e;
@@ -1632,6 +1754,8 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
   h->nc = p->num_cameras; h->ng = p->num_groups; h->np = p->num_points; h->nobs = p->num_obs;
   h->pd = o->use_homogeneous_point_parametrization ? 3 : 4;
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  StageScope stage(h->stream);   // (after `guard`: it waits for the stream before the handle can go)
+  PoolStreamScope pool_scope(h->stream);   // blocks that go back to the caches inside this call are tagged with an event on it
   for (auto& row : h->ev) for (auto& e : row) HIP_TRY(hipEventCreate(&e));
   HIP_TRY(hipHostMalloc((void**)&h->h_scal, sizeof(double) * 40, hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&h->h_state, 1024, hipHostMallocDefault));
@@ -1650,11 +1774,14 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
   // --- problem structure (bundle_adjuster.cc:116-221,357-380,477-527) ---
   std::vector<uint8_t> cam_used(h->nc, 0), pt_used(h->np, 0);
   std::vector<uint8_t> grp_used(h->ng, 0);
+  std::atomic<int> unsorted{0};
   {   // cameras with observations: flags per host thread, merged (the tracks' flags come with the key pass below)
     std::mutex mu;
     host_chunks(h->nobs, [&](int64_t i0, int64_t i1) {
       std::vector<uint8_t> mine(h->nc, 0);
-      for (int64_t i = i0; i < i1; ++i) mine[p->obs_cam[i]] = 1;
+      bool disorder = false;   // (the same pass: does the input come track by track?  see the track CSR below)
+      for (int64_t i = i0; i < i1; ++i) { mine[p->obs_cam[i]] = 1; disorder |= i > 0 && p->obs_pt[i] < p->obs_pt[i - 1]; }
+      if (disorder) unsorted.store(1, std::memory_order_relaxed);
       std::lock_guard<std::mutex> lk(mu);
       for (int c = 0; c < h->nc; ++c) cam_used[c] |= mine[c];
     });
@@ -1716,25 +1843,51 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
       fixed[i] = (h->cam_red[p->obs_cam[i]] < 0 && h->grp_red[p->cam_group[p->obs_cam[i]]] < 0 &&
                   p->point_const && p->point_const[p->obs_pt[i]]) ? 1 : 0;
   });
-  // per-track sums on host threads: every thread scans all observations and keeps those of its own range of tracks (the
-  // writes of the threads are disjoint and each thread's working set is its share of the arrays)
-  host_chunks(h->np, [&](int64_t q0, int64_t q1) {
-    for (int64_t i = 0; i < h->nobs; ++i) {
-      const int q = p->obs_pt[i];
-      if (q < q0 || q >= q1) continue;
-      pt_used[q] = 1;
-      const int rc = h->cam_part[p->obs_cam[i]];
-      if (rc >= 0) { nvar[q]++; if (rc < pkey[q]) pkey[q] = rc; }
+  // The input's observations grouped by track (CSR): toff[q] .. toff[q + 1] are track q's entries of tobs, in input order.
+  // Input that already comes track by track (obs_pt non-decreasing: what a flattened reconstruction looks like) needs no
+  // index array; anything else is counted, scattered with atomic cursors and put back into input order per track.
+  std::vector<int> toff((size_t)h->np + 1, 0);
+  HBuf<int> tobs_b;
+  const int* tobs = nullptr;   // nullptr: the identity
+  {
+    if (!unsorted.load()) {
+      host_chunks(h->nobs, [&](int64_t i0, int64_t i1) {   // toff[q] = first observation of a track >= q: disjoint writes
+        for (int64_t i = i0; i < i1; ++i)
+          if (i == 0 || p->obs_pt[i] != p->obs_pt[i - 1])
+            for (int q = i ? p->obs_pt[i - 1] + 1 : 0; q <= p->obs_pt[i]; ++q) toff[q] = (int)i;
+      });
+      for (int q = h->nobs ? p->obs_pt[h->nobs - 1] + 1 : 0; q <= h->np; ++q) toff[q] = (int)h->nobs;
+    } else {
+      if (!tobs_b.resize((size_t)std::max<int64_t>(1, h->nobs), true)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %lld observations failed", (long long)h->nobs);
+      int* const tb = tobs_b.data();
+      host_chunks(h->nobs, [&](int64_t i0, int64_t i1) { for (int64_t i = i0; i < i1; ++i) __atomic_fetch_add(&toff[(size_t)p->obs_pt[i] + 1], 1, __ATOMIC_RELAXED); });
+      for (int q = 0; q < h->np; ++q) toff[q + 1] += toff[q];
+      std::vector<int> cur(toff.begin(), toff.end() - 1);
+      host_chunks(h->nobs, [&](int64_t i0, int64_t i1) { for (int64_t i = i0; i < i1; ++i) tb[__atomic_fetch_add(&cur[p->obs_pt[i]], 1, __ATOMIC_RELAXED)] = (int)i; });
+      host_chunks(h->np, [&](int64_t q0, int64_t q1) { for (int64_t q = q0; q < q1; ++q) std::sort(tb + toff[q], tb + toff[q + 1]); });
+      tobs = tb;
+    }
+  }
+  std::vector<int> nfix(h->np, 0);   // residual blocks of a track whose blocks are all constant
+  host_chunks(h->np, [&](int64_t q0, int64_t q1) {   // per-track sums: tracks are independent
+    for (int64_t q = q0; q < q1; ++q) {
+      pt_used[q] = toff[q + 1] > toff[q];
+      for (int k = toff[q]; k < toff[q + 1]; ++k) {
+        const int i = tobs ? tobs[k] : k;
+        const int rc = h->cam_part[p->obs_cam[i]];
+        if (rc >= 0) { nvar[q]++; if (rc < pkey[q]) pkey[q] = rc; }
+        nfix[q] += fixed[i];
+      }
+      h->pt_const[q] = ((p->point_const && p->point_const[q]) || !pt_used[q]) ? 1 : 0;
     }
   });
-  for (int q = 0; q < h->np; ++q) h->pt_const[q] = ((p->point_const && p->point_const[q]) || !pt_used[q]) ? 1 : 0;
-  std::vector<int> porder(h->np), prank(h->np);
-  for (int q = 0; q < h->np; ++q) porder[q] = q;
+  std::vector<int> porder(h->np);
   // Inside one first-camera key, short tracks come first (classes by number of variable cameras): the fused Schur
   // kernel packs several short tracks into one wave step when a run of tracks touches few target blocks.
   std::vector<int> skey_pt(h->np);
-  {
-    for (int q = 0; q < h->np; ++q) {
+  host_chunks(h->np, [&](int64_t q0, int64_t q1) {
+    for (int64_t q = q0; q < q1; ++q) {
+      porder[q] = (int)q;
       // measured at 1k views / 500k tracks (K1 + K2 launch group): {<= 7 | >= 8} 0.575 ms, {<= 6 | >= 7} 0.599, {<= 5 | >= 6} 0.670,
       // {<= 8 | >= 9} 0.646, {<= 3 | 4..6 | >= 7} 0.636, one class 0.593
       static const int ncls = getenv("THEIA_HIP_FUSED_CLASSES") ? atoi(getenv("THEIA_HIP_FUSED_CLASSES")) : 2;
@@ -1746,49 +1899,96 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
       static const bool noclass = getenv("THEIA_HIP_FUSED_NOCLASS") != nullptr;
       skey_pt[q] = pkey[q] == std::numeric_limits<int>::max() ? pkey[q] : (((h->ni == 0 || h->fused_bw) && !noclass) ? pkey[q] * 4 + cls : pkey[q]);
     }
-  }
+  });
   tick("  structure: masks, keys");
-  {   // stable counting sort by key (keys are < 4 * (#variable cameras) + 4, or INT_MAX = no variable camera: last bucket)
+  // Stable counting sort of the tracks by key (keys are < 4 * (#variable cameras) + 4, or INT_MAX = no variable camera: last
+  // bucket) on host threads -- per-part histograms, offsets in (bucket, part) order -- and, in the same scatter, what the track
+  // of every RANK brings: its first-camera key and its fixed / non-fixed residual blocks.
+  std::vector<int64_t> cnt_main(h->np + 1, 0), cnt_fix(h->np + 1, 0);   // (offsets indexed by track rank, after the running sums)
+  std::vector<int> skey(h->np);                                         // run boundaries of the fused plan follow the first-camera key
+  {
     int maxkey = -1;
     for (int q = 0; q < h->np; ++q) if (skey_pt[q] != std::numeric_limits<int>::max()) maxkey = std::max(maxkey, skey_pt[q]);
+    auto place = [&](int64_t r, int q) {
+      porder[r] = q; skey[r] = pkey[q];
+      cnt_fix[r + 1] = nfix[q]; cnt_main[r + 1] = (toff[q + 1] - toff[q]) - nfix[q];
+    };
     if (maxkey >= 0 && (int64_t)maxkey < 8 * (int64_t)h->np + 1024) {
       const int nb = maxkey + 2;
-      std::vector<int> head(nb + 1, 0);
+      int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_thread_cap(), h->np / 32768));
+      if ((int64_t)parts * nb > ((int64_t)1 << 24)) parts = 1;
+      const int64_t per = ((int64_t)h->np + parts - 1) / parts;
+      std::vector<int> head((size_t)parts * nb, 0);
       auto bucket = [&](int q) { return skey_pt[q] == std::numeric_limits<int>::max() ? nb - 1 : skey_pt[q]; };
-      for (int q = 0; q < h->np; ++q) head[bucket(q) + 1]++;
-      for (int b = 0; b < nb; ++b) head[b + 1] += head[b];
-      for (int q = 0; q < h->np; ++q) porder[head[bucket(q)]++] = q;
+      host_parts(parts, true, [&](int t) {
+        int* hh = head.data() + (size_t)t * nb;
+        for (int64_t q = t * per; q < std::min<int64_t>(h->np, (t + 1) * per); ++q) hh[bucket((int)q)]++;
+      });
+      int run = 0;
+      for (int bk = 0; bk < nb; ++bk)
+        for (int t = 0; t < parts; ++t) { int& c = head[(size_t)t * nb + bk]; const int n = c; c = run; run += n; }
+      host_parts(parts, true, [&](int t) {
+        int* hh = head.data() + (size_t)t * nb;
+        for (int64_t q = t * per; q < std::min<int64_t>(h->np, (t + 1) * per); ++q) place(hh[bucket((int)q)]++, (int)q);
+      });
     } else {
       std::stable_sort(porder.begin(), porder.end(), [&](int x, int y) { return skey_pt[x] < skey_pt[y]; });
+      for (int r = 0; r < h->np; ++r) place(r, porder[r]);
     }
   }
   tick("  structure: sort tracks");
-  for (int r = 0; r < h->np; ++r) prank[porder[r]] = r;
-  // offsets indexed by track RANK
-  std::vector<int64_t> cnt_main(h->np + 1, 0), cnt_fix(h->np + 1, 0);
-  HBuf<int> orank;   // rank of an observation's track (pinned block of the host cache: reused, no page faults)
-  if (!orank.resize((size_t)std::max<int64_t>(1, h->nobs), true)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %lld observations failed", (long long)h->nobs);
-  host_chunks(h->nobs, [&](int64_t i0, int64_t i1) { for (int64_t i = i0; i < i1; ++i) orank[i] = prank[p->obs_pt[i]]; });
-  host_chunks(h->np, [&](int64_t r0, int64_t r1) {   // threads own ranges of ranks, as above
-    for (int64_t i = 0; i < h->nobs; ++i) {
-      const int r = orank[i];
-      if (r < r0 || r >= r1) continue;
-      (fixed[i] ? cnt_fix : cnt_main)[r + 1]++;
-    }
-  });
-  for (int q = 0; q < h->np; ++q) { cnt_main[q + 1] += cnt_main[q]; cnt_fix[q + 1] += cnt_fix[q]; }
+  for (int r = 0; r < h->np; ++r) { cnt_fix[r + 1] += cnt_fix[r]; cnt_main[r + 1] += cnt_main[r]; }   // ... as running sums
+  tick("    permutation: counts");
   h->nobs_main = cnt_main[h->np];
   if (!h->perm.resize((size_t)std::max<int64_t>(1, h->nobs), true)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %lld observations failed", (long long)h->nobs);
-  {
-    std::vector<int64_t> fm(cnt_main.begin(), cnt_main.end() - 1), ff(cnt_fix.begin(), cnt_fix.end() - 1);
-    host_chunks(h->np, [&](int64_t r0, int64_t r1) {   // observations of a track keep their input order
-      for (int64_t i = 0; i < h->nobs; ++i) {
-        const int q = orank[i];
-        if (q < r0 || q >= r1) continue;
-        if (fixed[i]) h->perm[h->nobs_main + ff[q]++] = i; else h->perm[fm[q]++] = i;
+  // The sorted observation arrays are staged in pinned blocks of the library's host cache: 24 bytes per observation of
+  // fresh pageable vectors cost more in page faults than the gather itself, and the copies below run as plain DMA.  They
+  // are filled in the pass that lays out the permutation -- a track's observations are read where they lie in the input
+  // (one run of it when the input comes track by track) instead of through 3 M random reads of a separate gather pass.
+  HBuf<double2> uv, si;
+  HBuf<int> ocam_b, opt_b, sred_b;
+  if (!uv.resize((size_t)std::max<int64_t>(1, h->nobs), true) || !ocam_b.resize((size_t)std::max<int64_t>(1, h->nobs), true) ||
+      !opt_b.resize((size_t)std::max<int64_t>(1, h->nobs), true) || !sred_b.resize((size_t)std::max<int64_t>(1, h->nobs_main), true) ||
+      (p->obs_sqrt_info && !si.resize((size_t)std::max<int64_t>(1, h->nobs), true)))
+    return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "pinned staging of %lld observations failed", (long long)h->nobs);
+  if (!p->obs_sqrt_info) si.n = 0;
+  int* const ocam = ocam_b.data();
+  int* const opt = opt_b.data();
+  int* const sred = sred_b.data();   // participating camera of a non-fixed observation (-1: constant camera and group)
+  host_chunks(h->np, [&](int64_t r0, int64_t r1) {   // observations of a track keep their input order
+    constexpr int kAhead = 12;   // the tracks of consecutive ranks lie anywhere in the input: their lines are requested ahead
+    for (int64_t r = r0; r < r1; ++r) {
+      if (r + 2 * kAhead < r1) __builtin_prefetch(&toff[porder[r + 2 * kAhead]]);
+      if (r + kAhead < r1) {
+        const int qn = porder[r + kAhead];
+        if (tobs) __builtin_prefetch(&tobs[toff[qn]]);
+        else {
+          const size_t i0 = (size_t)toff[qn];
+          __builtin_prefetch(p->obs_uv + 2 * i0); __builtin_prefetch(p->obs_uv + 2 * i0 + 8);
+          __builtin_prefetch(p->obs_cam + i0); __builtin_prefetch(&fixed[i0]);
+          if (p->obs_sqrt_info) { __builtin_prefetch(p->obs_sqrt_info + 2 * i0); __builtin_prefetch(p->obs_sqrt_info + 2 * i0 + 8); }
+        }
       }
-    });
-  }
+      const int q = porder[r];
+      int64_t m = cnt_main[r], f = h->nobs_main + cnt_fix[r];
+      for (int k = toff[q]; k < toff[q + 1]; ++k) {
+        const int i = tobs ? tobs[k] : k;
+        const int64_t s2 = fixed[i] ? f++ : m++;
+        h->perm[s2] = i;
+        uv[s2] = make_double2(p->obs_uv[2 * (size_t)i], p->obs_uv[2 * (size_t)i + 1]);
+        if (p->obs_sqrt_info) si[s2] = make_double2(p->obs_sqrt_info[2 * (size_t)i], p->obs_sqrt_info[2 * (size_t)i + 1]);
+        ocam[s2] = p->obs_cam[i]; opt[s2] = q;
+        if (!fixed[i]) sred[s2] = h->cam_part[p->obs_cam[i]];
+      }
+    }
+  });
+  tick("    permutation: fill");
+  // their uploads start now and run under the rest of the plan construction (pinned sources: nothing waits here; a block that
+  // goes back to the host cache on an early return is tagged with an event on this stream, see pool_scope above)
+#define UPP(buf, src, cnt, pin) do { rc = h->buf.upload(src, cnt, h->stream, pin); if (rc) return rc; } while (0)
+  UPP(obs_uv, uv.data(), (size_t)h->nobs, uv.pinned()); UPP(obs_si, si.data(), si.n, si.pinned());
+  UPP(obs_cam, ocam, (size_t)h->nobs, ocam_b.pinned()); UPP(obs_pt, opt, (size_t)h->nobs, opt_b.pinned());
+#undef UPP
   // wave tiles: <= 64 observations, never splitting a track
   std::vector<int> tstart, tcount, tkey;
   std::vector<int> l_obs, l_slot, l_start(1, 0), l_pt;  // long tracks (> 64 observations): slow path
@@ -1826,12 +2026,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
   tick("  structure: permutation");
   h->use_fused = (h->ni == 0 || h->fused_bw) && h->nobs_main > 0 && !getenv("THEIA_HIP_SCHUR_GATHER");
   const int fused_max_cams = h->fused_bw == 0 ? kFusedMaxCams : (h->fused_bw == 9 ? kFusedMaxCamsIntr : 10);
-  HBuf<int> sred_b;
-  int* sred = nullptr;
   if (h->use_fused) {
-    if (!sred_b.resize((size_t)h->nobs_main, true)) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %lld observations failed", (long long)h->nobs_main);
-    sred = sred_b.data();
-    host_chunks(h->nobs_main, [&](int64_t s0, int64_t s1) { for (int64_t s = s0; s < s1; ++s) sred[s] = h->cam_part[p->obs_cam[h->perm[s]]]; });
     std::atomic<long long> misfit{0};
     host_chunks(h->np, [&](int64_t q0, int64_t q1) {   // tracks are independent
       std::vector<int> tc;
@@ -1851,11 +2046,9 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
   }
   tick("  structure: fit check");
   if (h->use_fused) {
-    std::vector<int> skey(h->np);
-    for (int q = 0; q < h->np; ++q) skey[q] = pkey[porder[q]];   // run boundaries follow the first-camera key
-    // eight segments of tracks, cut where the first-camera key changes, built on host threads and merged in order (the
+    // 32 segments of tracks, cut where the first-camera key changes, built on host threads and merged in order (the
     // segment count is fixed: the plan -- and with it the summation order of S -- does not depend on the machine)
-    constexpr int kSegs = 8;
+    constexpr int kSegs = 32;
     std::vector<int> cut{0};
     if (h->np >= 65536)
       for (int k = 1; k < kSegs; ++k) {
@@ -1865,16 +2058,15 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
       }
     cut.push_back(h->np);
     std::vector<FusedSegment> segs(cut.size() - 1);
+    tick("    fused plan: keys + cuts");
     fplan.obs_lc.assign((size_t)std::max<int64_t>(1, h->nobs_main), 0xff);
     fplan.obs_tl.assign((size_t)std::max<int64_t>(1, h->nobs_main), 0);
-    {
-      std::vector<std::thread> th;
-      for (size_t k = 1; k < segs.size(); ++k)
-        th.emplace_back([&, k] { build_fused_segment(h, cnt_main, porder, sred, skey, cut[k], cut[k + 1], fplan.obs_lc.data(), fplan.obs_tl.data(), segs[k]); });
-      build_fused_segment(h, cnt_main, porder, sred, skey, cut[0], cut[1], fplan.obs_lc.data(), fplan.obs_tl.data(), segs[0]);
-      for (auto& x : th) x.join();
-    }
+    host_parts((int)segs.size(), true, [&](int k) {
+      build_fused_segment(h, cnt_main, porder, sred, skey, cut[k], cut[k + 1], fplan.obs_lc.data(), fplan.obs_tl.data(), segs[k]);
+    });
+    tick("    fused plan: segments built");
     merge_fused_segments(h, segs, tstart, tcount, tkey, l_obs, l_slot, l_start, l_pt, fplan);
+    tick("    fused plan: merged");
     if (h->fused_bw) {
       int n1 = 0, n2 = 0;
       build_sum_items_intr(h, p->cam_group, fplan, &n1, &n2);
@@ -1888,6 +2080,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
   }
   tick("  structure: fused plan / tiles");
   h->ntiles_main = (int)tstart.size();
+  tick("    (tiles)");
   // evaluation-only tiles over the long tracks' observations (no per-track sums there)
   h->long_nobs = (int)l_obs.size(); h->long_ntracks = (int)l_pt.size();
   for (int s2 = 0; s2 < h->long_ntracks; ++s2)
@@ -1897,50 +2090,43 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
   h->ntiles_eval = (int)tstart.size();
   build_tiles(cnt_fix, h->nobs_main, false);
   h->ntiles_all = (int)tstart.size();
-  // The sorted observation arrays are staged in pinned blocks of the library's host cache: 24 bytes per observation of
-  // fresh pageable vectors cost more in page faults than the gather itself, and the copies below run as plain DMA.
-  HBuf<double2> uv, si;
-  HBuf<int> ocam_b, opt_b;
-  if (!uv.resize((size_t)h->nobs, true) || !ocam_b.resize((size_t)h->nobs, true) || !opt_b.resize((size_t)h->nobs, true) ||
-      (p->obs_sqrt_info && !si.resize((size_t)h->nobs, true)))
-    return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "pinned staging of %lld observations failed", (long long)h->nobs);
-  int* const ocam = ocam_b.data();
-  int* const opt = opt_b.data();
-  host_chunks(h->nobs, [&](int64_t s0, int64_t s1) {   // gathers through the permutation: independent per observation
-    for (int64_t s = s0; s < s1; ++s) {
-      const int64_t i = h->perm[s];
-      uv[s] = make_double2(p->obs_uv[2 * i], p->obs_uv[2 * i + 1]);
-      if (p->obs_sqrt_info) si[s] = make_double2(p->obs_sqrt_info[2 * i], p->obs_sqrt_info[2 * i + 1]);
-      ocam[s] = p->obs_cam[i]; opt[s] = p->obs_pt[i];
-    }
-  });
   hipStream_t st = h->stream;
 #define UP(buf, vec) do { rc = h->buf.upload(vec, st); if (rc) return rc; } while (0)
 #define AL(buf, cnt) do { rc = h->buf.alloc(cnt); if (rc) return rc; } while (0)
   tick("structure, sort, tiles");
-#define UPP(buf, src, cnt, pin) do { rc = h->buf.upload(src, cnt, st, pin); if (rc) return rc; } while (0)
-  UPP(obs_uv, uv.data(), (size_t)h->nobs, uv.pinned()); UPP(obs_si, si.data(), si.n, si.pinned());
-  UPP(obs_cam, ocam, (size_t)h->nobs, ocam_b.pinned()); UPP(obs_pt, opt, (size_t)h->nobs, opt_b.pinned());
-#undef UPP
   h->inner = h->opt.use_inner_iterations != 0 && h->nobs_main > 0;
   if (h->inner) {
     // residual blocks that depend on a block: the camera's / the group's / the track's observations among the
     // non-fixed ones [0, nobs_main) of the sorted arrays (depth-prior rows do not depend on the intrinsics)
     const int64_t nm = h->nobs_main;
-    std::vector<int> coff(h->nc + 1, 0), cidx(nm), goff(h->ng + 1, 0), gidx, toff;
-    for (int64_t s = 0; s < nm; ++s) coff[ocam[s] + 1]++;
-    for (int c = 0; c < h->nc; ++c) coff[c + 1] += coff[c];
-    { std::vector<int> fill(coff.begin(), coff.end() - 1); for (int64_t s = 0; s < nm; ++s) cidx[fill[ocam[s]]++] = (int)s; }
-    if (h->ni) {
-      auto is_depth = [&](int64_t s) { return p->obs_kind && p->obs_kind[h->perm[s]]; };
-      for (int64_t s = 0; s < nm; ++s) if (!is_depth(s)) goff[p->cam_group[ocam[s]] + 1]++;
-      for (int g = 0; g < h->ng; ++g) goff[g + 1] += goff[g];
-      gidx.resize(goff[h->ng]);
-      std::vector<int> fill(goff.begin(), goff.end() - 1);
-      for (int64_t s = 0; s < nm; ++s) if (!is_depth(s)) gidx[fill[p->cam_group[ocam[s]]]++] = (int)s;
-    }
-    toff.push_back(0);
-    for (int64_t s = 1; s <= nm; ++s) if (s == nm || opt[s] != opt[s - 1]) toff.push_back((int)s);
+    // stable counting sorts by camera / by group on host threads: per-part histograms, offsets in (key, part) order
+    std::vector<int> coff(h->nc + 1, 0), cidx((size_t)nm), goff(h->ng + 1, 0), gidx, toff;
+    auto is_depth = [&](int64_t s) { return p->obs_kind && p->obs_kind[h->perm[s]]; };
+    auto bucket_sort = [&](int nkeys, std::vector<int>& off, std::vector<int>& idx, auto&& key_of) {   // key < 0: not listed
+      const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_thread_cap(), nm / 65536));
+      const int64_t per = (nm + parts - 1) / parts;
+      std::vector<int> hist((size_t)parts * nkeys, 0);
+      host_parts(parts, true, [&](int t) {
+        int* hh = hist.data() + (size_t)t * nkeys;
+        for (int64_t s = t * per; s < std::min<int64_t>(nm, (t + 1) * per); ++s) { const int k = key_of(s); if (k >= 0) hh[k]++; }
+      });
+      int run = 0;
+      for (int k = 0; k < nkeys; ++k) {
+        off[k] = run;
+        for (int t = 0; t < parts; ++t) { const int c = hist[(size_t)t * nkeys + k]; hist[(size_t)t * nkeys + k] = run; run += c; }
+      }
+      off[nkeys] = run;
+      idx.resize((size_t)run);
+      host_parts(parts, true, [&](int t) {
+        int* hh = hist.data() + (size_t)t * nkeys;
+        for (int64_t s = t * per; s < std::min<int64_t>(nm, (t + 1) * per); ++s) { const int k = key_of(s); if (k >= 0) idx[hh[k]++] = (int)s; }
+      });
+    };
+    bucket_sort(h->nc, coff, cidx, [&](int64_t s) { return ocam[s]; });
+    if (h->ni) bucket_sort(h->ng, goff, gidx, [&](int64_t s) { return is_depth(s) ? -1 : p->cam_group[ocam[s]]; });
+    toff.reserve((size_t)h->np + 1);   // the sorted observations of a track are one range: its non-fixed count
+    for (int r = 0; r < h->np; ++r) if (cnt_main[r + 1] > cnt_main[r]) toff.push_back((int)cnt_main[r]);
+    toff.push_back((int)nm);
     h->in_ntracks = (int)toff.size() - 1;
     if (gidx.empty()) gidx.push_back(0);
     UP(in_cam_off, coff); UP(in_cam_idx, cidx); UP(in_grp_off, goff); UP(in_grp_idx, gidx); UP(in_trk_off, toff);

@@ -377,6 +377,36 @@ def test_full_size_c4_properties():
     assert np.array_equal(tr4.cost[: tr4.size], tr.cost[: tr4.size]) and np.array_equal(tr4.step_norm[: tr4.size], tr.step_norm[: tr4.size])
 
 
+def test_observation_order_of_the_input_does_not_change_the_solve():
+    """create() groups the input's observations by track: input that comes track by track (obs_pt non-decreasing) is walked in
+    place, anything else goes through a counted scatter with atomic cursors and a per-track sort back into input order.  The
+    same problem with its observations INTERLEAVED (view-major, the order BundleAdjustReconstruction adds them in; the order
+    inside every track kept) must give the same plan and therefore the same trajectory bit for bit -- also with constant
+    cameras / points (fixed-cost blocks) and with one host thread."""
+    p = synth.ba_config("C2")     # 299 587 observations (> 262 144: the threaded passes run), tracks of <= 10: no track takes the
+    assert np.all(np.diff(p.obs_pt) >= 0) and p.obs_uv.shape[0] > 262144   # slow path, whose atomics are not bit-reproducible
+    p.cam_const = np.zeros(p.cam_ext.shape[0], np.uint8); p.cam_const[[0, 5]] = 3
+    p.point_const = np.zeros(p.points.shape[0], np.uint8); p.point_const[::7] = 1
+    within = np.arange(len(p.obs_pt)) - np.repeat(np.cumsum(np.bincount(p.obs_pt)) - np.bincount(p.obs_pt), np.bincount(p.obs_pt))
+    order = np.lexsort((p.obs_pt, within))                          # all first observations, then all second ones, ...
+    assert np.any(np.diff(p.obs_pt[order]) < 0)
+    q = capi.FlatProblem(p.cam_ext.copy(), p.intrinsics.copy(), p.group_model, p.cam_group, p.points.copy(), p.obs_uv[order],
+                         p.obs_cam[order], p.obs_pt[order], p.cam_const, p.group_const, p.point_const)
+    o = ba.default_options(); o.max_num_iterations = 4
+    pa, qa = p.copy(), q.copy()
+    sa, ta = ba.solve(pa, o)
+    sb, tb = ba.solve(qa, o)
+    assert sa.success and ta.size == tb.size and ta.size >= 3
+    assert np.array_equal(ta.cost[: ta.size], tb.cost[: tb.size]) and np.array_equal(ta.step_norm[: ta.size], tb.step_norm[: tb.size])
+    assert np.array_equal(pa.cam_ext, qa.cam_ext) and np.array_equal(pa.points, qa.points)
+    os.environ["THEIA_HIP_HOST_THREADS"] = "1"
+    try:
+        qc = q.copy(); sc, tc = ba.solve(qc, o)
+    finally:
+        del os.environ["THEIA_HIP_HOST_THREADS"]
+    assert np.array_equal(tc.cost[: tc.size], ta.cost[: ta.size]) and np.array_equal(qc.points, pa.points)
+
+
 @pytest.mark.parametrize("n", [1, 6, 24, 32, 33, 120, 121, 300, 1200])
 def test_dense_cholesky_kernel_against_numpy(n):
     """K3 alone (FP64-MFMA blocked Cholesky + substitutions) vs numpy."""
