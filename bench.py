@@ -510,7 +510,7 @@ def main():
         t10 = time.perf_counter(); s1, _ = ba.solve(q1, o1, trace_capacity=1); t11 = time.perf_counter()
         out["one_shot_call"] = {"workload": "theia_hip_ba_solve on the same problem from host arrays, 25 LM iterations",
                                 "total_ms": 1e3 * (t11 - t10), "iterations": int(s1.num_iterations),
-                                "note": "handle creation (host-side plan of 3.0 M observations) dominates: see DESIGN.md 3.4"}
+                                "note": "handle creation (host-side plan of 3.0 M observations) ~16 ms of it: see DESIGN.md 3.4"}
     if rank == 0 and world == 1 and not args.no_c2:
         # secondary block: BASELINE.json configs[1] (the round-1 headline), same measurement
         c2 = synth.ba_config("C2")

@@ -1838,11 +1838,6 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
   std::vector<uint8_t> fixed(h->nobs, 0);
   std::vector<int> pkey(h->np, std::numeric_limits<int>::max());
   std::vector<int> nvar(h->np, 0);   // variable cameras of a track
-  host_chunks(h->nobs, [&](int64_t i0, int64_t i1) {   // an observed track is constant iff the caller marked it
-    for (int64_t i = i0; i < i1; ++i)
-      fixed[i] = (h->cam_red[p->obs_cam[i]] < 0 && h->grp_red[p->cam_group[p->obs_cam[i]]] < 0 &&
-                  p->point_const && p->point_const[p->obs_pt[i]]) ? 1 : 0;
-  });
   // The input's observations grouped by track (CSR): toff[q] .. toff[q + 1] are track q's entries of tobs, in input order.
   // Input that already comes track by track (obs_pt non-decreasing: what a flattened reconstruction looks like) needs no
   // index array; anything else is counted, scattered with atomic cursors and put back into input order per track.
@@ -1872,10 +1867,14 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
   host_chunks(h->np, [&](int64_t q0, int64_t q1) {   // per-track sums: tracks are independent
     for (int64_t q = q0; q < q1; ++q) {
       pt_used[q] = toff[q + 1] > toff[q];
+      const bool qconst = p->point_const && p->point_const[q];
       for (int k = toff[q]; k < toff[q + 1]; ++k) {
         const int i = tobs ? tobs[k] : k;
-        const int rc = h->cam_part[p->obs_cam[i]];
+        const int c = p->obs_cam[i];
+        const int rc = h->cam_part[c];
         if (rc >= 0) { nvar[q]++; if (rc < pkey[q]) pkey[q] = rc; }
+        // a residual block whose blocks are all constant (an observed track is constant iff the caller marked it)
+        fixed[i] = (qconst && h->cam_red[c] < 0 && h->grp_red[p->cam_group[c]] < 0) ? 1 : 0;
         nfix[q] += fixed[i];
       }
       h->pt_const[q] = ((p->point_const && p->point_const[q]) || !pt_used[q]) ? 1 : 0;
