@@ -2090,7 +2090,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
   if (h->use_fused) {
     // 32 segments of tracks, cut where the first-camera key changes, built on host threads and merged in order (the
     // segment count is fixed: the plan -- and with it the summation order of S -- does not depend on the machine)
-    constexpr int kSegs = 32;
+    static const int kSegs = getenv("THEIA_HIP_PLAN_SEGS") ? std::max(1, atoi(getenv("THEIA_HIP_PLAN_SEGS"))) : 32;   // (the switch: measurement only)
     std::vector<int> cut{0};
     if (h->np >= 65536)
       for (int k = 1; k < kSegs; ++k) {

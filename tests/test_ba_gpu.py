@@ -1015,6 +1015,44 @@ def test_depth_prior_rows_are_validated():
         ba.solve_tracks_batch(p.copy(), o)
 
 
+def test_concurrent_creates_of_large_problems_share_the_host_thread_team():
+    """create() at > 262 144 observations runs its structure passes on the library's persistent team of host threads; the team
+    serves one region at a time and a second caller falls back to threads of its own.  Three host threads creating + solving the
+    C2 problem (299 587 observations) at once -- with free intrinsics on one of them, an interleaved input on another -- must
+    each reproduce the sequential result bit for bit."""
+    import threading
+    p = synth.ba_config("C2")
+    cnt = np.bincount(p.obs_pt)
+    within = np.arange(len(p.obs_pt)) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    order = np.lexsort((p.obs_pt, within))
+    q = capi.FlatProblem(p.cam_ext.copy(), p.intrinsics.copy(), p.group_model, p.cam_group, p.points.copy(), p.obs_uv[order],
+                         p.obs_cam[order], p.obs_pt[order], p.cam_const, p.group_const, p.point_const)
+    o = ba.default_options(); o.max_num_iterations = 3
+    oi = ba.default_options(); oi.max_num_iterations = 3; oi.intrinsics_to_optimize = 0x11
+    jobs = [(p, o), (q, o), (p, oi)]
+
+    def run(job):
+        x = job[0].copy(); s, t = ba.solve(x, job[1])
+        return t.cost[: t.size].copy(), x.cam_ext.copy(), x.points.copy(), x.intrinsics.copy()
+    ref = [run(j) for j in jobs]
+    out = [None] * 3; errs = []
+
+    def worker(k):
+        try:
+            for _ in range(3):
+                out[k] = run(jobs[k])
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    for k in range(3):
+        for a, b in zip(out[k], ref[k]):
+            assert np.array_equal(a, b), k
+    assert np.array_equal(ref[0][0], ref[1][0])     # the interleaved input: the same trajectory
+
+
 def test_entry_points_are_reentrant_across_host_threads():
     """SURVEY 8(b) threading: the pipelines call BundleAdjustTrack / the estimators from thread-pool workers; ctypes
     releases the GIL, so concurrent calls really overlap.  Concurrent solves must equal the sequential ones."""
