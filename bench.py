@@ -508,8 +508,19 @@ def main():
         o1.function_tolerance = o1.gradient_tolerance = o1.parameter_tolerance = 0.0
         q1 = pristine.copy()
         t10 = time.perf_counter(); s1, _ = ba.solve(q1, o1, trace_capacity=1); t11 = time.perf_counter()
+        # ... the same call with the reference's default tolerances (it stops when Ceres would), and the handle creation alone
+        # (second of two: the first one of a process also fills the library's device / pinned-block caches)
+        o2 = ba.default_options(); o2.max_num_iterations = 25; o2.use_inner_iterations = 0
+        q2 = pristine.copy()
+        t20 = time.perf_counter(); s2, _ = ba.solve(q2, o2, trace_capacity=1); t21 = time.perf_counter()
+        tc = []
+        for _ in range(2):
+            pc = pristine.copy()
+            t30 = time.perf_counter(); h3 = ba.BaHandle(pc, o2); tc.append(time.perf_counter() - t30); h3.close()
         out["one_shot_call"] = {"workload": "theia_hip_ba_solve on the same problem from host arrays, 25 LM iterations",
                                 "total_ms": 1e3 * (t11 - t10), "iterations": int(s1.num_iterations),
+                                "default_tolerances_total_ms": 1e3 * (t21 - t20), "default_tolerances_iterations": int(s2.num_iterations),
+                                "handle_creation_ms": 1e3 * tc[-1],
                                 "note": "handle creation (host-side plan of 3.0 M observations) ~16 ms of it: see DESIGN.md 3.4"}
     if rank == 0 and world == 1 and not args.no_c2:
         # secondary block: BASELINE.json configs[1] (the round-1 headline), same measurement

@@ -63,11 +63,14 @@ static double now_s() {
 // Small pageable sources (the ~60 index / flag vectors of a create()) are copied into pinned blocks that live until the
 // end of the call, so that their uploads queue behind the big ones instead of each waiting for the stream: a create() at
 // 3 M observations spent ~5 ms in those waits -- the DMA of the 72 MB of sorted observations in front of them -- while the
-// host had the K3 plan and the gather lists still to build.  The scope synchronises the stream before it lets go.
+// host had the K3 plan and the gather lists still to build.  The arena belongs to the handle: create() returns without waiting
+// for the uploads (everything else on the handle queues behind them on its stream); the blocks go back to the host cache at the
+// end of the first run() -- which has waited for the stream -- or with the handle, whose destructor waits for it.
 struct StageArena {
   std::vector<std::unique_ptr<HBuf<char>>> blocks;
   size_t used = 0;
   hipStream_t stream = nullptr;
+  void release() { blocks.clear(); used = 0; }   // (after a synchronisation of the stream)
   void* put(const void* src, size_t bytes) {
     const size_t al = (bytes + 63) & ~(size_t)63;
     if (blocks.empty() || used + al > blocks.back()->cap) {
@@ -82,11 +85,10 @@ struct StageArena {
   }
 };
 inline StageArena*& stage_arena() { static thread_local StageArena* a = nullptr; return a; }
-struct StageScope {
-  StageArena arena;
+struct StageScope {   // the arena (the handle's: it lives until the uploads are known to be done) serves this thread's uploads
   StageArena* prev;
-  explicit StageScope(hipStream_t st) : prev(stage_arena()) { arena.stream = st; stage_arena() = &arena; }
-  ~StageScope() { stage_arena() = prev; (void)hipStreamSynchronize(arena.stream); }
+  explicit StageScope(StageArena* a) : prev(stage_arena()) { stage_arena() = a; }
+  ~StageScope() { stage_arena() = prev; }
   StageScope(const StageScope&) = delete;
   StageScope& operator=(const StageScope&) = delete;
 };
@@ -245,6 +247,8 @@ struct theia_ba_handle_s {
   std::vector<uint8_t> tile_adj_local, tile_cls, tile_touch;   // tile_touch: this rank's observations / priors write into the tile column
   DevBuf<uint8_t> d_tile_cls;
   int n_pack_tiles = 0;
+
+  StageArena stage;                     // pinned staging of create()'s small uploads (released after the first run)
 
   ~theia_ba_handle_s() {
     if (idh) thip::id_handle_destroy(idh);
@@ -1797,7 +1801,8 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
   h->nc = p->num_cameras; h->ng = p->num_groups; h->np = p->num_points; h->nobs = p->num_obs;
   h->pd = o->use_homogeneous_point_parametrization ? 3 : 4;
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  StageScope stage(h->stream);   // (after `guard`: it waits for the stream before the handle can go)
+  h->stage.stream = h->stream;
+  StageScope stage_scope(&h->stage);
   PoolStreamScope pool_scope(h->stream);   // blocks that go back to the caches inside this call are tagged with an event on it
   for (auto& row : h->ev) for (auto& e : row) HIP_TRY(hipEventCreate(&e));
   HIP_TRY(hipHostMalloc((void**)&h->h_scal, sizeof(double) * 40, hipHostMallocDefault));
@@ -2142,9 +2147,15 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
     // non-fixed ones [0, nobs_main) of the sorted arrays (depth-prior rows do not depend on the intrinsics)
     const int64_t nm = h->nobs_main;
     // stable counting sorts by camera / by group on host threads: per-part histograms, offsets in (key, part) order
-    std::vector<int> coff(h->nc + 1, 0), cidx((size_t)nm), goff(h->ng + 1, 0), gidx, toff;
+    // (the index lists go into blocks of the pinned host cache and are uploaded from there: no zero-filled 12 MB vectors,
+    // no staging copy; a block that goes back to the cache at the end of this scope is tagged with an event on the stream)
+    std::vector<int> coff(h->nc + 1, 0), goff(h->ng + 1, 0), toff;
+    HBuf<int> cidx, gidx;
+    if (!cidx.resize((size_t)std::max<int64_t>(1, nm), true) || !gidx.resize((size_t)std::max<int64_t>(1, nm), true))
+      return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %lld observations failed", (long long)nm);
+    gidx[0] = 0; gidx.n = 1;
     auto is_depth = [&](int64_t s) { return p->obs_kind && p->obs_kind[h->perm[s]]; };
-    auto bucket_sort = [&](int nkeys, std::vector<int>& off, std::vector<int>& idx, auto&& key_of) {   // key < 0: not listed
+    auto bucket_sort = [&](int nkeys, std::vector<int>& off, HBuf<int>& idx, auto&& key_of) {   // key < 0: not listed
       const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_thread_cap(), nm / 65536));
       const int64_t per = (nm + parts - 1) / parts;
       std::vector<int> hist((size_t)parts * nkeys, 0);
@@ -2158,7 +2169,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
         for (int t = 0; t < parts; ++t) { const int c = hist[(size_t)t * nkeys + k]; hist[(size_t)t * nkeys + k] = run; run += c; }
       }
       off[nkeys] = run;
-      idx.resize((size_t)run);
+      idx.n = (size_t)std::max(1, run);
       host_parts(parts, true, [&](int t) {
         int* hh = hist.data() + (size_t)t * nkeys;
         for (int64_t s = t * per; s < std::min<int64_t>(nm, (t + 1) * per); ++s) { const int k = key_of(s); if (k >= 0) idx[hh[k]++] = (int)s; }
@@ -2170,8 +2181,8 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
     for (int r = 0; r < h->np; ++r) if (cnt_main[r + 1] > cnt_main[r]) toff.push_back((int)cnt_main[r]);
     toff.push_back((int)nm);
     h->in_ntracks = (int)toff.size() - 1;
-    if (gidx.empty()) gidx.push_back(0);
-    UP(in_cam_off, coff); UP(in_cam_idx, cidx); UP(in_grp_off, goff); UP(in_grp_idx, gidx); UP(in_trk_off, toff);
+    UP(in_cam_off, coff); UP(in_grp_off, goff); UP(in_trk_off, toff);
+    if ((rc = h->in_cam_idx.upload(cidx.data(), cidx.n, st, cidx.pinned())) || (rc = h->in_grp_idx.upload(gidx.data(), gidx.n, st, gidx.pinned()))) return rc;
     AL(in_cam, (size_t)6 * std::max(1, h->nc)); AL(in_pts, (size_t)4 * std::max(1, h->np));
     AL(in_intr, (size_t)THEIA_MAX_INTRINSICS * std::max(1, h->ng));
     AL(in_scal, 8); AL(in_part, 2 * (size_t)kInnerCostBlocks); AL(in_gate, 4);
@@ -2752,6 +2763,7 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   S->success = st.term != THEIA_TERM_FAILURE;
   S->initial_cost = st.initial_cost;
   S->final_cost = st.fail_at_first ? st.initial_cost : st.minimum_cost + h->fixed_cost;
+  h->stage.release();   // (the stream has been waited for: create()'s staged uploads are done)
   S->solve_time_in_seconds = now_s() - t_start;
   return 0;
 }

@@ -9,5 +9,6 @@ if len(sys.argv) > 1:
     o.intrinsics_to_optimize = int(sys.argv[1], 0)
 h = ba.BaHandle(p.copy(), o); h.close()
 for _ in range(3):
-    t0 = time.perf_counter(); h = ba.BaHandle(p.copy(), o); dt = time.perf_counter() - t0; h.close()
+    pc = p.copy()
+    t0 = time.perf_counter(); h = ba.BaHandle(pc, o); dt = time.perf_counter() - t0; h.close()
     print("C4 handle creation %.1f ms (use_inner_iterations = %d)" % (1e3 * dt, o.use_inner_iterations), flush=True)
