@@ -20,6 +20,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <new>
 #include <string>
 #include <atomic>
 #include <condition_variable>
@@ -310,9 +311,8 @@ class HostTeam {
   bool run(int nparts, unsigned cap, const std::function<void(int)>& fn) {
     std::unique_lock<std::mutex> use(use_, std::try_to_lock);
     if (!use.owns_lock()) return false;
-    if (pid_ != getpid()) {              // first use, or the child of a fork (threads do not survive one)
-      for (auto& t : workers_) t.detach();
-      workers_.clear();
+    if (pid_ != getpid()) {              // first use, or the child of a fork: the parent's threads do not exist here, and
+      if (!workers_.empty()) new (&workers_) std::vector<std::thread>();   // their handles can be neither joined nor detached
       pid_ = getpid();
     }
     const int helpers = (int)cap - 1;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstddef>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -32,7 +33,16 @@ inline hipEvent_t pool_mark() {
   if (hipEventRecord(e, s) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(e); (void)hipStreamSynchronize(s); return nullptr; }
   return e;
 }
-inline void pool_wait(hipEvent_t e) { if (e) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); } }
+inline void pool_wait(hipEvent_t e) {
+  if (!e) return;
+  const hipError_t a = hipEventSynchronize(e), b = hipEventDestroy(e);
+  if (a != hipSuccess || b != hipSuccess) {
+    (void)hipGetLastError();   // (not this caller's failure: the block is handed out after a device-wide wait instead)
+    static const bool report = getenv("THEIA_HIP_DEBUG_STICKY") != nullptr;
+    if (report) std::fprintf(stderr, "theia_hip: pool event failed: %s / %s\n", hipGetErrorString(a), hipGetErrorString(b));
+    if (a != hipSuccess) (void)hipDeviceSynchronize();
+  }
+}
 
 // Device blocks of a batch call come from a small process-wide cache: a verification pipeline calls the batch entry
 // points back to back with the same shapes, and hipMalloc / hipFree of the GB-sized model workspace cost more than the
