@@ -14,29 +14,62 @@
     manifold's definition: x (+) d = |x| H(x)^T [sin|d| d / |d|; cos|d|]), the robust losses HUBER / CAUCHY with Ceres' corrector
     for rho'' <= 0 (residual and Jacobian scaled by sqrt(rho')), and shared intrinsics blocks with a subset of free parameters
     (SubsetManifold) and the reference's lower bound on the focal length (bundle_adjuster.cc:406-409) by projection.
-Pinhole cameras."""
+Pinhole and double-sphere cameras."""
 import numpy as np
 import torch
 from torch.func import jacrev, vmap
 
 
-def _residual(cam, pt, intr, uv):
+def _residual(cam, pt, intr, uv, ds):
+    """ds > 0.5: the double-sphere model (double_sphere_camera_model.h:161-249; Usenko et al. 2018, eq. 40-45, written from the
+    paper's formula: pi(x) = (x, y) / (alpha d2 + (1 - alpha)(xi d1 + z))), else pinhole with two radial terms."""
     C, w = cam[:3], cam[3:6]
     p = pt[:3] - pt[3] * C
     th = torch.sqrt((w * w).sum())
     k = w / th
     q = p * torch.cos(th) + torch.linalg.cross(k, p) * torch.sin(th) + k * (k @ p) * (1.0 - torch.cos(th))
+    # pinhole
     x, y = q[0] / q[2], q[1] / q[2]
     r2 = x * x + y * y
     d = 1.0 + r2 * (intr[5] + intr[6] * r2)
-    xd, yd = x * d, y * d
+    xp, yp = x * d, y * d
+    # double sphere
+    xi, alpha = intr[5], intr[6]
+    d1 = torch.sqrt((q * q).sum())
+    kk = xi * d1 + q[2]
+    d2 = torch.sqrt(q[0] * q[0] + q[1] * q[1] + kk * kk)
+    nrm = alpha * d2 + (1.0 - alpha) * kk
+    xd = torch.where(ds > 0.5, q[0] / nrm, xp)
+    yd = torch.where(ds > 0.5, q[1] / nrm, yp)
     u = intr[0] * xd + intr[2] * yd + intr[3]
     v = intr[0] * intr[1] * yd + intr[4]
     return torch.stack([u - uv[0], v - uv[1]])
 
 
+def _ds_valid(cam, pt, intr):
+    """the projection's domain (DoubleSphereCameraModel::DistortPoint returns false outside it: the evaluation fails)"""
+    C, w = cam[:3], cam[3:6]
+    p = pt[:3] - pt[3] * C
+    th = torch.sqrt((w * w).sum())
+    k = w / th
+    q = p * torch.cos(th) + torch.linalg.cross(k, p) * torch.sin(th) + k * (k @ p) * (1.0 - torch.cos(th))
+    xi, alpha = intr[5], intr[6]
+    w1 = torch.where(alpha > 0.5, (1.0 - alpha) / alpha, alpha / (1.0 - alpha))
+    w2 = (w1 + xi) / torch.sqrt(2.0 * w1 * xi + xi * xi + 1.0)
+    return q[2] > -w2 * torch.sqrt((q * q).sum())
+
+
 _jac = vmap(jacrev(_residual, argnums=(0, 1, 2)))
+_val = vmap(_ds_valid)
 _res = vmap(_residual)
+CAM_DOUBLE_SPHERE = 5
+
+
+def project_to_bounds(model, v):
+    """the reference's parameter bounds (bundle_adjuster.cc:406-427): focal >= 1; double sphere xi in [-1, 1], alpha in [0, 1]"""
+    v[0] = max(v[0], 1.0)
+    if model == CAM_DOUBLE_SPHERE:
+        v[5] = min(max(v[5], -1.0), 1.0); v[6] = min(max(v[6], 0.0), 1.0)
 
 
 def householder(x):
@@ -86,8 +119,11 @@ class Problem:
         self.pts = np.array(flat.points, dtype=np.float64)
         self.intr = np.array(flat.intrinsics, dtype=np.float64)
         self.grp = np.asarray(flat.cam_group)
+        self.model = np.asarray(flat.group_model)
+        assert np.all((self.model == 0) | (self.model == CAM_DOUBLE_SPHERE))
         self.oc = np.asarray(flat.obs_cam); self.op = np.asarray(flat.obs_pt)
         self.uv = torch.tensor(np.asarray(flat.obs_uv), dtype=torch.float64)
+        self.ds = torch.tensor((self.model[self.grp[self.oc]] == CAM_DOUBLE_SPHERE).astype(np.float64))
         cc = np.asarray(flat.cam_const) if flat.cam_const is not None else np.zeros(len(self.grp), np.uint8)
         assert np.all((cc == 0) | (cc == 3)), "whole cameras constant or free"
         self.manifold, self.loss_kind, self.loss_width = manifold, loss_kind, loss_width
@@ -101,13 +137,17 @@ class Problem:
         self.off_pts = off + 6 * len(self.var_cam)
         self.n = self.off_pts + self.pd * self.pts.shape[0]
         if self.free:
-            self.intr[:, 0] = np.maximum(self.intr[:, 0], 1.0)
+            for g in range(self.intr.shape[0]):
+                project_to_bounds(self.model[g], self.intr[g])
 
     def evaluate(self, cam, pts, intr, jac):
         """cost, corrected residuals, corrected tangent-space Jacobian (or None)"""
         tc, tp = torch.tensor(cam[self.oc]), torch.tensor(pts[self.op])
         ti = torch.tensor(intr[self.grp[self.oc]])
-        r = _res(tc, tp, ti, self.uv).numpy()
+        r = _res(tc, tp, ti, self.uv, self.ds).numpy()
+        bad = (~_val(tc, tp, ti).numpy()) & (self.ds.numpy() > 0.5)
+        if bad.any():
+            r = r.copy(); r[bad] = np.nan                          # a failed evaluation: the caller sees a non-finite cost
         s = (r * r).sum(1)
         rho, rho1 = loss(self.loss_kind, self.loss_width, s)
         cost = 0.5 * float(rho.sum())
@@ -115,7 +155,7 @@ class Problem:
         rc = (r * sr[:, None]).reshape(-1)
         if not jac:
             return cost, rc, None
-        jc, jp, ji = (t.numpy() for t in _jac(tc, tp, ti, self.uv))
+        jc, jp, ji = (t.numpy() for t in _jac(tc, tp, ti, self.uv, self.ds))
         J = np.zeros((len(rc), self.n))
         PJ = {}
         for i in range(len(self.oc)):
@@ -137,7 +177,7 @@ class Problem:
         cam, pts, intr = cam.copy(), pts.copy(), intr.copy()
         for g, col in self.col_intr.items():
             intr[g, self.free] += delta[col:col + len(self.free)]
-            intr[g, 0] = max(intr[g, 0], 1.0)                       # ParameterBlock::Plus projects onto the bounds
+            project_to_bounds(self.model[g], intr[g])               # ParameterBlock::Plus projects onto the bounds
         for c, col in self.col_cam.items():
             cam[c] += delta[col:col + 6]
         dp = delta[self.off_pts:].reshape(-1, self.pd)
@@ -201,7 +241,7 @@ def solve(flat, max_num_iterations=50, function_tolerance=1e-6, gradient_toleran
         ccam, cpts, cintr = P.plus(cam, pts, intr, -y * scale)
         cand, rc, _ = P.evaluate(ccam, cpts, cintr, False)
         if not np.all(np.isfinite(rc)):
-            cand = np.inf
+            cand = np.finfo(np.float64).max                     # Ceres: a candidate that fails to evaluate costs DBL_MAX
         step_norm = P.norms(cam, pts, intr, ccam, cpts, cintr)
         if step_norm <= parameter_tolerance * (x_norm + parameter_tolerance):
             trace.append((cand, gmax, step_norm, radius, 0)); break
