@@ -360,11 +360,23 @@ void host_chunks(int64_t n, F&& fn) {
 }
 
 
+// A plain uninitialised array for the per-observation / per-track temporaries of create() that are written in full by the
+// pass that fills them: value-initialising 15 MB of std::vectors was a millisecond of single-threaded memset per create().
+template <class T>
+struct RawArray {
+  std::unique_ptr<T[]> p;
+  explicit RawArray(size_t n) : p(new T[std::max<size_t>(1, n)]) {}
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  T* data() { return p.get(); }
+};
+
 // One stable counting pass on host threads: `to` = `from` ordered by digit (0 <= digit < nb), ties in input order.  Per-part
 // histograms, offsets taken in (bucket, part) order; the result does not depend on the number of parts.
 template <class T, class Digit>
 void counting_pass(const T* from, T* to, int64_t n, int nb, Digit&& digit) {
   int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_thread_cap(), n / 32768));
+  if (n < 393216) parts = 1;   // (two regions of the thread team cost more than a serial pass over a few hundred thousand entries)
   if ((int64_t)parts * nb > ((int64_t)1 << 24)) parts = 1;
   const int64_t per = (n + parts - 1) / parts;
   std::vector<int> head((size_t)parts * nb, 0);
@@ -1845,7 +1857,8 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
   };
   tick("stream + events");
   // --- problem structure (bundle_adjuster.cc:116-221,357-380,477-527) ---
-  std::vector<uint8_t> cam_used(h->nc, 0), pt_used(h->np, 0);
+  std::vector<uint8_t> cam_used(h->nc, 0);
+  RawArray<uint8_t> pt_used((size_t)h->np);
   std::vector<uint8_t> grp_used(h->ng, 0);
   std::vector<int> toff((size_t)h->np + 1, 0);   // the track CSR (below)
   std::atomic<int> unsorted{0};
@@ -1914,9 +1927,9 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
   // window of cameras (LDS accumulation in k_linearize).  Observations are
   // sorted by that track order; residual blocks whose blocks are all constant
   // are evaluated once ("fixed cost", ceres reduced program).
-  std::vector<uint8_t> fixed(h->nobs, 0);
-  std::vector<int> pkey(h->np, std::numeric_limits<int>::max());
-  std::vector<int> nvar(h->np, 0);   // variable cameras of a track
+  RawArray<uint8_t> fixed((size_t)h->nobs);   // (these four are written by the per-track pass below)
+  RawArray<int> pkey((size_t)h->np);
+  RawArray<int> nvar((size_t)h->np);   // variable cameras of a track
   // The input's observations grouped by track (CSR): toff[q] .. toff[q + 1] are track q's entries of tobs, in input order.
   // Input that already comes track by track (obs_pt non-decreasing: what a flattened reconstruction looks like) needs no
   // index array; anything else is counted, scattered with atomic cursors and put back into input order per track.
@@ -1937,28 +1950,32 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
       tobs = tb;
     }
   }
-  std::vector<int> nfix(h->np, 0);   // residual blocks of a track whose blocks are all constant
+  RawArray<int> nfix((size_t)h->np);   // residual blocks of a track whose blocks are all constant
   host_chunks(h->np, [&](int64_t q0, int64_t q1) {   // per-track sums: tracks are independent
     for (int64_t q = q0; q < q1; ++q) {
       pt_used[q] = toff[q + 1] > toff[q];
       const bool qconst = p->point_const && p->point_const[q];
+      int nv = 0, pk = std::numeric_limits<int>::max(), nf = 0;
       for (int k = toff[q]; k < toff[q + 1]; ++k) {
         const int i = tobs ? tobs[k] : k;
         const int c = p->obs_cam[i];
         const int rc = h->cam_part[c];
-        if (rc >= 0) { nvar[q]++; if (rc < pkey[q]) pkey[q] = rc; }
+        if (rc >= 0) { nv++; if (rc < pk) pk = rc; }
         // a residual block whose blocks are all constant (an observed track is constant iff the caller marked it)
         fixed[i] = (qconst && h->cam_red[c] < 0 && h->grp_red[p->cam_group[c]] < 0) ? 1 : 0;
-        nfix[q] += fixed[i];
+        nf += fixed[i];
       }
+      nvar[q] = nv; pkey[q] = pk; nfix[q] = nf;
       h->pt_const[q] = ((p->point_const && p->point_const[q]) || !pt_used[q]) ? 1 : 0;
     }
   });
   std::vector<int> porder(h->np);
   // Inside one first-camera key, short tracks come first (classes by number of variable cameras): the fused Schur
   // kernel packs several short tracks into one wave step when a run of tracks touches few target blocks.
-  std::vector<int> skey_pt(h->np);
+  RawArray<int> skey_pt((size_t)h->np);
+  std::atomic<int> maxkey_all{-1};
   host_chunks(h->np, [&](int64_t q0, int64_t q1) {
+    int mk = -1;
     for (int64_t q = q0; q < q1; ++q) {
       porder[q] = (int)q;
       // measured at 1k views / 500k tracks (K1 + K2 launch group): {<= 7 | >= 8} 0.575 ms, {<= 6 | >= 7} 0.599, {<= 5 | >= 6} 0.670,
@@ -1971,7 +1988,10 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
       if (h->fused_bw && !getenv("THEIA_HIP_FUSED_CLASSES")) cls = nvar[q] <= 3 ? 0 : (nvar[q] <= 6 ? 1 : (nvar[q] <= 7 ? 2 : 3));
       static const bool noclass = getenv("THEIA_HIP_FUSED_NOCLASS") != nullptr;
       skey_pt[q] = pkey[q] == std::numeric_limits<int>::max() ? pkey[q] : (((h->ni == 0 || h->fused_bw) && !noclass) ? pkey[q] * 4 + cls : pkey[q]);
+      if (skey_pt[q] != std::numeric_limits<int>::max()) mk = std::max(mk, skey_pt[q]);
     }
+    int cur = maxkey_all.load();
+    while (mk > cur && !maxkey_all.compare_exchange_weak(cur, mk)) {}
   });
   tick("  structure: masks, keys");
   // Stable counting sort of the tracks by key (keys are < 4 * (#variable cameras) + 4, or INT_MAX = no variable camera: last
@@ -1980,11 +2000,17 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
   std::vector<int64_t> cnt_main(h->np + 1, 0), cnt_fix(h->np + 1, 0);   // (offsets indexed by track rank, after the running sums)
   std::vector<int> skey(h->np);                                         // run boundaries of the fused plan follow the first-camera key
   {
-    int maxkey = -1;
-    for (int q = 0; q < h->np; ++q) if (skey_pt[q] != std::numeric_limits<int>::max()) maxkey = std::max(maxkey, skey_pt[q]);
-    auto place = [&](int64_t r, int q) {
-      porder[r] = q; skey[r] = pkey[q];
-      cnt_fix[r + 1] = nfix[q]; cnt_main[r + 1] = (toff[q + 1] - toff[q]) - nfix[q];
+    const int maxkey = maxkey_all.load();
+    struct Ranked { int q, key, nfix, len; };   // one 16-byte record per rank: the scatter is ONE random write per track
+    RawArray<Ranked> rk((size_t)h->np);
+    auto place = [&](int64_t r, int q) { rk[(size_t)r] = Ranked{q, pkey[q], nfix[q], toff[q + 1] - toff[q]}; };
+    auto unpack = [&]() {   // ... and the arrays the later passes read come out of a sequential pass
+      host_chunks(h->np, [&](int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r) {
+          const Ranked& e = rk[(size_t)r];
+          porder[r] = e.q; skey[r] = e.key; cnt_fix[r + 1] = e.nfix; cnt_main[r + 1] = e.len - e.nfix;
+        }
+      });
     };
     if (maxkey >= 0 && (int64_t)maxkey < 8 * (int64_t)h->np + 1024) {
       const int nb = maxkey + 2;
@@ -2008,6 +2034,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
       std::stable_sort(porder.begin(), porder.end(), [&](int x, int y) { return skey_pt[x] < skey_pt[y]; });
       for (int r = 0; r < h->np; ++r) place(r, porder[r]);
     }
+    unpack();
   }
   tick("  structure: sort tracks");
   for (int r = 0; r < h->np; ++r) { cnt_fix[r + 1] += cnt_fix[r]; cnt_main[r + 1] += cnt_main[r]; }   // ... as running sums
