@@ -72,7 +72,8 @@ struct StageArena {
   size_t used = 0;
   hipStream_t stream = nullptr;
   void release() { blocks.clear(); used = 0; }   // (after a synchronisation of the stream)
-  void* reserve(size_t bytes) {   // room for `bytes` in a pinned block (the caller fills it)
+  void* reserve(size_t bytes) {   // room for `bytes` in a pinned block (the caller fills it); nullptr: the caller uploads from its source and waits
+    if (getenv("THEIA_HIP_NO_PINNED")) return nullptr;   // (test switch: a host that refuses to pin memory)
     const size_t al = (bytes + 63) & ~(size_t)63;
     if (blocks.empty() || used + al > blocks.back()->cap) {
       std::unique_ptr<HBuf<char>> b(new HBuf<char>);
@@ -747,14 +748,17 @@ int upload_parameters(theia_ba_handle_s* h, const theia_ba_problem* p) {
   // uploaded from there, nothing waits.  Otherwise (reset_parameters): pageable sources, the stream is waited for.
   StageArena* a = stage_arena();
   const bool staged = a && a->stream == h->stream;
+  bool must_wait = false;
   auto up = [&](double* dst0, double* dst1, const double* src, size_t count) -> int {
     if (!count) return 0;
     const double* from = src;
-    if (staged) {
-      double* st = static_cast<double*>(a->reserve(count * sizeof(double)));
-      if (!st) return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "pinned staging of %zu parameters failed", count);
+    double* st = staged ? static_cast<double*>(a->reserve(count * sizeof(double))) : nullptr;
+    if (st) {
       host_chunks((int64_t)count, [&](int64_t i0, int64_t i1) { std::memcpy(st + i0, src + i0, sizeof(double) * (size_t)(i1 - i0)); });
       from = st;
+    } else {
+      if (staged) (void)hipGetLastError();   // the host does not pin that much: the caller's array is the source, and is waited for
+      must_wait = true;
     }
     HIP_TRY(hipMemcpyAsync(dst0, from, sizeof(double) * count, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(dst1, dst0, sizeof(double) * count, hipMemcpyDeviceToDevice, h->stream));
@@ -767,9 +771,9 @@ int upload_parameters(theia_ba_handle_s* h, const theia_ba_problem* p) {
     std::vector<double> hk(p->intrinsics, p->intrinsics + (size_t)THEIA_MAX_INTRINSICS * h->ng);
     for (int g = 0; g < h->ng; ++g) if (h->grp_red[g] >= 0) project_intrinsics_to_bounds(p->group_model[g], &hk[(size_t)g * THEIA_MAX_INTRINSICS]);
     if ((rc = up(h->intr[0].p, h->intr[1].p, hk.data(), hk.size()))) return rc;
-    if (!staged) HIP_TRY(hipStreamSynchronize(h->stream));   // (hk is a local)
+    if (must_wait) HIP_TRY(hipStreamSynchronize(h->stream));   // (hk is a local)
   }
-  if (!staged) HIP_TRY(hipStreamSynchronize(h->stream));
+  if (must_wait) HIP_TRY(hipStreamSynchronize(h->stream));
   h->cur = 0;
   h->P.intr = h->intr[0].p; h->P.intr_cand = h->intr[1].p;
   h->have_scale = false;
