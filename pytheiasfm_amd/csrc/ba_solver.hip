@@ -352,7 +352,10 @@ void host_parts(int nparts, bool threaded, F&& fn) {
 template <class F>
 void host_chunks(int64_t n, F&& fn) {
   const unsigned cap = host_thread_cap();
-  if (n < 262144 || cap <= 1) { fn((int64_t)0, n); return; }
+  // (THEIA_HIP_HOST_CHUNK_MIN: test switch -- small problems through the threaded passes)
+  const char* cm = getenv("THEIA_HIP_HOST_CHUNK_MIN");
+  const int64_t min_n = cm ? std::max(1, atoi(cm)) : 262144;
+  if (n < min_n || cap <= 1) { fn((int64_t)0, n); return; }
   const int64_t per = (n + cap - 1) / cap;
   host_parts((int)cap, true, [&](int t) {
     const int64_t a = std::min<int64_t>(n, (int64_t)t * per), b = std::min<int64_t>(n, a + per);
@@ -360,6 +363,13 @@ void host_chunks(int64_t n, F&& fn) {
   });
 }
 
+
+// number of parts of a threaded pass over n items, `grain` items per part at least (the test switch lowers the grain)
+int host_part_count(int64_t n, int64_t grain) {
+  const char* cm = getenv("THEIA_HIP_HOST_CHUNK_MIN");
+  if (cm) grain = std::max<int64_t>(1, std::min<int64_t>(grain, atoi(cm)));
+  return (int)std::max<int64_t>(1, std::min<int64_t>(host_thread_cap(), n / grain));
+}
 
 // A plain uninitialised array for the per-observation / per-track temporaries of create() that are written in full by the
 // pass that fills them: value-initialising 15 MB of std::vectors was a millisecond of single-threaded memset per create().
@@ -376,8 +386,8 @@ struct RawArray {
 // histograms, offsets taken in (bucket, part) order; the result does not depend on the number of parts.
 template <class T, class Digit>
 void counting_pass(const T* from, T* to, int64_t n, int nb, Digit&& digit) {
-  int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_thread_cap(), n / 32768));
-  if (n < 393216) parts = 1;   // (two regions of the thread team cost more than a serial pass over a few hundred thousand entries)
+  int parts = host_part_count(n, 32768);
+  if (n < 393216 && !getenv("THEIA_HIP_HOST_CHUNK_MIN")) parts = 1;   // (two regions of the thread team cost more than a serial pass over a few hundred thousand entries)
   if ((int64_t)parts * nb > ((int64_t)1 << 24)) parts = 1;
   const int64_t per = (n + parts - 1) / parts;
   std::vector<int> head((size_t)parts * nb, 0);
@@ -2018,7 +2028,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
     };
     if (maxkey >= 0 && (int64_t)maxkey < 8 * (int64_t)h->np + 1024) {
       const int nb = maxkey + 2;
-      int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_thread_cap(), h->np / 32768));
+      int parts = host_part_count(h->np, 32768);
       if ((int64_t)parts * nb > ((int64_t)1 << 24)) parts = 1;
       const int64_t per = ((int64_t)h->np + parts - 1) / parts;
       std::vector<int> head((size_t)parts * nb, 0);
@@ -2154,7 +2164,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
     // segment count is fixed: the plan -- and with it the summation order of S -- does not depend on the machine)
     static const int kSegs = getenv("THEIA_HIP_PLAN_SEGS") ? std::max(1, atoi(getenv("THEIA_HIP_PLAN_SEGS"))) : 32;   // (the switch: measurement only)
     std::vector<int> cut{0};
-    if (h->np >= 65536)
+    if (h->np >= (getenv("THEIA_HIP_HOST_CHUNK_MIN") ? 64 : 65536))
       for (int k = 1; k < kSegs; ++k) {
         int q = (int)((int64_t)h->np * k / kSegs);
         while (q < h->np && q > 0 && skey[q] == skey[q - 1]) ++q;
@@ -2213,7 +2223,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
     gidx[0] = 0; gidx.n = 1;
     auto is_depth = [&](int64_t s) { return p->obs_kind && p->obs_kind[h->perm[s]]; };
     auto bucket_sort = [&](int nkeys, std::vector<int>& off, HBuf<int>& idx, auto&& key_of) {   // key < 0: not listed
-      const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(host_thread_cap(), nm / 65536));
+      const int parts = host_part_count(nm, 65536);
       const int64_t per = (nm + parts - 1) / parts;
       std::vector<int> hist((size_t)parts * nkeys, 0);
       host_parts(parts, true, [&](int t) {
