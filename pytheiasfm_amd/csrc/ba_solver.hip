@@ -364,6 +364,16 @@ void host_chunks(int64_t n, F&& fn) {
 }
 
 
+// std::vector without value-initialisation of trivially constructible elements (resize() leaves them uninitialised)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  template <class U, class... A>
+  void construct(U* ptr, A&&... args) {
+    if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(ptr)) U; else ::new (static_cast<void*>(ptr)) U(std::forward<A>(args)...);
+  }
+};
+
 // number of parts of a threaded pass over n items, `grain` items per part at least (the test switch lowers the grain)
 int host_part_count(int64_t n, int64_t grain) {
   const char* cm = getenv("THEIA_HIP_HOST_CHUNK_MIN");
@@ -1257,104 +1267,145 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
   // observations of such a track (slot_in_sum).  Tracks that see several variable groups keep their explicit pairs.
   // THEIA_HIP_INTR_PAIRS=1 keeps the lists of the first version (no sums).
   struct PairE { uint64_t key; int a, b; };
-  std::vector<PairE> cc, cg, gg;
   const bool track_sums = !getenv("THEIA_HIP_INTR_PAIRS");
   const int nslots = (int)order.size();
-  {   // room for the entries up front (an upper bound: untouched pages cost nothing, growing by doubling copies 100s of MB)
-    size_t sum_l2 = 0;
-    for (int64_t s0 = 0; s0 < nm;) {
-      int64_t s1 = s0 + 1;
-      while (s1 < nm && opt[s1] == opt[s0]) ++s1;
-      if (!h->pt_const[opt[s0]]) sum_l2 += (size_t)(s1 - s0) * (size_t)(s1 - s0);
-      s0 = s1;
-    }
-    cc.reserve(sum_l2 / 2 + (size_t)nm); cg.reserve(sum_l2); gg.reserve(sum_l2);
+  // The tracks are walked twice on host threads, in a fixed number of ranges of consecutive tracks: the first walk counts a
+  // range's entries and pseudo-records, the second writes them at the offsets the counts give -- the lists come out in track
+  // order whatever the number of threads (one thread pushing ~20 M entries into growing vectors took 145 ms at 1000 views).
+  std::vector<int64_t> tbeg;   // first sorted observation of every track with non-fixed observations, then nm
+  for (int64_t s0 = 0; s0 < nm;) {
+    int64_t s1 = s0 + 1;
+    while (s1 < nm && opt[s1] == opt[s0]) ++s1;
+    tbeg.push_back(s0);
+    s0 = s1;
   }
+  tbeg.push_back(nm);
+  const int64_t ntrk = (int64_t)tbeg.size() - 1;
+  constexpr int kTrackParts = 64;
+  struct PartCount { size_t cc = 0, cg = 0, gg = 0; int sums = 0; };
+  std::vector<PartCount> pc(kTrackParts + 1);
   std::vector<int> pt_sum(track_sums ? h->np : 0, -1);   // pseudo-record slot of a track, -1 = none
   std::vector<uint8_t> slot_sum(track_sums ? std::max(1, nslots) : 0, 0);
   std::vector<uint8_t> pt_cnt(track_sums ? h->np : 0, 0);   // number of summed groups of a track
   std::vector<int> sum_group;                               // group of a pseudo-record
-  int nsums = 0;
-  for (int64_t s0 = 0; s0 < nm;) {
-    int64_t s1 = s0 + 1;
-    while (s1 < nm && opt[s1] == opt[s0]) ++s1;
-    if (!h->pt_const[opt[s0]]) {
-      // the track's variable groups in order of first appearance (long tracks carry -1 everywhere: none).  A track is
-      // summed per group when that shortens its lists: one group, or fewer groups (at most kMaxSumGroups) than
-      // observations of variable groups
-      constexpr int kMaxSumGroups = 4;
-      int tgs[kMaxSumGroups], ntg = 0, lg = 0;
-      bool many = false;
-      for (int64_t b2 = s0; b2 < s1; ++b2) {
-        if (grd[b2] < 0) continue;
-        ++lg;
-        bool seen = false;
-        for (int k = 0; k < ntg; ++k) seen |= tgs[k] == grd[b2];
-        if (seen) continue;
-        if (ntg == kMaxSumGroups) { many = true; break; }
-        tgs[ntg++] = grd[b2];
-      }
-      const bool sum_mode = track_sums && !many && ntg >= 1 && (ntg == 1 || ntg < lg);
-      for (int64_t a = s0; a < s1; ++a)
-        for (int64_t b = s0; b < s1; ++b) {
-          if (a == b) continue;
-          if (red[a] >= 0 && red[b] >= 0 && red[a] >= red[b]) cc.push_back({((uint64_t)red[a] << 32) | (uint32_t)red[b], slot[a], slot[b]});
-          if (sum_mode) continue;
-          if (red[a] >= 0 && grd[b] >= 0) cg.push_back({((uint64_t)red[a] << 32) | (uint32_t)grd[b], slot[a], slot[b]});
-          if (grd[a] >= 0 && grd[b] >= 0 && grd[a] >= grd[b]) gg.push_back({((uint64_t)grd[a] << 32) | (uint32_t)grd[b], slot[a], slot[b]});
-        }
-      if (sum_mode) {
-        const int ps = nslots + nsums;   // pseudo-records ps .. ps + ntg - 1, one per group
-        nsums += ntg;
-        pt_sum[opt[s0]] = ps; pt_cnt[opt[s0]] = (uint8_t)ntg;
-        for (int k = 0; k < ntg; ++k) sum_group.push_back(tgs[k]);
-        for (int64_t a = s0; a < s1; ++a) {
-          if (slot[a] >= 0) slot_sum[slot[a]] = 1;
-          if (red[a] >= 0)
-            for (int k = 0; k < ntg; ++k) cg.push_back({((uint64_t)red[a] << 32) | (uint32_t)tgs[k], slot[a], ps + k});
-        }
-        for (int k = 0; k < ntg; ++k)
-          for (int k2 = 0; k2 < ntg; ++k2)
-            if (tgs[k] >= tgs[k2]) gg.push_back({((uint64_t)tgs[k] << 32) | (uint32_t)tgs[k2], ps + k, ps + k2});
-      }
+  PairE* ccp = nullptr; PairE* cgp = nullptr; PairE* ggp = nullptr;
+  // one track: sink_cc / sink_cg / sink_gg receive its entries in the order of the one-thread loop; `ps` is its first pseudo-record
+  auto walk_track = [&](int64_t s0, int64_t s1, int ps, bool write, PartCount& n) {
+    if (h->pt_const[opt[s0]]) return;
+    // the track's variable groups in order of first appearance (long tracks carry -1 everywhere: none).  A track is
+    // summed per group when that shortens its lists: one group, or fewer groups (at most kMaxSumGroups) than
+    // observations of variable groups
+    constexpr int kMaxSumGroups = 4;
+    int tgs[kMaxSumGroups], ntg = 0, lg = 0;
+    bool many = false;
+    for (int64_t b2 = s0; b2 < s1; ++b2) {
+      if (grd[b2] < 0) continue;
+      ++lg;
+      bool seen = false;
+      for (int k = 0; k < ntg; ++k) seen |= tgs[k] == grd[b2];
+      if (seen) continue;
+      if (ntg == kMaxSumGroups) { many = true; break; }
+      tgs[ntg++] = grd[b2];
     }
-    s0 = s1;
+    const bool sum_mode = track_sums && !many && ntg >= 1 && (ntg == 1 || ntg < lg);
+    auto put = [&](PairE* base, size_t& at, uint64_t key, int x, int y) { if (write) base[at] = PairE{key, x, y}; ++at; };
+    for (int64_t x = s0; x < s1; ++x)
+      for (int64_t y = s0; y < s1; ++y) {
+        if (x == y) continue;
+        if (red[x] >= 0 && red[y] >= 0 && red[x] >= red[y]) put(ccp, n.cc, ((uint64_t)red[x] << 32) | (uint32_t)red[y], slot[x], slot[y]);
+        if (sum_mode) continue;
+        if (red[x] >= 0 && grd[y] >= 0) put(cgp, n.cg, ((uint64_t)red[x] << 32) | (uint32_t)grd[y], slot[x], slot[y]);
+        if (grd[x] >= 0 && grd[y] >= 0 && grd[x] >= grd[y]) put(ggp, n.gg, ((uint64_t)grd[x] << 32) | (uint32_t)grd[y], slot[x], slot[y]);
+      }
+    if (sum_mode) {
+      const int my = ps + n.sums;   // pseudo-records my .. my + ntg - 1, one per group
+      if (write) {
+        pt_sum[opt[s0]] = my; pt_cnt[opt[s0]] = (uint8_t)ntg;
+        for (int k = 0; k < ntg; ++k) sum_group[(size_t)(my - nslots + k)] = tgs[k];
+      }
+      for (int64_t x = s0; x < s1; ++x) {
+        if (write && slot[x] >= 0) slot_sum[slot[x]] = 1;
+        if (red[x] >= 0)
+          for (int k = 0; k < ntg; ++k) put(cgp, n.cg, ((uint64_t)red[x] << 32) | (uint32_t)tgs[k], slot[x], my + k);
+      }
+      for (int k = 0; k < ntg; ++k)
+        for (int k2 = 0; k2 < ntg; ++k2)
+          if (tgs[k] >= tgs[k2]) put(ggp, n.gg, ((uint64_t)tgs[k] << 32) | (uint32_t)tgs[k2], my + k, my + k2);
+      n.sums += ntg;
+    }
+  };
+  auto part_range = [&](int k, int64_t* t0, int64_t* t1) { *t0 = ntrk * k / kTrackParts; *t1 = ntrk * (k + 1) / kTrackParts; };
+  host_parts(kTrackParts, ntrk >= 4096, [&](int k) {
+    int64_t t0, t1; part_range(k, &t0, &t1);
+    PartCount n;
+    for (int64_t t = t0; t < t1; ++t) walk_track(tbeg[t], tbeg[t + 1], 0, false, n);
+    pc[k + 1] = n;
+  });
+  for (int k = 0; k < kTrackParts; ++k) { pc[k + 1].cc += pc[k].cc; pc[k + 1].cg += pc[k].cg; pc[k + 1].gg += pc[k].gg; pc[k + 1].sums += pc[k].sums; }
+  const int nsums = pc[kTrackParts].sums;
+  std::vector<PairE, NoInitAlloc<PairE>> cc, cg, gg;   // (resize() does not touch the 100s of MB)
+  {
+    cc.resize(pc[kTrackParts].cc); cg.resize(pc[kTrackParts].cg); gg.resize(pc[kTrackParts].gg);
+    sum_group.assign((size_t)nsums, 0);
+    ccp = cc.data(); cgp = cg.data(); ggp = gg.data();
   }
+  host_parts(kTrackParts, ntrk >= 4096, [&](int k) {
+    int64_t t0, t1; part_range(k, &t0, &t1);
+    PartCount n = pc[k];
+    for (int64_t t = t0; t < t1; ++t) walk_track(tbeg[t], tbeg[t + 1], nslots, true, n);
+  });
   itick("pair entries");
-  std::vector<int2> pairs;
-  pairs.reserve(cc.size() + cg.size() + gg.size());
+  // (the pair list is written into a block of the pinned host cache and uploaded from there)
+  HBuf<int2> pairs;
+  size_t npairs = 0;
+  if (!pairs.resize(std::max<size_t>(1, cc.size() + cg.size() + gg.size()), true))
+    return set_error(THEIA_HIP_ERR_OUT_OF_MEMORY, "host staging of %zu pairs failed", cc.size() + cg.size() + gg.size());
   // entries are generated in ascending (a, b): two stable counting passes (low, then high half of the key)
   // order them by (key, a, b) without a comparison sort
   const size_t nbucket = (size_t)std::max(h->ncv, h->ngv) + 2;
-  auto emit_pairs = [&](std::vector<PairE>& v, auto&& per_key) {
-    {   // each pass over a fixed 8-way partition of the entries with per-part histograms, on host threads (stable)
-      constexpr int kParts = 8;
-      const size_t nv = v.size();
+  auto emit_pairs = [&](auto& v, auto&& per_key) {
+    const size_t nv = v.size();
+    RawArray<PairE> tmp_raw(nv);   // (uninitialised: a value-initialised vector of the 10 - 25 M entries was a 100+ MB memset)
+    PairE* a = v.data();
+    PairE* b = tmp_raw.data();
+    {   // each pass over a fixed 32-way partition of the entries with per-part histograms, on host threads (stable)
+      constexpr int kParts = 32;
       const bool threaded = nv >= 262144;
-      std::vector<PairE> tmp(nv);
       std::vector<std::vector<size_t>> cnt(kParts, std::vector<size_t>(nbucket));
       for (int pass = 0; pass < 2; ++pass) {
         const int sh = pass == 0 ? 0 : 32;
         host_parts(kParts, threaded, [&](int k) {
           std::fill(cnt[k].begin(), cnt[k].end(), 0);
-          for (size_t i = nv * k / kParts; i < nv * (k + 1) / kParts; ++i) cnt[k][(size_t)((v[i].key >> sh) & 0xffffffffu)]++;
+          for (size_t i = nv * k / kParts; i < nv * (k + 1) / kParts; ++i) cnt[k][(size_t)((a[i].key >> sh) & 0xffffffffu)]++;
         });
         size_t at = 0;
-        for (size_t b = 0; b < nbucket; ++b)
-          for (int k = 0; k < kParts; ++k) { const size_t c = cnt[k][b]; cnt[k][b] = at; at += c; }
+        for (size_t bk = 0; bk < nbucket; ++bk)
+          for (int k = 0; k < kParts; ++k) { const size_t c = cnt[k][bk]; cnt[k][bk] = at; at += c; }
         host_parts(kParts, threaded, [&](int k) {
-          for (size_t i = nv * k / kParts; i < nv * (k + 1) / kParts; ++i) tmp[cnt[k][(size_t)((v[i].key >> sh) & 0xffffffffu)]++] = v[i];
+          for (size_t i = nv * k / kParts; i < nv * (k + 1) / kParts; ++i) b[cnt[k][(size_t)((a[i].key >> sh) & 0xffffffffu)]++] = a[i];
         });
-        v.swap(tmp);
+        std::swap(a, b);
       }
     }
-    for (size_t q = 0; q < v.size();) {
-      size_t e = q + 1;
-      while (e < v.size() && v[e].key == v[q].key) ++e;
-      const int64_t beg = (int64_t)pairs.size();
-      for (size_t k = q; k < e; ++k) pairs.push_back(make_int2(v[k].a, v[k].b));
-      per_key((int)(v[q].key >> 32), (int)(v[q].key & 0xffffffffu), beg, (int64_t)pairs.size());
-      q = e;
+    // (two passes: the sorted entries are back in v) -- the pair list is their (a, b) columns, copied on host threads; the key
+    // boundaries come from one scan
+    const int64_t base = (int64_t)npairs;
+    npairs += nv;
+    int2* out = pairs.data() + base;
+    constexpr int kScanParts = 32;
+    std::vector<std::vector<size_t>> starts(kScanParts);   // first entries of the keys, per range of the scan
+    host_parts(kScanParts, nv >= 262144, [&](int k) {
+      for (size_t i = nv * k / kScanParts; i < nv * (k + 1) / kScanParts; ++i) {
+        out[i] = make_int2(a[i].a, a[i].b);
+        if (i == 0 || a[i].key != a[i - 1].key) starts[k].push_back(i);
+      }
+    });
+    std::vector<size_t> first;
+    for (const auto& v2 : starts) first.insert(first.end(), v2.begin(), v2.end());
+    first.push_back(nv);
+    for (size_t k = 0; k + 1 < first.size(); ++k) {
+      const size_t q = first[k], e = first[k + 1];
+      per_key((int)(a[q].key >> 32), (int)(a[q].key & 0xffffffffu), base + (int64_t)q, base + (int64_t)e);
     }
   };
   // cameras seen twice by a track give (c, c) lists: the camera block is then fed by two kinds of items
@@ -1371,7 +1422,7 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
   });
   // (the CG / GG targets also receive the per-observation diagonal items below: always atomic)
   itick("sorted pair lists");
-  if (pairs.size() > (size_t)std::numeric_limits<int>::max() - 64)
+  if (npairs > (size_t)std::numeric_limits<int>::max() - 64)
     return set_error(THEIA_HIP_ERR_UNSUPPORTED, "too many observation pairs for 32-bit pair lists");
   // ---- per-observation (diagonal) items over contiguous slot ranges
   for (size_t q = 0; q < order.size();) {   // per camera (inside its group)
@@ -1401,7 +1452,8 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
     if (sobs.empty()) sobs.push_back(0);
     UP(slot_obs, sobs);
   }
-  UP(cam_obs, slot); UP(blk_items, items); UP(blk_pairs, pairs);
+  UP(cam_obs, slot); UP(blk_items, items);
+  if ((rc = h->blk_pairs.upload(pairs.data(), std::max<size_t>(1, npairs), st, pairs.pinned()))) return rc;
   itick("items + uploads");
   h->n_trk_sums = nsums;
   h->sum_base = nslots;
