@@ -506,18 +506,22 @@ def main():
         # structure analysis + uploads + 25 LM iterations + download), for the record next to the steady-state rate
         o1 = ba.default_options(); o1.max_num_iterations = 25; o1.use_inner_iterations = 0
         o1.function_tolerance = o1.gradient_tolerance = o1.parameter_tolerance = 0.0
-        q1 = pristine.copy()
-        t10 = time.perf_counter(); s1, _ = ba.solve(q1, o1, trace_capacity=1); t11 = time.perf_counter()
+        def best_call(opts):   # best of three calls (one call is one sample of a 25 - 40 ms interval on a shared host)
+            best, sm = float("inf"), None
+            for _ in range(3):
+                qq = pristine.copy()
+                ta = time.perf_counter(); sm, _ = ba.solve(qq, opts, trace_capacity=1); best = min(best, time.perf_counter() - ta)
+            return best, sm
+        t1best, s1 = best_call(o1); t10, t11 = 0.0, t1best
         # ... the same call with the reference's default tolerances (it stops when Ceres would), and the handle creation alone
         # (second of two: the first one of a process also fills the library's device / pinned-block caches)
         o2 = ba.default_options(); o2.max_num_iterations = 25; o2.use_inner_iterations = 0
-        q2 = pristine.copy()
-        t20 = time.perf_counter(); s2, _ = ba.solve(q2, o2, trace_capacity=1); t21 = time.perf_counter()
+        t2best, s2 = best_call(o2); t20, t21 = 0.0, t2best
         tc = []
         for _ in range(2):
             pc = pristine.copy()
             t30 = time.perf_counter(); h3 = ba.BaHandle(pc, o2); tc.append(time.perf_counter() - t30); h3.close()
-        out["one_shot_call"] = {"workload": "theia_hip_ba_solve on the same problem from host arrays, 25 LM iterations",
+        out["one_shot_call"] = {"workload": "theia_hip_ba_solve on the same problem from host arrays, 25 LM iterations (best of three calls)",
                                 "total_ms": 1e3 * (t11 - t10), "iterations": int(s1.num_iterations),
                                 "default_tolerances_total_ms": 1e3 * (t21 - t20), "default_tolerances_iterations": int(s2.num_iterations),
                                 "handle_creation_ms": 1e3 * tc[-1],

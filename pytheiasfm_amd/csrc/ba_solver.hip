@@ -1363,9 +1363,11 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
   // entries are generated in ascending (a, b): two stable counting passes (low, then high half of the key)
   // order them by (key, a, b) without a comparison sort
   const size_t nbucket = (size_t)std::max(h->ncv, h->ngv) + 2;
+  // (one uninitialised scratch array for the three lists: a value-initialised vector of the 10 - 25 M entries was a 100+ MB memset,
+  // and a fresh one per list two more rounds of page faults)
+  RawArray<PairE> tmp_raw(std::max(cc.size(), std::max(cg.size(), gg.size())));
   auto emit_pairs = [&](auto& v, auto&& per_key) {
     const size_t nv = v.size();
-    RawArray<PairE> tmp_raw(nv);   // (uninitialised: a value-initialised vector of the 10 - 25 M entries was a 100+ MB memset)
     PairE* a = v.data();
     PairE* b = tmp_raw.data();
     {   // each pass over a fixed 32-way partition of the entries with per-part histograms, on host threads (stable)
