@@ -14,6 +14,7 @@
     manifold's definition: x (+) d = |x| H(x)^T [sin|d| d / |d|; cos|d|]), the robust losses HUBER / CAUCHY with Ceres' corrector
     for rho'' <= 0 (residual and Jacobian scaled by sqrt(rho')), and shared intrinsics blocks with a subset of free parameters
     (SubsetManifold) and the reference's lower bound on the focal length (bundle_adjuster.cc:406-409) by projection.
+  * optionally the position / gravity / orientation rows of AddViewPriors (no loss), written from their definitions.
 Pinhole and double-sphere cameras."""
 import numpy as np
 import torch
@@ -72,6 +73,28 @@ def project_to_bounds(model, v):
         v[5] = min(max(v[5], -1.0), 1.0); v[6] = min(max(v[6], 0.0), 1.0)
 
 
+def _rot(w):
+    th = torch.sqrt((w * w).sum())
+    k = w / th
+    K = torch.stack([torch.stack([torch.zeros_like(th), -k[2], k[1]]), torch.stack([k[2], torch.zeros_like(th), -k[0]]),
+                     torch.stack([-k[1], k[0], torch.zeros_like(th)])])
+    return torch.eye(3, dtype=w.dtype) + torch.sin(th) * K + (1.0 - torch.cos(th)) * (K @ K)
+
+
+def _prior(cam, kind, vec, S):
+    """AddViewPriors' rows (position_error.h:52-60, gravity_error.h:53-65, orientation_error.h:53-63), no loss:
+    position S (prior - C); gravity S (R(w) (0, 0, -1) - prior); orientation S log(R(w) R(prior)^T)."""
+    if kind == 1:
+        return S @ (vec - cam[:3])
+    if kind == 2:
+        return S @ (_rot(cam[3:6]) @ torch.tensor([0.0, 0.0, -1.0], dtype=cam.dtype) - vec)
+    E = _rot(cam[3:6]) @ _rot(vec).T
+    v = 0.5 * torch.stack([E[2, 1] - E[1, 2], E[0, 2] - E[2, 0], E[1, 0] - E[0, 1]])      # sin(theta) * axis
+    sn = torch.sqrt((v * v).sum())
+    theta = torch.atan2(sn, 0.5 * (E[0, 0] + E[1, 1] + E[2, 2] - 1.0))
+    return S @ (v * (theta / sn))
+
+
 def householder(x):
     """v, beta with (I - beta v v^T) x = |x| e_n (the last axis), v_n = 1: the reflection SphereManifold is built on."""
     n = len(x)
@@ -114,7 +137,7 @@ def loss(kind, a, s):
 
 
 class Problem:
-    def __init__(self, flat, manifold, loss_kind, loss_width, free_intr):
+    def __init__(self, flat, manifold, loss_kind, loss_width, free_intr, prior_mask=0):
         self.cam = np.array(flat.cam_ext, dtype=np.float64)
         self.pts = np.array(flat.points, dtype=np.float64)
         self.intr = np.array(flat.intrinsics, dtype=np.float64)
@@ -139,6 +162,15 @@ class Problem:
         if self.free:
             for g in range(self.intr.shape[0]):
                 project_to_bounds(self.model[g], self.intr[g])
+        # camera priors in use: the camera's bit AND the option's bit (bundle_adjuster.cc:159-172); variable cameras only here
+        self.prior_rows = []
+        if prior_mask and flat.cam_prior_mask is not None:
+            for c in range(len(self.grp)):
+                for bit, name in ((1, "position"), (2, "gravity"), (4, "orientation")):
+                    if (int(flat.cam_prior_mask[c]) & prior_mask & bit) and name in flat.priors:
+                        assert c in self.col_cam, "priors on variable cameras only"
+                        v, S = flat.priors[name]
+                        self.prior_rows.append((c, bit, torch.tensor(np.asarray(v[c], dtype=np.float64)), torch.tensor(np.asarray(S[c], dtype=np.float64))))
 
     def evaluate(self, cam, pts, intr, jac):
         """cost, corrected residuals, corrected tangent-space Jacobian (or None)"""
@@ -153,6 +185,11 @@ class Problem:
         cost = 0.5 * float(rho.sum())
         sr = np.sqrt(rho1)
         rc = (r * sr[:, None]).reshape(-1)
+        npr = 3 * len(self.prior_rows)
+        if npr:
+            rp = np.concatenate([_prior(torch.tensor(cam[c]), kind, v, S).numpy() for c, kind, v, S in self.prior_rows])
+            cost += 0.5 * float(rp @ rp)
+            rc = np.concatenate([rc, rp])
         if not jac:
             return cost, rc, None
         jc, jp, ji = (t.numpy() for t in _jac(tc, tp, ti, self.uv, self.ds))
@@ -171,6 +208,9 @@ class Problem:
                 J[rows, self.off_pts + 3 * p:self.off_pts + 3 * p + 3] = sr[i] * (jp[i] @ PJ[p])
             else:
                 J[rows, self.off_pts + 4 * p:self.off_pts + 4 * p + 4] = sr[i] * jp[i]
+        for k, (c, kind, v, S) in enumerate(self.prior_rows):
+            Jp = jacrev(lambda x: _prior(x, kind, v, S))(torch.tensor(cam[c])).numpy()
+            J[len(rc) - npr + 3 * k:len(rc) - npr + 3 * k + 3, self.col_cam[c]:self.col_cam[c] + 6] = Jp
         return cost, rc, J
 
     def plus(self, cam, pts, intr, delta):
@@ -200,10 +240,10 @@ class Problem:
 
 
 def solve(flat, max_num_iterations=50, function_tolerance=1e-6, gradient_tolerance=1e-10, parameter_tolerance=1e-8,
-          max_trust_region_radius=1e12, manifold=False, loss_kind="trivial", loss_width=1.0, free_intr=None):
+          max_trust_region_radius=1e12, manifold=False, loss_kind="trivial", loss_width=1.0, free_intr=None, prior_mask=0):
     """Returns the trace -- (cost, gradient max norm, step norm, radius, accepted) per entry, as the oracle and the library record
     it -- and the final (cameras, points, intrinsics)."""
-    P = Problem(flat, manifold, loss_kind, loss_width, free_intr)
+    P = Problem(flat, manifold, loss_kind, loss_width, free_intr, prior_mask)
     cam, pts, intr = P.cam, P.pts, P.intr
     x_cost, r, J = P.evaluate(cam, pts, intr, True)
     scale = 1.0 / (1.0 + np.sqrt((J * J).sum(0)))

@@ -424,9 +424,33 @@ LM_SCENARIOS = {
                                  dict(), dict(manifold=True), 1e-7),
     "double_sphere_intrinsics": (6, 60, 0xBA5E0100, dict(mixed_models=True), dict(intrinsics_to_optimize=0x11),
                                  dict(manifold=True, free_intr=[0, 5, 6]), 1e-6),
+    # AddViewPriors: position (GPS-like), gravity and orientation rows on most cameras, full 3 x 3 sqrt information, no loss
+    "priors": (8, 80, 0xBA5E0100, dict(_priors=True), dict(prior_mask=7), dict(manifold=True, prior_mask=7), 1e-7),
+    "priors_rejections": (6, 50, 0xBA5E0207, dict(_priors=True, sigma_pos=1.5, sigma_rot_deg=12.0, sigma_pt=1.5),
+                          dict(prior_mask=7), dict(manifold=True, prior_mask=7), 1e-7),
 }
 LM_OPTION_FIELDS = ("use_homogeneous_point_parametrization", "use_inner_iterations", "max_num_iterations", "loss_function_type",
-                    "robust_loss_width", "intrinsics_to_optimize")
+                    "robust_loss_width", "intrinsics_to_optimize", "prior_mask")
+
+
+def lm_scene_priors(p, truth, seed):
+    """position / gravity / orientation priors ~1 % off the TRUE cameras on all but every fifth camera"""
+    nc = p.cam_ext.shape[0]
+    st = synth.Stream(seed, 3)
+    i = np.arange(nc)
+    mask = np.where(i % 5 == 4, 0, 7).astype(np.uint8)
+    mask[1] = 1
+    pos = truth[:, :3] + 0.02 * np.stack([st.normal(3 * i), st.normal(3 * i + 1), st.normal(3 * i + 2)], 1)
+    R = synth.angle_axis_to_matrix(truth[:, 3:])
+    grav = R @ np.array([0, 0, -1.0]) + 0.005 * np.stack([st.normal(3 * i + 100), st.normal(3 * i + 101), st.normal(3 * i + 102)], 1)
+    ori = truth[:, 3:] + 0.003 * np.stack([st.normal(3 * i + 200), st.normal(3 * i + 201), st.normal(3 * i + 202)], 1)
+
+    def info(scale, off):
+        A = np.tile(np.eye(3) * scale, (nc, 1, 1))
+        A[:, 0, 1] = 0.1 * scale * st.normal(i + off); A[:, 2, 0] = -0.2 * scale * st.normal(i + off + 50)
+        return A
+    p.set_priors(mask, position=(pos, info(20.0, 300)), gravity=(grav, info(50.0, 400)), orientation=(ori, info(80.0, 500)))
+    return p
 
 
 def compare_with_independent_lm(name, solve):
@@ -434,7 +458,12 @@ def compare_with_independent_lm(name, solve):
     scenario; asserts the same accept / reject sequence, costs, radii, step norms and final parameters."""
     from tests import independent_lm as il
     nv, nt, seed, kw, opts, ilkw, ptol = LM_SCENARIOS[name]
-    p = synth.synth_ba_v1(nv, nt, seed=seed, num_groups=2, **kw)
+    kw = dict(kw)
+    if kw.pop("_priors", False):
+        p, cam_gt, _ = synth.synth_ba_v1(nv, nt, seed=seed, num_groups=2, return_truth=True, **kw)
+        p = lm_scene_priors(p, cam_gt, seed + 1)
+    else:
+        p = synth.synth_ba_v1(nv, nt, seed=seed, num_groups=2, **kw)
     o = ol.default_options()
     o.use_inner_iterations = 0; o.max_num_iterations = 40
     for k, v in opts.items():
