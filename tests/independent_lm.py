@@ -11,7 +11,7 @@
     (1e12, bundle_adjustment.h), gradient tolerance after
     successful steps only;
   * optionally: the homogeneous point on ceres::SphereManifold<4> (Householder form of Plus and its Jacobian, written from the
-    manifold's definition: x (+) d = |x| H(x)^T [sin|d| d / |d|; cos|d|]), the robust losses HUBER / CAUCHY with Ceres' corrector
+    manifold's definition: x (+) d = |x| H(x)^T [sin|d| d / |d|; cos|d|]), the robust losses HUBER / SOFTLONE / CAUCHY / ARCTAN / TUKEY and Theia's TRUNCATED with Ceres' corrector
     for rho'' <= 0 (residual and Jacobian scaled by sqrt(rho')), and shared intrinsics blocks with a subset of free parameters
     (SubsetManifold) and the reference's lower bound on the focal length (bundle_adjuster.cc:406-409) by projection.
   * optionally the position / gravity / orientation rows of AddViewPriors (no loss), written from their definitions.
@@ -133,6 +133,19 @@ def loss(kind, a, s):
     if kind == "cauchy":
         b = a * a
         return b * np.log1p(s / b), 1.0 / (1.0 + s / b)
+    if kind == "softl1":                                  # 2 b (sqrt(1 + s / b) - 1)
+        b = a * a
+        return 2.0 * b * (np.sqrt(1.0 + s / b) - 1.0), 1.0 / np.sqrt(1.0 + s / b)
+    if kind == "arctan":                                  # a atan(s / a)
+        return a * np.arctan2(s, a), 1.0 / (1.0 + (s / a) ** 2)
+    if kind == "tukey":                                   # a^2 / 3 (1 - (1 - s / a^2)^3) inside s <= a^2, constant outside
+        b = a * a
+        inside = s <= b
+        v = np.where(inside, 1.0 - s / b, 0.0)
+        return np.where(inside, b / 3.0 * (1.0 - v ** 3), b / 3.0), np.where(inside, v * v, 0.0)
+    if kind == "truncated":                               # theia TruncatedLoss (loss_functions.cc:40-44): min(s, a^2)
+        b = a * a
+        return np.minimum(s, b), np.where(s < b, 1.0, 0.0)
     return s, np.ones_like(s)
 
 

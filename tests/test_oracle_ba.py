@@ -412,6 +412,15 @@ LM_SCENARIOS = {
               dict(manifold=True, loss_kind="huber", loss_width=1.5), 1e-7),
     "cauchy": (6, 60, 0xBA5E0100, dict(pixel_noise=2.0), dict(loss_function_type=3, robust_loss_width=2.0),
                dict(manifold=True, loss_kind="cauchy", loss_width=2.0), 1e-4),
+    # the other losses: SoftLOne, Arctan (40 iterations into the radius cap like Cauchy), Theia's TruncatedLoss.  Tukey is left out
+    # and said so: its zero-weight observations leave near-singular point blocks, the two solvers (Schur vs the full normal
+    # equations) agree to 1e-8 over the first eight iterations and then drift apart
+    "softlone": (6, 60, 0xBA5E0100, dict(pixel_noise=2.0), dict(loss_function_type=2, robust_loss_width=1.5),
+                 dict(manifold=True, loss_kind="softl1", loss_width=1.5), 1e-7),
+    "arctan": (6, 60, 0xBA5E0100, dict(pixel_noise=2.0), dict(loss_function_type=4, robust_loss_width=3.0),
+               dict(manifold=True, loss_kind="arctan", loss_width=3.0), 1e-4),
+    "truncated": (6, 60, 0xBA5E0100, dict(pixel_noise=2.0), dict(loss_function_type=6, robust_loss_width=4.0),
+                  dict(manifold=True, loss_kind="truncated", loss_width=4.0), 1e-6),
     # shared intrinsics blocks with a SubsetManifold: focal + radial distortion, and all seven pinhole parameters
     "focal_radial": (6, 60, 0xBA5E0100, dict(), dict(intrinsics_to_optimize=0x11), dict(manifold=True, free_intr=[0, 5, 6]), 1e-7),
     "all_intrinsics": (6, 60, 0xBA5E0100, dict(), dict(intrinsics_to_optimize=0x3f),

@@ -373,7 +373,7 @@ def test_reference_lmed_scene_on_gpu():
 
 @pytest.mark.parametrize("name", ["plain", "rejections_a", "rejections_b", "manifold", "manifold_rejections", "huber", "cauchy",
                                   "focal_radial", "all_intrinsics", "double_sphere", "double_sphere_rejections",
-                                  "double_sphere_intrinsics", "priors", "priors_rejections"])
+                                  "double_sphere_intrinsics", "priors", "priors_rejections", "softlone", "arctan", "truncated"])
 def test_library_lm_trajectory_matches_an_independent_autograd_implementation(name):
     """The LIBRARY's LM trajectory (closed-form Jacobians, fused Schur assembly, tile Cholesky, device-side step control) against
     tests/independent_lm.py -- torch reverse-mode autodiff, the full normal equations by numpy Cholesky, Ceres' trust-region rules
