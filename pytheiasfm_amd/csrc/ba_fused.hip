@@ -31,6 +31,7 @@
 #include "ba_lane.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 namespace thip {
@@ -89,7 +90,7 @@ template <int PD> constexpr int rec_doubles() { return PD == 3 ? 22 : 26; }   //
 // alive across this phase; as a call they are saved once around it (callee-saved registers) instead of pushing the
 // register allocation of the pair-product loop into scratch.
 template <int PD, int TPS, unsigned MODELS>
-__device__ THIP_PHASE_L_ATTR void fused_phase_l(const DevProblem* __restrict__ Pp, const FusedRun* __restrict__ runp,
+__device__ THIP_PHASE_L_ATTR void fused_phase_l_v4(const DevProblem* __restrict__ Pp, const FusedRun* __restrict__ runp,
                                                         const double* __restrict__ pts, double inv_radius, int sc,
                                                         double* __restrict__ Vinv, double* __restrict__ tile_part,
                                                         double* __restrict__ s_rec,
@@ -117,7 +118,8 @@ __device__ THIP_PHASE_L_ATTR void fused_phase_l(const DevProblem* __restrict__ P
       segment_allsum_log<NT + PD>(sg, lane, tot);
       const int o = start + lane;
       const int tl = active ? P.obs_tl[o] : 0;
-      const unsigned lc = active ? P.obs_lc[o] : 0xffu;
+      unsigned lc = active ? P.obs_lc[o] : 0xffu;
+      if (lc & 0x80u) lc = 0xffu;   // (a staged constant camera of the new plan: no target here)
       const unsigned tmask = segment_or(sg, lane, (active && lc != 0xffu) ? (1u << lc) : 0u);
       double V[NT], Vi[NT], g[PD];
 #pragma unroll
@@ -200,7 +202,7 @@ __device__ THIP_PHASE_L_ATTR void fused_phase_l(const DevProblem* __restrict__ P
 
 // tile_part layout as k_lin_obs: [ntiles][4] = {cost, gmax_points, invalid, notpd}
 template <int PD, int TPS, unsigned MODELS>
-__global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevProblem P, const double* __restrict__ pts,
+__global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur_v4(DevProblem P, const double* __restrict__ pts,
                                                            const double* __restrict__ radius_p,
                                                            double* __restrict__ Vinv, double* __restrict__ tile_part) {
   constexpr int NT = PD * (PD + 1) / 2;
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
     // ------------------------------------------------------------------ phase L: lane = observation
     // the problem is read through its LDS copy: with the kernel-argument struct (SGPR bases, global instead of flat loads)
     // the timing is the same and 11 more VGPRs spill (WRITE_SIZE +50 MB per launch at 1000 views / 500k tracks)
-    fused_phase_l<PD, TPS, MODELS>(&s_P, &s_run, pts, inv_radius, sc, Vinv, tile_part, s_rec, s_tslot, s_tmask);
+    fused_phase_l_v4<PD, TPS, MODELS>(&s_P, &s_run, pts, inv_radius, sc, Vinv, tile_part, s_rec, s_tslot, s_tmask);
     __syncthreads();
     // ------------------------------------------------------------------ phase S: lane = target block
     if (!(P.fused_dbg & 1)) {
@@ -374,6 +376,546 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
   }   // runs of this workgroup
 }
 
+// Phase S of one sub-chunk: lane = target block (la, lb) of the track slice it serves; per-observation terms by the
+// lanes (local camera, row).  acc[] / dacc[] only ever see constant indices (they are registers of the caller).
+template <int PD, int RD>
+THIP_DEV void fused_phase_s(const double* __restrict__ s_rec, const uint8_t* __restrict__ s_tslot, const unsigned* __restrict__ s_tmask,
+                            int ntr, int tstride, int t0, bool slice_ok, unsigned tbits, int la, int lb, double diag_core,
+                            int dP, int dbase, unsigned dbit, int dlc, int da, double (&acc)[36], double (&dacc)[3]) {
+#pragma unroll 1
+  for (int base = 0; base < ntr; base += tstride) {   // wave-uniform trip count
+    {
+      const int t = base + t0;
+      const unsigned mask = (slice_ok && t < ntr) ? s_tmask[t] : 0u;
+      if ((mask & tbits) == tbits) {
+        const unsigned ca = s_tslot[t * kRowBytes + la], cb = s_tslot[t * kRowBytes + lb];
+        double Fa[12], Ea[2 * PD], Fb[12], Eb[2 * PD];
+        const double2* pa = reinterpret_cast<const double2*>(s_rec + ca * RD);
+        const double2* pb = reinterpret_cast<const double2*>(s_rec + cb * RD);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { const double2 u = pa[q]; Fa[2 * q] = u.x; Fa[2 * q + 1] = u.y; }
+#pragma unroll
+        for (int q = 0; q < PD; ++q) { const double2 u = pa[6 + q]; Ea[2 * q] = u.x; Ea[2 * q + 1] = u.y; }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { const double2 u = pb[q]; Fb[2 * q] = u.x; Fb[2 * q + 1] = u.y; }
+#pragma unroll
+        for (int q = 0; q < PD; ++q) { const double2 u = pb[6 + q]; Eb[2 * q] = u.x; Eb[2 * q + 1] = u.y; }
+        double M[2][2];   // Ehat_a Ehat_b^T
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            double sm = 0.0;
+#pragma unroll
+            for (int q = 0; q < PD; ++q) sm += Ea[i * PD + q] * Eb[j * PD + q];
+            M[i][j] = sm;
+          }
+        M[0][0] -= diag_core; M[1][1] -= diag_core;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const double t0v = Fa[a] * M[0][0] + Fa[6 + a] * M[1][0];   // (F_a^T M)[a][0..1]
+          const double t1v = Fa[a] * M[0][1] + Fa[6 + a] * M[1][1];
+#pragma unroll
+          for (int b2 = 0; b2 < 6; ++b2)   // two chained FMAs: `acc += x y + z w` compiles to mul + fma + add (no reassociation)
+            acc[a * 6 + b2] = __builtin_fma(t1v, Fb[6 + b2], __builtin_fma(t0v, Fb[b2], acc[a * 6 + b2]));
+        }
+      }
+    }
+    // per-observation terms: lane = (local camera, row), over the dP tracks this wave serves in the step
+#pragma unroll 1
+    for (int g2 = 0; g2 < dP; ++g2) {
+      const int t = base + dbase + g2;
+      const unsigned mask = (t < ntr) ? s_tmask[t] : 0u;
+      if (mask & dbit) {
+        const unsigned sd = s_tslot[t * kRowBytes + dlc];
+        const double2* px = reinterpret_cast<const double2*>(s_rec + sd * RD);
+        const double2 rr = px[6 + PD], rv = px[6 + PD + 1];   // r,  r - Ehat ghat
+        const double fa0 = s_rec[sd * RD + da], fa1 = s_rec[sd * RD + 6 + da];   // column da of F (no dynamic register indexing)
+        dacc[0] = __builtin_fma(fa1, rv.y, __builtin_fma(fa0, rv.x, dacc[0]));
+        dacc[1] = __builtin_fma(fa1, rr.y, __builtin_fma(fa0, rr.x, dacc[1]));
+        dacc[2] = __builtin_fma(fa1, fa1, __builtin_fma(fa0, fa0, dacc[2]));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Round 5: the same pass with (i) the per-camera blocks of a run staged in LDS once per run -- its W local cameras and
+// the constant cameras its tracks see (FusedRun::stage_off / nstage) -- instead of a 320-B gather from HBM per
+// observation, (ii) the observation stream of the NEXT sub-chunk (uv, point index, plan bytes; then the point, its
+// Jacobi scaling and constant flag) loaded while the current one is linearised / multiplied, so that phase L starts on
+// registers, (iii) the problem read through the kernel arguments (scalar loads), no LDS copy of it.
+// Development instrumentation (THEIA_HIP_FUSED_STAMPS=1 selects an instrumented instance of the kernel): s_memtime deltas
+// summed over all waves, per section of the kernel.
+__device__ unsigned long long g_fused_stamps[16];
+template <bool ON> struct Stamp {
+  unsigned long long t;
+  THIP_DEV void start() { if constexpr (ON) t = __builtin_amdgcn_s_memtime(); }
+  THIP_DEV void lap(unsigned long long (&acc)[12], int k) {
+    if constexpr (ON) { const unsigned long long n = __builtin_amdgcn_s_memtime(); acc[k] += n - t; t = n; }
+  }
+};
+constexpr int kCamLds = 42;   // doubles per staged camera block: 40 + 2, so that 16 consecutive blocks start on 16 distinct
+                              // 16-B slots of the 256-B bank row (a ds_read_b128 of one field by 16 cameras is conflict free)
+
+template <int PD>
+struct LanePre {      // one lane's observation of a sub-chunk, loaded ahead of its phase L
+  double2 uv, si;
+  double4 X;
+  double sp[PD];
+  int p;
+  unsigned lc, tl;
+  bool active, pconst, depth;
+};
+
+template <int PD, int TPS>
+THIP_DEV void pre_level1(const DevProblem& P, const FusedRun& run, int sc, int wv, int lane, int& tile_out, bool& tile_ok_out, LanePre<PD>& q) {
+  const int tile = run.tile0 + TPS * sc + wv;
+  const bool tile_ok = tile < run.tile0 + run.ntiles;
+  const int tile_s = tile_ok ? tile : run.tile0;          // (loads are unconditional: a clamped, always valid address)
+  const int cnt = tile_ok ? P.tile_count[tile_s] : 0;
+  const int start = P.tile_start[tile_s];
+  const int o = start + min(lane, max(cnt, 1) - 1);
+  q.uv = P.obs_uv[o];
+  q.p = P.obs_pt[o];
+  q.lc = P.obs_lc[o];
+  q.tl = P.obs_tl[o];
+  q.si = make_double2(1.0, 1.0);
+  if (P.obs_si) q.si = P.obs_si[o];
+  q.depth = P.obs_kind && P.obs_kind[o];
+  q.active = lane < cnt && !(P.fused_dbg & 2);
+  tile_out = tile; tile_ok_out = tile_ok;
+}
+template <int PD>
+THIP_DEV void pre_level2(const DevProblem& P, const double* __restrict__ pts, LanePre<PD>& q) {
+  q.X = reinterpret_cast<const double4*>(pts)[q.p];
+  q.pconst = P.pt_const[q.p] != 0;
+#pragma unroll
+  for (int k = 0; k < PD; ++k) q.sp[k] = P.scale_p[(size_t)PD * q.p + k];
+}
+
+// Phase L of one wave tile on prefetched registers: the linearisation of reprojection_error.h:54-110 (closed form, as
+// lane_linearize / observe_rot: the camera block comes from LDS), the track sums, V^-1, the record and the slot table.
+// LOSSK: 0 = trivial loss (no corrector code), 1 = Huber / SoftLOne / Tukey / Truncated, 2 = Cauchy / Arctan (log / atan2:
+// their polynomial constants are hoisted into registers for the whole kernel -- an instance of its own keeps them out of
+// the others' allocation).
+template <int LOSSK>
+THIP_DEV double loss_eval_k(int type, double a, double s, double* rho1) {
+  if constexpr (LOSSK == 1) {
+    switch (type) {
+      case THEIA_LOSS_HUBER: case THEIA_LOSS_SOFTLONE: case THEIA_LOSS_TUKEY: case THEIA_LOSS_TRUNCATED: return loss_eval(type, a, s, rho1);
+      default: *rho1 = 1.0; return s;   // (Cauchy / Arctan: not in this instance)
+    }
+  } else {
+    return loss_eval(type, a, s, rho1);
+  }
+}
+inline int loss_class(int type) {
+  if (type == THEIA_LOSS_TRIVIAL) return 0;
+  return (type == THEIA_LOSS_CAUCHY || type == THEIA_LOSS_ARCTAN) ? 2 : 1;
+}
+
+template <int PD, unsigned MODELS, int LOSSK, bool STAMPS>
+THIP_DEV void fused_phase_l5(const DevProblem& P, const LanePre<PD>& c, const double* __restrict__ s_cam, int W, int tile, bool tile_ok,
+                             int wv, int lane, double inv_radius, double* __restrict__ Vinv, double* __restrict__ tile_part,
+                             double* __restrict__ s_rec, uint8_t* __restrict__ s_tslot, unsigned* __restrict__ s_tmask,
+                             unsigned long long (&stamps)[12]) {
+  Stamp<STAMPS> sl;
+  sl.start();
+  constexpr int NT = PD * (PD + 1) / 2;
+  constexpr int RD = rec_doubles<PD>();
+  const bool active = c.active;
+  const bool is_tgt = !(c.lc & 0x80u);
+  const unsigned cslot = is_tgt ? c.lc : (unsigned)W + (c.lc & 0x7fu);
+  const double* cb = s_cam + cslot * kCamLds;
+  const double X[4] = {c.X.x, c.X.y, c.X.z, c.X.w};
+  // p = X - w C,  q = R p
+  const double2 c01 = *reinterpret_cast<const double2*>(cb), c23 = *reinterpret_cast<const double2*>(cb + 2), c45 = *reinterpret_cast<const double2*>(cb + 4);
+  const double C[3] = {c01.x, c01.y, c23.x}, w[3] = {c23.y, c45.x, c45.y};
+  const double p[3] = {X[0] - X[3] * C[0], X[1] - X[3] * C[1], X[2] - X[3] * C[2]};
+  const double sq = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+  const bool behind = sq < 1e-8;   // reprojection_error.h:78-80: the functor returns false, nothing is evaluated
+  double R[9];
+  {
+    const double2 r0 = *reinterpret_cast<const double2*>(cb + 6), r1 = *reinterpret_cast<const double2*>(cb + 8), r2 = *reinterpret_cast<const double2*>(cb + 10),
+                  r3 = *reinterpret_cast<const double2*>(cb + 12), r4 = *reinterpret_cast<const double2*>(cb + 14);
+    R[0] = r0.x; R[1] = r0.y; R[2] = r1.x; R[3] = r1.y; R[4] = r2.x; R[5] = r2.y; R[6] = r3.x; R[7] = r3.y; R[8] = r4.x;
+  }
+  const double q[3] = {R[0] * p[0] + R[1] * p[1] + R[2] * p[2], R[3] * p[0] + R[4] * p[1] + R[5] * p[2], R[6] * p[0] + R[7] * p[1] + R[8] * p[2]};
+  const int model = c.depth ? THIP_MODEL_DEPTH_ROW : (int)cb[kCamRotModel];
+  double uvp[2], Jq[6];
+  bool valid = project<true, false, MODELS>(model, cb + kCamRotIntr, q, uvp, Jq);
+  double r[2] = {c.si.x * (uvp[0] - c.uv.x), c.si.y * (uvp[1] - c.uv.y)};
+  const double s2 = r[0] * r[0] + r[1] * r[1];
+  double rho1 = 1.0, rho = s2, sr = 1.0;
+  if constexpr (LOSSK != 0) {
+    rho = loss_eval_k<LOSSK>(P.loss_type, c.depth ? P.loss_width_depth : P.loss_width, s2, &rho1);
+    sr = fsqrt(rho1);
+    r[0] *= sr; r[1] *= sr;
+  }
+  double cost = 0.5 * rho;
+  // camera block 2 x 6 and ambient point block 2 x 4
+  double Jc[12], Jt[2 * PD];
+  {
+    // d(R p)/d(omega) applied from the left to a row jq:  A (p x jq) + B ((jq . w) p + (w . p) jq) + (jq . h) w,
+    // h = -A p + cA (w x p) + cB (w . p) w   (0 for small angles: rotation_dq_dw, ba_device.h, written per row)
+    const double rA = cb[15], rB = cb[16], rcA = cb[17], rcB = cb[18];
+    const bool small = cb[19] != 0.0;
+    const double wxp[3] = {w[1] * p[2] - w[2] * p[1], w[2] * p[0] - w[0] * p[2], w[0] * p[1] - w[1] * p[0]};
+    const double d = w[0] * p[0] + w[1] * p[1] + w[2] * p[2];
+    double h[3] = {0.0, 0.0, 0.0};
+    if (!small) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) h[i] = -rA * p[i] + rcA * wxp[i] + rcB * d * w[i];
+    }
+    double scl[6];
+    {
+      const double2 s0 = *reinterpret_cast<const double2*>(cb + kCamRotScale), s1 = *reinterpret_cast<const double2*>(cb + kCamRotScale + 2),
+                    s2v = *reinterpret_cast<const double2*>(cb + kCamRotScale + 4);
+      scl[0] = s0.x; scl[1] = s0.y; scl[2] = s1.x; scl[3] = s1.y; scl[4] = s2v.x; scl[5] = s2v.y;   // 0 = frozen column
+    }
+    double v[4] = {X[0], X[1], X[2], 1.0}, beta = 0.0, nx = 1.0;   // SphereManifold<4>: householder4 / to_tangent (ba_device.h)
+    if constexpr (PD == 3) {
+      const double sigma = X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+      nx = fsqrt(X[3] * X[3] + sigma);           // |x| (= mu of the Householder vector)
+      if (sigma <= DBL_EPSILON) { if (X[3] < 0.0) beta = 2.0; }
+      else {
+        const double vp = (X[3] <= 0.0) ? X[3] - nx : -sigma / (X[3] + nx);
+        beta = 2.0 * vp * vp / (sigma + vp * vp);
+        const double ivp = 1.0 / vp;
+        v[0] *= ivp; v[1] *= ivp; v[2] *= ivp;
+      }
+    }
+    const double sia[2] = {c.si.x * sr, c.si.y * sr};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const double* jq = Jq + 3 * a;
+      const double A0 = jq[0] * R[0] + jq[1] * R[3] + jq[2] * R[6];   // A = Jq R  (1 x 3)
+      const double A1 = jq[0] * R[1] + jq[1] * R[4] + jq[2] * R[7];
+      const double A2 = jq[0] * R[2] + jq[1] * R[5] + jq[2] * R[8];
+      const double sa = sia[a], sw = -sa * X[3];
+      Jc[6 * a + 0] = sw * A0 * scl[0];   // dq/dC = -w R
+      Jc[6 * a + 1] = sw * A1 * scl[1];
+      Jc[6 * a + 2] = sw * A2 * scl[2];
+      const double pxj[3] = {p[1] * jq[2] - p[2] * jq[1], p[2] * jq[0] - p[0] * jq[2], p[0] * jq[1] - p[1] * jq[0]};
+      const double jw = jq[0] * w[0] + jq[1] * w[1] + jq[2] * w[2];
+      const double jh = jq[0] * h[0] + jq[1] * h[1] + jq[2] * h[2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        Jc[6 * a + 3 + k] = sa * scl[3 + k] * (rA * pxj[k] + rB * (jw * p[k] + d * jq[k]) + jh * w[k]);
+      // dq/dX = [R | -R C] from the right: [A | -A . C]
+      const double j4[4] = {A0, A1, A2, -(A0 * C[0] + A1 * C[1] + A2 * C[2])};
+      if constexpr (PD == 3) {
+        const double jv = j4[0] * v[0] + j4[1] * v[1] + j4[2] * v[2] + j4[3] * v[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Jt[3 * a + k] = (sa * c.sp[k]) * (nx * (j4[k] - beta * v[k] * jv));
+      } else {
+#pragma unroll
+        for (int k = 0; k < PD; ++k) Jt[PD * a + k] = (sa * c.sp[k]) * j4[k];
+      }
+    }
+  }
+  if (behind) {
+    valid = false; r[0] = 0.0; r[1] = 0.0; cost = 0.0;   // (rho(0) = 0 for every loss)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
+  }
+  const bool pzero = !active || c.pconst || behind;   // no point block: constant point, or nothing evaluated
+  if (pzero) {
+#pragma unroll
+    for (int i = 0; i < 2 * PD; ++i) Jt[i] = 0.0;
+  }
+  if (!active) { cost = 0.0; r[0] = 0.0; r[1] = 0.0; }
+  if constexpr (STAMPS) { asm volatile("" :: "v"(Jt[0]), "v"(Jc[11]), "v"(r[1])); }
+  sl.lap(stamps, 2);
+  const int pseg = active ? c.p : -1 - lane;   // inactive lanes are their own segment
+  const Segment sg = lane_segment_all(pseg, lane);
+  double tot[NT + PD];
+#pragma unroll
+  for (int a = 0; a < PD; ++a) {
+#pragma unroll
+    for (int b = 0; b <= a; ++b) tot[lidx(a, b)] = Jt[a] * Jt[b] + Jt[PD + a] * Jt[PD + b];
+    tot[NT + a] = Jt[a] * r[0] + Jt[PD + a] * r[1];
+  }
+  // Track sums: every lane leaves its NT + PD products (and its local-camera bit) in its OWN record slot -- free until the
+  // record is written below -- and every lane of a track then adds the slots of the track's lanes in lane order: <= maxlen
+  // steps of five wide LDS reads (all lanes of a track read one address: broadcasts) against the 92 ds_bpermute of the
+  // log-step scans, which the LDS serves at ~16 cycles each (the stamps showed them costing as much as the whole
+  // linearisation).  Same bits in every lane of the track (same operands, same order).
+  unsigned tmask = 0u;
+  {
+    constexpr int NS = NT + PD;                       // 9 (PD = 3) or 14 doubles, then one word for the camera bit
+    double* mine = s_rec + (wv * 64 + lane) * RD;
+#pragma unroll
+    for (int k = 0; k + 1 < NS; k += 2) *reinterpret_cast<double2*>(mine + k) = make_double2(tot[k], tot[k + 1]);
+    if constexpr (NS & 1) mine[NS - 1] = tot[NS - 1];
+    reinterpret_cast<unsigned*>(mine + NS)[0] = (active && is_tgt) ? (1u << c.lc) : 0u;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) tot[k] = 0.0;
+    for (int j = 0; j < sg.maxlen; ++j) {             // wave-uniform trip count
+      const bool take = j < sg.len;
+      const double* oth = s_rec + (wv * 64 + min(sg.start + j, 63)) * RD;
+      double v[NS];
+#pragma unroll
+      for (int k = 0; k + 1 < NS; k += 2) { const double2 u = *reinterpret_cast<const double2*>(oth + k); v[k] = u.x; v[k + 1] = u.y; }
+      if constexpr (NS & 1) v[NS - 1] = oth[NS - 1];
+      const unsigned ob = reinterpret_cast<const unsigned*>(oth + NS)[0];
+      if (take) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) tot[k] += v[k];
+        tmask |= ob;
+      }
+    }
+  }
+  if constexpr (STAMPS) { asm volatile("" :: "v"(tot[0]), "v"(tot[NT + PD - 1]), "v"(tmask)); }
+  sl.lap(stamps, 3);
+  double V[NT], Vi[NT], g[PD];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) V[k] = tot[k];
+#pragma unroll
+  for (int a = 0; a < PD; ++a) { g[a] = tot[NT + a]; V[lidx(a, a)] += fmin(fmax(V[lidx(a, a)], 1e-6), 1e32) * inv_radius; }
+  bool pd_ok = true;
+  double Li[PD][PD];
+#pragma unroll
+  for (int a = 0; a < PD; ++a)
+#pragma unroll
+    for (int b = 0; b < PD; ++b) Li[a][b] = 0.0;
+  const bool pvar = active && !c.pconst;
+  if (pvar) pd_ok = invert_spd<PD>(V, Vi, Li);
+  if (!pvar || !pd_ok) {
+#pragma unroll
+    for (int k = 0; k < NT; ++k) Vi[k] = 0.0;
+#pragma unroll
+    for (int a = 0; a < PD; ++a)
+#pragma unroll
+      for (int b = 0; b < PD; ++b) Li[a][b] = 0.0;
+  }
+  double gmax = 0.0;
+  double gh[PD];   // ghat = Li g, in every lane of the track (the record carries r - Ehat ghat)
+#pragma unroll
+  for (int a = 0; a < PD; ++a) {
+    double sm = 0.0;
+#pragma unroll
+    for (int k = 0; k <= a; ++k) sm += Li[a][k] * g[k];
+    gh[a] = sm;
+  }
+  if constexpr (STAMPS) { asm volatile("" :: "v"(gh[0]), "v"(gh[PD - 1]), "v"(Vi[0])); }
+  sl.lap(stamps, 4);
+  if (active && sg.head) {
+    s_tmask[c.tl] = tmask;
+    if (!c.pconst) {
+#pragma unroll
+      for (int k = 0; k < NT; ++k) Vinv[(size_t)NT * c.p + k] = Vi[k];
+#pragma unroll
+      for (int a = 0; a < PD; ++a) gmax = fmax(gmax, fabs(g[a] / c.sp[a]));
+    }
+  }
+  if (active && is_tgt) {
+    const int slot = wv * 64 + lane;
+    double eh[2 * PD];   // Ehat = E Li^T
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int b = 0; b < PD; ++b) {
+        double sm = 0.0;
+#pragma unroll
+        for (int k = 0; k <= b; ++k) sm += Jt[i * PD + k] * Li[b][k];
+        eh[i * PD + b] = sm;
+      }
+    double2* Rr = reinterpret_cast<double2*>(s_rec + slot * RD);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Rr[k] = make_double2(Jc[2 * k], Jc[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < PD; ++k) Rr[6 + k] = make_double2(eh[2 * k], eh[2 * k + 1]);
+    Rr[6 + PD] = make_double2(r[0], r[1]);
+    double v1[2];   // r - Ehat ghat: the camera's rhs row is F^T (r - Ehat ghat)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      double sm = 0.0;
+#pragma unroll
+      for (int b = 0; b < PD; ++b) sm += eh[i * PD + b] * gh[b];
+      v1[i] = r[i] - sm;
+    }
+    Rr[6 + PD + 1] = make_double2(v1[0], v1[1]);
+    s_tslot[c.tl * kRowBytes + c.lc] = (uint8_t)slot;
+  }
+  sl.lap(stamps, 5);
+  const double costw = wave_sum_all(cost);
+  gmax = wave_max_all(gmax);
+  const double inval = wave_count(active && !valid);
+  const double npd = wave_count(active && !pd_ok && sg.head);
+  if (lane == 0 && tile_ok) {
+    tile_part[4 * (size_t)tile + 0] = costw;
+    tile_part[4 * (size_t)tile + 1] = gmax;
+    tile_part[4 * (size_t)tile + 2] = inval;
+    tile_part[4 * (size_t)tile + 3] = npd;
+  }
+  sl.lap(stamps, 6);
+}
+
+// tile_part layout as k_lin_obs: [ntiles][4] = {cost, gmax_points, invalid, notpd}
+template <int PD, int TPS, unsigned MODELS, int LOSSK, bool STAMPS = false>
+__global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevProblem P, const double* __restrict__ pts,
+                                                           const double* __restrict__ radius_p,
+                                                           double* __restrict__ Vinv, double* __restrict__ tile_part) {
+  constexpr int RD = rec_doubles<PD>();
+  constexpr int SUB = TPS * kWave;                    // observations per sub-chunk
+  constexpr int SUBT = TPS * kFusedTileTracks;        // tracks per sub-chunk
+  constexpr int NWV = TPS;                            // waves of the workgroup
+  __shared__ __attribute__((aligned(16))) double s_rec[SUB * RD];
+  __shared__ __attribute__((aligned(16))) double s_cam[kFusedMaxStage * kCamLds];
+  __shared__ uint8_t s_tslot[SUBT * kRowBytes];   // (track, local camera) -> record slot, valid where the mask bit is set
+  __shared__ unsigned s_tmask[SUBT];              // local cameras of a track
+  static_assert(SUB * 18 <= SUB * RD, "slice-combination scratch does not fit the record buffer");
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const double radius = *radius_p;
+  const double inv_radius = 1.0 / radius;
+  __shared__ int s_next;
+  unsigned long long stamps[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) stamps[k] = 0;
+  Stamp<STAMPS> sk;
+  sk.start();
+  // runs are taken from a queue, longest first (ba_solver.hip), ONE RUN AHEAD: the pop's round trip -- and, behind it in the
+  // in-order memory counter, the drain of the previous run's partial-block stores -- is off the path between two runs
+  int pending = 0;
+  if (tid == 0) pending = atomicAdd(P.frun_next, 1);
+  for (;;) {
+  __syncthreads();   // the previous run's slice combination is done with the LDS scratch (and s_next, s_cam)
+  if (tid == 0) s_next = pending;
+  __syncthreads();
+  const int rix = __builtin_amdgcn_readfirstlane(s_next);   // (scalar: the run's fields and the tile geometry are s_loads)
+  if (rix >= P.n_fruns) break;
+  if (tid == 0) pending = atomicAdd(P.frun_next, 1);
+  const FusedRun run = P.fruns[P.frun_order[rix]];
+  const int nsc = (run.ntiles + TPS - 1) / TPS;
+  // ---- the run's per-camera blocks (k_cam_prep) -> LDS, 16 B per thread and step
+  for (int j = tid; j < run.nstage * (kCamRot / 2); j += SUB) {
+    const int k = j / (kCamRot / 2), piece = j - k * (kCamRot / 2);
+    const int cidx = P.frun_stage[run.stage_off + k];
+    reinterpret_cast<double2*>(s_cam + k * kCamLds)[piece] = reinterpret_cast<const double2*>(P.camrot + (size_t)kCamRot * cidx)[piece];
+  }
+  LanePre<PD> cur;
+  int tile = 0; bool tile_ok = false;
+  pre_level1<PD, TPS>(P, run, 0, wv, lane, tile, tile_ok, cur);
+  pre_level2<PD>(P, pts, cur);
+  __syncthreads();   // s_cam complete
+
+  // ---- phase-S role: which target block / per-camera row this lane owns, which tracks it walks
+  const int G = run.gp & 0xff, PS = run.gp >> 8; // waves per slice (1, 2, 4) / slices per wave (>= 1, only with G == 1)
+  int tix, t0, tstride;
+  bool slice_ok = true;
+  const int B = 64 / PS;
+  if (G == 1) { const int g = lane / B; tix = lane - g * B; slice_ok = g < PS; t0 = wv * PS + g; tstride = NWV * PS; }
+  else { tix = (wv % G) * 64 + lane; t0 = wv / G; tstride = NWV / G; }
+  const bool has_tgt = slice_ok && tix < run.ntgt;
+  int la = 0, lb = 0;
+  if (has_tgt) { const unsigned us = P.frun_tgt[run.tgt_off + tix]; la = us & 0xffu; lb = us >> 8; }
+  const int dix = (G == 1) ? lane : tix;         // per-camera rows: lanes of the wave (G == 1) / of the wave group
+  const bool has_d = dix < 6 * run.W;
+  const int dlc = has_d ? dix / 6 : 0, da = dix % 6;
+  const int dP = (G == 1) ? PS : 1, dbase = (G == 1) ? wv * PS : wv / G;
+  const unsigned tbits = has_tgt ? ((1u << la) | (1u << lb)) : 0xffffffffu;   // no target: never a subset (bit 31 unused)
+  const unsigned dbit = has_d ? (1u << dlc) : 0x80000000u;
+  // a DIAGONAL target (la == lb) accumulates  What What^T - F^T F  (its 2 x 2 core is  Ehat Ehat^T - I): the camera's
+  // F^T F rides the pair products, the per-observation lanes keep three sums (rhs, gradient, column norm) only
+  const double diag_core = (has_tgt && la == lb) ? 1.0 : 0.0;
+  double acc[36], dacc[3];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) dacc[k] = 0.0;
+
+  sk.lap(stamps, 0);
+  for (int sc = 0; sc < nsc; ++sc) {
+    // ------------------------------------------------------------------ phase L: lane = observation
+    LanePre<PD> nxt;
+    int ntile = 0; bool ntile_ok = false;
+    const int scn = min(sc + 1, nsc - 1);   // (the last sub-chunk reloads itself: unconditional loads, nothing is used)
+    pre_level1<PD, TPS>(P, run, scn, wv, lane, ntile, ntile_ok, nxt);
+    if (P.fused_dbg & 16) __builtin_amdgcn_s_setprio(1);   // development: issue priority to the latency-bound phase
+    fused_phase_l5<PD, MODELS, LOSSK, STAMPS>(P, cur, s_cam, run.W, tile, tile_ok, wv, lane, inv_radius, Vinv, tile_part, s_rec, s_tslot, s_tmask, stamps);
+    sk.lap(stamps, 1);
+    pre_level2<PD>(P, pts, nxt);
+    if (P.fused_dbg & 16) __builtin_amdgcn_s_setprio(0);
+    // phase S is pure issue (FMAs on registers and LDS words), phase L is a chain of latencies: with the co-resident workgroup's
+    // wave in the other phase, giving S the issue slots first and letting L fill the gaps measured 0.3725 against 0.3958 ms
+    if (!(P.fused_dbg & 32)) __builtin_amdgcn_s_setprio(1);
+    __syncthreads();
+    sk.lap(stamps, 7);
+    // ------------------------------------------------------------------ phase S: lane = target block
+    if (!(P.fused_dbg & 1)) {
+      const int last_tile = min(run.tile0 + TPS * sc + TPS - 1, run.tile0 + run.ntiles - 1);
+      const int ntr = P.tile_trk_end[last_tile];
+      fused_phase_s<PD, RD>(s_rec, s_tslot, s_tmask, ntr, tstride, t0, slice_ok, tbits, la, lb, diag_core, dP, dbase, dbit, dlc, da, acc, dacc);
+    }
+    sk.lap(stamps, 8);
+    if (!(P.fused_dbg & 32)) __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+    sk.lap(stamps, 9);
+    if constexpr (STAMPS) stamps[11] += 1;
+    cur = nxt; tile = ntile; tile_ok = ntile_ok;
+  }
+  // ---------------------------------------------------------------- combine the track slices, fixed order
+  double* scratch = s_rec;   // SUB x 18 doubles
+  double* out = P.fpart + run.part_off;
+  const int nrep = (G == 1) ? NWV * PS : NWV / G;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {   // fully unrolled: acc[] must only ever see constant indices (else it lives in scratch)
+    if (h) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 18; ++q) scratch[tid * 18 + q] = acc[18 * h + q];
+    __syncthreads();
+    if (has_tgt && tid == tix) {   // the first replica of the target adds the others, in slice order
+      double v[18];
+#pragma unroll
+      for (int q = 0; q < 18; ++q) v[q] = scratch[tid * 18 + q];
+#pragma unroll 1
+      for (int r = 1; r < nrep; ++r) {
+        const int oth = (G == 1) ? ((r / PS) * 64 + (r % PS) * B + tix) : (tix + r * G * 64);
+#pragma unroll
+        for (int q = 0; q < 18; ++q) v[q] += scratch[oth * 18 + q];
+      }
+#pragma unroll
+      for (int q = 0; q < 18; ++q) scratch[tid * 18 + q] = v[q];   // back into its own row (tid == tix: rows [0, ntgt) are the sums)
+    }
+    __syncthreads();
+    // the half blocks leave as 16-B pieces, consecutive threads on consecutive pieces of a 144-B half block (every lane
+    // storing its own 18 doubles 8 bytes at a time made 36 store instructions of 64 scattered words each)
+    for (int e = tid; e < run.ntgt * 9; e += SUB) {
+      const int k = e / 9, q2 = e - 9 * k;
+      reinterpret_cast<double2*>(out)[(size_t)k * 18 + 9 * h + q2] = reinterpret_cast<const double2*>(scratch)[k * 9 + q2];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 3; ++q) scratch[tid * 3 + q] = dacc[q];
+  __syncthreads();
+  if (has_d && tid == dix) {
+    const int nrd = (G == 1) ? NWV : NWV / G;
+    double v[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) v[q] = scratch[tid * 3 + q];
+#pragma unroll 1
+    for (int r = 1; r < nrd; ++r) {
+      const int oth = (G == 1) ? (r * 64 + dix) : (dix + r * G * 64);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) v[q] += scratch[oth * 3 + q];
+    }
+    double* od = out + (size_t)run.ntgt * 36 + (size_t)dix * 3;   // [local camera][row][rhs, gradient, column norm]
+#pragma unroll
+    for (int q = 0; q < 3; ++q) od[q] = v[q];
+  }
+  sk.lap(stamps, 10);
+  }   // runs of this workgroup
+  if constexpr (STAMPS) {
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) atomicAdd(&g_fused_stamps[k], stamps[k]);
+    }
+  }
+}
+
 // One wave per S block (ri, rj): the partial blocks of the runs that touch it are added in run order and the block
 // is WRITTEN (never accumulated): S_ij = - sum What_a What_b^T; for a camera (ri == rj) also the per-observation
 // sums  F^T F - ..,  rhs = F^T r - What ghat,  gradient, column norms.
@@ -439,12 +981,43 @@ void launch_linearize_fused(const DevProblem& P, const double* cam, const double
   static const int wgs = [] { const char* e = getenv("THEIA_HIP_FUSED_WGS"); return e ? std::max(1, atoi(e)) : 512; }();   // 2 per CU
   const int grid = std::min(P.n_fruns, wgs);
   const bool trig = (P.model_mask & ~kModelsNoTrig) != 0;   // FOV / fisheye groups present
-  if (P.pd == 3) {
-    if (trig) k_lin_schur<3, 4, kModelsAll><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
-    else k_lin_schur<3, 4, kModelsNoTrig><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
+  static const bool v4 = getenv("THEIA_HIP_FUSED_V4") != nullptr;   // development: the round-4 kernel (gather per observation)
+  if (v4) {
+    if (P.pd == 3) {
+      if (trig) k_lin_schur_v4<3, 4, kModelsAll><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
+      else k_lin_schur_v4<3, 4, kModelsNoTrig><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
+    } else {
+      if (trig) k_lin_schur_v4<4, 4, kModelsAll><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
+      else k_lin_schur_v4<4, 4, kModelsNoTrig><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
+    }
   } else {
-    if (trig) k_lin_schur<4, 4, kModelsAll><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
-    else k_lin_schur<4, 4, kModelsNoTrig><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
+    const int lk = loss_class(P.loss_type);
+    static const bool stamps = getenv("THEIA_HIP_FUSED_STAMPS") != nullptr;   // development: instrumented instance + report
+    if (stamps && P.pd == 3 && !trig && lk == 0) {
+      static int launches = 0;
+      k_lin_schur<3, 4, kModelsNoTrig, 0, true><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);
+      if (++launches % 16 == 0) {
+        unsigned long long hst[16], zero[16] = {0};
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(hst, HIP_SYMBOL(g_fused_stamps), sizeof(hst));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fused_stamps), zero, sizeof(zero));
+        static const char* nm[12] = {"run setup", "phase L", " L math", " L scan", " L inverse", " L stores", " L reductions", "prefetch2+barrier", "phase S", "barrier after S", "combine+write", "sub-chunks"};
+        double tot = 0.0;
+        for (int k : {0, 1, 7, 8, 9, 10}) tot += (double)hst[k];
+        fprintf(stderr, "theia_hip fused stamps (16 launches, wave-summed s_memtime ticks; share of the sections' total):\n");
+        for (int k = 0; k < 12; ++k) fprintf(stderr, "  %-20s %14llu  %5.1f%%  per wave sub-chunk %8.0f\n", nm[k], hst[k], 100.0 * (double)hst[k] / tot, (double)hst[k] / std::max(1.0, (double)hst[11]));
+      }
+      if (P.n_sum_items)
+        k_schur_sum<<<(P.n_sum_items + 3) / 4, 256, 0, st>>>(P.n_sum_items, P.sum_items, P.sum_src, P.fpart, rb.S, P.n, rb.rhs, rb.gc, rb.colsq);
+      return;
+    }
+#define THIP_LS(PD_, M_) do { \
+      if (lk == 0) k_lin_schur<PD_, 4, M_, 0><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part); \
+      else if (lk == 1) k_lin_schur<PD_, 4, M_, 1><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part); \
+      else k_lin_schur<PD_, 4, M_, 2><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part); } while (0)
+    if (P.pd == 3) { if (trig) THIP_LS(3, kModelsAll); else THIP_LS(3, kModelsNoTrig); }
+    else { if (trig) THIP_LS(4, kModelsAll); else THIP_LS(4, kModelsNoTrig); }
+#undef THIP_LS
   }
   if (P.n_sum_items)
     k_schur_sum<<<(P.n_sum_items + 3) / 4, 256, 0, st>>>(P.n_sum_items, P.sum_items, P.sum_src, P.fpart, rb.S, P.n, rb.rhs,

@@ -17,9 +17,13 @@ struct FusedRun {
   int part_off;          // doubles offset of the run's partial sums: [ntgt][36] then [W][6][3]
   int gp;                // G | PS << 8.  G = consumer waves per track slice: 1, 2 or 4 (64 G >= max(ntgt, 6 W));
                          // PS = track slices per consumer wave (only with G == 1): floor(64 / PS) >= ntgt, 6 W <= 64
+  int stage_off, nstage; // ba_fused.hip: frun_stage[stage_off + k] = camera index of the k-th per-camera block the run keeps in
+                         // LDS: its W local cameras, then the CONSTANT cameras its tracks see (obs_lc = 0x80 | index among them)
 };
 inline int fused_tiles_per_subchunk(int) { return 4; }   // one wave per tile, 256-thread workgroups
 constexpr int kFusedMaxCams = 22;        // -> at most 253 target blocks = one per thread
+constexpr int kFusedMaxConst = 22;       // constant cameras a run may see (their blocks are staged in LDS next to the local cameras')
+constexpr int kFusedMaxStage = kFusedMaxCams + kFusedMaxConst;
 constexpr int kFusedTileTracks = 32;     // tracks per wave tile (128 per sub-chunk)
 // fused assembly with intrinsics (ba_fused_intr.hip): compound camera blocks [extrinsics (6) | compact intrinsics rows (4)]
 constexpr int kFusedIntrRows = 4, kFusedIntrWidth = 6 + kFusedIntrRows;
@@ -91,8 +95,10 @@ struct DevProblem {
   const int* frun_order;       // [n_fruns] run indices, most expensive first: the order in which workgroups take runs
   int* frun_next;              // work-queue head of k_lin_schur (zeroed by k_cam_prep before every launch)
   const int* frun_cams;
+  const int* frun_stage;       // camera indices of the per-camera blocks a run stages in LDS (FusedRun::stage_off / nstage)
   const unsigned short* frun_tgt;
-  const uint8_t* obs_lc;       // [nobs_main] local camera index inside the run, 0xFF = constant camera
+  const uint8_t* obs_lc;       // [nobs_main] local camera index inside the run; constant camera: 0x80 | index among the run's
+                               // constant cameras (ba_fused.hip), 0xFF with compound blocks (ba_fused_intr.hip)
   const uint8_t* obs_tl;       // [nobs_main] track index inside the sub-chunk
   const int* tile_trk_end;     // [ntiles] tracks of the sub-chunk up to and including this tile
   double* fpart;               // per-run partial sums

@@ -224,7 +224,7 @@ struct theia_ba_handle_s {
   bool use_fused = false;
   unsigned model_mask = 0xffu;          // camera models present in the problem
   DevBuf<FusedRun> fruns;
-  DevBuf<int> frun_cams, tile_trk_end, sum_items, sum_src, frun_order, frun_next;
+  DevBuf<int> frun_cams, frun_stage, tile_trk_end, sum_items, sum_src, frun_order, frun_next;
   DevBuf<unsigned short> frun_tgt;
   DevBuf<uint8_t> obs_lc, obs_tl;
   DevBuf<double> fpart, camrot, camrot_cand, camdir;
@@ -752,7 +752,7 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.n_priors = h->n_priors; P.prior_cam = h->prior_cam.p; P.prior_kind = h->prior_kind.p;
   P.prior_vec = h->prior_vec.p; P.prior_info = h->prior_info.p;
   P.rec = h->rec.p; P.n_diag_items = h->n_diag_items; P.n_blk_items = h->n_blk_items;
-  P.n_fruns = h->use_fused ? h->n_fruns : 0; P.fruns = h->fruns.p; P.frun_order = h->frun_order.p; P.frun_next = h->frun_next.p; P.frun_cams = h->frun_cams.p; P.frun_tgt = h->frun_tgt.p;
+  P.n_fruns = h->use_fused ? h->n_fruns : 0; P.fruns = h->fruns.p; P.frun_order = h->frun_order.p; P.frun_next = h->frun_next.p; P.frun_cams = h->frun_cams.p; P.frun_stage = h->frun_stage.p; P.frun_tgt = h->frun_tgt.p;
   P.obs_lc = h->obs_lc.p; P.obs_tl = h->obs_tl.p; P.tile_trk_end = h->tile_trk_end.p; P.fpart = h->fpart.p; P.camrot = h->camrot.p; P.camrot_cand = h->camrot_cand.p; P.camdir = h->camdir.p;
   { const char* dbg = getenv("THEIA_HIP_FUSED_DBG"); P.fused_dbg = dbg ? atoi(dbg) : 0; }
   P.model_mask = h->model_mask;
@@ -1474,7 +1474,7 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
 // a camera seen twice) go to the per-observation slow path (k_long_*), like the > 64 ones before.
 struct FusedHost {
   std::vector<FusedRun> runs;
-  std::vector<int> cams, tile_trk_end, sum_items, sum_src;
+  std::vector<int> cams, stage, tile_trk_end, sum_items, sum_src;
   std::vector<unsigned short> tgts;
   std::vector<uint8_t> obs_lc, obs_tl;
   std::vector<uint8_t> tile_adj;   // [nt][nt] 64-wide tiles of S coupled by a variable track (the K3 plan's input)
@@ -1488,7 +1488,7 @@ struct FusedSegment {
   FusedHost fp;
 };
 void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>& off, const std::vector<int>& porder,
-                         const int* sred, const std::vector<int>& skey, int q_begin, int q_end,
+                         const int* sred, const int* ocam, const std::vector<int>& skey, int q_begin, int q_end,
                          uint8_t* obs_lc, uint8_t* obs_tl, FusedSegment& seg) {
   std::vector<int>& tstart = seg.tstart; std::vector<int>& tcount = seg.tcount; std::vector<int>& tkey = seg.tkey;
   std::vector<int>& l_obs = seg.l_obs; std::vector<int>& l_slot = seg.l_slot; std::vector<int>& l_start = seg.l_start;
@@ -1511,7 +1511,7 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
     return 1;
   };
   const char* rm = getenv("THEIA_HIP_FUSED_RUN_OBS");
-  const int64_t run_max = rm ? std::max(64, atoi(rm)) : std::max<int64_t>(256, std::min<int64_t>(1344, nm / 600));   // 3.0 M observations, runs taken from the queue: 1280..1408 0.46 ms, 1024 0.47, 2304 0.48, 512 0.49
+  const int64_t run_max = rm ? std::max(64, atoi(rm)) : std::max<int64_t>(256, std::min<int64_t>(2048, nm / 600));   // 3.0 M observations, round-5 kernel (cameras staged per run, queue popped one run ahead): 2048 0.364 ms, 1664 0.365, 1344 0.372, 1024 0.39 (round 4: 1344)
   // current tile / run
   int64_t t_start = 0, t_len = 0;
   int t_tracks = 0, sc_tracks = 0;
@@ -1527,6 +1527,12 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
   std::vector<int> prev_tc;
   std::vector<int> cam_stamp((size_t)std::max(1, h->ncp), 0);
   std::vector<uint8_t> cam_local((size_t)std::max(1, h->ncp), 0);   // camera -> index in the closing run's sorted table
+  // CONSTANT cameras the open run's tracks see (ba_fused.hip stages their blocks in LDS behind the local cameras'), in order
+  // of appearance; only without compound blocks (ba_fused_intr.hip reads a constant camera's block from HBM, obs_lc = 0xff)
+  const bool stage_const = bw == 0;
+  std::vector<int> run_ccams, tcc;
+  std::vector<int> ccam_stamp(stage_const ? (size_t)std::max(1, h->nc) : 1, 0);
+  std::vector<uint8_t> ccam_local(stage_const ? (size_t)std::max(1, h->nc) : 1, 0);
   constexpr int kPairSlots = 2048;     // > 4 x 253
   std::vector<int64_t> pair_key(kPairSlots, 0);
   std::vector<int> pair_stamp(kPairSlots, 0);
@@ -1561,7 +1567,7 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
     t_len = 0; t_tracks = 0;
   };
   auto finalize_run = [&]() {
-    if (!run_ntiles) { run_cams.clear(); run_pairs.clear(); run_obs = 0; run_key0 = -1; ++serial; return; }
+    if (!run_ntiles) { run_cams.clear(); run_pairs.clear(); run_ccams.clear(); run_obs = 0; run_key0 = -1; ++serial; return; }
     std::sort(run_cams.begin(), run_cams.end());
     std::sort(run_pairs.begin(), run_pairs.end());
     FusedRun r;
@@ -1579,12 +1585,20 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
     r.gp = G | ((G == 1 ? std::max(1, packing((size_t)r.ntgt, (size_t)r.W)) : 1) << 8);
     r.part_off = (int)fp.part_doubles;
     fp.part_doubles += (size_t)r.ntgt * part_tgt + (size_t)r.W * part_cam;
+    r.stage_off = (int)fp.stage.size(); r.nstage = 0;
+    if (stage_const) {
+      for (int pc : run_cams) fp.stage.push_back(h->part_cam[pc]);
+      fp.stage.insert(fp.stage.end(), run_ccams.begin(), run_ccams.end());
+      r.nstage = (int)(run_cams.size() + run_ccams.size());
+    }
     for (int t = run_tile0; t < run_tile0 + run_ntiles; ++t)
-      for (int s = tstart[t]; s < tstart[t] + tcount[t]; ++s)
+      for (int s = tstart[t]; s < tstart[t] + tcount[t]; ++s) {
         if (sred[s] >= 0) obs_lc[s] = cam_local[sred[s]];
+        else if (stage_const) obs_lc[s] = (uint8_t)(0x80 | ccam_local[ocam[s]]);
+      }
     fp.runs.push_back(r);
     run_tile0 += run_ntiles; run_ntiles = 0; run_obs = 0; run_key0 = -1;
-    run_cams.clear(); run_pairs.clear(); ++serial;
+    run_cams.clear(); run_pairs.clear(); run_ccams.clear(); ++serial;
   };
   auto push_long = [&](int q) {
     const int slot = (int)l_pt.size();
@@ -1597,12 +1611,16 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
     const int64_t L = off[q + 1] - off[q];
     if (L == 0) continue;
     // the track's variable cameras
-    tc.clear();
-    for (int64_t s = off[q]; s < off[q + 1]; ++s) if (sred[s] >= 0) tc.push_back(sred[s]);
+    tc.clear(); tcc.clear();
+    for (int64_t s = off[q]; s < off[q + 1]; ++s) {
+      if (sred[s] >= 0) tc.push_back(sred[s]);
+      else if (stage_const) tcc.push_back(ocam[s]);
+    }
     std::sort(tc.begin(), tc.end());
     const bool dup = std::adjacent_find(tc.begin(), tc.end()) != tc.end();
+    if (!tcc.empty()) { std::sort(tcc.begin(), tcc.end()); tcc.erase(std::unique(tcc.begin(), tcc.end()), tcc.end()); }
     mark_tiles(q);
-    if (L > 64 || dup || (int)tc.size() > max_cams) {
+    if (L > 64 || dup || (int)tc.size() > max_cams || (int)tcc.size() > kFusedMaxConst) {
       close_tile(q);            // tiles are contiguous observation ranges
       push_long(q);
       continue;
@@ -1619,6 +1637,11 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
       for (int64_t key : tp) upairs += pair_stamp[pair_slot(key)] != serial;
     }
     bool new_run = (int)ucams > max_cams || upairs > max_tgts;
+    if (!tcc.empty()) {
+      size_t uc = run_ccams.size();
+      for (int c : tcc) uc += ccam_stamp[c] != serial;
+      if (uc > (size_t)kFusedMaxConst) new_run = true;
+    }
     // a run keeps its packing level (track slices per wave) once it has some work, and stays inside one
     // first-camera key once it is large enough
     // (compound blocks: the level is the number of track slices a workgroup walks in parallel -- 4 / G, or 4 PS with one
@@ -1666,6 +1689,7 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
       }
       prev_tc = tc; prev_serial = serial;
     }
+    for (int c : tcc) if (ccam_stamp[c] != serial) { ccam_stamp[c] = serial; ccam_local[c] = (uint8_t)run_ccams.size(); run_ccams.push_back(c); }
   }
   close_tile(q_end);
   finalize_run();
@@ -1796,17 +1820,18 @@ void merge_fused_segments(const theia_ba_handle_s* h, std::vector<FusedSegment>&
   const int adj_nt = (h->n + 63) / 64;
   fp.tile_adj.assign((size_t)adj_nt * adj_nt, 0);
   for (FusedSegment& sg : segs) {
-    const int tile0 = (int)tstart.size(), cam0 = (int)fp.cams.size(), tgt0 = (int)fp.tgts.size();
+    const int tile0 = (int)tstart.size(), cam0 = (int)fp.cams.size(), tgt0 = (int)fp.tgts.size(), stage0 = (int)fp.stage.size();
     const int slot0 = (int)l_pt.size(), lobs0 = (int)l_obs.size();
     tstart.insert(tstart.end(), sg.tstart.begin(), sg.tstart.end());
     tcount.insert(tcount.end(), sg.tcount.begin(), sg.tcount.end());
     tkey.insert(tkey.end(), sg.tkey.begin(), sg.tkey.end());
     for (FusedRun r : sg.fp.runs) {
-      r.tile0 += tile0; r.cam_off += cam0; r.tgt_off += tgt0; r.part_off += (int)fp.part_doubles;
+      r.tile0 += tile0; r.cam_off += cam0; r.tgt_off += tgt0; r.part_off += (int)fp.part_doubles; r.stage_off += stage0;
       fp.runs.push_back(r);
     }
     fp.part_doubles += sg.fp.part_doubles;
     fp.cams.insert(fp.cams.end(), sg.fp.cams.begin(), sg.fp.cams.end());
+    fp.stage.insert(fp.stage.end(), sg.fp.stage.begin(), sg.fp.stage.end());
     fp.tgts.insert(fp.tgts.end(), sg.fp.tgts.begin(), sg.fp.tgts.end());
     fp.tile_trk_end.insert(fp.tile_trk_end.end(), sg.fp.tile_trk_end.begin(), sg.fp.tile_trk_end.end());
     l_obs.insert(l_obs.end(), sg.l_obs.begin(), sg.l_obs.end());
@@ -2051,6 +2076,10 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
       static const int ncls = getenv("THEIA_HIP_FUSED_CLASSES") ? atoi(getenv("THEIA_HIP_FUSED_CLASSES")) : 2;
       static const int cut0 = getenv("THEIA_HIP_FUSED_CUT0") ? atoi(getenv("THEIA_HIP_FUSED_CUT0")) : 7;
       int cls = ncls == 2 ? (nvar[q] <= cut0 ? 0 : 2) : (nvar[q] <= 3 ? 0 : (nvar[q] <= 6 ? 1 : 2));
+      {   // development: THEIA_HIP_FUSED_CUTS="a,b,c" -> classes {<= a | <= b | <= c | more}
+        static const std::vector<int> cuts = [] { std::vector<int> v; const char* e = getenv("THEIA_HIP_FUSED_CUTS"); if (e) { for (const char* c = e; *c;) { v.push_back(atoi(c)); while (*c && *c != ',') ++c; if (*c) ++c; } } return v; }();
+        if (!cuts.empty()) { cls = 0; for (int cu : cuts) if (nvar[q] > cu) ++cls; cls = std::min(cls, 3); }
+      }
       // compound blocks (three or four lanes per target): four classes, by the number of track slices a workgroup can walk
       // in parallel -- <= 3 cameras and 4 .. 6: four slices; 7: two; more: one
       if (h->fused_bw && !getenv("THEIA_HIP_FUSED_CLASSES")) cls = nvar[q] <= 3 ? 0 : (nvar[q] <= 6 ? 1 : (nvar[q] <= 7 ? 2 : 3));
@@ -2230,7 +2259,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
     fplan.obs_lc.assign((size_t)std::max<int64_t>(1, h->nobs_main), 0xff);
     fplan.obs_tl.assign((size_t)std::max<int64_t>(1, h->nobs_main), 0);
     host_parts((int)segs.size(), true, [&](int k) {
-      build_fused_segment(h, cnt_main, porder, sred, skey, cut[k], cut[k + 1], fplan.obs_lc.data(), fplan.obs_tl.data(), segs[k]);
+      build_fused_segment(h, cnt_main, porder, sred, ocam, skey, cut[k], cut[k + 1], fplan.obs_lc.data(), fplan.obs_tl.data(), segs[k]);
     });
     tick("    fused plan: segments built");
     merge_fused_segments(h, segs, tstart, tcount, tkey, l_obs, l_slot, l_start, l_pt, fplan);
@@ -2448,7 +2477,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
               fplan.runs.size(), nsc, nsc ? (double)h->nobs_main / nsc : 0.0, fplan.part_doubles, h->n_sum_items);
       for (auto& kv : by) fprintf(stderr, "  G=%d slices/wave=%d: %d runs, %d sub-chunks\n", kv.first & 0xff, kv.first >> 8, kv.second.first, kv.second.second);
     }
-    if (fplan.runs.empty()) fplan.runs.push_back(FusedRun{0, 0, 0, 0, 0, 0, 0, 1 | (1 << 8)});
+    if (fplan.runs.empty()) fplan.runs.push_back(FusedRun{0, 0, 0, 0, 0, 0, 0, 1 | (1 << 8), 0, 0});
     {   // the workgroups of k_lin_schur take runs from a queue, the most expensive first (cost ~ wave tiles, weighted by the
         // target blocks a wave step covers): the kernel ends when the last run does, and with ~4 runs per workgroup a
         // static round robin left workgroups with one run more than others waiting for them
@@ -2460,7 +2489,8 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
       UP(frun_order, order);
       AL(frun_next, 1);
     }
-    UP(fruns, fplan.runs); UP(frun_cams, fplan.cams); UP(frun_tgt, fplan.tgts); UP(obs_lc, fplan.obs_lc); UP(obs_tl, fplan.obs_tl);
+    fplan.stage.resize(std::max<size_t>(1, fplan.stage.size()));
+    UP(fruns, fplan.runs); UP(frun_cams, fplan.cams); UP(frun_stage, fplan.stage); UP(frun_tgt, fplan.tgts); UP(obs_lc, fplan.obs_lc); UP(obs_tl, fplan.obs_tl);
     UP(tile_trk_end, fplan.tile_trk_end); UP(sum_items, fplan.sum_items); UP(sum_src, fplan.sum_src);
     AL(fpart, std::max<size_t>(1, fplan.part_doubles));
     AL(camrot, (size_t)40 * std::max(1, h->nc)); AL(camrot_cand, (size_t)40 * std::max(1, h->nc)); AL(camdir, (size_t)12 * std::max(1, h->nc));
