@@ -293,6 +293,7 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
         const double id1 = 1.0 / d1, id2 = 1.0 / d2, in = 1.0 / n;
         const double dk[3] = {xi * q[0] * id1, xi * q[1] * id1, xi * q[2] * id1 + 1.0};
         const double dd2[3] = {(q[0] + kk * dk[0]) * id2, (q[1] + kk * dk[1]) * id2, (kk * dk[2]) * id2};
+#pragma unroll
         for (int i = 0; i < 3; ++i) {
           const double dn = alpha * dd2[i] + (1.0 - alpha) * dk[i];
           ddx[i] = -dx * dn * in;
@@ -321,6 +322,7 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
         if (WANT_JAC) {
           const double in = 1.0 / n, ir = 1.0 / rho;
           const double dn[3] = {alpha * beta * q[0] * ir, alpha * beta * q[1] * ir, alpha * q[2] * ir + (1.0 - alpha)};
+#pragma unroll
           for (int i = 0; i < 3; ++i) { ddx[i] = -dx * dn[i] * in; ddy[i] = -dy * dn[i] * in; }
           ddx[0] += in; ddy[1] += in;
         }
@@ -389,6 +391,7 @@ THIP_DEV bool project(int model, const double* k, const double q[3], double uv[2
   uv[0] = f * dx + sk * dy + cx;
   uv[1] = fa * dy + cy;
   if (WANT_JAC) {
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
       Jq[i] = f * ddx[i] + sk * ddy[i];
       Jq[3 + i] = fa * ddy[i];
@@ -423,8 +426,16 @@ THIP_DEV void observe_rot(int model, const double* ext, const RotTerms& t, const
   o.dc0 = 0.0; o.dc1 = 0.0;
   if (sq < 1e-8) {  // reprojection_error.h:78-80 -> functor returns false
     o.valid = false; o.r[0] = 0.0; o.r[1] = 0.0;
-    if (WANT_JAC) { for (int i = 0; i < 12; ++i) o.Jc[i] = 0.0; for (int i = 0; i < 8; ++i) o.Jx[i] = 0.0; }
-    if constexpr (WANT_KJAC) { for (int i = 0; i < 2 * THEIA_MAX_INTRINSICS; ++i) o.Jk[i] = 0.0; }
+    if (WANT_JAC) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) o.Jc[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o.Jx[i] = 0.0;
+    }
+    if constexpr (WANT_KJAC) {
+#pragma unroll
+      for (int i = 0; i < 2 * THEIA_MAX_INTRINSICS; ++i) o.Jk[i] = 0.0;
+    }
     return;
   }
   const double q[3] = {t.R[0] * p[0] + t.R[1] * p[1] + t.R[2] * p[2],
@@ -433,6 +444,7 @@ THIP_DEV void observe_rot(int model, const double* ext, const RotTerms& t, const
   double uv[2], Jq[6];
   if constexpr (WANT_KJAC) {
     o.valid = project<WANT_JAC, true, MODELS>(model, intr, q, uv, Jq, o.Jk);
+#pragma unroll
     for (int i = 0; i < THEIA_MAX_INTRINSICS; ++i) { o.Jk[i] *= six; o.Jk[THEIA_MAX_INTRINSICS + i] *= siy; }
   } else {
     o.valid = project<WANT_JAC, false, MODELS>(model, intr, q, uv, Jq);

@@ -157,6 +157,7 @@ struct InnerArgs {
   // the intrinsics sweep with grp_wgs > 1 workgroups per group (co-resident: cooperative launch): per group and pass parity
   // grp_wgs partial sums of kInnerGroupSums doubles in grp_part, arrival counters in grp_bar ([ng] counters | abort flag | [ng] done flags | pad, zeroed before the launch)
   double* grp_part = nullptr; int* grp_bar = nullptr; int grp_wgs = 1; int grp_max_polls = 200000;
+  int grp_parts = 1;            // parts a pass over a group's observations is dealt to (= the cooperative launch's workgroups per group; the one-workgroup launch walks them in order)
 };
 constexpr int kInnerGroupSums = 68;        // 55 (J'J, packed) + 10 (J'r) + cost + invalid count (+ 1 pad)
 constexpr int kInnerGroupMaxWgs = 32;

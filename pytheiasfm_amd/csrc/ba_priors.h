@@ -111,9 +111,14 @@ THIP_DEV void camera_prior(int kind, const double* ext, const double* prior, con
   }
   for (int a = 0; a < 3; ++a) r[a] = (v[0] * S[3 * a] + v[1] * S[3 * a + 1]) + v[2] * S[3 * a + 2];
   if (!want_jac) return;
-  for (int k = 0; k < 18; ++k) J[k] = 0.0;
+#pragma unroll
   for (int a = 0; a < 3; ++a)
-    for (int b = 0; b < 3; ++b) J[6 * a + col0 + b] = (S[3 * a] * D[b] + S[3 * a + 1] * D[3 + b]) + S[3 * a + 2] * D[6 + b];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {   // (constant indices: J[6 a + col0 + b] with a run-time col0 made J a scratch array in its callers)
+      const double val = (S[3 * a] * D[b] + S[3 * a + 1] * D[3 + b]) + S[3 * a + 2] * D[6 + b];
+      J[6 * a + b] = col0 == 0 ? val : 0.0;
+      J[6 * a + 3 + b] = col0 == 3 ? val : 0.0;
+    }
 }
 
 }  // namespace thip

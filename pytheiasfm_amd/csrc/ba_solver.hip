@@ -2336,6 +2336,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
     AL(in_cam, (size_t)6 * std::max(1, h->nc)); AL(in_pts, (size_t)4 * std::max(1, h->np));
     AL(in_intr, (size_t)THEIA_MAX_INTRINSICS * std::max(1, h->ng));
     AL(in_scal, 8); AL(in_part, 2 * (size_t)kInnerCostBlocks); AL(in_gate, 4);
+    if (!h->use_fused) AL(camrot_cand, (size_t)40 * std::max(1, h->nc));   // the track sweep reads the cameras as k_cam_prep-style blocks (k_inner_cam_blocks)
     if (h->ni && inner_group_wgs(h->ng) > 1) { AL(in_grp_part, (size_t)h->ng * 2 * inner_group_wgs(h->ng) * kInnerGroupSums); AL(in_grp_bar, 2 * (size_t)std::max(1, h->ng) + 2); }
   }
   if (p->obs_kind) {   // depth-prior rows (sorted like the other observation arrays)

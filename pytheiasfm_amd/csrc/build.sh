@@ -19,6 +19,9 @@ for f in $SRCS; do
     # the DLS elimination keeps a 93 x 120 matrix in registers; common-code sinking would index it at run time (dls_stage_a.h)
     # (upnp_kernels.hip: the same for its 141 x 149 template)
     case "$f" in dls_kernels.hip|upnp_kernels.hip) CONTRACT="off -mllvm -simplifycfg-sink-common=false" ;; esac
+    # ba_inner.hip: the same switch -- sinking the stores of two branches into one store through a pointer phi kept observe_rot()'s
+    # residual pair in scratch (24 B per lane, written and read per observation)
+    case "$f" in ba_inner.hip) CONTRACT="off -mllvm -simplifycfg-sink-common=false" ;; esac
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=$CONTRACT -munsafe-fp-atomics \
       -I../../include -I. -c "$f" -o "$o" &
     PIDS="$PIDS $!"

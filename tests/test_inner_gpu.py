@@ -113,3 +113,29 @@ def test_group_sweep_gives_up_and_redoes_when_its_workgroups_cannot_meet():
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.join(root, "tests", "test_inner_gpu.py"),
                         "-k", "intrinsics and follow_the_oracle"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "2 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_group_sweep_fallback_reproduces_the_cooperative_launch_bit_for_bit():
+    """the one-workgroup launch of k_inner_groups (cooperative launch refused, stream capture, or a timed-out
+    arrival) summed a group's observations in another order than the launch with several workgroups per group, so a timeout
+    decided the low bits of the refined intrinsics.  Both now deal a pass to the same parts and add them in the same order:
+    the solve with THEIA_HIP_INNER_GROUPS_MAX_POLLS=0 (every cooperative workgroup gives up, the follow-up launch redoes the
+    groups) and with THEIA_HIP_INNER_GROUPS_SINGLE=1 (no cooperative launch at all) must equal the normal solve exactly."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np\n"
+            "from pytheiasfm_amd import ba, sfm, synth\n"
+            "p = synth.synth_ba_v1(16, 1200, seed=11, mixed_models=True)\n"
+            "o = ba.default_options(); o.max_num_iterations = 6\n"
+            "o.intrinsics_to_optimize = int(sfm.OptimizeIntrinsicsType.FOCAL_LENGTH | sfm.OptimizeIntrinsicsType.RADIAL_DISTORTION)\n"
+            "s, tr = ba.solve(p, o)\n"
+            "print('HEX', p.intrinsics.tobytes().hex(), p.cam_ext.tobytes().hex()[:4096], repr(float(s.final_cost)))\n")
+    outs = []
+    for extra in ({}, {"THEIA_HIP_INNER_GROUPS_MAX_POLLS": "0"}, {"THEIA_HIP_INNER_GROUPS_SINGLE": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("HEX")][-1])
+    assert outs[0] == outs[1], "give-up-and-redo path differs from the cooperative launch"
+    assert outs[0] == outs[2], "one-workgroup launch differs from the cooperative launch"
