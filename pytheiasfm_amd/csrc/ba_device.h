@@ -579,8 +579,34 @@ THIP_DEV void to_tangent(const double X[4], const double Jx[8], double Jt[6]) {
   }
 }
 
+// sin(t) / t and cos(t) from t^2 for t^2 <= 0.5 (Taylor to t^20: truncation < 2e-21); THIP_LEAN_SINCOS (the large-solve
+// kernels): SphereManifold::Plus on a tangent step needs exactly these two, a BA point step is tiny, and libm's sincos brings
+// its range reduction, ~100 instructions and a set of hoisted constants into kernels that are issue and register bound.
+THIP_DEV void sinc_cos_small(double t2, double& sinc, double& cosv) {
+  double a = 1.0 / 51090942171709440000.0, b = 1.0 / 2432902008176640000.0;   // 1/21!, 1/20!
+  a = __builtin_fma(-a, t2, 1.0 / 121645100408832000.0);  b = __builtin_fma(-b, t2, 1.0 / 6402373705728000.0);    // 1/19!, 1/18!
+  a = __builtin_fma(-a, t2, 1.0 / 355687428096000.0);     b = __builtin_fma(-b, t2, 1.0 / 20922789888000.0);      // 1/17!, 1/16!
+  a = __builtin_fma(-a, t2, 1.0 / 1307674368000.0);       b = __builtin_fma(-b, t2, 1.0 / 87178291200.0);         // 1/15!, 1/14!
+  a = __builtin_fma(-a, t2, 1.0 / 6227020800.0);          b = __builtin_fma(-b, t2, 1.0 / 479001600.0);           // 1/13!, 1/12!
+  a = __builtin_fma(-a, t2, 1.0 / 39916800.0);            b = __builtin_fma(-b, t2, 1.0 / 3628800.0);             // 1/11!, 1/10!
+  a = __builtin_fma(-a, t2, 1.0 / 362880.0);              b = __builtin_fma(-b, t2, 1.0 / 40320.0);               // 1/9!, 1/8!
+  a = __builtin_fma(-a, t2, 1.0 / 5040.0);                b = __builtin_fma(-b, t2, 1.0 / 720.0);                 // 1/7!, 1/6!
+  a = __builtin_fma(-a, t2, 1.0 / 120.0);                 b = __builtin_fma(-b, t2, 1.0 / 24.0);                  // 1/5!, 1/4!
+  a = __builtin_fma(-a, t2, 1.0 / 6.0);                   b = __builtin_fma(-b, t2, 0.5);                         // 1/3!, 1/2!
+  sinc = __builtin_fma(-a, t2, 1.0);                      cosv = __builtin_fma(-b, t2, 1.0);
+}
 THIP_DEV void sphere_plus(const double x[4], const double d[3], double out[4]) {
-  const double nd = fsqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const double nd2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+#ifdef THIP_LEAN_SINCOS
+  if (nd2 == 0.0) { out[0] = x[0]; out[1] = x[1]; out[2] = x[2]; out[3] = x[3]; return; }
+  double v[4], beta;
+  householder4(x, v, beta);
+  const double nx = fsqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+  double sbd, c;
+  if (nd2 <= 0.5) sinc_cos_small(nd2, sbd, c);
+  else { const double nd = fsqrt(nd2); double s; sincos(nd, &s, &c); sbd = s / nd; }
+#else
+  const double nd = fsqrt(nd2);
   if (nd == 0.0) { out[0] = x[0]; out[1] = x[1]; out[2] = x[2]; out[3] = x[3]; return; }
   double v[4], beta;
   householder4(x, v, beta);
@@ -588,6 +614,7 @@ THIP_DEV void sphere_plus(const double x[4], const double d[3], double out[4]) {
   double s, c;
   sincos(nd, &s, &c);
   const double sbd = s / nd;
+#endif
   const double y[4] = {sbd * d[0], sbd * d[1], sbd * d[2], c};
   const double vty = v[0] * y[0] + v[1] * y[1] + v[2] * y[2] + v[3] * y[3];
   for (int i = 0; i < 4; ++i) out[i] = nx * (y[i] - v[i] * (beta * vty));

@@ -28,6 +28,7 @@
 // HBM traffic per LM iteration: the 24 B / observation stream + one byte pair of plan indices, the parameters,
 // V^-1 out, and the partial blocks (ntgt * 288 B + W * 432 B per run, written and read once).
 #define THIP_LEAN_SQRT 1   // ba_device.h: fsqrt() without range scaling / class selects
+#define THIP_LEAN_SINCOS 1 // ba_device.h: SphereManifold::Plus with sin(t) / t and cos(t) as polynomials in t^2 for small steps
 #include "ba_lane.h"
 
 #include <algorithm>
@@ -45,7 +46,7 @@ static_assert(kFusedMaxCams <= kRowBytes, "slot-table row too short");
 __global__ __launch_bounds__(256) void k_cam_prep(DevProblem P, const double* __restrict__ cam, const double* __restrict__ intr,
                                                   double* __restrict__ camrot, const double* __restrict__ ycam) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && P.frun_next) *P.frun_next = 0;   // head of k_lin_schur's run queue (the next kernel on the stream)
+  if (c == 0 && P.frun_next) { P.frun_next[0] = 0; P.frun_next[1] = 0; }   // heads of the run queues of k_lin_schur / k_backsub_runs (the next kernels on the stream)
   if (c >= P.nc) return;
   cam_prep_one(P, c, cam + 6 * (size_t)c, intr, camrot);
   if (ycam && P.camdir) {
@@ -916,14 +917,241 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// K4 + K5 on the same skeleton (round 5): back-substitution of the point steps, candidate points, model-cost change and the
+// trial cost, by persistent workgroups over the RUNS of the fused plan -- the per-camera blocks of a run (state: k_cam_prep;
+// trial step {D, v}: P.camdir; candidate: P.camrot_cand) staged in LDS once per run, the observation stream of the next
+// sub-chunk (and the points, their scaling and V^-1) prefetched, the problem through scalar loads, track sums through LDS
+// slots.  The arithmetic is k_backsub<PD, false, true>'s (ba_kernels.hip): F y_c as the directional derivative
+// s Jq (D p - w v), y_p = V^-1 E^T (r - F y_c), SphereManifold::Plus, residual at the candidate.  No phase S, no barrier
+// inside a run: the waves of a workgroup only share the staged cameras.
+// tile_part: [ntiles][5] = {cand_cost, mcc, stepsq, xnormsq, invalid}
+constexpr int kCamLdsB = 70;   // doubles per staged camera: camrot (40) | camdir (12) | candidate ext + R (16) | pad (2); 35 16-B pieces
+
+template <int PD, int TPS, unsigned MODELS, int LOSSK, int WPS>
+__global__ __launch_bounds__(64 * TPS, WPS) void k_backsub_runs(DevProblem P, const double* __restrict__ pts, double* __restrict__ cand_pts,
+                                                             const double* __restrict__ Vinv, double* __restrict__ tile_part) {
+  constexpr int NT = PD * (PD + 1) / 2;
+  constexpr int SUB = TPS * kWave;
+  __shared__ __attribute__((aligned(16))) double s_cam[kFusedMaxStage * kCamLdsB];
+  __shared__ __attribute__((aligned(16))) double s_slot[TPS][64 * 4];
+  __shared__ int s_next;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int pending = 0;
+  if (tid == 0) pending = atomicAdd(P.frun_next + 1, 1);
+  for (;;) {
+  __syncthreads();   // the previous run is done with s_cam (and s_next)
+  if (tid == 0) s_next = pending;
+  __syncthreads();
+  const int rix = __builtin_amdgcn_readfirstlane(s_next);
+  if (rix >= P.n_fruns) break;
+  if (tid == 0) pending = atomicAdd(P.frun_next + 1, 1);
+  const FusedRun run = P.fruns[P.frun_order[rix]];
+  const int nsc = (run.ntiles + TPS - 1) / TPS;
+  for (int j = tid; j < run.nstage * (kCamLdsB / 2); j += SUB) {
+    const int k = j / (kCamLdsB / 2), piece = j - k * (kCamLdsB / 2);
+    const int cidx = P.frun_stage[run.stage_off + k];
+    double2 v = make_double2(0.0, 0.0);
+    if (piece < 20) v = reinterpret_cast<const double2*>(P.camrot + (size_t)kCamRot * cidx)[piece];
+    else if (piece < 26) v = reinterpret_cast<const double2*>(P.camdir + (size_t)12 * cidx)[piece - 20];
+    else if (piece < 34) v = reinterpret_cast<const double2*>(P.camrot_cand + (size_t)kCamRot * cidx)[piece - 26];
+    reinterpret_cast<double2*>(s_cam + k * kCamLdsB)[piece] = v;
+  }
+  LanePre<PD> cur;
+  double viq[NT];
+  int tile = 0; bool tile_ok = false;
+  pre_level1<PD, TPS>(P, run, 0, wv, lane, tile, tile_ok, cur);
+  pre_level2<PD>(P, pts, cur);
+#pragma unroll
+  for (int k = 0; k < NT; ++k) viq[k] = Vinv[(size_t)NT * cur.p + k];
+  __syncthreads();   // s_cam complete
+  for (int sc = 0; sc < nsc; ++sc) {
+    LanePre<PD> nxt;
+    int ntile = 0; bool ntile_ok = false;
+    const int scn = min(sc + 1, nsc - 1);
+    pre_level1<PD, TPS>(P, run, scn, wv, lane, ntile, ntile_ok, nxt);
+    // ---------------------------------------------------------------- this lane's observation
+    const LanePre<PD>& c = cur;
+    const bool active = c.active;
+    const unsigned cslot = (c.lc & 0x80u) ? (unsigned)run.W + (c.lc & 0x7fu) : c.lc;
+    const double* cb = s_cam + cslot * kCamLdsB;
+    const double X[4] = {c.X.x, c.X.y, c.X.z, c.X.w};
+    const double2 c01 = *reinterpret_cast<const double2*>(cb), c2w = *reinterpret_cast<const double2*>(cb + 2);
+    const double C[3] = {c01.x, c01.y, c2w.x};
+    const double p[3] = {X[0] - X[3] * C[0], X[1] - X[3] * C[1], X[2] - X[3] * C[2]};
+    const bool behind = (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) < 1e-8;
+    double R[9];
+    {
+      const double2 r0 = *reinterpret_cast<const double2*>(cb + 6), r1 = *reinterpret_cast<const double2*>(cb + 8), r2 = *reinterpret_cast<const double2*>(cb + 10),
+                    r3 = *reinterpret_cast<const double2*>(cb + 12), r4 = *reinterpret_cast<const double2*>(cb + 14);
+      R[0] = r0.x; R[1] = r0.y; R[2] = r1.x; R[3] = r1.y; R[4] = r2.x; R[5] = r2.y; R[6] = r3.x; R[7] = r3.y; R[8] = r4.x;
+    }
+    const double q[3] = {R[0] * p[0] + R[1] * p[1] + R[2] * p[2], R[3] * p[0] + R[4] * p[1] + R[5] * p[2], R[6] * p[0] + R[7] * p[1] + R[8] * p[2]};
+    const int model = c.depth ? THIP_MODEL_DEPTH_ROW : (int)cb[kCamRotModel];
+    double uvp[2], Jq[6];
+    project<true, false, MODELS>(model, cb + kCamRotIntr, q, uvp, Jq);
+    double r[2] = {c.si.x * (uvp[0] - c.uv.x), c.si.y * (uvp[1] - c.uv.y)};
+    double sr = 1.0;
+    if constexpr (LOSSK != 0) {
+      double rho1;
+      (void)loss_eval_k<LOSSK>(P.loss_type, c.depth ? P.loss_width_depth : P.loss_width, r[0] * r[0] + r[1] * r[1], &rho1);
+      sr = fsqrt(rho1);
+      r[0] *= sr; r[1] *= sr;
+    }
+    double mc[2], Jt[2 * PD];
+    {
+      // the camera's step as {D, v}: F y_c = -sr s Jq (D p - w v)   (camera_step_direction, ba_device.h; zero for constant cameras)
+      double u[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) u[i] = (cb[40 + 3 * i] * p[0] + cb[40 + 3 * i + 1] * p[1] + cb[40 + 3 * i + 2] * p[2]) - X[3] * cb[49 + i];
+      double v[4] = {X[0], X[1], X[2], 1.0}, beta = 0.0, nx = 1.0;
+      if constexpr (PD == 3) {
+        const double sigma = X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+        nx = fsqrt(X[3] * X[3] + sigma);
+        if (sigma <= DBL_EPSILON) { if (X[3] < 0.0) beta = 2.0; }
+        else {
+          const double vp = (X[3] <= 0.0) ? X[3] - nx : -sigma / (X[3] + nx);
+          beta = 2.0 * vp * vp / (sigma + vp * vp);
+          const double ivp = 1.0 / vp;
+          v[0] *= ivp; v[1] *= ivp; v[2] *= ivp;
+        }
+      }
+      const double sia[2] = {c.si.x * sr, c.si.y * sr};
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const double* jq = Jq + 3 * a;
+        mc[a] = -sia[a] * (jq[0] * u[0] + jq[1] * u[1] + jq[2] * u[2]);
+        const double A0 = jq[0] * R[0] + jq[1] * R[3] + jq[2] * R[6];
+        const double A1 = jq[0] * R[1] + jq[1] * R[4] + jq[2] * R[7];
+        const double A2 = jq[0] * R[2] + jq[1] * R[5] + jq[2] * R[8];
+        const double j4[4] = {A0, A1, A2, -(A0 * C[0] + A1 * C[1] + A2 * C[2])};
+        if constexpr (PD == 3) {
+          const double jv = j4[0] * v[0] + j4[1] * v[1] + j4[2] * v[2] + j4[3] * v[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) Jt[3 * a + k] = (sia[a] * c.sp[k]) * (nx * (j4[k] - beta * v[k] * jv));
+        } else {
+#pragma unroll
+          for (int k = 0; k < PD; ++k) Jt[PD * a + k] = (sia[a] * c.sp[k]) * j4[k];
+        }
+      }
+    }
+    if (behind || !active) { r[0] = 0.0; r[1] = 0.0; mc[0] = 0.0; mc[1] = 0.0; }
+    if (behind || !active || c.pconst) {
+#pragma unroll
+      for (int i = 0; i < 2 * PD; ++i) Jt[i] = 0.0;
+    }
+    // t = E^T (r - F y_c), summed over the track through the wave's LDS slots
+    const int pseg = active ? c.p : -1 - lane;
+    const Segment sg = lane_segment_all(pseg, lane);
+    double tsum[PD];
+    {
+      double* mine = s_slot[wv] + lane * 4;
+      double in[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < PD; ++k) in[k] = Jt[k] * (r[0] - mc[0]) + Jt[PD + k] * (r[1] - mc[1]);
+      *reinterpret_cast<double2*>(mine) = make_double2(in[0], in[1]);
+      *reinterpret_cast<double2*>(mine + 2) = make_double2(in[2], in[3]);
+#pragma unroll
+      for (int k = 0; k < PD; ++k) tsum[k] = 0.0;
+      for (int j = 0; j < sg.maxlen; ++j) {
+        const double* oth = s_slot[wv] + min(sg.start + j, 63) * 4;
+        const double2 a = *reinterpret_cast<const double2*>(oth), b = *reinterpret_cast<const double2*>(oth + 2);
+        const double v4[4] = {a.x, a.y, b.x, b.y};
+        if (j < sg.len) {
+#pragma unroll
+          for (int k = 0; k < PD; ++k) tsum[k] += v4[k];
+        }
+      }
+    }
+    const bool pvar = active && !c.pconst;
+    double yp[PD];
+#pragma unroll
+    for (int a = 0; a < PD; ++a) {
+      double sm = 0.0;
+#pragma unroll
+      for (int b = 0; b < PD; ++b) sm += (pvar ? viq[a >= b ? lidx(a, b) : lidx(b, a)] : 0.0) * tsum[b];
+      yp[a] = sm;
+    }
+    // step = -y ; model residual m = Js * step ; mcc = -m . (r + m/2)
+    double mcc = 0.0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      double m = -mc[a];
+#pragma unroll
+      for (int k = 0; k < PD; ++k) m -= Jt[a * PD + k] * yp[k];
+      mcc -= m * (r[a] + m / 2.0);
+    }
+    if (!active) mcc = 0.0;
+    double Xp[4] = {X[0], X[1], X[2], X[3]};
+    double stepsq = 0.0, xnormsq = 0.0;
+    if (pvar) {
+      double d[PD];
+#pragma unroll
+      for (int k = 0; k < PD; ++k) d[k] = -yp[k] * c.sp[k];
+      if constexpr (PD == 3) { const double d3[3] = {d[0], d[1], d[2]}; sphere_plus(X, d3, Xp); }
+      else {
+#pragma unroll
+        for (int k = 0; k < PD; ++k) Xp[k] = X[k] + d[k];
+      }
+      if (sg.head) {
+        reinterpret_cast<double4*>(cand_pts)[c.p] = make_double4(Xp[0], Xp[1], Xp[2], Xp[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { stepsq += (X[k] - Xp[k]) * (X[k] - Xp[k]); xnormsq += Xp[k] * Xp[k]; }
+      }
+    }
+    // trial cost at the candidate (camera block: the candidate's position / rotation, the same intrinsics)
+    double ccost = 0.0;
+    bool cvalid = true;
+    {
+      const double* cc = cb + 52;
+      const double2 d01 = *reinterpret_cast<const double2*>(cc), d2w = *reinterpret_cast<const double2*>(cc + 2);
+      const double Cc[3] = {d01.x, d01.y, d2w.x};
+      const double pc[3] = {Xp[0] - Xp[3] * Cc[0], Xp[1] - Xp[3] * Cc[1], Xp[2] - Xp[3] * Cc[2]};
+      const bool cbehind = (pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]) < 1e-8;
+      double Rc[9];
+      {
+        const double2 r0 = *reinterpret_cast<const double2*>(cc + 6), r1 = *reinterpret_cast<const double2*>(cc + 8), r2 = *reinterpret_cast<const double2*>(cc + 10),
+                      r3 = *reinterpret_cast<const double2*>(cc + 12), r4 = *reinterpret_cast<const double2*>(cc + 14);
+        Rc[0] = r0.x; Rc[1] = r0.y; Rc[2] = r1.x; Rc[3] = r1.y; Rc[4] = r2.x; Rc[5] = r2.y; Rc[6] = r3.x; Rc[7] = r3.y; Rc[8] = r4.x;
+      }
+      const double qc[3] = {Rc[0] * pc[0] + Rc[1] * pc[1] + Rc[2] * pc[2], Rc[3] * pc[0] + Rc[4] * pc[1] + Rc[5] * pc[2], Rc[6] * pc[0] + Rc[7] * pc[1] + Rc[8] * pc[2]};
+      double uvc[2], Jqc[6];
+      cvalid = project<false, false, MODELS>(model, cb + kCamRotIntr, qc, uvc, Jqc);
+      const double rc0 = c.si.x * (uvc[0] - c.uv.x), rc1 = c.si.y * (uvc[1] - c.uv.y);
+      double s2 = rc0 * rc0 + rc1 * rc1;
+      if (cbehind) { cvalid = false; s2 = 0.0; }
+      double rho = s2;
+      if constexpr (LOSSK != 0) { double rho1; rho = loss_eval_k<LOSSK>(P.loss_type, c.depth ? P.loss_width_depth : P.loss_width, s2, &rho1); }
+      ccost = 0.5 * rho;
+      if (!active) { ccost = 0.0; cvalid = true; }
+    }
+    ccost = wave_sum_all(ccost);
+    mcc = wave_sum_all(mcc);
+    stepsq = wave_sum_all(stepsq);
+    xnormsq = wave_sum_all(xnormsq);
+    const double inval = wave_count(!cvalid);
+    if (lane == 0 && tile_ok) {
+      double* tp = tile_part + 5 * (size_t)tile;
+      tp[0] = ccost; tp[1] = mcc; tp[2] = stepsq; tp[3] = xnormsq; tp[4] = inval;
+    }
+    // ---------------------------------------------------------------- the next sub-chunk's points
+    pre_level2<PD>(P, pts, nxt);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) viq[k] = Vinv[(size_t)NT * nxt.p + k];
+    cur = nxt; tile = ntile; tile_ok = ntile_ok;
+  }
+  }   // runs of this workgroup
+}
+
 // One wave per S block (ri, rj): the partial blocks of the runs that touch it are added in run order and the block
 // is WRITTEN (never accumulated): S_ij = - sum What_a What_b^T; for a camera (ri == rj) also the per-observation
 // sums  F^T F - ..,  rhs = F^T r - What ghat,  gradient, column norms.
 __global__ __launch_bounds__(256) void k_schur_sum(int nitems, const int* __restrict__ items, const int* __restrict__ src,
                                                    const double* __restrict__ part, double* __restrict__ S, int n,
                                                    double* __restrict__ rhs, double* __restrict__ gc,
-                                                   double* __restrict__ colsq) {
+                                                   double* __restrict__ colsq, int* __restrict__ qhead) {
   const int it = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && qhead) *qhead = 0;   // k_lin_schur (the previous kernel on the stream) is done with its run queue: ready for the next launch
   if (it >= nitems) return;
   const int* d = items + 6 * it;
   const int ri = d[0], rj = d[1], tbeg = d[2], tend = d[3], dbeg = d[4], dend = d[5];
@@ -977,7 +1205,7 @@ void launch_cam_prep(const DevProblem& P, const double* cam, const double* intr,
 void launch_linearize_fused(const DevProblem& P, const double* cam, const double* pts, const double* radius,
                             const ReduceBuf& rb, double* Vinv, double* tile_part, hipStream_t st) {
   if (P.n_fruns == 0) return;
-  launch_cam_prep(P, cam, P.intr, P.camrot, st);
+  if (!P.camrot_current || P.n_sum_items == 0) launch_cam_prep(P, cam, P.intr, P.camrot, st);   // (otherwise k_schur_sum left the run queue's head at zero)
   static const int wgs = [] { const char* e = getenv("THEIA_HIP_FUSED_WGS"); return e ? std::max(1, atoi(e)) : 512; }();   // 2 per CU
   const int grid = std::min(P.n_fruns, wgs);
   const bool trig = (P.model_mask & ~kModelsNoTrig) != 0;   // FOV / fisheye groups present
@@ -1008,7 +1236,7 @@ void launch_linearize_fused(const DevProblem& P, const double* cam, const double
         for (int k = 0; k < 12; ++k) fprintf(stderr, "  %-20s %14llu  %5.1f%%  per wave sub-chunk %8.0f\n", nm[k], hst[k], 100.0 * (double)hst[k] / tot, (double)hst[k] / std::max(1.0, (double)hst[11]));
       }
       if (P.n_sum_items)
-        k_schur_sum<<<(P.n_sum_items + 3) / 4, 256, 0, st>>>(P.n_sum_items, P.sum_items, P.sum_src, P.fpart, rb.S, P.n, rb.rhs, rb.gc, rb.colsq);
+        k_schur_sum<<<(P.n_sum_items + 3) / 4, 256, 0, st>>>(P.n_sum_items, P.sum_items, P.sum_src, P.fpart, rb.S, P.n, rb.rhs, rb.gc, rb.colsq, P.frun_next);
       return;
     }
 #define THIP_LS(PD_, M_) do { \
@@ -1021,7 +1249,27 @@ void launch_linearize_fused(const DevProblem& P, const double* cam, const double
   }
   if (P.n_sum_items)
     k_schur_sum<<<(P.n_sum_items + 3) / 4, 256, 0, st>>>(P.n_sum_items, P.sum_items, P.sum_src, P.fpart, rb.S, P.n, rb.rhs,
-                                                         rb.gc, rb.colsq);
+                                                         rb.gc, rb.colsq, P.frun_next);
+}
+
+// K4 + K5 over the runs of the fused plan (k_backsub_runs); false: not applicable (the caller takes k_backsub)
+bool launch_backsub_runs(const DevProblem& P, const double* pts, double* cand_pts, const double* Vinv, double* tile_part, hipStream_t st) {
+  static const bool off = getenv("THEIA_HIP_BACKSUB_TILES") != nullptr;   // development: the round-4 kernel (one wave per tile, gathers)
+  if (off || P.ni || P.n_fruns == 0 || !P.camrot || !P.camrot_cand || !P.camdir || P.fused_bw) return false;
+  static const int wgs_env = [] { const char* e = getenv("THEIA_HIP_BACKSUB_WGS"); return e ? std::max(1, atoi(e)) : 0; }();
+  const bool trig = (P.model_mask & ~kModelsNoTrig) != 0;
+  const int lk = loss_class(P.loss_type);
+  static const int wps = [] { const char* e = getenv("THEIA_HIP_BACKSUB_WAVES"); return e ? atoi(e) : 3; }();   // waves per SIMD the register allocation aims at (trivial loss: 3 with 56 B of spills measured 0.901 ms per iteration against 0.925 at 2 without)
+  const int grid = std::min(P.n_fruns, wgs_env ? wgs_env : 256 * (wps == 3 && lk == 0 ? 3 : 2));
+#define THIP_BS(PD_, M_) do { \
+    if (wps == 3 && lk == 0) k_backsub_runs<PD_, 4, M_, 0, 3><<<grid, 256, 0, st>>>(P, pts, cand_pts, Vinv, tile_part); \
+    else if (lk == 0) k_backsub_runs<PD_, 4, M_, 0, 2><<<grid, 256, 0, st>>>(P, pts, cand_pts, Vinv, tile_part); \
+    else if (lk == 1) k_backsub_runs<PD_, 4, M_, 1, 2><<<grid, 256, 0, st>>>(P, pts, cand_pts, Vinv, tile_part); \
+    else k_backsub_runs<PD_, 4, M_, 2, 2><<<grid, 256, 0, st>>>(P, pts, cand_pts, Vinv, tile_part); } while (0)
+  if (P.pd == 3) { if (trig) THIP_BS(3, kModelsAll); else THIP_BS(3, kModelsNoTrig); }
+  else { if (trig) THIP_BS(4, kModelsAll); else THIP_BS(4, kModelsNoTrig); }
+#undef THIP_BS
+  return true;
 }
 
 }  // namespace thip

@@ -23,6 +23,7 @@
 // a step is valid iff the solve succeeded and its model-cost change is positive (else radius /= decrease_factor, five in a
 // row end the solve); parameter / function tolerance on the candidate; rho > 1e-3 accepts with
 // radius /= max(1/3, 1 - (2 rho - 1)^3); "if the optimization is a failure ... it won't change the parameters".
+#define THIP_LEAN_SINCOS 1 // ba_device.h: SphereManifold::Plus through polynomials for small steps (the point solves)
 #include "ba_kernels.h"
 #include "ba_device.h"
 #include "ba_priors.h"

@@ -93,7 +93,7 @@ struct DevProblem {
   int n_fruns;
   const FusedRun* fruns;
   const int* frun_order;       // [n_fruns] run indices, most expensive first: the order in which workgroups take runs
-  int* frun_next;              // work-queue head of k_lin_schur (zeroed by k_cam_prep before every launch)
+  int* frun_next;              // [2] work-queue heads of k_lin_schur / k_backsub_runs (zeroed by k_cam_prep before every launch)
   const int* frun_cams;
   const int* frun_stage;       // camera indices of the per-camera blocks a run stages in LDS (FusedRun::stage_off / nstage)
   const unsigned short* frun_tgt;
@@ -105,6 +105,7 @@ struct DevProblem {
   double* camrot;              // [nc][kCamRot] per-camera blocks at the linearisation point (k_cam_prep), null = not in use
   double* camrot_cand;         // the same for the candidate cameras of the trial step (back-substitution)
   double* camdir;              // [nc][12] the trial step of each camera as {D (3 x 3), v (3)} (camera_step_direction; k_cam_update)
+  int camrot_current;          // host-set per launch: camrot already holds the blocks of `cam` (launch_linearize_fused skips k_cam_prep)
   unsigned model_mask;         // bit m = some intrinsics group uses camera model m (picks the kernel instance)
   int fused_dbg;               // development switches (THEIA_HIP_FUSED_DBG): 1 = skip phase S, 2 = skip phase L arithmetic
   int n_sum_items;
@@ -192,6 +193,8 @@ void launch_linearize_fused_intr(const DevProblem& P, const double* cam, const d
 void launch_scatter_colsq(const DevProblem& P, const double* colsq_red, double* colsq_c, double* colsq_i, hipStream_t st);
 // per-camera blocks (rotation terms, masked scaling, intrinsics) of `cam` -> camrot (ba_fused.hip)
 void launch_cam_prep(const DevProblem& P, const double* cam, const double* intr, double* camrot, hipStream_t st, const double* ycam = nullptr);
+// K4 + K5 by persistent workgroups over the fused plan's runs (ba_fused.hip: k_backsub_runs); false = not applicable
+bool launch_backsub_runs(const DevProblem& P, const double* pts, double* cand_pts, const double* Vinv, double* tile_part, hipStream_t st);
 void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,
                          const int* field_is_max, double* scal, hipStream_t st, double* red_part = nullptr);
 // first stage of a two-stage reduction: kReduceBlocks workgroups fold contiguous slices of the per-tile partials into

@@ -17,6 +17,7 @@
 // (+ camera models), Ceres SchurEliminator semantics for the 3-group ordering of
 // bundle_adjuster.cc:547-577, Ceres LM diagonal (levenberg_marquardt_strategy.cc).
 #define THIP_LEAN_SQRT 1   // ba_device.h: fsqrt() without range scaling / class selects
+#define THIP_LEAN_SINCOS 1 // ba_device.h: SphereManifold::Plus through polynomials for small steps
 #include "ba_kernels.h"
 #include "ba_priors.h"
 
@@ -1559,6 +1560,7 @@ void launch_backsub(const DevProblem& P, const double* cam, const double* pts, c
   if (!P.ni && P.n_fruns > 0 && P.camrot && P.camrot_cand) {   // fused path: the state's blocks are in P.camrot already
     // (folding this into k_cam_update's single workgroup was slower: 26 us against 13 + 7)
     launch_cam_prep(P, cand_cam, P.intr, P.camrot_cand, st, ycc);   // + the cameras' steps as {D, v} (P.camdir)
+    if (launch_backsub_runs(P, pts, cand_pts, Vinv, tile_part, st)) return;   // round 5: per-run camera blocks in LDS, prefetched stream
     if (P.pd == 3) k_backsub<3, false, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
     else k_backsub<4, false, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
     return;

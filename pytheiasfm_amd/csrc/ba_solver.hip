@@ -233,6 +233,7 @@ struct theia_ba_handle_s {
   char* h_state = nullptr;   // pinned: LmState read-back
   int cur = 0;
   bool have_scale = false;
+  bool camrot_valid = false;     // P.camrot holds the per-camera blocks of the current state (k_lm_accept keeps it so on accepted steps)
   double fixed_cost = 0.0;
   theia_allreduce_fn allreduce = nullptr;
   void* allreduce_ctx = nullptr;
@@ -675,10 +676,14 @@ __global__ void k_lm_accept(const LmState* __restrict__ st, double* __restrict__
                             double* __restrict__ pts, const double* __restrict__ cand_pts, size_t npts,
                             double* __restrict__ intr, const double* __restrict__ cand_intr, size_t nintr,
                             const double* __restrict__ in_cam = nullptr, const double* __restrict__ in_pts = nullptr,
-                            const double* __restrict__ in_intr = nullptr) {
+                            const double* __restrict__ in_intr = nullptr, double* __restrict__ camrot = nullptr,
+                            const double* __restrict__ camrot_cand = nullptr, size_t ncamrot = 0) {
   if (!st->accepted) return;
   if (st->use_inner) { cand_cam = in_cam; cand_pts = in_pts; if (nintr) cand_intr = in_intr; }
   const size_t stride = (size_t)gridDim.x * blockDim.x;
+  // the candidate's per-camera blocks become the state's (enqueue_linearize then skips k_cam_prep); never with inner iterations
+  if (camrot && !st->use_inner)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncamrot; i += stride) camrot[i] = camrot_cand[i];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += stride) pts[i] = cand_pts[i];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncam; i += stride) cam[i] = cand_cam[i];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nintr; i += stride) intr[i] = cand_intr[i];
@@ -796,7 +801,7 @@ int upload_parameters(theia_ba_handle_s* h, const theia_ba_problem* p) {
   if (must_wait) HIP_TRY(hipStreamSynchronize(h->stream));
   h->cur = 0;
   h->P.intr = h->intr[0].p; h->P.intr_cand = h->intr[1].p;
-  h->have_scale = false;
+  h->have_scale = false; h->camrot_valid = false;
   return 0;
 }
 
@@ -861,7 +866,7 @@ int compute_scale(theia_ba_handle_s* h) {
   launch_make_scale((int)h->colsq_p0.n, h->colsq_p0.p, h->scale_p.p, h->stream);
   launch_make_scale((int)h->colsq_i0.n, h->colsq_i0.p, h->scale_i.p, h->stream);
   launch_build_scale_red(h->P, h->scale_red.p, h->stream);
-  h->have_scale = true;
+  h->have_scale = true; h->camrot_valid = false;   // (the blocks carry the Jacobi scaling of the extrinsics columns)
   return 0;
 }
 
@@ -878,7 +883,13 @@ int enqueue_linearize(theia_ba_handle_s* h, int slot = 0) {
   } else
     HIP_TRY(hipMemsetAsync(h->reduce.p, 0, sizeof(double) * h->reduce.n, h->stream));
   if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][4], h->stream));
+  // the state's per-camera blocks (k_cam_prep) are still current after the first body: an accepted step copies the candidate's
+  // blocks over them (k_lm_accept), a rejected one leaves the state where it was.  Not with inner iterations (the accepted
+  // point may be the swept one, and the sweep reuses the candidate's blocks) and not with free intrinsics.
+  const bool keep_blocks = h->use_fused && h->ni == 0 && !h->inner && !getenv("THEIA_HIP_CAM_PREP_ALWAYS");
+  h->P.camrot_current = keep_blocks && h->camrot_valid;
   launch_linearize(h->P, h->cam[h->cur].p, h->pts[h->cur].p, radius, h->rb, h->Vinv.p, h->gp.p, h->tile_part.p, h->stream);
+  h->camrot_valid = keep_blocks;
   if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][5], h->stream));
   // without an all-reduce (and without phase timing) the tile reduction rides in k_finalize_rcs: one launch less
   const bool fuse_reduce = !h->allreduce && slot < 0 && h->ntiles_main > 0;
@@ -2488,7 +2499,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
       auto cost = [&](int i) { const FusedRun& r = fplan.runs[i]; return (long long)r.ntiles * (64 + lanes_tgt * r.ntgt); };
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
       UP(frun_order, order);
-      AL(frun_next, 1);
+      AL(frun_next, 2);
     }
     fplan.stage.resize(std::max<size_t>(1, fplan.stage.size()));
     UP(fruns, fplan.runs); UP(frun_cams, fplan.cams); UP(frun_stage, fplan.stage); UP(frun_tgt, fplan.tgts); UP(obs_lc, fplan.obs_lc); UP(obs_tl, fplan.obs_tl);
@@ -2561,7 +2572,7 @@ int theia_hip_ba_restore_parameters(theia_ba_handle h) {
   }
   h->cur = 0;
   h->P.intr = h->intr[0].p; h->P.intr_cand = h->intr[1].p;
-  h->have_scale = false;
+  h->have_scale = false; h->camrot_valid = false;
   return 0;
 }
 
@@ -2821,7 +2832,8 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
     else k_lm_control<<<1, 1, 0, h->stream>>>(dst, h->rb.scal, h->scalB.p, dctl);
     k_lm_accept<<<256, 256, 0, h->stream>>>(dst, h->cam[0].p, h->cam[nxt].p, (size_t)6 * h->nc, h->pts[0].p, h->pts[nxt].p,
                                             (size_t)4 * h->np, h->intr[0].p, h->intr[nxt].p, h->ni ? (size_t)THEIA_MAX_INTRINSICS * h->ng : 0,
-                                            h->in_cam.p, h->in_pts.p, h->in_intr.p);
+                                            h->in_cam.p, h->in_pts.p, h->in_intr.p,
+                                            (h->use_fused && h->ni == 0 && !h->inner) ? h->camrot.p : nullptr, h->camrot_cand.p, (size_t)40 * h->nc);
     return 0;
   };
   // Phase timing (HIP events around the kernel groups) is opt-in: THEIA_HIP_PHASE_TIMING=1.
@@ -3024,6 +3036,7 @@ int theia_hip_ba_covariance(theia_ba_handle h, double* point_cov, double* cam_co
   const int pd = h->pd, NT = pd * (pd + 1) / 2;
   DevProblem Q = h->P;
   Q.scale_c = h->ones_c.p; Q.scale_p = h->ones_p.p; Q.scale_i = h->ones_i.p; Q.intr = h->intr[h->cur].p;
+  Q.camrot_current = 0; h->camrot_valid = false;   // (the per-camera blocks are rebuilt with the unit scales, and are the solve's no longer)
   LmState st;
   std::memset(&st, 0, sizeof(st));
   st.radius = 1e300;   // no LM damping: D = clamp(diag) / radius vanishes against the diagonal
