@@ -122,8 +122,37 @@ __device__ __forceinline__ void fusedi_phase_l(const DevProblem* __restrict__ Pp
     for (int b = 0; b <= a; ++b) tot[lidx(a, b)] = L.Jt[a] * L.Jt[b] + L.Jt[PD + a] * L.Jt[PD + b];
     tot[NT + a] = L.Jt[a] * L.r[0] + L.Jt[PD + a] * L.r[1];
   }
-  segment_allsum_log<NT + PD>(sg, lane, tot);
-  const unsigned tmask = segment_or_i(sg, lane, (active && lc != 0xffu) ? (1u << lc) : 0u);
+  unsigned tmask;
+  if constexpr (NT + PD + 1 <= RD - 2 * kBWP) {
+    // the track sums through the lanes' own record slots (round 5, as ba_fused.hip): the part of the record behind the camera
+    // rows is free until Ehat is written below; every lane of a track adds the slots of the track's lanes in lane order
+    // (broadcast reads) instead of 92 ds_bpermute of the log-step scans
+    constexpr int NS = NT + PD;
+    tmask = 0u;
+    double* mine = s_rec + (wv * 64 + lane) * RD + 2 * kBWP;
+#pragma unroll
+    for (int k = 0; k + 1 < NS; k += 2) *reinterpret_cast<double2*>(mine + k) = make_double2(tot[k], tot[k + 1]);
+    if constexpr (NS & 1) mine[NS - 1] = tot[NS - 1];
+    reinterpret_cast<unsigned*>(mine + NS)[0] = (active && lc != 0xffu) ? (1u << lc) : 0u;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) tot[k] = 0.0;
+    for (int j = 0; j < sg.maxlen; ++j) {   // wave-uniform trip count
+      const double* oth = s_rec + (wv * 64 + min(sg.start + j, 63)) * RD + 2 * kBWP;
+      double v[NS];
+#pragma unroll
+      for (int k = 0; k + 1 < NS; k += 2) { const double2 u = *reinterpret_cast<const double2*>(oth + k); v[k] = u.x; v[k + 1] = u.y; }
+      if constexpr (NS & 1) v[NS - 1] = oth[NS - 1];
+      const unsigned ob = reinterpret_cast<const unsigned*>(oth + NS)[0];
+      if (j < sg.len) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) tot[k] += v[k];
+        tmask |= ob;
+      }
+    }
+  } else {
+    segment_allsum_log<NT + PD>(sg, lane, tot);
+    tmask = segment_or_i(sg, lane, (active && lc != 0xffu) ? (1u << lc) : 0u);
+  }
   double V[NT], Vi[NT], g[PD];
 #pragma unroll
   for (int q = 0; q < NT; ++q) V[q] = tot[q];
@@ -226,11 +255,14 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
   if (tid == 0) s_P = P;
   const double inv_radius = 1.0 / *radius_p;
   const bool colnorm_only = (P.fused_dbg & 8) != 0;   // compute_scale: only the per-(camera, row) sums are read afterwards
+  int pending = 0;   // the run queue is popped one run ahead (the pop's round trip is off the path between two runs)
+  if (tid == 0) pending = atomicAdd(P.frun_next, 1);
   for (;;) {
     __syncthreads();
-    if (tid == 0) s_next = atomicAdd(P.frun_next, 1);
+    if (tid == 0) s_next = pending;
     __syncthreads();
     if (s_next >= P.n_fruns) break;
+    if (tid == 0) pending = atomicAdd(P.frun_next, 1);
     const FusedRun run = P.fruns[P.frun_order[s_next]];
     if (tid == 0) s_run = run;
     const int nsc = (run.ntiles + TPS - 1) / TPS;
@@ -246,6 +278,7 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
 
     for (int sc = 0; sc < nsc; ++sc) {
       fusedi_phase_l<PD, TPS, MODELS, KMASK>(&s_P, &s_run, pts, inv_radius, sc, Vinv, tile_part, s_rec, s_tslot, s_tmask);
+      __builtin_amdgcn_s_setprio(1);   // phase S is pure issue, phase L a chain of latencies: S first, L fills the gaps (ba_fused.hip)
       __syncthreads();
       {
         // ---- phase-S role (recomputed per sub-chunk: a dozen integers that need not stay in registers across phase L).  lix = lane index inside the track slice this lane serves: target block lix / NS, rows
@@ -336,6 +369,7 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
           }
         }
       }
+      __builtin_amdgcn_s_setprio(0);
       __syncthreads();
     }
     // ---- combine the track slices in a fixed order; the first replica of a lane role writes the rows it owns
