@@ -29,7 +29,7 @@ import numpy as np  # noqa: E402
 ITERS_PER_SOLVE = 8      # LM iterations per solve from the perturbed start (tolerances off: exactly this many)
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = FP64 matrix peak (half of the guide's 157.3 TF FP32 vector rate)
-PROFILE_TAG = "r4"       # committed rocprofv3 PMC passes of this command: profiles/<tag>_pmc_{fetch,write}_size.csv
+PROFILE_TAG = "r5"       # committed rocprofv3 PMC passes of this command: profiles/<tag>_pmc_{fetch,write}_size.csv
 
 
 def bench_options(ba, max_iters):
@@ -424,10 +424,11 @@ def main():
                        "baseline_config": "BASELINE.json configs[3] (north_star target configuration) on %d GPU%s" % (world, "" if world == 1 else "s"),
                        "reduced_system_n": info["n"], "k3_levels": info["k3_levels"], "fused_kernel_runs": info["fused_runs"],
                        "slow_path_tracks": info["slow_path_tracks"]},
-            "roofline": {"kernel": "linearize + Schur assembly launch group (k_cam_prep + k_lin_schur + k_schur_sum)",
+            "roofline": {"kernel": "linearize + Schur assembly launch group (k_lin_schur + k_schur_sum; k_cam_prep only on the first launch of a solve)",
                          "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(world),
+                         # counters collected on other kernel sources than the tree's are not this kernel's traffic: refused (null)
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic_bytes(world) if counters_stale() is False else None,
                          "traffic_source": "profiles/%s_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command, committed)" % PROFILE_TAG,
                          "traffic_source_stale": counters_stale(),   # True: the kernels changed since those passes
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": 1e3 * avg_lin,
