@@ -292,8 +292,7 @@ class HostTeam {
   std::atomic<int> next_{0};
   uint64_t gen_ = 0;
   pid_t pid_ = 0;
-  void worker(int id) {
-    uint64_t seen = 0;
+  void worker(int id, uint64_t seen) {    // seen: the generation at the worker's creation (it waits for the next one)
     for (;;) {
       const std::function<void(int)>* job;
       {
@@ -314,11 +313,22 @@ class HostTeam {
     std::unique_lock<std::mutex> use(use_, std::try_to_lock);
     if (!use.owns_lock()) return false;
     if (pid_ != getpid()) {              // first use, or the child of a fork: the parent's threads do not exist here, and
-      if (!workers_.empty()) new (&workers_) std::vector<std::thread>();   // their handles can be neither joined nor detached
+      if (!workers_.empty()) {           // their handles can be neither joined nor detached.  The region state is the
+        new (&workers_) std::vector<std::thread>();   // parent's too: a worker started against a stale generation would run
+        new (&mu_) std::mutex();         // an empty region and count itself out of the next one (and mu_ may have been
+        new (&work_) std::condition_variable();       // held by a parent thread at the fork)
+        new (&done_) std::condition_variable();
+        job_ = nullptr; nparts_ = 0; wanted_ = 0; active_ = 0; gen_ = 0;
+        next_.store(0, std::memory_order_relaxed);
+      }
       pid_ = getpid();
     }
     const int helpers = (int)cap - 1;
-    while ((int)workers_.size() < helpers) { const int id = (int)workers_.size(); workers_.emplace_back([this, id] { worker(id); }); }
+    if ((int)workers_.size() < helpers) {
+      std::lock_guard<std::mutex> lk(mu_);   // new workers take the current generation as already seen
+      const uint64_t g = gen_;
+      while ((int)workers_.size() < helpers) { const int id = (int)workers_.size(); workers_.emplace_back([this, id, g] { worker(id, g); }); }
+    }
     {
       std::lock_guard<std::mutex> lk(mu_);
       job_ = &fn; nparts_ = nparts; wanted_ = helpers; active_ = helpers;
@@ -768,6 +778,15 @@ void fill_devproblem(theia_ba_handle_s* h) {
   P.pt_sum_cnt = h->n_trk_sums ? h->pt_sum_cnt.p : nullptr; P.sum_group = h->n_trk_sums ? h->sum_group.p : nullptr; P.sum_base = h->sum_base;
 }
 
+// create()'s staged uploads sit in pinned blocks of the handle's arena until the stream is known to have passed them: every
+// entry point lets them go as soon as the stream is idle (a handle used only for evaluation, covariances or reset never
+// reaches the end of a run(), which is where they were released before)
+void release_stage_if_idle(theia_ba_handle_s* h) {
+  if (h->stage.blocks.empty()) return;
+  if (hipStreamQuery(h->stream) == hipSuccess) h->stage.release();
+  else (void)hipGetLastError();   // hipErrorNotReady: still copying
+}
+
 int upload_parameters(theia_ba_handle_s* h, const theia_ba_problem* p) {
   // Inside create() (a staging arena on this stream): the caller's arrays are copied into pinned blocks on host threads and
   // uploaded from there, nothing waits.  Otherwise (reset_parameters): pageable sources, the stream is waited for.
@@ -777,12 +796,15 @@ int upload_parameters(theia_ba_handle_s* h, const theia_ba_problem* p) {
   auto up = [&](double* dst0, double* dst1, const double* src, size_t count) -> int {
     if (!count) return 0;
     const double* from = src;
-    double* st = staged ? static_cast<double*>(a->reserve(count * sizeof(double))) : nullptr;
+    // (staged up to 64 MB per array -- C4's points are 16 MB; larger arrays go from the caller's memory and are waited for,
+    // like DevBuf::upload's cap: pinned blocks count against the 2 GiB pinned cache until the arena is released)
+    const bool fits = count * sizeof(double) <= ((size_t)64 << 20);
+    double* st = (staged && fits) ? static_cast<double*>(a->reserve(count * sizeof(double))) : nullptr;
     if (st) {
       host_chunks((int64_t)count, [&](int64_t i0, int64_t i1) { std::memcpy(st + i0, src + i0, sizeof(double) * (size_t)(i1 - i0)); });
       from = st;
     } else {
-      if (staged) (void)hipGetLastError();   // the host does not pin that much: the caller's array is the source, and is waited for
+      if (staged && fits) (void)hipGetLastError();   // the host does not pin that much: the caller's array is the source, and is waited for
       must_wait = true;
     }
     HIP_TRY(hipMemcpyAsync(dst0, from, sizeof(double) * count, hipMemcpyHostToDevice, h->stream));
@@ -2538,6 +2560,7 @@ int theia_hip_ba_reset_parameters(theia_ba_handle h, const theia_ba_problem* p) 
   if (h->idh) return thip::id_handle_reset(h->idh, p);
   if (p->num_cameras != h->nc || p->num_points != h->np || p->num_groups != h->ng)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "problem shape differs from the handle's");
+  release_stage_if_idle(h);
   return upload_parameters(h, p);
 }
 
@@ -2551,6 +2574,7 @@ int theia_hip_ba_set_shard(theia_ba_handle h, int32_t rank, int32_t world_size) 
 int theia_hip_ba_snapshot_parameters(theia_ba_handle h) {
   if (h && h->idh) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse-depth handle: snapshot is not built in this mode");
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
+  release_stage_if_idle(h);
   int rc;
   if ((rc = h->snap_cam.alloc(h->cam[0].n)) || (rc = h->snap_pts.alloc(h->pts[0].n)) || (rc = h->snap_intr.alloc(h->intr[0].n))) return rc;
   const int c = h->cur;
@@ -2565,6 +2589,7 @@ int theia_hip_ba_restore_parameters(theia_ba_handle h) {
   if (h && h->idh) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse-depth handle: restore is not built in this mode");
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
   if (!h->has_snapshot) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "no snapshot taken on this handle");
+  release_stage_if_idle(h);
   for (int k = 0; k < 2; ++k) {
     if (h->cam[k].n) HIP_TRY(hipMemcpyAsync(h->cam[k].p, h->snap_cam.p, sizeof(double) * h->cam[k].n, hipMemcpyDeviceToDevice, h->stream));
     if (h->pts[k].n) HIP_TRY(hipMemcpyAsync(h->pts[k].p, h->snap_pts.p, sizeof(double) * h->pts[k].n, hipMemcpyDeviceToDevice, h->stream));
@@ -2695,6 +2720,7 @@ int theia_hip_ba_download(theia_ba_handle h, theia_ba_problem* p) {
   if (h->idh) return thip::id_handle_download(h->idh, p);
   // caller-owned (pageable) destinations: drain the stream, then blocking copies
   HIP_TRY(hipStreamSynchronize(h->stream));
+  h->stage.release();
   if (h->nc) HIP_TRY(hipMemcpy(p->cam_ext, h->cam[h->cur].p, sizeof(double) * 6 * h->nc, hipMemcpyDeviceToHost));
   if (h->np) HIP_TRY(hipMemcpy(p->points, h->pts[h->cur].p, sizeof(double) * 4 * h->np, hipMemcpyDeviceToHost));
   if (h->ng && h->ni) HIP_TRY(hipMemcpy(p->intrinsics, h->intr[h->cur].p, sizeof(double) * THEIA_MAX_INTRINSICS * h->ng, hipMemcpyDeviceToHost));
@@ -2712,6 +2738,7 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
   if (!h || !S) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (h->idh) return thip::id_handle_run(h->idh, &h->opt, S);
   debug_sticky("run entry");
+  release_stage_if_idle(h);   // (a previous run() that returned early with an error did not reach its release)
   const theia_ba_options& O = h->opt;
   const double t_start = now_s();
   S->trace_size = 0; S->success = 0; S->num_iterations = 0; S->num_successful_steps = 0;
@@ -2966,6 +2993,7 @@ int theia_hip_ba_evaluate_ex(theia_ba_handle h, double* cost, double* residuals,
                              double* jac_intr, uint8_t* valid) {
   if (h && h->idh) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse-depth handle: evaluate is not built in this mode");
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
+  release_stage_if_idle(h);
   const int pd = h->pd;
   DevBuf<double> dr, djc, djp, dji; DevBuf<uint8_t> dv;
   int rc;
@@ -3006,6 +3034,7 @@ int theia_hip_ba_evaluate_ex(theia_ba_handle h, double* cost, double* residuals,
     if (jac_pt) std::copy(&hjp[2 * pd * s], &hjp[2 * pd * s] + 2 * pd, jac_pt + 2 * pd * i);
     if (valid) valid[i] = hv[s];
   }
+  release_stage_if_idle(h);
   return 0;
 }
 
@@ -3017,6 +3046,7 @@ int theia_hip_ba_evaluate_ex(theia_ba_handle h, double* cost, double* residuals,
 int theia_hip_ba_covariance(theia_ba_handle h, double* point_cov, double* cam_cov) {
   if (h && h->idh) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse-depth handle: covariance is not built in this mode");
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
+  release_stage_if_idle(h);
   if (!point_cov && !cam_cov) return 0;
   // Optimised intrinsics couple the cameras of a group: J'J of the views problem is an arrow, not block diagonal, and the
   // extrinsics blocks of its inverse need the whole factor (dense, on the host: a *WithCov call covers a handful of views).
@@ -3098,6 +3128,7 @@ int theia_hip_ba_covariance(theia_ba_handle h, double* point_cov, double* cam_co
             cam_cov[(size_t)c * 36 + a * 6 + b] = v;
           }
       }
+      release_stage_if_idle(h);
       return 0;
     }
     for (int c = 0; c < h->nc; ++c) {
@@ -3130,6 +3161,7 @@ int theia_hip_ba_covariance(theia_ba_handle h, double* point_cov, double* cam_co
         }
     }
   }
+  release_stage_if_idle(h);
   return 0;
 }
 

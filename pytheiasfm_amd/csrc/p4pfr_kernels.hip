@@ -438,13 +438,14 @@ constexpr int kEigX = 16 + kBasis * (kModel + 1);          // the work array X o
 constexpr int kEigLds = 2 * kBasis * kBasis + kEigX + 3 * kBasis;
 __global__ __launch_bounds__(64) void k_p4pfr_b(size_t nhyp, int B, const int* __restrict__ active_iters, const double* __restrict__ ws,
                                                 double max_f, double min_f, double max_d, double min_d, double* __restrict__ models,
-                                                int* __restrict__ counts, int* __restrict__ dense_count, int* __restrict__ tags, int* __restrict__ hyp_base) {
+                                                int* __restrict__ counts, int* __restrict__ dense_count, int* __restrict__ tags, int* __restrict__ hyp_base,
+                                                int* __restrict__ solver_counts) {
   __shared__ double lds[kTeamsPerWave][kEigLds];
   const int team = threadIdx.x / kTeam, tl = threadIdx.x % kTeam;
   const size_t hyp = (size_t)blockIdx.x * kTeamsPerWave + team;
   if (hyp >= nhyp) return;
   const int p = (int)(hyp / B), b = (int)(hyp % B);
-  if (b >= active_iters[p]) { if (tl == 0) counts[hyp] = 0; return; }
+  if (b >= active_iters[p]) { if (tl == 0) { counts[hyp] = 0; if (solver_counts) solver_counts[hyp] = 0; } return; }
   const double* w = ws + hyp * kWs;
   constexpr int n = kBasis;
   double* H = lds[team]; double* V = H + n * n; double* Xw = V + n * n; double* wr = Xw + kEigX; double* wi = wr + n; double* ort = wi + n;
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(64) void k_p4pfr_b(size_t nhyp, int B, const int* _
   rsc::team_sync();
   const bool good = rsc::eig_team<kTeam, true>(n, H, V, Xw, wr, wi, ort, tl);
   rsc::team_sync();
-  if (!good) { if (tl == 0) counts[hyp] = 0; return; }
+  if (!good) { if (tl == 0) { counts[hyp] = 0; if (solver_counts) solver_counts[hyp] = 0; } return; }
   // helper.cc:1384-1408: columns over their first row, |Im a1| <= 1e-6, real parts (EigenSolver::eigenvectors(): a column is real
   // when |Im lambda| <= 1e-12 |Re lambda| or it is the last one, else columns j, j + 1 are re +- i im; each normalised).  The
   // thirteen candidates -- slot k = real column k, or the first / second member of the pair that covers column k -- are dealt to
@@ -488,6 +489,7 @@ __global__ __launch_bounds__(64) void k_p4pfr_b(size_t nhyp, int B, const int* _
       else rsc::eig_cdiv(xr, xi, v0r, v0i, &re[q], &im[q]);
     }
     if (im[0] < -1e-6 || im[0] > 1e-6) continue;
+    out[0] = 2.0;   // one of the solver's valid_solutions (the function's return value counts these, :287); 1.0 below = kept
     // four_point_focal_length_radial_distortion.cc:219-285
     const double kk = re[2], P33 = re[3];
     const double alpha[4] = {re[0], re[1], wr[j], 1.0};
@@ -528,9 +530,10 @@ __global__ __launch_bounds__(64) void k_p4pfr_b(size_t nhyp, int B, const int* _
   }
   rsc::team_sync();
   if (tl != 0) return;
-  int nm = 0;
-  for (int k = 0; k < n; ++k) nm += slot[(kModel + 1) * k] != 0.0;
+  int nm = 0, nsolver = 0;
+  for (int k = 0; k < n; ++k) { nm += slot[(kModel + 1) * k] == 1.0; nsolver += slot[(kModel + 1) * k] != 0.0; }
   counts[hyp] = nm;
+  if (solver_counts) solver_counts[hyp] = nsolver;
   if (nm == 0) return;
   const int base = atomicAdd(&dense_count[p], nm);
   hyp_base[hyp] = base;
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(64) void k_p4pfr_b(size_t nhyp, int B, const int* _
   int jm = 0;
   for (int k = 0; k < n; ++k) {
     const double* sl = slot + (kModel + 1) * k;
-    if (sl[0] == 0.0) continue;
+    if (sl[0] != 1.0) continue;
     double* m = mo + (size_t)jm * THEIA_RANSAC_MODEL_STRIDE;
     for (int q = 0; q < kModel; ++q) m[q] = sl[1 + q];
     for (int q = kModel; q < THEIA_RANSAC_MODEL_STRIDE; ++q) m[q] = 0.0;
@@ -629,13 +632,13 @@ void p4pfr_rotation_from_draws(const double* v, double* R) {
 
 void launch_p4pfr_fit(int nprob, int B, const int64_t* offsets, const double* data, const int* samples, const int* active_iters,
                       const double* rot, const double* limits, double* ws, double* models, int* counts, int* dense_count, int* tags,
-                      int* hyp_base, hipStream_t st) {
+                      int* hyp_base, hipStream_t st, int* solver_counts) {
   using namespace p4pfrdev;
   const size_t nh = (size_t)nprob * B;
   k_p4pfr_pre<<<dim3((B + 63) / 64, nprob), 64, 0, st>>>(nprob, B, offsets, data, samples, active_iters, rot, ws);
   k_p4pfr_a<<<dim3(B, nprob), 64, 0, st>>>(B, active_iters, ws);
   k_p4pfr_b<<<(unsigned)((nh + kTeamsPerWave - 1) / kTeamsPerWave), 64, 0, st>>>(nh, B, active_iters, ws, limits[0], limits[1], limits[2], limits[3],
-                                                                               models, counts, dense_count, tags, hyp_base);
+                                                                               models, counts, dense_count, tags, hyp_base, solver_counts);
 }
 
 }  // namespace thip

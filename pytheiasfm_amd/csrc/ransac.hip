@@ -2100,7 +2100,7 @@ int theia_hip_four_point_pose_and_focal_length(int32_t num, const double* corr2d
 }
 
 int theia_hip_four_point_focal_length_radial_distortion(int32_t num, const double* corr2d3d, const double* limits, const double* rotation_draws,
-                                                        double* models, int32_t* num_solutions) {
+                                                        double* models, int32_t* num_solutions, int32_t* num_solver_solutions) {
   if (num < 0 || !limits || (num > 0 && (!corr2d3d || !models || !num_solutions))) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
   if (!(limits[1] >= 0.0 && limits[0] >= 0.0 && limits[0] >= limits[1] && limits[2] <= 0.0 && limits[3] <= 0.0 && limits[2] <= limits[3]))
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "P4Pfr: needs 0 <= min focal length <= max focal length and max distortion <= min distortion <= 0");
@@ -2113,8 +2113,9 @@ int theia_hip_four_point_focal_length_radial_distortion(int32_t num, const doubl
   CallSync mine;
   // one problem of four data per call row, one hypothesis each with the identity sample: the RANSAC stages as they are
   constexpr int kMm = 13, kMd = 14;
-  DBuf<double> dc, dws, dmod, drot; DBuf<int> dn, dsamp, dact, ddense, dtags, dbase; DBuf<int64_t> doff;
+  DBuf<double> dc, dws, dmod, drot; DBuf<int> dn, dsamp, dact, ddense, dtags, dbase, dsolver; DBuf<int64_t> doff;
   const size_t n = (size_t)num;
+  if ((rc = dsolver.ensure(n))) return rc;
   if ((rc = dc.ensure(n * 20)) || (rc = dws.ensure(n * (size_t)p4pfr_workspace_doubles())) || (rc = dmod.ensure(n * kMm * kStride)) || (rc = drot.ensure(n * 9)) ||
       (rc = dn.ensure(n)) || (rc = dsamp.ensure(n * 4)) || (rc = dact.ensure(n)) || (rc = ddense.ensure(n)) || (rc = dtags.ensure(n * kMm)) ||
       (rc = dbase.ensure(n)) || (rc = doff.ensure(n + 1)))
@@ -2138,7 +2139,8 @@ int theia_hip_four_point_focal_length_radial_distortion(int32_t num, const doubl
   HIP_TRYR(hipMemcpyAsync(drot.p, rot.data(), sizeof(double) * n * 9, hipMemcpyHostToDevice, st));
   HIP_TRYR(hipMemsetAsync(ddense.p, 0, sizeof(int) * n, st));
   HIP_TRYR(hipMemsetAsync(dmod.p, 0, sizeof(double) * n * kMm * kStride, st));
-  launch_p4pfr_fit(num, 1, doff.p, dc.p, dsamp.p, dact.p, drot.p, limits, dws.p, dmod.p, dn.p, ddense.p, dtags.p, dbase.p, st);
+  launch_p4pfr_fit(num, 1, doff.p, dc.p, dsamp.p, dact.p, drot.p, limits, dws.p, dmod.p, dn.p, ddense.p, dtags.p, dbase.p, st, dsolver.p);
+  if (num_solver_solutions) HIP_TRYR(hipMemcpyAsync(num_solver_solutions, dsolver.p, sizeof(int) * n, hipMemcpyDeviceToHost, st));
   std::vector<double> hm(n * kMm * kStride);
   HIP_TRYR(hipMemcpyAsync(hm.data(), dmod.p, sizeof(double) * hm.size(), hipMemcpyDeviceToHost, st));
   HIP_TRYR(hipMemcpyAsync(num_solutions, dn.p, sizeof(int) * n, hipMemcpyDeviceToHost, st));

@@ -111,9 +111,20 @@ __global__ __launch_bounds__(256) void k_sp_potrf_trsm(double* __restrict__ A, i
   const int* it = trsm_items + 5 * (blockIdx.x - npotrf);
   const int row0 = it[0], h = it[1], k0 = it[2], nb = it[3];
   const int tid = threadIdx.x;
+  // the tile P is fetched before the factorisation and parked in registers: its HBM latency hides behind the panel chain
+  double pv[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int t = tid + 256 * q, r = t >> 6, c = t & 63;
+    pv[q] = A[(size_t)(row0 + min(r, h - 1)) * lda + k0 + min(c, nb - 1)];
+  }
   potrf64_wg_core<false>(A, lda, k0, nb, Ls, Zs, rdiag, nullptr, nullptr);
   __syncthreads();
-  load_tile(Ls, A, lda, row0, h, k0, nb, tid);   // P
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int t = tid + 256 * q, r = t >> 6, c = t & 63;
+    Ls[r][c] = (r < h && c < nb) ? pv[q] : 0.0;
+  }
   __syncthreads();
   const int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   if (16 * wv >= h) return;

@@ -52,7 +52,7 @@ int p4pfr_workspace_doubles();
 void p4pfr_rotation_from_draws(const double* v, double* R);
 void launch_p4pfr_fit(int nprob, int B, const int64_t* offsets, const double* data, const int* samples, const int* active_iters,
                       const double* rot, const double* limits, double* ws, double* models, int* counts, int* dense_count, int* tags,
-                      int* hyp_base, hipStream_t st);
+                      int* hyp_base, hipStream_t st, int* solver_counts = nullptr);   // solver_counts[hyp]: solutions before the range tests
 // ba_invdepth.hip: bundle adjustment with the inverse-depth track parametrisation (THEIA_BA_FLAG_INVERSE_DEPTH)
 int ba_solve_inverse_depth(const theia_ba_problem* p, const theia_ba_options* o, theia_ba_summary* S);
 // the same problem as a device-resident object behind the handle API (theia_hip_ba_create with THEIA_BA_FLAG_INVERSE_DEPTH)

@@ -11,6 +11,8 @@ import pytest
 from pytheiasfm_amd import _capi as capi, sfm, synth
 from tests import oracle_lib as ol
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def digest(*arrays):
     h = hashlib.sha256()
@@ -348,3 +350,37 @@ def test_problem_fingerprint_separates_topology_from_parameters():
     if o is not None:
         o2 = ba.default_options(); o2.max_num_iterations = o.max_num_iterations + 1
         assert ba.problem_fingerprint(p, o2) != k0
+
+
+def test_host_thread_team_survives_a_fork():
+    """ba_solver.hip HostTeam: the worker threads of the parent do not exist in a fork child, and the region state
+    (generation, worker count, active count) must not be inherited either.  The validation pass of create() runs its
+    observation scan on the team (THEIA_HIP_HOST_CHUNK_MIN lowers the size at which it does) before any device call, so it
+    is reachable without a GPU: the parent runs it, forks, and the child runs it again -- with an out-of-range index in the
+    LAST part, which only a complete parallel region finds."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        os.environ["THEIA_HIP_HOST_CHUNK_MIN"] = "64"; os.environ["THEIA_HIP_HOST_THREADS"] = "6"
+        from pytheiasfm_amd import ba, _capi as capi, synth
+        p = synth.synth_ba_v1(8, 400, seed=3)
+        def create(q):
+            try:
+                ba.BaHandle(q, ba.default_options()).close()
+                return "ok"
+            except capi.TheiaHipError as e:
+                return str(e)
+        first = create(p)                       # parent: the team's workers start here
+        bad = p.copy(); bad.obs_cam = bad.obs_cam.copy(); bad.obs_cam[-1] = 10 ** 6
+        pid = os.fork()
+        if pid == 0:
+            msgs = [create(bad) for _ in range(3)] + [create(p)]
+            ok = all("out of range" in m for m in msgs[:3]) and msgs[3] == first
+            os._exit(0 if ok else 3)
+        _, status = os.waitpid(pid, 0)
+        again = create(bad)
+        sys.exit(0 if (os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0 and "out of range" in again) else 4)
+        """ % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], timeout=120, capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout[-400:], r.stderr[-400:])

@@ -57,6 +57,23 @@ def test_single_problem_binding_on_the_reference_scene():
     assert np.abs(Rs[j] - R).max() < 1e-8 and np.abs(ts[j] - t).max() < 1e-7 and abs(fs[j] - sc.FOCAL) < 1e-5 and abs(ks[j] / sc.DISTORTION - 1) < 1e-3
 
 
+def test_success_counts_the_solver_solutions_before_the_range_tests():
+    """four_point_focal_length_radial_distortion.cc:287 returns valid_solutions.size() > 0 -- the solver's count BEFORE the
+    focal-length / distortion range tests -- so limits that reject every solution still report success, with empty outputs
+    (ADVICE r4); the count after the tests stays what the batched form returns."""
+    f, W, R, t = sc.solver_scene("basic")
+    wide = ransac.RadialDistUncalibratedAbsolutePoseMetaData(min_focal_length=0.0, max_focal_length=2000.0, min_radial_distortion=-1e-10,
+                                                             max_radial_distortion=-1e-5)
+    none = ransac.RadialDistUncalibratedAbsolutePoseMetaData(min_focal_length=1e-6, max_focal_length=2e-6, min_radial_distortion=-1e-10,
+                                                             max_radial_distortion=-1e-5)
+    ok, Rs, ts, ks, fs = ransac.FourPointsPoseFocalLengthRadialDistortion(f, W, wide)
+    assert ok and len(Rs) > 0
+    ok2, Rs2, ts2, ks2, fs2 = ransac.FourPointsPoseFocalLengthRadialDistortion(f, W, none)
+    assert ok2 and Rs2 == [] and ts2 == [] and ks2 == [] and fs2 == []
+    ns, M = ransac.FourPointsPoseFocalLengthRadialDistortion(f[None], W[None], none)
+    assert int(ns[0]) == 0 and not M.any()
+
+
 def _batch(nprob, seed, ratio=0.75, noise=0.5):
     rng = np.random.default_rng(seed)
     data, offsets, truth = [], [0], []
