@@ -894,21 +894,53 @@ __global__ void k_build_scale_red(DevProblem P, double* __restrict__ scale_red) 
 
 // candidate cameras and intrinsics: x + (-y) * scale (intrinsics projected onto
 // their bounds, bundle_adjuster.cc:406-427); their |step|^2 and |x+|^2.
-__global__ void k_cam_update(DevProblem P, const double* __restrict__ cam, const double* __restrict__ y,
+// one extrinsics component of the candidate camera: the state's, or state + (-y) * scale on a free column
+THIP_DEV double cand_ext_component(const DevProblem& P, int c, int rc, int q, double x, const double* __restrict__ yc) {
+  if (rc >= 0 && !((P.cam_mask[c] >> q) & 1u)) return __builtin_fma(-yc[6 * rc + q], P.scale_c[6 * c + q], x);
+  return x;
+}
+
+// PREP (fused path without intrinsics): the workgroups behind the first one write the candidate's per-camera blocks
+// (P.camrot_cand) and the cameras' steps as {D, v} (P.camdir) -- what a k_cam_prep launch on the candidate did next on the
+// stream, from the SAME candidate components (cand_ext_component), so the two launches' work runs side by side: one launch
+// and its dependent boundary less per iteration.  (Folding that work into the single reducing workgroup was slower: 26 us
+// against 13 + 7.)
+template <bool PREP>
+__global__ __launch_bounds__(1024) void k_cam_update(DevProblem P, const double* __restrict__ cam, const double* __restrict__ y,
                              double* __restrict__ cand, double* __restrict__ cand_intr,
                              double* __restrict__ out_stepsq, double* __restrict__ out_xnormsq,
                              double* __restrict__ zero16) {
+  const double* yc = y + P.ni;
+  if constexpr (PREP) {
+    if (blockIdx.x > 0) {
+      if (threadIdx.x >= 256) return;   // 256 cameras per workgroup, as k_cam_prep: the blocks spread over the CUs
+      const int c = (blockIdx.x - 1) * 256 + threadIdx.x;
+      if (c == 0 && P.frun_next) { P.frun_next[0] = 0; P.frun_next[1] = 0; }   // (as k_cam_prep: heads of the run queues)
+      if (c >= P.nc) return;
+      const int rc = P.cam_red[c];
+      double xp[6], dl[6];
+      for (int q = 0; q < 6; ++q) {
+        const double x = cam[6 * c + q];
+        xp[q] = cand_ext_component(P, c, rc, q, x, yc);
+        dl[q] = (rc >= 0 && !((P.cam_mask[c] >> q) & 1u)) ? (-yc[6 * rc + q]) * P.scale_c[6 * c + q] : 0.0;
+      }
+      cam_prep_one(P, c, xp, P.intr, P.camrot_cand);
+      double ext[6], out[12];
+      RotTerms rt;
+      camrot_load(P.camrot + (size_t)kCamRot * c, ext, rt);
+      camera_step_direction(ext + 3, rt, dl, dl + 3, out);
+      for (int k = 0; k < 12; ++k) P.camdir[(size_t)12 * c + k] = out[k];
+      return;
+    }
+  }
   __shared__ double s1[1024], s2[1024];
   double st = 0.0, xn = 0.0;
-  const double* yc = y + P.ni;
   for (int c = threadIdx.x; c < P.nc; c += blockDim.x) {
     const int rc = P.cam_red[c];
     for (int q = 0; q < 6; ++q) {
       const double x = cam[6 * c + q];
-      double xp = x;
+      const double xp = cand_ext_component(P, c, rc, q, x, yc);
       if (rc >= 0) {
-        const unsigned mask = P.cam_mask[c];
-        if (!((mask >> q) & 1u)) xp = x + (-yc[6 * rc + q]) * P.scale_c[6 * c + q];
         st += (x - xp) * (x - xp);
         xn += xp * xp;
       }
@@ -1546,9 +1578,15 @@ void launch_finalize_rcs(const DevProblem& P, const double* radius, const Reduce
                                                                      tile_cls, want_cls);
 }
 
+// true when launch_cam_update writes the candidate's per-camera blocks itself (launch_backsub then skips its k_cam_prep)
+static bool cam_update_preps(const DevProblem& P) {
+  return !P.ni && P.n_fruns > 0 && P.camrot && P.camrot_cand && P.camdir && P.ntiles > 0 && !getenv("THEIA_HIP_CAM_PREP_SEPARATE");
+}
+
 void launch_cam_update(const DevProblem& P, const double* cam, const double* y, double* cand_cam,
                        double* cand_intr, double* out_stepsq, double* out_xnormsq, hipStream_t st, double* zero16) {
-  k_cam_update<<<1, 1024, 0, st>>>(P, cam, y, cand_cam, cand_intr, out_stepsq, out_xnormsq, zero16);
+  if (cam_update_preps(P)) k_cam_update<true><<<1 + (P.nc + 255) / 256, 1024, 0, st>>>(P, cam, y, cand_cam, cand_intr, out_stepsq, out_xnormsq, zero16);
+  else k_cam_update<false><<<1, 1024, 0, st>>>(P, cam, y, cand_cam, cand_intr, out_stepsq, out_xnormsq, zero16);
 }
 
 void launch_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,
@@ -1558,8 +1596,8 @@ void launch_backsub(const DevProblem& P, const double* cam, const double* pts, c
   if (P.ntiles == 0) return;
   const double* ycc = yc + P.ni;  // camera part of the solution
   if (!P.ni && P.n_fruns > 0 && P.camrot && P.camrot_cand) {   // fused path: the state's blocks are in P.camrot already
-    // (folding this into k_cam_update's single workgroup was slower: 26 us against 13 + 7)
-    launch_cam_prep(P, cand_cam, P.intr, P.camrot_cand, st, ycc);   // + the cameras' steps as {D, v} (P.camdir)
+    // the candidate's blocks + the cameras' steps as {D, v} (P.camdir): written by launch_cam_update's extra workgroups
+    if (!cam_update_preps(P)) launch_cam_prep(P, cand_cam, P.intr, P.camrot_cand, st, ycc);
     if (launch_backsub_runs(P, pts, cand_pts, Vinv, tile_part, st)) return;   // round 5: per-run camera blocks in LDS, prefetched stream
     if (P.pd == 3) k_backsub<3, false, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
     else k_backsub<4, false, true><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);

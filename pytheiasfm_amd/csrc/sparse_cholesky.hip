@@ -108,82 +108,96 @@ __global__ __launch_bounds__(256) void k_sp_potrf_trsm(double* __restrict__ A, i
     potrf64_wg_core<false>(A, lda, it[0], it[1], Ls, Zs, rdiag, Linv + (size_t)it[2] * NB * NB, fail_flag);
     return;
   }
-  const int* it = trsm_items + 5 * (blockIdx.x - npotrf);
+  // FOUR workgroups per tile, 16 of its rows each (wave = 16 of the 64 columns): the 64 x 64 x 64 product would keep this
+  // CU's matrix cores busy for 4096 cycles behind the factorisation (k_sp_update has the arithmetic)
+  const int* it = trsm_items + 5 * ((blockIdx.x - npotrf) >> 2);
+  const int rb = (blockIdx.x - npotrf) & 3;
   const int row0 = it[0], h = it[1], k0 = it[2], nb = it[3];
+  if (16 * rb >= h) return;
   const int tid = threadIdx.x;
-  // the tile P is fetched before the factorisation and parked in registers: its HBM latency hides behind the panel chain
-  double pv[16];
+  // the workgroup's rows of P are fetched before the factorisation and parked in registers: their HBM latency hides behind
+  // the panel chain
+  double pv[4];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int t = tid + 256 * q, r = t >> 6, c = t & 63;
+  for (int q = 0; q < 4; ++q) {
+    const int t = tid + 256 * q, r = 16 * rb + (t >> 6), c = t & 63;
     pv[q] = A[(size_t)(row0 + min(r, h - 1)) * lda + k0 + min(c, nb - 1)];
   }
   potrf64_wg_core<false>(A, lda, k0, nb, Ls, Zs, rdiag, nullptr, nullptr);
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
+  for (int q = 0; q < 4; ++q) {
     const int t = tid + 256 * q, r = t >> 6, c = t & 63;
-    Ls[r][c] = (r < h && c < nb) ? pv[q] : 0.0;
+    Ls[r][c] = (16 * rb + r < h && c < nb) ? pv[q] : 0.0;   // rows 0 .. 15 of Ls: the workgroup's rows of P
   }
   __syncthreads();
   const int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  if (16 * wv >= h) return;
-  double4_t acc[4];
+  double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  for (int kk = 0; kk < NB; kk += 4)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[li][kk + lk], Zs[16 * wv + li][kk + lk], acc, 0, 0, 0);
 #pragma unroll
-  for (int kk = 0; kk < NB; kk += 4) {
-    const double a = Ls[16 * wv + li][kk + lk];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Zs[16 * q + li][kk + lk], acc[q], 0, 0, 0);
+  for (int reg = 0; reg < 4; ++reg) {
+    const int r = 16 * rb + lk + 4 * reg, c = 16 * wv + li;
+    if (r < h && c < nb) A[(size_t)(row0 + r) * lda + k0 + c] = acc[reg];
   }
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int r = 16 * wv + lk + 4 * reg, c = 16 * q + li;
-      if (r < h && c < nb) A[(size_t)(row0 + r) * lda + k0 + c] = acc[q][reg];
-    }
 }
 
-// C(I,J) -= sum over the level's sources K of L(I,K) L(J,K)^T, fixed order
+// C(I,J) -= sum over the level's sources K of L(I,K) L(J,K)^T, fixed order.  FOUR workgroups per target, one 32 x 32
+// quadrant each (wave = one 16 x 16 MFMA tile of it): a 64 x 64 x 64 FP64 product keeps the matrix cores of ONE CU busy for
+// 4096 cycles (4 SIMDs x one v_mfma_f64_16x16x4 per 64 cycles) whatever the number of waves, so the product of a source is
+// spread over four CUs instead (1024 cycles each, half the operand rows staged per workgroup).  Every entry sees the same
+// MFMA sequence as before.
 __global__ __launch_bounds__(256) void k_sp_update(double* __restrict__ A, int lda, const int* __restrict__ items,
                                                    const int* __restrict__ srcs) {
-  __shared__ double Pr[NB][LDP];
-  __shared__ double Pc[NB][LDP];
-  const int* it = items + 7 * blockIdx.x;
+  __shared__ double Pr[32][LDP];
+  __shared__ double Pc[32][LDP];
+  const int* it = items + 7 * (blockIdx.x >> 2);
+  const int qr = (blockIdx.x >> 1) & 1, qc = blockIdx.x & 1;
   const int row0 = it[0], h = it[1], col0 = it[2], w = it[3], sbeg = it[4], send = it[5], diag = it[6];
+  if ((diag && qc > qr) || 32 * qr >= h || 32 * qc >= w) return;   // upper quadrant of a diagonal target / beyond a short tile
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  double4_t cold[4], acc[4];
+  const int tr = wv >> 1, tc = wv & 1;
+  const int hr = min(32, h - 32 * qr), wc = min(32, w - 32 * qc);   // valid rows of the two staged operand blocks
+  double4_t cold, acc = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int r = 16 * wv + lk + 4 * reg, c = 16 * q + li;
-      cold[q][reg] = A[(size_t)(row0 + min(r, h - 1)) * lda + col0 + min(c, w - 1)];
-    }
+  for (int reg = 0; reg < 4; ++reg) {
+    const int r = 32 * qr + 16 * tr + lk + 4 * reg, c = 32 * qc + 16 * tc + li;
+    cold[reg] = A[(size_t)(row0 + min(r, h - 1)) * lda + col0 + min(c, w - 1)];
   }
+  // the operand rows of source s + 1 are in flight (registers) while the matrix cores work on source s
+  double vr[8], vc[8];
+  int nb = 0;
+  auto fetch = [&](int s) {
+    const int k0 = srcs[2 * s];
+    nb = srcs[2 * s + 1];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int t = tid + 256 * q, r = t >> 6, c = min(t & 63, nb - 1);
+      vr[q] = A[(size_t)(row0 + 32 * qr + min(r, hr - 1)) * lda + k0 + c];
+      vc[q] = A[(size_t)(col0 + 32 * qc + min(r, wc - 1)) * lda + k0 + c];
+    }
+  };
+  if (sbeg < send) fetch(sbeg);
   for (int s = sbeg; s < send; ++s) {
-    const int k0 = srcs[2 * s], nb = srcs[2 * s + 1];
     if (s > sbeg) __syncthreads();
-    load_tile(Pr, A, lda, row0, h, k0, nb, tid);
-    load_tile(Pc, A, lda, col0, w, k0, nb, tid);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int t = tid + 256 * q, r = t >> 6, c = t & 63;
+      Pr[r][c] = (r < hr && c < nb) ? vr[q] : 0.0;
+      Pc[r][c] = (r < wc && c < nb) ? vc[q] : 0.0;
+    }
+    if (s + 1 < send) fetch(s + 1);
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < NB; kk += 4) {
-      const double a = Pr[16 * wv + li][kk + lk];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Pc[16 * q + li][kk + lk], acc[q], 0, 0, 0);
-    }
+    for (int kk = 0; kk < NB; kk += 4)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pr[16 * tr + li][kk + lk], Pc[16 * tc + li][kk + lk], acc, 0, 0, 0);
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int r = 16 * wv + lk + 4 * reg, c = 16 * q + li;
-      if (r < h && c < w && (!diag || c <= r)) A[(size_t)(row0 + r) * lda + col0 + c] = cold[q][reg] - acc[q][reg];
-    }
+  for (int reg = 0; reg < 4; ++reg) {
+    const int r = 32 * qr + 16 * tr + lk + 4 * reg, c = 32 * qc + 16 * tc + li;
+    if (r < h && c < w && (!diag || c <= r)) A[(size_t)(row0 + r) * lda + col0 + c] = cold[reg] - acc[reg];
+  }
 }
 
 // Deferred updates of the dense border (the shared-intrinsics tiles, ordered last): a target (I, J) with both tiles in
@@ -766,9 +780,9 @@ void chol_plan_solve_phase(const CholPlan* pl, int phase, double* A, int lda, do
       if (lv.npotrf) k_sp_potrf<<<lv.npotrf, 256, 0, st>>>(A, lda, pg + lv.potrf_off, Linv, fail_flag);
       if (lv.ntrsm) k_sp_trsm<<<lv.ntrsm, 256, 0, st>>>(A, lda, pg + lv.trsm_off, Linv);
     } else if (lv.npotrf + lv.ntrsm) {
-      k_sp_potrf_trsm<<<lv.npotrf + lv.ntrsm, 256, 0, st>>>(A, lda, pg + lv.potrf_off, lv.npotrf, pg + lv.trsm_off, Linv, fail_flag);
+      k_sp_potrf_trsm<<<lv.npotrf + 4 * lv.ntrsm, 256, 0, st>>>(A, lda, pg + lv.potrf_off, lv.npotrf, pg + lv.trsm_off, Linv, fail_flag);
     }
-    if (lv.nupd) k_sp_update<<<lv.nupd, 256, 0, st>>>(A, lda, pg + lv.upd_off, pg + lv.upd_src_off);
+    if (lv.nupd) k_sp_update<<<4 * lv.nupd, 256, 0, st>>>(A, lda, pg + lv.upd_off, pg + lv.upd_src_off);
   }
   if (phase == 0) return;
   const double* y = A + (size_t)n * lda;
