@@ -207,32 +207,48 @@ __global__ __launch_bounds__(256) void k_sp_update(double* __restrict__ A, int l
 // partial item: {row0, h, col0, w, sbeg, send, slot}; reduce item: {row0, h, col0, w, slot0, nslots, diag}
 __global__ __launch_bounds__(256) void k_sp_update_partial(const double* __restrict__ A, int lda, const int* __restrict__ items,
                                                            const int* __restrict__ srcs, double* __restrict__ scratch) {
-  __shared__ double Pr[NB][LDP];
-  __shared__ double Pc[NB][LDP];
-  const int* it = items + 7 * blockIdx.x;
+  // four workgroups per chunk, one 32 x 32 quadrant each, the next source's operand rows in flight (as k_sp_update)
+  __shared__ double Pr[32][LDP];
+  __shared__ double Pc[32][LDP];
+  const int* it = items + 7 * (blockIdx.x >> 2);
+  const int qr = (blockIdx.x >> 1) & 1, qc = blockIdx.x & 1;
   const int row0 = it[0], h = it[1], col0 = it[2], w = it[3], sbeg = it[4], send = it[5];
   double* out = scratch + (size_t)it[6] * NB * NB;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
-  double4_t acc[4];
+  const int tr = wv >> 1, tc = wv & 1;
+  double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+  if (32 * qr < h && 32 * qc < w) {     // (a quadrant beyond a short tile stores zeros: the reduction reads whole tiles)
+    const int hr = min(32, h - 32 * qr), wc = min(32, w - 32 * qc);
+    double vr[8], vc[8];
+    int nb = 0;
+    auto fetch = [&](int s) {
+      const int k0 = srcs[2 * s];
+      nb = srcs[2 * s + 1];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) acc[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  for (int s = sbeg; s < send; ++s) {
-    const int k0 = srcs[2 * s], nb = srcs[2 * s + 1];
-    if (s > sbeg) __syncthreads();
-    load_tile(Pr, A, lda, row0, h, k0, nb, tid);
-    load_tile(Pc, A, lda, col0, w, k0, nb, tid);
-    __syncthreads();
+      for (int q = 0; q < 8; ++q) {
+        const int t = tid + 256 * q, r = t >> 6, c = min(t & 63, nb - 1);
+        vr[q] = A[(size_t)(row0 + 32 * qr + min(r, hr - 1)) * lda + k0 + c];
+        vc[q] = A[(size_t)(col0 + 32 * qc + min(r, wc - 1)) * lda + k0 + c];
+      }
+    };
+    if (sbeg < send) fetch(sbeg);
+    for (int s = sbeg; s < send; ++s) {
+      if (s > sbeg) __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < NB; kk += 4) {
-      const double a = Pr[16 * wv + li][kk + lk];
+      for (int q = 0; q < 8; ++q) {
+        const int t = tid + 256 * q, r = t >> 6, c = t & 63;
+        Pr[r][c] = (r < hr && c < nb) ? vr[q] : 0.0;
+        Pc[r][c] = (r < wc && c < nb) ? vc[q] : 0.0;
+      }
+      if (s + 1 < send) fetch(s + 1);
+      __syncthreads();
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Pc[16 * q + li][kk + lk], acc[q], 0, 0, 0);
+      for (int kk = 0; kk < NB; kk += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pr[16 * tr + li][kk + lk], Pc[16 * tc + li][kk + lk], acc, 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) out[(16 * wv + lk + 4 * reg) * NB + 16 * q + li] = acc[q][reg];
+  for (int reg = 0; reg < 4; ++reg) out[(32 * qr + 16 * tr + lk + 4 * reg) * NB + 32 * qc + 16 * tc + li] = acc[reg];
 }
 
 __global__ __launch_bounds__(256) void k_sp_update_reduce(double* __restrict__ A, int lda, const int* __restrict__ items,
@@ -256,38 +272,43 @@ __global__ __launch_bounds__(256) void k_sp_update_reduce(double* __restrict__ A
   A[(size_t)(row0 + r) * lda + col0 + c] -= v;
 }
 
-// x_K = Linv_K^T (y_K - sum_I L(I,K)^T x_I), I over the (already solved) ancestors
+// x_K = Linv_K^T (y_K - sum_I L(I,K)^T x_I), I over the (already solved) ancestors.
+// A level of the back-substitution is a chain of dependent global-memory round trips (item -> source list -> operands);
+// everything that does not depend on the previous link is requested up front: the tile of the inverse factor and y_K
+// with the first source's operands, a source's L(I,K) columns together with its x_I.
 __global__ __launch_bounds__(256) void k_sp_back(const double* __restrict__ A, int lda, const int* __restrict__ items,
                                                  const int* __restrict__ srcs, const double* __restrict__ Linv,
                                                  const double* y, double* x) {   // x may alias y (in place)
-  __shared__ double xs[NB], yk[NB], part[4][NB];
+  __shared__ double xs[2][NB], yk[NB], part[4][NB];
   const int* it = items + 5 * blockIdx.x;
   const int k0 = it[0], nb = it[1], sbeg = it[3], send = it[4];
   const double* Z = Linv + (size_t)it[2] * NB * NB;
   const int tid = threadIdx.x, j = tid & 63, ch = tid >> 6;
+  double zt[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) zt[q] = Z[(ch * 16 + q) * NB + j];
+  const double yv = (tid < nb) ? y[k0 + tid] : 0.0;
   double s = 0.0;
   for (int q = sbeg; q < send; ++q) {
     const int row0 = srcs[2 * q], h = srcs[2 * q + 1];
-    __syncthreads();
-    if (tid < NB) xs[tid] = (tid < h) ? x[row0 + tid] : 0.0;
-    __syncthreads();
-    {
-      // unconditional (clamped) loads; xs is zero beyond h and columns >= nb are dropped below
-      const double* col = A + (size_t)row0 * lda + k0 + min(j, nb - 1);
-      double v[16];
+    // unconditional (clamped) loads; xs is zero beyond h and columns >= nb are dropped below
+    const double* col = A + (size_t)row0 * lda + k0 + min(j, nb - 1);
+    double v[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = col[(size_t)min(ch * 16 + r, h - 1) * lda];
+    for (int r = 0; r < 16; ++r) v[r] = col[(size_t)min(ch * 16 + r, h - 1) * lda];
+    double* xb = xs[(q - sbeg) & 1];   // two buffers: one barrier per source
+    if (tid < NB) xb[tid] = (tid < h) ? x[row0 + tid] : 0.0;
+    __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s += v[r] * xs[ch * 16 + r];
-    }
+    for (int r = 0; r < 16; ++r) s += v[r] * xb[ch * 16 + r];
   }
   part[ch][j] = s;
   __syncthreads();
-  if (tid < NB) yk[tid] = (tid < nb) ? y[k0 + tid] - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) : 0.0;
+  if (tid < NB) yk[tid] = (tid < nb) ? yv - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) : 0.0;
   __syncthreads();
   double t = 0.0;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) { const int r = ch * 16 + q; t += Z[r * NB + j] * yk[r]; }
+  for (int q = 0; q < 16; ++q) { const int r = ch * 16 + q; t += zt[q] * yk[r]; }
   __syncthreads();
   part[ch][j] = t;
   __syncthreads();
@@ -772,7 +793,7 @@ void chol_plan_solve_phase(const CholPlan* pl, int phase, double* A, int lda, do
   for (int li = l0; li < l1; ++li) {
     const Level& lv = pl->lev[li];
     if (li == pl->def_level && pl->n_def_part) {
-      k_sp_update_partial<<<pl->n_def_part, 256, 0, st>>>(A, lda, pg + pl->def_part_off, pg + pl->def_src_off, pl->scratch);
+      k_sp_update_partial<<<4 * pl->n_def_part, 256, 0, st>>>(A, lda, pg + pl->def_part_off, pg + pl->def_src_off, pl->scratch);
       k_sp_update_reduce<<<pl->n_def_red * 16, 256, 0, st>>>(A, lda, pg + pl->def_red_off, pl->scratch);
     }
     static const bool split = getenv("THEIA_HIP_K3_SPLIT_TRSM") != nullptr;   // development: the two launches
