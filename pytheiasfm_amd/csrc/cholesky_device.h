@@ -116,15 +116,15 @@ __device__ __forceinline__ void potrf64_wave(double* __restrict__ A, int lda, in
     for (int j = 0; j < 16; ++j) {
       double d = readlane_d(r16[j], c0 + j);
       if (!(d > 0.0)) { bad = 1; d = 1.0; }
-      // products s_ij s_kj first (they do not wait for 1 / d); the chain per column is then
-      // pivot -> rcp -> one Newton step (v_rcp_f64 carries ~26 bits, one step leaves < 2 ulp) -> one FMA
-      double pk[16];
-#pragma unroll
-      for (int k = j + 1; k < 16; ++k) pk[k] = r16[j] * readlane_d(r16[j], c0 + k);
+      // the row's entry over the pivot first, then ONE FMA per remaining column (s_ij / d_j) s_kj -- the older form
+      // (s_ij s_kj) / d_j took a multiply and an FMA per entry and step, and a wave issues one FP64 instruction per ~6 cycles
+      // whatever its parallelism: the sweep is bound by its instruction count.  Chain per column:
+      // pivot -> rcp -> one Newton step (v_rcp_f64 carries ~26 bits, one step leaves < 2 ulp) -> multiply -> FMA
       double w = __builtin_amdgcn_rcp(d);
       w = __builtin_fma(w, __builtin_fma(-d, w, 1.0), w);
+      const double t = -(r16[j] * w);
 #pragma unroll
-      for (int k = j + 1; k < 16; ++k) r16[k] = __builtin_fma(-pk[k], w, r16[k]);
+      for (int k = j + 1; k < 16; ++k) r16[k] = __builtin_fma(t, readlane_d(r16[j], c0 + k), r16[k]);
       rs[j] = d;
     }
     // 16 independent rsqrt refinements (v_rsq_f64 seed + two Newton steps, full
@@ -294,17 +294,17 @@ __device__ __forceinline__ void potrf64_wg_core(double* __restrict__ A, int lda,
         // broadcast reads (one ds_read_b64 each, issued back to back) instead of two v_readlane + hazard slots per value
         Ls[i][c0 + j] = r16[j];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        double d = Ls[c0 + j][c0 + j];
+        double d = Ls[c0 + j][c0 + j];   // (the pivot by v_readlane instead, to start 1 / d early: measured slower, 33.9 k against 33.4 k cycles)
         if (!(d > 0.0)) { bad = 1; d = 1.0; }
-        // products s_ij s_kj first (they do not wait for 1 / d); the chain per column is then
-        // pivot -> rcp -> one Newton step (v_rcp_f64 carries ~26 bits, one step leaves < 2 ulp) -> one FMA
-        double pk[16];
+        // (s_ij / d_j) s_kj: one FMA per entry and step (see potrf64_wave); the multipliers are read while 1 / d is computed
+        double mk[16];
 #pragma unroll
-        for (int k = j + 1; k < 16; ++k) pk[k] = r16[j] * Ls[c0 + k][c0 + j];
+        for (int k = j + 1; k < 16; ++k) mk[k] = Ls[c0 + k][c0 + j];
         double w = __builtin_amdgcn_rcp(d);
         w = __builtin_fma(w, __builtin_fma(-d, w, 1.0), w);
+        const double t = -(r16[j] * w);
 #pragma unroll
-        for (int k = j + 1; k < 16; ++k) r16[k] = __builtin_fma(-pk[k], w, r16[k]);
+        for (int k = j + 1; k < 16; ++k) r16[k] = __builtin_fma(t, mk[k], r16[k]);
         rs[j] = d;
       }
 #pragma unroll
