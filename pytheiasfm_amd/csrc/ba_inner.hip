@@ -824,12 +824,12 @@ __global__ __launch_bounds__(256) void k_inner_cam_blocks(InnerArgs A) {
 // the inner iterations ended at): out[0] = step^2, out[1] = |x_inner|^2.  Two fixed-order stages: kInnerCostBlocks
 // workgroups over contiguous slices of the blocks (one workgroup over 500k points took 0.44 ms), then one workgroup
 // over their partial sums.
-__global__ __launch_bounds__(256) void k_inner_norms(InnerArgs A, const double* __restrict__ cam0, const double* __restrict__ pts0,
-                                                     const double* __restrict__ intr0, double* __restrict__ part, int which) {
+__device__ __forceinline__ void inner_norms_body(const InnerArgs& A, const double* __restrict__ cam0, const double* __restrict__ pts0,
+                                                 const double* __restrict__ intr0, double* __restrict__ part, int which, int nb, int blk,
+                                                 double* s1, double* s2) {
   // which: 0 = every variable block, 1 = the points only (a track shard's share), 2 = cameras + intrinsics only
-  __shared__ double s1[256], s2[256];
   double a = 0.0, b = 0.0;
-  const int tid = threadIdx.x, nb = gridDim.x, blk = blockIdx.x;
+  const int tid = threadIdx.x;
   if (which != 2) {
     const int per = (A.P.np + nb - 1) / nb, p0 = blk * per, p1 = min(A.P.np, p0 + per);
     for (int p = p0 + tid; p < p1; p += 256) {
@@ -860,8 +860,12 @@ __global__ __launch_bounds__(256) void k_inner_norms(InnerArgs A, const double* 
   }
   if (tid == 0) { part[2 * blk] = s1[0]; part[2 * blk + 1] = s2[0]; }
 }
-__global__ __launch_bounds__(256) void k_inner_norms_reduce(int nparts, const double* __restrict__ part, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_inner_norms(InnerArgs A, const double* __restrict__ cam0, const double* __restrict__ pts0,
+                                                     const double* __restrict__ intr0, double* __restrict__ part, int which) {
   __shared__ double s1[256], s2[256];
+  inner_norms_body(A, cam0, pts0, intr0, part, which, gridDim.x, blockIdx.x, s1, s2);
+}
+__device__ __forceinline__ void inner_norms_reduce_body(int nparts, const double* __restrict__ part, double* __restrict__ out, double* s1, double* s2) {
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
   s1[threadIdx.x] = a; s2[threadIdx.x] = b;
@@ -873,12 +877,16 @@ __global__ __launch_bounds__(256) void k_inner_norms_reduce(int nparts, const do
   if (threadIdx.x == 0) { out[0] = s1[0]; out[1] = s2[0]; }
 }
 
-// cost at the inner-iteration point: every observation row (tiles or not), then the camera priors; two fixed-order stages
-__global__ __launch_bounds__(256) void k_inner_cost(InnerArgs A, double* __restrict__ part) {
-  if (!*A.gate) return;
+__global__ __launch_bounds__(256) void k_inner_norms_reduce(int nparts, const double* __restrict__ part, double* __restrict__ out) {
   __shared__ double s1[256], s2[256];
+  inner_norms_reduce_body(nparts, part, out, s1, s2);
+}
+
+// cost at the inner-iteration point: every observation row (tiles or not), then the camera priors; two fixed-order stages
+__device__ __forceinline__ void inner_cost_body(const InnerArgs& A, double* __restrict__ part, int nb, int blk, double* s1, double* s2) {
+  if (!*A.gate) return;
   double cst = 0.0, inv = 0.0;
-  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < A.nobs; o += (int64_t)gridDim.x * 256) {
+  for (int64_t o = (int64_t)blk * 256 + threadIdx.x; o < A.nobs; o += (int64_t)nb * 256) {
     const ObsRef ob = load_obs(A, (int)o);
     const int grp = A.P.cam_group[ob.cam];
     const double4 Xv = reinterpret_cast<const double4*>(A.pts)[ob.pt];
@@ -896,11 +904,15 @@ __global__ __launch_bounds__(256) void k_inner_cost(InnerArgs A, double* __restr
     if ((int)threadIdx.x < s) { s1[threadIdx.x] += s1[threadIdx.x + s]; s2[threadIdx.x] += s2[threadIdx.x + s]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { part[2 * blockIdx.x] = s1[0]; part[2 * blockIdx.x + 1] = s2[0]; }
+  if (threadIdx.x == 0) { part[2 * blk] = s1[0]; part[2 * blk + 1] = s2[0]; }
 }
-__global__ __launch_bounds__(256) void k_inner_cost_reduce(InnerArgs A, const double* __restrict__ part, int nblocks, double* __restrict__ out) {
-  if (!*A.gate) return;
+__global__ __launch_bounds__(256) void k_inner_cost(InnerArgs A, double* __restrict__ part) {
   __shared__ double s1[256], s2[256];
+  inner_cost_body(A, part, gridDim.x, blockIdx.x, s1, s2);
+}
+__device__ __forceinline__ void inner_cost_reduce_body(const InnerArgs& A, const double* __restrict__ part, int nblocks, double* __restrict__ out,
+                                                       double* s1, double* s2) {
+  if (!*A.gate) return;
   double cst = 0.0, inv = 0.0;
   for (int b = threadIdx.x; b < nblocks; b += 256) { cst += part[2 * b]; inv += part[2 * b + 1]; }
   for (int i = threadIdx.x; i < A.P.n_priors; i += 256) {
@@ -916,6 +928,25 @@ __global__ __launch_bounds__(256) void k_inner_cost_reduce(InnerArgs A, const do
     __syncthreads();
   }
   if (threadIdx.x == 0) { out[0] = s1[0]; out[1] = s2[0]; }
+}
+__global__ __launch_bounds__(256) void k_inner_cost_reduce(InnerArgs A, const double* __restrict__ part, int nblocks, double* __restrict__ out) {
+  __shared__ double s1[256], s2[256];
+  inner_cost_reduce_body(A, part, nblocks, out, s1, s2);
+}
+// the unsharded sweep's closing scalars in two launches instead of four: the step norms (workgroups [0, nbn)) and the cost
+// (workgroups [nbn, nbn + nbc)) side by side, then their two second stages by two workgroups.  Same partitions, same orders.
+__global__ __launch_bounds__(256) void k_inner_norms_cost(InnerArgs A, const double* __restrict__ cam0, const double* __restrict__ pts0,
+                                                          const double* __restrict__ intr0, double* __restrict__ part_n, int nbn,
+                                                          double* __restrict__ part_c, int nbc) {
+  __shared__ double s1[256], s2[256];
+  if ((int)blockIdx.x < nbn) inner_norms_body(A, cam0, pts0, intr0, part_n, 0, nbn, blockIdx.x, s1, s2);
+  else inner_cost_body(A, part_c, nbc, blockIdx.x - nbn, s1, s2);
+}
+__global__ __launch_bounds__(256) void k_inner_norms_cost_reduce(InnerArgs A, const double* __restrict__ part_n, int nbn, double* __restrict__ out_n,
+                                                                 const double* __restrict__ part_c, int nbc, double* __restrict__ out_c) {
+  __shared__ double s1[256], s2[256];
+  if (blockIdx.x == 0) inner_norms_reduce_body(nbn, part_n, out_n, s1, s2);
+  else inner_cost_reduce_body(A, part_c, nbc, out_c, s1, s2);
 }
 
 // sharded solves: this shard's candidate points at their global indices (the rest of the buffer is zero: the ranks' buffers
@@ -1028,6 +1059,15 @@ void launch_inner_sweep(const InnerArgs& A0, hipStream_t st, int stages) {   // 
       if (A.P.pd == 3) k_inner_long_tracks<3><<<(A.P.long_ntracks + 3) / 4, 256, 0, st>>>(A); else k_inner_long_tracks<4><<<(A.P.long_ntracks + 3) / 4, 256, 0, st>>>(A);
     }
   }
+}
+// part: 4 * kInnerCostBlocks doubles (the norms' partial sums, then the cost's)
+void launch_inner_norms_cost(const InnerArgs& A0, const double* cam0, const double* pts0, const double* intr0, double* out4, double* part,
+                             hipStream_t st) {
+  const InnerArgs A = normalised(A0);
+  const int nbc = (int)std::max<int64_t>(1, std::min<int64_t>(kInnerCostBlocks, (A.nobs + 255) / 256));
+  double* part_c = part + 2 * (size_t)kInnerCostBlocks;
+  k_inner_norms_cost<<<kInnerCostBlocks + nbc, 256, 0, st>>>(A, cam0, pts0, intr0, part, kInnerCostBlocks, part_c, nbc);
+  k_inner_norms_cost_reduce<<<2, 256, 0, st>>>(A, part, kInnerCostBlocks, out4, part_c, nbc, out4 + 2);
 }
 void launch_inner_norms(const InnerArgs& A, const double* cam0, const double* pts0, const double* intr0, double* out2, double* part,
                         hipStream_t st, int which) {

@@ -176,6 +176,9 @@ void launch_inner_keep_owned(double* x, int nblocks, int stride, int rank, int w
 // part: scratch of 2 * kInnerCostBlocks doubles
 constexpr int kInnerCostBlocks = 512;
 void launch_inner_cost(const InnerArgs& A, double* part, double* out2, hipStream_t st);
+// both in two launches (the unsharded sweep): out4 = {step^2, |x|^2, cost, invalid}; part: 4 * kInnerCostBlocks doubles
+void launch_inner_norms_cost(const InnerArgs& A, const double* cam0, const double* pts0, const double* intr0, double* out4, double* part,
+                             hipStream_t st);
 
 void launch_colnorm(const DevProblem& P, const double* cam, const double* pts, double* colsq_c,
                     double* colsq_p, double* colsq_i, hipStream_t st);

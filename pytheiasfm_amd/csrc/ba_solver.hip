@@ -2368,7 +2368,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
     if ((rc = h->in_cam_idx.upload(cidx.data(), cidx.n, st, cidx.pinned())) || (rc = h->in_grp_idx.upload(gidx.data(), gidx.n, st, gidx.pinned()))) return rc;
     AL(in_cam, (size_t)6 * std::max(1, h->nc)); AL(in_pts, (size_t)4 * std::max(1, h->np));
     AL(in_intr, (size_t)THEIA_MAX_INTRINSICS * std::max(1, h->ng));
-    AL(in_scal, 8); AL(in_part, 2 * (size_t)kInnerCostBlocks); AL(in_gate, 4);
+    AL(in_scal, 8); AL(in_part, 4 * (size_t)kInnerCostBlocks); AL(in_gate, 4);
     if (!h->use_fused) AL(camrot_cand, (size_t)40 * std::max(1, h->nc));   // the track sweep reads the cameras as k_cam_prep-style blocks (k_inner_cam_blocks)
     if (h->ni && inner_group_wgs(h->ng) > 1) { AL(in_grp_part, (size_t)h->ng * 2 * inner_group_wgs(h->ng) * kInnerGroupSums); AL(in_grp_bar, 2 * (size_t)std::max(1, h->ng) + 2); }
   }
@@ -2847,8 +2847,7 @@ int theia_hip_ba_run(theia_ba_handle h, theia_ba_summary* S) {
         launch_inner_combine(h->g_stage.p, h->g_stage.p + 4, h->in_scal.p, h->stream);
       } else {
       launch_inner_sweep(IA, h->stream);
-      launch_inner_norms(IA, h->cam[0].p, h->pts[0].p, h->intr[0].p, h->in_scal.p, h->in_part.p, h->stream);   // in_part: free until launch_inner_cost
-      launch_inner_cost(IA, h->in_part.p, h->in_scal.p + 2, h->stream);
+      launch_inner_norms_cost(IA, h->cam[0].p, h->pts[0].p, h->intr[0].p, h->in_scal.p, h->in_part.p, h->stream);   // step norms + cost, two launches
       }
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(h->ev[slot][3], h->stream));
