@@ -12,7 +12,7 @@ fi
 for u in rcp_acc lds_atomic; do [ -x scripts/ubench/$u ] && timeout 120 scripts/ubench/$u > gpurun_out/dev_$u.log 2>&1; done
 THEIA_HIP_CREATE_TIMING=1 timeout 600 python scripts/gpu_time_lin_kernel.py > gpurun_out/dev_time_default.log 2>&1
 tail -3 gpurun_out/dev_time_default.log
-for v in ${VARIANTS:-THEIA_HIP_FUSED_V4=1 THEIA_HIP_FUSED_DBG=1 THEIA_HIP_FUSED_DBG=2 THEIA_HIP_FUSED_DBG=3}; do
+for v in ${VARIANTS:-THEIA_HIP_FUSED_DBG=1 THEIA_HIP_FUSED_DBG=2 THEIA_HIP_FUSED_DBG=3}; do
   env $v timeout 600 python scripts/gpu_time_lin_kernel.py > "gpurun_out/dev_time_$v.log" 2>&1
   echo "$v: $(tail -1 "gpurun_out/dev_time_$v.log")"
 done
