@@ -19,7 +19,7 @@
 // long lists (the group x group blocks of a problem with one shared camera get a piece from every block of every run)
 // go through a second level.
 #define THIP_LEAN_SQRT 1
-#include "ba_lane.h"
+#include "ba_fused_lin.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -58,51 +58,56 @@ constexpr int nth_bit(unsigned m, int k) {
 
 // KMASK != 0: every variable group frees exactly the parameters KMASK (known at create()): the compact rows are picked
 // at compile time and the Jacobian columns of the other intrinsics are never computed.  KMASK == 0: per-lane masks.
-template <int PD, int TPS, unsigned MODELS, unsigned KMASK>
-__device__ __forceinline__ void fusedi_phase_l(const DevProblem* __restrict__ Pp, const FusedRun* __restrict__ runp,
-                                               const double* __restrict__ pts, double inv_radius, int sc,
+// Round 5: the linearisation is lin5 (ba_fused_lin.h) on the prefetched observation `c` and the camera's block in LDS (s_cam:
+// the run's local cameras, then the constant cameras its tracks see), as in k_lin_schur; the generic lane_linearize with its
+// 320-B gather per observation was two thirds of this kernel (407 of 612 us at C4 with the pair products switched off).
+template <int PD, int TPS, unsigned MODELS, unsigned KMASK, int LOSSK>
+__device__ __forceinline__ void fusedi_phase_l(const DevProblem& P, const LanePre<PD>& c, const double* __restrict__ s_cam, int W, int tile,
+                                               bool tile_ok, int wv, int lane, double inv_radius,
                                                double* __restrict__ Vinv, double* __restrict__ tile_part,
                                                double* __restrict__ s_rec, uint8_t* __restrict__ s_tslot,
                                                unsigned* __restrict__ s_tmask) {
   constexpr int NT = PD * (PD + 1) / 2;
   constexpr int RD = reci_doubles<PD>();
   constexpr int KR = kFusedIntrRows;
-  const DevProblem& P = *Pp;
-  const FusedRun& run = *runp;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int tile = run.tile0 + TPS * sc + wv;
-  const bool tile_ok = tile < run.tile0 + run.ntiles;
-  const int cnt = tile_ok ? P.tile_count[tile] : 0;
-  const int start = tile_ok ? P.tile_start[tile] : 0;
-  const bool active = lane < cnt;
-  LaneLin<PD, true> L;
-  lane_linearize<PD, true, true, true, MODELS>(P, P.camrot, pts, start + lane, active, lane, L);
-  // compact intrinsics rows: row k = the k-th free parameter of the camera's group (L.Jk is masked and scaled already)
+  const bool active = c.active;
+  const bool is_tgt = !(c.lc & 0x80u);
+  const unsigned cslot = is_tgt ? c.lc : (unsigned)W + (c.lc & 0x7fu);
+  const double* cb = s_cam + cslot * kCamLds;
+  struct { double r[2], Jc[12], Jt[2 * PD], Jk[2 * THEIA_MAX_INTRINSICS]; double cost; bool valid, pconst; int p; } L;
+  lin5<PD, MODELS, LOSSK, true>(P, c, cb, L.r, L.cost, L.valid, L.Jc, L.Jt, L.Jk);
+  L.pconst = c.pconst; L.p = active ? c.p : -1 - lane;
+  // Jacobi scale and free mask of the camera's group (constant group: zero rows); an inactive lane's rows are zero
+  const int grp = (int)cb[kCamRotGroup];
+  const int gr = active ? P.grp_red[grp] : -1;
+  unsigned fm = gr >= 0 ? P.grp_free[grp] : 0u;
+  // compact intrinsics rows: row k = the k-th free parameter of the camera's group
   double jk[2 * KR];
   if constexpr (KMASK != 0u) {
     constexpr int Q[KR] = {nth_bit(KMASK, 0), nth_bit(KMASK, 1), nth_bit(KMASK, 2), nth_bit(KMASK, 3)};
 #pragma unroll
-    for (int k = 0; k < KR; ++k) {   // (L.Jk is zero for an inactive lane or a constant group)
-      jk[k] = Q[k] >= 0 ? L.Jk[Q[k] >= 0 ? Q[k] : 0] : 0.0;
-      jk[KR + k] = Q[k] >= 0 ? L.Jk[THEIA_MAX_INTRINSICS + (Q[k] >= 0 ? Q[k] : 0)] : 0.0;
+    for (int k = 0; k < KR; ++k) {
+      double sc = 0.0;
+      if (Q[k] >= 0 && gr >= 0) sc = P.scale_i[(size_t)grp * THEIA_MAX_INTRINSICS + (Q[k] >= 0 ? Q[k] : 0)];
+      jk[k] = Q[k] >= 0 ? L.Jk[Q[k] >= 0 ? Q[k] : 0] * sc : 0.0;
+      jk[KR + k] = Q[k] >= 0 ? L.Jk[THEIA_MAX_INTRINSICS + (Q[k] >= 0 ? Q[k] : 0)] * sc : 0.0;
     }
   } else {
-    unsigned fm = (active && L.gr >= 0) ? P.red_free[L.gr] : 0u;
 #pragma unroll
     for (int k = 0; k < KR; ++k) {
       double v0 = 0.0, v1 = 0.0;
       if (fm) {
         const int q = __ffs(fm) - 1;
         fm &= fm - 1u;
+        const double sc = P.scale_i[(size_t)grp * THEIA_MAX_INTRINSICS + q];
 #pragma unroll
-        for (int j = 0; j < THEIA_MAX_INTRINSICS; ++j) if (j == q) { v0 = L.Jk[j]; v1 = L.Jk[THEIA_MAX_INTRINSICS + j]; }
+        for (int j = 0; j < THEIA_MAX_INTRINSICS; ++j) if (j == q) { v0 = L.Jk[j] * sc; v1 = L.Jk[THEIA_MAX_INTRINSICS + j] * sc; }
       }
       jk[k] = v0; jk[KR + k] = v1;
     }
   }
-  const int o = start + lane;
-  const int tl = active ? P.obs_tl[o] : 0;
-  const unsigned lc = active ? P.obs_lc[o] : 0xffu;
+  const int tl = active ? (int)c.tl : 0;
+  const unsigned lc = (active && is_tgt) ? c.lc : 0xffu;
   // the camera-side rows of the record leave the registers at once (20 doubles that nothing below needs again)
   if (active && lc != 0xffu) {
     double2* R = reinterpret_cast<double2*>(s_rec + (wv * 64 + lane) * RD);
@@ -188,7 +193,7 @@ __device__ __forceinline__ void fusedi_phase_l(const DevProblem* __restrict__ Pp
 #pragma unroll
       for (int q = 0; q < NT; ++q) Vinv[(size_t)NT * L.p + q] = Vi[q];
 #pragma unroll
-      for (int a = 0; a < PD; ++a) gmax = fmax(gmax, fabs(g[a] / P.scale_p[(size_t)PD * L.p + a]));
+      for (int a = 0; a < PD; ++a) gmax = fmax(gmax, fabs(g[a] / c.sp[a]));
     }
   }
   if (active && lc != 0xffu) {
@@ -232,7 +237,7 @@ __device__ __forceinline__ void fusedi_phase_l(const DevProblem* __restrict__ Pp
 
 // KI = 3 or 4: compact intrinsics rows in use (the widest free mask of the problem's groups); partial blocks are always
 // stored kBWP x kBWP, rows / columns >= 6 + KI are never written or read.
-template <int PD, int TPS, unsigned MODELS, int KI, unsigned KMASK>
+template <int PD, int TPS, unsigned MODELS, int KI, unsigned KMASK, int LOSSK>
 __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const double* __restrict__ pts,
                                                              const double* __restrict__ radius_p,
                                                              double* __restrict__ Vinv, double* __restrict__ tile_part) {
@@ -245,14 +250,12 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
   constexpr int NWV = TPS;
   constexpr int NA = kRPL * BW;                        // accumulators of a lane: its rows of the block
   __shared__ __attribute__((aligned(16))) double s_rec[SUB * RD];
+  __shared__ __attribute__((aligned(16))) double s_cam[kFusedMaxStageIntr * kCamLds];   // the run's camera blocks (k_cam_prep): local, then constant
   __shared__ uint8_t s_tslot[SUBT * kRowBytesI];
   __shared__ unsigned s_tmask[SUBT];
   static_assert(NA <= RD, "slice-combination scratch does not fit the record buffer");
-  __shared__ DevProblem s_P;
-  __shared__ FusedRun s_run;
   __shared__ int s_next;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) s_P = P;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const double inv_radius = 1.0 / *radius_p;
   const bool colnorm_only = (P.fused_dbg & 8) != 0;   // compute_scale: only the per-(camera, row) sums are read afterwards
   int pending = 0;   // the run queue is popped one run ahead (the pop's round trip is off the path between two runs)
@@ -261,11 +264,21 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
     __syncthreads();
     if (tid == 0) s_next = pending;
     __syncthreads();
-    if (s_next >= P.n_fruns) break;
+    const int rix = __builtin_amdgcn_readfirstlane(s_next);   // (scalar: the run's fields and the tile geometry are s_loads)
+    if (rix >= P.n_fruns) break;
     if (tid == 0) pending = atomicAdd(P.frun_next, 1);
-    const FusedRun run = P.fruns[P.frun_order[s_next]];
-    if (tid == 0) s_run = run;
+    const FusedRun run = P.fruns[P.frun_order[rix]];
     const int nsc = (run.ntiles + TPS - 1) / TPS;
+    // the run's per-camera blocks -> LDS, 16 B per thread and step; the first sub-chunk's observation stream meanwhile
+    for (int j = tid; j < run.nstage * (kCamRot / 2); j += SUB) {
+      const int k = j / (kCamRot / 2), piece = j - k * (kCamRot / 2);
+      const int cidx = P.frun_stage[run.stage_off + k];
+      reinterpret_cast<double2*>(s_cam + k * kCamLds)[piece] = reinterpret_cast<const double2*>(P.camrot + (size_t)kCamRot * cidx)[piece];
+    }
+    LanePre<PD> cur;
+    int tile = 0; bool tile_ok = false;
+    pre_level1<PD, TPS>(P, run, 0, wv, lane, tile, tile_ok, cur);
+    pre_level2<PD>(P, pts, cur);
     __syncthreads();
 
     const int G = run.gp & 0xff, PS = run.gp >> 8;
@@ -277,7 +290,12 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
     for (int k = 0; k < 3; ++k) dacc[k] = 0.0;
 
     for (int sc = 0; sc < nsc; ++sc) {
-      fusedi_phase_l<PD, TPS, MODELS, KMASK>(&s_P, &s_run, pts, inv_radius, sc, Vinv, tile_part, s_rec, s_tslot, s_tmask);
+      LanePre<PD> nxt;
+      int ntile = 0; bool ntile_ok = false;
+      const int scn = min(sc + 1, nsc - 1);   // (the last sub-chunk reloads itself: unconditional loads, nothing is used)
+      pre_level1<PD, TPS>(P, run, scn, wv, lane, ntile, ntile_ok, nxt);
+      fusedi_phase_l<PD, TPS, MODELS, KMASK, LOSSK>(P, cur, s_cam, run.W, tile, tile_ok, wv, lane, inv_radius, Vinv, tile_part, s_rec, s_tslot, s_tmask);
+      pre_level2<PD>(P, pts, nxt);
       __builtin_amdgcn_s_setprio(1);   // phase S is pure issue, phase L a chain of latencies: S first, L fills the gaps (ba_fused.hip)
       __syncthreads();
       {
@@ -371,6 +389,7 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
       }
       __builtin_amdgcn_s_setprio(0);
       __syncthreads();
+      cur = nxt; tile = ntile; tile_ok = ntile_ok;
     }
     // ---- combine the track slices in a fixed order; the first replica of a lane role writes the rows it owns
     // (the lane's role again:  lix = lane index inside the track slice this lane serves: target block lix / NS, rows
@@ -525,15 +544,18 @@ void launch_linearize_fused_intr(const DevProblem& P, const double* cam, const d
   const bool trig = (P.model_mask & ~kModelsNoTrig) != 0;
 // FOCAL_LENGTH | RADIAL_DISTORTION on the perspective / double-sphere / unified models (parameters 0, 5, 6): the pipelines' default
 constexpr unsigned kMaskFocalRadial = (1u << 0) | (3u << 5);
-#define THIP_LSI(PD_, M_)                                                                                    \
+#define THIP_LSI2(PD_, M_, LK_)                                                                              \
   do {                                                                                                         \
     if (P.fused_bw == 9 && P.fused_kmask == kMaskFocalRadial)                                                     \
-      k_lin_schur_i<PD_, 4, M_, 3, kMaskFocalRadial><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);         \
-    else if (P.fused_bw == 9) k_lin_schur_i<PD_, 4, M_, 3, 0u><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part); \
-    else k_lin_schur_i<PD_, 4, M_, 4, 0u><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);                  \
+      k_lin_schur_i<PD_, 4, M_, 3, kMaskFocalRadial, LK_><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);    \
+    else if (P.fused_bw == 9) k_lin_schur_i<PD_, 4, M_, 3, 0u, LK_><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part); \
+    else k_lin_schur_i<PD_, 4, M_, 4, 0u, LK_><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);             \
   } while (0)
+  // (two loss instances: the trivial loss without corrector code, everything else with the full corrector)
+#define THIP_LSI(PD_, M_) do { if (P.loss_type == THEIA_LOSS_TRIVIAL) THIP_LSI2(PD_, M_, 0); else THIP_LSI2(PD_, M_, 2); } while (0)
   if (P.pd == 3) { if (trig) THIP_LSI(3, kModelsAll); else THIP_LSI(3, kModelsNoTrig); }
   else { if (trig) THIP_LSI(4, kModelsAll); else THIP_LSI(4, kModelsNoTrig); }
+#undef THIP_LSI2
 #undef THIP_LSI
   const int2* src = reinterpret_cast<const int2*>(P.sum_src);
   if (P.n_sum_items)

@@ -28,6 +28,8 @@ constexpr int kFusedTileTracks = 32;     // tracks per wave tile (128 per sub-ch
 // fused assembly with intrinsics (ba_fused_intr.hip): compound camera blocks [extrinsics (6) | compact intrinsics rows (4)]
 constexpr int kFusedIntrRows = 4, kFusedIntrWidth = 6 + kFusedIntrRows;
 constexpr int kFusedMaxCamsIntr = 12;    // -> at most 78 target blocks x 3 lanes
+constexpr int kFusedMaxConstIntr = 12;   // constant cameras a run of the compound-block plan may see (staged in LDS as above)
+constexpr int kFusedMaxStageIntr = kFusedMaxCamsIntr + kFusedMaxConstIntr;
 
 // Device-resident problem (SoA, observations sorted by point and packed into
 // wave tiles of <= 64 observations that never split a point).

@@ -1560,9 +1560,10 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
   std::vector<int> prev_tc;
   std::vector<int> cam_stamp((size_t)std::max(1, h->ncp), 0);
   std::vector<uint8_t> cam_local((size_t)std::max(1, h->ncp), 0);   // camera -> index in the closing run's sorted table
-  // CONSTANT cameras the open run's tracks see (ba_fused.hip stages their blocks in LDS behind the local cameras'), in order
-  // of appearance; only without compound blocks (ba_fused_intr.hip reads a constant camera's block from HBM, obs_lc = 0xff)
-  const bool stage_const = bw == 0;
+  // CONSTANT cameras the open run's tracks see (the fused kernels stage their blocks in LDS behind the local cameras'), in order
+  // of appearance: obs_lc = 0x80 | index
+  const bool stage_const = true;
+  const int max_const = bw == 0 ? kFusedMaxConst : kFusedMaxConstIntr;
   std::vector<int> run_ccams, tcc;
   std::vector<int> ccam_stamp(stage_const ? (size_t)std::max(1, h->nc) : 1, 0);
   std::vector<uint8_t> ccam_local(stage_const ? (size_t)std::max(1, h->nc) : 1, 0);
@@ -1653,7 +1654,7 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
     const bool dup = std::adjacent_find(tc.begin(), tc.end()) != tc.end();
     if (!tcc.empty()) { std::sort(tcc.begin(), tcc.end()); tcc.erase(std::unique(tcc.begin(), tcc.end()), tcc.end()); }
     mark_tiles(q);
-    if (L > 64 || dup || (int)tc.size() > max_cams || (int)tcc.size() > kFusedMaxConst) {
+    if (L > 64 || dup || (int)tc.size() > max_cams || (int)tcc.size() > max_const) {
       close_tile(q);            // tiles are contiguous observation ranges
       push_long(q);
       continue;
@@ -1673,7 +1674,7 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
     if (!tcc.empty()) {
       size_t uc = run_ccams.size();
       for (int c : tcc) uc += ccam_stamp[c] != serial;
-      if (uc > (size_t)kFusedMaxConst) new_run = true;
+      if (uc > (size_t)max_const) new_run = true;
     }
     // a run keeps its packing level (track slices per wave) once it has some work, and stays inside one
     // first-camera key once it is large enough
