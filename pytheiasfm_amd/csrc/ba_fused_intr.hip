@@ -235,8 +235,8 @@ __device__ __forceinline__ void fusedi_phase_l(const DevProblem& P, const LanePr
   }
 }
 
-// KI = 3 or 4: compact intrinsics rows in use (the widest free mask of the problem's groups); partial blocks are always
-// stored kBWP x kBWP, rows / columns >= 6 + KI are never written or read.
+// KI = 3 or 4: compact intrinsics rows in use (the widest free mask of the problem's groups); a run's partial blocks are
+// BW x BW = (6 + KI)^2 doubles per target and BW x 3 per camera (ba_solver.hip: build_sum_items_intr reads them so).
 template <int PD, int TPS, unsigned MODELS, int KI, unsigned KMASK, int LOSSK>
 __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const double* __restrict__ pts,
                                                              const double* __restrict__ radius_p,
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
           for (int q = 0; q < BW; ++q) v[q] += scratch[oth * NA + a * BW + q];
         }
 #pragma unroll
-        for (int q = 0; q < BW; ++q) out[(size_t)tix * (kBWP * kBWP) + (row0 + a) * kBWP + q] = v[q];
+        for (int q = 0; q < BW; ++q) out[(size_t)tix * (BW * BW) + (row0 + a) * BW + q] = v[q];
       }
     }
     __syncthreads();
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
 #pragma unroll
         for (int q = 0; q < 3; ++q) v[q] += scratch[oth * 3 + q];
       }
-      double* od = out + (size_t)run.ntgt * (kBWP * kBWP) + ((size_t)dlc * kBWP + da) * 3;
+      double* od = out + (size_t)run.ntgt * (BW * BW) + ((size_t)dlc * BW + da) * 3;
 #pragma unroll
       for (int q = 0; q < 3; ++q) od[q] = v[q];
     }

@@ -1533,7 +1533,7 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
   // one lane per 6 x 6 block; ba_fused_intr.hip: 3 or 4 lanes per compound block, stored 10 x 10)
   const int bw = h->fused_bw;
   const size_t lanes_tgt = bw == 0 ? 1 : (bw == 9 ? 3 : 4), rows_cam = bw == 0 ? 6 : (size_t)bw;
-  const size_t part_tgt = bw == 0 ? 36 : 100, part_cam = bw == 0 ? 18 : 30;
+  const size_t part_tgt = bw == 0 ? 36 : (size_t)bw * bw, part_cam = bw == 0 ? 18 : (size_t)3 * bw;   // compound blocks: BW x BW per target, BW x 3 per camera
   const int max_cams = bw == 0 ? kFusedMaxCams : (bw == 9 ? kFusedMaxCamsIntr : 10);
   const size_t max_tgts = bw == 0 ? 253 : 256 / lanes_tgt;
   // track slices per consumer wave for a run of ntgt target blocks over W cameras (0 = needs more than one wave)
@@ -1737,7 +1737,7 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
 // Lists longer than 2 x chunk go through intermediate sums (SK_CHUNK items) and a second-level item.
 int build_sum_items_intr(theia_ba_handle_s* h, const int* cam_group, FusedHost& fp, int* n_items1, int* n_items2) {
   constexpr int SK_BLOCK = 0, SK_LOWER = 1, SK_VEC = 2, SK_CHUNK = 3;
-  const int KI = h->fused_bw - 6, ni = h->ni;
+  const int KI = h->fused_bw - 6, ni = h->ni, BW = h->fused_bw;   // a run's partial blocks: BW x BW per target (row stride BW), BW x 3 per camera
   struct Ent { int64_t key; int off, code, dims; };   // dims = nr | nc << 4 | kind << 8 | rgrp << 12 | cgrp << 13
   auto src_code = [](int r0, int c0, int tr, int stride) { return r0 | (c0 << 4) | (tr << 8) | (stride << 16); };
   auto dims = [](int nr, int nc, int kind, int rg, int cg) { return nr | (nc << 4) | (kind << 8) | (rg << 12) | (cg << 13); };
@@ -1755,25 +1755,25 @@ int build_sum_items_intr(theia_ba_handle_s* h, const int* cam_group, FusedHost& 
       const int la = us & 0xff, lb = us >> 8;
       const int ca = cam_of(la), cb = cam_of(lb);
       const int rca = h->cam_red[ca], rcb = h->cam_red[cb], ga = h->grp_red[cam_group[ca]], gb = h->grp_red[cam_group[cb]];
-      const int base = r.part_off + 100 * k;
+      const int base = r.part_off + BW * BW * k;
       if (rca >= 0 && rcb >= 0)
-        sink(Ent{key_blk(ni + 6 * rca, ni + 6 * rcb), base, src_code(0, 0, 0, 10), dims(6, 6, la == lb ? SK_LOWER : SK_BLOCK, 0, 0)});
+        sink(Ent{key_blk(ni + 6 * rca, ni + 6 * rcb), base, src_code(0, 0, 0, BW), dims(6, 6, la == lb ? SK_LOWER : SK_BLOCK, 0, 0)});
       if (rca >= 0 && gb >= 0)
-        sink(Ent{key_blk(ni + 6 * rca, 10 * gb), base, src_code(0, 6, 0, 10), dims(6, KI, SK_BLOCK, 0, 1)});
+        sink(Ent{key_blk(ni + 6 * rca, 10 * gb), base, src_code(0, 6, 0, BW), dims(6, KI, SK_BLOCK, 0, 1)});
       if (la != lb && rcb >= 0 && ga >= 0)
-        sink(Ent{key_blk(ni + 6 * rcb, 10 * ga), base, src_code(6, 0, 1, 10), dims(6, KI, SK_BLOCK, 0, 1)});
+        sink(Ent{key_blk(ni + 6 * rcb, 10 * ga), base, src_code(6, 0, 1, BW), dims(6, KI, SK_BLOCK, 0, 1)});
       if (ga >= 0 && gb >= 0) {
-        if (ga > gb) sink(Ent{key_blk(10 * ga, 10 * gb), base, src_code(6, 6, 0, 10), dims(KI, KI, SK_BLOCK, 1, 1)});
-        else if (ga < gb) sink(Ent{key_blk(10 * gb, 10 * ga), base, src_code(6, 6, 1, 10), dims(KI, KI, SK_BLOCK, 1, 1)});
+        if (ga > gb) sink(Ent{key_blk(10 * ga, 10 * gb), base, src_code(6, 6, 0, BW), dims(KI, KI, SK_BLOCK, 1, 1)});
+        else if (ga < gb) sink(Ent{key_blk(10 * gb, 10 * ga), base, src_code(6, 6, 1, BW), dims(KI, KI, SK_BLOCK, 1, 1)});
         else {
-          sink(Ent{key_blk(10 * ga, 10 * ga), base, src_code(6, 6, 0, 10), dims(KI, KI, SK_LOWER, 1, 1)});
-          if (la != lb) sink(Ent{key_blk(10 * ga, 10 * ga), base, src_code(6, 6, 1, 10), dims(KI, KI, SK_LOWER, 1, 1)});
+          sink(Ent{key_blk(10 * ga, 10 * ga), base, src_code(6, 6, 0, BW), dims(KI, KI, SK_LOWER, 1, 1)});
+          if (la != lb) sink(Ent{key_blk(10 * ga, 10 * ga), base, src_code(6, 6, 1, BW), dims(KI, KI, SK_LOWER, 1, 1)});
         }
       }
     }
     for (int l = 0; l < r.W; ++l) {
       const int c = cam_of(l), rc = h->cam_red[c], gr = h->grp_red[cam_group[c]];
-      const int base = r.part_off + 100 * r.ntgt + 30 * l;
+      const int base = r.part_off + BW * BW * r.ntgt + 3 * BW * l;
       if (rc >= 0) sink(Ent{key_vec(ni + 6 * rc), base, src_code(0, 0, 0, 3), dims(6, 3, SK_VEC, 0, 0)});
       if (gr >= 0) sink(Ent{key_vec(10 * gr), base, src_code(6, 0, 0, 3), dims(KI, 3, SK_VEC, 1, 0)});
     }
