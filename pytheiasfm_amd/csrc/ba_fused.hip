@@ -476,12 +476,21 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
 // tile_part: [ntiles][5] = {cand_cost, mcc, stepsq, xnormsq, invalid}
 constexpr int kCamLdsB = 70;   // doubles per staged camera: camrot (40) | camdir (12) | candidate ext + R (16) | pad (2); 35 16-B pieces
 
-template <int PD, int TPS, unsigned MODELS, int LOSSK, int WPS>
+// INTR (the compound-block plan, free intrinsics; KMASK as k_lin_schur_i): the camera block of an observation multiplies the
+// solved step itself -- F y_c + Fk y_k, from lin5's 2 x 6 and 2 x 10 blocks -- and the candidate carries its own intrinsics.
+// Staged per camera then: camrot (40) | y_c (6) | y_k scaled, free parameters only (10) | candidate ext + R (16) | candidate
+// intrinsics (10) = 82 doubles, 41 16-B pieces.  ysol: the solved step, intrinsics slots first (null without INTR).
+constexpr int kCamLdsBI = 82;
+template <int PD, int TPS, unsigned MODELS, int LOSSK, int WPS, bool INTR = false, unsigned KMASK = 0u>
 __global__ __launch_bounds__(64 * TPS, WPS) void k_backsub_runs(DevProblem P, const double* __restrict__ pts, double* __restrict__ cand_pts,
-                                                             const double* __restrict__ Vinv, double* __restrict__ tile_part) {
+                                                             const double* __restrict__ Vinv, double* __restrict__ tile_part,
+                                                             const double* __restrict__ ysol = nullptr) {
   constexpr int NT = PD * (PD + 1) / 2;
   constexpr int SUB = TPS * kWave;
-  __shared__ __attribute__((aligned(16))) double s_cam[kFusedMaxStage * kCamLdsB];
+  constexpr int PITCH = INTR ? kCamLdsBI : kCamLdsB;
+  constexpr int OFF_CAND = INTR ? 56 : 52;          // candidate ext + R inside a staged block
+  constexpr int OFF_CINTR = INTR ? 72 : kCamRotIntr;   // the intrinsics the candidate is projected with
+  __shared__ __attribute__((aligned(16))) double s_cam[(INTR ? kFusedMaxStageIntr : kFusedMaxStage) * PITCH];
   __shared__ __attribute__((aligned(16))) double s_slot[TPS][64 * 4];
   __shared__ int s_next;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -496,6 +505,31 @@ __global__ __launch_bounds__(64 * TPS, WPS) void k_backsub_runs(DevProblem P, co
   if (tid == 0) pending = atomicAdd(P.frun_next + 1, 1);
   const FusedRun run = P.fruns[P.frun_order[rix]];
   const int nsc = (run.ntiles + TPS - 1) / TPS;
+  if constexpr (INTR) {
+    for (int j = tid; j < run.nstage * (kCamLdsBI / 2); j += SUB) {
+      const int k = j / (kCamLdsBI / 2), piece = j - k * (kCamLdsBI / 2);
+      const int cidx = P.frun_stage[run.stage_off + k];
+      double2 v = make_double2(0.0, 0.0);
+      if (piece < 20) v = reinterpret_cast<const double2*>(P.camrot + (size_t)kCamRot * cidx)[piece];
+      else if (piece < 28) {   // the solved step of the camera (6) and of its group's free intrinsics (10, Jacobi-scaled)
+        const int rc = P.cam_red[cidx], g = P.cam_group[cidx], gr = P.grp_red[g];
+        const unsigned fm = gr >= 0 ? (KMASK != 0u ? KMASK : P.grp_free[g]) : 0u;
+        double e2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = 2 * (piece - 20) + h;
+          double val = 0.0;
+          if (e < 6) { if (rc >= 0) val = ysol[P.ni + 6 * rc + e]; }
+          else if ((fm >> (e - 6)) & 1u) val = ysol[10 * gr + (e - 6)] * P.scale_i[(size_t)g * THEIA_MAX_INTRINSICS + (e - 6)];
+          e2[h] = val;
+        }
+        v = make_double2(e2[0], e2[1]);
+      }
+      else if (piece < 36) v = reinterpret_cast<const double2*>(P.camrot_cand + (size_t)kCamRot * cidx)[piece - 28];
+      else v = reinterpret_cast<const double2*>(P.camrot_cand + (size_t)kCamRot * cidx + kCamRotIntr)[piece - 36];
+      reinterpret_cast<double2*>(s_cam + k * kCamLdsBI)[piece] = v;
+    }
+  } else
   for (int j = tid; j < run.nstage * (kCamLdsB / 2); j += SUB) {
     const int k = j / (kCamLdsB / 2), piece = j - k * (kCamLdsB / 2);
     const int cidx = P.frun_stage[run.stage_off + k];
@@ -522,64 +556,86 @@ __global__ __launch_bounds__(64 * TPS, WPS) void k_backsub_runs(DevProblem P, co
     const LanePre<PD>& c = cur;
     const bool active = c.active;
     const unsigned cslot = (c.lc & 0x80u) ? (unsigned)run.W + (c.lc & 0x7fu) : c.lc;
-    const double* cb = s_cam + cslot * kCamLdsB;
+    const double* cb = s_cam + cslot * PITCH;
     const double X[4] = {c.X.x, c.X.y, c.X.z, c.X.w};
-    const double2 c01 = *reinterpret_cast<const double2*>(cb), c2w = *reinterpret_cast<const double2*>(cb + 2);
-    const double C[3] = {c01.x, c01.y, c2w.x};
-    const double p[3] = {X[0] - X[3] * C[0], X[1] - X[3] * C[1], X[2] - X[3] * C[2]};
-    const bool behind = (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) < 1e-8;
-    double R[9];
-    {
-      const double2 r0 = *reinterpret_cast<const double2*>(cb + 6), r1 = *reinterpret_cast<const double2*>(cb + 8), r2 = *reinterpret_cast<const double2*>(cb + 10),
-                    r3 = *reinterpret_cast<const double2*>(cb + 12), r4 = *reinterpret_cast<const double2*>(cb + 14);
-      R[0] = r0.x; R[1] = r0.y; R[2] = r1.x; R[3] = r1.y; R[4] = r2.x; R[5] = r2.y; R[6] = r3.x; R[7] = r3.y; R[8] = r4.x;
-    }
-    const double q[3] = {R[0] * p[0] + R[1] * p[1] + R[2] * p[2], R[3] * p[0] + R[4] * p[1] + R[5] * p[2], R[6] * p[0] + R[7] * p[1] + R[8] * p[2]};
     const int model = c.depth ? THIP_MODEL_DEPTH_ROW : (int)cb[kCamRotModel];
-    double uvp[2], Jq[6];
-    project<true, false, MODELS>(model, cb + kCamRotIntr, q, uvp, Jq);
-    double r[2] = {c.si.x * (uvp[0] - c.uv.x), c.si.y * (uvp[1] - c.uv.y)};
-    double sr = 1.0;
-    if constexpr (LOSSK != 0) {
-      double rho1;
-      (void)loss_eval_k<LOSSK>(P.loss_type, c.depth ? P.loss_width_depth : P.loss_width, r[0] * r[0] + r[1] * r[1], &rho1);
-      sr = fsqrt(rho1);
-      r[0] *= sr; r[1] *= sr;
-    }
-    double mc[2], Jt[2 * PD];
-    {
-      // the camera's step as {D, v}: F y_c = -sr s Jq (D p - w v)   (camera_step_direction, ba_device.h; zero for constant cameras)
-      double u[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) u[i] = (cb[40 + 3 * i] * p[0] + cb[40 + 3 * i + 1] * p[1] + cb[40 + 3 * i + 2] * p[2]) - X[3] * cb[49 + i];
-      double v[4] = {X[0], X[1], X[2], 1.0}, beta = 0.0, nx = 1.0;
-      if constexpr (PD == 3) {
-        const double sigma = X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
-        nx = fsqrt(X[3] * X[3] + sigma);
-        if (sigma <= DBL_EPSILON) { if (X[3] < 0.0) beta = 2.0; }
-        else {
-          const double vp = (X[3] <= 0.0) ? X[3] - nx : -sigma / (X[3] + nx);
-          beta = 2.0 * vp * vp / (sigma + vp * vp);
-          const double ivp = 1.0 / vp;
-          v[0] *= ivp; v[1] *= ivp; v[2] *= ivp;
-        }
-      }
-      const double sia[2] = {c.si.x * sr, c.si.y * sr};
+    double r[2], mc[2], Jt[2 * PD];
+    bool behind = false;
+    if constexpr (INTR) {
+      // the compound camera block times the solved step: F y_c + Fk y_k (lin5 leaves r, F, Fk zero where nothing is evaluated,
+      // the point block zero for a constant point)
+      double Jc[12], Jk[2 * THEIA_MAX_INTRINSICS], cst;
+      bool vld;
+      lin5<PD, MODELS, LOSSK, true>(P, c, cb, r, cst, vld, Jc, Jt, Jk);
+      const double* ys = cb + 40;
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const double* jq = Jq + 3 * a;
-        mc[a] = -sia[a] * (jq[0] * u[0] + jq[1] * u[1] + jq[2] * u[2]);
-        const double A0 = jq[0] * R[0] + jq[1] * R[3] + jq[2] * R[6];
-        const double A1 = jq[0] * R[1] + jq[1] * R[4] + jq[2] * R[7];
-        const double A2 = jq[0] * R[2] + jq[1] * R[5] + jq[2] * R[8];
-        const double j4[4] = {A0, A1, A2, -(A0 * C[0] + A1 * C[1] + A2 * C[2])};
+        double sm = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sm += Jc[6 * a + k] * ys[k];
+#pragma unroll
+        for (int k = 0; k < THEIA_MAX_INTRINSICS; ++k) {
+          if (KMASK != 0u && !((KMASK >> k) & 1u)) continue;   // (a frozen parameter's step is zero)
+          sm += Jk[THEIA_MAX_INTRINSICS * a + k] * ys[6 + k];
+        }
+        mc[a] = sm;
+      }
+    } else {
+      const double2 c01 = *reinterpret_cast<const double2*>(cb), c2w = *reinterpret_cast<const double2*>(cb + 2);
+      const double C[3] = {c01.x, c01.y, c2w.x};
+      const double p[3] = {X[0] - X[3] * C[0], X[1] - X[3] * C[1], X[2] - X[3] * C[2]};
+      behind = (p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) < 1e-8;
+      double R[9];
+      {
+        const double2 r0 = *reinterpret_cast<const double2*>(cb + 6), r1 = *reinterpret_cast<const double2*>(cb + 8), r2 = *reinterpret_cast<const double2*>(cb + 10),
+                      r3 = *reinterpret_cast<const double2*>(cb + 12), r4 = *reinterpret_cast<const double2*>(cb + 14);
+        R[0] = r0.x; R[1] = r0.y; R[2] = r1.x; R[3] = r1.y; R[4] = r2.x; R[5] = r2.y; R[6] = r3.x; R[7] = r3.y; R[8] = r4.x;
+      }
+      const double q[3] = {R[0] * p[0] + R[1] * p[1] + R[2] * p[2], R[3] * p[0] + R[4] * p[1] + R[5] * p[2], R[6] * p[0] + R[7] * p[1] + R[8] * p[2]};
+      double uvp[2], Jq[6];
+      project<true, false, MODELS>(model, cb + kCamRotIntr, q, uvp, Jq);
+      r[0] = c.si.x * (uvp[0] - c.uv.x); r[1] = c.si.y * (uvp[1] - c.uv.y);
+      double sr = 1.0;
+      if constexpr (LOSSK != 0) {
+        double rho1;
+        (void)loss_eval_k<LOSSK>(P.loss_type, c.depth ? P.loss_width_depth : P.loss_width, r[0] * r[0] + r[1] * r[1], &rho1);
+        sr = fsqrt(rho1);
+        r[0] *= sr; r[1] *= sr;
+      }
+      {
+        // the camera's step as {D, v}: F y_c = -sr s Jq (D p - w v)   (camera_step_direction, ba_device.h; zero for constant cameras)
+        double u[3];
+  #pragma unroll
+        for (int i = 0; i < 3; ++i) u[i] = (cb[40 + 3 * i] * p[0] + cb[40 + 3 * i + 1] * p[1] + cb[40 + 3 * i + 2] * p[2]) - X[3] * cb[49 + i];
+        double v[4] = {X[0], X[1], X[2], 1.0}, beta = 0.0, nx = 1.0;
         if constexpr (PD == 3) {
-          const double jv = j4[0] * v[0] + j4[1] * v[1] + j4[2] * v[2] + j4[3] * v[3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) Jt[3 * a + k] = (sia[a] * c.sp[k]) * (nx * (j4[k] - beta * v[k] * jv));
-        } else {
-#pragma unroll
-          for (int k = 0; k < PD; ++k) Jt[PD * a + k] = (sia[a] * c.sp[k]) * j4[k];
+          const double sigma = X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+          nx = fsqrt(X[3] * X[3] + sigma);
+          if (sigma <= DBL_EPSILON) { if (X[3] < 0.0) beta = 2.0; }
+          else {
+            const double vp = (X[3] <= 0.0) ? X[3] - nx : -sigma / (X[3] + nx);
+            beta = 2.0 * vp * vp / (sigma + vp * vp);
+            const double ivp = 1.0 / vp;
+            v[0] *= ivp; v[1] *= ivp; v[2] *= ivp;
+          }
+        }
+        const double sia[2] = {c.si.x * sr, c.si.y * sr};
+  #pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const double* jq = Jq + 3 * a;
+          mc[a] = -sia[a] * (jq[0] * u[0] + jq[1] * u[1] + jq[2] * u[2]);
+          const double A0 = jq[0] * R[0] + jq[1] * R[3] + jq[2] * R[6];
+          const double A1 = jq[0] * R[1] + jq[1] * R[4] + jq[2] * R[7];
+          const double A2 = jq[0] * R[2] + jq[1] * R[5] + jq[2] * R[8];
+          const double j4[4] = {A0, A1, A2, -(A0 * C[0] + A1 * C[1] + A2 * C[2])};
+          if constexpr (PD == 3) {
+            const double jv = j4[0] * v[0] + j4[1] * v[1] + j4[2] * v[2] + j4[3] * v[3];
+  #pragma unroll
+            for (int k = 0; k < 3; ++k) Jt[3 * a + k] = (sia[a] * c.sp[k]) * (nx * (j4[k] - beta * v[k] * jv));
+          } else {
+  #pragma unroll
+            for (int k = 0; k < PD; ++k) Jt[PD * a + k] = (sia[a] * c.sp[k]) * j4[k];
+          }
         }
       }
     }
@@ -651,7 +707,7 @@ __global__ __launch_bounds__(64 * TPS, WPS) void k_backsub_runs(DevProblem P, co
     double ccost = 0.0;
     bool cvalid = true;
     {
-      const double* cc = cb + 52;
+      const double* cc = cb + OFF_CAND;
       const double2 d01 = *reinterpret_cast<const double2*>(cc), d2w = *reinterpret_cast<const double2*>(cc + 2);
       const double Cc[3] = {d01.x, d01.y, d2w.x};
       const double pc[3] = {Xp[0] - Xp[3] * Cc[0], Xp[1] - Xp[3] * Cc[1], Xp[2] - Xp[3] * Cc[2]};
@@ -664,7 +720,7 @@ __global__ __launch_bounds__(64 * TPS, WPS) void k_backsub_runs(DevProblem P, co
       }
       const double qc[3] = {Rc[0] * pc[0] + Rc[1] * pc[1] + Rc[2] * pc[2], Rc[3] * pc[0] + Rc[4] * pc[1] + Rc[5] * pc[2], Rc[6] * pc[0] + Rc[7] * pc[1] + Rc[8] * pc[2]};
       double uvc[2], Jqc[6];
-      cvalid = project<false, false, MODELS>(model, cb + kCamRotIntr, qc, uvc, Jqc);
+      cvalid = project<false, false, MODELS>(model, cb + OFF_CINTR, qc, uvc, Jqc);
       const double rc0 = c.si.x * (uvc[0] - c.uv.x), rc1 = c.si.y * (uvc[1] - c.uv.y);
       double s2 = rc0 * rc0 + rc1 * rc1;
       if (cbehind) { cvalid = false; s2 = 0.0; }
@@ -808,6 +864,26 @@ bool launch_backsub_runs(const DevProblem& P, const double* pts, double* cand_pt
   if (P.pd == 3) { if (trig) THIP_BS(3, kModelsAll); else THIP_BS(3, kModelsNoTrig); }
   else { if (trig) THIP_BS(4, kModelsAll); else THIP_BS(4, kModelsNoTrig); }
 #undef THIP_BS
+  return true;
+}
+
+// the same over the runs of the compound-block plan (free intrinsics): y = the solved step, intrinsics slots first
+bool launch_backsub_runs_intr(const DevProblem& P, const double* pts, double* cand_pts, const double* Vinv, double* tile_part,
+                              const double* y, hipStream_t st) {
+  static const bool off = getenv("THEIA_HIP_BACKSUB_TILES") != nullptr;
+  if (off || !P.ni || !P.fused_bw || P.n_fruns == 0 || !P.camrot || !P.camrot_cand || !P.frun_stage) return false;
+  constexpr unsigned kFR = (1u << 0) | (3u << 5);   // FOCAL_LENGTH | RADIAL_DISTORTION (ba_fused_intr.hip: kMaskFocalRadial)
+  const bool trig = (P.model_mask & ~kModelsNoTrig) != 0;
+  const bool trivial = P.loss_type == THEIA_LOSS_TRIVIAL;
+  const int grid = std::min(P.n_fruns, 512);
+#define THIP_BSI2(PD_, M_, LK_) do { \
+    if (P.fused_kmask == kFR) k_backsub_runs<PD_, 4, M_, LK_, 2, true, kFR><<<grid, 256, 0, st>>>(P, pts, cand_pts, Vinv, tile_part, y); \
+    else k_backsub_runs<PD_, 4, M_, LK_, 2, true, 0u><<<grid, 256, 0, st>>>(P, pts, cand_pts, Vinv, tile_part, y); } while (0)
+#define THIP_BSI(PD_, M_) do { if (trivial) THIP_BSI2(PD_, M_, 0); else THIP_BSI2(PD_, M_, 2); } while (0)
+  if (P.pd == 3) { if (trig) THIP_BSI(3, kModelsAll); else THIP_BSI(3, kModelsNoTrig); }
+  else { if (trig) THIP_BSI(4, kModelsAll); else THIP_BSI(4, kModelsNoTrig); }
+#undef THIP_BSI
+#undef THIP_BSI2
   return true;
 }
 

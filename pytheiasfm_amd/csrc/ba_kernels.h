@@ -200,6 +200,8 @@ void launch_scatter_colsq(const DevProblem& P, const double* colsq_red, double* 
 void launch_cam_prep(const DevProblem& P, const double* cam, const double* intr, double* camrot, hipStream_t st, const double* ycam = nullptr);
 // K4 + K5 by persistent workgroups over the fused plan's runs (ba_fused.hip: k_backsub_runs); false = not applicable
 bool launch_backsub_runs(const DevProblem& P, const double* pts, double* cand_pts, const double* Vinv, double* tile_part, hipStream_t st);
+bool launch_backsub_runs_intr(const DevProblem& P, const double* pts, double* cand_pts, const double* Vinv, double* tile_part,
+                              const double* y, hipStream_t st);   // the compound-block plan (free intrinsics); y: the solved step
 void launch_reduce_tiles(int ntiles, const double* tile_part, int nfields, const int* field_to_scal,
                          const int* field_is_max, double* scal, hipStream_t st, double* red_part = nullptr);
 // first stage of a two-stage reduction: kReduceBlocks workgroups fold contiguous slices of the per-tile partials into

@@ -1606,6 +1606,7 @@ void launch_backsub(const DevProblem& P, const double* cam, const double* pts, c
   if (P.ni && P.fused_bw > 0 && P.n_fruns > 0 && P.camrot && P.camrot_cand) {
     // fused path with intrinsics: the state's blocks are in P.camrot; the candidate cameras with the candidate intrinsics
     launch_cam_prep(P, cand_cam, P.intr_cand, P.camrot_cand, st);
+    if (launch_backsub_runs_intr(P, pts, cand_pts, Vinv, tile_part, yc, st)) return;   // round 5: over the runs, camera blocks in LDS
     constexpr unsigned kFR = (1u << 0) | (3u << 5);   // FOCAL_LENGTH | RADIAL_DISTORTION (ba_fused_intr.hip: kMaskFocalRadial)
     if (P.fused_kmask == kFR) {
       if (P.pd == 3) k_backsub<3, true, true, kFR><<<tile_blocks(P.ntiles), kBlock, 0, st>>>(P, cam, pts, cand_cam, cand_pts, ycc, Vinv, tile_part);
