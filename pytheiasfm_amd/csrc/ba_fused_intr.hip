@@ -27,19 +27,31 @@
 namespace thip {
 namespace {
 
-// Lane split of a compound block of width BW = 6 + KI: lane `sub` of a target owns rows [row0(sub), row0(sub) + 3) -- KI = 3:
-// three lanes {0, 3, 6}; KI = 4: four lanes {0, 3, 6, 8}, the last two with two rows each.
-template <int KI> constexpr int lanes_per_target() { return KI == 3 ? 3 : 4; }
-constexpr int kRPL = 3;                    // rows of the block per lane (accumulators: kRPL x BW)
-constexpr int kBWP = 10;                   // row stride of Jc inside a record (BW rounded up to even: 16-B aligned rows)
-template <int KI> THIP_DEV int sub_row0(int sub) { return sub < 2 ? 3 * sub : 6 + (KI == 3 ? 0 : 2 * (sub - 2)); }
-template <int KI> THIP_DEV int sub_rows(int sub) { return (KI == 3 || sub < 2) ? 3 : 2; }
-constexpr int kRowBytesI = 16;             // slot-table row: kFusedMaxCamsIntr rounded up
+// Lane split of a compound block of width BW = 6 + KI: lane `sub` of a target owns RPL consecutive rows of it, the last lanes
+// one row less where BW is not a multiple of RPL -- KI = 3: three lanes of three rows {0, 3, 6}; KI = 4: four lanes {0, 3, 6, 8};
+// KI = 7 (every intrinsic of the pinhole model free): four lanes of 4 + 3 + 3 + 3 rows {0, 4, 7, 10}, so that the 55 target
+// blocks of ten cameras still fit the 256 threads of a workgroup (the register budget is no constraint there: the records
+// of that width leave room for one workgroup per CU).
+template <int KI> constexpr int rpl() { return KI <= 4 ? 3 : 4; }   // rows of the block per lane (accumulators: RPL x BW)
+template <int KI> constexpr int lanes_per_target() { return (6 + KI + rpl<KI>() - 1) / rpl<KI>(); }
+template <int KI> constexpr int full_lanes() { return lanes_per_target<KI>() - (rpl<KI>() * lanes_per_target<KI>() - (6 + KI)); }   // lanes with RPL rows
+template <int KI> THIP_DEV int sub_row0(int sub) { return sub < full_lanes<KI>() ? rpl<KI>() * sub : rpl<KI>() * full_lanes<KI>() + (rpl<KI>() - 1) * (sub - full_lanes<KI>()); }
+template <int KI> THIP_DEV int sub_rows(int sub) { return sub < full_lanes<KI>() ? rpl<KI>() : rpl<KI>() - 1; }
+static_assert(lanes_per_target<3>() == 3 && lanes_per_target<4>() == 4 && full_lanes<4>() == 2 && lanes_per_target<7>() == 4 && full_lanes<7>() == 1, "lane split");
+template <int KI> constexpr int bwp() { return (6 + KI + 1) & ~1; }   // row stride of Jc inside a record (BW rounded up to even: 16-B aligned rows)
+constexpr int kRowBytesI = 16;             // slot-table row: the most local cameras of a run, rounded up
 static_assert(kFusedMaxCamsIntr <= kRowBytesI, "slot-table row too short");
-static_assert(kFusedIntrRows == 4 && kFusedIntrWidth == kBWP, "partial blocks are stored kBWP x kBWP");
-// LDS record of one observation: {Jc row 0 (kBWP) | Jc row 1 (kBWP) | Ehat (2 x PD, interleaved as in ba_fused.hip) | r (2) |
-// r - Ehat ghat (2)}, an odd number of 16-B pieces
-template <int PD> constexpr int reci_doubles() { return PD == 3 ? 30 : 34; }
+// LDS record of one observation: {Jc row 0 (BWP) | Jc row 1 (BWP) | Ehat (2 x PD, interleaved as in ba_fused.hip) | r (2) |
+// r - Ehat ghat (2)}, at least the RPL x BW doubles a lane parks there when the track slices are combined, an odd number of
+// 16-B pieces: 30 / 34 doubles (PD = 3 / 4) with three or four intrinsics rows, 54 with seven
+template <int PD, int KI> constexpr int reci_doubles() {
+  int rd = 2 * bwp<KI>() + 2 * PD + 4;
+  if (rd < rpl<KI>() * (6 + KI)) rd = rpl<KI>() * (6 + KI);
+  rd = (rd + 1) & ~1;
+  if ((rd / 2) % 2 == 0) rd += 2;
+  return rd;
+}
+static_assert(reci_doubles<3, 3>() == 30 && reci_doubles<4, 3>() == 34 && reci_doubles<3, 4>() == 30 && reci_doubles<4, 4>() == 34, "record layout of the three / four row instances");
 
 THIP_DEV unsigned segment_or_i(const Segment& s, int lane, unsigned v) {
   const int pos = lane - s.start;
@@ -61,15 +73,16 @@ constexpr int nth_bit(unsigned m, int k) {
 // Round 5: the linearisation is lin5 (ba_fused_lin.h) on the prefetched observation `c` and the camera's block in LDS (s_cam:
 // the run's local cameras, then the constant cameras its tracks see), as in k_lin_schur; the generic lane_linearize with its
 // 320-B gather per observation was two thirds of this kernel (407 of 612 us at C4 with the pair products switched off).
-template <int PD, int TPS, unsigned MODELS, unsigned KMASK, int LOSSK>
+template <int PD, int TPS, unsigned MODELS, unsigned KMASK, int LOSSK, int KI>
 __device__ __forceinline__ void fusedi_phase_l(const DevProblem& P, const LanePre<PD>& c, const double* __restrict__ s_cam, int W, int tile,
                                                bool tile_ok, int wv, int lane, double inv_radius,
                                                double* __restrict__ Vinv, double* __restrict__ tile_part,
                                                double* __restrict__ s_rec, uint8_t* __restrict__ s_tslot,
                                                unsigned* __restrict__ s_tmask) {
   constexpr int NT = PD * (PD + 1) / 2;
-  constexpr int RD = reci_doubles<PD>();
-  constexpr int KR = kFusedIntrRows;
+  constexpr int RD = reci_doubles<PD, KI>();
+  constexpr int kBWP = bwp<KI>();
+  constexpr int KR = kBWP - 6;             // compact intrinsics rows of a record (KI of them in use, the rest zero)
   const bool active = c.active;
   const bool is_tgt = !(c.lc & 0x80u);
   const unsigned cslot = is_tgt ? c.lc : (unsigned)W + (c.lc & 0x7fu);
@@ -84,7 +97,8 @@ __device__ __forceinline__ void fusedi_phase_l(const DevProblem& P, const LanePr
   // compact intrinsics rows: row k = the k-th free parameter of the camera's group
   double jk[2 * KR];
   if constexpr (KMASK != 0u) {
-    constexpr int Q[KR] = {nth_bit(KMASK, 0), nth_bit(KMASK, 1), nth_bit(KMASK, 2), nth_bit(KMASK, 3)};
+    static_assert(KMASK == 0u || KR == 4, "a compile-time mask picks at most four rows");
+    constexpr int Q[4] = {nth_bit(KMASK, 0), nth_bit(KMASK, 1), nth_bit(KMASK, 2), nth_bit(KMASK, 3)};
 #pragma unroll
     for (int k = 0; k < KR; ++k) {
       double sc = 0.0;
@@ -114,9 +128,9 @@ __device__ __forceinline__ void fusedi_phase_l(const DevProblem& P, const LanePr
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) R[5 * i + q] = make_double2(L.Jc[6 * i + 2 * q], L.Jc[6 * i + 2 * q + 1]);
+      for (int q = 0; q < 3; ++q) R[(kBWP / 2) * i + q] = make_double2(L.Jc[6 * i + 2 * q], L.Jc[6 * i + 2 * q + 1]);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) R[5 * i + 3 + q] = make_double2(jk[KR * i + 2 * q], jk[KR * i + 2 * q + 1]);
+      for (int q = 0; q < KR / 2; ++q) R[(kBWP / 2) * i + 3 + q] = make_double2(jk[KR * i + 2 * q], jk[KR * i + 2 * q + 1]);
     }
   }
   const Segment sg = lane_segment_all(L.p, lane);
@@ -241,13 +255,15 @@ template <int PD, int TPS, unsigned MODELS, int KI, unsigned KMASK, int LOSSK>
 __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const double* __restrict__ pts,
                                                              const double* __restrict__ radius_p,
                                                              double* __restrict__ Vinv, double* __restrict__ tile_part) {
-  constexpr int RD = reci_doubles<PD>();
+  constexpr int RD = reci_doubles<PD, KI>();
   constexpr int BW = 6 + KI;
+  constexpr int kBWP = bwp<KI>();
   constexpr int NS = lanes_per_target<KI>();
   constexpr int OE = 2 * kBWP;                         // offset of Ehat inside a record
   constexpr int SUB = TPS * kWave;
   constexpr int SUBT = TPS * kFusedTileTracks;
   constexpr int NWV = TPS;
+  constexpr int kRPL = rpl<KI>();
   constexpr int NA = kRPL * BW;                        // accumulators of a lane: its rows of the block
   __shared__ __attribute__((aligned(16))) double s_rec[SUB * RD];
   __shared__ __attribute__((aligned(16))) double s_cam[kFusedMaxStageIntr * kCamLds];   // the run's camera blocks (k_cam_prep): local, then constant
@@ -294,7 +310,7 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
       int ntile = 0; bool ntile_ok = false;
       const int scn = min(sc + 1, nsc - 1);   // (the last sub-chunk reloads itself: unconditional loads, nothing is used)
       pre_level1<PD, TPS>(P, run, scn, wv, lane, ntile, ntile_ok, nxt);
-      fusedi_phase_l<PD, TPS, MODELS, KMASK, LOSSK>(P, cur, s_cam, run.W, tile, tile_ok, wv, lane, inv_radius, Vinv, tile_part, s_rec, s_tslot, s_tmask);
+      fusedi_phase_l<PD, TPS, MODELS, KMASK, LOSSK, KI>(P, cur, s_cam, run.W, tile, tile_ok, wv, lane, inv_radius, Vinv, tile_part, s_rec, s_tslot, s_tmask);
       pre_level2<PD>(P, pts, nxt);
       __builtin_amdgcn_s_setprio(1);   // phase S is pure issue, phase L a chain of latencies: S first, L fills the gaps (ba_fused.hip)
       __syncthreads();
@@ -356,12 +372,12 @@ __global__ __launch_bounds__(64 * TPS, 2) void k_lin_schur_i(DevProblem P, const
                 t0v[a] = f0 * M[0][0] + f1 * M[1][0];
                 t1v[a] = f0 * M[0][1] + f1 * M[1][1];
               }
-              // Jc_b in two halves of columns (the whole block would hold 20 more registers across the products)
+              // Jc_b in pieces of five columns (the whole block would hold 20 more registers across the products)
 #pragma unroll
-              for (int hb = 0; hb < 2; ++hb) {
+              for (int hb = 0; hb < (BW + 4) / 5; ++hb) {
                 double Fb0[5], Fb1[5];
 #pragma unroll
-                for (int q = 0; q < 5; ++q) { Fb0[q] = rb[5 * hb + q]; Fb1[q] = rb[kBWP + 5 * hb + q]; }
+                for (int q = 0; q < 5; ++q) { Fb0[q] = (5 * hb + q < kBWP) ? rb[5 * hb + q] : 0.0; Fb1[q] = (5 * hb + q < kBWP) ? rb[kBWP + 5 * hb + q] : 0.0; }
 #pragma unroll
                 for (int a = 0; a < kRPL; ++a)
 #pragma unroll
@@ -549,7 +565,8 @@ constexpr unsigned kMaskFocalRadial = (1u << 0) | (3u << 5);
     if (P.fused_bw == 9 && P.fused_kmask == kMaskFocalRadial)                                                     \
       k_lin_schur_i<PD_, 4, M_, 3, kMaskFocalRadial, LK_><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);    \
     else if (P.fused_bw == 9) k_lin_schur_i<PD_, 4, M_, 3, 0u, LK_><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part); \
-    else k_lin_schur_i<PD_, 4, M_, 4, 0u, LK_><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);             \
+    else if (P.fused_bw == 10) k_lin_schur_i<PD_, 4, M_, 4, 0u, LK_><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part); \
+    else k_lin_schur_i<PD_, 4, M_, 7, 0u, LK_><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);   /* 13: up to seven rows */ \
   } while (0)
   // (two loss instances: the trivial loss without corrector code, everything else with the full corrector)
 #define THIP_LSI(PD_, M_) do { if (P.loss_type == THEIA_LOSS_TRIVIAL) THIP_LSI2(PD_, M_, 0); else THIP_LSI2(PD_, M_, 2); } while (0)

@@ -1505,6 +1505,17 @@ int build_gather_lists_intr(theia_ba_handle_s* h, const theia_ba_problem* p, con
 //   skey   : [np] ordering key of a track rank (its first variable camera)
 // Tracks that do not fit the fused kernel (more than 64 observations, more than kFusedMaxCams variable cameras,
 // a camera seen twice) go to the per-observation slow path (k_long_*), like the > 64 ones before.
+// local cameras a run of the fused plan may hold: its target blocks (pairs, diagonal included) times the lanes per block fit the
+// 256 threads of a workgroup -- 22 cameras / 253 blocks of one lane; compound blocks of width bw: three rows per lane
+inline int fused_run_cameras(int bw) {
+  if (bw == 0) return kFusedMaxCams;
+  if (bw == 9) return kFusedMaxCamsIntr;   // 78 blocks x 3 lanes
+  if (bw == 10) return 10;                 // 55 x 4
+  return 10;                               // 13 rows: 55 x 4
+}
+// lanes of a target block (ba_fused_intr.hip: lanes_per_target): three rows per lane up to width 10, four at 13
+inline int fused_lanes_per_target(int bw) { return bw == 0 ? 1 : (bw <= 10 ? (bw + 2) / 3 : (bw + 3) / 4); }
+
 struct FusedHost {
   std::vector<FusedRun> runs;
   std::vector<int> cams, stage, tile_trk_end, sum_items, sum_src;
@@ -1532,9 +1543,9 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
   // geometry of the consumer lanes: lanes per target block, rows per local camera, partial-sum doubles (ba_fused.hip:
   // one lane per 6 x 6 block; ba_fused_intr.hip: 3 or 4 lanes per compound block, stored 10 x 10)
   const int bw = h->fused_bw;
-  const size_t lanes_tgt = bw == 0 ? 1 : (bw == 9 ? 3 : 4), rows_cam = bw == 0 ? 6 : (size_t)bw;
+  const size_t lanes_tgt = bw == 0 ? 1 : (size_t)fused_lanes_per_target(bw), rows_cam = bw == 0 ? 6 : (size_t)bw;
   const size_t part_tgt = bw == 0 ? 36 : (size_t)bw * bw, part_cam = bw == 0 ? 18 : (size_t)3 * bw;   // compound blocks: BW x BW per target, BW x 3 per camera
-  const int max_cams = bw == 0 ? kFusedMaxCams : (bw == 9 ? kFusedMaxCamsIntr : 10);
+  const int max_cams = fused_run_cameras(bw);
   const size_t max_tgts = bw == 0 ? 253 : 256 / lanes_tgt;
   // track slices per consumer wave for a run of ntgt target blocks over W cameras (0 = needs more than one wave)
   auto packing = [&](size_t ntgt, size_t W) -> int {
@@ -2036,7 +2047,9 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
     int most = 0;
     for (int g = 0; g < h->ng; ++g) if (h->grp_red[g] >= 0) most = std::max(most, __builtin_popcount(h->grp_free[g]));
     const char* force = getenv("THEIA_HIP_INTR_ROWS");
-    h->fused_bw = (allow_fused_intr && h->ni > 0 && most <= 4 && !(force && atoi(force) == 10) && !getenv("THEIA_HIP_INTR_GATHER")) ? (most <= 3 ? 9 : 10) : 0;
+    // (block width 6 + rows: 9, 10, or 13 for five to seven free parameters -- every intrinsic of the pinhole model; more fall
+    // back to the gather kernels)
+    h->fused_bw = (allow_fused_intr && h->ni > 0 && most <= 7 && !(force && atoi(force) == 10) && !getenv("THEIA_HIP_INTR_GATHER")) ? (most <= 3 ? 9 : (most <= 4 ? 10 : 13)) : 0;
     h->fused_kmask = 0;
     {
       bool first = true, same = true;
@@ -2256,7 +2269,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
   FusedHost fplan;
   tick("  structure: permutation");
   h->use_fused = (h->ni == 0 || h->fused_bw) && h->nobs_main > 0 && !getenv("THEIA_HIP_SCHUR_GATHER");
-  const int fused_max_cams = h->fused_bw == 0 ? kFusedMaxCams : (h->fused_bw == 9 ? kFusedMaxCamsIntr : 10);
+  const int fused_max_cams = fused_run_cameras(h->fused_bw);
   if (h->use_fused) {
     std::atomic<long long> misfit{0};
     host_chunks(h->np, [&](int64_t q0, int64_t q1) {   // tracks are independent
@@ -2518,7 +2531,7 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
         // static round robin left workgroups with one run more than others waiting for them
       std::vector<int> order(fplan.runs.size());
       for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-      const int lanes_tgt = h->fused_bw == 0 ? 1 : (h->fused_bw == 9 ? 3 : 4);
+      const int lanes_tgt = fused_lanes_per_target(h->fused_bw);
       auto cost = [&](int i) { const FusedRun& r = fplan.runs[i]; return (long long)r.ntiles * (64 + lanes_tgt * r.ntgt); };
       std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });
       UP(frun_order, order);

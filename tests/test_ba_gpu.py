@@ -1307,9 +1307,13 @@ def test_two_view_ba_batch_matches_the_general_solver():
 
 
 @pytest.mark.parametrize("groups,intr,manifold,mixed", [(1, 0x11, 1, False), (3, 0x11, 1, True), (7, 0x11, 0, False),
-                                                          (2, 0x13, 1, False), (8, 0x11, 1, True)])
+                                                          (2, 0x13, 1, False), (8, 0x11, 1, True),
+                                                          # round 5: five to seven free parameters -> 13-row compound blocks
+                                                          (2, 0x1b, 1, False), (3, 0x1f, 1, True), (1, 0x3f, 1, False),
+                                                          (4, 0x3f, 0, True), (8, 0x3f, 1, True)])
 def test_fused_intrinsics_assembly_matches_gather_kernels_and_oracle(groups, intr, manifold, mixed):
-    """Intrinsics free (FOCAL_LENGTH | RADIAL_DISTORTION: three compact rows; with ASPECT_RATIO: four): the fused kernel of
+    """Intrinsics free (FOCAL_LENGTH | RADIAL_DISTORTION: three compact rows; with ASPECT_RATIO: four; up to every intrinsic of
+    the pinhole / double-sphere models -- OptimizeIntrinsicsType::ALL -- seven rows in 13-wide blocks): the fused kernel of
     ba_fused_intr.hip -- compound [extrinsics | intrinsics] blocks per camera pair, the groups' rows summed afterwards
     (k_sum_items) -- against the first-generation gather kernels (THEIA_HIP_INTR_GATHER=1) and the oracle: reduced system,
     LM trajectory, parameters.  fix_gauge holds two cameras constant whose intrinsics groups stay variable (they take part
@@ -1341,8 +1345,12 @@ def test_fused_intrinsics_assembly_matches_gather_kernels_and_oracle(groups, int
     assert a[3].num_iterations == b[3].num_iterations == so.num_iterations
     n = a[4].size
     assert np.array_equal(a[4].accepted[:n], tro.accepted[:n]) and rel(a[4].cost[:n], tro.cost[:n]) <= 1e-9
-    assert rel(a[2].intrinsics, qo.intrinsics) <= 1e-9 and np.abs(a[2].cam_ext - qo.cam_ext).max() <= 1e-8
-    assert np.abs(a[2].points - qo.points).max() <= 1e-8
+    # (five to seven free parameters per group -- skew, principal point -- leave the normal equations far worse conditioned: the
+    # same reduced system and accept sequence, parameters to 1e-7 of the oracle's and of the gather kernels')
+    ptol = 1e-9 if bin(intr).count("1") <= 2 or intr == 0x13 else 1e-7
+    assert rel(a[2].intrinsics, qo.intrinsics) <= ptol and np.abs(a[2].cam_ext - qo.cam_ext).max() <= 10 * ptol
+    assert rel(a[2].intrinsics, b[2].intrinsics) <= ptol and np.abs(a[2].cam_ext - b[2].cam_ext).max() <= 10 * ptol
+    assert np.abs(a[2].points - qo.points).max() <= 10 * ptol
     assert not np.array_equal(a[2].intrinsics[:, 0], p.intrinsics[:, 0])
 
 
