@@ -487,6 +487,22 @@ def main():
                                   "note": "intrinsics_to_optimize = FOCAL_LENGTH | RADIAL_DISTORTION over the problem's 8 shared groups "
                                           "(k_lin_schur_i + k_sum_items: fused, records in LDS, DESIGN.md 3.5); not the headline configuration"}
         del hk
+        # OptimizeIntrinsicsType::ALL on the same problem: seven free parameters per group on the pinhole and double-sphere models
+        # (13-wide compound blocks, round 5; until then the first-generation gather kernels)
+        oa = bench_options(ba, ITERS_PER_SOLVE); oa.intrinsics_to_optimize = 0x3f
+        ta0 = time.perf_counter(); ha = ba.BaHandle(pristine.copy(), oa); ta1 = time.perf_counter()
+        ha.reset(pristine); ha.snapshot()
+        ha.restore(); ha.run(trace_capacity=1)
+        torch.cuda.synchronize(); ta2 = time.perf_counter()
+        for _ in range(nrep):
+            ha.restore(); sa, _ = ha.run(trace_capacity=1)
+        torch.cuda.synchronize(); ta = time.perf_counter() - ta2
+        out["with_all_intrinsics"] = {"lm_iterations_per_sec": nrep * sa.num_iterations / ta,
+                                      "ms_per_step": 1e3 * ta / (nrep * sa.num_iterations), "iterations_per_solve": sa.num_iterations,
+                                      "handle_creation_ms": 1e3 * (ta1 - ta0),
+                                      "note": "intrinsics_to_optimize = ALL (0x3f): seven free parameters per group, 13-wide compound blocks "
+                                              "(DESIGN.md 3.5); not the headline configuration"}
+        del ha
         # the pipelines' REAL default: both of the above at once (reconstruction_estimator_options.h:281-283 frees FOCAL_LENGTH |
         # RADIAL_DISTORTION, bundle_adjustment.h:144 leaves use_inner_iterations on)
         ob = bench_options(ba, ITERS_PER_SOLVE); ob.intrinsics_to_optimize = 0x01 | 0x10; ob.use_inner_iterations = 1
