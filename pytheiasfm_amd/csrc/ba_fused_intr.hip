@@ -29,7 +29,8 @@ namespace {
 
 // Lane split of a compound block of width BW = 6 + KI: lane `sub` of a target owns RPL consecutive rows of it, the last lanes
 // one row less where BW is not a multiple of RPL -- KI = 3: three lanes of three rows {0, 3, 6}; KI = 4: four lanes {0, 3, 6, 8};
-// KI = 7 (every intrinsic of the pinhole model free): four lanes of 4 + 3 + 3 + 3 rows {0, 4, 7, 10}, so that the 55 target
+// KI = 7 (every intrinsic of the pinhole model free): four lanes of 4 + 3 + 3 + 3 rows {0, 4, 7, 10}; KI = 10 (the ten of the
+// radial-tangential model; nine of the fisheye model in ten rows): four lanes of four rows -- so that the 55 target
 // blocks of ten cameras still fit the 256 threads of a workgroup (the register budget is no constraint there: the records
 // of that width leave room for one workgroup per CU).
 template <int KI> constexpr int rpl() { return KI <= 4 ? 3 : 4; }   // rows of the block per lane (accumulators: RPL x BW)
@@ -43,7 +44,7 @@ constexpr int kRowBytesI = 16;             // slot-table row: the most local cam
 static_assert(kFusedMaxCamsIntr <= kRowBytesI, "slot-table row too short");
 // LDS record of one observation: {Jc row 0 (BWP) | Jc row 1 (BWP) | Ehat (2 x PD, interleaved as in ba_fused.hip) | r (2) |
 // r - Ehat ghat (2)}, at least the RPL x BW doubles a lane parks there when the track slices are combined, an odd number of
-// 16-B pieces: 30 / 34 doubles (PD = 3 / 4) with three or four intrinsics rows, 54 with seven
+// 16-B pieces: 30 / 34 doubles (PD = 3 / 4) with three or four intrinsics rows, 54 with seven, 66 with ten
 template <int PD, int KI> constexpr int reci_doubles() {
   int rd = 2 * bwp<KI>() + 2 * PD + 4;
   if (rd < rpl<KI>() * (6 + KI)) rd = rpl<KI>() * (6 + KI);
@@ -525,12 +526,14 @@ __global__ __launch_bounds__(256) void k_sum_items(int nitems, const int* __rest
   if (slot != 0 || !live) return;
   if (kind == SK_CHUNK) { part[(size_t)dst + e] = tot; return; }
   int ri = row0 + i, cj = col0 + j;
-  if (rgrp) { const int q = compact_param(red_free[row0 / THEIA_MAX_INTRINSICS], i); if (q < 0) return; ri = row0 + q; }
+  // (a group-side item may start at compact row / column `off` of its group: row0 = 10 g + off -- the 10 x 10 group blocks of the
+  // 16-row plan are two items of five compact rows)
+  if (rgrp) { const int g10 = row0 / THEIA_MAX_INTRINSICS * THEIA_MAX_INTRINSICS; const int q = compact_param(red_free[row0 / THEIA_MAX_INTRINSICS], i + (row0 - g10)); if (q < 0) return; ri = g10 + q; }
   if (kind == SK_VEC) {
     if (j == 0) rhs[ri] = tot; else if (j == 1) gc[ri] = tot; else colsq[ri] = tot;
     return;
   }
-  if (cgrp) { const int q = compact_param(red_free[col0 / THEIA_MAX_INTRINSICS], j); if (q < 0) return; cj = col0 + q; }
+  if (cgrp) { const int g10 = col0 / THEIA_MAX_INTRINSICS * THEIA_MAX_INTRINSICS; const int q = compact_param(red_free[col0 / THEIA_MAX_INTRINSICS], j + (col0 - g10)); if (q < 0) return; cj = g10 + q; }
   if (kind == SK_LOWER && cj > ri) return;
   S[(size_t)ri * n + cj] = -tot;
 }
@@ -566,7 +569,8 @@ constexpr unsigned kMaskFocalRadial = (1u << 0) | (3u << 5);
       k_lin_schur_i<PD_, 4, M_, 3, kMaskFocalRadial, LK_><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);    \
     else if (P.fused_bw == 9) k_lin_schur_i<PD_, 4, M_, 3, 0u, LK_><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part); \
     else if (P.fused_bw == 10) k_lin_schur_i<PD_, 4, M_, 4, 0u, LK_><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part); \
-    else k_lin_schur_i<PD_, 4, M_, 7, 0u, LK_><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);   /* 13: up to seven rows */ \
+    else if (P.fused_bw == 13) k_lin_schur_i<PD_, 4, M_, 7, 0u, LK_><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);   /* up to seven rows */ \
+    else k_lin_schur_i<PD_, 4, M_, 10, 0u, LK_><<<grid, 256, 0, st>>>(P, pts, radius, Vinv, tile_part);   /* 16: up to ten rows */ \
   } while (0)
   // (two loss instances: the trivial loss without corrector code, everything else with the full corrector)
 #define THIP_LSI(PD_, M_) do { if (P.loss_type == THEIA_LOSS_TRIVIAL) THIP_LSI2(PD_, M_, 0); else THIP_LSI2(PD_, M_, 2); } while (0)

@@ -1511,7 +1511,7 @@ inline int fused_run_cameras(int bw) {
   if (bw == 0) return kFusedMaxCams;
   if (bw == 9) return kFusedMaxCamsIntr;   // 78 blocks x 3 lanes
   if (bw == 10) return 10;                 // 55 x 4
-  return 10;                               // 13 rows: 55 x 4
+  return 10;                               // 13 / 16 rows: 55 x 4
 }
 // lanes of a target block (ba_fused_intr.hip: lanes_per_target): three rows per lane up to width 10, four at 13
 inline int fused_lanes_per_target(int bw) { return bw == 0 ? 1 : (bw <= 10 ? (bw + 2) / 3 : (bw + 3) / 4); }
@@ -1774,11 +1774,17 @@ int build_sum_items_intr(theia_ba_handle_s* h, const int* cam_group, FusedHost& 
       if (la != lb && rcb >= 0 && ga >= 0)
         sink(Ent{key_blk(ni + 6 * rcb, 10 * ga), base, src_code(6, 0, 1, BW), dims(6, KI, SK_BLOCK, 0, 1)});
       if (ga >= 0 && gb >= 0) {
-        if (ga > gb) sink(Ent{key_blk(10 * ga, 10 * gb), base, src_code(6, 6, 0, BW), dims(KI, KI, SK_BLOCK, 1, 1)});
-        else if (ga < gb) sink(Ent{key_blk(10 * gb, 10 * ga), base, src_code(6, 6, 1, BW), dims(KI, KI, SK_BLOCK, 1, 1)});
-        else {
-          sink(Ent{key_blk(10 * ga, 10 * ga), base, src_code(6, 6, 0, BW), dims(KI, KI, SK_LOWER, 1, 1)});
-          if (la != lb) sink(Ent{key_blk(10 * ga, 10 * ga), base, src_code(6, 6, 1, BW), dims(KI, KI, SK_LOWER, 1, 1)});
+        // (an item is one wave: nr x nc <= 64 elements.  Up to seven compact rows a group x group block is one item; the 10 x 10
+        // blocks of the 16-row plan go as two items of five compact rows, item row0 = 10 g + first compact row)
+        const int nh = KI > 7 ? 2 : 1, hr = KI > 7 ? KI / 2 : KI;
+        for (int hh = 0; hh < nh; ++hh) {
+          const int r0 = hh * hr, nr = (hh == nh - 1) ? KI - r0 : hr;
+          if (ga > gb) sink(Ent{key_blk(10 * ga + r0, 10 * gb), base, src_code(6 + r0, 6, 0, BW), dims(nr, KI, SK_BLOCK, 1, 1)});
+          else if (ga < gb) sink(Ent{key_blk(10 * gb + r0, 10 * ga), base, src_code(6, 6 + r0, 1, BW), dims(nr, KI, SK_BLOCK, 1, 1)});
+          else {
+            sink(Ent{key_blk(10 * ga + r0, 10 * ga), base, src_code(6 + r0, 6, 0, BW), dims(nr, KI, SK_LOWER, 1, 1)});
+            if (la != lb) sink(Ent{key_blk(10 * ga + r0, 10 * ga), base, src_code(6, 6 + r0, 1, BW), dims(nr, KI, SK_LOWER, 1, 1)});
+          }
         }
       }
     }
@@ -2047,9 +2053,9 @@ static int ba_create_impl(const theia_ba_problem* p, const theia_ba_options* o, 
     int most = 0;
     for (int g = 0; g < h->ng; ++g) if (h->grp_red[g] >= 0) most = std::max(most, __builtin_popcount(h->grp_free[g]));
     const char* force = getenv("THEIA_HIP_INTR_ROWS");
-    // (block width 6 + rows: 9, 10, or 13 for five to seven free parameters -- every intrinsic of the pinhole model; more fall
-    // back to the gather kernels)
-    h->fused_bw = (allow_fused_intr && h->ni > 0 && most <= 7 && !(force && atoi(force) == 10) && !getenv("THEIA_HIP_INTR_GATHER")) ? (most <= 3 ? 9 : (most <= 4 ? 10 : 13)) : 0;
+    // (block width 6 + rows: 9, 10, 13 for five to seven free parameters -- every intrinsic of the pinhole model --, 16 for up to
+    // the ten of the radial-tangential model)
+    h->fused_bw = (allow_fused_intr && h->ni > 0 && !(force && atoi(force) == 10) && !getenv("THEIA_HIP_INTR_GATHER")) ? (most <= 3 ? 9 : (most <= 4 ? 10 : (most <= 7 ? 13 : 16))) : 0;
     h->fused_kmask = 0;
     {
       bool first = true, same = true;

@@ -6,6 +6,9 @@ from pytheiasfm_amd import ba, synth
 groups = [int(g) for g in (sys.argv[1] if len(sys.argv) > 1 else "8").split(",")]
 for ng in groups:
     p = synth.synth_ba_v1(1000, 500000, seed=0xBA5E0004, num_groups=ng, mixed_models=ng > 1)
+    if os.environ.get("MODEL"):   # every group on one camera model (1 = radial-tangential: ten intrinsics, 2 = fisheye: nine)
+        k = {1: [1000.0, 1.02, 0.2, 960.0, 540.0, -0.1, 0.02, 0.001, 0.001, -0.002], 2: [600.0, 1.0, 0.1, 960.0, 540.0, 0.01, -0.002, 0.001, 0.0005]}[int(os.environ["MODEL"])]
+        p.group_model[:] = int(os.environ["MODEL"]); p.intrinsics[:] = 0.0; p.intrinsics[:, :len(k)] = k
     o = ba.default_options(); o.max_num_iterations = 8
     o.function_tolerance = o.gradient_tolerance = o.parameter_tolerance = 0.0
     o.use_inner_iterations = 0; o.intrinsics_to_optimize = int(os.environ.get("INTR", "0x11"), 0)

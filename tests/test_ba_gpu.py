@@ -1354,6 +1354,45 @@ def test_fused_intrinsics_assembly_matches_gather_kernels_and_oracle(groups, int
     assert not np.array_equal(a[2].intrinsics[:, 0], p.intrinsics[:, 0])
 
 
+@pytest.mark.parametrize("model,groups,manifold", [(1, 2, 1), (2, 3, 1), (1, 1, 0)])
+def test_fused_intrinsics_assembly_with_nine_and_ten_free_parameters(model, groups, manifold):
+    """OptimizeIntrinsicsType::ALL on the radial-tangential (ten free parameters) and fisheye (nine) models: 16-row compound
+    blocks (round 5; the 10 x 10 group blocks summed as two items of five rows) against the gather kernels and the oracle --
+    reduced system, accept sequence, cost trace."""
+    p = synth.synth_ba_v1(20, 1800, seed=0x2F5 + model, num_groups=groups, fix_gauge=True, pixel_noise=0.3)
+    k = CAMERA_MODEL_INTRINSICS[model]
+    p.group_model[:] = model
+    p.intrinsics[:] = 0.0
+    p.intrinsics[:, : len(k)] = k
+    o, oo = both_options(intrinsics_to_optimize=0x3f, max_num_iterations=5, use_homogeneous_point_parametrization=manifold, use_inner_iterations=0)
+    res = []
+    for gather in (False, True):
+        if gather:
+            os.environ["THEIA_HIP_INTR_GATHER"] = "1"
+        try:
+            with ba.BaHandle(p.copy(), o) as h:
+                S, rhs = h.reduced_system(1e4)
+                S2, rhs2 = h.reduced_system(1e4)
+                if not gather:
+                    assert np.array_equal(S, S2) and np.array_equal(rhs, rhs2), "fused assembly is not reproducible"
+                    assert h.plan_info()["fused_runs"] > 0
+            q = p.copy()
+            s, tr = ba.solve(q, o)
+            res.append((S, rhs, q, s, tr))
+        finally:
+            os.environ.pop("THEIA_HIP_INTR_GATHER", None)
+    a, b = res
+    So, ro = ol.reduced_system(p, oo, 1e4)
+    assert a[0].shape == b[0].shape == So.shape
+    assert rel(a[0], b[0]) <= 1e-11 and rel(a[1], b[1]) <= 1e-10
+    assert rel(a[0], So) <= 1e-9 and rel(a[1], ro) <= 1e-9
+    so, tro = ol.solve(p.copy(), oo)
+    assert a[3].num_iterations == b[3].num_iterations == so.num_iterations
+    n = a[4].size
+    fin = tro.cost[:n] < 1e300
+    assert np.array_equal(a[4].accepted[:n], tro.accepted[:n]) and rel(a[4].cost[:n][fin], tro.cost[:n][fin]) <= 1e-7
+
+
 def test_view_covariances_with_optimised_intrinsics():
     """BundleAdjustViewsWithCov with FOCAL_LENGTH | RADIAL_DISTORTION free: the views share intrinsics groups, J'J is an arrow
     (group columns against every camera of the group) and ceres::Covariance returns the extrinsics blocks of its inverse.
