@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytheiasfm_amd import _capi as capi, ba, synth
 from tests import oracle_lib as ol
 
+# SOAK_INTR: comma-separated intrinsics_to_optimize masks to draw from (default: none, none, FOCAL | RADIAL)
+INTR_CHOICES = [int(x, 0) for x in os.environ.get("SOAK_INTR", "0,0,0x11").split(",")]
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bad = 0; worst = 0.0
@@ -28,7 +30,7 @@ for k in range(count):
                              p.cam_const, p.group_const, p.point_const)
     o = ba.default_options(); oo = ol.default_options()
     its = int(rng.integers(3, 6))
-    cfg = dict(max_num_iterations=its, use_inner_iterations=int(rng.integers(0, 2)), intrinsics_to_optimize=int(rng.choice([0, 0, 0x11])),
+    cfg = dict(max_num_iterations=its, use_inner_iterations=int(rng.integers(0, 2)), intrinsics_to_optimize=int(rng.choice(INTR_CHOICES)),
                loss_function_type=int(rng.choice([0, 0, 1, 3])), robust_loss_width=2.0)
     for f, v in cfg.items():
         setattr(o, f, v); setattr(oo, f, v)
