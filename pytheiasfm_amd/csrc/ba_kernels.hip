@@ -905,13 +905,31 @@ THIP_DEV double cand_ext_component(const DevProblem& P, int c, int rc, int q, do
 // stream, from the SAME candidate components (cand_ext_component), so the two launches' work runs side by side: one launch
 // and its dependent boundary less per iteration.  (Folding that work into the single reducing workgroup was slower: 26 us
 // against 13 + 7.)
-template <bool PREP>
+// the candidate intrinsics of a group: x + (-y) * scale on its free parameters, projected onto their bounds
+// (bundle_adjuster.cc:406-427); gr < 0 (constant group): the state's
+THIP_DEV void cand_intrinsics(const DevProblem& P, int g, int gr, const double* __restrict__ y, double (&kk)[THEIA_MAX_INTRINSICS]) {
+  for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) {
+    kk[q] = P.intr[(size_t)g * THEIA_MAX_INTRINSICS + q];
+    if (gr >= 0 && ((P.grp_free[g] >> q) & 1u)) kk[q] = __builtin_fma(-y[10 * gr + q], P.scale_i[(size_t)g * THEIA_MAX_INTRINSICS + q], kk[q]);
+  }
+  if (gr >= 0) {
+    const int model = P.group_model[g];
+    if (kk[0] < 1.0) kk[0] = 1.0;
+    if (model == THEIA_CAM_DOUBLE_SPHERE) { kk[5] = fmin(1.0, fmax(-1.0, kk[5])); kk[6] = fmin(1.0, fmax(0.0, kk[6])); }
+    if (model == THEIA_CAM_EXTENDED_UNIFIED) { kk[5] = fmin(1.0, fmax(0.0, kk[5])); kk[6] = fmax(0.1, kk[6]); }
+  }
+}
+
+// PREP: 0 = the candidate parameters only; 1 = fused path without intrinsics (blocks + {D, v} steps, above); 2 = fused path with
+// free intrinsics: the candidate's blocks carry the candidate intrinsics of the camera's group (cand_intrinsics, the same
+// arithmetic as the reducing workgroup's), no {D, v} (the back-substitution multiplies the solved step itself there)
+template <int PREP>
 __global__ __launch_bounds__(1024) void k_cam_update(DevProblem P, const double* __restrict__ cam, const double* __restrict__ y,
                              double* __restrict__ cand, double* __restrict__ cand_intr,
                              double* __restrict__ out_stepsq, double* __restrict__ out_xnormsq,
                              double* __restrict__ zero16) {
   const double* yc = y + P.ni;
-  if constexpr (PREP) {
+  if constexpr (PREP != 0) {
     if (blockIdx.x > 0) {
       if (threadIdx.x >= 256) return;   // 256 cameras per workgroup, as k_cam_prep: the blocks spread over the CUs
       const int c = (blockIdx.x - 1) * 256 + threadIdx.x;
@@ -923,6 +941,13 @@ __global__ __launch_bounds__(1024) void k_cam_update(DevProblem P, const double*
         const double x = cam[6 * c + q];
         xp[q] = cand_ext_component(P, c, rc, q, x, yc);
         dl[q] = (rc >= 0 && !((P.cam_mask[c] >> q) & 1u)) ? (-yc[6 * rc + q]) * P.scale_c[6 * c + q] : 0.0;
+      }
+      if constexpr (PREP == 2) {
+        const int g = P.cam_group[c];
+        double kk[THEIA_MAX_INTRINSICS];
+        cand_intrinsics(P, g, P.grp_red ? P.grp_red[g] : -1, y, kk);
+        cam_prep_one_k(P, c, xp, kk, P.camrot_cand);
+        return;
       }
       cam_prep_one(P, c, xp, P.intr, P.camrot_cand);
       double ext[6], out[12];
@@ -951,16 +976,7 @@ __global__ __launch_bounds__(1024) void k_cam_update(DevProblem P, const double*
     for (int g = threadIdx.x; g < P.ng_total; g += blockDim.x) {
       const int gr = P.grp_red ? P.grp_red[g] : -1;
       double kk[THEIA_MAX_INTRINSICS];
-      for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) {
-        kk[q] = P.intr[(size_t)g * THEIA_MAX_INTRINSICS + q];
-        if (gr >= 0 && ((P.grp_free[g] >> q) & 1u)) kk[q] += (-y[10 * gr + q]) * P.scale_i[(size_t)g * THEIA_MAX_INTRINSICS + q];
-      }
-      if (gr >= 0) {
-        const int model = P.group_model[g];
-        if (kk[0] < 1.0) kk[0] = 1.0;
-        if (model == THEIA_CAM_DOUBLE_SPHERE) { kk[5] = fmin(1.0, fmax(-1.0, kk[5])); kk[6] = fmin(1.0, fmax(0.0, kk[6])); }
-        if (model == THEIA_CAM_EXTENDED_UNIFIED) { kk[5] = fmin(1.0, fmax(0.0, kk[5])); kk[6] = fmax(0.1, kk[6]); }
-      }
+      cand_intrinsics(P, g, gr, y, kk);
       for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) {
         const double x = P.intr[(size_t)g * THEIA_MAX_INTRINSICS + q];
         cand_intr[(size_t)g * THEIA_MAX_INTRINSICS + q] = kk[q];
@@ -1578,15 +1594,19 @@ void launch_finalize_rcs(const DevProblem& P, const double* radius, const Reduce
                                                                      tile_cls, want_cls);
 }
 
-// true when launch_cam_update writes the candidate's per-camera blocks itself (launch_backsub then skips its k_cam_prep)
-static bool cam_update_preps(const DevProblem& P) {
-  return !P.ni && P.n_fruns > 0 && P.camrot && P.camrot_cand && P.camdir && P.ntiles > 0 && !getenv("THEIA_HIP_CAM_PREP_SEPARATE");
+// 1 / 2 when launch_cam_update writes the candidate's per-camera blocks itself (launch_backsub then skips its k_cam_prep)
+static int cam_update_preps(const DevProblem& P) {
+  if (P.n_fruns == 0 || !P.camrot || !P.camrot_cand || P.ntiles == 0 || getenv("THEIA_HIP_CAM_PREP_SEPARATE")) return 0;
+  if (!P.ni) return P.camdir ? 1 : 0;
+  return P.fused_bw > 0 ? 2 : 0;
 }
 
 void launch_cam_update(const DevProblem& P, const double* cam, const double* y, double* cand_cam,
                        double* cand_intr, double* out_stepsq, double* out_xnormsq, hipStream_t st, double* zero16) {
-  if (cam_update_preps(P)) k_cam_update<true><<<1 + (P.nc + 255) / 256, 1024, 0, st>>>(P, cam, y, cand_cam, cand_intr, out_stepsq, out_xnormsq, zero16);
-  else k_cam_update<false><<<1, 1024, 0, st>>>(P, cam, y, cand_cam, cand_intr, out_stepsq, out_xnormsq, zero16);
+  const int prep = cam_update_preps(P);
+  if (prep == 1) k_cam_update<1><<<1 + (P.nc + 255) / 256, 1024, 0, st>>>(P, cam, y, cand_cam, cand_intr, out_stepsq, out_xnormsq, zero16);
+  else if (prep == 2) k_cam_update<2><<<1 + (P.nc + 255) / 256, 1024, 0, st>>>(P, cam, y, cand_cam, cand_intr, out_stepsq, out_xnormsq, zero16);
+  else k_cam_update<0><<<1, 1024, 0, st>>>(P, cam, y, cand_cam, cand_intr, out_stepsq, out_xnormsq, zero16);
 }
 
 void launch_backsub(const DevProblem& P, const double* cam, const double* pts, const double* cand_cam,
@@ -1605,7 +1625,7 @@ void launch_backsub(const DevProblem& P, const double* cam, const double* pts, c
   }
   if (P.ni && P.fused_bw > 0 && P.n_fruns > 0 && P.camrot && P.camrot_cand) {
     // fused path with intrinsics: the state's blocks are in P.camrot; the candidate cameras with the candidate intrinsics
-    launch_cam_prep(P, cand_cam, P.intr_cand, P.camrot_cand, st);
+    if (cam_update_preps(P) != 2) launch_cam_prep(P, cand_cam, P.intr_cand, P.camrot_cand, st);   // (else: launch_cam_update's extra workgroups)
     if (launch_backsub_runs_intr(P, pts, cand_pts, Vinv, tile_part, yc, st)) return;   // round 5: over the runs, camera blocks in LDS
     constexpr unsigned kFR = (1u << 0) | (3u << 5);   // FOCAL_LENGTH | RADIAL_DISTORTION (ba_fused_intr.hip: kMaskFocalRadial)
     if (P.fused_kmask == kFR) {

@@ -220,6 +220,19 @@ THIP_DEV void cam_prep_one(const DevProblem& P, int c, const double* ext, const 
   o[kCamRotGroup] = (double)g; o[39] = 0.0;
 }
 
+// the same with the intrinsics of the camera's group given directly (k_cam_update: the candidate's, not yet in memory)
+THIP_DEV void cam_prep_one_k(const DevProblem& P, int c, const double* ext, const double (&kgroup)[THEIA_MAX_INTRINSICS], double* __restrict__ camrot) {
+  double* o = camrot + (size_t)kCamRot * c;
+  camrot_store(ext, o);
+  const unsigned mask = P.cam_mask[c];
+  for (int q = 0; q < 6; ++q) o[kCamRotScale + q] = ((mask >> q) & 1u) ? 0.0 : P.scale_c[6 * c + q];
+  const int g = P.cam_group[c];
+  for (int q = 0; q < THEIA_MAX_INTRINSICS; ++q) o[kCamRotIntr + q] = kgroup[q];
+  o[kCamRotModel] = (double)P.group_model[g];
+  o[kCamRotRed] = (double)P.cam_red[c];
+  o[kCamRotGroup] = (double)g; o[39] = 0.0;
+}
+
 struct Segment {
   int start, len, maxlen, rank;  // rank = index of the track inside its tile
   bool head;
