@@ -31,7 +31,9 @@ namespace {
 // Squared column norms of the unscaled Jacobian at the initial point: the
 // Jacobi scaling 1/(1+sqrt(.)) is computed once from them
 // (ceres trust_region_minimizer.cc, jacobi_scaling = true).
-template <int PD, bool INTR>
+// ROT: the cameras as the per-camera blocks of k_cam_prep (P.camrot, written with the unit scales of this pass): no sin / cos and
+// no camera -> group -> intrinsics chain per observation
+template <int PD, bool INTR, bool ROT = false>
 __global__ __launch_bounds__(kBlock) void k_colnorm(DevProblem P, const double* __restrict__ cam,
                                                     const double* __restrict__ pts,
                                                     double* __restrict__ colsq_c,
@@ -43,7 +45,8 @@ __global__ __launch_bounds__(kBlock) void k_colnorm(DevProblem P, const double* 
   const int cnt = P.tile_count[tile];
   const int start = P.tile_start[tile];
   LaneLin<PD, INTR> L;
-  lane_linearize<PD, true, INTR>(P, cam, pts, start + lane, lane < cnt, lane, L);
+  if constexpr (ROT) lane_linearize<PD, true, INTR, true>(P, P.camrot, pts, start + lane, lane < cnt, lane, L);
+  else lane_linearize<PD, true, INTR>(P, cam, pts, start + lane, lane < cnt, lane, L);
   const Segment sg = lane_segment(L.p, lane);
   // camera / intrinsics columns: k_colnorm_gather, or the fused kernel itself (compute_scale), no atomics
   const bool gather = P.slot_obs != nullptr || P.fused_bw > 0;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void k_colnorm(DevProblem P, const double* 
 // record range of a camera / group (the diagonal items of the Schur assembly); the lanes re-linearise the
 // range's observations and the workgroup sums 6 (10) squared column norms.  Replaces 6 global FP64 atomics
 // per observation onto a few hundred addresses.
-template <int PD, bool INTR>
+template <int PD, bool INTR, bool ROT = false>
 __global__ __launch_bounds__(kBlock) void k_colnorm_gather(DevProblem P, const double* __restrict__ cam,
                                                            const double* __restrict__ pts,
                                                            double* __restrict__ colsq_c, double* __restrict__ colsq_i) {
@@ -98,7 +101,8 @@ __global__ __launch_bounds__(kBlock) void k_colnorm_gather(DevProblem P, const d
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (int q = beg + threadIdx.x; q < end; q += kBlock) {
     LaneLin<PD, INTR> L;
-    lane_linearize<PD, true, INTR>(P, cam, pts, P.slot_obs[q], true, lane, L);
+    if constexpr (ROT) lane_linearize<PD, true, INTR, true>(P, P.camrot, pts, P.slot_obs[q], true, lane, L);
+    else lane_linearize<PD, true, INTR>(P, cam, pts, P.slot_obs[q], true, lane, L);
     if (q == beg) s_idx = group_item ? L.g : L.c;
     if (group_item) {
       if constexpr (INTR) {
@@ -1448,9 +1452,15 @@ void launch_colnorm(const DevProblem& P, const double* cam, const double* pts, d
                     double* colsq_p, double* colsq_i, hipStream_t st) {
   if (P.ntiles == 0) return;
   const int nb = tile_blocks(P.ntiles);
+  // fused plan without intrinsics: the cameras through pre-rotated blocks (the handle keeps P.camrot for k_lin_schur)
+  const bool rot = !P.ni && P.camrot && P.n_fruns > 0 && !getenv("THEIA_HIP_COLNORM_DIRECT");
   if (P.ni) {
     if (P.pd == 3) k_colnorm<3, true><<<nb, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_p, colsq_i);
     else k_colnorm<4, true><<<nb, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_p, colsq_i);
+  } else if (rot) {
+    launch_cam_prep(P, cam, P.intr, P.camrot, st);   // (P carries the unit scales of this pass: the caller rebuilds the blocks afterwards)
+    if (P.pd == 3) k_colnorm<3, false, true><<<nb, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_p, colsq_i);
+    else k_colnorm<4, false, true><<<nb, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_p, colsq_i);
   } else {
     if (P.pd == 3) k_colnorm<3, false><<<nb, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_p, colsq_i);
     else k_colnorm<4, false><<<nb, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_p, colsq_i);
@@ -1459,6 +1469,9 @@ void launch_colnorm(const DevProblem& P, const double* cam, const double* pts, d
   if (P.ni && P.n_blk_items) {
     if (P.pd == 3) k_colnorm_gather<3, true><<<P.n_blk_items, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_i);
     else k_colnorm_gather<4, true><<<P.n_blk_items, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_i);
+  } else if (!P.ni && P.n_diag_items && rot) {
+    if (P.pd == 3) k_colnorm_gather<3, false, true><<<P.n_diag_items, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_i);
+    else k_colnorm_gather<4, false, true><<<P.n_diag_items, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_i);
   } else if (!P.ni && P.n_diag_items) {
     if (P.pd == 3) k_colnorm_gather<3, false><<<P.n_diag_items, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_i);
     else k_colnorm_gather<4, false><<<P.n_diag_items, kBlock, 0, st>>>(P, cam, pts, colsq_c, colsq_i);
