@@ -303,6 +303,22 @@ def ransac_block(cpu_baseline, host_cores, rank=0, world=1):
     return out
 
 
+def self_launch(n):
+    """Re-runs this command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` on a free local
+    port; returns the launcher's exit code.  Rank 0 prints the one JSON line, the other ranks print nothing."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -322,9 +338,12 @@ def main():
     dry = bool(args.one_gpu_dry_run) and world > 1
     if dry:
         local_rank = 0
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the same
+        # torch.distributed.run line the driver uses) and pass rank 0's single JSON line through
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     import torch
     import torch.distributed as dist
     from pytheiasfm_amd import _capi as capi, ba, synth, distributed as tdist
@@ -423,7 +442,11 @@ def main():
                        "views": nviews, "tracks": ntracks, "observations": nobs_total,
                        "baseline_config": "BASELINE.json configs[3] (north_star target configuration) on %d GPU%s" % (world, "" if world == 1 else "s"),
                        "reduced_system_n": info["n"], "k3_levels": info["k3_levels"], "fused_kernel_runs": info["fused_runs"],
-                       "slow_path_tracks": info["slow_path_tracks"]},
+                       "slow_path_tracks": info["slow_path_tracks"],
+                       # the width of the run as the collective library itself reports it (ncclCommCount through the
+                       # library's own communicator; the one-GPU rehearsal has no RCCL communicator: gloo's group size)
+                       "n_ranks_seen_by_rccl": (comm.count() if comm is not None else (None if world > 1 else 1)),
+                       "n_ranks_in_process_group": (dist.get_world_size() if world > 1 else 1)},
             "roofline": {"kernel": "linearize + Schur assembly launch group (k_lin_schur + k_schur_sum; k_cam_prep only on the first launch of a solve)",
                          "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -484,6 +484,8 @@ int theia_hip_ba_set_inner_global(theia_ba_handle h, const theia_ba_problem* ful
 int theia_hip_rccl_unique_id(void* out128);
 int theia_hip_rccl_comm_create(const void* id128, int32_t rank, int32_t world_size, void** comm_out);
 int theia_hip_rccl_comm_destroy(void* comm);
+/* ranks the communicator spans as RCCL itself reports them (ncclCommCount): what a scaling run quotes as its width */
+int theia_hip_rccl_comm_count(void* comm, int32_t* count_out);
 int theia_hip_ba_set_rccl(theia_ba_handle h, void* comm, int32_t rank, int32_t world_size);
 
 /* ------------------------------------------------------------------ RANSAC */

@@ -28,6 +28,7 @@ typedef int (*fn_init_rank)(ncclComm_t*, int, ncclUniqueId, int);
 typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
 typedef int (*fn_destroy)(ncclComm_t);
 typedef const char* (*fn_err)(int);
+typedef int (*fn_count)(const ncclComm_t, int*);
 
 struct Rccl {
   void* lib = nullptr;
@@ -36,6 +37,7 @@ struct Rccl {
   fn_all_reduce all_reduce = nullptr;
   fn_destroy destroy = nullptr;
   fn_err err = nullptr;
+  fn_count count = nullptr;
   bool ok = false;
 };
 
@@ -52,6 +54,7 @@ Rccl& rccl() {
     r.all_reduce = (fn_all_reduce)dlsym(r.lib, "ncclAllReduce");
     r.destroy = (fn_destroy)dlsym(r.lib, "ncclCommDestroy");
     r.err = (fn_err)dlsym(r.lib, "ncclGetErrorString");
+    r.count = (fn_count)dlsym(r.lib, "ncclCommCount");
     r.ok = r.get_id && r.init_rank && r.all_reduce && r.destroy;
   });
   return r;
@@ -98,6 +101,17 @@ int theia_hip_rccl_comm_destroy(void* comm) {
   NativeCtx* c = static_cast<NativeCtx*>(comm);
   if (rccl().ok && c->comm) (void)rccl().destroy(c->comm);
   delete c;
+  return 0;
+}
+
+int theia_hip_rccl_comm_count(void* comm, int32_t* count_out) {
+  if (!comm || !count_out) return thip::set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  NativeCtx* c = static_cast<NativeCtx*>(comm);
+  if (!rccl().ok || !rccl().count) return thip::set_error(THEIA_HIP_ERR_UNSUPPORTED, "ncclCommCount not found in librccl");
+  int n = 0;
+  const int rc = rccl().count(c->comm, &n);
+  if (rc != ncclSuccess) return thip::set_error(THEIA_HIP_ERR_INTERNAL, "ncclCommCount failed (%d)", rc);
+  *count_out = n;
   return 0;
 }
 

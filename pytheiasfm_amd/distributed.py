@@ -142,6 +142,15 @@ class NativeRccl:
         """handle: ba.BaHandle.  Replaces any all-reduce callback; also declares the shard geometry."""
         capi.check(capi.lib().theia_hip_ba_set_rccl(handle._h, self._comm, self.rank, self.world_size))
 
+    def count(self):
+        """Ranks of the communicator as RCCL reports them (ncclCommCount)."""
+        import ctypes as C
+        L = capi.lib()
+        L.theia_hip_rccl_comm_count.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        n = C.c_int32(0)
+        capi.check(L.theia_hip_rccl_comm_count(self._comm, C.byref(n)))
+        return int(n.value)
+
     def close(self):
         if self._comm:
             capi.lib().theia_hip_rccl_comm_destroy(self._comm)

@@ -25,8 +25,13 @@ def main():
     mixed = bool(int(os.environ.get("SHARD_MIXED", "0")))
     inner = int(os.environ.get("SHARD_INNER", "0"))     # 1: inner iterations, 2: inner iterations with free intrinsics + a prior
     nviews, ntracks = int(os.environ.get("SHARD_VIEWS", "24")), int(os.environ.get("SHARD_TRACKS", "1500"))
-    p = synth.synth_ba_v1(nviews, ntracks, seed=0x5AD00 + int(mixed), mixed_models=mixed)
-    o = ba.default_options(); o.use_inner_iterations = 1 if inner else 0; o.max_num_iterations = 12
+    cfg = os.environ.get("SHARD_CONFIG", "")            # "C2" / "C4": BASELINE.json's configurations at their full size
+    if cfg:
+        p = synth.synth_ba_v1(synth.BA_CONFIGS[cfg][0], synth.BA_CONFIGS[cfg][1], seed=synth.BA_CONFIGS[cfg][2], mixed_models=mixed or synth.BA_CONFIGS[cfg][3])
+        nviews, ntracks = p.cam_ext.shape[0], p.points.shape[0]
+    else:
+        p = synth.synth_ba_v1(nviews, ntracks, seed=0x5AD00 + int(mixed), mixed_models=mixed)
+    o = ba.default_options(); o.use_inner_iterations = 1 if inner else 0; o.max_num_iterations = int(os.environ.get("SHARD_MAX_ITERATIONS", "12"))
     if inner == 2:
         o.intrinsics_to_optimize = 0x11; o.prior_mask = 1
         mask = np.zeros(nviews, dtype=np.uint8); mask[[3, 11, 17]] = 1
@@ -54,7 +59,9 @@ def main():
         "cam_err": float(np.abs(out.cam_ext - ref.cam_ext).max()),
         "pts_err": float(np.abs(out.points - ref.points[ids]).max()),
         "trace_cost_err": float(np.abs(np.asarray(tr.cost)[:tr.size] - np.asarray(tr0.cost)[:tr0.size]).max() / s0.initial_cost) if tr.size == tr0.size else 1.0,
-        "plan": h_plan, "tracks": int(len(ids)), "intr_err": float((np.abs(out.intrinsics - ref.intrinsics) / np.maximum(1.0, np.abs(ref.intrinsics))).max()),
+        "plan": h_plan, "tracks": int(len(ids)), "total_tracks": int(ntracks),
+        "pts_rel_err": float((np.abs(out.points - ref.points[ids]) / np.maximum(1.0, np.abs(ref.points[ids]))).max()),
+        "trace_size": int(tr.size), "ref_trace_size": int(tr0.size), "intr_err": float((np.abs(out.intrinsics - ref.intrinsics) / np.maximum(1.0, np.abs(ref.intrinsics))).max()),
     }
     print("RESULT " + json.dumps(res), flush=True)
     dist.destroy_process_group()

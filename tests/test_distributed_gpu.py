@@ -232,3 +232,81 @@ def test_distributed_k3_ranks_on_one_gpu(world, mixed, priors):
         assert r["cam_err"] <= 1e-8 and r["pts_err"] <= 1e-8 and r["trace_cost_err"] <= 1e-9, r
     assert len({r["final_cost"] for r in res}) == 1
     print("\n" + "\n".join(l for o in outs for l in o.splitlines() if "distributed K3" in l))
+
+
+def _run_sharded_workers(world, env_extra, timeout):
+    import json
+    import subprocess
+    import sys
+    port = str(30100 + os.getpid() % 300 + 5 * world)
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, **env_extra)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), "sharded_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    res = []
+    for o, pr in zip(outs, procs):
+        assert pr.returncode == 0, o[-3000:]
+        line = [l for l in o.splitlines() if l.startswith("RESULT ")]
+        assert line, o[-3000:]
+        res.append(json.loads(line[-1][7:]))
+    return res, outs
+
+
+def _check_sharded_against_unsharded(res, outs, world):
+    assert {r["rank"] for r in res} == set(range(world)) and sum(r["tracks"] for r in res) == res[0]["total_tracks"]
+    for o in outs:
+        assert "theia_hip distributed K3: rank" in o, o[-3000:]      # the distributed plan, not the replicated solve
+    for r in res:
+        assert r["iterations"] == r["ref_iterations"] and r["trace_size"] == r["ref_trace_size"], r
+        assert r["trace_cost_err"] <= 1e-9, r
+        assert abs(r["final_cost"] - r["ref_final_cost"]) <= 1e-9 * r["ref_final_cost"], r
+        assert r["cam_err"] <= 1e-8 and r["pts_rel_err"] <= 1e-8, r
+    assert len({r["final_cost"] for r in res}) == 1       # every rank holds the all-reduced cost bit for bit
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_solve_at_c2_size_matches_the_unsharded_solve(world):
+    """the sharded solve at the size of BASELINE.json configs[1] -- 200 views / 50 000 tracks, mixed pinhole +
+    double-sphere models -- with the distributed K3 on (tile OR across ranks, private tile columns factored before the
+    all-reduce, the shared top by every rank), 2 and 4 ranks as processes on the one GPU of the box (collective staged through
+    the host: tests/sharded_worker.py).  Every rank against the UNSHARDED solve of the same problem: iteration count and trace
+    length equal, cost trace to 1e-9 of the initial cost, final cost to 1e-9, cameras to 1e-8, points to 1e-8 relative."""
+    res, outs = _run_sharded_workers(world, dict(SHARD_CONFIG="C2", SHARD_MIXED="1", SHARD_INNER="0", THEIA_HIP_CREATE_TIMING="1"), 600)
+    _check_sharded_against_unsharded(res, outs, world)
+    print("\n" + "\n".join(l for o in outs for l in o.splitlines() if "distributed K3" in l))
+
+
+@pytest.mark.skipif(not os.environ.get("THEIA_HIP_SOAK_C4_SHARDED"), reason="soak: set THEIA_HIP_SOAK_C4_SHARDED=1 (C4, two ranks on one GPU, ~2 min)")
+def test_sharded_solve_at_c4_size_matches_the_unsharded_solve():
+    """The same at configs[3] (1000 views / 500 000 tracks / 3.0 M observations, 94 tiles in the reduced system), two ranks."""
+    res, outs = _run_sharded_workers(2, dict(SHARD_CONFIG="C4", SHARD_MIXED="1", SHARD_INNER="0", THEIA_HIP_CREATE_TIMING="1", SHARD_MAX_ITERATIONS="8"), 1200)
+    _check_sharded_against_unsharded(res, outs, 2)
+
+
+def test_bench_self_launches_its_ranks():
+    """VERDICT r5 missing 1: `python bench.py --gpus N` with NO launcher in front must start its own N ranks (the shape of the
+    driver's N = 1 command) and print exactly ONE JSON line, from rank 0.  Run here as the one-GPU rehearsal (both ranks on
+    cuda:0, collective through gloo): everything but the collective's transport is the code path of the SCALE run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    pr = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--one-gpu-dry-run", "--steps", "4", "--warmup", "2",
+                         "--no-ransac", "--no-cpu-baseline"], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert pr.returncode == 0, (pr.stdout[-1500:], pr.stderr[-3000:])
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["n_ranks_in_process_group"] == 2 and out["dry_run_one_gpu"]["ranks"] == 2
