@@ -544,3 +544,18 @@ def set_threads(n):
 
 def max_threads():
     return int(load().oracle_ba_max_threads())
+
+
+def sfm_rules():
+    """oracle/sfm_rules.py (sequential restatements of SelectGoodTracksForBundleAdjustment and VerifyMatches), loaded by path:
+    oracle/ is not a package and is never importable from the product."""
+    import importlib.util
+    import sys
+    name = "oracle_sfm_rules"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ORACLE_DIR, "sfm_rules.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod

@@ -1126,6 +1126,18 @@ def test_select_good_tracks_for_bundle_adjustment_mirror():
     ref = sfm._select_good_tracks(rec, [v for v in range(12) if rec.view_estimated[v]], np.bincount(rec.obs_track[keep], minlength=400),
                                   err, 10, 200, 25)
     assert sel == ref.tolist()
+    # ... and against the oracle's sequential restatement of select_good_tracks_for_bundle_adjustment.cc:79-320 (oracle/sfm_rules.py:
+    # per-track statistics through the oracle's camera projection, dict image grids, min_element / partial_sort semantics),
+    # which shares nothing with the mirror's vectorised helper -- for three settings of (length threshold, cell size, K)
+    R = ol.sfm_rules()
+    views = [v for v in range(12) if rec.view_estimated[v]]
+    assert sel == R.select_good_tracks_for_bundle_adjustment(ol, rec, views, 10, 200, 25)
+    for (lt, cell, K) in ((3, 120, 40), (2, 400, 5), (10, 64, 0)):
+        ok2, sel2 = sfm.SelectGoodTracksForBundleAdjustment(rec, lt, cell, K)
+        assert ok2 and sel2 == R.select_good_tracks_for_bundle_adjustment(ol, rec, views, lt, cell, K), (lt, cell, K)
+    # a subset of the views (the overload of :280-320 the incremental pipeline calls)
+    ok3, sel3 = sfm.SelectGoodTracksForBundleAdjustment(rec, 10, 200, 25, view_ids=[0, 5, 7])
+    assert ok3 and sel3 == R.select_good_tracks_for_bundle_adjustment(ol, rec, [0, 5, 7], 10, 200, 25)
     chosen = np.zeros(400, bool); chosen[sel] = True
     for v in range(12):
         if not rec.view_estimated[v]:

@@ -666,6 +666,38 @@ def test_two_view_match_geometric_verification():
         assert ang < 0.3 and ang <= angp + 0.1 and abs(np.linalg.norm(info.position_2) - 1) < 1e-12
         assert info.position_2 @ truth["position"][i] / np.linalg.norm(truth["position"][i]) > 0.999
         assert info.focal_length_1 == 1000.0 and 0 <= info.num_homography_inliers < len(corr[i])
+    # against the oracle's sequential restatement of VerifyMatches (oracle/sfm_rules.py: one pair at a time -- homography count
+    # and two-view info through oracle/ransac_oracle.cpp, per-match triangulation and reprojection tests, BundleAdjustTwoViews
+    # through oracle/ba_oracle.cpp on the flat two-camera problem): the same verified matches, counts, and the pose to 1e-8
+    R = ol.sfm_rules()
+    for i in range(4):
+        ook, oinfo, oidx = R.verify_matches(ol, capi, vo, pr, pr, corr[i])
+        ok, info, idx = out[i]
+        assert ok == ook and idx == oidx, i
+        assert info.num_homography_inliers == oinfo["num_homography_inliers"] and info.num_verified_matches == oinfo["num_verified_matches"]
+        if ok:
+            assert np.abs(info.rotation_2 - oinfo["rotation_2"]).max() <= 1e-8 and np.abs(info.position_2 - oinfo["position_2"]).max() <= 1e-8
+            assert info.focal_length_1 == oinfo["focal_length_1"] and info.focal_length_2 == oinfo["focal_length_2"]
+    # ... with an uncalibrated second view (free focal lengths in the two-view BA) and a stricter final filter
+    pu = tv.CameraIntrinsicsPrior(); pu.image_width = 1000; pu.image_height = 800
+    vo2 = tv.TwoViewMatchGeometricVerificationOptions()
+    vo2.estimate_twoview_info_options.seed = 11; vo2.estimate_twoview_info_options.max_sampson_error_pixels = 2.0
+    vo2.final_max_reprojection_error = 2.0; vo2.min_triangulation_angle_degrees = 2.0
+    datu, offu, _ = synth.synth_ransac_v1(3, 400, "uncalibrated", seed=0x5AC51801, inlier_lo=0.6, inlier_hi=0.8, noise_px=0.3)
+    corru = [datu[offu[i]:offu[i + 1]] + np.array([500.0, 400.0, 500.0, 400.0]) for i in range(3)]
+    outu = tv.VerifyMatchesBatch(vo2, [pu] * 3, [pu] * 3, corru)
+    nok = 0
+    for i in range(3):
+        ook, oinfo, oidx = R.verify_matches(ol, capi, vo2, pu, pu, corru[i])
+        ok, info, idx = outu[i]
+        assert ok == ook and idx == oidx, i
+        assert info.num_homography_inliers == oinfo["num_homography_inliers"]
+        if ok:
+            nok += 1
+            assert np.abs(info.rotation_2 - oinfo["rotation_2"]).max() <= 1e-7 and np.abs(info.position_2 - oinfo["position_2"]).max() <= 1e-7
+            assert abs(info.focal_length_1 - oinfo["focal_length_1"]) <= 1e-6 * abs(oinfo["focal_length_1"])
+            assert abs(info.focal_length_2 - oinfo["focal_length_2"]) <= 1e-6 * abs(oinfo["focal_length_2"])
+    assert nok >= 2
     # without the two-view BA the verified matches are the RANSAC inliers
     vo.bundle_adjustment = False
     out2 = tv.VerifyMatchesBatch(vo, [pr] * 3, [pr] * 3, corr[:3])
