@@ -321,6 +321,18 @@ int theia_hip_optimize_homography_batch(int32_t num_problems, const int64_t* off
                                         const theia_ba_options* options,
                                         theia_ba_summary* summaries);
 
+/* N calls of OptimizeRelativePositionWithKnownRotation(correspondences, rotation1, rotation2, &relative_position)
+ * (bundle_adjustment/optimize_relative_position_with_known_rotation.cc:116-191; pybind sfm.cc:1621-1622; called once per
+ * view pair from a thread pool by RefineRelativeTranslationsWithKnownRotations, reconstruction_estimator_utils.cc:263-291):
+ * the IRLS null-vector solve on the epipolar constraints with both rotations known, at most 100 iterations, sign by the
+ * cheirality majority.  One pair per wavefront (csrc/relpos_irls.hip).  correspondences [total][4] = normalised
+ * (x1, y1, x2, y2); rotations [num_problems][6] = rotation1 | rotation2 as angle-axis (world -> camera, as
+ * Camera::GetOrientationAsAngleAxis); relative_positions [num_problems][3] out (unit vectors; the reference returns true
+ * always); num_iterations [num_problems] optional out.  An empty pair yields (0, 0, -1) like the reference's arithmetic. */
+int theia_hip_optimize_relative_position_batch(int32_t num_problems, const int64_t* offsets,
+                                               const double* correspondences, const double* rotations,
+                                               double* relative_positions, int32_t* num_iterations);
+
 /* N calls of OptimizeFundamentalMatrix(options, correspondences, &F) (bundle_adjust_two_views.cc:248-296;
  * RefineModel of the fundamental-matrix estimator, estimate_fundamental_matrix.cc:53-90): F moves on the
  * 7-dof manifold of fundamental_matrix_parameterization.h:15-75 (Plus through the SVD of the current F:

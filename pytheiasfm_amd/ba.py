@@ -390,6 +390,23 @@ def optimize_fundamental_matrix_batch(offsets, correspondences, fundamental_matr
     return [summ[i] for i in range(num)]
 
 
+def optimize_relative_position_batch(offsets, correspondences, rotations):
+    """theia_hip_optimize_relative_position_batch: N x OptimizeRelativePositionWithKnownRotation
+    (optimize_relative_position_with_known_rotation.cc:116-191), one pair per wavefront.  correspondences [total][4]
+    normalised, rotations [N][6] = rotation1 | rotation2 (angle-axis).  Returns (positions [N][3], iterations [N])."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    num = len(offsets) - 1
+    corr = np.ascontiguousarray(correspondences, dtype=np.float64).reshape(-1, 4)
+    rot = np.ascontiguousarray(rotations, dtype=np.float64).reshape(num, 6)
+    pos = np.zeros((num, 3)); it = np.zeros(max(1, num), dtype=np.int32)
+    L = capi.lib()
+    L.theia_hip_optimize_relative_position_batch.argtypes = [C.c_int32, C.POINTER(C.c_int64), capi.c_double_p, capi.c_double_p, capi.c_double_p,
+                                                             C.POINTER(C.c_int32)]
+    capi.check(L.theia_hip_optimize_relative_position_batch(num, offsets.ctypes.data_as(C.POINTER(C.c_int64)), capi.ptr(corr, C.c_double),
+                                                            capi.ptr(rot, C.c_double), capi.ptr(pos, C.c_double), it.ctypes.data_as(C.POINTER(C.c_int32))))
+    return pos, it[:num]
+
+
 def solve_tracks_batch(problem, options):
     """theia_hip_ba_tracks_batch: every point as an independent BundleAdjustTrack problem
     (bundle_adjustment.cc:262-285), cameras constant.  problem.points is updated in place;

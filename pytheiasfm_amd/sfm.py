@@ -485,6 +485,52 @@ def BundleAdjustTwoViewsAngularBatch(options, correspondences_list, two_view_inf
     return [BundleAdjustmentSummary(c) for c in summ]
 
 
+def OptimizeRelativePositionWithKnownRotation(correspondences, rotation1, rotation2):
+    """optimize_relative_position_with_known_rotation.cc:116-191 through its pybind wrapper
+    (bundle_adjustment_wrapper.cc:141-150) -> (success, relative_position)."""
+    pos = OptimizeRelativePositionWithKnownRotationBatch([correspondences], [rotation1], [rotation2])
+    return True, pos[0]
+
+
+def OptimizeRelativePositionWithKnownRotationBatch(correspondences_list, rotations1, rotations2):
+    """One call per view pair of the view graph in the reference (RefineRelativeTranslationsWithKnownRotations,
+    reconstruction_estimator_utils.cc:263-291, a thread pool); here all pairs as one launch, one wavefront per pair.
+    Returns the positions [N][3]."""
+    n = len(correspondences_list)
+    corr = [np.asarray(c, dtype=np.float64).reshape(-1, 4) for c in correspondences_list]
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([len(c) for c in corr])
+    rot = np.concatenate([np.asarray(rotations1, dtype=np.float64).reshape(n, 3), np.asarray(rotations2, dtype=np.float64).reshape(n, 3)], axis=1)
+    pos, _ = _ba.optimize_relative_position_batch(offsets, np.vstack(corr) if n else np.zeros((0, 4)), rot)
+    return pos
+
+
+def OptimizeAbsolutePoseOnNormFeatures(correspondences_2d_3d, rotation_init, position_init, ba_options):
+    """pose/pose_wrapper.cc:39-65 (pybind sfm.cc:1625-1626): BundleAdjustView of a one-view reconstruction whose camera is
+    the default pinhole (focal length 1, principal point 0) at (rotation_init, position_init), every world point an estimated
+    (hence constant) track.  correspondences_2d_3d: [N][5] = (x, y, X, Y, Z).  -> (success, rotation matrix, position)."""
+    out = OptimizeAbsolutePoseOnNormFeaturesBatch([correspondences_2d_3d], [rotation_init], [position_init], ba_options)
+    return out[0]
+
+
+def OptimizeAbsolutePoseOnNormFeaturesBatch(correspondences_list, rotations_init, positions_init, ba_options):
+    """N x OptimizeAbsolutePoseOnNormFeatures as one launch (theia_hip_ba_views_batch: one LM solve per wavefront)."""
+    from . import synth as _synth
+    n = len(correspondences_list)
+    c = [np.asarray(x, dtype=np.float64).reshape(-1, 5) for x in correspondences_list]
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum([len(x) for x in c])
+    allc = np.vstack(c) if n else np.zeros((0, 5))
+    cams = np.zeros((n, 6))
+    for k in range(n):
+        cams[k, :3] = np.asarray(positions_init[k], dtype=np.float64)
+        cams[k, 3:] = _synth.matrix_to_angle_axis(np.asarray(rotations_init[k], dtype=np.float64).reshape(3, 3))
+    intr = np.zeros((n, capi.THEIA_MAX_INTRINSICS)); intr[:, 0] = 1.0; intr[:, 1] = 1.0     # PinholeCameraModel defaults
+    pts = np.concatenate([allc[:, 2:5], np.ones((len(allc), 1))], axis=1)
+    summ = _ba.solve_views_batch(offsets, allc[:, 0:2], pts, cams, intr, np.zeros(n, np.int32), _no_inner(ba_options).to_c())
+    return [(bool(s.success), _synth.angle_axis_to_matrix(cams[k, 3:]), cams[k, :3].copy()) for k, s in enumerate(summ)]
+
+
 def BundleAdjustViewsIndependently(reconstruction, options, view_ids):
     """[BundleAdjustView(reconstruction, options, v) for v in view_ids] as one launch
     (theia_hip_ba_views_batch).  Returns the list of summaries."""

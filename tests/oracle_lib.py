@@ -546,6 +546,20 @@ def max_threads():
     return int(load().oracle_ba_max_threads())
 
 
+def optimize_relative_position(corr, rot1, rot2, order=0):
+    """oracle_optimize_relative_position_with_known_rotation -> (position [3], iterations).  order: 0 = sums in index order,
+    1 = in the device's wavefront order (64 interleaved partial sums + XOR butterfly)."""
+    L = rlib()
+    corr = np.ascontiguousarray(corr, dtype=np.float64).reshape(-1, 4)
+    r1 = np.ascontiguousarray(rot1, dtype=np.float64); r2 = np.ascontiguousarray(rot2, dtype=np.float64)
+    pos = np.zeros(3)
+    L.oracle_optimize_relative_position_with_known_rotation.argtypes = [C.c_int, capi.c_double_p, capi.c_double_p, capi.c_double_p, capi.c_double_p, C.c_int]
+    L.oracle_optimize_relative_position_with_known_rotation.restype = C.c_int
+    it = L.oracle_optimize_relative_position_with_known_rotation(corr.shape[0], capi.ptr(corr, C.c_double), capi.ptr(r1, C.c_double),
+                                                                 capi.ptr(r2, C.c_double), capi.ptr(pos, C.c_double), int(order))
+    return pos, int(it)
+
+
 def sfm_rules():
     """oracle/sfm_rules.py (sequential restatements of SelectGoodTracksForBundleAdjustment and VerifyMatches), loaded by path:
     oracle/ is not a package and is never importable from the product."""
