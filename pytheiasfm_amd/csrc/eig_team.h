@@ -28,6 +28,14 @@ __device__ __forceinline__ void team_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// The team's slice of a wave ballot (bit i = team lane i; the team is contiguous and TEAM-aligned, TEAM <= 32)
+template <int TEAM>
+__device__ __forceinline__ unsigned team_ballot(bool pred, int tl) {
+  const unsigned long long m = __ballot(pred);
+  const int base = (int)__lane_id() - tl;
+  return (unsigned)(m >> base) & (TEAM >= 32 ? 0xffffffffu : ((1u << (TEAM & 31)) - 1u));
+}
+
 //
 // NR > 0 (a caller that reads only NR rows of the eigenvector matrix, e.g. DLS: rows 0, 9, 3, 1): once the Householder
 // reflectors are accumulated, every later operation on V combines COLUMNS of one row -- the rows never mix again -- so
@@ -112,12 +120,20 @@ __device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double*
     for (int j = (i - 1 > 0 ? i - 1 : 0); j < nn; ++j) norm += fabs(HH(i, j));
   int iter = 0, total_iter = 0;
   while (n >= low) {
-    int l = n;
-    while (l > low) {
-      s = fabs(HH(l - 1, l - 1)) + fabs(HH(l, l));
-      if (s == 0.0) s = norm;
-      if (fabs(HH(l, l - 1)) < eps * s) break;
-      l--;
+    // the deflation scan "l = n; while (l > low && |H(l, l-1)| >= eps (|H(l-1, l-1)| + |H(l, l)|)) l--": every candidate l is
+    // tested by one team lane (the same arithmetic per candidate), the answer is the LARGEST small one = the first set bit of
+    // the team ballot.  The sequential loop ran ~(n - l) dependent iterations in every lane of the team.
+    int l = low;
+    for (int lb = n; lb > low; lb -= TEAM) {
+      const int lc = lb - tl;
+      bool small = false;
+      if (lc > low) {
+        double ss = fabs(HH(lc - 1, lc - 1)) + fabs(HH(lc, lc));
+        if (ss == 0.0) ss = norm;
+        small = fabs(HH(lc, lc - 1)) < eps * ss;
+      }
+      const unsigned bm = team_ballot<TEAM>(small, tl);
+      if (bm) { l = lb - (__ffs((int)bm) - 1); break; }
     }
     if (l == n) {  // one root
       const double v = HH(n, n) + exshift;
@@ -184,20 +200,36 @@ __device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double*
       }
       iter = iter + 1;
       if (++total_iter > 40 * nn) return false;
-      int m = n - 2;
-      while (m >= l) {
-        z = HH(m, m);
-        r = x - z; s = y - z;
-        p = (r * s - w) / HH(m + 1, m) + HH(m, m + 1);
-        q = HH(m + 1, m + 1) - z - r - s;
-        r = HH(m + 2, m + 1);
-        s = fabs(p) + fabs(q) + fabs(r);
-        p = p / s; q = q / s; r = r / s;
-        if (m == l) break;
-        if (fabs(HH(m, m - 1)) * (fabs(q) + fabs(r)) <
-            eps * (fabs(p) * (fabs(HH(m - 1, m - 1)) + fabs(z) + fabs(HH(m + 1, m + 1))))) break;
-        m--;
+      // The search for two consecutive small subdiagonal elements walks m = n - 2 down to l and stops at the first m that is l
+      // or passes the test; each step is four divisions in every lane of the team.  Here every candidate m is evaluated by ONE
+      // team lane with the sequential loop's arithmetic, the answer is the largest m that stops (first set bit of the ballot),
+      // and its (p, q, r) reach the team through ort[0..2] (free since the accumulation).
+      int m = l;
+      for (int mb = n - 2; mb >= l; mb -= TEAM) {
+        const int mc = mb - tl;
+        bool hit = false;
+        double pc = 0.0, qc = 0.0, rc = 0.0;
+        if (mc >= l) {
+          const double zc = HH(mc, mc);
+          const double r0 = x - zc, s0 = y - zc;
+          pc = (r0 * s0 - w) / HH(mc + 1, mc) + HH(mc, mc + 1);
+          qc = HH(mc + 1, mc + 1) - zc - r0 - s0;
+          rc = HH(mc + 2, mc + 1);
+          const double sc = fabs(pc) + fabs(qc) + fabs(rc);
+          pc = pc / sc; qc = qc / sc; rc = rc / sc;
+          hit = (mc == l) || (fabs(HH(mc, mc - 1)) * (fabs(qc) + fabs(rc)) <
+                              eps * (fabs(pc) * (fabs(HH(mc - 1, mc - 1)) + fabs(zc) + fabs(HH(mc + 1, mc + 1)))));
+        }
+        const unsigned bm = team_ballot<TEAM>(hit, tl);
+        if (bm) {
+          const int t0 = __ffs((int)bm) - 1;
+          m = mb - t0;
+          if (tl == t0) { ort[0] = pc; ort[1] = qc; ort[2] = rc; }
+          break;
+        }
       }
+      team_sync();
+      p = ort[0]; q = ort[1]; r = ort[2];
       team_sync();
       for (int i = m + 2 + tl; i <= n; i += TEAM) { HH(i, i - 2) = 0.0; if (i > m + 2) HH(i, i - 3) = 0.0; }
       team_sync();
@@ -227,18 +259,16 @@ __device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double*
             HH(k + 1, j) = HH(k + 1, j) - pp * y;
           }
           team_sync();
+          // column modification of H (rows 0 .. imax) and of the eigenvector rows in ONE pass over "virtual rows": the two sets
+          // are disjoint and see the same operation, and a team has lanes to spare (27 + 4 rows on 32 lanes: one round)
           const int imax = (n < k + 3) ? n : k + 3;
-          for (int i = tl; i <= imax; i += TEAM) {
-            double pp = x * HH(i, k) + y * HH(i, k + 1);
-            if (notlast) { pp = pp + z * HH(i, k + 2); HH(i, k + 2) = HH(i, k + 2) - pp * r; }
-            HH(i, k) = HH(i, k) - pp;
-            HH(i, k + 1) = HH(i, k + 1) - pp * q;
-          }
-          for (int i = tl; i < vrows; i += TEAM) {
-            double pp = x * VRR(i, k) + y * VRR(i, k + 1);
-            if (notlast) { pp = pp + z * VRR(i, k + 2); VRR(i, k + 2) = VRR(i, k + 2) - pp * r; }
-            VRR(i, k) = VRR(i, k) - pp;
-            VRR(i, k + 1) = VRR(i, k + 1) - pp * q;
+          const int nvrow = imax + 1 + vrows;
+          for (int v = tl; v < nvrow; v += TEAM) {
+            double* row = (v <= imax) ? (H + v * nn) : (VR + (v - imax - 1) * nn);
+            double pp = x * row[k] + y * row[k + 1];
+            if (notlast) { pp = pp + z * row[k + 2]; row[k + 2] = row[k + 2] - pp * r; }
+            row[k] = row[k] - pp;
+            row[k + 1] = row[k + 1] - pp * q;
           }
           team_sync();
         }
