@@ -23,7 +23,7 @@ for f in $SRCS; do
     # residual pair in scratch (24 B per lane, written and read per observation)
     case "$f" in ba_inner.hip) CONTRACT="off -mllvm -simplifycfg-sink-common=false" ;; esac
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=$CONTRACT -munsafe-fp-atomics \
-      -I../../include -I. -c "$f" -o "$o" &
+      -I../../include -I. ${THIP_EXTRA_DEFS:-} -c "$f" -o "$o" &
     PIDS="$PIDS $!"
   fi
   OBJS="$OBJS $o"

@@ -82,3 +82,13 @@ void launch_dls_solve_a(int num, const int64_t* offsets, const double* feat, con
 }
 
 }  // namespace thip
+
+#ifdef THIP_DLS_STAMPS
+// development: the section stamps of stage_a (dls_stage_a.h) summed since the last call; out[8]
+extern "C" int theia_hip_debug_dls_stamps(unsigned long long* out) {
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(thip::dlsdev::g_dls_stamps), sizeof(zero)) != hipSuccess) return -1;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(thip::dlsdev::g_dls_stamps), zero, sizeof(zero));
+  return 0;
+}
+#endif

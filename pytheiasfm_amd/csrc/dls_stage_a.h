@@ -183,6 +183,19 @@ __device__ __forceinline__ void bs_scale_row(const double (&a)[3][20], double in
   for (int i = 0; i < 5; ++i) xq[i] = a[Q][i] * inv_ukk;
 }
 
+// Development (-DTHIP_DLS_STAMPS): s_memtime ticks of thread 0 per section of stage_a, summed over the workgroups:
+// {front end, register load, elimination, back-substitution, M00 - M01 X + stores, calls}
+#ifdef THIP_DLS_STAMPS
+__device__ unsigned long long g_dls_stamps[8];
+#define DLS_STAMP_DECL unsigned long long ds_t = __builtin_amdgcn_s_memtime(), ds_acc[5] = {0, 0, 0, 0, 0}
+#define DLS_STAMP(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ds_acc[k] += n_ - ds_t; ds_t = n_; } while (0)
+#define DLS_STAMP_FLUSH do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < 5; ++k_) atomicAdd(&g_dls_stamps[k_], ds_acc[k_]); atomicAdd(&g_dls_stamps[5], 1ull); } } while (0)
+#else
+#define DLS_STAMP_DECL do {} while (0)
+#define DLS_STAMP(k) do {} while (0)
+#define DLS_STAMP_FLUSH do {} while (0)
+#endif
+
 // points: feat[i * fstride + {0,1}], world[i * wstride + {0,1,2}] for i = index ? index[k] : k, k < npts.
 // Writes action[729] (row-major) and tfac[27]; returns false when a pivot vanished (degenerate sample).
 // GDLS (GdlsSimilarityTransform, gdls_similarity_transform.cc:67-175): feat holds the UNIT ray direction (3), world the
@@ -196,6 +209,7 @@ __device__ __forceinline__ bool stage_a(WgLds& L, int npts, const double* __rest
   const int tid = threadIdx.x;
   const int g = tid >> 5, rg = tid & 31;
   const dls::Tables& tb = c_tab;
+  DLS_STAMP_DECL;
   if (tid < 4) L.u[tid] = u4[tid];
   if (tid == 0) L.flag = 0;
   if constexpr (GDLS) {
@@ -317,6 +331,7 @@ __device__ __forceinline__ bool stage_a(WgLds& L, int npts, const double* __rest
   __syncthreads();
   if (tid < 60) L.fe.f[tid] = (double)tb.fmul[tid] * L.fe.J[tb.fsrc[tid]];   // f_i = dJ'/ds_i
   __syncthreads();
+  DLS_STAMP(0);
   // ---- the augmented block [M11 | M10] into registers
   double a[3][20];
   {
@@ -335,6 +350,7 @@ __device__ __forceinline__ bool stage_a(WgLds& L, int npts, const double* __rest
 #pragma unroll
   for (int q = 0; q < 3; ++q) pos[q] = 3 * rg + q;
   __syncthreads();   // the front end's arrays share the pivot-row store
+  DLS_STAMP(1);
   // ---- elimination (oracle: dls_action_from_cost)
   int urow = 0;   // u_base(k), carried along
   for (int o = 0; o < 4; ++o) lu_six<20>(L, a, pos, o, g, rg, urow);
@@ -345,6 +361,7 @@ __device__ __forceinline__ bool stage_a(WgLds& L, int npts, const double* __rest
   // A right-hand side never leaves its column group: the 32 lanes of a half-wave hold its entries of all 96 rows, so every
   // half-wave runs the whole substitution on its own five columns: nothing crosses a wave and there is no barrier in the loop
   // (the pivot-row store is read-only here).
+  DLS_STAMP(2);
   double* Xn = action;   // the solved rows the result reads wait in the problem's own output slot
   __syncthreads();   // the factor buffer of the last elimination step becomes the hand-over buffer below
   int ucol[3];   // entry (pos[q], k) of the pivot-row store sits at ucol[q] + k
@@ -381,6 +398,7 @@ __device__ __forceinline__ bool stage_a(WgLds& L, int npts, const double* __rest
   }
   __threadfence_block();
   __syncthreads();
+  DLS_STAMP(3);
   // ---- M00 - M01 X, the columns of M01 in ascending order
   double res[4];
 #pragma unroll
@@ -400,6 +418,8 @@ __device__ __forceinline__ bool stage_a(WgLds& L, int npts, const double* __rest
   for (int t = 0; t < 4; ++t) { const int e = tid + kThreads * t; if (e < kReduced * kReduced) action[e] = res[t]; }
   if (tid < 27) tfac[tid] = L.T[tid];
   if (GDLS && tid < 9) tfac[27 + tid] = L.sf[tid];
+  DLS_STAMP(4);
+  DLS_STAMP_FLUSH;
   return L.flag == 0;
 }
 

@@ -28,6 +28,20 @@ __device__ __forceinline__ void team_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Development (-DTHIP_EIG_STAMPS): s_memtime ticks per phase of eig_team, summed over the teams' lane 0 into g_eig_stamps
+// {orthes, accumulate, hqr2 deflation scans + root branches, shift + start search, chase steps, back-substitution,
+// back-transformation, calls}; read back with theia_hip_debug_eig_stamps (ransac.hip).
+#ifdef THIP_EIG_STAMPS
+__device__ unsigned long long g_eig_stamps[8];
+#define EIG_STAMP_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define EIG_STAMP(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[k] += n_ - st_t; st_t = n_; } while (0)
+#define EIG_STAMP_FLUSH do { if (tl == 0) { for (int k_ = 0; k_ < 7; ++k_) atomicAdd(&g_eig_stamps[k_], st_acc[k_]); atomicAdd(&g_eig_stamps[7], 1ull); } } while (0)
+#else
+#define EIG_STAMP_DECL do {} while (0)
+#define EIG_STAMP(k) do {} while (0)
+#define EIG_STAMP_FLUSH do {} while (0)
+#endif
+
 // The team's slice of a wave ballot (bit i = team lane i; the team is contiguous and TEAM-aligned, TEAM <= 32)
 template <int TEAM>
 __device__ __forceinline__ unsigned team_ballot(bool pred, int tl) {
@@ -54,6 +68,7 @@ __device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double*
   double* const VR = NR > 0 ? Vk : V;
 #define VRR(i, j) VR[(i) * nn + (j)]
   const int low = 0, high = nn - 1;
+  EIG_STAMP_DECL;
   // ---- orthes
   for (int m = low + 1; m <= high - 1; ++m) {
     double scale = 0.0;
@@ -91,6 +106,7 @@ __device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double*
       team_sync();
     }
   }
+  EIG_STAMP(0);
   for (int e = tl; e < nn * nn; e += TEAM) V[e] = (e / nn == e % nn) ? 1.0 : 0.0;
   team_sync();
   for (int m = high - 1; m >= low + 1; --m) {
@@ -110,6 +126,7 @@ __device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double*
     for (int e = tl; e < NR * nn; e += TEAM) Vk[e] = VV(keep[e / nn], e % nn);
     team_sync();
   }
+  EIG_STAMP(1);
   // ---- hqr2
   int n = nn - 1;
   const double eps = 2.220446049250313e-16;
@@ -120,10 +137,16 @@ __device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double*
     for (int j = (i - 1 > 0 ? i - 1 : 0); j < nn; ++j) norm += fabs(HH(i, j));
   int iter = 0, total_iter = 0;
   while (n >= low) {
+    // Converged roots are peeled off in an inner loop until THIS team is due for a sweep (or done): the teams of a wave then
+    // meet in the sweep code every pass of the outer loop, instead of idling through the others' sweeps each time they
+    // split off a root (one matrix sees the same operations in the same order either way).
+    int l = low;
+    bool sweep_due = false;
+    while (n >= low) {
     // the deflation scan "l = n; while (l > low && |H(l, l-1)| >= eps (|H(l-1, l-1)| + |H(l, l)|)) l--": every candidate l is
     // tested by one team lane (the same arithmetic per candidate), the answer is the LARGEST small one = the first set bit of
     // the team ballot.  The sequential loop ran ~(n - l) dependent iterations in every lane of the team.
-    int l = low;
+    l = low;
     for (int lb = n; lb > low; lb -= TEAM) {
       const int lc = lb - tl;
       bool small = false;
@@ -141,7 +164,9 @@ __device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double*
       if (tl == 0) { HH(n, n) = v; wr[n] = v; wi[n] = 0.0; }
       team_sync();
       n--; iter = 0;
-    } else if (l == n - 1) {  // two roots
+      continue;
+    }
+    if (l == n - 1) {  // two roots
       w = HH(n, n - 1) * HH(n - 1, n);
       p = (HH(n - 1, n - 1) - HH(n, n)) / 2.0;
       q = p * p + w;
@@ -172,7 +197,13 @@ __device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double*
         team_sync();
       }
       n = n - 2; iter = 0;
-    } else {
+      continue;
+    }
+    sweep_due = true;
+    break;
+    }   // peel loop
+    if (!sweep_due) break;
+    {
       x = HH(n, n); y = 0.0; w = 0.0;
       if (l < n) { y = HH(n - 1, n - 1); w = HH(n, n - 1) * HH(n - 1, n); }
       if (iter == 10) {  // Wilkinson's original ad hoc shift
@@ -200,6 +231,7 @@ __device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double*
       }
       iter = iter + 1;
       if (++total_iter > 40 * nn) return false;
+      EIG_STAMP(2);
       // The search for two consecutive small subdiagonal elements walks m = n - 2 down to l and stops at the first m that is l
       // or passes the test; each step is four divisions in every lane of the team.  Here every candidate m is evaluated by ONE
       // team lane with the sequential loop's arithmetic, the answer is the largest m that stops (first set bit of the ballot),
@@ -233,6 +265,7 @@ __device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double*
       team_sync();
       for (int i = m + 2 + tl; i <= n; i += TEAM) { HH(i, i - 2) = 0.0; if (i > m + 2) HH(i, i - 3) = 0.0; }
       team_sync();
+      EIG_STAMP(3);
       for (int k = m; k <= n - 1; ++k) {
         const bool notlast = (k != n - 1);
         if (k != m) {
@@ -273,9 +306,11 @@ __device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double*
           team_sync();
         }
       }
+      EIG_STAMP(4);
     }
   }
   team_sync();
+  EIG_STAMP(2);
   if (norm == 0.0) return true;
   // ---- back-substitution: one lane per eigenvalue column.  The sequential routine overwrites column n of H with the
   // vector while columns < n still hold the triangular form; here the vectors go to X so that the columns are independent
@@ -353,6 +388,7 @@ __device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double*
     }
   }
   team_sync();
+  EIG_STAMP(5);
   // ---- back-transformation V <- V X, row i by lane (column j in descending order, in place as in the sequential code)
   for (int i = tl; i < vrows; i += TEAM)
     for (int j = nn - 1; j >= low; --j) {
@@ -362,6 +398,8 @@ __device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double*
       VRR(i, j) = z;
     }
   team_sync();
+  EIG_STAMP(6);
+  EIG_STAMP_FLUSH;
   return true;
 #undef HH
 #undef VV

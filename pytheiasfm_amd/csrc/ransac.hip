@@ -2263,3 +2263,13 @@ int theia_hip_dls_pnp(int32_t num, const int64_t* offsets, const double* feature
 void theia_hip_release_scratch(void) { dev_pool().release(); host_pool().release(); }
 
 }  // extern "C"
+
+#ifdef THIP_EIG_STAMPS
+// development: the phase stamps of eig_team (eig_team.h) summed since the last call; out[8]
+extern "C" int theia_hip_debug_eig_stamps(unsigned long long* out) {
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(thip::rsc::g_eig_stamps), sizeof(zero)) != hipSuccess) return -1;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(thip::rsc::g_eig_stamps), zero, sizeof(zero));
+  return 0;
+}
+#endif
