@@ -396,13 +396,20 @@ __global__ __launch_bounds__(score_threads(EST)) void k_score(int est_rt, int np
 // ---- LMED (lmed.h:64-70, lmed_quality_measurement.h:58-130): cost = median of the squared residuals, inliers by the
 // 2.5 * 1.4826 * (1 + 5 / (n - m)) * sqrt(median) rule.  One workgroup per model: squared residuals in LDS, the order
 // statistics by an 8-bit radix select on the IEEE bit patterns (exact: the median is an element, or the mean of two).
-__device__ double lmed_select(const double* sq, int n, int k, int* hist, int* sel) {
+// sq == nullptr (more data than the LDS holds: > 19 456 per problem): the squared residuals are re-evaluated in every pass --
+// the same bits each time, ten evaluations per datum instead of one; lmed_quality_measurement.h:56-63 has no size limit.
+__device__ __forceinline__ double lmed_sq(const double* sq, int est, const double* m, const double* pd, int ds, int i) {
+  if (sq) return sq[i];
+  const double r = model_error(est, m, pd + (size_t)i * ds);
+  return r * r;
+}
+__device__ double lmed_select(const double* sq, int n, int k, int* hist, int* sel, int est, const double* m, const double* pd, int ds) {
   unsigned long long prefix = 0ull, mask = 0ull;
   for (int shift = 56; shift >= 0; shift -= 8) {
     for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      const unsigned long long key = (unsigned long long)__double_as_longlong(sq[i]);
+      const unsigned long long key = (unsigned long long)__double_as_longlong(lmed_sq(sq, est, m, pd, ds, i));
       if ((key & mask) == prefix) atomicAdd(&hist[(int)((key >> shift) & 255ull)], 1);
     }
     __syncthreads();
@@ -423,10 +430,12 @@ __device__ double lmed_select(const double* sq, int n, int k, int* hist, int* se
 // returns the median (cost); *ninl = inlier count; mask (optional, global) receives the inlier flags
 __device__ double lmed_block(int est, const double* m, const double* pd, int n, int ds, int min_samples, double* sq,
                              int* hist, int* sel, int* ninl, uint8_t* mask, double* sqt_out = nullptr) {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) { const double r = model_error(est, m, pd + (size_t)i * ds); sq[i] = r * r; }
+  if (sq) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const double r = model_error(est, m, pd + (size_t)i * ds); sq[i] = r * r; }
+  }
   __syncthreads();
-  double median = lmed_select(sq, n, n / 2, hist, sel);
-  if ((n % 2) != 0) median = 0.5 * (lmed_select(sq, n, n / 2 - 1, hist, sel) + median);
+  double median = lmed_select(sq, n, n / 2, hist, sel, est, m, pd, ds);
+  if ((n % 2) != 0) median = 0.5 * (lmed_select(sq, n, n / 2 - 1, hist, sel, est, m, pd, ds) + median);
   const double thr = 2.5 * 1.4826 * (1 + 5.0 / (double)((size_t)n - (size_t)min_samples)) * sqrt(median);
   const double sqt = thr * thr;
   if (sqt_out && threadIdx.x == 0) *sqt_out = sqt;
@@ -434,7 +443,7 @@ __device__ double lmed_block(int est, const double* m, const double* pd, int n, 
   __syncthreads();
   int cnt = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const bool in = sq[i] < sqt;
+    const bool in = lmed_sq(sq, est, m, pd, ds, i) < sqt;
     cnt += in ? 1 : 0;
     if (mask) mask[i] = in ? 1 : 0;
   }
@@ -447,7 +456,7 @@ __device__ double lmed_block(int est, const double* m, const double* pd, int n, 
 __global__ __launch_bounds__(256) void k_score_lmed(int est, int nprob, int B, const int64_t* __restrict__ offsets,
                                                     const double* __restrict__ data, const double* __restrict__ models,
                                                     const int* __restrict__ dense_count, const int* __restrict__ tags,
-                                                    double* __restrict__ cost, int* __restrict__ ninl) {
+                                                    double* __restrict__ cost, int* __restrict__ ninl, int in_lds) {
   extern __shared__ __attribute__((aligned(16))) double sdata[];
   __shared__ int hist[256], sel[4];
   __shared__ double m[kStride];
@@ -459,7 +468,7 @@ __global__ __launch_bounds__(256) void k_score_lmed(int est, int nprob, int B, c
   if (threadIdx.x < kStride) m[threadIdx.x] = models[dense * (size_t)kStride + threadIdx.x];
   __syncthreads();
   int cnt;
-  const double med = lmed_block(est, m, data + (size_t)offsets[p] * ds, n, ds, sample_size(est), sdata, hist, sel, &cnt, nullptr);
+  const double med = lmed_block(est, m, data + (size_t)offsets[p] * ds, n, ds, sample_size(est), in_lds ? sdata : nullptr, hist, sel, &cnt, nullptr);
   if (threadIdx.x == 0) {
     const size_t out = dense;
     cost[out] = med; ninl[out] = cnt;
@@ -468,7 +477,7 @@ __global__ __launch_bounds__(256) void k_score_lmed(int est, int nprob, int B, c
 
 __global__ __launch_bounds__(256) void k_inlier_mask_lmed(int est, int nprob, const int64_t* __restrict__ offsets,
                                                           const double* __restrict__ data, const double* __restrict__ best_models,
-                                                          uint8_t* __restrict__ mask) {
+                                                          uint8_t* __restrict__ mask, int in_lds) {
   extern __shared__ __attribute__((aligned(16))) double sdata[];
   __shared__ int hist[256], sel[4];
   __shared__ double m[kStride];
@@ -478,14 +487,14 @@ __global__ __launch_bounds__(256) void k_inlier_mask_lmed(int est, int nprob, co
   if (threadIdx.x < kStride) m[threadIdx.x] = best_models[(size_t)p * kStride + threadIdx.x];
   __syncthreads();
   int cnt;
-  lmed_block(est, m, data + (size_t)offsets[p] * ds, n, ds, sample_size(est), sdata, hist, sel, &cnt, mask + offsets[p]);
+  lmed_block(est, m, data + (size_t)offsets[p] * ds, n, ds, sample_size(est), in_lds ? sdata : nullptr, hist, sel, &cnt, mask + offsets[p]);
 }
 
 // LO under LMED: the inliers RefineModel sees are the quality measurement's own (r^2 < its median-derived bound): the bound of
 // every LO event's model, for k_lo_gather
 __global__ __launch_bounds__(256) void k_lo_lmed_bound(int est, const int* __restrict__ ev_prob, const int64_t* __restrict__ offsets,
                                                        const double* __restrict__ data, const double* __restrict__ ev_model,
-                                                       double* __restrict__ ev_sqt) {
+                                                       double* __restrict__ ev_sqt, int in_lds) {
   extern __shared__ __attribute__((aligned(16))) double sdata[];
   __shared__ int hist[256], sel[4];
   __shared__ double m[kStride];
@@ -495,7 +504,7 @@ __global__ __launch_bounds__(256) void k_lo_lmed_bound(int est, const int* __res
   if (threadIdx.x < kStride) m[threadIdx.x] = ev_model[(size_t)e * kStride + threadIdx.x];
   __syncthreads();
   int cnt;
-  lmed_block(est, m, data + (size_t)offsets[p] * ds, n, ds, sample_size(est), sdata, hist, sel, &cnt, nullptr, ev_sqt + e);
+  lmed_block(est, m, data + (size_t)offsets[p] * ds, n, ds, sample_size(est), in_lds ? sdata : nullptr, hist, sel, &cnt, nullptr, ev_sqt + e);
 }
 
 // final pass: refit the winning hypothesis (deterministic -> identical model)
@@ -1520,10 +1529,12 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
                                                              // counts twice: the next chunk's first round is drawn while the GPU works)
   HBuf<double> h_cost;
   HBuf<int> h_hyp_base, h_prefix;   // per hypothesis: first model in its problem's dense order; per problem: first packed score
-  const size_t lmed_lds = (size_t)nmax * sizeof(double);
+  size_t lmed_lds = (size_t)nmax * sizeof(double);
+  int lmed_in_lds = 1;
   if (lmed) {
-    // the squared residuals of a model stay in LDS for the radix select: 160 KB per workgroup on gfx950, 8 KB kept for the rest
-    if (lmed_lds > 152 * 1024) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "LMED: more than 19456 data per problem (LDS-resident select)");
+    // the squared residuals of a model stay in LDS for the radix select: 160 KB per workgroup on gfx950, 8 KB kept for the rest;
+    // beyond that (more than 19 456 data in a problem) the passes of the select re-evaluate them (lmed_sq)
+    if (lmed_lds > 152 * 1024) { lmed_lds = 0; lmed_in_lds = 0; }
     if (lmed_lds > 48 * 1024) {
       HIP_TRYR(hipFuncSetAttribute((const void*)k_score_lmed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lmed_lds));
       HIP_TRYR(hipFuncSetAttribute((const void*)k_inlier_mask_lmed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lmed_lds));
@@ -1625,7 +1636,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
                                                  d_cur_models.p, d_ev_model.p, d_ev_cam.p, ep);
     if (lmed) {
       if ((rc2 = d_ev_sqt.ensure(nev))) return rc2;
-      k_lo_lmed_bound<<<nev, 256, lmed_lds, st>>>(est, d_ev_prob.p, d_off.p, d_data.p, d_ev_model.p, d_ev_sqt.p);
+      k_lo_lmed_bound<<<nev, 256, lmed_lds, st>>>(est, d_ev_prob.p, d_off.p, d_data.p, d_ev_model.p, d_ev_sqt.p, lmed_in_lds);
     }
     k_lo_gather<<<nev, 64, 0, st>>>(est, d_ev_prob.p, d_off.p, d_data.p, d_ev_model.p, P.error_thresh, lmed ? d_ev_sqt.p : nullptr, d_ev_off.p, d_ev_count.p,
                                     reinterpret_cast<double2*>(d_lo_uv.p), reinterpret_cast<double4*>(d_lo_X.p));
@@ -1816,7 +1827,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       HIP_TRYR(hipEventRecord(evm, st));
       if (lmed) {
         dim3 grid(B * kMaxModels, cn);
-        k_score_lmed<<<grid, 256, lmed_lds, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_models.p, d_dense.p, d_tags.p, d_cost.p, d_ninl.p);
+        k_score_lmed<<<grid, 256, lmed_lds, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_models.p, d_dense.p, d_tags.p, d_cost.p, d_ninl.p, lmed_in_lds);
       } else {
 #define THIP_SCORE(L, E, BYTES) k_score<L, E><<<dim3((B * kMaxModels + score_threads(E) - 1) / score_threads(E), cn), score_threads(E), BYTES, st>>>(est, cn, B, d_off.p + c0, d_data.p, d_models.p, d_dense.p, d_tags.p, P.error_thresh, P.use_mle, d_cost.p, d_ninl.p)
         if (use_lds) {
@@ -1992,7 +2003,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     k_select_models<<<(nprob + 63) / 64, 64, 0, st>>>(nprob, d_ev_slot.p, d_cur_models.p, d_best_models.p);
   }
   if (lmed) {
-    k_inlier_mask_lmed<<<nprob, 256, lmed_lds, st>>>(est, nprob, d_off.p, d_data.p, d_best_models.p, d_mask.p);
+    k_inlier_mask_lmed<<<nprob, 256, lmed_lds, st>>>(est, nprob, d_off.p, d_data.p, d_best_models.p, d_mask.p, lmed_in_lds);
   } else {
     dim3 grid((nmax + 255) / 256, nprob);
     k_inlier_mask<<<grid, 256, 0, st>>>(est, nprob, d_off.p, d_data.p, d_best_models.p, P.error_thresh, d_mask.p);

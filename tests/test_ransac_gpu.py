@@ -241,10 +241,13 @@ def test_lo_ransac_relative_pose_follows_oracle():
     assert moved >= 8 and res["num_lo_iterations"].sum() > 10
 
 
-@pytest.mark.parametrize("est,kind,n", [(0, "relative", 400), (2, "absolute", 301), (1, "relative", 64), (2, "absolute", 12001)])   # 12001: residuals beyond 64 KB of LDS
+@pytest.mark.parametrize("est,kind,n", [(0, "relative", 400), (2, "absolute", 301), (1, "relative", 64), (2, "absolute", 12001),   # 12001: residuals beyond 64 KB of LDS
+                                        (2, "absolute", 25001), (0, "relative", 19458)])   # beyond what the LDS holds: the select re-evaluates the residuals per pass
 def test_lmed_inlier_sets_bit_identical_to_oracle(est, kind, n):
     """RansacType::LMED (lmed.h:64-70): median-of-squared-residuals cost by an exact radix select, the
-    reference's even / odd median rule, inliers from the 2.5 * 1.4826 * (1 + 5/(n-m)) * sqrt(median) threshold."""
+    reference's even / odd median rule, inliers from the 2.5 * 1.4826 * (1 + 5/(n-m)) * sqrt(median) threshold.
+    No size limit (lmed_quality_measurement.h:56-63): up to 19 456 data the squared residuals of a model stay in LDS, beyond
+    that every pass of the select evaluates them again."""
     npairs = 8 if n < 5000 else 2
     data, offsets, truth = synth.synth_ransac_v1(npairs, n, kind, seed=0x5AC50900 + est, inlier_lo=0.6, inlier_hi=0.9)
     p = ransac.RansacParameters(); p.error_thresh = THR[est]; p.seed = 71; p.ransac_type = ransac.RansacType.LMED
