@@ -3067,12 +3067,11 @@ int theia_hip_ba_covariance(theia_ba_handle h, double* point_cov, double* cam_co
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
   release_stage_if_idle(h);
   if (!point_cov && !cam_cov) return 0;
-  // Optimised intrinsics couple the cameras of a group: J'J of the views problem is an arrow, not block diagonal, and the
-  // extrinsics blocks of its inverse need the whole factor (dense, on the host: a *WithCov call covers a handful of views).
-  constexpr int kMaxCovWithIntrinsics = 2048;
-  if (h->ni && point_cov) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "point covariances with optimised intrinsics are not built");
-  if (h->ni && h->n > kMaxCovWithIntrinsics)
-    return set_error(THEIA_HIP_ERR_UNSUPPORTED, "camera covariances with optimised intrinsics: reduced system of %d > %d columns", h->n, kMaxCovWithIntrinsics);
+  // Optimised intrinsics couple the cameras of a group: J'J of the views problem is an arrow per group, not block diagonal
+  // (handled below by the arrow's Schur complement, linear in the number of cameras).
+  // (point covariances on a handle with optimised intrinsics: not a case the reference can produce -- BundleAdjustTrack(s)
+  // holds every camera constant and with them the intrinsics groups, bundle_adjuster.cc:204-212 -- refused)
+  if (h->ni && point_cov) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "point covariances with optimised intrinsics: BundleAdjustTrack(s) keeps all intrinsics constant (bundle_adjuster.cc:204-212)");
   bool any_var_point = false;
   for (int q = 0; q < h->np; ++q) any_var_point |= !h->pt_const[q];
   if (point_cov && h->ncv > 0)
@@ -3112,38 +3111,96 @@ int theia_hip_ba_covariance(theia_ba_handle h, double* point_cov, double* cam_co
     HIP_TRY(hipStreamSynchronize(h->stream));
     std::fill(cam_cov, cam_cov + 36 * (size_t)h->nc, 0.0);
     if (h->ni) {
-      // (J'J)^-1 through the dense Cholesky factor of the lower triangle: Li = L^-1, covariance(a, b) = sum_k Li(k, a) Li(k, b).
-      // Frozen intrinsics slots are empty rows with a tiny diagonal (clamp / radius): they decouple.
-      std::vector<double> Lf((size_t)n * n, 0.0), Li((size_t)n * n, 0.0);
-      for (int i = 0; i < n; ++i)
-        for (int j = 0; j <= i; ++j) {
-          double v = S[(size_t)i * n + j];
-          const double* li = &Lf[(size_t)i * n];
-          const double* lj = &Lf[(size_t)j * n];
-          for (int k = 0; k < j; ++k) v -= li[k] * lj[k];
-          if (i == j) {
-            if (v == 0.0 && i < h->ni && S[(size_t)i * n + i] == 0.0) v = 1.0;   // slot of a parameter outside the optimised subset: no column
-            if (!(v > 0.0)) return set_error(THEIA_HIP_ERR_INTERNAL, "J'J is rank deficient at column %d (ceres::Covariance::Compute fails)", i);
-            Lf[(size_t)i * n + i] = std::sqrt(v);
-          } else Lf[(size_t)i * n + j] = v / Lf[(size_t)j * n + j];
+      // Optimised intrinsics: with every point constant J'J is an ARROW per intrinsics group -- [G_g  B^T; B  D], D block diagonal
+      // over the group's cameras (6 x 6 each), G_g the group's 10 x 10 block -- and groups do not couple.  The extrinsics block
+      // of camera c of (J'J)^-1 is   D_c^-1 + Y_c (G_g - sum_c' B_c'^T D_c'^-1 B_c')^-1 Y_c^T,   Y_c = D_c^-1 B_c :
+      // work linear in the number of cameras, no limit on the size of the reduced system (the dense host factorisation of the
+      // earlier rounds stopped at 2048 columns).  Slots of parameters outside the optimised subset are empty rows: left out.
+      const int ni = h->ni;
+      std::vector<double> G((size_t)ni * 10);   // [group][10][10] lower triangle mirrored
+      for (int i = 0; i < ni; ++i)
+        for (int j = 0; j < 10; ++j) { const int gs = 10 * (i / 10), r = std::max(i, gs + j), q = std::min(i, gs + j); G[(size_t)i * 10 + j] = S[(size_t)r * n + q]; }
+      std::vector<int> cg((size_t)std::max(1, h->nc));
+      if (h->nc) HIP_TRY(hipMemcpy(cg.data(), h->cam_group.p, sizeof(int) * h->nc, hipMemcpyDeviceToHost));
+      auto chol_inv = [](const double* A, int m, double* Ainv) -> bool {   // inverse of an SPD m x m matrix (m <= 10), row-major
+        double L[100], Li[100];
+        for (int i = 0; i < m; ++i)
+          for (int j = 0; j <= i; ++j) {
+            double v = A[i * m + j];
+            for (int k = 0; k < j; ++k) v -= L[i * m + k] * L[j * m + k];
+            if (i == j) { if (!(v > 0.0)) return false; L[i * m + i] = std::sqrt(v); }
+            else L[i * m + j] = v / L[j * m + j];
+          }
+        for (int i = 0; i < m; ++i) {
+          for (int j = 0; j < m; ++j) Li[i * m + j] = 0.0;
+          Li[i * m + i] = 1.0 / L[i * m + i];
+          for (int j = 0; j < i; ++j) {
+            double v = 0.0;
+            for (int k = j; k < i; ++k) v -= L[i * m + k] * Li[k * m + j];
+            Li[i * m + j] = v / L[i * m + i];
+          }
         }
-      for (int j = 0; j < n; ++j) {   // column j of L^-1 by forward substitution
-        Li[(size_t)j * n + j] = 1.0 / Lf[(size_t)j * n + j];
-        for (int i = j + 1; i < n; ++i) {
-          double v = 0.0;
-          const double* li = &Lf[(size_t)i * n];
-          for (int k = j; k < i; ++k) v -= li[k] * Li[(size_t)k * n + j];
-          Li[(size_t)i * n + j] = v / li[i];
-        }
+        for (int a = 0; a < m; ++a)
+          for (int b = 0; b < m; ++b) {
+            double v = 0.0;
+            for (int k = std::max(a, b); k < m; ++k) v += Li[k * m + a] * Li[k * m + b];
+            Ainv[a * m + b] = v;
+          }
+        return true;
+      };
+      const int ngv = ni / 10;
+      // per camera: D_c^-1 and Y_c = D_c^-1 B_c (6 x 10); per group: the Schur complement onto its intrinsics
+      std::vector<double> Dinv((size_t)36 * h->nc, 0.0), Y((size_t)60 * h->nc, 0.0), SG(G);
+      for (int c = 0; c < h->nc; ++c) {
+        const int rc = h->cam_red[c];
+        if (rc < 0) continue;
+        const int o = ni + 6 * rc, gr = h->grp_red[cg[c]];
+        double D[36];
+        for (int a = 0; a < 6; ++a)
+          for (int b = 0; b < 6; ++b) D[a * 6 + b] = S[(size_t)(o + std::max(a, b)) * n + o + std::min(a, b)];
+        if (!chol_inv(D, 6, &Dinv[(size_t)36 * c])) return set_error(THEIA_HIP_ERR_INTERNAL, "camera %d: J'J is rank deficient (ceres::Covariance::Compute fails)", c);
+        if (gr < 0) continue;
+        double* Yc = &Y[(size_t)60 * c];
+        for (int a = 0; a < 6; ++a)
+          for (int k = 0; k < 10; ++k) {
+            double v = 0.0;
+            for (int b = 0; b < 6; ++b) v += Dinv[(size_t)36 * c + a * 6 + b] * S[(size_t)(o + b) * n + 10 * gr + k];
+            Yc[a * 10 + k] = v;
+          }
+        for (int k = 0; k < 10; ++k)
+          for (int l = 0; l < 10; ++l) {
+            double v = 0.0;
+            for (int a = 0; a < 6; ++a) v += S[(size_t)(o + a) * n + 10 * gr + k] * Yc[a * 10 + l];
+            SG[(size_t)(10 * gr + k) * 10 + l] -= v;
+          }
+      }
+      std::vector<double> SGinv((size_t)ni * 10, 0.0);   // [group][10][10], zero rows / columns at the empty slots
+      for (int gr = 0; gr < ngv; ++gr) {
+        int act[10], na = 0;
+        for (int k = 0; k < 10; ++k) if (G[(size_t)(10 * gr + k) * 10 + k] != 0.0) act[na++] = k;
+        if (!na) continue;
+        double A[100], Ai[100];
+        for (int a = 0; a < na; ++a)
+          for (int b = 0; b < na; ++b) A[a * na + b] = SG[(size_t)(10 * gr + act[a]) * 10 + act[b]];
+        if (!chol_inv(A, na, Ai)) return set_error(THEIA_HIP_ERR_INTERNAL, "J'J is rank deficient in intrinsics group slot %d (ceres::Covariance::Compute fails)", gr);
+        for (int a = 0; a < na; ++a)
+          for (int b = 0; b < na; ++b) SGinv[(size_t)(10 * gr + act[a]) * 10 + act[b]] = Ai[a * na + b];
       }
       for (int c = 0; c < h->nc; ++c) {
         const int rc = h->cam_red[c];
         if (rc < 0) continue;
-        const int o = h->ni + 6 * rc;
+        const int gr = h->grp_red[cg[c]];
         for (int a = 0; a < 6; ++a)
           for (int b = 0; b < 6; ++b) {
-            double v = 0.0;
-            for (int k = o + std::max(a, b); k < n; ++k) v += Li[(size_t)k * n + o + a] * Li[(size_t)k * n + o + b];
+            double v = Dinv[(size_t)36 * c + a * 6 + b];
+            if (gr >= 0) {
+              const double* Yc = &Y[(size_t)60 * c];
+              for (int k = 0; k < 10; ++k) {
+                double t = 0.0;
+                for (int l = 0; l < 10; ++l) t += SGinv[(size_t)(10 * gr + k) * 10 + l] * Yc[b * 10 + l];
+                v += Yc[a * 10 + k] * t;
+              }
+            }
             cam_cov[(size_t)c * 36 + a * 6 + b] = v;
           }
       }

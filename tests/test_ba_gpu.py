@@ -1444,6 +1444,36 @@ def test_view_covariances_with_optimised_intrinsics():
     assert np.abs(np.linalg.inv(Jb.T @ Jb) * fv - cv[views[0]]).max() > 1e-3 * np.abs(cv[views[0]]).max()
 
 
+def test_view_covariances_with_intrinsics_have_no_size_limit():
+    """VERDICT r5 missing 6: camera covariances with optimised intrinsics on a reduced system of more than 2048 columns
+    (360 views, three shared groups: 30 + 2160 columns) -- the arrow structure of J'J is inverted group by group, linear in the
+    number of cameras (bundle_adjuster.cc:660-773 has no limit).  Reference value: numpy's dense inverse of J'J from the
+    oracle's Jets."""
+    p = synth.synth_ba_v1(360, 5000, seed=72, pixel_noise=0.5, num_groups=3)
+    opts = sfm.BundleAdjustmentOptions(); opts.max_num_iterations = 6
+    opts.intrinsics_to_optimize = 0x01 | 0x10
+    rec = sfm.Reconstruction.from_flat(p)
+    views = list(range(360))
+    sv, cv, fv = sfm.BundleAdjustViewsWithCov(rec, opts, views)
+    assert sv.success and fv > 0
+    flat = sfm._flatten(rec, views, [], options=opts)
+    free = [0, 5, 6]
+    ncol = 6 * 360 + 3 * len(free)
+    JTJ = np.zeros((ncol, ncol))
+    for i in range(len(flat.obs_cam)):
+        c = int(flat.obs_cam[i]); g = int(flat.cam_group[c])
+        ok, r, Je, Ji, Jp = ol.reprojection_error(int(flat.group_model[g]), flat.cam_ext[c], flat.intrinsics[g][:7], flat.points[flat.obs_pt[i]], flat.obs_uv[i])
+        idx = np.concatenate([np.arange(6 * c, 6 * c + 6), 2160 + 3 * g + np.arange(3)])
+        Jo = np.concatenate([Je, Ji[:, free]], axis=1)
+        JTJ[np.ix_(idx, idx)] += Jo.T @ Jo
+    cov = np.linalg.inv(JTJ) * fv
+    worst = 0.0
+    for v in views:
+        ref = cov[6 * v:6 * v + 6, 6 * v:6 * v + 6]
+        worst = max(worst, np.abs(cv[v] - ref).max() / np.abs(ref).max())
+    assert worst <= 1e-6, worst
+
+
 def test_problem_cache_reuses_the_handle_on_unchanged_topology():
     """SURVEY 8(f) row 4 (problem-IR cache): BundleAdjustReconstruction twice on the same topology with different
     parameters = one theia_hip_ba_create; the cached solve equals the one-shot theia_hip_ba_solve (1e-10); an edit of
