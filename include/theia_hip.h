@@ -733,9 +733,13 @@ int theia_hip_four_point_pose_and_focal_length(int32_t num, const double* corr2d
  * row-major), translation (3), focal length, radial distortion, zero padded; num_solutions[num] = solutions that passed the
  * focal-length / distortion range tests; num_solver_solutions[num] (may be NULL) = the solver's valid_solutions BEFORE those
  * tests -- the reference's return value is `valid_solutions.size() > 0` (:287), so it can report success with empty outputs. */
+int theia_hip_four_point_focal_length_radial_distortion_ex(int32_t num, const double* corr2d3d, const double* limits,
+                                                           const double* rotation_draws, double* models, int32_t* num_solutions,
+                                                           int32_t* num_solver_solutions);
+/* the same without the trailing output: the symbol and ABI of the earlier library versions (a caller built against the
+ * six-argument declaration must not find a seven-argument function behind it) */
 int theia_hip_four_point_focal_length_radial_distortion(int32_t num, const double* corr2d3d, const double* limits,
-                                                        const double* rotation_draws, double* models, int32_t* num_solutions,
-                                                        int32_t* num_solver_solutions);
+                                                        const double* rotation_draws, double* models, int32_t* num_solutions);
 
 /* The batch entry points above keep their device workspace and the pinned host blocks of their per-round transfers in
  * process-wide caches between calls (up to 6 GiB of device memory and 2 GiB of pinned host memory); the buffers of a

@@ -100,7 +100,8 @@ struct DevProblem {
   const int* frun_stage;       // camera indices of the per-camera blocks a run stages in LDS (FusedRun::stage_off / nstage)
   const unsigned short* frun_tgt;
   const uint8_t* obs_lc;       // [nobs_main] local camera index inside the run; constant camera: 0x80 | index among the run's
-                               // constant cameras (ba_fused.hip), 0xFF with compound blocks (ba_fused_intr.hip)
+                               // constant cameras (staged in LDS behind the W local ones: slot W + (lc & 0x7f)), for every
+                               // block width (ba_fused.hip, ba_fused_intr.hip); tracks outside the runs keep 0xFF
   const uint8_t* obs_tl;       // [nobs_main] track index inside the sub-chunk
   const int* tile_trk_end;     // [ntiles] tracks of the sub-chunk up to and including this tile
   double* fpart;               // per-run partial sums

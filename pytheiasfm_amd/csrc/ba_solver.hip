@@ -26,6 +26,7 @@
 #include <condition_variable>
 #include <functional>
 #include <unistd.h>
+#include <pthread.h>
 #include <thread>
 #include <vector>
 
@@ -343,7 +344,19 @@ class HostTeam {
     return true;
   }
 };
-HostTeam& host_team() { static HostTeam* team = new HostTeam; return *team; }   // never destroyed: its threads wait for work until the process ends
+// Never destroyed: its threads wait for work until the process ends.  The child of a fork gets a FRESH team (pthread_atfork):
+// the parent's may have been inside a region at that moment -- use_ held by a thread that does not exist in the child, which
+// would leave every host pass of the child serial for good -- and none of its mutexes can be trusted; the old object is
+// abandoned, not destroyed.
+HostTeam*& host_team_slot() { static HostTeam* team = nullptr; return team; }
+HostTeam& host_team() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    host_team_slot() = new HostTeam;
+    (void)pthread_atfork(nullptr, nullptr, [] { host_team_slot() = new HostTeam; });
+  });
+  return *host_team_slot();
+}
 
 thread_local bool g_in_host_region = false;
 // fn(k) for the parts k = 0 .. nparts-1 of a fixed partition (the result must not depend on who runs which part)
@@ -748,6 +761,7 @@ int validate(const theia_ba_problem* p, const theia_ba_options* o) {
 }
 
 void fill_devproblem(theia_ba_handle_s* h) {
+  h->camrot_valid = false;   // whoever rebuilds the device view may have touched cam[] / the scales: the next linearisation runs k_cam_prep
   DevProblem& P = h->P;
   P.nc = h->nc; P.np = h->np; P.ncv = h->ncv; P.ntiles = h->ntiles_main; P.nobs = h->nobs_main;
   P.n = h->n; P.pd = h->pd; P.loss_type = h->opt.loss_function_type; P.loss_width = h->opt.robust_loss_width;
@@ -1573,11 +1587,11 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
   std::vector<uint8_t> cam_local((size_t)std::max(1, h->ncp), 0);   // camera -> index in the closing run's sorted table
   // CONSTANT cameras the open run's tracks see (the fused kernels stage their blocks in LDS behind the local cameras'), in order
   // of appearance: obs_lc = 0x80 | index
-  const bool stage_const = true;
   const int max_const = bw == 0 ? kFusedMaxConst : kFusedMaxConstIntr;
+  static_assert(kFusedMaxConst <= 0x7f && kFusedMaxConstIntr <= 0x7f, "obs_lc keeps the constant-camera index in seven bits");
   std::vector<int> run_ccams, tcc;
-  std::vector<int> ccam_stamp(stage_const ? (size_t)std::max(1, h->nc) : 1, 0);
-  std::vector<uint8_t> ccam_local(stage_const ? (size_t)std::max(1, h->nc) : 1, 0);
+  std::vector<int> ccam_stamp((size_t)std::max(1, h->nc), 0);
+  std::vector<uint8_t> ccam_local((size_t)std::max(1, h->nc), 0);
   constexpr int kPairSlots = 2048;     // > 4 x 253
   std::vector<int64_t> pair_key(kPairSlots, 0);
   std::vector<int> pair_stamp(kPairSlots, 0);
@@ -1630,16 +1644,14 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
     r.gp = G | ((G == 1 ? std::max(1, packing((size_t)r.ntgt, (size_t)r.W)) : 1) << 8);
     r.part_off = (int)fp.part_doubles;
     fp.part_doubles += (size_t)r.ntgt * part_tgt + (size_t)r.W * part_cam;
-    r.stage_off = (int)fp.stage.size(); r.nstage = 0;
-    if (stage_const) {
-      for (int pc : run_cams) fp.stage.push_back(h->part_cam[pc]);
-      fp.stage.insert(fp.stage.end(), run_ccams.begin(), run_ccams.end());
-      r.nstage = (int)(run_cams.size() + run_ccams.size());
-    }
+    r.stage_off = (int)fp.stage.size();
+    for (int pc : run_cams) fp.stage.push_back(h->part_cam[pc]);
+    fp.stage.insert(fp.stage.end(), run_ccams.begin(), run_ccams.end());
+    r.nstage = (int)(run_cams.size() + run_ccams.size());
     for (int t = run_tile0; t < run_tile0 + run_ntiles; ++t)
       for (int s = tstart[t]; s < tstart[t] + tcount[t]; ++s) {
         if (sred[s] >= 0) obs_lc[s] = cam_local[sred[s]];
-        else if (stage_const) obs_lc[s] = (uint8_t)(0x80 | ccam_local[ocam[s]]);
+        else obs_lc[s] = (uint8_t)(0x80 | ccam_local[ocam[s]]);
       }
     fp.runs.push_back(r);
     run_tile0 += run_ntiles; run_ntiles = 0; run_obs = 0; run_key0 = -1;
@@ -1659,7 +1671,7 @@ void build_fused_segment(const theia_ba_handle_s* h, const std::vector<int64_t>&
     tc.clear(); tcc.clear();
     for (int64_t s = off[q]; s < off[q + 1]; ++s) {
       if (sred[s] >= 0) tc.push_back(sred[s]);
-      else if (stage_const) tcc.push_back(ocam[s]);
+      else tcc.push_back(ocam[s]);
     }
     std::sort(tc.begin(), tc.end());
     const bool dup = std::adjacent_find(tc.begin(), tc.end()) != tc.end();
@@ -2588,6 +2600,7 @@ int theia_hip_ba_set_shard(theia_ba_handle h, int32_t rank, int32_t world_size) 
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
   if (world_size < 1 || rank < 0 || rank >= world_size) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "rank / world_size out of range");
   h->shard_rank = rank; h->shard_world = world_size;
+  h->have_scale = false; h->camrot_valid = false;   // the Jacobi scales are all-reduced over the new geometry: recomputed, and the camera blocks with them
   return 0;
 }
 

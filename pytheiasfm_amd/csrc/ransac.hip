@@ -2111,7 +2111,13 @@ int theia_hip_four_point_pose_and_focal_length(int32_t num, const double* corr2d
 }
 
 int theia_hip_four_point_focal_length_radial_distortion(int32_t num, const double* corr2d3d, const double* limits, const double* rotation_draws,
-                                                        double* models, int32_t* num_solutions, int32_t* num_solver_solutions) {
+                                                        double* models, int32_t* num_solutions) {
+  // (the six-argument form of rounds 1 - 4 keeps its symbol and its ABI; the solver's pre-filter count is the _ex form's)
+  return theia_hip_four_point_focal_length_radial_distortion_ex(num, corr2d3d, limits, rotation_draws, models, num_solutions, nullptr);
+}
+
+int theia_hip_four_point_focal_length_radial_distortion_ex(int32_t num, const double* corr2d3d, const double* limits, const double* rotation_draws,
+                                                           double* models, int32_t* num_solutions, int32_t* num_solver_solutions) {
   if (num < 0 || !limits || (num > 0 && (!corr2d3d || !models || !num_solutions))) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
   if (!(limits[1] >= 0.0 && limits[0] >= 0.0 && limits[0] >= limits[1] && limits[2] <= 0.0 && limits[3] <= 0.0 && limits[2] <= limits[3]))
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "P4Pfr: needs 0 <= min focal length <= max focal length and max distortion <= min distortion <= 0");

@@ -113,7 +113,7 @@ def _sig():
                                         capi.c_double_p, capi.c_double_p, capi.c_int32_p]
         L.theia_hip_dls_macaulay_terms.argtypes = [C.c_int64, C.c_int64, capi.c_double_p]
         L.theia_hip_four_point_pose_and_focal_length.argtypes = [C.c_int32, capi.c_double_p, capi.c_double_p, capi.c_int32_p]
-        L.theia_hip_four_point_focal_length_radial_distortion.argtypes = [C.c_int32, capi.c_double_p, capi.c_double_p, capi.c_double_p,
+        L.theia_hip_four_point_focal_length_radial_distortion_ex.argtypes = [C.c_int32, capi.c_double_p, capi.c_double_p, capi.c_double_p,
                                                                           capi.c_double_p, capi.c_int32_p, capi.c_int32_p]
         L.theia_hip_dls_macaulay_terms.restype = None
         L.theia_ransac_params_default.argtypes = [C.POINTER(capi.RansacParams)]
@@ -600,7 +600,8 @@ def FourPointsPoseFocalLengthRadialDistortion(feature_vectors, world_points, met
     """pose_wrapper.cc:189-215 / four_point_focal_length_radial_distortion.cc:68-288 (P4Pfr, four 2D-3D correspondences per problem;
     batched when the inputs carry a leading batch dimension): (success, rotations, translations, radial distortions, focal lengths);
     success is the reference's `valid_solutions.size() > 0` -- the solver's count BEFORE the focal-length / distortion range tests
-    (:287), so it can be True with empty lists.  Batched: (num_solutions after the tests, models).
+    (:287), so it can be True with empty lists.  Batched: (num_solutions after the tests, models, solver counts before the
+    tests: success[i] = counts[i] > 0).
     rotation_draws: the three RandDouble(-0.5, 0.5) of every call ((num, 3)); None = the calls of a fresh process in order."""
     a = np.asarray(feature_vectors, dtype=np.float64); b = np.asarray(world_points, dtype=np.float64)
     single = a.ndim == 2
@@ -611,14 +612,14 @@ def FourPointsPoseFocalLengthRadialDistortion(feature_vectors, world_points, met
     lim = np.ascontiguousarray(meta_data.limits(), dtype=np.float64)
     rd = None if rotation_draws is None else np.ascontiguousarray(np.asarray(rotation_draws, dtype=np.float64).reshape(num, 3))
     M = np.zeros((num, 13, 14)); ns = np.zeros(num, dtype=np.int32); nsolver = np.zeros(num, dtype=np.int32)
-    capi.check(_sig().theia_hip_four_point_focal_length_radial_distortion(num, capi.ptr(corr, C.c_double), capi.ptr(lim, C.c_double),
+    capi.check(_sig().theia_hip_four_point_focal_length_radial_distortion_ex(num, capi.ptr(corr, C.c_double), capi.ptr(lim, C.c_double),
                                                                            None if rd is None else capi.ptr(rd, C.c_double),
                                                                            capi.ptr(M, C.c_double), capi.ptr(ns, C.c_int32), capi.ptr(nsolver, C.c_int32)))
     if single:
         k = int(ns[0])
         # success = the solver found solutions, whether or not any passed the range tests (:287: valid_solutions.size() > 0)
         return bool(nsolver[0] > 0), [M[0, j, :9].reshape(3, 3) for j in range(k)], [M[0, j, 9:12] for j in range(k)], [M[0, j, 13] for j in range(k)], [M[0, j, 12] for j in range(k)]
-    return ns, M
+    return ns, M, nsolver
 
 
 def FivePointRelativePose(image1_points, image2_points):

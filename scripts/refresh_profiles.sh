@@ -48,7 +48,8 @@ import hashlib, json, os, sys
 R = sys.argv[1]
 files = ["pytheiasfm_amd/csrc/ba_fused.hip", "pytheiasfm_amd/csrc/ba_fused_intr.hip", "pytheiasfm_amd/csrc/ba_lane.h", "pytheiasfm_amd/csrc/ba_device.h",
          "pytheiasfm_amd/csrc/sparse_cholesky.hip", "pytheiasfm_amd/csrc/cholesky_device.h", "pytheiasfm_amd/csrc/ba_kernels.h",
-         "pytheiasfm_amd/csrc/ba_solver.hip"]
+         "pytheiasfm_amd/csrc/ba_solver.hip", "pytheiasfm_amd/csrc/ba_fused_lin.h", "pytheiasfm_amd/csrc/ba_kernels.hip",
+         "pytheiasfm_amd/csrc/ba_priors.h", "pytheiasfm_amd/csrc/ba_inner.hip"]
 print(json.dumps({f: hashlib.sha256(open(os.path.join(R, f), "rb").read()).hexdigest()[:16] for f in files}))
 PY
 tail -c 300 "$OUT/bench.err"

@@ -10,7 +10,7 @@ num = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 F, W = T._minimal_problems(num, 2024)
 draws = np.random.default_rng(7).uniform(-0.5, 0.5, (num, 3))
 meta = ransac.RadialDistUncalibratedAbsolutePoseMetaData(min_focal_length=0.0, max_focal_length=1e5, min_radial_distortion=0.0, max_radial_distortion=-1.0)
-ns, M = ransac.FourPointsPoseFocalLengthRadialDistortion(F, W, meta, rotation_draws=draws)
+ns, M, _ = ransac.FourPointsPoseFocalLengthRadialDistortion(F, W, meta, rotation_draws=draws)
 bad = 0
 for i in range(num):
     o = ol.p4pfr_solve(F[i], W[i], draws[i], meta.limits())

@@ -32,7 +32,7 @@ def test_direct_solver_equals_the_oracle_bit_for_bit():
     draws = np.random.default_rng(3).uniform(-0.5, 0.5, (num, 3))
     meta = ransac.RadialDistUncalibratedAbsolutePoseMetaData(min_focal_length=0.0, max_focal_length=1e5, min_radial_distortion=0.0,
                                                              max_radial_distortion=-1.0)
-    ns, M = ransac.FourPointsPoseFocalLengthRadialDistortion(F, W, meta, rotation_draws=draws)
+    ns, M, nsolver = ransac.FourPointsPoseFocalLengthRadialDistortion(F, W, meta, rotation_draws=draws)
     total = 0
     for i in range(num):
         o = ol.p4pfr_solve(F[i], W[i], draws[i], meta.limits())
@@ -40,9 +40,10 @@ def test_direct_solver_equals_the_oracle_bit_for_bit():
         assert np.array_equal(o, M[i, :ns[i]]), i
         total += ns[i]
     assert total > 2 * num     # several real solutions per problem
+    assert np.all(nsolver >= ns)                                     # the range tests only remove solutions
     # rotation_draws = None: the draws of the first calls of a fresh process (std::mt19937(42))
     d42 = ol.mt_randdouble_stream(42, 3 * 50, -0.5, 0.5).reshape(50, 3)
-    ns2, M2 = ransac.FourPointsPoseFocalLengthRadialDistortion(F[:50], W[:50], meta)
+    ns2, M2, _ = ransac.FourPointsPoseFocalLengthRadialDistortion(F[:50], W[:50], meta)
     for i in range(50):
         assert np.array_equal(ol.p4pfr_solve(F[i], W[i], d42[i], meta.limits()), M2[i, :ns2[i]]), i
 
@@ -70,8 +71,8 @@ def test_success_counts_the_solver_solutions_before_the_range_tests():
     assert ok and len(Rs) > 0
     ok2, Rs2, ts2, ks2, fs2 = ransac.FourPointsPoseFocalLengthRadialDistortion(f, W, none)
     assert ok2 and Rs2 == [] and ts2 == [] and ks2 == [] and fs2 == []
-    ns, M = ransac.FourPointsPoseFocalLengthRadialDistortion(f[None], W[None], none)
-    assert int(ns[0]) == 0 and not M.any()
+    ns, M, nsol = ransac.FourPointsPoseFocalLengthRadialDistortion(f[None], W[None], none)
+    assert int(ns[0]) == 0 and not M.any() and int(nsol[0]) > 0     # the batched form carries the reference's success flag too
 
 
 def _batch(nprob, seed, ratio=0.75, noise=0.5):
