@@ -415,25 +415,18 @@ __global__ __launch_bounds__(64 * TPS, THIP_FUSED_WAVES) void k_lin_schur(DevPro
 #pragma unroll
     for (int q = 0; q < 18; ++q) scratch[tid * 18 + q] = acc[18 * h + q];
     __syncthreads();
-    if (has_tgt && tid == tix) {   // the first replica of the target adds the others, in slice order
-      double v[18];
-#pragma unroll
-      for (int q = 0; q < 18; ++q) v[q] = scratch[tid * 18 + q];
+    // every ENTRY (target, q) of the half blocks is summed over the target's replicas, in slice order (the order, and so the
+    // bits, of the one-lane-per-target loop this replaces: that left ntgt of the 256 lanes adding nrep - 1 rows of 18 each),
+    // and leaves for the partial-sum buffer at once: consecutive threads on consecutive doubles of a 144-B half block
+    for (int e = tid; e < run.ntgt * 18; e += SUB) {
+      const int k = e / 18, q = e - 18 * k;
+      double v = scratch[k * 18 + q];   // (replica 0 of target k is thread k)
 #pragma unroll 1
       for (int r = 1; r < nrep; ++r) {
-        const int oth = (G == 1) ? ((r / PS) * 64 + (r % PS) * B + tix) : (tix + r * G * 64);
-#pragma unroll
-        for (int q = 0; q < 18; ++q) v[q] += scratch[oth * 18 + q];
+        const int oth = (G == 1) ? ((r / PS) * 64 + (r % PS) * B + k) : (k + r * G * 64);
+        v += scratch[oth * 18 + q];
       }
-#pragma unroll
-      for (int q = 0; q < 18; ++q) scratch[tid * 18 + q] = v[q];   // back into its own row (tid == tix: rows [0, ntgt) are the sums)
-    }
-    __syncthreads();
-    // the half blocks leave as 16-B pieces, consecutive threads on consecutive pieces of a 144-B half block (every lane
-    // storing its own 18 doubles 8 bytes at a time made 36 store instructions of 64 scattered words each)
-    for (int e = tid; e < run.ntgt * 9; e += SUB) {
-      const int k = e / 9, q2 = e - 9 * k;
-      reinterpret_cast<double2*>(out)[(size_t)k * 18 + 9 * h + q2] = reinterpret_cast<const double2*>(scratch)[k * 9 + q2];
+      out[(size_t)k * 36 + 18 * h + q] = v;
     }
   }
   __syncthreads();

@@ -582,6 +582,11 @@ struct IdHandle {
   int upload_parameters(const theia_ba_problem* p);
   int run(const theia_ba_options* o, theia_ba_summary* S);
   int download(theia_ba_problem* p);
+  // theia_hip_ba_snapshot_parameters / restore_parameters: the current parameters <-> a device-side copy
+  Buf<double> snap_cam, snap_rho, snap_intr;
+  bool has_snapshot = false;
+  int snapshot();
+  int restore();
 };
 
 int IdHandle::create(const theia_ba_problem* p, const theia_ba_options* o) {
@@ -878,6 +883,26 @@ int IdHandle::run(const theia_ba_options* o, theia_ba_summary* S) {
   return 0;
 }
 
+int IdHandle::snapshot() {
+  int rc;
+  if ((rc = snap_cam.alloc((size_t)6 * std::max(1, nc))) || (rc = snap_rho.alloc((size_t)std::max(1, np))) || (rc = snap_intr.alloc((size_t)kKW * std::max(1, ng)))) return rc;
+  if (nc) HIP_TRY(hipMemcpyAsync(snap_cam.p, d_cam[cur].p, sizeof(double) * 6 * (size_t)nc, hipMemcpyDeviceToDevice, st));
+  if (np) HIP_TRY(hipMemcpyAsync(snap_rho.p, d_rho[cur].p, sizeof(double) * (size_t)np, hipMemcpyDeviceToDevice, st));
+  if (ng) HIP_TRY(hipMemcpyAsync(snap_intr.p, d_intr[cur].p, sizeof(double) * (size_t)kKW * ng, hipMemcpyDeviceToDevice, st));
+  has_snapshot = true;
+  return 0;
+}
+int IdHandle::restore() {
+  if (!has_snapshot) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "restore_parameters without a snapshot");
+  for (int k = 0; k < 2; ++k) {
+    if (nc) HIP_TRY(hipMemcpyAsync(d_cam[k].p, snap_cam.p, sizeof(double) * 6 * (size_t)nc, hipMemcpyDeviceToDevice, st));
+    if (np) HIP_TRY(hipMemcpyAsync(d_rho[k].p, snap_rho.p, sizeof(double) * (size_t)np, hipMemcpyDeviceToDevice, st));
+    if (ng) HIP_TRY(hipMemcpyAsync(d_intr[k].p, snap_intr.p, sizeof(double) * (size_t)kKW * ng, hipMemcpyDeviceToDevice, st));
+  }
+  cur = 0;
+  return 0;
+}
+
 int IdHandle::download(theia_ba_problem* p) {
   if (p->num_cameras != nc || p->num_points != np || p->num_groups != ng)
     return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "problem shape differs from the handle's");
@@ -914,5 +939,13 @@ int id_handle_reset(void* h, const theia_ba_problem* p) { return static_cast<IdH
 int id_handle_run(void* h, const theia_ba_options* o, theia_ba_summary* S) { return static_cast<IdHandle*>(h)->run(o, S); }
 int id_handle_download(void* h, theia_ba_problem* p) { return static_cast<IdHandle*>(h)->download(p); }
 void id_handle_destroy(void* h) { delete static_cast<IdHandle*>(h); }
+int id_handle_snapshot(void* h) { return static_cast<IdHandle*>(h)->snapshot(); }
+int id_handle_restore(void* h) { return static_cast<IdHandle*>(h)->restore(); }
+void id_handle_plan_info(void* h, int32_t* n, int32_t* k3_levels, double* k3_flops) {
+  IdHandle* H = static_cast<IdHandle*>(h);
+  if (n) *n = H->n;
+  if (k3_levels) *k3_levels = H->plan ? chol_plan_levels(H->plan) : 0;
+  if (k3_flops) *k3_flops = H->plan ? chol_plan_flops(H->plan) : 0.0;
+}
 
 }  // namespace thip

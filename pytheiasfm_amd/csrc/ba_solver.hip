@@ -2605,7 +2605,7 @@ int theia_hip_ba_set_shard(theia_ba_handle h, int32_t rank, int32_t world_size) 
 }
 
 int theia_hip_ba_snapshot_parameters(theia_ba_handle h) {
-  if (h && h->idh) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse-depth handle: snapshot is not built in this mode");
+  if (h && h->idh) return thip::id_handle_snapshot(h->idh);
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
   release_stage_if_idle(h);
   int rc;
@@ -2619,7 +2619,7 @@ int theia_hip_ba_snapshot_parameters(theia_ba_handle h) {
 }
 
 int theia_hip_ba_restore_parameters(theia_ba_handle h) {
-  if (h && h->idh) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse-depth handle: restore is not built in this mode");
+  if (h && h->idh) return thip::id_handle_restore(h->idh);
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
   if (!h->has_snapshot) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "no snapshot taken on this handle");
   release_stage_if_idle(h);
@@ -2738,7 +2738,12 @@ int theia_hip_ba_set_inner_global(theia_ba_handle h, const theia_ba_problem* ful
 
 int theia_hip_ba_plan_info(theia_ba_handle h, int32_t* n, int32_t* k3_levels, double* k3_flops, int32_t* fused_runs,
                            int32_t* slow_path_tracks) {
-  if (h && h->idh) return set_error(THEIA_HIP_ERR_UNSUPPORTED, "inverse-depth handle: plan info is not built in this mode");
+  if (h && h->idh) {   // (no fused runs / slow-path tracks in this mode: the per-track kernels of ba_invdepth.hip)
+    thip::id_handle_plan_info(h->idh, n, k3_levels, k3_flops);
+    if (fused_runs) *fused_runs = 0;
+    if (slow_path_tracks) *slow_path_tracks = 0;
+    return 0;
+  }
   if (!h) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "null handle");
   if (n) *n = h->n;
   if (k3_levels) *k3_levels = chol_plan_levels(h->plan);

@@ -61,4 +61,7 @@ int id_handle_reset(void* h, const theia_ba_problem* p);
 int id_handle_run(void* h, const theia_ba_options* o, theia_ba_summary* S);
 int id_handle_download(void* h, theia_ba_problem* p);
 void id_handle_destroy(void* h);
+int id_handle_snapshot(void* h);
+int id_handle_restore(void* h);
+void id_handle_plan_info(void* h, int32_t* n, int32_t* k3_levels, double* k3_flops);
 }  // namespace thip

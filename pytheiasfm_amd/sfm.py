@@ -74,7 +74,8 @@ class CameraIntrinsicsModelType(enum.IntEnum):  # camera_intrinsics_model_type.h
 class BundleAdjustmentOptions:
     """bundle_adjustment.h:87-167, same field names and defaults.  The
     linear-algebra selectors are accepted and ignored: the HIP backend is the
-    linear solver (Schur complement + dense FP64-MFMA Cholesky)."""
+    linear solver (Schur complement in the fused assembly kernels, then a tile-sparse, level-scheduled Cholesky of the
+    reduced camera system with FP64-MFMA triangular solves and updates; dense schedule where the tile graph is full)."""
 
     def __init__(self):
         self.loss_function_type = LossFunctionType.TRIVIAL

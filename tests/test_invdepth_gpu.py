@@ -179,6 +179,15 @@ def test_inverse_depth_handle_equals_the_one_shot_solve():
     h.reset(q); s6, _ = h.run(); h.download(q)
     assert s6.num_iterations == s5.num_iterations
     close(q, ref)
+    # snapshot / restore (round 6: the same handle API as the main path): restore + run reproduces the run after the snapshot
+    # (to rounding: this mode assembles the reduced system with FP64 atomics, whose order is not fixed)
+    h.reset(p); h.snapshot()
+    sa, _ = h.run(); ha = p.copy(); h.download(ha)
+    h.restore(); sb, _ = h.run(); hb = p.copy(); h.download(hb)
+    assert sa.num_iterations == sb.num_iterations and abs(sa.final_cost - sb.final_cost) <= 1e-12 * sa.final_cost
+    assert np.abs(ha.cam_ext - hb.cam_ext).max() <= 1e-10 and np.abs(ha.point_inverse_depth - hb.point_inverse_depth).max() <= 1e-10
+    info = h.plan_info()
+    assert info["n"] > 0 and info["fused_runs"] == 0
     o2 = ba.default_options(); o2.max_num_iterations = 6; o2.use_inner_iterations = 0; o2.intrinsics_to_optimize = 0; o2.prior_mask = 1
     with pytest.raises(capi.TheiaHipError):
         h.set_options(o2)                                  # structural option changed
