@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtheia_hip.so")
+LIB_PATH = os.environ.get("THEIA_HIP_LIBRARY") or os.path.join(_HERE, "libtheia_hip.so")   # (the override: development builds of the same library, scripts/dev_*.sh)
 
 THEIA_MAX_INTRINSICS = 10
 THEIA_RANSAC_MODEL_STRIDE = 24
