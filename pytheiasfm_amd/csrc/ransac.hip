@@ -382,6 +382,32 @@ __global__ __launch_bounds__(score_threads(EST)) void k_score(int est_rt, int np
       if (in) { cnt++; mle += r; }
       else mle += thresh;
     }
+  } else if (EST == THEIA_EST_ABSOLUTE_POSE_KNEIP || EST == THEIA_EST_ABSOLUTE_POSE_DLS || EST == THEIA_EST_ABSOLUTE_POSE_SQPNP) {
+    // | hnormalized(R (X - c)) - x |^2 < thresh  (estimate_calibrated_absolute_pose.cc:158-167) decided WITHOUT its two divisions
+    // wherever the margin allows: 1 / z from v_rcp_f64 + one Newton step (relative error < 2^-48: scripts/ubench/rcp_acc), the
+    // error of the squared distance computed with it bounded by  r 2^-20 + (|x / z| + |y / z|)^2 2^-60  (a cancellation in
+    // x / z - u costs absolute, not relative accuracy); inside that band -- and for an inlier whose value the MLE score adds --
+    // the reference's arithmetic runs.  Same decisions, same sums: the two divisions were ~half of this loop's instructions.
+    for (int i = 0; i < n; ++i) {
+      const double* d = pd + (size_t)i * ds;
+      const double dx = d[2] - m[9], dy = d[3] - m[10], dz = d[4] - m[11];
+      const double px = (m[0] * dx + m[1] * dy) + m[2] * dz;
+      const double py = (m[3] * dx + m[4] * dy) + m[5] * dz;
+      const double pz = (m[6] * dx + m[7] * dy) + m[8] * dz;
+      double iz = __builtin_amdgcn_rcp(pz);
+      iz = __builtin_fma(iz, __builtin_fma(-pz, iz, 1.0), iz);
+      const double qx = px * iz, qy = py * iz;
+      const double ax = qx - d[0], ay = qy - d[1];
+      const double ra = ax * ax + ay * ay;
+      const double qq = fabs(qx) + fabs(qy);
+      const double bound = ra * 0x1p-20 + (qq * qq) * 0x1p-60;
+      if (ra - bound > thresh) { mle += thresh; continue; }          // surely an outlier (an outlier's value is never used)
+      if (!use_mle && ra + bound < thresh) { cnt++; continue; }      // surely an inlier, and nobody asks for the value
+      const double ex = px / pz - d[0], ey = py / pz - d[1];
+      const double r = ex * ex + ey * ey;
+      if (r < thresh) { cnt++; mle += r; }
+      else mle += thresh;
+    }
   } else {
     for (int i = 0; i < n; ++i) {
       const double r = model_error(est, m, pd + (size_t)i * ds);
