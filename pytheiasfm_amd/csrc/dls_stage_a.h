@@ -143,7 +143,13 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
   if (pq == 0) { if (rg == prg) lu_pivot_row_out<NL, 0>(ub, a); }
   else if (pq == 1) { if (rg == prg) lu_pivot_row_out<NL, 1>(ub, a); }
   else { if (rg == prg) lu_pivot_row_out<NL, 2>(ub, a); }
-  __syncthreads();
+  // The piece of the pivot row at ub (= the columns of group g) is written by lane (g, prg) and read, in this step, by the lanes
+  // of column group g only: writer and readers are lanes of ONE wave, whose LDS operations complete in order -- a wavefront
+  // fence orders them; the workgroup barrier that stood here (round 4 - 5) made every step wait twice for its slowest wave.
+  // (Other waves read these rows in the back-substitution, many barriers later; lbuf / pinfo alternate by step parity, and a
+  // wave passes the next step's barrier only after it has consumed this step's values.)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   double l[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) l[q] = -L.lbuf[par][3 * rg + q];
