@@ -29,7 +29,7 @@ import numpy as np  # noqa: E402
 ITERS_PER_SOLVE = 8      # LM iterations per solve from the perturbed start (tolerances off: exactly this many)
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = FP64 matrix peak (half of the guide's 157.3 TF FP32 vector rate)
-PROFILE_TAG = "r5"       # committed rocprofv3 PMC passes of this command: profiles/<tag>_pmc_{fetch,write}_size.csv
+PROFILE_TAG = "r6"       # committed rocprofv3 PMC passes of this command: profiles/<tag>_pmc_{fetch,write}_size.csv
 
 
 def bench_options(ba, max_iters):
