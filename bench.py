@@ -303,6 +303,33 @@ def ransac_block(cpu_baseline, host_cores, rank=0, world=1):
     return out
 
 
+def relative_position_block(cpu_baseline):
+    """N x OptimizeRelativePositionWithKnownRotation (one per view-graph edge in the reference's global pipeline) as one launch:
+    4000 pairs x 400 correspondences, one IRLS per wavefront (csrc/relpos_irls.hip)."""
+    from pytheiasfm_amd import ba, synth
+    NP, NC = 4000, 400
+    corr, offsets, rot, truth = synth.synth_relpos_v1(NP, NC)
+    ba.optimize_relative_position_batch(offsets[:65], corr[:64 * NC], rot[:64])
+    t0 = time.perf_counter(); pos, it = ba.optimize_relative_position_batch(offsets, corr, rot); dt = time.perf_counter() - t0
+    out = {"workload": f"{NP} pairs x {NC} correspondences, noise 5e-4, IRLS to the reference's stopping rule (<= 100 iterations)",
+           "pairs_per_sec": NP / dt, "wall_s": dt, "mean_iterations": float(np.mean(it)),
+           "direction_recovered": float(np.mean(np.abs(np.sum(pos * truth, axis=1)) > 0.999)),
+           "note": "wall time of the C entry point from host arrays (upload + kernel + download)"}
+    if cpu_baseline:
+        from tests import oracle_lib as ol
+        ns = 200
+        t0 = time.perf_counter()
+        same = 0
+        for k in range(ns):
+            opos, oit = ol.optimize_relative_position(corr[offsets[k]:offsets[k + 1]], rot[k, :3], rot[k, 3:], order=1)
+            same += int(np.array_equal(opos, pos[k]) and oit == it[k])
+        dc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": ns / dc, "unit": "pairs/s", "cores": 1, "kind": "port",
+                               "sample": f"the first {ns} pairs through oracle/ransac_oracle.cpp (one thread), {dc:.1f} s"}
+        out["bit_identical_to_wave_order_oracle"] = {"pairs_equal": same, "pairs_compared": ns}
+    return out
+
+
 def self_launch(n):
     """Re-runs this command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` on a free local
     port; returns the launcher's exit code.  Rank 0 prints the one JSON line, the other ranks print nothing."""
@@ -608,6 +635,7 @@ def main():
 
     if world == 1 and not args.no_ransac:
         out["ransac"] = ransac_block(not args.no_cpu_baseline, host_cores)
+        out["relative_position_irls"] = relative_position_block(not args.no_cpu_baseline)
     elif not args.no_ransac:
         # configs[4] on N GPUs: the 10 000 pairs are dealt round robin over the ranks, no collective on the data path
         rb = ransac_block(False, host_cores, rank=rank, world=world)

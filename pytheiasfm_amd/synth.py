@@ -359,3 +359,22 @@ def synth_ransac_v1(num_problems, num_corr, kind="relative", seed=0x5AC50000, fo
     truth = {"R": R, "t": t, "position": -np.einsum("pji,pj->pi", R, t), "inlier": is_in, "ratio": ratio,
              "plane_normal": plane_n, "plane_d": plane_d}
     return np.ascontiguousarray(data), offsets, truth
+
+
+def synth_relpos_v1(npairs, ncorr, seed=0x5AC5E100, noise=5e-4):
+    """View pairs with KNOWN rotations for OptimizeRelativePositionWithKnownRotation (one call per view-graph edge in the
+    reference's global pipeline): normalised correspondences [npairs * ncorr][4], offsets, rotations [npairs][6] (angle-axis of
+    view 1 | view 2, world -> camera) and the true unit relative positions R1 (c2 - c1) / |.|."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    w = 0.3 * rng.randn(npairs, 2, 3)
+    c1 = 0.2 * rng.randn(npairs, 3); c2 = c1 + rng.randn(npairs, 3)
+    corr = np.zeros((npairs, ncorr, 4)); truth = np.zeros((npairs, 3))
+    for k in range(npairs):
+        R1 = angle_axis_to_matrix(w[k, 0]); R2 = angle_axis_to_matrix(w[k, 1])
+        X = rng.uniform(-2, 2, size=(ncorr, 3)) + R1.T @ np.array([0.0, 0.0, 6.0]) + c1[k]
+        p1 = (X - c1[k]) @ R1.T; p2 = (X - c2[k]) @ R2.T
+        corr[k, :, 0:2] = p1[:, :2] / p1[:, 2:3]; corr[k, :, 2:4] = p2[:, :2] / p2[:, 2:3]
+        t = R1 @ (c2[k] - c1[k]); truth[k] = t / np.linalg.norm(t)
+    corr += noise * rng.randn(npairs, ncorr, 4)
+    offsets = np.arange(npairs + 1, dtype=np.int64) * ncorr
+    return np.ascontiguousarray(corr.reshape(-1, 4)), offsets, np.ascontiguousarray(w.reshape(npairs, 6)), truth

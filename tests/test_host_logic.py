@@ -384,3 +384,27 @@ def test_host_thread_team_survives_a_fork():
         """ % ROOT)
     r = subprocess.run([sys.executable, "-c", code], timeout=120, capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout[-400:], r.stderr[-400:])
+
+
+def test_bench_self_launch_builds_the_torchrun_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset) re-runs itself under torch.distributed.run with one
+    process per GPU on 127.0.0.1 and a free port, the original arguments kept (bench.py: self_launch)."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+    def fake_call(cmd, env=None):
+        seen["cmd"] = cmd; seen["env"] = env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "2"])
+    assert bench.self_launch(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[:4] == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    i = cmd.index("--master-addr"); assert cmd[i + 1] == "127.0.0.1"
+    j = cmd.index("--master-port"); assert 1024 < int(cmd[j + 1]) < 65536
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "5", "--warmup", "2"] and os.path.basename(cmd[-7]) == "bench.py"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
