@@ -846,7 +846,10 @@ __global__ __launch_bounds__(64) void k_fit5_b(size_t nhyp, const int* __restric
 // ---- SQPnP fit in three stages (sqpnp_pre -> 9 x 9 SVD by teams of nine lanes in LDS -> sqpnp_post): the SVD was 77 % of
 // the one-thread-per-hypothesis kernel, whose 12.6 KB of arrays per lane lived in scratch.
 // ws per hypothesis: [Omega 81 | P 27 | centroid 3 | U 81 | S 9]
-constexpr int kSqWs = 201, kSqTeam = 9, kSqTeamsPerWave = 7;
+#ifndef THIP_SQ_TEAM
+#define THIP_SQ_TEAM 5   // lanes per 9 x 9 SVD (svd_team.h): 5 -> twelve matrices per wave; 9 (seven per wave) was rounds 3 - 5
+#endif
+constexpr int kSqWs = 201, kSqTeam = THIP_SQ_TEAM, kSqTeamsPerWave = 64 / kSqTeam;
 __global__ __launch_bounds__(64) void k_sqp_a(int nprob, int B, const int64_t* __restrict__ offsets, const double* __restrict__ data,
                                               const int* __restrict__ samples, const int* __restrict__ active_iters,
                                               double* __restrict__ ws, int* __restrict__ ok) {
@@ -880,9 +883,11 @@ __global__ __launch_bounds__(64) void k_sqp_b(size_t nhyp, const int* __restrict
   if (hyp >= nhyp || !ok[hyp]) return;
   double* W = lds[team]; double* U = W + 81; double* S = U + 81;
   double* w = ws + hyp * kSqWs;
-  rsc::svd9_team(w, W, U, S, tl);
-  for (int i = 0; i < 9; ++i) w[111 + i * 9 + tl] = U[i * 9 + tl];
-  w[192 + tl] = S[tl];
+  rsc::svd9_team<kSqTeam>(w, W, U, S, tl);
+  for (int e = tl; e < 9; e += kSqTeam) {
+    for (int i = 0; i < 9; ++i) w[111 + i * 9 + e] = U[i * 9 + e];
+    w[192 + e] = S[e];
+  }
 }
 
 __global__ __launch_bounds__(64) void k_sqp_c(int nprob, int B, const int* __restrict__ active_iters, const int* __restrict__ ok,
@@ -1046,8 +1051,8 @@ __global__ __launch_bounds__(64) void k_hom_b(size_t nhyp, int B, const int* __r
   if (hyp >= nhyp || (int)(hyp % B) >= active_iters[hyp / B]) return;
   double* W = lds[team]; double* U = W + 81; double* V = U + 81; double* S = V + 81;
   double* w = ws + hyp * kHomWs;
-  rsc::svd9_team(w, W, U, S, tl, V);
-  w[99 + tl] = V[9 * tl + 8];   // the last right singular vector
+  rsc::svd9_team<kSqTeam>(w, W, U, S, tl, V);
+  for (int e = tl; e < 9; e += kSqTeam) w[99 + e] = V[9 * e + 8];   // the last right singular vector
 }
 __global__ __launch_bounds__(64) void k_hom_c(int nprob, int B, const int* __restrict__ active_iters, const double* __restrict__ ws,
                                               double* __restrict__ models, int* __restrict__ counts, int* __restrict__ dense_count,

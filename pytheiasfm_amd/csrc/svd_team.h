@@ -19,20 +19,26 @@ namespace rsc {
 
 // A: 81 doubles (row-major, global or LDS), W / U: 81 doubles of LDS each, S: 9 doubles of LDS.  tl in [0, 9).
 // V (optional, 81 doubles of LDS): the right singular vectors, accumulated and sorted as svd_sq<9> does.
+// TEAM (round 6): lanes per matrix.  Lane tl owns the entries e = tl, tl + TEAM, .. < 9 of every row / column phase (TEAM = 9:
+// one each, the original; TEAM = 5: two, so that a wave holds twelve matrices and the rotation parameters -- seven divisions
+// and three square roots that EVERY lane of a team computes -- are shared by twelve instead of seven).
+template <int TEAM = 9>
 __device__ inline void svd9_team(const double* __restrict__ A, double* __restrict__ W, double* __restrict__ U,
                                  double* __restrict__ S, int tl, double* __restrict__ V = nullptr) {
   constexpr int N = 9;
-  for (int i = 0; i < N; ++i) {   // lane tl: column tl
-    W[i * N + tl] = A[i * N + tl];
-    U[i * N + tl] = (i == tl) ? 1.0 : 0.0;
-    if (V) V[i * N + tl] = (i == tl) ? 1.0 : 0.0;
-  }
+  for (int e = tl; e < N; e += TEAM)
+    for (int i = 0; i < N; ++i) {   // column e
+      W[i * N + e] = A[i * N + e];
+      U[i * N + e] = (i == e) ? 1.0 : 0.0;
+      if (V) V[i * N + e] = (i == e) ? 1.0 : 0.0;
+    }
   team_sync();
   double scale = 0.0;
   for (int i = 0; i < N * N; ++i) scale = fmax(scale, fabs(W[i]));
   if (scale == 0.0) scale = 1.0;
   team_sync();
-  for (int i = 0; i < N; ++i) W[i * N + tl] = W[i * N + tl] / scale;
+  for (int e = tl; e < N; e += TEAM)
+    for (int i = 0; i < N; ++i) W[i * N + e] = W[i * N + e] / scale;
   team_sync();
   const double precision = 2.0 * DBL_EPSILON;
   double maxdiag = 0.0;
@@ -58,19 +64,19 @@ __device__ inline void svd9_team(const double* __restrict__ A, double* __restric
           jacobi_rot_sym(n00, n01, n11, &jc, &js);
           const double lc = r1c * jc + r1s * js, ls = r1s * jc - r1c * js;
           team_sync();   // every lane has read the 2 x 2 block before the rows change
-          {   // rows p, q of W (entry tl) and columns p, q of U (entry tl)
-            const double a = W[p * N + tl], b = W[q * N + tl];
-            W[p * N + tl] = lc * a + ls * b; W[q * N + tl] = -ls * a + lc * b;
-            const double ua = U[tl * N + p], ub = U[tl * N + q];
-            U[tl * N + p] = lc * ua + ls * ub; U[tl * N + q] = -ls * ua + lc * ub;
+          for (int e = tl; e < N; e += TEAM) {   // rows p, q of W (entry e) and columns p, q of U (entry e)
+            const double a = W[p * N + e], b = W[q * N + e];
+            W[p * N + e] = lc * a + ls * b; W[q * N + e] = -ls * a + lc * b;
+            const double ua = U[e * N + p], ub = U[e * N + q];
+            U[e * N + p] = lc * ua + ls * ub; U[e * N + q] = -ls * ua + lc * ub;
           }
           team_sync();
-          {   // columns p, q of W (entry tl)
-            const double a = W[tl * N + p], b = W[tl * N + q];
-            W[tl * N + p] = jc * a - js * b; W[tl * N + q] = js * a + jc * b;
+          for (int e = tl; e < N; e += TEAM) {   // columns p, q of W (entry e)
+            const double a = W[e * N + p], b = W[e * N + q];
+            W[e * N + p] = jc * a - js * b; W[e * N + q] = js * a + jc * b;
             if (V) {
-              const double va = V[tl * N + p], vb = V[tl * N + q];
-              V[tl * N + p] = jc * va - js * vb; V[tl * N + q] = js * va + jc * vb;
+              const double va = V[e * N + p], vb = V[e * N + q];
+              V[e * N + p] = jc * va - js * vb; V[e * N + q] = js * va + jc * vb;
             }
           }
           team_sync();
@@ -78,10 +84,10 @@ __device__ inline void svd9_team(const double* __restrict__ A, double* __restric
         }
       }
   }
-  {   // singular values, sign into U: lane tl owns column tl here
-    const double a = W[tl * N + tl];
-    S[tl] = fabs(a);
-    if (a < 0) for (int k = 0; k < N; ++k) U[k * N + tl] = -U[k * N + tl];
+  for (int e = tl; e < N; e += TEAM) {   // singular values, sign into U: column e
+    const double a = W[e * N + e];
+    S[e] = fabs(a);
+    if (a < 0) for (int k = 0; k < N; ++k) U[k * N + e] = -U[k * N + e];
   }
   team_sync();
   for (int i = 0; i < N; ++i) {   // selection sort, descending (first maximum wins): lane tl swaps row tl of U's columns
@@ -90,12 +96,14 @@ __device__ inline void svd9_team(const double* __restrict__ A, double* __restric
     team_sync();   // every lane has chosen before S changes
     if (best != i) {
       if (tl == 0) { const double t = S[i]; S[i] = S[best]; S[best] = t; }
-      const double t = U[tl * N + i]; U[tl * N + i] = U[tl * N + best]; U[tl * N + best] = t;
-      if (V) { const double v = V[tl * N + i]; V[tl * N + i] = V[tl * N + best]; V[tl * N + best] = v; }
+      for (int e = tl; e < N; e += TEAM) {
+        const double t = U[e * N + i]; U[e * N + i] = U[e * N + best]; U[e * N + best] = t;
+        if (V) { const double v = V[e * N + i]; V[e * N + i] = V[e * N + best]; V[e * N + best] = v; }
+      }
     }
     team_sync();
   }
-  S[tl] *= scale;
+  for (int e = tl; e < N; e += TEAM) S[e] *= scale;
   team_sync();
 }
 
