@@ -741,6 +741,20 @@ int theia_hip_four_point_focal_length_radial_distortion_ex(int32_t num, const do
 int theia_hip_four_point_focal_length_radial_distortion(int32_t num, const double* corr2d3d, const double* limits,
                                                         const double* rotation_draws, double* models, int32_t* num_solutions);
 
+/* FindKNearestNeighbors of GuidedEpipolarMatcher (matching/guided_epipolar_matcher.cc:356-412), the descriptor search behind
+ * the guided_matching branch of TwoViewMatchGeometricVerification::VerifyMatches (two_view_match_geometric_verification.cc:
+ * 157-170), for all epiline groups of an image pair in one launch: group g has the query features q_idx[q_off[g] ..
+ * q_off[g+1]) of image 1 (rows of desc1 [n1][dim]) and the candidate features c_idx[c_off[g] .. c_off[g+1]) of image 2 (rows
+ * of desc2 [n2][dim]); for every query, in q order: nn_dist[2] = the two smallest squared L2 distances (float, summed over
+ * the dimensions in sequence), nn_index[2] = the candidates' feature indices (ties: the earlier candidate of the list, as the
+ * reference's partial_sort of (distance, position) pairs; -1 / FLT_MAX where the group has fewer than two candidates). */
+int theia_hip_guided_knn(int32_t num_groups, const int64_t* q_off, const int32_t* q_idx, const int64_t* c_off,
+                         const int32_t* c_idx, int32_t n1, int32_t n2, int32_t dim, const float* desc1, const float* desc2,
+                         float* nn_dist, int32_t* nn_index);
+/* n draws of RandomNumberGenerator(seed).RandInt(lo, hi) (util/random.cc:46-84): host code that follows the reference's
+ * generator outside the RANSAC sampler (the random candidates of GuidedEpipolarMatcher::FindFeaturesNearEpipolarLines). */
+int theia_hip_randint_stream(uint32_t seed, int32_t n, int32_t lo, int32_t hi, int32_t* out);
+
 /* The batch entry points above keep their device workspace and the pinned host blocks of their per-round transfers in
  * process-wide caches between calls (up to 6 GiB of device memory and 2 GiB of pinned host memory); the buffers of a
  * destroyed BA handle and the host staging of theia_hip_ba_create go to the same caches, so that a pipeline that

@@ -270,8 +270,15 @@ def _acceptable(ol, ext, intr, px, X, sq_max):
     return float(res[0] * res[0] + res[1] * res[1]) < sq_max
 
 
-def verify_matches(ol, capi, options, prior1, prior2, corr):
-    """VerifyMatches (:114-183) on pixel correspondences [(x1, y1, x2, y2)] -> (ok, info dict, verified indices)."""
+def verify_matches(ol, capi, options, prior1, prior2, corr, indexed=None):
+    """VerifyMatches (:114-183) on pixel correspondences [(x1, y1, x2, y2)] -> (ok, info dict, verified indices).
+    indexed = (keypoints1, descriptors1, keypoints2, descriptors2, matches [(feature1, feature2)]): the reference's own form of
+    the call; `corr` is then built from the matches, the guided-matching branch (:157-170) can run, and the third element of the
+    result is the list of verified (feature1, feature2) pairs."""
+    if indexed is not None:
+        kp1, ds1, kp2, ds2, mt = indexed
+        mt = [(int(a), int(b)) for a, b in mt]
+        corr = np.array([[kp1[a][0], kp1[a][1], kp2[b][0], kp2[b][1]] for a, b in mt], dtype=np.float64).reshape(-1, 4)
     corr = np.ascontiguousarray(corr, dtype=np.float64).reshape(-1, 4)
     info = {"focal_length_1": 0.0, "focal_length_2": 0.0, "rotation_2": np.zeros(3), "position_2": np.zeros(3),
             "num_verified_matches": 0, "num_homography_inliers": 0}
@@ -291,8 +298,16 @@ def verify_matches(ol, capi, options, prior1, prior2, corr):
     k1[0] = info["focal_length_1"]; k2[0] = info["focal_length_2"]
     ext1 = np.zeros(6)
     ext2 = np.concatenate([info["position_2"], info["rotation_2"]])
-    if options.guided_matching:
-        raise NotImplementedError("the guided-matching branch (:157-170) is outside this restatement")
+    tags = None
+    if indexed is not None:
+        tags = [mt[i] for i in matches]
+        if options.guided_matching:   # :157-170
+            tags = guided_epipolar_matches(ol, ext1, k1, ext2, k2, kp1, ds1, kp2, ds2, tags, options.guided_matching_max_distance_pixels,
+                                           options.guided_matching_lowes_ratio, eo.seed)
+        corr = np.array([[kp1[a][0], kp1[a][1], kp2[b][0], kp2[b][1]] for a, b in tags], dtype=np.float64).reshape(-1, 4)
+        matches = list(range(len(tags)))
+    elif options.guided_matching:
+        raise NotImplementedError("guided matching needs keypoints and descriptors (indexed form)")
     if options.bundle_adjustment and len(matches) > options.min_num_inlier_matches:
         # BundleAdjustRelativePose (:259-327) -- TriangulatePoints (:186-257)
         sq_tri = options.triangulation_max_reprojection_error ** 2
@@ -343,4 +358,151 @@ def verify_matches(ol, capi, options, prior1, prior2, corr):
         info["position_2"] = pos / math.sqrt(pos[0] * pos[0] + pos[1] * pos[1] + pos[2] * pos[2])
         info["focal_length_1"] = float(k1[0]); info["focal_length_2"] = float(k2[0])
     info["num_verified_matches"] = len(matches)
-    return len(matches) > options.min_num_inlier_matches, info, matches
+    return len(matches) > options.min_num_inlier_matches, info, (matches if tags is None else [tags[i] for i in matches])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# matching/guided_epipolar_matcher.cc (the guided_matching branch of VerifyMatches, :157-170)
+# Restated one feature / one sample point at a time.  Two orders the reference leaves to its containers are fixed here and in
+# the product (stated in DESIGN.md): the candidates of a group are searched in ASCENDING feature index (the reference walks a
+# std::unordered_set<int>; the order only breaks ties between equal float distances), and the squared descriptor distance is
+# summed over the dimensions in sequence, in float (Eigen's squaredNorm() sums in packets).  The random candidates that fill a
+# group up to 50 come from RandomNumberGenerator(seed).RandInt (the reference seeds that generator from the clock when
+# options.rng is null, as VerifyMatches leaves it: its own runs differ from each other there).
+def _projection_matrix(ext, intr):
+    """Camera::GetProjectionMatrix = K [R | -R c] (camera.cc:195-200, projection_matrix_utils.cc:50-58,119-135)."""
+    K = np.array([[intr[0], intr[2], intr[3]], [0.0, intr[0] * intr[1], intr[4]], [0.0, 0.0, 1.0]])
+    Rm = _angle_axis_to_matrix(ext[3:6])
+    P = np.zeros((3, 4))
+    P[:, :3] = Rm
+    P[:, 3] = -(Rm @ np.asarray(ext[0:3], dtype=np.float64))
+    return K @ P
+
+
+def _det4(M):
+    """4 x 4 determinant by cofactors of the first two rows against the last two (2 x 2 minors), the closed form of
+    Eigen's fixed-size determinant."""
+    def d2(a, b, c, d):
+        return a * d - b * c
+    s0 = d2(M[0][0], M[0][1], M[1][0], M[1][1]); s1 = d2(M[0][0], M[0][2], M[1][0], M[1][2]); s2 = d2(M[0][0], M[0][3], M[1][0], M[1][3])
+    s3 = d2(M[0][1], M[0][2], M[1][1], M[1][2]); s4 = d2(M[0][1], M[0][3], M[1][1], M[1][3]); s5 = d2(M[0][2], M[0][3], M[1][2], M[1][3])
+    c5 = d2(M[2][2], M[2][3], M[3][2], M[3][3]); c4 = d2(M[2][1], M[2][3], M[3][1], M[3][3]); c3 = d2(M[2][1], M[2][2], M[3][1], M[3][2])
+    c2 = d2(M[2][0], M[2][3], M[3][0], M[3][3]); c1 = d2(M[2][0], M[2][2], M[3][0], M[3][2]); c0 = d2(M[2][0], M[2][1], M[3][0], M[3][1])
+    return s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0
+
+
+def fundamental_from_projections(P_a, P_b):
+    """FundamentalMatrixFromProjectionMatrices(pmatrix1 = P_a, pmatrix2 = P_b) (fundamental_matrix_util.cc:218-237)."""
+    i1, i2 = (1, 2, 0), (2, 0, 1)
+    F = np.zeros((3, 3))
+    for r in range(3):
+        for c in range(3):
+            F[r, c] = _det4([P_b[i1[c]], P_b[i2[c]], P_a[i1[r]], P_a[i2[r]]])
+    return F
+
+
+def _grid_center(x, y, cs, ox, oy):
+    """ImageGrid::GetClosestGridCenter (guided_epipolar_matcher.cc:441-450): static_cast<int> truncates toward zero."""
+    return (int(math.floor((x - ox) / (2.0 * cs)) * 2.0 * cs + cs + ox), int(math.floor((y - oy) / (2.0 * cs)) * 2.0 * cs + cs + oy))
+
+
+def _u16(v):
+    return int(v) & 0xffff      # static_cast<uint16_t>(double) for the non-negative pixel coordinates this path sees
+
+
+def guided_epipolar_matches(ol, ext1, intr1, ext2, intr2, kp1, desc1, kp2, desc2, matches, max_distance_pixels, lowes_ratio, seed):
+    """GuidedEpipolarMatcher::GetMatches (:140-185) -> the input matches followed by the added ones [(feature1, feature2)]."""
+    matches = [(int(a), int(b)) for a, b in matches]
+    n1, n2 = len(kp1), len(kp2)
+    m1 = set(a for a, _ in matches); m2 = set(b for _, b in matches)
+    # Initialize (:92-138): four grids of cell size 2 d, offset by d in x / y / both; bounding box of the unmatched features of image 2
+    d = max_distance_pixels
+    offs = ((0.0, 0.0), (d, 0.0), (0.0, d), (d, d))
+    grids = [dict() for _ in range(4)]
+    xs, ys = [], []
+    for i in range(n2):
+        if i in m2:
+            continue
+        for j in range(4):
+            grids[j].setdefault(_grid_center(kp2[i][0], kp2[i][1], d, offs[j][0], offs[j][1]), []).append(i)
+        xs.append(kp2[i][0]); ys.append(kp2[i][1])
+    if not xs:
+        return matches
+    tl = (min(xs), min(ys)); br = (max(xs), max(ys))
+    # GroupEpipolarLines (:187-262)
+    F = fundamental_from_projections(_projection_matrix(ext2, intr2), _projection_matrix(ext1, intr1))
+    ends = []
+    for i in range(n1):
+        if i in m1:
+            continue
+        line = F @ np.array([kp1[i][0], kp1[i][1], 1.0])
+        line = line / math.sqrt(line[0] * line[0] + line[1] * line[1])
+        pts = []
+        yl = -(line[2] + line[0] * tl[0]) / line[1]
+        if tl[1] <= yl <= br[1]:
+            pts.append((tl[0], yl))
+        xt = -(line[2] + line[1] * tl[1]) / line[0]
+        if tl[0] <= xt <= br[0]:
+            pts.append((xt, tl[1]))
+        yr = -(line[2] + line[0] * br[0]) / line[1]
+        if tl[1] <= yr <= br[1]:
+            pts.append((br[0], yr))
+        xb = -(line[2] + line[1] * br[1]) / line[0]
+        if tl[0] <= xb <= br[0]:
+            pts.append((xb, br[1]))
+        if len(pts) != 2:
+            continue
+        code = (_u16(pts[0][0]) << 48) | (_u16(pts[0][1]) << 32) | (_u16(pts[1][0]) << 16) | _u16(pts[1][1])
+        ends.append((code, i))
+    ends.sort()
+    groups = []   # [endpoint0 (2), endpoint1 (2), features]
+    sq = d * d
+    for k, (code, i) in enumerate(ends):
+        e0 = np.array([float((code >> 48) & 0xffff), float((code >> 32) & 0xffff)]); e1 = np.array([float((code >> 16) & 0xffff), float(code & 0xffff)])
+        if k == 0 or float((groups[-1][0] - e0) @ (groups[-1][0] - e0)) > sq:
+            groups.append([e0.copy(), e1.copy(), []])
+        g = groups[-1]
+        g[2].append(i)
+        w = 1.0 / len(g[2])
+        g[0] = (1.0 - w) * g[0] + w * e0
+        g[1] = (1.0 - w) * g[1] + w * e1
+    # per group: candidates near the line (:264-306), two nearest neighbours (:356-412), Lowe's ratio (:163-177)
+    ratio_sq = lowes_ratio * lowes_ratio
+    need = sum(1 for _ in groups)
+    draws = ol.randint_stream(seed, [0] * (50 * need), [n2 - 1] * (50 * need)) if need else []
+    nd = 0
+    out = list(matches)
+    D1 = np.asarray(desc1, dtype=np.float32); D2 = np.asarray(desc2, dtype=np.float32)
+    for e0, e1, feats in groups:
+        diff = e1 - e0
+        num_steps = int(math.sqrt(diff[0] * diff[0] + diff[1] * diff[1]) / d)
+        cand = set()
+        if num_steps > 0:
+            delta = (e0 - e1) / float(num_steps)
+            sp = e1.copy()
+            for _ in range(num_steps):
+                sp = sp + delta
+                best, bd, bc = 0, float("inf"), None
+                for j in range(4):
+                    c = _grid_center(sp[0], sp[1], d, offs[j][0], offs[j][1])
+                    dist = (c[0] - sp[0]) ** 2 + (c[1] - sp[1]) ** 2
+                    if dist < bd:
+                        best, bd, bc = j, dist, c
+                cand.update(grids[best].get(bc, []))
+        if len(cand) < 50:
+            for _ in range(len(cand), 50):
+                cand.add(int(draws[nd])); nd += 1
+        cl = sorted(cand)
+        for q in feats:
+            best = []   # (distance, position)
+            for pos, ci in enumerate(cl):
+                acc = np.float32(0.0)
+                dv = D1[q] - D2[ci]
+                sqv = dv * dv
+                for t in range(len(sqv)):
+                    acc = np.float32(acc + sqv[t])
+                best.append((float(acc), pos))
+            best.sort()
+            if len(best) >= 2 and best[0][0] < best[1][0] * ratio_sq:
+                out.append((q, cl[best[0][1]]))
+    return out

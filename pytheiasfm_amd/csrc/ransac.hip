@@ -2141,6 +2141,16 @@ int theia_hip_four_point_pose_and_focal_length(int32_t num, const double* corr2d
   return 0;
 }
 
+// n draws of RandomNumberGenerator(seed).RandInt(lo, hi) (util/random.cc:46-84: std::mt19937 + uniform_int_distribution<int>), for
+// host code that has to follow the reference's generator outside the sampler (the random candidates of the guided matcher)
+int theia_hip_randint_stream(uint32_t seed, int32_t n, int32_t lo, int32_t hi, int32_t* out) {
+  if (n < 0 || hi < lo || (n > 0 && !out)) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+  Mt19937 g;
+  g.seed(seed);
+  for (int i = 0; i < n; ++i) out[i] = g.rand_int(lo, hi);
+  return 0;
+}
+
 int theia_hip_four_point_focal_length_radial_distortion(int32_t num, const double* corr2d3d, const double* limits, const double* rotation_draws,
                                                         double* models, int32_t* num_solutions) {
   // (the six-argument form of rounds 1 - 4 keeps its symbol and its ABI; the solver's pre-filter count is the _ex form's)

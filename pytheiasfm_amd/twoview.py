@@ -289,6 +289,8 @@ class TwoViewMatchGeometricVerificationOptions:  # two_view_match_geometric_veri
         self.estimate_twoview_info_options = EstimateTwoViewInfoOptions()
         self.min_num_inlier_matches = 30
         self.guided_matching = False
+        self.guided_matching_max_distance_pixels = 2.0
+        self.guided_matching_lowes_ratio = float(np.float32(0.8))   # a float in the reference
         self.bundle_adjustment = True
         self.triangulation_max_reprojection_error = 15.0
         self.min_triangulation_angle_degrees = 4.0
@@ -369,16 +371,156 @@ def _per_view_reprojection_batch(cams_list, corr_list, pts_list):
     return out
 
 
-def VerifyMatchesBatch(options, priors1, priors2, correspondences_list):
+# ------------------------------------------------------------------------------------------------
+# Guided matching (matching/guided_epipolar_matcher.cc), the optional step of VerifyMatches between the two-view geometry and
+# the two-view BA.  Host side: epipolar lines, their grouping and the grid walk (a few thousand elements per pair); the
+# descriptor search of all groups of a pair is ONE device launch (theia_hip_guided_knn, csrc/guided_knn.hip).
+class KeypointsAndDescriptors:  # matching/keypoints_and_descriptors.h (the fields this path reads)
+    def __init__(self, keypoints, descriptors):
+        self.keypoints = np.ascontiguousarray(keypoints, dtype=np.float64).reshape(-1, 2)
+        self.descriptors = np.ascontiguousarray(descriptors, dtype=np.float32).reshape(len(self.keypoints), -1)
+
+
+def _projection_matrix(cam):
+    from . import synth as _synth
+    f, ar, skew, px, py = cam["intr"][:5]
+    K = np.array([[f, skew, px], [0.0, f * ar, py], [0.0, 0.0, 1.0]])
+    R = _synth.angle_axis_to_matrix(cam["ext"][3:6])
+    return K @ np.concatenate([R, -(R @ cam["ext"][0:3])[:, None]], axis=1)
+
+
+def _fundamental_from_projections(Pa, Pb):
+    """FundamentalMatrixFromProjectionMatrices(Pa, Pb) (fundamental_matrix_util.cc:218-237): nine 4 x 4 determinants, each by
+    2 x 2 minors of its two row pairs."""
+    def minors(A, B):   # the six 2 x 2 minors of the row pair (A, B), column pairs 01 02 03 12 13 23
+        return np.array([A[0] * B[1] - A[1] * B[0], A[0] * B[2] - A[2] * B[0], A[0] * B[3] - A[3] * B[0],
+                         A[1] * B[2] - A[2] * B[1], A[1] * B[3] - A[3] * B[1], A[2] * B[3] - A[3] * B[2]])
+    i1, i2 = (1, 2, 0), (2, 0, 1)
+    F = np.zeros((3, 3))
+    for r in range(3):
+        lo = minors(Pa[i1[r]], Pa[i2[r]])
+        for c in range(3):
+            up = minors(Pb[i1[c]], Pb[i2[c]])
+            F[r, c] = up[0] * lo[5] - up[1] * lo[4] + up[2] * lo[3] + up[3] * lo[2] - up[4] * lo[1] + up[5] * lo[0]
+    return F
+
+
+def GuidedEpipolarMatches(camera1, camera2, features1, features2, matches, guided_matching_max_distance_pixels=2.0, lowes_ratio=0.8, seed=0):
+    """GuidedEpipolarMatcher(options, camera1, camera2, features1, features2).GetMatches(&matches)
+    (guided_epipolar_matcher.cc:140-185): returns the input matches [(feature1, feature2)] followed by the added ones.
+    camera = dict(ext[6], intr[>= 5], model PINHOLE).  Stated deviations: the candidates of a group are searched in ascending
+    feature index (the reference walks an unordered_set: the order only decides ties of equal distances), the descriptor
+    distance is summed in sequence in float, and the random candidates that fill a group up to 50 come from
+    RandomNumberGenerator(seed) (the reference seeds it from the clock when no generator is handed in)."""
+    import ctypes as C
+    matches = np.asarray(matches, dtype=np.int64).reshape(-1, 2)
+    kp1, kp2 = features1.keypoints, features2.keypoints
+    n1, n2 = len(kp1), len(kp2)
+    d = float(guided_matching_max_distance_pixels)
+    free2 = np.ones(n2, bool); free2[matches[:, 1]] = False
+    free1 = np.ones(n1, bool); free1[matches[:, 0]] = False
+    u2 = np.flatnonzero(free2)
+    if len(u2) == 0:
+        return [tuple(int(v) for v in m) for m in matches]
+    # the four grids (cell size 2 d; offsets 0 / d in x and y): centre of a point, features by centre
+    offs = np.array([[0.0, 0.0], [d, 0.0], [0.0, d], [d, d]])
+    def centres(pts):   # pts (M, 2) -> (M, 4, 2) int64
+        q = np.floor((pts[:, None, :] - offs[None]) / (2.0 * d)) * 2.0 * d + d + offs[None]
+        return np.trunc(q).astype(np.int64)
+    cells = {}
+    cu = centres(kp2[u2])
+    for k, i in enumerate(u2):
+        for j in range(4):
+            cells.setdefault((j, int(cu[k, j, 0]), int(cu[k, j, 1])), []).append(int(i))
+    tlx, tly = kp2[u2, 0].min(), kp2[u2, 1].min(); brx, bry = kp2[u2, 0].max(), kp2[u2, 1].max()
+    # epipolar lines of the unmatched features of image 1, their intersections with the bounding box (left, top, right, bottom)
+    F = _fundamental_from_projections(_projection_matrix(camera2), _projection_matrix(camera1))
+    u1 = np.flatnonzero(free1)
+    L = (F @ np.concatenate([kp1[u1], np.ones((len(u1), 1))], axis=1).T).T
+    L = L / np.sqrt(L[:, 0] * L[:, 0] + L[:, 1] * L[:, 1])[:, None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        yl = -(L[:, 2] + L[:, 0] * tlx) / L[:, 1]; xt = -(L[:, 2] + L[:, 1] * tly) / L[:, 0]
+        yr = -(L[:, 2] + L[:, 0] * brx) / L[:, 1]; xb = -(L[:, 2] + L[:, 1] * bry) / L[:, 0]
+    ok = np.stack([(yl >= tly) & (yl <= bry), (xt >= tlx) & (xt <= brx), (yr >= tly) & (yr <= bry), (xb >= tlx) & (xb <= brx)], axis=1)
+    px = np.stack([np.full(len(u1), tlx), xt, np.full(len(u1), brx), xb], axis=1)
+    py = np.stack([yl, np.full(len(u1), tly), yr, np.full(len(u1), bry)], axis=1)
+    two = ok.sum(1) == 2
+    sel = np.flatnonzero(two)
+    enc = np.zeros(len(sel), dtype=np.uint64)
+    for k, r in enumerate(sel):
+        a, b = np.flatnonzero(ok[r])
+        w = [int(px[r, a]) & 0xffff, int(py[r, a]) & 0xffff, int(px[r, b]) & 0xffff, int(py[r, b]) & 0xffff]
+        enc[k] = (w[0] << 48) | (w[1] << 32) | (w[2] << 16) | w[3]
+    order = np.lexsort((u1[sel], enc))
+    # groups of similar lines (a running mean of the decoded endpoints: inherently sequential)
+    groups = []
+    for k in order:
+        code = int(enc[k])
+        e0 = np.array([float((code >> 48) & 0xffff), float((code >> 32) & 0xffff)]); e1 = np.array([float((code >> 16) & 0xffff), float(code & 0xffff)])
+        if not groups or float(np.sum((groups[-1][0] - e0) ** 2)) > d * d:
+            groups.append([e0.copy(), e1.copy(), []])
+        g = groups[-1]
+        g[2].append(int(u1[sel[k]]))
+        w = 1.0 / len(g[2])
+        g[0] = (1.0 - w) * g[0] + w * e0; g[1] = (1.0 - w) * g[1] + w * e1
+    if not groups:
+        return [tuple(int(v) for v in m) for m in matches]
+    L_ = capi.lib()
+    draws = np.zeros(50 * len(groups), dtype=np.int32)
+    L_.theia_hip_randint_stream.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+    capi.check(L_.theia_hip_randint_stream(int(seed) & 0xFFFFFFFF, len(draws), 0, n2 - 1, draws.ctypes.data_as(C.POINTER(C.c_int32))))
+    nd = 0
+    q_off, c_off, q_idx, c_idx = [0], [0], [], []
+    for e0, e1, feats in groups:
+        steps = int(np.sqrt(np.sum((e1 - e0) ** 2)) / d)
+        cand = set()
+        if steps > 0:
+            delta = (e0 - e1) / float(steps)
+            pts = np.empty((steps, 2)); pt = e1.copy()
+            for k in range(steps):                                                  # the reference's running sum sample_point += line_delta
+                pt = pt + delta; pts[k] = pt
+            cc = centres(pts)
+            dist = np.sum((cc.astype(np.float64) - pts[:, None, :]) ** 2, axis=2)
+            jb = np.argmin(dist, axis=1)                                            # first minimum: the reference's strict <
+            for k in range(steps):
+                cand.update(cells.get((int(jb[k]), int(cc[k, jb[k], 0]), int(cc[k, jb[k], 1])), ()))
+        for _ in range(len(cand), 50):
+            cand.add(int(draws[nd])); nd += 1
+        cl = sorted(cand)
+        q_idx.extend(feats); c_idx.extend(cl)
+        q_off.append(len(q_idx)); c_off.append(len(c_idx))
+    q_off = np.asarray(q_off, dtype=np.int64); c_off = np.asarray(c_off, dtype=np.int64)
+    q_idx = np.asarray(q_idx, dtype=np.int32); c_idx = np.asarray(c_idx, dtype=np.int32)
+    nn_d = np.zeros((len(q_idx), 2), dtype=np.float32); nn_i = np.zeros((len(q_idx), 2), dtype=np.int32)
+    d1 = features1.descriptors; d2 = features2.descriptors
+    if d1.shape[1] != d2.shape[1]:
+        raise capi.TheiaHipError(capi.THEIA_HIP_ERR_INVALID_ARGUMENT, "descriptor dimensions differ")
+    L_.theia_hip_guided_knn.argtypes = [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int32,
+                                        C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    capi.check(L_.theia_hip_guided_knn(len(groups), q_off.ctypes.data_as(C.POINTER(C.c_int64)), q_idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       c_off.ctypes.data_as(C.POINTER(C.c_int64)), c_idx.ctypes.data_as(C.POINTER(C.c_int32)), n1, n2, d1.shape[1],
+                                       d1.ctypes.data_as(C.POINTER(C.c_float)), d2.ctypes.data_as(C.POINTER(C.c_float)),
+                                       nn_d.ctypes.data_as(C.POINTER(C.c_float)), nn_i.ctypes.data_as(C.POINTER(C.c_int32))))
+    ratio_sq = float(lowes_ratio) * float(lowes_ratio)
+    good = (nn_i[:, 1] >= 0) & (nn_d[:, 0].astype(np.float64) < nn_d[:, 1].astype(np.float64) * ratio_sq)
+    out = [tuple(int(v) for v in m) for m in matches]
+    out.extend((int(q_idx[k]), int(nn_i[k, 0])) for k in np.flatnonzero(good))
+    return out
+
+
+def VerifyMatchesBatch(options, priors1, priors2, correspondences_list, indexed=None):
     """TwoViewMatchGeometricVerification::VerifyMatches (two_view_match_geometric_verification.cc:114-183) for a list of
     image pairs given as pixel correspondences [(x1, y1, x2, y2)] (the reference indexes keypoint lists).  Returns a
     list of (success, TwoViewInfo, verified_indices).  The homography count (:331-368) and EstimateTwoViewInfo run as
     two RANSAC batches over all pairs, triangulation and the reprojection filters as device sweeps, the two-view BA of all
-    pairs as one launch (theia_hip_ba_two_views_batch).  Guided matching needs descriptors and is not built.  Stated deviation: the reference draws the
-    homography and the relative-pose samples from ONE generator in sequence; here both batches start from `seed`."""
+    pairs as one launch (theia_hip_ba_two_views_batch).  Guided matching (:157-170) needs the keypoints and descriptors of both
+    images: it runs in the indexed form (VerifyMatchesIndexedBatch: indexed = (features1, features2, matches) per pair; the
+    third element of a result is then the list of verified (feature1, feature2) pairs) and is refused here without them.
+    Stated deviation: the reference draws the homography and the relative-pose samples from ONE generator in sequence; here both
+    batches start from `seed`."""
     from . import ba as _ba
-    if options.guided_matching:
-        raise capi.TheiaHipError(capi.THEIA_HIP_ERR_UNSUPPORTED, "guided matching (descriptor search along epipolar lines) is not built")
+    if options.guided_matching and indexed is None:
+        raise capi.TheiaHipError(capi.THEIA_HIP_ERR_UNSUPPORTED, "guided matching needs keypoints and descriptors: use VerifyMatchesIndexed(Batch)")
     n = len(correspondences_list)
     corr = [np.ascontiguousarray(c, dtype=np.float64).reshape(-1, 4) for c in correspondences_list]
     results = [(False, TwoViewInfo(), []) for _ in range(n)]
@@ -402,8 +544,19 @@ def VerifyMatchesBatch(options, priors1, priors2, correspondences_list):
             results[i] = (False, info, [])
             continue
         idx = np.asarray(inliers, dtype=np.int64)
+        ci = corr[i][idx]
+        if indexed is not None:
+            # the indexed form carries (feature1, feature2) pairs instead of positions in the input list; guided matching
+            # (:157-170) appends pairs the input never held
+            f1, f2, mt = indexed[i]
+            idx = np.asarray(mt, dtype=np.int64).reshape(-1, 2)[idx]
+            if options.guided_matching:
+                cams_g = _setup_cameras(priors1[i], priors2[i], info)
+                idx = np.asarray(GuidedEpipolarMatches(cams_g[0], cams_g[1], f1, f2, idx, options.guided_matching_max_distance_pixels,
+                                                       options.guided_matching_lowes_ratio, seed=eo.seed), dtype=np.int64).reshape(-1, 2)
+                ci = np.concatenate([f1.keypoints[idx[:, 0]], f2.keypoints[idx[:, 1]]], axis=1)
         if options.bundle_adjustment and len(idx) > options.min_num_inlier_matches:
-            cand.append([i, info, idx, corr[i][idx], _setup_cameras(priors1[i], priors2[i], info)])
+            cand.append([i, info, idx, ci, _setup_cameras(priors1[i], priors2[i], info)])
             continue
         info.num_verified_matches = len(idx)
         results[i] = (len(idx) > options.min_num_inlier_matches, info, idx.tolist())
@@ -451,3 +604,21 @@ def VerifyMatchesBatch(options, priors1, priors2, correspondences_list):
 
 def VerifyMatches(options, intrinsics1, intrinsics2, correspondences):
     return VerifyMatchesBatch(options, [intrinsics1], [intrinsics2], [correspondences])[0]
+
+
+def VerifyMatchesIndexedBatch(options, priors1, priors2, features1_list, features2_list, matches_list):
+    """The reference's own form of the call: TwoViewMatchGeometricVerification(options, intrinsics1, intrinsics2, features1,
+    features2, matches).VerifyMatches(...) with KeypointsAndDescriptors and IndexedFeatureMatch lists
+    (two_view_match_geometric_verification.cc:86-183), guided matching included.  Returns per pair (success, TwoViewInfo,
+    verified (feature1, feature2) pairs)."""
+    corr, idxd = [], []
+    for f1, f2, m in zip(features1_list, features2_list, matches_list):
+        m = np.asarray(m, dtype=np.int64).reshape(-1, 2)
+        corr.append(np.concatenate([f1.keypoints[m[:, 0]], f2.keypoints[m[:, 1]]], axis=1) if len(m) else np.zeros((0, 4)))
+        idxd.append((f1, f2, m))
+    out = VerifyMatchesBatch(options, priors1, priors2, corr, indexed=idxd)
+    return [(ok, info, [tuple(int(v) for v in p) for p in pairs]) for ok, info, pairs in out]
+
+
+def VerifyMatchesIndexed(options, intrinsics1, intrinsics2, features1, features2, matches):
+    return VerifyMatchesIndexedBatch(options, [intrinsics1], [intrinsics2], [features1], [features2], [matches])[0]

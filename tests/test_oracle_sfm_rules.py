@@ -87,3 +87,28 @@ def test_midpoint_angle_and_ray_known_answers():
         Rm = R._angle_axis_to_matrix(np.array(w))
         assert np.abs(R._rotation_matrix_to_angle_axis(Rm) - np.array(w)).max() < 1e-12
     assert R.resolution_scaled_threshold(4.0, 0, 0) == 4.0 and R.resolution_scaled_threshold(4.0, 2048, 1000) == 8.0
+
+
+def test_guided_matcher_pieces_known_answers():
+    """oracle/sfm_rules.py, guided matcher: the 4 x 4 determinant, the fundamental matrix from two projection matrices (epipolar
+    constraint of projected points; maps image-1 points to image-2 lines), the grid centres (guided_epipolar_matcher.cc:441-450)."""
+    R = ol.sfm_rules()
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        M = rng.standard_normal((4, 4))
+        assert abs(R._det4(M) - np.linalg.det(M)) <= 1e-12 * max(1.0, abs(np.linalg.det(M)))
+    intr = [700.0, 1.1, 0.3, 320.0, 240.0]
+    e1 = np.array([0.1, -0.2, 0.05, 0.03, 0.02, -0.01]); e2 = np.array([1.0, 0.2, -0.1, -0.05, 0.2, 0.04])
+    P1 = R._projection_matrix(e1, intr); P2 = R._projection_matrix(e2, intr)
+    F = R.fundamental_from_projections(P2, P1)             # as GroupEpipolarLines calls it: (camera 2, camera 1)
+    for _ in range(10):
+        X = np.append(rng.uniform(-1, 1, 2), [rng.uniform(4, 8), 1.0])
+        x1 = P1 @ X; x1 /= x1[2]; x2 = P2 @ X; x2 /= x2[2]
+        line = F @ x1
+        assert abs(x2 @ line) / math.hypot(line[0], line[1]) < 1e-9       # x2 lies on the line of x1 (distance in pixels)
+    # cell size 2 d = 4, offset 0: x in [0, 4) -> centre 2, [4, 8) -> 6, negatives floor; offset d = 2: [2, 6) -> 4
+    assert R._grid_center(0.0, 3.9, 2.0, 0.0, 0.0) == (2, 2) and R._grid_center(4.0, 7.99, 2.0, 0.0, 0.0) == (6, 6)
+    assert R._grid_center(-0.5, -4.5, 2.0, 0.0, 0.0) == (-2, -6)
+    assert R._grid_center(2.0, 5.9, 2.0, 2.0, 2.0) == (4, 4) and R._grid_center(1.9, 6.0, 2.0, 2.0, 2.0) == (0, 8)
+    # a 2.5-pixel cell: centres are truncated to int as the reference's static_cast<int>
+    assert R._grid_center(6.0, 0.0, 2.5, 0.0, 0.0) == (7, 2)               # floor(6 / 5) * 5 + 2.5 = 7.5 -> 7 ; 2.5 -> 2
