@@ -3,8 +3,9 @@ restatements of two host-side rule sets of the reference that sit on either side
 mirrors batch them:
 
   * SelectGoodTracksForBundleAdjustment   (src/theia/sfm/select_good_tracks_for_bundle_adjustment.cc:79-320)
-  * TwoViewMatchGeometricVerification::VerifyMatches without the guided-matching branch
-                                          (src/theia/sfm/two_view_match_geometric_verification.cc:114-368)
+  * TwoViewMatchGeometricVerification::VerifyMatches, its guided-matching branch included
+                                          (src/theia/sfm/two_view_match_geometric_verification.cc:114-368,
+                                           src/theia/matching/guided_epipolar_matcher.cc:92-450)
 
 Both are written one element at a time in the order the reference walks (per track, per view, per match), with Python
 containers standing in for the reference's (dict = unordered_map / ImageGrid, list = vector) and the numerical pieces --
