@@ -104,3 +104,43 @@ def test_independent_numpy_route_and_conditioning():
         else:
             worst_clean = max(worst_clean, d)
     assert worst_clean < 1e-6 and worst_noisy < 5e-3, (worst_clean, worst_noisy)
+
+
+def reference_test_scene(seed, pixel_noise):
+    """The scene of the reference's own test (optimize_relative_position_with_known_rotation_test.cc:53-117,121-141): 100 points
+    with x in [-2, 2], y = -2 (its RandDouble(-2.0, -2.0)), z in [8, 10]; two cameras at random positions in [-1, 1]^3 (the second
+    normalised) with rotations 0.2 x rand, focal length 800, principal point (500, 500); pixel noise on both projections; the
+    features normalised by the calibration.  Returns (correspondences, rotation1, rotation2, true unit relative position)."""
+    rng = np.random.RandomState(seed)
+    pts = np.stack([rng.uniform(-2, 2, 100), np.full(100, -2.0), rng.uniform(8, 10, 100)], axis=1)
+    c1 = rng.uniform(-1, 1, 3); w1 = 0.2 * rng.uniform(-1, 1, 3)
+    c2 = rng.uniform(-1, 1, 3); c2 /= np.linalg.norm(c2); w2 = 0.2 * rng.uniform(-1, 1, 3)
+    R1 = synth.angle_axis_to_matrix(w1); R2 = synth.angle_axis_to_matrix(w2)
+    corr = np.zeros((100, 4))
+    for k, (R, c) in enumerate(((R1, c1), (R2, c2))):
+        p = (pts - c) @ R.T
+        px = 800.0 * p[:, :2] / p[:, 2:3] + 500.0 + pixel_noise * rng.randn(100, 2)
+        corr[:, 2 * k:2 * k + 2] = (px - 500.0) / 800.0
+    t = R1 @ (c2 - c1)
+    return corr, w1, w2, t / np.linalg.norm(t)
+
+
+def _angle_deg(a, b):
+    return np.degrees(np.arctan2(np.linalg.norm(np.cross(a, b)), a @ b))  # acos resolves 1.2e-6 degrees only
+
+
+def test_the_reference_tests_scenes_and_tolerances():
+    """NoNoise: 1e-6 degrees on every one of 40 scenes.  PixelNoise (1 px): the reference asserts 2 degrees on the ONE scene its
+    fixed seed draws; the baseline of the distribution can be as short as a tenth of the depth, where 1 px moves the direction by
+    more than that (and the planar scene has a second local minimum the IRLS can settle in), so over 40 scenes the bound is
+    asserted on the median (and 5 degrees on nine scenes of ten).  (The TranslationNoise variants perturb a start value
+    the function overwrites: :127-129.)"""
+    errs = {0.0: [], 1.0: []}
+    for noise in errs:
+        for seed in range(40):
+            corr, w1, w2, truth = reference_test_scene(5200 + seed, noise)
+            pos, _ = ol.optimize_relative_position(corr, w1, w2)
+            errs[noise].append(_angle_deg(pos, truth))
+    assert max(errs[0.0]) < 1e-6, max(errs[0.0])
+    assert np.median(errs[1.0]) < 2.0, np.median(errs[1.0])
+    assert np.mean(np.array(errs[1.0]) < 5.0) >= 0.9

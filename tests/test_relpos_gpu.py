@@ -92,3 +92,19 @@ def test_optimize_absolute_pose_on_norm_features():
         assert np.linalg.norm(pos - truth["position"][i]) < 0.02
     ok1, R1, p1 = sfm.OptimizeAbsolutePoseOnNormFeatures(c5[2], R0[2], p0[2], o)
     assert ok1 and np.array_equal(p1, out[2][2]) and np.array_equal(R1, out[2][1])
+
+
+def test_the_reference_tests_scenes_on_the_device():
+    """The scenes of optimize_relative_position_with_known_rotation_test.cc as one batch through the C entry point: NoNoise within
+    1e-6 degrees on all 40, PixelNoise within 2 degrees in the median (tests/test_relpos.py says why not on every scene), and
+    the same vectors as the oracle in the device's summation order."""
+    from tests.test_relpos import reference_test_scene, _angle_deg
+    for noise in (0.0, 1.0):
+        pairs = [reference_test_scene(5200 + seed, noise) for seed in range(40)]
+        offsets, corr, rot = _batch(pairs)
+        pos, it = ba.optimize_relative_position_batch(offsets, corr, rot)
+        err = np.array([_angle_deg(pos[k], pairs[k][3]) for k in range(40)])
+        assert (err.max() < 1e-6) if noise == 0.0 else (np.median(err) < 2.0), (noise, err.max())
+        for k in range(40):
+            want, wit = ol.optimize_relative_position(pairs[k][0], pairs[k][1], pairs[k][2], order=1)
+            assert np.array_equal(pos[k], want) and it[k] == wit, k
