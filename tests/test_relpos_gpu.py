@@ -108,3 +108,20 @@ def test_the_reference_tests_scenes_on_the_device():
         for k in range(40):
             want, wit = ol.optimize_relative_position(pairs[k][0], pairs[k][1], pairs[k][2], order=1)
             assert np.array_equal(pos[k], want) and it[k] == wit, k
+
+
+def test_relative_position_ragged_and_tiny_pairs():
+    """Pairs of 0, 1, 2 and 3 matches between ordinary ones, and an empty batch: the reference runs its loop on whatever it is given
+    (optimize_relative_position_with_known_rotation.cc:116-); the device returns the oracle's bits for every pair."""
+    pos, it = ba.optimize_relative_position_batch(np.zeros(1, np.int64), np.zeros((0, 4)), np.zeros((0, 6)))
+    assert pos.shape == (0, 3) and it.shape == (0,)
+    pairs = []
+    for k, n in enumerate((0, 150, 1, 2, 65, 3, 0, 64)):
+        c, w1, w2, _ = make_pair(7700 + k, max(n, 1))
+        pairs.append((c[:n], w1, w2))
+    offsets, corr, rot = _batch(pairs)
+    pos, it = ba.optimize_relative_position_batch(offsets, corr, rot)
+    for k, p in enumerate(pairs):
+        want, wit = ol.optimize_relative_position(p[0], p[1], p[2], order=1)
+        assert it[k] == wit, (k, it[k], wit)
+        assert np.array_equal(pos[k], want, equal_nan=True), (k, pos[k], want)
