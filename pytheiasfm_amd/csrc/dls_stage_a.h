@@ -131,6 +131,9 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
     }
   }
   __syncthreads();
+  double l[3];   // the step's factors of this lane's rows: requested with the pivot's position, used after the pivot row is out
+#pragma unroll
+  for (int q = 0; q < 3; ++q) l[q] = L.lbuf[par][3 * rg + q];
   const int pr = __builtin_amdgcn_readfirstlane(L.pinfo[par][0]), pp = __builtin_amdgcn_readfirstlane(L.pinfo[par][1]);
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
@@ -150,9 +153,8 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
   // wave passes the next step's barrier only after it has consumed this step's values.)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  double l[3];
 #pragma unroll
-  for (int q = 0; q < 3; ++q) l[q] = -L.lbuf[par][3 * rg + q];
+  for (int q = 0; q < 3; ++q) l[q] = -l[q];
   constexpr int I0 = SHIFT ? 1 : 0, D = SHIFT ? 1 : 0;
 #pragma unroll
   for (int c0 = I0; c0 < NL; c0 += 4) {   // four columns at a time: their LDS reads in flight together, no more
@@ -373,10 +375,23 @@ __device__ __forceinline__ bool stage_a(WgLds& L, int npts, const double* __rest
   int ucol[3];   // entry (pos[q], k) of the pivot-row store sits at ucol[q] + k
 #pragma unroll
   for (int q = 0; q < 3; ++q) ucol[q] = pos[q] < kBlock ? u_base(pos[q]) - 6 * (pos[q] / 6) : 0;
+  // what a step reads from LDS that does not depend on the step before it -- the pivot's row, 1 / u_kk, the three U entries of
+  // this lane's rows -- is requested one step ahead: the chain of a step is the hand-over and its FMAs only
+  int pr_n = (int)L.prow_of[kBlock - 1];
+  double inv_n = L.diag[kBlock - 1];   // 1 / u_kk, inverted once when the pivot was found
+  double u_n[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) u_n[q] = L.U[ucol[q] + kBlock - 1];
   for (int k = kBlock - 1; k >= 0; --k) {
-    const int pr = __builtin_amdgcn_readfirstlane((int)L.prow_of[k]);
+    const int pr = __builtin_amdgcn_readfirstlane(pr_n);
+    const double inv_ukk = inv_n;
+    const double u0 = u_n[0], u1 = u_n[1], u2 = u_n[2];
+    if (k > 0) {
+      pr_n = (int)L.prow_of[k - 1]; inv_n = L.diag[k - 1];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) u_n[q] = L.U[ucol[q] + k - 1];   // (in bounds for every row; used where pos[q] < k - 1)
+    }
     const int prg = pr / 3, pq = pr - 3 * prg, slot = tb.xslot[k];
-    const double inv_ukk = L.diag[k];   // 1 / u_kk, inverted once when the pivot was found
     double xq[5], x[5];
     if (pq == 0) bs_scale_row<0>(a, inv_ukk, xq); else if (pq == 1) bs_scale_row<1>(a, inv_ukk, xq); else bs_scale_row<2>(a, inv_ukk, xq);
     // the lane of row group prg hands its five values to the rest of its half-wave through LDS: writer and readers are
@@ -397,7 +412,7 @@ __device__ __forceinline__ bool stage_a(WgLds& L, int npts, const double* __rest
 #pragma unroll
     for (int q = 0; q < 3; ++q)
       if (pos[q] < k) {
-        const double u = -L.U[ucol[q] + k];
+        const double u = -(q == 0 ? u0 : (q == 1 ? u1 : u2));
 #pragma unroll
         for (int i = 0; i < 5; ++i) a[q][i] = __builtin_fma(u, x[i], a[q][i]);
       }
