@@ -84,9 +84,9 @@ void launch_dls_solve_a(int num, const int64_t* offsets, const double* feat, con
 }  // namespace thip
 
 #ifdef THIP_DLS_STAMPS
-// development: the section stamps of stage_a (dls_stage_a.h) summed since the last call; out[8]
+// development: the section stamps of stage_a (dls_stage_a.h) summed since the last call; out[16]
 extern "C" int theia_hip_debug_dls_stamps(unsigned long long* out) {
-  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long zero[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(thip::dlsdev::g_dls_stamps), sizeof(zero)) != hipSuccess) return -1;
   (void)hipMemcpyToSymbol(HIP_SYMBOL(thip::dlsdev::g_dls_stamps), zero, sizeof(zero));
   return 0;

@@ -28,6 +28,9 @@ struct WgLds {
   int pinfo[2][2];       // (row that holds the pivot, its position) by parity
   int flag;
   unsigned char prow_of[96];
+#ifdef THIP_DLS_STAMPS
+  unsigned long long st[5];
+#endif
 };
 
 // Eigen's Matrix4d::inverse() restated as adjugate over determinant (oracle/dls_oracle.h: gdls_inverse4)
@@ -80,6 +83,13 @@ __device__ __forceinline__ double dls_dpp_max16(double v) {   // all-reduce insi
   v = fmax(v, dpp_move_d<0x140>(v));   // row_mirror
   return v;
 }
+__device__ __forceinline__ unsigned dls_dpp_umax16(unsigned v) {   // all-reduce inside every row of 16 lanes
+  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true));
+  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));
+  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true));
+  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true));
+  return v;
+}
 __device__ __forceinline__ int dls_dpp_min16(int v) {
   v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
   v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
@@ -93,6 +103,14 @@ __device__ __forceinline__ int dls_dpp_min16(int v) {
 // pos[q]: position of the lane's row q in the oracle's (swapped) row order; a row pivoted at step j keeps pos = j, so
 // "still a candidate" is k <= pos < 93 (the padding rows 93..95 start at their own index and never are).
 #define THIP_DLS_FENCE() asm volatile("" ::: "memory")
+#ifdef THIP_DLS_STAMPS
+__device__ unsigned long long g_dls_stamps[16];   // [8 ..]: one elimination step, thread 0: {pivot block, barrier, row out, update, steps}
+#define DLS_STEP_T0 unsigned long long st_ = __builtin_amdgcn_s_memtime()
+#define DLS_STEP(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) L.st[k] += n_ - st_; st_ = n_; } while (0)
+#else
+#define DLS_STEP_T0 do {} while (0)
+#define DLS_STEP(k) do {} while (0)
+#endif
 // (the three instances carry different asm comments: identical blocks are merged by the compiler's code sinking into ONE
 // block that indexes a[][] by a runtime row, which sends the whole register array to scratch)
 template <int NL, int Q>
@@ -104,33 +122,61 @@ __device__ __forceinline__ void lu_pivot_row_out(double* __restrict__ ub, const 
 template <int NL, bool SHIFT>
 __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)[3], int k, int s, int g, int rg, int urow) {
   const int par = k & 1;
+  DLS_STEP_T0;
   if ((g >> 1) == (s >> 1)) {   // the wave whose half s & 1 holds column k in register 0 (the other half rides along)
-    // pivot = first maximum in POSITION order: largest |a|, then smallest position
+    // pivot = first maximum in POSITION order: largest |a|, then smallest position.  The block below is the critical path of a
+    // step -- one wave runs it while the other two wait at the barrier -- so it is written for dependent depth: no branches in
+    // the choice among a lane's three rows, the maximum of the 32 lanes as two unsigned 32-bit reductions (high word, then the
+    // low word among the lanes that hold the high maximum: |a| >= 0 orders like its bit pattern; a NaN never is a candidate,
+    // as under the comparison av > bav), the position tie-break only when two lanes hold the same |a|, and the step's four
+    // divisions side by side.
     double bv = 0.0, bav = -1.0; int bp = 1 << 20;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      const bool cand = pos[q] >= k && pos[q] < kBlock;
+      const bool cand = (pos[q] >= k) & (pos[q] < kBlock);
       const double av = fabs(a[q][0]);
-      if (cand && (av > bav || (av == bav && pos[q] < bp))) { bv = a[q][0]; bav = av; bp = pos[q]; }
+      const bool better = cand & ((av > bav) | ((av == bav) & (pos[q] < bp)));
+      bv = better ? a[q][0] : bv; bav = better ? av : bav; bp = better ? pos[q] : bp;
     }
     const int base = (s & 1) << 5;
-    const double m16 = dls_dpp_max16(bav);
-    const double gm = fmax(readlane_d(m16, base), readlane_d(m16, base + 16));
-    const int p16 = dls_dpp_min16(bav == gm ? bp : (1 << 20));
-    const int gp = min(__builtin_amdgcn_readlane(p16, base), __builtin_amdgcn_readlane(p16, base + 16));
-    const unsigned long long own = __builtin_amdgcn_ballot_w64(bp == gp && bav == gm) >> base;
-    double piv = readlane_d(bv, base + __builtin_ctz((unsigned)own));
+    const bool valid = bav >= 0.0;
+    const unsigned hi = valid ? (unsigned)__double2hiint(bav) : 0u, lo = (unsigned)__double2loint(bav);
+    const unsigned h16 = dls_dpp_umax16(hi);
+    const unsigned hm = max((unsigned)__builtin_amdgcn_readlane((int)h16, base), (unsigned)__builtin_amdgcn_readlane((int)h16, base + 16));
+    const bool top = valid & (hi == hm);
+    const unsigned l16 = dls_dpp_umax16(top ? lo : 0u);
+    const unsigned lm = max((unsigned)__builtin_amdgcn_readlane((int)l16, base), (unsigned)__builtin_amdgcn_readlane((int)l16, base + 16));
+    const bool match = top & (lo == lm);
+    unsigned own = (unsigned)(__builtin_amdgcn_ballot_w64(match) >> base);
+    if (__builtin_popcount(own) != 1) {   // the same |a| in two lanes (or no candidate that is a number): smallest position
+      const int p16 = dls_dpp_min16(match ? bp : (1 << 20));
+      const int gpt = min(__builtin_amdgcn_readlane(p16, base), __builtin_amdgcn_readlane(p16, base + 16));
+      own = (unsigned)(__builtin_amdgcn_ballot_w64(match & (bp == gpt)) >> base);
+    }
+    const int src = base + (own ? __builtin_ctz(own) : 0);
+    const int gp = __builtin_amdgcn_readlane(bp, src);
+    double piv = readlane_d(bv, src);
     if (g == s) {
-      if (piv == 0.0) { L.flag = 1; piv = 1.0; }   // singular block: the oracle gives up (no models); finish harmlessly
+      if (!(own != 0u) || piv == 0.0) { L.flag = 1; piv = 1.0; }   // singular block: the oracle gives up (no models); finish harmlessly
+      // (the four quotients over one pivot on a shared reciprocal -- the division sequence's first six instructions once, its
+      // last five per numerator, bit-identical to `/` on 2^24 operand pairs -- measured 0.6 % SLOWER than the plain divisions)
+      double qd[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) qd[q] = a[q][0] / piv;
+      const double ip = 1.0 / piv;
+      int mq = -1;
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        const bool cand = pos[q] >= k && pos[q] < kBlock, mine = cand && pos[q] == gp;
-        L.lbuf[par][3 * rg + q] = (!cand || mine) ? 0.0 : a[q][0] / piv;
-        if (mine) { L.pinfo[par][0] = 3 * rg + q; L.pinfo[par][1] = gp; L.diag[k] = 1.0 / piv; L.prow_of[k] = (unsigned char)(3 * rg + q); }
+        const bool cand = (pos[q] >= k) & (pos[q] < kBlock), mine = cand & (pos[q] == gp);
+        L.lbuf[par][3 * rg + q] = (!cand | mine) ? 0.0 : qd[q];
+        mq = mine ? q : mq;
       }
+      if (mq >= 0) { L.pinfo[par][0] = 3 * rg + mq; L.pinfo[par][1] = gp; L.diag[k] = ip; L.prow_of[k] = (unsigned char)(3 * rg + mq); }
     }
   }
+  DLS_STEP(0);
   __syncthreads();
+  DLS_STEP(1);
   double l[3];   // the step's factors of this lane's rows: requested with the pivot's position, used after the pivot row is out
 #pragma unroll
   for (int q = 0; q < 3; ++q) l[q] = L.lbuf[par][3 * rg + q];
@@ -153,6 +199,7 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
   // wave passes the next step's barrier only after it has consumed this step's values.)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  DLS_STEP(2);
 #pragma unroll
   for (int q = 0; q < 3; ++q) l[q] = -l[q];
   constexpr int I0 = SHIFT ? 1 : 0, D = SHIFT ? 1 : 0;
@@ -173,6 +220,10 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
 #pragma unroll
     for (int q = 0; q < 3; ++q) a[q][NL - 1] = 0.0;
   }
+  DLS_STEP(3);
+#ifdef THIP_DLS_STAMPS
+  if (threadIdx.x == 0) L.st[4] += 1ull;
+#endif
 }
 
 template <int NL>
@@ -194,10 +245,9 @@ __device__ __forceinline__ void bs_scale_row(const double (&a)[3][20], double in
 // Development (-DTHIP_DLS_STAMPS): s_memtime ticks of thread 0 per section of stage_a, summed over the workgroups:
 // {front end, register load, elimination, back-substitution, M00 - M01 X + stores, calls}
 #ifdef THIP_DLS_STAMPS
-__device__ unsigned long long g_dls_stamps[8];
-#define DLS_STAMP_DECL unsigned long long ds_t = __builtin_amdgcn_s_memtime(), ds_acc[5] = {0, 0, 0, 0, 0}
+#define DLS_STAMP_DECL unsigned long long ds_t = __builtin_amdgcn_s_memtime(), ds_acc[5] = {0, 0, 0, 0, 0}; if (threadIdx.x == 0) for (int k_ = 0; k_ < 5; ++k_) L.st[k_] = 0
 #define DLS_STAMP(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ds_acc[k] += n_ - ds_t; ds_t = n_; } while (0)
-#define DLS_STAMP_FLUSH do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < 5; ++k_) atomicAdd(&g_dls_stamps[k_], ds_acc[k_]); atomicAdd(&g_dls_stamps[5], 1ull); } } while (0)
+#define DLS_STAMP_FLUSH do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < 5; ++k_) atomicAdd(&g_dls_stamps[k_], ds_acc[k_]); atomicAdd(&g_dls_stamps[5], 1ull); for (int k_ = 0; k_ < 5; ++k_) atomicAdd(&g_dls_stamps[8 + k_], L.st[k_]); } } while (0)
 #else
 #define DLS_STAMP_DECL do {} while (0)
 #define DLS_STAMP(k) do {} while (0)

@@ -35,17 +35,20 @@ for leg, est, kind, thr in (("dls", ransac.EST_ABS_DLS, "absolute", (4 / 1000.0)
     ransac.estimate_batch(est, data, offsets, p)
     L.theia_hip_debug_eig_stamps(out)
     if leg == "dls":
-        L.theia_hip_debug_dls_stamps((C.c_ulonglong * 8)())
+        L.theia_hip_debug_dls_stamps((C.c_ulonglong * 16)())
     ransac.estimate_batch(est, data, offsets, p)
     L.theia_hip_debug_eig_stamps(out)
     if leg == "dls":
-        d = (C.c_ulonglong * 8)()
+        d = (C.c_ulonglong * 16)()
         L.theia_hip_debug_dls_stamps(d)
         dn = ["front end", "register load", "elimination", "back-substitution", "M00 - M01 X + stores"]
         dt = float(sum(d[:5]))
         print("dls stage A: workgroups", d[5], "ticks per workgroup", dt / max(1, d[5]))
         for k in range(5):
             print("  %-22s %5.1f %%  %10.0f ticks" % (dn[k], 100.0 * d[k] / dt, d[k] / max(1, d[5])))
+        sn = ["pivot block (thread 0's wave holds the pivot column in 2 of 6 steps)", "barrier", "pivot row out", "update"]
+        for k in range(4):
+            print("  step: %-70s %8.0f ticks per step" % (sn[k], d[8 + k] / max(1, d[12])))
     tot = float(sum(out[:7])); n = max(1, out[7])
     print(leg, "matrices", n, "ticks per matrix", tot / n)
     for k in range(7):
