@@ -130,6 +130,7 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
     // low word among the lanes that hold the high maximum: |a| >= 0 orders like its bit pattern; a NaN never is a candidate,
     // as under the comparison av > bav), the position tie-break only when two lanes hold the same |a|, and the step's four
     // divisions side by side.
+    __builtin_amdgcn_s_setprio(3);   // the workgroup's other waves wait for this block: ahead of the other workgroups' updates
     double bv = 0.0, bav = -1.0; int bp = 1 << 20;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -173,6 +174,7 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
       }
       if (mq >= 0) { L.pinfo[par][0] = 3 * rg + mq; L.pinfo[par][1] = gp; L.diag[k] = ip; L.prow_of[k] = (unsigned char)(3 * rg + mq); }
     }
+    __builtin_amdgcn_s_setprio(0);
   }
   DLS_STEP(0);
   __syncthreads();
