@@ -15,6 +15,7 @@
 #define THEIA_HIP_P4PF_DEVICE_H_
 
 #include "p4pf_tables.h"
+#include "wave_reduce.h"
 #include "ransac_device.h"
 
 namespace thip {
@@ -128,8 +129,7 @@ __device__ inline bool p4pf_action_wg(const double* __restrict__ pd, const int* 
     // pivot: the largest |G[i][k]| over i >= k, the first one on ties (every wave for itself)
     const int ia = k + lane, ib = ia + 64;
     const double va = ia < kElim ? fabs(G[ia * kLdP + k]) : -1.0, vb = ib < kElim ? fabs(G[ib * kLdP + k]) : -1.0;
-    double best = fmax(va, vb);
-    for (int o = 32; o >= 1; o >>= 1) best = fmax(best, __shfl_xor(best, o));
+    const double best = wave_max_abs(fmax(va, vb));   // (wave_reduce.h: fmax over the lanes' bits, on the DPP network)
     const unsigned long long ma = __ballot(va == best), mb = __ballot(vb == best);
     const int bi = ma ? k + __ffsll((long long)ma) - 1 : (mb ? k + 64 + __ffsll((long long)mb) - 1 : kElim);
     if (!(best > 0.0)) return false;   // the same verdict in every wave
@@ -195,8 +195,8 @@ __device__ inline bool p4pf_action_wg(const double* __restrict__ pd, const int* 
     double h1 = (two && lane + 64 < kRows) ? G[(lane + 64) * kLdP + kRows + q2] : 0.0;
     for (int k = kRows - 1; k >= 0; --k) {
       const double pk = pivv[k];
-      const double ek = k >= 64 ? __shfl(e1, k - 64) : __shfl(e0, k);
-      const double hk = k >= 64 ? __shfl(h1, k - 64) : __shfl(h0, k);
+      const double ek = k >= 64 ? lane_value(e1, k - 64) : lane_value(e0, k);
+      const double hk = k >= 64 ? lane_value(h1, k - 64) : lane_value(h0, k);
       const double y = ek / pk, y2 = hk / pk;
       if (lane == 0) { G[k * kLdP + kRows + q] = y; if (two) G[k * kLdP + kRows + q2] = y2; }
       if (lane < k) { const double a = G[lane * kLdP + k]; if (a != 0.0) { e0 = e0 - a * y; h0 = h0 - a * y2; } }

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "eig_team.h"
+#include "wave_reduce.h"
 #include "p4pfr_layout.h"
 #include "ransac_device.h"
 #include "theia_hip_internal.h"
@@ -366,12 +367,11 @@ __global__ __launch_bounds__(64) void k_p4pfr_a(int B, const int* __restrict__ a
     }
   for (int k = 0; k < kElim; ++k) {
     // the first strict maximum in column-major order: the largest value, in the lowest column that holds it
-    double gbest = best;
-    for (int s = 32; s > 0; s >>= 1) gbest = fmax(gbest, __shfl_xor(gbest, s));
+    const double gbest = wave_max_abs(best);   // (wave_reduce.h: fmax over the lanes' bits, on the DPP network)
     const unsigned long long holders = __ballot(best == gbest && lane >= k && lane < kRows);
     if (gbest == 0.0 || holders == 0ull) { nonzero = k; break; }
     const int bc = __ffsll((long long)holders) - 1;
-    const int br = __shfl(brow, bc);
+    const int br = __builtin_amdgcn_readlane(brow, bc);
     if (gbest > maxpivot) maxpivot = gbest;
     if (br != k && lane < kLd) { const double t = M[k * kLd + lane]; M[k * kLd + lane] = M[br * kLd + lane]; M[br * kLd + lane] = t; }
     __syncthreads();

@@ -23,6 +23,7 @@
 #include <mutex>
 
 #include "eig_team.h"
+#include "wave_reduce.h"
 #include "theia_hip_internal.h"
 #include "upnp_layout.h"
 
@@ -155,13 +156,6 @@ __device__ __forceinline__ double dpp_move_d(double v) {
 __device__ __forceinline__ double readlane_d(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
-__device__ __forceinline__ double wave_max_d(double v) {
-  v = fmax(v, dpp_move_d<0xB1>(v));    // quad_perm [1,0,3,2]
-  v = fmax(v, dpp_move_d<0x4E>(v));    // quad_perm [2,3,0,1]
-  v = fmax(v, dpp_move_d<0x141>(v));   // row_half_mirror
-  v = fmax(v, dpp_move_d<0x140>(v));   // row_mirror
-  return fmax(fmax(readlane_d(v, 0), readlane_d(v, 16)), fmax(readlane_d(v, 32), readlane_d(v, 48)));
-}
 __device__ __forceinline__ int wave_min_i(int v) {
   v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
   v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
@@ -194,8 +188,18 @@ __device__ __forceinline__ void gj_step(WgLds& L, double (&a)[kNRL][kNCL], int (
       const double v = fabs(L.colbuf[buf][pos]);
       if (v > babs) { babs = v; mine = pos; }
     }
-    const double m = wave_max_d(babs);
-    bpos = wave_min_i(babs == m ? mine : (1 << 20));
+    // the maximum as two unsigned 32-bit reductions (high word, then the low word among the lanes at the high maximum: a
+    // non-negative double orders like its bit pattern; a NaN is no candidate, as under `v > babs`), the position tie-break only
+    // when two lanes hold the same |a|: the search is on every wave's critical path between two barriers (dls_stage_a.h)
+    const bool valid = babs >= 0.0;
+    const unsigned hi = valid ? (unsigned)__double2hiint(babs) : 0u, lo = (unsigned)__double2loint(babs);
+    const unsigned hm = wave_max_u32(hi);
+    const bool top = valid & (hi == hm);
+    const unsigned lm = wave_max_u32(top ? lo : 0u);
+    const bool match = top & (lo == lm);
+    const unsigned long long own = __builtin_amdgcn_ballot_w64(match);
+    if (__builtin_popcountll(own) == 1) bpos = __builtin_amdgcn_readlane(mine, (int)__builtin_ctzll(own));
+    else bpos = wave_min_i(match ? mine : (1 << 20));
   }
   const double piv = L.colbuf[buf][bpos];
   // the pivot row as it stands (three register-indexed copies, at most one taken), then the swap of the two positions
