@@ -11,6 +11,7 @@
 #define THEIA_HIP_FIT5_TEAM_H_
 
 #include "eig_team.h"
+#include "wave_reduce.h"
 
 namespace thip {
 namespace rsc {
@@ -35,10 +36,25 @@ __device__ int fullpiv_lu_team(double* __restrict__ A, int ld, int rows, int col
         const double a = fabs(A[i * ld + j]);
         if (a > best) { best = a; br = i; bc = j; }
       }
+    if constexpr (TEAM == 16) {
+      // a team of 16 is one row of the DPP network: the maximum of |a| as two unsigned 32-bit all-reductions (wave_reduce.h),
+      // then -- the lanes hold disjoint columns, so (value, column) is a total order and any reduction tree returns the
+      // butterfly's answer -- the lowest column among the holders and that lane's row, two more
+      const bool valid = best >= 0.0;
+      const unsigned hi = valid ? (unsigned)__double2hiint(best) : 0u, lo = (unsigned)__double2loint(best);
+      const unsigned hm = row16_max_u32(hi);
+      const bool top = valid & (hi == hm);
+      const unsigned lm = row16_max_u32(top ? lo : 0u);
+      const bool holder = top & (lo == lm);
+      const unsigned gbc = row16_min_u32(holder ? (unsigned)bc : 0xffffffffu);
+      const unsigned gbr = row16_min_u32((holder & ((unsigned)bc == gbc)) ? (unsigned)br : 0xffffffffu);
+      if (gbc != 0xffffffffu) { best = __hiloint2double((int)hm, (int)lm); br = (int)gbr; bc = (int)gbc; }
+    } else {
     for (int o = TEAM / 2; o >= 1; o >>= 1) {
       const double ob = __shfl_xor(best, o, TEAM);
       const int obr = __shfl_xor(br, o, TEAM), obc = __shfl_xor(bc, o, TEAM);
       if (ob > best || (ob == best && obc < bc)) { best = ob; br = obr; bc = obc; }
+    }
     }
     if (best == 0.0) {
       nonzero = k;

@@ -1313,6 +1313,15 @@ hipStream_t solver_stream() {
   }();
   return s;
 }
+// transfers that may run beside the solver stream's kernels (no kernel ever goes here: no scratch arena)
+hipStream_t copy_stream() {
+  static hipStream_t s = [] {
+    hipStream_t x = nullptr;
+    if (hipStreamCreateWithFlags(&x, hipStreamNonBlocking) != hipSuccess) x = nullptr;
+    return x;
+  }();
+  return s;
+}
 struct CallSync {   // "my work on the shared stream is done"
   hipEvent_t e = nullptr;
   CallSync() { (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); }
@@ -1504,6 +1513,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     if (P.ransac_type == THEIA_RANSAC_EXHAUSTIVE) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "the exhaustive sampler draws pairs: sample size 4 does not fit");
     if ((rc = p4pfr_ensure_tables())) return rc;
   }
+  const auto t_entry = std::chrono::steady_clock::now();
   const int m = sample_size(est), ds = datum_size(est);
   const int64_t total = batch->offsets[nprob];
   int nmax = 0;
@@ -1528,8 +1538,19 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
 
   DBuf<double> d_data; DBuf<int64_t> d_off;
   if ((rc = d_data.ensure((size_t)total * ds)) || (rc = d_off.ensure(nprob + 1))) return rc;
-  HIP_TRYR(hipMemcpyAsync(d_data.p, batch->data, sizeof(double) * total * ds, hipMemcpyHostToDevice, st));
-  HIP_TRYR(hipMemcpyAsync(d_off.p, batch->offsets, sizeof(int64_t) * (nprob + 1), hipMemcpyHostToDevice, st));
+  // The correspondences come from pageable memory: the copy occupies the calling thread for total * ds * 8 B / ~11 GB/s (6 ms for
+  // 1000 pairs x 2000 matches).  It runs on a helper thread while this one draws the first chunk's sample streams; nothing is
+  // enqueued behind it on the stream before upload.wait() (the first device work of the chunk loop, and every exit path).
+  struct Upload {
+    std::thread th; hipError_t err = hipSuccess;
+    int wait() { if (th.joinable()) th.join(); return err == hipSuccess ? 0 : set_error(THEIA_HIP_ERR_INTERNAL, "upload of the correspondences: %s", hipGetErrorString(err)); }
+    ~Upload() { if (th.joinable()) th.join(); }
+  } upload;
+  {
+    const double* src = batch->data; double* dst = d_data.p; const size_t bytes = sizeof(double) * (size_t)total * ds;
+    const int dev = [] { int d = 0; (void)hipGetDevice(&d); return d; }();
+    upload.th = std::thread([&upload, src, dst, bytes, st, dev] { (void)hipSetDevice(dev); upload.err = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st); });
+  }
 
   const double log_failure_prob = std::log(P.failure_probability);
   // round size: everything at once when the iteration count is fixed/small,
@@ -1545,7 +1566,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   int chunk = (int)std::max<size_t>(1, ws_bytes / (per_hyp * (size_t)first_round));
   chunk = std::min(chunk, nprob);
 
-  DBuf<int> d_samples, d_counts, d_ninl, d_active, d_best_samples, d_best_slot, d_dense, d_tags;
+  DBuf<int> d_samples2[2], d_counts, d_ninl, d_active, d_best_samples, d_best_slot, d_dense, d_tags;   // d_samples2: by host sample buffer
   DBuf<int> d_hyp_base;   // [problem][iteration] first dense model of the hypothesis (k_fit)
   DBuf<int> d_save;       // {problem, hypothesis, slot} triples of k_save_best
   DBuf<double> d_models, d_cost, d_best_models;
@@ -1739,16 +1760,29 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     return 0;
   };
   int bufi = 0, pre_c0 = -1, pre_B = 0;   // pre_*: the first round of chunk pre_c0 already sits in buffer 1 - bufi
+  bool offsets_up = false;
+  // The sample streams of the NEXT chunk's first round are drawn while this chunk's kernels run (pre_*); their 30 MB go up on
+  // the copy stream at once, into the device buffer of their host buffer, and the solver stream waits for the event instead
+  // of copying them between two chunks' kernels.
+  hipStream_t copy_st = copy_stream();
+  struct PreUpload {
+    hipEvent_t ev = nullptr; bool pending = false;
+    PreUpload() { (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming); }
+    ~PreUpload() { if (ev) { if (pending) (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); } }   // (the buffers outlive the copy)
+  } pre_up;
+  const auto t_loop = std::chrono::steady_clock::now();
   for (int c0 = 0; c0 < nprob; c0 += chunk) {
     const int cn = std::min(chunk, nprob - c0);
     bool first = true;
     while (true) {
       int B = 0;
       const auto tp0 = std::chrono::steady_clock::now();
-      if (first && pre_c0 == c0) { bufi ^= 1; B = pre_B; pre_c0 = -1; }
+      bool samples_up = false;
+      if (first && pre_c0 == c0) { bufi ^= 1; B = pre_B; pre_c0 = -1; samples_up = pre_up.pending; }
       else if ((rc = gen_round(c0, cn, first, h_active2[bufi], h_samples2[bufi], h_rot2[bufi], &B))) return rc;
       HBuf<int>& h_active = h_active2[bufi];
       HBuf<int>& h_samples = h_samples2[bufi];
+      DBuf<int>& d_samples = d_samples2[bufi];
       if (B == 0) break;
       first = false;
       const auto tp1 = std::chrono::steady_clock::now();
@@ -1757,8 +1791,14 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
           (rc = d_cost.ensure(nh * kMaxModels)) || (rc = d_ninl.ensure(nh * kMaxModels)) || (rc = d_active.ensure(cn)) ||
           (rc = d_dense.ensure(cn)) || (rc = d_tags.ensure(nh * kMaxModels)) || (rc = d_hyp_base.ensure(nh)))
         return rc;
+      if (!offsets_up) {
+        if ((rc = upload.wait())) return rc;
+        HIP_TRYR(hipMemcpyAsync(d_off.p, batch->offsets, sizeof(int64_t) * (nprob + 1), hipMemcpyHostToDevice, st));
+        offsets_up = true;
+      }
       HIP_TRYR(hipMemsetAsync(d_dense.p, 0, sizeof(int) * cn, st));
-      HIP_TRYR(hipMemcpyAsync(d_samples.p, h_samples.data(), sizeof(int) * nh * m, hipMemcpyHostToDevice, st));
+      if (samples_up) { HIP_TRYR(hipStreamWaitEvent(st, pre_up.ev, 0)); pre_up.pending = false; }
+      else HIP_TRYR(hipMemcpyAsync(d_samples.p, h_samples.data(), sizeof(int) * nh * m, hipMemcpyHostToDevice, st));
       HIP_TRYR(hipMemcpyAsync(d_active.p, h_active.data(), sizeof(int) * cn, hipMemcpyHostToDevice, st));
       HIP_TRYR(hipEventRecord(ev0, st));
       if (dls_est) {
@@ -1887,6 +1927,13 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         const int nc0 = c0 + chunk;
         if ((rc = gen_round(nc0, std::min(chunk, nprob - nc0), true, h_active2[1 - bufi], h_samples2[1 - bufi], h_rot2[1 - bufi], &pre_B))) return rc;
         pre_c0 = nc0;
+        const size_t pnh = (size_t)std::min(chunk, nprob - nc0) * pre_B;
+        if (pre_B > 0 && copy_st && pre_up.ev && !pre_up.pending) {
+          if ((rc = d_samples2[1 - bufi].ensure(pnh * m))) return rc;
+          HIP_TRYR(hipMemcpyAsync(d_samples2[1 - bufi].p, h_samples2[1 - bufi].data(), sizeof(int) * pnh * m, hipMemcpyHostToDevice, copy_st));
+          HIP_TRYR(hipEventRecord(pre_up.ev, copy_st));
+          pre_up.pending = true;
+        }
       }
       HIP_TRYR(mine.wait(st));
       {   // the scores, packed: only the models that exist travel (all max_models slots of every hypothesis were 100 - 270 MB a round)
@@ -2011,6 +2058,11 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
       result->hypotheses_evaluated += n_hyp.load(); result->models_scored += n_scored.load();
     }
   }
+  const auto t_final = std::chrono::steady_clock::now();
+  if (!offsets_up) {   // (no round ran at all)
+    if ((rc = upload.wait())) return rc;
+    HIP_TRYR(hipMemcpyAsync(d_off.p, batch->offsets, sizeof(int64_t) * (nprob + 1), hipMemcpyHostToDevice, st));
+  }
   // final models + inlier masks
   for (int p = 0; p < nprob; ++p) {
     best_slot_all[p] = S[p].best_slot;
@@ -2078,6 +2130,11 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   }
   result->time_fit_score_seconds = fit_score_ms * 1e-3;
   result->time_fit_seconds = fit_ms * 1e-3; result->time_score_seconds = score_ms * 1e-3;
+  if (host_timing) {
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::fprintf(stderr, "[theia_hip ransac] call: set-up %.1f ms, rounds %.1f ms, best models + inlier masks + results %.1f ms\n", ms(t_entry, t_loop),
+                 ms(t_loop, t_final), ms(t_final, std::chrono::steady_clock::now()));
+  }
   return 0;
 }
 

@@ -19,6 +19,22 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
              max((unsigned)__builtin_amdgcn_readlane((int)v, 32), (unsigned)__builtin_amdgcn_readlane((int)v, 48)));
 }
 
+// all-reduce inside every row of 16 lanes (= a 16-lane team aligned to a DPP row)
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true));
+  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));
+  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true));
+  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true));
+  return v;
+}
+__device__ __forceinline__ unsigned row16_min_u32(unsigned v) {
+  v = min(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true));
+  v = min(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));
+  v = min(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true));
+  v = min(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true));
+  return v;
+}
+
 // the value lane `l` holds (l uniform): two v_readlane_b32 instead of the two ds_bpermute_b32 of a __shfl
 __device__ __forceinline__ double lane_value(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
