@@ -1840,6 +1840,8 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
         dim3 grid((B + 63) / 64, cn);
         k_fit5_a_team<<<(unsigned)((nh + 3) / 4), 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_ok.p);
         k_fit5_b<false><<<(unsigned)((nh + kFpTeamsPerWave - 1) / kFpTeamsPerWave), 64, 0, st>>>(nh, d_fp_ok.p, d_fp_ws.p, d_fp_sol.p, d_fp_mask.p);
+        // (one LANE per root on teams of 16 -- a lane carries one model instead of ten -- measured 8 % slower on the leg: two or
+        // three of a hypothesis' ten roots are real, so most lanes of such a team idle)
         if (est == THEIA_EST_RELATIVE_POSE)
           k_fit5_c<THEIA_EST_RELATIVE_POSE><<<grid, 64, 0, st>>>(cn, B, d_off.p + c0, d_data.p, d_samples.p, d_active.p, d_fp_ws.p, d_fp_sol.p,
                                                                 d_fp_mask.p, d_models.p, d_counts.p, d_dense.p, d_tags.p, d_hyp_base.p);
