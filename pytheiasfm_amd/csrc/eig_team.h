@@ -42,6 +42,34 @@ __device__ unsigned long long g_eig_stamps[8];
 #define EIG_STAMP_FLUSH do {} while (0)
 #endif
 
+// lane LANE of every row of 16 lanes, to the whole row (DPP row_newbcast: two v_mov_b32_dpp)
+template <int LANE>
+__device__ __forceinline__ double row16_bcast(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + LANE, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + LANE, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// lane LANE (0 .. 4) of every aligned group of 8 lanes, to the whole group: inside the quads by quad_perm, then the other
+// quad of the group takes it over a row shift by four lanes under a bank mask (4 v_mov_b32_dpp per double)
+template <int LANE>
+__device__ __forceinline__ int oct_bcast_i(int v) {
+  static_assert(LANE >= 0 && LANE <= 4, "lanes 0 .. 4");
+  constexpr int L4 = LANE & 3;
+  const int t = __builtin_amdgcn_mov_dpp(v, L4 * 0x55, 0xf, 0xf, false);          // quad_perm [L4, L4, L4, L4]
+  if (LANE < 4) return __builtin_amdgcn_update_dpp(t, t, 0x114, 0xf, 0xA, false);  // row_shr:4 into the upper quads
+  return __builtin_amdgcn_update_dpp(t, t, 0x104, 0xf, 0x5, false);                // row_shl:4 into the lower quads
+}
+template <int LANE>
+__device__ __forceinline__ double oct_bcast(double v) {
+  return __hiloint2double(oct_bcast_i<LANE>(__double2hiint(v)), oct_bcast_i<LANE>(__double2loint(v)));
+}
+// lane LANE (0 .. 4) of the team, to the team
+template <int TEAM, int LANE>
+__device__ __forceinline__ double team_bcast(double v) {
+  if constexpr (TEAM % 16 == 0) return row16_bcast<LANE>(v); else return oct_bcast<LANE>(v);
+}
+
 // The team's slice of a wave ballot (bit i = team lane i; the team is contiguous and TEAM-aligned, TEAM <= 32)
 template <int TEAM>
 __device__ __forceinline__ unsigned team_ballot(bool pred, int tl) {
@@ -273,7 +301,17 @@ __device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double*
           r = notlast ? HH(k + 2, k - 1) : 0.0;
           x = fabs(p) + fabs(q) + fabs(r);
           if (x == 0.0) continue;
+          if constexpr (TEAM % 16 == 0 || TEAM == 8) {
+            // The step's eight quotients are the same in every lane of the team, and their division sequences (11 instructions
+            // each) were most of a chase step's instruction stream.  They are dealt to lanes -- lane j of every DPP row (of every
+            // group of 8 lanes for the teams of 8) divides ONE pair and broadcasts the quotient -- : one division + 2 (4) moves
+            // per value instead of 3 (here) and 5 (below) divisions; the same operands, so the same bits.
+            const int l16 = tl & (TEAM == 8 ? 7 : 15);
+            const double quot = (l16 == 0 ? p : (l16 == 1 ? q : r)) / x;
+            p = team_bcast<TEAM, 0>(quot); q = team_bcast<TEAM, 1>(quot); r = team_bcast<TEAM, 2>(quot);
+          } else {
           p = p / x; q = q / x; r = r / x;
+          }
         }
         s = sqrt(p * p + q * q + r * r);
         if (p < 0) s = -s;
@@ -283,7 +321,16 @@ __device__ __forceinline__ bool eig_team(int nn, double* __restrict__ H, double*
             if (k != m) HH(k, k - 1) = -s * x;
             else if (l != m) HH(k, k - 1) = -HH(k, k - 1);
           }
-          p = p + s; x = p / s; y = q / s; z = r / s; q = q / p; r = r / p;
+          p = p + s;
+          if constexpr (TEAM % 16 == 0 || TEAM == 8) {   // x = p / s; y = q / s; z = r / s; q = q / p; r = r / p  -- lanes 0 .. 4
+            const int l16 = tl & (TEAM == 8 ? 7 : 15);
+            const double num = l16 == 0 ? p : ((l16 == 1 || l16 == 3) ? q : r), den = l16 < 3 ? s : p;
+            const double quot = num / den;
+            x = team_bcast<TEAM, 0>(quot); y = team_bcast<TEAM, 1>(quot); z = team_bcast<TEAM, 2>(quot);
+            q = team_bcast<TEAM, 3>(quot); r = team_bcast<TEAM, 4>(quot);
+          } else {
+          x = p / s; y = q / s; z = r / s; q = q / p; r = r / p;
+          }
           team_sync();
           for (int j = k + tl; j < nn; j += TEAM) {
             double pp = HH(k, j) + q * HH(k + 1, j);
