@@ -1119,7 +1119,10 @@ __global__ __launch_bounds__(64) void k_dls_b(int nprob, int B, const int64_t* _
 
 // stage B on chip: a team of 32 lanes per hypothesis, H / V / X in LDS (eig_team.h), lanes 0..26 turn one eigenvector
 // column each into a pose, kept in column order by a team prefix sum
-constexpr int kDlsTeam = 32, kDlsTeamsPerWave = 64 / kDlsTeam, kDlsTeamLds = 729 + 27 * dlsdev::kKeptRows + 81;   // H | kept rows of V | wr, wi, ort
+#ifndef THIP_DLS_TEAM
+#define THIP_DLS_TEAM 32
+#endif
+constexpr int kDlsTeam = THIP_DLS_TEAM, kDlsColRounds = (27 + kDlsTeam - 1) / kDlsTeam, kDlsTeamsPerWave = 64 / kDlsTeam, kDlsTeamLds = 729 + 27 * dlsdev::kKeptRows + 81;   // H | kept rows of V | wr, wi, ort
 __global__ __launch_bounds__(64) void k_dls_b_team(size_t nhyp, int B, const int64_t* __restrict__ offsets,
                                                    const double* __restrict__ data, const int* __restrict__ samples,
                                                    const int* __restrict__ active_iters, double* __restrict__ action,
@@ -1144,28 +1147,38 @@ __global__ __launch_bounds__(64) void k_dls_b_team(size_t nhyp, int B, const int
   int nn = 27;
   asm volatile("" : "+s"(nn));   // the order stays a run-time value: with the literal the loops unroll into 250 VGPRs (two waves per SIMD)
   const bool good = rsc::eig_team<kDlsTeam, true, dlsdev::kKeptRows>(nn, H, a, a, wr, wi, ort, tl, Vk, dlsdev::kKeptRow);
-  double quat[4], tr[3];
-  bool keep = false;
-  if (good && tl < 27) {
-    const double* pd = data + (size_t)offsets[p] * 5;
-    keep = dlsdev::column_solution<true>(Vk, wi, tl, tfac + hyp * 27, 3, pd + 2, 5, samples + hyp * 3, quat, tr);
+  // the 27 eigenvector columns by lane (kDlsColRounds rounds of the team), the poses kept in column order by team prefix sums
+  double quat[kDlsColRounds][4], tr[kDlsColRounds][3];
+  int rank[kDlsColRounds];
+  int nm = 0;
+#pragma unroll
+  for (int rd = 0; rd < kDlsColRounds; ++rd) {
+    const int col = tl + rd * kDlsTeam;
+    bool keep = false;
+    if (good && col < 27) {
+      const double* pd = data + (size_t)offsets[p] * 5;
+      keep = dlsdev::column_solution<true>(Vk, wi, col, tfac + hyp * 27, 3, pd + 2, 5, samples + hyp * 3, quat[rd], tr[rd]);
+    }
+    int incl = keep ? 1 : 0;
+    for (int o = 1; o < kDlsTeam; o <<= 1) { const int v = __shfl_up(incl, o, kDlsTeam); if (tl >= o) incl += v; }
+    rank[rd] = keep ? nm + incl - 1 : -1;
+    nm += __shfl(incl, kDlsTeam - 1, kDlsTeam);
   }
-  // rank of this lane's solution among the team's (column order) and the team's count
-  int incl = keep ? 1 : 0;
-  for (int o = 1; o < kDlsTeam; o <<= 1) { const int v = __shfl_up(incl, o, kDlsTeam); if (tl >= o) incl += v; }
-  const int nm = __shfl(incl, kDlsTeam - 1, kDlsTeam);
   int base = 0;
   if (tl == 0) { counts[hyp] = nm; if (nm) { base = atomicAdd(&dense_count[p], nm); hyp_base[hyp] = base; } }
   base = __shfl(base, 0, kDlsTeam);
-  if (!keep) return;
-  const int mm = dlsdev::kMaxSolutions, j = incl - 1;
-  double* m = models + ((size_t)p * B * mm + base + j) * (size_t)kStride;
-  double R[9];
-  rsc::quat_to_rot(quat, R);
-  for (int k = 0; k < 9; ++k) m[k] = R[k];
-  for (int c = 0; c < 3; ++c) m[9 + c] = -((R[c] * tr[0] + R[3 + c] * tr[1]) + R[6 + c] * tr[2]);
-  for (int k = 12; k < kStride; ++k) m[k] = 0.0;
-  tags[(size_t)p * B * mm + base + j] = b * mm + j;
+#pragma unroll
+  for (int rd = 0; rd < kDlsColRounds; ++rd) {
+    if (rank[rd] < 0) continue;
+    const int mm = dlsdev::kMaxSolutions, j = rank[rd];
+    double* m = models + ((size_t)p * B * mm + base + j) * (size_t)kStride;
+    double R[9];
+    rsc::quat_to_rot(quat[rd], R);
+    for (int k = 0; k < 9; ++k) m[k] = R[k];
+    for (int c = 0; c < 3; ++c) m[9 + c] = -((R[c] * tr[rd][0] + R[3 + c] * tr[rd][1]) + R[6 + c] * tr[rd][2]);
+    for (int k = 12; k < kStride; ++k) m[k] = 0.0;
+    tags[(size_t)p * B * mm + base + j] = b * mm + j;
+  }
 }
 
 __global__ __launch_bounds__(64) void k_gdls_b_team(size_t nhyp, int B, const int64_t* __restrict__ offsets,
@@ -1187,27 +1200,38 @@ __global__ __launch_bounds__(64) void k_gdls_b_team(size_t nhyp, int B, const in
   int nn = 27;
   asm volatile("" : "+s"(nn));
   const bool good = rsc::eig_team<kDlsTeam, true, dlsdev::kKeptRows>(nn, H, a, a, wr, wi, ort, tl, Vk, dlsdev::kKeptRow);
-  double quat[4], tr[3], sc = 0.0;
-  bool keep = false;
-  if (good && tl < 27)
-    keep = dlsdev::column_solution_gdls(Vk, wi, tl, tfac + hyp * 36, 4, data + (size_t)offsets[p] * kSimDatum, kSimDatum, 0, 9, 3,
-                                        samples + hyp * 4, quat, tr, &sc);
-  int incl = keep ? 1 : 0;
-  for (int o = 1; o < kDlsTeam; o <<= 1) { const int v = __shfl_up(incl, o, kDlsTeam); if (tl >= o) incl += v; }
-  const int nm = __shfl(incl, kDlsTeam - 1, kDlsTeam);
+  double quat[kDlsColRounds][4], tr[kDlsColRounds][3], sc[kDlsColRounds];
+  int rank[kDlsColRounds];
+  int nm = 0;
+#pragma unroll
+  for (int rd = 0; rd < kDlsColRounds; ++rd) {
+    const int col = tl + rd * kDlsTeam;
+    bool keep = false;
+    sc[rd] = 0.0;
+    if (good && col < 27)
+      keep = dlsdev::column_solution_gdls(Vk, wi, col, tfac + hyp * 36, 4, data + (size_t)offsets[p] * kSimDatum, kSimDatum, 0, 9, 3,
+                                          samples + hyp * 4, quat[rd], tr[rd], &sc[rd]);
+    int incl = keep ? 1 : 0;
+    for (int o = 1; o < kDlsTeam; o <<= 1) { const int v = __shfl_up(incl, o, kDlsTeam); if (tl >= o) incl += v; }
+    rank[rd] = keep ? nm + incl - 1 : -1;
+    nm += __shfl(incl, kDlsTeam - 1, kDlsTeam);
+  }
   int base = 0;
   if (tl == 0) { counts[hyp] = nm; if (nm) { base = atomicAdd(&dense_count[p], nm); hyp_base[hyp] = base; } }
   base = __shfl(base, 0, kDlsTeam);
-  if (!keep) return;
-  const int mm = dlsdev::kMaxSolutions, j = incl - 1;
-  double* m = models + ((size_t)p * B * mm + base + j) * (size_t)kStride;
-  double Rs[9];
-  rsc::quat_to_rot(quat, Rs);
-  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) m[3 * r + c] = Rs[3 * c + r];                              // rotation = R^T
-  for (int r = 0; r < 3; ++r) m[9 + r] = (m[3 * r] * -tr[0] + m[3 * r + 1] * -tr[1]) + m[3 * r + 2] * -tr[2];       // rotation * -t
-  m[12] = sc;
-  for (int k = 13; k < kStride; ++k) m[k] = 0.0;
-  tags[(size_t)p * B * mm + base + j] = b * mm + j;
+#pragma unroll
+  for (int rd = 0; rd < kDlsColRounds; ++rd) {
+    if (rank[rd] < 0) continue;
+    const int mm = dlsdev::kMaxSolutions, j = rank[rd];
+    double* m = models + ((size_t)p * B * mm + base + j) * (size_t)kStride;
+    double Rs[9];
+    rsc::quat_to_rot(quat[rd], Rs);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) m[3 * r + c] = Rs[3 * c + r];                              // rotation = R^T
+    for (int r = 0; r < 3; ++r) m[9 + r] = (m[3 * r] * -tr[rd][0] + m[3 * r + 1] * -tr[rd][1]) + m[3 * r + 2] * -tr[rd][2];       // rotation * -t
+    m[12] = sc[rd];
+    for (int k = 13; k < kStride; ++k) m[k] = 0.0;
+    tags[(size_t)p * B * mm + base + j] = b * mm + j;
+  }
 }
 
 // DlsPnp on problems of any size (the directly bound solver, sfm.cc:577): stage A per workgroup (dls_kernels.hip), then a thread per problem
