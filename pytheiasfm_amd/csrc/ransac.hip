@@ -35,9 +35,11 @@
 #include "theia_hip.h"
 #include <atomic>
 #include <mutex>
+#include <functional>
 #include <thread>
 
 #include "theia_hip_internal.h"
+#include "host_team.h"
 #include "pools.h"
 
 namespace thip {
@@ -1356,17 +1358,21 @@ struct CallSync {   // "my work on the shared stream is done"
   }
 };
 
-// Host-side loops over independent problems (sample streams, acceptance replay) on a few threads.
-// THEIA_HIP_HOST_THREADS caps the count (default min(hardware threads, 16); 1 = serial).
+// Host-side loops over independent problems (sample streams, acceptance replay) on the library's persistent team of host
+// threads (host_team.h: starting and joining 16 threads per loop cost ~0.6 ms, a round has two such loops); a second caller
+// inside the team's region falls back to threads of its own.  THEIA_HIP_HOST_THREADS caps the count (default min(hardware
+// threads, 32); 1 = serial).
 template <class F>
 void host_parallel_for(int n, F&& fn) {
   static const unsigned cap = [] {
     const char* e = getenv("THEIA_HIP_HOST_THREADS");
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    return e ? (unsigned)std::max(1, atoi(e)) : std::min(hw, 16u);
+    return e ? (unsigned)std::max(1, atoi(e)) : std::min(hw, 32u);
   }();
   const unsigned nt = std::min<unsigned>(cap, (unsigned)std::max(1, n / 4));
   if (nt < 2) { for (int i = 0; i < n; ++i) fn(i); return; }
+  const std::function<void(int)> job = [&fn](int i) { fn(i); };
+  if (host_team().run(n, nt, job)) return;
   std::atomic<int> next{0};
   std::vector<std::thread> th;
   th.reserve(nt);
