@@ -17,6 +17,7 @@
 // Eigen's product kernel runs blocked: bit-identical to the oracle run in wave order, ~1e-4 .. 1e-15 from the index-order run
 // depending on the pair's noise (the IRLS amplifies summation-order roundings: tests/test_relpos_gpu.py).
 #include "ransac_device.h"
+#include "wave_reduce.h"
 #include "theia_hip_internal.h"
 
 #include <algorithm>
@@ -34,16 +35,9 @@
 namespace thip {
 namespace {
 
-__device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ int wsum_i(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+// the XOR butterfly over the 64 lanes, on permlane swaps + DPP (wave_reduce.h: the bits of the __shfl_xor loop)
+__device__ __forceinline__ double wsum(double v) { return wave_sum_butterfly(v); }
+__device__ __forceinline__ int wsum_i(int v) { return wave_sum_butterfly(v); }
 
 __global__ __launch_bounds__(256) void k_relpos_irls(int num, const int64_t* __restrict__ offsets, const double4* __restrict__ corr,
                                                      const double* __restrict__ rotm, double* __restrict__ C,

@@ -14,6 +14,7 @@
 // from the linearised residuals, step acceptance rho > 1e-3, focal lengths projected onto >= 1).  Lane = point
 // (stride 64); the reduced system is wave-reduced; every lane keeps the same scalar state.
 #include "ba_device.h"
+#include "wave_reduce.h"
 #include "theia_hip_internal.h"
 
 #include <chrono>
@@ -32,16 +33,9 @@ namespace {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-__device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-__device__ __forceinline__ double wmax(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-  return v;
-}
+// the XOR butterfly over the 64 lanes, on permlane swaps + DPP (wave_reduce.h: the bits of the __shfl_xor loop)
+__device__ __forceinline__ double wsum(double v) { return wave_sum_butterfly(v); }
+__device__ __forceinline__ double wmax(double v) { return wave_max_butterfly(v); }
 
 struct TvBatch {
   int num;

@@ -17,6 +17,7 @@
 // With the default options (SPARSE_SCHUR; RefineModel of the uncalibrated relative-pose estimator,
 // estimate_uncalibrated_relative_pose.cc:142-176) the step is the exact solution (solve5).
 #include "ba_device.h"
+#include "wave_reduce.h"
 #include "ransac_device.h"
 #include "theia_hip_internal.h"
 
@@ -35,11 +36,8 @@ namespace {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-__device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+// the XOR butterfly over the 64 lanes, on permlane swaps + DPP (wave_reduce.h: the bits of the __shfl_xor loop)
+__device__ __forceinline__ double wsum(double v) { return wave_sum_butterfly(v); }
 __device__ __forceinline__ int tri(int a, int b) { return a * (a + 1) / 2 + b; }
 
 struct TwoViewBatch {
