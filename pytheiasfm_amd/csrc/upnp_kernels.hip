@@ -143,6 +143,9 @@ struct WgLds {
   double colbuf[2][kRowsPad];   // column k by POSITION
   double rowraw[2][kColsPad], rowbuf[2][kColsPad];
   double blk[20][29];
+#ifdef THIP_UPNP_STAMPS
+  unsigned long long st[8];
+#endif
 };
 
 // wave-wide reductions on the DPP network (rows of 16 lanes, then the four row results through v_readlane)
@@ -167,15 +170,27 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // One elimination step with the pivot column at local index LC (0 while the registers still shift) and NL live local columns
 // (the rest hold the zeros that were shifted in).  mypos[i]: the POSITION of the thread's row i in the reference's swapped row
 // order -- the column of step k is published by position, so the pivot search, the multipliers and the swap need no row table.
+// Development (-DTHIP_UPNP_STAMPS): s_memtime ticks of thread 0 per section of a Gauss-Jordan step, summed over the workgroups:
+// {column out + barrier, search, pivot row out + barrier, division + barrier, update, steps, workgroups}
+#ifdef THIP_UPNP_STAMPS
+__device__ unsigned long long g_upnp_stamps[8];
+#define UPNP_T0 unsigned long long ut_ = __builtin_amdgcn_s_memtime()
+#define UPNP_STAMP(k_) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) L.st[k_] += n_ - ut_; ut_ = n_; } while (0)
+#else
+#define UPNP_T0 do {} while (0)
+#define UPNP_STAMP(k_) do {} while (0)
+#endif
 template <int LC, int NL>
 __device__ __forceinline__ void gj_step(WgLds& L, double (&a)[kNRL][kNCL], int (&mypos)[kNRL], int k, int g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int gk = k & (kCG - 1), buf = k & 1;
+  UPNP_T0;
   if (g == gk) {
 #pragma unroll
     for (int i = 0; i < kNRL; ++i) L.colbuf[buf][mypos[i]] = a[i][LC];
   }
   __syncthreads();
+  UPNP_STAMP(0);
   double l[kNRL];
 #pragma unroll
   for (int i = 0; i < kNRL; ++i) l[i] = L.colbuf[buf][mypos[i]];
@@ -202,6 +217,7 @@ __device__ __forceinline__ void gj_step(WgLds& L, double (&a)[kNRL][kNCL], int (
     else bpos = wave_min_i(match ? mine : (1 << 20));
   }
   const double piv = L.colbuf[buf][bpos];
+  UPNP_STAMP(1);
   // the pivot row as it stands (three register-indexed copies, at most one taken), then the swap of the two positions
   if (mypos[0] == bpos) {
 #pragma unroll
@@ -216,8 +232,10 @@ __device__ __forceinline__ void gj_step(WgLds& L, double (&a)[kNRL][kNCL], int (
 #pragma unroll
   for (int i = 0; i < kNRL; ++i) mypos[i] = mypos[i] == bpos ? k : (mypos[i] == k ? bpos : mypos[i]);
   __syncthreads();
+  UPNP_STAMP(2);
   if (tid < kCG * NL) L.rowbuf[buf][tid] = (tid == kCG * LC + gk) ? 1.0 : L.rowraw[buf][tid] / piv;   // row /= pivot; (k, k) = 1
   __syncthreads();
+  UPNP_STAMP(3);
   double prow[NL];
 #pragma unroll
   for (int j = 0; j < NL; ++j) prow[j] = L.rowbuf[buf][kCG * j + g];
@@ -238,6 +256,10 @@ __device__ __forceinline__ void gj_step(WgLds& L, double (&a)[kNRL][kNCL], int (
       for (int j = 0; j < NL; ++j) a[i][j] = a[i][j] - l[i] * prow[j];
     }
   }
+  UPNP_STAMP(4);
+#ifdef THIP_UPNP_STAMPS
+  if (threadIdx.x == 0) L.st[5] += 1ull;
+#endif
 }
 
 template <int LC, int NL>
@@ -355,6 +377,9 @@ __global__ __launch_bounds__(kThreads) void k_upnp_a(int B, const int* __restric
       a[i][j] = s == 255 ? 0.0 : L.M1[s];
     }
   }
+#ifdef THIP_UPNP_STAMPS
+  if (tid == 0) for (int k_ = 0; k_ < 8; ++k_) L.st[k_] = 0;
+#endif
   // ---- GaussJordan(140, 121): top-down over all 141 rows.  After s shifts the local column j stands for 8 (j + s) + g <= 148,
   // i.e. 19 - s live registers per row
   gj_block<19>(L, a, mypos, 0, 4, g);
@@ -364,6 +389,9 @@ __global__ __launch_bounds__(kThreads) void k_upnp_a(int B, const int* __restric
   gj_steps<1, 5>(L, a, mypos, 120, 128, g);
   gj_steps<2, 5>(L, a, mypos, 128, 136, g);
   gj_steps<3, 5>(L, a, mypos, 136, 141, g);
+#ifdef THIP_UPNP_STAMPS
+  if (tid == 0) { for (int k_ = 0; k_ < 6; ++k_) atomicAdd(&g_upnp_stamps[k_], L.st[k_]); atomicAdd(&g_upnp_stamps[6], 1ull); }
+#endif
   // ---- bottom-up over the rows 140 .. 121 (gauss_jordan.h:152-193), columns 121 .. 148 (the others are never read again)
 #pragma unroll
   for (int i = 0; i < kNRL; ++i) {
@@ -581,3 +609,11 @@ void launch_upnp_fit(int nprob, int B, const int64_t* offsets, const double* dat
 }
 
 }  // namespace thip
+
+#ifdef THIP_UPNP_STAMPS
+extern "C" int theia_hip_debug_upnp_stamps(unsigned long long* out) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(thip::upnpdev::g_upnp_stamps), sizeof(z)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(thip::upnpdev::g_upnp_stamps), z, sizeof(z)) != hipSuccess;
+}
+#endif
