@@ -15,7 +15,7 @@ for fn in glob.glob("/tmp/prof_pmc/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"].replace("thip::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         a = acc[k][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
 for k, d in acc.items():
-    if not any(x in k for x in ("k_lin_schur", "k_backsub", "k_schur_sum", "k_sum_items", "k_sp_", "k_fit", "k_dls", "k_score", "k_sqp", "k_p4pf")): continue
+    if not any(x in k for x in ("k_lin_schur", "k_backsub", "k_schur_sum", "k_sum_items", "k_sp_", "k_fit", "k_dls", "k_score", "k_sqp", "k_p4pf", "k_id_")): continue
     print(k, {c: round(v[1] / v[0], 1) for c, v in d.items()})
 PY
 tail -n 2 /tmp/pmc_run.log
