@@ -1643,7 +1643,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
   }
   std::vector<int> best_samples_all((size_t)nprob * kMaxSample, 0), best_slot_all(nprob, -1);
   std::vector<ProblemState> S(nprob);
-  for (int p = 0; p < nprob; ++p) {
+  host_parallel_for(nprob, [&](int p) {   // (the generator's 624-word seeding and the index permutation of every problem: ~1 us each)
     ProblemState& s = S[p];
     s.n = (int)(batch->offsets[p + 1] - batch->offsets[p]);
     s.rng.seed(batch->seeds ? batch->seeds[p] : P.seed + (uint32_t)p);
@@ -1656,7 +1656,7 @@ int theia_hip_ransac_estimate_batch(const theia_ransac_batch* batch, const theia
     s.it = 0; s.done = s.max_iterations <= 0 || undersized[p]; s.best_slot = -1; s.kth = 1; s.ex_i = 0; s.ex_j = 1;
     s.base_it = 0; s.rb = 0; s.rj = 0; s.round_done = true; s.best_refined = false; s.pending_ratio = 0.0; s.num_lo = 0;
     for (int k = 0; k < kMaxSample; ++k) s.best_samples[k] = 0;
-  }
+  });
   double fit_score_ms = 0.0;
   // ---- LO-RANSAC (absolute / relative pose): batched RefineModel over a list of events
   DBuf<int> d_ev_prob, d_ev_samples, d_ev_slot, d_ev_hyp, d_ev_count, d_ev_success, d_lo_model_id;
