@@ -119,11 +119,10 @@ __device__ __forceinline__ void lu_pivot_row_out(double* __restrict__ ub, const 
 #pragma unroll
   for (int i = 0; i < NL; ++i) ub[6 * i] = a[Q][i];
 }
-template <int NL, bool SHIFT>
-__device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)[3], int k, int s, int g, int rg, int urow) {
+// The pivot block of step k (column k = register 0 of column group s): search and factors, published in the step's parity
+// buffers.  Called by the wave that holds the column (the half that does not rides along).
+__device__ __forceinline__ void lu_pivot_block(WgLds& L, const double (&a)[3][20], const int (&pos)[3], int k, int s, int g, int rg) {
   const int par = k & 1;
-  DLS_STEP_T0;
-  if ((g >> 1) == (s >> 1)) {   // the wave whose half s & 1 holds column k in register 0 (the other half rides along)
     // pivot = first maximum in POSITION order: largest |a|, then smallest position.  The block below is the critical path of a
     // step -- one wave runs it while the other two wait at the barrier -- so it is written for dependent depth: no branches in
     // the choice among a lane's three rows, the maximum of the 32 lanes as two unsigned 32-bit reductions (high word, then the
@@ -139,7 +138,7 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
       const bool better = cand & ((av > bav) | ((av == bav) & (pos[q] < bp)));
       bv = better ? a[q][0] : bv; bav = better ? av : bav; bp = better ? pos[q] : bp;
     }
-    const int base = (s & 1) << 5;
+    const int base = (s / 3) << 5;
     const bool valid = bav >= 0.0;
     const unsigned hi = valid ? (unsigned)__double2hiint(bav) : 0u, lo = (unsigned)__double2loint(bav);
     const unsigned h16 = dls_dpp_umax16(hi);
@@ -175,19 +174,15 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
       if (mq >= 0) { L.pinfo[par][0] = 3 * rg + mq; L.pinfo[par][1] = gp; L.diag[k] = ip; L.prow_of[k] = (unsigned char)(3 * rg + mq); }
     }
     __builtin_amdgcn_s_setprio(0);
-  }
-  DLS_STEP(0);
-  __syncthreads();
-  DLS_STEP(1);
-  double l[3];   // the step's factors of this lane's rows: requested with the pivot's position, used after the pivot row is out
-#pragma unroll
-  for (int q = 0; q < 3; ++q) l[q] = L.lbuf[par][3 * rg + q];
-  const int pr = __builtin_amdgcn_readfirstlane(L.pinfo[par][0]), pp = __builtin_amdgcn_readfirstlane(L.pinfo[par][1]);
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    if (pos[q] == pp) pos[q] = k;
-    else if (pos[q] == k) pos[q] = pp;
-  }
+}
+
+// a step whose pivot-row hand-over and update a wave has put off (see lu_step)
+struct LuPending { bool on; double l[3]; int pr, urow, skipg; };
+
+// The pivot row of a step out to the store and back, and the step's multiply-adds on this lane's rows.  l: the NEGATED factors;
+// skipg: the column group whose register 0 has taken this step already (look-ahead), or -1.
+template <int NL, bool SHIFT>
+__device__ __forceinline__ void lu_row_and_update(WgLds& L, double (&a)[3][20], const double (&l)[3], int pr, int urow, int g, int rg, int skipg) {
   // the six lanes of the pivot row put it where everybody reads it (pr is uniform: no selects)
   double* ub = L.U + urow + g;   // urow = u_base(k)
   const int prg = pr / 3, pq = pr - 3 * prg;
@@ -197,14 +192,11 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
   // The piece of the pivot row at ub (= the columns of group g) is written by lane (g, prg) and read, in this step, by the lanes
   // of column group g only: writer and readers are lanes of ONE wave, whose LDS operations complete in order -- a wavefront
   // fence orders them; the workgroup barrier that stood here (round 4 - 5) made every step wait twice for its slowest wave.
-  // (Other waves read these rows in the back-substitution, many barriers later; lbuf / pinfo alternate by step parity, and a
-  // wave passes the next step's barrier only after it has consumed this step's values.)
+  // (Other waves read these rows in the back-substitution, many barriers later.)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  DLS_STEP(2);
-#pragma unroll
-  for (int q = 0; q < 3; ++q) l[q] = -l[q];
   constexpr int I0 = SHIFT ? 1 : 0, D = SHIFT ? 1 : 0;
+  const bool skip0 = (g == skipg);
 #pragma unroll
   for (int c0 = I0; c0 < NL; c0 += 4) {   // four columns at a time: their LDS reads in flight together, no more
     double pv[4];
@@ -214,13 +206,62 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
     for (int j = 0; j < 4; ++j)
       if (c0 + j < NL) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) a[q][c0 + j - D] = __builtin_fma(l[q], pv[j], a[q][c0 + j]);
+        for (int q = 0; q < 3; ++q) {
+          const double v = __builtin_fma(l[q], pv[j], a[q][c0 + j]);
+          if (!SHIFT && c0 + j == 0) a[q][0] = skip0 ? a[q][0] : v; else a[q][c0 + j - D] = v;
+        }
       }
     THIP_DLS_FENCE();
   }
   if (SHIFT) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) a[q][NL - 1] = 0.0;
+  }
+}
+
+// One elimination step.  The step is a dependent chain: pivot block (one wave) -> barrier -> pivot position -> pivot row out
+// and back -> multiply-adds; with the column groups dealt to the waves so that consecutive pivot columns sit in DIFFERENT waves,
+// the wave that holds column k + 1 takes step k on that column alone (the pivot row's entry comes from its own registers),
+// runs the pivot block of step k + 1 at once -- while the other two waves do their hand-over and update of step k -- and puts
+// its own hand-over and update of step k off until after the next barrier (`pend`): the chain of a step is the pivot block
+// alone.  Every entry still takes the steps in order, with the same operands: the same bits.  lookahead: step k + 1 belongs to
+// this group of six (no look-ahead across the register shift).
+template <int NL, bool SHIFT>
+__device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)[3], int k, int s, int g, int rg, int urow, LuPending& pend,
+                                        bool lookahead) {
+  const int par = k & 1, wave = (int)(threadIdx.x >> 6);
+  DLS_STEP_T0;
+  if (s == 0 && wave == 0) lu_pivot_block(L, a, pos, k, 0, g, rg);   // (the later steps' blocks ran one step ahead)
+  DLS_STEP(0);
+  __syncthreads();
+  DLS_STEP(1);
+  double l[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) l[q] = -L.lbuf[par][3 * rg + q];
+  const int pr = __builtin_amdgcn_readfirstlane(L.pinfo[par][0]), pp = __builtin_amdgcn_readfirstlane(L.pinfo[par][1]);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    if (pos[q] == pp) pos[q] = k;
+    else if (pos[q] == k) pos[q] = pp;
+  }
+  if (pend.on) {   // the step this wave put off: before anything of step k touches its rows
+    lu_row_and_update<NL, false>(L, a, pend.l, pend.pr, pend.urow, g, rg, pend.skipg);
+    pend.on = false;
+  }
+  if (!SHIFT && lookahead && wave == (s + 1) % 3) {
+    // column k + 1 = register 0 of group s + 1: step k on it now, with the pivot row's entry from lane prg of that half
+    const int prg = pr / 3, pq = pr - 3 * prg, src = (((s + 1) / 3) << 5) + prg;
+    const double u = pq == 0 ? readlane_d(a[0][0], src) : (pq == 1 ? readlane_d(a[1][0], src) : readlane_d(a[2][0], src));
+    if (g == s + 1) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a[q][0] = __builtin_fma(l[q], u, a[q][0]);
+    }
+    lu_pivot_block(L, a, pos, k + 1, s + 1, g, rg);
+    pend.on = true; pend.pr = pr; pend.urow = urow; pend.skipg = s + 1;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) pend.l[q] = l[q];
+  } else {
+    lu_row_and_update<NL, SHIFT>(L, a, l, pr, urow, g, rg, -1);
   }
   DLS_STEP(3);
 #ifdef THIP_DLS_STAMPS
@@ -229,11 +270,11 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
 }
 
 template <int NL>
-__device__ __forceinline__ void lu_six(WgLds& L, double (&a)[3][20], int (&pos)[3], int o, int g, int rg, int& urow) {
-  const int k = 6 * o, ns = (k + 6 <= kBlock) ? 5 : kBlock - k, len = kBlock - k;   // 93 = 15 * 6 + 3
+__device__ __forceinline__ void lu_six(WgLds& L, double (&a)[3][20], int (&pos)[3], int o, int g, int rg, int& urow, LuPending& pend) {
+  const int k = 6 * o, full = (k + 6 <= kBlock), ns = full ? 5 : kBlock - k, len = kBlock - k;   // 93 = 15 * 6 + 3
 #pragma nounroll
-  for (int s = 0; s < ns; ++s, urow += len) lu_step<NL, false>(L, a, pos, k + s, s, g, rg, urow);
-  if (k + 6 <= kBlock) { lu_step<NL, true>(L, a, pos, k + 5, 5, g, rg, urow); urow += len; }
+  for (int s = 0; s < ns; ++s, urow += len) lu_step<NL, false>(L, a, pos, k + s, s, g, rg, urow, pend, full || s + 1 < ns);
+  if (full) { lu_step<NL, true>(L, a, pos, k + 5, 5, g, rg, urow, pend, false); urow += len; }
 }
 
 // back-substitution step: row Q of every lane times 1 / u_kk -- only the lanes of row group prg hold the row pivoted at
@@ -267,7 +308,8 @@ __device__ __forceinline__ bool stage_a(WgLds& L, int npts, const double* __rest
                                const double* __restrict__ u4, double* __restrict__ action, double* __restrict__ tfac,
                                const double* __restrict__ origin = nullptr, int ostride = 0) {
   const int tid = threadIdx.x;
-  const int g = tid >> 5, rg = tid & 31;
+  // column group g = lower halves of the waves 0 1 2, then their upper halves: the owners of consecutive steps are different waves
+  const int g = (tid >> 6) + 3 * ((tid >> 5) & 1), rg = tid & 31;
   const dls::Tables& tb = c_tab;
   DLS_STAMP_DECL;
   if (tid < 4) L.u[tid] = u4[tid];
@@ -395,7 +437,7 @@ __device__ __forceinline__ bool stage_a(WgLds& L, int npts, const double* __rest
   // ---- the augmented block [M11 | M10] into registers
   double a[3][20];
   {
-    const uint32_t* code = reinterpret_cast<const uint32_t*>(tb.init[tid]);
+    const uint32_t* code = reinterpret_cast<const uint32_t*>(tb.init[32 * g + rg]);   // (the table is laid out by column group)
 #pragma unroll
     for (int w = 0; w < 15; ++w) {
       const uint32_t cw = code[w];
@@ -413,10 +455,11 @@ __device__ __forceinline__ bool stage_a(WgLds& L, int npts, const double* __rest
   DLS_STAMP(1);
   // ---- elimination (oracle: dls_action_from_cost)
   int urow = 0;   // u_base(k), carried along
-  for (int o = 0; o < 4; ++o) lu_six<20>(L, a, pos, o, g, rg, urow);
-  for (int o = 4; o < 8; ++o) lu_six<16>(L, a, pos, o, g, rg, urow);
-  for (int o = 8; o < 12; ++o) lu_six<12>(L, a, pos, o, g, rg, urow);
-  for (int o = 12; o < 16; ++o) lu_six<8>(L, a, pos, o, g, rg, urow);
+  LuPending pend; pend.on = false; pend.pr = 0; pend.urow = 0; pend.skipg = -1; pend.l[0] = pend.l[1] = pend.l[2] = 0.0;
+  for (int o = 0; o < 4; ++o) lu_six<20>(L, a, pos, o, g, rg, urow, pend);
+  for (int o = 4; o < 8; ++o) lu_six<16>(L, a, pos, o, g, rg, urow, pend);
+  for (int o = 8; o < 12; ++o) lu_six<12>(L, a, pos, o, g, rg, urow, pend);
+  for (int o = 12; o < 16; ++o) lu_six<8>(L, a, pos, o, g, rg, urow, pend);
   // ---- back-substitution, column oriented: register i < 5 of a row now holds right-hand side 6 (i + 15) + g - 93
   // A right-hand side never leaves its column group: the 32 lanes of a half-wave hold its entries of all 96 rows, so every
   // half-wave runs the whole substitution on its own five columns: nothing crosses a wave and there is no barrier in the loop
