@@ -181,14 +181,21 @@ struct LuPending { bool on; double l[3]; int pr, urow, skipg; };
 
 // The pivot row of a step out to the store and back, and the step's multiply-adds on this lane's rows.  l: the NEGATED factors;
 // skipg: the column group whose register 0 has taken this step already (look-ahead), or -1.
-template <int NL, bool SHIFT>
-__device__ __forceinline__ void lu_row_and_update(WgLds& L, double (&a)[3][20], const double (&l)[3], int pr, int urow, int g, int rg, int skipg) {
+template <int NL>
+__device__ __forceinline__ void lu_row_out(WgLds& L, const double (&a)[3][20], int pr, int urow, int g, int rg) {
   // the six lanes of the pivot row put it where everybody reads it (pr is uniform: no selects)
   double* ub = L.U + urow + g;   // urow = u_base(k)
   const int prg = pr / 3, pq = pr - 3 * prg;
   if (pq == 0) { if (rg == prg) lu_pivot_row_out<NL, 0>(ub, a); }
   else if (pq == 1) { if (rg == prg) lu_pivot_row_out<NL, 1>(ub, a); }
   else { if (rg == prg) lu_pivot_row_out<NL, 2>(ub, a); }
+}
+// ROW_IS_OUT: the pivot row went out earlier (a deferred step: right behind the look-ahead, so that its way through LDS is
+// behind this wave by the time it catches up)
+template <int NL, bool SHIFT, bool ROW_IS_OUT = false>
+__device__ __forceinline__ void lu_row_and_update(WgLds& L, double (&a)[3][20], const double (&l)[3], int pr, int urow, int g, int rg, int skipg) {
+  double* ub = L.U + urow + g;
+  if (!ROW_IS_OUT) lu_row_out<NL>(L, a, pr, urow, g, rg);
   // The piece of the pivot row at ub (= the columns of group g) is written by lane (g, prg) and read, in this step, by the lanes
   // of column group g only: writer and readers are lanes of ONE wave, whose LDS operations complete in order -- a wavefront
   // fence orders them; the workgroup barrier that stood here (round 4 - 5) made every step wait twice for its slowest wave.
@@ -245,7 +252,7 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
     else if (pos[q] == k) pos[q] = pp;
   }
   if (pend.on) {   // the step this wave put off: before anything of step k touches its rows
-    lu_row_and_update<NL, false>(L, a, pend.l, pend.pr, pend.urow, g, rg, pend.skipg);
+    lu_row_and_update<NL, false, true>(L, a, pend.l, pend.pr, pend.urow, g, rg, pend.skipg);
     pend.on = false;
   }
   if (!SHIFT && lookahead && wave == (s + 1) % 3) {
@@ -257,6 +264,7 @@ __device__ __forceinline__ void lu_step(WgLds& L, double (&a)[3][20], int (&pos)
       for (int q = 0; q < 3; ++q) a[q][0] = __builtin_fma(l[q], u, a[q][0]);
     }
     lu_pivot_block(L, a, pos, k + 1, s + 1, g, rg);
+    lu_row_out<NL>(L, a, pr, urow, g, rg);   // (step k leaves its pivot row as it is: the row can go out now, the update waits)
     pend.on = true; pend.pr = pr; pend.urow = urow; pend.skipg = s + 1;
 #pragma unroll
     for (int q = 0; q < 3; ++q) pend.l[q] = l[q];
