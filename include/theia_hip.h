@@ -754,6 +754,11 @@ int theia_hip_guided_knn(int32_t num_groups, const int64_t* q_off, const int32_t
 /* n draws of RandomNumberGenerator(seed).RandInt(lo, hi) (util/random.cc:46-84): host code that follows the reference's
  * generator outside the RANSAC sampler (the random candidates of GuidedEpipolarMatcher::FindFeaturesNearEpipolarLines). */
 int theia_hip_randint_stream(uint32_t seed, int32_t n, int32_t lo, int32_t hi, int32_t* out);
+/* Self-check of the cross-lane primitives the bit-exact kernels stand on (wave_reduce.h: the XOR-butterfly sums on permlane swaps
+ * + DPP, the wave maximum of |a| as two unsigned reductions, the row broadcasts) against plain shuffle loops on `count` random
+ * wavefronts; *mismatches = lanes whose bits differ (0 on a device / compiler the library is right for).  No reference
+ * counterpart: a maintainer's first call on new hardware. */
+int theia_hip_selftest_wave_primitives(int32_t count, int32_t* mismatches);
 
 /* The batch entry points above keep their device workspace and the pinned host blocks of their per-round transfers in
  * process-wide caches between calls (up to 6 GiB of device memory and 2 GiB of pinned host memory); the buffers of a

@@ -153,7 +153,7 @@ EXPORTED_SYMBOLS = [
     "theia_hip_ba_set_allreduce", "theia_hip_ba_set_inner_global", "theia_hip_ba_plan_info", "theia_hip_rccl_unique_id", "theia_hip_rccl_comm_create",
     "theia_hip_optimize_relative_position_batch", "theia_hip_rccl_comm_destroy", "theia_hip_rccl_comm_count", "theia_hip_ba_set_rccl", "theia_hip_dense_spd_solve", "theia_ransac_params_default",
     "theia_hip_ransac_estimate_batch", "theia_hip_five_point_relative_pose",
-    "theia_hip_pose_from_three_points", "theia_hip_sqpnp", "theia_hip_dls_pnp", "theia_hip_dls_macaulay_terms", "theia_hip_four_point_pose_and_focal_length", "theia_hip_four_point_focal_length_radial_distortion", "theia_hip_four_point_focal_length_radial_distortion_ex", "theia_hip_release_scratch", "theia_hip_guided_knn", "theia_hip_randint_stream",
+    "theia_hip_pose_from_three_points", "theia_hip_sqpnp", "theia_hip_dls_pnp", "theia_hip_dls_macaulay_terms", "theia_hip_four_point_pose_and_focal_length", "theia_hip_four_point_focal_length_radial_distortion", "theia_hip_four_point_focal_length_radial_distortion_ex", "theia_hip_release_scratch", "theia_hip_guided_knn", "theia_hip_randint_stream", "theia_hip_selftest_wave_primitives",
 ]
 
 _lib = None

@@ -18,6 +18,7 @@
 // depending on the pair's noise (the IRLS amplifies summation-order roundings: tests/test_relpos_gpu.py).
 #include "ransac_device.h"
 #include "wave_reduce.h"
+#include "eig_team.h"
 #include "theia_hip_internal.h"
 
 #include <algorithm>
@@ -188,5 +189,50 @@ extern "C" int theia_hip_optimize_relative_position_batch(int32_t num_problems, 
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(relative_positions, d_pos.p, sizeof(double) * 3 * num, hipMemcpyDeviceToHost));
   if (num_iterations) HIP_TRY(hipMemcpy(num_iterations, d_it.p, sizeof(int32_t) * num, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- theia_hip_selftest_wave_primitives: wave_reduce.h / eig_team.h's broadcasts against shuffle loops
+namespace thip {
+namespace {
+__global__ __launch_bounds__(64) void k_selftest_wave(const double* __restrict__ in, int* __restrict__ bad) {
+  const int lane = threadIdx.x;
+  const double v = in[(size_t)blockIdx.x * 64 + lane];
+  double rs = v, rm = fabs(v);
+  int ri = lane * 3 + 1;
+  for (int off = 32; off > 0; off >>= 1) { rs += __shfl_xor(rs, off, 64); rm = fmax(rm, __shfl_xor(rm, off, 64)); ri += __shfl_xor(ri, off, 64); }
+  int wrong = 0;
+  wrong += __double_as_longlong(wave_sum_butterfly(v)) != __double_as_longlong(rs);
+  wrong += wave_sum_butterfly(lane * 3 + 1) != ri;
+  wrong += __double_as_longlong(wave_max_butterfly(fabs(v))) != __double_as_longlong(rm);
+  wrong += __double_as_longlong(wave_max_abs(fabs(v))) != __double_as_longlong(rm);
+  wrong += __double_as_longlong(wave_max_abs(lane & 1 ? fabs(v) : -1.0)) != __double_as_longlong([&] { double m = lane & 1 ? fabs(v) : -1.0; for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64)); return m; }());
+  wrong += __double_as_longlong(rsc::row16_bcast<5>(v)) != __double_as_longlong(__shfl(v, (lane & ~15) + 5, 64));
+  wrong += __double_as_longlong(rsc::oct_bcast<2>(v)) != __double_as_longlong(__shfl(v, (lane & ~7) + 2, 64));
+  wrong += __double_as_longlong(rsc::oct_bcast<4>(v)) != __double_as_longlong(__shfl(v, (lane & ~7) + 4, 64));
+  wrong += __double_as_longlong(lane_value(v, 37)) != __double_as_longlong(__shfl(v, 37, 64));
+  if (wrong) atomicAdd(bad, wrong);
+}
+}  // namespace
+}  // namespace thip
+
+extern "C" int theia_hip_selftest_wave_primitives(int32_t count, int32_t* mismatches) {
+  if (count < 1 || !mismatches) return set_error(THEIA_HIP_ERR_INVALID_ARGUMENT, "count < 1 or null output");
+  int rc = thip::ensure_device();
+  if (rc) return rc;
+  std::vector<double> h((size_t)count * 64);
+  uint64_t x = 0x9E3779B97F4A7C15ull;
+  for (auto& d : h) {   // doubles of mixed sign and magnitude (xorshift), a few exact ties
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    const double m = 1.0 + (double)(x >> 12) * 0x1p-52;
+    d = std::ldexp((x & 1) ? -m : m, (int)((x >> 3) % 41) - 20);
+    if (((x >> 9) & 31) == 0) d = 1.5;
+  }
+  DevBuf<double> d_in; DevBuf<int> d_bad;
+  if ((rc = d_in.up(h.data(), h.size())) || (rc = d_bad.alloc(1))) return rc;
+  HIP_TRY(hipMemset(d_bad.p, 0, sizeof(int)));
+  k_selftest_wave<<<count, 64, 0, nullptr>>>(d_in.p, d_bad.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(mismatches, d_bad.p, sizeof(int), hipMemcpyDeviceToHost));
   return 0;
 }

@@ -125,3 +125,16 @@ def test_relative_position_ragged_and_tiny_pairs():
         want, wit = ol.optimize_relative_position(p[0], p[1], p[2], order=1)
         assert it[k] == wit, (k, it[k], wit)
         assert np.array_equal(pos[k], want, equal_nan=True), (k, pos[k], want)
+
+
+def test_wave_primitives_selftest():
+    """theia_hip_selftest_wave_primitives: the cross-lane primitives of the bit-exact kernels (butterfly sums on permlane swaps + DPP,
+    the wave maximum of |a|, the row / half-row broadcasts, readlane) against shuffle loops, bit for bit, on 512 random wavefronts."""
+    import ctypes as C
+    L = capi.lib()
+    L.theia_hip_selftest_wave_primitives.argtypes = [C.c_int32, C.POINTER(C.c_int32)]
+    bad = C.c_int32(-1)
+    capi.check(L.theia_hip_selftest_wave_primitives(512, C.byref(bad)))
+    assert bad.value == 0
+    with pytest.raises(capi.TheiaHipError):
+        capi.check(L.theia_hip_selftest_wave_primitives(0, C.byref(bad)))
